@@ -1,0 +1,215 @@
+"""Seeded synthetic inputs and weights for the MV2D hot path.
+
+Everything here is platform-stable (numpy PCG64 by seed) so that fixtures, tests, the oracle and
+bench.py regenerate identical inputs/weights on any box instead of storing them.
+
+* camera rig: ring of yaw-spaced pinhole cameras, f = 0.8*W, principal point at the image centre,
+  ``extrinsics`` stored as the TRANSPOSED lidar->cam matrix and ``lidar2img = intrinsics @ extrinsics.T``
+  (the img_metas contract of mmdet3d_plugin/datasets/custom_nuscenes_dataset.py:141-150 and
+  mmdet3d_plugin/datasets/pipelines/transform_3d.py:587-591); a previous frame is the same rig
+  translated by 0.4 m with timestamp 0.5 s.
+* proposals: per view ``n`` boxes (x1,y1,x2,y2,score,label) like mmdet3d_plugin/models/detectors/mv2d.py:60-86.
+* weights: state-dict keyed exactly like the reference ``roi_head`` sub-module.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+EMBED = 256
+NUM_LAYERS = 6
+FFN_DIM = 2048
+NUM_CLASSES = 10
+CODE_SIZE = 10
+DEPTH_NUM = 64
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def make_img_metas(views_per_frame, img_h, img_w, frames=1, pad_w=None, pad_h=None, yaw_step_deg=None):
+    """Return a list of per-view img_meta dicts (len = views_per_frame*frames)."""
+    pad_w = img_w if pad_w is None else pad_w
+    pad_h = img_h if pad_h is None else pad_h
+    metas = []
+    nv = views_per_frame * frames
+    for f in range(frames):
+        for v in range(views_per_frame):
+            # full ring by default; rigs with < 6 cameras use a 40 degree step so that neighbouring views
+            # overlap (horizontal fov at f = 0.8 W is 64 degrees) and the epipolar correlation is exercised
+            step = (2.0 * math.pi / views_per_frame) if yaw_step_deg is None else math.radians(yaw_step_deg)
+            yaw = v * step
+            K = np.eye(4, dtype=np.float64)
+            K[0, 0] = K[1, 1] = 0.8 * img_w
+            K[0, 2] = img_w / 2.0
+            K[1, 2] = img_h / 2.0
+            c, s = math.cos(yaw), math.sin(yaw)
+            # lidar (x fwd, y left, z up) -> camera (x right, y down, z fwd), then yaw about lidar z
+            R0 = np.array([[0, -1, 0], [0, 0, -1], [1, 0, 0]], dtype=np.float64)
+            Rz = np.array([[c, s, 0], [-s, c, 0], [0, 0, 1]], dtype=np.float64)
+            T = np.eye(4, dtype=np.float64)
+            T[:3, :3] = R0 @ Rz
+            T[:3, 3] = [0.0, 1.5, -0.5 - 0.4 * f]
+            metas.append(dict(
+                intrinsics=K,
+                extrinsics=T.T.copy(),
+                lidar2img=K @ T,
+                pad_shape=(pad_h, pad_w, 3),
+                img_shape=(img_h, img_w, 3),
+                num_views=nv,
+                timestamp=0.5 * f,
+            ))
+    return metas
+
+
+def make_proposals(num_views, n_per_view, img_h, img_w, seed, wh_lo=(16.0, 16.0), wh_hi=(116.0, 96.0)):
+    """List of ``num_views`` float32 arrays [n,6] = (x1,y1,x2,y2,score,label)."""
+    g = _rng(seed)
+    if isinstance(n_per_view, int):
+        n_per_view = [n_per_view] * num_views
+    out = []
+    for v in range(num_views):
+        n = n_per_view[v]
+        xy = g.random((n, 2)) * np.array([max(img_w - 120.0, 1.0), max(img_h - 100.0, 1.0)])
+        wh = g.random((n, 2)) * (np.array(wh_hi) - np.array(wh_lo)) + np.array(wh_lo)
+        score = g.random((n, 1))
+        label = g.integers(0, NUM_CLASSES, (n, 1)).astype(np.float64)
+        out.append(np.concatenate([xy, xy + wh, score, label], 1).astype(np.float32))
+    return out
+
+
+def make_feat(num_views, h, w, seed, channels=EMBED):
+    """Stride-16 FPN map [V, 256, h, w] float32 ~ N(0,1)."""
+    g = _rng(seed)
+    return g.standard_normal((num_views, channels, h, w), dtype=np.float32)
+
+
+def _xavier(g, shape, gain=1.0):
+    fan_out = shape[0]
+    fan_in = int(np.prod(shape[1:]))
+    rf = 1
+    if len(shape) > 2:
+        rf = int(np.prod(shape[2:]))
+        fan_in = shape[1] * rf
+        fan_out = shape[0] * rf
+    a = gain * math.sqrt(6.0 / (fan_in + fan_out))
+    return ((g.random(shape, dtype=np.float32) * 2.0 - 1.0) * a).astype(np.float32)
+
+
+def _bias(g, n, a=0.05):
+    return ((g.random(n, dtype=np.float32) * 2.0 - 1.0) * a).astype(np.float32)
+
+
+def _ln(g, n):
+    w = (0.8 + 0.4 * g.random(n, dtype=np.float32)).astype(np.float32)
+    b = _bias(g, n, 0.1)
+    return w, b
+
+
+def make_head_state(seed=0, num_layers=NUM_LAYERS):
+    """OrderedDict[str, np.ndarray] with the reference ``roi_head.*`` state-dict key layout.
+
+    Xavier-uniform matrices like PETRTransformer.init_weights
+    (mmdet3d_plugin/models/utils/petr_transformer.py:65-71); biases / LayerNorm affine are small
+    non-trivial values so that every bias path is exercised by the parity tests.
+    """
+    g = _rng(seed)
+    C, F = EMBED, FFN_DIM
+    sd = OrderedDict()
+    dec = 'bbox_head.transformer.decoder.'
+    for i in range(num_layers):
+        p = f'{dec}layers.{i}.'
+        for a in (0, 1):
+            sd[p + f'attentions.{a}.attn.in_proj_weight'] = _xavier(g, (3 * C, C))
+            sd[p + f'attentions.{a}.attn.in_proj_bias'] = _bias(g, 3 * C)
+            sd[p + f'attentions.{a}.attn.out_proj.weight'] = _xavier(g, (C, C))
+            sd[p + f'attentions.{a}.attn.out_proj.bias'] = _bias(g, C)
+        sd[p + 'ffns.0.layers.0.0.weight'] = _xavier(g, (F, C))
+        sd[p + 'ffns.0.layers.0.0.bias'] = _bias(g, F)
+        sd[p + 'ffns.0.layers.1.weight'] = _xavier(g, (C, F))
+        sd[p + 'ffns.0.layers.1.bias'] = _bias(g, C)
+        for n in range(3):
+            w, b = _ln(g, C)
+            sd[p + f'norms.{n}.weight'] = w
+            sd[p + f'norms.{n}.bias'] = b
+    w, b = _ln(g, C)
+    sd[dec + 'post_norm.weight'] = w
+    sd[dec + 'post_norm.bias'] = b
+    sd['bbox_head.query_embedding.0.weight'] = _xavier(g, (C, C * 3 // 2))
+    sd['bbox_head.query_embedding.0.bias'] = _bias(g, C)
+    sd['bbox_head.query_embedding.2.weight'] = _xavier(g, (C, C))
+    sd['bbox_head.query_embedding.2.bias'] = _bias(g, C)
+    for l in range(num_layers):
+        p = f'bbox_head.cls_branches.{l}.'
+        sd[p + '0.weight'] = _xavier(g, (C, C)); sd[p + '0.bias'] = _bias(g, C)
+        sd[p + '1.weight'], sd[p + '1.bias'] = _ln(g, C)
+        sd[p + '3.weight'] = _xavier(g, (C, C)); sd[p + '3.bias'] = _bias(g, C)
+        sd[p + '4.weight'], sd[p + '4.bias'] = _ln(g, C)
+        sd[p + '6.weight'] = _xavier(g, (NUM_CLASSES, C))
+        # bias_init_with_prob(0.01) (cross_attention_head.py:193-197) plus a per-class spread
+        sd[p + '6.bias'] = (np.full(NUM_CLASSES, -math.log((1 - 0.01) / 0.01), np.float32) + _bias(g, NUM_CLASSES, 0.5))
+    for l in range(num_layers):
+        p = f'bbox_head.reg_branches.{l}.'
+        sd[p + '0.weight'] = _xavier(g, (C, C)); sd[p + '0.bias'] = _bias(g, C)
+        sd[p + '2.weight'] = _xavier(g, (C, C)); sd[p + '2.bias'] = _bias(g, C)
+        sd[p + '4.weight'] = _xavier(g, (CODE_SIZE, C)); sd[p + '4.bias'] = _bias(g, CODE_SIZE, 0.3)
+    sd['bbox_head.code_weights'] = np.array([1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.5, 1.5, 2.0, 2.0], np.float32)
+    # query generator (mmdet3d_plugin/models/roi_heads/utils/query_generator.py)
+    q = 'query_generator.'
+    sd[q + 'shared_convs.0.conv.weight'] = _xavier(g, (C, C, 3, 3))
+    sd[q + 'shared_convs.0.conv.bias'] = _bias(g, C)
+    sd[q + 'shared_fcs.0.weight'] = _xavier(g, (1024, C))
+    sd[q + 'shared_fcs.0.bias'] = _bias(g, 1024)
+    sd[q + 'extra_enc.0.weight'] = _xavier(g, (512, 1024 + 16))
+    sd[q + 'extra_enc.0.bias'] = _bias(g, 512)
+    sd[q + 'extra_enc.2.weight'] = _xavier(g, (C, 512))
+    sd[q + 'extra_enc.2.bias'] = _bias(g, C)
+    # (u, v, depth) in the 7x7 RoI frame: centre the prediction inside the RoI at ~25 m
+    wc = _xavier(g, (3, C))
+    wc[:2] *= 4.0
+    wc[2] *= 24.0
+    sd[q + 'fc_center.weight'] = wc
+    sd[q + 'fc_center.bias'] = np.array([3.5, 3.5, 25.0], np.float32)
+    # 3D position-aware key embedding (mmdet3d_plugin/models/utils/pe.py:50-82)
+    pe = 'position_encoding.'
+    sd[pe + 'position_encoder.0.weight'] = _xavier(g, (4 * C, 3 * DEPTH_NUM, 1, 1))
+    sd[pe + 'position_encoder.0.bias'] = _bias(g, 4 * C)
+    sd[pe + 'position_encoder.2.weight'] = _xavier(g, (C, 4 * C, 1, 1))
+    sd[pe + 'position_encoder.2.bias'] = _bias(g, C)
+    sd[pe + 'adapt_pos3d.0.weight'] = _xavier(g, (4 * C, C * 3 // 2, 1, 1))
+    sd[pe + 'adapt_pos3d.0.bias'] = _bias(g, 4 * C)
+    sd[pe + 'adapt_pos3d.2.weight'] = _xavier(g, (C, 4 * C, 1, 1))
+    sd[pe + 'adapt_pos3d.2.bias'] = _bias(g, C)
+    sd[pe + 'fpe.conv_reduce.weight'] = _xavier(g, (C, C, 1, 1))
+    sd[pe + 'fpe.conv_reduce.bias'] = _bias(g, C)
+    sd[pe + 'fpe.conv_expand.weight'] = _xavier(g, (C, C, 1, 1))
+    sd[pe + 'fpe.conv_expand.bias'] = _bias(g, C)
+    return sd
+
+
+# ---------------------------------------------------------------------------------------------
+# The five BASELINE.json configs as concrete synthetic problems.
+# ---------------------------------------------------------------------------------------------
+WORKLOADS = {
+    # name: (head kind, views/frame, frames, img_h, img_w, pad_w, boxes/view)
+    'micro_t': ('T', 2, 1, 128, 192, None, 6),
+    'micro_s': ('S', 2, 1, 128, 192, None, 6),
+    'cfg1_s': ('S', 2, 1, 224, 400, 416, 25),
+    'cfg1_t': ('T', 2, 1, 224, 400, 416, 25),
+    'cfg2_s': ('S', 6, 1, 512, 1408, None, 50),
+    'cfg3_t': ('T', 6, 2, 512, 1408, None, 25),
+    'cfg5_t': ('T', 6, 2, 640, 1600, None, 75),
+}
+
+
+def make_problem(name, seed=0):
+    """Return dict(kind, feat [V,256,h,w] f32, proposals list[V] of [n,6] f32, img_metas list[V])."""
+    kind, vpf, frames, H, W, pad_w, n = WORKLOADS[name]
+    pw = W if pad_w is None else pad_w
+    V = vpf * frames
+    metas = make_img_metas(vpf, H, W, frames, pad_w=pw, yaw_step_deg=(40.0 if vpf < 6 else None))
+    props = make_proposals(V, n, H, W, seed + 1)
+    feat = make_feat(V, H // 16, pw // 16, seed + 2)
+    return dict(kind=kind, feat=feat, proposals=props, img_metas=metas, name=name,
+                views_per_frame=vpf, frames=frames)

@@ -1,0 +1,178 @@
+"""Generate golden vectors from the UNMODIFIED reference (build container only).
+
+    python -B -m oracle.gen_golden            # writes tests/golden/*.npz
+
+Imports the reference hot-path modules from /root/reference under ``oracle/_stubs.py``, builds
+``MV2DSHead`` / ``MV2DTHead`` from the reference configs (restated in mv2d_amd/configs.py), loads the
+seeded synthetic weights (mv2d_amd/synthetic.make_head_state), runs ``simple_test`` on seeded synthetic
+problems and records stage outputs with wrappers/hooks.  Inputs are NOT stored: tests regenerate them
+from the same seeds (mv2d_amd/synthetic.make_problem); only special-case proposals are stored.
+
+The fixtures are DATA (inputs' seeds + reference outputs); no reference source travels.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from mv2d_amd import configs, synthetic  # noqa: E402
+from oracle import _stubs  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def build_reference_head(kind, S_cls, T_cls, sd_np, num_views):
+    cfg = configs.roi_head_cfg_s() if kind == 'S' else configs.roi_head_cfg_t()
+    cfg.pop('type')
+    cfg['test_cfg'] = configs.TEST_CFG_RCNN
+    if kind == 'T':
+        cfg['num_views'] = num_views
+    head = (S_cls if kind == 'S' else T_cls)(**cfg).eval()
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    missing, unexpected = head.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all('loss' in m for m in missing), missing
+    return head
+
+
+def run_case(head, kind, feat, proposals, metas, full):
+    rec = {}
+    metas = [dict(m, box_type_3d=(lambda b, d: b)) for m in metas]
+
+    def wrap(obj, name, fn):
+        orig = getattr(obj, name)
+
+        def g(*a, **k):
+            r = orig(*a, **k)
+            fn(a, k, r)
+            return r
+        setattr(obj, name, g)
+        return orig
+
+    restore = []
+
+    def W(obj, name, fn):
+        restore.append((obj, name, wrap(obj, name, fn)))
+
+    W(head, 'get_box_params', lambda a, k, r: rec.update(K_roi=r[0].numpy(), E=r[1].numpy()))
+    W(head.bbox_roi_extractor, 'forward', lambda a, k, r: rec.update(roi_align=r.numpy()))
+    W(head, 'process_intrins_feat', lambda a, k, r: rec.update(intr=r.numpy()))
+    W(head.query_generator, 'center2lidar', lambda a, k, r: rec.update(center_pred=a[0].detach().numpy().copy(),
+                                                                       xyz=r.detach().numpy().copy()))
+    W(head.position_encoding, 'forward', lambda a, k, r: rec.update(pe=r[0].numpy()))
+    if kind == 'S':
+        W(head.box_corr_module, 'gen_box_roi_correlation',
+          lambda a, k, r: rec.update(corr=r[0].numpy(), corr_mask=r[1].numpy()))
+    else:
+        W(head.box_corr_module, 'gen_box_correlation',
+          lambda a, k, r: rec.update(feat_for_rois=np.packbits(r.numpy().reshape(-1)),
+                                     feat_for_rois_shape=np.array(r.shape)))
+    bh = head.bbox_head
+
+    def on_bbox_head(a, k, r):
+        rec.update(ref=a[0].detach().numpy().copy(), cls=r[0].numpy().copy(), reg=r[1].numpy().copy())
+        if kind == 'T':
+            cam = k['cross_attn_mask'][..., 0, 0]
+            rec.update(blocked_attn=np.packbits(cam.numpy().reshape(-1)), blocked_shape=np.array(cam.shape),
+                       key_padding=a[2][0, :, 0, 0].numpy().copy())
+            if full:
+                rec.update(mem=a[1][0, :, :, 0, 0].numpy().copy(), mem_pe=a[3][0, :, :, 0, 0].numpy().copy())
+    W(bh, 'forward', on_bbox_head)
+    W(bh, 'position_embedding', lambda a, k, r: rec.update(qpos=r.detach().numpy().copy()))
+    W(bh.transformer, 'forward', lambda a, k, r: rec.update(outs_dec=r[0].numpy().copy()))
+    attn_w = []
+    hooks = []
+    cross_inputs = []
+    for i, layer in enumerate(bh.transformer.decoder.layers):
+        hooks.append(layer.attentions[1].attn.register_forward_hook(
+            lambda m, inp, out: attn_w.append(out[1].detach().numpy().copy())))
+        if i == 0:
+            hooks.append(layer.attentions[1].attn.register_forward_hook(
+                lambda m, inp, out, **kw: None))
+    # pre-softmax per-head logits of layer 0, recomputed from the hooked inputs with the module's own in_proj
+    l0 = bh.transformer.decoder.layers[0].attentions[1].attn
+
+    def pre_hook(m, args, kwargs):
+        cross_inputs.append((kwargs['query'].detach().clone(), kwargs['key'].detach().clone()))
+    hooks.append(l0.register_forward_pre_hook(pre_hook, with_kwargs=True))
+
+    with torch.no_grad():
+        x = [torch.from_numpy(feat)]
+        props = [torch.from_numpy(p) for p in proposals]
+        out = head.simple_test(x, props, metas)
+    for h in hooks:
+        h.remove()
+    for obj, name, orig in restore:
+        setattr(obj, name, orig)
+    boxes, scores, labels = out[0]
+    rec.update(boxes=boxes.numpy(), scores=scores.numpy(), labels=labels.numpy())
+    # bbox_index through the same torch.topk call as CB/coders/nms_free_coder.py:66 on the captured scores
+    cls_last = torch.from_numpy(rec['cls'][-1].reshape(-1, 10))
+    k = min(300, cls_last.numel())
+    sc, idx = cls_last.sigmoid().view(-1).topk(k)
+    rec.update(topk_index=idx.numpy(), topk_scores=sc.numpy())
+    if kind == 'T':
+        rec['attn_mean'] = np.stack([w[0] for w in attn_w]).astype(np.float32)          # [L, Q, S] head-averaged
+        q_in, k_in = cross_inputs[0]
+        C = 256
+        q = torch.nn.functional.linear(q_in[:, 0], l0.in_proj_weight[:C], l0.in_proj_bias[:C])
+        kk = torch.nn.functional.linear(k_in[:, 0], l0.in_proj_weight[C:2 * C], l0.in_proj_bias[C:2 * C])
+        qh = q.view(-1, 8, 32).transpose(0, 1) / (32 ** 0.5)
+        kh = kk.view(-1, 8, 32).transpose(0, 1)
+        rec['logits_l0'] = torch.bmm(qh, kh.transpose(1, 2)).detach().numpy().astype(np.float32)  # [8, Q, S] unmasked
+    if not full:
+        for k_ in ('roi_align', 'pe', 'mem', 'mem_pe', 'logits_l0', 'attn_mean', 'outs_dec', 'qpos'):
+            rec.pop(k_, None)
+    return rec
+
+
+def main():
+    S_cls, T_cls = _stubs.install('/root/reference')
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    sd_np = synthetic.make_head_state(seed=0)
+    cases = [('micro_t', True), ('micro_s', True), ('cfg1_t', False), ('cfg1_s', False)]
+    for name, full in cases:
+        prob = synthetic.make_problem(name, seed=0)
+        head = build_reference_head(prob['kind'], S_cls, T_cls, sd_np, prob['views_per_frame'])
+        rec = run_case(head, prob['kind'], prob['feat'], prob['proposals'], prob['img_metas'], full)
+        np.savez_compressed(os.path.join(OUT, name + '.npz'), **rec)
+        print(name, {k: (v.shape, str(v.dtype)) for k, v in rec.items()})
+    # --- two-frame T case (velocity / dt path, V > num_views) at micro size
+    metas = synthetic.make_img_metas(2, 128, 192, frames=2, yaw_step_deg=40.0)
+    props = synthetic.make_proposals(4, 4, 128, 192, seed=11)
+    feat = synthetic.make_feat(4, 8, 12, seed=12)
+    head = build_reference_head('T', S_cls, T_cls, sd_np, 2)
+    rec = run_case(head, 'T', feat, props, metas, False)
+    np.savez_compressed(os.path.join(OUT, 'twoframe_t.npz'), **rec)
+    print('twoframe_t', {k: v.shape for k, v in rec.items()})
+    # --- empty detections -> dummy proposal (RH/mv2d_head.py:105-108)
+    prob = synthetic.make_problem('micro_t', seed=0)
+    empty = [np.zeros((0, 6), np.float32) for _ in prob['proposals']]
+    for kind in ('T', 'S'):
+        head = build_reference_head(kind, S_cls, T_cls, sd_np, 2)
+        rec = run_case(head, kind, prob['feat'], empty, prob['img_metas'], False)
+        np.savez_compressed(os.path.join(OUT, f'empty_{kind.lower()}.npz'), **rec)
+        print('empty', kind, rec['boxes'].shape)
+    # --- a query whose every key is padding-masked (reference yields NaN)
+    metas = synthetic.make_img_metas(2, 128, 96, frames=1, pad_w=192, yaw_step_deg=40.0)
+    props = synthetic.make_proposals(2, 3, 128, 96, seed=21, wh_hi=(40.0, 40.0))
+    props[1] = np.concatenate([props[1], np.array([[150., 40., 180., 80., 0.9, 3.]], np.float32)])
+    feat = synthetic.make_feat(2, 8, 12, seed=22)
+    head = build_reference_head('T', S_cls, T_cls, sd_np, 2)
+    rec = run_case(head, 'T', feat, props, metas, False)
+    rec['proposals_v0'] = props[0]
+    rec['proposals_v1'] = props[1]
+    np.savez_compressed(os.path.join(OUT, 'nanrow_t.npz'), **rec)
+    print('nanrow_t: n_nan_cls =', int(np.isnan(rec['cls']).sum()), 'boxes', rec['boxes'].shape)
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print('total golden bytes:', tot)
+
+
+if __name__ == '__main__':
+    main()
