@@ -1,0 +1,139 @@
+/* mv2d_hip.h — C ABI of libmv2d_hip.so: the MI355X (gfx950) kernels behind MV2D's sparse cross-attention
+ * decoder hot path.
+ *
+ * The reference (tusen-ai/MV2D) is pure Python and has NO native boundary of its own; its hot path runs through
+ * third-party native ops (torch ATen, mmcv RoIAlign).  This header is therefore the boundary a maintainer binds
+ * (ctypes) in place of those calls; every entry point cites the reference code it replaces
+ * (paths relative to the reference root; RH = mmdet3d_plugin/models/roi_heads, MU = mmdet3d_plugin/models/utils,
+ * CB = mmdet3d_plugin/core/bbox).
+ *
+ * Conventions
+ *  - plain C types only: device pointers, sizes, strides; no torch types.
+ *  - every function returns 0 on success, <0 on error (-1 bad argument, -2 launch failure);
+ *    mv2d_last_error() returns a thread-local description.  No exceptions cross the ABI.
+ *  - all buffers (inputs, outputs, workspaces) are allocated and freed by the caller; kernels never allocate.
+ *  - asynchronous: work is only enqueued on `stream` (a hipStream_t; pass torch.cuda.current_stream().cuda_stream);
+ *    no implicit device synchronisation; re-entrant.
+ *  - "bf16" buffers are raw uint16 (upper half of an IEEE fp32, round-to-nearest-even).
+ *  - all matrices are row-major; "position-major map" = [V*h*w, 256] with the channel index fastest.
+ */
+#ifndef MV2D_HIP_H
+#define MV2D_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* mv2d_last_error(void);
+int mv2d_abi_version(void);
+int mv2d_device_arch(char* buf, int buflen);
+
+/* ---- dense contractions -------------------------------------------------------------------------------- */
+
+/* bf16 MFMA GEMM  C = epi(A[M,K] . W[N,K]^T + bias)  (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+ * Replaces: PE 1x1-conv MLPs + SE gate (MU/pe.py:64-77,36-48,158-166), key/value in_proj of all decoder layers
+ * (torch.nn.MultiheadAttention inside MU/petr_transformer.py:503-508), QueryGenerator shared 3x3 conv
+ * (RH/utils/query_generator.py:298-304,352-358) as an implicit GEMM (a_mode=1: A = RoI features [R,49,256]).
+ *  n_split>0: columns >= n_split read A2 (e.g. K columns from feat+pe rows, V columns from feat rows).
+ *  m_dev: optional device int; rows >= *m_dev are skipped (row count known only on the device).
+ *  epilogue: v = acc + bias; v *= mul[m,n]; v += add[m,n]; act (0 none, 1 relu, 2 sigmoid);
+ *            C[(n / c_blk_cols) * c_blk_stride + m * ldc + n % c_blk_cols] = v   (c_blk_cols = 0: C[m*ldc+n]);
+ *            C2[m*ldc2+n] = bf16(v + add2[m,n]). */
+int mv2d_gemm_bf16(const void* A, const void* A2, int n_split, int a_mode, const void* W, const float* bias, int M, int N,
+                   int K, int lda, const int* m_dev, int act, const float* mul, int ldmul, const float* add, int ldadd,
+                   void* C, int c_bf16, int ldc, long long c_blk_stride, int c_blk_cols, void* C2, const float* add2,
+                   int ldc2, int ldadd2, void* stream);
+
+/* exact-fp32 MFMA GEMM for the per-query (M = #queries) ops  C = epi((A . W^T + bias) * scale).
+ * Replaces nn.Linear calls of: query/out in_proj/out_proj and FFN (MU/petr_transformer.py:358-363,503-508; mmcv FFN),
+ * query_embedding / cls / reg branches (RH/bbox_heads/cross_attention_head.py:118-146,199-227),
+ * QueryGenerator fcs (RH/utils/query_generator.py:360-373,404).
+ *  split_k>1 writes split_k partial slabs (slab z at C + z*c_slice_stride elements); bias is added in slab 0. */
+int mv2d_gemm_f32(const float* A, const float* A2, int n_split, const float* W, const float* bias, int M, int N, int K,
+                  int lda, int ldw, int split_k, int act, float scale, void* C, int c_bf16, int ldc,
+                  long long c_slice_stride, void* stream);
+
+/* ---- row-wise ops on the [M,256] query state ------------------------------------------------------------- */
+
+/* y = [ReLU] [LayerNorm]( sum_z parts[z] + bias + residual );  out = y;  out_plus = y + addvec;  out2 = LN2(y).
+ * Replaces: mmcv BaseTransformerLayer residual adds + norms and the shared post_norm
+ * (MU/petr_transformer.py:563-565,586-592), Linear-LN-ReLU of the cls branch (cross_attention_head.py:127-133). */
+int mv2d_row_ln(const float* parts, int n_parts, long long part_stride, const float* bias, const float* residual,
+                const float* ln_w, const float* ln_b, int relu, float* out, const float* addvec, float* out_plus,
+                const float* ln2_w, const float* ln2_b, float* out2, int M, float eps, void* stream);
+
+/* AvgPool2d(7) over [R,49,256] fp32 -> out[r*ld_out + c]  (RH/utils/query_generator.py:322-331). */
+int mv2d_avgpool49(const float* x, float* out, int ld_out, int R, void* stream);
+
+int mv2d_f32_to_bf16(const float* x, void* y, long long n, void* stream);
+
+/* NCHW fp32 [V,C,HW] -> position-major [V*HW, C] fp32 (the layout every gather below reads). */
+int mv2d_nchw_to_nhwc(const float* x, float* y, int V, int C, int HW, void* stream);
+
+/* ---- attention ---------------------------------------------------------------------------------------- */
+
+/* FlattenMHSelfAttention core (MU/petr_transformer.py:317-370): qkv [R,768] fp32 = in_proj(q|k|v) -> ctx [R,256]. */
+int mv2d_self_attn_fwd(const float* qkv, float* ctx, int R, void* stream);
+
+/* PETRMultiheadAttention core (MU/petr_transformer.py:426-513) over the allowed (query,key) pairs only.
+ * q [R,256] fp32 pre-scaled by 1/sqrt(32); K,V [S,256] bf16; CSR row_ptr[R+1], col_idx[nnz] (key indices);
+ * ctx [R,256] fp32.  A query with no allowed key yields ctx = 0 (reference: NaN).
+ * dbg_logits (optional): pre-softmax logits, head h at dbg_logits[h*dbg_stride + e], e in CSR order. */
+int mv2d_sparse_xattn_fwd(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, float* ctx,
+                          float* dbg_logits, long long dbg_stride, int R, void* stream);
+
+/* ---- geometry / gather ---------------------------------------------------------------------------------- */
+
+/* MV2DHead.get_box_params + process_intrins_feat (RH/mv2d_head.py:51-72,95-101) and inverse(K_roi @ E^T).float()
+ * of QueryGenerator.center2lidar (RH/utils/query_generator.py:337-339).
+ * rois [R,5] fp32 (view,x1,y1,x2,y2); viewK/viewE [V,16] fp64; K_roi [R,16] fp64 (optional);
+ * intr[r*ld_intr + 0..15] fp32 (x0.1, zeroed for boxes < min_size, clamped to +-5e3); minv [R,16] fp32. */
+int mv2d_box_params(const float* rois, const double* viewK, const double* viewE, double* K_roi, float* intr, int ld_intr,
+                    float* minv, int R, float roi_size, float intr_scale, float min_size, void* stream);
+
+/* center2lidar mat-vec + pc_range normalisation (NOT clamped, RH/mv2d_t_head.py:51-57) + pos2posemb3d (MU/pe.py:21-33).
+ * center_pred rows (u,v,depth) at stride ld_cp; dim_t[128]; out xyz [R,3], ref [R,3], posemb [R,384] (y|x|z). */
+int mv2d_refpoint_posemb(const float* center_pred, int ld_cp, const float* minv, const float* dim_t, float* xyz, float* ref,
+                         float* posemb, int R, const float* pc_range, void* stream);
+
+/* mmcv.ops.RoIAlign(7, 1/16, sampling_ratio, 'avg', aligned=True) (call site RH/mv2d_head.py:114-115) on one or two
+ * position-major maps -> [R,49,256] bf16 and/or fp32 per map. */
+int mv2d_roi_align(const float* map0, const float* map1, const float* rois, void* out0, void* out1, float* out0_f32,
+                   float* out1_f32, int R, int H, int W, int channels, float spatial_scale, int sampling_ratio, void* stream);
+
+/* BoxCorrelation.epipolar_in_box, 'topk_matched:k:thr:ratio' (RH/utils/box_correlation.py:196-398).
+ * view_start[V+1]: first RoI of each view; trans [V,V,16] fp64 = lidar2img[b] @ inv(lidar2img[a]);
+ * lin[sample_size] = linspace(0,1); depths[num_depth] (LID); match [R,V,topk] int32: RoI id or -1, rank order. */
+int mv2d_box_correlation(const float* rois, const int* view_start, const double* trans, const float* lin, const float* depths,
+                         int* match, int R, int V, int sample_size, int num_depth, int topk, int pad_h, int pad_w,
+                         float depth_start, float iou_thr, float ratio, int max_per_view, void* stream);
+
+long long mv2d_csr_workspace_bytes(int R, int V, int h, int w);
+
+/* T-path masks -> compacted key list + CSR (BoxCorrelation.gen_box_correlation RH/utils/box_correlation.py:95-162 and
+ * the mask/gather block RH/mv2d_t_head.py:67-88).  roi_mask [V*h*w] bytes must be zeroed by the caller.
+ * out: rect [R,5]; pos2s [P]; s2pos [<=P]; *S_out; row_ptr [R+1]; col_idx [nnz]; *nnz_out. */
+int mv2d_mask_compact(const float* rois, const int* match, const unsigned char* pad_mask, unsigned char* roi_mask, int* rect,
+                      int* pos2s, int* s2pos, int* S_out, unsigned int* bits_ws, int* row_count, int* row_ptr, int* col_idx,
+                      int* nnz_out, int R, int V, int h, int w, int topk, float stride, float expand_stride, void* stream);
+
+/* S-path CSR over the RoI-feature memory rows r*49+cell (RH/mv2d_s_head.py:184-192). */
+int mv2d_csr_from_corr(const int* match, int* row_ptr, int* col_idx, int* nnz_out, int R, int V, int topk, void* stream);
+
+/* PE inputs at the listed key positions only (MU/pe.py:84-135 frustum, MU/positional_encoding.py:78-95 sine) + feature gather.
+ * out: A_frustum [S,3*D] bf16, A_sine [S,384] bf16, Xf_bf16 [S,256], Xf_f32 [S,256]. */
+int mv2d_pe_inputs(const int* s2pos, const int* S_dev, int S_max, const float* featcl, const double* img2lidar,
+                   const double* coords_w, const double* coords_h, const double* coords_d, const float* embeds,
+                   const float* dim_t, void* A_frustum, void* A_sine, void* Xf_bf16, float* Xf_f32, int V, int h, int w,
+                   int depth_num, const double* position_range, void* stream);
+
+/* NMSFreeCoder.decode_single + get_bboxes (CB/coders/nms_free_coder.py:49-102, CB/util.py:60-87,
+ * RH/bbox_heads/cross_attention_head.py:357-377): top-k over R*num_classes logits, denormalise, centre-range filter.
+ * out: boxes [<=max_num,9], scores, labels (int64), bbox_index (int64), *count_out. */
+int mv2d_decode_topk(const float* cls, const float* reg, int R, int num_classes, int max_num, const float* post_center_range,
+                     float* boxes, float* scores, long long* labels, long long* bbox_index, int* count_out,
+                     long long* topk_index_dbg, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,70 @@
+"""ctypes binding of libmv2d_hip.so (the C-ABI declared in include/mv2d_hip.h).
+
+The product path has NO fallback: if the library is missing or was built for a different arch, loading
+raises (``Mv2dHipError``) instead of silently running something else.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libmv2d_hip.so')
+
+
+class Mv2dHipError(RuntimeError):
+    pass
+
+
+P, I, LL, F, D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
+
+# name -> (restype, argtypes) — mirrors include/mv2d_hip.h one to one
+SIGNATURES = {
+    'mv2d_last_error': (C.c_char_p, []),
+    'mv2d_abi_version': (I, []),
+    'mv2d_device_arch': (I, [C.c_char_p, I]),
+    'mv2d_gemm_bf16': (I, [P, P, I, I, P, P, I, I, I, I, P, I, P, I, P, I, P, I, I, LL, I, P, P, I, I, P]),
+    'mv2d_gemm_f32': (I, [P, P, I, P, P, I, I, I, I, I, I, I, F, P, I, I, LL, P]),
+    'mv2d_row_ln': (I, [P, I, LL, P, P, P, P, I, P, P, P, P, P, P, I, F, P]),
+    'mv2d_avgpool49': (I, [P, P, I, I, P]),
+    'mv2d_f32_to_bf16': (I, [P, P, LL, P]),
+    'mv2d_nchw_to_nhwc': (I, [P, P, I, I, I, P]),
+    'mv2d_self_attn_fwd': (I, [P, P, I, P]),
+    'mv2d_sparse_xattn_fwd': (I, [P, P, P, P, P, P, P, LL, I, P]),
+    'mv2d_box_params': (I, [P, P, P, P, P, I, P, I, F, F, F, P]),
+    'mv2d_refpoint_posemb': (I, [P, I, P, P, P, P, P, I, P, P]),
+    'mv2d_roi_align': (I, [P, P, P, P, P, P, P, I, I, I, I, F, I, P]),
+    'mv2d_box_correlation': (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, F, F, F, I, P]),
+    'mv2d_csr_workspace_bytes': (LL, [I, I, I, I]),
+    'mv2d_mask_compact': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, F, P]),
+    'mv2d_csr_from_corr': (I, [P, P, P, P, I, I, I, P]),
+    'mv2d_pe_inputs': (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
+    'mv2d_decode_topk': (I, [P, P, I, I, I, P, P, P, P, P, P, P, P]),
+}
+
+_lib = None
+
+
+def load(path=None):
+    """Load (once) and return the ctypes library with typed entry points.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or os.environ.get('MV2D_HIP_LIB', LIB_PATH)
+    if not os.path.exists(path):
+        raise Mv2dHipError(
+            f'{path} not found: the MV2D HIP extension is not built.  Run `python -m mv2d_amd.build` '
+            '(or __graft_entry__.build()).  There is no CPU/PyTorch fallback for the product path.')
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise Mv2dHipError(f'{path} does not export {name}; rebuild with `python -m mv2d_amd.build --force`')
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().mv2d_last_error()
+        raise Mv2dHipError(f'{what} failed (rc={rc}): {msg.decode() if msg else ""}')

@@ -1,0 +1,77 @@
+"""Build libmv2d_hip.so (hand-written gfx950 HIP kernels + C-ABI) in-tree with hipcc.
+
+    python -m mv2d_amd.build            # compiles mv2d_amd/csrc/*.hip -> mv2d_amd/lib/libmv2d_hip.so
+
+hipcc cross-compiles for gfx950 without a GPU present.  The .so is git-ignored but travels to the GPU box.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+LIB = os.path.join(LIBDIR, 'libmv2d_hip.so')
+OBJDIR = os.path.join(LIBDIR, 'obj')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-Wno-unused-value']
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError('hipcc not found (set HIPCC=...)')
+
+
+def _sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def _digest():
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(f.encode())
+            h.update(fh.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def is_fresh():
+    stamp = LIB + '.sha256'
+    return os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == _digest()
+
+
+def build(force=False, verbose=True):
+    if not force and is_fresh():
+        return LIB
+    hipcc = _hipcc()
+    os.makedirs(OBJDIR, exist_ok=True)
+    srcs = _sources()
+
+    def cc(src):
+        obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + '.o')
+        cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed: %s\n%s' % (' '.join(cmd), r.stderr))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(cc, srcs))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed: %s\n%s' % (' '.join(cmd), r.stderr))
+    with open(LIB + '.sha256', 'w') as fh:
+        fh.write(_digest())
+    if verbose:
+        print('built', LIB, file=sys.stderr)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

@@ -1,0 +1,27 @@
+// C-ABI plumbing shared by all entry points: thread-local last-error string, version, device query.
+#include "common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+extern "C" void mv2d_set_error(const char* msg) {
+    strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
+    g_err[sizeof(g_err) - 1] = 0;
+}
+
+extern "C" const char* mv2d_last_error(void) { return g_err; }
+
+extern "C" int mv2d_abi_version(void) { return 1; }
+
+// returns the gfx arch name of the current device into buf (e.g. "gfx950:sramecc+:xnack-"); 0 on success
+extern "C" int mv2d_device_arch(char* buf, int buflen) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        mv2d_set_error("mv2d_device_arch: no HIP device");
+        return MV2D_ERR_LAUNCH;
+    }
+    strncpy(buf, prop.gcnArchName, buflen - 1);
+    buf[buflen - 1] = 0;
+    return MV2D_OK;
+}

@@ -1,0 +1,60 @@
+// Shared device helpers for the MV2D gfx950 kernels (CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MV2D_OK 0
+#define MV2D_ERR_ARG (-1)
+#define MV2D_ERR_LAUNCH (-2)
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // 8 bf16 = one MFMA 16x16x32 A/B fragment
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // one MFMA 16x16 C/D fragment
+
+extern "C" void mv2d_set_error(const char* msg);
+
+#define MV2D_CHECK_ARG(cond, msg)                 \
+    do {                                          \
+        if (!(cond)) {                            \
+            mv2d_set_error(msg);                  \
+            return MV2D_ERR_ARG;                  \
+        }                                         \
+    } while (0)
+
+#define MV2D_LAUNCH_CHECK()                                   \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) {                              \
+            mv2d_set_error(hipGetErrorString(e__));           \
+            return MV2D_ERR_LAUNCH;                           \
+        }                                                     \
+    } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) {
+    return __uint_as_float(((unsigned int)h) << 16);
+}
+
+// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

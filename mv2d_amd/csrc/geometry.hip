@@ -1,0 +1,675 @@
+// Geometry / gather kernels of the MV2D hot path (gfx950, wave64).  HBM/latency-bound integer, fp64 and
+// byte work: coalesced position-major rows, LDS bitmasks, wavefront ballots — no MFMA here on purpose.
+// Compiled with -ffp-contract=off: the fp64/fp32 comparisons against box edges must follow the reference's
+// operation order exactly (integer / boolean outputs are a bit-exact target).
+#include "common.h"
+
+namespace {
+
+constexpr int C = 256;
+
+// ------------------------------------------------------------------------------------------------
+// a3/a5/a7: per-RoI camera (RH/mv2d_head.py:51-72), intrinsics feature (:95-101) and
+//           inverse(K_roi @ E^T).float() of center2lidar (RH/utils/query_generator.py:333-341)
+// ------------------------------------------------------------------------------------------------
+__device__ bool inverse4x4(const double* m, double* inv) {
+    // Gauss-Jordan with partial pivoting (same pivoting rule as LAPACK getrf)
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { a[i][j] = m[i * 4 + j]; a[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c; double best = fabs(a[c][c]);
+        for (int r = c + 1; r < 4; ++r) { double v = fabs(a[r][c]); if (v > best) { best = v; piv = r; } }
+        if (best == 0.0) return false;
+        if (piv != c) for (int j = 0; j < 8; ++j) { double t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
+        double d = a[c][c];
+        for (int j = 0; j < 8; ++j) a[c][j] = a[c][j] / d;
+        for (int r = 0; r < 4; ++r) {
+            if (r == c) continue;
+            double f = a[r][c];
+            if (f != 0.0) for (int j = 0; j < 8; ++j) a[r][j] = a[r][j] - f * a[c][j];
+        }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) inv[i * 4 + j] = a[i][4 + j];
+    return true;
+}
+
+__global__ void box_params_kernel(const float* __restrict__ rois, const double* __restrict__ viewK, const double* __restrict__ viewE,
+                                  double* __restrict__ K_roi, float* __restrict__ intr, int ld_intr, float* __restrict__ minv,
+                                  int R, float roi_size, float intr_scale, float min_size) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float* b = rois + r * 5;
+    const int v = (int)b[0];
+    const float w = b[3] - b[1], h = b[4] - b[2];
+    const float sx = roi_size / w, sy = roi_size / h;
+    double K[16];
+    for (int i = 0; i < 16; ++i) K[i] = viewK[v * 16 + i];
+    K[2] = (K[2] - (double)b[1]) - (double)(0.5f / sx);
+    K[6] = (K[6] - (double)b[2]) - (double)(0.5f / sy);
+    for (int j = 0; j < 4; ++j) { K[j] = K[j] * (double)sx; K[4 + j] = K[4 + j] * (double)sy; }
+    const bool small = (w < min_size) || (h < min_size);
+    for (int i = 0; i < 16; ++i) {
+        if (K_roi) K_roi[r * 16 + i] = K[i];
+        float f = (float)K[i] * intr_scale;
+        f = small ? 0.f : f;
+        intr[(long long)r * ld_intr + i] = fminf(fmaxf(f, -5e3f), 5e3f);     // clamp of query_generator.py:369
+    }
+    // lidar2img = K_roi @ E^T  (E = "extrinsics", stored transposed), sequential k accumulation like bmm
+    const double* E = viewE + v * 16;
+    double L[16], Li[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; ++k) acc = acc + K[i * 4 + k] * E[j * 4 + k];
+            L[i * 4 + j] = acc;
+        }
+    bool ok = inverse4x4(L, Li);
+    for (int i = 0; i < 16; ++i) minv[r * 16 + i] = ok ? (float)Li[i] : __builtin_nanf("");
+}
+
+// ------------------------------------------------------------------------------------------------
+// a7/a8/a13: center2lidar mat-vec, pc_range normalisation (no clamp — RH/mv2d_t_head.py:51-57),
+//            pos2posemb3d (MU/pe.py:21-33): one wave per RoI, lanes over the 384 sine channels
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void refpoint_posemb_kernel(const float* __restrict__ center_pred, int ld_cp, const float* __restrict__ minv,
+                                                              const float* __restrict__ dim_t, float* __restrict__ xyz, float* __restrict__ ref,
+                                                              float* __restrict__ posemb, int R, float pc0, float pc1, float pc2,
+                                                              float pd0, float pd1, float pd2) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int lane = threadIdx.x & 63;
+    const float u = center_pred[(long long)r * ld_cp + 0], v = center_pred[(long long)r * ld_cp + 1], d = center_pred[(long long)r * ld_cp + 2];
+    const float c[4] = {u * d, v * d, d, 1.0f};
+    float p[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = acc + minv[r * 16 + i * 4 + k] * c[k];
+        p[i] = acc;
+    }
+    const float n0 = (p[0] - pc0) / pd0, n1 = (p[1] - pc1) / pd1, n2 = (p[2] - pc2) / pd2;
+    if (lane < 3) {
+        xyz[r * 3 + lane] = p[lane];
+        ref[r * 3 + lane] = lane == 0 ? n0 : (lane == 1 ? n1 : n2);
+    }
+    const float two_pi = 6.283185307179586f;
+    const float py = n1 * two_pi, px = n0 * two_pi, pz = n2 * two_pi;    // output order (y | x | z)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int ch = lane + 64 * j;           // 0..383
+        const int axis = ch >> 7, i = ch & 127;
+        const float pos = axis == 0 ? py : (axis == 1 ? px : pz);
+        const float a = pos / dim_t[i];
+        posemb[(long long)r * 384 + ch] = (i & 1) ? cosf(a) : sinf(a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a4: RoIAlign (mmcv 1.6.1 semantics: aligned, avg, adaptive sampling grid) on position-major maps.
+//     One block per RoI; thread = channel -> every bilinear tap is a fully coalesced C*4-byte row read.
+//     maps: up to two [V*h*w, 256] fp32 maps (feature, PE) -> out bf16 [R, 49, 256] each (+ optional fp32)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict__ map0, const float* __restrict__ map1, const float* __restrict__ rois,
+                                                        unsigned short* __restrict__ out0, unsigned short* __restrict__ out1,
+                                                        float* __restrict__ out0_f32, float* __restrict__ out1_f32, int H, int W,
+                                                        float spatial_scale, int sampling_ratio) {
+    const int r = blockIdx.x, c = threadIdx.x;
+    const float* b = rois + r * 5;
+    const int v = (int)b[0];
+    const float x1 = b[1] * spatial_scale - 0.5f, y1 = b[2] * spatial_scale - 0.5f;
+    const float x2 = b[3] * spatial_scale - 0.5f, y2 = b[4] * spatial_scale - 0.5f;
+    const float rw = x2 - x1, rh = y2 - y1;
+    const float bw = rw / 7.0f, bh = rh / 7.0f;
+    const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / 7.0f);
+    const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / 7.0f);
+    const float count = (float)max(gh * gw, 1);
+    const long long vbase = (long long)v * H * W;
+    const int nmaps = map1 ? 2 : 1;
+    for (int ph = 0; ph < 7; ++ph) {
+        for (int pw = 0; pw < 7; ++pw) {
+            float s0 = 0.f, s1 = 0.f;
+            for (int iy = 0; iy < gh; ++iy) {
+                const float yy = y1 + ph * bh + (iy + 0.5f) * bh / gh;
+                for (int ix = 0; ix < gw; ++ix) {
+                    const float xx = x1 + pw * bw + (ix + 0.5f) * bw / gw;
+                    if (yy < -1.0f || yy > (float)H || xx < -1.0f || xx > (float)W) continue;
+                    float y = fmaxf(yy, 0.f), x = fmaxf(xx, 0.f);
+                    int yl = (int)y, xl = (int)x, yh, xh;
+                    if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+                    if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+                    const float ly = y - yl, lx = x - xl, hy = 1.f - ly, hx = 1.f - lx;
+                    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                    const long long o1 = (vbase + (long long)yl * W + xl) * C + c, o2 = (vbase + (long long)yl * W + xh) * C + c;
+                    const long long o3 = (vbase + (long long)yh * W + xl) * C + c, o4 = (vbase + (long long)yh * W + xh) * C + c;
+                    s0 += w1 * map0[o1] + w2 * map0[o2] + w3 * map0[o3] + w4 * map0[o4];
+                    if (nmaps == 2) s1 += w1 * map1[o1] + w2 * map1[o2] + w3 * map1[o3] + w4 * map1[o4];
+                }
+            }
+            const long long o = ((long long)r * 49 + ph * 7 + pw) * C + c;
+            s0 = s0 / count;
+            if (out0) out0[o] = f32_to_bf16(s0);
+            if (out0_f32) out0_f32[o] = s0;
+            if (nmaps == 2) {
+                s1 = s1 / count;
+                if (out1) out1[o] = f32_to_bf16(s1);
+                if (out1_f32) out1_f32[o] = s1;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a9: epipolar box correlation (RH/utils/box_correlation.py:196-398, 'topk_matched:k:thr:ratio').
+//     One block per (RoI r, destination view b).  fp64 projection, fp32 compares, integer outputs.
+//     match[r][b][rank] = global RoI id or -1
+// ------------------------------------------------------------------------------------------------
+constexpr int MAX_PER_VIEW = 1024;
+
+__global__ __launch_bounds__(128) void box_corr_kernel(const float* __restrict__ rois, const int* __restrict__ view_start,
+                                                       const double* __restrict__ trans, const float* __restrict__ lin, const float* __restrict__ depths,
+                                                       int* __restrict__ match, int V, int ss, int D, int topk, float img_w_m1, float img_h_m1,
+                                                       float depth_start, float iou_thr, float ratio) {
+    __shared__ float su[128], sv[128];
+    __shared__ int svalid[128];
+    __shared__ float siou[MAX_PER_VIEW];
+    __shared__ float red[4][2];
+    __shared__ int flag[2];
+    const int r = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    int* out = match + ((long long)r * V + b) * topk;
+    for (int i = tid; i < topk; i += 128) out[i] = -1;
+    const float* rb = rois + r * 5;
+    const int a = (int)rb[0];
+    const int start = view_start[b], nb = view_start[b + 1] - start;
+    if (a == b || nb == 0) return;
+    if (tid < 2) flag[tid] = 0;
+    __syncthreads();
+    // ---- project the ss*ss*D samples of RoI r into view b
+    const int ns = ss * ss * D;   // <= 128 (host-checked)
+    bool valid = false;
+    float u32 = 0.f, v32 = 0.f;
+    if (tid < ns) {
+        const int pt = tid / D, dk = tid - pt * D;
+        const int iy = pt / ss, ix = pt - iy * ss;
+        const float wbox = rb[3] - rb[1], hbox = rb[4] - rb[2];
+        const float x = rb[1] + wbox * lin[ix], y = rb[2] + hbox * lin[iy];
+        const double d = (double)depths[dk];
+        const double hx = (double)x * d, hy = (double)y * d;
+        const double* T = trans + ((long long)a * V + b) * 16;
+        double cam[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double acc = 0.0;
+            acc = acc + T[i * 4 + 0] * hx;
+            acc = acc + T[i * 4 + 1] * hy;
+            acc = acc + T[i * 4 + 2] * d;
+            acc = acc + T[i * 4 + 3] * 1.0;
+            cam[i] = acc;
+        }
+        const double zc = cam[2] < 1e-2 ? 1e-2 : cam[2];      // clamp_min(1e-2); NaN stays NaN like torch
+        const double u = cam[0] / zc, vv = cam[1] / zc;
+        valid = !(cam[2] < (double)depth_start) && (0.0 <= u) && (u <= (double)img_w_m1) && (0.0 <= vv) && (vv <= (double)img_h_m1);
+        u32 = (float)u; v32 = (float)vv;
+    }
+    su[tid] = u32; sv[tid] = v32; svalid[tid] = valid ? 1 : 0;
+    if (valid) flag[0] = 1;
+    __syncthreads();
+    if (!flag[0]) return;
+    // ---- does any valid sample fall inside any RoI of view b? (closed intervals, :299-300)
+    if (valid) {
+        bool hit = false;
+        for (int m = 0; m < nb && !hit; ++m) {
+            const float* mb = rois + (long long)(start + m) * 5;
+            hit = (mb[1] <= u32) && (u32 <= mb[3]) && (mb[2] <= v32) && (v32 <= mb[4]);
+        }
+        if (hit) flag[1] = 1;
+    }
+    __syncthreads();
+    if (!flag[1]) return;
+    // ---- bounding rectangle of ALL valid projected samples (:347-355), sentinels +-1e4
+    float umin = valid ? u32 : 1e4f, vmin = valid ? v32 : 1e4f, umax = valid ? u32 : -1e4f, vmax = valid ? v32 : -1e4f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        umin = fminf(umin, __shfl_xor(umin, o, 64)); vmin = fminf(vmin, __shfl_xor(vmin, o, 64));
+        umax = fmaxf(umax, __shfl_xor(umax, o, 64)); vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = umin; red[1][tid >> 6] = vmin; red[2][tid >> 6] = umax; red[3][tid >> 6] = vmax; }
+    __syncthreads();
+    const float a0 = fminf(red[0][0], red[0][1]), a1 = fminf(red[1][0], red[1][1]);
+    const float a2 = fmaxf(red[2][0], red[2][1]), a3 = fmaxf(red[3][0], red[3][1]);
+    // ---- IoU against every RoI of view b (:385-398)
+    for (int m = tid; m < nb; m += 128) {
+        const float* mb = rois + (long long)(start + m) * 5;
+        const float xs = fmaxf(a0, mb[1]), ys = fmaxf(a1, mb[2]), xe = fminf(a2, mb[3]), ye = fminf(a3, mb[4]);
+        const float w = fmaxf(xe - xs, 0.f), h = fmaxf(ye - ys, 0.f);
+        const float inter = w * h;
+        const float area_a = (a2 - a0) * (a3 - a1), area_b = (mb[3] - mb[1]) * (mb[4] - mb[2]);
+        const float uni = area_a + area_b - inter;
+        siou[m] = inter / (uni + 1e-4f);
+    }
+    __syncthreads();
+    // ---- top-k by IoU, descending, stable (lower index first among equals); keep rule of :374
+    float top = 0.f;
+    for (int j = 0; j < nb; ++j) top = fmaxf(top, siou[j]);
+    for (int m = tid; m < nb; m += 128) {
+        const float x = siou[m];
+        int rank = 0;
+        for (int j = 0; j < nb; ++j) { const float y = siou[j]; rank += (y > x || (y == x && j < m)) ? 1 : 0; }
+        if (rank < topk) {
+            const bool keep = ((x > ratio * top) || (x > iou_thr)) && (x > 0.f);
+            out[rank] = keep ? (start + m) : -1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a11/a12: T-path masks -> compacted key list + CSR (RH/utils/box_correlation.py:101-115,147-157 and
+//          RH/mv2d_t_head.py:67-88).  cell centre c = (i + 0.5) * stride - 0.5; in-RoI iff
+//          c + 0.5*stride + e*stride >= x1  and  c - 0.5*stride - e*stride <= x2  (both axes).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void roi_cell_range(const float* rb, int h, int w, float stride, float expand, int& y0, int& y1, int& x0, int& x1) {
+    // explicit per-cell test (fp32, reference op order); the ranges are small so a scan of the axis is cheap
+    x0 = w; x1 = -1; y0 = h; y1 = -1;
+    for (int i = 0; i < w; ++i) {
+        const float c = ((float)i + 0.5f) * stride - 0.5f;
+        const bool in = ((c + 0.5f * stride) + expand * stride >= rb[1]) && ((c - 0.5f * stride) - expand * stride <= rb[3]);
+        if (in) { x0 = min(x0, i); x1 = max(x1, i); }
+    }
+    for (int i = 0; i < h; ++i) {
+        const float c = ((float)i + 0.5f) * stride - 0.5f;
+        const bool in = ((c + 0.5f * stride) + expand * stride >= rb[2]) && ((c - 0.5f * stride) - expand * stride <= rb[4]);
+        if (in) { y0 = min(y0, i); y1 = max(y1, i); }
+    }
+}
+
+// rect[r] = (view, y0, y1, x0, x1) and roi_mask[P] |= own-view rect   (roi_mask pre-zeroed)
+__global__ __launch_bounds__(64) void csr_mark_kernel(const float* __restrict__ rois, int* __restrict__ rect, unsigned char* __restrict__ roi_mask,
+                                                      int h, int w, float stride, float expand) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    __shared__ int sr[4];
+    const float* rb = rois + r * 5;
+    if (lane == 0) {
+        int y0, y1, x0, x1;
+        roi_cell_range(rb, h, w, stride, expand, y0, y1, x0, x1);
+        sr[0] = y0; sr[1] = y1; sr[2] = x0; sr[3] = x1;
+        rect[r * 5 + 0] = (int)rb[0]; rect[r * 5 + 1] = y0; rect[r * 5 + 2] = y1; rect[r * 5 + 3] = x0; rect[r * 5 + 4] = x1;
+    }
+    __syncthreads();
+    const int v = (int)rb[0], y0 = sr[0], y1 = sr[1], x0 = sr[2], x1 = sr[3];
+    if (y1 < y0 || x1 < x0) return;
+    const int nw = x1 - x0 + 1, n = (y1 - y0 + 1) * nw;
+    for (int i = lane; i < n; i += 64) {
+        const int y = y0 + i / nw, x = x0 + i % nw;
+        roi_mask[((long long)v * h + y) * w + x] = 1;
+    }
+}
+
+// single block: pos2s[P] = index into the compacted key list or -1 (not in any RoI rect, or padding),
+// s2pos[S] = flat (v,y,x) position, *S = count.  Row-major (v,y,x) order like the reference's boolean indexing.
+__global__ __launch_bounds__(1024) void csr_scan_positions_kernel(const unsigned char* __restrict__ roi_mask, const unsigned char* __restrict__ pad_mask,
+                                                                  int* __restrict__ pos2s, int* __restrict__ s2pos, int* __restrict__ S_out, int P) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < P; base += 1024) {
+        const int i = base + tid;
+        const int f = (i < P && roi_mask[i] && !pad_mask[i]) ? 1 : 0;
+        const unsigned long long bal = __ballot(f);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wv] = __popcll(bal);
+        __syncthreads();
+        int off = carry;
+        for (int k = 0; k < wv; ++k) off += wsum[k];
+        if (i < P) {
+            pos2s[i] = f ? off + pre : -1;
+            if (f) s2pos[off + pre] = i;
+        }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; carry += t; }
+        __syncthreads();
+    }
+    if (tid == 0) *S_out = carry;
+}
+
+// per query: OR the rects of (self + matched RoIs) into an LDS bitmask over P cells, drop cells that are not
+// in the key list (padding), write the bitmask and the row count.
+__global__ __launch_bounds__(256) void csr_count_kernel(const int* __restrict__ rect, const int* __restrict__ match, const int* __restrict__ pos2s,
+                                                        unsigned int* __restrict__ bits, int* __restrict__ row_count, int h, int w, int V, int topk, int P) {
+    extern __shared__ unsigned int sb[];
+    __shared__ int cnt;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int nwords = (P + 31) / 32;
+    for (int i = tid; i < nwords; i += 256) sb[i] = 0u;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    const int nm = 1 + V * topk;
+    for (int j = 0; j < nm; ++j) {
+        const int m = (j == 0) ? r : match[(long long)r * V * topk + (j - 1)];
+        if (m < 0) continue;
+        const int v = rect[m * 5], y0 = rect[m * 5 + 1], y1 = rect[m * 5 + 2], x0 = rect[m * 5 + 3], x1 = rect[m * 5 + 4];
+        if (y1 < y0 || x1 < x0) continue;
+        const int nw = x1 - x0 + 1, n = (y1 - y0 + 1) * nw;
+        for (int i = tid; i < n; i += 256) {
+            const int pos = (v * h + y0 + i / nw) * w + x0 + i % nw;
+            if (pos2s[pos] >= 0) atomicOr(&sb[pos >> 5], 1u << (pos & 31));
+        }
+    }
+    __syncthreads();
+    int c = 0;
+    for (int i = tid; i < nwords; i += 256) { const unsigned int x = sb[i]; bits[(long long)r * nwords + i] = x; c += __popc(x); }
+    c = (int)wave_sum((float)c);   // counts < 2^24: exact in fp32
+    if ((tid & 63) == 0) atomicAdd(&cnt, c);
+    __syncthreads();
+    if (tid == 0) row_count[r] = cnt;
+}
+
+// per query: row_ptr[r] = sum(row_count[0..r)), then expand the bitmask into ascending key indices.
+__global__ __launch_bounds__(256) void csr_fill_kernel(const unsigned int* __restrict__ bits, const int* __restrict__ row_count, const int* __restrict__ pos2s,
+                                                       int* __restrict__ row_ptr, int* __restrict__ col_idx, int* __restrict__ nnz_out, int R, int P) {
+    __shared__ int sbase;
+    __shared__ int wsum[4];
+    __shared__ int carry;
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int part = 0;
+    for (int i = tid; i < r; i += 256) part += row_count[i];
+    part = (int)wave_sum((float)part);
+    if (tid == 0) { sbase = 0; carry = 0; }
+    __syncthreads();
+    if (lane == 0) atomicAdd(&sbase, part);
+    __syncthreads();
+    const int base = sbase;
+    if (tid == 0) {
+        row_ptr[r] = base;
+        if (r == R - 1) { row_ptr[R] = base + row_count[r]; *nnz_out = base + row_count[r]; }
+    }
+    const int nwords = (P + 31) / 32;
+    for (int w0 = 0; w0 < nwords; w0 += 256) {
+        const int wi = w0 + tid;
+        const unsigned int x = wi < nwords ? bits[(long long)r * nwords + wi] : 0u;
+        const int c = __popc(x);
+        // inclusive wave scan of c
+        int s = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(s, o, 64); if (lane >= o) s += t; }
+        if (lane == 63) wsum[wv] = s;
+        __syncthreads();
+        int off = carry + s - c;
+        for (int k = 0; k < wv; ++k) off += wsum[k];
+        unsigned int y = x;
+        while (y) {
+            const int bit = __ffs(y) - 1;
+            y &= y - 1;
+            col_idx[base + off++] = pos2s[wi * 32 + bit];
+        }
+        __syncthreads();
+        if (tid == 0) carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+}
+
+// S-path CSR over the RoI-feature memory (R*49 rows): keys of query r = 49 cells of self, then of each kept
+// correlated RoI in (view, rank) order (RH/mv2d_s_head.py:184-192 + box_correlation.py:165-193).
+__global__ __launch_bounds__(1024) void csr_from_corr_kernel(const int* __restrict__ match, int* __restrict__ row_ptr, int* __restrict__ col_idx,
+                                                             int* __restrict__ nnz_out, int R, int V, int topk) {
+    __shared__ int cnts[1024];
+    __shared__ int carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < R; base += 1024) {
+        const int r = base + tid;
+        int n = 0;
+        if (r < R) { n = 1; for (int j = 0; j < V * topk; ++j) n += match[(long long)r * V * topk + j] >= 0 ? 1 : 0; }
+        cnts[tid] = n * 49;
+        __syncthreads();
+        if (tid == 0) { int acc = carry; for (int k = 0; k < 1024; ++k) { int t = cnts[k]; cnts[k] = acc; acc += t; } carry = acc; }
+        __syncthreads();
+        if (r < R) {
+            int o = cnts[tid];
+            row_ptr[r] = o;
+            for (int c = 0; c < 49; ++c) col_idx[o++] = r * 49 + c;
+            for (int j = 0; j < V * topk; ++j) {
+                const int m = match[(long long)r * V * topk + j];
+                if (m >= 0) for (int c = 0; c < 49; ++c) col_idx[o++] = m * 49 + c;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { row_ptr[R] = carry; *nnz_out = carry; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a2 inputs: for every key position s of the compacted list build the three PE-MLP input rows and gather
+// the feature row (MU/pe.py:84-135 frustum coords in fp64, MU/positional_encoding.py:78-95 sine features).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pe_inputs_kernel(const int* __restrict__ s2pos, const int* __restrict__ S_dev, const float* __restrict__ featcl,
+                                                        const double* __restrict__ img2lidar, const double* __restrict__ coords_w, const double* __restrict__ coords_h,
+                                                        const double* __restrict__ coords_d, const float* __restrict__ embeds, const float* __restrict__ dim_t,
+                                                        unsigned short* __restrict__ A_frustum, unsigned short* __restrict__ A_sine, unsigned short* __restrict__ Xf_bf16,
+                                                        float* __restrict__ Xf_f32, int h, int w, int P, int D, double pr0, double pr1, double pr2,
+                                                        double pd0, double pd1, double pd2) {
+    const int s = blockIdx.x, tid = threadIdx.x;
+    if (s >= *S_dev) return;
+    const int pos = s2pos[s];
+    const int v = pos / (h * w), rem = pos - v * h * w, y = rem / w, x = rem - y * w;
+    // feature row gather (fp32 kept for the K = feat + pe sum, bf16 for the SE gate and the V projection)
+    {
+        const float f = featcl[(long long)pos * C + tid];
+        Xf_f32[(long long)s * C + tid] = f;
+        Xf_bf16[(long long)s * C + tid] = f32_to_bf16(f);
+    }
+    if (tid < D) {
+        const double d = coords_d[tid];
+        const double dm = d < 1e-3 ? 1e-3 : d;
+        const double p[4] = {coords_w[x] * dm, coords_h[y] * dm, d, 1.0};
+        const double* M = img2lidar + v * 16;
+        const double pr[3] = {pr0, pr1, pr2}, pd[3] = {pd0, pd1, pd2};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = acc + M[i * 4 + k] * p[k];
+            double n = (acc - pr[i]) / pd[i];
+            n = n < 0.0 ? 0.0 : (n > 1.0 ? 1.0 : n);          // inverse_sigmoid: clamp(0,1)
+            const double x1 = n < 1e-5 ? 1e-5 : n;
+            const double x2 = (1.0 - n) < 1e-5 ? 1e-5 : (1.0 - n);
+            A_frustum[(long long)s * (3 * D) + tid * 3 + i] = f32_to_bf16((float)log(x1 / x2));
+        }
+    }
+    // sine features, channel order (n | y | x), even channel sin, odd channel cos
+    const float en = embeds[pos], ey = embeds[P + pos], ex = embeds[2 * P + pos];
+    for (int ch = tid; ch < 384; ch += 256) {
+        const int axis = ch >> 7, i = ch & 127;
+        const float e = axis == 0 ? en : (axis == 1 ? ey : ex);
+        const float a = e / dim_t[i];
+        A_sine[(long long)s * 384 + ch] = f32_to_bf16((i & 1) ? cosf(a) : sinf(a));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a21: NMS-free decode (CB/coders/nms_free_coder.py:49-102, CB/util.py:60-87,
+//      cross_attention_head.py:372): single block, bitonic sort of (logit, index) in LDS.
+//      Order: logit descending, lower flat index first among equals.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void decode_topk_kernel(const float* __restrict__ cls, const float* __restrict__ reg, int R, int ncls, int max_num,
+                                                           int npow2, float r0, float r1, float r2, float r3, float r4, float r5,
+                                                           float* __restrict__ boxes, float* __restrict__ scores, long long* __restrict__ labels,
+                                                           long long* __restrict__ bbox_index, int* __restrict__ count_out,
+                                                           long long* __restrict__ topk_index_dbg) {
+    extern __shared__ unsigned long long keys[];
+    __shared__ int kept_off[1025];
+    const int tid = threadIdx.x, n = R * ncls;
+    for (int i = tid; i < npow2; i += 1024) {
+        unsigned long long k = 0ull;                      // padding sorts last
+        if (i < n) {
+            unsigned int u = __float_as_uint(cls[i]);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);           // monotone float -> uint
+            k = ((unsigned long long)u << 32) | (unsigned int)(0xffffffffu - (unsigned int)i);
+        }
+        keys[i] = k;
+    }
+    __syncthreads();
+    for (int k2 = 2; k2 <= npow2; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npow2; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = keys[i], b = keys[ixj];
+                    const bool desc = (i & k2) == 0;
+                    if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int K = min(max_num, n);
+    // ---- gather + denormalise + centre-range filter, kept entries keep their rank order
+    int keep = 0;
+    float bx[9]; float sc = 0.f; int idx = 0;
+    if (tid < K) {
+        idx = (int)(0xffffffffu - (unsigned int)(keys[tid] & 0xffffffffull));
+        if (topk_index_dbg) topk_index_dbg[tid] = idx;
+        const int q = idx / ncls;
+        const float* bp = reg + (long long)q * 10;
+        sc = 1.0f / (1.0f + expf(-cls[idx]));
+        bx[0] = bp[0]; bx[1] = bp[1]; bx[2] = bp[4];
+        bx[3] = expf(bp[2]); bx[4] = expf(bp[3]); bx[5] = expf(bp[5]);
+        bx[6] = atan2f(bp[6], bp[7]); bx[7] = bp[8]; bx[8] = bp[9];
+        keep = (bx[0] >= r0 && bx[1] >= r1 && bx[2] >= r2 && bx[0] <= r3 && bx[1] <= r4 && bx[2] <= r5) ? 1 : 0;
+    }
+    kept_off[tid] = keep;
+    __syncthreads();
+    if (tid == 0) { int acc = 0; for (int i = 0; i < 1024; ++i) { int t = kept_off[i]; kept_off[i] = acc; acc += t; } kept_off[1024] = acc; *count_out = acc; }
+    __syncthreads();
+    if (keep) {
+        const int o = kept_off[tid];
+        bx[2] = bx[2] - bx[5] * 0.5f;                       // gravity centre -> bottom centre (:372)
+        for (int i = 0; i < 9; ++i) boxes[o * 9 + i] = bx[i];
+        scores[o] = sc;
+        labels[o] = idx % ncls;
+        bbox_index[o] = idx / ncls;
+    }
+}
+
+}  // namespace
+
+// ================================================================================================
+// C-ABI
+// ================================================================================================
+extern "C" int mv2d_box_params(const float* rois, const double* viewK, const double* viewE, double* K_roi, float* intr,
+                               int ld_intr, float* minv, int R, float roi_size, float intr_scale, float min_size, void* stream) {
+    MV2D_CHECK_ARG(rois && viewK && viewE && intr && minv && ld_intr >= 16, "mv2d_box_params: bad args");
+    if (R == 0) return MV2D_OK;
+    hipLaunchKernelGGL(box_params_kernel, dim3(cdiv(R, 64)), dim3(64), 0, (hipStream_t)stream, rois, viewK, viewE, K_roi, intr,
+                       ld_intr, minv, R, roi_size, intr_scale, min_size);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_refpoint_posemb(const float* center_pred, int ld_cp, const float* minv, const float* dim_t, float* xyz, float* ref,
+                                    float* posemb, int R, const float* pc_range, void* stream) {
+    MV2D_CHECK_ARG(center_pred && minv && dim_t && xyz && ref && posemb && pc_range, "mv2d_refpoint_posemb: bad args");
+    if (R == 0) return MV2D_OK;
+    hipLaunchKernelGGL(refpoint_posemb_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, center_pred, ld_cp, minv, dim_t,
+                       xyz, ref, posemb, R, pc_range[0], pc_range[1], pc_range[2], pc_range[3] - pc_range[0],
+                       pc_range[4] - pc_range[1], pc_range[5] - pc_range[2]);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_roi_align(const float* map0, const float* map1, const float* rois, void* out0, void* out1, float* out0_f32,
+                              float* out1_f32, int R, int H, int W, int channels, float spatial_scale, int sampling_ratio, void* stream) {
+    MV2D_CHECK_ARG(map0 && rois && channels == C, "mv2d_roi_align: needs 256-channel position-major maps");
+    MV2D_CHECK_ARG(out0 || out0_f32, "mv2d_roi_align: no output");
+    if (R == 0) return MV2D_OK;
+    hipLaunchKernelGGL(roi_align_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, map0, map1, rois, (unsigned short*)out0,
+                       (unsigned short*)out1, out0_f32, out1_f32, H, W, spatial_scale, sampling_ratio);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_box_correlation(const float* rois, const int* view_start, const double* trans, const float* lin, const float* depths,
+                                    int* match, int R, int V, int sample_size, int num_depth, int topk, int pad_h, int pad_w,
+                                    float depth_start, float iou_thr, float ratio, int max_per_view, void* stream) {
+    MV2D_CHECK_ARG(rois && view_start && trans && lin && depths && match, "mv2d_box_correlation: null pointer");
+    MV2D_CHECK_ARG(sample_size * sample_size * num_depth <= 128, "mv2d_box_correlation: sample_size^2*num_depth must be <= 128");
+    MV2D_CHECK_ARG(max_per_view <= MAX_PER_VIEW && topk >= 1, "mv2d_box_correlation: too many RoIs in one view (max 1024)");
+    if (R == 0) return MV2D_OK;
+    hipLaunchKernelGGL(box_corr_kernel, dim3(R, V), dim3(128), 0, (hipStream_t)stream, rois, view_start, trans, lin, depths, match, V,
+                       sample_size, num_depth, topk, (float)(pad_w - 1), (float)(pad_h - 1), depth_start, iou_thr, ratio);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" long long mv2d_csr_workspace_bytes(int R, int V, int h, int w) {
+    const long long P = (long long)V * h * w;
+    return (long long)R * ((P + 31) / 32) * 4;
+}
+
+// T-path: roi_mask must be zeroed by the caller (hipMemsetAsync) before this call.
+extern "C" int mv2d_mask_compact(const float* rois, const int* match, const unsigned char* pad_mask, unsigned char* roi_mask,
+                                 int* rect, int* pos2s, int* s2pos, int* S_out, unsigned int* bits_ws, int* row_count, int* row_ptr,
+                                 int* col_idx, int* nnz_out, int R, int V, int h, int w, int topk, float stride, float expand_stride,
+                                 void* stream) {
+    MV2D_CHECK_ARG(rois && match && pad_mask && roi_mask && rect && pos2s && s2pos && S_out && bits_ws && row_count && row_ptr &&
+                       col_idx && nnz_out, "mv2d_mask_compact: null pointer");
+    MV2D_CHECK_ARG(R > 0, "mv2d_mask_compact: R must be > 0");
+    const int P = V * h * w;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(csr_mark_kernel, dim3(R), dim3(64), 0, st, rois, rect, roi_mask, h, w, stride, expand_stride);
+    hipLaunchKernelGGL(csr_scan_positions_kernel, dim3(1), dim3(1024), 0, st, roi_mask, pad_mask, pos2s, s2pos, S_out, P);
+    const int nwords = (P + 31) / 32;
+    hipLaunchKernelGGL(csr_count_kernel, dim3(R), dim3(256), nwords * 4, st, rect, match, pos2s, bits_ws, row_count, h, w, V, topk, P);
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(R), dim3(256), 0, st, bits_ws, row_count, pos2s, row_ptr, col_idx, nnz_out, R, P);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_csr_from_corr(const int* match, int* row_ptr, int* col_idx, int* nnz_out, int R, int V, int topk, void* stream) {
+    MV2D_CHECK_ARG(match && row_ptr && col_idx && nnz_out && R > 0, "mv2d_csr_from_corr: bad args");
+    hipLaunchKernelGGL(csr_from_corr_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, match, row_ptr, col_idx, nnz_out, R, V, topk);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_pe_inputs(const int* s2pos, const int* S_dev, int S_max, const float* featcl, const double* img2lidar,
+                              const double* coords_w, const double* coords_h, const double* coords_d, const float* embeds,
+                              const float* dim_t, void* A_frustum, void* A_sine, void* Xf_bf16, float* Xf_f32, int V, int h, int w,
+                              int depth_num, const double* position_range, void* stream) {
+    MV2D_CHECK_ARG(s2pos && S_dev && featcl && img2lidar && coords_w && coords_h && coords_d && embeds && dim_t && A_frustum &&
+                       A_sine && Xf_bf16 && Xf_f32 && position_range, "mv2d_pe_inputs: null pointer");
+    MV2D_CHECK_ARG(depth_num <= 256, "mv2d_pe_inputs: depth_num must be <= 256");
+    if (S_max == 0) return MV2D_OK;
+    hipLaunchKernelGGL(pe_inputs_kernel, dim3(S_max), dim3(256), 0, (hipStream_t)stream, s2pos, S_dev, featcl, img2lidar, coords_w,
+                       coords_h, coords_d, embeds, dim_t, (unsigned short*)A_frustum, (unsigned short*)A_sine,
+                       (unsigned short*)Xf_bf16, Xf_f32, h, w, V * h * w, depth_num, position_range[0], position_range[1],
+                       position_range[2], position_range[3] - position_range[0], position_range[4] - position_range[1],
+                       position_range[5] - position_range[2]);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_decode_topk(const float* cls, const float* reg, int R, int num_classes, int max_num, const float* post_center_range,
+                                float* boxes, float* scores, long long* labels, long long* bbox_index, int* count_out,
+                                long long* topk_index_dbg, void* stream) {
+    MV2D_CHECK_ARG(cls && reg && post_center_range && boxes && scores && labels && bbox_index && count_out, "mv2d_decode_topk: null pointer");
+    MV2D_CHECK_ARG(max_num >= 1 && max_num <= 1024, "mv2d_decode_topk: max_num must be in [1, 1024]");
+    const int n = R * num_classes;
+    MV2D_CHECK_ARG(n > 0 && n <= 16384, "mv2d_decode_topk: R*num_classes must be in [1, 16384]");
+    int npow2 = 1024;
+    while (npow2 < n) npow2 <<= 1;
+    const size_t lds = (size_t)npow2 * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)decode_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(decode_topk_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, cls, reg, R, num_classes, max_num, npow2,
+                       post_center_range[0], post_center_range[1], post_center_range[2], post_center_range[3], post_center_range[4],
+                       post_center_range[5], boxes, scores, labels, bbox_index, count_out, topk_index_dbg);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}

@@ -1,0 +1,139 @@
+// Row-wise kernels over the [R, 256] query state of the MV2D decoder (gfx950, one wave64 per row,
+// 4 channels per lane, wavefront reductions — no LDS).
+#include "common.h"
+
+namespace {
+
+constexpr int C = 256;
+
+struct LnParams {
+    const float* parts; int n_parts; long long part_stride;   // sum of split-K partial slabs [n_parts][M][256]
+    const float* bias;          // [256] or null
+    const float* residual;      // [M,256] or null
+    const float* ln_w; const float* ln_b;   // LayerNorm affine (null -> no LN, plain sum)
+    int relu;                   // ReLU after LN
+    float* out;                 // [M,256]  y
+    const float* addvec; float* out_plus;   // out_plus = y + addvec (e.g. query_pos) or null
+    const float* ln2_w; const float* ln2_b; float* out2;   // out2 = LN2(y) (shared post_norm) or null
+    int M; float eps;
+};
+
+__device__ __forceinline__ float4 ln4(float4 v, const float* w, const float* b, int c0, float eps) {
+    float s = wave_sum(v.x + v.y + v.z + v.w);
+    float mean = s * (1.0f / C);
+    float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+    float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / C);
+    float rstd = 1.0f / sqrtf(var + eps);
+    float4 ww = *reinterpret_cast<const float4*>(w + c0);
+    float4 bb = *reinterpret_cast<const float4*>(b + c0);
+    return make_float4(dx * rstd * ww.x + bb.x, dy * rstd * ww.y + bb.y, dz * rstd * ww.z + bb.z, dw * rstd * ww.w + bb.w);
+}
+
+// MU/petr_transformer.py:563-565,589-590 (norms / post_norm), mmcv BaseTransformerLayer residual rules,
+// cross_attention_head.py:127-133 (Linear-LN-ReLU of the cls branch)
+__global__ __launch_bounds__(256) void row_ln_kernel(LnParams p) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const int lane = threadIdx.x & 63, c0 = lane * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < p.n_parts; ++s) {
+        float4 t = *reinterpret_cast<const float4*>(p.parts + s * p.part_stride + (long long)row * C + c0);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (p.bias) {
+        float4 t = *reinterpret_cast<const float4*>(p.bias + c0);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (p.residual) {
+        float4 t = *reinterpret_cast<const float4*>(p.residual + (long long)row * C + c0);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (p.ln_w) v = ln4(v, p.ln_w, p.ln_b, c0, p.eps);
+    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (p.out) *reinterpret_cast<float4*>(p.out + (long long)row * C + c0) = v;
+    if (p.out_plus) {
+        float4 t = *reinterpret_cast<const float4*>(p.addvec + (long long)row * C + c0);
+        *reinterpret_cast<float4*>(p.out_plus + (long long)row * C + c0) = make_float4(v.x + t.x, v.y + t.y, v.z + t.z, v.w + t.w);
+    }
+    if (p.out2) *reinterpret_cast<float4*>(p.out2 + (long long)row * C + c0) = ln4(v, p.ln2_w, p.ln2_b, c0, p.eps);
+}
+
+// RH/utils/query_generator.py:322-331: AvgPool2d(7) over the 49 cells of relu(conv) -> [R,256]
+__global__ __launch_bounds__(256) void avgpool49_kernel(const float* x, float* out, int ld_out, int R) {
+    const int r = blockIdx.x, c = threadIdx.x;
+    if (r >= R) return;
+    float s = 0.f;
+    for (int i = 0; i < 49; ++i) s += x[((long long)r * 49 + i) * C + c];
+    out[(long long)r * ld_out + c] = s / 49.0f;
+}
+
+// fp32 -> bf16 copy (weights / activations), n multiple of 4 handled with a tail
+__global__ void f32_to_bf16_kernel(const float* x, unsigned short* y, long long n) {
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        float4 v = *reinterpret_cast<const float4*>(x + i);
+        uint2 o = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        *reinterpret_cast<uint2*>(y + i) = o;
+    } else {
+        for (; i < n; ++i) y[i] = f32_to_bf16(x[i]);
+    }
+}
+
+// NCHW fp32 [V,C,h*w] -> position-major [V*h*w, C] fp32 (LDS-tiled transpose, coalesced both ways)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, float* y, int V, int Cn, int HW) {
+    __shared__ float tile[32][33];
+    const int v = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        int c = c0 + i, p = p0 + tx;
+        tile[i][tx] = (c < Cn && p < HW) ? x[((long long)v * Cn + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        int p = p0 + i, c = c0 + tx;
+        if (p < HW && c < Cn) y[((long long)v * HW + p) * Cn + c] = tile[tx][i];
+    }
+}
+
+}  // namespace
+
+extern "C" int mv2d_row_ln(const float* parts, int n_parts, long long part_stride, const float* bias,
+                           const float* residual, const float* ln_w, const float* ln_b, int relu, float* out,
+                           const float* addvec, float* out_plus, const float* ln2_w, const float* ln2_b, float* out2,
+                           int M, float eps, void* stream) {
+    MV2D_CHECK_ARG(parts && n_parts >= 1 && (out || out_plus || out2), "mv2d_row_ln: null input/output");
+    MV2D_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr), "mv2d_row_ln: ln_w/ln_b must both be set or null");
+    MV2D_CHECK_ARG(!out_plus || addvec, "mv2d_row_ln: out_plus needs addvec");
+    MV2D_CHECK_ARG(!out2 || (ln2_w && ln2_b), "mv2d_row_ln: out2 needs ln2_w/ln2_b");
+    if (M == 0) return MV2D_OK;
+    LnParams p{parts, n_parts, part_stride, bias, residual, ln_w, ln_b, relu, out, addvec, out_plus, ln2_w, ln2_b, out2, M, eps};
+    hipLaunchKernelGGL(row_ln_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, p);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_avgpool49(const float* x, float* out, int ld_out, int R, void* stream) {
+    MV2D_CHECK_ARG(x && out && ld_out >= 256, "mv2d_avgpool49: bad args");
+    if (R == 0) return MV2D_OK;
+    hipLaunchKernelGGL(avgpool49_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, x, out, ld_out, R);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_f32_to_bf16(const float* x, void* y, long long n, void* stream) {
+    MV2D_CHECK_ARG(x && y && n >= 0, "mv2d_f32_to_bf16: bad args");
+    if (n == 0) return MV2D_OK;
+    long long threads = (n + 3) / 4;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (unsigned short*)y, n);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_nchw_to_nhwc(const float* x, float* y, int V, int Cn, int HW, void* stream) {
+    MV2D_CHECK_ARG(x && y && V > 0 && Cn > 0 && HW > 0, "mv2d_nchw_to_nhwc: bad args");
+    dim3 grid(cdiv(HW, 32), cdiv(Cn, 32), V);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, V, Cn, HW);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}

@@ -1,0 +1,202 @@
+"""Torch-tensor wrappers over the C-ABI (include/mv2d_hip.h).  PyTorch is plumbing only: device memory,
+streams.  Every wrapper enqueues on ``torch.cuda.current_stream()`` and never synchronises.
+
+There is no CPU path here: tensors must live on a HIP device and the extension must be loadable.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _req(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.Mv2dHipError(f'{name}: tensor must be on the GPU (no CPU fallback in the product path)')
+    if t.dtype != dtype:
+        raise _lib.Mv2dHipError(f'{name}: expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise _lib.Mv2dHipError(f'{name}: tensor must be contiguous')
+
+
+def gemm_bf16(A, W, bias=None, *, M=None, A2=None, n_split=0, conv3x3=False, m_dev=None, act=0, mul=None, add=None,
+              out=None, out_dtype=BF16, c_blk_stride=0, c_blk_cols=0, out2=None, add2=None, lda=None, ldc=None):
+    """C = epi(A @ W.T + bias) with bf16 MFMA.  A [M,K] bf16 (or [R,49,256] when conv3x3), W [N,K] bf16."""
+    lib = _lib.load()
+    _req(A, BF16, 'A'); _req(W, BF16, 'W'); _req(A2, BF16, 'A2')
+    _req(bias, torch.float32, 'bias'); _req(mul, torch.float32, 'mul'); _req(add, torch.float32, 'add'); _req(add2, torch.float32, 'add2')
+    N, K = W.shape
+    if conv3x3:
+        Mrows = A.shape[0] * 49
+        lda_ = 256
+    else:
+        Mrows = A.shape[0]
+        lda_ = A.stride(0) if lda is None else lda
+    M = Mrows if M is None else M
+    if out is None and out2 is None:
+        out = torch.empty((M, N), device=A.device, dtype=out_dtype)
+    c_bf16 = 1 if (out is not None and out.dtype == BF16) else 0
+    ldc_ = (out.stride(0) if (out is not None and out.dim() == 2 and ldc is None) else (ldc or N))
+    rc = lib.mv2d_gemm_bf16(_p(A), _p(A2), n_split, 1 if conv3x3 else 0, _p(W), _p(bias), M, N, K, lda_, _p(m_dev), act,
+                            _p(mul), mul.stride(0) if mul is not None else 0, _p(add), add.stride(0) if add is not None else 0,
+                            _p(out), c_bf16, ldc_, c_blk_stride, c_blk_cols, _p(out2), _p(add2),
+                            out2.stride(0) if out2 is not None else 0, add2.stride(0) if add2 is not None else 0, _stream())
+    check(rc, 'mv2d_gemm_bf16')
+    return out if out is not None else out2
+
+
+def gemm_f32(A, W, bias=None, *, A2=None, n_split=0, split_k=1, act=0, scale=1.0, out=None, out_dtype=torch.float32,
+             M=None, lda=None, ldc=None):
+    """C = epi((A @ W.T + bias) * scale), exact fp32 MFMA.  A [M,K] fp32, W [N,K] fp32."""
+    lib = _lib.load()
+    _req(A, torch.float32, 'A'); _req(W, torch.float32, 'W'); _req(A2, torch.float32, 'A2'); _req(bias, torch.float32, 'bias')
+    N, K = W.shape
+    M = A.shape[0] if M is None else M
+    lda_ = A.stride(0) if lda is None else lda
+    if out is None:
+        shape = (split_k, M, N) if split_k > 1 else (M, N)
+        out = torch.empty(shape, device=A.device, dtype=out_dtype)
+    ldc_ = ldc if ldc is not None else (out.stride(-2))
+    slice_stride = out.stride(0) if (split_k > 1) else 0
+    rc = lib.mv2d_gemm_f32(_p(A), _p(A2), n_split, _p(W), _p(bias), M, N, K, lda_, W.stride(0), split_k, act, float(scale),
+                           _p(out), 1 if out.dtype == BF16 else 0, ldc_, slice_stride, _stream())
+    check(rc, 'mv2d_gemm_f32')
+    return out
+
+
+def row_ln(parts, *, bias=None, residual=None, ln=None, relu=False, out=None, addvec=None, out_plus=None, ln2=None, out2=None,
+           M=None, eps=1e-5):
+    """y = [relu][LN](sum parts + bias + residual); parts [M,256] or [Z,M,256]."""
+    lib = _lib.load()
+    _req(parts, torch.float32, 'parts')
+    if parts.dim() == 2:
+        n_parts, stride = 1, 0
+        M = parts.shape[0] if M is None else M
+    else:
+        n_parts, stride = parts.shape[0], parts.stride(0)
+        M = parts.shape[1] if M is None else M
+    if out is None and out_plus is None and out2 is None:
+        out = torch.empty((M, 256), device=parts.device, dtype=torch.float32)
+    lw, lb = ln if ln is not None else (None, None)
+    l2w, l2b = ln2 if ln2 is not None else (None, None)
+    rc = lib.mv2d_row_ln(_p(parts), n_parts, stride, _p(bias), _p(residual), _p(lw), _p(lb), 1 if relu else 0, _p(out),
+                         _p(addvec), _p(out_plus), _p(l2w), _p(l2b), _p(out2), M, float(eps), _stream())
+    check(rc, 'mv2d_row_ln')
+    return out
+
+
+def avgpool49(x, out, ld_out, R):
+    check(_lib.load().mv2d_avgpool49(_p(x), _p(out), ld_out, R, _stream()), 'mv2d_avgpool49')
+    return out
+
+
+def f32_to_bf16(x, out=None):
+    _req(x, torch.float32, 'x')
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=BF16)
+    check(_lib.load().mv2d_f32_to_bf16(_p(x), _p(out), x.numel(), _stream()), 'mv2d_f32_to_bf16')
+    return out
+
+
+def nchw_to_nhwc(x, out=None):
+    """[V,C,h,w] fp32 -> position-major [V*h*w, C] fp32."""
+    _req(x, torch.float32, 'x')
+    V, Cn, h, w = x.shape
+    if out is None:
+        out = torch.empty((V * h * w, Cn), device=x.device, dtype=torch.float32)
+    check(_lib.load().mv2d_nchw_to_nhwc(_p(x), _p(out), V, Cn, h * w, _stream()), 'mv2d_nchw_to_nhwc')
+    return out
+
+
+def self_attn(qkv, out=None, R=None):
+    _req(qkv, torch.float32, 'qkv')
+    R = qkv.shape[0] if R is None else R
+    if out is None:
+        out = torch.empty((R, 256), device=qkv.device, dtype=torch.float32)
+    check(_lib.load().mv2d_self_attn_fwd(_p(qkv), _p(out), R, _stream()), 'mv2d_self_attn_fwd')
+    return out
+
+
+def sparse_xattn(q, K, V, row_ptr, col_idx, out=None, R=None, dbg_logits=None):
+    _req(q, torch.float32, 'q'); _req(K, BF16, 'K'); _req(V, BF16, 'V')
+    _req(row_ptr, torch.int32, 'row_ptr'); _req(col_idx, torch.int32, 'col_idx')
+    R = q.shape[0] if R is None else R
+    if out is None:
+        out = torch.empty((R, 256), device=q.device, dtype=torch.float32)
+    check(_lib.load().mv2d_sparse_xattn_fwd(_p(q), _p(K), _p(V), _p(row_ptr), _p(col_idx), _p(out), _p(dbg_logits),
+                                            dbg_logits.stride(0) if dbg_logits is not None else 0, R, _stream()),
+          'mv2d_sparse_xattn_fwd')
+    return out
+
+
+def box_params(rois, viewK, viewE, intr, ld_intr, minv, K_roi=None, roi_size=7.0, intr_scale=0.1, min_size=4.0):
+    _req(rois, torch.float32, 'rois'); _req(viewK, torch.float64, 'viewK'); _req(viewE, torch.float64, 'viewE')
+    check(_lib.load().mv2d_box_params(_p(rois), _p(viewK), _p(viewE), _p(K_roi), _p(intr), ld_intr, _p(minv), rois.shape[0],
+                                      roi_size, intr_scale, min_size, _stream()), 'mv2d_box_params')
+
+
+def refpoint_posemb(center_pred, ld_cp, minv, dim_t, xyz, ref, posemb, R, pc_range_host):
+    check(_lib.load().mv2d_refpoint_posemb(_p(center_pred), ld_cp, _p(minv), _p(dim_t), _p(xyz), _p(ref), _p(posemb), R,
+                                           pc_range_host.data_ptr(), _stream()), 'mv2d_refpoint_posemb')
+
+
+def roi_align(map0, rois, H, W, *, map1=None, out0=None, out1=None, out0_f32=None, out1_f32=None, spatial_scale=1.0 / 16,
+              sampling_ratio=-1):
+    _req(map0, torch.float32, 'map0'); _req(map1, torch.float32, 'map1'); _req(rois, torch.float32, 'rois')
+    check(_lib.load().mv2d_roi_align(_p(map0), _p(map1), _p(rois), _p(out0), _p(out1), _p(out0_f32), _p(out1_f32), rois.shape[0],
+                                     H, W, map0.shape[-1], spatial_scale, sampling_ratio, _stream()), 'mv2d_roi_align')
+
+
+def box_correlation(rois, view_start, trans, lin, depths, match, V, topk, pad_h, pad_w, max_per_view, sample_size=4,
+                    num_depth=8, depth_start=0.5, iou_thr=0.0, ratio=0.0):
+    _req(rois, torch.float32, 'rois'); _req(view_start, torch.int32, 'view_start'); _req(trans, torch.float64, 'trans')
+    _req(match, torch.int32, 'match')
+    check(_lib.load().mv2d_box_correlation(_p(rois), _p(view_start), _p(trans), _p(lin), _p(depths), _p(match), rois.shape[0], V,
+                                           sample_size, num_depth, topk, pad_h, pad_w, depth_start, iou_thr, ratio, max_per_view,
+                                           _stream()), 'mv2d_box_correlation')
+
+
+def csr_workspace_bytes(R, V, h, w):
+    return _lib.load().mv2d_csr_workspace_bytes(R, V, h, w)
+
+
+def mask_compact(rois, match, pad_mask, roi_mask, rect, pos2s, s2pos, S_out, bits_ws, row_count, row_ptr, col_idx, nnz_out,
+                 R, V, h, w, topk, stride=16.0, expand_stride=2.0):
+    check(_lib.load().mv2d_mask_compact(_p(rois), _p(match), _p(pad_mask), _p(roi_mask), _p(rect), _p(pos2s), _p(s2pos), _p(S_out),
+                                        _p(bits_ws), _p(row_count), _p(row_ptr), _p(col_idx), _p(nnz_out), R, V, h, w, topk,
+                                        float(stride), float(expand_stride), _stream()), 'mv2d_mask_compact')
+
+
+def csr_from_corr(match, row_ptr, col_idx, nnz_out, R, V, topk):
+    check(_lib.load().mv2d_csr_from_corr(_p(match), _p(row_ptr), _p(col_idx), _p(nnz_out), R, V, topk, _stream()),
+          'mv2d_csr_from_corr')
+
+
+def pe_inputs(s2pos, S_dev, S_max, featcl, img2lidar, coords_w, coords_h, coords_d, embeds, dim_t, A_frustum, A_sine, Xf_bf16,
+              Xf_f32, V, h, w, depth_num, position_range_host):
+    check(_lib.load().mv2d_pe_inputs(_p(s2pos), _p(S_dev), S_max, _p(featcl), _p(img2lidar), _p(coords_w), _p(coords_h), _p(coords_d),
+                                     _p(embeds), _p(dim_t), _p(A_frustum), _p(A_sine), _p(Xf_bf16), _p(Xf_f32), V, h, w, depth_num,
+                                     position_range_host.data_ptr(), _stream()), 'mv2d_pe_inputs')
+
+
+def decode_topk(cls, reg, R, num_classes, max_num, post_center_range_host, boxes, scores, labels, bbox_index, count, topk_dbg=None):
+    _req(cls, torch.float32, 'cls'); _req(reg, torch.float32, 'reg')
+    check(_lib.load().mv2d_decode_topk(_p(cls), _p(reg), R, num_classes, max_num, post_center_range_host.data_ptr(), _p(boxes),
+                                       _p(scores), _p(labels), _p(bbox_index), _p(count), _p(topk_dbg), _stream()),
+          'mv2d_decode_topk')
+
+
+SCALE_Q = 1.0 / math.sqrt(32.0)

@@ -1,0 +1,394 @@
+"""Kernel-level parity: every C-ABI entry point against the oracle / a plain fp32-fp64 torch statement of the
+same op, on the GPU (-m gpu).  Integer / boolean results bit-exact; fp32 kernels 1e-5 rel-to-max; bf16 MFMA
+kernels compared with an fp64 reference evaluated on the SAME bf16-rounded operands (tolerance 2e-3 from
+accumulation order + output rounding)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mv2d_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+    from mv2d_amd import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+def relerr(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def rnd(shape, seed, scale=1.0):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy((g.standard_normal(shape) * scale).astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------ GEMMs
+@pytest.mark.parametrize('M,N,K', [(300, 256, 192), (1000, 1024, 384), (129, 128, 64), (2500, 256, 1024)])
+def test_gemm_bf16_plain(dev, M, N, K):
+    from mv2d_amd import ops
+    A = rnd((M, K), 1).to(dev).to(torch.bfloat16)
+    W = rnd((N, K), 2, 0.1).to(dev).to(torch.bfloat16)
+    b = rnd((N,), 3).to(dev)
+    ref = A.double() @ W.double().T + b.double()
+    out = ops.gemm_bf16(A, W, b, out_dtype=torch.float32)
+    assert relerr(out, ref) < 1e-4                      # asymmetric operands: a transposed C-write would fail
+    out_r = ops.gemm_bf16(A, W, b, act=1)               # relu + bf16 output
+    assert relerr(out_r.float(), ref.clamp_min(0)) < 5e-3
+    out_s = ops.gemm_bf16(A, W, b, act=2, out_dtype=torch.float32)
+    assert relerr(out_s, torch.sigmoid(ref)) < 1e-4
+
+
+def test_gemm_bf16_epilogues_and_layout(dev):
+    from mv2d_amd import ops
+    M, K, L = 700, 256, 3
+    Xk = rnd((M, K), 4).to(dev).to(torch.bfloat16)
+    Xv = rnd((M, K), 5).to(dev).to(torch.bfloat16)
+    W = rnd((2 * L * 256, K), 6, 0.1).to(dev).to(torch.bfloat16)
+    b = rnd((2 * L * 256,), 7).to(dev)
+    m_dev = torch.tensor([650], dtype=torch.int32, device=dev)
+    out = torch.zeros((2 * L, 800, 256), device=dev, dtype=torch.bfloat16)          # [K layers | V layers][S_max][256]
+    ops.gemm_bf16(Xk, W, b, A2=Xv, n_split=L * 256, m_dev=m_dev, out=out, ldc=256, c_blk_stride=800 * 256, c_blk_cols=256)
+    refk = (Xk.double() @ W[:L * 256].double().T + b[:L * 256].double())[:650]
+    refv = (Xv.double() @ W[L * 256:].double().T + b[L * 256:].double())[:650]
+    for l in range(L):
+        assert relerr(out[l, :650].float(), refk[:, l * 256:(l + 1) * 256]) < 5e-3
+        assert relerr(out[L + l, :650].float(), refv[:, l * 256:(l + 1) * 256]) < 5e-3
+    assert float(out[:, 650:].float().abs().max()) == 0.0                           # rows >= *m_dev untouched
+    # mul / add / second output
+    mul = rnd((M, 256), 8).to(dev)
+    add = rnd((M, 256), 9).to(dev)
+    add2 = rnd((M, 256), 10).to(dev)
+    W1 = W[:256].contiguous()
+    out1 = torch.empty((M, 256), device=dev, dtype=torch.float32)
+    out2 = torch.empty((M, 256), device=dev, dtype=torch.bfloat16)
+    ops.gemm_bf16(Xk, W1, b[:256].contiguous(), mul=mul, add=add, out=out1, out2=out2, add2=add2)
+    ref = (Xk.double() @ W1.double().T + b[:256].double()) * mul.double() + add.double()
+    assert relerr(out1, ref) < 1e-4
+    assert relerr(out2.float(), ref + add2.double()) < 5e-3
+
+
+def test_gemm_bf16_conv3x3(dev):
+    from mv2d_amd import ops
+    R = 37
+    x = rnd((R, 256, 7, 7), 11).to(torch.bfloat16)
+    w = rnd((256, 256, 3, 3), 12, 0.05).to(torch.bfloat16)
+    b = rnd((256,), 13)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))            # [R,256,7,7]
+    x_cl = x.flatten(2).transpose(1, 2).contiguous().to(dev)                         # [R,49,256]
+    w_r = w.permute(0, 2, 3, 1).reshape(256, 9 * 256).contiguous().to(dev)           # [out][tap][cin]
+    out = ops.gemm_bf16(x_cl, w_r, b.to(dev), conv3x3=True, act=1, out_dtype=torch.float32)
+    assert relerr(out.view(R, 49, 256).transpose(1, 2), ref.flatten(2)) < 1e-4
+
+
+@pytest.mark.parametrize('M,N,K,split', [(300, 256, 256, 1), (300, 768, 256, 1), (77, 10, 256, 1), (300, 256, 2048, 8), (900, 2048, 256, 1), (50, 512, 1056, 1)])
+def test_gemm_f32_exact(dev, M, N, K, split):
+    from mv2d_amd import ops
+    A = rnd((M, K), 20).to(dev)
+    W = rnd((N, K), 21, 0.1).to(dev)
+    b = rnd((N,), 22).to(dev)
+    ref = A.double() @ W.double().T + b.double()
+    out = ops.gemm_f32(A, W, b, split_k=split)
+    if split > 1:
+        out = out.sum(0)
+    assert relerr(out, ref) < 2e-6
+    out2 = ops.gemm_f32(A, W, b, act=1, scale=0.25, out_dtype=torch.bfloat16) if split == 1 else None
+    if out2 is not None:
+        assert relerr(out2.float(), (ref * 0.25).clamp_min(0)) < 5e-3
+
+
+def test_gemm_f32_a_select(dev):
+    from mv2d_amd import ops
+    A = rnd((300, 256), 23).to(dev)
+    A2 = rnd((300, 256), 24).to(dev)
+    W = rnd((768, 256), 25, 0.1).to(dev)
+    b = rnd((768,), 26).to(dev)
+    out = ops.gemm_f32(A, W, b, A2=A2, n_split=512)
+    ref = torch.cat([A.double() @ W[:512].double().T, A2.double() @ W[512:].double().T], 1) + b.double()
+    assert relerr(out, ref) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------ rows
+def test_row_ln(dev):
+    from mv2d_amd import ops
+    M = 301
+    parts = rnd((8, M, 256), 30).to(dev)
+    bias = rnd((256,), 31).to(dev)
+    res = rnd((M, 256), 32).to(dev)
+    w1, b1, w2, b2 = [rnd((256,), 33 + i).to(dev) for i in range(4)]
+    qpos = rnd((M, 256), 37).to(dev)
+    out = torch.empty((M, 256), device=dev)
+    outp = torch.empty((M, 256), device=dev)
+    out2 = torch.empty((M, 256), device=dev)
+    ops.row_ln(parts, bias=bias, residual=res, ln=(w1, b1), out=out, addvec=qpos, out_plus=outp, ln2=(w2, b2), out2=out2)
+    v = parts.double().sum(0) + bias.double() + res.double()
+    y = F.layer_norm(v, (256,), w1.double(), b1.double())
+    assert relerr(out, y) < 1e-5
+    assert relerr(outp, y + qpos.double()) < 1e-5
+    assert relerr(out2, F.layer_norm(y, (256,), w2.double(), b2.double())) < 1e-5
+    o3 = ops.row_ln(parts[0].contiguous(), ln=(w1, b1), relu=True)
+    assert relerr(o3, F.relu(F.layer_norm(parts[0].double(), (256,), w1.double(), b1.double()))) < 1e-5
+
+
+def test_transpose_and_cast(dev):
+    from mv2d_amd import ops
+    x = rnd((3, 256, 5, 7), 40).to(dev)
+    y = ops.nchw_to_nhwc(x)
+    assert torch.equal(y.view(3, 5, 7, 256), x.permute(0, 2, 3, 1))
+    z = ops.f32_to_bf16(x)
+    assert torch.equal(z, x.to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize('R', [12, 300, 333])
+def test_self_attn(dev, R):
+    from mv2d_amd import ops
+    qkv = rnd((R, 768), 50).to(dev)
+    out = ops.self_attn(qkv)
+    q, k, v = [t.double().view(R, 8, 32).transpose(0, 1) for t in qkv.split(256, 1)]
+    att = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(32), -1)
+    ref = (att @ v).transpose(0, 1).reshape(R, 256)
+    assert relerr(out, ref) < 1e-5
+
+
+def test_sparse_xattn(dev):
+    from mv2d_amd import ops
+    R, S = 301, 5000
+    g = np.random.Generator(np.random.PCG64(60))
+    allowed = torch.from_numpy(g.random((R, S)) < 0.02)
+    allowed[5] = False                                   # a query with no key -> ctx = 0
+    allowed[7, :] = False
+    allowed[7, 123] = True                               # a single key
+    q = rnd((R, 256), 61).to(dev)
+    K = rnd((S, 256), 62).to(dev).to(torch.bfloat16)
+    V = rnd((S, 256), 63).to(dev).to(torch.bfloat16)
+    counts = allowed.sum(1)
+    row_ptr = torch.zeros(R + 1, dtype=torch.int32)
+    row_ptr[1:] = counts.cumsum(0)
+    col = allowed.nonzero()[:, 1].to(torch.int32)
+    nnz = int(row_ptr[-1])
+    dbg = torch.zeros((8, nnz), device=dev)
+    out = ops.sparse_xattn(q, K, V, row_ptr.to(dev), col.to(dev), dbg_logits=dbg)
+    qh = q.double().view(R, 8, 32).transpose(0, 1)
+    kh = K.double().view(S, 8, 32).transpose(0, 1)
+    vh = V.double().view(S, 8, 32).transpose(0, 1)
+    logits = qh @ kh.transpose(1, 2)
+    lm = logits.masked_fill(~allowed.to(dev)[None], float('-inf'))
+    att = torch.softmax(lm, -1).nan_to_num(0.0)
+    ref = (att @ vh).transpose(0, 1).reshape(R, 256)
+    assert relerr(out, ref) < 1e-5
+    assert float(out[5].abs().max()) == 0.0
+    lg_ref = logits[:, allowed.to(dev)]                  # [8, nnz] in CSR (row-major) order
+    assert relerr(dbg, lg_ref) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ geometry
+def _problem(name):
+    prob = synthetic.make_problem(name, seed=0)
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    return prob, props
+
+
+@pytest.mark.parametrize('name', ['micro_t', 'cfg1_t', 'cfg3_t'])
+def test_box_params_roialign_refpoint(dev, name):
+    from mv2d_amd import calib, ops
+    from oracle import mv2d_oracle as O
+    prob, props = _problem(name)
+    metas = prob['img_metas']
+    feat = torch.from_numpy(prob['feat'])
+    V, C, h, w = feat.shape
+    rois = O.bbox2roi(props)
+    R = rois.shape[0]
+    K_ref, E_ref = O.get_box_params(props, [m['intrinsics'] for m in metas], [m['extrinsics'] for m in metas])
+    intr_ref = O.process_intrins_feat(rois, K_ref)
+    ft = calib.frame_tables(metas, h, w)
+    ct = calib.constant_tables()
+    K_roi = torch.empty((R, 16), dtype=torch.float64, device=dev)
+    intr = torch.zeros((R, 32), device=dev)
+    minv = torch.empty((R, 16), device=dev)
+    ops.box_params(rois.to(dev), ft['viewK'].to(dev), ft['viewE'].to(dev), intr, 32, minv, K_roi=K_roi)
+    assert torch.equal(K_roi.cpu().view(R, 4, 4), K_ref)                              # fp64, same op order: bit-exact
+    assert torch.equal(intr[:, :16].cpu(), intr_ref.clamp(-5e3, 5e3))
+    minv_ref = torch.inverse(torch.bmm(K_ref, E_ref.transpose(1, 2))).float()
+    assert relerr(minv.view(R, 4, 4), minv_ref) < 1e-6
+    # center2lidar + normalise + posemb on oracle-provided center_pred
+    cp = rnd((R, 3), 70).abs() * torch.tensor([3.0, 3.0, 20.0]) + torch.tensor([0.5, 0.5, 2.0])
+    xyz_ref = O.center2lidar(cp, K_ref, E_ref)
+    ref_ref = O.normalize_ref(xyz_ref)
+    pos_ref = O.pos2posemb3d(ref_ref)
+    xyz = torch.empty((R, 3), device=dev); ref = torch.empty((R, 3), device=dev); pos = torch.empty((R, 384), device=dev)
+    ops.refpoint_posemb(cp.to(dev), 3, minv, ct['dim_t'].to(dev), xyz, ref, pos, R, torch.tensor(O.PC_RANGE, dtype=torch.float32))
+    assert relerr(xyz, xyz_ref) < 1e-5
+    assert relerr(ref, ref_ref) < 1e-5
+    assert float((pos.cpu() - pos_ref).abs().max()) < 2e-5
+    # RoIAlign (fp32 output) vs the oracle restatement
+    if name != 'cfg3_t':
+        fcl = ops.nchw_to_nhwc(feat.to(dev))
+        out = torch.empty((R, 49, 256), device=dev)
+        outb = torch.empty((R, 49, 256), device=dev, dtype=torch.bfloat16)
+        ops.roi_align(fcl, rois.to(dev), h, w, out0=outb, out0_f32=out)
+        ra_ref = O.roi_align(feat, rois).flatten(2).transpose(1, 2)
+        assert relerr(out, ra_ref) < 1e-6
+        assert torch.equal(outb, out.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize('name,topk,expand', [('micro_t', 20, 2), ('cfg1_t', 20, 2), ('cfg1_s', 1, 0), ('cfg3_t', 20, 2), ('cfg2_s', 1, 0)])
+def test_box_correlation_and_csr_bit_exact(dev, name, topk, expand):
+    from mv2d_amd import calib, ops
+    from oracle import mv2d_oracle as O
+    prob, props = _problem(name)
+    metas = prob['img_metas']
+    V = len(metas)
+    h, w = prob['feat'].shape[2:]
+    rois = O.bbox2roi(props)
+    R = rois.shape[0]
+    npv = [len(p) for p in props]
+    ft = calib.frame_tables(metas, h, w)
+    ct = calib.constant_tables()
+    trans_ref = O.view_transforms(metas)
+    assert torch.equal(ft['trans'].view(V, V, 4, 4), trans_ref)
+    ep = O.epipolar_in_box(rois, npv, metas[0]['pad_shape'], trans_ref, topk)
+    vs = torch.tensor(np.concatenate([[0], np.cumsum(npv)]), dtype=torch.int32)
+    match = torch.full((R, V, topk), -7, dtype=torch.int32, device=dev)
+    ops.box_correlation(rois.to(dev), vs.to(dev), ft['trans'].to(dev), ct['lin'].to(dev), ct['depths'].to(dev), match, V, topk,
+                        ft['pad_h'], ft['pad_w'], max(npv))
+    m = match.cpu().view(R, -1)
+    n_mismatch = 0
+    for r in range(R):
+        got = [int(x) for x in m[r] if x >= 0]
+        exp = [i for (i, k) in ep[r] if k]
+        n_mismatch += int(got != exp)
+    assert n_mismatch == 0, f'{n_mismatch}/{R} RoIs with a different correlated-RoI list'
+    if expand == 0:
+        # S-path CSR over RoI-feature rows
+        row_ptr = torch.empty(R + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(R * (1 + V * topk) * 49, dtype=torch.int32, device=dev)
+        nnz = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.csr_from_corr(match, row_ptr, col, nnz, R, V, topk)
+        corr, cmask = O.gen_box_roi_correlation(rois, npv, metas, topk)
+        exp_cols = []
+        for r in range(R):
+            for j in range(corr.shape[1]):
+                if cmask[r, j]:
+                    exp_cols += [int(corr[r, j]) * 49 + c for c in range(49)]
+        assert int(nnz) == len(exp_cols)
+        assert col[:int(nnz)].cpu().tolist() == exp_cols
+        return
+    # T-path: compacted key list + CSR vs the oracle's boolean masks
+    P = V * h * w
+    ffr = O.gen_box_correlation(rois, npv, metas, h, w, 16, expand, topk)             # [R,V,h,w] bool
+    pad = O.padding_mask(metas, h, w)
+    assert torch.equal(ft['pad_mask'].bool().view(V, h, w), pad)
+    roi_mask = torch.zeros(P, dtype=torch.uint8, device=dev)
+    rect = torch.empty((R, 5), dtype=torch.int32, device=dev)
+    pos2s = torch.empty(P, dtype=torch.int32, device=dev)
+    s2pos = torch.empty(P, dtype=torch.int32, device=dev)
+    S_out = torch.zeros(1, dtype=torch.int32, device=dev)
+    bits = torch.empty(ops.csr_workspace_bytes(R, V, h, w) // 4, dtype=torch.int32, device=dev)
+    row_count = torch.empty(R, dtype=torch.int32, device=dev)
+    row_ptr = torch.empty(R + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(R * 2048, dtype=torch.int32, device=dev)
+    nnz = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.mask_compact(rois.to(dev), match, ft['pad_mask'].to(dev), roi_mask, rect, pos2s, s2pos, S_out, bits, row_count, row_ptr,
+                     col, nnz, R, V, h, w, topk, 16.0, float(expand))
+    assert torch.equal(roi_mask.cpu().bool().view(V, h, w), ffr.any(0))               # roi_mask of RH/mv2d_t_head.py:84
+    keep = (ffr.any(0) & ~pad).view(-1)
+    S = int(S_out)
+    assert S == int(keep.sum())
+    assert torch.equal(s2pos[:S].cpu().long(), keep.nonzero()[:, 0])
+    allowed = (ffr & ~pad[None]).view(R, -1)[:, keep]                                 # [R,S]
+    rp_ref, col_ref = O.csr_from_allowed(allowed)
+    assert torch.equal(row_ptr.cpu(), rp_ref)
+    assert int(nnz) == int(rp_ref[-1])
+    assert torch.equal(col[:int(nnz)].cpu(), col_ref)
+
+
+@pytest.mark.parametrize('name', ['micro_t', 'cfg1_t'])
+def test_pe_inputs(dev, name):
+    from mv2d_amd import calib, ops
+    from oracle import mv2d_oracle as O
+    prob, props = _problem(name)
+    metas = prob['img_metas']
+    feat = torch.from_numpy(prob['feat'])
+    V, C, h, w = feat.shape
+    P = V * h * w
+    ft = calib.frame_tables(metas, h, w)
+    ct = calib.constant_tables()
+    g = np.random.Generator(np.random.PCG64(80))
+    sel = np.sort(g.choice(P, size=P // 3, replace=False)).astype(np.int32)
+    S = len(sel)
+    s2pos = torch.from_numpy(sel).to(dev)
+    S_dev = torch.tensor([S], dtype=torch.int32, device=dev)
+    fcl = ops.nchw_to_nhwc(feat.to(dev))
+    A1 = torch.zeros((P, 192), dtype=torch.bfloat16, device=dev)
+    A2 = torch.zeros((P, 384), dtype=torch.bfloat16, device=dev)
+    Xb = torch.zeros((P, 256), dtype=torch.bfloat16, device=dev)
+    Xf = torch.zeros((P, 256), device=dev)
+    ops.pe_inputs(s2pos, S_dev, P, fcl, ft['img2lidar'].to(dev), ft['coords_w'].to(dev), ft['coords_h'].to(dev),
+                  ft['coords_d'].to(dev), ft['embeds'].to(dev), ct['dim_t'].to(dev), A1, A2, Xb, Xf, V, h, w, 64,
+                  torch.tensor(O.POST_RANGE, dtype=torch.float64))
+    x3 = O.pe_frustum_input(metas, h, w)                                              # [V,192,h,w] fp32
+    sin = O.sine_pe3d(O.padding_mask(metas, h, w)[None])[0]                           # [V,384,h,w]
+    x3 = x3.permute(0, 2, 3, 1).reshape(P, 192)[sel]
+    sin = sin.permute(0, 2, 3, 1).reshape(P, 384)[sel]
+    fr = feat.permute(0, 2, 3, 1).reshape(P, 256)[sel]
+    assert torch.equal(Xf[:S].cpu(), fr)
+    assert torch.equal(Xb[:S].cpu(), fr.to(torch.bfloat16))
+    # bf16-rounded outputs: compare with the bf16 rounding of the oracle values (allow 1 bf16 ulp for ulp-level log/sin diffs)
+    d1 = (A1[:S].float().cpu() - x3.to(torch.bfloat16).float()).abs()
+    assert float((d1 / x3.abs().clamp_min(1.0)).max()) < 1e-2
+    assert float((d1 > 0).float().mean()) < 1e-3
+    d2 = (A2[:S].float().cpu() - sin.to(torch.bfloat16).float()).abs()
+    assert float(d2.max()) < 1e-2
+    assert float((d2 > 0).float().mean()) < 2e-2
+    assert float(A1[S:].float().abs().max()) == 0.0
+
+
+def test_decode_topk_bit_exact(dev):
+    from mv2d_amd import ops
+    from oracle import mv2d_oracle as O
+    for R, seed in [(12, 90), (300, 91), (900, 92)]:
+        cls = rnd((R, 10), seed, 2.0) - 3.0
+        reg = rnd((R, 10), seed + 100)
+        reg[:, 0] *= 40.0; reg[:, 1] *= 40.0; reg[:, 4] *= 6.0                         # some centres fall outside the range
+        boxes = torch.zeros((300, 9), device=dev); scores = torch.zeros(300, device=dev)
+        labels = torch.zeros(300, dtype=torch.int64, device=dev); bidx = torch.zeros(300, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.decode_topk(cls.to(dev), reg.to(dev), R, 10, 300, torch.tensor(O.POST_RANGE, dtype=torch.float32), boxes, scores,
+                        labels, bidx, cnt)
+        b_ref, s_ref, l_ref, i_ref = O.decode(cls, reg)
+        n = int(cnt)
+        assert n == b_ref.shape[0]
+        assert torch.equal(labels[:n].cpu(), l_ref)                                   # bit-exact integers
+        assert torch.equal(bidx[:n].cpu(), i_ref)
+        assert relerr(scores[:n], s_ref) < 1e-6
+        assert relerr(boxes[:n], b_ref) < 1e-5
+
+
+def test_decode_topk_tie_order(dev):
+    """torch.topk leaves the order of equal scores unspecified (CB/coders/nms_free_coder.py:66); the kernel
+    defines it: equal logits are emitted lower flat index first."""
+    from mv2d_amd import ops
+    from oracle import mv2d_oracle as O
+    R = 40
+    cls = rnd((R, 10), 95, 2.0) - 3.0
+    cls[3, 4] = cls[2, 1] = cls[30, 9] = 5.0                                          # three-way tie at the top
+    reg = rnd((R, 10), 96) * 0.1
+    boxes = torch.zeros((300, 9), device=dev); scores = torch.zeros(300, device=dev)
+    labels = torch.zeros(300, dtype=torch.int64, device=dev); bidx = torch.zeros(300, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.decode_topk(cls.to(dev), reg.to(dev), R, 10, 300, torch.tensor(O.POST_RANGE, dtype=torch.float32), boxes, scores, labels,
+                    bidx, cnt)
+    assert int(cnt) == 300
+    assert bidx[:3].cpu().tolist() == [2, 3, 30] and labels[:3].cpu().tolist() == [1, 4, 9]
+    assert bool((scores[:299] >= scores[1:300]).all())
