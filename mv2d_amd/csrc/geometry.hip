@@ -479,13 +479,15 @@ __global__ __launch_bounds__(256) void pe_inputs_kernel(const int* __restrict__ 
             A_frustum[(long long)s * (3 * D) + tid * 3 + i] = f32_to_bf16((float)log(x1 / x2));
         }
     }
-    // sine features, channel order (n | y | x), even channel sin, odd channel cos
+    // sine features, channel order (n | y | x).  NOT interleaved: the reference stacks sin/cos on dim=4 of a
+    // 5-D tensor (MU/positional_encoding.py:86-94), so within an axis channels 0..63 = sin(e / dim_t[2j]) and
+    // channels 64..127 = cos(e / dim_t[2j+1]).
     const float en = embeds[pos], ey = embeds[P + pos], ex = embeds[2 * P + pos];
     for (int ch = tid; ch < 384; ch += 256) {
         const int axis = ch >> 7, i = ch & 127;
         const float e = axis == 0 ? en : (axis == 1 ? ey : ex);
-        const float a = e / dim_t[i];
-        A_sine[(long long)s * 384 + ch] = f32_to_bf16((i & 1) ? cosf(a) : sinf(a));
+        const float val = i < 64 ? sinf(e / dim_t[2 * i]) : cosf(e / dim_t[2 * (i - 64) + 1]);
+        A_sine[(long long)s * 384 + ch] = f32_to_bf16(val);
     }
 }
 
