@@ -47,19 +47,28 @@ int mv2d_gemm_bf16(const void* A, const void* A2, int n_split, int a_mode, const
  * Replaces nn.Linear calls of: query/out in_proj/out_proj and FFN (MU/petr_transformer.py:358-363,503-508; mmcv FFN),
  * query_embedding / cls / reg branches (RH/bbox_heads/cross_attention_head.py:118-146,199-227),
  * QueryGenerator fcs (RH/utils/query_generator.py:360-373,404).
- *  split_k>1 writes split_k partial slabs (slab z at C + z*c_slice_stride elements); bias is added in slab 0. */
+ *  split_k>1 writes split_k partial slabs (slab z at C + z*c_slice_stride elements); bias is added in slab 0.
+ *  clamp>0: v = min(max(v,-clamp),clamp) (RH/utils/query_generator.py:369).
+ *  groups>1 (needs split_k==1): grouped GEMM, group g reads A + g*a_gs, W + g*w_gs, bias + g*b_gs, writes C + g*c_gs
+ *  (the 6 per-layer cls/reg branches of cross_attention_head.py:216-227 in one launch). */
 int mv2d_gemm_f32(const float* A, const float* A2, int n_split, const float* W, const float* bias, int M, int N, int K,
-                  int lda, int ldw, int split_k, int act, float scale, void* C, int c_bf16, int ldc,
-                  long long c_slice_stride, void* stream);
+                  int lda, int ldw, int split_k, int act, float scale, float clamp, void* C, int c_bf16, int ldc,
+                  long long c_slice_stride, int groups, long long a_gs, long long w_gs, long long b_gs, long long c_gs,
+                  void* stream);
 
 /* ---- row-wise ops on the [M,256] query state ------------------------------------------------------------- */
 
 /* y = [ReLU] [LayerNorm]( sum_z parts[z] + bias + residual );  out = y;  out_plus = y + addvec;  out2 = LN2(y).
+ * rows_per_group>0: bias/ln_w/ln_b of row r are taken at offset (r / rows_per_group) * 256 (per-layer parameters).
  * Replaces: mmcv BaseTransformerLayer residual adds + norms and the shared post_norm
  * (MU/petr_transformer.py:563-565,586-592), Linear-LN-ReLU of the cls branch (cross_attention_head.py:127-133). */
 int mv2d_row_ln(const float* parts, int n_parts, long long part_stride, const float* bias, const float* residual,
                 const float* ln_w, const float* ln_b, int relu, float* out, const float* addvec, float* out_plus,
-                const float* ln2_w, const float* ln2_b, float* out2, int M, float eps, void* stream);
+                const float* ln2_w, const float* ln2_b, float* out2, int M, float eps, int rows_per_group, void* stream);
+
+/* Tail of CrossAttentionBoxHead.forward (RH/bbox_heads/cross_attention_head.py:219-238) + velocity / dt of
+ * MV2DTHead._bbox_forward (RH/mv2d_t_head.py:136-140, dt = 0: skipped).  reg [L,R,10] in place, ref [R,3]. */
+int mv2d_finalize_reg(float* reg, const float* ref, int L, int R, const float* pc_range, float dt, void* stream);
 
 /* AvgPool2d(7) over [R,49,256] fp32 -> out[r*ld_out + c]  (RH/utils/query_generator.py:322-331). */
 int mv2d_avgpool49(const float* x, float* out, int ld_out, int R, void* stream);
@@ -96,9 +105,11 @@ int mv2d_refpoint_posemb(const float* center_pred, int ld_cp, const float* minv,
                          float* posemb, int R, const float* pc_range, void* stream);
 
 /* mmcv.ops.RoIAlign(7, 1/16, sampling_ratio, 'avg', aligned=True) (call site RH/mv2d_head.py:114-115) on one or two
- * position-major maps -> [R,49,256] bf16 and/or fp32 per map. */
+ * position-major maps -> [R,49,256] bf16 and/or fp32 per map.  map1_index (optional): map1 is row-compacted, row of
+ * position p is map1_index[p].  out1_is_sum: out1 = bf16(map0 value + map1 value) (the S-path key input feat + pe). */
 int mv2d_roi_align(const float* map0, const float* map1, const float* rois, void* out0, void* out1, float* out0_f32,
-                   float* out1_f32, int R, int H, int W, int channels, float spatial_scale, int sampling_ratio, void* stream);
+                   float* out1_f32, int R, int H, int W, int channels, float spatial_scale, int sampling_ratio,
+                   const int* map1_index, int out1_is_sum, void* stream);
 
 /* BoxCorrelation.epipolar_in_box, 'topk_matched:k:thr:ratio' (RH/utils/box_correlation.py:196-398).
  * view_start[V+1]: first RoI of each view; trans [V,V,16] fp64 = lidar2img[b] @ inv(lidar2img[a]);
@@ -111,10 +122,17 @@ long long mv2d_csr_workspace_bytes(int R, int V, int h, int w);
 
 /* T-path masks -> compacted key list + CSR (BoxCorrelation.gen_box_correlation RH/utils/box_correlation.py:95-162 and
  * the mask/gather block RH/mv2d_t_head.py:67-88).  roi_mask [V*h*w] bytes must be zeroed by the caller.
- * out: rect [R,5]; pos2s [P]; s2pos [<=P]; *S_out; row_ptr [R+1]; col_idx [nnz]; *nnz_out. */
+ * out: rect [R,5]; pos2s [P]; s2pos [<=P]; *S_out; row_ptr [R+1]; col_idx [min(nnz,col_cap)];
+ * nnz_out[0] = nnz, nnz_out[1] = 1 if nnz exceeded col_cap (caller pre-zeroes nnz_out[1]). */
 int mv2d_mask_compact(const float* rois, const int* match, const unsigned char* pad_mask, unsigned char* roi_mask, int* rect,
                       int* pos2s, int* s2pos, int* S_out, unsigned int* bits_ws, int* row_count, int* row_ptr, int* col_idx,
-                      int* nnz_out, int R, int V, int h, int w, int topk, float stride, float expand_stride, void* stream);
+                      int* nnz_out, int col_cap, int R, int V, int h, int w, int topk, float stride, float expand_stride,
+                      void* stream);
+
+/* mark + scan only: compact list of the map positions inside any RoI rect expanded by expand_stride cells
+ * (S-path: the positions RoIAlign can touch, so that PE is evaluated only there). */
+int mv2d_roi_positions(const float* rois, const unsigned char* pad_mask, unsigned char* roi_mask, int* rect, int* pos2s,
+                       int* s2pos, int* S_out, int R, int V, int h, int w, float stride, float expand_stride, void* stream);
 
 /* S-path CSR over the RoI-feature memory rows r*49+cell (RH/mv2d_s_head.py:184-192). */
 int mv2d_csr_from_corr(const int* match, int* row_ptr, int* col_idx, int* nnz_out, int R, int V, int topk, void* stream);

@@ -22,8 +22,9 @@ SIGNATURES = {
     'mv2d_abi_version': (I, []),
     'mv2d_device_arch': (I, [C.c_char_p, I]),
     'mv2d_gemm_bf16': (I, [P, P, I, I, P, P, I, I, I, I, P, I, P, I, P, I, P, I, I, LL, I, P, P, I, I, P]),
-    'mv2d_gemm_f32': (I, [P, P, I, P, P, I, I, I, I, I, I, I, F, P, I, I, LL, P]),
-    'mv2d_row_ln': (I, [P, I, LL, P, P, P, P, I, P, P, P, P, P, P, I, F, P]),
+    'mv2d_gemm_f32': (I, [P, P, I, P, P, I, I, I, I, I, I, I, F, F, P, I, I, LL, I, LL, LL, LL, LL, P]),
+    'mv2d_row_ln': (I, [P, I, LL, P, P, P, P, I, P, P, P, P, P, P, I, F, I, P]),
+    'mv2d_finalize_reg': (I, [P, P, I, I, P, F, P]),
     'mv2d_avgpool49': (I, [P, P, I, I, P]),
     'mv2d_f32_to_bf16': (I, [P, P, LL, P]),
     'mv2d_nchw_to_nhwc': (I, [P, P, I, I, I, P]),
@@ -31,10 +32,11 @@ SIGNATURES = {
     'mv2d_sparse_xattn_fwd': (I, [P, P, P, P, P, P, P, LL, I, P]),
     'mv2d_box_params': (I, [P, P, P, P, P, I, P, I, F, F, F, P]),
     'mv2d_refpoint_posemb': (I, [P, I, P, P, P, P, P, I, P, P]),
-    'mv2d_roi_align': (I, [P, P, P, P, P, P, P, I, I, I, I, F, I, P]),
+    'mv2d_roi_align': (I, [P, P, P, P, P, P, P, I, I, I, I, F, I, P, I, P]),
     'mv2d_box_correlation': (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, F, F, F, I, P]),
     'mv2d_csr_workspace_bytes': (LL, [I, I, I, I]),
-    'mv2d_mask_compact': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, F, P]),
+    'mv2d_mask_compact': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, P]),
+    'mv2d_roi_positions': (I, [P, P, P, P, P, P, P, I, I, I, I, F, F, P]),
     'mv2d_csr_from_corr': (I, [P, P, P, P, I, I, I, P]),
     'mv2d_pe_inputs': (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
     'mv2d_decode_topk': (I, [P, P, I, I, I, P, P, P, P, P, P, P, P]),

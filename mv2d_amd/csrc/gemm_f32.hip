@@ -26,7 +26,10 @@ struct Params {
     int k_chunk;                  // K range per blockIdx.z slice (split-K), multiple of BK
     int act;                      // 0 none, 1 relu
     float scale;                  // v = (acc + bias) * scale
+    float clamp;                  // > 0: v = min(max(v, -clamp), clamp)  (query_generator.py:369)
     void* C; int c_bf16; int ldc; long long c_slice_stride;   // slice z writes C + z * c_slice_stride
+    int split_k;                  // blockIdx.z = group * split_k + slice
+    long long a_gs, w_gs, b_gs, c_gs;   // per-group element strides (grouped GEMM: one weight set per decoder layer)
 };
 
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * ROW_BYTES + ((slot ^ (row & 7)) << 4); }
@@ -36,10 +39,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(Params p) {
     unsigned char* As = smem;
     unsigned char* Bs = smem + 2 * A_BYTES;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * p.k_chunk;
+    const int grp = blockIdx.z / p.split_k, slice = blockIdx.z - grp * p.split_k;
+    const int kbeg = slice * p.k_chunk;
     const int kend = min(p.K, kbeg + p.k_chunk);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* Abase = (p.n_split > 0 && n0 >= p.n_split) ? p.A2 : p.A;
+    const float* Abase = ((p.n_split > 0 && n0 >= p.n_split) ? p.A2 : p.A) + grp * p.a_gs;
+    const float* Wbase = p.W + grp * p.w_gs;
 
     int a_row[2], a_slot[2];
     long long a_src[2];
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(Params p) {
     auto load_tile = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const float4*>(Abase + a_src[i] + k0 + a_slot[i] * 4);
-        rb = *reinterpret_cast<const float4*>(p.W + b_src + k0 + b_slot * 4);
+        rb = *reinterpret_cast<const float4*>(Wbase + b_src + k0 + b_slot * 4);
         if (!b_ok) rb = make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto store_tile = [&](int buf) {
@@ -101,18 +106,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(Params p) {
         __syncthreads();
     }
 
-    unsigned char* Cz = reinterpret_cast<unsigned char*>(p.C) + (long long)blockIdx.z * p.c_slice_stride * (p.c_bf16 ? 2 : 4);
+    unsigned char* Cz = reinterpret_cast<unsigned char*>(p.C) + ((long long)slice * p.c_slice_stride + grp * p.c_gs) * (p.c_bf16 ? 2 : 4);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + j * 16 + fr;
         if (n >= p.N) continue;
-        const float bn = (p.bias && blockIdx.z == 0) ? p.bias[n] : 0.f;
+        const float bn = (p.bias && slice == 0) ? p.bias[grp * p.b_gs + n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + wave * 16 + fg * 4 + r;
             if (m >= p.M) continue;
             float v = (acc[j][r] + bn) * p.scale;
             if (p.act == 1) v = fmaxf(v, 0.f);
+            if (p.clamp > 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
             long long o = (long long)m * p.ldc + n;
             if (p.c_bf16) reinterpret_cast<unsigned short*>(Cz)[o] = f32_to_bf16(v);
             else reinterpret_cast<float*>(Cz)[o] = v;
@@ -123,19 +129,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(Params p) {
 }  // namespace
 
 extern "C" int mv2d_gemm_f32(const float* A, const float* A2, int n_split, const float* W, const float* bias,
-                             int M, int N, int K, int lda, int ldw, int split_k, int act, float scale, void* C,
-                             int c_bf16, int ldc, long long c_slice_stride, void* stream) {
+                             int M, int N, int K, int lda, int ldw, int split_k, int act, float scale, float clamp, void* C,
+                             int c_bf16, int ldc, long long c_slice_stride, int groups, long long a_gs, long long w_gs,
+                             long long b_gs, long long c_gs, void* stream) {
     MV2D_CHECK_ARG(A && W && C, "mv2d_gemm_f32: null A/W/C");
     MV2D_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (K % BK) == 0, "mv2d_gemm_f32: K must be a positive multiple of 32");
     MV2D_CHECK_ARG((lda % 4) == 0 && (ldw % 4) == 0, "mv2d_gemm_f32: lda/ldw must be multiples of 4 (16-byte rows)");
     MV2D_CHECK_ARG(split_k >= 1 && (K % (split_k * BK)) == 0, "mv2d_gemm_f32: K must divide into split_k slices of multiples of 32");
     MV2D_CHECK_ARG(n_split == 0 || (A2 && (n_split % BN) == 0), "mv2d_gemm_f32: n_split must be a multiple of 32 with A2 set");
+    MV2D_CHECK_ARG(groups >= 1 && (groups == 1 || split_k == 1), "mv2d_gemm_f32: groups > 1 needs split_k == 1");
     if (M == 0) return MV2D_OK;
     Params p;
+    p.clamp = clamp; p.split_k = split_k; p.a_gs = a_gs; p.w_gs = w_gs; p.b_gs = b_gs; p.c_gs = c_gs;
     p.A = A; p.A2 = A2; p.n_split = n_split; p.W = W; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw;
     p.k_chunk = K / split_k; p.act = act; p.scale = scale; p.C = C; p.c_bf16 = c_bf16; p.ldc = ldc;
     p.c_slice_stride = c_slice_stride;
-    dim3 grid(cdiv(N, BN), cdiv(M, BM), split_k);
+    dim3 grid(cdiv(N, BN), cdiv(M, BM), split_k * groups);
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256) void refpoint_posemb_kernel(const float* __res
 __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict__ map0, const float* __restrict__ map1, const float* __restrict__ rois,
                                                         unsigned short* __restrict__ out0, unsigned short* __restrict__ out1,
                                                         float* __restrict__ out0_f32, float* __restrict__ out1_f32, int H, int W,
-                                                        float spatial_scale, int sampling_ratio) {
+                                                        float spatial_scale, int sampling_ratio, const int* __restrict__ map1_index,
+                                                        int out1_is_sum) {
     const int r = blockIdx.x, c = threadIdx.x;
     const float* b = rois + r * 5;
     const int v = (int)b[0];
@@ -144,7 +145,16 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
                     const long long o1 = (vbase + (long long)yl * W + xl) * C + c, o2 = (vbase + (long long)yl * W + xh) * C + c;
                     const long long o3 = (vbase + (long long)yh * W + xl) * C + c, o4 = (vbase + (long long)yh * W + xh) * C + c;
                     s0 += w1 * map0[o1] + w2 * map0[o2] + w3 * map0[o3] + w4 * map0[o4];
-                    if (nmaps == 2) s1 += w1 * map1[o1] + w2 * map1[o2] + w3 * map1[o3] + w4 * map1[o4];
+                    if (nmaps == 2) {
+                        if (map1_index) {   // map1 rows are compacted: row = map1_index[position]
+                            // rows outside the compacted list (index -1) can only be hit with weight 0; clamp to row 0
+                            const long long p1 = (long long)max(map1_index[vbase + (long long)yl * W + xl], 0) * C + c, p2 = (long long)max(map1_index[vbase + (long long)yl * W + xh], 0) * C + c;
+                            const long long p3 = (long long)max(map1_index[vbase + (long long)yh * W + xl], 0) * C + c, p4 = (long long)max(map1_index[vbase + (long long)yh * W + xh], 0) * C + c;
+                            s1 += w1 * map1[p1] + w2 * map1[p2] + w3 * map1[p3] + w4 * map1[p4];
+                        } else {
+                            s1 += w1 * map1[o1] + w2 * map1[o2] + w3 * map1[o3] + w4 * map1[o4];
+                        }
+                    }
                 }
             }
             const long long o = ((long long)r * 49 + ph * 7 + pw) * C + c;
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
             if (out0_f32) out0_f32[o] = s0;
             if (nmaps == 2) {
                 s1 = s1 / count;
-                if (out1) out1[o] = f32_to_bf16(s1);
+                if (out1) out1[o] = f32_to_bf16(out1_is_sum ? s0 + s1 : s1);
                 if (out1_f32) out1_f32[o] = s1;
             }
         }
@@ -368,7 +378,8 @@ __global__ __launch_bounds__(256) void csr_count_kernel(const int* __restrict__ 
 
 // per query: row_ptr[r] = sum(row_count[0..r)), then expand the bitmask into ascending key indices.
 __global__ __launch_bounds__(256) void csr_fill_kernel(const unsigned int* __restrict__ bits, const int* __restrict__ row_count, const int* __restrict__ pos2s,
-                                                       int* __restrict__ row_ptr, int* __restrict__ col_idx, int* __restrict__ nnz_out, int R, int P) {
+                                                       int* __restrict__ row_ptr, int* __restrict__ col_idx, int* __restrict__ nnz_out, int R, int P,
+                                                       int col_cap) {
     __shared__ int sbase;
     __shared__ int wsum[4];
     __shared__ int carry;
@@ -383,7 +394,8 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const unsigned int* __res
     const int base = sbase;
     if (tid == 0) {
         row_ptr[r] = base;
-        if (r == R - 1) { row_ptr[R] = base + row_count[r]; *nnz_out = base + row_count[r]; }
+        if (r == R - 1) { row_ptr[R] = base + row_count[r]; nnz_out[0] = base + row_count[r]; }
+        if (base + row_count[r] > col_cap) nnz_out[1] = 1;          // overflow flag: col_idx capacity exceeded
     }
     const int nwords = (P + 31) / 32;
     for (int w0 = 0; w0 < nwords; w0 += 256) {
@@ -402,7 +414,8 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const unsigned int* __res
         while (y) {
             const int bit = __ffs(y) - 1;
             y &= y - 1;
-            col_idx[base + off++] = pos2s[wi * 32 + bit];
+            if (base + off < col_cap) col_idx[base + off] = pos2s[wi * 32 + bit];
+            ++off;
         }
         __syncthreads();
         if (tid == 0) carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
@@ -583,12 +596,13 @@ extern "C" int mv2d_refpoint_posemb(const float* center_pred, int ld_cp, const f
 }
 
 extern "C" int mv2d_roi_align(const float* map0, const float* map1, const float* rois, void* out0, void* out1, float* out0_f32,
-                              float* out1_f32, int R, int H, int W, int channels, float spatial_scale, int sampling_ratio, void* stream) {
+                              float* out1_f32, int R, int H, int W, int channels, float spatial_scale, int sampling_ratio,
+                              const int* map1_index, int out1_is_sum, void* stream) {
     MV2D_CHECK_ARG(map0 && rois && channels == C, "mv2d_roi_align: needs 256-channel position-major maps");
     MV2D_CHECK_ARG(out0 || out0_f32, "mv2d_roi_align: no output");
     if (R == 0) return MV2D_OK;
     hipLaunchKernelGGL(roi_align_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, map0, map1, rois, (unsigned short*)out0,
-                       (unsigned short*)out1, out0_f32, out1_f32, H, W, spatial_scale, sampling_ratio);
+                       (unsigned short*)out1, out0_f32, out1_f32, H, W, spatial_scale, sampling_ratio, map1_index, out1_is_sum);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
@@ -614,8 +628,8 @@ extern "C" long long mv2d_csr_workspace_bytes(int R, int V, int h, int w) {
 // T-path: roi_mask must be zeroed by the caller (hipMemsetAsync) before this call.
 extern "C" int mv2d_mask_compact(const float* rois, const int* match, const unsigned char* pad_mask, unsigned char* roi_mask,
                                  int* rect, int* pos2s, int* s2pos, int* S_out, unsigned int* bits_ws, int* row_count, int* row_ptr,
-                                 int* col_idx, int* nnz_out, int R, int V, int h, int w, int topk, float stride, float expand_stride,
-                                 void* stream) {
+                                 int* col_idx, int* nnz_out, int col_cap, int R, int V, int h, int w, int topk, float stride,
+                                 float expand_stride, void* stream) {
     MV2D_CHECK_ARG(rois && match && pad_mask && roi_mask && rect && pos2s && s2pos && S_out && bits_ws && row_count && row_ptr &&
                        col_idx && nnz_out, "mv2d_mask_compact: null pointer");
     MV2D_CHECK_ARG(R > 0, "mv2d_mask_compact: R must be > 0");
@@ -625,7 +639,18 @@ extern "C" int mv2d_mask_compact(const float* rois, const int* match, const unsi
     hipLaunchKernelGGL(csr_scan_positions_kernel, dim3(1), dim3(1024), 0, st, roi_mask, pad_mask, pos2s, s2pos, S_out, P);
     const int nwords = (P + 31) / 32;
     hipLaunchKernelGGL(csr_count_kernel, dim3(R), dim3(256), nwords * 4, st, rect, match, pos2s, bits_ws, row_count, h, w, V, topk, P);
-    hipLaunchKernelGGL(csr_fill_kernel, dim3(R), dim3(256), 0, st, bits_ws, row_count, pos2s, row_ptr, col_idx, nnz_out, R, P);
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(R), dim3(256), 0, st, bits_ws, row_count, pos2s, row_ptr, col_idx, nnz_out, R, P, col_cap);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+// S-path helper: positions touched by RoIAlign taps (own rects expanded by `expand_stride` cells) -> compact list.
+extern "C" int mv2d_roi_positions(const float* rois, const unsigned char* pad_mask, unsigned char* roi_mask, int* rect, int* pos2s,
+                                  int* s2pos, int* S_out, int R, int V, int h, int w, float stride, float expand_stride, void* stream) {
+    MV2D_CHECK_ARG(rois && pad_mask && roi_mask && rect && pos2s && s2pos && S_out && R > 0, "mv2d_roi_positions: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(csr_mark_kernel, dim3(R), dim3(64), 0, st, rois, rect, roi_mask, h, w, stride, expand_stride);
+    hipLaunchKernelGGL(csr_scan_positions_kernel, dim3(1), dim3(1024), 0, st, roi_mask, pad_mask, pos2s, s2pos, S_out, V * h * w);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

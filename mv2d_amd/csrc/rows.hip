@@ -16,6 +16,7 @@ struct LnParams {
     const float* addvec; float* out_plus;   // out_plus = y + addvec (e.g. query_pos) or null
     const float* ln2_w; const float* ln2_b; float* out2;   // out2 = LN2(y) (shared post_norm) or null
     int M; float eps;
+    int rows_per_group;         // > 0: bias / ln_w / ln_b of row r are at + (r / rows_per_group) * 256
 };
 
 __device__ __forceinline__ float4 ln4(float4 v, const float* w, const float* b, int c0, float eps) {
@@ -35,20 +36,21 @@ __global__ __launch_bounds__(256) void row_ln_kernel(LnParams p) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.M) return;
     const int lane = threadIdx.x & 63, c0 = lane * 4;
+    const int goff = p.rows_per_group > 0 ? (row / p.rows_per_group) * C : 0;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = 0; s < p.n_parts; ++s) {
         float4 t = *reinterpret_cast<const float4*>(p.parts + s * p.part_stride + (long long)row * C + c0);
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
     if (p.bias) {
-        float4 t = *reinterpret_cast<const float4*>(p.bias + c0);
+        float4 t = *reinterpret_cast<const float4*>(p.bias + goff + c0);
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
     if (p.residual) {
         float4 t = *reinterpret_cast<const float4*>(p.residual + (long long)row * C + c0);
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
-    if (p.ln_w) v = ln4(v, p.ln_w, p.ln_b, c0, p.eps);
+    if (p.ln_w) v = ln4(v, p.ln_w + goff, p.ln_b + goff, c0, p.eps);
     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (p.out) *reinterpret_cast<float4*>(p.out + (long long)row * C + c0) = v;
     if (p.out_plus) {
@@ -95,18 +97,50 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, float
     }
 }
 
+// cross_attention_head.py:216-238 tail: reg[0:2] = sigmoid(reg[0:2] + isig(ref)[0:2]), reg[4] = sigmoid(reg[4] + isig(ref)[2]),
+// de-normalise to metres with pc_range; RH/mv2d_t_head.py:136-140: reg[8:10] /= dt when dt != 0.  reg [L,R,10] in place.
+__global__ void finalize_reg_kernel(float* reg, const float* __restrict__ ref, int L, int R, float pc0, float pc1, float pc2,
+                                    float pd0, float pd1, float pd2, float dt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L * R) return;
+    const int r = i % R;
+    float* t = reg + (long long)i * 10;
+    float is[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float x = fminf(fmaxf(ref[r * 3 + k], 0.f), 1.f);
+        is[k] = logf(fmaxf(x, 1e-5f) / fmaxf(1.f - x, 1e-5f));
+    }
+    const float s0 = 1.f / (1.f + expf(-(t[0] + is[0])));
+    const float s1 = 1.f / (1.f + expf(-(t[1] + is[1])));
+    const float s4 = 1.f / (1.f + expf(-(t[4] + is[2])));
+    t[0] = s0 * pd0 + pc0;
+    t[1] = s1 * pd1 + pc1;
+    t[4] = s4 * pd2 + pc2;
+    if (dt != 0.f) { t[8] = t[8] / dt; t[9] = t[9] / dt; }
+}
+
 }  // namespace
+
+extern "C" int mv2d_finalize_reg(float* reg, const float* ref, int L, int R, const float* pc_range, float dt, void* stream) {
+    MV2D_CHECK_ARG(reg && ref && pc_range && L > 0, "mv2d_finalize_reg: bad args");
+    if (R == 0) return MV2D_OK;
+    hipLaunchKernelGGL(finalize_reg_kernel, dim3(cdiv(L * R, 256)), dim3(256), 0, (hipStream_t)stream, reg, ref, L, R, pc_range[0],
+                       pc_range[1], pc_range[2], pc_range[3] - pc_range[0], pc_range[4] - pc_range[1], pc_range[5] - pc_range[2], dt);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
 
 extern "C" int mv2d_row_ln(const float* parts, int n_parts, long long part_stride, const float* bias,
                            const float* residual, const float* ln_w, const float* ln_b, int relu, float* out,
                            const float* addvec, float* out_plus, const float* ln2_w, const float* ln2_b, float* out2,
-                           int M, float eps, void* stream) {
+                           int M, float eps, int rows_per_group, void* stream) {
     MV2D_CHECK_ARG(parts && n_parts >= 1 && (out || out_plus || out2), "mv2d_row_ln: null input/output");
     MV2D_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr), "mv2d_row_ln: ln_w/ln_b must both be set or null");
     MV2D_CHECK_ARG(!out_plus || addvec, "mv2d_row_ln: out_plus needs addvec");
     MV2D_CHECK_ARG(!out2 || (ln2_w && ln2_b), "mv2d_row_ln: out2 needs ln2_w/ln2_b");
     if (M == 0) return MV2D_OK;
-    LnParams p{parts, n_parts, part_stride, bias, residual, ln_w, ln_b, relu, out, addvec, out_plus, ln2_w, ln2_b, out2, M, eps};
+    LnParams p{parts, n_parts, part_stride, bias, residual, ln_w, ln_b, relu, out, addvec, out_plus, ln2_w, ln2_b, out2, M, eps, rows_per_group};
     hipLaunchKernelGGL(row_ln_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;

@@ -1,0 +1,332 @@
+"""Fused MI355X inference engine for the MV2D RoI head hot path.
+
+One ``HeadEngine`` owns the packed weights (bf16 copies for the big-M MFMA GEMMs, fp32 for the per-query exact
+GEMMs, K/V in_proj of all decoder layers concatenated into one [2*L*256, 256] matrix), a shape-keyed workspace
+(every buffer pre-allocated, kernels never allocate) and enqueues the whole frame on the current HIP stream
+through the C-ABI (mv2d_amd.ops) without a single device->host synchronisation:
+
+  T path (MV2DTHead, RH/mv2d_t_head.py:26-142)        S path (MV2DSHead eval branch, RH/mv2d_s_head.py:122-211)
+  rois -> per-RoI camera -> RoIAlign(feat) -> QueryGenerator -> ref points -> query_pos
+  box correlation -> match lists                        box correlation (k=1) -> CSR over RoI-feature rows
+  masks -> key list S + CSR (device-side counts)        RoI tap positions -> PE there -> RoIAlign(feat, pe)
+  PE only at the S key positions -> K/V of all 6 layers (one bf16 MFMA GEMM each side)
+  6 x [self-attn, LN, sparse cross-attn, LN, FFN, LN] -> heads (grouped GEMMs) -> top-k decode
+
+The reference evaluates PE on the whole map and runs dense [8,R,S] attention with a boolean mask; the outputs
+are identical up to the bf16 rounding of the key side.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import calib, ops
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+C = 256
+L_DEFAULT = 6
+
+
+def _t(x, device, dtype=None):
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    x = x.detach()
+    if dtype is not None:
+        x = x.to(dtype)
+    return x.to(device).contiguous()
+
+
+class HeadEngine:
+    def __init__(self, state_dict, kind, device, num_views=6, topk=None, expand_stride=None, num_layers=L_DEFAULT,
+                 max_num=300, pc_range=(-51.2, -51.2, -5.0, 51.2, 51.2, 3.0),
+                 post_range=(-61.2, -61.2, -10.0, 61.2, 61.2, 10.0), depth_num=64, stride=16, col_cap_per_query=2048,
+                 iou_thr=0.0, ratio=0.0):
+        assert kind in ('S', 'T')
+        self.kind = kind
+        self.dev = torch.device(device)
+        self.L = num_layers
+        self.num_views = num_views
+        self.topk = topk if topk is not None else (1 if kind == 'S' else 20)
+        self.expand = float(expand_stride if expand_stride is not None else (0 if kind == 'S' else 2))
+        self.max_num = max_num
+        self.depth_num = depth_num
+        self.stride = stride
+        self.iou_thr, self.ratio = iou_thr, ratio
+        self.col_cap_per_query = col_cap_per_query
+        self.pc_range_h = torch.tensor(pc_range, dtype=F32)
+        self.post_range_h = torch.tensor(post_range, dtype=F32)
+        self.post_range_h64 = torch.tensor(post_range, dtype=torch.float64)
+        self.const = {k: v.to(self.dev) for k, v in calib.constant_tables().items()}
+        self._ws = {}
+        self.load_state(state_dict)
+
+    # ------------------------------------------------------------------------------------------ weights
+    def load_state(self, sd):
+        d, L = self.dev, self.L
+        g = lambda k: _t(sd[k], d, F32)
+        b16 = lambda t: ops.f32_to_bf16(t.contiguous())
+        w = {}
+        dec = 'bbox_head.transformer.decoder.'
+        for i in range(L):
+            p = f'{dec}layers.{i}.'
+            w[f'sa_in_w{i}'] = g(p + 'attentions.0.attn.in_proj_weight')
+            w[f'sa_in_b{i}'] = g(p + 'attentions.0.attn.in_proj_bias')
+            w[f'sa_out_w{i}'] = g(p + 'attentions.0.attn.out_proj.weight')
+            w[f'sa_out_b{i}'] = g(p + 'attentions.0.attn.out_proj.bias')
+            inw, inb = g(p + 'attentions.1.attn.in_proj_weight'), g(p + 'attentions.1.attn.in_proj_bias')
+            w[f'ca_q_w{i}'] = inw[:C].contiguous()
+            w[f'ca_q_b{i}'] = inb[:C].contiguous()
+            w[f'_k_w{i}'], w[f'_k_b{i}'] = inw[C:2 * C], inb[C:2 * C]
+            w[f'_v_w{i}'], w[f'_v_b{i}'] = inw[2 * C:], inb[2 * C:]
+            w[f'ca_out_w{i}'] = g(p + 'attentions.1.attn.out_proj.weight')
+            w[f'ca_out_b{i}'] = g(p + 'attentions.1.attn.out_proj.bias')
+            w[f'ffn_w1{i}'] = g(p + 'ffns.0.layers.0.0.weight')
+            w[f'ffn_b1{i}'] = g(p + 'ffns.0.layers.0.0.bias')
+            w[f'ffn_w2{i}'] = g(p + 'ffns.0.layers.1.weight')
+            w[f'ffn_b2{i}'] = g(p + 'ffns.0.layers.1.bias')
+            for n in range(3):
+                w[f'ln{n}_w{i}'] = g(p + f'norms.{n}.weight')
+                w[f'ln{n}_b{i}'] = g(p + f'norms.{n}.bias')
+        # K/V in_proj of every layer in one matrix: rows [K_0..K_{L-1} | V_0..V_{L-1}]
+        kv_w = torch.cat([w.pop(f'_k_w{i}') for i in range(L)] + [w.pop(f'_v_w{i}') for i in range(L)], 0).contiguous()
+        kv_b = torch.cat([w.pop(f'_k_b{i}') for i in range(L)] + [w.pop(f'_v_b{i}') for i in range(L)], 0).contiguous()
+        w['kv_w'], w['kv_b'] = b16(kv_w), kv_b
+        w['post_w'], w['post_b'] = g(dec + 'post_norm.weight'), g(dec + 'post_norm.bias')
+        w['qe_w0'], w['qe_b0'] = g('bbox_head.query_embedding.0.weight'), g('bbox_head.query_embedding.0.bias')
+        w['qe_w2'], w['qe_b2'] = g('bbox_head.query_embedding.2.weight'), g('bbox_head.query_embedding.2.bias')
+        st = lambda fmt: torch.stack([g(fmt.format(l)) for l in range(L)]).contiguous()
+        for n in ('0', '3'):
+            w[f'cls_w{n}'], w[f'cls_b{n}'] = st('bbox_head.cls_branches.{}.' + n + '.weight'), st('bbox_head.cls_branches.{}.' + n + '.bias')
+        for n in ('1', '4'):
+            w[f'cls_lnw{n}'], w[f'cls_lnb{n}'] = st('bbox_head.cls_branches.{}.' + n + '.weight'), st('bbox_head.cls_branches.{}.' + n + '.bias')
+        w['cls_w6'], w['cls_b6'] = st('bbox_head.cls_branches.{}.6.weight'), st('bbox_head.cls_branches.{}.6.bias')
+        for n in ('0', '2', '4'):
+            w[f'reg_w{n}'], w[f'reg_b{n}'] = st('bbox_head.reg_branches.{}.' + n + '.weight'), st('bbox_head.reg_branches.{}.' + n + '.bias')
+        q = 'query_generator.'
+        conv = g(q + 'shared_convs.0.conv.weight')                                    # [256,256,3,3] -> [out][tap][cin]
+        w['qg_conv_w'] = b16(conv.permute(0, 2, 3, 1).reshape(C, 9 * C))
+        w['qg_conv_b'] = g(q + 'shared_convs.0.conv.bias')
+        w['qg_fc_w'], w['qg_fc_b'] = g(q + 'shared_fcs.0.weight'), g(q + 'shared_fcs.0.bias')
+        e0 = g(q + 'extra_enc.0.weight')                                              # [512,1040] -> K padded to 1056
+        e0p = torch.zeros((e0.shape[0], 1056), device=d, dtype=F32)
+        e0p[:, :e0.shape[1]] = e0
+        w['qg_e0_w'], w['qg_e0_b'] = e0p, g(q + 'extra_enc.0.bias')
+        w['qg_e2_w'], w['qg_e2_b'] = g(q + 'extra_enc.2.weight'), g(q + 'extra_enc.2.bias')
+        w['qg_c_w'], w['qg_c_b'] = g(q + 'fc_center.weight'), g(q + 'fc_center.bias')
+        pe = 'position_encoding.'
+        c1 = lambda k: g(pe + k).flatten(1)
+        w['pe_w1a'], w['pe_b1a'] = b16(c1('position_encoder.0.weight')), g(pe + 'position_encoder.0.bias')
+        w['pe_w1b'], w['pe_b1b'] = b16(c1('position_encoder.2.weight')), g(pe + 'position_encoder.2.bias')
+        w['pe_w2a'], w['pe_b2a'] = b16(c1('adapt_pos3d.0.weight')), g(pe + 'adapt_pos3d.0.bias')
+        w['pe_w2b'], w['pe_b2b'] = b16(c1('adapt_pos3d.2.weight')), g(pe + 'adapt_pos3d.2.bias')
+        w['pe_wr'], w['pe_br'] = b16(c1('fpe.conv_reduce.weight')), g(pe + 'fpe.conv_reduce.bias')
+        w['pe_we'], w['pe_be'] = b16(c1('fpe.conv_expand.weight')), g(pe + 'fpe.conv_expand.bias')
+        self.w = w
+
+    # ------------------------------------------------------------------------------------------ workspace
+    def _workspace(self, V, h, w, R):
+        key = (V, h, w, R)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        d, L = self.dev, self.L
+        P = V * h * w
+        e = lambda shape, dt=F32: torch.empty(shape, device=d, dtype=dt)
+        z = lambda shape, dt=F32: torch.zeros(shape, device=d, dtype=dt)
+        ws = dict(P=P)
+        # calibration blob layout (fp64 tables first, then fp32, then bytes)
+        lay, off = {}, 0
+        for name, n, dt in [('viewK', V * 16, torch.float64), ('viewE', V * 16, torch.float64), ('img2lidar', V * 16, torch.float64),
+                            ('trans', V * V * 16, torch.float64), ('coords_w', w, torch.float64), ('coords_h', h, torch.float64),
+                            ('coords_d', self.depth_num, torch.float64), ('embeds', 3 * P, F32), ('pad_mask', P, torch.uint8)]:
+            sz = n * torch.empty(0, dtype=dt).element_size()
+            lay[name] = (off, n, dt)
+            off += (sz + 15) // 16 * 16
+        ws['blob_layout'], ws['blob_bytes'] = lay, off
+        ws['blob_h'] = torch.empty(off, dtype=torch.uint8).pin_memory()
+        ws['blob_d'] = e(off, torch.uint8)
+        ws['tab'] = {k: ws['blob_d'][o:o + n * torch.empty(0, dtype=dt).element_size()].view(dt) for k, (o, n, dt) in lay.items()}
+        ws['rois'] = e((R, 5)); ws['view_start'] = e(V + 1, torch.int32)
+        ws['rois_h'] = torch.empty((R, 5), dtype=F32).pin_memory()
+        ws['view_start_h'] = torch.empty(V + 1, dtype=torch.int32).pin_memory()
+        ws['featcl'] = e((P, C))
+        ws['enc'] = z((R, 1056)); ws['minv'] = e((R, 16))
+        ws['roi_feat'] = e((R, 49, C), BF16)
+        ws['conv_out'] = e((R * 49, C)); ws['enc1'] = e((R, 512)); ws['enc2'] = e((R, C)); ws['center'] = e((R, 3))
+        ws['xyz'] = e((R, 3)); ws['ref'] = e((R, 3)); ws['posemb'] = e((R, 384)); ws['qe1'] = e((R, C)); ws['qpos'] = e((R, C))
+        ws['match'] = e((R, V, self.topk), torch.int32)
+        ws['roi_mask'] = z(P, torch.uint8); ws['zero_mask'] = z(P, torch.uint8)
+        ws['rect'] = e((R, 5), torch.int32); ws['pos2s'] = e(P, torch.int32); ws['s2pos'] = e(P, torch.int32)
+        ws['S_dev'] = z(1, torch.int32); ws['nnz'] = z(2, torch.int32)
+        ws['row_ptr'] = e(R + 1, torch.int32)
+        if self.kind == 'T':
+            ws['bits'] = e(max(ops.csr_workspace_bytes(R, V, h, w) // 4, 1), torch.int32)
+            ws['row_count'] = e(R, torch.int32)
+            ws['col_cap'] = R * self.col_cap_per_query
+            ws['S_kv'] = P
+        else:
+            ws['col_cap'] = R * (1 + V * self.topk) * 49
+            ws['S_kv'] = R * 49
+            ws['roi_sum'] = e((R, 49, C), BF16)
+        ws['col_idx'] = e(ws['col_cap'], torch.int32)
+        ws['A1'] = e((P, 3 * self.depth_num), BF16); ws['A2'] = e((P, 384), BF16)
+        ws['Xf_b'] = e((P, C), BF16); ws['Xf32'] = e((P, C))
+        ws['H1'] = e((P, 4 * C), BF16); ws['H2'] = e((P, 4 * C), BF16); ws['Hg'] = e((P, C), BF16)
+        ws['gate'] = e((P, C)); ws['Pg'] = e((P, C)); ws['pe'] = e((P, C)); ws['Xk'] = e((P, C), BF16)
+        ws['KV'] = e((2 * L, ws['S_kv'], C), BF16)
+        for n in ('x', 'xq', 'x1', 'x1q', 'x2', 'ctx', 'o', 'q'):
+            ws[n] = e((R, C))
+        ws['qkv'] = e((R, 3 * C)); ws['hdn'] = e((R, 2048)); ws['parts'] = e((8, R, C)); ws['outs'] = e((L, R, C))
+        ws['hc1'] = e((L, R, C)); ws['hc2'] = e((L, R, C)); ws['cls'] = e((L, R, 10)); ws['reg'] = e((L, R, 10))
+        ws['boxes'] = z((self.max_num, 9)); ws['scores'] = z(self.max_num)
+        ws['labels'] = z(self.max_num, torch.int64); ws['bbox_index'] = z(self.max_num, torch.int64); ws['count'] = z(1, torch.int32)
+        self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------------------------------ host side
+    @staticmethod
+    def _rois_host(proposals):
+        """bbox2roi (mmdet) + dummy proposal rule (RH/mv2d_head.py:105-108) on the host; returns (rois [R,5], counts)."""
+        props = [p if torch.is_tensor(p) else torch.from_numpy(np.asarray(p)) for p in proposals]
+        if sum(int(p.shape[0]) for p in props) == 0:
+            props = [torch.tensor([[0, 50, 50, 100, 100, 0]], dtype=F32)] + list(props[1:])
+        rows, counts = [], []
+        for i, p in enumerate(props):
+            counts.append(int(p.shape[0]))
+            if p.shape[0] > 0:
+                pc = p.detach().to('cpu', F32)
+                rows.append(torch.cat([torch.full((pc.shape[0], 1), float(i)), pc[:, :4]], 1))
+        return torch.cat(rows, 0), counts
+
+    def _upload_frame(self, ws, img_metas, h, w):
+        ft = calib.frame_tables(img_metas, h, w, stride=self.stride, depth_num=self.depth_num,
+                                position_range=tuple(self.post_range_h64.tolist()))
+        bh = ws['blob_h']
+        for k, (o, n, dt) in ws['blob_layout'].items():
+            nb = n * torch.empty(0, dtype=dt).element_size()
+            bh[o:o + nb].view(dt).copy_(ft[k].reshape(-1))
+        ws['blob_d'].copy_(bh, non_blocking=True)
+        return ft
+
+    # ------------------------------------------------------------------------------------------ forward
+    def run(self, feat, proposals, img_metas, keep_stages=False):
+        """feat [V,256,h,w] fp32 on the GPU (NCHW, or channels_last memory format); proposals list of [n,6]."""
+        o, W_ = ops, self.w
+        assert feat.is_cuda and feat.dtype == F32 and feat.dim() == 4 and feat.shape[1] == C
+        V, _, h, w = feat.shape
+        rois_h, counts = self._rois_host(proposals)
+        R = rois_h.shape[0]
+        ws = self._workspace(V, h, w, R)
+        P, L, T = ws['P'], self.L, ws['tab']
+        ft = self._upload_frame(ws, img_metas, h, w)
+        ws['rois_h'].copy_(rois_h)
+        ws['view_start_h'].copy_(torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32))
+        ws['rois'].copy_(ws['rois_h'], non_blocking=True)
+        ws['view_start'].copy_(ws['view_start_h'], non_blocking=True)
+        rois = ws['rois']
+        # position-major feature map
+        if feat.is_contiguous(memory_format=torch.channels_last) and not feat.is_contiguous():
+            featcl = feat.permute(0, 2, 3, 1).reshape(P, C)                         # already position-major: no copy
+        else:
+            featcl = o.nchw_to_nhwc(feat.contiguous(), ws['featcl'])
+        # a3/a5/a7 per-RoI camera
+        o.box_params(rois, T['viewK'], T['viewE'], ws['enc'][:, 1024:], 1056, ws['minv'])
+        # a9 epipolar correlation (independent of the features)
+        o.box_correlation(rois, ws['view_start'], T['trans'], self.const['lin'], self.const['depths'], ws['match'], V, self.topk,
+                          ft['pad_h'], ft['pad_w'], max(counts), iou_thr=self.iou_thr, ratio=self.ratio)
+        ws['roi_mask'].zero_()
+        ws['nnz'].zero_()
+        if self.kind == 'T':
+            # a11/a12: key list + CSR, then a4 RoIAlign of the feature half only
+            o.mask_compact(rois, ws['match'], T['pad_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'],
+                           ws['bits'], ws['row_count'], ws['row_ptr'], ws['col_idx'], ws['nnz'], R, V, h, w, self.topk,
+                           self.stride, self.expand, col_cap=ws['col_cap'])
+            o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'])
+        else:
+            # positions any RoIAlign tap can touch (own rect + 1 cell) -> PE only there
+            o.roi_positions(rois, ws['zero_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'], R, V, h, w,
+                            self.stride, 1.0)
+            o.csr_from_corr(ws['match'], ws['row_ptr'], ws['col_idx'], ws['nnz'], R, V, self.topk)
+        # a2: PE at the listed positions (3 two-layer MLPs on bf16 MFMA)
+        o.pe_inputs(ws['s2pos'], ws['S_dev'], P, featcl, T['img2lidar'], T['coords_w'], T['coords_h'], T['coords_d'], T['embeds'],
+                    self.const['dim_t'], ws['A1'], ws['A2'], ws['Xf_b'], ws['Xf32'], V, h, w, self.depth_num, self.post_range_h64)
+        md = ws['S_dev']
+        o.gemm_bf16(ws['A1'], W_['pe_w1a'], W_['pe_b1a'], m_dev=md, act=1, out=ws['H1'])
+        o.gemm_bf16(ws['A2'], W_['pe_w2a'], W_['pe_b2a'], m_dev=md, act=1, out=ws['H2'])
+        o.gemm_bf16(ws['Xf_b'], W_['pe_wr'], W_['pe_br'], m_dev=md, act=1, out=ws['Hg'])
+        o.gemm_bf16(ws['Hg'], W_['pe_we'], W_['pe_be'], m_dev=md, act=2, out=ws['gate'])
+        o.gemm_bf16(ws['H1'], W_['pe_w1b'], W_['pe_b1b'], m_dev=md, mul=ws['gate'], out=ws['Pg'])
+        o.gemm_bf16(ws['H2'], W_['pe_w2b'], W_['pe_b2b'], m_dev=md, add=ws['Pg'], out=ws['pe'], out2=ws['Xk'], add2=ws['Xf32'])
+        if self.kind == 'S':
+            o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=ws['pos2s'],
+                        out1_is_sum=True)
+        # a6: QueryGenerator
+        o.gemm_bf16(ws['roi_feat'], W_['qg_conv_w'], W_['qg_conv_b'], conv3x3=True, act=1, out=ws['conv_out'])
+        o.avgpool49(ws['conv_out'], ws['x2'], C, R)
+        o.gemm_f32(ws['x2'], W_['qg_fc_w'], W_['qg_fc_b'], act=1, clamp=5e3, out=ws['enc'], ldc=1056)
+        o.gemm_f32(ws['enc'], W_['qg_e0_w'], W_['qg_e0_b'], act=1, out=ws['enc1'])
+        o.gemm_f32(ws['enc1'], W_['qg_e2_w'], W_['qg_e2_b'], act=1, out=ws['enc2'])
+        o.gemm_f32(ws['enc2'], W_['qg_c_w'], W_['qg_c_b'], out=ws['center'])
+        # a7/a8/a13: reference points + query positional embedding
+        o.refpoint_posemb(ws['center'], 3, ws['minv'], self.const['dim_t'], ws['xyz'], ws['ref'], ws['posemb'], R, self.pc_range_h)
+        o.gemm_f32(ws['posemb'], W_['qe_w0'], W_['qe_b0'], act=1, out=ws['qe1'])
+        o.gemm_f32(ws['qe1'], W_['qe_w2'], W_['qe_b2'], out=ws['qpos'])
+        # a18 key side: K/V projections of all layers at once
+        S_kv = ws['S_kv']
+        if self.kind == 'T':
+            o.gemm_bf16(ws['Xk'], W_['kv_w'], W_['kv_b'], A2=ws['Xf_b'], n_split=L * C, m_dev=md, out=ws['KV'], ldc=C,
+                        c_blk_stride=S_kv * C, c_blk_cols=C)
+        else:
+            o.gemm_bf16(ws['roi_sum'].view(R * 49, C), W_['kv_w'], W_['kv_b'], A2=ws['roi_feat'].view(R * 49, C), n_split=L * C,
+                        out=ws['KV'], ldc=C, c_blk_stride=S_kv * C, c_blk_cols=C)
+        # a16-a19: decoder
+        x, xq = ws['x'], ws['xq']
+        x.zero_()
+        xq.copy_(ws['qpos'])
+        for i in range(L):
+            o.gemm_f32(xq, W_[f'sa_in_w{i}'], W_[f'sa_in_b{i}'], A2=x, n_split=2 * C, out=ws['qkv'])
+            o.self_attn(ws['qkv'], ws['ctx'], R)
+            o.gemm_f32(ws['ctx'], W_[f'sa_out_w{i}'], W_[f'sa_out_b{i}'], out=ws['o'])
+            o.row_ln(ws['o'], residual=x, ln=(W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), out=ws['x1'], addvec=ws['qpos'], out_plus=ws['x1q'])
+            o.gemm_f32(ws['x1q'], W_[f'ca_q_w{i}'], W_[f'ca_q_b{i}'], scale=ops.SCALE_Q, out=ws['q'])
+            o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R)
+            o.gemm_f32(ws['ctx'], W_[f'ca_out_w{i}'], W_[f'ca_out_b{i}'], out=ws['o'])
+            o.row_ln(ws['o'], residual=ws['x1'], ln=(W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), out=ws['x2'])
+            o.gemm_f32(ws['x2'], W_[f'ffn_w1{i}'], W_[f'ffn_b1{i}'], act=1, out=ws['hdn'])
+            o.gemm_f32(ws['hdn'], W_[f'ffn_w2{i}'], W_[f'ffn_b2{i}'], split_k=8, out=ws['parts'])
+            o.row_ln(ws['parts'], residual=ws['x2'], ln=(W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), out=x, addvec=ws['qpos'], out_plus=xq,
+                     ln2=(W_['post_w'], W_['post_b']), out2=ws['outs'][i])
+        # a14: per-layer heads, 6 layers per launch (grouped GEMMs)
+        LR = L * R
+        gk = dict(groups=L, a_gs=R * C, c_gs=R * C)
+        o.gemm_f32(ws['outs'], W_['cls_w0'], W_['cls_b0'], out=ws['hc1'], M=R, lda=C, ldc=C, **gk)
+        o.row_ln(ws['hc1'].view(LR, C), ln=(W_['cls_lnw1'], W_['cls_lnb1']), relu=True, out=ws['hc2'].view(LR, C), rows_per_group=R)
+        o.gemm_f32(ws['hc2'], W_['cls_w3'], W_['cls_b3'], out=ws['hc1'], M=R, lda=C, ldc=C, **gk)
+        o.row_ln(ws['hc1'].view(LR, C), ln=(W_['cls_lnw4'], W_['cls_lnb4']), relu=True, out=ws['hc2'].view(LR, C), rows_per_group=R)
+        o.gemm_f32(ws['hc2'], W_['cls_w6'], W_['cls_b6'], out=ws['cls'], M=R, lda=C, ldc=10, groups=L, a_gs=R * C, c_gs=R * 10)
+        o.gemm_f32(ws['outs'], W_['reg_w0'], W_['reg_b0'], act=1, out=ws['hc1'], M=R, lda=C, ldc=C, **gk)
+        o.gemm_f32(ws['hc1'], W_['reg_w2'], W_['reg_b2'], act=1, out=ws['hc2'], M=R, lda=C, ldc=C, **gk)
+        o.gemm_f32(ws['hc2'], W_['reg_w4'], W_['reg_b4'], out=ws['reg'], M=R, lda=C, ldc=10, groups=L, a_gs=R * C, c_gs=R * 10)
+        dt = 0.0
+        if self.kind == 'T' and len(img_metas) > self.num_views:
+            ts = ft['timestamps']
+            dt = float(ts[self.num_views:].mean() - ts[:self.num_views].mean())
+        o.finalize_reg(ws['reg'], ws['ref'], L, R, self.pc_range_h, dt)
+        # a21: NMS-free decode of the last layer
+        o.decode_topk(ws['cls'][L - 1], ws['reg'][L - 1], R, 10, self.max_num, self.post_range_h, ws['boxes'], ws['scores'],
+                      ws['labels'], ws['bbox_index'], ws['count'])
+        out = dict(R=R, ws=ws, cls=ws['cls'], reg=ws['reg'], boxes=ws['boxes'], scores=ws['scores'], labels=ws['labels'],
+                   bbox_index=ws['bbox_index'], count=ws['count'])
+        if keep_stages:
+            out['stages'] = {k: ws[k].clone() for k in ('rois', 'minv', 'enc', 'roi_feat', 'center', 'xyz', 'ref', 'posemb', 'qpos',
+                                                        'match', 'roi_mask', 'pos2s', 's2pos', 'S_dev', 'nnz', 'row_ptr', 'col_idx',
+                                                        'pe', 'Xk', 'Xf_b', 'KV', 'outs', 'cls', 'reg')}
+        return out
+
+    def results(self, out):
+        """Synchronising accessor: sliced (boxes [K,9], scores [K], labels [K]) like simple_test returns."""
+        n = int(out['count'].item())
+        if int(out['ws']['nnz'][1].item()) != 0:
+            raise RuntimeError('mv2d engine: CSR capacity exceeded (raise col_cap_per_query)')
+        return out['boxes'][:n], out['scores'][:n], out['labels'][:n]

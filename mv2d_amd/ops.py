@@ -58,27 +58,33 @@ def gemm_bf16(A, W, bias=None, *, M=None, A2=None, n_split=0, conv3x3=False, m_d
     return out if out is not None else out2
 
 
-def gemm_f32(A, W, bias=None, *, A2=None, n_split=0, split_k=1, act=0, scale=1.0, out=None, out_dtype=torch.float32,
-             M=None, lda=None, ldc=None):
+def gemm_f32(A, W, bias=None, *, A2=None, n_split=0, split_k=1, act=0, scale=1.0, clamp=0.0, out=None, out_dtype=torch.float32,
+             M=None, lda=None, ldc=None, groups=1, a_gs=0, w_gs=0, b_gs=0, c_gs=0):
     """C = epi((A @ W.T + bias) * scale), exact fp32 MFMA.  A [M,K] fp32, W [N,K] fp32."""
     lib = _lib.load()
     _req(A, torch.float32, 'A'); _req(W, torch.float32, 'W'); _req(A2, torch.float32, 'A2'); _req(bias, torch.float32, 'bias')
-    N, K = W.shape
-    M = A.shape[0] if M is None else M
-    lda_ = A.stride(0) if lda is None else lda
+    N, K = W.shape[-2], W.shape[-1]
+    M = A.shape[-2] if M is None else M
+    lda_ = A.stride(-2) if lda is None else lda
     if out is None:
-        shape = (split_k, M, N) if split_k > 1 else (M, N)
+        shape = (split_k, M, N) if split_k > 1 else ((groups, M, N) if groups > 1 else (M, N))
         out = torch.empty(shape, device=A.device, dtype=out_dtype)
     ldc_ = ldc if ldc is not None else (out.stride(-2))
     slice_stride = out.stride(0) if (split_k > 1) else 0
-    rc = lib.mv2d_gemm_f32(_p(A), _p(A2), n_split, _p(W), _p(bias), M, N, K, lda_, W.stride(0), split_k, act, float(scale),
-                           _p(out), 1 if out.dtype == BF16 else 0, ldc_, slice_stride, _stream())
+    if groups > 1:
+        a_gs = a_gs or (A.stride(0) if A.dim() == 3 else 0)
+        w_gs = w_gs or W.stride(0)
+        b_gs = b_gs or (bias.stride(0) if bias is not None else 0)
+        c_gs = c_gs or out.stride(0)
+    rc = lib.mv2d_gemm_f32(_p(A), _p(A2), n_split, _p(W), _p(bias), M, N, K, lda_, W.stride(-2), split_k, act, float(scale),
+                           float(clamp), _p(out), 1 if out.dtype == BF16 else 0, ldc_, slice_stride, groups, a_gs, w_gs, b_gs,
+                           c_gs, _stream())
     check(rc, 'mv2d_gemm_f32')
     return out
 
 
 def row_ln(parts, *, bias=None, residual=None, ln=None, relu=False, out=None, addvec=None, out_plus=None, ln2=None, out2=None,
-           M=None, eps=1e-5):
+           M=None, eps=1e-5, rows_per_group=0):
     """y = [relu][LN](sum parts + bias + residual); parts [M,256] or [Z,M,256]."""
     lib = _lib.load()
     _req(parts, torch.float32, 'parts')
@@ -93,9 +99,13 @@ def row_ln(parts, *, bias=None, residual=None, ln=None, relu=False, out=None, ad
     lw, lb = ln if ln is not None else (None, None)
     l2w, l2b = ln2 if ln2 is not None else (None, None)
     rc = lib.mv2d_row_ln(_p(parts), n_parts, stride, _p(bias), _p(residual), _p(lw), _p(lb), 1 if relu else 0, _p(out),
-                         _p(addvec), _p(out_plus), _p(l2w), _p(l2b), _p(out2), M, float(eps), _stream())
+                         _p(addvec), _p(out_plus), _p(l2w), _p(l2b), _p(out2), M, float(eps), rows_per_group, _stream())
     check(rc, 'mv2d_row_ln')
     return out
+
+
+def finalize_reg(reg, ref, L, R, pc_range_host, dt=0.0):
+    check(_lib.load().mv2d_finalize_reg(_p(reg), _p(ref), L, R, pc_range_host.data_ptr(), float(dt), _stream()), 'mv2d_finalize_reg')
 
 
 def avgpool49(x, out, ld_out, R):
@@ -154,10 +164,11 @@ def refpoint_posemb(center_pred, ld_cp, minv, dim_t, xyz, ref, posemb, R, pc_ran
 
 
 def roi_align(map0, rois, H, W, *, map1=None, out0=None, out1=None, out0_f32=None, out1_f32=None, spatial_scale=1.0 / 16,
-              sampling_ratio=-1):
+              sampling_ratio=-1, map1_index=None, out1_is_sum=False, R=None):
     _req(map0, torch.float32, 'map0'); _req(map1, torch.float32, 'map1'); _req(rois, torch.float32, 'rois')
-    check(_lib.load().mv2d_roi_align(_p(map0), _p(map1), _p(rois), _p(out0), _p(out1), _p(out0_f32), _p(out1_f32), rois.shape[0],
-                                     H, W, map0.shape[-1], spatial_scale, sampling_ratio, _stream()), 'mv2d_roi_align')
+    check(_lib.load().mv2d_roi_align(_p(map0), _p(map1), _p(rois), _p(out0), _p(out1), _p(out0_f32), _p(out1_f32),
+                                     rois.shape[0] if R is None else R, H, W, map0.shape[-1], spatial_scale, sampling_ratio,
+                                     _p(map1_index), 1 if out1_is_sum else 0, _stream()), 'mv2d_roi_align')
 
 
 def box_correlation(rois, view_start, trans, lin, depths, match, V, topk, pad_h, pad_w, max_per_view, sample_size=4,
@@ -174,10 +185,16 @@ def csr_workspace_bytes(R, V, h, w):
 
 
 def mask_compact(rois, match, pad_mask, roi_mask, rect, pos2s, s2pos, S_out, bits_ws, row_count, row_ptr, col_idx, nnz_out,
-                 R, V, h, w, topk, stride=16.0, expand_stride=2.0):
+                 R, V, h, w, topk, stride=16.0, expand_stride=2.0, col_cap=None):
+    col_cap = col_idx.numel() if col_cap is None else col_cap
     check(_lib.load().mv2d_mask_compact(_p(rois), _p(match), _p(pad_mask), _p(roi_mask), _p(rect), _p(pos2s), _p(s2pos), _p(S_out),
-                                        _p(bits_ws), _p(row_count), _p(row_ptr), _p(col_idx), _p(nnz_out), R, V, h, w, topk,
+                                        _p(bits_ws), _p(row_count), _p(row_ptr), _p(col_idx), _p(nnz_out), col_cap, R, V, h, w, topk,
                                         float(stride), float(expand_stride), _stream()), 'mv2d_mask_compact')
+
+
+def roi_positions(rois, pad_mask, roi_mask, rect, pos2s, s2pos, S_out, R, V, h, w, stride=16.0, expand_stride=1.0):
+    check(_lib.load().mv2d_roi_positions(_p(rois), _p(pad_mask), _p(roi_mask), _p(rect), _p(pos2s), _p(s2pos), _p(S_out), R, V, h, w,
+                                         float(stride), float(expand_stride), _stream()), 'mv2d_roi_positions')
 
 
 def csr_from_corr(match, row_ptr, col_idx, nnz_out, R, V, topk):

@@ -1,0 +1,169 @@
+"""End-to-end parity of the fused HIP engine (mv2d_amd.engine.HeadEngine) against the oracle on the same seeded
+inputs (-m gpu).  Integer / boolean stages (correlated-RoI lists, key list, CSR) are bit-exact; float stages are
+bounded by the bf16 rounding of the key side + bf16 MFMA of the PE / conv GEMMs (tolerances written below,
+relative to the stage's max magnitude); the final top-k is compared gap-aware: every index whose oracle score is
+separated from the K-th score by more than the score tolerance must be selected."""
+import numpy as np
+import pytest
+import torch
+
+from mv2d_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+# measured on MI355X (round 1): center 3e-4, ref 1e-4, qpos 2e-4, pe 4e-3, outs 8e-4, cls 4e-4, reg 1e-3 -> ~4x headroom
+TOL = dict(center=2e-3, ref=1e-3, qpos=1e-3, pe=1e-2, outs=4e-3, cls=2e-3, reg=5e-3, roi_feat=5e-3, score=5e-3)
+
+
+def relmax(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def run_both(name, prob=None):
+    from mv2d_amd.engine import HeadEngine
+    from oracle import mv2d_oracle as O
+    prob = prob or synthetic.make_problem(name, seed=0)
+    sd = synthetic.make_head_state(seed=0)
+    dev = torch.device('cuda:0')
+    eng = HeadEngine(sd, prob['kind'], dev, num_views=prob['views_per_frame'])
+    feat = torch.from_numpy(prob['feat'])
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    out = eng.run(feat.to(dev), props, prob['img_metas'], keep_stages=True)
+    torch.cuda.synchronize()
+    st = {}
+    if prob['kind'] == 'T':
+        O.forward_t(sd, feat, props, prob['img_metas'], num_views=prob['views_per_frame'], stages=st)
+    else:
+        O.forward_s(sd, feat, props, prob['img_metas'], stages=st)
+    return eng, out, st
+
+
+def check_topk(out, st, eng):
+    n = int(out['count'].item())
+    got = set((out['bbox_index'][:n] * 10 + out['labels'][:n]).cpu().tolist())
+    cls = st['cls'][-1].reshape(-1, 10)
+    scores = cls.sigmoid().view(-1)
+    k = min(300, scores.numel())
+    top, idx = scores.topk(k)
+    kth = float(top[-1])
+    # candidates kept by the centre-range filter in the oracle
+    exp = set((st['bbox_index'] * 10 + st['labels']).tolist())
+    if k < scores.numel():
+        margin = TOL['score'] * float(top[0])
+        must = {int(i) for i, s in zip(idx.tolist(), top.tolist()) if s - kth > margin and int(i) in exp}
+    else:
+        must = exp
+    missing = must - got
+    assert not missing, f'{len(missing)} confidently-top-k indices missing'
+    # scores of common entries agree
+    gs = dict(zip((out['bbox_index'][:n] * 10 + out['labels'][:n]).cpu().tolist(), out['scores'][:n].cpu().tolist()))
+    common = [i for i in exp if i in gs]
+    err = max(abs(gs[i] - float(scores[i])) for i in common) / float(top[0])
+    assert err < TOL['score'], err
+    return len(exp & got) / max(len(exp), 1)
+
+
+@pytest.mark.parametrize('name', ['micro_t', 'cfg1_t', 'cfg3_t'])
+def test_engine_t_path(name):
+    from oracle import mv2d_oracle as O
+    eng, out, st = run_both(name)
+    s = out['stages']
+    R = out['R']
+    # --- integer / boolean stages: bit-exact
+    ffr = st['feat_for_rois']
+    pad = st['key_padding']
+    V, h, w = ffr.shape[1:]
+    assert torch.equal(s['roi_mask'].cpu().bool().view(V, h, w), st['roi_mask'])
+    keep = (st['roi_mask'] & ~O.padding_mask(eng_metas(name), h, w)).view(-1)
+    S = int(s['S_dev'])
+    assert S == int(keep.sum())
+    assert torch.equal(s['s2pos'][:S].cpu().long(), keep.nonzero()[:, 0])
+    allowed = (ffr & ~O.padding_mask(eng_metas(name), h, w)[None]).view(R, -1)[:, keep]
+    rp, col = O.csr_from_allowed(allowed)
+    assert torch.equal(s['row_ptr'].cpu(), rp)
+    assert torch.equal(s['col_idx'][:int(rp[-1])].cpu(), col)
+    # --- float stages
+    errs = dict(center=relmax(s['center'], st['center_pred']), ref=relmax(s['ref'], st['ref']),
+                qpos=relmax(s['qpos'], st['qpos']))
+    pe_ref = st['pe'].permute(0, 2, 3, 1).reshape(-1, 256)[keep]
+    errs['pe'] = relmax(s['pe'][:S], pe_ref)
+    errs['outs'] = relmax(s['outs'], st['outs_dec'])
+    errs['cls'] = relmax(s['cls'], st['cls'])
+    errs['reg'] = relmax(s['reg'], st['reg'])
+    print(name, 'R', R, 'S', S, 'nnz', int(rp[-1]), {k: f'{v:.2e}' for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < TOL[k], (k, v)
+    frac = check_topk(out, st, eng)
+    print(name, 'top-k overlap', frac)
+    assert frac > 0.9
+
+
+def eng_metas(name):
+    return synthetic.make_problem(name, seed=0)['img_metas']
+
+
+@pytest.mark.parametrize('name', ['micro_s', 'cfg1_s', 'cfg2_s'])
+def test_engine_s_path(name):
+    eng, out, st = run_both(name)
+    s = out['stages']
+    R = out['R']
+    corr, cmask = st['corr'], st['corr_mask']
+    exp_cols = []
+    for r in range(R):
+        for j in range(corr.shape[1]):
+            if cmask[r, j]:
+                exp_cols += [int(corr[r, j]) * 49 + c for c in range(49)]
+    nnz = int(s['nnz'][0])
+    assert nnz == len(exp_cols)
+    assert s['col_idx'][:nnz].cpu().tolist() == exp_cols
+    errs = dict(center=relmax(s['center'], st['center_pred']), ref=relmax(s['ref'], st['ref']), qpos=relmax(s['qpos'], st['qpos']),
+                outs=relmax(s['outs'], st['outs_dec']), cls=relmax(s['cls'], st['cls']), reg=relmax(s['reg'], st['reg']))
+    rf = st['roi_feats'].flatten(2).transpose(1, 2)
+    errs['roi_feat'] = relmax(s['roi_feat'].float(), rf)
+    print(name, 'R', R, 'nnz', nnz, {k: f'{v:.2e}' for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < TOL.get(k, 1e-2), (k, v)
+    frac = check_topk(out, st, eng)
+    print(name, 'top-k overlap', frac)
+    assert frac > 0.9
+
+
+def test_engine_two_frame_velocity_and_empty():
+    from mv2d_amd.engine import HeadEngine
+    from oracle import mv2d_oracle as O
+    sd = synthetic.make_head_state(seed=0)
+    dev = torch.device('cuda:0')
+    prob = dict(kind='T', views_per_frame=2, img_metas=synthetic.make_img_metas(2, 128, 192, frames=2, yaw_step_deg=40.0),
+                proposals=synthetic.make_proposals(4, 4, 128, 192, seed=11), feat=synthetic.make_feat(4, 8, 12, seed=12))
+    eng, out, st = run_both(None, prob)
+    assert relmax(out['stages']['reg'], st['reg']) < TOL['reg']                      # includes (vx, vy) / dt
+    # empty detections -> one dummy proposal in view 0
+    prob = synthetic.make_problem('micro_t', seed=0)
+    prob['proposals'] = [np.zeros((0, 6), np.float32) for _ in prob['proposals']]
+    eng, out, st = run_both(None, prob)
+    assert out['R'] == 1
+    assert relmax(out['stages']['cls'], st['cls']) < TOL['cls']
+    b, s_, l = eng.results(out)
+    assert b.shape[0] == st['boxes'].shape[0]
+    assert torch.equal(l.cpu(), st['labels'])
+
+
+def test_engine_is_deterministic_and_reusable():
+    """Same frame twice through the same engine/workspace -> bitwise identical outputs (no atomics in the float path)."""
+    from mv2d_amd.engine import HeadEngine
+    prob = synthetic.make_problem('cfg1_t', seed=0)
+    sd = synthetic.make_head_state(seed=0)
+    dev = torch.device('cuda:0')
+    eng = HeadEngine(sd, 'T', dev, num_views=2)
+    feat = torch.from_numpy(prob['feat']).to(dev)
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    o1 = eng.run(feat, props, prob['img_metas'])
+    c1, r1 = o1['cls'].clone(), o1['reg'].clone()
+    b1 = [t.clone() for t in eng.results(o1)]
+    o2 = eng.run(feat, props, prob['img_metas'])
+    b2 = eng.results(o2)
+    assert torch.equal(c1, o2['cls']) and torch.equal(r1, o2['reg'])
+    for a, b in zip(b1, b2):
+        assert torch.equal(a, b)

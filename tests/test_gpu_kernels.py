@@ -298,7 +298,7 @@ def test_box_correlation_and_csr_bit_exact(dev, name, topk, expand):
     row_count = torch.empty(R, dtype=torch.int32, device=dev)
     row_ptr = torch.empty(R + 1, dtype=torch.int32, device=dev)
     col = torch.empty(R * 2048, dtype=torch.int32, device=dev)
-    nnz = torch.zeros(1, dtype=torch.int32, device=dev)
+    nnz = torch.zeros(2, dtype=torch.int32, device=dev)
     ops.mask_compact(rois.to(dev), match, ft['pad_mask'].to(dev), roi_mask, rect, pos2s, s2pos, S_out, bits, row_count, row_ptr,
                      col, nnz, R, V, h, w, topk, 16.0, float(expand))
     assert torch.equal(roi_mask.cpu().bool().view(V, h, w), ffr.any(0))               # roi_mask of RH/mv2d_t_head.py:84
@@ -309,8 +309,8 @@ def test_box_correlation_and_csr_bit_exact(dev, name, topk, expand):
     allowed = (ffr & ~pad[None]).view(R, -1)[:, keep]                                 # [R,S]
     rp_ref, col_ref = O.csr_from_allowed(allowed)
     assert torch.equal(row_ptr.cpu(), rp_ref)
-    assert int(nnz) == int(rp_ref[-1])
-    assert torch.equal(col[:int(nnz)].cpu(), col_ref)
+    assert int(nnz[0]) == int(rp_ref[-1]) and int(nnz[1]) == 0
+    assert torch.equal(col[:int(nnz[0])].cpu(), col_ref)
 
 
 @pytest.mark.parametrize('name', ['micro_t', 'cfg1_t'])
