@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""bench.py — MV2D RoI-head hot path on MI355X: multi-view samples/s + decoder ms/iter (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path (PE -> RoI gather -> query generator -> box correlation -> key list/CSR
+-> K/V projection -> 6-layer decoder -> heads -> top-k decode, + the all-gather of decoded boxes when N > 1) over
+one batch of `--inflight` synthetic 6-camera frames per GPU (each frame = one independent sample on its own HIP
+stream, replayed as a hipGraph).  Inputs are resident in HBM before the timed region.  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def stage_flops(kind, R, S, L=6):
+    """Algorithmic FLOPs (2 x MAC) of the dense bf16 MFMA launches of one frame."""
+    C = 256
+    return {
+        'pe_gemm_192x1024': 2.0 * S * 192 * 1024,
+        'pe_gemm_384x1024': 2.0 * S * 384 * 1024,
+        'pe_gemm_1024x256_a': 2.0 * S * 1024 * 256,
+        'pe_gemm_1024x256_b': 2.0 * S * 1024 * 256,
+        'qg_conv_gemm': 2.0 * R * 49 * 2304 * 256,
+        'kv_gemm': 2.0 * (S if kind == 'T' else R * 49) * C * (2 * L * C),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--workload', default='cfg2_s', help='cfg2_s (MV2D-S 6 cams 1408x512, headline) | cfg3_t | cfg5_t | cfg1_s ...')
+    ap.add_argument('--inflight', type=int, default=4, help='independent frames per GPU per step (one HIP stream each)')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-iters', type=int, default=3)
+    args = ap.parse_args()
+
+    from mv2d_amd import dist as mdist
+    from mv2d_amd import synthetic
+    from mv2d_amd.engine import HeadEngine
+    import torch.distributed as dist
+
+    rank, world, local = mdist.init_from_env()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    prob = synthetic.make_problem(args.workload, seed=rank)        # weak scaling: every rank its own frames
+    kind = prob['kind']
+    sd = synthetic.make_head_state(seed=0)
+    base = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'])
+    engines = [base] + [base.clone_shared() for _ in range(args.inflight - 1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)]
+    feat = torch.from_numpy(prob['feat']).to(dev)
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    metas = prob['img_metas']
+    use_graph = not args.no_graph
+    payload = torch.zeros((args.inflight, 300 * 11 + 1), device=dev)
+
+    def step():
+        cur = torch.cuda.current_stream()
+        outs = []
+        for e, s in zip(engines, streams):
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                outs.append(e.run(feat, props, metas, use_graph=use_graph))
+        for i, (o, s) in enumerate(zip(outs, streams)):
+            with torch.cuda.stream(s):
+                payload[i].copy_(mdist.pack_detections(o['boxes'], o['scores'], o['labels'], o['count']))
+            cur.wait_stream(s)
+        if world > 1:
+            return mdist.gather_detections(payload)       # the one collective of an evaluation step (RCCL all-gather)
+        return payload
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    samples = world * args.inflight * args.steps
+    value = samples / elapsed
+
+    # ---------------- per-stage timing of the same frame with HIP events on the launch stream (single stream, eager)
+    eng = base
+    out0 = eng.run(feat, props, metas)
+    torch.cuda.synchronize()
+    R = out0['R']
+    ws = out0['ws']
+    S = int(ws['S_dev'].item())
+    nnz = int(ws['nnz'][0].item())
+    eng.prof = {}
+    n_prof = max(5, min(args.steps, 20))
+    for _ in range(n_prof):
+        eng.run(feat, props, metas)
+    torch.cuda.synchronize()
+    prof, eng.prof = eng.prof, None
+    names = list(prof.keys())
+    stage_ms = {}
+    for a, b in zip(names[:-1], names[1:]):
+        stage_ms[a] = statistics.mean(x.elapsed_time(y) for x, y in zip(prof[a], prof[b]))
+    fl = stage_flops(kind, R, S)
+    dom = max(fl, key=lambda k: stage_ms.get(k, 0.0))
+    dom_ms = stage_ms[dom]
+    achieved = fl[dom] / (dom_ms * 1e-3) / 1e12
+    roofline = dict(bound='mfma', kernel=f'gemm_bf16_kernel[{dom}]', achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS,
+                    unit='TFLOP/s', frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None, launch_ms=round(dom_ms, 4),
+                    flops_per_launch=fl[dom])
+
+    # ---------------- decoder ms/iter (CrossAttentionBoxHead transformer on prepared inputs), hipGraph replay
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        eng._enqueue_decoder(ws, R)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        eng._enqueue_decoder(ws, R)
+    for _ in range(5):
+        g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    decoder_ms = e0.elapsed_time(e1) / 50
+
+    # ---------------- CPU baseline: the oracle (port of the reference algorithm) on the host cores, bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import mv2d_oracle as O
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        fn = O.forward_t if kind == 'T' else O.forward_s
+        kw = {'num_views': prob['views_per_frame']} if kind == 'T' else {}
+        fcpu = torch.from_numpy(prob['feat'])
+        with torch.no_grad():
+            fn(sd, fcpu, props, metas, **kw)
+            ts = []
+            for _ in range(args.cpu_iters):
+                c0 = time.perf_counter()
+                fn(sd, fcpu, props, metas, **kw)
+                ts.append(time.perf_counter() - c0)
+        med = statistics.median(ts)
+        cpu = dict(value=round(1.0 / med, 4), unit='samples/s', cores=cores, kind='port',
+                   sample=f'{args.cpu_iters} frames of {args.workload} after 1 warm-up, median {med * 1e3:.0f} ms/frame, '
+                          f'torch {torch.__version__} CPU fp32/fp64, {cores} threads')
+
+    if rank == 0:
+        line = {
+            'metric': 'multi-view samples/sec (6-cam frames) through the MV2D RoI-head hot path',
+            'value': round(value, 2), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16 (key side MFMA) / f32 (query side)', 'data': 'synthetic',
+            'config': {'workload': f'{args.workload}: MV2D-{kind} head, {len(metas)} views {metas[0]["img_shape"][1]}x{metas[0]["img_shape"][0]}, '
+                                   f'R={R} queries, S={S} key positions, nnz={nnz} allowed (q,k) pairs',
+                       'frames_per_step_per_gpu': args.inflight, 'global_batch': world * args.inflight,
+                       'parallelism': f'dp{world}', 'hipgraph': use_graph},
+            'decoder_ms_per_iter': round(decoder_ms, 4),
+            'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},
+            'roofline': roofline,
+            'cpu_baseline': cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -59,6 +59,7 @@ class HeadEngine:
         self.post_range_h64 = torch.tensor(post_range, dtype=torch.float64)
         self.const = {k: v.to(self.dev) for k, v in calib.constant_tables().items()}
         self._ws = {}
+        self.prof = None              # dict name -> [events] when stage timing is on (bench.py)
         self.load_state(state_dict)
 
     # ------------------------------------------------------------------------------------------ weights
@@ -199,42 +200,73 @@ class HeadEngine:
                 rows.append(torch.cat([torch.full((pc.shape[0], 1), float(i)), pc[:, :4]], 1))
         return torch.cat(rows, 0), counts
 
-    def _upload_frame(self, ws, img_metas, h, w):
-        ft = calib.frame_tables(img_metas, h, w, stride=self.stride, depth_num=self.depth_num,
-                                position_range=tuple(self.post_range_h64.tolist()))
-        bh = ws['blob_h']
-        for k, (o, n, dt) in ws['blob_layout'].items():
-            nb = n * torch.empty(0, dtype=dt).element_size()
-            bh[o:o + nb].view(dt).copy_(ft[k].reshape(-1))
-        ws['blob_d'].copy_(bh, non_blocking=True)
-        return ft
-
     # ------------------------------------------------------------------------------------------ forward
-    def run(self, feat, proposals, img_metas, keep_stages=False):
-        """feat [V,256,h,w] fp32 on the GPU (NCHW, or channels_last memory format); proposals list of [n,6]."""
-        o, W_ = ops, self.w
-        assert feat.is_cuda and feat.dtype == F32 and feat.dim() == 4 and feat.shape[1] == C
-        V, _, h, w = feat.shape
+    def _frame_key(self, img_metas):
+        parts = []
+        for m in img_metas:
+            parts.append(np.asarray(m['lidar2img'], dtype=np.float64).tobytes())
+            parts.append(np.asarray(m['intrinsics'], dtype=np.float64).tobytes())
+            parts.append(np.asarray(m['extrinsics'], dtype=np.float64).tobytes())
+            parts.append(repr((tuple(m['pad_shape']), tuple(m['img_shape']), float(m.get('timestamp', 0.0)))).encode())
+        return hash(b''.join(parts))
+
+    def _host_prepare(self, proposals, img_metas, V, h, w):
+        """Host side of one frame: RoI list + calibration tables into the workspace's pinned staging buffers.
+        The calibration tables are pure functions of img_metas; they are rebuilt only when img_metas change."""
         rois_h, counts = self._rois_host(proposals)
         R = rois_h.shape[0]
         ws = self._workspace(V, h, w, R)
-        P, L, T = ws['P'], self.L, ws['tab']
-        ft = self._upload_frame(ws, img_metas, h, w)
+        if 'done_ev' in ws:
+            ws['done_ev'].synchronize()      # the previous frame on this workspace must have consumed the staging buffers
+        key = self._frame_key(img_metas)
+        if ws.get('frame_key') != key:
+            ft = calib.frame_tables(img_metas, h, w, stride=self.stride, depth_num=self.depth_num,
+                                    position_range=tuple(self.post_range_h64.tolist()))
+            bh = ws['blob_h']
+            for k, (o_, n, dt_) in ws['blob_layout'].items():
+                nb = n * torch.empty(0, dtype=dt_).element_size()
+                bh[o_:o_ + nb].view(dt_).copy_(ft[k].reshape(-1))
+            dt = 0.0
+            if self.kind == 'T' and len(img_metas) > self.num_views:
+                ts = ft['timestamps']
+                dt = float(ts[self.num_views:].mean() - ts[:self.num_views].mean())
+            ws['frame_key'], ws['frame_scalars'] = key, dict(pad_h=ft['pad_h'], pad_w=ft['pad_w'], dt=dt)
         ws['rois_h'].copy_(rois_h)
         ws['view_start_h'].copy_(torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32))
+        sc = dict(ws['frame_scalars'])
+        sc['max_per_view'] = max(counts)
+        return ws, R, sc
+
+    def _tick(self, name):
+        if self.prof is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.prof.setdefault(name, []).append(ev)
+
+    def _enqueue(self, ws, feat, R, V, h, w, sc):
+        """Device side of one frame: everything below is enqueued on the current stream, no host sync."""
+        o, W_ = ops, self.w
+        P, L, T = ws['P'], self.L, ws['tab']
+        tk = self._tick
+        tk('h2d')
+        ws['blob_d'].copy_(ws['blob_h'], non_blocking=True)
         ws['rois'].copy_(ws['rois_h'], non_blocking=True)
         ws['view_start'].copy_(ws['view_start_h'], non_blocking=True)
         rois = ws['rois']
+        tk('transpose')
         # position-major feature map
         if feat.is_contiguous(memory_format=torch.channels_last) and not feat.is_contiguous():
             featcl = feat.permute(0, 2, 3, 1).reshape(P, C)                         # already position-major: no copy
         else:
-            featcl = o.nchw_to_nhwc(feat.contiguous(), ws['featcl'])
+            featcl = o.nchw_to_nhwc(feat, ws['featcl'])
+        tk('box_params')
         # a3/a5/a7 per-RoI camera
         o.box_params(rois, T['viewK'], T['viewE'], ws['enc'][:, 1024:], 1056, ws['minv'])
+        tk('box_corr')
         # a9 epipolar correlation (independent of the features)
         o.box_correlation(rois, ws['view_start'], T['trans'], self.const['lin'], self.const['depths'], ws['match'], V, self.topk,
-                          ft['pad_h'], ft['pad_w'], max(counts), iou_thr=self.iou_thr, ratio=self.ratio)
+                          sc['pad_h'], sc['pad_w'], sc['max_per_view'], iou_thr=self.iou_thr, ratio=self.ratio)
+        tk('csr')
         ws['roi_mask'].zero_()
         ws['nnz'].zero_()
         if self.kind == 'T':
@@ -242,27 +274,37 @@ class HeadEngine:
             o.mask_compact(rois, ws['match'], T['pad_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'],
                            ws['bits'], ws['row_count'], ws['row_ptr'], ws['col_idx'], ws['nnz'], R, V, h, w, self.topk,
                            self.stride, self.expand, col_cap=ws['col_cap'])
-            o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'])
+            tk('roi_align')
+            o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'], R=R)
         else:
             # positions any RoIAlign tap can touch (own rect + 1 cell) -> PE only there
             o.roi_positions(rois, ws['zero_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'], R, V, h, w,
                             self.stride, 1.0)
             o.csr_from_corr(ws['match'], ws['row_ptr'], ws['col_idx'], ws['nnz'], R, V, self.topk)
+        tk('pe_inputs')
         # a2: PE at the listed positions (3 two-layer MLPs on bf16 MFMA)
         o.pe_inputs(ws['s2pos'], ws['S_dev'], P, featcl, T['img2lidar'], T['coords_w'], T['coords_h'], T['coords_d'], T['embeds'],
                     self.const['dim_t'], ws['A1'], ws['A2'], ws['Xf_b'], ws['Xf32'], V, h, w, self.depth_num, self.post_range_h64)
         md = ws['S_dev']
+        tk('pe_gemm_192x1024')
         o.gemm_bf16(ws['A1'], W_['pe_w1a'], W_['pe_b1a'], m_dev=md, act=1, out=ws['H1'])
+        tk('pe_gemm_384x1024')
         o.gemm_bf16(ws['A2'], W_['pe_w2a'], W_['pe_b2a'], m_dev=md, act=1, out=ws['H2'])
+        tk('pe_gemm_gate')
         o.gemm_bf16(ws['Xf_b'], W_['pe_wr'], W_['pe_br'], m_dev=md, act=1, out=ws['Hg'])
         o.gemm_bf16(ws['Hg'], W_['pe_we'], W_['pe_be'], m_dev=md, act=2, out=ws['gate'])
+        tk('pe_gemm_1024x256_a')
         o.gemm_bf16(ws['H1'], W_['pe_w1b'], W_['pe_b1b'], m_dev=md, mul=ws['gate'], out=ws['Pg'])
+        tk('pe_gemm_1024x256_b')
         o.gemm_bf16(ws['H2'], W_['pe_w2b'], W_['pe_b2b'], m_dev=md, add=ws['Pg'], out=ws['pe'], out2=ws['Xk'], add2=ws['Xf32'])
         if self.kind == 'S':
+            tk('roi_align')
             o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=ws['pos2s'],
-                        out1_is_sum=True)
+                        out1_is_sum=True, R=R)
         # a6: QueryGenerator
+        tk('qg_conv_gemm')
         o.gemm_bf16(ws['roi_feat'], W_['qg_conv_w'], W_['qg_conv_b'], conv3x3=True, act=1, out=ws['conv_out'])
+        tk('qg_rest')
         o.avgpool49(ws['conv_out'], ws['x2'], C, R)
         o.gemm_f32(ws['x2'], W_['qg_fc_w'], W_['qg_fc_b'], act=1, clamp=5e3, out=ws['enc'], ldc=1056)
         o.gemm_f32(ws['enc'], W_['qg_e0_w'], W_['qg_e0_b'], act=1, out=ws['enc1'])
@@ -273,6 +315,7 @@ class HeadEngine:
         o.gemm_f32(ws['posemb'], W_['qe_w0'], W_['qe_b0'], act=1, out=ws['qe1'])
         o.gemm_f32(ws['qe1'], W_['qe_w2'], W_['qe_b2'], out=ws['qpos'])
         # a18 key side: K/V projections of all layers at once
+        tk('kv_gemm')
         S_kv = ws['S_kv']
         if self.kind == 'T':
             o.gemm_bf16(ws['Xk'], W_['kv_w'], W_['kv_b'], A2=ws['Xf_b'], n_split=L * C, m_dev=md, out=ws['KV'], ldc=C,
@@ -281,6 +324,20 @@ class HeadEngine:
             o.gemm_bf16(ws['roi_sum'].view(R * 49, C), W_['kv_w'], W_['kv_b'], A2=ws['roi_feat'].view(R * 49, C), n_split=L * C,
                         out=ws['KV'], ldc=C, c_blk_stride=S_kv * C, c_blk_cols=C)
         # a16-a19: decoder
+        tk('decoder')
+        self._enqueue_decoder(ws, R)
+        tk('heads')
+        self._enqueue_heads(ws, R, sc['dt'])
+        tk('decode')
+        # a21: NMS-free decode of the last layer
+        o.decode_topk(ws['cls'][L - 1], ws['reg'][L - 1], R, 10, self.max_num, self.post_range_h, ws['boxes'], ws['scores'],
+                      ws['labels'], ws['bbox_index'], ws['count'])
+        tk('end')
+
+    def _enqueue_decoder(self, ws, R):
+        """CrossAttentionBoxHead.forward's transformer call on already-prepared inputs (qpos, KV, CSR):
+        the "decoder ms/iter" half of the headline metric."""
+        o, W_, L = ops, self.w, self.L
         x, xq = ws['x'], ws['xq']
         x.zero_()
         xq.copy_(ws['qpos'])
@@ -297,7 +354,10 @@ class HeadEngine:
             o.gemm_f32(ws['hdn'], W_[f'ffn_w2{i}'], W_[f'ffn_b2{i}'], split_k=8, out=ws['parts'])
             o.row_ln(ws['parts'], residual=ws['x2'], ln=(W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), out=x, addvec=ws['qpos'], out_plus=xq,
                      ln2=(W_['post_w'], W_['post_b']), out2=ws['outs'][i])
+
+    def _enqueue_heads(self, ws, R, dt):
         # a14: per-layer heads, 6 layers per launch (grouped GEMMs)
+        o, W_, L = ops, self.w, self.L
         LR = L * R
         gk = dict(groups=L, a_gs=R * C, c_gs=R * C)
         o.gemm_f32(ws['outs'], W_['cls_w0'], W_['cls_b0'], out=ws['hc1'], M=R, lda=C, ldc=C, **gk)
@@ -308,14 +368,9 @@ class HeadEngine:
         o.gemm_f32(ws['outs'], W_['reg_w0'], W_['reg_b0'], act=1, out=ws['hc1'], M=R, lda=C, ldc=C, **gk)
         o.gemm_f32(ws['hc1'], W_['reg_w2'], W_['reg_b2'], act=1, out=ws['hc2'], M=R, lda=C, ldc=C, **gk)
         o.gemm_f32(ws['hc2'], W_['reg_w4'], W_['reg_b4'], out=ws['reg'], M=R, lda=C, ldc=10, groups=L, a_gs=R * C, c_gs=R * 10)
-        dt = 0.0
-        if self.kind == 'T' and len(img_metas) > self.num_views:
-            ts = ft['timestamps']
-            dt = float(ts[self.num_views:].mean() - ts[:self.num_views].mean())
         o.finalize_reg(ws['reg'], ws['ref'], L, R, self.pc_range_h, dt)
-        # a21: NMS-free decode of the last layer
-        o.decode_topk(ws['cls'][L - 1], ws['reg'][L - 1], R, 10, self.max_num, self.post_range_h, ws['boxes'], ws['scores'],
-                      ws['labels'], ws['bbox_index'], ws['count'])
+
+    def _result(self, ws, R, keep_stages=False):
         out = dict(R=R, ws=ws, cls=ws['cls'], reg=ws['reg'], boxes=ws['boxes'], scores=ws['scores'], labels=ws['labels'],
                    bbox_index=ws['bbox_index'], count=ws['count'])
         if keep_stages:
@@ -323,6 +378,56 @@ class HeadEngine:
                                                         'match', 'roi_mask', 'pos2s', 's2pos', 'S_dev', 'nnz', 'row_ptr', 'col_idx',
                                                         'pe', 'Xk', 'Xf_b', 'KV', 'outs', 'cls', 'reg')}
         return out
+
+    def run(self, feat, proposals, img_metas, keep_stages=False, use_graph=False):
+        """feat [V,256,h,w] fp32 on the GPU (NCHW, or channels_last memory format); proposals list of [n,6].
+        Enqueues one frame on the current stream; use_graph replays a captured hipGraph of the same shape."""
+        assert feat.is_cuda and feat.dtype == F32 and feat.dim() == 4 and feat.shape[1] == C
+        V, _, h, w = feat.shape
+        ws, R, sc = self._host_prepare(proposals, img_metas, V, h, w)
+        if not use_graph:
+            if not (feat.is_contiguous(memory_format=torch.channels_last) and not feat.is_contiguous()):
+                feat = feat.contiguous()
+            self._enqueue(ws, feat, R, V, h, w, sc)
+            self._mark_done(ws)
+            return self._result(ws, R, keep_stages)
+        # the graph bakes in the input pointer (the producer's output buffer is static under graph replay) and the
+        # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
+        if not (feat.is_contiguous(memory_format=torch.channels_last) and not feat.is_contiguous()):
+            feat = feat.contiguous()
+        gkey = (feat.data_ptr(), sc['pad_h'], sc['pad_w'], sc['dt'], sc['max_per_view'])
+        g = ws.get('graph')
+        if g is None or ws.get('graph_key') != gkey:
+            prof, self.prof = self.prof, None
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._enqueue(ws, feat, R, V, h, w, sc)                    # warm-up outside capture (lazy inits)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._enqueue(ws, feat, R, V, h, w, sc)
+            self.prof = prof
+            ws['graph'], ws['graph_key'], ws['graph_feat'] = g, gkey, feat
+        g.replay()
+        self._mark_done(ws)
+        return self._result(ws, R, keep_stages)
+
+    @staticmethod
+    def _mark_done(ws):
+        if 'done_ev' not in ws:
+            ws['done_ev'] = torch.cuda.Event()
+        ws['done_ev'].record()
+
+    def clone_shared(self):
+        """A second engine sharing the packed weights / constant tables but with its own workspaces, so that several
+        frames can be in flight on different HIP streams (one engine per stream)."""
+        other = object.__new__(HeadEngine)
+        other.__dict__.update(self.__dict__)
+        other._ws = {}
+        other.prof = None
+        return other
 
     def results(self, out):
         """Synchronising accessor: sliced (boxes [K,9], scores [K], labels [K]) like simple_test returns."""
