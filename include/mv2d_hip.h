@@ -104,6 +104,13 @@ int mv2d_box_params(const float* rois, const double* viewK, const double* viewE,
 int mv2d_refpoint_posemb(const float* center_pred, int ld_cp, const float* minv, const float* dim_t, float* xyz, float* ref,
                          float* posemb, int R, const float* pc_range, void* stream);
 
+/* inverse(bmm(K_roi, E^T)).float() of QueryGenerator.center2lidar (RH/utils/query_generator.py:337-339) for per-RoI
+ * fp64 matrices K_roi, E [R,16] -> minv [R,16] fp32. */
+int mv2d_lidar2img_inverse(const double* K_roi, const double* E, float* minv, int R, void* stream);
+
+/* pos2posemb3d (MU/pe.py:21-33) alone: ref [R,3] (x,y,z normalised) -> posemb [R,384] in (y|x|z) order. */
+int mv2d_posemb3d(const float* ref, const float* dim_t, float* posemb, int R, void* stream);
+
 /* mmcv.ops.RoIAlign(7, 1/16, sampling_ratio, 'avg', aligned=True) (call site RH/mv2d_head.py:114-115) on one or two
  * position-major maps -> [R,49,256] bf16 and/or fp32 per map.  map1_index (optional): map1 is row-compacted, row of
  * position p is map1_index[p].  out1_is_sum: out1 = bf16(map0 value + map1 value) (the S-path key input feat + pe). */

@@ -32,6 +32,8 @@ SIGNATURES = {
     'mv2d_sparse_xattn_fwd': (I, [P, P, P, P, P, P, P, LL, I, P]),
     'mv2d_box_params': (I, [P, P, P, P, P, I, P, I, F, F, F, P]),
     'mv2d_refpoint_posemb': (I, [P, I, P, P, P, P, P, I, P, P]),
+    'mv2d_lidar2img_inverse': (I, [P, P, P, I, P]),
+    'mv2d_posemb3d': (I, [P, P, P, I, P]),
     'mv2d_roi_align': (I, [P, P, P, P, P, P, P, I, I, I, I, F, I, P, I, P]),
     'mv2d_box_correlation': (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, F, F, F, I, P]),
     'mv2d_csr_workspace_bytes': (LL, [I, I, I, I]),

@@ -68,6 +68,21 @@ __global__ void box_params_kernel(const float* __restrict__ rois, const double* 
     for (int i = 0; i < 16; ++i) minv[r * 16 + i] = ok ? (float)Li[i] : __builtin_nanf("");
 }
 
+// inverse(K_roi @ E^T).float() for arbitrary per-RoI fp64 matrices (module-level QueryGenerator.center2lidar)
+__global__ void lidar2img_inverse_kernel(const double* __restrict__ K_roi, const double* __restrict__ E, float* __restrict__ minv, int R) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    double L[16], Li[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; ++k) acc = acc + K_roi[r * 16 + i * 4 + k] * E[r * 16 + j * 4 + k];
+            L[i * 4 + j] = acc;
+        }
+    bool ok = inverse4x4(L, Li);
+    for (int i = 0; i < 16; ++i) minv[r * 16 + i] = ok ? (float)Li[i] : __builtin_nanf("");
+}
+
 // ------------------------------------------------------------------------------------------------
 // a7/a8/a13: center2lidar mat-vec, pc_range normalisation (no clamp — RH/mv2d_t_head.py:51-57),
 //            pos2posemb3d (MU/pe.py:21-33): one wave per RoI, lanes over the 384 sine channels
@@ -99,6 +114,23 @@ __global__ __launch_bounds__(256) void refpoint_posemb_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         const int ch = lane + 64 * j;           // 0..383
+        const int axis = ch >> 7, i = ch & 127;
+        const float pos = axis == 0 ? py : (axis == 1 ? px : pz);
+        const float a = pos / dim_t[i];
+        posemb[(long long)r * 384 + ch] = (i & 1) ? cosf(a) : sinf(a);
+    }
+}
+
+// pos2posemb3d alone (MU/pe.py:21-33) for the module-level CrossAttentionBoxHead.position_embedding
+__global__ __launch_bounds__(256) void posemb3d_kernel(const float* __restrict__ ref, const float* __restrict__ dim_t, float* __restrict__ posemb, int R) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int lane = threadIdx.x & 63;
+    const float two_pi = 6.283185307179586f;
+    const float py = ref[r * 3 + 1] * two_pi, px = ref[r * 3 + 0] * two_pi, pz = ref[r * 3 + 2] * two_pi;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int ch = lane + 64 * j;
         const int axis = ch >> 7, i = ch & 127;
         const float pos = axis == 0 ? py : (axis == 1 ? px : pz);
         const float a = pos / dim_t[i];
@@ -591,6 +623,22 @@ extern "C" int mv2d_refpoint_posemb(const float* center_pred, int ld_cp, const f
     hipLaunchKernelGGL(refpoint_posemb_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, center_pred, ld_cp, minv, dim_t,
                        xyz, ref, posemb, R, pc_range[0], pc_range[1], pc_range[2], pc_range[3] - pc_range[0],
                        pc_range[4] - pc_range[1], pc_range[5] - pc_range[2]);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_lidar2img_inverse(const double* K_roi, const double* E, float* minv, int R, void* stream) {
+    MV2D_CHECK_ARG(K_roi && E && minv, "mv2d_lidar2img_inverse: bad args");
+    if (R == 0) return MV2D_OK;
+    hipLaunchKernelGGL(lidar2img_inverse_kernel, dim3(cdiv(R, 64)), dim3(64), 0, (hipStream_t)stream, K_roi, E, minv, R);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_posemb3d(const float* ref, const float* dim_t, float* posemb, int R, void* stream) {
+    MV2D_CHECK_ARG(ref && dim_t && posemb, "mv2d_posemb3d: bad args");
+    if (R == 0) return MV2D_OK;
+    hipLaunchKernelGGL(posemb3d_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, ref, dim_t, posemb, R);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

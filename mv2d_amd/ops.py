@@ -163,6 +163,24 @@ def refpoint_posemb(center_pred, ld_cp, minv, dim_t, xyz, ref, posemb, R, pc_ran
                                            pc_range_host.data_ptr(), _stream()), 'mv2d_refpoint_posemb')
 
 
+def lidar2img_inverse(K_roi, E, out=None):
+    _req(K_roi, torch.float64, 'K_roi'); _req(E, torch.float64, 'E')
+    R = K_roi.shape[0]
+    if out is None:
+        out = torch.empty((R, 16), device=K_roi.device, dtype=torch.float32)
+    check(_lib.load().mv2d_lidar2img_inverse(_p(K_roi), _p(E), _p(out), R, _stream()), 'mv2d_lidar2img_inverse')
+    return out
+
+
+def posemb3d(ref, dim_t, out=None):
+    _req(ref, torch.float32, 'ref')
+    R = ref.shape[0]
+    if out is None:
+        out = torch.empty((R, 384), device=ref.device, dtype=torch.float32)
+    check(_lib.load().mv2d_posemb3d(_p(ref), _p(dim_t), _p(out), R, _stream()), 'mv2d_posemb3d')
+    return out
+
+
 def roi_align(map0, rois, H, W, *, map1=None, out0=None, out1=None, out0_f32=None, out1_f32=None, spatial_scale=1.0 / 16,
               sampling_ratio=-1, map1_index=None, out1_is_sum=False, R=None):
     _req(map0, torch.float32, 'map0'); _req(map1, torch.float32, 'map1'); _req(rois, torch.float32, 'rois')

@@ -1,0 +1,221 @@
+"""MV2DHead / MV2DSHead / MV2DTHead / CrossAttentionBoxHead — the reference's RoI-head registry surface
+(RH/mv2d_head.py, RH/mv2d_s_head.py, RH/mv2d_t_head.py, RH/bbox_heads/cross_attention_head.py) on MI355X.
+
+``simple_test(x, proposal_list, img_metas, rescale=False)`` keeps the reference signature and return value
+(``[[boxes, scores, labels]]``) and runs the fused HIP engine (mv2d_amd.engine.HeadEngine), which is built lazily
+from the module's own ``state_dict`` — so a checkpoint loaded with the reference key layout is what runs.
+Training entry points (forward_train, losses, denoising queries) are outside this tier's scope and raise.
+"""
+import copy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import calib, ops
+from ..engine import HeadEngine
+from ..registry import HEADS, build_bbox_coder, build_head, build_loss, build_roi_extractor, build_transformer
+from .modules import BoxCorrelation, PE, QueryGenerator, _f, _rows
+
+C = 256
+
+
+@HEADS.register_module()
+class CrossAttentionBoxHead(nn.Module):
+    """RH/bbox_heads/cross_attention_head.py:86-242,357-377 (forward + get_bboxes)."""
+
+    def __init__(self, num_classes, transformer, pc_range, embed_dims=256, num_reg_fcs=2, group_reg_dims=(2, 2, 1, 1, 2, 2),
+                 use_reg_layer=False, pre_embed=False,
+                 loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0),
+                 loss_bbox=dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0),
+                 bbox_coder=dict(type='NMSFreeCoder', post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
+                                 pc_range=[-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], max_num=100, num_classes=10),
+                 sync_cls_avg_factor=False, train_cfg=None, test_cfg=None, **kwargs):
+        super().__init__()
+        assert not use_reg_layer and not pre_embed and embed_dims == C and num_reg_fcs == 2 and num_classes == 10, \
+            'kernel path implements the shipped head configuration'
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_bbox = build_loss(loss_bbox)
+        self.transformer = build_transformer(transformer)
+        self.pc_range, self.embed_dims, self.pre_embed = pc_range, embed_dims, pre_embed
+        self.query_embedding = nn.Sequential(nn.Linear(embed_dims * 3 // 2, embed_dims), nn.ReLU(), nn.Linear(embed_dims, embed_dims))
+        self.num_pred = transformer['decoder']['num_layers']
+        self.num_classes = self.cls_out_channels = num_classes
+        cls_branch = []
+        for _ in range(num_reg_fcs):
+            cls_branch += [nn.Linear(embed_dims, embed_dims), nn.LayerNorm(embed_dims), nn.ReLU(inplace=True)]
+        cls_branch.append(nn.Linear(embed_dims, num_classes))
+        reg_branch = []
+        for _ in range(num_reg_fcs):
+            reg_branch += [nn.Linear(embed_dims, embed_dims), nn.ReLU()]
+        reg_branch.append(nn.Linear(embed_dims, sum(group_reg_dims)))
+        self.cls_branches = nn.ModuleList([copy.deepcopy(nn.Sequential(*cls_branch)) for _ in range(self.num_pred)])
+        self.reg_branches = nn.ModuleList([copy.deepcopy(nn.Sequential(*reg_branch)) for _ in range(self.num_pred)])
+        self.bbox_coder = build_bbox_coder(bbox_coder)
+        self.code_size = kwargs.get('code_size', 10)
+        cw = kwargs.get('code_weights', [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2])[:self.code_size]
+        self.code_weights = nn.Parameter(torch.tensor(cw, requires_grad=False), requires_grad=False)
+        self.sync_cls_avg_factor, self.train_cfg, self.test_cfg = sync_cls_avg_factor, train_cfg, test_cfg
+        self.bg_cls_weight = 0
+        self.fp16_enabled = False
+
+    def init_weights(self):
+        self.transformer.init_weights()
+        for m in self.cls_branches:
+            nn.init.constant_(m[-1].bias, float(-np.log((1 - 0.01) / 0.01)))
+
+    def position_embedding(self, query_pos):
+        shp = query_pos.shape[:-1]
+        ct = calib.constant_tables()
+        pe = ops.posemb3d(query_pos.reshape(-1, 3).float().contiguous(), ct['dim_t'].to(query_pos.device))
+        q0, q2 = self.query_embedding[0], self.query_embedding[2]
+        h = ops.gemm_f32(pe, _f(q0.weight), _f(q0.bias), act=1)
+        return ops.gemm_f32(h, _f(q2.weight), _f(q2.bias)).view(*shp, C)
+
+    def forward(self, reference_points, x, masks, pos_embed, attn_mask=None, cross_attn_mask=None, force_fp32=False,
+                query_embeds=None, return_query_feats=False, **kwargs):
+        """reference_points [bs,Q,3], x / pos_embed [bs,n,c,h,w], masks [bs,n,h,w] -> (all_cls_scores, all_bbox_preds) [L,bs,Q,10].
+        Stray kwargs (e.g. ``pe=(module, x, metas)`` of RH/mv2d_head.py:172) are accepted and ignored like in the reference."""
+        assert not self.training, 'inference kernels only (SURVEY.md §8 f3)'
+        if not self.pre_embed:
+            query_embeds = self.position_embedding(reference_points)
+        outs_dec, _ = self.transformer(x.float(), masks, query_embeds.float(), pos_embed.float(), attn_mask=attn_mask,
+                                       cross_attn_mask=cross_attn_mask)
+        L, bs, Q, _ = outs_dec.shape
+        M = bs * Q
+        dev = outs_dec.device
+        od = outs_dec.reshape(L, M, C).float().contiguous()
+        st = lambda idx, attr: torch.stack([_f(getattr(br[idx], attr)) for br in self._cur]).contiguous()
+        gk = dict(groups=L, a_gs=M * C, c_gs=M * C)
+        self._cur = self.cls_branches
+        h1 = ops.gemm_f32(od, st(0, 'weight'), st(0, 'bias'), M=M, lda=C, ldc=C, **gk)
+        h2 = ops.row_ln(h1.view(L * M, C), ln=(st(1, 'weight'), st(1, 'bias')), relu=True, rows_per_group=M).view(L, M, C)
+        h1 = ops.gemm_f32(h2, st(3, 'weight'), st(3, 'bias'), M=M, lda=C, ldc=C, **gk)
+        h2 = ops.row_ln(h1.view(L * M, C), ln=(st(4, 'weight'), st(4, 'bias')), relu=True, rows_per_group=M).view(L, M, C)
+        cls = torch.empty((L, M, 10), device=dev)
+        ops.gemm_f32(h2, st(6, 'weight'), st(6, 'bias'), out=cls, M=M, lda=C, ldc=10, groups=L, a_gs=M * C, c_gs=M * 10)
+        self._cur = self.reg_branches
+        r1 = ops.gemm_f32(od, st(0, 'weight'), st(0, 'bias'), act=1, M=M, lda=C, ldc=C, **gk)
+        r2 = ops.gemm_f32(r1, st(2, 'weight'), st(2, 'bias'), act=1, M=M, lda=C, ldc=C, **gk)
+        reg = torch.empty((L, M, 10), device=dev)
+        ops.gemm_f32(r2, st(4, 'weight'), st(4, 'bias'), out=reg, M=M, lda=C, ldc=10, groups=L, a_gs=M * C, c_gs=M * 10)
+        del self._cur
+        ops.finalize_reg(reg, reference_points.reshape(M, 3).float().contiguous(), L, M, torch.tensor(self.pc_range, dtype=torch.float32), 0.0)
+        all_cls_scores, all_bbox_preds = cls.view(L, bs, Q, 10), reg.view(L, bs, Q, 10)
+        if return_query_feats:
+            return all_cls_scores, all_bbox_preds, outs_dec[-1]
+        return all_cls_scores, all_bbox_preds
+
+    def get_bboxes(self, preds_dicts, img_metas, rescale=False):
+        preds = self.bbox_coder.decode(preds_dicts)
+        ret = []
+        for i, p in enumerate(preds):
+            bboxes = p['bboxes']
+            bboxes[:, 2] = bboxes[:, 2] - bboxes[:, 5] * 0.5
+            box_type = img_metas[i].get('box_type_3d') if isinstance(img_metas[i], dict) else None
+            if box_type is not None:
+                bboxes = box_type(bboxes, bboxes.size(-1))
+            ret.append([bboxes, p['scores'], p['labels']])
+        return ret
+
+    def loss(self, *a, **k):
+        raise NotImplementedError('training losses are outside the hot-path scope (SURVEY.md §8 f3)')
+
+
+@HEADS.register_module()
+class MV2DHead(nn.Module):
+    """RH/mv2d_head.py:18-267 (base RoI head: T-path forward with use_denoise never set)."""
+
+    KIND = 'T'
+
+    def __init__(self, bbox_roi_extractor, bbox_head, query_generator, pe, box_correlation, pc_range, intrins_feat_scale=0.1,
+                 feat_lvl=0, force_fp32=False, train_cfg=None, test_cfg=None, **kwargs):
+        super().__init__()
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.bbox_roi_extractor = build_roi_extractor(bbox_roi_extractor)
+        bbox_head = dict(bbox_head)
+        bbox_head.update(dict(train_cfg=train_cfg, test_cfg=test_cfg))
+        self.bbox_head = build_head(bbox_head)
+        self.roi_size = bbox_roi_extractor['roi_layer']['output_size']
+        if isinstance(self.roi_size, int):
+            self.roi_size = [self.roi_size, self.roi_size]
+        query_generator = dict(query_generator)
+        query_generator.update(dict(loss_cls=self.bbox_head.loss_cls))
+        self.query_generator = QueryGenerator(**query_generator)
+        self.position_encoding = PE(**pe)
+        self.box_corr_module = BoxCorrelation(**box_correlation)
+        self.pc_range, self.intrins_feat_scale, self.feat_lvl, self.force_fp32 = pc_range, intrins_feat_scale, feat_lvl, force_fp32
+        self.stage_loss_weights = train_cfg.get('stage_loss_weights') if train_cfg else None
+        self._engine, self._engine_ver = None, None
+
+    with_bbox = True
+
+    @property
+    def strides(self):
+        return self.position_encoding.strides
+
+    @property
+    def num_classes(self):
+        return self.bbox_head.num_classes
+
+    # ---- engine plumbing ------------------------------------------------------------------------------
+    def _engine_num_views(self, img_metas):
+        return len(img_metas)
+
+    def engine(self, device, img_metas):
+        ver = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(device), self._engine_num_views(img_metas))
+        if self._engine is None or self._engine_ver != ver:
+            sd = {k: v for k, v in self.state_dict().items()}
+            bc = self.box_corr_module
+            coder = self.bbox_head.bbox_coder
+            self._engine = HeadEngine(sd, self.KIND, device, num_views=self._engine_num_views(img_metas), topk=bc.topk,
+                                      expand_stride=bc.expand_stride, num_layers=self.bbox_head.num_pred, max_num=coder.max_num,
+                                      pc_range=tuple(self.pc_range), post_range=tuple(coder.post_center_range),
+                                      depth_num=self.position_encoding.depth_num, stride=self.strides[self.feat_lvl],
+                                      iou_thr=bc.iou_thr, ratio=bc.ratio)
+            self._engine_ver = ver
+        return self._engine
+
+    def simple_test(self, x, proposal_list, img_metas, rescale=False):
+        """x: list with the stride-16 map [V,256,h,w]; proposal_list: V x [n,6]; img_metas: V dicts -> [[boxes, scores, labels]]."""
+        assert len(img_metas) // img_metas[0]['num_views'] == 1
+        feat = x[self.feat_lvl]
+        eng = self.engine(feat.device, img_metas)
+        out = eng.run(feat.float(), proposal_list, img_metas)
+        boxes, scores, labels = eng.results(out)
+        boxes = boxes.clone()
+        box_type = img_metas[0].get('box_type_3d')
+        if box_type is not None:
+            boxes = box_type(boxes, boxes.size(-1))
+        return [[boxes, scores.clone(), labels.clone()]]
+
+    def forward_train(self, *a, **k):
+        raise NotImplementedError('training (denoising queries, Hungarian loss) is outside the hot-path scope (SURVEY.md §8 f3)')
+
+
+@HEADS.register_module()
+class MV2DSHead(MV2DHead):
+    """RH/mv2d_s_head.py:18-305 (eval branch :181-192: RoI-gather cross attention)."""
+
+    KIND = 'S'
+
+    def __init__(self, use_denoise=False, neg_bbox_loss=False, denoise_scalar=10, denoise_noise_scale=1.0, denoise_noise_trans=0.0,
+                 denoise_weight=1.0, denoise_split=0.75, **kwargs):
+        super().__init__(**kwargs)
+        self.use_denoise, self.neg_bbox_loss, self.denoise_scalar = use_denoise, neg_bbox_loss, denoise_scalar
+        self.denoise_noise_scale, self.denoise_noise_trans = denoise_noise_scale, denoise_noise_trans
+        self.denoise_weight, self.denoise_split = denoise_weight, denoise_split
+
+
+@HEADS.register_module()
+class MV2DTHead(MV2DSHead):
+    """RH/mv2d_t_head.py:18-142 (masked-map cross attention, velocity / dt for two-frame input)."""
+
+    KIND = 'T'
+
+    def __init__(self, num_views=6, **kwargs):
+        super().__init__(**kwargs)
+        self.num_views = num_views
+
+    def _engine_num_views(self, img_metas):
+        return self.num_views

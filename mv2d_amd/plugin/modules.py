@@ -1,0 +1,628 @@
+"""Host-side mirror of the reference's transformer / attention / PE / query-generator modules.
+
+Same registry type strings, constructor arguments, ``forward`` signatures and ``state_dict`` key layout as the
+reference classes (cited per class), but every ``forward`` runs the hand-written gfx950 kernels through the C-ABI
+(mv2d_amd.ops).  torch.nn layers appear only as PARAMETER CONTAINERS (so released checkpoints load by key); no
+torch compute op is on the product path and there is no CPU fallback: inputs must be on the GPU.
+
+The fused whole-frame path lives in mv2d_amd.engine.HeadEngine (used by the heads' ``simple_test``); the modules here
+give the same kernels at module granularity so that the classes drop into other decoders through the registries.
+"""
+import copy
+import math
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import calib, ops
+from ..registry import (ATTENTION, BBOX_CODERS, FEEDFORWARD_NETWORK, HEADS, LOSSES, POSITIONAL_ENCODING, ROI_EXTRACTORS,
+                        TRANSFORMER, TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE, build_attention,
+                        build_positional_encoding, build_transformer_layer_sequence)
+
+BF16 = torch.bfloat16
+C = 256
+
+
+def _f(t):
+    return t.detach().float().contiguous()
+
+
+def _rows(x):
+    """[n, b, c] -> contiguous [n*b, c] fp32 view/copy."""
+    return x.reshape(-1, x.shape[-1]).float().contiguous()
+
+
+class _Bf16Cache:
+    """bf16 copies of fp32 parameters for the MFMA GEMMs, refreshed when the parameter is modified in place."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, name, tensor):
+        ver = (tensor.data_ptr(), tensor._version)
+        hit = self._c.get(name)
+        if hit is None or hit[0] != ver:
+            hit = (ver, ops.f32_to_bf16(_f(tensor)))
+            self._c[name] = hit
+        return hit[1]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# losses / roi extractor: third-party type strings that must resolve inside the reference config subtree
+# ---------------------------------------------------------------------------------------------------------------
+class _LossStub(nn.Module):
+    """FocalLoss / L1Loss placeholders (CFG-T:91-98): the inference hot path only reads ``use_sigmoid``."""
+
+    def __init__(self, use_sigmoid=False, **kwargs):
+        super().__init__()
+        self.use_sigmoid = use_sigmoid
+        self.cfg = kwargs
+
+    def forward(self, *a, **k):
+        raise NotImplementedError('training losses are outside the hot-path scope (SURVEY.md §8 f3)')
+
+
+for _n in ('FocalLoss', 'L1Loss', 'CrossEntropyLoss', 'SmoothL1Loss'):
+    LOSSES.register_module(name=_n, module=_LossStub, force=True)
+
+
+@ROI_EXTRACTORS.register_module()
+class SingleRoIExtractor(nn.Module):
+    """mmdet SingleRoIExtractor + mmcv RoIAlign, single stride (CFG-T:49-53; call site RH/mv2d_head.py:114-115)."""
+
+    def __init__(self, roi_layer, out_channels, featmap_strides, **kwargs):
+        super().__init__()
+        assert roi_layer['type'] == 'RoIAlign' and len(featmap_strides) == 1
+        self.output_size = roi_layer['output_size']
+        self.sampling_ratio = roi_layer.get('sampling_ratio', 0)
+        self.featmap_strides = featmap_strides
+        self.out_channels = out_channels
+        assert self.output_size == 7, 'the gfx950 RoIAlign kernel is specialised for 7x7 bins'
+
+    @property
+    def num_inputs(self):
+        return len(self.featmap_strides)
+
+    def forward(self, feats, rois):
+        x = feats[0]
+        V, Cn, h, w = x.shape
+        assert Cn % C == 0 and Cn // C in (1, 2)
+        R = rois.shape[0]
+        rois = rois.float().contiguous()
+        maps = [ops.nchw_to_nhwc(x[:, i * C:(i + 1) * C].float().contiguous()) for i in range(Cn // C)]
+        outs = [torch.empty((R, 49, C), device=x.device, dtype=torch.float32) for _ in maps]
+        ops.roi_align(maps[0], rois, h, w, map1=maps[1] if len(maps) > 1 else None, out0_f32=outs[0],
+                      out1_f32=outs[1] if len(maps) > 1 else None, spatial_scale=1.0 / self.featmap_strides[0],
+                      sampling_ratio=self.sampling_ratio)
+        return torch.cat([o.view(R, 7, 7, C).permute(0, 3, 1, 2) for o in outs], 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# positional encodings
+# ---------------------------------------------------------------------------------------------------------------
+@POSITIONAL_ENCODING.register_module()
+class SinePositionalEncoding3D(nn.Module):
+    """MU/positional_encoding.py:14-96.  Parameter-free; the engine/PE module evaluate it inside mv2d_pe_inputs from
+    the host-computed normalised cumsum embeds (mv2d_amd.calib.frame_tables)."""
+
+    def __init__(self, num_feats, temperature=10000, normalize=False, scale=2 * math.pi, eps=1e-6, offset=0.0, init_cfg=None):
+        super().__init__()
+        self.num_feats, self.temperature, self.normalize = num_feats, temperature, normalize
+        self.scale, self.eps, self.offset = scale, eps, offset
+        assert normalize and num_feats == 128 and offset == 0.0, 'kernel path implements the shipped config (128, normalize)'
+
+
+@POSITIONAL_ENCODING.register_module()
+class LearnedPositionalEncoding3D(nn.Module):
+    """MU/positional_encoding.py:109-155 — unused by every shipped config; constructible for completeness only."""
+
+    def __init__(self, num_feats, row_num_embed=50, col_num_embed=50, init_cfg=None):
+        super().__init__()
+        self.row_embed = nn.Embedding(row_num_embed, num_feats)
+        self.col_embed = nn.Embedding(col_num_embed, num_feats)
+
+    def forward(self, mask):
+        raise NotImplementedError('LearnedPositionalEncoding3D is not used by the MV2D configs (SURVEY.md §2 #7)')
+
+
+class SELayer(nn.Module):
+    """MU/pe.py:36-48 parameter container (fpe.conv_reduce / fpe.conv_expand)."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.conv_reduce = nn.Conv2d(channels, channels, 1, bias=True)
+        self.conv_expand = nn.Conv2d(channels, channels, 1, bias=True)
+
+
+class PE(nn.Module):
+    """MU/pe.py:50-169: 3-D position-aware key embedding.  ``forward`` returns the embedding of the WHOLE map like the
+    reference; the fused engine evaluates it only at the key positions it needs."""
+
+    def __init__(self, positional_encoding, strides, position_range, depth_num, depth_start=1, LID=True, embed_dims=256,
+                 with_fpe=False, adapt_pos3d=True, no_sin_enc=False):
+        super().__init__()
+        assert LID and with_fpe and adapt_pos3d and not no_sin_enc and embed_dims == C, 'kernel path implements the shipped config'
+        self.strides, self.position_range, self.depth_num, self.depth_start = strides, position_range, depth_num, depth_start
+        self.embed_dims, self.with_fpe = embed_dims, with_fpe
+        self.position_encoder = nn.Sequential(nn.Conv2d(3 * depth_num, 4 * C, 1), nn.ReLU(), nn.Conv2d(4 * C, C, 1))
+        self.adapt_pos3d = nn.Sequential(nn.Conv2d(C * 3 // 2, 4 * C, 1), nn.ReLU(), nn.Conv2d(4 * C, C, 1))
+        self.positional_encoding = build_positional_encoding(positional_encoding)
+        self.fpe = SELayer(C)
+        self._b = _Bf16Cache()
+
+    def forward(self, mlvl_feats, img_metas):
+        assert len(mlvl_feats) == len(self.strides) == 1
+        x = mlvl_feats[0]
+        V, _, h, w = x.shape
+        P = V * h * w
+        dev = x.device
+        ft = calib.frame_tables(img_metas, h, w, stride=self.strides[0], depth_num=self.depth_num, depth_start=self.depth_start,
+                                position_range=tuple(self.position_range))
+        ct = calib.constant_tables()
+        s2pos = torch.arange(P, dtype=torch.int32, device=dev)
+        S_dev = torch.tensor([P], dtype=torch.int32, device=dev)
+        fcl = ops.nchw_to_nhwc(x.float().contiguous())
+        e = lambda n, dt=BF16: torch.empty((P, n), device=dev, dtype=dt)
+        A1, A2, Xb, Xf = e(3 * self.depth_num), e(384), e(C), e(C, torch.float32)
+        ops.pe_inputs(s2pos, S_dev, P, fcl, ft['img2lidar'].to(dev), ft['coords_w'].to(dev), ft['coords_h'].to(dev),
+                      ft['coords_d'].to(dev), ft['embeds'].to(dev), ct['dim_t'].to(dev), A1, A2, Xb, Xf, V, h, w, self.depth_num,
+                      torch.tensor(self.position_range, dtype=torch.float64))
+        g = lambda name, mod: (self._b.get(name, mod.weight.flatten(1)), _f(mod.bias))
+        w1a, b1a = g('w1a', self.position_encoder[0]); w1b, b1b = g('w1b', self.position_encoder[2])
+        w2a, b2a = g('w2a', self.adapt_pos3d[0]); w2b, b2b = g('w2b', self.adapt_pos3d[2])
+        wr, br = g('wr', self.fpe.conv_reduce); we, be = g('we', self.fpe.conv_expand)
+        H1 = ops.gemm_bf16(A1, w1a, b1a, act=1)
+        H2 = ops.gemm_bf16(A2, w2a, b2a, act=1)
+        Hg = ops.gemm_bf16(Xb, wr, br, act=1)
+        gate = ops.gemm_bf16(Hg, we, be, act=2, out_dtype=torch.float32)
+        Pg = ops.gemm_bf16(H1, w1b, b1b, mul=gate, out_dtype=torch.float32)
+        pe = ops.gemm_bf16(H2, w2b, b2b, add=Pg, out_dtype=torch.float32)
+        return [pe.view(V, h, w, C).permute(0, 3, 1, 2)]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# transformer bricks
+# ---------------------------------------------------------------------------------------------------------------
+@FEEDFORWARD_NETWORK.register_module()
+class FFN(nn.Module):
+    """mmcv FFN (Linear-ReLU-Dropout-Linear-Dropout + identity); state-dict keys ``layers.0.0.*`` / ``layers.1.*``."""
+
+    def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2, act_cfg=dict(type='ReLU', inplace=True), ffn_drop=0.0,
+                 dropout_layer=None, add_identity=True, init_cfg=None, **kwargs):
+        super().__init__()
+        assert num_fcs == 2 and embed_dims == C
+        self.embed_dims, self.add_identity = embed_dims, add_identity
+        self.layers = nn.Sequential(nn.Sequential(nn.Linear(embed_dims, feedforward_channels), nn.ReLU(inplace=True), nn.Dropout(ffn_drop)),
+                                    nn.Linear(feedforward_channels, embed_dims), nn.Dropout(ffn_drop))
+
+    def forward(self, x, identity=None):
+        shp = x.shape
+        xr = _rows(x)
+        fc1, fc2 = self.layers[0][0], self.layers[1]
+        hdn = ops.gemm_f32(xr, _f(fc1.weight), _f(fc1.bias), act=1)
+        sk = 8 if fc2.weight.shape[1] % 256 == 0 else 1
+        parts = ops.gemm_f32(hdn, _f(fc2.weight), _f(fc2.bias), split_k=sk)
+        if not self.add_identity:
+            return ops.row_ln(parts).view(shp)
+        res = xr if identity is None else _rows(identity)
+        return ops.row_ln(parts, residual=res).view(shp)
+
+
+class _AttnBase(nn.Module):
+    def __init__(self, embed_dims, num_heads, attn_drop=0.0, proj_drop=0.0, dropout_layer=dict(type='Dropout', drop_prob=0.0),
+                 init_cfg=None, batch_first=False, **kwargs):
+        super().__init__()
+        if 'dropout' in kwargs:
+            warnings.warn('The arguments `dropout` in MultiheadAttention has been deprecated', DeprecationWarning)
+            attn_drop = kwargs.pop('dropout')
+        assert embed_dims == C and num_heads == 8, 'kernels are specialised for 256 channels, 8 heads x 32'
+        self.embed_dims, self.num_heads, self.batch_first = embed_dims, num_heads, batch_first
+        self.attn = nn.MultiheadAttention(embed_dims, num_heads, attn_drop, **kwargs)       # parameter container only
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.dropout_layer = nn.Dropout(dropout_layer.get('drop_prob', 0.0)) if dropout_layer else nn.Identity()
+        self._b = _Bf16Cache()
+
+    @staticmethod
+    def _default_pos(query, key, query_pos, key_pos, name):
+        if key_pos is None and query_pos is not None:
+            if query_pos.shape == key.shape:
+                key_pos = query_pos
+            else:
+                warnings.warn(f'position encoding of key is missing in {name}.')
+        return key_pos
+
+
+@ATTENTION.register_module()
+class FlattenMHSelfAttention(_AttnBase):
+    """MU/petr_transformer.py:314-370: all n*b queries attend to each other."""
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, attn_mask=None,
+                key_padding_mask=None, **kwargs):
+        assert not self.training, 'inference kernels only (SURVEY.md §8 f3)'
+        key = query if key is None else key
+        value = key if value is None else value
+        identity = query if identity is None else identity
+        key_pos = self._default_pos(query, key, query_pos, key_pos, self.__class__.__name__)
+        if attn_mask is not None or key_padding_mask is not None:
+            raise NotImplementedError('self-attention masks are only used by the denoising TRAINING path (RH/mv2d_s_head.py:39-120)')
+        assert key is query and value is query, 'FlattenMHSelfAttention is called with key = value = query (mmcv BaseTransformerLayer)'
+        shp = query.shape
+        x = _rows(query)
+        xq = x if query_pos is None else _rows(query + query_pos)
+        a = self.attn
+        qkv = ops.gemm_f32(xq, _f(a.in_proj_weight), _f(a.in_proj_bias), A2=x, n_split=2 * C)
+        ctx = ops.self_attn(qkv)
+        o = ops.gemm_f32(ctx, _f(a.out_proj.weight), _f(a.out_proj.bias))
+        return ops.row_ln(o, residual=_rows(identity)).view(shp)
+
+
+@ATTENTION.register_module()
+class PETRMultiheadAttention(_AttnBase):
+    """MU/petr_transformer.py:373-513: cross attention, q = query + query_pos, k = key + key_pos, v = value.
+    Boolean masks follow torch.nn.MultiheadAttention: True = excluded; only the allowed (query,key) pairs are visited."""
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, attn_mask=None,
+                key_padding_mask=None, **kwargs):
+        assert not self.training, 'inference kernels only (SURVEY.md §8 f3)'
+        key = query if key is None else key
+        value = key if value is None else value
+        identity = query if identity is None else identity
+        key_pos = self._default_pos(query, key, query_pos, key_pos, self.__class__.__name__)
+        if self.batch_first:
+            query, key, value = query.transpose(0, 1), key.transpose(0, 1), value.transpose(0, 1)
+            identity = identity.transpose(0, 1)
+            query_pos = None if query_pos is None else query_pos.transpose(0, 1)
+            key_pos = None if key_pos is None else key_pos.transpose(0, 1)
+        nq, bs, _ = query.shape
+        nk = key.shape[0]
+        a = self.attn
+        w_in, b_in = a.in_proj_weight, _f(a.in_proj_bias)
+        xq = _rows(query if query_pos is None else query + query_pos)
+        q = ops.gemm_f32(xq, _f(w_in[:C]), b_in[:C].contiguous(), scale=ops.SCALE_Q)
+        kin = ops.f32_to_bf16(_rows(key if key_pos is None else key + key_pos))
+        vin = ops.f32_to_bf16(_rows(value))
+        Kp = ops.gemm_bf16(kin, self._b.get('wk', w_in[C:2 * C]), b_in[C:2 * C].contiguous())
+        Vp = ops.gemm_bf16(vin, self._b.get('wv', w_in[2 * C:]), b_in[2 * C:].contiguous())
+        # CSR over flattened rows (query row = i*bs + b, key row = k*bs + b)
+        allowed = torch.ones((nq, bs, nk), dtype=torch.bool, device=query.device)
+        if attn_mask is not None:
+            assert attn_mask.dtype == torch.bool and attn_mask.shape == (nq, nk)
+            allowed &= ~attn_mask[:, None, :]
+        if key_padding_mask is not None:
+            allowed &= ~key_padding_mask.to(torch.bool)[None, :, :]
+        nz = allowed.view(nq * bs, nk).nonzero()                                       # sorted by row, then key
+        b_of_row = nz[:, 0] % bs
+        col = (nz[:, 1] * bs + b_of_row).to(torch.int32).contiguous()
+        counts = allowed.view(nq * bs, nk).sum(1)
+        row_ptr = torch.zeros(nq * bs + 1, dtype=torch.int32, device=query.device)
+        row_ptr[1:] = counts.cumsum(0)
+        if col.numel() == 0:
+            col = torch.zeros(1, dtype=torch.int32, device=query.device)
+        ctx = ops.sparse_xattn(q, Kp, Vp, row_ptr, col)
+        o = ops.gemm_f32(ctx, _f(a.out_proj.weight), _f(a.out_proj.bias))
+        out = ops.row_ln(o, residual=_rows(identity)).view(nq, bs, C)
+        return out.transpose(0, 1) if self.batch_first else out
+
+
+@TRANSFORMER_LAYER.register_module()
+class PETRTransformerDecoderLayer(nn.Module):
+    """MU/petr_transformer.py:194-311 over mmcv BaseTransformerLayer (operation_order loop, post-norm residual rules).
+    state-dict keys: attentions.{0,1}.attn.*, ffns.0.layers.*, norms.{0,1,2}.*"""
+
+    def __init__(self, attn_cfgs, feedforward_channels, ffn_dropout=0.0, operation_order=None, act_cfg=dict(type='ReLU', inplace=True),
+                 norm_cfg=dict(type='LN'), ffn_num_fcs=2, with_cp=True, batch_first=False, **kwargs):
+        super().__init__()
+        assert len(operation_order) == 6 and set(operation_order) == {'self_attn', 'norm', 'cross_attn', 'ffn'}
+        assert norm_cfg['type'] == 'LN'
+        n_attn = operation_order.count('self_attn') + operation_order.count('cross_attn')
+        if isinstance(attn_cfgs, dict):
+            attn_cfgs = [copy.deepcopy(attn_cfgs) for _ in range(n_attn)]
+        self.operation_order, self.num_attn, self.use_checkpoint = operation_order, n_attn, with_cp
+        self.pre_norm = operation_order[0] == 'norm'
+        self.attentions = nn.ModuleList()
+        i = 0
+        for op in operation_order:
+            if op in ('self_attn', 'cross_attn'):
+                cfg = dict(attn_cfgs[i]); cfg.setdefault('batch_first', batch_first)
+                att = build_attention(cfg); att.operation_name = op
+                self.attentions.append(att); i += 1
+        self.embed_dims = self.attentions[0].embed_dims
+        self.ffns = nn.ModuleList([FFN(self.embed_dims, feedforward_channels, ffn_num_fcs, act_cfg, ffn_dropout)
+                                   for _ in range(operation_order.count('ffn'))])
+        self.norms = nn.ModuleList([nn.LayerNorm(self.embed_dims) for _ in range(operation_order.count('norm'))])
+
+    def forward(self, query, key=None, value=None, query_pos=None, key_pos=None, attn_masks=None, query_key_padding_mask=None,
+                key_padding_mask=None, **kwargs):
+        ni = ai = fi = 0
+        identity = query
+        if attn_masks is None:
+            attn_masks = [None] * self.num_attn
+        elif isinstance(attn_masks, torch.Tensor):
+            attn_masks = [attn_masks for _ in range(self.num_attn)]
+        assert len(attn_masks) == self.num_attn
+        for op in self.operation_order:
+            if op == 'self_attn':
+                query = self.attentions[ai](query, query, query, identity if self.pre_norm else None, query_pos=query_pos,
+                                            key_pos=query_pos, attn_mask=attn_masks[ai], key_padding_mask=query_key_padding_mask)
+                ai += 1; identity = query
+            elif op == 'norm':
+                n = self.norms[ni]; ni += 1
+                query = ops.row_ln(_rows(query), ln=(_f(n.weight), _f(n.bias)), eps=n.eps).view(query.shape)
+            elif op == 'cross_attn':
+                query = self.attentions[ai](query, key, value, identity if self.pre_norm else None, query_pos=query_pos,
+                                            key_pos=key_pos, attn_mask=attn_masks[ai], key_padding_mask=key_padding_mask)
+                ai += 1; identity = query
+            elif op == 'ffn':
+                query = self.ffns[fi](query, identity if self.pre_norm else None); fi += 1
+        return query
+
+
+@TRANSFORMER_LAYER_SEQUENCE.register_module()
+class PETRTransformerDecoder(nn.Module):
+    """MU/petr_transformer.py:546-593: L layers + ONE post_norm shared by every intermediate output."""
+
+    def __init__(self, transformerlayers=None, num_layers=None, post_norm_cfg=dict(type='LN'), return_intermediate=False, init_cfg=None):
+        super().__init__()
+        if isinstance(transformerlayers, dict):
+            transformerlayers = [copy.deepcopy(transformerlayers) for _ in range(num_layers)]
+        self.num_layers = num_layers
+        self.layers = nn.ModuleList([TRANSFORMER_LAYER.build(c) for c in transformerlayers])
+        self.embed_dims = self.layers[0].embed_dims
+        self.pre_norm = self.layers[0].pre_norm
+        self.return_intermediate = return_intermediate
+        self.post_norm = nn.LayerNorm(self.embed_dims) if post_norm_cfg is not None else None
+
+    def _pn(self, x):
+        if self.post_norm is None:
+            return x
+        return ops.row_ln(_rows(x), ln=(_f(self.post_norm.weight), _f(self.post_norm.bias)), eps=self.post_norm.eps).view(x.shape)
+
+    def forward(self, query, *args, **kwargs):
+        inter = []
+        for layer in self.layers:
+            query = layer(query, *args, **kwargs)
+            if self.return_intermediate:
+                inter.append(self._pn(query))
+        if not self.return_intermediate:
+            return self._pn(query)[None]
+        return torch.stack(inter)
+
+
+@TRANSFORMER_LAYER_SEQUENCE.register_module()
+class PETRTransformerEncoder(nn.Module):
+    """MU/petr_transformer.py:516-543 — not instantiated by any MV2D config (encoder=None); registered so the type resolves."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError('PETRTransformerEncoder is unused by the MV2D configs (SURVEY.md §2 #9)')
+
+
+@TRANSFORMER.register_module()
+class PETRTransformer(nn.Module):
+    """MU/petr_transformer.py:36-113."""
+
+    def __init__(self, encoder=None, decoder=None, init_cfg=None, cross=False):
+        super().__init__()
+        assert encoder is None, 'MV2D configs use decoder-only transformers'
+        self.encoder = None
+        self.decoder = build_transformer_layer_sequence(decoder)
+        self.embed_dims = self.decoder.embed_dims
+        self.cross = cross
+
+    def init_weights(self):
+        for m in self.modules():
+            if hasattr(m, 'weight') and m.weight is not None and m.weight.dim() > 1:
+                nn.init.xavier_uniform_(m.weight)
+
+    def forward(self, x, mask, query_embed, pos_embed, reg_branch=None):
+        bs, n, c, h, w = x.shape
+        memory = x.permute(1, 3, 4, 0, 2).reshape(-1, bs, c)
+        pos_embed = pos_embed.permute(1, 3, 4, 0, 2).reshape(-1, bs, c)
+        query_embed = query_embed.unsqueeze(1).repeat(1, bs, 1)
+        mask = mask.view(bs, -1)
+        target = torch.zeros_like(query_embed)
+        out_dec = self.decoder(query=target, key=memory, value=memory, key_pos=pos_embed, query_pos=query_embed, key_padding_mask=mask)
+        return out_dec.transpose(1, 2), memory.reshape(n, h, w, bs, c).permute(3, 0, 4, 1, 2)
+
+
+@TRANSFORMER.register_module()
+class PETRDNTransformer(PETRTransformer):
+    """MU/petr_transformer.py:116-190 (denoising variant, training only) — registered so the type string resolves."""
+
+    def forward(self, *a, **k):
+        raise NotImplementedError('PETRDNTransformer is not used by the MV2D configs')
+
+
+@TRANSFORMER.register_module()
+class MV2DTransformer(PETRTransformer):
+    """RH/bbox_heads/cross_attention_head.py:22-49."""
+
+    def forward(self, x, mask, query_embed, pos_embed, attn_mask=None, cross_attn_mask=None, **kwargs):
+        bs, n, c, h, w = x.shape
+        memory = x.permute(1, 3, 4, 0, 2).reshape(n * h * w, bs, c)
+        mask = mask.view(bs, n * h * w)
+        query_embed = query_embed.permute(1, 0, 2)
+        pos_embed = pos_embed.permute(1, 3, 4, 0, 2).reshape(n * h * w, bs, c)
+        target = torch.zeros_like(query_embed)
+        if cross_attn_mask is not None:
+            cross_attn_mask = cross_attn_mask.flatten(1, 3)
+        out_dec = self.decoder(query=target, key=memory, value=memory, key_pos=pos_embed, query_pos=query_embed,
+                               key_padding_mask=mask, attn_masks=[attn_mask, cross_attn_mask])
+        return out_dec.transpose(1, 2), memory.reshape(n, h, w, bs, c).permute(3, 0, 4, 1, 2)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bbox coder
+# ---------------------------------------------------------------------------------------------------------------
+@BBOX_CODERS.register_module()
+class NMSFreeCoder:
+    """CB/coders/nms_free_coder.py:17-123 (decode only)."""
+
+    def __init__(self, pc_range, post_center_range=None, max_num=100, score_threshold=None, num_classes=10):
+        self.pc_range, self.post_center_range, self.max_num = pc_range, post_center_range, max_num
+        self.score_threshold, self.num_classes = score_threshold, num_classes
+        assert score_threshold is None, 'shipped configs use score_threshold=None'
+        assert post_center_range is not None, 'Need to reorganize output as a batch, only support post_center_range is not None for now!'
+
+    def encode(self):
+        pass
+
+    def decode_single(self, cls_scores, bbox_preds, sigmoid_cls=False):
+        assert not sigmoid_cls
+        dev = cls_scores.device
+        R = cls_scores.shape[0]
+        K = self.max_num
+        boxes = torch.zeros((K, 9), device=dev); scores = torch.zeros(K, device=dev)
+        labels = torch.zeros(K, dtype=torch.int64, device=dev); bidx = torch.zeros(K, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.decode_topk(cls_scores.float().contiguous(), bbox_preds.float().contiguous(), R, self.num_classes, K,
+                        torch.tensor(self.post_center_range, dtype=torch.float32), boxes, scores, labels, bidx, cnt)
+        n = int(cnt.item())
+        # NOTE: mv2d_decode_topk already applies cross_attention_head.py:372 (z -= h/2); undo it here so that
+        # CrossAttentionBoxHead.get_bboxes can apply it exactly like the reference does.
+        b = boxes[:n].clone()
+        b[:, 2] = b[:, 2] + b[:, 5] * 0.5
+        return {'bboxes': b, 'scores': scores[:n], 'labels': labels[:n], 'bbox_index': bidx[:n]}
+
+    def decode(self, preds_dicts, sigmoid_cls=False):
+        cls_scores, bbox_preds = preds_dicts['cls_scores'], preds_dicts['bbox_preds']
+        return [self.decode_single(cls_scores[i], bbox_preds[i], sigmoid_cls=sigmoid_cls) for i in range(len(cls_scores))]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# box correlation (plain class constructed by kwargs, RH/mv2d_head.py:42)
+# ---------------------------------------------------------------------------------------------------------------
+class BoxCorrelation(nn.Module):
+    """RH/utils/box_correlation.py:11-398 ('topk_matched:k:thr:ratio' mode).  Returns the same tensors as the reference
+    (boolean feature masks for the T path, padded id lists for the S path) built from the device-side match lists."""
+
+    def __init__(self, sample_size=4, num_depth=8, depth_start=0.5, depth_end=70, correlation_mode=None, LID=True, expand_stride=0,
+                 force_cpu=False):
+        super().__init__()
+        assert LID and correlation_mode is not None and correlation_mode.startswith('topk_matched'), \
+            'kernel path implements the shipped topk_matched modes'
+        info = correlation_mode.split(':')
+        self.topk, self.iou_thr, self.ratio = int(info[1]), float(info[2]), float(info[3])
+        self.sample_size, self.num_depth, self.depth_start, self.depth_end = sample_size, num_depth, depth_start, depth_end
+        self.correlation_mode, self.expand_stride = correlation_mode, expand_stride
+
+    def _match(self, rois, num_proposals_per_img, img_metas):
+        dev = rois.device
+        V = len(img_metas)
+        R = rois.shape[0]
+        l2i = torch.from_numpy(np.stack([np.asarray(m['lidar2img'], dtype=np.float64) for m in img_metas]))
+        trans = torch.matmul(l2i[None], torch.inverse(l2i)[:, None]).reshape(V, V, 16).contiguous().to(dev)
+        ct = calib.constant_tables(self.sample_size, self.num_depth, self.depth_start, self.depth_end)
+        vs = torch.tensor(np.concatenate([[0], np.cumsum(num_proposals_per_img)]), dtype=torch.int32, device=dev)
+        match = torch.empty((R, V, self.topk), dtype=torch.int32, device=dev)
+        pad_h, pad_w, _ = img_metas[0]['pad_shape']
+        ops.box_correlation(rois.float().contiguous(), vs, trans, ct['lin'].to(dev), ct['depths'].to(dev), match, V, self.topk,
+                            int(pad_h), int(pad_w), max(num_proposals_per_img), self.sample_size, self.num_depth,
+                            self.depth_start, self.iou_thr, self.ratio)
+        return match
+
+    @torch.no_grad()
+    def gen_box_roi_correlation(self, rois, num_proposals_per_img, img_metas):
+        if rois.numel() == 0:
+            return rois.new_zeros((0, 0), dtype=torch.int64), rois.new_zeros((0, 0), dtype=torch.bool)
+        R = rois.shape[0]
+        m = self._match(rois, num_proposals_per_img, img_metas).view(R, -1).to(torch.int64)
+        ids = torch.cat([torch.arange(R, device=rois.device)[:, None], m], 1)
+        valid = ids >= 0
+        order = torch.argsort((~valid).to(torch.int8), dim=1, stable=True)           # valid entries first, order preserved
+        ids, valid = torch.gather(ids, 1, order), torch.gather(valid, 1, order)
+        n_c = int(valid.sum(1).max().item())
+        ids = torch.where(valid, ids, torch.zeros_like(ids))
+        return ids[:, :n_c].contiguous(), valid[:, :n_c].contiguous()
+
+    @torch.no_grad()
+    def gen_box_correlation(self, rois, num_proposals_per_img, img_metas, feat, stride):
+        V, _, h, w = feat.shape
+        R = rois.shape[0]
+        dev = rois.device
+        match = self._match(rois, num_proposals_per_img, img_metas)
+        P = V * h * w
+        z8 = torch.zeros(P, dtype=torch.uint8, device=dev)
+        roi_mask = torch.zeros(P, dtype=torch.uint8, device=dev)
+        rect = torch.empty((R, 5), dtype=torch.int32, device=dev)
+        pos2s = torch.empty(P, dtype=torch.int32, device=dev); s2pos = torch.empty(P, dtype=torch.int32, device=dev)
+        S = torch.zeros(1, dtype=torch.int32, device=dev); nnz = torch.zeros(2, dtype=torch.int32, device=dev)
+        bits = torch.empty(max(ops.csr_workspace_bytes(R, V, h, w) // 4, 1), dtype=torch.int32, device=dev)
+        rc = torch.empty(R, dtype=torch.int32, device=dev); rp = torch.empty(R + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(1, dtype=torch.int32, device=dev)
+        # the per-query bitmask over all P cells IS the reference's feat_in_corr_rois (no padding exclusion here)
+        ops.mask_compact(rois.float().contiguous(), match, z8, roi_mask, rect, pos2s, s2pos, S, bits, rc, rp, col, nnz, R, V, h, w,
+                         self.topk, float(stride), float(self.expand_stride), col_cap=0)
+        nwords = (P + 31) // 32
+        words = bits.view(R, nwords)
+        shifts = torch.arange(32, device=dev, dtype=torch.int32)
+        out = ((words[:, :, None] >> shifts) & 1).to(torch.bool).view(R, nwords * 32)[:, :P]
+        return out.view(R, V, h, w)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# query generator
+# ---------------------------------------------------------------------------------------------------------------
+class _ConvModule(nn.Module):
+    """mmcv ConvModule(conv_cfg=None, norm_cfg=None) container: ``conv`` + ReLU."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, 3, padding=1)
+
+
+@HEADS.register_module()
+class QueryGenerator(nn.Module):
+    """RH/utils/query_generator.py:18-405 in the shipped configuration (1 shared 3x3 conv, avg-pool, 1 shared fc, 2-layer
+    extra encoding of the 16 scaled intrinsics, fc_center only)."""
+
+    def __init__(self, return_cfg=dict(), wich_cp=False, with_avg_pool=True, with_cls=False, with_size=False, with_center=True,
+                 with_heading=False, with_attr=False, attr_dim=2, roi_feat_size=7, in_channels=256, num_classes=10,
+                 reg_class_agnostic=False, reg_predictor_cfg=dict(type='Linear'), cls_predictor_cfg=dict(type='Linear'),
+                 extra_encoding=dict(num_layers=2, feat_channels=[512, 256], features=[dict(type='intrinsic', in_channels=16)]),
+                 num_shared_convs=1, num_shared_fcs=1, conv_out_channels=256, fc_out_channels=1024, loss_cls=None, conv_cfg=None,
+                 norm_cfg=None, init_cfg=None, **kwargs):
+        super().__init__()
+        assert with_center and with_avg_pool and not (with_cls or with_size or with_heading or with_attr)
+        assert num_shared_convs == 1 and num_shared_fcs == 1 and in_channels == C and conv_out_channels == C and roi_feat_size == 7
+        assert all(kwargs.get(k, 0) == 0 for k in kwargs if k.startswith('num_')), 'branch convs/fcs are 0 in the shipped configs'
+        fc = extra_encoding['feat_channels']
+        assert extra_encoding['num_layers'] == 2 and len(extra_encoding['features']) == 1 and extra_encoding['features'][0]['in_channels'] == 16
+        self.return_cfg = return_cfg
+        self.shared_convs = nn.ModuleList([_ConvModule(in_channels, conv_out_channels)])
+        self.shared_fcs = nn.ModuleList([nn.Linear(conv_out_channels, fc_out_channels)])
+        self.extra_enc = nn.Sequential(nn.Linear(fc_out_channels + 16, fc[0]), nn.ReLU(inplace=True), nn.Linear(fc[0], fc[1]), nn.ReLU(inplace=True))
+        self.fc_center = nn.Linear(fc[1], 3)
+        self.fc_out_channels = fc_out_channels
+        self._b = _Bf16Cache()
+
+    def forward(self, x, intrinsics, extrinsics, extra_feats=dict()):
+        """x [R,256,7,7]; intrinsics/extrinsics [R,4,4] fp64 (per-RoI); extra_feats['intrinsic'] [R,16] -> (xyz [R,3], {})."""
+        assert not self.training
+        dev = x.device
+        R = x.shape[0]
+        xcl = ops.f32_to_bf16(x.float().flatten(2).transpose(1, 2).contiguous())           # [R,49,256]
+        conv = self.shared_convs[0].conv
+        wconv = self._b.get('conv', conv.weight.permute(0, 2, 3, 1).reshape(C, 9 * C))
+        co = ops.gemm_bf16(xcl, wconv, _f(conv.bias), conv3x3=True, act=1, out_dtype=torch.float32)
+        K1 = self.fc_out_channels + 16
+        Kp = (K1 + 31) // 32 * 32
+        enc = torch.zeros((R, Kp), device=dev)
+        pooled = torch.empty((R, C), device=dev)
+        ops.avgpool49(co, pooled, C, R)
+        fc = self.shared_fcs[0]
+        ops.gemm_f32(pooled, _f(fc.weight), _f(fc.bias), act=1, clamp=5e3, out=enc, ldc=Kp)
+        enc[:, self.fc_out_channels:K1] = extra_feats['intrinsic'].float().clamp(-5e3, 5e3)
+        e0, e2 = self.extra_enc[0], self.extra_enc[2]
+        w0 = torch.zeros((e0.weight.shape[0], Kp), device=dev)
+        w0[:, :K1] = _f(e0.weight)
+        h1 = ops.gemm_f32(enc, w0, _f(e0.bias), act=1)
+        h2 = ops.gemm_f32(h1, _f(e2.weight), _f(e2.bias), act=1)
+        center = ops.gemm_f32(h2, _f(self.fc_center.weight), _f(self.fc_center.bias))
+        minv = ops.lidar2img_inverse(intrinsics.double().reshape(R, 16).contiguous(), extrinsics.double().reshape(R, 16).contiguous())
+        xyz = torch.empty((R, 3), device=dev); ref = torch.empty((R, 3), device=dev); pos = torch.empty((R, 384), device=dev)
+        ct = calib.constant_tables()
+        ops.refpoint_posemb(center, 3, minv, ct['dim_t'].to(dev), xyz, ref, pos, R, torch.tensor([0., 0., 0., 1., 1., 1.]))
+        return xyz, dict()

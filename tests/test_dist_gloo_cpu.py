@@ -1,0 +1,65 @@
+"""Multi-rank path on CPU: world_size-2 gloo processes shard the samples with no data-path collective and exchange
+the decoded boxes with ONE fixed-size all-gather per step (mv2d_amd/dist.py)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mv2d_amd import dist as mdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    r, w, _ = mdist.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    mine = mdist.shard_samples(5, rank, world)
+    payloads = []
+    for s in mine[:2]:
+        n = 3 + s
+        boxes = torch.zeros((300, 9)); boxes[:n] = float(s + 1)
+        scores = torch.zeros(300); scores[:n] = 0.5
+        labels = torch.zeros(300, dtype=torch.int64); labels[:n] = s
+        payloads.append(mdist.pack_detections(boxes, scores, labels, torch.tensor([n], dtype=torch.int32)))
+    out = mdist.gather_detections(torch.stack(payloads))
+    res = []
+    for rr in range(world):
+        for b in range(out.shape[1]):
+            bx, sc, lb = mdist.unpack_detections(out[rr, b])
+            res.append((rr, b, bx.shape[0], float(bx.sum()), int(lb.sum())))
+    q.put((rank, mine, res))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_shard_and_gather():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort()
+    assert got[0][1] == [0, 2, 4] and got[1][1] == [1, 3]
+    assert got[0][2] == got[1][2]                                         # every rank sees the same gathered result
+    by = {(rr, b): (n, s, l) for rr, b, n, s, l in got[0][2]}
+    assert by[(0, 0)][0] == 3 and by[(0, 1)][0] == 5 and by[(1, 0)][0] == 4 and by[(1, 1)][0] == 6
+    assert by[(1, 1)] == (6, 6 * 9 * 4.0, 6 * 3)
+
+
+def test_single_process_gather_is_identity():
+    p = torch.arange(2 * 3301, dtype=torch.float32).view(2, 3301)
+    assert torch.equal(mdist.gather_detections(p)[0], p)

@@ -1,0 +1,124 @@
+"""The reference's registry surface on the GPU (-m gpu): heads built from the verbatim reference configs, weights loaded
+through ``load_state_dict`` with the reference key layout, ``simple_test`` and the module-level forwards against the
+oracle."""
+import numpy as np
+import pytest
+import torch
+
+import mv2d_amd
+from mv2d_amd import configs, synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def relmax(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def build(kind, num_views=None):
+    cfg = configs.roi_head_cfg_s() if kind == 'S' else configs.roi_head_cfg_t()
+    if num_views is not None and kind == 'T':
+        cfg['num_views'] = num_views
+    head = mv2d_amd.build_head(cfg, test_cfg=configs.TEST_CFG_RCNN)
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.make_head_state(seed=0).items()}
+    head.load_state_dict(sd, strict=True)
+    return head.to(DEV).eval()
+
+
+def oracle(prob):
+    from oracle import mv2d_oracle as O
+    st = {}
+    sd = synthetic.make_head_state(seed=0)
+    feat = torch.from_numpy(prob['feat'])
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    if prob['kind'] == 'T':
+        O.forward_t(sd, feat, props, prob['img_metas'], num_views=prob['views_per_frame'], stages=st)
+    else:
+        O.forward_s(sd, feat, props, prob['img_metas'], stages=st)
+    return st
+
+
+@pytest.mark.parametrize('name', ['cfg1_t', 'cfg1_s'])
+def test_simple_test_matches_oracle(name):
+    prob = synthetic.make_problem(name, seed=0)
+    head = build(prob['kind'], prob['views_per_frame'])
+    st = oracle(prob)
+    metas = [dict(m, box_type_3d=None) for m in prob['img_metas']]
+    res = head.simple_test([torch.from_numpy(prob['feat']).to(DEV)], [torch.from_numpy(p).to(DEV) for p in prob['proposals']], metas)
+    boxes, scores, labels = res[0]
+    assert boxes.shape[1] == 9
+    exp = {(int(i), int(l)): float(s) for i, l, s in zip(st['bbox_index'], st['labels'], st['scores'])}
+    eng_out = head._engine
+    # labels multiset and scores agree on (nearly) all entries
+    n_common = min(len(labels), len(st['labels']))
+    same = (labels[:n_common].cpu() == st['labels'][:n_common]).float().mean()
+    assert same > 0.95
+    assert relmax(scores[:n_common], st['scores'][:n_common]) < 5e-3
+
+
+def test_module_level_forward_t_path():
+    """CrossAttentionBoxHead.forward with the reference's dense-mask arguments (RH/mv2d_t_head.py:103-109)."""
+    from oracle import mv2d_oracle as O
+    prob = synthetic.make_problem('cfg1_t', seed=0)
+    head = build('T', 2)
+    st = oracle(prob)
+    roi_mask = st['roi_mask']
+    feat = torch.from_numpy(prob['feat'])
+    mem = feat.permute(0, 2, 3, 1)[roi_mask][..., None, None]
+    pe = st['pe'].permute(0, 2, 3, 1)[roi_mask][..., None, None]
+    kpm = st['key_padding'][..., None, None]
+    cam = (~st['feat_for_rois'])[:, roi_mask][..., None, None]
+    cls, reg = head.bbox_head(st['ref'][None].to(DEV), mem[None].to(DEV), kpm[None].to(DEV), pe[None].to(DEV),
+                              cross_attn_mask=cam.to(DEV), force_fp32=True, pe=('ignored', None, None))
+    assert cls.shape == (6, 1, st['ref'].shape[0], 10)
+    assert relmax(cls[:, 0], st['cls']) < 2e-3
+    assert relmax(reg[:, 0], st['reg']) < 5e-3
+    out = head.bbox_head.get_bboxes({'cls_scores': [cls[-1, 0]], 'bbox_preds': [reg[-1, 0]]}, [dict()])
+    # near-ties in the scores may swap neighbouring ranks (bf16 key side): compare position-wise agreement, not equality
+    n = min(len(out[0][2]), len(st['labels']))
+    assert (out[0][2][:n].cpu() == st['labels'][:n]).float().mean() > 0.95
+    assert relmax(out[0][1][:n], st['scores'][:n]) < 5e-3
+
+
+def test_module_level_forward_s_path():
+    """bs = R queries with their own key sets (RH/mv2d_s_head.py:184-192)."""
+    prob = synthetic.make_problem('cfg1_s', seed=0)
+    head = build('S')
+    st = oracle(prob)
+    corr, cmask = st['corr'], st['corr_mask']
+    cf = st['roi_feats'][corr]
+    cp = st['roi_pe'][corr]
+    m = (~cmask)[..., None, None].expand_as(cf[:, :, 0])
+    cls, reg = head.bbox_head(st['ref'][:, None].to(DEV), cf.to(DEV), m.to(DEV), cp.to(DEV), attn_mask=None, cross_attn_mask=None)
+    assert relmax(cls[:, :, 0], st['cls']) < 2e-3
+    assert relmax(reg[:, :, 0], st['reg']) < 5e-3
+
+
+def test_pe_roi_extractor_boxcorr_querygen_modules():
+    from oracle import mv2d_oracle as O
+    prob = synthetic.make_problem('cfg1_t', seed=0)
+    head = build('T', 2)
+    st = oracle(prob)
+    feat = torch.from_numpy(prob['feat']).to(DEV)
+    metas = prob['img_metas']
+    pe = head.position_encoding([feat], metas)[0]
+    assert relmax(pe, st['pe']) < 1e-2
+    rois = st['rois'].to(DEV)
+    x512 = torch.cat([feat, pe], 1)
+    ra = head.bbox_roi_extractor([x512], rois)
+    assert ra.shape == (rois.shape[0], 512, 7, 7)
+    assert relmax(ra[:, :256], st['roi_feats']) < 1e-5
+    npv = [len(p) for p in prob['proposals']]
+    ffr = head.box_corr_module.gen_box_correlation(rois, npv, metas, feat, 16)
+    assert torch.equal(ffr.cpu(), st['feat_for_rois'])                              # bit-exact boolean masks
+    xyz, _ = head.query_generator(st['roi_feats'].to(DEV), st['K_roi'].to(DEV), st['E'].to(DEV), dict(intrinsic=st['intr'].to(DEV)))
+    assert relmax(xyz, st['xyz']) < 2e-3
+    # S-path correlation API
+    probs = synthetic.make_problem('cfg1_s', seed=0)
+    heads = build('S')
+    sts = oracle(probs)
+    corr, mask = heads.box_corr_module.gen_box_roi_correlation(sts['rois'].to(DEV), [len(p) for p in probs['proposals']], probs['img_metas'])
+    assert torch.equal(corr.cpu(), sts['corr']) and torch.equal(mask.cpu(), sts['corr_mask'])
