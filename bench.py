@@ -51,6 +51,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-iters', type=int, default=3)
+    ap.add_argument('--cpu-threads', type=int, default=16)
+    ap.add_argument('--cpu-timeout', type=int, default=150)
     args = ap.parse_args()
 
     from mv2d_amd import dist as mdist
@@ -159,23 +161,16 @@ def main():
     # ---------------- CPU baseline: the oracle (port of the reference algorithm) on the host cores, bounded sample
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import mv2d_oracle as O
-        cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
-        fn = O.forward_t if kind == 'T' else O.forward_s
-        kw = {'num_views': prob['views_per_frame']} if kind == 'T' else {}
-        fcpu = torch.from_numpy(prob['feat'])
-        with torch.no_grad():
-            fn(sd, fcpu, props, metas, **kw)
-            ts = []
-            for _ in range(args.cpu_iters):
-                c0 = time.perf_counter()
-                fn(sd, fcpu, props, metas, **kw)
-                ts.append(time.perf_counter() - c0)
-        med = statistics.median(ts)
-        cpu = dict(value=round(1.0 / med, 4), unit='samples/s', cores=cores, kind='port',
-                   sample=f'{args.cpu_iters} frames of {args.workload} after 1 warm-up, median {med * 1e3:.0f} ms/frame, '
-                          f'torch {torch.__version__} CPU fp32/fp64, {cores} threads')
+        import subprocess
+        threads = min(os.cpu_count() or 1, args.cpu_threads)
+        try:
+            r = subprocess.run([sys.executable, '-m', 'oracle.cpu_baseline', '--workload', args.workload, '--iters', str(args.cpu_iters),
+                                '--threads', str(threads)], cwd=ROOT, capture_output=True, text=True, timeout=args.cpu_timeout)
+            lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+            cpu = json.loads(lines[-1]) if lines else dict(value=None, unit='samples/s', cores=threads, kind='port',
+                                                           sample=f'oracle subprocess failed: {r.stderr[-200:]}')
+        except subprocess.TimeoutExpired:
+            cpu = dict(value=None, unit='samples/s', cores=threads, kind='port', sample=f'oracle did not finish {args.cpu_iters}+1 frames in {args.cpu_timeout}s')
 
     if rank == 0:
         line = {

@@ -1,0 +1,48 @@
+"""CPU baseline leg of bench.py: time the oracle (a port of the reference algorithm, torch CPU fp32/fp64) on a bounded
+sample of the bench workload.  Run as a subprocess so that a slow host cannot hang the benchmark.
+
+    python -m oracle.cpu_baseline --workload cfg2_s --iters 3 --threads 16   ->  one JSON line
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--workload', default='cfg2_s')
+    ap.add_argument('--iters', type=int, default=3)
+    ap.add_argument('--threads', type=int, default=16)
+    a = ap.parse_args()
+    import torch
+    from mv2d_amd import synthetic
+    from oracle import mv2d_oracle as O
+    torch.set_num_threads(a.threads)
+    prob = synthetic.make_problem(a.workload, seed=0)
+    sd = synthetic.make_head_state(seed=0)
+    fn = O.forward_t if prob['kind'] == 'T' else O.forward_s
+    kw = {'num_views': prob['views_per_frame']} if prob['kind'] == 'T' else {}
+    feat = torch.from_numpy(prob['feat'])
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    ts = []
+    with torch.no_grad():
+        fn(sd, feat, props, prob['img_metas'], **kw)
+        for _ in range(a.iters):
+            t0 = time.perf_counter()
+            fn(sd, feat, props, prob['img_metas'], **kw)
+            ts.append(time.perf_counter() - t0)
+    med = statistics.median(ts)
+    print(json.dumps(dict(value=round(1.0 / med, 4), unit='samples/s', cores=a.threads, kind='port',
+                          sample=f'{a.iters} frames of {a.workload} after 1 warm-up, median {med * 1e3:.0f} ms/frame, torch '
+                                 f'{torch.__version__} CPU fp32/fp64, {a.threads} threads of {os.cpu_count()} host cores')))
+
+
+if __name__ == '__main__':
+    main()
