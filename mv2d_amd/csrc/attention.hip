@@ -14,11 +14,30 @@ namespace {
 constexpr int C = 256, HEADS = 8, HD = 32;
 
 // ------------------------------------------------------------------------------------------------
-// self attention: one wave per (16-query tile, head)
+// self attention: one 4-wave block per (16-query tile, head); the key tiles are dealt round-robin to the
+// 4 waves (flash-decoding style split), each wave prefetches its next tile's K/V fragments while the MFMAs of
+// the current one run, and the 4 partial (m, l, O) states are merged through 8.5 KB of LDS.
 //   qkv: [R, 768] fp32 = (q | k | v) in_proj outputs (q NOT yet scaled), ctx: [R, 256] fp32
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void self_attn_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int R, float scale) {
-    const int lane = threadIdx.x, fr = lane & 15, fg = lane >> 4;
+struct KVFrag { float4 ka, kb; float v0[4], v1[4]; };
+
+__device__ __forceinline__ void load_kv(KVFrag& f, const float* __restrict__ qkv, int t, int h, int fr, int fg, int R) {
+    const int krow = min(t * 16 + fr, R - 1);
+    const float* kp = qkv + (long long)krow * 768 + C + h * HD + 4 * fg;
+    f.ka = *reinterpret_cast<const float4*>(kp);
+    f.kb = *reinterpret_cast<const float4*>(kp + 16);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int vrow = min(t * 16 + 4 * fg + r, R - 1);
+        const float* vp = qkv + (long long)vrow * 768 + 2 * C + h * HD + fr;
+        f.v0[r] = vp[0];
+        f.v1[r] = vp[16];
+    }
+}
+
+__global__ __launch_bounds__(256) void self_attn_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int R, float scale) {
+    __shared__ float sm[4][16], sl[4][16], so[4][32][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int q0 = blockIdx.x * 16, h = blockIdx.y;
     const int qrow = min(q0 + fr, R - 1);
     const float* qp = qkv + (long long)qrow * 768 + h * HD + 4 * fg;
@@ -27,22 +46,21 @@ __global__ __launch_bounds__(64) void self_attn_kernel(const float* __restrict__
     float m_run = -INFINITY, l_run = 0.f;
     f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
     const int ntiles = (R + 15) / 16;
-    for (int t = 0; t < ntiles; ++t) {
-        const int krow = min(t * 16 + fr, R - 1);
-        const float* kp = qkv + (long long)krow * 768 + C + h * HD + 4 * fg;
-        const float4 ka = *reinterpret_cast<const float4*>(kp);
-        const float4 kb = *reinterpret_cast<const float4*>(kp + 16);
+    KVFrag cur, nxt;
+    if (wave < ntiles) load_kv(cur, qkv, wave, h, fr, fg, R);
+    for (int t = wave; t < ntiles; t += 4) {
+        if (t + 4 < ntiles) load_kv(nxt, qkv, t + 4, h, fr, fg, R);
         // S^T[key = 16t + 4fg + reg][query = fr]; the d index is spread over (MFMA step, lane group) by the
         // same bijection for K and Q: step j of the first half contracts d = 4g + j, g = 0..3.
         f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.x, qa.x, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.y, qa.y, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.z, qa.z, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.w, qa.w, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.x, qb.x, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.y, qb.y, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.z, qb.z, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.w, qb.w, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.ka.x, qa.x, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.ka.y, qa.y, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.ka.z, qa.z, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.ka.w, qa.w, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.kb.x, qb.x, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.kb.y, qb.y, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.kb.z, qb.z, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.kb.w, qb.w, s, 0, 0, 0);
         float p[4];
         float tmax = -INFINITY;
 #pragma unroll
@@ -67,56 +85,79 @@ __global__ __launch_bounds__(64) void self_attn_kernel(const float* __restrict__
         // O^T[d][query] += sum_key V[key][d] * P^T[key][query]; MFMA step r contracts keys 16t + 4g + r
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int vrow = min(t * 16 + 4 * fg + r, R - 1);
-            const float* vp = qkv + (long long)vrow * 768 + 2 * C + h * HD + fr;
-            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[0], p[r], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[16], p[r], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.v0[r], p[r], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.v1[r], p[r], o1, 0, 0, 0);
         }
+        cur = nxt;
     }
-    if (q0 + fr < R) {
-        const float inv = 1.0f / l_run;
-        float* op = ctx + (long long)(q0 + fr) * C + h * HD + 4 * fg;
-        *reinterpret_cast<float4*>(op) = make_float4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
-        *reinterpret_cast<float4*>(op + 16) = make_float4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
+    if (fg == 0) { sm[wave][fr] = m_run; sl[wave][fr] = l_run; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { so[wave][4 * fg + r][fr] = o0[r]; so[wave][16 + 4 * fg + r][fr] = o1[r]; }
+    __syncthreads();
+    // merge: thread -> query q = tid & 15, two d values
+    const int q = tid & 15, d0 = (tid >> 4) * 2;
+    if (q0 + q < R) {
+        const float M = fmaxf(fmaxf(sm[0][q], sm[1][q]), fmaxf(sm[2][q], sm[3][q]));
+        float den = 0.f, n0 = 0.f, n1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float e = expf(sm[w][q] - M);        // waves without a tile: exp(-inf) = 0
+            den += sl[w][q] * e;
+            n0 += so[w][d0][q] * e;
+            n1 += so[w][d0 + 1][q] * e;
+        }
+        const float inv = 1.0f / den;
+        *reinterpret_cast<float2*>(ctx + (long long)(q0 + q) * C + h * HD + d0) = make_float2(n0 * inv, n1 * inv);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// sparse cross attention, one wave per query; lane l owns channels 4l..4l+3 (head = l >> 3).
+// sparse cross attention: one 4-wave block per query; lane l of every wave owns channels 4l..4l+3 (head = l >> 3).
+// The row's keys are dealt to the waves in chunks of 8 (round robin); each wave prefetches its next chunk
+// (indices, then K/V rows: 512 B coalesced per key) while it works on the current one; merge through LDS.
 //   q: [R,256] fp32 already scaled by 1/sqrt(32); K,V: [S,256] bf16; out ctx [R,256] fp32
 //   A query with no allowed key gets ctx = 0 (the reference yields NaN there — DESIGN.md).
-//   Optional debug outputs: logits [8][nnz] (pre-softmax, CSR order).
+//   Optional debug output: logits [8][nnz] (pre-softmax, CSR order).
 // ------------------------------------------------------------------------------------------------
 constexpr int KCH = 8;   // keys per chunk (independent loads in flight)
+
+struct KeyChunk { uint2 kk[KCH], vv[KCH]; };
+
+__device__ __forceinline__ void load_chunk(KeyChunk& c, const unsigned short* __restrict__ K, const unsigned short* __restrict__ V,
+                                           const int* __restrict__ col_idx, int base, int end, int lane) {
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+        const int e = min(base + i, end - 1);
+        const long long row = (long long)col_idx[e] * C + 4 * lane;
+        c.kk[i] = *reinterpret_cast<const uint2*>(K + row);
+        c.vv[i] = *reinterpret_cast<const uint2*>(V + row);
+    }
+}
 
 __global__ __launch_bounds__(256) void sparse_xattn_kernel(const float* __restrict__ q, const unsigned short* __restrict__ K,
                                                            const unsigned short* __restrict__ V, const int* __restrict__ row_ptr,
                                                            const int* __restrict__ col_idx, float* __restrict__ ctx,
                                                            float* __restrict__ dbg_logits, long long dbg_stride, int R) {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= R) return;
-    const int lane = threadIdx.x & 63;
+    __shared__ float sm[4][8], sl[4][8], sacc[4][C];
+    const int r = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float4 q4 = *reinterpret_cast<const float4*>(q + (long long)r * C + 4 * lane);
     const int beg = row_ptr[r], end = row_ptr[r + 1];
     float m_run = -INFINITY, l_run = 0.f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = beg; base < end; base += KCH) {
-        uint2 kk[KCH], vv[KCH];
+    KeyChunk cur, nxt;
+    int base = beg + wave * KCH;
+    if (base < end) load_chunk(cur, K, V, col_idx, base, end, lane);
+    for (; base < end; base += 4 * KCH) {
+        if (base + 4 * KCH < end) load_chunk(nxt, K, V, col_idx, base + 4 * KCH, end, lane);
         float lg[KCH];
-#pragma unroll
-        for (int i = 0; i < KCH; ++i) {
-            const int e = min(base + i, end - 1);
-            const long long row = (long long)col_idx[e] * C + 4 * lane;
-            kk[i] = *reinterpret_cast<const uint2*>(K + row);
-            vv[i] = *reinterpret_cast<const uint2*>(V + row);
-        }
         float cmax = -INFINITY;
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
-            float d = __uint_as_float(kk[i].x << 16) * q4.x;
-            d = fmaf(__uint_as_float(kk[i].x & 0xffff0000u), q4.y, d);
-            d = fmaf(__uint_as_float(kk[i].y << 16), q4.z, d);
-            d = fmaf(__uint_as_float(kk[i].y & 0xffff0000u), q4.w, d);
+            float d = __uint_as_float(cur.kk[i].x << 16) * q4.x;
+            d = fmaf(__uint_as_float(cur.kk[i].x & 0xffff0000u), q4.y, d);
+            d = fmaf(__uint_as_float(cur.kk[i].y << 16), q4.z, d);
+            d = fmaf(__uint_as_float(cur.kk[i].y & 0xffff0000u), q4.w, d);
             d += __shfl_xor(d, 1, 64);
             d += __shfl_xor(d, 2, 64);
             d += __shfl_xor(d, 4, 64);
@@ -132,16 +173,32 @@ __global__ __launch_bounds__(256) void sparse_xattn_kernel(const float* __restri
         for (int i = 0; i < KCH; ++i) {
             const float pi = expf(lg[i] - m_new);
             psum += pi;
-            acc.x = fmaf(pi, __uint_as_float(vv[i].x << 16), acc.x);
-            acc.y = fmaf(pi, __uint_as_float(vv[i].x & 0xffff0000u), acc.y);
-            acc.z = fmaf(pi, __uint_as_float(vv[i].y << 16), acc.z);
-            acc.w = fmaf(pi, __uint_as_float(vv[i].y & 0xffff0000u), acc.w);
+            acc.x = fmaf(pi, __uint_as_float(cur.vv[i].x << 16), acc.x);
+            acc.y = fmaf(pi, __uint_as_float(cur.vv[i].x & 0xffff0000u), acc.y);
+            acc.z = fmaf(pi, __uint_as_float(cur.vv[i].y << 16), acc.z);
+            acc.w = fmaf(pi, __uint_as_float(cur.vv[i].y & 0xffff0000u), acc.w);
         }
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        cur = nxt;
     }
-    const float inv = (end > beg) ? 1.0f / l_run : 0.f;
-    *reinterpret_cast<float4*>(ctx + (long long)r * C + 4 * lane) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    if ((lane & 7) == 0) { sm[wave][lane >> 3] = m_run; sl[wave][lane >> 3] = l_run; }
+    *reinterpret_cast<float4*>(&sacc[wave][4 * lane]) = acc;
+    __syncthreads();
+    const int hh = tid >> 5;                 // thread tid -> channel tid, head tid / 32
+    float out = 0.f;
+    if (end > beg) {
+        const float M = fmaxf(fmaxf(sm[0][hh], sm[1][hh]), fmaxf(sm[2][hh], sm[3][hh]));
+        float den = 0.f, num = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float e = expf(sm[w][hh] - M);
+            den += sl[w][hh] * e;
+            num += sacc[w][tid] * e;
+        }
+        out = num / den;
+    }
+    ctx[(long long)r * C + tid] = out;
 }
 
 }  // namespace
@@ -149,7 +206,7 @@ __global__ __launch_bounds__(256) void sparse_xattn_kernel(const float* __restri
 extern "C" int mv2d_self_attn_fwd(const float* qkv, float* ctx, int R, void* stream) {
     MV2D_CHECK_ARG(qkv && ctx && R >= 0, "mv2d_self_attn_fwd: bad args");
     if (R == 0) return MV2D_OK;
-    hipLaunchKernelGGL(self_attn_kernel, dim3(cdiv(R, 16), HEADS), dim3(64), 0, (hipStream_t)stream, qkv, ctx, R,
+    hipLaunchKernelGGL(self_attn_kernel, dim3(cdiv(R, 16), HEADS), dim3(256), 0, (hipStream_t)stream, qkv, ctx, R,
                        1.0f / sqrtf((float)HD));
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
@@ -159,7 +216,7 @@ extern "C" int mv2d_sparse_xattn_fwd(const float* q, const void* K, const void* 
                                      float* ctx, float* dbg_logits, long long dbg_stride, int R, void* stream) {
     MV2D_CHECK_ARG(q && K && V && row_ptr && col_idx && ctx && R >= 0, "mv2d_sparse_xattn_fwd: bad args");
     if (R == 0) return MV2D_OK;
-    hipLaunchKernelGGL(sparse_xattn_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, q, (const unsigned short*)K,
+    hipLaunchKernelGGL(sparse_xattn_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, q, (const unsigned short*)K,
                        (const unsigned short*)V, row_ptr, col_idx, ctx, dbg_logits, dbg_stride, R);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;

@@ -9,7 +9,11 @@
 // Tile 128x128x64, 256 threads = 4 waves as 2x2, each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 tiles.
 // A/W tiles are register-staged (16 B per lane, one 128 B row per 8 lanes -> full-line coalesced reads)
 // into an XOR-swizzled LDS image (byte ^= (row&7)<<4) so the ds_read_b128 fragment reads are <=2-way.
-// Double-buffered LDS, one barrier per K step; the next tile's global loads are issued before the MFMAs.
+// ONE 32 KiB LDS stage (A 16 KiB + W 16 KiB): the next tile's global loads are issued into registers before the
+// MFMAs of the current tile and written to LDS after them (T14 issue-early / write-late), so 3 blocks are
+// resident per CU and cover each other's load latency (K is only 192..2304 here: 3..36 steps).
+// bf16 outputs leave through the same LDS: each wave stages its 64x64 sub-tile (XOR-swizzled) and writes
+// whole 128-byte row segments with 16-byte stores instead of 2-byte scattered stores.
 #include "common.h"
 
 namespace {
@@ -40,10 +44,10 @@ struct Params {
 
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * ROW_BYTES + ((slot ^ (row & 7)) << 4); }
 
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(Params p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;                    // [2][TILE_BYTES]
-    unsigned char* Bs = smem + 2 * TILE_BYTES;   // [2][TILE_BYTES]
+__global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(Params p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + TILE_BYTES;
 
     int M = p.M;
     if (p.m_dev) { int md = *p.m_dev; M = md < M ? md : M; }
@@ -109,12 +113,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Params p) {
             rb[i] = w;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int off = lds_off(a_row[i], a_slot[i]);
-            *reinterpret_cast<uint4*>(As + buf * TILE_BYTES + off) = ra[i];
-            *reinterpret_cast<uint4*>(Bs + buf * TILE_BYTES + off) = rb[i];
+            *reinterpret_cast<uint4*>(As + off) = ra[i];
+            *reinterpret_cast<uint4*>(Bs + off) = rb[i];
         }
     };
 
@@ -126,26 +130,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Params p) {
 
     const int nk = p.K / BK;
     load_tile(0);
-    store_tile(0);
+    store_tile();
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile((kt + 1) * BK);
-        const unsigned char* a_t = As + buf * TILE_BYTES;
-        const unsigned char* b_t = Bs + buf * TILE_BYTES;
+        if (kt + 1 < nk) load_tile((kt + 1) * BK);          // in flight during the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             mfma_bf16x8 af[4], bfr[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int row = wr * 64 + i * 16 + fr;
-                af[i] = *reinterpret_cast<const mfma_bf16x8*>(a_t + lds_off(row, ks * 4 + fg));
+                af[i] = *reinterpret_cast<const mfma_bf16x8*>(As + lds_off(row, ks * 4 + fg));
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int row = wc * 64 + j * 16 + fr;
-                bfr[j] = *reinterpret_cast<const mfma_bf16x8*>(b_t + lds_off(row, ks * 4 + fg));
+                bfr[j] = *reinterpret_cast<const mfma_bf16x8*>(Bs + lds_off(row, ks * 4 + fg));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -153,39 +154,79 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Params p) {
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
+        __syncthreads();                                    // every wave is done reading this stage
+        if (kt + 1 < nk) {
+            store_tile();
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: lane holds C[m = .. + fg*4 + reg][n = .. + fr]
+    // The bf16 result (C when c_bf16, else C2) is staged per wave in LDS (64 rows x 128 B, 32-B units XOR-swizzled by
+    // the 4-row group so the four lane groups of an MFMA column store land on different banks) and written out as
+    // whole 128-byte row segments.  fp32 results are stored directly (64-byte segments per lane group).
+    unsigned short* stage = reinterpret_cast<unsigned short*>(smem + wave * 8192);
+    const bool stage_c = p.C && p.c_bf16, stage_c2 = p.C2 != nullptr;
+    const bool staged = (stage_c || stage_c2) && ((p.N & 63) == 0) && (p.c_blk_cols == 0 || (p.c_blk_cols & 63) == 0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = n0 + wc * 64 + j * 16 + fr;
-        if (n >= p.N) continue;
-        const float bn = p.bias ? p.bias[n] : 0.f;
+        const bool n_ok = n < p.N;
+        const float bn = (p.bias && n_ok) ? p.bias[n] : 0.f;
         const int nb = p.c_blk_cols > 0 ? n / p.c_blk_cols : 0;
         const int nc = p.c_blk_cols > 0 ? n - nb * p.c_blk_cols : n;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wr * 64 + i * 16 + fg * 4 + r;
-                if (m >= M) continue;
+                const int lrow = i * 16 + fg * 4 + r;                   // row inside the wave's 64x64 sub-tile
+                const int m = m0 + wr * 64 + lrow;
+                const bool ok = n_ok && m < M;
                 float v = acc[i][j][r] + bn;
-                if (p.mul) v *= p.mul[(long long)m * p.ldmul + n];
-                if (p.add) v += p.add[(long long)m * p.ldadd + n];
+                if (ok && p.mul) v *= p.mul[(long long)m * p.ldmul + n];
+                if (ok && p.add) v += p.add[(long long)m * p.ldadd + n];
                 if (p.act == 1) v = fmaxf(v, 0.f);
                 else if (p.act == 2) v = 1.f / (1.f + __expf(-v));
-                if (p.C) {
+                float v2 = v;
+                if (ok && p.C2 && p.add2) v2 = v + p.add2[(long long)m * p.ldadd2 + n];
+                if (ok && p.C && !p.c_bf16) {
                     long long o = (long long)nb * p.c_blk_stride + (long long)m * p.ldc + nc;
-                    if (p.c_bf16) reinterpret_cast<unsigned short*>(p.C)[o] = f32_to_bf16(v);
-                    else reinterpret_cast<float*>(p.C)[o] = v;
+                    reinterpret_cast<float*>(p.C)[o] = v;
                 }
-                if (p.C2) {
-                    float v2 = v + (p.add2 ? p.add2[(long long)m * p.ldadd2 + n] : 0.f);
-                    p.C2[(long long)m * p.ldc2 + n] = f32_to_bf16(v2);
+                if (staged) {
+                    const int lcol = j * 16 + fr;
+                    const int byte = lrow * 128 + ((lcol * 2) ^ (((lrow >> 2) & 3) << 5));
+                    stage[byte >> 1] = f32_to_bf16(stage_c2 ? v2 : v);
+                } else if (ok) {
+                    if (stage_c) {
+                        long long o = (long long)nb * p.c_blk_stride + (long long)m * p.ldc + nc;
+                        reinterpret_cast<unsigned short*>(p.C)[o] = f32_to_bf16(v);
+                    }
+                    if (stage_c2) p.C2[(long long)m * p.ldc2 + n] = f32_to_bf16(v2);
                 }
             }
+        }
+    }
+    if (staged) {
+        // wave-local hand-off through LDS (each wave reads back only its own 8 KiB): LDS ops of one wave are ordered
+        __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0)
+        const int nsub = n0 + wc * 64;          // first column of this wave's sub-tile
+        unsigned short* dst;
+        long long ldd;
+        if (stage_c2) { dst = p.C2 + nsub; ldd = p.ldc2; }
+        else {
+            const int nb = p.c_blk_cols > 0 ? nsub / p.c_blk_cols : 0;
+            const int nc = p.c_blk_cols > 0 ? nsub - nb * p.c_blk_cols : nsub;
+            dst = reinterpret_cast<unsigned short*>(p.C) + (long long)nb * p.c_blk_stride + nc;
+            ldd = p.ldc;
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int lrow = it * 8 + (lane >> 3), chunk = lane & 7;
+            const int m = m0 + wr * 64 + lrow;
+            const int byte = lrow * 128 + ((chunk * 16) ^ (((lrow >> 2) & 3) << 5));
+            const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(stage) + byte);
+            if (m < M) *reinterpret_cast<uint4*>(dst + (long long)m * ldd + chunk * 8) = v;
         }
     }
 }
@@ -203,6 +244,9 @@ extern "C" int mv2d_gemm_bf16(const void* A, const void* A2, int n_split, int a_
     MV2D_CHECK_ARG(a_mode == 0 || (a_mode == 1 && K == 9 * 256 && (M % 49) == 0), "mv2d_gemm_bf16: conv3x3 mode needs K=2304, M=R*49");
     MV2D_CHECK_ARG(a_mode == 1 || (lda % 8) == 0, "mv2d_gemm_bf16: lda must be a multiple of 8 (16-byte rows)");
     MV2D_CHECK_ARG(n_split == 0 || (A2 && (n_split % BN) == 0), "mv2d_gemm_bf16: n_split must be a multiple of 128 with A2 set");
+    MV2D_CHECK_ARG(!(C2 && C && c_bf16), "mv2d_gemm_bf16: with a second (bf16) output the primary output must be fp32");
+    MV2D_CHECK_ARG(((uintptr_t)C2 & 15) == 0 && (!c_bf16 || ((uintptr_t)C & 15) == 0) && (ldc2 % 8) == 0 && (!c_bf16 || (ldc % 8) == 0),
+                   "mv2d_gemm_bf16: bf16 outputs need 16-byte aligned base and row stride");
     if (M == 0) return MV2D_OK;
     Params p;
     p.A = (const unsigned short*)A; p.A2 = (const unsigned short*)A2; p.W = (const unsigned short*)W; p.bias = bias;
@@ -212,7 +256,7 @@ extern "C" int mv2d_gemm_bf16(const void* A, const void* A2, int n_split, int a_
     p.ldc2 = ldc2; p.ldadd2 = ldadd2;
     p.n_tiles = cdiv(N, BN);
     dim3 grid(((cdiv(M, BM) + 7) / 8) * 8 * p.n_tiles);
-    hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
