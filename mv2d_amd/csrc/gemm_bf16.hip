@@ -6,21 +6,22 @@
 // (MU/petr_transformer.py:503-508 in_proj of key/value), QueryGenerator conv3x3 as implicit GEMM
 // (RH/utils/query_generator.py:298-304).
 //
-// Tile 128x128x64, 256 threads = 4 waves as 2x2, each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 tiles.
+// Tile BMxBNx64 (128x128 or 64x64), 256 threads = 4 waves as 2x2, v_mfma_f32_16x16x32_bf16.
 // A/W tiles are register-staged (16 B per lane, one 128 B row per 8 lanes -> full-line coalesced reads)
 // into an XOR-swizzled LDS image (byte ^= (row&7)<<4) so the ds_read_b128 fragment reads are <=2-way.
-// ONE 32 KiB LDS stage (A 16 KiB + W 16 KiB): the next tile's global loads are issued into registers before the
-// MFMAs of the current tile and written to LDS after them (T14 issue-early / write-late), so 3 blocks are
-// resident per CU and cover each other's load latency (K is only 192..2304 here: 3..36 steps).
-// bf16 outputs leave through the same LDS: each wave stages its 64x64 sub-tile (XOR-swizzled) and writes
-// whole 128-byte row segments with 16-byte stores instead of 2-byte scattered stores.
+// ONE LDS stage: the next tile's global loads are issued into registers before the MFMAs of the current
+// tile and written to LDS after them (issue-early / write-late), several blocks resident per CU cover each
+// other's load latency (K is only 192..2304 here: 3..36 steps).  The 64x64 variant exists because the N=256
+// GEMMs over ~9-15k rows would otherwise be < 256 blocks (one per CU, nothing to overlap with).
+// Epilogue (round-1 profile: 2-byte scattered stores + per-element address math cost more than the K loop at
+// K=256): every 16-row MFMA slab is staged per wave through padded fp32 LDS and leaves as whole rows — 8
+// consecutive columns per lane, float4 reads of the fused mul/add operands, 16-byte bf16 / 2x16-byte fp32 stores.
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BK = 64;
 constexpr int ROW_BYTES = BK * 2;              // 128 B per LDS row
-constexpr int TILE_BYTES = BM * ROW_BYTES;     // 16 KiB
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 
@@ -44,10 +45,25 @@ struct Params {
 
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * ROW_BYTES + ((slot ^ (row & 7)) << 4); }
 
-__global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(Params p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+template <int BM, int BN>
+struct Cfg {
+    static constexpr int WM = BM / 2, WN = BN / 2;            // wave tile
+    static constexpr int TI = WM / 16, TJ = WN / 16;          // MFMA tiles per wave
+    static constexpr int CA = BM / 32, CB = BN / 32;          // 16-byte staging chunks per thread
+    static constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
+    static constexpr int SLD = WN + 4;                        // padded fp32 row of the epilogue stage
+    static constexpr int STAGE_BYTES = 16 * SLD * 4;          // one 16-row slab per wave
+    static constexpr int LDS_BYTES = (A_BYTES + B_BYTES) > 4 * STAGE_BYTES ? (A_BYTES + B_BYTES) : 4 * STAGE_BYTES;
+    static constexpr int CPR = WN / 8;                        // 8-column chunks per slab row
+    static constexpr int EIT = 16 * CPR / 64;                 // epilogue chunks per lane per slab (2 or 1)
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, (BM == 128 ? 3 : 4)) void gemm_bf16_kernel(Params p) {
+    using G = Cfg<BM, BN>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
     unsigned char* As = smem;
-    unsigned char* Bs = smem + TILE_BYTES;
+    unsigned char* Bs = smem + G::A_BYTES;
 
     int M = p.M;
     if (p.m_dev) { int md = *p.m_dev; M = md < M ? md : M; }
@@ -61,72 +77,75 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(Params p) {
     const int wr = wave >> 1, wc = wave & 1;
     const unsigned short* Abase = (p.n_split > 0 && n0 >= p.n_split) ? p.A2 : p.A;
 
-    // ---- per-thread staging assignment: 4 chunks of 16 B per operand
-    int a_row[4], a_slot[4];
-    long long a_src[4];            // element offset of the row start (plain) / roi base (conv)
-    int c_py[4], c_px[4];
-    bool a_ok[4];
-    long long b_src[4];
-    bool b_ok[4];
+    // ---- per-thread staging assignment
+    int a_off[G::CA], b_off[G::CB];
+    long long a_src[G::CA], b_src[G::CB];
+    int c_py[G::CA], c_px[G::CA];
+    bool a_ok[G::CA], b_ok[G::CB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int c = tid + 256 * i;
-        int row = c >> 3, slot = c & 7;
-        a_row[i] = row; a_slot[i] = slot;
-        int m = m0 + row;
+    for (int i = 0; i < G::CA; ++i) {
+        const int c = tid + 256 * i, row = c >> 3, slot = c & 7;
+        a_off[i] = lds_off(row, slot);
+        const int m = m0 + row;
         a_ok[i] = m < M;
-        int mc = a_ok[i] ? m : (M - 1);
+        const int mc = a_ok[i] ? m : (M - 1);
         if (p.a_mode == 0) {
-            a_src[i] = (long long)mc * p.lda;
+            a_src[i] = (long long)mc * p.lda + slot * 8;
             c_py[i] = c_px[i] = 0;
         } else {
-            int r = mc / 49, cell = mc - r * 49;
+            const int r = mc / 49, cell = mc - r * 49;
             c_py[i] = cell / 7; c_px[i] = cell - c_py[i] * 7;
-            a_src[i] = (long long)r * 49 * 256;
+            a_src[i] = (long long)r * 49 * 256 + slot * 8;
         }
-        int n = n0 + row;
+    }
+#pragma unroll
+    for (int i = 0; i < G::CB; ++i) {
+        const int c = tid + 256 * i, row = c >> 3, slot = c & 7;
+        b_off[i] = lds_off(row, slot);
+        const int n = n0 + row;
         b_ok[i] = n < p.N;
-        b_src[i] = (long long)(b_ok[i] ? n : (p.N - 1)) * p.K;
+        b_src[i] = (long long)(b_ok[i] ? n : (p.N - 1)) * p.K + slot * 8;
     }
 
-    uint4 ra[4], rb[4];
+    uint4 ra[G::CA], rb[G::CB];
     auto load_tile = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < G::CA; ++i) {
             const unsigned short* src;
             bool ok = a_ok[i];
             if (p.a_mode == 0) {
-                src = Abase + a_src[i] + k0 + a_slot[i] * 8;
+                src = Abase + a_src[i] + k0;
             } else {
-                int tap = k0 >> 8, c0 = (k0 & 255) + a_slot[i] * 8;
-                int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-                int y = c_py[i] + dy, x = c_px[i] + dx;
+                const int tap = k0 >> 8, c0 = k0 & 255;
+                const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+                const int y = c_py[i] + dy, x = c_px[i] + dx;
                 ok = ok && y >= 0 && y < 7 && x >= 0 && x < 7;
-                int yy = ok ? y : 0, xx = ok ? x : 0;
+                const int yy = ok ? y : 0, xx = ok ? x : 0;
                 src = Abase + a_src[i] + (yy * 7 + xx) * 256 + c0;
             }
             uint4 v = *reinterpret_cast<const uint4*>(src);
             if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
             ra[i] = v;
-            uint4 w = *reinterpret_cast<const uint4*>(p.W + b_src[i] + k0 + a_slot[i] * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < G::CB; ++i) {
+            uint4 w = *reinterpret_cast<const uint4*>(p.W + b_src[i] + k0);
             if (!b_ok[i]) w = make_uint4(0u, 0u, 0u, 0u);
             rb[i] = w;
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int off = lds_off(a_row[i], a_slot[i]);
-            *reinterpret_cast<uint4*>(As + off) = ra[i];
-            *reinterpret_cast<uint4*>(Bs + off) = rb[i];
-        }
+        for (int i = 0; i < G::CA; ++i) *reinterpret_cast<uint4*>(As + a_off[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < G::CB; ++i) *reinterpret_cast<uint4*>(Bs + b_off[i]) = rb[i];
     };
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[G::TI][G::TJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < G::TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < G::TJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
     load_tile(0);
@@ -137,21 +156,17 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(Params p) {
         if (kt + 1 < nk) load_tile((kt + 1) * BK);          // in flight during the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            mfma_bf16x8 af[4], bfr[4];
+            mfma_bf16x8 af[G::TI], bfr[G::TJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int row = wr * 64 + i * 16 + fr;
-                af[i] = *reinterpret_cast<const mfma_bf16x8*>(As + lds_off(row, ks * 4 + fg));
-            }
+            for (int i = 0; i < G::TI; ++i)
+                af[i] = *reinterpret_cast<const mfma_bf16x8*>(As + lds_off(wr * G::WM + i * 16 + fr, ks * 4 + fg));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int row = wc * 64 + j * 16 + fr;
-                bfr[j] = *reinterpret_cast<const mfma_bf16x8*>(Bs + lds_off(row, ks * 4 + fg));
-            }
+            for (int j = 0; j < G::TJ; ++j)
+                bfr[j] = *reinterpret_cast<const mfma_bf16x8*>(Bs + lds_off(wc * G::WN + j * 16 + fr, ks * 4 + fg));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < G::TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < G::TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();                                    // every wave is done reading this stage
@@ -161,73 +176,77 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(Params p) {
         }
     }
 
-    // ---- epilogue: lane holds C[m = .. + fg*4 + reg][n = .. + fr]
-    // The bf16 result (C when c_bf16, else C2) is staged per wave in LDS (64 rows x 128 B, 32-B units XOR-swizzled by
-    // the 4-row group so the four lane groups of an MFMA column store land on different banks) and written out as
-    // whole 128-byte row segments.  fp32 results are stored directly (64-byte segments per lane group).
-    unsigned short* stage = reinterpret_cast<unsigned short*>(smem + wave * 8192);
-    const bool stage_c = p.C && p.c_bf16, stage_c2 = p.C2 != nullptr;
-    const bool staged = (stage_c || stage_c2) && ((p.N & 63) == 0) && (p.c_blk_cols == 0 || (p.c_blk_cols & 63) == 0);
+    // ---- epilogue.  MFMA layout: lane holds C[row = 4*fg + reg][col = fr] of each 16x16 tile.
+    // Per 16-row slab i: all TJ tiles go to the wave's private padded fp32 stage, then each lane takes CPR-aligned
+    // chunks of 8 consecutive columns of one row and applies bias / mul / add / act / casts with vector accesses.
+    float* stage = reinterpret_cast<float*>(smem + wave * G::STAGE_BYTES);
+    const int chunk = lane % G::CPR;                        // column chunk of this lane (same in every iteration)
+    const int ncol = n0 + wc * G::WN + chunk * 8;           // first of its 8 global columns
+    const bool col_ok = ncol < p.N;                         // N is a multiple of 8 (host-checked)
+    float bias8[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wc * 64 + j * 16 + fr;
-        const bool n_ok = n < p.N;
-        const float bn = (p.bias && n_ok) ? p.bias[n] : 0.f;
-        const int nb = p.c_blk_cols > 0 ? n / p.c_blk_cols : 0;
-        const int nc = p.c_blk_cols > 0 ? n - nb * p.c_blk_cols : n;
+    for (int e = 0; e < 8; ++e) bias8[e] = (p.bias && col_ok) ? p.bias[ncol + e] : 0.f;
+    const int nb = p.c_blk_cols > 0 ? ncol / p.c_blk_cols : 0;
+    const long long c_col = (long long)nb * p.c_blk_stride + (p.c_blk_cols > 0 ? ncol - nb * p.c_blk_cols : ncol);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < G::TI; ++i) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lrow = i * 16 + fg * 4 + r;                   // row inside the wave's 64x64 sub-tile
-                const int m = m0 + wr * 64 + lrow;
-                const bool ok = n_ok && m < M;
-                float v = acc[i][j][r] + bn;
-                if (ok && p.mul) v *= p.mul[(long long)m * p.ldmul + n];
-                if (ok && p.add) v += p.add[(long long)m * p.ldadd + n];
-                if (p.act == 1) v = fmaxf(v, 0.f);
-                else if (p.act == 2) v = 1.f / (1.f + __expf(-v));
-                float v2 = v;
-                if (ok && p.C2 && p.add2) v2 = v + p.add2[(long long)m * p.ldadd2 + n];
-                if (ok && p.C && !p.c_bf16) {
-                    long long o = (long long)nb * p.c_blk_stride + (long long)m * p.ldc + nc;
-                    reinterpret_cast<float*>(p.C)[o] = v;
+        for (int j = 0; j < G::TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[(fg * 4 + r) * G::SLD + j * 16 + fr] = acc[i][j][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): own LDS writes landed (wave-private region)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < G::EIT; ++it) {
+            const int lrow = (it * 64 + lane) / G::CPR;
+            const int m = m0 + wr * G::WM + i * 16 + lrow;
+            const float4 s0 = *reinterpret_cast<const float4*>(stage + lrow * G::SLD + chunk * 8);
+            const float4 s1 = *reinterpret_cast<const float4*>(stage + lrow * G::SLD + chunk * 8 + 4);
+            if (m < M && col_ok) {
+                float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+                if (p.mul) {
+                    const float4 a0 = *reinterpret_cast<const float4*>(p.mul + (long long)m * p.ldmul + ncol);
+                    const float4 a1 = *reinterpret_cast<const float4*>(p.mul + (long long)m * p.ldmul + ncol + 4);
+                    v[0] *= a0.x; v[1] *= a0.y; v[2] *= a0.z; v[3] *= a0.w; v[4] *= a1.x; v[5] *= a1.y; v[6] *= a1.z; v[7] *= a1.w;
                 }
-                if (staged) {
-                    const int lcol = j * 16 + fr;
-                    const int byte = lrow * 128 + ((lcol * 2) ^ (((lrow >> 2) & 3) << 5));
-                    stage[byte >> 1] = f32_to_bf16(stage_c2 ? v2 : v);
-                } else if (ok) {
-                    if (stage_c) {
-                        long long o = (long long)nb * p.c_blk_stride + (long long)m * p.ldc + nc;
-                        reinterpret_cast<unsigned short*>(p.C)[o] = f32_to_bf16(v);
+                if (p.add) {
+                    const float4 a0 = *reinterpret_cast<const float4*>(p.add + (long long)m * p.ldadd + ncol);
+                    const float4 a1 = *reinterpret_cast<const float4*>(p.add + (long long)m * p.ldadd + ncol + 4);
+                    v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+                }
+                if (p.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (p.act == 2) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+                }
+                if (p.C) {
+                    const long long o = c_col + (long long)m * p.ldc;
+                    if (p.c_bf16) {
+                        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.C) + o) =
+                            make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+                    } else {
+                        float* cp = reinterpret_cast<float*>(p.C) + o;
+                        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
                     }
-                    if (stage_c2) p.C2[(long long)m * p.ldc2 + n] = f32_to_bf16(v2);
+                }
+                if (p.C2) {
+                    if (p.add2) {
+                        const float4 a0 = *reinterpret_cast<const float4*>(p.add2 + (long long)m * p.ldadd2 + ncol);
+                        const float4 a1 = *reinterpret_cast<const float4*>(p.add2 + (long long)m * p.ldadd2 + ncol + 4);
+                        v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+                    }
+                    *reinterpret_cast<uint4*>(p.C2 + (long long)m * p.ldc2 + ncol) =
+                        make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
                 }
             }
         }
-    }
-    if (staged) {
-        // wave-local hand-off through LDS (each wave reads back only its own 8 KiB): LDS ops of one wave are ordered
-        __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0)
-        const int nsub = n0 + wc * 64;          // first column of this wave's sub-tile
-        unsigned short* dst;
-        long long ldd;
-        if (stage_c2) { dst = p.C2 + nsub; ldd = p.ldc2; }
-        else {
-            const int nb = p.c_blk_cols > 0 ? nsub / p.c_blk_cols : 0;
-            const int nc = p.c_blk_cols > 0 ? nsub - nb * p.c_blk_cols : nsub;
-            dst = reinterpret_cast<unsigned short*>(p.C) + (long long)nb * p.c_blk_stride + nc;
-            ldd = p.ldc;
-        }
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int lrow = it * 8 + (lane >> 3), chunk = lane & 7;
-            const int m = m0 + wr * 64 + lrow;
-            const int byte = lrow * 128 + ((chunk * 16) ^ (((lrow >> 2) & 3) << 5));
-            const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(stage) + byte);
-            if (m < M) *reinterpret_cast<uint4*>(dst + (long long)m * ldd + chunk * 8) = v;
-        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                 // own LDS reads retired before the next slab overwrites the stage
+        asm volatile("" ::: "memory");
     }
 }
 
@@ -241,12 +260,18 @@ extern "C" int mv2d_gemm_bf16(const void* A, const void* A2, int n_split, int a_
                               int ldc2, int ldadd2, void* stream) {
     MV2D_CHECK_ARG(A && W && (C || C2), "mv2d_gemm_bf16: null A/W/C");
     MV2D_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (K % BK) == 0, "mv2d_gemm_bf16: K must be a positive multiple of 64");
+    MV2D_CHECK_ARG((N % 8) == 0, "mv2d_gemm_bf16: N must be a multiple of 8");
     MV2D_CHECK_ARG(a_mode == 0 || (a_mode == 1 && K == 9 * 256 && (M % 49) == 0), "mv2d_gemm_bf16: conv3x3 mode needs K=2304, M=R*49");
     MV2D_CHECK_ARG(a_mode == 1 || (lda % 8) == 0, "mv2d_gemm_bf16: lda must be a multiple of 8 (16-byte rows)");
-    MV2D_CHECK_ARG(n_split == 0 || (A2 && (n_split % BN) == 0), "mv2d_gemm_bf16: n_split must be a multiple of 128 with A2 set");
+    MV2D_CHECK_ARG(n_split == 0 || (A2 && (n_split % 128) == 0), "mv2d_gemm_bf16: n_split must be a multiple of 128 with A2 set");
     MV2D_CHECK_ARG(!(C2 && C && c_bf16), "mv2d_gemm_bf16: with a second (bf16) output the primary output must be fp32");
-    MV2D_CHECK_ARG(((uintptr_t)C2 & 15) == 0 && (!c_bf16 || ((uintptr_t)C & 15) == 0) && (ldc2 % 8) == 0 && (!c_bf16 || (ldc % 8) == 0),
-                   "mv2d_gemm_bf16: bf16 outputs need 16-byte aligned base and row stride");
+    MV2D_CHECK_ARG(c_blk_cols == 0 || (c_blk_cols % 8) == 0, "mv2d_gemm_bf16: c_blk_cols must be a multiple of 8");
+    MV2D_CHECK_ARG(((uintptr_t)C & 15) == 0 && ((uintptr_t)C2 & 15) == 0 && ((uintptr_t)mul & 15) == 0 && ((uintptr_t)add & 15) == 0 &&
+                       ((uintptr_t)add2 & 15) == 0,
+                   "mv2d_gemm_bf16: outputs and fused operands must be 16-byte aligned");
+    MV2D_CHECK_ARG((ldc % (c_bf16 ? 8 : 4)) == 0 && (ldc2 % 8) == 0 && (ldmul % 4) == 0 && (ldadd % 4) == 0 && (ldadd2 % 4) == 0 &&
+                       (c_blk_stride % 8) == 0,
+                   "mv2d_gemm_bf16: row strides must keep 16-byte alignment");
     if (M == 0) return MV2D_OK;
     Params p;
     p.A = (const unsigned short*)A; p.A2 = (const unsigned short*)A2; p.W = (const unsigned short*)W; p.bias = bias;
@@ -254,9 +279,17 @@ extern "C" int mv2d_gemm_bf16(const void* A, const void* A2, int n_split, int a_
     p.mul = mul; p.ldmul = ldmul; p.add = add; p.ldadd = ldadd; p.C = C; p.c_bf16 = c_bf16; p.ldc = ldc;
     p.c_blk_stride = c_blk_stride; p.c_blk_cols = c_blk_cols; p.C2 = (unsigned short*)C2; p.add2 = add2;
     p.ldc2 = ldc2; p.ldadd2 = ldadd2;
-    p.n_tiles = cdiv(N, BN);
-    dim3 grid(((cdiv(M, BM) + 7) / 8) * 8 * p.n_tiles);
-    hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    // tile choice: 128x128 when that already gives >= 3 blocks per CU, else 64x64 (4x the blocks)
+    const long long big_blocks = (long long)cdiv(M, 128) * cdiv(N, 128);
+    if (big_blocks >= 768) {
+        p.n_tiles = cdiv(N, 128);
+        dim3 grid(((cdiv(M, 128) + 7) / 8) * 8 * p.n_tiles);
+        hipLaunchKernelGGL((gemm_bf16_kernel<128, 128>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        p.n_tiles = cdiv(N, 64);
+        dim3 grid(((cdiv(M, 64) + 7) / 8) * 8 * p.n_tiles);
+        hipLaunchKernelGGL((gemm_bf16_kernel<64, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
