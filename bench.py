@@ -76,22 +76,35 @@ def main():
     props = [torch.from_numpy(p) for p in prob['proposals']]
     metas = prob['img_metas']
     use_graph = not args.no_graph
-    payload = torch.zeros((args.inflight, 300 * 11 + 1), device=dev)
+    # ping-pong payload buffers: the streams free-run (no per-step join on one GPU); with N > 1 the all-gather of step k
+    # runs on the main stream behind the frames of step k while the frames of step k+1 are already executing.
+    payload = [torch.zeros((args.inflight, 300 * 11 + 1), device=dev) for _ in range(2)]
+    gathered_ev = [None, None]
+    step_no = [0]
 
     def step():
+        k = step_no[0] & 1
+        step_no[0] += 1
         cur = torch.cuda.current_stream()
-        outs = []
-        for e, s in zip(engines, streams):
-            s.wait_stream(cur)
+        done = []
+        for i, (e, s) in enumerate(zip(engines, streams)):
             with torch.cuda.stream(s):
-                outs.append(e.run(feat, props, metas, use_graph=use_graph))
-        for i, (o, s) in enumerate(zip(outs, streams)):
-            with torch.cuda.stream(s):
-                payload[i].copy_(mdist.pack_detections(o['boxes'], o['scores'], o['labels'], o['count']))
-            cur.wait_stream(s)
+                if gathered_ev[k] is not None:
+                    s.wait_event(gathered_ev[k])
+                o = e.run(feat, props, metas, use_graph=use_graph)
+                payload[k][i].copy_(mdist.pack_detections(o['boxes'], o['scores'], o['labels'], o['count']))
+                if world > 1:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    done.append(ev)
         if world > 1:
-            return mdist.gather_detections(payload)       # the one collective of an evaluation step (RCCL all-gather)
-        return payload
+            for ev in done:
+                cur.wait_event(ev)
+            out = mdist.gather_detections(payload[k])     # the one collective of an evaluation step (RCCL all-gather)
+            gathered_ev[k] = torch.cuda.Event()
+            gathered_ev[k].record()
+            return out
+        return payload[k]
 
     def barrier():
         torch.cuda.synchronize()

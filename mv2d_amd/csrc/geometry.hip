@@ -148,7 +148,9 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
                                                         float* __restrict__ out0_f32, float* __restrict__ out1_f32, int H, int W,
                                                         float spatial_scale, int sampling_ratio, const int* __restrict__ map1_index,
                                                         int out1_is_sum) {
-    const int r = blockIdx.x, c = threadIdx.x;
+    // grid (R, 7): one block per RoI and bin row, thread = channel -> 2100 blocks keep every CU busy and each
+    // thread's dependent chain is 7 bins instead of 49
+    const int r = blockIdx.x, ph = blockIdx.y, c = threadIdx.x;
     const float* b = rois + r * 5;
     const int v = (int)b[0];
     const float x1 = b[1] * spatial_scale - 0.5f, y1 = b[2] * spatial_scale - 0.5f;
@@ -160,44 +162,39 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
     const float count = (float)max(gh * gw, 1);
     const long long vbase = (long long)v * H * W;
     const int nmaps = map1 ? 2 : 1;
-    for (int ph = 0; ph < 7; ++ph) {
-        for (int pw = 0; pw < 7; ++pw) {
-            float s0 = 0.f, s1 = 0.f;
-            for (int iy = 0; iy < gh; ++iy) {
-                const float yy = y1 + ph * bh + (iy + 0.5f) * bh / gh;
-                for (int ix = 0; ix < gw; ++ix) {
-                    const float xx = x1 + pw * bw + (ix + 0.5f) * bw / gw;
-                    if (yy < -1.0f || yy > (float)H || xx < -1.0f || xx > (float)W) continue;
-                    float y = fmaxf(yy, 0.f), x = fmaxf(xx, 0.f);
-                    int yl = (int)y, xl = (int)x, yh, xh;
-                    if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
-                    if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
-                    const float ly = y - yl, lx = x - xl, hy = 1.f - ly, hx = 1.f - lx;
-                    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-                    const long long o1 = (vbase + (long long)yl * W + xl) * C + c, o2 = (vbase + (long long)yl * W + xh) * C + c;
-                    const long long o3 = (vbase + (long long)yh * W + xl) * C + c, o4 = (vbase + (long long)yh * W + xh) * C + c;
-                    s0 += w1 * map0[o1] + w2 * map0[o2] + w3 * map0[o3] + w4 * map0[o4];
-                    if (nmaps == 2) {
-                        if (map1_index) {   // map1 rows are compacted: row = map1_index[position]
-                            // rows outside the compacted list (index -1) can only be hit with weight 0; clamp to row 0
-                            const long long p1 = (long long)max(map1_index[vbase + (long long)yl * W + xl], 0) * C + c, p2 = (long long)max(map1_index[vbase + (long long)yl * W + xh], 0) * C + c;
-                            const long long p3 = (long long)max(map1_index[vbase + (long long)yh * W + xl], 0) * C + c, p4 = (long long)max(map1_index[vbase + (long long)yh * W + xh], 0) * C + c;
-                            s1 += w1 * map1[p1] + w2 * map1[p2] + w3 * map1[p3] + w4 * map1[p4];
-                        } else {
-                            s1 += w1 * map1[o1] + w2 * map1[o2] + w3 * map1[o3] + w4 * map1[o4];
-                        }
+    for (int pw = 0; pw < 7; ++pw) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int iy = 0; iy < gh; ++iy) {
+            const float yy = y1 + ph * bh + (iy + 0.5f) * bh / gh;
+            for (int ix = 0; ix < gw; ++ix) {
+                const float xx = x1 + pw * bw + (ix + 0.5f) * bw / gw;
+                if (yy < -1.0f || yy > (float)H || xx < -1.0f || xx > (float)W) continue;
+                float y = fmaxf(yy, 0.f), x = fmaxf(xx, 0.f);
+                int yl = (int)y, xl = (int)x, yh, xh;
+                if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+                if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+                const float ly = y - yl, lx = x - xl, hy = 1.f - ly, hx = 1.f - lx;
+                const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                const long long q1 = vbase + (long long)yl * W + xl, q2 = vbase + (long long)yl * W + xh;
+                const long long q3 = vbase + (long long)yh * W + xl, q4 = vbase + (long long)yh * W + xh;
+                s0 += w1 * map0[q1 * C + c] + w2 * map0[q2 * C + c] + w3 * map0[q3 * C + c] + w4 * map0[q4 * C + c];
+                if (nmaps == 2) {
+                    long long p1 = q1, p2 = q2, p3 = q3, p4 = q4;
+                    if (map1_index) {   // map1 rows are compacted: row = map1_index[position]; -1 rows only ever carry weight 0
+                        p1 = max(map1_index[q1], 0); p2 = max(map1_index[q2], 0); p3 = max(map1_index[q3], 0); p4 = max(map1_index[q4], 0);
                     }
+                    s1 += w1 * map1[p1 * C + c] + w2 * map1[p2 * C + c] + w3 * map1[p3 * C + c] + w4 * map1[p4 * C + c];
                 }
             }
-            const long long o = ((long long)r * 49 + ph * 7 + pw) * C + c;
-            s0 = s0 / count;
-            if (out0) out0[o] = f32_to_bf16(s0);
-            if (out0_f32) out0_f32[o] = s0;
-            if (nmaps == 2) {
-                s1 = s1 / count;
-                if (out1) out1[o] = f32_to_bf16(out1_is_sum ? s0 + s1 : s1);
-                if (out1_f32) out1_f32[o] = s1;
-            }
+        }
+        const long long o = ((long long)r * 49 + ph * 7 + pw) * C + c;
+        s0 = s0 / count;
+        if (out0) out0[o] = f32_to_bf16(s0);
+        if (out0_f32) out0_f32[o] = s0;
+        if (nmaps == 2) {
+            s1 = s1 / count;
+            if (out1) out1[o] = f32_to_bf16(out1_is_sum ? s0 + s1 : s1);
+            if (out1_f32) out1_f32[o] = s1;
         }
     }
 }
@@ -356,18 +353,37 @@ __global__ __launch_bounds__(1024) void csr_scan_positions_kernel(const unsigned
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) carry = 0;
     __syncthreads();
-    for (int base = 0; base < P; base += 1024) {
-        const int i = base + tid;
-        const int f = (i < P && roi_mask[i] && !pad_mask[i]) ? 1 : 0;
-        const unsigned long long bal = __ballot(f);
-        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wv] = __popcll(bal);
+    // every thread owns 16 consecutive cells per sweep (P is a multiple of 16 bytes only by luck: guard the tail)
+    for (int base = 0; base < P; base += 1024 * 16) {
+        const int i0 = base + tid * 16;
+        unsigned int bits = 0u;
+        if (i0 + 15 < P && ((P & 15) == 0)) {
+            const uint4 a = *reinterpret_cast<const uint4*>(roi_mask + i0);
+            const uint4 b = *reinterpret_cast<const uint4*>(pad_mask + i0);
+            const unsigned int aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const unsigned int ra = (aw[k >> 2] >> ((k & 3) * 8)) & 0xffu, pb = (bw[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+                bits |= ((ra != 0u && pb == 0u) ? 1u : 0u) << k;
+            }
+        } else {
+            for (int k = 0; k < 16; ++k) { const int i = i0 + k; if (i < P && roi_mask[i] && !pad_mask[i]) bits |= 1u << k; }
+        }
+        const int cnt = __popc(bits);
+        int sc = cnt;                                        // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(sc, o, 64); if (lane >= o) sc += t; }
+        if (lane == 63) wsum[wv] = sc;
         __syncthreads();
-        int off = carry;
+        int off = carry + sc - cnt;
         for (int k = 0; k < wv; ++k) off += wsum[k];
-        if (i < P) {
-            pos2s[i] = f ? off + pre : -1;
-            if (f) s2pos[off + pre] = i;
+        for (int k = 0; k < 16; ++k) {
+            const int i = i0 + k;
+            if (i < P) {
+                const bool f = (bits >> k) & 1u;
+                pos2s[i] = f ? off : -1;
+                if (f) { s2pos[off] = i; ++off; }
+            }
         }
         __syncthreads();
         if (tid == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; carry += t; }
@@ -459,21 +475,24 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const unsigned int* __res
 // correlated RoI in (view, rank) order (RH/mv2d_s_head.py:184-192 + box_correlation.py:165-193).
 __global__ __launch_bounds__(1024) void csr_from_corr_kernel(const int* __restrict__ match, int* __restrict__ row_ptr, int* __restrict__ col_idx,
                                                              int* __restrict__ nnz_out, int R, int V, int topk) {
-    __shared__ int cnts[1024];
+    __shared__ int wsum[16];
     __shared__ int carry;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) carry = 0;
     __syncthreads();
     for (int base = 0; base < R; base += 1024) {
         const int r = base + tid;
         int n = 0;
         if (r < R) { n = 1; for (int j = 0; j < V * topk; ++j) n += match[(long long)r * V * topk + j] >= 0 ? 1 : 0; }
-        cnts[tid] = n * 49;
+        const int cnt = n * 49;
+        int sc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(sc, o, 64); if (lane >= o) sc += t; }
+        if (lane == 63) wsum[wv] = sc;
         __syncthreads();
-        if (tid == 0) { int acc = carry; for (int k = 0; k < 1024; ++k) { int t = cnts[k]; cnts[k] = acc; acc += t; } carry = acc; }
-        __syncthreads();
+        int o = carry + sc - cnt;
+        for (int k = 0; k < wv; ++k) o += wsum[k];
         if (r < R) {
-            int o = cnts[tid];
             row_ptr[r] = o;
             for (int c = 0; c < 49; ++c) col_idx[o++] = r * 49 + c;
             for (int j = 0; j < V * topk; ++j) {
@@ -481,6 +500,8 @@ __global__ __launch_bounds__(1024) void csr_from_corr_kernel(const int* __restri
                 if (m >= 0) for (int c = 0; c < 49; ++c) col_idx[o++] = m * 49 + c;
             }
         }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; carry += t; }
         __syncthreads();
     }
     if (tid == 0) { row_ptr[R] = carry; *nnz_out = carry; }
@@ -546,33 +567,75 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(const float* __restri
                                                            float* __restrict__ boxes, float* __restrict__ scores, long long* __restrict__ labels,
                                                            long long* __restrict__ bbox_index, int* __restrict__ count_out,
                                                            long long* __restrict__ topk_index_dbg) {
-    extern __shared__ unsigned long long keys[];
+    // keys: 64-bit (monotone logit bits << 32 | ~index) -> all distinct, "larger" = higher logit, then LOWER index.
+    // 1) 8 rounds of 8-bit radix select find the K-th largest key; 2) the K survivors are ranked by counting
+    //    (K^2 compares spread over 1024 threads) — no full sort of the R*ncls candidates.
+    extern __shared__ unsigned long long keys[];               // [n] all keys, then [1024] survivors
+    __shared__ int hist[256];
+    __shared__ unsigned long long prefix_s;
+    __shared__ int want_s, nsel;
     __shared__ int kept_off[1025];
     const int tid = threadIdx.x, n = R * ncls;
-    for (int i = tid; i < npow2; i += 1024) {
-        unsigned long long k = 0ull;                      // padding sorts last
-        if (i < n) {
-            unsigned int u = __float_as_uint(cls[i]);
-            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);           // monotone float -> uint
-            k = ((unsigned long long)u << 32) | (unsigned int)(0xffffffffu - (unsigned int)i);
+    const int K = min(max_num, n);
+    unsigned long long* sel = keys + npow2;
+    for (int i = tid; i < n; i += 1024) {
+        unsigned int u = __float_as_uint(cls[i]);
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);           // monotone float -> uint
+        keys[i] = ((unsigned long long)u << 32) | (unsigned int)(0xffffffffu - (unsigned int)i);
+    }
+    if (tid == 0) { prefix_s = 0ull; want_s = K; nsel = 0; }
+    __syncthreads();
+    // radix select over the 32 logit bits (4 rounds); the bin holding the K-th element is found by one wave with a
+    // suffix scan over 256 bins (4 bins per lane)
+    for (int shift = 56; shift >= 32; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned long long prefix = prefix_s;
+        const unsigned long long mask_hi = shift == 56 ? 0ull : (~0ull << (shift + 8));
+        for (int i = tid; i < n; i += 1024) {
+            const unsigned long long k = keys[i];
+            if ((k & mask_hi) == prefix) atomicAdd(&hist[(int)((k >> shift) & 0xffull)], 1);
         }
-        keys[i] = k;
+        __syncthreads();
+        if (tid < 64) {
+            const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const int s4 = h0 + h1 + h2 + h3;
+            int suf = s4;                                   // inclusive suffix sum over lanes tid..63
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_down(suf, o, 64); if (tid + o < 64) suf += t; }
+            const int want = want_s;
+            const unsigned long long bal = __ballot(suf >= want);
+            const int hit = 63 - __clzll(bal);              // highest lane whose suffix still covers `want`
+            if (tid == hit) {
+                int w = want - (suf - s4);                  // still wanted inside this lane's 4 bins
+                int b = 4 * tid + 3;
+                const int hh[4] = {h0, h1, h2, h3};
+                for (int e = 3; e > 0; --e) { if (hh[e] >= w) break; w -= hh[e]; --b; }
+                prefix_s = prefix | ((unsigned long long)b << shift);
+                want_s = w;
+            }
+        }
+        __syncthreads();
+    }
+    const unsigned long long kth_hi = prefix_s;                   // upper 32 bits of the K-th largest key
+    for (int i = tid; i < n; i += 1024) {
+        const unsigned long long k = keys[i];
+        if ((k & 0xffffffff00000000ull) >= kth_hi) { const int slot = atomicAdd(&nsel, 1); if (slot < 1024) sel[slot] = k; }
     }
     __syncthreads();
-    for (int k2 = 2; k2 <= npow2; k2 <<= 1) {
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < npow2; i += 1024) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = keys[i], b = keys[ixj];
-                    const bool desc = (i & k2) == 0;
-                    if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
+    // rank by counting among the survivors (K plus, rarely, a few equal-logit candidates; ties resolved by the low
+    // 32 bits = lower index first); ranks >= K are dropped
+    const int ns = min(nsel, 1024);
+    unsigned long long mine = 0ull;
+    int rank = 1 << 30;
+    if (tid < ns) {
+        mine = sel[tid];
+        rank = 0;
+        for (int j = 0; j < ns; ++j) rank += sel[j] > mine ? 1 : 0;
     }
-    const int K = min(max_num, n);
+    __syncthreads();
+    if (rank < K) keys[rank] = mine;                              // keys[0..K) now sorted descending
+    __syncthreads();
     // ---- gather + denormalise + centre-range filter, kept entries keep their rank order
     int keep = 0;
     float bx[9]; float sc = 0.f; int idx = 0;
@@ -587,10 +650,17 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(const float* __restri
         bx[6] = atan2f(bp[6], bp[7]); bx[7] = bp[8]; bx[8] = bp[9];
         keep = (bx[0] >= r0 && bx[1] >= r1 && bx[2] >= r2 && bx[0] <= r3 && bx[1] <= r4 && bx[2] <= r5) ? 1 : 0;
     }
-    kept_off[tid] = keep;
-    __syncthreads();
-    if (tid == 0) { int acc = 0; for (int i = 0; i < 1024; ++i) { int t = kept_off[i]; kept_off[i] = acc; acc += t; } kept_off[1024] = acc; *count_out = acc; }
-    __syncthreads();
+    // exclusive scan of the keep flags over 1024 threads (wave ballots)
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) hist[wv] = __popcll(bal);
+        __syncthreads();
+        int off = 0;
+        for (int k = 0; k < wv; ++k) off += hist[k];
+        kept_off[tid] = off + __popcll(bal & ((1ull << lane) - 1ull));
+        if (tid == 1023) { *count_out = kept_off[tid] + keep; }
+    }
     if (keep) {
         const int o = kept_off[tid];
         bx[2] = bx[2] - bx[5] * 0.5f;                       // gravity centre -> bottom centre (:372)
@@ -649,7 +719,7 @@ extern "C" int mv2d_roi_align(const float* map0, const float* map1, const float*
     MV2D_CHECK_ARG(map0 && rois && channels == C, "mv2d_roi_align: needs 256-channel position-major maps");
     MV2D_CHECK_ARG(out0 || out0_f32, "mv2d_roi_align: no output");
     if (R == 0) return MV2D_OK;
-    hipLaunchKernelGGL(roi_align_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, map0, map1, rois, (unsigned short*)out0,
+    hipLaunchKernelGGL(roi_align_kernel, dim3(R, 7), dim3(256), 0, (hipStream_t)stream, map0, map1, rois, (unsigned short*)out0,
                        (unsigned short*)out1, out0_f32, out1_f32, H, W, spatial_scale, sampling_ratio, map1_index, out1_is_sum);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
@@ -736,10 +806,10 @@ extern "C" int mv2d_decode_topk(const float* cls, const float* reg, int R, int n
     MV2D_CHECK_ARG(n > 0 && n <= 16384, "mv2d_decode_topk: R*num_classes must be in [1, 16384]");
     int npow2 = 1024;
     while (npow2 < n) npow2 <<= 1;
-    const size_t lds = (size_t)npow2 * 8;
+    const size_t lds = (size_t)(npow2 + 1024) * 8;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)decode_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+        hipFuncSetAttribute((const void*)decode_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (16384 + 1024) * 8);
         attr_set = true;
     }
     hipLaunchKernelGGL(decode_topk_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, cls, reg, R, num_classes, max_num, npow2,
