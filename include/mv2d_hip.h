@@ -56,6 +56,12 @@ int mv2d_gemm_f32(const float* A, const float* A2, int n_split, const float* W, 
                   long long c_slice_stride, int groups, long long a_gs, long long w_gs, long long b_gs, long long c_gs,
                   void* stream);
 
+/* Fused FFN partial sums (mmcv FFN 256 -> hidden -> 256 of the decoder layer, configs/mv2d/exp/*:78-79):
+ * slabs[s] = relu(X . W1[64s:64s+64]^T + b1[64s:64s+64]) . W2[:, 64s:64s+64]^T  for the hidden/64 slices s, exact fp32.
+ * X [M,256], W1 [hidden,256], W2 [256,hidden], slabs [hidden/64, M, 256]; the caller sums the slabs + b2 + residual
+ * (mv2d_row_ln with n_parts = hidden/64) — fixed summation order, deterministic. */
+int mv2d_ffn_fused(const float* X, const float* W1, const float* b1, const float* W2, float* slabs, int M, int hidden, void* stream);
+
 /* ---- row-wise ops on the [M,256] query state ------------------------------------------------------------- */
 
 /* y = [ReLU] [LayerNorm]( sum_z parts[z] + bias + residual );  out = y;  out_plus = y + addvec;  out2 = LN2(y).

@@ -15,6 +15,7 @@
 // Grid: (N/32, M/32, groups*split_k) blocks of 2x2 waves -> 304 waves for a 300x256 output.
 // split-K slices are written as separate partial slabs that the following row kernel sums in a fixed order.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -34,57 +35,72 @@ struct Params {
     long long a_gs, w_gs, b_gs, c_gs;   // per-group element strides (grouped GEMM: one weight set per decoder layer)
 };
 
+template <int NT>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(Params p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int m0 = blockIdx.y * 32 + (wave >> 1) * 16, n0 = blockIdx.x * 32 + (wave & 1) * 16;
+    const int m0 = blockIdx.y * 32 + (wave >> 1) * 16, n0 = blockIdx.x * (32 * NT) + (wave & 1) * (16 * NT);
     if (m0 >= p.M || n0 >= p.N) return;
     const int grp = blockIdx.z / p.split_k, slice = blockIdx.z - grp * p.split_k;
     const int kbeg = slice * p.k_chunk, kend = min(p.K, kbeg + p.k_chunk);
     const float* Abase = ((p.n_split > 0 && n0 >= p.n_split) ? p.A2 : p.A) + grp * p.a_gs;
     const int arow = min(m0 + fr, p.M - 1);
-    const bool wok = (n0 + fr) < p.N;
     const float* ap = Abase + (long long)arow * p.lda + 4 * fg;
-    const float* wp = p.W + grp * p.w_gs + (long long)(wok ? n0 + fr : p.N - 1) * p.ldw + 4 * fg;
+    const float* wp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int wrow = n0 + 16 * t + fr;
+        wp[t] = p.W + grp * p.w_gs + (long long)(wrow < p.N ? wrow : p.N - 1) * p.ldw + 4 * fg;
+    }
 
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     for (int k0 = kbeg; k0 < kend; k0 += KP) {
         const int nch = min(NCH, (kend - k0) / 16);     // k ranges are multiples of 32 -> whole 16-chunks
-        float4 a[NCH], w[NCH];
+        float4 a[NCH], w[NT][NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             if (c < nch) {
                 a[c] = *reinterpret_cast<const float4*>(ap + k0 + 16 * c);
-                w[c] = *reinterpret_cast<const float4*>(wp + k0 + 16 * c);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) w[t][c] = *reinterpret_cast<const float4*>(wp[t] + k0 + 16 * c);
             } else {
                 a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                w[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) w[t][c] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].x, w[c].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].y, w[c].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].z, w[c].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].w, w[c].w, acc, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].x, w[t][c].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].y, w[t][c].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].z, w[t][c].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].w, w[t][c].w, acc[t], 0, 0, 0);
+            }
         }
     }
 
-    // lane holds C[m = m0 + 4*fg + r][n = n0 + fr]
-    const int n = n0 + fr;
-    if (n >= p.N) return;
+    // lane holds C[m = m0 + 4*fg + r][n = n0 + 16t + fr]
     unsigned char* Cz = reinterpret_cast<unsigned char*>(p.C) + ((long long)slice * p.c_slice_stride + grp * p.c_gs) * (p.c_bf16 ? 2 : 4);
-    const float bn = (p.bias && slice == 0) ? p.bias[grp * p.b_gs + n] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = m0 + fg * 4 + r;
-        if (m >= p.M) continue;
-        float v = (acc[r] + bn) * p.scale;
-        if (p.act == 1) v = fmaxf(v, 0.f);
-        if (p.clamp > 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
-        const long long o = (long long)m * p.ldc + n;
-        if (p.c_bf16) reinterpret_cast<unsigned short*>(Cz)[o] = f32_to_bf16(v);
-        else reinterpret_cast<float*>(Cz)[o] = v;
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + 16 * t + fr;
+        if (n >= p.N) continue;
+        const float bn = (p.bias && slice == 0) ? p.bias[grp * p.b_gs + n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + fg * 4 + r;
+            if (m >= p.M) continue;
+            float v = (acc[t][r] + bn) * p.scale;
+            if (p.act == 1) v = fmaxf(v, 0.f);
+            if (p.clamp > 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
+            const long long o = (long long)m * p.ldc + n;
+            if (p.c_bf16) reinterpret_cast<unsigned short*>(Cz)[o] = f32_to_bf16(v);
+            else reinterpret_cast<float*>(Cz)[o] = v;
+        }
     }
 }
 
@@ -106,8 +122,16 @@ extern "C" int mv2d_gemm_f32(const float* A, const float* A2, int n_split, const
     p.A = A; p.A2 = A2; p.n_split = n_split; p.W = W; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw;
     p.k_chunk = K / split_k; p.act = act; p.scale = scale; p.C = C; p.c_bf16 = c_bf16; p.ldc = ldc;
     p.c_slice_stride = c_slice_stride;
-    dim3 grid(cdiv(N, 32), cdiv(M, 32), split_k * groups);
-    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    // wide outputs: two column tiles per wave share one A fragment (half the A requests, half the waves)
+    static const int nt_env = getenv("MV2D_F32_NT") ? atoi(getenv("MV2D_F32_NT")) : 0;
+    const int nt = nt_env ? nt_env : ((N >= 1024 && n_split == 0) ? 2 : 1);
+    if (nt == 2) {
+        dim3 grid(cdiv(N, 64), cdiv(M, 32), split_k * groups);
+        hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        dim3 grid(cdiv(N, 32), cdiv(M, 32), split_k * groups);
+        hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

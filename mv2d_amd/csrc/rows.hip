@@ -38,9 +38,21 @@ __global__ __launch_bounds__(256) void row_ln_kernel(LnParams p) {
     const int lane = threadIdx.x & 63, c0 = lane * 4;
     const int goff = p.rows_per_group > 0 ? (row / p.rows_per_group) * C : 0;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < p.n_parts; ++s) {
-        float4 t = *reinterpret_cast<const float4*>(p.parts + s * p.part_stride + (long long)row * C + c0);
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    {
+        // partial slabs: 8 loads in flight per step; the summation ORDER stays s = 0, 1, 2, ... (deterministic)
+        const float* pp = p.parts + (long long)row * C + c0;
+        int s = 0;
+        for (; s + 8 <= p.n_parts; s += 8) {
+            float4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const float4*>(pp + (s + j) * p.part_stride);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
+        }
+        for (; s < p.n_parts; ++s) {
+            const float4 t = *reinterpret_cast<const float4*>(pp + s * p.part_stride);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
     }
     if (p.bias) {
         float4 t = *reinterpret_cast<const float4*>(p.bias + goff + c0);

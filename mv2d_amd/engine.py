@@ -178,7 +178,7 @@ class HeadEngine:
         ws['KV'] = e((2 * L, ws['S_kv'], C), BF16)
         for n in ('x', 'xq', 'x1', 'x1q', 'x2', 'ctx', 'o', 'q'):
             ws[n] = e((R, C))
-        ws['qkv'] = e((R, 3 * C)); ws['hdn'] = e((R, 2048)); ws['parts'] = e((8, R, C)); ws['outs'] = e((L, R, C))
+        ws['qkv'] = e((R, 3 * C)); ws['hdn'] = e((R, 2048)); ws['parts'] = e((2048 // 64, R, C)); ws['outs'] = e((L, R, C))
         ws['hc1'] = e((L, R, C)); ws['hc2'] = e((L, R, C)); ws['cls'] = e((L, R, 10)); ws['reg'] = e((L, R, 10))
         ws['boxes'] = z((self.max_num, 9)); ws['scores'] = z(self.max_num)
         ws['labels'] = z(self.max_num, torch.int64); ws['bbox_index'] = z(self.max_num, torch.int64); ws['count'] = z(1, torch.int32)
@@ -350,9 +350,8 @@ class HeadEngine:
             o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R)
             o.gemm_f32(ws['ctx'], W_[f'ca_out_w{i}'], W_[f'ca_out_b{i}'], out=ws['o'])
             o.row_ln(ws['o'], residual=ws['x1'], ln=(W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), out=ws['x2'])
-            o.gemm_f32(ws['x2'], W_[f'ffn_w1{i}'], W_[f'ffn_b1{i}'], act=1, out=ws['hdn'])
-            o.gemm_f32(ws['hdn'], W_[f'ffn_w2{i}'], W_[f'ffn_b2{i}'], split_k=8, out=ws['parts'])
-            o.row_ln(ws['parts'], residual=ws['x2'], ln=(W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), out=x, addvec=ws['qpos'], out_plus=xq,
+            o.ffn_fused(ws['x2'], W_[f'ffn_w1{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2{i}'], ws['parts'], R)
+            o.row_ln(ws['parts'], bias=W_[f'ffn_b2{i}'], residual=ws['x2'], ln=(W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), out=x, addvec=ws['qpos'], out_plus=xq,
                      ln2=(W_['post_w'], W_['post_b']), out2=ws['outs'][i])
 
     def _enqueue_heads(self, ws, R, dt):

@@ -83,6 +83,17 @@ def gemm_f32(A, W, bias=None, *, A2=None, n_split=0, split_k=1, act=0, scale=1.0
     return out
 
 
+def ffn_fused(x, W1, b1, W2, slabs=None, M=None):
+    """slabs [hidden/64, M, 256] of partial FFN outputs (sum them + b2 + residual with row_ln)."""
+    _req(x, torch.float32, 'x'); _req(W1, torch.float32, 'W1'); _req(W2, torch.float32, 'W2'); _req(b1, torch.float32, 'b1')
+    M = x.shape[0] if M is None else M
+    hidden = W1.shape[0]
+    if slabs is None:
+        slabs = torch.empty((hidden // 64, M, 256), device=x.device, dtype=torch.float32)
+    check(_lib.load().mv2d_ffn_fused(_p(x), _p(W1), _p(b1), _p(W2), _p(slabs), M, hidden, _stream()), 'mv2d_ffn_fused')
+    return slabs
+
+
 def row_ln(parts, *, bias=None, residual=None, ln=None, relu=False, out=None, addvec=None, out_plus=None, ln2=None, out2=None,
            M=None, eps=1e-5, rows_per_group=0):
     """y = [relu][LN](sum parts + bias + residual); parts [M,256] or [Z,M,256]."""

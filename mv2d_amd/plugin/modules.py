@@ -201,13 +201,12 @@ class FFN(nn.Module):
         shp = x.shape
         xr = _rows(x)
         fc1, fc2 = self.layers[0][0], self.layers[1]
-        hdn = ops.gemm_f32(xr, _f(fc1.weight), _f(fc1.bias), act=1)
-        sk = 8 if fc2.weight.shape[1] % 256 == 0 else 1
-        parts = ops.gemm_f32(hdn, _f(fc2.weight), _f(fc2.bias), split_k=sk)
+        assert fc1.weight.shape[0] % 64 == 0
+        parts = ops.ffn_fused(xr, _f(fc1.weight), _f(fc1.bias), _f(fc2.weight))
         if not self.add_identity:
-            return ops.row_ln(parts).view(shp)
+            return ops.row_ln(parts, bias=_f(fc2.bias)).view(shp)
         res = xr if identity is None else _rows(identity)
-        return ops.row_ln(parts, residual=res).view(shp)
+        return ops.row_ln(parts, bias=_f(fc2.bias), residual=res).view(shp)
 
 
 class _AttnBase(nn.Module):

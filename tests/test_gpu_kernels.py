@@ -118,6 +118,18 @@ def test_gemm_f32_a_select(dev):
     assert relerr(out, ref) < 2e-6
 
 
+def test_ffn_fused_exact(dev):
+    from mv2d_amd import ops
+    for M in (300, 33, 900):
+        x = rnd((M, 256), 27).to(dev)
+        W1 = rnd((2048, 256), 28, 0.1).to(dev); b1 = rnd((2048,), 29).to(dev)
+        W2 = rnd((256, 2048), 30, 0.05).to(dev)
+        slabs = ops.ffn_fused(x, W1, b1, W2)
+        assert slabs.shape == (32, M, 256)
+        ref = F.relu(x.double() @ W1.double().T + b1.double()) @ W2.double().T
+        assert relerr(slabs.sum(0), ref) < 2e-6
+
+
 # ------------------------------------------------------------------------------------------ rows
 def test_row_ln(dev):
     from mv2d_amd import ops
