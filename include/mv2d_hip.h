@@ -56,11 +56,34 @@ int mv2d_gemm_f32(const float* A, const float* A2, int n_split, const float* W, 
                   long long c_slice_stride, int groups, long long a_gs, long long w_gs, long long b_gs, long long c_gs,
                   void* stream);
 
+/* Row-block fused attention tail: x_out = LayerNorm(ctx . Wo^T + bo + resid); optional second stage
+ * q_out = ((x_out + qpos) . Wq^T + bq) * qscale.  Replaces out_proj + identity add of FlattenMHSelfAttention /
+ * PETRMultiheadAttention (MU/petr_transformer.py:358-370, 503-513), the following 'norm' of the mmcv layer and the query
+ * in_proj of the next cross attention.  All [M,256] fp32, weights [256,256] fp32 (nn.Linear layout). */
+int mv2d_attn_out_fused(const float* ctx, const float* resid, const float* Wo, const float* bo, const float* ln_w, const float* ln_b,
+                        float* x_out, const float* qpos, const float* Wq, const float* bq, float qscale, float* q_out, int M, float eps,
+                        void* stream);
+
+/* All per-layer prediction branches in one launch (RH/bbox_heads/cross_attention_head.py:127-146, 216-238; velocity / dt of
+ * RH/mv2d_t_head.py:136-140).  outs [L,M,256]; cls_w = {w0,b0,ln1w,ln1b,w3,b3,ln4w,ln4b,w6,b6}, reg_w = {w0,b0,w2,b2,w4,b4}: HOST
+ * arrays of device pointers, every tensor stacked over the L layers; ref [M,3]; out cls, reg [L,M,10] (reg final: sigmoid / ref /
+ * pc_range / dt applied). */
+int mv2d_heads_fused(const float* outs, const float* const* cls_w, const float* const* reg_w, const float* ref, float* cls, float* reg,
+                     int M, int L, float eps, const float* pc_range, float dt, void* stream);
+
 /* Fused FFN partial sums (mmcv FFN 256 -> hidden -> 256 of the decoder layer, configs/mv2d/exp/*:78-79):
  * slabs[s] = relu(X . W1[64s:64s+64]^T + b1[64s:64s+64]) . W2[:, 64s:64s+64]^T  for the hidden/64 slices s, exact fp32.
  * X [M,256], W1 [hidden,256], W2 [256,hidden], slabs [hidden/64, M, 256]; the caller sums the slabs + b2 + residual
  * (mv2d_row_ln with n_parts = hidden/64) — fixed summation order, deterministic. */
 int mv2d_ffn_fused(const float* X, const float* W1, const float* b1, const float* W2, float* slabs, int M, int hidden, void* stream);
+
+/* fp32-class GEMM on the bf16 matrix cores (split precision "bf16x3"): same contract as mv2d_gemm_f32 but the weights are
+ * given as the bf16 pair Whi = bf16(W), Wlo = bf16(W - Whi) (see mv2d_split_bf16x2) and A is split on the fly;
+ * relative error ~1e-5 instead of bit-exact fp32, 3/16 of the matrix-core time. */
+int mv2d_gemm_x3(const float* A, const float* A2, int n_split, const void* Whi, const void* Wlo, const float* bias, int M, int N,
+                 int K, int lda, int ldw, int split_k, int act, float scale, float clamp, void* C, int c_bf16, int ldc,
+                 long long c_slice_stride, int groups, long long a_gs, long long w_gs, long long b_gs, long long c_gs, void* stream);
+int mv2d_split_bf16x2(const float* x, void* hi, void* lo, long long n, void* stream);
 
 /* ---- row-wise ops on the [M,256] query state ------------------------------------------------------------- */
 

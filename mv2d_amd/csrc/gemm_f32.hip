@@ -53,9 +53,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(Params p) {
         wp[t] = p.W + grp * p.w_gs + (long long)(wrow < p.N ? wrow : p.N - 1) * p.ldw + 4 * fg;
     }
 
-    f32x4_t acc[NT];
+    // two accumulator chains per tile (even / odd 16-wide k chunks): the dependent-accumulator latency of
+    // v_mfma_f32_16x16x4_f32 is 40 cycles against a 32-cycle issue interval
+    f32x4_t acc[NT], accb[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) { acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accb[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
     for (int k0 = kbeg; k0 < kend; k0 += KP) {
         const int nch = min(NCH, (kend - k0) / 16);     // k ranges are multiples of 32 -> whole 16-chunks
         float4 a[NCH], w[NT][NCH];
@@ -72,16 +74,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(Params p) {
             }
         }
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
+        for (int c = 0; c < NCH; c += 2) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].x, w[t][c].x, acc[t], 0, 0, 0);
+                accb[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c + 1].x, w[t][c + 1].x, accb[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].y, w[t][c].y, acc[t], 0, 0, 0);
+                accb[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c + 1].y, w[t][c + 1].y, accb[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].z, w[t][c].z, acc[t], 0, 0, 0);
+                accb[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c + 1].z, w[t][c + 1].z, accb[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].w, w[t][c].w, acc[t], 0, 0, 0);
+                accb[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c + 1].w, w[t][c + 1].w, accb[t], 0, 0, 0);
             }
         }
     }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] += accb[t][r];
 
     // lane holds C[m = m0 + 4*fg + r][n = n0 + 16t + fr]
     unsigned char* Cz = reinterpret_cast<unsigned char*>(p.C) + ((long long)slice * p.c_slice_stride + grp * p.c_gs) * (p.c_bf16 ? 2 : 4);
@@ -124,7 +134,7 @@ extern "C" int mv2d_gemm_f32(const float* A, const float* A2, int n_split, const
     p.c_slice_stride = c_slice_stride;
     // wide outputs: two column tiles per wave share one A fragment (half the A requests, half the waves)
     static const int nt_env = getenv("MV2D_F32_NT") ? atoi(getenv("MV2D_F32_NT")) : 0;
-    const int nt = nt_env ? nt_env : ((N >= 1024 && n_split == 0) ? 2 : 1);
+    const int nt = nt_env ? nt_env : 1;
     if (nt == 2) {
         dim3 grid(cdiv(N, 64), cdiv(M, 32), split_k * groups);
         hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);

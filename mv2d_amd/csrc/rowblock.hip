@@ -1,0 +1,242 @@
+// Row-block fused kernels of the MV2D decoder (gfx950, exact fp32 MFMA): one 4-wave block owns 16 query rows and
+// chains several 256x256 linears / LayerNorms / residual adds on an activation tile that never leaves LDS.
+//
+//   mv2d_attn_out_fused  : ctx -> out_proj + bias + residual -> LayerNorm -> x_out  [-> (+query_pos) -> q in_proj * scale -> q]
+//                          (mmcv BaseTransformerLayer steps 'self_attn' tail + 'norm' + 'cross_attn' head, and 'cross_attn' tail + 'norm';
+//                           MU/petr_transformer.py:358-370, 487-513, norms of :269-311)
+//   mv2d_heads_fused     : per decoder layer, cls branch (Linear-LN-ReLU x2 + Linear) and reg branch (Linear-ReLU x2 + Linear) + the
+//                          reference-point / sigmoid / pc_range tail (RH/bbox_heads/cross_attention_head.py:216-238) and velocity / dt
+//                          (RH/mv2d_t_head.py:136-140)
+//
+// Why: the round-1 profile showed ~5 us of fixed cost per dependent kernel; these chains were 3-9 launches of 7 us each.
+// A 256x256 fp32 linear on one CU costs ~3.4 us of MFMA time (256 FLOP/clk/CU), so chains of up to ~3 linears fit.
+// Weights stream from L2 as MFMA fragments (16 float4 per lane per 16-column tile, next tile in flight behind the current one).
+#include "common.h"
+
+namespace {
+
+constexpr int C = 256;
+
+__device__ __forceinline__ int toff(int row, int col) { return row * C + ((((col >> 2) ^ (row & 15))) << 2) + (col & 3); }
+
+struct Frag { float4 v[16]; };
+
+__device__ __forceinline__ void load_w(Frag& f, const float* __restrict__ W, int ldw, int nrow, int nmax, int fg) {
+    const float* wp = W + (long long)min(nrow, nmax - 1) * ldw + 4 * fg;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) f.v[c] = *reinterpret_cast<const float4*>(wp + 16 * c);
+}
+
+__device__ __forceinline__ f32x4_t tile_mma(const float* __restrict__ As, const Frag& f, int fr, int fg) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float4 a = *reinterpret_cast<const float4*>(As + fr * C + (((4 * c + fg) ^ fr) << 2));
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, f.v[c].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, f.v[c].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, f.v[c].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, f.v[c].w, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// Out[16,256] = As[16,256] . W[256,256]^T: wave w computes columns 64w .. 64w+63 (4 tiles), results returned in registers
+__device__ __forceinline__ void linear256(const float* __restrict__ As, const float* __restrict__ W, int wave, int fr, int fg, f32x4_t acc[4]) {
+    Frag fa, fb;
+    load_w(fa, W, C, wave * 64 + fr, C, fg);
+    load_w(fb, W, C, wave * 64 + 16 + fr, C, fg);
+    acc[0] = tile_mma(As, fa, fr, fg);
+    load_w(fa, W, C, wave * 64 + 32 + fr, C, fg);
+    acc[1] = tile_mma(As, fb, fr, fg);
+    load_w(fb, W, C, wave * 64 + 48 + fr, C, fg);
+    acc[2] = tile_mma(As, fa, fr, fg);
+    acc[3] = tile_mma(As, fb, fr, fg);
+}
+
+// write the wave's 4 tiles (+bias, optional relu, optional scale) into an LDS tile
+__device__ __forceinline__ void store_tile(float* __restrict__ Ds, const f32x4_t acc[4], const float* __restrict__ bias, int wave, int fr, int fg,
+                                           bool relu, float scale) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int col = wave * 64 + 16 * t + fr;
+        const float b = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = (acc[t][r] + b) * scale;
+            if (relu) v = fmaxf(v, 0.f);
+            Ds[toff(4 * fg + r, col)] = v;
+        }
+    }
+}
+
+// load 16 rows x 256 floats (rows m0.., clamped) into an LDS tile; optional elementwise add of a second global tile
+__device__ __forceinline__ void load_rows(float* __restrict__ Ds, const float* __restrict__ G, const float* __restrict__ G2, int m0, int M, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 6, slot = idx & 63;
+        const long long g = (long long)min(m0 + row, M - 1) * C + slot * 4;
+        float4 v = *reinterpret_cast<const float4*>(G + g);
+        if (G2) { const float4 u = *reinterpret_cast<const float4*>(G2 + g); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+        *reinterpret_cast<float4*>(Ds + row * C + ((slot ^ (row & 15)) << 2)) = v;
+    }
+}
+
+// in-place LayerNorm (+ optional residual rows added first, + optional relu) of a 16x256 LDS tile; wave w owns rows 4w..4w+3.
+// Optionally writes the result rows to global (out) and a second tile / global with `addvec` rows added.
+__device__ __forceinline__ void ln_tile(float* __restrict__ Ds, const float* __restrict__ resid, const float* __restrict__ lw, const float* __restrict__ lb,
+                                        bool relu, float* __restrict__ out, const float* __restrict__ addvec, float* __restrict__ Ds_plus,
+                                        int m0, int M, int wave, int lane, float eps) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = wave * 4 + rr, m = m0 + row;
+        float* p = Ds + row * C + ((lane ^ (row & 15)) << 2);
+        float4 v = *reinterpret_cast<const float4*>(p);
+        const long long g = (long long)min(m, M - 1) * C + lane * 4;
+        if (resid) { const float4 u = *reinterpret_cast<const float4*>(resid + g); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+        const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
+        const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+        const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / C);
+        const float rstd = 1.0f / sqrtf(var + eps);
+        const float4 ww = *reinterpret_cast<const float4*>(lw + lane * 4), bb = *reinterpret_cast<const float4*>(lb + lane * 4);
+        v = make_float4(dx * rstd * ww.x + bb.x, dy * rstd * ww.y + bb.y, dz * rstd * ww.z + bb.z, dw * rstd * ww.w + bb.w);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(p) = v;
+        if (out && m < M) *reinterpret_cast<float4*>(out + g) = v;
+        if (Ds_plus) {
+            const float4 u = *reinterpret_cast<const float4*>(addvec + g);
+            *reinterpret_cast<float4*>(Ds_plus + row * C + ((lane ^ (row & 15)) << 2)) = make_float4(v.x + u.x, v.y + u.y, v.z + u.z, v.w + u.w);
+        }
+    }
+}
+
+struct AttnOutParams {
+    const float* ctx; const float* resid; const float* Wo; const float* bo; const float* lw; const float* lb;
+    float* x_out;
+    const float* qpos; const float* Wq; const float* bq; float qscale; float* q_out;     // optional second stage (Wq null -> skipped)
+    int M; float eps;
+};
+
+__global__ __launch_bounds__(256, 1) void attn_out_fused_kernel(AttnOutParams p) {
+    __shared__ __attribute__((aligned(16))) float ta[16 * C];
+    __shared__ __attribute__((aligned(16))) float tb[16 * C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int m0 = blockIdx.x * 16;
+    load_rows(ta, p.ctx, nullptr, m0, p.M, tid);
+    __syncthreads();
+    f32x4_t acc[4];
+    linear256(ta, p.Wo, wave, fr, fg, acc);
+    store_tile(tb, acc, p.bo, wave, fr, fg, false, 1.0f);
+    __syncthreads();
+    ln_tile(tb, p.resid, p.lw, p.lb, false, p.x_out, p.qpos, p.Wq ? ta : nullptr, m0, p.M, wave, lane, p.eps);
+    if (!p.Wq) return;
+    __syncthreads();
+    linear256(ta, p.Wq, wave, fr, fg, acc);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int col = wave * 64 + 16 * t + fr;
+        const float b = p.bq[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 4 * fg + r;
+            if (m < p.M) p.q_out[(long long)m * C + col] = (acc[t][r] + b) * p.qscale;
+        }
+    }
+}
+
+struct HeadsParams {
+    const float* outs;            // [L, M, 256]
+    const float* w0; const float* b0; const float* lnw1; const float* lnb1; const float* w3; const float* b3; const float* lnw4; const float* lnb4;
+    const float* w6; const float* b6;                                   // cls branch, stacked per layer
+    const float* r0; const float* rb0; const float* r2; const float* rb2; const float* r4; const float* rb4;   // reg branch
+    const float* ref;             // [M,3]
+    float* cls; float* reg;       // [L, M, 10]
+    int M, L; float eps; float pc0, pc1, pc2, pd0, pd1, pd2, dt;
+};
+
+__global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p) {
+    __shared__ __attribute__((aligned(16))) float ta[16 * C];
+    __shared__ __attribute__((aligned(16))) float tb[16 * C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int m0 = blockIdx.x * 16, l = blockIdx.y, branch = blockIdx.z;
+    const long long wl = (long long)l * C * C, bl = (long long)l * C;
+    load_rows(ta, p.outs + (long long)l * p.M * C, nullptr, m0, p.M, tid);
+    __syncthreads();
+    f32x4_t acc[4];
+    const float* wlast; const float* blast; float* outp;
+    if (branch == 0) {
+        linear256(ta, p.w0 + wl, wave, fr, fg, acc);
+        store_tile(tb, acc, p.b0 + bl, wave, fr, fg, false, 1.0f);
+        __syncthreads();
+        ln_tile(tb, nullptr, p.lnw1 + bl, p.lnb1 + bl, true, nullptr, nullptr, nullptr, m0, p.M, wave, lane, p.eps);
+        __syncthreads();
+        linear256(tb, p.w3 + wl, wave, fr, fg, acc);
+        store_tile(ta, acc, p.b3 + bl, wave, fr, fg, false, 1.0f);
+        __syncthreads();
+        ln_tile(ta, nullptr, p.lnw4 + bl, p.lnb4 + bl, true, nullptr, nullptr, nullptr, m0, p.M, wave, lane, p.eps);
+        __syncthreads();
+        wlast = p.w6 + (long long)l * 10 * C; blast = p.b6 + l * 10; outp = p.cls;
+    } else {
+        linear256(ta, p.r0 + wl, wave, fr, fg, acc);
+        store_tile(tb, acc, p.rb0 + bl, wave, fr, fg, true, 1.0f);
+        __syncthreads();
+        linear256(tb, p.r2 + wl, wave, fr, fg, acc);
+        store_tile(ta, acc, p.rb2 + bl, wave, fr, fg, true, 1.0f);
+        __syncthreads();
+        wlast = p.r4 + (long long)l * 10 * C; blast = p.rb4 + l * 10; outp = p.reg;
+    }
+    if (wave != 0) return;
+    // final Linear(256 -> 10): one 16x16 tile, weight rows >= 10 clamped and masked
+    Frag f;
+    load_w(f, wlast, C, fr, 10, fg);
+    const f32x4_t o = tile_mma(ta, f, fr, fg);
+    if (fr >= 10) return;
+    const float b = blast[fr];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 4 * fg + r;
+        if (m >= p.M) continue;
+        float v = o[r] + b;
+        if (branch == 1) {
+            // cross_attention_head.py:219-238: add inverse_sigmoid(ref) to (cx, cy) and cz, sigmoid, de-normalise; T head: v / dt
+            if (fr == 0 || fr == 1 || fr == 4) {
+                const int k = fr == 4 ? 2 : fr;
+                const float x = fminf(fmaxf(p.ref[m * 3 + k], 0.f), 1.f);
+                const float is = logf(fmaxf(x, 1e-5f) / fmaxf(1.f - x, 1e-5f));
+                const float s = 1.f / (1.f + expf(-(v + is)));
+                v = fr == 0 ? s * p.pd0 + p.pc0 : (fr == 1 ? s * p.pd1 + p.pc1 : s * p.pd2 + p.pc2);
+            } else if (fr >= 8 && p.dt != 0.f) {
+                v = v / p.dt;
+            }
+        }
+        outp[((long long)l * p.M + m) * 10 + fr] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int mv2d_attn_out_fused(const float* ctx, const float* resid, const float* Wo, const float* bo, const float* ln_w, const float* ln_b,
+                                   float* x_out, const float* qpos, const float* Wq, const float* bq, float qscale, float* q_out, int M,
+                                   float eps, void* stream) {
+    MV2D_CHECK_ARG(ctx && resid && Wo && bo && ln_w && ln_b && x_out, "mv2d_attn_out_fused: null pointer");
+    MV2D_CHECK_ARG(!Wq || (qpos && bq && q_out), "mv2d_attn_out_fused: the q stage needs qpos, bq and q_out");
+    if (M == 0) return MV2D_OK;
+    AttnOutParams p{ctx, resid, Wo, bo, ln_w, ln_b, x_out, qpos, Wq, bq, qscale, q_out, M, eps};
+    hipLaunchKernelGGL(attn_out_fused_kernel, dim3(cdiv(M, 16)), dim3(256), 0, (hipStream_t)stream, p);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_heads_fused(const float* outs, const float* const* cls_w, const float* const* reg_w, const float* ref, float* cls, float* reg,
+                                int M, int L, float eps, const float* pc_range, float dt, void* stream) {
+    // cls_w: {w0,b0,lnw1,lnb1,w3,b3,lnw4,lnb4,w6,b6} device pointers (each stacked over L layers); reg_w: {w0,b0,w2,b2,w4,b4}
+    MV2D_CHECK_ARG(outs && cls_w && reg_w && ref && cls && reg && pc_range && L > 0, "mv2d_heads_fused: null pointer");
+    for (int i = 0; i < 10; ++i) MV2D_CHECK_ARG(cls_w[i] != nullptr, "mv2d_heads_fused: null cls weight");
+    for (int i = 0; i < 6; ++i) MV2D_CHECK_ARG(reg_w[i] != nullptr, "mv2d_heads_fused: null reg weight");
+    if (M == 0) return MV2D_OK;
+    HeadsParams p{outs, cls_w[0], cls_w[1], cls_w[2], cls_w[3], cls_w[4], cls_w[5], cls_w[6], cls_w[7], cls_w[8], cls_w[9],
+                  reg_w[0], reg_w[1], reg_w[2], reg_w[3], reg_w[4], reg_w[5], ref, cls, reg, M, L, eps,
+                  pc_range[0], pc_range[1], pc_range[2], pc_range[3] - pc_range[0], pc_range[4] - pc_range[1], pc_range[5] - pc_range[2], dt};
+    hipLaunchKernelGGL(heads_fused_kernel, dim3(cdiv(M, 16), L, 2), dim3(256), 0, (hipStream_t)stream, p);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}

@@ -124,6 +124,8 @@ class HeadEngine:
         w['pe_wr'], w['pe_br'] = b16(c1('fpe.conv_reduce.weight')), g(pe + 'fpe.conv_reduce.bias')
         w['pe_we'], w['pe_be'] = b16(c1('fpe.conv_expand.weight')), g(pe + 'fpe.conv_expand.bias')
         self.w = w
+        self.cls_ptrs = ops.make_ptr_array([w[k] for k in ('cls_w0', 'cls_b0', 'cls_lnw1', 'cls_lnb1', 'cls_w3', 'cls_b3', 'cls_lnw4', 'cls_lnb4', 'cls_w6', 'cls_b6')])
+        self.reg_ptrs = ops.make_ptr_array([w[k] for k in ('reg_w0', 'reg_b0', 'reg_w2', 'reg_b2', 'reg_w4', 'reg_b4')])
 
     # ------------------------------------------------------------------------------------------ workspace
     def _workspace(self, V, h, w, R):
@@ -344,6 +346,8 @@ class HeadEngine:
         for i in range(L):
             o.gemm_f32(xq, W_[f'sa_in_w{i}'], W_[f'sa_in_b{i}'], A2=x, n_split=2 * C, out=ws['qkv'])
             o.self_attn(ws['qkv'], ws['ctx'], R)
+            # (a row-block fusion of out_proj + LN + q in_proj exists — mv2d_attn_out_fused — but 19 blocks of chained
+            #  fp32 MFMAs measured 2x slower than these N-parallel launches on MI355X)
             o.gemm_f32(ws['ctx'], W_[f'sa_out_w{i}'], W_[f'sa_out_b{i}'], out=ws['o'])
             o.row_ln(ws['o'], residual=x, ln=(W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), out=ws['x1'], addvec=ws['qpos'], out_plus=ws['x1q'])
             o.gemm_f32(ws['x1q'], W_[f'ca_q_w{i}'], W_[f'ca_q_b{i}'], scale=ops.SCALE_Q, out=ws['q'])
@@ -355,19 +359,8 @@ class HeadEngine:
                      ln2=(W_['post_w'], W_['post_b']), out2=ws['outs'][i])
 
     def _enqueue_heads(self, ws, R, dt):
-        # a14: per-layer heads, 6 layers per launch (grouped GEMMs)
-        o, W_, L = ops, self.w, self.L
-        LR = L * R
-        gk = dict(groups=L, a_gs=R * C, c_gs=R * C)
-        o.gemm_f32(ws['outs'], W_['cls_w0'], W_['cls_b0'], out=ws['hc1'], M=R, lda=C, ldc=C, **gk)
-        o.row_ln(ws['hc1'].view(LR, C), ln=(W_['cls_lnw1'], W_['cls_lnb1']), relu=True, out=ws['hc2'].view(LR, C), rows_per_group=R)
-        o.gemm_f32(ws['hc2'], W_['cls_w3'], W_['cls_b3'], out=ws['hc1'], M=R, lda=C, ldc=C, **gk)
-        o.row_ln(ws['hc1'].view(LR, C), ln=(W_['cls_lnw4'], W_['cls_lnb4']), relu=True, out=ws['hc2'].view(LR, C), rows_per_group=R)
-        o.gemm_f32(ws['hc2'], W_['cls_w6'], W_['cls_b6'], out=ws['cls'], M=R, lda=C, ldc=10, groups=L, a_gs=R * C, c_gs=R * 10)
-        o.gemm_f32(ws['outs'], W_['reg_w0'], W_['reg_b0'], act=1, out=ws['hc1'], M=R, lda=C, ldc=C, **gk)
-        o.gemm_f32(ws['hc1'], W_['reg_w2'], W_['reg_b2'], act=1, out=ws['hc2'], M=R, lda=C, ldc=C, **gk)
-        o.gemm_f32(ws['hc2'], W_['reg_w4'], W_['reg_b4'], out=ws['reg'], M=R, lda=C, ldc=10, groups=L, a_gs=R * C, c_gs=R * 10)
-        o.finalize_reg(ws['reg'], ws['ref'], L, R, self.pc_range_h, dt)
+        # a14: every per-layer cls / reg branch + the reference-point tail in ONE launch (row-block fused)
+        ops.heads_fused(ws['outs'], self.cls_ptrs, self.reg_ptrs, ws['ref'], ws['cls'], ws['reg'], R, self.L, self.pc_range_h, dt)
 
     def _result(self, ws, R, keep_stages=False):
         out = dict(R=R, ws=ws, cls=ws['cls'], reg=ws['reg'], boxes=ws['boxes'], scores=ws['scores'], labels=ws['labels'],

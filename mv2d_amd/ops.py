@@ -83,6 +83,24 @@ def gemm_f32(A, W, bias=None, *, A2=None, n_split=0, split_k=1, act=0, scale=1.0
     return out
 
 
+def attn_out_fused(ctx, resid, Wo, bo, ln, x_out, *, qpos=None, Wq=None, bq=None, qscale=1.0, q_out=None, M=None, eps=1e-5):
+    """x_out = LN(ctx @ Wo.T + bo + resid); optionally q_out = ((x_out + qpos) @ Wq.T + bq) * qscale."""
+    M = ctx.shape[0] if M is None else M
+    check(_lib.load().mv2d_attn_out_fused(_p(ctx), _p(resid), _p(Wo), _p(bo), _p(ln[0]), _p(ln[1]), _p(x_out), _p(qpos), _p(Wq), _p(bq),
+                                          float(qscale), _p(q_out), M, float(eps), _stream()), 'mv2d_attn_out_fused')
+    return x_out
+
+
+def make_ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def heads_fused(outs, cls_ptrs, reg_ptrs, ref, cls, reg, M, L, pc_range_host, dt=0.0, eps=1e-5):
+    check(_lib.load().mv2d_heads_fused(_p(outs), cls_ptrs, reg_ptrs, _p(ref), _p(cls), _p(reg), M, L, float(eps),
+                                       pc_range_host.data_ptr(), float(dt), _stream()), 'mv2d_heads_fused')
+
+
 def ffn_fused(x, W1, b1, W2, slabs=None, M=None):
     """slabs [hidden/64, M, 256] of partial FFN outputs (sum them + b2 + residual with row_ln)."""
     _req(x, torch.float32, 'x'); _req(W1, torch.float32, 'W1'); _req(W2, torch.float32, 'W2'); _req(b1, torch.float32, 'b1')
@@ -92,6 +110,41 @@ def ffn_fused(x, W1, b1, W2, slabs=None, M=None):
         slabs = torch.empty((hidden // 64, M, 256), device=x.device, dtype=torch.float32)
     check(_lib.load().mv2d_ffn_fused(_p(x), _p(W1), _p(b1), _p(W2), _p(slabs), M, hidden, _stream()), 'mv2d_ffn_fused')
     return slabs
+
+
+def split_bf16x2(w):
+    """fp32 tensor -> (hi, lo) bf16 pair with w ~= hi + lo (|err| ~ 2^-17 |w|)."""
+    _req(w, torch.float32, 'w')
+    hi = torch.empty(w.shape, device=w.device, dtype=BF16)
+    lo = torch.empty(w.shape, device=w.device, dtype=BF16)
+    check(_lib.load().mv2d_split_bf16x2(_p(w), _p(hi), _p(lo), w.numel(), _stream()), 'mv2d_split_bf16x2')
+    return hi, lo
+
+
+def gemm_x3(A, Whl, bias=None, *, A2=None, n_split=0, split_k=1, act=0, scale=1.0, clamp=0.0, out=None, out_dtype=torch.float32,
+            M=None, lda=None, ldc=None, groups=1, a_gs=0, w_gs=0, b_gs=0, c_gs=0):
+    """Same contract as gemm_f32 with Whl = split_bf16x2(W): fp32-class accuracy on the bf16 matrix cores."""
+    lib = _lib.load()
+    Whi, Wlo = Whl
+    _req(A, torch.float32, 'A'); _req(Whi, BF16, 'Whi'); _req(Wlo, BF16, 'Wlo'); _req(A2, torch.float32, 'A2'); _req(bias, torch.float32, 'bias')
+    N, K = Whi.shape[-2], Whi.shape[-1]
+    M = A.shape[-2] if M is None else M
+    lda_ = A.stride(-2) if lda is None else lda
+    if out is None:
+        shape = (split_k, M, N) if split_k > 1 else ((groups, M, N) if groups > 1 else (M, N))
+        out = torch.empty(shape, device=A.device, dtype=out_dtype)
+    ldc_ = ldc if ldc is not None else (out.stride(-2))
+    slice_stride = out.stride(0) if (split_k > 1) else 0
+    if groups > 1:
+        a_gs = a_gs or (A.stride(0) if A.dim() == 3 else 0)
+        w_gs = w_gs or Whi.stride(0)
+        b_gs = b_gs or (bias.stride(0) if bias is not None else 0)
+        c_gs = c_gs or out.stride(0)
+    rc = lib.mv2d_gemm_x3(_p(A), _p(A2), n_split, _p(Whi), _p(Wlo), _p(bias), M, N, K, lda_, Whi.stride(-2), split_k, act, float(scale),
+                          float(clamp), _p(out), 1 if out.dtype == BF16 else 0, ldc_, slice_stride, groups, a_gs, w_gs, b_gs, c_gs,
+                          _stream())
+    check(rc, 'mv2d_gemm_x3')
+    return out
 
 
 def row_ln(parts, *, bias=None, residual=None, ln=None, relu=False, out=None, addvec=None, out_plus=None, ln2=None, out2=None,

@@ -118,6 +118,42 @@ def test_gemm_f32_a_select(dev):
     assert relerr(out, ref) < 2e-6
 
 
+def test_attn_out_fused(dev):
+    from mv2d_amd import ops
+    for M in (300, 21):
+        ctx = rnd((M, 256), 41).to(dev); res = rnd((M, 256), 42).to(dev); qpos = rnd((M, 256), 43).to(dev)
+        Wo = rnd((256, 256), 44, 0.1).to(dev); bo = rnd((256,), 45).to(dev); Wq = rnd((256, 256), 46, 0.1).to(dev); bq = rnd((256,), 47).to(dev)
+        lw = rnd((256,), 48).to(dev); lb = rnd((256,), 49).to(dev)
+        x1 = torch.empty((M, 256), device=dev); q = torch.empty((M, 256), device=dev)
+        ops.attn_out_fused(ctx, res, Wo, bo, (lw, lb), x1, qpos=qpos, Wq=Wq, bq=bq, qscale=0.25, q_out=q)
+        r1 = F.layer_norm(ctx.double() @ Wo.double().T + bo.double() + res.double(), (256,), lw.double(), lb.double())
+        assert relerr(x1, r1) < 1e-5
+        assert relerr(q, ((r1 + qpos.double()) @ Wq.double().T + bq.double()) * 0.25) < 1e-5
+        x2 = torch.empty((M, 256), device=dev)
+        ops.attn_out_fused(ctx, res, Wo, bo, (lw, lb), x2)
+        assert torch.equal(x1, x2)
+
+
+def test_heads_fused(dev):
+    from mv2d_amd import ops
+    from oracle import mv2d_oracle as O
+    sd = synthetic.make_head_state(seed=0)
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    L, M = 6, 77
+    outs = rnd((L, M, 256), 51)
+    ref = torch.from_numpy(np.random.Generator(np.random.PCG64(52)).random((M, 3)).astype(np.float32)) * 1.4 - 0.2
+    cls_ref, reg_ref = O.pred_heads(sdt, outs, ref)
+    reg_ref = torch.cat([reg_ref[..., :8], reg_ref[..., 8:] / 0.5], -1)
+    st = lambda fmt: torch.stack([sdt[fmt.format(l)] for l in range(L)]).contiguous().to(dev)
+    cw = [st('bbox_head.cls_branches.{}.' + n) for n in ('0.weight', '0.bias', '1.weight', '1.bias', '3.weight', '3.bias', '4.weight', '4.bias', '6.weight', '6.bias')]
+    rw = [st('bbox_head.reg_branches.{}.' + n) for n in ('0.weight', '0.bias', '2.weight', '2.bias', '4.weight', '4.bias')]
+    cls = torch.empty((L, M, 10), device=dev); reg = torch.empty((L, M, 10), device=dev)
+    ops.heads_fused(outs.to(dev), ops.make_ptr_array(cw), ops.make_ptr_array(rw), ref.to(dev), cls, reg, M, L,
+                    torch.tensor(O.PC_RANGE, dtype=torch.float32), dt=0.5)
+    assert relerr(cls, cls_ref) < 1e-5
+    assert relerr(reg, reg_ref) < 1e-5
+
+
 def test_ffn_fused_exact(dev):
     from mv2d_amd import ops
     for M in (300, 33, 900):
