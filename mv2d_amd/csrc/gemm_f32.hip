@@ -33,6 +33,7 @@ struct Params {
     void* C; int c_bf16; int ldc; long long c_slice_stride;   // slice z writes C + z * c_slice_stride
     int split_k;                  // blockIdx.z = group * split_k + slice
     long long a_gs, w_gs, b_gs, c_gs;   // per-group element strides (grouped GEMM: one weight set per decoder layer)
+    int dbg;                      // MV2D_F32_DBG ablation: 1 = loads only (no MFMA), 2 = MFMA only (no loads), 3 = neither
 };
 
 template <int NT>
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(Params p) {
         float4 a[NCH], w[NT][NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            if (c < nch) {
+            if (c < nch && !(p.dbg & 2)) {
                 a[c] = *reinterpret_cast<const float4*>(ap + k0 + 16 * c);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) w[t][c] = *reinterpret_cast<const float4*>(wp[t] + k0 + 16 * c);
@@ -72,6 +73,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(Params p) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) w[t][c] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        }
+        if (p.dbg & 1) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t][0] += a[c].x * w[t][c].x + a[c].y * w[t][c].y + a[c].z * w[t][c].z + a[c].w * w[t][c].w;
+            continue;
         }
 #pragma unroll
         for (int c = 0; c < NCH; c += 2) {
@@ -132,6 +140,8 @@ extern "C" int mv2d_gemm_f32(const float* A, const float* A2, int n_split, const
     p.A = A; p.A2 = A2; p.n_split = n_split; p.W = W; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw;
     p.k_chunk = K / split_k; p.act = act; p.scale = scale; p.C = C; p.c_bf16 = c_bf16; p.ldc = ldc;
     p.c_slice_stride = c_slice_stride;
+    static const int dbg_env = getenv("MV2D_F32_DBG") ? atoi(getenv("MV2D_F32_DBG")) : 0;
+    p.dbg = dbg_env;
     // wide outputs: two column tiles per wave share one A fragment (half the A requests, half the waves)
     static const int nt_env = getenv("MV2D_F32_NT") ? atoi(getenv("MV2D_F32_NT")) : 0;
     const int nt = nt_env ? nt_env : 1;

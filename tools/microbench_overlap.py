@@ -45,3 +45,18 @@ def pe(e, o):
                   out=ws['KV'], ldc=256, c_blk_stride=ws['S_kv'] * 256, c_blk_cols=256)
 big = [capture(lambda e=e, o=o: pe(e, o)) for e, o in zip(engines, outs)]
 bench('big_gemms', big)
+
+# mixed: decoder graph on one stream + big GEMM graph on another (different engines' buffers)
+def mixed(nd, nb):
+    sd_ = [torch.cuda.Stream() for _ in range(nd)]; sb_ = [torch.cuda.Stream() for _ in range(nb)]
+    def run(reps):
+        for _ in range(reps):
+            for g, s in zip(dec[:nd], sd_):
+                with torch.cuda.stream(s): g.replay()
+            for g, s in zip(big[4:4 + nb], sb_):
+                with torch.cuda.stream(s):
+                    for _ in range(4): g.replay()
+    run(3); torch.cuda.synchronize()
+    t0 = time.perf_counter(); run(30); torch.cuda.synchronize(); t1 = time.perf_counter()
+    print(f'mixed: {nd} decoder graph(s) + {nb} x4 big-gemm graph(s) per round: {1e3*(t1-t0)/30:.3f} ms per round')
+mixed(1, 0); mixed(0, 1); mixed(1, 1); mixed(2, 2)
