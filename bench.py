@@ -70,6 +70,7 @@ def main():
     kind = prob['kind']
     sd = synthetic.make_head_state(seed=0)
     base = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'])
+    base.fork_qg = args.inflight == 1      # intra-frame two-stream fork helps latency, hurts when several frames are already in flight
     engines = [base] + [base.clone_shared() for _ in range(args.inflight - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)]
     feat = torch.from_numpy(prob['feat']).to(dev)

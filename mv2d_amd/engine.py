@@ -60,6 +60,7 @@ class HeadEngine:
         self.const = {k: v.to(self.dev) for k, v in calib.constant_tables().items()}
         self._ws = {}
         self.prof = None              # dict name -> [events] when stage timing is on (bench.py)
+        self.fork_qg = True           # T path: query-generator chain on a second stream
         self.load_state(state_dict)
 
     # ------------------------------------------------------------------------------------------ weights
@@ -150,18 +151,27 @@ class HeadEngine:
         ws['blob_h'] = torch.empty(off, dtype=torch.uint8).pin_memory()
         ws['blob_d'] = e(off, torch.uint8)
         ws['tab'] = {k: ws['blob_d'][o:o + n * torch.empty(0, dtype=dt).element_size()].view(dt) for k, (o, n, dt) in lay.items()}
-        ws['rois'] = e((R, 5)); ws['view_start'] = e(V + 1, torch.int32)
-        ws['rois_h'] = torch.empty((R, 5), dtype=F32).pin_memory()
-        ws['view_start_h'] = torch.empty(V + 1, dtype=torch.int32).pin_memory()
+        # per-frame dynamic inputs: RoI list + per-view offsets, one pinned staging buffer -> one H2D copy
+        dyn_words = R * 5 + (V + 1)
+        ws['dyn_h'] = torch.empty(dyn_words, dtype=torch.int32).pin_memory()
+        ws['dyn_d'] = e(dyn_words, torch.int32)
+        ws['rois_h'] = ws['dyn_h'][:R * 5].view(F32).view(R, 5)
+        ws['view_start_h'] = ws['dyn_h'][R * 5:]
+        ws['rois'] = ws['dyn_d'][:R * 5].view(F32).view(R, 5)
+        ws['view_start'] = ws['dyn_d'][R * 5:]
         ws['featcl'] = e((P, C))
         ws['enc'] = z((R, 1056)); ws['minv'] = e((R, 16))
         ws['roi_feat'] = e((R, 49, C), BF16)
         ws['conv_out'] = e((R * 49, C)); ws['enc1'] = e((R, 512)); ws['enc2'] = e((R, C)); ws['center'] = e((R, 3))
         ws['xyz'] = e((R, 3)); ws['ref'] = e((R, 3)); ws['posemb'] = e((R, 384)); ws['qe1'] = e((R, C)); ws['qpos'] = e((R, C))
         ws['match'] = e((R, V, self.topk), torch.int32)
-        ws['roi_mask'] = z(P, torch.uint8); ws['zero_mask'] = z(P, torch.uint8)
+        Pp = (P + 15) // 16 * 16
+        ws['zbuf'] = z(Pp + 16, torch.uint8)                     # roi_mask | nnz[2]: cleared by ONE fill per frame
+        ws['roi_mask'] = ws['zbuf'][:P]
+        ws['nnz'] = ws['zbuf'][Pp:Pp + 8].view(torch.int32)
+        ws['zero_mask'] = z(P, torch.uint8)
         ws['rect'] = e((R, 5), torch.int32); ws['pos2s'] = e(P, torch.int32); ws['s2pos'] = e(P, torch.int32)
-        ws['S_dev'] = z(1, torch.int32); ws['nnz'] = z(2, torch.int32)
+        ws['S_dev'] = z(1, torch.int32)
         ws['row_ptr'] = e(R + 1, torch.int32)
         if self.kind == 'T':
             ws['bits'] = e(max(ops.csr_workspace_bytes(R, V, h, w) // 4, 1), torch.int32)
@@ -233,6 +243,9 @@ class HeadEngine:
                 ts = ft['timestamps']
                 dt = float(ts[self.num_views:].mean() - ts[:self.num_views].mean())
             ws['frame_key'], ws['frame_scalars'] = key, dict(pad_h=ft['pad_h'], pad_w=ft['pad_w'], dt=dt)
+            # the calibration tables change only when img_metas change: upload them here (stream-ordered before the frame),
+            # not once per frame
+            ws['blob_d'].copy_(bh, non_blocking=True)
         ws['rois_h'].copy_(rois_h)
         ws['view_start_h'].copy_(torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32))
         sc = dict(ws['frame_scalars'])
@@ -251,9 +264,7 @@ class HeadEngine:
         P, L, T = ws['P'], self.L, ws['tab']
         tk = self._tick
         tk('h2d')
-        ws['blob_d'].copy_(ws['blob_h'], non_blocking=True)
-        ws['rois'].copy_(ws['rois_h'], non_blocking=True)
-        ws['view_start'].copy_(ws['view_start_h'], non_blocking=True)
+        ws['dyn_d'].copy_(ws['dyn_h'], non_blocking=True)
         rois = ws['rois']
         tk('transpose')
         # position-major feature map
@@ -269,15 +280,27 @@ class HeadEngine:
         o.box_correlation(rois, ws['view_start'], T['trans'], self.const['lin'], self.const['depths'], ws['match'], V, self.topk,
                           sc['pad_h'], sc['pad_w'], sc['max_per_view'], iou_thr=self.iou_thr, ratio=self.ratio)
         tk('csr')
-        ws['roi_mask'].zero_()
-        ws['nnz'].zero_()
+        ws['zbuf'].zero_()
+        # T path: the query-generator chain (RoIAlign -> conv -> fcs -> ref points -> query_pos) only needs the feature map and
+        # the per-RoI cameras, the key chain (correlation -> key list -> PE -> K/V) only the boxes: run them on two streams
+        forked = self.kind == 'T' and self.prof is None and self.fork_qg
+        if forked:
+            main = torch.cuda.current_stream()
+            side = ws.get('side_stream')
+            if side is None:
+                side = ws['side_stream'] = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'], R=R)
+                self._enqueue_qg(ws, R)
         if self.kind == 'T':
             # a11/a12: key list + CSR, then a4 RoIAlign of the feature half only
             o.mask_compact(rois, ws['match'], T['pad_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'],
                            ws['bits'], ws['row_count'], ws['row_ptr'], ws['col_idx'], ws['nnz'], R, V, h, w, self.topk,
                            self.stride, self.expand, col_cap=ws['col_cap'])
-            tk('roi_align')
-            o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'], R=R)
+            if not forked:
+                tk('roi_align')
+                o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'], R=R)
         else:
             # positions any RoIAlign tap can touch (own rect + 1 cell) -> PE only there
             o.roi_positions(rois, ws['zero_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'], R, V, h, w,
@@ -303,6 +326,33 @@ class HeadEngine:
             tk('roi_align')
             o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=ws['pos2s'],
                         out1_is_sum=True, R=R)
+        if not forked:
+            self._enqueue_qg(ws, R)
+        # a18 key side: K/V projections of all layers at once
+        tk('kv_gemm')
+        S_kv = ws['S_kv']
+        if self.kind == 'T':
+            o.gemm_bf16(ws['Xk'], W_['kv_w'], W_['kv_b'], A2=ws['Xf_b'], n_split=L * C, m_dev=md, out=ws['KV'], ldc=C,
+                        c_blk_stride=S_kv * C, c_blk_cols=C)
+        else:
+            o.gemm_bf16(ws['roi_sum'].view(R * 49, C), W_['kv_w'], W_['kv_b'], A2=ws['roi_feat'].view(R * 49, C), n_split=L * C,
+                        out=ws['KV'], ldc=C, c_blk_stride=S_kv * C, c_blk_cols=C)
+        if forked:
+            torch.cuda.current_stream().wait_stream(side)
+        # a16-a19: decoder
+        tk('decoder')
+        self._enqueue_decoder(ws, R)
+        tk('heads')
+        self._enqueue_heads(ws, R, sc['dt'])
+        tk('decode')
+        # a21: NMS-free decode of the last layer
+        o.decode_topk(ws['cls'][L - 1], ws['reg'][L - 1], R, 10, self.max_num, self.post_range_h, ws['boxes'], ws['scores'],
+                      ws['labels'], ws['bbox_index'], ws['count'])
+        tk('end')
+
+    def _enqueue_qg(self, ws, R):
+        """a6-a8, a13: QueryGenerator on the RoI features -> reference points -> query positional embedding."""
+        o, W_, tk = ops, self.w, self._tick
         # a6: QueryGenerator
         tk('qg_conv_gemm')
         o.gemm_bf16(ws['roi_feat'], W_['qg_conv_w'], W_['qg_conv_b'], conv3x3=True, act=1, out=ws['conv_out'])
@@ -316,25 +366,6 @@ class HeadEngine:
         o.refpoint_posemb(ws['center'], 3, ws['minv'], self.const['dim_t'], ws['xyz'], ws['ref'], ws['posemb'], R, self.pc_range_h)
         o.gemm_f32(ws['posemb'], W_['qe_w0'], W_['qe_b0'], act=1, out=ws['qe1'])
         o.gemm_f32(ws['qe1'], W_['qe_w2'], W_['qe_b2'], out=ws['qpos'])
-        # a18 key side: K/V projections of all layers at once
-        tk('kv_gemm')
-        S_kv = ws['S_kv']
-        if self.kind == 'T':
-            o.gemm_bf16(ws['Xk'], W_['kv_w'], W_['kv_b'], A2=ws['Xf_b'], n_split=L * C, m_dev=md, out=ws['KV'], ldc=C,
-                        c_blk_stride=S_kv * C, c_blk_cols=C)
-        else:
-            o.gemm_bf16(ws['roi_sum'].view(R * 49, C), W_['kv_w'], W_['kv_b'], A2=ws['roi_feat'].view(R * 49, C), n_split=L * C,
-                        out=ws['KV'], ldc=C, c_blk_stride=S_kv * C, c_blk_cols=C)
-        # a16-a19: decoder
-        tk('decoder')
-        self._enqueue_decoder(ws, R)
-        tk('heads')
-        self._enqueue_heads(ws, R, sc['dt'])
-        tk('decode')
-        # a21: NMS-free decode of the last layer
-        o.decode_topk(ws['cls'][L - 1], ws['reg'][L - 1], R, 10, self.max_num, self.post_range_h, ws['boxes'], ws['scores'],
-                      ws['labels'], ws['bbox_index'], ws['count'])
-        tk('end')
 
     def _enqueue_decoder(self, ws, R):
         """CrossAttentionBoxHead.forward's transformer call on already-prepared inputs (qpos, KV, CSR):
