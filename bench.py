@@ -50,6 +50,7 @@ def main():
     ap.add_argument('--inflight', type=int, default=4, help='independent frames per GPU per step (one HIP stream each)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL; gloo only for single-GPU dry runs)')
     ap.add_argument('--cpu-iters', type=int, default=3)
     ap.add_argument('--cpu-threads', type=int, default=16)
     ap.add_argument('--cpu-timeout', type=int, default=150)
@@ -60,10 +61,11 @@ def main():
     from mv2d_amd.engine import HeadEngine
     import torch.distributed as dist
 
-    rank, world, local = mdist.init_from_env()
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
+    local = int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)    # one rank per GPU
     torch.cuda.set_device(local)
+    rank, world, _ = mdist.init_from_env(backend=args.backend)
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     dev = torch.device('cuda', local)
 
     prob = synthetic.make_problem(args.workload, seed=rank)        # weak scaling: every rank its own frames

@@ -40,17 +40,20 @@ __device__ __forceinline__ f32x4_t tile_mma(const float* __restrict__ As, const 
     return acc;
 }
 
-// Out[16,256] = As[16,256] . W[256,256]^T: wave w computes columns 64w .. 64w+63 (4 tiles), results returned in registers
+// Out[16,256] = As[16,256] . W[256,256]^T: wave w computes columns 64w .. 64w+63 (4 tiles), results returned in registers.
+// All 64 weight-fragment loads of the wave (4 tiles x 16 float4 = 256 VGPRs; the kernels run one wave per SIMD) are issued before
+// the first MFMA: the weights come from the Infinity Cache (~2.5 us away) and must be waited for once, not once per tile.
 __device__ __forceinline__ void linear256(const float* __restrict__ As, const float* __restrict__ W, int wave, int fr, int fg, f32x4_t acc[4]) {
-    Frag fa, fb;
-    load_w(fa, W, C, wave * 64 + fr, C, fg);
-    load_w(fb, W, C, wave * 64 + 16 + fr, C, fg);
-    acc[0] = tile_mma(As, fa, fr, fg);
-    load_w(fa, W, C, wave * 64 + 32 + fr, C, fg);
-    acc[1] = tile_mma(As, fb, fr, fg);
-    load_w(fb, W, C, wave * 64 + 48 + fr, C, fg);
-    acc[2] = tile_mma(As, fa, fr, fg);
-    acc[3] = tile_mma(As, fb, fr, fg);
+    Frag f0, f1, f2, f3;
+    load_w(f0, W, C, wave * 64 + fr, C, fg);
+    load_w(f1, W, C, wave * 64 + 16 + fr, C, fg);
+    load_w(f2, W, C, wave * 64 + 32 + fr, C, fg);
+    load_w(f3, W, C, wave * 64 + 48 + fr, C, fg);
+    __builtin_amdgcn_sched_barrier(0);          // keep the compiler from sinking the loads back next to their MFMAs
+    acc[0] = tile_mma(As, f0, fr, fg);
+    acc[1] = tile_mma(As, f1, fr, fg);
+    acc[2] = tile_mma(As, f2, fr, fg);
+    acc[3] = tile_mma(As, f3, fr, fg);
 }
 
 // write the wave's 4 tiles (+bias, optional relu, optional scale) into an LDS tile
