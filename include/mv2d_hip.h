@@ -187,6 +187,12 @@ int mv2d_decode_topk(const float* cls, const float* reg, int R, int num_classes,
                      float* boxes, float* scores, long long* labels, long long* bbox_index, int* count_out,
                      long long* topk_index_dbg, void* stream);
 
+/* "next" row f1 — the caller's post-decoder step (mmdet3d_plugin/models/detectors/mv2d.py:265-287): mmdet3d
+ * box3d_multiclass_nms(score_thr, nms_thr = 1.0 => no suppression, max_num) + result ordering: class-major, score-descending
+ * (global score order only when more than max_num boxes survive).  in: boxes [n,9], scores [n], labels [n] int64, *count = n (<= 1024). */
+int mv2d_result_pack(const float* boxes, const float* scores, const long long* labels, const int* count, float score_thr, int max_num,
+                     float* out_boxes, float* out_scores, long long* out_labels, int* out_count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -671,6 +671,51 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// f1 ("next" row): the caller's post-decoder step (mmdet3d_plugin/models/detectors/mv2d.py:265-287): scores scattered to
+// [K, num_classes+1], mmdet3d box3d_multiclass_nms with nms_thr = 1.0 (rotated IoU can never exceed 1 -> nothing is suppressed):
+// per class, boxes with score > score_thr in descending score order, classes concatenated in ascending order; only if more than
+// max_num survive, the max_num best by score (then globally score-descending).  Single block, rank by counting (n <= 1024).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void result_pack_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, const long long* __restrict__ labels,
+                                                           const int* __restrict__ count, float score_thr, int max_num, float* __restrict__ out_boxes,
+                                                           float* __restrict__ out_scores, long long* __restrict__ out_labels, int* __restrict__ out_count) {
+    __shared__ float ss[1024];
+    __shared__ int sl[1024];
+    __shared__ int nkeep;
+    const int tid = threadIdx.x, n = min(*count, 1024);
+    const bool have = tid < n;
+    const float sc = have ? scores[tid] : 0.f;
+    const int lb = have ? (int)labels[tid] : 0;
+    const bool keep = have && sc > score_thr;
+    ss[tid] = keep ? sc : -1.f;
+    sl[tid] = keep ? lb : 1 << 20;
+    if (tid == 0) nkeep = 0;
+    __syncthreads();
+    if (keep) atomicAdd(&nkeep, 1);
+    __syncthreads();
+    const int total = nkeep;
+    if (!keep) { if (tid == 0) *out_count = min(total, max_num); return; }
+    int rank = 0;
+    if (total <= max_num) {
+        for (int j = 0; j < n; ++j) {          // (label asc, score desc, index asc)
+            const int lj = sl[j]; const float sj = ss[j];
+            rank += (lj < lb || (lj == lb && (sj > sc || (sj == sc && j < tid)))) ? 1 : 0;
+        }
+    } else {
+        for (int j = 0; j < n; ++j) {          // global score desc, index asc
+            const float sj = ss[j];
+            rank += (sl[j] < (1 << 20) && (sj > sc || (sj == sc && j < tid))) ? 1 : 0;
+        }
+    }
+    if (rank < max_num) {
+        for (int i = 0; i < 9; ++i) out_boxes[rank * 9 + i] = boxes[tid * 9 + i];
+        out_scores[rank] = sc;
+        out_labels[rank] = lb;
+    }
+    if (tid == 0) *out_count = min(total, max_num);
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -793,6 +838,16 @@ extern "C" int mv2d_pe_inputs(const int* s2pos, const int* S_dev, int S_max, con
                        (unsigned short*)Xf_bf16, Xf_f32, h, w, V * h * w, depth_num, position_range[0], position_range[1],
                        position_range[2], position_range[3] - position_range[0], position_range[4] - position_range[1],
                        position_range[5] - position_range[2]);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_result_pack(const float* boxes, const float* scores, const long long* labels, const int* count, float score_thr, int max_num,
+                                float* out_boxes, float* out_scores, long long* out_labels, int* out_count, void* stream) {
+    MV2D_CHECK_ARG(boxes && scores && labels && count && out_boxes && out_scores && out_labels && out_count, "mv2d_result_pack: null pointer");
+    MV2D_CHECK_ARG(max_num >= 1 && max_num <= 1024, "mv2d_result_pack: max_num must be in [1, 1024]");
+    hipLaunchKernelGGL(result_pack_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, boxes, scores, labels, count, score_thr, max_num,
+                       out_boxes, out_scores, out_labels, out_count);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

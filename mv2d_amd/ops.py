@@ -298,4 +298,9 @@ def decode_topk(cls, reg, R, num_classes, max_num, post_center_range_host, boxes
           'mv2d_decode_topk')
 
 
+def result_pack(boxes, scores, labels, count, score_thr, max_num, out_boxes, out_scores, out_labels, out_count):
+    check(_lib.load().mv2d_result_pack(_p(boxes), _p(scores), _p(labels), _p(count), float(score_thr), max_num, _p(out_boxes), _p(out_scores),
+                                       _p(out_labels), _p(out_count), _stream()), 'mv2d_result_pack')
+
+
 SCALE_Q = 1.0 / math.sqrt(32.0)

@@ -1,0 +1,60 @@
+"""The steps either side of the RoI-head boundary ("next" rows f1 / f2 of SURVEY.md §8(f)).
+
+* ``process_2d_detections`` — MV2D.process_2d_detections (mmdet3d_plugin/models/detectors/mv2d.py:60-86): per-class arrays of the 2-D
+  detector -> one [n,6] (x1,y1,x2,y2,score,label) tensor per view + the min_bbox_size filter.  Host-side data plumbing.
+* ``pack_results`` — the 3-D "NMS" + result packing after the head (mv2d.py:265-293).  With the shipped ``nms_thr=1.0`` mmdet3d's
+  box3d_multiclass_nms suppresses nothing (a rotated IoU never exceeds 1): it only drops scores <= score_thr, orders the boxes
+  class-major / score-descending and caps them at max_per_scene.  Runs as one tiny HIP kernel (mv2d_result_pack).
+  mmdet3d is third-party and absent from the reference tree: this row is parity-unpinned (restated from mmdet3d 1.0.0).
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+def process_2d_detections(results, device, min_bbox_size=0):
+    dets = []
+    for res in results:
+        rows = [torch.cat([torch.as_tensor(np.asarray(b), dtype=torch.float32).reshape(-1, 5),
+                           torch.full((len(b), 1), float(label_id), dtype=torch.float32)], 1) for label_id, b in enumerate(res)]
+        det = torch.cat(rows, 0) if rows else torch.zeros((0, 6))
+        if min_bbox_size > 0:
+            wh = det[:, 2:4] - det[:, 0:2]
+            det = det[(wh >= min_bbox_size).all(1)]
+        dets.append(det.to(device))
+    return dets
+
+
+def pack_results(boxes, scores, labels, count, score_thr=0.0, max_per_scene=300):
+    """boxes [n,9], scores [n], labels [n] (device, first *count valid) -> dict(boxes_3d, scores_3d, labels_3d) on the host
+    (mmdet3d bbox3d2result), ordered like box3d_multiclass_nms with nms_thr = 1.0."""
+    dev = boxes.device
+    ob = torch.zeros((max_per_scene, 9), device=dev)
+    os_ = torch.zeros(max_per_scene, device=dev)
+    ol = torch.zeros(max_per_scene, dtype=torch.int64, device=dev)
+    oc = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.result_pack(boxes.contiguous(), scores.contiguous(), labels.contiguous(), count, score_thr, max_per_scene, ob, os_, ol, oc)
+    n = int(oc.item())
+    return dict(boxes_3d=ob[:n].cpu(), scores_3d=os_[:n].cpu(), labels_3d=ol[:n].cpu())
+
+
+def simple_test_from_detections(roi_head, feat_maps, det_results, img_metas, rcnn_test_cfg, min_bbox_size=0):
+    """The part of MV2D.simple_test (mv2d.py:225-295, batch 1) that surrounds the RoI head: 2-D detector results ->
+    proposals -> head (HIP engine) -> result packing, with one host synchronisation at the very end.
+    rcnn_test_cfg: dict(score_thr, max_per_scene, nms=dict(nms_thr)) (CFG-T:154-158); nms_thr must be 1.0 (the shipped value)."""
+    nms = rcnn_test_cfg.get('nms', rcnn_test_cfg)
+    if float(nms.get('nms_thr', 1.0)) < 1.0:
+        raise NotImplementedError('rotated-IoU suppression (nms_thr < 1) is not part of the shipped configs')
+    feat = feat_maps[roi_head.feat_lvl]
+    proposals = process_2d_detections(det_results, feat.device, min_bbox_size)
+    eng = roi_head.engine(feat.device, img_metas)
+    out = eng.run(feat.float(), proposals, img_metas)
+    res = pack_results(out['boxes'], out['scores'], out['labels'], out['count'], rcnn_test_cfg.get('score_thr', 0.0),
+                       rcnn_test_cfg.get('max_per_scene', 300))
+    if int(out['ws']['nnz'][1].item()) != 0:
+        raise RuntimeError('mv2d engine: CSR capacity exceeded (raise col_cap_per_query)')
+    box_type = img_metas[0].get('box_type_3d')
+    if box_type is not None:
+        res['boxes_3d'] = box_type(res['boxes_3d'], res['boxes_3d'].size(-1))
+    return [res]

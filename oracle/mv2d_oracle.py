@@ -575,6 +575,38 @@ def decode(cls_scores, bbox_preds, max_num=300, num_classes=10, post_center_rang
 
 
 # --------------------------------------------------------------------------------------------
+# f1 ("next"): post-decoder 3-D NMS + packing (DET/mv2d.py:265-287 -> mmdet3d==1.0.0 box3d_multiclass_nms, THIRD PARTY,
+#     parity unpinned).  nms_thr = 1.0: nms_bev keeps everything in descending score order.
+# --------------------------------------------------------------------------------------------
+def post_nms_pack(boxes, scores, labels, num_classes=10, score_thr=0.0, max_num=300):
+    sc = scores.new_zeros((len(scores), num_classes + 1)).scatter_(1, labels[:, None], scores[:, None])
+    ob, os_, ol = [], [], []
+    for i in range(num_classes):
+        inds = sc[:, i] > score_thr
+        if not inds.any():
+            continue
+        s_i = sc[inds, i]
+        order = torch.argsort(s_i, descending=True, stable=True)
+        ob.append(boxes[inds][order]); os_.append(s_i[order]); ol.append(torch.full((int(inds.sum()),), i, dtype=torch.long))
+    if not ob:
+        return boxes.new_zeros((0, boxes.shape[1])), scores.new_zeros((0,)), labels.new_zeros((0,))
+    ob, os_, ol = torch.cat(ob), torch.cat(os_), torch.cat(ol)
+    if ob.shape[0] > max_num:
+        inds = torch.argsort(os_, descending=True, stable=True)[:max_num]
+        ob, os_, ol = ob[inds], os_[inds], ol[inds]
+    return ob, os_, ol
+
+
+def process_2d_detections(results, min_bbox_size=0):
+    """DET/mv2d.py:60-86."""
+    dets = [torch.cat([torch.cat([torch.tensor(b), torch.full((len(b), 1), label_id, dtype=torch.float)], dim=1)
+                       for label_id, b in enumerate(res)], dim=0) for res in results]
+    if min_bbox_size > 0:
+        dets = [d[((d[:, 2:4] - d[:, 0:2]) >= min_bbox_size).all(dim=1)] for d in dets]
+    return dets
+
+
+# --------------------------------------------------------------------------------------------
 # a1: orchestration — MV2DTHead / MV2DSHead.simple_test  (RH/mv2d_head.py:249-267)
 # --------------------------------------------------------------------------------------------
 def _to_t(sd):

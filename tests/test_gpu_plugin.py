@@ -122,3 +122,51 @@ def test_pe_roi_extractor_boxcorr_querygen_modules():
     sts = oracle(probs)
     corr, mask = heads.box_corr_module.gen_box_roi_correlation(sts['rois'].to(DEV), [len(p) for p in probs['proposals']], probs['img_metas'])
     assert torch.equal(corr.cpu(), sts['corr']) and torch.equal(mask.cpu(), sts['corr_mask'])
+
+
+def test_next_rows_postprocess_and_detection_glue():
+    """f1 / f2 of SURVEY.md §8(f): result packing after the head and the 2-D detection glue before it, vs the oracle."""
+    from mv2d_amd import postprocess
+    from oracle import mv2d_oracle as O
+    g = np.random.Generator(np.random.PCG64(7))
+    for n, max_num in ((300, 300), (180, 300), (300, 100)):
+        boxes = torch.from_numpy(g.standard_normal((n, 9)).astype(np.float32))
+        scores = torch.from_numpy(g.random(n).astype(np.float32))
+        scores[5] = scores[9]                                                         # a tie inside / across classes
+        labels = torch.from_numpy(g.integers(0, 10, n))
+        labels[9] = labels[5]
+        eb, es, el = O.post_nms_pack(boxes, scores, labels, max_num=max_num)
+        pad = lambda t, shape: torch.cat([t, t.new_zeros((300 - t.shape[0],) + shape)])
+        res = postprocess.pack_results(pad(boxes, (9,)).to(DEV), pad(scores, ()).to(DEV), pad(labels, ()).to(DEV),
+                                       torch.tensor([n], dtype=torch.int32, device=DEV), 0.0, max_num)
+        assert torch.equal(res['labels_3d'], el) and torch.equal(res['scores_3d'], es) and torch.equal(res['boxes_3d'], eb)
+    results = [[g.random((int(g.integers(0, 6)), 5)).astype(np.float32) * 200 for _ in range(10)] for _ in range(3)]
+    d_ref = O.process_2d_detections(results, 8)
+    d_got = postprocess.process_2d_detections(results, 'cpu', 8)
+    for a, b in zip(d_got, d_ref):
+        assert torch.equal(a, b)
+
+
+def test_simple_test_from_detections_end_to_end():
+    """2-D detector result lists -> proposals -> head -> packed results == oracle tail applied to the oracle head."""
+    from mv2d_amd import postprocess
+    from oracle import mv2d_oracle as O
+    prob = synthetic.make_problem('cfg1_s', seed=0)
+    head = build('S')
+    st = oracle(prob)
+    # per-view per-class arrays as a 2-D detector returns them, rebuilt from the synthetic [n,6] proposals
+    det_results = [[p[p[:, 5] == c][:, :5] for c in range(10)] for p in prob['proposals']]
+    metas = [dict(m, box_type_3d=None) for m in prob['img_metas']]
+    res = postprocess.simple_test_from_detections(head, [torch.from_numpy(prob['feat']).to(DEV)], det_results, metas, configs.TEST_CFG_RCNN)[0]
+    # proposals regrouped class-major per view: the oracle sees the same regrouped proposals
+    props = O.process_2d_detections(det_results, 0)
+    st2 = {}
+    O.forward_s(synthetic.make_head_state(seed=0), torch.from_numpy(prob['feat']), props, prob['img_metas'], stages=st2)
+    eb, es, el = O.post_nms_pack(st2['boxes'], st2['scores'], st2['labels'])
+    assert len(res['labels_3d']) == len(el)
+    assert (res['labels_3d'] == el).float().mean() > 0.95
+    assert relmax(torch.sort(res['scores_3d'])[0], torch.sort(es)[0]) < 5e-3
+    lab = res['labels_3d']
+    assert bool((lab[1:] >= lab[:-1]).all())                                          # class-major
+    same = lab[1:] == lab[:-1]
+    assert bool((res['scores_3d'][1:][same] <= res['scores_3d'][:-1][same]).all())    # score-descending inside a class
