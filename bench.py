@@ -74,7 +74,13 @@ def main():
     base = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'])
     base.fork_qg = args.inflight == 1      # intra-frame two-stream fork helps latency, hurts when several frames are already in flight
     engines = [base] + [base.clone_shared() for _ in range(args.inflight - 1)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)]
+    # frames in flight go on streams that were MEASURED to run concurrently (queue/pipe sharing serialises others)
+    from mv2d_amd.streams import concurrent_streams
+    if os.environ.get('MV2D_NAIVE_STREAMS', '0') == '1':
+        streams = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)]
+    else:
+        pool = concurrent_streams(min(args.inflight, 4), dev)
+        streams = [pool[i % len(pool)] for i in range(args.inflight)]
     feat = torch.from_numpy(prob['feat']).to(dev)
     props = [torch.from_numpy(p) for p in prob['proposals']]
     metas = prob['img_metas']

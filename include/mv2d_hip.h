@@ -26,6 +26,8 @@ extern "C" {
 const char* mv2d_last_error(void);
 int mv2d_abi_version(void);
 int mv2d_device_arch(char* buf, int buflen);
+/* calibration kernel of the stream planner: one wave spinning for usec microseconds on `stream` (no reference counterpart) */
+int mv2d_spin(int usec, void* stream);
 
 /* ---- dense contractions -------------------------------------------------------------------------------- */
 

@@ -25,3 +25,18 @@ extern "C" int mv2d_device_arch(char* buf, int buflen) {
     buf[buflen - 1] = 0;
     return MV2D_OK;
 }
+
+// Calibration kernel for the stream planner (mv2d_amd/streams.py): one wave that spins for `usec` microseconds of the
+// constant 100 MHz wall clock.  Two HIP streams whose hardware queues really run side by side finish N of these in the time
+// of N, streams multiplexed onto one queue/pipe take 2N.
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+extern "C" int mv2d_spin(int usec, void* stream) {
+    MV2D_CHECK_ARG(usec >= 0 && usec <= 100000, "mv2d_spin: usec must be in [0, 100000]");
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)usec * 100);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}

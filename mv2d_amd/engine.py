@@ -61,6 +61,8 @@ class HeadEngine:
         self._ws = {}
         self.prof = None              # dict name -> [events] when stage timing is on (bench.py)
         self.fork_qg = True           # T path: query-generator chain on a second stream
+        import os
+        self.fuse_rows = os.environ.get('MV2D_FUSE_ROWS', '0') == '1'
         self.load_state(state_dict)
 
     # ------------------------------------------------------------------------------------------ weights
@@ -379,12 +381,18 @@ class HeadEngine:
             o.self_attn(ws['qkv'], ws['ctx'], R)
             # (a row-block fusion of out_proj + LN + q in_proj exists — mv2d_attn_out_fused — but 19 blocks of chained
             #  fp32 MFMAs measured 2x slower than these N-parallel launches on MI355X)
-            o.gemm_f32(ws['ctx'], W_[f'sa_out_w{i}'], W_[f'sa_out_b{i}'], out=ws['o'])
-            o.row_ln(ws['o'], residual=x, ln=(W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), out=ws['x1'], addvec=ws['qpos'], out_plus=ws['x1q'])
-            o.gemm_f32(ws['x1q'], W_[f'ca_q_w{i}'], W_[f'ca_q_b{i}'], scale=ops.SCALE_Q, out=ws['q'])
-            o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R)
-            o.gemm_f32(ws['ctx'], W_[f'ca_out_w{i}'], W_[f'ca_out_b{i}'], out=ws['o'])
-            o.row_ln(ws['o'], residual=ws['x1'], ln=(W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), out=ws['x2'])
+            if self.fuse_rows:
+                o.attn_out_fused(ws['ctx'], x, W_[f'sa_out_w{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
+                                 qpos=ws['qpos'], Wq=W_[f'ca_q_w{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, q_out=ws['q'], M=R)
+                o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R)
+                o.attn_out_fused(ws['ctx'], ws['x1'], W_[f'ca_out_w{i}'], W_[f'ca_out_b{i}'], (W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), ws['x2'], M=R)
+            else:
+                o.gemm_f32(ws['ctx'], W_[f'sa_out_w{i}'], W_[f'sa_out_b{i}'], out=ws['o'])
+                o.row_ln(ws['o'], residual=x, ln=(W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), out=ws['x1'], addvec=ws['qpos'], out_plus=ws['x1q'])
+                o.gemm_f32(ws['x1q'], W_[f'ca_q_w{i}'], W_[f'ca_q_b{i}'], scale=ops.SCALE_Q, out=ws['q'])
+                o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R)
+                o.gemm_f32(ws['ctx'], W_[f'ca_out_w{i}'], W_[f'ca_out_b{i}'], out=ws['o'])
+                o.row_ln(ws['o'], residual=ws['x1'], ln=(W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), out=ws['x2'])
             o.ffn_fused(ws['x2'], W_[f'ffn_w1{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2{i}'], ws['parts'], R)
             o.row_ln(ws['parts'], bias=W_[f'ffn_b2{i}'], residual=ws['x2'], ln=(W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), out=x, addvec=ws['qpos'], out_plus=xq,
                      ln2=(W_['post_w'], W_['post_b']), out2=ws['outs'][i])
