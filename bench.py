@@ -41,6 +41,23 @@ def stage_flops(kind, R, S, L=6):
     }
 
 
+def stage_bytes(kind, R, S, L=6):
+    """Algorithmic HBM bytes of the same launches: A read once + weights once + output written once (bf16 = 2 B, fp32 = 4 B)."""
+    C = 256
+    Mkv = S if kind == 'T' else R * 49
+    return {
+        'pe_gemm_192x1024': S * 192 * 2 + 192 * 1024 * 2 + S * 1024 * 2,
+        'pe_gemm_384x1024': S * 384 * 2 + 384 * 1024 * 2 + S * 1024 * 2,
+        'pe_gemm_1024x256_a': S * 1024 * 2 + 1024 * 256 * 2 + S * 256 * 4 + S * 256 * 4,          # + gate operand, fp32 out
+        'pe_gemm_1024x256_b': S * 1024 * 2 + 1024 * 256 * 2 + 2 * S * 256 * 4 + S * 256 * (4 + 2),  # + add operands, fp32 + bf16 out
+        'qg_conv_gemm': R * 49 * 256 * 2 + 2304 * 256 * 2 + R * 49 * 256 * 4,
+        'kv_gemm': 2 * Mkv * C * 2 + 2 * L * C * C * 2 + Mkv * 2 * L * C * 2,
+    }
+
+
+STAGE_KERNEL = {'kv_gemm': 'kvproj_kernel', 'qg_conv_gemm': 'gemm_bf16_kernel<64,64> (implicit conv3x3)'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -157,10 +174,11 @@ def main():
     stage_ms = {}
     for a, b in zip(names[:-1], names[1:]):
         stage_ms[a] = statistics.median(x.elapsed_time(y) for x, y in zip(prof[a], prof[b]))
-    fl = stage_flops(kind, R, S)
+    fl, by = stage_flops(kind, R, S), stage_bytes(kind, R, S)
     dom = max(fl, key=lambda k: stage_ms.get(k, 0.0))
     dom_ms = stage_ms[dom]
-    achieved = fl[dom] / (dom_ms * 1e-3) / 1e12
+    tflops = fl[dom] / (dom_ms * 1e-3) / 1e12
+    gbs = by[dom] / (dom_ms * 1e-3) / 1e9
     # HBM traffic of that launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected offline with
     # tools/rocpd_pmc.py and committed under profiles/): counters cannot be read from inside this process
     traffic = None
@@ -172,9 +190,19 @@ def main():
                        'source': 'profiles/pmc_traffic.json (rocprofv3 --pmc, separate run)'}
     except Exception:
         pass
-    roofline = dict(bound='mfma', kernel=f'gemm_bf16_kernel[{dom}]', achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS,
-                    unit='TFLOP/s', frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=traffic, launch_ms=round(dom_ms, 4),
-                    flops_per_launch=fl[dom])
+    # the roofline that binds this launch is the one it sits closer to
+    f_mfma, f_hbm = tflops / PEAK_BF16_TFLOPS, gbs / PEAK_HBM_GBS
+    kname = f"{STAGE_KERNEL.get(dom, 'gemm_bf16_kernel')}[{dom}]"
+    if f_hbm > f_mfma:
+        roofline = dict(bound='hbm', kernel=kname, achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(f_hbm, 4),
+                        traffic=traffic, launch_ms=round(dom_ms, 4), bytes_per_launch=by[dom], flops_per_launch=fl[dom],
+                        mfma_frac=round(f_mfma, 4))
+    else:
+        roofline = dict(bound='mfma', kernel=kname, achieved=round(tflops, 2), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
+                        frac=round(f_mfma, 4), traffic=traffic, launch_ms=round(dom_ms, 4), flops_per_launch=fl[dom],
+                        bytes_per_launch=by[dom], hbm_frac=round(f_hbm, 4))
+    stage_roofline = {k: dict(ms=round(stage_ms[k], 4), tflops=round(fl[k] / (stage_ms[k] * 1e-3) / 1e12, 1),
+                              gbs=round(by[k] / (stage_ms[k] * 1e-3) / 1e9, 1)) for k in fl if k in stage_ms}
 
     # ---------------- decoder ms/iter (CrossAttentionBoxHead transformer on prepared inputs), hipGraph replay
     g = torch.cuda.CUDAGraph()
@@ -220,7 +248,7 @@ def main():
                        'parallelism': f'dp{world}', 'hipgraph': use_graph},
             'decoder_ms_per_iter': round(decoder_ms, 4),
             'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},
-            'roofline': roofline,
+            'roofline': roofline, 'stage_roofline': stage_roofline,
             'cpu_baseline': cpu,
         }
         print(json.dumps(line))

@@ -66,6 +66,12 @@ int mv2d_attn_out_fused(const float* ctx, const float* resid, const float* Wo, c
                         float* x_out, const float* qpos, const float* Wq, const float* bq, float qscale, float* q_out, int M, float eps,
                         void* stream);
 
+/* K/V in_proj of all decoder layers, shape-specialised (K = 256): C = A . W^T + bias, bf16 in / bf16 out, same operand and
+ * output-block conventions as mv2d_gemm_bf16 (A2 / n_split, m_dev, c_blk_stride / c_blk_cols) and bit-identical results.
+ * A rows stay in registers, W streams through a 2-stage LDS ring filled by the LDS-DMA (MU/petr_transformer.py:503-508). */
+int mv2d_kv_proj(const void* A, const void* A2, int n_split, int lda, const void* W, const float* bias, int M, int N,
+                 const int* m_dev, void* C, int ldc, long long c_blk_stride, int c_blk_cols, void* stream);
+
 /* All per-layer prediction branches in one launch (RH/bbox_heads/cross_attention_head.py:127-146, 216-238; velocity / dt of
  * RH/mv2d_t_head.py:136-140).  outs [L,M,256]; cls_w = {w0,b0,ln1w,ln1b,w3,b3,ln4w,ln4b,w6,b6}, reg_w = {w0,b0,w2,b2,w4,b4}: HOST
  * arrays of device pointers, every tensor stacked over the L layers; ref [M,3]; out cls, reg [L,M,10] (reg final: sigmoid / ref /

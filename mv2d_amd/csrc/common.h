@@ -41,8 +41,12 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
     return (unsigned short)(u >> 16);
 }
 
+// two fp32 -> packed bf16 pair with the gfx950 hardware convert (v_cvt_pk_bf16_f32, round-to-nearest-even)
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-    return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+    typedef __attribute__((ext_vector_type(2))) float f32x2_cv;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_cv;
+    const f32x2_cv v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_cv));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -17,6 +17,7 @@
 // K=256): every 16-row MFMA slab is staged per wave through padded fp32 LDS and leaves as whole rows — 8
 // consecutive columns per lane, float4 reads of the fused mul/add operands, 16-byte bf16 / 2x16-byte fp32 stores.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -281,7 +282,8 @@ extern "C" int mv2d_gemm_bf16(const void* A, const void* A2, int n_split, int a_
     p.ldc2 = ldc2; p.ldadd2 = ldadd2;
     // tile choice: 128x128 when that already gives >= 3 blocks per CU, else 64x64 (4x the blocks)
     const long long big_blocks = (long long)cdiv(M, 128) * cdiv(N, 128);
-    if (big_blocks >= 768) {
+    static const int thr_env = getenv("MV2D_BF16_BIG") ? atoi(getenv("MV2D_BF16_BIG")) : 768;
+    if (big_blocks >= thr_env) {
         p.n_tiles = cdiv(N, 128);
         dim3 grid(((cdiv(M, 128) + 7) / 8) * 8 * p.n_tiles);
         hipLaunchKernelGGL((gemm_bf16_kernel<128, 128>), grid, dim3(256), 0, (hipStream_t)stream, p);

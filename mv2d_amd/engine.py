@@ -334,11 +334,11 @@ class HeadEngine:
         tk('kv_gemm')
         S_kv = ws['S_kv']
         if self.kind == 'T':
-            o.gemm_bf16(ws['Xk'], W_['kv_w'], W_['kv_b'], A2=ws['Xf_b'], n_split=L * C, m_dev=md, out=ws['KV'], ldc=C,
-                        c_blk_stride=S_kv * C, c_blk_cols=C)
+            o.kv_proj(ws['Xk'], W_['kv_w'], W_['kv_b'], ws['KV'], A2=ws['Xf_b'], n_split=L * C, m_dev=md, ldc=C,
+                      c_blk_stride=S_kv * C, c_blk_cols=C)
         else:
-            o.gemm_bf16(ws['roi_sum'].view(R * 49, C), W_['kv_w'], W_['kv_b'], A2=ws['roi_feat'].view(R * 49, C), n_split=L * C,
-                        out=ws['KV'], ldc=C, c_blk_stride=S_kv * C, c_blk_cols=C)
+            o.kv_proj(ws['roi_sum'].view(R * 49, C), W_['kv_w'], W_['kv_b'], ws['KV'], A2=ws['roi_feat'].view(R * 49, C),
+                      n_split=L * C, ldc=C, c_blk_stride=S_kv * C, c_blk_cols=C)
         if forked:
             torch.cuda.current_stream().wait_stream(side)
         # a16-a19: decoder

@@ -58,6 +58,16 @@ def gemm_bf16(A, W, bias=None, *, M=None, A2=None, n_split=0, conv3x3=False, m_d
     return out if out is not None else out2
 
 
+def kv_proj(A, W, bias, out, *, A2=None, n_split=0, m_dev=None, M=None, ldc=None, c_blk_stride=0, c_blk_cols=0):
+    """out = A @ W.T + bias (bf16, K = 256) with the weight-streaming kernel; layer-major output blocks like gemm_bf16."""
+    _req(A, BF16, 'A'); _req(W, BF16, 'W'); _req(A2, BF16, 'A2'); _req(bias, torch.float32, 'bias'); _req(out, BF16, 'out')
+    assert W.shape[1] == 256 and A.shape[-1] == 256
+    M = A.shape[0] if M is None else M
+    check(_lib.load().mv2d_kv_proj(_p(A), _p(A2), n_split, A.stride(0), _p(W), _p(bias), M, W.shape[0], _p(m_dev), _p(out),
+                                   ldc if ldc is not None else out.stride(-2), c_blk_stride, c_blk_cols, _stream()), 'mv2d_kv_proj')
+    return out
+
+
 def gemm_f32(A, W, bias=None, *, A2=None, n_split=0, split_k=1, act=0, scale=1.0, clamp=0.0, out=None, out_dtype=torch.float32,
              M=None, lda=None, ldc=None, groups=1, a_gs=0, w_gs=0, b_gs=0, c_gs=0):
     """C = epi((A @ W.T + bias) * scale), exact fp32 MFMA.  A [M,K] fp32, W [N,K] fp32."""

@@ -440,3 +440,30 @@ def test_decode_topk_tie_order(dev):
     assert int(cnt) == 300
     assert bidx[:3].cpu().tolist() == [2, 3, 30] and labels[:3].cpu().tolist() == [1, 4, 9]
     assert bool((scores[:299] >= scores[1:300]).all())
+
+
+@pytest.mark.parametrize('M,use_mdev', [(128, False), (1000, False), (14700, False), (5000, True)])
+def test_kv_proj_bit_identical_to_tile_gemm(dev, M, use_mdev):
+    from mv2d_amd import ops
+    DEV = dev
+    """mv2d_kv_proj (A in registers, W through the LDS-DMA ring) == mv2d_gemm_bf16 bit for bit (same k order)."""
+    g = torch.Generator(device='cpu').manual_seed(M)
+    L = 6
+    A = torch.randn(M, 256, generator=g).to(DEV).bfloat16()
+    A2 = torch.randn(M, 256, generator=g).to(DEV).bfloat16()
+    W = (torch.randn(2 * L * 256, 256, generator=g) * 0.06).to(DEV).bfloat16()
+    b = torch.randn(2 * L * 256, generator=g).to(DEV)
+    m_dev = torch.tensor([M - 37], dtype=torch.int32, device=DEV) if use_mdev else None
+    ref = torch.full((2 * L, M, 256), 7.0, device=DEV, dtype=torch.bfloat16)
+    got = ref.clone()
+    ops.gemm_bf16(A, W, b, A2=A2, n_split=L * 256, m_dev=m_dev, out=ref, ldc=256, c_blk_stride=M * 256, c_blk_cols=256)
+    ops.kv_proj(A, W, b, got, A2=A2, n_split=L * 256, m_dev=m_dev, ldc=256, c_blk_stride=M * 256, c_blk_cols=256)
+    torch.cuda.synchronize()
+    assert torch.equal(ref.view(torch.int16), got.view(torch.int16))
+    # and against fp32 math
+    Mv = M - 37 if use_mdev else M
+    exp = torch.cat([A[:Mv].float() @ W[:L * 256].float().T, A2[:Mv].float() @ W[L * 256:].float().T], 1) + b
+    exp = exp.view(Mv, 2 * L, 256).permute(1, 0, 2)
+    assert (got[:, :Mv].float() - exp).abs().max() < 0.05
+    if use_mdev:
+        assert bool((got[:, Mv:].float() == 7.0).all())
