@@ -21,8 +21,7 @@
 
 namespace {
 
-constexpr int BK = 64;
-constexpr int ROW_BYTES = BK * 2;              // 128 B per LDS row
+constexpr int BK_MIN = 64;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 
@@ -44,13 +43,17 @@ struct Params {
     unsigned short* C2; const float* add2; int ldc2; int ldadd2;   // C2 = bf16(v + add2[m, n])
 };
 
-__device__ __forceinline__ int lds_off(int row, int slot) { return row * ROW_BYTES + ((slot ^ (row & 7)) << 4); }
+// LDS image: one tile row = BK bf16 (128 or 256 B) in 16-byte slots, slot index XOR-ed with the low row bits
+template <int BK>
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * (BK * 2) + ((slot ^ (row & (BK / 8 - 1))) << 4); }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 struct Cfg {
+    static constexpr int ROW_BYTES = BK * 2;
+    static constexpr int SPR = BK / 8;                        // 16-byte slots per row
     static constexpr int WM = BM / 2, WN = BN / 2;            // wave tile
     static constexpr int TI = WM / 16, TJ = WN / 16;          // MFMA tiles per wave
-    static constexpr int CA = BM / 32, CB = BN / 32;          // 16-byte staging chunks per thread
+    static constexpr int CA = BM * SPR / 256, CB = BN * SPR / 256;   // 16-byte staging chunks per thread
     static constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
     static constexpr int SLD = WN + 4;                        // padded fp32 row of the epilogue stage
     static constexpr int STAGE_BYTES = 16 * SLD * 4;          // one 16-row slab per wave
@@ -59,9 +62,9 @@ struct Cfg {
     static constexpr int EIT = 16 * CPR / 64;                 // epilogue chunks per lane per slab (2 or 1)
 };
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256, (BM == 128 ? 3 : 4)) void gemm_bf16_kernel(Params p) {
-    using G = Cfg<BM, BN>;
+    using G = Cfg<BM, BN, BK>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
     unsigned char* As = smem;
     unsigned char* Bs = smem + G::A_BYTES;
@@ -85,8 +88,8 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 4)) void gemm_bf16_kernel(Par
     bool a_ok[G::CA], b_ok[G::CB];
 #pragma unroll
     for (int i = 0; i < G::CA; ++i) {
-        const int c = tid + 256 * i, row = c >> 3, slot = c & 7;
-        a_off[i] = lds_off(row, slot);
+        const int c = tid + 256 * i, row = c / G::SPR, slot = c % G::SPR;
+        a_off[i] = lds_off<BK>(row, slot);
         const int m = m0 + row;
         a_ok[i] = m < M;
         const int mc = a_ok[i] ? m : (M - 1);
@@ -101,8 +104,8 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 4)) void gemm_bf16_kernel(Par
     }
 #pragma unroll
     for (int i = 0; i < G::CB; ++i) {
-        const int c = tid + 256 * i, row = c >> 3, slot = c & 7;
-        b_off[i] = lds_off(row, slot);
+        const int c = tid + 256 * i, row = c / G::SPR, slot = c % G::SPR;
+        b_off[i] = lds_off<BK>(row, slot);
         const int n = n0 + row;
         b_ok[i] = n < p.N;
         b_src[i] = (long long)(b_ok[i] ? n : (p.N - 1)) * p.K + slot * 8;
@@ -156,14 +159,14 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 4)) void gemm_bf16_kernel(Par
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) load_tile((kt + 1) * BK);          // in flight during the MFMAs below
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BK / 32; ++ks) {
             mfma_bf16x8 af[G::TI], bfr[G::TJ];
 #pragma unroll
             for (int i = 0; i < G::TI; ++i)
-                af[i] = *reinterpret_cast<const mfma_bf16x8*>(As + lds_off(wr * G::WM + i * 16 + fr, ks * 4 + fg));
+                af[i] = *reinterpret_cast<const mfma_bf16x8*>(As + lds_off<BK>(wr * G::WM + i * 16 + fr, ks * 4 + fg));
 #pragma unroll
             for (int j = 0; j < G::TJ; ++j)
-                bfr[j] = *reinterpret_cast<const mfma_bf16x8*>(Bs + lds_off(wc * G::WN + j * 16 + fr, ks * 4 + fg));
+                bfr[j] = *reinterpret_cast<const mfma_bf16x8*>(Bs + lds_off<BK>(wc * G::WN + j * 16 + fr, ks * 4 + fg));
 #pragma unroll
             for (int i = 0; i < G::TI; ++i)
 #pragma unroll
@@ -260,7 +263,7 @@ extern "C" int mv2d_gemm_bf16(const void* A, const void* A2, int n_split, int a_
                               int ldc, long long c_blk_stride, int c_blk_cols, void* C2, const float* add2,
                               int ldc2, int ldadd2, void* stream) {
     MV2D_CHECK_ARG(A && W && (C || C2), "mv2d_gemm_bf16: null A/W/C");
-    MV2D_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (K % BK) == 0, "mv2d_gemm_bf16: K must be a positive multiple of 64");
+    MV2D_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (K % BK_MIN) == 0, "mv2d_gemm_bf16: K must be a positive multiple of 64");
     MV2D_CHECK_ARG((N % 8) == 0, "mv2d_gemm_bf16: N must be a multiple of 8");
     MV2D_CHECK_ARG(a_mode == 0 || (a_mode == 1 && K == 9 * 256 && (M % 49) == 0), "mv2d_gemm_bf16: conv3x3 mode needs K=2304, M=R*49");
     MV2D_CHECK_ARG(a_mode == 1 || (lda % 8) == 0, "mv2d_gemm_bf16: lda must be a multiple of 8 (16-byte rows)");
@@ -286,11 +289,14 @@ extern "C" int mv2d_gemm_bf16(const void* A, const void* A2, int n_split, int a_
     if (big_blocks >= thr_env) {
         p.n_tiles = cdiv(N, 128);
         dim3 grid(((cdiv(M, 128) + 7) / 8) * 8 * p.n_tiles);
-        hipLaunchKernelGGL((gemm_bf16_kernel<128, 128>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
     } else {
         p.n_tiles = cdiv(N, 64);
         dim3 grid(((cdiv(M, 64) + 7) / 8) * 8 * p.n_tiles);
-        hipLaunchKernelGGL((gemm_bf16_kernel<64, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        static const int bk_env = getenv("MV2D_BF16_BK") ? atoi(getenv("MV2D_BF16_BK")) : 128;
+        // deep K: 128-wide k tiles (twice the bytes in flight per block, half the barriers)
+        if (bk_env == 128 && (K % 128) == 0 && K >= 512) hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 128>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
     }
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
