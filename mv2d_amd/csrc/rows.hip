@@ -109,6 +109,33 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, float
     }
 }
 
+// same, 64 channels x 64 positions per block with 16-byte accesses on both sides (needs HW % 4 == 0, Cn % 4 == 0):
+// every global row segment is 256 B, 4 loads + 4 stores in flight per thread instead of 4-byte accesses.
+__global__ __launch_bounds__(256) void nchw_to_nhwc64_kernel(const float* __restrict__ x, float* __restrict__ y, int V, int Cn, int HW) {
+    __shared__ float tile[64][65];
+    const int v = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+    const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 x 16
+    float4 in[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 16 * i, p = p0 + tq * 4;
+        in[i] = (c < Cn && p < HW) ? *reinterpret_cast<const float4*>(x + ((long long)v * Cn + c) * HW + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float* t = &tile[ty + 16 * i][tq * 4];
+        t[0] = in[i].x; t[1] = in[i].y; t[2] = in[i].z; t[3] = in[i].w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pl = ty + 16 * i, p = p0 + pl, c = c0 + tq * 4;
+        if (p < HW && c < Cn)
+            *reinterpret_cast<float4*>(y + ((long long)v * HW + p) * Cn + c) =
+                make_float4(tile[tq * 4][pl], tile[tq * 4 + 1][pl], tile[tq * 4 + 2][pl], tile[tq * 4 + 3][pl]);
+    }
+}
+
 // cross_attention_head.py:216-238 tail: reg[0:2] = sigmoid(reg[0:2] + isig(ref)[0:2]), reg[4] = sigmoid(reg[4] + isig(ref)[2]),
 // de-normalise to metres with pc_range; RH/mv2d_t_head.py:136-140: reg[8:10] /= dt when dt != 0.  reg [L,R,10] in place.
 __global__ void finalize_reg_kernel(float* reg, const float* __restrict__ ref, int L, int R, float pc0, float pc1, float pc2,
@@ -178,8 +205,13 @@ extern "C" int mv2d_f32_to_bf16(const float* x, void* y, long long n, void* stre
 
 extern "C" int mv2d_nchw_to_nhwc(const float* x, float* y, int V, int Cn, int HW, void* stream) {
     MV2D_CHECK_ARG(x && y && V > 0 && Cn > 0 && HW > 0, "mv2d_nchw_to_nhwc: bad args");
-    dim3 grid(cdiv(HW, 32), cdiv(Cn, 32), V);
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, V, Cn, HW);
+    if ((HW % 4) == 0 && (Cn % 4) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0) {
+        dim3 grid(cdiv(HW, 64), cdiv(Cn, 64), V);
+        hipLaunchKernelGGL(nchw_to_nhwc64_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, V, Cn, HW);
+    } else {
+        dim3 grid(cdiv(HW, 32), cdiv(Cn, 32), V);
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, V, Cn, HW);
+    }
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -193,6 +193,9 @@ def test_transpose_and_cast(dev):
     x = rnd((3, 256, 5, 7), 40).to(dev)
     y = ops.nchw_to_nhwc(x)
     assert torch.equal(y.view(3, 5, 7, 256), x.permute(0, 2, 3, 1))
+    for shape in ((2, 256, 32, 88), (2, 256, 14, 26), (1, 256, 9, 12)):          # 16-byte path: full / ragged tiles
+        x2 = rnd(shape, 41).to(dev)
+        assert torch.equal(ops.nchw_to_nhwc(x2).view(shape[0], shape[2], shape[3], 256), x2.permute(0, 2, 3, 1))
     z = ops.f32_to_bf16(x)
     assert torch.equal(z, x.to(torch.bfloat16))
 
