@@ -68,7 +68,9 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL; gloo only for single-GPU dry runs)')
-    ap.add_argument('--cpu-iters', type=int, default=3)
+    ap.add_argument('--corr-topk', type=int, default=None)    # S path: correlated RoIs per other view (reference default 1); T path: 20
+    ap.add_argument('--force-nc', type=int, default=None)     # S path sweep: synthetic correlation lists, n_c RoIs per query
+    ap.add_argument('--cpu-iters', type=int, default=24)       # ~10 s of CPU work on the bounded sample
     ap.add_argument('--cpu-threads', type=int, default=16)
     ap.add_argument('--cpu-timeout', type=int, default=150)
     args = ap.parse_args()
@@ -88,7 +90,8 @@ def main():
     prob = synthetic.make_problem(args.workload, seed=rank)        # weak scaling: every rank its own frames
     kind = prob['kind']
     sd = synthetic.make_head_state(seed=0)
-    base = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'])
+    base = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'], topk=args.corr_topk)
+    base.force_nc = args.force_nc
     base.fork_qg = args.inflight == 1      # intra-frame two-stream fork helps latency, hurts when several frames are already in flight
     engines = [base] + [base.clone_shared() for _ in range(args.inflight - 1)]
     # frames in flight go on streams that were MEASURED to run concurrently (queue/pipe sharing serialises others)
@@ -181,13 +184,14 @@ def main():
     gbs = by[dom] / (dom_ms * 1e-3) / 1e9
     # HBM traffic of that launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected offline with
     # tools/rocpd_pmc.py and committed under profiles/): counters cannot be read from inside this process
-    traffic = None
+    traffic, traffic_detail = None, None
     try:
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
         t = pmc.get(args.workload, {}).get(dom)
         if t:
-            traffic = {'bytes': t['fetch_bytes'] + t['write_bytes'], 'fetch_bytes': t['fetch_bytes'], 'write_bytes': t['write_bytes'],
-                       'source': 'profiles/pmc_traffic.json (rocprofv3 --pmc, separate run)'}
+            traffic = t['fetch_bytes'] + t['write_bytes']            # HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)
+            traffic_detail = {'fetch_bytes': t['fetch_bytes'], 'write_bytes': t['write_bytes'],
+                              'source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'}
     except Exception:
         pass
     # the roofline that binds this launch is the one it sits closer to
@@ -201,6 +205,7 @@ def main():
         roofline = dict(bound='mfma', kernel=kname, achieved=round(tflops, 2), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
                         frac=round(f_mfma, 4), traffic=traffic, launch_ms=round(dom_ms, 4), flops_per_launch=fl[dom],
                         bytes_per_launch=by[dom], hbm_frac=round(f_hbm, 4))
+    roofline['traffic_detail'] = traffic_detail
     stage_roofline = {k: dict(ms=round(stage_ms[k], 4), tflops=round(fl[k] / (stage_ms[k] * 1e-3) / 1e12, 1),
                               gbs=round(by[k] / (stage_ms[k] * 1e-3) / 1e9, 1)) for k in fl if k in stage_ms}
 
@@ -243,7 +248,7 @@ def main():
             'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16 (key side MFMA) / f32 (query side)', 'data': 'synthetic',
             'config': {'workload': f'{args.workload}: MV2D-{kind} head, {len(metas)} views {metas[0]["img_shape"][1]}x{metas[0]["img_shape"][0]}, '
-                                   f'R={R} queries, S={S} key positions, nnz={nnz} allowed (q,k) pairs',
+                                   f'R={R} queries, S={S} key positions, nnz={nnz} allowed (q,k) pairs' + (f', corr_topk={args.corr_topk}' if args.corr_topk else '') + (f', forced n_c={args.force_nc}' if args.force_nc else ''),
                        'frames_per_step_per_gpu': args.inflight, 'global_batch': world * args.inflight,
                        'parallelism': f'dp{world}', 'hipgraph': use_graph},
             'decoder_ms_per_iter': round(decoder_ms, 4),

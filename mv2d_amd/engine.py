@@ -61,6 +61,7 @@ class HeadEngine:
         self._ws = {}
         self.prof = None              # dict name -> [events] when stage timing is on (bench.py)
         self.fork_qg = True           # T path: query-generator chain on a second stream
+        self.force_nc = None          # bench only (S path): overwrite the correlation lists so that every query reads n_c RoIs
         import os
         self.fuse_rows = os.environ.get('MV2D_FUSE_ROWS', '0') == '1'
         self.load_state(state_dict)
@@ -307,6 +308,18 @@ class HeadEngine:
             # positions any RoIAlign tap can touch (own rect + 1 cell) -> PE only there
             o.roi_positions(rois, ws['zero_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'], R, V, h, w,
                             self.stride, 1.0)
+            if self.force_nc is not None:
+                # the synthetic rig barely correlates RoIs across views, so the S-path sweep over n_c
+                # (RoIs per query) substitutes a synthetic correlation list: own RoI + (n_c - 1) others
+                fm = ws.get('forced_match')
+                if fm is None or fm.shape != ws['match'].shape:
+                    assert self.force_nc - 1 <= V * self.topk, 'raise corr_topk for this n_c'
+                    fmh = torch.full((R, V * self.topk), -1, dtype=torch.int32)
+                    ar = torch.arange(R, dtype=torch.int32)
+                    for j in range(1, self.force_nc):
+                        fmh[:, j - 1] = (ar + 37 * j) % R
+                    fm = ws['forced_match'] = fmh.view(R, V, self.topk).to(self.dev)
+                ws['match'].copy_(fm)
             o.csr_from_corr(ws['match'], ws['row_ptr'], ws['col_idx'], ws['nnz'], R, V, self.topk)
         tk('pe_inputs')
         # a2: PE at the listed positions (3 two-layer MLPs on bf16 MFMA)

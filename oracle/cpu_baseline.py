@@ -38,8 +38,27 @@ def main():
             t0 = time.perf_counter()
             fn(sd, feat, props, prob['img_metas'], **kw)
             ts.append(time.perf_counter() - t0)
+        # decoder-only leg (CrossAttentionBoxHead.forward on prepared inputs: 6 layers + heads), the second headline metric
+        st = {}
+        fn(sd, feat, props, prob['img_metas'], stages=st, **kw)
+        sdt = O._to_t(sd)
+        if prob['kind'] == 'T':
+            mem = feat.permute(0, 2, 3, 1)[st['roi_mask']]
+            mpe = st['pe'].permute(0, 2, 3, 1)[st['roi_mask']]
+            dec = lambda: O.pred_heads(sdt, O.decoder(sdt, st['qpos'], mem + mpe, mem, st['blocked']), st['ref'])
+        else:
+            rf = st['roi_feats'].flatten(2).transpose(1, 2)
+            rp = st['roi_pe'].flatten(2).transpose(1, 2)
+            dec = lambda: O.pred_heads(sdt, O.decoder_s(sdt, st['qpos'], rf + rp, rf, st['corr'], st['corr_mask']), st['ref'])
+        dec()
+        td = []
+        for _ in range(max(3, a.iters // 4)):
+            t0 = time.perf_counter()
+            dec()
+            td.append(time.perf_counter() - t0)
     med = statistics.median(ts)
     print(json.dumps(dict(value=round(1.0 / med, 4), unit='samples/s', cores=a.threads, kind='port',
+                          decoder_ms_per_iter=round(statistics.median(td) * 1e3, 2),
                           sample=f'{a.iters} frames of {a.workload} after 1 warm-up, median {med * 1e3:.0f} ms/frame, torch '
                                  f'{torch.__version__} CPU fp32/fp64, {a.threads} threads of {os.cpu_count()} host cores')))
 
