@@ -112,44 +112,56 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// sparse cross attention: one 4-wave block per query; lane l of every wave owns channels 4l..4l+3 (head = l >> 3).
-// The row's keys are dealt to the waves in chunks of 8 (round robin); each wave prefetches its next chunk
-// (indices, then K/V rows: 512 B coalesced per key) while it works on the current one; merge through LDS.
+// sparse cross attention: one NW-wave block per query; lane l of every wave owns channels 4l..4l+3 (head = l >> 3).
+// The row's keys are dealt to the waves in chunks of KCH (round robin).  A row is a serial chain of dependent gathers
+// (index -> K/V rows), so the kernel's time is the LONGEST row's chain: three chunks are in flight per wave — the indices of
+// chunk c+2 (one coalesced load, broadcast with readlane), the K/V rows of chunk c+1 (512 B coalesced per key) and the
+// arithmetic of chunk c — and long rows get 8 waves x 16 keys per round.  Partial (m, l, acc) states merge through LDS.
 //   q: [R,256] fp32 already scaled by 1/sqrt(32); K,V: [S,256] bf16; out ctx [R,256] fp32
 //   A query with no allowed key gets ctx = 0 (the reference yields NaN there — DESIGN.md).
 //   Optional debug output: logits [8][nnz] (pre-softmax, CSR order).
 // ------------------------------------------------------------------------------------------------
-constexpr int KCH = 8;   // keys per chunk (independent loads in flight)
-
+template <int KCH>
 struct KeyChunk { uint2 kk[KCH], vv[KCH]; };
 
-__device__ __forceinline__ void load_chunk(KeyChunk& c, const unsigned short* __restrict__ K, const unsigned short* __restrict__ V,
-                                           const int* __restrict__ col_idx, int base, int end, int lane) {
+template <int KCH>
+__device__ __forceinline__ int load_idx(const int* __restrict__ col_idx, int base, int end, int lane) {
+    const int e = min(base + (lane & (KCH - 1)), end - 1);
+    return base < end ? col_idx[e] : 0;
+}
+
+template <int KCH>
+__device__ __forceinline__ void load_rows(KeyChunk<KCH>& c, const unsigned short* __restrict__ K, const unsigned short* __restrict__ V,
+                                          int idx, int lane) {
 #pragma unroll
     for (int i = 0; i < KCH; ++i) {
-        const int e = min(base + i, end - 1);
-        const long long row = (long long)col_idx[e] * C + 4 * lane;
+        const long long row = (long long)__builtin_amdgcn_readlane(idx, i) * C + 4 * lane;
         c.kk[i] = *reinterpret_cast<const uint2*>(K + row);
         c.vv[i] = *reinterpret_cast<const uint2*>(V + row);
     }
 }
 
-__global__ __launch_bounds__(256) void sparse_xattn_kernel(const float* __restrict__ q, const unsigned short* __restrict__ K,
-                                                           const unsigned short* __restrict__ V, const int* __restrict__ row_ptr,
-                                                           const int* __restrict__ col_idx, float* __restrict__ ctx,
-                                                           float* __restrict__ dbg_logits, long long dbg_stride, int R) {
-    __shared__ float sm[4][8], sl[4][8], sacc[4][C];
+template <int NW, int KCH>
+__global__ __launch_bounds__(64 * NW) void sparse_xattn_kernel(const float* __restrict__ q, const unsigned short* __restrict__ K,
+                                                               const unsigned short* __restrict__ V, const int* __restrict__ row_ptr,
+                                                               const int* __restrict__ col_idx, float* __restrict__ ctx,
+                                                               float* __restrict__ dbg_logits, long long dbg_stride, int R) {
+    __shared__ float sm[NW][8], sl[NW][8], sacc[NW][C];
     const int r = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float4 q4 = *reinterpret_cast<const float4*>(q + (long long)r * C + 4 * lane);
     const int beg = row_ptr[r], end = row_ptr[r + 1];
+    constexpr int STEP = NW * KCH;
+    int base = beg + wave * KCH;
+    int idx_next = load_idx<KCH>(col_idx, base, end, lane);
+    int idx_next2 = load_idx<KCH>(col_idx, base + STEP, end, lane);
+    const float4 q4 = *reinterpret_cast<const float4*>(q + (long long)r * C + 4 * lane);
     float m_run = -INFINITY, l_run = 0.f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    KeyChunk cur, nxt;
-    int base = beg + wave * KCH;
-    if (base < end) load_chunk(cur, K, V, col_idx, base, end, lane);
-    for (; base < end; base += 4 * KCH) {
-        if (base + 4 * KCH < end) load_chunk(nxt, K, V, col_idx, base + 4 * KCH, end, lane);
+    KeyChunk<KCH> cur, nxt;
+    if (base < end) load_rows<KCH>(cur, K, V, idx_next, lane);
+    for (; base < end; base += STEP) {
+        if (base + STEP < end) load_rows<KCH>(nxt, K, V, idx_next2, lane);
+        idx_next2 = load_idx<KCH>(col_idx, base + 2 * STEP, end, lane);
         float lg[KCH];
         float cmax = -INFINITY;
 #pragma unroll
@@ -185,20 +197,24 @@ __global__ __launch_bounds__(256) void sparse_xattn_kernel(const float* __restri
     if ((lane & 7) == 0) { sm[wave][lane >> 3] = m_run; sl[wave][lane >> 3] = l_run; }
     *reinterpret_cast<float4*>(&sacc[wave][4 * lane]) = acc;
     __syncthreads();
-    const int hh = tid >> 5;                 // thread tid -> channel tid, head tid / 32
-    float out = 0.f;
-    if (end > beg) {
-        const float M = fmaxf(fmaxf(sm[0][hh], sm[1][hh]), fmaxf(sm[2][hh], sm[3][hh]));
-        float den = 0.f, num = 0.f;
+    if (tid < C) {                               // thread tid -> channel tid, head tid / 32
+        const int hh = tid >> 5;
+        float out = 0.f;
+        if (end > beg) {
+            float M = sm[0][hh];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float e = expf(sm[w][hh] - M);
-            den += sl[w][hh] * e;
-            num += sacc[w][tid] * e;
+            for (int w = 1; w < NW; ++w) M = fmaxf(M, sm[w][hh]);
+            float den = 0.f, num = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float e = expf(sm[w][hh] - M);
+                den += sl[w][hh] * e;
+                num += sacc[w][tid] * e;
+            }
+            out = num / den;
         }
-        out = num / den;
+        ctx[(long long)r * C + tid] = out;
     }
-    ctx[(long long)r * C + tid] = out;
 }
 
 }  // namespace
@@ -216,7 +232,8 @@ extern "C" int mv2d_sparse_xattn_fwd(const float* q, const void* K, const void* 
                                      float* ctx, float* dbg_logits, long long dbg_stride, int R, void* stream) {
     MV2D_CHECK_ARG(q && K && V && row_ptr && col_idx && ctx && R >= 0, "mv2d_sparse_xattn_fwd: bad args");
     if (R == 0) return MV2D_OK;
-    hipLaunchKernelGGL(sparse_xattn_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, q, (const unsigned short*)K,
+    // 8 waves x 8-key chunks: measured best of {4,8,16} waves x {4,8,16} keys on cfg2_s / cfg3_t / cfg5_t
+    hipLaunchKernelGGL((sparse_xattn_kernel<8, 8>), dim3(R), dim3(512), 0, (hipStream_t)stream, q, (const unsigned short*)K,
                        (const unsigned short*)V, row_ptr, col_idx, ctx, dbg_logits, dbg_stride, R);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
