@@ -346,30 +346,37 @@ __global__ __launch_bounds__(64) void csr_mark_kernel(const float* __restrict__ 
 
 // single block: pos2s[P] = index into the compacted key list or -1 (not in any RoI rect, or padding),
 // s2pos[S] = flat (v,y,x) position, *S = count.  Row-major (v,y,x) order like the reference's boolean indexing.
+// Every thread owns 64 consecutive cells per sweep (4 x 16-byte mask loads, 16 x 16-byte pos2s stores): one sweep and one
+// block-wide scan cover P <= 65536 map positions (cfg 5: 48000).
 __global__ __launch_bounds__(1024) void csr_scan_positions_kernel(const unsigned char* __restrict__ roi_mask, const unsigned char* __restrict__ pad_mask,
                                                                   int* __restrict__ pos2s, int* __restrict__ s2pos, int* __restrict__ S_out, int P) {
     __shared__ int wsum[16];
     __shared__ int carry;
+    constexpr int CPT = 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) carry = 0;
     __syncthreads();
-    // every thread owns 16 consecutive cells per sweep (P is a multiple of 16 bytes only by luck: guard the tail)
-    for (int base = 0; base < P; base += 1024 * 16) {
-        const int i0 = base + tid * 16;
-        unsigned int bits = 0u;
-        if (i0 + 15 < P && ((P & 15) == 0)) {
-            const uint4 a = *reinterpret_cast<const uint4*>(roi_mask + i0);
-            const uint4 b = *reinterpret_cast<const uint4*>(pad_mask + i0);
-            const unsigned int aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+    const bool vec_ok = (P & 15) == 0 && ((uintptr_t)roi_mask & 15) == 0 && ((uintptr_t)pad_mask & 15) == 0 && ((uintptr_t)pos2s & 15) == 0;
+    for (int base = 0; base < P; base += 1024 * CPT) {
+        const int i0 = base + tid * CPT;
+        unsigned long long bits = 0ull;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const unsigned int ra = (aw[k >> 2] >> ((k & 3) * 8)) & 0xffu, pb = (bw[k >> 2] >> ((k & 3) * 8)) & 0xffu;
-                bits |= ((ra != 0u && pb == 0u) ? 1u : 0u) << k;
+        for (int c = 0; c < CPT / 16; ++c) {
+            const int j0 = i0 + 16 * c;
+            if (vec_ok && j0 + 15 < P) {
+                const uint4 a = *reinterpret_cast<const uint4*>(roi_mask + j0);
+                const uint4 b = *reinterpret_cast<const uint4*>(pad_mask + j0);
+                const unsigned int aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const unsigned int ra = (aw[k >> 2] >> ((k & 3) * 8)) & 0xffu, pb = (bw[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+                    bits |= (unsigned long long)((ra != 0u && pb == 0u) ? 1u : 0u) << (16 * c + k);
+                }
+            } else {
+                for (int k = 0; k < 16; ++k) { const int i = j0 + k; if (i < P && roi_mask[i] && !pad_mask[i]) bits |= 1ull << (16 * c + k); }
             }
-        } else {
-            for (int k = 0; k < 16; ++k) { const int i = i0 + k; if (i < P && roi_mask[i] && !pad_mask[i]) bits |= 1u << k; }
         }
-        const int cnt = __popc(bits);
+        const int cnt = __popcll(bits);
         int sc = cnt;                                        // inclusive wave scan
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(sc, o, 64); if (lane >= o) sc += t; }
@@ -377,13 +384,18 @@ __global__ __launch_bounds__(1024) void csr_scan_positions_kernel(const unsigned
         __syncthreads();
         int off = carry + sc - cnt;
         for (int k = 0; k < wv; ++k) off += wsum[k];
-        for (int k = 0; k < 16; ++k) {
-            const int i = i0 + k;
-            if (i < P) {
-                const bool f = (bits >> k) & 1u;
-                pos2s[i] = f ? off : -1;
-                if (f) { s2pos[off] = i; ++off; }
+#pragma unroll
+        for (int c = 0; c < CPT / 4; ++c) {
+            const int j0 = i0 + 4 * c;
+            int v4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool f = (bits >> (4 * c + k)) & 1ull;
+                v4[k] = f ? off : -1;
+                if (f) { s2pos[off] = j0 + k; ++off; }
             }
+            if (vec_ok && j0 + 3 < P) *reinterpret_cast<int4*>(pos2s + j0) = make_int4(v4[0], v4[1], v4[2], v4[3]);
+            else for (int k = 0; k < 4; ++k) if (j0 + k < P) pos2s[j0 + k] = v4[k];
         }
         __syncthreads();
         if (tid == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; carry += t; }
