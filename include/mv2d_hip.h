@@ -85,6 +85,12 @@ int mv2d_heads_fused(const float* outs, const float* const* cls_w, const float* 
  * (mv2d_row_ln with n_parts = hidden/64) — fixed summation order, deterministic. */
 int mv2d_ffn_fused(const float* X, const float* W1, const float* b1, const float* W2, float* slabs, int M, int hidden, void* stream);
 
+/* The same fused FFN in split precision on the bf16 matrix cores ("bf16x3": x = x_hi + x_lo as a bf16 pair, three bf16 MFMAs per
+ * product, fp32 accumulation): ~1e-5 relative error instead of bit-exact fp32, 3/16 of the matrix-pipe time.  W1/W2 are given as
+ * the pairs produced by mv2d_split_bf16x2 ([hidden,256] and [256,hidden] bf16 each); same slab output as mv2d_ffn_fused. */
+int mv2d_ffn_fused_x3(const float* X, const void* W1hi, const void* W1lo, const float* b1, const void* W2hi, const void* W2lo,
+                      float* slabs, int M, int hidden, void* stream);
+
 /* fp32-class GEMM on the bf16 matrix cores (split precision "bf16x3"): same contract as mv2d_gemm_f32 but the weights are
  * given as the bf16 pair Whi = bf16(W), Wlo = bf16(W - Whi) (see mv2d_split_bf16x2) and A is split on the fly;
  * relative error ~1e-5 instead of bit-exact fp32, 3/16 of the matrix-core time. */

@@ -1,0 +1,144 @@
+// Fused FFN of the MV2D decoder layer on the bf16 matrix cores in split precision ("bf16x3"), same block structure and slab
+// output as ffn.hip (mmcv FFN 256 -> 2048 -> 256, configs/mv2d/exp/*:78-79; MU/petr_transformer.py:269-311).
+//
+// The exact-fp32 kernel (ffn.hip) is bound by v_mfma_f32_16x16x4_f32: 256 of them per wave at 32 cycles each, two blocks per
+// CU.  Here every fp32 operand is carried as a bf16 pair x = x_hi + x_lo (x_hi = bf16(x), x_lo = bf16(x - x_hi)) and a
+// product is a_hi.w_hi + a_lo.w_hi + a_hi.w_lo on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: every partial product is
+// exact in fp32, the dropped a_lo.w_lo term is ~2^-18 relative -> ~1e-5 relative error (plain bf16: 4e-3), at 3/16 of the
+// matrix-pipe time.  The weights are split once at load time (mv2d_split_bf16x2), X when it is staged into LDS, the hidden
+// activations when they are written to LDS.  Both phases run swapped (D^T = W.A^T), so a lane always ends with 4 consecutive
+// columns of one row: 8-byte LDS writes of H, 16-byte stores of the slab.
+#include "common.h"
+
+namespace {
+
+constexpr int C = 256, HS = 64, BR = 32;      // channels, hidden slice, rows per block
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+union Frag { uint4 u; mfma_bf16x8 v; };
+
+// bf16 LDS images: X [32][256] (512 B rows, 32 slots of 16 B), H [32][64] (128 B rows, 8 slots); slot ^= row bits
+__device__ __forceinline__ int xoff(int row, int slot) { return row * (C * 2) + ((slot ^ (row & 15)) << 4); }
+__device__ __forceinline__ int hoff(int row, int slot) { return row * (HS * 2) + ((slot ^ (row & 7)) << 4); }
+
+__device__ __forceinline__ void split2(float a, float b, unsigned int& hi, unsigned int& lo) {
+    hi = pack_bf16x2(a, b);
+    lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+
+__global__ __launch_bounds__(256, 2) void ffn_x3_kernel(const float* __restrict__ X, const unsigned short* __restrict__ W1h,
+                                                        const unsigned short* __restrict__ W1l, const float* __restrict__ b1,
+                                                        const unsigned short* __restrict__ W2h, const unsigned short* __restrict__ W2l,
+                                                        float* __restrict__ slabs, int M, int hidden) {
+    __shared__ __attribute__((aligned(16))) unsigned char xh[BR * C * 2], xl[BR * C * 2], hh[BR * HS * 2], hl[BR * HS * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int slice = blockIdx.x, m0 = blockIdx.y * BR;
+    const int rt = wave >> 1, half = wave & 1;
+    // ---- issue everything that does not depend on LDS: X rows (coalesced), W1 slice fragments (hi, lo)
+    float4 xr[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 5, slot = idx & 31;            // 32 slots of 8 floats per row
+        const float* xp = X + (long long)min(m0 + row, M - 1) * C + slot * 8;
+        xr[i][0] = *reinterpret_cast<const float4*>(xp);
+        xr[i][1] = *reinterpret_cast<const float4*>(xp + 4);
+    }
+    Frag w1h[2][8], w1l[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const long long wo = (long long)(slice * HS + (2 * half + t) * 16 + fr) * C + 8 * fg;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            w1h[t][s].u = *reinterpret_cast<const uint4*>(W1h + wo + 32 * s);
+            w1l[t][s].u = *reinterpret_cast<const uint4*>(W1l + wo + 32 * s);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 5, slot = idx & 31;
+        uint4 h4, l4;
+        split2(xr[i][0].x, xr[i][0].y, h4.x, l4.x); split2(xr[i][0].z, xr[i][0].w, h4.y, l4.y);
+        split2(xr[i][1].x, xr[i][1].y, h4.z, l4.z); split2(xr[i][1].z, xr[i][1].w, h4.w, l4.w);
+        *reinterpret_cast<uint4*>(xh + xoff(row, slot)) = h4;
+        *reinterpret_cast<uint4*>(xl + xoff(row, slot)) = l4;
+    }
+    __syncthreads();
+    // W2 slice fragments: in flight while phase 1 computes.  Tile t, fragment row fr -> output column 128*half + 16*(fr>>2) + 4t'...
+    // (interleaved so that a lane ends with 4 consecutive columns per tile pair; see the store below)
+    Frag w2h[8][2], w2l[8][2];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int n = 128 * half + 16 * t + fr;
+        const long long wo = (long long)n * hidden + slice * HS + 8 * fg;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            w2h[t][s].u = *reinterpret_cast<const uint4*>(W2h + wo + 32 * s);
+            w2l[t][s].u = *reinterpret_cast<const uint4*>(W2l + wo + 32 * s);
+        }
+    }
+    // ---- phase 1 (swapped): lane (fr, fg) ends with hidden columns 4fg..4fg+3 of row fr for each of its two 16-wide tiles
+    f32x4_t h0[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}}, h1[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        Frag ah, al;
+        ah.u = *reinterpret_cast<const uint4*>(xh + xoff(rt * 16 + fr, 4 * s + fg));
+        al.u = *reinterpret_cast<const uint4*>(xl + xoff(rt * 16 + fr, 4 * s + fg));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            h0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1h[t][s].v, ah.v, h0[t], 0, 0, 0);
+            h1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1h[t][s].v, al.v, h1[t], 0, 0, 0);
+            h1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1l[t][s].v, ah.v, h1[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int col = (2 * half + t) * 16 + 4 * fg;                               // first of 4 hidden columns (local to the slice)
+        const float4 bb = *reinterpret_cast<const float4*>(b1 + slice * HS + col);
+        const float v0 = fmaxf(h0[t][0] + h1[t][0] + bb.x, 0.f), v1 = fmaxf(h0[t][1] + h1[t][1] + bb.y, 0.f);
+        const float v2 = fmaxf(h0[t][2] + h1[t][2] + bb.z, 0.f), v3 = fmaxf(h0[t][3] + h1[t][3] + bb.w, 0.f);
+        uint2 hi, lo;
+        split2(v0, v1, hi.x, lo.x); split2(v2, v3, hi.y, lo.y);
+        const int row = rt * 16 + fr, off = hoff(row, col >> 3) + (col & 4) * 2;
+        *reinterpret_cast<uint2*>(hh + off) = hi;
+        *reinterpret_cast<uint2*>(hl + off) = lo;
+    }
+    __syncthreads();
+    // ---- phase 2 (swapped): eight 16-column tiles per wave, K = 64
+    f32x4_t a0[8], a1[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { a0[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; a1[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        Frag gh, gl;
+        gh.u = *reinterpret_cast<const uint4*>(hh + hoff(rt * 16 + fr, 4 * s + fg));
+        gl.u = *reinterpret_cast<const uint4*>(hl + hoff(rt * 16 + fr, 4 * s + fg));
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            a0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2h[t][s].v, gh.v, a0[t], 0, 0, 0);
+            a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2h[t][s].v, gl.v, a1[t], 0, 0, 0);
+            a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2l[t][s].v, gh.v, a1[t], 0, 0, 0);
+        }
+    }
+    const int m = m0 + rt * 16 + fr;
+    if (m < M) {
+        float* out = slabs + ((long long)slice * M + m) * C + 128 * half + 4 * fg;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            *reinterpret_cast<float4*>(out + 16 * t) = make_float4(a0[t][0] + a1[t][0], a0[t][1] + a1[t][1], a0[t][2] + a1[t][2], a0[t][3] + a1[t][3]);
+    }
+}
+
+}  // namespace
+
+extern "C" int mv2d_ffn_fused_x3(const float* X, const void* W1hi, const void* W1lo, const float* b1, const void* W2hi, const void* W2lo,
+                                 float* slabs, int M, int hidden, void* stream) {
+    MV2D_CHECK_ARG(X && W1hi && W1lo && b1 && W2hi && W2lo && slabs, "mv2d_ffn_fused_x3: null pointer");
+    MV2D_CHECK_ARG(hidden > 0 && (hidden % HS) == 0, "mv2d_ffn_fused_x3: hidden must be a multiple of 64");
+    MV2D_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)W1hi & 15) == 0 && ((uintptr_t)W1lo & 15) == 0 && ((uintptr_t)W2hi & 15) == 0 &&
+                       ((uintptr_t)W2lo & 15) == 0 && ((uintptr_t)slabs & 15) == 0 && ((uintptr_t)b1 & 15) == 0,
+                   "mv2d_ffn_fused_x3: operands must be 16-byte aligned");
+    if (M == 0) return MV2D_OK;
+    hipLaunchKernelGGL(ffn_x3_kernel, dim3(hidden / HS, cdiv(M, BR)), dim3(256), 0, (hipStream_t)stream, X, (const unsigned short*)W1hi,
+                       (const unsigned short*)W1lo, b1, (const unsigned short*)W2hi, (const unsigned short*)W2lo, slabs, M, hidden);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}

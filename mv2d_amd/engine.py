@@ -16,6 +16,7 @@ The reference evaluates PE on the whole map and runs dense [8,R,S] attention wit
 are identical up to the bf16 rounding of the key side.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -61,9 +62,9 @@ class HeadEngine:
         self._ws = {}
         self.prof = None              # dict name -> [events] when stage timing is on (bench.py)
         self.fork_qg = True           # T path: query-generator chain on a second stream
+        self.ffn_x3 = os.environ.get('MV2D_FFN_X3', '0') == '1'   # FFN in bf16x3 split precision: -3 % latency, -7 % throughput -> off
         self.force_nc = None          # bench only (S path): overwrite the correlation lists so that every query reads n_c RoIs
-        import os
-        self.fuse_rows = os.environ.get('MV2D_FUSE_ROWS', '0') == '1'
+        self.fuse_rows = os.environ.get('MV2D_FUSE_ROWS', '0') == '1'   # row-block fused out_proj+LN(+q proj): measured slower, kept for A/B
         self.load_state(state_dict)
 
     # ------------------------------------------------------------------------------------------ weights
@@ -90,6 +91,9 @@ class HeadEngine:
             w[f'ffn_b1{i}'] = g(p + 'ffns.0.layers.0.0.bias')
             w[f'ffn_w2{i}'] = g(p + 'ffns.0.layers.1.weight')
             w[f'ffn_b2{i}'] = g(p + 'ffns.0.layers.1.bias')
+            if self.ffn_x3:
+                w[f'ffn_w1x{i}'] = ops.split_bf16x2(w[f'ffn_w1{i}'])
+                w[f'ffn_w2x{i}'] = ops.split_bf16x2(w[f'ffn_w2{i}'])
             for n in range(3):
                 w[f'ln{n}_w{i}'] = g(p + f'norms.{n}.weight')
                 w[f'ln{n}_b{i}'] = g(p + f'norms.{n}.bias')
@@ -406,7 +410,10 @@ class HeadEngine:
                 o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R)
                 o.gemm_f32(ws['ctx'], W_[f'ca_out_w{i}'], W_[f'ca_out_b{i}'], out=ws['o'])
                 o.row_ln(ws['o'], residual=ws['x1'], ln=(W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), out=ws['x2'])
-            o.ffn_fused(ws['x2'], W_[f'ffn_w1{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2{i}'], ws['parts'], R)
+            if self.ffn_x3:
+                o.ffn_fused_x3(ws['x2'], W_[f'ffn_w1x{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2x{i}'], ws['parts'], R)
+            else:
+                o.ffn_fused(ws['x2'], W_[f'ffn_w1{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2{i}'], ws['parts'], R)
             o.row_ln(ws['parts'], bias=W_[f'ffn_b2{i}'], residual=ws['x2'], ln=(W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), out=x, addvec=ws['qpos'], out_plus=xq,
                      ln2=(W_['post_w'], W_['post_b']), out2=ws['outs'][i])
 

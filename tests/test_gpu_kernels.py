@@ -166,6 +166,21 @@ def test_ffn_fused_exact(dev):
         assert relerr(slabs.sum(0), ref) < 2e-6
 
 
+def test_ffn_fused_x3_split_precision(dev):
+    """bf16x3 FFN: fp32-class accuracy (<= 3e-5 of the output maximum) against fp64, same slab contract as the exact kernel."""
+    from mv2d_amd import ops
+    for M in (300, 33, 900):
+        x = rnd((M, 256), 27).to(dev)
+        W1 = rnd((2048, 256), 28, 0.1).to(dev); b1 = rnd((2048,), 29).to(dev)
+        W2 = rnd((256, 2048), 30, 0.05).to(dev)
+        slabs = ops.ffn_fused_x3(x, ops.split_bf16x2(W1), b1, ops.split_bf16x2(W2))
+        assert slabs.shape == (32, M, 256)
+        ref = F.relu(x.double() @ W1.double().T + b1.double()) @ W2.double().T
+        assert relerr(slabs.sum(0), ref) < 3e-5
+        exact = ops.ffn_fused(x, W1, b1, W2)
+        assert relerr(slabs.sum(0), exact.sum(0)) < 3e-5
+
+
 # ------------------------------------------------------------------------------------------ rows
 def test_row_ln(dev):
     from mv2d_amd import ops
