@@ -128,10 +128,10 @@ int mv2d_self_attn_fwd(const float* qkv, float* ctx, int R, void* stream);
 
 /* PETRMultiheadAttention core (MU/petr_transformer.py:426-513) over the allowed (query,key) pairs only.
  * q [R,256] fp32 pre-scaled by 1/sqrt(32); K,V [S,256] bf16; CSR row_ptr[R+1], col_idx[nnz] (key indices);
- * ctx [R,256] fp32.  A query with no allowed key yields ctx = 0 (reference: NaN).
+ * ctx [R,256] fp32.  A query with no allowed key yields NaN like nn.MultiheadAttention (empty_nan = 1) or 0 (empty_nan = 0).
  * dbg_logits (optional): pre-softmax logits, head h at dbg_logits[h*dbg_stride + e], e in CSR order. */
 int mv2d_sparse_xattn_fwd(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, float* ctx,
-                          float* dbg_logits, long long dbg_stride, int R, void* stream);
+                          float* dbg_logits, long long dbg_stride, int R, int empty_nan, void* stream);
 
 /* ---- geometry / gather ---------------------------------------------------------------------------------- */
 

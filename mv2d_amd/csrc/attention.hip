@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float* __restrict_
 // chunk c+2 (one coalesced load, broadcast with readlane), the K/V rows of chunk c+1 (512 B coalesced per key) and the
 // arithmetic of chunk c — and long rows get 8 waves x 16 keys per round.  Partial (m, l, acc) states merge through LDS.
 //   q: [R,256] fp32 already scaled by 1/sqrt(32); K,V: [S,256] bf16; out ctx [R,256] fp32
-//   A query with no allowed key gets ctx = 0 (the reference yields NaN there — DESIGN.md).
+//   A query with no allowed key gets ctx = NaN like the reference (empty_nan = 1; the NaN then spreads to every query through
+//   the next self attention) or ctx = 0 (empty_nan = 0) — DESIGN.md.
 //   Optional debug output: logits [8][nnz] (pre-softmax, CSR order).
 // ------------------------------------------------------------------------------------------------
 template <int KCH>
@@ -145,7 +146,7 @@ template <int NW, int KCH>
 __global__ __launch_bounds__(64 * NW) void sparse_xattn_kernel(const float* __restrict__ q, const unsigned short* __restrict__ K,
                                                                const unsigned short* __restrict__ V, const int* __restrict__ row_ptr,
                                                                const int* __restrict__ col_idx, float* __restrict__ ctx,
-                                                               float* __restrict__ dbg_logits, long long dbg_stride, int R) {
+                                                               float* __restrict__ dbg_logits, long long dbg_stride, int R, int empty_nan) {
     __shared__ float sm[NW][8], sl[NW][8], sacc[NW][C];
     const int r = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(64 * NW) void sparse_xattn_kernel(const float* __re
     __syncthreads();
     if (tid < C) {                               // thread tid -> channel tid, head tid / 32
         const int hh = tid >> 5;
-        float out = 0.f;
+        float out = empty_nan ? __uint_as_float(0x7fc00000u) : 0.f;   // no allowed key: NaN like nn.MultiheadAttention, or 0
         if (end > beg) {
             float M = sm[0][hh];
 #pragma unroll
@@ -229,12 +230,12 @@ extern "C" int mv2d_self_attn_fwd(const float* qkv, float* ctx, int R, void* str
 }
 
 extern "C" int mv2d_sparse_xattn_fwd(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx,
-                                     float* ctx, float* dbg_logits, long long dbg_stride, int R, void* stream) {
+                                     float* ctx, float* dbg_logits, long long dbg_stride, int R, int empty_nan, void* stream) {
     MV2D_CHECK_ARG(q && K && V && row_ptr && col_idx && ctx && R >= 0, "mv2d_sparse_xattn_fwd: bad args");
     if (R == 0) return MV2D_OK;
     // 8 waves x 8-key chunks: measured best of {4,8,16} waves x {4,8,16} keys on cfg2_s / cfg3_t / cfg5_t
     hipLaunchKernelGGL((sparse_xattn_kernel<8, 8>), dim3(R), dim3(512), 0, (hipStream_t)stream, q, (const unsigned short*)K,
-                       (const unsigned short*)V, row_ptr, col_idx, ctx, dbg_logits, dbg_stride, R);
+                       (const unsigned short*)V, row_ptr, col_idx, ctx, dbg_logits, dbg_stride, R, empty_nan);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -49,6 +49,9 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_cv));
 }
 
+// ReLU that keeps NaN like torch.relu (fmaxf(NaN, 0) would return 0 and hide a poisoned row)
+__device__ __forceinline__ float relu_f(float v) { return v < 0.f ? 0.f : v; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

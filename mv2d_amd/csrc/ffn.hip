@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = rt * 16 + 4 * fg + r;
-            hs_[hoff(row, col >> 2) + (col & 3)] = fmaxf(h[t][r] + bb, 0.f);
+            hs_[hoff(row, col >> 2) + (col & 3)] = relu_f(h[t][r] + bb);
         }
     }
     __syncthreads();

@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256, 2) void ffn_x3_kernel(const float* __restrict_
     for (int t = 0; t < 2; ++t) {
         const int col = (2 * half + t) * 16 + 4 * fg;                               // first of 4 hidden columns (local to the slice)
         const float4 bb = *reinterpret_cast<const float4*>(b1 + slice * HS + col);
-        const float v0 = fmaxf(h0[t][0] + h1[t][0] + bb.x, 0.f), v1 = fmaxf(h0[t][1] + h1[t][1] + bb.y, 0.f);
-        const float v2 = fmaxf(h0[t][2] + h1[t][2] + bb.z, 0.f), v3 = fmaxf(h0[t][3] + h1[t][3] + bb.w, 0.f);
+        const float v0 = relu_f(h0[t][0] + h1[t][0] + bb.x), v1 = relu_f(h0[t][1] + h1[t][1] + bb.y);
+        const float v2 = relu_f(h0[t][2] + h1[t][2] + bb.z), v3 = relu_f(h0[t][3] + h1[t][3] + bb.w);
         uint2 hi, lo;
         split2(v0, v1, hi.x, lo.x); split2(v2, v3, hi.y, lo.y);
         const int row = rt * 16 + fr, off = hoff(row, col >> 3) + (col & 4) * 2;

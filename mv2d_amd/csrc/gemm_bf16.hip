@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 4)) void gemm_bf16_kernel(Par
                 }
                 if (p.act == 1) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
                 } else if (p.act == 2) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(Params p) {
         const int m = m0 + fg * 4 + r;
         if (m >= p.M) continue;
         float v = ((acc0[r] + acc1[r]) + bn) * p.scale;
-        if (p.act == 1) v = fmaxf(v, 0.f);
+        if (p.act == 1) v = relu_f(v);
         if (p.clamp > 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
         const long long o = (long long)m * p.ldc + n;
         if (p.c_bf16) reinterpret_cast<unsigned short*>(Cz)[o] = f32_to_bf16(v);

@@ -66,7 +66,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ Ds, const f32x4_t
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = (acc[t][r] + b) * scale;
-            if (relu) v = fmaxf(v, 0.f);
+            if (relu) v = relu_f(v);
             Ds[toff(4 * fg + r, col)] = v;
         }
     }
@@ -102,7 +102,7 @@ __device__ __forceinline__ void ln_tile(float* __restrict__ Ds, const float* __r
         const float rstd = 1.0f / sqrtf(var + eps);
         const float4 ww = *reinterpret_cast<const float4*>(lw + lane * 4), bb = *reinterpret_cast<const float4*>(lb + lane * 4);
         v = make_float4(dx * rstd * ww.x + bb.x, dy * rstd * ww.y + bb.y, dz * rstd * ww.z + bb.z, dw * rstd * ww.w + bb.w);
-        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (relu) { v.x = relu_f(v.x); v.y = relu_f(v.y); v.z = relu_f(v.z); v.w = relu_f(v.w); }
         *reinterpret_cast<float4*>(p) = v;
         if (out && m < M) *reinterpret_cast<float4*>(out + g) = v;
         if (Ds_plus) {

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void row_ln_kernel(LnParams p) {
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
     if (p.ln_w) v = ln4(v, p.ln_w + goff, p.ln_b + goff, c0, p.eps);
-    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (p.relu) { v.x = relu_f(v.x); v.y = relu_f(v.y); v.z = relu_f(v.z); v.w = relu_f(v.w); }
     if (p.out) *reinterpret_cast<float4*>(p.out + (long long)row * C + c0) = v;
     if (p.out_plus) {
         float4 t = *reinterpret_cast<const float4*>(p.addvec + (long long)row * C + c0);

@@ -42,7 +42,7 @@ class HeadEngine:
     def __init__(self, state_dict, kind, device, num_views=6, topk=None, expand_stride=None, num_layers=L_DEFAULT,
                  max_num=300, pc_range=(-51.2, -51.2, -5.0, 51.2, 51.2, 3.0),
                  post_range=(-61.2, -61.2, -10.0, 61.2, 61.2, 10.0), depth_num=64, stride=16, col_cap_per_query=2048,
-                 iou_thr=0.0, ratio=0.0):
+                 iou_thr=0.0, ratio=0.0, masked_row='nan'):
         assert kind in ('S', 'T')
         self.kind = kind
         self.dev = torch.device(device)
@@ -55,6 +55,10 @@ class HeadEngine:
         self.stride = stride
         self.iou_thr, self.ratio = iou_thr, ratio
         self.col_cap_per_query = col_cap_per_query
+        # a query whose every key is masked: 'nan' = the reference's behaviour (nn.MultiheadAttention yields NaN, the next self
+        # attention spreads it to every query, the frame returns no boxes), 'zero' = zero attention output for that query only
+        assert masked_row in ('nan', 'zero')
+        self.empty_nan = masked_row == 'nan'
         self.pc_range_h = torch.tensor(pc_range, dtype=F32)
         self.post_range_h = torch.tensor(post_range, dtype=F32)
         self.post_range_h64 = torch.tensor(post_range, dtype=torch.float64)
@@ -401,13 +405,13 @@ class HeadEngine:
             if self.fuse_rows:
                 o.attn_out_fused(ws['ctx'], x, W_[f'sa_out_w{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
                                  qpos=ws['qpos'], Wq=W_[f'ca_q_w{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, q_out=ws['q'], M=R)
-                o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R)
+                o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R, empty_nan=self.empty_nan)
                 o.attn_out_fused(ws['ctx'], ws['x1'], W_[f'ca_out_w{i}'], W_[f'ca_out_b{i}'], (W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), ws['x2'], M=R)
             else:
                 o.gemm_f32(ws['ctx'], W_[f'sa_out_w{i}'], W_[f'sa_out_b{i}'], out=ws['o'])
                 o.row_ln(ws['o'], residual=x, ln=(W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), out=ws['x1'], addvec=ws['qpos'], out_plus=ws['x1q'])
                 o.gemm_f32(ws['x1q'], W_[f'ca_q_w{i}'], W_[f'ca_q_b{i}'], scale=ops.SCALE_Q, out=ws['q'])
-                o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R)
+                o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R, empty_nan=self.empty_nan)
                 o.gemm_f32(ws['ctx'], W_[f'ca_out_w{i}'], W_[f'ca_out_b{i}'], out=ws['o'])
                 o.row_ln(ws['o'], residual=ws['x1'], ln=(W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), out=ws['x2'])
             if self.ffn_x3:

@@ -228,14 +228,14 @@ def self_attn(qkv, out=None, R=None):
     return out
 
 
-def sparse_xattn(q, K, V, row_ptr, col_idx, out=None, R=None, dbg_logits=None):
+def sparse_xattn(q, K, V, row_ptr, col_idx, out=None, R=None, dbg_logits=None, empty_nan=True):
     _req(q, torch.float32, 'q'); _req(K, BF16, 'K'); _req(V, BF16, 'V')
     _req(row_ptr, torch.int32, 'row_ptr'); _req(col_idx, torch.int32, 'col_idx')
     R = q.shape[0] if R is None else R
     if out is None:
         out = torch.empty((R, 256), device=q.device, dtype=torch.float32)
     check(_lib.load().mv2d_sparse_xattn_fwd(_p(q), _p(K), _p(V), _p(row_ptr), _p(col_idx), _p(out), _p(dbg_logits),
-                                            dbg_logits.stride(0) if dbg_logits is not None else 0, R, _stream()),
+                                            dbg_logits.stride(0) if dbg_logits is not None else 0, R, 1 if empty_nan else 0, _stream()),
           'mv2d_sparse_xattn_fwd')
     return out
 

@@ -244,7 +244,9 @@ def test_sparse_xattn(dev):
     col = allowed.nonzero()[:, 1].to(torch.int32)
     nnz = int(row_ptr[-1])
     dbg = torch.zeros((8, nnz), device=dev)
-    out = ops.sparse_xattn(q, K, V, row_ptr.to(dev), col.to(dev), dbg_logits=dbg)
+    out = ops.sparse_xattn(q, K, V, row_ptr.to(dev), col.to(dev), dbg_logits=dbg, empty_nan=False)
+    out_nan = ops.sparse_xattn(q, K, V, row_ptr.to(dev), col.to(dev))      # default: NaN like nn.MultiheadAttention
+    assert bool(torch.isnan(out_nan[5]).all()) and torch.equal(out_nan[6:], out[6:]) and torch.equal(out_nan[:5], out[:5])
     qh = q.double().view(R, 8, 32).transpose(0, 1)
     kh = K.double().view(S, 8, 32).transpose(0, 1)
     vh = V.double().view(S, 8, 32).transpose(0, 1)
