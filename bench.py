@@ -50,12 +50,12 @@ def stage_bytes(kind, R, S, L=6):
         'pe_gemm_384x1024': S * 384 * 2 + 384 * 1024 * 2 + S * 1024 * 2,
         'pe_gemm_1024x256_a': S * 1024 * 2 + 1024 * 256 * 2 + S * 256 * 4 + S * 256 * 4,          # + gate operand, fp32 out
         'pe_gemm_1024x256_b': S * 1024 * 2 + 1024 * 256 * 2 + 2 * S * 256 * 4 + S * 256 * (4 + 2),  # + add operands, fp32 + bf16 out
-        'qg_conv_gemm': R * 49 * 256 * 2 + 2304 * 256 * 2 + R * 49 * 256 * 4,
+        'qg_conv_gemm': R * 49 * 256 * 2 + 2304 * 256 * 2 + R * 256 * 4,                       # pooled [R,256] output
         'kv_gemm': 2 * Mkv * C * 2 + 2 * L * C * C * 2 + Mkv * 2 * L * C * 2,
     }
 
 
-STAGE_KERNEL = {'kv_gemm': 'kvproj_kernel', 'qg_conv_gemm': 'gemm_bf16_kernel<64,64> (implicit conv3x3)'}
+STAGE_KERNEL = {'kv_gemm': 'kvproj_kernel', 'qg_conv_gemm': 'roi_conv_pool_kernel (conv3x3 + ReLU + avgpool fused)'}
 
 
 def main():

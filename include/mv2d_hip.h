@@ -66,6 +66,13 @@ int mv2d_attn_out_fused(const float* ctx, const float* resid, const float* Wo, c
                         float* x_out, const float* qpos, const float* Wq, const float* bq, float qscale, float* q_out, int M, float eps,
                         void* stream);
 
+/* QueryGenerator shared conv + pooling fused, one block per RoI (RH/utils/query_generator.py:298-304,322-331,352-358):
+ * out[r, n] = mean over the 49 cells of relu(conv3x3(roi_feat[r])[cell, n] + bias[n]).  roi_feat [R,49,256] bf16 (cell-major),
+ * Wp = the conv weight [256][tap][cin] (bf16, K = 2304) in FRAGMENT-MAJOR order as produced by mv2d_pack_wfrag_bf16 (weights are
+ * static: one fragment = one contiguous 1 KB load); out [R, ld_out] fp32.  Same k order as mv2d_gemm_bf16(a_mode = 1). */
+int mv2d_pack_wfrag_bf16(const void* W, void* Wp, int N, int K, void* stream);   /* Wp[K/32][N/16][64][8] <- W[N][K] */
+int mv2d_qg_conv_pool(const void* roi_feat, const void* W, const float* bias, float* out, int ld_out, int R, void* stream);
+
 /* K/V in_proj of all decoder layers, shape-specialised (K = 256): C = A . W^T + bias, bf16 in / bf16 out, same operand and
  * output-block conventions as mv2d_gemm_bf16 (A2 / n_split, m_dev, c_blk_stride / c_blk_cols) and bit-identical results.
  * A rows stay in registers, W streams through a 2-stage LDS ring filled by the LDS-DMA (MU/petr_transformer.py:503-508). */

@@ -1,0 +1,126 @@
+// QueryGenerator shared conv: Conv2d(256, 256, 3, padding=1) + ReLU on the 7x7 RoI features, followed by AvgPool2d(7)
+// (RH/utils/query_generator.py:298-304, 322-331, 352-358) — one block per RoI, conv + bias + ReLU + pooling fused.
+//
+// The implicit-GEMM route (gemm_bf16.hip, a_mode = 1) re-gathers every RoI row 9 times through L2 in 64x64 tiles, writes the
+// [R*49, 256] fp32 conv output and needs a pooling launch.  Here the block keeps its RoI (49 cells x 256 channels bf16 = 25 KB)
+// in LDS once and every tap is just a remapped row index into it (out-of-range neighbours -> a zero row); the weights
+// (256 x 2304 bf16) are never staged: each wave streams the 64 output columns it owns as MFMA fragments straight from L2 through
+// a 4-deep register ring.  The weights are static, so they are stored FRAGMENT-MAJOR (mv2d_pack_wfrag_bf16: [k-step][column
+// tile][lane][8]): a fragment load is one contiguous 1 KB per wave instead of 16 rows x 64 B (row-major fragment loads
+// measured 74 us for this kernel: the TA walks 16 half-used lines per instruction and the L1 thrashes).  After the single staging barrier the waves run free — no barrier, no LDS write in the 72-step k loop
+// (fully unrolled so that hipcc keeps exact vmcnt counts for the ring).  The epilogue pools in registers + two shuffles and
+// writes [R, 256] fp32: the 15 MB conv output and the avgpool launch disappear.
+// k order = (tap, channel) like the implicit GEMM, so the conv sums are bit-identical; only the 49-term pooling sum is
+// re-associated (fp32, ~1e-7).
+#include "common.h"
+
+namespace {
+
+constexpr int C = 256, CELLS = 49, KT = 9 * C;
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+union Frag { uint4 u; mfma_bf16x8 v; };
+
+__global__ __launch_bounds__(256, 2) void roi_conv_pool_kernel(const unsigned short* __restrict__ feat, const unsigned short* __restrict__ W,
+                                                               const float* __restrict__ bias, float* __restrict__ out, int ld_out, int R) {
+    __shared__ __attribute__((aligned(16))) unsigned char xs[(CELLS + 1) * C * 2];       // rows 0..48 + a zero row (49)
+    const int roi = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    // ---- stage the RoI: 16-byte chunks, chunk c of row r at slot c ^ (r & 15)
+    for (int c = tid; c < (CELLS + 1) * 32; c += 256) {
+        const int row = c >> 5, slot = c & 31;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row < CELLS) v = *reinterpret_cast<const uint4*>(feat + ((long long)roi * CELLS + row) * C + slot * 8);
+        *reinterpret_cast<uint4*>(xs + row * (C * 2) + ((slot ^ (row & 15)) << 4)) = v;
+    }
+    // ---- weight fragments of this wave's 64 output columns, 4-deep ring over the 72 k-steps
+    // fragment-major weights: fragment (k-step ks, column tile jt) = 64 lanes x 16 B at ((ks * 16 + jt) * 64 + lane) * 8
+    const unsigned short* w_src = W + ((long long)(wave * 4) * 64 + lane) * 8;
+    constexpr int KS_STRIDE = 16 * 64 * 8, JT_STRIDE = 64 * 8;
+    Frag wq[4][4];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wq[p][j].u = *reinterpret_cast<const uint4*>(w_src + p * KS_STRIDE + j * JT_STRIDE);
+    // cell coordinates of the 4 row tiles of this lane (row = 16 i + fr)
+    int cy[4], cx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = 16 * i + fr; cy[i] = r / 7; cx[i] = r - cy[i] * 7; }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+#pragma unroll
+    for (int ks = 0; ks < 72; ++ks) {
+        const int tap = ks >> 3, s = ks & 7;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        if (ks + 3 < 72) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wq[(ks + 3) & 3][j].u = *reinterpret_cast<const uint4*>(w_src + (ks + 3) * KS_STRIDE + j * JT_STRIDE);
+        }
+        __builtin_amdgcn_sched_barrier(0);           // keep the prefetch 3 steps ahead (hipcc otherwise sinks the loads to their use)
+        Frag a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int y = cy[i] + dy, x = cx[i] + dx;
+            const bool ok = (16 * i + fr) < CELLS && y >= 0 && y < 7 && x >= 0 && x < 7;
+            const int src = ok ? y * 7 + x : CELLS;
+            a[i].u = *reinterpret_cast<const uint4*>(xs + src * (C * 2) + (((4 * s + fg) ^ (src & 15)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, wq[ks & 3][j].v, acc[i][j], 0, 0, 0);
+    }
+    // ---- bias + ReLU + mean over the 49 cells: lane holds rows 16 i + 4 fg + r of column 64 wave + 16 j + fr
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = wave * 64 + 16 * j + fr;
+        const float b = bias[n];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 * i + 4 * fg + r < CELLS) sum += relu_f(acc[i][j][r] + b);
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        if (fg == 0) out[(long long)roi * ld_out + n] = sum / 49.0f;
+    }
+}
+
+// row-major W [N, K] bf16 -> fragment-major Wp[K/32][N/16][64][8]: Wp[ks][jt][fr + 16 fg][e] = W[16 jt + fr][32 ks + 8 fg + e]
+__global__ void pack_wfrag_kernel(const unsigned short* __restrict__ W, unsigned short* __restrict__ Wp, int N, int K) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte chunk per thread
+    const long long total = (long long)N * K / 8;
+    if (idx >= total) return;
+    const int lane = idx & 63;
+    const long long t = idx >> 6;
+    const int jt = (int)(t % (N / 16)), ks = (int)(t / (N / 16));
+    const int fr = lane & 15, fg = lane >> 4;
+    *reinterpret_cast<uint4*>(Wp + idx * 8) = *reinterpret_cast<const uint4*>(W + (long long)(16 * jt + fr) * K + 32 * ks + 8 * fg);
+}
+
+}  // namespace
+
+extern "C" int mv2d_pack_wfrag_bf16(const void* W, void* Wp, int N, int K, void* stream) {
+    MV2D_CHECK_ARG(W && Wp && N > 0 && K > 0 && (N % 16) == 0 && (K % 32) == 0, "mv2d_pack_wfrag_bf16: N % 16 == 0 and K % 32 == 0 required");
+    const long long total = (long long)N * K / 8;
+    hipLaunchKernelGGL(pack_wfrag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)W, (unsigned short*)Wp, N, K);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_qg_conv_pool(const void* roi_feat, const void* W, const float* bias, float* out, int ld_out, int R, void* stream) {
+    MV2D_CHECK_ARG(roi_feat && W && bias && out && ld_out >= C, "mv2d_qg_conv_pool: bad args");
+    MV2D_CHECK_ARG(((uintptr_t)roi_feat & 15) == 0 && ((uintptr_t)W & 15) == 0, "mv2d_qg_conv_pool: operands must be 16-byte aligned");
+    if (R == 0) return MV2D_OK;
+    hipLaunchKernelGGL(roi_conv_pool_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)roi_feat,
+                       (const unsigned short*)W, bias, out, ld_out, R);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}

@@ -119,6 +119,7 @@ class HeadEngine:
         q = 'query_generator.'
         conv = g(q + 'shared_convs.0.conv.weight')                                    # [256,256,3,3] -> [out][tap][cin]
         w['qg_conv_w'] = b16(conv.permute(0, 2, 3, 1).reshape(C, 9 * C))
+        w['qg_conv_wp'] = ops.pack_wfrag(w['qg_conv_w'])                              # fragment-major copy for the fused conv kernel
         w['qg_conv_b'] = g(q + 'shared_convs.0.conv.bias')
         w['qg_fc_w'], w['qg_fc_b'] = g(q + 'shared_fcs.0.weight'), g(q + 'shared_fcs.0.bias')
         e0 = g(q + 'extra_enc.0.weight')                                              # [512,1040] -> K padded to 1056
@@ -378,9 +379,8 @@ class HeadEngine:
         o, W_, tk = ops, self.w, self._tick
         # a6: QueryGenerator
         tk('qg_conv_gemm')
-        o.gemm_bf16(ws['roi_feat'], W_['qg_conv_w'], W_['qg_conv_b'], conv3x3=True, act=1, out=ws['conv_out'])
+        o.qg_conv_pool(ws['roi_feat'], W_['qg_conv_wp'], W_['qg_conv_b'], ws['x2'], R=R)
         tk('qg_rest')
-        o.avgpool49(ws['conv_out'], ws['x2'], C, R)
         o.gemm_f32(ws['x2'], W_['qg_fc_w'], W_['qg_fc_b'], act=1, clamp=5e3, out=ws['enc'], ldc=1056)
         o.gemm_f32(ws['enc'], W_['qg_e0_w'], W_['qg_e0_b'], act=1, out=ws['enc1'])
         o.gemm_f32(ws['enc1'], W_['qg_e2_w'], W_['qg_e2_b'], act=1, out=ws['enc2'])

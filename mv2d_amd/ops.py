@@ -196,6 +196,24 @@ def finalize_reg(reg, ref, L, R, pc_range_host, dt=0.0):
     check(_lib.load().mv2d_finalize_reg(_p(reg), _p(ref), L, R, pc_range_host.data_ptr(), float(dt), _stream()), 'mv2d_finalize_reg')
 
 
+def pack_wfrag(W):
+    """row-major bf16 weight [N,K] -> fragment-major copy (one MFMA fragment = one contiguous 1 KB)."""
+    _req(W, BF16, 'W')
+    N, K = W.shape
+    Wp = torch.empty(N * K, device=W.device, dtype=BF16)
+    check(_lib.load().mv2d_pack_wfrag_bf16(_p(W), _p(Wp), N, K, _stream()), 'mv2d_pack_wfrag_bf16')
+    return Wp
+
+
+def qg_conv_pool(roi_feat, W, bias, out, R=None, ld_out=None):
+    """out[r] = avgpool7x7(relu(conv3x3(roi_feat[r]) + bias)); roi_feat [R,49,256] bf16, W = pack_wfrag(conv weight [256,2304])."""
+    _req(roi_feat, BF16, 'roi_feat'); _req(W, BF16, 'W'); _req(bias, torch.float32, 'bias'); _req(out, torch.float32, 'out')
+    R = roi_feat.shape[0] if R is None else R
+    check(_lib.load().mv2d_qg_conv_pool(_p(roi_feat), _p(W), _p(bias), _p(out), out.stride(0) if ld_out is None else ld_out, R, _stream()),
+          'mv2d_qg_conv_pool')
+    return out
+
+
 def avgpool49(x, out, ld_out, R):
     check(_lib.load().mv2d_avgpool49(_p(x), _p(out), ld_out, R, _stream()), 'mv2d_avgpool49')
     return out

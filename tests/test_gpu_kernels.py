@@ -487,3 +487,24 @@ def test_kv_proj_bit_identical_to_tile_gemm(dev, M, use_mdev):
     assert (got[:, :Mv].float() - exp).abs().max() < 0.05
     if use_mdev:
         assert bool((got[:, Mv:].float() == 7.0).all())
+
+
+def test_qg_conv_pool_fused(dev):
+    """conv3x3 + ReLU + AvgPool2d(7) per RoI in one kernel == implicit-GEMM conv + avgpool49 (same k order; pooling re-associated)
+    and == F.conv2d on the bf16-rounded operands."""
+    from mv2d_amd import ops
+    for R in (1, 37, 300):
+        x = rnd((R, 256, 7, 7), 70).to(dev)
+        w = rnd((256, 256, 3, 3), 71, 0.03).to(dev)
+        b = rnd((256,), 72).to(dev)
+        xr = x.permute(0, 2, 3, 1).reshape(R, 49, 256).contiguous().to(torch.bfloat16)
+        wr = w.permute(0, 2, 3, 1).reshape(256, 2304).contiguous().to(torch.bfloat16)
+        out = torch.empty((R, 256), device=dev)
+        ops.qg_conv_pool(xr, ops.pack_wfrag(wr), b, out)
+        conv = ops.gemm_bf16(xr, wr, b, conv3x3=True, act=1, out_dtype=torch.float32)
+        pooled = torch.empty((R, 256), device=dev)
+        ops.avgpool49(conv, pooled, 256, R)
+        assert relerr(out, pooled) < 1e-6
+        ref = F.avg_pool2d(F.relu(F.conv2d(xr.float().view(R, 7, 7, 256).permute(0, 3, 1, 2).double(),
+                                           wr.float().view(256, 3, 3, 256).permute(0, 3, 1, 2).double(), b.double(), padding=1)), 7).flatten(1)
+        assert relerr(out, ref) < 1e-5
