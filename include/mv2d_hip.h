@@ -89,7 +89,10 @@ int mv2d_heads_fused(const float* outs, const float* const* cls_w, const float* 
 /* Fused FFN partial sums (mmcv FFN 256 -> hidden -> 256 of the decoder layer, configs/mv2d/exp/*:78-79):
  * slabs[s] = relu(X . W1[64s:64s+64]^T + b1[64s:64s+64]) . W2[:, 64s:64s+64]^T  for the hidden/64 slices s, exact fp32.
  * X [M,256], W1 [hidden,256], W2 [256,hidden], slabs [hidden/64, M, 256]; the caller sums the slabs + b2 + residual
- * (mv2d_row_ln with n_parts = hidden/64) — fixed summation order, deterministic. */
+ * (mv2d_row_ln with n_parts = hidden/64) — fixed summation order, deterministic.
+ * W1p / W2p: the weights in the fragment-major order produced by mv2d_ffn_pack_weights (static data: every weight load of a wave is one
+ * contiguous 1 KB). */
+int mv2d_ffn_pack_weights(const float* W1, const float* W2, float* W1p, float* W2p, int hidden, void* stream);
 int mv2d_ffn_fused(const float* X, const float* W1, const float* b1, const float* W2, float* slabs, int M, int hidden, void* stream);
 
 /* The same fused FFN in split precision on the bf16 matrix cores ("bf16x3": x = x_hi + x_lo as a bf16 pair, three bf16 MFMAs per

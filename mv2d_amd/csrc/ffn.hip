@@ -8,6 +8,8 @@
 //   phase 2: P = H[32,64] . W2[:, slice]^T                      (H stays in LDS, W2 slice straight to VGPRs)
 // and writes the partial sum P as slab `slice`; the following row kernel adds the 32 slabs, b2 and the residual in a
 // fixed order (deterministic) and applies LayerNorm.  Operand traffic drops to 160 KB per 2.1 MFLOP block (51 MB).
+// The weights are static and are read FRAGMENT-MAJOR (mv2d_ffn_pack_weights): the float4 a lane needs for (tile, k chunk c) sits at
+// [...][c][lane], so every weight load of a wave is one contiguous 1 KB instead of 16 rows x 64 B.
 #include "common.h"
 
 namespace {
@@ -34,9 +36,10 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const float* __restri
     float4 w1[2][16];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const float* wp = W1 + (long long)(slice * HS + (2 * half + t) * 16 + fr) * C + 4 * fg;
+        // W1p[slice][tile (4)][c (16)][lane][4]
+        const float* wp = W1 + ((long long)((slice * 4 + 2 * half + t) * 16) * 64 + lane) * 4;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) w1[t][c] = *reinterpret_cast<const float4*>(wp + 16 * c);
+        for (int c = 0; c < 16; ++c) w1[t][c] = *reinterpret_cast<const float4*>(wp + c * 256);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -48,9 +51,10 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const float* __restri
     float4 w2[8][4];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const float* wp = W2 + (long long)((8 * half + t) * 16 + fr) * hidden + slice * HS + 4 * fg;
+        // W2p[slice][tile (16)][c (4)][lane][4]
+        const float* wp = W2 + ((long long)((slice * 16 + 8 * half + t) * 4) * 64 + lane) * 4;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) w2[t][c] = *reinterpret_cast<const float4*>(wp + 16 * c);
+        for (int c = 0; c < 4; ++c) w2[t][c] = *reinterpret_cast<const float4*>(wp + c * 256);
     }
     // ---- phase 1: two 16x16 tiles of H per wave, K = 256 (k spread over (MFMA step, lane group) identically for A and W)
     f32x4_t h[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
@@ -103,7 +107,34 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const float* __restri
     }
 }
 
+// W1 [hidden,256], W2 [256,hidden] (nn.Linear layout) -> the fragment-major copies the kernel reads:
+//   W1p[slice][tile][c][fr + 16 fg][e] = W1[64 slice + 16 tile + fr][16 c + 4 fg + e]          (4 tiles, 16 chunks)
+//   W2p[slice][tile][c][fr + 16 fg][e] = W2[16 tile + fr][64 slice + 16 c + 4 fg + e]          (16 tiles, 4 chunks)
+__global__ void ffn_pack_kernel(const float* __restrict__ W1, const float* __restrict__ W2, float* __restrict__ W1p, float* __restrict__ W2p, int hidden) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // one float4 per thread and matrix
+    const long long total = (long long)hidden * C / 4;
+    if (idx >= total) return;
+    const int lane = idx & 63, fr = lane & 15, fg = lane >> 4;
+    long long t = idx >> 6;
+    {   // W1p
+        const int c = (int)(t % 16), tile = (int)((t / 16) % 4), slice = (int)(t / 64);
+        *reinterpret_cast<float4*>(W1p + idx * 4) = *reinterpret_cast<const float4*>(W1 + (long long)(64 * slice + 16 * tile + fr) * C + 16 * c + 4 * fg);
+    }
+    {   // W2p
+        const int c = (int)(t % 4), tile = (int)((t / 4) % 16), slice = (int)(t / 64);
+        *reinterpret_cast<float4*>(W2p + idx * 4) = *reinterpret_cast<const float4*>(W2 + (long long)(16 * tile + fr) * hidden + 64 * slice + 16 * c + 4 * fg);
+    }
+}
+
 }  // namespace
+
+extern "C" int mv2d_ffn_pack_weights(const float* W1, const float* W2, float* W1p, float* W2p, int hidden, void* stream) {
+    MV2D_CHECK_ARG(W1 && W2 && W1p && W2p && hidden > 0 && (hidden % HS) == 0, "mv2d_ffn_pack_weights: bad args");
+    const long long total = (long long)hidden * C / 4;
+    hipLaunchKernelGGL(ffn_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W1, W2, W1p, W2p, hidden);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
 
 extern "C" int mv2d_ffn_fused(const float* X, const float* W1, const float* b1, const float* W2, float* slabs, int M, int hidden,
                               void* stream) {

@@ -95,6 +95,7 @@ class HeadEngine:
             w[f'ffn_b1{i}'] = g(p + 'ffns.0.layers.0.0.bias')
             w[f'ffn_w2{i}'] = g(p + 'ffns.0.layers.1.weight')
             w[f'ffn_b2{i}'] = g(p + 'ffns.0.layers.1.bias')
+            w[f'ffn_w1p{i}'], w[f'ffn_w2p{i}'] = ops.ffn_pack_weights(w[f'ffn_w1{i}'], w[f'ffn_w2{i}'])   # fragment-major copies
             if self.ffn_x3:
                 w[f'ffn_w1x{i}'] = ops.split_bf16x2(w[f'ffn_w1{i}'])
                 w[f'ffn_w2x{i}'] = ops.split_bf16x2(w[f'ffn_w2{i}'])
@@ -417,7 +418,7 @@ class HeadEngine:
             if self.ffn_x3:
                 o.ffn_fused_x3(ws['x2'], W_[f'ffn_w1x{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2x{i}'], ws['parts'], R)
             else:
-                o.ffn_fused(ws['x2'], W_[f'ffn_w1{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2{i}'], ws['parts'], R)
+                o.ffn_fused(ws['x2'], W_[f'ffn_w1p{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2p{i}'], ws['parts'], R)
             o.row_ln(ws['parts'], bias=W_[f'ffn_b2{i}'], residual=ws['x2'], ln=(W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), out=x, addvec=ws['qpos'], out_plus=xq,
                      ln2=(W_['post_w'], W_['post_b']), out2=ws['outs'][i])
 

@@ -111,8 +111,16 @@ def heads_fused(outs, cls_ptrs, reg_ptrs, ref, cls, reg, M, L, pc_range_host, dt
                                        pc_range_host.data_ptr(), float(dt), _stream()), 'mv2d_heads_fused')
 
 
+def ffn_pack_weights(W1, W2):
+    """nn.Linear weights W1 [hidden,256], W2 [256,hidden] -> fragment-major copies (W1p, W2p) for ffn_fused."""
+    _req(W1, torch.float32, 'W1'); _req(W2, torch.float32, 'W2')
+    W1p, W2p = torch.empty_like(W1), torch.empty_like(W2)
+    check(_lib.load().mv2d_ffn_pack_weights(_p(W1), _p(W2), _p(W1p), _p(W2p), W1.shape[0], _stream()), 'mv2d_ffn_pack_weights')
+    return W1p, W2p
+
+
 def ffn_fused(x, W1, b1, W2, slabs=None, M=None):
-    """slabs [hidden/64, M, 256] of partial FFN outputs (sum them + b2 + residual with row_ln)."""
+    """slabs [hidden/64, M, 256] of partial FFN outputs (sum them + b2 + residual with row_ln); W1, W2 = ffn_pack_weights(...)."""
     _req(x, torch.float32, 'x'); _req(W1, torch.float32, 'W1'); _req(W2, torch.float32, 'W2'); _req(b1, torch.float32, 'b1')
     M = x.shape[0] if M is None else M
     hidden = W1.shape[0]

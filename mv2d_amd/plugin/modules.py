@@ -202,7 +202,11 @@ class FFN(nn.Module):
         xr = _rows(x)
         fc1, fc2 = self.layers[0][0], self.layers[1]
         assert fc1.weight.shape[0] % 64 == 0
-        parts = ops.ffn_fused(xr, _f(fc1.weight), _f(fc1.bias), _f(fc2.weight))
+        ver = (fc1.weight.data_ptr(), fc1.weight._version, fc2.weight.data_ptr(), fc2.weight._version, str(fc1.weight.device))
+        if getattr(self, '_packed_ver', None) != ver:                 # fragment-major weight copies, rebuilt when the weights change
+            self._packed = ops.ffn_pack_weights(_f(fc1.weight), _f(fc2.weight))
+            self._packed_ver = ver
+        parts = ops.ffn_fused(xr, self._packed[0], _f(fc1.bias), self._packed[1])
         if not self.add_identity:
             return ops.row_ln(parts, bias=_f(fc2.bias)).view(shp)
         res = xr if identity is None else _rows(identity)

@@ -160,7 +160,7 @@ def test_ffn_fused_exact(dev):
         x = rnd((M, 256), 27).to(dev)
         W1 = rnd((2048, 256), 28, 0.1).to(dev); b1 = rnd((2048,), 29).to(dev)
         W2 = rnd((256, 2048), 30, 0.05).to(dev)
-        slabs = ops.ffn_fused(x, W1, b1, W2)
+        slabs = ops.ffn_fused(x, *ops.ffn_pack_weights(W1, W2)[:1], b1, ops.ffn_pack_weights(W1, W2)[1])
         assert slabs.shape == (32, M, 256)
         ref = F.relu(x.double() @ W1.double().T + b1.double()) @ W2.double().T
         assert relerr(slabs.sum(0), ref) < 2e-6
@@ -177,7 +177,8 @@ def test_ffn_fused_x3_split_precision(dev):
         assert slabs.shape == (32, M, 256)
         ref = F.relu(x.double() @ W1.double().T + b1.double()) @ W2.double().T
         assert relerr(slabs.sum(0), ref) < 3e-5
-        exact = ops.ffn_fused(x, W1, b1, W2)
+        W1p, W2p = ops.ffn_pack_weights(W1, W2)
+        exact = ops.ffn_fused(x, W1p, b1, W2p)
         assert relerr(slabs.sum(0), exact.sum(0)) < 3e-5
 
 
