@@ -82,7 +82,9 @@ int mv2d_kv_proj(const void* A, const void* A2, int n_split, int lda, const void
 /* All per-layer prediction branches in one launch (RH/bbox_heads/cross_attention_head.py:127-146, 216-238; velocity / dt of
  * RH/mv2d_t_head.py:136-140).  outs [L,M,256]; cls_w = {w0,b0,ln1w,ln1b,w3,b3,ln4w,ln4b,w6,b6}, reg_w = {w0,b0,w2,b2,w4,b4}: HOST
  * arrays of device pointers, every tensor stacked over the L layers; ref [M,3]; out cls, reg [L,M,10] (reg final: sigmoid / ref /
- * pc_range / dt applied). */
+ * pc_range / dt applied).  The four 256x256 matrices per layer (cls w0, w3; reg w0, w2) are passed FRAGMENT-MAJOR: the stacked [L*256, 256]
+ * tensor run through mv2d_pack_wfrag_f32 (static weights: one contiguous 1 KB per fragment load); the 10x256 output layers stay row-major. */
+int mv2d_pack_wfrag_f32(const float* W, float* Wp, int N, int K, int ldw, void* stream);   /* Wp[ceil(N/16)][K/16][64][4] <- W[N][ldw] */
 int mv2d_heads_fused(const float* outs, const float* const* cls_w, const float* const* reg_w, const float* ref, float* cls, float* reg,
                      int M, int L, float eps, const float* pc_range, float dt, void* stream);
 

@@ -27,6 +27,14 @@ __device__ __forceinline__ void load_w(Frag& f, const float* __restrict__ W, int
     for (int c = 0; c < 16; ++c) f.v[c] = *reinterpret_cast<const float4*>(wp + 16 * c);
 }
 
+// the same fragment from a FRAGMENT-MAJOR weight copy (mv2d_pack_wfrag_f32: [16-row tile][k chunk c][lane][4]): one contiguous
+// 1 KB per load instead of 16 rows x 64 B
+__device__ __forceinline__ void load_w_frag(Frag& f, const float* __restrict__ Wp, int tile, int lane) {
+    const float* wp = Wp + ((long long)tile * 16 * 64 + lane) * 4;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) f.v[c] = *reinterpret_cast<const float4*>(wp + c * 256);
+}
+
 __device__ __forceinline__ f32x4_t tile_mma(const float* __restrict__ As, const Frag& f, int fr, int fg) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -43,12 +51,21 @@ __device__ __forceinline__ f32x4_t tile_mma(const float* __restrict__ As, const 
 // Out[16,256] = As[16,256] . W[256,256]^T: wave w computes columns 64w .. 64w+63 (4 tiles), results returned in registers.
 // All 64 weight-fragment loads of the wave (4 tiles x 16 float4 = 256 VGPRs; the kernels run one wave per SIMD) are issued before
 // the first MFMA: the weights come from the Infinity Cache (~2.5 us away) and must be waited for once, not once per tile.
+template <bool FRAG = false>
 __device__ __forceinline__ void linear256(const float* __restrict__ As, const float* __restrict__ W, int wave, int fr, int fg, f32x4_t acc[4]) {
     Frag f0, f1, f2, f3;
-    load_w(f0, W, C, wave * 64 + fr, C, fg);
-    load_w(f1, W, C, wave * 64 + 16 + fr, C, fg);
-    load_w(f2, W, C, wave * 64 + 32 + fr, C, fg);
-    load_w(f3, W, C, wave * 64 + 48 + fr, C, fg);
+    if (FRAG) {
+        const int lane = fr + 16 * fg;
+        load_w_frag(f0, W, wave * 4, lane);
+        load_w_frag(f1, W, wave * 4 + 1, lane);
+        load_w_frag(f2, W, wave * 4 + 2, lane);
+        load_w_frag(f3, W, wave * 4 + 3, lane);
+    } else {
+        load_w(f0, W, C, wave * 64 + fr, C, fg);
+        load_w(f1, W, C, wave * 64 + 16 + fr, C, fg);
+        load_w(f2, W, C, wave * 64 + 32 + fr, C, fg);
+        load_w(f3, W, C, wave * 64 + 48 + fr, C, fg);
+    }
     __builtin_amdgcn_sched_barrier(0);          // keep the compiler from sinking the loads back next to their MFMAs
     acc[0] = tile_mma(As, f0, fr, fg);
     acc[1] = tile_mma(As, f1, fr, fg);
@@ -167,22 +184,22 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p) {
     f32x4_t acc[4];
     const float* wlast; const float* blast; float* outp;
     if (branch == 0) {
-        linear256(ta, p.w0 + wl, wave, fr, fg, acc);
+        linear256<true>(ta, p.w0 + wl, wave, fr, fg, acc);
         store_tile(tb, acc, p.b0 + bl, wave, fr, fg, false, 1.0f);
         __syncthreads();
         ln_tile(tb, nullptr, p.lnw1 + bl, p.lnb1 + bl, true, nullptr, nullptr, nullptr, m0, p.M, wave, lane, p.eps);
         __syncthreads();
-        linear256(tb, p.w3 + wl, wave, fr, fg, acc);
+        linear256<true>(tb, p.w3 + wl, wave, fr, fg, acc);
         store_tile(ta, acc, p.b3 + bl, wave, fr, fg, false, 1.0f);
         __syncthreads();
         ln_tile(ta, nullptr, p.lnw4 + bl, p.lnb4 + bl, true, nullptr, nullptr, nullptr, m0, p.M, wave, lane, p.eps);
         __syncthreads();
         wlast = p.w6 + (long long)l * 10 * C; blast = p.b6 + l * 10; outp = p.cls;
     } else {
-        linear256(ta, p.r0 + wl, wave, fr, fg, acc);
+        linear256<true>(ta, p.r0 + wl, wave, fr, fg, acc);
         store_tile(tb, acc, p.rb0 + bl, wave, fr, fg, true, 1.0f);
         __syncthreads();
-        linear256(tb, p.r2 + wl, wave, fr, fg, acc);
+        linear256<true>(tb, p.r2 + wl, wave, fr, fg, acc);
         store_tile(ta, acc, p.rb2 + bl, wave, fr, fg, true, 1.0f);
         __syncthreads();
         wlast = p.r4 + (long long)l * 10 * C; blast = p.rb4 + l * 10; outp = p.reg;
@@ -215,7 +232,27 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p) {
     }
 }
 
+// W [N, ldw] fp32 -> fragment-major Wp[ceil(N/16)][K/16][64][4]: Wp[tile][c][fr + 16 fg][e] = W[min(16 tile + fr, N-1)][16 c + 4 fg + e]
+__global__ void pack_wfrag_f32_kernel(const float* __restrict__ W, float* __restrict__ Wp, int N, int K, int ldw) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // one float4 per thread
+    const int tiles = (N + 15) / 16, kc = K / 16;
+    if (idx >= (long long)tiles * kc * 64) return;
+    const int lane = idx & 63, fr = lane & 15, fg = lane >> 4;
+    const long long t = idx >> 6;
+    const int c = (int)(t % kc), tile = (int)(t / kc);
+    const int row = min(16 * tile + fr, N - 1);
+    *reinterpret_cast<float4*>(Wp + idx * 4) = *reinterpret_cast<const float4*>(W + (long long)row * ldw + 16 * c + 4 * fg);
+}
+
 }  // namespace
+
+extern "C" int mv2d_pack_wfrag_f32(const float* W, float* Wp, int N, int K, int ldw, void* stream) {
+    MV2D_CHECK_ARG(W && Wp && N > 0 && K > 0 && (K % 16) == 0 && (ldw % 4) == 0 && ldw >= K, "mv2d_pack_wfrag_f32: bad args");
+    const long long total = (long long)((N + 15) / 16) * (K / 16) * 64;
+    hipLaunchKernelGGL(pack_wfrag_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, Wp, N, K, ldw);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
 
 extern "C" int mv2d_attn_out_fused(const float* ctx, const float* resid, const float* Wo, const float* bo, const float* ln_w, const float* ln_b,
                                    float* x_out, const float* qpos, const float* Wq, const float* bq, float qscale, float* q_out, int M,

@@ -138,8 +138,10 @@ class HeadEngine:
         w['pe_wr'], w['pe_br'] = b16(c1('fpe.conv_reduce.weight')), g(pe + 'fpe.conv_reduce.bias')
         w['pe_we'], w['pe_be'] = b16(c1('fpe.conv_expand.weight')), g(pe + 'fpe.conv_expand.bias')
         self.w = w
-        self.cls_ptrs = ops.make_ptr_array([w[k] for k in ('cls_w0', 'cls_b0', 'cls_lnw1', 'cls_lnb1', 'cls_w3', 'cls_b3', 'cls_lnw4', 'cls_lnb4', 'cls_w6', 'cls_b6')])
-        self.reg_ptrs = ops.make_ptr_array([w[k] for k in ('reg_w0', 'reg_b0', 'reg_w2', 'reg_b2', 'reg_w4', 'reg_b4')])
+        for k in ('cls_w0', 'cls_w3', 'reg_w0', 'reg_w2'):                              # [L,256,256] -> fragment-major copies for heads_fused
+            w[k + 'p'] = ops.pack_wfrag_f32(w[k])
+        self.cls_ptrs = ops.make_ptr_array([w[k] for k in ('cls_w0p', 'cls_b0', 'cls_lnw1', 'cls_lnb1', 'cls_w3p', 'cls_b3', 'cls_lnw4', 'cls_lnb4', 'cls_w6', 'cls_b6')])
+        self.reg_ptrs = ops.make_ptr_array([w[k] for k in ('reg_w0p', 'reg_b0', 'reg_w2p', 'reg_b2', 'reg_w4', 'reg_b4')])
 
     # ------------------------------------------------------------------------------------------ workspace
     def _workspace(self, V, h, w, R):

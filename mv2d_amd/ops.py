@@ -106,6 +106,17 @@ def make_ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+def pack_wfrag_f32(W):
+    """fp32 weight [..., N, K] (rows stacked) -> fragment-major copy of the [prod(...)*N, K] matrix (same number of elements
+    when the row count is a multiple of 16)."""
+    _req(W, torch.float32, 'W')
+    W2 = W.reshape(-1, W.shape[-1]).contiguous()
+    N, K = W2.shape
+    Wp = torch.empty(((N + 15) // 16) * 16 * K, device=W.device, dtype=torch.float32)
+    check(_lib.load().mv2d_pack_wfrag_f32(_p(W2), _p(Wp), N, K, K, _stream()), 'mv2d_pack_wfrag_f32')
+    return Wp
+
+
 def heads_fused(outs, cls_ptrs, reg_ptrs, ref, cls, reg, M, L, pc_range_host, dt=0.0, eps=1e-5):
     check(_lib.load().mv2d_heads_fused(_p(outs), cls_ptrs, reg_ptrs, _p(ref), _p(cls), _p(reg), M, L, float(eps),
                                        pc_range_host.data_ptr(), float(dt), _stream()), 'mv2d_heads_fused')

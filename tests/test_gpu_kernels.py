@@ -147,6 +147,10 @@ def test_heads_fused(dev):
     st = lambda fmt: torch.stack([sdt[fmt.format(l)] for l in range(L)]).contiguous().to(dev)
     cw = [st('bbox_head.cls_branches.{}.' + n) for n in ('0.weight', '0.bias', '1.weight', '1.bias', '3.weight', '3.bias', '4.weight', '4.bias', '6.weight', '6.bias')]
     rw = [st('bbox_head.reg_branches.{}.' + n) for n in ('0.weight', '0.bias', '2.weight', '2.bias', '4.weight', '4.bias')]
+    for i in (0, 4):
+        cw[i] = ops.pack_wfrag_f32(cw[i])            # the 256x256 matrices go in fragment-major
+    for i in (0, 2):
+        rw[i] = ops.pack_wfrag_f32(rw[i])
     cls = torch.empty((L, M, 10), device=dev); reg = torch.empty((L, M, 10), device=dev)
     ops.heads_fused(outs.to(dev), ops.make_ptr_array(cw), ops.make_ptr_array(rw), ref.to(dev), cls, reg, M, L,
                     torch.tensor(O.PC_RANGE, dtype=torch.float32), dt=0.5)
