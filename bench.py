@@ -32,10 +32,7 @@ def stage_flops(kind, R, S, L=6):
     """Algorithmic FLOPs (2 x MAC) of the dense bf16 MFMA launches of one frame."""
     C = 256
     return {
-        'pe_gemm_192x1024': 2.0 * S * 192 * 1024,
-        'pe_gemm_384x1024': 2.0 * S * 384 * 1024,
-        'pe_gemm_1024x256_a': 2.0 * S * 1024 * 256,
-        'pe_gemm_1024x256_b': 2.0 * S * 1024 * 256,
+        'pe_fused': 2.0 * S * (192 * 1024 + 384 * 1024 + 2 * 1024 * 256 + 2 * 256 * 256),     # 2.49 MFLOP per key position
         'qg_conv_gemm': 2.0 * R * 49 * 2304 * 256,
         'kv_gemm': 2.0 * (S if kind == 'T' else R * 49) * C * (2 * L * C),
     }
@@ -46,16 +43,14 @@ def stage_bytes(kind, R, S, L=6):
     C = 256
     Mkv = S if kind == 'T' else R * 49
     return {
-        'pe_gemm_192x1024': S * 192 * 2 + 192 * 1024 * 2 + S * 1024 * 2,
-        'pe_gemm_384x1024': S * 384 * 2 + 384 * 1024 * 2 + S * 1024 * 2,
-        'pe_gemm_1024x256_a': S * 1024 * 2 + 1024 * 256 * 2 + S * 256 * 4 + S * 256 * 4,          # + gate operand, fp32 out
-        'pe_gemm_1024x256_b': S * 1024 * 2 + 1024 * 256 * 2 + 2 * S * 256 * 4 + S * 256 * (4 + 2),  # + add operands, fp32 + bf16 out
+        # inputs (A1, A2, Xf bf16, Xf fp32) + the six weight matrices once + pe fp32 and Xk bf16 out
+        'pe_fused': S * (192 + 384 + 256) * 2 + S * 256 * 4 + (192 * 1024 + 384 * 1024 + 2 * 1024 * 256 + 2 * 256 * 256) * 2 + S * 256 * 6,
         'qg_conv_gemm': R * 49 * 256 * 2 + 2304 * 256 * 2 + R * 256 * 4,                       # pooled [R,256] output
         'kv_gemm': 2 * Mkv * C * 2 + 2 * L * C * C * 2 + Mkv * 2 * L * C * 2,
     }
 
 
-STAGE_KERNEL = {'kv_gemm': 'kvproj_kernel', 'qg_conv_gemm': 'roi_conv_pool_kernel (conv3x3 + ReLU + avgpool fused)'}
+STAGE_KERNEL = {'pe_fused': 'pe_fused_kernel (3 two-layer MLPs + gate + sum)', 'kv_gemm': 'kvproj_kernel', 'qg_conv_gemm': 'roi_conv_pool_kernel (conv3x3 + ReLU + avgpool fused)'}
 
 
 def main():

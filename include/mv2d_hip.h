@@ -66,6 +66,16 @@ int mv2d_attn_out_fused(const float* ctx, const float* resid, const float* Wo, c
                         float* x_out, const float* qpos, const float* Wq, const float* bq, float qscale, float* q_out, int M, float eps,
                         void* stream);
 
+/* The position-encoding block of the PE module fused into one launch (MU/pe.py:36-48,64-77,150-166):
+ *   pe = adapt_pos3d(A2) + position_encoder(A1) * sigmoid(conv_expand(relu(conv_reduce(Xf)))),  Xk = bf16(pe + Xf32)
+ * A1 [M,192], A2 [M,384], Xfb [M,256] bf16 and Xf32 [M,256] fp32 rows (the outputs of mv2d_pe_inputs); all six weights in the
+ * FRAGMENT-MAJOR order of mv2d_pack_wfrag_bf16 (W1a [1024,192], W1b [256,1024], W2a [1024,384], W2b [256,1024], Wr/We [256,256]);
+ * m_dev: optional device-side row count.  pe [M,256] fp32, Xk [M,256] bf16.  Bit-identical to the chain of six mv2d_gemm_bf16 calls. */
+int mv2d_pe_fused(const void* A1, const void* A2, const void* Xfb, const float* Xf32, const int* m_dev, int M,
+                  const void* W1a, const float* b1a, const void* W1b, const float* b1b,
+                  const void* W2a, const float* b2a, const void* W2b, const float* b2b,
+                  const void* Wr, const float* br, const void* We, const float* be, float* pe, void* Xk, void* stream);
+
 /* QueryGenerator shared conv + pooling fused, one block per RoI (RH/utils/query_generator.py:298-304,322-331,352-358):
  * out[r, n] = mean over the 49 cells of relu(conv3x3(roi_feat[r])[cell, n] + bias[n]).  roi_feat [R,49,256] bf16 (cell-major),
  * Wp = the conv weight [256][tap][cin] (bf16, K = 2304) in FRAGMENT-MAJOR order as produced by mv2d_pack_wfrag_bf16 (weights are

@@ -67,6 +67,7 @@ class HeadEngine:
         self.prof = None              # dict name -> [events] when stage timing is on (bench.py)
         self.fork_qg = True           # T path: query-generator chain on a second stream
         self.ffn_x3 = os.environ.get('MV2D_FFN_X3', '0') == '1'   # FFN in bf16x3 split precision: -3 % latency, -7 % throughput -> off
+        self.pe_fused = os.environ.get('MV2D_PE_FUSED', '1') == '1'   # one fused launch for the PE block instead of six GEMMs
         self.force_nc = None          # bench only (S path): overwrite the correlation lists so that every query reads n_c RoIs
         self.fuse_rows = os.environ.get('MV2D_FUSE_ROWS', '0') == '1'   # row-block fused out_proj+LN(+q proj): measured slower, kept for A/B
         self.load_state(state_dict)
@@ -137,6 +138,10 @@ class HeadEngine:
         w['pe_w2b'], w['pe_b2b'] = b16(c1('adapt_pos3d.2.weight')), g(pe + 'adapt_pos3d.2.bias')
         w['pe_wr'], w['pe_br'] = b16(c1('fpe.conv_reduce.weight')), g(pe + 'fpe.conv_reduce.bias')
         w['pe_we'], w['pe_be'] = b16(c1('fpe.conv_expand.weight')), g(pe + 'fpe.conv_expand.bias')
+        # fragment-major copies for the fused PE kernel
+        w['pe_pack'] = dict(w1a=ops.pack_wfrag(w['pe_w1a']), b1a=w['pe_b1a'], w1b=ops.pack_wfrag(w['pe_w1b']), b1b=w['pe_b1b'],
+                            w2a=ops.pack_wfrag(w['pe_w2a']), b2a=w['pe_b2a'], w2b=ops.pack_wfrag(w['pe_w2b']), b2b=w['pe_b2b'],
+                            wr=ops.pack_wfrag(w['pe_wr']), br=w['pe_br'], we=ops.pack_wfrag(w['pe_we']), be=w['pe_be'])
         self.w = w
         for k in ('cls_w0', 'cls_w3', 'reg_w0', 'reg_w2'):                              # [L,256,256] -> fragment-major copies for heads_fused
             w[k + 'p'] = ops.pack_wfrag_f32(w[k])
@@ -338,17 +343,16 @@ class HeadEngine:
         o.pe_inputs(ws['s2pos'], ws['S_dev'], P, featcl, T['img2lidar'], T['coords_w'], T['coords_h'], T['coords_d'], T['embeds'],
                     self.const['dim_t'], ws['A1'], ws['A2'], ws['Xf_b'], ws['Xf32'], V, h, w, self.depth_num, self.post_range_h64)
         md = ws['S_dev']
-        tk('pe_gemm_192x1024')
-        o.gemm_bf16(ws['A1'], W_['pe_w1a'], W_['pe_b1a'], m_dev=md, act=1, out=ws['H1'])
-        tk('pe_gemm_384x1024')
-        o.gemm_bf16(ws['A2'], W_['pe_w2a'], W_['pe_b2a'], m_dev=md, act=1, out=ws['H2'])
-        tk('pe_gemm_gate')
-        o.gemm_bf16(ws['Xf_b'], W_['pe_wr'], W_['pe_br'], m_dev=md, act=1, out=ws['Hg'])
-        o.gemm_bf16(ws['Hg'], W_['pe_we'], W_['pe_be'], m_dev=md, act=2, out=ws['gate'])
-        tk('pe_gemm_1024x256_a')
-        o.gemm_bf16(ws['H1'], W_['pe_w1b'], W_['pe_b1b'], m_dev=md, mul=ws['gate'], out=ws['Pg'])
-        tk('pe_gemm_1024x256_b')
-        o.gemm_bf16(ws['H2'], W_['pe_w2b'], W_['pe_b2b'], m_dev=md, add=ws['Pg'], out=ws['pe'], out2=ws['Xk'], add2=ws['Xf32'])
+        tk('pe_fused')
+        if self.pe_fused:
+            o.pe_fused(ws['A1'], ws['A2'], ws['Xf_b'], ws['Xf32'], md, W_['pe_pack'], ws['pe'], ws['Xk'], M=P)
+        else:
+            o.gemm_bf16(ws['A1'], W_['pe_w1a'], W_['pe_b1a'], m_dev=md, act=1, out=ws['H1'])
+            o.gemm_bf16(ws['A2'], W_['pe_w2a'], W_['pe_b2a'], m_dev=md, act=1, out=ws['H2'])
+            o.gemm_bf16(ws['Xf_b'], W_['pe_wr'], W_['pe_br'], m_dev=md, act=1, out=ws['Hg'])
+            o.gemm_bf16(ws['Hg'], W_['pe_we'], W_['pe_be'], m_dev=md, act=2, out=ws['gate'])
+            o.gemm_bf16(ws['H1'], W_['pe_w1b'], W_['pe_b1b'], m_dev=md, mul=ws['gate'], out=ws['Pg'])
+            o.gemm_bf16(ws['H2'], W_['pe_w2b'], W_['pe_b2b'], m_dev=md, add=ws['Pg'], out=ws['pe'], out2=ws['Xk'], add2=ws['Xf32'])
         if self.kind == 'S':
             tk('roi_align')
             o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=ws['pos2s'],

@@ -513,3 +513,33 @@ def test_qg_conv_pool_fused(dev):
         ref = F.avg_pool2d(F.relu(F.conv2d(xr.float().view(R, 7, 7, 256).permute(0, 3, 1, 2).double(),
                                            wr.float().view(256, 3, 3, 256).permute(0, 3, 1, 2).double(), b.double(), padding=1)), 7).flatten(1)
         assert relerr(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize('M,use_mdev', [(64, False), (1000, False), (8794, True)])
+def test_pe_fused_bit_identical_to_gemm_chain(dev, M, use_mdev):
+    """mv2d_pe_fused (three two-layer MLPs + gate + sum in one launch, hidden layers resident in LDS, fragment-major weights)
+    == the chain of six mv2d_gemm_bf16 launches, bit for bit (same k order, same bf16 rounding of the hidden layers)."""
+    from mv2d_amd import ops
+    bf = torch.bfloat16
+    A1 = rnd((M, 192), 90).to(dev).to(bf); A2 = rnd((M, 384), 91).to(dev).to(bf)
+    Xf32 = rnd((M, 256), 92).to(dev); Xfb = Xf32.to(bf)
+    W = dict(w1a=rnd((1024, 192), 93, 0.08), w1b=rnd((256, 1024), 94, 0.04), w2a=rnd((1024, 384), 95, 0.06), w2b=rnd((256, 1024), 96, 0.04),
+             wr=rnd((256, 256), 97, 0.07), we=rnd((256, 256), 98, 0.07))
+    W = {k: v.to(dev).to(bf) for k, v in W.items()}
+    B = {k: rnd((n,), 99 + i).to(dev) for i, (k, n) in enumerate(dict(b1a=1024, b1b=256, b2a=1024, b2b=256, br=256, be=256).items())}
+    md = torch.tensor([M - 13], dtype=torch.int32, device=dev) if use_mdev else None
+    H1 = ops.gemm_bf16(A1, W['w1a'], B['b1a'], m_dev=md, act=1)
+    H2 = ops.gemm_bf16(A2, W['w2a'], B['b2a'], m_dev=md, act=1)
+    Hg = ops.gemm_bf16(Xfb, W['wr'], B['br'], m_dev=md, act=1)
+    gate = ops.gemm_bf16(Hg, W['we'], B['be'], m_dev=md, act=2, out_dtype=torch.float32)
+    Pg = ops.gemm_bf16(H1, W['w1b'], B['b1b'], m_dev=md, mul=gate, out_dtype=torch.float32)
+    pe_ref = torch.zeros((M, 256), device=dev); xk_ref = torch.zeros((M, 256), device=dev, dtype=bf)
+    ops.gemm_bf16(H2, W['w2b'], B['b2b'], m_dev=md, add=Pg, out=pe_ref, out2=xk_ref, add2=Xf32)
+    wp = {k: ops.pack_wfrag(v) for k, v in W.items()}
+    wp.update(B)
+    pe = torch.zeros((M, 256), device=dev); xk = torch.zeros((M, 256), device=dev, dtype=bf)
+    ops.pe_fused(A1, A2, Xfb, Xf32, md, wp, pe, xk)
+    torch.cuda.synchronize()
+    Mv = M - 13 if use_mdev else M
+    assert torch.equal(pe[:Mv], pe_ref[:Mv])
+    assert torch.equal(xk[:Mv].view(torch.int16), xk_ref[:Mv].view(torch.int16))
