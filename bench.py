@@ -87,7 +87,10 @@ def main():
     sd = synthetic.make_head_state(seed=0)
     base = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'], topk=args.corr_topk)
     base.force_nc = args.force_nc
-    base.fork_qg = args.inflight == 1      # intra-frame two-stream fork helps latency, hurts when several frames are already in flight
+    base.fork_qg = args.inflight == 1
+    # several frames in flight: the row-fused out_proj + LN (+ q proj) kernels (19 blocks x 16 waves) leave the chip to the other
+    # frames and win; one frame in flight: the N-parallel launches are faster
+    base.fuse_rows = args.inflight > 1 if os.environ.get('MV2D_FUSE_ROWS') is None else os.environ['MV2D_FUSE_ROWS'] == '1'      # intra-frame two-stream fork helps latency, hurts when several frames are already in flight
     engines = [base] + [base.clone_shared() for _ in range(args.inflight - 1)]
     # frames in flight go on streams that were MEASURED to run concurrently (queue/pipe sharing serialises others)
     from mv2d_amd.streams import concurrent_streams

@@ -136,30 +136,59 @@ struct AttnOutParams {
     int M; float eps;
 };
 
-__global__ __launch_bounds__(256, 1) void attn_out_fused_kernel(AttnOutParams p) {
+// 16 waves per block: wave w owns the 16-column tile w of BOTH linears (one 16x16x256 tile each = exactly the work a wave of the
+// N-parallel GEMM kernel does, so the chain is not longer than two separate launches), then row w of the LayerNorm.
+// (The first version of this kernel gave a wave four tiles per linear: 19 blocks x 4 waves chained 8 tiles each and lost to three
+//  separate launches.)  VGPR budget at 4 waves per SIMD is 128: the activation tile is staged through LDS by one 16-byte load
+// per thread, only the weight fragment (64 VGPRs) is held in registers; the Wq fragment is fetched into the same registers
+// behind the first tile's MFMAs and arrives under the LayerNorm.
+__global__ __launch_bounds__(1024) void attn_out_fused_kernel(AttnOutParams p) {
     __shared__ __attribute__((aligned(16))) float ta[16 * C];
     __shared__ __attribute__((aligned(16))) float tb[16 * C];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int m0 = blockIdx.x * 16;
-    load_rows(ta, p.ctx, nullptr, m0, p.M, tid);
+    // activation tile: thread -> (row = wave, 16-byte slot = lane), weight fragment of column tile `wave`
+    const long long grow = (long long)min(m0 + wave, p.M - 1) * C + lane * 4;
+    const float4 av = *reinterpret_cast<const float4*>(p.ctx + grow);
+    Frag f;
+    load_w(f, p.Wo, C, wave * 16 + fr, C, fg);
+    *reinterpret_cast<float4*>(ta + wave * C + ((lane ^ (wave & 15)) << 2)) = av;
     __syncthreads();
-    f32x4_t acc[4];
-    linear256(ta, p.Wo, wave, fr, fg, acc);
-    store_tile(tb, acc, p.bo, wave, fr, fg, false, 1.0f);
+    f32x4_t acc = tile_mma(ta, f, fr, fg);
+    if (p.Wq) load_w(f, p.Wq, C, wave * 16 + fr, C, fg);        // in flight during the LayerNorm
+    {
+        const int col = wave * 16 + fr;
+        const float b = p.bo[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tb[toff(4 * fg + r, col)] = acc[r] + b;
+    }
     __syncthreads();
-    ln_tile(tb, p.resid, p.lw, p.lb, false, p.x_out, p.qpos, p.Wq ? ta : nullptr, m0, p.M, wave, lane, p.eps);
+    {   // row `wave`: residual + LayerNorm exactly like row_ln_kernel (lane = 4 consecutive columns, wavefront reductions)
+        const int row = wave, m = m0 + row;
+        float4 v = *reinterpret_cast<const float4*>(tb + row * C + ((lane ^ (row & 15)) << 2));
+        const float4 u = *reinterpret_cast<const float4*>(p.resid + grow);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
+        const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+        const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / C);
+        const float rstd = 1.0f / sqrtf(var + p.eps);
+        const float4 ww = *reinterpret_cast<const float4*>(p.lw + lane * 4), bb = *reinterpret_cast<const float4*>(p.lb + lane * 4);
+        v = make_float4(dx * rstd * ww.x + bb.x, dy * rstd * ww.y + bb.y, dz * rstd * ww.z + bb.z, dw * rstd * ww.w + bb.w);
+        if (m < p.M) *reinterpret_cast<float4*>(p.x_out + grow) = v;
+        if (p.Wq) {
+            const float4 qp = *reinterpret_cast<const float4*>(p.qpos + grow);
+            *reinterpret_cast<float4*>(ta + row * C + ((lane ^ (row & 15)) << 2)) = make_float4(v.x + qp.x, v.y + qp.y, v.z + qp.z, v.w + qp.w);
+        }
+    }
     if (!p.Wq) return;
     __syncthreads();
-    linear256(ta, p.Wq, wave, fr, fg, acc);
+    acc = tile_mma(ta, f, fr, fg);
+    const int col = wave * 16 + fr;
+    const float b = p.bq[col];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int col = wave * 64 + 16 * t + fr;
-        const float b = p.bq[col];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + 4 * fg + r;
-            if (m < p.M) p.q_out[(long long)m * C + col] = (acc[t][r] + b) * p.qscale;
-        }
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 4 * fg + r;
+        if (m < p.M) p.q_out[(long long)m * C + col] = (acc[r] + b) * p.qscale;
     }
 }
 
@@ -261,7 +290,7 @@ extern "C" int mv2d_attn_out_fused(const float* ctx, const float* resid, const f
     MV2D_CHECK_ARG(!Wq || (qpos && bq && q_out), "mv2d_attn_out_fused: the q stage needs qpos, bq and q_out");
     if (M == 0) return MV2D_OK;
     AttnOutParams p{ctx, resid, Wo, bo, ln_w, ln_b, x_out, qpos, Wq, bq, qscale, q_out, M, eps};
-    hipLaunchKernelGGL(attn_out_fused_kernel, dim3(cdiv(M, 16)), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(attn_out_fused_kernel, dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
