@@ -88,9 +88,6 @@ def main():
     base = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'], topk=args.corr_topk)
     base.force_nc = args.force_nc
     base.fork_qg = args.inflight == 1
-    # several frames in flight: the row-fused out_proj + LN (+ q proj) kernels (19 blocks x 16 waves) leave the chip to the other
-    # frames and win; one frame in flight: the N-parallel launches are faster
-    base.fuse_rows = args.inflight > 1 if os.environ.get('MV2D_FUSE_ROWS') is None else os.environ['MV2D_FUSE_ROWS'] == '1'      # intra-frame two-stream fork helps latency, hurts when several frames are already in flight
     engines = [base] + [base.clone_shared() for _ in range(args.inflight - 1)]
     # frames in flight go on streams that were MEASURED to run concurrently (queue/pipe sharing serialises others)
     from mv2d_amd.streams import concurrent_streams
@@ -244,7 +241,7 @@ def main():
             'metric': 'multi-view samples/sec (6-cam frames) through the MV2D RoI-head hot path',
             'value': round(value, 2), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16 (key side MFMA) / f32 (query side)', 'data': 'synthetic',
+            'dtype': 'bf16 (key side MFMA) / f32 + bf16x3 split precision (query side)', 'data': 'synthetic',
             'config': {'workload': f'{args.workload}: MV2D-{kind} head, {len(metas)} views {metas[0]["img_shape"][1]}x{metas[0]["img_shape"][0]}, '
                                    f'R={R} queries, S={S} key positions, nnz={nnz} allowed (q,k) pairs' + (f', corr_topk={args.corr_topk}' if args.corr_topk else '') + (f', forced n_c={args.force_nc}' if args.force_nc else ''),
                        'frames_per_step_per_gpu': args.inflight, 'global_batch': world * args.inflight,

@@ -89,6 +89,12 @@ int mv2d_qg_conv_pool(const void* roi_feat, const void* W, const float* bias, fl
 int mv2d_kv_proj(const void* A, const void* A2, int n_split, int lda, const void* W, const float* bias, int M, int N,
                  const int* m_dev, void* C, int ldc, long long c_blk_stride, int c_blk_cols, void* stream);
 
+/* The same chain in split precision (bf16x3, ~1e-5 relative): Wo / Wq as bf16 hi/lo pairs (mv2d_split_bf16x2), each in the
+ * fragment-major order of mv2d_pack_wfrag_bf16. */
+int mv2d_attn_out_fused_x3(const float* ctx, const float* resid, const void* Wo_hi, const void* Wo_lo, const float* bo,
+                           const float* ln_w, const float* ln_b, float* x_out, const float* qpos, const void* Wq_hi,
+                           const void* Wq_lo, const float* bq, float qscale, float* q_out, int M, float eps, void* stream);
+
 /* All per-layer prediction branches in one launch (RH/bbox_heads/cross_attention_head.py:127-146, 216-238; velocity / dt of
  * RH/mv2d_t_head.py:136-140).  outs [L,M,256]; cls_w = {w0,b0,ln1w,ln1b,w3,b3,ln4w,ln4b,w6,b6}, reg_w = {w0,b0,w2,b2,w4,b4}: HOST
  * arrays of device pointers, every tensor stacked over the L layers; ref [M,3]; out cls, reg [L,M,10] (reg final: sigmoid / ref /

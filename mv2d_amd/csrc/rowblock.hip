@@ -192,6 +192,112 @@ __global__ __launch_bounds__(1024) void attn_out_fused_kernel(AttnOutParams p) {
     }
 }
 
+// The same fused chain in split precision ("bf16x3", cf. ffn_x3.hip / gemm_x3.hip): both weights come as bf16 hi/lo pairs in
+// fragment-major order (mv2d_split_bf16x2 + mv2d_pack_wfrag_bf16), the activation tile is split when it is staged into LDS.
+// 24 v_mfma_f32_16x16x32_bf16 per tile instead of 64 v_mfma_f32_16x16x4_f32 (408 vs 2048 matrix-pipe cycles per wave, and a
+// block's 16 waves share one CU), ~1e-5 relative error.
+struct AttnOutX3Params {
+    const float* ctx; const float* resid; const unsigned short* Woh; const unsigned short* Wol; const float* bo; const float* lw; const float* lb;
+    float* x_out;
+    const float* qpos; const unsigned short* Wqh; const unsigned short* Wql; const float* bq; float qscale; float* q_out;
+    int M; float eps;
+};
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+union BFrag { uint4 u; mfma_bf16x8 v; };
+
+__device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
+    hi = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    lo = make_uint2(pack_bf16x2(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xffff0000u)),
+                    pack_bf16x2(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xffff0000u)));
+}
+
+// one 16x16 tile: sum over 8 k-steps of a_hi.w_hi + a_lo.w_hi + a_hi.w_lo; activation rows from the bf16 LDS images (512 B rows,
+// 16-byte chunk c of row r at c ^ r), weight fragments (hi, lo) already in registers
+__device__ __forceinline__ f32x4_t tile_mma_x3(const unsigned char* __restrict__ ah, const unsigned char* __restrict__ al, const BFrag wh[8],
+                                               const BFrag wl[8], int fr, int fg) {
+    f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        BFrag xh, xl;
+        const int off = fr * 512 + (((4 * s + fg) ^ fr) << 4);
+        xh.u = *reinterpret_cast<const uint4*>(ah + off);
+        xl.u = *reinterpret_cast<const uint4*>(al + off);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh.v, wh[s].v, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl.v, wh[s].v, a1, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh.v, wl[s].v, a1, 0, 0, 0);
+    }
+    return f32x4_t{a0[0] + a1[0], a0[1] + a1[1], a0[2] + a1[2], a0[3] + a1[3]};
+}
+
+__device__ __forceinline__ void load_w_x3(BFrag wh[8], BFrag wl[8], const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl,
+                                          int tile, int lane) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {                 // fragment-major [k-step][16 column tiles][lane][8]
+        const long long o = (((long long)s * 16 + tile) * 64 + lane) * 8;
+        wh[s].u = *reinterpret_cast<const uint4*>(Wh + o);
+        wl[s].u = *reinterpret_cast<const uint4*>(Wl + o);
+    }
+}
+
+__global__ __launch_bounds__(1024) void attn_out_fused_x3_kernel(AttnOutX3Params p) {
+    __shared__ __attribute__((aligned(16))) unsigned char ah[16 * 512], al[16 * 512];
+    __shared__ __attribute__((aligned(16))) float tb[16 * C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int m0 = blockIdx.x * 16;
+    const long long grow = (long long)min(m0 + wave, p.M - 1) * C + lane * 4;
+    const float4 av = *reinterpret_cast<const float4*>(p.ctx + grow);
+    BFrag wh[8], wl[8];
+    load_w_x3(wh, wl, p.Woh, p.Wol, wave, lane);
+    const int aoff = wave * 512 + (((lane >> 1) ^ wave) << 4) + (lane & 1) * 8;     // this thread's 4 values in the bf16 images
+    {
+        uint2 hi, lo;
+        split4(av, hi, lo);
+        *reinterpret_cast<uint2*>(ah + aoff) = hi;
+        *reinterpret_cast<uint2*>(al + aoff) = lo;
+    }
+    __syncthreads();
+    f32x4_t acc = tile_mma_x3(ah, al, wh, wl, fr, fg);
+    if (p.Wqh) load_w_x3(wh, wl, p.Wqh, p.Wql, wave, lane);        // in flight during the LayerNorm
+    {
+        const int col = wave * 16 + fr;
+        const float b = p.bo[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tb[toff(4 * fg + r, col)] = acc[r] + b;
+    }
+    __syncthreads();
+    {
+        const int row = wave, m = m0 + row;
+        float4 v = *reinterpret_cast<const float4*>(tb + row * C + ((lane ^ (row & 15)) << 2));
+        const float4 u = *reinterpret_cast<const float4*>(p.resid + grow);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
+        const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+        const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / C);
+        const float rstd = 1.0f / sqrtf(var + p.eps);
+        const float4 ww = *reinterpret_cast<const float4*>(p.lw + lane * 4), bb = *reinterpret_cast<const float4*>(p.lb + lane * 4);
+        v = make_float4(dx * rstd * ww.x + bb.x, dy * rstd * ww.y + bb.y, dz * rstd * ww.z + bb.z, dw * rstd * ww.w + bb.w);
+        if (m < p.M) *reinterpret_cast<float4*>(p.x_out + grow) = v;
+        if (p.Wqh) {
+            const float4 qp = *reinterpret_cast<const float4*>(p.qpos + grow);
+            uint2 hi, lo;
+            split4(make_float4(v.x + qp.x, v.y + qp.y, v.z + qp.z, v.w + qp.w), hi, lo);
+            *reinterpret_cast<uint2*>(ah + aoff) = hi;
+            *reinterpret_cast<uint2*>(al + aoff) = lo;
+        }
+    }
+    if (!p.Wqh) return;
+    __syncthreads();
+    acc = tile_mma_x3(ah, al, wh, wl, fr, fg);
+    const int col = wave * 16 + fr;
+    const float b = p.bq[col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 4 * fg + r;
+        if (m < p.M) p.q_out[(long long)m * C + col] = (acc[r] + b) * p.qscale;
+    }
+}
+
 struct HeadsParams {
     const float* outs;            // [L, M, 256]
     const float* w0; const float* b0; const float* lnw1; const float* lnb1; const float* w3; const float* b3; const float* lnw4; const float* lnb4;
@@ -291,6 +397,19 @@ extern "C" int mv2d_attn_out_fused(const float* ctx, const float* resid, const f
     if (M == 0) return MV2D_OK;
     AttnOutParams p{ctx, resid, Wo, bo, ln_w, ln_b, x_out, qpos, Wq, bq, qscale, q_out, M, eps};
     hipLaunchKernelGGL(attn_out_fused_kernel, dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_attn_out_fused_x3(const float* ctx, const float* resid, const void* Wo_hi, const void* Wo_lo, const float* bo,
+                                      const float* ln_w, const float* ln_b, float* x_out, const float* qpos, const void* Wq_hi,
+                                      const void* Wq_lo, const float* bq, float qscale, float* q_out, int M, float eps, void* stream) {
+    MV2D_CHECK_ARG(ctx && resid && Wo_hi && Wo_lo && bo && ln_w && ln_b && x_out, "mv2d_attn_out_fused_x3: null pointer");
+    MV2D_CHECK_ARG(!Wq_hi || (Wq_lo && qpos && bq && q_out), "mv2d_attn_out_fused_x3: the q stage needs Wq_lo, qpos, bq and q_out");
+    if (M == 0) return MV2D_OK;
+    AttnOutX3Params p{ctx, resid, (const unsigned short*)Wo_hi, (const unsigned short*)Wo_lo, bo, ln_w, ln_b, x_out, qpos,
+                      (const unsigned short*)Wq_hi, (const unsigned short*)Wq_lo, bq, qscale, q_out, M, eps};
+    hipLaunchKernelGGL(attn_out_fused_x3_kernel, dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -69,7 +69,11 @@ class HeadEngine:
         self.ffn_x3 = os.environ.get('MV2D_FFN_X3', '0') == '1'   # FFN in bf16x3 split precision: -3 % latency, -7 % throughput -> off
         self.pe_fused = os.environ.get('MV2D_PE_FUSED', '1') == '1'   # one fused launch for the PE block instead of six GEMMs
         self.force_nc = None          # bench only (S path): overwrite the correlation lists so that every query reads n_c RoIs
-        self.fuse_rows = os.environ.get('MV2D_FUSE_ROWS', '0') == '1'   # row-block fused out_proj+LN(+q proj): measured slower, kept for A/B
+        # out_proj + residual + LayerNorm (+ q in_proj) as one row-fused kernel per attention (8 instead of 11 launches per layer),
+        # its two linears in bf16x3 split precision (fp32-class: ~1e-5 relative).  MV2D_ROWS_X3=0: exact-fp32 fused kernel (slower than
+        # the unfused launches with one frame in flight); MV2D_FUSE_ROWS=0: separate exact-fp32 GEMM + LN launches.
+        self.rows_x3 = os.environ.get('MV2D_ROWS_X3', '1') == '1'
+        self.fuse_rows = os.environ.get('MV2D_FUSE_ROWS', '1') == '1'
         self.load_state(state_dict)
 
     # ------------------------------------------------------------------------------------------ weights
@@ -96,6 +100,8 @@ class HeadEngine:
             w[f'ffn_b1{i}'] = g(p + 'ffns.0.layers.0.0.bias')
             w[f'ffn_w2{i}'] = g(p + 'ffns.0.layers.1.weight')
             w[f'ffn_b2{i}'] = g(p + 'ffns.0.layers.1.bias')
+            for k in ('sa_out_w', 'ca_q_w', 'ca_out_w'):                                 # bf16x3 + fragment-major copies (row-fused kernels)
+                w[f'{k}x{i}'] = ops.pack_x3(w[f'{k}{i}'])
             w[f'ffn_w1p{i}'], w[f'ffn_w2p{i}'] = ops.ffn_pack_weights(w[f'ffn_w1{i}'], w[f'ffn_w2{i}'])   # fragment-major copies
             if self.ffn_x3:
                 w[f'ffn_w1x{i}'] = ops.split_bf16x2(w[f'ffn_w1{i}'])
@@ -407,9 +413,12 @@ class HeadEngine:
         for i in range(L):
             o.gemm_f32(xq, W_[f'sa_in_w{i}'], W_[f'sa_in_b{i}'], A2=x, n_split=2 * C, out=ws['qkv'])
             o.self_attn(ws['qkv'], ws['ctx'], R)
-            # (a row-block fusion of out_proj + LN + q in_proj exists — mv2d_attn_out_fused — but 19 blocks of chained
-            #  fp32 MFMAs measured 2x slower than these N-parallel launches on MI355X)
-            if self.fuse_rows:
+            if self.fuse_rows and self.rows_x3:
+                o.attn_out_fused_x3(ws['ctx'], x, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
+                                    qpos=ws['qpos'], Wq_x3=W_[f'ca_q_wx{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, q_out=ws['q'], M=R)
+                o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R, empty_nan=self.empty_nan)
+                o.attn_out_fused_x3(ws['ctx'], ws['x1'], W_[f'ca_out_wx{i}'], W_[f'ca_out_b{i}'], (W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), ws['x2'], M=R)
+            elif self.fuse_rows:
                 o.attn_out_fused(ws['ctx'], x, W_[f'sa_out_w{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
                                  qpos=ws['qpos'], Wq=W_[f'ca_q_w{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, q_out=ws['q'], M=R)
                 o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R, empty_nan=self.empty_nan)

@@ -101,6 +101,21 @@ def attn_out_fused(ctx, resid, Wo, bo, ln, x_out, *, qpos=None, Wq=None, bq=None
     return x_out
 
 
+def pack_x3(W):
+    """fp32 [256,256] weight -> (hi, lo) bf16 pair, each fragment-major, for attn_out_fused_x3."""
+    hi, lo = split_bf16x2(W.contiguous())
+    return pack_wfrag(hi), pack_wfrag(lo)
+
+
+def attn_out_fused_x3(ctx, resid, Wo_x3, bo, ln, x_out, *, qpos=None, Wq_x3=None, bq=None, qscale=1.0, q_out=None, M=None, eps=1e-5):
+    M = ctx.shape[0] if M is None else M
+    wq = Wq_x3 if Wq_x3 is not None else (None, None)
+    check(_lib.load().mv2d_attn_out_fused_x3(_p(ctx), _p(resid), _p(Wo_x3[0]), _p(Wo_x3[1]), _p(bo), _p(ln[0]), _p(ln[1]), _p(x_out), _p(qpos),
+                                             _p(wq[0]), _p(wq[1]), _p(bq), float(qscale), _p(q_out), M, float(eps), _stream()),
+          'mv2d_attn_out_fused_x3')
+    return x_out
+
+
 def make_ptr_array(tensors):
     import ctypes
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])

@@ -543,3 +543,20 @@ def test_pe_fused_bit_identical_to_gemm_chain(dev, M, use_mdev):
     Mv = M - 13 if use_mdev else M
     assert torch.equal(pe[:Mv], pe_ref[:Mv])
     assert torch.equal(xk[:Mv].view(torch.int16), xk_ref[:Mv].view(torch.int16))
+
+
+def test_attn_out_fused_x3(dev):
+    """split-precision (bf16x3) row-fused out_proj + LN (+ q proj): fp32-class accuracy against fp64."""
+    from mv2d_amd import ops
+    for M in (300, 37):
+        ctx, res, qpos = rnd((M, 256), 110).to(dev), rnd((M, 256), 111).to(dev), rnd((M, 256), 112).to(dev)
+        Wo, Wq = rnd((256, 256), 113, 0.06).to(dev), rnd((256, 256), 114, 0.06).to(dev)
+        bo, bq, lw, lb = rnd((256,), 115).to(dev), rnd((256,), 116).to(dev), rnd((256,), 117).to(dev), rnd((256,), 118).to(dev)
+        x1 = torch.empty((M, 256), device=dev); q = torch.empty((M, 256), device=dev)
+        ops.attn_out_fused_x3(ctx, res, ops.pack_x3(Wo), bo, (lw, lb), x1, qpos=qpos, Wq_x3=ops.pack_x3(Wq), bq=bq, qscale=0.25, q_out=q)
+        xr = F.layer_norm(ctx.double() @ Wo.double().T + bo.double() + res.double(), (256,), lw.double(), lb.double())
+        qr = ((xr + qpos.double()) @ Wq.double().T + bq.double()) * 0.25
+        assert relerr(x1, xr) < 3e-5 and relerr(q, qr) < 3e-5
+        x2 = torch.empty((M, 256), device=dev)
+        ops.attn_out_fused_x3(ctx, res, ops.pack_x3(Wo), bo, (lw, lb), x2)
+        assert torch.equal(x1, x2)
