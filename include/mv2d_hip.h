@@ -95,6 +95,16 @@ int mv2d_attn_out_fused_x3(const float* ctx, const float* resid, const void* Wo_
                            const float* ln_w, const float* ln_b, float* x_out, const float* qpos, const void* Wq_hi,
                            const void* Wq_lo, const float* bq, float qscale, float* q_out, int M, float eps, void* stream);
 
+/* FFN tail + the next layer's self-attention in_proj, row-fused: y = LN(sum_z parts[z] + b2 + resid); x_out = y; xq_out = y + qpos;
+ * outs = post_norm(y) (optional); qkv [M,768] = [xq.Wq^T + bq | xq.Wk^T + bk | y.Wv^T + bv] in bf16x3 split precision (optional:
+ * Win_hi = null for the last layer).  Win_hi / Win_lo: nn.MultiheadAttention in_proj_weight [768,256] as a bf16 hi/lo pair
+ * (mv2d_split_bf16x2), each fragment-major (mv2d_pack_wfrag_bf16).  Replaces mv2d_row_ln + mv2d_gemm_f32 between two layers
+ * (mmcv FFN identity + norm, decoder post_norm, FlattenMHSelfAttention in_proj: MU/petr_transformer.py:269-311, 346-363, 563-565). */
+int mv2d_ffn_out_fused_x3(const float* parts, int n_parts, long long part_stride, const float* b2, const float* resid,
+                          const float* ln_w, const float* ln_b, const float* post_w, const float* post_b, float* x_out,
+                          const float* qpos, float* xq_out, float* outs, const void* Win_hi, const void* Win_lo,
+                          const float* b_in, float* qkv, int M, float eps, void* stream);
+
 /* All per-layer prediction branches in one launch (RH/bbox_heads/cross_attention_head.py:127-146, 216-238; velocity / dt of
  * RH/mv2d_t_head.py:136-140).  outs [L,M,256]; cls_w = {w0,b0,ln1w,ln1b,w3,b3,ln4w,ln4b,w6,b6}, reg_w = {w0,b0,w2,b2,w4,b4}: HOST
  * arrays of device pointers, every tensor stacked over the L layers; ref [M,3]; out cls, reg [L,M,10] (reg final: sigmoid / ref /

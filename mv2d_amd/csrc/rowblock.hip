@@ -298,6 +298,122 @@ __global__ __launch_bounds__(1024) void attn_out_fused_x3_kernel(AttnOutX3Params
     }
 }
 
+// FFN tail + the NEXT layer's self-attention in_proj in one row-fused kernel (16 rows per block, 16 waves):
+//   y   = LayerNorm(sum of the FFN slabs + b2 + residual)            (mmcv FFN identity + 'norm', MU/petr_transformer.py:269-311)
+//   out = post_norm(y)                                               (decoder post_norm of the intermediate output, :563-565)
+//   x = y, xq = y + query_pos, qkv = [xq.Wq^T + bq | xq.Wk^T + bk | x.Wv^T + bv]   (FlattenMHSelfAttention in_proj, :346-363)
+// The in_proj runs in bf16x3 split precision like attn_out_fused_x3: wave w owns column tile w of q, of k (activation xq) and of v
+// (activation x); its weight fragments stream as half-tiles (4 k-steps, hi + lo = 32 VGPRs) through a double buffer, the next
+// half-tile in flight behind the MFMAs of the current one (VGPR budget 128 at 4 waves per SIMD).
+struct FfnOutParams {
+    const float* parts; int n_parts; long long part_stride; const float* b2; const float* resid;
+    const float* lw; const float* lb; const float* pw; const float* pb;
+    float* x_out; const float* qpos; float* xq_out; float* outs;
+    const unsigned short* Wh; const unsigned short* Wl; const float* b_in; float* qkv;     // Wh null -> no in_proj (last layer)
+    int M; float eps;
+};
+
+__device__ __forceinline__ float4 ln_row(float4 v, const float* __restrict__ w, const float* __restrict__ b, int c0, float eps) {
+    const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
+    const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+    const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / C);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float4 ww = *reinterpret_cast<const float4*>(w + c0), bb = *reinterpret_cast<const float4*>(b + c0);
+    return make_float4(dx * rstd * ww.x + bb.x, dy * rstd * ww.y + bb.y, dz * rstd * ww.z + bb.z, dw * rstd * ww.w + bb.w);
+}
+
+__global__ __launch_bounds__(1024) void ffn_out_fused_x3_kernel(FfnOutParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char qh[16 * 512], ql[16 * 512], xh[16 * 512], xl[16 * 512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int m0 = blockIdx.x * 16;
+    const int m = m0 + wave;                                     // LayerNorm stage: row = wave, lane = 4 consecutive columns
+    const long long grow = (long long)min(m, p.M - 1) * C + lane * 4;
+    // first weight half-tile (q tile of this wave, k-steps 0..3) goes out before anything else
+    BFrag wh[2][4], wl[2][4];
+    auto load_half = [&](int buf, int st) {                      // stage st = 2 * tile_kind + half; tile_kind 0/1/2 = q/k/v
+        const int tile = (st >> 1) * 16 + wave, s0 = (st & 1) * 4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {                            // fragment-major [k-step][48 column tiles][lane][8]
+            const long long o = (((long long)(s0 + s) * 48 + tile) * 64 + lane) * 8;
+            wh[buf][s].u = *reinterpret_cast<const uint4*>(p.Wh + o);
+            wl[buf][s].u = *reinterpret_cast<const uint4*>(p.Wl + o);
+        }
+    };
+    if (p.Wh) load_half(0, 0);
+    // ---- sum of the slabs (fixed order) + b2 + residual -> LN -> x, xq, post-norm output
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        const float* pp = p.parts + grow;
+        int s = 0;
+        for (; s + 8 <= p.n_parts; s += 8) {
+            float4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const float4*>(pp + (s + j) * p.part_stride);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
+        }
+        for (; s < p.n_parts; ++s) {
+            const float4 t = *reinterpret_cast<const float4*>(pp + s * p.part_stride);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+    }
+    {
+        const float4 t = *reinterpret_cast<const float4*>(p.b2 + lane * 4), u = *reinterpret_cast<const float4*>(p.resid + grow);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    v = ln_row(v, p.lw, p.lb, lane * 4, p.eps);
+    const float4 qp = *reinterpret_cast<const float4*>(p.qpos + grow);
+    const float4 vq = make_float4(v.x + qp.x, v.y + qp.y, v.z + qp.z, v.w + qp.w);
+    if (m < p.M) {
+        *reinterpret_cast<float4*>(p.x_out + grow) = v;
+        *reinterpret_cast<float4*>(p.xq_out + grow) = vq;
+        if (p.outs) *reinterpret_cast<float4*>(p.outs + grow) = ln_row(v, p.pw, p.pb, lane * 4, p.eps);
+    } else if (p.outs) {
+        (void)ln_row(v, p.pw, p.pb, lane * 4, p.eps);            // keep the wave-wide reductions convergent
+    }
+    if (!p.Wh) return;
+    {
+        const int aoff = wave * 512 + (((lane >> 1) ^ wave) << 4) + (lane & 1) * 8;
+        uint2 hi, lo;
+        split4(vq, hi, lo);
+        *reinterpret_cast<uint2*>(qh + aoff) = hi; *reinterpret_cast<uint2*>(ql + aoff) = lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<uint2*>(xh + aoff) = hi; *reinterpret_cast<uint2*>(xl + aoff) = lo;
+    }
+    __syncthreads();
+    // ---- in_proj: 6 half-tile stages (q0 q1 k0 k1 v0 v1), double-buffered weight fragments
+#pragma unroll
+    for (int kind = 0; kind < 3; ++kind) {
+        const unsigned char* ah = kind < 2 ? qh : xh;
+        const unsigned char* al = kind < 2 ? ql : xl;
+        f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int st = 2 * kind + h, buf = st & 1;
+            if (st + 1 < 6) load_half(buf ^ 1, st + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                BFrag ya, yb;
+                const int off = fr * 512 + (((4 * (4 * h + s) + fg) ^ fr) << 4);
+                ya.u = *reinterpret_cast<const uint4*>(ah + off);
+                yb.u = *reinterpret_cast<const uint4*>(al + off);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya.v, wh[buf][s].v, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yb.v, wh[buf][s].v, a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya.v, wl[buf][s].v, a1, 0, 0, 0);
+            }
+        }
+        const int col = kind * 256 + wave * 16 + fr;
+        const float b = p.b_in[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mm = m0 + 4 * fg + r;
+            if (mm < p.M) p.qkv[(long long)mm * 768 + col] = (a0[r] + a1[r]) + b;
+        }
+    }
+}
+
 struct HeadsParams {
     const float* outs;            // [L, M, 256]
     const float* w0; const float* b0; const float* lnw1; const float* lnb1; const float* w3; const float* b3; const float* lnw4; const float* lnb4;
@@ -410,6 +526,21 @@ extern "C" int mv2d_attn_out_fused_x3(const float* ctx, const float* resid, cons
     AttnOutX3Params p{ctx, resid, (const unsigned short*)Wo_hi, (const unsigned short*)Wo_lo, bo, ln_w, ln_b, x_out, qpos,
                       (const unsigned short*)Wq_hi, (const unsigned short*)Wq_lo, bq, qscale, q_out, M, eps};
     hipLaunchKernelGGL(attn_out_fused_x3_kernel, dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_ffn_out_fused_x3(const float* parts, int n_parts, long long part_stride, const float* b2, const float* resid,
+                                     const float* ln_w, const float* ln_b, const float* post_w, const float* post_b, float* x_out,
+                                     const float* qpos, float* xq_out, float* outs, const void* Win_hi, const void* Win_lo,
+                                     const float* b_in, float* qkv, int M, float eps, void* stream) {
+    MV2D_CHECK_ARG(parts && n_parts > 0 && b2 && resid && ln_w && ln_b && x_out && qpos && xq_out, "mv2d_ffn_out_fused_x3: null pointer");
+    MV2D_CHECK_ARG(!outs || (post_w && post_b), "mv2d_ffn_out_fused_x3: outs needs the post_norm parameters");
+    MV2D_CHECK_ARG(!Win_hi || (Win_lo && b_in && qkv), "mv2d_ffn_out_fused_x3: the in_proj stage needs Win_lo, b_in and qkv");
+    if (M == 0) return MV2D_OK;
+    FfnOutParams p{parts, n_parts, part_stride, b2, resid, ln_w, ln_b, post_w, post_b, x_out, qpos, xq_out, outs,
+                   (const unsigned short*)Win_hi, (const unsigned short*)Win_lo, b_in, qkv, M, eps};
+    hipLaunchKernelGGL(ffn_out_fused_x3_kernel, dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -100,7 +100,7 @@ class HeadEngine:
             w[f'ffn_b1{i}'] = g(p + 'ffns.0.layers.0.0.bias')
             w[f'ffn_w2{i}'] = g(p + 'ffns.0.layers.1.weight')
             w[f'ffn_b2{i}'] = g(p + 'ffns.0.layers.1.bias')
-            for k in ('sa_out_w', 'ca_q_w', 'ca_out_w'):                                 # bf16x3 + fragment-major copies (row-fused kernels)
+            for k in ('sa_in_w', 'sa_out_w', 'ca_q_w', 'ca_out_w'):                      # bf16x3 + fragment-major copies (row-fused kernels)
                 w[f'{k}x{i}'] = ops.pack_x3(w[f'{k}{i}'])
             w[f'ffn_w1p{i}'], w[f'ffn_w2p{i}'] = ops.ffn_pack_weights(w[f'ffn_w1{i}'], w[f'ffn_w2{i}'])   # fragment-major copies
             if self.ffn_x3:
@@ -410,8 +410,10 @@ class HeadEngine:
         x, xq = ws['x'], ws['xq']
         x.zero_()
         xq.copy_(ws['qpos'])
+        fuse_tail = self.fuse_rows and self.rows_x3          # FFN tail + next layer's in_proj as one row-fused kernel
         for i in range(L):
-            o.gemm_f32(xq, W_[f'sa_in_w{i}'], W_[f'sa_in_b{i}'], A2=x, n_split=2 * C, out=ws['qkv'])
+            if i == 0 or not fuse_tail:
+                o.gemm_f32(xq, W_[f'sa_in_w{i}'], W_[f'sa_in_b{i}'], A2=x, n_split=2 * C, out=ws['qkv'])
             o.self_attn(ws['qkv'], ws['ctx'], R)
             if self.fuse_rows and self.rows_x3:
                 o.attn_out_fused_x3(ws['ctx'], x, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
@@ -434,8 +436,14 @@ class HeadEngine:
                 o.ffn_fused_x3(ws['x2'], W_[f'ffn_w1x{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2x{i}'], ws['parts'], R)
             else:
                 o.ffn_fused(ws['x2'], W_[f'ffn_w1p{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2p{i}'], ws['parts'], R)
-            o.row_ln(ws['parts'], bias=W_[f'ffn_b2{i}'], residual=ws['x2'], ln=(W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), out=x, addvec=ws['qpos'], out_plus=xq,
-                     ln2=(W_['post_w'], W_['post_b']), out2=ws['outs'][i])
+            if fuse_tail:
+                nxt = i + 1 < L
+                o.ffn_out_fused_x3(ws['parts'], W_[f'ffn_b2{i}'], ws['x2'], (W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), (W_['post_w'], W_['post_b']),
+                                   x, ws['qpos'], xq, outs=ws['outs'][i], Win_x3=W_[f'sa_in_wx{i + 1}'] if nxt else None,
+                                   b_in=W_[f'sa_in_b{i + 1}'] if nxt else None, qkv=ws['qkv'] if nxt else None, M=R)
+            else:
+                o.row_ln(ws['parts'], bias=W_[f'ffn_b2{i}'], residual=ws['x2'], ln=(W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), out=x, addvec=ws['qpos'],
+                         out_plus=xq, ln2=(W_['post_w'], W_['post_b']), out2=ws['outs'][i])
 
     def _enqueue_heads(self, ws, R, dt):
         # a14: every per-layer cls / reg branch + the reference-point tail in ONE launch (row-block fused)

@@ -116,6 +116,17 @@ def attn_out_fused_x3(ctx, resid, Wo_x3, bo, ln, x_out, *, qpos=None, Wq_x3=None
     return x_out
 
 
+def ffn_out_fused_x3(parts, b2, resid, ln, post, x_out, qpos, xq_out, outs=None, Win_x3=None, b_in=None, qkv=None, M=None, eps=1e-5):
+    """y = LN(sum(parts) + b2 + resid) -> x_out, xq_out = y + qpos, outs = post_norm(y); qkv = in_proj(xq, xq, y) (bf16x3)."""
+    M = x_out.shape[0] if M is None else M
+    w = Win_x3 if Win_x3 is not None else (None, None)
+    check(_lib.load().mv2d_ffn_out_fused_x3(_p(parts), parts.shape[0], parts.stride(0), _p(b2), _p(resid), _p(ln[0]), _p(ln[1]),
+                                            _p(post[0]) if post else None, _p(post[1]) if post else None, _p(x_out), _p(qpos), _p(xq_out),
+                                            _p(outs), _p(w[0]), _p(w[1]), _p(b_in), _p(qkv), M, float(eps), _stream()),
+          'mv2d_ffn_out_fused_x3')
+    return x_out
+
+
 def make_ptr_array(tensors):
     import ctypes
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])

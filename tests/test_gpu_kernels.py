@@ -560,3 +560,28 @@ def test_attn_out_fused_x3(dev):
         x2 = torch.empty((M, 256), device=dev)
         ops.attn_out_fused_x3(ctx, res, ops.pack_x3(Wo), bo, (lw, lb), x2)
         assert torch.equal(x1, x2)
+
+
+def test_ffn_out_fused_x3(dev):
+    """FFN tail (slab sum + b2 + residual + LN + post_norm) + next layer's in_proj (bf16x3) in one kernel, against fp64."""
+    from mv2d_amd import ops
+    for M in (300, 37):
+        parts = rnd((32, M, 256), 120, 0.3).to(dev)
+        b2, res, qpos = rnd((256,), 121).to(dev), rnd((M, 256), 122).to(dev), rnd((M, 256), 123).to(dev)
+        lw, lb, pw, pb = rnd((256,), 124).to(dev), rnd((256,), 125).to(dev), rnd((256,), 126).to(dev), rnd((256,), 127).to(dev)
+        Win, b_in = rnd((768, 256), 128, 0.06).to(dev), rnd((768,), 129).to(dev)
+        x = torch.empty((M, 256), device=dev); xq = torch.empty_like(x); outs = torch.empty_like(x); qkv = torch.empty((M, 768), device=dev)
+        ops.ffn_out_fused_x3(parts, b2, res, (lw, lb), (pw, pb), x, qpos, xq, outs=outs, Win_x3=ops.pack_x3(Win), b_in=b_in, qkv=qkv)
+        y = F.layer_norm(parts.double().sum(0) + b2.double() + res.double(), (256,), lw.double(), lb.double())
+        assert relerr(x, y) < 1e-5 and relerr(xq, y + qpos.double()) < 1e-5
+        assert relerr(outs, F.layer_norm(y, (256,), pw.double(), pb.double())) < 1e-5
+        yq = y + qpos.double()
+        ref = torch.cat([yq @ Win[:512].double().T, y @ Win[512:].double().T], 1) + b_in.double()
+        assert relerr(qkv, ref) < 3e-5
+        # same LN as row_ln (bit-identical), and the last-layer form without in_proj
+        x_r = torch.empty_like(x); xq_r = torch.empty_like(x); o_r = torch.empty_like(x)
+        ops.row_ln(parts, bias=b2, residual=res, ln=(lw, lb), out=x_r, addvec=qpos, out_plus=xq_r, ln2=(pw, pb), out2=o_r)
+        assert torch.equal(x, x_r) and torch.equal(xq, xq_r) and torch.equal(outs, o_r)
+        x2 = torch.empty_like(x); xq2 = torch.empty_like(x)
+        ops.ffn_out_fused_x3(parts, b2, res, (lw, lb), None, x2, qpos, xq2)
+        assert torch.equal(x2, x)
