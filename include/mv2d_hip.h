@@ -125,7 +125,8 @@ int mv2d_ffn_fused(const float* X, const float* W1, const float* b1, const float
 
 /* The same fused FFN in split precision on the bf16 matrix cores ("bf16x3": x = x_hi + x_lo as a bf16 pair, three bf16 MFMAs per
  * product, fp32 accumulation): ~1e-5 relative error instead of bit-exact fp32, 3/16 of the matrix-pipe time.  W1/W2 are given as
- * the pairs produced by mv2d_split_bf16x2 ([hidden,256] and [256,hidden] bf16 each); same slab output as mv2d_ffn_fused. */
+ * the pairs produced by mv2d_split_bf16x2 ([hidden,256] and [256,hidden] bf16 each), each stored fragment-major
+ * (mv2d_pack_wfrag_bf16); same slab output as mv2d_ffn_fused. */
 int mv2d_ffn_fused_x3(const float* X, const void* W1hi, const void* W1lo, const float* b1, const void* W2hi, const void* W2lo,
                       float* slabs, int M, int hidden, void* stream);
 

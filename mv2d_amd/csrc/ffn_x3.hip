@@ -5,7 +5,8 @@
 // CU.  Here every fp32 operand is carried as a bf16 pair x = x_hi + x_lo (x_hi = bf16(x), x_lo = bf16(x - x_hi)) and a
 // product is a_hi.w_hi + a_lo.w_hi + a_hi.w_lo on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: every partial product is
 // exact in fp32, the dropped a_lo.w_lo term is ~2^-18 relative -> ~1e-5 relative error (plain bf16: 4e-3), at 3/16 of the
-// matrix-pipe time.  The weights are split once at load time (mv2d_split_bf16x2), X when it is staged into LDS, the hidden
+// matrix-pipe time.  The weights are split once at load time (mv2d_split_bf16x2) and stored fragment-major (mv2d_pack_wfrag_bf16),
+// X is split when it is staged into LDS, the hidden
 // activations when they are written to LDS.  Both phases run swapped (D^T = W.A^T), so a lane always ends with 4 consecutive
 // columns of one row: 8-byte LDS writes of H, 16-byte stores of the slab.
 #include "common.h"
@@ -45,11 +46,13 @@ __global__ __launch_bounds__(256, 2) void ffn_x3_kernel(const float* __restrict_
     Frag w1h[2][8], w1l[2][8];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const long long wo = (long long)(slice * HS + (2 * half + t) * 16 + fr) * C + 8 * fg;
+        // fragment-major W1 [hidden,256]: [k-step (8)][hidden/16 column tiles][lane][8]
+        const int tile = slice * 4 + 2 * half + t, nt = hidden / 16;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            w1h[t][s].u = *reinterpret_cast<const uint4*>(W1h + wo + 32 * s);
-            w1l[t][s].u = *reinterpret_cast<const uint4*>(W1l + wo + 32 * s);
+            const long long wo = (((long long)s * nt + tile) * 64 + lane) * 8;
+            w1h[t][s].u = *reinterpret_cast<const uint4*>(W1h + wo);
+            w1l[t][s].u = *reinterpret_cast<const uint4*>(W1l + wo);
         }
     }
 #pragma unroll
@@ -67,12 +70,12 @@ __global__ __launch_bounds__(256, 2) void ffn_x3_kernel(const float* __restrict_
     Frag w2h[8][2], w2l[8][2];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const int n = 128 * half + 16 * t + fr;
-        const long long wo = (long long)n * hidden + slice * HS + 8 * fg;
+        // fragment-major W2 [256,hidden]: [k-step (hidden/32)][16 column tiles][lane][8]
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            w2h[t][s].u = *reinterpret_cast<const uint4*>(W2h + wo + 32 * s);
-            w2l[t][s].u = *reinterpret_cast<const uint4*>(W2l + wo + 32 * s);
+            const long long wo = (((long long)(slice * 2 + s) * 16 + 8 * half + t) * 64 + lane) * 8;
+            w2h[t][s].u = *reinterpret_cast<const uint4*>(W2h + wo);
+            w2l[t][s].u = *reinterpret_cast<const uint4*>(W2l + wo);
         }
     }
     // ---- phase 1 (swapped): lane (fr, fg) ends with hidden columns 4fg..4fg+3 of row fr for each of its two 16-wide tiles

@@ -66,7 +66,7 @@ class HeadEngine:
         self._ws = {}
         self.prof = None              # dict name -> [events] when stage timing is on (bench.py)
         self.fork_qg = True           # T path: query-generator chain on a second stream
-        self.ffn_x3 = os.environ.get('MV2D_FFN_X3', '0') == '1'   # FFN in bf16x3 split precision: -3 % latency, -7 % throughput -> off
+        self.ffn_x3 = os.environ.get('MV2D_FFN_X3', '1') == '1'   # FFN in bf16x3 split precision (fragment-major hi/lo weights); 0: exact fp32
         self.pe_fused = os.environ.get('MV2D_PE_FUSED', '1') == '1'   # one fused launch for the PE block instead of six GEMMs
         self.force_nc = None          # bench only (S path): overwrite the correlation lists so that every query reads n_c RoIs
         # out_proj + residual + LayerNorm (+ q in_proj) as one row-fused kernel per attention (8 instead of 11 launches per layer),
@@ -104,8 +104,8 @@ class HeadEngine:
                 w[f'{k}x{i}'] = ops.pack_x3(w[f'{k}{i}'])
             w[f'ffn_w1p{i}'], w[f'ffn_w2p{i}'] = ops.ffn_pack_weights(w[f'ffn_w1{i}'], w[f'ffn_w2{i}'])   # fragment-major copies
             if self.ffn_x3:
-                w[f'ffn_w1x{i}'] = ops.split_bf16x2(w[f'ffn_w1{i}'])
-                w[f'ffn_w2x{i}'] = ops.split_bf16x2(w[f'ffn_w2{i}'])
+                w[f'ffn_w1x{i}'] = ops.pack_x3(w[f'ffn_w1{i}'])
+                w[f'ffn_w2x{i}'] = ops.pack_x3(w[f'ffn_w2{i}'])
             for n in range(3):
                 w[f'ln{n}_w{i}'] = g(p + f'norms.{n}.weight')
                 w[f'ln{n}_b{i}'] = g(p + f'norms.{n}.bias')

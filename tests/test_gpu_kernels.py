@@ -177,7 +177,7 @@ def test_ffn_fused_x3_split_precision(dev):
         x = rnd((M, 256), 27).to(dev)
         W1 = rnd((2048, 256), 28, 0.1).to(dev); b1 = rnd((2048,), 29).to(dev)
         W2 = rnd((256, 2048), 30, 0.05).to(dev)
-        slabs = ops.ffn_fused_x3(x, ops.split_bf16x2(W1), b1, ops.split_bf16x2(W2))
+        slabs = ops.ffn_fused_x3(x, ops.pack_x3(W1), b1, ops.pack_x3(W2))
         assert slabs.shape == (32, M, 256)
         ref = F.relu(x.double() @ W1.double().T + b1.double()) @ W2.double().T
         assert relerr(slabs.sum(0), ref) < 3e-5
