@@ -201,7 +201,8 @@ def test_engine_full_size_properties_cfg5():
     b1 = [t.clone() for t in eng.results(out)]
     # decode == host top-k on the same logits (integers bit-exact)
     cl = c1[-1].cpu()
-    scores, idx = cl.view(-1).topk(300)                                            # no ties expected in fp32 random logits
+    idx = torch.argsort(cl.view(-1), descending=True, stable=True)[:300]          # ties (9000 fp32 logits: ~1 expected): lower flat index first,
+    scores = cl.view(-1)[idx]                                                      # the order the decode kernel defines
     n = int(out['count'].item())
     bp = r1[-1].cpu()[idx // 10]
     keep = ((bp[:, 0].abs() <= 61.2) & (bp[:, 1].abs() <= 61.2) & (bp[:, 4].abs() <= 10.0))
