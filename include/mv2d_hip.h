@@ -95,6 +95,14 @@ int mv2d_attn_out_fused_x3(const float* ctx, const float* resid, const void* Wo_
                            const float* ln_w, const float* ln_b, float* x_out, const float* qpos, const void* Wq_hi,
                            const void* Wq_lo, const float* bq, float qscale, float* q_out, int M, float eps, void* stream);
 
+/* Self-attention core (all 8 heads of 16 queries against all R keys, exact fp32) + out_proj + residual + LayerNorm + optional
+ * cross-attention q projection in one row-fused kernel: mv2d_self_attn_fwd followed by mv2d_attn_out_fused_x3 without the context
+ * round trip (FlattenMHSelfAttention + norm + PETRMultiheadAttention q in_proj, MU/petr_transformer.py:317-370, 487-513).
+ * qkv [M,768] fp32 = in_proj(q | k | v), q unscaled; the other arguments as in mv2d_attn_out_fused_x3. */
+int mv2d_sa_block_fused_x3(const float* qkv, const float* resid, const void* Wo_hi, const void* Wo_lo, const float* bo,
+                           const float* ln_w, const float* ln_b, float* x_out, const float* qpos, const void* Wq_hi,
+                           const void* Wq_lo, const float* bq, float qscale, float* q_out, int M, float eps, void* stream);
+
 /* FFN tail + the next layer's self-attention in_proj, row-fused: y = LN(sum_z parts[z] + b2 + resid); x_out = y; xq_out = y + qpos;
  * outs = post_norm(y) (optional); qkv [M,768] = [xq.Wq^T + bq | xq.Wk^T + bk | y.Wv^T + bv] in bf16x3 split precision (optional:
  * Win_hi = null for the last layer).  Win_hi / Win_lo: nn.MultiheadAttention in_proj_weight [768,256] as a bf16 hi/lo pair

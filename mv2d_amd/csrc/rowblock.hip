@@ -298,6 +298,152 @@ __global__ __launch_bounds__(1024) void attn_out_fused_x3_kernel(AttnOutX3Params
     }
 }
 
+__device__ __forceinline__ float4 ln_row(float4 v, const float* __restrict__ w, const float* __restrict__ b, int c0, float eps);
+
+// Self-attention core + out_proj + residual + LayerNorm + cross-attention q projection for 16 queries in one block (16 waves):
+// the attention part is self_attn_kernel's (attention.hip: exact fp32 MFMA, S^T = K.Q^T, online softmax, P feeds P.V from registers)
+// with two waves per head splitting the key tiles; the merged context tile goes straight into the bf16 hi/lo LDS images that
+// the out_proj reads — it never visits global memory, and one dependent launch per layer disappears.
+//   qkv [R,768] fp32 = in_proj outputs (q | k | v), q not yet scaled.
+struct SaKV { float4 ka, kb; float v0[4], v1[4]; };
+
+__device__ __forceinline__ void sa_load_kv(SaKV& f, const float* __restrict__ qkv, int t, int h, int fr, int fg, int R) {
+    const int krow = min(t * 16 + fr, R - 1);
+    const float* kp = qkv + (long long)krow * 768 + C + h * 32 + 4 * fg;
+    f.ka = *reinterpret_cast<const float4*>(kp);
+    f.kb = *reinterpret_cast<const float4*>(kp + 16);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int vrow = min(t * 16 + 4 * fg + r, R - 1);
+        const float* vp = qkv + (long long)vrow * 768 + 2 * C + h * 32 + fr;
+        f.v0[r] = vp[0];
+        f.v1[r] = vp[16];
+    }
+}
+
+__global__ __launch_bounds__(1024) void sa_block_fused_x3_kernel(AttnOutX3Params p, const float* __restrict__ qkv, float scale) {
+    __shared__ __attribute__((aligned(16))) unsigned char ah[16 * 512], al[16 * 512];
+    __shared__ __attribute__((aligned(16))) float tb[16 * C];
+    __shared__ float sm[16][16], sl[16][16], so[16][32][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int m0 = blockIdx.x * 16, R = p.M;
+    // ---- self attention: head h = wave / 2, key tiles t = part, part + 2, ...
+    {
+        const int h = wave >> 1, part = wave & 1;
+        const int qrow = min(m0 + fr, R - 1);
+        const float* qp = qkv + (long long)qrow * 768 + h * 32 + 4 * fg;
+        const float4 qa = *reinterpret_cast<const float4*>(qp);
+        const float4 qb = *reinterpret_cast<const float4*>(qp + 16);
+        float m_run = -INFINITY, l_run = 0.f;
+        f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+        const int ntiles = (R + 15) / 16;
+        SaKV cur, nxt;
+        if (part < ntiles) sa_load_kv(cur, qkv, part, h, fr, fg, R);
+        for (int t = part; t < ntiles; t += 2) {
+            if (t + 2 < ntiles) sa_load_kv(nxt, qkv, t + 2, h, fr, fg, R);
+            f32x4_t sc = {0.f, 0.f, 0.f, 0.f};
+            sc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.ka.x, qa.x, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.ka.y, qa.y, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.ka.z, qa.z, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.ka.w, qa.w, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.kb.x, qb.x, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.kb.y, qb.y, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.kb.z, qb.z, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.kb.w, qb.w, sc, 0, 0, 0);
+            float pr[4];
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = t * 16 + 4 * fg + r;
+                pr[r] = key < R ? sc[r] * scale : -INFINITY;
+                tmax = fmaxf(tmax, pr[r]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = expf(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pr[r] = expf(pr[r] - m_new); psum += pr[r]; }
+            psum += __shfl_xor(psum, 16, 64);
+            psum += __shfl_xor(psum, 32, 64);
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.v0[r], pr[r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.v1[r], pr[r], o1, 0, 0, 0);
+            }
+            cur = nxt;
+        }
+        if (fg == 0) { sm[wave][fr] = m_run; sl[wave][fr] = l_run; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { so[wave][4 * fg + r][fr] = o0[r]; so[wave][16 + 4 * fg + r][fr] = o1[r]; }
+    }
+    // out_proj fragments of column tile `wave`: in flight during the merge
+    BFrag wh[8], wl[8];
+    load_w_x3(wh, wl, p.Woh, p.Wol, wave, lane);
+    __syncthreads();
+    {   // merge the two partial states of a head: thread -> (head, query, 4 consecutive d) -> bf16 hi/lo images of the context tile
+        const int h = tid >> 7, q = tid & 15, d0 = ((tid >> 4) & 7) * 4;
+        const float ma = sm[2 * h][q], mb = sm[2 * h + 1][q];
+        const float Mx = fmaxf(ma, mb);
+        const float ea = expf(ma - Mx), eb = expf(mb - Mx);          // a wave without a tile: exp(-inf) = 0
+        const float inv = 1.0f / (sl[2 * h][q] * ea + sl[2 * h + 1][q] * eb);
+        float4 c;
+        c.x = (so[2 * h][d0][q] * ea + so[2 * h + 1][d0][q] * eb) * inv;
+        c.y = (so[2 * h][d0 + 1][q] * ea + so[2 * h + 1][d0 + 1][q] * eb) * inv;
+        c.z = (so[2 * h][d0 + 2][q] * ea + so[2 * h + 1][d0 + 2][q] * eb) * inv;
+        c.w = (so[2 * h][d0 + 3][q] * ea + so[2 * h + 1][d0 + 3][q] * eb) * inv;
+        const int col = h * 32 + d0;                                 // 4 consecutive columns of row q
+        const int off = q * 512 + (((col >> 3) ^ q) << 4) + (col & 4) * 2;
+        uint2 hi, lo;
+        split4(c, hi, lo);
+        *reinterpret_cast<uint2*>(ah + off) = hi;
+        *reinterpret_cast<uint2*>(al + off) = lo;
+    }
+    __syncthreads();
+    // ---- out_proj + residual + LayerNorm + q projection: identical to attn_out_fused_x3_kernel from here on
+    const long long grow = (long long)min(m0 + wave, p.M - 1) * C + lane * 4;
+    const int aoff = wave * 512 + (((lane >> 1) ^ wave) << 4) + (lane & 1) * 8;
+    f32x4_t acc = tile_mma_x3(ah, al, wh, wl, fr, fg);
+    if (p.Wqh) load_w_x3(wh, wl, p.Wqh, p.Wql, wave, lane);
+    {
+        const int col = wave * 16 + fr;
+        const float b = p.bo[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tb[toff(4 * fg + r, col)] = acc[r] + b;
+    }
+    __syncthreads();
+    {
+        const int row = wave, m = m0 + row;
+        float4 v = *reinterpret_cast<const float4*>(tb + row * C + ((lane ^ (row & 15)) << 2));
+        const float4 u = *reinterpret_cast<const float4*>(p.resid + grow);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        v = ln_row(v, p.lw, p.lb, lane * 4, p.eps);
+        if (m < p.M) *reinterpret_cast<float4*>(p.x_out + grow) = v;
+        if (p.Wqh) {
+            const float4 qp = *reinterpret_cast<const float4*>(p.qpos + grow);
+            uint2 hi, lo;
+            split4(make_float4(v.x + qp.x, v.y + qp.y, v.z + qp.z, v.w + qp.w), hi, lo);
+            *reinterpret_cast<uint2*>(ah + aoff) = hi;
+            *reinterpret_cast<uint2*>(al + aoff) = lo;
+        }
+    }
+    if (!p.Wqh) return;
+    __syncthreads();
+    acc = tile_mma_x3(ah, al, wh, wl, fr, fg);
+    const int col = wave * 16 + fr;
+    const float b = p.bq[col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 4 * fg + r;
+        if (m < p.M) p.q_out[(long long)m * C + col] = (acc[r] + b) * p.qscale;
+    }
+}
+
 // FFN tail + the NEXT layer's self-attention in_proj in one row-fused kernel (16 rows per block, 16 waves):
 //   y   = LayerNorm(sum of the FFN slabs + b2 + residual)            (mmcv FFN identity + 'norm', MU/petr_transformer.py:269-311)
 //   out = post_norm(y)                                               (decoder post_norm of the intermediate output, :563-565)
@@ -343,14 +489,16 @@ __global__ __launch_bounds__(1024) void ffn_out_fused_x3_kernel(FfnOutParams p) 
     // ---- sum of the slabs (fixed order) + b2 + residual -> LN -> x, xq, post-norm output
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     {
+        // the slabs were just written by other XCDs (they come from the Infinity Cache, ~2 us away): 16 loads in flight per round trip,
+        // summed in the fixed order s = 0, 1, 2, ... (bit-identical to mv2d_row_ln)
         const float* pp = p.parts + grow;
         int s = 0;
-        for (; s + 8 <= p.n_parts; s += 8) {
-            float4 t[8];
+        for (; s + 16 <= p.n_parts; s += 16) {
+            float4 t[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const float4*>(pp + (s + j) * p.part_stride);
+            for (int j = 0; j < 16; ++j) t[j] = *reinterpret_cast<const float4*>(pp + (s + j) * p.part_stride);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
+            for (int j = 0; j < 16; ++j) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
         }
         for (; s < p.n_parts; ++s) {
             const float4 t = *reinterpret_cast<const float4*>(pp + s * p.part_stride);
@@ -526,6 +674,19 @@ extern "C" int mv2d_attn_out_fused_x3(const float* ctx, const float* resid, cons
     AttnOutX3Params p{ctx, resid, (const unsigned short*)Wo_hi, (const unsigned short*)Wo_lo, bo, ln_w, ln_b, x_out, qpos,
                       (const unsigned short*)Wq_hi, (const unsigned short*)Wq_lo, bq, qscale, q_out, M, eps};
     hipLaunchKernelGGL(attn_out_fused_x3_kernel, dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_sa_block_fused_x3(const float* qkv, const float* resid, const void* Wo_hi, const void* Wo_lo, const float* bo,
+                                      const float* ln_w, const float* ln_b, float* x_out, const float* qpos, const void* Wq_hi,
+                                      const void* Wq_lo, const float* bq, float qscale, float* q_out, int M, float eps, void* stream) {
+    MV2D_CHECK_ARG(qkv && resid && Wo_hi && Wo_lo && bo && ln_w && ln_b && x_out, "mv2d_sa_block_fused_x3: null pointer");
+    MV2D_CHECK_ARG(!Wq_hi || (Wq_lo && qpos && bq && q_out), "mv2d_sa_block_fused_x3: the q stage needs Wq_lo, qpos, bq and q_out");
+    if (M == 0) return MV2D_OK;
+    AttnOutX3Params p{nullptr, resid, (const unsigned short*)Wo_hi, (const unsigned short*)Wo_lo, bo, ln_w, ln_b, x_out, qpos,
+                      (const unsigned short*)Wq_hi, (const unsigned short*)Wq_lo, bq, qscale, q_out, M, eps};
+    hipLaunchKernelGGL(sa_block_fused_x3_kernel, dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p, qkv, 1.0f / sqrtf(32.0f));
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -74,6 +74,9 @@ class HeadEngine:
         # the unfused launches with one frame in flight); MV2D_FUSE_ROWS=0: separate exact-fp32 GEMM + LN launches.
         self.rows_x3 = os.environ.get('MV2D_ROWS_X3', '1') == '1'
         self.fuse_rows = os.environ.get('MV2D_FUSE_ROWS', '1') == '1'
+        # self-attention core inside the row-fused kernel: measured SLOWER (decoder 0.357 -> 0.432 ms: the fp32 MFMAs of 152 attention
+        # blocks land on 19 CUs) -> off; kept as an ABI entry / A-B switch
+        self.sa_fused = os.environ.get('MV2D_SA_FUSED', '0') == '1'
         self.load_state(state_dict)
 
     # ------------------------------------------------------------------------------------------ weights
@@ -414,10 +417,13 @@ class HeadEngine:
         for i in range(L):
             if i == 0 or not fuse_tail:
                 o.gemm_f32(xq, W_[f'sa_in_w{i}'], W_[f'sa_in_b{i}'], A2=x, n_split=2 * C, out=ws['qkv'])
-            o.self_attn(ws['qkv'], ws['ctx'], R)
+            sa_fused = self.fuse_rows and self.rows_x3 and self.sa_fused
+            if not sa_fused:
+                o.self_attn(ws['qkv'], ws['ctx'], R)
             if self.fuse_rows and self.rows_x3:
-                o.attn_out_fused_x3(ws['ctx'], x, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
-                                    qpos=ws['qpos'], Wq_x3=W_[f'ca_q_wx{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, q_out=ws['q'], M=R)
+                sa_tail = o.sa_block_fused_x3 if sa_fused else o.attn_out_fused_x3      # self-attention core inside the row kernel, or not
+                sa_tail(ws['qkv'] if sa_fused else ws['ctx'], x, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
+                        qpos=ws['qpos'], Wq_x3=W_[f'ca_q_wx{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, q_out=ws['q'], M=R)
                 o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R, empty_nan=self.empty_nan)
                 o.attn_out_fused_x3(ws['ctx'], ws['x1'], W_[f'ca_out_wx{i}'], W_[f'ca_out_b{i}'], (W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), ws['x2'], M=R)
             elif self.fuse_rows:

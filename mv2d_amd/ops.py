@@ -116,6 +116,16 @@ def attn_out_fused_x3(ctx, resid, Wo_x3, bo, ln, x_out, *, qpos=None, Wq_x3=None
     return x_out
 
 
+def sa_block_fused_x3(qkv, resid, Wo_x3, bo, ln, x_out, *, qpos=None, Wq_x3=None, bq=None, qscale=1.0, q_out=None, M=None, eps=1e-5):
+    """self_attn(qkv) -> out_proj + resid -> LN -> x_out [-> (+qpos) q projection -> q_out]; linears in bf16x3."""
+    M = qkv.shape[0] if M is None else M
+    wq = Wq_x3 if Wq_x3 is not None else (None, None)
+    check(_lib.load().mv2d_sa_block_fused_x3(_p(qkv), _p(resid), _p(Wo_x3[0]), _p(Wo_x3[1]), _p(bo), _p(ln[0]), _p(ln[1]), _p(x_out), _p(qpos),
+                                             _p(wq[0]), _p(wq[1]), _p(bq), float(qscale), _p(q_out), M, float(eps), _stream()),
+          'mv2d_sa_block_fused_x3')
+    return x_out
+
+
 def ffn_out_fused_x3(parts, b2, resid, ln, post, x_out, qpos, xq_out, outs=None, Win_x3=None, b_in=None, qkv=None, M=None, eps=1e-5):
     """y = LN(sum(parts) + b2 + resid) -> x_out, xq_out = y + qpos, outs = post_norm(y); qkv = in_proj(xq, xq, y) (bf16x3)."""
     M = x_out.shape[0] if M is None else M

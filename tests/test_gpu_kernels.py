@@ -585,3 +585,21 @@ def test_ffn_out_fused_x3(dev):
         x2 = torch.empty_like(x); xq2 = torch.empty_like(x)
         ops.ffn_out_fused_x3(parts, b2, res, (lw, lb), None, x2, qpos, xq2)
         assert torch.equal(x2, x)
+
+
+@pytest.mark.parametrize('R', [300, 37, 900])
+def test_sa_block_fused_x3(dev, R):
+    """self-attention core + out_proj + LN + q projection in one kernel == self_attn followed by attn_out_fused_x3 (same
+    arithmetic after the context tile; the attention partial states are merged from 2 instead of 4 waves per head)."""
+    from mv2d_amd import ops
+    qkv = rnd((R, 768), 130).to(dev)
+    res, qpos = rnd((R, 256), 131).to(dev), rnd((R, 256), 132).to(dev)
+    Wo, Wq = ops.pack_x3(rnd((256, 256), 133, 0.06).to(dev)), ops.pack_x3(rnd((256, 256), 134, 0.06).to(dev))
+    bo, bq, lw, lb = rnd((256,), 135).to(dev), rnd((256,), 136).to(dev), rnd((256,), 137).to(dev), rnd((256,), 138).to(dev)
+    ctx = torch.empty((R, 256), device=dev)
+    ops.self_attn(qkv, ctx, R)
+    x_ref = torch.empty((R, 256), device=dev); q_ref = torch.empty((R, 256), device=dev)
+    ops.attn_out_fused_x3(ctx, res, Wo, bo, (lw, lb), x_ref, qpos=qpos, Wq_x3=Wq, bq=bq, qscale=0.25, q_out=q_ref)
+    x1 = torch.empty((R, 256), device=dev); q1 = torch.empty((R, 256), device=dev)
+    ops.sa_block_fused_x3(qkv, res, Wo, bo, (lw, lb), x1, qpos=qpos, Wq_x3=Wq, bq=bq, qscale=0.25, q_out=q1)
+    assert relerr(x1, x_ref) < 2e-5 and relerr(q1, q_ref) < 2e-5
