@@ -103,6 +103,15 @@ int mv2d_sa_block_fused_x3(const float* qkv, const float* resid, const void* Wo_
                            const float* ln_w, const float* ln_b, float* x_out, const float* qpos, const void* Wq_hi,
                            const void* Wq_lo, const float* bq, float qscale, float* q_out, int M, float eps, void* stream);
 
+/* Tail of the query generator + query positional embedding, row-fused: center = fc_center(enc2) (exact fp32), xyz = center2lidar,
+ * ref = normalised reference point (no clamp), posemb = pos2posemb3d(ref), qpos = query_embedding(posemb) (Linear-ReLU-Linear in
+ * bf16x3; W0 [256,384] and W2 [256,256] as bf16 hi/lo pairs, each fragment-major).  RH/utils/query_generator.py:333-341,404,
+ * RH/mv2d_t_head.py:51-57, MU/pe.py:21-33, RH/bbox_heads/cross_attention_head.py:118-125.  pc_range: host array of 6. */
+int mv2d_query_embed_fused_x3(const float* enc2, const float* Wc, const float* bc, const float* minv, const float* dim_t,
+                              const float* pc_range, const void* W0_hi, const void* W0_lo, const float* b0, const void* W2_hi,
+                              const void* W2_lo, const float* b2, float* center, float* xyz, float* ref, float* posemb,
+                              float* qpos, int R, void* stream);
+
 /* FFN tail + the next layer's self-attention in_proj, row-fused: y = LN(sum_z parts[z] + b2 + resid); x_out = y; xq_out = y + qpos;
  * outs = post_norm(y) (optional); qkv [M,768] = [xq.Wq^T + bq | xq.Wk^T + bk | y.Wv^T + bv] in bf16x3 split precision (optional:
  * Win_hi = null for the last layer).  Win_hi / Win_lo: nn.MultiheadAttention in_proj_weight [768,256] as a bf16 hi/lo pair

@@ -30,6 +30,7 @@ SIGNATURES = {
     'mv2d_gemm_f32': (I, [P, P, I, P, P, I, I, I, I, I, I, I, F, F, P, I, I, LL, I, LL, LL, LL, LL, P]),
     'mv2d_attn_out_fused': (I, [P, P, P, P, P, P, P, P, P, P, F, P, I, F, P]),
     'mv2d_sa_block_fused_x3': (I, [P, P, P, P, P, P, P, P, P, P, P, P, F, P, I, F, P]),
+    'mv2d_query_embed_fused_x3': (I, [P] * 17 + [I, P]),
     'mv2d_ffn_out_fused_x3': (I, [P, I, LL, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, F, P]),
     'mv2d_attn_out_fused_x3': (I, [P, P, P, P, P, P, P, P, P, P, P, P, F, P, I, F, P]),
     'mv2d_pack_wfrag_f32': (I, [P, P, I, I, I, P]),

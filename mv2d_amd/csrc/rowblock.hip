@@ -562,6 +562,131 @@ __global__ __launch_bounds__(1024) void ffn_out_fused_x3_kernel(FfnOutParams p) 
     }
 }
 
+// Tail of the query generator + the query positional embedding, row-fused (16 RoIs per block, 16 waves):
+//   center = fc_center(enc2)                       (RH/utils/query_generator.py:404; exact fp32, wave = RoI, wavefront dot products)
+//   xyz = center2lidar(center), ref = (xyz - pc_min) / pc_extent   (query_generator.py:333-341, RH/mv2d_t_head.py:51-57 — no clamp)
+//   posemb = pos2posemb3d(ref)                     (MU/pe.py:21-33, (y | x | z) blocks of sin/cos pairs)
+//   qpos = query_embedding(posemb) = Linear(384,256)-ReLU-Linear(256,256)   (cross_attention_head.py:118-125; bf16x3)
+// replaces 4 dependent launches (GEMM N=3, refpoint kernel, 2 GEMMs).
+struct QEmbParams {
+    const float* enc2; const float* Wc; const float* bc; const float* minv; const float* dim_t;
+    float pc0, pc1, pc2, pd0, pd1, pd2;
+    const unsigned short* W0h; const unsigned short* W0l; const float* b0; const unsigned short* W2h; const unsigned short* W2l; const float* b2;
+    float* center; float* xyz; float* ref; float* posemb; float* qpos; int R;
+};
+
+__global__ __launch_bounds__(1024) void query_embed_fused_x3_kernel(QEmbParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char eh[16 * 1024], el[16 * 1024];      // posemb tile, K = 384 (1 KB pitch)
+    __shared__ __attribute__((aligned(16))) unsigned char hh[16 * 512], hl[16 * 512];        // hidden tile, K = 256
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int m0 = blockIdx.x * 16;
+    const int r = min(m0 + wave, p.R - 1);
+    const bool live = m0 + wave < p.R;
+    // first-layer weight fragments of column tile `wave` (12 k-steps, hi + lo, fragment-major [k-step][16 tiles][lane][8]): the first
+    // 8 now, the last 4 into the slots of the first 4 once those are consumed (VGPR budget 128)
+    BFrag wh[8], wl[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const long long o = (((long long)s * 16 + wave) * 64 + lane) * 8;
+        wh[s].u = *reinterpret_cast<const uint4*>(p.W0h + o);
+        wl[s].u = *reinterpret_cast<const uint4*>(p.W0l + o);
+    }
+    // ---- fc_center: three 256-long dot products per RoI
+    const float4 e = *reinterpret_cast<const float4*>(p.enc2 + (long long)r * C + lane * 4);
+    float cp[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float4 w = *reinterpret_cast<const float4*>(p.Wc + k * C + lane * 4);
+        cp[k] = wave_sum(e.x * w.x + e.y * w.y + e.z * w.z + e.w * w.w) + p.bc[k];
+    }
+    // ---- center2lidar + normalisation (same operation order as refpoint_posemb_kernel)
+    const float cc[4] = {cp[0] * cp[2], cp[1] * cp[2], cp[2], 1.0f};
+    float pt[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = acc + p.minv[r * 16 + i * 4 + k] * cc[k];
+        pt[i] = acc;
+    }
+    const float n0 = (pt[0] - p.pc0) / p.pd0, n1 = (pt[1] - p.pc1) / p.pd1, n2 = (pt[2] - p.pc2) / p.pd2;
+    if (live && lane < 3) {
+        p.center[r * 3 + lane] = cp[lane];
+        p.xyz[r * 3 + lane] = pt[lane];
+        p.ref[r * 3 + lane] = lane == 0 ? n0 : (lane == 1 ? n1 : n2);
+    }
+    // ---- pos2posemb3d: 384 channels per RoI -> global + bf16 hi/lo images (row = wave)
+    {
+        const float two_pi = 6.283185307179586f;
+        const float py = n1 * two_pi, px = n0 * two_pi, pz = n2 * two_pi;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int ch = lane + 64 * j, axis = ch >> 7, i = ch & 127;
+            const float pos = axis == 0 ? py : (axis == 1 ? px : pz);
+            const float a = pos / p.dim_t[i];
+            const float v = (i & 1) ? cosf(a) : sinf(a);
+            if (live) p.posemb[(long long)r * 384 + ch] = v;
+            const unsigned short hi = f32_to_bf16(v), lo = f32_to_bf16(v - bf16_to_f32(hi));
+            const int off = wave * 1024 + (((ch >> 3) ^ wave) << 4) + (ch & 7) * 2;
+            *reinterpret_cast<unsigned short*>(eh + off) = hi;
+            *reinterpret_cast<unsigned short*>(el + off) = lo;
+        }
+    }
+    __syncthreads();
+    // ---- query_embedding.0 + ReLU -> hidden tile images
+    {
+        f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 12; ++s) {
+            BFrag xh, xl;
+            const int off = fr * 1024 + (((4 * s + fg) ^ fr) << 4);
+            xh.u = *reinterpret_cast<const uint4*>(eh + off);
+            xl.u = *reinterpret_cast<const uint4*>(el + off);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh.v, wh[s & 7].v, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl.v, wh[s & 7].v, a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh.v, wl[s & 7].v, a1, 0, 0, 0);
+            if (s == 3) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const long long o = (((long long)(8 + t) * 16 + wave) * 64 + lane) * 8;
+                    wh[t].u = *reinterpret_cast<const uint4*>(p.W0h + o);
+                    wl[t].u = *reinterpret_cast<const uint4*>(p.W0l + o);
+                }
+            }
+        }
+        // second-layer fragments into the same registers, in flight during the hidden-tile write
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const long long o = (((long long)s * 16 + wave) * 64 + lane) * 8;
+            wh[s].u = *reinterpret_cast<const uint4*>(p.W2h + o);
+            wl[s].u = *reinterpret_cast<const uint4*>(p.W2l + o);
+        }
+        const int col = wave * 16 + fr;
+        const float b = p.b0[col];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = 4 * fg + q;
+            const float v = relu_f((a0[q] + a1[q]) + b);
+            const unsigned short hi = f32_to_bf16(v), lo = f32_to_bf16(v - bf16_to_f32(hi));
+            const int off = row * 512 + (((col >> 3) ^ row) << 4) + (col & 7) * 2;
+            *reinterpret_cast<unsigned short*>(hh + off) = hi;
+            *reinterpret_cast<unsigned short*>(hl + off) = lo;
+        }
+    }
+    __syncthreads();
+    // ---- query_embedding.2
+    {
+        const f32x4_t acc = tile_mma_x3(hh, hl, wh, wl, fr, fg);
+        const int col = wave * 16 + fr;
+        const float b = p.b2[col];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = m0 + 4 * fg + q;
+            if (m < p.R) p.qpos[(long long)m * C + col] = acc[q] + b;
+        }
+    }
+}
+
 struct HeadsParams {
     const float* outs;            // [L, M, 256]
     const float* w0; const float* b0; const float* lnw1; const float* lnb1; const float* w3; const float* b3; const float* lnw4; const float* lnb4;
@@ -687,6 +812,21 @@ extern "C" int mv2d_sa_block_fused_x3(const float* qkv, const float* resid, cons
     AttnOutX3Params p{nullptr, resid, (const unsigned short*)Wo_hi, (const unsigned short*)Wo_lo, bo, ln_w, ln_b, x_out, qpos,
                       (const unsigned short*)Wq_hi, (const unsigned short*)Wq_lo, bq, qscale, q_out, M, eps};
     hipLaunchKernelGGL(sa_block_fused_x3_kernel, dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p, qkv, 1.0f / sqrtf(32.0f));
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_query_embed_fused_x3(const float* enc2, const float* Wc, const float* bc, const float* minv, const float* dim_t,
+                                        const float* pc_range, const void* W0_hi, const void* W0_lo, const float* b0, const void* W2_hi,
+                                        const void* W2_lo, const float* b2, float* center, float* xyz, float* ref, float* posemb,
+                                        float* qpos, int R, void* stream) {
+    MV2D_CHECK_ARG(enc2 && Wc && bc && minv && dim_t && pc_range && W0_hi && W0_lo && b0 && W2_hi && W2_lo && b2 && center && xyz && ref &&
+                       posemb && qpos, "mv2d_query_embed_fused_x3: null pointer");
+    if (R == 0) return MV2D_OK;
+    QEmbParams p{enc2, Wc, bc, minv, dim_t, pc_range[0], pc_range[1], pc_range[2], pc_range[3] - pc_range[0], pc_range[4] - pc_range[1],
+                 pc_range[5] - pc_range[2], (const unsigned short*)W0_hi, (const unsigned short*)W0_lo, b0, (const unsigned short*)W2_hi,
+                 (const unsigned short*)W2_lo, b2, center, xyz, ref, posemb, qpos, R};
+    hipLaunchKernelGGL(query_embed_fused_x3_kernel, dim3(cdiv(R, 16)), dim3(1024), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

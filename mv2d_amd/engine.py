@@ -119,6 +119,7 @@ class HeadEngine:
         w['post_w'], w['post_b'] = g(dec + 'post_norm.weight'), g(dec + 'post_norm.bias')
         w['qe_w0'], w['qe_b0'] = g('bbox_head.query_embedding.0.weight'), g('bbox_head.query_embedding.0.bias')
         w['qe_w2'], w['qe_b2'] = g('bbox_head.query_embedding.2.weight'), g('bbox_head.query_embedding.2.bias')
+        w['qe_w0x'], w['qe_w2x'] = ops.pack_x3(w['qe_w0']), ops.pack_x3(w['qe_w2'])      # bf16x3 + fragment-major (row-fused kernel)
         st = lambda fmt: torch.stack([g(fmt.format(l)) for l in range(L)]).contiguous()
         for n in ('0', '3'):
             w[f'cls_w{n}'], w[f'cls_b{n}'] = st('bbox_head.cls_branches.{}.' + n + '.weight'), st('bbox_head.cls_branches.{}.' + n + '.bias')
@@ -400,6 +401,11 @@ class HeadEngine:
         o.gemm_f32(ws['x2'], W_['qg_fc_w'], W_['qg_fc_b'], act=1, clamp=5e3, out=ws['enc'], ldc=1056)
         o.gemm_f32(ws['enc'], W_['qg_e0_w'], W_['qg_e0_b'], act=1, out=ws['enc1'])
         o.gemm_f32(ws['enc1'], W_['qg_e2_w'], W_['qg_e2_b'], act=1, out=ws['enc2'])
+        if self.rows_x3:
+            # fc_center + reference points + pos2posemb3d + query_embedding in one row-fused kernel
+            o.query_embed_fused_x3(ws['enc2'], W_['qg_c_w'], W_['qg_c_b'], ws['minv'], self.const['dim_t'], self.pc_range_h, W_['qe_w0x'],
+                                   W_['qe_b0'], W_['qe_w2x'], W_['qe_b2'], ws['center'], ws['xyz'], ws['ref'], ws['posemb'], ws['qpos'], R=R)
+            return
         o.gemm_f32(ws['enc2'], W_['qg_c_w'], W_['qg_c_b'], out=ws['center'])
         # a7/a8/a13: reference points + query positional embedding
         o.refpoint_posemb(ws['center'], 3, ws['minv'], self.const['dim_t'], ws['xyz'], ws['ref'], ws['posemb'], R, self.pc_range_h)

@@ -126,6 +126,14 @@ def sa_block_fused_x3(qkv, resid, Wo_x3, bo, ln, x_out, *, qpos=None, Wq_x3=None
     return x_out
 
 
+def query_embed_fused_x3(enc2, Wc, bc, minv, dim_t, pc_range_host, W0_x3, b0, W2_x3, b2, center, xyz, ref, posemb, qpos, R=None):
+    R = enc2.shape[0] if R is None else R
+    check(_lib.load().mv2d_query_embed_fused_x3(_p(enc2), _p(Wc), _p(bc), _p(minv), _p(dim_t), pc_range_host.data_ptr(), _p(W0_x3[0]),
+                                                _p(W0_x3[1]), _p(b0), _p(W2_x3[0]), _p(W2_x3[1]), _p(b2), _p(center), _p(xyz), _p(ref),
+                                                _p(posemb), _p(qpos), R, _stream()), 'mv2d_query_embed_fused_x3')
+    return qpos
+
+
 def ffn_out_fused_x3(parts, b2, resid, ln, post, x_out, qpos, xq_out, outs=None, Win_x3=None, b_in=None, qkv=None, M=None, eps=1e-5):
     """y = LN(sum(parts) + b2 + resid) -> x_out, xq_out = y + qpos, outs = post_norm(y); qkv = in_proj(xq, xq, y) (bf16x3)."""
     M = x_out.shape[0] if M is None else M

@@ -603,3 +603,25 @@ def test_sa_block_fused_x3(dev, R):
     x1 = torch.empty((R, 256), device=dev); q1 = torch.empty((R, 256), device=dev)
     ops.sa_block_fused_x3(qkv, res, Wo, bo, (lw, lb), x1, qpos=qpos, Wq_x3=Wq, bq=bq, qscale=0.25, q_out=q1)
     assert relerr(x1, x_ref) < 2e-5 and relerr(q1, q_ref) < 2e-5
+
+
+def test_query_embed_fused_x3(dev):
+    """fc_center + center2lidar + normalisation + pos2posemb3d + query_embedding (bf16x3) in one kernel == the four-launch chain."""
+    from mv2d_amd import ops, calib
+    for R in (300, 37):
+        enc2 = rnd((R, 256), 140).to(dev)
+        Wc = rnd((3, 256), 141, 0.05).to(dev); bc = torch.tensor([3.5, 3.5, 25.0], device=dev)
+        minv = rnd((R, 16), 142, 0.5).to(dev)
+        W0, b0, W2, b2 = rnd((256, 384), 143, 0.06).to(dev), rnd((256,), 144).to(dev), rnd((256, 256), 145, 0.06).to(dev), rnd((256,), 146).to(dev)
+        dim_t = calib.constant_tables()['dim_t'].to(dev)
+        pc = torch.tensor([-51.2, -51.2, -5.0, 51.2, 51.2, 3.0])
+        center = ops.gemm_f32(enc2, Wc, bc)
+        xyz, ref, posemb = torch.empty((R, 3), device=dev), torch.empty((R, 3), device=dev), torch.empty((R, 384), device=dev)
+        ops.refpoint_posemb(center, 3, minv, dim_t, xyz, ref, posemb, R, pc)
+        qpos_ref = ops.gemm_f32(ops.gemm_f32(posemb, W0, b0, act=1), W2, b2)
+        c2, x2, r2, p2, q2 = (torch.empty((R, 3), device=dev), torch.empty((R, 3), device=dev), torch.empty((R, 3), device=dev),
+                              torch.empty((R, 384), device=dev), torch.empty((R, 256), device=dev))
+        ops.query_embed_fused_x3(enc2, Wc, bc, minv, dim_t, pc, ops.pack_x3(W0), b0, ops.pack_x3(W2), b2, c2, x2, r2, p2, q2)
+        assert relerr(c2, center) < 1e-5 and relerr(x2, xyz) < 1e-4 and relerr(r2, ref) < 1e-4
+        assert float((p2 - posemb).abs().max()) < 5e-3          # sin/cos of arguments up to ~2 pi * ref / 1: differences of the fp32 centre propagate
+        assert relerr(q2, qpos_ref) < 5e-3
