@@ -80,6 +80,7 @@ def main():
     torch.cuda.set_device(local)
     rank, world, _ = mdist.init_from_env(backend=args.backend)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    collective = world > 1 or os.environ.get('MV2D_FORCE_COLLECTIVE', '0') == '1'    # the per-step all-gather of decoded boxes
     dev = torch.device('cuda', local)
 
     prob = synthetic.make_problem(args.workload, seed=rank)        # weak scaling: every rank its own frames
@@ -117,11 +118,11 @@ def main():
                     s.wait_event(gathered_ev[k])
                 o = e.run(feat, props, metas, use_graph=use_graph)
                 payload[k][i].copy_(mdist.pack_detections(o['boxes'], o['scores'], o['labels'], o['count']))
-                if world > 1:
+                if collective:
                     ev = torch.cuda.Event()
                     ev.record()
                     done.append(ev)
-        if world > 1:
+        if collective:
             for ev in done:
                 cur.wait_event(ev)
             out = mdist.gather_detections(payload[k])     # the one collective of an evaluation step (RCCL all-gather)
@@ -252,7 +253,7 @@ def main():
             'cpu_baseline': cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

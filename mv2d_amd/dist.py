@@ -18,7 +18,9 @@ def init_from_env(backend=None):
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    # MV2D_FORCE_COLLECTIVE=1: initialise the process group even for one rank (exercises the RCCL path on a 1-GPU box)
+    force = os.environ.get('MV2D_FORCE_COLLECTIVE', '0') == '1'
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
@@ -46,7 +48,8 @@ def unpack_detections(payload, max_num=300):
 
 def gather_detections(payload):
     """payload [B, max_num*11+1] of this rank -> [world, B, max_num*11+1] on every rank (one collective)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    force = os.environ.get('MV2D_FORCE_COLLECTIVE', '0') == '1'
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return payload[None]
     world = dist.get_world_size()
     out = torch.empty((world,) + tuple(payload.shape), dtype=payload.dtype, device=payload.device)
