@@ -177,6 +177,14 @@ int mv2d_f32_to_bf16(const float* x, void* y, long long n, void* stream);
 /* NCHW fp32 [V,C,HW] -> position-major [V*HW, C] fp32 (the layout every gather below reads). */
 int mv2d_nchw_to_nhwc(const float* x, float* y, int V, int C, int HW, void* stream);
 
+/* "next" row f2 — the extra FPN level between the 2-D detector and the RoI head (mmdet FPN, start_level = end_level = 2, num_outs = 1:
+ * configs/mv2d/exp/*:32-39, mmdet3d_plugin/models/detectors/mv2d.py:122-127): out = conv3x3(conv1x1(x) + b_lat) + b_fpn.
+ *  mv2d_nchw_to_nhwc_bf16: detector output [V,C,HW] fp32 -> position-major bf16 (operand of the 1x1 lateral conv = mv2d_gemm_bf16);
+ *  mv2d_map_conv3x3: in [V,h,w,256] bf16 (position-major), Wp = conv weight [256][tap][cin] in the fragment-major order of
+ *  mv2d_pack_wfrag_bf16, out [V,h,w,256] fp32 position-major (what the RoI-head engine consumes without a transpose). */
+int mv2d_nchw_to_nhwc_bf16(const float* x, void* y, int V, int C, int HW, void* stream);
+int mv2d_map_conv3x3(const void* in, const void* Wp, const float* bias, float* out, int V, int h, int w, void* stream);
+
 /* ---- attention ---------------------------------------------------------------------------------------- */
 
 /* FlattenMHSelfAttention core (MU/petr_transformer.py:317-370): qkv [R,768] fp32 = in_proj(q|k|v) -> ctx [R,256]. */

@@ -6,9 +6,9 @@ PETRMultiheadAttention, SinePositionalEncoding3D, NMSFreeCoder, ...) in mv2d_amd
 mmcv/mmdet is importable — mirrors them into the OpenMMLab registries so reference configs resolve to this code.
 """
 from . import registry  # noqa: F401
-from .plugin import heads, modules  # noqa: F401
-from .registry import build_head  # noqa: F401
+from .plugin import heads, modules, neck  # noqa: F401
+from .registry import build_head, build_neck  # noqa: F401
 
-__all__ = ['registry', 'build_head']
+__all__ = ['registry', 'build_head', 'build_neck']
 
 registry.mirror_into_openmmlab()

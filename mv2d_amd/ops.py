@@ -302,6 +302,25 @@ def f32_to_bf16(x, out=None):
     return out
 
 
+def nchw_to_nhwc_bf16(x, out=None):
+    """[V,C,h,w] fp32 NCHW -> position-major bf16 [V*h*w, C]."""
+    _req(x, torch.float32, 'x')
+    V, Cn, h, w = x.shape
+    if out is None:
+        out = torch.empty((V * h * w, Cn), device=x.device, dtype=BF16)
+    check(_lib.load().mv2d_nchw_to_nhwc_bf16(_p(x), _p(out), V, Cn, h * w, _stream()), 'mv2d_nchw_to_nhwc_bf16')
+    return out
+
+
+def map_conv3x3(x_cl, Wp, bias, V, h, w, out=None):
+    """x_cl [V*h*w,256] bf16 position-major, Wp = pack_wfrag(conv weight as [256, 9*256] ([out][tap][cin])) -> [V*h*w,256] fp32."""
+    _req(x_cl, BF16, 'x_cl'); _req(Wp, BF16, 'Wp'); _req(bias, torch.float32, 'bias')
+    if out is None:
+        out = torch.empty((V * h * w, 256), device=x_cl.device, dtype=torch.float32)
+    check(_lib.load().mv2d_map_conv3x3(_p(x_cl), _p(Wp), _p(bias), _p(out), V, h, w, _stream()), 'mv2d_map_conv3x3')
+    return out
+
+
 def nchw_to_nhwc(x, out=None):
     """[V,C,h,w] fp32 -> position-major [V*h*w, C] fp32."""
     _req(x, torch.float32, 'x')

@@ -55,6 +55,7 @@ POSITIONAL_ENCODING = Registry('position encoding')
 BBOX_CODERS = Registry('bbox_coder')
 ROI_EXTRACTORS = Registry('roi_extractor')
 LOSSES = Registry('loss')
+NECKS = Registry('neck')
 
 
 def build_from_cfg(cfg, registry, default_args=None):
@@ -79,19 +80,22 @@ build_transformer_layer_sequence = TRANSFORMER_LAYER_SEQUENCE.build
 build_attention = ATTENTION.build
 build_positional_encoding = POSITIONAL_ENCODING.build
 build_loss = LOSSES.build
+build_neck = NECKS.build
 
 
 def mirror_into_openmmlab():
     """Best effort: register this implementation's classes into real mmcv / mmdet registries when present."""
     done = []
     try:
-        from mmdet.models.builder import HEADS as MM_HEADS                    # type: ignore
+        from mmdet.models.builder import HEADS as MM_HEADS, NECKS as MM_NECKS   # type: ignore
         from mmdet.models.utils.builder import TRANSFORMER as MM_TR           # type: ignore
         from mmdet.core.bbox.builder import BBOX_CODERS as MM_CODERS          # type: ignore
         from mmcv.cnn.bricks.registry import (ATTENTION as MM_ATT, TRANSFORMER_LAYER as MM_TL,            # type: ignore
                                               TRANSFORMER_LAYER_SEQUENCE as MM_TLS, POSITIONAL_ENCODING as MM_PE)
     except Exception:
         return done
+    # NECKS is deliberately NOT mirrored: mmdet's own FPN must keep serving the 2-D detector (only the single-level MV2D neck is built here)
+    _ = MM_NECKS
     for src, dst in ((HEADS, MM_HEADS), (TRANSFORMER, MM_TR), (BBOX_CODERS, MM_CODERS), (ATTENTION, MM_ATT),
                      (TRANSFORMER_LAYER, MM_TL), (TRANSFORMER_LAYER_SEQUENCE, MM_TLS), (POSITIONAL_ENCODING, MM_PE)):
         for name, cls in src.module_dict.items():

@@ -597,6 +597,12 @@ def post_nms_pack(boxes, scores, labels, num_classes=10, score_thr=0.0, max_num=
     return ob, os_, ol
 
 
+def fpn_neck(x_lvl, w_lat, b_lat, w_fpn, b_fpn):
+    """f2: mmdet==2.25.1 FPN with start_level == end_level, num_outs == 1 (THIRD PARTY, parity unpinned; configs/mv2d/exp/*:32-39,
+    DET/mv2d.py:122-127): one lateral 1x1 conv + one 3x3 fpn conv, ConvModule(norm_cfg=None, act_cfg=None) = plain Conv2d with bias."""
+    return F.conv2d(F.conv2d(x_lvl, w_lat, b_lat), w_fpn, b_fpn, padding=1)
+
+
 def process_2d_detections(results, min_bbox_size=0):
     """DET/mv2d.py:60-86."""
     dets = [torch.cat([torch.cat([torch.tensor(b), torch.full((len(b), 1), label_id, dtype=torch.float)], dim=1)

@@ -170,3 +170,49 @@ def test_simple_test_from_detections_end_to_end():
     assert bool((lab[1:] >= lab[:-1]).all())                                          # class-major
     same = lab[1:] == lab[:-1]
     assert bool((res['scores_3d'][1:][same] <= res['scores_3d'][:-1][same]).all())    # score-descending inside a class
+
+
+@pytest.mark.parametrize('shape', [(6, 256, 32, 88), (2, 256, 14, 26), (1, 256, 5, 7)])
+def test_fpn_neck_single_level(shape):
+    """f2: the extra FPN level (1x1 lateral + 3x3 conv) on HIP vs the oracle restatement (bf16 MFMA tolerance) and vs conv2d on the
+    bf16-rounded operands (tight); the output is position-major (channels_last) so the head takes it without a transpose."""
+    from oracle import mv2d_oracle as O
+    g = np.random.Generator(np.random.PCG64(31))
+    V, C, h, w = shape
+    neck = mv2d_amd.build_neck(dict(type='FPN', in_channels=[256] * 5, out_channels=256, start_level=2, end_level=2, num_outs=1)).to(DEV)
+    assert set(neck.state_dict()) == {'lateral_convs.0.conv.weight', 'lateral_convs.0.conv.bias', 'fpn_convs.0.conv.weight', 'fpn_convs.0.conv.bias'}
+    with torch.no_grad():
+        for p_ in neck.parameters():
+            p_.copy_(torch.from_numpy((g.standard_normal(tuple(p_.shape)) * (0.05 if p_.dim() == 4 else 0.5)).astype(np.float32)))
+    feats = [torch.from_numpy(g.standard_normal((V, C, h * 2 ** (2 - l), w * 2 ** (2 - l)) if l == 2 else (1, 1, 1, 1)).astype(np.float32)).to(DEV)
+             for l in range(5)]
+    out, = neck(feats)
+    assert out.shape == (V, 256, h, w) and out.is_contiguous(memory_format=torch.channels_last)
+    sd = {k: v.detach().cpu() for k, v in neck.state_dict().items()}
+    x = feats[2].cpu()
+    ref = O.fpn_neck(x, sd['lateral_convs.0.conv.weight'], sd['lateral_convs.0.conv.bias'], sd['fpn_convs.0.conv.weight'], sd['fpn_convs.0.conv.bias'])
+    assert relmax(out, ref) < 1.5e-2
+    bf = lambda t: t.to(torch.bfloat16).double()
+    lat = torch.nn.functional.conv2d(bf(x), bf(sd['lateral_convs.0.conv.weight']), sd['lateral_convs.0.conv.bias'].double())
+    tight = torch.nn.functional.conv2d(bf(lat.float()), bf(sd['fpn_convs.0.conv.weight']), sd['fpn_convs.0.conv.bias'].double(), padding=1)
+    assert relmax(out, tight) < 1e-3                 # a few lateral activations round to the neighbouring bf16 (fp32 vs fp64 accumulation)
+
+
+def test_neck_output_feeds_head_without_transpose():
+    """The neck's position-major (channels_last) output goes into the RoI-head engine as is: same results as its NCHW copy."""
+    prob = synthetic.make_problem('cfg1_s', seed=0)
+    head = build('S')
+    g = np.random.Generator(np.random.PCG64(32))
+    neck = mv2d_amd.build_neck(dict(type='FPN', in_channels=[256] * 5, out_channels=256, start_level=2, end_level=2, num_outs=1)).to(DEV)
+    with torch.no_grad():
+        for p_ in neck.parameters():
+            p_.copy_(torch.from_numpy((g.standard_normal(tuple(p_.shape)) * (0.03 if p_.dim() == 4 else 0.1)).astype(np.float32)))
+    feats = [None, None, torch.from_numpy(prob['feat']).to(DEV), None, None]
+    x = neck(feats)
+    assert not x[0].is_contiguous()
+    props = [torch.from_numpy(p).to(DEV) for p in prob['proposals']]
+    metas = [dict(m, box_type_3d=None) for m in prob['img_metas']]
+    r1 = head.simple_test(list(x), props, metas)[0]
+    r2 = head.simple_test([x[0].contiguous()], props, metas)[0]
+    for a, b in zip(r1, r2):
+        assert torch.equal(a, b)

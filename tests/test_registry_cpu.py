@@ -75,3 +75,14 @@ def test_product_does_not_import_the_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), f'{f} imports the oracle'
+
+
+def test_neck_registry_and_scope():
+    """f2: the single-level FPN of the MV2D configs builds through the registry with mmdet's state-dict keys; anything else fails loudly."""
+    import mv2d_amd
+    neck = mv2d_amd.build_neck(dict(type='FPN', in_channels=[256] * 5, out_channels=256, start_level=2, end_level=2, num_outs=1))
+    assert set(neck.state_dict()) == {'lateral_convs.0.conv.weight', 'lateral_convs.0.conv.bias', 'fpn_convs.0.conv.weight', 'fpn_convs.0.conv.bias'}
+    assert neck.state_dict()['fpn_convs.0.conv.weight'].shape == (256, 256, 3, 3)
+    import pytest
+    with pytest.raises(NotImplementedError):
+        mv2d_amd.build_neck(dict(type='FPN', in_channels=[256] * 5, out_channels=256, num_outs=5))
