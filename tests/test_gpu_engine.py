@@ -244,3 +244,26 @@ def test_stream_planner_returns_concurrent_streams():
     assert single > 10 * 40e-6 * 0.9                                   # the spin kernel really spins
     if len(pool) >= 2:
         assert min(timed(pool[:2]) for _ in range(3)) < 1.5 * single
+
+
+@pytest.mark.parametrize('kind', ['t', 's'])
+def test_engine_ragged_views(kind):
+    """Ragged input: a view without any 2-D detection beside views with detections, a single box in another, and a box that leaves
+    the image — against the oracle (the reference's bbox2roi skips empty views; RoI indices shift accordingly)."""
+    prob = synthetic.make_problem('cfg1_' + kind, seed=0)
+    props = [np.asarray(p).copy() for p in prob['proposals']]
+    props[0] = props[0][:0]                                   # no detection in view 0
+    props[1] = props[1][:7]
+    props[1][3, :4] = [350.0, 180.0, 430.0, 240.0]            # sticks out of the 400x224 image into the padding
+    if len(props) > 2:
+        props[2] = props[2][:1]
+    prob = dict(prob, proposals=props)
+    eng, out, st = run_both(None, prob)
+    s, R = out['stages'], out['R']
+    assert R == sum(len(p) for p in props) == st['rois'].shape[0]
+    assert torch.equal(s['rois'][:R].cpu(), st['rois'])
+    errs = dict(center=relmax(s['center'][:R], st['center_pred']), ref=relmax(s['ref'][:R], st['ref']),
+                cls=relmax(out['cls'][:, :R], st['cls']), reg=relmax(out['reg'][:, :R], st['reg']))
+    for k, v in errs.items():
+        assert v < TOL[k], (k, v)
+    assert check_topk(out, st, eng) > 0.9
