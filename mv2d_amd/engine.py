@@ -64,6 +64,7 @@ class HeadEngine:
         self.post_range_h64 = torch.tensor(post_range, dtype=torch.float64)
         self.const = {k: v.to(self.dev) for k, v in calib.constant_tables().items()}
         self._ws = {}
+        self._ws_base = {}
         self.prof = None              # dict name -> [events] when stage timing is on (bench.py)
         self.fork_qg = True           # T path: query-generator chain on a second stream
         self.ffn_x3 = os.environ.get('MV2D_FFN_X3', '1') == '1'   # FFN in bf16x3 split precision (fragment-major hi/lo weights); 0: exact fp32
@@ -160,14 +161,49 @@ class HeadEngine:
 
     # ------------------------------------------------------------------------------------------ workspace
     def _workspace(self, V, h, w, R):
+        """Buffers of one (map shape, R) problem.  The number of RoIs changes from frame to frame in real use, so the STORAGE is
+        allocated once per (map shape, R rounded up to a multiple of 64) and every exact R only gets a dict of dense views into it
+        (kernels index [*, R, *] tensors densely) plus its own hipGraph; staging buffers, calibration cache and the stream-order
+        guard are shared by all R of a bucket."""
         key = (V, h, w, R)
         ws = self._ws.get(key)
         if ws is not None:
             return ws
+        cap = max(64, -(-R // 64) * 64)
+        bkey = (V, h, w, cap)
+        base = self._ws_base.get(bkey)
+        if base is None:
+            store = []
+
+            def alloc(shape, dt=F32, zero=False, pinned=False):
+                shape = (shape,) if isinstance(shape, int) else tuple(shape)
+                t = (torch.zeros if zero else torch.empty)(shape, dtype=dt, device='cpu' if pinned else self.dev)
+                if pinned:
+                    t = t.pin_memory()
+                store.append(t)
+                return t
+            self._build_ws(V, h, w, cap, alloc)
+            base = self._ws_base[bkey] = dict(store=store, shared={})
+        it = iter(base['store'])
+
+        def view(shape, dt=F32, zero=False, pinned=False):
+            shape = (shape,) if isinstance(shape, int) else tuple(shape)
+            n = 1
+            for v_ in shape:
+                n *= v_
+            t = next(it)
+            assert t.dtype == dt and t.numel() >= n
+            return t.view(-1)[:n].view(shape)
+        ws = self._build_ws(V, h, w, R, view)
+        ws['shared'] = base['shared']
+        self._ws[key] = ws
+        return ws
+
+    def _build_ws(self, V, h, w, R, alloc):
         d, L = self.dev, self.L
         P = V * h * w
-        e = lambda shape, dt=F32: torch.empty(shape, device=d, dtype=dt)
-        z = lambda shape, dt=F32: torch.zeros(shape, device=d, dtype=dt)
+        e = lambda shape, dt=F32: alloc(shape, dt)
+        z = lambda shape, dt=F32: alloc(shape, dt, zero=True)
         ws = dict(P=P)
         # calibration blob layout (fp64 tables first, then fp32, then bytes)
         lay, off = {}, 0
@@ -178,12 +214,12 @@ class HeadEngine:
             lay[name] = (off, n, dt)
             off += (sz + 15) // 16 * 16
         ws['blob_layout'], ws['blob_bytes'] = lay, off
-        ws['blob_h'] = torch.empty(off, dtype=torch.uint8).pin_memory()
+        ws['blob_h'] = alloc(off, torch.uint8, pinned=True)
         ws['blob_d'] = e(off, torch.uint8)
         ws['tab'] = {k: ws['blob_d'][o:o + n * torch.empty(0, dtype=dt).element_size()].view(dt) for k, (o, n, dt) in lay.items()}
         # per-frame dynamic inputs: RoI list + per-view offsets, one pinned staging buffer -> one H2D copy
         dyn_words = R * 5 + (V + 1)
-        ws['dyn_h'] = torch.empty(dyn_words, dtype=torch.int32).pin_memory()
+        ws['dyn_h'] = alloc(dyn_words, torch.int32, pinned=True)
         ws['dyn_d'] = e(dyn_words, torch.int32)
         ws['rois_h'] = ws['dyn_h'][:R * 5].view(F32).view(R, 5)
         ws['view_start_h'] = ws['dyn_h'][R * 5:]
@@ -192,7 +228,7 @@ class HeadEngine:
         ws['featcl'] = e((P, C))
         ws['enc'] = z((R, 1056)); ws['minv'] = e((R, 16))
         ws['roi_feat'] = e((R, 49, C), BF16)
-        ws['conv_out'] = e((R * 49, C)); ws['enc1'] = e((R, 512)); ws['enc2'] = e((R, C)); ws['center'] = e((R, 3))
+        ws['enc1'] = e((R, 512)); ws['enc2'] = e((R, C)); ws['center'] = e((R, 3))
         ws['xyz'] = e((R, 3)); ws['ref'] = e((R, 3)); ws['posemb'] = e((R, 384)); ws['qe1'] = e((R, C)); ws['qpos'] = e((R, C))
         ws['match'] = e((R, V, self.topk), torch.int32)
         Pp = (P + 15) // 16 * 16
@@ -215,16 +251,17 @@ class HeadEngine:
         ws['col_idx'] = e(ws['col_cap'], torch.int32)
         ws['A1'] = e((P, 3 * self.depth_num), BF16); ws['A2'] = e((P, 384), BF16)
         ws['Xf_b'] = e((P, C), BF16); ws['Xf32'] = e((P, C))
-        ws['H1'] = e((P, 4 * C), BF16); ws['H2'] = e((P, 4 * C), BF16); ws['Hg'] = e((P, C), BF16)
-        ws['gate'] = e((P, C)); ws['Pg'] = e((P, C)); ws['pe'] = e((P, C)); ws['Xk'] = e((P, C), BF16)
+        if not self.pe_fused:                                    # intermediates of the six-GEMM PE route only
+            ws['H1'] = e((P, 4 * C), BF16); ws['H2'] = e((P, 4 * C), BF16); ws['Hg'] = e((P, C), BF16)
+            ws['gate'] = e((P, C)); ws['Pg'] = e((P, C))
+        ws['pe'] = e((P, C)); ws['Xk'] = e((P, C), BF16)
         ws['KV'] = e((2 * L, ws['S_kv'], C), BF16)
         for n in ('x', 'xq', 'x1', 'x1q', 'x2', 'ctx', 'o', 'q'):
             ws[n] = e((R, C))
-        ws['qkv'] = e((R, 3 * C)); ws['hdn'] = e((R, 2048)); ws['parts'] = e((2048 // 64, R, C)); ws['outs'] = e((L, R, C))
-        ws['hc1'] = e((L, R, C)); ws['hc2'] = e((L, R, C)); ws['cls'] = e((L, R, 10)); ws['reg'] = e((L, R, 10))
+        ws['qkv'] = e((R, 3 * C)); ws['parts'] = e((2048 // 64, R, C)); ws['outs'] = e((L, R, C))
+        ws['cls'] = e((L, R, 10)); ws['reg'] = e((L, R, 10))
         ws['boxes'] = z((self.max_num, 9)); ws['scores'] = z(self.max_num)
         ws['labels'] = z(self.max_num, torch.int64); ws['bbox_index'] = z(self.max_num, torch.int64); ws['count'] = z(1, torch.int32)
-        self._ws[key] = ws
         return ws
 
     # ------------------------------------------------------------------------------------------ host side
@@ -258,10 +295,11 @@ class HeadEngine:
         rois_h, counts = self._rois_host(proposals)
         R = rois_h.shape[0]
         ws = self._workspace(V, h, w, R)
-        if 'done_ev' in ws:
-            ws['done_ev'].synchronize()      # the previous frame on this workspace must have consumed the staging buffers
+        sh = ws['shared']
+        if 'done_ev' in sh:
+            sh['done_ev'].synchronize()      # the previous frame on this workspace must have consumed the staging buffers
         key = self._frame_key(img_metas)
-        if ws.get('frame_key') != key:
+        if sh.get('frame_key') != key:
             ft = calib.frame_tables(img_metas, h, w, stride=self.stride, depth_num=self.depth_num,
                                     position_range=tuple(self.post_range_h64.tolist()))
             bh = ws['blob_h']
@@ -272,13 +310,13 @@ class HeadEngine:
             if self.kind == 'T' and len(img_metas) > self.num_views:
                 ts = ft['timestamps']
                 dt = float(ts[self.num_views:].mean() - ts[:self.num_views].mean())
-            ws['frame_key'], ws['frame_scalars'] = key, dict(pad_h=ft['pad_h'], pad_w=ft['pad_w'], dt=dt)
+            sh['frame_key'], sh['frame_scalars'] = key, dict(pad_h=ft['pad_h'], pad_w=ft['pad_w'], dt=dt)
             # the calibration tables change only when img_metas change: upload them here (stream-ordered before the frame),
             # not once per frame
             ws['blob_d'].copy_(bh, non_blocking=True)
         ws['rois_h'].copy_(rois_h)
         ws['view_start_h'].copy_(torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32))
-        sc = dict(ws['frame_scalars'])
+        sc = dict(sh['frame_scalars'])
         sc['max_per_view'] = max(counts)
         return ws, R, sc
 
@@ -507,9 +545,10 @@ class HeadEngine:
 
     @staticmethod
     def _mark_done(ws):
-        if 'done_ev' not in ws:
-            ws['done_ev'] = torch.cuda.Event()
-        ws['done_ev'].record()
+        sh = ws['shared']
+        if 'done_ev' not in sh:
+            sh['done_ev'] = torch.cuda.Event()
+        sh['done_ev'].record()
 
     def clone_shared(self):
         """A second engine sharing the packed weights / constant tables but with its own workspaces, so that several
@@ -517,6 +556,7 @@ class HeadEngine:
         other = object.__new__(HeadEngine)
         other.__dict__.update(self.__dict__)
         other._ws = {}
+        other._ws_base = {}
         other.prof = None
         return other
 

@@ -169,6 +169,31 @@ def test_engine_is_deterministic_and_reusable():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('kind,name', [('T', 'cfg1_t'), ('S', 'cfg1_s')])
+def test_engine_varying_roi_count_shares_one_storage(kind, name):
+    """Real frames have a different number of RoIs every time: the engine must serve them from ONE storage bucket (views per R)
+    and every frame must equal what a fresh engine computes for it, also when a smaller frame follows a larger one (graphs too)."""
+    from mv2d_amd.engine import HeadEngine
+    prob = synthetic.make_problem(name, seed=0)
+    sd = synthetic.make_head_state(seed=0)
+    dev = torch.device('cuda:0')
+    vpf = prob['views_per_frame']
+    feat = torch.from_numpy(prob['feat']).to(dev)
+    full = [torch.from_numpy(p) for p in prob['proposals']]
+    variants = [full, [p[:max(1, p.shape[0] - 2 - i)] for i, p in enumerate(full)], [p[:max(1, p.shape[0] // 2)] for p in full], full]
+    eng = HeadEngine(sd, kind, dev, num_views=vpf)
+    for use_graph in (False, True):
+        for props in variants:
+            out = eng.run(feat, props, prob['img_metas'], use_graph=use_graph)
+            got = [out['cls'].clone(), out['reg'].clone()] + [t.clone() for t in eng.results(out)]
+            fresh = HeadEngine(sd, kind, dev, num_views=vpf)
+            ref = fresh.run(feat, props, prob['img_metas'])
+            want = [ref['cls'], ref['reg']] + list(fresh.results(ref))
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), (use_graph, out['R'])
+    assert len(eng._ws_base) == 1 and len(eng._ws) == 3
+
+
 def test_engine_full_size_properties_cfg5():
     """BASELINE.json's largest configuration (R101 1600x640, 12 views, 900 queries) through size-independent properties:
     CSR well-formedness, idempotence (same frame twice -> bitwise identical), fork/no-fork equality, and the decode kernel
