@@ -12,9 +12,9 @@
 //     of a layer for all 64 rows, so each weight fragment is read by exactly one wave (measured: 4 waves x 64 rows = 8 waves x 64
 //     rows = 4 waves x 32 rows with two blocks per CU, within 5 %);
 //   * the weights are never staged: fragment-major copies (mv2d_pack_wfrag_bf16) stream straight from L2 into a 4-deep register
-//     ring, one contiguous 1 KB per fragment load, prefetched 3 steps ahead across the layer-1 / layer-2 boundary of a part (its
-//     step list is unrolled at compile time, so hipcc keeps exact vmcnt counts);
-//   * hidden activations never leave the CU; P1, G, P2 are combined in registers; one fp32 + one bf16 store per output.
+//     ring, one contiguous 1 KB per fragment load, prefetched 3 steps ahead through all layer / part / MLP boundaries;
+//   * hidden activations never leave the CU; P1, G, P2 are combined in registers (LDS allows one block per CU anyway, so a wave
+//     may use all 512 registers); one fp32 + one bf16 store per output.
 // MFMAs run swapped (D^T = W.A^T): a lane ends with 4 consecutive columns of one row -> 8-byte LDS writes of the hidden layer,
 // 16-byte global stores.  Same k order and the same bf16 rounding of the hidden layers as the GEMM route: results are bit-identical.
 #include "common.h"
@@ -44,175 +44,268 @@ struct PeParams {
     float* pe; unsigned short* Xk;
 };
 
-// two-layer MLP on the block's 64 rows: acc2[i][j] (row tile i, column tile j of this wave's 64 output columns) =
-// relu(A . W1^T + b1) . W2^T, A [64, K1] bf16 rows m0.. of `Ag` (ld = K1), hidden HID, output 256.
-template <int K1, int HID>
-__device__ __forceinline__ void run_mlp(unsigned char* __restrict__ As, unsigned char* __restrict__ Hs, const unsigned short* __restrict__ Ag,
-                                        int m0, int M, const unsigned short* __restrict__ W1, const float* __restrict__ b1,
-                                        const unsigned short* __restrict__ W2, f32x4_t acc2[RT][CT2], int tid) {
-    constexpr int PITCH_A = K1 <= 256 ? 512 : 1024;       // power-of-two row pitch so that the chunk XOR stays inside the row
-    constexpr int CPR = K1 / 8;                           // 16-byte chunks per input row
-    constexpr int HPL = HID >= HP ? HP : HID;             // hidden columns per part (512, or 256 for the gate)
-    constexpr int NH = HID / HPL;
-    constexpr int TPW = HPL / 16 / NW;                    // hidden column tiles per wave and part ...
-    constexpr int PT1 = TPW >= 4 ? 4 : TPW, NPASS = TPW / PT1;   // ... in passes of PT1
-    constexpr int KS1 = K1 / 32, L1 = NPASS * KS1, L2 = HPL / 32;
-    static_assert(L2 >= 4 && TPW >= 1 && CT2 >= 1, "the register ring runs through layer 1 into layer 2");
-    constexpr int NT1 = HID / 16;
-    const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+// ---- building blocks -------------------------------------------------------------------------------------------------------
+// The kernel is ONE software pipeline over the 152 k-steps of the three MLPs (gate 16, frustum 2 x 28, sine 2 x 40): every step
+// consumes four 1 KB weight fragments from a 4-slot register ring that is fed three steps ahead, also across the layer / part /
+// MLP boundaries (the successor's first three steps are requested in the last three steps of a part), so the ring never drains.
+// Everything else a step needs is requested earlier as well: the LDS fragments of step t+1 during step t, the hidden-layer bias
+// at the first k-step of a pass, the next MLP's input tile / the epilogue operands at the start of the last layer 2.  (Round-1
+// profile of the previous version: 950 cycles per step against 256 cycles of MFMA work; the input staging loop and the
+// epilogues were one exposed memory round trip per 16 bytes, the bias loads drained the ring once per pass.)
+// All step indices are compile-time (one function instance per part, unrolled step loops): hipcc keeps exact vmcnt counts.
+template <int K1_, int HID_>
+struct Mlp {
+    static constexpr int K1 = K1_, HID = HID_;
+    static constexpr int PITCH_A = K1 <= 256 ? 512 : 1024;       // power-of-two row pitch so that the chunk XOR stays inside the row
+    static constexpr int CPR = K1 / 8;                           // 16-byte chunks per input row
+    static constexpr int HPL = HID >= HP ? HP : HID;             // hidden columns per part (512, or 256 for the gate)
+    static constexpr int NH = HID / HPL;
+    static constexpr int TPW = HPL / 16 / NW;                    // hidden column tiles per wave and part ...
+    static constexpr int PT1 = 4, NPASS = TPW / PT1;             // ... in passes of 4
+    static constexpr int KS1 = K1 / 32, L1 = NPASS * KS1, L2 = HPL / 32, NSTEP = L1 + L2;
+    static constexpr int NT1 = HID / 16;
+    static constexpr int NST = BM * CPR / (64 * NW) / 2;         // staging loads per thread and half (two register arrays: hipcc
+                                                                 // leaves a 12 x 16-byte array in scratch)
+    static_assert(TPW % 4 == 0 && CT2 == 4, "four fragments per step");
+    static_assert(NSTEP % 4 == 0 && L1 % 4 == 0, "ring slots stay aligned across parts");
+    static_assert(BM * CPR % (2 * 64 * NW) == 0, "whole staging rounds");
+};
+using MlpG = Mlp<256, 256>;
+using MlpA = Mlp<192, 1024>;
+using MlpB = Mlp<384, 1024>;
 
-    // ---- stage the input tile (rows beyond M clamp to the last valid row; their results are never stored)
-    for (int c = tid; c < BM * CPR; c += 64 * NW) {
-        const int row = c / CPR, chunk = c - row * CPR;
-        const int m = min(m0 + row, M - 1);
-        *reinterpret_cast<uint4*>(As + row * PITCH_A + ((chunk ^ (row & 15)) << 4)) =
-            *reinterpret_cast<const uint4*>(Ag + (long long)m * K1 + chunk * 8);
+struct WPtr { const unsigned short* w1; const unsigned short* w2; };     // per-wave, per-lane bases of the two fragment-major matrices
+
+// fragment group (4 consecutive column tiles = 4 KB) of step t of part H
+template <class ML, int H>
+__device__ __forceinline__ const unsigned short* step_ptr(const WPtr& w, int t) {
+    if (t < ML::L1) {
+        const int pass = t / ML::KS1, ks = t - pass * ML::KS1;
+        return w.w1 + (long long)(ks * ML::NT1 + H * (ML::HPL / 16) + pass * ML::PT1) * 512;
     }
+    return w.w2 + (long long)((H * (ML::HPL / 32) + (t - ML::L1)) * 16) * 512;
+}
+__device__ __forceinline__ void load4(Frag (&dst)[4], const unsigned short* wp) {
 #pragma unroll
-    for (int i = 0; i < RT; ++i)
+    for (int j = 0; j < 4; ++j) dst[j].u = *reinterpret_cast<const uint4*>(wp + j * 512);
+}
+#define MMA(w, a, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((w).v, (a).v, c, 0, 0, 0)
+__device__ __forceinline__ void load_a(Frag (&a)[RT], const unsigned char* S, int pitch, int kstep, int fr, int fg) {
 #pragma unroll
-        for (int j = 0; j < CT2; ++j) acc2[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    f32x4_t acc1[RT][PT1];
-    __syncthreads();
+    for (int i = 0; i < RT; ++i) a[i].u = *reinterpret_cast<const uint4*>(S + (16 * i + fr) * pitch + (((4 * kstep + fg) ^ fr) << 4));
+}
 
-#pragma unroll 1
-    for (int h = 0; h < NH; ++h) {                     // one resident part of the hidden layer at a time (runtime loop)
-        // fragment group (4 consecutive column tiles = 4 KB) of step t of this part: compile-time offsets from two bases
-        const unsigned short* w1b = W1 + ((long long)(h * HPL / 16 + wave * TPW) * 64 + lane) * 8;
-        const unsigned short* w2b = W2 + (((long long)(h * (HPL / 32)) * 16 + wave * CT2) * 64 + lane) * 8;
-        auto wptr = [&](int t) -> const unsigned short* {
-            if (t < L1) { const int pass = t / KS1, ks = t - pass * KS1; return w1b + ((long long)ks * NT1 + pass * PT1) * 512; }
-            return w2b + (long long)(t - L1) * 16 * 512;
-        };
-        Frag wq[4][4];
+// input tile rows m0.. of `Ag` (ld = K1): all loads of a thread are issued together (rows beyond M clamp to the last valid row; their
+// results are never stored), the LDS writes follow when the tile buffer is free
+template <class ML>
+__device__ __forceinline__ void stage_issue(uint4 (&sa)[ML::NST], uint4 (&sb)[ML::NST], const unsigned short* __restrict__ Ag, int m0, int M, int tid) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const unsigned short* wp = wptr(t);
+    for (int i = 0; i < 2 * ML::NST; ++i) {
+        const int c = tid + i * (64 * NW), row = c / ML::CPR, chunk = c - row * ML::CPR;
+        const uint4 v = *reinterpret_cast<const uint4*>(Ag + (long long)min(m0 + row, M - 1) * ML::K1 + chunk * 8);
+        if (i < ML::NST) sa[i] = v; else sb[i - ML::NST] = v;
+    }
+}
+template <class ML>
+__device__ __forceinline__ void stage_write(unsigned char* As, const uint4 (&sa)[ML::NST], const uint4 (&sb)[ML::NST], int tid) {
 #pragma unroll
-            for (int j = 0; j < (t < L1 ? PT1 : CT2); ++j) wq[t & 3][j].u = *reinterpret_cast<const uint4*>(wp + j * 512);
-        }
-        // ---- layer 1 of this part (L1 steps), then layer 2 (L2 steps); the ring runs through (L1 is a multiple of 4)
-#pragma unroll
-        for (int t = 0; t < L1; ++t) {
-            {
-                const unsigned short* wp = wptr(t + 3);
-#pragma unroll
-                for (int j = 0; j < (t + 3 < L1 ? PT1 : CT2); ++j) wq[(t + 3) & 3][j].u = *reinterpret_cast<const uint4*>(wp + j * 512);
-            }
-            __builtin_amdgcn_sched_barrier(0);           // keep the prefetch 3 steps ahead
-            const int pass = t / KS1, ks = t - pass * KS1;
-            if (ks == 0) {
-#pragma unroll
-                for (int i = 0; i < RT; ++i)
-#pragma unroll
-                    for (int j = 0; j < PT1; ++j) acc1[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            }
-            Frag a[RT];
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-                a[i].u = *reinterpret_cast<const uint4*>(As + (16 * i + fr) * PITCH_A + (((4 * ks + fg) ^ fr) << 4));
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-#pragma unroll
-                for (int j = 0; j < PT1; ++j)
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[t & 3][j].v, a[i].v, acc1[i][j], 0, 0, 0);
-            if (ks == KS1 - 1) {
-                // hidden tile of this pass: lane (fr, fg) holds hidden columns 4fg..4fg+3 of row 16i + fr -> bias, ReLU, bf16, 8-byte write
-#pragma unroll
-                for (int j = 0; j < PT1; ++j) {
-                    const int lcol = (wave * TPW + pass * PT1 + j) * 16 + 4 * fg;             // column inside the resident part
-                    const float4 bb = *reinterpret_cast<const float4*>(b1 + h * HPL + lcol);
-#pragma unroll
-                    for (int i = 0; i < RT; ++i) {
-                        const uint2 hv = make_uint2(pack_bf16x2(relu_f(acc1[i][j][0] + bb.x), relu_f(acc1[i][j][1] + bb.y)),
-                                                    pack_bf16x2(relu_f(acc1[i][j][2] + bb.z), relu_f(acc1[i][j][3] + bb.w)));
-                        *reinterpret_cast<uint2*>(Hs + (16 * i + fr) * PITCH_H + (((lcol >> 3) ^ fr) << 4) + (lcol & 4) * 2) = hv;
-                    }
-                }
-            }
-        }
-        __syncthreads();                               // the resident part of the hidden layer is complete
-#pragma unroll
-        for (int t2 = 0; t2 < L2; ++t2) {
-            if (t2 + 3 < L2) {
-                const unsigned short* wp = wptr(L1 + t2 + 3);
-#pragma unroll
-                for (int j = 0; j < CT2; ++j) wq[(L1 + t2 + 3) & 3][j].u = *reinterpret_cast<const uint4*>(wp + j * 512);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            Frag a[RT];
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-                a[i].u = *reinterpret_cast<const uint4*>(Hs + (16 * i + fr) * PITCH_H + (((4 * t2 + fg) ^ fr) << 4));
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-#pragma unroll
-                for (int j = 0; j < CT2; ++j)
-                    acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[(L1 + t2) & 3][j].v, a[i].v, acc2[i][j], 0, 0, 0);
-        }
-        __syncthreads();                               // everybody is done reading this part (and, after the last one, As / Hs are free)
+    for (int i = 0; i < 2 * ML::NST; ++i) {
+        const int c = tid + i * (64 * NW), row = c / ML::CPR, chunk = c - row * ML::CPR;
+        *reinterpret_cast<uint4*>(As + row * ML::PITCH_A + ((chunk ^ (row & 15)) << 4)) = i < ML::NST ? sa[i] : sb[i - ML::NST];
     }
 }
 
-__global__ __launch_bounds__(64 * NW, 2) void pe_fused_kernel(PeParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + H_BYTES];
+// what a part requests at the start of its layer 2 (the first point where the input tile buffer / the dead layer-1 accumulators
+// are free), for use after its last step:
+enum Mid { MID_NONE = 0, MID_STAGE = 1, MID_STAGE_PARKED = 2, MID_FINAL = 3 };
+struct Ctx { const unsigned short* next_in; float* pe; const float* Xf32; int m0, M, tid, n0; };
+// all biases live in LDS (a global load in the middle of the pipeline would have to be waited for through the whole ring)
+enum { B_R = 0, B_E = 256, B_1A = 512, B_1B = 1536, B_2A = 1792, B_2B = 2816, B_FLOATS = 3072 };
+
+// One resident part H of MLP `ML` on the block's rows: acc2 += relu(A . W1[part]^T + b1[part]) . W2[:, part]^T.
+// On entry the ring holds steps 0..2 of this part; its last three steps request steps 0..2 of part NXH of `NX` (HAS_NEXT).
+template <class ML, int H, class NX, int NXH, bool HAS_NEXT, int MID>
+__device__ __forceinline__ void mlp_part(const unsigned char* As, unsigned char* Hs, const WPtr& w, const float* b1 /* LDS */, const WPtr& nw,
+                                         f32x4_t (&acc2)[RT][CT2], Frag (&wq)[4][4], int lane, int wave, const Ctx& cx,
+                                         uint4 (&sa)[NX::NST], uint4 (&sb)[NX::NST], float4 (&pk)[RT][CT2], float4 (&f)[RT][CT2]) {
+    const int fr = lane & 15, fg = lane >> 4;
+    f32x4_t acc1[RT][4];
+    Frag a[2][RT];
+    load_a(a[0], As, ML::PITCH_A, 0, fr, fg);
+#pragma unroll
+    for (int t = 0; t < ML::L1; ++t) {
+        if (t + 3 < ML::NSTEP) load4(wq[(t + 3) & 3], step_ptr<ML, H>(w, t + 3));
+        const int pass = t / ML::KS1, ks = t - pass * ML::KS1;
+        if (ks == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < RT; ++i) acc1[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        if (t + 1 < ML::L1) load_a(a[(t + 1) & 1], As, ML::PITCH_A, (t + 1) % ML::KS1, fr, fg);
+        __builtin_amdgcn_sched_barrier(0);               // keep the requests ahead of this step's MFMAs
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc1[i][j] = MMA(wq[t & 3][j], a[t & 1][i], acc1[i][j]);
+        if (ks == ML::KS1 - 1) {
+            // hidden tile of this pass: lane (fr, fg) holds hidden columns 4fg..4fg+3 of row 16i + fr -> bias, ReLU, bf16, 8-byte write
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int lcol = (wave * ML::TPW + pass * 4 + j) * 16 + 4 * fg;             // column inside the resident part
+                const float4 bb = *reinterpret_cast<const float4*>(b1 + H * ML::HPL + lcol);
+#pragma unroll
+                for (int i = 0; i < RT; ++i) {
+                    const uint2 hv = make_uint2(pack_bf16x2(relu_f(acc1[i][j][0] + bb.x), relu_f(acc1[i][j][1] + bb.y)),
+                                                pack_bf16x2(relu_f(acc1[i][j][2] + bb.z), relu_f(acc1[i][j][3] + bb.w)));
+                    *reinterpret_cast<uint2*>(Hs + (16 * i + fr) * PITCH_H + (((lcol >> 3) ^ fr) << 4) + (lcol & 4) * 2) = hv;
+                }
+            }
+        }
+    }
+    __syncthreads();                                   // the resident part of the hidden layer is complete
+    if (MID == MID_STAGE || MID == MID_STAGE_PARKED) stage_issue<NX>(sa, sb, cx.next_in, cx.m0, cx.M, cx.tid);
+    if (MID == MID_STAGE_PARKED || MID == MID_FINAL) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < CT2; ++j) {
+                const long long o = (long long)min(cx.m0 + 16 * i + fr, cx.M - 1) * C + cx.n0 + 16 * j;
+                pk[i][j] = *reinterpret_cast<const float4*>(cx.pe + o);
+                if (MID == MID_FINAL) f[i][j] = *reinterpret_cast<const float4*>(cx.Xf32 + o);
+            }
+    }
+    load_a(a[0], Hs, PITCH_H, 0, fr, fg);
+#pragma unroll
+    for (int t2 = 0; t2 < ML::L2; ++t2) {
+        const int t = ML::L1 + t2;
+        if (t + 3 < ML::NSTEP) load4(wq[(t + 3) & 3], step_ptr<ML, H>(w, t + 3));
+        else if (HAS_NEXT) load4(wq[(t + 3) & 3], step_ptr<NX, NXH>(nw, t + 3 - ML::NSTEP));
+        if (t2 + 1 < ML::L2) load_a(a[(t2 + 1) & 1], Hs, PITCH_H, t2 + 1, fr, fg);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < CT2; ++j)
+                acc2[i][j] = MMA(wq[t & 3][j], a[t2 & 1][i], acc2[i][j]);
+    }
+    __syncthreads();                                   // everybody is done reading this part (and, after the last one, As / Hs are free)
+}
+
+__device__ __forceinline__ void zero_acc(f32x4_t (&acc)[RT][CT2]) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+}
+
+__global__ __launch_bounds__(64 * NW, 1) void pe_fused_kernel(PeParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + H_BYTES + B_FLOATS * 4];
     unsigned char* As = smem;
     unsigned char* Hs = smem + A_BYTES;
+    float* Bs = reinterpret_cast<float*>(smem + A_BYTES + H_BYTES);
     int M = p.M;
     if (p.m_dev) { const int md = *p.m_dev; M = md < M ? md : M; }
     const int m0 = blockIdx.x * BM;
     if (m0 >= M) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int n0 = wave * (CT2 * 16) + 4 * fg;          // this lane's 4 output columns of column tile j start at n0 + 16 j
 
-    // The three MLPs hand their results over through the output buffer itself (every lane re-reads exactly the addresses it
-    // wrote): carrying P1 and the gate in registers across the next MLP costs 64-128 more VGPRs and pushes the kernel into spills.
+    const long long lo = (long long)lane * 8;
+    const WPtr wG{p.Wr + (long long)(wave * MlpG::TPW) * 512 + lo, p.We + (long long)(wave * CT2) * 512 + lo};
+    const WPtr wA{p.W1a + (long long)(wave * MlpA::TPW) * 512 + lo, p.W1b + (long long)(wave * CT2) * 512 + lo};
+    const WPtr wB{p.W2a + (long long)(wave * MlpB::TPW) * 512 + lo, p.W2b + (long long)(wave * CT2) * 512 + lo};
+    Frag wq[4][4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) load4(wq[t], step_ptr<MlpG, 0>(wG, t));
+    {
+        // biases -> LDS: float4 index tid + 256 r of [br | be | b1a | b1b | b2a | b2b]
+        float4 bv[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int q = tid + 256 * r;
+            const float* src = q < 64 ? p.br + 4 * q : q < 128 ? p.be + 4 * (q - 64) : q < 384 ? p.b1a + 4 * (q - 128)
+                             : q < 448 ? p.b1b + 4 * (q - 384) : q < 704 ? p.b2a + 4 * (q - 448) : p.b2b + 4 * (q - 704);
+            bv[r] = *reinterpret_cast<const float4*>(src);
+        }
+        uint4 sa[MlpG::NST], sb[MlpG::NST];
+        stage_issue<MlpG>(sa, sb, p.Xfb, m0, M, tid);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) *reinterpret_cast<float4*>(Bs + 4 * (tid + 256 * r)) = bv[r];
+        stage_write<MlpG>(As, sa, sb, tid);
+    }
+    __syncthreads();
     f32x4_t acc[RT][CT2];
+    float4 pk[RT][CT2], f[RT][CT2];                     // value parked in the output buffer; feature rows
+    Ctx cx{p.A1, p.pe, p.Xf32, m0, M, tid, n0};
+
+    // The gate and P1 * gate wait in the output buffer `pe` while the next MLP runs (every lane re-reads exactly the addresses it
+    // wrote, requested a whole layer 2 ahead): carrying them in registers costs 64 more VGPRs than the kernel has.
     // 1. gate = sigmoid(conv_expand(relu(conv_reduce(feat))))            -> pe (temporary)
-    run_mlp<256, 256>(As, Hs, p.Xfb, m0, M, p.Wr, p.br, p.We, acc, tid);
+    zero_acc(acc);
+    {
+        uint4 sa[MlpA::NST], sb[MlpA::NST];
+        mlp_part<MlpG, 0, MlpA, 0, true, MID_STAGE>(As, Hs, wG, Bs + B_R, wA, acc, wq, lane, wave, cx, sa, sb, pk, f);
+        stage_write<MlpA>(As, sa, sb, tid);
+    }
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-        const int m = m0 + 16 * i + fr;
-        if (m >= M) continue;
+    for (int j = 0; j < CT2; ++j) {
+        const float4 eb = *reinterpret_cast<const float4*>(Bs + B_E + n0 + 16 * j);
 #pragma unroll
-        for (int j = 0; j < CT2; ++j) {
-            const int n = wave * (CT2 * 16) + 16 * j + 4 * fg;
-            const float4 bb = *reinterpret_cast<const float4*>(p.be + n);
-            *reinterpret_cast<float4*>(p.pe + (long long)m * C + n) =
-                make_float4(1.f / (1.f + __expf(-(acc[i][j][0] + bb.x))), 1.f / (1.f + __expf(-(acc[i][j][1] + bb.y))),
-                            1.f / (1.f + __expf(-(acc[i][j][2] + bb.z))), 1.f / (1.f + __expf(-(acc[i][j][3] + bb.w))));
+        for (int i = 0; i < RT; ++i) {
+            const int m = m0 + 16 * i + fr;
+            if (m < M)
+                *reinterpret_cast<float4*>(p.pe + (long long)m * C + n0 + 16 * j) =
+                    make_float4(1.f / (1.f + __expf(-(acc[i][j][0] + eb.x))), 1.f / (1.f + __expf(-(acc[i][j][1] + eb.y))),
+                                1.f / (1.f + __expf(-(acc[i][j][2] + eb.z))), 1.f / (1.f + __expf(-(acc[i][j][3] + eb.w))));
         }
     }
+    __syncthreads();
     // 2. P1 = position_encoder(A1);  Pg = (P1 + b) * gate                 -> pe (temporary)
-    run_mlp<192, 1024>(As, Hs, p.A1, m0, M, p.W1a, p.b1a, p.W1b, acc, tid);
+    zero_acc(acc);
+    {
+        uint4 s0[MlpA::NST], s1[MlpA::NST];
+        mlp_part<MlpA, 0, MlpA, 1, true, MID_NONE>(As, Hs, wA, Bs + B_1A, wA, acc, wq, lane, wave, cx, s0, s1, pk, f);
+    }
+    cx.next_in = p.A2;
+    {
+        uint4 sa[MlpB::NST], sb[MlpB::NST];
+        mlp_part<MlpA, 1, MlpB, 0, true, MID_STAGE_PARKED>(As, Hs, wA, Bs + B_1A, wB, acc, wq, lane, wave, cx, sa, sb, pk, f);
+        stage_write<MlpB>(As, sa, sb, tid);
+    }
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-        const int m = m0 + 16 * i + fr;
-        if (m >= M) continue;
+    for (int j = 0; j < CT2; ++j) {
+        const float4 eb = *reinterpret_cast<const float4*>(Bs + B_1B + n0 + 16 * j);
 #pragma unroll
-        for (int j = 0; j < CT2; ++j) {
-            const int n = wave * (CT2 * 16) + 16 * j + 4 * fg;
-            const float4 bb = *reinterpret_cast<const float4*>(p.b1b + n);
-            float4* dst = reinterpret_cast<float4*>(p.pe + (long long)m * C + n);
-            const float4 g = *dst;
-            *dst = make_float4((acc[i][j][0] + bb.x) * g.x, (acc[i][j][1] + bb.y) * g.y, (acc[i][j][2] + bb.z) * g.z, (acc[i][j][3] + bb.w) * g.w);
+        for (int i = 0; i < RT; ++i) {
+            const int m = m0 + 16 * i + fr;
+            if (m < M)
+                *reinterpret_cast<float4*>(p.pe + (long long)m * C + n0 + 16 * j) =
+                    make_float4((acc[i][j][0] + eb.x) * pk[i][j].x, (acc[i][j][1] + eb.y) * pk[i][j].y,
+                                (acc[i][j][2] + eb.z) * pk[i][j].z, (acc[i][j][3] + eb.w) * pk[i][j].w);
         }
     }
+    __syncthreads();
     // 3. P2 = adapt_pos3d(A2);  pe = (P2 + b) + Pg;  Xk = bf16(pe + feat)
-    run_mlp<384, 1024>(As, Hs, p.A2, m0, M, p.W2a, p.b2a, p.W2b, acc, tid);
+    zero_acc(acc);
+    {
+        uint4 s0[MlpB::NST], s1[MlpB::NST];
+        mlp_part<MlpB, 0, MlpB, 1, true, MID_NONE>(As, Hs, wB, Bs + B_2A, wB, acc, wq, lane, wave, cx, s0, s1, pk, f);
+        mlp_part<MlpB, 1, MlpB, 1, false, MID_FINAL>(As, Hs, wB, Bs + B_2A, wB, acc, wq, lane, wave, cx, s0, s1, pk, f);
+    }
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-        const int m = m0 + 16 * i + fr;
-        if (m >= M) continue;
+    for (int j = 0; j < CT2; ++j) {
+        const float4 eb = *reinterpret_cast<const float4*>(Bs + B_2B + n0 + 16 * j);
 #pragma unroll
-        for (int j = 0; j < CT2; ++j) {
-            const int n = wave * (CT2 * 16) + 16 * j + 4 * fg;
-            const float4 bb = *reinterpret_cast<const float4*>(p.b2b + n);
-            float4* dst = reinterpret_cast<float4*>(p.pe + (long long)m * C + n);
-            const float4 pg = *dst;
-            const float4 v = make_float4((acc[i][j][0] + bb.x) + pg.x, (acc[i][j][1] + bb.y) + pg.y, (acc[i][j][2] + bb.z) + pg.z, (acc[i][j][3] + bb.w) + pg.w);
-            *dst = v;
-            const float4 f = *reinterpret_cast<const float4*>(p.Xf32 + (long long)m * C + n);
-            *reinterpret_cast<uint2*>(p.Xk + (long long)m * C + n) = make_uint2(pack_bf16x2(v.x + f.x, v.y + f.y), pack_bf16x2(v.z + f.z, v.w + f.w));
+        for (int i = 0; i < RT; ++i) {
+            const int m = m0 + 16 * i + fr, n = n0 + 16 * j;
+            if (m >= M) continue;
+            const float4 v = make_float4((acc[i][j][0] + eb.x) + pk[i][j].x, (acc[i][j][1] + eb.y) + pk[i][j].y,
+                                         (acc[i][j][2] + eb.z) + pk[i][j].z, (acc[i][j][3] + eb.w) + pk[i][j].w);
+            *reinterpret_cast<float4*>(p.pe + (long long)m * C + n) = v;
+            *reinterpret_cast<uint2*>(p.Xk + (long long)m * C + n) =
+                make_uint2(pack_bf16x2(v.x + f[i][j].x, v.y + f[i][j].y), pack_bf16x2(v.z + f[i][j].z, v.w + f[i][j].w));
         }
     }
 }

@@ -23,16 +23,10 @@ union Frag { uint4 u; mfma_bf16x8 v; };
 __global__ __launch_bounds__(256, 2) void roi_conv_pool_kernel(const unsigned short* __restrict__ feat, const unsigned short* __restrict__ W,
                                                                const float* __restrict__ bias, float* __restrict__ out, int ld_out, int R) {
     __shared__ __attribute__((aligned(16))) unsigned char xs[(CELLS + 1) * C * 2];       // rows 0..48 + a zero row (49)
+    __shared__ float bs[C];
     const int roi = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-    // ---- stage the RoI: 16-byte chunks, chunk c of row r at slot c ^ (r & 15)
-    for (int c = tid; c < (CELLS + 1) * 32; c += 256) {
-        const int row = c >> 5, slot = c & 31;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (row < CELLS) v = *reinterpret_cast<const uint4*>(feat + ((long long)roi * CELLS + row) * C + slot * 8);
-        *reinterpret_cast<uint4*>(xs + row * (C * 2) + ((slot ^ (row & 15)) << 4)) = v;
-    }
-    // ---- weight fragments of this wave's 64 output columns, 4-deep ring over the 72 k-steps
+    // ---- weight fragments of this wave's 64 output columns, 4-deep ring over the 72 k-steps (requested first: in flight while the RoI is staged)
     // fragment-major weights: fragment (k-step ks, column tile jt) = 64 lanes x 16 B at ((ks * 16 + jt) * 64 + lane) * 8
     const unsigned short* w_src = W + ((long long)(wave * 4) * 64 + lane) * 8;
     constexpr int KS_STRIDE = 16 * 64 * 8, JT_STRIDE = 64 * 8;
@@ -41,6 +35,26 @@ __global__ __launch_bounds__(256, 2) void roi_conv_pool_kernel(const unsigned sh
     for (int p = 0; p < 3; ++p)
 #pragma unroll
         for (int j = 0; j < 4; ++j) wq[p][j].u = *reinterpret_cast<const uint4*>(w_src + p * KS_STRIDE + j * JT_STRIDE);
+    // ---- stage the RoI: 16-byte chunks, chunk c of row r at slot c ^ (r & 15).  All loads of a thread are issued before the first
+    // LDS write (a rolled loop is one exposed memory round trip per iteration: 7 of them were a fifth of the block's time).
+    {
+        constexpr int NST = ((CELLS + 1) * 32 + 255) / 256;
+        uint4 st[NST];
+        float bv = 0.f;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int c = tid + 256 * i, row = c >> 5, slot = c & 31;
+            st[i] = *reinterpret_cast<const uint4*>(feat + ((long long)roi * CELLS + min(row, CELLS - 1)) * C + slot * 8);   // branch-free
+            if (row >= CELLS) st[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        bv = bias[tid];
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int c = tid + 256 * i, row = c >> 5, slot = c & 31;
+            if (row <= CELLS) *reinterpret_cast<uint4*>(xs + row * (C * 2) + ((slot ^ (row & 15)) << 4)) = st[i];
+        }
+        bs[tid] = bv;                                    // the bias waits in LDS: a global load in the epilogue is another round trip
+    }
     // cell coordinates of the 4 row tiles of this lane (row = 16 i + fr)
     int cy[4], cx[4];
 #pragma unroll
@@ -79,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void roi_conv_pool_kernel(const unsigned sh
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = wave * 64 + 16 * j + fr;
-        const float b = bias[n];
+        const float b = bs[n];
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)

@@ -150,9 +150,14 @@ class HeadEngine:
         w['pe_wr'], w['pe_br'] = b16(c1('fpe.conv_reduce.weight')), g(pe + 'fpe.conv_reduce.bias')
         w['pe_we'], w['pe_be'] = b16(c1('fpe.conv_expand.weight')), g(pe + 'fpe.conv_expand.bias')
         # fragment-major copies for the fused PE kernel
-        w['pe_pack'] = dict(w1a=ops.pack_wfrag(w['pe_w1a']), b1a=w['pe_b1a'], w1b=ops.pack_wfrag(w['pe_w1b']), b1b=w['pe_b1b'],
-                            w2a=ops.pack_wfrag(w['pe_w2a']), b2a=w['pe_b2a'], w2b=ops.pack_wfrag(w['pe_w2b']), b2b=w['pe_b2b'],
-                            wr=ops.pack_wfrag(w['pe_wr']), br=w['pe_br'], we=ops.pack_wfrag(w['pe_we']), be=w['pe_be'])
+        # (one allocation, in the order the kernel streams them)
+        names = ('wr', 'we', 'w1a', 'w1b', 'w2a', 'w2b')
+        packs = [ops.pack_wfrag(w['pe_' + n]).view(-1) for n in names]
+        flat, off = torch.cat(packs), 0
+        w['pe_pack'] = dict(b1a=w['pe_b1a'], b1b=w['pe_b1b'], b2a=w['pe_b2a'], b2b=w['pe_b2b'], br=w['pe_br'], be=w['pe_be'], flat=flat)
+        for n, t in zip(names, packs):
+            w['pe_pack'][n] = flat[off:off + t.numel()]
+            off += t.numel()
         self.w = w
         for k in ('cls_w0', 'cls_w3', 'reg_w0', 'reg_w2'):                              # [L,256,256] -> fragment-major copies for heads_fused
             w[k + 'p'] = ops.pack_wfrag_f32(w[k])
