@@ -129,7 +129,8 @@ int mv2d_ffn_out_fused_x3(const float* parts, int n_parts, long long part_stride
  * tensor run through mv2d_pack_wfrag_f32 (static weights: one contiguous 1 KB per fragment load); the 10x256 output layers stay row-major. */
 int mv2d_pack_wfrag_f32(const float* W, float* Wp, int N, int K, int ldw, void* stream);   /* Wp[ceil(N/16)][K/16][64][4] <- W[N][ldw] */
 int mv2d_heads_fused(const float* outs, const float* const* cls_w, const float* const* reg_w, const float* ref, float* cls, float* reg,
-                     int M, int L, float eps, const float* pc_range, float dt, void* stream);
+                     int M, int L, float eps, const float* pc_range, float dt, const float* dt_rows /* optional [M]: per-row dt of a
+                     batch of samples, overrides dt */, void* stream);
 
 /* Fused FFN partial sums (mmcv FFN 256 -> hidden -> 256 of the decoder layer, configs/mv2d/exp/*:78-79):
  * slabs[s] = relu(X . W1[64s:64s+64]^T + b1[64s:64s+64]) . W2[:, 64s:64s+64]^T  for the hidden/64 slices s, exact fp32.
@@ -187,8 +188,15 @@ int mv2d_map_conv3x3(const void* in, const void* Wp, const float* bias, float* o
 
 /* ---- attention ---------------------------------------------------------------------------------------- */
 
+/* ---- batches of samples ---------------------------------------------------------------------------------
+ * The reference runs ONE sample (V views) per GPU and call (RH/mv2d_head.py asserts batch size 1).  Here several
+ * samples can share every launch: their views are numbered consecutively (view a belongs to sample a / V), their RoIs / queries are
+ * concatenated, and grp_start[n_samples + 1] holds the first query row of every sample.  Everything that couples queries or
+ * views (box correlation, self attention, top-k decode, result packing, velocity / dt) stays inside a sample, so a sample's
+ * result does not depend on what else is in the batch.  grp_start == NULL means one sample. */
+
 /* FlattenMHSelfAttention core (MU/petr_transformer.py:317-370): qkv [R,768] fp32 = in_proj(q|k|v) -> ctx [R,256]. */
-int mv2d_self_attn_fwd(const float* qkv, float* ctx, int R, void* stream);
+int mv2d_self_attn_fwd(const float* qkv, float* ctx, int R, const int* grp_start, int n_samples, void* stream);
 
 /* PETRMultiheadAttention core (MU/petr_transformer.py:426-513) over the allowed (query,key) pairs only.
  * q [R,256] fp32 pre-scaled by 1/sqrt(32); K,V [S,256] bf16; CSR row_ptr[R+1], col_idx[nnz] (key indices);
@@ -226,8 +234,9 @@ int mv2d_roi_align(const float* map0, const float* map1, const float* rois, void
                    const int* map1_index, int out1_is_sum, void* stream);
 
 /* BoxCorrelation.epipolar_in_box, 'topk_matched:k:thr:ratio' (RH/utils/box_correlation.py:196-398).
- * view_start[V+1]: first RoI of each view; trans [V,V,16] fp64 = lidar2img[b] @ inv(lidar2img[a]);
- * lin[sample_size] = linspace(0,1); depths[num_depth] (LID); match [R,V,topk] int32: RoI id or -1, rank order. */
+ * V = views per sample; view_start[n_views+1]: first RoI of each view; trans [n_views,V,16] fp64 = lidar2img[b] @ inv(lidar2img[a])
+ * for source view a (global index) and destination view b of the same sample (local index);
+ * lin[sample_size] = linspace(0,1); depths[num_depth] (LID); match [R,V,topk] int32: (global) RoI id or -1, rank order. */
 int mv2d_box_correlation(const float* rois, const int* view_start, const double* trans, const float* lin, const float* depths,
                          int* match, int R, int V, int sample_size, int num_depth, int topk, int pad_h, int pad_w,
                          float depth_start, float iou_thr, float ratio, int max_per_view, void* stream);
@@ -241,7 +250,7 @@ long long mv2d_csr_workspace_bytes(int R, int V, int h, int w);
 int mv2d_mask_compact(const float* rois, const int* match, const unsigned char* pad_mask, unsigned char* roi_mask, int* rect,
                       int* pos2s, int* s2pos, int* S_out, unsigned int* bits_ws, int* row_count, int* row_ptr, int* col_idx,
                       int* nnz_out, int col_cap, int R, int V, int h, int w, int topk, float stride, float expand_stride,
-                      void* stream);
+                      int n_samples /* maps of n_samples * V views; V = views per sample */, void* stream);
 
 /* mark + scan only: compact list of the map positions inside any RoI rect expanded by expand_stride cells
  * (S-path: the positions RoIAlign can touch, so that PE is evaluated only there). */
@@ -260,16 +269,20 @@ int mv2d_pe_inputs(const int* s2pos, const int* S_dev, int S_max, const float* f
 
 /* NMSFreeCoder.decode_single + get_bboxes (CB/coders/nms_free_coder.py:49-102, CB/util.py:60-87,
  * RH/bbox_heads/cross_attention_head.py:357-377): top-k over R*num_classes logits, denormalise, centre-range filter.
- * out: boxes [<=max_num,9], scores, labels (int64), bbox_index (int64), *count_out. */
+ * out: boxes [<=max_num,9], scores, labels (int64), bbox_index (int64), *count_out.
+ * A batch (grp_start != NULL): one top-k per sample, outputs [n_samples][max_num], count_out [n_samples], bbox_index relative to
+ * the sample's first row; max_grp_rows = rows of the largest sample. */
 int mv2d_decode_topk(const float* cls, const float* reg, int R, int num_classes, int max_num, const float* post_center_range,
                      float* boxes, float* scores, long long* labels, long long* bbox_index, int* count_out,
-                     long long* topk_index_dbg, void* stream);
+                     long long* topk_index_dbg, const int* grp_start, int n_samples, int max_grp_rows, void* stream);
 
 /* "next" row f1 — the caller's post-decoder step (mmdet3d_plugin/models/detectors/mv2d.py:265-287): mmdet3d
  * box3d_multiclass_nms(score_thr, nms_thr = 1.0 => no suppression, max_num) + result ordering: class-major, score-descending
  * (global score order only when more than max_num boxes survive).  in: boxes [n,9], scores [n], labels [n] int64, *count = n (<= 1024). */
 int mv2d_result_pack(const float* boxes, const float* scores, const long long* labels, const int* count, float score_thr, int max_num,
-                     float* out_boxes, float* out_scores, long long* out_labels, int* out_count, void* stream);
+                     float* out_boxes, float* out_scores, long long* out_labels, int* out_count,
+                     int n_samples /* inputs [n_samples][in_stride], count [n_samples]; outputs [n_samples][max_num] */, int in_stride,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,7 @@ SIGNATURES = {
     'mv2d_ffn_out_fused_x3': (I, [P, I, LL, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, F, P]),
     'mv2d_attn_out_fused_x3': (I, [P, P, P, P, P, P, P, P, P, P, P, P, F, P, I, F, P]),
     'mv2d_pack_wfrag_f32': (I, [P, P, I, I, I, P]),
-    'mv2d_heads_fused': (I, [P, P, P, P, P, P, I, I, F, P, F, P]),
+    'mv2d_heads_fused': (I, [P, P, P, P, P, P, I, I, F, P, F, P, P]),
     'mv2d_ffn_fused': (I, [P, P, P, P, P, I, I, P]),
     'mv2d_ffn_pack_weights': (I, [P, P, P, P, I, P]),
     'mv2d_ffn_fused_x3': (I, [P, P, P, P, P, P, P, I, I, P]),
@@ -47,7 +47,7 @@ SIGNATURES = {
     'mv2d_nchw_to_nhwc': (I, [P, P, I, I, I, P]),
     'mv2d_nchw_to_nhwc_bf16': (I, [P, P, I, I, I, P]),
     'mv2d_map_conv3x3': (I, [P, P, P, P, I, I, I, P]),
-    'mv2d_self_attn_fwd': (I, [P, P, I, P]),
+    'mv2d_self_attn_fwd': (I, [P, P, I, P, I, P]),
     'mv2d_sparse_xattn_fwd': (I, [P, P, P, P, P, P, P, LL, I, I, P]),
     'mv2d_box_params': (I, [P, P, P, P, P, I, P, I, F, F, F, P]),
     'mv2d_refpoint_posemb': (I, [P, I, P, P, P, P, P, I, P, P]),
@@ -56,12 +56,12 @@ SIGNATURES = {
     'mv2d_roi_align': (I, [P, P, P, P, P, P, P, I, I, I, I, F, I, P, I, P]),
     'mv2d_box_correlation': (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, F, F, F, I, P]),
     'mv2d_csr_workspace_bytes': (LL, [I, I, I, I]),
-    'mv2d_mask_compact': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, P]),
+    'mv2d_mask_compact': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, I, P]),
     'mv2d_roi_positions': (I, [P, P, P, P, P, P, P, I, I, I, I, F, F, P]),
     'mv2d_csr_from_corr': (I, [P, P, P, P, I, I, I, P]),
     'mv2d_pe_inputs': (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
-    'mv2d_result_pack': (I, [P, P, P, P, F, I, P, P, P, P, P]),
-    'mv2d_decode_topk': (I, [P, P, I, I, I, P, P, P, P, P, P, P, P]),
+    'mv2d_result_pack': (I, [P, P, P, P, F, I, P, P, P, P, I, I, P]),
+    'mv2d_decode_topk': (I, [P, P, I, I, I, P, P, P, P, P, P, P, P, I, I, P]),
 }
 
 _lib = None

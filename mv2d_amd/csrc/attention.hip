@@ -35,10 +35,25 @@ __device__ __forceinline__ void load_kv(KVFrag& f, const float* __restrict__ qkv
     }
 }
 
-__global__ __launch_bounds__(256) void self_attn_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int R, float scale) {
+// Several samples in one launch (grp_start[n_grp + 1] = first query row of every sample): attention stays inside a sample, and the
+// query / key tiles are counted from the sample's first row, so a sample's result does not depend on what else is in the batch.
+__global__ __launch_bounds__(256) void self_attn_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int R, float scale,
+                                                        const int* __restrict__ grp_start, int n_grp) {
     __shared__ float sm[4][16], sl[4][16], so[4][32][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-    const int q0 = blockIdx.x * 16, h = blockIdx.y;
+    int tile = blockIdx.x;
+    if (grp_start) {
+        int g = 0, gs = 0, ge = 0;
+        for (; g < n_grp; ++g) {
+            gs = grp_start[g]; ge = grp_start[g + 1];
+            const int nt = (ge - gs + 15) >> 4;
+            if (tile < nt) break;
+            tile -= nt;
+        }
+        if (g == n_grp) return;
+        qkv += (long long)gs * 768; ctx += (long long)gs * C; R = ge - gs;
+    } else if (tile * 16 >= R) return;
+    const int q0 = tile * 16, h = blockIdx.y;
     const int qrow = min(q0 + fr, R - 1);
     const float* qp = qkv + (long long)qrow * 768 + h * HD + 4 * fg;
     const float4 qa = *reinterpret_cast<const float4*>(qp);
@@ -220,11 +235,12 @@ __global__ __launch_bounds__(64 * NW) void sparse_xattn_kernel(const float* __re
 
 }  // namespace
 
-extern "C" int mv2d_self_attn_fwd(const float* qkv, float* ctx, int R, void* stream) {
-    MV2D_CHECK_ARG(qkv && ctx && R >= 0, "mv2d_self_attn_fwd: bad args");
+extern "C" int mv2d_self_attn_fwd(const float* qkv, float* ctx, int R, const int* grp_start, int n_grp, void* stream) {
+    MV2D_CHECK_ARG(qkv && ctx && R >= 0 && (!grp_start || n_grp >= 1), "mv2d_self_attn_fwd: bad args");
     if (R == 0) return MV2D_OK;
-    hipLaunchKernelGGL(self_attn_kernel, dim3(cdiv(R, 16), HEADS), dim3(256), 0, (hipStream_t)stream, qkv, ctx, R,
-                       1.0f / sqrtf((float)HD));
+    const int tiles = grp_start ? cdiv(R, 16) + n_grp - 1 : cdiv(R, 16);       // upper bound of sum_g ceil(R_g / 16)
+    hipLaunchKernelGGL(self_attn_kernel, dim3(tiles, HEADS), dim3(256), 0, (hipStream_t)stream, qkv, ctx, R,
+                       1.0f / sqrtf((float)HD), grp_start, n_grp);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

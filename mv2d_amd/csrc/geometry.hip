@@ -201,8 +201,9 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------------------------------------
 // a9: epipolar box correlation (RH/utils/box_correlation.py:196-398, 'topk_matched:k:thr:ratio').
-//     One block per (RoI r, destination view b).  fp64 projection, fp32 compares, integer outputs.
-//     match[r][b][rank] = global RoI id or -1
+//     One block per (RoI r, destination view b of r's sample).  fp64 projection, fp32 compares, integer outputs.
+//     match[r][b][rank] = global RoI id or -1.  V = views per sample; a batch of samples numbers its views consecutively
+//     (view a belongs to sample a / V), correlation stays inside a sample, trans is [all views][V][16].
 // ------------------------------------------------------------------------------------------------
 constexpr int MAX_PER_VIEW = 1024;
 
@@ -215,11 +216,12 @@ __global__ __launch_bounds__(128) void box_corr_kernel(const float* __restrict__
     __shared__ float siou[MAX_PER_VIEW];
     __shared__ float red[4][2];
     __shared__ int flag[2];
-    const int r = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    int* out = match + ((long long)r * V + b) * topk;
+    const int r = blockIdx.x, bl = blockIdx.y, tid = threadIdx.x;
+    int* out = match + ((long long)r * V + bl) * topk;
     for (int i = tid; i < topk; i += 128) out[i] = -1;
     const float* rb = rois + r * 5;
     const int a = (int)rb[0];
+    const int b = (a / V) * V + bl;                        // destination view (global index)
     const int start = view_start[b], nb = view_start[b + 1] - start;
     if (a == b || nb == 0) return;
     if (tid < 2) flag[tid] = 0;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(128) void box_corr_kernel(const float* __restrict__
         const float x = rb[1] + wbox * lin[ix], y = rb[2] + hbox * lin[iy];
         const double d = (double)depths[dk];
         const double hx = (double)x * d, hy = (double)y * d;
-        const double* T = trans + ((long long)a * V + b) * 16;
+        const double* T = trans + ((long long)a * V + bl) * 16;
         double cam[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -406,12 +408,14 @@ __global__ __launch_bounds__(1024) void csr_scan_positions_kernel(const unsigned
 
 // per query: OR the rects of (self + matched RoIs) into an LDS bitmask over P cells, drop cells that are not
 // in the key list (padding), write the bitmask and the row count.
+// (a batch of samples: the keys of a query lie in its own sample's Pg = V*h*w cells, so the bitmask only covers the 32-cell words
+//  [w0, w0 + nwords) that overlap them, w0 = sample * Pg / 32)
 __global__ __launch_bounds__(256) void csr_count_kernel(const int* __restrict__ rect, const int* __restrict__ match, const int* __restrict__ pos2s,
-                                                        unsigned int* __restrict__ bits, int* __restrict__ row_count, int h, int w, int V, int topk, int P) {
+                                                        unsigned int* __restrict__ bits, int* __restrict__ row_count, int h, int w, int V, int topk, int nwords) {
     extern __shared__ unsigned int sb[];
     __shared__ int cnt;
     const int r = blockIdx.x, tid = threadIdx.x;
-    const int nwords = (P + 31) / 32;
+    const int w0 = (int)(((long long)(rect[r * 5] / V) * V * h * w) >> 5);
     for (int i = tid; i < nwords; i += 256) sb[i] = 0u;
     if (tid == 0) cnt = 0;
     __syncthreads();
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(256) void csr_count_kernel(const int* __restrict__ 
         const int nw = x1 - x0 + 1, n = (y1 - y0 + 1) * nw;
         for (int i = tid; i < n; i += 256) {
             const int pos = (v * h + y0 + i / nw) * w + x0 + i % nw;
-            if (pos2s[pos] >= 0) atomicOr(&sb[pos >> 5], 1u << (pos & 31));
+            if (pos2s[pos] >= 0) atomicOr(&sb[(pos >> 5) - w0], 1u << (pos & 31));
         }
     }
     __syncthreads();
@@ -438,8 +442,8 @@ __global__ __launch_bounds__(256) void csr_count_kernel(const int* __restrict__ 
 
 // per query: row_ptr[r] = sum(row_count[0..r)), then expand the bitmask into ascending key indices.
 __global__ __launch_bounds__(256) void csr_fill_kernel(const unsigned int* __restrict__ bits, const int* __restrict__ row_count, const int* __restrict__ pos2s,
-                                                       int* __restrict__ row_ptr, int* __restrict__ col_idx, int* __restrict__ nnz_out, int R, int P,
-                                                       int col_cap) {
+                                                       const int* __restrict__ rect, int* __restrict__ row_ptr, int* __restrict__ col_idx,
+                                                       int* __restrict__ nnz_out, int R, int nwords, int cells_per_sample, int V, int col_cap) {
     __shared__ int sbase;
     __shared__ int wsum[4];
     __shared__ int carry;
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const unsigned int* __res
         if (r == R - 1) { row_ptr[R] = base + row_count[r]; nnz_out[0] = base + row_count[r]; }
         if (base + row_count[r] > col_cap) nnz_out[1] = 1;          // overflow flag: col_idx capacity exceeded
     }
-    const int nwords = (P + 31) / 32;
+    const int wbase = (int)(((long long)(rect[r * 5] / V) * cells_per_sample) >> 5);
     for (int w0 = 0; w0 < nwords; w0 += 256) {
         const int wi = w0 + tid;
         const unsigned int x = wi < nwords ? bits[(long long)r * nwords + wi] : 0u;
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const unsigned int* __res
         while (y) {
             const int bit = __ffs(y) - 1;
             y &= y - 1;
-            if (base + off < col_cap) col_idx[base + off] = pos2s[wi * 32 + bit];
+            if (base + off < col_cap) col_idx[base + off] = pos2s[(wbase + wi) * 32 + bit];
             ++off;
         }
         __syncthreads();
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(const float* __restri
                                                            int npow2, float r0, float r1, float r2, float r3, float r4, float r5,
                                                            float* __restrict__ boxes, float* __restrict__ scores, long long* __restrict__ labels,
                                                            long long* __restrict__ bbox_index, int* __restrict__ count_out,
-                                                           long long* __restrict__ topk_index_dbg) {
+                                                           long long* __restrict__ topk_index_dbg, const int* __restrict__ grp_start) {
     // keys: 64-bit (monotone logit bits << 32 | ~index) -> all distinct, "larger" = higher logit, then LOWER index.
     // 1) 8 rounds of 8-bit radix select find the K-th largest key; 2) the K survivors are ranked by counting
     //    (K^2 compares spread over 1024 threads) — no full sort of the R*ncls candidates.
@@ -587,6 +591,15 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(const float* __restri
     __shared__ unsigned long long prefix_s;
     __shared__ int want_s, nsel;
     __shared__ int kept_off[1025];
+    // one block per sample of the batch: rows [grp_start[g], grp_start[g+1]), outputs [g][max_num] (bbox_index relative to the sample)
+    if (grp_start) {
+        const int g = blockIdx.x, gs = grp_start[g];
+        R = grp_start[g + 1] - gs;
+        cls += (long long)gs * ncls; reg += (long long)gs * 10;
+        boxes += (long long)g * max_num * 9; scores += (long long)g * max_num; labels += (long long)g * max_num;
+        bbox_index += (long long)g * max_num; count_out += g;
+        if (topk_index_dbg) topk_index_dbg += (long long)g * max_num;
+    }
     const int tid = threadIdx.x, n = R * ncls;
     const int K = min(max_num, n);
     unsigned long long* sel = keys + npow2;
@@ -691,10 +704,16 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void result_pack_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, const long long* __restrict__ labels,
                                                            const int* __restrict__ count, float score_thr, int max_num, float* __restrict__ out_boxes,
-                                                           float* __restrict__ out_scores, long long* __restrict__ out_labels, int* __restrict__ out_count) {
+                                                           float* __restrict__ out_scores, long long* __restrict__ out_labels, int* __restrict__ out_count,
+                                                           int in_stride) {
     __shared__ float ss[1024];
     __shared__ int sl[1024];
     __shared__ int nkeep;
+    {   // one block per sample of the batch
+        const long long g = blockIdx.x;
+        boxes += g * in_stride * 9; scores += g * in_stride; labels += g * in_stride; count += g;
+        out_boxes += g * max_num * 9; out_scores += g * max_num; out_labels += g * max_num; out_count += g;
+    }
     const int tid = threadIdx.x, n = min(*count, 1024);
     const bool have = tid < n;
     const float sc = have ? scores[tid] : 0.f;
@@ -795,26 +814,29 @@ extern "C" int mv2d_box_correlation(const float* rois, const int* view_start, co
     return MV2D_OK;
 }
 
+// words of the per-query key bitmask: the cells of one sample (V views) plus one word of slack for a window that starts mid-word
+static inline int csr_words(int V, int h, int w) { return (V * h * w + 31) / 32 + 1; }
+
 extern "C" long long mv2d_csr_workspace_bytes(int R, int V, int h, int w) {
-    const long long P = (long long)V * h * w;
-    return (long long)R * ((P + 31) / 32) * 4;
+    return (long long)R * csr_words(V, h, w) * 4;
 }
 
 // T-path: roi_mask must be zeroed by the caller (hipMemsetAsync) before this call.
 extern "C" int mv2d_mask_compact(const float* rois, const int* match, const unsigned char* pad_mask, unsigned char* roi_mask,
                                  int* rect, int* pos2s, int* s2pos, int* S_out, unsigned int* bits_ws, int* row_count, int* row_ptr,
                                  int* col_idx, int* nnz_out, int col_cap, int R, int V, int h, int w, int topk, float stride,
-                                 float expand_stride, void* stream) {
+                                 float expand_stride, int n_samples, void* stream) {
     MV2D_CHECK_ARG(rois && match && pad_mask && roi_mask && rect && pos2s && s2pos && S_out && bits_ws && row_count && row_ptr &&
                        col_idx && nnz_out, "mv2d_mask_compact: null pointer");
-    MV2D_CHECK_ARG(R > 0, "mv2d_mask_compact: R must be > 0");
-    const int P = V * h * w;
+    MV2D_CHECK_ARG(R > 0 && n_samples >= 1, "mv2d_mask_compact: R and n_samples must be > 0");
+    const int P = n_samples * V * h * w;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(csr_mark_kernel, dim3(R), dim3(64), 0, st, rois, rect, roi_mask, h, w, stride, expand_stride);
     hipLaunchKernelGGL(csr_scan_positions_kernel, dim3(1), dim3(1024), 0, st, roi_mask, pad_mask, pos2s, s2pos, S_out, P);
-    const int nwords = (P + 31) / 32;
-    hipLaunchKernelGGL(csr_count_kernel, dim3(R), dim3(256), nwords * 4, st, rect, match, pos2s, bits_ws, row_count, h, w, V, topk, P);
-    hipLaunchKernelGGL(csr_fill_kernel, dim3(R), dim3(256), 0, st, bits_ws, row_count, pos2s, row_ptr, col_idx, nnz_out, R, P, col_cap);
+    const int nwords = csr_words(V, h, w);
+    hipLaunchKernelGGL(csr_count_kernel, dim3(R), dim3(256), nwords * 4, st, rect, match, pos2s, bits_ws, row_count, h, w, V, topk, nwords);
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(R), dim3(256), 0, st, bits_ws, row_count, pos2s, rect, row_ptr, col_idx, nnz_out, R, nwords,
+                       V * h * w, V, col_cap);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
@@ -855,22 +877,24 @@ extern "C" int mv2d_pe_inputs(const int* s2pos, const int* S_dev, int S_max, con
 }
 
 extern "C" int mv2d_result_pack(const float* boxes, const float* scores, const long long* labels, const int* count, float score_thr, int max_num,
-                                float* out_boxes, float* out_scores, long long* out_labels, int* out_count, void* stream) {
+                                float* out_boxes, float* out_scores, long long* out_labels, int* out_count, int n_samples, int in_stride,
+                                void* stream) {
     MV2D_CHECK_ARG(boxes && scores && labels && count && out_boxes && out_scores && out_labels && out_count, "mv2d_result_pack: null pointer");
-    MV2D_CHECK_ARG(max_num >= 1 && max_num <= 1024, "mv2d_result_pack: max_num must be in [1, 1024]");
-    hipLaunchKernelGGL(result_pack_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, boxes, scores, labels, count, score_thr, max_num,
-                       out_boxes, out_scores, out_labels, out_count);
+    MV2D_CHECK_ARG(max_num >= 1 && max_num <= 1024 && n_samples >= 1, "mv2d_result_pack: max_num must be in [1, 1024], n_samples >= 1");
+    hipLaunchKernelGGL(result_pack_kernel, dim3(n_samples), dim3(1024), 0, (hipStream_t)stream, boxes, scores, labels, count, score_thr, max_num,
+                       out_boxes, out_scores, out_labels, out_count, in_stride);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
 
 extern "C" int mv2d_decode_topk(const float* cls, const float* reg, int R, int num_classes, int max_num, const float* post_center_range,
                                 float* boxes, float* scores, long long* labels, long long* bbox_index, int* count_out,
-                                long long* topk_index_dbg, void* stream) {
+                                long long* topk_index_dbg, const int* grp_start, int n_grp, int max_grp_rows, void* stream) {
     MV2D_CHECK_ARG(cls && reg && post_center_range && boxes && scores && labels && bbox_index && count_out, "mv2d_decode_topk: null pointer");
     MV2D_CHECK_ARG(max_num >= 1 && max_num <= 1024, "mv2d_decode_topk: max_num must be in [1, 1024]");
-    const int n = R * num_classes;
-    MV2D_CHECK_ARG(n > 0 && n <= 16384, "mv2d_decode_topk: R*num_classes must be in [1, 16384]");
+    MV2D_CHECK_ARG(!grp_start || (n_grp >= 1 && max_grp_rows >= 1 && max_grp_rows <= R), "mv2d_decode_topk: bad sample list");
+    const int n = (grp_start ? max_grp_rows : R) * num_classes;
+    MV2D_CHECK_ARG(n > 0 && n <= 16384, "mv2d_decode_topk: rows (of one sample) * num_classes must be in [1, 16384]");
     int npow2 = 1024;
     while (npow2 < n) npow2 <<= 1;
     const size_t lds = (size_t)(npow2 + 1024) * 8;
@@ -879,9 +903,9 @@ extern "C" int mv2d_decode_topk(const float* cls, const float* reg, int R, int n
         hipFuncSetAttribute((const void*)decode_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (16384 + 1024) * 8);
         attr_set = true;
     }
-    hipLaunchKernelGGL(decode_topk_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, cls, reg, R, num_classes, max_num, npow2,
+    hipLaunchKernelGGL(decode_topk_kernel, dim3(grp_start ? n_grp : 1), dim3(1024), lds, (hipStream_t)stream, cls, reg, R, num_classes, max_num, npow2,
                        post_center_range[0], post_center_range[1], post_center_range[2], post_center_range[3], post_center_range[4],
-                       post_center_range[5], boxes, scores, labels, bbox_index, count_out, topk_index_dbg);
+                       post_center_range[5], boxes, scores, labels, bbox_index, count_out, topk_index_dbg, grp_start);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -695,6 +695,7 @@ struct HeadsParams {
     const float* ref;             // [M,3]
     float* cls; float* reg;       // [L, M, 10]
     int M, L; float eps; float pc0, pc1, pc2, pd0, pd1, pd2, dt;
+    const float* dt_rows;         // optional [M]: per-row time step (a batch of samples), overrides dt
 };
 
 __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p) {
@@ -748,8 +749,9 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p) {
                 const float is = logf(fmaxf(x, 1e-5f) / fmaxf(1.f - x, 1e-5f));
                 const float s = 1.f / (1.f + expf(-(v + is)));
                 v = fr == 0 ? s * p.pd0 + p.pc0 : (fr == 1 ? s * p.pd1 + p.pc1 : s * p.pd2 + p.pc2);
-            } else if (fr >= 8 && p.dt != 0.f) {
-                v = v / p.dt;
+            } else if (fr >= 8) {
+                const float dt = p.dt_rows ? p.dt_rows[m] : p.dt;
+                if (dt != 0.f) v = v / dt;
             }
         }
         outp[((long long)l * p.M + m) * 10 + fr] = v;
@@ -847,7 +849,7 @@ extern "C" int mv2d_ffn_out_fused_x3(const float* parts, int n_parts, long long 
 }
 
 extern "C" int mv2d_heads_fused(const float* outs, const float* const* cls_w, const float* const* reg_w, const float* ref, float* cls, float* reg,
-                                int M, int L, float eps, const float* pc_range, float dt, void* stream) {
+                                int M, int L, float eps, const float* pc_range, float dt, const float* dt_rows, void* stream) {
     // cls_w: {w0,b0,lnw1,lnb1,w3,b3,lnw4,lnb4,w6,b6} device pointers (each stacked over L layers); reg_w: {w0,b0,w2,b2,w4,b4}
     MV2D_CHECK_ARG(outs && cls_w && reg_w && ref && cls && reg && pc_range && L > 0, "mv2d_heads_fused: null pointer");
     for (int i = 0; i < 10; ++i) MV2D_CHECK_ARG(cls_w[i] != nullptr, "mv2d_heads_fused: null cls weight");
@@ -855,7 +857,7 @@ extern "C" int mv2d_heads_fused(const float* outs, const float* const* cls_w, co
     if (M == 0) return MV2D_OK;
     HeadsParams p{outs, cls_w[0], cls_w[1], cls_w[2], cls_w[3], cls_w[4], cls_w[5], cls_w[6], cls_w[7], cls_w[8], cls_w[9],
                   reg_w[0], reg_w[1], reg_w[2], reg_w[3], reg_w[4], reg_w[5], ref, cls, reg, M, L, eps,
-                  pc_range[0], pc_range[1], pc_range[2], pc_range[3] - pc_range[0], pc_range[4] - pc_range[1], pc_range[5] - pc_range[2], dt};
+                  pc_range[0], pc_range[1], pc_range[2], pc_range[3] - pc_range[0], pc_range[4] - pc_range[1], pc_range[5] - pc_range[2], dt, dt_rows};
     hipLaunchKernelGGL(heads_fused_kernel, dim3(cdiv(M, 16), L, 2), dim3(256), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;

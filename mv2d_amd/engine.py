@@ -65,6 +65,7 @@ class HeadEngine:
         self.const = {k: v.to(self.dev) for k, v in calib.constant_tables().items()}
         self._ws = {}
         self._ws_base = {}
+        self._tab_cache = {}
         self.prof = None              # dict name -> [events] when stage timing is on (bench.py)
         self.fork_qg = True           # T path: query-generator chain on a second stream
         self.ffn_x3 = os.environ.get('MV2D_FFN_X3', '1') == '1'   # FFN in bf16x3 split precision (fragment-major hi/lo weights); 0: exact fp32
@@ -165,17 +166,18 @@ class HeadEngine:
         self.reg_ptrs = ops.make_ptr_array([w[k] for k in ('reg_w0p', 'reg_b0', 'reg_w2p', 'reg_b2', 'reg_w4', 'reg_b4')])
 
     # ------------------------------------------------------------------------------------------ workspace
-    def _workspace(self, V, h, w, R):
+    def _workspace(self, V, h, w, R, Vg=None):
         """Buffers of one (map shape, R) problem.  The number of RoIs changes from frame to frame in real use, so the STORAGE is
         allocated once per (map shape, R rounded up to a multiple of 64) and every exact R only gets a dict of dense views into it
         (kernels index [*, R, *] tensors densely) plus its own hipGraph; staging buffers, calibration cache and the stream-order
         guard are shared by all R of a bucket."""
-        key = (V, h, w, R)
+        Vg = V if Vg is None else Vg                     # views per sample; V = all views of the batch
+        key = (V, h, w, R, Vg)
         ws = self._ws.get(key)
         if ws is not None:
             return ws
         cap = max(64, -(-R // 64) * 64)
-        bkey = (V, h, w, cap)
+        bkey = (V, h, w, cap, Vg)
         base = self._ws_base.get(bkey)
         if base is None:
             store = []
@@ -187,7 +189,7 @@ class HeadEngine:
                     t = t.pin_memory()
                 store.append(t)
                 return t
-            self._build_ws(V, h, w, cap, alloc)
+            self._build_ws(V, h, w, cap, alloc, Vg)
             base = self._ws_base[bkey] = dict(store=store, shared={})
         it = iter(base['store'])
 
@@ -199,21 +201,22 @@ class HeadEngine:
             t = next(it)
             assert t.dtype == dt and t.numel() >= n
             return t.view(-1)[:n].view(shape)
-        ws = self._build_ws(V, h, w, R, view)
+        ws = self._build_ws(V, h, w, R, view, Vg)
         ws['shared'] = base['shared']
         self._ws[key] = ws
         return ws
 
-    def _build_ws(self, V, h, w, R, alloc):
+    def _build_ws(self, V, h, w, R, alloc, Vg):
         d, L = self.dev, self.L
         P = V * h * w
+        B = V // Vg                                      # samples sharing every launch
         e = lambda shape, dt=F32: alloc(shape, dt)
         z = lambda shape, dt=F32: alloc(shape, dt, zero=True)
-        ws = dict(P=P)
+        ws = dict(P=P, B=B, Vg=Vg)
         # calibration blob layout (fp64 tables first, then fp32, then bytes)
         lay, off = {}, 0
         for name, n, dt in [('viewK', V * 16, torch.float64), ('viewE', V * 16, torch.float64), ('img2lidar', V * 16, torch.float64),
-                            ('trans', V * V * 16, torch.float64), ('coords_w', w, torch.float64), ('coords_h', h, torch.float64),
+                            ('trans', V * Vg * 16, torch.float64), ('coords_w', w, torch.float64), ('coords_h', h, torch.float64),
                             ('coords_d', self.depth_num, torch.float64), ('embeds', 3 * P, F32), ('pad_mask', P, torch.uint8)]:
             sz = n * torch.empty(0, dtype=dt).element_size()
             lay[name] = (off, n, dt)
@@ -222,20 +225,23 @@ class HeadEngine:
         ws['blob_h'] = alloc(off, torch.uint8, pinned=True)
         ws['blob_d'] = e(off, torch.uint8)
         ws['tab'] = {k: ws['blob_d'][o:o + n * torch.empty(0, dtype=dt).element_size()].view(dt) for k, (o, n, dt) in lay.items()}
-        # per-frame dynamic inputs: RoI list + per-view offsets, one pinned staging buffer -> one H2D copy
-        dyn_words = R * 5 + (V + 1)
+        # per-frame dynamic inputs: RoI list, per-view offsets, first query row of every sample, per-row time step (T path);
+        # one pinned staging buffer -> one H2D copy
+        o1, o2, o3 = R * 5, R * 5 + (V + 1), R * 5 + (V + 1) + (B + 1)
+        dyn_words = o3 + R
         ws['dyn_h'] = alloc(dyn_words, torch.int32, pinned=True)
         ws['dyn_d'] = e(dyn_words, torch.int32)
-        ws['rois_h'] = ws['dyn_h'][:R * 5].view(F32).view(R, 5)
-        ws['view_start_h'] = ws['dyn_h'][R * 5:]
-        ws['rois'] = ws['dyn_d'][:R * 5].view(F32).view(R, 5)
-        ws['view_start'] = ws['dyn_d'][R * 5:]
+        for sfx, buf in (('_h', ws['dyn_h']), ('', ws['dyn_d'])):
+            ws['rois' + sfx] = buf[:o1].view(F32).view(R, 5)
+            ws['view_start' + sfx] = buf[o1:o2]
+            ws['grp_start' + sfx] = buf[o2:o3]
+            ws['dt_rows' + sfx] = buf[o3:].view(F32)
         ws['featcl'] = e((P, C))
         ws['enc'] = z((R, 1056)); ws['minv'] = e((R, 16))
         ws['roi_feat'] = e((R, 49, C), BF16)
         ws['enc1'] = e((R, 512)); ws['enc2'] = e((R, C)); ws['center'] = e((R, 3))
         ws['xyz'] = e((R, 3)); ws['ref'] = e((R, 3)); ws['posemb'] = e((R, 384)); ws['qe1'] = e((R, C)); ws['qpos'] = e((R, C))
-        ws['match'] = e((R, V, self.topk), torch.int32)
+        ws['match'] = e((R, Vg, self.topk), torch.int32)
         Pp = (P + 15) // 16 * 16
         ws['zbuf'] = z(Pp + 16, torch.uint8)                     # roi_mask | nnz[2]: cleared by ONE fill per frame
         ws['roi_mask'] = ws['zbuf'][:P]
@@ -245,12 +251,12 @@ class HeadEngine:
         ws['S_dev'] = z(1, torch.int32)
         ws['row_ptr'] = e(R + 1, torch.int32)
         if self.kind == 'T':
-            ws['bits'] = e(max(ops.csr_workspace_bytes(R, V, h, w) // 4, 1), torch.int32)
+            ws['bits'] = e(max(ops.csr_workspace_bytes(R, Vg, h, w) // 4, 1), torch.int32)
             ws['row_count'] = e(R, torch.int32)
             ws['col_cap'] = R * self.col_cap_per_query
             ws['S_kv'] = P
         else:
-            ws['col_cap'] = R * (1 + V * self.topk) * 49
+            ws['col_cap'] = R * (1 + Vg * self.topk) * 49
             ws['S_kv'] = R * 49
             ws['roi_sum'] = e((R, 49, C), BF16)
         ws['col_idx'] = e(ws['col_cap'], torch.int32)
@@ -265,14 +271,15 @@ class HeadEngine:
             ws[n] = e((R, C))
         ws['qkv'] = e((R, 3 * C)); ws['parts'] = e((2048 // 64, R, C)); ws['outs'] = e((L, R, C))
         ws['cls'] = e((L, R, 10)); ws['reg'] = e((L, R, 10))
-        ws['boxes'] = z((self.max_num, 9)); ws['scores'] = z(self.max_num)
-        ws['labels'] = z(self.max_num, torch.int64); ws['bbox_index'] = z(self.max_num, torch.int64); ws['count'] = z(1, torch.int32)
+        ws['boxes'] = z((B, self.max_num, 9)); ws['scores'] = z((B, self.max_num))
+        ws['labels'] = z((B, self.max_num), torch.int64); ws['bbox_index'] = z((B, self.max_num), torch.int64); ws['count'] = z(B, torch.int32)
         return ws
 
     # ------------------------------------------------------------------------------------------ host side
     @staticmethod
-    def _rois_host(proposals):
-        """bbox2roi (mmdet) + dummy proposal rule (RH/mv2d_head.py:105-108) on the host; returns (rois [R,5], counts)."""
+    def _rois_host(proposals, view0=0):
+        """bbox2roi (mmdet) + dummy proposal rule (RH/mv2d_head.py:105-108) on the host; returns (rois [R,5], counts).
+        view0: index of the sample's first view inside a batch of samples."""
         props = [p if torch.is_tensor(p) else torch.from_numpy(np.asarray(p)) for p in proposals]
         if sum(int(p.shape[0]) for p in props) == 0:
             props = [torch.tensor([[0, 50, 50, 100, 100, 0]], dtype=F32)] + list(props[1:])
@@ -281,7 +288,7 @@ class HeadEngine:
             counts.append(int(p.shape[0]))
             if p.shape[0] > 0:
                 pc = p.detach().to('cpu', F32)
-                rows.append(torch.cat([torch.full((pc.shape[0], 1), float(i)), pc[:, :4]], 1))
+                rows.append(torch.cat([torch.full((pc.shape[0], 1), float(view0 + i)), pc[:, :4]], 1))
         return torch.cat(rows, 0), counts
 
     # ------------------------------------------------------------------------------------------ forward
@@ -294,35 +301,66 @@ class HeadEngine:
             parts.append(repr((tuple(m['pad_shape']), tuple(m['img_shape']), float(m.get('timestamp', 0.0)))).encode())
         return hash(b''.join(parts))
 
-    def _host_prepare(self, proposals, img_metas, V, h, w):
-        """Host side of one frame: RoI list + calibration tables into the workspace's pinned staging buffers.
-        The calibration tables are pure functions of img_metas; they are rebuilt only when img_metas change."""
-        rois_h, counts = self._rois_host(proposals)
+    def _sample_tables(self, img_metas, h, w):
+        """calibration tables of one sample: pure functions of img_metas, cached by their content"""
+        key = self._frame_key(img_metas)
+        hit = self._tab_cache.get(key)
+        if hit is None:
+            hit = calib.frame_tables(img_metas, h, w, stride=self.stride, depth_num=self.depth_num,
+                                     position_range=tuple(self.post_range_h64.tolist()))
+            hit['dt'] = 0.0
+            if self.kind == 'T' and len(img_metas) > self.num_views:
+                ts = hit['timestamps']
+                hit['dt'] = float(ts[self.num_views:].mean() - ts[:self.num_views].mean())
+            if len(self._tab_cache) >= 64:
+                self._tab_cache.pop(next(iter(self._tab_cache)))
+            self._tab_cache[key] = hit
+        return key, hit
+
+    def _host_prepare(self, proposals_list, metas_list, V, h, w):
+        """Host side of one batch of samples: RoI lists + calibration tables into the workspace's pinned staging buffers.
+        The calibration tables are rebuilt / re-uploaded only when some sample's img_metas change."""
+        B = len(proposals_list)
+        Vg = V // B
+        rois_l, counts, grp = [], [], [0]
+        for b, (props, metas) in enumerate(zip(proposals_list, metas_list)):
+            assert len(props) == Vg and len(metas) == Vg, 'every sample of a batch needs the same number of views'
+            r, c = self._rois_host(props, b * Vg)
+            rois_l.append(r); counts += c; grp.append(grp[-1] + r.shape[0])
+        rois_h = torch.cat(rois_l, 0) if B > 1 else rois_l[0]
         R = rois_h.shape[0]
-        ws = self._workspace(V, h, w, R)
+        ws = self._workspace(V, h, w, R, Vg)
         sh = ws['shared']
         if 'done_ev' in sh:
             sh['done_ev'].synchronize()      # the previous frame on this workspace must have consumed the staging buffers
-        key = self._frame_key(img_metas)
+        tabs = [self._sample_tables(m, h, w) for m in metas_list]
+        key = tuple(k for k, _ in tabs)
+        fts = [t for _, t in tabs]
         if sh.get('frame_key') != key:
-            ft = calib.frame_tables(img_metas, h, w, stride=self.stride, depth_num=self.depth_num,
-                                    position_range=tuple(self.post_range_h64.tolist()))
+            f0 = fts[0]
+            assert all(t['pad_h'] == f0['pad_h'] and t['pad_w'] == f0['pad_w'] for t in fts), 'samples of a batch share one pad_shape'
             bh = ws['blob_h']
             for k, (o_, n, dt_) in ws['blob_layout'].items():
                 nb = n * torch.empty(0, dtype=dt_).element_size()
-                bh[o_:o_ + nb].view(dt_).copy_(ft[k].reshape(-1))
-            dt = 0.0
-            if self.kind == 'T' and len(img_metas) > self.num_views:
-                ts = ft['timestamps']
-                dt = float(ts[self.num_views:].mean() - ts[:self.num_views].mean())
-            sh['frame_key'], sh['frame_scalars'] = key, dict(pad_h=ft['pad_h'], pad_w=ft['pad_w'], dt=dt)
+                if k in ('coords_w', 'coords_h', 'coords_d'):
+                    src = f0[k]
+                elif k == 'embeds':
+                    src = torch.cat([t[k] for t in fts], 1) if B > 1 else f0[k]        # [3, P]: the samples side by side
+                else:
+                    src = torch.cat([t[k].reshape(-1) for t in fts]) if B > 1 else f0[k]
+                bh[o_:o_ + nb].view(dt_).copy_(src.reshape(-1))
+            sh['frame_key'], sh['frame_scalars'] = key, dict(pad_h=f0['pad_h'], pad_w=f0['pad_w'], dt=f0['dt'])
             # the calibration tables change only when img_metas change: upload them here (stream-ordered before the frame),
             # not once per frame
             ws['blob_d'].copy_(bh, non_blocking=True)
         ws['rois_h'].copy_(rois_h)
         ws['view_start_h'].copy_(torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32))
+        ws['grp_start_h'].copy_(torch.tensor(grp, dtype=torch.int32))
+        if self.kind == 'T' and B > 1:
+            ws['dt_rows_h'].copy_(torch.cat([torch.full((grp[b + 1] - grp[b],), fts[b]['dt'], dtype=F32) for b in range(B)]))
         sc = dict(sh['frame_scalars'])
         sc['max_per_view'] = max(counts)
+        sc['max_rows'] = max(grp[b + 1] - grp[b] for b in range(B))
         return ws, R, sc
 
     def _tick(self, name):
@@ -335,13 +373,19 @@ class HeadEngine:
         """Device side of one frame: everything below is enqueued on the current stream, no host sync."""
         o, W_ = ops, self.w
         P, L, T = ws['P'], self.L, ws['tab']
+        B, Vg = ws['B'], ws['Vg']
+        grp = ws['grp_start'] if B > 1 else None          # several samples share every launch (include/mv2d_hip.h "batches of samples")
         tk = self._tick
         tk('h2d')
         ws['dyn_d'].copy_(ws['dyn_h'], non_blocking=True)
         rois = ws['rois']
         tk('transpose')
         # position-major feature map
-        if feat.is_contiguous(memory_format=torch.channels_last) and not feat.is_contiguous():
+        if isinstance(feat, (list, tuple)):
+            featcl, Pg = ws['featcl'], P // B
+            for b, f in enumerate(feat):
+                o.nchw_to_nhwc(f, featcl[b * Pg:(b + 1) * Pg])
+        elif feat.is_contiguous(memory_format=torch.channels_last) and not feat.is_contiguous():
             featcl = feat.permute(0, 2, 3, 1).reshape(P, C)                         # already position-major: no copy
         else:
             featcl = o.nchw_to_nhwc(feat, ws['featcl'])
@@ -350,7 +394,7 @@ class HeadEngine:
         o.box_params(rois, T['viewK'], T['viewE'], ws['enc'][:, 1024:], 1056, ws['minv'])
         tk('box_corr')
         # a9 epipolar correlation (independent of the features)
-        o.box_correlation(rois, ws['view_start'], T['trans'], self.const['lin'], self.const['depths'], ws['match'], V, self.topk,
+        o.box_correlation(rois, ws['view_start'], T['trans'], self.const['lin'], self.const['depths'], ws['match'], Vg, self.topk,
                           sc['pad_h'], sc['pad_w'], sc['max_per_view'], iou_thr=self.iou_thr, ratio=self.ratio)
         tk('csr')
         ws['zbuf'].zero_()
@@ -369,8 +413,8 @@ class HeadEngine:
         if self.kind == 'T':
             # a11/a12: key list + CSR, then a4 RoIAlign of the feature half only
             o.mask_compact(rois, ws['match'], T['pad_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'],
-                           ws['bits'], ws['row_count'], ws['row_ptr'], ws['col_idx'], ws['nnz'], R, V, h, w, self.topk,
-                           self.stride, self.expand, col_cap=ws['col_cap'])
+                           ws['bits'], ws['row_count'], ws['row_ptr'], ws['col_idx'], ws['nnz'], R, Vg, h, w, self.topk,
+                           self.stride, self.expand, col_cap=ws['col_cap'], n_samples=B)
             if not forked:
                 tk('roi_align')
                 o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'], R=R)
@@ -383,14 +427,14 @@ class HeadEngine:
                 # (RoIs per query) substitutes a synthetic correlation list: own RoI + (n_c - 1) others
                 fm = ws.get('forced_match')
                 if fm is None or fm.shape != ws['match'].shape:
-                    assert self.force_nc - 1 <= V * self.topk, 'raise corr_topk for this n_c'
-                    fmh = torch.full((R, V * self.topk), -1, dtype=torch.int32)
+                    assert self.force_nc - 1 <= Vg * self.topk, 'raise corr_topk for this n_c'
+                    fmh = torch.full((R, Vg * self.topk), -1, dtype=torch.int32)
                     ar = torch.arange(R, dtype=torch.int32)
                     for j in range(1, self.force_nc):
                         fmh[:, j - 1] = (ar + 37 * j) % R
-                    fm = ws['forced_match'] = fmh.view(R, V, self.topk).to(self.dev)
+                    fm = ws['forced_match'] = fmh.view(R, Vg, self.topk).to(self.dev)
                 ws['match'].copy_(fm)
-            o.csr_from_corr(ws['match'], ws['row_ptr'], ws['col_idx'], ws['nnz'], R, V, self.topk)
+            o.csr_from_corr(ws['match'], ws['row_ptr'], ws['col_idx'], ws['nnz'], R, Vg, self.topk)
         tk('pe_inputs')
         # a2: PE at the listed positions (3 two-layer MLPs on bf16 MFMA)
         o.pe_inputs(ws['s2pos'], ws['S_dev'], P, featcl, T['img2lidar'], T['coords_w'], T['coords_h'], T['coords_d'], T['embeds'],
@@ -429,9 +473,9 @@ class HeadEngine:
         tk('heads')
         self._enqueue_heads(ws, R, sc['dt'])
         tk('decode')
-        # a21: NMS-free decode of the last layer
+        # a21: NMS-free decode of the last layer (one top-k per sample)
         o.decode_topk(ws['cls'][L - 1], ws['reg'][L - 1], R, 10, self.max_num, self.post_range_h, ws['boxes'], ws['scores'],
-                      ws['labels'], ws['bbox_index'], ws['count'])
+                      ws['labels'], ws['bbox_index'], ws['count'], grp_start=grp, max_grp_rows=sc['max_rows'] if B > 1 else 0)
         tk('end')
 
     def _enqueue_qg(self, ws, R):
@@ -468,7 +512,7 @@ class HeadEngine:
                 o.gemm_f32(xq, W_[f'sa_in_w{i}'], W_[f'sa_in_b{i}'], A2=x, n_split=2 * C, out=ws['qkv'])
             sa_fused = self.fuse_rows and self.rows_x3 and self.sa_fused
             if not sa_fused:
-                o.self_attn(ws['qkv'], ws['ctx'], R)
+                o.self_attn(ws['qkv'], ws['ctx'], R, grp_start=ws['grp_start'] if ws['B'] > 1 else None)
             if self.fuse_rows and self.rows_x3:
                 sa_tail = o.sa_block_fused_x3 if sa_fused else o.attn_out_fused_x3      # self-attention core inside the row kernel, or not
                 sa_tail(ws['qkv'] if sa_fused else ws['ctx'], x, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
@@ -502,11 +546,13 @@ class HeadEngine:
 
     def _enqueue_heads(self, ws, R, dt):
         # a14: every per-layer cls / reg branch + the reference-point tail in ONE launch (row-block fused)
-        ops.heads_fused(ws['outs'], self.cls_ptrs, self.reg_ptrs, ws['ref'], ws['cls'], ws['reg'], R, self.L, self.pc_range_h, dt)
+        ops.heads_fused(ws['outs'], self.cls_ptrs, self.reg_ptrs, ws['ref'], ws['cls'], ws['reg'], R, self.L, self.pc_range_h, dt,
+                        dt_rows=ws['dt_rows'] if (self.kind == 'T' and ws['B'] > 1) else None)
 
-    def _result(self, ws, R, keep_stages=False):
-        out = dict(R=R, ws=ws, cls=ws['cls'], reg=ws['reg'], boxes=ws['boxes'], scores=ws['scores'], labels=ws['labels'],
-                   bbox_index=ws['bbox_index'], count=ws['count'])
+    def _result(self, ws, R, keep_stages=False, batch=False):
+        sel = (lambda t: t) if batch else (lambda t: t[0])
+        out = dict(R=R, ws=ws, cls=ws['cls'], reg=ws['reg'], boxes=sel(ws['boxes']), scores=sel(ws['scores']), labels=sel(ws['labels']),
+                   bbox_index=sel(ws['bbox_index']), count=ws['count'] if batch else ws['count'][:1], grp_start=ws['grp_start_h'].clone())
         if keep_stages:
             out['stages'] = {k: ws[k].clone() for k in ('rois', 'minv', 'enc', 'roi_feat', 'center', 'xyz', 'ref', 'posemb', 'qpos',
                                                         'match', 'roi_mask', 'pos2s', 's2pos', 'S_dev', 'nnz', 'row_ptr', 'col_idx',
@@ -514,22 +560,44 @@ class HeadEngine:
         return out
 
     def run(self, feat, proposals, img_metas, keep_stages=False, use_graph=False):
-        """feat [V,256,h,w] fp32 on the GPU (NCHW, or channels_last memory format); proposals list of [n,6].
-        Enqueues one frame on the current stream; use_graph replays a captured hipGraph of the same shape."""
-        assert feat.is_cuda and feat.dtype == F32 and feat.dim() == 4 and feat.shape[1] == C
-        V, _, h, w = feat.shape
-        ws, R, sc = self._host_prepare(proposals, img_metas, V, h, w)
-        if not use_graph:
+        """One sample.  feat [V,256,h,w] fp32 on the GPU (NCHW, or channels_last memory format); proposals list of [n,6].
+        Enqueues the frame on the current stream; use_graph replays a captured hipGraph of the same shape."""
+        return self._run([feat], [proposals], [img_metas], keep_stages, use_graph, batch=False)
+
+    def run_batch(self, feats, proposals_list, metas_list, keep_stages=False, use_graph=False):
+        """Several samples through ONE sequence of launches (the reference runs one sample per call): feats = list of [V,256,h,w]
+        maps (or one stacked [B*V,256,h,w] tensor), proposals_list / metas_list = one entry per sample.  Outputs: cls / reg
+        [L,R_total,10] with the samples' queries concatenated (out['grp_start']), boxes [B,max_num,9], scores, labels, count [B]."""
+        return self._run(feats, proposals_list, metas_list, keep_stages, use_graph, batch=True)
+
+    def _run(self, feats, proposals_list, metas_list, keep_stages, use_graph, batch):
+        B = len(proposals_list)
+        stacked = torch.is_tensor(feats)
+        fl = [feats] if stacked else list(feats)
+        for f in fl:
+            assert f.is_cuda and f.dtype == F32 and f.dim() == 4 and f.shape[1] == C
+        if stacked or B == 1:
+            feat = fl[0]
             if not (feat.is_contiguous(memory_format=torch.channels_last) and not feat.is_contiguous()):
                 feat = feat.contiguous()
+            V, _, h, w = feat.shape
+            ptrs = (feat.data_ptr(),)
+        else:
+            assert len(fl) == B
+            feat = [f.contiguous() for f in fl]
+            Vg, _, h, w = feat[0].shape
+            assert all(tuple(f.shape) == tuple(feat[0].shape) for f in feat), 'samples of a batch share one map shape'
+            V = Vg * B
+            ptrs = tuple(f.data_ptr() for f in feat)
+        assert V % B == 0
+        ws, R, sc = self._host_prepare(proposals_list, metas_list, V, h, w)
+        if not use_graph:
             self._enqueue(ws, feat, R, V, h, w, sc)
             self._mark_done(ws)
-            return self._result(ws, R, keep_stages)
-        # the graph bakes in the input pointer (the producer's output buffer is static under graph replay) and the
+            return self._result(ws, R, keep_stages, batch)
+        # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
-        if not (feat.is_contiguous(memory_format=torch.channels_last) and not feat.is_contiguous()):
-            feat = feat.contiguous()
-        gkey = (feat.data_ptr(), sc['pad_h'], sc['pad_w'], sc['dt'], sc['max_per_view'])
+        gkey = (ptrs, sc['pad_h'], sc['pad_w'], sc['dt'], sc['max_per_view'], sc['max_rows'])
         g = ws.get('graph')
         if g is None or ws.get('graph_key') != gkey:
             prof, self.prof = self.prof, None
@@ -546,7 +614,7 @@ class HeadEngine:
             ws['graph'], ws['graph_key'], ws['graph_feat'] = g, gkey, feat
         g.replay()
         self._mark_done(ws)
-        return self._result(ws, R, keep_stages)
+        return self._result(ws, R, keep_stages, batch)
 
     @staticmethod
     def _mark_done(ws):
@@ -562,12 +630,20 @@ class HeadEngine:
         other.__dict__.update(self.__dict__)
         other._ws = {}
         other._ws_base = {}
+        other._tab_cache = {}
         other.prof = None
         return other
 
     def results(self, out):
         """Synchronising accessor: sliced (boxes [K,9], scores [K], labels [K]) like simple_test returns."""
-        n = int(out['count'].item())
+        n = int(out['count'][0].item())
         if int(out['ws']['nnz'][1].item()) != 0:
             raise RuntimeError('mv2d engine: CSR capacity exceeded (raise col_cap_per_query)')
         return out['boxes'][:n], out['scores'][:n], out['labels'][:n]
+
+    def results_batch(self, out):
+        """Synchronising accessor of run_batch: one (boxes [K,9], scores [K], labels [K]) per sample."""
+        counts = out['count'].tolist()
+        if int(out['ws']['nnz'][1].item()) != 0:
+            raise RuntimeError('mv2d engine: CSR capacity exceeded (raise col_cap_per_query)')
+        return [(out['boxes'][b, :n], out['scores'][b, :n], out['labels'][b, :n]) for b, n in enumerate(counts)]

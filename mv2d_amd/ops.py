@@ -161,9 +161,9 @@ def pack_wfrag_f32(W):
     return Wp
 
 
-def heads_fused(outs, cls_ptrs, reg_ptrs, ref, cls, reg, M, L, pc_range_host, dt=0.0, eps=1e-5):
+def heads_fused(outs, cls_ptrs, reg_ptrs, ref, cls, reg, M, L, pc_range_host, dt=0.0, eps=1e-5, dt_rows=None):
     check(_lib.load().mv2d_heads_fused(_p(outs), cls_ptrs, reg_ptrs, _p(ref), _p(cls), _p(reg), M, L, float(eps),
-                                       pc_range_host.data_ptr(), float(dt), _stream()), 'mv2d_heads_fused')
+                                       pc_range_host.data_ptr(), float(dt), _p(dt_rows), _stream()), 'mv2d_heads_fused')
 
 
 def ffn_pack_weights(W1, W2):
@@ -331,12 +331,14 @@ def nchw_to_nhwc(x, out=None):
     return out
 
 
-def self_attn(qkv, out=None, R=None):
+def self_attn(qkv, out=None, R=None, grp_start=None):
+    """grp_start (int32 [n+1], device): first query row of every sample of a batch; attention stays inside a sample."""
     _req(qkv, torch.float32, 'qkv')
     R = qkv.shape[0] if R is None else R
     if out is None:
         out = torch.empty((R, 256), device=qkv.device, dtype=torch.float32)
-    check(_lib.load().mv2d_self_attn_fwd(_p(qkv), _p(out), R, _stream()), 'mv2d_self_attn_fwd')
+    n = 0 if grp_start is None else grp_start.numel() - 1
+    check(_lib.load().mv2d_self_attn_fwd(_p(qkv), _p(out), R, _p(grp_start), n, _stream()), 'mv2d_self_attn_fwd')
     return out
 
 
@@ -403,11 +405,12 @@ def csr_workspace_bytes(R, V, h, w):
 
 
 def mask_compact(rois, match, pad_mask, roi_mask, rect, pos2s, s2pos, S_out, bits_ws, row_count, row_ptr, col_idx, nnz_out,
-                 R, V, h, w, topk, stride=16.0, expand_stride=2.0, col_cap=None):
+                 R, V, h, w, topk, stride=16.0, expand_stride=2.0, col_cap=None, n_samples=1):
+    """V = views per sample; the maps hold n_samples * V views."""
     col_cap = col_idx.numel() if col_cap is None else col_cap
     check(_lib.load().mv2d_mask_compact(_p(rois), _p(match), _p(pad_mask), _p(roi_mask), _p(rect), _p(pos2s), _p(s2pos), _p(S_out),
                                         _p(bits_ws), _p(row_count), _p(row_ptr), _p(col_idx), _p(nnz_out), col_cap, R, V, h, w, topk,
-                                        float(stride), float(expand_stride), _stream()), 'mv2d_mask_compact')
+                                        float(stride), float(expand_stride), n_samples, _stream()), 'mv2d_mask_compact')
 
 
 def roi_positions(rois, pad_mask, roi_mask, rect, pos2s, s2pos, S_out, R, V, h, w, stride=16.0, expand_stride=1.0):
@@ -427,16 +430,20 @@ def pe_inputs(s2pos, S_dev, S_max, featcl, img2lidar, coords_w, coords_h, coords
                                      position_range_host.data_ptr(), _stream()), 'mv2d_pe_inputs')
 
 
-def decode_topk(cls, reg, R, num_classes, max_num, post_center_range_host, boxes, scores, labels, bbox_index, count, topk_dbg=None):
+def decode_topk(cls, reg, R, num_classes, max_num, post_center_range_host, boxes, scores, labels, bbox_index, count, topk_dbg=None,
+                grp_start=None, max_grp_rows=0):
+    """grp_start (int32 [n+1], device) + max_grp_rows: one top-k per sample of a batch, outputs [n][max_num]."""
     _req(cls, torch.float32, 'cls'); _req(reg, torch.float32, 'reg')
+    n = 0 if grp_start is None else grp_start.numel() - 1
     check(_lib.load().mv2d_decode_topk(_p(cls), _p(reg), R, num_classes, max_num, post_center_range_host.data_ptr(), _p(boxes),
-                                       _p(scores), _p(labels), _p(bbox_index), _p(count), _p(topk_dbg), _stream()),
-          'mv2d_decode_topk')
+                                       _p(scores), _p(labels), _p(bbox_index), _p(count), _p(topk_dbg), _p(grp_start), n, max_grp_rows,
+                                       _stream()), 'mv2d_decode_topk')
 
 
-def result_pack(boxes, scores, labels, count, score_thr, max_num, out_boxes, out_scores, out_labels, out_count):
+def result_pack(boxes, scores, labels, count, score_thr, max_num, out_boxes, out_scores, out_labels, out_count, n_samples=1, in_stride=0):
+    """n_samples > 1: inputs [n_samples][in_stride], count [n_samples]; outputs [n_samples][max_num], out_count [n_samples]."""
     check(_lib.load().mv2d_result_pack(_p(boxes), _p(scores), _p(labels), _p(count), float(score_thr), max_num, _p(out_boxes), _p(out_scores),
-                                       _p(out_labels), _p(out_count), _stream()), 'mv2d_result_pack')
+                                       _p(out_labels), _p(out_count), n_samples, in_stride, _stream()), 'mv2d_result_pack')
 
 
 SCALE_Q = 1.0 / math.sqrt(32.0)

@@ -558,7 +558,7 @@ class BoxCorrelation(nn.Module):
         # the per-query bitmask over all P cells IS the reference's feat_in_corr_rois (no padding exclusion here)
         ops.mask_compact(rois.float().contiguous(), match, z8, roi_mask, rect, pos2s, s2pos, S, bits, rc, rp, col, nnz, R, V, h, w,
                          self.topk, float(stride), float(self.expand_stride), col_cap=0)
-        nwords = (P + 31) // 32
+        nwords = (P + 31) // 32 + 1                        # one sample: the bitmask window starts at cell 0, one word of slack
         words = bits.view(R, nwords)
         shifts = torch.arange(32, device=dev, dtype=torch.int32)
         out = ((words[:, :, None] >> shifts) & 1).to(torch.bool).view(R, nwords * 32)[:, :P]

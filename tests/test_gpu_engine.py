@@ -194,6 +194,55 @@ def test_engine_varying_roi_count_shares_one_storage(kind, name):
     assert len(eng._ws_base) == 1 and len(eng._ws) == 3
 
 
+def _varied_samples(name, n):
+    """n different samples of one workload: own features, own proposals (different counts), own camera rig / timestamps"""
+    out = []
+    for i in range(n):
+        prob = synthetic.make_problem(name, seed=10 * i)
+        props = [torch.from_numpy(p[:max(1, p.shape[0] - (2 * i + j) % 5)]) for j, p in enumerate(prob['proposals'])]
+        metas = [dict(m) for m in prob['img_metas']]
+        if i:
+            import numpy as np
+            rot = np.eye(4); a = 0.03 * i
+            rot[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]; rot[0, 3] = 0.2 * i
+            for m in metas:
+                e2 = np.asarray(m['extrinsics'], dtype=np.float64).T @ rot              # lidar -> camera of a slightly moved rig
+                m['extrinsics'] = np.ascontiguousarray(e2.T)
+                m['lidar2img'] = np.asarray(m['intrinsics'], dtype=np.float64) @ e2
+                if 'timestamp' in m:
+                    m['timestamp'] = float(m['timestamp']) * (1.0 + 0.1 * i)
+        out.append((torch.from_numpy(prob['feat']), props, metas, prob['views_per_frame']))
+    return out
+
+
+@pytest.mark.parametrize('kind,name,n', [('S', 'cfg1_s', 3), ('T', 'cfg1_t', 3), ('S', 'cfg2_s', 2), ('T', 'cfg3_t', 2)])
+def test_engine_batch_of_samples_equals_single_runs(kind, name, n):
+    """run_batch puts several samples through ONE sequence of launches; nothing may leak between samples: every sample's
+    outputs are bitwise what a single-sample run gives (box correlation, self attention, top-k, dt stay inside a sample)."""
+    from mv2d_amd.engine import HeadEngine
+    sd = synthetic.make_head_state(seed=0)
+    dev = torch.device('cuda:0')
+    samples = _varied_samples(name, n)
+    vpf = samples[0][3]
+    eng = HeadEngine(sd, kind, dev, num_views=vpf)
+    feats = [s[0].to(dev) for s in samples]
+    for use_graph in (False, True):
+        out = eng.run_batch(feats, [s[1] for s in samples], [s[2] for s in samples], use_graph=use_graph)
+        res = [[t.clone() for t in r] for r in eng.results_batch(out)]
+        cls, reg, grp = out['cls'].clone(), out['reg'].clone(), out['grp_start'].tolist()
+        assert len(res) == n and grp[-1] == out['R']
+        single = HeadEngine(sd, kind, dev, num_views=vpf)
+        for b, (f, props, metas, _) in enumerate(samples):
+            ref = single.run(feats[b], props, metas)
+            assert ref['R'] == grp[b + 1] - grp[b]
+            assert torch.equal(cls[:, grp[b]:grp[b + 1]], ref['cls']) and torch.equal(reg[:, grp[b]:grp[b + 1]], ref['reg']), (use_graph, b)
+            for a, w in zip(res[b], single.results(ref)):
+                assert torch.equal(a, w), (use_graph, b)
+    # a stacked [B*V,256,h,w] map is accepted as well
+    out = eng.run_batch(torch.cat(feats, 0), [s[1] for s in samples], [s[2] for s in samples])
+    assert torch.equal(out['cls'], cls)
+
+
 def test_engine_full_size_properties_cfg5():
     """BASELINE.json's largest configuration (R101 1600x640, 12 views, 900 queries) through size-independent properties:
     CSR well-formedness, idempotence (same frame twice -> bitwise identical), fork/no-fork equality, and the decode kernel
