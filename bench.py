@@ -59,7 +59,8 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='cfg2_s', help='cfg2_s (MV2D-S 6 cams 1408x512, headline) | cfg3_t | cfg5_t | cfg1_s ...')
-    ap.add_argument('--inflight', type=int, default=4, help='independent frames per GPU per step (one HIP stream each)')
+    ap.add_argument('--inflight', type=int, default=4, help='HIP streams per GPU, each running its own launch sequence per step')
+    ap.add_argument('--batch', type=int, default=4, help='samples sharing every launch of a stream (HeadEngine.run_batch)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL; gloo only for single-GPU dry runs)')
@@ -100,10 +101,16 @@ def main():
     feat = torch.from_numpy(prob['feat']).to(dev)
     props = [torch.from_numpy(p) for p in prob['proposals']]
     metas = prob['img_metas']
+    B = args.batch
+    if B > 1:                                                      # the samples of a batch are different frames
+        more = [synthetic.make_problem(args.workload, seed=1000 * (b + 1) + rank) for b in range(B - 1)]
+        feats_b = [feat] + [torch.from_numpy(m['feat']).to(dev) for m in more]
+        props_b = [props] + [[torch.from_numpy(p) for p in m['proposals']] for m in more]
+        metas_b = [metas] + [m['img_metas'] for m in more]
     use_graph = not args.no_graph
     # ping-pong payload buffers: the streams free-run (no per-step join on one GPU); with N > 1 the all-gather of step k
     # runs on the main stream behind the frames of step k while the frames of step k+1 are already executing.
-    payload = [torch.zeros((args.inflight, 300 * 11 + 1), device=dev) for _ in range(2)]
+    payload = [torch.zeros((args.inflight * B, 300 * 11 + 1), device=dev) for _ in range(2)]
     gathered_ev = [None, None]
     step_no = [0]
 
@@ -116,8 +123,12 @@ def main():
             with torch.cuda.stream(s):
                 if gathered_ev[k] is not None:
                     s.wait_event(gathered_ev[k])
-                o = e.run(feat, props, metas, use_graph=use_graph)
-                payload[k][i].copy_(mdist.pack_detections(o['boxes'], o['scores'], o['labels'], o['count']))
+                if B > 1:
+                    o = e.run_batch(feats_b, props_b, metas_b, use_graph=use_graph)
+                    payload[k][i * B:(i + 1) * B].copy_(mdist.pack_detections_batch(o['boxes'], o['scores'], o['labels'], o['count']))
+                else:
+                    o = e.run(feat, props, metas, use_graph=use_graph)
+                    payload[k][i].copy_(mdist.pack_detections(o['boxes'], o['scores'], o['labels'], o['count']))
                 if collective:
                     ev = torch.cuda.Event()
                     ev.record()
@@ -149,24 +160,25 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    samples = world * args.inflight * args.steps
+    samples = world * args.inflight * B * args.steps
     value = samples / elapsed
 
     # ---------------- per-stage timing of the same frame with HIP events on the launch stream (single stream, eager)
     eng = base
-    out0 = eng.run(feat, props, metas)
+    run_once = (lambda: eng.run_batch(feats_b, props_b, metas_b)) if B > 1 else (lambda: eng.run(feat, props, metas))
+    out0 = run_once()                                    # the launches of the timed region: B samples each
     torch.cuda.synchronize()
     R = out0['R']
     ws = out0['ws']
     S = int(ws['S_dev'].item())
     nnz = int(ws['nnz'][0].item())
     for _ in range(3):
-        eng.run(feat, props, metas)                      # eager warm-up of the instrumented path
+        run_once()                                       # eager warm-up of the instrumented path
     torch.cuda.synchronize()
     eng.prof = {}
     n_prof = max(5, min(args.steps, 20))
     for _ in range(n_prof):
-        eng.run(feat, props, metas)
+        run_once()
     torch.cuda.synchronize()
     prof, eng.prof = eng.prof, None
     names = list(prof.keys())
@@ -244,10 +256,11 @@ def main():
             'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16 (key side MFMA) / f32 + bf16x3 split precision (query side)', 'data': 'synthetic',
             'config': {'workload': f'{args.workload}: MV2D-{kind} head, {len(metas)} views {metas[0]["img_shape"][1]}x{metas[0]["img_shape"][0]}, '
-                                   f'R={R} queries, S={S} key positions, nnz={nnz} allowed (q,k) pairs' + (f', corr_topk={args.corr_topk}' if args.corr_topk else '') + (f', forced n_c={args.force_nc}' if args.force_nc else ''),
-                       'frames_per_step_per_gpu': args.inflight, 'global_batch': world * args.inflight,
+                                   f'R={R} queries, S={S} key positions, nnz={nnz} allowed (q,k) pairs' + (f' (totals of the {B} samples of a launch)' if B > 1 else '') + (f', corr_topk={args.corr_topk}' if args.corr_topk else '') + (f', forced n_c={args.force_nc}' if args.force_nc else ''),
+                       'frames_per_step_per_gpu': args.inflight * B, 'global_batch': world * args.inflight * B,
+                       'streams_per_gpu': args.inflight, 'samples_per_launch': B,
                        'parallelism': f'dp{world}', 'hipgraph': use_graph},
-            'decoder_ms_per_iter': round(decoder_ms, 4),
+            'decoder_ms_per_iter': round(decoder_ms / B, 4), 'decoder_ms_per_launch': round(decoder_ms, 4),
             'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},
             'roofline': roofline, 'stage_roofline': stage_roofline,
             'cpu_baseline': cpu,

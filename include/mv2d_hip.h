@@ -144,9 +144,10 @@ int mv2d_ffn_fused(const float* X, const float* W1, const float* b1, const float
 /* The same fused FFN in split precision on the bf16 matrix cores ("bf16x3": x = x_hi + x_lo as a bf16 pair, three bf16 MFMAs per
  * product, fp32 accumulation): ~1e-5 relative error instead of bit-exact fp32, 3/16 of the matrix-pipe time.  W1/W2 are given as
  * the pairs produced by mv2d_split_bf16x2 ([hidden,256] and [256,hidden] bf16 each), each stored fragment-major
- * (mv2d_pack_wfrag_bf16); same slab output as mv2d_ffn_fused. */
+ * (mv2d_pack_wfrag_bf16); same slab output as mv2d_ffn_fused, except that slices_per_block (1, 2 or 4) consecutive hidden slices are
+ * accumulated per block: slabs [hidden/64/slices_per_block, M, 256] (less slab traffic when M is large enough to fill the chip). */
 int mv2d_ffn_fused_x3(const float* X, const void* W1hi, const void* W1lo, const float* b1, const void* W2hi, const void* W2lo,
-                      float* slabs, int M, int hidden, void* stream);
+                      float* slabs, int M, int hidden, int slices_per_block, void* stream);
 
 /* fp32-class GEMM on the bf16 matrix cores (split precision "bf16x3"): same contract as mv2d_gemm_f32 but the weights are
  * given as the bf16 pair Whi = bf16(W), Wlo = bf16(W - Whi) (see mv2d_split_bf16x2) and A is split on the fly;

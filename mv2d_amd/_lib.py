@@ -37,7 +37,7 @@ SIGNATURES = {
     'mv2d_heads_fused': (I, [P, P, P, P, P, P, I, I, F, P, F, P, P]),
     'mv2d_ffn_fused': (I, [P, P, P, P, P, I, I, P]),
     'mv2d_ffn_pack_weights': (I, [P, P, P, P, I, P]),
-    'mv2d_ffn_fused_x3': (I, [P, P, P, P, P, P, P, I, I, P]),
+    'mv2d_ffn_fused_x3': (I, [P, P, P, P, P, P, P, I, I, I, P]),
     'mv2d_gemm_x3': (I, [P, P, I, P, P, P, I, I, I, I, I, I, I, F, F, P, I, I, LL, I, LL, LL, LL, LL, P]),
     'mv2d_split_bf16x2': (I, [P, P, P, LL, P]),
     'mv2d_row_ln': (I, [P, I, LL, P, P, P, P, I, P, P, P, P, P, P, I, F, I, P]),

@@ -40,6 +40,13 @@ def pack_detections(boxes, scores, labels, count, max_num=300):
     return torch.cat([(rows * valid).reshape(-1), count.to(boxes.dtype).reshape(1)])
 
 
+def pack_detections_batch(boxes, scores, labels, count, max_num=300):
+    """run_batch outputs (boxes [B,max_num,9], scores [B,max_num], labels [B,max_num] int64, count [B] int32) -> [B, max_num*11 + 1]."""
+    rows = torch.cat([boxes[:, :max_num], scores[:, :max_num, None], labels[:, :max_num, None].to(boxes.dtype)], 2)
+    valid = (torch.arange(max_num, device=boxes.device)[None, :] < count.to(torch.int64)[:, None]).to(boxes.dtype)[:, :, None]
+    return torch.cat([(rows * valid).reshape(rows.shape[0], -1), count.to(boxes.dtype)[:, None]], 1)
+
+
 def unpack_detections(payload, max_num=300):
     n = int(payload[-1].item())
     rows = payload[:-1].view(max_num, ROW)[:n]

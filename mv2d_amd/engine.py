@@ -69,6 +69,7 @@ class HeadEngine:
         self.prof = None              # dict name -> [events] when stage timing is on (bench.py)
         self.fork_qg = True           # T path: query-generator chain on a second stream
         self.ffn_x3 = os.environ.get('MV2D_FFN_X3', '1') == '1'   # FFN in bf16x3 split precision (fragment-major hi/lo weights); 0: exact fp32
+        self.ffn_groups = int(os.environ.get('MV2D_FFN_G', '0'))   # hidden slices per FFN block (0: by the number of rows)
         self.pe_fused = os.environ.get('MV2D_PE_FUSED', '1') == '1'   # one fused launch for the PE block instead of six GEMMs
         self.force_nc = None          # bench only (S path): overwrite the correlation lists so that every query reads n_c RoIs
         # out_proj + residual + LayerNorm (+ q in_proj) as one row-fused kernel per attention (8 instead of 11 launches per layer),
@@ -531,17 +532,22 @@ class HeadEngine:
                 o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R, empty_nan=self.empty_nan)
                 o.gemm_f32(ws['ctx'], W_[f'ca_out_w{i}'], W_[f'ca_out_b{i}'], out=ws['o'])
                 o.row_ln(ws['o'], residual=ws['x1'], ln=(W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), out=ws['x2'])
+            parts = ws['parts']
             if self.ffn_x3:
-                o.ffn_fused_x3(ws['x2'], W_[f'ffn_w1x{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2x{i}'], ws['parts'], R)
+                # two hidden slices accumulated per block (half the slabs to write and re-read) pay off for one sample (decoder 0.361 ->
+                # 0.344 ms at R = 300); with a batch (R = 1200) the one-block-per-CU variant loses what the slab traffic saves
+                G = self.ffn_groups if self.ffn_groups else (2 if R <= 400 else 1)
+                parts = parts[:parts.shape[0] // G]
+                o.ffn_fused_x3(ws['x2'], W_[f'ffn_w1x{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2x{i}'], parts, R, groups=G)
             else:
-                o.ffn_fused(ws['x2'], W_[f'ffn_w1p{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2p{i}'], ws['parts'], R)
+                o.ffn_fused(ws['x2'], W_[f'ffn_w1p{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2p{i}'], parts, R)
             if fuse_tail:
                 nxt = i + 1 < L
-                o.ffn_out_fused_x3(ws['parts'], W_[f'ffn_b2{i}'], ws['x2'], (W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), (W_['post_w'], W_['post_b']),
+                o.ffn_out_fused_x3(parts, W_[f'ffn_b2{i}'], ws['x2'], (W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), (W_['post_w'], W_['post_b']),
                                    x, ws['qpos'], xq, outs=ws['outs'][i], Win_x3=W_[f'sa_in_wx{i + 1}'] if nxt else None,
                                    b_in=W_[f'sa_in_b{i + 1}'] if nxt else None, qkv=ws['qkv'] if nxt else None, M=R)
             else:
-                o.row_ln(ws['parts'], bias=W_[f'ffn_b2{i}'], residual=ws['x2'], ln=(W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), out=x, addvec=ws['qpos'],
+                o.row_ln(parts, bias=W_[f'ffn_b2{i}'], residual=ws['x2'], ln=(W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), out=x, addvec=ws['qpos'],
                          out_plus=xq, ln2=(W_['post_w'], W_['post_b']), out2=ws['outs'][i])
 
     def _enqueue_heads(self, ws, R, dt):

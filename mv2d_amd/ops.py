@@ -185,17 +185,18 @@ def ffn_fused(x, W1, b1, W2, slabs=None, M=None):
     return slabs
 
 
-def ffn_fused_x3(x, W1hl, b1, W2hl, slabs=None, M=None):
-    """ffn_fused in bf16x3 split precision; W1hl / W2hl = pack_x3(W1) / pack_x3(W2)."""
+def ffn_fused_x3(x, W1hl, b1, W2hl, slabs=None, M=None, groups=1):
+    """ffn_fused in bf16x3 split precision; W1hl / W2hl = pack_x3(W1) / pack_x3(W2).  groups (1, 2, 4) consecutive hidden slices are
+    accumulated per block: hidden/64/groups slabs come out."""
     _req(x, torch.float32, 'x'); _req(b1, torch.float32, 'b1')
     for t in (*W1hl, *W2hl):
         _req(t, BF16, 'W')
     M = x.shape[0] if M is None else M
     hidden = W1hl[0].numel() // 256                  # packed (fragment-major) copies are flat
     if slabs is None:
-        slabs = torch.empty((hidden // 64, M, 256), device=x.device, dtype=torch.float32)
-    check(_lib.load().mv2d_ffn_fused_x3(_p(x), _p(W1hl[0]), _p(W1hl[1]), _p(b1), _p(W2hl[0]), _p(W2hl[1]), _p(slabs), M, hidden, _stream()),
-          'mv2d_ffn_fused_x3')
+        slabs = torch.empty((hidden // 64 // groups, M, 256), device=x.device, dtype=torch.float32)
+    check(_lib.load().mv2d_ffn_fused_x3(_p(x), _p(W1hl[0]), _p(W1hl[1]), _p(b1), _p(W2hl[0]), _p(W2hl[1]), _p(slabs), M, hidden, groups,
+                                        _stream()), 'mv2d_ffn_fused_x3')
     return slabs
 
 
