@@ -132,6 +132,13 @@ int mv2d_heads_fused(const float* outs, const float* const* cls_w, const float* 
                      int M, int L, float eps, const float* pc_range, float dt, const float* dt_rows /* optional [M]: per-row dt of a
                      batch of samples, overrides dt */, void* stream);
 
+/* The same branches with their four 256x256 linears per (layer, branch) in split precision (bf16x3, ~1e-5 relative; the 256 -> 10
+ * output layers stay exact fp32).  cls_w = {w0_hi,w0_lo,b0,ln1w,ln1b,w3_hi,w3_lo,b3,ln4w,ln4b,w6,b6}, reg_w = {w0_hi,w0_lo,b0,w2_hi,
+ * w2_lo,b2,w4,b4}: every tensor stacked over the L layers, the *_hi/_lo matrices are per-layer mv2d_split_bf16x2 +
+ * mv2d_pack_wfrag_bf16 copies. */
+int mv2d_heads_fused_x3(const float* outs, const void* const* cls_w, const void* const* reg_w, const float* ref, float* cls, float* reg,
+                        int M, int L, float eps, const float* pc_range, float dt, const float* dt_rows, void* stream);
+
 /* Fused FFN partial sums (mmcv FFN 256 -> hidden -> 256 of the decoder layer, configs/mv2d/exp/*:78-79):
  * slabs[s] = relu(X . W1[64s:64s+64]^T + b1[64s:64s+64]) . W2[:, 64s:64s+64]^T  for the hidden/64 slices s, exact fp32.
  * X [M,256], W1 [hidden,256], W2 [256,hidden], slabs [hidden/64, M, 256]; the caller sums the slabs + b2 + residual

@@ -770,6 +770,131 @@ __global__ void pack_wfrag_f32_kernel(const float* __restrict__ W, float* __rest
     *reinterpret_cast<float4*>(Wp + idx * 4) = *reinterpret_cast<const float4*>(W + (long long)row * ldw + 16 * c + 4 * fg);
 }
 
+
+// The prediction branches in split precision (bf16x3): same chain as heads_fused_kernel with the four 256x256 linears of a
+// (layer, branch) on v_mfma_f32_16x16x32_bf16 (hi/lo pairs, ~1e-5 relative), 16 waves per block: wave w owns column tile w of a
+// linear and row w of the LayerNorm / ReLU stage; the 256 -> 10 output layer stays exact fp32.  (Profile of a 4-sample batch: the
+// exact-fp32 kernel spent 93 us in 2048-cycle MFMA chains per wave.)
+struct HeadsX3Params {
+    const float* outs;
+    const unsigned short* w0h; const unsigned short* w0l; const float* b0; const float* lnw1; const float* lnb1;
+    const unsigned short* w3h; const unsigned short* w3l; const float* b3; const float* lnw4; const float* lnb4;
+    const float* w6; const float* b6;
+    const unsigned short* r0h; const unsigned short* r0l; const float* rb0; const unsigned short* r2h; const unsigned short* r2l; const float* rb2;
+    const float* r4; const float* rb4;
+    const float* ref; float* cls; float* reg;
+    int M, L; float eps; float pc0, pc1, pc2, pd0, pd1, pd2, dt; const float* dt_rows;
+};
+
+// RT row tiles (16 rows each) per block share one load of the weight fragments: with many rows (a batch of samples) the kernel is
+// bound by the L2 -> CU traffic of the weights (0.5 MB per block), not by the matrix pipe.
+template <int RT>
+__global__ __launch_bounds__(1024) void heads_fused_x3_kernel(HeadsX3Params p) {
+    __shared__ __attribute__((aligned(16))) unsigned char ah[RT * 16 * 512], al[RT * 16 * 512];
+    __shared__ __attribute__((aligned(16))) float tb[RT * 16 * C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int mb = blockIdx.x * (16 * RT), l = blockIdx.y, branch = blockIdx.z;
+    const long long wo = (long long)l * C * C, bl = (long long)l * C;
+    const unsigned short* W1h = (branch == 0 ? p.w0h : p.r0h) + wo;
+    const unsigned short* W1l = (branch == 0 ? p.w0l : p.r0l) + wo;
+    const unsigned short* W2h = (branch == 0 ? p.w3h : p.r2h) + wo;
+    const unsigned short* W2l = (branch == 0 ? p.w3l : p.r2l) + wo;
+    const float* B1 = (branch == 0 ? p.b0 : p.rb0) + bl;
+    const float* B2 = (branch == 0 ? p.b3 : p.rb2) + bl;
+    float4 av[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+        av[t] = *reinterpret_cast<const float4*>(p.outs + ((long long)l * p.M + min(mb + 16 * t + wave, p.M - 1)) * C + lane * 4);
+    BFrag wh[8], wl[8];
+    load_w_x3(wh, wl, W1h, W1l, wave, lane);
+    const int aoff = wave * 512 + (((lane >> 1) ^ wave) << 4) + (lane & 1) * 8;     // this thread's 4 values in the bf16 images of a tile
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        uint2 hi, lo;
+        split4(av[t], hi, lo);
+        *reinterpret_cast<uint2*>(ah + t * 8192 + aoff) = hi;
+        *reinterpret_cast<uint2*>(al + t * 8192 + aoff) = lo;
+    }
+    __syncthreads();
+    const int col = wave * 16 + fr;
+    float* trow = tb + wave * C + ((lane ^ (wave & 15)) << 2);          // row = wave of a tile, columns 4 lane ..
+    // ---- linear 1 -> (LayerNorm) -> ReLU
+    f32x4_t acc[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] = tile_mma_x3(ah + t * 8192, al + t * 8192, wh, wl, fr, fg);
+    load_w_x3(wh, wl, W2h, W2l, wave, lane);                            // in flight during the row stage
+    {
+        const float b = B1[col];
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tb[t * 16 * C + toff(4 * fg + r, col)] = acc[t][r] + b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        float4 v = *reinterpret_cast<float4*>(trow + t * 16 * C);
+        if (branch == 0) v = ln_row(v, p.lnw1 + bl, p.lnb1 + bl, lane * 4, p.eps);
+        v = make_float4(relu_f(v.x), relu_f(v.y), relu_f(v.z), relu_f(v.w));
+        uint2 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<uint2*>(ah + t * 8192 + aoff) = hi;
+        *reinterpret_cast<uint2*>(al + t * 8192 + aoff) = lo;
+    }
+    __syncthreads();
+    // ---- linear 2 -> (LayerNorm) -> ReLU, kept as an fp32 tile for the output layer
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] = tile_mma_x3(ah + t * 8192, al + t * 8192, wh, wl, fr, fg);
+    {
+        const float b = B2[col];
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tb[t * 16 * C + toff(4 * fg + r, col)] = acc[t][r] + b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        float4 v = *reinterpret_cast<float4*>(trow + t * 16 * C);
+        if (branch == 0) v = ln_row(v, p.lnw4 + bl, p.lnb4 + bl, lane * 4, p.eps);
+        *reinterpret_cast<float4*>(trow + t * 16 * C) = make_float4(relu_f(v.x), relu_f(v.y), relu_f(v.z), relu_f(v.w));
+    }
+    __syncthreads();
+    if (wave >= RT) return;
+    const int m0 = mb + 16 * wave;                                      // wave t finishes row tile t
+    if (m0 >= p.M) return;
+    const float* tbt = tb + wave * 16 * C;
+    // ---- final Linear(256 -> 10): one 16x16 tile, weight rows >= 10 clamped and masked
+    const float* wlast = branch == 0 ? p.w6 + (long long)l * 10 * C : p.r4 + (long long)l * 10 * C;
+    const float* blast = branch == 0 ? p.b6 + l * 10 : p.rb4 + l * 10;
+    float* outp = branch == 0 ? p.cls : p.reg;
+    Frag f;
+    load_w(f, wlast, C, fr, 10, fg);
+    const f32x4_t o = tile_mma(tbt, f, fr, fg);
+    if (fr >= 10) return;
+    const float b = blast[fr];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 4 * fg + r;
+        if (m >= p.M) continue;
+        float v = o[r] + b;
+        if (branch == 1) {
+            // cross_attention_head.py:219-238: add inverse_sigmoid(ref) to (cx, cy) and cz, sigmoid, de-normalise; T head: v / dt
+            if (fr == 0 || fr == 1 || fr == 4) {
+                const int k = fr == 4 ? 2 : fr;
+                const float x = fminf(fmaxf(p.ref[m * 3 + k], 0.f), 1.f);
+                const float is = logf(fmaxf(x, 1e-5f) / fmaxf(1.f - x, 1e-5f));
+                const float sg = 1.f / (1.f + expf(-(v + is)));
+                v = fr == 0 ? sg * p.pd0 + p.pc0 : (fr == 1 ? sg * p.pd1 + p.pc1 : sg * p.pd2 + p.pc2);
+            } else if (fr >= 8) {
+                const float dt = p.dt_rows ? p.dt_rows[m] : p.dt;
+                if (dt != 0.f) v = v / dt;
+            }
+        }
+        outp[((long long)l * p.M + m) * 10 + fr] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" int mv2d_pack_wfrag_f32(const float* W, float* Wp, int N, int K, int ldw, void* stream) {
@@ -859,6 +984,27 @@ extern "C" int mv2d_heads_fused(const float* outs, const float* const* cls_w, co
                   reg_w[0], reg_w[1], reg_w[2], reg_w[3], reg_w[4], reg_w[5], ref, cls, reg, M, L, eps,
                   pc_range[0], pc_range[1], pc_range[2], pc_range[3] - pc_range[0], pc_range[4] - pc_range[1], pc_range[5] - pc_range[2], dt, dt_rows};
     hipLaunchKernelGGL(heads_fused_kernel, dim3(cdiv(M, 16), L, 2), dim3(256), 0, (hipStream_t)stream, p);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_heads_fused_x3(const float* outs, const void* const* cls_w, const void* const* reg_w, const float* ref, float* cls, float* reg,
+                                   int M, int L, float eps, const float* pc_range, float dt, const float* dt_rows, void* stream) {
+    // cls_w: {w0_hi,w0_lo,b0,lnw1,lnb1,w3_hi,w3_lo,b3,lnw4,lnb4,w6,b6}; reg_w: {w0_hi,w0_lo,b0,w2_hi,w2_lo,b2,w4,b4} device pointers,
+    // every tensor stacked over the L layers; the *_hi/_lo matrices are per-layer mv2d_split_bf16x2 + mv2d_pack_wfrag_bf16 copies
+    MV2D_CHECK_ARG(outs && cls_w && reg_w && ref && cls && reg && pc_range && L > 0, "mv2d_heads_fused_x3: null pointer");
+    for (int i = 0; i < 12; ++i) MV2D_CHECK_ARG(cls_w[i] != nullptr, "mv2d_heads_fused_x3: null cls weight");
+    for (int i = 0; i < 8; ++i) MV2D_CHECK_ARG(reg_w[i] != nullptr, "mv2d_heads_fused_x3: null reg weight");
+    if (M == 0) return MV2D_OK;
+    typedef const unsigned short* U; typedef const float* Fp;
+    HeadsX3Params p{outs, (U)cls_w[0], (U)cls_w[1], (Fp)cls_w[2], (Fp)cls_w[3], (Fp)cls_w[4], (U)cls_w[5], (U)cls_w[6], (Fp)cls_w[7], (Fp)cls_w[8],
+                    (Fp)cls_w[9], (Fp)cls_w[10], (Fp)cls_w[11],
+                    (U)reg_w[0], (U)reg_w[1], (Fp)reg_w[2], (U)reg_w[3], (U)reg_w[4], (Fp)reg_w[5], (Fp)reg_w[6], (Fp)reg_w[7],
+                    ref, cls, reg, M, L, eps,
+                    pc_range[0], pc_range[1], pc_range[2], pc_range[3] - pc_range[0], pc_range[4] - pc_range[1], pc_range[5] - pc_range[2], dt, dt_rows};
+    if (M <= 512) hipLaunchKernelGGL(heads_fused_x3_kernel<1>, dim3(cdiv(M, 16), L, 2), dim3(1024), 0, (hipStream_t)stream, p);
+    else if (M <= 1024) hipLaunchKernelGGL(heads_fused_x3_kernel<2>, dim3(cdiv(M, 32), L, 2), dim3(1024), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(heads_fused_x3_kernel<4>, dim3(cdiv(M, 64), L, 2), dim3(1024), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

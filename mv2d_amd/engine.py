@@ -80,6 +80,7 @@ class HeadEngine:
         # self-attention core inside the row-fused kernel: measured SLOWER (decoder 0.357 -> 0.432 ms: the fp32 MFMAs of 152 attention
         # blocks land on 19 CUs) -> off; kept as an ABI entry / A-B switch
         self.sa_fused = os.environ.get('MV2D_SA_FUSED', '0') == '1'
+        self.heads_x3 = os.environ.get('MV2D_HEADS_X3', '1') == '1'    # prediction branches in bf16x3 (0: exact fp32)
         self.load_state(state_dict)
 
     # ------------------------------------------------------------------------------------------ weights
@@ -163,6 +164,12 @@ class HeadEngine:
         self.w = w
         for k in ('cls_w0', 'cls_w3', 'reg_w0', 'reg_w2'):                              # [L,256,256] -> fragment-major copies for heads_fused
             w[k + 'p'] = ops.pack_wfrag_f32(w[k])
+        if self.heads_x3:
+            for k in ('cls_w0', 'cls_w3', 'reg_w0', 'reg_w2'):
+                w[k + 'x'] = ops.pack_x3_stack(w[k])
+            self.cls_ptrs_x3 = ops.make_ptr_array([*w['cls_w0x'], w['cls_b0'], w['cls_lnw1'], w['cls_lnb1'], *w['cls_w3x'], w['cls_b3'], w['cls_lnw4'],
+                                                   w['cls_lnb4'], w['cls_w6'], w['cls_b6']])
+            self.reg_ptrs_x3 = ops.make_ptr_array([*w['reg_w0x'], w['reg_b0'], *w['reg_w2x'], w['reg_b2'], w['reg_w4'], w['reg_b4']])
         self.cls_ptrs = ops.make_ptr_array([w[k] for k in ('cls_w0p', 'cls_b0', 'cls_lnw1', 'cls_lnb1', 'cls_w3p', 'cls_b3', 'cls_lnw4', 'cls_lnb4', 'cls_w6', 'cls_b6')])
         self.reg_ptrs = ops.make_ptr_array([w[k] for k in ('reg_w0p', 'reg_b0', 'reg_w2p', 'reg_b2', 'reg_w4', 'reg_b4')])
 
@@ -552,8 +559,13 @@ class HeadEngine:
 
     def _enqueue_heads(self, ws, R, dt):
         # a14: every per-layer cls / reg branch + the reference-point tail in ONE launch (row-block fused)
-        ops.heads_fused(ws['outs'], self.cls_ptrs, self.reg_ptrs, ws['ref'], ws['cls'], ws['reg'], R, self.L, self.pc_range_h, dt,
-                        dt_rows=ws['dt_rows'] if (self.kind == 'T' and ws['B'] > 1) else None)
+        dt_rows = ws['dt_rows'] if (self.kind == 'T' and ws['B'] > 1) else None
+        if self.heads_x3:
+            ops.heads_fused_x3(ws['outs'], self.cls_ptrs_x3, self.reg_ptrs_x3, ws['ref'], ws['cls'], ws['reg'], R, self.L, self.pc_range_h, dt,
+                               dt_rows=dt_rows)
+        else:
+            ops.heads_fused(ws['outs'], self.cls_ptrs, self.reg_ptrs, ws['ref'], ws['cls'], ws['reg'], R, self.L, self.pc_range_h, dt,
+                            dt_rows=dt_rows)
 
     def _result(self, ws, R, keep_stages=False, batch=False):
         sel = (lambda t: t) if batch else (lambda t: t[0])

@@ -166,6 +166,18 @@ def heads_fused(outs, cls_ptrs, reg_ptrs, ref, cls, reg, M, L, pc_range_host, dt
                                        pc_range_host.data_ptr(), float(dt), _p(dt_rows), _stream()), 'mv2d_heads_fused')
 
 
+def heads_fused_x3(outs, cls_ptrs, reg_ptrs, ref, cls, reg, M, L, pc_range_host, dt=0.0, eps=1e-5, dt_rows=None):
+    """heads_fused with the 256x256 linears in bf16x3; cls_ptrs / reg_ptrs as documented in include/mv2d_hip.h (pack_x3_stack)."""
+    check(_lib.load().mv2d_heads_fused_x3(_p(outs), cls_ptrs, reg_ptrs, _p(ref), _p(cls), _p(reg), M, L, float(eps),
+                                          pc_range_host.data_ptr(), float(dt), _p(dt_rows), _stream()), 'mv2d_heads_fused_x3')
+
+
+def pack_x3_stack(W):
+    """fp32 [L,256,256] -> (hi, lo): per-layer pack_x3 copies stacked, [L, 65536] bf16 each."""
+    packs = [pack_x3(W[l]) for l in range(W.shape[0])]
+    return torch.stack([p[0].view(-1) for p in packs]).contiguous(), torch.stack([p[1].view(-1) for p in packs]).contiguous()
+
+
 def ffn_pack_weights(W1, W2):
     """nn.Linear weights W1 [hidden,256], W2 [256,hidden] -> fragment-major copies (W1p, W2p) for ffn_fused."""
     _req(W1, torch.float32, 'W1'); _req(W2, torch.float32, 'W2')

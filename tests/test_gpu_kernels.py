@@ -158,6 +158,32 @@ def test_heads_fused(dev):
     assert relerr(reg, reg_ref) < 1e-5
 
 
+@pytest.mark.parametrize('M', [77, 531])            # one / two row tiles per block
+def test_heads_fused_x3(dev, M):
+    """prediction branches with the 256x256 linears in bf16x3: fp32-class agreement with the oracle, per-row dt of a batch"""
+    from mv2d_amd import ops
+    from oracle import mv2d_oracle as O
+    sd = synthetic.make_head_state(seed=0)
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    L = 6
+    outs = rnd((L, M, 256), 51)
+    ref = torch.from_numpy(np.random.Generator(np.random.PCG64(52)).random((M, 3)).astype(np.float32)) * 1.4 - 0.2
+    cls_ref, reg_ref = O.pred_heads(sdt, outs, ref)
+    dt_rows = torch.where(torch.arange(M) < 40, 0.5, 0.25).float()
+    reg_ref = torch.cat([reg_ref[..., :8], reg_ref[..., 8:] / dt_rows[None, :, None]], -1)
+    st = lambda fmt: torch.stack([sdt[fmt.format(l)] for l in range(L)]).contiguous().to(dev)
+    c = {n: st('bbox_head.cls_branches.{}.' + n) for n in ('0.weight', '0.bias', '1.weight', '1.bias', '3.weight', '3.bias', '4.weight', '4.bias', '6.weight', '6.bias')}
+    r = {n: st('bbox_head.reg_branches.{}.' + n) for n in ('0.weight', '0.bias', '2.weight', '2.bias', '4.weight', '4.bias')}
+    cw = [*ops.pack_x3_stack(c['0.weight']), c['0.bias'], c['1.weight'], c['1.bias'], *ops.pack_x3_stack(c['3.weight']), c['3.bias'], c['4.weight'],
+          c['4.bias'], c['6.weight'], c['6.bias']]
+    rw = [*ops.pack_x3_stack(r['0.weight']), r['0.bias'], *ops.pack_x3_stack(r['2.weight']), r['2.bias'], r['4.weight'], r['4.bias']]
+    cls = torch.empty((L, M, 10), device=dev); reg = torch.empty((L, M, 10), device=dev)
+    ops.heads_fused_x3(outs.to(dev), ops.make_ptr_array(cw), ops.make_ptr_array(rw), ref.to(dev), cls, reg, M, L,
+                       torch.tensor(O.PC_RANGE, dtype=torch.float32), dt=123.0, dt_rows=dt_rows.to(dev))
+    assert relerr(cls, cls_ref) < 5e-5
+    assert relerr(reg, reg_ref) < 5e-5
+
+
 def test_ffn_fused_exact(dev):
     from mv2d_amd import ops
     for M in (300, 33, 900):
