@@ -132,6 +132,13 @@ int mv2d_heads_fused(const float* outs, const float* const* cls_w, const float* 
                      int M, int L, float eps, const float* pc_range, float dt, const float* dt_rows /* optional [M]: per-row dt of a
                      batch of samples, overrides dt */, void* stream);
 
+/* C[M,N] = act(A[M,K] . W[N,K]^T + bias) in split precision (bf16x3, ~1e-5 relative) for the per-query MLPs (QueryGenerator fcs
+ * RH/utils/query_generator.py:359-381, first self-attention in_proj): LDS-tiled (A chunk shared by 8 column tiles, fragment-major
+ * weights Whi / Wlo = mv2d_split_bf16x2 + mv2d_pack_wfrag_bf16 of W), act 1 = ReLU, clamp > 0 clamps to [-clamp, clamp];
+ * columns >= n_split (multiple of 128) read A2 instead of A. */
+int mv2d_linear_x3(const float* A, const float* A2, int n_split, int lda, const void* Whi, const void* Wlo, const float* bias,
+                   float* C, int ldc, int M, int N, int K, int act, float clamp, void* stream);
+
 /* The same branches with their four 256x256 linears per (layer, branch) in split precision (bf16x3, ~1e-5 relative; the 256 -> 10
  * output layers stay exact fp32).  cls_w = {w0_hi,w0_lo,b0,ln1w,ln1b,w3_hi,w3_lo,b3,ln4w,ln4b,w6,b6}, reg_w = {w0_hi,w0_lo,b0,w2_hi,
  * w2_lo,b2,w4,b4}: every tensor stacked over the L layers, the *_hi/_lo matrices are per-layer mv2d_split_bf16x2 +

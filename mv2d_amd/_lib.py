@@ -35,6 +35,7 @@ SIGNATURES = {
     'mv2d_attn_out_fused_x3': (I, [P, P, P, P, P, P, P, P, P, P, P, P, F, P, I, F, P]),
     'mv2d_pack_wfrag_f32': (I, [P, P, I, I, I, P]),
     'mv2d_heads_fused': (I, [P, P, P, P, P, P, I, I, F, P, F, P, P]),
+    'mv2d_linear_x3': (I, [P, P, I, I, P, P, P, P, I, I, I, I, I, F, P]),
     'mv2d_heads_fused_x3': (I, [P, P, P, P, P, P, I, I, F, P, F, P, P]),
     'mv2d_ffn_fused': (I, [P, P, P, P, P, I, I, P]),
     'mv2d_ffn_pack_weights': (I, [P, P, P, P, I, P]),

@@ -771,6 +771,108 @@ __global__ void pack_wfrag_f32_kernel(const float* __restrict__ W, float* __rest
 }
 
 
+// Plain linear layer C = act(A . W^T + b) in split precision for the per-query MLPs with several hundred to a few thousand rows
+// (query generator: 256 -> 1024, 1056 -> 512, 512 -> 256; first self-attention in_proj): the per-wave-tile kernels (gemm_f32 /
+// gemm_x3: no LDS, every 16x16 tile fetches its own operands) are latency kernels for a few hundred rows and L2-bound beyond.
+// Block = RT x 16 rows x 128 columns, 8 waves (wave w = column tile w for all row tiles); K runs in chunks of 256: the fp32 A chunk
+// is split into bf16 hi / lo LDS images (double buffered), the fragment-major weight chunk (hi, lo) sits in registers, both are
+// requested one chunk ahead.  Columns >= n_split read A2 instead of A (in_proj of (q, k | v) from two inputs).
+struct LinX3Params {
+    const float* A; const float* A2; int n_split; int lda; const unsigned short* Wh; const unsigned short* Wl; const float* bias;
+    float* C; int ldc; int M, N, K; int act; float clamp;
+};
+
+template <int RT>
+__global__ __launch_bounds__(512) void linear_x3_kernel(LinX3Params p) {
+    __shared__ __attribute__((aligned(16))) unsigned char ah[2][RT * 16 * 512], al[2][RT * 16 * 512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int mb = blockIdx.y * (16 * RT), n0 = blockIdx.x * 128;
+    const int ntile = p.N >> 4, tile = min((n0 >> 4) + wave, ntile - 1);       // clamped: the extra waves of a ragged last block recompute
+    const float* A = (p.n_split > 0 && n0 >= p.n_split) ? p.A2 : p.A;
+    const int nchunk = (p.K + 255) >> 8;
+    constexpr int NA = RT * 2;                                                  // float4 per thread and chunk
+    float4 ar[NA];
+    BFrag wh[8], wl[8], wh2[8], wl2[8];
+    auto load_a = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = tid + 512 * i, row = idx >> 6, q = idx & 63, k = 256 * c + 4 * q;
+            ar[i] = k < p.K ? *reinterpret_cast<const float4*>(A + (long long)min(mb + row, p.M - 1) * p.lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = tid + 512 * i, row = idx >> 6, q = idx & 63;
+            const int off = row * 512 + (((q >> 1) ^ (row & 15)) << 4) + (q & 1) * 8;
+            uint2 hi, lo;
+            split4(ar[i], hi, lo);
+            *reinterpret_cast<uint2*>(ah[buf] + off) = hi;
+            *reinterpret_cast<uint2*>(al[buf] + off) = lo;
+        }
+    };
+    auto load_w = [&](BFrag (&h)[8], BFrag (&l)[8], int c) {
+        const int ns = min(8, (p.K - 256 * c) >> 5);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s < ns) {                                                       // fragment-major [K/32][N/16][lane][8]
+                const long long o = (((long long)(8 * c + s) * ntile + tile) * 64 + lane) * 8;
+                h[s].u = *reinterpret_cast<const uint4*>(p.Wh + o);
+                l[s].u = *reinterpret_cast<const uint4*>(p.Wl + o);
+            }
+        }
+    };
+    load_a(0);
+    load_w(wh, wl, 0);
+    store_a(0);
+    __syncthreads();
+    f32x4_t a0[RT], a1[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) { a0[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; a1[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    for (int c = 0; c < nchunk; ++c) {
+        const bool more = c + 1 < nchunk;
+        if (more) { load_a(c + 1); load_w(wh2, wl2, c + 1); }
+        const int ns = min(8, (p.K - 256 * c) >> 5);
+        const unsigned char* bh = ah[c & 1];
+        const unsigned char* bl = al[c & 1];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s < ns) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    BFrag xh, xl;
+                    const int off = t * 8192 + fr * 512 + (((4 * s + fg) ^ fr) << 4);
+                    xh.u = *reinterpret_cast<const uint4*>(bh + off);
+                    xl.u = *reinterpret_cast<const uint4*>(bl + off);
+                    a0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh.v, wh[s].v, a0[t], 0, 0, 0);
+                    a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl.v, wh[s].v, a1[t], 0, 0, 0);
+                    a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh.v, wl[s].v, a1[t], 0, 0, 0);
+                }
+            }
+        }
+        if (more) {
+            store_a((c + 1) & 1);              // the other buffer: its last readers passed the previous barrier
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 8; ++s) { wh[s] = wh2[s]; wl[s] = wl2[s]; }
+        }
+    }
+    const int col = tile * 16 + fr;
+    if ((n0 >> 4) + wave >= ntile) return;
+    const float b = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mb + 16 * t + 4 * fg + r;
+            if (m >= p.M) continue;
+            float v = (a0[t][r] + a1[t][r]) + b;
+            if (p.act == 1) v = relu_f(v);
+            if (p.clamp > 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
+            p.C[(long long)m * p.ldc + col] = v;
+        }
+}
+
 // The prediction branches in split precision (bf16x3): same chain as heads_fused_kernel with the four 256x256 linears of a
 // (layer, branch) on v_mfma_f32_16x16x32_bf16 (hi/lo pairs, ~1e-5 relative), 16 waves per block: wave w owns column tile w of a
 // linear and row w of the LayerNorm / ReLU stage; the 256 -> 10 output layer stays exact fp32.  (Profile of a 4-sample batch: the
@@ -1005,6 +1107,20 @@ extern "C" int mv2d_heads_fused_x3(const float* outs, const void* const* cls_w, 
     if (M <= 512) hipLaunchKernelGGL(heads_fused_x3_kernel<1>, dim3(cdiv(M, 16), L, 2), dim3(1024), 0, (hipStream_t)stream, p);
     else if (M <= 1024) hipLaunchKernelGGL(heads_fused_x3_kernel<2>, dim3(cdiv(M, 32), L, 2), dim3(1024), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(heads_fused_x3_kernel<4>, dim3(cdiv(M, 64), L, 2), dim3(1024), 0, (hipStream_t)stream, p);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_linear_x3(const float* A, const float* A2, int n_split, int lda, const void* Whi, const void* Wlo, const float* bias,
+                              float* C, int ldc, int M, int N, int K, int act, float clamp, void* stream) {
+    MV2D_CHECK_ARG(A && Whi && Wlo && C, "mv2d_linear_x3: null pointer");
+    MV2D_CHECK_ARG(M >= 0 && N > 0 && (N % 16) == 0 && K > 0 && (K % 32) == 0, "mv2d_linear_x3: N % 16 == 0 and K % 32 == 0 required");
+    MV2D_CHECK_ARG((lda % 4) == 0 && lda >= K && ldc >= N && ((uintptr_t)A & 15) == 0, "mv2d_linear_x3: A rows must be 16-byte aligned");
+    MV2D_CHECK_ARG(n_split == 0 || (A2 && (n_split % 128) == 0 && ((uintptr_t)A2 & 15) == 0), "mv2d_linear_x3: n_split must be a multiple of 128 with A2 set");
+    if (M == 0) return MV2D_OK;
+    LinX3Params p{A, A2, n_split, lda, (const unsigned short*)Whi, (const unsigned short*)Wlo, bias, C, ldc, M, N, K, act, clamp};
+    if (M <= 512) hipLaunchKernelGGL(linear_x3_kernel<1>, dim3(cdiv(N, 128), cdiv(M, 16)), dim3(512), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(linear_x3_kernel<2>, dim3(cdiv(N, 128), cdiv(M, 32)), dim3(512), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

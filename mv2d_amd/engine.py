@@ -80,6 +80,7 @@ class HeadEngine:
         # self-attention core inside the row-fused kernel: measured SLOWER (decoder 0.357 -> 0.432 ms: the fp32 MFMAs of 152 attention
         # blocks land on 19 CUs) -> off; kept as an ABI entry / A-B switch
         self.sa_fused = os.environ.get('MV2D_SA_FUSED', '0') == '1'
+        self.qg_x3 = os.environ.get('MV2D_QG_X3', '1') == '1'          # query-generator fcs + first in_proj as LDS-tiled bf16x3 linears (0: exact fp32)
         self.heads_x3 = os.environ.get('MV2D_HEADS_X3', '1') == '1'    # prediction branches in bf16x3 (0: exact fp32)
         self.load_state(state_dict)
 
@@ -144,6 +145,9 @@ class HeadEngine:
         w['qg_e0_w'], w['qg_e0_b'] = e0p, g(q + 'extra_enc.0.bias')
         w['qg_e2_w'], w['qg_e2_b'] = g(q + 'extra_enc.2.weight'), g(q + 'extra_enc.2.bias')
         w['qg_c_w'], w['qg_c_b'] = g(q + 'fc_center.weight'), g(q + 'fc_center.bias')
+        if self.qg_x3:                                                                # LDS-tiled bf16x3 linears (mv2d_linear_x3)
+            for k in ('qg_fc_w', 'qg_e0_w', 'qg_e2_w'):
+                w[k + 'x'] = ops.pack_x3(w[k])
         pe = 'position_encoding.'
         c1 = lambda k: g(pe + k).flatten(1)
         w['pe_w1a'], w['pe_b1a'] = b16(c1('position_encoder.0.weight')), g(pe + 'position_encoder.0.bias')
@@ -493,9 +497,14 @@ class HeadEngine:
         tk('qg_conv_gemm')
         o.qg_conv_pool(ws['roi_feat'], W_['qg_conv_wp'], W_['qg_conv_b'], ws['x2'], R=R)
         tk('qg_rest')
-        o.gemm_f32(ws['x2'], W_['qg_fc_w'], W_['qg_fc_b'], act=1, clamp=5e3, out=ws['enc'], ldc=1056)
-        o.gemm_f32(ws['enc'], W_['qg_e0_w'], W_['qg_e0_b'], act=1, out=ws['enc1'])
-        o.gemm_f32(ws['enc1'], W_['qg_e2_w'], W_['qg_e2_b'], act=1, out=ws['enc2'])
+        if self.qg_x3:
+            o.linear_x3(ws['x2'], W_['qg_fc_wx'], W_['qg_fc_b'], N=1024, K=256, act=1, clamp=5e3, out=ws['enc'], ldc=1056, M=R)
+            o.linear_x3(ws['enc'], W_['qg_e0_wx'], W_['qg_e0_b'], N=512, K=1056, act=1, out=ws['enc1'], M=R)
+            o.linear_x3(ws['enc1'], W_['qg_e2_wx'], W_['qg_e2_b'], N=256, K=512, act=1, out=ws['enc2'], M=R)
+        else:
+            o.gemm_f32(ws['x2'], W_['qg_fc_w'], W_['qg_fc_b'], act=1, clamp=5e3, out=ws['enc'], ldc=1056)
+            o.gemm_f32(ws['enc'], W_['qg_e0_w'], W_['qg_e0_b'], act=1, out=ws['enc1'])
+            o.gemm_f32(ws['enc1'], W_['qg_e2_w'], W_['qg_e2_b'], act=1, out=ws['enc2'])
         if self.rows_x3:
             # fc_center + reference points + pos2posemb3d + query_embedding in one row-fused kernel
             o.query_embed_fused_x3(ws['enc2'], W_['qg_c_w'], W_['qg_c_b'], ws['minv'], self.const['dim_t'], self.pc_range_h, W_['qe_w0x'],
@@ -516,7 +525,9 @@ class HeadEngine:
         xq.copy_(ws['qpos'])
         fuse_tail = self.fuse_rows and self.rows_x3          # FFN tail + next layer's in_proj as one row-fused kernel
         for i in range(L):
-            if i == 0 or not fuse_tail:
+            if i == 0 and self.qg_x3:
+                o.linear_x3(xq, W_['sa_in_wx0'], W_['sa_in_b0'], N=3 * C, K=C, A2=x, n_split=2 * C, out=ws['qkv'], M=R)
+            elif i == 0 or not fuse_tail:
                 o.gemm_f32(xq, W_[f'sa_in_w{i}'], W_[f'sa_in_b{i}'], A2=x, n_split=2 * C, out=ws['qkv'])
             sa_fused = self.fuse_rows and self.rows_x3 and self.sa_fused
             if not sa_fused:
@@ -541,9 +552,10 @@ class HeadEngine:
                 o.row_ln(ws['o'], residual=ws['x1'], ln=(W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), out=ws['x2'])
             parts = ws['parts']
             if self.ffn_x3:
-                # two hidden slices accumulated per block (half the slabs to write and re-read) pay off for one sample (decoder 0.361 ->
-                # 0.344 ms at R = 300); with a batch (R = 1200) the one-block-per-CU variant loses what the slab traffic saves
-                G = self.ffn_groups if self.ffn_groups else (2 if R <= 400 else 1)
+                # hidden slices accumulated per block (fewer slabs to write and re-read): G = 2 pays off for one sample (decoder 0.361 ->
+                # 0.344 ms at R = 300), with a batch (R = 1200) the one-block-per-CU variant loses what the slab traffic saves.  It
+                # changes the summation order, so it is not chosen by the row count: a sample's result must not depend on the batch.
+                G = self.ffn_groups if self.ffn_groups else 1
                 parts = parts[:parts.shape[0] // G]
                 o.ffn_fused_x3(ws['x2'], W_[f'ffn_w1x{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2x{i}'], parts, R, groups=G)
             else:

@@ -166,6 +166,17 @@ def heads_fused(outs, cls_ptrs, reg_ptrs, ref, cls, reg, M, L, pc_range_host, dt
                                        pc_range_host.data_ptr(), float(dt), _p(dt_rows), _stream()), 'mv2d_heads_fused')
 
 
+def linear_x3(A, W_x3, bias=None, *, N, K, A2=None, n_split=0, act=0, clamp=0.0, out=None, M=None, lda=None, ldc=None):
+    """out = act(A @ W.T + bias) in bf16x3; W_x3 = pack_x3(W) of the [N,K] weight (K % 32 == 0, N % 16 == 0)."""
+    _req(A, torch.float32, 'A'); _req(A2, torch.float32, 'A2'); _req(bias, torch.float32, 'bias')
+    M = A.shape[0] if M is None else M
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    check(_lib.load().mv2d_linear_x3(_p(A), _p(A2), n_split, A.stride(0) if lda is None else lda, _p(W_x3[0]), _p(W_x3[1]), _p(bias), _p(out),
+                                     out.stride(0) if ldc is None else ldc, M, N, K, act, float(clamp), _stream()), 'mv2d_linear_x3')
+    return out
+
+
 def heads_fused_x3(outs, cls_ptrs, reg_ptrs, ref, cls, reg, M, L, pc_range_host, dt=0.0, eps=1e-5, dt_rows=None):
     """heads_fused with the 256x256 linears in bf16x3; cls_ptrs / reg_ptrs as documented in include/mv2d_hip.h (pack_x3_stack)."""
     check(_lib.load().mv2d_heads_fused_x3(_p(outs), cls_ptrs, reg_ptrs, _p(ref), _p(cls), _p(reg), M, L, float(eps),

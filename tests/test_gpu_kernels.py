@@ -184,6 +184,26 @@ def test_heads_fused_x3(dev, M):
     assert relerr(reg, reg_ref) < 5e-5
 
 
+@pytest.mark.parametrize('M,N,K', [(300, 1024, 256), (1200, 512, 1056), (77, 256, 512), (531, 768, 256), (1, 16, 32)])
+def test_linear_x3(dev, M, N, K):
+    """LDS-tiled bf16x3 linear: fp32-class agreement with fp64, ReLU / clamp epilogue, leading dimensions, ragged edges, two inputs"""
+    from mv2d_amd import ops
+    A = rnd((M, K), 61).to(dev); A2 = rnd((M, K), 62).to(dev)
+    W = rnd((N, K), 63, 0.1).to(dev); b = rnd((N,), 64).to(dev)
+    Wx = ops.pack_x3(W)
+    ref = A.double() @ W.double().T + b.double()
+    out = ops.linear_x3(A, Wx, b, N=N, K=K)
+    assert relerr(out, ref) < 3e-5
+    big = torch.full((M, N + 40), 7.0, device=dev)
+    ops.linear_x3(A, Wx, b, N=N, K=K, act=1, clamp=1.5, out=big, ldc=N + 40)
+    err = float((big[:, :N].double() - ref.relu().clamp(max=1.5)).abs().max() / ref.abs().max())       # error relative to the pre-clamp scale
+    assert err < 3e-5 and bool((big[:, N:] == 7.0).all())
+    if N % 256 == 0:
+        out2 = ops.linear_x3(A, Wx, b, N=N, K=K, A2=A2, n_split=N // 2)
+        ref2 = torch.cat([ref[:, :N // 2], (A2.double() @ W.double().T + b.double())[:, N // 2:]], 1)
+        assert relerr(out2, ref2) < 3e-5
+
+
 def test_ffn_fused_exact(dev):
     from mv2d_amd import ops
     for M in (300, 33, 900):
