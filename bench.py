@@ -72,7 +72,7 @@ def main():
     args = ap.parse_args()
 
     from mv2d_amd import dist as mdist
-    from mv2d_amd import synthetic
+    from mv2d_amd import ops, synthetic
     from mv2d_amd.engine import HeadEngine
     import torch.distributed as dist
 
@@ -104,7 +104,8 @@ def main():
     B = args.batch
     if B > 1:                                                      # the samples of a batch are different frames
         more = [synthetic.make_problem(args.workload, seed=1000 * (b + 1) + rank) for b in range(B - 1)]
-        feats_b = [feat] + [torch.from_numpy(m['feat']).to(dev) for m in more]
+        # the producer (backbone + neck of a batch) hands over one stacked [B*V,256,h,w] map
+        feats_b = torch.cat([feat] + [torch.from_numpy(m['feat']).to(dev) for m in more], 0).contiguous()
         props_b = [props] + [[torch.from_numpy(p) for p in m['proposals']] for m in more]
         metas_b = [metas] + [m['img_metas'] for m in more]
     use_graph = not args.no_graph
@@ -125,10 +126,9 @@ def main():
                     s.wait_event(gathered_ev[k])
                 if B > 1:
                     o = e.run_batch(feats_b, props_b, metas_b, use_graph=use_graph)
-                    payload[k][i * B:(i + 1) * B].copy_(mdist.pack_detections_batch(o['boxes'], o['scores'], o['labels'], o['count']))
                 else:
                     o = e.run(feat, props, metas, use_graph=use_graph)
-                    payload[k][i].copy_(mdist.pack_detections(o['boxes'], o['scores'], o['labels'], o['count']))
+                ops.pack_detections(o['boxes'], o['scores'], o['labels'], o['count'], payload[k][i * B:(i + 1) * B])
                 if collective:
                     ev = torch.cuda.Event()
                     ev.record()

@@ -299,6 +299,12 @@ int mv2d_result_pack(const float* boxes, const float* scores, const long long* l
                      int n_samples /* inputs [n_samples][in_stride], count [n_samples]; outputs [n_samples][max_num] */, int in_stride,
                      void* stream);
 
+/* Wire format of the evaluation step's all-gather of decoded boxes (replaces multi_gpu_test's pickle / tmpdir collection,
+ * tools/test.py:249-250): out [n_samples][max_num*11 + 1] fp32 = max_num rows of (box[9], score, label), rows >= count zeroed, then
+ * the count.  in: boxes [n_samples][in_stride][9], scores / labels [n_samples][in_stride], count [n_samples]. */
+int mv2d_pack_detections(const float* boxes, const float* scores, const long long* labels, const int* count, float* out, int n_samples,
+                         int max_num, int in_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

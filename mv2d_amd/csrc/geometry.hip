@@ -346,64 +346,72 @@ __global__ __launch_bounds__(64) void csr_mark_kernel(const float* __restrict__ 
     }
 }
 
-// single block: pos2s[P] = index into the compacted key list or -1 (not in any RoI rect, or padding),
+// pos2s[P] = index into the compacted key list or -1 (not in any RoI rect, or padding),
 // s2pos[S] = flat (v,y,x) position, *S = count.  Row-major (v,y,x) order like the reference's boolean indexing.
-// Every thread owns 64 consecutive cells per sweep (4 x 16-byte mask loads, 16 x 16-byte pos2s stores): one sweep and one
-// block-wide scan cover P <= 65536 map positions (cfg 5: 48000).
+// One block per segment of SCAN_SEG cells: a block first counts the kept cells of all earlier segments itself (a few KB of mask
+// bytes per thread-block, cheaper than a second launch or a look-back chain), then scans its own segment.  (A batch of 4 samples
+// is P = 67584 cells: the single-block version of round 1 took 40 us there.)
+constexpr int SCAN_SEG = 16384, SCAN_CPT = 16;      // cells per block and per thread
+
+__device__ __forceinline__ unsigned int kept16(const unsigned char* __restrict__ roi_mask, const unsigned char* __restrict__ pad_mask, int j0, int P,
+                                               bool vec_ok) {
+    unsigned int bits = 0u;
+    if (vec_ok && j0 + 15 < P) {
+        const uint4 a = *reinterpret_cast<const uint4*>(roi_mask + j0);
+        const uint4 b = *reinterpret_cast<const uint4*>(pad_mask + j0);
+        const unsigned int aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const unsigned int ra = (aw[k >> 2] >> ((k & 3) * 8)) & 0xffu, pb = (bw[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+            bits |= ((ra != 0u && pb == 0u) ? 1u : 0u) << k;
+        }
+    } else {
+        for (int k = 0; k < 16; ++k) { const int i = j0 + k; if (i < P && roi_mask[i] && !pad_mask[i]) bits |= 1u << k; }
+    }
+    return bits;
+}
+
 __global__ __launch_bounds__(1024) void csr_scan_positions_kernel(const unsigned char* __restrict__ roi_mask, const unsigned char* __restrict__ pad_mask,
                                                                   int* __restrict__ pos2s, int* __restrict__ s2pos, int* __restrict__ S_out, int P) {
     __shared__ int wsum[16];
     __shared__ int carry;
-    constexpr int CPT = 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
+    const int seg0 = blockIdx.x * SCAN_SEG;
     const bool vec_ok = (P & 15) == 0 && ((uintptr_t)roi_mask & 15) == 0 && ((uintptr_t)pad_mask & 15) == 0 && ((uintptr_t)pos2s & 15) == 0;
-    for (int base = 0; base < P; base += 1024 * CPT) {
-        const int i0 = base + tid * CPT;
-        unsigned long long bits = 0ull;
+    // ---- kept cells before this segment
+    int before = 0;
+    for (int j0 = tid * 16; j0 < seg0; j0 += 1024 * 16) before += __popc(kept16(roi_mask, pad_mask, j0, P, vec_ok));
+    before = (int)wave_sum((float)before);               // counts < 2^24: exact in fp32
+    if (lane == 0) wsum[wv] = before;
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; carry = t; }
+    __syncthreads();
+    // ---- this segment: 16 cells per thread
+    const int i0 = seg0 + tid * SCAN_CPT;
+    const unsigned int bits = i0 < P ? kept16(roi_mask, pad_mask, i0, P, vec_ok) : 0u;
+    const int cnt = __popc(bits);
+    int sc = cnt;                                        // inclusive wave scan
 #pragma unroll
-        for (int c = 0; c < CPT / 16; ++c) {
-            const int j0 = i0 + 16 * c;
-            if (vec_ok && j0 + 15 < P) {
-                const uint4 a = *reinterpret_cast<const uint4*>(roi_mask + j0);
-                const uint4 b = *reinterpret_cast<const uint4*>(pad_mask + j0);
-                const unsigned int aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(sc, o, 64); if (lane >= o) sc += t; }
+    __syncthreads();                                     // wsum is reused
+    if (lane == 63) wsum[wv] = sc;
+    __syncthreads();
+    int off = carry + sc - cnt;
+    for (int k = 0; k < wv; ++k) off += wsum[k];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const unsigned int ra = (aw[k >> 2] >> ((k & 3) * 8)) & 0xffu, pb = (bw[k >> 2] >> ((k & 3) * 8)) & 0xffu;
-                    bits |= (unsigned long long)((ra != 0u && pb == 0u) ? 1u : 0u) << (16 * c + k);
-                }
-            } else {
-                for (int k = 0; k < 16; ++k) { const int i = j0 + k; if (i < P && roi_mask[i] && !pad_mask[i]) bits |= 1ull << (16 * c + k); }
-            }
+    for (int c = 0; c < SCAN_CPT / 4; ++c) {
+        const int j0 = i0 + 4 * c;
+        int v4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool f = (bits >> (4 * c + k)) & 1u;
+            v4[k] = f ? off : -1;
+            if (f) { s2pos[off] = j0 + k; ++off; }
         }
-        const int cnt = __popcll(bits);
-        int sc = cnt;                                        // inclusive wave scan
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(sc, o, 64); if (lane >= o) sc += t; }
-        if (lane == 63) wsum[wv] = sc;
-        __syncthreads();
-        int off = carry + sc - cnt;
-        for (int k = 0; k < wv; ++k) off += wsum[k];
-#pragma unroll
-        for (int c = 0; c < CPT / 4; ++c) {
-            const int j0 = i0 + 4 * c;
-            int v4[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bool f = (bits >> (4 * c + k)) & 1ull;
-                v4[k] = f ? off : -1;
-                if (f) { s2pos[off] = j0 + k; ++off; }
-            }
-            if (vec_ok && j0 + 3 < P) *reinterpret_cast<int4*>(pos2s + j0) = make_int4(v4[0], v4[1], v4[2], v4[3]);
-            else for (int k = 0; k < 4; ++k) if (j0 + k < P) pos2s[j0 + k] = v4[k];
-        }
-        __syncthreads();
-        if (tid == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; carry += t; }
-        __syncthreads();
+        if (vec_ok && j0 + 3 < P) *reinterpret_cast<int4*>(pos2s + j0) = make_int4(v4[0], v4[1], v4[2], v4[3]);
+        else for (int k = 0; k < 4; ++k) if (j0 + k < P) pos2s[j0 + k] = v4[k];
     }
-    if (tid == 0) *S_out = carry;
+    if (blockIdx.x == gridDim.x - 1 && tid == 1023) *S_out = off;          // the last thread of the last segment ends at the total
 }
 
 // per query: OR the rects of (self + matched RoIs) into an LDS bitmask over P cells, drop cells that are not
@@ -747,6 +755,22 @@ __global__ __launch_bounds__(1024) void result_pack_kernel(const float* __restri
     if (tid == 0) *out_count = min(total, max_num);
 }
 
+// wire format of the per-step all-gather of decoded boxes (mv2d_amd/dist.py): per sample max_num rows of (box[9], score, label) as
+// fp32, rows >= count zeroed, then the count
+__global__ __launch_bounds__(256) void pack_detections_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, const long long* __restrict__ labels,
+                                                              const int* __restrict__ count, float* __restrict__ out, int max_num, int in_stride) {
+    const long long g = blockIdx.x;
+    const int n = min(count[g], max_num);
+    float* o = out + g * ((long long)max_num * 11 + 1);
+    for (int i = threadIdx.x; i < max_num * 11; i += 256) {
+        const int r = i / 11, c = i - r * 11;
+        float v = 0.f;
+        if (r < n) v = c < 9 ? boxes[(g * in_stride + r) * 9 + c] : (c == 9 ? scores[g * in_stride + r] : (float)labels[g * in_stride + r]);
+        o[i] = v;
+    }
+    if (threadIdx.x == 0) o[(long long)max_num * 11] = (float)count[g];
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -832,7 +856,7 @@ extern "C" int mv2d_mask_compact(const float* rois, const int* match, const unsi
     const int P = n_samples * V * h * w;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(csr_mark_kernel, dim3(R), dim3(64), 0, st, rois, rect, roi_mask, h, w, stride, expand_stride);
-    hipLaunchKernelGGL(csr_scan_positions_kernel, dim3(1), dim3(1024), 0, st, roi_mask, pad_mask, pos2s, s2pos, S_out, P);
+    hipLaunchKernelGGL(csr_scan_positions_kernel, dim3(cdiv(P, SCAN_SEG)), dim3(1024), 0, st, roi_mask, pad_mask, pos2s, s2pos, S_out, P);
     const int nwords = csr_words(V, h, w);
     hipLaunchKernelGGL(csr_count_kernel, dim3(R), dim3(256), nwords * 4, st, rect, match, pos2s, bits_ws, row_count, h, w, V, topk, nwords);
     hipLaunchKernelGGL(csr_fill_kernel, dim3(R), dim3(256), 0, st, bits_ws, row_count, pos2s, rect, row_ptr, col_idx, nnz_out, R, nwords,
@@ -847,7 +871,7 @@ extern "C" int mv2d_roi_positions(const float* rois, const unsigned char* pad_ma
     MV2D_CHECK_ARG(rois && pad_mask && roi_mask && rect && pos2s && s2pos && S_out && R > 0, "mv2d_roi_positions: bad args");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(csr_mark_kernel, dim3(R), dim3(64), 0, st, rois, rect, roi_mask, h, w, stride, expand_stride);
-    hipLaunchKernelGGL(csr_scan_positions_kernel, dim3(1), dim3(1024), 0, st, roi_mask, pad_mask, pos2s, s2pos, S_out, V * h * w);
+    hipLaunchKernelGGL(csr_scan_positions_kernel, dim3(cdiv(V * h * w, SCAN_SEG)), dim3(1024), 0, st, roi_mask, pad_mask, pos2s, s2pos, S_out, V * h * w);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
@@ -906,6 +930,14 @@ extern "C" int mv2d_decode_topk(const float* cls, const float* reg, int R, int n
     hipLaunchKernelGGL(decode_topk_kernel, dim3(grp_start ? n_grp : 1), dim3(1024), lds, (hipStream_t)stream, cls, reg, R, num_classes, max_num, npow2,
                        post_center_range[0], post_center_range[1], post_center_range[2], post_center_range[3], post_center_range[4],
                        post_center_range[5], boxes, scores, labels, bbox_index, count_out, topk_index_dbg, grp_start);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_pack_detections(const float* boxes, const float* scores, const long long* labels, const int* count, float* out, int n_samples,
+                                    int max_num, int in_stride, void* stream) {
+    MV2D_CHECK_ARG(boxes && scores && labels && count && out && n_samples >= 1 && max_num >= 1 && in_stride >= max_num, "mv2d_pack_detections: bad args");
+    hipLaunchKernelGGL(pack_detections_kernel, dim3(n_samples), dim3(256), 0, (hipStream_t)stream, boxes, scores, labels, count, out, max_num, in_stride);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

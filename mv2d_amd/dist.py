@@ -34,7 +34,8 @@ def shard_samples(num_samples, rank, world):
 
 
 def pack_detections(boxes, scores, labels, count, max_num=300):
-    """(boxes [max_num,9], scores [max_num], labels [max_num] int64, count [1] int32) -> [max_num*11 + 1] fp32."""
+    """(boxes [max_num,9], scores [max_num], labels [max_num] int64, count [1] int32) -> [max_num*11 + 1] fp32.
+    (torch formulation: CPU / gloo tests; on the GPU the same payload comes from one launch of mv2d_pack_detections)"""
     rows = torch.cat([boxes[:max_num], scores[:max_num, None], labels[:max_num, None].to(boxes.dtype)], 1)
     valid = (torch.arange(max_num, device=boxes.device) < count.to(torch.int64)).to(boxes.dtype)[:, None]
     return torch.cat([(rows * valid).reshape(-1), count.to(boxes.dtype).reshape(1)])

@@ -281,6 +281,7 @@ class HeadEngine:
         ws['KV'] = e((2 * L, ws['S_kv'], C), BF16)
         for n in ('x', 'xq', 'x1', 'x1q', 'x2', 'ctx', 'o', 'q'):
             ws[n] = e((R, C))
+        ws['zero_rows'] = z((R, C))                              # never written
         ws['qkv'] = e((R, 3 * C)); ws['parts'] = e((2048 // 64, R, C)); ws['outs'] = e((L, R, C))
         ws['cls'] = e((L, R, 10)); ws['reg'] = e((L, R, 10))
         ws['boxes'] = z((B, self.max_num, 9)); ws['scores'] = z((B, self.max_num))
@@ -521,31 +522,39 @@ class HeadEngine:
         the "decoder ms/iter" half of the headline metric."""
         o, W_, L = ops, self.w, self.L
         x, xq = ws['x'], ws['xq']
-        x.zero_()
-        xq.copy_(ws['qpos'])
         fuse_tail = self.fuse_rows and self.rows_x3          # FFN tail + next layer's in_proj as one row-fused kernel
+        if fuse_tail:
+            # the decoder starts from target = 0 (cross_attention_head.py:32): layer 0 reads a constant zero buffer and qpos
+            # directly, from layer 1 on x / xq are the buffers the fused FFN tail writes
+            x_in, xq_in = ws['zero_rows'], ws['qpos']
+        else:
+            x.zero_()
+            xq.copy_(ws['qpos'])
+            x_in, xq_in = x, xq
         for i in range(L):
+            if i == 1:
+                x_in, xq_in = x, xq
             if i == 0 and self.qg_x3:
-                o.linear_x3(xq, W_['sa_in_wx0'], W_['sa_in_b0'], N=3 * C, K=C, A2=x, n_split=2 * C, out=ws['qkv'], M=R)
+                o.linear_x3(xq_in, W_['sa_in_wx0'], W_['sa_in_b0'], N=3 * C, K=C, A2=x_in, n_split=2 * C, out=ws['qkv'], M=R)
             elif i == 0 or not fuse_tail:
-                o.gemm_f32(xq, W_[f'sa_in_w{i}'], W_[f'sa_in_b{i}'], A2=x, n_split=2 * C, out=ws['qkv'])
+                o.gemm_f32(xq_in, W_[f'sa_in_w{i}'], W_[f'sa_in_b{i}'], A2=x_in, n_split=2 * C, out=ws['qkv'], M=R)
             sa_fused = self.fuse_rows and self.rows_x3 and self.sa_fused
             if not sa_fused:
                 o.self_attn(ws['qkv'], ws['ctx'], R, grp_start=ws['grp_start'] if ws['B'] > 1 else None)
             if self.fuse_rows and self.rows_x3:
                 sa_tail = o.sa_block_fused_x3 if sa_fused else o.attn_out_fused_x3      # self-attention core inside the row kernel, or not
-                sa_tail(ws['qkv'] if sa_fused else ws['ctx'], x, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
+                sa_tail(ws['qkv'] if sa_fused else ws['ctx'], x_in, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
                         qpos=ws['qpos'], Wq_x3=W_[f'ca_q_wx{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, q_out=ws['q'], M=R)
                 o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R, empty_nan=self.empty_nan)
                 o.attn_out_fused_x3(ws['ctx'], ws['x1'], W_[f'ca_out_wx{i}'], W_[f'ca_out_b{i}'], (W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), ws['x2'], M=R)
             elif self.fuse_rows:
-                o.attn_out_fused(ws['ctx'], x, W_[f'sa_out_w{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
+                o.attn_out_fused(ws['ctx'], x_in, W_[f'sa_out_w{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
                                  qpos=ws['qpos'], Wq=W_[f'ca_q_w{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, q_out=ws['q'], M=R)
                 o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R, empty_nan=self.empty_nan)
                 o.attn_out_fused(ws['ctx'], ws['x1'], W_[f'ca_out_w{i}'], W_[f'ca_out_b{i}'], (W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), ws['x2'], M=R)
             else:
                 o.gemm_f32(ws['ctx'], W_[f'sa_out_w{i}'], W_[f'sa_out_b{i}'], out=ws['o'])
-                o.row_ln(ws['o'], residual=x, ln=(W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), out=ws['x1'], addvec=ws['qpos'], out_plus=ws['x1q'])
+                o.row_ln(ws['o'], residual=x_in, ln=(W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), out=ws['x1'], addvec=ws['qpos'], out_plus=ws['x1q'])
                 o.gemm_f32(ws['x1q'], W_[f'ca_q_w{i}'], W_[f'ca_q_b{i}'], scale=ops.SCALE_Q, out=ws['q'])
                 o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R, empty_nan=self.empty_nan)
                 o.gemm_f32(ws['ctx'], W_[f'ca_out_w{i}'], W_[f'ca_out_b{i}'], out=ws['o'])

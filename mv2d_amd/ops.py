@@ -470,4 +470,13 @@ def result_pack(boxes, scores, labels, count, score_thr, max_num, out_boxes, out
                                        _p(out_labels), _p(out_count), n_samples, in_stride, _stream()), 'mv2d_result_pack')
 
 
+def pack_detections(boxes, scores, labels, count, out, max_num=300):
+    """boxes [n,M,9] (or [M,9]), scores, labels int64, count [n] int32 -> out [n, max_num*11 + 1] fp32 (the all-gather payload)."""
+    n = count.numel()
+    in_stride = scores.shape[-1]
+    check(_lib.load().mv2d_pack_detections(_p(boxes), _p(scores), _p(labels), _p(count), _p(out), n, max_num, in_stride, _stream()),
+          'mv2d_pack_detections')
+    return out
+
+
 SCALE_Q = 1.0 / math.sqrt(32.0)

@@ -216,3 +216,20 @@ def test_neck_output_feeds_head_without_transpose():
     r2 = head.simple_test([x[0].contiguous()], props, metas)[0]
     for a, b in zip(r1, r2):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_pack_detections_kernel_equals_torch_formulation():
+    """the all-gather payload from one launch == mv2d_amd.dist.pack_detections_batch (the torch formulation the gloo tests use)"""
+    from mv2d_amd import dist as mdist, ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    B, M = 3, 300
+    boxes = torch.randn(B, M, 9, generator=g).to(dev); scores = torch.rand(B, M, generator=g).to(dev)
+    labels = torch.randint(0, 10, (B, M), generator=g).to(dev); count = torch.tensor([300, 0, 117], dtype=torch.int32, device=dev)
+    out = torch.full((B, M * 11 + 1), -1.0, device=dev)
+    ops.pack_detections(boxes, scores, labels, count, out)
+    assert torch.equal(out, mdist.pack_detections_batch(boxes, scores, labels, count))
+    one = torch.empty((1, M * 11 + 1), device=dev)
+    ops.pack_detections(boxes[2], scores[2], labels[2], count[2:3], one)
+    assert torch.equal(one[0], mdist.pack_detections(boxes[2], scores[2], labels[2], count[2:3]))
