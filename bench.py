@@ -195,7 +195,7 @@ def main():
     traffic, traffic_detail = None, None
     try:
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-        t = pmc.get(args.workload, {}).get(dom)
+        t = pmc.get(f'{args.workload}@{B}', {}).get(dom)              # counters of a launch with the same number of samples
         if t:
             traffic = t['fetch_bytes'] + t['write_bytes']            # HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)
             traffic_detail = {'fetch_bytes': t['fetch_bytes'], 'write_bytes': t['write_bytes'],
