@@ -243,6 +243,34 @@ def test_engine_batch_of_samples_equals_single_runs(kind, name, n):
     assert torch.equal(out['cls'], cls)
 
 
+@pytest.mark.parametrize('kind', ['S', 'T'])
+def test_engine_batch_edge_cases(kind):
+    """A batch mixing the edge cases: a sample without any detection (dummy proposal in ITS first view), a sample with an empty view and a
+    single box, a full sample; 'nan' semantics stay inside the sample that triggers them.  Each sample == its single-sample run."""
+    from mv2d_amd.engine import HeadEngine
+    sd = synthetic.make_head_state(seed=0)
+    dev = torch.device('cuda:0')
+    base = synthetic.make_problem('cfg1_' + kind.lower(), seed=0)
+    full = [torch.from_numpy(p) for p in base['proposals']]
+    none = [p[:0] for p in full]
+    ragged = [full[0][:0], full[1][:1]] + [p[:3] for p in full[2:]]
+    plist = [none, full, ragged, none]
+    metas = [base['img_metas']] * len(plist)
+    feats = [torch.from_numpy(synthetic.make_problem('cfg1_' + kind.lower(), seed=s)['feat']).to(dev) for s in (0, 3, 4, 5)]
+    eng = HeadEngine(sd, kind, dev, num_views=base['views_per_frame'])
+    out = eng.run_batch(feats, plist, metas)
+    grp = out['grp_start'].tolist()
+    assert [grp[i + 1] - grp[i] for i in range(4)] == [1, sum(len(p) for p in full), sum(len(p) for p in ragged), 1]
+    res = eng.results_batch(out)
+    single = HeadEngine(sd, kind, dev, num_views=base['views_per_frame'])
+    for b in range(4):
+        ref = single.run(feats[b], plist[b], metas[b])
+        a, w = out['cls'][:, grp[b]:grp[b + 1]], ref['cls']
+        assert torch.equal(torch.isnan(a), torch.isnan(w)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(w)), b
+        for x, y in zip(res[b], single.results(ref)):
+            assert torch.equal(x, y), b
+
+
 def test_engine_full_size_properties_cfg5():
     """BASELINE.json's largest configuration (R101 1600x640, 12 views, 900 queries) through size-independent properties:
     CSR well-formedness, idempotence (same frame twice -> bitwise identical), fork/no-fork equality, and the decode kernel
