@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void posemb3d_kernel(const float* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 // a4: RoIAlign (mmcv 1.6.1 semantics: aligned, avg, adaptive sampling grid) on position-major maps.
-//     One block per RoI; thread = channel -> every bilinear tap is a fully coalesced C*4-byte row read.
+//     One block per (RoI, bin row); every bilinear tap is a fully coalesced C*4-byte row read.
 //     maps: up to two [V*h*w, 256] fp32 maps (feature, PE) -> out bf16 [R, 49, 256] each (+ optional fp32)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict__ map0, const float* __restrict__ map1, const float* __restrict__ rois,
@@ -148,9 +148,9 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
                                                         float* __restrict__ out0_f32, float* __restrict__ out1_f32, int H, int W,
                                                         float spatial_scale, int sampling_ratio, const int* __restrict__ map1_index,
                                                         int out1_is_sum) {
-    // grid (R, 7): one block per RoI and bin row, thread = channel -> 2100 blocks keep every CU busy and each
-    // thread's dependent chain is 7 bins instead of 49
-    const int r = blockIdx.x, ph = blockIdx.y, c = threadIdx.x;
+    // grid (R, 7): one block per RoI and bin row; wave w takes the bins w, w + 4 of the row, lane l the channels 4l .. 4l+3: every
+    // bilinear tap is one 16-byte load per lane (a full 1 KB row per wave), every output one 8-byte (bf16) / 16-byte (fp32) store
+    const int r = blockIdx.x, ph = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
     const float* b = rois + r * 5;
     const int v = (int)b[0];
     const float x1 = b[1] * spatial_scale - 0.5f, y1 = b[2] * spatial_scale - 0.5f;
@@ -162,8 +162,13 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
     const float count = (float)max(gh * gw, 1);
     const long long vbase = (long long)v * H * W;
     const int nmaps = map1 ? 2 : 1;
-    for (int pw = 0; pw < 7; ++pw) {
-        float s0 = 0.f, s1 = 0.f;
+    auto ld = [&](const float* m, long long q) { return *reinterpret_cast<const float4*>(m + q * C + c); };
+    auto tap4 = [](float w1, const float4& a, float w2, const float4& bq, float w3, const float4& cq, float w4, const float4& d, float4& s) {
+        s.x += w1 * a.x + w2 * bq.x + w3 * cq.x + w4 * d.x; s.y += w1 * a.y + w2 * bq.y + w3 * cq.y + w4 * d.y;
+        s.z += w1 * a.z + w2 * bq.z + w3 * cq.z + w4 * d.z; s.w += w1 * a.w + w2 * bq.w + w3 * cq.w + w4 * d.w;
+    };
+    for (int pw = wave; pw < 7; pw += 4) {
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
         for (int iy = 0; iy < gh; ++iy) {
             const float yy = y1 + ph * bh + (iy + 0.5f) * bh / gh;
             for (int ix = 0; ix < gw; ++ix) {
@@ -177,24 +182,27 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
                 const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
                 const long long q1 = vbase + (long long)yl * W + xl, q2 = vbase + (long long)yl * W + xh;
                 const long long q3 = vbase + (long long)yh * W + xl, q4 = vbase + (long long)yh * W + xh;
-                s0 += w1 * map0[q1 * C + c] + w2 * map0[q2 * C + c] + w3 * map0[q3 * C + c] + w4 * map0[q4 * C + c];
+                tap4(w1, ld(map0, q1), w2, ld(map0, q2), w3, ld(map0, q3), w4, ld(map0, q4), s0);
                 if (nmaps == 2) {
                     long long p1 = q1, p2 = q2, p3 = q3, p4 = q4;
                     if (map1_index) {   // map1 rows are compacted: row = map1_index[position]; -1 rows only ever carry weight 0
                         p1 = max(map1_index[q1], 0); p2 = max(map1_index[q2], 0); p3 = max(map1_index[q3], 0); p4 = max(map1_index[q4], 0);
                     }
-                    s1 += w1 * map1[p1 * C + c] + w2 * map1[p2 * C + c] + w3 * map1[p3 * C + c] + w4 * map1[p4 * C + c];
+                    tap4(w1, ld(map1, p1), w2, ld(map1, p2), w3, ld(map1, p3), w4, ld(map1, p4), s1);
                 }
             }
         }
         const long long o = ((long long)r * 49 + ph * 7 + pw) * C + c;
-        s0 = s0 / count;
-        if (out0) out0[o] = f32_to_bf16(s0);
-        if (out0_f32) out0_f32[o] = s0;
+        s0 = make_float4(s0.x / count, s0.y / count, s0.z / count, s0.w / count);
+        if (out0) *reinterpret_cast<uint2*>(out0 + o) = make_uint2(pack_bf16x2(s0.x, s0.y), pack_bf16x2(s0.z, s0.w));
+        if (out0_f32) *reinterpret_cast<float4*>(out0_f32 + o) = s0;
         if (nmaps == 2) {
-            s1 = s1 / count;
-            if (out1) out1[o] = f32_to_bf16(out1_is_sum ? s0 + s1 : s1);
-            if (out1_f32) out1_f32[o] = s1;
+            s1 = make_float4(s1.x / count, s1.y / count, s1.z / count, s1.w / count);
+            if (out1) {
+                const float4 t = out1_is_sum ? make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w) : s1;
+                *reinterpret_cast<uint2*>(out1 + o) = make_uint2(pack_bf16x2(t.x, t.y), pack_bf16x2(t.z, t.w));
+            }
+            if (out1_f32) *reinterpret_cast<float4*>(out1_f32 + o) = s1;
         }
     }
 }
@@ -535,24 +543,31 @@ __global__ __launch_bounds__(1024) void csr_from_corr_kernel(const int* __restri
 // a2 inputs: for every key position s of the compacted list build the three PE-MLP input rows and gather
 // the feature row (MU/pe.py:84-135 frustum coords in fp64, MU/positional_encoding.py:78-95 sine features).
 // ------------------------------------------------------------------------------------------------
+// One wave per key position (4 per block): lane l moves channels 4l..4l+3 of the feature row with 16-byte accesses, computes depth
+// bin l of the frustum row (3 coordinates) and 6 sine channels; the two bf16 input rows (384 B, 768 B) are assembled in LDS and
+// written with 16-byte stores.  (Round 1: one block per position with 2- and 4-byte accesses ran at 2 TB/s of its 130 MB.)
 __global__ __launch_bounds__(256) void pe_inputs_kernel(const int* __restrict__ s2pos, const int* __restrict__ S_dev, const float* __restrict__ featcl,
                                                         const double* __restrict__ img2lidar, const double* __restrict__ coords_w, const double* __restrict__ coords_h,
                                                         const double* __restrict__ coords_d, const float* __restrict__ embeds, const float* __restrict__ dim_t,
                                                         unsigned short* __restrict__ A_frustum, unsigned short* __restrict__ A_sine, unsigned short* __restrict__ Xf_bf16,
                                                         float* __restrict__ Xf_f32, int h, int w, int P, int D, double pr0, double pr1, double pr2,
                                                         double pd0, double pd1, double pd2) {
-    const int s = blockIdx.x, tid = threadIdx.x;
-    if (s >= *S_dev) return;
+    __shared__ __attribute__((aligned(16))) unsigned short rowbuf[4][3 * 256 + 384];      // frustum row (<= 768 values) | sine row (384)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = blockIdx.x * 4 + wave;
+    if (s >= *S_dev) return;                                  // (whole waves leave; no block barrier below)
     const int pos = s2pos[s];
     const int v = pos / (h * w), rem = pos - v * h * w, y = rem / w, x = rem - y * w;
+    unsigned short* fr_row = rowbuf[wave];
+    unsigned short* si_row = rowbuf[wave] + 3 * 256;
     // feature row gather (fp32 kept for the K = feat + pe sum, bf16 for the SE gate and the V projection)
     {
-        const float f = featcl[(long long)pos * C + tid];
-        Xf_f32[(long long)s * C + tid] = f;
-        Xf_bf16[(long long)s * C + tid] = f32_to_bf16(f);
+        const float4 f = *reinterpret_cast<const float4*>(featcl + (long long)pos * C + 4 * lane);
+        *reinterpret_cast<float4*>(Xf_f32 + (long long)s * C + 4 * lane) = f;
+        *reinterpret_cast<uint2*>(Xf_bf16 + (long long)s * C + 4 * lane) = make_uint2(pack_bf16x2(f.x, f.y), pack_bf16x2(f.z, f.w));
     }
-    if (tid < D) {
-        const double d = coords_d[tid];
+    for (int dk = lane; dk < D; dk += 64) {
+        const double d = coords_d[dk];
         const double dm = d < 1e-3 ? 1e-3 : d;
         const double p[4] = {coords_w[x] * dm, coords_h[y] * dm, d, 1.0};
         const double* M = img2lidar + v * 16;
@@ -566,19 +581,31 @@ __global__ __launch_bounds__(256) void pe_inputs_kernel(const int* __restrict__ 
             n = n < 0.0 ? 0.0 : (n > 1.0 ? 1.0 : n);          // inverse_sigmoid: clamp(0,1)
             const double x1 = n < 1e-5 ? 1e-5 : n;
             const double x2 = (1.0 - n) < 1e-5 ? 1e-5 : (1.0 - n);
-            A_frustum[(long long)s * (3 * D) + tid * 3 + i] = f32_to_bf16((float)log(x1 / x2));
+            // the quotient in fp64 like the reference (MU/pe.py:119-130 runs on double coordinates), its logarithm in fp32: 1e-7
+            // against a value that is rounded to bf16 right here (a double log is ~100 fp64 instructions, 192 of them per position)
+            fr_row[dk * 3 + i] = f32_to_bf16(logf((float)(x1 / x2)));
         }
     }
     // sine features, channel order (n | y | x).  NOT interleaved: the reference stacks sin/cos on dim=4 of a
     // 5-D tensor (MU/positional_encoding.py:86-94), so within an axis channels 0..63 = sin(e / dim_t[2j]) and
     // channels 64..127 = cos(e / dim_t[2j+1]).
     const float en = embeds[pos], ey = embeds[P + pos], ex = embeds[2 * P + pos];
-    for (int ch = tid; ch < 384; ch += 256) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int ch = lane + 64 * k;
         const int axis = ch >> 7, i = ch & 127;
         const float e = axis == 0 ? en : (axis == 1 ? ey : ex);
-        const float val = i < 64 ? sinf(e / dim_t[2 * i]) : cosf(e / dim_t[2 * (i - 64) + 1]);
-        A_sine[(long long)s * 384 + ch] = f32_to_bf16(val);
+        // arguments lie in [0, 2 pi]: the hardware sin / cos (v_sin_f32 on x / 2 pi, ~1e-6 absolute) is as good as the library call
+        // for a value that is rounded to bf16 right here
+        const float a = e / dim_t[i < 64 ? 2 * i : 2 * (i - 64) + 1];
+        si_row[ch] = f32_to_bf16(i < 64 ? __sinf(a) : __cosf(a));
     }
+    __builtin_amdgcn_wave_barrier();                          // the rows are read back by the same wave only
+    __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): LDS writes landed
+    const int nf = 3 * D / 8;                                 // 16-byte chunks of the frustum row (D % 8 == 0)
+    for (int q = lane; q < nf; q += 64)
+        *reinterpret_cast<uint4*>(A_frustum + (long long)s * (3 * D) + 8 * q) = *reinterpret_cast<const uint4*>(fr_row + 8 * q);
+    if (lane < 48) *reinterpret_cast<uint4*>(A_sine + (long long)s * 384 + 8 * lane) = *reinterpret_cast<const uint4*>(si_row + 8 * lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -889,9 +916,9 @@ extern "C" int mv2d_pe_inputs(const int* s2pos, const int* S_dev, int S_max, con
                               int depth_num, const double* position_range, void* stream) {
     MV2D_CHECK_ARG(s2pos && S_dev && featcl && img2lidar && coords_w && coords_h && coords_d && embeds && dim_t && A_frustum &&
                        A_sine && Xf_bf16 && Xf_f32 && position_range, "mv2d_pe_inputs: null pointer");
-    MV2D_CHECK_ARG(depth_num <= 256, "mv2d_pe_inputs: depth_num must be <= 256");
+    MV2D_CHECK_ARG(depth_num <= 256 && (depth_num % 8) == 0, "mv2d_pe_inputs: depth_num must be a multiple of 8, <= 256");
     if (S_max == 0) return MV2D_OK;
-    hipLaunchKernelGGL(pe_inputs_kernel, dim3(S_max), dim3(256), 0, (hipStream_t)stream, s2pos, S_dev, featcl, img2lidar, coords_w,
+    hipLaunchKernelGGL(pe_inputs_kernel, dim3(cdiv(S_max, 4)), dim3(256), 0, (hipStream_t)stream, s2pos, S_dev, featcl, img2lidar, coords_w,
                        coords_h, coords_d, embeds, dim_t, (unsigned short*)A_frustum, (unsigned short*)A_sine,
                        (unsigned short*)Xf_bf16, Xf_f32, h, w, V * h * w, depth_num, position_range[0], position_range[1],
                        position_range[2], position_range[3] - position_range[0], position_range[4] - position_range[1],
