@@ -60,7 +60,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='cfg2_s', help='cfg2_s (MV2D-S 6 cams 1408x512, headline) | cfg3_t | cfg5_t | cfg1_s ...')
     ap.add_argument('--inflight', type=int, default=4, help='HIP streams per GPU, each running its own launch sequence per step')
-    ap.add_argument('--batch', type=int, default=4, help='samples sharing every launch of a stream (HeadEngine.run_batch)')
+    ap.add_argument('--batch', type=int, default=6, help='samples sharing every launch of a stream (HeadEngine.run_batch)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL; gloo only for single-GPU dry runs)')
@@ -265,9 +265,19 @@ def main():
             'roofline': roofline, 'stage_roofline': stage_roofline,
             'cpu_baseline': cpu,
         }
-        print(json.dumps(line))
+    # RCCL writes its version banner through C stdio (block-buffered on a pipe, so it would come out at process exit, after the JSON
+    # line): every rank flushes it now, the barrier orders that before rank 0 prints, and the JSON line stays the last line of stdout
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == '__main__':
