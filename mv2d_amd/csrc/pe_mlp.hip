@@ -117,8 +117,12 @@ __device__ __forceinline__ void stage_write(unsigned char* As, const uint4 (&sa)
 
 // what a part requests at the start of its layer 2 (the first point where the input tile buffer / the dead layer-1 accumulators
 // are free), for use after its last step:
-enum Mid { MID_NONE = 0, MID_STAGE = 1, MID_STAGE_PARKED = 2, MID_FINAL = 3 };
-struct Ctx { const unsigned short* next_in; float* pe; const float* Xf32; int m0, M, tid, n0; };
+enum Mid { MID_NONE = 0, MID_STAGE = 1, MID_FINAL = 3 };
+// the feature rows of the last epilogue: requested at the start of the last layer 2 (64 more live registers) or in the epilogue itself
+constexpr bool F_EARLY = false;
+// layer 1: LDS fragments of step t+1 requested during step t (16 more live registers where the pressure peaks) or at the start of step t
+constexpr bool A_AHEAD_L1 = false;
+struct Ctx { const unsigned short* next_in; const float* Xf32; int m0, M, tid, n0; };
 // all biases live in LDS (a global load in the middle of the pipeline would have to be waited for through the whole ring)
 enum { B_R = 0, B_E = 256, B_1A = 512, B_1B = 1536, B_2A = 1792, B_2B = 2816, B_FLOATS = 3072 };
 
@@ -127,7 +131,7 @@ enum { B_R = 0, B_E = 256, B_1A = 512, B_1B = 1536, B_2A = 1792, B_2B = 2816, B_
 template <class ML, int H, class NX, int NXH, bool HAS_NEXT, int MID>
 __device__ __forceinline__ void mlp_part(const unsigned char* As, unsigned char* Hs, const WPtr& w, const float* b1 /* LDS */, const WPtr& nw,
                                          f32x4_t (&acc2)[RT][CT2], Frag (&wq)[4][4], int lane, int wave, const Ctx& cx,
-                                         uint4 (&sa)[NX::NST], uint4 (&sb)[NX::NST], float4 (&pk)[RT][CT2], float4 (&f)[RT][CT2]) {
+                                         uint4 (&sa)[NX::NST], uint4 (&sb)[NX::NST], float4 (&f)[RT][CT2]) {
     const int fr = lane & 15, fg = lane >> 4;
     f32x4_t acc1[RT][4];
     Frag a[2][RT];
@@ -142,7 +146,8 @@ __device__ __forceinline__ void mlp_part(const unsigned char* As, unsigned char*
 #pragma unroll
                 for (int i = 0; i < RT; ++i) acc1[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
-        if (t + 1 < ML::L1) load_a(a[(t + 1) & 1], As, ML::PITCH_A, (t + 1) % ML::KS1, fr, fg);
+        if (A_AHEAD_L1 && t + 1 < ML::L1) load_a(a[(t + 1) & 1], As, ML::PITCH_A, (t + 1) % ML::KS1, fr, fg);
+        if (!A_AHEAD_L1 && t > 0) load_a(a[t & 1], As, ML::PITCH_A, t % ML::KS1, fr, fg);
         __builtin_amdgcn_sched_barrier(0);               // keep the requests ahead of this step's MFMAs
 #pragma unroll
         for (int i = 0; i < RT; ++i)
@@ -165,16 +170,13 @@ __device__ __forceinline__ void mlp_part(const unsigned char* As, unsigned char*
         }
     }
     __syncthreads();                                   // the resident part of the hidden layer is complete
-    if (MID == MID_STAGE || MID == MID_STAGE_PARKED) stage_issue<NX>(sa, sb, cx.next_in, cx.m0, cx.M, cx.tid);
-    if (MID == MID_STAGE_PARKED || MID == MID_FINAL) {
+    if (MID == MID_STAGE) stage_issue<NX>(sa, sb, cx.next_in, cx.m0, cx.M, cx.tid);
+    if (MID == MID_FINAL && F_EARLY) {
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
-            for (int j = 0; j < CT2; ++j) {
-                const long long o = (long long)min(cx.m0 + 16 * i + fr, cx.M - 1) * C + cx.n0 + 16 * j;
-                pk[i][j] = *reinterpret_cast<const float4*>(cx.pe + o);
-                if (MID == MID_FINAL) f[i][j] = *reinterpret_cast<const float4*>(cx.Xf32 + o);
-            }
+            for (int j = 0; j < CT2; ++j)
+                f[i][j] = *reinterpret_cast<const float4*>(cx.Xf32 + (long long)min(cx.m0 + 16 * i + fr, cx.M - 1) * C + cx.n0 + 16 * j);
     }
     load_a(a[0], Hs, PITCH_H, 0, fr, fg);
 #pragma unroll
@@ -237,62 +239,60 @@ __global__ __launch_bounds__(64 * NW, 1) void pe_fused_kernel(PeParams p) {
     }
     __syncthreads();
     f32x4_t acc[RT][CT2];
-    float4 pk[RT][CT2], f[RT][CT2];                     // value parked in the output buffer; feature rows
-    Ctx cx{p.A1, p.pe, p.Xf32, m0, M, tid, n0};
+    f32x4_t g[RT][CT2];                                 // the gate, then P1 * gate: carried in registers through the next MLP
+    float4 f[RT][CT2];                                  // feature rows
+    Ctx cx{p.A1, p.Xf32, m0, M, tid, n0};
 
-    // The gate and P1 * gate wait in the output buffer `pe` while the next MLP runs (every lane re-reads exactly the addresses it
-    // wrote, requested a whole layer 2 ahead): carrying them in registers costs 64 more VGPRs than the kernel has.
-    // 1. gate = sigmoid(conv_expand(relu(conv_reduce(feat))))            -> pe (temporary)
+    // 1. gate = sigmoid(conv_expand(relu(conv_reduce(feat))))
     zero_acc(acc);
     {
         uint4 sa[MlpA::NST], sb[MlpA::NST];
-        mlp_part<MlpG, 0, MlpA, 0, true, MID_STAGE>(As, Hs, wG, Bs + B_R, wA, acc, wq, lane, wave, cx, sa, sb, pk, f);
+        mlp_part<MlpG, 0, MlpA, 0, true, MID_STAGE>(As, Hs, wG, Bs + B_R, wA, acc, wq, lane, wave, cx, sa, sb, f);
         stage_write<MlpA>(As, sa, sb, tid);
     }
 #pragma unroll
     for (int j = 0; j < CT2; ++j) {
         const float4 eb = *reinterpret_cast<const float4*>(Bs + B_E + n0 + 16 * j);
 #pragma unroll
-        for (int i = 0; i < RT; ++i) {
-            const int m = m0 + 16 * i + fr;
-            if (m < M)
-                *reinterpret_cast<float4*>(p.pe + (long long)m * C + n0 + 16 * j) =
-                    make_float4(1.f / (1.f + __expf(-(acc[i][j][0] + eb.x))), 1.f / (1.f + __expf(-(acc[i][j][1] + eb.y))),
-                                1.f / (1.f + __expf(-(acc[i][j][2] + eb.z))), 1.f / (1.f + __expf(-(acc[i][j][3] + eb.w))));
-        }
+        for (int i = 0; i < RT; ++i)
+            g[i][j] = f32x4_t{1.f / (1.f + __expf(-(acc[i][j][0] + eb.x))), 1.f / (1.f + __expf(-(acc[i][j][1] + eb.y))),
+                              1.f / (1.f + __expf(-(acc[i][j][2] + eb.z))), 1.f / (1.f + __expf(-(acc[i][j][3] + eb.w)))};
     }
     __syncthreads();
-    // 2. P1 = position_encoder(A1);  Pg = (P1 + b) * gate                 -> pe (temporary)
+    // 2. P1 = position_encoder(A1);  g = (P1 + b) * gate
     zero_acc(acc);
     {
         uint4 s0[MlpA::NST], s1[MlpA::NST];
-        mlp_part<MlpA, 0, MlpA, 1, true, MID_NONE>(As, Hs, wA, Bs + B_1A, wA, acc, wq, lane, wave, cx, s0, s1, pk, f);
+        mlp_part<MlpA, 0, MlpA, 1, true, MID_NONE>(As, Hs, wA, Bs + B_1A, wA, acc, wq, lane, wave, cx, s0, s1, f);
     }
     cx.next_in = p.A2;
     {
         uint4 sa[MlpB::NST], sb[MlpB::NST];
-        mlp_part<MlpA, 1, MlpB, 0, true, MID_STAGE_PARKED>(As, Hs, wA, Bs + B_1A, wB, acc, wq, lane, wave, cx, sa, sb, pk, f);
+        mlp_part<MlpA, 1, MlpB, 0, true, MID_STAGE>(As, Hs, wA, Bs + B_1A, wB, acc, wq, lane, wave, cx, sa, sb, f);
         stage_write<MlpB>(As, sa, sb, tid);
     }
 #pragma unroll
     for (int j = 0; j < CT2; ++j) {
         const float4 eb = *reinterpret_cast<const float4*>(Bs + B_1B + n0 + 16 * j);
 #pragma unroll
-        for (int i = 0; i < RT; ++i) {
-            const int m = m0 + 16 * i + fr;
-            if (m < M)
-                *reinterpret_cast<float4*>(p.pe + (long long)m * C + n0 + 16 * j) =
-                    make_float4((acc[i][j][0] + eb.x) * pk[i][j].x, (acc[i][j][1] + eb.y) * pk[i][j].y,
-                                (acc[i][j][2] + eb.z) * pk[i][j].z, (acc[i][j][3] + eb.w) * pk[i][j].w);
-        }
+        for (int i = 0; i < RT; ++i)
+            g[i][j] = f32x4_t{(acc[i][j][0] + eb.x) * g[i][j][0], (acc[i][j][1] + eb.y) * g[i][j][1],
+                              (acc[i][j][2] + eb.z) * g[i][j][2], (acc[i][j][3] + eb.w) * g[i][j][3]};
     }
     __syncthreads();
-    // 3. P2 = adapt_pos3d(A2);  pe = (P2 + b) + Pg;  Xk = bf16(pe + feat)
+    // 3. P2 = adapt_pos3d(A2);  pe = (P2 + b) + g;  Xk = bf16(pe + feat)
     zero_acc(acc);
     {
         uint4 s0[MlpB::NST], s1[MlpB::NST];
-        mlp_part<MlpB, 0, MlpB, 1, true, MID_NONE>(As, Hs, wB, Bs + B_2A, wB, acc, wq, lane, wave, cx, s0, s1, pk, f);
-        mlp_part<MlpB, 1, MlpB, 1, false, MID_FINAL>(As, Hs, wB, Bs + B_2A, wB, acc, wq, lane, wave, cx, s0, s1, pk, f);
+        mlp_part<MlpB, 0, MlpB, 1, true, MID_NONE>(As, Hs, wB, Bs + B_2A, wB, acc, wq, lane, wave, cx, s0, s1, f);
+        mlp_part<MlpB, 1, MlpB, 1, false, MID_FINAL>(As, Hs, wB, Bs + B_2A, wB, acc, wq, lane, wave, cx, s0, s1, f);
+    }
+    if (!F_EARLY) {                                      // all 16 requests of a lane in one go: one exposed round trip per block
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < CT2; ++j)
+                f[i][j] = *reinterpret_cast<const float4*>(p.Xf32 + (long long)min(m0 + 16 * i + fr, M - 1) * C + n0 + 16 * j);
     }
 #pragma unroll
     for (int j = 0; j < CT2; ++j) {
@@ -301,8 +301,8 @@ __global__ __launch_bounds__(64 * NW, 1) void pe_fused_kernel(PeParams p) {
         for (int i = 0; i < RT; ++i) {
             const int m = m0 + 16 * i + fr, n = n0 + 16 * j;
             if (m >= M) continue;
-            const float4 v = make_float4((acc[i][j][0] + eb.x) + pk[i][j].x, (acc[i][j][1] + eb.y) + pk[i][j].y,
-                                         (acc[i][j][2] + eb.z) + pk[i][j].z, (acc[i][j][3] + eb.w) + pk[i][j].w);
+            const float4 v = make_float4((acc[i][j][0] + eb.x) + g[i][j][0], (acc[i][j][1] + eb.y) + g[i][j][1],
+                                         (acc[i][j][2] + eb.z) + g[i][j][2], (acc[i][j][3] + eb.w) + g[i][j][3]);
             *reinterpret_cast<float4*>(p.pe + (long long)m * C + n) = v;
             *reinterpret_cast<uint2*>(p.Xk + (long long)m * C + n) =
                 make_uint2(pack_bf16x2(v.x + f[i][j].x, v.y + f[i][j].y), pack_bf16x2(v.z + f[i][j].z, v.w + f[i][j].w));
