@@ -249,9 +249,17 @@ extern "C" int mv2d_sparse_xattn_fwd(const float* q, const void* K, const void* 
                                      float* ctx, float* dbg_logits, long long dbg_stride, int R, int empty_nan, void* stream) {
     MV2D_CHECK_ARG(q && K && V && row_ptr && col_idx && ctx && R >= 0, "mv2d_sparse_xattn_fwd: bad args");
     if (R == 0) return MV2D_OK;
-    // 8 waves x 8-key chunks: measured best of {4,8,16} waves x {4,8,16} keys on cfg2_s / cfg3_t / cfg5_t
-    hipLaunchKernelGGL((sparse_xattn_kernel<8, 8>), dim3(R), dim3(512), 0, (hipStream_t)stream, q, (const unsigned short*)K,
-                       (const unsigned short*)V, row_ptr, col_idx, ctx, dbg_logits, dbg_stride, R, empty_nan);
+    // 8 waves x 4-key chunks: best of {2,4,8} waves x {4,8,16} keys with several samples per launch (cfg2_s decoder 0.671 -> 0.655 ms per
+    // 6-sample batch, cfg3_t 0.845 -> 0.817); with one sample per launch 8 x 8 was marginally ahead
+    static const int cfg = getenv("MV2D_XATTN_CFG") ? atoi(getenv("MV2D_XATTN_CFG")) : 84;      // experiment switch: waves * 10 + keys per chunk
+#define MV2D_XA(NW, KC) hipLaunchKernelGGL((sparse_xattn_kernel<NW, KC>), dim3(R), dim3(64 * NW), 0, (hipStream_t)stream, q, (const unsigned short*)K, \
+                                           (const unsigned short*)V, row_ptr, col_idx, ctx, dbg_logits, dbg_stride, R, empty_nan)
+    if (cfg == 48) MV2D_XA(4, 8);
+    else if (cfg == 416) MV2D_XA(4, 16);
+    else if (cfg == 28) MV2D_XA(2, 8);
+    else if (cfg == 88) MV2D_XA(8, 8);
+    else MV2D_XA(8, 4);
+#undef MV2D_XA
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
