@@ -25,7 +25,7 @@ constexpr int KD = 256;                      // K extent (fixed)
 constexpr int BM = 128, BN = 64;
 constexpr int ROWB = KD * 2;                 // 512 B per weight row
 constexpr int STAGE_BYTES = BN * ROWB;       // 32 KB
-constexpr int NR_MAX = 768;                  // columns per block
+constexpr int NR_MAX = 1536;                 // most columns per block (bias slice in LDS)
 constexpr int LDS_BYTES = 2 * STAGE_BYTES + NR_MAX * 4;
 
 // LDS image of a weight stage: row n = 512 B, 16-byte chunk c at position c ^ key(n), key = row bits {0,1,3,4}: the 16 rows a
@@ -210,6 +210,7 @@ extern "C" int mv2d_kv_proj(const void* A, const void* A2, int n_split, int lda,
     }
     static const int nr_env = getenv("MV2D_KV_NR") ? atoi(getenv("MV2D_KV_NR")) : 0;
     if (nr_env) nr = nr_env;
+    MV2D_CHECK_ARG(nr <= NR_MAX && (N % nr) == 0 && (nr % BN) == 0, "mv2d_kv_proj: columns per block must divide N, be a multiple of 64 and <= 1536");
     MV2D_CHECK_ARG(n_split == 0 || (A2 && (n_split % nr) == 0), "mv2d_kv_proj: n_split must be a multiple of 256 with A2 set");
     KvParams p;
     p.A = (const unsigned short*)A; p.A2 = (const unsigned short*)A2; p.n_split = n_split; p.lda = lda;

@@ -513,7 +513,7 @@ def test_decode_topk_tie_order(dev):
     assert bool((scores[:299] >= scores[1:300]).all())
 
 
-@pytest.mark.parametrize('M,use_mdev', [(128, False), (1000, False), (14700, False), (5000, True)])
+@pytest.mark.parametrize('M,use_mdev', [(128, False), (1000, False), (14700, False), (5000, True), (41000, False), (45000, True)])   # >= 40000 rows: 1536-column ranges
 def test_kv_proj_bit_identical_to_tile_gemm(dev, M, use_mdev):
     from mv2d_amd import ops
     DEV = dev
