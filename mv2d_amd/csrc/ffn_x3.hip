@@ -13,7 +13,7 @@
 
 namespace {
 
-constexpr int C = 256, HS = 64, BR = 32;      // channels, hidden slice, rows per block
+constexpr int C = 256, HS = 64;               // channels, hidden slice (rows per block: template parameter, 8 per wave)
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 union Frag { uint4 u; mfma_bf16x8 v; };
 
@@ -29,8 +29,10 @@ __device__ __forceinline__ void split2(float a, float b, unsigned int& hi, unsig
 // G consecutive 64-wide hidden slices per block, accumulated in registers: hidden/(64 G) slabs instead of hidden/64.  With many rows
 // (a batch of samples) there are enough blocks anyway, and the slab round trip through memory ([32, M, 256] fp32 written here, read
 // by the row kernel that follows) was as expensive as the FFN itself.
-template <int G>
-__global__ __launch_bounds__(256, G == 1 ? 2 : 1) void ffn_x3_kernel(const float* __restrict__ X, const unsigned short* __restrict__ W1h,
+// BR = 32 rows (4 waves) or 64 rows (8 waves) per block: the waves of the row tiles share the weight fragments of their column half
+// through the L1, so 64-row blocks halve the L2 -> CU weight traffic -- which turned out not to be what limits the kernel (slower).
+template <int G, int BR>
+__global__ __launch_bounds__(BR * 8, (G == 1 && BR == 32) ? 2 : 1) void ffn_x3_kernel(const float* __restrict__ X, const unsigned short* __restrict__ W1h,
                                                         const unsigned short* __restrict__ W1l, const float* __restrict__ b1,
                                                         const unsigned short* __restrict__ W2h, const unsigned short* __restrict__ W2l,
                                                         float* __restrict__ slabs, int M, int hidden) {
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(256, G == 1 ? 2 : 1) void ffn_x3_kernel(const float
     float4 xr[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int idx = tid + 256 * i, row = idx >> 5, slot = idx & 31;            // 32 slots of 8 floats per row
+        const int idx = tid + (BR * 8) * i, row = idx >> 5, slot = idx & 31;       // 32 slots of 8 floats per row
         const float* xp = X + (long long)min(m0 + row, M - 1) * C + slot * 8;
         xr[i][0] = *reinterpret_cast<const float4*>(xp);
         xr[i][1] = *reinterpret_cast<const float4*>(xp + 4);
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256, G == 1 ? 2 : 1) void ffn_x3_kernel(const float
     load_w1(slab * G);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int idx = tid + 256 * i, row = idx >> 5, slot = idx & 31;
+        const int idx = tid + (BR * 8) * i, row = idx >> 5, slot = idx & 31;
         uint4 h4, l4;
         split2(xr[i][0].x, xr[i][0].y, h4.x, l4.x); split2(xr[i][0].z, xr[i][0].w, h4.y, l4.y);
         split2(xr[i][1].x, xr[i][1].y, h4.z, l4.z); split2(xr[i][1].z, xr[i][1].w, h4.w, l4.w);
@@ -157,11 +159,18 @@ extern "C" int mv2d_ffn_fused_x3(const float* X, const void* W1hi, const void* W
     const int G = slices_per_block;
     MV2D_CHECK_ARG((G == 1 || G == 2 || G == 4) && (hidden / HS) % G == 0, "mv2d_ffn_fused_x3: slices_per_block must be 1, 2 or 4 and divide hidden/64");
     if (M == 0) return MV2D_OK;
-    const dim3 grid(hidden / HS / G, cdiv(M, BR));
     const unsigned short *w1h = (const unsigned short*)W1hi, *w1l = (const unsigned short*)W1lo, *w2h = (const unsigned short*)W2hi, *w2l = (const unsigned short*)W2lo;
-    if (G == 1) hipLaunchKernelGGL(ffn_x3_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, X, w1h, w1l, b1, w2h, w2l, slabs, M, hidden);
-    else if (G == 2) hipLaunchKernelGGL(ffn_x3_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, X, w1h, w1l, b1, w2h, w2l, slabs, M, hidden);
-    else hipLaunchKernelGGL(ffn_x3_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, X, w1h, w1l, b1, w2h, w2l, slabs, M, hidden);
+    static const int br_env = getenv("MV2D_FFN_BR") ? atoi(getenv("MV2D_FFN_BR")) : 0;
+    const int br = br_env ? br_env : 32;            // measured at M = 1800: 64-row blocks 0.69 vs 0.658 ms per decoder pass -> experiment switch only
+    if (G == 1 && br == 64) {
+        hipLaunchKernelGGL((ffn_x3_kernel<1, 64>), dim3(hidden / HS, cdiv(M, 64)), dim3(512), 0, (hipStream_t)stream, X, w1h, w1l, b1, w2h, w2l, slabs, M, hidden);
+        MV2D_LAUNCH_CHECK();
+        return MV2D_OK;
+    }
+    const dim3 grid(hidden / HS / G, cdiv(M, 32));
+    if (G == 1) hipLaunchKernelGGL((ffn_x3_kernel<1, 32>), grid, dim3(256), 0, (hipStream_t)stream, X, w1h, w1l, b1, w2h, w2l, slabs, M, hidden);
+    else if (G == 2) hipLaunchKernelGGL((ffn_x3_kernel<2, 32>), grid, dim3(256), 0, (hipStream_t)stream, X, w1h, w1l, b1, w2h, w2l, slabs, M, hidden);
+    else hipLaunchKernelGGL((ffn_x3_kernel<4, 32>), grid, dim3(256), 0, (hipStream_t)stream, X, w1h, w1l, b1, w2h, w2l, slabs, M, hidden);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
