@@ -240,36 +240,51 @@ __device__ __forceinline__ void load_w_x3(BFrag wh[8], BFrag wl[8], const unsign
     }
 }
 
+// RT row tiles (16 rows each) per block share one fetch of the weight fragments.  A block is bound by fetching its 0.5 MB of weights
+// through one CU's L1 (~57 GB/s), whatever the number of rows: with a batch of samples (M > 512) two row tiles per block take the
+// same time on half as many CUs, which the other streams' wide kernels can use.
+template <int RT>
 __global__ __launch_bounds__(1024) void attn_out_fused_x3_kernel(AttnOutX3Params p) {
-    __shared__ __attribute__((aligned(16))) unsigned char ah[16 * 512], al[16 * 512];
-    __shared__ __attribute__((aligned(16))) float tb[16 * C];
+    __shared__ __attribute__((aligned(16))) unsigned char ah[RT * 16 * 512], al[RT * 16 * 512];
+    __shared__ __attribute__((aligned(16))) float tb[RT * 16 * C];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-    const int m0 = blockIdx.x * 16;
-    const long long grow = (long long)min(m0 + wave, p.M - 1) * C + lane * 4;
-    const float4 av = *reinterpret_cast<const float4*>(p.ctx + grow);
+    const int mb = blockIdx.x * (16 * RT);
+    long long grow[RT];
+    float4 av[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        grow[t] = (long long)min(mb + 16 * t + wave, p.M - 1) * C + lane * 4;
+        av[t] = *reinterpret_cast<const float4*>(p.ctx + grow[t]);
+    }
     BFrag wh[8], wl[8];
     load_w_x3(wh, wl, p.Woh, p.Wol, wave, lane);
-    const int aoff = wave * 512 + (((lane >> 1) ^ wave) << 4) + (lane & 1) * 8;     // this thread's 4 values in the bf16 images
-    {
+    const int aoff = wave * 512 + (((lane >> 1) ^ wave) << 4) + (lane & 1) * 8;     // this thread's 4 values in the bf16 images of a tile
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
         uint2 hi, lo;
-        split4(av, hi, lo);
-        *reinterpret_cast<uint2*>(ah + aoff) = hi;
-        *reinterpret_cast<uint2*>(al + aoff) = lo;
+        split4(av[t], hi, lo);
+        *reinterpret_cast<uint2*>(ah + t * 8192 + aoff) = hi;
+        *reinterpret_cast<uint2*>(al + t * 8192 + aoff) = lo;
     }
     __syncthreads();
-    f32x4_t acc = tile_mma_x3(ah, al, wh, wl, fr, fg);
+    f32x4_t acc[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] = tile_mma_x3(ah + t * 8192, al + t * 8192, wh, wl, fr, fg);
     if (p.Wqh) load_w_x3(wh, wl, p.Wqh, p.Wql, wave, lane);        // in flight during the LayerNorm
     {
         const int col = wave * 16 + fr;
         const float b = p.bo[col];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tb[toff(4 * fg + r, col)] = acc[r] + b;
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tb[t * 16 * C + toff(4 * fg + r, col)] = acc[t][r] + b;
     }
     __syncthreads();
-    {
-        const int row = wave, m = m0 + row;
-        float4 v = *reinterpret_cast<const float4*>(tb + row * C + ((lane ^ (row & 15)) << 2));
-        const float4 u = *reinterpret_cast<const float4*>(p.resid + grow);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int row = wave, m = mb + 16 * t + row;
+        float4 v = *reinterpret_cast<float4*>(tb + t * 16 * C + row * C + ((lane ^ (row & 15)) << 2));
+        const float4 u = *reinterpret_cast<const float4*>(p.resid + grow[t]);
         v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
         const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
@@ -277,25 +292,28 @@ __global__ __launch_bounds__(1024) void attn_out_fused_x3_kernel(AttnOutX3Params
         const float rstd = 1.0f / sqrtf(var + p.eps);
         const float4 ww = *reinterpret_cast<const float4*>(p.lw + lane * 4), bb = *reinterpret_cast<const float4*>(p.lb + lane * 4);
         v = make_float4(dx * rstd * ww.x + bb.x, dy * rstd * ww.y + bb.y, dz * rstd * ww.z + bb.z, dw * rstd * ww.w + bb.w);
-        if (m < p.M) *reinterpret_cast<float4*>(p.x_out + grow) = v;
+        if (m < p.M) *reinterpret_cast<float4*>(p.x_out + grow[t]) = v;
         if (p.Wqh) {
-            const float4 qp = *reinterpret_cast<const float4*>(p.qpos + grow);
+            const float4 qp = *reinterpret_cast<const float4*>(p.qpos + grow[t]);
             uint2 hi, lo;
             split4(make_float4(v.x + qp.x, v.y + qp.y, v.z + qp.z, v.w + qp.w), hi, lo);
-            *reinterpret_cast<uint2*>(ah + aoff) = hi;
-            *reinterpret_cast<uint2*>(al + aoff) = lo;
+            *reinterpret_cast<uint2*>(ah + t * 8192 + aoff) = hi;
+            *reinterpret_cast<uint2*>(al + t * 8192 + aoff) = lo;
         }
     }
     if (!p.Wqh) return;
     __syncthreads();
-    acc = tile_mma_x3(ah, al, wh, wl, fr, fg);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] = tile_mma_x3(ah + t * 8192, al + t * 8192, wh, wl, fr, fg);
     const int col = wave * 16 + fr;
     const float b = p.bq[col];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 4 * fg + r;
-        if (m < p.M) p.q_out[(long long)m * C + col] = (acc[r] + b) * p.qscale;
-    }
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mb + 16 * t + 4 * fg + r;
+            if (m < p.M) p.q_out[(long long)m * C + col] = (acc[t][r] + b) * p.qscale;
+        }
 }
 
 __device__ __forceinline__ float4 ln_row(float4 v, const float* __restrict__ w, const float* __restrict__ b, int c0, float eps);
@@ -1027,7 +1045,8 @@ extern "C" int mv2d_attn_out_fused_x3(const float* ctx, const float* resid, cons
     if (M == 0) return MV2D_OK;
     AttnOutX3Params p{ctx, resid, (const unsigned short*)Wo_hi, (const unsigned short*)Wo_lo, bo, ln_w, ln_b, x_out, qpos,
                       (const unsigned short*)Wq_hi, (const unsigned short*)Wq_lo, bq, qscale, q_out, M, eps};
-    hipLaunchKernelGGL(attn_out_fused_x3_kernel, dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p);
+    if (M <= 512) hipLaunchKernelGGL(attn_out_fused_x3_kernel<1>, dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(attn_out_fused_x3_kernel<2>, dim3(cdiv(M, 32)), dim3(1024), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
