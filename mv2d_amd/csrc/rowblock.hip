@@ -486,12 +486,12 @@ __device__ __forceinline__ float4 ln_row(float4 v, const float* __restrict__ w, 
     return make_float4(dx * rstd * ww.x + bb.x, dy * rstd * ww.y + bb.y, dz * rstd * ww.z + bb.z, dw * rstd * ww.w + bb.w);
 }
 
+// (RT row tiles per block share the in_proj weight fragments, as in attn_out_fused_x3_kernel)
+template <int RT>
 __global__ __launch_bounds__(1024) void ffn_out_fused_x3_kernel(FfnOutParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char qh[16 * 512], ql[16 * 512], xh[16 * 512], xl[16 * 512];
+    __shared__ __attribute__((aligned(16))) unsigned char qh[RT * 16 * 512], ql[RT * 16 * 512], xh[RT * 16 * 512], xl[RT * 16 * 512];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-    const int m0 = blockIdx.x * 16;
-    const int m = m0 + wave;                                     // LayerNorm stage: row = wave, lane = 4 consecutive columns
-    const long long grow = (long long)min(m, p.M - 1) * C + lane * 4;
+    const int mb = blockIdx.x * (16 * RT);
     // first weight half-tile (q tile of this wave, k-steps 0..3) goes out before anything else
     BFrag wh[2][4], wl[2][4];
     auto load_half = [&](int buf, int st) {                      // stage st = 2 * tile_kind + half; tile_kind 0/1/2 = q/k/v
@@ -504,56 +504,63 @@ __global__ __launch_bounds__(1024) void ffn_out_fused_x3_kernel(FfnOutParams p) 
         }
     };
     if (p.Wh) load_half(0, 0);
-    // ---- sum of the slabs (fixed order) + b2 + residual -> LN -> x, xq, post-norm output
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    {
-        // the slabs were just written by other XCDs (they come from the Infinity Cache, ~2 us away): 16 loads in flight per round trip,
-        // summed in the fixed order s = 0, 1, 2, ... (bit-identical to mv2d_row_ln)
-        const float* pp = p.parts + grow;
-        int s = 0;
-        for (; s + 16 <= p.n_parts; s += 16) {
-            float4 t[16];
+    const int aoff = wave * 512 + (((lane >> 1) ^ wave) << 4) + (lane & 1) * 8;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) t[j] = *reinterpret_cast<const float4*>(pp + (s + j) * p.part_stride);
+    for (int rt = 0; rt < RT; ++rt) {
+        const int m = mb + 16 * rt + wave;                       // LayerNorm stage: row = wave, lane = 4 consecutive columns
+        const long long grow = (long long)min(m, p.M - 1) * C + lane * 4;
+        // ---- sum of the slabs (fixed order) + b2 + residual -> LN -> x, xq, post-norm output
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        {
+            // the slabs were just written by other XCDs (they come from the Infinity Cache, ~2 us away): 16 loads in flight per round trip,
+            // summed in the fixed order s = 0, 1, 2, ... (bit-identical to mv2d_row_ln)
+            const float* pp = p.parts + grow;
+            int s = 0;
+            for (; s + 16 <= p.n_parts; s += 16) {
+                float4 t[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
+                for (int j = 0; j < 16; ++j) t[j] = *reinterpret_cast<const float4*>(pp + (s + j) * p.part_stride);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
+            }
+            for (; s < p.n_parts; ++s) {
+                const float4 t = *reinterpret_cast<const float4*>(pp + s * p.part_stride);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
         }
-        for (; s < p.n_parts; ++s) {
-            const float4 t = *reinterpret_cast<const float4*>(pp + s * p.part_stride);
+        {
+            const float4 t = *reinterpret_cast<const float4*>(p.b2 + lane * 4), u = *reinterpret_cast<const float4*>(p.resid + grow);
             v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
-    }
-    {
-        const float4 t = *reinterpret_cast<const float4*>(p.b2 + lane * 4), u = *reinterpret_cast<const float4*>(p.resid + grow);
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-    }
-    v = ln_row(v, p.lw, p.lb, lane * 4, p.eps);
-    const float4 qp = *reinterpret_cast<const float4*>(p.qpos + grow);
-    const float4 vq = make_float4(v.x + qp.x, v.y + qp.y, v.z + qp.z, v.w + qp.w);
-    if (m < p.M) {
-        *reinterpret_cast<float4*>(p.x_out + grow) = v;
-        *reinterpret_cast<float4*>(p.xq_out + grow) = vq;
-        if (p.outs) *reinterpret_cast<float4*>(p.outs + grow) = ln_row(v, p.pw, p.pb, lane * 4, p.eps);
-    } else if (p.outs) {
-        (void)ln_row(v, p.pw, p.pb, lane * 4, p.eps);            // keep the wave-wide reductions convergent
+        v = ln_row(v, p.lw, p.lb, lane * 4, p.eps);
+        const float4 qp = *reinterpret_cast<const float4*>(p.qpos + grow);
+        const float4 vq = make_float4(v.x + qp.x, v.y + qp.y, v.z + qp.z, v.w + qp.w);
+        if (m < p.M) {
+            *reinterpret_cast<float4*>(p.x_out + grow) = v;
+            *reinterpret_cast<float4*>(p.xq_out + grow) = vq;
+            if (p.outs) *reinterpret_cast<float4*>(p.outs + grow) = ln_row(v, p.pw, p.pb, lane * 4, p.eps);
+        } else if (p.outs) {
+            (void)ln_row(v, p.pw, p.pb, lane * 4, p.eps);        // keep the wave-wide reductions convergent
+        }
+        if (p.Wh) {
+            uint2 hi, lo;
+            split4(vq, hi, lo);
+            *reinterpret_cast<uint2*>(qh + rt * 8192 + aoff) = hi; *reinterpret_cast<uint2*>(ql + rt * 8192 + aoff) = lo;
+            split4(v, hi, lo);
+            *reinterpret_cast<uint2*>(xh + rt * 8192 + aoff) = hi; *reinterpret_cast<uint2*>(xl + rt * 8192 + aoff) = lo;
+        }
     }
     if (!p.Wh) return;
-    {
-        const int aoff = wave * 512 + (((lane >> 1) ^ wave) << 4) + (lane & 1) * 8;
-        uint2 hi, lo;
-        split4(vq, hi, lo);
-        *reinterpret_cast<uint2*>(qh + aoff) = hi; *reinterpret_cast<uint2*>(ql + aoff) = lo;
-        split4(v, hi, lo);
-        *reinterpret_cast<uint2*>(xh + aoff) = hi; *reinterpret_cast<uint2*>(xl + aoff) = lo;
-    }
     __syncthreads();
     // ---- in_proj: 6 half-tile stages (q0 q1 k0 k1 v0 v1), double-buffered weight fragments
 #pragma unroll
     for (int kind = 0; kind < 3; ++kind) {
         const unsigned char* ah = kind < 2 ? qh : xh;
         const unsigned char* al = kind < 2 ? ql : xl;
-        f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4_t a0[RT], a1[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) { a0[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; a1[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int st = 2 * kind + h, buf = st & 1;
@@ -561,22 +568,27 @@ __global__ __launch_bounds__(1024) void ffn_out_fused_x3_kernel(FfnOutParams p) 
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                BFrag ya, yb;
-                const int off = fr * 512 + (((4 * (4 * h + s) + fg) ^ fr) << 4);
-                ya.u = *reinterpret_cast<const uint4*>(ah + off);
-                yb.u = *reinterpret_cast<const uint4*>(al + off);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya.v, wh[buf][s].v, a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yb.v, wh[buf][s].v, a1, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya.v, wl[buf][s].v, a1, 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    BFrag ya, yb;
+                    const int off = rt * 8192 + fr * 512 + (((4 * (4 * h + s) + fg) ^ fr) << 4);
+                    ya.u = *reinterpret_cast<const uint4*>(ah + off);
+                    yb.u = *reinterpret_cast<const uint4*>(al + off);
+                    a0[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya.v, wh[buf][s].v, a0[rt], 0, 0, 0);
+                    a1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yb.v, wh[buf][s].v, a1[rt], 0, 0, 0);
+                    a1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya.v, wl[buf][s].v, a1[rt], 0, 0, 0);
+                }
             }
         }
         const int col = kind * 256 + wave * 16 + fr;
         const float b = p.b_in[col];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int mm = m0 + 4 * fg + r;
-            if (mm < p.M) p.qkv[(long long)mm * 768 + col] = (a0[r] + a1[r]) + b;
-        }
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mm = mb + 16 * rt + 4 * fg + r;
+                if (mm < p.M) p.qkv[(long long)mm * 768 + col] = (a0[rt][r] + a1[rt][r]) + b;
+            }
     }
 }
 
@@ -1089,7 +1101,9 @@ extern "C" int mv2d_ffn_out_fused_x3(const float* parts, int n_parts, long long 
     if (M == 0) return MV2D_OK;
     FfnOutParams p{parts, n_parts, part_stride, b2, resid, ln_w, ln_b, post_w, post_b, x_out, qpos, xq_out, outs,
                    (const unsigned short*)Win_hi, (const unsigned short*)Win_lo, b_in, qkv, M, eps};
-    hipLaunchKernelGGL(ffn_out_fused_x3_kernel, dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p);
+    static const int rt2 = getenv("MV2D_FFNOUT_RT2") ? atoi(getenv("MV2D_FFNOUT_RT2")) : 0;     // experiment switch: no gain (the slab sum doubles per block)
+    if (M <= 512 || !rt2) hipLaunchKernelGGL(ffn_out_fused_x3_kernel<1>, dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(ffn_out_fused_x3_kernel<2>, dim3(cdiv(M, 32)), dim3(1024), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
