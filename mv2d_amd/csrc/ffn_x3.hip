@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256, G == 1 ? 2 : 1) void ffn_x3_kernel(const float
                                                         const unsigned short* __restrict__ W1l, const float* __restrict__ b1,
                                                         const unsigned short* __restrict__ W2h, const unsigned short* __restrict__ W2l,
                                                         float* __restrict__ slabs, int M, int hidden) {
-    __shared__ __attribute__((aligned(16))) unsigned char xh[BR * C * 2], xl[BR * C * 2], hh[2][BR * HS * 2], hl[2][BR * HS * 2];
+    constexpr int NHB = G > 1 ? 2 : 1;                   // H buffers (they alternate between the slices of a block)
+    __shared__ __attribute__((aligned(16))) unsigned char xh[BR * C * 2], xl[BR * C * 2], hh[NHB][BR * HS * 2], hl[NHB][BR * HS * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int slab = blockIdx.x, m0 = blockIdx.y * BR;
     const int nt = hidden / 16;
@@ -78,16 +79,25 @@ __global__ __launch_bounds__(256, G == 1 ? 2 : 1) void ffn_x3_kernel(const float
         *reinterpret_cast<uint4*>(xl + xoff(row, slot)) = l4;
     }
     __syncthreads();
-    f32x4_t a0[RTB][4], a1[RTB][4];
+    // separate accumulators for the hi.hi products and the two correction products, or (MV2D_FFN_MERGE, needed for 4 row tiles per
+    // block to fit the registers) one fp32 accumulator for all three
+#ifdef MV2D_FFN_MERGE
+    constexpr int NACC = 1;
+#else
+    constexpr int NACC = 2;
+#endif
+    f32x4_t acc[NACC][RTB][4];
 #pragma unroll
-    for (int r = 0; r < RTB; ++r)
+    for (int n = 0; n < NACC; ++n)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { a0[r][t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; a1[r][t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+        for (int r = 0; r < RTB; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[n][r][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int slice = slab * G + g;
-        unsigned char* hhg = hh[g & 1];
-        unsigned char* hlg = hl[g & 1];
+        unsigned char* hhg = hh[g & (NHB - 1)];
+        unsigned char* hlg = hl[g & (NHB - 1)];
         // W2 slice fragments of this wave's four output tiles: in flight while phase 1 computes
         Frag w2h[4][2], w2l[4][2];
 #pragma unroll
@@ -142,9 +152,9 @@ __global__ __launch_bounds__(256, G == 1 ? 2 : 1) void ffn_x3_kernel(const float
                 gl.u = *reinterpret_cast<const uint4*>(hlg + hoff(r * 16 + fr, 4 * s + fg));
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    a0[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2h[t][s].v, gh.v, a0[r][t], 0, 0, 0);
-                    a1[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2h[t][s].v, gl.v, a1[r][t], 0, 0, 0);
-                    a1[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2l[t][s].v, gh.v, a1[r][t], 0, 0, 0);
+                    acc[0][r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2h[t][s].v, gh.v, acc[0][r][t], 0, 0, 0);
+                    acc[NACC - 1][r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2h[t][s].v, gl.v, acc[NACC - 1][r][t], 0, 0, 0);
+                    acc[NACC - 1][r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2l[t][s].v, gh.v, acc[NACC - 1][r][t], 0, 0, 0);
                 }
             }
         }
@@ -156,8 +166,10 @@ __global__ __launch_bounds__(256, G == 1 ? 2 : 1) void ffn_x3_kernel(const float
             float* out = slabs + ((long long)slab * M + m) * C + 64 * wave + 4 * fg;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                *reinterpret_cast<float4*>(out + 16 * t) =
-                    make_float4(a0[r][t][0] + a1[r][t][0], a0[r][t][1] + a1[r][t][1], a0[r][t][2] + a1[r][t][2], a0[r][t][3] + a1[r][t][3]);
+                *reinterpret_cast<float4*>(out + 16 * t) = NACC == 2
+                    ? make_float4(acc[0][r][t][0] + acc[NACC - 1][r][t][0], acc[0][r][t][1] + acc[NACC - 1][r][t][1],
+                                  acc[0][r][t][2] + acc[NACC - 1][r][t][2], acc[0][r][t][3] + acc[NACC - 1][r][t][3])
+                    : make_float4(acc[0][r][t][0], acc[0][r][t][1], acc[0][r][t][2], acc[0][r][t][3]);
         }
     }
 }
