@@ -258,6 +258,9 @@ extern "C" int mv2d_sparse_xattn_fwd(const float* q, const void* K, const void* 
     else if (cfg == 416) MV2D_XA(4, 16);
     else if (cfg == 28) MV2D_XA(2, 8);
     else if (cfg == 88) MV2D_XA(8, 8);
+    else if (cfg == 164) MV2D_XA(16, 4);
+    else if (cfg == 162) MV2D_XA(16, 2);
+    else if (cfg == 82) MV2D_XA(8, 2);
     else MV2D_XA(8, 4);
 #undef MV2D_XA
     MV2D_LAUNCH_CHECK();

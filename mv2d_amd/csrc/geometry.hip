@@ -581,9 +581,10 @@ __global__ __launch_bounds__(256) void pe_inputs_kernel(const int* __restrict__ 
             n = n < 0.0 ? 0.0 : (n > 1.0 ? 1.0 : n);          // inverse_sigmoid: clamp(0,1)
             const double x1 = n < 1e-5 ? 1e-5 : n;
             const double x2 = (1.0 - n) < 1e-5 ? 1e-5 : (1.0 - n);
-            // the quotient in fp64 like the reference (MU/pe.py:119-130 runs on double coordinates), its logarithm in fp32: 1e-7
-            // against a value that is rounded to bf16 right here (a double log is ~100 fp64 instructions, 192 of them per position)
-            fr_row[dk * 3 + i] = f32_to_bf16(logf((float)(x1 / x2)));
+            // the normalised coordinate in fp64 like the reference (MU/pe.py:119-130 runs on double coordinates); quotient and
+            // logarithm in fp32: 1e-7 absolute against a value that is rounded to bf16 right here (a double division + double log
+            // are ~130 fp64 instructions, 192 of them per position: the kernel was bound by them)
+            fr_row[dk * 3 + i] = f32_to_bf16(logf((float)x1 / (float)x2));
         }
     }
     // sine features, channel order (n | y | x).  NOT interleaved: the reference stacks sin/cos on dim=4 of a
