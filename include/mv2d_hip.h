@@ -220,6 +220,13 @@ int mv2d_self_attn_fwd(const float* qkv, float* ctx, int R, const int* grp_start
 int mv2d_sparse_xattn_fwd(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, float* ctx,
                           float* dbg_logits, long long dbg_stride, int R, int empty_nan, void* stream);
 
+/* Backward of mv2d_sparse_xattn_fwd ("next" row f3, the training path of the head): given dctx [R,256] returns dq [R,256] (gradient
+ * with respect to the pre-scaled q) and ACCUMULATES dK, dV [S,256] fp32 with atomics (the caller zeroes them; several queries share a
+ * key).  ctx = the forward output (D = dctx.ctx per head); the softmax statistics are recomputed, no forward state is kept.  Rows
+ * without an allowed key get dq = 0. */
+int mv2d_sparse_xattn_bwd(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
+                          const float* dctx, float* dq, float* dK, float* dV, int R, void* stream);
+
 /* ---- geometry / gather ---------------------------------------------------------------------------------- */
 
 /* MV2DHead.get_box_params + process_intrins_feat (RH/mv2d_head.py:51-72,95-101) and inverse(K_roi @ E^T).float()

@@ -233,6 +233,84 @@ __global__ __launch_bounds__(64 * NW) void sparse_xattn_kernel(const float* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward of the sparse cross attention ("next" row f3: the training path of the head needs it; forward = sparse_xattn_kernel).
+//   s_j = q.k_j, p = softmax_j(s) per head, ctx = sum_j p_j v_j   over the keys j the CSR row allows
+//   d ctx given:  dp_j = dctx.v_j,  ds_j = p_j (dp_j - D),  D = sum_j p_j dp_j = dctx.ctx (per head)
+//   dq = sum_j ds_j k_j,   dK[j] += ds_j q,   dV[j] += p_j dctx        (dK / dV: fp32 atomics, several queries share a key)
+// One 4-wave block per query, lane l = channels 4l..4l+3 (head l >> 3) like the forward kernel; the keys of the row are dealt to
+// the waves round robin.  Pass 1 recomputes the softmax statistics (no forward state is kept), pass 2 forms the gradients.
+// q is the SCALED query the forward kernel received (dq is the gradient with respect to it).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float head_sum(float d) {
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    return d;
+}
+__device__ __forceinline__ float4 bf16x4(const uint2 u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+
+__global__ __launch_bounds__(256) void sparse_xattn_bwd_kernel(const float* __restrict__ q, const unsigned short* __restrict__ K,
+                                                               const unsigned short* __restrict__ V, const int* __restrict__ row_ptr,
+                                                               const int* __restrict__ col_idx, const float* __restrict__ ctx,
+                                                               const float* __restrict__ dctx, float* __restrict__ dq, float* __restrict__ dK,
+                                                               float* __restrict__ dV, int R) {
+    __shared__ float sm[4][8], sl[4][8], sdq[4][C];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 3;
+    const int beg = row_ptr[r], end = row_ptr[r + 1];
+    const long long ro = (long long)r * C + 4 * lane;
+    if (end <= beg) {                                        // no key: the forward output does not depend on q
+        if (wave == 0) *reinterpret_cast<float4*>(dq + ro) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const float4 q4 = *reinterpret_cast<const float4*>(q + ro);
+    const float4 c4 = *reinterpret_cast<const float4*>(ctx + ro);
+    const float4 d4 = *reinterpret_cast<const float4*>(dctx + ro);
+    const float D = head_sum(d4.x * c4.x + d4.y * c4.y + d4.z * c4.z + d4.w * c4.w);
+    // ---- pass 1: softmax statistics of the row (per head)
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int e = beg + wave; e < end; e += 4) {
+        const float4 k4 = bf16x4(*reinterpret_cast<const uint2*>(K + (long long)col_idx[e] * C + 4 * lane));
+        const float sv = head_sum(k4.x * q4.x + k4.y * q4.y + k4.z * q4.z + k4.w * q4.w);
+        const float m_new = fmaxf(m_run, sv);
+        l_run = l_run * expf(m_run - m_new) + expf(sv - m_new);
+        m_run = m_new;
+    }
+    if ((lane & 7) == 0) { sm[wave][h] = m_run; sl[wave][h] = l_run; }
+    __syncthreads();
+    float M = fmaxf(fmaxf(sm[0][h], sm[1][h]), fmaxf(sm[2][h], sm[3][h])), den = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) den += sl[w][h] * expf(sm[w][h] - M);      // waves without a key: exp(-inf) = 0
+    const float lse = M + logf(den);
+    // ---- pass 2: gradients
+    float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = beg + wave; e < end; e += 4) {
+        const long long ko = (long long)col_idx[e] * C + 4 * lane;
+        const float4 k4 = bf16x4(*reinterpret_cast<const uint2*>(K + ko));
+        const float4 v4 = bf16x4(*reinterpret_cast<const uint2*>(V + ko));
+        const float sv = head_sum(k4.x * q4.x + k4.y * q4.y + k4.z * q4.z + k4.w * q4.w);
+        const float pj = expf(sv - lse);
+        const float dp = head_sum(d4.x * v4.x + d4.y * v4.y + d4.z * v4.z + d4.w * v4.w);
+        const float ds = pj * (dp - D);
+        gq.x = fmaf(ds, k4.x, gq.x); gq.y = fmaf(ds, k4.y, gq.y); gq.z = fmaf(ds, k4.z, gq.z); gq.w = fmaf(ds, k4.w, gq.w);
+        atomicAdd(dK + ko + 0, ds * q4.x); atomicAdd(dK + ko + 1, ds * q4.y); atomicAdd(dK + ko + 2, ds * q4.z); atomicAdd(dK + ko + 3, ds * q4.w);
+        atomicAdd(dV + ko + 0, pj * d4.x); atomicAdd(dV + ko + 1, pj * d4.y); atomicAdd(dV + ko + 2, pj * d4.z); atomicAdd(dV + ko + 3, pj * d4.w);
+    }
+    *reinterpret_cast<float4*>(&sdq[wave][4 * lane]) = gq;
+    __syncthreads();
+    if (wave == 0) {
+        float4 o = *reinterpret_cast<float4*>(&sdq[0][4 * lane]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float4 t = *reinterpret_cast<float4*>(&sdq[w][4 * lane]);
+            o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+        }
+        *reinterpret_cast<float4*>(dq + ro) = o;
+    }
+}
+
 }  // namespace
 
 extern "C" int mv2d_self_attn_fwd(const float* qkv, float* ctx, int R, const int* grp_start, int n_grp, void* stream) {
@@ -263,6 +341,16 @@ extern "C" int mv2d_sparse_xattn_fwd(const float* q, const void* K, const void* 
     else if (cfg == 82) MV2D_XA(8, 2);
     else MV2D_XA(8, 4);
 #undef MV2D_XA
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_sparse_xattn_bwd(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
+                                     const float* dctx, float* dq, float* dK, float* dV, int R, void* stream) {
+    MV2D_CHECK_ARG(q && K && V && row_ptr && col_idx && ctx && dctx && dq && dK && dV && R >= 0, "mv2d_sparse_xattn_bwd: bad args");
+    if (R == 0) return MV2D_OK;
+    hipLaunchKernelGGL(sparse_xattn_bwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, q, (const unsigned short*)K, (const unsigned short*)V,
+                       row_ptr, col_idx, ctx, dctx, dq, dK, dV, R);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

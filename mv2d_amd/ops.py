@@ -378,6 +378,36 @@ def sparse_xattn(q, K, V, row_ptr, col_idx, out=None, R=None, dbg_logits=None, e
     return out
 
 
+
+def sparse_xattn_bwd(q, K, V, row_ptr, col_idx, ctx, dctx, R=None):
+    """Backward of sparse_xattn: returns (dq [R,256] fp32 w.r.t. the pre-scaled q, dK, dV [S,256] fp32)."""
+    _req(q, torch.float32, 'q'); _req(K, BF16, 'K'); _req(V, BF16, 'V'); _req(ctx, torch.float32, 'ctx'); _req(dctx, torch.float32, 'dctx')
+    R = q.shape[0] if R is None else R
+    dq = torch.empty((R, 256), device=q.device, dtype=torch.float32)
+    dK = torch.zeros(K.shape, device=q.device, dtype=torch.float32)
+    dV = torch.zeros(V.shape, device=q.device, dtype=torch.float32)
+    check(_lib.load().mv2d_sparse_xattn_bwd(_p(q), _p(K), _p(V), _p(row_ptr), _p(col_idx), _p(ctx), _p(dctx.contiguous()), _p(dq), _p(dK), _p(dV),
+                                            R, _stream()), 'mv2d_sparse_xattn_bwd')
+    return dq, dK, dV
+
+
+class SparseCrossAttention(torch.autograd.Function):
+    """ctx = softmax over the allowed keys (q . K^T) . V per head; q [R,256] fp32 pre-scaled, K / V [S,256] bf16, CSR (row_ptr, col_idx).
+    Differentiable in q, K, V (dK / dV returned in bf16 like their inputs): the attention core of PETRMultiheadAttention for the
+    training path of the head."""
+
+    @staticmethod
+    def forward(fctx, q, K, V, row_ptr, col_idx, empty_nan=False):
+        out = sparse_xattn(q.contiguous(), K.contiguous(), V.contiguous(), row_ptr, col_idx, R=q.shape[0], empty_nan=empty_nan)
+        fctx.save_for_backward(q, K, V, row_ptr, col_idx, out)
+        return out
+
+    @staticmethod
+    def backward(fctx, dout):
+        q, K, V, row_ptr, col_idx, out = fctx.saved_tensors
+        dq, dK, dV = sparse_xattn_bwd(q.contiguous(), K.contiguous(), V.contiguous(), row_ptr, col_idx, out, dout.float().contiguous())
+        return dq, dK.to(K.dtype), dV.to(V.dtype), None, None, None
+
 def box_params(rois, viewK, viewE, intr, ld_intr, minv, K_roi=None, roi_size=7.0, intr_scale=0.1, min_size=4.0):
     _req(rois, torch.float32, 'rois'); _req(viewK, torch.float64, 'viewK'); _req(viewE, torch.float64, 'viewE')
     check(_lib.load().mv2d_box_params(_p(rois), _p(viewK), _p(viewE), _p(K_roi), _p(intr), ld_intr, _p(minv), rois.shape[0],

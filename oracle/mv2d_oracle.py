@@ -619,6 +619,20 @@ def _to_t(sd):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v for k, v in sd.items()}
 
 
+def masked_cross_attention(q, K, V, allowed):
+    """Attention core of PETRMultiheadAttention (MU/petr_transformer.py:487-513 -> nn.MultiheadAttention with a boolean attn_mask):
+    q [Q,256] already scaled by 1/sqrt(32), K / V [S,256], allowed [Q,S] bool; 8 heads x 32; rows without an allowed key give 0
+    here (the module itself gives NaN).  Differentiable: torch autograd of this function is the oracle of mv2d_sparse_xattn_bwd."""
+    Q, S = q.shape[0], K.shape[0]
+    qh = q.view(Q, 8, 32).transpose(0, 1)
+    kh = K.view(S, 8, 32).transpose(0, 1)
+    vh = V.view(S, 8, 32).transpose(0, 1)
+    logits = (qh @ kh.transpose(1, 2)).masked_fill(~allowed[None], float('-inf'))
+    att = torch.softmax(logits, -1)
+    att = torch.where(allowed.any(1)[None, :, None], att, torch.zeros_like(att))
+    return (att @ vh).transpose(0, 1).reshape(Q, 256)
+
+
 def csr_from_allowed(allowed):
     """allowed [Q,S] bool -> (row_ptr int32 [Q+1], col_idx int32 [nnz]) row-major."""
     counts = allowed.sum(1)

@@ -311,6 +311,45 @@ def test_sparse_xattn(dev):
     assert relerr(dbg, lg_ref) < 1e-5
 
 
+@pytest.mark.parametrize('R,S,dens', [(37, 500, 0.05), (301, 5000, 0.02), (64, 49 * 64, -1.0)])
+def test_sparse_xattn_backward(dev, R, S, dens):
+    """"next" row f3: gradients of the sparse cross attention (dq, dK, dV) == torch autograd of the oracle's dense masked attention in
+    fp64 on the same bf16-rounded keys / values; keys shared by several queries, a row without keys, a single-key row; dens < 0 = the
+    S-path pattern (every query reads the 49 cells of its own RoI)."""
+    from mv2d_amd import ops
+    from oracle import mv2d_oracle as O
+    g = np.random.Generator(np.random.PCG64(160 + R))
+    if dens > 0:
+        allowed = torch.from_numpy(g.random((R, S)) < dens)
+        allowed[5] = False                                   # no key at all
+        allowed[7, :] = False
+        allowed[7, 123] = True                               # a single key
+    else:
+        allowed = torch.zeros((R, S), dtype=torch.bool)
+        for r in range(R):
+            allowed[r, r * 49:(r + 1) * 49] = True
+            allowed[r, ((r + 3) % R) * 49:((r + 3) % R) * 49 + 49] = True    # one correlated RoI
+    q = rnd((R, 256), 161).to(dev)
+    K = rnd((S, 256), 162).to(dev).to(torch.bfloat16)
+    V = rnd((S, 256), 163).to(dev).to(torch.bfloat16)
+    dout = rnd((R, 256), 164).to(dev)
+    row_ptr, col = O.csr_from_allowed(allowed)
+    qd = q.double().requires_grad_(True); Kd = K.double().requires_grad_(True); Vd = V.double().requires_grad_(True)
+    ref = O.masked_cross_attention(qd, Kd, Vd, allowed.to(dev))
+    ref.backward(dout.double())
+    # through the autograd wrapper of the product path
+    q2 = q.clone().requires_grad_(True); K2 = K.clone().requires_grad_(True); V2 = V.clone().requires_grad_(True)
+    out = ops.SparseCrossAttention.apply(q2, K2, V2, row_ptr.to(dev), col.to(dev))
+    assert relerr(out, ref) < 1e-5
+    out.backward(dout)
+    assert relerr(q2.grad, qd.grad) < 1e-5
+    dq, dK, dV = ops.sparse_xattn_bwd(q, K, V, row_ptr.to(dev), col.to(dev), out.detach(), dout)       # fp32 gradients
+    assert relerr(dq, qd.grad) < 1e-5 and relerr(dK, Kd.grad) < 2e-5 and relerr(dV, Vd.grad) < 2e-5
+    assert relerr(K2.grad.float(), Kd.grad) < 8e-3 and relerr(V2.grad.float(), Vd.grad) < 8e-3           # returned in bf16
+    if dens > 0:
+        assert float(dq[5].abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------------------------------ geometry
 def _problem(name):
     prob = synthetic.make_problem(name, seed=0)
