@@ -221,11 +221,14 @@ int mv2d_sparse_xattn_fwd(const float* q, const void* K, const void* V, const in
                           float* dbg_logits, long long dbg_stride, int R, int empty_nan, void* stream);
 
 /* Backward of mv2d_sparse_xattn_fwd ("next" row f3, the training path of the head): given dctx [R,256] returns dq [R,256] (gradient
- * with respect to the pre-scaled q) and ACCUMULATES dK, dV [S,256] fp32 with atomics (the caller zeroes them; several queries share a
- * key).  ctx = the forward output (D = dctx.ctx per head); the softmax statistics are recomputed, no forward state is kept.  Rows
- * without an allowed key get dq = 0. */
+ * with respect to the pre-scaled q) and dK, dV [S,256] fp32 (every key row is written; keys nobody reads get 0).  Two launches, no
+ * atomics, deterministic: a pass over the queries (softmax statistics recomputed, no forward state kept; writes dq and, per allowed pair
+ * e and head, p and ds into pair_ws [nnz,16]) and a pass over the keys that needs the pairs sorted by key: key_ptr [S+1], pair_idx [nnz]
+ * (pair ids in CSR order, grouped by key), pair_row [nnz] (query of pair e).  ctx = the forward output.  Rows without an allowed key
+ * get dq = 0. */
 int mv2d_sparse_xattn_bwd(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
-                          const float* dctx, float* dq, float* dK, float* dV, int R, void* stream);
+                          const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws,
+                          float* dq, float* dK, float* dV, int R, int S, void* stream);
 
 /* ---- geometry / gather ---------------------------------------------------------------------------------- */
 

@@ -51,7 +51,7 @@ SIGNATURES = {
     'mv2d_map_conv3x3': (I, [P, P, P, P, I, I, I, P]),
     'mv2d_self_attn_fwd': (I, [P, P, I, P, I, P]),
     'mv2d_sparse_xattn_fwd': (I, [P, P, P, P, P, P, P, LL, I, I, P]),
-    'mv2d_sparse_xattn_bwd': (I, [P, P, P, P, P, P, P, P, P, P, I, P]),
+    'mv2d_sparse_xattn_bwd': (I, [P] * 14 + [I, I, P]),
     'mv2d_box_params': (I, [P, P, P, P, P, I, P, I, F, F, F, P]),
     'mv2d_refpoint_posemb': (I, [P, I, P, P, P, P, P, I, P, P]),
     'mv2d_lidar2img_inverse': (I, [P, P, P, I, P]),

@@ -252,11 +252,11 @@ __device__ __forceinline__ float4 bf16x4(const uint2 u) {
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
 }
 
-__global__ __launch_bounds__(256) void sparse_xattn_bwd_kernel(const float* __restrict__ q, const unsigned short* __restrict__ K,
-                                                               const unsigned short* __restrict__ V, const int* __restrict__ row_ptr,
-                                                               const int* __restrict__ col_idx, const float* __restrict__ ctx,
-                                                               const float* __restrict__ dctx, float* __restrict__ dq, float* __restrict__ dK,
-                                                               float* __restrict__ dV, int R) {
+// pass over the queries: dq, and per allowed pair e the probabilities / logit gradients of the 8 heads: pd[e][0..7] = p, pd[e][8..15] = ds
+__global__ __launch_bounds__(256) void sparse_xattn_bwd_q_kernel(const float* __restrict__ q, const unsigned short* __restrict__ K,
+                                                                 const unsigned short* __restrict__ V, const int* __restrict__ row_ptr,
+                                                                 const int* __restrict__ col_idx, const float* __restrict__ ctx,
+                                                                 const float* __restrict__ dctx, float* __restrict__ dq, float* __restrict__ pd, int R) {
     __shared__ float sm[4][8], sl[4][8], sdq[4][C];
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 3;
     const int beg = row_ptr[r], end = row_ptr[r + 1];
@@ -269,14 +269,19 @@ __global__ __launch_bounds__(256) void sparse_xattn_bwd_kernel(const float* __re
     const float4 c4 = *reinterpret_cast<const float4*>(ctx + ro);
     const float4 d4 = *reinterpret_cast<const float4*>(dctx + ro);
     const float D = head_sum(d4.x * c4.x + d4.y * c4.y + d4.z * c4.z + d4.w * c4.w);
-    // ---- pass 1: softmax statistics of the row (per head)
+    // ---- pass 1: softmax statistics of the row (per head); the next key's row is requested before the current one is used
     float m_run = -INFINITY, l_run = 0.f;
-    for (int e = beg + wave; e < end; e += 4) {
-        const float4 k4 = bf16x4(*reinterpret_cast<const uint2*>(K + (long long)col_idx[e] * C + 4 * lane));
-        const float sv = head_sum(k4.x * q4.x + k4.y * q4.y + k4.z * q4.z + k4.w * q4.w);
-        const float m_new = fmaxf(m_run, sv);
-        l_run = l_run * expf(m_run - m_new) + expf(sv - m_new);
-        m_run = m_new;
+    {
+        int e = beg + wave;
+        uint2 kn = e < end ? *reinterpret_cast<const uint2*>(K + (long long)col_idx[e] * C + 4 * lane) : make_uint2(0u, 0u);
+        for (; e < end; e += 4) {
+            const float4 k4 = bf16x4(kn);
+            if (e + 4 < end) kn = *reinterpret_cast<const uint2*>(K + (long long)col_idx[e + 4] * C + 4 * lane);
+            const float sv = head_sum(k4.x * q4.x + k4.y * q4.y + k4.z * q4.z + k4.w * q4.w);
+            const float m_new = fmaxf(m_run, sv);
+            l_run = l_run * expf(m_run - m_new) + expf(sv - m_new);
+            m_run = m_new;
+        }
     }
     if ((lane & 7) == 0) { sm[wave][h] = m_run; sl[wave][h] = l_run; }
     __syncthreads();
@@ -284,19 +289,28 @@ __global__ __launch_bounds__(256) void sparse_xattn_bwd_kernel(const float* __re
 #pragma unroll
     for (int w = 0; w < 4; ++w) den += sl[w][h] * expf(sm[w][h] - M);      // waves without a key: exp(-inf) = 0
     const float lse = M + logf(den);
-    // ---- pass 2: gradients
+    // ---- pass 2: p, ds per pair and head; dq
     float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int e = beg + wave; e < end; e += 4) {
-        const long long ko = (long long)col_idx[e] * C + 4 * lane;
-        const float4 k4 = bf16x4(*reinterpret_cast<const uint2*>(K + ko));
-        const float4 v4 = bf16x4(*reinterpret_cast<const uint2*>(V + ko));
-        const float sv = head_sum(k4.x * q4.x + k4.y * q4.y + k4.z * q4.z + k4.w * q4.w);
-        const float pj = expf(sv - lse);
-        const float dp = head_sum(d4.x * v4.x + d4.y * v4.y + d4.z * v4.z + d4.w * v4.w);
-        const float ds = pj * (dp - D);
-        gq.x = fmaf(ds, k4.x, gq.x); gq.y = fmaf(ds, k4.y, gq.y); gq.z = fmaf(ds, k4.z, gq.z); gq.w = fmaf(ds, k4.w, gq.w);
-        atomicAdd(dK + ko + 0, ds * q4.x); atomicAdd(dK + ko + 1, ds * q4.y); atomicAdd(dK + ko + 2, ds * q4.z); atomicAdd(dK + ko + 3, ds * q4.w);
-        atomicAdd(dV + ko + 0, pj * d4.x); atomicAdd(dV + ko + 1, pj * d4.y); atomicAdd(dV + ko + 2, pj * d4.z); atomicAdd(dV + ko + 3, pj * d4.w);
+    {
+        int e = beg + wave;
+        uint2 kn = make_uint2(0u, 0u), vn = kn;
+        if (e < end) {
+            const long long ko = (long long)col_idx[e] * C + 4 * lane;
+            kn = *reinterpret_cast<const uint2*>(K + ko); vn = *reinterpret_cast<const uint2*>(V + ko);
+        }
+        for (; e < end; e += 4) {
+            const float4 k4 = bf16x4(kn), v4 = bf16x4(vn);
+            if (e + 4 < end) {
+                const long long ko = (long long)col_idx[e + 4] * C + 4 * lane;
+                kn = *reinterpret_cast<const uint2*>(K + ko); vn = *reinterpret_cast<const uint2*>(V + ko);
+            }
+            const float sv = head_sum(k4.x * q4.x + k4.y * q4.y + k4.z * q4.z + k4.w * q4.w);
+            const float pj = expf(sv - lse);
+            const float dp = head_sum(d4.x * v4.x + d4.y * v4.y + d4.z * v4.z + d4.w * v4.w);
+            const float ds = pj * (dp - D);
+            gq.x = fmaf(ds, k4.x, gq.x); gq.y = fmaf(ds, k4.y, gq.y); gq.z = fmaf(ds, k4.z, gq.z); gq.w = fmaf(ds, k4.w, gq.w);
+            if ((lane & 7) == 0) { pd[(long long)e * 16 + h] = pj; pd[(long long)e * 16 + 8 + h] = ds; }
+        }
     }
     *reinterpret_cast<float4*>(&sdq[wave][4 * lane]) = gq;
     __syncthreads();
@@ -309,6 +323,29 @@ __global__ __launch_bounds__(256) void sparse_xattn_bwd_kernel(const float* __re
         }
         *reinterpret_cast<float4*>(dq + ro) = o;
     }
+}
+
+// pass over the keys (one wave per key, deterministic, no atomics): dK[s] = sum over the pairs (r, s) of ds . q[r], dV[s] = sum p . dctx[r];
+// key_ptr [S+1] / pair_idx [nnz] = the allowed pairs sorted by key (pair ids in CSR order), pair_row [nnz] = query of every pair
+__global__ __launch_bounds__(256) void sparse_xattn_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ dctx, const float* __restrict__ pd,
+                                                                  const int* __restrict__ key_ptr, const int* __restrict__ pair_idx,
+                                                                  const int* __restrict__ pair_row, float* __restrict__ dK, float* __restrict__ dV, int S) {
+    const int lane = threadIdx.x & 63, h = lane >> 3;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= S) return;
+    float4 gk = make_float4(0.f, 0.f, 0.f, 0.f), gv = gk;
+    const int beg = key_ptr[s], end = key_ptr[s + 1];
+    for (int i = beg; i < end; ++i) {
+        const int e = pair_idx[i];
+        const long long ro = (long long)pair_row[e] * C + 4 * lane;
+        const float pj = pd[(long long)e * 16 + h], ds = pd[(long long)e * 16 + 8 + h];
+        const float4 q4 = *reinterpret_cast<const float4*>(q + ro);
+        const float4 d4 = *reinterpret_cast<const float4*>(dctx + ro);
+        gk.x = fmaf(ds, q4.x, gk.x); gk.y = fmaf(ds, q4.y, gk.y); gk.z = fmaf(ds, q4.z, gk.z); gk.w = fmaf(ds, q4.w, gk.w);
+        gv.x = fmaf(pj, d4.x, gv.x); gv.y = fmaf(pj, d4.y, gv.y); gv.z = fmaf(pj, d4.z, gv.z); gv.w = fmaf(pj, d4.w, gv.w);
+    }
+    *reinterpret_cast<float4*>(dK + (long long)s * C + 4 * lane) = gk;
+    *reinterpret_cast<float4*>(dV + (long long)s * C + 4 * lane) = gv;
 }
 
 }  // namespace
@@ -346,11 +383,17 @@ extern "C" int mv2d_sparse_xattn_fwd(const float* q, const void* K, const void* 
 }
 
 extern "C" int mv2d_sparse_xattn_bwd(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
-                                     const float* dctx, float* dq, float* dK, float* dV, int R, void* stream) {
-    MV2D_CHECK_ARG(q && K && V && row_ptr && col_idx && ctx && dctx && dq && dK && dV && R >= 0, "mv2d_sparse_xattn_bwd: bad args");
-    if (R == 0) return MV2D_OK;
-    hipLaunchKernelGGL(sparse_xattn_bwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, q, (const unsigned short*)K, (const unsigned short*)V,
-                       row_ptr, col_idx, ctx, dctx, dq, dK, dV, R);
+                                     const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws,
+                                     float* dq, float* dK, float* dV, int R, int S, void* stream) {
+    MV2D_CHECK_ARG(q && K && V && row_ptr && col_idx && ctx && dctx && key_ptr && pair_idx && pair_row && pair_ws && dq && dK && dV,
+                   "mv2d_sparse_xattn_bwd: null pointer");
+    MV2D_CHECK_ARG(R >= 0 && S >= 0, "mv2d_sparse_xattn_bwd: bad sizes");
+    if (R > 0)
+        hipLaunchKernelGGL(sparse_xattn_bwd_q_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, q, (const unsigned short*)K, (const unsigned short*)V,
+                           row_ptr, col_idx, ctx, dctx, dq, pair_ws, R);
+    if (S > 0)
+        hipLaunchKernelGGL(sparse_xattn_bwd_kv_kernel, dim3(cdiv(S, 4)), dim3(256), 0, (hipStream_t)stream, q, dctx, pair_ws, key_ptr, pair_idx, pair_row,
+                           dK, dV, S);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

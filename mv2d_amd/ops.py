@@ -379,34 +379,56 @@ def sparse_xattn(q, K, V, row_ptr, col_idx, out=None, R=None, dbg_logits=None, e
 
 
 
-def sparse_xattn_bwd(q, K, V, row_ptr, col_idx, ctx, dctx, R=None):
-    """Backward of sparse_xattn: returns (dq [R,256] fp32 w.r.t. the pre-scaled q, dK, dV [S,256] fp32)."""
+def csr_transpose(row_ptr, col_idx, S):
+    """The allowed pairs grouped by key (for the key pass of sparse_xattn_bwd): key_ptr [S+1], pair_idx [nnz] (pair ids in CSR order,
+    stable within a key), pair_row [nnz] (query of every pair); torch ops on the device of the CSR."""
+    nnz = col_idx.numel()
+    R = row_ptr.numel() - 1
+    counts = (row_ptr[1:] - row_ptr[:-1]).long()
+    pair_row = torch.repeat_interleave(torch.arange(R, device=col_idx.device, dtype=torch.int32), counts, output_size=nnz)
+    pair_idx = torch.sort(col_idx.long(), stable=True).indices.to(torch.int32)
+    key_ptr = torch.zeros(S + 1, device=col_idx.device, dtype=torch.int32)
+    key_ptr[1:] = torch.bincount(col_idx.long(), minlength=S).cumsum(0).to(torch.int32)
+    return key_ptr, pair_idx, pair_row
+
+
+def sparse_xattn_bwd(q, K, V, row_ptr, col_idx, ctx, dctx, R=None, transposed=None):
+    """Backward of sparse_xattn: returns (dq [R,256] fp32 w.r.t. the pre-scaled q, dK, dV [S,256] fp32); transposed = csr_transpose(...)
+    of the same CSR when the caller keeps it."""
     _req(q, torch.float32, 'q'); _req(K, BF16, 'K'); _req(V, BF16, 'V'); _req(ctx, torch.float32, 'ctx'); _req(dctx, torch.float32, 'dctx')
     R = q.shape[0] if R is None else R
+    S = K.shape[0]
+    nnz = col_idx.numel()
+    key_ptr, pair_idx, pair_row = transposed if transposed is not None else csr_transpose(row_ptr, col_idx[:nnz], S)
     dq = torch.empty((R, 256), device=q.device, dtype=torch.float32)
-    dK = torch.zeros(K.shape, device=q.device, dtype=torch.float32)
-    dV = torch.zeros(V.shape, device=q.device, dtype=torch.float32)
-    check(_lib.load().mv2d_sparse_xattn_bwd(_p(q), _p(K), _p(V), _p(row_ptr), _p(col_idx), _p(ctx), _p(dctx.contiguous()), _p(dq), _p(dK), _p(dV),
-                                            R, _stream()), 'mv2d_sparse_xattn_bwd')
+    dK = torch.empty((S, 256), device=q.device, dtype=torch.float32)
+    dV = torch.empty((S, 256), device=q.device, dtype=torch.float32)
+    pair_ws = torch.empty((max(nnz, 1), 16), device=q.device, dtype=torch.float32)
+    check(_lib.load().mv2d_sparse_xattn_bwd(_p(q), _p(K), _p(V), _p(row_ptr), _p(col_idx), _p(ctx), _p(dctx.contiguous()), _p(key_ptr), _p(pair_idx),
+                                            _p(pair_row), _p(pair_ws), _p(dq), _p(dK), _p(dV), R, S, _stream()), 'mv2d_sparse_xattn_bwd')
     return dq, dK, dV
 
 
 class SparseCrossAttention(torch.autograd.Function):
     """ctx = softmax over the allowed keys (q . K^T) . V per head; q [R,256] fp32 pre-scaled, K / V [S,256] bf16, CSR (row_ptr, col_idx).
     Differentiable in q, K, V (dK / dV returned in bf16 like their inputs): the attention core of PETRMultiheadAttention for the
-    training path of the head."""
+    training path of the head.  transposed = csr_transpose(row_ptr, col_idx, S): the decoder layers share
+    one CSR, so the caller builds it once for all of them (otherwise it is built in every backward)."""
 
     @staticmethod
-    def forward(fctx, q, K, V, row_ptr, col_idx, empty_nan=False):
+    def forward(fctx, q, K, V, row_ptr, col_idx, empty_nan=False, transposed=None):
         out = sparse_xattn(q.contiguous(), K.contiguous(), V.contiguous(), row_ptr, col_idx, R=q.shape[0], empty_nan=empty_nan)
         fctx.save_for_backward(q, K, V, row_ptr, col_idx, out)
+        fctx.transposed = transposed
         return out
 
     @staticmethod
     def backward(fctx, dout):
         q, K, V, row_ptr, col_idx, out = fctx.saved_tensors
-        dq, dK, dV = sparse_xattn_bwd(q.contiguous(), K.contiguous(), V.contiguous(), row_ptr, col_idx, out, dout.float().contiguous())
-        return dq, dK.to(K.dtype), dV.to(V.dtype), None, None, None
+        dq, dK, dV = sparse_xattn_bwd(q.contiguous(), K.contiguous(), V.contiguous(), row_ptr, col_idx, out, dout.float().contiguous(),
+                                      transposed=fctx.transposed)
+        return dq, dK.to(K.dtype), dV.to(V.dtype), None, None, None, None
+
 
 def box_params(rois, viewK, viewE, intr, ld_intr, minv, K_roi=None, roi_size=7.0, intr_scale=0.1, min_size=4.0):
     _req(rois, torch.float32, 'rois'); _req(viewK, torch.float64, 'viewK'); _req(viewE, torch.float64, 'viewE')

@@ -339,15 +339,20 @@ def test_sparse_xattn_backward(dev, R, S, dens):
     ref.backward(dout.double())
     # through the autograd wrapper of the product path
     q2 = q.clone().requires_grad_(True); K2 = K.clone().requires_grad_(True); V2 = V.clone().requires_grad_(True)
-    out = ops.SparseCrossAttention.apply(q2, K2, V2, row_ptr.to(dev), col.to(dev))
+    tr = ops.csr_transpose(row_ptr.to(dev), col.to(dev), S)
+    out = ops.SparseCrossAttention.apply(q2, K2, V2, row_ptr.to(dev), col.to(dev), False, tr)
     assert relerr(out, ref) < 1e-5
     out.backward(dout)
     assert relerr(q2.grad, qd.grad) < 1e-5
     dq, dK, dV = ops.sparse_xattn_bwd(q, K, V, row_ptr.to(dev), col.to(dev), out.detach(), dout)       # fp32 gradients
     assert relerr(dq, qd.grad) < 1e-5 and relerr(dK, Kd.grad) < 2e-5 and relerr(dV, Vd.grad) < 2e-5
     assert relerr(K2.grad.float(), Kd.grad) < 8e-3 and relerr(V2.grad.float(), Vd.grad) < 8e-3           # returned in bf16
+    d2 = ops.sparse_xattn_bwd(q, K, V, row_ptr.to(dev), col.to(dev), out.detach(), dout)
+    assert all(torch.equal(a, b) for a, b in zip((dq, dK, dV), d2))                                    # deterministic (no atomics)
     if dens > 0:
         assert float(dq[5].abs().max()) == 0.0
+        unused = ~allowed.any(0)
+        assert float(dK[unused.to(dev)].abs().max()) == 0.0 and float(dV[unused.to(dev)].abs().max()) == 0.0
 
 
 # ------------------------------------------------------------------------------------------ geometry

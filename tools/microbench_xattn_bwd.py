@@ -37,7 +37,8 @@ for name in ('S-path', 'T-path'):
     dout = torch.randn(R, 256, generator=g).to(dev)
     out = ops.sparse_xattn(q, K, V, row_ptr, col)
     tf = bench(lambda: ops.sparse_xattn(q, K, V, row_ptr, col, out=out))
-    tb = bench(lambda: ops.sparse_xattn_bwd(q, K, V, row_ptr, col, out, dout))
+    tr = ops.csr_transpose(row_ptr, col, S)
+    tb = bench(lambda: ops.sparse_xattn_bwd(q, K, V, row_ptr, col, out, dout, transposed=tr))
+    tt = bench(lambda: ops.csr_transpose(row_ptr, col, S))
     nnz = R * per
-    print(f'{name}: R={R} S={S} nnz={nnz}: forward {tf:.1f} us ({nnz * 1024 / tf / 1e6:.2f} TB/s of K/V rows), backward {tb:.1f} us '
-          f'(incl. zeroing dK/dV: {2 * S * 1024 / 1e6:.0f} MB)')
+    print(f'{name}: R={R} S={S} nnz={nnz}: forward {tf:.1f} us ({nnz * 1024 / tf / 1e6:.2f} TB/s of K/V rows), backward {tb:.1f} us (+ {tt:.1f} us to group the pairs by key, torch ops)')
