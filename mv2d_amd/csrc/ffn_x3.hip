@@ -39,7 +39,7 @@ __device__ __forceinline__ void split2(float a, float b, unsigned int& hi, unsig
 constexpr int RTB = MV2D_FFN_RTB, BR = 16 * RTB, NXR = BR / 8;      // row tiles / rows per block, X staging rounds
 
 template <int G>
-__global__ __launch_bounds__(256, G == 1 ? 2 : 1) void ffn_x3_kernel(const float* __restrict__ X, const unsigned short* __restrict__ W1h,
+__global__ __launch_bounds__(256, 2) void ffn_x3_kernel(const float* __restrict__ X, const unsigned short* __restrict__ W1h,
                                                         const unsigned short* __restrict__ W1l, const float* __restrict__ b1,
                                                         const unsigned short* __restrict__ W2h, const unsigned short* __restrict__ W2l,
                                                         float* __restrict__ slabs, int M, int hidden) {
@@ -184,13 +184,14 @@ extern "C" int mv2d_ffn_fused_x3(const float* X, const void* W1hi, const void* W
                        ((uintptr_t)W2lo & 15) == 0 && ((uintptr_t)slabs & 15) == 0 && ((uintptr_t)b1 & 15) == 0,
                    "mv2d_ffn_fused_x3: operands must be 16-byte aligned");
     const int G = slices_per_block;
-    MV2D_CHECK_ARG((G == 1 || G == 2 || G == 4) && (hidden / HS) % G == 0, "mv2d_ffn_fused_x3: slices_per_block must be 1, 2 or 4 and divide hidden/64");
+    MV2D_CHECK_ARG((G == 1 || G == 2 || G == 4 || G == 8) && (hidden / HS) % G == 0, "mv2d_ffn_fused_x3: slices_per_block must be 1, 2, 4 or 8 and divide hidden/64");
     if (M == 0) return MV2D_OK;
     const unsigned short *w1h = (const unsigned short*)W1hi, *w1l = (const unsigned short*)W1lo, *w2h = (const unsigned short*)W2hi, *w2l = (const unsigned short*)W2lo;
     const dim3 grid(hidden / HS / G, cdiv(M, BR));
     if (G == 1) hipLaunchKernelGGL(ffn_x3_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, X, w1h, w1l, b1, w2h, w2l, slabs, M, hidden);
     else if (G == 2) hipLaunchKernelGGL(ffn_x3_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, X, w1h, w1l, b1, w2h, w2l, slabs, M, hidden);
-    else hipLaunchKernelGGL(ffn_x3_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, X, w1h, w1l, b1, w2h, w2l, slabs, M, hidden);
+    else if (G == 4) hipLaunchKernelGGL(ffn_x3_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, X, w1h, w1l, b1, w2h, w2l, slabs, M, hidden);
+    else hipLaunchKernelGGL(ffn_x3_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, X, w1h, w1l, b1, w2h, w2l, slabs, M, hidden);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

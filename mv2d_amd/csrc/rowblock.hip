@@ -523,6 +523,13 @@ __global__ __launch_bounds__(1024) void ffn_out_fused_x3_kernel(FfnOutParams p) 
 #pragma unroll
                 for (int j = 0; j < 16; ++j) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
             }
+            for (; s + 4 <= p.n_parts; s += 4) {               // (8 or 4 slabs when the FFN accumulates several slices per block)
+                float4 t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const float4*>(pp + (s + j) * p.part_stride);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
+            }
             for (; s < p.n_parts; ++s) {
                 const float4 t = *reinterpret_cast<const float4*>(pp + s * p.part_stride);
                 v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;

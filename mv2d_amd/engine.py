@@ -561,10 +561,10 @@ class HeadEngine:
                 o.row_ln(ws['o'], residual=ws['x1'], ln=(W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), out=ws['x2'])
             parts = ws['parts']
             if self.ffn_x3:
-                # hidden slices accumulated per block (fewer slabs to write and re-read): G = 2 pays off for one sample (decoder 0.361 ->
-                # 0.344 ms at R = 300), with a batch (R = 1200) the one-block-per-CU variant loses what the slab traffic saves.  It
-                # changes the summation order, so it is not chosen by the row count: a sample's result must not depend on the batch.
-                G = self.ffn_groups if self.ffn_groups else 1
+                # four hidden slices accumulated per block: 8 slabs to write and re-read instead of 32 (6030 vs 5620 samples/s; one
+                # sample alone: decoder 0.336 vs 0.340 ms).  It fixes the summation order, so it is NOT chosen by the row count:
+                # a sample's result must not depend on the batch it is in.
+                G = self.ffn_groups if self.ffn_groups else 4
                 parts = parts[:parts.shape[0] // G]
                 o.ffn_fused_x3(ws['x2'], W_[f'ffn_w1x{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2x{i}'], parts, R, groups=G)
             else:

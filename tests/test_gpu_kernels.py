@@ -230,6 +230,9 @@ def test_ffn_fused_x3_split_precision(dev):
         W1p, W2p = ops.ffn_pack_weights(W1, W2)
         exact = ops.ffn_fused(x, W1p, b1, W2p)
         assert relerr(slabs.sum(0), exact.sum(0)) < 3e-5
+        for G in (2, 4, 8):                                   # G hidden slices accumulated per block: 32 / G slabs
+            sg = ops.ffn_fused_x3(x, ops.pack_x3(W1), b1, ops.pack_x3(W2), groups=G)
+            assert sg.shape == (32 // G, M, 256) and relerr(sg.sum(0), ref) < 3e-5
 
 
 # ------------------------------------------------------------------------------------------ rows
