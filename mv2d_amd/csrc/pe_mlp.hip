@@ -21,6 +21,13 @@
 
 namespace {
 
+#ifdef MV2D_PE_TRACE
+__device__ long long g_pe_trace[64];
+#define PE_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_pe_trace[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PE_STAMP(i) do {} while (0)
+#endif
+
 #ifndef MV2D_PE_BM
 #define MV2D_PE_BM 64
 #endif
@@ -122,7 +129,7 @@ enum Mid { MID_NONE = 0, MID_STAGE = 1, MID_FINAL = 3 };
 constexpr bool F_EARLY = false;
 // layer 1: LDS fragments of step t+1 requested during step t (16 more live registers where the pressure peaks) or at the start of step t
 constexpr bool A_AHEAD_L1 = false;
-struct Ctx { const unsigned short* next_in; const float* Xf32; int m0, M, tid, n0; };
+struct Ctx { const unsigned short* next_in; const float* Xf32; int m0, M, tid, n0; int stamp; };
 // all biases live in LDS (a global load in the middle of the pipeline would have to be waited for through the whole ring)
 enum { B_R = 0, B_E = 256, B_1A = 512, B_1B = 1536, B_2A = 1792, B_2B = 2816, B_FLOATS = 3072 };
 
@@ -169,7 +176,9 @@ __device__ __forceinline__ void mlp_part(const unsigned char* As, unsigned char*
             }
         }
     }
+    PE_STAMP(cx.stamp);                                // end of layer 1 (before the barrier)
     __syncthreads();                                   // the resident part of the hidden layer is complete
+    PE_STAMP(cx.stamp + 1);
     if (MID == MID_STAGE) stage_issue<NX>(sa, sb, cx.next_in, cx.m0, cx.M, cx.tid);
     if (MID == MID_FINAL && F_EARLY) {
 #pragma unroll
@@ -192,7 +201,10 @@ __device__ __forceinline__ void mlp_part(const unsigned char* As, unsigned char*
             for (int j = 0; j < CT2; ++j)
                 acc2[i][j] = MMA(wq[t & 3][j], a[t2 & 1][i], acc2[i][j]);
     }
+    PE_STAMP(cx.stamp + 2);                            // end of layer 2 (before the barrier)
     __syncthreads();                                   // everybody is done reading this part (and, after the last one, As / Hs are free)
+    PE_STAMP(cx.stamp + 3);
+    const_cast<Ctx&>(cx).stamp += 4;
 }
 
 __device__ __forceinline__ void zero_acc(f32x4_t (&acc)[RT][CT2]) {
@@ -241,7 +253,8 @@ __global__ __launch_bounds__(64 * NW, 1) void pe_fused_kernel(PeParams p) {
     f32x4_t acc[RT][CT2];
     f32x4_t g[RT][CT2];                                 // the gate, then P1 * gate: carried in registers through the next MLP
     float4 f[RT][CT2];                                  // feature rows
-    Ctx cx{p.A1, p.Xf32, m0, M, tid, n0};
+    Ctx cx{p.A1, p.Xf32, m0, M, tid, n0, 1};
+    PE_STAMP(0);
 
     // 1. gate = sigmoid(conv_expand(relu(conv_reduce(feat))))
     zero_acc(acc);
@@ -287,27 +300,41 @@ __global__ __launch_bounds__(64 * NW, 1) void pe_fused_kernel(PeParams p) {
         mlp_part<MlpB, 0, MlpB, 1, true, MID_NONE>(As, Hs, wB, Bs + B_2A, wB, acc, wq, lane, wave, cx, s0, s1, f);
         mlp_part<MlpB, 1, MlpB, 1, false, MID_FINAL>(As, Hs, wB, Bs + B_2A, wB, acc, wq, lane, wave, cx, s0, s1, f);
     }
-    if (!F_EARLY) {                                      // all 16 requests of a lane in one go: one exposed round trip per block
-#pragma unroll
-        for (int i = 0; i < RT; ++i)
-#pragma unroll
-            for (int j = 0; j < CT2; ++j)
-                f[i][j] = *reinterpret_cast<const float4*>(p.Xf32 + (long long)min(m0 + 16 * i + fr, M - 1) * C + n0 + 16 * j);
-    }
+    // ---- final epilogue.  The MFMA layout gives a lane 4 columns of 16 different rows: stored directly, every store instruction touches
+    // 16 rows x 64 bytes and the epilogue took 20 % of the kernel (store-issue bound, 19k cycles).  The tile goes through LDS (free
+    // after the last barrier) and comes back row-major: a wave stores 4 rows x 256 contiguous bytes per instruction, and the feature
+    // rows of Xk = bf16(pe + feat) are read the same way.
+    (void)f;
+    float* ot = reinterpret_cast<float*>(smem) + wave * (BM * 68);          // [BM rows][64 columns of this wave], pitch 68 floats
 #pragma unroll
     for (int j = 0; j < CT2; ++j) {
         const float4 eb = *reinterpret_cast<const float4*>(Bs + B_2B + n0 + 16 * j);
 #pragma unroll
-        for (int i = 0; i < RT; ++i) {
-            const int m = m0 + 16 * i + fr, n = n0 + 16 * j;
-            if (m >= M) continue;
-            const float4 v = make_float4((acc[i][j][0] + eb.x) + g[i][j][0], (acc[i][j][1] + eb.y) + g[i][j][1],
-                                         (acc[i][j][2] + eb.z) + g[i][j][2], (acc[i][j][3] + eb.w) + g[i][j][3]);
-            *reinterpret_cast<float4*>(p.pe + (long long)m * C + n) = v;
-            *reinterpret_cast<uint2*>(p.Xk + (long long)m * C + n) =
-                make_uint2(pack_bf16x2(v.x + f[i][j].x, v.y + f[i][j].y), pack_bf16x2(v.z + f[i][j].z, v.w + f[i][j].w));
+        for (int i = 0; i < RT; ++i)
+            *reinterpret_cast<float4*>(ot + (16 * i + fr) * 68 + 16 * j + 4 * fg) =
+                make_float4((acc[i][j][0] + eb.x) + g[i][j][0], (acc[i][j][1] + eb.y) + g[i][j][1],
+                            (acc[i][j][2] + eb.z) + g[i][j][2], (acc[i][j][3] + eb.w) + g[i][j][3]);
+    }
+    __builtin_amdgcn_wave_barrier();                         // the tile is read back by the same wave only
+    {
+        const int c4 = (lane & 15) * 4, r0 = lane >> 4;
+        const long long gcol = wave * (CT2 * 16) + c4;
+        float4 fv[BM / 4];
+#pragma unroll
+        for (int k = 0; k < BM / 4; ++k)
+            fv[k] = *reinterpret_cast<const float4*>(p.Xf32 + (long long)min(m0 + 4 * k + r0, M - 1) * C + gcol);
+#pragma unroll
+        for (int k = 0; k < BM / 4; ++k) {
+            const int row = 4 * k + r0, m = m0 + row;
+            const float4 v = *reinterpret_cast<const float4*>(ot + row * 68 + c4);
+            if (m < M) {
+                *reinterpret_cast<float4*>(p.pe + (long long)m * C + gcol) = v;
+                *reinterpret_cast<uint2*>(p.Xk + (long long)m * C + gcol) =
+                    make_uint2(pack_bf16x2(v.x + fv[k].x, v.y + fv[k].y), pack_bf16x2(v.z + fv[k].z, v.w + fv[k].w));
+            }
         }
     }
+    PE_STAMP(cx.stamp);
 }
 
 }  // namespace
@@ -329,3 +356,9 @@ extern "C" int mv2d_pe_fused(const void* A1, const void* A2, const void* Xfb, co
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
+
+#ifdef MV2D_PE_TRACE
+extern "C" int mv2d_pe_trace_read(long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pe_trace), n * sizeof(long long)) == hipSuccess ? 0 : -2;
+}
+#endif
