@@ -159,18 +159,27 @@ __global__ __launch_bounds__(256, 2) void ffn_x3_kernel(const float* __restrict_
             }
         }
     }
+    // The MFMA layout gives a lane 4 columns of 16 different rows (a store instruction would touch 16 rows x 64 bytes): the wave's
+    // 32 x 64 tile goes through its quarter of the X images (free since the barrier before the last phase 2) and is stored row-major,
+    // 4 rows x 256 contiguous bytes per instruction.
+    float4* ot = reinterpret_cast<float4*>(wave < 2 ? xh : xl) + (wave & 1) * (BR * 16);          // 8 KB per wave (RTB = 2)
+    static_assert(RTB == 2, "output staging assumes 32 rows per block");
 #pragma unroll
-    for (int r = 0; r < RTB; ++r) {
-        const int m = m0 + r * 16 + fr;
-        if (m < M) {
-            float* out = slabs + ((long long)slab * M + m) * C + 64 * wave + 4 * fg;
+    for (int r = 0; r < RTB; ++r)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                *reinterpret_cast<float4*>(out + 16 * t) = NACC == 2
-                    ? make_float4(acc[0][r][t][0] + acc[NACC - 1][r][t][0], acc[0][r][t][1] + acc[NACC - 1][r][t][1],
-                                  acc[0][r][t][2] + acc[NACC - 1][r][t][2], acc[0][r][t][3] + acc[NACC - 1][r][t][3])
-                    : make_float4(acc[0][r][t][0], acc[0][r][t][1], acc[0][r][t][2], acc[0][r][t][3]);
+        for (int t = 0; t < 4; ++t) {
+            const int row = 16 * r + fr;
+            ot[row * 16 + ((4 * t + fg) ^ (row & 15))] = NACC == 2
+                ? make_float4(acc[0][r][t][0] + acc[NACC - 1][r][t][0], acc[0][r][t][1] + acc[NACC - 1][r][t][1],
+                              acc[0][r][t][2] + acc[NACC - 1][r][t][2], acc[0][r][t][3] + acc[NACC - 1][r][t][3])
+                : make_float4(acc[0][r][t][0], acc[0][r][t][1], acc[0][r][t][2], acc[0][r][t][3]);
         }
+    __builtin_amdgcn_wave_barrier();                         // read back by the same wave only
+#pragma unroll
+    for (int k = 0; k < BR / 4; ++k) {
+        const int row = 4 * k + (lane >> 4), c4 = lane & 15, m = m0 + row;
+        const float4 v = ot[row * 16 + (c4 ^ (row & 15))];
+        if (m < M) *reinterpret_cast<float4*>(slabs + ((long long)slab * M + m) * C + 64 * wave + 4 * c4) = v;
     }
 }
 
