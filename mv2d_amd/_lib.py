@@ -15,6 +15,7 @@ class Mv2dHipError(RuntimeError):
 
 
 P, I, LL, F, D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
+ABI_VERSION = 2                  # include/mv2d_hip.h: mv2d_abi_version()
 
 # name -> (restype, argtypes) — mirrors include/mv2d_hip.h one to one
 SIGNATURES = {
@@ -88,6 +89,8 @@ def load(path=None):
             raise Mv2dHipError(f'{path} does not export {name}; rebuild with `python -m mv2d_amd.build --force`')
         fn.restype = res
         fn.argtypes = args
+    if lib.mv2d_abi_version() != ABI_VERSION:
+        raise Mv2dHipError(f'{path} implements ABI version {lib.mv2d_abi_version()}, this package needs {ABI_VERSION}: rebuild with `python -m mv2d_amd.build --force`')
     _lib = lib
     return lib
 
