@@ -68,10 +68,12 @@ int mv2d_attn_out_fused(const float* ctx, const float* resid, const float* Wo, c
 
 /* The position-encoding block of the PE module fused into one launch (MU/pe.py:36-48,64-77,150-166):
  *   pe = adapt_pos3d(A2) + position_encoder(A1) * sigmoid(conv_expand(relu(conv_reduce(Xf)))),  Xk = bf16(pe + Xf32)
- * A1 [M,192], A2 [M,384], Xfb [M,256] bf16 and Xf32 [M,256] fp32 rows (the outputs of mv2d_pe_inputs); all six weights in the
+ * A1 [M,192], A2 [M,384], Xfb [M,256] bf16 and Xf32 [M,256] fp32 rows (the outputs of mv2d_pe_inputs) -- or, with row_index != NULL,
+ * Xf32 = the position-major feature map itself and row_index [M] = the map row of every key (mv2d_pe_inputs then need not copy the fp32
+ * rows: its Xf_f32 output may be NULL); all six weights in the
  * FRAGMENT-MAJOR order of mv2d_pack_wfrag_bf16 (W1a [1024,192], W1b [256,1024], W2a [1024,384], W2b [256,1024], Wr/We [256,256]);
  * m_dev: optional device-side row count.  pe [M,256] fp32, Xk [M,256] bf16.  Bit-identical to the chain of six mv2d_gemm_bf16 calls. */
-int mv2d_pe_fused(const void* A1, const void* A2, const void* Xfb, const float* Xf32, const int* m_dev, int M,
+int mv2d_pe_fused(const void* A1, const void* A2, const void* Xfb, const float* Xf32, const int* row_index, const int* m_dev, int M,
                   const void* W1a, const float* b1a, const void* W1b, const float* b1b,
                   const void* W2a, const float* b2a, const void* W2b, const float* b2b,
                   const void* Wr, const float* br, const void* We, const float* be, float* pe, void* Xk, void* stream);
@@ -286,7 +288,7 @@ int mv2d_roi_positions(const float* rois, const unsigned char* pad_mask, unsigne
 int mv2d_csr_from_corr(const int* match, int* row_ptr, int* col_idx, int* nnz_out, int R, int V, int topk, void* stream);
 
 /* PE inputs at the listed key positions only (MU/pe.py:84-135 frustum, MU/positional_encoding.py:78-95 sine) + feature gather.
- * out: A_frustum [S,3*D] bf16, A_sine [S,384] bf16, Xf_bf16 [S,256], Xf_f32 [S,256]. */
+ * out: A_frustum [S,3*D] bf16, A_sine [S,384] bf16, Xf_bf16 [S,256], Xf_f32 [S,256] (optional: NULL when mv2d_pe_fused reads the map). */
 int mv2d_pe_inputs(const int* s2pos, const int* S_dev, int S_max, const float* featcl, const double* img2lidar,
                    const double* coords_w, const double* coords_h, const double* coords_d, const float* embeds,
                    const float* dim_t, void* A_frustum, void* A_sine, void* Xf_bf16, float* Xf_f32, int V, int h, int w,

@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void pe_inputs_kernel(const int* __restrict__ 
     // feature row gather (fp32 kept for the K = feat + pe sum, bf16 for the SE gate and the V projection)
     {
         const float4 f = *reinterpret_cast<const float4*>(featcl + (long long)pos * C + 4 * lane);
-        *reinterpret_cast<float4*>(Xf_f32 + (long long)s * C + 4 * lane) = f;
+        if (Xf_f32) *reinterpret_cast<float4*>(Xf_f32 + (long long)s * C + 4 * lane) = f;
         *reinterpret_cast<uint2*>(Xf_bf16 + (long long)s * C + 4 * lane) = make_uint2(pack_bf16x2(f.x, f.y), pack_bf16x2(f.z, f.w));
     }
     for (int dk = lane; dk < D; dk += 64) {
@@ -916,7 +916,7 @@ extern "C" int mv2d_pe_inputs(const int* s2pos, const int* S_dev, int S_max, con
                               const float* dim_t, void* A_frustum, void* A_sine, void* Xf_bf16, float* Xf_f32, int V, int h, int w,
                               int depth_num, const double* position_range, void* stream) {
     MV2D_CHECK_ARG(s2pos && S_dev && featcl && img2lidar && coords_w && coords_h && coords_d && embeds && dim_t && A_frustum &&
-                       A_sine && Xf_bf16 && Xf_f32 && position_range, "mv2d_pe_inputs: null pointer");
+                       A_sine && Xf_bf16 && position_range, "mv2d_pe_inputs: null pointer");
     MV2D_CHECK_ARG(depth_num <= 256 && (depth_num % 8) == 0, "mv2d_pe_inputs: depth_num must be a multiple of 8, <= 256");
     if (S_max == 0) return MV2D_OK;
     hipLaunchKernelGGL(pe_inputs_kernel, dim3(cdiv(S_max, 4)), dim3(256), 0, (hipStream_t)stream, s2pos, S_dev, featcl, img2lidar, coords_w,

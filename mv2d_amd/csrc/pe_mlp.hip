@@ -44,7 +44,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 union Frag { uint4 u; mfma_bf16x8 v; };
 
 struct PeParams {
-    const unsigned short* A1; const unsigned short* A2; const unsigned short* Xfb; const float* Xf32; const int* m_dev; int M;
+    const unsigned short* A1; const unsigned short* A2; const unsigned short* Xfb; const float* Xf32; const int* row_index; const int* m_dev; int M;
     const unsigned short* W1a; const float* b1a; const unsigned short* W1b; const float* b1b;
     const unsigned short* W2a; const float* b2a; const unsigned short* W2b; const float* b2b;
     const unsigned short* Wr; const float* br; const unsigned short* We; const float* be;
@@ -320,9 +320,17 @@ __global__ __launch_bounds__(64 * NW, 1) void pe_fused_kernel(PeParams p) {
         const int c4 = (lane & 15) * 4, r0 = lane >> 4;
         const long long gcol = wave * (CT2 * 16) + c4;
         float4 fv[BM / 4];
+        if (p.row_index) {                                   // feature rows straight from the position-major map (row of key m = row_index[m])
+            int ri[BM / 4];
 #pragma unroll
-        for (int k = 0; k < BM / 4; ++k)
-            fv[k] = *reinterpret_cast<const float4*>(p.Xf32 + (long long)min(m0 + 4 * k + r0, M - 1) * C + gcol);
+            for (int k = 0; k < BM / 4; ++k) ri[k] = p.row_index[min(m0 + 4 * k + r0, M - 1)];
+#pragma unroll
+            for (int k = 0; k < BM / 4; ++k) fv[k] = *reinterpret_cast<const float4*>(p.Xf32 + (long long)ri[k] * C + gcol);
+        } else {
+#pragma unroll
+            for (int k = 0; k < BM / 4; ++k)
+                fv[k] = *reinterpret_cast<const float4*>(p.Xf32 + (long long)min(m0 + 4 * k + r0, M - 1) * C + gcol);
+        }
 #pragma unroll
         for (int k = 0; k < BM / 4; ++k) {
             const int row = 4 * k + r0, m = m0 + row;
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pe_fused_kernel(PeParams p) {
 }  // namespace
 
 // C-ABI: see include/mv2d_hip.h
-extern "C" int mv2d_pe_fused(const void* A1, const void* A2, const void* Xfb, const float* Xf32, const int* m_dev, int M,
+extern "C" int mv2d_pe_fused(const void* A1, const void* A2, const void* Xfb, const float* Xf32, const int* row_index, const int* m_dev, int M,
                              const void* W1a, const float* b1a, const void* W1b, const float* b1b,
                              const void* W2a, const float* b2a, const void* W2b, const float* b2b,
                              const void* Wr, const float* br, const void* We, const float* be,
@@ -349,7 +357,7 @@ extern "C" int mv2d_pe_fused(const void* A1, const void* A2, const void* Xfb, co
                    "mv2d_pe_fused: null pointer");
     MV2D_CHECK_ARG(M >= 0, "mv2d_pe_fused: M must be >= 0");
     if (M == 0) return MV2D_OK;
-    PeParams p{(const unsigned short*)A1, (const unsigned short*)A2, (const unsigned short*)Xfb, Xf32, m_dev, M,
+    PeParams p{(const unsigned short*)A1, (const unsigned short*)A2, (const unsigned short*)Xfb, Xf32, row_index, m_dev, M,
                (const unsigned short*)W1a, b1a, (const unsigned short*)W1b, b1b, (const unsigned short*)W2a, b2a,
                (const unsigned short*)W2b, b2b, (const unsigned short*)Wr, br, (const unsigned short*)We, be, pe, (unsigned short*)Xk};
     hipLaunchKernelGGL(pe_fused_kernel, dim3(cdiv(M, BM)), dim3(64 * NW), 0, (hipStream_t)stream, p);

@@ -273,7 +273,8 @@ class HeadEngine:
             ws['roi_sum'] = e((R, 49, C), BF16)
         ws['col_idx'] = e(ws['col_cap'], torch.int32)
         ws['A1'] = e((P, 3 * self.depth_num), BF16); ws['A2'] = e((P, 384), BF16)
-        ws['Xf_b'] = e((P, C), BF16); ws['Xf32'] = e((P, C))
+        ws['Xf_b'] = e((P, C), BF16)
+        ws['Xf32'] = None if self.pe_fused else e((P, C))      # the fused PE kernel reads the feature rows from the map itself
         if not self.pe_fused:                                    # intermediates of the six-GEMM PE route only
             ws['H1'] = e((P, 4 * C), BF16); ws['H2'] = e((P, 4 * C), BF16); ws['Hg'] = e((P, C), BF16)
             ws['gate'] = e((P, C)); ws['Pg'] = e((P, C))
@@ -455,7 +456,7 @@ class HeadEngine:
         md = ws['S_dev']
         tk('pe_fused')
         if self.pe_fused:
-            o.pe_fused(ws['A1'], ws['A2'], ws['Xf_b'], ws['Xf32'], md, W_['pe_pack'], ws['pe'], ws['Xk'], M=P)
+            o.pe_fused(ws['A1'], ws['A2'], ws['Xf_b'], featcl, md, W_['pe_pack'], ws['pe'], ws['Xk'], M=P, row_index=ws['s2pos'])
         else:
             o.gemm_bf16(ws['A1'], W_['pe_w1a'], W_['pe_b1a'], m_dev=md, act=1, out=ws['H1'])
             o.gemm_bf16(ws['A2'], W_['pe_w2a'], W_['pe_b2a'], m_dev=md, act=1, out=ws['H2'])

@@ -283,12 +283,12 @@ def finalize_reg(reg, ref, L, R, pc_range_host, dt=0.0):
     check(_lib.load().mv2d_finalize_reg(_p(reg), _p(ref), L, R, pc_range_host.data_ptr(), float(dt), _stream()), 'mv2d_finalize_reg')
 
 
-def pe_fused(A1, A2, Xfb, Xf32, m_dev, wp, pe, Xk, M=None):
+def pe_fused(A1, A2, Xfb, Xf32, m_dev, wp, pe, Xk, M=None, row_index=None):
     """wp: dict with the fragment-major PE weights 'w1a','w1b','w2a','w2b','wr','we' (pack_wfrag) and fp32 biases 'b1a',...,'be'."""
     _req(A1, BF16, 'A1'); _req(A2, BF16, 'A2'); _req(Xfb, BF16, 'Xfb'); _req(Xf32, torch.float32, 'Xf32')
     _req(pe, torch.float32, 'pe'); _req(Xk, BF16, 'Xk')
     M = A1.shape[0] if M is None else M
-    check(_lib.load().mv2d_pe_fused(_p(A1), _p(A2), _p(Xfb), _p(Xf32), _p(m_dev), M,
+    check(_lib.load().mv2d_pe_fused(_p(A1), _p(A2), _p(Xfb), _p(Xf32), _p(row_index), _p(m_dev), M,
                                     _p(wp['w1a']), _p(wp['b1a']), _p(wp['w1b']), _p(wp['b1b']), _p(wp['w2a']), _p(wp['b2a']),
                                     _p(wp['w2b']), _p(wp['b2b']), _p(wp['wr']), _p(wp['br']), _p(wp['we']), _p(wp['be']),
                                     _p(pe), _p(Xk), _stream()), 'mv2d_pe_fused')
