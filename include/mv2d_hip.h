@@ -137,9 +137,12 @@ int mv2d_heads_fused(const float* outs, const float* const* cls_w, const float* 
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias) in split precision (bf16x3, ~1e-5 relative) for the per-query MLPs (QueryGenerator fcs
  * RH/utils/query_generator.py:359-381, first self-attention in_proj): LDS-tiled (A chunk shared by 8 column tiles, fragment-major
  * weights Whi / Wlo = mv2d_split_bf16x2 + mv2d_pack_wfrag_bf16 of W), act 1 = ReLU, clamp > 0 clamps to [-clamp, clamp];
- * columns >= n_split (multiple of 128) read A2 instead of A. */
+ * columns >= n_split (multiple of 128) read A2 instead of A.  groups > 1: a batch of independent linears of the same shape in one
+ * launch, group g at A + g*a_gs, W + g*w_gs, bias + g*b_gs, C + g*c_gs (element strides) -- e.g. the per-head maps of
+ * mv2d_raw_xattn_fwd. */
 int mv2d_linear_x3(const float* A, const float* A2, int n_split, int lda, const void* Whi, const void* Wlo, const float* bias,
-                   float* C, int ldc, int M, int N, int K, int act, float clamp, void* stream);
+                   float* C, int ldc, int M, int N, int K, int act, float clamp, int groups, long long a_gs, long long w_gs,
+                   long long b_gs, long long c_gs, void* stream);
 
 /* The same branches with their four 256x256 linears per (layer, branch) in split precision (bf16x3, ~1e-5 relative; the 256 -> 10
  * output layers stay exact fp32).  cls_w = {w0_hi,w0_lo,b0,ln1w,ln1b,w3_hi,w3_lo,b3,ln4w,ln4b,w6,b6}, reg_w = {w0_hi,w0_lo,b0,w2_hi,
@@ -221,6 +224,15 @@ int mv2d_self_attn_fwd(const float* qkv, float* ctx, int R, const int* grp_start
  * dbg_logits (optional): pre-softmax logits, head h at dbg_logits[h*dbg_stride + e], e in CSR order. */
 int mv2d_sparse_xattn_fwd(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, float* ctx,
                           float* dbg_logits, long long dbg_stride, int R, int empty_nan, void* stream);
+
+/* The same attention in the INPUT space of the key / value projections: logits_h[j] = (Wk_h^T q_h) . x_j (+ a constant that cancels in the
+ * softmax), ctx_h = Wv_h (sum_j p_hj v_j) + bv_h -- keys and values are never projected.  qk [R,8,256] fp32 = the per-head maps of the
+ * pre-scaled query into the key input space (a grouped mv2d_linear_x3 with the transposed head slices of Wk), Xk / Xv [S,256] bf16 = the
+ * UNPROJECTED key / value input rows (key + key_pos, key), shared by all layers; out z [R,8,256] fp32 = sum_j p_hj v_j per head (a
+ * second grouped mv2d_linear_x3 with the head slices of Wv and bv gives ctx [R,256]).  Rows without an allowed key: NaN / 0 like
+ * mv2d_sparse_xattn_fwd. */
+int mv2d_raw_xattn_fwd(const float* qk, const void* Xk, const void* Xv, const int* row_ptr, const int* col_idx, float* z, int R,
+                       int empty_nan, void* stream);
 
 /* Backward of mv2d_sparse_xattn_fwd ("next" row f3, the training path of the head): given dctx [R,256] returns dq [R,256] (gradient
  * with respect to the pre-scaled q) and dK, dV [S,256] fp32 (every key row is written; keys nobody reads get 0).  Two launches, no

@@ -36,7 +36,7 @@ SIGNATURES = {
     'mv2d_attn_out_fused_x3': (I, [P, P, P, P, P, P, P, P, P, P, P, P, F, P, I, F, P]),
     'mv2d_pack_wfrag_f32': (I, [P, P, I, I, I, P]),
     'mv2d_heads_fused': (I, [P, P, P, P, P, P, I, I, F, P, F, P, P]),
-    'mv2d_linear_x3': (I, [P, P, I, I, P, P, P, P, I, I, I, I, I, F, P]),
+    'mv2d_linear_x3': (I, [P, P, I, I, P, P, P, P, I, I, I, I, I, F, I, LL, LL, LL, LL, P]),
     'mv2d_heads_fused_x3': (I, [P, P, P, P, P, P, I, I, F, P, F, P, P]),
     'mv2d_ffn_fused': (I, [P, P, P, P, P, I, I, P]),
     'mv2d_ffn_pack_weights': (I, [P, P, P, P, I, P]),
@@ -52,6 +52,7 @@ SIGNATURES = {
     'mv2d_map_conv3x3': (I, [P, P, P, P, I, I, I, P]),
     'mv2d_self_attn_fwd': (I, [P, P, I, P, I, P]),
     'mv2d_sparse_xattn_fwd': (I, [P, P, P, P, P, P, P, LL, I, I, P]),
+    'mv2d_raw_xattn_fwd': (I, [P, P, P, P, P, P, I, I, P]),
     'mv2d_sparse_xattn_bwd': (I, [P] * 14 + [I, I, P]),
     'mv2d_box_params': (I, [P, P, P, P, P, I, P, I, F, F, F, P]),
     'mv2d_refpoint_posemb': (I, [P, I, P, P, P, P, P, I, P, P]),

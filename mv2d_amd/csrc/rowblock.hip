@@ -817,10 +817,18 @@ __global__ void pack_wfrag_f32_kernel(const float* __restrict__ W, float* __rest
 struct LinX3Params {
     const float* A; const float* A2; int n_split; int lda; const unsigned short* Wh; const unsigned short* Wl; const float* bias;
     float* C; int ldc; int M, N, K; int act; float clamp;
+    long long a_gs, w_gs, b_gs, c_gs;       // element strides between the groups of a batched call (blockIdx.z = group)
 };
 
 template <int RT>
 __global__ __launch_bounds__(512) void linear_x3_kernel(LinX3Params p) {
+    {   // group g of a batched call: its own A columns / weights / bias / C columns
+        const long long g = blockIdx.z;
+        p.A += g * p.a_gs; if (p.A2) p.A2 += g * p.a_gs;
+        p.Wh += g * p.w_gs; p.Wl += g * p.w_gs;
+        if (p.bias) p.bias += g * p.b_gs;
+        p.C += g * p.c_gs;
+    }
     __shared__ __attribute__((aligned(16))) unsigned char ah[2][RT * 16 * 512], al[2][RT * 16 * 512];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int mb = blockIdx.y * (16 * RT), n0 = blockIdx.x * 128;
@@ -1152,15 +1160,18 @@ extern "C" int mv2d_heads_fused_x3(const float* outs, const void* const* cls_w, 
 }
 
 extern "C" int mv2d_linear_x3(const float* A, const float* A2, int n_split, int lda, const void* Whi, const void* Wlo, const float* bias,
-                              float* C, int ldc, int M, int N, int K, int act, float clamp, void* stream) {
+                              float* C, int ldc, int M, int N, int K, int act, float clamp, int groups, long long a_gs, long long w_gs,
+                              long long b_gs, long long c_gs, void* stream) {
     MV2D_CHECK_ARG(A && Whi && Wlo && C, "mv2d_linear_x3: null pointer");
     MV2D_CHECK_ARG(M >= 0 && N > 0 && (N % 16) == 0 && K > 0 && (K % 32) == 0, "mv2d_linear_x3: N % 16 == 0 and K % 32 == 0 required");
     MV2D_CHECK_ARG((lda % 4) == 0 && lda >= K && ldc >= N && ((uintptr_t)A & 15) == 0, "mv2d_linear_x3: A rows must be 16-byte aligned");
     MV2D_CHECK_ARG(n_split == 0 || (A2 && (n_split % 128) == 0 && ((uintptr_t)A2 & 15) == 0), "mv2d_linear_x3: n_split must be a multiple of 128 with A2 set");
+    MV2D_CHECK_ARG(groups >= 1 && (groups == 1 || ((a_gs % 4) == 0 && (w_gs % 8) == 0)), "mv2d_linear_x3: group strides must keep 16-byte alignment");
     if (M == 0) return MV2D_OK;
-    LinX3Params p{A, A2, n_split, lda, (const unsigned short*)Whi, (const unsigned short*)Wlo, bias, C, ldc, M, N, K, act, clamp};
-    if (M <= 512) hipLaunchKernelGGL(linear_x3_kernel<1>, dim3(cdiv(N, 128), cdiv(M, 16)), dim3(512), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(linear_x3_kernel<2>, dim3(cdiv(N, 128), cdiv(M, 32)), dim3(512), 0, (hipStream_t)stream, p);
+    LinX3Params p{A, A2, n_split, lda, (const unsigned short*)Whi, (const unsigned short*)Wlo, bias, C, ldc, M, N, K, act, clamp,
+                  a_gs, w_gs, b_gs, c_gs};
+    if (M <= 512) hipLaunchKernelGGL(linear_x3_kernel<1>, dim3(cdiv(N, 128), cdiv(M, 16), groups), dim3(512), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(linear_x3_kernel<2>, dim3(cdiv(N, 128), cdiv(M, 32), groups), dim3(512), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -80,6 +80,13 @@ class HeadEngine:
         # self-attention core inside the row-fused kernel: measured SLOWER (decoder 0.357 -> 0.432 ms: the fp32 MFMAs of 152 attention
         # blocks land on 19 CUs) -> off; kept as an ABI entry / A-B switch
         self.sa_fused = os.environ.get('MV2D_SA_FUSED', '0') == '1'
+        # EXPERIMENT (off): cross attention on the UNPROJECTED key / value rows (mv2d_raw_xattn_fwd).  The query is mapped into the key
+        # input space per head, the K/V projection of all layers and its 90 MB per sample of output disappear; numerically it is at
+        # least as good (no bf16 rounding of K).  As implemented it loses 5 % (cfg2_s 5900 vs 6210 samples/s): the attention kernel takes
+        # 41 instead of 26 us per layer (8 x 256 instead of 8 x 32 multiply-adds per pair and side) and the two grouped per-head linears
+        # around it 14 us each for their [R,8,256] fp32 intermediates, against 28 us of K/V projection per layer.
+        # 'zero' rows need the projected route anyway (the value bias must not reach a query without keys).
+        self.raw_attn = os.environ.get('MV2D_RAW_ATTN', '0') == '1' and self.empty_nan
         self.qg_x3 = os.environ.get('MV2D_QG_X3', '1') == '1'          # query-generator fcs + first in_proj as LDS-tiled bf16x3 linears (0: exact fp32)
         self.heads_x3 = os.environ.get('MV2D_HEADS_X3', '1') == '1'    # prediction branches in bf16x3 (0: exact fp32)
         self.load_state(state_dict)
@@ -102,6 +109,9 @@ class HeadEngine:
             w[f'ca_q_b{i}'] = inb[:C].contiguous()
             w[f'_k_w{i}'], w[f'_k_b{i}'] = inw[C:2 * C], inb[C:2 * C]
             w[f'_v_w{i}'], w[f'_v_b{i}'] = inw[2 * C:], inb[2 * C:]
+            if self.raw_attn:                                                            # per-head maps around the raw-row attention
+                w[f'ca_hin{i}'], w[f'ca_hout{i}'] = ops.pack_head_maps(inw[C:2 * C].contiguous(), inw[2 * C:].contiguous())
+                w[f'ca_v_b{i}'] = inb[2 * C:].contiguous()
             w[f'ca_out_w{i}'] = g(p + 'attentions.1.attn.out_proj.weight')
             w[f'ca_out_b{i}'] = g(p + 'attentions.1.attn.out_proj.bias')
             w[f'ffn_w1{i}'] = g(p + 'ffns.0.layers.0.0.weight')
@@ -279,7 +289,11 @@ class HeadEngine:
             ws['H1'] = e((P, 4 * C), BF16); ws['H2'] = e((P, 4 * C), BF16); ws['Hg'] = e((P, C), BF16)
             ws['gate'] = e((P, C)); ws['Pg'] = e((P, C))
         ws['pe'] = e((P, C)); ws['Xk'] = e((P, C), BF16)
-        ws['KV'] = e((2 * L, ws['S_kv'], C), BF16)
+        if self.raw_attn:
+            ws['KV'] = None
+            ws['qkh'] = e((R, 8 * C)); ws['zh'] = e((R, 8 * C))
+        else:
+            ws['KV'] = e((2 * L, ws['S_kv'], C), BF16)
         for n in ('x', 'xq', 'x1', 'x1q', 'x2', 'ctx', 'o', 'q'):
             ws[n] = e((R, C))
         ws['zero_rows'] = z((R, C))                              # never written
@@ -470,10 +484,12 @@ class HeadEngine:
                         out1_is_sum=True, R=R)
         if not forked:
             self._enqueue_qg(ws, R)
-        # a18 key side: K/V projections of all layers at once
+        # a18 key side: K/V projections of all layers at once (not needed by the raw-row attention)
         tk('kv_gemm')
         S_kv = ws['S_kv']
-        if self.kind == 'T':
+        if self.raw_attn:
+            pass
+        elif self.kind == 'T':
             o.kv_proj(ws['Xk'], W_['kv_w'], W_['kv_b'], ws['KV'], A2=ws['Xf_b'], n_split=L * C, m_dev=md, ldc=C,
                       c_blk_stride=S_kv * C, c_blk_cols=C)
         else:
@@ -524,6 +540,19 @@ class HeadEngine:
         o, W_, L = ops, self.w, self.L
         x, xq = ws['x'], ws['xq']
         fuse_tail = self.fuse_rows and self.rows_x3          # FFN tail + next layer's in_proj as one row-fused kernel
+        if self.raw_attn:
+            xk_rows = ws['Xk'] if self.kind == 'T' else ws['roi_sum'].view(R * 49, C)
+            xv_rows = ws['Xf_b'] if self.kind == 'T' else ws['roi_feat'].view(R * 49, C)
+
+        def cross_attn(i):
+            if not self.raw_attn:
+                o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R, empty_nan=self.empty_nan)
+                return
+            o.linear_x3(ws['q'], W_[f'ca_hin{i}'], None, N=C, K=32, out=ws['qkh'], ldc=8 * C, M=R, lda=C, groups=8, a_gs=32, w_gs=C * 32, c_gs=C)
+            o.raw_xattn(ws['qkh'], xk_rows, xv_rows, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=True)
+            o.linear_x3(ws['zh'], W_[f'ca_hout{i}'], W_[f'ca_v_b{i}'], N=32, K=C, out=ws['ctx'], ldc=C, M=R, lda=8 * C, groups=8, a_gs=C,
+                        w_gs=32 * C, b_gs=32, c_gs=32)
+
         if fuse_tail:
             # the decoder starts from target = 0 (cross_attention_head.py:32): layer 0 reads a constant zero buffer and qpos
             # directly, from layer 1 on x / xq are the buffers the fused FFN tail writes
@@ -546,18 +575,18 @@ class HeadEngine:
                 sa_tail = o.sa_block_fused_x3 if sa_fused else o.attn_out_fused_x3      # self-attention core inside the row kernel, or not
                 sa_tail(ws['qkv'] if sa_fused else ws['ctx'], x_in, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
                         qpos=ws['qpos'], Wq_x3=W_[f'ca_q_wx{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, q_out=ws['q'], M=R)
-                o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R, empty_nan=self.empty_nan)
+                cross_attn(i)
                 o.attn_out_fused_x3(ws['ctx'], ws['x1'], W_[f'ca_out_wx{i}'], W_[f'ca_out_b{i}'], (W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), ws['x2'], M=R)
             elif self.fuse_rows:
                 o.attn_out_fused(ws['ctx'], x_in, W_[f'sa_out_w{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
                                  qpos=ws['qpos'], Wq=W_[f'ca_q_w{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, q_out=ws['q'], M=R)
-                o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R, empty_nan=self.empty_nan)
+                cross_attn(i)
                 o.attn_out_fused(ws['ctx'], ws['x1'], W_[f'ca_out_w{i}'], W_[f'ca_out_b{i}'], (W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), ws['x2'], M=R)
             else:
                 o.gemm_f32(ws['ctx'], W_[f'sa_out_w{i}'], W_[f'sa_out_b{i}'], out=ws['o'])
                 o.row_ln(ws['o'], residual=x_in, ln=(W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), out=ws['x1'], addvec=ws['qpos'], out_plus=ws['x1q'])
                 o.gemm_f32(ws['x1q'], W_[f'ca_q_w{i}'], W_[f'ca_q_b{i}'], scale=ops.SCALE_Q, out=ws['q'])
-                o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R, empty_nan=self.empty_nan)
+                cross_attn(i)
                 o.gemm_f32(ws['ctx'], W_[f'ca_out_w{i}'], W_[f'ca_out_b{i}'], out=ws['o'])
                 o.row_ln(ws['o'], residual=ws['x1'], ln=(W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), out=ws['x2'])
             parts = ws['parts']
@@ -594,9 +623,9 @@ class HeadEngine:
         out = dict(R=R, ws=ws, cls=ws['cls'], reg=ws['reg'], boxes=sel(ws['boxes']), scores=sel(ws['scores']), labels=sel(ws['labels']),
                    bbox_index=sel(ws['bbox_index']), count=ws['count'] if batch else ws['count'][:1], grp_start=ws['grp_start_h'].clone())
         if keep_stages:
-            out['stages'] = {k: ws[k].clone() for k in ('rois', 'minv', 'enc', 'roi_feat', 'center', 'xyz', 'ref', 'posemb', 'qpos',
+            out['stages'] = {k: ws[k].clone() for k in (kk for kk in ('rois', 'minv', 'enc', 'roi_feat', 'center', 'xyz', 'ref', 'posemb', 'qpos',
                                                         'match', 'roi_mask', 'pos2s', 's2pos', 'S_dev', 'nnz', 'row_ptr', 'col_idx',
-                                                        'pe', 'Xk', 'Xf_b', 'KV', 'outs', 'cls', 'reg')}
+                                                        'pe', 'Xk', 'Xf_b', 'KV', 'outs', 'cls', 'reg') if ws[kk] is not None)}
         return out
 
     def run(self, feat, proposals, img_metas, keep_stages=False, use_graph=False):

@@ -166,14 +166,17 @@ def heads_fused(outs, cls_ptrs, reg_ptrs, ref, cls, reg, M, L, pc_range_host, dt
                                        pc_range_host.data_ptr(), float(dt), _p(dt_rows), _stream()), 'mv2d_heads_fused')
 
 
-def linear_x3(A, W_x3, bias=None, *, N, K, A2=None, n_split=0, act=0, clamp=0.0, out=None, M=None, lda=None, ldc=None):
-    """out = act(A @ W.T + bias) in bf16x3; W_x3 = pack_x3(W) of the [N,K] weight (K % 32 == 0, N % 16 == 0)."""
+def linear_x3(A, W_x3, bias=None, *, N, K, A2=None, n_split=0, act=0, clamp=0.0, out=None, M=None, lda=None, ldc=None, groups=1,
+              a_gs=0, w_gs=0, b_gs=0, c_gs=0):
+    """out = act(A @ W.T + bias) in bf16x3; W_x3 = pack_x3(W) of the [N,K] weight (K % 32 == 0, N % 16 == 0).  groups > 1: that many
+    linears of the same shape in one launch, group g at A + g*a_gs, W + g*w_gs, bias + g*b_gs, out + g*c_gs (elements)."""
     _req(A, torch.float32, 'A'); _req(A2, torch.float32, 'A2'); _req(bias, torch.float32, 'bias')
     M = A.shape[0] if M is None else M
     if out is None:
         out = torch.empty((M, N), device=A.device, dtype=torch.float32)
     check(_lib.load().mv2d_linear_x3(_p(A), _p(A2), n_split, A.stride(0) if lda is None else lda, _p(W_x3[0]), _p(W_x3[1]), _p(bias), _p(out),
-                                     out.stride(0) if ldc is None else ldc, M, N, K, act, float(clamp), _stream()), 'mv2d_linear_x3')
+                                     out.stride(0) if ldc is None else ldc, M, N, K, act, float(clamp), groups, a_gs, w_gs, b_gs, c_gs,
+                                     _stream()), 'mv2d_linear_x3')
     return out
 
 
@@ -377,6 +380,27 @@ def sparse_xattn(q, K, V, row_ptr, col_idx, out=None, R=None, dbg_logits=None, e
           'mv2d_sparse_xattn_fwd')
     return out
 
+
+
+def raw_xattn(qk, Xk, Xv, row_ptr, col_idx, out=None, R=None, empty_nan=True):
+    """Attention on unprojected key / value rows: qk [R,8,256] fp32 (per-head query maps), Xk / Xv [S,256] bf16 -> z [R,8,256] fp32."""
+    _req(qk, torch.float32, 'qk'); _req(Xk, BF16, 'Xk'); _req(Xv, BF16, 'Xv')
+    R = qk.shape[0] if R is None else R
+    if out is None:
+        out = torch.empty((R, 8, 256), device=qk.device, dtype=torch.float32)
+    check(_lib.load().mv2d_raw_xattn_fwd(_p(qk), _p(Xk), _p(Xv), _p(row_ptr), _p(col_idx), _p(out), R, 1 if empty_nan else 0, _stream()),
+          'mv2d_raw_xattn_fwd')
+    return out
+
+
+def pack_head_maps(Wk, Wv):
+    """Per-layer weights of the raw-row attention: (in_x3, out_x3) for the two grouped linears around raw_xattn.
+    in: qk[:, h] = q[:, 32h:32h+32] @ Wk[32h:32h+32, :]   -> group weight [N=256, K=32] = Wk[32h:32h+32, :].T
+    out: ctx[:, 32h:32h+32] = z[:, h] @ Wv[32h:32h+32, :].T -> group weight [N=32, K=256] = Wv[32h:32h+32, :]"""
+    ins = [pack_x3(Wk[32 * h:32 * h + 32, :].t().contiguous()) for h in range(8)]
+    outs = [pack_x3(Wv[32 * h:32 * h + 32, :].contiguous()) for h in range(8)]
+    cat = lambda parts, i: torch.stack([p[i].view(-1) for p in parts]).contiguous()
+    return (cat(ins, 0), cat(ins, 1)), (cat(outs, 0), cat(outs, 1))
 
 
 def csr_transpose(row_ptr, col_idx, S):

@@ -271,6 +271,28 @@ def test_engine_batch_edge_cases(kind):
             assert torch.equal(x, y), b
 
 
+@pytest.mark.parametrize('kind,name', [('S', 'cfg1_s'), ('T', 'cfg1_t')])
+def test_engine_raw_row_attention_route(kind, name, monkeypatch):
+    """MV2D_RAW_ATTN=1: cross attention on the unprojected key / value rows (no K/V projection at all) gives the same frame results as the
+    default route up to the bf16 rounding of K/V that only the default route has."""
+    from mv2d_amd.engine import HeadEngine
+    prob = synthetic.make_problem(name, seed=0)
+    sd = synthetic.make_head_state(seed=0)
+    dev = torch.device('cuda:0')
+    feat = torch.from_numpy(prob['feat']).to(dev)
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    ref_eng = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'])
+    ref = ref_eng.run(feat, props, prob['img_metas'])
+    monkeypatch.setenv('MV2D_RAW_ATTN', '1')
+    eng = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'])
+    assert eng.raw_attn
+    out = eng.run(feat, props, prob['img_metas'])
+    assert out['ws']['KV'] is None
+    assert relmax(out['cls'], ref['cls']) < 2e-3 and relmax(out['reg'], ref['reg']) < 5e-3
+    o2 = eng.run(feat, props, prob['img_metas'], use_graph=True)
+    assert torch.equal(o2['cls'], out['cls'])
+
+
 def test_engine_full_size_properties_cfg5():
     """BASELINE.json's largest configuration (R101 1600x640, 12 views, 900 queries) through size-independent properties:
     CSR well-formedness, idempotence (same frame twice -> bitwise identical), fork/no-fork equality, and the decode kernel

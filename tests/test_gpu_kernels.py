@@ -358,6 +358,46 @@ def test_sparse_xattn_backward(dev, R, S, dens):
         assert float(dK[unused.to(dev)].abs().max()) == 0.0 and float(dV[unused.to(dev)].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('R,S,dens', [(37, 500, 0.05), (301, 5000, 0.02), (64, 49 * 64, -1.0)])
+def test_raw_xattn_equals_projected_attention(dev, R, S, dens):
+    """Attention in the input space of the K/V projections: grouped linear (q -> qk) + raw_xattn on the UNPROJECTED rows + grouped linear
+    (z -> ctx) == masked attention on K = Xk Wk^T + bk, V = Xv Wv^T + bv in fp64 (the bk term cancels in the softmax, bv rides on sum p = 1)."""
+    from mv2d_amd import ops
+    from oracle import mv2d_oracle as O
+    g = np.random.Generator(np.random.PCG64(260 + R))
+    if dens > 0:
+        allowed = torch.from_numpy(g.random((R, S)) < dens)
+        allowed[5] = False
+        allowed[7, :] = False
+        allowed[7, 123] = True
+    else:
+        allowed = torch.zeros((R, S), dtype=torch.bool)
+        for r in range(R):
+            allowed[r, r * 49:(r + 1) * 49] = True
+            allowed[r, ((r + 3) % R) * 49:((r + 3) % R) * 49 + 49] = True
+    q = (rnd((R, 256), 261) * 0.3).to(dev)
+    Xk = rnd((S, 256), 262).to(dev).to(torch.bfloat16)
+    Xv = rnd((S, 256), 263).to(dev).to(torch.bfloat16)
+    Wk = rnd((256, 256), 264, 0.06).to(dev); bk = rnd((256,), 265).to(dev)
+    Wv = rnd((256, 256), 266, 0.06).to(dev); bv = rnd((256,), 267).to(dev)
+    row_ptr, col = O.csr_from_allowed(allowed)
+    ref = O.masked_cross_attention(q.double(), Xk.double() @ Wk.double().T + bk.double(), Xv.double() @ Wv.double().T + bv.double(), allowed.to(dev))
+    w_in, w_out = ops.pack_head_maps(Wk, Wv)
+    qk = torch.empty((R, 8, 256), device=dev)
+    ops.linear_x3(q, w_in, None, N=256, K=32, out=qk, ldc=2048, M=R, lda=256, groups=8, a_gs=32, w_gs=256 * 32, c_gs=256)
+    qk_ref = torch.einsum('rhd,hdc->rhc', q.double().view(R, 8, 32), Wk.double().view(8, 32, 256))
+    assert relerr(qk, qk_ref) < 3e-5
+    z = ops.raw_xattn(qk, Xk, Xv, row_ptr.to(dev), col.to(dev), empty_nan=False)
+    ctx = torch.empty((R, 256), device=dev)
+    ops.linear_x3(z.view(R, 2048), w_out, bv, N=32, K=256, out=ctx, ldc=256, M=R, lda=2048, groups=8, a_gs=256, w_gs=32 * 256, b_gs=32, c_gs=32)
+    has = allowed.any(1).to(dev)
+    assert relerr(ctx[has], ref[has]) < 5e-5
+    if dens > 0:
+        assert float(z[5].abs().max()) == 0.0
+        zn = ops.raw_xattn(qk, Xk, Xv, row_ptr.to(dev), col.to(dev))
+        assert bool(torch.isnan(zn[5]).all()) and torch.equal(zn[6:], z[6:])
+
+
 # ------------------------------------------------------------------------------------------ geometry
 def _problem(name):
     prob = synthetic.make_problem(name, seed=0)
