@@ -63,3 +63,30 @@ def test_two_rank_gloo_shard_and_gather():
 def test_single_process_gather_is_identity():
     p = torch.arange(2 * 3301, dtype=torch.float32).view(2, 3301)
     assert torch.equal(mdist.gather_detections(p)[0], p)
+
+
+def test_batch_payload_equals_per_sample_payloads():
+    """run_batch outputs ([B,max_num,...], count [B]) pack into the same rows as B single-sample payloads (the wire format the
+    GPU path produces with one launch of mv2d_pack_detections)."""
+    g = torch.Generator().manual_seed(5)
+    B, M = 4, 300
+    boxes = torch.randn(B, M, 9, generator=g); scores = torch.rand(B, M, generator=g)
+    labels = torch.randint(0, 10, (B, M), generator=g); count = torch.tensor([300, 0, 1, 123], dtype=torch.int32)
+    batch = mdist.pack_detections_batch(boxes, scores, labels, count)
+    assert batch.shape == (B, M * 11 + 1)
+    for b in range(B):
+        assert torch.equal(batch[b], mdist.pack_detections(boxes[b], scores[b], labels[b], count[b:b + 1]))
+        bx, sc, lb = mdist.unpack_detections(batch[b])
+        n = int(count[b])
+        assert bx.shape == (n, 9) and torch.equal(bx, boxes[b, :n]) and torch.equal(lb, labels[b, :n])
+
+
+def test_csr_transpose_groups_pairs_by_key():
+    """ops.csr_transpose (torch ops, device agnostic): the allowed (query, key) pairs grouped by key, stable inside a key."""
+    from mv2d_amd import ops
+    row_ptr = torch.tensor([0, 3, 3, 5, 9], dtype=torch.int32)
+    col = torch.tensor([4, 1, 2, 1, 0, 2, 4, 1, 3], dtype=torch.int32)
+    key_ptr, pair_idx, pair_row = ops.csr_transpose(row_ptr, col, 6)
+    assert pair_row.tolist() == [0, 0, 0, 2, 2, 3, 3, 3, 3]
+    assert key_ptr.tolist() == [0, 1, 4, 6, 7, 9, 9]
+    assert pair_idx.tolist() == [4, 1, 3, 7, 2, 5, 8, 0, 6]
