@@ -60,7 +60,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='cfg2_s', help='cfg2_s (MV2D-S 6 cams 1408x512, headline) | cfg3_t | cfg5_t | cfg1_s ...')
     ap.add_argument('--inflight', type=int, default=4, help='HIP streams per GPU, each running its own launch sequence per step')
-    ap.add_argument('--batch', type=int, default=6, help='samples sharing every launch of a stream (HeadEngine.run_batch)')
+    ap.add_argument('--batch', type=int, default=8, help='samples sharing every launch of a stream (HeadEngine.run_batch)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL; gloo only for single-GPU dry runs)')
