@@ -190,6 +190,25 @@ class MV2DHead(nn.Module):
             boxes = box_type(boxes, boxes.size(-1))
         return [[boxes, scores.clone(), labels.clone()]]
 
+    def simple_test_batch(self, x, proposal_lists, img_metas_list, rescale=False):
+        """Several samples through ONE sequence of launches (the reference asserts one sample per call, mv2d_head.py / SURVEY.md 2.2;
+        a dataloader with samples_per_gpu > 1 would call this once instead of looping over simple_test).
+        x: list with the stacked stride-16 map [B*V,256,h,w] (sample-major, as the backbone / neck of a batch produce it);
+        proposal_lists: B x (V x [n,6]); img_metas_list: B x (V dicts) -> B x [boxes, scores, labels]."""
+        B = len(proposal_lists)
+        feat = x[self.feat_lvl]
+        assert feat.shape[0] % B == 0 and all(len(m) == feat.shape[0] // B for m in img_metas_list)
+        eng = self.engine(feat.device, img_metas_list[0])
+        out = eng.run_batch(feat.float(), proposal_lists, img_metas_list)
+        res = []
+        for b, (boxes, scores, labels) in enumerate(eng.results_batch(out)):
+            boxes = boxes.clone()
+            box_type = img_metas_list[b][0].get('box_type_3d')
+            if box_type is not None:
+                boxes = box_type(boxes, boxes.size(-1))
+            res.append([boxes, scores.clone(), labels.clone()])
+        return res
+
     def forward_train(self, *a, **k):
         raise NotImplementedError('training (denoising queries, Hungarian loss) is outside the hot-path scope (SURVEY.md §8 f3)')
 

@@ -39,6 +39,42 @@ def pack_results(boxes, scores, labels, count, score_thr=0.0, max_per_scene=300)
     return dict(boxes_3d=ob[:n].cpu(), scores_3d=os_[:n].cpu(), labels_3d=ol[:n].cpu())
 
 
+def pack_results_batch(boxes, scores, labels, count, score_thr=0.0, max_per_scene=300):
+    """run_batch outputs (boxes [B,n,9], scores [B,n], labels [B,n], count [B]) -> B dicts like pack_results, one launch and one host
+    synchronisation for the whole batch."""
+    dev, B = boxes.device, count.numel()
+    ob = torch.zeros((B, max_per_scene, 9), device=dev)
+    os_ = torch.zeros((B, max_per_scene), device=dev)
+    ol = torch.zeros((B, max_per_scene), dtype=torch.int64, device=dev)
+    oc = torch.zeros(B, dtype=torch.int32, device=dev)
+    ops.result_pack(boxes.contiguous(), scores.contiguous(), labels.contiguous(), count, score_thr, max_per_scene, ob, os_, ol, oc,
+                    n_samples=B, in_stride=scores.shape[-1])
+    ns = oc.tolist()
+    ob, os_, ol = ob.cpu(), os_.cpu(), ol.cpu()
+    return [dict(boxes_3d=ob[b, :n], scores_3d=os_[b, :n], labels_3d=ol[b, :n]) for b, n in enumerate(ns)]
+
+
+def simple_test_batch_from_detections(roi_head, feat_maps, det_results_list, img_metas_list, rcnn_test_cfg, min_bbox_size=0):
+    """simple_test_from_detections for a batch of samples: feat_maps[lvl] = the stacked [B*V,256,h,w] map, det_results_list / img_metas_list
+    = one entry per sample.  One sequence of launches, one host synchronisation."""
+    nms = rcnn_test_cfg.get('nms', rcnn_test_cfg)
+    if float(nms.get('nms_thr', 1.0)) < 1.0:
+        raise NotImplementedError('rotated-IoU suppression (nms_thr < 1) is not part of the shipped configs')
+    feat = feat_maps[roi_head.feat_lvl]
+    proposals = [process_2d_detections(d, feat.device, min_bbox_size) for d in det_results_list]
+    eng = roi_head.engine(feat.device, img_metas_list[0])
+    out = eng.run_batch(feat.float(), proposals, img_metas_list)
+    res = pack_results_batch(out['boxes'], out['scores'], out['labels'], out['count'], rcnn_test_cfg.get('score_thr', 0.0),
+                             rcnn_test_cfg.get('max_per_scene', 300))
+    if int(out['ws']['nnz'][1].item()) != 0:
+        raise RuntimeError('mv2d engine: CSR capacity exceeded (raise col_cap_per_query)')
+    for b, r in enumerate(res):
+        box_type = img_metas_list[b][0].get('box_type_3d')
+        if box_type is not None:
+            r['boxes_3d'] = box_type(r['boxes_3d'], r['boxes_3d'].size(-1))
+    return res
+
+
 def simple_test_from_detections(roi_head, feat_maps, det_results, img_metas, rcnn_test_cfg, min_bbox_size=0):
     """The part of MV2D.simple_test (mv2d.py:225-295, batch 1) that surrounds the RoI head: 2-D detector results ->
     proposals -> head (HIP engine) -> result packing, with one host synchronisation at the very end.

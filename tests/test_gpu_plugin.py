@@ -172,6 +172,30 @@ def test_simple_test_from_detections_end_to_end():
     assert bool((res['scores_3d'][1:][same] <= res['scores_3d'][:-1][same]).all())    # score-descending inside a class
 
 
+def test_batched_plugin_entry_points_equal_single_sample_calls():
+    """head.simple_test_batch / postprocess.simple_test_batch_from_detections (several samples, one sequence of launches) return exactly what
+    the single-sample entry points return for every sample."""
+    from mv2d_amd import postprocess
+    head = build('S')
+    probs = [synthetic.make_problem('cfg1_s', seed=s) for s in (0, 4, 9)]
+    probs[1]['proposals'] = [p[:max(1, len(p) - 3)] for p in probs[1]['proposals']]
+    feats = [torch.from_numpy(p['feat']).to(DEV) for p in probs]
+    stacked = torch.cat(feats, 0)
+    metas = [[dict(m, box_type_3d=None) for m in p['img_metas']] for p in probs]
+    props = [[torch.from_numpy(x) for x in p['proposals']] for p in probs]
+    got = head.simple_test_batch([stacked], props, metas)
+    dets = [[[x[x[:, 5] == c][:, :5] for c in range(10)] for x in p['proposals']] for p in probs]
+    got2 = postprocess.simple_test_batch_from_detections(head, [stacked], dets, metas, configs.TEST_CFG_RCNN)
+    assert len(got) == len(got2) == 3
+    for b in range(3):
+        one = head.simple_test([feats[b]], props[b], metas[b])[0]
+        for a, w in zip(got[b], one):
+            assert torch.equal(a, w)
+        one2 = postprocess.simple_test_from_detections(head, [feats[b]], dets[b], metas[b], configs.TEST_CFG_RCNN)[0]
+        for k in ('boxes_3d', 'scores_3d', 'labels_3d'):
+            assert torch.equal(got2[b][k], one2[k]), (b, k)
+
+
 @pytest.mark.parametrize('shape', [(6, 256, 32, 88), (2, 256, 14, 26), (1, 256, 5, 7)])
 def test_fpn_neck_single_level(shape):
     """f2: the extra FPN level (1x1 lateral + 3x3 conv) on HIP vs the oracle restatement (bf16 MFMA tolerance) and vs conv2d on the
