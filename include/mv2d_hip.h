@@ -329,6 +329,26 @@ int mv2d_result_pack(const float* boxes, const float* scores, const long long* l
 int mv2d_pack_detections(const float* boxes, const float* scores, const long long* labels, const int* count, float* out, int n_samples,
                          int max_num, int in_stride, void* stream);
 
+/* ---- training targets of the box head ------------------------------------------------------------------------
+ * Cost matrix of HungarianAssigner3D.assign (mmdet3d_plugin/core/bbox/assigners/hungarian_assigner_3d.py:120-131) for n_layers decoder
+ * layers in one launch: cost[l][r][g] = FocalLossCost(cls[l][r], gt_labels[g]) * cls_weight + L1(box[l][r][:8], normalize_bbox(gt[g])[:8])
+ * * reg_weight, then nan_to_num(nan = 100, +inf = 100, -inf = -100).  cls [n_layers][R][C] logits, box [n_layers][R][10] head codes,
+ * gt [G][9] = (cx, cy, cz, w, l, h, yaw, vx, vy) (the caller's cat(gravity_center, tensor[:, 3:]), cross_attention_head.py:449-451).
+ * The assignment (scipy linear_sum_assignment in the reference) stays on the host. */
+int mv2d_match_cost(const float* cls, const float* box, const float* gt, const int* gt_labels, float* cost, int n_layers, int R, int G,
+                    int C, float cls_weight, float reg_weight, float alpha, float gamma, void* stream);
+
+/* Set-prediction loss of CrossAttentionBoxHead.loss_single (cross_attention_head.py:380-434) and dn_loss_single (:477-538) with its
+ * gradient, all layers in one launch.  match [n_layers][R]: row of gt / gt_labels assigned to the query, -1 = background; a gt label
+ * equal to C is a background target (denoising negatives; their boxes are skipped when skip_background_boxes != 0).  loss [n_layers][2]
+ * = (loss_cls, loss_bbox) = (sum focal / cls_avg_factor * loss_cls_weight, sum |box - normalize_bbox(gt)| * code_weights over rows with
+ * finite targets / box_avg_factor * loss_bbox_weight), nan_to_num applied.  dcls / dbox (may be null): gradient of
+ * sum_l layer_weights[l] * (loss_cls[l] + loss_bbox[l]) (layer_weights null = ones). */
+int mv2d_set_loss(const float* cls, const float* box, const int* match, const float* gt, const int* gt_labels, const float* code_weights,
+                  const float* layer_weights, float* loss, float* dcls, float* dbox, int n_layers, int R, int G, int C,
+                  float cls_avg_factor, float box_avg_factor, float alpha, float gamma, float loss_cls_weight, float loss_bbox_weight,
+                  int skip_background_boxes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,3 +96,10 @@ def roi_head_cfg_t():
 
 
 TEST_CFG_RCNN = dict(score_thr=0.0, nms=dict(nms_thr=1.0, use_rotate_nms=True), max_per_scene=300)  # CFG-T:154-158
+
+# configs/mv2d/exp/mv2d_r50_frcnn_two_frames_1408x512_ep24.py:134-145 (`train_cfg.rcnn`; the single-frame configs carry the same block)
+TRAIN_CFG_RCNN = dict(
+    stage_loss_weights=[0.1, 0.1, 0.1, 0.1, 0.1, 0.1],
+    assigner=dict(type='HungarianAssigner3D', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                  reg_cost=dict(type='BBox3DL1Cost', weight=0.25), iou_cost=dict(type='IoUCost', weight=0.0), pc_range=POINT_CLOUD_RANGE),
+    sampler_cfg=dict(type='PseudoSampler'), pos_weight=-1, debug=False)

@@ -555,4 +555,30 @@ def pack_detections(boxes, scores, labels, count, out, max_num=300):
     return out
 
 
+def match_cost(cls, box, gt, gt_labels, cls_weight=2.0, reg_weight=0.25, alpha=0.25, gamma=2.0):
+    """cls [L,R,C] logits, box [L,R,10], gt [G,9] fp32, gt_labels [G] int32 -> cost [L,R,G] fp32 of the Hungarian assignment."""
+    L, R, C = cls.shape
+    G = gt.shape[0]
+    cost = torch.empty(L, R, G, device=cls.device, dtype=torch.float32)
+    check(_lib.load().mv2d_match_cost(_p(cls), _p(box), _p(gt), _p(gt_labels), _p(cost), L, R, G, C, cls_weight, reg_weight, alpha, gamma,
+                                      _stream()), 'mv2d_match_cost')
+    return cost
+
+
+def set_loss(cls, box, match, gt, gt_labels, code_weights, layer_weights, cls_avg_factor, box_avg_factor, alpha=0.25, gamma=2.0,
+             loss_cls_weight=2.0, loss_bbox_weight=0.25, skip_background_boxes=False, need_grad=True):
+    """Focal + L1 loss of L layers and its gradient: returns (loss [L,2], dcls [L,R,C] | None, dbox [L,R,10] | None)."""
+    L, R, C = cls.shape
+    G = gt.shape[0]
+    loss = torch.empty(L, 2, device=cls.device, dtype=torch.float32)
+    dcls = torch.empty_like(cls) if need_grad else None
+    dbox = torch.empty_like(box) if need_grad else None
+    check(_lib.load().mv2d_set_loss(_p(cls), _p(box), _p(match), _p(gt), _p(gt_labels), _p(code_weights),
+                                    _p(layer_weights) if layer_weights is not None else None, _p(loss),
+                                    _p(dcls) if need_grad else None, _p(dbox) if need_grad else None, L, R, G, C, float(cls_avg_factor),
+                                    float(box_avg_factor), alpha, gamma, loss_cls_weight, loss_bbox_weight, int(skip_background_boxes),
+                                    _stream()), 'mv2d_set_loss')
+    return loss, dcls, dbox
+
+
 SCALE_Q = 1.0 / math.sqrt(32.0)

@@ -56,6 +56,7 @@ BBOX_CODERS = Registry('bbox_coder')
 ROI_EXTRACTORS = Registry('roi_extractor')
 LOSSES = Registry('loss')
 NECKS = Registry('neck')
+BBOX_ASSIGNERS = Registry('bbox_assigner')
 
 
 def build_from_cfg(cfg, registry, default_args=None):

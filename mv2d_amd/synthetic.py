@@ -213,3 +213,54 @@ def make_problem(name, seed=0):
     feat = make_feat(V, H // 16, pw // 16, seed + 2)
     return dict(kind=kind, feat=feat, proposals=props, img_metas=metas, name=name,
                 views_per_frame=vpf, frames=frames)
+
+
+# ---- training targets / losses: head outputs + ground truth -----------------------------------------------------------
+TRAIN_CASES = {'small': (40, 7, 3), 'mid': (300, 45, 5), 'few_queries': (5, 12, 7), 'no_gt': (30, 0, 9), 'nan_velocity': (60, 11, 13)}
+
+
+def make_train_case(R, G, seed, num_layers=NUM_LAYERS, num_classes=10):
+    """Seeded head outputs of `num_layers` decoder layers (cls [L,R,C] logits, box [L,R,10] codes) and ground truth: `gt_bottom` [G,9]
+    bottom-centre boxes (x, y, z, w, l, h, yaw, vx, vy) as the dataset stores them, `gt` [G,9] with the gravity centre (what the loss
+    sees), labels, and denoising targets (`known_bboxs` [n,9] gravity-centre boxes, `known_labels` [n], label == num_classes = negative).
+    The first min(R, G) queries sit near a ground-truth box so that the assignment is not arbitrary."""
+    g = _rng(seed)
+    gt = np.zeros((G, 9), np.float32)
+    gt[:, 0:2] = g.uniform(-50, 50, (G, 2))
+    gt[:, 2] = g.uniform(-3, 0, G)
+    gt[:, 3:6] = g.uniform(0.5, 5.0, (G, 3))
+    gt[:, 6] = g.uniform(-np.pi, np.pi, G)
+    gt[:, 7:9] = g.uniform(-3, 3, (G, 2))
+    if seed == 13 and G > 2:
+        gt[2, 7:9] = np.nan                                  # nuScenes boxes without a velocity estimate
+    labels = g.integers(0, num_classes, G).astype(np.int64)
+    grav = gt.copy()
+    grav[:, 2] += gt[:, 5] * 0.5
+    code = np.stack([grav[:, 0], grav[:, 1], np.log(grav[:, 3]), np.log(grav[:, 4]), grav[:, 2], np.log(grav[:, 5]),
+                     np.sin(grav[:, 6]), np.cos(grav[:, 6]), np.nan_to_num(grav[:, 7]), np.nan_to_num(grav[:, 8])], 1).astype(np.float32)
+    box = np.zeros((num_layers, R, 10), np.float32)
+    box[..., 0:2] = g.uniform(-50, 50, (num_layers, R, 2))
+    box[..., 2:4] = g.uniform(-0.5, 1.5, (num_layers, R, 2))
+    box[..., 4] = g.uniform(-3, 2, (num_layers, R))
+    box[..., 5] = g.uniform(-0.5, 1.5, (num_layers, R))
+    box[..., 6:8] = g.uniform(-1, 1, (num_layers, R, 2))
+    box[..., 8:10] = g.uniform(-3, 3, (num_layers, R, 2))
+    cls = g.normal(-2.0, 1.5, (num_layers, R, num_classes)).astype(np.float32)
+    n = min(R, G)
+    if n:
+        pick = g.permutation(G)[:n]
+        for l in range(num_layers):
+            box[l, :n] = code[pick] + g.normal(0, 0.3 / (l + 1), (n, 10)).astype(np.float32)
+            cls[l, np.arange(n), labels[pick]] += 2.0
+    nk = min(R, 24)
+    known = np.zeros((nk, 9), np.float32)
+    known[:, 0:2] = g.uniform(-50, 50, (nk, 2))
+    known[:, 2] = g.uniform(-2, 2, nk)
+    known[:, 3:6] = g.uniform(0.5, 5.0, (nk, 3))
+    known[:, 6] = g.uniform(-np.pi, np.pi, nk)
+    known[:, 7:9] = g.uniform(-3, 3, (nk, 2))
+    known_labels = g.integers(0, num_classes + 1, nk).astype(np.int64)
+    if nk:
+        known_labels[0] = num_classes
+    return dict(cls=cls, box=box.astype(np.float32), gt_bottom=gt, gt=grav.astype(np.float32), gt_labels=labels, known_bboxs=known,
+                known_labels=known_labels, dn_num_tgt=max(nk * 2 // 3, 1))

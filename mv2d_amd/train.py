@@ -1,0 +1,154 @@
+"""Training targets and losses of the box head — host side.
+
+Mirrors the reference interface for this step:
+
+* ``HungarianAssigner3D`` (registry ``BBOX_ASSIGNERS``; mmdet3d_plugin/core/bbox/assigners/hungarian_assigner_3d.py:28-150): the cost
+  matrix of all decoder layers is one HIP launch (``mv2d_match_cost``), the assignment itself is scipy's ``linear_sum_assignment`` on
+  the host exactly as in the reference (:137), one device->host copy for all layers.
+* ``SetPredictionLoss`` (autograd Function) / ``head_loss``: ``CrossAttentionBoxHead.loss`` per layer with the stage weights of
+  ``MV2DSHead.forward_train`` (mmdet3d_plugin/models/roi_heads/mv2d_s_head.py:276-303) — sigmoid focal loss + code-weighted L1 on the
+  finite targets, forward and gradient in one HIP launch for all layers (``mv2d_set_loss``).
+* ``dn_loss``: ``dn_loss_single`` (cross_attention_head.py:477-538) for all layers.
+
+No CPU fallback: the device tensors must be on the GPU and the HIP library present.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .registry import BBOX_ASSIGNERS
+
+
+def _reduce_mean(v):
+    """mmdet.core.reduce_mean on a python scalar: average over the ranks when torch.distributed is up (one all-reduce)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(v)
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.tensor([float(v)], device=dev)
+    dist.all_reduce(t)
+    return float(t.item()) / dist.get_world_size()
+
+
+@BBOX_ASSIGNERS.register_module()
+class HungarianAssigner3D:
+    def __init__(self, cls_cost=dict(type='FocalLossCost', weight=2.0), reg_cost=dict(type='BBox3DL1Cost', weight=0.25),
+                 iou_cost=dict(type='IoUCost', weight=0.0), pc_range=None):
+        if cls_cost.get('type', 'FocalLossCost') != 'FocalLossCost' or reg_cost.get('type', 'BBox3DL1Cost') != 'BBox3DL1Cost':
+            raise NotImplementedError('HungarianAssigner3D: only FocalLossCost + BBox3DL1Cost (the shipped configs) are built')
+        self.cls_weight = float(cls_cost.get('weight', 1.0))
+        self.alpha = float(cls_cost.get('alpha', 0.25))
+        self.gamma = float(cls_cost.get('gamma', 2.0))
+        self.reg_weight = float(reg_cost.get('weight', 1.0))
+        self.pc_range = pc_range
+
+    def cost(self, bbox_pred, cls_pred, gt_bboxes, gt_labels):
+        """[L,R,10], [L,R,C], [G,9] gravity-centre boxes, [G] -> cost [L,R,G] (device)."""
+        return ops.match_cost(cls_pred, bbox_pred, gt_bboxes, gt_labels.to(torch.int32), self.cls_weight, self.reg_weight, self.alpha,
+                              self.gamma)
+
+    def assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels):
+        """Returns match [L,R] int32 (device): index of the assigned ground-truth box or -1 (the reference's ``gt_inds - 1``).
+        A 2-D input ([R,10] / [R,C]) is one layer."""
+        from scipy.optimize import linear_sum_assignment
+        single = bbox_pred.dim() == 2
+        if single:
+            bbox_pred, cls_pred = bbox_pred[None], cls_pred[None]
+        L, R = cls_pred.shape[:2]
+        G = gt_bboxes.shape[0]
+        match = np.full((L, R), -1, np.int32)
+        if R and G:
+            cost = self.cost(bbox_pred.contiguous(), cls_pred.contiguous(), gt_bboxes.contiguous(), gt_labels).cpu().numpy()
+            for l in range(L):
+                rows, cols = linear_sum_assignment(cost[l])
+                match[l, rows] = cols
+        out = torch.from_numpy(match).to(cls_pred.device)
+        return out[0] if single else out
+
+
+class SetPredictionLoss(torch.autograd.Function):
+    """total = sum_l layer_w[l] * (loss_cls[l] + loss_bbox[l]); also returns the unweighted per-layer losses [L,2] (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, cls, box, match, gt, gt_labels, code_w, layer_w, cls_avg, box_avg, alpha, gamma, w_cls, w_box, skip_bg):
+        need = cls.requires_grad or box.requires_grad
+        loss, dcls, dbox = ops.set_loss(cls.contiguous(), box.contiguous(), match, gt, gt_labels, code_w, layer_w, cls_avg, box_avg, alpha,
+                                        gamma, w_cls, w_box, skip_bg, need_grad=need)
+        ctx.save_for_backward(dcls, dbox)
+        ctx.mark_non_differentiable(loss)
+        return (loss.sum(1) * layer_w).sum(), loss
+
+    @staticmethod
+    def backward(ctx, g_total, _g_loss):
+        dcls, dbox = ctx.saved_tensors
+        return (dcls * g_total, dbox * g_total) + (None,) * 12
+
+
+class HeadLoss:
+    """The loss part of ``CrossAttentionBoxHead`` (constructor arguments as in the reference config: ``loss_cls``, ``loss_bbox``,
+    ``code_weights``, ``train_cfg['assigner']``)."""
+
+    def __init__(self, num_classes=10, loss_cls=None, loss_bbox=None, code_weights=None, train_cfg=None, device='cuda'):
+        loss_cls = loss_cls or dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=2.0)
+        loss_bbox = loss_bbox or dict(type='L1Loss', loss_weight=0.25)
+        if loss_cls.get('type') != 'FocalLoss' or not loss_cls.get('use_sigmoid', True) or loss_bbox.get('type') != 'L1Loss':
+            raise NotImplementedError('HeadLoss: sigmoid FocalLoss + L1Loss (the shipped configs) only')
+        self.num_classes = num_classes
+        self.alpha, self.gamma = float(loss_cls.get('alpha', 0.25)), float(loss_cls.get('gamma', 2.0))
+        self.w_cls, self.w_box = float(loss_cls.get('loss_weight', 1.0)), float(loss_bbox.get('loss_weight', 1.0))
+        cw = code_weights or [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2]
+        self.code_weights = torch.tensor(cw[:10], dtype=torch.float32, device=device)
+        dn = list(cw[:10])
+        dn[6] = dn[7] = 0.0                                              # cross_attention_head.py:531
+        self.dn_code_weights = torch.tensor(dn, dtype=torch.float32, device=device)
+        train_cfg = train_cfg or {}
+        a = dict(train_cfg.get('assigner') or dict(type='HungarianAssigner3D'))
+        self.assigner = BBOX_ASSIGNERS.build(a)
+        self.stage_loss_weights = train_cfg.get('stage_loss_weights')
+        self.device = device
+
+    def _layer_w(self, L, scale=1.0):
+        w = self.stage_loss_weights or [1.0] * L
+        return torch.tensor([float(x) * scale for x in w[:L]], dtype=torch.float32, device=self.device)
+
+    def loss(self, all_cls_scores, all_bbox_preds, gt_bboxes, gt_labels, match=None):
+        """all_cls_scores [L,R,C], all_bbox_preds [L,R,10] (one sample), gt_bboxes [G,9] gravity-centre boxes, gt_labels [G].
+        Returns (losses, total): the reference's dict keys ``l{i}.loss_cls`` / ``l{i}.loss_bbox`` (already times the stage weight,
+        mv2d_s_head.py:299-302) as a [L,2] tensor view, and the differentiable total."""
+        L, R = all_cls_scores.shape[:2]
+        gt_bboxes = gt_bboxes.to(self.device, torch.float32).contiguous()
+        labels32 = gt_labels.to(self.device, torch.int32).contiguous()
+        if match is None:
+            match = self.assigner.assign(all_bbox_preds.detach(), all_cls_scores.detach(), gt_bboxes, labels32)
+        num_pos = min(R, gt_bboxes.shape[0])                             # a full assignment matches min(R, G) pairs in every layer
+        cls_avg = max(num_pos * 1.0, 1.0)                                # bg_cls_weight = 0, sync_cls_avg_factor False
+        box_avg = max(_reduce_mean(num_pos), 1.0)                        # reduce_mean(num_total_pos).clamp(min=1), :419-420
+        lw = self._layer_w(L)
+        total, per_layer = SetPredictionLoss.apply(all_cls_scores, all_bbox_preds, match, gt_bboxes, labels32, self.code_weights, lw,
+                                                   cls_avg, box_avg, self.alpha, self.gamma, self.w_cls, self.w_box, False)
+        weighted = per_layer * lw[:, None]
+        losses = {}
+        for l in range(L):
+            losses[f'l{l}.loss_cls'] = weighted[l, 0]
+            losses[f'l{l}.loss_bbox'] = weighted[l, 1]
+        return losses, total, match
+
+    def dn_loss(self, output_known_class, output_known_coord, known_bboxs, known_labels, num_tgt, split, neg_bbox_loss=False,
+                denoise_weight=1.0):
+        """``dn_loss_single`` for all layers: outputs of the denoising queries [L,N,C] / [L,N,10], their targets known_bboxs [N,9],
+        known_labels [N] (== num_classes: negative).  Keys ``l{i}.dn_loss_cls`` / ``l{i}.dn_loss_bbox`` (mv2d_s_head.py:292-297)."""
+        L, N = output_known_class.shape[:2]
+        cls_avg = max(num_tgt * 3.14159 / 6 * split * split * split, 1.0)
+        box_avg = max(_reduce_mean(num_tgt), 1.0)
+        lw = self._layer_w(L, denoise_weight)
+        match = torch.arange(N, dtype=torch.int32, device=self.device).repeat(L, 1)
+        total, per_layer = SetPredictionLoss.apply(output_known_class, output_known_coord, match,
+                                                   known_bboxs.to(self.device, torch.float32).contiguous(),
+                                                   known_labels.to(self.device, torch.int32).contiguous(), self.dn_code_weights, lw,
+                                                   cls_avg, box_avg, self.alpha, self.gamma, self.w_cls, self.w_box, not neg_bbox_loss)
+        weighted = per_layer * lw[:, None]
+        losses = {}
+        for l in range(L):
+            losses[f'l{l}.dn_loss_cls'] = weighted[l, 0]
+            losses[f'l{l}.dn_loss_bbox'] = weighted[l, 1]
+        return losses, total

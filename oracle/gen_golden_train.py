@@ -1,0 +1,61 @@
+"""Golden vectors of the training targets / losses from the UNMODIFIED reference (build container only).
+
+    python -B -m oracle.gen_golden_train      # writes tests/golden/train_loss.npz
+
+Runs the reference's own HungarianAssigner3D.assign, CrossAttentionBoxHead.loss (-> loss_single -> get_targets -> _get_target_single)
+and dn_loss_single on seeded synthetic head outputs and ground truth (mv2d_amd/synthetic.make_train_case; inputs are regenerated from
+the seed by the tests, only outputs are stored).  The mmdet classes those functions call are restated in oracle/_stubs_train.py.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from mv2d_amd import configs, synthetic  # noqa: E402
+from oracle import _stubs_train  # noqa: E402
+from oracle.gen_golden import build_reference_head  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden', 'train_loss.npz')
+
+
+def main():
+    (S_cls, T_cls), Assigner = _stubs_train.install('/root/reference')
+    head = build_reference_head('S', S_cls, T_cls, synthetic.make_head_state(seed=0), 2)
+    cfg = configs.roi_head_cfg_s()['bbox_head']
+    bh = _stubs_train.arm_bbox_head(head.bbox_head, Assigner, configs.TRAIN_CFG_RCNN, cfg['loss_cls'], cfg['loss_bbox'])
+    assert [float(x) for x in bh.code_weights] == cfg['code_weights']
+    rec = {}
+    for name, (R, G, seed) in synthetic.TRAIN_CASES.items():
+        c = synthetic.make_train_case(R, G, seed)
+        cls, box = torch.from_numpy(c['cls']), torch.from_numpy(c['box'])
+        gt = _stubs_train.GtBoxes(torch.from_numpy(c['gt_bottom']))
+        labels = torch.from_numpy(c['gt_labels'])
+        match, lc, lb = [], [], []
+        for l in range(cls.shape[0]):
+            gtc = torch.cat((gt.gravity_center, gt.tensor[:, 3:]), 1)
+            res = bh.assigner.assign(box[l], cls[l], gtc, labels)
+            match.append((res.gt_inds - 1).numpy())
+            out = bh.loss([gt], [labels], {'cls_scores': [cls[l]], 'bbox_preds': [box[l]]})
+            lc.append(float(out['loss_cls']))
+            lb.append(float(out['loss_bbox']))
+        rec[name + '.match'] = np.stack(match).astype(np.int32)
+        rec[name + '.loss'] = np.stack([lc, lb], 1).astype(np.float32)
+        # denoising loss: the first n rows as denoising queries with given targets (labels == 10 are negatives)
+        n = min(R, c['known_labels'].shape[0])
+        for neg in (False, True):
+            dn = [bh.dn_loss_single(cls[l][:n].clone(), box[l][:n].clone(), torch.from_numpy(c['known_bboxs'][:n]).clone(),
+                                    torch.from_numpy(c['known_labels'][:n]), c['dn_num_tgt'], configs.POINT_CLOUD_RANGE, 0.6, neg_bbox_loss=neg)
+                  for l in range(cls.shape[0])]
+            rec[name + ('.dn_neg' if neg else '.dn')] = np.array([[float(a), float(b)] for a, b in dn], np.float32)
+        print(name, rec[name + '.loss'][-1], rec[name + '.dn'][-1], 'matched', int((rec[name + '.match'][-1] >= 0).sum()))
+    np.savez_compressed(OUT, **rec)
+    print('wrote', OUT, os.path.getsize(OUT), 'bytes')
+
+
+if __name__ == '__main__':
+    main()

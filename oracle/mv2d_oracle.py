@@ -703,3 +703,91 @@ def forward_s(sd, feat, proposals, img_metas, topk=1, stages=None):
               center_pred=center_pred, xyz=xyz, ref=ref, corr=corr, corr_mask=cmask, qpos=qpos, outs_dec=outs,
               cls=cls_all, reg=reg_all, boxes=boxes, scores=scores, labels=labels, bbox_index=bidx)
     return boxes, scores, labels
+
+
+# --------------------------------------------------------------------------------------------
+# training targets and losses of the box head
+# --------------------------------------------------------------------------------------------
+CODE_WEIGHTS = [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.5, 1.5, 2.0, 2.0]      # configs/mv2d/exp/*:90
+
+
+def normalize_bbox(b):
+    """CB/util.py:37-58: (cx, cy, cz, w, l, h, yaw, vx, vy) -> (cx, cy, log w, log l, cz, log h, sin, cos, vx, vy)."""
+    return torch.cat([b[..., 0:1], b[..., 1:2], b[..., 3:4].log(), b[..., 4:5].log(), b[..., 2:3], b[..., 5:6].log(),
+                      b[..., 6:7].sin(), b[..., 6:7].cos(), b[..., 7:9]], -1)
+
+
+def focal_loss_cost(cls_pred, gt_labels, weight=2.0, alpha=0.25, gamma=2.0, eps=1e-12):
+    """mmdet==2.25.1 FocalLossCost._focal_loss_cost (third party, restated; cfg `cls_cost`, configs/mv2d/exp/*:138)."""
+    p = cls_pred.sigmoid()
+    neg = -(1 - p + eps).log() * (1 - alpha) * p.pow(gamma)
+    pos = -(p + eps).log() * alpha * (1 - p).pow(gamma)
+    return (pos[:, gt_labels] - neg[:, gt_labels]) * weight
+
+
+def match_cost(bbox_pred, cls_pred, gt_bboxes, gt_labels, reg_weight=0.25):
+    """CB/assigners/hungarian_assigner_3d.py:120-134: focal cost + L1 cdist on the first 8 codes (CB/match_costs/match_cost.py:24), nan_to_num."""
+    cost = focal_loss_cost(cls_pred, gt_labels) + torch.cdist(bbox_pred[:, :8], normalize_bbox(gt_bboxes)[:, :8], p=1) * reg_weight
+    return torch.nan_to_num(cost, nan=100.0, posinf=100.0, neginf=-100.0)
+
+
+def hungarian_assign(bbox_pred, cls_pred, gt_bboxes, gt_labels):
+    """HungarianAssigner3D.assign (:65-150) + PseudoSampler: match [R] = index of the assigned gt or -1 (background)."""
+    from scipy.optimize import linear_sum_assignment
+    R, G = bbox_pred.size(0), gt_bboxes.size(0)
+    match = torch.full((R,), -1, dtype=torch.long)
+    if R == 0 or G == 0:
+        return match
+    rows, cols = linear_sum_assignment(match_cost(bbox_pred, cls_pred, gt_bboxes, gt_labels).detach().cpu())
+    match[torch.from_numpy(rows)] = torch.from_numpy(cols)
+    return match
+
+
+def sigmoid_focal_loss_sum(pred, labels, num_classes, alpha=0.25, gamma=2.0):
+    """mmdet==2.25.1 py_sigmoid_focal_loss summed over all elements (third party, restated); label == num_classes is background."""
+    t = F.one_hot(labels, num_classes + 1)[:, :num_classes].type_as(pred)
+    p = pred.sigmoid()
+    pt = (1 - p) * t + p * (1 - t)
+    fw = (alpha * t + (1 - alpha) * (1 - t)) * pt.pow(gamma)
+    return (F.binary_cross_entropy_with_logits(pred, t, reduction='none') * fw).sum()
+
+
+def loss_single(cls_scores, bbox_preds, gt_bboxes, gt_labels, match=None, num_classes=10, code_weights=CODE_WEIGHTS,
+                loss_cls_weight=2.0, loss_bbox_weight=0.25):
+    """CrossAttentionBoxHead.loss_single for one sample (RH/bbox_heads/cross_attention_head.py:380-434 with _get_target_single
+    :234-302): cls_scores [R,C], bbox_preds [R,10], gt_bboxes [G,9], gt_labels [G] -> (loss_cls, loss_bbox, match)."""
+    R = cls_scores.size(0)
+    if match is None:
+        match = hungarian_assign(bbox_preds, cls_scores, gt_bboxes, gt_labels)
+    pos = match >= 0
+    labels = torch.full((R,), num_classes, dtype=torch.long)
+    labels[pos] = gt_labels[match[pos]]
+    targets = torch.zeros(R, 9, dtype=bbox_preds.dtype)
+    if gt_bboxes.size(0):
+        targets[pos] = gt_bboxes[match[pos]].to(bbox_preds.dtype)
+    weights = torch.zeros_like(bbox_preds)
+    weights[pos] = 1.0
+    num_pos = int(pos.sum())
+    cls_avg = max(num_pos * 1.0, 1)                          # bg_cls_weight = 0 (:153), sync_cls_avg_factor False
+    loss_cls = sigmoid_focal_loss_sum(cls_scores, labels, num_classes) / cls_avg * loss_cls_weight
+    nt = normalize_bbox(targets)
+    ok = torch.isfinite(nt).all(-1)
+    weights = weights * torch.tensor(code_weights, dtype=bbox_preds.dtype)
+    loss_bbox = ((bbox_preds[ok, :10] - nt[ok, :10]).abs() * weights[ok, :10]).sum() / max(num_pos, 1) * loss_bbox_weight
+    return torch.nan_to_num(loss_cls), torch.nan_to_num(loss_bbox), match
+
+
+def dn_loss_single(cls_scores, bbox_preds, known_bboxs, known_labels, num_total_pos, split, num_classes=10,
+                   code_weights=CODE_WEIGHTS, loss_cls_weight=2.0, loss_bbox_weight=0.25, neg_bbox_loss=False):
+    """CrossAttentionBoxHead.dn_loss_single (:477-538): rows are the denoising queries, targets given (no matching)."""
+    cls_avg = max(num_total_pos * 3.14159 / 6 * split * split * split, 1)
+    loss_cls = sigmoid_focal_loss_sum(cls_scores, known_labels.long(), num_classes) / cls_avg * loss_cls_weight
+    known_bboxs = known_bboxs.clone()
+    if not neg_bbox_loss:
+        known_bboxs[known_labels == num_classes] = 0
+    nt = normalize_bbox(known_bboxs)
+    ok = torch.isfinite(nt).all(-1)
+    weights = torch.ones_like(bbox_preds) * torch.tensor(code_weights, dtype=bbox_preds.dtype)
+    weights[:, 6:8] = 0
+    loss_bbox = ((bbox_preds[ok, :10] - nt[ok, :10]).abs() * weights[ok, :10]).sum() / max(num_total_pos, 1) * loss_bbox_weight
+    return torch.nan_to_num(loss_cls), torch.nan_to_num(loss_bbox)

@@ -1,0 +1,122 @@
+"""Training targets / losses of the box head on the GPU: HIP kernels through the C-ABI vs the oracle restatement and the
+goldens recorded from the reference's own assigner / loss code (tests/golden/train_loss.npz, oracle/gen_golden_train.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from mv2d_amd import configs, synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _case(name):
+    R, G, seed = synthetic.TRAIN_CASES[name]
+    c = synthetic.make_train_case(R, G, seed)
+    return c, {k: torch.from_numpy(v).to(DEV) for k, v in c.items() if isinstance(v, np.ndarray)}
+
+
+def _head_loss():
+    from mv2d_amd import train
+    cfg = configs.roi_head_cfg_s()['bbox_head']
+    return train.HeadLoss(num_classes=10, loss_cls=cfg['loss_cls'], loss_bbox=cfg['loss_bbox'], code_weights=cfg['code_weights'],
+                          train_cfg=configs.TRAIN_CFG_RCNN, device=DEV)
+
+
+@pytest.mark.parametrize('name', list(synthetic.TRAIN_CASES))
+def test_match_cost_and_assignment(name):
+    from oracle import mv2d_oracle as O
+    c, d = _case(name)
+    hl = _head_loss()
+    if c['gt'].shape[0] and c['cls'].shape[1]:
+        cost = hl.assigner.cost(d['box'], d['cls'], d['gt'], d['gt_labels']).cpu()
+        for l in range(cost.shape[0]):
+            want = O.match_cost(torch.from_numpy(c['box'][l]), torch.from_numpy(c['cls'][l]), torch.from_numpy(c['gt']),
+                                torch.from_numpy(c['gt_labels']))
+            assert torch.allclose(cost[l], want, rtol=2e-5, atol=2e-5), (l, float((cost[l] - want).abs().max()))
+    match = hl.assigner.assign(d['box'], d['cls'], d['gt'], d['gt_labels'])
+    assert match.dtype == torch.int32 and np.array_equal(match.cpu().numpy(), load_golden('train_loss')[name + '.match'])
+    one = hl.assigner.assign(d['box'][2], d['cls'][2], d['gt'], d['gt_labels'])          # the reference's per-layer call shape
+    assert torch.equal(one, match[2])
+
+
+def test_match_cost_nan_to_num():
+    """nan / +-inf costs become 100 / 100 / -100 (hungarian_assigner_3d.py:136)."""
+    from mv2d_amd import ops
+    cls = torch.zeros(1, 3, 10, device=DEV)
+    box = torch.zeros(1, 3, 10, device=DEV)
+    box[0, 0, 0] = float('nan')
+    box[0, 1, 1] = float('inf')
+    gt = torch.tensor([[0., 0, 0, 1, 1, 1, 0, 0, 0]], device=DEV)
+    cost = ops.match_cost(cls, box, gt, torch.zeros(1, dtype=torch.int32, device=DEV)).cpu()
+    assert cost[0, 0, 0] == 100.0 and cost[0, 1, 0] == 100.0 and torch.isfinite(cost[0, 2, 0])
+
+
+@pytest.mark.parametrize('name', list(synthetic.TRAIN_CASES))
+def test_head_loss_matches_reference_and_autograd(name):
+    from oracle import mv2d_oracle as O
+    c, d = _case(name)
+    gold = load_golden('train_loss')
+    hl = _head_loss()
+    cls = d['cls'].clone().requires_grad_(True)
+    box = d['box'].clone().requires_grad_(True)
+    losses, total, match = hl.loss(cls, box, d['gt'], d['gt_labels'])
+    L = cls.shape[0]
+    got = torch.stack([torch.stack([losses[f'l{l}.loss_cls'], losses[f'l{l}.loss_bbox']]) for l in range(L)]).cpu().numpy()
+    np.testing.assert_allclose(got, gold[name + '.loss'] * 0.1, rtol=1e-5, atol=1e-7)      # stage_loss_weights = 0.1
+    total.backward()
+    # gradient: torch autograd (fp64) through the oracle restatement with the same assignment
+    ocls = torch.from_numpy(c['cls']).double().requires_grad_(True)
+    obox = torch.from_numpy(c['box']).double().requires_grad_(True)
+    tot = 0
+    for l in range(L):
+        lc, lb, _ = O.loss_single(ocls[l], obox[l], torch.from_numpy(c['gt']).double(), torch.from_numpy(c['gt_labels']),
+                                  match=match[l].cpu().long())
+        tot = tot + 0.1 * (lc + lb)
+    tot.backward()
+    assert abs(float(total.detach()) - float(tot.detach())) <= 1e-5 * max(1.0, abs(float(tot.detach())))
+    for g, w in ((cls.grad, ocls.grad), (box.grad, obox.grad)):
+        w = w.float()
+        assert float((g.cpu() - w).abs().max()) <= 1e-5 * max(float(w.abs().max()), 1e-6), name
+
+
+@pytest.mark.parametrize('neg', [False, True])
+@pytest.mark.parametrize('name', ['small', 'mid', 'few_queries'])
+def test_dn_loss_matches_reference_and_autograd(name, neg):
+    from oracle import mv2d_oracle as O
+    c, d = _case(name)
+    gold = load_golden('train_loss')[name + ('.dn_neg' if neg else '.dn')]
+    hl = _head_loss()
+    n = c['known_labels'].shape[0]
+    cls = d['cls'][:, :n].contiguous().requires_grad_(True)
+    box = d['box'][:, :n].contiguous().requires_grad_(True)
+    losses, total = hl.dn_loss(cls, box, d['known_bboxs'], d['known_labels'], c['dn_num_tgt'], 0.6, neg_bbox_loss=neg)
+    L = cls.shape[0]
+    got = torch.stack([torch.stack([losses[f'l{l}.dn_loss_cls'], losses[f'l{l}.dn_loss_bbox']]) for l in range(L)]).cpu().numpy()
+    np.testing.assert_allclose(got, gold * 0.1, rtol=1e-5, atol=1e-7)
+    total.backward()
+    ocls = torch.from_numpy(c['cls'][:, :n]).double().requires_grad_(True)
+    obox = torch.from_numpy(c['box'][:, :n]).double().requires_grad_(True)
+    tot = 0
+    for l in range(L):
+        lc, lb = O.dn_loss_single(ocls[l], obox[l], torch.from_numpy(c['known_bboxs']).double(), torch.from_numpy(c['known_labels']),
+                                  c['dn_num_tgt'], 0.6, neg_bbox_loss=neg)
+        tot = tot + 0.1 * (lc + lb)
+    tot.backward()
+    for g, w in ((cls.grad, ocls.grad), (box.grad, obox.grad)):
+        w = w.float()
+        assert float((g.cpu() - w).abs().max()) <= 1e-5 * max(float(w.abs().max()), 1e-6)
+
+
+def test_set_loss_is_deterministic_and_rejects_bad_factors():
+    from mv2d_amd import _lib, ops
+    c, d = _case('mid')
+    hl = _head_loss()
+    match = hl.assigner.assign(d['box'], d['cls'], d['gt'], d['gt_labels'])
+    lab = d['gt_labels'].to(torch.int32)
+    a = ops.set_loss(d['cls'], d['box'], match, d['gt'], lab, hl.code_weights, None, 45.0, 45.0)
+    b = ops.set_loss(d['cls'], d['box'], match, d['gt'], lab, hl.code_weights, None, 45.0, 45.0)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    with pytest.raises(_lib.Mv2dHipError):
+        ops.set_loss(d['cls'], d['box'], match, d['gt'], lab, hl.code_weights, None, 0.0, 45.0)

@@ -136,3 +136,24 @@ def test_fully_masked_row_is_nan_in_reference():
     assert np.isnan(g['cls']).sum() == g['cls'].size - 0 or np.isnan(g['cls']).any()
     assert torch.isnan(st['cls'][-1]).all()
     assert st['boxes'].shape[0] == 0 and g['boxes'].shape[0] == 0
+
+
+# ---- training targets / losses: oracle restatement vs the reference's own assigner / loss code ------------------------
+TRAIN = load_golden('train_loss')
+
+
+@pytest.mark.parametrize('name', list(synthetic.TRAIN_CASES))
+def test_training_targets_and_losses_match_reference(name):
+    R, G, seed = synthetic.TRAIN_CASES[name]
+    c = synthetic.make_train_case(R, G, seed)
+    cls, box = torch.from_numpy(c['cls']), torch.from_numpy(c['box'])
+    gt, labels = torch.from_numpy(c['gt']), torch.from_numpy(c['gt_labels'])
+    n = c['known_labels'].shape[0]
+    for l in range(cls.shape[0]):
+        lc, lb, match = O.loss_single(cls[l], box[l], gt, labels)
+        assert np.array_equal(match.numpy().astype(np.int32), TRAIN[name + '.match'][l])
+        np.testing.assert_allclose([float(lc), float(lb)], TRAIN[name + '.loss'][l], rtol=2e-6, atol=1e-7)
+        for neg in (False, True):
+            dc, db = O.dn_loss_single(cls[l][:n], box[l][:n], torch.from_numpy(c['known_bboxs']), torch.from_numpy(c['known_labels']),
+                                      c['dn_num_tgt'], 0.6, neg_bbox_loss=neg)
+            np.testing.assert_allclose([float(dc), float(db)], TRAIN[name + ('.dn_neg' if neg else '.dn')][l], rtol=2e-6, atol=1e-7)
