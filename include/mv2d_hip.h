@@ -218,6 +218,11 @@ int mv2d_map_conv3x3(const void* in, const void* Wp, const float* bias, float* o
 /* FlattenMHSelfAttention core (MU/petr_transformer.py:317-370): qkv [R,768] fp32 = in_proj(q|k|v) -> ctx [R,256]. */
 int mv2d_self_attn_fwd(const float* qkv, float* ctx, int R, const int* grp_start, int n_samples, void* stream);
 
+/* Training variant: the first dn_pad rows are denoising queries in groups of dn_single rows; the attention mask of
+ * prepare_for_dn (mmdet3d_plugin/models/roi_heads/mv2d_s_head.py:95-107) is evaluated in the kernel: a key is visible iff
+ * key >= dn_pad, or query < dn_pad and key / dn_single == query / dn_single.  One sample per launch. */
+int mv2d_self_attn_dn_fwd(const float* qkv, float* ctx, int R, int dn_pad, int dn_single, void* stream);
+
 /* PETRMultiheadAttention core (MU/petr_transformer.py:426-513) over the allowed (query,key) pairs only.
  * q [R,256] fp32 pre-scaled by 1/sqrt(32); K,V [S,256] bf16; CSR row_ptr[R+1], col_idx[nnz] (key indices);
  * ctx [R,256] fp32.  A query with no allowed key yields NaN like nn.MultiheadAttention (empty_nan = 1) or 0 (empty_nan = 0).
@@ -348,6 +353,14 @@ int mv2d_set_loss(const float* cls, const float* box, const int* match, const fl
                   const float* layer_weights, float* loss, float* dcls, float* dbox, int n_layers, int R, int G, int C,
                   float cls_avg_factor, float box_avg_factor, float alpha, float gamma, float loss_cls_weight, float loss_bbox_weight,
                   int skip_background_boxes, void* stream);
+
+/* Denoising queries of MV2DSHead.prepare_for_dn (mmdet3d_plugin/models/roi_heads/mv2d_s_head.py:39-78), one sample: row i = (repeat
+ * i / G, box i % G) for i < G * scalar.  rnd [G*scalar][3] uniform in [0, 1) (the reference's torch.rand_like).  With noise_scale > 0:
+ * centre += (2 rnd - 1) * (size / 2 + noise_trans) * noise_scale, normalised by pc_range_host (6 floats, host memory), clamped to
+ * [eps, 1 - eps]; rows with |2 rnd - 1|_2 > split get label num_classes.  With noise_scale <= 0 the centre is copied unnormalised (as the
+ * reference does).  ref [G*scalar][3], labels [G*scalar] int64, boxes [G*scalar][9] (the repeated targets). */
+int mv2d_dn_queries(const float* gt, const int* gt_labels, const float* rnd, int G, int scalar, float noise_scale, float noise_trans, float split,
+                    int num_classes, const float* pc_range_host, float eps, float* ref, long long* labels, float* boxes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -37,8 +37,11 @@ __device__ __forceinline__ void load_kv(KVFrag& f, const float* __restrict__ qkv
 
 // Several samples in one launch (grp_start[n_grp + 1] = first query row of every sample): attention stays inside a sample, and the
 // query / key tiles are counted from the sample's first row, so a sample's result does not depend on what else is in the batch.
+// DN (training): the first dn_pad rows are denoising queries in groups of dn_single (prepare_for_dn's attn_mask,
+// RH/mv2d_s_head.py:95-107): a key is visible iff it is a matched query (key >= dn_pad) or the query is a denoising query of the same group.
+template <bool DN>
 __global__ __launch_bounds__(256) void self_attn_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int R, float scale,
-                                                        const int* __restrict__ grp_start, int n_grp) {
+                                                        const int* __restrict__ grp_start, int n_grp, int dn_pad, int dn_single) {
     __shared__ float sm[4][16], sl[4][16], so[4][32][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     int tile = blockIdx.x;
@@ -81,16 +84,19 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int key = t * 16 + 4 * fg + r;
-            p[r] = key < R ? s[r] * scale : -INFINITY;
+            bool vis = key < R;
+            if (DN) vis = vis && (key >= dn_pad || (q0 + fr < dn_pad && key / dn_single == (q0 + fr) / dn_single));
+            p[r] = vis ? s[r] * scale : -INFINITY;
             tmax = fmaxf(tmax, p[r]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = expf(m_run - m_new);
+        const float m_use = (DN && m_new == -INFINITY) ? 0.f : m_new;      // nothing visible to this query so far: (m, l, o) stay (-inf, 0, 0), no NaN
+        const float alpha = expf(m_run - m_use);
         float psum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { p[r] = expf(p[r] - m_new); psum += p[r]; }
+        for (int r = 0; r < 4; ++r) { p[r] = expf(p[r] - m_use); psum += p[r]; }
         psum += __shfl_xor(psum, 16, 64);
         psum += __shfl_xor(psum, 32, 64);
         l_run = l_run * alpha + psum;
@@ -498,8 +504,19 @@ extern "C" int mv2d_self_attn_fwd(const float* qkv, float* ctx, int R, const int
     MV2D_CHECK_ARG(qkv && ctx && R >= 0 && (!grp_start || n_grp >= 1), "mv2d_self_attn_fwd: bad args");
     if (R == 0) return MV2D_OK;
     const int tiles = grp_start ? cdiv(R, 16) + n_grp - 1 : cdiv(R, 16);       // upper bound of sum_g ceil(R_g / 16)
-    hipLaunchKernelGGL(self_attn_kernel, dim3(tiles, HEADS), dim3(256), 0, (hipStream_t)stream, qkv, ctx, R,
-                       1.0f / sqrtf((float)HD), grp_start, n_grp);
+    hipLaunchKernelGGL(self_attn_kernel<false>, dim3(tiles, HEADS), dim3(256), 0, (hipStream_t)stream, qkv, ctx, R,
+                       1.0f / sqrtf((float)HD), grp_start, n_grp, 0, 1);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_self_attn_dn_fwd(const float* qkv, float* ctx, int R, int dn_pad, int dn_single, void* stream) {
+    MV2D_CHECK_ARG(qkv && ctx && R >= 0, "mv2d_self_attn_dn_fwd: bad args");
+    MV2D_CHECK_ARG(dn_pad >= 0 && dn_pad <= R && (dn_pad == 0 || (dn_single >= 1 && dn_pad % dn_single == 0)),
+                   "mv2d_self_attn_dn_fwd: dn_pad must be a multiple of dn_single and at most R");
+    if (R == 0) return MV2D_OK;
+    hipLaunchKernelGGL(self_attn_kernel<true>, dim3(cdiv(R, 16), HEADS), dim3(256), 0, (hipStream_t)stream, qkv, ctx, R,
+                       1.0f / sqrtf((float)HD), (const int*)nullptr, 0, dn_pad, dn_pad ? dn_single : 1);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -154,6 +154,38 @@ __global__ __launch_bounds__(256) void set_loss_kernel(LossArgs a) {
     }
 }
 
+// prepare_for_dn (RH/mv2d_s_head.py:39-78): row i = (repeat i / G, ground-truth box i % G).
+__global__ __launch_bounds__(256) void dn_queries_kernel(const float* __restrict__ gt, const int* __restrict__ gt_labels,
+                                                          const float* __restrict__ rnd, int G, int n, float noise_scale, float noise_trans,
+                                                          float split, int num_classes, float r0, float r1, float r2, float r3, float r4,
+                                                          float r5, float eps, float* __restrict__ ref, long long* __restrict__ labels,
+                                                          float* __restrict__ boxes) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* g = gt + (long long)(i % G) * GT_CODE;
+#pragma unroll
+    for (int k = 0; k < GT_CODE; ++k) boxes[(long long)i * GT_CODE + k] = g[k];
+    float c[3] = {g[0], g[1], g[2]};
+    long long lab = gt_labels[i % G];
+    if (noise_scale > 0.f) {
+        const float lo[3] = {r0, r1, r2}, hi[3] = {r3, r4, r5};
+        float nrm = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float rp = rnd[(long long)i * 3 + k] * 2.f - 1.0f;
+            const float diff = g[3 + k] / 2.f + noise_trans;
+            c[k] += rp * diff * noise_scale;
+            c[k] = (c[k] - lo[k]) / (hi[k] - lo[k]);
+            c[k] = fminf(fmaxf(c[k], 0.0f + eps), 1.0f - eps);
+            nrm += rp * rp;
+        }
+        if (sqrtf(nrm) > split) lab = num_classes;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ref[(long long)i * 3 + k] = c[k];
+    labels[i] = lab;
+}
+
 }  // namespace
 
 extern "C" int mv2d_match_cost(const float* cls, const float* box, const float* gt, const int* gt_labels, float* cost, int n_layers,
@@ -183,6 +215,21 @@ extern "C" int mv2d_set_loss(const float* cls, const float* box, const int* matc
     LossArgs a{cls, box, match, gt, gt_labels, code_weights, layer_weights, loss, dcls, dbox, R, C, G, cls_avg_factor, box_avg_factor,
                alpha, gamma, loss_cls_weight, loss_bbox_weight, skip_background_boxes};
     hipLaunchKernelGGL(set_loss_kernel, dim3(n_layers), dim3(256), 0, (hipStream_t)stream, a);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_dn_queries(const float* gt, const int* gt_labels, const float* rnd, int G, int scalar, float noise_scale, float noise_trans,
+                               float split, int num_classes, const float* pc_range_host, float eps, float* ref, long long* labels,
+                               float* boxes, void* stream) {
+    MV2D_CHECK_ARG(G >= 0 && scalar >= 0, "mv2d_dn_queries: bad sizes");
+    const long long n = (long long)G * scalar;
+    if (n == 0) return MV2D_OK;
+    MV2D_CHECK_ARG(n < (1ll << 30), "mv2d_dn_queries: too many denoising queries");
+    MV2D_CHECK_ARG(gt && gt_labels && ref && labels && boxes && pc_range_host && (rnd || noise_scale <= 0.f), "mv2d_dn_queries: null pointer");
+    const float* r = pc_range_host;
+    hipLaunchKernelGGL(dn_queries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gt, gt_labels, rnd, G, (int)n,
+                       noise_scale, noise_trans, split, num_classes, r[0], r[1], r[2], r[3], r[4], r[5], eps, ref, labels, boxes);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

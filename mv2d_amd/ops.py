@@ -369,6 +369,31 @@ def self_attn(qkv, out=None, R=None, grp_start=None):
     return out
 
 
+def self_attn_dn(qkv, dn_pad, dn_single, out=None):
+    """Self attention of one training sample: the first dn_pad rows are denoising queries in groups of dn_single (prepare_for_dn's mask)."""
+    _req(qkv, torch.float32, 'qkv')
+    R = qkv.shape[0]
+    if out is None:
+        out = torch.empty((R, 256), device=qkv.device, dtype=torch.float32)
+    check(_lib.load().mv2d_self_attn_dn_fwd(_p(qkv), _p(out), R, int(dn_pad), int(dn_single), _stream()), 'mv2d_self_attn_dn_fwd')
+    return out
+
+
+def dn_queries(gt, gt_labels, rnd, scalar, noise_scale, noise_trans, split, num_classes, pc_range, eps=1e-4):
+    """gt [G,9] fp32, gt_labels [G] int32, rnd [G*scalar,3] fp32 in [0,1) -> (ref [G*scalar,3], labels int64, boxes [G*scalar,9])."""
+    import ctypes
+    G = gt.shape[0]
+    n = G * scalar
+    ref = torch.empty(n, 3, device=gt.device, dtype=torch.float32)
+    labels = torch.empty(n, device=gt.device, dtype=torch.int64)
+    boxes = torch.empty(n, 9, device=gt.device, dtype=torch.float32)
+    rng = (ctypes.c_float * 6)(*[float(x) for x in pc_range])
+    check(_lib.load().mv2d_dn_queries(_p(gt), _p(gt_labels), _p(rnd), G, int(scalar), float(noise_scale), float(noise_trans), float(split),
+                                      int(num_classes), ctypes.cast(rng, ctypes.c_void_p), float(eps), _p(ref), _p(labels), _p(boxes),
+                                      _stream()), 'mv2d_dn_queries')
+    return ref, labels, boxes
+
+
 def sparse_xattn(q, K, V, row_ptr, col_idx, out=None, R=None, dbg_logits=None, empty_nan=True):
     _req(q, torch.float32, 'q'); _req(K, BF16, 'K'); _req(V, BF16, 'V')
     _req(row_ptr, torch.int32, 'row_ptr'); _req(col_idx, torch.int32, 'col_idx')

@@ -264,3 +264,13 @@ def make_train_case(R, G, seed, num_layers=NUM_LAYERS, num_classes=10):
         known_labels[0] = num_classes
     return dict(cls=cls, box=box.astype(np.float32), gt_bottom=gt, gt=grav.astype(np.float32), gt_labels=labels, known_bboxs=known,
                 known_labels=known_labels, dn_num_tgt=max(nk * 2 // 3, 1))
+
+
+# prepare_for_dn cases: name -> (R, G, seed, denoise_scalar, denoise_noise_scale, denoise_split)
+DN_CASES = {'dn_default': (12, 7, 3, 10, 1.0, 0.75), 'dn_two_frames': (40, 11, 13, 10, 1.25, 0.6), 'dn_no_noise': (9, 4, 5, 3, 0.0, 0.75),
+            'dn_no_gt': (6, 0, 9, 10, 1.0, 0.75)}
+
+
+def make_dn_noise(n, seed):
+    """[n,3] uniform in [0,1): stands for torch.rand_like in prepare_for_dn (and, with another seed, for reference points)."""
+    return _rng(seed + 7919).random((n, 3)).astype(np.float32)

@@ -152,3 +152,42 @@ class HeadLoss:
             losses[f'l{l}.dn_loss_cls'] = weighted[l, 0]
             losses[f'l{l}.dn_loss_bbox'] = weighted[l, 1]
         return losses, total
+
+
+def prepare_for_dn(reference_points, gt_bboxes, gt_labels, denoise_scalar=10, denoise_noise_scale=1.0, denoise_noise_trans=0.0,
+                   denoise_split=0.75, num_classes=10, pc_range=None, rnd=None, eps=1e-4, dense_mask=True):
+    """``MV2DSHead.prepare_for_dn`` for the training branch and one sample (mmdet3d_plugin/models/roi_heads/mv2d_s_head.py:39-121;
+    ``batch_size`` is 1 there, :249).  reference_points [R,3] (device), gt_bboxes [G,9] gravity-centre boxes, gt_labels [G];
+    ``rnd`` [G*denoise_scalar,3] uniform in [0,1) stands for the reference's ``torch.rand_like`` (drawn on the device when None).
+
+    Returns (padded_reference_points [1, pad+R, 3], attn_mask bool [pad+R, pad+R] (True = masked) or None when ``dense_mask`` is False,
+    mask_dict).  mask_dict has the reference's keys plus ``dn_single``: the attention kernels take (pad_size, dn_single) instead of the
+    dense mask (``ops.self_attn_dn``)."""
+    dev = reference_points.device
+    G = int(gt_bboxes.shape[0])
+    R = int(reference_points.shape[0])
+    pad = G * denoise_scalar
+    gt = gt_bboxes.to(dev, torch.float32).contiguous()
+    lab = gt_labels.to(dev, torch.int32).contiguous()
+    if rnd is None and denoise_noise_scale > 0:
+        rnd = torch.rand(pad, 3, device=dev)
+    ref, known_labels, known_bboxs = ops.dn_queries(gt, lab, rnd, denoise_scalar, denoise_noise_scale, denoise_noise_trans, denoise_split,
+                                                    num_classes, pc_range or [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], eps)
+    padded = torch.cat([ref, reference_points.to(torch.float32)], 0)[None]
+    attn_mask = None
+    if dense_mask:
+        i = torch.arange(pad + R, device=dev)
+        grp = i // max(G, 1)
+        visible = (i[None, :] >= pad) | ((i[:, None] < pad) & (grp[:, None] == grp[None, :]))
+        attn_mask = ~visible
+    idx = torch.arange(G, device=dev)
+    mask_dict = {
+        'known_indice': idx.repeat(denoise_scalar),
+        'batch_idx': torch.zeros(G, dtype=torch.long, device=dev),
+        'map_known_indice': torch.arange(pad, device=dev),
+        'known_lbs_bboxes': (known_labels, known_bboxs),
+        'know_idx': [torch.ones(G, dtype=torch.long, device=dev)],
+        'pad_size': pad,
+        'dn_single': G,
+    }
+    return padded, attn_mask, mask_dict

@@ -53,6 +53,31 @@ def main():
                   for l in range(cls.shape[0])]
             rec[name + ('.dn_neg' if neg else '.dn')] = np.array([[float(a), float(b)] for a, b in dn], np.float32)
         print(name, rec[name + '.loss'][-1], rec[name + '.dn'][-1], 'matched', int((rec[name + '.match'][-1] >= 0).sum()))
+    # --- prepare_for_dn: the reference's own method on the S head (training branch).  `.cuda()` (no GPU here) and `torch.rand_like`
+    # (the noise, regenerated from the seed by the tests) are patched for the call; everything else runs unmodified.
+    head.train()
+    head.use_denoise = True
+    for name, (R, G, seed, scalar, nscale, split) in synthetic.DN_CASES.items():
+        c = synthetic.make_train_case(R, G, seed)
+        rnd = torch.from_numpy(synthetic.make_dn_noise(G * scalar, seed))
+        head.denoise_scalar, head.denoise_noise_scale, head.denoise_split, head.denoise_noise_trans = scalar, nscale, split, 0.0
+        meta = dict(gt_bboxes_3d=_stubs_train.GtBoxes(torch.from_numpy(c['gt_bottom'])), gt_labels_3d=torch.from_numpy(c['gt_labels']))
+        ref = torch.from_numpy(synthetic.make_dn_noise(R, seed + 100))
+        cuda, rand_like = torch.Tensor.cuda, torch.rand_like
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.rand_like = lambda t, *a, **k: rnd.to(t.dtype)
+        try:
+            padded, attn_mask, md = head.prepare_for_dn(1, ref, [meta], R)
+        finally:
+            torch.Tensor.cuda, torch.rand_like = cuda, rand_like
+        rec[name + '.padded'] = padded.numpy()
+        rec[name + '.attn_mask'] = np.packbits(attn_mask.numpy())
+        rec[name + '.known_labels'] = md['known_lbs_bboxes'][0].numpy()
+        rec[name + '.known_bboxs'] = md['known_lbs_bboxes'][1].numpy()
+        rec[name + '.map_known_indice'] = md['map_known_indice'].numpy()
+        rec[name + '.known_indice'] = md['known_indice'].numpy()
+        rec[name + '.pad_size'] = np.int64(md['pad_size'])
+        print(name, padded.shape, attn_mask.shape, 'negatives', int((md['known_lbs_bboxes'][0] == 10).sum()))
     np.savez_compressed(OUT, **rec)
     print('wrote', OUT, os.path.getsize(OUT), 'bytes')
 

@@ -791,3 +791,34 @@ def dn_loss_single(cls_scores, bbox_preds, known_bboxs, known_labels, num_total_
     weights[:, 6:8] = 0
     loss_bbox = ((bbox_preds[ok, :10] - nt[ok, :10]).abs() * weights[ok, :10]).sum() / max(num_total_pos, 1) * loss_bbox_weight
     return torch.nan_to_num(loss_cls), torch.nan_to_num(loss_bbox)
+
+
+def prepare_for_dn(reference_points, gt_bboxes, gt_labels, rnd, scalar=10, noise_scale=1.0, noise_trans=0.0, split=0.75,
+                   num_classes=10, pc_range=PC_RANGE, eps=1e-4):
+    """MV2DSHead.prepare_for_dn, training branch, one sample (RH/mv2d_s_head.py:39-121).  `rnd` [G*scalar,3] in [0,1) replaces
+    torch.rand_like.  Returns (padded reference points [1,pad+R,3], attn_mask bool [T,T], known_labels, known_bboxs, pad_size)."""
+    G, R = gt_bboxes.size(0), reference_points.size(0)
+    known_labels = gt_labels.repeat(scalar, 1).view(-1).long()
+    known_bboxs = gt_bboxes.repeat(scalar, 1)
+    center = known_bboxs[:, :3].clone()
+    scale = known_bboxs[:, 3:6].clone()
+    if noise_scale > 0:
+        diff = scale / 2 + noise_trans
+        rand_prob = rnd * 2 - 1.0
+        center += torch.mul(rand_prob, diff) * noise_scale
+        for k in range(3):
+            center[..., k:k + 1] = (center[..., k:k + 1] - pc_range[k]) / (pc_range[k + 3] - pc_range[k])
+        center = center.clamp(min=0.0 + eps, max=1.0 - eps)
+        known_labels[torch.norm(rand_prob, 2, 1) > split] = num_classes
+    single_pad = G
+    pad = single_pad * scalar
+    padded = torch.cat([torch.zeros(pad, 3), reference_points], 0).unsqueeze(0)
+    if pad:
+        padded[0, :pad] = center                       # map_known_indice = arange(G) + single_pad * i: the identity for one sample
+    T = pad + R
+    attn_mask = torch.zeros(T, T, dtype=torch.bool)
+    attn_mask[pad:, :pad] = True
+    for i in range(scalar):
+        attn_mask[single_pad * i:single_pad * (i + 1), single_pad * (i + 1):pad] = True
+        attn_mask[single_pad * i:single_pad * (i + 1), :single_pad * i] = True
+    return padded, attn_mask, known_labels, known_bboxs, pad

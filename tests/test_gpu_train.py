@@ -120,3 +120,50 @@ def test_set_loss_is_deterministic_and_rejects_bad_factors():
     assert all(torch.equal(x, y) for x, y in zip(a, b))
     with pytest.raises(_lib.Mv2dHipError):
         ops.set_loss(d['cls'], d['box'], match, d['gt'], lab, hl.code_weights, None, 0.0, 45.0)
+
+
+@pytest.mark.parametrize('name', list(synthetic.DN_CASES))
+def test_prepare_for_dn_matches_reference(name):
+    """Host prepare_for_dn (HIP kernel for the noised queries) vs the goldens of the reference's own method."""
+    from mv2d_amd import train
+    gold = load_golden('train_loss')
+    R, G, seed, scalar, nscale, split = synthetic.DN_CASES[name]
+    c = synthetic.make_train_case(R, G, seed)
+    rnd = torch.from_numpy(synthetic.make_dn_noise(G * scalar, seed)).to(DEV)
+    ref = torch.from_numpy(synthetic.make_dn_noise(R, seed + 100)).to(DEV)
+    padded, attn_mask, md = train.prepare_for_dn(ref, torch.from_numpy(c['gt']), torch.from_numpy(c['gt_labels']), scalar, nscale, 0.0, split,
+                                                 rnd=rnd)
+    assert md['pad_size'] == int(gold[name + '.pad_size'])
+    want = gold[name + '.padded']
+    assert padded.shape == want.shape
+    assert float((padded.cpu() - torch.from_numpy(want)).abs().max()) <= 2e-7 if want.size else True    # fp32 ulp (fused multiply-add)
+    assert np.array_equal(np.packbits(attn_mask.cpu().numpy()), gold[name + '.attn_mask'])
+    kl, kb = md['known_lbs_bboxes']
+    assert np.array_equal(kl.cpu().numpy(), gold[name + '.known_labels']) and np.array_equal(kb.cpu().numpy(), gold[name + '.known_bboxs'], equal_nan=True)
+    assert np.array_equal(md['map_known_indice'].cpu().numpy(), gold[name + '.map_known_indice'])
+    assert np.array_equal(md['known_indice'].cpu().numpy(), gold[name + '.known_indice'])
+    # drawn on the device when no noise is given: same structure, labels either the ground truth's or the negative class
+    p2, _, md2 = train.prepare_for_dn(ref, torch.from_numpy(c['gt']), torch.from_numpy(c['gt_labels']), scalar, nscale, 0.0, split, dense_mask=False)
+    assert p2.shape == padded.shape and torch.equal(p2[0, md['pad_size']:], ref)
+    if G:
+        l2 = md2['known_lbs_bboxes'][0].cpu()
+        assert bool(((l2 == torch.from_numpy(c['gt_labels']).repeat(scalar)) | (l2 == 10)).all())
+
+
+@pytest.mark.parametrize('R,pad,single', [(82, 70, 7), (150, 110, 11), (33, 0, 1), (64, 64, 16), (300, 290, 29), (17, 3, 3)])
+def test_self_attn_with_denoising_mask(R, pad, single):
+    """ops.self_attn_dn evaluates prepare_for_dn's attn_mask from (pad_size, single_pad): equal to dense masked attention in fp64."""
+    import math
+    from mv2d_amd import ops
+    from oracle import mv2d_oracle as O
+    g = torch.Generator().manual_seed(R + pad)
+    qkv = torch.randn(R, 768, generator=g).to(DEV)
+    out = ops.self_attn_dn(qkv, pad, single)
+    _, mask, _, _, _ = O.prepare_for_dn(torch.zeros(R - pad, 3), torch.ones(single if pad else 0, 9), torch.zeros(single if pad else 0).long(),
+                                        torch.zeros(pad, 3), scalar=pad // single if pad else 0, noise_scale=0.0)
+    q, k, v = [t.double().cpu().view(R, 8, 32).transpose(0, 1) for t in qkv.split(256, 1)]
+    logits = (q @ k.transpose(1, 2) / math.sqrt(32)).masked_fill(mask[None], float('-inf'))
+    want = (torch.softmax(logits, -1) @ v).transpose(0, 1).reshape(R, 256)
+    assert float((out.cpu().double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    if pad == 0:
+        assert torch.equal(out, ops.self_attn(qkv))          # no denoising rows: the inference kernel's arithmetic

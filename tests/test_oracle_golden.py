@@ -157,3 +157,18 @@ def test_training_targets_and_losses_match_reference(name):
             dc, db = O.dn_loss_single(cls[l][:n], box[l][:n], torch.from_numpy(c['known_bboxs']), torch.from_numpy(c['known_labels']),
                                       c['dn_num_tgt'], 0.6, neg_bbox_loss=neg)
             np.testing.assert_allclose([float(dc), float(db)], TRAIN[name + ('.dn_neg' if neg else '.dn')][l], rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('name', list(synthetic.DN_CASES))
+def test_prepare_for_dn_matches_reference(name):
+    R, G, seed, scalar, nscale, split = synthetic.DN_CASES[name]
+    c = synthetic.make_train_case(R, G, seed)
+    rnd = torch.from_numpy(synthetic.make_dn_noise(G * scalar, seed))
+    ref = torch.from_numpy(synthetic.make_dn_noise(R, seed + 100))
+    padded, attn_mask, kl, kb, pad = O.prepare_for_dn(ref, torch.from_numpy(c['gt']), torch.from_numpy(c['gt_labels']), rnd, scalar, nscale,
+                                                      0.0, split)
+    assert pad == int(TRAIN[name + '.pad_size']) == G * scalar
+    assert np.array_equal(padded.numpy(), TRAIN[name + '.padded'])
+    assert np.array_equal(np.packbits(attn_mask.numpy()), TRAIN[name + '.attn_mask'])
+    assert np.array_equal(kl.numpy(), TRAIN[name + '.known_labels']) and np.array_equal(kb.numpy(), TRAIN[name + '.known_bboxs'], equal_nan=True)
+    assert np.array_equal(TRAIN[name + '.map_known_indice'], np.arange(pad))
