@@ -1,0 +1,216 @@
+"""nuScenes I/O contract on the input side of the hot path — host code, numpy only.
+
+What the head consumes per view is ``img_metas[v]`` = {intrinsics 4x4, extrinsics 4x4 (lidar->camera, stored transposed), lidar2img 4x4,
+timestamp, img_shape, pad_shape}; this module builds those from the on-disk records exactly as the reference's dataset / pipeline do:
+
+* ``camera_geometry``        — ``CustomNuScenesDataset.get_data_info`` (test mode), mmdet3d_plugin/datasets/custom_nuscenes_dataset.py:100-163
+* ``sweep_camera_record``    — ``add_frame`` of tools/generate_sweep_pkl.py:32-82 (the sweep cameras in the key frame's lidar frame)
+* ``append_sweeps``          — ``LoadMultiViewImageFromMultiSweepsFiles.__call__``, mmdet3d_plugin/datasets/pipelines/loading.py:53-163
+* ``sample_augmentation`` / ``image_aug_matrix`` / ``resize_crop_flip`` — ``ResizeCropFlipImageMono`` (without the 2-D box branch),
+  mmdet3d_plugin/datasets/pipelines/transform_3d.py:456-591
+* ``split_view_metas``       — the per-view split of ``MV2D.simple_test``, mmdet3d_plugin/models/detectors/mv2d.py:232-246
+
+Out of this slice: image decoding itself (an ``imread`` callable is injected), the 2-D annotation matching of the training branch, and the
+result JSON (``_format_bbox`` / nuScenes eval live in mmdet3d and the nuscenes devkit, not in the reference tree).
+"""
+import numpy as np
+
+SENSORS = ['CAM_FRONT', 'CAM_FRONT_RIGHT', 'CAM_FRONT_LEFT', 'CAM_BACK', 'CAM_BACK_LEFT', 'CAM_BACK_RIGHT']
+
+
+def _lidar2cam(sensor2lidar_rotation, sensor2lidar_translation):
+    """The 4x4 the reference calls ``lidar2cam_rt`` (row-vector convention: points_h @ lidar2cam_rt = points in the camera frame)."""
+    r = np.linalg.inv(sensor2lidar_rotation)
+    t = sensor2lidar_translation @ r.T
+    rt = np.eye(4)
+    rt[:3, :3] = r.T
+    rt[3, :3] = -t
+    return rt
+
+
+def _viewpad(intrinsic):
+    intrinsic = np.asarray(intrinsic)
+    pad = np.eye(4)
+    pad[:intrinsic.shape[0], :intrinsic.shape[1]] = intrinsic
+    return pad
+
+
+def camera_geometry(info):
+    """One key-frame record of the info pkl -> the geometry part of ``get_data_info``'s input_dict (fp64 matrices, in camera order)."""
+    out = dict(sample_idx=info['token'], pts_filename=info['lidar_path'], sweeps=info['sweeps'], timestamp=info['timestamp'] / 1e6,
+               img_timestamp=[], img_filename=[], lidar2img=[], intrinsics=[], extrinsics=[])
+    for _cam, c in info['cams'].items():
+        out['img_timestamp'].append(c['timestamp'] / 1e6)
+        out['img_filename'].append(c['data_path'])
+        rt = _lidar2cam(c['sensor2lidar_rotation'], c['sensor2lidar_translation'])
+        pad = _viewpad(c['cam_intrinsic'])
+        out['lidar2img'].append(pad @ rt.T)
+        out['intrinsics'].append(pad)
+        out['extrinsics'].append(rt)        # lidar -> camera, transposed (the reference's comment at :150)
+    out['img_info'] = info
+    return out
+
+
+def quaternion_rotation_matrix(q):
+    """(w, x, y, z) -> 3x3 rotation (what pyquaternion's ``Quaternion(q).rotation_matrix`` returns; the quaternion is normalised first)."""
+    w, x, y, z = np.asarray(q, np.float64) / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def sweep_camera_record(sensor2ego_rotation, sensor2ego_translation, ego2global_rotation, ego2global_translation, cam_intrinsic,
+                        key_l2e_r_mat, key_l2e_t, key_e2g_r_mat, key_e2g_t):
+    """A sweep camera in the key frame's lidar frame (``add_frame``): rotations of the sweep as quaternions (w, x, y, z), the key frame's
+    lidar->ego and ego->global as 3x3 matrices + translations.  Returns sensor2lidar_rotation / _translation (fp64) and the float32
+    intrinsics / extrinsics / lidar2img the loader appends."""
+    s2e = quaternion_rotation_matrix(sensor2ego_rotation)
+    e2g = quaternion_rotation_matrix(ego2global_rotation)
+    back = np.linalg.inv(key_e2g_r_mat).T @ np.linalg.inv(key_l2e_r_mat).T
+    R = (s2e.T @ e2g.T) @ back
+    T = (np.asarray(sensor2ego_translation) @ e2g.T + np.asarray(ego2global_translation)) @ back
+    T -= np.asarray(key_e2g_t) @ back + np.asarray(key_l2e_t) @ np.linalg.inv(key_l2e_r_mat).T
+    rec = dict(sensor2lidar_rotation=R.T, sensor2lidar_translation=T)
+    rt = _lidar2cam(rec['sensor2lidar_rotation'], rec['sensor2lidar_translation'])
+    pad = _viewpad(np.array(cam_intrinsic))
+    rec['intrinsics'] = pad.astype(np.float32)
+    rec['extrinsics'] = rt.astype(np.float32)
+    rec['lidar2img'] = (pad @ rt.T).astype(np.float32)
+    return rec
+
+
+def append_sweeps(results, sweeps_num=5, sweep_range=(3, 27), sweeps_id=None, sensors=SENSORS, test_mode=True, pad_empty_sweeps=False,
+                  prob=1.0, to_float32=False, imread=None, rng=np.random):
+    """``LoadMultiViewImageFromMultiSweepsFiles``: appends the chosen previous frame(s) — images (through ``imread(path)``; None keeps the
+    paths only), file names, geometry — and turns ``results['timestamp']`` into the per-image time offsets to the lidar timestamp.
+    ``rng`` supplies ``random()`` / ``choice()`` for the training-time choice (the reference uses the global numpy state)."""
+    imgs = list(results.get('img', []))
+    lidar_ts = results['timestamp']
+    ts = [lidar_ts - t for t in results['img_timestamp']]
+    out_imgs, out_ts = list(imgs), list(ts)
+    nums = len(results['img_timestamp'])
+    if pad_empty_sweeps and len(results['sweeps']) == 0:
+        for _ in range(sweeps_num):
+            out_imgs.extend(imgs)
+            mean_time = (sweep_range[0] + sweep_range[1]) / 2.0 * 0.083
+            out_ts.extend([t + mean_time for t in ts])
+            for j in range(nums):
+                results['filename'].append(results['filename'][j])
+                for k in ('lidar2img', 'intrinsics', 'extrinsics'):
+                    results[k].append(np.copy(results[k][j]))
+    else:
+        n_sw = len(results['sweeps'])
+        mid = [int((sweep_range[0] + sweep_range[1]) / 2) - 1]
+        if sweeps_id:
+            choices = sweeps_id
+        elif n_sw <= sweeps_num:
+            choices = np.arange(n_sw)
+        elif test_mode:
+            choices = mid
+        elif rng.random() < prob:
+            cand = list(range(sweep_range[0], min(sweep_range[1], n_sw))) if sweep_range[0] < n_sw else list(range(*sweep_range))
+            choices = rng.choice(cand, sweeps_num, replace=False)
+        else:
+            choices = mid
+        for idx in choices:
+            si = min(idx, n_sw - 1)
+            sweep = results['sweeps'][si]
+            if len(sweep.keys()) < len(sensors):
+                sweep = results['sweeps'][si - 1]
+            results['filename'].extend([sweep[s]['data_path'] for s in sensors])
+            if imread is not None:
+                for s in sensors:
+                    im = imread(sweep[s]['data_path'])
+                    out_imgs.append(im.astype(np.float32) if to_float32 else im)
+            out_ts.extend([lidar_ts - sweep[s]['timestamp'] / 1e6 for s in sensors])
+            for s in sensors:
+                results['lidar2img'].append(sweep[s]['lidar2img'])
+                results['intrinsics'].append(sweep[s]['intrinsics'])
+                results['extrinsics'].append(sweep[s]['extrinsics'])
+    results['img'] = out_imgs
+    results['timestamp'] = out_ts
+    return results
+
+
+def sample_augmentation(conf, training, rng=np.random):
+    """``ResizeCropFlipImage._sample_augmentation``: (resize, resize_dims, crop, flip, rotate); draws in the reference's order."""
+    H, W = conf['H'], conf['W']
+    fH, fW = conf['final_dim']
+    if training:
+        resize = rng.uniform(*conf['resize_lim'])
+        resize_dims = (int(W * resize), int(H * resize))
+        newW, newH = resize_dims
+        crop_h = int((1 - rng.uniform(*conf['bot_pct_lim'])) * newH) - fH
+        crop_w = int(rng.uniform(0, max(0, newW - fW)))
+        crop = (crop_w, crop_h, crop_w + fW, crop_h + fH)
+        flip = bool(conf['rand_flip'] and rng.choice([0, 1]))
+        rotate = rng.uniform(*conf['rot_lim'])
+    else:
+        resize = max(fH / H, fW / W)
+        resize_dims = (int(W * resize), int(H * resize))
+        newW, newH = resize_dims
+        crop_h = int((1 - np.mean(conf['bot_pct_lim'])) * newH) - fH
+        crop_w = int(max(0, newW - fW) / 2)
+        crop = (crop_w, crop_h, crop_w + fW, crop_h + fH)
+        flip, rotate = False, 0
+    return resize, resize_dims, crop, flip, rotate
+
+
+def image_aug_matrix(resize, crop, flip, rotate):
+    """The 3x3 ``ida_mat`` of ``_img_transform`` (fp32 like the reference's torch.Tensor arithmetic): pixel (u, v, 1) of the source image
+    -> pixel of the resized / cropped / flipped / rotated image."""
+    f32 = np.float32
+    rot = np.eye(2, dtype=f32) * f32(resize)
+    tran = np.zeros(2, f32) - np.array(crop[:2], f32)
+    if flip:
+        A = np.array([[-1, 0], [0, 1]], f32)
+        b = np.array([crop[2] - crop[0], 0], f32)
+        rot = A @ rot
+        tran = A @ tran + b
+    h = rotate / 180 * np.pi
+    A = np.array([[np.cos(h), np.sin(h)], [-np.sin(h), np.cos(h)]], f32)
+    b = np.array([crop[2] - crop[0], crop[3] - crop[1]], f32) / f32(2)
+    b = A @ (-b) + b
+    rot = A @ rot
+    tran = A @ tran + b
+    m = np.eye(3, dtype=f32)
+    m[:2, :2] = rot
+    m[:2, 2] = tran
+    return m
+
+
+def resize_crop_flip(results, conf, training=False, rng=np.random, transform_images=True):
+    """``ResizeCropFlipImageMono.__call__`` (``with_bbox_2d=False``): one augmentation for all views; intrinsics[:3,:3] <- ida @ intrinsics
+    [:3,:3] in place, lidar2img rebuilt as intrinsics @ extrinsics.T; the images go through PIL as in the reference when
+    ``transform_images``."""
+    resize, resize_dims, crop, flip, rotate = sample_augmentation(conf, training, rng)
+    ida = image_aug_matrix(resize, crop, flip, rotate)
+    if transform_images and results.get('img'):
+        from PIL import Image
+        new = []
+        for im in results['img']:
+            p = Image.fromarray(np.uint8(im)).resize(resize_dims).crop(crop)
+            if flip:
+                p = p.transpose(method=Image.FLIP_LEFT_RIGHT)
+            new.append(np.array(p.rotate(rotate)).astype(np.float32))
+        results['img'] = new
+    for i in range(len(results['intrinsics'])):
+        results['intrinsics'][i][:3, :3] = ida @ results['intrinsics'][i][:3, :3]
+    results['lidar2img'] = [results['intrinsics'][i] @ results['extrinsics'][i].T for i in range(len(results['extrinsics']))]
+    return results
+
+
+def split_view_metas(img_metas_views, num_views):
+    """One sample's collated img_metas (lists over views) -> the per-view dicts the head takes (``MV2D.simple_test``)."""
+    out = []
+    for j in range(num_views):
+        m = dict(num_views=num_views)
+        for k, v in img_metas_views.items():
+            if isinstance(v, list):
+                m[k] = v[j]
+            elif k == 'ori_shape':
+                m[k] = v[:3]
+            else:
+                m[k] = v
+        out.append(m)
+    return out

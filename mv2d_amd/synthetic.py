@@ -274,3 +274,70 @@ DN_CASES = {'dn_default': (12, 7, 3, 10, 1.0, 0.75), 'dn_two_frames': (40, 11, 1
 def make_dn_noise(n, seed):
     """[n,3] uniform in [0,1): stands for torch.rand_like in prepare_for_dn (and, with another seed, for reference points)."""
     return _rng(seed + 7919).random((n, 3)).astype(np.float32)
+
+
+# ---- nuScenes I/O contract (SURVEY 8(f) f4): a synthetic info record of the dataset pkl ----------------------------------------------------
+NUSC_SENSORS = ['CAM_FRONT', 'CAM_FRONT_RIGHT', 'CAM_FRONT_LEFT', 'CAM_BACK', 'CAM_BACK_LEFT', 'CAM_BACK_RIGHT']
+NUSC_AUG_CONF = dict(resize_lim=(0.8, 1.0), final_dim=(512, 1408), bot_pct_lim=(0.0, 0.0), rot_lim=(0.0, 0.0), H=900, W=1600,
+                     rand_flip=True)                                   # configs/mv2d/data/two_frames.py:23-31
+NUSC_AUG_CONF_SMALL = dict(resize_lim=(0.8, 1.0), final_dim=(48, 128), bot_pct_lim=(0.0, 0.2), rot_lim=(-5.4, 5.4), H=90, W=160,
+                           rand_flip=True)                             # same structure at 1/10 size, with rotation, for the image tests
+
+
+def _rand_rotation(g):
+    q, r = np.linalg.qr(g.normal(size=(3, 3)))
+    q = q * np.sign(np.diag(r))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q
+
+
+def make_nusc_info(seed, n_sweeps=6, incomplete_sweep=None):
+    """One key-frame record shaped like the info pkl the reference's dataset reads (custom_nuscenes_dataset.py:117-150) plus the camera
+    sweeps written by tools/generate_sweep_pkl.py (per sensor: data_path, timestamp in us, float32 lidar2img / intrinsics / extrinsics)."""
+    g = _rng(seed)
+    t0 = 1533151603547590 + int(g.integers(0, 10 ** 6))
+    cams = {}
+    for i, s in enumerate(NUSC_SENSORS):
+        f = float(g.uniform(1100, 1300))
+        cams[s] = dict(data_path=f'samples/{s}/frame_{seed}_{i}.jpg', timestamp=t0 - int(g.integers(0, 50000)),
+                       sensor2lidar_rotation=_rand_rotation(g), sensor2lidar_translation=g.uniform(-2, 2, 3),
+                       cam_intrinsic=np.array([[f, 0, 800 + g.uniform(-30, 30)], [0, f, 450 + g.uniform(-30, 30)], [0, 0, 1]]))
+    sweeps = []
+    for k in range(n_sweeps):
+        sw = {}
+        for i, s in enumerate(NUSC_SENSORS):
+            if incomplete_sweep == k and i >= 4:
+                continue
+            sw[s] = dict(data_path=f'sweeps/{s}/sweep_{seed}_{k}_{i}.jpg', timestamp=t0 - (k + 1) * 83000 - int(g.integers(0, 20000)),
+                         lidar2img=g.normal(size=(4, 4)).astype(np.float32), intrinsics=g.normal(size=(4, 4)).astype(np.float32),
+                         extrinsics=g.normal(size=(4, 4)).astype(np.float32))
+        sweeps.append(sw)
+    return dict(token=f'token{seed}', lidar_path=f'samples/LIDAR_TOP/{seed}.bin', sweeps=sweeps, timestamp=t0, cams=cams)
+
+
+def make_view_images(n, h, w, seed):
+    g = _rng(seed + 31)
+    return [g.integers(0, 256, (h, w, 3)).astype(np.float32) for _ in range(n)]
+
+
+def fake_image(path, h=90, w=160):
+    """A seeded uint8 image per file name (stands for reading the file in the I/O tests)."""
+    import zlib
+    g = _rng(zlib.crc32(path.encode()) % (2 ** 31))
+    return g.integers(0, 256, (h, w, 3)).astype(np.uint8)
+
+
+NUSC_CASES = {
+    'test_two_frames': dict(seed=1, sweeps=dict(sweeps_num=1, to_float32=True, pad_empty_sweeps=True, sweep_range=[3, 27]),
+                            conf=NUSC_AUG_CONF_SMALL, training=False, n_sweeps=20),
+    'test_few_sweeps': dict(seed=2, sweeps=dict(sweeps_num=1, to_float32=True, pad_empty_sweeps=True, sweep_range=[3, 27]),
+                            conf=NUSC_AUG_CONF_SMALL, training=False, n_sweeps=1),
+    'test_no_sweeps_padded': dict(seed=3, sweeps=dict(sweeps_num=1, to_float32=True, pad_empty_sweeps=True, sweep_range=[3, 27]),
+                                  conf=NUSC_AUG_CONF_SMALL, training=False, n_sweeps=0),
+    'train_random_sweep': dict(seed=4, sweeps=dict(sweeps_num=1, to_float32=True, pad_empty_sweeps=True, test_mode=False, sweep_range=[3, 27]),
+                               conf=NUSC_AUG_CONF_SMALL, training=True, n_sweeps=30),
+    'train_incomplete_sweep': dict(seed=5, sweeps=dict(sweeps_num=2, to_float32=False, pad_empty_sweeps=True, test_mode=False,
+                                                       sweep_range=[3, 8]),
+                                   conf=NUSC_AUG_CONF_SMALL, training=True, n_sweeps=9, incomplete_sweep=5),
+}

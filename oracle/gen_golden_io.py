@@ -1,0 +1,119 @@
+"""Golden vectors of the nuScenes I/O contract from the UNMODIFIED reference (build container only).
+
+    python -B -m oracle.gen_golden_io        # writes tests/golden/nusc_io.npz
+
+Calls the reference's own ``CustomNuScenesDataset.get_data_info`` (test mode), ``LoadMultiViewImageFromMultiSweepsFiles.__call__`` and
+``ResizeCropFlipImageMono.__call__`` on seeded synthetic records (mv2d_amd/synthetic.make_nusc_info; the tests rebuild the inputs from the
+seeds, only outputs are stored).  The OpenMMLab / nuscenes-devkit / pyquaternion modules those files import at module level are absent here
+and replaced by empty placeholders (none of them is reached by the three methods); ``mmcv.imread`` is replaced by a function returning a
+seeded synthetic image (there are no image files).
+"""
+import copy
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from mv2d_amd import synthetic  # noqa: E402
+from oracle import _stubs  # noqa: E402
+from oracle._stubs import Registry, _mod  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden', 'nusc_io.npz')
+
+
+def fake_imread(path, *a, **k):
+    """Stands for mmcv.imread: a seeded image per path (the tests use the same function through synthetic.fake_image)."""
+    return synthetic.fake_image(path)
+
+
+def install():
+    _stubs.install('/root/reference')
+    ph = lambda n: type(n, (), {})  # noqa: E731
+    pipelines = Registry('pipeline')
+    _mod('mmcv', imread=fake_imread, load=None)
+    _mod('mmcv.parallel', DataContainer=ph('DataContainer'))
+    _mod('mmdet.datasets', DATASETS=Registry('dataset'), PIPELINES=pipelines)
+    _mod('mmdet.datasets.builder', PIPELINES=pipelines)
+    _mod('mmdet.datasets.pipelines', to_tensor=None)
+    _mod('mmdet.datasets.api_wrappers', COCO=ph('COCO'))
+    _mod('mmdet.core.visualization')
+    _mod('mmdet.core.visualization.image', imshow_det_bboxes=None, imshow_gt_det_bboxes=None)
+    _mod('mmdet3d.core')
+    _mod('mmdet3d.core.points', BasePoints=ph('BasePoints'), get_points_type=None)
+    _mod('mmdet3d.core.bbox', CameraInstance3DBoxes=ph('CameraInstance3DBoxes'), DepthInstance3DBoxes=ph('DepthInstance3DBoxes'),
+         LiDARInstance3DBoxes=ph('LiDARInstance3DBoxes'), box_np_ops=None, get_box_type=None, Box3DMode=None)
+    _mod('mmdet3d.core.visualizer', show_multi_modality_result=None)
+    _mod('mmdet3d.core.visualizer.image_vis', draw_lidar_bbox3d_on_img=None)
+    _mod('mmdet3d.datasets', NuScenesMonoDataset=ph('NuScenesMonoDataset'), NuScenesDataset=ph('NuScenesDataset'), PIPELINES=pipelines)
+    _mod('mmdet3d.datasets.pipelines')
+    _mod('mmdet3d.datasets.pipelines.transforms_3d', ObjectRangeFilter=ph('ObjectRangeFilter'), ObjectNameFilter=ph('ObjectNameFilter'))
+    _mod('mmdet3d.datasets.pipelines.loading', LoadAnnotations3D=ph('LoadAnnotations3D'))
+    _mod('mmdet3d.datasets.pipelines.formating', DefaultFormatBundle3D=ph('DefaultFormatBundle3D'), Collect3D=ph('Collect3D'))
+    _mod('pyquaternion')
+    _mod('nuscenes')
+    _mod('nuscenes.utils')
+    _mod('nuscenes.utils.data_classes', Box=ph('Box'))
+    _mod('nuscenes.eval')
+    _mod('nuscenes.eval.common')
+    _mod('nuscenes.eval.common.data_classes', EvalBoxes=ph('EvalBoxes'))
+    root = '/root/reference/mmdet3d_plugin'
+    _mod('mmdet3d_plugin.datasets').__path__ = [root + '/datasets']
+    _mod('mmdet3d_plugin.datasets.pipelines').__path__ = [root + '/datasets/pipelines']
+    from mmdet3d_plugin.datasets.custom_nuscenes_dataset import CustomNuScenesDataset
+    from mmdet3d_plugin.datasets.pipelines.loading import LoadMultiViewImageFromMultiSweepsFiles
+    from mmdet3d_plugin.datasets.pipelines.transform_3d import ResizeCropFlipImageMono
+    return CustomNuScenesDataset, LoadMultiViewImageFromMultiSweepsFiles, ResizeCropFlipImageMono
+
+
+def stack(lst):
+    return np.stack([np.asarray(x) for x in lst]) if len(lst) else np.zeros((0,))
+
+
+def main():
+    Dataset, Sweeps, Resize = install()
+    rec = {}
+    for name, kw in synthetic.NUSC_CASES.items():
+        info = synthetic.make_nusc_info(kw['seed'], n_sweeps=kw.get('n_sweeps', 6), incomplete_sweep=kw.get('incomplete_sweep'))
+        fake_self = types.SimpleNamespace(load_separate=False, data_infos=[copy.deepcopy(info)], test_mode=True)
+        d = Dataset.get_data_info(fake_self, 0)
+        for k in ('lidar2img', 'intrinsics', 'extrinsics'):
+            rec[f'{name}.info.{k}'] = stack(d[k])
+        rec[f'{name}.info.img_timestamp'] = np.array(d['img_timestamp'])
+        rec[f'{name}.info.timestamp'] = np.float64(d['timestamp'])
+        # what LoadMultiViewImageFromFiles leaves behind (mmdet3d, third party): the key-frame images and their file names
+        d['img'] = [fake_imread(p).astype(np.float32) for p in d['img_filename']]
+        d['filename'] = list(d['img_filename'])
+        np.random.seed(kw['seed'])
+        d = Sweeps(**kw['sweeps'])(d)
+        rec[f'{name}.sweeps.timestamp'] = np.array(d['timestamp'])
+        rec[f'{name}.sweeps.filename'] = np.array(d['filename'])
+        for k in ('lidar2img', 'intrinsics', 'extrinsics'):
+            rec[f'{name}.sweeps.{k}'] = stack([np.asarray(x, np.float64) for x in d[k]])
+        rec[f'{name}.sweeps.img_sum'] = np.array([float(np.asarray(im, np.float64).sum()) for im in d['img']])
+        np.random.seed(kw['seed'] + 1)
+        d = Resize(data_aug_conf=kw['conf'], training=kw['training'], with_bbox_2d=False)(d)
+        rec[f'{name}.aug.intrinsics'] = stack([np.asarray(x, np.float64) for x in d['intrinsics']])
+        rec[f'{name}.aug.lidar2img'] = stack([np.asarray(x, np.float64) for x in d['lidar2img']])
+        rec[f'{name}.aug.img_shape'] = np.array(d['img'][0].shape)
+        rec[f'{name}.aug.img_sum'] = np.array([float(im.astype(np.float64).sum()) for im in d['img']])
+        print(name, 'views', len(d['img']), 'img', d['img'][0].shape, 'ts', np.round(rec[f'{name}.sweeps.timestamp'][[0, -1]], 4))
+    # the augmentation matrix on the full-size config: _sample_augmentation + _img_transform only (one blank image)
+    from PIL import Image
+    for training in (False, True):
+        np.random.seed(77)
+        r = Resize(data_aug_conf=synthetic.NUSC_AUG_CONF, training=training)
+        args = r._sample_augmentation()
+        _, ida = r._img_transform(Image.fromarray(np.zeros((900, 1600, 3), np.uint8)), *args)
+        rec[f'fullsize.{int(training)}.ida'] = ida.numpy()
+        rec[f'fullsize.{int(training)}.args'] = np.array([args[0], *args[1], *args[2], float(args[3]), args[4]], np.float64)
+    np.savez_compressed(OUT, **rec)
+    print('wrote', OUT, os.path.getsize(OUT), 'bytes')
+
+
+if __name__ == '__main__':
+    main()

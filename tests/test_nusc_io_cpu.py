@@ -1,0 +1,105 @@
+"""nuScenes I/O contract: mv2d_amd.nuscenes_io vs goldens recorded from the reference's own dataset / pipeline classes
+(oracle/gen_golden_io.py -> tests/golden/nusc_io.npz).  Host code only, runs on CPU."""
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from mv2d_amd import nuscenes_io as nio
+from mv2d_amd import synthetic
+
+GOLD = load_golden('nusc_io')
+
+
+def _eq(a, b, name):
+    a = np.stack([np.asarray(x, np.float64) for x in a]) if len(a) else np.zeros((0,))
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    assert np.array_equal(a, b), (name, float(np.abs(a - b).max()))
+
+
+@pytest.mark.parametrize('name', list(synthetic.NUSC_CASES))
+def test_pipeline_geometry_matches_reference(name):
+    kw = synthetic.NUSC_CASES[name]
+    info = synthetic.make_nusc_info(kw['seed'], n_sweeps=kw.get('n_sweeps', 6), incomplete_sweep=kw.get('incomplete_sweep'))
+    d = nio.camera_geometry(copy.deepcopy(info))
+    for k in ('lidar2img', 'intrinsics', 'extrinsics'):
+        _eq(d[k], GOLD[f'{name}.info.{k}'], k)
+    assert np.array_equal(np.array(d['img_timestamp']), GOLD[f'{name}.info.img_timestamp'])
+    assert d['timestamp'] == float(GOLD[f'{name}.info.timestamp'])
+    d['img'] = [synthetic.fake_image(p).astype(np.float32) for p in d['img_filename']]
+    d['filename'] = list(d['img_filename'])
+    sw = dict(kw['sweeps'])
+    np.random.seed(kw['seed'])
+    d = nio.append_sweeps(d, imread=synthetic.fake_image, **sw)
+    assert np.array_equal(np.array(d['timestamp']), GOLD[f'{name}.sweeps.timestamp'])
+    assert list(d['filename']) == list(GOLD[f'{name}.sweeps.filename'])
+    for k in ('lidar2img', 'intrinsics', 'extrinsics'):
+        _eq(d[k], GOLD[f'{name}.sweeps.{k}'], 'sweeps.' + k)
+    assert np.array_equal(np.array([float(np.asarray(im, np.float64).sum()) for im in d['img']]), GOLD[f'{name}.sweeps.img_sum'])
+    np.random.seed(kw['seed'] + 1)
+    d = nio.resize_crop_flip(d, kw['conf'], training=kw['training'])
+    _eq(d['intrinsics'], GOLD[f'{name}.aug.intrinsics'], 'aug.intrinsics')
+    _eq(d['lidar2img'], GOLD[f'{name}.aug.lidar2img'], 'aug.lidar2img')
+    assert tuple(d['img'][0].shape) == tuple(GOLD[f'{name}.aug.img_shape'])
+    assert np.array_equal(np.array([float(im.astype(np.float64).sum()) for im in d['img']]), GOLD[f'{name}.aug.img_sum'])
+
+
+@pytest.mark.parametrize('training', [False, True])
+def test_full_size_augmentation_matrix(training):
+    np.random.seed(77)
+    args = nio.sample_augmentation(synthetic.NUSC_AUG_CONF, training)
+    want = GOLD[f'fullsize.{int(training)}.args']
+    assert np.array_equal(np.array([args[0], *args[1], *args[2], float(args[3]), args[4]], np.float64), want)
+    assert np.array_equal(nio.image_aug_matrix(args[0], args[2], args[3], args[4]), GOLD[f'fullsize.{int(training)}.ida'])
+    if not training:                      # the shipped test pipeline: 1600x900 -> resize 0.88 -> crop rows 280.. -> 1408x512
+        assert args[1] == (1408, 792) and args[2] == (0, 280, 1408, 792)
+
+
+def test_split_view_metas_and_geometry_only_path():
+    info = synthetic.make_nusc_info(8, n_sweeps=20)
+    d = nio.camera_geometry(info)
+    d['filename'] = list(d['img_filename'])
+    d = nio.append_sweeps(d, sweeps_num=1, pad_empty_sweeps=True)                  # no images: paths and geometry only
+    assert d['img'] == [] and len(d['lidar2img']) == 12 and len(d['timestamp']) == 12
+    K0 = [k.copy() for k in d['intrinsics']]
+    d = nio.resize_crop_flip(d, synthetic.NUSC_AUG_CONF, training=False, transform_images=False)
+    ida = nio.image_aug_matrix(0.88, (0, 280, 1408, 792), False, 0)
+    for k0, k1, e, l in zip(K0, d['intrinsics'], d['extrinsics'], d['lidar2img']):
+        assert np.array_equal(k1[:3, :3], ida @ k0[:3, :3]) and np.array_equal(l, k1 @ e.T)
+    metas = nio.split_view_metas(dict(lidar2img=d['lidar2img'], intrinsics=d['intrinsics'], extrinsics=d['extrinsics'],
+                                      timestamp=d['timestamp'], ori_shape=(900, 1600, 3, 12), pad_shape=(512, 1408, 3), box_type_3d='x'), 12)
+    assert len(metas) == 12 and metas[3]['num_views'] == 12 and metas[3]['ori_shape'] == (900, 1600, 3)
+    assert metas[7]['timestamp'] == d['timestamp'][7] and metas[7]['pad_shape'] == (512, 1408, 3) and metas[0]['box_type_3d'] == 'x'
+    assert np.array_equal(metas[11]['lidar2img'], d['lidar2img'][11])
+
+
+def test_sweep_camera_record_against_homogeneous_composition():
+    """add_frame (tools/generate_sweep_pkl.py:32-82) is a script (not importable): checked against composing 4x4 transforms directly,
+    sensor -> ego(sweep) -> global -> ego(key) -> lidar(key), and against the identity case."""
+    g = np.random.default_rng(5)
+
+    def quat():
+        q = g.normal(size=4)
+        return q / np.linalg.norm(q)
+
+    def hom(R, t):
+        m = np.eye(4)
+        m[:3, :3], m[:3, 3] = R, t
+        return m
+    qs, qe, qkl, qke = quat(), quat(), quat(), quat()
+    ts, te, tkl, tke = g.normal(size=3), g.normal(size=3) * 10, g.normal(size=3), g.normal(size=3) * 10
+    K = np.array([[1250., 0, 800], [0, 1250., 450], [0, 0, 1]])
+    Rkl, Rke = nio.quaternion_rotation_matrix(qkl), nio.quaternion_rotation_matrix(qke)
+    rec = nio.sweep_camera_record(qs, ts, qe, te, K, Rkl, tkl, Rke, tke)
+    s2l = np.linalg.inv(hom(Rkl, tkl)) @ np.linalg.inv(hom(Rke, tke)) @ hom(nio.quaternion_rotation_matrix(qe), te) @ \
+        hom(nio.quaternion_rotation_matrix(qs), ts)
+    assert np.allclose(rec['sensor2lidar_rotation'], s2l[:3, :3], atol=1e-12) and np.allclose(rec['sensor2lidar_translation'], s2l[:3, 3], atol=1e-9)
+    l2i = nio._viewpad(K) @ np.linalg.inv(s2l)
+    assert np.allclose(rec['lidar2img'], l2i.astype(np.float32), rtol=1e-5, atol=1e-3) and rec['lidar2img'].dtype == np.float32
+    assert np.allclose(rec['extrinsics'].T, np.linalg.inv(s2l), atol=1e-5)
+    R = nio.quaternion_rotation_matrix(qs)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(R) - 1) < 1e-12
+    assert np.allclose(nio.quaternion_rotation_matrix([1, 0, 0, 0]), np.eye(3))
+    assert np.allclose(nio.quaternion_rotation_matrix([np.cos(0.3), 0, 0, np.sin(0.3)])[:2, :2],
+                       [[np.cos(0.6), -np.sin(0.6)], [np.sin(0.6), np.cos(0.6)]])
