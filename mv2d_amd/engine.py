@@ -570,7 +570,10 @@ class HeadEngine:
                 o.gemm_f32(xq_in, W_[f'sa_in_w{i}'], W_[f'sa_in_b{i}'], A2=x_in, n_split=2 * C, out=ws['qkv'], M=R)
             sa_fused = self.fuse_rows and self.rows_x3 and self.sa_fused
             if not sa_fused:
-                o.self_attn(ws['qkv'], ws['ctx'], R, grp_start=ws['grp_start'] if ws['B'] > 1 else None)
+                if ws.get('dn'):
+                    o.self_attn_dn(ws['qkv'], ws['dn'][0], ws['dn'][1], out=ws['ctx'])      # training: denoising rows first (train_forward)
+                else:
+                    o.self_attn(ws['qkv'], ws['ctx'], R, grp_start=ws['grp_start'] if ws['B'] > 1 else None)
             if self.fuse_rows and self.rows_x3:
                 sa_tail = o.sa_block_fused_x3 if sa_fused else o.attn_out_fused_x3      # self-attention core inside the row kernel, or not
                 sa_tail(ws['qkv'] if sa_fused else ws['ctx'], x_in, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
@@ -610,7 +613,7 @@ class HeadEngine:
 
     def _enqueue_heads(self, ws, R, dt):
         # a14: every per-layer cls / reg branch + the reference-point tail in ONE launch (row-block fused)
-        dt_rows = ws['dt_rows'] if (self.kind == 'T' and ws['B'] > 1) else None
+        dt_rows = ws['dt_rows'] if (self.kind == 'T' and (ws['B'] > 1 or ws.get('dn'))) else None
         if self.heads_x3:
             ops.heads_fused_x3(ws['outs'], self.cls_ptrs_x3, self.reg_ptrs_x3, ws['ref'], ws['cls'], ws['reg'], R, self.L, self.pc_range_h, dt,
                                dt_rows=dt_rows)
@@ -663,7 +666,7 @@ class HeadEngine:
         if not use_graph:
             self._enqueue(ws, feat, R, V, h, w, sc)
             self._mark_done(ws)
-            return self._result(ws, R, keep_stages, batch)
+            return dict(self._result(ws, R, keep_stages, batch), dt=sc['dt'])
         # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
         gkey = (ptrs, sc['pad_h'], sc['pad_w'], sc['dt'], sc['max_per_view'], sc['max_rows'])
@@ -683,7 +686,55 @@ class HeadEngine:
             ws['graph'], ws['graph_key'], ws['graph_feat'] = g, gkey, feat
         g.replay()
         self._mark_done(ws)
-        return self._result(ws, R, keep_stages, batch)
+        return dict(self._result(ws, R, keep_stages, batch), dt=sc['dt'])
+
+    def train_forward(self, out, dn_ref=None, dn_single=0):
+        """Training forward of the decoder + heads on top of a finished ``run`` of ONE sample: the decoder runs again
+        over [denoising queries | the sample's queries] with the self-attention mask of ``prepare_for_dn`` evaluated in the kernel and the
+        denoising rows attending to every key some RoI can see (RH/mv2d_t_head.py:90-98: ``cross_attn_mask.all(dim=0)``;
+        RH/mv2d_s_head.py:158-171).  ``dn_ref`` [pad,3] normalised reference points of the denoising queries (``train.prepare_for_dn``),
+        ``dn_single`` rows per group.  Returns (all_cls [L,pad+R,10], all_reg [L,pad+R,10]); the denoising rows' velocities are not divided
+        by the frame time step (the reference splits them off before ``_bbox_forward`` does that, RH/mv2d_t_head.py:104-110,132-137).
+        Without ``dn_ref`` the inference outputs of all layers are returned (use_denoise=False).  Forward only; synchronises."""
+        ws, R = out['ws'], out['R']
+        L, d, o, W_ = self.L, self.dev, ops, self.w
+        if ws['B'] != 1:
+            raise ValueError('train_forward: one sample per run (the reference asserts the same, RH/mv2d_s_head.py:249)')
+        if self.raw_attn or (self.fuse_rows and self.rows_x3 and self.sa_fused):
+            raise NotImplementedError('train_forward: not available with MV2D_RAW_ATTN / MV2D_SA_FUSED')
+        row_ptr = ws['row_ptr'][:R + 1]
+        nnz = int(row_ptr[R].item())
+        if int(ws['nnz'][1].item()) != 0:
+            raise RuntimeError('mv2d engine: CSR capacity exceeded (raise col_cap_per_query)')
+        if self.kind == 'T' and bool((row_ptr[1:] == row_ptr[:-1]).any().item()):
+            # the reference un-masks position (view 0, 0, 0) for such a RoI in training (RH/mv2d_t_head.py:80-82)
+            raise NotImplementedError('train_forward: a RoI without a single visible key (training-time fallback key not built)')
+        if dn_ref is None or dn_ref.shape[0] == 0:
+            return ws['cls'][:, :R].clone(), ws['reg'][:, :R].clone()
+        pad = int(dn_ref.shape[0])
+        T = pad + R
+        col = ws['col_idx'][:nnz]
+        keys = torch.unique(col).to(torch.int32)               # every key at least one RoI can see (sorted)
+        nk = int(keys.numel())
+        e = lambda *shape: torch.empty(shape, device=d, dtype=F32)  # noqa: E731
+        posemb = o.posemb3d(dn_ref.to(F32).contiguous(), self.const['dim_t'])
+        if self.rows_x3:
+            q1 = o.linear_x3(posemb, W_['qe_w0x'], W_['qe_b0'], N=C, K=384, act=1)
+            qdn = o.linear_x3(q1, W_['qe_w2x'], W_['qe_b2'], N=C, K=C)
+        else:
+            q1 = o.gemm_f32(posemb, W_['qe_w0'], W_['qe_b0'], act=1, out=e(pad, C))
+            qdn = o.gemm_f32(q1, W_['qe_w2'], W_['qe_b2'], out=e(pad, C))
+        tws = dict(B=1, Vg=ws['Vg'], dn=(pad, max(int(dn_single), 1)), grp_start=None, KV=ws['KV'],
+                   row_ptr=torch.cat([torch.arange(pad, device=d, dtype=torch.int32) * nk, row_ptr + pad * nk]),
+                   col_idx=torch.cat([keys.repeat(pad), col]).contiguous(),
+                   ref=torch.cat([dn_ref.to(F32), ws['ref'][:R]]).contiguous(), qpos=torch.cat([qdn, ws['qpos'][:R]]).contiguous(),
+                   zero_rows=torch.zeros(T, C, device=d), qkv=e(T, 3 * C), parts=e(2048 // 64, T, C), outs=e(L, T, C), cls=e(L, T, 10),
+                   reg=e(L, T, 10), dt_rows=torch.cat([torch.zeros(pad, device=d), torch.full((R,), float(out.get('dt', 0.0)), device=d)]))
+        for n in ('x', 'xq', 'x1', 'x1q', 'x2', 'ctx', 'o', 'q'):
+            tws[n] = e(T, C)
+        self._enqueue_decoder(tws, T)
+        self._enqueue_heads(tws, T, float(out.get('dt', 0.0)))
+        return tws['cls'], tws['reg']
 
     @staticmethod
     def _mark_done(ws):

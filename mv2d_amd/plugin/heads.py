@@ -4,7 +4,7 @@
 ``simple_test(x, proposal_list, img_metas, rescale=False)`` keeps the reference signature and return value
 (``[[boxes, scores, labels]]``) and runs the fused HIP engine (mv2d_amd.engine.HeadEngine), which is built lazily
 from the module's own ``state_dict`` — so a checkpoint loaded with the reference key layout is what runs.
-Training entry points (forward_train, losses, denoising queries) are outside this tier's scope and raise.
+``forward_train`` keeps the reference signature too but is forward only so far (losses without parameter gradients).
 """
 import copy
 
@@ -209,8 +209,53 @@ class MV2DHead(nn.Module):
             res.append([boxes, scores.clone(), labels.clone()])
         return res
 
-    def forward_train(self, *a, **k):
-        raise NotImplementedError('training (denoising queries, Hungarian loss) is outside the hot-path scope (SURVEY.md §8 f3)')
+    def _head_loss(self, device):
+        from ..train import HeadLoss
+        if getattr(self, '_hl', None) is None or self._hl.device != device:
+            bh = self.bbox_head
+            lc = dict(type='FocalLoss', use_sigmoid=bh.loss_cls.use_sigmoid, **bh.loss_cls.cfg)
+            lb = dict(type='L1Loss', **bh.loss_bbox.cfg)
+            self._hl = HeadLoss(num_classes=bh.num_classes, loss_cls=lc, loss_bbox=lb, code_weights=[float(x) for x in bh.code_weights],
+                                train_cfg=self.train_cfg, device=device)
+        return self._hl
+
+    def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_3d, gt_labels_3d, ori_gt_bboxes_3d,
+                      ori_gt_labels_3d, attr_labels=None, gt_bboxes_ignore=None, gt_masks=None, dn_noise=None, **kwargs):
+        """The reference's signature (RH/mv2d_head.py:196-246, RH/mv2d_s_head.py:235-305); **forward only** — the losses are the
+        reference's (keys ``l{i}.loss_cls`` / ``l{i}.loss_bbox`` / ``l{i}.dn_loss_cls`` / ``l{i}.dn_loss_bbox``, times the stage weights) but
+        they carry no gradient to the head's parameters yet (no backward of the fused decoder kernels).
+        ``ori_gt_bboxes_3d[0]``: a LiDARInstance3DBoxes-like object (``gravity_center``, ``tensor``) or a [G,9] tensor of gravity-centre
+        boxes; ``dn_noise`` [G*denoise_scalar,3] in [0,1) replaces the on-device draw of the denoising noise."""
+        from .. import train
+        assert len(img_metas) // img_metas[0]['num_views'] == 1
+        feat = x[self.feat_lvl]
+        dev = feat.device
+        eng = self.engine(dev, img_metas)
+        out = eng.run(feat.float(), [p[:, :6] for p in proposal_list], img_metas)
+        g = ori_gt_bboxes_3d[0]
+        gt = g if torch.is_tensor(g) else torch.cat((g.gravity_center, g.tensor[:, 3:]), dim=1)
+        gt = gt.to(dev, torch.float32).contiguous()
+        labels = ori_gt_labels_3d[0].to(dev)
+        hl = self._head_loss(dev)
+        R = out['R']
+        losses = {}
+        if getattr(self, 'use_denoise', False):
+            ref = out['ws']['ref'][:R]
+            padded, _, md = train.prepare_for_dn(ref, gt, labels, self.denoise_scalar, self.denoise_noise_scale, self.denoise_noise_trans,
+                                                 self.denoise_split, self.num_classes, list(self.pc_range), rnd=dn_noise, dense_mask=False)
+            pad = md['pad_size']
+            all_cls, all_reg = eng.train_forward(out, padded[0, :pad], md['dn_single'])
+            if pad > 0:
+                known_labels, known_bboxs = md['known_lbs_bboxes']
+                dn, _ = hl.dn_loss(all_cls[:, :pad].contiguous(), all_reg[:, :pad].contiguous(), known_bboxs, known_labels, pad,
+                                   self.denoise_split, neg_bbox_loss=self.neg_bbox_loss, denoise_weight=self.denoise_weight)
+                losses.update(dn)
+            all_cls, all_reg = all_cls[:, pad:].contiguous(), all_reg[:, pad:].contiguous()
+        else:
+            all_cls, all_reg = eng.train_forward(out)
+        main, _, _ = hl.loss(all_cls, all_reg, gt, labels)
+        losses.update(main)
+        return losses
 
 
 @HEADS.register_module()

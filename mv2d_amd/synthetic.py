@@ -341,3 +341,23 @@ NUSC_CASES = {
                                                        sweep_range=[3, 8]),
                                    conf=NUSC_AUG_CONF_SMALL, training=True, n_sweeps=9, incomplete_sweep=5),
 }
+
+
+# forward_train cases: name -> (problem of make_problem, head kind, number of ground-truth boxes, seed)
+FWD_TRAIN_CASES = {'train_micro_t': ('micro_t', 'T', 5, 21), 'train_cfg1_t': ('cfg1_t', 'T', 9, 22), 'train_micro_s': ('micro_s', 'S', 4, 23),
+                   'train_cfg1_s': ('cfg1_s', 'S', 30, 24)}
+
+
+def make_train_gt(G, seed):
+    """Ground truth of a training sample: `gt_bottom` [G,9] bottom-centre boxes inside the point-cloud range, `gt` with the gravity
+    centre, labels."""
+    g = _rng(seed + 5000)
+    gt = np.zeros((G, 9), np.float32)
+    gt[:, 0:2] = g.uniform(-45, 45, (G, 2))
+    gt[:, 2] = g.uniform(-3, 0, G)
+    gt[:, 3:6] = g.uniform(0.5, 5.0, (G, 3))
+    gt[:, 6] = g.uniform(-np.pi, np.pi, G)
+    gt[:, 7:9] = g.uniform(-3, 3, (G, 2))
+    grav = gt.copy()
+    grav[:, 2] += gt[:, 5] * 0.5
+    return dict(gt_bottom=gt, gt=grav, gt_labels=g.integers(0, 10, G).astype(np.int64))

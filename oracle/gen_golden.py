@@ -26,10 +26,12 @@ from oracle import _stubs  # noqa: E402
 OUT = os.path.join(ROOT, 'tests', 'golden')
 
 
-def build_reference_head(kind, S_cls, T_cls, sd_np, num_views):
+def build_reference_head(kind, S_cls, T_cls, sd_np, num_views, train_cfg=None):
     cfg = configs.roi_head_cfg_s() if kind == 'S' else configs.roi_head_cfg_t()
     cfg.pop('type')
     cfg['test_cfg'] = configs.TEST_CFG_RCNN
+    if train_cfg is not None:
+        cfg['train_cfg'] = train_cfg
     if kind == 'T':
         cfg['num_views'] = num_views
     head = (S_cls if kind == 'S' else T_cls)(**cfg).eval()

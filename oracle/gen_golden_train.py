@@ -78,6 +78,52 @@ def main():
         rec[name + '.known_indice'] = md['known_indice'].numpy()
         rec[name + '.pad_size'] = np.int64(md['pad_size'])
         print(name, padded.shape, attn_mask.shape, 'negatives', int((md['known_lbs_bboxes'][0] == 10).sum()))
+    # --- forward_train of the whole head (forward only): the reference's losses on seeded problems.  Dropout is switched off (p = 0: the
+    # golden must not depend on torch's dropout stream); `.cuda()` / `torch.rand_like` patched as above.
+    import torch.nn as nn
+    for name, (prob_name, kind, G, seed) in synthetic.FWD_TRAIN_CASES.items():
+        prob = synthetic.make_problem(prob_name, seed=0)
+        h = build_reference_head(kind, S_cls, T_cls, synthetic.make_head_state(seed=0), prob['views_per_frame'], train_cfg=configs.TRAIN_CFG_RCNN)
+        cfgk = (configs.roi_head_cfg_s() if kind == 'S' else configs.roi_head_cfg_t())['bbox_head']
+        _stubs_train.arm_bbox_head(h.bbox_head, Assigner, configs.TRAIN_CFG_RCNN, cfgk['loss_cls'], cfgk['loss_bbox'])
+        h.train()
+        for m in h.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = 0.0
+            if isinstance(m, nn.MultiheadAttention):
+                m.dropout = 0.0                      # the attention-probability dropout (attn_drop) is a float attribute, not a module
+        gtc = synthetic.make_train_gt(G, seed)
+        gt = _stubs_train.GtBoxes(torch.from_numpy(gtc['gt_bottom']))
+        labels = torch.from_numpy(gtc['gt_labels'])
+        rnd = torch.from_numpy(synthetic.make_dn_noise(G * 10, seed))
+        metas = [dict(m, box_type_3d=(lambda b, d: b)) for m in prob['img_metas']]
+        props = [torch.from_numpy(p) for p in prob['proposals']]
+        captured = {}
+        orig = h._bbox_forward_train
+
+        def wrapped(*a, **k):
+            r = orig(*a, **k)
+            captured['res'] = r
+            return r
+        h._bbox_forward_train = wrapped
+        cuda, rand_like = torch.Tensor.cuda, torch.rand_like
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.rand_like = lambda t, *a, **k: rnd.to(t.dtype)
+        try:
+            with torch.no_grad():
+                losses = h.forward_train([torch.from_numpy(prob['feat'])], metas, props, None, None, None, None, [gt], [labels], None)
+        finally:
+            torch.Tensor.cuda, torch.rand_like = cuda, rand_like
+        for k, v in losses.items():
+            rec[f'{name}.loss.{k}'] = np.float32(float(v))
+        res = captured['res']
+        rec[f'{name}.cls'] = torch.stack(res['pred']['cls_scores']).numpy()
+        rec[f'{name}.reg'] = torch.stack(res['pred']['bbox_preds']).numpy()
+        md = res.get('dn_mask_dict')
+        if md:
+            rec[f'{name}.dn_cls'] = md['output_known_lbs_bboxes'][0][:, 0].numpy()
+            rec[f'{name}.dn_reg'] = md['output_known_lbs_bboxes'][1][:, 0].numpy()
+        print(name, {k: round(float(v), 5) for k, v in list(losses.items())[-4:]}, 'rows', rec[f'{name}.cls'].shape)
     np.savez_compressed(OUT, **rec)
     print('wrote', OUT, os.path.getsize(OUT), 'bytes')
 

@@ -167,3 +167,51 @@ def test_self_attn_with_denoising_mask(R, pad, single):
     assert float((out.cpu().double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
     if pad == 0:
         assert torch.equal(out, ops.self_attn(qkv))          # no denoising rows: the inference kernel's arithmetic
+
+
+@pytest.mark.parametrize('name', list(synthetic.FWD_TRAIN_CASES))
+def test_forward_train_losses_match_reference(name):
+    """The whole training forward (engine + denoising rows + assignment + losses) vs the reference's forward_train (dropout off)."""
+    from mv2d_amd import registry
+    import mv2d_amd.plugin  # noqa: F401
+    gold = load_golden('train_loss')
+    prob_name, kind, G, seed = synthetic.FWD_TRAIN_CASES[name]
+    prob = synthetic.make_problem(prob_name, seed=0)
+    cfg = configs.roi_head_cfg_s() if kind == 'S' else configs.roi_head_cfg_t()
+    if kind == 'T':
+        cfg['num_views'] = prob['views_per_frame']
+    head = registry.build_head(cfg, train_cfg=configs.TRAIN_CFG_RCNN, test_cfg=configs.TEST_CFG_RCNN)
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_head_state(seed=0).items()}, strict=False)
+    head = head.to(DEV)
+    gtc = synthetic.make_train_gt(G, seed)
+    rnd = torch.from_numpy(synthetic.make_dn_noise(G * 10, seed)).to(DEV)
+    feat = torch.from_numpy(prob['feat']).to(DEV)
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    metas = [dict(m, box_type_3d=None) for m in prob['img_metas']]
+    losses = head.forward_train([feat], metas, props, None, None, None, None, [torch.from_numpy(gtc['gt'])], [torch.from_numpy(gtc['gt_labels'])],
+                                None, dn_noise=rnd)
+    want = {k[len(name) + 6:]: float(v) for k, v in gold.items() if k.startswith(name + '.loss.')}
+    assert set(losses) == set(want), (sorted(losses), sorted(want))
+    for k, v in want.items():
+        assert abs(float(losses[k]) - v) <= 2e-3 * max(abs(v), 1e-2), (k, float(losses[k]), v)
+    # the rows behind the losses: [denoising queries | the sample's queries] of every layer vs the reference's training forward
+    from mv2d_amd import train
+    eng = head.engine(feat.device, metas)
+    out = eng.run(feat, [p[:, :6] for p in props], metas)
+    R, pad = out['R'], 0
+    if kind == 'T':
+        gt, labels = torch.from_numpy(gtc['gt']).to(DEV), torch.from_numpy(gtc['gt_labels']).to(DEV)
+        padded, _, md = train.prepare_for_dn(out['ws']['ref'][:R], gt, labels, head.denoise_scalar, head.denoise_noise_scale,
+                                             head.denoise_noise_trans, head.denoise_split, 10, list(head.pc_range), rnd=rnd, dense_mask=False)
+        pad = md['pad_size']
+        cls, reg = eng.train_forward(out, padded[0, :pad], md['dn_single'])
+        assert pad == 10 * G
+        for got, key in ((cls[:, :pad], '.dn_cls'), (reg[:, :pad], '.dn_reg')):
+            w = torch.from_numpy(gold[name + key])
+            assert float((got.cpu() - w).abs().max()) <= 2e-3 * float(w.abs().max()), key
+    else:
+        cls, reg = eng.train_forward(out)
+    for got, key in ((cls[:, pad:], '.cls'), (reg[:, pad:], '.reg')):
+        w = torch.from_numpy(gold[name + key])
+        assert float((got.cpu() - w).abs().max()) <= 2e-3 * float(w.abs().max()), key
+    assert torch.equal(cls[:, pad:], out['ws']['cls'][:, :R]) if pad == 0 else True
