@@ -460,13 +460,16 @@ def sparse_xattn_bwd(q, K, V, row_ptr, col_idx, ctx, dctx, R=None, transposed=No
 
 class SparseCrossAttention(torch.autograd.Function):
     """ctx = softmax over the allowed keys (q . K^T) . V per head; q [R,256] fp32 pre-scaled, K / V [S,256] bf16, CSR (row_ptr, col_idx).
-    Differentiable in q, K, V (dK / dV returned in bf16 like their inputs): the attention core of PETRMultiheadAttention for the
+    Differentiable in q, K, V (dK / dV returned in the dtype of their inputs; fp32 K / V are rounded to bf16 for the kernels): the attention core of PETRMultiheadAttention for the
     training path of the head.  transposed = csr_transpose(row_ptr, col_idx, S): the decoder layers share
     one CSR, so the caller builds it once for all of them (otherwise it is built in every backward)."""
 
     @staticmethod
     def forward(fctx, q, K, V, row_ptr, col_idx, empty_nan=False, transposed=None):
-        out = sparse_xattn(q.contiguous(), K.contiguous(), V.contiguous(), row_ptr, col_idx, R=q.shape[0], empty_nan=empty_nan)
+        # fp32 K / V are rounded to bf16 here (what the kernels read) and get fp32 gradients back
+        fctx.kv_dtypes = (K.dtype, V.dtype)
+        q, K, V = q.contiguous(), K.to(BF16).contiguous(), V.to(BF16).contiguous()
+        out = sparse_xattn(q, K, V, row_ptr, col_idx, R=q.shape[0], empty_nan=empty_nan)
         fctx.save_for_backward(q, K, V, row_ptr, col_idx, out)
         fctx.transposed = transposed
         return out
@@ -474,9 +477,8 @@ class SparseCrossAttention(torch.autograd.Function):
     @staticmethod
     def backward(fctx, dout):
         q, K, V, row_ptr, col_idx, out = fctx.saved_tensors
-        dq, dK, dV = sparse_xattn_bwd(q.contiguous(), K.contiguous(), V.contiguous(), row_ptr, col_idx, out, dout.float().contiguous(),
-                                      transposed=fctx.transposed)
-        return dq, dK.to(K.dtype), dV.to(V.dtype), None, None, None, None
+        dq, dK, dV = sparse_xattn_bwd(q, K, V, row_ptr, col_idx, out, dout.float().contiguous(), transposed=fctx.transposed)
+        return dq, dK.to(fctx.kv_dtypes[0]), dV.to(fctx.kv_dtypes[1]), None, None, None, None
 
 
 def box_params(rois, viewK, viewE, intr, ld_intr, minv, K_roi=None, roi_size=7.0, intr_scale=0.1, min_size=4.0):

@@ -209,6 +209,41 @@ class MV2DHead(nn.Module):
             res.append([boxes, scores.clone(), labels.clone()])
         return res
 
+    def _forward_train_autograd(self, eng, out, hl, gt, labels, dn_noise):
+        from .. import train
+        ws, R = out['ws'], out['R']
+        row_ptr = ws['row_ptr'][:R + 1]
+        nnz = int(row_ptr[R].item())
+        if self.KIND == 'T' and bool((row_ptr[1:] == row_ptr[:-1]).any().item()):
+            raise NotImplementedError('forward_train: a RoI without a single visible key (training-time fallback key not built)')
+        col = ws['col_idx'][:nnz]
+        if self.KIND == 'T':
+            S = int(ws['S_dev'].item())
+            key_in, val_in = ws['Xk'][:S], ws['Xf_b'][:S]
+        else:
+            key_in, val_in = ws['roi_sum'][:R].reshape(R * 49, C), ws['roi_feat'][:R].reshape(R * 49, C)
+        ref, pad, single, md = ws['ref'][:R], 0, 1, None
+        if getattr(self, 'use_denoise', False):
+            padded, _, md = train.prepare_for_dn(ref, gt, labels, self.denoise_scalar, self.denoise_noise_scale, self.denoise_noise_trans,
+                                                 self.denoise_split, self.num_classes, list(self.pc_range), rnd=dn_noise, dense_mask=False)
+            pad, single = md['pad_size'], max(md['dn_single'], 1)
+            ref = padded[0]
+            keys = torch.unique(col).to(torch.int32)
+            row_ptr = torch.cat([torch.arange(pad, device=col.device, dtype=torch.int32) * keys.numel(), row_ptr + pad * keys.numel()])
+            col = torch.cat([keys.repeat(pad), col])
+        if getattr(self, '_train_decoder', None) is None:
+            self._train_decoder = train.TrainDecoder(self)
+        all_cls, all_reg = self._train_decoder(ref, key_in.detach(), val_in.detach(), row_ptr, col, pad, single, float(out.get('dt', 0.0)))
+        losses = {}
+        if pad > 0:
+            known_labels, known_bboxs = md['known_lbs_bboxes']
+            dn, _ = hl.dn_loss(all_cls[:, :pad], all_reg[:, :pad], known_bboxs, known_labels, pad, self.denoise_split,
+                               neg_bbox_loss=self.neg_bbox_loss, denoise_weight=self.denoise_weight)
+            losses.update(dn)
+        main, _, _ = hl.loss(all_cls[:, pad:], all_reg[:, pad:], gt, labels)
+        losses.update(main)
+        return losses
+
     def _head_loss(self, device):
         from ..train import HeadLoss
         if getattr(self, '_hl', None) is None or self._hl.device != device:
@@ -220,10 +255,13 @@ class MV2DHead(nn.Module):
         return self._hl
 
     def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_3d, gt_labels_3d, ori_gt_bboxes_3d,
-                      ori_gt_labels_3d, attr_labels=None, gt_bboxes_ignore=None, gt_masks=None, dn_noise=None, **kwargs):
-        """The reference's signature (RH/mv2d_head.py:196-246, RH/mv2d_s_head.py:235-305); **forward only** — the losses are the
-        reference's (keys ``l{i}.loss_cls`` / ``l{i}.loss_bbox`` / ``l{i}.dn_loss_cls`` / ``l{i}.dn_loss_bbox``, times the stage weights) but
-        they carry no gradient to the head's parameters yet (no backward of the fused decoder kernels).
+                      ori_gt_labels_3d, attr_labels=None, gt_bboxes_ignore=None, gt_masks=None, dn_noise=None, autograd=None, **kwargs):
+        """The reference's signature (RH/mv2d_head.py:196-246, RH/mv2d_s_head.py:235-305) and loss dict (keys ``l{i}.loss_cls`` /
+        ``l{i}.loss_bbox`` / ``l{i}.dn_loss_cls`` / ``l{i}.dn_loss_bbox``, times the stage weights).  Two routes:
+        ``autograd=False`` — everything through the fused engine kernels, forward only; ``autograd=True`` (default when gradients are
+        enabled) — query generator / PE / key gathering through the engine (no gradient: they are treated as constants), decoder + heads
+        through ``train.TrainDecoder`` (torch autograd around the HIP attention forward / backward kernels) and the HIP loss kernel, so
+        ``sum(losses.values()).backward()`` fills the gradients of the decoder, the branches and ``query_embedding``.
         ``ori_gt_bboxes_3d[0]``: a LiDARInstance3DBoxes-like object (``gravity_center``, ``tensor``) or a [G,9] tensor of gravity-centre
         boxes; ``dn_noise`` [G*denoise_scalar,3] in [0,1) replaces the on-device draw of the denoising noise."""
         from .. import train
@@ -239,6 +277,10 @@ class MV2DHead(nn.Module):
         hl = self._head_loss(dev)
         R = out['R']
         losses = {}
+        if autograd is None:
+            autograd = torch.is_grad_enabled() and any(p.requires_grad for p in self.bbox_head.parameters())
+        if autograd:
+            return self._forward_train_autograd(eng, out, hl, gt, labels, dn_noise)
         if getattr(self, 'use_denoise', False):
             ref = out['ws']['ref'][:R]
             padded, _, md = train.prepare_for_dn(ref, gt, labels, self.denoise_scalar, self.denoise_noise_scale, self.denoise_noise_trans,

@@ -361,3 +361,9 @@ def make_train_gt(G, seed):
     grav = gt.copy()
     grav[:, 2] += gt[:, 5] * 0.5
     return dict(gt_bottom=gt, gt=grav, gt_labels=g.integers(0, 10, G).astype(np.int64))
+
+
+def grad_probe(name, n):
+    """A seeded probe vector per parameter name: gradient goldens store (norm, grad . probe) instead of the full gradient."""
+    import zlib
+    return _rng(zlib.crc32(name.encode()) % (2 ** 31)).normal(size=n).astype(np.float32)

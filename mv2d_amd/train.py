@@ -67,7 +67,9 @@ class HungarianAssigner3D:
 
 
 class SetPredictionLoss(torch.autograd.Function):
-    """total = sum_l layer_w[l] * (loss_cls[l] + loss_bbox[l]); also returns the unweighted per-layer losses [L,2] (no gradient)."""
+    """Returns the per-layer losses times the layer weights, [L,2] = (layer_w[l] * loss_cls[l], layer_w[l] * loss_bbox[l]) — the entries of
+    the reference's loss dict — differentiable in the logits (through the first column only) and the box codes (second column only):
+    forward and both gradients are one launch (``mv2d_set_loss``)."""
 
     @staticmethod
     def forward(ctx, cls, box, match, gt, gt_labels, code_w, layer_w, cls_avg, box_avg, alpha, gamma, w_cls, w_box, skip_bg):
@@ -75,13 +77,12 @@ class SetPredictionLoss(torch.autograd.Function):
         loss, dcls, dbox = ops.set_loss(cls.contiguous(), box.contiguous(), match, gt, gt_labels, code_w, layer_w, cls_avg, box_avg, alpha,
                                         gamma, w_cls, w_box, skip_bg, need_grad=need)
         ctx.save_for_backward(dcls, dbox)
-        ctx.mark_non_differentiable(loss)
-        return (loss.sum(1) * layer_w).sum(), loss
+        return loss * layer_w[:, None]
 
     @staticmethod
-    def backward(ctx, g_total, _g_loss):
-        dcls, dbox = ctx.saved_tensors
-        return (dcls * g_total, dbox * g_total) + (None,) * 12
+    def backward(ctx, g):
+        dcls, dbox = ctx.saved_tensors                      # gradients of layer_w[l] * loss_cls[l] / layer_w[l] * loss_bbox[l]
+        return (dcls * g[:, 0, None, None], dbox * g[:, 1, None, None]) + (None,) * 12
 
 
 class HeadLoss:
@@ -114,7 +115,8 @@ class HeadLoss:
     def loss(self, all_cls_scores, all_bbox_preds, gt_bboxes, gt_labels, match=None):
         """all_cls_scores [L,R,C], all_bbox_preds [L,R,10] (one sample), gt_bboxes [G,9] gravity-centre boxes, gt_labels [G].
         Returns (losses, total): the reference's dict keys ``l{i}.loss_cls`` / ``l{i}.loss_bbox`` (already times the stage weight,
-        mv2d_s_head.py:299-302) as a [L,2] tensor view, and the differentiable total."""
+        mv2d_s_head.py:299-302), every entry differentiable (``sum(losses.values()).backward()`` as mmdet's ``_parse_losses`` does), their sum,
+        and the assignment."""
         L, R = all_cls_scores.shape[:2]
         gt_bboxes = gt_bboxes.to(self.device, torch.float32).contiguous()
         labels32 = gt_labels.to(self.device, torch.int32).contiguous()
@@ -124,9 +126,9 @@ class HeadLoss:
         cls_avg = max(num_pos * 1.0, 1.0)                                # bg_cls_weight = 0, sync_cls_avg_factor False
         box_avg = max(_reduce_mean(num_pos), 1.0)                        # reduce_mean(num_total_pos).clamp(min=1), :419-420
         lw = self._layer_w(L)
-        total, per_layer = SetPredictionLoss.apply(all_cls_scores, all_bbox_preds, match, gt_bboxes, labels32, self.code_weights, lw,
-                                                   cls_avg, box_avg, self.alpha, self.gamma, self.w_cls, self.w_box, False)
-        weighted = per_layer * lw[:, None]
+        weighted = SetPredictionLoss.apply(all_cls_scores, all_bbox_preds, match, gt_bboxes, labels32, self.code_weights, lw,
+                                           cls_avg, box_avg, self.alpha, self.gamma, self.w_cls, self.w_box, False)
+        total = weighted.sum()
         losses = {}
         for l in range(L):
             losses[f'l{l}.loss_cls'] = weighted[l, 0]
@@ -142,11 +144,11 @@ class HeadLoss:
         box_avg = max(_reduce_mean(num_tgt), 1.0)
         lw = self._layer_w(L, denoise_weight)
         match = torch.arange(N, dtype=torch.int32, device=self.device).repeat(L, 1)
-        total, per_layer = SetPredictionLoss.apply(output_known_class, output_known_coord, match,
-                                                   known_bboxs.to(self.device, torch.float32).contiguous(),
-                                                   known_labels.to(self.device, torch.int32).contiguous(), self.dn_code_weights, lw,
-                                                   cls_avg, box_avg, self.alpha, self.gamma, self.w_cls, self.w_box, not neg_bbox_loss)
-        weighted = per_layer * lw[:, None]
+        weighted = SetPredictionLoss.apply(output_known_class, output_known_coord, match,
+                                           known_bboxs.to(self.device, torch.float32).contiguous(),
+                                           known_labels.to(self.device, torch.int32).contiguous(), self.dn_code_weights, lw,
+                                           cls_avg, box_avg, self.alpha, self.gamma, self.w_cls, self.w_box, not neg_bbox_loss)
+        total = weighted.sum()
         losses = {}
         for l in range(L):
             losses[f'l{l}.dn_loss_cls'] = weighted[l, 0]
@@ -191,3 +193,88 @@ def prepare_for_dn(reference_points, gt_bboxes, gt_labels, denoise_scalar=10, de
         'dn_single': G,
     }
     return padded, attn_mask, mask_dict
+
+
+class TrainDecoder:
+    """Differentiable decoder + prediction heads of ``CrossAttentionBoxHead`` for training: the dense linears, layer
+    norms and the FFN go through torch (rocBLAS GEMMs, torch autograd), **both attentions through the HIP sparse-attention kernels**
+    (``ops.SparseCrossAttention``: forward ``mv2d_sparse_xattn_fwd``, backward ``mv2d_sparse_xattn_bwd``) — the self attention as a CSR
+    with the denoising mask of ``prepare_for_dn`` as its pattern.  Parameters are read from the head module itself (the reference's
+    state-dict names), so their ``.grad`` is what an optimizer / DDP sees.  K / V are rounded to bf16 for the attention kernels (as in
+    the inference engine); everything else is fp32.
+
+    Mirrors PETRTransformerDecoder (6 post-norm layers: self_attn, norm, cross_attn, norm, ffn, norm; shared post_norm on every
+    intermediate; mmdet3d_plugin/models/utils/petr_transformer.py) and the branches of cross_attention_head.py:200-242."""
+
+    def __init__(self, roi_head, num_heads=8):
+        self.p = dict(roi_head.named_parameters())
+        bh = roi_head.bbox_head
+        self.L, self.pc_range, self.H = bh.num_pred, [float(x) for x in roi_head.pc_range], num_heads
+
+    @staticmethod
+    def self_attention_pattern(T, pad, single, device):
+        """CSR of prepare_for_dn's attn_mask: key j visible to query i iff j >= pad, or i < pad and i // single == j // single."""
+        i = torch.arange(T, device=device)
+        grp = i // max(single, 1)
+        vis = (i[None, :] >= pad) | ((i[:, None] < pad) & (grp[:, None] == grp[None, :]))
+        row_ptr = torch.zeros(T + 1, dtype=torch.int32, device=device)
+        row_ptr[1:] = vis.sum(1).cumsum(0).to(torch.int32)
+        return row_ptr, vis.nonzero()[:, 1].to(torch.int32).contiguous()
+
+    def _attn(self, q_in, k_in, v_in, name, csr, tr):
+        import torch.nn.functional as F
+        w, b = self.p[name + '.attn.in_proj_weight'], self.p[name + '.attn.in_proj_bias']
+        Cc = q_in.shape[-1]
+        q = F.linear(q_in, w[:Cc], b[:Cc]) * (1.0 / (Cc // self.H) ** 0.5)
+        k = F.linear(k_in, w[Cc:2 * Cc], b[Cc:2 * Cc])
+        v = F.linear(v_in, w[2 * Cc:], b[2 * Cc:])
+        ctx = ops.SparseCrossAttention.apply(q, k, v, csr[0], csr[1], False, tr)
+        return F.linear(ctx, self.p[name + '.attn.out_proj.weight'], self.p[name + '.attn.out_proj.bias'])
+
+    def __call__(self, ref, key_in, val_in, row_ptr, col_idx, pad=0, single=1, dt=0.0):
+        """ref [T,3] normalised reference points (denoising rows first), key_in / val_in [S,256] (memory + key_pos, memory), CSR of the
+        cross attention over the T rows.  Returns (all_cls [L,T,C], all_reg [L,T,10]); rows >= pad get v / dt when dt != 0."""
+        import torch.nn.functional as F
+        P, T, dev = self.p, ref.shape[0], ref.device
+        pre = 'bbox_head.transformer.decoder.'
+        ref = ref.detach().to(torch.float32).contiguous()
+        dim_t = torch.arange(128, dtype=torch.float32)
+        dim_t = (10000 ** (2 * (dim_t // 2) / 128)).to(dev)                              # MU/pe.py:24-25, as mv2d_amd.calib builds it
+        posemb = ops.posemb3d(ref, dim_t.contiguous())
+        qpos = F.linear(F.relu(F.linear(posemb, P['bbox_head.query_embedding.0.weight'], P['bbox_head.query_embedding.0.bias'])),
+                        P['bbox_head.query_embedding.2.weight'], P['bbox_head.query_embedding.2.bias'])
+        key_in, val_in = key_in.float(), val_in.float()
+        S = key_in.shape[0]
+        sa = self.self_attention_pattern(T, pad, single, dev)
+        sa_t = ops.csr_transpose(sa[0], sa[1], T)
+        ca = (row_ptr.contiguous(), col_idx.contiguous())
+        ca_t = ops.csr_transpose(ca[0], ca[1], S)
+        x = torch.zeros(T, qpos.shape[1], device=dev)
+        outs = []
+        ln = lambda t, n: F.layer_norm(t, (t.shape[-1],), P[n + '.weight'], P[n + '.bias'])  # noqa: E731
+        for i in range(self.L):
+            lp = f'{pre}layers.{i}.'
+            x = ln(x + self._attn(x + qpos, x + qpos, x, lp + 'attentions.0', sa, sa_t), lp + 'norms.0')
+            x = ln(x + self._attn(x + qpos, key_in, val_in, lp + 'attentions.1', ca, ca_t), lp + 'norms.1')
+            h = F.relu(F.linear(x, P[lp + 'ffns.0.layers.0.0.weight'], P[lp + 'ffns.0.layers.0.0.bias']))
+            x = ln(x + F.linear(h, P[lp + 'ffns.0.layers.1.weight'], P[lp + 'ffns.0.layers.1.bias']), lp + 'norms.2')
+            outs.append(ln(x, pre + 'post_norm'))
+        r = ref.clamp(0, 1)
+        inv = torch.log(r.clamp(min=1e-5) / (1 - r).clamp(min=1e-5))                 # inverse_sigmoid, mmdet
+        lo, hi = self.pc_range[:3], self.pc_range[3:]
+        all_cls, all_reg = [], []
+        for l in range(self.L):
+            c, g = f'bbox_head.cls_branches.{l}.', f'bbox_head.reg_branches.{l}.'
+            y = F.relu(ln(F.linear(outs[l], P[c + '0.weight'], P[c + '0.bias']), c + '1'))
+            y = F.relu(ln(F.linear(y, P[c + '3.weight'], P[c + '3.bias']), c + '4'))
+            all_cls.append(F.linear(y, P[c + '6.weight'], P[c + '6.bias']))
+            t = F.relu(F.linear(outs[l], P[g + '0.weight'], P[g + '0.bias']))
+            t = F.linear(F.relu(F.linear(t, P[g + '2.weight'], P[g + '2.bias'])), P[g + '4.weight'], P[g + '4.bias'])
+            cx = (t[:, 0:1] + inv[:, 0:1]).sigmoid() * (hi[0] - lo[0]) + lo[0]
+            cy = (t[:, 1:2] + inv[:, 1:2]).sigmoid() * (hi[1] - lo[1]) + lo[1]
+            cz = (t[:, 4:5] + inv[:, 2:3]).sigmoid() * (hi[2] - lo[2]) + lo[2]
+            vel = t[:, 8:10]
+            if dt:
+                vel = torch.cat([vel[:pad], vel[pad:] / dt])
+            all_reg.append(torch.cat([cx, cy, t[:, 2:4], cz, t[:, 5:8], vel], 1))
+        return torch.stack(all_cls), torch.stack(all_reg)

@@ -116,13 +116,37 @@ def main():
             torch.Tensor.cuda, torch.rand_like = cuda, rand_like
         for k, v in losses.items():
             rec[f'{name}.loss.{k}'] = np.float32(float(v))
+        # the same forward with autograd: gradients of sum(losses) w.r.t. the decoder / branches / query_embedding parameters, stored as
+        # (L2 norm, projection on a seeded probe vector) per parameter
+        for q in h.parameters():
+            q.grad = None
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.rand_like = lambda t, *a, **k: rnd.to(t.dtype)
+        try:
+            losses_g = h.forward_train([torch.from_numpy(prob['feat'])], metas, props, None, None, None, None, [gt], [labels], None)
+        finally:
+            torch.Tensor.cuda, torch.rand_like = cuda, rand_like
+        sum(losses_g.values()).backward()
+        names, norms, projs = [], [], []
+        for pn, q in h.named_parameters():
+            if pn.startswith('bbox_head.') and q.grad is not None:
+                names.append(pn)
+                norms.append(float(q.grad.double().norm()))
+                projs.append(float((q.grad.double().flatten() * torch.from_numpy(synthetic.grad_probe(pn, q.numel())).double()).sum()))
+        rec[f'{name}.grad_names'] = np.array(names)
+        rec[f'{name}.grad_norm'] = np.array(norms)
+        rec[f'{name}.grad_proj'] = np.array(projs)
+        print('   grads:', len(names), 'params, max norm', max(norms))
         res = captured['res']
-        rec[f'{name}.cls'] = torch.stack(res['pred']['cls_scores']).numpy()
-        rec[f'{name}.reg'] = torch.stack(res['pred']['bbox_preds']).numpy()
+        rec[f'{name}.cls'] = torch.stack(res['pred']['cls_scores']).detach().numpy()
+        rec[f'{name}.reg'] = torch.stack(res['pred']['bbox_preds']).detach().numpy()
+        gtc9 = torch.cat((gt.gravity_center, gt.tensor[:, 3:]), 1)
+        rec[f'{name}.match'] = np.stack([(h.bbox_head.assigner.assign(b.detach(), c.detach(), gtc9, labels).gt_inds - 1).numpy()
+                                         for c, b in zip(res['pred']['cls_scores'], res['pred']['bbox_preds'])]).astype(np.int32)
         md = res.get('dn_mask_dict')
         if md:
-            rec[f'{name}.dn_cls'] = md['output_known_lbs_bboxes'][0][:, 0].numpy()
-            rec[f'{name}.dn_reg'] = md['output_known_lbs_bboxes'][1][:, 0].numpy()
+            rec[f'{name}.dn_cls'] = md['output_known_lbs_bboxes'][0][:, 0].detach().numpy()
+            rec[f'{name}.dn_reg'] = md['output_known_lbs_bboxes'][1][:, 0].detach().numpy()
         print(name, {k: round(float(v), 5) for k, v in list(losses.items())[-4:]}, 'rows', rec[f'{name}.cls'].shape)
     np.savez_compressed(OUT, **rec)
     print('wrote', OUT, os.path.getsize(OUT), 'bytes')
