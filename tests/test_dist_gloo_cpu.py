@@ -90,3 +90,29 @@ def test_csr_transpose_groups_pairs_by_key():
     assert pair_row.tolist() == [0, 0, 0, 2, 2, 3, 3, 3, 3]
     assert key_ptr.tolist() == [0, 1, 4, 6, 7, 9, 9]
     assert pair_idx.tolist() == [4, 1, 3, 7, 2, 5, 8, 0, 6]
+
+
+def _reduce_mean_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from mv2d_amd import train
+    q.put((rank, train._reduce_mean(10.0 if rank == 0 else 40.0)))
+    dist.destroy_process_group()
+
+
+def test_reduce_mean_of_positives_world2():
+    """The loss's averaging factor is the mean number of positives over the ranks (mmdet reduce_mean, cross_attention_head.py:419-420)."""
+    import torch.multiprocessing as mp
+    from mv2d_amd import train
+    assert train._reduce_mean(7) == 7.0                      # no process group: the local value
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_reduce_mean_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(timeout=60)
+    assert got == {0: 25.0, 1: 25.0}
