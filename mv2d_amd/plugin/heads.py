@@ -222,18 +222,17 @@ class MV2DHead(nn.Module):
             key_in, val_in = ws['Xk'][:S], ws['Xf_b'][:S]
         else:
             key_in, val_in = ws['roi_sum'][:R].reshape(R * 49, C), ws['roi_feat'][:R].reshape(R * 49, C)
-        ref, pad, single, md = ws['ref'][:R], 0, 1, None
+        ref, pad, single, md, keys = ws['ref'][:R], 0, 1, None, None
         if getattr(self, 'use_denoise', False):
             padded, _, md = train.prepare_for_dn(ref, gt, labels, self.denoise_scalar, self.denoise_noise_scale, self.denoise_noise_trans,
                                                  self.denoise_split, self.num_classes, list(self.pc_range), rnd=dn_noise, dense_mask=False)
             pad, single = md['pad_size'], max(md['dn_single'], 1)
             ref = padded[0]
-            keys = torch.unique(col).to(torch.int32)
-            row_ptr = torch.cat([torch.arange(pad, device=col.device, dtype=torch.int32) * keys.numel(), row_ptr + pad * keys.numel()])
-            col = torch.cat([keys.repeat(pad), col])
+            keys = torch.unique(col)                   # the denoising rows see every key some RoI can see: a dense block
         if getattr(self, '_train_decoder', None) is None:
             self._train_decoder = train.TrainDecoder(self)
-        all_cls, all_reg = self._train_decoder(ref, key_in.detach(), val_in.detach(), row_ptr, col, pad, single, float(out.get('dt', 0.0)))
+        all_cls, all_reg = self._train_decoder(ref, key_in.detach(), val_in.detach(), row_ptr, col, pad, single, float(out.get('dt', 0.0)),
+                                               dn_keys=keys if pad > 0 else None)
         losses = {}
         if pad > 0:
             known_labels, known_bboxs = md['known_lbs_bboxes']

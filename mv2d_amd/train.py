@@ -221,19 +221,31 @@ class TrainDecoder:
         row_ptr[1:] = vis.sum(1).cumsum(0).to(torch.int32)
         return row_ptr, vis.nonzero()[:, 1].to(torch.int32).contiguous()
 
-    def _attn(self, q_in, k_in, v_in, name, csr, tr):
+    def _attn(self, q_in, k_in, v_in, name, csr, tr, dense=None):
+        """dense = (n, keys): the first n query rows see exactly the key rows `keys` (the denoising rows of the cross attention) — a dense
+        block, computed with batched GEMMs instead of n rows of len(keys) pairs each in the sparse kernels; csr then covers rows n.."""
         import torch.nn.functional as F
         w, b = self.p[name + '.attn.in_proj_weight'], self.p[name + '.attn.in_proj_bias']
         Cc = q_in.shape[-1]
         q = F.linear(q_in, w[:Cc], b[:Cc]) * (1.0 / (Cc // self.H) ** 0.5)
         k = F.linear(k_in, w[Cc:2 * Cc], b[Cc:2 * Cc])
         v = F.linear(v_in, w[2 * Cc:], b[2 * Cc:])
-        ctx = ops.SparseCrossAttention.apply(q, k, v, csr[0], csr[1], False, tr)
+        if dense is not None and dense[0] > 0:
+            n, keys = dense
+            H, d = self.H, Cc // self.H
+            qh = q[:n].view(n, H, d).transpose(0, 1)
+            kh = k[keys].view(-1, H, d).transpose(0, 1)
+            vh = v[keys].view(-1, H, d).transpose(0, 1)
+            top = (torch.softmax(qh @ kh.transpose(1, 2), -1) @ vh).transpose(0, 1).reshape(n, Cc)
+            ctx = torch.cat([top, ops.SparseCrossAttention.apply(q[n:], k, v, csr[0], csr[1], False, tr)])
+        else:
+            ctx = ops.SparseCrossAttention.apply(q, k, v, csr[0], csr[1], False, tr)
         return F.linear(ctx, self.p[name + '.attn.out_proj.weight'], self.p[name + '.attn.out_proj.bias'])
 
-    def __call__(self, ref, key_in, val_in, row_ptr, col_idx, pad=0, single=1, dt=0.0):
+    def __call__(self, ref, key_in, val_in, row_ptr, col_idx, pad=0, single=1, dt=0.0, dn_keys=None):
         """ref [T,3] normalised reference points (denoising rows first), key_in / val_in [S,256] (memory + key_pos, memory), CSR of the
-        cross attention over the T rows.  Returns (all_cls [L,T,C], all_reg [L,T,10]); rows >= pad get v / dt when dt != 0."""
+        cross attention over the T rows — or, with ``dn_keys`` (sorted key rows every denoising query sees), over the T - pad matched
+        rows only.  Returns (all_cls [L,T,C], all_reg [L,T,10]); rows >= pad get v / dt when dt != 0."""
         import torch.nn.functional as F
         P, T, dev = self.p, ref.shape[0], ref.device
         pre = 'bbox_head.transformer.decoder.'
@@ -255,7 +267,8 @@ class TrainDecoder:
         for i in range(self.L):
             lp = f'{pre}layers.{i}.'
             x = ln(x + self._attn(x + qpos, x + qpos, x, lp + 'attentions.0', sa, sa_t), lp + 'norms.0')
-            x = ln(x + self._attn(x + qpos, key_in, val_in, lp + 'attentions.1', ca, ca_t), lp + 'norms.1')
+            x = ln(x + self._attn(x + qpos, key_in, val_in, lp + 'attentions.1', ca, ca_t, None if dn_keys is None else (pad, dn_keys.long())),
+                   lp + 'norms.1')
             h = F.relu(F.linear(x, P[lp + 'ffns.0.layers.0.0.weight'], P[lp + 'ffns.0.layers.0.0.bias']))
             x = ln(x + F.linear(h, P[lp + 'ffns.0.layers.1.weight'], P[lp + 'ffns.0.layers.1.bias']), lp + 'norms.2')
             outs.append(ln(x, pre + 'post_norm'))
