@@ -291,3 +291,39 @@ class TrainDecoder:
                 vel = torch.cat([vel[:pad], vel[pad:] / dt])
             all_reg.append(torch.cat([cx, cy, t[:, 2:4], cz, t[:, 5:8], vel], 1))
         return torch.stack(all_cls), torch.stack(all_reg)
+
+
+def allreduce_gradients(parameters, bucket_bytes=256 << 20, average=True, group=None):
+    """Data-parallel gradient synchronisation of a training step ("DDP all-reduce over RCCL"): the gradients are packed
+    into flat fp32 buckets and each bucket is ONE all-reduce (backend ``nccl`` = RCCL on ROCm).  The whole head has 5.6 M parameters =
+    22 MB, so with the default bucket size a step is a single collective — xGMI rings are per-link latency-bound for small messages, one
+    large message beats the reference's DDP default of 25 MB buckets per ~100 tensors.  Parameters without a gradient on some rank (e.g.
+    no denoising rows on a sample without ground truth) take part with zeros, so that every rank issues the same collectives.
+    Returns the number of all-reduces issued; a no-op (0) without an initialised process group or with one rank."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    params = [p for p in parameters if p.requires_grad]
+    world = dist.get_world_size(group)
+    calls, i = 0, 0
+    while i < len(params):
+        bucket, size = [], 0
+        while i < len(params) and (not bucket or size + params[i].numel() * 4 <= bucket_bytes):
+            bucket.append(params[i])
+            size += params[i].numel() * 4
+            i += 1
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in bucket])
+        dist.all_reduce(flat, group=group)
+        if average:
+            flat /= world
+        off = 0
+        for p in bucket:
+            n = p.numel()
+            g = flat[off:off + n].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+        calls += 1
+    return calls

@@ -116,3 +116,47 @@ def test_reduce_mean_of_positives_world2():
     for p in ps:
         p.join(timeout=60)
     assert got == {0: 25.0, 1: 25.0}
+
+
+def _allreduce_grads_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from mv2d_amd import train
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 2))
+    x = torch.full((3, 8), float(rank + 1))
+    net[:3](x).sum().backward()                     # the last layer has no gradient on any rank ...
+    if rank == 1:
+        net[3].weight.grad = torch.ones_like(net[3].weight)      # ... except its weight on rank 1
+    local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+    one = train.allreduce_gradients(net.parameters())
+    got = [p.grad.clone() for p in net.parameters()]
+    for p, g in zip(net.parameters(), local):
+        p.grad = None if g is None else g.clone()
+    many = train.allreduce_gradients(net.parameters(), bucket_bytes=64)
+    same = all(torch.equal(a, p.grad) for a, p in zip(got, net.parameters()))
+    q.put((rank, one, many, same, [g.tolist() for g in got], [None if g is None else g.tolist() for g in local]))
+    dist.destroy_process_group()
+
+
+def test_allreduce_gradients_world2():
+    """One flat all-reduce per bucket; result = mean over the ranks, missing gradients count as zeros, bucket size does not change it."""
+    import torch.multiprocessing as mp
+    from mv2d_amd import train
+    assert train.allreduce_gradients(torch.nn.Linear(2, 2).parameters()) == 0          # no process group: no-op
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_allreduce_grads_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = {r[0]: r for r in (q.get(timeout=120) for _ in range(2))}
+    for p in ps:
+        p.join(timeout=60)
+    assert res[0][1] == res[1][1] == 1 and res[0][2] == res[1][2] > 1 and res[0][3] and res[1][3]
+    assert res[0][4] == res[1][4]                                                    # both ranks hold the same gradients
+    for k, (a, b) in enumerate(zip(res[0][5], res[1][5])):
+        za = torch.zeros_like(torch.tensor(res[0][4][k])) if a is None else torch.tensor(a)
+        zb = torch.zeros_like(torch.tensor(res[0][4][k])) if b is None else torch.tensor(b)
+        assert torch.allclose(torch.tensor(res[0][4][k]), (za + zb) / 2)
