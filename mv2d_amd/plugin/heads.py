@@ -218,20 +218,24 @@ class MV2DHead(nn.Module):
             raise NotImplementedError('forward_train: a RoI without a single visible key (training-time fallback key not built)')
         col = ws['col_idx'][:nnz]
         if self.KIND == 'T':
+            # keys / values with the gradient of the PE block: recomputed from the inputs the engine prepared
             S = int(ws['S_dev'].item())
-            key_in, val_in = ws['Xk'][:S], ws['Xf_b'][:S]
+            key_in, val_in = train.key_embedding_autograd(self, ws['A1'][:S], ws['A2'][:S], ws['Xf_b'][:S])
         else:
-            key_in, val_in = ws['roi_sum'][:R].reshape(R * 49, C), ws['roi_feat'][:R].reshape(R * 49, C)
-        ref, pad, single, md, keys = ws['ref'][:R], 0, 1, None, None
+            # S path: the PE half went through RoIAlign (no backward yet): constants
+            key_in, val_in = ws['roi_sum'][:R].reshape(R * 49, C).detach(), ws['roi_feat'][:R].reshape(R * 49, C).detach()
+        # reference points with the gradient of the query generator
+        ref = train.query_generator_autograd(self, ws['roi_feat'][:R], ws['enc'][:R, 1024:1040], ws['minv'][:R])
+        ref_const, pad, single, md, keys = ws['ref'][:R], 0, 1, None, None
         if getattr(self, 'use_denoise', False):
-            padded, _, md = train.prepare_for_dn(ref, gt, labels, self.denoise_scalar, self.denoise_noise_scale, self.denoise_noise_trans,
+            padded, _, md = train.prepare_for_dn(ref_const, gt, labels, self.denoise_scalar, self.denoise_noise_scale, self.denoise_noise_trans,
                                                  self.denoise_split, self.num_classes, list(self.pc_range), rnd=dn_noise, dense_mask=False)
             pad, single = md['pad_size'], max(md['dn_single'], 1)
-            ref = padded[0]
+            ref = torch.cat([padded[0, :pad], ref])
             keys = torch.unique(col)                   # the denoising rows see every key some RoI can see: a dense block
         if getattr(self, '_train_decoder', None) is None:
             self._train_decoder = train.TrainDecoder(self)
-        all_cls, all_reg = self._train_decoder(ref, key_in.detach(), val_in.detach(), row_ptr, col, pad, single, float(out.get('dt', 0.0)),
+        all_cls, all_reg = self._train_decoder(ref, key_in, val_in, row_ptr, col, pad, single, float(out.get('dt', 0.0)),
                                                dn_keys=keys if pad > 0 else None)
         losses = {}
         if pad > 0:

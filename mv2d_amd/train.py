@@ -12,6 +12,8 @@ Mirrors the reference interface for this step:
 
 No CPU fallback: the device tensors must be on the GPU and the HIP library present.
 """
+import math
+
 import numpy as np
 import torch
 
@@ -249,10 +251,16 @@ class TrainDecoder:
         import torch.nn.functional as F
         P, T, dev = self.p, ref.shape[0], ref.device
         pre = 'bbox_head.transformer.decoder.'
-        ref = ref.detach().to(torch.float32).contiguous()
+        ref = ref.to(torch.float32)
         dim_t = torch.arange(128, dtype=torch.float32)
         dim_t = (10000 ** (2 * (dim_t // 2) / 128)).to(dev)                              # MU/pe.py:24-25, as mv2d_amd.calib builds it
-        posemb = ops.posemb3d(ref, dim_t.contiguous())
+        if ref.requires_grad:                                                           # gradient into the query generator: pos2posemb3d in torch
+            def emb(p):
+                p = (p * (2 * math.pi))[..., None] / dim_t
+                return torch.stack((p[..., 0::2].sin(), p[..., 1::2].cos()), dim=-1).flatten(-2)
+            posemb = torch.cat((emb(ref[..., 1]), emb(ref[..., 0]), emb(ref[..., 2])), dim=-1)
+        else:
+            posemb = ops.posemb3d(ref.contiguous(), dim_t.contiguous())
         qpos = F.linear(F.relu(F.linear(posemb, P['bbox_head.query_embedding.0.weight'], P['bbox_head.query_embedding.0.bias'])),
                         P['bbox_head.query_embedding.2.weight'], P['bbox_head.query_embedding.2.bias'])
         key_in, val_in = key_in.float(), val_in.float()
@@ -327,3 +335,40 @@ def allreduce_gradients(parameters, bucket_bytes=256 << 20, average=True, group=
             off += n
         calls += 1
     return calls
+
+
+def query_generator_autograd(roi_head, roi_feat, intr_feat, minv):
+    """``QueryGenerator.forward`` + ``center2lidar`` + the reference-point normalisation (RH/utils/query_generator.py:352-405,333-341;
+    RH/mv2d_s_head.py:146-152) as torch autograd over the module's own parameters, on the engine's RoIAlign output: roi_feat [R,49,256]
+    (bf16, cell-major 7x7), intr_feat [R,16] (scaled intrinsics), minv [R,16] = inverse(K_roi E^T) fp32.  Returns the normalised
+    reference points [R,3], differentiable w.r.t. the query generator's parameters (not w.r.t. the feature map: no RoIAlign backward)."""
+    import torch.nn.functional as F
+    qg = roi_head.query_generator
+    R = roi_feat.shape[0]
+    x = roi_feat.detach().float().view(R, 7, 7, -1).permute(0, 3, 1, 2)
+    conv = qg.shared_convs[0].conv
+    x = F.avg_pool2d(F.relu(F.conv2d(x, conv.weight, conv.bias, padding=1)), 7).flatten(1)
+    x = F.relu(qg.shared_fcs[0](x))
+    x = torch.cat([x, intr_feat.detach().float()], 1).clamp(min=-5e3, max=5e3)
+    x = F.relu(F.linear(x, qg.extra_enc[0].weight, qg.extra_enc[0].bias))
+    x = F.relu(F.linear(x, qg.extra_enc[2].weight, qg.extra_enc[2].bias))
+    c = qg.fc_center(x)
+    hom = torch.cat([c[:, :2] * c[:, 2:3], c[:, 2:3], torch.ones_like(c[:, :1])], 1)
+    xyz = torch.bmm(minv.detach().view(R, 4, 4), hom[..., None])[:, :3, 0]
+    pr = [float(v) for v in roi_head.pc_range]
+    lo = xyz.new_tensor(pr[:3])
+    return (xyz - lo) / (xyz.new_tensor(pr[3:]) - lo)
+
+
+def key_embedding_autograd(roi_head, A1, A2, Xf):
+    """The PE block at the gathered key positions (MU/pe.py:36-48,150-166) as torch autograd over the module's parameters, on the inputs the
+    engine prepared: A1 [S,192] inverse-sigmoid frustum coordinates, A2 [S,384] sine embedding, Xf [S,256] feature rows (all bf16).
+    Returns (key_in = feat + pe, val_in = feat) [S,256] fp32 — the T path's keys / values."""
+    import torch.nn.functional as F
+    pe = roi_head.position_encoding
+    lin = lambda conv, t: F.linear(t, conv.weight.flatten(1), conv.bias)  # noqa: E731   (1x1 convs)
+    feat = Xf.detach().float()
+    p3d = lin(pe.position_encoder[2], F.relu(lin(pe.position_encoder[0], A1.detach().float())))
+    gate = torch.sigmoid(lin(pe.fpe.conv_expand, F.relu(lin(pe.fpe.conv_reduce, feat))))
+    sine = lin(pe.adapt_pos3d[2], F.relu(lin(pe.adapt_pos3d[0], A2.detach().float())))
+    return feat + p3d * gate + sine, feat

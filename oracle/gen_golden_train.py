@@ -129,7 +129,7 @@ def main():
         sum(losses_g.values()).backward()
         names, norms, projs = [], [], []
         for pn, q in h.named_parameters():
-            if pn.startswith('bbox_head.') and q.grad is not None:
+            if q.grad is not None:
                 names.append(pn)
                 norms.append(float(q.grad.double().norm()))
                 projs.append(float((q.grad.double().flatten() * torch.from_numpy(synthetic.grad_probe(pn, q.numel())).double()).sum()))

@@ -220,7 +220,7 @@ def test_forward_train_losses_match_reference(name):
 @pytest.mark.parametrize('name', list(synthetic.FWD_TRAIN_CASES))
 def test_forward_train_gradients_match_reference(name):
     """forward_train through the autograd route (torch linears around the HIP attention forward / backward and the HIP loss kernel):
-    losses and the gradients of every decoder / branch / query_embedding parameter vs the reference's autograd (goldens store the norm and a
+    losses and the gradients of every parameter of the head (decoder, branches, query embedding, query generator, PE) vs the reference's autograd (goldens store the norm and a
     seeded projection of each gradient)."""
     from mv2d_amd import registry
     import mv2d_amd.plugin  # noqa: F401
@@ -265,10 +265,13 @@ def test_forward_train_gradients_match_reference(name):
     sum(losses.values()).backward()
     params = dict(head.named_parameters())
     names = [str(n) for n in gold[name + '.grad_names']]
-    assert len(names) == 210
+    assert len(names) == 232                                # every parameter of the head: decoder, branches, query embedding, query generator, PE
     worst, errs, top = (0.0, None), [], float(gold[name + '.grad_norm'].max())
     for n, norm, proj in zip(names, gold[name + '.grad_norm'], gold[name + '.grad_proj']):
         g = params[n].grad
+        if kind == 'S' and n.startswith('position_encoding.'):
+            assert g is None                              # S path: the PE half of the keys went through RoIAlign, no backward for it yet
+            continue
         assert g is not None, n
         if norm < 1e-5 * top:
             continue                                      # numerically zero in the reference (layer-0 self attention: every query row equal)

@@ -57,6 +57,6 @@ for name, (prob_name, kind, G, seed) in synthetic.FWD_TRAIN_CASES.items():
         gp = float((g.flatten() * torch.from_numpy(synthetic.grad_probe(str(n), g.numel())).double()).sum())
         rows.append((abs(float(g.norm()) - norm) / max(norm, 1e-9), str(n), float(g.norm()), norm, gp, proj))
     rows.sort(reverse=True)
-    for r in rows[:8]:
+    for r in rows[:14]:
         print('   ', r)
     print('    median norm err', sorted(x[0] for x in rows)[len(rows) // 2])
