@@ -362,6 +362,12 @@ int mv2d_set_loss(const float* cls, const float* box, const int* match, const fl
 int mv2d_dn_queries(const float* gt, const int* gt_labels, const float* rnd, int G, int scalar, float noise_scale, float noise_trans, float split,
                     int num_classes, const float* pc_range_host, float eps, float* ref, long long* labels, float* boxes, void* stream);
 
+/* Backward of mv2d_roi_align w.r.t. one map (training; mmcv's roi_align backward): grad_out [R][49][256] fp32 ->
+ * grad_map [rows][256] fp32, ACCUMULATED with hardware fp32 atomics (the caller zeroes it; the summation order varies between runs).
+ * index (may be null): position -> row of a compacted map, negative = no row (as map1_index of the forward). */
+int mv2d_roi_align_bwd(const float* grad_out, const float* rois, float* grad_map, const int* index, int R, int H, int W, int channels,
+                       float spatial_scale, int sampling_ratio, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

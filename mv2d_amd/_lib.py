@@ -69,6 +69,7 @@ SIGNATURES = {
     'mv2d_pe_inputs': (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
     'mv2d_result_pack': (I, [P, P, P, P, F, I, P, P, P, P, I, I, P]),
     'mv2d_pack_detections': (I, [P, P, P, P, P, I, I, I, P]),
+    'mv2d_roi_align_bwd': (I, [P, P, P, P, I, I, I, I, F, I, P]),
     'mv2d_match_cost': (I, [P, P, P, P, P, I, I, I, I, F, F, F, F, P]),
     'mv2d_set_loss': (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, F, I, P]),
     'mv2d_decode_topk': (I, [P, P, I, I, I, P, P, P, P, P, P, P, P, I, I, P]),

@@ -207,6 +207,54 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
     }
 }
 
+// Backward of roi_align_kernel w.r.t. one map (training): the gradient of every output bin is spread over the bilinear taps
+// of its samples with the forward's weights / count.  Same grid and loops as the forward; fp32 hardware atomics into the (zeroed) map
+// gradient, so the summation order — not the values' set — varies from run to run (mmcv's RoIAlign backward does the same).
+// index: optional position -> row of a compacted map (rows < 0 are skipped).
+__global__ __launch_bounds__(256) void roi_align_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gmap,
+                                                            const int* __restrict__ index, int H, int W, float spatial_scale, int sampling_ratio) {
+    const int r = blockIdx.x, ph = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
+    const float* b = rois + r * 5;
+    const int v = (int)b[0];
+    const float x1 = b[1] * spatial_scale - 0.5f, y1 = b[2] * spatial_scale - 0.5f;
+    const float x2 = b[3] * spatial_scale - 0.5f, y2 = b[4] * spatial_scale - 0.5f;
+    const float rw = x2 - x1, rh = y2 - y1;
+    const float bw = rw / 7.0f, bh = rh / 7.0f;
+    const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / 7.0f);
+    const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / 7.0f);
+    const float count = (float)max(gh * gw, 1);
+    const long long vbase = (long long)v * H * W;
+    auto add = [&](long long q, float wgt, const float4& g) {
+        if (index) {
+            const int row = index[q];
+            if (row < 0) return;
+            q = row;
+        }
+        float* d = gmap + q * C + c;
+        unsafeAtomicAdd(d, wgt * g.x); unsafeAtomicAdd(d + 1, wgt * g.y); unsafeAtomicAdd(d + 2, wgt * g.z); unsafeAtomicAdd(d + 3, wgt * g.w);
+    };
+    for (int pw = wave; pw < 7; pw += 4) {
+        float4 g = *reinterpret_cast<const float4*>(gout + ((long long)r * 49 + ph * 7 + pw) * C + c);
+        g = make_float4(g.x / count, g.y / count, g.z / count, g.w / count);
+        for (int iy = 0; iy < gh; ++iy) {
+            const float yy = y1 + ph * bh + (iy + 0.5f) * bh / gh;
+            for (int ix = 0; ix < gw; ++ix) {
+                const float xx = x1 + pw * bw + (ix + 0.5f) * bw / gw;
+                if (yy < -1.0f || yy > (float)H || xx < -1.0f || xx > (float)W) continue;
+                float y = fmaxf(yy, 0.f), x = fmaxf(xx, 0.f);
+                int yl = (int)y, xl = (int)x, yh, xh;
+                if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+                if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+                const float ly = y - yl, lx = x - xl, hy = 1.f - ly, hx = 1.f - lx;
+                add(vbase + (long long)yl * W + xl, hy * hx, g);
+                add(vbase + (long long)yl * W + xh, hy * lx, g);
+                add(vbase + (long long)yh * W + xl, ly * hx, g);
+                add(vbase + (long long)yh * W + xh, ly * lx, g);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // a9: epipolar box correlation (RH/utils/box_correlation.py:196-398, 'topk_matched:k:thr:ratio').
 //     One block per (RoI r, destination view b of r's sample).  fp64 projection, fp32 compares, integer outputs.
@@ -849,6 +897,16 @@ extern "C" int mv2d_roi_align(const float* map0, const float* map1, const float*
     if (R == 0) return MV2D_OK;
     hipLaunchKernelGGL(roi_align_kernel, dim3(R, 7), dim3(256), 0, (hipStream_t)stream, map0, map1, rois, (unsigned short*)out0,
                        (unsigned short*)out1, out0_f32, out1_f32, H, W, spatial_scale, sampling_ratio, map1_index, out1_is_sum);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_roi_align_bwd(const float* grad_out, const float* rois, float* grad_map, const int* index, int R, int H, int W,
+                                  int channels, float spatial_scale, int sampling_ratio, void* stream) {
+    MV2D_CHECK_ARG(grad_out && rois && grad_map && channels == C, "mv2d_roi_align_bwd: needs fp32 [R,49,256] gradients and a 256-channel position-major map");
+    if (R == 0) return MV2D_OK;
+    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(R, 7), dim3(256), 0, (hipStream_t)stream, grad_out, rois, grad_map, index, H, W, spatial_scale,
+                       sampling_ratio);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

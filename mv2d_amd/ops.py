@@ -582,6 +582,35 @@ def pack_detections(boxes, scores, labels, count, out, max_num=300):
     return out
 
 
+class RoIAlignRows(torch.autograd.Function):
+    """RoIAlign (mmcv semantics, 7x7, stride 16) of a position-major fp32 map [rows,256] -> [R,49,256] fp32, differentiable w.r.t. the
+    map (``mv2d_roi_align`` / ``mv2d_roi_align_bwd``).  ``index`` (int32 [V*H*W] or None): position -> row of a compacted map (the PE rows
+    of the S path); ``full`` is then any full-size map the kernel can read alongside (its output is discarded)."""
+
+    @staticmethod
+    def forward(ctx, rows, index, rois, H, W, full=None):
+        R = rois.shape[0]
+        out = torch.empty((R, 49, 256), device=rows.device, dtype=torch.float32)
+        rows_c = rows.contiguous()
+        if index is None:
+            roi_align(rows_c, rois, H, W, out0_f32=out, R=R)
+        else:
+            scratch = torch.empty_like(out)
+            roi_align(full.contiguous(), rois, H, W, map1=rows_c, out0_f32=scratch, out1_f32=out, map1_index=index, R=R)
+        ctx.save_for_backward(rois, index if index is not None else torch.empty(0, dtype=torch.int32, device=rows.device))
+        ctx.meta = (H, W, rows.shape[0], index is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        rois, index = ctx.saved_tensors
+        H, W, n, indexed = ctx.meta
+        gmap = torch.zeros((n, 256), device=gout.device, dtype=torch.float32)
+        check(_lib.load().mv2d_roi_align_bwd(_p(gout.contiguous().float()), _p(rois), _p(gmap), _p(index) if indexed else None, rois.shape[0], H, W,
+                                             256, 1.0 / 16, -1, _stream()), 'mv2d_roi_align_bwd')
+        return gmap, None, None, None, None, None
+
+
 def match_cost(cls, box, gt, gt_labels, cls_weight=2.0, reg_weight=0.25, alpha=0.25, gamma=2.0):
     """cls [L,R,C] logits, box [L,R,10], gt [G,9] fp32, gt_labels [G] int32 -> cost [L,R,G] fp32 of the Hungarian assignment."""
     L, R, C = cls.shape

@@ -209,7 +209,7 @@ class MV2DHead(nn.Module):
             res.append([boxes, scores.clone(), labels.clone()])
         return res
 
-    def _forward_train_autograd(self, eng, out, hl, gt, labels, dn_noise):
+    def _forward_train_autograd(self, eng, out, hl, gt, labels, dn_noise, feat):
         from .. import train
         ws, R = out['ws'], out['R']
         row_ptr = ws['row_ptr'][:R + 1]
@@ -217,15 +217,22 @@ class MV2DHead(nn.Module):
         if self.KIND == 'T' and bool((row_ptr[1:] == row_ptr[:-1]).any().item()):
             raise NotImplementedError('forward_train: a RoI without a single visible key (training-time fallback key not built)')
         col = ws['col_idx'][:nnz]
+        # the input map, position-major, as a differentiable view: its gradient comes back through RoIAlign and the key rows
+        V, _, h, w = feat.shape
+        fm = feat.float().permute(0, 2, 3, 1).reshape(V * h * w, C)
+        rois = ws['rois'][:R].clone()
+        bbox_feats = ops.RoIAlignRows.apply(fm, None, rois, h, w)                                   # [R,49,256]
+        S = int(ws['S_dev'].item())
+        # the PE block at the positions the engine listed (T: the gathered keys; S: every position a RoIAlign tap can touch)
+        key_rows, val_rows, pe_rows = train.key_embedding_autograd(self, ws['A1'][:S], ws['A2'][:S], fm[ws['s2pos'][:S].long()])
         if self.KIND == 'T':
-            # keys / values with the gradient of the PE block: recomputed from the inputs the engine prepared
-            S = int(ws['S_dev'].item())
-            key_in, val_in = train.key_embedding_autograd(self, ws['A1'][:S], ws['A2'][:S], ws['Xf_b'][:S])
+            key_in, val_in = key_rows, val_rows
         else:
-            # S path: the PE half went through RoIAlign (no backward yet): constants
-            key_in, val_in = ws['roi_sum'][:R].reshape(R * 49, C).detach(), ws['roi_feat'][:R].reshape(R * 49, C).detach()
+            pe_aligned = ops.RoIAlignRows.apply(pe_rows, ws['pos2s'].clone(), rois, h, w, fm.detach())
+            val_in = bbox_feats.reshape(R * 49, C)
+            key_in = val_in + pe_aligned.reshape(R * 49, C)
         # reference points with the gradient of the query generator
-        ref = train.query_generator_autograd(self, ws['roi_feat'][:R], ws['enc'][:R, 1024:1040], ws['minv'][:R])
+        ref = train.query_generator_autograd(self, bbox_feats, ws['enc'][:R, 1024:1040], ws['minv'][:R])
         ref_const, pad, single, md, keys = ws['ref'][:R], 0, 1, None, None
         if getattr(self, 'use_denoise', False):
             padded, _, md = train.prepare_for_dn(ref_const, gt, labels, self.denoise_scalar, self.denoise_noise_scale, self.denoise_noise_trans,
@@ -283,7 +290,7 @@ class MV2DHead(nn.Module):
         if autograd is None:
             autograd = torch.is_grad_enabled() and any(p.requires_grad for p in self.bbox_head.parameters())
         if autograd:
-            return self._forward_train_autograd(eng, out, hl, gt, labels, dn_noise)
+            return self._forward_train_autograd(eng, out, hl, gt, labels, dn_noise, feat)
         if getattr(self, 'use_denoise', False):
             ref = out['ws']['ref'][:R]
             padded, _, md = train.prepare_for_dn(ref, gt, labels, self.denoise_scalar, self.denoise_noise_scale, self.denoise_noise_trans,

@@ -341,11 +341,12 @@ def query_generator_autograd(roi_head, roi_feat, intr_feat, minv):
     """``QueryGenerator.forward`` + ``center2lidar`` + the reference-point normalisation (RH/utils/query_generator.py:352-405,333-341;
     RH/mv2d_s_head.py:146-152) as torch autograd over the module's own parameters, on the engine's RoIAlign output: roi_feat [R,49,256]
     (bf16, cell-major 7x7), intr_feat [R,16] (scaled intrinsics), minv [R,16] = inverse(K_roi E^T) fp32.  Returns the normalised
-    reference points [R,3], differentiable w.r.t. the query generator's parameters (not w.r.t. the feature map: no RoIAlign backward)."""
+    reference points [R,3], differentiable w.r.t. the query generator's parameters and w.r.t. roi_feat (``ops.RoIAlignRows`` carries the
+    gradient on to the feature map)."""
     import torch.nn.functional as F
     qg = roi_head.query_generator
     R = roi_feat.shape[0]
-    x = roi_feat.detach().float().view(R, 7, 7, -1).permute(0, 3, 1, 2)
+    x = roi_feat.float().view(R, 7, 7, -1).permute(0, 3, 1, 2)
     conv = qg.shared_convs[0].conv
     x = F.avg_pool2d(F.relu(F.conv2d(x, conv.weight, conv.bias, padding=1)), 7).flatten(1)
     x = F.relu(qg.shared_fcs[0](x))
@@ -362,13 +363,14 @@ def query_generator_autograd(roi_head, roi_feat, intr_feat, minv):
 
 def key_embedding_autograd(roi_head, A1, A2, Xf):
     """The PE block at the gathered key positions (MU/pe.py:36-48,150-166) as torch autograd over the module's parameters, on the inputs the
-    engine prepared: A1 [S,192] inverse-sigmoid frustum coordinates, A2 [S,384] sine embedding, Xf [S,256] feature rows (all bf16).
-    Returns (key_in = feat + pe, val_in = feat) [S,256] fp32 — the T path's keys / values."""
+    engine prepared: A1 [S,192] inverse-sigmoid frustum coordinates, A2 [S,384] sine embedding (bf16, no gradient), Xf [S,256] feature rows
+    (differentiable).  Returns (feat + pe, feat, pe) [S,256] fp32: the T path's keys / values; the S path RoI-aligns pe."""
     import torch.nn.functional as F
     pe = roi_head.position_encoding
     lin = lambda conv, t: F.linear(t, conv.weight.flatten(1), conv.bias)  # noqa: E731   (1x1 convs)
-    feat = Xf.detach().float()
+    feat = Xf.float()
     p3d = lin(pe.position_encoder[2], F.relu(lin(pe.position_encoder[0], A1.detach().float())))
     gate = torch.sigmoid(lin(pe.fpe.conv_expand, F.relu(lin(pe.fpe.conv_reduce, feat))))
     sine = lin(pe.adapt_pos3d[2], F.relu(lin(pe.adapt_pos3d[0], A2.detach().float())))
-    return feat + p3d * gate + sine, feat
+    pos = p3d * gate + sine
+    return feat + pos, feat, pos

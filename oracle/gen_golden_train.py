@@ -123,7 +123,8 @@ def main():
         torch.Tensor.cuda = lambda self, *a, **k: self
         torch.rand_like = lambda t, *a, **k: rnd.to(t.dtype)
         try:
-            losses_g = h.forward_train([torch.from_numpy(prob['feat'])], metas, props, None, None, None, None, [gt], [labels], None)
+            xg = torch.from_numpy(prob['feat']).clone().requires_grad_(True)
+            losses_g = h.forward_train([xg], metas, props, None, None, None, None, [gt], [labels], None)
         finally:
             torch.Tensor.cuda, torch.rand_like = cuda, rand_like
         sum(losses_g.values()).backward()
@@ -133,6 +134,9 @@ def main():
                 names.append(pn)
                 norms.append(float(q.grad.double().norm()))
                 projs.append(float((q.grad.double().flatten() * torch.from_numpy(synthetic.grad_probe(pn, q.numel())).double()).sum()))
+        rec[f'{name}.dfeat_norm'] = np.float64(float(xg.grad.double().norm()))
+        rec[f'{name}.dfeat_proj'] = np.float64(float((xg.grad.double().flatten() * torch.from_numpy(synthetic.grad_probe('feat', xg.numel())).double()).sum()))
+        rec[f'{name}.dfeat_view_norms'] = xg.grad.double().flatten(1).norm(dim=1).numpy()
         rec[f'{name}.grad_names'] = np.array(names)
         rec[f'{name}.grad_norm'] = np.array(norms)
         rec[f'{name}.grad_proj'] = np.array(projs)

@@ -221,7 +221,7 @@ def test_forward_train_losses_match_reference(name):
 def test_forward_train_gradients_match_reference(name):
     """forward_train through the autograd route (torch linears around the HIP attention forward / backward and the HIP loss kernel):
     losses and the gradients of every parameter of the head (decoder, branches, query embedding, query generator, PE) vs the reference's autograd (goldens store the norm and a
-    seeded projection of each gradient)."""
+    seeded projection of each gradient), and the gradient w.r.t. the input feature map."""
     from mv2d_amd import registry
     import mv2d_amd.plugin  # noqa: F401
     gold = load_golden('train_loss')
@@ -235,7 +235,7 @@ def test_forward_train_gradients_match_reference(name):
     head = head.to(DEV)
     gtc = synthetic.make_train_gt(G, seed)
     rnd = torch.from_numpy(synthetic.make_dn_noise(G * 10, seed)).to(DEV)
-    feat = torch.from_numpy(prob['feat']).to(DEV)
+    feat = torch.from_numpy(prob['feat']).to(DEV).requires_grad_(True)      # the backbone's output: it gets a gradient too
     props = [torch.from_numpy(p) for p in prob['proposals']]
     metas = [dict(m, box_type_3d=None) for m in prob['img_metas']]
     # the Hungarian assignment is discontinuous: a near-tie can flip under the 5e-4 difference of the rows.  The comparison of losses and
@@ -269,9 +269,6 @@ def test_forward_train_gradients_match_reference(name):
     worst, errs, top = (0.0, None), [], float(gold[name + '.grad_norm'].max())
     for n, norm, proj in zip(names, gold[name + '.grad_norm'], gold[name + '.grad_proj']):
         g = params[n].grad
-        if kind == 'S' and n.startswith('position_encoding.'):
-            assert g is None                              # S path: the PE half of the keys went through RoIAlign, no backward for it yet
-            continue
         assert g is not None, n
         if norm < 1e-5 * top:
             continue                                      # numerically zero in the reference (layer-0 self attention: every query row equal)
@@ -283,7 +280,44 @@ def test_forward_train_gradients_match_reference(name):
         errs.append(e)
         if e > worst[0]:
             worst = (e, n)
+    # gradient w.r.t. the feature map (RoIAlign backward + the gathered key rows): norm, probe projection, per-view norms
+    gf = feat.grad.double().cpu()
+    fn = float(gold[name + '.dfeat_norm'])
+    assert abs(float(gf.norm()) - fn) <= 2e-2 * fn
+    assert abs(float((gf.flatten() * torch.from_numpy(synthetic.grad_probe('feat', gf.numel())).double()).sum()) - float(gold[name + '.dfeat_proj'])) <= 6e-2 * fn
+    assert torch.allclose(gf.flatten(1).norm(dim=1), torch.from_numpy(gold[name + '.dfeat_view_norms']), rtol=3e-2, atol=1e-3 * fn)
     errs.sort()
     # bf16-rounded K / V in both attentions (as in the inference engine), everything else fp32.  The L1 term's gradient is sign(pred - target):
     # a coordinate within 1e-3 of its target can flip, which moves a handful of small-norm gradients by several per cent on the 12-row cases
     assert worst[0] <= 0.15 and errs[len(errs) // 2] <= 1e-2, (worst, errs[len(errs) // 2])
+
+
+def test_roi_align_backward_matches_autograd_of_the_oracle():
+    """ops.RoIAlignRows (mv2d_roi_align / mv2d_roi_align_bwd) vs torch autograd through the oracle's RoIAlign: full map and compacted map."""
+    from mv2d_amd import ops
+    from oracle import mv2d_oracle as O
+    g = torch.Generator().manual_seed(5)
+    V, H, W = 2, 9, 13
+    feat = torch.randn(V, 256, H, W, generator=g)
+    rois = torch.tensor([[0, 10., 12., 90., 70.], [1, -20., 30., 60., 150.], [1, 100., 5., 207., 143.], [0, 150., 100., 230., 160.],
+                         [0, 33., 40., 36., 44.]])
+    gout = torch.randn(rois.shape[0], 256, 7, 7, generator=g)
+    f0 = feat.clone().requires_grad_(True)
+    want = O.roi_align(f0, rois)
+    want.backward(gout)
+    rows = feat.permute(0, 2, 3, 1).reshape(V * H * W, 256).to(DEV).requires_grad_(True)
+    out = ops.RoIAlignRows.apply(rows, None, rois.to(DEV), H, W)                      # [R,49,256]
+    got = out.view(-1, 7, 7, 256).permute(0, 3, 1, 2)
+    assert float((got.detach().cpu() - want.detach()).abs().max()) <= 1e-5 * float(want.detach().abs().max())
+    out.backward(gout.permute(0, 2, 3, 1).reshape(-1, 49, 256).to(DEV).contiguous())
+    wg = f0.grad.permute(0, 2, 3, 1).reshape(V * H * W, 256)
+    assert float((rows.grad.cpu() - wg).abs().max()) <= 1e-5 * float(wg.abs().max())
+    # compacted map: only the positions with a non-zero reference gradient are listed (others: index -1, never read with weight > 0)
+    keep = wg.abs().sum(1) > 0
+    index = torch.full((V * H * W,), -1, dtype=torch.int32)
+    index[keep] = torch.arange(int(keep.sum()), dtype=torch.int32)
+    small = feat.permute(0, 2, 3, 1).reshape(V * H * W, 256)[keep].to(DEV).requires_grad_(True)
+    out2 = ops.RoIAlignRows.apply(small, index.to(DEV), rois.to(DEV), H, W, rows.detach())
+    assert torch.allclose(out2, out.detach(), rtol=0, atol=1e-6)
+    out2.backward(gout.permute(0, 2, 3, 1).reshape(-1, 49, 256).to(DEV).contiguous())
+    assert float((small.grad.cpu() - wg[keep]).abs().max()) <= 1e-5 * float(wg.abs().max())

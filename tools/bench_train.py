@@ -35,7 +35,7 @@ def main():
     head = head.to(dev)
     gtc = synthetic.make_train_gt(a.gt, 3)
     gt, labels = [torch.from_numpy(gtc['gt'])], [torch.from_numpy(gtc['gt_labels'])]
-    feat = torch.from_numpy(prob['feat']).to(dev)
+    feat = torch.from_numpy(prob['feat']).to(dev).requires_grad_(True)      # the backbone's output: the step includes its gradient
     props = [torch.from_numpy(p) for p in prob['proposals']]
     metas = [dict(m, box_type_3d=None) for m in prob['img_metas']]
 
@@ -44,6 +44,7 @@ def main():
         if backward:
             for p in head.parameters():
                 p.grad = None
+            feat.grad = None
             sum(losses.values()).backward()
         return losses
 
@@ -61,7 +62,7 @@ def main():
     fwd_autograd = timed(lambda: step(True, False), a.iters)
     fwd_bwd = timed(lambda: step(True, True), a.iters)
     eng = head.engine(feat.device, metas)
-    infer = timed(lambda: eng.results(eng.run(feat, props, metas)), a.iters)
+    infer = timed(lambda: eng.results(eng.run(feat.detach(), props, metas)), a.iters)
     R = sum(len(p) for p in prob['proposals'])
     print(json.dumps(dict(metric='head training step', problem=a.problem, kind=kind, queries=R, gt_boxes=a.gt,
                           denoising_queries=10 * a.gt if getattr(head, 'use_denoise', False) else 0,

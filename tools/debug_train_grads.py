@@ -19,7 +19,7 @@ for name, (prob_name, kind, G, seed) in synthetic.FWD_TRAIN_CASES.items():
     head = head.to(DEV)
     gtc = synthetic.make_train_gt(G, seed)
     rnd = torch.from_numpy(synthetic.make_dn_noise(G * 10, seed)).to(DEV)
-    feat = torch.from_numpy(prob['feat']).to(DEV)
+    feat = torch.from_numpy(prob['feat']).to(DEV).requires_grad_(True)
     props = [torch.from_numpy(p) for p in prob['proposals']]
     metas = [dict(m, box_type_3d=None) for m in prob['img_metas']]
     cap = {}
@@ -56,7 +56,10 @@ for name, (prob_name, kind, G, seed) in synthetic.FWD_TRAIN_CASES.items():
         g = g.double().cpu()
         gp = float((g.flatten() * torch.from_numpy(synthetic.grad_probe(str(n), g.numel())).double()).sum())
         rows.append((abs(float(g.norm()) - norm) / max(norm, 1e-9), str(n), float(g.norm()), norm, gp, proj))
+    gf = feat.grad.double().cpu()
+    print('   dfeat norm', float(gf.norm()), 'ref', float(gold[name + '.dfeat_norm']), 'proj', float((gf.flatten() * torch.from_numpy(synthetic.grad_probe('feat', gf.numel())).double()).sum()), 'ref', float(gold[name + '.dfeat_proj']))
+    print('   per-view', [round(float(x), 5) for x in gf.flatten(1).norm(dim=1)], 'ref', [round(float(x), 5) for x in gold[name + '.dfeat_view_norms']])
     rows.sort(reverse=True)
-    for r in rows[:14]:
+    for r in rows[:5]:
         print('   ', r)
     print('    median norm err', sorted(x[0] for x in rows)[len(rows) // 2])
