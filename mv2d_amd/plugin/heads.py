@@ -162,8 +162,15 @@ class MV2DHead(nn.Module):
     def _engine_num_views(self, img_metas):
         return len(img_metas)
 
-    def engine(self, device, img_metas):
-        ver = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(device), self._engine_num_views(img_metas))
+    def engine(self, device, img_metas, allow_stale=False):
+        """The fused engine packed from the module's current parameters (re-packed whenever a parameter changed).  ``allow_stale``: the
+        caller only reads what does not depend on the parameters (RoI list, correlation / key list / CSR, PE inputs, per-RoI cameras) — the
+        autograd route of forward_train —, so an engine packed from older parameter values will do and an optimizer step does not force
+        a re-pack."""
+        tail = (str(device), self._engine_num_views(img_metas))
+        if allow_stale and self._engine is not None and self._engine_ver[-2:] == tail:
+            return self._engine
+        ver = tuple((p.data_ptr(), p._version) for p in self.parameters()) + tail
         if self._engine is None or self._engine_ver != ver:
             sd = {k: v for k, v in self.state_dict().items()}
             bc = self.box_corr_module
@@ -278,8 +285,10 @@ class MV2DHead(nn.Module):
         assert len(img_metas) // img_metas[0]['num_views'] == 1
         feat = x[self.feat_lvl]
         dev = feat.device
-        eng = self.engine(dev, img_metas)
-        out = eng.run(feat.float(), [p[:, :6] for p in proposal_list], img_metas)
+        if autograd is None:
+            autograd = torch.is_grad_enabled() and any(p.requires_grad for p in self.bbox_head.parameters())
+        eng = self.engine(dev, img_metas, allow_stale=bool(autograd))
+        out = eng.run(feat.detach().float(), [p[:, :6] for p in proposal_list], img_metas)
         g = ori_gt_bboxes_3d[0]
         gt = g if torch.is_tensor(g) else torch.cat((g.gravity_center, g.tensor[:, 3:]), dim=1)
         gt = gt.to(dev, torch.float32).contiguous()
@@ -287,8 +296,6 @@ class MV2DHead(nn.Module):
         hl = self._head_loss(dev)
         R = out['R']
         losses = {}
-        if autograd is None:
-            autograd = torch.is_grad_enabled() and any(p.requires_grad for p in self.bbox_head.parameters())
         if autograd:
             return self._forward_train_autograd(eng, out, hl, gt, labels, dn_noise, feat)
         if getattr(self, 'use_denoise', False):

@@ -321,3 +321,34 @@ def test_roi_align_backward_matches_autograd_of_the_oracle():
     assert torch.allclose(out2, out.detach(), rtol=0, atol=1e-6)
     out2.backward(gout.permute(0, 2, 3, 1).reshape(-1, 49, 256).to(DEV).contiguous())
     assert float((small.grad.cpu() - wg[keep]).abs().max()) <= 1e-5 * float(wg.abs().max())
+
+
+@pytest.mark.parametrize('kind,prob_name', [('T', 'micro_t'), ('S', 'micro_s')])
+def test_a_few_optimizer_steps_reduce_the_loss(kind, prob_name):
+    """The gradients are usable: AdamW on the head's parameters lowers the training loss of a fixed sample (fixed denoising noise)."""
+    from mv2d_amd import registry
+    import mv2d_amd.plugin  # noqa: F401
+    prob = synthetic.make_problem(prob_name, seed=0)
+    cfg = configs.roi_head_cfg_s() if kind == 'S' else configs.roi_head_cfg_t()
+    if kind == 'T':
+        cfg['num_views'] = prob['views_per_frame']
+    head = registry.build_head(cfg, train_cfg=configs.TRAIN_CFG_RCNN, test_cfg=configs.TEST_CFG_RCNN)
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_head_state(seed=0).items()}, strict=False)
+    head = head.to(DEV)
+    gtc = synthetic.make_train_gt(5, 31)
+    gt, labels = [torch.from_numpy(gtc['gt'])], [torch.from_numpy(gtc['gt_labels'])]
+    rnd = torch.from_numpy(synthetic.make_dn_noise(50, 31)).to(DEV)
+    feat = torch.from_numpy(prob['feat']).to(DEV)
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    metas = [dict(m, box_type_3d=None) for m in prob['img_metas']]
+    opt = torch.optim.AdamW([p for p in head.parameters() if p.requires_grad], lr=2e-4, weight_decay=0.0)
+    hist = []
+    for _ in range(12):
+        losses = head.forward_train([feat], metas, props, None, None, None, None, gt, labels, None, dn_noise=rnd)
+        total = sum(losses.values())
+        opt.zero_grad()
+        total.backward()
+        torch.nn.utils.clip_grad_norm_(head.parameters(), 35.0)               # the reference's optimizer_config (grad_clip max_norm = 35)
+        opt.step()
+        hist.append(float(total.detach()))
+    assert all(h == h for h in hist) and min(hist[-3:]) < 0.8 * hist[0], hist

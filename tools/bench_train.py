@@ -58,16 +58,25 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
 
+    opt = torch.optim.AdamW([p for p in head.parameters() if p.requires_grad], lr=1e-6)
+
+    def full_step():
+        losses = step(True, True)
+        torch.nn.utils.clip_grad_norm_(head.parameters(), 35.0)
+        opt.step()
+        return losses
+
     fwd_engine = timed(lambda: step(False, False), a.iters)
     fwd_autograd = timed(lambda: step(True, False), a.iters)
     fwd_bwd = timed(lambda: step(True, True), a.iters)
+    full = timed(full_step, a.iters)
     eng = head.engine(feat.device, metas)
     infer = timed(lambda: eng.results(eng.run(feat.detach(), props, metas)), a.iters)
     R = sum(len(p) for p in prob['proposals'])
     print(json.dumps(dict(metric='head training step', problem=a.problem, kind=kind, queries=R, gt_boxes=a.gt,
                           denoising_queries=10 * a.gt if getattr(head, 'use_denoise', False) else 0,
                           inference_ms=round(infer, 3), forward_engine_route_ms=round(fwd_engine, 3),
-                          forward_autograd_route_ms=round(fwd_autograd, 3), forward_backward_ms=round(fwd_bwd, 3),
+                          forward_autograd_route_ms=round(fwd_autograd, 3), forward_backward_ms=round(fwd_bwd, 3), step_with_clip_and_adamw_ms=round(full, 3),
                           note='one sample per step, eager launches, Hungarian assignment on the host inside the timed region')))
 
 
