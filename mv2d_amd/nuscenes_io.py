@@ -10,7 +10,10 @@ timestamp, img_shape, pad_shape}; this module builds those from the on-disk reco
   mmdet3d_plugin/datasets/pipelines/transform_3d.py:456-591
 * ``split_view_metas``       — the per-view split of ``MV2D.simple_test``, mmdet3d_plugin/models/detectors/mv2d.py:232-246
 
-Out of this slice: image decoding itself (an ``imread`` callable is injected), the 2-D annotation matching of the training branch, and the
+* ``global_rot_scale_trans`` — ``GlobalRotScaleTransImage`` (transform_3d.py:822-904); ``center_match`` — custom_nuscenes_dataset.py:199-208;
+  ``pad_multi_view`` / ``normalize_multiview`` — ``PadMultiViewImage`` / ``NormalizeMultiviewImage`` (transform_3d.py:121-203)
+
+Out of this slice: image decoding itself (an ``imread`` callable is injected), the COCO-style 2-D annotation files of the training branch, and the
 result JSON (``_format_bbox`` / nuScenes eval live in mmdet3d and the nuscenes devkit, not in the reference tree).
 """
 import numpy as np
@@ -214,3 +217,73 @@ def split_view_metas(img_metas_views, num_views):
                 m[k] = v
         out.append(m)
     return out
+
+
+def global_rot_scale_trans(results, rot_range=(-0.3925, 0.3925), scale_ratio_range=(0.95, 1.05), reverse_angle=False, rng=np.random):
+    """``GlobalRotScaleTransImage.__call__`` (mmdet3d_plugin/datasets/pipelines/transform_3d.py:822-904): a random rotation about z and a
+    random isotropic scale of the lidar frame, folded into every view's ``lidar2img`` / ``extrinsics`` (fp32, like the reference's torch
+    arithmetic) and applied to ``results['gt_bboxes_3d']`` through its own ``rotate`` / ``scale`` methods (mmdet3d's box class, third
+    party).  Returns (rot_angle passed to the boxes, scale_ratio)."""
+    f32 = np.float32
+    angle = rng.uniform(*rot_range)
+    c, s = f32(np.cos(f32(angle))), f32(np.sin(f32(angle)))
+    rot = np.array([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], f32)
+    rot_inv = rot if reverse_angle else np.linalg.inv(rot).astype(f32)
+
+    def fold(m_inv):
+        for v in range(len(results['lidar2img'])):
+            results['lidar2img'][v] = np.asarray(results['lidar2img'][v], f32) @ m_inv
+            results['extrinsics'][v] = m_inv.T @ np.asarray(results['extrinsics'][v], f32)
+    fold(rot_inv)
+    box_angle = -angle if reverse_angle else angle
+    results['gt_bboxes_3d'].rotate(np.array(box_angle))
+    ratio = rng.uniform(*scale_ratio_range)
+    fold(np.linalg.inv(np.diag(np.array([ratio, ratio, ratio, 1], f32))).astype(f32))
+    results['gt_bboxes_3d'].scale(ratio)
+    return box_angle, ratio
+
+
+def center_match(bboxes_a, bboxes_b):
+    """``CustomNuScenesDataset.center_match`` (custom_nuscenes_dataset.py:199-208): for every camera-frame 2-D annotation the index of the
+    3-D box whose centre coincides (L1 distance <= 1e-3), else -1."""
+    cts_a, cts_b = bboxes_a[:, :3], bboxes_b[:, :3]
+    if len(cts_a) == 0 or len(cts_b) == 0:
+        return np.zeros(len(cts_a), dtype=np.int32) - 1
+    dist = np.abs(cts_a[:, None] - cts_b[None]).sum(-1)
+    match = dist.argmin(1)
+    match[dist.min(1) > 1e-3] = -1
+    return match
+
+
+def pad_multi_view(results, size=None, size_divisor=None, pad_val=0):
+    """``PadMultiViewImage`` (transform_3d.py:121-170; mmcv's ``impad`` / ``impad_to_multiple`` restated: constant padding at the bottom /
+    right): records ``img_shape`` (before) and ``pad_shape`` (after) — the two shapes the head's padding mask is built from."""
+    assert (size is None) != (size_divisor is None)
+    out = []
+    for img in results['img']:
+        h, w = img.shape[:2]
+        H, W = size if size is not None else (int(np.ceil(h / size_divisor)) * size_divisor, int(np.ceil(w / size_divisor)) * size_divisor)
+        p = np.full((H, W) + img.shape[2:], pad_val, dtype=img.dtype)
+        p[:h, :w] = img
+        out.append(p)
+    results['img_shape'] = [img.shape for img in results['img']]
+    results['img'] = out
+    results['pad_shape'] = [img.shape for img in out]
+    results['pad_fixed_size'], results['pad_size_divisor'] = size, size_divisor
+    return results
+
+
+def normalize_multiview(results, mean, std, to_rgb=True):
+    """``NormalizeMultiviewImage`` (transform_3d.py:173-203; mmcv's ``imnormalize`` restated: optional BGR->RGB, (img - mean) * (1 / std) in
+    fp32)."""
+    mean, std = np.array(mean, np.float32), np.array(std, np.float32)
+    stdinv = (1 / np.float64(std.reshape(1, -1))).astype(np.float32)
+    out = []
+    for img in results['img']:
+        x = np.asarray(img, np.float32)
+        if to_rgb:
+            x = x[..., ::-1]
+        out.append((x - mean.reshape(1, -1)) * stdinv)
+    results['img'] = out
+    results['img_norm_cfg'] = dict(mean=mean, std=std, to_rgb=to_rgb)
+    return results

@@ -367,3 +367,16 @@ def grad_probe(name, n):
     """A seeded probe vector per parameter name: gradient goldens store (norm, grad . probe) instead of the full gradient."""
     import zlib
     return _rng(zlib.crc32(name.encode()) % (2 ** 31)).normal(size=n).astype(np.float32)
+
+
+class RecordingBoxes:
+    """Stands for mmdet3d's LiDARInstance3DBoxes in the I/O tests: records the rotate / scale calls it receives."""
+
+    def __init__(self):
+        self.calls = []
+
+    def rotate(self, angle):
+        self.calls.append(('rotate', float(angle)))
+
+    def scale(self, ratio):
+        self.calls.append(('scale', float(ratio)))

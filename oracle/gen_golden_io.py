@@ -66,7 +66,8 @@ def install():
     _mod('mmdet3d_plugin.datasets.pipelines').__path__ = [root + '/datasets/pipelines']
     from mmdet3d_plugin.datasets.custom_nuscenes_dataset import CustomNuScenesDataset
     from mmdet3d_plugin.datasets.pipelines.loading import LoadMultiViewImageFromMultiSweepsFiles
-    from mmdet3d_plugin.datasets.pipelines.transform_3d import ResizeCropFlipImageMono
+    from mmdet3d_plugin.datasets.pipelines.transform_3d import GlobalRotScaleTransImage, ResizeCropFlipImageMono
+    install.extra = (GlobalRotScaleTransImage,)
     return CustomNuScenesDataset, LoadMultiViewImageFromMultiSweepsFiles, ResizeCropFlipImageMono
 
 
@@ -111,6 +112,25 @@ def main():
         _, ida = r._img_transform(Image.fromarray(np.zeros((900, 1600, 3), np.uint8)), *args)
         rec[f'fullsize.{int(training)}.ida'] = ida.numpy()
         rec[f'fullsize.{int(training)}.args'] = np.array([args[0], *args[1], *args[2], float(args[3]), args[4]], np.float64)
+    # GlobalRotScaleTransImage (the matrices; the box object only records what it is asked to do) and center_match
+    (Grst,) = install.extra
+    for reverse in (False, True):
+        info = synthetic.make_nusc_info(11, n_sweeps=0)
+        fake_self = types.SimpleNamespace(load_separate=False, data_infos=[copy.deepcopy(info)], test_mode=True)
+        d = Dataset.get_data_info(fake_self, 0)
+        box = synthetic.RecordingBoxes()
+        d['gt_bboxes_3d'] = box
+        np.random.seed(5)
+        d = Grst(reverse_angle=reverse, training=True)(d)
+        rec[f'grst.{int(reverse)}.lidar2img'] = stack(d['lidar2img'])
+        rec[f'grst.{int(reverse)}.extrinsics'] = stack(d['extrinsics'])
+        rec[f'grst.{int(reverse)}.calls'] = np.array([float(v) for _, v in box.calls])
+    g = np.random.default_rng(3)
+    b = g.normal(size=(9, 7))
+    a = np.concatenate([b[[4, 1, 7]] + 1e-5, g.normal(size=(2, 7)), b[[2]] + 2e-3])
+    rec['center_match.match'] = Dataset.center_match(None, a, b)
+    rec['center_match.empty_a'] = Dataset.center_match(None, a[:0], b)
+    rec['center_match.empty_b'] = Dataset.center_match(None, a, b[:0])
     np.savez_compressed(OUT, **rec)
     print('wrote', OUT, os.path.getsize(OUT), 'bytes')
 

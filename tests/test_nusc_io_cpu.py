@@ -103,3 +103,46 @@ def test_sweep_camera_record_against_homogeneous_composition():
     assert np.allclose(nio.quaternion_rotation_matrix([1, 0, 0, 0]), np.eye(3))
     assert np.allclose(nio.quaternion_rotation_matrix([np.cos(0.3), 0, 0, np.sin(0.3)])[:2, :2],
                        [[np.cos(0.6), -np.sin(0.6)], [np.sin(0.6), np.cos(0.6)]])
+
+
+@pytest.mark.parametrize('reverse', [False, True])
+def test_global_rot_scale_trans_matches_reference(reverse):
+    info = synthetic.make_nusc_info(11, n_sweeps=0)
+    d = nio.camera_geometry(info)
+    box = synthetic.RecordingBoxes()
+    d['gt_bboxes_3d'] = box
+    np.random.seed(5)
+    angle, ratio = nio.global_rot_scale_trans(d, reverse_angle=reverse)
+    if reverse:          # no matrix inverse involved: bit-exact
+        _eq(d['lidar2img'], GOLD['grst.1.lidar2img'], 'lidar2img')
+        _eq(d['extrinsics'], GOLD['grst.1.extrinsics'], 'extrinsics')
+    else:                # torch.inverse (LU, fp32) vs numpy's: one fp32 ulp
+        assert np.allclose(np.stack(d['lidar2img']), GOLD['grst.0.lidar2img'], rtol=2e-6, atol=1e-6)
+        assert np.allclose(np.stack(d['extrinsics']), GOLD['grst.0.extrinsics'], rtol=2e-6, atol=1e-6)
+    assert [c[0] for c in box.calls] == ['rotate', 'scale']
+    assert np.array_equal(np.array([v for _, v in box.calls]), GOLD[f'grst.{int(reverse)}.calls']) and box.calls[1][1] == ratio
+
+
+def test_center_match_matches_reference():
+    g = np.random.default_rng(3)
+    b = g.normal(size=(9, 7))
+    a = np.concatenate([b[[4, 1, 7]] + 1e-5, g.normal(size=(2, 7)), b[[2]] + 2e-3])
+    m = nio.center_match(a, b)
+    assert np.array_equal(m, GOLD['center_match.match']) and list(m[:3]) == [4, 1, 7] and m[-1] == -1
+    assert np.array_equal(nio.center_match(a[:0], b), GOLD['center_match.empty_a'])
+    assert np.array_equal(nio.center_match(a, b[:0]), GOLD['center_match.empty_b'])
+
+
+def test_pad_and_normalize():
+    imgs = synthetic.make_view_images(2, 50, 70, 1)
+    r = nio.pad_multi_view(dict(img=[i.copy() for i in imgs]), size_divisor=32)
+    assert r['img_shape'] == [(50, 70, 3)] * 2 and r['pad_shape'] == [(64, 96, 3)] * 2
+    assert np.array_equal(r['img'][1][:50, :70], imgs[1]) and not r['img'][1][50:].any() and not r['img'][1][:, 70:].any()
+    r = nio.pad_multi_view(dict(img=[imgs[0]]), size=(64, 80))
+    assert r['pad_shape'] == [(64, 80, 3)] and r['pad_fixed_size'] == (64, 80)
+    mean, std = [103.530, 116.280, 123.675], [57.375, 57.120, 58.395]
+    n = nio.normalize_multiview(dict(img=[imgs[0]]), mean, std, to_rgb=False)
+    want = (imgs[0].astype(np.float64) - np.array(mean)) / np.array(std)
+    assert n['img'][0].dtype == np.float32 and np.allclose(n['img'][0], want, atol=1e-5)
+    n2 = nio.normalize_multiview(dict(img=[imgs[0]]), mean, std, to_rgb=True)
+    assert np.allclose(n2['img'][0], (imgs[0][..., ::-1].astype(np.float64) - np.array(mean)) / np.array(std), atol=1e-5)
