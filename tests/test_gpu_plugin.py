@@ -257,3 +257,45 @@ def test_pack_detections_kernel_equals_torch_formulation():
     one = torch.empty((1, M * 11 + 1), device=dev)
     ops.pack_detections(boxes[2], scores[2], labels[2], count[2:3], one)
     assert torch.equal(one[0], mdist.pack_detections(boxes[2], scores[2], labels[2], count[2:3]))
+
+
+def test_head_on_metas_built_by_the_nuscenes_io_pipeline():
+    """f4 -> hot path: an info record (two ring cameras, no sweeps) goes through camera_geometry -> append_sweeps (padded second frame)
+    -> resize_crop_flip -> normalize -> pad -> split_view_metas; the head (two-frame T path) on those metas matches the oracle."""
+    import math
+    from mv2d_amd import nuscenes_io as nio
+    from oracle import mv2d_oracle as O
+    H0, W0 = 225, 400
+    cams = {}
+    for v, name in enumerate(['CAM_FRONT', 'CAM_FRONT_RIGHT']):
+        yaw = v * math.radians(40.0)
+        c, s = math.cos(yaw), math.sin(yaw)
+        T = np.eye(4)
+        T[:3, :3] = np.array([[0, -1, 0], [0, 0, -1], [1, 0, 0.]]) @ np.array([[c, s, 0], [-s, c, 0], [0, 0, 1.]])
+        T[:3, 3] = [0.0, 1.5, -0.5]
+        r = T[:3, :3]
+        cams[name] = dict(data_path=f'{name}.jpg', timestamp=1_000_000 - 20_000 * v, sensor2lidar_rotation=r.T.copy(),
+                          sensor2lidar_translation=-T[:3, 3] @ r, cam_intrinsic=np.array([[0.8 * W0, 0, W0 / 2], [0, 0.8 * W0, H0 / 2], [0, 0, 1.]]))
+    info = dict(token='t', lidar_path='l.bin', sweeps=[], timestamp=1_010_000, cams=cams)
+    d = nio.camera_geometry(info)
+    d['img'] = [synthetic.fake_image(p, H0, W0).astype(np.float32) for p in d['img_filename']]
+    d['filename'] = list(d['img_filename'])
+    d = nio.append_sweeps(d, sweeps_num=1, pad_empty_sweeps=True, sweep_range=[3, 27], to_float32=True)
+    conf = dict(resize_lim=(0.8, 1.0), final_dim=(128, 192), bot_pct_lim=(0.0, 0.0), rot_lim=(0.0, 0.0), H=H0, W=W0, rand_flip=True)
+    d = nio.resize_crop_flip(d, conf, training=False)
+    d = nio.normalize_multiview(d, [103.530, 116.280, 123.675], [57.375, 57.120, 58.395], to_rgb=False)
+    d = nio.pad_multi_view(d, size_divisor=32)
+    assert d['pad_shape'] == [(128, 192, 3)] * 4 and len(d['timestamp']) == 4
+    metas = nio.split_view_metas(dict(intrinsics=d['intrinsics'], extrinsics=d['extrinsics'], lidar2img=d['lidar2img'], timestamp=d['timestamp'],
+                                      img_shape=d['img_shape'], pad_shape=d['pad_shape'][0], box_type_3d=None), 4)
+    assert abs((metas[2]['timestamp'] - metas[0]['timestamp']) - 15 * 0.083) < 1e-9
+    props = synthetic.make_proposals(4, 4, 128, 192, seed=11)
+    feat = synthetic.make_feat(4, 8, 12, seed=12)
+    head = build('T', 2)
+    res = head.simple_test([torch.from_numpy(feat).to(DEV)], [torch.from_numpy(p).to(DEV) for p in props], metas)[0]
+    st = {}
+    O.forward_t(synthetic.make_head_state(seed=0), torch.from_numpy(feat), [torch.from_numpy(p) for p in props], metas, num_views=2, stages=st)
+    n = min(len(res[2]), len(st['labels']))
+    assert n > 0 and (res[2][:n].cpu() == st['labels'][:n]).float().mean() > 0.95
+    assert relmax(res[1][:n], st['scores'][:n]) < 5e-3
+    assert relmax(res[0][:n, 7:9], st['boxes'][:n, 7:9]) < 2e-2          # velocities: divided by the 1.245 s between the (padded) frames
