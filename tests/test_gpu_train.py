@@ -352,3 +352,33 @@ def test_a_few_optimizer_steps_reduce_the_loss(kind, prob_name):
         opt.step()
         hist.append(float(total.detach()))
     assert all(h == h for h in hist) and min(hist[-3:]) < 0.8 * hist[0], hist
+
+
+@pytest.mark.parametrize('kind,prob_name', [('T', 'micro_t'), ('S', 'micro_s')])
+def test_forward_train_without_ground_truth(kind, prob_name):
+    """A frame without objects: every query is background, no denoising rows, the box loss is zero, gradients still flow (both routes)."""
+    from mv2d_amd import registry
+    import mv2d_amd.plugin  # noqa: F401
+    prob = synthetic.make_problem(prob_name, seed=0)
+    cfg = configs.roi_head_cfg_s() if kind == 'S' else configs.roi_head_cfg_t()
+    if kind == 'T':
+        cfg['num_views'] = prob['views_per_frame']
+    head = registry.build_head(cfg, train_cfg=configs.TRAIN_CFG_RCNN, test_cfg=configs.TEST_CFG_RCNN)
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_head_state(seed=0).items()}, strict=False)
+    head = head.to(DEV)
+    feat = torch.from_numpy(prob['feat']).to(DEV)
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    metas = [dict(m, box_type_3d=None) for m in prob['img_metas']]
+    gt, labels = [torch.zeros(0, 9)], [torch.zeros(0, dtype=torch.long)]
+    a = head.forward_train([feat], metas, props, None, None, None, None, gt, labels, None, autograd=False)
+    b = head.forward_train([feat], metas, props, None, None, None, None, gt, labels, None, autograd=True)
+    assert set(a) == set(b) == {f'l{i}.{k}' for i in range(6) for k in ('loss_cls', 'loss_bbox')}
+    for k in a:
+        assert float(a[k].detach()) == float(a[k].detach()) and abs(float(a[k].detach()) - float(b[k].detach())) <= 5e-3 * max(abs(float(a[k].detach())), 1e-3)
+        if k.endswith('loss_bbox'):
+            assert float(a[k].detach()) == 0.0 and float(b[k].detach()) == 0.0
+        else:
+            assert float(a[k].detach()) > 0.0
+    sum(b.values()).backward()
+    g = head.bbox_head.cls_branches[5][6].weight.grad
+    assert g is not None and float(g.abs().sum()) > 0 and bool(torch.isfinite(g).all())
