@@ -345,7 +345,9 @@ NUSC_CASES = {
 
 # forward_train cases: name -> (problem of make_problem, head kind, number of ground-truth boxes, seed)
 FWD_TRAIN_CASES = {'train_micro_t': ('micro_t', 'T', 5, 21), 'train_cfg1_t': ('cfg1_t', 'T', 9, 22), 'train_micro_s': ('micro_s', 'S', 4, 23),
-                   'train_cfg1_s': ('cfg1_s', 'S', 30, 24)}
+                   'train_cfg1_s': ('cfg1_s', 'S', 30, 24),
+                   # the S head with denoising queries (use_denoise=True: not a shipped config, but what MV2DSHead's training branch does)
+                   'train_micro_s_dn': ('micro_s', 'S+DN', 6, 25)}
 
 
 def make_train_gt(G, seed):

@@ -83,7 +83,11 @@ def main():
     import torch.nn as nn
     for name, (prob_name, kind, G, seed) in synthetic.FWD_TRAIN_CASES.items():
         prob = synthetic.make_problem(prob_name, seed=0)
+        with_dn = kind.endswith('+DN')
+        kind = kind[0]
         h = build_reference_head(kind, S_cls, T_cls, synthetic.make_head_state(seed=0), prob['views_per_frame'], train_cfg=configs.TRAIN_CFG_RCNN)
+        if with_dn:
+            h.use_denoise = True
         cfgk = (configs.roi_head_cfg_s() if kind == 'S' else configs.roi_head_cfg_t())['bbox_head']
         _stubs_train.arm_bbox_head(h.bbox_head, Assigner, configs.TRAIN_CFG_RCNN, cfgk['loss_cls'], cfgk['loss_bbox'])
         h.train()

@@ -177,9 +177,12 @@ def test_forward_train_losses_match_reference(name):
     gold = load_golden('train_loss')
     prob_name, kind, G, seed = synthetic.FWD_TRAIN_CASES[name]
     prob = synthetic.make_problem(prob_name, seed=0)
+    with_dn, kind = kind.endswith('+DN'), kind[0]
     cfg = configs.roi_head_cfg_s() if kind == 'S' else configs.roi_head_cfg_t()
     if kind == 'T':
         cfg['num_views'] = prob['views_per_frame']
+    if with_dn:
+        cfg['use_denoise'] = True
     head = registry.build_head(cfg, train_cfg=configs.TRAIN_CFG_RCNN, test_cfg=configs.TEST_CFG_RCNN)
     head.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_head_state(seed=0).items()}, strict=False)
     head = head.to(DEV)
@@ -199,7 +202,7 @@ def test_forward_train_losses_match_reference(name):
     eng = head.engine(feat.device, metas)
     out = eng.run(feat, [p[:, :6] for p in props], metas)
     R, pad = out['R'], 0
-    if kind == 'T':
+    if kind == 'T' or with_dn:
         gt, labels = torch.from_numpy(gtc['gt']).to(DEV), torch.from_numpy(gtc['gt_labels']).to(DEV)
         padded, _, md = train.prepare_for_dn(out['ws']['ref'][:R], gt, labels, head.denoise_scalar, head.denoise_noise_scale,
                                              head.denoise_noise_trans, head.denoise_split, 10, list(head.pc_range), rnd=rnd, dense_mask=False)
@@ -227,9 +230,12 @@ def test_forward_train_gradients_match_reference(name):
     gold = load_golden('train_loss')
     prob_name, kind, G, seed = synthetic.FWD_TRAIN_CASES[name]
     prob = synthetic.make_problem(prob_name, seed=0)
+    with_dn, kind = kind.endswith('+DN'), kind[0]
     cfg = configs.roi_head_cfg_s() if kind == 'S' else configs.roi_head_cfg_t()
     if kind == 'T':
         cfg['num_views'] = prob['views_per_frame']
+    if with_dn:
+        cfg['use_denoise'] = True
     head = registry.build_head(cfg, train_cfg=configs.TRAIN_CFG_RCNN, test_cfg=configs.TEST_CFG_RCNN)
     head.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_head_state(seed=0).items()}, strict=False)
     head = head.to(DEV)
@@ -329,9 +335,12 @@ def test_a_few_optimizer_steps_reduce_the_loss(kind, prob_name):
     from mv2d_amd import registry
     import mv2d_amd.plugin  # noqa: F401
     prob = synthetic.make_problem(prob_name, seed=0)
+    with_dn, kind = kind.endswith('+DN'), kind[0]
     cfg = configs.roi_head_cfg_s() if kind == 'S' else configs.roi_head_cfg_t()
     if kind == 'T':
         cfg['num_views'] = prob['views_per_frame']
+    if with_dn:
+        cfg['use_denoise'] = True
     head = registry.build_head(cfg, train_cfg=configs.TRAIN_CFG_RCNN, test_cfg=configs.TEST_CFG_RCNN)
     head.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_head_state(seed=0).items()}, strict=False)
     head = head.to(DEV)
@@ -360,9 +369,12 @@ def test_forward_train_without_ground_truth(kind, prob_name):
     from mv2d_amd import registry
     import mv2d_amd.plugin  # noqa: F401
     prob = synthetic.make_problem(prob_name, seed=0)
+    with_dn, kind = kind.endswith('+DN'), kind[0]
     cfg = configs.roi_head_cfg_s() if kind == 'S' else configs.roi_head_cfg_t()
     if kind == 'T':
         cfg['num_views'] = prob['views_per_frame']
+    if with_dn:
+        cfg['use_denoise'] = True
     head = registry.build_head(cfg, train_cfg=configs.TRAIN_CFG_RCNN, test_cfg=configs.TEST_CFG_RCNN)
     head.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_head_state(seed=0).items()}, strict=False)
     head = head.to(DEV)

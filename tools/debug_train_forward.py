@@ -12,9 +12,12 @@ DEV = 'cuda'
 gold = load_golden('train_loss')
 for name, (prob_name, kind, G, seed) in synthetic.FWD_TRAIN_CASES.items():
     prob = synthetic.make_problem(prob_name, seed=0)
+    with_dn, kind = kind.endswith('+DN'), kind[0]
     cfg = configs.roi_head_cfg_s() if kind == 'S' else configs.roi_head_cfg_t()
     if kind == 'T':
         cfg['num_views'] = prob['views_per_frame']
+    if with_dn:
+        cfg['use_denoise'] = True
     head = registry.build_head(cfg, train_cfg=configs.TRAIN_CFG_RCNN, test_cfg=configs.TEST_CFG_RCNN)
     head.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_head_state(seed=0).items()}, strict=False)
     head = head.to(DEV)
