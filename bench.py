@@ -28,11 +28,15 @@ PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X
 PEAK_HBM_GBS = 8000.0
 
 
+SINE_TABLE = os.environ.get('MV2D_PE_SINE_TABLE', '0') == '1'      # opt-in experiment: the sine branch of the PE block from a table
+
+
 def stage_flops(kind, R, S, L=6):
     """Algorithmic FLOPs (2 x MAC) of the dense bf16 MFMA launches of one frame."""
     C = 256
+    sine = 0 if SINE_TABLE else 384 * 1024 + 1024 * 256
     return {
-        'pe_fused': 2.0 * S * (192 * 1024 + 384 * 1024 + 2 * 1024 * 256 + 2 * 256 * 256),     # 2.49 MFLOP per key position
+        'pe_fused': 2.0 * S * (192 * 1024 + 1024 * 256 + 2 * 256 * 256 + sine),                # 2.49 MFLOP per key position
         'qg_conv_gemm': 2.0 * R * 49 * 2304 * 256,
         'kv_gemm': 2.0 * (S if kind == 'T' else R * 49) * C * (2 * L * C),
     }
@@ -44,7 +48,8 @@ def stage_bytes(kind, R, S, L=6):
     Mkv = S if kind == 'T' else R * 49
     return {
         # inputs (A1, A2, Xf bf16, Xf fp32) + the six weight matrices once + pe fp32 and Xk bf16 out
-        'pe_fused': S * (192 + 384 + 256) * 2 + S * 256 * 4 + (192 * 1024 + 384 * 1024 + 2 * 1024 * 256 + 2 * 256 * 256) * 2 + S * 256 * 6,
+        'pe_fused': (S * (192 + 256) * 2 + S * 256 * 4 * 2 + (192 * 1024 + 1024 * 256 + 2 * 256 * 256) * 2 + S * 256 * 6) if SINE_TABLE else
+                    (S * (192 + 384 + 256) * 2 + S * 256 * 4 + (192 * 1024 + 384 * 1024 + 2 * 1024 * 256 + 2 * 256 * 256) * 2 + S * 256 * 6),
         'qg_conv_gemm': R * 49 * 256 * 2 + 2304 * 256 * 2 + R * 256 * 4,                       # pooled [R,256] output
         'kv_gemm': 2 * Mkv * C * 2 + 2 * L * C * C * 2 + Mkv * 2 * L * C * 2,
     }
@@ -258,7 +263,7 @@ def main():
             'config': {'workload': f'{args.workload}: MV2D-{kind} head, {len(metas)} views {metas[0]["img_shape"][1]}x{metas[0]["img_shape"][0]}, '
                                    f'R={R} queries, S={S} key positions, nnz={nnz} allowed (q,k) pairs' + (f' (totals of the {B} samples of a launch)' if B > 1 else '') + (f', corr_topk={args.corr_topk}' if args.corr_topk else '') + (f', forced n_c={args.force_nc}' if args.force_nc else ''),
                        'frames_per_step_per_gpu': args.inflight * B, 'global_batch': world * args.inflight * B,
-                       'streams_per_gpu': args.inflight, 'samples_per_launch': B,
+                       'streams_per_gpu': args.inflight, 'samples_per_launch': B, **({'pe_sine_branch': 'per-geometry table (opt-in MV2D_PE_SINE_TABLE=1, not the default path)'} if SINE_TABLE else {}),
                        'parallelism': f'dp{world}', 'hipgraph': use_graph},
             'decoder_ms_per_iter': round(decoder_ms / B, 4), 'decoder_ms_per_launch': round(decoder_ms, 4),
             'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},

@@ -78,6 +78,15 @@ int mv2d_pe_fused(const void* A1, const void* A2, const void* Xfb, const float* 
                   const void* W2a, const float* b2a, const void* W2b, const float* b2b,
                   const void* Wr, const float* br, const void* We, const float* be, float* pe, void* Xk, void* stream);
 
+/* Opt-in variant (not the default path, DESIGN.md section 8 "the sine branch is a constant"): the adapt_pos3d(sine) branch of the PE block
+ * depends only on the weights and on the padding geometry, so it is read from sine_tab [tab_period][256] fp32 = adapt_pos3d(sine)(position)
+ * + b2b, indexed by the key's map position (row_index[m], or m) modulo tab_period (= positions of one sample when the samples of a batch
+ * share their geometry).  pe = position_encoder(A1) * gate + sine_tab[position]. */
+int mv2d_pe_fused_tab(const void* A1, const void* Xfb, const float* Xf32, const int* row_index, const int* m_dev, int M,
+                      const void* W1a, const float* b1a, const void* W1b, const float* b1b,
+                      const void* Wr, const float* br, const void* We, const float* be,
+                      const float* sine_tab, int tab_period, float* pe, void* Xk, void* stream);
+
 /* QueryGenerator shared conv + pooling fused, one block per RoI (RH/utils/query_generator.py:298-304,322-331,352-358):
  * out[r, n] = mean over the 49 cells of relu(conv3x3(roi_feat[r])[cell, n] + bias[n]).  roi_feat [R,49,256] bf16 (cell-major),
  * Wp = the conv weight [256][tap][cin] (bf16, K = 2304) in FRAGMENT-MAJOR order as produced by mv2d_pack_wfrag_bf16 (weights are

@@ -25,6 +25,7 @@ SIGNATURES = {
     'mv2d_spin': (I, [I, P]),
     'mv2d_gemm_bf16': (I, [P, P, I, I, P, P, I, I, I, I, P, I, P, I, P, I, P, I, I, LL, I, P, P, I, I, P]),
     'mv2d_pe_fused': (I, [P, P, P, P, P, P, I] + [P] * 14 + [P]),
+    'mv2d_pe_fused_tab': (I, [P, P, P, P, P, I] + [P] * 9 + [I, P, P, P]),
     'mv2d_qg_conv_pool': (I, [P, P, P, P, I, I, P]),
     'mv2d_pack_wfrag_bf16': (I, [P, P, I, I, P]),
     'mv2d_kv_proj': (I, [P, P, I, I, P, P, I, I, P, P, I, LL, I, P]),

@@ -49,6 +49,7 @@ struct PeParams {
     const unsigned short* W2a; const float* b2a; const unsigned short* W2b; const float* b2b;
     const unsigned short* Wr; const float* br; const unsigned short* We; const float* be;
     float* pe; unsigned short* Xk;
+    const float* sine_tab; int tab_period;      // TAB variant: adapt_pos3d(sine) + b2b per map position (a constant of weights + padding geometry)
 };
 
 // ---- building blocks -------------------------------------------------------------------------------------------------------
@@ -214,6 +215,8 @@ __device__ __forceinline__ void zero_acc(f32x4_t (&acc)[RT][CT2]) {
         for (int j = 0; j < CT2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 }
 
+// TAB: the sine branch (stage 3, 80 of the 152 k-steps) is read from p.sine_tab[position % tab_period] instead of being evaluated.
+template <bool TAB>
 __global__ __launch_bounds__(64 * NW, 1) void pe_fused_kernel(PeParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + H_BYTES + B_FLOATS * 4];
     unsigned char* As = smem;
@@ -279,7 +282,10 @@ __global__ __launch_bounds__(64 * NW, 1) void pe_fused_kernel(PeParams p) {
         mlp_part<MlpA, 0, MlpA, 1, true, MID_NONE>(As, Hs, wA, Bs + B_1A, wA, acc, wq, lane, wave, cx, s0, s1, f);
     }
     cx.next_in = p.A2;
-    {
+    if (TAB) {
+        uint4 s0[MlpA::NST], s1[MlpA::NST];
+        mlp_part<MlpA, 1, MlpA, 1, false, MID_FINAL>(As, Hs, wA, Bs + B_1A, wA, acc, wq, lane, wave, cx, s0, s1, f);
+    } else {
         uint4 sa[MlpB::NST], sb[MlpB::NST];
         mlp_part<MlpA, 1, MlpB, 0, true, MID_STAGE>(As, Hs, wA, Bs + B_1A, wB, acc, wq, lane, wave, cx, sa, sb, f);
         stage_write<MlpB>(As, sa, sb, tid);
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pe_fused_kernel(PeParams p) {
     __syncthreads();
     // 3. P2 = adapt_pos3d(A2);  pe = (P2 + b) + g;  Xk = bf16(pe + feat)
     zero_acc(acc);
-    {
+    if (!TAB) {
         uint4 s0[MlpB::NST], s1[MlpB::NST];
         mlp_part<MlpB, 0, MlpB, 1, true, MID_NONE>(As, Hs, wB, Bs + B_2A, wB, acc, wq, lane, wave, cx, s0, s1, f);
         mlp_part<MlpB, 1, MlpB, 1, false, MID_FINAL>(As, Hs, wB, Bs + B_2A, wB, acc, wq, lane, wave, cx, s0, s1, f);
@@ -308,33 +314,36 @@ __global__ __launch_bounds__(64 * NW, 1) void pe_fused_kernel(PeParams p) {
     float* ot = reinterpret_cast<float*>(smem) + wave * (BM * 68);          // [BM rows][64 columns of this wave], pitch 68 floats
 #pragma unroll
     for (int j = 0; j < CT2; ++j) {
-        const float4 eb = *reinterpret_cast<const float4*>(Bs + B_2B + n0 + 16 * j);
+        const float4 eb = TAB ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(Bs + B_2B + n0 + 16 * j);
 #pragma unroll
         for (int i = 0; i < RT; ++i)
             *reinterpret_cast<float4*>(ot + (16 * i + fr) * 68 + 16 * j + 4 * fg) =
-                make_float4((acc[i][j][0] + eb.x) + g[i][j][0], (acc[i][j][1] + eb.y) + g[i][j][1],
-                            (acc[i][j][2] + eb.z) + g[i][j][2], (acc[i][j][3] + eb.w) + g[i][j][3]);
+                TAB ? make_float4(g[i][j][0], g[i][j][1], g[i][j][2], g[i][j][3])
+                    : make_float4((acc[i][j][0] + eb.x) + g[i][j][0], (acc[i][j][1] + eb.y) + g[i][j][1],
+                                  (acc[i][j][2] + eb.z) + g[i][j][2], (acc[i][j][3] + eb.w) + g[i][j][3]);
     }
     __builtin_amdgcn_wave_barrier();                         // the tile is read back by the same wave only
     {
         const int c4 = (lane & 15) * 4, r0 = lane >> 4;
         const long long gcol = wave * (CT2 * 16) + c4;
-        float4 fv[BM / 4];
-        if (p.row_index) {                                   // feature rows straight from the position-major map (row of key m = row_index[m])
-            int ri[BM / 4];
+        float4 fv[BM / 4], tv[BM / 4];
+        int ri[BM / 4];
 #pragma unroll
-            for (int k = 0; k < BM / 4; ++k) ri[k] = p.row_index[min(m0 + 4 * k + r0, M - 1)];
+        for (int k = 0; k < BM / 4; ++k) {                   // map position of key row m: row_index[m], or m itself (the whole map)
+            const int m = min(m0 + 4 * k + r0, M - 1);
+            ri[k] = p.row_index ? p.row_index[m] : m;
+        }
 #pragma unroll
-            for (int k = 0; k < BM / 4; ++k) fv[k] = *reinterpret_cast<const float4*>(p.Xf32 + (long long)ri[k] * C + gcol);
-        } else {
-#pragma unroll
-            for (int k = 0; k < BM / 4; ++k)
-                fv[k] = *reinterpret_cast<const float4*>(p.Xf32 + (long long)min(m0 + 4 * k + r0, M - 1) * C + gcol);
+        for (int k = 0; k < BM / 4; ++k) {
+            // feature rows straight from the position-major map when there is a row index, else from the gathered fp32 rows
+            fv[k] = *reinterpret_cast<const float4*>(p.Xf32 + (long long)(p.row_index ? ri[k] : min(m0 + 4 * k + r0, M - 1)) * C + gcol);
+            if (TAB) tv[k] = *reinterpret_cast<const float4*>(p.sine_tab + (long long)(ri[k] % p.tab_period) * C + gcol);
         }
 #pragma unroll
         for (int k = 0; k < BM / 4; ++k) {
             const int row = 4 * k + r0, m = m0 + row;
-            const float4 v = *reinterpret_cast<const float4*>(ot + row * 68 + c4);
+            float4 v = *reinterpret_cast<const float4*>(ot + row * 68 + c4);
+            if (TAB) v = make_float4(v.x + tv[k].x, v.y + tv[k].y, v.z + tv[k].z, v.w + tv[k].w);
             if (m < M) {
                 *reinterpret_cast<float4*>(p.pe + (long long)m * C + gcol) = v;
                 *reinterpret_cast<uint2*>(p.Xk + (long long)m * C + gcol) =
@@ -359,8 +368,25 @@ extern "C" int mv2d_pe_fused(const void* A1, const void* A2, const void* Xfb, co
     if (M == 0) return MV2D_OK;
     PeParams p{(const unsigned short*)A1, (const unsigned short*)A2, (const unsigned short*)Xfb, Xf32, row_index, m_dev, M,
                (const unsigned short*)W1a, b1a, (const unsigned short*)W1b, b1b, (const unsigned short*)W2a, b2a,
-               (const unsigned short*)W2b, b2b, (const unsigned short*)Wr, br, (const unsigned short*)We, be, pe, (unsigned short*)Xk};
-    hipLaunchKernelGGL(pe_fused_kernel, dim3(cdiv(M, BM)), dim3(64 * NW), 0, (hipStream_t)stream, p);
+               (const unsigned short*)W2b, b2b, (const unsigned short*)Wr, br, (const unsigned short*)We, be, pe, (unsigned short*)Xk, nullptr, 1};
+    hipLaunchKernelGGL(pe_fused_kernel<false>, dim3(cdiv(M, BM)), dim3(64 * NW), 0, (hipStream_t)stream, p);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_pe_fused_tab(const void* A1, const void* Xfb, const float* Xf32, const int* row_index, const int* m_dev, int M,
+                                 const void* W1a, const float* b1a, const void* W1b, const float* b1b,
+                                 const void* Wr, const float* br, const void* We, const float* be,
+                                 const float* sine_tab, int tab_period, float* pe, void* Xk, void* stream) {
+    MV2D_CHECK_ARG(A1 && Xfb && Xf32 && W1a && b1a && W1b && b1b && Wr && br && We && be && sine_tab && pe && Xk, "mv2d_pe_fused_tab: null pointer");
+    MV2D_CHECK_ARG(M >= 0 && tab_period > 0, "mv2d_pe_fused_tab: M must be >= 0 and tab_period > 0");
+    if (M == 0) return MV2D_OK;
+    // the bias staging reads b2a / b2b too: point them at valid memory (b1a has 1024 floats, b1b 256)
+    PeParams p{(const unsigned short*)A1, (const unsigned short*)A1, (const unsigned short*)Xfb, Xf32, row_index, m_dev, M,
+               (const unsigned short*)W1a, b1a, (const unsigned short*)W1b, b1b, (const unsigned short*)W1a, b1a,
+               (const unsigned short*)W1b, b1b, (const unsigned short*)Wr, br, (const unsigned short*)We, be, pe, (unsigned short*)Xk, sine_tab,
+               tab_period};
+    hipLaunchKernelGGL(pe_fused_kernel<true>, dim3(cdiv(M, BM)), dim3(64 * NW), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

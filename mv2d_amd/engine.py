@@ -71,6 +71,8 @@ class HeadEngine:
         self.ffn_x3 = os.environ.get('MV2D_FFN_X3', '1') == '1'   # FFN in bf16x3 split precision (fragment-major hi/lo weights); 0: exact fp32
         self.ffn_groups = int(os.environ.get('MV2D_FFN_G', '0'))   # hidden slices per FFN block (0: by the number of rows)
         self.pe_fused = os.environ.get('MV2D_PE_FUSED', '1') == '1'   # one fused launch for the PE block instead of six GEMMs
+        # opt-in experiment ("the sine branch is a constant"): adapt_pos3d(sine) from a per-geometry table
+        self.pe_sine_table = self.pe_fused and os.environ.get('MV2D_PE_SINE_TABLE', '0') == '1'
         self.force_nc = None          # bench only (S path): overwrite the correlation lists so that every query reads n_c RoIs
         # out_proj + residual + LayerNorm (+ q in_proj) as one row-fused kernel per attention (8 instead of 11 launches per layer),
         # its two linears in bf16x3 split precision (fp32-class: ~1e-5 relative).  MV2D_ROWS_X3=0: exact-fp32 fused kernel (slower than
@@ -381,6 +383,33 @@ class HeadEngine:
             # the calibration tables change only when img_metas change: upload them here (stream-ordered before the frame),
             # not once per frame
             ws['blob_d'].copy_(bh, non_blocking=True)
+        if self.pe_sine_table:
+            # the sine branch depends on the padding geometry of the samples only (not on calibration): rebuilt when that changes
+            skey = tuple(tuple((tuple(m['pad_shape'][:2]), tuple(m['img_shape'][:2])) for m in metas) for metas in metas_list)
+            if sh.get('sine_key') != skey:
+                same = all(k == skey[0] for k in skey)
+                P = V * h * w
+                Pt = P // B if same else P                                  # one sample's positions when all samples share the geometry
+                T, o, W_ = ws['tab'], ops, self.w
+                s2 = torch.arange(Pt, dtype=torch.int32, device=self.dev)
+                a1 = torch.empty((Pt, 3 * self.depth_num), device=self.dev, dtype=BF16)
+                a2 = torch.empty((Pt, 384), device=self.dev, dtype=BF16)
+                xb = torch.empty((Pt, C), device=self.dev, dtype=BF16)
+                o.pe_inputs(s2, torch.tensor([Pt], dtype=torch.int32, device=self.dev), Pt, ws['featcl'], T['img2lidar'], T['coords_w'], T['coords_h'],
+                            T['coords_d'], T['embeds'], self.const['dim_t'], a1, a2, xb, None, V, h, w, self.depth_num, self.post_range_h64)
+                h2 = o.gemm_bf16(a2, W_['pe_w2a'], W_['pe_b2a'], act=1)
+                tab = o.gemm_bf16(h2, W_['pe_w2b'], W_['pe_b2b'], out_dtype=torch.float32)
+                # kept with the tables the workspaces of this map shape share; a captured graph holds the pointer: same shape -> refreshed in place
+                if sh.get('sine_tab') is None or sh['sine_tab'].shape != tab.shape:
+                    sh['sine_tab'] = tab
+                    sh['sine_gen'] = sh.get('sine_gen', 0) + 1
+                else:
+                    sh['sine_tab'].copy_(tab)
+                sh['sine_period'] = Pt
+                sh['sine_key'] = skey
+            if ws.get('sine_gen') != sh['sine_gen']:
+                ws['sine_gen'] = sh['sine_gen']
+                ws.pop('graph', None)                                        # this workspace's graph was captured with another table
         ws['rois_h'].copy_(rois_h)
         ws['view_start_h'].copy_(torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32))
         ws['grp_start_h'].copy_(torch.tensor(grp, dtype=torch.int32))
@@ -470,7 +499,11 @@ class HeadEngine:
         md = ws['S_dev']
         tk('pe_fused')
         if self.pe_fused:
-            o.pe_fused(ws['A1'], ws['A2'], ws['Xf_b'], featcl, md, W_['pe_pack'], ws['pe'], ws['Xk'], M=P, row_index=ws['s2pos'])
+            if self.pe_sine_table:
+                o.pe_fused_tab(ws['A1'], ws['Xf_b'], featcl, md, W_['pe_pack'], ws['shared']['sine_tab'], ws['shared']['sine_period'], ws['pe'], ws['Xk'], M=P,
+                               row_index=ws['s2pos'])
+            else:
+                o.pe_fused(ws['A1'], ws['A2'], ws['Xf_b'], featcl, md, W_['pe_pack'], ws['pe'], ws['Xk'], M=P, row_index=ws['s2pos'])
         else:
             o.gemm_bf16(ws['A1'], W_['pe_w1a'], W_['pe_b1a'], m_dev=md, act=1, out=ws['H1'])
             o.gemm_bf16(ws['A2'], W_['pe_w2a'], W_['pe_b2a'], m_dev=md, act=1, out=ws['H2'])

@@ -298,6 +298,16 @@ def pe_fused(A1, A2, Xfb, Xf32, m_dev, wp, pe, Xk, M=None, row_index=None):
     return pe, Xk
 
 
+def pe_fused_tab(A1, Xfb, Xf32, m_dev, wp, sine_tab, tab_period, pe, Xk, M=None, row_index=None):
+    """pe_fused with the sine branch read from sine_tab [tab_period,256] fp32 (map position -> adapt_pos3d(sine) + bias); opt-in."""
+    _req(A1, BF16, 'A1'); _req(Xfb, BF16, 'Xfb'); _req(Xf32, torch.float32, 'Xf32'); _req(sine_tab, torch.float32, 'sine_tab')
+    M = A1.shape[0] if M is None else M
+    check(_lib.load().mv2d_pe_fused_tab(_p(A1), _p(Xfb), _p(Xf32), _p(row_index), _p(m_dev), M, _p(wp['w1a']), _p(wp['b1a']), _p(wp['w1b']),
+                                        _p(wp['b1b']), _p(wp['wr']), _p(wp['br']), _p(wp['we']), _p(wp['be']), _p(sine_tab), int(tab_period),
+                                        _p(pe), _p(Xk), _stream()), 'mv2d_pe_fused_tab')
+    return pe, Xk
+
+
 def pack_wfrag(W):
     """row-major bf16 weight [N,K] -> fragment-major copy (one MFMA fragment = one contiguous 1 KB)."""
     _req(W, BF16, 'W')

@@ -391,3 +391,36 @@ def test_engine_ragged_views(kind):
     for k, v in errs.items():
         assert v < TOL[k], (k, v)
     assert check_topk(out, st, eng) > 0.9
+
+
+@pytest.mark.parametrize('kind', ['S', 'T'])
+def test_sine_table_variant_matches_the_default_path(kind):
+    """Opt-in MV2D_PE_SINE_TABLE: adapt_pos3d(sine) read from a per-geometry table instead of evaluated per frame.
+    Same PE / keys / outputs as the default path up to the accumulation order of one MLP; also with a padded view and with a batch whose
+    samples differ in padding geometry (one table row per position of the whole batch then)."""
+    from mv2d_amd import engine as E
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.make_head_state(seed=0).items()}
+    name = 'cfg1_s' if kind == 'S' else 'cfg1_t'
+    prob = synthetic.make_problem(name, seed=0)
+    nv = prob['views_per_frame']
+    a = E.HeadEngine(sd, kind, 'cuda', num_views=nv)
+    b = E.HeadEngine(sd, kind, 'cuda', num_views=nv)
+    b.pe_sine_table = True
+    feat = torch.from_numpy(prob['feat']).cuda()
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    metas = prob['img_metas']
+    narrow = [dict(m, img_shape=(m['img_shape'][0], m['img_shape'][1] - 48, 3)) for m in metas]      # a padded strip on the right
+    for ms in (metas, narrow):
+        oa = a.run(feat, props, ms, keep_stages=True)
+        ob = b.run(feat, props, ms, keep_stages=True)
+        S = int(oa['stages']['S_dev'])
+        assert S == int(ob['stages']['S_dev']) and torch.equal(oa['stages']['s2pos'][:S], ob['stages']['s2pos'][:S])
+        pa, pb = oa['stages']['pe'][:S], ob['stages']['pe'][:S]
+        assert float((pa - pb).abs().max()) <= 2e-5 * float(pa.abs().max())
+        assert float((oa['cls'].float() - ob['cls'].float()).abs().max()) <= 2e-4 * float(oa['cls'].abs().max())
+        assert torch.equal(oa['labels'], ob['labels'])
+    # a batch of two samples with different padding geometry == the two single runs (bitwise, as for the default path)
+    single = [b.run(feat, props, ms)['cls'].clone() for ms in (metas, narrow)]
+    R = single[0].shape[1]
+    ob = b.run_batch([feat, feat], [props, props], [metas, narrow])
+    assert torch.equal(ob['cls'][:, :R], single[0][:, :R]) and torch.equal(ob['cls'][:, R:2 * R], single[1][:, :R])
