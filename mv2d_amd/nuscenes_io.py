@@ -6,14 +6,14 @@ timestamp, img_shape, pad_shape}; this module builds those from the on-disk reco
 * ``camera_geometry``        — ``CustomNuScenesDataset.get_data_info`` (test mode), mmdet3d_plugin/datasets/custom_nuscenes_dataset.py:100-163
 * ``sweep_camera_record``    — ``add_frame`` of tools/generate_sweep_pkl.py:32-82 (the sweep cameras in the key frame's lidar frame)
 * ``append_sweeps``          — ``LoadMultiViewImageFromMultiSweepsFiles.__call__``, mmdet3d_plugin/datasets/pipelines/loading.py:53-163
-* ``sample_augmentation`` / ``image_aug_matrix`` / ``resize_crop_flip`` — ``ResizeCropFlipImageMono`` (without the 2-D box branch),
+* ``sample_augmentation`` / ``image_aug_matrix`` / ``resize_crop_flip`` — ``ResizeCropFlipImageMono`` (incl. the 2-D box branch),
   mmdet3d_plugin/datasets/pipelines/transform_3d.py:456-591
 * ``split_view_metas``       — the per-view split of ``MV2D.simple_test``, mmdet3d_plugin/models/detectors/mv2d.py:232-246
 
 * ``global_rot_scale_trans`` — ``GlobalRotScaleTransImage`` (transform_3d.py:822-904); ``center_match`` — custom_nuscenes_dataset.py:199-208;
   ``pad_multi_view`` / ``normalize_multiview`` — ``PadMultiViewImage`` / ``NormalizeMultiviewImage`` (transform_3d.py:121-203)
 
-Out of this slice: image decoding itself (an ``imread`` callable is injected), the COCO-style 2-D annotation files of the training branch, and the
+Out of this slice: image decoding itself (an ``imread`` callable is injected), reading the COCO-style 2-D annotation files of the training branch, and the
 result JSON (``_format_bbox`` / nuScenes eval live in mmdet3d and the nuscenes devkit, not in the reference tree).
 """
 import numpy as np
@@ -182,7 +182,38 @@ def image_aug_matrix(resize, crop, flip, rotate):
     return m
 
 
-def resize_crop_flip(results, conf, training=False, rng=np.random, transform_images=True):
+def _aug_boxes_2d(boxes, resize, crop, flip, rotate, filter_small):
+    """The 2-D box side of ``ResizeCropFlipImageMono`` (transform_3d.py:607-664) for one view: resize, crop + clip, optional flip, rotate
+    (bounding box of the rotated corners, clipped).  Returns (boxes, keep) with ``keep`` the index list of the surviving input rows
+    (area > 64 after the crop and again after the rotation) when ``filter_small`` — the ignore boxes are only filtered after the crop and
+    neither clipped nor filtered after the rotation, as in the reference."""
+    b = boxes * resize
+    b[:, 0::2] = np.clip(b[:, 0::2], crop[0], crop[2]) - crop[0]
+    b[:, 1::2] = np.clip(b[:, 1::2], crop[1], crop[3]) - crop[1]
+    keep = np.nonzero((b[:, 2:] - b[:, :2]).prod(1) > 64)[0]
+    b = b[keep]
+    if flip:
+        f = b.copy()
+        wd = crop[2] - crop[0]
+        f[..., 0::4] = wd - b[..., 2::4]
+        f[..., 2::4] = wd - b[..., 0::4]
+        b = f
+    h = rotate / 180 * np.pi
+    A = np.array([[np.cos(h), np.sin(h)], [-np.sin(h), np.cos(h)]], np.float32)
+    t = np.array([crop[2] - crop[0], crop[3] - crop[1]], np.float32) / np.float32(2)
+    t = A @ (-t) + t
+    corners = np.stack([b[:, 0], b[:, 1], b[:, 0], b[:, 3], b[:, 2], b[:, 3], b[:, 2], b[:, 1]], axis=1).reshape(-1, 4, 2)
+    corners = corners @ A.T + t[None, None]
+    b = np.concatenate([corners.min(1), corners.max(1)], axis=1)
+    if filter_small:
+        b[:, 0::2] = np.clip(b[:, 0::2], 0, crop[2] - crop[0])
+        b[:, 1::2] = np.clip(b[:, 1::2], 0, crop[3] - crop[1])
+        k2 = np.nonzero((b[:, 2:] - b[:, :2]).prod(1) > 64)[0]
+        b, keep = b[k2], keep[k2]
+    return b, keep
+
+
+def resize_crop_flip(results, conf, training=False, rng=np.random, transform_images=True, with_bbox_2d=False, num_views=6):
     """``ResizeCropFlipImageMono.__call__`` (``with_bbox_2d=False``): one augmentation for all views; intrinsics[:3,:3] <- ida @ intrinsics
     [:3,:3] in place, lidar2img rebuilt as intrinsics @ extrinsics.T; the images go through PIL as in the reference when
     ``transform_images``."""
@@ -200,6 +231,17 @@ def resize_crop_flip(results, conf, training=False, rng=np.random, transform_ima
     for i in range(len(results['intrinsics'])):
         results['intrinsics'][i][:3, :3] = ida @ results['intrinsics'][i][:3, :3]
     results['lidar2img'] = [results['intrinsics'][i] @ results['extrinsics'][i].T for i in range(len(results['extrinsics']))]
+    if with_bbox_2d:
+        # the per-view 2-D ground truth of the key frame's views (transform_3d.py:593-674)
+        out = dict(gt_bboxes_2d=[], gt_labels_2d=[], gt_bboxes_2d_to_3d=[], gt_bboxes_ignore=[])
+        for i in range(min(len(results['intrinsics']), num_views)):
+            b, keep = _aug_boxes_2d(results['gt_bboxes_2d'][i], resize, crop, flip, rotate, True)
+            ign, _ = _aug_boxes_2d(results['gt_bboxes_ignore'][i], resize, crop, flip, rotate, False)
+            out['gt_bboxes_2d'].append(b)
+            out['gt_labels_2d'].append(results['gt_labels_2d'][i][keep])
+            out['gt_bboxes_2d_to_3d'].append(results['gt_bboxes_2d_to_3d'][i][keep])
+            out['gt_bboxes_ignore'].append(ign)
+        results.update(out)
     return results
 
 

@@ -382,3 +382,19 @@ class RecordingBoxes:
 
     def scale(self, ratio):
         self.calls.append(('scale', float(ratio)))
+
+
+def make_boxes_2d(num_views, seed, w=160, h=90):
+    """Per-view 2-D ground truth at the raw image size: boxes [n,4] (x1, y1, x2, y2) fp64 like the COCO-style annotation arrays, labels,
+    the index of the matching 3-D box, ignore boxes."""
+    g = _rng(seed + 900)
+    out = dict(gt_bboxes_2d=[], gt_labels_2d=[], gt_bboxes_2d_to_3d=[], gt_bboxes_ignore=[])
+    for _ in range(num_views):
+        n, m = int(g.integers(0, 7)), int(g.integers(0, 3))
+        for key, cnt in (('gt_bboxes_2d', n), ('gt_bboxes_ignore', m)):
+            xy = np.stack([g.uniform(-5, w - 10, cnt), g.uniform(-5, h - 8, cnt)], 1)
+            wh = np.stack([g.uniform(2, 70, cnt), g.uniform(2, 50, cnt)], 1)
+            out[key].append(np.concatenate([xy, xy + wh], 1))
+        out['gt_labels_2d'].append(g.integers(0, 10, n))
+        out['gt_bboxes_2d_to_3d'].append(g.integers(-1, 12, n))
+    return out

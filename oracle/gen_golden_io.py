@@ -112,6 +112,18 @@ def main():
         _, ida = r._img_transform(Image.fromarray(np.zeros((900, 1600, 3), np.uint8)), *args)
         rec[f'fullsize.{int(training)}.ida'] = ida.numpy()
         rec[f'fullsize.{int(training)}.args'] = np.array([args[0], *args[1], *args[2], float(args[3]), args[4]], np.float64)
+    # the 2-D box branch of ResizeCropFlipImageMono (with_bbox_2d=True), training-time augmentation incl. rotation and flip
+    for seed in (21, 22, 23):
+        info = synthetic.make_nusc_info(seed, n_sweeps=0)
+        fake_self = types.SimpleNamespace(load_separate=False, data_infos=[copy.deepcopy(info)], test_mode=True)
+        d = Dataset.get_data_info(fake_self, 0)
+        d['img'] = [fake_imread(p).astype(np.float32) for p in d['img_filename']]
+        d.update(synthetic.make_boxes_2d(6, seed))
+        np.random.seed(seed)
+        d = Resize(data_aug_conf=synthetic.NUSC_AUG_CONF_SMALL, training=True, with_bbox_2d=True, num_views=6)(d)
+        for k in ('gt_bboxes_2d', 'gt_labels_2d', 'gt_bboxes_2d_to_3d', 'gt_bboxes_ignore'):
+            for v in range(6):
+                rec[f'box2d.{seed}.{k}.{v}'] = np.asarray(d[k][v])
     # GlobalRotScaleTransImage (the matrices; the box object only records what it is asked to do) and center_match
     (Grst,) = install.extra
     for reverse in (False, True):

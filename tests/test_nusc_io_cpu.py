@@ -146,3 +146,19 @@ def test_pad_and_normalize():
     assert n['img'][0].dtype == np.float32 and np.allclose(n['img'][0], want, atol=1e-5)
     n2 = nio.normalize_multiview(dict(img=[imgs[0]]), mean, std, to_rgb=True)
     assert np.allclose(n2['img'][0], (imgs[0][..., ::-1].astype(np.float64) - np.array(mean)) / np.array(std), atol=1e-5)
+
+
+@pytest.mark.parametrize('seed', [21, 22, 23])
+def test_resize_crop_flip_with_2d_boxes_matches_reference(seed):
+    info = synthetic.make_nusc_info(seed, n_sweeps=0)
+    d = nio.camera_geometry(info)
+    d['img'] = [synthetic.fake_image(p).astype(np.float32) for p in d['img_filename']]
+    d.update(synthetic.make_boxes_2d(6, seed))
+    np.random.seed(seed)
+    d = nio.resize_crop_flip(d, synthetic.NUSC_AUG_CONF_SMALL, training=True, with_bbox_2d=True, num_views=6)
+    for k in ('gt_bboxes_2d', 'gt_labels_2d', 'gt_bboxes_2d_to_3d', 'gt_bboxes_ignore'):
+        for v in range(6):
+            want = GOLD[f'box2d.{seed}.{k}.{v}']
+            got = np.asarray(d[k][v])
+            assert got.shape == want.shape, (k, v, got.shape, want.shape)
+            assert np.allclose(got, want, rtol=1e-6, atol=1e-4), (k, v)
