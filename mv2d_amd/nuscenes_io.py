@@ -13,6 +13,9 @@ timestamp, img_shape, pad_shape}; this module builds those from the on-disk reco
 * ``global_rot_scale_trans`` — ``GlobalRotScaleTransImage`` (transform_3d.py:822-904); ``center_match`` — custom_nuscenes_dataset.py:199-208;
   ``pad_multi_view`` / ``normalize_multiview`` — ``PadMultiViewImage`` / ``NormalizeMultiviewImage`` (transform_3d.py:121-203)
 
+* ``parse_ann_2d`` / ``attach_2d_annotations`` — ``get_ann_info_2d`` and the training branch of ``get_data_info``
+  (custom_nuscenes_dataset.py:165-196,262-322)
+
 Out of this slice: image decoding itself (an ``imread`` callable is injected), reading the COCO-style 2-D annotation files of the training branch, and the
 result JSON (``_format_bbox`` / nuScenes eval live in mmdet3d and the nuscenes devkit, not in the reference tree).
 """
@@ -329,3 +332,49 @@ def normalize_multiview(results, mean, std, to_rgb=True):
     results['img'] = out
     results['img_norm_cfg'] = dict(mean=mean, std=std, to_rgb=to_rgb)
     return results
+
+
+def parse_ann_2d(img_info_2d, ann_info_2d, cat_ids, cat2label):
+    """``CustomNuScenesDataset.get_ann_info_2d`` (custom_nuscenes_dataset.py:262-322): the COCO-style per-image annotation list (dicts with
+    ``bbox`` = x, y, w, h, ``area``, ``category_id``, ``bbox_cam3d``, optional ``ignore`` / ``iscrowd``) -> boxes (x1, y1, x2, y2), labels,
+    camera-frame 3-D boxes and ignore boxes.  Boxes outside the image, degenerate boxes and unknown categories are dropped."""
+    boxes, labels, ignore, cam3d = [], [], [], []
+    for ann in ann_info_2d:
+        if ann.get('ignore', False):
+            continue
+        x1, y1, w, h = ann['bbox']
+        inter_w = max(0, min(x1 + w, img_info_2d['width']) - max(x1, 0))
+        inter_h = max(0, min(y1 + h, img_info_2d['height']) - max(y1, 0))
+        if inter_w * inter_h == 0 or ann['area'] <= 0 or w < 1 or h < 1 or ann['category_id'] not in cat_ids:
+            continue
+        box = [x1, y1, x1 + w, y1 + h]
+        if ann.get('iscrowd', False):
+            ignore.append(box)
+        else:
+            boxes.append(box)
+            labels.append(cat2label[ann['category_id']])
+            cam3d.append(np.array(ann['bbox_cam3d']).reshape(1, -1).squeeze())
+    return dict(bboxes_cam=np.array(cam3d, dtype=np.float32) if cam3d else np.zeros((0, 6), np.float32),
+                bboxes_2d=np.array(boxes, dtype=np.float32) if boxes else np.zeros((0, 4), np.float32),
+                gt_bboxes_ignore=np.array(ignore, dtype=np.float32) if ignore else np.zeros((0, 4), np.float32),
+                labels=np.array(labels, dtype=np.int64))
+
+
+def attach_2d_annotations(input_dict, anns_2d, centers_lidar, gt_labels_3d):
+    """Training branch of ``get_data_info`` (custom_nuscenes_dataset.py:165-196): per view, the 2-D annotations of that image
+    (``parse_ann_2d`` results, in ``img_filename`` order) and the index of the 3-D box each belongs to — the camera-frame centre of the
+    annotation against the lidar-frame gravity centres moved into that camera (``center_match``).  Returns the four lists the reference
+    puts into ``ann_info``; raises if a matched pair disagrees on the label (the reference asserts)."""
+    out = dict(gt_bboxes_2d=[], gt_labels_2d=[], gt_bboxes_2d_to_3d=[], gt_bboxes_ignore=[])
+    hom = np.concatenate([centers_lidar, np.ones((len(centers_lidar), 1))], axis=1)
+    for cam_i, ann in enumerate(anns_2d):
+        lidar2cam = input_dict['extrinsics'][cam_i].T
+        centers_cam = (hom @ lidar2cam.T)[:, :3]
+        match = center_match(ann['bboxes_cam'], centers_cam)
+        if not (ann['labels'][match > -1] == np.asarray(gt_labels_3d)[match[match > -1]]).all():
+            raise AssertionError('a 2-D annotation and the 3-D box at the same centre disagree on the class')
+        out['gt_bboxes_2d'].append(ann['bboxes_2d'])
+        out['gt_bboxes_2d_to_3d'].append(match)
+        out['gt_labels_2d'].append(ann['labels'])
+        out['gt_bboxes_ignore'].append(ann['gt_bboxes_ignore'])
+    return out

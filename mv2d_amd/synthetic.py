@@ -398,3 +398,33 @@ def make_boxes_2d(num_views, seed, w=160, h=90):
         out['gt_labels_2d'].append(g.integers(0, 10, n))
         out['gt_bboxes_2d_to_3d'].append(g.integers(-1, 12, n))
     return out
+
+
+def make_ann_2d_case(info, seed, n_boxes=7):
+    """COCO-style 2-D annotations for the six images of an info record, consistent with a set of 3-D boxes: every annotation's
+    ``bbox_cam3d`` starts with the box centre in that camera's frame.  Includes an ignored, a crowd, an out-of-image, a degenerate and an
+    unknown-category annotation."""
+    g = _rng(seed + 1700)
+    centers = np.concatenate([g.uniform(-30, 30, (n_boxes, 2)), g.uniform(-2, 1, (n_boxes, 1))], 1)
+    labels3d = g.integers(0, 10, n_boxes)
+    cat_ids = [11, 12, 13, 14, 15, 16, 17, 18, 19, 20]
+    cat2label = {c: i for i, c in enumerate(cat_ids)}
+    images = {}
+    for _cam, c in info['cams'].items():
+        r = np.linalg.inv(c['sensor2lidar_rotation'])
+        t = c['sensor2lidar_translation'] @ r.T
+        cam = centers @ r.T - t                                   # lidar -> camera (row vectors), as get_data_info builds lidar2cam
+        anns = []
+        for j in g.permutation(n_boxes)[:int(g.integers(2, n_boxes + 1))]:
+            x, y = float(g.uniform(0, 1400)), float(g.uniform(0, 800))
+            w, h = float(g.uniform(5, 300)), float(g.uniform(5, 200))
+            anns.append(dict(bbox=[x, y, w, h], area=w * h, category_id=cat_ids[int(labels3d[j])],
+                             bbox_cam3d=[*cam[j].tolist(), 1.0, 2.0, 3.0], iscrowd=0))
+        anns.append(dict(bbox=[10., 10., 50., 50.], area=2500., category_id=11, bbox_cam3d=[0, 0, 0, 1, 1, 1], ignore=True))
+        anns.append(dict(bbox=[100., 100., 80., 60.], area=4800., category_id=12, bbox_cam3d=[0, 0, 0, 1, 1, 1], iscrowd=1))
+        anns.append(dict(bbox=[1700., 100., 80., 60.], area=4800., category_id=12, bbox_cam3d=[0, 0, 0, 1, 1, 1]))
+        anns.append(dict(bbox=[200., 100., 0.5, 60.], area=30., category_id=12, bbox_cam3d=[0, 0, 0, 1, 1, 1]))
+        anns.append(dict(bbox=[300., 100., 40., 60.], area=2400., category_id=99, bbox_cam3d=[0, 0, 0, 1, 1, 1]))
+        order = g.permutation(len(anns))
+        images[c['data_path']] = (dict(width=1600, height=900, file_name=c['data_path']), [anns[i] for i in order])
+    return dict(images=images, centers_lidar=centers, gt_labels_3d=labels3d, cat_ids=cat_ids, cat2label=cat2label)

@@ -124,6 +124,25 @@ def main():
         for k in ('gt_bboxes_2d', 'gt_labels_2d', 'gt_bboxes_2d_to_3d', 'gt_bboxes_ignore'):
             for v in range(6):
                 rec[f'box2d.{seed}.{k}.{v}'] = np.asarray(d[k][v])
+    # get_ann_info_2d and the training branch of get_data_info (2-D annotations matched to the 3-D boxes by their camera-frame centre)
+    for seed in (31, 32):
+        info = synthetic.make_nusc_info(seed, n_sweeps=0)
+        case = synthetic.make_ann_2d_case(info, seed)
+        fs = types.SimpleNamespace(load_separate=False, data_infos=[copy.deepcopy(info)], test_mode=False, cat_ids=case['cat_ids'],
+                                   cat2label=case['cat2label'])
+        parsed = {}
+        for path, (img_info, anns) in case['images'].items():
+            parsed[path] = Dataset.get_ann_info_2d(fs, img_info, anns)
+        fs.impath_to_ann2d = lambda p: parsed[p]
+        fs.center_match = lambda a, b: Dataset.center_match(fs, a, b)
+        fs.get_ann_info = lambda idx: dict(gt_bboxes_3d=types.SimpleNamespace(gravity_center=__import__('torch').from_numpy(case['centers_lidar'])),
+                                           gt_labels_3d=case['gt_labels_3d'])
+        d = Dataset.get_data_info(fs, 0)
+        for v, path in enumerate(d['img_filename']):
+            for k in ('bboxes_cam', 'bboxes_2d', 'gt_bboxes_ignore', 'labels'):
+                rec[f'ann2d.{seed}.parse.{v}.{k}'] = parsed[path][k]
+            for k in ('gt_bboxes_2d', 'gt_labels_2d', 'gt_bboxes_2d_to_3d', 'gt_bboxes_ignore'):
+                rec[f'ann2d.{seed}.info.{v}.{k}'] = np.asarray(d['ann_info'][k][v])
     # GlobalRotScaleTransImage (the matrices; the box object only records what it is asked to do) and center_match
     (Grst,) = install.extra
     for reverse in (False, True):

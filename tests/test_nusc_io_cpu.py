@@ -162,3 +162,22 @@ def test_resize_crop_flip_with_2d_boxes_matches_reference(seed):
             got = np.asarray(d[k][v])
             assert got.shape == want.shape, (k, v, got.shape, want.shape)
             assert np.allclose(got, want, rtol=1e-6, atol=1e-4), (k, v)
+
+
+@pytest.mark.parametrize('seed', [31, 32])
+def test_2d_annotations_parse_and_match_like_the_reference(seed):
+    info = synthetic.make_nusc_info(seed, n_sweeps=0)
+    case = synthetic.make_ann_2d_case(info, seed)
+    d = nio.camera_geometry(copy.deepcopy(info))
+    parsed = [nio.parse_ann_2d(*case['images'][p], case['cat_ids'], case['cat2label']) for p in d['img_filename']]
+    for v, a in enumerate(parsed):
+        for k in ('bboxes_cam', 'bboxes_2d', 'gt_bboxes_ignore', 'labels'):
+            want = GOLD[f'ann2d.{seed}.parse.{v}.{k}']
+            assert a[k].dtype == want.dtype and np.array_equal(a[k], want), (v, k)
+    out = nio.attach_2d_annotations(d, parsed, case['centers_lidar'], case['gt_labels_3d'])
+    n_matched = 0
+    for v in range(6):
+        for k in ('gt_bboxes_2d', 'gt_labels_2d', 'gt_bboxes_2d_to_3d', 'gt_bboxes_ignore'):
+            assert np.array_equal(np.asarray(out[k][v]), GOLD[f'ann2d.{seed}.info.{v}.{k}']), (v, k)
+        n_matched += int((out['gt_bboxes_2d_to_3d'][v] > -1).sum())
+    assert n_matched > 0
