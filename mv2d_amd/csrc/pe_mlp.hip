@@ -326,24 +326,35 @@ __global__ __launch_bounds__(64 * NW, 1) void pe_fused_kernel(PeParams p) {
     {
         const int c4 = (lane & 15) * 4, r0 = lane >> 4;
         const long long gcol = wave * (CT2 * 16) + c4;
-        float4 fv[BM / 4], tv[BM / 4];
-        int ri[BM / 4];
+        float4 fv[BM / 4], tv[TAB ? BM / 4 : 1];
+        if (TAB) {
+            int ri[BM / 4];
 #pragma unroll
-        for (int k = 0; k < BM / 4; ++k) {                   // map position of key row m: row_index[m], or m itself (the whole map)
-            const int m = min(m0 + 4 * k + r0, M - 1);
-            ri[k] = p.row_index ? p.row_index[m] : m;
-        }
+            for (int k = 0; k < BM / 4; ++k) {               // map position of key row m: row_index[m], or m itself (the whole map)
+                const int m = min(m0 + 4 * k + r0, M - 1);
+                ri[k] = p.row_index ? p.row_index[m] : m;
+            }
 #pragma unroll
-        for (int k = 0; k < BM / 4; ++k) {
-            // feature rows straight from the position-major map when there is a row index, else from the gathered fp32 rows
-            fv[k] = *reinterpret_cast<const float4*>(p.Xf32 + (long long)(p.row_index ? ri[k] : min(m0 + 4 * k + r0, M - 1)) * C + gcol);
-            if (TAB) tv[k] = *reinterpret_cast<const float4*>(p.sine_tab + (long long)(ri[k] % p.tab_period) * C + gcol);
+            for (int k = 0; k < BM / 4; ++k) {
+                fv[k] = *reinterpret_cast<const float4*>(p.Xf32 + (long long)(p.row_index ? ri[k] : min(m0 + 4 * k + r0, M - 1)) * C + gcol);
+                tv[TAB ? k : 0] = *reinterpret_cast<const float4*>(p.sine_tab + (long long)(ri[k] % p.tab_period) * C + gcol);
+            }
+        } else if (p.row_index) {                            // feature rows straight from the position-major map (row of key m = row_index[m])
+            int ri[BM / 4];
+#pragma unroll
+            for (int k = 0; k < BM / 4; ++k) ri[k] = p.row_index[min(m0 + 4 * k + r0, M - 1)];
+#pragma unroll
+            for (int k = 0; k < BM / 4; ++k) fv[k] = *reinterpret_cast<const float4*>(p.Xf32 + (long long)ri[k] * C + gcol);
+        } else {
+#pragma unroll
+            for (int k = 0; k < BM / 4; ++k)
+                fv[k] = *reinterpret_cast<const float4*>(p.Xf32 + (long long)min(m0 + 4 * k + r0, M - 1) * C + gcol);
         }
 #pragma unroll
         for (int k = 0; k < BM / 4; ++k) {
             const int row = 4 * k + r0, m = m0 + row;
             float4 v = *reinterpret_cast<const float4*>(ot + row * 68 + c4);
-            if (TAB) v = make_float4(v.x + tv[k].x, v.y + tv[k].y, v.z + tv[k].z, v.w + tv[k].w);
+            if (TAB) v = make_float4(v.x + tv[TAB ? k : 0].x, v.y + tv[TAB ? k : 0].y, v.z + tv[TAB ? k : 0].z, v.w + tv[TAB ? k : 0].w);
             if (m < M) {
                 *reinterpret_cast<float4*>(p.pe + (long long)m * C + gcol) = v;
                 *reinterpret_cast<uint2*>(p.Xk + (long long)m * C + gcol) =
