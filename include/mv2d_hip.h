@@ -248,6 +248,28 @@ int mv2d_sparse_xattn_fwd(const float* q, const void* K, const void* V, const in
 int mv2d_raw_xattn_fwd(const float* qk, const void* Xk, const void* Xv, const int* row_ptr, const int* col_idx, float* z, int R,
                        int empty_nan, void* stream);
 
+/* ---- cross attention on MFMA tiles, K/V projections folded into the query side (the default route; csrc/xattn_tile.hip) ----
+ * Replaces PETRMultiheadAttention's in_proj of key / value + attention core (MU/petr_transformer.py:426-513,
+ * torch.nn.MultiheadAttention with attn_mask / key_padding_mask): no per-layer K/V is written.  Per layer three enqueues:
+ *
+ * mv2d_xattn_qmap: q [R,256] fp32 (query in_proj output, pre-scaled by 1/sqrt(32)) -> Qt [R][8][64][8] bf16: the per-head maps
+ *   Wk_h^T q_h of the query into the 256-dim key INPUT space as a 16 x 256 MFMA operand per query (rows 0-7: bf16 hi parts of
+ *   the 8 heads, rows 8-15: lo remainders), fragment-major.  WA_hi / WA_lo = the packed key in_proj weight
+ *   (mv2d_amd.ops.pack_xattn_maps: [8 heads][16 tiles][64 lanes][8] bf16, layout in csrc/xattn_tile.hip).
+ * mv2d_xattn_tile_fwd: one block per query; Xk / Xv [S,256] bf16 = the UNPROJECTED key / value input rows (key + key_pos, key)
+ *   shared by all layers and heads; CSR row_ptr [R+1] / col_idx [nnz]; z [R,8,256] fp32 = sum_j p_hj v_j per head.  Key tiles of
+ *   16 rows are gathered with whole-row coalesced loads into swizzled LDS tiles, logits and P.V run on bf16 MFMAs (hi / lo split
+ *   of the query map and of P: fp32-class on the query side), online softmax.  waves = 4 | 8 waves per query (0: default).
+ *   Rows without an allowed key: z = NaN (empty_nan = 1) or 0.  dbg_logits (optional): head h at dbg_logits[h*dbg_stride + e],
+ *   e in CSR order, WITHOUT the per-(query, head) constant q_h . bk_h that cancels in the softmax.
+ * mv2d_xattn_ctxmap: ctx [R,256] = Wv_h z_h + bv (bf16x3; WB_hi / WB_lo = the packed value in_proj weight); rows without an
+ *   allowed key (row_ptr) give NaN / 0 like nn.MultiheadAttention / the 'zero' policy of the engine. */
+int mv2d_xattn_qmap(const float* q, const void* WA_hi, const void* WA_lo, void* Qt, int R, void* stream);
+int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* Xv, const int* row_ptr, const int* col_idx, float* z,
+                        float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves, void* stream);
+int mv2d_xattn_ctxmap(const float* z, const void* WB_hi, const void* WB_lo, const float* bv, const int* row_ptr, float* ctx, int R,
+                      int empty_nan, void* stream);
+
 /* Backward of mv2d_sparse_xattn_fwd ("next" row f3, the training path of the head): given dctx [R,256] returns dq [R,256] (gradient
  * with respect to the pre-scaled q) and dK, dV [S,256] fp32 (every key row is written; keys nobody reads get 0).  Two launches, no
  * atomics, deterministic: a pass over the queries (softmax statistics recomputed, no forward state kept; writes dq and, per allowed pair

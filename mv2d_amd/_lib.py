@@ -15,7 +15,7 @@ class Mv2dHipError(RuntimeError):
 
 
 P, I, LL, F, D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
-ABI_VERSION = 2                  # include/mv2d_hip.h: mv2d_abi_version()
+ABI_VERSION = 3                  # include/mv2d_hip.h: mv2d_abi_version()
 
 # name -> (restype, argtypes) — mirrors include/mv2d_hip.h one to one
 SIGNATURES = {
@@ -57,6 +57,9 @@ SIGNATURES = {
     'mv2d_sparse_xattn_fwd': (I, [P, P, P, P, P, P, P, LL, I, I, P]),
     'mv2d_raw_xattn_fwd': (I, [P, P, P, P, P, P, I, I, P]),
     'mv2d_sparse_xattn_bwd': (I, [P] * 14 + [I, I, P]),
+    'mv2d_xattn_qmap': (I, [P, P, P, P, I, P]),
+    'mv2d_xattn_tile_fwd': (I, [P, P, P, P, P, P, P, LL, I, I, I, P]),
+    'mv2d_xattn_ctxmap': (I, [P, P, P, P, P, P, I, I, P]),
     'mv2d_box_params': (I, [P, P, P, P, P, I, P, I, F, F, F, P]),
     'mv2d_refpoint_posemb': (I, [P, I, P, P, P, P, P, I, P, P]),
     'mv2d_lidar2img_inverse': (I, [P, P, P, I, P]),

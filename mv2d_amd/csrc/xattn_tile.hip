@@ -1,0 +1,373 @@
+// Cross attention of the MV2D decoder on MFMA tiles, fused with the key / value projections (gfx950 / CDNA4, wave64).
+//
+// Replaces  kvproj_kernel (K/V of six layers written to HBM) + sparse_xattn_kernel (one VALU dot product per allowed pair)
+// for PETRMultiheadAttention's core (MU/petr_transformer.py:426-513, nn.MultiheadAttention with an attn_mask).
+//
+// The in_proj of the keys / values is folded into the QUERY side, so the key side of every layer and head reads the same two
+// bf16 row arrays (Xk = feat + pe, Xv = feat at the gathered positions / RoI cells) and nothing per layer is written for the keys:
+//
+//   logit_h[j] = q_h . (Wk_h x_j + bk_h)      = (Wk_h^T q_h) . x_j + const_h      (const_h cancels in the softmax over j)
+//   ctx_h      = sum_j p_hj (Wv_h v_j + bv_h) = Wv_h (sum_j p_hj v_j) + bv_h      (sum_j p_hj = 1)
+//
+// Three launches per layer:
+//   xattn_qmap_kernel    Qt[r] = (Wk_h^T q_h)_h as a 16 x 256 bf16 MFMA operand per query: rows 0-7 = bf16 "hi" parts of the
+//                        eight heads, rows 8-15 = the "lo" remainders (fp32-class query side), stored fragment-major.
+//   xattn_tile_kernel    one block per query, the keys of its CSR row dealt to the waves in tiles of 16: the tile's Xk rows are
+//                        gathered with whole-row (512 B) coalesced loads into an XOR-swizzled LDS tile, logits S[16 x 16] =
+//                        Qt . Xk_tile^T on v_mfma_f32_16x16x32_bf16 (hi and lo rows of Qt in one instruction: the sum of the
+//                        two row groups is the fp32-class logit), online softmax per head, P split hi / lo into the same 16
+//                        operand rows, z += P . Xv_tile on v_mfma_f32_16x16x16_bf16 with the Xv rows loaded row-contiguous
+//                        (16 B per lane) and transposed in registers (v_perm) into key-major B fragments.
+//   xattn_ctxmap_kernel  ctx = Wv_h z_h + bv (bf16x3), empty CSR rows -> NaN (the reference's behaviour) or 0.
+#include "common.h"
+
+namespace {
+
+constexpr int C = 256, HEADS = 8;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 xt_bf16x8;
+typedef __attribute__((ext_vector_type(4))) short xt_s16x4;
+union XtFrag { uint4 u; xt_bf16x8 v; };
+
+__device__ __forceinline__ void xt_split8(const float4& x0, const float4& x1, XtFrag& hi, XtFrag& lo) {
+    const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    unsigned int h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+        l[i] = pack_bf16x2(f[2 * i] - __uint_as_float(h[i] << 16), f[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
+    }
+    hi.u = make_uint4(h[0], h[1], h[2], h[3]);
+    lo.u = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// query map: Qt[r][s][16 g + n][e] = part_n( sum_d q[r][32 h + d] Wk[32 h + d][32 s + 8 g + e] ),  h = n & 7, part = hi (n < 8) / lo
+// Block = 16 queries, wave = head.  "Swapped" product D[channel][query] so that a lane ends up with 8 CONSECUTIVE channels of one
+// query (rows 4g..4g+3 of two channel tiles whose row -> channel assignment is interleaved by the weight packing) = exactly one
+// 16-byte chunk of the operand the tile kernel reads.
+//   WA_hi / WA_lo [8 heads][16 tiles][64 lanes][8]: lane (m = l & 15, g = l >> 4), e: Wk[32 h + 8 g + e][chan(t, m)],
+//   chan(t, m) = 32 (t >> 1) + 8 (m >> 2) + 4 (t & 1) + (m & 3)                                 (ops.pack_xattn_maps)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void xattn_qmap_kernel(const float* __restrict__ q, const uint4* __restrict__ WA_hi,
+                                                         const uint4* __restrict__ WA_lo, uint4* __restrict__ Qt, int R) {
+    const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * 16;
+    const int row = min(q0 + n, R - 1);
+    const float* qp = q + (long long)row * C + 32 * h + 8 * g;
+    XtFrag bh, bl;
+    xt_split8(*reinterpret_cast<const float4*>(qp), *reinterpret_cast<const float4*>(qp + 4), bh, bl);
+    const uint4* wh = WA_hi + (long long)h * 16 * 64 + lane;
+    const uint4* wl = WA_lo + (long long)h * 16 * 64 + lane;
+    f32x4_t acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        XtFrag ah, al;
+        ah.u = wh[t * 64];
+        al.u = wl[t * 64];
+        f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.v, bh.v, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bl.v, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bh.v, a, 0, 0, 0);
+        acc[t] = a;
+    }
+    if (q0 + n < R) {
+        uint4* out = Qt + ((long long)(q0 + n) * 8) * 64 + 16 * g + h;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            XtFrag hi, lo;
+            xt_split8(make_float4(acc[2 * u][0], acc[2 * u][1], acc[2 * u][2], acc[2 * u][3]),
+                      make_float4(acc[2 * u + 1][0], acc[2 * u + 1][1], acc[2 * u + 1][2], acc[2 * u + 1][3]), hi, lo);
+            out[u * 64] = hi.u;
+            out[u * 64 + 8] = lo.u;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// context map: ctx[r][32 h + d] = sum_c Wv[32 h + d][c] z[r][h][c] + bv[32 h + d]   (bf16x3: z split hi / lo, Wv split hi / lo)
+// Block = 16 queries, wave = head.  WB_hi / WB_lo [8 heads][8 k-steps][2 column tiles][64 lanes][8]:
+//   lane (n, g), e: Wv[32 h + 16 nt + n][32 s + 8 g + e]                                          (ops.pack_xattn_maps)
+// A CSR row without a key: ctx = NaN (empty_nan, like nn.MultiheadAttention) or 0 — the value bias must not reach such a query.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void xattn_ctxmap_kernel(const float* __restrict__ z, const uint4* __restrict__ WB_hi,
+                                                           const uint4* __restrict__ WB_lo, const float* __restrict__ bv,
+                                                           const int* __restrict__ row_ptr, float* __restrict__ ctx, int R, int empty_nan) {
+    const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * 16;
+    const int row = min(q0 + n, R - 1);
+    const float* zp = z + ((long long)row * HEADS + h) * C + 8 * g;
+    const uint4* wh = WB_hi + (long long)h * 16 * 64 + lane;
+    const uint4* wl = WB_lo + (long long)h * 16 * 64 + lane;
+    f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float4 x0[8], x1[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        x0[s] = *reinterpret_cast<const float4*>(zp + 32 * s);
+        x1[s] = *reinterpret_cast<const float4*>(zp + 32 * s + 4);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        XtFrag ah, al;
+        xt_split8(x0[s], x1[s], ah, al);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            XtFrag bh, bl;
+            bh.u = wh[(s * 2 + nt) * 64];
+            bl.u = wl[(s * 2 + nt) * 64];
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.v, bh.v, acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bl.v, acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bh.v, acc[nt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = q0 + 4 * g + i;
+        if (r < R) {
+            const bool empty = row_ptr[r + 1] <= row_ptr[r];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int col = 32 * h + 16 * nt + n;
+                float v = acc[nt][i] + bv[col];
+                if (empty) v = empty_nan ? __uint_as_float(0x7fc00000u) : 0.f;
+                ctx[(long long)r * C + col] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile attention: see the file header.  One block (NW waves) per query; wave w takes the key tiles w, w + NW, ...
+//   Qt  [R][8 k-steps][64 lanes][8] bf16 (xattn_qmap_kernel), Xk / Xv [S][256] bf16, CSR row_ptr / col_idx, z [R][8][256] fp32
+// LDS (one array): per wave an 8 KB key tile (16 rows x 32 chunks of 16 B, chunk c of row r at slot c ^ (r & 15): the
+// fragment reads of 16 different rows hit 16 different bank slots) that later holds the wave's partial z, 512 B of P, and the
+// softmax statistics of the merge.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int xt_lo_pair(unsigned int a, unsigned int b) { return (a & 0xffffu) | (b << 16); }          // (a.lo16, b.lo16): one v_perm_b32
+__device__ __forceinline__ unsigned int xt_hi_pair(unsigned int a, unsigned int b) { return (a >> 16) | (b & 0xffff0000u); }      // (a.hi16, b.hi16)
+
+template <int NW, bool DBG>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void xattn_tile_kernel(const uint4* __restrict__ Qt, const unsigned short* __restrict__ Xk,
+                                                             const unsigned short* __restrict__ Xv, const int* __restrict__ row_ptr,
+                                                             const int* __restrict__ col_idx, float* __restrict__ z,
+                                                             float* __restrict__ dbg_logits, long long dbg_stride, int R, int empty_nan) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NW * 8192 + NW * 512 + NW * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
+    // XCD-aware block -> query map (block b runs on XCD b % 8): every XCD gets one contiguous range of queries, so neighbouring
+    // queries (T path: overlapping key sets) share an L2.  Speed only; any map is correct.
+    int r;
+    {
+        const int b = blockIdx.x, x = b & 7, qn = R >> 3, rem = R & 7;
+        r = (x < rem ? x * (qn + 1) : rem * (qn + 1) + (x - rem) * qn) + (b >> 3);
+    }
+    const int beg = row_ptr[r], end = row_ptr[r + 1];
+    float* zr = z + (long long)r * (HEADS * C);
+    if (end <= beg) {
+        const float v = empty_nan ? __uint_as_float(0x7fc00000u) : 0.f;
+        for (int i = tid; i < HEADS * C; i += 64 * NW) zr[i] = v;
+        return;
+    }
+    uint4* kt = reinterpret_cast<uint4*>(smem) + wave * 512;
+    float* pl = reinterpret_cast<float*>(smem + NW * 8192) + wave * 128;
+    float* sst = reinterpret_cast<float*>(smem + NW * 8192 + NW * 512);              // [NW][8] running max, [NW][8] sums
+
+    // this lane's rows of S / z: operand rows 4g + i; rows 0-7 carry the hi parts, 8-15 the lo parts of head (4 (g & 1) + i)
+    float m_run[4], l_run[4];
+    f32x4_t Z[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { m_run[i] = -INFINITY; l_run[i] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) Z[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int ntile = (end - beg + 15) >> 4;
+    XtFrag qa[8];
+    if (wave < ntile) {
+        const uint4* qp = Qt + (long long)r * 512 + lane;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) qa[s].u = qp[s * 64];
+    }
+    for (int tt = wave; tt < ntile; tt += NW) {
+        const int kbase = beg + 16 * tt;
+        const int myidx = col_idx[min(kbase + n, end - 1)];                          // lane (n, *): key n of the tile
+        // ---- gather: Xk rows whole (lanes 0-31 one row, 32-63 the next), Xv rows as 16-byte column chunks of keys 4g..4g+3
+        uint4 kreg[8], vreg[4][2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ridx = __shfl(myidx, 2 * i + (lane >> 5), 64);
+            kreg[i] = *reinterpret_cast<const uint4*>(Xk + (long long)ridx * C + (lane & 31) * 8);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int vidx = __shfl(myidx, 4 * g + e, 64);
+            const unsigned short* vp = Xv + (long long)vidx * C + 8 * n;
+            vreg[e][0] = *reinterpret_cast<const uint4*>(vp);
+            vreg[e][1] = *reinterpret_cast<const uint4*>(vp + 128);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rowi = 2 * i + (lane >> 5);
+            kt[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = kreg[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- logits of the tile: D[row 4g+i][key n] = sum_c Qt[row][c] Xk[key][c]
+        f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            XtFrag kb;
+            kb.u = kt[n * 32 + ((4 * s + g) ^ n)];
+            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[s].v, kb.v, sacc, 0, 0, 0);
+        }
+        const bool valid = kbase + n < end;
+        float sv[4], p[4], alpha[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float full = sacc[i] + __shfl_xor(sacc[i], 32, 64);              // hi rows + lo rows: head 4 (g & 1) + i
+            if (DBG && dbg_logits && g < 2 && valid) dbg_logits[(long long)(4 * g + i) * dbg_stride + kbase + n] = full;
+            sv[i] = valid ? full : -INFINITY;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float tm = sv[i];
+            tm = fmaxf(tm, __shfl_xor(tm, 1, 64));
+            tm = fmaxf(tm, __shfl_xor(tm, 2, 64));
+            tm = fmaxf(tm, __shfl_xor(tm, 4, 64));
+            tm = fmaxf(tm, __shfl_xor(tm, 8, 64));
+            const float m_new = fmaxf(m_run[i], tm);
+            alpha[i] = expf(m_run[i] - m_new);
+            p[i] = expf(sv[i] - m_new);
+            l_run[i] = l_run[i] * alpha[i] + p[i];                                   // per-lane share of the row sum (reduced at the end)
+            m_run[i] = m_new;
+        }
+        // ---- P as the A operand of the 16x16x16 MFMA: lane (row n, g): keys 4g..4g+3 of head n & 7, hi (n < 8) or lo part
+        if (g < 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pl[(4 * g + i) * 16 + n] = p[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        xt_s16x4 pa;
+        {
+            const float4 pv = *reinterpret_cast<const float4*>(pl + (n & 7) * 16 + 4 * g);
+            const unsigned int h0 = pack_bf16x2(pv.x, pv.y), h1 = pack_bf16x2(pv.z, pv.w);
+            const unsigned int l0 = pack_bf16x2(pv.x - __uint_as_float(h0 << 16), pv.y - __uint_as_float(h0 & 0xffff0000u));
+            const unsigned int l1 = pack_bf16x2(pv.z - __uint_as_float(h1 << 16), pv.w - __uint_as_float(h1 & 0xffff0000u));
+            const uint2 sel = n < 8 ? make_uint2(h0, h1) : make_uint2(l0, l1);
+            pa = __builtin_bit_cast(xt_s16x4, sel);
+        }
+        // ---- z = alpha z + P . Xv_tile; column tile (H, w): output column n <-> channel 128 H + 8 n + w
+#pragma unroll
+        for (int H = 0; H < 2; ++H) {
+            const unsigned int r0[4] = {vreg[0][H].x, vreg[0][H].y, vreg[0][H].z, vreg[0][H].w};
+            const unsigned int r1[4] = {vreg[1][H].x, vreg[1][H].y, vreg[1][H].z, vreg[1][H].w};
+            const unsigned int r2[4] = {vreg[2][H].x, vreg[2][H].y, vreg[2][H].z, vreg[2][H].w};
+            const unsigned int r3[4] = {vreg[3][H].x, vreg[3][H].y, vreg[3][H].z, vreg[3][H].w};
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const int d = w >> 1;
+                const uint2 vb = (w & 1) ? make_uint2(xt_hi_pair(r0[d], r1[d]), xt_hi_pair(r2[d], r3[d]))
+                                         : make_uint2(xt_lo_pair(r0[d], r1[d]), xt_lo_pair(r2[d], r3[d]));
+                f32x4_t zc = Z[H * 8 + w];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) zc[i] *= alpha[i];
+                Z[H * 8 + w] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, __builtin_bit_cast(xt_s16x4, vb), zc, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                                             // before the next tile overwrites kt / pl
+    }
+    // ---- row sums over the 16 key lanes; partial (m, l, z) of the wave -> LDS (z into the wave's own key-tile region)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float l = l_run[i];
+        l += __shfl_xor(l, 1, 64);
+        l += __shfl_xor(l, 2, 64);
+        l += __shfl_xor(l, 4, 64);
+        l += __shfl_xor(l, 8, 64);
+        l_run[i] = l;
+    }
+    if (n == 0 && g < 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sst[wave * 8 + 4 * g + i] = m_run[i];
+            sst[NW * 8 + wave * 8 + 4 * g + i] = l_run[i];
+        }
+    }
+    {
+        float* szw = reinterpret_cast<float*>(smem) + wave * (HEADS * C);
+#pragma unroll
+        for (int H = 0; H < 2; ++H)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[8];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v[w] = Z[H * 8 + w][i] + __shfl_xor(Z[H * 8 + w][i], 32, 64);   // hi rows + lo rows
+                if (g < 2) {
+                    float* dst = szw + (4 * g + i) * C + 128 * H + 8 * n;
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
+    }
+    __syncthreads();
+    // ---- merge the waves: thread -> (channel, half of the heads)
+    {
+        const float* sz = reinterpret_cast<const float*>(smem);
+        constexpr int HPT = HEADS * C / (64 * NW);                                   // heads per thread
+        const int c = tid & (C - 1), h0 = (tid >> 8) * HPT;
+#pragma unroll
+        for (int hh = 0; hh < HPT; ++hh) {
+            const int h = h0 + hh;
+            float M = sst[h];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) M = fmaxf(M, sst[w * 8 + h]);
+            float den = 0.f, num = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float e = expf(sst[w * 8 + h] - M);                          // waves without a tile: exp(-inf) = 0
+                den += sst[NW * 8 + w * 8 + h] * e;
+                num += sz[(w * HEADS + h) * C + c] * e;
+            }
+            zr[h * C + c] = num / den;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mv2d_xattn_qmap(const float* q, const void* WA_hi, const void* WA_lo, void* Qt, int R, void* stream) {
+    MV2D_CHECK_ARG(q && WA_hi && WA_lo && Qt && R >= 0, "mv2d_xattn_qmap: bad args");
+    MV2D_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)WA_hi & 15) == 0 && ((uintptr_t)WA_lo & 15) == 0 && ((uintptr_t)Qt & 15) == 0,
+                   "mv2d_xattn_qmap: operands must be 16-byte aligned");
+    if (R == 0) return MV2D_OK;
+    hipLaunchKernelGGL(xattn_qmap_kernel, dim3(cdiv(R, 16)), dim3(512), 0, (hipStream_t)stream, q, (const uint4*)WA_hi, (const uint4*)WA_lo,
+                       (uint4*)Qt, R);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_xattn_ctxmap(const float* z, const void* WB_hi, const void* WB_lo, const float* bv, const int* row_ptr, float* ctx, int R,
+                                 int empty_nan, void* stream) {
+    MV2D_CHECK_ARG(z && WB_hi && WB_lo && bv && row_ptr && ctx && R >= 0, "mv2d_xattn_ctxmap: bad args");
+    MV2D_CHECK_ARG(((uintptr_t)z & 15) == 0 && ((uintptr_t)WB_hi & 15) == 0 && ((uintptr_t)WB_lo & 15) == 0, "mv2d_xattn_ctxmap: operands must be 16-byte aligned");
+    if (R == 0) return MV2D_OK;
+    hipLaunchKernelGGL(xattn_ctxmap_kernel, dim3(cdiv(R, 16)), dim3(512), 0, (hipStream_t)stream, z, (const uint4*)WB_hi, (const uint4*)WB_lo, bv,
+                       row_ptr, ctx, R, empty_nan);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* Xv, const int* row_ptr, const int* col_idx, float* z,
+                                   float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves, void* stream) {
+    MV2D_CHECK_ARG(Qt && Xk && Xv && row_ptr && col_idx && z && R >= 0, "mv2d_xattn_tile_fwd: bad args");
+    MV2D_CHECK_ARG(((uintptr_t)Qt & 15) == 0 && ((uintptr_t)Xk & 15) == 0 && ((uintptr_t)Xv & 15) == 0 && ((uintptr_t)z & 15) == 0,
+                   "mv2d_xattn_tile_fwd: operands must be 16-byte aligned");
+    MV2D_CHECK_ARG(waves == 0 || waves == 4 || waves == 8, "mv2d_xattn_tile_fwd: waves per query must be 4 or 8 (0: default)");
+    if (R == 0) return MV2D_OK;
+    static const int env_nw = getenv("MV2D_XATTN_NW") ? atoi(getenv("MV2D_XATTN_NW")) : 0;       // experiment switch
+    const int nw = waves ? waves : (env_nw == 8 ? 8 : 4);
+#define MV2D_XT(NW, DBG) hipLaunchKernelGGL((xattn_tile_kernel<NW, DBG>), dim3(R), dim3(64 * NW), 0, (hipStream_t)stream, (const uint4*)Qt, \
+                                            (const unsigned short*)Xk, (const unsigned short*)Xv, row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan)
+    if (dbg_logits) { if (nw == 8) MV2D_XT(8, true); else MV2D_XT(4, true); }
+    else { if (nw == 8) MV2D_XT(8, false); else MV2D_XT(4, false); }
+#undef MV2D_XT
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}

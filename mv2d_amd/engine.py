@@ -89,6 +89,12 @@ class HeadEngine:
         # around it 14 us each for their [R,8,256] fp32 intermediates, against 28 us of K/V projection per layer.
         # 'zero' rows need the projected route anyway (the value bias must not reach a query without keys).
         self.raw_attn = os.environ.get('MV2D_RAW_ATTN', '0') == '1' and self.empty_nan
+        # DEFAULT cross-attention route (csrc/xattn_tile.hip): the K/V in_proj folded into per-head query / context maps, the attention
+        # core on bf16 MFMA tiles over the UNPROJECTED key / value rows gathered into LDS — no per-layer K/V in HBM, no kvproj launch.
+        # MV2D_XATTN=sparse selects the round-1 route (kvproj_kernel + one-block-per-query VALU kernel) for A/B runs.
+        self.tile_attn = os.environ.get('MV2D_XATTN', 'tile') == 'tile' and not self.raw_attn
+        nw = os.environ.get('MV2D_XATTN_NW')
+        self.xattn_waves = int(nw) if nw else (8 if kind == 'T' else 4)     # waves per query: T-path rows are long (150-600 keys)
         self.qg_x3 = os.environ.get('MV2D_QG_X3', '1') == '1'          # query-generator fcs + first in_proj as LDS-tiled bf16x3 linears (0: exact fp32)
         self.heads_x3 = os.environ.get('MV2D_HEADS_X3', '1') == '1'    # prediction branches in bf16x3 (0: exact fp32)
         self.load_state(state_dict)
@@ -113,6 +119,9 @@ class HeadEngine:
             w[f'_v_w{i}'], w[f'_v_b{i}'] = inw[2 * C:], inb[2 * C:]
             if self.raw_attn:                                                            # per-head maps around the raw-row attention
                 w[f'ca_hin{i}'], w[f'ca_hout{i}'] = ops.pack_head_maps(inw[C:2 * C].contiguous(), inw[2 * C:].contiguous())
+                w[f'ca_v_b{i}'] = inb[2 * C:].contiguous()
+            if self.tile_attn:                                                           # packed operands of xattn_qmap / xattn_ctxmap
+                w[f'ca_mapA{i}'], w[f'ca_mapB{i}'] = ops.pack_xattn_maps(inw[C:2 * C].contiguous(), inw[2 * C:].contiguous())
                 w[f'ca_v_b{i}'] = inb[2 * C:].contiguous()
             w[f'ca_out_w{i}'] = g(p + 'attentions.1.attn.out_proj.weight')
             w[f'ca_out_b{i}'] = g(p + 'attentions.1.attn.out_proj.bias')
@@ -291,11 +300,19 @@ class HeadEngine:
             ws['H1'] = e((P, 4 * C), BF16); ws['H2'] = e((P, 4 * C), BF16); ws['Hg'] = e((P, C), BF16)
             ws['gate'] = e((P, C)); ws['Pg'] = e((P, C))
         ws['pe'] = e((P, C)); ws['Xk'] = e((P, C), BF16)
-        if self.raw_attn:
+        if self.tile_attn:
+            ws['KV'] = None
+            ws['Qt'] = e((R, 16 * C), BF16); ws['zh'] = e((R, 8 * C))
+        elif self.raw_attn:
             ws['KV'] = None
             ws['qkh'] = e((R, 8 * C)); ws['zh'] = e((R, 8 * C))
         else:
             ws['KV'] = e((2 * L, ws['S_kv'], C), BF16)
+        # unprojected key / value input rows of the cross attention (key + key_pos, key): shared by all layers
+        if self.kind == 'T':
+            ws['xk_rows'], ws['xv_rows'] = ws['Xk'], ws['Xf_b']
+        else:
+            ws['xk_rows'], ws['xv_rows'] = ws['roi_sum'].view(R * 49, C), ws['roi_feat'].view(R * 49, C)
         for n in ('x', 'xq', 'x1', 'x1q', 'x2', 'ctx', 'o', 'q'):
             ws[n] = e((R, C))
         ws['zero_rows'] = z((R, C))                              # never written
@@ -520,7 +537,7 @@ class HeadEngine:
         # a18 key side: K/V projections of all layers at once (not needed by the raw-row attention)
         tk('kv_gemm')
         S_kv = ws['S_kv']
-        if self.raw_attn:
+        if self.raw_attn or self.tile_attn:
             pass
         elif self.kind == 'T':
             o.kv_proj(ws['Xk'], W_['kv_w'], W_['kv_b'], ws['KV'], A2=ws['Xf_b'], n_split=L * C, m_dev=md, ldc=C,
@@ -573,11 +590,14 @@ class HeadEngine:
         o, W_, L = ops, self.w, self.L
         x, xq = ws['x'], ws['xq']
         fuse_tail = self.fuse_rows and self.rows_x3          # FFN tail + next layer's in_proj as one row-fused kernel
-        if self.raw_attn:
-            xk_rows = ws['Xk'] if self.kind == 'T' else ws['roi_sum'].view(R * 49, C)
-            xv_rows = ws['Xf_b'] if self.kind == 'T' else ws['roi_feat'].view(R * 49, C)
+        xk_rows, xv_rows = ws['xk_rows'], ws['xv_rows']
 
         def cross_attn(i):
+            if self.tile_attn:
+                o.xattn_qmap(ws['q'], W_[f'ca_mapA{i}'], ws['Qt'], R=R)
+                o.xattn_tile(ws['Qt'], xk_rows, xv_rows, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=self.empty_nan, waves=self.xattn_waves)
+                o.xattn_ctxmap(ws['zh'], W_[f'ca_mapB{i}'], W_[f'ca_v_b{i}'], ws['row_ptr'], ws['ctx'], R, empty_nan=self.empty_nan)
+                return
             if not self.raw_attn:
                 o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R, empty_nan=self.empty_nan)
                 return
@@ -757,7 +777,8 @@ class HeadEngine:
         else:
             q1 = o.gemm_f32(posemb, W_['qe_w0'], W_['qe_b0'], act=1, out=e(pad, C))
             qdn = o.gemm_f32(q1, W_['qe_w2'], W_['qe_b2'], out=e(pad, C))
-        tws = dict(B=1, Vg=ws['Vg'], dn=(pad, max(int(dn_single), 1)), grp_start=None, KV=ws['KV'],
+        tws = dict(B=1, Vg=ws['Vg'], dn=(pad, max(int(dn_single), 1)), grp_start=None, KV=ws['KV'], xk_rows=ws['xk_rows'], xv_rows=ws['xv_rows'],
+                   Qt=torch.empty((T, 16 * C), device=d, dtype=BF16), zh=e(T, 8 * C),
                    row_ptr=torch.cat([torch.arange(pad, device=d, dtype=torch.int32) * nk, row_ptr + pad * nk]),
                    col_idx=torch.cat([keys.repeat(pad), col]).contiguous(),
                    ref=torch.cat([dn_ref.to(F32), ws['ref'][:R]]).contiguous(), qpos=torch.cat([qdn, ws['qpos'][:R]]).contiguous(),

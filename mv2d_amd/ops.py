@@ -428,6 +428,57 @@ def raw_xattn(qk, Xk, Xv, row_ptr, col_idx, out=None, R=None, empty_nan=True):
     return out
 
 
+def pack_xattn_maps(Wk, Wv):
+    """Key / value in_proj weights [256,256] fp32 (rows = output channels) -> the packed operands of the tile cross attention
+    (csrc/xattn_tile.hip): (WA_hi, WA_lo) for ``xattn_qmap`` and (WB_hi, WB_lo) for ``xattn_ctxmap``, bf16 hi / lo pairs.
+      WA [8 heads][16 tiles][64 lanes = 16 g + m][8 e] = Wk[32 h + 8 g + e][32 (t >> 1) + 8 (m >> 2) + 4 (t & 1) + (m & 3)]
+      WB [8 heads][8 steps][2 column tiles][64 lanes = 16 g + n][8 e] = Wv[32 h + 16 nt + n][32 s + 8 g + e]"""
+    _req(Wk, torch.float32, 'Wk'); _req(Wv, torch.float32, 'Wv')
+    d = Wk.device
+    ar = lambda n_: torch.arange(n_, device=d)
+    h, t, g, m, e = torch.meshgrid(ar(8), ar(16), ar(4), ar(16), ar(8), indexing='ij')
+    wa = Wk[32 * h + 8 * g + e, 32 * (t >> 1) + 8 * (m >> 2) + 4 * (t & 1) + (m & 3)].contiguous()
+    h, s, nt, g, n_, e = torch.meshgrid(ar(8), ar(8), ar(2), ar(4), ar(16), ar(8), indexing='ij')
+    wb = Wv[32 * h + 16 * nt + n_, 32 * s + 8 * g + e].contiguous()
+    return split_bf16x2(wa.view(-1)), split_bf16x2(wb.view(-1))
+
+
+def xattn_qmap(q, WA, Qt=None, R=None):
+    """q [R,256] fp32 (pre-scaled) -> Qt [R,4096] bf16: the fragment-major 16 x 256 operand (hi / lo rows of the 8 per-head maps)."""
+    _req(q, torch.float32, 'q'); _req(WA[0], BF16, 'WA_hi'); _req(WA[1], BF16, 'WA_lo')
+    R = q.shape[0] if R is None else R
+    if Qt is None:
+        Qt = torch.empty((R, 4096), device=q.device, dtype=BF16)
+    _req(Qt, BF16, 'Qt')
+    check(_lib.load().mv2d_xattn_qmap(_p(q), _p(WA[0]), _p(WA[1]), _p(Qt), R, _stream()), 'mv2d_xattn_qmap')
+    return Qt
+
+
+def xattn_tile(Qt, Xk, Xv, row_ptr, col_idx, out=None, R=None, dbg_logits=None, empty_nan=True, waves=0):
+    """Tile cross attention on the unprojected key / value rows: Qt from xattn_qmap, Xk / Xv [S,256] bf16 -> z [R,8,256] fp32."""
+    _req(Qt, BF16, 'Qt'); _req(Xk, BF16, 'Xk'); _req(Xv, BF16, 'Xv')
+    _req(row_ptr, torch.int32, 'row_ptr'); _req(col_idx, torch.int32, 'col_idx'); _req(dbg_logits, torch.float32, 'dbg_logits')
+    R = Qt.shape[0] if R is None else R
+    if out is None:
+        out = torch.empty((R, 8, 256), device=Qt.device, dtype=torch.float32)
+    check(_lib.load().mv2d_xattn_tile_fwd(_p(Qt), _p(Xk), _p(Xv), _p(row_ptr), _p(col_idx), _p(out), _p(dbg_logits),
+                                          dbg_logits.stride(0) if dbg_logits is not None else 0, R, 1 if empty_nan else 0, int(waves), _stream()),
+          'mv2d_xattn_tile_fwd')
+    return out
+
+
+def xattn_ctxmap(z, WB, bv, row_ptr, out=None, R=None, empty_nan=True):
+    """z [R,8,256] fp32 -> ctx [R,256] = Wv_h z_h + bv; rows without a key (row_ptr) give NaN / 0."""
+    _req(z, torch.float32, 'z'); _req(WB[0], BF16, 'WB_hi'); _req(WB[1], BF16, 'WB_lo'); _req(bv, torch.float32, 'bv')
+    _req(row_ptr, torch.int32, 'row_ptr')
+    R = z.shape[0] if R is None else R
+    if out is None:
+        out = torch.empty((R, 256), device=z.device, dtype=torch.float32)
+    check(_lib.load().mv2d_xattn_ctxmap(_p(z), _p(WB[0]), _p(WB[1]), _p(bv), _p(row_ptr), _p(out), R, 1 if empty_nan else 0, _stream()),
+          'mv2d_xattn_ctxmap')
+    return out
+
+
 def pack_head_maps(Wk, Wv):
     """Per-layer weights of the raw-row attention: (in_x3, out_x3) for the two grouped linears around raw_xattn.
     in: qk[:, h] = q[:, 32h:32h+32] @ Wk[32h:32h+32, :]   -> group weight [N=256, K=32] = Wk[32h:32h+32, :].T

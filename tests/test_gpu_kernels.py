@@ -398,6 +398,72 @@ def test_raw_xattn_equals_projected_attention(dev, R, S, dens):
         assert bool(torch.isnan(zn[5]).all()) and torch.equal(zn[6:], z[6:])
 
 
+def _unpack_qt(Qt, R):
+    """Qt [R,4096] bf16 (fragment-major 16 x 256 operand) -> (hi [R,8,256], lo [R,8,256]) fp64: Qt[r][s][16 g + n][e] = row n, channel 32 s + 8 g + e."""
+    t = Qt.view(R, 8, 4, 16, 8).double().cpu()                      # [r][s][g][n][e]
+    rows = t.permute(0, 3, 1, 2, 4).reshape(R, 16, 256)             # [r][n][c = 32 s + 8 g + e]
+    return rows[:, :8], rows[:, 8:]
+
+
+@pytest.mark.parametrize('R,S,dens,waves', [(37, 500, 0.05, 4), (301, 5000, 0.02, 8), (64, 49 * 64, -1.0, 4), (20, 2000, 0.3, 4), (20, 2000, 0.3, 8)])
+def test_xattn_tile_equals_projected_attention(dev, R, S, dens, waves):
+    """The default cross-attention route (csrc/xattn_tile.hip): query map -> MFMA tile attention on the UNPROJECTED rows -> context map
+    == masked attention on K = Xk Wk^T + bk, V = Xv Wv^T + bv in fp64 (PETRMultiheadAttention's in_proj + core, MU/petr_transformer.py:487-513).
+    Asymmetric random operands, rows of 1..600 keys (several tiles per wave, online-softmax rescales), an empty row, the RoI pattern of the
+    S path; the intermediate operands are checked too, so that a transposed fragment cannot hide behind the softmax."""
+    from mv2d_amd import ops
+    from oracle import mv2d_oracle as O
+    g = np.random.Generator(np.random.PCG64(360 + R))
+    if dens > 0:
+        allowed = torch.from_numpy(g.random((R, S)) < dens)
+        allowed[5] = False
+        allowed[7, :] = False
+        allowed[7, 123] = True
+    else:
+        allowed = torch.zeros((R, S), dtype=torch.bool)
+        for r in range(R):
+            allowed[r, r * 49:(r + 1) * 49] = True
+            allowed[r, ((r + 3) % R) * 49:((r + 3) % R) * 49 + 49] = True
+    q = (rnd((R, 256), 361) * 0.3).to(dev)
+    q[3] *= 8.0                                                       # one query with sharp logits: the running maximum jumps between tiles
+    Xk = rnd((S, 256), 362).to(dev).to(torch.bfloat16)
+    Xv = rnd((S, 256), 363).to(dev).to(torch.bfloat16)
+    Wk = rnd((256, 256), 364, 0.06).to(dev); bk = rnd((256,), 365).to(dev)
+    Wv = rnd((256, 256), 366, 0.06).to(dev); bv = rnd((256,), 367).to(dev)
+    row_ptr, col = O.csr_from_allowed(allowed)
+    row_ptr, col = row_ptr.to(dev), col.to(dev)
+    ref = O.masked_cross_attention(q.double(), Xk.double() @ Wk.double().T + bk.double(), Xv.double() @ Wv.double().T + bv.double(), allowed.to(dev))
+    WA, WB = ops.pack_xattn_maps(Wk, Wv)
+    Qt = ops.xattn_qmap(q, WA)
+    qk_ref = torch.einsum('rhd,hdc->rhc', q.double().view(R, 8, 32), Wk.double().view(8, 32, 256)).cpu()
+    hi, lo = _unpack_qt(Qt, R)
+    assert float((hi + lo - qk_ref).abs().max() / qk_ref.abs().max()) < 3e-5          # hi + lo = the fp32-class map
+    assert float((hi - qk_ref).abs().max() / qk_ref.abs().max()) < 6e-3               # hi alone = its bf16 rounding
+    nnz = int(col.numel())
+    dbg = torch.zeros((8, nnz), device=dev)
+    z = ops.xattn_tile(Qt, Xk, Xv, row_ptr, col, empty_nan=False, waves=waves, dbg_logits=dbg)
+    # logits (without the per-row constant q_h . bk_h) and z against fp64 on the same bf16 rows
+    rows = torch.repeat_interleave(torch.arange(R), allowed.sum(1))
+    lg_ref = torch.einsum('ehc,ec->he', qk_ref[rows], Xk.double().cpu()[col.cpu().long()])
+    assert float((dbg.double().cpu() - lg_ref).abs().max() / lg_ref.abs().max()) < 2e-5
+    att = torch.einsum('rhc,sc->hrs', qk_ref, Xk.double().cpu()).masked_fill(~allowed[None], float('-inf')).softmax(-1)
+    att = torch.where(allowed.any(1)[None, :, None], att, torch.zeros_like(att))
+    z_ref = torch.einsum('hrs,sc->rhc', att, Xv.double().cpu())
+    assert relerr(z, z_ref) < 3e-5
+    ctx = ops.xattn_ctxmap(z, WB, bv, row_ptr, empty_nan=False)
+    has = allowed.any(1).to(dev)
+    assert relerr(ctx[has], ref[has]) < 5e-5
+    assert float(ctx[~has].abs().max()) == 0.0 if bool((~has).any()) else True          # 'zero' policy: no value bias for a query without keys
+    z2 = ops.xattn_tile(Qt, Xk, Xv, row_ptr, col, empty_nan=False, waves=waves)
+    assert torch.equal(z2, z)                                                           # deterministic, debug output does not change the result
+    if dens > 0:
+        assert float(z[5].abs().max()) == 0.0
+        zn = ops.xattn_tile(Qt, Xk, Xv, row_ptr, col, waves=waves)
+        assert bool(torch.isnan(zn[5]).all()) and torch.equal(zn[6:], z[6:])
+        cn = ops.xattn_ctxmap(zn, WB, bv, row_ptr)
+        assert bool(torch.isnan(cn[5]).all()) and torch.equal(cn[6:], ctx[6:])
+
+
 # ------------------------------------------------------------------------------------------ geometry
 def _problem(name):
     prob = synthetic.make_problem(name, seed=0)
