@@ -24,6 +24,7 @@
 namespace {
 
 constexpr int C = 256, HEADS = 8;
+constexpr float LOG2E = 1.4426950408889634f;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 xt_bf16x8;
 typedef __attribute__((ext_vector_type(4))) short xt_s16x4;
@@ -42,7 +43,9 @@ __device__ __forceinline__ void xt_split8(const float4& x0, const float4& x1, Xt
 }
 
 // ------------------------------------------------------------------------------------------------
-// query map: Qt[r][s][16 g + n][e] = part_n( sum_d q[r][32 h + d] Wk[32 h + d][32 s + 8 g + e] ),  h = n & 7, part = hi (n < 8) / lo
+// query map: Qt[r][h][s][g][part][e] = part( sum_d q[r][32 h + d] Wk[32 h + d][32 s + 8 g + e] ), part = hi / lo  (operand row n of the
+// tile kernel = head n & 7, part n >> 3; one (query, head) = 1 KB contiguous: a wave of this kernel fills whole lines, a fragment load of
+// the tile kernel reads 8 whole lines)
 // Block = 16 queries, wave = head.  "Swapped" product D[channel][query] so that a lane ends up with 8 CONSECUTIVE channels of one
 // query (rows 4g..4g+3 of two channel tiles whose row -> channel assignment is interleaved by the weight packing) = exactly one
 // 16-byte chunk of the operand the tile kernel reads.
@@ -72,14 +75,14 @@ __global__ __launch_bounds__(512) void xattn_qmap_kernel(const float* __restrict
         acc[t] = a;
     }
     if (q0 + n < R) {
-        uint4* out = Qt + ((long long)(q0 + n) * 8) * 64 + 16 * g + h;
+        uint4* out = Qt + (long long)(q0 + n) * 512 + h * 64 + g * 2;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             XtFrag hi, lo;
             xt_split8(make_float4(acc[2 * u][0], acc[2 * u][1], acc[2 * u][2], acc[2 * u][3]),
                       make_float4(acc[2 * u + 1][0], acc[2 * u + 1][1], acc[2 * u + 1][2], acc[2 * u + 1][3]), hi, lo);
-            out[u * 64] = hi.u;
-            out[u * 64 + 8] = lo.u;
+            out[u * 8] = hi.u;
+            out[u * 8 + 1] = lo.u;
         }
     }
 }
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(512) void xattn_ctxmap_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------------
 // tile attention: see the file header.  One block (NW waves) per query; wave w takes the key tiles w, w + NW, ...
-//   Qt  [R][8 k-steps][64 lanes][8] bf16 (xattn_qmap_kernel), Xk / Xv [S][256] bf16, CSR row_ptr / col_idx, z [R][8][256] fp32
+//   Qt  [R][8 heads][8 k-steps][4][hi | lo][8] bf16 (xattn_qmap_kernel), Xk / Xv [S][256] bf16, CSR row_ptr / col_idx, z [R][8][256] fp32
 // LDS (one array): per wave an 8 KB key tile (16 rows x 32 chunks of 16 B, chunk c of row r at slot c ^ (r & 15): the
 // fragment reads of 16 different rows hit 16 different bank slots) that later holds the wave's partial z, 512 B of P, and the
 // softmax statistics of the merge.
@@ -182,9 +185,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void xattn_tile_kernel(co
     const int ntile = (end - beg + 15) >> 4;
     XtFrag qa[8];
     if (wave < ntile) {
-        const uint4* qp = Qt + (long long)r * 512 + lane;
+        const uint4* qp = Qt + (long long)r * 512 + (n & 7) * 64 + g * 2 + (n >> 3);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) qa[s].u = qp[s * 64];
+        for (int s = 0; s < 8; ++s) qa[s].u = qp[s * 8];
     }
     for (int tt = wave; tt < ntile; tt += NW) {
         const int kbase = beg + 16 * tt;
@@ -218,12 +221,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void xattn_tile_kernel(co
             sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[s].v, kb.v, sacc, 0, 0, 0);
         }
         const bool valid = kbase + n < end;
+        const bool first = tt == wave;                                              // (wave-uniform) nothing accumulated yet: no rescale
         float sv[4], p[4], alpha[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float full = sacc[i] + __shfl_xor(sacc[i], 32, 64);              // hi rows + lo rows: head 4 (g & 1) + i
             if (DBG && dbg_logits && g < 2 && valid) dbg_logits[(long long)(4 * g + i) * dbg_stride + kbase + n] = full;
-            sv[i] = valid ? full : -INFINITY;
+            sv[i] = valid ? full * LOG2E : -INFINITY;                               // the softmax runs in base 2 (v_exp_f32)
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -233,8 +237,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void xattn_tile_kernel(co
             tm = fmaxf(tm, __shfl_xor(tm, 4, 64));
             tm = fmaxf(tm, __shfl_xor(tm, 8, 64));
             const float m_new = fmaxf(m_run[i], tm);
-            alpha[i] = expf(m_run[i] - m_new);
-            p[i] = expf(sv[i] - m_new);
+            alpha[i] = __builtin_amdgcn_exp2f(m_run[i] - m_new);
+            p[i] = __builtin_amdgcn_exp2f(sv[i] - m_new);
             l_run[i] = l_run[i] * alpha[i] + p[i];                                   // per-lane share of the row sum (reduced at the end)
             m_run[i] = m_new;
         }
@@ -266,8 +270,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void xattn_tile_kernel(co
                 const uint2 vb = (w & 1) ? make_uint2(xt_hi_pair(r0[d], r1[d]), xt_hi_pair(r2[d], r3[d]))
                                          : make_uint2(xt_lo_pair(r0[d], r1[d]), xt_lo_pair(r2[d], r3[d]));
                 f32x4_t zc = Z[H * 8 + w];
+                if (!first) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) zc[i] *= alpha[i];
+                    for (int i = 0; i < 4; ++i) zc[i] *= alpha[i];
+                }
                 Z[H * 8 + w] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, __builtin_bit_cast(xt_s16x4, vb), zc, 0, 0, 0);
             }
         }
@@ -291,19 +297,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void xattn_tile_kernel(co
         }
     }
     {
+        // hi rows (lanes 0-31) + lo rows (lanes 32-63) of z with ONE half-wave exchange per register pair (v_permlane32_swap): afterwards
+        // lanes g < 2 hold the sums of column tiles w = 0..3 and lanes g >= 2 those of w = 4..7 (for head 4 (g & 1) + i), so that every lane
+        // stores one float4 per (half, row)
         float* szw = reinterpret_cast<float*>(smem) + wave * (HEADS * C);
 #pragma unroll
         for (int H = 0; H < 2; ++H)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float v[8];
+                float v[4];
 #pragma unroll
-                for (int w = 0; w < 8; ++w) v[w] = Z[H * 8 + w][i] + __shfl_xor(Z[H * 8 + w][i], 32, 64);   // hi rows + lo rows
-                if (g < 2) {
-                    float* dst = szw + (4 * g + i) * C + 128 * H + 8 * n;
-                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                for (int w = 0; w < 4; ++w) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(Z[H * 8 + w][i]), __float_as_uint(Z[H * 8 + w + 4][i]), false, false);
+                    v[w] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
                 }
+                float* dst = szw + (4 * (g & 1) + i) * C + 128 * H + 8 * n + 4 * (g >> 1);
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             }
     }
     __syncthreads();
@@ -321,11 +330,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void xattn_tile_kernel(co
             float den = 0.f, num = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                const float e = expf(sst[w * 8 + h] - M);                          // waves without a tile: exp(-inf) = 0
+                const float e = __builtin_amdgcn_exp2f(sst[w * 8 + h] - M);        // waves without a tile: 2^(-inf) = 0
                 den += sst[NW * 8 + w * 8 + h] * e;
                 num += sz[(w * HEADS + h) * C + c] * e;
             }
-            zr[h * C + c] = num / den;
+            zr[h * C + c] = num * __builtin_amdgcn_rcpf(den);
         }
     }
 }
@@ -362,7 +371,7 @@ extern "C" int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* X
     MV2D_CHECK_ARG(waves == 0 || waves == 4 || waves == 8, "mv2d_xattn_tile_fwd: waves per query must be 4 or 8 (0: default)");
     if (R == 0) return MV2D_OK;
     static const int env_nw = getenv("MV2D_XATTN_NW") ? atoi(getenv("MV2D_XATTN_NW")) : 0;       // experiment switch
-    const int nw = waves ? waves : (env_nw == 8 ? 8 : 4);
+    const int nw = waves ? waves : (env_nw == 8 ? 8 : 4);      // 4: best of {4, 8} on both paths (cfg2_s 41 vs 74 us, cfg3_t 73 vs 104 us per layer)
 #define MV2D_XT(NW, DBG) hipLaunchKernelGGL((xattn_tile_kernel<NW, DBG>), dim3(R), dim3(64 * NW), 0, (hipStream_t)stream, (const uint4*)Qt, \
                                             (const unsigned short*)Xk, (const unsigned short*)Xv, row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan)
     if (dbg_logits) { if (nw == 8) MV2D_XT(8, true); else MV2D_XT(4, true); }

@@ -94,7 +94,7 @@ class HeadEngine:
         # MV2D_XATTN=sparse selects the round-1 route (kvproj_kernel + one-block-per-query VALU kernel) for A/B runs.
         self.tile_attn = os.environ.get('MV2D_XATTN', 'tile') == 'tile' and not self.raw_attn
         nw = os.environ.get('MV2D_XATTN_NW')
-        self.xattn_waves = int(nw) if nw else (8 if kind == 'T' else 4)     # waves per query: T-path rows are long (150-600 keys)
+        self.xattn_waves = int(nw) if nw else 4                             # waves per query (8 measured slower on both paths)
         self.qg_x3 = os.environ.get('MV2D_QG_X3', '1') == '1'          # query-generator fcs + first in_proj as LDS-tiled bf16x3 linears (0: exact fp32)
         self.heads_x3 = os.environ.get('MV2D_HEADS_X3', '1') == '1'    # prediction branches in bf16x3 (0: exact fp32)
         self.load_state(state_dict)

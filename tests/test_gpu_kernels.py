@@ -399,10 +399,9 @@ def test_raw_xattn_equals_projected_attention(dev, R, S, dens):
 
 
 def _unpack_qt(Qt, R):
-    """Qt [R,4096] bf16 (fragment-major 16 x 256 operand) -> (hi [R,8,256], lo [R,8,256]) fp64: Qt[r][s][16 g + n][e] = row n, channel 32 s + 8 g + e."""
-    t = Qt.view(R, 8, 4, 16, 8).double().cpu()                      # [r][s][g][n][e]
-    rows = t.permute(0, 3, 1, 2, 4).reshape(R, 16, 256)             # [r][n][c = 32 s + 8 g + e]
-    return rows[:, :8], rows[:, 8:]
+    """Qt [R,4096] bf16 -> (hi [R,8,256], lo [R,8,256]) fp64: Qt[r][h][s][g][part][e] = part (hi | lo) of head h, channel 32 s + 8 g + e."""
+    t = Qt.view(R, 8, 8, 4, 2, 8).double().cpu()                    # [r][h][s][g][part][e]
+    return t[:, :, :, :, 0].reshape(R, 8, 256), t[:, :, :, :, 1].reshape(R, 8, 256)
 
 
 @pytest.mark.parametrize('R,S,dens,waves', [(37, 500, 0.05, 4), (301, 5000, 0.02, 8), (64, 49 * 64, -1.0, 4), (20, 2000, 0.3, 4), (20, 2000, 0.3, 8)])
