@@ -6,9 +6,14 @@
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the whole hot path (PE -> RoI gather -> query generator -> box correlation -> key list/CSR
--> K/V projection -> 6-layer decoder -> heads -> top-k decode, + the all-gather of decoded boxes when N > 1) over
-one batch of `--inflight` synthetic 6-camera frames per GPU (each frame = one independent sample on its own HIP
-stream, replayed as a hipGraph).  Inputs are resident in HBM before the timed region.  Prints ONE JSON line.
+-> 6-layer decoder with the tile cross attention -> heads -> top-k decode, + the all-gather of decoded boxes when N > 1) over
+`--inflight` x `--batch` synthetic frames per GPU: `--inflight` HIP streams, each replaying hipGraphs whose launches carry `--batch`
+samples.  Every stream has its OWN frames and rotates through `--rotate` distinct frame sets (feature maps, 2-D boxes) from step to
+step; on the two-frame (T) workloads every sample of every step also has its own img_metas (ego motion, time stamps), so the
+calibration tables are rebuilt on the host and uploaded inside the timed loop.  Inputs are resident in HBM before the timed region.
+Extra legs after the timed region (same process, reported beside `value`): the round-1 protocol (every stream replays the same
+frames), one sample per launch on 4 streams, and one sample on one stream with a synchronisation per frame (latency).
+Prints ONE JSON line.
 """
 import argparse
 import json
@@ -28,7 +33,7 @@ PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X
 PEAK_HBM_GBS = 8000.0
 
 
-SINE_TABLE = os.environ.get('MV2D_PE_SINE_TABLE', '0') == '1'      # opt-in experiment: the sine branch of the PE block from a table
+SINE_TABLE = os.environ.get('MV2D_PE_SINE_TABLE', '1') == '1'      # default: the input-independent sine branch of the PE block is folded into a per-(weights, geometry) table; its FLOPs are NOT counted
 
 
 def stage_flops(kind, R, S, L=6):
@@ -66,13 +71,15 @@ def main():
     ap.add_argument('--workload', default='cfg2_s', help='cfg2_s (MV2D-S 6 cams 1408x512, headline) | cfg3_t | cfg5_t | cfg1_s ...')
     ap.add_argument('--inflight', type=int, default=4, help='HIP streams per GPU, each running its own launch sequence per step')
     ap.add_argument('--batch', type=int, default=8, help='samples sharing every launch of a stream (HeadEngine.run_batch)')
+    ap.add_argument('--rotate', type=int, default=4, help='distinct frame sets every stream cycles through (1: the same frames every step)')
+    ap.add_argument('--no-extra-legs', action='store_true', help='skip the fixed-input / batch-1 / latency legs')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL; gloo only for single-GPU dry runs)')
     ap.add_argument('--corr-topk', type=int, default=None)    # S path: correlated RoIs per other view (reference default 1); T path: 20
     ap.add_argument('--force-nc', type=int, default=None)     # S path sweep: synthetic correlation lists, n_c RoIs per query
     ap.add_argument('--cpu-iters', type=int, default=24)       # ~10 s of CPU work on the bounded sample
-    ap.add_argument('--cpu-threads', type=int, default=16)
+    ap.add_argument('--cpu-threads', type=int, default=16)      # second CPU leg; the first uses os.cpu_count() threads (BASELINE.md protocol)
     ap.add_argument('--cpu-timeout', type=int, default=150)
     args = ap.parse_args()
 
@@ -107,45 +114,85 @@ def main():
     props = [torch.from_numpy(p) for p in prob['proposals']]
     metas = prob['img_metas']
     B = args.batch
-    if B > 1:                                                      # the samples of a batch are different frames
-        more = [synthetic.make_problem(args.workload, seed=1000 * (b + 1) + rank) for b in range(B - 1)]
-        # the producer (backbone + neck of a batch) hands over one stacked [B*V,256,h,w] map
-        feats_b = torch.cat([feat] + [torch.from_numpy(m['feat']).to(dev) for m in more], 0).contiguous()
-        props_b = [props] + [[torch.from_numpy(p) for p in m['proposals']] for m in more]
-        metas_b = [metas] + [m['img_metas'] for m in more]
     use_graph = not args.no_graph
+    two_frame = prob['frames'] > 1
+    K = max(1, args.rotate)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+
+    def frame_sets(n_streams, Bs, k_sets):
+        """[stream][set] -> (feats [Bs*V,256,h,w] on the device, proposals per sample, metas per sample): every stream its own frames.
+        Set 0 of stream 0 starts with the seed-0 problem (the one the CPU baseline and the stage timings use)."""
+        out = []
+        for i in range(n_streams):
+            sets = []
+            for k in range(k_sets):
+                fl, pl, ml = [], [], []
+                for b in range(Bs):
+                    if i == 0 and k == 0 and b == 0:
+                        fl.append(feat); pl.append(props); ml.append(metas)
+                        continue
+                    m = synthetic.make_problem(args.workload, seed=100000 * (i + 1) + 1000 * k + 10 * b + rank, with_feat=False)
+                    fl.append(torch.randn(feat.shape, device=dev, generator=gen))
+                    pl.append([torch.from_numpy(p) for p in m['proposals']]); ml.append(m['img_metas'])
+                sets.append((torch.cat(fl, 0).contiguous() if Bs > 1 else fl[0], pl, ml))
+            out.append(sets)
+        return out
+
+    def meta_pool(n_streams, n):
+        """Two-frame workloads: n distinct per-sample img_metas per stream (own ego motion / time stamps each).  n exceeds the engine's
+        table cache (64 entries, FIFO), so every use rebuilds the camera tables on the host -- as a stream of real frames would."""
+        if not two_frame:
+            return None
+        return [[synthetic.make_problem(args.workload, seed=0, with_feat=False, ego=0.003 * (j + 1) + 0.5 * i)['img_metas'] for j in range(n)]
+                for i in range(n_streams)]
+
+    sets_main = frame_sets(args.inflight, B, K)
+    pool_main = meta_pool(args.inflight, 96)
+    feats_b, props_b, metas_b = sets_main[0][0]                    # stage timings / decoder leg: the first set of stream 0
     # ping-pong payload buffers: the streams free-run (no per-step join on one GPU); with N > 1 the all-gather of step k
     # runs on the main stream behind the frames of step k while the frames of step k+1 are already executing.
     payload = [torch.zeros((args.inflight * B, 300 * 11 + 1), device=dev) for _ in range(2)]
     gathered_ev = [None, None]
     step_no = [0]
 
-    def step():
-        k = step_no[0] & 1
-        step_no[0] += 1
-        cur = torch.cuda.current_stream()
-        done = []
-        for i, (e, s) in enumerate(zip(engines, streams)):
-            with torch.cuda.stream(s):
-                if gathered_ev[k] is not None:
-                    s.wait_event(gathered_ev[k])
-                if B > 1:
-                    o = e.run_batch(feats_b, props_b, metas_b, use_graph=use_graph)
-                else:
-                    o = e.run(feat, props, metas, use_graph=use_graph)
-                ops.pack_detections(o['boxes'], o['scores'], o['labels'], o['count'], payload[k][i * B:(i + 1) * B])
-                if collective:
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    done.append(ev)
-        if collective:
-            for ev in done:
-                cur.wait_event(ev)
-            out = mdist.gather_detections(payload[k])     # the one collective of an evaluation step (RCCL all-gather)
-            gathered_ev[k] = torch.cuda.Event()
-            gathered_ev[k].record()
-            return out
-        return payload[k]
+    def make_step(engs, strs, sets, pool, Bs, pay, rotate=True):
+        cnt = [0]
+
+        def step():
+            n = cnt[0]
+            cnt[0] += 1
+            k = step_no[0] & 1
+            step_no[0] += 1
+            cur = torch.cuda.current_stream()
+            done = []
+            for i, (e, s_) in enumerate(zip(engs, strs)):
+                fb, pb, mb = sets[i][(n % len(sets[i])) if rotate else 0]
+                if pool is not None and rotate:
+                    mb = [pool[i][(n * Bs + b) % len(pool[i])] for b in range(Bs)]
+                with torch.cuda.stream(s_):
+                    if gathered_ev[k] is not None:
+                        s_.wait_event(gathered_ev[k])
+                    if Bs > 1:
+                        o = e.run_batch(fb, pb, mb, use_graph=use_graph)
+                    else:
+                        o = e.run(fb, pb[0], mb[0], use_graph=use_graph)
+                    ops.pack_detections(o['boxes'], o['scores'], o['labels'], o['count'], pay[k][i * Bs:(i + 1) * Bs])
+                    if collective:
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        done.append(ev)
+            if collective:
+                for ev in done:
+                    cur.wait_event(ev)
+                out = mdist.gather_detections(pay[k])     # the one collective of an evaluation step (RCCL all-gather)
+                gathered_ev[k] = torch.cuda.Event()
+                gathered_ev[k].record()
+                return out
+            return pay[k]
+        return step
+
+    step = make_step(engines, streams, sets_main, pool_main, B, payload)
 
     def barrier():
         torch.cuda.synchronize()
@@ -167,6 +214,46 @@ def main():
         elapsed = float(t.item())
     samples = world * args.inflight * B * args.steps
     value = samples / elapsed
+
+    # ---------------- extra legs (single GPU): what the headline's batching / streams / input rotation are worth
+    extra = dict(samples_s_rotating_inputs=round(value, 2), rotating_frame_sets_per_stream=K,
+                 img_metas='unique per sample and step (camera tables rebuilt + uploaded in the timed loop)' if two_frame else
+                           'one static rig (single-frame workload): tables uploaded once')
+    if world == 1 and not args.no_extra_legs:
+        def timed(fn, n_steps, n_warm):
+            for _ in range(n_warm):
+                fn()
+            barrier()
+            t_ = time.perf_counter()
+            for _ in range(n_steps):
+                fn()
+            barrier()
+            return time.perf_counter() - t_
+        n_x = max(10, min(args.steps, 50))
+        # (a) the round-1 protocol: every stream replays the same frames, img_metas never change
+        same = [[sets_main[0][0]] for _ in range(args.inflight)]
+        el = timed(make_step(engines, streams, same, None, B, payload, rotate=False), n_x, 3)
+        extra['samples_s_fixed_inputs'] = round(args.inflight * B * n_x / el, 2)
+        # (b) one sample per launch (the reference's call shape) on the same streams, rotating inputs
+        sets1 = frame_sets(args.inflight, 1, K) if B > 1 else sets_main
+        pool1 = meta_pool(args.inflight, 96) if B > 1 else pool_main
+        pay1 = [torch.zeros((args.inflight, 300 * 11 + 1), device=dev) for _ in range(2)]
+        el = timed(make_step(engines, streams, sets1, pool1, 1, pay1), n_x, K + 1)
+        extra['samples_s_batch1'] = round(args.inflight * n_x / el, 2)
+        # (c) one stream, one sample, host synchronisation after every frame: the latency a single rig sees
+        lat = []
+        for n_ in range(K + 1 + n_x):
+            fb, pb, mb = sets1[0][n_ % len(sets1[0])]
+            m0 = pool1[0][n_ % len(pool1[0])] if pool1 is not None else mb[0]
+            t_ = time.perf_counter()
+            with torch.cuda.stream(streams[0]):
+                o_ = engines[0].run(fb, pb[0], m0, use_graph=use_graph)
+                ops.pack_detections(o_['boxes'], o_['scores'], o_['labels'], o_['count'], pay1[0][:1])
+            streams[0].synchronize()
+            if n_ > K:
+                lat.append(time.perf_counter() - t_)
+        extra['latency_ms_single_stream'] = round(statistics.median(lat) * 1e3, 4)
+        extra['samples_s_single_stream'] = round(1.0 / statistics.median(lat), 2)
 
     # ---------------- per-stage timing of the same frame with HIP events on the launch stream (single stream, eager)
     eng = base
@@ -240,19 +327,44 @@ def main():
     torch.cuda.synchronize()
     decoder_ms = e0.elapsed_time(e1) / 50
 
+    # ---------------- the tile cross-attention kernel alone (HBM-bound gather): HIP events around 20 launches on the prepared buffers
+    xattn = None
+    if getattr(eng, 'tile_attn', False):
+        xk, xv = ws['xk_rows'], ws['xv_rows']
+        for _ in range(3):
+            ops.xattn_tile(ws['Qt'], xk, xv, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=eng.empty_nan, waves=eng.xattn_waves)
+        e0.record()
+        for _ in range(20):
+            ops.xattn_tile(ws['Qt'], xk, xv, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=eng.empty_nan, waves=eng.xattn_waves)
+        e1.record()
+        torch.cuda.synchronize()
+        x_ms = e0.elapsed_time(e1) / 20
+        x_bytes = nnz * 2 * 256 * 2 + R * (16 * 256 * 2 + 8 * 256 * 4)          # K and V rows of every allowed pair (bf16) + Qt in + z out
+        x_flops = 2.0 * nnz * 8 * 256 * 2                                          # logits + P.V in the 256-dim input space, 8 heads
+        xattn = dict(kernel='xattn_tile_kernel', ms=round(x_ms, 4), bytes_per_launch=x_bytes, gbs=round(x_bytes / (x_ms * 1e-3) / 1e9, 1),
+                     hbm_frac=round(x_bytes / (x_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), tflops=round(x_flops / (x_ms * 1e-3) / 1e12, 2),
+                     note='bytes = rows gathered per allowed (query, key) pair; keys shared by several queries are served by L2 / Infinity Cache')
+
     # ---------------- CPU baseline: the oracle (port of the reference algorithm) on the host cores, bounded sample
-    cpu = None
+    cpu, cpu2 = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import subprocess
-        threads = min(os.cpu_count() or 1, args.cpu_threads)
-        try:
-            r = subprocess.run([sys.executable, '-m', 'oracle.cpu_baseline', '--workload', args.workload, '--iters', str(args.cpu_iters),
-                                '--threads', str(threads)], cwd=ROOT, capture_output=True, text=True, timeout=args.cpu_timeout)
-            lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
-            cpu = json.loads(lines[-1]) if lines else dict(value=None, unit='samples/s', cores=threads, kind='port',
-                                                           sample=f'oracle subprocess failed: {r.stderr[-200:]}')
-        except subprocess.TimeoutExpired:
-            cpu = dict(value=None, unit='samples/s', cores=threads, kind='port', sample=f'oracle did not finish {args.cpu_iters}+1 frames in {args.cpu_timeout}s')
+
+        def cpu_leg(threads, iters, tmo):
+            try:
+                r = subprocess.run([sys.executable, '-m', 'oracle.cpu_baseline', '--workload', args.workload, '--iters', str(iters),
+                                    '--threads', str(threads)], cwd=ROOT, capture_output=True, text=True, timeout=tmo)
+                lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+                return json.loads(lines[-1]) if lines else dict(value=None, unit='samples/s', cores=threads, kind='port',
+                                                                sample=f'oracle subprocess failed: {r.stderr[-200:]}')
+            except subprocess.TimeoutExpired:
+                return dict(value=None, unit='samples/s', cores=threads, kind='port', sample=f'oracle did not finish {iters}+1 frames (+ the decoder-only leg) in {tmo}s with {threads} threads')
+        # the 16-thread leg is the baseline the ratios are quoted against; BASELINE.md section 3 / SURVEY 8(d) name
+        # torch.set_num_threads(os.cpu_count()), so that leg is run too (bounded: on a 256-thread host the oracle's many small operators
+        # spend their time waking threads and may not finish; reported as measured either way)
+        cpu = cpu_leg(min(os.cpu_count() or 1, args.cpu_threads), args.cpu_iters, args.cpu_timeout)
+        if (os.cpu_count() or 1) != args.cpu_threads:
+            cpu2 = cpu_leg(os.cpu_count() or 1, 3, 75)
 
     if rank == 0:
         line = {
@@ -263,12 +375,13 @@ def main():
             'config': {'workload': f'{args.workload}: MV2D-{kind} head, {len(metas)} views {metas[0]["img_shape"][1]}x{metas[0]["img_shape"][0]}, '
                                    f'R={R} queries, S={S} key positions, nnz={nnz} allowed (q,k) pairs' + (f' (totals of the {B} samples of a launch)' if B > 1 else '') + (f', corr_topk={args.corr_topk}' if args.corr_topk else '') + (f', forced n_c={args.force_nc}' if args.force_nc else ''),
                        'frames_per_step_per_gpu': args.inflight * B, 'global_batch': world * args.inflight * B,
-                       'streams_per_gpu': args.inflight, 'samples_per_launch': B, **({'pe_sine_branch': 'per-geometry table (opt-in MV2D_PE_SINE_TABLE=1, not the default path)'} if SINE_TABLE else {}),
+                       'streams_per_gpu': args.inflight, 'samples_per_launch': B, 'pe_sine_branch': 'folded into a per-(weights, geometry) table, FLOPs not counted' if SINE_TABLE else 'evaluated per frame (MV2D_PE_SINE_TABLE=0)',
                        'parallelism': f'dp{world}', 'hipgraph': use_graph},
             'decoder_ms_per_iter': round(decoder_ms / B, 4), 'decoder_ms_per_launch': round(decoder_ms, 4),
             'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},
-            'roofline': roofline, 'stage_roofline': stage_roofline,
-            'cpu_baseline': cpu,
+            'roofline': roofline, 'stage_roofline': stage_roofline, 'xattn_tile': xattn,
+            'cpu_baseline': cpu, 'cpu_baseline_all_cores': cpu2,
+            **extra,
         }
     # RCCL writes its version banner through C stdio (block-buffered on a pipe, so it would come out at process exit, after the JSON
     # line): every rank flushes it now, the barrier orders that before rank 0 prints, and the JSON line stays the last line of stdout

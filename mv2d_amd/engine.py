@@ -65,14 +65,17 @@ class HeadEngine:
         self.const = {k: v.to(self.dev) for k, v in calib.constant_tables().items()}
         self._ws = {}
         self._ws_base = {}
-        self._tab_cache = {}
+        self._shape_cache = {}
         self.prof = None              # dict name -> [events] when stage timing is on (bench.py)
         self.fork_qg = True           # T path: query-generator chain on a second stream
         self.ffn_x3 = os.environ.get('MV2D_FFN_X3', '1') == '1'   # FFN in bf16x3 split precision (fragment-major hi/lo weights); 0: exact fp32
         self.ffn_groups = int(os.environ.get('MV2D_FFN_G', '0'))   # hidden slices per FFN block (0: by the number of rows)
         self.pe_fused = os.environ.get('MV2D_PE_FUSED', '1') == '1'   # one fused launch for the PE block instead of six GEMMs
-        # opt-in experiment ("the sine branch is a constant"): adapt_pos3d(sine) from a per-geometry table
-        self.pe_sine_table = self.pe_fused and os.environ.get('MV2D_PE_SINE_TABLE', '0') == '1'
+        # adapt_pos3d(sine) (MU/pe.py:164-166) depends only on the weights and on the padding geometry of the rig, not on features, boxes
+        # or calibration: it is constant-folded into a per-(weights version, geometry) table that the fused PE kernel adds in its
+        # epilogue (default; MV2D_PE_SINE_TABLE=0 evaluates the branch per frame like the reference does)
+        self.pe_sine_table = self.pe_fused and os.environ.get('MV2D_PE_SINE_TABLE', '1') == '1'
+        self._weights_version = 0     # bumped by every load_state(): invalidates whatever was folded from the weights
         self.force_nc = None          # bench only (S path): overwrite the correlation lists so that every query reads n_c RoIs
         # out_proj + residual + LayerNorm (+ q in_proj) as one row-fused kernel per attention (8 instead of 11 launches per layer),
         # its two linears in bf16x3 split precision (fp32-class: ~1e-5 relative).  MV2D_ROWS_X3=0: exact-fp32 fused kernel (slower than
@@ -102,6 +105,7 @@ class HeadEngine:
     # ------------------------------------------------------------------------------------------ weights
     def load_state(self, sd):
         d, L = self.dev, self.L
+        self._weights_version = getattr(self, '_weights_version', 0) + 1
         g = lambda k: _t(sd[k], d, F32)
         b16 = lambda t: ops.f32_to_bf16(t.contiguous())
         w = {}
@@ -322,89 +326,83 @@ class HeadEngine:
         ws['labels'] = z((B, self.max_num), torch.int64); ws['bbox_index'] = z((B, self.max_num), torch.int64); ws['count'] = z(B, torch.int32)
         return ws
 
-    # ------------------------------------------------------------------------------------------ host side
-    @staticmethod
-    def _rois_host(proposals, view0=0):
-        """bbox2roi (mmdet) + dummy proposal rule (RH/mv2d_head.py:105-108) on the host; returns (rois [R,5], counts).
-        view0: index of the sample's first view inside a batch of samples."""
-        props = [p if torch.is_tensor(p) else torch.from_numpy(np.asarray(p)) for p in proposals]
-        if sum(int(p.shape[0]) for p in props) == 0:
-            props = [torch.tensor([[0, 50, 50, 100, 100, 0]], dtype=F32)] + list(props[1:])
-        rows, counts = [], []
-        for i, p in enumerate(props):
-            counts.append(int(p.shape[0]))
-            if p.shape[0] > 0:
-                pc = p.detach().to('cpu', F32)
-                rows.append(torch.cat([torch.full((pc.shape[0], 1), float(view0 + i)), pc[:, :4]], 1))
-        return torch.cat(rows, 0), counts
-
     # ------------------------------------------------------------------------------------------ forward
-    def _frame_key(self, img_metas):
-        parts = []
-        for m in img_metas:
-            parts.append(np.asarray(m['lidar2img'], dtype=np.float64).tobytes())
-            parts.append(np.asarray(m['intrinsics'], dtype=np.float64).tobytes())
-            parts.append(np.asarray(m['extrinsics'], dtype=np.float64).tobytes())
-            parts.append(repr((tuple(m['pad_shape']), tuple(m['img_shape']), float(m.get('timestamp', 0.0)))).encode())
-        return hash(b''.join(parts))
-
-    def _sample_tables(self, img_metas, h, w):
-        """calibration tables of one sample: pure functions of img_metas, cached by their content"""
-        key = self._frame_key(img_metas)
-        hit = self._tab_cache.get(key)
-        if hit is None:
-            hit = calib.frame_tables(img_metas, h, w, stride=self.stride, depth_num=self.depth_num,
+    def _shape_tables(self, img_metas, h, w):
+        """Tables of the padding geometry (frustum grid, padding mask, sine embeds: tens of ms to build), pure functions of the shapes
+        they are cached by."""
+        skey = (calib.meta_shapes(img_metas), h, w)
+        sht = self._shape_cache.get(skey)
+        if sht is None:
+            sht = calib.shape_tables(skey[0], h, w, stride=self.stride, depth_num=self.depth_num,
                                      position_range=tuple(self.post_range_h64.tolist()))
-            hit['dt'] = 0.0
-            if self.kind == 'T' and len(img_metas) > self.num_views:
-                ts = hit['timestamps']
-                hit['dt'] = float(ts[self.num_views:].mean() - ts[:self.num_views].mean())
-            if len(self._tab_cache) >= 64:
-                self._tab_cache.pop(next(iter(self._tab_cache)))
-            self._tab_cache[key] = hit
-        return key, hit
+            if len(self._shape_cache) >= 16:
+                self._shape_cache.pop(next(iter(self._shape_cache)))
+            self._shape_cache[skey] = sht
+        return skey, sht
 
     def _host_prepare(self, proposals_list, metas_list, V, h, w):
         """Host side of one batch of samples: RoI lists + calibration tables into the workspace's pinned staging buffers.
-        The calibration tables are rebuilt / re-uploaded only when some sample's img_metas change."""
+        The camera matrices are compared with the previous frame's and, when they differ (every frame on the two-frame path: ego motion),
+        the derived tables are rebuilt with batched calls and uploaded; the tables of the padding geometry only when the shapes change."""
         B = len(proposals_list)
         Vg = V // B
-        rois_l, counts, grp = [], [], [0]
+        # bbox2roi (mmdet) + the dummy proposal rule (RH/mv2d_head.py:105-108), in numpy straight into the staging buffer
+        arrs, counts, grp = [], [], [0]
         for b, (props, metas) in enumerate(zip(proposals_list, metas_list)):
             assert len(props) == Vg and len(metas) == Vg, 'every sample of a batch needs the same number of views'
-            r, c = self._rois_host(props, b * Vg)
-            rois_l.append(r); counts += c; grp.append(grp[-1] + r.shape[0])
-        rois_h = torch.cat(rois_l, 0) if B > 1 else rois_l[0]
-        R = rois_h.shape[0]
+            pa = [(p.detach().to('cpu', F32).numpy() if torch.is_tensor(p) else np.asarray(p, dtype=np.float32)).reshape(-1, 6 if len(p) == 0 else np.shape(p)[-1])
+                  for p in props]
+            if sum(a.shape[0] for a in pa) == 0:
+                pa[0] = np.array([[0, 50, 50, 100, 100, 0]], dtype=np.float32)
+            arrs += pa
+            counts += [a.shape[0] for a in pa]
+            grp.append(grp[-1] + sum(a.shape[0] for a in pa))
+        R = grp[-1]
         ws = self._workspace(V, h, w, R, Vg)
         sh = ws['shared']
         if 'done_ev' in sh:
             sh['done_ev'].synchronize()      # the previous frame on this workspace must have consumed the staging buffers
-        tabs = [self._sample_tables(m, h, w) for m in metas_list]
-        key = tuple(k for k, _ in tabs)
-        fts = [t for _, t in tabs]
-        if sh.get('frame_key') != key:
-            f0 = fts[0]
+        rois_np = ws['rois_h'].numpy()
+        rois_np[:, 0] = np.repeat(np.arange(V, dtype=np.float32), counts)
+        rois_np[:, 1:] = np.concatenate([a[:, :4] for a in arrs if a.shape[0]], 0)
+        bh, lay = ws['blob_h'], ws['blob_layout']
+
+        def put(k, src):
+            o_, n, dt_ = lay[k]
+            bh[o_:o_ + n * torch.empty(0, dtype=dt_).element_size()].view(dt_).copy_(src.reshape(-1))
+        split = lay['coords_w'][0]                     # [0, split): camera matrices (per frame); [split, end): padding geometry (per rig)
+        shp = [self._shape_tables(m, h, w) for m in metas_list]
+        shape_key = tuple(k for k, _ in shp)
+        fts = [t for _, t in shp]
+        f0 = fts[0]
+        if sh.get('shape_key') != shape_key:
             assert all(t['pad_h'] == f0['pad_h'] and t['pad_w'] == f0['pad_w'] for t in fts), 'samples of a batch share one pad_shape'
-            bh = ws['blob_h']
-            for k, (o_, n, dt_) in ws['blob_layout'].items():
-                nb = n * torch.empty(0, dtype=dt_).element_size()
-                if k in ('coords_w', 'coords_h', 'coords_d'):
-                    src = f0[k]
-                elif k == 'embeds':
-                    src = torch.cat([t[k] for t in fts], 1) if B > 1 else f0[k]        # [3, P]: the samples side by side
-                else:
-                    src = torch.cat([t[k].reshape(-1) for t in fts]) if B > 1 else f0[k]
-                bh[o_:o_ + nb].view(dt_).copy_(src.reshape(-1))
-            sh['frame_key'], sh['frame_scalars'] = key, dict(pad_h=f0['pad_h'], pad_w=f0['pad_w'], dt=f0['dt'])
-            # the calibration tables change only when img_metas change: upload them here (stream-ordered before the frame),
-            # not once per frame
-            ws['blob_d'].copy_(bh, non_blocking=True)
+            for k in ('coords_w', 'coords_h', 'coords_d'):
+                put(k, f0[k])
+            put('embeds', torch.cat([t['embeds'] for t in fts], 1) if B > 1 else f0['embeds'])        # [3, P]: the samples side by side
+            put('pad_mask', torch.cat([t['pad_mask'] for t in fts]) if B > 1 else f0['pad_mask'])
+            ws['blob_d'][split:].copy_(bh[split:], non_blocking=True)
+            sh['shape_key'] = shape_key
+        flat = [m for metas in metas_list for m in metas]
+        mats = np.stack([np.stack([np.asarray(m[k]) for m in flat]) for k in ('intrinsics', 'extrinsics', 'lidar2img')]).astype(np.float64, copy=False)
+        ts = np.array([m.get('timestamp', 0.0) for m in flat], dtype=np.float64).reshape(B, Vg)
+        prev = sh.get('mats')
+        if prev is None or prev.shape != mats.shape or not np.array_equal(prev, mats):
+            # the camera matrices changed: inverse / view-to-view tables rebuilt on the host (batched, ~0.5 ms for 8 x 12 views) and uploaded
+            # here, stream-ordered before the frame (23 KB per 12-view sample)
+            _, img2lidar, trans, _ = calib.geometry_tables_batch(metas_list)
+            put('viewK', torch.from_numpy(mats[0])); put('viewE', torch.from_numpy(mats[1]))
+            put('img2lidar', img2lidar); put('trans', trans)
+            ws['blob_d'][:split].copy_(bh[:split], non_blocking=True)
+            sh['mats'] = mats
+        nv = self.num_views
+        dts = [float(ts[b, nv:].mean() - ts[b, :nv].mean()) if (self.kind == 'T' and Vg > nv) else 0.0 for b in range(B)]
+        sh['frame_scalars'] = dict(pad_h=f0['pad_h'], pad_w=f0['pad_w'], dt=dts[0])
         if self.pe_sine_table:
             # the sine branch depends on the padding geometry of the samples only (not on calibration): rebuilt when that changes
-            skey = tuple(tuple((tuple(m['pad_shape'][:2]), tuple(m['img_shape'][:2])) for m in metas) for metas in metas_list)
+            skey = (self._weights_version,) + tuple(k[0] for k in shape_key)
             if sh.get('sine_key') != skey:
-                same = all(k == skey[0] for k in skey)
+                same = all(k == skey[1] for k in skey[1:])
                 P = V * h * w
                 Pt = P // B if same else P                                  # one sample's positions when all samples share the geometry
                 T, o, W_ = ws['tab'], ops, self.w
@@ -426,12 +424,12 @@ class HeadEngine:
                 sh['sine_key'] = skey
             if ws.get('sine_gen') != sh['sine_gen']:
                 ws['sine_gen'] = sh['sine_gen']
-                ws.pop('graph', None)                                        # this workspace's graph was captured with another table
-        ws['rois_h'].copy_(rois_h)
-        ws['view_start_h'].copy_(torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32))
-        ws['grp_start_h'].copy_(torch.tensor(grp, dtype=torch.int32))
-        if self.kind == 'T' and B > 1:
-            ws['dt_rows_h'].copy_(torch.cat([torch.full((grp[b + 1] - grp[b],), fts[b]['dt'], dtype=F32) for b in range(B)]))
+                ws['graph_stale'] = True                                     # this workspace's graphs were captured with another table
+        ws['view_start_h'].numpy()[:] = np.concatenate([[0], np.cumsum(counts)])
+        ws['grp_start_h'].numpy()[:] = grp
+        if self.kind == 'T':
+            # the frame time step is DATA (per row), not a scalar baked into a captured graph: real time stamps differ from frame to frame
+            ws['dt_rows_h'].numpy()[:] = np.repeat(np.asarray(dts, dtype=np.float32), np.diff(grp))
         sc = dict(sh['frame_scalars'])
         sc['max_per_view'] = max(counts)
         sc['max_rows'] = max(grp[b + 1] - grp[b] for b in range(B))
@@ -666,7 +664,7 @@ class HeadEngine:
 
     def _enqueue_heads(self, ws, R, dt):
         # a14: every per-layer cls / reg branch + the reference-point tail in ONE launch (row-block fused)
-        dt_rows = ws['dt_rows'] if (self.kind == 'T' and (ws['B'] > 1 or ws.get('dn'))) else None
+        dt_rows = ws['dt_rows'] if self.kind == 'T' else None
         if self.heads_x3:
             ops.heads_fused_x3(ws['outs'], self.cls_ptrs_x3, self.reg_ptrs_x3, ws['ref'], ws['cls'], ws['reg'], R, self.L, self.pc_range_h, dt,
                                dt_rows=dt_rows)
@@ -722,9 +720,13 @@ class HeadEngine:
             return dict(self._result(ws, R, keep_stages, batch), dt=sc['dt'])
         # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
-        gkey = (ptrs, sc['pad_h'], sc['pad_w'], sc['dt'], sc['max_per_view'], sc['max_rows'])
-        g = ws.get('graph')
-        if g is None or ws.get('graph_key') != gkey:
+        gkey = (ptrs, sc['pad_h'], sc['pad_w'], sc['max_per_view'], sc['max_rows'], self._weights_version)   # load_state() re-allocates the weights
+        graphs = ws.setdefault('graphs', {})             # one graph per (input buffers, frame scalars): a producer that alternates between
+        g = graphs.get(gkey)                             # a few static output buffers replays a few graphs, it does not re-capture
+        if ws.pop('graph_stale', False):
+            graphs.clear()
+            g = None
+        if g is None:
             prof, self.prof = self.prof, None
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -736,7 +738,11 @@ class HeadEngine:
             with torch.cuda.graph(g):
                 self._enqueue(ws, feat, R, V, h, w, sc)
             self.prof = prof
-            ws['graph'], ws['graph_key'], ws['graph_feat'] = g, gkey, feat
+            if len(graphs) >= 8:
+                graphs.pop(next(iter(graphs)))
+            graphs[gkey] = (g, feat)
+        else:
+            g = g[0]
         g.replay()
         self._mark_done(ws)
         return dict(self._result(ws, R, keep_stages, batch), dt=sc['dt'])
@@ -804,7 +810,7 @@ class HeadEngine:
         other.__dict__.update(self.__dict__)
         other._ws = {}
         other._ws_base = {}
-        other._tab_cache = {}
+        other._shape_cache = self._shape_cache      # pure functions of the padding geometry: shared
         other.prof = None
         return other
 

@@ -28,8 +28,9 @@ def _rng(seed):
     return np.random.Generator(np.random.PCG64(seed))
 
 
-def make_img_metas(views_per_frame, img_h, img_w, frames=1, pad_w=None, pad_h=None, yaw_step_deg=None):
-    """Return a list of per-view img_meta dicts (len = views_per_frame*frames)."""
+def make_img_metas(views_per_frame, img_h, img_w, frames=1, pad_w=None, pad_h=None, yaw_step_deg=None, ego=0.0):
+    """Return a list of per-view img_meta dicts (len = views_per_frame*frames).  ego: extra ego motion between the frames (metres along
+    the driving direction) and time-stamp jitter of the previous frame -- every real two-frame sample has its own."""
     pad_w = img_w if pad_w is None else pad_w
     pad_h = img_h if pad_h is None else pad_h
     metas = []
@@ -50,7 +51,7 @@ def make_img_metas(views_per_frame, img_h, img_w, frames=1, pad_w=None, pad_h=No
             Rz = np.array([[c, s, 0], [-s, c, 0], [0, 0, 1]], dtype=np.float64)
             T = np.eye(4, dtype=np.float64)
             T[:3, :3] = R0 @ Rz
-            T[:3, 3] = [0.0, 1.5, -0.5 - 0.4 * f]
+            T[:3, 3] = [0.0, 1.5, -0.5 - (0.4 + ego) * f]
             metas.append(dict(
                 intrinsics=K,
                 extrinsics=T.T.copy(),
@@ -58,7 +59,7 @@ def make_img_metas(views_per_frame, img_h, img_w, frames=1, pad_w=None, pad_h=No
                 pad_shape=(pad_h, pad_w, 3),
                 img_shape=(img_h, img_w, 3),
                 num_views=nv,
-                timestamp=0.5 * f,
+                timestamp=(0.5 + 0.02 * ego) * f,
             ))
     return metas
 
@@ -203,14 +204,15 @@ WORKLOADS = {
 }
 
 
-def make_problem(name, seed=0):
-    """Return dict(kind, feat [V,256,h,w] f32, proposals list[V] of [n,6] f32, img_metas list[V])."""
+def make_problem(name, seed=0, with_feat=True, ego=0.0):
+    """Return dict(kind, feat [V,256,h,w] f32, proposals list[V] of [n,6] f32, img_metas list[V]).  with_feat=False: no feature map
+    (bench.py draws the maps of its rotating frame sets on the device); ego: see make_img_metas."""
     kind, vpf, frames, H, W, pad_w, n = WORKLOADS[name]
     pw = W if pad_w is None else pad_w
     V = vpf * frames
-    metas = make_img_metas(vpf, H, W, frames, pad_w=pw, yaw_step_deg=(40.0 if vpf < 6 else None))
+    metas = make_img_metas(vpf, H, W, frames, pad_w=pw, yaw_step_deg=(40.0 if vpf < 6 else None), ego=ego)
     props = make_proposals(V, n, H, W, seed + 1)
-    feat = make_feat(V, H // 16, pw // 16, seed + 2)
+    feat = make_feat(V, H // 16, pw // 16, seed + 2) if with_feat else None
     return dict(kind=kind, feat=feat, proposals=props, img_metas=metas, name=name,
                 views_per_frame=vpf, frames=frames)
 

@@ -404,17 +404,18 @@ def test_engine_ragged_views(kind):
 
 @pytest.mark.parametrize('kind', ['S', 'T'])
 def test_sine_table_variant_matches_the_default_path(kind):
-    """Opt-in MV2D_PE_SINE_TABLE: adapt_pos3d(sine) read from a per-geometry table instead of evaluated per frame.
-    Same PE / keys / outputs as the default path up to the accumulation order of one MLP; also with a padded view and with a batch whose
-    samples differ in padding geometry (one table row per position of the whole batch then)."""
+    """Default path: adapt_pos3d(sine) read from a per-(weights, geometry) table; MV2D_PE_SINE_TABLE=0 evaluates it per frame like the
+    reference.  Same PE / keys / outputs up to the accumulation order of one MLP; also with a padded view and with a
+    batch whose samples differ in padding geometry (one table row per position of the whole batch then)."""
     from mv2d_amd import engine as E
     sd = {k: torch.from_numpy(v) for k, v in synthetic.make_head_state(seed=0).items()}
     name = 'cfg1_s' if kind == 'S' else 'cfg1_t'
     prob = synthetic.make_problem(name, seed=0)
     nv = prob['views_per_frame']
     a = E.HeadEngine(sd, kind, 'cuda', num_views=nv)
+    a.pe_sine_table = False
     b = E.HeadEngine(sd, kind, 'cuda', num_views=nv)
-    b.pe_sine_table = True
+    assert b.pe_sine_table
     feat = torch.from_numpy(prob['feat']).cuda()
     props = [torch.from_numpy(p) for p in prob['proposals']]
     metas = prob['img_metas']
@@ -433,3 +434,29 @@ def test_sine_table_variant_matches_the_default_path(kind):
     R = single[0].shape[1]
     ob = b.run_batch([feat, feat], [props, props], [metas, narrow])
     assert torch.equal(ob['cls'][:, :R], single[0][:, :R]) and torch.equal(ob['cls'][:, R:2 * R], single[1][:, :R])
+
+
+@pytest.mark.parametrize('kind', ['S', 'T'])
+def test_sine_table_follows_the_weights(kind):
+    """The folded sine branch is keyed on the weights as well as on the geometry: load_state() with other adapt_pos3d weights must give
+    exactly what a fresh engine with those weights gives (hipGraph replay included), and never the stale table."""
+    from mv2d_amd import engine as E
+    sd = {k: torch.from_numpy(v).clone() for k, v in synthetic.make_head_state(seed=0).items()}
+    name = 'cfg1_s' if kind == 'S' else 'cfg1_t'
+    prob = synthetic.make_problem(name, seed=0)
+    nv = prob['views_per_frame']
+    feat = torch.from_numpy(prob['feat']).cuda()
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    metas = prob['img_metas']
+    eng = E.HeadEngine(sd, kind, 'cuda', num_views=nv)
+    assert eng.pe_sine_table
+    first = eng.run(feat, props, metas, use_graph=True)['cls'].clone()
+    sd2 = dict(sd)
+    for k in ('position_encoding.adapt_pos3d.0.weight', 'position_encoding.adapt_pos3d.2.weight', 'position_encoding.adapt_pos3d.2.bias'):
+        sd2[k] = sd[k] * 1.5 + 0.01
+    eng.load_state(sd2)
+    again = eng.run(feat, props, metas, use_graph=True)['cls'].clone()
+    fresh = E.HeadEngine(sd2, kind, 'cuda', num_views=nv).run(feat, props, metas)['cls']
+    assert torch.equal(again, fresh)
+    assert not torch.equal(again, first)
+
