@@ -260,13 +260,14 @@ int mv2d_raw_xattn_fwd(const float* qk, const void* Xk, const void* Xv, const in
  *   shared by all layers and heads; CSR row_ptr [R+1] / col_idx [nnz]; z [R,8,256] fp32 = sum_j p_hj v_j per head.  Key tiles of
  *   16 rows are gathered with whole-row coalesced loads into swizzled LDS tiles, logits and P.V run on bf16 MFMAs (hi / lo split
  *   of the query map and of P: fp32-class on the query side), online softmax.  waves = 4 | 8 waves per query (0: default).
- *   Rows without an allowed key: z = NaN (empty_nan = 1) or 0.  dbg_logits (optional): head h at dbg_logits[h*dbg_stride + e],
+ *   Xk_lo / Xv_lo (both or neither, may be NULL): bf16 remainders of the rows (rows = Xk + Xk_lo): the fp32-class key side of the
+ *   engine's index-exact validation mode.  Rows without an allowed key: z = NaN (empty_nan = 1) or 0.  dbg_logits (optional): head h at dbg_logits[h*dbg_stride + e],
  *   e in CSR order, WITHOUT the per-(query, head) constant q_h . bk_h that cancels in the softmax.
  * mv2d_xattn_ctxmap: ctx [R,256] = Wv_h z_h + bv (bf16x3; WB_hi / WB_lo = the packed value in_proj weight); rows without an
  *   allowed key (row_ptr) give NaN / 0 like nn.MultiheadAttention / the 'zero' policy of the engine. */
 int mv2d_xattn_qmap(const float* q, const void* WA_hi, const void* WA_lo, void* Qt, int R, void* stream);
-int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* Xv, const int* row_ptr, const int* col_idx, float* z,
-                        float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves, void* stream);
+int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
+                        const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves, void* stream);
 int mv2d_xattn_ctxmap(const float* z, const void* WB_hi, const void* WB_lo, const float* bv, const int* row_ptr, float* ctx, int R,
                       int empty_nan, void* stream);
 
@@ -336,11 +337,13 @@ int mv2d_roi_positions(const float* rois, const unsigned char* pad_mask, unsigne
 int mv2d_csr_from_corr(const int* match, int* row_ptr, int* col_idx, int* nnz_out, int R, int V, int topk, void* stream);
 
 /* PE inputs at the listed key positions only (MU/pe.py:84-135 frustum, MU/positional_encoding.py:78-95 sine) + feature gather.
- * out: A_frustum [S,3*D] bf16, A_sine [S,384] bf16, Xf_bf16 [S,256], Xf_f32 [S,256] (optional: NULL when mv2d_pe_fused reads the map). */
+ * out: A_frustum [S,3*D] bf16, A_sine [S,384] bf16, Xf_bf16 [S,256], Xf_f32 [S,256] (optional: NULL when mv2d_pe_fused reads the map).
+ * A_frustum_f32 / A_sine_f32 (optional, the engine's index-exact validation mode): the same rows unrounded, with the logarithm in
+ * fp64 and library sin / cos. */
 int mv2d_pe_inputs(const int* s2pos, const int* S_dev, int S_max, const float* featcl, const double* img2lidar,
                    const double* coords_w, const double* coords_h, const double* coords_d, const float* embeds,
-                   const float* dim_t, void* A_frustum, void* A_sine, void* Xf_bf16, float* Xf_f32, int V, int h, int w,
-                   int depth_num, const double* position_range, void* stream);
+                   const float* dim_t, void* A_frustum, void* A_sine, void* Xf_bf16, float* Xf_f32, float* A_frustum_f32,
+                   float* A_sine_f32, int V, int h, int w, int depth_num, const double* position_range, void* stream);
 
 /* NMSFreeCoder.decode_single + get_bboxes (CB/coders/nms_free_coder.py:49-102, CB/util.py:60-87,
  * RH/bbox_heads/cross_attention_head.py:357-377): top-k over R*num_classes logits, denormalise, centre-range filter.

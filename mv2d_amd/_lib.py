@@ -58,7 +58,7 @@ SIGNATURES = {
     'mv2d_raw_xattn_fwd': (I, [P, P, P, P, P, P, I, I, P]),
     'mv2d_sparse_xattn_bwd': (I, [P] * 14 + [I, I, P]),
     'mv2d_xattn_qmap': (I, [P, P, P, P, I, P]),
-    'mv2d_xattn_tile_fwd': (I, [P, P, P, P, P, P, P, LL, I, I, I, P]),
+    'mv2d_xattn_tile_fwd': (I, [P, P, P, P, P, P, P, P, P, LL, I, I, I, P]),
     'mv2d_xattn_ctxmap': (I, [P, P, P, P, P, P, I, I, P]),
     'mv2d_box_params': (I, [P, P, P, P, P, I, P, I, F, F, F, P]),
     'mv2d_refpoint_posemb': (I, [P, I, P, P, P, P, P, I, P, P]),
@@ -70,7 +70,7 @@ SIGNATURES = {
     'mv2d_mask_compact': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, I, P]),
     'mv2d_roi_positions': (I, [P, P, P, P, P, P, P, I, I, I, I, F, F, P]),
     'mv2d_csr_from_corr': (I, [P, P, P, P, I, I, I, P]),
-    'mv2d_pe_inputs': (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
+    'mv2d_pe_inputs': (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
     'mv2d_result_pack': (I, [P, P, P, P, F, I, P, P, P, P, I, I, P]),
     'mv2d_pack_detections': (I, [P, P, P, P, P, I, I, I, P]),
     'mv2d_roi_align_bwd': (I, [P, P, P, P, I, I, I, I, F, I, P]),

@@ -598,7 +598,8 @@ __global__ __launch_bounds__(256) void pe_inputs_kernel(const int* __restrict__ 
                                                         const double* __restrict__ img2lidar, const double* __restrict__ coords_w, const double* __restrict__ coords_h,
                                                         const double* __restrict__ coords_d, const float* __restrict__ embeds, const float* __restrict__ dim_t,
                                                         unsigned short* __restrict__ A_frustum, unsigned short* __restrict__ A_sine, unsigned short* __restrict__ Xf_bf16,
-                                                        float* __restrict__ Xf_f32, int h, int w, int P, int D, double pr0, double pr1, double pr2,
+                                                        float* __restrict__ Xf_f32, float* __restrict__ A_frustum_f32, float* __restrict__ A_sine_f32,
+                                                        int h, int w, int P, int D, double pr0, double pr1, double pr2,
                                                         double pd0, double pd1, double pd2) {
     __shared__ __attribute__((aligned(16))) unsigned short rowbuf[4][3 * 256 + 384];      // frustum row (<= 768 values) | sine row (384)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -633,6 +634,8 @@ __global__ __launch_bounds__(256) void pe_inputs_kernel(const int* __restrict__ 
             // logarithm in fp32: 1e-7 absolute against a value that is rounded to bf16 right here (a double division + double log
             // are ~130 fp64 instructions, 192 of them per position: the kernel was bound by them)
             fr_row[dk * 3 + i] = f32_to_bf16(logf((float)x1 / (float)x2));
+            // index-exact validation mode: the unrounded fp32 row, quotient and logarithm in fp64 like the reference (MU/pe.py:130)
+            if (A_frustum_f32) A_frustum_f32[(long long)s * (3 * D) + dk * 3 + i] = (float)log(x1 / x2);
         }
     }
     // sine features, channel order (n | y | x).  NOT interleaved: the reference stacks sin/cos on dim=4 of a
@@ -648,6 +651,7 @@ __global__ __launch_bounds__(256) void pe_inputs_kernel(const int* __restrict__ 
         // for a value that is rounded to bf16 right here
         const float a = e / dim_t[i < 64 ? 2 * i : 2 * (i - 64) + 1];
         si_row[ch] = f32_to_bf16(i < 64 ? __sinf(a) : __cosf(a));
+        if (A_sine_f32) A_sine_f32[(long long)s * 384 + ch] = i < 64 ? sinf(a) : cosf(a);
     }
     __builtin_amdgcn_wave_barrier();                          // the rows are read back by the same wave only
     __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): LDS writes landed
@@ -971,15 +975,15 @@ extern "C" int mv2d_csr_from_corr(const int* match, int* row_ptr, int* col_idx, 
 
 extern "C" int mv2d_pe_inputs(const int* s2pos, const int* S_dev, int S_max, const float* featcl, const double* img2lidar,
                               const double* coords_w, const double* coords_h, const double* coords_d, const float* embeds,
-                              const float* dim_t, void* A_frustum, void* A_sine, void* Xf_bf16, float* Xf_f32, int V, int h, int w,
-                              int depth_num, const double* position_range, void* stream) {
+                              const float* dim_t, void* A_frustum, void* A_sine, void* Xf_bf16, float* Xf_f32, float* A_frustum_f32,
+                              float* A_sine_f32, int V, int h, int w, int depth_num, const double* position_range, void* stream) {
     MV2D_CHECK_ARG(s2pos && S_dev && featcl && img2lidar && coords_w && coords_h && coords_d && embeds && dim_t && A_frustum &&
                        A_sine && Xf_bf16 && position_range, "mv2d_pe_inputs: null pointer");
     MV2D_CHECK_ARG(depth_num <= 256 && (depth_num % 8) == 0, "mv2d_pe_inputs: depth_num must be a multiple of 8, <= 256");
     if (S_max == 0) return MV2D_OK;
     hipLaunchKernelGGL(pe_inputs_kernel, dim3(cdiv(S_max, 4)), dim3(256), 0, (hipStream_t)stream, s2pos, S_dev, featcl, img2lidar, coords_w,
                        coords_h, coords_d, embeds, dim_t, (unsigned short*)A_frustum, (unsigned short*)A_sine,
-                       (unsigned short*)Xf_bf16, Xf_f32, h, w, V * h * w, depth_num, position_range[0], position_range[1],
+                       (unsigned short*)Xf_bf16, Xf_f32, A_frustum_f32, A_sine_f32, h, w, V * h * w, depth_num, position_range[0], position_range[1],
                        position_range[2], position_range[3] - position_range[0], position_range[4] - position_range[1],
                        position_range[5] - position_range[2]);
     MV2D_LAUNCH_CHECK();

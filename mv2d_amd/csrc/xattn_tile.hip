@@ -149,12 +149,15 @@ __global__ __launch_bounds__(512) void xattn_ctxmap_kernel(const float* __restri
 __device__ __forceinline__ unsigned int xt_lo_pair(unsigned int a, unsigned int b) { return (a & 0xffffu) | (b << 16); }          // (a.lo16, b.lo16): one v_perm_b32
 __device__ __forceinline__ unsigned int xt_hi_pair(unsigned int a, unsigned int b) { return (a >> 16) | (b & 0xffff0000u); }      // (a.hi16, b.hi16)
 
-template <int NW, bool DBG>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void xattn_tile_kernel(const uint4* __restrict__ Qt, const unsigned short* __restrict__ Xk,
-                                                             const unsigned short* __restrict__ Xv, const int* __restrict__ row_ptr,
+// XLO (the engine's index-exact validation mode): the key / value rows come as bf16 hi + lo pairs (fp32-class key side):
+// logits += Qt_hi . Xk_lo, z += P_hi . Xv_lo (the lo x lo terms, 2^-18 relative, are dropped).
+template <int NW, bool DBG, bool XLO>
+__global__ __launch_bounds__(64 * NW, XLO ? 1 : 2) void xattn_tile_kernel(const uint4* __restrict__ Qt, const unsigned short* __restrict__ Xk,
+                                                             const unsigned short* __restrict__ Xv, const unsigned short* __restrict__ Xk_lo,
+                                                             const unsigned short* __restrict__ Xv_lo, const int* __restrict__ row_ptr,
                                                              const int* __restrict__ col_idx, float* __restrict__ z,
                                                              float* __restrict__ dbg_logits, long long dbg_stride, int R, int empty_nan) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NW * 8192 + NW * 512 + NW * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NW * 8192 + NW * 512 + NW * 64 + (XLO ? NW * 8192 : 0)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
     // XCD-aware block -> query map (block b runs on XCD b % 8): every XCD gets one contiguous range of queries, so neighbouring
     // queries (T path: overlapping key sets) share an L2.  Speed only; any map is correct.
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void xattn_tile_kernel(co
     uint4* kt = reinterpret_cast<uint4*>(smem) + wave * 512;
     float* pl = reinterpret_cast<float*>(smem + NW * 8192) + wave * 128;
     float* sst = reinterpret_cast<float*>(smem + NW * 8192 + NW * 512);              // [NW][8] running max, [NW][8] sums
+    uint4* kt2 = reinterpret_cast<uint4*>(smem + NW * 8192 + NW * 512 + NW * 64) + wave * 512;      // XLO: the lo parts of the key tile
 
     // this lane's rows of S / z: operand rows 4g + i; rows 0-7 carry the hi parts, 8-15 the lo parts of head (4 (g & 1) + i)
     float m_run[4], l_run[4];
@@ -211,6 +215,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void xattn_tile_kernel(co
             const int rowi = 2 * i + (lane >> 5);
             kt[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = kreg[i];
         }
+        uint4 vlo[4][2];
+        if (XLO) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int rowi = 2 * i + (lane >> 5);
+                const int ridx = __shfl(myidx, rowi, 64);
+                kt2[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = *reinterpret_cast<const uint4*>(Xk_lo + (long long)ridx * C + (lane & 31) * 8);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int vidx = __shfl(myidx, 4 * g + e, 64);
+                const unsigned short* vp = Xv_lo + (long long)vidx * C + 8 * n;
+                vlo[e][0] = *reinterpret_cast<const uint4*>(vp);
+                vlo[e][1] = *reinterpret_cast<const uint4*>(vp + 128);
+            }
+        }
         __builtin_amdgcn_wave_barrier();
         // ---- logits of the tile: D[row 4g+i][key n] = sum_c Qt[row][c] Xk[key][c]
         f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
@@ -219,6 +239,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void xattn_tile_kernel(co
             XtFrag kb;
             kb.u = kt[n * 32 + ((4 * s + g) ^ n)];
             sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[s].v, kb.v, sacc, 0, 0, 0);
+            if (XLO) {
+                XtFrag kl, qh;
+                kl.u = kt2[n * 32 + ((4 * s + g) ^ n)];
+                qh.u = n < 8 ? qa[s].u : make_uint4(0u, 0u, 0u, 0u);              // hi rows only
+                sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh.v, kl.v, sacc, 0, 0, 0);
+            }
         }
         const bool valid = kbase + n < end;
         const bool first = tt == wave;                                              // (wave-uniform) nothing accumulated yet: no rescale
@@ -248,7 +274,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void xattn_tile_kernel(co
             for (int i = 0; i < 4; ++i) pl[(4 * g + i) * 16 + n] = p[i];
         }
         __builtin_amdgcn_wave_barrier();
-        xt_s16x4 pa;
+        xt_s16x4 pa, pah;
         {
             const float4 pv = *reinterpret_cast<const float4*>(pl + (n & 7) * 16 + 4 * g);
             const unsigned int h0 = pack_bf16x2(pv.x, pv.y), h1 = pack_bf16x2(pv.z, pv.w);
@@ -256,6 +282,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void xattn_tile_kernel(co
             const unsigned int l1 = pack_bf16x2(pv.z - __uint_as_float(h1 << 16), pv.w - __uint_as_float(h1 & 0xffff0000u));
             const uint2 sel = n < 8 ? make_uint2(h0, h1) : make_uint2(l0, l1);
             pa = __builtin_bit_cast(xt_s16x4, sel);
+            pah = __builtin_bit_cast(xt_s16x4, n < 8 ? make_uint2(h0, h1) : make_uint2(0u, 0u));
         }
         // ---- z = alpha z + P . Xv_tile; column tile (H, w): output column n <-> channel 128 H + 8 n + w
 #pragma unroll
@@ -274,7 +301,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void xattn_tile_kernel(co
 #pragma unroll
                     for (int i = 0; i < 4; ++i) zc[i] *= alpha[i];
                 }
-                Z[H * 8 + w] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, __builtin_bit_cast(xt_s16x4, vb), zc, 0, 0, 0);
+                zc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, __builtin_bit_cast(xt_s16x4, vb), zc, 0, 0, 0);
+                if (XLO) {
+                    const unsigned int q0[4] = {vlo[0][H].x, vlo[0][H].y, vlo[0][H].z, vlo[0][H].w}, q1[4] = {vlo[1][H].x, vlo[1][H].y, vlo[1][H].z, vlo[1][H].w};
+                    const unsigned int q2[4] = {vlo[2][H].x, vlo[2][H].y, vlo[2][H].z, vlo[2][H].w}, q3[4] = {vlo[3][H].x, vlo[3][H].y, vlo[3][H].z, vlo[3][H].w};
+                    const uint2 vl = (w & 1) ? make_uint2(xt_hi_pair(q0[d], q1[d]), xt_hi_pair(q2[d], q3[d]))
+                                             : make_uint2(xt_lo_pair(q0[d], q1[d]), xt_lo_pair(q2[d], q3[d]));
+                    zc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pah, __builtin_bit_cast(xt_s16x4, vl), zc, 0, 0, 0);
+                }
+                Z[H * 8 + w] = zc;
             }
         }
         __builtin_amdgcn_wave_barrier();                                             // before the next tile overwrites kt / pl
@@ -363,19 +398,22 @@ extern "C" int mv2d_xattn_ctxmap(const float* z, const void* WB_hi, const void* 
     return MV2D_OK;
 }
 
-extern "C" int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* Xv, const int* row_ptr, const int* col_idx, float* z,
-                                   float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves, void* stream) {
+extern "C" int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
+                                   const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves, void* stream) {
     MV2D_CHECK_ARG(Qt && Xk && Xv && row_ptr && col_idx && z && R >= 0, "mv2d_xattn_tile_fwd: bad args");
-    MV2D_CHECK_ARG(((uintptr_t)Qt & 15) == 0 && ((uintptr_t)Xk & 15) == 0 && ((uintptr_t)Xv & 15) == 0 && ((uintptr_t)z & 15) == 0,
-                   "mv2d_xattn_tile_fwd: operands must be 16-byte aligned");
+    MV2D_CHECK_ARG((Xk_lo == nullptr) == (Xv_lo == nullptr), "mv2d_xattn_tile_fwd: Xk_lo and Xv_lo come together");
+    MV2D_CHECK_ARG(((uintptr_t)Qt & 15) == 0 && ((uintptr_t)Xk & 15) == 0 && ((uintptr_t)Xv & 15) == 0 && ((uintptr_t)z & 15) == 0 &&
+                       ((uintptr_t)Xk_lo & 15) == 0 && ((uintptr_t)Xv_lo & 15) == 0, "mv2d_xattn_tile_fwd: operands must be 16-byte aligned");
     MV2D_CHECK_ARG(waves == 0 || waves == 4 || waves == 8, "mv2d_xattn_tile_fwd: waves per query must be 4 or 8 (0: default)");
     if (R == 0) return MV2D_OK;
     static const int env_nw = getenv("MV2D_XATTN_NW") ? atoi(getenv("MV2D_XATTN_NW")) : 0;       // experiment switch
     const int nw = waves ? waves : (env_nw == 8 ? 8 : 4);      // 4: best of {4, 8} on both paths (cfg2_s 41 vs 74 us, cfg3_t 73 vs 104 us per layer)
-#define MV2D_XT(NW, DBG) hipLaunchKernelGGL((xattn_tile_kernel<NW, DBG>), dim3(R), dim3(64 * NW), 0, (hipStream_t)stream, (const uint4*)Qt, \
-                                            (const unsigned short*)Xk, (const unsigned short*)Xv, row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan)
-    if (dbg_logits) { if (nw == 8) MV2D_XT(8, true); else MV2D_XT(4, true); }
-    else { if (nw == 8) MV2D_XT(8, false); else MV2D_XT(4, false); }
+#define MV2D_XT(NW, DBG, XLO) hipLaunchKernelGGL((xattn_tile_kernel<NW, DBG, XLO>), dim3(R), dim3(64 * NW), 0, (hipStream_t)stream, (const uint4*)Qt, \
+                                                 (const unsigned short*)Xk, (const unsigned short*)Xv, (const unsigned short*)Xk_lo, (const unsigned short*)Xv_lo, \
+                                                 row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan)
+    if (Xk_lo) { if (dbg_logits) MV2D_XT(4, true, true); else MV2D_XT(4, false, true); }            // validation mode: 4 waves only
+    else if (dbg_logits) { if (nw == 8) MV2D_XT(8, true, false); else MV2D_XT(4, true, false); }
+    else { if (nw == 8) MV2D_XT(8, false, false); else MV2D_XT(4, false, false); }
 #undef MV2D_XT
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;

@@ -42,7 +42,7 @@ class HeadEngine:
     def __init__(self, state_dict, kind, device, num_views=6, topk=None, expand_stride=None, num_layers=L_DEFAULT,
                  max_num=300, pc_range=(-51.2, -51.2, -5.0, 51.2, 51.2, 3.0),
                  post_range=(-61.2, -61.2, -10.0, 61.2, 61.2, 10.0), depth_num=64, stride=16, col_cap_per_query=2048,
-                 iou_thr=0.0, ratio=0.0, masked_row='nan'):
+                 iou_thr=0.0, ratio=0.0, masked_row='nan', exact=None):
         assert kind in ('S', 'T')
         self.kind = kind
         self.dev = torch.device(device)
@@ -100,6 +100,15 @@ class HeadEngine:
         self.xattn_waves = int(nw) if nw else 4                             # waves per query (8 measured slower on both paths)
         self.qg_x3 = os.environ.get('MV2D_QG_X3', '1') == '1'          # query-generator fcs + first in_proj as LDS-tiled bf16x3 linears (0: exact fp32)
         self.heads_x3 = os.environ.get('MV2D_HEADS_X3', '1') == '1'    # prediction branches in bf16x3 (0: exact fp32)
+        # INDEX-EXACT VALIDATION MODE (exact=True / MV2D_EXACT=1): every bf16 rounding of the default path is replaced by fp32-class
+        # arithmetic -- PE MLPs and the query generator's conv in bf16x3 / exact-fp32 MFMA GEMMs on unrounded inputs, key / value rows as
+        # bf16 hi + lo pairs in the tile attention -- so that the INTEGER outputs (labels, bbox_index) can be compared bit for bit with
+        # the reference's (tests/test_gpu_golden.py).  Eager only (device-side counts are read back, buffers allocated per frame), several
+        # times slower: a checker for the default path's near-tie reorderings, not a deployment mode.
+        self.exact = (os.environ.get('MV2D_EXACT', '0') == '1') if exact is None else bool(exact)
+        if self.exact:
+            assert self.tile_attn, 'the exact mode runs on the tile cross-attention route'
+            self.pe_sine_table = False
         self.load_state(state_dict)
 
     # ------------------------------------------------------------------------------------------ weights
@@ -190,6 +199,11 @@ class HeadEngine:
         for n, t in zip(names, packs):
             w['pe_pack'][n] = flat[off:off + t.numel()]
             off += t.numel()
+        if self.exact:
+            for n_, k_ in (('w1a', 'position_encoder.0'), ('w1b', 'position_encoder.2'), ('w2a', 'adapt_pos3d.0'), ('w2b', 'adapt_pos3d.2'),
+                           ('wr', 'fpe.conv_reduce'), ('we', 'fpe.conv_expand')):
+                w['pe_' + n_ + '_hl'] = ops.split_bf16x2(c1(k_ + '.weight').contiguous())
+            w['qg_conv_w32'] = conv.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous()
         self.w = w
         for k in ('cls_w0', 'cls_w3', 'reg_w0', 'reg_w2'):                              # [L,256,256] -> fragment-major copies for heads_fused
             w[k + 'p'] = ops.pack_wfrag_f32(w[k])
@@ -472,7 +486,7 @@ class HeadEngine:
         ws['zbuf'].zero_()
         # T path: the query-generator chain (RoIAlign -> conv -> fcs -> ref points -> query_pos) only needs the feature map and
         # the per-RoI cameras, the key chain (correlation -> key list -> PE -> K/V) only the boxes: run them on two streams
-        forked = self.kind == 'T' and self.prof is None and self.fork_qg
+        forked = self.kind == 'T' and self.prof is None and self.fork_qg and not self.exact
         if forked:
             main = torch.cuda.current_stream()
             side = ws.get('side_stream')
@@ -489,7 +503,9 @@ class HeadEngine:
                            self.stride, self.expand, col_cap=ws['col_cap'], n_samples=B)
             if not forked:
                 tk('roi_align')
-                o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'], R=R)
+                if self.exact:
+                    ws['roi_feat32'] = torch.empty((R, 49, C), device=self.dev, dtype=F32)
+                o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'], out0_f32=ws.get('roi_feat32') if self.exact else None, R=R)
         else:
             # positions any RoIAlign tap can touch (own rect + 1 cell) -> PE only there
             o.roi_positions(rois, ws['zero_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'], R, V, h, w,
@@ -513,7 +529,9 @@ class HeadEngine:
                     self.const['dim_t'], ws['A1'], ws['A2'], ws['Xf_b'], ws['Xf32'], V, h, w, self.depth_num, self.post_range_h64)
         md = ws['S_dev']
         tk('pe_fused')
-        if self.pe_fused:
+        if self.exact:
+            self._exact_pe(ws, featcl, P, V, h, w)
+        elif self.pe_fused:
             if self.pe_sine_table:
                 o.pe_fused_tab(ws['A1'], ws['Xf_b'], featcl, md, W_['pe_pack'], ws['shared']['sine_tab'], ws['shared']['sine_period'], ws['pe'], ws['Xk'], M=P,
                                row_index=ws['s2pos'])
@@ -528,8 +546,19 @@ class HeadEngine:
             o.gemm_bf16(ws['H2'], W_['pe_w2b'], W_['pe_b2b'], m_dev=md, add=ws['Pg'], out=ws['pe'], out2=ws['Xk'], add2=ws['Xf32'])
         if self.kind == 'S':
             tk('roi_align')
-            o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=ws['pos2s'],
-                        out1_is_sum=True, R=R)
+            if self.exact:
+                ws['roi_feat32'] = torch.empty((R, 49, C), device=self.dev, dtype=F32)
+                pe32 = torch.empty((R, 49, C), device=self.dev, dtype=F32)
+                o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], out0_f32=ws['roi_feat32'], out1_f32=pe32,
+                            map1_index=ws['pos2s'], out1_is_sum=True, R=R)
+                # key rows = RoIAlign(feat) + RoIAlign(pe), value rows = RoIAlign(feat): bf16 hi + lo pairs
+                ks, kl = o.split_bf16x2((ws['roi_feat32'] + pe32).view(R * 49, C))
+                vs, vl = o.split_bf16x2(ws['roi_feat32'].view(R * 49, C))
+                ws['roi_sum'].view(R * 49, C).copy_(ks); ws['roi_feat'].view(R * 49, C).copy_(vs)
+                ws['xk_lo'], ws['xv_lo'] = kl, vl
+            else:
+                o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=ws['pos2s'],
+                            out1_is_sum=True, R=R)
         if not forked:
             self._enqueue_qg(ws, R)
         # a18 key side: K/V projections of all layers at once (not needed by the raw-row attention)
@@ -556,12 +585,46 @@ class HeadEngine:
                       ws['labels'], ws['bbox_index'], ws['count'], grp_start=grp, max_grp_rows=sc['max_rows'] if B > 1 else 0)
         tk('end')
 
+    def _exact_pe(self, ws, featcl, P, V, h, w):
+        """Index-exact validation mode: the PE block (MU/pe.py:36-48,64-77,150-166) on unrounded fp32 inputs with bf16x3 GEMMs
+        (mv2d_gemm_x3), pe rows into ws['pe']; T path: key / value rows as bf16 hi + lo pairs.  Synchronises (reads S)."""
+        o, W_, T = ops, self.w, ws['tab']
+        S = int(ws['S_dev'].item())
+        d = self.dev
+        a1 = torch.empty((max(S, 1), 3 * self.depth_num), device=d, dtype=F32)
+        a2 = torch.empty((max(S, 1), 384), device=d, dtype=F32)
+        o.pe_inputs(ws['s2pos'], ws['S_dev'], P, featcl, T['img2lidar'], T['coords_w'], T['coords_h'], T['coords_d'], T['embeds'],
+                    self.const['dim_t'], ws['A1'], ws['A2'], ws['Xf_b'], None, V, h, w, self.depth_num, self.post_range_h64,
+                    A_frustum_f32=a1, A_sine_f32=a2)
+        if S == 0:
+            return
+        xf = featcl[ws['s2pos'][:S].long()].contiguous()                                 # gathered feature rows, fp32
+        lin = lambda x, n_, act=0: o.gemm_x3(x, W_['pe_' + n_ + '_hl'], W_['pe_b' + n_[1:]], act=act)
+        p1 = lin(lin(a1[:S], 'w1a', 1), 'w1b')
+        gate = torch.sigmoid(lin(lin(xf, 'wr', 1), 'we'))
+        p2 = lin(lin(a2[:S], 'w2a', 1), 'w2b')
+        pe = p1 * gate + p2
+        ws['pe'][:S].copy_(pe)
+        if self.kind == 'T':
+            ks, kl = o.split_bf16x2((xf + pe).contiguous())
+            vs, vl = o.split_bf16x2(xf)
+            ws['Xk'][:S].copy_(ks); ws['Xf_b'][:S].copy_(vs)
+            ws['xk_lo'] = torch.zeros((P, C), device=d, dtype=BF16); ws['xk_lo'][:S].copy_(kl)
+            ws['xv_lo'] = torch.zeros((P, C), device=d, dtype=BF16); ws['xv_lo'][:S].copy_(vl)
+
     def _enqueue_qg(self, ws, R):
         """a6-a8, a13: QueryGenerator on the RoI features -> reference points -> query positional embedding."""
         o, W_, tk = ops, self.w, self._tick
         # a6: QueryGenerator
         tk('qg_conv_gemm')
-        o.qg_conv_pool(ws['roi_feat'], W_['qg_conv_wp'], W_['qg_conv_b'], ws['x2'], R=R)
+        if self.exact:
+            # conv3x3 + ReLU + AvgPool2d(7) on the UNROUNDED RoI features: im2col (index plumbing) + exact-fp32 MFMA GEMM + pooling kernel
+            x = torch.nn.functional.pad(ws['roi_feat32'].view(R, 7, 7, C), (0, 0, 1, 1, 1, 1))
+            cols = torch.cat([x[:, ky:ky + 7, kx:kx + 7] for ky in range(3) for kx in range(3)], -1).reshape(R * 49, 9 * C).contiguous()
+            y = o.gemm_f32(cols, W_['qg_conv_w32'], W_['qg_conv_b'], act=1)
+            o.avgpool49(y, ws['x2'], C, R)
+        else:
+            o.qg_conv_pool(ws['roi_feat'], W_['qg_conv_wp'], W_['qg_conv_b'], ws['x2'], R=R)
         tk('qg_rest')
         if self.qg_x3:
             o.linear_x3(ws['x2'], W_['qg_fc_wx'], W_['qg_fc_b'], N=1024, K=256, act=1, clamp=5e3, out=ws['enc'], ldc=1056, M=R)
@@ -593,7 +656,8 @@ class HeadEngine:
         def cross_attn(i):
             if self.tile_attn:
                 o.xattn_qmap(ws['q'], W_[f'ca_mapA{i}'], ws['Qt'], R=R)
-                o.xattn_tile(ws['Qt'], xk_rows, xv_rows, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=self.empty_nan, waves=self.xattn_waves)
+                o.xattn_tile(ws['Qt'], xk_rows, xv_rows, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=self.empty_nan, waves=self.xattn_waves,
+                             Xk_lo=ws.get('xk_lo'), Xv_lo=ws.get('xv_lo'))
                 o.xattn_ctxmap(ws['zh'], W_[f'ca_mapB{i}'], W_[f'ca_v_b{i}'], ws['row_ptr'], ws['ctx'], R, empty_nan=self.empty_nan)
                 return
             if not self.raw_attn:
@@ -714,7 +778,7 @@ class HeadEngine:
             ptrs = tuple(f.data_ptr() for f in feat)
         assert V % B == 0
         ws, R, sc = self._host_prepare(proposals_list, metas_list, V, h, w)
-        if not use_graph:
+        if not use_graph or self.exact:
             self._enqueue(ws, feat, R, V, h, w, sc)
             self._mark_done(ws)
             return dict(self._result(ws, R, keep_stages, batch), dt=sc['dt'])

@@ -454,14 +454,15 @@ def xattn_qmap(q, WA, Qt=None, R=None):
     return Qt
 
 
-def xattn_tile(Qt, Xk, Xv, row_ptr, col_idx, out=None, R=None, dbg_logits=None, empty_nan=True, waves=0):
-    """Tile cross attention on the unprojected key / value rows: Qt from xattn_qmap, Xk / Xv [S,256] bf16 -> z [R,8,256] fp32."""
-    _req(Qt, BF16, 'Qt'); _req(Xk, BF16, 'Xk'); _req(Xv, BF16, 'Xv')
+def xattn_tile(Qt, Xk, Xv, row_ptr, col_idx, out=None, R=None, dbg_logits=None, empty_nan=True, waves=0, Xk_lo=None, Xv_lo=None):
+    """Tile cross attention on the unprojected key / value rows: Qt from xattn_qmap, Xk / Xv [S,256] bf16 -> z [R,8,256] fp32.
+    Xk_lo / Xv_lo: optional bf16 remainders of the rows (index-exact validation mode: fp32-class key side)."""
+    _req(Qt, BF16, 'Qt'); _req(Xk, BF16, 'Xk'); _req(Xv, BF16, 'Xv'); _req(Xk_lo, BF16, 'Xk_lo'); _req(Xv_lo, BF16, 'Xv_lo')
     _req(row_ptr, torch.int32, 'row_ptr'); _req(col_idx, torch.int32, 'col_idx'); _req(dbg_logits, torch.float32, 'dbg_logits')
     R = Qt.shape[0] if R is None else R
     if out is None:
         out = torch.empty((R, 8, 256), device=Qt.device, dtype=torch.float32)
-    check(_lib.load().mv2d_xattn_tile_fwd(_p(Qt), _p(Xk), _p(Xv), _p(row_ptr), _p(col_idx), _p(out), _p(dbg_logits),
+    check(_lib.load().mv2d_xattn_tile_fwd(_p(Qt), _p(Xk), _p(Xv), _p(Xk_lo), _p(Xv_lo), _p(row_ptr), _p(col_idx), _p(out), _p(dbg_logits),
                                           dbg_logits.stride(0) if dbg_logits is not None else 0, R, 1 if empty_nan else 0, int(waves), _stream()),
           'mv2d_xattn_tile_fwd')
     return out
@@ -612,10 +613,11 @@ def csr_from_corr(match, row_ptr, col_idx, nnz_out, R, V, topk):
 
 
 def pe_inputs(s2pos, S_dev, S_max, featcl, img2lidar, coords_w, coords_h, coords_d, embeds, dim_t, A_frustum, A_sine, Xf_bf16,
-              Xf_f32, V, h, w, depth_num, position_range_host):
+              Xf_f32, V, h, w, depth_num, position_range_host, A_frustum_f32=None, A_sine_f32=None):
+    _req(A_frustum_f32, torch.float32, 'A_frustum_f32'); _req(A_sine_f32, torch.float32, 'A_sine_f32')
     check(_lib.load().mv2d_pe_inputs(_p(s2pos), _p(S_dev), S_max, _p(featcl), _p(img2lidar), _p(coords_w), _p(coords_h), _p(coords_d),
-                                     _p(embeds), _p(dim_t), _p(A_frustum), _p(A_sine), _p(Xf_bf16), _p(Xf_f32), V, h, w, depth_num,
-                                     position_range_host.data_ptr(), _stream()), 'mv2d_pe_inputs')
+                                     _p(embeds), _p(dim_t), _p(A_frustum), _p(A_sine), _p(Xf_bf16), _p(Xf_f32), _p(A_frustum_f32),
+                                     _p(A_sine_f32), V, h, w, depth_num, position_range_host.data_ptr(), _stream()), 'mv2d_pe_inputs')
 
 
 def decode_topk(cls, reg, R, num_classes, max_num, post_center_range_host, boxes, scores, labels, bbox_index, count, topk_dbg=None,

@@ -45,7 +45,7 @@ def check_common(st, g):
     close(st['cls'].numpy().reshape(g['cls'].shape) if st['cls'].numel() == g['cls'].size else st['cls'], g['cls'], 1e-4)
 
 
-@pytest.mark.parametrize('name', ['micro_t', 'cfg1_t'])
+@pytest.mark.parametrize('name', ['micro_t', 'cfg1_t', 'cfg3_t'])
 def test_t_path_matches_reference(name):
     g = load_golden(name)
     st = run(name)
@@ -55,7 +55,12 @@ def test_t_path_matches_reference(name):
     blocked = unpack_bits(g['blocked_attn'], g['blocked_shape'])
     np.testing.assert_array_equal((~st['feat_for_rois'])[:, st['roi_mask']].numpy(), blocked)
     np.testing.assert_array_equal(st['key_padding'].numpy(), g['key_padding'])
-    close(st['reg'].numpy().reshape(g['reg'].shape), g['reg'], 1e-4)
+    reg = st['reg'].numpy().reshape(g['reg'].shape)
+    if name == 'cfg3_t':
+        # two frames: the golden 'reg' is CrossAttentionBoxHead.forward's output, BEFORE RH/mv2d_t_head.py:136-140 divides the velocities
+        # by dt = 0.5 s (the golden 'boxes' are after it)
+        reg = np.concatenate([reg[..., :8], reg[..., 8:] * 0.5], -1)
+    close(reg, g['reg'], 1e-4)
     # integer decode outputs: bit-exact
     idx = (st['bbox_index'] * 10 + st['labels']).numpy()
     # the reference applies the centre-range filter after top-k; compare on the kept set
@@ -76,7 +81,7 @@ def test_t_path_matches_reference(name):
             close(cap[l]['attn_mean'], g['attn_mean'][l], 1e-4)
 
 
-@pytest.mark.parametrize('name', ['micro_s', 'cfg1_s'])
+@pytest.mark.parametrize('name', ['micro_s', 'cfg1_s', 'cfg2_s'])
 def test_s_path_matches_reference(name):
     g = load_golden(name)
     st = run(name)
