@@ -120,7 +120,7 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
 
-    def frame_sets(n_streams, Bs, k_sets):
+    def frame_sets(n_streams, Bs, k_sets, vary_rois=False):
         """[stream][set] -> (feats [Bs*V,256,h,w] on the device, proposals per sample, metas per sample): every stream its own frames.
         Set 0 of stream 0 starts with the seed-0 problem (the one the CPU baseline and the stage timings use)."""
         out = []
@@ -132,7 +132,15 @@ def main():
                     if i == 0 and k == 0 and b == 0:
                         fl.append(feat); pl.append(props); ml.append(metas)
                         continue
-                    m = synthetic.make_problem(args.workload, seed=100000 * (i + 1) + 1000 * k + 10 * b + rank, with_feat=False)
+                    seed_ = 100000 * (i + 1) + 1000 * k + 10 * b + rank
+                    m = synthetic.make_problem(args.workload, seed=seed_, with_feat=False)
+                    if vary_rois:
+                        # every sample its own number of 2-D boxes: 5/6 .. 7/6 of the nominal count per view (250 .. 350 per 300-query sample)
+                        g_ = np.random.Generator(np.random.PCG64(seed_))
+                        wl = synthetic.WORKLOADS[args.workload]
+                        n_nom = wl[6]
+                        counts_ = [int(x) for x in g_.integers(n_nom * 5 // 6, n_nom * 7 // 6 + 1, len(m['proposals']))]
+                        m['proposals'] = synthetic.make_proposals(len(counts_), counts_, wl[3], wl[4], seed_ + 1)
                     fl.append(torch.randn(feat.shape, device=dev, generator=gen))
                     pl.append([torch.from_numpy(p) for p in m['proposals']]); ml.append(m['img_metas'])
                 sets.append((torch.cat(fl, 0).contiguous() if Bs > 1 else fl[0], pl, ml))
@@ -234,6 +242,12 @@ def main():
         same = [[sets_main[0][0]] for _ in range(args.inflight)]
         el = timed(make_step(engines, streams, same, None, B, payload, rotate=False), n_x, 3)
         extra['samples_s_fixed_inputs'] = round(args.inflight * B * n_x / el, 2)
+        # (a2) the number of RoIs differs from sample to sample and from step to step (launches run on 64-row buckets, one graph per bucket)
+        sets_v = frame_sets(args.inflight, B, K, vary_rois=True)
+        el = timed(make_step(engines, streams, sets_v, pool_main, B, payload), n_x, K + 1)
+        extra['samples_s_varying_rois'] = round(args.inflight * B * n_x / el, 2)
+        extra['varying_rois_per_sample'] = [int(sum(p.shape[0] for p in pl_)) for pl_ in sets_v[0][0][1]][:8]
+        del sets_v
         # (b) one sample per launch (the reference's call shape) on the same streams, rotating inputs
         sets1 = frame_sets(args.inflight, 1, K) if B > 1 else sets_main
         pool1 = meta_pool(args.inflight, 96) if B > 1 else pool_main

@@ -372,13 +372,18 @@ class HeadEngine:
             counts += [a.shape[0] for a in pa]
             grp.append(grp[-1] + sum(a.shape[0] for a in pa))
         R = grp[-1]
-        ws = self._workspace(V, h, w, R, Vg)
+        # The number of RoIs changes with every real frame.  All launches run on the BUCKET size (R rounded up to a multiple of 64): the
+        # rows R..cap-1 are copies of the last RoI that belong to no sample (not in view_start / grp_start), so nothing attends to them,
+        # nothing decodes them and the key set is unchanged; every R of a bucket shares one workspace and ONE captured graph.
+        cap = max(64, -(-R // 64) * 64)
+        ws = self._workspace(V, h, w, cap, Vg)
         sh = ws['shared']
         if 'done_ev' in sh:
             sh['done_ev'].synchronize()      # the previous frame on this workspace must have consumed the staging buffers
         rois_np = ws['rois_h'].numpy()
-        rois_np[:, 0] = np.repeat(np.arange(V, dtype=np.float32), counts)
-        rois_np[:, 1:] = np.concatenate([a[:, :4] for a in arrs if a.shape[0]], 0)
+        rois_np[:R, 0] = np.repeat(np.arange(V, dtype=np.float32), counts)
+        rois_np[:R, 1:] = np.concatenate([a[:, :4] for a in arrs if a.shape[0]], 0)
+        rois_np[R:] = rois_np[R - 1]
         bh, lay = ws['blob_h'], ws['blob_layout']
 
         def put(k, src):
@@ -443,10 +448,19 @@ class HeadEngine:
         ws['grp_start_h'].numpy()[:] = grp
         if self.kind == 'T':
             # the frame time step is DATA (per row), not a scalar baked into a captured graph: real time stamps differ from frame to frame
-            ws['dt_rows_h'].numpy()[:] = np.repeat(np.asarray(dts, dtype=np.float32), np.diff(grp))
+            dtr = ws['dt_rows_h'].numpy()
+            dtr[:R] = np.repeat(np.asarray(dts, dtype=np.float32), np.diff(grp))
+            dtr[R:] = dts[-1]
         sc = dict(sh['frame_scalars'])
+        assert max(counts) <= 1024, 'at most 1024 RoIs per view (mv2d_box_correlation)'
         sc['max_per_view'] = max(counts)
-        sc['max_rows'] = max(grp[b + 1] - grp[b] for b in range(B))
+        # top-k decode: the kernel sizes its candidate buffer by a power of two >= rows * classes; the launch gets the largest row count
+        # of that size class, so that frames with different RoI counts share the launch configuration (and the graph)
+        n_pow2 = 1024
+        while n_pow2 < max(grp[b + 1] - grp[b] for b in range(B)) * 10:
+            n_pow2 <<= 1
+        sc['max_rows'] = min(n_pow2 // 10, cap)
+        sc['cap'] = cap
         return ws, R, sc
 
     def _tick(self, name):
@@ -460,7 +474,7 @@ class HeadEngine:
         o, W_ = ops, self.w
         P, L, T = ws['P'], self.L, ws['tab']
         B, Vg = ws['B'], ws['Vg']
-        grp = ws['grp_start'] if B > 1 else None          # several samples share every launch (include/mv2d_hip.h "batches of samples")
+        grp = ws['grp_start']                             # first query row of every sample (device): sample-local self attention / top-k; the rows behind the last sample are bucket padding
         tk = self._tick
         tk('h2d')
         ws['dyn_d'].copy_(ws['dyn_h'], non_blocking=True)
@@ -582,7 +596,7 @@ class HeadEngine:
         tk('decode')
         # a21: NMS-free decode of the last layer (one top-k per sample)
         o.decode_topk(ws['cls'][L - 1], ws['reg'][L - 1], R, 10, self.max_num, self.post_range_h, ws['boxes'], ws['scores'],
-                      ws['labels'], ws['bbox_index'], ws['count'], grp_start=grp, max_grp_rows=sc['max_rows'] if B > 1 else 0)
+                      ws['labels'], ws['bbox_index'], ws['count'], grp_start=grp, max_grp_rows=sc['max_rows'])
         tk('end')
 
     def _exact_pe(self, ws, featcl, P, V, h, w):
@@ -688,7 +702,7 @@ class HeadEngine:
                 if ws.get('dn'):
                     o.self_attn_dn(ws['qkv'], ws['dn'][0], ws['dn'][1], out=ws['ctx'])      # training: denoising rows first (train_forward)
                 else:
-                    o.self_attn(ws['qkv'], ws['ctx'], R, grp_start=ws['grp_start'] if ws['B'] > 1 else None)
+                    o.self_attn(ws['qkv'], ws['ctx'], R, grp_start=ws['grp_start'])
             if self.fuse_rows and self.rows_x3:
                 sa_tail = o.sa_block_fused_x3 if sa_fused else o.attn_out_fused_x3      # self-attention core inside the row kernel, or not
                 sa_tail(ws['qkv'] if sa_fused else ws['ctx'], x_in, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
@@ -738,12 +752,20 @@ class HeadEngine:
 
     def _result(self, ws, R, keep_stages=False, batch=False):
         sel = (lambda t: t) if batch else (lambda t: t[0])
-        out = dict(R=R, ws=ws, cls=ws['cls'], reg=ws['reg'], boxes=sel(ws['boxes']), scores=sel(ws['scores']), labels=sel(ws['labels']),
+        out = dict(R=R, ws=ws, cls=ws['cls'][:, :R], reg=ws['reg'][:, :R], boxes=sel(ws['boxes']), scores=sel(ws['scores']), labels=sel(ws['labels']),
                    bbox_index=sel(ws['bbox_index']), count=ws['count'] if batch else ws['count'][:1], grp_start=ws['grp_start_h'].clone())
         if keep_stages:
-            out['stages'] = {k: ws[k].clone() for k in (kk for kk in ('rois', 'minv', 'enc', 'roi_feat', 'center', 'xyz', 'ref', 'posemb', 'qpos',
-                                                        'match', 'roi_mask', 'pos2s', 's2pos', 'S_dev', 'nnz', 'row_ptr', 'col_idx',
-                                                        'pe', 'Xk', 'Xf_b', 'KV', 'outs', 'cls', 'reg') if ws[kk] is not None)}
+            # copies of the intermediate buffers restricted to the REAL rows (the launches run on the bucket size, see _host_prepare)
+            rows0 = ('rois', 'minv', 'enc', 'roi_feat', 'center', 'xyz', 'ref', 'posemb', 'qpos', 'match')
+            st = {}
+            for kk in rows0 + ('roi_mask', 'pos2s', 's2pos', 'S_dev', 'col_idx', 'pe', 'Xk', 'Xf_b', 'KV'):
+                if ws.get(kk) is not None:
+                    st[kk] = (ws[kk][:R] if kk in rows0 else ws[kk]).clone()
+            for kk in ('outs', 'cls', 'reg'):
+                st[kk] = ws[kk][:, :R].clone()
+            st['row_ptr'] = ws['row_ptr'][:R + 1].clone()
+            st['nnz'] = torch.stack([ws['row_ptr'][R], ws['nnz'][1]])          # allowed pairs of the real rows | capacity-overflow flag
+            out['stages'] = st
         return out
 
     def run(self, feat, proposals, img_metas, keep_stages=False, use_graph=False):
@@ -778,13 +800,14 @@ class HeadEngine:
             ptrs = tuple(f.data_ptr() for f in feat)
         assert V % B == 0
         ws, R, sc = self._host_prepare(proposals_list, metas_list, V, h, w)
+        Rc = sc['cap']                     # launches run on the bucket size; R = the real rows
         if not use_graph or self.exact:
-            self._enqueue(ws, feat, R, V, h, w, sc)
+            self._enqueue(ws, feat, Rc, V, h, w, sc)
             self._mark_done(ws)
             return dict(self._result(ws, R, keep_stages, batch), dt=sc['dt'])
         # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
-        gkey = (ptrs, sc['pad_h'], sc['pad_w'], sc['max_per_view'], sc['max_rows'], self._weights_version)   # load_state() re-allocates the weights
+        gkey = (ptrs, sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version)   # load_state() re-allocates the weights
         graphs = ws.setdefault('graphs', {})             # one graph per (input buffers, frame scalars): a producer that alternates between
         g = graphs.get(gkey)                             # a few static output buffers replays a few graphs, it does not re-capture
         if ws.pop('graph_stale', False):
@@ -795,12 +818,12 @@ class HeadEngine:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                self._enqueue(ws, feat, R, V, h, w, sc)                    # warm-up outside capture (lazy inits)
+                self._enqueue(ws, feat, Rc, V, h, w, sc)                   # warm-up outside capture (lazy inits)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._enqueue(ws, feat, R, V, h, w, sc)
+                self._enqueue(ws, feat, Rc, V, h, w, sc)
             self.prof = prof
             if len(graphs) >= 8:
                 graphs.pop(next(iter(graphs)))
