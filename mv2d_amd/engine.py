@@ -227,7 +227,7 @@ class HeadEngine:
         ws = self._ws.get(key)
         if ws is not None:
             return ws
-        cap = max(64, -(-R // 64) * 64)
+        cap = max(64, -(-R // 32) * 32)
         bkey = (V, h, w, cap, Vg)
         base = self._ws_base.get(bkey)
         if base is None:
@@ -372,10 +372,10 @@ class HeadEngine:
             counts += [a.shape[0] for a in pa]
             grp.append(grp[-1] + sum(a.shape[0] for a in pa))
         R = grp[-1]
-        # The number of RoIs changes with every real frame.  All launches run on the BUCKET size (R rounded up to a multiple of 64): the
+        # The number of RoIs changes with every real frame.  All launches run on the BUCKET size (R rounded up to a multiple of 32, at least 64): the
         # rows R..cap-1 are copies of the last RoI that belong to no sample (not in view_start / grp_start), so nothing attends to them,
         # nothing decodes them and the key set is unchanged; every R of a bucket shares one workspace and ONE captured graph.
-        cap = max(64, -(-R // 64) * 64)
+        cap = max(64, -(-R // 32) * 32)
         ws = self._workspace(V, h, w, cap, Vg)
         sh = ws['shared']
         if 'done_ev' in sh:
@@ -489,6 +489,7 @@ class HeadEngine:
             featcl = feat.permute(0, 2, 3, 1).reshape(P, C)                         # already position-major: no copy
         else:
             featcl = o.nchw_to_nhwc(feat, ws['featcl'])
+        ws['featcl_cur'], ws['map_shape'] = featcl, (V, h, w)
         tk('box_params')
         # a3/a5/a7 per-RoI camera
         o.box_params(rois, T['viewK'], T['viewE'], ws['enc'][:, 1024:], 1056, ws['minv'])
@@ -625,6 +626,18 @@ class HeadEngine:
             ws['Xk'][:S].copy_(ks); ws['Xf_b'][:S].copy_(vs)
             ws['xk_lo'] = torch.zeros((P, C), device=d, dtype=BF16); ws['xk_lo'][:S].copy_(kl)
             ws['xv_lo'] = torch.zeros((P, C), device=d, dtype=BF16); ws['xv_lo'][:S].copy_(vl)
+
+    def pe_input_rows(self, ws, positions, V, h, w):
+        """PE input rows (frustum [n,192], sine [n,384], bf16) at the given map positions (int32, device) with the calibration tables of the
+        workspace's current frame: the training route needs them for a key position no RoI lists (RH/mv2d_t_head.py:80-82)."""
+        n = int(positions.numel())
+        T, d = ws['tab'], self.dev
+        a1 = torch.empty((n, 3 * self.depth_num), device=d, dtype=BF16)
+        a2 = torch.empty((n, 384), device=d, dtype=BF16)
+        xb = torch.empty((n, C), device=d, dtype=BF16)
+        ops.pe_inputs(positions.contiguous(), torch.tensor([n], dtype=torch.int32, device=d), n, ws['featcl'], T['img2lidar'], T['coords_w'],
+                      T['coords_h'], T['coords_d'], T['embeds'], self.const['dim_t'], a1, a2, xb, None, V, h, w, self.depth_num, self.post_range_h64)
+        return a1, a2
 
     def _enqueue_qg(self, ws, R):
         """a6-a8, a13: QueryGenerator on the RoI features -> reference points -> query positional embedding."""
@@ -852,14 +865,34 @@ class HeadEngine:
         nnz = int(row_ptr[R].item())
         if int(ws['nnz'][1].item()) != 0:
             raise RuntimeError('mv2d engine: CSR capacity exceeded (raise col_cap_per_query)')
+        col_fb = None
         if self.kind == 'T' and bool((row_ptr[1:] == row_ptr[:-1]).any().item()):
-            # the reference un-masks position (view 0, 0, 0) for such a RoI in training (RH/mv2d_t_head.py:80-82)
-            raise NotImplementedError('train_forward: a RoI without a single visible key (training-time fallback key not built)')
-        if dn_ref is None or dn_ref.shape[0] == 0:
+            # the reference un-masks the key at map position (view 0, 0, 0) for a RoI without a visible key in training
+            # (RH/mv2d_t_head.py:80-82); if no RoI lists that position its key / value rows are appended behind the S listed ones
+            if not self.tile_attn:
+                raise NotImplementedError('train_forward: the training-time fallback key needs the tile cross-attention route')
+            from .train import fallback_key_csr
+            s0 = int(ws['pos2s'][0].item())
+            if s0 < 0:
+                s0 = int(ws['S_dev'].item())
+                V_, h_, w_ = ws['map_shape']
+                a1, a2 = self.pe_input_rows(ws, torch.zeros(1, dtype=torch.int32, device=d), V_, h_, w_)
+                f0 = ws['featcl_cur'][:1].contiguous()
+                g_ = lambda x, n_, **kw: o.gemm_bf16(x, W_['pe_w' + n_], W_['pe_b' + n_], **kw)  # noqa: E731  (the six-GEMM PE route, one row)
+                gate = g_(g_(o.f32_to_bf16(f0), 'r', act=1), 'e', act=2, out_dtype=F32)
+                pg = g_(g_(a1, '1a', act=1), '1b', mul=gate, out_dtype=F32)
+                pe0 = g_(g_(a2, '2a', act=1), '2b', add=pg, out_dtype=F32)
+                ws['Xk'][s0:s0 + 1].copy_(o.f32_to_bf16(pe0 + f0)); ws['Xf_b'][s0:s0 + 1].copy_(o.f32_to_bf16(f0))
+            row_ptr, col_fb, _ = fallback_key_csr(row_ptr.clone(), ws['col_idx'][:int(row_ptr[R].item())].clone(), s0)
+        no_dn = dn_ref is None or dn_ref.shape[0] == 0
+        if no_dn and col_fb is None:
             return ws['cls'][:, :R].clone(), ws['reg'][:, :R].clone()
+        if no_dn:
+            dn_ref = torch.zeros((0, 3), device=d, dtype=F32)
         pad = int(dn_ref.shape[0])
         T = pad + R
-        col = ws['col_idx'][:nnz]
+        col = ws['col_idx'][:nnz] if col_fb is None else col_fb
+        nnz = int(col.numel())
         keys = torch.unique(col).to(torch.int32)               # every key at least one RoI can see (sorted)
         nk = int(keys.numel())
         e = lambda *shape: torch.empty(shape, device=d, dtype=F32)  # noqa: E731

@@ -219,19 +219,28 @@ class MV2DHead(nn.Module):
     def _forward_train_autograd(self, eng, out, hl, gt, labels, dn_noise, feat):
         from .. import train
         ws, R = out['ws'], out['R']
-        row_ptr = ws['row_ptr'][:R + 1]
+        # everything that enters an autograd Function is COPIED out of the engine's workspace: the next run() on the same bucket rewrites
+        # those buffers through raw pointers (a second forward before backward(), an eval hook), which autograd's version counters cannot see
+        row_ptr = ws['row_ptr'][:R + 1].clone()
         nnz = int(row_ptr[R].item())
-        if self.KIND == 'T' and bool((row_ptr[1:] == row_ptr[:-1]).any().item()):
-            raise NotImplementedError('forward_train: a RoI without a single visible key (training-time fallback key not built)')
-        col = ws['col_idx'][:nnz]
+        col = ws['col_idx'][:nnz].clone()
         # the input map, position-major, as a differentiable view: its gradient comes back through RoIAlign and the key rows
         V, _, h, w = feat.shape
         fm = feat.float().permute(0, 2, 3, 1).reshape(V * h * w, C)
         rois = ws['rois'][:R].clone()
         bbox_feats = ops.RoIAlignRows.apply(fm, None, rois, h, w)                                   # [R,49,256]
         S = int(ws['S_dev'].item())
+        A1, A2, s2pos = ws['A1'][:S].clone(), ws['A2'][:S].clone(), ws['s2pos'][:S].long()
+        if self.KIND == 'T' and bool((row_ptr[1:] == row_ptr[:-1]).any().item()):
+            # a RoI without a single visible key: in training the reference un-masks the key at map position (view 0, 0, 0) for it
+            # (RH/mv2d_t_head.py:80-82) instead of producing a NaN row; that position joins the key list if no RoI lists it
+            s0 = int(ws['pos2s'][0].item())
+            if s0 < 0:
+                a1, a2 = eng.pe_input_rows(ws, torch.zeros(1, dtype=torch.int32, device=fm.device), V, h, w)
+                A1, A2, s2pos, s0 = torch.cat([A1, a1]), torch.cat([A2, a2]), torch.cat([s2pos, s2pos.new_zeros(1)]), S
+            row_ptr, col, _ = train.fallback_key_csr(row_ptr, col, s0)
         # the PE block at the positions the engine listed (T: the gathered keys; S: every position a RoIAlign tap can touch)
-        key_rows, val_rows, pe_rows = train.key_embedding_autograd(self, ws['A1'][:S], ws['A2'][:S], fm[ws['s2pos'][:S].long()])
+        key_rows, val_rows, pe_rows = train.key_embedding_autograd(self, A1, A2, fm[s2pos])
         if self.KIND == 'T':
             key_in, val_in = key_rows, val_rows
         else:
@@ -239,8 +248,8 @@ class MV2DHead(nn.Module):
             val_in = bbox_feats.reshape(R * 49, C)
             key_in = val_in + pe_aligned.reshape(R * 49, C)
         # reference points with the gradient of the query generator
-        ref = train.query_generator_autograd(self, bbox_feats, ws['enc'][:R, 1024:1040], ws['minv'][:R])
-        ref_const, pad, single, md, keys = ws['ref'][:R], 0, 1, None, None
+        ref = train.query_generator_autograd(self, bbox_feats, ws['enc'][:R, 1024:1040].clone(), ws['minv'][:R].clone())
+        ref_const, pad, single, md, keys = ws['ref'][:R].clone(), 0, 1, None, None
         if getattr(self, 'use_denoise', False):
             padded, _, md = train.prepare_for_dn(ref_const, gt, labels, self.denoise_scalar, self.denoise_noise_scale, self.denoise_noise_trans,
                                                  self.denoise_split, self.num_classes, list(self.pc_range), rnd=dn_noise, dense_mask=False)
@@ -263,10 +272,13 @@ class MV2DHead(nn.Module):
 
     def _head_loss(self, device):
         from ..train import HeadLoss
-        if getattr(self, '_hl', None) is None or self._hl.device != device:
-            bh = self.bbox_head
-            lc = dict(type='FocalLoss', use_sigmoid=bh.loss_cls.use_sigmoid, **bh.loss_cls.cfg)
-            lb = dict(type='L1Loss', **bh.loss_bbox.cfg)
+        bh = self.bbox_head
+        cw_key = (bh.code_weights.data_ptr(), bh.code_weights._version)          # a checkpoint loaded later changes the code weights
+        if getattr(self, '_hl', None) is None or self._hl.device != device or getattr(self, '_hl_key', None) != cw_key:
+            self._hl_key = cw_key
+            # the CONFIGURED loss types are handed on, so that an unsupported one raises in HeadLoss instead of training with focal + L1
+            lc = dict(bh.loss_cls.cfg, type=getattr(bh.loss_cls, 'type', 'FocalLoss'), use_sigmoid=bh.loss_cls.use_sigmoid)
+            lb = dict(bh.loss_bbox.cfg, type=getattr(bh.loss_bbox, 'type', 'L1Loss'))
             self._hl = HeadLoss(num_classes=bh.num_classes, loss_cls=lc, loss_bbox=lb, code_weights=[float(x) for x in bh.code_weights],
                                 train_cfg=self.train_cfg, device=device)
         return self._hl

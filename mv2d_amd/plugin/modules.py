@@ -65,7 +65,8 @@ class _LossStub(nn.Module):
 
 
 for _n in ('FocalLoss', 'L1Loss', 'CrossEntropyLoss', 'SmoothL1Loss'):
-    LOSSES.register_module(name=_n, module=_LossStub, force=True)
+    # one class per configured type string: the training route reads ``.type`` back (train.HeadLoss rejects what it does not implement)
+    LOSSES.register_module(name=_n, module=type(_n, (_LossStub,), {'type': _n}), force=True)
 
 
 @ROI_EXTRACTORS.register_module()
@@ -219,7 +220,8 @@ class _AttnBase(nn.Module):
         super().__init__()
         if 'dropout' in kwargs:
             warnings.warn('The arguments `dropout` in MultiheadAttention has been deprecated', DeprecationWarning)
-            attn_drop = kwargs.pop('dropout')
+            attn_drop = kwargs['dropout']                      # as the reference (MU/petr_transformer.py:405-412): probabilities AND output path
+            dropout_layer = dict(dropout_layer or dict(type='Dropout'), drop_prob=kwargs.pop('dropout'))
         assert embed_dims == C and num_heads == 8, 'kernels are specialised for 256 channels, 8 heads x 32'
         self.embed_dims, self.num_heads, self.batch_first = embed_dims, num_heads, batch_first
         self.attn = nn.MultiheadAttention(embed_dims, num_heads, attn_drop, **kwargs)       # parameter container only

@@ -197,6 +197,25 @@ def prepare_for_dn(reference_points, gt_bboxes, gt_labels, denoise_scalar=10, de
     return padded, attn_mask, mask_dict
 
 
+def fallback_key_csr(row_ptr, col_idx, key_index):
+    """Training-time rule of the two-frame head (RH/mv2d_t_head.py:80-82): a RoI that sees no key at all gets the key at map position
+    (view 0, 0, 0) un-masked instead of a fully masked row (NaN).  row_ptr [R+1] / col_idx [nnz] int32 -> the CSR with one entry
+    ``key_index`` (the compacted index of that position) in every empty row; also returns the bool mask of the patched rows."""
+    R = row_ptr.numel() - 1
+    counts = (row_ptr[1:] - row_ptr[:-1]).long()
+    empty = counts == 0
+    if not bool(empty.any()):
+        return row_ptr, col_idx, empty
+    counts2 = torch.where(empty, torch.ones_like(counts), counts)
+    rp = torch.zeros(R + 1, dtype=torch.int32, device=row_ptr.device)
+    rp[1:] = counts2.cumsum(0).to(torch.int32)
+    col = torch.full((int(rp[-1].item()),), int(key_index), dtype=torch.int32, device=row_ptr.device)
+    before = empty.long().cumsum(0) - empty.long()                    # patched rows in front of every row
+    row_of = torch.repeat_interleave(torch.arange(R, device=row_ptr.device), counts)
+    col[torch.arange(col_idx.numel(), device=row_ptr.device) + before[row_of]] = col_idx
+    return rp, col, empty
+
+
 class TrainDecoder:
     """Differentiable decoder + prediction heads of ``CrossAttentionBoxHead`` for training: the dense linears, layer
     norms and the FFN go through torch (rocBLAS GEMMs, torch autograd), **both attentions through the HIP sparse-attention kernels**
@@ -212,6 +231,21 @@ class TrainDecoder:
         self.p = dict(roi_head.named_parameters())
         bh = roi_head.bbox_head
         self.L, self.pc_range, self.H = bh.num_pred, [float(x) for x in roi_head.pc_range], num_heads
+        # dropout (shipped configs: 0.1 on both attentions and in the FFN, configs/mv2d/exp/*:67-79): the module tree carries the
+        # nn.Dropout objects of the reference's layers (mmcv MultiheadAttention: attn_drop on the probabilities + dropout_layer on the
+        # output path; FFN: after the activation and after the second linear); they are applied here when the head is in training mode
+        self.roi_head = roi_head
+        self.layers = getattr(getattr(bh.transformer, 'decoder', None), 'layers', None)
+        self._warned = False
+
+    def _drops(self, i, j):
+        """(attention-probability p, output-path callable) of attention j of layer i; identity / 0 in eval mode or without a module tree"""
+        if self.layers is None or not self.roi_head.training:
+            return 0.0, (lambda t: t)
+        att = self.layers[i].attentions[j]
+        p_attn = float(getattr(getattr(att, 'attn', None), 'dropout', 0.0) or 0.0)
+        pd, dl = getattr(att, 'proj_drop', None), getattr(att, 'dropout_layer', None)
+        return p_attn, (lambda t: (dl(pd(t) if pd is not None else t) if dl is not None else t))
 
     @staticmethod
     def self_attention_pattern(T, pad, single, device):
@@ -223,7 +257,7 @@ class TrainDecoder:
         row_ptr[1:] = vis.sum(1).cumsum(0).to(torch.int32)
         return row_ptr, vis.nonzero()[:, 1].to(torch.int32).contiguous()
 
-    def _attn(self, q_in, k_in, v_in, name, csr, tr, dense=None):
+    def _attn(self, q_in, k_in, v_in, name, csr, tr, dense=None, p_attn=0.0):
         """dense = (n, keys): the first n query rows see exactly the key rows `keys` (the denoising rows of the cross attention) — a dense
         block, computed with batched GEMMs instead of n rows of len(keys) pairs each in the sparse kernels; csr then covers rows n.."""
         import torch.nn.functional as F
@@ -238,7 +272,7 @@ class TrainDecoder:
             qh = q[:n].view(n, H, d).transpose(0, 1)
             kh = k[keys].view(-1, H, d).transpose(0, 1)
             vh = v[keys].view(-1, H, d).transpose(0, 1)
-            top = (torch.softmax(qh @ kh.transpose(1, 2), -1) @ vh).transpose(0, 1).reshape(n, Cc)
+            top = (F.dropout(torch.softmax(qh @ kh.transpose(1, 2), -1), p_attn, p_attn > 0) @ vh).transpose(0, 1).reshape(n, Cc)
             ctx = torch.cat([top, ops.SparseCrossAttention.apply(q[n:], k, v, csr[0], csr[1], False, tr)])
         else:
             ctx = ops.SparseCrossAttention.apply(q, k, v, csr[0], csr[1], False, tr)
@@ -272,13 +306,31 @@ class TrainDecoder:
         x = torch.zeros(T, qpos.shape[1], device=dev)
         outs = []
         ln = lambda t, n: F.layer_norm(t, (t.shape[-1],), P[n + '.weight'], P[n + '.bias'])  # noqa: E731
+        training = self.layers is not None and self.roi_head.training
         for i in range(self.L):
             lp = f'{pre}layers.{i}.'
-            x = ln(x + self._attn(x + qpos, x + qpos, x, lp + 'attentions.0', sa, sa_t), lp + 'norms.0')
-            x = ln(x + self._attn(x + qpos, key_in, val_in, lp + 'attentions.1', ca, ca_t, None if dn_keys is None else (pad, dn_keys.long())),
-                   lp + 'norms.1')
+            p_sa, drop_sa = self._drops(i, 0)
+            p_ca, drop_ca = self._drops(i, 1)
+            if max(p_sa, p_ca) > 0 and not self._warned:
+                import warnings
+                warnings.warn(f'mv2d_amd.train.TrainDecoder: attention-PROBABILITY dropout (p = {max(p_sa, p_ca)}) is not applied inside the sparse '
+                              'attention kernels (it is on the dense denoising block); the output-path and FFN dropouts of the reference ARE '
+                              'applied.  Set dropout=0 in the attention configs to silence this.', RuntimeWarning)
+                self._warned = True
+            x = ln(x + drop_sa(self._attn(x + qpos, x + qpos, x, lp + 'attentions.0', sa, sa_t)), lp + 'norms.0')
+            x = ln(x + drop_ca(self._attn(x + qpos, key_in, val_in, lp + 'attentions.1', ca, ca_t,
+                                          None if dn_keys is None else (pad, dn_keys.long()), p_attn=p_ca)), lp + 'norms.1')
             h = F.relu(F.linear(x, P[lp + 'ffns.0.layers.0.0.weight'], P[lp + 'ffns.0.layers.0.0.bias']))
-            x = ln(x + F.linear(h, P[lp + 'ffns.0.layers.1.weight'], P[lp + 'ffns.0.layers.1.bias']), lp + 'norms.2')
+            y = None
+            if training:
+                ffn = self.layers[i].ffns[0]                      # mmcv FFN: Linear-ReLU-Dropout, Linear-Dropout, (+ dropout_layer) + identity
+                h = ffn.layers[0][2](h)
+            y = F.linear(h, P[lp + 'ffns.0.layers.1.weight'], P[lp + 'ffns.0.layers.1.bias'])
+            if training:
+                y = ffn.layers[2](y)
+                dl = getattr(ffn, 'dropout_layer', None)
+                y = dl(y) if dl is not None else y
+            x = ln(x + y, lp + 'norms.2')
             outs.append(ln(x, pre + 'post_norm'))
         r = ref.clamp(0, 1)
         inv = torch.log(r.clamp(min=1e-5) / (1 - r).clamp(min=1e-5))                 # inverse_sigmoid, mmdet
