@@ -354,6 +354,13 @@ int mv2d_decode_topk(const float* cls, const float* reg, int R, int num_classes,
                      float* boxes, float* scores, long long* labels, long long* bbox_index, int* count_out,
                      long long* topk_index_dbg, const int* grp_start, int n_samples, int max_grp_rows, void* stream);
 
+/* Rotated bird's-eye-view NMS for nms_thr < 1 (not a shipped value: with 1.0 nothing is suppressed and mv2d_result_pack alone is the
+ * step after the head, mmdet3d_plugin/models/detectors/mv2d.py:265-287): per class, greedy in score order, IoU of the rotated
+ * rectangles (x, y, dx, dy, yaw) of boxes [n_samples][in_stride][9]; scores_out = scores with the suppressed entries at -inf (feed it
+ * to mv2d_result_pack).  mmdet3d box3d_multiclass_nms / mmcv nms_rotated are third party: parity unpinned. */
+int mv2d_nms_bev(const float* boxes, const float* scores, const long long* labels, const int* count, float nms_thr, float* scores_out,
+                 int n_samples, int in_stride, void* stream);
+
 /* "next" row f1 — the caller's post-decoder step (mmdet3d_plugin/models/detectors/mv2d.py:265-287): mmdet3d
  * box3d_multiclass_nms(score_thr, nms_thr = 1.0 => no suppression, max_num) + result ordering: class-major, score-descending
  * (global score order only when more than max_num boxes survive).  in: boxes [n,9], scores [n], labels [n] int64, *count = n (<= 1024). */

@@ -72,6 +72,7 @@ SIGNATURES = {
     'mv2d_csr_from_corr': (I, [P, P, P, P, I, I, I, P]),
     'mv2d_pe_inputs': (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
     'mv2d_result_pack': (I, [P, P, P, P, F, I, P, P, P, P, I, I, P]),
+    'mv2d_nms_bev': (I, [P, P, P, P, F, P, I, I, P]),
     'mv2d_pack_detections': (I, [P, P, P, P, P, I, I, I, P]),
     'mv2d_roi_align_bwd': (I, [P, P, P, P, I, I, I, I, F, I, P]),
     'mv2d_match_cost': (I, [P, P, P, P, P, I, I, I, I, F, F, F, F, P]),

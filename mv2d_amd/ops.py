@@ -636,6 +636,14 @@ def result_pack(boxes, scores, labels, count, score_thr, max_num, out_boxes, out
                                        _p(out_labels), _p(out_count), n_samples, in_stride, _stream()), 'mv2d_result_pack')
 
 
+def nms_bev(boxes, scores, labels, count, nms_thr, n_samples=1):
+    """Rotated BEV NMS per class (nms_thr < 1): returns scores with the suppressed entries at -inf; boxes [n,M,9] or [M,9], count [n] int32."""
+    out = torch.empty_like(scores)
+    check(_lib.load().mv2d_nms_bev(_p(boxes.contiguous()), _p(scores.contiguous()), _p(labels.contiguous()), _p(count), float(nms_thr), _p(out),
+                                   int(n_samples), int(scores.shape[-1]), _stream()), 'mv2d_nms_bev')
+    return out
+
+
 def pack_detections(boxes, scores, labels, count, out, max_num=300):
     """boxes [n,M,9] (or [M,9]), scores, labels int64, count [n] int32 -> out [n, max_num*11 + 1] fp32 (the all-gather payload)."""
     n = count.numel()

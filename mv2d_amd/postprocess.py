@@ -26,10 +26,12 @@ def process_2d_detections(results, device, min_bbox_size=0):
     return dets
 
 
-def pack_results(boxes, scores, labels, count, score_thr=0.0, max_per_scene=300):
+def pack_results(boxes, scores, labels, count, score_thr=0.0, max_per_scene=300, nms_thr=1.0):
     """boxes [n,9], scores [n], labels [n] (device, first *count valid) -> dict(boxes_3d, scores_3d, labels_3d) on the host
-    (mmdet3d bbox3d2result), ordered like box3d_multiclass_nms with nms_thr = 1.0."""
+    (mmdet3d bbox3d2result), ordered like box3d_multiclass_nms.  nms_thr < 1: rotated BEV suppression per class first (mv2d_nms_bev)."""
     dev = boxes.device
+    if float(nms_thr) < 1.0:
+        scores = ops.nms_bev(boxes, scores, labels, count, nms_thr)
     ob = torch.zeros((max_per_scene, 9), device=dev)
     os_ = torch.zeros(max_per_scene, device=dev)
     ol = torch.zeros(max_per_scene, dtype=torch.int64, device=dev)
@@ -39,10 +41,12 @@ def pack_results(boxes, scores, labels, count, score_thr=0.0, max_per_scene=300)
     return dict(boxes_3d=ob[:n].cpu(), scores_3d=os_[:n].cpu(), labels_3d=ol[:n].cpu())
 
 
-def pack_results_batch(boxes, scores, labels, count, score_thr=0.0, max_per_scene=300):
+def pack_results_batch(boxes, scores, labels, count, score_thr=0.0, max_per_scene=300, nms_thr=1.0):
     """run_batch outputs (boxes [B,n,9], scores [B,n], labels [B,n], count [B]) -> B dicts like pack_results, one launch and one host
     synchronisation for the whole batch."""
     dev, B = boxes.device, count.numel()
+    if float(nms_thr) < 1.0:
+        scores = ops.nms_bev(boxes, scores, labels, count, nms_thr, n_samples=B)
     ob = torch.zeros((B, max_per_scene, 9), device=dev)
     os_ = torch.zeros((B, max_per_scene), device=dev)
     ol = torch.zeros((B, max_per_scene), dtype=torch.int64, device=dev)
@@ -54,43 +58,40 @@ def pack_results_batch(boxes, scores, labels, count, score_thr=0.0, max_per_scen
     return [dict(boxes_3d=ob[b, :n], scores_3d=os_[b, :n], labels_3d=ol[b, :n]) for b, n in enumerate(ns)]
 
 
-def simple_test_batch_from_detections(roi_head, feat_maps, det_results_list, img_metas_list, rcnn_test_cfg, min_bbox_size=0):
+def simple_test_batch_from_detections(roi_head, feat_maps, det_results_list, img_metas_list, rcnn_test_cfg, min_bbox_size=0, wrap_pts_bbox=False):
     """simple_test_from_detections for a batch of samples: feat_maps[lvl] = the stacked [B*V,256,h,w] map, det_results_list / img_metas_list
     = one entry per sample.  One sequence of launches, one host synchronisation."""
-    nms = rcnn_test_cfg.get('nms', rcnn_test_cfg)
-    if float(nms.get('nms_thr', 1.0)) < 1.0:
-        raise NotImplementedError('rotated-IoU suppression (nms_thr < 1) is not part of the shipped configs')
+    nms_thr = float(rcnn_test_cfg.get('nms', rcnn_test_cfg).get('nms_thr', 1.0))
     feat = feat_maps[roi_head.feat_lvl]
     proposals = [process_2d_detections(d, feat.device, min_bbox_size) for d in det_results_list]
     eng = roi_head.engine(feat.device, img_metas_list[0])
     out = eng.run_batch(feat.float(), proposals, img_metas_list)
     res = pack_results_batch(out['boxes'], out['scores'], out['labels'], out['count'], rcnn_test_cfg.get('score_thr', 0.0),
-                             rcnn_test_cfg.get('max_per_scene', 300))
+                             rcnn_test_cfg.get('max_per_scene', 300), nms_thr)
     if int(out['ws']['nnz'][1].item()) != 0:
         raise RuntimeError('mv2d engine: CSR capacity exceeded (raise col_cap_per_query)')
     for b, r in enumerate(res):
         box_type = img_metas_list[b][0].get('box_type_3d')
         if box_type is not None:
             r['boxes_3d'] = box_type(r['boxes_3d'], r['boxes_3d'].size(-1))
-    return res
+    return [dict(pts_bbox=r) for r in res] if wrap_pts_bbox else res
 
 
-def simple_test_from_detections(roi_head, feat_maps, det_results, img_metas, rcnn_test_cfg, min_bbox_size=0):
+def simple_test_from_detections(roi_head, feat_maps, det_results, img_metas, rcnn_test_cfg, min_bbox_size=0, wrap_pts_bbox=False):
     """The part of MV2D.simple_test (mv2d.py:225-295, batch 1) that surrounds the RoI head: 2-D detector results ->
     proposals -> head (HIP engine) -> result packing, with one host synchronisation at the very end.
-    rcnn_test_cfg: dict(score_thr, max_per_scene, nms=dict(nms_thr)) (CFG-T:154-158); nms_thr must be 1.0 (the shipped value)."""
-    nms = rcnn_test_cfg.get('nms', rcnn_test_cfg)
-    if float(nms.get('nms_thr', 1.0)) < 1.0:
-        raise NotImplementedError('rotated-IoU suppression (nms_thr < 1) is not part of the shipped configs')
+    rcnn_test_cfg: dict(score_thr, max_per_scene, nms=dict(nms_thr)) (CFG-T:154-158).  wrap_pts_bbox=True returns the reference's
+    ``[{'pts_bbox': {...}}]`` (mv2d.py:283-292) instead of the bare dict."""
+    nms_thr = float(rcnn_test_cfg.get('nms', rcnn_test_cfg).get('nms_thr', 1.0))
     feat = feat_maps[roi_head.feat_lvl]
     proposals = process_2d_detections(det_results, feat.device, min_bbox_size)
     eng = roi_head.engine(feat.device, img_metas)
     out = eng.run(feat.float(), proposals, img_metas)
     res = pack_results(out['boxes'], out['scores'], out['labels'], out['count'], rcnn_test_cfg.get('score_thr', 0.0),
-                       rcnn_test_cfg.get('max_per_scene', 300))
+                       rcnn_test_cfg.get('max_per_scene', 300), nms_thr)
     if int(out['ws']['nnz'][1].item()) != 0:
         raise RuntimeError('mv2d engine: CSR capacity exceeded (raise col_cap_per_query)')
     box_type = img_metas[0].get('box_type_3d')
     if box_type is not None:
         res['boxes_3d'] = box_type(res['boxes_3d'], res['boxes_3d'].size(-1))
-    return [res]
+    return [dict(pts_bbox=res)] if wrap_pts_bbox else [res]

@@ -822,3 +822,55 @@ def prepare_for_dn(reference_points, gt_bboxes, gt_labels, rnd, scalar=10, noise
         attn_mask[single_pad * i:single_pad * (i + 1), single_pad * (i + 1):pad] = True
         attn_mask[single_pad * i:single_pad * (i + 1), :single_pad * i] = True
     return padded, attn_mask, known_labels, known_bboxs, pad
+
+
+# ---- rotated BEV NMS for nms_thr < 1 (mmdet3d box3d_multiclass_nms -> nms_bev -> mmcv nms_rotated; third party, parity unpinned) -------
+def _bev_corners(b):
+    import numpy as np
+    cx, cy, dx, dy, yaw = float(b[0]), float(b[1]), float(b[3]), float(b[4]), float(b[6])
+    c, s = np.cos(yaw), np.sin(yaw)
+    loc = np.array([[dx / 2, dy / 2], [-dx / 2, dy / 2], [-dx / 2, -dy / 2], [dx / 2, -dy / 2]])
+    return loc @ np.array([[c, s], [-s, c]]) + np.array([cx, cy])
+
+
+def rotated_iou_bev(a, b):
+    """IoU of the rotated rectangles (x, y, dx, dy, yaw) of two 9-code boxes (fp64; convex clipping, one half plane at a time)."""
+    import numpy as np
+    P, Q = _bev_corners(a), _bev_corners(b)
+    poly = [tuple(p) for p in P]
+    for e in range(4):
+        q0, q1 = Q[e], Q[(e + 1) % 4]
+        ex, ey = q1 - q0
+        side = lambda p: ex * (p[1] - q0[1]) - ey * (p[0] - q0[0])  # noqa: E731
+        out = []
+        for i in range(len(poly)):
+            s_, t_ = poly[i], poly[(i + 1) % len(poly)]
+            ds, dt = side(s_), side(t_)
+            if ds >= 0:
+                out.append(s_)
+            if (ds >= 0) != (dt >= 0):
+                u = ds / (ds - dt)
+                out.append((s_[0] + u * (t_[0] - s_[0]), s_[1] + u * (t_[1] - s_[1])))
+        poly = out
+        if not poly:
+            break
+    inter = 0.5 * abs(sum(poly[i][0] * poly[(i + 1) % len(poly)][1] - poly[(i + 1) % len(poly)][0] * poly[i][1] for i in range(len(poly)))) if poly else 0.0
+    aa, ab = abs(float(a[3]) * float(a[4])), abs(float(b[3]) * float(b[4]))
+    return inter / max(aa + ab - inter, 1e-8)
+
+
+def nms_bev(boxes, scores, labels, thr):
+    """Per class, greedy in score order (ties: lower index first): keep mask [n] bool."""
+    import numpy as np
+    boxes, scores, labels = np.asarray(boxes, np.float64), np.asarray(scores, np.float64), np.asarray(labels)
+    keep = np.ones(len(scores), bool)
+    for c in np.unique(labels):
+        idx = [i for i in np.argsort(-scores, kind='stable') if labels[i] == c]
+        for a_, i in enumerate(idx):
+            if not keep[i]:
+                continue
+            for j in idx[a_ + 1:]:
+                if keep[j] and rotated_iou_bev(boxes[j], boxes[i]) > thr:
+                    keep[j] = False
+    return keep
+

@@ -299,3 +299,41 @@ def test_head_on_metas_built_by_the_nuscenes_io_pipeline():
     assert n > 0 and (res[2][:n].cpu() == st['labels'][:n]).float().mean() > 0.95
     assert relmax(res[1][:n], st['scores'][:n]) < 5e-3
     assert relmax(res[0][:n, 7:9], st['boxes'][:n, 7:9]) < 2e-2          # velocities: divided by the 1.245 s between the (padded) frames
+
+
+def test_rotated_bev_nms_below_threshold_one():
+    """nms_thr < 1 (not a shipped value): mv2d_nms_bev + mv2d_result_pack against the oracle's per-class greedy rotated NMS (fp64 clipping),
+    plus closed-form IoUs: identical boxes 1, a square turned by 45 degrees against itself 2 (sqrt 2 - 1) / (2 - ... ) etc."""
+    import math
+    from mv2d_amd import ops, postprocess
+    from oracle import mv2d_oracle as O
+    dev = torch.device('cuda:0')
+    # closed forms: unit squares shifted by half -> 1/3; a 2x1 rectangle turned by 90 degrees about its centre -> 1/3
+    a = [0, 0, 0, 1, 1, 1, 0, 0, 0]
+    assert abs(O.rotated_iou_bev(a, [0.5, 0, 0, 1, 1, 1, 0, 0, 0]) - 1 / 3) < 1e-12
+    assert abs(O.rotated_iou_bev([0, 0, 0, 2, 1, 1, 0, 0, 0], [0, 0, 0, 2, 1, 1, math.pi / 2, 0, 0]) - 1 / 3) < 1e-12
+    oct_area = 2 * (math.sqrt(2) - 1)                                  # unit square and its 45-degree turn: regular octagon
+    assert abs(O.rotated_iou_bev(a, [0, 0, 0, 1, 1, 1, math.pi / 4, 0, 0]) - oct_area / (2 - oct_area)) < 1e-12
+    g = np.random.Generator(np.random.PCG64(5))
+    n, M = 260, 300
+    centres = g.random((20, 2)) * 40 - 20                              # 20 clusters -> plenty of overlaps
+    boxes = np.zeros((M, 9), np.float32)
+    which = g.integers(0, 20, n)
+    boxes[:n, :2] = centres[which] + g.normal(0, 0.8, (n, 2))
+    boxes[:n, 3:5] = g.random((n, 2)) * 3 + 1.5
+    boxes[:n, 5] = 1.5
+    boxes[:n, 6] = g.random(n) * 2 * math.pi - math.pi
+    scores = np.zeros(M, np.float32); scores[:n] = g.random(n).astype(np.float32)
+    labels = np.zeros(M, np.int64); labels[:n] = g.integers(0, 4, n)
+    thr = 0.2
+    keep = O.nms_bev(boxes[:n], scores[:n], labels[:n], thr)
+    assert 20 < keep.sum() < n - 20
+    cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+    s2 = ops.nms_bev(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), torch.from_numpy(labels).to(dev), cnt, thr)
+    got = torch.isfinite(s2[:n]).cpu().numpy()
+    np.testing.assert_array_equal(got, keep)
+    res = postprocess.pack_results(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), torch.from_numpy(labels).to(dev), cnt,
+                                   score_thr=0.0, max_per_scene=300, nms_thr=thr)
+    want = O.post_nms_pack(torch.from_numpy(boxes[:n][keep]), torch.from_numpy(scores[:n][keep]), torch.from_numpy(labels[:n][keep]), score_thr=0.0, max_num=300)
+    assert torch.equal(res['labels_3d'], want[2]) and torch.equal(res['scores_3d'], want[1]) and torch.equal(res['boxes_3d'], want[0])
+
