@@ -45,7 +45,7 @@ def check_common(st, g):
     close(st['cls'].numpy().reshape(g['cls'].shape) if st['cls'].numel() == g['cls'].size else st['cls'], g['cls'], 1e-4)
 
 
-@pytest.mark.parametrize('name', ['micro_t', 'cfg1_t', 'cfg3_t'])
+@pytest.mark.parametrize('name', ['micro_t', 'cfg1_t', 'cfg3_t', 'cfg5_t'])
 def test_t_path_matches_reference(name):
     g = load_golden(name)
     st = run(name)
@@ -56,7 +56,7 @@ def test_t_path_matches_reference(name):
     np.testing.assert_array_equal((~st['feat_for_rois'])[:, st['roi_mask']].numpy(), blocked)
     np.testing.assert_array_equal(st['key_padding'].numpy(), g['key_padding'])
     reg = st['reg'].numpy().reshape(g['reg'].shape)
-    if name == 'cfg3_t':
+    if name in ('cfg3_t', 'cfg5_t'):
         # two frames: the golden 'reg' is CrossAttentionBoxHead.forward's output, BEFORE RH/mv2d_t_head.py:136-140 divides the velocities
         # by dt = 0.5 s (the golden 'boxes' are after it)
         reg = np.concatenate([reg[..., :8], reg[..., 8:] * 0.5], -1)
