@@ -271,6 +271,19 @@ int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* Xv, const vo
 int mv2d_xattn_ctxmap(const float* z, const void* WB_hi, const void* WB_lo, const float* bv, const int* row_ptr, float* ctx, int R,
                       int empty_nan, void* stream);
 
+/* The two row kernels around the tile cross attention with its per-head maps fused in (one launch each instead of two; bitwise the
+ * same results):
+ * mv2d_attn_out_qmap_x3 = mv2d_attn_out_fused_x3 (out_proj + residual + LayerNorm of the self attention, cross-attention q projection)
+ *   followed by mv2d_xattn_qmap on the q tile while it is still in LDS; writes x_out and Qt (q itself is not written).
+ * mv2d_attn_out_zmap_x3 = mv2d_xattn_ctxmap on z [M,8,256] (+ the empty-row rule) followed by mv2d_attn_out_fused_x3 without a q
+ *   stage (out_proj + residual + LayerNorm of the cross attention). */
+int mv2d_attn_out_qmap_x3(const float* ctx, const float* resid, const void* Wo_hi, const void* Wo_lo, const float* bo, const float* ln_w,
+                          const float* ln_b, float* x_out, const float* qpos, const void* Wq_hi, const void* Wq_lo, const float* bq,
+                          float qscale, const void* WA_hi, const void* WA_lo, void* Qt, int M, float eps, void* stream);
+int mv2d_attn_out_zmap_x3(const float* z, const void* WB_hi, const void* WB_lo, const float* bv, const int* row_ptr, int empty_nan,
+                          const float* resid, const void* Wo_hi, const void* Wo_lo, const float* bo, const float* ln_w, const float* ln_b,
+                          float* x_out, int M, float eps, void* stream);
+
 /* Backward of mv2d_sparse_xattn_fwd ("next" row f3, the training path of the head): given dctx [R,256] returns dq [R,256] (gradient
  * with respect to the pre-scaled q) and dK, dV [S,256] fp32 (every key row is written; keys nobody reads get 0).  Two launches, no
  * atomics, deterministic: a pass over the queries (softmax statistics recomputed, no forward state kept; writes dq and, per allowed pair
@@ -338,6 +351,7 @@ int mv2d_csr_from_corr(const int* match, int* row_ptr, int* col_idx, int* nnz_ou
 
 /* PE inputs at the listed key positions only (MU/pe.py:84-135 frustum, MU/positional_encoding.py:78-95 sine) + feature gather.
  * out: A_frustum [S,3*D] bf16, A_sine [S,384] bf16, Xf_bf16 [S,256], Xf_f32 [S,256] (optional: NULL when mv2d_pe_fused reads the map).
+ * A_sine may be NULL (the sine branch of the PE block comes from the engine's folded table: the row is not produced).
  * A_frustum_f32 / A_sine_f32 (optional, the engine's index-exact validation mode): the same rows unrounded, with the logarithm in
  * fp64 and library sin / cos. */
 int mv2d_pe_inputs(const int* s2pos, const int* S_dev, int S_max, const float* featcl, const double* img2lidar,

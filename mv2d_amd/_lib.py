@@ -58,6 +58,8 @@ SIGNATURES = {
     'mv2d_raw_xattn_fwd': (I, [P, P, P, P, P, P, I, I, P]),
     'mv2d_sparse_xattn_bwd': (I, [P] * 14 + [I, I, P]),
     'mv2d_xattn_qmap': (I, [P, P, P, P, I, P]),
+    'mv2d_attn_out_qmap_x3': (I, [P] * 12 + [F, P, P, P, I, F, P]),
+    'mv2d_attn_out_zmap_x3': (I, [P, P, P, P, P, I, P, P, P, P, P, P, P, I, F, P]),
     'mv2d_xattn_tile_fwd': (I, [P, P, P, P, P, P, P, P, P, LL, I, I, I, P]),
     'mv2d_xattn_ctxmap': (I, [P, P, P, P, P, P, I, I, P]),
     'mv2d_box_params': (I, [P, P, P, P, P, I, P, I, F, F, F, P]),

@@ -594,6 +594,7 @@ __global__ __launch_bounds__(1024) void csr_from_corr_kernel(const int* __restri
 // One wave per key position (4 per block): lane l moves channels 4l..4l+3 of the feature row with 16-byte accesses, computes depth
 // bin l of the frustum row (3 coordinates) and 6 sine channels; the two bf16 input rows (384 B, 768 B) are assembled in LDS and
 // written with 16-byte stores.  (Round 1: one block per position with 2- and 4-byte accesses ran at 2 TB/s of its 130 MB.)
+template <bool EXACT>      // EXACT: also the unrounded fp32 rows of the engine's index-exact validation mode (fp64 log, library sin / cos)
 __global__ __launch_bounds__(256) void pe_inputs_kernel(const int* __restrict__ s2pos, const int* __restrict__ S_dev, const float* __restrict__ featcl,
                                                         const double* __restrict__ img2lidar, const double* __restrict__ coords_w, const double* __restrict__ coords_h,
                                                         const double* __restrict__ coords_d, const float* __restrict__ embeds, const float* __restrict__ dim_t,
@@ -635,12 +636,20 @@ __global__ __launch_bounds__(256) void pe_inputs_kernel(const int* __restrict__ 
             // are ~130 fp64 instructions, 192 of them per position: the kernel was bound by them)
             fr_row[dk * 3 + i] = f32_to_bf16(logf((float)x1 / (float)x2));
             // index-exact validation mode: the unrounded fp32 row, quotient and logarithm in fp64 like the reference (MU/pe.py:130)
-            if (A_frustum_f32) A_frustum_f32[(long long)s * (3 * D) + dk * 3 + i] = (float)log(x1 / x2);
+            if (EXACT) A_frustum_f32[(long long)s * (3 * D) + dk * 3 + i] = (float)log(x1 / x2);
         }
     }
     // sine features, channel order (n | y | x).  NOT interleaved: the reference stacks sin/cos on dim=4 of a
     // 5-D tensor (MU/positional_encoding.py:86-94), so within an axis channels 0..63 = sin(e / dim_t[2j]) and
     // channels 64..127 = cos(e / dim_t[2j+1]).
+    if (!A_sine) {                                            // the sine branch comes from the engine's folded table: only the frustum row is needed
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        const int nf0 = 3 * D / 8;
+        for (int q = lane; q < nf0; q += 64)
+            *reinterpret_cast<uint4*>(A_frustum + (long long)s * (3 * D) + 8 * q) = *reinterpret_cast<const uint4*>(fr_row + 8 * q);
+        return;
+    }
     const float en = embeds[pos], ey = embeds[P + pos], ex = embeds[2 * P + pos];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -651,7 +660,7 @@ __global__ __launch_bounds__(256) void pe_inputs_kernel(const int* __restrict__ 
         // for a value that is rounded to bf16 right here
         const float a = e / dim_t[i < 64 ? 2 * i : 2 * (i - 64) + 1];
         si_row[ch] = f32_to_bf16(i < 64 ? __sinf(a) : __cosf(a));
-        if (A_sine_f32) A_sine_f32[(long long)s * 384 + ch] = i < 64 ? sinf(a) : cosf(a);
+        if (EXACT) A_sine_f32[(long long)s * 384 + ch] = i < 64 ? sinf(a) : cosf(a);
     }
     __builtin_amdgcn_wave_barrier();                          // the rows are read back by the same wave only
     __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): LDS writes landed
@@ -978,14 +987,18 @@ extern "C" int mv2d_pe_inputs(const int* s2pos, const int* S_dev, int S_max, con
                               const float* dim_t, void* A_frustum, void* A_sine, void* Xf_bf16, float* Xf_f32, float* A_frustum_f32,
                               float* A_sine_f32, int V, int h, int w, int depth_num, const double* position_range, void* stream) {
     MV2D_CHECK_ARG(s2pos && S_dev && featcl && img2lidar && coords_w && coords_h && coords_d && embeds && dim_t && A_frustum &&
-                       A_sine && Xf_bf16 && position_range, "mv2d_pe_inputs: null pointer");
+                       Xf_bf16 && position_range, "mv2d_pe_inputs: null pointer");
+    MV2D_CHECK_ARG(A_sine || !A_sine_f32, "mv2d_pe_inputs: the exact rows need A_sine");
     MV2D_CHECK_ARG(depth_num <= 256 && (depth_num % 8) == 0, "mv2d_pe_inputs: depth_num must be a multiple of 8, <= 256");
     if (S_max == 0) return MV2D_OK;
-    hipLaunchKernelGGL(pe_inputs_kernel, dim3(cdiv(S_max, 4)), dim3(256), 0, (hipStream_t)stream, s2pos, S_dev, featcl, img2lidar, coords_w,
-                       coords_h, coords_d, embeds, dim_t, (unsigned short*)A_frustum, (unsigned short*)A_sine,
-                       (unsigned short*)Xf_bf16, Xf_f32, A_frustum_f32, A_sine_f32, h, w, V * h * w, depth_num, position_range[0], position_range[1],
-                       position_range[2], position_range[3] - position_range[0], position_range[4] - position_range[1],
-                       position_range[5] - position_range[2]);
+    MV2D_CHECK_ARG((A_frustum_f32 == nullptr) == (A_sine_f32 == nullptr), "mv2d_pe_inputs: the fp32 rows come together");
+#define MV2D_PEI(EX) hipLaunchKernelGGL(pe_inputs_kernel<EX>, dim3(cdiv(S_max, 4)), dim3(256), 0, (hipStream_t)stream, s2pos, S_dev, featcl, img2lidar, coords_w, \
+                       coords_h, coords_d, embeds, dim_t, (unsigned short*)A_frustum, (unsigned short*)A_sine,                                      \
+                       (unsigned short*)Xf_bf16, Xf_f32, A_frustum_f32, A_sine_f32, h, w, V * h * w, depth_num, position_range[0], position_range[1], \
+                       position_range[2], position_range[3] - position_range[0], position_range[4] - position_range[1],                               \
+                       position_range[5] - position_range[2])
+    if (A_frustum_f32) MV2D_PEI(true); else MV2D_PEI(false);
+#undef MV2D_PEI
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

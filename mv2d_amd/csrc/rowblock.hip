@@ -201,6 +201,11 @@ struct AttnOutX3Params {
     float* x_out;
     const float* qpos; const unsigned short* Wqh; const unsigned short* Wql; const float* bq; float qscale; float* q_out;
     int M; float eps;
+    // ZMAP (cross attention, csrc/xattn_tile.hip): the context tile is computed here from the tile attention's z [M,8,256]:
+    //   ctx[:, 32 h + d] = Wv_h z_h + bv (packed WB, see xattn_ctxmap_kernel); rows without a key (row_ptr) -> NaN / 0
+    const float* z; const uint4* WBh; const uint4* WBl; const float* bv; const int* row_ptr; int empty_nan;
+    // QMAP: the query tile goes on into the per-head query maps Qt (packed WA, see xattn_qmap_kernel) instead of q_out
+    const uint4* WAh; const uint4* WAl; uint4* Qt;
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
@@ -243,7 +248,15 @@ __device__ __forceinline__ void load_w_x3(BFrag wh[8], BFrag wl[8], const unsign
 // RT row tiles (16 rows each) per block share one fetch of the weight fragments.  A block is bound by fetching its 0.5 MB of weights
 // through one CU's L1 (~57 GB/s), whatever the number of rows: with a batch of samples (M > 512) two row tiles per block take the
 // same time on half as many CUs, which the other streams' wide kernels can use.
-template <int RT>
+__device__ __forceinline__ void split8(const float4& x0, const float4& x1, BFrag& hi, BFrag& lo) {
+    uint2 h0, l0, h1, l1;
+    split4(x0, h0, l0);
+    split4(x1, h1, l1);
+    hi.u = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    lo.u = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
+template <int RT, bool ZMAP, bool QMAP>
 __global__ __launch_bounds__(1024) void attn_out_fused_x3_kernel(AttnOutX3Params p) {
     __shared__ __attribute__((aligned(16))) unsigned char ah[RT * 16 * 512], al[RT * 16 * 512];
     __shared__ __attribute__((aligned(16))) float tb[RT * 16 * C];
@@ -254,17 +267,55 @@ __global__ __launch_bounds__(1024) void attn_out_fused_x3_kernel(AttnOutX3Params
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
         grow[t] = (long long)min(mb + 16 * t + wave, p.M - 1) * C + lane * 4;
-        av[t] = *reinterpret_cast<const float4*>(p.ctx + grow[t]);
+        if (!ZMAP) av[t] = *reinterpret_cast<const float4*>(p.ctx + grow[t]);
     }
     BFrag wh[8], wl[8];
-    load_w_x3(wh, wl, p.Woh, p.Wol, wave, lane);
-    const int aoff = wave * 512 + (((lane >> 1) ^ wave) << 4) + (lane & 1) * 8;     // this thread's 4 values in the bf16 images of a tile
+    if (ZMAP) {
+        // context map of the tile cross attention: wave w = (head w >> 1, column half w & 1) computes the 16 x 16 block of ctx it would
+        // otherwise have loaded as rows, in xattn_ctxmap_kernel's arithmetic (same fragments, same MFMA order), and writes it into the images
+        const int h = wave >> 1, nt = wave & 1;
+        const uint4* wbh = p.WBh + (long long)h * 16 * 64 + nt * 64 + lane;
+        const uint4* wbl = p.WBl + (long long)h * 16 * 64 + nt * 64 + lane;
+        const float bias = p.bv[16 * wave + fr];
 #pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        uint2 hi, lo;
-        split4(av[t], hi, lo);
-        *reinterpret_cast<uint2*>(ah + t * 8192 + aoff) = hi;
-        *reinterpret_cast<uint2*>(al + t * 8192 + aoff) = lo;
+        for (int t = 0; t < RT; ++t) {
+            const float* zp = p.z + ((long long)min(mb + 16 * t + fr, p.M - 1) * 8 + h) * C + 8 * fg;
+            f32x4_t ca = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                BFrag zh, zl, bh, bl;
+                split8(*reinterpret_cast<const float4*>(zp + 32 * s), *reinterpret_cast<const float4*>(zp + 32 * s + 4), zh, zl);
+                bh.u = wbh[s * 128];
+                bl.u = wbl[s * 128];
+                ca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zl.v, bh.v, ca, 0, 0, 0);
+                ca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zh.v, bl.v, ca, 0, 0, 0);
+                ca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zh.v, bh.v, ca, 0, 0, 0);
+            }
+            const int col = 16 * wave + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * fg + r, m = min(mb + 16 * t + row, p.M - 1);
+                float v = ca[r] + bias;
+                if (p.row_ptr[m + 1] <= p.row_ptr[m]) v = p.empty_nan ? __uint_as_float(0x7fc00000u) : 0.f;
+                const unsigned short hb = f32_to_bf16(v);
+                const int off = t * 8192 + row * 512 + (((col >> 3) ^ row) << 4) + (col & 7) * 2;
+                *reinterpret_cast<unsigned short*>(ah + off) = hb;
+                *reinterpret_cast<unsigned short*>(al + off) = f32_to_bf16(v - bf16_to_f32(hb));
+            }
+        }
+        load_w_x3(wh, wl, p.Woh, p.Wol, wave, lane);
+    } else {
+        load_w_x3(wh, wl, p.Woh, p.Wol, wave, lane);
+    }
+    const int aoff = wave * 512 + (((lane >> 1) ^ wave) << 4) + (lane & 1) * 8;     // this thread's 4 values in the bf16 images of a tile
+    if (!ZMAP) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            uint2 hi, lo;
+            split4(av[t], hi, lo);
+            *reinterpret_cast<uint2*>(ah + t * 8192 + aoff) = hi;
+            *reinterpret_cast<uint2*>(al + t * 8192 + aoff) = lo;
+        }
     }
     __syncthreads();
     f32x4_t acc[RT];
@@ -307,13 +358,56 @@ __global__ __launch_bounds__(1024) void attn_out_fused_x3_kernel(AttnOutX3Params
     for (int t = 0; t < RT; ++t) acc[t] = tile_mma_x3(ah + t * 8192, al + t * 8192, wh, wl, fr, fg);
     const int col = wave * 16 + fr;
     const float b = p.bq[col];
+    if (!QMAP) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mb + 16 * t + 4 * fg + r;
+                if (m < p.M) p.q_out[(long long)m * C + col] = (acc[t][r] + b) * p.qscale;
+            }
+        return;
+    }
+    // query map of the tile cross attention (xattn_qmap_kernel's arithmetic): the q tile goes through LDS (tb is free: every wave has
+    // passed the barrier behind the LayerNorm reads), wave w = (head w >> 1, channel tiles 8 (w & 1) ..): Qt[m][h][s][g][hi | lo]
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = mb + 16 * t + 4 * fg + r;
-            if (m < p.M) p.q_out[(long long)m * C + col] = (acc[t][r] + b) * p.qscale;
+        for (int r = 0; r < 4; ++r) tb[t * 16 * C + toff(4 * fg + r, col)] = (acc[t][r] + b) * p.qscale;
+    __syncthreads();
+    {
+        const int h = wave >> 1, half = wave & 1;
+        const uint4* wah = p.WAh + ((long long)h * 16 + 8 * half) * 64 + lane;
+        const uint4* wal = p.WAl + ((long long)h * 16 + 8 * half) * 64 + lane;
+        BFrag ahf[8], alf[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ahf[k].u = wah[k * 64]; alf[k].u = wal[k * 64]; }
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            BFrag bh, bl;
+            const float* qrow = tb + t * 16 * C;
+            const int c0 = 32 * h + 8 * fg;
+            split8(*reinterpret_cast<const float4*>(qrow + toff(fr, c0)), *reinterpret_cast<const float4*>(qrow + toff(fr, c0 + 4)), bh, bl);
+            const int m = mb + 16 * t + fr;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alf[2 * u].v, bh.v, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf[2 * u].v, bl.v, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf[2 * u].v, bh.v, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alf[2 * u + 1].v, bh.v, a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf[2 * u + 1].v, bl.v, a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf[2 * u + 1].v, bh.v, a1, 0, 0, 0);
+                BFrag hi, lo;
+                split8(make_float4(a0[0], a0[1], a0[2], a0[3]), make_float4(a1[0], a1[1], a1[2], a1[3]), hi, lo);
+                if (m < p.M) {
+                    uint4* out = p.Qt + (long long)m * 512 + h * 64 + (4 * half + u) * 8 + fg * 2;
+                    out[0] = hi.u;
+                    out[1] = lo.u;
+                }
+            }
         }
+    }
 }
 
 __device__ __forceinline__ float4 ln_row(float4 v, const float* __restrict__ w, const float* __restrict__ b, int c0, float eps);
@@ -1071,9 +1165,44 @@ extern "C" int mv2d_attn_out_fused_x3(const float* ctx, const float* resid, cons
     MV2D_CHECK_ARG(!Wq_hi || (Wq_lo && qpos && bq && q_out), "mv2d_attn_out_fused_x3: the q stage needs Wq_lo, qpos, bq and q_out");
     if (M == 0) return MV2D_OK;
     AttnOutX3Params p{ctx, resid, (const unsigned short*)Wo_hi, (const unsigned short*)Wo_lo, bo, ln_w, ln_b, x_out, qpos,
-                      (const unsigned short*)Wq_hi, (const unsigned short*)Wq_lo, bq, qscale, q_out, M, eps};
-    if (M <= 512) hipLaunchKernelGGL(attn_out_fused_x3_kernel<1>, dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(attn_out_fused_x3_kernel<2>, dim3(cdiv(M, 32)), dim3(1024), 0, (hipStream_t)stream, p);
+                      (const unsigned short*)Wq_hi, (const unsigned short*)Wq_lo, bq, qscale, q_out, M, eps,
+                      nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+    if (M <= 512) hipLaunchKernelGGL((attn_out_fused_x3_kernel<1, false, false>), dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attn_out_fused_x3_kernel<2, false, false>), dim3(cdiv(M, 32)), dim3(1024), 0, (hipStream_t)stream, p);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+// The two row kernels around the tile cross attention with its per-head maps fused in (csrc/xattn_tile.hip):
+//   mv2d_attn_out_qmap_x3: out_proj + residual + LayerNorm of the SELF attention, cross-attention q projection, and the query map
+//                          Qt (= mv2d_attn_out_fused_x3 + mv2d_xattn_qmap, bitwise; q itself is not written)
+//   mv2d_attn_out_zmap_x3: context map of z (= mv2d_xattn_ctxmap) + out_proj + residual + LayerNorm of the CROSS attention
+extern "C" int mv2d_attn_out_qmap_x3(const float* ctx, const float* resid, const void* Wo_hi, const void* Wo_lo, const float* bo,
+                                     const float* ln_w, const float* ln_b, float* x_out, const float* qpos, const void* Wq_hi,
+                                     const void* Wq_lo, const float* bq, float qscale, const void* WA_hi, const void* WA_lo, void* Qt, int M,
+                                     float eps, void* stream) {
+    MV2D_CHECK_ARG(ctx && resid && Wo_hi && Wo_lo && bo && ln_w && ln_b && x_out && qpos && Wq_hi && Wq_lo && bq && WA_hi && WA_lo && Qt,
+                   "mv2d_attn_out_qmap_x3: null pointer");
+    if (M == 0) return MV2D_OK;
+    AttnOutX3Params p{ctx, resid, (const unsigned short*)Wo_hi, (const unsigned short*)Wo_lo, bo, ln_w, ln_b, x_out, qpos,
+                      (const unsigned short*)Wq_hi, (const unsigned short*)Wq_lo, bq, qscale, nullptr, M, eps,
+                      nullptr, nullptr, nullptr, nullptr, nullptr, 0, (const uint4*)WA_hi, (const uint4*)WA_lo, (uint4*)Qt};
+    if (M <= 512) hipLaunchKernelGGL((attn_out_fused_x3_kernel<1, false, true>), dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attn_out_fused_x3_kernel<2, false, true>), dim3(cdiv(M, 32)), dim3(1024), 0, (hipStream_t)stream, p);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_attn_out_zmap_x3(const float* z, const void* WB_hi, const void* WB_lo, const float* bv, const int* row_ptr, int empty_nan,
+                                     const float* resid, const void* Wo_hi, const void* Wo_lo, const float* bo, const float* ln_w,
+                                     const float* ln_b, float* x_out, int M, float eps, void* stream) {
+    MV2D_CHECK_ARG(z && WB_hi && WB_lo && bv && row_ptr && resid && Wo_hi && Wo_lo && bo && ln_w && ln_b && x_out, "mv2d_attn_out_zmap_x3: null pointer");
+    if (M == 0) return MV2D_OK;
+    AttnOutX3Params p{nullptr, resid, (const unsigned short*)Wo_hi, (const unsigned short*)Wo_lo, bo, ln_w, ln_b, x_out, nullptr,
+                      nullptr, nullptr, nullptr, 1.0f, nullptr, M, eps,
+                      z, (const uint4*)WB_hi, (const uint4*)WB_lo, bv, row_ptr, empty_nan, nullptr, nullptr, nullptr};
+    if (M <= 512) hipLaunchKernelGGL((attn_out_fused_x3_kernel<1, true, false>), dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attn_out_fused_x3_kernel<2, true, false>), dim3(cdiv(M, 32)), dim3(1024), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -76,6 +76,7 @@ class HeadEngine:
         # epilogue (default; MV2D_PE_SINE_TABLE=0 evaluates the branch per frame like the reference does)
         self.pe_sine_table = self.pe_fused and os.environ.get('MV2D_PE_SINE_TABLE', '1') == '1'
         self._weights_version = 0     # bumped by every load_state(): invalidates whatever was folded from the weights
+        self.keep_sine_rows = False   # the training route reads the per-key sine rows (ws['A2']) although the inference kernel does not
         self.force_nc = None          # bench only (S path): overwrite the correlation lists so that every query reads n_c RoIs
         # out_proj + residual + LayerNorm (+ q in_proj) as one row-fused kernel per attention (8 instead of 11 launches per layer),
         # its two linears in bf16x3 split precision (fp32-class: ~1e-5 relative).  MV2D_ROWS_X3=0: exact-fp32 fused kernel (slower than
@@ -96,6 +97,11 @@ class HeadEngine:
         # core on bf16 MFMA tiles over the UNPROJECTED key / value rows gathered into LDS — no per-layer K/V in HBM, no kvproj launch.
         # MV2D_XATTN=sparse selects the round-1 route (kvproj_kernel + one-block-per-query VALU kernel) for A/B runs.
         self.tile_attn = os.environ.get('MV2D_XATTN', 'tile') == 'tile' and not self.raw_attn
+        # OPT-IN (measured slower): the per-head maps of the tile route inside the neighbouring row kernels (mv2d_attn_out_qmap_x3 /
+        # _zmap_x3: 6 instead of 8 launches per layer, bitwise the same results).  cfg2_s, 8 samples per launch: 27.4 + 25.7 us for the two
+        # fused kernels against 15.6 + 11.0 + 10.2 + 8.0 us for the four separate ones -- a row kernel is bound by streaming its weights
+        # through ONE CU per 32 rows, and the fused ones stream twice as much on 75 blocks while the separate map kernels spread over 150
+        self.fuse_maps = os.environ.get('MV2D_XATTN_FUSE_MAPS', '0') == '1'
         nw = os.environ.get('MV2D_XATTN_NW')
         self.xattn_waves = int(nw) if nw else 4                             # waves per query (8 measured slower on both paths)
         self.qg_x3 = os.environ.get('MV2D_QG_X3', '1') == '1'          # query-generator fcs + first in_proj as LDS-tiled bf16x3 linears (0: exact fp32)
@@ -541,7 +547,8 @@ class HeadEngine:
         tk('pe_inputs')
         # a2: PE at the listed positions (3 two-layer MLPs on bf16 MFMA)
         o.pe_inputs(ws['s2pos'], ws['S_dev'], P, featcl, T['img2lidar'], T['coords_w'], T['coords_h'], T['coords_d'], T['embeds'],
-                    self.const['dim_t'], ws['A1'], ws['A2'], ws['Xf_b'], ws['Xf32'], V, h, w, self.depth_num, self.post_range_h64)
+                    self.const['dim_t'], ws['A1'], None if (self.pe_sine_table and not self.keep_sine_rows) else ws['A2'], ws['Xf_b'], ws['Xf32'],
+                    V, h, w, self.depth_num, self.post_range_h64)
         md = ws['S_dev']
         tk('pe_fused')
         if self.exact:
@@ -680,12 +687,16 @@ class HeadEngine:
         fuse_tail = self.fuse_rows and self.rows_x3          # FFN tail + next layer's in_proj as one row-fused kernel
         xk_rows, xv_rows = ws['xk_rows'], ws['xv_rows']
 
+        maps_fused = self.tile_attn and self.fuse_maps and self.fuse_rows and self.rows_x3 and not self.sa_fused
+
         def cross_attn(i):
             if self.tile_attn:
-                o.xattn_qmap(ws['q'], W_[f'ca_mapA{i}'], ws['Qt'], R=R)
+                if not maps_fused:
+                    o.xattn_qmap(ws['q'], W_[f'ca_mapA{i}'], ws['Qt'], R=R)
                 o.xattn_tile(ws['Qt'], xk_rows, xv_rows, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=self.empty_nan, waves=self.xattn_waves,
                              Xk_lo=ws.get('xk_lo'), Xv_lo=ws.get('xv_lo'))
-                o.xattn_ctxmap(ws['zh'], W_[f'ca_mapB{i}'], W_[f'ca_v_b{i}'], ws['row_ptr'], ws['ctx'], R, empty_nan=self.empty_nan)
+                if not maps_fused:
+                    o.xattn_ctxmap(ws['zh'], W_[f'ca_mapB{i}'], W_[f'ca_v_b{i}'], ws['row_ptr'], ws['ctx'], R, empty_nan=self.empty_nan)
                 return
             if not self.raw_attn:
                 o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R, empty_nan=self.empty_nan)
@@ -716,7 +727,14 @@ class HeadEngine:
                     o.self_attn_dn(ws['qkv'], ws['dn'][0], ws['dn'][1], out=ws['ctx'])      # training: denoising rows first (train_forward)
                 else:
                     o.self_attn(ws['qkv'], ws['ctx'], R, grp_start=ws['grp_start'])
-            if self.fuse_rows and self.rows_x3:
+            if maps_fused:
+                o.attn_out_qmap_x3(ws['ctx'], x_in, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
+                                   qpos=ws['qpos'], Wq_x3=W_[f'ca_q_wx{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, WA=W_[f'ca_mapA{i}'],
+                                   Qt=ws['Qt'], M=R)
+                cross_attn(i)
+                o.attn_out_zmap_x3(ws['zh'], W_[f'ca_mapB{i}'], W_[f'ca_v_b{i}'], ws['row_ptr'], ws['x1'], W_[f'ca_out_wx{i}'], W_[f'ca_out_b{i}'],
+                                   (W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), ws['x2'], empty_nan=self.empty_nan, M=R)
+            elif self.fuse_rows and self.rows_x3:
                 sa_tail = o.sa_block_fused_x3 if sa_fused else o.attn_out_fused_x3      # self-attention core inside the row kernel, or not
                 sa_tail(ws['qkv'] if sa_fused else ws['ctx'], x_in, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
                         qpos=ws['qpos'], Wq_x3=W_[f'ca_q_wx{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, q_out=ws['q'], M=R)

@@ -116,6 +116,23 @@ def attn_out_fused_x3(ctx, resid, Wo_x3, bo, ln, x_out, *, qpos=None, Wq_x3=None
     return x_out
 
 
+def attn_out_qmap_x3(ctx, resid, Wo_x3, bo, ln, x_out, *, qpos, Wq_x3, bq, qscale, WA, Qt, M=None, eps=1e-5):
+    """attn_out_fused_x3 with the query map of the tile cross attention fused in: writes x_out and Qt (see xattn_qmap), not q."""
+    M = ctx.shape[0] if M is None else M
+    check(_lib.load().mv2d_attn_out_qmap_x3(_p(ctx), _p(resid), _p(Wo_x3[0]), _p(Wo_x3[1]), _p(bo), _p(ln[0]), _p(ln[1]), _p(x_out), _p(qpos),
+                                            _p(Wq_x3[0]), _p(Wq_x3[1]), _p(bq), float(qscale), _p(WA[0]), _p(WA[1]), _p(Qt), M, float(eps), _stream()),
+          'mv2d_attn_out_qmap_x3')
+    return x_out
+
+
+def attn_out_zmap_x3(z, WB, bv, row_ptr, resid, Wo_x3, bo, ln, x_out, *, empty_nan=True, M=None, eps=1e-5):
+    """xattn_ctxmap + attn_out_fused_x3 (no q stage) in one launch: z [M,8,256] -> x_out = LN(ctx @ Wo.T + bo + resid)."""
+    M = z.shape[0] if M is None else M
+    check(_lib.load().mv2d_attn_out_zmap_x3(_p(z), _p(WB[0]), _p(WB[1]), _p(bv), _p(row_ptr), 1 if empty_nan else 0, _p(resid), _p(Wo_x3[0]),
+                                            _p(Wo_x3[1]), _p(bo), _p(ln[0]), _p(ln[1]), _p(x_out), M, float(eps), _stream()), 'mv2d_attn_out_zmap_x3')
+    return x_out
+
+
 def sa_block_fused_x3(qkv, resid, Wo_x3, bo, ln, x_out, *, qpos=None, Wq_x3=None, bq=None, qscale=1.0, q_out=None, M=None, eps=1e-5):
     """self_attn(qkv) -> out_proj + resid -> LN -> x_out [-> (+qpos) q projection -> q_out]; linears in bf16x3."""
     M = qkv.shape[0] if M is None else M
