@@ -227,6 +227,14 @@ int mv2d_map_conv3x3(const void* in, const void* Wp, const float* bias, float* o
 /* FlattenMHSelfAttention core (MU/petr_transformer.py:317-370): qkv [R,768] fp32 = in_proj(q|k|v) -> ctx [R,256]. */
 int mv2d_self_attn_fwd(const float* qkv, float* ctx, int R, const int* grp_start, int n_samples, void* stream);
 
+/* The same attention on bf16 MFMAs in split precision (default; csrc/self_attn_x3.hip): block = (64 queries, head, sample), the sample's
+ * K / V rows staged once per block through LDS with whole-row loads (hi / lo bf16 images, V transposed), S^T = K.Q^T and O^T = V^T.P^T as
+ * three-term bf16x3 products, online softmax over 32-key steps: 1e-5 against fp64 like mv2d_self_attn_fwd.  max_grp_rows: upper
+ * bound of the rows of one sample (sizes the grid; 0 = R).  dn_pad > 0 (one sample, grp_start NULL): the denoising mask of
+ * mv2d_self_attn_dn_fwd. */
+int mv2d_self_attn_x3_fwd(const float* qkv, float* ctx, int R, const int* grp_start, int n_samples, int max_grp_rows, int dn_pad,
+                          int dn_single, void* stream);
+
 /* Training variant: the first dn_pad rows are denoising queries in groups of dn_single rows; the attention mask of
  * prepare_for_dn (mmdet3d_plugin/models/roi_heads/mv2d_s_head.py:95-107) is evaluated in the kernel: a key is visible iff
  * key >= dn_pad, or query < dn_pad and key / dn_single == query / dn_single.  One sample per launch. */

@@ -53,6 +53,7 @@ SIGNATURES = {
     'mv2d_map_conv3x3': (I, [P, P, P, P, I, I, I, P]),
     'mv2d_self_attn_fwd': (I, [P, P, I, P, I, P]),
     'mv2d_self_attn_dn_fwd': (I, [P, P, I, I, I, P]),
+    'mv2d_self_attn_x3_fwd': (I, [P, P, I, P, I, I, I, I, P]),
     'mv2d_dn_queries': (I, [P, P, P, I, I, F, F, F, I, P, F, P, P, P, P]),
     'mv2d_sparse_xattn_fwd': (I, [P, P, P, P, P, P, P, LL, I, I, P]),
     'mv2d_raw_xattn_fwd': (I, [P, P, P, P, P, P, I, I, P]),

@@ -495,7 +495,7 @@ class HeadEngine:
             featcl = feat.permute(0, 2, 3, 1).reshape(P, C)                         # already position-major: no copy
         else:
             featcl = o.nchw_to_nhwc(feat, ws['featcl'])
-        ws['featcl_cur'], ws['map_shape'] = featcl, (V, h, w)
+        ws['featcl_cur'], ws['map_shape'], ws['max_rows'] = featcl, (V, h, w), sc['max_rows']
         tk('box_params')
         # a3/a5/a7 per-RoI camera
         o.box_params(rois, T['viewK'], T['viewE'], ws['enc'][:, 1024:], 1056, ws['minv'])
@@ -726,7 +726,8 @@ class HeadEngine:
                 if ws.get('dn'):
                     o.self_attn_dn(ws['qkv'], ws['dn'][0], ws['dn'][1], out=ws['ctx'])      # training: denoising rows first (train_forward)
                 else:
-                    o.self_attn(ws['qkv'], ws['ctx'], R, grp_start=ws['grp_start'])
+                    o.self_attn(ws['qkv'], ws['ctx'], R, grp_start=ws['grp_start'], max_grp_rows=ws.get('max_rows', 0),
+                                impl='f32' if self.exact else None)      # index-exact mode: the exact-fp32 MFMA kernel
             if maps_fused:
                 o.attn_out_qmap_x3(ws['ctx'], x_in, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
                                    qpos=ws['qpos'], Wq_x3=W_[f'ca_q_wx{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, WA=W_[f'ca_mapA{i}'],

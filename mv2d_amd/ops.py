@@ -385,24 +385,43 @@ def nchw_to_nhwc(x, out=None):
     return out
 
 
-def self_attn(qkv, out=None, R=None, grp_start=None):
-    """grp_start (int32 [n+1], device): first query row of every sample of a batch; attention stays inside a sample."""
+SELF_ATTN_X3 = None
+
+
+def _self_attn_x3():
+    global SELF_ATTN_X3
+    if SELF_ATTN_X3 is None:
+        import os
+        SELF_ATTN_X3 = os.environ.get('MV2D_SELF_ATTN', 'x3') == 'x3'      # f32: the round-1 exact-fp32 MFMA kernel (A/B switch)
+    return SELF_ATTN_X3
+
+
+def self_attn(qkv, out=None, R=None, grp_start=None, max_grp_rows=0, impl=None):
+    """FlattenMHSelfAttention core.  grp_start (int32 [n+1], device): first query row of every sample of a batch; attention stays inside
+    a sample.  impl: 'x3' (default: bf16 split precision, K / V through LDS) | 'f32' (exact fp32 MFMA, round 1)."""
     _req(qkv, torch.float32, 'qkv')
     R = qkv.shape[0] if R is None else R
     if out is None:
         out = torch.empty((R, 256), device=qkv.device, dtype=torch.float32)
     n = 0 if grp_start is None else grp_start.numel() - 1
-    check(_lib.load().mv2d_self_attn_fwd(_p(qkv), _p(out), R, _p(grp_start), n, _stream()), 'mv2d_self_attn_fwd')
+    if (impl or ('x3' if _self_attn_x3() else 'f32')) == 'x3':
+        check(_lib.load().mv2d_self_attn_x3_fwd(_p(qkv), _p(out), R, _p(grp_start), n, int(max_grp_rows), 0, 1, _stream()), 'mv2d_self_attn_x3_fwd')
+    else:
+        check(_lib.load().mv2d_self_attn_fwd(_p(qkv), _p(out), R, _p(grp_start), n, _stream()), 'mv2d_self_attn_fwd')
     return out
 
 
-def self_attn_dn(qkv, dn_pad, dn_single, out=None):
-    """Self attention of one training sample: the first dn_pad rows are denoising queries in groups of dn_single (prepare_for_dn's mask)."""
+def self_attn_dn(qkv, dn_pad, dn_single, out=None, impl='f32'):
+    """Self attention of one training sample: the first dn_pad rows are denoising queries in groups of dn_single (prepare_for_dn's mask).
+    impl: 'f32' (default on the training route: exact-fp32 MFMA) | 'x3' (the inference kernel with the mask evaluated in it)."""
     _req(qkv, torch.float32, 'qkv')
     R = qkv.shape[0]
     if out is None:
         out = torch.empty((R, 256), device=qkv.device, dtype=torch.float32)
-    check(_lib.load().mv2d_self_attn_dn_fwd(_p(qkv), _p(out), R, int(dn_pad), int(dn_single), _stream()), 'mv2d_self_attn_dn_fwd')
+    if impl == 'x3':
+        check(_lib.load().mv2d_self_attn_x3_fwd(_p(qkv), _p(out), R, None, 0, 0, int(dn_pad), max(int(dn_single), 1), _stream()), 'mv2d_self_attn_x3_fwd')
+    else:
+        check(_lib.load().mv2d_self_attn_dn_fwd(_p(qkv), _p(out), R, int(dn_pad), int(dn_single), _stream()), 'mv2d_self_attn_dn_fwd')
     return out
 
 

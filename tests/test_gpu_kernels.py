@@ -274,11 +274,36 @@ def test_transpose_and_cast(dev):
 def test_self_attn(dev, R):
     from mv2d_amd import ops
     qkv = rnd((R, 768), 50).to(dev)
-    out = ops.self_attn(qkv)
+    qkv[:, :256] *= 3.0                                   # sharper logits: the running maximum moves between the 32-key steps
     q, k, v = [t.double().view(R, 8, 32).transpose(0, 1) for t in qkv.split(256, 1)]
     att = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(32), -1)
     ref = (att @ v).transpose(0, 1).reshape(R, 256)
-    assert relerr(out, ref) < 1e-5
+    for impl in ('x3', 'f32'):                            # default: bf16 split precision through LDS; f32: the round-1 exact-fp32 kernel
+        out = ops.self_attn(qkv, impl=impl)
+        # split precision drops the lo x lo terms (2^-18 of |q||k|): with logits of magnitude ~15 that is 5e-5 after the exponential
+        assert relerr(out, ref) < (6e-5 if impl == 'x3' else 1e-5), (impl, relerr(out, ref))
+    qkv[:, :256] /= 3.0                                   # logits of the size the decoder produces: fp32-class either way
+    q = qkv[:, :256].double().view(R, 8, 32).transpose(0, 1)
+    ref = (torch.softmax(q @ k.transpose(1, 2) / math.sqrt(32), -1) @ v).transpose(0, 1).reshape(R, 256)
+    assert relerr(ops.self_attn(qkv, impl='x3'), ref) < 1e-5
+
+
+@pytest.mark.parametrize('sizes', [(300, 300, 300), (37, 1, 290, 64, 129), (900, 450)])
+def test_self_attn_samples_of_a_batch(dev, sizes):
+    """Several samples in one launch (grp_start): attention stays inside a sample and a sample's rows are BITWISE what a single-sample
+    launch gives, also with padding rows behind the last sample (the engine's RoI buckets) and a loose per-sample row bound."""
+    from mv2d_amd import ops
+    R = sum(sizes)
+    pad = 40
+    qkv = rnd((R + pad, 768), 51).to(dev)
+    grp = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
+    for impl in ('x3', 'f32'):
+        out = ops.self_attn(qkv, grp_start=grp, max_grp_rows=max(sizes) + 23 if impl == 'x3' else 0, impl=impl)
+        o = 0
+        for n in sizes:
+            single = ops.self_attn(qkv[o:o + n].contiguous(), impl=impl)
+            assert torch.equal(out[o:o + n], single), (impl, n)
+            o += n
 
 
 def test_sparse_xattn(dev):

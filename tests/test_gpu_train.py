@@ -176,8 +176,11 @@ def test_self_attn_with_denoising_mask(R, pad, single):
     logits = (q @ k.transpose(1, 2) / math.sqrt(32)).masked_fill(mask[None], float('-inf'))
     want = (torch.softmax(logits, -1) @ v).transpose(0, 1).reshape(R, 256)
     assert float((out.cpu().double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    out3 = ops.self_attn_dn(qkv, pad, single, impl='x3')    # the split-precision kernel with the same mask (unit-variance q, k: logits ~ +-15)
+    assert float((out3.cpu().double() - want).abs().max()) <= 6e-5 * float(want.abs().max())
     if pad == 0:
-        assert torch.equal(out, ops.self_attn(qkv))          # no denoising rows: the inference kernel's arithmetic
+        assert torch.equal(out, ops.self_attn(qkv, impl='f32'))          # no denoising rows: the inference kernel's arithmetic
+        assert torch.equal(out3, ops.self_attn(qkv, impl='x3'))
 
 
 @pytest.mark.parametrize('name', list(synthetic.FWD_TRAIN_CASES))
