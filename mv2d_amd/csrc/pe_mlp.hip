@@ -17,6 +17,7 @@
 //     may use all 512 registers); one fp32 + one bf16 store per output.
 // MFMAs run swapped (D^T = W.A^T): a lane ends with 4 consecutive columns of one row -> 8-byte LDS writes of the hidden layer,
 // 16-byte global stores.  Same k order and the same bf16 rounding of the hidden layers as the GEMM route: results are bit-identical.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -385,6 +386,11 @@ extern "C" int mv2d_pe_fused(const void* A1, const void* A2, const void* Xfb, co
     return MV2D_OK;
 }
 
+extern "C" int mv2d_pe_fused_tab2(const void* A1, const void* Xfb, const float* Xf32, const int* row_index, const int* m_dev, int M,
+                                  const void* W1a, const float* b1a, const void* W1b, const float* b1b,
+                                  const void* Wr, const float* br, const void* We, const float* be,
+                                  const float* sine_tab, int tab_period, float* pe, void* Xk, int shape, void* stream);   // pe_tab96.hip
+
 extern "C" int mv2d_pe_fused_tab(const void* A1, const void* Xfb, const float* Xf32, const int* row_index, const int* m_dev, int M,
                                  const void* W1a, const float* b1a, const void* W1b, const float* b1b,
                                  const void* Wr, const float* br, const void* We, const float* be,
@@ -392,6 +398,14 @@ extern "C" int mv2d_pe_fused_tab(const void* A1, const void* Xfb, const float* X
     MV2D_CHECK_ARG(A1 && Xfb && Xf32 && W1a && b1a && W1b && b1b && Wr && br && We && be && sine_tab && pe && Xk, "mv2d_pe_fused_tab: null pointer");
     MV2D_CHECK_ARG(M >= 0 && tab_period > 0, "mv2d_pe_fused_tab: M must be >= 0 and tab_period > 0");
     if (M == 0) return MV2D_OK;
+    // read per call (a host-side launch decision; graphs keep what they captured).  Default: pe_tab96.hip's kernel in its 96-row /
+    // 8-wave shape; MV2D_PE_TAB_KERNEL=2: its two-64-row-blocks-per-CU shape; =64: this file's kernel (one wave per SIMD).  All three
+    // give bit-identical results (128 / 155 / 148 us on 70 k rows).
+    const char* sel = getenv("MV2D_PE_TAB_KERNEL");
+    const int ksel = sel ? atoi(sel) : 96;
+    if (ksel != 64)
+        return mv2d_pe_fused_tab2(A1, Xfb, Xf32, row_index, m_dev, M, W1a, b1a, W1b, b1b, Wr, br, We, be, sine_tab, tab_period, pe, Xk,
+                                  ksel == 2 ? 0 : 1, stream);
     // the bias staging reads b2a / b2b too: point them at valid memory (b1a has 1024 floats, b1b 256)
     PeParams p{(const unsigned short*)A1, (const unsigned short*)A1, (const unsigned short*)Xfb, Xf32, row_index, m_dev, M,
                (const unsigned short*)W1a, b1a, (const unsigned short*)W1b, b1b, (const unsigned short*)W1a, b1a,

@@ -768,6 +768,37 @@ def test_pe_fused_bit_identical_to_gemm_chain(dev, M, use_mdev):
     assert torch.equal(xk[:Mv].view(torch.int16), xk_ref[:Mv].view(torch.int16))
 
 
+@pytest.mark.parametrize('M,use_mdev,use_ri', [(95, False, False), (97, False, True), (1000, True, True), (8794, True, False), (70349, False, True)])
+def test_pe_fused_tab_kernels_bit_identical(dev, M, use_mdev, use_ri, monkeypatch):
+    """mv2d_pe_fused_tab: the 96-row / 8-wave kernel (default) == its two-blocks-per-CU shape (MV2D_PE_TAB_KERNEL=2) == the
+    one-wave-per-SIMD kernel of pe_mlp.hip (=64), bit for bit."""
+    from mv2d_amd import ops
+    bf = torch.bfloat16
+    NP = M + 50 if use_ri else M
+    A1 = rnd((M, 192), 90).to(dev).to(bf)
+    Xf32 = rnd((NP, 256), 92).to(dev)
+    ri = torch.randperm(NP, generator=torch.Generator().manual_seed(5))[:M].to(torch.int32).to(dev) if use_ri else None
+    Xfb = (Xf32[ri.long()] if use_ri else Xf32).to(bf)
+    W = dict(w1a=rnd((1024, 192), 93, 0.08), w1b=rnd((256, 1024), 94, 0.04), wr=rnd((256, 256), 97, 0.07), we=rnd((256, 256), 98, 0.07))
+    wp = {k: ops.pack_wfrag(v.to(dev).to(bf)) for k, v in W.items()}
+    wp.update({k: rnd((n,), 99 + i).to(dev) for i, (k, n) in enumerate(dict(b1a=1024, b1b=256, br=256, be=256).items())})
+    period = 37
+    tab = rnd((period, 256), 131).to(dev)
+    md = torch.tensor([M - 13], dtype=torch.int32, device=dev) if use_mdev else None
+    outs = {}
+    for sel in ('64', '96', '2'):
+        monkeypatch.setenv('MV2D_PE_TAB_KERNEL', sel)
+        pe = torch.zeros((M, 256), device=dev); xk = torch.zeros((M, 256), device=dev, dtype=bf)
+        ops.pe_fused_tab(A1, Xfb, Xf32, md, wp, tab, period, pe, xk, M=M, row_index=ri)
+        torch.cuda.synchronize()
+        outs[sel] = (pe, xk)
+    Mv = M - 13 if use_mdev else M
+    for sel in ('96', '2'):
+        assert torch.equal(outs['64'][0][:Mv], outs[sel][0][:Mv])
+        assert torch.equal(outs['64'][1][:Mv].view(torch.int16), outs[sel][1][:Mv].view(torch.int16))
+        assert not outs[sel][0][Mv:].any() and outs[sel][0][:Mv].abs().sum() > 0
+
+
 def test_attn_out_fused_x3(dev):
     """split-precision (bf16x3) row-fused out_proj + LN (+ q proj): fp32-class accuracy against fp64."""
     from mv2d_amd import ops
