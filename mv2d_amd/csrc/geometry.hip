@@ -147,10 +147,14 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
                                                         unsigned short* __restrict__ out0, unsigned short* __restrict__ out1,
                                                         float* __restrict__ out0_f32, float* __restrict__ out1_f32, int H, int W,
                                                         float spatial_scale, int sampling_ratio, const int* __restrict__ map1_index,
-                                                        int out1_is_sum) {
-    // grid (R, 7): one block per RoI and bin row; wave w takes the bins w, w + 4 of the row, lane l the channels 4l .. 4l+3: every
-    // bilinear tap is one 16-byte load per lane (a full 1 KB row per wave), every output one 8-byte (bf16) / 16-byte (fp32) store
-    const int r = blockIdx.x, ph = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
+                                                        int out1_is_sum, int R) {
+    // one block per RoI and bin row; wave w takes the bins w, w + 4 of the row, lane l the channels 4l .. 4l+3: every
+    // bilinear tap is one 16-byte load per lane (a full 1 KB row per wave), every output one 8-byte (bf16) / 16-byte (fp32) store.
+    // XCD-aware block map (block b runs on XCD b % 8): the 7 bin rows of a RoI tap overlapping map rows, so they take consecutive slots
+    // of ONE XCD and share its L2 (a (R, 7) grid ran them R blocks apart).  Speed only; any map is correct.
+    const int slot = blockIdx.x >> 3, ph = slot % 7, r = (slot / 7) * 8 + (blockIdx.x & 7);
+    if (r >= R) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
     const float* b = rois + r * 5;
     const int v = (int)b[0];
     const float x1 = b[1] * spatial_scale - 0.5f, y1 = b[2] * spatial_scale - 0.5f;
@@ -908,8 +912,8 @@ extern "C" int mv2d_roi_align(const float* map0, const float* map1, const float*
     MV2D_CHECK_ARG(map0 && rois && channels == C, "mv2d_roi_align: needs 256-channel position-major maps");
     MV2D_CHECK_ARG(out0 || out0_f32, "mv2d_roi_align: no output");
     if (R == 0) return MV2D_OK;
-    hipLaunchKernelGGL(roi_align_kernel, dim3(R, 7), dim3(256), 0, (hipStream_t)stream, map0, map1, rois, (unsigned short*)out0,
-                       (unsigned short*)out1, out0_f32, out1_f32, H, W, spatial_scale, sampling_ratio, map1_index, out1_is_sum);
+    hipLaunchKernelGGL(roi_align_kernel, dim3(56 * cdiv(R, 8)), dim3(256), 0, (hipStream_t)stream, map0, map1, rois, (unsigned short*)out0,
+                       (unsigned short*)out1, out0_f32, out1_f32, H, W, spatial_scale, sampling_ratio, map1_index, out1_is_sum, R);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -29,20 +29,24 @@ __device__ __forceinline__ void sa_split4(const float4& v, uint2& hi, uint2& lo)
 
 template <bool DN>
 __global__ __launch_bounds__(256) void self_attn_x3_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int R, float scale,
-                                                           const int* __restrict__ grp_start, int dn_pad, int dn_single) {
+                                                           const int* __restrict__ grp_start, int dn_pad, int dn_single, int nx, int npair) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KC * 64 + 2 * HD * VPITCH];
     unsigned char* Kh = smem;                              // [KC][64 B]: 16-byte slot c of key k at slot c ^ ((k >> 2) & 3)
     unsigned char* Kl = smem + KC * 64;
     unsigned char* Vh = smem + 2 * KC * 64;                // [32 d][VPITCH]: key k of channel d at d * VPITCH + 2 k
     unsigned char* Vl = Vh + HD * VPITCH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
-    const int h = blockIdx.y;
+    // XCD-aware block map (block b runs on XCD b % 8, each XCD has its own L2): the nx query blocks of one (sample, head) pair read the
+    // same K / V slice, so pair p goes to XCD p % 8 and its query blocks to consecutive slots there.  Speed only; any map is correct.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, qb = slot % nx, pair = (slot / nx) * 8 + xcd;
+    if (pair >= npair) return;                             // (block-uniform; the pair count is padded to a multiple of 8)
+    const int h = pair & 7, grp = pair >> 3;
     if (grp_start) {
-        const int gs = grp_start[blockIdx.z], ge = grp_start[blockIdx.z + 1];
+        const int gs = grp_start[grp], ge = grp_start[grp + 1];
         qkv += (long long)gs * 768; ctx += (long long)gs * C; R = ge - gs;
     }
-    const int q0 = blockIdx.x * 64 + wave * 16;            // this wave's 16 queries (rows of the sample)
-    if (blockIdx.x * 64 >= R) return;                      // (block-uniform)
+    const int q0 = qb * 64 + wave * 16;                    // this wave's 16 queries (rows of the sample)
+    if (qb * 64 >= R) return;                              // (block-uniform)
     const bool wave_on = q0 < R;
     // B operand of S^T = K.Q^T: lane (query n, g): q[query][32 h + 8 g .. + 7] * scale, hi / lo
     SFrag qh, ql;
@@ -177,12 +181,13 @@ extern "C" int mv2d_self_attn_x3_fwd(const float* qkv, float* ctx, int R, const 
     MV2D_CHECK_ARG(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)ctx & 15) == 0, "mv2d_self_attn_x3_fwd: operands must be 16-byte aligned");
     if (R == 0) return MV2D_OK;
     const int rows = (grp_start && max_grp_rows > 0) ? min(max_grp_rows, R) : R;
-    const dim3 grid(cdiv(rows, 64), 8, grp_start ? n_grp : 1);
+    const int nx = cdiv(rows, 64), npair = 8 * (grp_start ? n_grp : 1);
+    const dim3 grid(nx * 8 * cdiv(npair, 8));
     const float scale = 1.0f / sqrtf((float)HD);
     if (dn_pad > 0)
-        hipLaunchKernelGGL(self_attn_x3_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, qkv, ctx, R, scale, grp_start, dn_pad, dn_single);
+        hipLaunchKernelGGL(self_attn_x3_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, qkv, ctx, R, scale, grp_start, dn_pad, dn_single, nx, npair);
     else
-        hipLaunchKernelGGL(self_attn_x3_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, qkv, ctx, R, scale, grp_start, 0, 1);
+        hipLaunchKernelGGL(self_attn_x3_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, qkv, ctx, R, scale, grp_start, 0, 1, nx, npair);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
