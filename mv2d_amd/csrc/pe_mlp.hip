@@ -400,7 +400,7 @@ extern "C" int mv2d_pe_fused_tab(const void* A1, const void* Xfb, const float* X
     if (M == 0) return MV2D_OK;
     // read per call (a host-side launch decision; graphs keep what they captured).  Default: pe_tab96.hip's kernel in its 96-row /
     // 8-wave shape; MV2D_PE_TAB_KERNEL=2: its two-64-row-blocks-per-CU shape; =64: this file's kernel (one wave per SIMD).  All three
-    // give bit-identical results (128 / 155 / 148 us on 70 k rows).
+    // give bit-identical results (110 / 134 / 145 us on 70 k rows).
     const char* sel = getenv("MV2D_PE_TAB_KERNEL");
     const int ksel = sel ? atoi(sel) : 96;
     if (ksel != 64)

@@ -33,6 +33,7 @@ enum { B_R = 0, B_E = 256, B_1A = 512, B_1B = 1536, B_FLOATS = 1792 };
 constexpr int OT_PITCH = 36;                                // floats per row of a wave's output tile [BM][32 columns]
 typedef __attribute__((ext_vector_type(8))) __bf16 pt_bf16x8;
 union PFrag { uint4 u; pt_bf16x8 v; };
+typedef unsigned int pt_u32x4 __attribute__((ext_vector_type(4)));   // staging registers (arrays of HIP's uint4 struct end up in scratch)
 
 struct PeTabParams {
     const unsigned short* A1; const unsigned short* Xfb; const float* Xf32; const int* row_index; const int* m_dev; int M;
@@ -172,11 +173,11 @@ __global__ __launch_bounds__(S::NTHR, 2) void pe_tab_kernel(PeTabParams p) {
                 bv[i] = *reinterpret_cast<const float4*>(src);
             }
         }
-        uint4 sa[NA];
+        pt_u32x4 sa[NA];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int c = tid + NTHR * i, row = c / 24, chunk = c - row * 24;
-            if (c < BM * 24) sa[i] = *reinterpret_cast<const uint4*>(p.A1 + (long long)min(m0 + row, M - 1) * 192 + chunk * 8);
+            if (c < BM * 24) sa[i] = *reinterpret_cast<const pt_u32x4*>(p.A1 + (long long)min(m0 + row, M - 1) * 192 + chunk * 8);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i)
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(S::NTHR, 2) void pe_tab_kernel(PeTabParams p) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int c = tid + NTHR * i, row = c / 24, chunk = c - row * 24;
-            if (c < BM * 24) *reinterpret_cast<uint4*>(As + row * PITCH + ((chunk ^ (row & 15)) << 4)) = sa[i];
+            if (c < BM * 24) *reinterpret_cast<pt_u32x4*>(As + row * PITCH + ((chunk ^ (row & 15)) << 4)) = sa[i];
         }
     }
     __syncthreads();
@@ -211,17 +212,17 @@ __global__ __launch_bounds__(S::NTHR, 2) void pe_tab_kernel(PeTabParams p) {
     {
         // the feature rows of the tile (256 channels = 32 chunks per row) travel while the last layer 2 runs
         constexpr int NX = BM * 32 / NTHR;
-        uint4 sa[NX];
+        pt_u32x4 sa[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int c = tid + NTHR * i, row = c >> 5, chunk = c & 31;
-            sa[i] = *reinterpret_cast<const uint4*>(p.Xfb + (long long)min(m0 + row, M - 1) * C + chunk * 8);
+            sa[i] = *reinterpret_cast<const pt_u32x4*>(p.Xfb + (long long)min(m0 + row, M - 1) * C + chunk * 8);
         }
         steps<S, first_of(3) + 6, 8>(accf, wq, a, w, Hs1, fr, fg);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int c = tid + NTHR * i, row = c >> 5, chunk = c & 31;
-            *reinterpret_cast<uint4*>(As + row * PITCH + ((chunk ^ (row & 15)) << 4)) = sa[i];
+            *reinterpret_cast<pt_u32x4*>(As + row * PITCH + ((chunk ^ (row & 15)) << 4)) = sa[i];
         }
     }
     PE_STAMP(9);

@@ -15,7 +15,7 @@ pe = torch.empty((M, 256), device=dev); xk = torch.empty((M, 256), device=dev, d
 lib = ctypes.CDLL(sys.argv[1])
 P = ctypes.c_void_p
 p = lambda t: P(t.data_ptr())
-for ex, shape in (('0', 0), ('3', 0), ('0', 1)):
+for ex, shape in (('0', 1),):
     os.environ['MV2D_PE_EXP'] = ex
     for _ in range(3):
         rc = lib.mv2d_pe_fused_tab2(p(A1), p(Xfb), p(Xf32), None, None, M, p(wp['w1a']), p(wp['b1a']), p(wp['w1b']), p(wp['b1b']), p(wp['wr']), p(wp['br']),
