@@ -60,7 +60,8 @@ def stage_bytes(kind, R, S, L=6):
     }
 
 
-STAGE_KERNEL = {'pe_fused': 'pe_fused_kernel (3 two-layer MLPs + gate + sum)', 'kv_gemm': 'kvproj_kernel', 'qg_conv_gemm': 'roi_conv_pool_kernel (conv3x3 + ReLU + avgpool fused)'}
+STAGE_KERNEL = {'pe_fused': 'pe_tab_kernel (frustum MLP + gate, sine branch from the table)' if SINE_TABLE else 'pe_fused_kernel (3 two-layer MLPs + gate + sum)',
+                'kv_gemm': 'kvproj_kernel (MV2D_XATTN=sparse route only)', 'qg_conv_gemm': 'roi_conv_pool_kernel (conv3x3 + ReLU + avgpool fused)'}
 
 
 def main():
@@ -292,36 +293,30 @@ def main():
     for a, b in zip(names[:-1], names[1:]):
         stage_ms[a] = statistics.median(x.elapsed_time(y) for x, y in zip(prof[a], prof[b]))
     fl, by = stage_flops(kind, R, S), stage_bytes(kind, R, S)
-    dom = max(fl, key=lambda k: stage_ms.get(k, 0.0))
-    dom_ms = stage_ms[dom]
-    tflops = fl[dom] / (dom_ms * 1e-3) / 1e12
-    gbs = by[dom] / (dom_ms * 1e-3) / 1e9
-    # HBM traffic of that launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected offline with
-    # tools/rocpd_pmc.py and committed under profiles/): counters cannot be read from inside this process
-    traffic, traffic_detail = None, None
+    if getattr(eng, 'tile_attn', False):                 # the K / V projection GEMM only exists on the MV2D_XATTN=sparse route
+        fl.pop('kv_gemm'); by.pop('kv_gemm')
     try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-        t = pmc.get(f'{args.workload}@{B}', {}).get(dom)              # counters of a launch with the same number of samples
-        if t:
-            traffic = t['fetch_bytes'] + t['write_bytes']            # HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)
-            traffic_detail = {'fetch_bytes': t['fetch_bytes'], 'write_bytes': t['write_bytes'],
-                              'source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'}
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get(f'{args.workload}@{B}', {})
     except Exception:
-        pass
-    # the roofline that binds this launch is the one it sits closer to
-    f_mfma, f_hbm = tflops / PEAK_BF16_TFLOPS, gbs / PEAK_HBM_GBS
-    kname = f"{STAGE_KERNEL.get(dom, 'gemm_bf16_kernel')}[{dom}]"
-    if f_hbm > f_mfma:
-        roofline = dict(bound='hbm', kernel=kname, achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(f_hbm, 4),
-                        traffic=traffic, launch_ms=round(dom_ms, 4), bytes_per_launch=by[dom], flops_per_launch=fl[dom],
-                        mfma_frac=round(f_mfma, 4))
-    else:
-        roofline = dict(bound='mfma', kernel=kname, achieved=round(tflops, 2), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
-                        frac=round(f_mfma, 4), traffic=traffic, launch_ms=round(dom_ms, 4), flops_per_launch=fl[dom],
-                        bytes_per_launch=by[dom], hbm_frac=round(f_hbm, 4))
-    roofline['traffic_detail'] = traffic_detail
-    stage_roofline = {k: dict(ms=round(stage_ms[k], 4), tflops=round(fl[k] / (stage_ms[k] * 1e-3) / 1e12, 1),
-                              gbs=round(by[k] / (stage_ms[k] * 1e-3) / 1e9, 1)) for k in fl if k in stage_ms}
+        pmc = {}
+
+    def roof(name, kernel, ms, flops, nbytes, launches=1):
+        """roofline object of one kernel: achieved = algorithmic flops / bytes of ONE launch over its duration (HIP events on the launch
+        stream); traffic = HBM bytes of one launch from the PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, profiles/pmc_traffic.json)."""
+        tf, gb = flops / (ms * 1e-3) / 1e12, nbytes / (ms * 1e-3) / 1e9
+        f_mfma, f_hbm = tf / PEAK_BF16_TFLOPS, gb / PEAK_HBM_GBS
+        t = pmc.get(name)
+        o = dict(bound='hbm' if f_hbm > f_mfma else 'mfma', kernel=kernel, launch_ms=round(ms, 4), launches_per_step=launches,
+                 bytes_per_launch=int(nbytes), flops_per_launch=float(flops))
+        if f_hbm > f_mfma:
+            o.update(achieved=round(gb, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(f_hbm, 4), mfma_frac=round(f_mfma, 4))
+        else:
+            o.update(achieved=round(tf, 2), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s', frac=round(f_mfma, 4), hbm_frac=round(f_hbm, 4))
+        o['traffic'] = (t['fetch_bytes'] + t['write_bytes']) if t else None
+        o['traffic_detail'] = dict(t, source='profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)') if t else None
+        return o
+
+    stage_roofline = {k: roof(k, f"{STAGE_KERNEL.get(k, 'gemm_bf16_kernel')}[{k}]", stage_ms[k], fl[k], by[k]) for k in fl if k in stage_ms}
 
     # ---------------- decoder ms/iter (CrossAttentionBoxHead transformer on prepared inputs), hipGraph replay
     g = torch.cuda.CUDAGraph()
@@ -355,9 +350,13 @@ def main():
         x_ms = e0.elapsed_time(e1) / 20
         x_bytes = nnz * 2 * 256 * 2 + R * (16 * 256 * 2 + 8 * 256 * 4)          # K and V rows of every allowed pair (bf16) + Qt in + z out
         x_flops = 2.0 * nnz * 8 * 256 * 2                                          # logits + P.V in the 256-dim input space, 8 heads
-        xattn = dict(kernel='xattn_tile_kernel', ms=round(x_ms, 4), bytes_per_launch=x_bytes, gbs=round(x_bytes / (x_ms * 1e-3) / 1e9, 1),
-                     hbm_frac=round(x_bytes / (x_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), tflops=round(x_flops / (x_ms * 1e-3) / 1e12, 2),
-                     note='bytes = rows gathered per allowed (query, key) pair; keys shared by several queries are served by L2 / Infinity Cache')
+        xattn = roof('xattn_tile', 'xattn_tile_kernel (sparse cross-attention in the raw key space, one launch per decoder layer)', x_ms, x_flops, x_bytes,
+                     launches=eng.L)
+        xattn['note'] = 'bytes = K and V rows gathered per allowed (query, key) pair + Qt in + z out; keys shared by several queries are served by L2 / Infinity Cache'
+        stage_roofline['xattn_tile'] = xattn
+    # the dominant kernel = the one with the most time per step (launch duration x launches per step)
+    dom = max(stage_roofline, key=lambda k: stage_roofline[k]['launch_ms'] * stage_roofline[k]['launches_per_step'])
+    roofline = stage_roofline[dom]
 
     # ---------------- CPU baseline: the oracle (port of the reference algorithm) on the host cores, bounded sample
     cpu, cpu2 = None, None
@@ -393,7 +392,7 @@ def main():
                        'parallelism': f'dp{world}', 'hipgraph': use_graph},
             'decoder_ms_per_iter': round(decoder_ms / B, 4), 'decoder_ms_per_launch': round(decoder_ms, 4),
             'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},
-            'roofline': roofline, 'stage_roofline': stage_roofline, 'xattn_tile': xattn,
+            'roofline': roofline, 'stage_roofline': stage_roofline,
             'cpu_baseline': cpu, 'cpu_baseline_all_cores': cpu2,
             **extra,
         }
