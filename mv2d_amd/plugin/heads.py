@@ -4,7 +4,9 @@
 ``simple_test(x, proposal_list, img_metas, rescale=False)`` keeps the reference signature and return value
 (``[[boxes, scores, labels]]``) and runs the fused HIP engine (mv2d_amd.engine.HeadEngine), which is built lazily
 from the module's own ``state_dict`` — so a checkpoint loaded with the reference key layout is what runs.
-``forward_train`` keeps the reference signature too but is forward only so far (losses without parameter gradients).
+``forward_train`` keeps the reference signature and loss dict; with gradients enabled it runs the autograd route (HIP attention / RoIAlign /
+loss kernels under torch autograd for the dense part) and fills the gradients of every parameter of the head and of the feature map
+(DESIGN.md 7.1).
 """
 import copy
 
@@ -118,8 +120,44 @@ class CrossAttentionBoxHead(nn.Module):
             ret.append([bboxes, p['scores'], p['labels']])
         return ret
 
-    def loss(self, *a, **k):
-        raise NotImplementedError('training losses are outside the hot-path scope (SURVEY.md §8 f3)')
+    def _hip_loss(self, device):
+        # the HIP loss kernels behind the reference's per-layer interface: no stage weights here, the RoI head applies them (mv2d_s_head.py:292-302)
+        from ..train import HeadLoss
+        key = (str(device), self.code_weights.data_ptr(), self.code_weights._version)
+        if getattr(self, '_hl_key', None) != key:
+            lc = dict(self.loss_cls.cfg, type=getattr(self.loss_cls, 'type', 'FocalLoss'), use_sigmoid=self.loss_cls.use_sigmoid)
+            lb = dict(self.loss_bbox.cfg, type=getattr(self.loss_bbox, 'type', 'L1Loss'))
+            tc = dict(assigner=(self.train_cfg or {}).get('assigner')) if self.train_cfg else None
+            self._hl = HeadLoss(num_classes=self.num_classes, loss_cls=lc, loss_bbox=lb, code_weights=[float(x) for x in self.code_weights],
+                                train_cfg=tc, device=device)
+            self._hl_key = key
+        return self._hl
+
+    def loss(self, gt_bboxes_3d_list, gt_labels_3d_list, preds_dicts, cls_reg_targets=None, gt_bboxes_ignore=None):
+        """cross_attention_head.py:436-463: Hungarian assignment + sigmoid focal loss + code-weighted L1 of ONE decoder layer
+        (``preds_dicts['cls_scores']`` [1,R,C], ``['bbox_preds']`` [1,R,10]) -> ``dict(loss_cls, loss_bbox)``, both differentiable, through
+        mv2d_match_cost / scipy / mv2d_set_loss (train.HeadLoss).  One sample per call like the RoI head (mv2d_head.py:251);
+        precomputed ``cls_reg_targets`` are not supported (the reference's RoI heads never pass them)."""
+        assert gt_bboxes_ignore is None, f'{self.__class__.__name__} only supports for gt_bboxes_ignore setting to None.'
+        if cls_reg_targets is not None:
+            raise NotImplementedError('CrossAttentionBoxHead.loss: precomputed cls_reg_targets')
+        cls_scores, bbox_preds = preds_dicts['cls_scores'], preds_dicts['bbox_preds']
+        assert cls_scores.shape[0] == 1 and len(gt_bboxes_3d_list) == 1, 'one sample per call'
+        dev = cls_scores.device
+        g = gt_bboxes_3d_list[0]
+        gt = g if torch.is_tensor(g) else torch.cat((g.gravity_center, g.tensor[:, 3:]), dim=1)
+        losses, _, _ = self._hip_loss(dev).loss(cls_scores.float().contiguous(), bbox_preds.float().contiguous(),
+                                               gt.to(dev, torch.float32).contiguous(), gt_labels_3d_list[0].to(dev))
+        return dict(loss_cls=losses['l0.loss_cls'], loss_bbox=losses['l0.loss_bbox'])
+
+    def dn_loss_single(self, cls_scores, bbox_preds, known_bboxs, known_labels, num_total_pos, pc_range=None, split=0.75, neg_bbox_loss=False):
+        """cross_attention_head.py:476-538 for one layer: outputs of the denoising queries [N,C] / [N,10] (or with a leading 1) against their
+        targets -> (dn_loss_cls, dn_loss_bbox) (the reference's return order, weighted by its ``dn_weight`` = 1)."""
+        dev = cls_scores.device
+        c = cls_scores.reshape(1, -1, cls_scores.shape[-1]).float().contiguous()
+        b = bbox_preds.reshape(1, -1, bbox_preds.shape[-1]).float().contiguous()
+        losses, _ = self._hip_loss(dev).dn_loss(c, b, known_bboxs, known_labels, num_total_pos, split, neg_bbox_loss=neg_bbox_loss)
+        return losses['l0.dn_loss_cls'], losses['l0.dn_loss_bbox']
 
 
 @HEADS.register_module()

@@ -92,6 +92,30 @@ def test_head_loss_matches_reference_and_autograd(name):
         assert float((g.cpu() - w).abs().max()) <= 1e-5 * max(float(w.abs().max()), 1e-6), name
 
 
+@pytest.mark.parametrize('name', ['small', 'mid'])
+def test_bbox_head_loss_interface_matches_reference(name):
+    """CrossAttentionBoxHead.loss / dn_loss_single (the reference's per-layer interface, cross_attention_head.py:436-463, 476-538) against the
+    reference's own values in the golden (layer by layer, unit stage weight) and with gradients flowing."""
+    c, d = _case(name)
+    gold = load_golden('train_loss')
+    from mv2d_amd import registry
+    head = registry.build_head(configs.roi_head_cfg_s(), train_cfg=configs.TRAIN_CFG_RCNN, test_cfg=configs.TEST_CFG_RCNN).to(DEV)
+    bh = head.bbox_head
+    L = d['cls'].shape[0]
+    for l in range(L):
+        cls = d['cls'][l:l + 1].clone().requires_grad_(True)
+        box = d['box'][l:l + 1].clone().requires_grad_(True)
+        out = bh.loss([d['gt']], [d['gt_labels']], dict(cls_scores=cls, bbox_preds=box))
+        got = np.array([float(out['loss_cls']), float(out['loss_bbox'])])
+        np.testing.assert_allclose(got, gold[name + '.loss'][l], rtol=1e-5, atol=1e-7)
+        (out['loss_cls'] + out['loss_bbox']).backward()
+        assert float(cls.grad.abs().sum()) > 0 and float(box.grad.abs().sum()) > 0
+    n = c['known_labels'].shape[0]
+    lc, lb = bh.dn_loss_single(d['cls'][0, :n].contiguous(), d['box'][0, :n].contiguous(), d['known_bboxs'], d['known_labels'], c['dn_num_tgt'],
+                               split=0.6)
+    np.testing.assert_allclose(np.array([float(lc), float(lb)]), gold[name + '.dn'][0], rtol=1e-5, atol=1e-7)
+
+
 @pytest.mark.parametrize('neg', [False, True])
 @pytest.mark.parametrize('name', ['small', 'mid', 'few_queries'])
 def test_dn_loss_matches_reference_and_autograd(name, neg):
