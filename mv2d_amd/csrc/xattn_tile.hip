@@ -354,11 +354,8 @@ __global__ __launch_bounds__(64 * NW, XLO ? 1 : 2) void xattn_tile_kernel(const 
     // ---- merge the waves: thread -> (channel, half of the heads)
     {
         const float* sz = reinterpret_cast<const float*>(smem);
-        constexpr int HPT = HEADS * C / (64 * NW);                                   // heads per thread
-        const int c = tid & (C - 1), h0 = (tid >> 8) * HPT;
-#pragma unroll
-        for (int hh = 0; hh < HPT; ++hh) {
-            const int h = h0 + hh;
+        for (int idx = tid; idx < HEADS * C; idx += 64 * NW) {
+            const int h = idx >> 8, c = idx & (C - 1);
             float M = sst[h];
 #pragma unroll
             for (int w = 1; w < NW; ++w) M = fmaxf(M, sst[w * 8 + h]);
@@ -404,16 +401,16 @@ extern "C" int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* X
     MV2D_CHECK_ARG((Xk_lo == nullptr) == (Xv_lo == nullptr), "mv2d_xattn_tile_fwd: Xk_lo and Xv_lo come together");
     MV2D_CHECK_ARG(((uintptr_t)Qt & 15) == 0 && ((uintptr_t)Xk & 15) == 0 && ((uintptr_t)Xv & 15) == 0 && ((uintptr_t)z & 15) == 0 &&
                        ((uintptr_t)Xk_lo & 15) == 0 && ((uintptr_t)Xv_lo & 15) == 0, "mv2d_xattn_tile_fwd: operands must be 16-byte aligned");
-    MV2D_CHECK_ARG(waves == 0 || waves == 4 || waves == 8, "mv2d_xattn_tile_fwd: waves per query must be 4 or 8 (0: default)");
+    MV2D_CHECK_ARG(waves == 0 || waves == 1 || waves == 2 || waves == 4 || waves == 8, "mv2d_xattn_tile_fwd: waves per query must be 1, 2, 4 or 8 (0: default)");
     if (R == 0) return MV2D_OK;
     static const int env_nw = getenv("MV2D_XATTN_NW") ? atoi(getenv("MV2D_XATTN_NW")) : 0;       // experiment switch
-    const int nw = waves ? waves : (env_nw == 8 ? 8 : 4);      // 4: best of {4, 8} on both paths (cfg2_s 41 vs 74 us, cfg3_t 73 vs 104 us per layer)
+    const int nw = env_nw ? env_nw : (waves ? waves : 2);      // the engine passes its own choice (2: see engine.py)
 #define MV2D_XT(NW, DBG, XLO) hipLaunchKernelGGL((xattn_tile_kernel<NW, DBG, XLO>), dim3(R), dim3(64 * NW), 0, (hipStream_t)stream, (const uint4*)Qt, \
                                                  (const unsigned short*)Xk, (const unsigned short*)Xv, (const unsigned short*)Xk_lo, (const unsigned short*)Xv_lo, \
                                                  row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan)
     if (Xk_lo) { if (dbg_logits) MV2D_XT(4, true, true); else MV2D_XT(4, false, true); }            // validation mode: 4 waves only
-    else if (dbg_logits) { if (nw == 8) MV2D_XT(8, true, false); else MV2D_XT(4, true, false); }
-    else { if (nw == 8) MV2D_XT(8, false, false); else MV2D_XT(4, false, false); }
+    else if (dbg_logits) { if (nw == 8) MV2D_XT(8, true, false); else if (nw == 2) MV2D_XT(2, true, false); else if (nw == 1) MV2D_XT(1, true, false); else MV2D_XT(4, true, false); }
+    else { if (nw == 8) MV2D_XT(8, false, false); else if (nw == 2) MV2D_XT(2, false, false); else if (nw == 1) MV2D_XT(1, false, false); else MV2D_XT(4, false, false); }
 #undef MV2D_XT
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;

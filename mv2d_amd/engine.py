@@ -103,7 +103,10 @@ class HeadEngine:
         # through ONE CU per 32 rows, and the fused ones stream twice as much on 75 blocks while the separate map kernels spread over 150
         self.fuse_maps = os.environ.get('MV2D_XATTN_FUSE_MAPS', '0') == '1'
         nw = os.environ.get('MV2D_XATTN_NW')
-        self.xattn_waves = int(nw) if nw else 4                             # waves per query (8 measured slower on both paths)
+        # waves per query: the kernel alone takes the same 32-33 us per layer with 1, 2 or 4 (it moves its 161 MB at ~5 TB/s either way), but a
+        # launch with fewer waves leaves more of the chip to the other streams' kernels: cfg2_s 8067 / 8043 / 7869 samples/s for 1 / 2 / 4,
+        # cfg3_t (rows of ~200 keys) 5803 / 5868 / 5758; 8 is slower everywhere
+        self.xattn_waves = int(nw) if nw else 2
         self.qg_x3 = os.environ.get('MV2D_QG_X3', '1') == '1'          # query-generator fcs + first in_proj as LDS-tiled bf16x3 linears (0: exact fp32)
         self.heads_x3 = os.environ.get('MV2D_HEADS_X3', '1') == '1'    # prediction branches in bf16x3 (0: exact fp32)
         # INDEX-EXACT VALIDATION MODE (exact=True / MV2D_EXACT=1): every bf16 rounding of the default path is replaced by fp32-class

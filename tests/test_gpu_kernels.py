@@ -429,7 +429,8 @@ def _unpack_qt(Qt, R):
     return t[:, :, :, :, 0].reshape(R, 8, 256), t[:, :, :, :, 1].reshape(R, 8, 256)
 
 
-@pytest.mark.parametrize('R,S,dens,waves', [(37, 500, 0.05, 4), (301, 5000, 0.02, 8), (64, 49 * 64, -1.0, 4), (20, 2000, 0.3, 4), (20, 2000, 0.3, 8)])
+@pytest.mark.parametrize('R,S,dens,waves', [(37, 500, 0.05, 4), (37, 500, 0.05, 1), (301, 5000, 0.02, 8), (301, 5000, 0.02, 2), (64, 49 * 64, -1.0, 2),
+                                            (20, 2000, 0.3, 4), (20, 2000, 0.3, 8), (20, 2000, 0.3, 1)])
 def test_xattn_tile_equals_projected_attention(dev, R, S, dens, waves):
     """The default cross-attention route (csrc/xattn_tile.hip): query map -> MFMA tile attention on the UNPROJECTED rows -> context map
     == masked attention on K = Xk Wk^T + bk, V = Xv Wv^T + bv in fp64 (PETRMultiheadAttention's in_proj + core, MU/petr_transformer.py:487-513).
