@@ -12,6 +12,7 @@
 // writes [R, 256] fp32: the 15 MB conv output and the avgpool launch disappear.
 // k order = (tap, channel) like the implicit GEMM, so the conv sums are bit-identical; only the 49-term pooling sum is
 // re-associated (fp32, ~1e-7).
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -19,49 +20,60 @@ namespace {
 constexpr int C = 256, CELLS = 49, KT = 9 * C;
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 union Frag { uint4 u; mfma_bf16x8 v; };
+typedef unsigned int cv_u32x4 __attribute__((ext_vector_type(4)));
 
+// NR RoIs per block: with NR = 2 the wave's weight fragments feed 8 instead of 4 row tiles (the kernel is bound by streaming the
+// 1.18 MB of conv weights through L2 / L1 once per block: 2.8 GB per 2400 RoIs at NR = 1).  Every RoI keeps its own four row tiles
+// (rows 64 rl .. 64 rl + 48 of the block), so the arithmetic per RoI — and the result, bit for bit — does not depend on NR or on which
+// RoI it is paired with.
+template <int NR>
 __global__ __launch_bounds__(256, 2) void roi_conv_pool_kernel(const unsigned short* __restrict__ feat, const unsigned short* __restrict__ W,
                                                                const float* __restrict__ bias, float* __restrict__ out, int ld_out, int R) {
-    __shared__ __attribute__((aligned(16))) unsigned char xs[(CELLS + 1) * C * 2];       // rows 0..48 + a zero row (49)
+    // LDS rows: RoI rl at rows RS rl .. RS rl + 48, its zero row at RS rl + 49 (RS = 64 for NR = 2: a multiple of 16, so the chunk
+    // swizzle and with it every fragment address of RoI 1 is that of RoI 0 plus a constant -> an instruction offset, no registers)
+    constexpr int RS = NR == 1 ? CELLS + 1 : 64, NROWS = RS * (NR - 1) + CELLS + 1, RING = NR == 1 ? 4 : 3, RT = 4 * NR;
+    __shared__ __attribute__((aligned(16))) unsigned char xs[NROWS * C * 2];
     __shared__ float bs[C];
-    const int roi = blockIdx.x;
+    const int roi0 = blockIdx.x * NR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-    // ---- weight fragments of this wave's 64 output columns, 4-deep ring over the 72 k-steps (requested first: in flight while the RoI is staged)
+    // ---- weight fragments of this wave's 64 output columns, register ring over the 72 k-steps (requested first: in flight while the RoIs are staged)
     // fragment-major weights: fragment (k-step ks, column tile jt) = 64 lanes x 16 B at ((ks * 16 + jt) * 64 + lane) * 8
     const unsigned short* w_src = W + ((long long)(wave * 4) * 64 + lane) * 8;
     constexpr int KS_STRIDE = 16 * 64 * 8, JT_STRIDE = 64 * 8;
-    Frag wq[4][4];
+    Frag wq[RING][4];
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < RING - 1; ++p)
 #pragma unroll
         for (int j = 0; j < 4; ++j) wq[p][j].u = *reinterpret_cast<const uint4*>(w_src + p * KS_STRIDE + j * JT_STRIDE);
-    // ---- stage the RoI: 16-byte chunks, chunk c of row r at slot c ^ (r & 15).  All loads of a thread are issued before the first
+    // ---- stage the RoIs: 16-byte chunks, chunk c of row r at slot c ^ (r & 15).  All loads of a thread are issued before the first
     // LDS write (a rolled loop is one exposed memory round trip per iteration: 7 of them were a fifth of the block's time).
     {
-        constexpr int NST = ((CELLS + 1) * 32 + 255) / 256;
-        uint4 st[NST];
+        constexpr int NST = (NROWS * 32 + 255) / 256;
+        cv_u32x4 st[NST];
         float bv = 0.f;
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int c = tid + 256 * i, row = c >> 5, slot = c & 31;
-            st[i] = *reinterpret_cast<const uint4*>(feat + ((long long)roi * CELLS + min(row, CELLS - 1)) * C + slot * 8);   // branch-free
-            if (row >= CELLS) st[i] = make_uint4(0u, 0u, 0u, 0u);
+            const int rl = min(row / RS, NR - 1), cell = min(row - rl * RS, CELLS - 1);
+            const bool ok = row - rl * RS < CELLS && roi0 + rl < R;
+            st[i] = *reinterpret_cast<const cv_u32x4*>(feat + ((long long)min(roi0 + rl, R - 1) * CELLS + cell) * C + slot * 8);   // branch-free
+            if (!ok) st[i] = cv_u32x4{0u, 0u, 0u, 0u};
         }
         bv = bias[tid];
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int c = tid + 256 * i, row = c >> 5, slot = c & 31;
-            if (row <= CELLS) *reinterpret_cast<uint4*>(xs + row * (C * 2) + ((slot ^ (row & 15)) << 4)) = st[i];
+            if (row < NROWS) *reinterpret_cast<cv_u32x4*>(xs + row * (C * 2) + ((slot ^ (row & 15)) << 4)) = st[i];
         }
         bs[tid] = bv;                                    // the bias waits in LDS: a global load in the epilogue is another round trip
     }
-    // cell coordinates of the 4 row tiles of this lane (row = 16 i + fr)
+    // cell coordinates of the 4 row tiles of a RoI for this lane (cell = 16 i + fr)
     int cy[4], cx[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int r = 16 * i + fr; cy[i] = r / 7; cx[i] = r - cy[i] * 7; }
-    f32x4_t acc[4][4];
+    f32x4_t acc[RT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
@@ -70,39 +82,46 @@ __global__ __launch_bounds__(256, 2) void roi_conv_pool_kernel(const unsigned sh
     for (int ks = 0; ks < 72; ++ks) {
         const int tap = ks >> 3, s = ks & 7;
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        if (ks + 3 < 72) {
+        if (ks + RING - 1 < 72) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wq[(ks + 3) & 3][j].u = *reinterpret_cast<const uint4*>(w_src + (ks + 3) * KS_STRIDE + j * JT_STRIDE);
+            for (int j = 0; j < 4; ++j) wq[(ks + RING - 1) % RING][j].u = *reinterpret_cast<const uint4*>(w_src + (ks + RING - 1) * KS_STRIDE + j * JT_STRIDE);
         }
-        __builtin_amdgcn_sched_barrier(0);           // keep the prefetch 3 steps ahead (hipcc otherwise sinks the loads to their use)
-        Frag a[4];
+        __builtin_amdgcn_sched_barrier(0);           // keep the prefetch ahead (hipcc otherwise sinks the loads to their use)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int y = cy[i] + dy, x = cx[i] + dx;
-            const bool ok = (16 * i + fr) < CELLS && y >= 0 && y < 7 && x >= 0 && x < 7;
-            const int src = ok ? y * 7 + x : CELLS;
-            a[i].u = *reinterpret_cast<const uint4*>(xs + src * (C * 2) + (((4 * s + fg) ^ (src & 15)) << 4));
+        for (int rl = 0; rl < NR; ++rl) {               // one RoI's four row tiles at a time: 4 fragment registers, not 4 NR
+            Frag a[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int y = cy[it] + dy, x = cx[it] + dx;
+                const bool ok = (16 * it + fr) < CELLS && y >= 0 && y < 7 && x >= 0 && x < 7;
+                const int src = ok ? y * 7 + x : CELLS;
+                a[it].u = *reinterpret_cast<const uint4*>(xs + rl * (RS * C * 2) + src * (C * 2) + (((4 * s + fg) ^ (src & 15)) << 4));
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[4 * rl + it][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[it].v, wq[ks % RING][j].v, acc[4 * rl + it][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, wq[ks & 3][j].v, acc[i][j], 0, 0, 0);
     }
-    // ---- bias + ReLU + mean over the 49 cells: lane holds rows 16 i + 4 fg + r of column 64 wave + 16 j + fr
+    // ---- bias + ReLU + mean over the 49 cells: lane holds cells 16 i + 4 fg + r of column 64 wave + 16 j + fr
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = wave * 64 + 16 * j + fr;
-        const float b = bs[n];
-        float sum = 0.f;
+    for (int rl = 0; rl < NR; ++rl) {
+        if (roi0 + rl >= R) break;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            const int n = wave * 64 + 16 * j + fr;
+            const float b = bs[n];
+            float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (16 * i + 4 * fg + r < CELLS) sum += relu_f(acc[i][j][r] + b);
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        if (fg == 0) out[(long long)roi * ld_out + n] = sum / 49.0f;
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * i + 4 * fg + r < CELLS) sum += relu_f(acc[4 * rl + i][j][r] + b);
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            if (fg == 0) out[(long long)(roi0 + rl) * ld_out + n] = sum / 49.0f;
+        }
     }
 }
 
@@ -133,8 +152,15 @@ extern "C" int mv2d_qg_conv_pool(const void* roi_feat, const void* W, const floa
     MV2D_CHECK_ARG(roi_feat && W && bias && out && ld_out >= C, "mv2d_qg_conv_pool: bad args");
     MV2D_CHECK_ARG(((uintptr_t)roi_feat & 15) == 0 && ((uintptr_t)W & 15) == 0, "mv2d_qg_conv_pool: operands must be 16-byte aligned");
     if (R == 0) return MV2D_OK;
-    hipLaunchKernelGGL(roi_conv_pool_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)roi_feat,
-                       (const unsigned short*)W, bias, out, ld_out, R);
+    // two RoIs per block once the grid fills the chip either way (identical results, see the kernel); MV2D_QG_CONV_NR=1|2 forces a shape
+    static const int env_nr = getenv("MV2D_QG_CONV_NR") ? atoi(getenv("MV2D_QG_CONV_NR")) : 0;
+    const int nr = env_nr ? env_nr : (R >= 1024 ? 2 : 1);
+    if (nr == 2)
+        hipLaunchKernelGGL(roi_conv_pool_kernel<2>, dim3(cdiv(R, 2)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)roi_feat,
+                           (const unsigned short*)W, bias, out, ld_out, R);
+    else
+        hipLaunchKernelGGL(roi_conv_pool_kernel<1>, dim3(R), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)roi_feat,
+                           (const unsigned short*)W, bias, out, ld_out, R);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
