@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void ffn_x3_kernel(const float* __restrict_
     // 32 x 64 tile goes through its quarter of the X images (free since the barrier before the last phase 2) and is stored row-major,
     // 4 rows x 256 contiguous bytes per instruction.
     float4* ot = reinterpret_cast<float4*>(wave < 2 ? xh : xl) + (wave & 1) * (BR * 16);          // 8 KB per wave (RTB = 2)
-    static_assert(RTB == 2, "output staging assumes 32 rows per block");
+    static_assert(RTB >= 1 && RTB <= 4, "output staging: a wave's BR x 64 tile in its quarter of the X images");
 #pragma unroll
     for (int r = 0; r < RTB; ++r)
 #pragma unroll
