@@ -482,21 +482,59 @@ __global__ __launch_bounds__(256) void csr_count_kernel(const int* __restrict__ 
                                                         unsigned int* __restrict__ bits, int* __restrict__ row_count, int h, int w, int V, int topk, int nwords) {
     extern __shared__ unsigned int sb[];
     __shared__ int cnt;
-    const int r = blockIdx.x, tid = threadIdx.x;
+    __shared__ int rfirst[256], rnw[256];         // per listed rect: its first cell, cells per row
+    __shared__ int rstart[257];                   // items before rect j of the chunk (an item = one cell of one rect)
+    __shared__ int wtot[4];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int w0 = (int)(((long long)(rect[r * 5] / V) * V * h * w) >> 5);
     for (int i = tid; i < nwords; i += 256) sb[i] = 0u;
     if (tid == 0) cnt = 0;
-    __syncthreads();
     const int nm = 1 + V * topk;
-    for (int j = 0; j < nm; ++j) {
-        const int m = (j == 0) ? r : match[(long long)r * V * topk + (j - 1)];
-        if (m < 0) continue;
-        const int v = rect[m * 5], y0 = rect[m * 5 + 1], y1 = rect[m * 5 + 2], x0 = rect[m * 5 + 3], x1 = rect[m * 5 + 4];
-        if (y1 < y0 || x1 < x0) continue;
-        const int nw = x1 - x0 + 1, n = (y1 - y0 + 1) * nw;
-        for (int i = tid; i < n; i += 256) {
-            const int pos = (v * h + y0 + i / nw) * w + x0 + i % nw;
-            if (pos2s[pos] >= 0) atomicOr(&sb[(pos >> 5) - w0], 1u << (pos & 31));
+    // The T path lists 1 + 12 * 20 candidates per query, nearly all of them -1: a loop over them is 241 dependent match -> rect -> key-list
+    // round trips (67 us per launch).  Here the candidates are fetched 256 at a time, one per thread, their sizes scanned, and the cells of
+    // all listed rects are walked as one flat item list with the key-list reads of a pass in flight together.
+    for (int base = 0; base < nm; base += 256) {
+        int n = 0, first = 0, nw = 1;
+        const int j = base + tid;
+        if (j < nm) {
+            const int m = (j == 0) ? r : match[(long long)r * V * topk + (j - 1)];
+            if (m >= 0) {
+                const int v = rect[m * 5], y0 = rect[m * 5 + 1], y1 = rect[m * 5 + 2], x0 = rect[m * 5 + 3], x1 = rect[m * 5 + 4];
+                if (y1 >= y0 && x1 >= x0) { nw = x1 - x0 + 1; n = (y1 - y0 + 1) * nw; first = (v * h + y0) * w + x0; }
+            }
+        }
+        int s_ = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(s_, o, 64); if (lane >= o) s_ += t; }
+        __syncthreads();                             // (the previous chunk's readers of rstart / rfirst are done; sb is zeroed)
+        if (lane == 63) wtot[wv] = s_;
+        __syncthreads();
+        int off = 0;
+        for (int q = 0; q < wv; ++q) off += wtot[q];
+        rfirst[tid] = first; rnw[tid] = nw;
+        rstart[tid + 1] = off + s_;
+        if (tid == 0) rstart[0] = 0;
+        __syncthreads();
+        const int total = rstart[256];
+        for (int i0 = 0; i0 < total; i0 += 256 * 4) {
+            int pos[4];
+            bool on[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int it = i0 + 256 * k + tid;
+                pos[k] = 0; on[k] = false;
+                if (it < total) {
+                    int lo = 0, hi = 255;              // the rect of item `it`: last j with rstart[j] <= it
+#pragma unroll
+                    for (int stp = 0; stp < 8; ++stp) { const int mid = (lo + hi + 1) >> 1; if (rstart[mid] <= it) lo = mid; else hi = mid - 1; }
+                    const int i = it - rstart[lo], nwl = rnw[lo];
+                    pos[k] = rfirst[lo] + (i / nwl) * w + i % nwl;
+                    on[k] = pos2s[pos[k]] >= 0;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (on[k]) atomicOr(&sb[(pos[k] >> 5) - w0], 1u << (pos[k] & 31));
         }
     }
     __syncthreads();
