@@ -12,7 +12,10 @@ wp = {k: ops.pack_wfrag(v.to(bf)) for k, v in dict(w1a=r(1024, 192, sc=.08), w1b
 wp.update(dict(b1a=r(1024), b1b=r(256), br=r(256), be=r(256)))
 tab = r(8800, 256)
 pe = torch.empty((M, 256), device=dev); xk = torch.empty((M, 256), device=dev, dtype=bf)
-for sel, ex in (('64', '0'), ('96', '0'), ('96', '3'), ('2', '0'), ('2', '3')):
+VARIANTS = (('64', '0'), ('96', '0'), ('96', '3'), ('2', '0'), ('2', '3'))
+if os.environ.get('MV2D_PE_ONLY'):
+    VARIANTS = ((os.environ['MV2D_PE_ONLY'], '0'),)
+for sel, ex in VARIANTS:
     os.environ['MV2D_PE_TAB_KERNEL'] = sel; os.environ['MV2D_PE_EXP'] = ex
     for _ in range(5):
         ops.pe_fused_tab(A1, Xfb, Xf32, None, wp, tab, 8800, pe, xk, M=M)
