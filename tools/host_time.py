@@ -3,10 +3,11 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mv2d_amd import synthetic
 from mv2d_amd.engine import HeadEngine
-B = 8
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+WL = sys.argv[1] if len(sys.argv) > 1 else 'cfg2_s'
 dev = torch.device('cuda:0')
-probs = [synthetic.make_problem('cfg2_s', seed=s) for s in range(B)]
-eng = HeadEngine(synthetic.make_head_state(seed=0), 'S', dev, num_views=6)
+probs = [synthetic.make_problem(WL, seed=s) for s in range(B)]
+eng = HeadEngine(synthetic.make_head_state(seed=0), probs[0]['kind'], dev, num_views=probs[0]['views_per_frame'])
 feats = torch.cat([torch.as_tensor(p['feat']).to(dev) for p in probs])
 props = [[torch.as_tensor(q) for q in p['proposals']] for p in probs]
 metas = [p['img_metas'] for p in probs]
