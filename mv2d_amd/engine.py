@@ -101,7 +101,12 @@ class HeadEngine:
         # _zmap_x3: 6 instead of 8 launches per layer, bitwise the same results).  cfg2_s, 8 samples per launch: 27.4 + 25.7 us for the two
         # fused kernels against 15.6 + 11.0 + 10.2 + 8.0 us for the four separate ones -- a row kernel is bound by streaming its weights
         # through ONE CU per 32 rows, and the fused ones stream twice as much on 75 blocks while the separate map kernels spread over 150
-        self.fuse_maps = os.environ.get('MV2D_XATTN_FUSE_MAPS', '0') == '1'
+        # ... so they are used for SMALL launches only (<= 512 query rows, i.e. one sample per call: there the two saved launches per layer
+        # count and 19-38 blocks do not contend for L2: 0.764 -> 0.726 ms submit-to-result for one sample, 3780 -> 4114 samples/s with one
+        # sample per launch on 4 streams).  Bitwise the same results either way, so the choice may depend on the launch size.
+        # MV2D_XATTN_FUSE_MAPS=1 / 0 forces them on / off.
+        fm = os.environ.get('MV2D_XATTN_FUSE_MAPS')
+        self.fuse_maps = None if fm is None else fm == '1'
         nw = os.environ.get('MV2D_XATTN_NW')
         # waves per query: the kernel alone takes the same 32-33 us per layer with 1, 2 or 4 (it moves its 161 MB at ~5 TB/s either way), but a
         # launch with fewer waves leaves more of the chip to the other streams' kernels: cfg2_s 8067 / 8043 / 7869 samples/s for 1 / 2 / 4,
@@ -690,7 +695,8 @@ class HeadEngine:
         fuse_tail = self.fuse_rows and self.rows_x3          # FFN tail + next layer's in_proj as one row-fused kernel
         xk_rows, xv_rows = ws['xk_rows'], ws['xv_rows']
 
-        maps_fused = self.tile_attn and self.fuse_maps and self.fuse_rows and self.rows_x3 and not self.sa_fused
+        fuse_maps = (R <= 512) if self.fuse_maps is None else self.fuse_maps
+        maps_fused = self.tile_attn and fuse_maps and self.fuse_rows and self.rows_x3 and not self.sa_fused
 
         def cross_attn(i):
             if self.tile_attn:
