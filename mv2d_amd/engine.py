@@ -107,6 +107,7 @@ class HeadEngine:
         # MV2D_XATTN_FUSE_MAPS=1 / 0 forces them on / off.
         fm = os.environ.get('MV2D_XATTN_FUSE_MAPS')
         self.fuse_maps = None if fm is None else fm == '1'
+        self.keep_xk = os.environ.get('MV2D_KEEP_XK', '0') == '1'   # S path: also write the position-major key rows Xk (nothing on that path reads them)
         nw = os.environ.get('MV2D_XATTN_NW')
         # waves per query: the kernel alone takes the same 32-33 us per layer with 1, 2 or 4 (it moves its 161 MB at ~5 TB/s either way), but a
         # launch with fewer waves leaves more of the chip to the other streams' kernels: cfg2_s 8067 / 8043 / 7869 samples/s for 1 / 2 / 4,
@@ -570,7 +571,8 @@ class HeadEngine:
             self._exact_pe(ws, featcl, P, V, h, w)
         elif self.pe_fused:
             if self.pe_sine_table:
-                o.pe_fused_tab(ws['A1'], ws['Xf_b'], featcl, md, W_['pe_pack'], ws['shared']['sine_tab'], ws['shared']['sine_period'], ws['pe'], ws['Xk'], M=P,
+                o.pe_fused_tab(ws['A1'], ws['Xf_b'], featcl, md, W_['pe_pack'], ws['shared']['sine_tab'], ws['shared']['sine_period'], ws['pe'],
+                               ws['Xk'] if (self.kind == 'T' or self.keep_xk) else None, M=P,
                                row_index=ws['s2pos'])
             else:
                 o.pe_fused(ws['A1'], ws['A2'], ws['Xf_b'], featcl, md, W_['pe_pack'], ws['pe'], ws['Xk'], M=P, row_index=ws['s2pos'])

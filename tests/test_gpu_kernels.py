@@ -794,6 +794,11 @@ def test_pe_fused_tab_kernels_bit_identical(dev, M, use_mdev, use_ri, monkeypatc
         torch.cuda.synchronize()
         outs[sel] = (pe, xk)
     Mv = M - 13 if use_mdev else M
+    for sel in ('64', '96'):                                   # Xk is optional (S path): pe alone is the same
+        monkeypatch.setenv('MV2D_PE_TAB_KERNEL', sel)
+        pe_only = torch.zeros((M, 256), device=dev)
+        ops.pe_fused_tab(A1, Xfb, Xf32, md, wp, tab, period, pe_only, None, M=M, row_index=ri)
+        assert torch.equal(pe_only[:Mv], outs['64'][0][:Mv])
     for sel in ('96', '2'):
         assert torch.equal(outs['64'][0][:Mv], outs[sel][0][:Mv])
         assert torch.equal(outs['64'][1][:Mv].view(torch.int16), outs[sel][1][:Mv].view(torch.int16))
