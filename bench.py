@@ -53,10 +53,10 @@ def stage_bytes(kind, R, S, L=6):
     Mkv = S if kind == 'T' else R * 49
     return {
         # inputs (A1, A2, Xf bf16, Xf fp32) + the six weight matrices once + pe fp32 and Xk bf16 out
-        # table variant: A1 + Xf bf16 in, table row fp32 in, pe fp32 out; the T path also reads the fp32 feature row and writes Xk bf16
-        # (the S path's keys are RoI-aligned rows: no position-major Xk)
-        'pe_fused': (S * (192 + 256) * 2 + S * 256 * 4 + (192 * 1024 + 1024 * 256 + 2 * 256 * 256) * 2 + S * 256 * 4 +
-                     (S * 256 * 6 if kind == 'T' else 0)) if SINE_TABLE else
+        # table variant: A1 + Xf bf16 in, table row fp32 in; S path: pe fp32 out (RoIAlign reads it; its keys are RoI-aligned rows);
+        # T path: fp32 feature row in, Xk bf16 out (nothing reads pe there)
+        'pe_fused': (S * (192 + 256) * 2 + S * 256 * 4 + (192 * 1024 + 1024 * 256 + 2 * 256 * 256) * 2 +
+                     (S * 256 * (4 + 2) if kind == 'T' else S * 256 * 4)) if SINE_TABLE else
                     (S * (192 + 384 + 256) * 2 + S * 256 * 4 + (192 * 1024 + 384 * 1024 + 2 * 1024 * 256 + 2 * 256 * 256) * 2 + S * 256 * 6),
         'qg_conv_gemm': R * 49 * 256 * 2 + 2304 * 256 * 2 + R * 256 * 4,                       # pooled [R,256] output
         'kv_gemm': 2 * Mkv * C * 2 + 2 * L * C * C * 2 + Mkv * 2 * L * C * 2,

@@ -82,7 +82,7 @@ int mv2d_pe_fused(const void* A1, const void* A2, const void* Xfb, const float* 
  * depends only on the weights and on the padding geometry, so it is read from sine_tab [tab_period][256] fp32 = adapt_pos3d(sine)(position)
  * + b2b, indexed by the key's map position (row_index[m], or m) modulo tab_period (= positions of one sample when the samples of a batch
  * share their geometry).  pe = position_encoder(A1) * gate + sine_tab[position].  Xk may be NULL (then Xf32 is not read either): the S path's
- * keys are RoI-aligned rows, it only needs pe. */
+ * keys are RoI-aligned rows, it only needs pe; pe may be NULL when Xk is given: on the T path nothing reads pe. */
 int mv2d_pe_fused_tab(const void* A1, const void* Xfb, const float* Xf32, const int* row_index, const int* m_dev, int M,
                       const void* W1a, const float* b1a, const void* W1b, const float* b1b,
                       const void* Wr, const float* br, const void* We, const float* be,

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pe_fused_kernel(PeParams p) {
             float4 v = *reinterpret_cast<const float4*>(ot + row * 68 + c4);
             if (TAB) v = make_float4(v.x + tv[TAB ? k : 0].x, v.y + tv[TAB ? k : 0].y, v.z + tv[TAB ? k : 0].z, v.w + tv[TAB ? k : 0].w);
             if (m < M) {
-                *reinterpret_cast<float4*>(p.pe + (long long)m * C + gcol) = v;
+                if (!TAB || p.pe) *reinterpret_cast<float4*>(p.pe + (long long)m * C + gcol) = v;
                 if (!TAB || p.Xk)
                     *reinterpret_cast<uint2*>(p.Xk + (long long)m * C + gcol) =
                         make_uint2(pack_bf16x2(v.x + fv[k].x, v.y + fv[k].y), pack_bf16x2(v.z + fv[k].z, v.w + fv[k].w));
@@ -396,7 +396,7 @@ extern "C" int mv2d_pe_fused_tab(const void* A1, const void* Xfb, const float* X
                                  const void* W1a, const float* b1a, const void* W1b, const float* b1b,
                                  const void* Wr, const float* br, const void* We, const float* be,
                                  const float* sine_tab, int tab_period, float* pe, void* Xk, void* stream) {
-    MV2D_CHECK_ARG(A1 && Xfb && (Xf32 || !Xk) && W1a && b1a && W1b && b1b && Wr && br && We && be && sine_tab && pe, "mv2d_pe_fused_tab: null pointer");
+    MV2D_CHECK_ARG(A1 && Xfb && (Xf32 || !Xk) && W1a && b1a && W1b && b1b && Wr && br && We && be && sine_tab && (pe || Xk), "mv2d_pe_fused_tab: null pointer");
     MV2D_CHECK_ARG(M >= 0 && tab_period > 0, "mv2d_pe_fused_tab: M must be >= 0 and tab_period > 0");
     if (M == 0) return MV2D_OK;
     // read per call (a host-side launch decision; graphs keep what they captured).  Default: pe_tab96.hip's kernel in its 96-row /

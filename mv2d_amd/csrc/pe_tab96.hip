@@ -3,7 +3,8 @@
 //   P1 = position_encoder(A1)                                   192 -> 1024 -> 256     (MU/pe.py:64-77, 158-160)
 //   G  = sigmoid(conv_expand(relu(conv_reduce(feat))))          256 -> 256 -> 256      (MU/pe.py:36-48, 162-166)
 //   pe = tab[position] + P1 * G ,  Xk = bf16(pe + feat)         tab = adapt_pos3d(sine) + bias, constant per (weights, padding geometry)
-//   (Xk optional: the S path's keys are RoI-aligned rows, it only needs pe -- no feature-row read, a third less traffic)
+//   (Xk optional: the S path's keys are RoI-aligned rows, it only needs pe -- no feature-row read, a third less traffic;
+//    pe optional: the T path's keys are the Xk rows, nothing reads pe there)
 //
 // pe_fused_kernel<true> (pe_mlp.hip: 4 waves, 64 rows, ONE wave per SIMD, one block per CU) spends less than half of a block's life in
 // its MFMA loops: prologue, the staging of the second input tile and above all the output phase (1.5 KB written and 2 KB read per row)
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(S::NTHR, 2) void pe_tab_kernel(PeTabParams p) {
             float4 v = *reinterpret_cast<const float4*>(ot + row * OT_PITCH + c4);
             v = make_float4(v.x + tv[k].x, v.y + tv[k].y, v.z + tv[k].z, v.w + tv[k].w);
             if (m < M) {
-                *reinterpret_cast<float4*>(p.pe + (long long)m * C + gcol) = v;
+                if (p.pe) *reinterpret_cast<float4*>(p.pe + (long long)m * C + gcol) = v;
                 if (p.Xk)
                     *reinterpret_cast<uint2*>(p.Xk + (long long)m * C + gcol) =
                         make_uint2(pack_bf16x2(v.x + fv[k].x, v.y + fv[k].y), pack_bf16x2(v.z + fv[k].z, v.w + fv[k].w));
@@ -314,7 +315,7 @@ extern "C" int mv2d_pe_fused_tab2(const void* A1, const void* Xfb, const float* 
                                   const void* W1a, const float* b1a, const void* W1b, const float* b1b,
                                   const void* Wr, const float* br, const void* We, const float* be,
                                   const float* sine_tab, int tab_period, float* pe, void* Xk, int shape, void* stream) {
-    MV2D_CHECK_ARG(A1 && Xfb && (Xf32 || !Xk) && W1a && b1a && W1b && b1b && Wr && br && We && be && sine_tab && pe, "mv2d_pe_fused_tab: null pointer");
+    MV2D_CHECK_ARG(A1 && Xfb && (Xf32 || !Xk) && W1a && b1a && W1b && b1b && Wr && br && We && be && sine_tab && (pe || Xk), "mv2d_pe_fused_tab: null pointer");
     MV2D_CHECK_ARG(M >= 0 && tab_period > 0, "mv2d_pe_fused_tab: M must be >= 0 and tab_period > 0");
     if (M == 0) return MV2D_OK;
     PeTabParams p{(const unsigned short*)A1, (const unsigned short*)Xfb, Xf32, row_index, m_dev, M, (const unsigned short*)W1a, b1a,

@@ -107,7 +107,7 @@ class HeadEngine:
         # MV2D_XATTN_FUSE_MAPS=1 / 0 forces them on / off.
         fm = os.environ.get('MV2D_XATTN_FUSE_MAPS')
         self.fuse_maps = None if fm is None else fm == '1'
-        self.keep_xk = os.environ.get('MV2D_KEEP_XK', '0') == '1'   # S path: also write the position-major key rows Xk (nothing on that path reads them)
+        self.keep_xk = os.environ.get('MV2D_KEEP_XK', '0') == '1'   # always write both pe and Xk (S path: nothing reads Xk; T path: nothing reads pe)
         nw = os.environ.get('MV2D_XATTN_NW')
         # waves per query: the kernel alone takes the same 32-33 us per layer with 1, 2 or 4 (it moves its 161 MB at ~5 TB/s either way), but a
         # launch with fewer waves leaves more of the chip to the other streams' kernels: cfg2_s 8067 / 8043 / 7869 samples/s for 1 / 2 / 4,
@@ -571,8 +571,11 @@ class HeadEngine:
             self._exact_pe(ws, featcl, P, V, h, w)
         elif self.pe_fused:
             if self.pe_sine_table:
-                o.pe_fused_tab(ws['A1'], ws['Xf_b'], featcl, md, W_['pe_pack'], ws['shared']['sine_tab'], ws['shared']['sine_period'], ws['pe'],
-                               ws['Xk'] if (self.kind == 'T' or self.keep_xk) else None, M=P,
+                # only what the path reads is written: S: pe (RoIAlign reads it; its keys are RoI-aligned rows), T: Xk (nothing reads pe);
+                # a keep_stages run writes both
+                dbg = self.keep_xk or getattr(self, '_stage_outputs', False)
+                o.pe_fused_tab(ws['A1'], ws['Xf_b'], featcl, md, W_['pe_pack'], ws['shared']['sine_tab'], ws['shared']['sine_period'],
+                               ws['pe'] if (self.kind == 'S' or dbg) else None, ws['Xk'] if (self.kind == 'T' or dbg) else None, M=P,
                                row_index=ws['s2pos'])
             else:
                 o.pe_fused(ws['A1'], ws['A2'], ws['Xf_b'], featcl, md, W_['pe_pack'], ws['pe'], ws['Xk'], M=P, row_index=ws['s2pos'])
@@ -850,6 +853,7 @@ class HeadEngine:
             ptrs = tuple(f.data_ptr() for f in feat)
         assert V % B == 0
         ws, R, sc = self._host_prepare(proposals_list, metas_list, V, h, w)
+        self._stage_outputs = bool(keep_stages)          # intermediate buffers nothing downstream reads (pe on the T path, Xk on the S path)
         Rc = sc['cap']                     # launches run on the bucket size; R = the real rows
         if not use_graph or self.exact:
             self._enqueue(ws, feat, Rc, V, h, w, sc)
@@ -857,7 +861,7 @@ class HeadEngine:
             return dict(self._result(ws, R, keep_stages, batch), dt=sc['dt'])
         # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
-        gkey = (ptrs, sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version)   # load_state() re-allocates the weights
+        gkey = (ptrs, sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs)   # load_state() re-allocates the weights
         graphs = ws.setdefault('graphs', {})             # one graph per (input buffers, frame scalars): a producer that alternates between
         g = graphs.get(gkey)                             # a few static output buffers replays a few graphs, it does not re-capture
         if ws.pop('graph_stale', False):

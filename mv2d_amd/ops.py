@@ -317,7 +317,7 @@ def pe_fused(A1, A2, Xfb, Xf32, m_dev, wp, pe, Xk, M=None, row_index=None):
 
 def pe_fused_tab(A1, Xfb, Xf32, m_dev, wp, sine_tab, tab_period, pe, Xk, M=None, row_index=None):
     """pe_fused with the sine branch read from sine_tab [tab_period,256] fp32 (map position -> adapt_pos3d(sine) + bias).  Xk may be None
-    (S path: only pe is needed; the feature rows are then not read)."""
+    (S path: only pe is needed; the feature rows are then not read), pe may be None when Xk is given (T path)."""
     _req(A1, BF16, 'A1'); _req(Xfb, BF16, 'Xfb'); _req(Xf32, torch.float32, 'Xf32'); _req(sine_tab, torch.float32, 'sine_tab')
     M = A1.shape[0] if M is None else M
     check(_lib.load().mv2d_pe_fused_tab(_p(A1), _p(Xfb), _p(Xf32), _p(row_index), _p(m_dev), M, _p(wp['w1a']), _p(wp['b1a']), _p(wp['w1b']),
