@@ -124,7 +124,7 @@ int mv2d_query_embed_fused_x3(const float* enc2, const float* Wc, const float* b
                               const void* W2_lo, const float* b2, float* center, float* xyz, float* ref, float* posemb,
                               float* qpos, int R, void* stream);
 
-/* FFN tail + the next layer's self-attention in_proj, row-fused: y = LN(sum_z parts[z] + b2 + resid); x_out = y; xq_out = y + qpos;
+/* FFN tail + the next layer's self-attention in_proj, row-fused: y = LN(sum_z parts[z] + b2 + resid); x_out = y; xq_out = y + qpos (may be NULL);
  * outs = post_norm(y) (optional); qkv [M,768] = [xq.Wq^T + bq | xq.Wk^T + bk | y.Wv^T + bv] in bf16x3 split precision (optional:
  * Win_hi = null for the last layer).  Win_hi / Win_lo: nn.MultiheadAttention in_proj_weight [768,256] as a bf16 hi/lo pair
  * (mv2d_split_bf16x2), each fragment-major (mv2d_pack_wfrag_bf16).  Replaces mv2d_row_ln + mv2d_gemm_f32 between two layers

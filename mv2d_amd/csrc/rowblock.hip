@@ -639,7 +639,7 @@ __global__ __launch_bounds__(1024) void ffn_out_fused_x3_kernel(FfnOutParams p) 
         const float4 vq = make_float4(v.x + qp.x, v.y + qp.y, v.z + qp.z, v.w + qp.w);
         if (m < p.M) {
             *reinterpret_cast<float4*>(p.x_out + grow) = v;
-            *reinterpret_cast<float4*>(p.xq_out + grow) = vq;
+            if (p.xq_out) *reinterpret_cast<float4*>(p.xq_out + grow) = vq;       // (optional: with the next in_proj fused nobody reads x + qpos)
             if (p.outs) *reinterpret_cast<float4*>(p.outs + grow) = ln_row(v, p.pw, p.pb, lane * 4, p.eps);
         } else if (p.outs) {
             (void)ln_row(v, p.pw, p.pb, lane * 4, p.eps);        // keep the wave-wide reductions convergent
@@ -1239,7 +1239,7 @@ extern "C" int mv2d_ffn_out_fused_x3(const float* parts, int n_parts, long long 
                                      const float* ln_w, const float* ln_b, const float* post_w, const float* post_b, float* x_out,
                                      const float* qpos, float* xq_out, float* outs, const void* Win_hi, const void* Win_lo,
                                      const float* b_in, float* qkv, int M, float eps, void* stream) {
-    MV2D_CHECK_ARG(parts && n_parts > 0 && b2 && resid && ln_w && ln_b && x_out && qpos && xq_out, "mv2d_ffn_out_fused_x3: null pointer");
+    MV2D_CHECK_ARG(parts && n_parts > 0 && b2 && resid && ln_w && ln_b && x_out && qpos, "mv2d_ffn_out_fused_x3: null pointer");
     MV2D_CHECK_ARG(!outs || (post_w && post_b), "mv2d_ffn_out_fused_x3: outs needs the post_norm parameters");
     MV2D_CHECK_ARG(!Win_hi || (Win_lo && b_in && qkv), "mv2d_ffn_out_fused_x3: the in_proj stage needs Win_lo, b_in and qkv");
     if (M == 0) return MV2D_OK;

@@ -787,7 +787,7 @@ class HeadEngine:
             if fuse_tail:
                 nxt = i + 1 < L
                 o.ffn_out_fused_x3(parts, W_[f'ffn_b2{i}'], ws['x2'], (W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), (W_['post_w'], W_['post_b']),
-                                   x, ws['qpos'], xq, outs=ws['outs'][i], Win_x3=W_[f'sa_in_wx{i + 1}'] if nxt else None,
+                                   x, ws['qpos'], None, outs=ws['outs'][i], Win_x3=W_[f'sa_in_wx{i + 1}'] if nxt else None,
                                    b_in=W_[f'sa_in_b{i + 1}'] if nxt else None, qkv=ws['qkv'] if nxt else None, M=R)
             else:
                 o.row_ln(parts, bias=W_[f'ffn_b2{i}'], residual=ws['x2'], ln=(W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), out=x, addvec=ws['qpos'],
