@@ -15,11 +15,11 @@ pe = torch.empty((M, 256), device=dev); xk = torch.empty((M, 256), device=dev, d
 lib = ctypes.CDLL(sys.argv[1])
 P = ctypes.c_void_p
 p = lambda t: P(t.data_ptr())
-for ex, shape in (('0', 1),):
+for ex, shape, with_xk in (('0', 1, True), ('0', 1, False)):
     os.environ['MV2D_PE_EXP'] = ex
     for _ in range(3):
         rc = lib.mv2d_pe_fused_tab2(p(A1), p(Xfb), p(Xf32), None, None, M, p(wp['w1a']), p(wp['b1a']), p(wp['w1b']), p(wp['b1b']), p(wp['wr']), p(wp['br']),
-                                     p(wp['we']), p(wp['be']), p(tab), 8800, p(pe), p(xk), shape, None)
+                                     p(wp['we']), p(wp['be']), p(tab), 8800, p(pe), p(xk) if with_xk else None, shape, None)
         assert rc == 0
     torch.cuda.synchronize()
     buf = (ctypes.c_longlong * 64)()
@@ -27,7 +27,7 @@ for ex, shape in (('0', 1),):
     t = list(buf)
     names = ['start', 'prologue', 'A0 L1+bar', 'A0 L2', 'A1 L1+bar', 'A1 L2', 'A2 L1+bar', 'A2 L2', 'A3 L1+bar', 'A3 L2 + stage', 'barrier', 'G L1+bar', 'G L2',
              'ri + gate math + barrier', 'out cols 0', 'out cols 1']
-    print('exp', ex, 'shape', shape)
+    print('exp', ex, 'shape', shape, 'Xk written' if with_xk else 'pe only (S path)')
     prev = t[0]
     for n, v in zip(names, t):
         print(f'  {n:18s} +{(v - prev) / 100.0:7.2f} us   (at {(v - t[0]) / 100.0:7.2f})')
