@@ -70,8 +70,8 @@ STAGE_KERNEL = {'pe_fused': 'pe_tab_kernel (frustum MLP + gate, sine branch from
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=500)      # 500 steps x ~4 ms: a timed region of ~2 s (a GPU-busy sampler sees it)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default='cfg2_s', help='cfg2_s (MV2D-S 6 cams 1408x512, headline) | cfg3_t | cfg5_t | cfg1_s ...')
     ap.add_argument('--inflight', type=int, default=4, help='HIP streams per GPU, each running its own launch sequence per step')
     ap.add_argument('--batch', type=int, default=8, help='samples sharing every launch of a stream (HeadEngine.run_batch)')
@@ -241,7 +241,7 @@ def main():
                 fn()
             barrier()
             return time.perf_counter() - t_
-        n_x = max(10, min(args.steps, 50))
+        n_x = max(10, min(args.steps, 100))
         # (a) the round-1 protocol: every stream replays the same frames, img_metas never change
         same = [[sets_main[0][0]] for _ in range(args.inflight)]
         el = timed(make_step(engines, streams, same, None, B, payload, rotate=False), n_x, 3)
