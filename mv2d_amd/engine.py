@@ -107,6 +107,9 @@ class HeadEngine:
         # MV2D_XATTN_FUSE_MAPS=1 / 0 forces them on / off.
         fm = os.environ.get('MV2D_XATTN_FUSE_MAPS')
         self.fuse_maps = None if fm is None else fm == '1'
+        # OPT-IN: evaluate the cls / reg branches of the last decoder layer only (what decoding reads).  Not the default: out['cls'] / out['reg']
+        # then carry stale rows for the other layers, and the reference's forward does evaluate all six.
+        self.last_stage_heads = os.environ.get('MV2D_LAST_STAGE_HEADS', '0') == '1'
         self.keep_xk = os.environ.get('MV2D_KEEP_XK', '0') == '1'   # always write both pe and Xk (S path: nothing reads Xk; T path: nothing reads pe)
         nw = os.environ.get('MV2D_XATTN_NW')
         # waves per query: the kernel alone takes the same 32-33 us per layer with 1, 2 or 4 (it moves its 161 MB at ~5 TB/s either way), but a
@@ -228,6 +231,12 @@ class HeadEngine:
             self.cls_ptrs_x3 = ops.make_ptr_array([*w['cls_w0x'], w['cls_b0'], w['cls_lnw1'], w['cls_lnb1'], *w['cls_w3x'], w['cls_b3'], w['cls_lnw4'],
                                                    w['cls_lnb4'], w['cls_w6'], w['cls_b6']])
             self.reg_ptrs_x3 = ops.make_ptr_array([*w['reg_w0x'], w['reg_b0'], *w['reg_w2x'], w['reg_b2'], w['reg_w4'], w['reg_b4']])
+            # the same tensors from the last decoder layer on: the launch of the last_stage_heads option (every tensor is stacked over L)
+            ll = self.L - 1
+            self._last_cls = [t[ll:] for t in (*w['cls_w0x'], w['cls_b0'], w['cls_lnw1'], w['cls_lnb1'], *w['cls_w3x'], w['cls_b3'], w['cls_lnw4'],
+                                               w['cls_lnb4'], w['cls_w6'], w['cls_b6'])]
+            self._last_reg = [t[ll:] for t in (*w['reg_w0x'], w['reg_b0'], *w['reg_w2x'], w['reg_b2'], w['reg_w4'], w['reg_b4'])]
+            self.cls_ptrs_x3_last, self.reg_ptrs_x3_last = ops.make_ptr_array(self._last_cls), ops.make_ptr_array(self._last_reg)
         self.cls_ptrs = ops.make_ptr_array([w[k] for k in ('cls_w0p', 'cls_b0', 'cls_lnw1', 'cls_lnb1', 'cls_w3p', 'cls_b3', 'cls_lnw4', 'cls_lnb4', 'cls_w6', 'cls_b6')])
         self.reg_ptrs = ops.make_ptr_array([w[k] for k in ('reg_w0p', 'reg_b0', 'reg_w2p', 'reg_b2', 'reg_w4', 'reg_b4')])
 
@@ -796,7 +805,13 @@ class HeadEngine:
     def _enqueue_heads(self, ws, R, dt):
         # a14: every per-layer cls / reg branch + the reference-point tail in ONE launch (row-block fused)
         dt_rows = ws['dt_rows'] if self.kind == 'T' else None
-        if self.heads_x3:
+        if self.heads_x3 and self.last_stage_heads and not getattr(self, '_stage_outputs', False):
+            # inference needs the branches of the LAST decoder layer only (the reference evaluates all six and reads [-1],
+            # cross_attention_head.py:202-242 / RH/mv2d_head.py:170-194); cls / reg of the other layers are then not written
+            ll = self.L - 1
+            ops.heads_fused_x3(ws['outs'][ll:], self.cls_ptrs_x3_last, self.reg_ptrs_x3_last, ws['ref'], ws['cls'][ll:], ws['reg'][ll:], R, 1,
+                               self.pc_range_h, dt, dt_rows=dt_rows)
+        elif self.heads_x3:
             ops.heads_fused_x3(ws['outs'], self.cls_ptrs_x3, self.reg_ptrs_x3, ws['ref'], ws['cls'], ws['reg'], R, self.L, self.pc_range_h, dt,
                                dt_rows=dt_rows)
         else:
@@ -861,7 +876,7 @@ class HeadEngine:
             return dict(self._result(ws, R, keep_stages, batch), dt=sc['dt'])
         # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
-        gkey = (ptrs, sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs)   # load_state() re-allocates the weights
+        gkey = (ptrs, sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs, self.last_stage_heads)   # load_state() re-allocates the weights
         graphs = ws.setdefault('graphs', {})             # one graph per (input buffers, frame scalars): a producer that alternates between
         g = graphs.get(gkey)                             # a few static output buffers replays a few graphs, it does not re-capture
         if ws.pop('graph_stale', False):

@@ -472,3 +472,26 @@ def test_sine_table_follows_the_weights(kind):
     assert torch.equal(again, fresh)
     assert not torch.equal(again, first)
 
+
+
+@pytest.mark.parametrize('name,kind', [('cfg1_s', 'S'), ('cfg1_t', 'T')])
+def test_last_stage_heads_option(name, kind):
+    """HeadEngine.last_stage_heads (opt-in): only the branches of the last decoder layer are evaluated; the decoded result and the last
+    layer's logits / box codes are bitwise those of the default (all six layers, like the reference's forward)."""
+    from mv2d_amd.engine import HeadEngine
+    prob = synthetic.make_problem(name, seed=0)
+    sd = synthetic.make_head_state(seed=0)
+    dev = torch.device('cuda:0')
+    feat = torch.from_numpy(prob['feat']).to(dev)
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    a = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'])
+    b = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'])
+    b.last_stage_heads = True
+    for use_graph in (False, True):
+        oa = a.run(feat, props, prob['img_metas'], use_graph=use_graph)
+        ob = b.run(feat, props, prob['img_metas'], use_graph=use_graph)
+        for k in ('boxes', 'scores', 'labels', 'bbox_index', 'count'):
+            assert torch.equal(oa[k], ob[k]), k
+        assert torch.equal(oa['cls'][-1], ob['cls'][-1]) and torch.equal(oa['reg'][-1], ob['reg'][-1])
+    ok = b.run(feat, props, prob['img_metas'], keep_stages=True)                  # a keep_stages run evaluates all layers again
+    assert torch.equal(ok['cls'], oa['cls'])
