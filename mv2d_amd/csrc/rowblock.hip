@@ -317,6 +317,12 @@ __global__ __launch_bounds__(1024) void attn_out_fused_x3_kernel(AttnOutX3Params
             *reinterpret_cast<uint2*>(al + t * 8192 + aoff) = lo;
         }
     }
+    // everything the epilogue reads from global memory is requested BEFORE the barrier and the MFMAs (each of these was a dependent round
+    // trip of its own behind them: bias, residual rows; the LayerNorm parameters do not fit the 128-register budget of 16 waves per block)
+    float4 ures[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) ures[t] = *reinterpret_cast<const float4*>(p.resid + grow[t]);
+    const float bo_c = p.bo[wave * 16 + fr];
     __syncthreads();
     f32x4_t acc[RT];
 #pragma unroll
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(1024) void attn_out_fused_x3_kernel(AttnOutX3Params
     if (p.Wqh) load_w_x3(wh, wl, p.Wqh, p.Wql, wave, lane);        // in flight during the LayerNorm
     {
         const int col = wave * 16 + fr;
-        const float b = p.bo[col];
+        const float b = bo_c;
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(1024) void attn_out_fused_x3_kernel(AttnOutX3Params
     for (int t = 0; t < RT; ++t) {
         const int row = wave, m = mb + 16 * t + row;
         float4 v = *reinterpret_cast<float4*>(tb + t * 16 * C + row * C + ((lane ^ (row & 15)) << 2));
-        const float4 u = *reinterpret_cast<const float4*>(p.resid + grow[t]);
+        const float4 u = ures[t];
         v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / C);
         const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;

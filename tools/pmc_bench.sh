@@ -9,7 +9,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python $R/tools/rocpd_pmc.py $(find $R/gpurun_out/$OUT/$c -name "p_results.db" | head -1) --by-grid > $R/gpurun_out/$OUT/${c}.txt 2>&1
   rm -rf $R/gpurun_out/$OUT/$c
 done
-timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$OUT/stats -o s -- python $R/bench.py --no-cpu-baseline --no-extra-legs > $R/gpurun_out/$OUT/bench_under_rocprof.json 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$OUT/stats -o s -- python $R/bench.py --steps 100 --no-cpu-baseline --no-extra-legs > $R/gpurun_out/$OUT/bench_under_rocprof.json 2>/dev/null
 python $R/tools/rocpd_stats.py $(find $R/gpurun_out/$OUT/stats -name "s_results.db" | head -1) > $R/gpurun_out/$OUT/kernel_stats.txt 2>&1
 rm -rf $R/gpurun_out/$OUT/stats
 head -30 $R/gpurun_out/$OUT/kernel_stats.txt
