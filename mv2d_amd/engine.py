@@ -221,7 +221,9 @@ class HeadEngine:
             for n_, k_ in (('w1a', 'position_encoder.0'), ('w1b', 'position_encoder.2'), ('w2a', 'adapt_pos3d.0'), ('w2b', 'adapt_pos3d.2'),
                            ('wr', 'fpe.conv_reduce'), ('we', 'fpe.conv_expand')):
                 w['pe_' + n_ + '_hl'] = ops.split_bf16x2(c1(k_ + '.weight').contiguous())
+                w['pe_' + n_ + '_x3'] = ops.pack_x3(c1(k_ + '.weight').contiguous())
             w['qg_conv_w32'] = conv.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous()
+            w['qg_conv_wx3'] = ops.pack_x3(w['qg_conv_w32'])
         self.w = w
         for k in ('cls_w0', 'cls_w3', 'reg_w0', 'reg_w2'):                              # [L,256,256] -> fragment-major copies for heads_fused
             w[k + 'p'] = ops.pack_wfrag_f32(w[k])
@@ -650,7 +652,11 @@ class HeadEngine:
         if S == 0:
             return
         xf = featcl[ws['s2pos'][:S].long()].contiguous()                                 # gathered feature rows, fp32
-        lin = lambda x, n_, act=0: o.gemm_x3(x, W_['pe_' + n_ + '_hl'], W_['pe_b' + n_[1:]], act=act)
+        if os.environ.get('MV2D_EXACT_PE', 'linear') == 'gemm':
+            lin = lambda x, n_, act=0: o.gemm_x3(x, W_['pe_' + n_ + '_hl'], W_['pe_b' + n_[1:]], act=act)
+        else:       # the LDS-tiled bf16x3 linear (same split-precision arithmetic, 3-4x faster than the generic kernel on these shapes)
+            lin = lambda x, n_, act=0: o.linear_x3(x.contiguous(), W_['pe_' + n_ + '_x3'], W_['pe_b' + n_[1:]], N=W_['pe_b' + n_[1:]].numel(),
+                                                   K=x.shape[1], act=act)
         p1 = lin(lin(a1[:S], 'w1a', 1), 'w1b')
         gate = torch.sigmoid(lin(lin(xf, 'wr', 1), 'we'))
         p2 = lin(lin(a2[:S], 'w2a', 1), 'w2b')
@@ -684,7 +690,10 @@ class HeadEngine:
             # conv3x3 + ReLU + AvgPool2d(7) on the UNROUNDED RoI features: im2col (index plumbing) + exact-fp32 MFMA GEMM + pooling kernel
             x = torch.nn.functional.pad(ws['roi_feat32'].view(R, 7, 7, C), (0, 0, 1, 1, 1, 1))
             cols = torch.cat([x[:, ky:ky + 7, kx:kx + 7] for ky in range(3) for kx in range(3)], -1).reshape(R * 49, 9 * C).contiguous()
-            y = o.gemm_f32(cols, W_['qg_conv_w32'], W_['qg_conv_b'], act=1)
+            if os.environ.get('MV2D_EXACT_CONV', 'f32') == 'x3':      # bf16x3 instead of the exact-fp32 MFMA GEMM (1e-5 relative; 4x faster)
+                y = o.linear_x3(cols, W_['qg_conv_wx3'], W_['qg_conv_b'], N=C, K=9 * C, act=1)
+            else:
+                y = o.gemm_f32(cols, W_['qg_conv_w32'], W_['qg_conv_b'], act=1)
             o.avgpool49(y, ws['x2'], C, R)
         else:
             o.qg_conv_pool(ws['roi_feat'], W_['qg_conv_wp'], W_['qg_conv_b'], ws['x2'], R=R)
