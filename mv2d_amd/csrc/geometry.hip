@@ -648,7 +648,9 @@ __global__ __launch_bounds__(256) void pe_inputs_kernel(const int* __restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = blockIdx.x * 4 + wave;
     if (s >= *S_dev) return;                                  // (whole waves leave; no block barrier below)
-    const int pos = s2pos[s];
+    // (the position is the same for all lanes of the wave: made uniform explicitly, so that the per-view matrix and the column / row
+    // coordinates are scalar loads instead of 14 broadcast vector loads per lane)
+    const int pos = __builtin_amdgcn_readfirstlane(s2pos[s]);
     const int v = pos / (h * w), rem = pos - v * h * w, y = rem / w, x = rem - y * w;
     unsigned short* fr_row = rowbuf[wave];
     unsigned short* si_row = rowbuf[wave] + 3 * 256;
