@@ -151,6 +151,17 @@ __device__ __forceinline__ unsigned int xt_hi_pair(unsigned int a, unsigned int 
 
 // XLO (the engine's index-exact validation mode): the key / value rows come as bf16 hi + lo pairs (fp32-class key side):
 // logits += Qt_hi . Xk_lo, z += P_hi . Xv_lo (the lo x lo terms, 2^-18 relative, are dropped).
+// maximum over the 16 lanes of a DPP row (lane & 15 = the key of a tile): two quad permutes, then the half-row and the row mirror.  Four
+// v_max with a DPP operand instead of four dependent ds_bpermute round trips per softmax row.
+#define XT_DPP(v, ctrl) __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), ctrl, 0xF, 0xF, true))
+__device__ __forceinline__ float xt_row16_max(float v) {
+    v = fmaxf(v, XT_DPP(v, 0xB1));      // quad_perm [1,0,3,2]
+    v = fmaxf(v, XT_DPP(v, 0x4E));      // quad_perm [2,3,0,1]
+    v = fmaxf(v, XT_DPP(v, 0x141));     // row_half_mirror
+    v = fmaxf(v, XT_DPP(v, 0x140));     // row_mirror
+    return v;
+}
+
 template <int NW, bool DBG, bool XLO>
 __global__ __launch_bounds__(64 * NW, XLO ? 1 : 2) void xattn_tile_kernel(const uint4* __restrict__ Qt, const unsigned short* __restrict__ Xk,
                                                              const unsigned short* __restrict__ Xv, const unsigned short* __restrict__ Xk_lo,
@@ -251,17 +262,16 @@ __global__ __launch_bounds__(64 * NW, XLO ? 1 : 2) void xattn_tile_kernel(const 
         float sv[4], p[4], alpha[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float full = sacc[i] + __shfl_xor(sacc[i], 32, 64);              // hi rows + lo rows: head 4 (g & 1) + i
+            // hi rows + lo rows (head 4 (g & 1) + i) sit 32 lanes apart: one v_permlane32_swap instead of a trip through the LDS crossbar
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sacc[i]), __float_as_uint(sacc[i]), false, false);
+            const float full = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
             if (DBG && dbg_logits && g < 2 && valid) dbg_logits[(long long)(4 * g + i) * dbg_stride + kbase + n] = full;
             sv[i] = valid ? full * LOG2E : -INFINITY;                               // the softmax runs in base 2 (v_exp_f32)
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float tm = sv[i];
-            tm = fmaxf(tm, __shfl_xor(tm, 1, 64));
-            tm = fmaxf(tm, __shfl_xor(tm, 2, 64));
-            tm = fmaxf(tm, __shfl_xor(tm, 4, 64));
-            tm = fmaxf(tm, __shfl_xor(tm, 8, 64));
+            tm = xt_row16_max(tm);                                                   // over the 16 key lanes, DPP (no LDS round trips)
             const float m_new = fmaxf(m_run[i], tm);
             alpha[i] = __builtin_amdgcn_exp2f(m_run[i] - m_new);
             p[i] = __builtin_amdgcn_exp2f(sv[i] - m_new);
