@@ -52,15 +52,32 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
 // ReLU that keeps NaN like torch.relu (fmaxf(NaN, 0) would return 0 and hide a poisoned row)
 __device__ __forceinline__ float relu_f(float v) { return v < 0.f ? 0.f : v; }
 
+// Reductions over the 64 lanes of a wave without the LDS crossbar, in the order of the xor butterfly they replace (32, 16, 8, 4, 2, 1):
+// v_permlane32_swap, v_permlane16_swap, then DPP row rotations by 8 and 4 (after the step before them lanes j and j ^ 8, resp. j ^ 4, hold
+// the same value, so the rotated partner carries exactly the xor partner's value) and the two quad permutes.  Bit for bit the result of six
+// dependent ds_bpermute round trips.
+#define MV2D_DPP_F(v, ctrl) __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), ctrl, 0xF, 0xF, true))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    v += MV2D_DPP_F(v, 0x128);                       // row_ror:8
+    v += MV2D_DPP_F(v, 0x124);                       // row_ror:4
+    v += MV2D_DPP_F(v, 0x4E);                        // quad_perm [2,3,0,1]
+    v += MV2D_DPP_F(v, 0xB1);                        // quad_perm [1,0,3,2]
     return v;
 }
 
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    v = fmaxf(v, MV2D_DPP_F(v, 0x128));
+    v = fmaxf(v, MV2D_DPP_F(v, 0x124));
+    v = fmaxf(v, MV2D_DPP_F(v, 0x4E));
+    v = fmaxf(v, MV2D_DPP_F(v, 0xB1));
     return v;
 }
 

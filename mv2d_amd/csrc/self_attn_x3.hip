@@ -129,16 +129,24 @@ __global__ __launch_bounds__(256) void self_attn_x3_kernel(const float* __restri
                     p[4 * t + i] = vis ? s[t][i] : -INFINITY;
                     tmax = fmaxf(tmax, p[4 * t + i]);
                 }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            {   // over the four 16-lane rows (the key groups of a step): v_permlane16_swap / v_permlane32_swap, no LDS crossbar trips
+                const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+                tmax = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+                const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+                tmax = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+            }
             const float m_new = fmaxf(m_run, tmax);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;    // nothing visible so far: (m, l, o) stay (-inf, 0, 0), no NaN
             const float alpha = __expf(m_run - m_use);
             float psum = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { p[j] = __expf(p[j] - m_use); psum += p[j]; }
-            psum += __shfl_xor(psum, 16, 64);
-            psum += __shfl_xor(psum, 32, 64);
+            {
+                const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(psum), __float_as_uint(psum), false, false);
+                psum = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+                const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(psum), __float_as_uint(psum), false, false);
+                psum = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+            }
             l_run = l_run * alpha + psum;
             m_run = m_new;
 #pragma unroll
