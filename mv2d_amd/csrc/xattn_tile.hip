@@ -146,8 +146,9 @@ __global__ __launch_bounds__(512) void xattn_ctxmap_kernel(const float* __restri
 // fragment reads of 16 different rows hit 16 different bank slots) that later holds the wave's partial z, 512 B of P, and the
 // softmax statistics of the merge.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned int xt_lo_pair(unsigned int a, unsigned int b) { return (a & 0xffffu) | (b << 16); }          // (a.lo16, b.lo16): one v_perm_b32
-__device__ __forceinline__ unsigned int xt_hi_pair(unsigned int a, unsigned int b) { return (a >> 16) | (b & 0xffff0000u); }      // (a.hi16, b.hi16)
+// (v_perm_b32: bytes 0-3 of the selector index {S1 = a: 0..3, S0 = b: 4..7}; the shift / mask formulation compiled to two VALU ops per pair)
+__device__ __forceinline__ unsigned int xt_lo_pair(unsigned int a, unsigned int b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }     // (a.lo16, b.lo16)
+__device__ __forceinline__ unsigned int xt_hi_pair(unsigned int a, unsigned int b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }     // (a.hi16, b.hi16)
 
 // XLO (the engine's index-exact validation mode): the key / value rows come as bf16 hi + lo pairs (fp32-class key side):
 // logits += Qt_hi . Xk_lo, z += P_hi . Xv_lo (the lo x lo terms, 2^-18 relative, are dropped).
