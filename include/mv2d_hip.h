@@ -269,6 +269,7 @@ int mv2d_raw_xattn_fwd(const float* qk, const void* Xk, const void* Xv, const in
  *   shared by all layers and heads; CSR row_ptr [R+1] / col_idx [nnz]; z [R,8,256] fp32 = sum_j p_hj v_j per head.  Key tiles of
  *   16 rows are gathered with whole-row coalesced loads into swizzled LDS tiles, logits and P.V run on bf16 MFMAs (hi / lo split
  *   of the query map and of P: fp32-class on the query side), online softmax.  waves = 1 | 2 | 4 | 8 waves per query (0: default = 2).
+ *   The row arrays are addressed with 32-bit byte offsets: fewer than 2^23 rows (4 GB) each.
  *   Xk_lo / Xv_lo (both or neither, may be NULL): bf16 remainders of the rows (rows = Xk + Xk_lo): the fp32-class key side of the
  *   engine's index-exact validation mode.  Rows without an allowed key: z = NaN (empty_nan = 1) or 0.  dbg_logits (optional): head h at dbg_logits[h*dbg_stride + e],
  *   e in CSR order, WITHOUT the per-(query, head) constant q_h . bk_h that cancels in the softmax.

@@ -212,15 +212,17 @@ __global__ __launch_bounds__(64 * NW, XLO ? 1 : 2) void xattn_tile_kernel(const 
         uint4 kreg[8], vreg[4][2];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int ridx = __shfl(myidx, 2 * i + (lane >> 5), 64);
-            kreg[i] = *reinterpret_cast<const uint4*>(Xk + (long long)ridx * C + (lane & 31) * 8);
+            // (byte offsets as 32-bit unsigned: scalar base + vector offset addressing instead of 64-bit address arithmetic per row;
+            //  the row arrays must stay below 4 GB = 2^23 rows, include/mv2d_hip.h)
+            const unsigned int ridx = (unsigned int)__shfl(myidx, 2 * i + (lane >> 5), 64);
+            kreg[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Xk) + (ridx * (unsigned)(C * 2) + (unsigned)(lane & 31) * 16u));
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int vidx = __shfl(myidx, 4 * g + e, 64);
-            const unsigned short* vp = Xv + (long long)vidx * C + 8 * n;
+            const unsigned int vidx = (unsigned int)__shfl(myidx, 4 * g + e, 64);
+            const char* vp = reinterpret_cast<const char*>(Xv) + (vidx * (unsigned)(C * 2) + 16u * (unsigned)n);
             vreg[e][0] = *reinterpret_cast<const uint4*>(vp);
-            vreg[e][1] = *reinterpret_cast<const uint4*>(vp + 128);
+            vreg[e][1] = *reinterpret_cast<const uint4*>(vp + 256);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
