@@ -359,11 +359,18 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         x_ms = e0.elapsed_time(e1) / 20
-        x_bytes = nnz * 2 * 256 * 2 + R * (16 * 256 * 2 + 8 * 256 * 4)          # K and V rows of every allowed pair (bf16) + Qt in + z out
+        # algorithmic HBM bytes: every key row that some query reads, once (K and V, bf16) + Qt in + z out.  Rows read by several queries
+        # (T path: 2.9 per row) are counted once here — the repeats are L2 / Infinity Cache traffic; `gathered_bytes` counts them all.
+        n_rows = min(nnz, S if kind == 'T' else R * 49)
+        x_bytes = n_rows * 2 * 256 * 2 + R * (16 * 256 * 2 + 8 * 256 * 4)
+        x_gathered = nnz * 2 * 256 * 2 + R * (16 * 256 * 2 + 8 * 256 * 4)
         x_flops = 2.0 * nnz * 8 * 256 * 2                                          # logits + P.V in the 256-dim input space, 8 heads
         xattn = roof('xattn_tile', 'xattn_tile_kernel (sparse cross-attention in the raw key space, one launch per decoder layer)', x_ms, x_flops, x_bytes,
                      launches=eng.L)
-        xattn['note'] = 'bytes = K and V rows gathered per allowed (query, key) pair + Qt in + z out; keys shared by several queries are served by L2 / Infinity Cache'
+        xattn['gathered_bytes_per_launch'] = int(x_gathered)
+        xattn['gathered_gbs'] = round(x_gathered / (x_ms * 1e-3) / 1e9, 1)
+        xattn['note'] = ('bytes_per_launch = K and V rows read by at least one query, once, + Qt in + z out (the HBM lower bound); '
+                         'gathered_bytes_per_launch = the rows of every allowed (query, key) pair (repeats are served by L2 / Infinity Cache)')
         stage_roofline['xattn_tile'] = xattn
     # the dominant kernel = the one with the most time per step (launch duration x launches per step)
     dom = max(stage_roofline, key=lambda k: stage_roofline[k]['launch_ms'] * stage_roofline[k]['launches_per_step'])
