@@ -611,6 +611,9 @@ __global__ __launch_bounds__(1024) void ffn_out_fused_x3_kernel(FfnOutParams p) 
         const long long grow = (long long)min(m, p.M - 1) * C + lane * 4;
         // ---- sum of the slabs (fixed order) + b2 + residual -> LN -> x, xq, post-norm output
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        // bias, residual row and query_pos row are requested together with the slabs (each was a dependent round trip of its own behind them)
+        const float4 t_b2 = *reinterpret_cast<const float4*>(p.b2 + lane * 4), u_res = *reinterpret_cast<const float4*>(p.resid + grow);
+        const float4 qp = *reinterpret_cast<const float4*>(p.qpos + grow);
         {
             // the slabs were just written by other XCDs (they come from the Infinity Cache, ~2 us away): 16 loads in flight per round trip,
             // summed in the fixed order s = 0, 1, 2, ... (bit-identical to mv2d_row_ln)
@@ -636,12 +639,11 @@ __global__ __launch_bounds__(1024) void ffn_out_fused_x3_kernel(FfnOutParams p) 
             }
         }
         {
-            const float4 t = *reinterpret_cast<const float4*>(p.b2 + lane * 4), u = *reinterpret_cast<const float4*>(p.resid + grow);
+            const float4 t = t_b2, u = u_res;
             v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
             v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
         v = ln_row(v, p.lw, p.lb, lane * 4, p.eps);
-        const float4 qp = *reinterpret_cast<const float4*>(p.qpos + grow);
         const float4 vq = make_float4(v.x + qp.x, v.y + qp.y, v.z + qp.z, v.w + qp.w);
         if (m < p.M) {
             *reinterpret_cast<float4*>(p.x_out + grow) = v;
