@@ -42,7 +42,7 @@ class HeadEngine:
     def __init__(self, state_dict, kind, device, num_views=6, topk=None, expand_stride=None, num_layers=L_DEFAULT,
                  max_num=300, pc_range=(-51.2, -51.2, -5.0, 51.2, 51.2, 3.0),
                  post_range=(-61.2, -61.2, -10.0, 61.2, 61.2, 10.0), depth_num=64, stride=16, col_cap_per_query=2048,
-                 iou_thr=0.0, ratio=0.0, masked_row='nan', exact=None):
+                 iou_thr=0.0, ratio=0.0, masked_row='nan', exact=None, num_classes=10):
         assert kind in ('S', 'T')
         self.kind = kind
         self.dev = torch.device(device)
@@ -51,6 +51,8 @@ class HeadEngine:
         self.topk = topk if topk is not None else (1 if kind == 'S' else 20)
         self.expand = float(expand_stride if expand_stride is not None else (0 if kind == 'S' else 2))
         self.max_num = max_num
+        self.num_classes = int(num_classes)
+        assert self.num_classes == 10, 'the fused prediction-branch kernels (mv2d_heads_fused*) are built for 10 classes'
         self.depth_num = depth_num
         self.stride = stride
         self.iou_thr, self.ratio = iou_thr, ratio
@@ -78,6 +80,10 @@ class HeadEngine:
         self._weights_version = 0     # bumped by every load_state(): invalidates whatever was folded from the weights
         self.keep_sine_rows = False   # the training route reads the per-key sine rows (ws['A2']) although the inference kernel does not
         self.force_nc = None          # bench only (S path): overwrite the correlation lists so that every query reads n_c RoIs
+        # tests only (eager runs): keep the pre-softmax per-head logits of every layer's cross attention (out['stages']['dbg_logits']
+        # [L,8,col_cap] in CSR order, WITHOUT the per-(query, head) constant q_h . bk_h that cancels in the softmax) and the scaled,
+        # projected queries ('dbg_q' [L,R,256]) they were computed from
+        self.debug_attn = False
         # out_proj + residual + LayerNorm (+ q in_proj) as one row-fused kernel per attention (8 instead of 11 launches per layer),
         # its two linears in bf16x3 split precision (fp32-class: ~1e-5 relative).  MV2D_ROWS_X3=0: exact-fp32 fused kernel (slower than
         # the unfused launches with one frame in flight); MV2D_FUSE_ROWS=0: separate exact-fp32 GEMM + LN launches.
@@ -85,7 +91,11 @@ class HeadEngine:
         self.fuse_rows = os.environ.get('MV2D_FUSE_ROWS', '1') == '1'
         # self-attention core inside the row-fused kernel: measured SLOWER (decoder 0.357 -> 0.432 ms: the fp32 MFMAs of 152 attention
         # blocks land on 19 CUs) -> off; kept as an ABI entry / A-B switch
-        self.sa_fused = os.environ.get('MV2D_SA_FUSED', '0') == '1'
+        # (round 3: every launch runs on bucket-padded rows / several samples and mv2d_sa_block_fused_x3 takes no grp_start, so the engine
+        #  no longer routes through it at all; the kernel stays an ABI entry with its own kernel-level test)
+        if os.environ.get('MV2D_SA_FUSED', '0') == '1':
+            raise NotImplementedError('MV2D_SA_FUSED: mv2d_sa_block_fused_x3 has no per-sample row ranges (grp_start); the engine runs on bucket-padded rows')
+        self.sa_fused = False
         # EXPERIMENT (off): cross attention on the UNPROJECTED key / value rows (mv2d_raw_xattn_fwd).  The query is mapped into the key
         # input space per head, the K/V projection of all layers and its 90 MB per sample of output disappear; numerically it is at
         # least as good (no bf16 rounding of K).  As implemented it loses 5 % (cfg2_s 5900 vs 6210 samples/s): the attention kernel takes
@@ -245,7 +255,7 @@ class HeadEngine:
     # ------------------------------------------------------------------------------------------ workspace
     def _workspace(self, V, h, w, R, Vg=None):
         """Buffers of one (map shape, R) problem.  The number of RoIs changes from frame to frame in real use, so the STORAGE is
-        allocated once per (map shape, R rounded up to a multiple of 64) and every exact R only gets a dict of dense views into it
+        allocated once per (map shape, R rounded up to a multiple of 32, at least 64) and every exact R only gets a dict of dense views into it
         (kernels index [*, R, *] tensors densely) plus its own hipGraph; staging buffers, calibration cache and the stream-order
         guard are shared by all R of a bucket."""
         Vg = V if Vg is None else Vg                     # views per sample; V = all views of the batch
@@ -490,9 +500,9 @@ class HeadEngine:
         # top-k decode: the kernel sizes its candidate buffer by a power of two >= rows * classes; the launch gets the largest row count
         # of that size class, so that frames with different RoI counts share the launch configuration (and the graph)
         n_pow2 = 1024
-        while n_pow2 < max(grp[b + 1] - grp[b] for b in range(B)) * 10:
+        while n_pow2 < max(grp[b + 1] - grp[b] for b in range(B)) * self.num_classes:
             n_pow2 <<= 1
-        sc['max_rows'] = min(n_pow2 // 10, cap)
+        sc['max_rows'] = min(n_pow2 // self.num_classes, cap)
         sc['cap'] = cap
         return ws, R, sc
 
@@ -634,7 +644,7 @@ class HeadEngine:
         self._enqueue_heads(ws, R, sc['dt'])
         tk('decode')
         # a21: NMS-free decode of the last layer (one top-k per sample)
-        o.decode_topk(ws['cls'][L - 1], ws['reg'][L - 1], R, 10, self.max_num, self.post_range_h, ws['boxes'], ws['scores'],
+        o.decode_topk(ws['cls'][L - 1], ws['reg'][L - 1], R, self.num_classes, self.max_num, self.post_range_h, ws['boxes'], ws['scores'],
                       ws['labels'], ws['bbox_index'], ws['count'], grp_start=grp, max_grp_rows=sc['max_rows'])
         tk('end')
 
@@ -726,14 +736,17 @@ class HeadEngine:
         xk_rows, xv_rows = ws['xk_rows'], ws['xv_rows']
 
         fuse_maps = (R <= 512) if self.fuse_maps is None else self.fuse_maps
-        maps_fused = self.tile_attn and fuse_maps and self.fuse_rows and self.rows_x3 and not self.sa_fused
+        dbg = ws.get('dbg_logits')
+        maps_fused = self.tile_attn and fuse_maps and self.fuse_rows and self.rows_x3 and not self.sa_fused and dbg is None
 
         def cross_attn(i):
             if self.tile_attn:
                 if not maps_fused:
                     o.xattn_qmap(ws['q'], W_[f'ca_mapA{i}'], ws['Qt'], R=R)
+                if dbg is not None:
+                    ws['dbg_q'][i].copy_(ws['q'])
                 o.xattn_tile(ws['Qt'], xk_rows, xv_rows, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=self.empty_nan, waves=self.xattn_waves,
-                             Xk_lo=ws.get('xk_lo'), Xv_lo=ws.get('xv_lo'))
+                             Xk_lo=ws.get('xk_lo'), Xv_lo=ws.get('xv_lo'), dbg_logits=None if dbg is None else dbg[i])
                 if not maps_fused:
                     o.xattn_ctxmap(ws['zh'], W_[f'ca_mapB{i}'], W_[f'ca_v_b{i}'], ws['row_ptr'], ws['ctx'], R, empty_nan=self.empty_nan)
                 return
@@ -835,7 +848,7 @@ class HeadEngine:
             # copies of the intermediate buffers restricted to the REAL rows (the launches run on the bucket size, see _host_prepare)
             rows0 = ('rois', 'minv', 'enc', 'roi_feat', 'center', 'xyz', 'ref', 'posemb', 'qpos', 'match')
             st = {}
-            for kk in rows0 + ('roi_mask', 'pos2s', 's2pos', 'S_dev', 'col_idx', 'pe', 'Xk', 'Xf_b', 'KV'):
+            for kk in rows0 + ('roi_mask', 'pos2s', 's2pos', 'S_dev', 'col_idx', 'pe', 'Xk', 'Xf_b', 'KV', 'dbg_logits', 'dbg_q'):
                 if ws.get(kk) is not None:
                     st[kk] = (ws[kk][:R] if kk in rows0 else ws[kk]).clone()
             for kk in ('outs', 'cls', 'reg'):
@@ -879,13 +892,20 @@ class HeadEngine:
         ws, R, sc = self._host_prepare(proposals_list, metas_list, V, h, w)
         self._stage_outputs = bool(keep_stages)          # intermediate buffers nothing downstream reads (pe on the T path, Xk on the S path)
         Rc = sc['cap']                     # launches run on the bucket size; R = the real rows
+        if self.debug_attn:
+            assert self.tile_attn and not use_graph, 'debug_attn: eager runs on the tile cross-attention route'
+            ws['dbg_logits'] = torch.zeros((self.L, 8, ws['col_cap']), device=self.dev, dtype=F32)
+            ws['dbg_q'] = torch.zeros((self.L, Rc, C), device=self.dev, dtype=F32)
+        else:
+            ws.pop('dbg_logits', None); ws.pop('dbg_q', None)
         if not use_graph or self.exact:
             self._enqueue(ws, feat, Rc, V, h, w, sc)
             self._mark_done(ws)
             return dict(self._result(ws, R, keep_stages, batch), dt=sc['dt'])
         # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
-        gkey = (ptrs, sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs, self.last_stage_heads)   # load_state() re-allocates the weights
+        gkey = (ptrs, sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs, self.last_stage_heads,
+                self.xattn_waves, self.fuse_maps, self.keep_sine_rows, self.keep_xk, self.ffn_groups, self.force_nc)   # load_state() re-allocates the weights
         graphs = ws.setdefault('graphs', {})             # one graph per (input buffers, frame scalars): a producer that alternates between
         g = graphs.get(gkey)                             # a few static output buffers replays a few graphs, it does not re-capture
         if ws.pop('graph_stale', False):

@@ -217,7 +217,7 @@ class MV2DHead(nn.Module):
                                       expand_stride=bc.expand_stride, num_layers=self.bbox_head.num_pred, max_num=coder.max_num,
                                       pc_range=tuple(self.pc_range), post_range=tuple(coder.post_center_range),
                                       depth_num=self.position_encoding.depth_num, stride=self.strides[self.feat_lvl],
-                                      iou_thr=bc.iou_thr, ratio=bc.ratio,
+                                      iou_thr=bc.iou_thr, ratio=bc.ratio, num_classes=self.bbox_head.num_classes,
                                       masked_row=(self.test_cfg or {}).get('masked_row', 'nan'))
             self._engine_ver = ver
         return self._engine

@@ -26,11 +26,25 @@ def process_2d_detections(results, device, min_bbox_size=0):
     return dets
 
 
+_NMS_WARNED = [False]
+
+
+def _warn_unpinned_nms():
+    # mmcv 1.6.1's nms_bev is absent from the reference tree: the rotated-IoU suppression is pinned against this repo's oracle only
+    # (DESIGN.md section 7.1 f1).  Every shipped config uses nms_thr = 1.0 and never gets here.
+    if not _NMS_WARNED[0]:
+        import warnings
+        warnings.warn('mv2d_amd: nms_thr < 1 runs mv2d_nms_bev, whose parity with mmcv 1.6.1 nms_bev is not pinned by a reference-side golden '
+                      '(no shipped MV2D config sets nms_thr < 1)', RuntimeWarning)
+        _NMS_WARNED[0] = True
+
+
 def pack_results(boxes, scores, labels, count, score_thr=0.0, max_per_scene=300, nms_thr=1.0):
     """boxes [n,9], scores [n], labels [n] (device, first *count valid) -> dict(boxes_3d, scores_3d, labels_3d) on the host
     (mmdet3d bbox3d2result), ordered like box3d_multiclass_nms.  nms_thr < 1: rotated BEV suppression per class first (mv2d_nms_bev)."""
     dev = boxes.device
     if float(nms_thr) < 1.0:
+        _warn_unpinned_nms()
         scores = ops.nms_bev(boxes, scores, labels, count, nms_thr)
     ob = torch.zeros((max_per_scene, 9), device=dev)
     os_ = torch.zeros(max_per_scene, device=dev)
@@ -46,6 +60,7 @@ def pack_results_batch(boxes, scores, labels, count, score_thr=0.0, max_per_scen
     synchronisation for the whole batch."""
     dev, B = boxes.device, count.numel()
     if float(nms_thr) < 1.0:
+        _warn_unpinned_nms()
         scores = ops.nms_bev(boxes, scores, labels, count, nms_thr, n_samples=B)
     ob = torch.zeros((B, max_per_scene, 9), device=dev)
     os_ = torch.zeros((B, max_per_scene), device=dev)

@@ -28,7 +28,7 @@ def _rng(seed):
     return np.random.Generator(np.random.PCG64(seed))
 
 
-def make_img_metas(views_per_frame, img_h, img_w, frames=1, pad_w=None, pad_h=None, yaw_step_deg=None, ego=0.0):
+def make_img_metas(views_per_frame, img_h, img_w, frames=1, pad_w=None, pad_h=None, yaw_step_deg=None, ego=0.0, baseline=0.0):
     """Return a list of per-view img_meta dicts (len = views_per_frame*frames).  ego: extra ego motion between the frames (metres along
     the driving direction) and time-stamp jitter of the previous frame -- every real two-frame sample has its own."""
     pad_w = img_w if pad_w is None else pad_w
@@ -51,7 +51,7 @@ def make_img_metas(views_per_frame, img_h, img_w, frames=1, pad_w=None, pad_h=No
             Rz = np.array([[c, s, 0], [-s, c, 0], [0, 0, 1]], dtype=np.float64)
             T = np.eye(4, dtype=np.float64)
             T[:3, :3] = R0 @ Rz
-            T[:3, 3] = [0.0, 1.5, -0.5 - (0.4 + ego) * f]
+            T[:3, 3] = [baseline * v, 1.5, -0.5 - (0.4 + ego) * f]
             metas.append(dict(
                 intrinsics=K,
                 extrinsics=T.T.copy(),
@@ -201,7 +201,12 @@ WORKLOADS = {
     'cfg2_s': ('S', 6, 1, 512, 1408, None, 50),
     'cfg3_t': ('T', 6, 2, 512, 1408, None, 25),
     'cfg5_t': ('T', 6, 2, 640, 1600, None, 75),
+    # S path with MANY correlated RoIs per query (the n_c sweep): six cameras 8 degrees apart with a lateral baseline, so that
+    # every view overlaps every other one and the reference's epipolar correlation (top-1 per other view) yields up to 1 + 5 RoIs per query
+    'nc6_s': ('S', 6, 1, 224, 400, 416, 14),
 }
+# rigs that are not a full ring: yaw step in degrees and lateral camera spacing in metres
+RIG = {'nc6_s': (8.0, 0.35)}
 
 
 def make_problem(name, seed=0, with_feat=True, ego=0.0):
@@ -210,7 +215,8 @@ def make_problem(name, seed=0, with_feat=True, ego=0.0):
     kind, vpf, frames, H, W, pad_w, n = WORKLOADS[name]
     pw = W if pad_w is None else pad_w
     V = vpf * frames
-    metas = make_img_metas(vpf, H, W, frames, pad_w=pw, yaw_step_deg=(40.0 if vpf < 6 else None), ego=ego)
+    yaw, base = RIG.get(name, ((40.0 if vpf < 6 else None), 0.0))
+    metas = make_img_metas(vpf, H, W, frames, pad_w=pw, yaw_step_deg=yaw, ego=ego, baseline=base)
     props = make_proposals(V, n, H, W, seed + 1)
     feat = make_feat(V, H // 16, pw // 16, seed + 2) if with_feat else None
     return dict(kind=kind, feat=feat, proposals=props, img_metas=metas, name=name,

@@ -1,0 +1,107 @@
+"""Golden cross-attention logits / attention weights of the UNMODIFIED reference on the allowed (query, key) pairs (build container only).
+
+    python -B -m oracle.gen_golden_logits        # writes tests/golden/attn_pairs.npz
+
+`north_star` states the floating-point tolerance of the hot path on the ATTENTION LOGITS ("bf16 attention logits within 1e-2 rel").
+tests/golden/micro_t.npz holds the dense per-head layer-0 logits of the micro problem; this script adds the same quantity at
+BASELINE.json's configs[0] (both heads), at configs[1] (the headline, S head), at configs[2] (T head) and on the many-correlated-RoIs S
+problem `nc6_s`, stored for the allowed pairs only (the big cases: of every 2nd / 4th query) so that the fixture stays small:
+
+  <case>/pairs    int32 [nnz,2]   (query, key) of every allowed pair, query-major, keys ascending.  T head: key = index into the gathered
+                                  key list (row-major (view, y, x) order of the reference's boolean indexing, RH/mv2d_t_head.py:84-88);
+                                  S head: key = slot * 49 + cell of the query's own [n_c * 49] key list (RH/mv2d_s_head.py:184-192)
+  <case>/logits   fp32 [8,nnz]    pre-softmax per-head logits of decoder layer 0: (q_h / sqrt(32)) . k_h with the module's own in_proj
+                                  (MU/petr_transformer.py:501-508 -> torch.nn.MultiheadAttention), recomputed from the hooked inputs
+  <case>/attn     fp32 [L,nnz]   head-averaged post-softmax weights of every layer = the module's second return value
+
+The fixture is DATA (reference outputs); inputs are regenerated from seeds by mv2d_amd.synthetic.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from mv2d_amd import synthetic  # noqa: E402
+from oracle import _stubs  # noqa: E402
+from oracle.gen_golden import build_reference_head  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden', 'attn_pairs.npz')
+CASES = ['cfg1_t', 'cfg1_s', 'micro_s', 'cfg2_s', 'cfg3_t', 'nc6_s']
+QUERY_STEP = {'cfg2_s': 2, 'cfg3_t': 4, 'nc6_s': 2}
+
+
+def run_case(head, kind, prob):
+    bh = head.bbox_head
+    layers = bh.transformer.decoder.layers
+    attn_w, cross_in, masks = [], [], {}
+    hooks = []
+    for layer in layers:
+        hooks.append(layer.attentions[1].attn.register_forward_hook(lambda m, inp, out: attn_w.append(out[1].detach().clone())))
+    l0 = layers[0].attentions[1].attn
+
+    def pre_hook(m, args, kwargs):
+        cross_in.append((kwargs['query'].detach().clone(), kwargs['key'].detach().clone(),
+                         None if kwargs.get('attn_mask') is None else kwargs['attn_mask'].detach().clone(),
+                         None if kwargs.get('key_padding_mask') is None else kwargs['key_padding_mask'].detach().clone()))
+    hooks.append(l0.register_forward_pre_hook(pre_hook, with_kwargs=True))
+    metas = [dict(m, box_type_3d=(lambda b, d: b)) for m in prob['img_metas']]
+    with torch.no_grad():
+        head.simple_test([torch.from_numpy(prob['feat'])], [torch.from_numpy(p) for p in prob['proposals']], metas)
+    for h in hooks:
+        h.remove()
+    q_in, k_in, attn_mask, kpm = cross_in[0]
+    C = 256
+    W, b = l0.in_proj_weight, l0.in_proj_bias
+    if kind == 'T':
+        # query [R,1,C], key [S,1,C]; attn_mask [R,S] bool (True = blocked), key_padding_mask [1,S]
+        q = torch.nn.functional.linear(q_in[:, 0], W[:C], b[:C]).view(-1, 8, 32).transpose(0, 1) / (32 ** 0.5)
+        k = torch.nn.functional.linear(k_in[:, 0], W[C:2 * C], b[C:2 * C]).view(-1, 8, 32).transpose(0, 1)
+        logits = torch.bmm(q, k.transpose(1, 2)).detach()                                   # [8,R,S]
+        am = attn_mask
+        if am.dim() == 3:
+            am = am[0]
+        allowed = ~am.bool()
+        if kpm is not None:
+            allowed = allowed & ~kpm[0].bool()[None]
+        w = torch.stack([a[0] for a in attn_w])                                    # [L,R,S]
+    else:
+        # query [1,R,C], key [n_c*49,R,C]; key_padding_mask [R, n_c*49] (True = padding slot)
+        q = torch.nn.functional.linear(q_in[0], W[:C], b[:C]).view(-1, 8, 32) / (32 ** 0.5)            # [R,8,32]
+        k = torch.nn.functional.linear(k_in, W[C:2 * C], b[C:2 * C]).view(k_in.shape[0], -1, 8, 32)    # [K,R,8,32]
+        logits = torch.einsum("rhd,krhd->hrk", q, k).detach()                               # [8,R,K]
+        allowed = ~kpm.bool()
+        w = torch.stack([a[:, 0] for a in attn_w])                                 # [L,R,K]  (bs = R, one query each)
+    pairs = allowed.nonzero().to(torch.int32)                                      # query-major, keys ascending
+    r_, k_ = pairs[:, 0].long(), pairs[:, 1].long()
+    blocked_w = float(w[:, ~allowed].abs().max()) if (~allowed).any() else 0.0
+    assert blocked_w == 0.0, blocked_w                                             # the weights of blocked pairs are exactly zero
+    return dict(pairs=pairs.numpy(), logits=logits[:, r_, k_].numpy().astype(np.float32), attn=w[:, r_, k_].numpy().astype(np.float32))
+
+
+def main():
+    S_cls, T_cls = _stubs.install('/root/reference')
+    torch.set_num_threads(8)
+    sd_np = synthetic.make_head_state(seed=0)
+    rec = {}
+    for name in CASES:
+        prob = synthetic.make_problem(name, seed=0)
+        head = build_reference_head(prob['kind'], S_cls, T_cls, sd_np, prob['views_per_frame'])
+        r = run_case(head, prob['kind'], prob)
+        step = QUERY_STEP.get(name, 1)            # the big cases keep every step-th query (all of its pairs)
+        if step > 1:
+            keep = r['pairs'][:, 0] % step == 0
+            r = dict(pairs=r['pairs'][keep], logits=r['logits'][:, keep], attn=r['attn'][:, keep])
+        for k, v in r.items():
+            rec[f'{name}/{k}'] = v
+        print(name, {k: v.shape for k, v in r.items()}, 'max |logit|', float(np.abs(r['logits']).max()))
+    np.savez_compressed(OUT, **rec)
+    print('bytes:', os.path.getsize(OUT))
+
+
+if __name__ == '__main__':
+    main()

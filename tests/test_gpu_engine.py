@@ -104,7 +104,7 @@ def eng_metas(name):
     return synthetic.make_problem(name, seed=0)['img_metas']
 
 
-@pytest.mark.parametrize('name', ['micro_s', 'cfg1_s', 'cfg2_s'])
+@pytest.mark.parametrize('name', ['micro_s', 'cfg1_s', 'cfg2_s', 'nc6_s'])
 def test_engine_s_path(name):
     eng, out, st = run_both(name)
     s = out['stages']

@@ -539,7 +539,7 @@ def test_box_params_roialign_refpoint(dev, name):
         assert torch.equal(outb, out.to(torch.bfloat16))
 
 
-@pytest.mark.parametrize('name,topk,expand', [('micro_t', 20, 2), ('cfg1_t', 20, 2), ('cfg1_s', 1, 0), ('cfg3_t', 20, 2), ('cfg2_s', 1, 0)])
+@pytest.mark.parametrize('name,topk,expand', [('micro_t', 20, 2), ('cfg1_t', 20, 2), ('cfg1_s', 1, 0), ('cfg3_t', 20, 2), ('cfg2_s', 1, 0), ('nc6_s', 1, 0)])
 def test_box_correlation_and_csr_bit_exact(dev, name, topk, expand):
     from mv2d_amd import calib, ops
     from oracle import mv2d_oracle as O

@@ -81,7 +81,7 @@ def test_t_path_matches_reference(name):
             close(cap[l]['attn_mean'], g['attn_mean'][l], 1e-4)
 
 
-@pytest.mark.parametrize('name', ['micro_s', 'cfg1_s', 'cfg2_s'])
+@pytest.mark.parametrize('name', ['micro_s', 'cfg1_s', 'cfg2_s', 'nc6_s'])      # nc6_s: up to 6 correlated RoIs per query
 def test_s_path_matches_reference(name):
     g = load_golden(name)
     st = run(name)
@@ -177,3 +177,19 @@ def test_prepare_for_dn_matches_reference(name):
     assert np.array_equal(np.packbits(attn_mask.numpy()), TRAIN[name + '.attn_mask'])
     assert np.array_equal(kl.numpy(), TRAIN[name + '.known_labels']) and np.array_equal(kb.numpy(), TRAIN[name + '.known_bboxs'], equal_nan=True)
     assert np.array_equal(TRAIN[name + '.map_known_indice'], np.arange(pad))
+
+
+@pytest.mark.parametrize('name', ['cfg1_t'])
+def test_oracle_logits_on_allowed_pairs(name):
+    """The oracle's layer-0 cross-attention logits / head-averaged weights against tests/golden/attn_pairs.npz (reference outputs on the
+    allowed pairs, oracle/gen_golden_logits.py)."""
+    ap = load_golden('attn_pairs')
+    st = run(name)
+    pairs = ap[f'{name}/pairs']
+    rr, kk = pairs[:, 0], pairs[:, 1]
+    allowed = ~st['blocked'].numpy()
+    np.testing.assert_array_equal(np.stack(np.nonzero(allowed), 1), pairs)
+    cap = st['capture']
+    close(cap[0]['logits'].numpy()[:, rr, kk], ap[f'{name}/logits'], 1e-4)
+    for l in range(6):
+        close(cap[l]['attn_mean'].numpy()[rr, kk], ap[f'{name}/attn'][l], 1e-4)
