@@ -153,6 +153,17 @@ int mv2d_heads_fused(const float* outs, const float* const* cls_w, const float* 
 int mv2d_linear_x3(const float* A, const float* A2, int n_split, int lda, const void* Whi, const void* Wlo, const float* bias,
                    float* C, int ldc, int M, int N, int K, int act, float clamp, int groups, long long a_gs, long long w_gs,
                    long long b_gs, long long c_gs, void* stream);
+/* mv2d_linear_x3 with the operands the engine's index-exact route needs (MU/pe.py:36-48,64-77,150-166 and the QueryGenerator conv,
+ * RH/utils/query_generator.py:298-304, all in fp32-class arithmetic without a host synchronisation): m_dev = device-side row count
+ * (rows >= *m_dev are skipped; NULL: M), conv3x3 = 1: A is [R,49,256] RoI cells and C = conv3x3(A) as an implicit GEMM (K = 2304 =
+ * [tap][cin], zero padding, M = 49 R), act 2 = sigmoid, then C = C * mul + add with optional fp32 operands [M, ld_ma]. */
+int mv2d_linear_x3_ex(const float* A, const float* A2, int n_split, int lda, const void* Whi, const void* Wlo, const float* bias,
+                      float* C, int ldc, int M, int N, int K, int act, float clamp, int groups, long long a_gs, long long w_gs,
+                      long long b_gs, long long c_gs, const int* m_dev, int conv3x3, const float* mul, const float* add, int ld_ma,
+                      void* stream);
+/* (hi, lo) bf16 pair of every element of a (+ b, optional): hi = bf16(x), lo = bf16(x - hi); a, b fp32 [M, cols]; rows >= *m_dev
+ * (optional) are not written.  The key / value rows of the index-exact route (key = feat + pe, value = feat). */
+int mv2d_split_rows_bf16x2(const float* a, const float* b, void* hi, void* lo, int M, int cols, const int* m_dev, void* stream);
 
 /* The same branches with their four 256x256 linears per (layer, branch) in split precision (bf16x3, ~1e-5 relative; the 256 -> 10
  * output layers stay exact fp32).  cls_w = {w0_hi,w0_lo,b0,ln1w,ln1b,w3_hi,w3_lo,b3,ln4w,ln4b,w6,b6}, reg_w = {w0_hi,w0_lo,b0,w2_hi,

@@ -38,6 +38,8 @@ SIGNATURES = {
     'mv2d_pack_wfrag_f32': (I, [P, P, I, I, I, P]),
     'mv2d_heads_fused': (I, [P, P, P, P, P, P, I, I, F, P, F, P, P]),
     'mv2d_linear_x3': (I, [P, P, I, I, P, P, P, P, I, I, I, I, I, F, I, LL, LL, LL, LL, P]),
+    'mv2d_linear_x3_ex': (I, [P, P, I, I, P, P, P, P, I, I, I, I, I, F, I, LL, LL, LL, LL, P, I, P, P, I, P]),
+    'mv2d_split_rows_bf16x2': (I, [P, P, P, P, I, I, P, P]),
     'mv2d_heads_fused_x3': (I, [P, P, P, P, P, P, I, I, F, P, F, P, P]),
     'mv2d_ffn_fused': (I, [P, P, P, P, P, I, I, P]),
     'mv2d_ffn_pack_weights': (I, [P, P, P, P, I, P]),

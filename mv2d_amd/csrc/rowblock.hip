@@ -920,6 +920,10 @@ struct LinX3Params {
     const float* A; const float* A2; int n_split; int lda; const unsigned short* Wh; const unsigned short* Wl; const float* bias;
     float* C; int ldc; int M, N, K; int act; float clamp;
     long long a_gs, w_gs, b_gs, c_gs;       // element strides between the groups of a batched call (blockIdx.z = group)
+    // extensions (mv2d_linear_x3_ex; the index-exact route of the engine): device-side row count, implicit 3x3 convolution over
+    // [R,49,256] RoI cells (chunk c of K = 2304 is tap c: the A row of (RoI, cell) is the neighbouring cell's 256 channels or zero),
+    // sigmoid (act == 2), C = v * mul + add with fp32 operands [M, ld_ma]
+    const int* m_dev; int conv3x3; const float* mul; const float* add; int ld_ma;
 };
 
 template <int RT>
@@ -934,6 +938,10 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinX3Params p) {
     __shared__ __attribute__((aligned(16))) unsigned char ah[2][RT * 16 * 512], al[2][RT * 16 * 512];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int mb = blockIdx.y * (16 * RT), n0 = blockIdx.x * 128;
+    if (p.m_dev) {                                                              // device-side M (block-uniform exit before any barrier)
+        p.M = min(p.M, *p.m_dev);
+        if (mb >= p.M) return;
+    }
     const int ntile = p.N >> 4, tile = min((n0 >> 4) + wave, ntile - 1);       // clamped: the extra waves of a ragged last block recompute
     const float* A = (p.n_split > 0 && n0 >= p.n_split) ? p.A2 : p.A;
     const int nchunk = (p.K + 255) >> 8;
@@ -944,6 +952,13 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinX3Params p) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int idx = tid + 512 * i, row = idx >> 6, q = idx & 63, k = 256 * c + 4 * q;
+            if (p.conv3x3) {
+                const int m = min(mb + row, p.M - 1), r = m / 49, cell = m - 49 * r;
+                const int yy = cell / 7 + c / 3 - 1, xx = cell % 7 + c % 3 - 1;
+                ar[i] = (yy >= 0 && yy < 7 && xx >= 0 && xx < 7) ? *reinterpret_cast<const float4*>(A + ((long long)r * 49 + yy * 7 + xx) * 256 + 4 * q)
+                                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                continue;
+            }
             ar[i] = k < p.K ? *reinterpret_cast<const float4*>(A + (long long)min(mb + row, p.M - 1) * p.lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -1015,9 +1030,25 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinX3Params p) {
             if (m >= p.M) continue;
             float v = (a0[t][r] + a1[t][r]) + b;
             if (p.act == 1) v = relu_f(v);
+            else if (p.act == 2) v = 1.f / (1.f + expf(-v));
             if (p.clamp > 0.f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
+            if (p.mul) v = v * p.mul[(long long)m * p.ld_ma + col];
+            if (p.add) v = v + p.add[(long long)m * p.ld_ma + col];
             p.C[(long long)m * p.ldc + col] = v;
         }
+}
+
+// (hi, lo) bf16 rows of a (+ b): the key / value rows of the index-exact route.  n4 = number of float4; rows beyond *m_dev are skipped.
+__global__ void split_rows_kernel(const float4* __restrict__ a, const float4* __restrict__ b, uint2* __restrict__ hi, uint2* __restrict__ lo,
+                                  long long n4, const int* __restrict__ m_dev, int row4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4 || (m_dev && i >= (long long)*m_dev * row4)) return;
+    float4 v = a[i];
+    if (b) { const float4 w = b[i]; v = make_float4(v.x + w.x, v.y + w.y, v.z + w.z, v.w + w.w); }
+    uint2 h, l;
+    split4(v, h, l);
+    hi[i] = h;
+    lo[i] = l;
 }
 
 // The prediction branches in split precision (bf16x3): same chain as heads_fused_kernel with the four 256x256 linears of a
@@ -1296,17 +1327,44 @@ extern "C" int mv2d_heads_fused_x3(const float* outs, const void* const* cls_w, 
     return MV2D_OK;
 }
 
+extern "C" int mv2d_linear_x3_ex(const float* A, const float* A2, int n_split, int lda, const void* Whi, const void* Wlo, const float* bias,
+                                 float* C, int ldc, int M, int N, int K, int act, float clamp, int groups, long long a_gs, long long w_gs,
+                                 long long b_gs, long long c_gs, const int* m_dev, int conv3x3, const float* mul, const float* add, int ld_ma,
+                                 void* stream);
+
 extern "C" int mv2d_linear_x3(const float* A, const float* A2, int n_split, int lda, const void* Whi, const void* Wlo, const float* bias,
                               float* C, int ldc, int M, int N, int K, int act, float clamp, int groups, long long a_gs, long long w_gs,
                               long long b_gs, long long c_gs, void* stream) {
+    return mv2d_linear_x3_ex(A, A2, n_split, lda, Whi, Wlo, bias, C, ldc, M, N, K, act, clamp, groups, a_gs, w_gs, b_gs, c_gs, nullptr, 0,
+                             nullptr, nullptr, 0, stream);
+}
+
+extern "C" int mv2d_split_rows_bf16x2(const float* a, const float* b, void* hi, void* lo, int M, int cols, const int* m_dev, void* stream) {
+    MV2D_CHECK_ARG(a && hi && lo && M >= 0 && cols > 0 && (cols % 4) == 0, "mv2d_split_rows_bf16x2: bad args (cols % 4 == 0)");
+    MV2D_CHECK_ARG(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 && ((uintptr_t)hi & 7) == 0 && ((uintptr_t)lo & 7) == 0,
+                   "mv2d_split_rows_bf16x2: operands must be 16-byte aligned");
+    if (M == 0) return MV2D_OK;
+    const long long n4 = (long long)M * (cols / 4);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const float4*)b,
+                       (uint2*)hi, (uint2*)lo, n4, m_dev, cols / 4);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_linear_x3_ex(const float* A, const float* A2, int n_split, int lda, const void* Whi, const void* Wlo, const float* bias,
+                                 float* C, int ldc, int M, int N, int K, int act, float clamp, int groups, long long a_gs, long long w_gs,
+                                 long long b_gs, long long c_gs, const int* m_dev, int conv3x3, const float* mul, const float* add, int ld_ma,
+                                 void* stream) {
     MV2D_CHECK_ARG(A && Whi && Wlo && C, "mv2d_linear_x3: null pointer");
+    MV2D_CHECK_ARG(!conv3x3 || (K == 2304 && n_split == 0 && groups == 1), "mv2d_linear_x3_ex: conv3x3 reads [R,49,256] cells, K = 9 * 256");
+    MV2D_CHECK_ARG((!mul && !add) || ld_ma >= N, "mv2d_linear_x3_ex: ld_ma < N");
     MV2D_CHECK_ARG(M >= 0 && N > 0 && (N % 16) == 0 && K > 0 && (K % 32) == 0, "mv2d_linear_x3: N % 16 == 0 and K % 32 == 0 required");
     MV2D_CHECK_ARG((lda % 4) == 0 && lda >= K && ldc >= N && ((uintptr_t)A & 15) == 0, "mv2d_linear_x3: A rows must be 16-byte aligned");
     MV2D_CHECK_ARG(n_split == 0 || (A2 && (n_split % 128) == 0 && ((uintptr_t)A2 & 15) == 0), "mv2d_linear_x3: n_split must be a multiple of 128 with A2 set");
     MV2D_CHECK_ARG(groups >= 1 && (groups == 1 || ((a_gs % 4) == 0 && (w_gs % 8) == 0)), "mv2d_linear_x3: group strides must keep 16-byte alignment");
     if (M == 0) return MV2D_OK;
     LinX3Params p{A, A2, n_split, lda, (const unsigned short*)Whi, (const unsigned short*)Wlo, bias, C, ldc, M, N, K, act, clamp,
-                  a_gs, w_gs, b_gs, c_gs};
+                  a_gs, w_gs, b_gs, c_gs, m_dev, conv3x3, mul, add, ld_ma};
     if (M <= 512) hipLaunchKernelGGL(linear_x3_kernel<1>, dim3(cdiv(N, 128), cdiv(M, 16), groups), dim3(512), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(linear_x3_kernel<2>, dim3(cdiv(N, 128), cdiv(M, 32), groups), dim3(512), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();

@@ -131,8 +131,8 @@ class HeadEngine:
         # INDEX-EXACT VALIDATION MODE (exact=True / MV2D_EXACT=1): every bf16 rounding of the default path is replaced by fp32-class
         # arithmetic -- PE MLPs and the query generator's conv in bf16x3 / exact-fp32 MFMA GEMMs on unrounded inputs, key / value rows as
         # bf16 hi + lo pairs in the tile attention -- so that the INTEGER outputs (labels, bbox_index) can be compared bit for bit with
-        # the reference's (tests/test_gpu_golden.py).  Eager only (device-side counts are read back, buffers allocated per frame), several
-        # times slower: a checker for the default path's near-tie reorderings, not a deployment mode.
+        # the reference's (tests/test_gpu_golden.py).  Round 3: no host synchronisation, no per-frame allocation, no torch glue -- the
+        # route is enqueue-only and hipGraph-replayable like the default one (bench.py: samples_s_index_exact).
         self.exact = (os.environ.get('MV2D_EXACT', '0') == '1') if exact is None else bool(exact)
         if self.exact:
             assert self.tile_attn, 'the exact mode runs on the tile cross-attention route'
@@ -230,10 +230,8 @@ class HeadEngine:
         if self.exact:
             for n_, k_ in (('w1a', 'position_encoder.0'), ('w1b', 'position_encoder.2'), ('w2a', 'adapt_pos3d.0'), ('w2b', 'adapt_pos3d.2'),
                            ('wr', 'fpe.conv_reduce'), ('we', 'fpe.conv_expand')):
-                w['pe_' + n_ + '_hl'] = ops.split_bf16x2(c1(k_ + '.weight').contiguous())
                 w['pe_' + n_ + '_x3'] = ops.pack_x3(c1(k_ + '.weight').contiguous())
-            w['qg_conv_w32'] = conv.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous()
-            w['qg_conv_wx3'] = ops.pack_x3(w['qg_conv_w32'])
+            w['qg_conv_wx3'] = ops.pack_x3(conv.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous())
         self.w = w
         for k in ('cls_w0', 'cls_w3', 'reg_w0', 'reg_w2'):                              # [L,256,256] -> fragment-major copies for heads_fused
             w[k + 'p'] = ops.pack_wfrag_f32(w[k])
@@ -349,7 +347,19 @@ class HeadEngine:
         ws['col_idx'] = e(ws['col_cap'], torch.int32)
         ws['A1'] = e((P, 3 * self.depth_num), BF16); ws['A2'] = e((P, 384), BF16)
         ws['Xf_b'] = e((P, C), BF16)
-        ws['Xf32'] = None if self.pe_fused else e((P, C))      # the fused PE kernel reads the feature rows from the map itself
+        ws['Xf32'] = None if (self.pe_fused and not self.exact) else e((P, C))      # the fused PE kernel reads the feature rows from the map itself
+        if self.exact:
+            # index-exact route: unrounded fp32 operands of the PE block (frustum / sine inputs, hidden layers, gate, sine branch), the fp32
+            # RoIAlign outputs, the lo halves of the key / value rows, the conv output before pooling -- all pre-allocated (no per-frame
+            # allocation, no host synchronisation: the route is graph-replayable like the default one)
+            ws['xa1'] = e((P, 3 * self.depth_num)); ws['xa2'] = e((P, 384)); ws['xh'] = e((P, 4 * C))
+            ws['xg'] = e((P, C)); ws['xgate'] = e((P, C)); ws['xp2'] = e((P, C))
+            ws['roi_feat32'] = e((R, 49, C)); ws['convy'] = e((R * 49, C))
+            if self.kind == 'T':
+                ws['xk_lo'] = z((P, C), BF16); ws['xv_lo'] = z((P, C), BF16)
+            else:
+                ws['roi_pe32'] = e((R, 49, C))
+                ws['xk_lo'] = z((R * 49, C), BF16); ws['xv_lo'] = z((R * 49, C), BF16)
         if not self.pe_fused:                                    # intermediates of the six-GEMM PE route only
             ws['H1'] = e((P, 4 * C), BF16); ws['H2'] = e((P, 4 * C), BF16); ws['Hg'] = e((P, C), BF16)
             ws['gate'] = e((P, C)); ws['Pg'] = e((P, C))
@@ -561,8 +571,6 @@ class HeadEngine:
                            self.stride, self.expand, col_cap=ws['col_cap'], n_samples=B)
             if not forked:
                 tk('roi_align')
-                if self.exact:
-                    ws['roi_feat32'] = torch.empty((R, 49, C), device=self.dev, dtype=F32)
                 o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'], out0_f32=ws.get('roi_feat32') if self.exact else None, R=R)
         else:
             # positions any RoIAlign tap can touch (own rect + 1 cell) -> PE only there
@@ -583,9 +591,10 @@ class HeadEngine:
             o.csr_from_corr(ws['match'], ws['row_ptr'], ws['col_idx'], ws['nnz'], R, Vg, self.topk)
         tk('pe_inputs')
         # a2: PE at the listed positions (3 two-layer MLPs on bf16 MFMA)
-        o.pe_inputs(ws['s2pos'], ws['S_dev'], P, featcl, T['img2lidar'], T['coords_w'], T['coords_h'], T['coords_d'], T['embeds'],
-                    self.const['dim_t'], ws['A1'], None if (self.pe_sine_table and not self.keep_sine_rows) else ws['A2'], ws['Xf_b'], ws['Xf32'],
-                    V, h, w, self.depth_num, self.post_range_h64)
+        if not self.exact:                       # (the exact route requests the fp32 rows as well: _exact_pe)
+            o.pe_inputs(ws['s2pos'], ws['S_dev'], P, featcl, T['img2lidar'], T['coords_w'], T['coords_h'], T['coords_d'], T['embeds'],
+                        self.const['dim_t'], ws['A1'], None if (self.pe_sine_table and not self.keep_sine_rows) else ws['A2'], ws['Xf_b'], ws['Xf32'],
+                        V, h, w, self.depth_num, self.post_range_h64)
         md = ws['S_dev']
         tk('pe_fused')
         if self.exact:
@@ -610,15 +619,12 @@ class HeadEngine:
         if self.kind == 'S':
             tk('roi_align')
             if self.exact:
-                ws['roi_feat32'] = torch.empty((R, 49, C), device=self.dev, dtype=F32)
-                pe32 = torch.empty((R, 49, C), device=self.dev, dtype=F32)
-                o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], out0_f32=ws['roi_feat32'], out1_f32=pe32,
-                            map1_index=ws['pos2s'], out1_is_sum=True, R=R)
+                o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], out0_f32=ws['roi_feat32'],
+                            out1_f32=ws['roi_pe32'], map1_index=ws['pos2s'], out1_is_sum=True, R=R)
                 # key rows = RoIAlign(feat) + RoIAlign(pe), value rows = RoIAlign(feat): bf16 hi + lo pairs
-                ks, kl = o.split_bf16x2((ws['roi_feat32'] + pe32).view(R * 49, C))
-                vs, vl = o.split_bf16x2(ws['roi_feat32'].view(R * 49, C))
-                ws['roi_sum'].view(R * 49, C).copy_(ks); ws['roi_feat'].view(R * 49, C).copy_(vs)
-                ws['xk_lo'], ws['xv_lo'] = kl, vl
+                f32_, p32_ = ws['roi_feat32'].view(R * 49, C), ws['roi_pe32'].view(R * 49, C)
+                o.split_rows(f32_, p32_, hi=ws['roi_sum'].view(R * 49, C), lo=ws['xk_lo'])
+                o.split_rows(f32_, None, hi=ws['roi_feat'].view(R * 49, C), lo=ws['xv_lo'])
             else:
                 o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=ws['pos2s'],
                             out1_is_sum=True, R=R)
@@ -649,35 +655,24 @@ class HeadEngine:
         tk('end')
 
     def _exact_pe(self, ws, featcl, P, V, h, w):
-        """Index-exact validation mode: the PE block (MU/pe.py:36-48,64-77,150-166) on unrounded fp32 inputs with bf16x3 GEMMs
-        (mv2d_gemm_x3), pe rows into ws['pe']; T path: key / value rows as bf16 hi + lo pairs.  Synchronises (reads S)."""
+        """Index-exact route: the PE block (MU/pe.py:36-48,64-77,150-166) on UNROUNDED fp32 inputs through the bf16x3 linear
+        (mv2d_linear_x3_ex: device-side row count S, sigmoid and the gate product / sine-branch sum in the epilogues), pe rows into
+        ws['pe']; T path: key / value rows as bf16 hi + lo pairs.  No host synchronisation, no allocation: graph-replayable."""
         o, W_, T = ops, self.w, ws['tab']
-        S = int(ws['S_dev'].item())
-        d = self.dev
-        a1 = torch.empty((max(S, 1), 3 * self.depth_num), device=d, dtype=F32)
-        a2 = torch.empty((max(S, 1), 384), device=d, dtype=F32)
-        o.pe_inputs(ws['s2pos'], ws['S_dev'], P, featcl, T['img2lidar'], T['coords_w'], T['coords_h'], T['coords_d'], T['embeds'],
-                    self.const['dim_t'], ws['A1'], ws['A2'], ws['Xf_b'], None, V, h, w, self.depth_num, self.post_range_h64,
-                    A_frustum_f32=a1, A_sine_f32=a2)
-        if S == 0:
-            return
-        xf = featcl[ws['s2pos'][:S].long()].contiguous()                                 # gathered feature rows, fp32
-        if os.environ.get('MV2D_EXACT_PE', 'linear') == 'gemm':
-            lin = lambda x, n_, act=0: o.gemm_x3(x, W_['pe_' + n_ + '_hl'], W_['pe_b' + n_[1:]], act=act)
-        else:       # the LDS-tiled bf16x3 linear (same split-precision arithmetic, 3-4x faster than the generic kernel on these shapes)
-            lin = lambda x, n_, act=0: o.linear_x3(x.contiguous(), W_['pe_' + n_ + '_x3'], W_['pe_b' + n_[1:]], N=W_['pe_b' + n_[1:]].numel(),
-                                                   K=x.shape[1], act=act)
-        p1 = lin(lin(a1[:S], 'w1a', 1), 'w1b')
-        gate = torch.sigmoid(lin(lin(xf, 'wr', 1), 'we'))
-        p2 = lin(lin(a2[:S], 'w2a', 1), 'w2b')
-        pe = p1 * gate + p2
-        ws['pe'][:S].copy_(pe)
+        md = ws['S_dev']
+        o.pe_inputs(ws['s2pos'], md, P, featcl, T['img2lidar'], T['coords_w'], T['coords_h'], T['coords_d'], T['embeds'],
+                    self.const['dim_t'], ws['A1'], ws['A2'], ws['Xf_b'], ws['Xf32'], V, h, w, self.depth_num, self.post_range_h64,
+                    A_frustum_f32=ws['xa1'], A_sine_f32=ws['xa2'])
+
+        def lin(x, n_, out, act=0, **kw):
+            b_ = W_['pe_b' + n_[1:]]
+            return o.linear_x3(x, W_['pe_' + n_ + '_x3'], b_, N=b_.numel(), K=x.shape[1], act=act, out=out, M=P, m_dev=md, **kw)
+        lin(lin(ws['Xf32'], 'wr', ws['xg'], 1), 'we', ws['xgate'], 2)                      # SE gate: sigmoid(expand(relu(reduce(feat))))
+        lin(lin(ws['xa2'], 'w2a', ws['xh'], 1), 'w2b', ws['xp2'])                          # adapt_pos3d(sine)
+        lin(lin(ws['xa1'], 'w1a', ws['xh'], 1), 'w1b', ws['pe'], mul=ws['xgate'], add=ws['xp2'])      # position_encoder(frustum) * gate + sine branch
         if self.kind == 'T':
-            ks, kl = o.split_bf16x2((xf + pe).contiguous())
-            vs, vl = o.split_bf16x2(xf)
-            ws['Xk'][:S].copy_(ks); ws['Xf_b'][:S].copy_(vs)
-            ws['xk_lo'] = torch.zeros((P, C), device=d, dtype=BF16); ws['xk_lo'][:S].copy_(kl)
-            ws['xv_lo'] = torch.zeros((P, C), device=d, dtype=BF16); ws['xv_lo'][:S].copy_(vl)
+            o.split_rows(ws['Xf32'], ws['pe'], hi=ws['Xk'], lo=ws['xk_lo'], m_dev=md, M=P)   # key rows = feat + pe
+            o.split_rows(ws['Xf32'], None, hi=ws['Xf_b'], lo=ws['xv_lo'], m_dev=md, M=P)     # value rows = feat
 
     def pe_input_rows(self, ws, positions, V, h, w):
         """PE input rows (frustum [n,192], sine [n,384], bf16) at the given map positions (int32, device) with the calibration tables of the
@@ -697,14 +692,10 @@ class HeadEngine:
         # a6: QueryGenerator
         tk('qg_conv_gemm')
         if self.exact:
-            # conv3x3 + ReLU + AvgPool2d(7) on the UNROUNDED RoI features: im2col (index plumbing) + exact-fp32 MFMA GEMM + pooling kernel
-            x = torch.nn.functional.pad(ws['roi_feat32'].view(R, 7, 7, C), (0, 0, 1, 1, 1, 1))
-            cols = torch.cat([x[:, ky:ky + 7, kx:kx + 7] for ky in range(3) for kx in range(3)], -1).reshape(R * 49, 9 * C).contiguous()
-            if os.environ.get('MV2D_EXACT_CONV', 'f32') == 'x3':      # bf16x3 instead of the exact-fp32 MFMA GEMM (1e-5 relative; 4x faster)
-                y = o.linear_x3(cols, W_['qg_conv_wx3'], W_['qg_conv_b'], N=C, K=9 * C, act=1)
-            else:
-                y = o.gemm_f32(cols, W_['qg_conv_w32'], W_['qg_conv_b'], act=1)
-            o.avgpool49(y, ws['x2'], C, R)
+            # conv3x3 + ReLU + AvgPool2d(7) on the UNROUNDED RoI features: implicit GEMM inside the bf16x3 linear (every tap = one 256-wide
+            # K chunk read from the neighbouring cell's row), then the pooling kernel
+            o.linear_x3(ws['roi_feat32'], W_['qg_conv_wx3'], W_['qg_conv_b'], N=C, K=9 * C, act=1, conv3x3=True, out=ws['convy'], M=R * 49)
+            o.avgpool49(ws['convy'], ws['x2'], C, R)
         else:
             o.qg_conv_pool(ws['roi_feat'], W_['qg_conv_wp'], W_['qg_conv_b'], ws['x2'], R=R)
         tk('qg_rest')
@@ -898,7 +889,7 @@ class HeadEngine:
             ws['dbg_q'] = torch.zeros((self.L, Rc, C), device=self.dev, dtype=F32)
         else:
             ws.pop('dbg_logits', None); ws.pop('dbg_q', None)
-        if not use_graph or self.exact:
+        if not use_graph:
             self._enqueue(ws, feat, Rc, V, h, w, sc)
             self._mark_done(ws)
             return dict(self._result(ws, R, keep_stages, batch), dt=sc['dt'])

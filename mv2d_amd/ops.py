@@ -184,17 +184,36 @@ def heads_fused(outs, cls_ptrs, reg_ptrs, ref, cls, reg, M, L, pc_range_host, dt
 
 
 def linear_x3(A, W_x3, bias=None, *, N, K, A2=None, n_split=0, act=0, clamp=0.0, out=None, M=None, lda=None, ldc=None, groups=1,
-              a_gs=0, w_gs=0, b_gs=0, c_gs=0):
+              a_gs=0, w_gs=0, b_gs=0, c_gs=0, m_dev=None, conv3x3=False, mul=None, add=None):
     """out = act(A @ W.T + bias) in bf16x3; W_x3 = pack_x3(W) of the [N,K] weight (K % 32 == 0, N % 16 == 0).  groups > 1: that many
     linears of the same shape in one launch, group g at A + g*a_gs, W + g*w_gs, bias + g*b_gs, out + g*c_gs (elements)."""
     _req(A, torch.float32, 'A'); _req(A2, torch.float32, 'A2'); _req(bias, torch.float32, 'bias')
+    _req(mul, torch.float32, 'mul'); _req(add, torch.float32, 'add'); _req(m_dev, torch.int32, 'm_dev')
+    if conv3x3:                                                   # A = [R,49,256] RoI cells, implicit 3x3 convolution (K = 9 * 256)
+        M = A.shape[0] * 49 if M is None else M
+        lda = 256
     M = A.shape[0] if M is None else M
     if out is None:
         out = torch.empty((M, N), device=A.device, dtype=torch.float32)
-    check(_lib.load().mv2d_linear_x3(_p(A), _p(A2), n_split, A.stride(0) if lda is None else lda, _p(W_x3[0]), _p(W_x3[1]), _p(bias), _p(out),
-                                     out.stride(0) if ldc is None else ldc, M, N, K, act, float(clamp), groups, a_gs, w_gs, b_gs, c_gs,
-                                     _stream()), 'mv2d_linear_x3')
+    ma = mul if mul is not None else add
+    check(_lib.load().mv2d_linear_x3_ex(_p(A), _p(A2), n_split, A.stride(0) if lda is None else lda, _p(W_x3[0]), _p(W_x3[1]), _p(bias), _p(out),
+                                        out.stride(0) if ldc is None else ldc, M, N, K, act, float(clamp), groups, a_gs, w_gs, b_gs, c_gs,
+                                        _p(m_dev), 1 if conv3x3 else 0, _p(mul), _p(add), ma.stride(0) if ma is not None else 0,
+                                        _stream()), 'mv2d_linear_x3')
     return out
+
+
+def split_rows(a, b=None, hi=None, lo=None, m_dev=None, M=None):
+    """(hi, lo) bf16 rows of a (+ b): fp32 [M,cols] -> two bf16 [M,cols]; rows >= *m_dev (int32, device) are left untouched."""
+    _req(a, torch.float32, 'a'); _req(b, torch.float32, 'b'); _req(hi, BF16, 'hi'); _req(lo, BF16, 'lo'); _req(m_dev, torch.int32, 'm_dev')
+    M = a.shape[0] if M is None else M
+    cols = a.shape[-1]
+    if hi is None:
+        hi = torch.empty((M, cols), device=a.device, dtype=BF16)
+    if lo is None:
+        lo = torch.empty((M, cols), device=a.device, dtype=BF16)
+    check(_lib.load().mv2d_split_rows_bf16x2(_p(a), _p(b), _p(hi), _p(lo), M, cols, _p(m_dev), _stream()), 'mv2d_split_rows_bf16x2')
+    return hi, lo
 
 
 def heads_fused_x3(outs, cls_ptrs, reg_ptrs, ref, cls, reg, M, L, pc_range_host, dt=0.0, eps=1e-5, dt_rows=None):
