@@ -44,6 +44,17 @@ int mv2d_gemm_bf16(const void* A, const void* A2, int n_split, int a_mode, const
                    int K, int lda, const int* m_dev, int act, const float* mul, int ldmul, const float* add, int ldadd,
                    void* C, int c_bf16, int ldc, long long c_blk_stride, int c_blk_cols, void* C2, const float* add2,
                    int ldc2, int ldadd2, void* stream);
+/* mv2d_gemm_bf16 with two additions for the engine's index-exact route, which runs fp32-class products through the plain bf16 GEMM by
+ * K-concatenation: [a_hi | a_lo | a_hi] . [w_hi | w_hi | w_lo]^T = a_hi w_hi + a_lo w_hi + a_hi w_lo (K' = 3 K, one fp32 accumulation).
+ * c_split3 = 1: the (bf16) output is written as that operand for the next GEMM: [hi | lo | hi] in column blocks of N (ldc >= 3 N).
+ * Conv mode (a_mode 1): lda = channels per RoI cell (256, or 768 for [hi | lo | hi] cells), K = 9 * lda with k = (tap, channel). */
+int mv2d_gemm_bf16_ex(const void* A, const void* A2, int n_split, int a_mode, const void* W, const float* bias, int M, int N, int K, int lda,
+                      const int* m_dev, int act, const float* mul, int ldmul, const float* add, int ldadd, void* C, int c_bf16, int ldc,
+                      long long c_blk_stride, int c_blk_cols, void* C2, const float* add2, int ldc2, int ldadd2, int c_split3, const int* add_idx /* optional:
+                      the add operand's row for output row m is add_idx[m] % add_period (a gathered table) */, int add_period, void* stream);
+/* out [M, 3 cols] bf16 = [hi | lo | hi] of a (+ b, optional) fp32 [M, cols]: hi = bf16(x), lo = bf16(x - hi); rows >= *m_dev (optional)
+ * are not written. */
+int mv2d_split3_rows(const float* a, const float* b, void* out, int M, int cols, const int* m_dev, void* stream);
 
 /* exact-fp32 MFMA GEMM for the per-query (M = #queries) ops  C = epi((A . W^T + bias) * scale).
  * Replaces nn.Linear calls of: query/out in_proj/out_proj and FFN (MU/petr_transformer.py:358-363,503-508; mmcv FFN),
@@ -94,6 +105,10 @@ int mv2d_pe_fused_tab(const void* A1, const void* Xfb, const float* Xf32, const 
  * static: one fragment = one contiguous 1 KB load); out [R, ld_out] fp32.  Same k order as mv2d_gemm_bf16(a_mode = 1). */
 int mv2d_pack_wfrag_bf16(const void* W, void* Wp, int N, int K, void* stream);   /* Wp[K/32][N/16][64][8] <- W[N][K] */
 int mv2d_qg_conv_pool(const void* roi_feat, const void* W, const float* bias, float* out, int ld_out, int R, void* stream);
+/* The same in split precision (index-exact route): RoI cells as bf16 hi + lo pairs [R,49,256] (mv2d_roi_align_ex), weights as fragment-major
+ * hi / lo copies of the [256, 2304] matrix (mv2d_split_bf16x2 + mv2d_pack_wfrag_bf16); products a_lo w_hi + a_hi w_lo + a_hi w_hi. */
+int mv2d_qg_conv_pool_x3(const void* roi_feat_hi, const void* roi_feat_lo, const void* W_hi, const void* W_lo, const float* bias, float* out,
+                         int ld_out, int R, void* stream);
 
 /* K/V in_proj of all decoder layers, shape-specialised (K = 256): C = A . W^T + bias, bf16 in / bf16 out, same operand and
  * output-block conventions as mv2d_gemm_bf16 (A2 / n_split, m_dev, c_blk_stride / c_blk_cols) and bit-identical results.
@@ -342,6 +357,11 @@ int mv2d_posemb3d(const float* ref, const float* dim_t, float* posemb, int R, vo
 int mv2d_roi_align(const float* map0, const float* map1, const float* rois, void* out0, void* out1, float* out0_f32,
                    float* out1_f32, int R, int H, int W, int channels, float spatial_scale, int sampling_ratio,
                    const int* map1_index, int out1_is_sum, void* stream);
+/* mv2d_roi_align with bf16 REMAINDER outputs: out0_lo / out1_lo = bf16(x - bf16(x)) next to out0 / out1 (x ~ hi + lo, 2^-17 relative):
+ * the fp32-class key / value / conv-input rows of the index-exact route. */
+int mv2d_roi_align_ex(const float* map0, const float* map1, const float* rois, void* out0, void* out1, float* out0_f32, float* out1_f32,
+                      int R, int H, int W, int channels, float spatial_scale, int sampling_ratio, const int* map1_index, int out1_is_sum,
+                      void* out0_lo, void* out1_lo, void* stream);
 
 /* BoxCorrelation.epipolar_in_box, 'topk_matched:k:thr:ratio' (RH/utils/box_correlation.py:196-398).
  * V = views per sample; view_start[n_views+1]: first RoI of each view; trans [n_views,V,16] fp64 = lidar2img[b] @ inv(lidar2img[a])

@@ -24,9 +24,12 @@ SIGNATURES = {
     'mv2d_device_arch': (I, [C.c_char_p, I]),
     'mv2d_spin': (I, [I, P]),
     'mv2d_gemm_bf16': (I, [P, P, I, I, P, P, I, I, I, I, P, I, P, I, P, I, P, I, I, LL, I, P, P, I, I, P]),
+    'mv2d_gemm_bf16_ex': (I, [P, P, I, I, P, P, I, I, I, I, P, I, P, I, P, I, P, I, I, LL, I, P, P, I, I, I, P, I, P]),
+    'mv2d_split3_rows': (I, [P, P, P, I, I, P, P]),
     'mv2d_pe_fused': (I, [P, P, P, P, P, P, I] + [P] * 14 + [P]),
     'mv2d_pe_fused_tab': (I, [P, P, P, P, P, I] + [P] * 9 + [I, P, P, P]),
     'mv2d_qg_conv_pool': (I, [P, P, P, P, I, I, P]),
+    'mv2d_qg_conv_pool_x3': (I, [P, P, P, P, P, P, I, I, P]),
     'mv2d_pack_wfrag_bf16': (I, [P, P, I, I, P]),
     'mv2d_kv_proj': (I, [P, P, I, I, P, P, I, I, P, P, I, LL, I, P]),
     'mv2d_gemm_f32': (I, [P, P, I, P, P, I, I, I, I, I, I, I, F, F, P, I, I, LL, I, LL, LL, LL, LL, P]),
@@ -70,6 +73,7 @@ SIGNATURES = {
     'mv2d_lidar2img_inverse': (I, [P, P, P, I, P]),
     'mv2d_posemb3d': (I, [P, P, P, I, P]),
     'mv2d_roi_align': (I, [P, P, P, P, P, P, P, I, I, I, I, F, I, P, I, P]),
+    'mv2d_roi_align_ex': (I, [P, P, P, P, P, P, P, I, I, I, I, F, I, P, I, P, P, P]),
     'mv2d_box_correlation': (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, F, F, F, I, P]),
     'mv2d_csr_workspace_bytes': (LL, [I, I, I, I]),
     'mv2d_mask_compact': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, I, P]),

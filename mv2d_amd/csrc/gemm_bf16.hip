@@ -41,6 +41,8 @@ struct Params {
     void* C; int c_bf16; int ldc;  // primary output
     long long c_blk_stride; int c_blk_cols;   // out = C + (n / c_blk_cols) * c_blk_stride + m * ldc + n % c_blk_cols
     unsigned short* C2; const float* add2; int ldc2; int ldadd2;   // C2 = bf16(v + add2[m, n])
+    const int* add_idx; int add_period;   // optional: the add operand's row of output row m is add_idx[m] % add_period (a gathered table)
+    int c_split3;                  // bf16 output as the split-precision operand of a following GEMM: [hi | lo | hi] in column blocks of N (ldc >= 3 N)
 };
 
 // LDS image: one tile row = BK bf16 (128 or 256 B) in 16-byte slots, slot index XOR-ed with the low row bits
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 4)) void gemm_bf16_kernel(Par
         } else {
             const int r = mc / 49, cell = mc - r * 49;
             c_py[i] = cell / 7; c_px[i] = cell - c_py[i] * 7;
-            a_src[i] = (long long)r * 49 * 256 + slot * 8;
+            a_src[i] = (long long)r * 49 * p.lda + slot * 8;          // conv mode: lda = channels per cell (256, or 768 for [hi | lo | hi] cells)
         }
     }
 #pragma unroll
@@ -120,12 +122,12 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 4)) void gemm_bf16_kernel(Par
             if (p.a_mode == 0) {
                 src = Abase + a_src[i] + k0;
             } else {
-                const int tap = k0 >> 8, c0 = k0 & 255;
+                const int tap = k0 / p.lda, c0 = k0 - tap * p.lda;
                 const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
                 const int y = c_py[i] + dy, x = c_px[i] + dx;
                 ok = ok && y >= 0 && y < 7 && x >= 0 && x < 7;
                 const int yy = ok ? y : 0, xx = ok ? x : 0;
-                src = Abase + a_src[i] + (yy * 7 + xx) * 256 + c0;
+                src = Abase + a_src[i] + (yy * 7 + xx) * p.lda + c0;
             }
             uint4 v = *reinterpret_cast<const uint4*>(src);
             if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
@@ -216,8 +218,9 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 4)) void gemm_bf16_kernel(Par
                     v[0] *= a0.x; v[1] *= a0.y; v[2] *= a0.z; v[3] *= a0.w; v[4] *= a1.x; v[5] *= a1.y; v[6] *= a1.z; v[7] *= a1.w;
                 }
                 if (p.add) {
-                    const float4 a0 = *reinterpret_cast<const float4*>(p.add + (long long)m * p.ldadd + ncol);
-                    const float4 a1 = *reinterpret_cast<const float4*>(p.add + (long long)m * p.ldadd + ncol + 4);
+                    const long long ar = p.add_idx ? (long long)(p.add_idx[m] % p.add_period) : (long long)m;
+                    const float4 a0 = *reinterpret_cast<const float4*>(p.add + ar * p.ldadd + ncol);
+                    const float4 a1 = *reinterpret_cast<const float4*>(p.add + ar * p.ldadd + ncol + 4);
                     v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
                 }
                 if (p.act == 1) {
@@ -229,7 +232,18 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 4)) void gemm_bf16_kernel(Par
                 }
                 if (p.C) {
                     const long long o = c_col + (long long)m * p.ldc;
-                    if (p.c_bf16) {
+                    if (p.c_split3) {
+                        unsigned int h[4], l[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            h[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                            l[e] = pack_bf16x2(v[2 * e] - __uint_as_float(h[e] << 16), v[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u));
+                        }
+                        unsigned short* cp = reinterpret_cast<unsigned short*>(p.C) + o;
+                        *reinterpret_cast<uint4*>(cp) = make_uint4(h[0], h[1], h[2], h[3]);
+                        *reinterpret_cast<uint4*>(cp + p.N) = make_uint4(l[0], l[1], l[2], l[3]);
+                        *reinterpret_cast<uint4*>(cp + 2 * p.N) = make_uint4(h[0], h[1], h[2], h[3]);
+                    } else if (p.c_bf16) {
                         *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.C) + o) =
                             make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
                     } else {
@@ -254,7 +268,42 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 4)) void gemm_bf16_kernel(Par
     }
 }
 
+// (hi | lo | hi) bf16 row of a (+ b): the A operand of a split-precision product through the plain bf16 GEMM,
+//   [a_hi | a_lo | a_hi] . [w_hi | w_hi | w_lo]^T = a_hi w_hi + a_lo w_hi + a_hi w_lo   (K' = 3 K, fp32 accumulation in the MFMA accumulators)
+__global__ void split3_rows_kernel(const float4* __restrict__ a, const float4* __restrict__ b, unsigned short* __restrict__ out, long long n4,
+                                   const int* __restrict__ m_dev, int row4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4 || (m_dev && i >= (long long)*m_dev * row4)) return;
+    float4 v = a[i];
+    if (b) { const float4 w = b[i]; v = make_float4(v.x + w.x, v.y + w.y, v.z + w.z, v.w + w.w); }
+    const unsigned int h0 = pack_bf16x2(v.x, v.y), h1 = pack_bf16x2(v.z, v.w);
+    const unsigned int l0 = pack_bf16x2(v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xffff0000u));
+    const unsigned int l1 = pack_bf16x2(v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xffff0000u));
+    const long long row = i / row4, c4 = i - row * row4;
+    unsigned short* o = out + row * (12LL * row4) + 4 * c4;
+    *reinterpret_cast<uint2*>(o) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(o + 4 * row4) = make_uint2(l0, l1);
+    *reinterpret_cast<uint2*>(o + 8 * row4) = make_uint2(h0, h1);
+}
+
 }  // namespace
+
+extern "C" int mv2d_split3_rows(const float* a, const float* b, void* out, int M, int cols, const int* m_dev, void* stream) {
+    MV2D_CHECK_ARG(a && out && M >= 0 && cols > 0 && (cols % 4) == 0, "mv2d_split3_rows: bad args (cols % 4 == 0)");
+    MV2D_CHECK_ARG(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 && ((uintptr_t)out & 7) == 0, "mv2d_split3_rows: operands must be 16-byte aligned");
+    if (M == 0) return MV2D_OK;
+    const long long n4 = (long long)M * (cols / 4);
+    hipLaunchKernelGGL(split3_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const float4*)b,
+                       (unsigned short*)out, n4, m_dev, cols / 4);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_gemm_bf16_ex(const void* A, const void* A2, int n_split, int a_mode, const void* W,
+                                 const float* bias, int M, int N, int K, int lda, const int* m_dev, int act,
+                                 const float* mul, int ldmul, const float* add, int ldadd, void* C, int c_bf16,
+                                 int ldc, long long c_blk_stride, int c_blk_cols, void* C2, const float* add2,
+                                 int ldc2, int ldadd2, int c_split3, const int* add_idx, int add_period, void* stream);
 
 // C-ABI: see include/mv2d_hip.h
 extern "C" int mv2d_gemm_bf16(const void* A, const void* A2, int n_split, int a_mode, const void* W,
@@ -262,11 +311,21 @@ extern "C" int mv2d_gemm_bf16(const void* A, const void* A2, int n_split, int a_
                               const float* mul, int ldmul, const float* add, int ldadd, void* C, int c_bf16,
                               int ldc, long long c_blk_stride, int c_blk_cols, void* C2, const float* add2,
                               int ldc2, int ldadd2, void* stream) {
+    return mv2d_gemm_bf16_ex(A, A2, n_split, a_mode, W, bias, M, N, K, a_mode == 1 ? 256 : lda, m_dev, act, mul, ldmul, add, ldadd, C, c_bf16, ldc,
+                             c_blk_stride, c_blk_cols, C2, add2, ldc2, ldadd2, 0, nullptr, 0, stream);
+}
+
+extern "C" int mv2d_gemm_bf16_ex(const void* A, const void* A2, int n_split, int a_mode, const void* W,
+                                 const float* bias, int M, int N, int K, int lda, const int* m_dev, int act,
+                                 const float* mul, int ldmul, const float* add, int ldadd, void* C, int c_bf16,
+                                 int ldc, long long c_blk_stride, int c_blk_cols, void* C2, const float* add2,
+                                 int ldc2, int ldadd2, int c_split3, const int* add_idx, int add_period, void* stream) {
     MV2D_CHECK_ARG(A && W && (C || C2), "mv2d_gemm_bf16: null A/W/C");
+    MV2D_CHECK_ARG(!c_split3 || (C && c_bf16 && !C2 && c_blk_cols == 0 && ldc >= 3 * N), "mv2d_gemm_bf16_ex: c_split3 writes bf16 [hi | lo | hi], ldc >= 3 N");
     MV2D_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (K % BK_MIN) == 0, "mv2d_gemm_bf16: K must be a positive multiple of 64");
     MV2D_CHECK_ARG((N % 8) == 0, "mv2d_gemm_bf16: N must be a multiple of 8");
-    MV2D_CHECK_ARG(a_mode == 0 || (a_mode == 1 && K == 9 * 256 && (M % 49) == 0), "mv2d_gemm_bf16: conv3x3 mode needs K=2304, M=R*49");
-    MV2D_CHECK_ARG(a_mode == 1 || (lda % 8) == 0, "mv2d_gemm_bf16: lda must be a multiple of 8 (16-byte rows)");
+    MV2D_CHECK_ARG(a_mode == 0 || (a_mode == 1 && (lda % 128) == 0 && K == 9 * lda && (M % 49) == 0), "mv2d_gemm_bf16: conv3x3 mode needs K = 9 * lda (channels per cell, a multiple of 128), M=R*49");
+    MV2D_CHECK_ARG((lda % 8) == 0, "mv2d_gemm_bf16: lda must be a multiple of 8 (16-byte rows)");
     MV2D_CHECK_ARG(n_split == 0 || (A2 && (n_split % 128) == 0), "mv2d_gemm_bf16: n_split must be a multiple of 128 with A2 set");
     MV2D_CHECK_ARG(!(C2 && C && c_bf16), "mv2d_gemm_bf16: with a second (bf16) output the primary output must be fp32");
     MV2D_CHECK_ARG(c_blk_cols == 0 || (c_blk_cols % 8) == 0, "mv2d_gemm_bf16: c_blk_cols must be a multiple of 8");
@@ -282,7 +341,7 @@ extern "C" int mv2d_gemm_bf16(const void* A, const void* A2, int n_split, int a_
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.m_dev = m_dev; p.a_mode = a_mode; p.n_split = n_split; p.act = act;
     p.mul = mul; p.ldmul = ldmul; p.add = add; p.ldadd = ldadd; p.C = C; p.c_bf16 = c_bf16; p.ldc = ldc;
     p.c_blk_stride = c_blk_stride; p.c_blk_cols = c_blk_cols; p.C2 = (unsigned short*)C2; p.add2 = add2;
-    p.ldc2 = ldc2; p.ldadd2 = ldadd2;
+    p.ldc2 = ldc2; p.ldadd2 = ldadd2; p.c_split3 = c_split3; p.add_idx = add_idx; p.add_period = add_idx ? (add_period > 0 ? add_period : 1) : 0;
     // tile choice: 128x128 when that already gives >= 3 blocks per CU, else 64x64 (4x the blocks)
     const long long big_blocks = (long long)cdiv(M, 128) * cdiv(N, 128);
     static const int thr_env = getenv("MV2D_BF16_BIG") ? atoi(getenv("MV2D_BF16_BIG")) : 768;

@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
                                                         unsigned short* __restrict__ out0, unsigned short* __restrict__ out1,
                                                         float* __restrict__ out0_f32, float* __restrict__ out1_f32, int H, int W,
                                                         float spatial_scale, int sampling_ratio, const int* __restrict__ map1_index,
-                                                        int out1_is_sum, int R) {
+                                                        int out1_is_sum, int R, unsigned short* __restrict__ out0_lo,
+                                                        unsigned short* __restrict__ out1_lo) {
     // one block per RoI and bin row; wave w takes the bins w, w + 4 of the row, lane l the channels 4l .. 4l+3: every
     // bilinear tap is one 16-byte load per lane (a full 1 KB row per wave), every output one 8-byte (bf16) / 16-byte (fp32) store.
     // XCD-aware block map (block b runs on XCD b % 8): the 7 bin rows of a RoI tap overlapping map rows, so they take consecutive slots
@@ -198,13 +199,20 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
         }
         const long long o = ((long long)r * 49 + ph * 7 + pw) * C + c;
         s0 = make_float4(s0.x / count, s0.y / count, s0.z / count, s0.w / count);
-        if (out0) *reinterpret_cast<uint2*>(out0 + o) = make_uint2(pack_bf16x2(s0.x, s0.y), pack_bf16x2(s0.z, s0.w));
+        // (out*_lo: the bf16 remainder x - bf16(x) next to the bf16 value: the fp32-class hi + lo rows of the index-exact route)
+        auto put = [&](unsigned short* hi, unsigned short* lo, const float4& t) {
+            const unsigned int h0 = pack_bf16x2(t.x, t.y), h1 = pack_bf16x2(t.z, t.w);
+            *reinterpret_cast<uint2*>(hi + o) = make_uint2(h0, h1);
+            if (lo) *reinterpret_cast<uint2*>(lo + o) = make_uint2(pack_bf16x2(t.x - __uint_as_float(h0 << 16), t.y - __uint_as_float(h0 & 0xffff0000u)),
+                                                                   pack_bf16x2(t.z - __uint_as_float(h1 << 16), t.w - __uint_as_float(h1 & 0xffff0000u)));
+        };
+        if (out0) put(out0, out0_lo, s0);
         if (out0_f32) *reinterpret_cast<float4*>(out0_f32 + o) = s0;
         if (nmaps == 2) {
             s1 = make_float4(s1.x / count, s1.y / count, s1.z / count, s1.w / count);
             if (out1) {
                 const float4 t = out1_is_sum ? make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w) : s1;
-                *reinterpret_cast<uint2*>(out1 + o) = make_uint2(pack_bf16x2(t.x, t.y), pack_bf16x2(t.z, t.w));
+                put(out1, out1_lo, t);
             }
             if (out1_f32) *reinterpret_cast<float4*>(out1_f32 + o) = s1;
         }
@@ -946,16 +954,25 @@ extern "C" int mv2d_posemb3d(const float* ref, const float* dim_t, float* posemb
     return MV2D_OK;
 }
 
+extern "C" int mv2d_roi_align_ex(const float* map0, const float* map1, const float* rois, void* out0, void* out1, float* out0_f32,
+                                 float* out1_f32, int R, int H, int W, int channels, float spatial_scale, int sampling_ratio,
+                                 const int* map1_index, int out1_is_sum, void* out0_lo, void* out1_lo, void* stream) {
+    MV2D_CHECK_ARG(map0 && rois && channels == C, "mv2d_roi_align: needs 256-channel position-major maps");
+    MV2D_CHECK_ARG(out0 || out0_f32, "mv2d_roi_align: no output");
+    MV2D_CHECK_ARG((!out0_lo || out0) && (!out1_lo || out1), "mv2d_roi_align_ex: a lo output needs its bf16 (hi) output");
+    if (R == 0) return MV2D_OK;
+    hipLaunchKernelGGL(roi_align_kernel, dim3(56 * cdiv(R, 8)), dim3(256), 0, (hipStream_t)stream, map0, map1, rois, (unsigned short*)out0,
+                       (unsigned short*)out1, out0_f32, out1_f32, H, W, spatial_scale, sampling_ratio, map1_index, out1_is_sum, R,
+                       (unsigned short*)out0_lo, (unsigned short*)out1_lo);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
 extern "C" int mv2d_roi_align(const float* map0, const float* map1, const float* rois, void* out0, void* out1, float* out0_f32,
                               float* out1_f32, int R, int H, int W, int channels, float spatial_scale, int sampling_ratio,
                               const int* map1_index, int out1_is_sum, void* stream) {
-    MV2D_CHECK_ARG(map0 && rois && channels == C, "mv2d_roi_align: needs 256-channel position-major maps");
-    MV2D_CHECK_ARG(out0 || out0_f32, "mv2d_roi_align: no output");
-    if (R == 0) return MV2D_OK;
-    hipLaunchKernelGGL(roi_align_kernel, dim3(56 * cdiv(R, 8)), dim3(256), 0, (hipStream_t)stream, map0, map1, rois, (unsigned short*)out0,
-                       (unsigned short*)out1, out0_f32, out1_f32, H, W, spatial_scale, sampling_ratio, map1_index, out1_is_sum, R);
-    MV2D_LAUNCH_CHECK();
-    return MV2D_OK;
+    return mv2d_roi_align_ex(map0, map1, rois, out0, out1, out0_f32, out1_f32, R, H, W, channels, spatial_scale, sampling_ratio, map1_index,
+                             out1_is_sum, nullptr, nullptr, stream);
 }
 
 extern "C" int mv2d_roi_align_bwd(const float* grad_out, const float* rois, float* grad_map, const int* index, int R, int H, int W,
@@ -1035,7 +1052,7 @@ extern "C" int mv2d_pe_inputs(const int* s2pos, const int* S_dev, int S_max, con
     MV2D_CHECK_ARG(A_sine || !A_sine_f32, "mv2d_pe_inputs: the exact rows need A_sine");
     MV2D_CHECK_ARG(depth_num <= 256 && (depth_num % 8) == 0, "mv2d_pe_inputs: depth_num must be a multiple of 8, <= 256");
     if (S_max == 0) return MV2D_OK;
-    MV2D_CHECK_ARG((A_frustum_f32 == nullptr) == (A_sine_f32 == nullptr), "mv2d_pe_inputs: the fp32 rows come together");
+    MV2D_CHECK_ARG(A_frustum_f32 || !A_sine_f32, "mv2d_pe_inputs: fp32 sine rows only together with the fp32 frustum rows");
 #define MV2D_PEI(EX) hipLaunchKernelGGL(pe_inputs_kernel<EX>, dim3(cdiv(S_max, 4)), dim3(256), 0, (hipStream_t)stream, s2pos, S_dev, featcl, img2lidar, coords_w, \
                        coords_h, coords_d, embeds, dim_t, (unsigned short*)A_frustum, (unsigned short*)A_sine,                                      \
                        (unsigned short*)Xf_bf16, Xf_f32, A_frustum_f32, A_sine_f32, h, w, V * h * w, depth_num, position_range[0], position_range[1], \

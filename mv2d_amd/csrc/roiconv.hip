@@ -125,6 +125,113 @@ __global__ __launch_bounds__(256, 2) void roi_conv_pool_kernel(const unsigned sh
     }
 }
 
+// Split-precision variant (index-exact route of the engine): the RoI cells come as bf16 hi + lo pairs (mv2d_roi_align_ex: x ~ hi + lo), the
+// weights as fragment-major hi / lo copies (mv2d_split_bf16x2 + mv2d_pack_wfrag_bf16); every product is a_lo w_hi + a_hi w_lo + a_hi w_hi
+// (three MFMAs into one fp32 accumulator; the lo x lo term, 2^-18 relative, is dropped).  One RoI per block: two 25 KB LDS images, a
+// 3-deep ring for both weight streams, the same tap remapping and epilogue as the bf16 kernel.  MFMA-bound (3 x 2304 MFMAs per wave
+// against 2.4 MB of weight fragments per block).
+__global__ __launch_bounds__(256, 2) void roi_conv_pool_x3_kernel(const unsigned short* __restrict__ feat_hi, const unsigned short* __restrict__ feat_lo,
+                                                                  const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl,
+                                                                  const float* __restrict__ bias, float* __restrict__ out, int ld_out, int R) {
+    constexpr int NROWS = CELLS + 1, RING = 3;
+    __shared__ __attribute__((aligned(16))) unsigned char xh[NROWS * C * 2], xl[NROWS * C * 2];
+    __shared__ float bs[C];
+    const int roi = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const long long w_off = ((long long)(wave * 4) * 64 + lane) * 8;
+    constexpr int KS_STRIDE = 16 * 64 * 8, JT_STRIDE = 64 * 8;
+    Frag wqh[RING][4], wql[RING][4];
+#pragma unroll
+    for (int p = 0; p < RING - 1; ++p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            wqh[p][j].u = *reinterpret_cast<const uint4*>(Wh + w_off + p * KS_STRIDE + j * JT_STRIDE);
+            wql[p][j].u = *reinterpret_cast<const uint4*>(Wl + w_off + p * KS_STRIDE + j * JT_STRIDE);
+        }
+    {
+        constexpr int NST = (NROWS * 32 + 255) / 256;
+        cv_u32x4 sh[NST], sl[NST];
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int c = tid + 256 * i, row = c >> 5, slot = c & 31;
+            const bool ok = row < CELLS;
+            const long long src = ((long long)roi * CELLS + min(row, CELLS - 1)) * C + slot * 8;
+            sh[i] = *reinterpret_cast<const cv_u32x4*>(feat_hi + src);
+            sl[i] = *reinterpret_cast<const cv_u32x4*>(feat_lo + src);
+            if (!ok) { sh[i] = cv_u32x4{0u, 0u, 0u, 0u}; sl[i] = cv_u32x4{0u, 0u, 0u, 0u}; }
+        }
+        const float bv = bias[tid];
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int c = tid + 256 * i, row = c >> 5, slot = c & 31;
+            if (row < NROWS) {
+                *reinterpret_cast<cv_u32x4*>(xh + row * (C * 2) + ((slot ^ (row & 15)) << 4)) = sh[i];
+                *reinterpret_cast<cv_u32x4*>(xl + row * (C * 2) + ((slot ^ (row & 15)) << 4)) = sl[i];
+            }
+        }
+        bs[tid] = bv;
+    }
+    int cy[4], cx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = 16 * i + fr; cy[i] = r / 7; cx[i] = r - cy[i] * 7; }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+#pragma unroll
+    for (int ks = 0; ks < 72; ++ks) {
+        const int tap = ks >> 3, s = ks & 7;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        if (ks + RING - 1 < 72) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                wqh[(ks + RING - 1) % RING][j].u = *reinterpret_cast<const uint4*>(Wh + w_off + (ks + RING - 1) * KS_STRIDE + j * JT_STRIDE);
+                wql[(ks + RING - 1) % RING][j].u = *reinterpret_cast<const uint4*>(Wl + w_off + (ks + RING - 1) * KS_STRIDE + j * JT_STRIDE);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        Frag ah[4], al[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int y = cy[it] + dy, x = cx[it] + dx;
+            const bool ok = (16 * it + fr) < CELLS && y >= 0 && y < 7 && x >= 0 && x < 7;
+            const int src = ok ? y * 7 + x : CELLS;
+            const int off = src * (C * 2) + (((4 * s + fg) ^ (src & 15)) << 4);
+            ah[it].u = *reinterpret_cast<const uint4*>(xh + off);
+            al[it].u = *reinterpret_cast<const uint4*>(xl + off);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[it][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[it].v, wqh[ks % RING][j].v, acc[it][j], 0, 0, 0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[it][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[it].v, wql[ks % RING][j].v, acc[it][j], 0, 0, 0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[it][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[it].v, wqh[ks % RING][j].v, acc[it][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = wave * 64 + 16 * j + fr;
+        const float b = bs[n];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 * i + 4 * fg + r < CELLS) sum += relu_f(acc[i][j][r] + b);
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        if (fg == 0) out[(long long)roi * ld_out + n] = sum / 49.0f;
+    }
+}
+
 // row-major W [N, K] bf16 -> fragment-major Wp[K/32][N/16][64][8]: Wp[ks][jt][fr + 16 fg][e] = W[16 jt + fr][32 ks + 8 fg + e]
 __global__ void pack_wfrag_kernel(const unsigned short* __restrict__ W, unsigned short* __restrict__ Wp, int N, int K) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte chunk per thread
@@ -161,6 +268,18 @@ extern "C" int mv2d_qg_conv_pool(const void* roi_feat, const void* W, const floa
     else
         hipLaunchKernelGGL(roi_conv_pool_kernel<1>, dim3(R), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)roi_feat,
                            (const unsigned short*)W, bias, out, ld_out, R);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_qg_conv_pool_x3(const void* roi_feat_hi, const void* roi_feat_lo, const void* W_hi, const void* W_lo, const float* bias, float* out,
+                                    int ld_out, int R, void* stream) {
+    MV2D_CHECK_ARG(roi_feat_hi && roi_feat_lo && W_hi && W_lo && bias && out && ld_out >= C, "mv2d_qg_conv_pool_x3: bad args");
+    MV2D_CHECK_ARG(((uintptr_t)roi_feat_hi & 15) == 0 && ((uintptr_t)roi_feat_lo & 15) == 0 && ((uintptr_t)W_hi & 15) == 0 && ((uintptr_t)W_lo & 15) == 0,
+                   "mv2d_qg_conv_pool_x3: operands must be 16-byte aligned");
+    if (R == 0) return MV2D_OK;
+    hipLaunchKernelGGL(roi_conv_pool_x3_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)roi_feat_hi,
+                       (const unsigned short*)roi_feat_lo, (const unsigned short*)W_hi, (const unsigned short*)W_lo, bias, out, ld_out, R);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

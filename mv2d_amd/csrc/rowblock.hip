@@ -1359,7 +1359,7 @@ extern "C" int mv2d_linear_x3_ex(const float* A, const float* A2, int n_split, i
     MV2D_CHECK_ARG(!conv3x3 || (K == 2304 && n_split == 0 && groups == 1), "mv2d_linear_x3_ex: conv3x3 reads [R,49,256] cells, K = 9 * 256");
     MV2D_CHECK_ARG((!mul && !add) || ld_ma >= N, "mv2d_linear_x3_ex: ld_ma < N");
     MV2D_CHECK_ARG(M >= 0 && N > 0 && (N % 16) == 0 && K > 0 && (K % 32) == 0, "mv2d_linear_x3: N % 16 == 0 and K % 32 == 0 required");
-    MV2D_CHECK_ARG((lda % 4) == 0 && lda >= K && ldc >= N && ((uintptr_t)A & 15) == 0, "mv2d_linear_x3: A rows must be 16-byte aligned");
+    MV2D_CHECK_ARG((lda % 4) == 0 && (conv3x3 || lda >= K) && ldc >= N && ((uintptr_t)A & 15) == 0, "mv2d_linear_x3: A rows must be 16-byte aligned");
     MV2D_CHECK_ARG(n_split == 0 || (A2 && (n_split % 128) == 0 && ((uintptr_t)A2 & 15) == 0), "mv2d_linear_x3: n_split must be a multiple of 128 with A2 set");
     MV2D_CHECK_ARG(groups >= 1 && (groups == 1 || ((a_gs % 4) == 0 && (w_gs % 8) == 0)), "mv2d_linear_x3: group strides must keep 16-byte alignment");
     if (M == 0) return MV2D_OK;

@@ -164,7 +164,7 @@ __device__ __forceinline__ float xt_row16_max(float v) {
 }
 
 template <int NW, bool DBG, bool XLO>
-__global__ __launch_bounds__(64 * NW, XLO ? 1 : 2) void xattn_tile_kernel(const uint4* __restrict__ Qt, const unsigned short* __restrict__ Xk,
+__global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __restrict__ Qt, const unsigned short* __restrict__ Xk,
                                                              const unsigned short* __restrict__ Xv, const unsigned short* __restrict__ Xk_lo,
                                                              const unsigned short* __restrict__ Xv_lo, const int* __restrict__ row_ptr,
                                                              const int* __restrict__ col_idx, float* __restrict__ z,
@@ -421,7 +421,8 @@ extern "C" int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* X
 #define MV2D_XT(NW, DBG, XLO) hipLaunchKernelGGL((xattn_tile_kernel<NW, DBG, XLO>), dim3(R), dim3(64 * NW), 0, (hipStream_t)stream, (const uint4*)Qt, \
                                                  (const unsigned short*)Xk, (const unsigned short*)Xv, (const unsigned short*)Xk_lo, (const unsigned short*)Xv_lo, \
                                                  row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan)
-    if (Xk_lo) { if (dbg_logits) MV2D_XT(4, true, true); else MV2D_XT(4, false, true); }            // validation mode: 4 waves only
+    // index-exact route (hi + lo rows): two waves per SIMD like the default (round 3: the 312-register build ran one wave per SIMD, 133 us per layer)
+    if (Xk_lo) { if (dbg_logits) MV2D_XT(4, true, true); else if (nw == 4) MV2D_XT(4, false, true); else MV2D_XT(2, false, true); }
     else if (dbg_logits) { if (nw == 8) MV2D_XT(8, true, false); else if (nw == 2) MV2D_XT(2, true, false); else if (nw == 1) MV2D_XT(1, true, false); else MV2D_XT(4, true, false); }
     else { if (nw == 8) MV2D_XT(8, false, false); else if (nw == 2) MV2D_XT(2, false, false); else if (nw == 1) MV2D_XT(1, false, false); else MV2D_XT(4, false, false); }
 #undef MV2D_XT

@@ -134,9 +134,14 @@ class HeadEngine:
         # the reference's (tests/test_gpu_golden.py).  Round 3: no host synchronisation, no per-frame allocation, no torch glue -- the
         # route is enqueue-only and hipGraph-replayable like the default one (bench.py: samples_s_index_exact).
         self.exact = (os.environ.get('MV2D_EXACT', '0') == '1') if exact is None else bool(exact)
+        self.exact_linear = False
         if self.exact:
             assert self.tile_attn, 'the exact mode runs on the tile cross-attention route'
-            self.pe_sine_table = False
+            # MV2D_EXACT_GEMM=linear: the round-3a route through mv2d_linear_x3_ex (A/B switch; the default runs the fp32-class products
+            # through the plain bf16 tile GEMM by K-concatenation, see _exact_pe)
+            self.exact_linear = os.environ.get('MV2D_EXACT_GEMM', 'cat3') == 'linear'
+            if self.exact_linear:
+                self.pe_sine_table = False
         self.load_state(state_dict)
 
     # ------------------------------------------------------------------------------------------ weights
@@ -232,6 +237,10 @@ class HeadEngine:
                            ('wr', 'fpe.conv_reduce'), ('we', 'fpe.conv_expand')):
                 w['pe_' + n_ + '_x3'] = ops.pack_x3(c1(k_ + '.weight').contiguous())
             w['qg_conv_wx3'] = ops.pack_x3(conv.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous())
+            # K-concatenated split-precision weights [w_hi | w_hi | w_lo] for the plain bf16 GEMM (partner of mv2d_split3_rows)
+            for n_, k_ in (('w1a', 'position_encoder.0'), ('w1b', 'position_encoder.2'), ('w2a', 'adapt_pos3d.0'), ('w2b', 'adapt_pos3d.2'),
+                           ('wr', 'fpe.conv_reduce'), ('we', 'fpe.conv_expand')):
+                w['pe_' + n_ + '_c3'] = ops.cat3_weight(c1(k_ + '.weight').contiguous())
         self.w = w
         for k in ('cls_w0', 'cls_w3', 'reg_w0', 'reg_w2'):                              # [L,256,256] -> fragment-major copies for heads_fused
             w[k + 'p'] = ops.pack_wfrag_f32(w[k])
@@ -352,14 +361,21 @@ class HeadEngine:
             # index-exact route: unrounded fp32 operands of the PE block (frustum / sine inputs, hidden layers, gate, sine branch), the fp32
             # RoIAlign outputs, the lo halves of the key / value rows, the conv output before pooling -- all pre-allocated (no per-frame
             # allocation, no host synchronisation: the route is graph-replayable like the default one)
-            ws['xa1'] = e((P, 3 * self.depth_num)); ws['xa2'] = e((P, 384)); ws['xh'] = e((P, 4 * C))
-            ws['xg'] = e((P, C)); ws['xgate'] = e((P, C)); ws['xp2'] = e((P, C))
-            ws['roi_feat32'] = e((R, 49, C)); ws['convy'] = e((R * 49, C))
+            ws['xa1'] = e((P, 3 * self.depth_num)); ws['xa2'] = e((P, 384))
+            ws['xgate'] = e((P, C)); ws['xp2'] = e((P, C))
+            if self.exact_linear:
+                ws['xh'] = e((P, 4 * C)); ws['xg'] = e((P, C)); ws['roi_feat32'] = e((R, 49, C)); ws['convy'] = e((R * 49, C))
+                if self.kind == 'S':
+                    ws['roi_pe32'] = e((R, 49, C))
+            else:
+                # [hi | lo | hi] bf16 operands of the K-concatenated GEMMs: one scratch for the input rows (<= 3 * 384 wide), one for the hidden layer
+                ws['x3a'] = e((P, 3 * 384), BF16); ws['x3h'] = e((P, 3 * 4 * C), BF16)
             if self.kind == 'T':
                 ws['xk_lo'] = z((P, C), BF16); ws['xv_lo'] = z((P, C), BF16)
+                ws['roi_lo'] = e((R, 49, C), BF16)                 # lo halves of the RoI cells (conv input)
             else:
-                ws['roi_pe32'] = e((R, 49, C))
                 ws['xk_lo'] = z((R * 49, C), BF16); ws['xv_lo'] = z((R * 49, C), BF16)
+                ws['roi_lo'] = ws['xv_lo'].view(R, 49, C)          # S path: the value rows ARE the RoI cells
         if not self.pe_fused:                                    # intermediates of the six-GEMM PE route only
             ws['H1'] = e((P, 4 * C), BF16); ws['H2'] = e((P, 4 * C), BF16); ws['Hg'] = e((P, C), BF16)
             ws['gate'] = e((P, C)); ws['Pg'] = e((P, C))
@@ -484,8 +500,18 @@ class HeadEngine:
                 xb = torch.empty((Pt, C), device=self.dev, dtype=BF16)
                 o.pe_inputs(s2, torch.tensor([Pt], dtype=torch.int32, device=self.dev), Pt, ws['featcl'], T['img2lidar'], T['coords_w'], T['coords_h'],
                             T['coords_d'], T['embeds'], self.const['dim_t'], a1, a2, xb, None, V, h, w, self.depth_num, self.post_range_h64)
-                h2 = o.gemm_bf16(a2, W_['pe_w2a'], W_['pe_b2a'], act=1)
-                tab = o.gemm_bf16(h2, W_['pe_w2b'], W_['pe_b2b'], out_dtype=torch.float32)
+                if self.exact:            # fp32-class table: fp32 sine rows, K-concatenated split-precision GEMMs
+                    a1f = torch.empty((Pt, 3 * self.depth_num), device=self.dev, dtype=F32)
+                    a2f = torch.empty((Pt, 384), device=self.dev, dtype=F32)
+                    o.pe_inputs(s2, torch.tensor([Pt], dtype=torch.int32, device=self.dev), Pt, ws['featcl'], T['img2lidar'], T['coords_w'], T['coords_h'],
+                                T['coords_d'], T['embeds'], self.const['dim_t'], a1, a2, xb, None, V, h, w, self.depth_num, self.post_range_h64,
+                                A_frustum_f32=a1f, A_sine_f32=a2f)
+                    h2 = o.gemm_bf16(o.split3_rows(a2f), W_['pe_w2a_c3'], W_['pe_b2a'], act=1, split3=True)
+                    tab = o.gemm_bf16(h2, W_['pe_w2b_c3'], W_['pe_b2b'], out_dtype=torch.float32)
+                    del a1f, a2f
+                else:
+                    h2 = o.gemm_bf16(a2, W_['pe_w2a'], W_['pe_b2a'], act=1)
+                    tab = o.gemm_bf16(h2, W_['pe_w2b'], W_['pe_b2b'], out_dtype=torch.float32)
                 # kept with the tables the workspaces of this map shape share; a captured graph holds the pointer: same shape -> refreshed in place
                 if sh.get('sine_tab') is None or sh['sine_tab'].shape != tab.shape:
                     sh['sine_tab'] = tab
@@ -571,7 +597,8 @@ class HeadEngine:
                            self.stride, self.expand, col_cap=ws['col_cap'], n_samples=B)
             if not forked:
                 tk('roi_align')
-                o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'], out0_f32=ws.get('roi_feat32') if self.exact else None, R=R)
+                o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'], out0_f32=ws.get('roi_feat32') if self.exact else None,
+                            out0_lo=ws.get('roi_lo') if (self.exact and not self.exact_linear) else None, R=R)
         else:
             # positions any RoIAlign tap can touch (own rect + 1 cell) -> PE only there
             o.roi_positions(rois, ws['zero_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'], R, V, h, w,
@@ -618,13 +645,17 @@ class HeadEngine:
             o.gemm_bf16(ws['H2'], W_['pe_w2b'], W_['pe_b2b'], m_dev=md, add=ws['Pg'], out=ws['pe'], out2=ws['Xk'], add2=ws['Xf32'])
         if self.kind == 'S':
             tk('roi_align')
-            if self.exact:
+            if self.exact and self.exact_linear:
                 o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], out0_f32=ws['roi_feat32'],
                             out1_f32=ws['roi_pe32'], map1_index=ws['pos2s'], out1_is_sum=True, R=R)
                 # key rows = RoIAlign(feat) + RoIAlign(pe), value rows = RoIAlign(feat): bf16 hi + lo pairs
                 f32_, p32_ = ws['roi_feat32'].view(R * 49, C), ws['roi_pe32'].view(R * 49, C)
                 o.split_rows(f32_, p32_, hi=ws['roi_sum'].view(R * 49, C), lo=ws['xk_lo'])
                 o.split_rows(f32_, None, hi=ws['roi_feat'].view(R * 49, C), lo=ws['xv_lo'])
+            elif self.exact:
+                # key rows = RoIAlign(feat) + RoIAlign(pe), value rows = RoIAlign(feat), both as bf16 hi + lo pairs straight from the kernel
+                o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=ws['pos2s'], out1_is_sum=True,
+                            out0_lo=ws['xv_lo'], out1_lo=ws['xk_lo'], R=R)
             else:
                 o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=ws['pos2s'],
                             out1_is_sum=True, R=R)
@@ -660,16 +691,37 @@ class HeadEngine:
         ws['pe']; T path: key / value rows as bf16 hi + lo pairs.  No host synchronisation, no allocation: graph-replayable."""
         o, W_, T = ops, self.w, ws['tab']
         md = ws['S_dev']
+        tab = self.pe_sine_table and not self.keep_sine_rows
         o.pe_inputs(ws['s2pos'], md, P, featcl, T['img2lidar'], T['coords_w'], T['coords_h'], T['coords_d'], T['embeds'],
-                    self.const['dim_t'], ws['A1'], ws['A2'], ws['Xf_b'], ws['Xf32'], V, h, w, self.depth_num, self.post_range_h64,
-                    A_frustum_f32=ws['xa1'], A_sine_f32=ws['xa2'])
+                    self.const['dim_t'], ws['A1'], None if tab else ws['A2'], ws['Xf_b'], ws['Xf32'], V, h, w, self.depth_num, self.post_range_h64,
+                    A_frustum_f32=ws['xa1'], A_sine_f32=None if tab else ws['xa2'])
 
-        def lin(x, n_, out, act=0, **kw):
-            b_ = W_['pe_b' + n_[1:]]
-            return o.linear_x3(x, W_['pe_' + n_ + '_x3'], b_, N=b_.numel(), K=x.shape[1], act=act, out=out, M=P, m_dev=md, **kw)
-        lin(lin(ws['Xf32'], 'wr', ws['xg'], 1), 'we', ws['xgate'], 2)                      # SE gate: sigmoid(expand(relu(reduce(feat))))
-        lin(lin(ws['xa2'], 'w2a', ws['xh'], 1), 'w2b', ws['xp2'])                          # adapt_pos3d(sine)
-        lin(lin(ws['xa1'], 'w1a', ws['xh'], 1), 'w1b', ws['pe'], mul=ws['xgate'], add=ws['xp2'])      # position_encoder(frustum) * gate + sine branch
+        if self.exact_linear:
+            def lin(x, n_, out, act=0, **kw):
+                b_ = W_['pe_b' + n_[1:]]
+                return o.linear_x3(x, W_['pe_' + n_ + '_x3'], b_, N=b_.numel(), K=x.shape[1], act=act, out=out, M=P, m_dev=md, **kw)
+            lin(lin(ws['Xf32'], 'wr', ws['xg'], 1), 'we', ws['xgate'], 2)                      # SE gate: sigmoid(expand(relu(reduce(feat))))
+            lin(lin(ws['xa2'], 'w2a', ws['xh'], 1), 'w2b', ws['xp2'])                          # adapt_pos3d(sine)
+            lin(lin(ws['xa1'], 'w1a', ws['xh'], 1), 'w1b', ws['pe'], mul=ws['xgate'], add=ws['xp2'])      # position_encoder(frustum) * gate + sine branch
+        else:
+            # fp32-class products on the plain bf16 tile GEMM: [a_hi | a_lo | a_hi] . [w_hi | w_hi | w_lo]^T (K' = 3 K); the hidden layers leave
+            # the GEMM already in that form (c_split3 epilogue)
+            def mlp(x32, n1, n2, **kw):
+                K1 = x32.shape[1]
+                a3 = ws['x3a'].view(-1)[:P * 3 * K1].view(P, 3 * K1)
+                o.split3_rows(x32, None, out=a3, m_dev=md, M=P)
+                b1 = W_['pe_b' + n1[1:]]
+                N1 = b1.numel()
+                h3 = ws['x3h'].view(-1)[:P * 3 * N1].view(P, 3 * N1)
+                o.gemm_bf16(a3, W_['pe_' + n1 + '_c3'], b1, m_dev=md, act=1, out=h3, split3=True, M=P)
+                return o.gemm_bf16(h3, W_['pe_' + n2 + '_c3'], W_['pe_b' + n2[1:]], m_dev=md, M=P, **kw)
+            mlp(ws['Xf32'], 'wr', 'we', act=2, out=ws['xgate'])                               # SE gate
+            if self.pe_sine_table:
+                sh = ws['shared']
+                mlp(ws['xa1'], 'w1a', 'w1b', mul=ws['xgate'], add=sh['sine_tab'], add_index=ws['s2pos'], add_period=sh['sine_period'], out=ws['pe'])
+            else:
+                mlp(ws['xa2'], 'w2a', 'w2b', out=ws['xp2'])                                   # adapt_pos3d(sine)
+                mlp(ws['xa1'], 'w1a', 'w1b', mul=ws['xgate'], add=ws['xp2'], out=ws['pe'])   # position_encoder(frustum) * gate + sine branch
         if self.kind == 'T':
             o.split_rows(ws['Xf32'], ws['pe'], hi=ws['Xk'], lo=ws['xk_lo'], m_dev=md, M=P)   # key rows = feat + pe
             o.split_rows(ws['Xf32'], None, hi=ws['Xf_b'], lo=ws['xv_lo'], m_dev=md, M=P)     # value rows = feat
@@ -694,8 +746,12 @@ class HeadEngine:
         if self.exact:
             # conv3x3 + ReLU + AvgPool2d(7) on the UNROUNDED RoI features: implicit GEMM inside the bf16x3 linear (every tap = one 256-wide
             # K chunk read from the neighbouring cell's row), then the pooling kernel
-            o.linear_x3(ws['roi_feat32'], W_['qg_conv_wx3'], W_['qg_conv_b'], N=C, K=9 * C, act=1, conv3x3=True, out=ws['convy'], M=R * 49)
-            o.avgpool49(ws['convy'], ws['x2'], C, R)
+            if self.exact_linear:
+                o.linear_x3(ws['roi_feat32'], W_['qg_conv_wx3'], W_['qg_conv_b'], N=C, K=9 * C, act=1, conv3x3=True, out=ws['convy'], M=R * 49)
+                o.avgpool49(ws['convy'], ws['x2'], C, R)
+            else:
+                # the fused conv + ReLU + pool kernel in split precision on the hi + lo RoI cells
+                o.qg_conv_pool_x3(ws['roi_feat'], ws['roi_lo'], W_['qg_conv_wx3'], W_['qg_conv_b'], ws['x2'], R=R)
         else:
             o.qg_conv_pool(ws['roi_feat'], W_['qg_conv_wp'], W_['qg_conv_b'], ws['x2'], R=R)
         tk('qg_rest')

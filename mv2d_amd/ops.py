@@ -33,7 +33,8 @@ def _req(t, dtype, name):
 
 
 def gemm_bf16(A, W, bias=None, *, M=None, A2=None, n_split=0, conv3x3=False, m_dev=None, act=0, mul=None, add=None,
-              out=None, out_dtype=BF16, c_blk_stride=0, c_blk_cols=0, out2=None, add2=None, lda=None, ldc=None):
+              out=None, out_dtype=BF16, c_blk_stride=0, c_blk_cols=0, out2=None, add2=None, lda=None, ldc=None, split3=False,
+              add_index=None, add_period=0):
     """C = epi(A @ W.T + bias) with bf16 MFMA.  A [M,K] bf16 (or [R,49,256] when conv3x3), W [N,K] bf16."""
     lib = _lib.load()
     _req(A, BF16, 'A'); _req(W, BF16, 'W'); _req(A2, BF16, 'A2')
@@ -41,19 +42,22 @@ def gemm_bf16(A, W, bias=None, *, M=None, A2=None, n_split=0, conv3x3=False, m_d
     N, K = W.shape
     if conv3x3:
         Mrows = A.shape[0] * 49
-        lda_ = 256
+        lda_ = A.shape[-1]                 # channels per cell: 256, or 768 for [hi | lo | hi] cells (index-exact route)
     else:
         Mrows = A.shape[0]
         lda_ = A.stride(0) if lda is None else lda
     M = Mrows if M is None else M
     if out is None and out2 is None:
-        out = torch.empty((M, N), device=A.device, dtype=out_dtype)
+        out = torch.empty((M, 3 * N if split3 else N), device=A.device, dtype=out_dtype)
     c_bf16 = 1 if (out is not None and out.dtype == BF16) else 0
     ldc_ = (out.stride(0) if (out is not None and out.dim() == 2 and ldc is None) else (ldc or N))
-    rc = lib.mv2d_gemm_bf16(_p(A), _p(A2), n_split, 1 if conv3x3 else 0, _p(W), _p(bias), M, N, K, lda_, _p(m_dev), act,
-                            _p(mul), mul.stride(0) if mul is not None else 0, _p(add), add.stride(0) if add is not None else 0,
-                            _p(out), c_bf16, ldc_, c_blk_stride, c_blk_cols, _p(out2), _p(add2),
-                            out2.stride(0) if out2 is not None else 0, add2.stride(0) if add2 is not None else 0, _stream())
+    if split3:
+        ldc_ = out.stride(0)
+    rc = lib.mv2d_gemm_bf16_ex(_p(A), _p(A2), n_split, 1 if conv3x3 else 0, _p(W), _p(bias), M, N, K, lda_, _p(m_dev), act,
+                               _p(mul), mul.stride(0) if mul is not None else 0, _p(add), add.stride(0) if add is not None else 0,
+                               _p(out), c_bf16, ldc_, c_blk_stride, c_blk_cols, _p(out2), _p(add2),
+                               out2.stride(0) if out2 is not None else 0, add2.stride(0) if add2 is not None else 0, 1 if split3 else 0,
+                               _p(add_index), int(add_period), _stream())
     check(rc, 'mv2d_gemm_bf16')
     return out if out is not None else out2
 
@@ -201,6 +205,26 @@ def linear_x3(A, W_x3, bias=None, *, N, K, A2=None, n_split=0, act=0, clamp=0.0,
                                         _p(m_dev), 1 if conv3x3 else 0, _p(mul), _p(add), ma.stride(0) if ma is not None else 0,
                                         _stream()), 'mv2d_linear_x3')
     return out
+
+
+def split3_rows(a, b=None, out=None, m_dev=None, M=None):
+    """fp32 [M,cols] (+ b) -> bf16 [M, 3 cols] = [hi | lo | hi]: the A operand of a split-precision product through gemm_bf16 (weights
+    concatenated as [w_hi | w_hi | w_lo], ``cat3_weight``)."""
+    _req(a, torch.float32, 'a'); _req(b, torch.float32, 'b'); _req(out, BF16, 'out'); _req(m_dev, torch.int32, 'm_dev')
+    M = a.shape[0] if M is None else M
+    cols = a.shape[-1]
+    if out is None:
+        out = torch.empty((M, 3 * cols), device=a.device, dtype=BF16)
+    check(_lib.load().mv2d_split3_rows(_p(a), _p(b), _p(out), M, cols, _p(m_dev), _stream()), 'mv2d_split3_rows')
+    return out
+
+
+def cat3_weight(W, taps=1):
+    """fp32 weight [N, taps * K] -> bf16 [N, taps * 3 K]: per tap [w_hi | w_hi | w_lo] (the partner of split3_rows)."""
+    hi, lo = split_bf16x2(W.contiguous())
+    N = W.shape[0]
+    hi, lo = hi.view(N, taps, -1), lo.view(N, taps, -1)
+    return torch.cat([hi, hi, lo], 2).reshape(N, -1).contiguous()
 
 
 def split_rows(a, b=None, hi=None, lo=None, m_dev=None, M=None):
@@ -360,6 +384,15 @@ def qg_conv_pool(roi_feat, W, bias, out, R=None, ld_out=None):
     R = roi_feat.shape[0] if R is None else R
     check(_lib.load().mv2d_qg_conv_pool(_p(roi_feat), _p(W), _p(bias), _p(out), out.stride(0) if ld_out is None else ld_out, R, _stream()),
           'mv2d_qg_conv_pool')
+    return out
+
+
+def qg_conv_pool_x3(roi_hi, roi_lo, W_x3, bias, out, R=None, ld_out=None):
+    """qg_conv_pool in split precision: RoI cells as bf16 hi + lo [R,49,256], W_x3 = pack_x3(conv weight [256,2304])."""
+    _req(roi_hi, BF16, 'roi_hi'); _req(roi_lo, BF16, 'roi_lo'); _req(bias, torch.float32, 'bias'); _req(out, torch.float32, 'out')
+    R = roi_hi.shape[0] if R is None else R
+    check(_lib.load().mv2d_qg_conv_pool_x3(_p(roi_hi), _p(roi_lo), _p(W_x3[0]), _p(W_x3[1]), _p(bias), _p(out),
+                                           out.stride(0) if ld_out is None else ld_out, R, _stream()), 'mv2d_qg_conv_pool_x3')
     return out
 
 
@@ -629,11 +662,12 @@ def posemb3d(ref, dim_t, out=None):
 
 
 def roi_align(map0, rois, H, W, *, map1=None, out0=None, out1=None, out0_f32=None, out1_f32=None, spatial_scale=1.0 / 16,
-              sampling_ratio=-1, map1_index=None, out1_is_sum=False, R=None):
+              sampling_ratio=-1, map1_index=None, out1_is_sum=False, R=None, out0_lo=None, out1_lo=None):
     _req(map0, torch.float32, 'map0'); _req(map1, torch.float32, 'map1'); _req(rois, torch.float32, 'rois')
-    check(_lib.load().mv2d_roi_align(_p(map0), _p(map1), _p(rois), _p(out0), _p(out1), _p(out0_f32), _p(out1_f32),
-                                     rois.shape[0] if R is None else R, H, W, map0.shape[-1], spatial_scale, sampling_ratio,
-                                     _p(map1_index), 1 if out1_is_sum else 0, _stream()), 'mv2d_roi_align')
+    _req(out0_lo, BF16, 'out0_lo'); _req(out1_lo, BF16, 'out1_lo')
+    check(_lib.load().mv2d_roi_align_ex(_p(map0), _p(map1), _p(rois), _p(out0), _p(out1), _p(out0_f32), _p(out1_f32),
+                                        rois.shape[0] if R is None else R, H, W, map0.shape[-1], spatial_scale, sampling_ratio,
+                                        _p(map1_index), 1 if out1_is_sum else 0, _p(out0_lo), _p(out1_lo), _stream()), 'mv2d_roi_align')
 
 
 def box_correlation(rois, view_start, trans, lin, depths, match, V, topk, pad_h, pad_w, max_per_view, sample_size=4,
