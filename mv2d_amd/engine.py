@@ -121,6 +121,10 @@ class HeadEngine:
         # then carry stale rows for the other layers, and the reference's forward does evaluate all six.
         self.last_stage_heads = os.environ.get('MV2D_LAST_STAGE_HEADS', '0') == '1'
         self.keep_xk = os.environ.get('MV2D_KEEP_XK', '0') == '1'   # always write both pe and Xk (S path: nothing reads Xk; T path: nothing reads pe)
+        # T path: cross attention over QUERY TILES with shared key tiles (csrc/xattn_qtile.hip; round 3): the queries of a sample ordered by their
+        # smallest key, 16 per workgroup, the union of their key lists streamed once through LDS.  MV2D_XATTN_QTILE=0: one block per query
+        # (xattn_tile_kernel) as in round 2.  The index-exact route (hi + lo rows) and debug runs stay on the per-query kernel.
+        self.qtile = kind == 'T' and self.tile_attn and os.environ.get('MV2D_XATTN_QTILE', '1') == '1'
         nw = os.environ.get('MV2D_XATTN_NW')
         # waves per query: the kernel alone takes the same 32-33 us per layer with 1, 2 or 4 (it moves its 161 MB at ~5 TB/s either way), but a
         # launch with fewer waves leaves more of the chip to the other streams' kernels: cfg2_s 8067 / 8043 / 7869 samples/s for 1 / 2 / 4,
@@ -340,6 +344,7 @@ class HeadEngine:
         ws['zbuf'] = z(Pp + 16, torch.uint8)                     # roi_mask | nnz[2]: cleared by ONE fill per frame
         ws['roi_mask'] = ws['zbuf'][:P]
         ws['nnz'] = ws['zbuf'][Pp:Pp + 8].view(torch.int32)
+        ws['qt_ctl'] = ws['zbuf'][Pp + 8:Pp + 16].view(torch.int32)      # query-tile tables: allocation counter | overflow flag (zeroed with zbuf)
         ws['zero_mask'] = z(P, torch.uint8)
         ws['rect'] = e((R, 5), torch.int32); ws['pos2s'] = e(P, torch.int32); ws['s2pos'] = e(P, torch.int32)
         ws['S_dev'] = z(1, torch.int32)
@@ -349,6 +354,9 @@ class HeadEngine:
             ws['row_count'] = e(R, torch.int32)
             ws['col_cap'] = R * self.col_cap_per_query
             ws['S_kv'] = P
+            ws['csr_words'] = ops.csr_workspace_bytes(1, Vg, h, w) // 4
+            if getattr(self, 'qtile', False) and not self.exact:
+                ws['qt'] = ops.xattn_qtile_alloc(R, B, ws['col_cap'], self.dev, alloc=lambda n_: alloc(n_, torch.int32, zero=True))
         else:
             ws['col_cap'] = R * (1 + Vg * self.topk) * 49
             ws['S_kv'] = R * 49
@@ -595,6 +603,9 @@ class HeadEngine:
             o.mask_compact(rois, ws['match'], T['pad_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'],
                            ws['bits'], ws['row_count'], ws['row_ptr'], ws['col_idx'], ws['nnz'], R, Vg, h, w, self.topk,
                            self.stride, self.expand, col_cap=ws['col_cap'], n_samples=B)
+            if ws.get('qt') is not None:
+                o.xattn_qtile_build(ws['qt'], ws['row_ptr'], ws['col_idx'], grp, R, ws['bits'], ws['csr_words'], ws['rect'], Vg, Vg * h * w, ws['pos2s'],
+                                    ws['qt_ctl'])
             if not forked:
                 tk('roi_align')
                 o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'], out0_f32=ws.get('roi_feat32') if self.exact else None,
@@ -792,8 +803,11 @@ class HeadEngine:
                     o.xattn_qmap(ws['q'], W_[f'ca_mapA{i}'], ws['Qt'], R=R)
                 if dbg is not None:
                     ws['dbg_q'][i].copy_(ws['q'])
-                o.xattn_tile(ws['Qt'], xk_rows, xv_rows, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=self.empty_nan, waves=self.xattn_waves,
-                             Xk_lo=ws.get('xk_lo'), Xv_lo=ws.get('xv_lo'), dbg_logits=None if dbg is None else dbg[i])
+                if ws.get('qt') is not None and dbg is None:
+                    o.xattn_qtile(ws['Qt'], xk_rows, xv_rows, ws['qt'], ws['zh'], R, empty_nan=self.empty_nan)
+                else:
+                    o.xattn_tile(ws['Qt'], xk_rows, xv_rows, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=self.empty_nan, waves=self.xattn_waves,
+                                 Xk_lo=ws.get('xk_lo'), Xv_lo=ws.get('xv_lo'), dbg_logits=None if dbg is None else dbg[i])
                 if not maps_fused:
                     o.xattn_ctxmap(ws['zh'], W_[f'ca_mapB{i}'], W_[f'ca_v_b{i}'], ws['row_ptr'], ws['ctx'], R, empty_nan=self.empty_nan)
                 return
@@ -1066,16 +1080,22 @@ class HeadEngine:
         other.prof = None
         return other
 
+    @staticmethod
+    def _check_capacity(ws):
+        if int(ws['nnz'][1].item()) != 0:
+            raise RuntimeError('mv2d engine: CSR capacity exceeded (raise col_cap_per_query)')
+        if ws.get('qt') is not None and int(ws['qt_ctl'][1].item()) != 0:
+            raise RuntimeError('mv2d engine: a query tile of the shared-key cross attention exceeded its capacity (8192 distinct keys per 16 queries / '
+                               '4096 queries per sample): run with MV2D_XATTN_QTILE=0')
+
     def results(self, out):
         """Synchronising accessor: sliced (boxes [K,9], scores [K], labels [K]) like simple_test returns."""
         n = int(out['count'][0].item())
-        if int(out['ws']['nnz'][1].item()) != 0:
-            raise RuntimeError('mv2d engine: CSR capacity exceeded (raise col_cap_per_query)')
+        self._check_capacity(out['ws'])
         return out['boxes'][:n], out['scores'][:n], out['labels'][:n]
 
     def results_batch(self, out):
         """Synchronising accessor of run_batch: one (boxes [K,9], scores [K], labels [K]) per sample."""
         counts = out['count'].tolist()
-        if int(out['ws']['nnz'][1].item()) != 0:
-            raise RuntimeError('mv2d engine: CSR capacity exceeded (raise col_cap_per_query)')
+        self._check_capacity(out['ws'])
         return [(out['boxes'][b, :n], out['scores'][b, :n], out['labels'][b, :n]) for b, n in enumerate(counts)]

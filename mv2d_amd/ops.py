@@ -557,6 +557,36 @@ def xattn_tile(Qt, Xk, Xv, row_ptr, col_idx, out=None, R=None, dbg_logits=None, 
     return out
 
 
+def xattn_qtile_alloc(R, n_samples, col_cap, device, alloc=None):
+    """Tables of the shared-key-tile cross attention (T path) for launches of R query rows / n_samples samples / col_cap CSR entries.
+    alloc(n) -> zeroed int32 tensor of n elements (default: torch.zeros on `device`)."""
+    nt = int(_lib.load().mv2d_xattn_qtile_max_tiles(R, n_samples))
+    ucap = (col_cap + 16 * nt + 15) // 16 * 16
+    i32 = alloc if alloc is not None else (lambda n: torch.zeros(n, dtype=torch.int32, device=device))
+    return dict(perm=i32(R), tq0=i32(nt), tqn=i32(nt), nt=i32(1), uptr=i32(nt), ucnt=i32(nt), ukeys=i32(ucap), mask=i32(ucap // 16 * 8), ucap=ucap,
+                max_tiles=nt, n_samples=n_samples)
+
+
+def xattn_qtile_build(qt, row_ptr, col_idx, grp_start, R, bits, nwords, rect, V, cells_per_sample, pos2s, ctl):
+    """qt = xattn_qtile_alloc(...); ctl int32 [2] = (allocation counter, overflow flag), zeroed by the caller for this frame."""
+    check(_lib.load().mv2d_xattn_qtile_build(_p(row_ptr), _p(col_idx), _p(grp_start), qt['n_samples'], R, _p(bits), nwords, _p(rect), V, cells_per_sample,
+                                             _p(pos2s), _p(qt['perm']), _p(qt['tq0']), _p(qt['tqn']), _p(qt['nt']), _p(qt['uptr']), _p(qt['ucnt']),
+                                             _p(qt['ukeys']), qt['ucap'], _p(qt['mask']), ctl.data_ptr(), ctl.data_ptr() + 4, _stream()),
+          'mv2d_xattn_qtile_build')
+
+
+def xattn_qtile(Qt, Xk, Xv, qt, out=None, R=None, empty_nan=True):
+    """Cross attention over query tiles with shared key tiles (tables from xattn_qtile_build): z [R,8,256] fp32 like xattn_tile."""
+    _req(Qt, BF16, 'Qt'); _req(Xk, BF16, 'Xk'); _req(Xv, BF16, 'Xv')
+    R = Qt.shape[0] if R is None else R
+    if out is None:
+        out = torch.empty((R, 8, 256), device=Qt.device, dtype=torch.float32)
+    check(_lib.load().mv2d_xattn_qtile_fwd(_p(Qt), _p(Xk), _p(Xv), _p(qt['perm']), _p(qt['tq0']), _p(qt['tqn']), _p(qt['nt']), _p(qt['uptr']),
+                                           _p(qt['ucnt']), _p(qt['ukeys']), _p(qt['mask']), _p(out), R, qt['n_samples'], 1 if empty_nan else 0, _stream()),
+          'mv2d_xattn_qtile_fwd')
+    return out
+
+
 def xattn_ctxmap(z, WB, bv, row_ptr, out=None, R=None, empty_nan=True):
     """z [R,8,256] fp32 -> ctx [R,256] = Wv_h z_h + bv; rows without a key (row_ptr) give NaN / 0."""
     _req(z, torch.float32, 'z'); _req(WB[0], BF16, 'WB_hi'); _req(WB[1], BF16, 'WB_lo'); _req(bv, torch.float32, 'bv')

@@ -495,3 +495,64 @@ def test_last_stage_heads_option(name, kind):
         assert torch.equal(oa['cls'][-1], ob['cls'][-1]) and torch.equal(oa['reg'][-1], ob['reg'][-1])
     ok = b.run(feat, props, prob['img_metas'], keep_stages=True)                  # a keep_stages run evaluates all layers again
     assert torch.equal(ok['cls'], oa['cls'])
+
+
+@pytest.mark.parametrize('name,n', [('micro_t', 1), ('cfg1_t', 1), ('cfg1_t', 3), ('cfg3_t', 1), ('cfg3_t', 2)])
+def test_query_tile_cross_attention_tables_and_result(name, n):
+    """T path, shared-key-tile cross attention (csrc/xattn_qtile.hip): (1) the tables mv2d_xattn_qtile_build derives from the CSR -- query
+    order, tiles, union key lists, pair masks -- reproduce EXACTLY the allowed (query, key) pairs of the CSR (which is bit-exact against the
+    reference's masks, tests/test_gpu_golden.py); (2) the query-tile kernel and the one-block-per-query kernel (verified against fp64 in
+    tests/test_gpu_kernels.py) give the same z on the engine's own operands up to the order of the fp32 sums."""
+    from mv2d_amd import ops
+    from mv2d_amd.engine import HeadEngine
+    dev = torch.device('cuda:0')
+    sd = synthetic.make_head_state(seed=0)
+    probs = [synthetic.make_problem(name, seed=s) for s in range(n)]
+    eng = HeadEngine(sd, 'T', dev, num_views=probs[0]['views_per_frame'])
+    assert eng.qtile
+    feats = [torch.from_numpy(p['feat']).to(dev) for p in probs]
+    props = [[torch.from_numpy(x) for x in p['proposals']] for p in probs]
+    metas = [p['img_metas'] for p in probs]
+    out = eng.run_batch(feats, props, metas) if n > 1 else eng.run(feats[0], props[0], metas[0])
+    torch.cuda.synchronize()
+    ws = out['ws']
+    qt = ws['qt']
+    Rl = ws['x'].shape[0]                                        # rows of the launch (RoI-count bucket)
+    assert int(ws['qt_ctl'][1].item()) == 0
+    rp, ci = ws['row_ptr'][:Rl + 1].cpu().numpy(), ws['col_idx'].cpu().numpy()
+    perm, nt = qt['perm'].cpu().numpy(), int(qt['nt'].item())
+    tq0, tqn = qt['tq0'].cpu().numpy()[:nt], qt['tqn'].cpu().numpy()[:nt]
+    uptr, ucnt, ukeys = qt['uptr'].cpu().numpy()[:nt], qt['ucnt'].cpu().numpy()[:nt], qt['ukeys'].cpu().numpy()
+    mask = qt['mask'].cpu().numpy().view(np.uint32)
+    grp = list(ws['grp_start_h'].numpy()) + [Rl]
+    assert sorted(perm[:Rl].tolist()) == list(range(Rl))
+    for a, b in zip(grp[:-1], grp[1:]):                          # the order stays inside a sample and is ascending in the smallest key
+        assert sorted(perm[a:b].tolist()) == list(range(a, b))
+        firsts = [ci[rp[r]] if rp[r + 1] > rp[r] else 2 ** 31 - 1 for r in perm[a:b]]
+        assert firsts == sorted(firsts)
+    seen = set()
+    tot_union = 0
+    for t in range(nt):
+        keys = ukeys[uptr[t]:uptr[t] + ucnt[t]]
+        assert (np.diff(keys) > 0).all()
+        tot_union += int(ucnt[t])
+        nut = (ucnt[t] + 15) // 16
+        mw = mask[(uptr[t] // 16) * 8:(uptr[t] // 16 + nut) * 8].reshape(nut, 8)
+        for j in range(tqn[t]):
+            r = int(perm[tq0[t] + j])
+            seen.add(r)
+            m16 = (mw[:, j // 2] >> (16 * (j % 2))) & 0xffff
+            bits = ((m16[:, None] >> np.arange(16)[None]) & 1).astype(bool).reshape(-1)[:ucnt[t]]
+            np.testing.assert_array_equal(keys[bits], np.sort(ci[rp[r]:rp[r + 1]]))
+    assert seen == set(range(Rl))
+    nnz, S = int(rp[out['R']]), int(ws['S_dev'].item())
+    print(f'{name} x{n}: {nt} query tiles, sum of union lists {tot_union} = {tot_union / max(S, 1):.2f} x the {S} distinct keys (per-query lists: {nnz} = {nnz / max(S, 1):.2f} x)')
+    # the same Qt (last decoder layer) through both kernels
+    z_q = ops.xattn_qtile(ws['Qt'], ws['xk_rows'], ws['xv_rows'], qt, R=Rl, empty_nan=False)
+    z_t = ops.xattn_tile(ws['Qt'], ws['xk_rows'], ws['xv_rows'], ws['row_ptr'], ws['col_idx'], R=Rl, empty_nan=False, waves=2)
+    torch.cuda.synchronize()
+    err = float((z_q - z_t).abs().max() / z_t.abs().max())
+    print(f'   query-tile kernel vs per-query kernel: max |dz| / max |z| = {err:.1e}')
+    assert err < 2e-5
+    z_q2 = ops.xattn_qtile(ws['Qt'], ws['xk_rows'], ws['xv_rows'], qt, R=Rl, empty_nan=False)
+    assert torch.equal(z_q, z_q2)                               # deterministic
