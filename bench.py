@@ -430,11 +430,12 @@ def main():
     xattn = None
     if getattr(eng, 'tile_attn', False):
         xk, xv = ws['xk_rows'], ws['xv_rows']
+        q_ord = ws.get('q_order')                          # T path: blocks in the order of the queries' smallest key (as the engine launches it)
         for _ in range(3):
-            ops.xattn_tile(ws['Qt'], xk, xv, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=eng.empty_nan, waves=eng.xattn_waves)
+            ops.xattn_tile(ws['Qt'], xk, xv, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=eng.empty_nan, waves=eng.xattn_waves, order=q_ord)
         e0.record()
         for _ in range(20):
-            ops.xattn_tile(ws['Qt'], xk, xv, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=eng.empty_nan, waves=eng.xattn_waves)
+            ops.xattn_tile(ws['Qt'], xk, xv, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=eng.empty_nan, waves=eng.xattn_waves, order=q_ord)
         e1.record()
         torch.cuda.synchronize()
         x_ms = e0.elapsed_time(e1) / 20

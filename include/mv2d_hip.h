@@ -304,6 +304,11 @@ int mv2d_raw_xattn_fwd(const float* qk, const void* Xk, const void* Xv, const in
 int mv2d_xattn_qmap(const float* q, const void* WA_hi, const void* WA_lo, void* Qt, int R, void* stream);
 int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                         const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves, void* stream);
+/* The same with a block -> query order (order [R]: a permutation of the query rows, e.g. mv2d_xattn_qtile_build's perm = the queries of every
+ * sample sorted by their smallest key): neighbouring blocks then read overlapping key sets and share an L2.  Results are identical. */
+int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
+                                const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
+                                const int* order, void* stream);
 int mv2d_xattn_ctxmap(const float* z, const void* WB_hi, const void* WB_lo, const float* bv, const int* row_ptr, float* ctx, int R,
                       int empty_nan, void* stream);
 
@@ -312,18 +317,21 @@ int mv2d_xattn_ctxmap(const float* z, const void* WB_hi, const void* WB_lo, cons
  * mv2d_xattn_qtile_build (once per frame, after mv2d_mask_compact on the same stream): orders the queries of every sample by their
  * smallest key index (perm [R]), cuts the order into tiles (tile_q0 / tile_qn [max_tiles], *n_tiles on the device) and writes per tile the
  * ascending union key list (ukeys + uptr / ucnt, padded to multiples of 16; ucap = capacity in keys, a multiple of 16, >= nnz + 16 max_tiles)
- * and the pair masks (qmask: ucap / 16 * 8 dwords).  bits / nwords / rect / pos2s: the per-query cell bitmasks and tables mv2d_mask_compact
+ * and the pair masks (qmask: ucap / 16 * queries_per_tile / 2 dwords; queries_per_tile = 8 (4 waves per workgroup) or 16 (8 waves)).  bits / nwords / rect / pos2s: the per-query cell bitmasks and tables mv2d_mask_compact
  * left in its workspace; grp_start [n_samples + 1] = first query row of every sample (rows behind the last sample: bucket padding, tiled
  * as a group of their own).  alloc / flags: device int32 words the caller zeroes per frame; flags[0] != 0 afterwards = a capacity was
  * exceeded (more than 8192 distinct keys in one query tile, more than 4096 queries in a sample, ucap).
  * mv2d_xattn_qtile_fwd: z [R][8][256] like mv2d_xattn_tile_fwd (same Qt / Xk / Xv operands); differs from it in the order of the fp32 sums only. */
-long long mv2d_xattn_qtile_max_tiles(int R, int n_samples);
+long long mv2d_xattn_qtile_max_tiles(int R, int n_samples, int queries_per_tile /* 8 or 16 */);
+/* The query order alone: perm [R] = the rows of every sample sorted by their smallest key index (CSR rows ascending, as mv2d_mask_compact writes
+ * them); flags[0] != 0: more than 4096 queries in a sample (natural order kept).  For mv2d_xattn_tile_fwd_ordered. */
+int mv2d_xattn_query_order(const int* row_ptr, const int* col_idx, const int* grp_start, int n_samples, int R, int* perm, int* flags, void* stream);
 int mv2d_xattn_qtile_build(const int* row_ptr, const int* col_idx, const int* grp_start, int n_samples, int R, const void* bits, int nwords,
                            const int* rect, int V, int cells_per_sample, const int* pos2s, int* perm, int* tile_q0, int* tile_qn, int* n_tiles,
-                           int* uptr, int* ucnt, int* ukeys, int ucap, void* qmask, int* alloc, int* flags, void* stream);
+                           int* uptr, int* ucnt, int* ukeys, int ucap, void* qmask, int* alloc, int* flags, int queries_per_tile, void* stream);
 int mv2d_xattn_qtile_fwd(const void* Qt, const void* Xk, const void* Xv, const int* perm, const int* tile_q0, const int* tile_qn,
                          const int* n_tiles, const int* uptr, const int* ucnt, const int* ukeys, const void* qmask, float* z, int R,
-                         int n_samples, int empty_nan, void* stream);
+                         int n_samples, int empty_nan, int queries_per_tile, void* stream);
 
 /* The two row kernels around the tile cross attention with its per-head maps fused in (one launch each instead of two; bitwise the
  * same results):

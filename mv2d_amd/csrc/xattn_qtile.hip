@@ -21,18 +21,20 @@
 //                       z[(q, h)][ch]          += sum over 32 k = [P_hi | P_lo][(q, h)][key] . [Xv ; Xv][key][ch]         16 x v_mfma_f32_16x16x32_bf16
 //                     A wave whose two queries have no allowed key in a union tile skips it (its mask word is zero).
 // The result differs from xattn_tile_kernel's only in the order of the fp32 sums (tests compare both with fp64).
+#include <cstdlib>
 #include "common.h"
 
 namespace {
 
 constexpr int C = 256, HEADS = 8;
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr int QT = 16;                       // queries per tile (2 per wave x 8 waves)
+constexpr int QT_MAX = 16;                   // queries per tile: 16 (8 waves x 2) or 8 (4 waves x 2)
 constexpr int UT_MAX = 512;                  // union tiles (of 16 keys) a query tile may have: 8192 keys
 constexpr int GRP_MAX = 4096;                // queries per sample the ordering kernel ranks in LDS
 
 typedef __attribute__((ext_vector_type(8))) __bf16 qt_bf16x8;
-union QFrag { uint4 u; qt_bf16x8 v; };
+typedef unsigned int qt_u32x4 __attribute__((ext_vector_type(4)));      // native vector: arrays of HIP's uint4 STRUCT end up in scratch
+union QFrag { uint4 u; qt_bf16x8 v; qt_u32x4 n; };
 
 #define QT_DPP(v, ctrl) __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), ctrl, 0xF, 0xF, true))
 __device__ __forceinline__ float qt_row16_max(float v) {
@@ -51,7 +53,7 @@ __device__ __forceinline__ unsigned int qt_hi_pair(unsigned int a, unsigned int 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void qt_order_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const int* __restrict__ grp_start,
                                                         int n_grp, int R, int* __restrict__ perm, int* __restrict__ tile_q0, int* __restrict__ tile_qn,
-                                                        int* __restrict__ n_tiles, int* __restrict__ flags) {
+                                                        int* __restrict__ n_tiles, int* __restrict__ flags, int QT) {
     __shared__ int key[GRP_MAX];
     const int g = blockIdx.x, tid = threadIdx.x;
     const int lo = g < n_grp ? grp_start[g] : grp_start[n_grp];
@@ -64,8 +66,10 @@ __global__ __launch_bounds__(1024) void qt_order_kernel(const int* __restrict__ 
         tb += (nk + QT - 1) / QT;
     }
     const int nt = (n + QT - 1) / QT;
-    for (int i = tid; i < nt; i += 1024) { tile_q0[tb + i] = lo + i * QT; tile_qn[tb + i] = min(QT, n - i * QT); }
-    if (g == n_grp && tid == 0) *n_tiles = tb + nt;
+    if (tile_q0) {                                             // (null: only the order is wanted, mv2d_xattn_query_order)
+        for (int i = tid; i < nt; i += 1024) { tile_q0[tb + i] = lo + i * QT; tile_qn[tb + i] = min(QT, n - i * QT); }
+        if (g == n_grp && tid == 0) *n_tiles = tb + nt;
+    }
     if (n > GRP_MAX) {                                         // too many queries in one sample for the LDS ranking: keep the natural order
         if (tid == 0) flags[0] = 1;
         for (int i = tid; i < n; i += 1024) perm[lo + i] = lo + i;
@@ -90,6 +94,7 @@ __global__ __launch_bounds__(1024) void qt_order_kernel(const int* __restrict__ 
 // qmask[(uptr >> 4) + t][w] = (mask of query slot 2w) | (mask of slot 2w + 1) << 16: the allowed keys of the slots among the 16 keys of union tile t.  Storage is handed out by an atomic bump
 // counter (alloc[0], zeroed per frame): the placement of a tile is arbitrary, its contents are not.
 // ------------------------------------------------------------------------------------------------
+template <int QT>
 __global__ __launch_bounds__(256) void qt_build_kernel(const unsigned int* __restrict__ bits, int nwords, const int* __restrict__ rect, int V,
                                                        int cells_per_sample, const int* __restrict__ pos2s, const int* __restrict__ perm,
                                                        const int* __restrict__ tile_q0, const int* __restrict__ tile_qn, const int* __restrict__ n_tiles,
@@ -180,28 +185,40 @@ __global__ __launch_bounds__(256) void qt_build_kernel(const unsigned int* __res
 //   Qt [R][8 heads][8 k-steps][4][hi | lo][8] bf16 (xattn_qmap_kernel), Xk / Xv [S][256] bf16, z [R][8][256] fp32
 // MFMA rows m = 8 * (query of the wave) + head.
 // ------------------------------------------------------------------------------------------------
+// LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [lds_base, lds_base + 1 KB), lane linear (the swizzle of the tile
+// image is applied to the SOURCE chunk).  Issued from inline asm and ordered by hand (counted vmcnt + barrier), like csrc/kvproj.hip: a
+// compiler-visible DMA is drained before every following ds_read.
+__device__ __forceinline__ void qt_dma16(const void* gsrc, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_base) : "memory");
+}
+template <int CNT>
+__device__ __forceinline__ void qt_wait_vm() { __builtin_amdgcn_s_waitcnt(0x0F70 | (CNT & 15) | ((CNT >> 4) << 14)); }
+
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void xattn_qtile_kernel(const uint4* __restrict__ Qt, const unsigned short* __restrict__ Xk,
                                                                  const unsigned short* __restrict__ Xv, const int* __restrict__ perm,
                                                                  const int* __restrict__ tile_q0, const int* __restrict__ tile_qn,
                                                                  const int* __restrict__ n_tiles, const int* __restrict__ uptr, const int* __restrict__ ucnt,
                                                                  const int* __restrict__ ukeys, const unsigned int* __restrict__ qmask,
-                                                                 float* __restrict__ z, int empty_nan) {
-    static_assert(2 * NW == QT, "two queries per wave");
-    constexpr int NT = 64 * NW, CP = 512 / NT;                  // 16-byte chunks of a K (or V) tile per thread
-    __shared__ __attribute__((aligned(16))) uint4 kt[2][512], vt[2][512];
-    __shared__ __attribute__((aligned(16))) float pls[NW][256];
-    constexpr int SEG = 256;                                    // union tiles whose key indices / masks are resident in LDS at a time
-    __shared__ int uk[SEG * 16];
-    __shared__ unsigned int mk[SEG * NW];
+                                                                 float* __restrict__ z, int empty_nan, int dbg_mode) {
+    constexpr int QT = 2 * NW;
+    constexpr int NT = 64 * NW;
+    constexpr int NB = 4;                                       // ring of K / V tile buffers: NB - 1 tiles in flight behind the one being computed
+    constexpr int PW = 16 / NW;                                 // 1 KB DMA pieces per wave and tile (8 of the K tile + 8 of the V tile per block)
+    constexpr int SEG = 128;                                    // union tiles whose key indices / masks are resident in LDS at a time
+    constexpr int TILE_B = 16384, RING_B = NB * TILE_B, PL_B = NW * 1024, UK_B = SEG * 16 * 4, MK_B = SEG * NW * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RING_B + PL_B + UK_B + MK_B];
+    float* pls = reinterpret_cast<float*>(smem + RING_B);
+    int* uk = reinterpret_cast<int*>(smem + RING_B + PL_B);
+    unsigned int* mk = reinterpret_cast<unsigned int*>(smem + RING_B + PL_B + UK_B);
     const int tb = blockIdx.x;
     if (tb >= *n_tiles) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 15, g = lane >> 4;
     const int q0 = tile_q0[tb], qn = tile_qn[tb], u0 = uptr[tb], U = ucnt[tb];
     const int ntile = (U + 15) >> 4;
     const int j0 = 2 * wave, j1 = 2 * wave + 1;          // (mask dword of a union tile: slot j0 in the low half, j1 in the high half)
     const int r0 = j0 < qn ? perm[q0 + j0] : -1, r1 = j1 < qn ? perm[q0 + j1] : -1;
-    float* pl = pls[wave];
+    float* pl = pls + wave * 256;
 
     // this wave's A operand of the logits: rows m = 8 qsel + h, 16 k-steps (8 of the hi parts, 8 of the lo parts)
     QFrag qa[16];
@@ -218,39 +235,34 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_qtile_kernel(const uint4* __
 #pragma unroll
     for (int u = 0; u < 16; ++u) Z[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // ---- tile ring: registers hold the rows of the tile two steps ahead, LDS buffer (t & 1) the tile being computed
-    uint4 rk[2][CP], rv[2][CP];
-    auto load_tile = [&](int t, uint4 (&k_)[CP], uint4 (&v_)[CP]) {
+    // ---- tile ring (LDS-DMA): tile image = [16 rows][32 slots of 16 B], chunk c of row r in slot c ^ r; K image then V image.
+    // Piece p (0..15) of a tile = rows 2 (p & 7), 2 (p & 7) + 1 of the K (p < 8) or V (p >= 8) image; wave w issues pieces w PW .. w PW + PW - 1.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int dma_half = lane >> 5, dma_slot = lane & 31;
+    auto issue = [&](int t) {
+        const unsigned bufb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(t % NB) * TILE_B);
 #pragma unroll
-        for (int i = 0; i < CP; ++i) {
-            const int c = tid + NT * i, row = c >> 5, ch = c & 31;
-            const unsigned int ridx = (unsigned int)uk[16 * t + row];
-            const unsigned int off = ridx * (unsigned)(C * 2) + (unsigned)ch * 16u;
-            k_[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Xk) + off);
-            v_[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Xv) + off);
-        }
-    };
-    auto store_tile = [&](int buf, const uint4 (&k_)[CP], const uint4 (&v_)[CP]) {
-#pragma unroll
-        for (int i = 0; i < CP; ++i) {
-            const int c = tid + NT * i, row = c >> 5, ch = c & 31;
-            kt[buf][row * 32 + (ch ^ (row & 15))] = k_[i];
-            vt[buf][row * 32 + (ch ^ (row & 15))] = v_[i];
+        for (int j = 0; j < PW; ++j) {
+            const int p = wave * PW + j, row = 2 * (p & 7) + dma_half;
+            const unsigned int ridx = dbg_mode == 2 ? (unsigned int)(row + 16 * (blockIdx.x & 255)) : (unsigned int)uk[16 * t + row];
+            const unsigned int off = ridx * (unsigned)(C * 2) + (unsigned)((dma_slot ^ row) << 4);
+            const char* src = reinterpret_cast<const char*>(p < 8 ? Xk : Xv) + off;
+            qt_dma16(src, bufb + (unsigned)p * 1024u);
         }
     };
     const unsigned int* qm = qmask + (long long)(u0 >> 4) * NW;
 
-    auto compute = [&](int t, int buf) {
+    auto compute = [&](int t) {
         // the two queries' masks for this union tile (wave-uniform)
         const unsigned int mm = __builtin_amdgcn_readfirstlane(mk[t * NW + wave]);
-        if (mm == 0u) return;
-        const uint4* ktb = kt[buf];
-        const uint4* vtb = vt[buf];
+        if (mm == 0u || dbg_mode == 1) return;
+        const qt_u32x4* ktb = reinterpret_cast<const qt_u32x4*>(smem + (t % NB) * TILE_B);
+        const qt_u32x4* vtb = ktb + 512;
         f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             QFrag kb;
-            kb.u = ktb[n * 32 + ((4 * s + g) ^ n)];
+            kb.n = ktb[n * 32 + ((4 * s + g) ^ n)];
             sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[8 + s].v, kb.v, sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[s].v, kb.v, sacc, 0, 0, 0);
         }
@@ -284,28 +296,28 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_qtile_kernel(const uint4* __
             }
             pa.u = g < 2 ? make_uint4(h[0], h[1], h[2], h[3]) : make_uint4(l[0], l[1], l[2], l[3]);
         }
+        // (once a row's running maximum has settled alpha is exactly 1: skip the 64 rescaling multiplies when that holds for the whole wave)
+        const bool rescale = __builtin_amdgcn_ballot_w64((alpha[0] != 1.f) | (alpha[1] != 1.f) | (alpha[2] != 1.f) | (alpha[3] != 1.f)) != 0ull;
         // z = alpha z + P . Xv_tile; column tile (H, w): output column n <-> channel 128 H + 8 n + w; B[k = 8g + e][n] = Xv[key 8 (g & 1) + e][channel]
 #pragma unroll
         for (int H = 0; H < 2; ++H) {
-            uint4 vr[8];
+            qt_u32x4 vr[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int row = 8 * (g & 1) + e;
-                vr[e] = vtb[row * 32 + ((16 * H + n) ^ (row & 15))];
+                vr[e] = vtb[row * 32 + ((16 * H + n) ^ row)];
             }
 #pragma unroll
             for (int w = 0; w < 8; ++w) {
                 const int d = w >> 1;
-                const unsigned int a0 = d == 0 ? vr[0].x : d == 1 ? vr[0].y : d == 2 ? vr[0].z : vr[0].w, a1 = d == 0 ? vr[1].x : d == 1 ? vr[1].y : d == 2 ? vr[1].z : vr[1].w;
-                const unsigned int a2 = d == 0 ? vr[2].x : d == 1 ? vr[2].y : d == 2 ? vr[2].z : vr[2].w, a3 = d == 0 ? vr[3].x : d == 1 ? vr[3].y : d == 2 ? vr[3].z : vr[3].w;
-                const unsigned int a4 = d == 0 ? vr[4].x : d == 1 ? vr[4].y : d == 2 ? vr[4].z : vr[4].w, a5 = d == 0 ? vr[5].x : d == 1 ? vr[5].y : d == 2 ? vr[5].z : vr[5].w;
-                const unsigned int a6 = d == 0 ? vr[6].x : d == 1 ? vr[6].y : d == 2 ? vr[6].z : vr[6].w, a7 = d == 0 ? vr[7].x : d == 1 ? vr[7].y : d == 2 ? vr[7].z : vr[7].w;
                 QFrag vb;
-                vb.u = (w & 1) ? make_uint4(qt_hi_pair(a0, a1), qt_hi_pair(a2, a3), qt_hi_pair(a4, a5), qt_hi_pair(a6, a7))
-                               : make_uint4(qt_lo_pair(a0, a1), qt_lo_pair(a2, a3), qt_lo_pair(a4, a5), qt_lo_pair(a6, a7));
+                vb.u = (w & 1) ? make_uint4(qt_hi_pair(vr[0][d], vr[1][d]), qt_hi_pair(vr[2][d], vr[3][d]), qt_hi_pair(vr[4][d], vr[5][d]), qt_hi_pair(vr[6][d], vr[7][d]))
+                               : make_uint4(qt_lo_pair(vr[0][d], vr[1][d]), qt_lo_pair(vr[2][d], vr[3][d]), qt_lo_pair(vr[4][d], vr[5][d]), qt_lo_pair(vr[6][d], vr[7][d]));
                 f32x4_t zc = Z[H * 8 + w];
+                if (rescale) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) zc[i] *= alpha[i];
+                    for (int i = 0; i < 4; ++i) zc[i] *= alpha[i];
+                }
                 Z[H * 8 + w] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa.v, vb.v, zc, 0, 0, 0);
             }
         }
@@ -314,26 +326,20 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_qtile_kernel(const uint4* __
 
     for (int seg0 = 0; seg0 < ntile; seg0 += SEG) {
         const int nseg = min(SEG, ntile - seg0);
-        __syncthreads();                                                    // (the previous segment's readers of uk / mk / the tile buffers are done)
+        __syncthreads();                                                    // (the previous segment's readers of uk / mk / the ring are done)
         for (int i = tid; i < nseg * 16; i += NT) uk[i] = ukeys[u0 + 16 * seg0 + i];
         for (int i = tid; i < nseg * NW; i += NT) mk[i] = qm[seg0 * NW + i];
         __syncthreads();
-        load_tile(0, rk[0], rv[0]);
-        if (nseg > 1) load_tile(1, rk[1], rv[1]);
-        store_tile(0, rk[0], rv[0]);
-        __syncthreads();
-        for (int t = 0; t < nseg; t += 2) {
-            // even step: compute tile t from buffer 0; registers: set 1 = tile t + 1 (in flight), set 0 free -> tile t + 2
-            if (t + 2 < nseg) load_tile(t + 2, rk[0], rv[0]);
-            compute(t, 0);
-            if (t + 1 < nseg) store_tile(1, rk[1], rv[1]);
-            __syncthreads();
-            if (t + 1 >= nseg) break;
-            // odd step
-            if (t + 3 < nseg) load_tile(t + 3, rk[1], rv[1]);
-            compute(t + 1, 1);
-            if (t + 2 < nseg) store_tile(0, rk[0], rv[0]);
-            __syncthreads();
+        qt_wait_vm<0>();                                                    // no ordinary load may be in flight beside the counted DMA pieces
+        for (int t = 0; t < NB - 1 && t < nseg; ++t) issue(t);
+        for (int t = 0; t < nseg; ++t) {
+            // this wave's pieces of tile t have landed (younger pieces, of the tiles issued after it, may stay in flight); then everybody's
+            const int ahead = min(nseg, t + NB - 1) - t - 1;                // tiles issued behind tile t
+            if (ahead >= 2) qt_wait_vm<2 * PW>(); else if (ahead == 1) qt_wait_vm<PW>(); else qt_wait_vm<0>();
+            __builtin_amdgcn_s_barrier();                                   // ... and every wave is done with tile t - 1: its buffer is free
+            asm volatile("" ::: "memory");
+            if (t + NB - 1 < nseg) issue(t + NB - 1);
+            compute(t);
         }
     }
     // ---- row sums over the 16 key lanes, normalise, store: row 4g + i = (query g >> 1, head 4 (g & 1) + i); lane n holds channels
@@ -368,35 +374,62 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_qtile_kernel(const uint4* __
 
 }  // namespace
 
-extern "C" long long mv2d_xattn_qtile_max_tiles(int R, int n_samples) { return (long long)(R + QT - 1) / QT + n_samples + 1; }
+static inline int qt_size(int queries_per_tile) { return queries_per_tile == 16 ? 16 : 8; }
+extern "C" long long mv2d_xattn_qtile_max_tiles(int R, int n_samples, int queries_per_tile) {
+    const int QT = qt_size(queries_per_tile);
+    return (long long)(R + QT - 1) / QT + n_samples + 1;
+}
+
+// Query order alone (T path): perm [R] = the queries of every sample sorted by their smallest key (bucket-padding rows behind the last sample keep
+// their places as a group of their own).  xattn_tile_kernel launched in this order reads overlapping key sets from neighbouring blocks.
+extern "C" int mv2d_xattn_query_order(const int* row_ptr, const int* col_idx, const int* grp_start, int n_samples, int R, int* perm, int* flags, void* stream) {
+    MV2D_CHECK_ARG(row_ptr && col_idx && grp_start && perm && flags && R > 0 && n_samples >= 1, "mv2d_xattn_query_order: bad args");
+    hipLaunchKernelGGL(qt_order_kernel, dim3(n_samples + 1), dim3(1024), 0, (hipStream_t)stream, row_ptr, col_idx, grp_start, n_samples, R, perm, (int*)nullptr,
+                       (int*)nullptr, (int*)nullptr, flags, 8);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
 
 // Per frame, after mv2d_mask_compact (same stream): query order + tile table + union key lists + pair masks.  alloc / flags: int32
 // device words zeroed by the caller before the call (flags[0] != 0 afterwards: a capacity was exceeded and the tables are unusable).
 extern "C" int mv2d_xattn_qtile_build(const int* row_ptr, const int* col_idx, const int* grp_start, int n_samples, int R, const void* bits, int nwords,
                                       const int* rect, int V, int cells_per_sample, const int* pos2s, int* perm, int* tile_q0, int* tile_qn,
-                                      int* n_tiles, int* uptr, int* ucnt, int* ukeys, int ucap, void* qmask, int* alloc, int* flags, void* stream) {
+                                      int* n_tiles, int* uptr, int* ucnt, int* ukeys, int ucap, void* qmask, int* alloc, int* flags, int queries_per_tile,
+                                      void* stream) {
     MV2D_CHECK_ARG(row_ptr && col_idx && grp_start && bits && rect && pos2s && perm && tile_q0 && tile_qn && n_tiles && uptr && ucnt && ukeys && qmask &&
                        alloc && flags, "mv2d_xattn_qtile_build: null pointer");
     MV2D_CHECK_ARG(R > 0 && n_samples >= 1 && nwords > 0 && nwords <= 8192 && ucap > 0 && (ucap % 16) == 0, "mv2d_xattn_qtile_build: bad sizes");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(qt_order_kernel, dim3(n_samples + 1), dim3(1024), 0, st, row_ptr, col_idx, grp_start, n_samples, R, perm, tile_q0, tile_qn, n_tiles, flags);
-    const int ntmax = (int)mv2d_xattn_qtile_max_tiles(R, n_samples);
-    hipLaunchKernelGGL(qt_build_kernel, dim3(ntmax), dim3(256), nwords * 8, st, (const unsigned int*)bits, nwords, rect, V, cells_per_sample, pos2s, perm,
-                       tile_q0, tile_qn, n_tiles, uptr, ucnt, ukeys, ucap, (unsigned int*)qmask, alloc, flags);
+    MV2D_CHECK_ARG(queries_per_tile == 8 || queries_per_tile == 16, "mv2d_xattn_qtile_build: 8 or 16 queries per tile");
+    const int QT = qt_size(queries_per_tile);
+    hipLaunchKernelGGL(qt_order_kernel, dim3(n_samples + 1), dim3(1024), 0, st, row_ptr, col_idx, grp_start, n_samples, R, perm, tile_q0, tile_qn, n_tiles, flags, QT);
+    const int ntmax = (int)mv2d_xattn_qtile_max_tiles(R, n_samples, QT);
+    if (QT == 16)
+        hipLaunchKernelGGL(qt_build_kernel<16>, dim3(ntmax), dim3(256), nwords * 8, st, (const unsigned int*)bits, nwords, rect, V, cells_per_sample, pos2s, perm,
+                           tile_q0, tile_qn, n_tiles, uptr, ucnt, ukeys, ucap, (unsigned int*)qmask, alloc, flags);
+    else
+        hipLaunchKernelGGL(qt_build_kernel<8>, dim3(ntmax), dim3(256), nwords * 8, st, (const unsigned int*)bits, nwords, rect, V, cells_per_sample, pos2s, perm,
+                           tile_q0, tile_qn, n_tiles, uptr, ucnt, ukeys, ucap, (unsigned int*)qmask, alloc, flags);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
 
 extern "C" int mv2d_xattn_qtile_fwd(const void* Qt, const void* Xk, const void* Xv, const int* perm, const int* tile_q0, const int* tile_qn,
                                     const int* n_tiles, const int* uptr, const int* ucnt, const int* ukeys, const void* qmask, float* z, int R,
-                                    int n_samples, int empty_nan, void* stream) {
+                                    int n_samples, int empty_nan, int queries_per_tile, void* stream) {
     MV2D_CHECK_ARG(Qt && Xk && Xv && perm && tile_q0 && tile_qn && n_tiles && uptr && ucnt && ukeys && qmask && z && R >= 0, "mv2d_xattn_qtile_fwd: bad args");
     MV2D_CHECK_ARG(((uintptr_t)Qt & 15) == 0 && ((uintptr_t)Xk & 15) == 0 && ((uintptr_t)Xv & 15) == 0 && ((uintptr_t)z & 15) == 0,
                    "mv2d_xattn_qtile_fwd: operands must be 16-byte aligned");
     if (R == 0) return MV2D_OK;
-    const int ntmax = (int)mv2d_xattn_qtile_max_tiles(R, n_samples);
-    hipLaunchKernelGGL((xattn_qtile_kernel<8>), dim3(ntmax), dim3(512), 0, (hipStream_t)stream, (const uint4*)Qt, (const unsigned short*)Xk,
-                       (const unsigned short*)Xv, perm, tile_q0, tile_qn, n_tiles, uptr, ucnt, ukeys, (const unsigned int*)qmask, z, empty_nan);
+    MV2D_CHECK_ARG(queries_per_tile == 8 || queries_per_tile == 16, "mv2d_xattn_qtile_fwd: 8 or 16 queries per tile (as built)");
+    static const int dbg_mode = getenv("MV2D_QTILE_DBG") ? atoi(getenv("MV2D_QTILE_DBG")) : 0;      // timing experiments: 1 = no arithmetic, 2 = the same 16 rows every tile
+    const int ntmax = (int)mv2d_xattn_qtile_max_tiles(R, n_samples, queries_per_tile);
+    if (queries_per_tile == 16)
+        hipLaunchKernelGGL((xattn_qtile_kernel<8>), dim3(ntmax), dim3(512), 0, (hipStream_t)stream, (const uint4*)Qt, (const unsigned short*)Xk,
+                           (const unsigned short*)Xv, perm, tile_q0, tile_qn, n_tiles, uptr, ucnt, ukeys, (const unsigned int*)qmask, z, empty_nan, dbg_mode);
+    else
+        hipLaunchKernelGGL((xattn_qtile_kernel<4>), dim3(ntmax), dim3(256), 0, (hipStream_t)stream, (const uint4*)Qt, (const unsigned short*)Xk,
+                           (const unsigned short*)Xv, perm, tile_q0, tile_qn, n_tiles, uptr, ucnt, ukeys, (const unsigned int*)qmask, z, empty_nan, dbg_mode);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

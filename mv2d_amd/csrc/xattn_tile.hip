@@ -168,7 +168,8 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
                                                              const unsigned short* __restrict__ Xv, const unsigned short* __restrict__ Xk_lo,
                                                              const unsigned short* __restrict__ Xv_lo, const int* __restrict__ row_ptr,
                                                              const int* __restrict__ col_idx, float* __restrict__ z,
-                                                             float* __restrict__ dbg_logits, long long dbg_stride, int R, int empty_nan) {
+                                                             float* __restrict__ dbg_logits, long long dbg_stride, int R, int empty_nan,
+                                                             const int* __restrict__ order) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[NW * 8192 + NW * 512 + NW * 64 + (XLO ? NW * 8192 : 0)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
     // XCD-aware block -> query map (block b runs on XCD b % 8): every XCD gets one contiguous range of queries, so neighbouring
@@ -177,6 +178,9 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
     {
         const int b = blockIdx.x, x = b & 7, qn = R >> 3, rem = R & 7;
         r = (x < rem ? x * (qn + 1) : rem * (qn + 1) + (x - rem) * qn) + (b >> 3);
+        // optional query order (T path: the queries of a sample sorted by their smallest key, mv2d_xattn_qtile_build's perm): blocks that run
+        // side by side on an XCD then read overlapping key sets and share its L2.  Speed only.
+        if (order) r = order[r];
     }
     const int beg = row_ptr[r], end = row_ptr[r + 1];
     float* zr = z + (long long)r * (HEADS * C);
@@ -408,8 +412,18 @@ extern "C" int mv2d_xattn_ctxmap(const float* z, const void* WB_hi, const void* 
     return MV2D_OK;
 }
 
+extern "C" int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
+                                           const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
+                                           const int* order, void* stream);
+
 extern "C" int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                    const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves, void* stream) {
+    return mv2d_xattn_tile_fwd_ordered(Qt, Xk, Xv, Xk_lo, Xv_lo, row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan, waves, nullptr, stream);
+}
+
+extern "C" int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
+                                           const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
+                                           const int* order, void* stream) {
     MV2D_CHECK_ARG(Qt && Xk && Xv && row_ptr && col_idx && z && R >= 0, "mv2d_xattn_tile_fwd: bad args");
     MV2D_CHECK_ARG((Xk_lo == nullptr) == (Xv_lo == nullptr), "mv2d_xattn_tile_fwd: Xk_lo and Xv_lo come together");
     MV2D_CHECK_ARG(((uintptr_t)Qt & 15) == 0 && ((uintptr_t)Xk & 15) == 0 && ((uintptr_t)Xv & 15) == 0 && ((uintptr_t)z & 15) == 0 &&
@@ -420,7 +434,7 @@ extern "C" int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* X
     const int nw = env_nw ? env_nw : (waves ? waves : 2);      // the engine passes its own choice (2: see engine.py)
 #define MV2D_XT(NW, DBG, XLO) hipLaunchKernelGGL((xattn_tile_kernel<NW, DBG, XLO>), dim3(R), dim3(64 * NW), 0, (hipStream_t)stream, (const uint4*)Qt, \
                                                  (const unsigned short*)Xk, (const unsigned short*)Xv, (const unsigned short*)Xk_lo, (const unsigned short*)Xv_lo, \
-                                                 row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan)
+                                                 row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan, order)
     // index-exact route (hi + lo rows): two waves per SIMD like the default (round 3: the 312-register build ran one wave per SIMD, 133 us per layer)
     if (Xk_lo) { if (dbg_logits) MV2D_XT(4, true, true); else if (nw == 4) MV2D_XT(4, false, true); else MV2D_XT(2, false, true); }
     else if (dbg_logits) { if (nw == 8) MV2D_XT(8, true, false); else if (nw == 2) MV2D_XT(2, true, false); else if (nw == 1) MV2D_XT(1, true, false); else MV2D_XT(4, true, false); }

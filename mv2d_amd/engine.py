@@ -121,10 +121,16 @@ class HeadEngine:
         # then carry stale rows for the other layers, and the reference's forward does evaluate all six.
         self.last_stage_heads = os.environ.get('MV2D_LAST_STAGE_HEADS', '0') == '1'
         self.keep_xk = os.environ.get('MV2D_KEEP_XK', '0') == '1'   # always write both pe and Xk (S path: nothing reads Xk; T path: nothing reads pe)
-        # T path: cross attention over QUERY TILES with shared key tiles (csrc/xattn_qtile.hip; round 3): the queries of a sample ordered by their
-        # smallest key, 16 per workgroup, the union of their key lists streamed once through LDS.  MV2D_XATTN_QTILE=0: one block per query
-        # (xattn_tile_kernel) as in round 2.  The index-exact route (hi + lo rows) and debug runs stay on the per-query kernel.
-        self.qtile = kind == 'T' and self.tile_attn and os.environ.get('MV2D_XATTN_QTILE', '1') == '1'
+        # T path (round 3): the blocks of the per-query tile kernel run in the order of the queries' SMALLEST KEY (mv2d_xattn_query_order):
+        # neighbouring blocks of an XCD then read overlapping key sets from its L2 (cfg3_t 54.8 -> 47.6 us per layer, cfg5_t 60.2 -> 51.7 us;
+        # bitwise the same results).  MV2D_XATTN_ORDER=0 switches it off.
+        self.q_order = kind == 'T' and self.tile_attn and os.environ.get('MV2D_XATTN_ORDER', '1') == '1'
+        # OPT-IN, measured SLOWER: cross attention over QUERY TILES with shared key tiles (csrc/xattn_qtile.hip): the
+        # queries of a sample in that order, 8 or 16 per workgroup, the union of their key lists streamed once through an LDS-DMA ring,
+        # 16-bit pair masks.  It reads 1.40 x (16 per tile) the distinct rows instead of 2.99 x, but a union tile of 16 keys is only ~35 % allowed
+        # pairs for a given pair of queries, so the masked MFMA / softmax work triples and the kernel takes 137 - 172 us against 48 us.
+        self.qtile = kind == 'T' and self.tile_attn and os.environ.get('MV2D_XATTN_QTILE', '0') == '1'
+        self.qtile_queries = int(os.environ.get('MV2D_XATTN_QT', '8'))        # queries per tile: 8 (4 waves per workgroup) or 16 (8 waves)
         nw = os.environ.get('MV2D_XATTN_NW')
         # waves per query: the kernel alone takes the same 32-33 us per layer with 1, 2 or 4 (it moves its 161 MB at ~5 TB/s either way), but a
         # launch with fewer waves leaves more of the chip to the other streams' kernels: cfg2_s 8067 / 8043 / 7869 samples/s for 1 / 2 / 4,
@@ -355,8 +361,10 @@ class HeadEngine:
             ws['col_cap'] = R * self.col_cap_per_query
             ws['S_kv'] = P
             ws['csr_words'] = ops.csr_workspace_bytes(1, Vg, h, w) // 4
+            ws['q_order'] = alloc(R, torch.int32, zero=True) if getattr(self, 'q_order', False) else None
             if getattr(self, 'qtile', False) and not self.exact:
-                ws['qt'] = ops.xattn_qtile_alloc(R, B, ws['col_cap'], self.dev, alloc=lambda n_: alloc(n_, torch.int32, zero=True))
+                ws['qt'] = ops.xattn_qtile_alloc(R, B, ws['col_cap'], self.dev, alloc=lambda n_: alloc(n_, torch.int32, zero=True),
+                                                     queries_per_tile=self.qtile_queries)
         else:
             ws['col_cap'] = R * (1 + Vg * self.topk) * 49
             ws['S_kv'] = R * 49
@@ -603,6 +611,8 @@ class HeadEngine:
             o.mask_compact(rois, ws['match'], T['pad_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'],
                            ws['bits'], ws['row_count'], ws['row_ptr'], ws['col_idx'], ws['nnz'], R, Vg, h, w, self.topk,
                            self.stride, self.expand, col_cap=ws['col_cap'], n_samples=B)
+            if ws.get('q_order') is not None and ws.get('qt') is None:
+                o.xattn_query_order(ws['row_ptr'], ws['col_idx'], grp, R, ws['q_order'], ws['qt_ctl'][1:])
             if ws.get('qt') is not None:
                 o.xattn_qtile_build(ws['qt'], ws['row_ptr'], ws['col_idx'], grp, R, ws['bits'], ws['csr_words'], ws['rect'], Vg, Vg * h * w, ws['pos2s'],
                                     ws['qt_ctl'])
@@ -807,7 +817,8 @@ class HeadEngine:
                     o.xattn_qtile(ws['Qt'], xk_rows, xv_rows, ws['qt'], ws['zh'], R, empty_nan=self.empty_nan)
                 else:
                     o.xattn_tile(ws['Qt'], xk_rows, xv_rows, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=self.empty_nan, waves=self.xattn_waves,
-                                 Xk_lo=ws.get('xk_lo'), Xv_lo=ws.get('xv_lo'), dbg_logits=None if dbg is None else dbg[i])
+                                 Xk_lo=ws.get('xk_lo'), Xv_lo=ws.get('xv_lo'), dbg_logits=None if dbg is None else dbg[i],
+                                 order=ws['qt']['perm'] if ws.get('qt') is not None else ws.get('q_order'))
                 if not maps_fused:
                     o.xattn_ctxmap(ws['zh'], W_[f'ca_mapB{i}'], W_[f'ca_v_b{i}'], ws['row_ptr'], ws['ctx'], R, empty_nan=self.empty_nan)
                 return
@@ -1084,7 +1095,7 @@ class HeadEngine:
     def _check_capacity(ws):
         if int(ws['nnz'][1].item()) != 0:
             raise RuntimeError('mv2d engine: CSR capacity exceeded (raise col_cap_per_query)')
-        if ws.get('qt') is not None and int(ws['qt_ctl'][1].item()) != 0:
+        if ws.get('qt') is not None and int(ws['qt_ctl'][1].item()) != 0:         # (for the order alone the flag only means: natural order kept)
             raise RuntimeError('mv2d engine: a query tile of the shared-key cross attention exceeded its capacity (8192 distinct keys per 16 queries / '
                                '4096 queries per sample): run with MV2D_XATTN_QTILE=0')
 

@@ -543,7 +543,7 @@ def xattn_qmap(q, WA, Qt=None, R=None):
     return Qt
 
 
-def xattn_tile(Qt, Xk, Xv, row_ptr, col_idx, out=None, R=None, dbg_logits=None, empty_nan=True, waves=0, Xk_lo=None, Xv_lo=None):
+def xattn_tile(Qt, Xk, Xv, row_ptr, col_idx, out=None, R=None, dbg_logits=None, empty_nan=True, waves=0, Xk_lo=None, Xv_lo=None, order=None):
     """Tile cross attention on the unprojected key / value rows: Qt from xattn_qmap, Xk / Xv [S,256] bf16 -> z [R,8,256] fp32.
     Xk_lo / Xv_lo: optional bf16 remainders of the rows (index-exact validation mode: fp32-class key side)."""
     _req(Qt, BF16, 'Qt'); _req(Xk, BF16, 'Xk'); _req(Xv, BF16, 'Xv'); _req(Xk_lo, BF16, 'Xk_lo'); _req(Xv_lo, BF16, 'Xv_lo')
@@ -551,27 +551,35 @@ def xattn_tile(Qt, Xk, Xv, row_ptr, col_idx, out=None, R=None, dbg_logits=None, 
     R = Qt.shape[0] if R is None else R
     if out is None:
         out = torch.empty((R, 8, 256), device=Qt.device, dtype=torch.float32)
-    check(_lib.load().mv2d_xattn_tile_fwd(_p(Qt), _p(Xk), _p(Xv), _p(Xk_lo), _p(Xv_lo), _p(row_ptr), _p(col_idx), _p(out), _p(dbg_logits),
-                                          dbg_logits.stride(0) if dbg_logits is not None else 0, R, 1 if empty_nan else 0, int(waves), _stream()),
-          'mv2d_xattn_tile_fwd')
+    _req(order, torch.int32, 'order')
+    check(_lib.load().mv2d_xattn_tile_fwd_ordered(_p(Qt), _p(Xk), _p(Xv), _p(Xk_lo), _p(Xv_lo), _p(row_ptr), _p(col_idx), _p(out), _p(dbg_logits),
+                                                  dbg_logits.stride(0) if dbg_logits is not None else 0, R, 1 if empty_nan else 0, int(waves),
+                                                  _p(order), _stream()), 'mv2d_xattn_tile_fwd')
     return out
 
 
-def xattn_qtile_alloc(R, n_samples, col_cap, device, alloc=None):
+def xattn_query_order(row_ptr, col_idx, grp_start, R, perm, flags):
+    """perm [R] int32 = the query rows of every sample (grp_start [n+1], device) sorted by their smallest key; flags int32 [>=1] (zeroed by the caller)."""
+    check(_lib.load().mv2d_xattn_query_order(_p(row_ptr), _p(col_idx), _p(grp_start), grp_start.numel() - 1, R, _p(perm), _p(flags), _stream()),
+          'mv2d_xattn_query_order')
+    return perm
+
+
+def xattn_qtile_alloc(R, n_samples, col_cap, device, alloc=None, queries_per_tile=8):
     """Tables of the shared-key-tile cross attention (T path) for launches of R query rows / n_samples samples / col_cap CSR entries.
     alloc(n) -> zeroed int32 tensor of n elements (default: torch.zeros on `device`)."""
-    nt = int(_lib.load().mv2d_xattn_qtile_max_tiles(R, n_samples))
+    nt = int(_lib.load().mv2d_xattn_qtile_max_tiles(R, n_samples, queries_per_tile))
     ucap = (col_cap + 16 * nt + 15) // 16 * 16
     i32 = alloc if alloc is not None else (lambda n: torch.zeros(n, dtype=torch.int32, device=device))
     return dict(perm=i32(R), tq0=i32(nt), tqn=i32(nt), nt=i32(1), uptr=i32(nt), ucnt=i32(nt), ukeys=i32(ucap), mask=i32(ucap // 16 * 8), ucap=ucap,
-                max_tiles=nt, n_samples=n_samples)
+                max_tiles=nt, n_samples=n_samples, qt=queries_per_tile)
 
 
 def xattn_qtile_build(qt, row_ptr, col_idx, grp_start, R, bits, nwords, rect, V, cells_per_sample, pos2s, ctl):
     """qt = xattn_qtile_alloc(...); ctl int32 [2] = (allocation counter, overflow flag), zeroed by the caller for this frame."""
     check(_lib.load().mv2d_xattn_qtile_build(_p(row_ptr), _p(col_idx), _p(grp_start), qt['n_samples'], R, _p(bits), nwords, _p(rect), V, cells_per_sample,
                                              _p(pos2s), _p(qt['perm']), _p(qt['tq0']), _p(qt['tqn']), _p(qt['nt']), _p(qt['uptr']), _p(qt['ucnt']),
-                                             _p(qt['ukeys']), qt['ucap'], _p(qt['mask']), ctl.data_ptr(), ctl.data_ptr() + 4, _stream()),
+                                             _p(qt['ukeys']), qt['ucap'], _p(qt['mask']), ctl.data_ptr(), ctl.data_ptr() + 4, qt['qt'], _stream()),
           'mv2d_xattn_qtile_build')
 
 
@@ -582,7 +590,7 @@ def xattn_qtile(Qt, Xk, Xv, qt, out=None, R=None, empty_nan=True):
     if out is None:
         out = torch.empty((R, 8, 256), device=Qt.device, dtype=torch.float32)
     check(_lib.load().mv2d_xattn_qtile_fwd(_p(Qt), _p(Xk), _p(Xv), _p(qt['perm']), _p(qt['tq0']), _p(qt['tqn']), _p(qt['nt']), _p(qt['uptr']),
-                                           _p(qt['ucnt']), _p(qt['ukeys']), _p(qt['mask']), _p(out), R, qt['n_samples'], 1 if empty_nan else 0, _stream()),
+                                           _p(qt['ucnt']), _p(qt['ukeys']), _p(qt['mask']), _p(out), R, qt['n_samples'], 1 if empty_nan else 0, qt['qt'], _stream()),
           'mv2d_xattn_qtile_fwd')
     return out
 

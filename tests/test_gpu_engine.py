@@ -497,8 +497,8 @@ def test_last_stage_heads_option(name, kind):
     assert torch.equal(ok['cls'], oa['cls'])
 
 
-@pytest.mark.parametrize('name,n', [('micro_t', 1), ('cfg1_t', 1), ('cfg1_t', 3), ('cfg3_t', 1), ('cfg3_t', 2)])
-def test_query_tile_cross_attention_tables_and_result(name, n):
+@pytest.mark.parametrize('name,n,qpt', [('micro_t', 1, 8), ('cfg1_t', 1, 16), ('cfg1_t', 3, 8), ('cfg3_t', 1, 8), ('cfg3_t', 2, 16)])
+def test_query_tile_cross_attention_tables_and_result(name, n, qpt):
     """T path, shared-key-tile cross attention (csrc/xattn_qtile.hip): (1) the tables mv2d_xattn_qtile_build derives from the CSR -- query
     order, tiles, union key lists, pair masks -- reproduce EXACTLY the allowed (query, key) pairs of the CSR (which is bit-exact against the
     reference's masks, tests/test_gpu_golden.py); (2) the query-tile kernel and the one-block-per-query kernel (verified against fp64 in
@@ -509,7 +509,7 @@ def test_query_tile_cross_attention_tables_and_result(name, n):
     sd = synthetic.make_head_state(seed=0)
     probs = [synthetic.make_problem(name, seed=s) for s in range(n)]
     eng = HeadEngine(sd, 'T', dev, num_views=probs[0]['views_per_frame'])
-    assert eng.qtile
+    eng.qtile, eng.qtile_queries = True, qpt                      # (opt-in route: measured slower than the ordered per-query kernel)
     feats = [torch.from_numpy(p['feat']).to(dev) for p in probs]
     props = [[torch.from_numpy(x) for x in p['proposals']] for p in probs]
     metas = [p['img_metas'] for p in probs]
@@ -537,7 +537,8 @@ def test_query_tile_cross_attention_tables_and_result(name, n):
         assert (np.diff(keys) > 0).all()
         tot_union += int(ucnt[t])
         nut = (ucnt[t] + 15) // 16
-        mw = mask[(uptr[t] // 16) * 8:(uptr[t] // 16 + nut) * 8].reshape(nut, 8)
+        nw = qpt // 2
+        mw = mask[(uptr[t] // 16) * nw:(uptr[t] // 16 + nut) * nw].reshape(nut, nw)
         for j in range(tqn[t]):
             r = int(perm[tq0[t] + j])
             seen.add(r)
@@ -556,3 +557,13 @@ def test_query_tile_cross_attention_tables_and_result(name, n):
     assert err < 2e-5
     z_q2 = ops.xattn_qtile(ws['Qt'], ws['xk_rows'], ws['xv_rows'], qt, R=Rl, empty_nan=False)
     assert torch.equal(z_q, z_q2)                               # deterministic
+    # the per-query kernel with its blocks in the smallest-key order (the engine's default on the T path): bitwise the same rows
+    z_o = ops.xattn_tile(ws['Qt'], ws['xk_rows'], ws['xv_rows'], ws['row_ptr'], ws['col_idx'], R=Rl, empty_nan=False, waves=2, order=qt['perm'])
+    assert torch.equal(z_o, z_t)
+    # ... and the engine's own order table (default route) is the same permutation
+    eng2 = HeadEngine(sd, 'T', dev, num_views=probs[0]['views_per_frame'])
+    assert eng2.q_order and not eng2.qtile
+    out2 = eng2.run_batch(feats, props, metas) if n > 1 else eng2.run(feats[0], props[0], metas[0])
+    torch.cuda.synchronize()
+    assert torch.equal(out2['ws']['q_order'][:Rl], qt['perm'][:Rl])
+    assert float((out2['cls'] - out['cls']).abs().max() / out['cls'].abs().max()) < 1e-4      # the two attention kernels, end to end
