@@ -67,6 +67,60 @@ STAGE_KERNEL = {'pe_fused': 'pe_tab_kernel (frustum MLP + gate, sine branch from
                 'kv_gemm': 'kvproj_kernel (MV2D_XATTN=sparse route only)', 'qg_conv_gemm': 'roi_conv_pool_kernel (conv3x3 + ReLU + avgpool fused)'}
 
 
+def build_step(engs, strs, sets, pool, Bs, pay, state, *, collective, use_graph, rotate=True, pack=None, gather=None, cuda=True):
+    """One bench step over `len(engs)` streams: every stream runs its engine on its current frame set (``Bs`` samples per launch), packs the
+    decoded boxes into rows [i * Bs, (i + 1) * Bs) of the ping-pong payload buffer ``pay[k]``; with ``collective`` the main stream then
+    waits for all of them and runs the ONE all-gather of the step (mv2d_amd.dist.gather_detections) while the streams already work on the
+    next step's frames in the other buffer.  ``state`` = dict(gathered_ev=[None, None], step_no=0) shared by the steps built on the same
+    buffers.  ``cuda=False`` (tests/test_dist_gloo_cpu.py, world-2 gloo): the same control flow without HIP streams / events, ``pack`` /
+    ``gather`` then default to the torch formulations of mv2d_amd.dist."""
+    import contextlib
+    from mv2d_amd import dist as mdist
+    if pack is None:
+        if cuda:
+            from mv2d_amd import ops
+            pack = ops.pack_detections
+        else:
+            pack = lambda bx, sc, lb, cnt, out: out.copy_(mdist.pack_detections_batch(bx.view(-1, *bx.shape[-2:]), sc.view(-1, sc.shape[-1]),  # noqa: E731
+                                                                                       lb.view(-1, lb.shape[-1]), cnt.view(-1)))
+    gather = gather or mdist.gather_detections
+    cnt = [0]
+
+    def step():
+        n = cnt[0]
+        cnt[0] += 1
+        k = state['step_no'] & 1
+        state['step_no'] += 1
+        cur = torch.cuda.current_stream() if cuda else None
+        done = []
+        for i, (e, s_) in enumerate(zip(engs, strs)):
+            fb, pb, mb = sets[i][(n % len(sets[i])) if rotate else 0]
+            if pool is not None and rotate:
+                mb = [pool[i][(n * Bs + b) % len(pool[i])] for b in range(Bs)]
+            with (torch.cuda.stream(s_) if cuda else contextlib.nullcontext()):
+                if cuda and state['gathered_ev'][k] is not None:
+                    s_.wait_event(state['gathered_ev'][k])
+                if Bs > 1:
+                    o = e.run_batch(fb, pb, mb, use_graph=use_graph)
+                else:
+                    o = e.run(fb, pb[0], mb[0], use_graph=use_graph)
+                pack(o['boxes'], o['scores'], o['labels'], o['count'], pay[k][i * Bs:(i + 1) * Bs])
+                if collective and cuda:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    done.append(ev)
+        if collective:
+            for ev in done:
+                cur.wait_event(ev)
+            out = gather(pay[k])     # the one collective of an evaluation step (RCCL all-gather; gloo in the CPU test)
+            if cuda:
+                state['gathered_ev'][k] = torch.cuda.Event()
+                state['gathered_ev'][k].record()
+            return out
+        return pay[k]
+    return step
+
+
 def ws_rows(out):
     """rows the launches of a frame run on (the RoI-count bucket, >= the real R)."""
     return int(out['ws']['x'].shape[0])
@@ -175,44 +229,10 @@ def main():
     # ping-pong payload buffers: the streams free-run (no per-step join on one GPU); with N > 1 the all-gather of step k
     # runs on the main stream behind the frames of step k while the frames of step k+1 are already executing.
     payload = [torch.zeros((args.inflight * B, 300 * 11 + 1), device=dev) for _ in range(2)]
-    gathered_ev = [None, None]
-    step_no = [0]
+    state = dict(gathered_ev=[None, None], step_no=0)
 
     def make_step(engs, strs, sets, pool, Bs, pay, rotate=True):
-        cnt = [0]
-
-        def step():
-            n = cnt[0]
-            cnt[0] += 1
-            k = step_no[0] & 1
-            step_no[0] += 1
-            cur = torch.cuda.current_stream()
-            done = []
-            for i, (e, s_) in enumerate(zip(engs, strs)):
-                fb, pb, mb = sets[i][(n % len(sets[i])) if rotate else 0]
-                if pool is not None and rotate:
-                    mb = [pool[i][(n * Bs + b) % len(pool[i])] for b in range(Bs)]
-                with torch.cuda.stream(s_):
-                    if gathered_ev[k] is not None:
-                        s_.wait_event(gathered_ev[k])
-                    if Bs > 1:
-                        o = e.run_batch(fb, pb, mb, use_graph=use_graph)
-                    else:
-                        o = e.run(fb, pb[0], mb[0], use_graph=use_graph)
-                    ops.pack_detections(o['boxes'], o['scores'], o['labels'], o['count'], pay[k][i * Bs:(i + 1) * Bs])
-                    if collective:
-                        ev = torch.cuda.Event()
-                        ev.record()
-                        done.append(ev)
-            if collective:
-                for ev in done:
-                    cur.wait_event(ev)
-                out = mdist.gather_detections(pay[k])     # the one collective of an evaluation step (RCCL all-gather)
-                gathered_ev[k] = torch.cuda.Event()
-                gathered_ev[k].record()
-                return out
-            return pay[k]
-        return step
+        return build_step(engs, strs, sets, pool, Bs, pay, state, collective=collective, use_graph=use_graph, rotate=rotate)
 
     step = make_step(engines, streams, sets_main, pool_main, B, payload)
 

@@ -160,3 +160,70 @@ def test_allreduce_gradients_world2():
         za = torch.zeros_like(torch.tensor(res[0][4][k])) if a is None else torch.tensor(a)
         zb = torch.zeros_like(torch.tensor(res[0][4][k])) if b is None else torch.tensor(b)
         assert torch.allclose(torch.tensor(res[0][4][k]), (za + zb) / 2)
+
+
+# ---- the N > 1 branch of bench.py's step (pack -> all-gather -> unpack, ping-pong payload buffers) on two gloo ranks ------------------------
+class _FakeEngine:
+    """Stands for HeadEngine in bench.build_step: deterministic decoded boxes per (rank, stream, call)."""
+
+    def __init__(self, rank, stream):
+        self.rank, self.stream, self.calls = rank, stream, 0
+
+    def run_batch(self, fb, pb, mb, use_graph=False):
+        B = len(pb)
+        n = torch.tensor([(self.rank * 7 + self.stream * 3 + self.calls + b) % 300 + 1 for b in range(B)], dtype=torch.int32)
+        boxes = torch.zeros(B, 300, 9); scores = torch.zeros(B, 300); labels = torch.zeros(B, 300, dtype=torch.int64)
+        for b in range(B):
+            boxes[b, :n[b]] = 100.0 * self.rank + 10.0 * self.stream + self.calls + 0.1 * b
+            scores[b, :n[b]] = 0.25
+            labels[b, :n[b]] = (self.calls + b) % 10
+        self.calls += 1
+        return dict(boxes=boxes, scores=scores, labels=labels, count=n)
+
+
+def _bench_step_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    mdist.init_from_env(backend='gloo')
+    inflight, B = 2, 3
+    engs = [_FakeEngine(rank, i) for i in range(inflight)]
+    sets = [[(None, [None] * B, [None] * B)] for _ in range(inflight)]
+    pay = [torch.zeros((inflight * B, 300 * 11 + 1)) for _ in range(2)]
+    state = dict(gathered_ev=[None, None], step_no=0)
+    step = bench.build_step(engs, [None] * inflight, sets, None, B, pay, state, collective=True, use_graph=False, cuda=False)
+    res = []
+    for it in range(3):
+        out = step()                                  # [world, inflight * B, 3301]
+        assert out.shape == (world, inflight * B, 300 * 11 + 1)
+        rows = []
+        for rr in range(world):
+            for j in range(inflight * B):
+                bx, sc, lb = mdist.unpack_detections(out[rr, j])
+                rows.append((rr, j, bx.shape[0], round(float(bx[0, 0]), 3), int(lb[0])))
+        res.append(rows)
+    q.put((rank, res, state['step_no']))
+    dist.destroy_process_group()
+
+
+def test_bench_step_two_ranks_gloo():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_step_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] and got[0][2] == got[1][2] == 3          # both ranks hold the same gathered detections; ping-pong advanced
+    inflight, B = 2, 3
+    for it, rows in enumerate(got[0][1]):
+        for rr, j, n, v, lab in rows:
+            i, b = divmod(j, B)
+            assert n == (rr * 7 + i * 3 + it + b) % 300 + 1
+            assert abs(v - (100.0 * rr + 10.0 * i + it + 0.1 * b)) < 1e-3 and lab == (it + b) % 10
