@@ -484,6 +484,20 @@ int mv2d_set_loss(const float* cls, const float* box, const int* match, const fl
 int mv2d_dn_queries(const float* gt, const int* gt_labels, const float* rnd, int G, int scalar, float noise_scale, float noise_trans, float split,
                     int num_classes, const float* pc_range_host, float eps, float* ref, long long* labels, float* boxes, void* stream);
 
+/* ---- dense building blocks of the training route (csrc/train_ops.hip) ----------------------------------------------------
+ * Every product of a linear layer's forward and backward is C = A B^T on the bf16 tile GEMM (mv2d_gemm_bf16_ex) in split precision by
+ * K-concatenation; mv2d_split3_operand builds the operands: dst [rows_out, 3 k_pad] bf16 from the fp32 matrix src (row stride ld), read as
+ * is ([rows, k]) or TRANSPOSED (src is [k, rows]), zero-padded to rows_out x k_pad; side 0 = A operand [hi | lo | hi], side 1 = B operand
+ * [hi | hi | lo].  forward y = x W^T: A = x, B = W; dx = dy W: A = dy, B = W transposed; dW = dy^T x: A = dy transposed, B = x transposed. */
+int mv2d_split3_operand(const float* src, long long ld, int rows, int k, int transpose, void* dst, int rows_out, int k_pad, int side, void* stream);
+/* out [cols] = column sums of x [rows, cols] (row stride ld), fixed summation order (bias gradients). */
+int mv2d_colsum(const float* x, long long ld, int rows, int cols, float* out, void* stream);
+/* nn.LayerNorm(256) backward (MU/petr_transformer.py norms, cross_attention_head.py:127-133): dx [M,256], dw [256], db [256] from x, dy, w
+ * (mean / rstd recomputed); dw_part / db_part: scratch [mv2d_layer_norm_bwd_blocks(M), 256] each. */
+int mv2d_layer_norm_bwd_blocks(int M);
+int mv2d_layer_norm_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw_part, float* db_part, float* dw, float* db, int M,
+                        float eps, void* stream);
+
 /* Backward of mv2d_roi_align w.r.t. one map (training; mmcv's roi_align backward): grad_out [R][49][256] fp32 ->
  * grad_map [rows][256] fp32, ACCUMULATED with hardware fp32 atomics (the caller zeroes it; the summation order varies between runs).
  * index (may be null): position -> row of a compacted map, negative = no row (as map1_index of the forward). */

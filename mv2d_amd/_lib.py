@@ -89,6 +89,10 @@ SIGNATURES = {
     'mv2d_nms_bev': (I, [P, P, P, P, F, P, I, I, P]),
     'mv2d_pack_detections': (I, [P, P, P, P, P, I, I, I, P]),
     'mv2d_roi_align_bwd': (I, [P, P, P, P, I, I, I, I, F, I, P]),
+    'mv2d_split3_operand': (I, [P, LL, I, I, I, P, I, I, I, P]),
+    'mv2d_colsum': (I, [P, LL, I, I, P, P]),
+    'mv2d_layer_norm_bwd_blocks': (I, [I]),
+    'mv2d_layer_norm_bwd': (I, [P, P, P, P, P, P, P, P, I, F, P]),
     'mv2d_match_cost': (I, [P, P, P, P, P, I, I, I, I, F, F, F, F, P]),
     'mv2d_set_loss': (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, F, I, P]),
     'mv2d_decode_topk': (I, [P, P, I, I, I, P, P, P, P, P, P, P, P, I, I, P]),

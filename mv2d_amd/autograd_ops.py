@@ -1,0 +1,149 @@
+"""Differentiable dense operators of the head's training route on the hand-written HIP kernels.
+
+The reference trains the head in fp32 under torch autograd (``nn.Linear`` / ``nn.LayerNorm`` / mmcv ``FFN`` inside
+MU/petr_transformer.py:195-311 and RH/bbox_heads/cross_attention_head.py:118-142).  Here every matrix product of the forward AND the backward
+pass is C = A B^T on ``mv2d_gemm_bf16_ex`` in split precision by K-concatenation (csrc/train_ops.hip, ~1e-5 relative, i.e. fp32-class), the
+layer norms run on ``mv2d_row_ln`` / ``mv2d_layer_norm_bwd``, bias gradients on ``mv2d_colsum``: no rocBLAS / MIOpen kernel is launched.
+PyTorch supplies the autograd graph, the element-wise glue (residual adds, dropout masks, ReLU masks) and the parameter containers.
+
+No CPU path: tensors must live on the GPU.
+"""
+import torch
+
+from . import _lib, ops
+from ._lib import check
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _pad(n, m):
+    return -(-n // m) * m
+
+
+def split3_operand(src, transpose, rows_out, k_pad, side):
+    """fp32 2-D ``src`` (any row stride, unit column stride) -> bf16 [rows_out, 3 * k_pad]: op(src) zero-padded, op = transpose or identity;
+    side 0 = [hi | lo | hi] (A operand), 1 = [hi | hi | lo] (B operand)."""
+    assert src.dtype == F32 and src.dim() == 2 and src.is_cuda and src.stride(1) == 1
+    rows, k = (src.shape[1], src.shape[0]) if transpose else src.shape
+    out = torch.empty((rows_out, 3 * k_pad), device=src.device, dtype=BF16)
+    check(_lib.load().mv2d_split3_operand(_p(src), src.stride(0), rows, k, 1 if transpose else 0, _p(out), rows_out, k_pad, side, _stream()),
+          'mv2d_split3_operand')
+    return out
+
+
+def matmul_nt(A, B, bias=None, act=0, trans_a=False, trans_b=False):
+    """C = act(op(A) op(B)^T + bias) in fp32-class split precision on the bf16 tile GEMM; op(X) = X^T when trans_x.  A, B fp32 2-D; bias [N]."""
+    A = A if A.stride(-1) == 1 else A.contiguous()
+    B = B if B.stride(-1) == 1 else B.contiguous()
+    M, K = (A.shape[1], A.shape[0]) if trans_a else A.shape
+    N, Kb = (B.shape[1], B.shape[0]) if trans_b else B.shape
+    assert K == Kb, (A.shape, B.shape, trans_a, trans_b)
+    if M == 0 or N == 0:
+        return torch.zeros((M, N), device=A.device, dtype=F32)
+    kp, Np = _pad(K, 64), _pad(N, 8)
+    a3 = split3_operand(A, trans_a, M, kp, 0)
+    b3 = split3_operand(B, trans_b, Np, kp, 1)
+    if bias is not None and Np != N:
+        bias = torch.cat([bias, bias.new_zeros(Np - N)])
+    out = torch.empty((M, Np), device=A.device, dtype=F32)
+    ops.gemm_bf16(a3, b3, bias, act=act, out=out, M=M)
+    return out if Np == N else out[:, :N]
+
+
+def colsum(x):
+    x = x if x.stride(-1) == 1 else x.contiguous()
+    out = torch.empty(x.shape[1], device=x.device, dtype=F32)
+    check(_lib.load().mv2d_colsum(_p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), _stream()), 'mv2d_colsum')
+    return out
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b), act 0 = none / 1 = ReLU; x [M,K], W [N,K] (nn.Linear layout), b [N] or None.  Forward and the three backward
+    products (dx = g W, dW = g^T x, db = column sums of g; g = dy masked by the ReLU) on the HIP GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act):
+        x2 = x.reshape(-1, x.shape[-1]).float()
+        y = matmul_nt(x2, W.float(), None if b is None else b.float(), act)
+        ctx.save_for_backward(x2, W, y if act == 1 else None)
+        ctx.meta = (x.shape, b is not None, act)
+        return y.reshape(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, y = ctx.saved_tensors
+        shape, has_b, act = ctx.meta
+        g = dy.reshape(-1, dy.shape[-1]).float()
+        if act == 1:
+            g = g * (y > 0)
+        g = g.contiguous()
+        dx = matmul_nt(g, W.float(), trans_b=True).reshape(shape) if ctx.needs_input_grad[0] else None
+        dW = matmul_nt(g, x2, trans_a=True, trans_b=True).to(W.dtype) if ctx.needs_input_grad[1] else None
+        db = colsum(g) if (has_b and ctx.needs_input_grad[2]) else None
+        return dx, dW, db, None
+
+
+def linear(x, W, b=None, act=0):
+    return LinearFn.apply(x, W, b, act)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dimension of 256 (eps 1e-5): forward ``mv2d_row_ln``, backward ``mv2d_layer_norm_bwd``."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x2 = x.reshape(-1, 256).float().contiguous()
+        y = ops.row_ln(x2, ln=(w.float().contiguous(), b.float().contiguous()), eps=eps)
+        ctx.save_for_backward(x2, w)
+        ctx.meta = (x.shape, eps)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        shape, eps = ctx.meta
+        lib = _lib.load()
+        M = x2.shape[0]
+        g = dy.reshape(-1, 256).float().contiguous()
+        dx = torch.empty_like(x2)
+        nb = max(int(lib.mv2d_layer_norm_bwd_blocks(M)), 1)
+        part = torch.empty((2, nb, 256), device=x2.device, dtype=F32)
+        dw = torch.empty(256, device=x2.device, dtype=F32)
+        db = torch.empty(256, device=x2.device, dtype=F32)
+        check(lib.mv2d_layer_norm_bwd(_p(x2), _p(g), _p(w.float().contiguous()), _p(dx), _p(part[0]), _p(part[1]), _p(dw), _p(db), M, float(eps),
+                                      _stream()), 'mv2d_layer_norm_bwd')
+        return dx.reshape(shape), dw.to(w.dtype), db.to(w.dtype), None
+
+
+def layer_norm(x, w, b, eps=1e-5):
+    assert x.shape[-1] == 256, 'the HIP layer norm is built for 256 channels (every norm of the head)'
+    return LayerNormFn.apply(x, w, b, eps)
+
+
+class MatmulNTFn(torch.autograd.Function):
+    """C = A B^T with both operands differentiable (the dense denoising block of the cross attention: per-head logits and P V)."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        ctx.save_for_backward(A, B)
+        return matmul_nt(A.float(), B.float())
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        dC = dC.float().contiguous()
+        dA = matmul_nt(dC, B.float(), trans_b=True) if ctx.needs_input_grad[0] else None        # dC [M,N] . B [N,K]
+        dB = matmul_nt(dC, A.float(), trans_a=True, trans_b=True) if ctx.needs_input_grad[1] else None   # dC^T [N,M] . A [M,K]
+        return dA, dB
+
+
+def matmul_nt_ad(A, B):
+    return MatmulNTFn.apply(A, B)

@@ -261,28 +261,33 @@ class TrainDecoder:
         """dense = (n, keys): the first n query rows see exactly the key rows `keys` (the denoising rows of the cross attention) — a dense
         block, computed with batched GEMMs instead of n rows of len(keys) pairs each in the sparse kernels; csr then covers rows n.."""
         import torch.nn.functional as F
+        from .autograd_ops import linear, matmul_nt_ad
         w, b = self.p[name + '.attn.in_proj_weight'], self.p[name + '.attn.in_proj_bias']
         Cc = q_in.shape[-1]
-        q = F.linear(q_in, w[:Cc], b[:Cc]) * (1.0 / (Cc // self.H) ** 0.5)
-        k = F.linear(k_in, w[Cc:2 * Cc], b[Cc:2 * Cc])
-        v = F.linear(v_in, w[2 * Cc:], b[2 * Cc:])
+        # (round 3: every projection forward + backward on the HIP GEMM, mv2d_amd/autograd_ops.py; no rocBLAS)
+        q = linear(q_in, w[:Cc], b[:Cc]) * (1.0 / (Cc // self.H) ** 0.5)
+        k = linear(k_in, w[Cc:2 * Cc], b[Cc:2 * Cc])
+        v = linear(v_in, w[2 * Cc:], b[2 * Cc:])
         if dense is not None and dense[0] > 0:
             n, keys = dense
             H, d = self.H, Cc // self.H
-            qh = q[:n].view(n, H, d).transpose(0, 1)
-            kh = k[keys].view(-1, H, d).transpose(0, 1)
-            vh = v[keys].view(-1, H, d).transpose(0, 1)
-            top = (F.dropout(torch.softmax(qh @ kh.transpose(1, 2), -1), p_attn, p_attn > 0) @ vh).transpose(0, 1).reshape(n, Cc)
-            ctx = torch.cat([top, ops.SparseCrossAttention.apply(q[n:], k, v, csr[0], csr[1], False, tr)])
+            kd, vd = k[keys], v[keys]
+            tops = []
+            for h in range(H):                  # the dense denoising block per head: logits and P V as HIP products, softmax / dropout element-wise
+                sl = slice(h * d, (h + 1) * d)
+                prob = F.dropout(torch.softmax(matmul_nt_ad(q[:n, sl].contiguous(), kd[:, sl].contiguous()), -1), p_attn, p_attn > 0)
+                tops.append(matmul_nt_ad(prob, vd[:, sl].t().contiguous()))
+            ctx = torch.cat([torch.cat(tops, 1), ops.SparseCrossAttention.apply(q[n:], k, v, csr[0], csr[1], False, tr)])
         else:
             ctx = ops.SparseCrossAttention.apply(q, k, v, csr[0], csr[1], False, tr)
-        return F.linear(ctx, self.p[name + '.attn.out_proj.weight'], self.p[name + '.attn.out_proj.bias'])
+        return linear(ctx, self.p[name + '.attn.out_proj.weight'], self.p[name + '.attn.out_proj.bias'])
 
     def __call__(self, ref, key_in, val_in, row_ptr, col_idx, pad=0, single=1, dt=0.0, dn_keys=None):
         """ref [T,3] normalised reference points (denoising rows first), key_in / val_in [S,256] (memory + key_pos, memory), CSR of the
         cross attention over the T rows — or, with ``dn_keys`` (sorted key rows every denoising query sees), over the T - pad matched
         rows only.  Returns (all_cls [L,T,C], all_reg [L,T,10]); rows >= pad get v / dt when dt != 0."""
         import torch.nn.functional as F
+        from .autograd_ops import layer_norm, linear
         P, T, dev = self.p, ref.shape[0], ref.device
         pre = 'bbox_head.transformer.decoder.'
         ref = ref.to(torch.float32)
@@ -295,8 +300,8 @@ class TrainDecoder:
             posemb = torch.cat((emb(ref[..., 1]), emb(ref[..., 0]), emb(ref[..., 2])), dim=-1)
         else:
             posemb = ops.posemb3d(ref.contiguous(), dim_t.contiguous())
-        qpos = F.linear(F.relu(F.linear(posemb, P['bbox_head.query_embedding.0.weight'], P['bbox_head.query_embedding.0.bias'])),
-                        P['bbox_head.query_embedding.2.weight'], P['bbox_head.query_embedding.2.bias'])
+        qpos = linear(linear(posemb, P['bbox_head.query_embedding.0.weight'], P['bbox_head.query_embedding.0.bias'], 1),
+                      P['bbox_head.query_embedding.2.weight'], P['bbox_head.query_embedding.2.bias'])
         key_in, val_in = key_in.float(), val_in.float()
         S = key_in.shape[0]
         sa = self.self_attention_pattern(T, pad, single, dev)
@@ -305,7 +310,7 @@ class TrainDecoder:
         ca_t = ops.csr_transpose(ca[0], ca[1], S)
         x = torch.zeros(T, qpos.shape[1], device=dev)
         outs = []
-        ln = lambda t, n: F.layer_norm(t, (t.shape[-1],), P[n + '.weight'], P[n + '.bias'])  # noqa: E731
+        ln = lambda t, n: layer_norm(t, P[n + '.weight'], P[n + '.bias'])  # noqa: E731      (mv2d_row_ln / mv2d_layer_norm_bwd)
         training = self.layers is not None and self.roi_head.training
         for i in range(self.L):
             lp = f'{pre}layers.{i}.'
@@ -320,12 +325,12 @@ class TrainDecoder:
             x = ln(x + drop_sa(self._attn(x + qpos, x + qpos, x, lp + 'attentions.0', sa, sa_t)), lp + 'norms.0')
             x = ln(x + drop_ca(self._attn(x + qpos, key_in, val_in, lp + 'attentions.1', ca, ca_t,
                                           None if dn_keys is None else (pad, dn_keys.long()), p_attn=p_ca)), lp + 'norms.1')
-            h = F.relu(F.linear(x, P[lp + 'ffns.0.layers.0.0.weight'], P[lp + 'ffns.0.layers.0.0.bias']))
+            h = linear(x, P[lp + 'ffns.0.layers.0.0.weight'], P[lp + 'ffns.0.layers.0.0.bias'], 1)
             y = None
             if training:
                 ffn = self.layers[i].ffns[0]                      # mmcv FFN: Linear-ReLU-Dropout, Linear-Dropout, (+ dropout_layer) + identity
                 h = ffn.layers[0][2](h)
-            y = F.linear(h, P[lp + 'ffns.0.layers.1.weight'], P[lp + 'ffns.0.layers.1.bias'])
+            y = linear(h, P[lp + 'ffns.0.layers.1.weight'], P[lp + 'ffns.0.layers.1.bias'])
             if training:
                 y = ffn.layers[2](y)
                 dl = getattr(ffn, 'dropout_layer', None)
@@ -338,11 +343,11 @@ class TrainDecoder:
         all_cls, all_reg = [], []
         for l in range(self.L):
             c, g = f'bbox_head.cls_branches.{l}.', f'bbox_head.reg_branches.{l}.'
-            y = F.relu(ln(F.linear(outs[l], P[c + '0.weight'], P[c + '0.bias']), c + '1'))
-            y = F.relu(ln(F.linear(y, P[c + '3.weight'], P[c + '3.bias']), c + '4'))
-            all_cls.append(F.linear(y, P[c + '6.weight'], P[c + '6.bias']))
-            t = F.relu(F.linear(outs[l], P[g + '0.weight'], P[g + '0.bias']))
-            t = F.linear(F.relu(F.linear(t, P[g + '2.weight'], P[g + '2.bias'])), P[g + '4.weight'], P[g + '4.bias'])
+            y = F.relu(ln(linear(outs[l], P[c + '0.weight'], P[c + '0.bias']), c + '1'))
+            y = F.relu(ln(linear(y, P[c + '3.weight'], P[c + '3.bias']), c + '4'))
+            all_cls.append(linear(y, P[c + '6.weight'], P[c + '6.bias']))
+            t = linear(outs[l], P[g + '0.weight'], P[g + '0.bias'], 1)
+            t = linear(linear(t, P[g + '2.weight'], P[g + '2.bias'], 1), P[g + '4.weight'], P[g + '4.bias'])
             cx = (t[:, 0:1] + inv[:, 0:1]).sigmoid() * (hi[0] - lo[0]) + lo[0]
             cy = (t[:, 1:2] + inv[:, 1:2]).sigmoid() * (hi[1] - lo[1]) + lo[1]
             cz = (t[:, 4:5] + inv[:, 2:3]).sigmoid() * (hi[2] - lo[2]) + lo[2]
@@ -396,18 +401,22 @@ def query_generator_autograd(roi_head, roi_feat, intr_feat, minv):
     reference points [R,3], differentiable w.r.t. the query generator's parameters and w.r.t. roi_feat (``ops.RoIAlignRows`` carries the
     gradient on to the feature map)."""
     import torch.nn.functional as F
+    from .autograd_ops import linear
     qg = roi_head.query_generator
     R = roi_feat.shape[0]
-    x = roi_feat.float().view(R, 7, 7, -1).permute(0, 3, 1, 2)
+    Cc = roi_feat.shape[-1]
+    # conv3x3 (padding 1) as im2col (index plumbing: pad + 9 shifted views) + ONE product on the HIP GEMM, k order (tap, channel)
+    xp = F.pad(roi_feat.float().view(R, 7, 7, Cc), (0, 0, 1, 1, 1, 1))
+    cols = torch.cat([xp[:, ky:ky + 7, kx:kx + 7] for ky in range(3) for kx in range(3)], -1).reshape(R * 49, 9 * Cc)
     conv = qg.shared_convs[0].conv
-    x = F.avg_pool2d(F.relu(F.conv2d(x, conv.weight, conv.bias, padding=1)), 7).flatten(1)
-    x = F.relu(qg.shared_fcs[0](x))
+    x = linear(cols, conv.weight.permute(0, 2, 3, 1).reshape(conv.weight.shape[0], 9 * Cc), conv.bias, 1).view(R, 49, -1).mean(1)   # ReLU, AvgPool2d(7)
+    x = linear(x, qg.shared_fcs[0].weight, qg.shared_fcs[0].bias, 1)
     x = torch.cat([x, intr_feat.detach().float()], 1).clamp(min=-5e3, max=5e3)
-    x = F.relu(F.linear(x, qg.extra_enc[0].weight, qg.extra_enc[0].bias))
-    x = F.relu(F.linear(x, qg.extra_enc[2].weight, qg.extra_enc[2].bias))
-    c = qg.fc_center(x)
+    x = linear(x, qg.extra_enc[0].weight, qg.extra_enc[0].bias, 1)
+    x = linear(x, qg.extra_enc[2].weight, qg.extra_enc[2].bias, 1)
+    c = linear(x, qg.fc_center.weight, qg.fc_center.bias)
     hom = torch.cat([c[:, :2] * c[:, 2:3], c[:, 2:3], torch.ones_like(c[:, :1])], 1)
-    xyz = torch.bmm(minv.detach().view(R, 4, 4), hom[..., None])[:, :3, 0]
+    xyz = (minv.detach().view(R, 4, 4) * hom[:, None, :]).sum(-1)[:, :3]                 # per-RoI 4x4 matrix . vector, element-wise (no BLAS call)
     pr = [float(v) for v in roi_head.pc_range]
     lo = xyz.new_tensor(pr[:3])
     return (xyz - lo) / (xyz.new_tensor(pr[3:]) - lo)
@@ -417,12 +426,12 @@ def key_embedding_autograd(roi_head, A1, A2, Xf):
     """The PE block at the gathered key positions (MU/pe.py:36-48,150-166) as torch autograd over the module's parameters, on the inputs the
     engine prepared: A1 [S,192] inverse-sigmoid frustum coordinates, A2 [S,384] sine embedding (bf16, no gradient), Xf [S,256] feature rows
     (differentiable).  Returns (feat + pe, feat, pe) [S,256] fp32: the T path's keys / values; the S path RoI-aligns pe."""
-    import torch.nn.functional as F
+    from .autograd_ops import linear
     pe = roi_head.position_encoding
-    lin = lambda conv, t: F.linear(t, conv.weight.flatten(1), conv.bias)  # noqa: E731   (1x1 convs)
+    lin = lambda conv, t, act=0: linear(t, conv.weight.flatten(1), conv.bias, act)  # noqa: E731   (1x1 convs on the HIP GEMM)
     feat = Xf.float()
-    p3d = lin(pe.position_encoder[2], F.relu(lin(pe.position_encoder[0], A1.detach().float())))
-    gate = torch.sigmoid(lin(pe.fpe.conv_expand, F.relu(lin(pe.fpe.conv_reduce, feat))))
-    sine = lin(pe.adapt_pos3d[2], F.relu(lin(pe.adapt_pos3d[0], A2.detach().float())))
+    p3d = lin(pe.position_encoder[2], lin(pe.position_encoder[0], A1.detach().float(), 1))
+    gate = torch.sigmoid(lin(pe.fpe.conv_expand, lin(pe.fpe.conv_reduce, feat, 1)))
+    sine = lin(pe.adapt_pos3d[2], lin(pe.adapt_pos3d[0], A2.detach().float(), 1))
     pos = p3d * gate + sine
     return feat + pos, feat, pos
