@@ -51,7 +51,9 @@ int mv2d_gemm_bf16(const void* A, const void* A2, int n_split, int a_mode, const
 int mv2d_gemm_bf16_ex(const void* A, const void* A2, int n_split, int a_mode, const void* W, const float* bias, int M, int N, int K, int lda,
                       const int* m_dev, int act, const float* mul, int ldmul, const float* add, int ldadd, void* C, int c_bf16, int ldc,
                       long long c_blk_stride, int c_blk_cols, void* C2, const float* add2, int ldc2, int ldadd2, int c_split3, const int* add_idx /* optional:
-                      the add operand's row for output row m is add_idx[m] % add_period (a gathered table) */, int add_period, void* stream);
+                      the add operand's row for output row m is add_idx[m] % add_period (a gathered table) */, int add_period,
+                      int k_splits /* >= 1; > 1: split-K, split s writes the plain fp32 partial product of its K range to C + s * c_split_stride
+                      (bias in slab 0; no activation / fused operands): sum the slabs with mv2d_colsum */, long long c_split_stride, void* stream);
 /* out [M, 3 cols] bf16 = [hi | lo | hi] of a (+ b, optional) fp32 [M, cols]: hi = bf16(x), lo = bf16(x - hi); rows >= *m_dev (optional)
  * are not written. */
 int mv2d_split3_rows(const float* a, const float* b, void* out, int M, int cols, const int* m_dev, void* stream);
@@ -355,6 +357,15 @@ int mv2d_attn_out_zmap_x3(const float* z, const void* WB_hi, const void* WB_lo, 
 int mv2d_sparse_xattn_bwd(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
                           const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws,
                           float* dq, float* dK, float* dV, int R, int S, void* stream);
+/* The same pair with ATTENTION-PROBABILITY DROPOUT (nn.MultiheadAttention(dropout=p) in training, MU/petr_transformer.py:404-418): the softmax
+ * probabilities are dropped with probability p_drop and the kept ones scaled by 1 / (1 - p_drop) before the value sum.  The keep decision of
+ * (allowed pair e in CSR order, head h) is a counter-based hash of (seed, 8 e + h) (murmur3 finaliser; u >= p_drop * 2^32 keeps), so the
+ * backward regenerates the forward's mask from the same (p_drop, seed) and nothing is stored.  p_drop = 0: identical to the plain entries. */
+int mv2d_sparse_xattn_fwd_drop(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, float* ctx, float* dbg_logits,
+                               long long dbg_stride, int R, int empty_nan, float p_drop, unsigned int seed, void* stream);
+int mv2d_sparse_xattn_bwd_drop(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
+                               const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws, float* dq, float* dK,
+                               float* dV, int R, int S, float p_drop, unsigned int seed, void* stream);
 
 /* ---- geometry / gather ---------------------------------------------------------------------------------- */
 
@@ -490,8 +501,10 @@ int mv2d_dn_queries(const float* gt, const int* gt_labels, const float* rnd, int
  * is ([rows, k]) or TRANSPOSED (src is [k, rows]), zero-padded to rows_out x k_pad; side 0 = A operand [hi | lo | hi], side 1 = B operand
  * [hi | hi | lo].  forward y = x W^T: A = x, B = W; dx = dy W: A = dy, B = W transposed; dW = dy^T x: A = dy transposed, B = x transposed. */
 int mv2d_split3_operand(const float* src, long long ld, int rows, int k, int transpose, void* dst, int rows_out, int k_pad, int side, void* stream);
-/* out [cols] = column sums of x [rows, cols] (row stride ld), fixed summation order (bias gradients). */
-int mv2d_colsum(const float* x, long long ld, int rows, int cols, float* out, void* stream);
+/* out [cols] = column sums of x [rows, cols] (row stride ld), fixed summation order (bias gradients, split-K slabs).  Long matrices are summed
+ * in two passes through scratch [mv2d_colsum_scratch_rows(rows), cols] (0 rows: not needed; NULL: one pass). */
+int mv2d_colsum_scratch_rows(int rows);
+int mv2d_colsum(const float* x, long long ld, int rows, int cols, float* out, float* scratch, void* stream);
 /* nn.LayerNorm(256) backward (MU/petr_transformer.py norms, cross_attention_head.py:127-133): dx [M,256], dw [256], db [256] from x, dy, w
  * (mean / rstd recomputed); dw_part / db_part: scratch [mv2d_layer_norm_bwd_blocks(M), 256] each. */
 int mv2d_layer_norm_bwd_blocks(int M);

@@ -24,7 +24,7 @@ SIGNATURES = {
     'mv2d_device_arch': (I, [C.c_char_p, I]),
     'mv2d_spin': (I, [I, P]),
     'mv2d_gemm_bf16': (I, [P, P, I, I, P, P, I, I, I, I, P, I, P, I, P, I, P, I, I, LL, I, P, P, I, I, P]),
-    'mv2d_gemm_bf16_ex': (I, [P, P, I, I, P, P, I, I, I, I, P, I, P, I, P, I, P, I, I, LL, I, P, P, I, I, I, P, I, P]),
+    'mv2d_gemm_bf16_ex': (I, [P, P, I, I, P, P, I, I, I, I, P, I, P, I, P, I, P, I, I, LL, I, P, P, I, I, I, P, I, I, LL, P]),
     'mv2d_split3_rows': (I, [P, P, P, I, I, P, P]),
     'mv2d_pe_fused': (I, [P, P, P, P, P, P, I] + [P] * 14 + [P]),
     'mv2d_pe_fused_tab': (I, [P, P, P, P, P, I] + [P] * 9 + [I, P, P, P]),
@@ -63,6 +63,8 @@ SIGNATURES = {
     'mv2d_sparse_xattn_fwd': (I, [P, P, P, P, P, P, P, LL, I, I, P]),
     'mv2d_raw_xattn_fwd': (I, [P, P, P, P, P, P, I, I, P]),
     'mv2d_sparse_xattn_bwd': (I, [P] * 14 + [I, I, P]),
+    'mv2d_sparse_xattn_fwd_drop': (I, [P, P, P, P, P, P, P, LL, I, I, F, C.c_uint, P]),
+    'mv2d_sparse_xattn_bwd_drop': (I, [P] * 14 + [I, I, F, C.c_uint, P]),
     'mv2d_xattn_qmap': (I, [P, P, P, P, I, P]),
     'mv2d_attn_out_qmap_x3': (I, [P] * 12 + [F, P, P, P, I, F, P]),
     'mv2d_attn_out_zmap_x3': (I, [P, P, P, P, P, I, P, P, P, P, P, P, P, I, F, P]),
@@ -90,7 +92,8 @@ SIGNATURES = {
     'mv2d_pack_detections': (I, [P, P, P, P, P, I, I, I, P]),
     'mv2d_roi_align_bwd': (I, [P, P, P, P, I, I, I, I, F, I, P]),
     'mv2d_split3_operand': (I, [P, LL, I, I, I, P, I, I, I, P]),
-    'mv2d_colsum': (I, [P, LL, I, I, P, P]),
+    'mv2d_colsum_scratch_rows': (I, [I]),
+    'mv2d_colsum': (I, [P, LL, I, I, P, P, P]),
     'mv2d_layer_norm_bwd_blocks': (I, [I]),
     'mv2d_layer_norm_bwd': (I, [P, P, P, P, P, P, P, P, I, F, P]),
     'mv2d_match_cost': (I, [P, P, P, P, P, I, I, I, I, F, F, F, F, P]),

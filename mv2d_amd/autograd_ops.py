@@ -46,22 +46,36 @@ def matmul_nt(A, B, bias=None, act=0, trans_a=False, trans_b=False):
     M, K = (A.shape[1], A.shape[0]) if trans_a else A.shape
     N, Kb = (B.shape[1], B.shape[0]) if trans_b else B.shape
     assert K == Kb, (A.shape, B.shape, trans_a, trans_b)
-    if M == 0 or N == 0:
+    if M == 0 or N == 0 or K == 0:
         return torch.zeros((M, N), device=A.device, dtype=F32)
     kp, Np = _pad(K, 64), _pad(N, 8)
     a3 = split3_operand(A, trans_a, M, kp, 0)
     b3 = split3_operand(B, trans_b, Np, kp, 1)
     if bias is not None and Np != N:
         bias = torch.cat([bias, bias.new_zeros(Np - N)])
-    out = torch.empty((M, Np), device=A.device, dtype=F32)
-    ops.gemm_bf16(a3, b3, bias, act=act, out=out, M=M)
+    # few output tiles with a long contraction (the weight gradients: K = the rows of the layer's input): split K over the grid's y dimension
+    # into fp32 slabs and sum them in fixed order
+    tiles = -(-M // 64) * -(-Np // 64)
+    splits = 1
+    if act == 0 and tiles < 256 and kp >= 1024:
+        splits = int(min(max(512 // tiles, 1), 3 * kp // 256, 64))
+    if splits > 1:
+        slabs = torch.empty((splits, M, Np), device=A.device, dtype=F32)
+        ops.gemm_bf16(a3, b3, bias, out=slabs[0], M=M, k_splits=splits, split_stride=M * Np)
+        out = colsum(slabs.view(splits, M * Np)).view(M, Np)
+    else:
+        out = torch.empty((M, Np), device=A.device, dtype=F32)
+        ops.gemm_bf16(a3, b3, bias, act=act, out=out, M=M)
     return out if Np == N else out[:, :N]
 
 
 def colsum(x):
     x = x if x.stride(-1) == 1 else x.contiguous()
+    lib = _lib.load()
     out = torch.empty(x.shape[1], device=x.device, dtype=F32)
-    check(_lib.load().mv2d_colsum(_p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), _stream()), 'mv2d_colsum')
+    nch = int(lib.mv2d_colsum_scratch_rows(x.shape[0]))
+    scratch = torch.empty((nch, x.shape[1]), device=x.device, dtype=F32) if nch else None
+    check(lib.mv2d_colsum(_p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), _p(scratch), _stream()), 'mv2d_colsum')
     return out
 
 
@@ -85,6 +99,9 @@ class LinearFn(torch.autograd.Function):
         if act == 1:
             g = g * (y > 0)
         g = g.contiguous()
+        if g.shape[0] == 0:
+            return (torch.zeros(shape, device=g.device) if ctx.needs_input_grad[0] else None, torch.zeros_like(W) if ctx.needs_input_grad[1] else None,
+                    torch.zeros(W.shape[0], device=g.device) if (has_b and ctx.needs_input_grad[2]) else None, None)
         dx = matmul_nt(g, W.float(), trans_b=True).reshape(shape) if ctx.needs_input_grad[0] else None
         dW = matmul_nt(g, x2, trans_a=True, trans_b=True).to(W.dtype) if ctx.needs_input_grad[1] else None
         db = colsum(g) if (has_b and ctx.needs_input_grad[2]) else None

@@ -163,11 +163,24 @@ __device__ __forceinline__ void load_rows(KeyChunk<KCH>& c, const unsigned short
     }
 }
 
+// Attention-probability dropout (nn.MultiheadAttention's `dropout`, MU/petr_transformer.py:404-418, in training): the keep decision of the
+// probability of (allowed pair e, head h) is a counter-based hash of (seed, 8 e + h) (murmur3 finaliser) compared with thr = p * 2^32, so the
+// forward and the backward kernels regenerate the same mask without storing it; kept probabilities are scaled by 1 / (1 - p).
+// thr == 0: no dropout (every pair kept, scale 1).
+struct AttnDrop { unsigned int thr, seed; float scale; };
+__device__ __forceinline__ float attn_drop_factor(const AttnDrop& d, long long e, int h) {
+    if (d.thr == 0u) return 1.f;
+    unsigned int u = ((unsigned int)(e * 8 + h) * 0x9E3779B1u) ^ d.seed;
+    u ^= u >> 16; u *= 0x85EBCA6Bu; u ^= u >> 13; u *= 0xC2B2AE35u; u ^= u >> 16;
+    return u >= d.thr ? d.scale : 0.f;
+}
+
 template <int NW, int KCH>
 __global__ __launch_bounds__(64 * NW) void sparse_xattn_kernel(const float* __restrict__ q, const unsigned short* __restrict__ K,
                                                                const unsigned short* __restrict__ V, const int* __restrict__ row_ptr,
                                                                const int* __restrict__ col_idx, float* __restrict__ ctx,
-                                                               float* __restrict__ dbg_logits, long long dbg_stride, int R, int empty_nan) {
+                                                               float* __restrict__ dbg_logits, long long dbg_stride, int R, int empty_nan,
+                                                               AttnDrop drop) {
     __shared__ float sm[NW][8], sl[NW][8], sacc[NW][C];
     const int r = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -205,8 +218,9 @@ __global__ __launch_bounds__(64 * NW) void sparse_xattn_kernel(const float* __re
         float psum = 0.f;
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
-            const float pi = expf(lg[i] - m_new);
-            psum += pi;
+            float pi = expf(lg[i] - m_new);
+            psum += pi;                                                    // the softmax denominator sees every allowed key
+            pi *= attn_drop_factor(drop, base + i, lane >> 3);             // dropped / rescaled probability enters the value sum only
             acc.x = fmaf(pi, __uint_as_float(cur.vv[i].x << 16), acc.x);
             acc.y = fmaf(pi, __uint_as_float(cur.vv[i].x & 0xffff0000u), acc.y);
             acc.z = fmaf(pi, __uint_as_float(cur.vv[i].y << 16), acc.z);
@@ -406,7 +420,8 @@ __device__ __forceinline__ float head_sum(float d) {
 __global__ __launch_bounds__(256) void sparse_xattn_bwd_q_kernel(const float* __restrict__ q, const unsigned short* __restrict__ K,
                                                                  const unsigned short* __restrict__ V, const int* __restrict__ row_ptr,
                                                                  const int* __restrict__ col_idx, const float* __restrict__ ctx,
-                                                                 const float* __restrict__ dctx, float* __restrict__ dq, float* __restrict__ pd, int R) {
+                                                                 const float* __restrict__ dctx, float* __restrict__ dq, float* __restrict__ pd, int R,
+                                                                 AttnDrop drop) {
     __shared__ float sm[4][8], sl[4][8], sdq[4][C];
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 3;
     const int beg = row_ptr[r], end = row_ptr[r + 1];
@@ -456,10 +471,12 @@ __global__ __launch_bounds__(256) void sparse_xattn_bwd_q_kernel(const float* __
             }
             const float sv = head_sum(k4.x * q4.x + k4.y * q4.y + k4.z * q4.z + k4.w * q4.w);
             const float pj = expf(sv - lse);
-            const float dp = head_sum(d4.x * v4.x + d4.y * v4.y + d4.z * v4.z + d4.w * v4.w);
+            // with dropout ctx = sum_j (p_j m_j) v_j: dL/dp_j = m_j dctx.v_j, D = sum_j p_j m_j dctx.v_j = dctx.ctx still holds, dV_j = (p_j m_j) dctx
+            const float ms = attn_drop_factor(drop, e, h);
+            const float dp = head_sum(d4.x * v4.x + d4.y * v4.y + d4.z * v4.z + d4.w * v4.w) * ms;
             const float ds = pj * (dp - D);
             gq.x = fmaf(ds, k4.x, gq.x); gq.y = fmaf(ds, k4.y, gq.y); gq.z = fmaf(ds, k4.z, gq.z); gq.w = fmaf(ds, k4.w, gq.w);
-            if ((lane & 7) == 0) { pd[(long long)e * 16 + h] = pj; pd[(long long)e * 16 + 8 + h] = ds; }
+            if ((lane & 7) == 0) { pd[(long long)e * 16 + h] = pj * ms; pd[(long long)e * 16 + 8 + h] = ds; }
         }
     }
     *reinterpret_cast<float4*>(&sdq[wave][4 * lane]) = gq;
@@ -521,15 +538,38 @@ extern "C" int mv2d_self_attn_dn_fwd(const float* qkv, float* ctx, int R, int dn
     return MV2D_OK;
 }
 
+static inline AttnDrop make_drop(float p_drop, unsigned int seed) {
+    AttnDrop d{0u, seed, 1.f};
+    if (p_drop > 0.f) {
+        const double t = (double)p_drop * 4294967296.0;
+        d.thr = t >= 4294967295.0 ? 0xffffffffu : (unsigned int)t;
+        if (d.thr == 0u) d.thr = 1u;
+        d.scale = 1.f / (1.f - p_drop);
+    }
+    return d;
+}
+
+extern "C" int mv2d_sparse_xattn_fwd_drop(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx,
+                                          float* ctx, float* dbg_logits, long long dbg_stride, int R, int empty_nan, float p_drop,
+                                          unsigned int seed, void* stream);
+
 extern "C" int mv2d_sparse_xattn_fwd(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx,
                                      float* ctx, float* dbg_logits, long long dbg_stride, int R, int empty_nan, void* stream) {
+    return mv2d_sparse_xattn_fwd_drop(q, K, V, row_ptr, col_idx, ctx, dbg_logits, dbg_stride, R, empty_nan, 0.f, 0u, stream);
+}
+
+extern "C" int mv2d_sparse_xattn_fwd_drop(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx,
+                                          float* ctx, float* dbg_logits, long long dbg_stride, int R, int empty_nan, float p_drop,
+                                          unsigned int seed, void* stream) {
     MV2D_CHECK_ARG(q && K && V && row_ptr && col_idx && ctx && R >= 0, "mv2d_sparse_xattn_fwd: bad args");
+    MV2D_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mv2d_sparse_xattn_fwd_drop: p_drop in [0, 1)");
+    const AttnDrop drop = make_drop(p_drop, seed);
     if (R == 0) return MV2D_OK;
     // 8 waves x 4-key chunks: best of {2,4,8} waves x {4,8,16} keys with several samples per launch (cfg2_s decoder 0.671 -> 0.655 ms per
     // 6-sample batch, cfg3_t 0.845 -> 0.817); with one sample per launch 8 x 8 was marginally ahead
     static const int cfg = getenv("MV2D_XATTN_CFG") ? atoi(getenv("MV2D_XATTN_CFG")) : 84;      // experiment switch: waves * 10 + keys per chunk
 #define MV2D_XA(NW, KC) hipLaunchKernelGGL((sparse_xattn_kernel<NW, KC>), dim3(R), dim3(64 * NW), 0, (hipStream_t)stream, q, (const unsigned short*)K, \
-                                           (const unsigned short*)V, row_ptr, col_idx, ctx, dbg_logits, dbg_stride, R, empty_nan)
+                                           (const unsigned short*)V, row_ptr, col_idx, ctx, dbg_logits, dbg_stride, R, empty_nan, drop)
     if (cfg == 48) MV2D_XA(4, 8);
     else if (cfg == 416) MV2D_XA(4, 16);
     else if (cfg == 28) MV2D_XA(2, 8);
@@ -543,15 +583,26 @@ extern "C" int mv2d_sparse_xattn_fwd(const float* q, const void* K, const void* 
     return MV2D_OK;
 }
 
+extern "C" int mv2d_sparse_xattn_bwd_drop(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
+                                          const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws,
+                                          float* dq, float* dK, float* dV, int R, int S, float p_drop, unsigned int seed, void* stream);
+
 extern "C" int mv2d_sparse_xattn_bwd(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
                                      const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws,
                                      float* dq, float* dK, float* dV, int R, int S, void* stream) {
+    return mv2d_sparse_xattn_bwd_drop(q, K, V, row_ptr, col_idx, ctx, dctx, key_ptr, pair_idx, pair_row, pair_ws, dq, dK, dV, R, S, 0.f, 0u, stream);
+}
+
+extern "C" int mv2d_sparse_xattn_bwd_drop(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
+                                          const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws,
+                                          float* dq, float* dK, float* dV, int R, int S, float p_drop, unsigned int seed, void* stream) {
     MV2D_CHECK_ARG(q && K && V && row_ptr && col_idx && ctx && dctx && key_ptr && pair_idx && pair_row && pair_ws && dq && dK && dV,
                    "mv2d_sparse_xattn_bwd: null pointer");
-    MV2D_CHECK_ARG(R >= 0 && S >= 0, "mv2d_sparse_xattn_bwd: bad sizes");
+    MV2D_CHECK_ARG(R >= 0 && S >= 0 && p_drop >= 0.f && p_drop < 1.f, "mv2d_sparse_xattn_bwd: bad sizes / p_drop");
+    const AttnDrop drop = make_drop(p_drop, seed);
     if (R > 0)
         hipLaunchKernelGGL(sparse_xattn_bwd_q_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, q, (const unsigned short*)K, (const unsigned short*)V,
-                           row_ptr, col_idx, ctx, dctx, dq, pair_ws, R);
+                           row_ptr, col_idx, ctx, dctx, dq, pair_ws, R, drop);
     if (S > 0)
         hipLaunchKernelGGL(sparse_xattn_bwd_kv_kernel, dim3(cdiv(S, 4)), dim3(256), 0, (hipStream_t)stream, q, dctx, pair_ws, key_ptr, pair_idx, pair_row,
                            dK, dV, S);

@@ -42,6 +42,7 @@ struct Params {
     long long c_blk_stride; int c_blk_cols;   // out = C + (n / c_blk_cols) * c_blk_stride + m * ldc + n % c_blk_cols
     unsigned short* C2; const float* add2; int ldc2; int ldadd2;   // C2 = bf16(v + add2[m, n])
     const int* add_idx; int add_period;   // optional: the add operand's row of output row m is add_idx[m] % add_period (a gathered table)
+    int k_splits; long long c_split_stride;   // split-K: blockIdx.y = split s of the K range, output slab C + s * c_split_stride (fp32, no act; bias in slab 0)
     int c_split3;                  // bf16 output as the split-precision operand of a following GEMM: [hi | lo | hi] in column blocks of N (ldc >= 3 N)
 };
 
@@ -153,12 +154,16 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 4)) void gemm_bf16_kernel(Par
 #pragma unroll
         for (int j = 0; j < G::TJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
-    load_tile(0);
-    store_tile();
+    // split-K (blockIdx.y): this block's range of k tiles; a split without tiles writes zeros
+    const int nk_all = p.K / BK, per = (nk_all + p.k_splits - 1) / p.k_splits;
+    const int kt0 = blockIdx.y * per, nk = min(nk_all, kt0 + per);
+    if (kt0 < nk) {
+        load_tile(kt0 * BK);
+        store_tile();
+    }
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         if (kt + 1 < nk) load_tile((kt + 1) * BK);          // in flight during the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 4)) void gemm_bf16_kernel(Par
     const bool col_ok = ncol < p.N;                         // N is a multiple of 8 (host-checked)
     float bias8[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias8[e] = (p.bias && col_ok) ? p.bias[ncol + e] : 0.f;
+    for (int e = 0; e < 8; ++e) bias8[e] = (p.bias && col_ok && blockIdx.y == 0) ? p.bias[ncol + e] : 0.f;
     const int nb = p.c_blk_cols > 0 ? ncol / p.c_blk_cols : 0;
     const long long c_col = (long long)nb * p.c_blk_stride + (p.c_blk_cols > 0 ? ncol - nb * p.c_blk_cols : ncol);
 #pragma unroll
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 4)) void gemm_bf16_kernel(Par
                         *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.C) + o) =
                             make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
                     } else {
-                        float* cp = reinterpret_cast<float*>(p.C) + o;
+                        float* cp = reinterpret_cast<float*>(p.C) + o + (long long)blockIdx.y * p.c_split_stride;
                         *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
                         *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
                     }
@@ -303,7 +308,8 @@ extern "C" int mv2d_gemm_bf16_ex(const void* A, const void* A2, int n_split, int
                                  const float* bias, int M, int N, int K, int lda, const int* m_dev, int act,
                                  const float* mul, int ldmul, const float* add, int ldadd, void* C, int c_bf16,
                                  int ldc, long long c_blk_stride, int c_blk_cols, void* C2, const float* add2,
-                                 int ldc2, int ldadd2, int c_split3, const int* add_idx, int add_period, void* stream);
+                                 int ldc2, int ldadd2, int c_split3, const int* add_idx, int add_period, int k_splits, long long c_split_stride,
+                                 void* stream);
 
 // C-ABI: see include/mv2d_hip.h
 extern "C" int mv2d_gemm_bf16(const void* A, const void* A2, int n_split, int a_mode, const void* W,
@@ -312,16 +318,19 @@ extern "C" int mv2d_gemm_bf16(const void* A, const void* A2, int n_split, int a_
                               int ldc, long long c_blk_stride, int c_blk_cols, void* C2, const float* add2,
                               int ldc2, int ldadd2, void* stream) {
     return mv2d_gemm_bf16_ex(A, A2, n_split, a_mode, W, bias, M, N, K, a_mode == 1 ? 256 : lda, m_dev, act, mul, ldmul, add, ldadd, C, c_bf16, ldc,
-                             c_blk_stride, c_blk_cols, C2, add2, ldc2, ldadd2, 0, nullptr, 0, stream);
+                             c_blk_stride, c_blk_cols, C2, add2, ldc2, ldadd2, 0, nullptr, 0, 1, 0, stream);
 }
 
 extern "C" int mv2d_gemm_bf16_ex(const void* A, const void* A2, int n_split, int a_mode, const void* W,
                                  const float* bias, int M, int N, int K, int lda, const int* m_dev, int act,
                                  const float* mul, int ldmul, const float* add, int ldadd, void* C, int c_bf16,
                                  int ldc, long long c_blk_stride, int c_blk_cols, void* C2, const float* add2,
-                                 int ldc2, int ldadd2, int c_split3, const int* add_idx, int add_period, void* stream) {
+                                 int ldc2, int ldadd2, int c_split3, const int* add_idx, int add_period, int k_splits, long long c_split_stride,
+                                 void* stream) {
     MV2D_CHECK_ARG(A && W && (C || C2), "mv2d_gemm_bf16: null A/W/C");
     MV2D_CHECK_ARG(!c_split3 || (C && c_bf16 && !C2 && c_blk_cols == 0 && ldc >= 3 * N), "mv2d_gemm_bf16_ex: c_split3 writes bf16 [hi | lo | hi], ldc >= 3 N");
+    MV2D_CHECK_ARG(k_splits >= 1 && (k_splits == 1 || (C && !c_bf16 && !C2 && act == 0 && !mul && !add && c_blk_cols == 0 && (c_split_stride % 4) == 0)),
+                   "mv2d_gemm_bf16_ex: split-K writes plain fp32 partial slabs (no activation / fused operands)");
     MV2D_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (K % BK_MIN) == 0, "mv2d_gemm_bf16: K must be a positive multiple of 64");
     MV2D_CHECK_ARG((N % 8) == 0, "mv2d_gemm_bf16: N must be a multiple of 8");
     MV2D_CHECK_ARG(a_mode == 0 || (a_mode == 1 && (lda % 128) == 0 && K == 9 * lda && (M % 49) == 0), "mv2d_gemm_bf16: conv3x3 mode needs K = 9 * lda (channels per cell, a multiple of 128), M=R*49");
@@ -342,16 +351,17 @@ extern "C" int mv2d_gemm_bf16_ex(const void* A, const void* A2, int n_split, int
     p.mul = mul; p.ldmul = ldmul; p.add = add; p.ldadd = ldadd; p.C = C; p.c_bf16 = c_bf16; p.ldc = ldc;
     p.c_blk_stride = c_blk_stride; p.c_blk_cols = c_blk_cols; p.C2 = (unsigned short*)C2; p.add2 = add2;
     p.ldc2 = ldc2; p.ldadd2 = ldadd2; p.c_split3 = c_split3; p.add_idx = add_idx; p.add_period = add_idx ? (add_period > 0 ? add_period : 1) : 0;
+    p.k_splits = k_splits; p.c_split_stride = c_split_stride;
     // tile choice: 128x128 when that already gives >= 3 blocks per CU, else 64x64 (4x the blocks)
-    const long long big_blocks = (long long)cdiv(M, 128) * cdiv(N, 128);
+    const long long big_blocks = (long long)cdiv(M, 128) * cdiv(N, 128) * k_splits;
     static const int thr_env = getenv("MV2D_BF16_BIG") ? atoi(getenv("MV2D_BF16_BIG")) : 768;
     if (big_blocks >= thr_env) {
         p.n_tiles = cdiv(N, 128);
-        dim3 grid(((cdiv(M, 128) + 7) / 8) * 8 * p.n_tiles);
+        dim3 grid(((cdiv(M, 128) + 7) / 8) * 8 * p.n_tiles, k_splits);
         hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
     } else {
         p.n_tiles = cdiv(N, 64);
-        dim3 grid(((cdiv(M, 64) + 7) / 8) * 8 * p.n_tiles);
+        dim3 grid(((cdiv(M, 64) + 7) / 8) * 8 * p.n_tiles, k_splits);
         static const int bk_env = getenv("MV2D_BF16_BK") ? atoi(getenv("MV2D_BF16_BK")) : 128;
         // deep K: 128-wide k tiles (twice the bytes in flight per block, half the barriers)
         if (bk_env == 128 && (K % 128) == 0 && K >= 512) hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 128>), grid, dim3(256), 0, (hipStream_t)stream, p);

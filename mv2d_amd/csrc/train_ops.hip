@@ -56,12 +56,17 @@ __global__ __launch_bounds__(256) void split3_op_kernel(const float* __restrict_
 
 // out[c] = sum_r x[r, c]  (fp32, fixed order: deterministic): one block per 64 columns, 4 row groups of 64 lanes each, partial sums
 // through LDS.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long ld, int rows, int cols, float* __restrict__ out) {
+// (blockIdx.y = chunk of CS_ROWS rows, written to out + blockIdx.y * out_stride: long matrices are summed in two passes, both in fixed order)
+constexpr int CS_ROWS = 512;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long ld, int rows, int cols, float* __restrict__ out,
+                                                     long long out_stride = 0, int chunk = 1 << 30) {
     __shared__ float part[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int r_begin = blockIdx.y * chunk, r_end = min(rows, r_begin + chunk);
+    out += (long long)blockIdx.y * out_stride;
     float s = 0.f;
     if (c < cols)
-        for (int r = g; r < rows; r += 4) s += x[(long long)r * ld + c];
+        for (int r = r_begin + g; r < r_end; r += 4) s += x[(long long)r * ld + c];
     part[g][threadIdx.x & 63] = s;
     __syncthreads();
     if (g == 0 && c < cols) out[c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
@@ -116,9 +121,17 @@ extern "C" int mv2d_split3_operand(const float* src, long long ld, int rows, int
     return MV2D_OK;
 }
 
-extern "C" int mv2d_colsum(const float* x, long long ld, int rows, int cols, float* out, void* stream) {
+extern "C" int mv2d_colsum_scratch_rows(int rows) { return rows > 2 * CS_ROWS ? cdiv(rows, CS_ROWS) : 0; }
+
+extern "C" int mv2d_colsum(const float* x, long long ld, int rows, int cols, float* out, float* scratch /* [mv2d_colsum_scratch_rows(rows), cols] or NULL */,
+                           void* stream) {
     MV2D_CHECK_ARG(x && out && rows >= 0 && cols > 0, "mv2d_colsum: bad args");
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream, x, ld, rows, cols, out);
+    const int nch = mv2d_colsum_scratch_rows(rows);
+    if (nch > 0 && scratch) {
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64), nch), dim3(256), 0, (hipStream_t)stream, x, ld, rows, cols, scratch, (long long)cols, CS_ROWS);
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, (long long)cols, nch, cols, out, 0LL, 1 << 30);
+    } else
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream, x, ld, rows, cols, out, 0LL, 1 << 30);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
@@ -132,8 +145,8 @@ extern "C" int mv2d_layer_norm_bwd(const float* x, const float* dy, const float*
                    "mv2d_layer_norm_bwd: operands must be 16-byte aligned (rows of 256 fp32)");
     const int nb = cdiv(M, LNB_ROWS);
     if (nb > 0) hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, dy, w, dx, dw_part, db_part, M, eps);
-    hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, (const float*)dw_part, 256LL, nb, 256, dw);
-    hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, (const float*)db_part, 256LL, nb, 256, db);
+    hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, (const float*)dw_part, 256LL, nb, 256, dw, 0LL, 1 << 30);
+    hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, (const float*)db_part, 256LL, nb, 256, db, 0LL, 1 << 30);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -34,7 +34,7 @@ def _req(t, dtype, name):
 
 def gemm_bf16(A, W, bias=None, *, M=None, A2=None, n_split=0, conv3x3=False, m_dev=None, act=0, mul=None, add=None,
               out=None, out_dtype=BF16, c_blk_stride=0, c_blk_cols=0, out2=None, add2=None, lda=None, ldc=None, split3=False,
-              add_index=None, add_period=0):
+              add_index=None, add_period=0, k_splits=1, split_stride=0):
     """C = epi(A @ W.T + bias) with bf16 MFMA.  A [M,K] bf16 (or [R,49,256] when conv3x3), W [N,K] bf16."""
     lib = _lib.load()
     _req(A, BF16, 'A'); _req(W, BF16, 'W'); _req(A2, BF16, 'A2')
@@ -57,7 +57,7 @@ def gemm_bf16(A, W, bias=None, *, M=None, A2=None, n_split=0, conv3x3=False, m_d
                                _p(mul), mul.stride(0) if mul is not None else 0, _p(add), add.stride(0) if add is not None else 0,
                                _p(out), c_bf16, ldc_, c_blk_stride, c_blk_cols, _p(out2), _p(add2),
                                out2.stride(0) if out2 is not None else 0, add2.stride(0) if add2 is not None else 0, 1 if split3 else 0,
-                               _p(add_index), int(add_period), _stream())
+                               _p(add_index), int(add_period), int(k_splits), int(split_stride), _stream())
     check(rc, 'mv2d_gemm_bf16')
     return out if out is not None else out2
 
@@ -493,15 +493,15 @@ def dn_queries(gt, gt_labels, rnd, scalar, noise_scale, noise_trans, split, num_
     return ref, labels, boxes
 
 
-def sparse_xattn(q, K, V, row_ptr, col_idx, out=None, R=None, dbg_logits=None, empty_nan=True):
+def sparse_xattn(q, K, V, row_ptr, col_idx, out=None, R=None, dbg_logits=None, empty_nan=True, p_drop=0.0, seed=0):
     _req(q, torch.float32, 'q'); _req(K, BF16, 'K'); _req(V, BF16, 'V')
     _req(row_ptr, torch.int32, 'row_ptr'); _req(col_idx, torch.int32, 'col_idx')
     R = q.shape[0] if R is None else R
     if out is None:
         out = torch.empty((R, 256), device=q.device, dtype=torch.float32)
-    check(_lib.load().mv2d_sparse_xattn_fwd(_p(q), _p(K), _p(V), _p(row_ptr), _p(col_idx), _p(out), _p(dbg_logits),
-                                            dbg_logits.stride(0) if dbg_logits is not None else 0, R, 1 if empty_nan else 0, _stream()),
-          'mv2d_sparse_xattn_fwd')
+    check(_lib.load().mv2d_sparse_xattn_fwd_drop(_p(q), _p(K), _p(V), _p(row_ptr), _p(col_idx), _p(out), _p(dbg_logits),
+                                                 dbg_logits.stride(0) if dbg_logits is not None else 0, R, 1 if empty_nan else 0, float(p_drop),
+                                                 int(seed) & 0xffffffff, _stream()), 'mv2d_sparse_xattn_fwd')
     return out
 
 
@@ -630,7 +630,21 @@ def csr_transpose(row_ptr, col_idx, S):
     return key_ptr, pair_idx, pair_row
 
 
-def sparse_xattn_bwd(q, K, V, row_ptr, col_idx, ctx, dctx, R=None, transposed=None):
+def attn_drop_mask(nnz, seed, p_drop):
+    """The keep / scale factors [nnz, 8] the kernels derive from (seed, p_drop) (numpy restatement of the device hash, for tests)."""
+    import numpy as np
+    if p_drop <= 0:
+        return np.ones((nnz, 8), np.float32)
+    thr = min(int(p_drop * 4294967296.0), 0xffffffff) or 1
+    with np.errstate(over='ignore'):
+        u = (np.arange(nnz * 8, dtype=np.uint64) * np.uint64(0x9E3779B1)).astype(np.uint32) ^ np.uint32(seed & 0xffffffff)
+        u ^= u >> np.uint32(16); u = (u.astype(np.uint64) * np.uint64(0x85EBCA6B)).astype(np.uint32)
+        u ^= u >> np.uint32(13); u = (u.astype(np.uint64) * np.uint64(0xC2B2AE35)).astype(np.uint32)
+        u ^= u >> np.uint32(16)
+    return np.where(u >= np.uint32(thr), np.float32(1.0 / (1.0 - p_drop)), np.float32(0)).reshape(nnz, 8)
+
+
+def sparse_xattn_bwd(q, K, V, row_ptr, col_idx, ctx, dctx, R=None, transposed=None, p_drop=0.0, seed=0):
     """Backward of sparse_xattn: returns (dq [R,256] fp32 w.r.t. the pre-scaled q, dK, dV [S,256] fp32); transposed = csr_transpose(...)
     of the same CSR when the caller keeps it."""
     _req(q, torch.float32, 'q'); _req(K, BF16, 'K'); _req(V, BF16, 'V'); _req(ctx, torch.float32, 'ctx'); _req(dctx, torch.float32, 'dctx')
@@ -642,8 +656,9 @@ def sparse_xattn_bwd(q, K, V, row_ptr, col_idx, ctx, dctx, R=None, transposed=No
     dK = torch.empty((S, 256), device=q.device, dtype=torch.float32)
     dV = torch.empty((S, 256), device=q.device, dtype=torch.float32)
     pair_ws = torch.empty((max(nnz, 1), 16), device=q.device, dtype=torch.float32)
-    check(_lib.load().mv2d_sparse_xattn_bwd(_p(q), _p(K), _p(V), _p(row_ptr), _p(col_idx), _p(ctx), _p(dctx.contiguous()), _p(key_ptr), _p(pair_idx),
-                                            _p(pair_row), _p(pair_ws), _p(dq), _p(dK), _p(dV), R, S, _stream()), 'mv2d_sparse_xattn_bwd')
+    check(_lib.load().mv2d_sparse_xattn_bwd_drop(_p(q), _p(K), _p(V), _p(row_ptr), _p(col_idx), _p(ctx), _p(dctx.contiguous()), _p(key_ptr), _p(pair_idx),
+                                                 _p(pair_row), _p(pair_ws), _p(dq), _p(dK), _p(dV), R, S, float(p_drop), int(seed) & 0xffffffff, _stream()),
+          'mv2d_sparse_xattn_bwd')
     return dq, dK, dV
 
 
@@ -654,20 +669,23 @@ class SparseCrossAttention(torch.autograd.Function):
     one CSR, so the caller builds it once for all of them (otherwise it is built in every backward)."""
 
     @staticmethod
-    def forward(fctx, q, K, V, row_ptr, col_idx, empty_nan=False, transposed=None):
+    def forward(fctx, q, K, V, row_ptr, col_idx, empty_nan=False, transposed=None, p_drop=0.0, seed=0):
         # fp32 K / V are rounded to bf16 here (what the kernels read) and get fp32 gradients back
+        # p_drop / seed: attention-probability dropout (training); the backward regenerates the mask from the same pair
         fctx.kv_dtypes = (K.dtype, V.dtype)
         q, K, V = q.contiguous(), K.to(BF16).contiguous(), V.to(BF16).contiguous()
-        out = sparse_xattn(q, K, V, row_ptr, col_idx, R=q.shape[0], empty_nan=empty_nan)
+        out = sparse_xattn(q, K, V, row_ptr, col_idx, R=q.shape[0], empty_nan=empty_nan, p_drop=p_drop, seed=seed)
         fctx.save_for_backward(q, K, V, row_ptr, col_idx, out)
         fctx.transposed = transposed
+        fctx.drop = (float(p_drop), int(seed))
         return out
 
     @staticmethod
     def backward(fctx, dout):
         q, K, V, row_ptr, col_idx, out = fctx.saved_tensors
-        dq, dK, dV = sparse_xattn_bwd(q, K, V, row_ptr, col_idx, out, dout.float().contiguous(), transposed=fctx.transposed)
-        return dq, dK.to(fctx.kv_dtypes[0]), dV.to(fctx.kv_dtypes[1]), None, None, None, None
+        dq, dK, dV = sparse_xattn_bwd(q, K, V, row_ptr, col_idx, out, dout.float().contiguous(), transposed=fctx.transposed, p_drop=fctx.drop[0],
+                                      seed=fctx.drop[1])
+        return dq, dK.to(fctx.kv_dtypes[0]), dV.to(fctx.kv_dtypes[1]), None, None, None, None, None, None
 
 
 def box_params(rois, viewK, viewE, intr, ld_intr, minv, K_roi=None, roi_size=7.0, intr_scale=0.1, min_size=4.0):

@@ -247,6 +247,14 @@ class TrainDecoder:
         pd, dl = getattr(att, 'proj_drop', None), getattr(att, 'dropout_layer', None)
         return p_attn, (lambda t: (dl(pd(t) if pd is not None else t) if dl is not None else t))
 
+    def _next_seed(self, p_attn):
+        """seed of the next attention-probability dropout mask: a counter on top of torch's seed (torch.manual_seed makes a run repeatable; no
+        device synchronisation)"""
+        if p_attn <= 0:
+            return 0
+        self._drop_calls = getattr(self, '_drop_calls', 0) + 1
+        return (torch.initial_seed() * 2654435761 + self._drop_calls * 40503) & 0xffffffff
+
     @staticmethod
     def self_attention_pattern(T, pad, single, device):
         """CSR of prepare_for_dn's attn_mask: key j visible to query i iff j >= pad, or i < pad and i // single == j // single."""
@@ -277,9 +285,9 @@ class TrainDecoder:
                 sl = slice(h * d, (h + 1) * d)
                 prob = F.dropout(torch.softmax(matmul_nt_ad(q[:n, sl].contiguous(), kd[:, sl].contiguous()), -1), p_attn, p_attn > 0)
                 tops.append(matmul_nt_ad(prob, vd[:, sl].t().contiguous()))
-            ctx = torch.cat([torch.cat(tops, 1), ops.SparseCrossAttention.apply(q[n:], k, v, csr[0], csr[1], False, tr)])
+            ctx = torch.cat([torch.cat(tops, 1), ops.SparseCrossAttention.apply(q[n:], k, v, csr[0], csr[1], False, tr, p_attn, self._next_seed(p_attn))])
         else:
-            ctx = ops.SparseCrossAttention.apply(q, k, v, csr[0], csr[1], False, tr)
+            ctx = ops.SparseCrossAttention.apply(q, k, v, csr[0], csr[1], False, tr, p_attn, self._next_seed(p_attn))
         return linear(ctx, self.p[name + '.attn.out_proj.weight'], self.p[name + '.attn.out_proj.bias'])
 
     def __call__(self, ref, key_in, val_in, row_ptr, col_idx, pad=0, single=1, dt=0.0, dn_keys=None):
@@ -316,13 +324,8 @@ class TrainDecoder:
             lp = f'{pre}layers.{i}.'
             p_sa, drop_sa = self._drops(i, 0)
             p_ca, drop_ca = self._drops(i, 1)
-            if max(p_sa, p_ca) > 0 and not self._warned:
-                import warnings
-                warnings.warn(f'mv2d_amd.train.TrainDecoder: attention-PROBABILITY dropout (p = {max(p_sa, p_ca)}) is not applied inside the sparse '
-                              'attention kernels (it is on the dense denoising block); the output-path and FFN dropouts of the reference ARE '
-                              'applied.  Set dropout=0 in the attention configs to silence this.', RuntimeWarning)
-                self._warned = True
-            x = ln(x + drop_sa(self._attn(x + qpos, x + qpos, x, lp + 'attentions.0', sa, sa_t)), lp + 'norms.0')
+            # (round 3: the attention-probability dropout of both attentions runs inside the sparse kernels, mv2d_sparse_xattn_*_drop)
+            x = ln(x + drop_sa(self._attn(x + qpos, x + qpos, x, lp + 'attentions.0', sa, sa_t, p_attn=p_sa)), lp + 'norms.0')
             x = ln(x + drop_ca(self._attn(x + qpos, key_in, val_in, lp + 'attentions.1', ca, ca_t,
                                           None if dn_keys is None else (pad, dn_keys.long()), p_attn=p_ca)), lp + 'norms.1')
             h = linear(x, P[lp + 'ffns.0.layers.0.0.weight'], P[lp + 'ffns.0.layers.0.0.bias'], 1)
