@@ -879,10 +879,10 @@ class HeadEngine:
                 o.row_ln(ws['o'], residual=ws['x1'], ln=(W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), out=ws['x2'])
             parts = ws['parts']
             if self.ffn_x3:
-                # four hidden slices accumulated per block: 8 slabs to write and re-read instead of 32 (6030 vs 5620 samples/s; one
-                # sample alone: decoder 0.336 vs 0.340 ms).  It fixes the summation order, so it is NOT chosen by the row count:
-                # a sample's result must not depend on the batch it is in.
-                G = self.ffn_groups if self.ffn_groups else 4
+                # eight hidden slices accumulated per block: 4 slabs to write and re-read instead of 32 (round 3: 8371 vs 8289 samples/s for
+                # 8 vs 4 slices, and half the slab traffic: 22 instead of 44 MB per 8-sample launch and layer).  It fixes the summation
+                # order, so it is NOT chosen by the row count: a sample's result must not depend on the batch it is in.
+                G = self.ffn_groups if self.ffn_groups else 8
                 parts = parts[:parts.shape[0] // G]
                 o.ffn_fused_x3(ws['x2'], W_[f'ffn_w1x{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2x{i}'], parts, R, groups=G)
             else:
