@@ -121,6 +121,32 @@ def build_step(engs, strs, sets, pool, Bs, pay, state, *, collective, use_graph,
     return step
 
 
+def golden_for(args):
+    """The reference's own output on the seed-0 frame of the workload (tests/golden/<workload>.npz, oracle/gen_golden.py), or None."""
+    gpath = os.path.join(ROOT, 'tests', 'golden', args.workload + '.npz')
+    if os.path.exists(gpath) and args.corr_topk is None and args.force_nc is None:
+        return np.load(gpath)
+    return None
+
+
+def index_mismatches(e, gold, feat, props, metas):
+    """Integer parity of one engine run against the reference golden: ranked labels / ranked (query, class) indices / top-k set entries that
+    differ, and the largest score difference."""
+    o_ = e.run(feat, props, metas)
+    torch.cuda.synchronize()
+    n = int(o_['count'].item())
+    gl, ref = gold['labels'], gold['topk_index']
+    m = min(n, len(gl))
+    lab = o_['labels'][:n].cpu().numpy()
+    flat = o_['bbox_index'][:n].cpu().numpy() * 10 + lab
+    d = dict(ranked_labels=int((lab[:m] != gl[:m]).sum()) + abs(n - len(gl)), of=int(len(gl)))
+    if len(ref) == len(gl):
+        d['ranked_indices'] = int((flat[:m] != ref[:m]).sum()) + abs(n - len(ref))
+        d['topk_set'] = len(set(flat.tolist()) - set(ref.tolist()))
+    d['max_score_err'] = float(np.abs(o_['scores'][:m].cpu().numpy() - gold['scores'][:m]).max())
+    return d
+
+
 def ws_rows(out):
     """rows the launches of a frame run on (the RoI-count bucket, >= the real R)."""
     return int(out['ws']['x'].shape[0])
@@ -146,6 +172,7 @@ def main():
     ap.add_argument('--cpu-timeout', type=int, default=150)
     ap.add_argument('--brief', action='store_true', help='headline timing + tile-kernel roofline only (what the other_workloads legs of the default run call)')
     ap.add_argument('--no-other-workloads', action='store_true', help='skip the short cfg3_t / cfg5_t legs (sub-processes of this script)')
+    ap.add_argument('--no-parity-leg', action='store_true', help='skip the single-sample run that counts the integer mismatches against the reference golden')
     ap.add_argument('--min-seconds', type=float, default=1.0, help='when the K timed steps take less than this, a second, longer loop of the same step is timed and reported beside them')
     args = ap.parse_args()
     if args.brief:
@@ -337,28 +364,17 @@ def main():
         extra['index_exact_vs_default'] = round(extra['samples_s_index_exact'] / value, 3)
         # (e) integer parity of both routes against the REFERENCE's own output on the seed-0 frame of this workload (tests/golden/<workload>.npz,
         # produced by the unmodified reference, oracle/gen_golden.py): ranked labels / ranked (query, class) indices / top-k set entries that differ
-        gpath = os.path.join(ROOT, 'tests', 'golden', args.workload + '.npz')
-        if os.path.exists(gpath) and args.corr_topk is None and args.force_nc is None:
-            gold = np.load(gpath)
-
-            def mismatches(e):
-                o_ = e.run(feat, props, metas)
-                torch.cuda.synchronize()
-                n = int(o_['count'].item())
-                gl, ref = gold['labels'], gold['topk_index']
-                m = min(n, len(gl))
-                lab = o_['labels'][:n].cpu().numpy()
-                flat = o_['bbox_index'][:n].cpu().numpy() * 10 + lab
-                d = dict(ranked_labels=int((lab[:m] != gl[:m]).sum()) + abs(n - len(gl)), of=int(len(gl)))
-                if len(ref) == len(gl):
-                    d['ranked_indices'] = int((flat[:m] != ref[:m]).sum()) + abs(n - len(ref))
-                    d['topk_set'] = len(set(flat.tolist()) - set(ref.tolist()))
-                d['max_score_err'] = float(np.abs(o_['scores'][:m].cpu().numpy() - gold['scores'][:m]).max())
-                return d
-            extra['index_mismatches'] = dict(default=mismatches(base), index_exact=mismatches(ex_base),
+        gold = golden_for(args)
+        if gold is not None:
+            extra['index_mismatches'] = dict(default=index_mismatches(base, gold, feat, props, metas), index_exact=index_mismatches(ex_base, gold, feat, props, metas),
                                              reference='tests/golden/%s.npz (unmodified reference, seed-0 frame)' % args.workload)
         del ex_engines, ex_base
 
+    if 'index_mismatches' not in extra and world == 1 and not args.no_parity_leg:
+        gold = golden_for(args)
+        if gold is not None:            # (--brief / --no-extra-legs: the default route only)
+            extra['index_mismatches'] = dict(default=index_mismatches(base, gold, feat, props, metas),
+                                             reference='tests/golden/%s.npz (unmodified reference, seed-0 frame)' % args.workload)
     # ---------------- per-stage timing of the same frame with HIP events on the launch stream (single stream, eager)
     eng = base
     run_once = (lambda: eng.run_batch(feats_b, props_b, metas_b)) if B > 1 else (lambda: eng.run(feat, props, metas))
@@ -427,7 +443,7 @@ def main():
     decoder_ms = e0.elapsed_time(e1) / 50
     # the same for ONE sample per call (the reference's call shape, DET/mv2d.py:143)
     decoder_ms_b1 = None
-    if B > 1 and not args.brief:
+    if B > 1 and not args.brief and not args.no_parity_leg:
         o1 = eng.run(feat, props, metas)
         torch.cuda.synchronize()
         ws1, R1 = o1['ws'], ws_rows(o1)
@@ -513,7 +529,8 @@ def main():
                                     '--brief'], cwd=ROOT, capture_output=True, text=True, timeout=240)
                 ls_ = [l for l in r.stdout.splitlines() if l.startswith('{')]
                 d_ = json.loads(ls_[-1])
-                other[wl_] = {k: d_[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'config', 'decoder_ms_per_iter', 'decoder_ms_per_launch', 'roofline')}
+                other[wl_] = {k: d_.get(k) for k in ('value', 'unit', 'ms_per_step', 'steps', 'config', 'decoder_ms_per_iter', 'decoder_ms_per_launch', 'roofline',
+                                                     'index_mismatches')}
             except Exception as ex_:          # noqa: BLE001
                 other[wl_] = dict(value=None, error=repr(ex_)[:300])
 
