@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
                                                              const unsigned short* __restrict__ Xv_lo, const int* __restrict__ row_ptr,
                                                              const int* __restrict__ col_idx, float* __restrict__ z,
                                                              float* __restrict__ dbg_logits, long long dbg_stride, int R, int empty_nan,
-                                                             const int* __restrict__ order) {
+                                                             const int* __restrict__ order, unsigned int row_bytes) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[NW * 8192 + NW * 512 + NW * 64 + (XLO ? NW * 8192 : 0)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
     // XCD-aware block -> query map (block b runs on XCD b % 8): every XCD gets one contiguous range of queries, so neighbouring
@@ -219,12 +219,12 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
             // (byte offsets as 32-bit unsigned: scalar base + vector offset addressing instead of 64-bit address arithmetic per row;
             //  the row arrays must stay below 4 GB = 2^23 rows, include/mv2d_hip.h)
             const unsigned int ridx = (unsigned int)__shfl(myidx, 2 * i + (lane >> 5), 64);
-            kreg[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Xk) + (ridx * (unsigned)(C * 2) + (unsigned)(lane & 31) * 16u));
+            kreg[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Xk) + (ridx * row_bytes + (unsigned)(lane & 31) * 16u));
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const unsigned int vidx = (unsigned int)__shfl(myidx, 4 * g + e, 64);
-            const char* vp = reinterpret_cast<const char*>(Xv) + (vidx * (unsigned)(C * 2) + 16u * (unsigned)n);
+            const char* vp = reinterpret_cast<const char*>(Xv) + (vidx * row_bytes + 16u * (unsigned)n);
             vreg[e][0] = *reinterpret_cast<const uint4*>(vp);
             vreg[e][1] = *reinterpret_cast<const uint4*>(vp + 256);
         }
@@ -239,14 +239,14 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
             for (int i = 0; i < 8; ++i) {
                 const int rowi = 2 * i + (lane >> 5);
                 const int ridx = __shfl(myidx, rowi, 64);
-                kt2[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = *reinterpret_cast<const uint4*>(Xk_lo + (long long)ridx * C + (lane & 31) * 8);
+                kt2[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Xk_lo) + ((unsigned)ridx * row_bytes + (unsigned)(lane & 31) * 16u));
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int vidx = __shfl(myidx, 4 * g + e, 64);
-                const unsigned short* vp = Xv_lo + (long long)vidx * C + 8 * n;
+                const char* vp = reinterpret_cast<const char*>(Xv_lo) + ((unsigned)vidx * row_bytes + 16u * (unsigned)n);
                 vlo[e][0] = *reinterpret_cast<const uint4*>(vp);
-                vlo[e][1] = *reinterpret_cast<const uint4*>(vp + 128);
+                vlo[e][1] = *reinterpret_cast<const uint4*>(vp + 256);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -415,6 +415,9 @@ extern "C" int mv2d_xattn_ctxmap(const float* z, const void* WB_hi, const void* 
 extern "C" int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                            const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
                                            const int* order, void* stream);
+extern "C" int mv2d_xattn_tile_fwd_ex(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
+                                      const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
+                                      const int* order, int row_bytes, void* stream);
 
 extern "C" int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                    const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves, void* stream) {
@@ -424,6 +427,13 @@ extern "C" int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* X
 extern "C" int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                            const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
                                            const int* order, void* stream) {
+    return mv2d_xattn_tile_fwd_ex(Qt, Xk, Xv, Xk_lo, Xv_lo, row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan, waves, order, C * 2, stream);
+}
+
+extern "C" int mv2d_xattn_tile_fwd_ex(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
+                                      const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
+                                      const int* order, int row_bytes, void* stream) {
+    MV2D_CHECK_ARG(row_bytes >= C * 2 && (row_bytes % 16) == 0, "mv2d_xattn_tile_fwd_ex: row_bytes >= 512, a multiple of 16");
     MV2D_CHECK_ARG(Qt && Xk && Xv && row_ptr && col_idx && z && R >= 0, "mv2d_xattn_tile_fwd: bad args");
     MV2D_CHECK_ARG((Xk_lo == nullptr) == (Xv_lo == nullptr), "mv2d_xattn_tile_fwd: Xk_lo and Xv_lo come together");
     MV2D_CHECK_ARG(((uintptr_t)Qt & 15) == 0 && ((uintptr_t)Xk & 15) == 0 && ((uintptr_t)Xv & 15) == 0 && ((uintptr_t)z & 15) == 0 &&
@@ -434,7 +444,7 @@ extern "C" int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const
     const int nw = env_nw ? env_nw : (waves ? waves : 2);      // the engine passes its own choice (2: see engine.py)
 #define MV2D_XT(NW, DBG, XLO) hipLaunchKernelGGL((xattn_tile_kernel<NW, DBG, XLO>), dim3(R), dim3(64 * NW), 0, (hipStream_t)stream, (const uint4*)Qt, \
                                                  (const unsigned short*)Xk, (const unsigned short*)Xv, (const unsigned short*)Xk_lo, (const unsigned short*)Xv_lo, \
-                                                 row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan, order)
+                                                 row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan, order, (unsigned int)row_bytes)
     // index-exact route (hi + lo rows): two waves per SIMD like the default (round 3: the 312-register build ran one wave per SIMD, 133 us per layer)
     if (Xk_lo) { if (dbg_logits) MV2D_XT(4, true, true); else if (nw == 4) MV2D_XT(4, false, true); else MV2D_XT(2, false, true); }
     else if (dbg_logits) { if (nw == 8) MV2D_XT(8, true, false); else if (nw == 2) MV2D_XT(2, true, false); else if (nw == 1) MV2D_XT(1, true, false); else MV2D_XT(4, true, false); }

@@ -218,7 +218,8 @@ class MV2DHead(nn.Module):
                                       pc_range=tuple(self.pc_range), post_range=tuple(coder.post_center_range),
                                       depth_num=self.position_encoding.depth_num, stride=self.strides[self.feat_lvl],
                                       iou_thr=bc.iou_thr, ratio=bc.ratio, num_classes=self.bbox_head.num_classes,
-                                      masked_row=(self.test_cfg or {}).get('masked_row', 'nan'))
+                                      masked_row=(self.test_cfg or {}).get('masked_row', 'nan'),
+                                      exact=(self.test_cfg or {}).get('index_exact', None))      # None: MV2D_EXACT decides
             self._engine_ver = ver
         return self._engine
 
