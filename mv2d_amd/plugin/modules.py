@@ -250,15 +250,27 @@ class FlattenMHSelfAttention(_AttnBase):
         value = key if value is None else value
         identity = query if identity is None else identity
         key_pos = self._default_pos(query, key, query_pos, key_pos, self.__class__.__name__)
-        if attn_mask is not None or key_padding_mask is not None:
-            raise NotImplementedError('self-attention masks are only used by the denoising TRAINING path (RH/mv2d_s_head.py:39-120)')
+        if key_padding_mask is not None:
+            raise NotImplementedError('FlattenMHSelfAttention: key_padding_mask is never passed by the reference (MU/petr_transformer.py:346-360)')
         assert key is query and value is query, 'FlattenMHSelfAttention is called with key = value = query (mmcv BaseTransformerLayer)'
         shp = query.shape
         x = _rows(query)
         xq = x if query_pos is None else _rows(query + query_pos)
         a = self.attn
         qkv = ops.gemm_f32(xq, _f(a.in_proj_weight), _f(a.in_proj_bias), A2=x, n_split=2 * C)
-        ctx = ops.self_attn(qkv)
+        if attn_mask is not None:
+            # a boolean [T, T] mask over the flattened queries (True = blocked; the denoising mask of prepare_for_dn, RH/mv2d_s_head.py:39-120):
+            # only the allowed pairs are visited, through the CSR attention kernel (keys / values rounded to bf16 like the cross attention's)
+            T = x.shape[0]
+            assert attn_mask.dtype == torch.bool and tuple(attn_mask.shape) == (T, T), 'attn_mask: bool [n*b, n*b] over the flattened queries'
+            allowed = ~attn_mask.to(x.device)
+            row_ptr = torch.zeros(T + 1, dtype=torch.int32, device=x.device)
+            row_ptr[1:] = allowed.sum(1).cumsum(0).to(torch.int32)
+            col = allowed.nonzero()[:, 1].to(torch.int32).contiguous()
+            ctx = ops.sparse_xattn((qkv[:, :C] * ops.SCALE_Q).contiguous(), ops.f32_to_bf16(qkv[:, C:2 * C].contiguous()),
+                                   ops.f32_to_bf16(qkv[:, 2 * C:].contiguous()), row_ptr, col, R=T, empty_nan=True)
+        else:
+            ctx = ops.self_attn(qkv)
         o = ops.gemm_f32(ctx, _f(a.out_proj.weight), _f(a.out_proj.bias))
         return ops.row_ln(o, residual=_rows(identity)).view(shp)
 

@@ -358,3 +358,31 @@ def test_simple_test_index_exact_switch_equals_reference_indices(name):
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name + '.npz'))
     assert labels.cpu().numpy().tolist() == g['labels'].tolist()
     assert float(np.abs(scores.cpu().numpy() - g['scores']).max()) < 3e-5 * float(g['scores'].max()) + 1e-6
+
+
+def test_module_level_self_attention_with_attn_mask():
+    """FlattenMHSelfAttention.forward with a boolean attn_mask over the flattened queries (the denoising mask pattern of prepare_for_dn):
+    equals torch.nn.MultiheadAttention with the same mask (reference: MU/petr_transformer.py:317-370)."""
+    import numpy as np
+    from mv2d_amd.plugin.modules import FlattenMHSelfAttention
+    g = torch.Generator().manual_seed(11)
+    m = FlattenMHSelfAttention(256, 8, attn_drop=0.0, proj_drop=0.0).to(DEV).eval()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * 0.06)
+    T, pad, single = 70, 30, 10
+    x = torch.randn(T, 1, 256, generator=g).to(DEV)
+    pos = torch.randn(T, 1, 256, generator=g).to(DEV)
+    i = torch.arange(T)
+    vis = (i[None, :] >= pad) | ((i[:, None] < pad) & ((i // single)[:, None] == (i // single)[None, :]))
+    mask = ~vis
+    out = m(x, query_pos=pos, attn_mask=mask.to(DEV))
+    ref_attn = torch.nn.MultiheadAttention(256, 8).double()
+    ref_attn.load_state_dict({k: v.double().cpu() for k, v in m.attn.state_dict().items()})
+    xd, pd = x.double().cpu(), pos.double().cpu()
+    ref = xd + ref_attn(xd + pd, xd + pd, xd, attn_mask=mask)[0]
+    err = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
+    print('masked module-level self attention: rel err', err)
+    assert err < 3e-3
+    with pytest.raises(NotImplementedError):
+        m(x, query_pos=pos, key_padding_mask=torch.zeros(1, T, dtype=torch.bool, device=DEV))
