@@ -457,7 +457,7 @@ class HeadEngine:
         ws = self._workspace(V, h, w, cap, Vg)
         sh = ws['shared']
         if 'done_ev' in sh:
-            sh['done_ev'].synchronize()      # the previous frame on this workspace must have consumed the staging buffers
+            sh['done_ev'].synchronize()      # the previous frame on this workspace must have consumed the pinned staging buffers (its uploads have run)
         rois_np = ws['rois_h'].numpy()
         rois_np[:R, 0] = np.repeat(np.arange(V, dtype=np.float32), counts)
         rois_np[:R, 1:] = np.concatenate([a[:, :4] for a in arrs if a.shape[0]], 0)
@@ -572,8 +572,7 @@ class HeadEngine:
         grp = ws['grp_start']                             # first query row of every sample (device): sample-local self attention / top-k; the rows behind the last sample are bucket padding
         tk = self._tick
         tk('h2d')
-        ws['dyn_d'].copy_(ws['dyn_h'], non_blocking=True)
-        rois = ws['rois']
+        rois = ws['rois']                                 # (the RoI list / row tables were uploaded by _run, outside any captured graph)
         tk('transpose')
         # position-major feature map
         if isinstance(feat, (list, tuple)):
@@ -962,6 +961,12 @@ class HeadEngine:
             ptrs = tuple(f.data_ptr() for f in feat)
         assert V % B == 0
         ws, R, sc = self._host_prepare(proposals_list, metas_list, V, h, w)
+        # upload of the per-frame tables (RoI list, view / sample offsets, time steps): stream-ordered before the frame, OUTSIDE the captured graph,
+        # and the "staging consumed" event right behind it -- the host may fill the pinned staging buffers for the NEXT frame on this workspace as
+        # soon as this copy has run, i.e. while this frame's kernels are still executing (round 3: the event used to sit at the end of the frame,
+        # which kept every stream one whole frame behind its host: one sample per launch x 4 streams 4100 -> see DESIGN.md section 8)
+        ws['dyn_d'].copy_(ws['dyn_h'], non_blocking=True)
+        self._mark_done(ws)
         self._stage_outputs = bool(keep_stages)          # intermediate buffers nothing downstream reads (pe on the T path, Xk on the S path)
         Rc = sc['cap']                     # launches run on the bucket size; R = the real rows
         if self.debug_attn:
@@ -972,7 +977,6 @@ class HeadEngine:
             ws.pop('dbg_logits', None); ws.pop('dbg_q', None)
         if not use_graph:
             self._enqueue(ws, feat, Rc, V, h, w, sc)
-            self._mark_done(ws)
             return dict(self._result(ws, R, keep_stages, batch), dt=sc['dt'])
         # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
@@ -1001,7 +1005,6 @@ class HeadEngine:
         else:
             g = g[0]
         g.replay()
-        self._mark_done(ws)
         return dict(self._result(ws, R, keep_stages, batch), dt=sc['dt'])
 
     def train_forward(self, out, dn_ref=None, dn_single=0):

@@ -27,4 +27,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(20):
     out = eng.run_batch(feats, props, metas, use_graph=True)
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(18)
+pstats.Stats(pr).sort_stats('tottime').print_stats(int(os.environ.get('ROWS', '18')))
