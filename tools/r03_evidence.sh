@@ -6,7 +6,7 @@ mkdir -p $O
 timeout 600 python bench.py --steps 100 > $O/default_bench_cfg2s.json 2> $O/bench.err
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/driver_shape_bench_cfg2s.json 2>> $O/bench.err
 # 2. rocprofv3 kernel summary of the same default command (extra legs off) + PMC FETCH / WRITE passes of the eager single-stream bench
-HEAD=5 tools/prof_stats.sh r03/stats_default > /dev/null 2>&1
+HEAD=5 tools/prof_stats.sh r03/stats_default --no-extra-legs --no-parity-leg > /dev/null 2>&1
 mv $O/stats_default/kernel_stats.txt $O/default_bench_cfg2s_kernel_stats.txt; mv $O/stats_default/bench_under_rocprof.json $O/default_bench_cfg2s_under_rocprof.json; rmdir $O/stats_default
 bash tools/pmc_bench.sh r03/pmc_cfg2s > /dev/null 2>&1
 # 3. T path: bench lines, per-kernel stats with the ordered per-query kernel, the kernel microbenchmark (query tiles vs per-query, ordered or not)
