@@ -961,12 +961,14 @@ class HeadEngine:
             ptrs = tuple(f.data_ptr() for f in feat)
         assert V % B == 0
         ws, R, sc = self._host_prepare(proposals_list, metas_list, V, h, w)
-        # upload of the per-frame tables (RoI list, view / sample offsets, time steps): stream-ordered before the frame, OUTSIDE the captured graph,
-        # and the "staging consumed" event right behind it -- the host may fill the pinned staging buffers for the NEXT frame on this workspace as
-        # soon as this copy has run, i.e. while this frame's kernels are still executing (round 3: the event used to sit at the end of the frame,
-        # which kept every stream one whole frame behind its host: one sample per launch x 4 streams 4100 -> see DESIGN.md section 8)
+        # upload of the per-frame tables (RoI list, view / sample offsets, time steps): stream-ordered before the frame, outside the captured graph.
+        # The "staging consumed" event stays at the END of the frame by default: recording it right behind this copy (MV2D_EARLY_STAGING_EVENT=1) lets the
+        # host run a frame ahead on every stream and measured +1 % in long runs (8474 -> 8499 samples/s) but 7400-7900 instead of 8300 in short ones --
+        # without the host's wait the four streams drift into phase and their wide kernels collide
         ws['dyn_d'].copy_(ws['dyn_h'], non_blocking=True)
-        self._mark_done(ws)
+        late = os.environ.get('MV2D_EARLY_STAGING_EVENT', '0') != '1'
+        if not late:
+            self._mark_done(ws)
         self._stage_outputs = bool(keep_stages)          # intermediate buffers nothing downstream reads (pe on the T path, Xk on the S path)
         Rc = sc['cap']                     # launches run on the bucket size; R = the real rows
         if self.debug_attn:
@@ -977,6 +979,8 @@ class HeadEngine:
             ws.pop('dbg_logits', None); ws.pop('dbg_q', None)
         if not use_graph:
             self._enqueue(ws, feat, Rc, V, h, w, sc)
+            if late:
+                self._mark_done(ws)
             return dict(self._result(ws, R, keep_stages, batch), dt=sc['dt'])
         # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
@@ -1005,6 +1009,8 @@ class HeadEngine:
         else:
             g = g[0]
         g.replay()
+        if late:
+            self._mark_done(ws)
         return dict(self._result(ws, R, keep_stages, batch), dt=sc['dt'])
 
     def train_forward(self, out, dn_ref=None, dn_single=0):
