@@ -170,6 +170,7 @@ def main():
     ap.add_argument('--cpu-iters', type=int, default=24)       # ~10 s of CPU work on the bounded sample
     ap.add_argument('--cpu-threads', type=int, default=16)      # second CPU leg; the first uses os.cpu_count() threads (BASELINE.md protocol)
     ap.add_argument('--cpu-timeout', type=int, default=150)
+    ap.add_argument('--exact', action='store_true', help='run the timed loop on the index-exact route (HeadEngine(exact=True)) instead of the default route')
     ap.add_argument('--brief', action='store_true', help='headline timing + tile-kernel roofline only (what the other_workloads legs of the default run call)')
     ap.add_argument('--no-other-workloads', action='store_true', help='skip the short cfg3_t / cfg5_t legs (sub-processes of this script)')
     ap.add_argument('--no-parity-leg', action='store_true', help='skip the single-sample run that counts the integer mismatches against the reference golden')
@@ -194,7 +195,7 @@ def main():
     prob = synthetic.make_problem(args.workload, seed=rank)        # weak scaling: every rank its own frames
     kind = prob['kind']
     sd = synthetic.make_head_state(seed=0)
-    base = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'], topk=args.corr_topk)
+    base = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'], topk=args.corr_topk, exact=True if args.exact else None)
     base.force_nc = args.force_nc
     base.fork_qg = args.inflight == 1
     engines = [base] + [base.clone_shared() for _ in range(args.inflight - 1)]
@@ -531,6 +532,14 @@ def main():
                 d_ = json.loads(ls_[-1])
                 other[wl_] = {k: d_.get(k) for k in ('value', 'unit', 'ms_per_step', 'steps', 'config', 'decoder_ms_per_iter', 'decoder_ms_per_launch', 'roofline',
                                                      'index_mismatches')}
+                # ... and the same loop on the index-exact route
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), '--workload', wl_, '--batch', str(b_), '--steps', '60', '--warmup', '10',
+                                    '--brief', '--exact'], cwd=ROOT, capture_output=True, text=True, timeout=240)
+                ls_ = [l for l in r.stdout.splitlines() if l.startswith('{')]
+                d2_ = json.loads(ls_[-1])
+                other[wl_]['samples_s_index_exact'] = d2_.get('value')
+                other[wl_]['index_exact_vs_default'] = round(d2_['value'] / d_['value'], 3) if d_.get('value') else None
+                other[wl_]['index_mismatches_index_exact'] = (d2_.get('index_mismatches') or {}).get('default')
             except Exception as ex_:          # noqa: BLE001
                 other[wl_] = dict(value=None, error=repr(ex_)[:300])
 
@@ -539,7 +548,8 @@ def main():
             'metric': 'multi-view samples/sec (6-cam frames) through the MV2D RoI-head hot path',
             'value': round(value, 2), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16 (key side MFMA) / f32 + bf16x3 split precision (query side)', 'data': 'synthetic',
+            'dtype': ('bf16 hi + lo split precision on the key side (index-exact route) / bf16x3 (query side)' if args.exact else
+                      'bf16 (key side MFMA) / f32 + bf16x3 split precision (query side)'), 'data': 'synthetic', 'route': 'index_exact' if args.exact else 'default',
             'config': {'workload': f'{args.workload}: MV2D-{kind} head, {len(metas)} views {metas[0]["img_shape"][1]}x{metas[0]["img_shape"][0]}, '
                                    f'R={R} queries, S={S} key positions, nnz={nnz} allowed (q,k) pairs' + (f' (totals of the {B} samples of a launch)' if B > 1 else '') + (f', corr_topk={args.corr_topk}' if args.corr_topk else '') + (f', forced n_c={args.force_nc}' if args.force_nc else ''),
                        'frames_per_step_per_gpu': args.inflight * B, 'global_batch': world * args.inflight * B,

@@ -252,8 +252,10 @@ class TrainDecoder:
         device synchronisation)"""
         if p_attn <= 0:
             return 0
+        import torch.distributed as dist
         self._drop_calls = getattr(self, '_drop_calls', 0) + 1
-        return (torch.initial_seed() * 2654435761 + self._drop_calls * 40503) & 0xffffffff
+        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0      # data-parallel ranks draw different masks
+        return (torch.initial_seed() * 2654435761 + self._drop_calls * 40503 + rank * 7919) & 0xffffffff
 
     @staticmethod
     def self_attention_pattern(T, pad, single, device):
