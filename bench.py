@@ -160,7 +160,7 @@ def main():
     ap.add_argument('--prime', type=int, default=200, help='untimed setup steps in front of the warm-up (graph captures, clock ramp)')
     ap.add_argument('--workload', default='cfg2_s', help='cfg2_s (MV2D-S 6 cams 1408x512, headline) | cfg3_t | cfg5_t | cfg1_s ...')
     ap.add_argument('--inflight', type=int, default=4, help='HIP streams per GPU, each running its own launch sequence per step')
-    ap.add_argument('--batch', type=int, default=8, help='samples sharing every launch of a stream (HeadEngine.run_batch)')
+    ap.add_argument('--batch', type=int, default=16, help='samples sharing every launch of a stream (HeadEngine.run_batch); 16 since round 3 (8: -5 %%)')
     ap.add_argument('--rotate', type=int, default=4, help='distinct frame sets every stream cycles through (1: the same frames every step)')
     ap.add_argument('--no-extra-legs', action='store_true', help='skip the fixed-input / batch-1 / latency legs')
     ap.add_argument('--no-graph', action='store_true')
@@ -529,7 +529,7 @@ def main():
         # short legs of the T-path workloads in the same JSON line (sub-processes of this script, after this process' GPU work is done)
         import subprocess
         other = {}
-        for wl_, b_ in (('cfg3_t', 8), ('cfg5_t', 2)):
+        for wl_, b_ in (('cfg3_t', 16), ('cfg5_t', 4)):
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), '--workload', wl_, '--batch', str(b_), '--steps', '100', '--warmup', '10',
                                     '--brief'], cwd=ROOT, capture_output=True, text=True, timeout=240)

@@ -11,7 +11,7 @@ mv $O/stats_default/kernel_stats.txt $O/default_bench_cfg2s_kernel_stats.txt; mv
 bash tools/pmc_bench.sh r03/pmc_cfg2s > /dev/null 2>&1
 # 3. T path: bench lines, per-kernel stats with the ordered per-query kernel, the kernel microbenchmark (query tiles vs per-query, ordered or not)
 timeout 300 python bench.py --steps 100 --workload cfg3_t --no-cpu-baseline --no-extra-legs > $O/bench_cfg3t.json 2>> $O/bench.err
-timeout 300 python bench.py --steps 100 --workload cfg5_t --batch 2 --no-cpu-baseline --no-extra-legs > $O/bench_cfg5t.json 2>> $O/bench.err
+timeout 300 python bench.py --steps 100 --workload cfg5_t --batch 4 --no-cpu-baseline --no-extra-legs > $O/bench_cfg5t.json 2>> $O/bench.err
 HEAD=40 tools/prof_cmd.sh r03/prof_cfg3t python tools/run_engine.py --workload cfg3_t --steps 20 > /dev/null 2>&1
 HEAD=40 tools/prof_cmd.sh r03/prof_cfg5t python tools/run_engine.py --workload cfg5_t --batch 2 --steps 20 > /dev/null 2>&1
 timeout 200 python tools/microbench_qtile.py --workload cfg3_t --batch 8 2>/dev/null > $O/microbench_xattn_cfg3t.txt
