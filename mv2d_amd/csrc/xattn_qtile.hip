@@ -51,41 +51,50 @@ __device__ __forceinline__ unsigned int qt_hi_pair(unsigned int a, unsigned int 
 // groups: sample b = rows [grp_start[b], grp_start[b+1]), b < n_grp; the bucket-padding rows [grp_start[n_grp], R) form one more group.
 // perm[slot] = query of sorted slot `slot` (slots of a group = its row range); tiles of QT consecutive slots inside a group.
 // ------------------------------------------------------------------------------------------------
+constexpr int ORD_CHUNK = 128;               // queries ranked per block of qt_order_kernel (8 threads per query)
 __global__ __launch_bounds__(1024) void qt_order_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const int* __restrict__ grp_start,
                                                         int n_grp, int R, int* __restrict__ perm, int* __restrict__ tile_q0, int* __restrict__ tile_qn,
                                                         int* __restrict__ n_tiles, int* __restrict__ flags, int QT) {
+    // grid (groups, chunks of ORD_CHUNK queries): every block holds the group's keys in LDS and ranks its chunk, 8 threads per query
+    // (round 3: one block per group took 39 us for the ~950-query samples of cfg5_t)
     __shared__ int key[GRP_MAX];
-    const int g = blockIdx.x, tid = threadIdx.x;
+    const int g = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
     const int lo = g < n_grp ? grp_start[g] : grp_start[n_grp];
     const int hi = g < n_grp ? grp_start[g + 1] : R;
     const int n = hi - lo;
-    // tiles of the groups before this one
-    int tb = 0;
-    for (int k = 0; k < g; ++k) {
-        const int nk = (k < n_grp ? grp_start[k + 1] : R) - (k < n_grp ? grp_start[k] : grp_start[n_grp]);
-        tb += (nk + QT - 1) / QT;
-    }
-    const int nt = (n + QT - 1) / QT;
-    if (tile_q0) {                                             // (null: only the order is wanted, mv2d_xattn_query_order)
+    if (chunk == 0 && tile_q0) {                               // (null: only the order is wanted, mv2d_xattn_query_order)
+        int tb = 0;                                            // tiles of the groups before this one
+        for (int k = 0; k < g; ++k) {
+            const int nk = (k < n_grp ? grp_start[k + 1] : R) - (k < n_grp ? grp_start[k] : grp_start[n_grp]);
+            tb += (nk + QT - 1) / QT;
+        }
+        const int nt = (n + QT - 1) / QT;
         for (int i = tid; i < nt; i += 1024) { tile_q0[tb + i] = lo + i * QT; tile_qn[tb + i] = min(QT, n - i * QT); }
         if (g == n_grp && tid == 0) *n_tiles = tb + nt;
     }
     if (n > GRP_MAX) {                                         // too many queries in one sample for the LDS ranking: keep the natural order
-        if (tid == 0) flags[0] = 1;
-        for (int i = tid; i < n; i += 1024) perm[lo + i] = lo + i;
+        if (chunk == 0) {
+            if (tid == 0) flags[0] = 1;
+            for (int i = tid; i < n; i += 1024) perm[lo + i] = lo + i;
+        }
         return;
     }
+    if (chunk * ORD_CHUNK >= n) return;
     for (int i = tid; i < n; i += 1024) {
         const int b = row_ptr[lo + i], e = row_ptr[lo + i + 1];
         key[i] = e > b ? col_idx[b] : 0x7fffffff;              // the CSR rows are ascending: the first entry is the smallest key
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
+    const int i = chunk * ORD_CHUNK + (tid >> 3), sub = tid & 7;
+    int rank = 0;
+    if (i < n) {
         const int ki = key[i];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) { const int kj = key[j]; rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
-        perm[lo + rank] = lo + i;
+        for (int j = sub; j < n; j += 8) { const int kj = key[j]; rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
     }
+    rank += __shfl_xor(rank, 1);
+    rank += __shfl_xor(rank, 2);
+    rank += __shfl_xor(rank, 4);
+    if (i < n && sub == 0) perm[lo + rank] = lo + i;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -374,6 +383,7 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_qtile_kernel(const uint4* __
 
 }  // namespace
 
+static inline int qt_order_chunks(int R) { const int n = R < GRP_MAX ? R : GRP_MAX; return (n + ORD_CHUNK - 1) / ORD_CHUNK; }
 static inline int qt_size(int queries_per_tile) { return queries_per_tile == 16 ? 16 : 8; }
 extern "C" long long mv2d_xattn_qtile_max_tiles(int R, int n_samples, int queries_per_tile) {
     const int QT = qt_size(queries_per_tile);
@@ -384,7 +394,7 @@ extern "C" long long mv2d_xattn_qtile_max_tiles(int R, int n_samples, int querie
 // their places as a group of their own).  xattn_tile_kernel launched in this order reads overlapping key sets from neighbouring blocks.
 extern "C" int mv2d_xattn_query_order(const int* row_ptr, const int* col_idx, const int* grp_start, int n_samples, int R, int* perm, int* flags, void* stream) {
     MV2D_CHECK_ARG(row_ptr && col_idx && grp_start && perm && flags && R > 0 && n_samples >= 1, "mv2d_xattn_query_order: bad args");
-    hipLaunchKernelGGL(qt_order_kernel, dim3(n_samples + 1), dim3(1024), 0, (hipStream_t)stream, row_ptr, col_idx, grp_start, n_samples, R, perm, (int*)nullptr,
+    hipLaunchKernelGGL(qt_order_kernel, dim3(n_samples + 1, qt_order_chunks(R)), dim3(1024), 0, (hipStream_t)stream, row_ptr, col_idx, grp_start, n_samples, R, perm, (int*)nullptr,
                        (int*)nullptr, (int*)nullptr, flags, 8);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
@@ -402,7 +412,7 @@ extern "C" int mv2d_xattn_qtile_build(const int* row_ptr, const int* col_idx, co
     hipStream_t st = (hipStream_t)stream;
     MV2D_CHECK_ARG(queries_per_tile == 8 || queries_per_tile == 16, "mv2d_xattn_qtile_build: 8 or 16 queries per tile");
     const int QT = qt_size(queries_per_tile);
-    hipLaunchKernelGGL(qt_order_kernel, dim3(n_samples + 1), dim3(1024), 0, st, row_ptr, col_idx, grp_start, n_samples, R, perm, tile_q0, tile_qn, n_tiles, flags, QT);
+    hipLaunchKernelGGL(qt_order_kernel, dim3(n_samples + 1, qt_order_chunks(R)), dim3(1024), 0, st, row_ptr, col_idx, grp_start, n_samples, R, perm, tile_q0, tile_qn, n_tiles, flags, QT);
     const int ntmax = (int)mv2d_xattn_qtile_max_tiles(R, n_samples, QT);
     if (QT == 16)
         hipLaunchKernelGGL(qt_build_kernel<16>, dim3(ntmax), dim3(256), nwords * 8, st, (const unsigned int*)bits, nwords, rect, V, cells_per_sample, pos2s, perm,

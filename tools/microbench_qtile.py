@@ -37,7 +37,7 @@ def timed(fn, n=20):
 
 for qpt in (8, 16):
     eng = HeadEngine(sd, 'T', dev, num_views=probs[0]['views_per_frame'])
-    eng.qtile_queries = qpt
+    eng.qtile, eng.qtile_queries = True, qpt          # (opt-in since the per-query kernel in smallest-key order shipped)
     out = eng.run_batch(feats, props, metas) if a.batch > 1 else eng.run(feats, props[0], metas[0])
     torch.cuda.synchronize()
     ws, qt = out['ws'], out['ws']['qt']

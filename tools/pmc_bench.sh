@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/$OUT/$c -o p -- python $R/bench.py --steps 3 --warmup 1 --inflight 1 --rotate 1 --no-extra-legs --no-graph --no-cpu-baseline --no-other-workloads --no-parity-leg --min-seconds 0 > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/$OUT/$c -o p -- python $R/bench.py --steps 3 --warmup 1 --inflight 1 --rotate 1 --no-extra-legs --no-graph --no-cpu-baseline --no-other-workloads --no-parity-leg --min-seconds 0 --prime 0 > /dev/null 2>&1
   python $R/tools/rocpd_pmc.py $(find $R/gpurun_out/$OUT/$c -name "p_results.db" | head -1) --by-grid > $R/gpurun_out/$OUT/${c}.txt 2>&1
   rm -rf $R/gpurun_out/$OUT/$c
 done
