@@ -436,7 +436,7 @@ def main():
     with torch.cuda.stream(side):
         eng._enqueue_decoder(ws, R)
     torch.cuda.synchronize()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode='thread_local'):
         eng._enqueue_decoder(ws, R)
     for _ in range(5):
         g.replay()
@@ -457,7 +457,7 @@ def main():
         with torch.cuda.stream(side):
             eng._enqueue_decoder(ws1, R1)
         torch.cuda.synchronize()
-        with torch.cuda.graph(g1):
+        with torch.cuda.graph(g1, capture_error_mode='thread_local'):
             eng._enqueue_decoder(ws1, R1)
         for _ in range(5):
             g1.replay()

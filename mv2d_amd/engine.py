@@ -1000,7 +1000,8 @@ class HeadEngine:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread-local capture mode: another thread of the process (RCCL's proxy, a data loader) may call into HIP while this one captures
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 self._enqueue(ws, feat, Rc, V, h, w, sc)
             self.prof = prof
             if len(graphs) >= 8:
