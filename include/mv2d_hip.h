@@ -515,6 +515,19 @@ int mv2d_colsum(const float* x, long long ld, int rows, int cols, float* out, fl
 int mv2d_layer_norm_bwd_blocks(int M);
 int mv2d_layer_norm_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw_part, float* db_part, float* dw, float* db, int M,
                         float eps, void* stream);
+/* Composite entries: the whole launch sequence of one split-precision product / of one linear layer's backward per call, on a caller-provided
+ * workspace (256-byte aligned, >= the _ws_bytes of the shape), so that a training step is not bound by per-launch host time.
+ * mv2d_matmul_nt_x3: C [M, ldc] fp32 = act(op(A) op(B)^T + bias), A [M,K] (trans_a: [K,M]), B [N,K] (trans_b: [K,N]) fp32 with row strides
+ * lda / ldb, bias [N] or NULL, act 0 / 1 (ReLU); ldc >= N rounded up to 8 (the pad columns are written).  Operand split, GEMM, split-K slabs
+ * and their fixed-order sum as in the single entries above (nn.Linear / mmcv FFN forward and backward, MU/petr_transformer.py:195-311).
+ * mv2d_linear_bwd_x3: backward of y = act(x W^T + b): g = dy masked by y > 0 (y NULL: no activation); dx [M, pad8(K)] = g W, dW [N, pad8(K)] =
+ * g^T x, db [N] = column sums of g; each output optional (NULL). */
+long long mv2d_matmul_nt_x3_ws_bytes(int M, int N, int K);
+int mv2d_matmul_nt_x3(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act, float* C,
+                      int ldc, int M, int N, int K, void* ws, long long ws_bytes, void* stream);
+long long mv2d_linear_bwd_x3_ws_bytes(int M, int N, int K);
+int mv2d_linear_bwd_x3(const float* x, const float* W, const float* y, const float* dy, float* dx, float* dW, float* db, int M, int N, int K, void* ws,
+                       long long ws_bytes, void* stream);
 
 /* Backward of mv2d_roi_align w.r.t. one map (training; mmcv's roi_align backward): grad_out [R][49][256] fp32 ->
  * grad_map [rows][256] fp32, ACCUMULATED with hardware fp32 atomics (the caller zeroes it; the summation order varies between runs).

@@ -20,7 +20,13 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+_RAW_STREAM, _GET_DEV = getattr(torch._C, '_cuda_getCurrentRawStream', None), getattr(torch._C, '_cuda_getDevice', None)
+
+
 def _stream():
+    # (torch.cuda.current_stream() costs ~5 us of Python per call -- three calls per launch added up to milliseconds per training step)
+    if _RAW_STREAM is not None and _GET_DEV is not None:
+        return _RAW_STREAM(_GET_DEV())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -39,33 +45,36 @@ def split3_operand(src, transpose, rows_out, k_pad, side):
     return out
 
 
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    """One scratch buffer per (device, stream): the composite entries below use it strictly in stream order, so consecutive products reuse it."""
+    key = (device.index, _stream())
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _WS[key] = torch.empty(int(nbytes * 1.25) + 4096, device=device, dtype=torch.uint8)
+    return buf
+
+
 def matmul_nt(A, B, bias=None, act=0, trans_a=False, trans_b=False):
-    """C = act(op(A) op(B)^T + bias) in fp32-class split precision on the bf16 tile GEMM; op(X) = X^T when trans_x.  A, B fp32 2-D; bias [N]."""
+    """C = act(op(A) op(B)^T + bias) in fp32-class split precision on the bf16 tile GEMM; op(X) = X^T when trans_x.  A, B fp32 2-D; bias [N].
+    One C call (``mv2d_matmul_nt_x3``): operand splits, GEMM (split-K for few output tiles with a long contraction) and the slab sum."""
     A = A if A.stride(-1) == 1 else A.contiguous()
     B = B if B.stride(-1) == 1 else B.contiguous()
     M, K = (A.shape[1], A.shape[0]) if trans_a else A.shape
     N, Kb = (B.shape[1], B.shape[0]) if trans_b else B.shape
     assert K == Kb, (A.shape, B.shape, trans_a, trans_b)
+    assert A.dtype == F32 and B.dtype == F32 and A.is_cuda and B.is_cuda
     if M == 0 or N == 0 or K == 0:
         return torch.zeros((M, N), device=A.device, dtype=F32)
-    kp, Np = _pad(K, 64), _pad(N, 8)
-    a3 = split3_operand(A, trans_a, M, kp, 0)
-    b3 = split3_operand(B, trans_b, Np, kp, 1)
-    if bias is not None and Np != N:
-        bias = torch.cat([bias, bias.new_zeros(Np - N)])
-    # few output tiles with a long contraction (the weight gradients: K = the rows of the layer's input): split K over the grid's y dimension
-    # into fp32 slabs and sum them in fixed order
-    tiles = -(-M // 64) * -(-Np // 64)
-    splits = 1
-    if act == 0 and tiles < 256 and kp >= 1024:
-        splits = int(min(max(512 // tiles, 1), 3 * kp // 256, 64))
-    if splits > 1:
-        slabs = torch.empty((splits, M, Np), device=A.device, dtype=F32)
-        ops.gemm_bf16(a3, b3, bias, out=slabs[0], M=M, k_splits=splits, split_stride=M * Np)
-        out = colsum(slabs.view(splits, M * Np)).view(M, Np)
-    else:
-        out = torch.empty((M, Np), device=A.device, dtype=F32)
-        ops.gemm_bf16(a3, b3, bias, act=act, out=out, M=M)
+    lib = _lib.load()
+    Np = _pad(N, 8)
+    out = torch.empty((M, Np), device=A.device, dtype=F32)
+    nb = int(lib.mv2d_matmul_nt_x3_ws_bytes(M, N, K))
+    ws = _workspace(nb, A.device)
+    check(lib.mv2d_matmul_nt_x3(_p(A), A.stride(0), 1 if trans_a else 0, _p(B), B.stride(0), 1 if trans_b else 0, _p(bias), act, _p(out), Np, M, N, K,
+                                _p(ws), ws.numel(), _stream()), 'mv2d_matmul_nt_x3')
     return out if Np == N else out[:, :N]
 
 
@@ -85,8 +94,11 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, b, act):
-        x2 = x.reshape(-1, x.shape[-1]).float()
+        x2 = x.reshape(-1, x.shape[-1])
+        x2 = x2 if (x2.dtype == F32 and x2.is_contiguous()) else x2.float().contiguous()
         y = matmul_nt(x2, W.float(), None if b is None else b.float(), act)
+        if act == 1 and not y.is_contiguous():
+            y = y.contiguous()
         ctx.save_for_backward(x2, W, y if act == 1 else None)
         ctx.meta = (x.shape, b is not None, act)
         return y.reshape(*x.shape[:-1], W.shape[0])
@@ -95,17 +107,28 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, W, y = ctx.saved_tensors
         shape, has_b, act = ctx.meta
-        g = dy.reshape(-1, dy.shape[-1]).float()
-        if act == 1:
-            g = g * (y > 0)
-        g = g.contiguous()
-        if g.shape[0] == 0:
-            return (torch.zeros(shape, device=g.device) if ctx.needs_input_grad[0] else None, torch.zeros_like(W) if ctx.needs_input_grad[1] else None,
-                    torch.zeros(W.shape[0], device=g.device) if (has_b and ctx.needs_input_grad[2]) else None, None)
-        dx = matmul_nt(g, W.float(), trans_b=True).reshape(shape) if ctx.needs_input_grad[0] else None
-        dW = matmul_nt(g, x2, trans_a=True, trans_b=True).to(W.dtype) if ctx.needs_input_grad[1] else None
-        db = colsum(g) if (has_b and ctx.needs_input_grad[2]) else None
-        return dx, dW, db, None
+        g = dy.reshape(-1, dy.shape[-1])
+        g = g if (g.dtype == F32 and g.is_contiguous()) else g.float().contiguous()
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2]
+        M, N, K = g.shape[0], W.shape[0], W.shape[1]
+        dev = g.device
+        if M == 0:
+            return (torch.zeros(shape, device=dev) if need_x else None, torch.zeros_like(W) if need_w else None,
+                    torch.zeros(N, device=dev) if need_b else None, None)
+        # one C call: ReLU mask of the gradient, dx = g W, dW = g^T x, db = column sums of g (mv2d_linear_bwd_x3)
+        lib = _lib.load()
+        Wf = W if (W.dtype == F32 and W.is_contiguous()) else W.float().contiguous()
+        Kp = _pad(K, 8)
+        dx = torch.empty((M, Kp), device=dev, dtype=F32) if need_x else None
+        dW = torch.empty((N, Kp), device=dev, dtype=F32) if need_w else None
+        db = torch.empty(N, device=dev, dtype=F32) if need_b else None
+        ws = _workspace(int(lib.mv2d_linear_bwd_x3_ws_bytes(M, N, K)), dev)
+        check(lib.mv2d_linear_bwd_x3(_p(x2), _p(Wf), _p(y) if act == 1 else 0, _p(g), _p(dx), _p(dW), _p(db), M, N, K, _p(ws), ws.numel(), _stream()),
+              'mv2d_linear_bwd_x3')
+        if Kp != K:
+            dx = dx[:, :K] if need_x else None
+            dW = dW[:, :K] if need_w else None
+        return (dx.reshape(shape) if need_x else None), (dW.to(W.dtype) if need_w else None), db, None
 
 
 def linear(x, W, b=None, act=0):

@@ -108,6 +108,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     db_part[(long long)blockIdx.x * 256 + c] = (sb[0][c] + sb[1][c]) + (sb[2][c] + sb[3][c]);
 }
 
+// g = dy where y > 0 else 0 (the ReLU of a linear layer's forward, applied to the incoming gradient)
+__global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ g, long long n) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 d = *reinterpret_cast<const float4*>(dy + i), v = *reinterpret_cast<const float4*>(y + i);
+        *reinterpret_cast<float4*>(g + i) = make_float4(v.x > 0.f ? d.x : 0.f, v.y > 0.f ? d.y : 0.f, v.z > 0.f ? d.z : 0.f, v.w > 0.f ? d.w : 0.f);
+    } else
+        for (long long j = i; j < n; ++j) g[j] = y[j] > 0.f ? dy[j] : 0.f;
+}
+
 }  // namespace
 
 extern "C" int mv2d_split3_operand(const float* src, long long ld, int rows, int k, int transpose, void* dst, int rows_out, int k_pad, int side,
@@ -148,5 +158,105 @@ extern "C" int mv2d_layer_norm_bwd(const float* x, const float* dy, const float*
     hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, (const float*)dw_part, 256LL, nb, 256, dw, 0LL, 1 << 30);
     hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, (const float*)db_part, 256LL, nb, 256, db, 0LL, 1 << 30);
     MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Composite entries (round 3): one call = the whole launch sequence of a split-precision product / of a linear layer's backward, on a
+// caller-provided workspace.  The training step was launch-bound from Python (~1500 launches of ~20 us host time each); the sequences
+// below are issued from C at a few microseconds per launch.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+extern "C" int mv2d_gemm_bf16_ex(const void* A, const void* A2, int n_split, int a_mode, const void* W, const float* bias, int M, int N, int K, int lda,
+                                 const int* m_dev, int act, const float* mul, int ldmul, const float* add, int ldadd, void* C, int c_bf16, int ldc,
+                                 long long c_blk_stride, int c_blk_cols, void* C2, const float* add2, int ldc2, int ldadd2, int c_split3,
+                                 const int* add_idx, int add_period, int k_splits, long long c_split_stride, void* stream);
+
+static inline long long al256(long long b) { return (b + 255) & ~255LL; }
+static inline int pad_to(int n, int m) { return (n + m - 1) / m * m; }
+static int mm_splits(int M, int Np, int kp, int act) {
+    // few output tiles with a long contraction (weight gradients: K = the rows of the layer input): split K over the grid's y dimension
+    const long long tiles = (long long)cdiv(M, 64) * cdiv(Np, 64);
+    if (act != 0 || tiles >= 256 || kp < 1024) return 1;
+    long long s = 512 / tiles;
+    if (s < 1) s = 1;
+    if (s > 3LL * kp / 256) s = 3LL * kp / 256;
+    if (s > 64) s = 64;
+    return (int)s;
+}
+
+// bytes of workspace mv2d_matmul_nt_x3 needs for C[M,N] = op(A) op(B)^T with a contraction of K
+extern "C" long long mv2d_matmul_nt_x3_ws_bytes(int M, int N, int K) {
+    const int kp = pad_to(K, 64), Np = pad_to(N, 8);
+    const int splits = mm_splits(M, Np, kp, 0);
+    long long b = al256((long long)M * 3 * kp * 2) + al256((long long)Np * 3 * kp * 2) + al256((long long)Np * 4);
+    if (splits > 1) b += al256((long long)splits * M * Np * 4) + al256((long long)mv2d_colsum_scratch_rows(splits) * M * Np * 4);
+    return b;
+}
+
+// C [M, ldc >= pad8(N)] fp32 = act(op(A) op(B)^T + bias): A fp32 [M,K] (or [K,M] with trans_a), B fp32 [N,K] (or [K,N] with trans_b), unit
+// column stride, row strides lda / ldb; bias [N] or NULL; act 0 none / 1 ReLU.  Columns N .. pad8(N) of C are written too (zeros + nothing).
+extern "C" int mv2d_matmul_nt_x3(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act,
+                                 float* C, int ldc, int M, int N, int K, void* ws, long long ws_bytes, void* stream) {
+    MV2D_CHECK_ARG(A && B && C && M >= 0 && N > 0 && K > 0 && (act == 0 || act == 1), "mv2d_matmul_nt_x3: bad args");
+    if (M == 0) return MV2D_OK;
+    const int kp = pad_to(K, 64), Np = pad_to(N, 8);
+    MV2D_CHECK_ARG(ldc >= Np && (ldc % 4) == 0, "mv2d_matmul_nt_x3: ldc >= N rounded up to 8, a multiple of 4");
+    MV2D_CHECK_ARG(ws && ws_bytes >= mv2d_matmul_nt_x3_ws_bytes(M, N, K) && ((uintptr_t)ws & 255) == 0, "mv2d_matmul_nt_x3: workspace too small / misaligned");
+    const int splits = mm_splits(M, Np, kp, act);
+    char* w = (char*)ws;
+    void* a3 = w; w += al256((long long)M * 3 * kp * 2);
+    void* b3 = w; w += al256((long long)Np * 3 * kp * 2);
+    float* bias_p = (float*)w; w += al256((long long)Np * 4);
+    float* slabs = (float*)w; if (splits > 1) w += al256((long long)splits * M * Np * 4);
+    float* scratch = (float*)w;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = mv2d_split3_operand(A, lda, M, K, trans_a, a3, M, kp, 0, stream)) != MV2D_OK) return rc;
+    if ((rc = mv2d_split3_operand(B, ldb, N, K, trans_b, b3, Np, kp, 1, stream)) != MV2D_OK) return rc;
+    const float* bp = bias;
+    if (bias && Np != N) {
+        if (hipMemsetAsync(bias_p, 0, (size_t)Np * 4, st) != hipSuccess || hipMemcpyAsync(bias_p, bias, (size_t)N * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return MV2D_ERR_LAUNCH;
+        bp = bias_p;
+    }
+    if (splits > 1) {
+        MV2D_CHECK_ARG(ldc == Np, "mv2d_matmul_nt_x3: the split-K route writes a dense C (ldc = N rounded up to 8)");
+        if ((rc = mv2d_gemm_bf16_ex(a3, nullptr, 0, 0, b3, bp, M, Np, 3 * kp, 3 * kp, nullptr, 0, nullptr, 0, nullptr, 0, slabs, 0, Np, 0, 0, nullptr, nullptr,
+                                    0, 0, 0, nullptr, 0, splits, (long long)M * Np, stream)) != MV2D_OK) return rc;
+        return mv2d_colsum(slabs, (long long)M * Np, splits, M * Np, C, mv2d_colsum_scratch_rows(splits) ? scratch : nullptr, stream);
+    }
+    return mv2d_gemm_bf16_ex(a3, nullptr, 0, 0, b3, bp, M, Np, 3 * kp, 3 * kp, nullptr, act, nullptr, 0, nullptr, 0, C, 0, ldc, 0, 0, nullptr, nullptr, 0, 0, 0,
+                             nullptr, 0, 1, 0, stream);
+}
+
+extern "C" long long mv2d_linear_bwd_x3_ws_bytes(int M, int N, int K) {
+    const long long a = mv2d_matmul_nt_x3_ws_bytes(M, K, N), b = mv2d_matmul_nt_x3_ws_bytes(N, K, M);
+    return al256((long long)M * N * 4) + (a > b ? a : b) + al256((long long)mv2d_colsum_scratch_rows(M) * N * 4);
+}
+
+// Backward of y = act(x W^T + b), x [M,K], W [N,K], dy / y [M,N] (dense rows): g = dy (masked by y > 0 when y is given);
+// dx [M, pad8(K)] = g W (skipped when NULL), dW [N, pad8(K)] = g^T x (skipped when NULL), db [N] = column sums of g (skipped when NULL).
+extern "C" int mv2d_linear_bwd_x3(const float* x, const float* W, const float* y, const float* dy, float* dx, float* dW, float* db, int M, int N, int K,
+                                  void* ws, long long ws_bytes, void* stream) {
+    MV2D_CHECK_ARG(x && W && dy && M >= 0 && N > 0 && K > 0, "mv2d_linear_bwd_x3: bad args");
+    MV2D_CHECK_ARG(ws && ws_bytes >= mv2d_linear_bwd_x3_ws_bytes(M, N, K) && ((uintptr_t)ws & 255) == 0, "mv2d_linear_bwd_x3: workspace too small / misaligned");
+    if (M == 0) return MV2D_OK;                      // (the caller zero-fills dW / db for an empty batch)
+    char* w = (char*)ws;
+    const float* g = dy;
+    if (y) {
+        float* gm = (float*)w;
+        const long long n = (long long)M * N;
+        hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)cdiv((int)((n + 3) / 4), 256)), dim3(256), 0, (hipStream_t)stream, dy, y, gm, n);
+        MV2D_LAUNCH_CHECK();
+        g = gm;
+    }
+    w += al256((long long)M * N * 4);
+    const long long a = mv2d_matmul_nt_x3_ws_bytes(M, K, N), b = mv2d_matmul_nt_x3_ws_bytes(N, K, M), mm = a > b ? a : b;
+    void* mws = w; w += mm;
+    int rc;
+    const int Kp = pad_to(K, 8);
+    if (dx && (rc = mv2d_matmul_nt_x3(g, N, 0, W, K, 1, nullptr, 0, dx, Kp, M, K, N, mws, mm, stream)) != MV2D_OK) return rc;          // g [M,N] . (W^T [K,N])^T
+    if (dW && (rc = mv2d_matmul_nt_x3(g, N, 1, x, K, 1, nullptr, 0, dW, Kp, N, K, M, mws, mm, stream)) != MV2D_OK) return rc;          // g^T [N,M] . (x^T [K,M])^T
+    if (db) return mv2d_colsum(g, N, M, N, db, mv2d_colsum_scratch_rows(M) ? (float*)w : nullptr, stream);
     return MV2D_OK;
 }

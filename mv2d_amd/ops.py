@@ -13,7 +13,13 @@ from ._lib import check
 BF16 = torch.bfloat16
 
 
+_RAW_STREAM, _GET_DEV = getattr(torch._C, '_cuda_getCurrentRawStream', None), getattr(torch._C, '_cuda_getDevice', None)
+
+
 def _stream():
+    # (torch.cuda.current_stream() costs ~5 us of Python per call -- three calls per launch added up to milliseconds per training step)
+    if _RAW_STREAM is not None and _GET_DEV is not None:
+        return _RAW_STREAM(_GET_DEV())
     return torch.cuda.current_stream().cuda_stream
 
 
