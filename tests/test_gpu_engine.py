@@ -12,7 +12,9 @@ from mv2d_amd import synthetic
 pytestmark = pytest.mark.gpu
 
 # measured on MI355X (round 1): center 3e-4, ref 1e-4, qpos 2e-4, pe 4e-3, outs 8e-4, cls 4e-4, reg 1e-3 -> ~4x headroom
-TOL = dict(center=2e-3, ref=1e-3, qpos=1e-3, pe=1e-2, outs=4e-3, cls=2e-3, reg=5e-3, roi_feat=5e-3, score=5e-3)
+# engine vs oracle on the same inputs; bounds = ~2 x the largest measured value (round 3: center 3.3e-4, ref 1.2e-4, qpos 2.2e-4, pe 4.3e-3 and
+# roi_feat 2.7e-3 (bf16 outputs), outs 5.2e-4, cls 2.3e-4, reg 4.3e-4)
+TOL = dict(center=7e-4, ref=3e-4, qpos=5e-4, pe=9e-3, outs=1.1e-3, cls=5e-4, reg=1.1e-3, roi_feat=6e-3, score=5e-3)
 
 
 def relmax(a, b):
