@@ -220,8 +220,13 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_qtile_kernel(const uint4* __
     float* pls = reinterpret_cast<float*>(smem + RING_B);
     int* uk = reinterpret_cast<int*>(smem + RING_B + PL_B);
     unsigned int* mk = reinterpret_cast<unsigned int*>(smem + RING_B + PL_B + UK_B);
-    const int tb = blockIdx.x;
-    if (tb >= *n_tiles) return;
+    // XCD-aware block -> tile map (block b runs on XCD b % 8): every XCD takes one contiguous range of the (ordered) tiles, neighbours share its L2
+    int tb;
+    {
+        const int nt_all = *n_tiles, b = blockIdx.x, x = b & 7, qn_ = nt_all >> 3, rem = nt_all & 7, k = b >> 3;
+        if (k >= qn_ + (x < rem ? 1 : 0)) return;
+        tb = (x < rem ? x * (qn_ + 1) : rem * (qn_ + 1) + (x - rem) * qn_) + k;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 15, g = lane >> 4;
     const int q0 = tile_q0[tb], qn = tile_qn[tb], u0 = uptr[tb], U = ucnt[tb];
     const int ntile = (U + 15) >> 4;
@@ -384,7 +389,8 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_qtile_kernel(const uint4* __
 }  // namespace
 
 static inline int qt_order_chunks(int R) { const int n = R < GRP_MAX ? R : GRP_MAX; return (n + ORD_CHUNK - 1) / ORD_CHUNK; }
-static inline int qt_size(int queries_per_tile) { return queries_per_tile == 16 ? 16 : 8; }
+static inline int qt_size(int queries_per_tile) { return queries_per_tile == 16 ? 16 : queries_per_tile == 2 ? 2 : queries_per_tile == 4 ? 4 : 8; }
+static inline bool qt_ok(int q) { return q == 2 || q == 4 || q == 8 || q == 16; }
 extern "C" long long mv2d_xattn_qtile_max_tiles(int R, int n_samples, int queries_per_tile) {
     const int QT = qt_size(queries_per_tile);
     return (long long)(R + QT - 1) / QT + n_samples + 1;
@@ -410,16 +416,14 @@ extern "C" int mv2d_xattn_qtile_build(const int* row_ptr, const int* col_idx, co
                        alloc && flags, "mv2d_xattn_qtile_build: null pointer");
     MV2D_CHECK_ARG(R > 0 && n_samples >= 1 && nwords > 0 && nwords <= 8192 && ucap > 0 && (ucap % 16) == 0, "mv2d_xattn_qtile_build: bad sizes");
     hipStream_t st = (hipStream_t)stream;
-    MV2D_CHECK_ARG(queries_per_tile == 8 || queries_per_tile == 16, "mv2d_xattn_qtile_build: 8 or 16 queries per tile");
+    MV2D_CHECK_ARG(qt_ok(queries_per_tile), "mv2d_xattn_qtile_build: 2, 4, 8 or 16 queries per tile");
     const int QT = qt_size(queries_per_tile);
     hipLaunchKernelGGL(qt_order_kernel, dim3(n_samples + 1, qt_order_chunks(R)), dim3(1024), 0, st, row_ptr, col_idx, grp_start, n_samples, R, perm, tile_q0, tile_qn, n_tiles, flags, QT);
     const int ntmax = (int)mv2d_xattn_qtile_max_tiles(R, n_samples, QT);
-    if (QT == 16)
-        hipLaunchKernelGGL(qt_build_kernel<16>, dim3(ntmax), dim3(256), nwords * 8, st, (const unsigned int*)bits, nwords, rect, V, cells_per_sample, pos2s, perm,
-                           tile_q0, tile_qn, n_tiles, uptr, ucnt, ukeys, ucap, (unsigned int*)qmask, alloc, flags);
-    else
-        hipLaunchKernelGGL(qt_build_kernel<8>, dim3(ntmax), dim3(256), nwords * 8, st, (const unsigned int*)bits, nwords, rect, V, cells_per_sample, pos2s, perm,
-                           tile_q0, tile_qn, n_tiles, uptr, ucnt, ukeys, ucap, (unsigned int*)qmask, alloc, flags);
+#define MV2D_QB(Q) hipLaunchKernelGGL(qt_build_kernel<Q>, dim3(ntmax), dim3(256), nwords * 8, st, (const unsigned int*)bits, nwords, rect, V, cells_per_sample, pos2s, \
+                                      perm, tile_q0, tile_qn, n_tiles, uptr, ucnt, ukeys, ucap, (unsigned int*)qmask, alloc, flags)
+    if (QT == 16) MV2D_QB(16); else if (QT == 8) MV2D_QB(8); else if (QT == 4) MV2D_QB(4); else MV2D_QB(2);
+#undef MV2D_QB
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
@@ -431,15 +435,13 @@ extern "C" int mv2d_xattn_qtile_fwd(const void* Qt, const void* Xk, const void* 
     MV2D_CHECK_ARG(((uintptr_t)Qt & 15) == 0 && ((uintptr_t)Xk & 15) == 0 && ((uintptr_t)Xv & 15) == 0 && ((uintptr_t)z & 15) == 0,
                    "mv2d_xattn_qtile_fwd: operands must be 16-byte aligned");
     if (R == 0) return MV2D_OK;
-    MV2D_CHECK_ARG(queries_per_tile == 8 || queries_per_tile == 16, "mv2d_xattn_qtile_fwd: 8 or 16 queries per tile (as built)");
+    MV2D_CHECK_ARG(qt_ok(queries_per_tile), "mv2d_xattn_qtile_fwd: 2, 4, 8 or 16 queries per tile (as built)");
     static const int dbg_mode = getenv("MV2D_QTILE_DBG") ? atoi(getenv("MV2D_QTILE_DBG")) : 0;      // timing experiments: 1 = no arithmetic, 2 = the same 16 rows every tile
     const int ntmax = (int)mv2d_xattn_qtile_max_tiles(R, n_samples, queries_per_tile);
-    if (queries_per_tile == 16)
-        hipLaunchKernelGGL((xattn_qtile_kernel<8>), dim3(ntmax), dim3(512), 0, (hipStream_t)stream, (const uint4*)Qt, (const unsigned short*)Xk,
-                           (const unsigned short*)Xv, perm, tile_q0, tile_qn, n_tiles, uptr, ucnt, ukeys, (const unsigned int*)qmask, z, empty_nan, dbg_mode);
-    else
-        hipLaunchKernelGGL((xattn_qtile_kernel<4>), dim3(ntmax), dim3(256), 0, (hipStream_t)stream, (const uint4*)Qt, (const unsigned short*)Xk,
-                           (const unsigned short*)Xv, perm, tile_q0, tile_qn, n_tiles, uptr, ucnt, ukeys, (const unsigned int*)qmask, z, empty_nan, dbg_mode);
+#define MV2D_QA(W) hipLaunchKernelGGL((xattn_qtile_kernel<W>), dim3(ntmax), dim3(64 * W), 0, (hipStream_t)stream, (const uint4*)Qt, (const unsigned short*)Xk, \
+                                      (const unsigned short*)Xv, perm, tile_q0, tile_qn, n_tiles, uptr, ucnt, ukeys, (const unsigned int*)qmask, z, empty_nan, dbg_mode)
+    if (queries_per_tile == 16) MV2D_QA(8); else if (queries_per_tile == 8) MV2D_QA(4); else if (queries_per_tile == 4) MV2D_QA(2); else MV2D_QA(1);
+#undef MV2D_QA
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -499,7 +499,7 @@ def test_last_stage_heads_option(name, kind):
     assert torch.equal(ok['cls'], oa['cls'])
 
 
-@pytest.mark.parametrize('name,n,qpt', [('micro_t', 1, 8), ('cfg1_t', 1, 16), ('cfg1_t', 3, 8), ('cfg3_t', 1, 8), ('cfg3_t', 2, 16)])
+@pytest.mark.parametrize('name,n,qpt', [('micro_t', 1, 8), ('cfg1_t', 1, 16), ('cfg1_t', 3, 8), ('cfg3_t', 1, 8), ('cfg3_t', 2, 16), ('cfg1_t', 2, 2), ('cfg3_t', 2, 2), ('cfg3_t', 1, 4)])
 def test_query_tile_cross_attention_tables_and_result(name, n, qpt):
     """T path, shared-key-tile cross attention (csrc/xattn_qtile.hip): (1) the tables mv2d_xattn_qtile_build derives from the CSR -- query
     order, tiles, union key lists, pair masks -- reproduce EXACTLY the allowed (query, key) pairs of the CSR (which is bit-exact against the

@@ -35,7 +35,7 @@ def timed(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for qpt in (8, 16):
+for qpt in (2, 4, 8, 16):
     eng = HeadEngine(sd, 'T', dev, num_views=probs[0]['views_per_frame'])
     eng.qtile, eng.qtile_queries = True, qpt          # (opt-in since the per-query kernel in smallest-key order shipped)
     out = eng.run_batch(feats, props, metas) if a.batch > 1 else eng.run(feats, props[0], metas[0])
