@@ -218,7 +218,8 @@ def fallback_key_csr(row_ptr, col_idx, key_index):
 
 class TrainDecoder:
     """Differentiable decoder + prediction heads of ``CrossAttentionBoxHead`` for training: the dense linears, layer
-    norms and the FFN go through torch (rocBLAS GEMMs, torch autograd), **both attentions through the HIP sparse-attention kernels**
+    norms and the FFN go through ``mv2d_amd.autograd_ops`` (forward and backward on the HIP split-precision GEMM / layer-norm kernels; torch
+    keeps the autograd graph and the element-wise glue), **both attentions through the HIP sparse-attention kernels**
     (``ops.SparseCrossAttention``: forward ``mv2d_sparse_xattn_fwd``, backward ``mv2d_sparse_xattn_bwd``) — the self attention as a CSR
     with the denoising mask of ``prepare_for_dn`` as its pattern.  Parameters are read from the head module itself (the reference's
     state-dict names), so their ``.grad`` is what an optimizer / DDP sees.  K / V are rounded to bf16 for the attention kernels (as in
