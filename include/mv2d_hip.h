@@ -520,11 +520,17 @@ int mv2d_layer_norm_bwd(const float* x, const float* dy, const float* w, float* 
  * mv2d_matmul_nt_x3: C [M, ldc] fp32 = act(op(A) op(B)^T + bias), A [M,K] (trans_a: [K,M]), B [N,K] (trans_b: [K,N]) fp32 with row strides
  * lda / ldb, bias [N] or NULL, act 0 / 1 (ReLU); ldc >= N rounded up to 8 (the pad columns are written).  Operand split, GEMM, split-K slabs
  * and their fixed-order sum as in the single entries above (nn.Linear / mmcv FFN forward and backward, MU/petr_transformer.py:195-311).
- * mv2d_linear_bwd_x3: backward of y = act(x W^T + b): g = dy masked by y > 0 (y NULL: no activation); dx [M, pad8(K)] = g W, dW [N, pad8(K)] =
- * g^T x, db [N] = column sums of g; each output optional (NULL). */
+ * mv2d_linear_bwd_x3: backward of y = act(x W^T + b): g = dy masked by y > 0 (y NULL: no activation); dx [M,K] = g W, dW [N,K] =
+ * g^T x (both on mv2d_gemm_f32x3), db [N] = column sums of g; each output optional (NULL). */
 long long mv2d_matmul_nt_x3_ws_bytes(int M, int N, int K);
 int mv2d_matmul_nt_x3(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act, float* C,
                       int ldc, int M, int N, int K, void* ws, long long ws_bytes, void* stream);
+/* Split-precision product on fp32 operands read IN PLACE in either orientation (csrc/gemm_f32x3.hip): C [M, ldc] = act(op(A) op(B)^T + bias),
+ * op(X) = X^T when trans_x; operands are split into bf16 hi / lo while a tile is staged into LDS (a transposed operand through a register
+ * transpose), three MFMAs per k-step; split-K slabs + their fixed-order sum in `ws` (mv2d_gemm_f32x3_ws_bytes; 256-byte aligned; optional). */
+long long mv2d_gemm_f32x3_ws_bytes(int M, int N, int K);
+int mv2d_gemm_f32x3(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act, float* C,
+                    long long ldc, int M, int N, int K, void* ws, long long ws_bytes, void* stream);
 long long mv2d_linear_bwd_x3_ws_bytes(int M, int N, int K);
 int mv2d_linear_bwd_x3(const float* x, const float* W, const float* y, const float* dy, float* dx, float* dW, float* db, int M, int N, int K, void* ws,
                        long long ws_bytes, void* stream);

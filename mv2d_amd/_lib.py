@@ -97,6 +97,8 @@ SIGNATURES = {
     'mv2d_colsum': (I, [P, LL, I, I, P, P, P]),
     'mv2d_matmul_nt_x3_ws_bytes': (LL, [I, I, I]),
     'mv2d_matmul_nt_x3': (I, [P, LL, I, P, LL, I, P, I, P, I, I, I, I, P, LL, P]),
+    'mv2d_gemm_f32x3_ws_bytes': (LL, [I, I, I]),
+    'mv2d_gemm_f32x3': (I, [P, LL, I, P, LL, I, P, I, P, LL, I, I, I, P, LL, P]),
     'mv2d_linear_bwd_x3_ws_bytes': (LL, [I, I, I]),
     'mv2d_linear_bwd_x3': (I, [P, P, P, P, P, P, P, I, I, I, P, LL, P]),
     'mv2d_layer_norm_bwd_blocks': (I, [I]),

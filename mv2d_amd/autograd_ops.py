@@ -8,6 +8,8 @@ PyTorch supplies the autograd graph, the element-wise glue (residual adds, dropo
 
 No CPU path: tensors must live on the GPU.
 """
+import os
+
 import torch
 
 from . import _lib, ops
@@ -59,7 +61,8 @@ def _workspace(nbytes, device):
 
 def matmul_nt(A, B, bias=None, act=0, trans_a=False, trans_b=False):
     """C = act(op(A) op(B)^T + bias) in fp32-class split precision on the bf16 tile GEMM; op(X) = X^T when trans_x.  A, B fp32 2-D; bias [N].
-    One C call (``mv2d_matmul_nt_x3``): operand splits, GEMM (split-K for few output tiles with a long contraction) and the slab sum."""
+    One C call (``mv2d_gemm_f32x3``: fp32 operands read in place in either orientation, split while staged into LDS; split-K for few output
+    tiles with a long contraction, slabs summed in fixed order)."""
     A = A if A.stride(-1) == 1 else A.contiguous()
     B = B if B.stride(-1) == 1 else B.contiguous()
     M, K = (A.shape[1], A.shape[0]) if trans_a else A.shape
@@ -69,13 +72,19 @@ def matmul_nt(A, B, bias=None, act=0, trans_a=False, trans_b=False):
     if M == 0 or N == 0 or K == 0:
         return torch.zeros((M, N), device=A.device, dtype=F32)
     lib = _lib.load()
-    Np = _pad(N, 8)
-    out = torch.empty((M, Np), device=A.device, dtype=F32)
-    nb = int(lib.mv2d_matmul_nt_x3_ws_bytes(M, N, K))
-    ws = _workspace(nb, A.device)
-    check(lib.mv2d_matmul_nt_x3(_p(A), A.stride(0), 1 if trans_a else 0, _p(B), B.stride(0), 1 if trans_b else 0, _p(bias), act, _p(out), Np, M, N, K,
-                                _p(ws), ws.numel(), _stream()), 'mv2d_matmul_nt_x3')
-    return out if Np == N else out[:, :N]
+    if os.environ.get('MV2D_TRAIN_GEMM', 'f32x3') == 'kcat':       # A/B switch: the round-3 first build (operand images in HBM + the bf16 tile GEMM)
+        Np = _pad(N, 8)
+        out = torch.empty((M, Np), device=A.device, dtype=F32)
+        ws = _workspace(int(lib.mv2d_matmul_nt_x3_ws_bytes(M, N, K)), A.device)
+        check(lib.mv2d_matmul_nt_x3(_p(A), A.stride(0), 1 if trans_a else 0, _p(B), B.stride(0), 1 if trans_b else 0, _p(bias), act, _p(out), Np, M, N, K,
+                                    _p(ws), ws.numel(), _stream()), 'mv2d_matmul_nt_x3')
+        return out if Np == N else out[:, :N]
+    out = torch.empty((M, N), device=A.device, dtype=F32)
+    nb = int(lib.mv2d_gemm_f32x3_ws_bytes(M, N, K))
+    ws = _workspace(nb, A.device) if nb else None
+    check(lib.mv2d_gemm_f32x3(_p(A), A.stride(0), 1 if trans_a else 0, _p(B), B.stride(0), 1 if trans_b else 0, _p(bias), act, _p(out), N, M, N, K,
+                              _p(ws), ws.numel() if ws is not None else 0, _stream()), 'mv2d_gemm_f32x3')
+    return out
 
 
 def colsum(x):
@@ -97,8 +106,6 @@ class LinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         x2 = x2 if (x2.dtype == F32 and x2.is_contiguous()) else x2.float().contiguous()
         y = matmul_nt(x2, W.float(), None if b is None else b.float(), act)
-        if act == 1 and not y.is_contiguous():
-            y = y.contiguous()
         ctx.save_for_backward(x2, W, y if act == 1 else None)
         ctx.meta = (x.shape, b is not None, act)
         return y.reshape(*x.shape[:-1], W.shape[0])
@@ -116,23 +123,79 @@ class LinearFn(torch.autograd.Function):
             return (torch.zeros(shape, device=dev) if need_x else None, torch.zeros_like(W) if need_w else None,
                     torch.zeros(N, device=dev) if need_b else None, None)
         # one C call: ReLU mask of the gradient, dx = g W, dW = g^T x, db = column sums of g (mv2d_linear_bwd_x3)
-        lib = _lib.load()
         Wf = W if (W.dtype == F32 and W.is_contiguous()) else W.float().contiguous()
-        Kp = _pad(K, 8)
-        dx = torch.empty((M, Kp), device=dev, dtype=F32) if need_x else None
-        dW = torch.empty((N, Kp), device=dev, dtype=F32) if need_w else None
-        db = torch.empty(N, device=dev, dtype=F32) if need_b else None
-        ws = _workspace(int(lib.mv2d_linear_bwd_x3_ws_bytes(M, N, K)), dev)
-        check(lib.mv2d_linear_bwd_x3(_p(x2), _p(Wf), _p(y) if act == 1 else 0, _p(g), _p(dx), _p(dW), _p(db), M, N, K, _p(ws), ws.numel(), _stream()),
-              'mv2d_linear_bwd_x3')
-        if Kp != K:
-            dx = dx[:, :K] if need_x else None
-            dW = dW[:, :K] if need_w else None
+        dx, dW, db = _linear_bwd(x2, Wf, y if act == 1 else None, g, need_x, need_w, need_b)
         return (dx.reshape(shape) if need_x else None), (dW.to(W.dtype) if need_w else None), db, None
 
 
 def linear(x, W, b=None, act=0):
     return LinearFn.apply(x, W, b, act)
+
+
+def _linear_bwd(x2, W, y, g, need_x, need_w, need_b, dW_out=None, db_out=None):
+    """One ``mv2d_linear_bwd_x3`` call; dW / db optionally written into caller-provided (row-slice) buffers."""
+    lib = _lib.load()
+    M, N, K = g.shape[0], W.shape[0], W.shape[1]
+    dev = g.device
+    dx = torch.empty((M, K), device=dev, dtype=F32) if need_x else None
+    dW = (dW_out if dW_out is not None else torch.empty((N, K), device=dev, dtype=F32)) if need_w else None
+    db = (db_out if db_out is not None else torch.empty(N, device=dev, dtype=F32)) if need_b else None
+    ws = _workspace(int(lib.mv2d_linear_bwd_x3_ws_bytes(M, N, K)), dev)
+    check(lib.mv2d_linear_bwd_x3(_p(x2), _p(W), _p(y), _p(g), _p(dx), _p(dW), _p(db), M, N, K, _p(ws), ws.numel(), _stream()), 'mv2d_linear_bwd_x3')
+    return dx, dW, db
+
+
+def _rows(t):
+    t = t.reshape(-1, t.shape[-1])
+    return t if (t.dtype == F32 and t.is_contiguous()) else t.float().contiguous()
+
+
+class InProjFn(torch.autograd.Function):
+    """The three input projections of ``nn.MultiheadAttention`` (MU/petr_transformer.py:501-508 -> F.multi_head_attention_forward:
+    q = (q_in W_q^T + b_q) / sqrt(d), k = k_in W_k^T + b_k, v = v_in W_v^T + b_v with W = in_proj_weight [3C, C]) as ONE autograd node:
+    the weight / bias gradients are written straight into the row blocks of one [3C, C] / [3C] buffer (slicing the parameter in Python
+    costs a zero-filled full-size gradient + a copy + an accumulation per slice and step)."""
+
+    @staticmethod
+    def forward(ctx, q_in, k_in, v_in, W, b, q_scale):
+        Cc = W.shape[1]
+        Wf = W if (W.dtype == F32 and W.is_contiguous()) else W.float().contiguous()
+        bf = b if b.dtype == F32 else b.float()
+        xs = [_rows(q_in), _rows(k_in), _rows(v_in)]
+        outs = [matmul_nt(xs[i], Wf[i * Cc:(i + 1) * Cc], bf[i * Cc:(i + 1) * Cc]) for i in range(3)]
+        if q_scale != 1.0:
+            outs[0].mul_(q_scale)
+        ctx.save_for_backward(xs[0], xs[1], xs[2], Wf)
+        ctx.meta = (q_in.shape, k_in.shape, v_in.shape, q_scale, W.dtype, b.dtype)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, gq, gk, gv):
+        x0, x1, x2, Wf = ctx.saved_tensors
+        sq, sk, sv, q_scale, wdt, bdt = ctx.meta
+        Cc = Wf.shape[1]
+        dev = Wf.device
+        need_w, need_b = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
+        dW = torch.empty_like(Wf) if need_w else None
+        db = torch.empty(3 * Cc, device=dev, dtype=F32) if need_b else None
+        dxs = []
+        for i, (x, g, shp) in enumerate(((x0, gq, sq), (x1, gk, sk), (x2, gv, sv))):
+            g = _rows(g)
+            if i == 0 and q_scale != 1.0:
+                g = g * q_scale
+            if g.shape[0] == 0:
+                if need_w: dW[i * Cc:(i + 1) * Cc].zero_()
+                if need_b: db[i * Cc:(i + 1) * Cc].zero_()
+                dxs.append(torch.zeros(shp, device=dev) if ctx.needs_input_grad[i] else None)
+                continue
+            dx, _, _ = _linear_bwd(x, Wf[i * Cc:(i + 1) * Cc], None, g, ctx.needs_input_grad[i], need_w, need_b,
+                                   dW[i * Cc:(i + 1) * Cc] if need_w else None, db[i * Cc:(i + 1) * Cc] if need_b else None)
+            dxs.append(dx.reshape(shp) if dx is not None else None)
+        return dxs[0], dxs[1], dxs[2], (dW.to(wdt) if need_w else None), (db.to(bdt) if need_b else None), None
+
+
+def in_proj(q_in, k_in, v_in, W, b, q_scale=1.0):
+    return InProjFn.apply(q_in, k_in, v_in, W, b, q_scale)
 
 
 class LayerNormFn(torch.autograd.Function):

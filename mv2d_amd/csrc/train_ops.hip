@@ -229,13 +229,18 @@ extern "C" int mv2d_matmul_nt_x3(const float* A, long long lda, int trans_a, con
                              nullptr, 0, 1, 0, stream);
 }
 
+extern "C" long long mv2d_gemm_f32x3_ws_bytes(int M, int N, int K);
+extern "C" int mv2d_gemm_f32x3(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act,
+                               float* C, long long ldc, int M, int N, int K, void* ws, long long ws_bytes, void* stream);
+
 extern "C" long long mv2d_linear_bwd_x3_ws_bytes(int M, int N, int K) {
-    const long long a = mv2d_matmul_nt_x3_ws_bytes(M, K, N), b = mv2d_matmul_nt_x3_ws_bytes(N, K, M);
-    return al256((long long)M * N * 4) + (a > b ? a : b) + al256((long long)mv2d_colsum_scratch_rows(M) * N * 4);
+    const long long a = al256(mv2d_gemm_f32x3_ws_bytes(M, K, N)), b = al256(mv2d_gemm_f32x3_ws_bytes(N, K, M));
+    return al256((long long)M * N * 4) + (a > b ? a : b) + 256 + al256((long long)mv2d_colsum_scratch_rows(M) * N * 4);
 }
 
 // Backward of y = act(x W^T + b), x [M,K], W [N,K], dy / y [M,N] (dense rows): g = dy (masked by y > 0 when y is given);
-// dx [M, pad8(K)] = g W (skipped when NULL), dW [N, pad8(K)] = g^T x (skipped when NULL), db [N] = column sums of g (skipped when NULL).
+// dx [M,K] = g W (skipped when NULL), dW [N,K] = g^T x (skipped when NULL), db [N] = column sums of g (skipped when NULL).  The two
+// products run on mv2d_gemm_f32x3 (fp32 operands read in place, transposed where the product needs it; split-K for dW over many rows).
 extern "C" int mv2d_linear_bwd_x3(const float* x, const float* W, const float* y, const float* dy, float* dx, float* dW, float* db, int M, int N, int K,
                                   void* ws, long long ws_bytes, void* stream) {
     MV2D_CHECK_ARG(x && W && dy && M >= 0 && N > 0 && K > 0, "mv2d_linear_bwd_x3: bad args");
@@ -251,12 +256,11 @@ extern "C" int mv2d_linear_bwd_x3(const float* x, const float* W, const float* y
         g = gm;
     }
     w += al256((long long)M * N * 4);
-    const long long a = mv2d_matmul_nt_x3_ws_bytes(M, K, N), b = mv2d_matmul_nt_x3_ws_bytes(N, K, M), mm = a > b ? a : b;
+    const long long a = al256(mv2d_gemm_f32x3_ws_bytes(M, K, N)), b = al256(mv2d_gemm_f32x3_ws_bytes(N, K, M)), mm = (a > b ? a : b) + 256;
     void* mws = w; w += mm;
     int rc;
-    const int Kp = pad_to(K, 8);
-    if (dx && (rc = mv2d_matmul_nt_x3(g, N, 0, W, K, 1, nullptr, 0, dx, Kp, M, K, N, mws, mm, stream)) != MV2D_OK) return rc;          // g [M,N] . (W^T [K,N])^T
-    if (dW && (rc = mv2d_matmul_nt_x3(g, N, 1, x, K, 1, nullptr, 0, dW, Kp, N, K, M, mws, mm, stream)) != MV2D_OK) return rc;          // g^T [N,M] . (x^T [K,M])^T
+    if (dx && (rc = mv2d_gemm_f32x3(g, N, 0, W, K, 1, nullptr, 0, dx, K, M, K, N, mws, mm, stream)) != MV2D_OK) return rc;          // g [M,N] . (W^T [K,N])^T
+    if (dW && (rc = mv2d_gemm_f32x3(g, N, 1, x, K, 1, nullptr, 0, dW, K, N, K, M, mws, mm, stream)) != MV2D_OK) return rc;          // g^T [N,M] . (x^T [K,M])^T
     if (db) return mv2d_colsum(g, N, M, N, db, mv2d_colsum_scratch_rows(M) ? (float*)w : nullptr, stream);
     return MV2D_OK;
 }

@@ -272,13 +272,11 @@ class TrainDecoder:
         """dense = (n, keys): the first n query rows see exactly the key rows `keys` (the denoising rows of the cross attention) — a dense
         block, computed with batched GEMMs instead of n rows of len(keys) pairs each in the sparse kernels; csr then covers rows n.."""
         import torch.nn.functional as F
-        from .autograd_ops import linear, matmul_nt_ad
+        from .autograd_ops import in_proj, linear, matmul_nt_ad
         w, b = self.p[name + '.attn.in_proj_weight'], self.p[name + '.attn.in_proj_bias']
         Cc = q_in.shape[-1]
         # (round 3: every projection forward + backward on the HIP GEMM, mv2d_amd/autograd_ops.py; no rocBLAS)
-        q = linear(q_in, w[:Cc], b[:Cc]) * (1.0 / (Cc // self.H) ** 0.5)
-        k = linear(k_in, w[Cc:2 * Cc], b[Cc:2 * Cc])
-        v = linear(v_in, w[2 * Cc:], b[2 * Cc:])
+        q, k, v = in_proj(q_in, k_in, v_in, w, b, 1.0 / (Cc // self.H) ** 0.5)       # one autograd node: dW / db land in one [3C, C] / [3C] buffer
         if dense is not None and dense[0] > 0:
             n, keys = dense
             H, d = self.H, Cc // self.H
@@ -346,22 +344,27 @@ class TrainDecoder:
         r = ref.clamp(0, 1)
         inv = torch.log(r.clamp(min=1e-5) / (1 - r).clamp(min=1e-5))                 # inverse_sigmoid, mmdet
         lo, hi = self.pc_range[:3], self.pc_range[3:]
-        all_cls, all_reg = [], []
+        all_cls, ts = [], []
         for l in range(self.L):
             c, g = f'bbox_head.cls_branches.{l}.', f'bbox_head.reg_branches.{l}.'
             y = F.relu(ln(linear(outs[l], P[c + '0.weight'], P[c + '0.bias']), c + '1'))
             y = F.relu(ln(linear(y, P[c + '3.weight'], P[c + '3.bias']), c + '4'))
             all_cls.append(linear(y, P[c + '6.weight'], P[c + '6.bias']))
             t = linear(outs[l], P[g + '0.weight'], P[g + '0.bias'], 1)
-            t = linear(linear(t, P[g + '2.weight'], P[g + '2.bias'], 1), P[g + '4.weight'], P[g + '4.bias'])
-            cx = (t[:, 0:1] + inv[:, 0:1]).sigmoid() * (hi[0] - lo[0]) + lo[0]
-            cy = (t[:, 1:2] + inv[:, 1:2]).sigmoid() * (hi[1] - lo[1]) + lo[1]
-            cz = (t[:, 4:5] + inv[:, 2:3]).sigmoid() * (hi[2] - lo[2]) + lo[2]
-            vel = t[:, 8:10]
-            if dt:
-                vel = torch.cat([vel[:pad], vel[pad:] / dt])
-            all_reg.append(torch.cat([cx, cy, t[:, 2:4], cz, t[:, 5:8], vel], 1))
-        return torch.stack(all_cls), torch.stack(all_reg)
+            ts.append(linear(linear(t, P[g + '2.weight'], P[g + '2.bias'], 1), P[g + '4.weight'], P[g + '4.bias']))
+        # box code of all layers at once (cross_attention_head.py:219-233; element-wise the same expressions as per layer)
+        t = torch.stack(ts)                                                              # [L,T,10]
+        if getattr(self, '_range_dev', None) != dev:                                    # (constants: uploaded once)
+            self._range_dev = dev
+            self._span = torch.tensor([hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]], device=dev)
+            self._low = torch.tensor(lo, device=dev)
+        span, low = self._span, self._low
+        cxyz = (t[..., [0, 1, 4]] + inv).sigmoid() * span + low
+        vel = t[..., 8:10]
+        if dt:
+            vel = torch.cat([vel[:, :pad], vel[:, pad:] / dt], 1)
+        all_reg = torch.cat([cxyz[..., 0:2], t[..., 2:4], cxyz[..., 2:3], t[..., 5:8], vel], -1)
+        return torch.stack(all_cls), all_reg
 
 
 def allreduce_gradients(parameters, bucket_bytes=256 << 20, average=True, group=None):

@@ -40,3 +40,4 @@ ka = p.key_averages()
 tot_k = sum(e.count for e in ka if e.device_type.name == 'CUDA' or getattr(e,'self_device_time_total',0) > 0)
 print('events with device time:', tot_k)
 print(ka.table(sort_by='self_cpu_time_total', row_limit=25, max_name_column_width=50))
+print(ka.table(sort_by='self_device_time_total', row_limit=22, max_name_column_width=70))
