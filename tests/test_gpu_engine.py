@@ -272,7 +272,7 @@ def _varied_samples(name, n):
     return out
 
 
-@pytest.mark.parametrize('kind,name,n', [('S', 'cfg1_s', 3), ('T', 'cfg1_t', 3), ('S', 'cfg2_s', 2), ('T', 'cfg3_t', 2)])
+@pytest.mark.parametrize('kind,name,n', [('S', 'cfg1_s', 3), ('T', 'cfg1_t', 3), ('S', 'cfg2_s', 2), ('T', 'cfg3_t', 2), ('S', 'cfg1_s', 16), ('T', 'cfg1_t', 16)])      # 16: the samples per launch of the bench
 def test_engine_batch_of_samples_equals_single_runs(kind, name, n):
     """run_batch puts several samples through ONE sequence of launches; nothing may leak between samples: every sample's
     outputs are bitwise what a single-sample run gives (box correlation, self attention, top-k, dt stay inside a sample)."""
