@@ -74,16 +74,32 @@ __global__ __launch_bounds__(512) void xattn_qmap_kernel(const float* __restrict
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bh.v, a, 0, 0, 0);
         acc[t] = a;
     }
-    if (q0 + n < R) {
-        uint4* out = Qt + (long long)(q0 + n) * 512 + h * 64 + g * 2;
+    // the wave's 16 rows x 1 KB go through LDS (two halves of 8 rows) so that every store instruction writes ONE row's 1 KB contiguously: the MFMA
+    // leaves a lane 32-byte pieces 128 bytes apart (round 3: 18.2 -> 15.3 us for 4800 rows; the kernel is bound by its 39 MB of output, 6.2 us without)
+    __shared__ uint4 stage[8][8 * 64];                           // [wave][8 rows x 64 chunks of 16 B], chunk index XOR-ed with the row
+    uint4* st = stage[h];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            XtFrag hi, lo;
-            xt_split8(make_float4(acc[2 * u][0], acc[2 * u][1], acc[2 * u][2], acc[2 * u][3]),
-                      make_float4(acc[2 * u + 1][0], acc[2 * u + 1][1], acc[2 * u + 1][2], acc[2 * u + 1][3]), hi, lo);
-            out[u * 8] = hi.u;
-            out[u * 8 + 1] = lo.u;
+    for (int half = 0; half < 2; ++half) {
+        if ((n >> 3) == half) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                XtFrag hi, lo;
+                xt_split8(make_float4(acc[2 * u][0], acc[2 * u][1], acc[2 * u][2], acc[2 * u][3]),
+                          make_float4(acc[2 * u + 1][0], acc[2 * u + 1][1], acc[2 * u + 1][2], acc[2 * u + 1][3]), hi, lo);
+                const int c = u * 8 + g * 2, r8 = n & 7;
+                st[r8 * 64 + (c ^ (r8 << 1))] = hi.u;
+                st[r8 * 64 + ((c + 1) ^ (r8 << 1))] = lo.u;
+            }
         }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): the wave's LDS writes have landed
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {
+            const int row = q0 + 8 * half + r8;
+            const uint4 v = st[r8 * 64 + (lane ^ (r8 << 1))];
+            if (row < R) Qt[(long long)row * 512 + h * 64 + lane] = v;
+        }
+        __builtin_amdgcn_wave_barrier();                         // before the second half overwrites the stage
     }
 }
 
@@ -104,11 +120,44 @@ __global__ __launch_bounds__(512) void xattn_ctxmap_kernel(const float* __restri
     const uint4* wl = WB_lo + (long long)h * 16 * 64 + lane;
     f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float4 x0[8], x1[8];
+#ifdef MV2D_CTXMAP_DIRECT
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         x0[s] = *reinterpret_cast<const float4*>(zp + 32 * s);
         x1[s] = *reinterpret_cast<const float4*>(zp + 32 * s + 4);
     }
+#else
+    {
+        // a lane needs 32-byte pieces 128 bytes apart of its row's 1 KB: the rows are read whole (one load instruction = one row's 1 KB) and
+        // redistributed through LDS, two halves of 8 rows (chunk index XOR-ed with the row)
+        (void)zp;
+        __shared__ float4 stage[8][8 * 64];
+        float4* st = stage[h];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 v[8];
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int rr = min(q0 + 8 * half + r8, R - 1);
+                v[r8] = *reinterpret_cast<const float4*>(z + ((long long)rr * HEADS + h) * C + 4 * lane);
+            }
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) st[r8 * 64 + (lane ^ (r8 << 1))] = v[r8];
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if ((n >> 3) == half) {
+                const int r8 = n & 7;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const int c = s * 8 + g * 2;
+                    x0[s] = st[r8 * 64 + (c ^ (r8 << 1))];
+                    x1[s] = st[r8 * 64 + ((c + 1) ^ (r8 << 1))];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+#endif
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         XtFrag ah, al;
