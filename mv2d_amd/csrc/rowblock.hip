@@ -1284,7 +1284,9 @@ extern "C" int mv2d_ffn_out_fused_x3(const float* parts, int n_parts, long long 
     if (M == 0) return MV2D_OK;
     FfnOutParams p{parts, n_parts, part_stride, b2, resid, ln_w, ln_b, post_w, post_b, x_out, qpos, xq_out, outs,
                    (const unsigned short*)Win_hi, (const unsigned short*)Win_lo, b_in, qkv, M, eps};
-    static const int rt2 = getenv("MV2D_FFNOUT_RT2") ? atoi(getenv("MV2D_FFNOUT_RT2")) : 0;     // experiment switch: no gain (the slab sum doubles per block)
+    // 32 rows per block above 512 rows (bitwise the same rows either way, tests/test_gpu_engine.py batch == single): no gain at 8 samples per launch
+    // (the slab sum doubles per block), +1.2 % samples/s at 16 per launch (150 instead of 300 blocks, half the weight stream); MV2D_FFNOUT_RT2=0: 16 rows
+    static const int rt2 = getenv("MV2D_FFNOUT_RT2") ? atoi(getenv("MV2D_FFNOUT_RT2")) : 1;
     if (M <= 512 || !rt2) hipLaunchKernelGGL(ffn_out_fused_x3_kernel<1>, dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(ffn_out_fused_x3_kernel<2>, dim3(cdiv(M, 32)), dim3(1024), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
