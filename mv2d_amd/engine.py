@@ -850,7 +850,7 @@ class HeadEngine:
                     o.self_attn_dn(ws['qkv'], ws['dn'][0], ws['dn'][1], out=ws['ctx'])      # training: denoising rows first (train_forward)
                 else:
                     o.self_attn(ws['qkv'], ws['ctx'], R, grp_start=ws['grp_start'], max_grp_rows=ws.get('max_rows', 0),
-                                impl='f32' if self.exact else None)      # index-exact mode: the exact-fp32 MFMA kernel
+                                impl='f32' if (self.exact and os.environ.get('MV2D_EXACT_SA', 'x3') == 'f32') else None)      # (index-exact route: the bf16x3 kernel too since the end of round 3 -- same mismatch counts, cls error 4-5e-6 either way, +2.8 %; MV2D_EXACT_SA=f32: the exact-fp32 MFMA kernel)
             if maps_fused:
                 o.attn_out_qmap_x3(ws['ctx'], x_in, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
                                    qpos=ws['qpos'], Wq_x3=W_[f'ca_q_wx{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, WA=W_[f'ca_mapA{i}'],
