@@ -473,19 +473,21 @@ def main():
     if getattr(eng, 'tile_attn', False):
         xk, xv = ws['xk_rows'], ws['xv_rows']
         q_ord = ws.get('q_order')                          # T path: blocks in the order of the queries' smallest key (as the engine launches it)
+        xlo = dict(Xk_lo=ws['xk_lo'], Xv_lo=ws['xv_lo']) if (getattr(eng, 'exact', False) and ws.get('xk_lo') is not None) else {}      # index-exact route: hi + lo rows
         for _ in range(3):
-            ops.xattn_tile(ws['Qt'], xk, xv, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=eng.empty_nan, waves=eng.xattn_waves, order=q_ord)
+            ops.xattn_tile(ws['Qt'], xk, xv, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=eng.empty_nan, waves=eng.xattn_waves, order=q_ord, **xlo)
         e0.record()
         for _ in range(20):
-            ops.xattn_tile(ws['Qt'], xk, xv, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=eng.empty_nan, waves=eng.xattn_waves, order=q_ord)
+            ops.xattn_tile(ws['Qt'], xk, xv, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=eng.empty_nan, waves=eng.xattn_waves, order=q_ord, **xlo)
         e1.record()
         torch.cuda.synchronize()
         x_ms = e0.elapsed_time(e1) / 20
         # algorithmic HBM bytes: every key row that some query reads, once (K and V, bf16) + Qt in + z out.  Rows read by several queries
         # (T path: 2.9 per row) are counted once here — the repeats are L2 / Infinity Cache traffic; `gathered_bytes` counts them all.
         n_rows = min(nnz, S if kind == 'T' else R * 49)
-        x_bytes = n_rows * 2 * 256 * 2 + R * (16 * 256 * 2 + 8 * 256 * 4)
-        x_gathered = nnz * 2 * 256 * 2 + R * (16 * 256 * 2 + 8 * 256 * 4)
+        row_b = 2 * 256 * 2 * (2 if xlo else 1)                                     # K + V row, bf16 (index-exact route: hi + lo rows)
+        x_bytes = n_rows * row_b + R * (16 * 256 * 2 + 8 * 256 * 4)
+        x_gathered = nnz * row_b + R * (16 * 256 * 2 + 8 * 256 * 4)
         x_flops = 2.0 * nnz * 8 * 256 * 2                                          # logits + P.V in the 256-dim input space, 8 heads
         xattn = roof('xattn_tile', 'xattn_tile_kernel (sparse cross-attention in the raw key space, one launch per decoder layer)', x_ms, x_flops, x_bytes,
                      launches=eng.L)
