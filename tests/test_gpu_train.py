@@ -571,6 +571,31 @@ def test_hip_matmul_nt_both_operands_differentiable():
     assert rel(C, Cr) < 5e-5 and rel(A.grad, Ad.grad) < 5e-5 and rel(B.grad, Bd.grad) < 5e-5
 
 
+@pytest.mark.parametrize('ta,tb', [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize('M,N,K,pad', [(37, 10, 70, 0), (300, 256, 256, 0), (129, 65, 1040, 3), (256, 256, 14700, 0), (5, 3, 7, 1)])
+def test_gemm_f32x3_all_orientations(ta, tb, M, N, K, pad):
+    """mv2d_gemm_f32x3 directly: C = act(op(A) op(B)^T + bias) for every (trans_a, trans_b), ragged sizes, row strides that are not multiples
+    of 4 floats (`pad`: the scalar load path), and a contraction long enough for the split-K route (slabs + fixed-order sum), vs fp64."""
+    from mv2d_amd.autograd_ops import matmul_nt
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + 2 * ta + tb)
+    def operand(rows, cols, trans):
+        shape = (cols, rows) if trans else (rows, cols)
+        full = torch.randn(shape[0], shape[1] + pad, generator=g).to(dev)
+        return full[:, :shape[1]]                                              # a view with row stride shape[1] + pad
+    A, B = operand(M, K, ta), operand(N, K, tb) * 0.1
+    bias = torch.randn(N, generator=g).to(dev)
+    for act in (0, 1):
+        C = matmul_nt(A, B, bias, act, trans_a=ta, trans_b=tb)
+        ref = (A.double().t() if ta else A.double()) @ (B.double() if tb else B.double().t()) + bias.double()
+        if act:
+            mask = (C > 0).double()
+            assert float((torch.relu(ref) - ref * mask).abs().max()) < 1e-4 * float(ref.abs().max())
+            ref = ref * mask
+        err = float((C.double() - ref).abs().max() / ref.abs().max())
+        assert C.shape == (M, N) and err < 5e-5, (ta, tb, M, N, K, act, err)
+
+
 def test_training_step_launches_no_blas_kernel():
     """The autograd route of forward_train + backward: the only matrix products are the HIP GEMM's (kernel names of a profiled step
     contain no rocBLAS / hipBLASLt 'Cijk_' / 'gemm' symbol from outside libmv2d_hip)."""
