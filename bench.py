@@ -33,38 +33,28 @@ PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X
 PEAK_HBM_GBS = 8000.0
 
 
-SINE_TABLE = os.environ.get('MV2D_PE_SINE_TABLE', '1') == '1'      # default: the input-independent sine branch of the PE block is folded into a per-(weights, geometry) table; its FLOPs are NOT counted
-
 
 def stage_flops(kind, R, S, L=6):
     """Algorithmic FLOPs (2 x MAC) of the dense bf16 MFMA launches of one frame."""
-    C = 256
-    sine = 0 if SINE_TABLE else 384 * 1024 + 1024 * 256
+    # (the input-independent sine branch of the PE block is folded into a per-(weights, geometry) table, DESIGN.md section 8: its FLOPs are NOT counted)
     return {
-        'pe_fused': 2.0 * S * (192 * 1024 + 1024 * 256 + 2 * 256 * 256 + sine),                # 2.49 MFLOP per key position
+        'pe_fused': 2.0 * S * (192 * 1024 + 1024 * 256 + 2 * 256 * 256),                       # 1.16 MFLOP per key position
         'qg_conv_gemm': 2.0 * R * 49 * 2304 * 256,
-        'kv_gemm': 2.0 * (S if kind == 'T' else R * 49) * C * (2 * L * C),
     }
 
 
 def stage_bytes(kind, R, S, L=6):
     """Algorithmic HBM bytes of the same launches: A read once + weights once + output written once (bf16 = 2 B, fp32 = 4 B)."""
-    C = 256
-    Mkv = S if kind == 'T' else R * 49
     return {
-        # inputs (A1, A2, Xf bf16, Xf fp32) + the six weight matrices once + pe fp32 and Xk bf16 out
-        # table variant: A1 + Xf bf16 in, table row fp32 in; S path: pe fp32 out (RoIAlign reads it; its keys are RoI-aligned rows);
-        # T path: fp32 feature row in, Xk bf16 out (nothing reads pe there)
+        # A1 + Xf key16 (fp16) in, table row fp32 in, the four weight matrices once; S path: pe fp32 out (RoIAlign reads it; its keys are
+        # RoI-aligned rows); T path: fp32 feature row in, Xk key16 out (nothing reads pe there)
         'pe_fused': (S * (192 + 256) * 2 + S * 256 * 4 + (192 * 1024 + 1024 * 256 + 2 * 256 * 256) * 2 +
-                     (S * 256 * (4 + 2) if kind == 'T' else S * 256 * 4)) if SINE_TABLE else
-                    (S * (192 + 384 + 256) * 2 + S * 256 * 4 + (192 * 1024 + 384 * 1024 + 2 * 1024 * 256 + 2 * 256 * 256) * 2 + S * 256 * 6),
+                     (S * 256 * (4 + 2) if kind == 'T' else S * 256 * 4)),
         'qg_conv_gemm': R * 49 * 256 * 2 + 2304 * 256 * 2 + R * 256 * 4,                       # pooled [R,256] output
-        'kv_gemm': 2 * Mkv * C * 2 + 2 * L * C * C * 2 + Mkv * 2 * L * C * 2,
     }
 
 
-STAGE_KERNEL = {'pe_fused': 'pe_tab_kernel (frustum MLP + gate, sine branch from the table)' if SINE_TABLE else 'pe_fused_kernel (3 two-layer MLPs + gate + sum)',
-                'kv_gemm': 'kvproj_kernel (MV2D_XATTN=sparse route only)', 'qg_conv_gemm': 'roi_conv_pool_kernel (conv3x3 + ReLU + avgpool fused)'}
+STAGE_KERNEL = {'pe_fused': 'pe_tab_kernel (frustum MLP + gate, sine branch from the table)', 'qg_conv_gemm': 'roi_conv_pool_kernel (conv3x3 + ReLU + avgpool fused)'}
 
 
 def build_step(engs, strs, sets, pool, Bs, pay, state, *, collective, use_graph, rotate=True, pack=None, gather=None, cuda=True):
@@ -176,9 +166,19 @@ def main():
     ap.add_argument('--no-other-workloads', action='store_true', help='skip the short cfg3_t / cfg5_t legs (sub-processes of this script)')
     ap.add_argument('--no-parity-leg', action='store_true', help='skip the single-sample run that counts the integer mismatches against the reference golden')
     ap.add_argument('--min-seconds', type=float, default=1.0, help='when the K timed steps take less than this, a second, longer loop of the same step is timed and reported beside them')
+    ap.add_argument('--force-collective', action='store_true', help='one rank: initialise the process group (nccl = RCCL) anyway and run the per-step all-gather of decoded boxes')
+    ap.add_argument('--no-collective-leg', action='store_true', help='skip the one-rank RCCL leg (a sub-process of this script with --force-collective)')
     args = ap.parse_args()
+    if args.force_collective:
+        os.environ['MV2D_FORCE_COLLECTIVE'] = '1'
+        if 'MASTER_PORT' not in os.environ:
+            import socket
+            s_ = socket.socket()
+            s_.bind(('127.0.0.1', 0))
+            os.environ['MASTER_PORT'] = str(s_.getsockname()[1])
+            s_.close()
     if args.brief:
-        args.no_extra_legs = args.no_cpu_baseline = args.no_other_workloads = True
+        args.no_extra_legs = args.no_cpu_baseline = args.no_other_workloads = args.no_collective_leg = True
 
     from mv2d_amd import dist as mdist
     from mv2d_amd import ops, synthetic
@@ -202,11 +202,8 @@ def main():
     engines = [base] + [base.clone_shared() for _ in range(args.inflight - 1)]
     # frames in flight go on streams that were MEASURED to run concurrently (queue/pipe sharing serialises others)
     from mv2d_amd.streams import concurrent_streams
-    if os.environ.get('MV2D_NAIVE_STREAMS', '0') == '1':
-        streams = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)]
-    else:
-        pool = concurrent_streams(min(args.inflight, 4), dev)
-        streams = [pool[i % len(pool)] for i in range(args.inflight)]
+    pool = concurrent_streams(min(args.inflight, 4), dev)
+    streams = [pool[i % len(pool)] for i in range(args.inflight)]
     feat = torch.from_numpy(prob['feat']).to(dev)
     props = [torch.from_numpy(p) for p in prob['proposals']]
     metas = prob['img_metas']
@@ -306,6 +303,18 @@ def main():
             el_long = float(t.item())
         long_run = dict(steps=n_long, seconds=round(el_long, 3), samples_s=round(world * args.inflight * B * n_long / el_long, 2))
 
+    # ---------------- with a collective in the step: the gathered tensor's slice of this rank must be bit-identical to the payload it packed
+    collective_check = None
+    if collective:
+        out_g = step()
+        torch.cuda.synchronize()
+        k_last = (state['step_no'] - 1) & 1
+        mine = out_g[rank].contiguous().view(torch.int32)
+        collective_check = dict(backend=dist.get_backend(), world=world, gathered_shape=list(out_g.shape),
+                                gathered_equals_packed=bool(torch.equal(mine, payload[k_last].view(torch.int32))),
+                                payload_nonzero_entries=int((payload[k_last] != 0).sum().item()),
+                                steps_with_collective=state['step_no'], hipgraph=use_graph)
+
     # ---------------- extra legs (single GPU): what the headline's batching / streams / input rotation are worth
     extra = dict(samples_s_rotating_inputs=round(value, 2), rotating_frame_sets_per_stream=K,
                  img_metas='unique per sample and step (camera tables rebuilt + uploaded in the timed loop)' if two_frame else
@@ -404,12 +413,15 @@ def main():
     for a, b in zip(names[:-1], names[1:]):
         stage_ms[a] = statistics.median(x.elapsed_time(y) for x, y in zip(prof[a], prof[b]))
     fl, by = stage_flops(kind, R, S), stage_bytes(kind, R, S)
-    if getattr(eng, 'tile_attn', False):                 # the K / V projection GEMM only exists on the MV2D_XATTN=sparse route
-        fl.pop('kv_gemm'); by.pop('kv_gemm')
     try:
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get(f'{args.workload}@{B}', {})
     except Exception:
         pmc = {}
+    try:
+        lib_sha = open(os.path.join(ROOT, 'mv2d_amd', 'lib', 'libmv2d_hip.so.sha256')).read().strip()
+    except OSError:
+        lib_sha = None
+    pmc_stale = bool(pmc) and pmc.get('_csrc_sha256') != lib_sha       # the counters were collected on other kernel sources than the library that runs
 
     def roof(name, kernel, ms, flops, nbytes, launches=1):
         """roofline object of one kernel: achieved = algorithmic flops / bytes of ONE launch over its duration (HIP events on the launch
@@ -424,7 +436,9 @@ def main():
         else:
             o.update(achieved=round(tf, 2), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s', frac=round(f_mfma, 4), hbm_frac=round(f_hbm, 4))
         o['traffic'] = (t['fetch_bytes'] + t['write_bytes']) if t else None
-        o['traffic_source'] = 'committed profile (profiles/pmc_traffic.json: rocprofv3 --pmc passes of this build, tools/pmc_bench.sh); not measured in this run' if t else None
+        o['traffic_source'] = ('committed profile (profiles/pmc_traffic.json: rocprofv3 --pmc passes, tools/pmc_bench.sh); not measured in this run' +
+                               ('; STALE: collected on other kernel sources than this library (csrc digest differs)' if pmc_stale else '; same csrc digest as this library')) if t else None
+        o['traffic_stale'] = pmc_stale if t else None
         o['traffic_detail'] = dict(t, source='profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)') if t else None
         return o
 
@@ -470,7 +484,7 @@ def main():
 
     # ---------------- the tile cross-attention kernel alone (HBM-bound gather): HIP events around 20 launches on the prepared buffers
     xattn = None
-    if getattr(eng, 'tile_attn', False):
+    if True:
         xk, xv = ws['xk_rows'], ws['xv_rows']
         q_ord = ws.get('q_order')                          # T path: blocks in the order of the queries' smallest key (as the engine launches it)
         xlo = dict(Xk_lo=ws['xk_lo'], Xv_lo=ws['xv_lo']) if (getattr(eng, 'exact', False) and ws.get('xk_lo') is not None) else {}      # index-exact route: hi + lo rows
@@ -482,10 +496,10 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         x_ms = e0.elapsed_time(e1) / 20
-        # algorithmic HBM bytes: every key row that some query reads, once (K and V, bf16) + Qt in + z out.  Rows read by several queries
+        # algorithmic HBM bytes: every key row that some query reads, once (K and V, key16 = 2 B per element) + Qt in + z out.  Rows read by several queries
         # (T path: 2.9 per row) are counted once here — the repeats are L2 / Infinity Cache traffic; `gathered_bytes` counts them all.
         n_rows = min(nnz, S if kind == 'T' else R * 49)
-        row_b = 2 * 256 * 2 * (2 if xlo else 1)                                     # K + V row, bf16 (index-exact route: hi + lo rows)
+        row_b = 2 * 256 * 2 * (2 if xlo else 1)                                     # K + V row, key16 (index-exact route: hi + lo rows)
         x_bytes = n_rows * row_b + R * (16 * 256 * 2 + 8 * 256 * 4)
         x_gathered = nnz * row_b + R * (16 * 256 * 2 + 8 * 256 * 4)
         x_flops = 2.0 * nnz * 8 * 256 * 2                                          # logits + P.V in the 256-dim input space, 8 heads
@@ -550,21 +564,39 @@ def main():
             except Exception as ex_:          # noqa: BLE001
                 other[wl_] = dict(value=None, error=repr(ex_)[:300])
 
+    coll_leg = None
+    if rank == 0 and world == 1 and not collective and not args.no_collective_leg:
+        # RCCL on the one GPU there is: the same step with the process group initialised (nccl, one rank) and the per-step all-gather of the
+        # decoded boxes in it (mv2d_amd.dist.gather_detections, what N > 1 ranks run), >= 200 steps under hipGraph replay, gathered == packed
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--workload', args.workload, '--batch', str(B), '--inflight', str(args.inflight),
+                                '--rotate', str(args.rotate), '--steps', str(max(200, args.steps)), '--warmup', '10', '--brief', '--force-collective', '--no-parity-leg'],
+                               cwd=ROOT, capture_output=True, text=True, timeout=300)
+            ls_ = [l for l in r.stdout.splitlines() if l.startswith('{')]
+            d_ = json.loads(ls_[-1])
+            coll_leg = dict(samples_s=d_.get('value'), steps=d_.get('steps'), ms_per_step=d_.get('ms_per_step'), check=d_.get('collective_check'),
+                            vs_value=round(d_['value'] / value, 4) if d_.get('value') else None)
+        except Exception as ex_:          # noqa: BLE001
+            coll_leg = dict(samples_s=None, error=repr(ex_)[:300])
+
     if rank == 0:
         line = {
             'metric': 'multi-view samples/sec (6-cam frames) through the MV2D RoI-head hot path',
             'value': round(value, 2), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'setup_steps': args.prime,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': ('bf16 hi + lo split precision on the key side (index-exact route) / bf16x3 (query side)' if args.exact else
-                      'bf16 (key side MFMA) / f32 + bf16x3 split precision (query side)'), 'data': 'synthetic', 'route': 'index_exact' if args.exact else 'default',
+            'dtype': (('%s hi + lo split precision on the key side (index-exact route) / bf16x3 (query side)' if args.exact else
+                       '%s (key side MFMA) / f32 + bf16x3 split precision (query side)') % ('f16' if ops.key16_dtype() == torch.float16 else 'bf16')), 'data': 'synthetic', 'route': 'index_exact' if args.exact else 'default',
             'config': {'workload': f'{args.workload}: MV2D-{kind} head, {len(metas)} views {metas[0]["img_shape"][1]}x{metas[0]["img_shape"][0]}, '
-                                   f'R={R} queries, S={S} key positions, nnz={nnz} allowed (q,k) pairs' + (f' (totals of the {B} samples of a launch)' if B > 1 else '') + (f', corr_topk={args.corr_topk}' if args.corr_topk else '') + (f', forced n_c={args.force_nc}' if args.force_nc else ''),
+                                   f'R={R} queries, S={S} key positions, nnz={nnz} allowed (q,k) pairs = {nnz / max(R, 1):.1f} keys per query' + (f' (totals of the {B} samples of a launch)' if B > 1 else '') + (f', corr_topk={args.corr_topk}' if args.corr_topk else '') + (f', forced n_c={args.force_nc}' if args.force_nc else ''),
                        'frames_per_step_per_gpu': args.inflight * B, 'global_batch': world * args.inflight * B,
-                       'streams_per_gpu': args.inflight, 'samples_per_launch': B, 'pe_sine_branch': 'folded into a per-(weights, geometry) table, FLOPs not counted' if SINE_TABLE else 'evaluated per frame (MV2D_PE_SINE_TABLE=0)',
+                       'streams_per_gpu': args.inflight, 'samples_per_launch': B, 'pe_sine_branch': 'folded into a per-(weights, geometry) table, FLOPs not counted',
                        'parallelism': f'dp{world}', 'hipgraph': use_graph},
             'decoder_ms_per_iter': round(decoder_ms / B, 4), 'decoder_ms_per_launch': round(decoder_ms, 4),
             'decoder_ms_per_iter_batch1': round(decoder_ms_b1, 4) if decoder_ms_b1 is not None else (round(decoder_ms, 4) if B == 1 else None),
             'long_run': long_run, 'other_workloads': other,
+            'collective_check': collective_check,
+            'samples_s_with_collective': coll_leg.get('samples_s') if coll_leg else None, 'collective_leg': coll_leg,
             'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},
             'roofline': roofline, 'stage_roofline': stage_roofline,
             'cpu_baseline': cpu, 'cpu_baseline_all_cores': cpu2,

@@ -25,6 +25,13 @@ extern "C" {
 
 const char* mv2d_last_error(void);
 int mv2d_abi_version(void);
+/* The 16-bit storage / MFMA operand format of the KEY SIDE ("key16": gathered key / value rows, RoI cells, PE-MLP operands + hidden layer and
+ * the weights those kernels read; csrc/common.h): 1 = IEEE fp16 (round 4: 11 significand bits, conversions saturate at +-65504), 0 = bf16 (a
+ * -DMV2D_KEY16_BF16 build).  Every `void*` below that is documented as key16 holds that format; the query side (bf16x3 split precision on fp32
+ * operands) and the generic tile GEMM mv2d_gemm_bf16 are bf16 in either build. */
+int mv2d_key16_format(void);
+/* fp32 -> key16: hi [n] = key16(x) and, when lo != NULL, lo [n] = key16(x - hi) (x ~ hi + lo: static weights of the key-side kernels) */
+int mv2d_f32_to_key16(const float* x, void* hi, void* lo, long long n, void* stream);
 int mv2d_device_arch(char* buf, int buflen);
 /* calibration kernel of the stream planner: one wave spinning for usec microseconds on `stream` (no reference counterpart) */
 int mv2d_spin(int usec, void* stream);
@@ -79,44 +86,35 @@ int mv2d_attn_out_fused(const float* ctx, const float* resid, const float* Wo, c
                         float* x_out, const float* qpos, const float* Wq, const float* bq, float qscale, float* q_out, int M, float eps,
                         void* stream);
 
-/* The position-encoding block of the PE module fused into one launch (MU/pe.py:36-48,64-77,150-166):
- *   pe = adapt_pos3d(A2) + position_encoder(A1) * sigmoid(conv_expand(relu(conv_reduce(Xf)))),  Xk = bf16(pe + Xf32)
- * A1 [M,192], A2 [M,384], Xfb [M,256] bf16 and Xf32 [M,256] fp32 rows (the outputs of mv2d_pe_inputs) -- or, with row_index != NULL,
- * Xf32 = the position-major feature map itself and row_index [M] = the map row of every key (mv2d_pe_inputs then need not copy the fp32
- * rows: its Xf_f32 output may be NULL); all six weights in the
- * FRAGMENT-MAJOR order of mv2d_pack_wfrag_bf16 (W1a [1024,192], W1b [256,1024], W2a [1024,384], W2b [256,1024], Wr/We [256,256]);
- * m_dev: optional device-side row count.  pe [M,256] fp32, Xk [M,256] bf16.  Bit-identical to the chain of six mv2d_gemm_bf16 calls. */
-int mv2d_pe_fused(const void* A1, const void* A2, const void* Xfb, const float* Xf32, const int* row_index, const int* m_dev, int M,
-                  const void* W1a, const float* b1a, const void* W1b, const float* b1b,
-                  const void* W2a, const float* b2a, const void* W2b, const float* b2b,
-                  const void* Wr, const float* br, const void* We, const float* be, float* pe, void* Xk, void* stream);
-
-/* Opt-in variant (not the default path, DESIGN.md section 8 "the sine branch is a constant"): the adapt_pos3d(sine) branch of the PE block
- * depends only on the weights and on the padding geometry, so it is read from sine_tab [tab_period][256] fp32 = adapt_pos3d(sine)(position)
- * + b2b, indexed by the key's map position (row_index[m], or m) modulo tab_period (= positions of one sample when the samples of a batch
- * share their geometry).  pe = position_encoder(A1) * gate + sine_tab[position].  Xk may be NULL (then Xf32 is not read either): the S path's
- * keys are RoI-aligned rows, it only needs pe; pe may be NULL when Xk is given: on the T path nothing reads pe. */
+/* The position-encoding block of the PE module as one launch (MU/pe.py:36-48,64-77,150-166; csrc/pe_tab96.hip):
+ *   pe = sine_tab[position] + position_encoder(A1) * sigmoid(conv_expand(relu(conv_reduce(Xf)))),  Xk = key16(pe + Xf32)
+ * The adapt_pos3d(sine) branch depends only on the weights and on the padding geometry, so it is read from sine_tab [tab_period][256] fp32 =
+ * adapt_pos3d(sine)(position) + b2b, indexed by the key's map position (row_index[m], or m) modulo tab_period (= positions of one sample when
+ * the samples of a batch share their geometry).  A1 [M,192], Xfb [M,256] key16 rows (mv2d_pe_inputs); Xf32 = fp32 feature rows [M,256] or,
+ * with row_index != NULL, the position-major feature map itself (row_index [M] = the map row of every key); the four weights key16 in the
+ * FRAGMENT-MAJOR order of mv2d_pack_wfrag_bf16 (W1a [1024,192], W1b [256,1024], Wr / We [256,256]); m_dev: optional device-side row count.
+ * Xk may be NULL (then Xf32 is not read either): the S path's keys are RoI-aligned rows, it only needs pe [M,256] fp32; pe may be NULL when
+ * Xk [M,256] key16 is given: on the T path nothing reads pe.  mv2d_pe_fused_tab2: the same with the block shape exposed (1 = 96 rows x 8 waves,
+ * the default; 0 = 64 rows x 4 waves, two blocks per CU; bit-identical). */
 int mv2d_pe_fused_tab(const void* A1, const void* Xfb, const float* Xf32, const int* row_index, const int* m_dev, int M,
                       const void* W1a, const float* b1a, const void* W1b, const float* b1b,
                       const void* Wr, const float* br, const void* We, const float* be,
                       const float* sine_tab, int tab_period, float* pe, void* Xk, void* stream);
+int mv2d_pe_fused_tab2(const void* A1, const void* Xfb, const float* Xf32, const int* row_index, const int* m_dev, int M,
+                       const void* W1a, const float* b1a, const void* W1b, const float* b1b,
+                       const void* Wr, const float* br, const void* We, const float* be,
+                       const float* sine_tab, int tab_period, float* pe, void* Xk, int shape, void* stream);
 
 /* QueryGenerator shared conv + pooling fused, one block per RoI (RH/utils/query_generator.py:298-304,322-331,352-358):
- * out[r, n] = mean over the 49 cells of relu(conv3x3(roi_feat[r])[cell, n] + bias[n]).  roi_feat [R,49,256] bf16 (cell-major),
- * Wp = the conv weight [256][tap][cin] (bf16, K = 2304) in FRAGMENT-MAJOR order as produced by mv2d_pack_wfrag_bf16 (weights are
+ * out[r, n] = mean over the 49 cells of relu(conv3x3(roi_feat[r])[cell, n] + bias[n]).  roi_feat [R,49,256] key16 (cell-major),
+ * Wp = the conv weight [256][tap][cin] (key16, K = 2304) in FRAGMENT-MAJOR order as produced by mv2d_pack_wfrag_bf16 (weights are
  * static: one fragment = one contiguous 1 KB load); out [R, ld_out] fp32.  Same k order as mv2d_gemm_bf16(a_mode = 1). */
 int mv2d_pack_wfrag_bf16(const void* W, void* Wp, int N, int K, void* stream);   /* Wp[K/32][N/16][64][8] <- W[N][K] */
 int mv2d_qg_conv_pool(const void* roi_feat, const void* W, const float* bias, float* out, int ld_out, int R, void* stream);
-/* The same in split precision (index-exact route): RoI cells as bf16 hi + lo pairs [R,49,256] (mv2d_roi_align_ex), weights as fragment-major
- * hi / lo copies of the [256, 2304] matrix (mv2d_split_bf16x2 + mv2d_pack_wfrag_bf16); products a_lo w_hi + a_hi w_lo + a_hi w_hi. */
+/* The same in split precision (index-exact route): RoI cells as key16 hi + lo pairs [R,49,256] (mv2d_roi_align_ex), weights as fragment-major
+ * key16 hi / lo copies of the [256, 2304] matrix (mv2d_f32_to_key16 + mv2d_pack_wfrag_bf16); products a_lo w_hi + a_hi w_lo + a_hi w_hi. */
 int mv2d_qg_conv_pool_x3(const void* roi_feat_hi, const void* roi_feat_lo, const void* W_hi, const void* W_lo, const float* bias, float* out,
                          int ld_out, int R, void* stream);
-
-/* K/V in_proj of all decoder layers, shape-specialised (K = 256): C = A . W^T + bias, bf16 in / bf16 out, same operand and
- * output-block conventions as mv2d_gemm_bf16 (A2 / n_split, m_dev, c_blk_stride / c_blk_cols) and bit-identical results.
- * A rows stay in registers, W streams through a 2-stage LDS ring filled by the LDS-DMA (MU/petr_transformer.py:503-508). */
-int mv2d_kv_proj(const void* A, const void* A2, int n_split, int lda, const void* W, const float* bias, int M, int N,
-                 const int* m_dev, void* C, int ldc, long long c_blk_stride, int c_blk_cols, void* stream);
 
 /* The same chain in split precision (bf16x3, ~1e-5 relative): Wo / Wq as bf16 hi/lo pairs (mv2d_split_bf16x2), each in the
  * fragment-major order of mv2d_pack_wfrag_bf16. */
@@ -165,8 +163,7 @@ int mv2d_heads_fused(const float* outs, const float* const* cls_w, const float* 
  * RH/utils/query_generator.py:359-381, first self-attention in_proj): LDS-tiled (A chunk shared by 8 column tiles, fragment-major
  * weights Whi / Wlo = mv2d_split_bf16x2 + mv2d_pack_wfrag_bf16 of W), act 1 = ReLU, clamp > 0 clamps to [-clamp, clamp];
  * columns >= n_split (multiple of 128) read A2 instead of A.  groups > 1: a batch of independent linears of the same shape in one
- * launch, group g at A + g*a_gs, W + g*w_gs, bias + g*b_gs, C + g*c_gs (element strides) -- e.g. the per-head maps of
- * mv2d_raw_xattn_fwd. */
+ * launch, group g at A + g*a_gs, W + g*w_gs, bias + g*b_gs, C + g*c_gs (element strides). */
 int mv2d_linear_x3(const float* A, const float* A2, int n_split, int lda, const void* Whi, const void* Wlo, const float* bias,
                    float* C, int ldc, int M, int N, int K, int act, float clamp, int groups, long long a_gs, long long w_gs,
                    long long b_gs, long long c_gs, void* stream);
@@ -178,9 +175,9 @@ int mv2d_linear_x3_ex(const float* A, const float* A2, int n_split, int lda, con
                       float* C, int ldc, int M, int N, int K, int act, float clamp, int groups, long long a_gs, long long w_gs,
                       long long b_gs, long long c_gs, const int* m_dev, int conv3x3, const float* mul, const float* add, int ld_ma,
                       void* stream);
-/* (hi, lo) bf16 pair of every element of a (+ b, optional): hi = bf16(x), lo = bf16(x - hi); a, b fp32 [M, cols]; rows >= *m_dev
+/* (hi, lo) key16 pair of every element of a (+ b, optional): hi = key16(x), lo = key16(x - hi); a, b fp32 [M, cols]; rows >= *m_dev
  * (optional) are not written.  The key / value rows of the index-exact route (key = feat + pe, value = feat). */
-int mv2d_split_rows_bf16x2(const float* a, const float* b, void* hi, void* lo, int M, int cols, const int* m_dev, void* stream);
+int mv2d_split_rows_key16(const float* a, const float* b, void* hi, void* lo, int M, int cols, const int* m_dev, void* stream);
 
 /* The same branches with their four 256x256 linears per (layer, branch) in split precision (bf16x3, ~1e-5 relative; the 256 -> 10
  * output layers stay exact fp32).  cls_w = {w0_hi,w0_lo,b0,ln1w,ln1b,w3_hi,w3_lo,b3,ln4w,ln4b,w6,b6}, reg_w = {w0_hi,w0_lo,b0,w2_hi,
@@ -206,12 +203,7 @@ int mv2d_ffn_fused(const float* X, const float* W1, const float* b1, const float
 int mv2d_ffn_fused_x3(const float* X, const void* W1hi, const void* W1lo, const float* b1, const void* W2hi, const void* W2lo,
                       float* slabs, int M, int hidden, int slices_per_block, void* stream);
 
-/* fp32-class GEMM on the bf16 matrix cores (split precision "bf16x3"): same contract as mv2d_gemm_f32 but the weights are
- * given as the bf16 pair Whi = bf16(W), Wlo = bf16(W - Whi) (see mv2d_split_bf16x2) and A is split on the fly;
- * relative error ~1e-5 instead of bit-exact fp32, 3/16 of the matrix-core time. */
-int mv2d_gemm_x3(const float* A, const float* A2, int n_split, const void* Whi, const void* Wlo, const float* bias, int M, int N,
-                 int K, int lda, int ldw, int split_k, int act, float scale, float clamp, void* C, int c_bf16, int ldc,
-                 long long c_slice_stride, int groups, long long a_gs, long long w_gs, long long b_gs, long long c_gs, void* stream);
+/* Whi = bf16(W), Wlo = bf16(W - Whi): the weight pairs of the bf16x3 (query-side) kernels */
 int mv2d_split_bf16x2(const float* x, void* hi, void* lo, long long n, void* stream);
 
 /* ---- row-wise ops on the [M,256] query state ------------------------------------------------------------- */
@@ -276,29 +268,20 @@ int mv2d_self_attn_dn_fwd(const float* qkv, float* ctx, int R, int dn_pad, int d
 int mv2d_sparse_xattn_fwd(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, float* ctx,
                           float* dbg_logits, long long dbg_stride, int R, int empty_nan, void* stream);
 
-/* The same attention in the INPUT space of the key / value projections: logits_h[j] = (Wk_h^T q_h) . x_j (+ a constant that cancels in the
- * softmax), ctx_h = Wv_h (sum_j p_hj v_j) + bv_h -- keys and values are never projected.  qk [R,8,256] fp32 = the per-head maps of the
- * pre-scaled query into the key input space (a grouped mv2d_linear_x3 with the transposed head slices of Wk), Xk / Xv [S,256] bf16 = the
- * UNPROJECTED key / value input rows (key + key_pos, key), shared by all layers; out z [R,8,256] fp32 = sum_j p_hj v_j per head (a
- * second grouped mv2d_linear_x3 with the head slices of Wv and bv gives ctx [R,256]).  Rows without an allowed key: NaN / 0 like
- * mv2d_sparse_xattn_fwd. */
-int mv2d_raw_xattn_fwd(const float* qk, const void* Xk, const void* Xv, const int* row_ptr, const int* col_idx, float* z, int R,
-                       int empty_nan, void* stream);
-
 /* ---- cross attention on MFMA tiles, K/V projections folded into the query side (the default route; csrc/xattn_tile.hip) ----
  * Replaces PETRMultiheadAttention's in_proj of key / value + attention core (MU/petr_transformer.py:426-513,
  * torch.nn.MultiheadAttention with attn_mask / key_padding_mask): no per-layer K/V is written.  Per layer three enqueues:
  *
- * mv2d_xattn_qmap: q [R,256] fp32 (query in_proj output, pre-scaled by 1/sqrt(32)) -> Qt [R][8][64][8] bf16: the per-head maps
- *   Wk_h^T q_h of the query into the 256-dim key INPUT space as a 16 x 256 MFMA operand per query (rows 0-7: bf16 hi parts of
- *   the 8 heads, rows 8-15: lo remainders), fragment-major.  WA_hi / WA_lo = the packed key in_proj weight
+ * mv2d_xattn_qmap: q [R,256] fp32 (query in_proj output, pre-scaled by 1/sqrt(32)) -> Qt [R][8][64][8] key16: the per-head maps
+ *   Wk_h^T q_h of the query into the 256-dim key INPUT space as a 16 x 256 MFMA operand per query (rows 0-7: key16 hi parts of
+ *   the 8 heads, rows 8-15: lo remainders), fragment-major.  (The map itself is a bf16x3 product; its result is stored in the key-side format.)  WA_hi / WA_lo = the packed key in_proj weight
  *   (mv2d_amd.ops.pack_xattn_maps: [8 heads][16 tiles][64 lanes][8] bf16, layout in csrc/xattn_tile.hip).
- * mv2d_xattn_tile_fwd: one block per query; Xk / Xv [S,256] bf16 = the UNPROJECTED key / value input rows (key + key_pos, key)
+ * mv2d_xattn_tile_fwd: one block per query; Xk / Xv [S,256] key16 = the UNPROJECTED key / value input rows (key + key_pos, key)
  *   shared by all layers and heads; CSR row_ptr [R+1] / col_idx [nnz]; z [R,8,256] fp32 = sum_j p_hj v_j per head.  Key tiles of
- *   16 rows are gathered with whole-row coalesced loads into swizzled LDS tiles, logits and P.V run on bf16 MFMAs (hi / lo split
+ *   16 rows are gathered with whole-row coalesced loads into swizzled LDS tiles, logits and P.V run on key16 (fp16) MFMAs (hi / lo split
  *   of the query map and of P: fp32-class on the query side), online softmax.  waves = 1 | 2 | 4 | 8 waves per query (0: default = 2).
  *   The row arrays are addressed with 32-bit byte offsets: fewer than 2^23 rows (4 GB) each.
- *   Xk_lo / Xv_lo (both or neither, may be NULL): bf16 remainders of the rows (rows = Xk + Xk_lo): the fp32-class key side of the
+ *   Xk_lo / Xv_lo (both or neither, may be NULL): key16 remainders of the rows (rows = Xk + Xk_lo): the fp32-class key side of the
  *   engine's index-exact validation mode.  Rows without an allowed key: z = NaN (empty_nan = 1) or 0.  dbg_logits (optional): head h at dbg_logits[h*dbg_stride + e],
  *   e in CSR order, WITHOUT the per-(query, head) constant q_h . bk_h that cancels in the softmax.
  * mv2d_xattn_ctxmap: ctx [R,256] = Wv_h z_h + bv (bf16x3; WB_hi / WB_lo = the packed value in_proj weight); rows without an
@@ -306,7 +289,7 @@ int mv2d_raw_xattn_fwd(const float* qk, const void* Xk, const void* Xv, const in
 int mv2d_xattn_qmap(const float* q, const void* WA_hi, const void* WA_lo, void* Qt, int R, void* stream);
 int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                         const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves, void* stream);
-/* The same with a block -> query order (order [R]: a permutation of the query rows, e.g. mv2d_xattn_qtile_build's perm = the queries of every
+/* The same with a block -> query order (order [R]: a permutation of the query rows, e.g. mv2d_xattn_query_order's perm = the queries of every
  * sample sorted by their smallest key): neighbouring blocks then read overlapping key sets and share an L2.  Results are identical. */
 int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                 const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
@@ -319,27 +302,9 @@ int mv2d_xattn_tile_fwd_ex(const void* Qt, const void* Xk, const void* Xv, const
 int mv2d_xattn_ctxmap(const float* z, const void* WB_hi, const void* WB_lo, const float* bv, const int* row_ptr, float* ctx, int R,
                       int empty_nan, void* stream);
 
-/* T path (masked-map cross attention, RH/mv2d_t_head.py:79-109): the same attention with SHARED KEY TILES -- one workgroup per tile of 16
- * queries, the union of the tile's key lists streamed once through LDS, 16-bit masks per (query, 16-key union tile) (csrc/xattn_qtile.hip).
- * mv2d_xattn_qtile_build (once per frame, after mv2d_mask_compact on the same stream): orders the queries of every sample by their
- * smallest key index (perm [R]), cuts the order into tiles (tile_q0 / tile_qn [max_tiles], *n_tiles on the device) and writes per tile the
- * ascending union key list (ukeys + uptr / ucnt, padded to multiples of 16; ucap = capacity in keys, a multiple of 16, >= nnz + 16 max_tiles)
- * and the pair masks (qmask: ucap / 16 * queries_per_tile / 2 dwords; queries_per_tile = 8 (4 waves per workgroup) or 16 (8 waves)).  bits / nwords / rect / pos2s: the per-query cell bitmasks and tables mv2d_mask_compact
- * left in its workspace; grp_start [n_samples + 1] = first query row of every sample (rows behind the last sample: bucket padding, tiled
- * as a group of their own).  alloc / flags: device int32 words the caller zeroes per frame; flags[0] != 0 afterwards = a capacity was
- * exceeded (more than 8192 distinct keys in one query tile, more than 4096 queries in a sample, ucap).
- * mv2d_xattn_qtile_fwd: z [R][8][256] like mv2d_xattn_tile_fwd (same Qt / Xk / Xv operands); differs from it in the order of the fp32 sums only. */
-long long mv2d_xattn_qtile_max_tiles(int R, int n_samples, int queries_per_tile /* 8 or 16 */);
-/* The query order alone: perm [R] = the rows of every sample sorted by their smallest key index (CSR rows ascending, as mv2d_mask_compact writes
+/* T path (masked-map cross attention, RH/mv2d_t_head.py:79-109), launch order of the per-query blocks (csrc/xattn_order.hip): perm [R] = the rows of every sample sorted by their smallest key index (CSR rows ascending, as mv2d_mask_compact writes
  * them); flags[0] != 0: more than 4096 queries in a sample (natural order kept).  For mv2d_xattn_tile_fwd_ordered. */
 int mv2d_xattn_query_order(const int* row_ptr, const int* col_idx, const int* grp_start, int n_samples, int R, int* perm, int* flags, void* stream);
-int mv2d_xattn_qtile_build(const int* row_ptr, const int* col_idx, const int* grp_start, int n_samples, int R, const void* bits, int nwords,
-                           const int* rect, int V, int cells_per_sample, const int* pos2s, int* perm, int* tile_q0, int* tile_qn, int* n_tiles,
-                           int* uptr, int* ucnt, int* ukeys, int ucap, void* qmask, int* alloc, int* flags, int queries_per_tile, void* stream);
-int mv2d_xattn_qtile_fwd(const void* Qt, const void* Xk, const void* Xv, const int* perm, const int* tile_q0, const int* tile_qn,
-                         const int* n_tiles, const int* uptr, const int* ucnt, const int* ukeys, const void* qmask, float* z, int R,
-                         int n_samples, int empty_nan, int queries_per_tile, void* stream);
-
 /* The two row kernels around the tile cross attention with its per-head maps fused in (one launch each instead of two; bitwise the
  * same results):
  * mv2d_attn_out_qmap_x3 = mv2d_attn_out_fused_x3 (out_proj + residual + LayerNorm of the self attention, cross-attention q projection)
@@ -394,12 +359,12 @@ int mv2d_lidar2img_inverse(const double* K_roi, const double* E, float* minv, in
 int mv2d_posemb3d(const float* ref, const float* dim_t, float* posemb, int R, void* stream);
 
 /* mmcv.ops.RoIAlign(7, 1/16, sampling_ratio, 'avg', aligned=True) (call site RH/mv2d_head.py:114-115) on one or two
- * position-major maps -> [R,49,256] bf16 and/or fp32 per map.  map1_index (optional): map1 is row-compacted, row of
- * position p is map1_index[p].  out1_is_sum: out1 = bf16(map0 value + map1 value) (the S-path key input feat + pe). */
+ * position-major maps -> [R,49,256] key16 and/or fp32 per map.  map1_index (optional): map1 is row-compacted, row of
+ * position p is map1_index[p].  out1_is_sum: out1 = key16(map0 value + map1 value) (the S-path key input feat + pe). */
 int mv2d_roi_align(const float* map0, const float* map1, const float* rois, void* out0, void* out1, float* out0_f32,
                    float* out1_f32, int R, int H, int W, int channels, float spatial_scale, int sampling_ratio,
                    const int* map1_index, int out1_is_sum, void* stream);
-/* mv2d_roi_align with bf16 REMAINDER outputs: out0_lo / out1_lo = bf16(x - bf16(x)) next to out0 / out1 (x ~ hi + lo, 2^-17 relative):
+/* mv2d_roi_align with key16 REMAINDER outputs: out0_lo / out1_lo = key16(x - key16(x)) next to out0 / out1 (x ~ hi + lo, ~2^-22 relative):
  * the fp32-class key / value / conv-input rows of the index-exact route. */
 int mv2d_roi_align_ex(const float* map0, const float* map1, const float* rois, void* out0, void* out1, float* out0_f32, float* out1_f32,
                       int R, int H, int W, int channels, float spatial_scale, int sampling_ratio, const int* map1_index, int out1_is_sum,
@@ -433,13 +398,13 @@ int mv2d_roi_positions(const float* rois, const unsigned char* pad_mask, unsigne
 int mv2d_csr_from_corr(const int* match, int* row_ptr, int* col_idx, int* nnz_out, int R, int V, int topk, void* stream);
 
 /* PE inputs at the listed key positions only (MU/pe.py:84-135 frustum, MU/positional_encoding.py:78-95 sine) + feature gather.
- * out: A_frustum [S,3*D] bf16, A_sine [S,384] bf16, Xf_bf16 [S,256], Xf_f32 [S,256] (optional: NULL when mv2d_pe_fused reads the map).
+ * out: A_frustum [S,3*D] key16, A_sine [S,384] key16, Xf_k16 [S,256] key16, Xf_f32 [S,256] (optional: NULL when mv2d_pe_fused_tab reads the map).
  * A_sine may be NULL (the sine branch of the PE block comes from the engine's folded table: the row is not produced).
  * A_frustum_f32 / A_sine_f32 (optional, the engine's index-exact validation mode): the same rows unrounded, with the logarithm in
  * fp64 and library sin / cos. */
 int mv2d_pe_inputs(const int* s2pos, const int* S_dev, int S_max, const float* featcl, const double* img2lidar,
                    const double* coords_w, const double* coords_h, const double* coords_d, const float* embeds,
-                   const float* dim_t, void* A_frustum, void* A_sine, void* Xf_bf16, float* Xf_f32, float* A_frustum_f32,
+                   const float* dim_t, void* A_frustum, void* A_sine, void* Xf_k16, float* Xf_f32, float* A_frustum_f32,
                    float* A_sine_f32, int V, int h, int w, int depth_num, const double* position_range, void* stream);
 
 /* NMSFreeCoder.decode_single + get_bboxes (CB/coders/nms_free_coder.py:49-102, CB/util.py:60-87,
@@ -501,11 +466,8 @@ int mv2d_dn_queries(const float* gt, const int* gt_labels, const float* rnd, int
                     int num_classes, const float* pc_range_host, float eps, float* ref, long long* labels, float* boxes, void* stream);
 
 /* ---- dense building blocks of the training route (csrc/train_ops.hip) ----------------------------------------------------
- * Every product of a linear layer's forward and backward is C = A B^T on the bf16 tile GEMM (mv2d_gemm_bf16_ex) in split precision by
- * K-concatenation; mv2d_split3_operand builds the operands: dst [rows_out, 3 k_pad] bf16 from the fp32 matrix src (row stride ld), read as
- * is ([rows, k]) or TRANSPOSED (src is [k, rows]), zero-padded to rows_out x k_pad; side 0 = A operand [hi | lo | hi], side 1 = B operand
- * [hi | hi | lo].  forward y = x W^T: A = x, B = W; dx = dy W: A = dy, B = W transposed; dW = dy^T x: A = dy transposed, B = x transposed. */
-int mv2d_split3_operand(const float* src, long long ld, int rows, int k, int transpose, void* dst, int rows_out, int k_pad, int side, void* stream);
+ * Every product of a linear layer's forward and backward runs on mv2d_gemm_f32x3 (below): forward y = x W^T, dx = dy W (W transposed),
+ * dW = dy^T x (both operands transposed).  (mv2d_split3_operand / mv2d_matmul_nt_x3, round 3's first build on operand images, are retired.) */
 /* out [cols] = column sums of x [rows, cols] (row stride ld), fixed summation order (bias gradients, split-K slabs).  Long matrices are summed
  * in two passes through scratch [mv2d_colsum_scratch_rows(rows), cols] (0 rows: not needed; NULL: one pass). */
 int mv2d_colsum_scratch_rows(int rows);
@@ -515,16 +477,10 @@ int mv2d_colsum(const float* x, long long ld, int rows, int cols, float* out, fl
 int mv2d_layer_norm_bwd_blocks(int M);
 int mv2d_layer_norm_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw_part, float* db_part, float* dw, float* db, int M,
                         float eps, void* stream);
-/* Composite entries: the whole launch sequence of one split-precision product / of one linear layer's backward per call, on a caller-provided
- * workspace (256-byte aligned, >= the _ws_bytes of the shape), so that a training step is not bound by per-launch host time.
- * mv2d_matmul_nt_x3: C [M, ldc] fp32 = act(op(A) op(B)^T + bias), A [M,K] (trans_a: [K,M]), B [N,K] (trans_b: [K,N]) fp32 with row strides
- * lda / ldb, bias [N] or NULL, act 0 / 1 (ReLU); ldc >= N rounded up to 8 (the pad columns are written).  Operand split, GEMM, split-K slabs
- * and their fixed-order sum as in the single entries above (nn.Linear / mmcv FFN forward and backward, MU/petr_transformer.py:195-311).
- * mv2d_linear_bwd_x3: backward of y = act(x W^T + b): g = dy masked by y > 0 (y NULL: no activation); dx [M,K] = g W, dW [N,K] =
- * g^T x (both on mv2d_gemm_f32x3), db [N] = column sums of g; each output optional (NULL). */
-long long mv2d_matmul_nt_x3_ws_bytes(int M, int N, int K);
-int mv2d_matmul_nt_x3(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act, float* C,
-                      int ldc, int M, int N, int K, void* ws, long long ws_bytes, void* stream);
+/* Composite entry: the whole launch sequence of one linear layer's backward per call, on a caller-provided workspace (256-byte aligned, >=
+ * mv2d_linear_bwd_x3_ws_bytes of the shape), so that a training step is not bound by per-launch host time.
+ * mv2d_linear_bwd_x3: backward of y = act(x W^T + b): g = dy masked by y > 0 (y NULL: no activation; dense [M,N] rows, any alignment); dx [M,K] =
+ * g W, dW [N,K] = g^T x (both on mv2d_gemm_f32x3), db [N] = column sums of g; each output optional (NULL). */
 /* Split-precision product on fp32 operands read IN PLACE in either orientation (csrc/gemm_f32x3.hip): C [M, ldc] = act(op(A) op(B)^T + bias),
  * op(X) = X^T when trans_x; operands are split into bf16 hi / lo while a tile is staged into LDS (a transposed operand through a register
  * transpose), three MFMAs per k-step; split-K slabs + their fixed-order sum in `ws` (mv2d_gemm_f32x3_ws_bytes; 256-byte aligned; optional). */

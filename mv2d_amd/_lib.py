@@ -26,12 +26,14 @@ SIGNATURES = {
     'mv2d_gemm_bf16': (I, [P, P, I, I, P, P, I, I, I, I, P, I, P, I, P, I, P, I, I, LL, I, P, P, I, I, P]),
     'mv2d_gemm_bf16_ex': (I, [P, P, I, I, P, P, I, I, I, I, P, I, P, I, P, I, P, I, I, LL, I, P, P, I, I, I, P, I, I, LL, P]),
     'mv2d_split3_rows': (I, [P, P, P, I, I, P, P]),
-    'mv2d_pe_fused': (I, [P, P, P, P, P, P, I] + [P] * 14 + [P]),
     'mv2d_pe_fused_tab': (I, [P, P, P, P, P, I] + [P] * 9 + [I, P, P, P]),
+    'mv2d_pe_fused_tab2': (I, [P, P, P, P, P, I] + [P] * 9 + [I, P, P, I, P]),
+    'mv2d_key16_format': (I, []),
+    'mv2d_f32_to_key16': (I, [P, P, P, LL, P]),
+    'mv2d_split_rows_key16': (I, [P, P, P, P, I, I, P, P]),
     'mv2d_qg_conv_pool': (I, [P, P, P, P, I, I, P]),
     'mv2d_qg_conv_pool_x3': (I, [P, P, P, P, P, P, I, I, P]),
     'mv2d_pack_wfrag_bf16': (I, [P, P, I, I, P]),
-    'mv2d_kv_proj': (I, [P, P, I, I, P, P, I, I, P, P, I, LL, I, P]),
     'mv2d_gemm_f32': (I, [P, P, I, P, P, I, I, I, I, I, I, I, F, F, P, I, I, LL, I, LL, LL, LL, LL, P]),
     'mv2d_attn_out_fused': (I, [P, P, P, P, P, P, P, P, P, P, F, P, I, F, P]),
     'mv2d_sa_block_fused_x3': (I, [P, P, P, P, P, P, P, P, P, P, P, P, F, P, I, F, P]),
@@ -42,12 +44,10 @@ SIGNATURES = {
     'mv2d_heads_fused': (I, [P, P, P, P, P, P, I, I, F, P, F, P, P]),
     'mv2d_linear_x3': (I, [P, P, I, I, P, P, P, P, I, I, I, I, I, F, I, LL, LL, LL, LL, P]),
     'mv2d_linear_x3_ex': (I, [P, P, I, I, P, P, P, P, I, I, I, I, I, F, I, LL, LL, LL, LL, P, I, P, P, I, P]),
-    'mv2d_split_rows_bf16x2': (I, [P, P, P, P, I, I, P, P]),
     'mv2d_heads_fused_x3': (I, [P, P, P, P, P, P, I, I, F, P, F, P, P]),
     'mv2d_ffn_fused': (I, [P, P, P, P, P, I, I, P]),
     'mv2d_ffn_pack_weights': (I, [P, P, P, P, I, P]),
     'mv2d_ffn_fused_x3': (I, [P, P, P, P, P, P, P, I, I, I, P]),
-    'mv2d_gemm_x3': (I, [P, P, I, P, P, P, I, I, I, I, I, I, I, F, F, P, I, I, LL, I, LL, LL, LL, LL, P]),
     'mv2d_split_bf16x2': (I, [P, P, P, LL, P]),
     'mv2d_row_ln': (I, [P, I, LL, P, P, P, P, I, P, P, P, P, P, P, I, F, I, P]),
     'mv2d_finalize_reg': (I, [P, P, I, I, P, F, P]),
@@ -61,7 +61,6 @@ SIGNATURES = {
     'mv2d_self_attn_x3_fwd': (I, [P, P, I, P, I, I, I, I, P]),
     'mv2d_dn_queries': (I, [P, P, P, I, I, F, F, F, I, P, F, P, P, P, P]),
     'mv2d_sparse_xattn_fwd': (I, [P, P, P, P, P, P, P, LL, I, I, P]),
-    'mv2d_raw_xattn_fwd': (I, [P, P, P, P, P, P, I, I, P]),
     'mv2d_sparse_xattn_bwd': (I, [P] * 14 + [I, I, P]),
     'mv2d_sparse_xattn_fwd_drop': (I, [P, P, P, P, P, P, P, LL, I, I, F, C.c_uint, P]),
     'mv2d_sparse_xattn_bwd_drop': (I, [P] * 14 + [I, I, F, C.c_uint, P]),
@@ -72,9 +71,6 @@ SIGNATURES = {
     'mv2d_xattn_tile_fwd_ex': (I, [P, P, P, P, P, P, P, P, P, LL, I, I, I, P, I, P]),
     'mv2d_xattn_tile_fwd_ordered': (I, [P, P, P, P, P, P, P, P, P, LL, I, I, I, P, P]),
     'mv2d_xattn_query_order': (I, [P, P, P, I, I, P, P, P]),
-    'mv2d_xattn_qtile_max_tiles': (LL, [I, I, I]),
-    'mv2d_xattn_qtile_build': (I, [P, P, P, I, I, P, I, P, I, I, P, P, P, P, P, P, P, P, I, P, P, P, I, P]),
-    'mv2d_xattn_qtile_fwd': (I, [P] * 12 + [I, I, I, I, P]),
     'mv2d_xattn_ctxmap': (I, [P, P, P, P, P, P, I, I, P]),
     'mv2d_box_params': (I, [P, P, P, P, P, I, P, I, F, F, F, P]),
     'mv2d_refpoint_posemb': (I, [P, I, P, P, P, P, P, I, P, P]),
@@ -92,11 +88,8 @@ SIGNATURES = {
     'mv2d_nms_bev': (I, [P, P, P, P, F, P, I, I, P]),
     'mv2d_pack_detections': (I, [P, P, P, P, P, I, I, I, P]),
     'mv2d_roi_align_bwd': (I, [P, P, P, P, I, I, I, I, F, I, P]),
-    'mv2d_split3_operand': (I, [P, LL, I, I, I, P, I, I, I, P]),
     'mv2d_colsum_scratch_rows': (I, [I]),
     'mv2d_colsum': (I, [P, LL, I, I, P, P, P]),
-    'mv2d_matmul_nt_x3_ws_bytes': (LL, [I, I, I]),
-    'mv2d_matmul_nt_x3': (I, [P, LL, I, P, LL, I, P, I, P, I, I, I, I, P, LL, P]),
     'mv2d_gemm_f32x3_ws_bytes': (LL, [I, I, I]),
     'mv2d_gemm_f32x3': (I, [P, LL, I, P, LL, I, P, I, P, LL, I, I, I, P, LL, P]),
     'mv2d_linear_bwd_x3_ws_bytes': (LL, [I, I, I]),

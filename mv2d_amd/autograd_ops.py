@@ -2,14 +2,14 @@
 
 The reference trains the head in fp32 under torch autograd (``nn.Linear`` / ``nn.LayerNorm`` / mmcv ``FFN`` inside
 MU/petr_transformer.py:195-311 and RH/bbox_heads/cross_attention_head.py:118-142).  Here every matrix product of the forward AND the backward
-pass is C = A B^T on ``mv2d_gemm_bf16_ex`` in split precision by K-concatenation (csrc/train_ops.hip, ~1e-5 relative, i.e. fp32-class), the
-layer norms run on ``mv2d_row_ln`` / ``mv2d_layer_norm_bwd``, bias gradients on ``mv2d_colsum``: no rocBLAS / MIOpen kernel is launched.
+pass is C = op(A) op(B)^T on ``mv2d_gemm_f32x3`` (csrc/gemm_f32x3.hip: the fp32 operands are read in place in either orientation and split into
+bf16 hi / lo while they are staged into LDS, three MFMAs per product, ~1e-5 relative, i.e. fp32-class), a linear layer's whole backward is one
+``mv2d_linear_bwd_x3`` call, the layer norms run on ``mv2d_row_ln`` / ``mv2d_layer_norm_bwd``, bias gradients on ``mv2d_colsum``: no rocBLAS /
+MIOpen kernel is launched.
 PyTorch supplies the autograd graph, the element-wise glue (residual adds, dropout masks, ReLU masks) and the parameter containers.
 
 No CPU path: tensors must live on the GPU.
 """
-import os
-
 import torch
 
 from . import _lib, ops
@@ -32,21 +32,6 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _pad(n, m):
-    return -(-n // m) * m
-
-
-def split3_operand(src, transpose, rows_out, k_pad, side):
-    """fp32 2-D ``src`` (any row stride, unit column stride) -> bf16 [rows_out, 3 * k_pad]: op(src) zero-padded, op = transpose or identity;
-    side 0 = [hi | lo | hi] (A operand), 1 = [hi | hi | lo] (B operand)."""
-    assert src.dtype == F32 and src.dim() == 2 and src.is_cuda and src.stride(1) == 1
-    rows, k = (src.shape[1], src.shape[0]) if transpose else src.shape
-    out = torch.empty((rows_out, 3 * k_pad), device=src.device, dtype=BF16)
-    check(_lib.load().mv2d_split3_operand(_p(src), src.stride(0), rows, k, 1 if transpose else 0, _p(out), rows_out, k_pad, side, _stream()),
-          'mv2d_split3_operand')
-    return out
-
-
 _WS = {}
 
 
@@ -60,8 +45,8 @@ def _workspace(nbytes, device):
 
 
 def matmul_nt(A, B, bias=None, act=0, trans_a=False, trans_b=False):
-    """C = act(op(A) op(B)^T + bias) in fp32-class split precision on the bf16 tile GEMM; op(X) = X^T when trans_x.  A, B fp32 2-D; bias [N].
-    One C call (``mv2d_gemm_f32x3``: fp32 operands read in place in either orientation, split while staged into LDS; split-K for few output
+    """C = act(op(A) op(B)^T + bias) in fp32-class split precision (bf16 hi / lo, three MFMAs per product); op(X) = X^T when trans_x.  A, B fp32
+    2-D; bias [N].  One C call (``mv2d_gemm_f32x3``: fp32 operands read in place in either orientation, split while staged into LDS; split-K for few output
     tiles with a long contraction, slabs summed in fixed order)."""
     A = A if A.stride(-1) == 1 else A.contiguous()
     B = B if B.stride(-1) == 1 else B.contiguous()
@@ -72,13 +57,6 @@ def matmul_nt(A, B, bias=None, act=0, trans_a=False, trans_b=False):
     if M == 0 or N == 0 or K == 0:
         return torch.zeros((M, N), device=A.device, dtype=F32)
     lib = _lib.load()
-    if os.environ.get('MV2D_TRAIN_GEMM', 'f32x3') == 'kcat':       # A/B switch: the round-3 first build (operand images in HBM + the bf16 tile GEMM)
-        Np = _pad(N, 8)
-        out = torch.empty((M, Np), device=A.device, dtype=F32)
-        ws = _workspace(int(lib.mv2d_matmul_nt_x3_ws_bytes(M, N, K)), A.device)
-        check(lib.mv2d_matmul_nt_x3(_p(A), A.stride(0), 1 if trans_a else 0, _p(B), B.stride(0), 1 if trans_b else 0, _p(bias), act, _p(out), Np, M, N, K,
-                                    _p(ws), ws.numel(), _stream()), 'mv2d_matmul_nt_x3')
-        return out if Np == N else out[:, :N]
     out = torch.empty((M, N), device=A.device, dtype=F32)
     nb = int(lib.mv2d_gemm_f32x3_ws_bytes(M, N, K))
     ws = _workspace(nb, A.device) if nb else None

@@ -253,151 +253,8 @@ __global__ __launch_bounds__(64 * NW) void sparse_xattn_kernel(const float* __re
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Cross attention in the INPUT space of the key / value projections ("raw rows").
-//   logits_h[j] = q_h . K_h[j] = q_h . (Wk_h x_j + bk_h) = (Wk_h^T q_h) . x_j + const        (the constant cancels in the softmax)
-//   ctx_h = sum_j p_hj (Wv_h v_j + bv_h) = Wv_h (sum_j p_hj v_j) + bv_h                      (sum_j p_hj = 1)
-// so the keys and values never have to be projected: the query is mapped into the 256-dim input space per head (qk [R, 8, 256],
-// one small grouped linear), attention runs on the UNPROJECTED rows x_j (Xk) / v_j (Xv) -- the same two bf16 arrays for all six
-// layers and all heads -- and returns z [R, 8, 256] = sum_j p_hj v_j, which a second grouped linear maps to ctx.  The K/V projection
-// of all layers (the largest writer of the pipeline: 90 MB per sample) and its read-back disappear; the price is 8 x 256 instead of
-// 8 x 32 multiply-adds per (query, key) and side.
-// One 4-wave block per query; the key tiles (16 keys) are dealt round robin to the waves.  Per tile: S^T[key][head] = Xk_tile . qk^T
-// on bf16 MFMAs (qk split hi/lo: fp32-class logits; A fragments = 16 key rows straight from global memory), softmax statistics per
-// head across the tile (4 values per lane + 2 shuffles), P through 512 B of wave-private LDS, then z += P^T . Xv_tile on the VALU
-// (lane l owns channels 4l..4l+3 of all 8 heads: 32 accumulators, 32 FMAs per key).  Partial (m, l, z) of the waves merge through LDS.
-// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float4 bf16x4(const uint2 u) {
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
-}
-typedef __attribute__((ext_vector_type(8))) __bf16 xa_bf16x8;
-union XFrag { uint4 u; xa_bf16x8 v; };
-
-__device__ __forceinline__ void xa_split8(const float4& x0, const float4& x1, XFrag& hi, XFrag& lo) {
-    const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-    unsigned int h[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        h[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
-        l[i] = pack_bf16x2(f[2 * i] - __uint_as_float(h[i] << 16), f[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
-    }
-    hi.u = make_uint4(h[0], h[1], h[2], h[3]);
-    lo.u = make_uint4(l[0], l[1], l[2], l[3]);
-}
-
-__global__ __launch_bounds__(256) void raw_xattn_kernel(const float* __restrict__ qk, const unsigned short* __restrict__ Xk,
-                                                        const unsigned short* __restrict__ Xv, const int* __restrict__ row_ptr,
-                                                        const int* __restrict__ col_idx, float* __restrict__ z, int R, int empty_nan) {
-    __shared__ __attribute__((aligned(16))) float pl[4][16][8];          // P of the current tile per wave: [key][head]
-    __shared__ __attribute__((aligned(16))) float al[4][8];              // rescale factor of the running z per wave and head
-    __shared__ float sm[4][8], sl[4][8];
-    __shared__ __attribute__((aligned(16))) float sz[4][8][C];           // merge: z partials [wave][head][channel]
-    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-    const int beg = row_ptr[r], end = row_ptr[r + 1], n = end - beg;
-    if (n <= 0) {
-        const float v = empty_nan ? __uint_as_float(0x7fc00000u) : 0.f;
-#pragma unroll
-        for (int h = 0; h < 8; ++h) z[(long long)r * (8 * C) + h * C + tid] = v;
-        return;
-    }
-    // B operand: qk of head (fr & 7) (columns 8..15 of the tile repeat the 8 heads and are ignored), split hi / lo
-    XFrag qh[8], ql[8];
-    {
-        const float* qp = qk + (long long)r * (8 * C) + (fr & 7) * C + 8 * fg;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) xa_split8(*reinterpret_cast<const float4*>(qp + 32 * s), *reinterpret_cast<const float4*>(qp + 32 * s + 4), qh[s], ql[s]);
-    }
-    float m_run = -INFINITY, l_run = 0.f;                                // of head fr & 7 (identical in the lanes sharing fr & 7)
-    float4 zacc[8];
-#pragma unroll
-    for (int h = 0; h < 8; ++h) zacc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int ntile = (n + 15) >> 4;
-    for (int t = wave; t < ntile; t += 4) {
-        const int kbase = beg + 16 * t;
-        const int idx = col_idx[min(kbase + fr, end - 1)];               // lane (fr, *) : key row fr of the tile
-        // ---- logits of the tile: S^T[key][head]
-        f32x4_t sv = {0.f, 0.f, 0.f, 0.f};
-        {
-            const unsigned short* kp = Xk + (long long)idx * C + 8 * fg;
-            XFrag a[8];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) a[s].u = *reinterpret_cast<const uint4*>(kp + 32 * s);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s].v, qh[s].v, sv, 0, 0, 0);
-                sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s].v, ql[s].v, sv, 0, 0, 0);
-            }
-        }
-        // the value rows of the tile: requested now, used after the softmax (lane l: channels 4l..4l+3 of every key row)
-        uint2 xv[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const long long row = (long long)__builtin_amdgcn_readlane(idx, j) * C + 4 * lane;
-            xv[j] = *reinterpret_cast<const uint2*>(Xv + row);
-        }
-        // ---- softmax statistics of head fr over the 16 keys: this lane holds keys 4 fg + i
-        float lg[4], tmax = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            lg[i] = (kbase + 4 * fg + i < end) ? sv[i] : -INFINITY;
-            tmax = fmaxf(tmax, lg[i]);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = expf(m_run - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { lg[i] = expf(lg[i] - m_new); psum += lg[i]; }
-        psum += __shfl_xor(psum, 16, 64);
-        psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-        if (fr < 8) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pl[wave][4 * fg + i][fr] = lg[i];
-            if (fg == 0) al[wave][fr] = alpha;
-        }
-        __builtin_amdgcn_wave_barrier();                                 // P / alpha are read back by the same wave only
-        // ---- z = alpha z + P^T . Xv_tile
-        {
-            const float4 a0 = *reinterpret_cast<const float4*>(&al[wave][0]), a1 = *reinterpret_cast<const float4*>(&al[wave][4]);
-            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-            for (int h = 0; h < 8; ++h) { zacc[h].x *= av[h]; zacc[h].y *= av[h]; zacc[h].z *= av[h]; zacc[h].w *= av[h]; }
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (kbase + j < end) {                                       // (uniform)
-                const float4 x = bf16x4(xv[j]);
-                const float4 p0 = *reinterpret_cast<const float4*>(&pl[wave][j][0]), p1 = *reinterpret_cast<const float4*>(&pl[wave][j][4]);
-                const float pv[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-#pragma unroll
-                for (int h = 0; h < 8; ++h) {
-                    zacc[h].x = fmaf(pv[h], x.x, zacc[h].x); zacc[h].y = fmaf(pv[h], x.y, zacc[h].y);
-                    zacc[h].z = fmaf(pv[h], x.z, zacc[h].z); zacc[h].w = fmaf(pv[h], x.w, zacc[h].w);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();                                 // before the next tile overwrites P
-    }
-    // ---- merge the waves
-    if (fr < 8 && fg == 0) { sm[wave][fr] = m_run; sl[wave][fr] = l_run; }
-#pragma unroll
-    for (int h = 0; h < 8; ++h) *reinterpret_cast<float4*>(&sz[wave][h][4 * lane]) = zacc[h];
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 8; ++h) {
-        const float M = fmaxf(fmaxf(sm[0][h], sm[1][h]), fmaxf(sm[2][h], sm[3][h]));
-        float den = 0.f, num = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float e = expf(sm[w][h] - M);                          // waves without a tile: exp(-inf) = 0
-            den += sl[w][h] * e;
-            num += sz[w][h][tid] * e;
-        }
-        z[(long long)r * (8 * C) + h * C + tid] = num / den;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -567,18 +424,8 @@ extern "C" int mv2d_sparse_xattn_fwd_drop(const float* q, const void* K, const v
     if (R == 0) return MV2D_OK;
     // 8 waves x 4-key chunks: best of {2,4,8} waves x {4,8,16} keys with several samples per launch (cfg2_s decoder 0.671 -> 0.655 ms per
     // 6-sample batch, cfg3_t 0.845 -> 0.817); with one sample per launch 8 x 8 was marginally ahead
-    static const int cfg = getenv("MV2D_XATTN_CFG") ? atoi(getenv("MV2D_XATTN_CFG")) : 84;      // experiment switch: waves * 10 + keys per chunk
-#define MV2D_XA(NW, KC) hipLaunchKernelGGL((sparse_xattn_kernel<NW, KC>), dim3(R), dim3(64 * NW), 0, (hipStream_t)stream, q, (const unsigned short*)K, \
-                                           (const unsigned short*)V, row_ptr, col_idx, ctx, dbg_logits, dbg_stride, R, empty_nan, drop)
-    if (cfg == 48) MV2D_XA(4, 8);
-    else if (cfg == 416) MV2D_XA(4, 16);
-    else if (cfg == 28) MV2D_XA(2, 8);
-    else if (cfg == 88) MV2D_XA(8, 8);
-    else if (cfg == 164) MV2D_XA(16, 4);
-    else if (cfg == 162) MV2D_XA(16, 2);
-    else if (cfg == 82) MV2D_XA(8, 2);
-    else MV2D_XA(8, 4);
-#undef MV2D_XA
+    hipLaunchKernelGGL((sparse_xattn_kernel<8, 4>), dim3(R), dim3(64 * 8), 0, (hipStream_t)stream, q, (const unsigned short*)K, (const unsigned short*)V,
+                       row_ptr, col_idx, ctx, dbg_logits, dbg_stride, R, empty_nan, drop);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
@@ -606,17 +453,6 @@ extern "C" int mv2d_sparse_xattn_bwd_drop(const float* q, const void* K, const v
     if (S > 0)
         hipLaunchKernelGGL(sparse_xattn_bwd_kv_kernel, dim3(cdiv(S, 4)), dim3(256), 0, (hipStream_t)stream, q, dctx, pair_ws, key_ptr, pair_idx, pair_row,
                            dK, dV, S);
-    MV2D_LAUNCH_CHECK();
-    return MV2D_OK;
-}
-
-extern "C" int mv2d_raw_xattn_fwd(const float* qk, const void* Xk, const void* Xv, const int* row_ptr, const int* col_idx, float* z, int R,
-                                  int empty_nan, void* stream) {
-    MV2D_CHECK_ARG(qk && Xk && Xv && row_ptr && col_idx && z && R >= 0, "mv2d_raw_xattn_fwd: bad args");
-    MV2D_CHECK_ARG(((uintptr_t)qk & 15) == 0 && ((uintptr_t)Xk & 15) == 0 && ((uintptr_t)Xv & 7) == 0, "mv2d_raw_xattn_fwd: operands must be 16-byte aligned");
-    if (R == 0) return MV2D_OK;
-    hipLaunchKernelGGL(raw_xattn_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, qk, (const unsigned short*)Xk, (const unsigned short*)Xv, row_ptr,
-                       col_idx, z, R, empty_nan);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -49,6 +49,81 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_cv));
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// "key16": the 16-bit storage / MFMA operand format of the KEY SIDE of the hot path -- the gathered key / value rows of the cross
+// attention, the RoI cells of the query generator's conv, the operands and the hidden layer of the PE MLPs, and the weights those
+// kernels multiply them with.  Round 4: IEEE fp16 (11 significand bits; v_mfma_f32_16x16x32_f16 runs at the bf16 rate on the same
+// bytes) instead of bf16 (8 bits): the key-side rounding, which dominated the deviation from the fp32 reference, shrinks 8 x.  Range
+// guard: conversions SATURATE at +-65504 (FPN features / PE activations are O(1..100); a saturated element is finite and visible, an
+// inf would poison the softmax row).  fp16 subnormals are kept by the MFMA under hipcc's default kernel mode (denorm mode 3; probed on
+// MI355X by tools/f16_mfma_probe.hip), so a hi + lo pair carries ~22 bits down to an absolute 2^-24.
+// -DMV2D_KEY16_BF16 builds the round-3 format for A/B runs (tools/build_variant.sh); mv2d_key16_format() reports which one a library has.
+// The QUERY side (bf16x3 split precision on fp32 operands) and the generic tile GEMM (gemm_bf16.hip) are bf16 either way.
+// ------------------------------------------------------------------------------------------------------------------------------
+#ifdef MV2D_KEY16_BF16
+#define MV2D_KEY16_IS_F16 0
+typedef __attribute__((ext_vector_type(8))) __bf16 k16x8_t;
+typedef __attribute__((ext_vector_type(4))) short k16x4_t;
+__device__ __forceinline__ unsigned int pack_k16x2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+__device__ __forceinline__ unsigned short f32_to_k16(float f) { return f32_to_bf16(f); }
+__device__ __forceinline__ float k16_to_f32(unsigned short h) { return bf16_to_f32(h); }
+__device__ __forceinline__ float k16_lo_of_pair(unsigned int p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float k16_hi_of_pair(unsigned int p) { return __uint_as_float(p & 0xffff0000u); }
+__device__ __forceinline__ f32x4_t mfma_k16_16x16x32(const uint4& a, const uint4& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(k16x8_t, a), __builtin_bit_cast(k16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_t mfma_k16_16x16x16(const uint2& a, const uint2& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(k16x4_t, a), __builtin_bit_cast(k16x4_t, b), c, 0, 0, 0);
+}
+#else
+#define MV2D_KEY16_IS_F16 1
+typedef __attribute__((ext_vector_type(8))) _Float16 k16x8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 k16x4_t;
+// two fp32 -> packed fp16 pair, round-to-nearest-even, saturating at the largest finite fp16; NaN stays NaN (the clamp is written with
+// comparisons, which are false for NaN)
+__device__ __forceinline__ float k16_sat(float v) { return v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v); }
+__device__ __forceinline__ unsigned int pack_k16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_cv;
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_cv;
+    const f32x2_cv v = {k16_sat(lo), k16_sat(hi)};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2_cv));
+}
+__device__ __forceinline__ unsigned short f32_to_k16(float f) { return __builtin_bit_cast(unsigned short, (_Float16)k16_sat(f)); }
+__device__ __forceinline__ float k16_to_f32(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ float k16_lo_of_pair(unsigned int p) { return k16_to_f32((unsigned short)(p & 0xffffu)); }
+__device__ __forceinline__ float k16_hi_of_pair(unsigned int p) { return k16_to_f32((unsigned short)(p >> 16)); }
+__device__ __forceinline__ f32x4_t mfma_k16_16x16x32(const uint4& a, const uint4& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(k16x8_t, a), __builtin_bit_cast(k16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_t mfma_k16_16x16x16(const uint2& a, const uint2& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(k16x4_t, a), __builtin_bit_cast(k16x4_t, b), c, 0, 0, 0);
+}
+#endif
+// the same for values KNOWN to lie inside the fp16 range (softmax probabilities): no clamp
+__device__ __forceinline__ void split_k16x2_bounded(float a, float b, unsigned int& hi, unsigned int& lo) {
+#if MV2D_KEY16_IS_F16
+    typedef __attribute__((ext_vector_type(2))) float f32x2_cv;
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_cv;
+    const f32x2_cv v = {a, b};
+    hi = __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2_cv));
+    const f32x2_cv r = {a - k16_lo_of_pair(hi), b - k16_hi_of_pair(hi)};
+    lo = __builtin_bit_cast(unsigned int, __builtin_convertvector(r, f16x2_cv));
+#else
+    hi = pack_bf16x2(a, b);
+    lo = pack_bf16x2(a - k16_lo_of_pair(hi), b - k16_hi_of_pair(hi));
+#endif
+}
+// hi + lo split of two fp32 values into key16 pairs: x ~ hi + lo (the remainder of a saturated / non-finite value is forced to 0)
+__device__ __forceinline__ void split_k16x2(float a, float b, unsigned int& hi, unsigned int& lo) {
+    hi = pack_k16x2(a, b);
+    float ra = a - k16_lo_of_pair(hi), rb = b - k16_hi_of_pair(hi);
+#if MV2D_KEY16_IS_F16
+    ra = fabsf(a) < 65504.f ? ra : 0.f;
+    rb = fabsf(b) < 65504.f ? rb : 0.f;
+#endif
+    lo = pack_k16x2(ra, rb);
+}
+
 // ReLU that keeps NaN like torch.relu (fmaxf(NaN, 0) would return 0 and hide a poisoned row)
 __device__ __forceinline__ float relu_f(float v) { return v < 0.f ? 0.f : v; }
 

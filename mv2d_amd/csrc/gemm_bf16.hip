@@ -354,17 +354,15 @@ extern "C" int mv2d_gemm_bf16_ex(const void* A, const void* A2, int n_split, int
     p.k_splits = k_splits; p.c_split_stride = c_split_stride;
     // tile choice: 128x128 when that already gives >= 3 blocks per CU, else 64x64 (4x the blocks)
     const long long big_blocks = (long long)cdiv(M, 128) * cdiv(N, 128) * k_splits;
-    static const int thr_env = getenv("MV2D_BF16_BIG") ? atoi(getenv("MV2D_BF16_BIG")) : 768;
-    if (big_blocks >= thr_env) {
+    if (big_blocks >= 768) {
         p.n_tiles = cdiv(N, 128);
         dim3 grid(((cdiv(M, 128) + 7) / 8) * 8 * p.n_tiles, k_splits);
         hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
     } else {
         p.n_tiles = cdiv(N, 64);
         dim3 grid(((cdiv(M, 64) + 7) / 8) * 8 * p.n_tiles, k_splits);
-        static const int bk_env = getenv("MV2D_BF16_BK") ? atoi(getenv("MV2D_BF16_BK")) : 128;
         // deep K: 128-wide k tiles (twice the bytes in flight per block, half the barriers)
-        if (bk_env == 128 && (K % 128) == 0 && K >= 512) hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 128>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        if ((K % 128) == 0 && K >= 512) hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 128>), grid, dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
     }
     MV2D_LAUNCH_CHECK();

@@ -140,18 +140,10 @@ extern "C" int mv2d_gemm_f32(const float* A, const float* A2, int n_split, const
     p.A = A; p.A2 = A2; p.n_split = n_split; p.W = W; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw;
     p.k_chunk = K / split_k; p.act = act; p.scale = scale; p.C = C; p.c_bf16 = c_bf16; p.ldc = ldc;
     p.c_slice_stride = c_slice_stride;
-    static const int dbg_env = getenv("MV2D_F32_DBG") ? atoi(getenv("MV2D_F32_DBG")) : 0;
-    p.dbg = dbg_env;
-    // wide outputs: two column tiles per wave share one A fragment (half the A requests, half the waves)
-    static const int nt_env = getenv("MV2D_F32_NT") ? atoi(getenv("MV2D_F32_NT")) : 0;
-    const int nt = nt_env ? nt_env : 1;
-    if (nt == 2) {
-        dim3 grid(cdiv(N, 64), cdiv(M, 32), split_k * groups);
-        hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    } else {
-        dim3 grid(cdiv(N, 32), cdiv(M, 32), split_k * groups);
-        hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    }
+    p.dbg = 0;
+    // (two column tiles per wave sharing one A fragment -- gemm_f32_kernel<2> -- measured no gain in round 1; one tile per wave)
+    dim3 grid(cdiv(N, 32), cdiv(M, 32), split_k * groups);
+    hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

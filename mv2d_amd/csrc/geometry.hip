@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void posemb3d_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------------
 // a4: RoIAlign (mmcv 1.6.1 semantics: aligned, avg, adaptive sampling grid) on position-major maps.
 //     One block per (RoI, bin row); every bilinear tap is a fully coalesced C*4-byte row read.
-//     maps: up to two [V*h*w, 256] fp32 maps (feature, PE) -> out bf16 [R, 49, 256] each (+ optional fp32)
+//     maps: up to two [V*h*w, 256] fp32 maps (feature, PE) -> out key16 (fp16) [R, 49, 256] each (+ optional fp32)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict__ map0, const float* __restrict__ map1, const float* __restrict__ rois,
                                                         unsigned short* __restrict__ out0, unsigned short* __restrict__ out1,
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
                                                         int out1_is_sum, int R, unsigned short* __restrict__ out0_lo,
                                                         unsigned short* __restrict__ out1_lo) {
     // one block per RoI and bin row; wave w takes the bins w, w + 4 of the row, lane l the channels 4l .. 4l+3: every
-    // bilinear tap is one 16-byte load per lane (a full 1 KB row per wave), every output one 8-byte (bf16) / 16-byte (fp32) store.
+    // bilinear tap is one 16-byte load per lane (a full 1 KB row per wave), every output one 8-byte (key16) / 16-byte (fp32) store.
     // XCD-aware block map (block b runs on XCD b % 8): the 7 bin rows of a RoI tap overlapping map rows, so they take consecutive slots
     // of ONE XCD and share its L2 (a (R, 7) grid ran them R blocks apart).  Speed only; any map is correct.
     const int slot = blockIdx.x >> 3, ph = slot % 7, r = (slot / 7) * 8 + (blockIdx.x & 7);
@@ -199,12 +199,18 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
         }
         const long long o = ((long long)r * 49 + ph * 7 + pw) * C + c;
         s0 = make_float4(s0.x / count, s0.y / count, s0.z / count, s0.w / count);
-        // (out*_lo: the bf16 remainder x - bf16(x) next to the bf16 value: the fp32-class hi + lo rows of the index-exact route)
+        // key16 outputs (common.h: fp16 since round 4); out*_lo: the remainder x - key16(x) next to the value: the fp32-class hi + lo rows of the
+        // index-exact route
         auto put = [&](unsigned short* hi, unsigned short* lo, const float4& t) {
-            const unsigned int h0 = pack_bf16x2(t.x, t.y), h1 = pack_bf16x2(t.z, t.w);
-            *reinterpret_cast<uint2*>(hi + o) = make_uint2(h0, h1);
-            if (lo) *reinterpret_cast<uint2*>(lo + o) = make_uint2(pack_bf16x2(t.x - __uint_as_float(h0 << 16), t.y - __uint_as_float(h0 & 0xffff0000u)),
-                                                                   pack_bf16x2(t.z - __uint_as_float(h1 << 16), t.w - __uint_as_float(h1 & 0xffff0000u)));
+            if (lo) {
+                uint2 hh, ll;
+                split_k16x2(t.x, t.y, hh.x, ll.x);
+                split_k16x2(t.z, t.w, hh.y, ll.y);
+                *reinterpret_cast<uint2*>(hi + o) = hh;
+                *reinterpret_cast<uint2*>(lo + o) = ll;
+            } else {
+                *reinterpret_cast<uint2*>(hi + o) = make_uint2(pack_k16x2(t.x, t.y), pack_k16x2(t.z, t.w));
+            }
         };
         if (out0) put(out0, out0_lo, s0);
         if (out0_f32) *reinterpret_cast<float4*>(out0_f32 + o) = s0;
@@ -642,13 +648,13 @@ __global__ __launch_bounds__(1024) void csr_from_corr_kernel(const int* __restri
 // the feature row (MU/pe.py:84-135 frustum coords in fp64, MU/positional_encoding.py:78-95 sine features).
 // ------------------------------------------------------------------------------------------------
 // One wave per key position (4 per block): lane l moves channels 4l..4l+3 of the feature row with 16-byte accesses, computes depth
-// bin l of the frustum row (3 coordinates) and 6 sine channels; the two bf16 input rows (384 B, 768 B) are assembled in LDS and
+// bin l of the frustum row (3 coordinates) and 6 sine channels; the two key16 (fp16) input rows (384 B, 768 B) are assembled in LDS and
 // written with 16-byte stores.  (Round 1: one block per position with 2- and 4-byte accesses ran at 2 TB/s of its 130 MB.)
 template <bool EXACT>      // EXACT: also the unrounded fp32 rows of the engine's index-exact validation mode (fp64 log, library sin / cos)
 __global__ __launch_bounds__(256) void pe_inputs_kernel(const int* __restrict__ s2pos, const int* __restrict__ S_dev, const float* __restrict__ featcl,
                                                         const double* __restrict__ img2lidar, const double* __restrict__ coords_w, const double* __restrict__ coords_h,
                                                         const double* __restrict__ coords_d, const float* __restrict__ embeds, const float* __restrict__ dim_t,
-                                                        unsigned short* __restrict__ A_frustum, unsigned short* __restrict__ A_sine, unsigned short* __restrict__ Xf_bf16,
+                                                        unsigned short* __restrict__ A_frustum, unsigned short* __restrict__ A_sine, unsigned short* __restrict__ Xf_k16,
                                                         float* __restrict__ Xf_f32, float* __restrict__ A_frustum_f32, float* __restrict__ A_sine_f32,
                                                         int h, int w, int P, int D, double pr0, double pr1, double pr2,
                                                         double pd0, double pd1, double pd2) {
@@ -662,11 +668,11 @@ __global__ __launch_bounds__(256) void pe_inputs_kernel(const int* __restrict__ 
     const int v = pos / (h * w), rem = pos - v * h * w, y = rem / w, x = rem - y * w;
     unsigned short* fr_row = rowbuf[wave];
     unsigned short* si_row = rowbuf[wave] + 3 * 256;
-    // feature row gather (fp32 kept for the K = feat + pe sum, bf16 for the SE gate and the V projection)
+    // feature row gather (fp32 kept for the K = feat + pe sum, key16 for the SE gate and the value rows)
     {
         const float4 f = *reinterpret_cast<const float4*>(featcl + (long long)pos * C + 4 * lane);
         if (Xf_f32) *reinterpret_cast<float4*>(Xf_f32 + (long long)s * C + 4 * lane) = f;
-        *reinterpret_cast<uint2*>(Xf_bf16 + (long long)s * C + 4 * lane) = make_uint2(pack_bf16x2(f.x, f.y), pack_bf16x2(f.z, f.w));
+        *reinterpret_cast<uint2*>(Xf_k16 + (long long)s * C + 4 * lane) = make_uint2(pack_k16x2(f.x, f.y), pack_k16x2(f.z, f.w));
     }
     for (int dk = lane; dk < D; dk += 64) {
         const double d = coords_d[dk];
@@ -684,9 +690,9 @@ __global__ __launch_bounds__(256) void pe_inputs_kernel(const int* __restrict__ 
             const double x1 = n < 1e-5 ? 1e-5 : n;
             const double x2 = (1.0 - n) < 1e-5 ? 1e-5 : (1.0 - n);
             // the normalised coordinate in fp64 like the reference (MU/pe.py:119-130 runs on double coordinates); quotient and
-            // logarithm in fp32: 1e-7 absolute against a value that is rounded to bf16 right here (a double division + double log
+            // logarithm in fp32: 1e-7 absolute against a value that is rounded to key16 (fp16) right here (a double division + double log
             // are ~130 fp64 instructions, 192 of them per position: the kernel was bound by them)
-            fr_row[dk * 3 + i] = f32_to_bf16(logf((float)x1 / (float)x2));
+            fr_row[dk * 3 + i] = f32_to_k16(logf((float)x1 / (float)x2));
             // index-exact validation mode: the unrounded fp32 row, quotient and logarithm in fp64 like the reference (MU/pe.py:130)
             if (EXACT) A_frustum_f32[(long long)s * (3 * D) + dk * 3 + i] = (float)log(x1 / x2);
         }
@@ -709,9 +715,9 @@ __global__ __launch_bounds__(256) void pe_inputs_kernel(const int* __restrict__ 
         const int axis = ch >> 7, i = ch & 127;
         const float e = axis == 0 ? en : (axis == 1 ? ey : ex);
         // arguments lie in [0, 2 pi]: the hardware sin / cos (v_sin_f32 on x / 2 pi, ~1e-6 absolute) is as good as the library call
-        // for a value that is rounded to bf16 right here
+        // for a value that is rounded to key16 (fp16) right here
         const float a = e / dim_t[i < 64 ? 2 * i : 2 * (i - 64) + 1];
-        si_row[ch] = f32_to_bf16(i < 64 ? __sinf(a) : __cosf(a));
+        si_row[ch] = f32_to_k16(i < 64 ? __sinf(a) : __cosf(a));
         if (EXACT) A_sine_f32[(long long)s * 384 + ch] = i < 64 ? sinf(a) : cosf(a);
     }
     __builtin_amdgcn_wave_barrier();                          // the rows are read back by the same wave only
@@ -959,7 +965,7 @@ extern "C" int mv2d_roi_align_ex(const float* map0, const float* map1, const flo
                                  const int* map1_index, int out1_is_sum, void* out0_lo, void* out1_lo, void* stream) {
     MV2D_CHECK_ARG(map0 && rois && channels == C, "mv2d_roi_align: needs 256-channel position-major maps");
     MV2D_CHECK_ARG(out0 || out0_f32, "mv2d_roi_align: no output");
-    MV2D_CHECK_ARG((!out0_lo || out0) && (!out1_lo || out1), "mv2d_roi_align_ex: a lo output needs its bf16 (hi) output");
+    MV2D_CHECK_ARG((!out0_lo || out0) && (!out1_lo || out1), "mv2d_roi_align_ex: a lo output needs its key16 (hi) output");
     if (R == 0) return MV2D_OK;
     hipLaunchKernelGGL(roi_align_kernel, dim3(56 * cdiv(R, 8)), dim3(256), 0, (hipStream_t)stream, map0, map1, rois, (unsigned short*)out0,
                        (unsigned short*)out1, out0_f32, out1_f32, H, W, spatial_scale, sampling_ratio, map1_index, out1_is_sum, R,
@@ -1045,17 +1051,17 @@ extern "C" int mv2d_csr_from_corr(const int* match, int* row_ptr, int* col_idx, 
 
 extern "C" int mv2d_pe_inputs(const int* s2pos, const int* S_dev, int S_max, const float* featcl, const double* img2lidar,
                               const double* coords_w, const double* coords_h, const double* coords_d, const float* embeds,
-                              const float* dim_t, void* A_frustum, void* A_sine, void* Xf_bf16, float* Xf_f32, float* A_frustum_f32,
+                              const float* dim_t, void* A_frustum, void* A_sine, void* Xf_k16, float* Xf_f32, float* A_frustum_f32,
                               float* A_sine_f32, int V, int h, int w, int depth_num, const double* position_range, void* stream) {
     MV2D_CHECK_ARG(s2pos && S_dev && featcl && img2lidar && coords_w && coords_h && coords_d && embeds && dim_t && A_frustum &&
-                       Xf_bf16 && position_range, "mv2d_pe_inputs: null pointer");
+                       Xf_k16 && position_range, "mv2d_pe_inputs: null pointer");
     MV2D_CHECK_ARG(A_sine || !A_sine_f32, "mv2d_pe_inputs: the exact rows need A_sine");
     MV2D_CHECK_ARG(depth_num <= 256 && (depth_num % 8) == 0, "mv2d_pe_inputs: depth_num must be a multiple of 8, <= 256");
     if (S_max == 0) return MV2D_OK;
     MV2D_CHECK_ARG(A_frustum_f32 || !A_sine_f32, "mv2d_pe_inputs: fp32 sine rows only together with the fp32 frustum rows");
 #define MV2D_PEI(EX) hipLaunchKernelGGL(pe_inputs_kernel<EX>, dim3(cdiv(S_max, 4)), dim3(256), 0, (hipStream_t)stream, s2pos, S_dev, featcl, img2lidar, coords_w, \
                        coords_h, coords_d, embeds, dim_t, (unsigned short*)A_frustum, (unsigned short*)A_sine,                                      \
-                       (unsigned short*)Xf_bf16, Xf_f32, A_frustum_f32, A_sine_f32, h, w, V * h * w, depth_num, position_range[0], position_range[1], \
+                       (unsigned short*)Xf_k16, Xf_f32, A_frustum_f32, A_sine_f32, h, w, V * h * w, depth_num, position_range[0], position_range[1], \
                        position_range[2], position_range[3] - position_range[0], position_range[4] - position_range[1],                               \
                        position_range[5] - position_range[2])
     if (A_frustum_f32) MV2D_PEI(true); else MV2D_PEI(false);

@@ -1,23 +1,22 @@
-// The PE block with the sine branch folded into a table (the engine's default, see pe_mlp.hip for the block itself), rebuilt for
-// two waves per SIMD:
+// The PE block of the key side, with the sine branch folded into a table (MU/pe.py:36-48,64-77,150-166; the branch adapt_pos3d(sine)
+// depends only on the weights and the padding geometry, the engine evaluates it once per (weights, geometry) into `sine_tab`):
 //   P1 = position_encoder(A1)                                   192 -> 1024 -> 256     (MU/pe.py:64-77, 158-160)
 //   G  = sigmoid(conv_expand(relu(conv_reduce(feat))))          256 -> 256 -> 256      (MU/pe.py:36-48, 162-166)
-//   pe = tab[position] + P1 * G ,  Xk = bf16(pe + feat)         tab = adapt_pos3d(sine) + bias, constant per (weights, padding geometry)
+//   pe = tab[position] + P1 * G ,  Xk = key16(pe + feat)        tab = adapt_pos3d(sine) + bias, constant per (weights, padding geometry)
 //   (Xk optional: the S path's keys are RoI-aligned rows, it only needs pe -- no feature-row read, a third less traffic;
 //    pe optional: the T path's keys are the Xk rows, nothing reads pe there)
 //
-// pe_fused_kernel<true> (pe_mlp.hip: 4 waves, 64 rows, ONE wave per SIMD, one block per CU) spends less than half of a block's life in
-// its MFMA loops: prologue, the staging of the second input tile and above all the output phase (1.5 KB written and 2 KB read per row)
-// run with the matrix pipe idle, and since all blocks of a round move in lockstep those phases hit HBM as a burst (11 B/clk/CU) while
-// the MFMA phases leave it idle.  With the table this kernel is HBM-bound, not MFMA-bound (356 MB per 70 k rows against 83 GFLOP).
-// Two shapes of one template, same fragment-major weights, k order and bf16 rounding of the hidden layer as pe_fused_kernel
-// (bit-identical results):
+// Its round-1/2 predecessor (pe_fused_kernel: 4 waves, 64 rows, ONE wave per SIMD, one block per CU; retired in round 4) spent less than half
+// of a block's life in its MFMA loops: prologue, the staging of the second input tile and above all the output phase (1.5 KB written and 2 KB
+// read per row) ran with the matrix pipe idle, and since all blocks of a round move in lockstep those phases hit HBM as a burst (11 B/clk/CU)
+// while the MFMA phases left it idle.  With the table this kernel is HBM-bound, not MFMA-bound (356 MB per 70 k rows against 83 GFLOP).
+// All 16-bit operands (input rows, weights, hidden layer, Xk) are in the key-side format of common.h (key16 = fp16 since round 4).
+// Two shapes of one template, same fragment-major weights and k order (bit-identical results):
 //   * <RT=4, NW=4, CT=4>: 64 rows, 4 waves, 71 KB of LDS and <= 256 registers -> TWO INDEPENDENT BLOCKS PER CU: one block's memory
 //     phases run under the other's MFMA loops and the blocks drift out of lockstep;
 //   * <RT=6, NW=8, CT=2>: 96 rows, 8 waves (2 per SIMD) in one block per CU; a weight fragment feeds 6 MFMAs instead of 4 and the
 //     hidden tile is double-buffered (one barrier per part).
 // The gate comes LAST so that only two accumulator sets are ever live (P1 and the running one).
-#include <cstdlib>
 #include "common.h"
 
 #ifdef MV2D_PE_TRACE
@@ -33,8 +32,7 @@ constexpr int C = 256;
 constexpr int PITCH = 512;                                  // bytes per row of the LDS tiles (256 bf16), 16-byte chunk c of row r at c ^ (r & 15)
 enum { B_R = 0, B_E = 256, B_1A = 512, B_1B = 1536, B_FLOATS = 1792 };
 constexpr int OT_PITCH = 36;                                // floats per row of a wave's output tile [BM][32 columns]
-typedef __attribute__((ext_vector_type(8))) __bf16 pt_bf16x8;
-union PFrag { uint4 u; pt_bf16x8 v; };
+struct PFrag { uint4 u; };
 typedef unsigned int pt_u32x4 __attribute__((ext_vector_type(4)));   // staging registers (arrays of HIP's uint4 struct end up in scratch)
 
 struct PeTabParams {
@@ -105,7 +103,7 @@ __device__ __forceinline__ void steps(f32x4_t (&acc)[S::RT][S::CT], PFrag (&wq)[
         for (int i = 0; i < S::RT; ++i)
 #pragma unroll
             for (int j = 0; j < S::CT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[(T0 + K) % S::RING][j].v, a[(S::EXP & 2) ? 0 : (K & 1)][i].v, acc[i][j], 0, 0, 0);
+                acc[i][j] = mfma_k16_16x16x32(wq[(T0 + K) % S::RING][j].u, a[(S::EXP & 2) ? 0 : (K & 1)][i].u, acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
         steps<S, T0, N, K + 1>(acc, wq, a, w, L, fr, fg);
     }
@@ -119,7 +117,7 @@ __device__ __forceinline__ void zero_acc(f32x4_t (&acc)[S::RT][S::CT]) {
         for (int j = 0; j < S::CT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 }
 
-// layer 1 of part P into a hidden buffer: lane (fr, fg) holds hidden columns lcol..lcol+3 of row 16 i + fr -> bias, ReLU, bf16, 8-byte
+// layer 1 of part P into a hidden buffer: lane (fr, fg) holds hidden columns lcol..lcol+3 of row 16 i + fr -> bias, ReLU, key16, 8-byte
 // write.  Barrier after: the tile is complete.  With two hidden buffers the one written here was last read two barriers ago; with one,
 // a barrier before the stores waits for the previous part's layer 2.
 template <class S, int P>
@@ -135,8 +133,8 @@ __device__ __forceinline__ void layer1(PFrag (&wq)[S::RING][S::CT], PFrag (&a)[2
         const float4 bb = *reinterpret_cast<const float4*>(bias + lcol);
 #pragma unroll
         for (int i = 0; i < S::RT; ++i) {
-            const uint2 hv = make_uint2(pack_bf16x2(relu_f(acc1[i][j][0] + bb.x), relu_f(acc1[i][j][1] + bb.y)),
-                                        pack_bf16x2(relu_f(acc1[i][j][2] + bb.z), relu_f(acc1[i][j][3] + bb.w)));
+            const uint2 hv = make_uint2(pack_k16x2(relu_f(acc1[i][j][0] + bb.x), relu_f(acc1[i][j][1] + bb.y)),
+                                        pack_k16x2(relu_f(acc1[i][j][2] + bb.z), relu_f(acc1[i][j][3] + bb.w)));
             *reinterpret_cast<uint2*>(Hb + (16 * i + fr) * PITCH + (((lcol >> 3) ^ fr) << 4) + (lcol & 4) * 2) = hv;
         }
     }
@@ -246,7 +244,7 @@ __global__ __launch_bounds__(S::NTHR, 2) void pe_tab_kernel(PeTabParams p) {
     zero_acc<S>(acc);
     steps<S, first_of(4) + 8, 8>(acc, wq, a, w, Hs0, fr, fg);
     PE_STAMP(12);
-    // ---- 3. pe = tab + (P1 + b) * gate, Xk = bf16(pe + feat): through a wave-private LDS tile [BM rows][32 columns], then whole
+    // ---- 3. pe = tab + (P1 + b) * gate, Xk = key16(pe + feat): through a wave-private LDS tile [BM rows][32 columns], then whole
     // 128-byte row pieces (the MFMA layout would store 16 rows x 16 bytes per instruction).  The feature and table rows of the first
     // 32 columns are requested before the gate math (their latency is this phase's floor).
     float4 fv[NK], tv[NK];
@@ -294,7 +292,7 @@ __global__ __launch_bounds__(S::NTHR, 2) void pe_tab_kernel(PeTabParams p) {
                 if (p.pe) *reinterpret_cast<float4*>(p.pe + (long long)m * C + gcol) = v;
                 if (p.Xk)
                     *reinterpret_cast<uint2*>(p.Xk + (long long)m * C + gcol) =
-                        make_uint2(pack_bf16x2(v.x + fv[k].x, v.y + fv[k].y), pack_bf16x2(v.z + fv[k].z, v.w + fv[k].w));
+                        make_uint2(pack_k16x2(v.x + fv[k].x, v.y + fv[k].y), pack_k16x2(v.z + fv[k].z, v.w + fv[k].w));
             }
         }
         if (jp + 1 < CT / 2) request(jp + 1);
@@ -309,8 +307,8 @@ void launch(const PeTabParams& p, hipStream_t stream) {
 
 }  // namespace
 
-// same contract as mv2d_pe_fused_tab (include/mv2d_hip.h), which forwards here unless MV2D_PE_TAB_KERNEL=64 (pe_mlp.hip's kernel);
-// shape: 1 = 96 rows x 8 waves, one block per CU (default); 0 = 64 rows x 4 waves, two blocks per CU
+// mv2d_pe_fused_tab (include/mv2d_hip.h) = shape 1; mv2d_pe_fused_tab2 exposes the shape for the kernel tests:
+// shape 1 = 96 rows x 8 waves, one block per CU (default); 0 = 64 rows x 4 waves, two blocks per CU (bit-identical, slower: 134 vs 110 us on 70 k rows)
 extern "C" int mv2d_pe_fused_tab2(const void* A1, const void* Xfb, const float* Xf32, const int* row_index, const int* m_dev, int M,
                                   const void* W1a, const float* b1a, const void* W1b, const float* b1b,
                                   const void* Wr, const float* br, const void* We, const float* be,
@@ -321,18 +319,18 @@ extern "C" int mv2d_pe_fused_tab2(const void* A1, const void* Xfb, const float* 
     PeTabParams p{(const unsigned short*)A1, (const unsigned short*)Xfb, Xf32, row_index, m_dev, M, (const unsigned short*)W1a, b1a,
                   (const unsigned short*)W1b, b1b, (const unsigned short*)Wr, br, (const unsigned short*)We, be, sine_tab, tab_period, pe,
                   (unsigned short*)Xk};
-    const char* ex = getenv("MV2D_PE_EXP");
-    const int exp = ex ? atoi(ex) : 0;
     hipStream_t st = (hipStream_t)stream;
-    if (shape == 1) {
-        if (exp == 3) launch<Shape<6, 8, 2, 2, 4, 3>>(p, st);
-        else launch<Shape<6, 8, 2, 2, 4, 0>>(p, st);
-    } else {
-        if (exp == 3) launch<Shape<4, 4, 4, 1, 3, 3>>(p, st);
-        else launch<Shape<4, 4, 4, 1, 3, 0>>(p, st);
-    }
+    if (shape == 1) launch<Shape<6, 8, 2, 2, 4, 0>>(p, st);
+    else launch<Shape<4, 4, 4, 1, 3, 0>>(p, st);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
+}
+
+extern "C" int mv2d_pe_fused_tab(const void* A1, const void* Xfb, const float* Xf32, const int* row_index, const int* m_dev, int M,
+                                 const void* W1a, const float* b1a, const void* W1b, const float* b1b,
+                                 const void* Wr, const float* br, const void* We, const float* be,
+                                 const float* sine_tab, int tab_period, float* pe, void* Xk, void* stream) {
+    return mv2d_pe_fused_tab2(A1, Xfb, Xf32, row_index, m_dev, M, W1a, b1a, W1b, b1b, Wr, br, We, be, sine_tab, tab_period, pe, Xk, 1, stream);
 }
 
 #ifdef MV2D_PE_TRACE

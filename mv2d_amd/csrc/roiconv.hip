@@ -2,9 +2,9 @@
 // (RH/utils/query_generator.py:298-304, 322-331, 352-358) — one block per RoI, conv + bias + ReLU + pooling fused.
 //
 // The implicit-GEMM route (gemm_bf16.hip, a_mode = 1) re-gathers every RoI row 9 times through L2 in 64x64 tiles, writes the
-// [R*49, 256] fp32 conv output and needs a pooling launch.  Here the block keeps its RoI (49 cells x 256 channels bf16 = 25 KB)
+// [R*49, 256] fp32 conv output and needs a pooling launch.  Here the block keeps its RoI (49 cells x 256 channels key16 = 25 KB)
 // in LDS once and every tap is just a remapped row index into it (out-of-range neighbours -> a zero row); the weights
-// (256 x 2304 bf16) are never staged: each wave streams the 64 output columns it owns as MFMA fragments straight from L2 through
+// (256 x 2304 key16) are never staged: each wave streams the 64 output columns it owns as MFMA fragments straight from L2 through
 // a 4-deep register ring.  The weights are static, so they are stored FRAGMENT-MAJOR (mv2d_pack_wfrag_bf16: [k-step][column
 // tile][lane][8]): a fragment load is one contiguous 1 KB per wave instead of 16 rows x 64 B (row-major fragment loads
 // measured 74 us for this kernel: the TA walks 16 half-used lines per instruction and the L1 thrashes).  After the single staging barrier the waves run free — no barrier, no LDS write in the 72-step k loop
@@ -12,14 +12,12 @@
 // writes [R, 256] fp32: the 15 MB conv output and the avgpool launch disappear.
 // k order = (tap, channel) like the implicit GEMM, so the conv sums are bit-identical; only the 49-term pooling sum is
 // re-associated (fp32, ~1e-7).
-#include <cstdlib>
 #include "common.h"
 
 namespace {
 
 constexpr int C = 256, CELLS = 49, KT = 9 * C;
-typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
-union Frag { uint4 u; mfma_bf16x8 v; };
+struct Frag { uint4 u; };                     // one MFMA operand fragment: 8 key16 values (common.h: fp16 since round 4)
 typedef unsigned int cv_u32x4 __attribute__((ext_vector_type(4)));
 
 // NR RoIs per block: with NR = 2 the wave's weight fragments feed 8 instead of 4 row tiles (the kernel is bound by streaming the
@@ -101,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void roi_conv_pool_kernel(const unsigned sh
             for (int it = 0; it < 4; ++it)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[4 * rl + it][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[it].v, wq[ks % RING][j].v, acc[4 * rl + it][j], 0, 0, 0);
+                    acc[4 * rl + it][j] = mfma_k16_16x16x32(a[it].u, wq[ks % RING][j].u, acc[4 * rl + it][j]);
         }
     }
     // ---- bias + ReLU + mean over the 49 cells: lane holds cells 16 i + 4 fg + r of column 64 wave + 16 j + fr
@@ -125,8 +123,8 @@ __global__ __launch_bounds__(256, 2) void roi_conv_pool_kernel(const unsigned sh
     }
 }
 
-// Split-precision variant (index-exact route of the engine): the RoI cells come as bf16 hi + lo pairs (mv2d_roi_align_ex: x ~ hi + lo), the
-// weights as fragment-major hi / lo copies (mv2d_split_bf16x2 + mv2d_pack_wfrag_bf16); every product is a_lo w_hi + a_hi w_lo + a_hi w_hi
+// Split-precision variant (index-exact route of the engine): the RoI cells come as key16 hi + lo pairs (mv2d_roi_align_ex: x ~ hi + lo), the
+// weights as fragment-major key16 hi / lo copies (mv2d_split_key16 + mv2d_pack_wfrag_bf16); every product is a_lo w_hi + a_hi w_lo + a_hi w_hi
 // (three MFMAs into one fp32 accumulator; the lo x lo term, 2^-18 relative, is dropped).  One RoI per block: two 25 KB LDS images, a
 // 3-deep ring for both weight streams, the same tap remapping and epilogue as the bf16 kernel.  MFMA-bound (3 x 2304 MFMAs per wave
 // against 2.4 MB of weight fragments per block).
@@ -206,15 +204,15 @@ __global__ __launch_bounds__(256, 2) void roi_conv_pool_x3_kernel(const unsigned
 #pragma unroll
         for (int it = 0; it < 4; ++it)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[it][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[it].v, wqh[ks % RING][j].v, acc[it][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[it][j] = mfma_k16_16x16x32(al[it].u, wqh[ks % RING][j].u, acc[it][j]);
 #pragma unroll
         for (int it = 0; it < 4; ++it)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[it][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[it].v, wql[ks % RING][j].v, acc[it][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[it][j] = mfma_k16_16x16x32(ah[it].u, wql[ks % RING][j].u, acc[it][j]);
 #pragma unroll
         for (int it = 0; it < 4; ++it)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[it][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[it].v, wqh[ks % RING][j].v, acc[it][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[it][j] = mfma_k16_16x16x32(ah[it].u, wqh[ks % RING][j].u, acc[it][j]);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -259,9 +257,8 @@ extern "C" int mv2d_qg_conv_pool(const void* roi_feat, const void* W, const floa
     MV2D_CHECK_ARG(roi_feat && W && bias && out && ld_out >= C, "mv2d_qg_conv_pool: bad args");
     MV2D_CHECK_ARG(((uintptr_t)roi_feat & 15) == 0 && ((uintptr_t)W & 15) == 0, "mv2d_qg_conv_pool: operands must be 16-byte aligned");
     if (R == 0) return MV2D_OK;
-    // two RoIs per block once the grid fills the chip either way (identical results, see the kernel); MV2D_QG_CONV_NR=1|2 forces a shape
-    static const int env_nr = getenv("MV2D_QG_CONV_NR") ? atoi(getenv("MV2D_QG_CONV_NR")) : 0;
-    const int nr = env_nr ? env_nr : (R >= 1024 ? 2 : 1);
+    // two RoIs per block once the grid fills the chip either way (identical results, see the kernel)
+    const int nr = R >= 1024 ? 2 : 1;
     if (nr == 2)
         hipLaunchKernelGGL(roi_conv_pool_kernel<2>, dim3(cdiv(R, 2)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)roi_feat,
                            (const unsigned short*)W, bias, out, ld_out, R);

@@ -405,7 +405,14 @@ __global__ __launch_bounds__(1024) void attn_out_fused_x3_kernel(AttnOutX3Params
                 a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf[2 * u + 1].v, bl.v, a1, 0, 0, 0);
                 a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf[2 * u + 1].v, bh.v, a1, 0, 0, 0);
                 BFrag hi, lo;
-                split8(make_float4(a0[0], a0[1], a0[2], a0[3]), make_float4(a1[0], a1[1], a1[2], a1[3]), hi, lo);
+                {
+                    // the operand of the tile cross attention is stored in the KEY-SIDE format (common.h key16: fp16), like xattn_qmap_kernel
+                    unsigned int hh[4], ll[4];
+                    split_k16x2(a0[0], a0[1], hh[0], ll[0]); split_k16x2(a0[2], a0[3], hh[1], ll[1]);
+                    split_k16x2(a1[0], a1[1], hh[2], ll[2]); split_k16x2(a1[2], a1[3], hh[3], ll[3]);
+                    hi.u = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+                    lo.u = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+                }
                 if (m < p.M) {
                     uint4* out = p.Qt + (long long)m * 512 + h * 64 + (4 * half + u) * 8 + fg * 2;
                     out[0] = hi.u;
@@ -1038,7 +1045,7 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinX3Params p) {
         }
 }
 
-// (hi, lo) bf16 rows of a (+ b): the key / value rows of the index-exact route.  n4 = number of float4; rows beyond *m_dev are skipped.
+// (hi, lo) key16 rows (common.h: fp16) of a (+ b): the key / value rows of the index-exact route.  n4 = number of float4; rows beyond *m_dev are skipped.
 __global__ void split_rows_kernel(const float4* __restrict__ a, const float4* __restrict__ b, uint2* __restrict__ hi, uint2* __restrict__ lo,
                                   long long n4, const int* __restrict__ m_dev, int row4) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1046,7 +1053,8 @@ __global__ void split_rows_kernel(const float4* __restrict__ a, const float4* __
     float4 v = a[i];
     if (b) { const float4 w = b[i]; v = make_float4(v.x + w.x, v.y + w.y, v.z + w.z, v.w + w.w); }
     uint2 h, l;
-    split4(v, h, l);
+    split_k16x2(v.x, v.y, h.x, l.x);
+    split_k16x2(v.z, v.w, h.y, l.y);
     hi[i] = h;
     lo[i] = l;
 }
@@ -1285,9 +1293,8 @@ extern "C" int mv2d_ffn_out_fused_x3(const float* parts, int n_parts, long long 
     FfnOutParams p{parts, n_parts, part_stride, b2, resid, ln_w, ln_b, post_w, post_b, x_out, qpos, xq_out, outs,
                    (const unsigned short*)Win_hi, (const unsigned short*)Win_lo, b_in, qkv, M, eps};
     // 32 rows per block above 512 rows (bitwise the same rows either way, tests/test_gpu_engine.py batch == single): no gain at 8 samples per launch
-    // (the slab sum doubles per block), +1.2 % samples/s at 16 per launch (150 instead of 300 blocks, half the weight stream); MV2D_FFNOUT_RT2=0: 16 rows
-    static const int rt2 = getenv("MV2D_FFNOUT_RT2") ? atoi(getenv("MV2D_FFNOUT_RT2")) : 1;
-    if (M <= 512 || !rt2) hipLaunchKernelGGL(ffn_out_fused_x3_kernel<1>, dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p);
+    // (the slab sum doubles per block), +1.2 % samples/s at 16 per launch (150 instead of 300 blocks, half the weight stream)
+    if (M <= 512) hipLaunchKernelGGL(ffn_out_fused_x3_kernel<1>, dim3(cdiv(M, 16)), dim3(1024), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(ffn_out_fused_x3_kernel<2>, dim3(cdiv(M, 32)), dim3(1024), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
@@ -1341,10 +1348,10 @@ extern "C" int mv2d_linear_x3(const float* A, const float* A2, int n_split, int 
                              nullptr, nullptr, 0, stream);
 }
 
-extern "C" int mv2d_split_rows_bf16x2(const float* a, const float* b, void* hi, void* lo, int M, int cols, const int* m_dev, void* stream) {
-    MV2D_CHECK_ARG(a && hi && lo && M >= 0 && cols > 0 && (cols % 4) == 0, "mv2d_split_rows_bf16x2: bad args (cols % 4 == 0)");
+extern "C" int mv2d_split_rows_key16(const float* a, const float* b, void* hi, void* lo, int M, int cols, const int* m_dev, void* stream) {
+    MV2D_CHECK_ARG(a && hi && lo && M >= 0 && cols > 0 && (cols % 4) == 0, "mv2d_split_rows_key16: bad args (cols % 4 == 0)");
     MV2D_CHECK_ARG(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 && ((uintptr_t)hi & 7) == 0 && ((uintptr_t)lo & 7) == 0,
-                   "mv2d_split_rows_bf16x2: operands must be 16-byte aligned");
+                   "mv2d_split_rows_key16: operands must be 16-byte aligned");
     if (M == 0) return MV2D_OK;
     const long long n4 = (long long)M * (cols / 4);
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const float4*)b,

@@ -93,6 +93,31 @@ __global__ void f32_to_bf16_kernel(const float* x, unsigned short* y, long long 
     }
 }
 
+// fp32 -> (hi, lo) bf16 pair with x ~ hi + lo (static weights of the bf16x3 query-side kernels)
+__global__ void split_bf16x2_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float f = x[i];
+    const unsigned short h = f32_to_bf16(f);
+    hi[i] = h;
+    lo[i] = f32_to_bf16(f - __uint_as_float(((unsigned int)h) << 16));
+}
+
+// fp32 -> key16 (common.h: the key-side 16-bit format, fp16 since round 4): static weights of the key-side kernels; hi only, or hi + lo
+__global__ void f32_to_key16_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, long long n) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i >= n) return;
+    const float a = x[i], b = i + 1 < n ? x[i + 1] : 0.f;
+    unsigned int h, l;
+    split_k16x2(a, b, h, l);
+    hi[i] = (unsigned short)(h & 0xffffu);
+    if (lo) lo[i] = (unsigned short)(l & 0xffffu);
+    if (i + 1 < n) {
+        hi[i + 1] = (unsigned short)(h >> 16);
+        if (lo) lo[i + 1] = (unsigned short)(l >> 16);
+    }
+}
+
 // NCHW fp32 [V,C,h*w] -> position-major [V*h*w, C] fp32 (LDS-tiled transpose, coalesced both ways)
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, float* y, int V, int Cn, int HW) {
     __shared__ float tile[32][33];
@@ -199,6 +224,28 @@ extern "C" int mv2d_f32_to_bf16(const float* x, void* y, long long n, void* stre
     long long threads = (n + 3) / 4;
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
                        (unsigned short*)y, n);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_split_bf16x2(const float* x, void* hi, void* lo, long long n, void* stream) {
+    MV2D_CHECK_ARG(x && hi && lo && n >= 0, "mv2d_split_bf16x2: bad args");
+    if (n == 0) return MV2D_OK;
+    hipLaunchKernelGGL(split_bf16x2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)hi,
+                       (unsigned short*)lo, n);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+// 1 = IEEE fp16, 0 = bf16 (a -DMV2D_KEY16_BF16 build): the 16-bit format of the key side, see common.h
+extern "C" int mv2d_key16_format(void) { return MV2D_KEY16_IS_F16; }
+
+extern "C" int mv2d_f32_to_key16(const float* x, void* hi, void* lo, long long n, void* stream) {
+    MV2D_CHECK_ARG(x && hi && n >= 0, "mv2d_f32_to_key16: bad args");
+    if (n == 0) return MV2D_OK;
+    const long long threads = (n + 1) / 2;
+    hipLaunchKernelGGL(f32_to_key16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)hi,
+                       (unsigned short*)lo, n);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -1,58 +1,13 @@
-// Dense building blocks of the head's TRAINING route: forward and backward of the decoder's linears / layer norms /
-// FFN / prediction branches run on the hand-written bf16 tile GEMM (gemm_bf16.hip) in split precision by K-concatenation,
-//     [a_hi | a_lo | a_hi] . [b_hi | b_hi | b_lo]^T = a_hi b_hi + a_lo b_hi + a_hi b_lo          (fp32 accumulation, ~1e-5 relative),
-// instead of torch autograd over rocBLAS.  The three products of a linear layer y = x W^T (MU/petr_transformer.py:195-311,
-// RH/bbox_heads/cross_attention_head.py:118-142; mmcv FFN) all have the form C = A B^T once the operands are laid out right:
-//     forward   y  [M,N] = x  [M,K] . W   [N,K]^T
-//     backward  dx [M,K] = dy [M,N] . W^T [K,N]^T          (the B operand is the TRANSPOSE of W)
-//               dW [N,K] = dy^T [N,M] . x^T [K,M]^T        (both operands transposed; the contraction runs over the M rows)
-// so the only new kernels are the operand builders below (fp32 matrix, optionally transposed, zero-padded -> bf16 [rows, 3 K'] in the
-// [hi | lo | hi] (A side) or [hi | hi | lo] (B side) form), the layer-norm backward and a deterministic column sum (bias gradients).
+// Dense building blocks of the head's TRAINING route: the backward of a linear layer y = act(x W^T + b)
+// (MU/petr_transformer.py:195-311, RH/bbox_heads/cross_attention_head.py:118-142; mmcv FFN) as ONE call (ReLU mask of the gradient,
+//     dx [M,K] = g W,   dW [N,K] = g^T x,   db [N] = column sums of g,
+// both products on mv2d_gemm_f32x3 (csrc/gemm_f32x3.hip: fp32 operands read in place in either orientation, split into bf16 hi / lo while a
+// tile is staged, three MFMAs per product), the layer-norm backward and a deterministic column sum (bias gradients, split-K slabs).
+// (Round 3's first build of the products -- operand images [hi | lo | hi] in HBM + the bf16 tile GEMM, mv2d_split3_operand /
+//  mv2d_matmul_nt_x3 -- was retired in round 4.)
 #include "common.h"
 
 namespace {
-
-__device__ __forceinline__ void tr_split(float v, unsigned short& hi, unsigned short& lo) {
-    hi = f32_to_bf16(v);
-    lo = f32_to_bf16(v - bf16_to_f32(hi));
-}
-
-// dst [rows_out, 3 * kp] bf16 from src fp32: element (r, k) = transpose ? src[k * ld + r] : src[r * ld + k] for r < rows, k < kk, else 0.
-// side 0 (A operand): [hi | lo | hi]; side 1 (B operand): [hi | hi | lo].  32 x 32 tiles through LDS so that both the reads and the writes
-// are row-contiguous in either orientation.
-__global__ __launch_bounds__(256) void split3_op_kernel(const float* __restrict__ src, long long ld, int rows, int kk, int transpose,
-                                                        unsigned short* __restrict__ dst, int rows_out, int kp, int side) {
-    __shared__ float tile[32][33];
-    const int r0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;              // 32 x 8
-    if (transpose) {
-        // src is [kk, rows]: read rows of src (index k) contiguous in r
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = k0 + ty + 8 * j, r = r0 + tx;
-            tile[ty + 8 * j][tx] = (k < kk && r < rows) ? src[(long long)k * ld + r] : 0.f;       // tile[k_local][r_local]
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = r0 + ty + 8 * j, k = k0 + tx;
-            tile[tx][ty + 8 * j] = (r < rows && k < kk) ? src[(long long)r * ld + k] : 0.f;       // tile[k_local][r_local]
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = r0 + ty + 8 * j, k = k0 + tx;
-        if (r < rows_out && k < kp) {
-            unsigned short hi, lo;
-            tr_split(tile[tx][ty + 8 * j], hi, lo);
-            unsigned short* o = dst + (long long)r * (3LL * kp) + k;
-            o[0] = hi;
-            o[kp] = side ? hi : lo;
-            o[2 * kp] = side ? lo : hi;
-        }
-    }
-}
 
 // out[c] = sum_r x[r, c]  (fp32, fixed order: deterministic): one block per 64 columns, 4 row groups of 64 lanes each, partial sums
 // through LDS.
@@ -111,25 +66,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 // g = dy where y > 0 else 0 (the ReLU of a linear layer's forward, applied to the incoming gradient)
 __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ g, long long n) {
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i + 3 < n) {
+    // (dy may be a contiguous slice with a storage offset, e.g. rows of 10 floats: 16-byte accesses only when all three pointers allow them)
+    const bool vec = ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
+    if (vec && i + 3 < n) {
         const float4 d = *reinterpret_cast<const float4*>(dy + i), v = *reinterpret_cast<const float4*>(y + i);
         *reinterpret_cast<float4*>(g + i) = make_float4(v.x > 0.f ? d.x : 0.f, v.y > 0.f ? d.y : 0.f, v.z > 0.f ? d.z : 0.f, v.w > 0.f ? d.w : 0.f);
     } else
-        for (long long j = i; j < n; ++j) g[j] = y[j] > 0.f ? dy[j] : 0.f;
+        for (long long j = i; j < n && j < i + 4; ++j) g[j] = y[j] > 0.f ? dy[j] : 0.f;
 }
 
 }  // namespace
-
-extern "C" int mv2d_split3_operand(const float* src, long long ld, int rows, int k, int transpose, void* dst, int rows_out, int k_pad, int side,
-                                   void* stream) {
-    MV2D_CHECK_ARG(src && dst && rows >= 0 && k > 0 && rows_out >= rows && k_pad >= k && (k_pad % 8) == 0 && (side == 0 || side == 1),
-                   "mv2d_split3_operand: bad args (k_pad >= k, a multiple of 8; side 0 = [hi|lo|hi], 1 = [hi|hi|lo])");
-    if (rows_out == 0) return MV2D_OK;
-    hipLaunchKernelGGL(split3_op_kernel, dim3(cdiv(k_pad, 32), cdiv(rows_out, 32)), dim3(256), 0, (hipStream_t)stream, src, ld, rows, k, transpose,
-                       (unsigned short*)dst, rows_out, k_pad, side);
-    MV2D_LAUNCH_CHECK();
-    return MV2D_OK;
-}
 
 extern "C" int mv2d_colsum_scratch_rows(int rows) { return rows > 2 * CS_ROWS ? cdiv(rows, CS_ROWS) : 0; }
 
@@ -162,72 +108,10 @@ extern "C" int mv2d_layer_norm_bwd(const float* x, const float* dy, const float*
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
-// Composite entries (round 3): one call = the whole launch sequence of a split-precision product / of a linear layer's backward, on a
-// caller-provided workspace.  The training step was launch-bound from Python (~1500 launches of ~20 us host time each); the sequences
-// below are issued from C at a few microseconds per launch.
+// Composite entry: one call = the whole launch sequence of a linear layer's backward, on a caller-provided workspace (the training step was
+// launch-bound from Python; the sequence below is issued from C at a few microseconds per launch).
 // ---------------------------------------------------------------------------------------------------------------------------------------
-extern "C" int mv2d_gemm_bf16_ex(const void* A, const void* A2, int n_split, int a_mode, const void* W, const float* bias, int M, int N, int K, int lda,
-                                 const int* m_dev, int act, const float* mul, int ldmul, const float* add, int ldadd, void* C, int c_bf16, int ldc,
-                                 long long c_blk_stride, int c_blk_cols, void* C2, const float* add2, int ldc2, int ldadd2, int c_split3,
-                                 const int* add_idx, int add_period, int k_splits, long long c_split_stride, void* stream);
-
 static inline long long al256(long long b) { return (b + 255) & ~255LL; }
-static inline int pad_to(int n, int m) { return (n + m - 1) / m * m; }
-static int mm_splits(int M, int Np, int kp, int act) {
-    // few output tiles with a long contraction (weight gradients: K = the rows of the layer input): split K over the grid's y dimension
-    const long long tiles = (long long)cdiv(M, 64) * cdiv(Np, 64);
-    if (act != 0 || tiles >= 256 || kp < 1024) return 1;
-    long long s = 512 / tiles;
-    if (s < 1) s = 1;
-    if (s > 3LL * kp / 256) s = 3LL * kp / 256;
-    if (s > 64) s = 64;
-    return (int)s;
-}
-
-// bytes of workspace mv2d_matmul_nt_x3 needs for C[M,N] = op(A) op(B)^T with a contraction of K
-extern "C" long long mv2d_matmul_nt_x3_ws_bytes(int M, int N, int K) {
-    const int kp = pad_to(K, 64), Np = pad_to(N, 8);
-    const int splits = mm_splits(M, Np, kp, 0);
-    long long b = al256((long long)M * 3 * kp * 2) + al256((long long)Np * 3 * kp * 2) + al256((long long)Np * 4);
-    if (splits > 1) b += al256((long long)splits * M * Np * 4) + al256((long long)mv2d_colsum_scratch_rows(splits) * M * Np * 4);
-    return b;
-}
-
-// C [M, ldc >= pad8(N)] fp32 = act(op(A) op(B)^T + bias): A fp32 [M,K] (or [K,M] with trans_a), B fp32 [N,K] (or [K,N] with trans_b), unit
-// column stride, row strides lda / ldb; bias [N] or NULL; act 0 none / 1 ReLU.  Columns N .. pad8(N) of C are written too (zeros + nothing).
-extern "C" int mv2d_matmul_nt_x3(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act,
-                                 float* C, int ldc, int M, int N, int K, void* ws, long long ws_bytes, void* stream) {
-    MV2D_CHECK_ARG(A && B && C && M >= 0 && N > 0 && K > 0 && (act == 0 || act == 1), "mv2d_matmul_nt_x3: bad args");
-    if (M == 0) return MV2D_OK;
-    const int kp = pad_to(K, 64), Np = pad_to(N, 8);
-    MV2D_CHECK_ARG(ldc >= Np && (ldc % 4) == 0, "mv2d_matmul_nt_x3: ldc >= N rounded up to 8, a multiple of 4");
-    MV2D_CHECK_ARG(ws && ws_bytes >= mv2d_matmul_nt_x3_ws_bytes(M, N, K) && ((uintptr_t)ws & 255) == 0, "mv2d_matmul_nt_x3: workspace too small / misaligned");
-    const int splits = mm_splits(M, Np, kp, act);
-    char* w = (char*)ws;
-    void* a3 = w; w += al256((long long)M * 3 * kp * 2);
-    void* b3 = w; w += al256((long long)Np * 3 * kp * 2);
-    float* bias_p = (float*)w; w += al256((long long)Np * 4);
-    float* slabs = (float*)w; if (splits > 1) w += al256((long long)splits * M * Np * 4);
-    float* scratch = (float*)w;
-    hipStream_t st = (hipStream_t)stream;
-    int rc;
-    if ((rc = mv2d_split3_operand(A, lda, M, K, trans_a, a3, M, kp, 0, stream)) != MV2D_OK) return rc;
-    if ((rc = mv2d_split3_operand(B, ldb, N, K, trans_b, b3, Np, kp, 1, stream)) != MV2D_OK) return rc;
-    const float* bp = bias;
-    if (bias && Np != N) {
-        if (hipMemsetAsync(bias_p, 0, (size_t)Np * 4, st) != hipSuccess || hipMemcpyAsync(bias_p, bias, (size_t)N * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
-            return MV2D_ERR_LAUNCH;
-        bp = bias_p;
-    }
-    if (splits > 1) {
-        MV2D_CHECK_ARG(ldc == Np, "mv2d_matmul_nt_x3: the split-K route writes a dense C (ldc = N rounded up to 8)");
-        if ((rc = mv2d_gemm_bf16_ex(a3, nullptr, 0, 0, b3, bp, M, Np, 3 * kp, 3 * kp, nullptr, 0, nullptr, 0, nullptr, 0, slabs, 0, Np, 0, 0, nullptr, nullptr,
-                                    0, 0, 0, nullptr, 0, splits, (long long)M * Np, stream)) != MV2D_OK) return rc;
-        return mv2d_colsum(slabs, (long long)M * Np, splits, M * Np, C, mv2d_colsum_scratch_rows(splits) ? scratch : nullptr, stream);
-    }
-    return mv2d_gemm_bf16_ex(a3, nullptr, 0, 0, b3, bp, M, Np, 3 * kp, 3 * kp, nullptr, act, nullptr, 0, nullptr, 0, C, 0, ldc, 0, 0, nullptr, nullptr, 0, 0, 0,
-                             nullptr, 0, 1, 0, stream);
-}
 
 extern "C" long long mv2d_gemm_f32x3_ws_bytes(int M, int N, int K);
 extern "C" int mv2d_gemm_f32x3(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act,

@@ -4,19 +4,21 @@
 // for PETRMultiheadAttention's core (MU/petr_transformer.py:426-513, nn.MultiheadAttention with an attn_mask).
 //
 // The in_proj of the keys / values is folded into the QUERY side, so the key side of every layer and head reads the same two
-// bf16 row arrays (Xk = feat + pe, Xv = feat at the gathered positions / RoI cells) and nothing per layer is written for the keys:
+// key16 row arrays (common.h: fp16 since round 4; Xk = feat + pe, Xv = feat at the gathered positions / RoI cells) and nothing per layer is
+// written for the keys:
 //
 //   logit_h[j] = q_h . (Wk_h x_j + bk_h)      = (Wk_h^T q_h) . x_j + const_h      (const_h cancels in the softmax over j)
 //   ctx_h      = sum_j p_hj (Wv_h v_j + bv_h) = Wv_h (sum_j p_hj v_j) + bv_h      (sum_j p_hj = 1)
 //
 // Three launches per layer:
-//   xattn_qmap_kernel    Qt[r] = (Wk_h^T q_h)_h as a 16 x 256 bf16 MFMA operand per query: rows 0-7 = bf16 "hi" parts of the
-//                        eight heads, rows 8-15 = the "lo" remainders (fp32-class query side), stored fragment-major.
+//   xattn_qmap_kernel    Qt[r] = (Wk_h^T q_h)_h as a 16 x 256 key16 MFMA operand per query: rows 0-7 = the "hi" parts of the
+//                        eight heads, rows 8-15 = the "lo" remainders (fp32-class query side), stored fragment-major.  (The map
+//                        itself is a bf16x3 product on the fp32 query; only its RESULT is split into the key-side format.)
 //   xattn_tile_kernel    one block per query, the keys of its CSR row dealt to the waves in tiles of 16: the tile's Xk rows are
 //                        gathered with whole-row (512 B) coalesced loads into an XOR-swizzled LDS tile, logits S[16 x 16] =
-//                        Qt . Xk_tile^T on v_mfma_f32_16x16x32_bf16 (hi and lo rows of Qt in one instruction: the sum of the
+//                        Qt . Xk_tile^T on v_mfma_f32_16x16x32_f16 (hi and lo rows of Qt in one instruction: the sum of the
 //                        two row groups is the fp32-class logit), online softmax per head, P split hi / lo into the same 16
-//                        operand rows, z += P . Xv_tile on v_mfma_f32_16x16x16_bf16 with the Xv rows loaded row-contiguous
+//                        operand rows, z += P . Xv_tile on v_mfma_f32_16x16x16_f16 with the Xv rows loaded row-contiguous
 //                        (16 B per lane) and transposed in registers (v_perm) into key-major B fragments.
 //   xattn_ctxmap_kernel  ctx = Wv_h z_h + bv (bf16x3), empty CSR rows -> NaN (the reference's behaviour) or 0.
 #include "common.h"
@@ -27,7 +29,6 @@ constexpr int C = 256, HEADS = 8;
 constexpr float LOG2E = 1.4426950408889634f;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 xt_bf16x8;
-typedef __attribute__((ext_vector_type(4))) short xt_s16x4;
 union XtFrag { uint4 u; xt_bf16x8 v; };
 
 __device__ __forceinline__ void xt_split8(const float4& x0, const float4& x1, XtFrag& hi, XtFrag& lo) {
@@ -38,6 +39,16 @@ __device__ __forceinline__ void xt_split8(const float4& x0, const float4& x1, Xt
         h[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
         l[i] = pack_bf16x2(f[2 * i] - __uint_as_float(h[i] << 16), f[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
     }
+    hi.u = make_uint4(h[0], h[1], h[2], h[3]);
+    lo.u = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// fp32 x 8 -> key16 hi / lo fragments (the format the tile kernel's MFMAs read)
+__device__ __forceinline__ void xt_split8_k16(const float4& x0, const float4& x1, XtFrag& hi, XtFrag& lo) {
+    const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    unsigned int h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_k16x2(f[2 * i], f[2 * i + 1], h[i], l[i]);
     hi.u = make_uint4(h[0], h[1], h[2], h[3]);
     lo.u = make_uint4(l[0], l[1], l[2], l[3]);
 }
@@ -84,8 +95,8 @@ __global__ __launch_bounds__(512) void xattn_qmap_kernel(const float* __restrict
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 XtFrag hi, lo;
-                xt_split8(make_float4(acc[2 * u][0], acc[2 * u][1], acc[2 * u][2], acc[2 * u][3]),
-                          make_float4(acc[2 * u + 1][0], acc[2 * u + 1][1], acc[2 * u + 1][2], acc[2 * u + 1][3]), hi, lo);
+                xt_split8_k16(make_float4(acc[2 * u][0], acc[2 * u][1], acc[2 * u][2], acc[2 * u][3]),
+                              make_float4(acc[2 * u + 1][0], acc[2 * u + 1][1], acc[2 * u + 1][2], acc[2 * u + 1][3]), hi, lo);
                 const int c = u * 8 + g * 2, r8 = n & 7;
                 st[r8 * 64 + (c ^ (r8 << 1))] = hi.u;
                 st[r8 * 64 + ((c + 1) ^ (r8 << 1))] = lo.u;
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(512) void xattn_ctxmap_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------------
 // tile attention: see the file header.  One block (NW waves) per query; wave w takes the key tiles w, w + NW, ...
-//   Qt  [R][8 heads][8 k-steps][4][hi | lo][8] bf16 (xattn_qmap_kernel), Xk / Xv [S][256] bf16, CSR row_ptr / col_idx, z [R][8][256] fp32
+//   Qt  [R][8 heads][8 k-steps][4][hi | lo][8] key16 (xattn_qmap_kernel), Xk / Xv [S][256] key16, CSR row_ptr / col_idx, z [R][8][256] fp32
 // LDS (one array): per wave an 8 KB key tile (16 rows x 32 chunks of 16 B, chunk c of row r at slot c ^ (r & 15): the
 // fragment reads of 16 different rows hit 16 different bank slots) that later holds the wave's partial z, 512 B of P, and the
 // softmax statistics of the merge.
@@ -199,7 +210,7 @@ __global__ __launch_bounds__(512) void xattn_ctxmap_kernel(const float* __restri
 __device__ __forceinline__ unsigned int xt_lo_pair(unsigned int a, unsigned int b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }     // (a.lo16, b.lo16)
 __device__ __forceinline__ unsigned int xt_hi_pair(unsigned int a, unsigned int b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }     // (a.hi16, b.hi16)
 
-// XLO (the engine's index-exact validation mode): the key / value rows come as bf16 hi + lo pairs (fp32-class key side):
+// XLO (the engine's index-exact route): the key / value rows come as key16 hi + lo pairs (fp32-class key side):
 // logits += Qt_hi . Xk_lo, z += P_hi . Xv_lo (the lo x lo terms, 2^-18 relative, are dropped).
 // maximum over the 16 lanes of a DPP row (lane & 15 = the key of a tile): two quad permutes, then the half-row and the row mirror.  Four
 // v_max with a DPP operand instead of four dependent ds_bpermute round trips per softmax row.
@@ -305,12 +316,12 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
         for (int s = 0; s < 8; ++s) {
             XtFrag kb;
             kb.u = kt[n * 32 + ((4 * s + g) ^ n)];
-            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[s].v, kb.v, sacc, 0, 0, 0);
+            sacc = mfma_k16_16x16x32(qa[s].u, kb.u, sacc);
             if (XLO) {
                 XtFrag kl, qh;
                 kl.u = kt2[n * 32 + ((4 * s + g) ^ n)];
                 qh.u = n < 8 ? qa[s].u : make_uint4(0u, 0u, 0u, 0u);              // hi rows only
-                sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh.v, kl.v, sacc, 0, 0, 0);
+                sacc = mfma_k16_16x16x32(qh.u, kl.u, sacc);
             }
         }
         const bool valid = kbase + n < end;
@@ -340,15 +351,14 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
             for (int i = 0; i < 4; ++i) pl[(4 * g + i) * 16 + n] = p[i];
         }
         __builtin_amdgcn_wave_barrier();
-        xt_s16x4 pa, pah;
+        uint2 pa, pah;
         {
             const float4 pv = *reinterpret_cast<const float4*>(pl + (n & 7) * 16 + 4 * g);
-            const unsigned int h0 = pack_bf16x2(pv.x, pv.y), h1 = pack_bf16x2(pv.z, pv.w);
-            const unsigned int l0 = pack_bf16x2(pv.x - __uint_as_float(h0 << 16), pv.y - __uint_as_float(h0 & 0xffff0000u));
-            const unsigned int l1 = pack_bf16x2(pv.z - __uint_as_float(h1 << 16), pv.w - __uint_as_float(h1 & 0xffff0000u));
-            const uint2 sel = n < 8 ? make_uint2(h0, h1) : make_uint2(l0, l1);
-            pa = __builtin_bit_cast(xt_s16x4, sel);
-            pah = __builtin_bit_cast(xt_s16x4, n < 8 ? make_uint2(h0, h1) : make_uint2(0u, 0u));
+            unsigned int h0, h1, l0, l1;
+            split_k16x2_bounded(pv.x, pv.y, h0, l0);                               // probabilities: inside the fp16 range, no clamp
+            split_k16x2_bounded(pv.z, pv.w, h1, l1);
+            pa = n < 8 ? make_uint2(h0, h1) : make_uint2(l0, l1);
+            pah = n < 8 ? make_uint2(h0, h1) : make_uint2(0u, 0u);
         }
         // ---- z = alpha z + P . Xv_tile; column tile (H, w): output column n <-> channel 128 H + 8 n + w
 #pragma unroll
@@ -367,13 +377,13 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
 #pragma unroll
                     for (int i = 0; i < 4; ++i) zc[i] *= alpha[i];
                 }
-                zc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, __builtin_bit_cast(xt_s16x4, vb), zc, 0, 0, 0);
+                zc = mfma_k16_16x16x16(pa, vb, zc);
                 if (XLO) {
                     const unsigned int q0[4] = {vlo[0][H].x, vlo[0][H].y, vlo[0][H].z, vlo[0][H].w}, q1[4] = {vlo[1][H].x, vlo[1][H].y, vlo[1][H].z, vlo[1][H].w};
                     const unsigned int q2[4] = {vlo[2][H].x, vlo[2][H].y, vlo[2][H].z, vlo[2][H].w}, q3[4] = {vlo[3][H].x, vlo[3][H].y, vlo[3][H].z, vlo[3][H].w};
                     const uint2 vl = (w & 1) ? make_uint2(xt_hi_pair(q0[d], q1[d]), xt_hi_pair(q2[d], q3[d]))
                                              : make_uint2(xt_lo_pair(q0[d], q1[d]), xt_lo_pair(q2[d], q3[d]));
-                    zc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pah, __builtin_bit_cast(xt_s16x4, vl), zc, 0, 0, 0);
+                    zc = mfma_k16_16x16x16(pah, vl, zc);
                 }
                 Z[H * 8 + w] = zc;
             }
@@ -489,8 +499,7 @@ extern "C" int mv2d_xattn_tile_fwd_ex(const void* Qt, const void* Xk, const void
                        ((uintptr_t)Xk_lo & 15) == 0 && ((uintptr_t)Xv_lo & 15) == 0, "mv2d_xattn_tile_fwd: operands must be 16-byte aligned");
     MV2D_CHECK_ARG(waves == 0 || waves == 1 || waves == 2 || waves == 4 || waves == 8, "mv2d_xattn_tile_fwd: waves per query must be 1, 2, 4 or 8 (0: default)");
     if (R == 0) return MV2D_OK;
-    static const int env_nw = getenv("MV2D_XATTN_NW") ? atoi(getenv("MV2D_XATTN_NW")) : 0;       // experiment switch
-    const int nw = env_nw ? env_nw : (waves ? waves : 2);      // the engine passes its own choice (2: see engine.py)
+    const int nw = waves ? waves : 2;      // the engine passes its own choice (2: see engine.py)
 #define MV2D_XT(NW, DBG, XLO) hipLaunchKernelGGL((xattn_tile_kernel<NW, DBG, XLO>), dim3(R), dim3(64 * NW), 0, (hipStream_t)stream, (const uint4*)Qt, \
                                                  (const unsigned short*)Xk, (const unsigned short*)Xv, (const unsigned short*)Xk_lo, (const unsigned short*)Xv_lo, \
                                                  row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan, order, (unsigned int)row_bytes)

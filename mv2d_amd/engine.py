@@ -1,19 +1,18 @@
 """Fused MI355X inference engine for the MV2D RoI head hot path.
 
-One ``HeadEngine`` owns the packed weights (bf16 copies for the big-M MFMA GEMMs, fp32 for the per-query exact
-GEMMs, K/V in_proj of all decoder layers concatenated into one [2*L*256, 256] matrix), a shape-keyed workspace
-(every buffer pre-allocated, kernels never allocate) and enqueues the whole frame on the current HIP stream
-through the C-ABI (mv2d_amd.ops) without a single device->host synchronisation:
+One ``HeadEngine`` owns the packed weights (key16 = fp16 fragment-major copies for the key-side MFMA kernels, bf16 hi / lo pairs for the
+split-precision query-side kernels), a shape-keyed workspace (every buffer pre-allocated, kernels never allocate) and enqueues the whole
+frame on the current HIP stream through the C-ABI (mv2d_amd.ops) without a single device->host synchronisation:
 
   T path (MV2DTHead, RH/mv2d_t_head.py:26-142)        S path (MV2DSHead eval branch, RH/mv2d_s_head.py:122-211)
   rois -> per-RoI camera -> RoIAlign(feat) -> QueryGenerator -> ref points -> query_pos
   box correlation -> match lists                        box correlation (k=1) -> CSR over RoI-feature rows
   masks -> key list S + CSR (device-side counts)        RoI tap positions -> PE there -> RoIAlign(feat, pe)
-  PE only at the S key positions -> K/V of all 6 layers (one bf16 MFMA GEMM each side)
-  6 x [self-attn, LN, sparse cross-attn, LN, FFN, LN] -> heads (grouped GEMMs) -> top-k decode
+  PE only at the S key positions -> key rows (feat + pe) / value rows (feat), key16, shared by all layers and heads
+  6 x [self-attn, LN, cross-attn in the raw key space (K / V in_proj folded into the query side), LN, FFN, LN] -> heads -> top-k decode
 
 The reference evaluates PE on the whole map and runs dense [8,R,S] attention with a boolean mask; the outputs
-are identical up to the bf16 rounding of the key side.
+are identical up to the fp16 rounding of the key side; ``exact=True`` carries the key side as hi + lo pairs.
 """
 import math
 import os
@@ -70,13 +69,12 @@ class HeadEngine:
         self._shape_cache = {}
         self.prof = None              # dict name -> [events] when stage timing is on (bench.py)
         self.fork_qg = True           # T path: query-generator chain on a second stream
-        self.ffn_x3 = os.environ.get('MV2D_FFN_X3', '1') == '1'   # FFN in bf16x3 split precision (fragment-major hi/lo weights); 0: exact fp32
-        self.ffn_groups = int(os.environ.get('MV2D_FFN_G', '0'))   # hidden slices per FFN block (0: by the number of rows)
-        self.pe_fused = os.environ.get('MV2D_PE_FUSED', '1') == '1'   # one fused launch for the PE block instead of six GEMMs
+        # ---- route options (round 4: the retired A/B routes left the engine; what remains are ATTRIBUTES a caller may set before the first
+        # run, every one of them part of the hipGraph key -- DESIGN.md "switches" table).  The only environment variable the engine reads is
+        # MV2D_EXACT.
+        self.ffn_groups = 0           # hidden slices per FFN block (0: 8; it fixes the summation order, so it is NOT chosen by the row count)
         # adapt_pos3d(sine) (MU/pe.py:164-166) depends only on the weights and on the padding geometry of the rig, not on features, boxes
-        # or calibration: it is constant-folded into a per-(weights version, geometry) table that the fused PE kernel adds in its
-        # epilogue (default; MV2D_PE_SINE_TABLE=0 evaluates the branch per frame like the reference does)
-        self.pe_sine_table = self.pe_fused and os.environ.get('MV2D_PE_SINE_TABLE', '1') == '1'
+        # or calibration: it is constant-folded into a per-(weights version, geometry) table that the fused PE kernel adds in its epilogue
         self._weights_version = 0     # bumped by every load_state(): invalidates whatever was folded from the weights
         self.keep_sine_rows = False   # the training route reads the per-key sine rows (ws['A2']) although the inference kernel does not
         self.force_nc = None          # bench only (S path): overwrite the correlation lists so that every query reads n_c RoIs
@@ -84,74 +82,29 @@ class HeadEngine:
         # [L,8,col_cap] in CSR order, WITHOUT the per-(query, head) constant q_h . bk_h that cancels in the softmax) and the scaled,
         # projected queries ('dbg_q' [L,R,256]) they were computed from
         self.debug_attn = False
-        # out_proj + residual + LayerNorm (+ q in_proj) as one row-fused kernel per attention (8 instead of 11 launches per layer),
-        # its two linears in bf16x3 split precision (fp32-class: ~1e-5 relative).  MV2D_ROWS_X3=0: exact-fp32 fused kernel (slower than
-        # the unfused launches with one frame in flight); MV2D_FUSE_ROWS=0: separate exact-fp32 GEMM + LN launches.
-        self.rows_x3 = os.environ.get('MV2D_ROWS_X3', '1') == '1'
-        self.fuse_rows = os.environ.get('MV2D_FUSE_ROWS', '1') == '1'
-        # self-attention core inside the row-fused kernel: measured SLOWER (decoder 0.357 -> 0.432 ms: the fp32 MFMAs of 152 attention
-        # blocks land on 19 CUs) -> off; kept as an ABI entry / A-B switch
-        # (round 3: every launch runs on bucket-padded rows / several samples and mv2d_sa_block_fused_x3 takes no grp_start, so the engine
-        #  no longer routes through it at all; the kernel stays an ABI entry with its own kernel-level test)
-        if os.environ.get('MV2D_SA_FUSED', '0') == '1':
-            raise NotImplementedError('MV2D_SA_FUSED: mv2d_sa_block_fused_x3 has no per-sample row ranges (grp_start); the engine runs on bucket-padded rows')
-        self.sa_fused = False
-        # EXPERIMENT (off): cross attention on the UNPROJECTED key / value rows (mv2d_raw_xattn_fwd).  The query is mapped into the key
-        # input space per head, the K/V projection of all layers and its 90 MB per sample of output disappear; numerically it is at
-        # least as good (no bf16 rounding of K).  As implemented it loses 5 % (cfg2_s 5900 vs 6210 samples/s): the attention kernel takes
-        # 41 instead of 26 us per layer (8 x 256 instead of 8 x 32 multiply-adds per pair and side) and the two grouped per-head linears
-        # around it 14 us each for their [R,8,256] fp32 intermediates, against 28 us of K/V projection per layer.
-        # 'zero' rows need the projected route anyway (the value bias must not reach a query without keys).
-        self.raw_attn = os.environ.get('MV2D_RAW_ATTN', '0') == '1' and self.empty_nan
-        # DEFAULT cross-attention route (csrc/xattn_tile.hip): the K/V in_proj folded into per-head query / context maps, the attention
-        # core on bf16 MFMA tiles over the UNPROJECTED key / value rows gathered into LDS — no per-layer K/V in HBM, no kvproj launch.
-        # MV2D_XATTN=sparse selects the round-1 route (kvproj_kernel + one-block-per-query VALU kernel) for A/B runs.
-        self.tile_attn = os.environ.get('MV2D_XATTN', 'tile') == 'tile' and not self.raw_attn
-        # OPT-IN (measured slower): the per-head maps of the tile route inside the neighbouring row kernels (mv2d_attn_out_qmap_x3 /
-        # _zmap_x3: 6 instead of 8 launches per layer, bitwise the same results).  cfg2_s, 8 samples per launch: 27.4 + 25.7 us for the two
-        # fused kernels against 15.6 + 11.0 + 10.2 + 8.0 us for the four separate ones -- a row kernel is bound by streaming its weights
-        # through ONE CU per 32 rows, and the fused ones stream twice as much on 75 blocks while the separate map kernels spread over 150
-        # ... so they are used for SMALL launches only (<= 512 query rows, i.e. one sample per call: there the two saved launches per layer
-        # count and 19-38 blocks do not contend for L2: 0.764 -> 0.726 ms submit-to-result for one sample, 3780 -> 4114 samples/s with one
-        # sample per launch on 4 streams).  Bitwise the same results either way, so the choice may depend on the launch size.
-        # MV2D_XATTN_FUSE_MAPS=1 / 0 forces them on / off.
-        fm = os.environ.get('MV2D_XATTN_FUSE_MAPS')
-        self.fuse_maps = None if fm is None else fm == '1'
+        # The per-head query / context maps of the tile cross attention run inside the neighbouring row kernels (mv2d_attn_out_qmap_x3 /
+        # _zmap_x3: 6 instead of 8 launches per layer, bitwise the same results) for SMALL launches (<= 512 query rows, i.e. one sample per
+        # call: the two saved launches per layer count there) and as separate kernels for batches (a row kernel is bound by streaming its
+        # weights through ONE CU per 32 rows; the fused ones stream twice as much).  None: by the row count; True / False forces it.
+        self.fuse_maps = None
         # OPT-IN: evaluate the cls / reg branches of the last decoder layer only (what decoding reads).  Not the default: out['cls'] / out['reg']
         # then carry stale rows for the other layers, and the reference's forward does evaluate all six.
-        self.last_stage_heads = os.environ.get('MV2D_LAST_STAGE_HEADS', '0') == '1'
-        self.keep_xk = os.environ.get('MV2D_KEEP_XK', '0') == '1'   # always write both pe and Xk (S path: nothing reads Xk; T path: nothing reads pe)
-        # T path (round 3): the blocks of the per-query tile kernel run in the order of the queries' SMALLEST KEY (mv2d_xattn_query_order):
-        # neighbouring blocks of an XCD then read overlapping key sets from its L2 (cfg3_t 54.8 -> 47.6 us per layer, cfg5_t 60.2 -> 51.7 us;
-        # bitwise the same results).  MV2D_XATTN_ORDER=0 switches it off.
-        self.q_order = kind == 'T' and self.tile_attn and os.environ.get('MV2D_XATTN_ORDER', '1') == '1'
-        # OPT-IN, measured SLOWER: cross attention over QUERY TILES with shared key tiles (csrc/xattn_qtile.hip): the
-        # queries of a sample in that order, 8 or 16 per workgroup, the union of their key lists streamed once through an LDS-DMA ring,
-        # 16-bit pair masks.  It reads 1.40 x (16 per tile) the distinct rows instead of 2.99 x, but a union tile of 16 keys is only ~35 % allowed
-        # pairs for a given pair of queries, so the masked MFMA / softmax work triples and the kernel takes 137 - 172 us against 48 us.
-        self.qtile = kind == 'T' and self.tile_attn and os.environ.get('MV2D_XATTN_QTILE', '0') == '1'
-        self.qtile_queries = int(os.environ.get('MV2D_XATTN_QT', '8'))        # queries per tile: 8 (4 waves per workgroup) or 16 (8 waves)
-        nw = os.environ.get('MV2D_XATTN_NW')
-        # waves per query: the kernel alone takes the same 32-33 us per layer with 1, 2 or 4 (it moves its 161 MB at ~5 TB/s either way), but a
-        # launch with fewer waves leaves more of the chip to the other streams' kernels: cfg2_s 8067 / 8043 / 7869 samples/s for 1 / 2 / 4,
-        # cfg3_t (rows of ~200 keys) 5803 / 5868 / 5758; 8 is slower everywhere
-        self.xattn_waves = int(nw) if nw else 2
-        self.qg_x3 = os.environ.get('MV2D_QG_X3', '1') == '1'          # query-generator fcs + first in_proj as LDS-tiled bf16x3 linears (0: exact fp32)
-        self.heads_x3 = os.environ.get('MV2D_HEADS_X3', '1') == '1'    # prediction branches in bf16x3 (0: exact fp32)
-        # INDEX-EXACT VALIDATION MODE (exact=True / MV2D_EXACT=1): every bf16 rounding of the default path is replaced by fp32-class
-        # arithmetic -- PE MLPs and the query generator's conv in bf16x3 / exact-fp32 MFMA GEMMs on unrounded inputs, key / value rows as
-        # bf16 hi + lo pairs in the tile attention -- so that the INTEGER outputs (labels, bbox_index) can be compared bit for bit with
-        # the reference's (tests/test_gpu_golden.py).  Round 3: no host synchronisation, no per-frame allocation, no torch glue -- the
-        # route is enqueue-only and hipGraph-replayable like the default one (bench.py: samples_s_index_exact).
+        self.last_stage_heads = False
+        self.keep_xk = False          # always write both pe and Xk (S path: nothing reads Xk; T path: nothing reads pe)
+        # T path: the blocks of the per-query tile kernel run in the order of the queries' SMALLEST KEY (mv2d_xattn_query_order): neighbouring
+        # blocks of an XCD then read overlapping key sets from its L2 (cfg3_t 54.8 -> 47.6 us per layer; bitwise the same results)
+        self.q_order = kind == 'T'
+        # waves per query of the tile kernel: the kernel alone takes the same time with 1, 2 or 4 (it is bound by what the memory system
+        # delivers), but a launch with fewer waves leaves more of the chip to the other streams' kernels: cfg2_s 8067 / 8043 / 7869
+        # samples/s for 1 / 2 / 4, cfg3_t (rows of ~200 keys) 5803 / 5868 / 5758
+        self.xattn_waves = 2
+        # INDEX-EXACT ROUTE (exact=True / MV2D_EXACT=1 / test_cfg.index_exact): every 16-bit rounding of the default route's key side is
+        # replaced by fp32-class arithmetic -- PE MLPs as K-concatenated split-precision products on unrounded inputs, the query generator's
+        # conv and the key / value rows of the tile attention as key16 hi + lo pairs -- so that the INTEGER outputs (labels, bbox_index)
+        # can be compared bit for bit with the reference's (tests/test_gpu_golden.py).  Enqueue-only and hipGraph-replayable like the
+        # default route (bench.py: samples_s_index_exact).
         self.exact = (os.environ.get('MV2D_EXACT', '0') == '1') if exact is None else bool(exact)
-        self.exact_linear = False
-        if self.exact:
-            assert self.tile_attn, 'the exact mode runs on the tile cross-attention route'
-            # MV2D_EXACT_GEMM=linear: the round-3a route through mv2d_linear_x3_ex (A/B switch; the default runs the fp32-class products
-            # through the plain bf16 tile GEMM by K-concatenation, see _exact_pe)
-            self.exact_linear = os.environ.get('MV2D_EXACT_GEMM', 'cat3') == 'linear'
-            if self.exact_linear:
-                self.pe_sine_table = False
+        self.K16 = ops.key16_dtype()  # dtype of the key side's 16-bit buffers (csrc/common.h "key16": fp16 since round 4)
         self.load_state(state_dict)
 
     # ------------------------------------------------------------------------------------------ weights
@@ -159,49 +112,34 @@ class HeadEngine:
         d, L = self.dev, self.L
         self._weights_version = getattr(self, '_weights_version', 0) + 1
         g = lambda k: _t(sd[k], d, F32)
-        b16 = lambda t: ops.f32_to_bf16(t.contiguous())
+        k16 = ops.pack_key16                                                             # fp32 [N,K] -> key16, fragment-major (key-side kernels)
         w = {}
         dec = 'bbox_head.transformer.decoder.'
         for i in range(L):
             p = f'{dec}layers.{i}.'
-            w[f'sa_in_w{i}'] = g(p + 'attentions.0.attn.in_proj_weight')
             w[f'sa_in_b{i}'] = g(p + 'attentions.0.attn.in_proj_bias')
-            w[f'sa_out_w{i}'] = g(p + 'attentions.0.attn.out_proj.weight')
             w[f'sa_out_b{i}'] = g(p + 'attentions.0.attn.out_proj.bias')
             inw, inb = g(p + 'attentions.1.attn.in_proj_weight'), g(p + 'attentions.1.attn.in_proj_bias')
-            w[f'ca_q_w{i}'] = inw[:C].contiguous()
             w[f'ca_q_b{i}'] = inb[:C].contiguous()
-            w[f'_k_w{i}'], w[f'_k_b{i}'] = inw[C:2 * C], inb[C:2 * C]
-            w[f'_v_w{i}'], w[f'_v_b{i}'] = inw[2 * C:], inb[2 * C:]
-            if self.raw_attn:                                                            # per-head maps around the raw-row attention
-                w[f'ca_hin{i}'], w[f'ca_hout{i}'] = ops.pack_head_maps(inw[C:2 * C].contiguous(), inw[2 * C:].contiguous())
-                w[f'ca_v_b{i}'] = inb[2 * C:].contiguous()
-            if self.tile_attn:                                                           # packed operands of xattn_qmap / xattn_ctxmap
-                w[f'ca_mapA{i}'], w[f'ca_mapB{i}'] = ops.pack_xattn_maps(inw[C:2 * C].contiguous(), inw[2 * C:].contiguous())
-                w[f'ca_v_b{i}'] = inb[2 * C:].contiguous()
-            w[f'ca_out_w{i}'] = g(p + 'attentions.1.attn.out_proj.weight')
+            # packed operands of xattn_qmap / xattn_ctxmap: the K / V in_proj ride on the query side (bf16x3)
+            w[f'ca_mapA{i}'], w[f'ca_mapB{i}'] = ops.pack_xattn_maps(inw[C:2 * C].contiguous(), inw[2 * C:].contiguous())
+            w[f'ca_v_b{i}'] = inb[2 * C:].contiguous()
             w[f'ca_out_b{i}'] = g(p + 'attentions.1.attn.out_proj.bias')
-            w[f'ffn_w1{i}'] = g(p + 'ffns.0.layers.0.0.weight')
             w[f'ffn_b1{i}'] = g(p + 'ffns.0.layers.0.0.bias')
-            w[f'ffn_w2{i}'] = g(p + 'ffns.0.layers.1.weight')
             w[f'ffn_b2{i}'] = g(p + 'ffns.0.layers.1.bias')
-            for k in ('sa_in_w', 'sa_out_w', 'ca_q_w', 'ca_out_w'):                      # bf16x3 + fragment-major copies (row-fused kernels)
-                w[f'{k}x{i}'] = ops.pack_x3(w[f'{k}{i}'])
-            w[f'ffn_w1p{i}'], w[f'ffn_w2p{i}'] = ops.ffn_pack_weights(w[f'ffn_w1{i}'], w[f'ffn_w2{i}'])   # fragment-major copies
-            if self.ffn_x3:
-                w[f'ffn_w1x{i}'] = ops.pack_x3(w[f'ffn_w1{i}'])
-                w[f'ffn_w2x{i}'] = ops.pack_x3(w[f'ffn_w2{i}'])
+            # bf16x3 + fragment-major copies (row-fused kernels, fused FFN)
+            w[f'sa_in_wx{i}'] = ops.pack_x3(g(p + 'attentions.0.attn.in_proj_weight'))
+            w[f'sa_out_wx{i}'] = ops.pack_x3(g(p + 'attentions.0.attn.out_proj.weight'))
+            w[f'ca_q_wx{i}'] = ops.pack_x3(inw[:C].contiguous())
+            w[f'ca_out_wx{i}'] = ops.pack_x3(g(p + 'attentions.1.attn.out_proj.weight'))
+            w[f'ffn_w1x{i}'] = ops.pack_x3(g(p + 'ffns.0.layers.0.0.weight'))
+            w[f'ffn_w2x{i}'] = ops.pack_x3(g(p + 'ffns.0.layers.1.weight'))
             for n in range(3):
                 w[f'ln{n}_w{i}'] = g(p + f'norms.{n}.weight')
                 w[f'ln{n}_b{i}'] = g(p + f'norms.{n}.bias')
-        # K/V in_proj of every layer in one matrix: rows [K_0..K_{L-1} | V_0..V_{L-1}]
-        kv_w = torch.cat([w.pop(f'_k_w{i}') for i in range(L)] + [w.pop(f'_v_w{i}') for i in range(L)], 0).contiguous()
-        kv_b = torch.cat([w.pop(f'_k_b{i}') for i in range(L)] + [w.pop(f'_v_b{i}') for i in range(L)], 0).contiguous()
-        w['kv_w'], w['kv_b'] = b16(kv_w), kv_b
         w['post_w'], w['post_b'] = g(dec + 'post_norm.weight'), g(dec + 'post_norm.bias')
-        w['qe_w0'], w['qe_b0'] = g('bbox_head.query_embedding.0.weight'), g('bbox_head.query_embedding.0.bias')
-        w['qe_w2'], w['qe_b2'] = g('bbox_head.query_embedding.2.weight'), g('bbox_head.query_embedding.2.bias')
-        w['qe_w0x'], w['qe_w2x'] = ops.pack_x3(w['qe_w0']), ops.pack_x3(w['qe_w2'])      # bf16x3 + fragment-major (row-fused kernel)
+        w['qe_b0'], w['qe_b2'] = g('bbox_head.query_embedding.0.bias'), g('bbox_head.query_embedding.2.bias')
+        w['qe_w0x'], w['qe_w2x'] = ops.pack_x3(g('bbox_head.query_embedding.0.weight')), ops.pack_x3(g('bbox_head.query_embedding.2.weight'))
         st = lambda fmt: torch.stack([g(fmt.format(l)) for l in range(L)]).contiguous()
         for n in ('0', '3'):
             w[f'cls_w{n}'], w[f'cls_b{n}'] = st('bbox_head.cls_branches.{}.' + n + '.weight'), st('bbox_head.cls_branches.{}.' + n + '.bias')
@@ -211,63 +149,57 @@ class HeadEngine:
         for n in ('0', '2', '4'):
             w[f'reg_w{n}'], w[f'reg_b{n}'] = st('bbox_head.reg_branches.{}.' + n + '.weight'), st('bbox_head.reg_branches.{}.' + n + '.bias')
         q = 'query_generator.'
-        conv = g(q + 'shared_convs.0.conv.weight')                                    # [256,256,3,3] -> [out][tap][cin]
-        w['qg_conv_w'] = b16(conv.permute(0, 2, 3, 1).reshape(C, 9 * C))
-        w['qg_conv_wp'] = ops.pack_wfrag(w['qg_conv_w'])                              # fragment-major copy for the fused conv kernel
+        conv = g(q + 'shared_convs.0.conv.weight').permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous()       # [256,256,3,3] -> [out][tap][cin]
+        w['qg_conv_wp'] = k16(conv)                                                   # key16, fragment-major: the fused conv kernel
         w['qg_conv_b'] = g(q + 'shared_convs.0.conv.bias')
-        w['qg_fc_w'], w['qg_fc_b'] = g(q + 'shared_fcs.0.weight'), g(q + 'shared_fcs.0.bias')
+        w['qg_fc_b'] = g(q + 'shared_fcs.0.bias')
         e0 = g(q + 'extra_enc.0.weight')                                              # [512,1040] -> K padded to 1056
         e0p = torch.zeros((e0.shape[0], 1056), device=d, dtype=F32)
         e0p[:, :e0.shape[1]] = e0
-        w['qg_e0_w'], w['qg_e0_b'] = e0p, g(q + 'extra_enc.0.bias')
-        w['qg_e2_w'], w['qg_e2_b'] = g(q + 'extra_enc.2.weight'), g(q + 'extra_enc.2.bias')
+        w['qg_e0_b'], w['qg_e2_b'] = g(q + 'extra_enc.0.bias'), g(q + 'extra_enc.2.bias')
         w['qg_c_w'], w['qg_c_b'] = g(q + 'fc_center.weight'), g(q + 'fc_center.bias')
-        if self.qg_x3:                                                                # LDS-tiled bf16x3 linears (mv2d_linear_x3)
-            for k in ('qg_fc_w', 'qg_e0_w', 'qg_e2_w'):
-                w[k + 'x'] = ops.pack_x3(w[k])
+        # LDS-tiled bf16x3 linears (mv2d_linear_x3)
+        w['qg_fc_wx'], w['qg_e0_wx'], w['qg_e2_wx'] = ops.pack_x3(g(q + 'shared_fcs.0.weight')), ops.pack_x3(e0p), ops.pack_x3(g(q + 'extra_enc.2.weight'))
         pe = 'position_encoding.'
-        c1 = lambda k: g(pe + k).flatten(1)
-        w['pe_w1a'], w['pe_b1a'] = b16(c1('position_encoder.0.weight')), g(pe + 'position_encoder.0.bias')
-        w['pe_w1b'], w['pe_b1b'] = b16(c1('position_encoder.2.weight')), g(pe + 'position_encoder.2.bias')
-        w['pe_w2a'], w['pe_b2a'] = b16(c1('adapt_pos3d.0.weight')), g(pe + 'adapt_pos3d.0.bias')
-        w['pe_w2b'], w['pe_b2b'] = b16(c1('adapt_pos3d.2.weight')), g(pe + 'adapt_pos3d.2.bias')
-        w['pe_wr'], w['pe_br'] = b16(c1('fpe.conv_reduce.weight')), g(pe + 'fpe.conv_reduce.bias')
-        w['pe_we'], w['pe_be'] = b16(c1('fpe.conv_expand.weight')), g(pe + 'fpe.conv_expand.bias')
-        # fragment-major copies for the fused PE kernel
-        # (one allocation, in the order the kernel streams them)
-        names = ('wr', 'we', 'w1a', 'w1b', 'w2a', 'w2b')
-        packs = [ops.pack_wfrag(w['pe_' + n]).view(-1) for n in names]
+        c1 = lambda k: g(pe + k).flatten(1).contiguous()
+        pe_names = (('w1a', 'position_encoder.0'), ('w1b', 'position_encoder.2'), ('w2a', 'adapt_pos3d.0'), ('w2b', 'adapt_pos3d.2'),
+                    ('wr', 'fpe.conv_reduce'), ('we', 'fpe.conv_expand'))
+        for n_, k_ in pe_names:
+            w['pe_b' + n_[1:]] = g(pe + k_ + '.bias')
+        self._pe_w32 = {n_: c1(k_ + '.weight') for n_, k_ in pe_names}               # fp32 originals (3 MB): _c3 builds split copies on demand
+        # fragment-major key16 copies for the fused PE kernel (one allocation, in the order the kernel streams them)
+        names = ('wr', 'we', 'w1a', 'w1b')
+        packs = [k16(c1(dict(pe_names)[n] + '.weight')).view(-1) for n in names]
         flat, off = torch.cat(packs), 0
-        w['pe_pack'] = dict(b1a=w['pe_b1a'], b1b=w['pe_b1b'], b2a=w['pe_b2a'], b2b=w['pe_b2b'], br=w['pe_br'], be=w['pe_be'], flat=flat)
+        w['pe_pack'] = dict(b1a=w['pe_b1a'], b1b=w['pe_b1b'], br=w['pe_br'], be=w['pe_be'], flat=flat)
         for n, t in zip(names, packs):
             w['pe_pack'][n] = flat[off:off + t.numel()]
             off += t.numel()
+        # K-concatenated split-precision weights [w_hi | w_hi | w_lo] (bf16) for the plain tile GEMM (partner of mv2d_split3_rows): the sine
+        # branch's table is built in fp32-class arithmetic on BOTH routes (once per (weights, geometry)); the index-exact route runs all three
+        # PE MLPs that way per frame
+        for n_, k_ in (pe_names if self.exact else pe_names[2:4]):
+            w['pe_' + n_ + '_c3'] = ops.cat3_weight(c1(k_ + '.weight'))
         if self.exact:
-            for n_, k_ in (('w1a', 'position_encoder.0'), ('w1b', 'position_encoder.2'), ('w2a', 'adapt_pos3d.0'), ('w2b', 'adapt_pos3d.2'),
-                           ('wr', 'fpe.conv_reduce'), ('we', 'fpe.conv_expand')):
-                w['pe_' + n_ + '_x3'] = ops.pack_x3(c1(k_ + '.weight').contiguous())
-            w['qg_conv_wx3'] = ops.pack_x3(conv.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous())
-            # K-concatenated split-precision weights [w_hi | w_hi | w_lo] for the plain bf16 GEMM (partner of mv2d_split3_rows)
-            for n_, k_ in (('w1a', 'position_encoder.0'), ('w1b', 'position_encoder.2'), ('w2a', 'adapt_pos3d.0'), ('w2b', 'adapt_pos3d.2'),
-                           ('wr', 'fpe.conv_reduce'), ('we', 'fpe.conv_expand')):
-                w['pe_' + n_ + '_c3'] = ops.cat3_weight(c1(k_ + '.weight').contiguous())
+            w['qg_conv_wx3'] = ops.pack_key16_x3(conv)
         self.w = w
-        for k in ('cls_w0', 'cls_w3', 'reg_w0', 'reg_w2'):                              # [L,256,256] -> fragment-major copies for heads_fused
-            w[k + 'p'] = ops.pack_wfrag_f32(w[k])
-        if self.heads_x3:
-            for k in ('cls_w0', 'cls_w3', 'reg_w0', 'reg_w2'):
-                w[k + 'x'] = ops.pack_x3_stack(w[k])
-            self.cls_ptrs_x3 = ops.make_ptr_array([*w['cls_w0x'], w['cls_b0'], w['cls_lnw1'], w['cls_lnb1'], *w['cls_w3x'], w['cls_b3'], w['cls_lnw4'],
-                                                   w['cls_lnb4'], w['cls_w6'], w['cls_b6']])
-            self.reg_ptrs_x3 = ops.make_ptr_array([*w['reg_w0x'], w['reg_b0'], *w['reg_w2x'], w['reg_b2'], w['reg_w4'], w['reg_b4']])
-            # the same tensors from the last decoder layer on: the launch of the last_stage_heads option (every tensor is stacked over L)
-            ll = self.L - 1
-            self._last_cls = [t[ll:] for t in (*w['cls_w0x'], w['cls_b0'], w['cls_lnw1'], w['cls_lnb1'], *w['cls_w3x'], w['cls_b3'], w['cls_lnw4'],
-                                               w['cls_lnb4'], w['cls_w6'], w['cls_b6'])]
-            self._last_reg = [t[ll:] for t in (*w['reg_w0x'], w['reg_b0'], *w['reg_w2x'], w['reg_b2'], w['reg_w4'], w['reg_b4'])]
-            self.cls_ptrs_x3_last, self.reg_ptrs_x3_last = ops.make_ptr_array(self._last_cls), ops.make_ptr_array(self._last_reg)
-        self.cls_ptrs = ops.make_ptr_array([w[k] for k in ('cls_w0p', 'cls_b0', 'cls_lnw1', 'cls_lnb1', 'cls_w3p', 'cls_b3', 'cls_lnw4', 'cls_lnb4', 'cls_w6', 'cls_b6')])
-        self.reg_ptrs = ops.make_ptr_array([w[k] for k in ('reg_w0p', 'reg_b0', 'reg_w2p', 'reg_b2', 'reg_w4', 'reg_b4')])
+        for k in ('cls_w0', 'cls_w3', 'reg_w0', 'reg_w2'):                              # [L,256,256] -> bf16x3, fragment-major, stacked over L
+            w[k + 'x'] = ops.pack_x3_stack(w[k])
+        cls_t = (*w['cls_w0x'], w['cls_b0'], w['cls_lnw1'], w['cls_lnb1'], *w['cls_w3x'], w['cls_b3'], w['cls_lnw4'], w['cls_lnb4'], w['cls_w6'], w['cls_b6'])
+        reg_t = (*w['reg_w0x'], w['reg_b0'], *w['reg_w2x'], w['reg_b2'], w['reg_w4'], w['reg_b4'])
+        self.cls_ptrs_x3, self.reg_ptrs_x3 = ops.make_ptr_array(list(cls_t)), ops.make_ptr_array(list(reg_t))
+        # the same tensors from the last decoder layer on: the launch of the last_stage_heads option (every tensor is stacked over L)
+        ll = self.L - 1
+        self._last_cls, self._last_reg = [t[ll:] for t in cls_t], [t[ll:] for t in reg_t]
+        self.cls_ptrs_x3_last, self.reg_ptrs_x3_last = ops.make_ptr_array(self._last_cls), ops.make_ptr_array(self._last_reg)
+
+    def _c3(self, name):
+        """K-concatenated split-precision copy [w_hi | w_hi | w_lo] of a PE weight ('w1a', 'w1b', 'w2a', 'w2b', 'wr', 'we'), built on first use
+        on the default route (which only keeps the sine branch's pair; the index-exact route holds all six)."""
+        k = 'pe_' + name + '_c3'
+        if k not in self.w:
+            self.w[k] = ops.cat3_weight(self._pe_w32[name])
+        return self.w[k]
 
     # ------------------------------------------------------------------------------------------ workspace
     def _workspace(self, V, h, w, R, Vg=None):
@@ -340,9 +272,10 @@ class HeadEngine:
             ws['view_start' + sfx] = buf[o1:o2]
             ws['grp_start' + sfx] = buf[o2:o3]
             ws['dt_rows' + sfx] = buf[o3:].view(F32)
+        K16 = self.K16
         ws['featcl'] = e((P, C))
         ws['enc'] = z((R, 1056)); ws['minv'] = e((R, 16))
-        ws['roi_feat'] = e((R, 49, C), BF16)
+        ws['roi_feat'] = e((R, 49, C), K16)
         ws['enc1'] = e((R, 512)); ws['enc2'] = e((R, C)); ws['center'] = e((R, 3))
         ws['xyz'] = e((R, 3)); ws['ref'] = e((R, 3)); ws['posemb'] = e((R, 384)); ws['qe1'] = e((R, C)); ws['qpos'] = e((R, C))
         ws['match'] = e((R, Vg, self.topk), torch.int32)
@@ -350,7 +283,7 @@ class HeadEngine:
         ws['zbuf'] = z(Pp + 16, torch.uint8)                     # roi_mask | nnz[2]: cleared by ONE fill per frame
         ws['roi_mask'] = ws['zbuf'][:P]
         ws['nnz'] = ws['zbuf'][Pp:Pp + 8].view(torch.int32)
-        ws['qt_ctl'] = ws['zbuf'][Pp + 8:Pp + 16].view(torch.int32)      # query-tile tables: allocation counter | overflow flag (zeroed with zbuf)
+        ws['qt_ctl'] = ws['zbuf'][Pp + 8:Pp + 16].view(torch.int32)      # query-order flags (zeroed with zbuf)
         ws['zero_mask'] = z(P, torch.uint8)
         ws['rect'] = e((R, 5), torch.int32); ws['pos2s'] = e(P, torch.int32); ws['s2pos'] = e(P, torch.int32)
         ws['S_dev'] = z(1, torch.int32)
@@ -360,56 +293,39 @@ class HeadEngine:
             ws['row_count'] = e(R, torch.int32)
             ws['col_cap'] = R * self.col_cap_per_query
             ws['S_kv'] = P
-            ws['csr_words'] = ops.csr_workspace_bytes(1, Vg, h, w) // 4
-            ws['q_order'] = alloc(R, torch.int32, zero=True) if getattr(self, 'q_order', False) else None
-            if getattr(self, 'qtile', False) and not self.exact:
-                ws['qt'] = ops.xattn_qtile_alloc(R, B, ws['col_cap'], self.dev, alloc=lambda n_: alloc(n_, torch.int32, zero=True),
-                                                     queries_per_tile=self.qtile_queries)
+            ws['q_order'] = alloc(R, torch.int32, zero=True) if self.q_order else None
         else:
             ws['col_cap'] = R * (1 + Vg * self.topk) * 49
             ws['S_kv'] = R * 49
-            ws['roi_sum'] = e((R, 49, C), BF16)
+            ws['roi_sum'] = e((R, 49, C), K16)
         ws['col_idx'] = e(ws['col_cap'], torch.int32)
-        ws['A1'] = e((P, 3 * self.depth_num), BF16); ws['A2'] = e((P, 384), BF16)
-        ws['Xf_b'] = e((P, C), BF16)
-        ws['Xf32'] = None if (self.pe_fused and not self.exact) else e((P, C))      # the fused PE kernel reads the feature rows from the map itself
+        # key16 rows of the PE block's inputs: frustum [.,192], sine [.,384] (training route only: the inference kernel reads the folded
+        # table), feature rows [.,256] (the SE gate's input; the value rows of the T path)
+        ws['A1'] = e((P, 3 * self.depth_num), K16); ws['A2'] = e((P, 384), K16)
+        ws['Xf_b'] = e((P, C), K16)
+        ws['Xf32'] = e((P, C)) if self.exact else None            # the fused PE kernel reads the feature rows from the map itself
         if self.exact:
-            # index-exact route: unrounded fp32 operands of the PE block (frustum / sine inputs, hidden layers, gate, sine branch), the fp32
-            # RoIAlign outputs, the lo halves of the key / value rows, the conv output before pooling -- all pre-allocated (no per-frame
-            # allocation, no host synchronisation: the route is graph-replayable like the default one)
+            # index-exact route: unrounded fp32 operands of the PE block (frustum inputs, gate), [hi | lo | hi] bf16 operands of its
+            # K-concatenated GEMMs, the lo halves of the key / value rows and RoI cells -- all pre-allocated (no per-frame allocation, no host
+            # synchronisation: the route is graph-replayable like the default one)
             ws['xa1'] = e((P, 3 * self.depth_num)); ws['xa2'] = e((P, 384))
             ws['xgate'] = e((P, C)); ws['xp2'] = e((P, C))
-            if self.exact_linear:
-                ws['xh'] = e((P, 4 * C)); ws['xg'] = e((P, C)); ws['roi_feat32'] = e((R, 49, C)); ws['convy'] = e((R * 49, C))
-                if self.kind == 'S':
-                    ws['roi_pe32'] = e((R, 49, C))
-            else:
-                # [hi | lo | hi] bf16 operands of the K-concatenated GEMMs: one scratch for the input rows (<= 3 * 384 wide), one for the hidden layer
-                ws['x3a'] = e((P, 3 * 384), BF16); ws['x3h'] = e((P, 3 * 4 * C), BF16)
+            ws['x3a'] = e((P, 3 * 384), BF16); ws['x3h'] = e((P, 3 * 4 * C), BF16)
             if self.kind == 'T':
-                ws['xk_lo'] = z((P, C), BF16); ws['xv_lo'] = z((P, C), BF16)
-                ws['roi_lo'] = e((R, 49, C), BF16)                 # lo halves of the RoI cells (conv input)
+                ws['xk_lo'] = z((P, C), K16); ws['xv_lo'] = z((P, C), K16)
+                ws['roi_lo'] = e((R, 49, C), K16)                 # lo halves of the RoI cells (conv input)
             else:
-                ws['xk_lo'] = z((R * 49, C), BF16); ws['xv_lo'] = z((R * 49, C), BF16)
+                ws['xk_lo'] = z((R * 49, C), K16); ws['xv_lo'] = z((R * 49, C), K16)
                 ws['roi_lo'] = ws['xv_lo'].view(R, 49, C)          # S path: the value rows ARE the RoI cells
-        if not self.pe_fused:                                    # intermediates of the six-GEMM PE route only
-            ws['H1'] = e((P, 4 * C), BF16); ws['H2'] = e((P, 4 * C), BF16); ws['Hg'] = e((P, C), BF16)
-            ws['gate'] = e((P, C)); ws['Pg'] = e((P, C))
-        ws['pe'] = e((P, C)); ws['Xk'] = e((P, C), BF16)
-        if self.tile_attn:
-            ws['KV'] = None
-            ws['Qt'] = e((R, 16 * C), BF16); ws['zh'] = e((R, 8 * C))
-        elif self.raw_attn:
-            ws['KV'] = None
-            ws['qkh'] = e((R, 8 * C)); ws['zh'] = e((R, 8 * C))
-        else:
-            ws['KV'] = e((2 * L, ws['S_kv'], C), BF16)
+        ws['pe'] = e((P, C)); ws['Xk'] = e((P, C), K16)
+        # cross attention in the raw key space: per-query operand Qt (key16 hi | lo rows of the 8 per-head maps), per-head context sums z
+        ws['Qt'] = e((R, 16 * C), K16); ws['zh'] = e((R, 8 * C))
         # unprojected key / value input rows of the cross attention (key + key_pos, key): shared by all layers
         if self.kind == 'T':
             ws['xk_rows'], ws['xv_rows'] = ws['Xk'], ws['Xf_b']
         else:
             ws['xk_rows'], ws['xv_rows'] = ws['roi_sum'].view(R * 49, C), ws['roi_feat'].view(R * 49, C)
-        for n in ('x', 'xq', 'x1', 'x1q', 'x2', 'ctx', 'o', 'q'):
+        for n in ('x', 'x1', 'x2', 'ctx', 'q'):
             ws[n] = e((R, C))
         ws['zero_rows'] = z((R, C))                              # never written
         ws['qkv'] = e((R, 3 * C)); ws['parts'] = e((2048 // 64, R, C)); ws['outs'] = e((L, R, C))
@@ -502,43 +418,36 @@ class HeadEngine:
         nv = self.num_views
         dts = [float(ts[b, nv:].mean() - ts[b, :nv].mean()) if (self.kind == 'T' and Vg > nv) else 0.0 for b in range(B)]
         sh['frame_scalars'] = dict(pad_h=f0['pad_h'], pad_w=f0['pad_w'], dt=dts[0])
-        if self.pe_sine_table:
-            # the sine branch depends on the padding geometry of the samples only (not on calibration): rebuilt when that changes
-            skey = (self._weights_version,) + tuple(k[0] for k in shape_key)
-            if sh.get('sine_key') != skey:
-                same = all(k == skey[1] for k in skey[1:])
-                P = V * h * w
-                Pt = P // B if same else P                                  # one sample's positions when all samples share the geometry
-                T, o, W_ = ws['tab'], ops, self.w
-                s2 = torch.arange(Pt, dtype=torch.int32, device=self.dev)
-                a1 = torch.empty((Pt, 3 * self.depth_num), device=self.dev, dtype=BF16)
-                a2 = torch.empty((Pt, 384), device=self.dev, dtype=BF16)
-                xb = torch.empty((Pt, C), device=self.dev, dtype=BF16)
-                o.pe_inputs(s2, torch.tensor([Pt], dtype=torch.int32, device=self.dev), Pt, ws['featcl'], T['img2lidar'], T['coords_w'], T['coords_h'],
-                            T['coords_d'], T['embeds'], self.const['dim_t'], a1, a2, xb, None, V, h, w, self.depth_num, self.post_range_h64)
-                if self.exact:            # fp32-class table: fp32 sine rows, K-concatenated split-precision GEMMs
-                    a1f = torch.empty((Pt, 3 * self.depth_num), device=self.dev, dtype=F32)
-                    a2f = torch.empty((Pt, 384), device=self.dev, dtype=F32)
-                    o.pe_inputs(s2, torch.tensor([Pt], dtype=torch.int32, device=self.dev), Pt, ws['featcl'], T['img2lidar'], T['coords_w'], T['coords_h'],
-                                T['coords_d'], T['embeds'], self.const['dim_t'], a1, a2, xb, None, V, h, w, self.depth_num, self.post_range_h64,
-                                A_frustum_f32=a1f, A_sine_f32=a2f)
-                    h2 = o.gemm_bf16(o.split3_rows(a2f), W_['pe_w2a_c3'], W_['pe_b2a'], act=1, split3=True)
-                    tab = o.gemm_bf16(h2, W_['pe_w2b_c3'], W_['pe_b2b'], out_dtype=torch.float32)
-                    del a1f, a2f
-                else:
-                    h2 = o.gemm_bf16(a2, W_['pe_w2a'], W_['pe_b2a'], act=1)
-                    tab = o.gemm_bf16(h2, W_['pe_w2b'], W_['pe_b2b'], out_dtype=torch.float32)
-                # kept with the tables the workspaces of this map shape share; a captured graph holds the pointer: same shape -> refreshed in place
-                if sh.get('sine_tab') is None or sh['sine_tab'].shape != tab.shape:
-                    sh['sine_tab'] = tab
-                    sh['sine_gen'] = sh.get('sine_gen', 0) + 1
-                else:
-                    sh['sine_tab'].copy_(tab)
-                sh['sine_period'] = Pt
-                sh['sine_key'] = skey
-            if ws.get('sine_gen') != sh['sine_gen']:
-                ws['sine_gen'] = sh['sine_gen']
-                ws['graph_stale'] = True                                     # this workspace's graphs were captured with another table
+        # the sine branch adapt_pos3d(sine) depends on the padding geometry of the samples only (not on calibration): its table is rebuilt when
+        # that (or the weights) change -- in fp32-class arithmetic on both routes (fp32 sine rows, K-concatenated split-precision GEMMs:
+        # a once-per-rig cost), so that the table adds no 16-bit rounding of its own to pe
+        skey = (self._weights_version,) + tuple(k[0] for k in shape_key)
+        if sh.get('sine_key') != skey:
+            same = all(k == skey[1] for k in skey[1:])
+            P = V * h * w
+            Pt = P // B if same else P                                  # one sample's positions when all samples share the geometry
+            T, o, W_ = ws['tab'], ops, self.w
+            s2 = torch.arange(Pt, dtype=torch.int32, device=self.dev)
+            k16e = lambda n_: torch.empty((Pt, n_), device=self.dev, dtype=self.K16)
+            a2f = torch.empty((Pt, 384), device=self.dev, dtype=F32)
+            a1f = torch.empty((Pt, 3 * self.depth_num), device=self.dev, dtype=F32)
+            o.pe_inputs(s2, torch.tensor([Pt], dtype=torch.int32, device=self.dev), Pt, ws['featcl'], T['img2lidar'], T['coords_w'], T['coords_h'],
+                        T['coords_d'], T['embeds'], self.const['dim_t'], k16e(3 * self.depth_num), k16e(384), k16e(C), None, V, h, w, self.depth_num,
+                        self.post_range_h64, A_frustum_f32=a1f, A_sine_f32=a2f)
+            h2 = o.gemm_bf16(o.split3_rows(a2f), W_['pe_w2a_c3'], W_['pe_b2a'], act=1, split3=True)
+            tab = o.gemm_bf16(h2, W_['pe_w2b_c3'], W_['pe_b2b'], out_dtype=torch.float32)
+            del a1f, a2f, h2
+            # kept with the tables the workspaces of this map shape share; a captured graph holds the pointer: same shape -> refreshed in place
+            if sh.get('sine_tab') is None or sh['sine_tab'].shape != tab.shape:
+                sh['sine_tab'] = tab
+                sh['sine_gen'] = sh.get('sine_gen', 0) + 1
+            else:
+                sh['sine_tab'].copy_(tab)
+            sh['sine_period'] = Pt
+            sh['sine_key'] = skey
+        if ws.get('sine_gen') != sh['sine_gen']:
+            ws['sine_gen'] = sh['sine_gen']
+            ws['graph_stale'] = True                                     # this workspace's graphs were captured with another table
         ws['view_start_h'].numpy()[:] = np.concatenate([[0], np.cumsum(counts)])
         ws['grp_start_h'].numpy()[:] = grp
         if self.kind == 'T':
@@ -610,15 +519,11 @@ class HeadEngine:
             o.mask_compact(rois, ws['match'], T['pad_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'],
                            ws['bits'], ws['row_count'], ws['row_ptr'], ws['col_idx'], ws['nnz'], R, Vg, h, w, self.topk,
                            self.stride, self.expand, col_cap=ws['col_cap'], n_samples=B)
-            if ws.get('q_order') is not None and ws.get('qt') is None:
+            if self.q_order and ws.get('q_order') is not None:
                 o.xattn_query_order(ws['row_ptr'], ws['col_idx'], grp, R, ws['q_order'], ws['qt_ctl'][1:])
-            if ws.get('qt') is not None:
-                o.xattn_qtile_build(ws['qt'], ws['row_ptr'], ws['col_idx'], grp, R, ws['bits'], ws['csr_words'], ws['rect'], Vg, Vg * h * w, ws['pos2s'],
-                                    ws['qt_ctl'])
             if not forked:
                 tk('roi_align')
-                o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'], out0_f32=ws.get('roi_feat32') if self.exact else None,
-                            out0_lo=ws.get('roi_lo') if (self.exact and not self.exact_linear) else None, R=R)
+                o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'], out0_lo=ws.get('roi_lo') if self.exact else None, R=R)
         else:
             # positions any RoIAlign tap can touch (own rect + 1 cell) -> PE only there
             o.roi_positions(rois, ws['zero_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'], R, V, h, w,
@@ -636,62 +541,30 @@ class HeadEngine:
                     fm = ws['forced_match'] = fmh.view(R, Vg, self.topk).to(self.dev)
                 ws['match'].copy_(fm)
             o.csr_from_corr(ws['match'], ws['row_ptr'], ws['col_idx'], ws['nnz'], R, Vg, self.topk)
-        tk('pe_inputs')
-        # a2: PE at the listed positions (3 two-layer MLPs on bf16 MFMA)
-        if not self.exact:                       # (the exact route requests the fp32 rows as well: _exact_pe)
-            o.pe_inputs(ws['s2pos'], ws['S_dev'], P, featcl, T['img2lidar'], T['coords_w'], T['coords_h'], T['coords_d'], T['embeds'],
-                        self.const['dim_t'], ws['A1'], None if (self.pe_sine_table and not self.keep_sine_rows) else ws['A2'], ws['Xf_b'], ws['Xf32'],
-                        V, h, w, self.depth_num, self.post_range_h64)
         md = ws['S_dev']
-        tk('pe_fused')
+        # a2: PE at the listed positions only
         if self.exact:
+            tk('pe_inputs'); tk('pe_fused')
             self._exact_pe(ws, featcl, P, V, h, w)
-        elif self.pe_fused:
-            if self.pe_sine_table:
-                # only what the path reads is written: S: pe (RoIAlign reads it; its keys are RoI-aligned rows), T: Xk (nothing reads pe);
-                # a keep_stages run writes both
-                dbg = self.keep_xk or getattr(self, '_stage_outputs', False)
-                o.pe_fused_tab(ws['A1'], ws['Xf_b'], featcl, md, W_['pe_pack'], ws['shared']['sine_tab'], ws['shared']['sine_period'],
-                               ws['pe'] if (self.kind == 'S' or dbg) else None, ws['Xk'] if (self.kind == 'T' or dbg) else None, M=P,
-                               row_index=ws['s2pos'])
-            else:
-                o.pe_fused(ws['A1'], ws['A2'], ws['Xf_b'], featcl, md, W_['pe_pack'], ws['pe'], ws['Xk'], M=P, row_index=ws['s2pos'])
         else:
-            o.gemm_bf16(ws['A1'], W_['pe_w1a'], W_['pe_b1a'], m_dev=md, act=1, out=ws['H1'])
-            o.gemm_bf16(ws['A2'], W_['pe_w2a'], W_['pe_b2a'], m_dev=md, act=1, out=ws['H2'])
-            o.gemm_bf16(ws['Xf_b'], W_['pe_wr'], W_['pe_br'], m_dev=md, act=1, out=ws['Hg'])
-            o.gemm_bf16(ws['Hg'], W_['pe_we'], W_['pe_be'], m_dev=md, act=2, out=ws['gate'])
-            o.gemm_bf16(ws['H1'], W_['pe_w1b'], W_['pe_b1b'], m_dev=md, mul=ws['gate'], out=ws['Pg'])
-            o.gemm_bf16(ws['H2'], W_['pe_w2b'], W_['pe_b2b'], m_dev=md, add=ws['Pg'], out=ws['pe'], out2=ws['Xk'], add2=ws['Xf32'])
+            tk('pe_inputs')
+            o.pe_inputs(ws['s2pos'], md, P, featcl, T['img2lidar'], T['coords_w'], T['coords_h'], T['coords_d'], T['embeds'],
+                        self.const['dim_t'], ws['A1'], ws['A2'] if self.keep_sine_rows else None, ws['Xf_b'], None,
+                        V, h, w, self.depth_num, self.post_range_h64)
+            tk('pe_fused')
+            # only what the path reads is written: S: pe (RoIAlign reads it; its keys are RoI-aligned rows), T: Xk (nothing reads pe);
+            # a keep_stages run writes both
+            dbg = self.keep_xk or getattr(self, '_stage_outputs', False)
+            o.pe_fused_tab(ws['A1'], ws['Xf_b'], featcl, md, W_['pe_pack'], ws['shared']['sine_tab'], ws['shared']['sine_period'],
+                           ws['pe'] if (self.kind == 'S' or dbg) else None, ws['Xk'] if (self.kind == 'T' or dbg) else None, M=P,
+                           row_index=ws['s2pos'])
         if self.kind == 'S':
             tk('roi_align')
-            if self.exact and self.exact_linear:
-                o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], out0_f32=ws['roi_feat32'],
-                            out1_f32=ws['roi_pe32'], map1_index=ws['pos2s'], out1_is_sum=True, R=R)
-                # key rows = RoIAlign(feat) + RoIAlign(pe), value rows = RoIAlign(feat): bf16 hi + lo pairs
-                f32_, p32_ = ws['roi_feat32'].view(R * 49, C), ws['roi_pe32'].view(R * 49, C)
-                o.split_rows(f32_, p32_, hi=ws['roi_sum'].view(R * 49, C), lo=ws['xk_lo'])
-                o.split_rows(f32_, None, hi=ws['roi_feat'].view(R * 49, C), lo=ws['xv_lo'])
-            elif self.exact:
-                # key rows = RoIAlign(feat) + RoIAlign(pe), value rows = RoIAlign(feat), both as bf16 hi + lo pairs straight from the kernel
-                o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=ws['pos2s'], out1_is_sum=True,
-                            out0_lo=ws['xv_lo'], out1_lo=ws['xk_lo'], R=R)
-            else:
-                o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=ws['pos2s'],
-                            out1_is_sum=True, R=R)
+            # key rows = RoIAlign(feat) + RoIAlign(pe), value rows = RoIAlign(feat) (index-exact route: both as key16 hi + lo pairs)
+            o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=ws['pos2s'], out1_is_sum=True,
+                        out0_lo=ws['xv_lo'] if self.exact else None, out1_lo=ws['xk_lo'] if self.exact else None, R=R)
         if not forked:
             self._enqueue_qg(ws, R)
-        # a18 key side: K/V projections of all layers at once (not needed by the raw-row attention)
-        tk('kv_gemm')
-        S_kv = ws['S_kv']
-        if self.raw_attn or self.tile_attn:
-            pass
-        elif self.kind == 'T':
-            o.kv_proj(ws['Xk'], W_['kv_w'], W_['kv_b'], ws['KV'], A2=ws['Xf_b'], n_split=L * C, m_dev=md, ldc=C,
-                      c_blk_stride=S_kv * C, c_blk_cols=C)
-        else:
-            o.kv_proj(ws['roi_sum'].view(R * 49, C), W_['kv_w'], W_['kv_b'], ws['KV'], A2=ws['roi_feat'].view(R * 49, C),
-                      n_split=L * C, ldc=C, c_blk_stride=S_kv * C, c_blk_cols=C)
         if forked:
             torch.cuda.current_stream().wait_stream(side)
         # a16-a19: decoder
@@ -706,210 +579,131 @@ class HeadEngine:
         tk('end')
 
     def _exact_pe(self, ws, featcl, P, V, h, w):
-        """Index-exact route: the PE block (MU/pe.py:36-48,64-77,150-166) on UNROUNDED fp32 inputs through the bf16x3 linear
-        (mv2d_linear_x3_ex: device-side row count S, sigmoid and the gate product / sine-branch sum in the epilogues), pe rows into
-        ws['pe']; T path: key / value rows as bf16 hi + lo pairs.  No host synchronisation, no allocation: graph-replayable."""
+        """Index-exact route: the PE block (MU/pe.py:36-48,64-77,150-166) on UNROUNDED fp32 inputs as fp32-class products on the plain
+        bf16 tile GEMM by K-concatenation, [a_hi | a_lo | a_hi] . [w_hi | w_hi | w_lo]^T (K' = 3 K; the hidden layers leave the GEMM already
+        in that form, c_split3 epilogue; device-side row count S; sigmoid and the gate product / sine-table sum in the epilogues), pe rows
+        into ws['pe']; T path: key / value rows as key16 hi + lo pairs.  No host synchronisation, no allocation: graph-replayable."""
         o, W_, T = ops, self.w, ws['tab']
         md = ws['S_dev']
-        tab = self.pe_sine_table and not self.keep_sine_rows
         o.pe_inputs(ws['s2pos'], md, P, featcl, T['img2lidar'], T['coords_w'], T['coords_h'], T['coords_d'], T['embeds'],
-                    self.const['dim_t'], ws['A1'], None if tab else ws['A2'], ws['Xf_b'], ws['Xf32'], V, h, w, self.depth_num, self.post_range_h64,
-                    A_frustum_f32=ws['xa1'], A_sine_f32=None if tab else ws['xa2'])
+                    self.const['dim_t'], ws['A1'], ws['A2'] if self.keep_sine_rows else None, ws['Xf_b'], ws['Xf32'], V, h, w, self.depth_num,
+                    self.post_range_h64, A_frustum_f32=ws['xa1'], A_sine_f32=ws['xa2'] if self.keep_sine_rows else None)
 
-        if self.exact_linear:
-            def lin(x, n_, out, act=0, **kw):
-                b_ = W_['pe_b' + n_[1:]]
-                return o.linear_x3(x, W_['pe_' + n_ + '_x3'], b_, N=b_.numel(), K=x.shape[1], act=act, out=out, M=P, m_dev=md, **kw)
-            lin(lin(ws['Xf32'], 'wr', ws['xg'], 1), 'we', ws['xgate'], 2)                      # SE gate: sigmoid(expand(relu(reduce(feat))))
-            lin(lin(ws['xa2'], 'w2a', ws['xh'], 1), 'w2b', ws['xp2'])                          # adapt_pos3d(sine)
-            lin(lin(ws['xa1'], 'w1a', ws['xh'], 1), 'w1b', ws['pe'], mul=ws['xgate'], add=ws['xp2'])      # position_encoder(frustum) * gate + sine branch
-        else:
-            # fp32-class products on the plain bf16 tile GEMM: [a_hi | a_lo | a_hi] . [w_hi | w_hi | w_lo]^T (K' = 3 K); the hidden layers leave
-            # the GEMM already in that form (c_split3 epilogue)
-            def mlp(x32, n1, n2, **kw):
-                K1 = x32.shape[1]
-                a3 = ws['x3a'].view(-1)[:P * 3 * K1].view(P, 3 * K1)
-                o.split3_rows(x32, None, out=a3, m_dev=md, M=P)
-                b1 = W_['pe_b' + n1[1:]]
-                N1 = b1.numel()
-                h3 = ws['x3h'].view(-1)[:P * 3 * N1].view(P, 3 * N1)
-                o.gemm_bf16(a3, W_['pe_' + n1 + '_c3'], b1, m_dev=md, act=1, out=h3, split3=True, M=P)
-                return o.gemm_bf16(h3, W_['pe_' + n2 + '_c3'], W_['pe_b' + n2[1:]], m_dev=md, M=P, **kw)
-            mlp(ws['Xf32'], 'wr', 'we', act=2, out=ws['xgate'])                               # SE gate
-            if self.pe_sine_table:
-                sh = ws['shared']
-                mlp(ws['xa1'], 'w1a', 'w1b', mul=ws['xgate'], add=sh['sine_tab'], add_index=ws['s2pos'], add_period=sh['sine_period'], out=ws['pe'])
-            else:
-                mlp(ws['xa2'], 'w2a', 'w2b', out=ws['xp2'])                                   # adapt_pos3d(sine)
-                mlp(ws['xa1'], 'w1a', 'w1b', mul=ws['xgate'], add=ws['xp2'], out=ws['pe'])   # position_encoder(frustum) * gate + sine branch
+        def mlp(x32, n1, n2, **kw):
+            K1 = x32.shape[1]
+            a3 = ws['x3a'].view(-1)[:P * 3 * K1].view(P, 3 * K1)
+            o.split3_rows(x32, None, out=a3, m_dev=md, M=P)
+            b1 = W_['pe_b' + n1[1:]]
+            N1 = b1.numel()
+            h3 = ws['x3h'].view(-1)[:P * 3 * N1].view(P, 3 * N1)
+            o.gemm_bf16(a3, W_['pe_' + n1 + '_c3'], b1, m_dev=md, act=1, out=h3, split3=True, M=P)
+            return o.gemm_bf16(h3, W_['pe_' + n2 + '_c3'], W_['pe_b' + n2[1:]], m_dev=md, M=P, **kw)
+        mlp(ws['Xf32'], 'wr', 'we', act=2, out=ws['xgate'])                               # SE gate
+        sh = ws['shared']
+        mlp(ws['xa1'], 'w1a', 'w1b', mul=ws['xgate'], add=sh['sine_tab'], add_index=ws['s2pos'], add_period=sh['sine_period'], out=ws['pe'])
         if self.kind == 'T':
             o.split_rows(ws['Xf32'], ws['pe'], hi=ws['Xk'], lo=ws['xk_lo'], m_dev=md, M=P)   # key rows = feat + pe
             o.split_rows(ws['Xf32'], None, hi=ws['Xf_b'], lo=ws['xv_lo'], m_dev=md, M=P)     # value rows = feat
 
-    def pe_input_rows(self, ws, positions, V, h, w):
-        """PE input rows (frustum [n,192], sine [n,384], bf16) at the given map positions (int32, device) with the calibration tables of the
-        workspace's current frame: the training route needs them for a key position no RoI lists (RH/mv2d_t_head.py:80-82)."""
+    def pe_input_rows(self, ws, positions, V, h, w, f32=False):
+        """PE input rows (frustum [n,192], sine [n,384]; key16, or unrounded fp32 with f32=True) at the given map positions (int32, device)
+        with the calibration tables of the workspace's current frame: the training route needs them for a key position no RoI lists
+        (RH/mv2d_t_head.py:80-82)."""
         n = int(positions.numel())
         T, d = ws['tab'], self.dev
-        a1 = torch.empty((n, 3 * self.depth_num), device=d, dtype=BF16)
-        a2 = torch.empty((n, 384), device=d, dtype=BF16)
-        xb = torch.empty((n, C), device=d, dtype=BF16)
+        a1 = torch.empty((n, 3 * self.depth_num), device=d, dtype=self.K16)
+        a2 = torch.empty((n, 384), device=d, dtype=self.K16)
+        xb = torch.empty((n, C), device=d, dtype=self.K16)
+        a1f = torch.empty((n, 3 * self.depth_num), device=d, dtype=F32) if f32 else None
+        a2f = torch.empty((n, 384), device=d, dtype=F32) if f32 else None
         ops.pe_inputs(positions.contiguous(), torch.tensor([n], dtype=torch.int32, device=d), n, ws['featcl'], T['img2lidar'], T['coords_w'],
-                      T['coords_h'], T['coords_d'], T['embeds'], self.const['dim_t'], a1, a2, xb, None, V, h, w, self.depth_num, self.post_range_h64)
-        return a1, a2
+                      T['coords_h'], T['coords_d'], T['embeds'], self.const['dim_t'], a1, a2, xb, None, V, h, w, self.depth_num, self.post_range_h64,
+                      A_frustum_f32=a1f, A_sine_f32=a2f)
+        return (a1f, a2f) if f32 else (a1, a2)
 
     def _enqueue_qg(self, ws, R):
         """a6-a8, a13: QueryGenerator on the RoI features -> reference points -> query positional embedding."""
         o, W_, tk = ops, self.w, self._tick
-        # a6: QueryGenerator
+        # a6: QueryGenerator: conv3x3 + ReLU + AvgPool2d(7) fused, one block per RoI (index-exact route: in split precision on the hi + lo cells)
         tk('qg_conv_gemm')
         if self.exact:
-            # conv3x3 + ReLU + AvgPool2d(7) on the UNROUNDED RoI features: implicit GEMM inside the bf16x3 linear (every tap = one 256-wide
-            # K chunk read from the neighbouring cell's row), then the pooling kernel
-            if self.exact_linear:
-                o.linear_x3(ws['roi_feat32'], W_['qg_conv_wx3'], W_['qg_conv_b'], N=C, K=9 * C, act=1, conv3x3=True, out=ws['convy'], M=R * 49)
-                o.avgpool49(ws['convy'], ws['x2'], C, R)
-            else:
-                # the fused conv + ReLU + pool kernel in split precision on the hi + lo RoI cells
-                o.qg_conv_pool_x3(ws['roi_feat'], ws['roi_lo'], W_['qg_conv_wx3'], W_['qg_conv_b'], ws['x2'], R=R)
+            o.qg_conv_pool_x3(ws['roi_feat'], ws['roi_lo'], W_['qg_conv_wx3'], W_['qg_conv_b'], ws['x2'], R=R)
         else:
             o.qg_conv_pool(ws['roi_feat'], W_['qg_conv_wp'], W_['qg_conv_b'], ws['x2'], R=R)
         tk('qg_rest')
-        if self.qg_x3:
-            o.linear_x3(ws['x2'], W_['qg_fc_wx'], W_['qg_fc_b'], N=1024, K=256, act=1, clamp=5e3, out=ws['enc'], ldc=1056, M=R)
-            o.linear_x3(ws['enc'], W_['qg_e0_wx'], W_['qg_e0_b'], N=512, K=1056, act=1, out=ws['enc1'], M=R)
-            o.linear_x3(ws['enc1'], W_['qg_e2_wx'], W_['qg_e2_b'], N=256, K=512, act=1, out=ws['enc2'], M=R)
-        else:
-            o.gemm_f32(ws['x2'], W_['qg_fc_w'], W_['qg_fc_b'], act=1, clamp=5e3, out=ws['enc'], ldc=1056)
-            o.gemm_f32(ws['enc'], W_['qg_e0_w'], W_['qg_e0_b'], act=1, out=ws['enc1'])
-            o.gemm_f32(ws['enc1'], W_['qg_e2_w'], W_['qg_e2_b'], act=1, out=ws['enc2'])
-        if self.rows_x3:
-            # fc_center + reference points + pos2posemb3d + query_embedding in one row-fused kernel
-            o.query_embed_fused_x3(ws['enc2'], W_['qg_c_w'], W_['qg_c_b'], ws['minv'], self.const['dim_t'], self.pc_range_h, W_['qe_w0x'],
-                                   W_['qe_b0'], W_['qe_w2x'], W_['qe_b2'], ws['center'], ws['xyz'], ws['ref'], ws['posemb'], ws['qpos'], R=R)
-            return
-        o.gemm_f32(ws['enc2'], W_['qg_c_w'], W_['qg_c_b'], out=ws['center'])
-        # a7/a8/a13: reference points + query positional embedding
-        o.refpoint_posemb(ws['center'], 3, ws['minv'], self.const['dim_t'], ws['xyz'], ws['ref'], ws['posemb'], R, self.pc_range_h)
-        o.gemm_f32(ws['posemb'], W_['qe_w0'], W_['qe_b0'], act=1, out=ws['qe1'])
-        o.gemm_f32(ws['qe1'], W_['qe_w2'], W_['qe_b2'], out=ws['qpos'])
+        o.linear_x3(ws['x2'], W_['qg_fc_wx'], W_['qg_fc_b'], N=1024, K=256, act=1, clamp=5e3, out=ws['enc'], ldc=1056, M=R)
+        o.linear_x3(ws['enc'], W_['qg_e0_wx'], W_['qg_e0_b'], N=512, K=1056, act=1, out=ws['enc1'], M=R)
+        o.linear_x3(ws['enc1'], W_['qg_e2_wx'], W_['qg_e2_b'], N=256, K=512, act=1, out=ws['enc2'], M=R)
+        # fc_center + reference points (a7/a8) + pos2posemb3d + query_embedding (a13) in one row-fused kernel
+        o.query_embed_fused_x3(ws['enc2'], W_['qg_c_w'], W_['qg_c_b'], ws['minv'], self.const['dim_t'], self.pc_range_h, W_['qe_w0x'],
+                               W_['qe_b0'], W_['qe_w2x'], W_['qe_b2'], ws['center'], ws['xyz'], ws['ref'], ws['posemb'], ws['qpos'], R=R)
 
     def _enqueue_decoder(self, ws, R):
-        """CrossAttentionBoxHead.forward's transformer call on already-prepared inputs (qpos, KV, CSR):
-        the "decoder ms/iter" half of the headline metric."""
+        """CrossAttentionBoxHead.forward's transformer call on already-prepared inputs (qpos, key / value rows, CSR):
+        the "decoder ms/iter" half of the headline metric.  Per layer: self attention (bf16x3 MFMA, K / V through LDS), out_proj + LN +
+        cross-attention q projection (row-fused, bf16x3), cross attention in the raw key space (query map, tile kernel, context map), out_proj
+        + LN, fused FFN (bf16x3) and its tail (slab sum + LN + post_norm + the next layer's in_proj)."""
         o, W_, L = ops, self.w, self.L
-        x, xq = ws['x'], ws['xq']
-        fuse_tail = self.fuse_rows and self.rows_x3          # FFN tail + next layer's in_proj as one row-fused kernel
+        x = ws['x']
         xk_rows, xv_rows = ws['xk_rows'], ws['xv_rows']
-
-        fuse_maps = (R <= 512) if self.fuse_maps is None else self.fuse_maps
         dbg = ws.get('dbg_logits')
-        maps_fused = self.tile_attn and fuse_maps and self.fuse_rows and self.rows_x3 and not self.sa_fused and dbg is None
+        maps_fused = ((R <= 512) if self.fuse_maps is None else self.fuse_maps) and dbg is None
 
-        def cross_attn(i):
-            if self.tile_attn:
-                if not maps_fused:
-                    o.xattn_qmap(ws['q'], W_[f'ca_mapA{i}'], ws['Qt'], R=R)
-                if dbg is not None:
-                    ws['dbg_q'][i].copy_(ws['q'])
-                if ws.get('qt') is not None and dbg is None:
-                    o.xattn_qtile(ws['Qt'], xk_rows, xv_rows, ws['qt'], ws['zh'], R, empty_nan=self.empty_nan)
-                else:
-                    o.xattn_tile(ws['Qt'], xk_rows, xv_rows, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=self.empty_nan, waves=self.xattn_waves,
-                                 Xk_lo=ws.get('xk_lo'), Xv_lo=ws.get('xv_lo'), dbg_logits=None if dbg is None else dbg[i],
-                                 order=ws['qt']['perm'] if ws.get('qt') is not None else ws.get('q_order'))
-                if not maps_fused:
-                    o.xattn_ctxmap(ws['zh'], W_[f'ca_mapB{i}'], W_[f'ca_v_b{i}'], ws['row_ptr'], ws['ctx'], R, empty_nan=self.empty_nan)
-                return
-            if not self.raw_attn:
-                o.sparse_xattn(ws['q'], ws['KV'][i], ws['KV'][L + i], ws['row_ptr'], ws['col_idx'], ws['ctx'], R, empty_nan=self.empty_nan)
-                return
-            o.linear_x3(ws['q'], W_[f'ca_hin{i}'], None, N=C, K=32, out=ws['qkh'], ldc=8 * C, M=R, lda=C, groups=8, a_gs=32, w_gs=C * 32, c_gs=C)
-            o.raw_xattn(ws['qkh'], xk_rows, xv_rows, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=True)
-            o.linear_x3(ws['zh'], W_[f'ca_hout{i}'], W_[f'ca_v_b{i}'], N=32, K=C, out=ws['ctx'], ldc=C, M=R, lda=8 * C, groups=8, a_gs=C,
-                        w_gs=32 * C, b_gs=32, c_gs=32)
+        def tile_attn(i):
+            if dbg is not None:
+                ws['dbg_q'][i].copy_(ws['q'])
+            o.xattn_tile(ws['Qt'], xk_rows, xv_rows, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=self.empty_nan, waves=self.xattn_waves,
+                         Xk_lo=ws.get('xk_lo'), Xv_lo=ws.get('xv_lo'), dbg_logits=None if dbg is None else dbg[i],
+                         order=ws.get('q_order') if self.q_order else None)
 
-        if fuse_tail:
-            # the decoder starts from target = 0 (cross_attention_head.py:32): layer 0 reads a constant zero buffer and qpos
-            # directly, from layer 1 on x / xq are the buffers the fused FFN tail writes
-            x_in, xq_in = ws['zero_rows'], ws['qpos']
-        else:
-            x.zero_()
-            xq.copy_(ws['qpos'])
-            x_in, xq_in = x, xq
+        # the decoder starts from target = 0 (cross_attention_head.py:32): layer 0 reads a constant zero buffer and qpos directly, from
+        # layer 1 on x / xq are the buffers the fused FFN tail writes
+        x_in, xq_in = ws['zero_rows'], ws['qpos']
         for i in range(L):
             if i == 1:
-                x_in, xq_in = x, xq
-            if i == 0 and self.qg_x3:
+                x_in = x
+            if i == 0:
                 o.linear_x3(xq_in, W_['sa_in_wx0'], W_['sa_in_b0'], N=3 * C, K=C, A2=x_in, n_split=2 * C, out=ws['qkv'], M=R)
-            elif i == 0 or not fuse_tail:
-                o.gemm_f32(xq_in, W_[f'sa_in_w{i}'], W_[f'sa_in_b{i}'], A2=x_in, n_split=2 * C, out=ws['qkv'], M=R)
-            sa_fused = self.fuse_rows and self.rows_x3 and self.sa_fused
-            if not sa_fused:
-                if ws.get('dn'):
-                    o.self_attn_dn(ws['qkv'], ws['dn'][0], ws['dn'][1], out=ws['ctx'])      # training: denoising rows first (train_forward)
-                else:
-                    o.self_attn(ws['qkv'], ws['ctx'], R, grp_start=ws['grp_start'], max_grp_rows=ws.get('max_rows', 0),
-                                impl='f32' if (self.exact and os.environ.get('MV2D_EXACT_SA', 'x3') == 'f32') else None)      # (index-exact route: the bf16x3 kernel too since the end of round 3 -- same mismatch counts, cls error 4-5e-6 either way, +2.8 %; MV2D_EXACT_SA=f32: the exact-fp32 MFMA kernel)
+            if ws.get('dn'):
+                o.self_attn_dn(ws['qkv'], ws['dn'][0], ws['dn'][1], out=ws['ctx'])      # training: denoising rows first (train_forward)
+            else:
+                o.self_attn(ws['qkv'], ws['ctx'], R, grp_start=ws['grp_start'], max_grp_rows=ws.get('max_rows', 0))
+            sa_args = (ws['ctx'], x_in, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'])
+            q_args = dict(qpos=ws['qpos'], Wq_x3=W_[f'ca_q_wx{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, M=R)
             if maps_fused:
-                o.attn_out_qmap_x3(ws['ctx'], x_in, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
-                                   qpos=ws['qpos'], Wq_x3=W_[f'ca_q_wx{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, WA=W_[f'ca_mapA{i}'],
-                                   Qt=ws['Qt'], M=R)
-                cross_attn(i)
+                o.attn_out_qmap_x3(*sa_args, WA=W_[f'ca_mapA{i}'], Qt=ws['Qt'], **q_args)
+                tile_attn(i)
                 o.attn_out_zmap_x3(ws['zh'], W_[f'ca_mapB{i}'], W_[f'ca_v_b{i}'], ws['row_ptr'], ws['x1'], W_[f'ca_out_wx{i}'], W_[f'ca_out_b{i}'],
                                    (W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), ws['x2'], empty_nan=self.empty_nan, M=R)
-            elif self.fuse_rows and self.rows_x3:
-                sa_tail = o.sa_block_fused_x3 if sa_fused else o.attn_out_fused_x3      # self-attention core inside the row kernel, or not
-                sa_tail(ws['qkv'] if sa_fused else ws['ctx'], x_in, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
-                        qpos=ws['qpos'], Wq_x3=W_[f'ca_q_wx{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, q_out=ws['q'], M=R)
-                cross_attn(i)
+            else:
+                o.attn_out_fused_x3(*sa_args, q_out=ws['q'], **q_args)
+                o.xattn_qmap(ws['q'], W_[f'ca_mapA{i}'], ws['Qt'], R=R)
+                tile_attn(i)
+                o.xattn_ctxmap(ws['zh'], W_[f'ca_mapB{i}'], W_[f'ca_v_b{i}'], ws['row_ptr'], ws['ctx'], R, empty_nan=self.empty_nan)
                 o.attn_out_fused_x3(ws['ctx'], ws['x1'], W_[f'ca_out_wx{i}'], W_[f'ca_out_b{i}'], (W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), ws['x2'], M=R)
-            elif self.fuse_rows:
-                o.attn_out_fused(ws['ctx'], x_in, W_[f'sa_out_w{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'],
-                                 qpos=ws['qpos'], Wq=W_[f'ca_q_w{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, q_out=ws['q'], M=R)
-                cross_attn(i)
-                o.attn_out_fused(ws['ctx'], ws['x1'], W_[f'ca_out_w{i}'], W_[f'ca_out_b{i}'], (W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), ws['x2'], M=R)
-            else:
-                o.gemm_f32(ws['ctx'], W_[f'sa_out_w{i}'], W_[f'sa_out_b{i}'], out=ws['o'])
-                o.row_ln(ws['o'], residual=x_in, ln=(W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), out=ws['x1'], addvec=ws['qpos'], out_plus=ws['x1q'])
-                o.gemm_f32(ws['x1q'], W_[f'ca_q_w{i}'], W_[f'ca_q_b{i}'], scale=ops.SCALE_Q, out=ws['q'])
-                cross_attn(i)
-                o.gemm_f32(ws['ctx'], W_[f'ca_out_w{i}'], W_[f'ca_out_b{i}'], out=ws['o'])
-                o.row_ln(ws['o'], residual=ws['x1'], ln=(W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), out=ws['x2'])
-            parts = ws['parts']
-            if self.ffn_x3:
-                # eight hidden slices accumulated per block: 4 slabs to write and re-read instead of 32 (round 3: 8371 vs 8289 samples/s for
-                # 8 vs 4 slices, and half the slab traffic: 22 instead of 44 MB per 8-sample launch and layer).  It fixes the summation
-                # order, so it is NOT chosen by the row count: a sample's result must not depend on the batch it is in.
-                G = self.ffn_groups if self.ffn_groups else 8
-                parts = parts[:parts.shape[0] // G]
-                o.ffn_fused_x3(ws['x2'], W_[f'ffn_w1x{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2x{i}'], parts, R, groups=G)
-            else:
-                o.ffn_fused(ws['x2'], W_[f'ffn_w1p{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2p{i}'], parts, R)
-            if fuse_tail:
-                nxt = i + 1 < L
-                o.ffn_out_fused_x3(parts, W_[f'ffn_b2{i}'], ws['x2'], (W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), (W_['post_w'], W_['post_b']),
-                                   x, ws['qpos'], None, outs=ws['outs'][i], Win_x3=W_[f'sa_in_wx{i + 1}'] if nxt else None,
-                                   b_in=W_[f'sa_in_b{i + 1}'] if nxt else None, qkv=ws['qkv'] if nxt else None, M=R)
-            else:
-                o.row_ln(parts, bias=W_[f'ffn_b2{i}'], residual=ws['x2'], ln=(W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), out=x, addvec=ws['qpos'],
-                         out_plus=xq, ln2=(W_['post_w'], W_['post_b']), out2=ws['outs'][i])
+            # eight hidden slices accumulated per block: 4 slabs to write and re-read instead of 32 (round 3: 8371 vs 8289 samples/s for
+            # 8 vs 4 slices, and half the slab traffic).  It fixes the summation order, so it is NOT chosen by the row count: a sample's
+            # result must not depend on the batch it is in.
+            G = self.ffn_groups if self.ffn_groups else 8
+            parts = ws['parts'][:ws['parts'].shape[0] // G]
+            o.ffn_fused_x3(ws['x2'], W_[f'ffn_w1x{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2x{i}'], parts, R, groups=G)
+            nxt = i + 1 < L
+            o.ffn_out_fused_x3(parts, W_[f'ffn_b2{i}'], ws['x2'], (W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), (W_['post_w'], W_['post_b']),
+                               x, ws['qpos'], None, outs=ws['outs'][i], Win_x3=W_[f'sa_in_wx{i + 1}'] if nxt else None,
+                               b_in=W_[f'sa_in_b{i + 1}'] if nxt else None, qkv=ws['qkv'] if nxt else None, M=R)
 
     def _enqueue_heads(self, ws, R, dt):
-        # a14: every per-layer cls / reg branch + the reference-point tail in ONE launch (row-block fused)
+        # a14: every per-layer cls / reg branch + the reference-point tail in ONE launch (row-block fused, bf16x3)
         dt_rows = ws['dt_rows'] if self.kind == 'T' else None
-        if self.heads_x3 and self.last_stage_heads and not getattr(self, '_stage_outputs', False):
+        if self.last_stage_heads and not getattr(self, '_stage_outputs', False):
             # inference needs the branches of the LAST decoder layer only (the reference evaluates all six and reads [-1],
             # cross_attention_head.py:202-242 / RH/mv2d_head.py:170-194); cls / reg of the other layers are then not written
             ll = self.L - 1
             ops.heads_fused_x3(ws['outs'][ll:], self.cls_ptrs_x3_last, self.reg_ptrs_x3_last, ws['ref'], ws['cls'][ll:], ws['reg'][ll:], R, 1,
                                self.pc_range_h, dt, dt_rows=dt_rows)
-        elif self.heads_x3:
+        else:
             ops.heads_fused_x3(ws['outs'], self.cls_ptrs_x3, self.reg_ptrs_x3, ws['ref'], ws['cls'], ws['reg'], R, self.L, self.pc_range_h, dt,
                                dt_rows=dt_rows)
-        else:
-            ops.heads_fused(ws['outs'], self.cls_ptrs, self.reg_ptrs, ws['ref'], ws['cls'], ws['reg'], R, self.L, self.pc_range_h, dt,
-                            dt_rows=dt_rows)
 
     def _result(self, ws, R, keep_stages=False, batch=False):
         sel = (lambda t: t) if batch else (lambda t: t[0])
@@ -919,7 +713,7 @@ class HeadEngine:
             # copies of the intermediate buffers restricted to the REAL rows (the launches run on the bucket size, see _host_prepare)
             rows0 = ('rois', 'minv', 'enc', 'roi_feat', 'center', 'xyz', 'ref', 'posemb', 'qpos', 'match')
             st = {}
-            for kk in rows0 + ('roi_mask', 'pos2s', 's2pos', 'S_dev', 'col_idx', 'pe', 'Xk', 'Xf_b', 'KV', 'dbg_logits', 'dbg_q'):
+            for kk in rows0 + ('roi_mask', 'pos2s', 's2pos', 'S_dev', 'col_idx', 'pe', 'Xk', 'Xf_b', 'dbg_logits', 'dbg_q'):
                 if ws.get(kk) is not None:
                     st[kk] = (ws[kk][:R] if kk in rows0 else ws[kk]).clone()
             for kk in ('outs', 'cls', 'reg'):
@@ -962,30 +756,27 @@ class HeadEngine:
         assert V % B == 0
         ws, R, sc = self._host_prepare(proposals_list, metas_list, V, h, w)
         # upload of the per-frame tables (RoI list, view / sample offsets, time steps): stream-ordered before the frame, outside the captured graph.
-        # The "staging consumed" event stays at the END of the frame by default: recording it right behind this copy (MV2D_EARLY_STAGING_EVENT=1) lets the
-        # host run a frame ahead on every stream and measured +1 % in long runs (8474 -> 8499 samples/s) but 7400-7900 instead of 8300 in short ones --
-        # without the host's wait the four streams drift into phase and their wide kernels collide
+        # The "staging consumed" event stays at the END of the frame: recording it right behind this copy would let the host run a frame ahead on every
+        # stream; measured in round 3: +1 % in long runs but 7400-7900 instead of 8300 samples/s in short ones -- without the host's wait the four
+        # streams drift into phase and their wide kernels collide
         ws['dyn_d'].copy_(ws['dyn_h'], non_blocking=True)
-        late = os.environ.get('MV2D_EARLY_STAGING_EVENT', '0') != '1'
-        if not late:
-            self._mark_done(ws)
         self._stage_outputs = bool(keep_stages)          # intermediate buffers nothing downstream reads (pe on the T path, Xk on the S path)
         Rc = sc['cap']                     # launches run on the bucket size; R = the real rows
         if self.debug_attn:
-            assert self.tile_attn and not use_graph, 'debug_attn: eager runs on the tile cross-attention route'
+            assert not use_graph, 'debug_attn: eager runs only'
             ws['dbg_logits'] = torch.zeros((self.L, 8, ws['col_cap']), device=self.dev, dtype=F32)
             ws['dbg_q'] = torch.zeros((self.L, Rc, C), device=self.dev, dtype=F32)
         else:
             ws.pop('dbg_logits', None); ws.pop('dbg_q', None)
         if not use_graph:
             self._enqueue(ws, feat, Rc, V, h, w, sc)
-            if late:
-                self._mark_done(ws)
+            self._mark_done(ws)
             return dict(self._result(ws, R, keep_stages, batch), dt=sc['dt'])
         # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
         gkey = (ptrs, sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs, self.last_stage_heads,
-                self.xattn_waves, self.fuse_maps, self.keep_sine_rows, self.keep_xk, self.ffn_groups, self.force_nc)   # load_state() re-allocates the weights
+                self.xattn_waves, self.fuse_maps, self.keep_sine_rows, self.keep_xk, self.ffn_groups, self.force_nc, self.q_order,
+                self.fork_qg)   # load_state() re-allocates the weights; every route option of __init__ is in the key
         graphs = ws.setdefault('graphs', {})             # one graph per (input buffers, frame scalars): a producer that alternates between
         g = graphs.get(gkey)                             # a few static output buffers replays a few graphs, it does not re-capture
         if ws.pop('graph_stale', False):
@@ -1010,8 +801,7 @@ class HeadEngine:
         else:
             g = g[0]
         g.replay()
-        if late:
-            self._mark_done(ws)
+        self._mark_done(ws)
         return dict(self._result(ws, R, keep_stages, batch), dt=sc['dt'])
 
     def train_forward(self, out, dn_ref=None, dn_single=0):
@@ -1026,8 +816,6 @@ class HeadEngine:
         L, d, o, W_ = self.L, self.dev, ops, self.w
         if ws['B'] != 1:
             raise ValueError('train_forward: one sample per run (the reference asserts the same, RH/mv2d_s_head.py:249)')
-        if self.raw_attn or (self.fuse_rows and self.rows_x3 and self.sa_fused):
-            raise NotImplementedError('train_forward: not available with MV2D_RAW_ATTN / MV2D_SA_FUSED')
         row_ptr = ws['row_ptr'][:R + 1]
         nnz = int(row_ptr[R].item())
         if int(ws['nnz'][1].item()) != 0:
@@ -1036,20 +824,21 @@ class HeadEngine:
         if self.kind == 'T' and bool((row_ptr[1:] == row_ptr[:-1]).any().item()):
             # the reference un-masks the key at map position (view 0, 0, 0) for a RoI without a visible key in training
             # (RH/mv2d_t_head.py:80-82); if no RoI lists that position its key / value rows are appended behind the S listed ones
-            if not self.tile_attn:
-                raise NotImplementedError('train_forward: the training-time fallback key needs the tile cross-attention route')
             from .train import fallback_key_csr
             s0 = int(ws['pos2s'][0].item())
             if s0 < 0:
                 s0 = int(ws['S_dev'].item())
                 V_, h_, w_ = ws['map_shape']
-                a1, a2 = self.pe_input_rows(ws, torch.zeros(1, dtype=torch.int32, device=d), V_, h_, w_)
+                # the PE row of that one position, fp32-class (K-concatenated products like the index-exact route; one row, outside any graph)
+                a1f, a2f = self.pe_input_rows(ws, torch.zeros(1, dtype=torch.int32, device=d), V_, h_, w_, f32=True)
                 f0 = ws['featcl_cur'][:1].contiguous()
-                g_ = lambda x, n_, **kw: o.gemm_bf16(x, W_['pe_w' + n_], W_['pe_b' + n_], **kw)  # noqa: E731  (the six-GEMM PE route, one row)
-                gate = g_(g_(o.f32_to_bf16(f0), 'r', act=1), 'e', act=2, out_dtype=F32)
-                pg = g_(g_(a1, '1a', act=1), '1b', mul=gate, out_dtype=F32)
-                pe0 = g_(g_(a2, '2a', act=1), '2b', add=pg, out_dtype=F32)
-                ws['Xk'][s0:s0 + 1].copy_(o.f32_to_bf16(pe0 + f0)); ws['Xf_b'][s0:s0 + 1].copy_(o.f32_to_bf16(f0))
+                def mlp1(x32, n1, n2, **kw):
+                    h3 = o.gemm_bf16(o.split3_rows(x32), self._c3(n1), W_['pe_b' + n1[1:]], act=1, split3=True)
+                    return o.gemm_bf16(h3, self._c3(n2), W_['pe_b' + n2[1:]], out_dtype=F32, **kw)
+                gate = mlp1(f0, 'wr', 'we', act=2)
+                pg = mlp1(a1f, 'w1a', 'w1b', mul=gate)
+                pe0 = mlp1(a2f, 'w2a', 'w2b', add=pg)
+                ws['Xk'][s0:s0 + 1].copy_(o.f32_to_key16(pe0 + f0)); ws['Xf_b'][s0:s0 + 1].copy_(o.f32_to_key16(f0))
             row_ptr, col_fb, _ = fallback_key_csr(row_ptr.clone(), ws['col_idx'][:int(row_ptr[R].item())].clone(), s0)
         no_dn = dn_ref is None or dn_ref.shape[0] == 0
         if no_dn and col_fb is None:
@@ -1064,20 +853,16 @@ class HeadEngine:
         nk = int(keys.numel())
         e = lambda *shape: torch.empty(shape, device=d, dtype=F32)  # noqa: E731
         posemb = o.posemb3d(dn_ref.to(F32).contiguous(), self.const['dim_t'])
-        if self.rows_x3:
-            q1 = o.linear_x3(posemb, W_['qe_w0x'], W_['qe_b0'], N=C, K=384, act=1)
-            qdn = o.linear_x3(q1, W_['qe_w2x'], W_['qe_b2'], N=C, K=C)
-        else:
-            q1 = o.gemm_f32(posemb, W_['qe_w0'], W_['qe_b0'], act=1, out=e(pad, C))
-            qdn = o.gemm_f32(q1, W_['qe_w2'], W_['qe_b2'], out=e(pad, C))
-        tws = dict(B=1, Vg=ws['Vg'], dn=(pad, max(int(dn_single), 1)), grp_start=None, KV=ws['KV'], xk_rows=ws['xk_rows'], xv_rows=ws['xv_rows'],
-                   Qt=torch.empty((T, 16 * C), device=d, dtype=BF16), zh=e(T, 8 * C),
+        q1 = o.linear_x3(posemb, W_['qe_w0x'], W_['qe_b0'], N=C, K=384, act=1)
+        qdn = o.linear_x3(q1, W_['qe_w2x'], W_['qe_b2'], N=C, K=C)
+        tws = dict(B=1, Vg=ws['Vg'], dn=(pad, max(int(dn_single), 1)), grp_start=None, xk_rows=ws['xk_rows'], xv_rows=ws['xv_rows'],
+                   Qt=torch.empty((T, 16 * C), device=d, dtype=self.K16), zh=e(T, 8 * C),
                    row_ptr=torch.cat([torch.arange(pad, device=d, dtype=torch.int32) * nk, row_ptr + pad * nk]),
                    col_idx=torch.cat([keys.repeat(pad), col]).contiguous(),
                    ref=torch.cat([dn_ref.to(F32), ws['ref'][:R]]).contiguous(), qpos=torch.cat([qdn, ws['qpos'][:R]]).contiguous(),
                    zero_rows=torch.zeros(T, C, device=d), qkv=e(T, 3 * C), parts=e(2048 // 64, T, C), outs=e(L, T, C), cls=e(L, T, 10),
                    reg=e(L, T, 10), dt_rows=torch.cat([torch.zeros(pad, device=d), torch.full((R,), float(out.get('dt', 0.0)), device=d)]))
-        for n in ('x', 'xq', 'x1', 'x1q', 'x2', 'ctx', 'o', 'q'):
+        for n in ('x', 'x1', 'x2', 'ctx', 'q'):
             tws[n] = e(T, C)
         self._enqueue_decoder(tws, T)
         self._enqueue_heads(tws, T, float(out.get('dt', 0.0)))
@@ -1105,9 +890,6 @@ class HeadEngine:
     def _check_capacity(ws):
         if int(ws['nnz'][1].item()) != 0:
             raise RuntimeError('mv2d engine: CSR capacity exceeded (raise col_cap_per_query)')
-        if ws.get('qt') is not None and int(ws['qt_ctl'][1].item()) != 0:         # (for the order alone the flag only means: natural order kept)
-            raise RuntimeError('mv2d engine: a query tile of the shared-key cross attention exceeded its capacity (8192 distinct keys per 16 queries / '
-                               '4096 queries per sample): run with MV2D_XATTN_QTILE=0')
 
     def results(self, out):
         """Synchronising accessor: sliced (boxes [K,9], scores [K], labels [K]) like simple_test returns."""

@@ -11,6 +11,16 @@ from . import _lib
 from ._lib import check
 
 BF16 = torch.bfloat16
+_K16 = None
+
+
+def key16_dtype():
+    """torch dtype of the key side's 16-bit format (csrc/common.h "key16"): torch.float16 since round 4 (mv2d_key16_format() == 1); a library
+    built with -DMV2D_KEY16_BF16 reports 0 -> torch.bfloat16.  Buffers handed to the key-side kernels must have this dtype."""
+    global _K16
+    if _K16 is None:
+        _K16 = torch.float16 if _lib.load().mv2d_key16_format() == 1 else torch.bfloat16
+    return _K16
 
 
 _RAW_STREAM, _GET_DEV = getattr(torch._C, '_cuda_getCurrentRawStream', None), getattr(torch._C, '_cuda_getDevice', None)
@@ -36,6 +46,20 @@ def _req(t, dtype, name):
         raise _lib.Mv2dHipError(f'{name}: expected {dtype}, got {t.dtype}')
     if not t.is_contiguous():
         raise _lib.Mv2dHipError(f'{name}: tensor must be contiguous')
+
+
+def _req16(t, name):
+    _req(t, key16_dtype(), name)
+
+
+def f32_to_key16(x, out=None, with_lo=False):
+    """fp32 -> key16 (the key-side format); with_lo: returns (hi, lo) with x ~ hi + lo."""
+    _req(x, torch.float32, 'x')
+    hi = torch.empty(x.shape, device=x.device, dtype=key16_dtype()) if out is None else out
+    lo = torch.empty(x.shape, device=x.device, dtype=key16_dtype()) if with_lo else None
+    _req16(hi, 'out')
+    check(_lib.load().mv2d_f32_to_key16(_p(x), _p(hi), _p(lo), x.numel(), _stream()), 'mv2d_f32_to_key16')
+    return (hi, lo) if with_lo else hi
 
 
 def gemm_bf16(A, W, bias=None, *, M=None, A2=None, n_split=0, conv3x3=False, m_dev=None, act=0, mul=None, add=None,
@@ -66,16 +90,6 @@ def gemm_bf16(A, W, bias=None, *, M=None, A2=None, n_split=0, conv3x3=False, m_d
                                _p(add_index), int(add_period), int(k_splits), int(split_stride), _stream())
     check(rc, 'mv2d_gemm_bf16')
     return out if out is not None else out2
-
-
-def kv_proj(A, W, bias, out, *, A2=None, n_split=0, m_dev=None, M=None, ldc=None, c_blk_stride=0, c_blk_cols=0):
-    """out = A @ W.T + bias (bf16, K = 256) with the weight-streaming kernel; layer-major output blocks like gemm_bf16."""
-    _req(A, BF16, 'A'); _req(W, BF16, 'W'); _req(A2, BF16, 'A2'); _req(bias, torch.float32, 'bias'); _req(out, BF16, 'out')
-    assert W.shape[1] == 256 and A.shape[-1] == 256
-    M = A.shape[0] if M is None else M
-    check(_lib.load().mv2d_kv_proj(_p(A), _p(A2), n_split, A.stride(0), _p(W), _p(bias), M, W.shape[0], _p(m_dev), _p(out),
-                                   ldc if ldc is not None else out.stride(-2), c_blk_stride, c_blk_cols, _stream()), 'mv2d_kv_proj')
-    return out
 
 
 def gemm_f32(A, W, bias=None, *, A2=None, n_split=0, split_k=1, act=0, scale=1.0, clamp=0.0, out=None, out_dtype=torch.float32,
@@ -112,8 +126,19 @@ def attn_out_fused(ctx, resid, Wo, bo, ln, x_out, *, qpos=None, Wq=None, bq=None
 
 
 def pack_x3(W):
-    """fp32 [256,256] weight -> (hi, lo) bf16 pair, each fragment-major, for attn_out_fused_x3."""
+    """fp32 [N,K] weight -> (hi, lo) bf16 pair, each fragment-major, for the bf16x3 (query-side) kernels."""
     hi, lo = split_bf16x2(W.contiguous())
+    return pack_wfrag(hi), pack_wfrag(lo)
+
+
+def pack_key16(W):
+    """fp32 [N,K] weight -> key16, fragment-major: the weights of the key-side kernels (PE MLPs, query-generator conv)."""
+    return pack_wfrag(f32_to_key16(W.contiguous()))
+
+
+def pack_key16_x3(W):
+    """fp32 [N,K] weight -> (hi, lo) key16 pair, each fragment-major (split-precision conv of the index-exact route)."""
+    hi, lo = f32_to_key16(W.contiguous(), with_lo=True)
     return pack_wfrag(hi), pack_wfrag(lo)
 
 
@@ -234,15 +259,15 @@ def cat3_weight(W, taps=1):
 
 
 def split_rows(a, b=None, hi=None, lo=None, m_dev=None, M=None):
-    """(hi, lo) bf16 rows of a (+ b): fp32 [M,cols] -> two bf16 [M,cols]; rows >= *m_dev (int32, device) are left untouched."""
-    _req(a, torch.float32, 'a'); _req(b, torch.float32, 'b'); _req(hi, BF16, 'hi'); _req(lo, BF16, 'lo'); _req(m_dev, torch.int32, 'm_dev')
+    """(hi, lo) key16 rows of a (+ b): fp32 [M,cols] -> two key16 [M,cols]; rows >= *m_dev (int32, device) are left untouched."""
+    _req(a, torch.float32, 'a'); _req(b, torch.float32, 'b'); _req16(hi, 'hi'); _req16(lo, 'lo'); _req(m_dev, torch.int32, 'm_dev')
     M = a.shape[0] if M is None else M
     cols = a.shape[-1]
     if hi is None:
-        hi = torch.empty((M, cols), device=a.device, dtype=BF16)
+        hi = torch.empty((M, cols), device=a.device, dtype=key16_dtype())
     if lo is None:
-        lo = torch.empty((M, cols), device=a.device, dtype=BF16)
-    check(_lib.load().mv2d_split_rows_bf16x2(_p(a), _p(b), _p(hi), _p(lo), M, cols, _p(m_dev), _stream()), 'mv2d_split_rows_bf16x2')
+        lo = torch.empty((M, cols), device=a.device, dtype=key16_dtype())
+    check(_lib.load().mv2d_split_rows_key16(_p(a), _p(b), _p(hi), _p(lo), M, cols, _p(m_dev), _stream()), 'mv2d_split_rows_key16')
     return hi, lo
 
 
@@ -301,32 +326,6 @@ def split_bf16x2(w):
     return hi, lo
 
 
-def gemm_x3(A, Whl, bias=None, *, A2=None, n_split=0, split_k=1, act=0, scale=1.0, clamp=0.0, out=None, out_dtype=torch.float32,
-            M=None, lda=None, ldc=None, groups=1, a_gs=0, w_gs=0, b_gs=0, c_gs=0):
-    """Same contract as gemm_f32 with Whl = split_bf16x2(W): fp32-class accuracy on the bf16 matrix cores."""
-    lib = _lib.load()
-    Whi, Wlo = Whl
-    _req(A, torch.float32, 'A'); _req(Whi, BF16, 'Whi'); _req(Wlo, BF16, 'Wlo'); _req(A2, torch.float32, 'A2'); _req(bias, torch.float32, 'bias')
-    N, K = Whi.shape[-2], Whi.shape[-1]
-    M = A.shape[-2] if M is None else M
-    lda_ = A.stride(-2) if lda is None else lda
-    if out is None:
-        shape = (split_k, M, N) if split_k > 1 else ((groups, M, N) if groups > 1 else (M, N))
-        out = torch.empty(shape, device=A.device, dtype=out_dtype)
-    ldc_ = ldc if ldc is not None else (out.stride(-2))
-    slice_stride = out.stride(0) if (split_k > 1) else 0
-    if groups > 1:
-        a_gs = a_gs or (A.stride(0) if A.dim() == 3 else 0)
-        w_gs = w_gs or Whi.stride(0)
-        b_gs = b_gs or (bias.stride(0) if bias is not None else 0)
-        c_gs = c_gs or out.stride(0)
-    rc = lib.mv2d_gemm_x3(_p(A), _p(A2), n_split, _p(Whi), _p(Wlo), _p(bias), M, N, K, lda_, Whi.stride(-2), split_k, act, float(scale),
-                          float(clamp), _p(out), 1 if out.dtype == BF16 else 0, ldc_, slice_stride, groups, a_gs, w_gs, b_gs, c_gs,
-                          _stream())
-    check(rc, 'mv2d_gemm_x3')
-    return out
-
-
 def row_ln(parts, *, bias=None, residual=None, ln=None, relu=False, out=None, addvec=None, out_plus=None, ln2=None, out2=None,
            M=None, eps=1e-5, rows_per_group=0):
     """y = [relu][LN](sum parts + bias + residual); parts [M,256] or [Z,M,256]."""
@@ -352,41 +351,33 @@ def finalize_reg(reg, ref, L, R, pc_range_host, dt=0.0):
     check(_lib.load().mv2d_finalize_reg(_p(reg), _p(ref), L, R, pc_range_host.data_ptr(), float(dt), _stream()), 'mv2d_finalize_reg')
 
 
-def pe_fused(A1, A2, Xfb, Xf32, m_dev, wp, pe, Xk, M=None, row_index=None):
-    """wp: dict with the fragment-major PE weights 'w1a','w1b','w2a','w2b','wr','we' (pack_wfrag) and fp32 biases 'b1a',...,'be'."""
-    _req(A1, BF16, 'A1'); _req(A2, BF16, 'A2'); _req(Xfb, BF16, 'Xfb'); _req(Xf32, torch.float32, 'Xf32')
-    _req(pe, torch.float32, 'pe'); _req(Xk, BF16, 'Xk')
+def pe_fused_tab(A1, Xfb, Xf32, m_dev, wp, sine_tab, tab_period, pe, Xk, M=None, row_index=None, shape=1):
+    """The PE block of the key side in one launch: pe = sine_tab[position] + position_encoder(A1) * gate(Xf), Xk = key16(pe + Xf32).
+    wp: dict with the fragment-major key16 weights 'w1a','w1b','wr','we' (pack_key16) and fp32 biases 'b1a','b1b','br','be'; sine_tab
+    [tab_period,256] fp32 (map position -> adapt_pos3d(sine) + bias).  Xk may be None (S path: only pe is needed; the feature rows are then
+    not read), pe may be None when Xk is given (T path).  shape: 1 = 96-row blocks (default), 0 = 64-row blocks (bit-identical)."""
+    _req16(A1, 'A1'); _req16(Xfb, 'Xfb'); _req(Xf32, torch.float32, 'Xf32'); _req(sine_tab, torch.float32, 'sine_tab'); _req16(Xk, 'Xk')
     M = A1.shape[0] if M is None else M
-    check(_lib.load().mv2d_pe_fused(_p(A1), _p(A2), _p(Xfb), _p(Xf32), _p(row_index), _p(m_dev), M,
-                                    _p(wp['w1a']), _p(wp['b1a']), _p(wp['w1b']), _p(wp['b1b']), _p(wp['w2a']), _p(wp['b2a']),
-                                    _p(wp['w2b']), _p(wp['b2b']), _p(wp['wr']), _p(wp['br']), _p(wp['we']), _p(wp['be']),
-                                    _p(pe), _p(Xk), _stream()), 'mv2d_pe_fused')
-    return pe, Xk
-
-
-def pe_fused_tab(A1, Xfb, Xf32, m_dev, wp, sine_tab, tab_period, pe, Xk, M=None, row_index=None):
-    """pe_fused with the sine branch read from sine_tab [tab_period,256] fp32 (map position -> adapt_pos3d(sine) + bias).  Xk may be None
-    (S path: only pe is needed; the feature rows are then not read), pe may be None when Xk is given (T path)."""
-    _req(A1, BF16, 'A1'); _req(Xfb, BF16, 'Xfb'); _req(Xf32, torch.float32, 'Xf32'); _req(sine_tab, torch.float32, 'sine_tab')
-    M = A1.shape[0] if M is None else M
-    check(_lib.load().mv2d_pe_fused_tab(_p(A1), _p(Xfb), _p(Xf32), _p(row_index), _p(m_dev), M, _p(wp['w1a']), _p(wp['b1a']), _p(wp['w1b']),
-                                        _p(wp['b1b']), _p(wp['wr']), _p(wp['br']), _p(wp['we']), _p(wp['be']), _p(sine_tab), int(tab_period),
-                                        _p(pe), _p(Xk), _stream()), 'mv2d_pe_fused_tab')
+    check(_lib.load().mv2d_pe_fused_tab2(_p(A1), _p(Xfb), _p(Xf32), _p(row_index), _p(m_dev), M, _p(wp['w1a']), _p(wp['b1a']), _p(wp['w1b']),
+                                         _p(wp['b1b']), _p(wp['wr']), _p(wp['br']), _p(wp['we']), _p(wp['be']), _p(sine_tab), int(tab_period),
+                                         _p(pe), _p(Xk), int(shape), _stream()), 'mv2d_pe_fused_tab')
     return pe, Xk
 
 
 def pack_wfrag(W):
-    """row-major bf16 weight [N,K] -> fragment-major copy (one MFMA fragment = one contiguous 1 KB)."""
-    _req(W, BF16, 'W')
+    """row-major 16-bit weight [N,K] (bf16 or key16) -> fragment-major copy of the same dtype (one MFMA fragment = one contiguous 1 KB)."""
+    if W.dtype not in (BF16, torch.float16):
+        raise _lib.Mv2dHipError(f'pack_wfrag: expected a 16-bit weight, got {W.dtype}')
+    _req(W, W.dtype, 'W')
     N, K = W.shape
-    Wp = torch.empty(N * K, device=W.device, dtype=BF16)
+    Wp = torch.empty(N * K, device=W.device, dtype=W.dtype)
     check(_lib.load().mv2d_pack_wfrag_bf16(_p(W), _p(Wp), N, K, _stream()), 'mv2d_pack_wfrag_bf16')
     return Wp
 
 
 def qg_conv_pool(roi_feat, W, bias, out, R=None, ld_out=None):
-    """out[r] = avgpool7x7(relu(conv3x3(roi_feat[r]) + bias)); roi_feat [R,49,256] bf16, W = pack_wfrag(conv weight [256,2304])."""
-    _req(roi_feat, BF16, 'roi_feat'); _req(W, BF16, 'W'); _req(bias, torch.float32, 'bias'); _req(out, torch.float32, 'out')
+    """out[r] = avgpool7x7(relu(conv3x3(roi_feat[r]) + bias)); roi_feat [R,49,256] key16, W = pack_key16(conv weight [256,2304])."""
+    _req16(roi_feat, 'roi_feat'); _req16(W, 'W'); _req(bias, torch.float32, 'bias'); _req(out, torch.float32, 'out')
     R = roi_feat.shape[0] if R is None else R
     check(_lib.load().mv2d_qg_conv_pool(_p(roi_feat), _p(W), _p(bias), _p(out), out.stride(0) if ld_out is None else ld_out, R, _stream()),
           'mv2d_qg_conv_pool')
@@ -394,8 +385,8 @@ def qg_conv_pool(roi_feat, W, bias, out, R=None, ld_out=None):
 
 
 def qg_conv_pool_x3(roi_hi, roi_lo, W_x3, bias, out, R=None, ld_out=None):
-    """qg_conv_pool in split precision: RoI cells as bf16 hi + lo [R,49,256], W_x3 = pack_x3(conv weight [256,2304])."""
-    _req(roi_hi, BF16, 'roi_hi'); _req(roi_lo, BF16, 'roi_lo'); _req(bias, torch.float32, 'bias'); _req(out, torch.float32, 'out')
+    """qg_conv_pool in split precision: RoI cells as key16 hi + lo [R,49,256], W_x3 = pack_key16_x3(conv weight [256,2304])."""
+    _req16(roi_hi, 'roi_hi'); _req16(roi_lo, 'roi_lo'); _req16(W_x3[0], 'W_hi'); _req16(W_x3[1], 'W_lo'); _req(bias, torch.float32, 'bias'); _req(out, torch.float32, 'out')
     R = roi_hi.shape[0] if R is None else R
     check(_lib.load().mv2d_qg_conv_pool_x3(_p(roi_hi), _p(roi_lo), _p(W_x3[0]), _p(W_x3[1]), _p(bias), _p(out),
                                            out.stride(0) if ld_out is None else ld_out, R, _stream()), 'mv2d_qg_conv_pool_x3')
@@ -444,17 +435,6 @@ def nchw_to_nhwc(x, out=None):
     return out
 
 
-SELF_ATTN_X3 = None
-
-
-def _self_attn_x3():
-    global SELF_ATTN_X3
-    if SELF_ATTN_X3 is None:
-        import os
-        SELF_ATTN_X3 = os.environ.get('MV2D_SELF_ATTN', 'x3') == 'x3'      # f32: the round-1 exact-fp32 MFMA kernel (A/B switch)
-    return SELF_ATTN_X3
-
-
 def self_attn(qkv, out=None, R=None, grp_start=None, max_grp_rows=0, impl=None):
     """FlattenMHSelfAttention core.  grp_start (int32 [n+1], device): first query row of every sample of a batch; attention stays inside
     a sample.  impl: 'x3' (default: bf16 split precision, K / V through LDS) | 'f32' (exact fp32 MFMA, round 1)."""
@@ -463,7 +443,7 @@ def self_attn(qkv, out=None, R=None, grp_start=None, max_grp_rows=0, impl=None):
     if out is None:
         out = torch.empty((R, 256), device=qkv.device, dtype=torch.float32)
     n = 0 if grp_start is None else grp_start.numel() - 1
-    if (impl or ('x3' if _self_attn_x3() else 'f32')) == 'x3':
+    if (impl or 'x3') == 'x3':
         check(_lib.load().mv2d_self_attn_x3_fwd(_p(qkv), _p(out), R, _p(grp_start), n, int(max_grp_rows), 0, 1, _stream()), 'mv2d_self_attn_x3_fwd')
     else:
         check(_lib.load().mv2d_self_attn_fwd(_p(qkv), _p(out), R, _p(grp_start), n, _stream()), 'mv2d_self_attn_fwd')
@@ -512,17 +492,6 @@ def sparse_xattn(q, K, V, row_ptr, col_idx, out=None, R=None, dbg_logits=None, e
 
 
 
-def raw_xattn(qk, Xk, Xv, row_ptr, col_idx, out=None, R=None, empty_nan=True):
-    """Attention on unprojected key / value rows: qk [R,8,256] fp32 (per-head query maps), Xk / Xv [S,256] bf16 -> z [R,8,256] fp32."""
-    _req(qk, torch.float32, 'qk'); _req(Xk, BF16, 'Xk'); _req(Xv, BF16, 'Xv')
-    R = qk.shape[0] if R is None else R
-    if out is None:
-        out = torch.empty((R, 8, 256), device=qk.device, dtype=torch.float32)
-    check(_lib.load().mv2d_raw_xattn_fwd(_p(qk), _p(Xk), _p(Xv), _p(row_ptr), _p(col_idx), _p(out), R, 1 if empty_nan else 0, _stream()),
-          'mv2d_raw_xattn_fwd')
-    return out
-
-
 def pack_xattn_maps(Wk, Wv):
     """Key / value in_proj weights [256,256] fp32 (rows = output channels) -> the packed operands of the tile cross attention
     (csrc/xattn_tile.hip): (WA_hi, WA_lo) for ``xattn_qmap`` and (WB_hi, WB_lo) for ``xattn_ctxmap``, bf16 hi / lo pairs.
@@ -539,23 +508,23 @@ def pack_xattn_maps(Wk, Wv):
 
 
 def xattn_qmap(q, WA, Qt=None, R=None):
-    """q [R,256] fp32 (pre-scaled) -> Qt [R,4096] bf16: the fragment-major 16 x 256 operand (hi / lo rows of the 8 per-head maps)."""
+    """q [R,256] fp32 (pre-scaled) -> Qt [R,4096] key16: the fragment-major 16 x 256 operand (hi / lo rows of the 8 per-head maps)."""
     _req(q, torch.float32, 'q'); _req(WA[0], BF16, 'WA_hi'); _req(WA[1], BF16, 'WA_lo')
     R = q.shape[0] if R is None else R
     if Qt is None:
-        Qt = torch.empty((R, 4096), device=q.device, dtype=BF16)
-    _req(Qt, BF16, 'Qt')
+        Qt = torch.empty((R, 4096), device=q.device, dtype=key16_dtype())
+    _req16(Qt, 'Qt')
     check(_lib.load().mv2d_xattn_qmap(_p(q), _p(WA[0]), _p(WA[1]), _p(Qt), R, _stream()), 'mv2d_xattn_qmap')
     return Qt
 
 
 def xattn_tile(Qt, Xk, Xv, row_ptr, col_idx, out=None, R=None, dbg_logits=None, empty_nan=True, waves=0, Xk_lo=None, Xv_lo=None, order=None,
                row_bytes=512):
-    """Tile cross attention on the unprojected key / value rows: Qt from xattn_qmap, Xk / Xv [S,256] bf16 -> z [R,8,256] fp32.
-    Xk_lo / Xv_lo: optional bf16 remainders of the rows (index-exact validation mode: fp32-class key side)."""
-    _req(Qt, BF16, 'Qt')
+    """Tile cross attention on the unprojected key / value rows: Qt from xattn_qmap, Xk / Xv [S,256] key16 -> z [R,8,256] fp32.
+    Xk_lo / Xv_lo: optional key16 remainders of the rows (index-exact route: fp32-class key side)."""
+    _req16(Qt, 'Qt')
     if row_bytes == 512:
-        _req(Xk, BF16, 'Xk'); _req(Xv, BF16, 'Xv'); _req(Xk_lo, BF16, 'Xk_lo'); _req(Xv_lo, BF16, 'Xv_lo')
+        _req16(Xk, 'Xk'); _req16(Xv, 'Xv'); _req16(Xk_lo, 'Xk_lo'); _req16(Xv_lo, 'Xv_lo')
     _req(row_ptr, torch.int32, 'row_ptr'); _req(col_idx, torch.int32, 'col_idx'); _req(dbg_logits, torch.float32, 'dbg_logits')
     R = Qt.shape[0] if R is None else R
     if out is None:
@@ -574,36 +543,6 @@ def xattn_query_order(row_ptr, col_idx, grp_start, R, perm, flags):
     return perm
 
 
-def xattn_qtile_alloc(R, n_samples, col_cap, device, alloc=None, queries_per_tile=8):
-    """Tables of the shared-key-tile cross attention (T path) for launches of R query rows / n_samples samples / col_cap CSR entries.
-    alloc(n) -> zeroed int32 tensor of n elements (default: torch.zeros on `device`)."""
-    nt = int(_lib.load().mv2d_xattn_qtile_max_tiles(R, n_samples, queries_per_tile))
-    ucap = (col_cap + 16 * nt + 15) // 16 * 16
-    i32 = alloc if alloc is not None else (lambda n: torch.zeros(n, dtype=torch.int32, device=device))
-    return dict(perm=i32(R), tq0=i32(nt), tqn=i32(nt), nt=i32(1), uptr=i32(nt), ucnt=i32(nt), ukeys=i32(ucap), mask=i32(ucap // 16 * 8), ucap=ucap,
-                max_tiles=nt, n_samples=n_samples, qt=queries_per_tile)
-
-
-def xattn_qtile_build(qt, row_ptr, col_idx, grp_start, R, bits, nwords, rect, V, cells_per_sample, pos2s, ctl):
-    """qt = xattn_qtile_alloc(...); ctl int32 [2] = (allocation counter, overflow flag), zeroed by the caller for this frame."""
-    check(_lib.load().mv2d_xattn_qtile_build(_p(row_ptr), _p(col_idx), _p(grp_start), qt['n_samples'], R, _p(bits), nwords, _p(rect), V, cells_per_sample,
-                                             _p(pos2s), _p(qt['perm']), _p(qt['tq0']), _p(qt['tqn']), _p(qt['nt']), _p(qt['uptr']), _p(qt['ucnt']),
-                                             _p(qt['ukeys']), qt['ucap'], _p(qt['mask']), ctl.data_ptr(), ctl.data_ptr() + 4, qt['qt'], _stream()),
-          'mv2d_xattn_qtile_build')
-
-
-def xattn_qtile(Qt, Xk, Xv, qt, out=None, R=None, empty_nan=True):
-    """Cross attention over query tiles with shared key tiles (tables from xattn_qtile_build): z [R,8,256] fp32 like xattn_tile."""
-    _req(Qt, BF16, 'Qt'); _req(Xk, BF16, 'Xk'); _req(Xv, BF16, 'Xv')
-    R = Qt.shape[0] if R is None else R
-    if out is None:
-        out = torch.empty((R, 8, 256), device=Qt.device, dtype=torch.float32)
-    check(_lib.load().mv2d_xattn_qtile_fwd(_p(Qt), _p(Xk), _p(Xv), _p(qt['perm']), _p(qt['tq0']), _p(qt['tqn']), _p(qt['nt']), _p(qt['uptr']),
-                                           _p(qt['ucnt']), _p(qt['ukeys']), _p(qt['mask']), _p(out), R, qt['n_samples'], 1 if empty_nan else 0, qt['qt'], _stream()),
-          'mv2d_xattn_qtile_fwd')
-    return out
-
-
 def xattn_ctxmap(z, WB, bv, row_ptr, out=None, R=None, empty_nan=True):
     """z [R,8,256] fp32 -> ctx [R,256] = Wv_h z_h + bv; rows without a key (row_ptr) give NaN / 0."""
     _req(z, torch.float32, 'z'); _req(WB[0], BF16, 'WB_hi'); _req(WB[1], BF16, 'WB_lo'); _req(bv, torch.float32, 'bv')
@@ -614,16 +553,6 @@ def xattn_ctxmap(z, WB, bv, row_ptr, out=None, R=None, empty_nan=True):
     check(_lib.load().mv2d_xattn_ctxmap(_p(z), _p(WB[0]), _p(WB[1]), _p(bv), _p(row_ptr), _p(out), R, 1 if empty_nan else 0, _stream()),
           'mv2d_xattn_ctxmap')
     return out
-
-
-def pack_head_maps(Wk, Wv):
-    """Per-layer weights of the raw-row attention: (in_x3, out_x3) for the two grouped linears around raw_xattn.
-    in: qk[:, h] = q[:, 32h:32h+32] @ Wk[32h:32h+32, :]   -> group weight [N=256, K=32] = Wk[32h:32h+32, :].T
-    out: ctx[:, 32h:32h+32] = z[:, h] @ Wv[32h:32h+32, :].T -> group weight [N=32, K=256] = Wv[32h:32h+32, :]"""
-    ins = [pack_x3(Wk[32 * h:32 * h + 32, :].t().contiguous()) for h in range(8)]
-    outs = [pack_x3(Wv[32 * h:32 * h + 32, :].contiguous()) for h in range(8)]
-    cat = lambda parts, i: torch.stack([p[i].view(-1) for p in parts]).contiguous()
-    return (cat(ins, 0), cat(ins, 1)), (cat(outs, 0), cat(outs, 1))
 
 
 def csr_transpose(row_ptr, col_idx, S):
@@ -644,13 +573,17 @@ def attn_drop_mask(nnz, seed, p_drop):
     import numpy as np
     if p_drop <= 0:
         return np.ones((nnz, 8), np.float32)
-    thr = min(int(p_drop * 4294967296.0), 0xffffffff) or 1
+    # exactly as make_drop() (csrc/attention.hip): the kernels receive p_drop as a C float -- thr = (unsigned)((double)(float)p * 2^32),
+    # scale = 1.f / (1.f - p) in fp32 (a Python double here would differ by a few counts of the threshold and one ulp of the scale)
+    pf = np.float32(p_drop)
+    t = float(pf) * 4294967296.0
+    thr = (0xffffffff if t >= 4294967295.0 else int(t)) or 1
     with np.errstate(over='ignore'):
         u = (np.arange(nnz * 8, dtype=np.uint64) * np.uint64(0x9E3779B1)).astype(np.uint32) ^ np.uint32(seed & 0xffffffff)
         u ^= u >> np.uint32(16); u = (u.astype(np.uint64) * np.uint64(0x85EBCA6B)).astype(np.uint32)
         u ^= u >> np.uint32(13); u = (u.astype(np.uint64) * np.uint64(0xC2B2AE35)).astype(np.uint32)
         u ^= u >> np.uint32(16)
-    return np.where(u >= np.uint32(thr), np.float32(1.0 / (1.0 - p_drop)), np.float32(0)).reshape(nnz, 8)
+    return np.where(u >= np.uint32(thr), np.float32(1.0) / (np.float32(1.0) - pf), np.float32(0)).reshape(nnz, 8)
 
 
 def sparse_xattn_bwd(q, K, V, row_ptr, col_idx, ctx, dctx, R=None, transposed=None, p_drop=0.0, seed=0):
@@ -729,7 +662,7 @@ def posemb3d(ref, dim_t, out=None):
 def roi_align(map0, rois, H, W, *, map1=None, out0=None, out1=None, out0_f32=None, out1_f32=None, spatial_scale=1.0 / 16,
               sampling_ratio=-1, map1_index=None, out1_is_sum=False, R=None, out0_lo=None, out1_lo=None):
     _req(map0, torch.float32, 'map0'); _req(map1, torch.float32, 'map1'); _req(rois, torch.float32, 'rois')
-    _req(out0_lo, BF16, 'out0_lo'); _req(out1_lo, BF16, 'out1_lo')
+    _req16(out0, 'out0'); _req16(out1, 'out1'); _req16(out0_lo, 'out0_lo'); _req16(out1_lo, 'out1_lo')
     check(_lib.load().mv2d_roi_align_ex(_p(map0), _p(map1), _p(rois), _p(out0), _p(out1), _p(out0_f32), _p(out1_f32),
                                         rois.shape[0] if R is None else R, H, W, map0.shape[-1], spatial_scale, sampling_ratio,
                                         _p(map1_index), 1 if out1_is_sum else 0, _p(out0_lo), _p(out1_lo), _stream()), 'mv2d_roi_align')
@@ -767,11 +700,13 @@ def csr_from_corr(match, row_ptr, col_idx, nnz_out, R, V, topk):
           'mv2d_csr_from_corr')
 
 
-def pe_inputs(s2pos, S_dev, S_max, featcl, img2lidar, coords_w, coords_h, coords_d, embeds, dim_t, A_frustum, A_sine, Xf_bf16,
+def pe_inputs(s2pos, S_dev, S_max, featcl, img2lidar, coords_w, coords_h, coords_d, embeds, dim_t, A_frustum, A_sine, Xf_k16,
               Xf_f32, V, h, w, depth_num, position_range_host, A_frustum_f32=None, A_sine_f32=None):
+    """A_frustum [S,3D], A_sine [S,384] (may be None), Xf_k16 [S,256]: key16 rows; *_f32: the same rows unrounded (optional)."""
+    _req16(A_frustum, 'A_frustum'); _req16(A_sine, 'A_sine'); _req16(Xf_k16, 'Xf_k16')
     _req(A_frustum_f32, torch.float32, 'A_frustum_f32'); _req(A_sine_f32, torch.float32, 'A_sine_f32')
     check(_lib.load().mv2d_pe_inputs(_p(s2pos), _p(S_dev), S_max, _p(featcl), _p(img2lidar), _p(coords_w), _p(coords_h), _p(coords_d),
-                                     _p(embeds), _p(dim_t), _p(A_frustum), _p(A_sine), _p(Xf_bf16), _p(Xf_f32), _p(A_frustum_f32),
+                                     _p(embeds), _p(dim_t), _p(A_frustum), _p(A_sine), _p(Xf_k16), _p(Xf_f32), _p(A_frustum_f32),
                                      _p(A_sine_f32), V, h, w, depth_num, position_range_host.data_ptr(), _stream()), 'mv2d_pe_inputs')
 
 

@@ -165,11 +165,14 @@ class PE(nn.Module):
         s2pos = torch.arange(P, dtype=torch.int32, device=dev)
         S_dev = torch.tensor([P], dtype=torch.int32, device=dev)
         fcl = ops.nchw_to_nhwc(x.float().contiguous())
-        e = lambda n, dt=BF16: torch.empty((P, n), device=dev, dtype=dt)
-        A1, A2, Xb, Xf = e(3 * self.depth_num), e(384), e(C), e(C, torch.float32)
+        # module-level call (whole map, not the engine's hot path): the kernel's fp32 rows feed the generic bf16 tile GEMM chain
+        k16, f32 = ops.key16_dtype(), torch.float32
+        e = lambda n, dt: torch.empty((P, n), device=dev, dtype=dt)
+        A1f, A2f, Xf = e(3 * self.depth_num, f32), e(384, f32), e(C, f32)
         ops.pe_inputs(s2pos, S_dev, P, fcl, ft['img2lidar'].to(dev), ft['coords_w'].to(dev), ft['coords_h'].to(dev),
-                      ft['coords_d'].to(dev), ft['embeds'].to(dev), ct['dim_t'].to(dev), A1, A2, Xb, Xf, V, h, w, self.depth_num,
-                      torch.tensor(self.position_range, dtype=torch.float64))
+                      ft['coords_d'].to(dev), ft['embeds'].to(dev), ct['dim_t'].to(dev), e(3 * self.depth_num, k16), e(384, k16), e(C, k16), Xf, V, h, w,
+                      self.depth_num, torch.tensor(self.position_range, dtype=torch.float64), A_frustum_f32=A1f, A_sine_f32=A2f)
+        A1, A2, Xb = ops.f32_to_bf16(A1f), ops.f32_to_bf16(A2f), ops.f32_to_bf16(Xf)
         g = lambda name, mod: (self._b.get(name, mod.weight.flatten(1)), _f(mod.bias))
         w1a, b1a = g('w1a', self.position_encoder[0]); w1b, b1b = g('w1b', self.position_encoder[2])
         w2a, b2a = g('w2a', self.adapt_pos3d[0]); w2b, b2b = g('w2b', self.adapt_pos3d[2])

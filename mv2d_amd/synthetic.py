@@ -204,9 +204,12 @@ WORKLOADS = {
     # S path with MANY correlated RoIs per query (the n_c sweep): six cameras 8 degrees apart with a lateral baseline, so that
     # every view overlaps every other one and the reference's epipolar correlation (top-1 per other view) yields up to 1 + 5 RoIs per query
     'nc6_s': ('S', 6, 1, 224, 400, 416, 14),
+    # the same overlapping rig at the HEADLINE size (BASELINE.json configs[1]: 6 cams 1408x512, 300 RoIs): the non-trivial S workload of the bench
+    # line (round 4) -- every query reads its own RoI plus up to five matched ones instead of the 1.01 RoIs of the ring rig
+    'cfg2_s_nc6': ('S', 6, 1, 512, 1408, None, 50),
 }
 # rigs that are not a full ring: yaw step in degrees and lateral camera spacing in metres
-RIG = {'nc6_s': (8.0, 0.35)}
+RIG = {'nc6_s': (8.0, 0.35), 'cfg2_s_nc6': (8.0, 0.35)}
 
 
 def make_problem(name, seed=0, with_feat=True, ego=0.0):

@@ -141,7 +141,8 @@ def main():
     # the headline sizes (BASELINE.json configs[1] / configs[2]) contribute compact outputs only: index lists, bit-packed masks,
     # per-layer [6,R,10] heads, final boxes (3P-derived arrays are listed in tests/golden/README.md)
     cases = [('micro_t', True), ('micro_s', True), ('cfg1_t', False), ('cfg1_s', False), ('cfg2_s', False), ('cfg3_t', False), ('cfg5_t', False),
-             ('nc6_s', False)]      # S path with up to 6 correlated RoIs per query (overlapping views, mv2d_amd/synthetic.py RIG)
+             ('nc6_s', False),      # S path with up to 6 correlated RoIs per query (overlapping views, mv2d_amd/synthetic.py RIG)
+             ('cfg2_s_nc6', False)]  # ... and the same rig at the headline size (round 4)
     only = [a for a in sys.argv[1:] if not a.startswith('-')]
     if only:
         cases = [c for c in cases if c[0] in only]

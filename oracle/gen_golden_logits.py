@@ -31,8 +31,8 @@ from oracle import _stubs  # noqa: E402
 from oracle.gen_golden import build_reference_head  # noqa: E402
 
 OUT = os.path.join(ROOT, 'tests', 'golden', 'attn_pairs.npz')
-CASES = ['cfg1_t', 'cfg1_s', 'micro_s', 'cfg2_s', 'cfg3_t', 'nc6_s']
-QUERY_STEP = {'cfg2_s': 2, 'cfg3_t': 4, 'nc6_s': 2}
+CASES = ['cfg1_t', 'cfg1_s', 'micro_s', 'cfg2_s', 'cfg3_t', 'nc6_s', 'cfg5_t', 'cfg2_s_nc6']       # the last two: round 4 (configs[4]; the overlapping rig at headline size)
+QUERY_STEP = {'cfg2_s': 2, 'cfg3_t': 4, 'nc6_s': 2, 'cfg5_t': 16, 'cfg2_s_nc6': 6}
 
 
 def run_case(head, kind, prob):

@@ -329,10 +329,10 @@ def test_engine_batch_edge_cases(kind):
 
 
 @pytest.mark.parametrize('kind,name', [('S', 'cfg1_s'), ('T', 'cfg1_t')])
-def test_engine_cross_attention_routes_agree(kind, name, monkeypatch):
-    """The default route (tile cross attention on the unprojected key / value rows, no K/V projection, csrc/xattn_tile.hip) against the
-    round-1 routes kept for A/B runs: MV2D_XATTN=sparse (kvproj_kernel + per-query VALU kernel) and MV2D_RAW_ATTN=1 (VALU P.V on raw
-    rows).  They differ by the bf16 rounding of the projected K/V that only the sparse route has."""
+def test_engine_map_kernels_fused_or_separate_bitwise_equal(kind, name):
+    """The per-head query / context maps of the tile cross attention run inside the neighbouring row kernels (chosen for launches of <= 512
+    rows, i.e. here) or as separate kernels (batches): bitwise the same results, which is why the choice may depend on the launch size; the
+    option is part of the hipGraph key.  The T path's block order (queries by smallest key) is a speed-only option: same results without it."""
     from mv2d_amd.engine import HeadEngine
     prob = synthetic.make_problem(name, seed=0)
     sd = synthetic.make_head_state(seed=0)
@@ -340,33 +340,41 @@ def test_engine_cross_attention_routes_agree(kind, name, monkeypatch):
     feat = torch.from_numpy(prob['feat']).to(dev)
     props = [torch.from_numpy(p) for p in prob['proposals']]
     eng = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'])
-    assert eng.tile_attn and not eng.raw_attn
     out = eng.run(feat, props, prob['img_metas'])
-    assert out['ws']['KV'] is None
     o2 = eng.run(feat, props, prob['img_metas'], use_graph=True)
     assert torch.equal(o2['cls'], out['cls'])
-    # the per-head maps inside the neighbouring row kernels (chosen for launches of <= 512 rows, i.e. here) or as separate kernels: bitwise
-    # the same results, which is why the choice may depend on the launch size
     assert eng.fuse_maps is None and out['R'] <= 512
-    for forced in ('0', '1'):
-        monkeypatch.setenv('MV2D_XATTN_FUSE_MAPS', forced)
-        sep_eng = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'])
-        assert sep_eng.fuse_maps is (forced == '1')
-        sep = sep_eng.run(feat, props, prob['img_metas'])
-        assert torch.equal(sep['cls'], out['cls']) and torch.equal(sep['reg'], out['reg'])
-    monkeypatch.delenv('MV2D_XATTN_FUSE_MAPS')
-    monkeypatch.setenv('MV2D_XATTN', 'sparse')
-    ref_eng = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'])
-    assert not ref_eng.tile_attn
-    ref = ref_eng.run(feat, props, prob['img_metas'])
-    assert ref['ws']['KV'] is not None
-    assert relmax(out['cls'], ref['cls']) < 2e-3 and relmax(out['reg'], ref['reg']) < 5e-3
-    monkeypatch.setenv('MV2D_RAW_ATTN', '1')
-    raw_eng = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'])
-    assert raw_eng.raw_attn and not raw_eng.tile_attn
-    raw = raw_eng.run(feat, props, prob['img_metas'])
-    assert raw['ws']['KV'] is None
-    assert relmax(out['cls'], raw['cls']) < 3e-4 and relmax(out['reg'], raw['reg']) < 1e-3      # same arithmetic up to fp32 summation order
+    ref = {k: out[k].clone() for k in ('cls', 'reg')}
+    for forced in (False, True):
+        eng.fuse_maps = forced
+        sep = eng.run(feat, props, prob['img_metas'], use_graph=True)                # (a new graph: the option is in the key)
+        assert torch.equal(sep['cls'], ref['cls']) and torch.equal(sep['reg'], ref['reg'])
+    eng.fuse_maps = None
+    if kind == 'T':
+        assert eng.q_order
+        eng.q_order = False
+        nat = eng.run(feat, props, prob['img_metas'])
+        assert torch.equal(nat['cls'], ref['cls']) and torch.equal(nat['reg'], ref['reg'])
+
+
+def test_engine_stays_finite_when_features_exceed_the_fp16_range():
+    """Range guard of the fp16 key side (csrc/common.h): feature values beyond +-65504 SATURATE in the key / value rows and RoI cells instead of
+    becoming inf -- every output of the frame stays finite (an inf in a key row would turn its softmax rows into NaN and, through the next self
+    attention, the whole frame).  The index-exact route carries the same guard in its hi + lo pairs."""
+    from mv2d_amd.engine import HeadEngine
+    prob = synthetic.make_problem('micro_t', seed=0)
+    sd = synthetic.make_head_state(seed=0)
+    dev = torch.device('cuda:0')
+    feat = torch.from_numpy(prob['feat']).to(dev) * 4.0e4                             # |values| up to ~1.6e5
+    assert float(feat.abs().max()) > 65504.0
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    for exact in (False, True):
+        eng = HeadEngine(sd, 'T', dev, num_views=prob['views_per_frame'], exact=exact)
+        out = eng.run(feat, props, prob['img_metas'], keep_stages=True)
+        torch.cuda.synchronize()
+        R = out['R']
+        assert bool(torch.isfinite(out['cls'][:, :R]).all()) and bool(torch.isfinite(out['reg'][:, :R]).all()), exact
+        assert bool(torch.isfinite(out['stages']['Xk'].float()).all())
 
 
 def test_engine_full_size_properties_cfg5():
@@ -470,32 +478,32 @@ def test_engine_ragged_views(kind):
 
 
 @pytest.mark.parametrize('kind', ['S', 'T'])
-def test_sine_table_variant_matches_the_default_path(kind):
-    """Default path: adapt_pos3d(sine) read from a per-(weights, geometry) table; MV2D_PE_SINE_TABLE=0 evaluates it per frame like the
-    reference.  Same PE / keys / outputs up to the accumulation order of one MLP; also with a padded view and with a
-    batch whose samples differ in padding geometry (one table row per position of the whole batch then)."""
+def test_sine_table_with_padded_views_and_mixed_geometry_batches(kind):
+    """adapt_pos3d(sine) is read from a per-(weights, geometry) table.  With a padded view the PE rows still equal the
+    oracle's (which evaluates the branch per frame like the reference), and a batch whose samples differ in padding geometry (one table row
+    per position of the whole batch then) == the two single runs, bitwise."""
     from mv2d_amd import engine as E
-    sd = {k: torch.from_numpy(v) for k, v in synthetic.make_head_state(seed=0).items()}
+    from oracle import mv2d_oracle as O
+    sd_np = synthetic.make_head_state(seed=0)
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
     name = 'cfg1_s' if kind == 'S' else 'cfg1_t'
     prob = synthetic.make_problem(name, seed=0)
     nv = prob['views_per_frame']
-    a = E.HeadEngine(sd, kind, 'cuda', num_views=nv)
-    a.pe_sine_table = False
     b = E.HeadEngine(sd, kind, 'cuda', num_views=nv)
-    assert b.pe_sine_table
-    feat = torch.from_numpy(prob['feat']).cuda()
+    feat_h = torch.from_numpy(prob['feat'])
+    feat = feat_h.cuda()
     props = [torch.from_numpy(p) for p in prob['proposals']]
     metas = prob['img_metas']
     narrow = [dict(m, img_shape=(m['img_shape'][0], m['img_shape'][1] - 48, 3)) for m in metas]      # a padded strip on the right
     for ms in (metas, narrow):
-        oa = a.run(feat, props, ms, keep_stages=True)
         ob = b.run(feat, props, ms, keep_stages=True)
-        S = int(oa['stages']['S_dev'])
-        assert S == int(ob['stages']['S_dev']) and torch.equal(oa['stages']['s2pos'][:S], ob['stages']['s2pos'][:S])
-        pa, pb = oa['stages']['pe'][:S], ob['stages']['pe'][:S]
-        assert float((pa - pb).abs().max()) <= 2e-5 * float(pa.abs().max())
-        assert float((oa['cls'].float() - ob['cls'].float()).abs().max()) <= 2e-4 * float(oa['cls'].abs().max())
-        assert torch.equal(oa['labels'], ob['labels'])
+        st = {}
+        (O.forward_t if kind == 'T' else O.forward_s)(sd_np, feat_h, props, ms, stages=st, **({'num_views': nv} if kind == 'T' else {}))
+        S = int(ob['stages']['S_dev'])
+        pos = ob['stages']['s2pos'][:S].cpu().long()
+        pe_ref = st['pe'].permute(0, 2, 3, 1).reshape(-1, 256)[pos]
+        assert relmax(ob['stages']['pe'][:S], pe_ref) < TOL['pe']
+        assert relmax(ob['cls'], st['cls']) < TOL['cls']
     # a batch of two samples with different padding geometry == the two single runs (bitwise, as for the default path)
     single = [b.run(feat, props, ms)['cls'].clone() for ms in (metas, narrow)]
     R = single[0].shape[1]
@@ -516,7 +524,6 @@ def test_sine_table_follows_the_weights(kind):
     props = [torch.from_numpy(p) for p in prob['proposals']]
     metas = prob['img_metas']
     eng = E.HeadEngine(sd, kind, 'cuda', num_views=nv)
-    assert eng.pe_sine_table
     first = eng.run(feat, props, metas, use_graph=True)['cls'].clone()
     sd2 = dict(sd)
     for k in ('position_encoding.adapt_pos3d.0.weight', 'position_encoding.adapt_pos3d.2.weight', 'position_encoding.adapt_pos3d.2.bias'):
@@ -552,73 +559,32 @@ def test_last_stage_heads_option(name, kind):
     assert torch.equal(ok['cls'], oa['cls'])
 
 
-@pytest.mark.parametrize('name,n,qpt', [('micro_t', 1, 8), ('cfg1_t', 1, 16), ('cfg1_t', 3, 8), ('cfg3_t', 1, 8), ('cfg3_t', 2, 16), ('cfg1_t', 2, 2), ('cfg3_t', 2, 2), ('cfg3_t', 1, 4)])
-def test_query_tile_cross_attention_tables_and_result(name, n, qpt):
-    """T path, shared-key-tile cross attention (csrc/xattn_qtile.hip): (1) the tables mv2d_xattn_qtile_build derives from the CSR -- query
-    order, tiles, union key lists, pair masks -- reproduce EXACTLY the allowed (query, key) pairs of the CSR (which is bit-exact against the
-    reference's masks, tests/test_gpu_golden.py); (2) the query-tile kernel and the one-block-per-query kernel (verified against fp64 in
-    tests/test_gpu_kernels.py) give the same z on the engine's own operands up to the order of the fp32 sums."""
+@pytest.mark.parametrize('name,n', [('micro_t', 1), ('cfg1_t', 3), ('cfg3_t', 2)])
+def test_query_order_of_the_t_path(name, n):
+    """T path: mv2d_xattn_query_order ranks the queries of every sample by their smallest key (csrc/xattn_order.hip); the tile kernel launched
+    in that order gives bitwise the rows of the natural order (the order only decides which blocks share an L2)."""
     from mv2d_amd import ops
     from mv2d_amd.engine import HeadEngine
     dev = torch.device('cuda:0')
     sd = synthetic.make_head_state(seed=0)
     probs = [synthetic.make_problem(name, seed=s) for s in range(n)]
     eng = HeadEngine(sd, 'T', dev, num_views=probs[0]['views_per_frame'])
-    eng.qtile, eng.qtile_queries = True, qpt                      # (opt-in route: measured slower than the ordered per-query kernel)
     feats = [torch.from_numpy(p['feat']).to(dev) for p in probs]
     props = [[torch.from_numpy(x) for x in p['proposals']] for p in probs]
     metas = [p['img_metas'] for p in probs]
     out = eng.run_batch(feats, props, metas) if n > 1 else eng.run(feats[0], props[0], metas[0])
     torch.cuda.synchronize()
     ws = out['ws']
-    qt = ws['qt']
     Rl = ws['x'].shape[0]                                        # rows of the launch (RoI-count bucket)
-    assert int(ws['qt_ctl'][1].item()) == 0
     rp, ci = ws['row_ptr'][:Rl + 1].cpu().numpy(), ws['col_idx'].cpu().numpy()
-    perm, nt = qt['perm'].cpu().numpy(), int(qt['nt'].item())
-    tq0, tqn = qt['tq0'].cpu().numpy()[:nt], qt['tqn'].cpu().numpy()[:nt]
-    uptr, ucnt, ukeys = qt['uptr'].cpu().numpy()[:nt], qt['ucnt'].cpu().numpy()[:nt], qt['ukeys'].cpu().numpy()
-    mask = qt['mask'].cpu().numpy().view(np.uint32)
+    perm = ws['q_order'].cpu().numpy()
     grp = list(ws['grp_start_h'].numpy()) + [Rl]
-    assert sorted(perm[:Rl].tolist()) == list(range(Rl))
+    assert sorted(perm[:Rl].tolist()) == list(range(Rl)) and int(ws['qt_ctl'][1].item()) == 0
     for a, b in zip(grp[:-1], grp[1:]):                          # the order stays inside a sample and is ascending in the smallest key
         assert sorted(perm[a:b].tolist()) == list(range(a, b))
         firsts = [ci[rp[r]] if rp[r + 1] > rp[r] else 2 ** 31 - 1 for r in perm[a:b]]
         assert firsts == sorted(firsts)
-    seen = set()
-    tot_union = 0
-    for t in range(nt):
-        keys = ukeys[uptr[t]:uptr[t] + ucnt[t]]
-        assert (np.diff(keys) > 0).all()
-        tot_union += int(ucnt[t])
-        nut = (ucnt[t] + 15) // 16
-        nw = qpt // 2
-        mw = mask[(uptr[t] // 16) * nw:(uptr[t] // 16 + nut) * nw].reshape(nut, nw)
-        for j in range(tqn[t]):
-            r = int(perm[tq0[t] + j])
-            seen.add(r)
-            m16 = (mw[:, j // 2] >> (16 * (j % 2))) & 0xffff
-            bits = ((m16[:, None] >> np.arange(16)[None]) & 1).astype(bool).reshape(-1)[:ucnt[t]]
-            np.testing.assert_array_equal(keys[bits], np.sort(ci[rp[r]:rp[r + 1]]))
-    assert seen == set(range(Rl))
-    nnz, S = int(rp[out['R']]), int(ws['S_dev'].item())
-    print(f'{name} x{n}: {nt} query tiles, sum of union lists {tot_union} = {tot_union / max(S, 1):.2f} x the {S} distinct keys (per-query lists: {nnz} = {nnz / max(S, 1):.2f} x)')
-    # the same Qt (last decoder layer) through both kernels
-    z_q = ops.xattn_qtile(ws['Qt'], ws['xk_rows'], ws['xv_rows'], qt, R=Rl, empty_nan=False)
     z_t = ops.xattn_tile(ws['Qt'], ws['xk_rows'], ws['xv_rows'], ws['row_ptr'], ws['col_idx'], R=Rl, empty_nan=False, waves=2)
-    torch.cuda.synchronize()
-    err = float((z_q - z_t).abs().max() / z_t.abs().max())
-    print(f'   query-tile kernel vs per-query kernel: max |dz| / max |z| = {err:.1e}')
-    assert err < 2e-5
-    z_q2 = ops.xattn_qtile(ws['Qt'], ws['xk_rows'], ws['xv_rows'], qt, R=Rl, empty_nan=False)
-    assert torch.equal(z_q, z_q2)                               # deterministic
-    # the per-query kernel with its blocks in the smallest-key order (the engine's default on the T path): bitwise the same rows
-    z_o = ops.xattn_tile(ws['Qt'], ws['xk_rows'], ws['xv_rows'], ws['row_ptr'], ws['col_idx'], R=Rl, empty_nan=False, waves=2, order=qt['perm'])
+    z_o = ops.xattn_tile(ws['Qt'], ws['xk_rows'], ws['xv_rows'], ws['row_ptr'], ws['col_idx'], R=Rl, empty_nan=False, waves=2, order=ws['q_order'])
     assert torch.equal(z_o, z_t)
-    # ... and the engine's own order table (default route) is the same permutation
-    eng2 = HeadEngine(sd, 'T', dev, num_views=probs[0]['views_per_frame'])
-    assert eng2.q_order and not eng2.qtile
-    out2 = eng2.run_batch(feats, props, metas) if n > 1 else eng2.run(feats[0], props[0], metas[0])
-    torch.cuda.synchronize()
-    assert torch.equal(out2['ws']['q_order'][:Rl], qt['perm'][:Rl])
-    assert float((out2['cls'] - out['cls']).abs().max() / out['cls'].abs().max()) < 1e-4      # the two attention kernels, end to end
+

@@ -269,6 +269,28 @@ def test_transpose_and_cast(dev):
     assert torch.equal(z, x.to(torch.bfloat16))
 
 
+def test_key16_conversion_rounds_to_nearest_and_saturates(dev):
+    """The key-side 16-bit format (csrc/common.h key16 = fp16 since round 4): round-to-nearest-even, SATURATING at +-65504 (an fp16 inf in a
+    key row would poison a softmax row; a saturated element is finite), NaN kept; hi + lo pairs carry ~22 bits down to an absolute 2^-24."""
+    from mv2d_amd import ops
+    k16 = ops.key16_dtype()
+    x = torch.cat([rnd((4099,), 43) * 3.0, torch.tensor([0., 1., -1., 1e-3, 3e-8, 6e-5, 2049.0, 2051.0, 65504., 65519.9, 65520., 7e4, -1e9, float('inf'), float('-inf')])]).to(dev)
+    hi = ops.f32_to_key16(x)
+    hi2, lo = ops.f32_to_key16(x, with_lo=True)
+    assert torch.equal(hi, hi2)
+    if k16 == torch.float16:
+        assert torch.equal(hi, x.clamp(-65504.0, 65504.0).to(k16))
+        assert bool(torch.isfinite(hi.float()).all())
+        fin = x.abs() < 65504.0
+        err = (hi.double() + lo.double() - x.double()).abs()[fin]
+        assert float((err - (x.double().abs()[fin] * 2.0 ** -21)).clamp_min(0).max()) <= 2.0 ** -24      # 2^-22-class relative, 2^-25 absolute floor
+        assert float(lo[~fin].float().abs().max()) == 0.0                                                    # a saturated value has no remainder
+    else:
+        assert torch.equal(hi, x.to(k16))
+    n = ops.f32_to_key16(torch.tensor([float('nan'), 1.0], device=dev))
+    assert bool(torch.isnan(n[0])) and float(n[1]) == 1.0
+
+
 # ------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize('R', [12, 300, 333])
 def test_self_attn(dev, R):
@@ -383,48 +405,8 @@ def test_sparse_xattn_backward(dev, R, S, dens):
         assert float(dK[unused.to(dev)].abs().max()) == 0.0 and float(dV[unused.to(dev)].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('R,S,dens', [(37, 500, 0.05), (301, 5000, 0.02), (64, 49 * 64, -1.0)])
-def test_raw_xattn_equals_projected_attention(dev, R, S, dens):
-    """Attention in the input space of the K/V projections: grouped linear (q -> qk) + raw_xattn on the UNPROJECTED rows + grouped linear
-    (z -> ctx) == masked attention on K = Xk Wk^T + bk, V = Xv Wv^T + bv in fp64 (the bk term cancels in the softmax, bv rides on sum p = 1)."""
-    from mv2d_amd import ops
-    from oracle import mv2d_oracle as O
-    g = np.random.Generator(np.random.PCG64(260 + R))
-    if dens > 0:
-        allowed = torch.from_numpy(g.random((R, S)) < dens)
-        allowed[5] = False
-        allowed[7, :] = False
-        allowed[7, 123] = True
-    else:
-        allowed = torch.zeros((R, S), dtype=torch.bool)
-        for r in range(R):
-            allowed[r, r * 49:(r + 1) * 49] = True
-            allowed[r, ((r + 3) % R) * 49:((r + 3) % R) * 49 + 49] = True
-    q = (rnd((R, 256), 261) * 0.3).to(dev)
-    Xk = rnd((S, 256), 262).to(dev).to(torch.bfloat16)
-    Xv = rnd((S, 256), 263).to(dev).to(torch.bfloat16)
-    Wk = rnd((256, 256), 264, 0.06).to(dev); bk = rnd((256,), 265).to(dev)
-    Wv = rnd((256, 256), 266, 0.06).to(dev); bv = rnd((256,), 267).to(dev)
-    row_ptr, col = O.csr_from_allowed(allowed)
-    ref = O.masked_cross_attention(q.double(), Xk.double() @ Wk.double().T + bk.double(), Xv.double() @ Wv.double().T + bv.double(), allowed.to(dev))
-    w_in, w_out = ops.pack_head_maps(Wk, Wv)
-    qk = torch.empty((R, 8, 256), device=dev)
-    ops.linear_x3(q, w_in, None, N=256, K=32, out=qk, ldc=2048, M=R, lda=256, groups=8, a_gs=32, w_gs=256 * 32, c_gs=256)
-    qk_ref = torch.einsum('rhd,hdc->rhc', q.double().view(R, 8, 32), Wk.double().view(8, 32, 256))
-    assert relerr(qk, qk_ref) < 3e-5
-    z = ops.raw_xattn(qk, Xk, Xv, row_ptr.to(dev), col.to(dev), empty_nan=False)
-    ctx = torch.empty((R, 256), device=dev)
-    ops.linear_x3(z.view(R, 2048), w_out, bv, N=32, K=256, out=ctx, ldc=256, M=R, lda=2048, groups=8, a_gs=256, w_gs=32 * 256, b_gs=32, c_gs=32)
-    has = allowed.any(1).to(dev)
-    assert relerr(ctx[has], ref[has]) < 5e-5
-    if dens > 0:
-        assert float(z[5].abs().max()) == 0.0
-        zn = ops.raw_xattn(qk, Xk, Xv, row_ptr.to(dev), col.to(dev))
-        assert bool(torch.isnan(zn[5]).all()) and torch.equal(zn[6:], z[6:])
-
-
 def _unpack_qt(Qt, R):
-    """Qt [R,4096] bf16 -> (hi [R,8,256], lo [R,8,256]) fp64: Qt[r][h][s][g][part][e] = part (hi | lo) of head h, channel 32 s + 8 g + e."""
+    """Qt [R,4096] key16 -> (hi [R,8,256], lo [R,8,256]) fp64: Qt[r][h][s][g][part][e] = part (hi | lo) of head h, channel 32 s + 8 g + e."""
     t = Qt.view(R, 8, 8, 4, 2, 8).double().cpu()                    # [r][h][s][g][part][e]
     return t[:, :, :, :, 0].reshape(R, 8, 256), t[:, :, :, :, 1].reshape(R, 8, 256)
 
@@ -451,8 +433,8 @@ def test_xattn_tile_equals_projected_attention(dev, R, S, dens, waves):
             allowed[r, ((r + 3) % R) * 49:((r + 3) % R) * 49 + 49] = True
     q = (rnd((R, 256), 361) * 0.3).to(dev)
     q[3] *= 8.0                                                       # one query with sharp logits: the running maximum jumps between tiles
-    Xk = rnd((S, 256), 362).to(dev).to(torch.bfloat16)
-    Xv = rnd((S, 256), 363).to(dev).to(torch.bfloat16)
+    Xk = rnd((S, 256), 362).to(dev).to(ops.key16_dtype())             # key16 rows (fp16 since round 4)
+    Xv = rnd((S, 256), 363).to(dev).to(ops.key16_dtype())
     Wk = rnd((256, 256), 364, 0.06).to(dev); bk = rnd((256,), 365).to(dev)
     Wv = rnd((256, 256), 366, 0.06).to(dev); bv = rnd((256,), 367).to(dev)
     row_ptr, col = O.csr_from_allowed(allowed)
@@ -463,7 +445,7 @@ def test_xattn_tile_equals_projected_attention(dev, R, S, dens, waves):
     qk_ref = torch.einsum('rhd,hdc->rhc', q.double().view(R, 8, 32), Wk.double().view(8, 32, 256)).cpu()
     hi, lo = _unpack_qt(Qt, R)
     assert float((hi + lo - qk_ref).abs().max() / qk_ref.abs().max()) < 3e-5          # hi + lo = the fp32-class map
-    assert float((hi - qk_ref).abs().max() / qk_ref.abs().max()) < 6e-3               # hi alone = its bf16 rounding
+    assert float((hi - qk_ref).abs().max() / qk_ref.abs().max()) < (8e-4 if ops.key16_dtype() == torch.float16 else 6e-3)      # hi alone = its key16 rounding
     nnz = int(col.numel())
     dbg = torch.zeros((8, nnz), device=dev)
     z = ops.xattn_tile(Qt, Xk, Xv, row_ptr, col, empty_nan=False, waves=waves, dbg_logits=dbg)
@@ -532,11 +514,15 @@ def test_box_params_roialign_refpoint(dev, name):
     if name != 'cfg3_t':
         fcl = ops.nchw_to_nhwc(feat.to(dev))
         out = torch.empty((R, 49, 256), device=dev)
-        outb = torch.empty((R, 49, 256), device=dev, dtype=torch.bfloat16)
-        ops.roi_align(fcl, rois.to(dev), h, w, out0=outb, out0_f32=out)
+        k16 = ops.key16_dtype()
+        outb = torch.empty((R, 49, 256), device=dev, dtype=k16)
+        outl = torch.empty((R, 49, 256), device=dev, dtype=k16)
+        ops.roi_align(fcl, rois.to(dev), h, w, out0=outb, out0_f32=out, out0_lo=outl)
         ra_ref = O.roi_align(feat, rois).flatten(2).transpose(1, 2)
         assert relerr(out, ra_ref) < 1e-6
-        assert torch.equal(outb, out.to(torch.bfloat16))
+        assert torch.equal(outb, out.to(k16))                                        # the key16 output = the rounded fp32 output
+        assert torch.equal(outl, (out - outb.float()).to(k16))                       # ... and its remainder (index-exact route: hi + lo rows)
+        assert float((outb.double() + outl.double() - out.double()).abs().max()) < (1e-6 if k16 == torch.float16 else 1e-4) * float(out.abs().max())
 
 
 @pytest.mark.parametrize('name,topk,expand', [('micro_t', 20, 2), ('cfg1_t', 20, 2), ('cfg1_s', 1, 0), ('cfg3_t', 20, 2), ('cfg2_s', 1, 0), ('nc6_s', 1, 0)])
@@ -627,9 +613,11 @@ def test_pe_inputs(dev, name):
     s2pos = torch.from_numpy(sel).to(dev)
     S_dev = torch.tensor([S], dtype=torch.int32, device=dev)
     fcl = ops.nchw_to_nhwc(feat.to(dev))
-    A1 = torch.zeros((P, 192), dtype=torch.bfloat16, device=dev)
-    A2 = torch.zeros((P, 384), dtype=torch.bfloat16, device=dev)
-    Xb = torch.zeros((P, 256), dtype=torch.bfloat16, device=dev)
+    k16 = ops.key16_dtype()
+    ulp = 1e-3 if k16 == torch.float16 else 1e-2                                      # one key16 ulp, relative
+    A1 = torch.zeros((P, 192), dtype=k16, device=dev)
+    A2 = torch.zeros((P, 384), dtype=k16, device=dev)
+    Xb = torch.zeros((P, 256), dtype=k16, device=dev)
     Xf = torch.zeros((P, 256), device=dev)
     ops.pe_inputs(s2pos, S_dev, P, fcl, ft['img2lidar'].to(dev), ft['coords_w'].to(dev), ft['coords_h'].to(dev),
                   ft['coords_d'].to(dev), ft['embeds'].to(dev), ct['dim_t'].to(dev), A1, A2, Xb, Xf, V, h, w, 64,
@@ -640,14 +628,14 @@ def test_pe_inputs(dev, name):
     sin = sin.permute(0, 2, 3, 1).reshape(P, 384)[sel]
     fr = feat.permute(0, 2, 3, 1).reshape(P, 256)[sel]
     assert torch.equal(Xf[:S].cpu(), fr)
-    assert torch.equal(Xb[:S].cpu(), fr.to(torch.bfloat16))
-    # bf16-rounded outputs: compare with the bf16 rounding of the oracle values (allow 1 bf16 ulp for ulp-level log/sin diffs)
-    d1 = (A1[:S].float().cpu() - x3.to(torch.bfloat16).float()).abs()
-    assert float((d1 / x3.abs().clamp_min(1.0)).max()) < 1e-2
-    assert float((d1 > 0).float().mean()) < 1e-3
-    d2 = (A2[:S].float().cpu() - sin.to(torch.bfloat16).float()).abs()
-    assert float(d2.max()) < 1e-2
-    assert float((d2 > 0).float().mean()) < 2e-2
+    assert torch.equal(Xb[:S].cpu(), fr.to(k16))
+    # key16-rounded outputs: compare with the key16 rounding of the oracle values (allow 1 ulp for ulp-level log / sin differences)
+    d1 = (A1[:S].float().cpu() - x3.to(k16).float()).abs()
+    assert float((d1 / x3.abs().clamp_min(1.0)).max()) < ulp
+    assert float((d1 > 0).float().mean()) < (1e-2 if k16 == torch.float16 else 1e-3)
+    d2 = (A2[:S].float().cpu() - sin.to(k16).float()).abs()
+    assert float(d2.max()) < ulp
+    assert float((d2 > 0).float().mean()) < (1e-1 if k16 == torch.float16 else 2e-2)
     assert float(A1[S:].float().abs().max()) == 0.0
 
 
@@ -691,118 +679,77 @@ def test_decode_topk_tie_order(dev):
     assert bool((scores[:299] >= scores[1:300]).all())
 
 
-@pytest.mark.parametrize('M,use_mdev', [(128, False), (1000, False), (14700, False), (5000, True), (41000, False), (45000, True)])   # >= 40000 rows: 1536-column ranges
-def test_kv_proj_bit_identical_to_tile_gemm(dev, M, use_mdev):
-    from mv2d_amd import ops
-    DEV = dev
-    """mv2d_kv_proj (A in registers, W through the LDS-DMA ring) == mv2d_gemm_bf16 bit for bit (same k order)."""
-    g = torch.Generator(device='cpu').manual_seed(M)
-    L = 6
-    A = torch.randn(M, 256, generator=g).to(DEV).bfloat16()
-    A2 = torch.randn(M, 256, generator=g).to(DEV).bfloat16()
-    W = (torch.randn(2 * L * 256, 256, generator=g) * 0.06).to(DEV).bfloat16()
-    b = torch.randn(2 * L * 256, generator=g).to(DEV)
-    m_dev = torch.tensor([M - 37], dtype=torch.int32, device=DEV) if use_mdev else None
-    ref = torch.full((2 * L, M, 256), 7.0, device=DEV, dtype=torch.bfloat16)
-    got = ref.clone()
-    ops.gemm_bf16(A, W, b, A2=A2, n_split=L * 256, m_dev=m_dev, out=ref, ldc=256, c_blk_stride=M * 256, c_blk_cols=256)
-    ops.kv_proj(A, W, b, got, A2=A2, n_split=L * 256, m_dev=m_dev, ldc=256, c_blk_stride=M * 256, c_blk_cols=256)
-    torch.cuda.synchronize()
-    assert torch.equal(ref.view(torch.int16), got.view(torch.int16))
-    # and against fp32 math
-    Mv = M - 37 if use_mdev else M
-    exp = torch.cat([A[:Mv].float() @ W[:L * 256].float().T, A2[:Mv].float() @ W[L * 256:].float().T], 1) + b
-    exp = exp.view(Mv, 2 * L, 256).permute(1, 0, 2)
-    assert (got[:, :Mv].float() - exp).abs().max() < 0.05
-    if use_mdev:
-        assert bool((got[:, Mv:].float() == 7.0).all())
-
-
 def test_qg_conv_pool_fused(dev):
-    """conv3x3 + ReLU + AvgPool2d(7) per RoI in one kernel == implicit-GEMM conv + avgpool49 (same k order; pooling re-associated)
-    and == F.conv2d on the bf16-rounded operands."""
+    """conv3x3 + ReLU + AvgPool2d(7) per RoI in one kernel == F.conv2d in fp64 on the key16-rounded operands; the split-precision variant
+    (hi + lo cells and weights, index-exact route) == the same on the UNROUNDED operands."""
     from mv2d_amd import ops
-    for R in (1, 37, 300):
+    k16 = ops.key16_dtype()
+    for R in (1, 37, 300, 1301):
         x = rnd((R, 256, 7, 7), 70).to(dev)
         w = rnd((256, 256, 3, 3), 71, 0.03).to(dev)
         b = rnd((256,), 72).to(dev)
-        xr = x.permute(0, 2, 3, 1).reshape(R, 49, 256).contiguous().to(torch.bfloat16)
-        wr = w.permute(0, 2, 3, 1).reshape(256, 2304).contiguous().to(torch.bfloat16)
+        x32 = x.permute(0, 2, 3, 1).reshape(R, 49, 256).contiguous()
+        w32 = w.permute(0, 2, 3, 1).reshape(256, 2304).contiguous()
+        xr, wr = x32.to(k16), w32.to(k16)
         out = torch.empty((R, 256), device=dev)
-        ops.qg_conv_pool(xr, ops.pack_wfrag(wr), b, out)
-        conv = ops.gemm_bf16(xr, wr, b, conv3x3=True, act=1, out_dtype=torch.float32)
-        pooled = torch.empty((R, 256), device=dev)
-        ops.avgpool49(conv, pooled, 256, R)
-        assert relerr(out, pooled) < 1e-6
+        ops.qg_conv_pool(xr, ops.pack_key16(w32), b, out)
+        xh, xl = ops.f32_to_key16(x32, with_lo=True)
+        assert torch.equal(xh, xr)
+        outx = torch.empty((R, 256), device=dev)
+        ops.qg_conv_pool_x3(xh, xl, ops.pack_key16_x3(w32), b, outx)
+        refx = F.avg_pool2d(F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)), 7).flatten(1)
+        assert relerr(outx, refx) < (3e-6 if k16 == torch.float16 else 3e-5)
         ref = F.avg_pool2d(F.relu(F.conv2d(xr.float().view(R, 7, 7, 256).permute(0, 3, 1, 2).double(),
                                            wr.float().view(256, 3, 3, 256).permute(0, 3, 1, 2).double(), b.double(), padding=1)), 7).flatten(1)
         assert relerr(out, ref) < 1e-5
 
 
-@pytest.mark.parametrize('M,use_mdev', [(64, False), (1000, False), (8794, True)])
-def test_pe_fused_bit_identical_to_gemm_chain(dev, M, use_mdev):
-    """mv2d_pe_fused (three two-layer MLPs + gate + sum in one launch, hidden layers resident in LDS, fragment-major weights)
-    == the chain of six mv2d_gemm_bf16 launches, bit for bit (same k order, same bf16 rounding of the hidden layers)."""
-    from mv2d_amd import ops
-    bf = torch.bfloat16
-    A1 = rnd((M, 192), 90).to(dev).to(bf); A2 = rnd((M, 384), 91).to(dev).to(bf)
-    Xf32 = rnd((M, 256), 92).to(dev); Xfb = Xf32.to(bf)
-    W = dict(w1a=rnd((1024, 192), 93, 0.08), w1b=rnd((256, 1024), 94, 0.04), w2a=rnd((1024, 384), 95, 0.06), w2b=rnd((256, 1024), 96, 0.04),
-             wr=rnd((256, 256), 97, 0.07), we=rnd((256, 256), 98, 0.07))
-    W = {k: v.to(dev).to(bf) for k, v in W.items()}
-    B = {k: rnd((n,), 99 + i).to(dev) for i, (k, n) in enumerate(dict(b1a=1024, b1b=256, b2a=1024, b2b=256, br=256, be=256).items())}
-    md = torch.tensor([M - 13], dtype=torch.int32, device=dev) if use_mdev else None
-    H1 = ops.gemm_bf16(A1, W['w1a'], B['b1a'], m_dev=md, act=1)
-    H2 = ops.gemm_bf16(A2, W['w2a'], B['b2a'], m_dev=md, act=1)
-    Hg = ops.gemm_bf16(Xfb, W['wr'], B['br'], m_dev=md, act=1)
-    gate = ops.gemm_bf16(Hg, W['we'], B['be'], m_dev=md, act=2, out_dtype=torch.float32)
-    Pg = ops.gemm_bf16(H1, W['w1b'], B['b1b'], m_dev=md, mul=gate, out_dtype=torch.float32)
-    pe_ref = torch.zeros((M, 256), device=dev); xk_ref = torch.zeros((M, 256), device=dev, dtype=bf)
-    ops.gemm_bf16(H2, W['w2b'], B['b2b'], m_dev=md, add=Pg, out=pe_ref, out2=xk_ref, add2=Xf32)
-    wp = {k: ops.pack_wfrag(v) for k, v in W.items()}
-    wp.update(B)
-    pe = torch.zeros((M, 256), device=dev); xk = torch.zeros((M, 256), device=dev, dtype=bf)
-    ops.pe_fused(A1, A2, Xfb, Xf32, md, wp, pe, xk)
-    torch.cuda.synchronize()
-    Mv = M - 13 if use_mdev else M
-    assert torch.equal(pe[:Mv], pe_ref[:Mv])
-    assert torch.equal(xk[:Mv].view(torch.int16), xk_ref[:Mv].view(torch.int16))
-
-
 @pytest.mark.parametrize('M,use_mdev,use_ri', [(95, False, False), (97, False, True), (1000, True, True), (8794, True, False), (70349, False, True)])
-def test_pe_fused_tab_kernels_bit_identical(dev, M, use_mdev, use_ri, monkeypatch):
-    """mv2d_pe_fused_tab: the 96-row / 8-wave kernel (default) == its two-blocks-per-CU shape (MV2D_PE_TAB_KERNEL=2) == the
-    one-wave-per-SIMD kernel of pe_mlp.hip (=64), bit for bit."""
+def test_pe_fused_tab_kernel(dev, M, use_mdev, use_ri):
+    """mv2d_pe_fused_tab (csrc/pe_tab96.hip: position_encoder MLP + SE gate + table row + feature row in one launch, key16 = fp16 operands and
+    hidden layer): against the same chain in fp64 on the key16-rounded operands (hidden layer rounded to key16 like the kernel does), and the
+    96-row / 8-wave shape (default) == the two-64-row-blocks-per-CU shape bit for bit."""
     from mv2d_amd import ops
-    bf = torch.bfloat16
+    k16 = ops.key16_dtype()
     NP = M + 50 if use_ri else M
-    A1 = rnd((M, 192), 90).to(dev).to(bf)
+    A1 = rnd((M, 192), 90).to(dev).to(k16)
     Xf32 = rnd((NP, 256), 92).to(dev)
     ri = torch.randperm(NP, generator=torch.Generator().manual_seed(5))[:M].to(torch.int32).to(dev) if use_ri else None
-    Xfb = (Xf32[ri.long()] if use_ri else Xf32).to(bf)
-    W = dict(w1a=rnd((1024, 192), 93, 0.08), w1b=rnd((256, 1024), 94, 0.04), wr=rnd((256, 256), 97, 0.07), we=rnd((256, 256), 98, 0.07))
-    wp = {k: ops.pack_wfrag(v.to(dev).to(bf)) for k, v in W.items()}
-    wp.update({k: rnd((n,), 99 + i).to(dev) for i, (k, n) in enumerate(dict(b1a=1024, b1b=256, br=256, be=256).items())})
+    Xrows = Xf32[ri.long()] if use_ri else Xf32
+    Xfb = Xrows.to(k16)
+    W = {k: v.to(dev) for k, v in dict(w1a=rnd((1024, 192), 93, 0.08), w1b=rnd((256, 1024), 94, 0.04), wr=rnd((256, 256), 97, 0.07),
+                                        we=rnd((256, 256), 98, 0.07)).items()}
+    wp = {k: ops.pack_key16(v) for k, v in W.items()}
+    bias = {k: rnd((n,), 99 + i).to(dev) for i, (k, n) in enumerate(dict(b1a=1024, b1b=256, br=256, be=256).items())}
+    wp.update(bias)
     period = 37
     tab = rnd((period, 256), 131).to(dev)
     md = torch.tensor([M - 13], dtype=torch.int32, device=dev) if use_mdev else None
     outs = {}
-    for sel in ('64', '96', '2'):
-        monkeypatch.setenv('MV2D_PE_TAB_KERNEL', sel)
-        pe = torch.zeros((M, 256), device=dev); xk = torch.zeros((M, 256), device=dev, dtype=bf)
-        ops.pe_fused_tab(A1, Xfb, Xf32, md, wp, tab, period, pe, xk, M=M, row_index=ri)
+    for shape in (1, 0):
+        pe = torch.zeros((M, 256), device=dev); xk = torch.zeros((M, 256), device=dev, dtype=k16)
+        ops.pe_fused_tab(A1, Xfb, Xf32, md, wp, tab, period, pe, xk, M=M, row_index=ri, shape=shape)
         torch.cuda.synchronize()
-        outs[sel] = (pe, xk)
+        outs[shape] = (pe, xk)
     Mv = M - 13 if use_mdev else M
-    for sel in ('64', '96'):                                   # Xk is optional (S path): pe alone is the same
-        monkeypatch.setenv('MV2D_PE_TAB_KERNEL', sel)
+    for shape in (1, 0):                                         # Xk is optional (S path): pe alone is the same
         pe_only = torch.zeros((M, 256), device=dev)
-        ops.pe_fused_tab(A1, Xfb, Xf32, md, wp, tab, period, pe_only, None, M=M, row_index=ri)
-        assert torch.equal(pe_only[:Mv], outs['64'][0][:Mv])
-    for sel in ('96', '2'):
-        assert torch.equal(outs['64'][0][:Mv], outs[sel][0][:Mv])
-        assert torch.equal(outs['64'][1][:Mv].view(torch.int16), outs[sel][1][:Mv].view(torch.int16))
-        assert not outs[sel][0][Mv:].any() and outs[sel][0][:Mv].abs().sum() > 0
+        ops.pe_fused_tab(A1, Xfb, Xf32, md, wp, tab, period, pe_only, None, M=M, row_index=ri, shape=shape)
+        assert torch.equal(pe_only[:Mv], outs[1][0][:Mv])
+    assert torch.equal(outs[1][0][:Mv], outs[0][0][:Mv])
+    assert torch.equal(outs[1][1][:Mv].view(torch.int16), outs[0][1][:Mv].view(torch.int16))
+    assert not outs[1][0][Mv:].any() and outs[1][0][:Mv].abs().sum() > 0
+    # fp64 reference on the rounded operands
+    r = lambda t: t.to(k16).double()                                                   # noqa: E731
+    h1 = torch.relu(A1.double() @ r(W['w1a']).T + bias['b1a'].double()).float().to(k16).double()
+    p1 = h1 @ r(W['w1b']).T + bias['b1b'].double()
+    hg = torch.relu(Xfb.double() @ r(W['wr']).T + bias['br'].double()).float().to(k16).double()
+    gate = torch.sigmoid(hg @ r(W['we']).T + bias['be'].double())
+    pos = (ri.long() if use_ri else torch.arange(M, device=dev)) % period
+    pe_ref = tab.double()[pos] + p1 * gate
+    assert relerr(outs[1][0][:Mv], pe_ref[:Mv]) < 1e-4                                  # (a hidden value on a rounding boundary may flip one key16 ulp)
+    xk_ref = pe_ref + Xrows.double()
+    assert relerr(outs[1][1][:Mv].double(), xk_ref[:Mv]) < (1e-3 if k16 == torch.float16 else 8e-3)
 
 
 def test_attn_out_fused_x3(dev):

@@ -81,7 +81,7 @@ def test_t_path_matches_reference(name):
             close(cap[l]['attn_mean'], g['attn_mean'][l], 1e-4)
 
 
-@pytest.mark.parametrize('name', ['micro_s', 'cfg1_s', 'cfg2_s', 'nc6_s'])      # nc6_s: up to 6 correlated RoIs per query
+@pytest.mark.parametrize('name', ['micro_s', 'cfg1_s', 'cfg2_s', 'nc6_s', 'cfg2_s_nc6'])      # nc6_s / cfg2_s_nc6: up to 6 correlated RoIs per query
 def test_s_path_matches_reference(name):
     g = load_golden(name)
     st = run(name)

@@ -4,7 +4,7 @@ Per-launch HBM bytes of the kernels bench.py's roofline objects describe (averag
 doubled on gfx950, MI355X_MICROARCH.md section HBM)."""
 import json, os, sys
 
-KERNELS = {'pe_fused': ('pe_tab_kernel', 'pe_fused_kernel'), 'qg_conv_gemm': ('roi_conv_pool_kernel',), 'xattn_tile': ('xattn_tile_kernel',),
+KERNELS = {'pe_fused': ('pe_tab_kernel', 'pe_fused_kernel'), 'nchw_to_nhwc': ('nchw_to_nhwc',), 'pe_inputs': ('pe_inputs_kernel',), 'qg_conv_gemm': ('roi_conv_pool_kernel',), 'xattn_tile': ('xattn_tile_kernel',),
            'roi_align': ('roi_align_kernel',), 'self_attn': ('self_attn_x3_kernel', 'self_attn_kernel'), 'ffn': ('ffn_x3_kernel',)}
 
 
@@ -43,6 +43,12 @@ def main():
     whole_w = sum(c * a for v in wr.values() for c, a in v) * 1024
     out['_whole_run'] = dict(fetch_bytes=int(whole_f), write_bytes=int(whole_w), note='all kernels of the profiled run (warm-up + 3 steps + stage timing + set-up)')
     out['_provenance'] = note
+    # stamp: digest of the kernel sources the counters were measured on (mv2d_amd/build.py writes it next to the library); bench.py flags the
+    # entry as stale when the library it runs has another digest
+    try:
+        out['_csrc_sha256'] = open(os.path.join(root, 'mv2d_amd', 'lib', 'libmv2d_hip.so.sha256')).read().strip()
+    except OSError:
+        out['_csrc_sha256'] = None
     js[key] = out
     json.dump(js, open(path, 'w'), indent=1)
     print(json.dumps(out, indent=1))
