@@ -334,6 +334,13 @@ def main():
         same = [[sets_main[0][0]] for _ in range(args.inflight)]
         el = timed(make_step(engines, streams, same, None, B, payload, rotate=False), n_x, 3)
         extra['samples_s_fixed_inputs'] = round(args.inflight * B * n_x / el, 2)
+        # (a1) round-over-round continuity (the default moved from 8 to 16 samples per launch at the end of round 3): the same protocol at 8
+        if B == 16:
+            sets8 = frame_sets(args.inflight, 8, K)
+            pay8 = [torch.zeros((args.inflight * 8, 300 * 11 + 1), device=dev) for _ in range(2)]
+            el = timed(make_step(engines, streams, sets8, pool_main, 8, pay8), n_x, K + 1)
+            extra['samples_s_batch8'] = round(args.inflight * 8 * n_x / el, 2)
+            del sets8, pay8
         # (a2) the number of RoIs differs from sample to sample and from step to step (launches run on 64-row buckets, one graph per bucket)
         sets_v = frame_sets(args.inflight, B, K, vary_rois=True)
         el = timed(make_step(engines, streams, sets_v, pool_main, B, payload), n_x, K + 1)
@@ -545,7 +552,9 @@ def main():
         # short legs of the T-path workloads in the same JSON line (sub-processes of this script, after this process' GPU work is done)
         import subprocess
         other = {}
-        for wl_, b_ in (('cfg3_t', 16), ('cfg5_t', 4)):
+        # cfg2_s_nc6: the headline size on the overlapping rig (mv2d_amd/synthetic.py RIG): the reference's own correlation gives every query its
+        # RoI plus up to five matched ones (3.99 on average) instead of the 1.01 of the ring rig -- the non-trivial S workload
+        for wl_, b_ in (('cfg2_s_nc6', 16), ('cfg3_t', 16), ('cfg5_t', 4)):
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), '--workload', wl_, '--batch', str(b_), '--steps', '100', '--warmup', '10',
                                     '--brief'], cwd=ROOT, capture_output=True, text=True, timeout=240)
@@ -580,6 +589,18 @@ def main():
         except Exception as ex_:          # noqa: BLE001
             coll_leg = dict(samples_s=None, error=repr(ex_)[:300])
 
+    # integer parity of BOTH routes against the reference goldens for all workloads of this line, at the top level (ranked (query, class)
+    # indices that differ / list length; the reference ranks sigmoid(cls).view(-1).topk(300), CB/coders/nms_free_coder.py:49-102)
+    parity = None
+    if rank == 0 and 'index_mismatches' in extra:
+        def _cnt(d_):
+            return None if not d_ else '%s/%s' % (d_.get('ranked_indices'), d_.get('of'))
+        im_ = extra['index_mismatches']
+        parity = {args.workload: dict(default=_cnt(im_.get('default')), index_exact=_cnt(im_.get('index_exact')))}
+        for wl_, d_ in (other or {}).items():
+            if isinstance(d_, dict) and d_.get('index_mismatches'):
+                parity[wl_] = dict(default=_cnt(d_['index_mismatches'].get('default')), index_exact=_cnt(d_.get('index_mismatches_index_exact')))
+
     if rank == 0:
         line = {
             'metric': 'multi-view samples/sec (6-cam frames) through the MV2D RoI-head hot path',
@@ -594,7 +615,7 @@ def main():
                        'parallelism': f'dp{world}', 'hipgraph': use_graph},
             'decoder_ms_per_iter': round(decoder_ms / B, 4), 'decoder_ms_per_launch': round(decoder_ms, 4),
             'decoder_ms_per_iter_batch1': round(decoder_ms_b1, 4) if decoder_ms_b1 is not None else (round(decoder_ms, 4) if B == 1 else None),
-            'long_run': long_run, 'other_workloads': other,
+            'long_run': long_run, 'ranked_index_mismatches_vs_reference': parity, 'other_workloads': other,
             'collective_check': collective_check,
             'samples_s_with_collective': coll_leg.get('samples_s') if coll_leg else None, 'collective_leg': coll_leg,
             'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},

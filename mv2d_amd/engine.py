@@ -104,6 +104,9 @@ class HeadEngine:
         # can be compared bit for bit with the reference's (tests/test_gpu_golden.py).  Enqueue-only and hipGraph-replayable like the
         # default route (bench.py: samples_s_index_exact).
         self.exact = (os.environ.get('MV2D_EXACT', '0') == '1') if exact is None else bool(exact)
+        # diagnostics (tools/ablate_exact.py): stages of the index-exact route that fall back to the default route's single key16 rounding --
+        # any of 'attn' (hi rows only in the tile attention), 'pe' (fused key16 PE kernel), 'conv' (single-precision RoI conv); in the graph key
+        self.exact_skip = frozenset()
         self.K16 = ops.key16_dtype()  # dtype of the key side's 16-bit buffers (csrc/common.h "key16": fp16 since round 4)
         self.load_state(state_dict)
 
@@ -543,7 +546,7 @@ class HeadEngine:
             o.csr_from_corr(ws['match'], ws['row_ptr'], ws['col_idx'], ws['nnz'], R, Vg, self.topk)
         md = ws['S_dev']
         # a2: PE at the listed positions only
-        if self.exact:
+        if self.exact and 'pe' not in self.exact_skip:
             tk('pe_inputs'); tk('pe_fused')
             self._exact_pe(ws, featcl, P, V, h, w)
         else:
@@ -554,7 +557,7 @@ class HeadEngine:
             tk('pe_fused')
             # only what the path reads is written: S: pe (RoIAlign reads it; its keys are RoI-aligned rows), T: Xk (nothing reads pe);
             # a keep_stages run writes both
-            dbg = self.keep_xk or getattr(self, '_stage_outputs', False)
+            dbg = self.keep_xk or getattr(self, '_stage_outputs', False) or self.exact
             o.pe_fused_tab(ws['A1'], ws['Xf_b'], featcl, md, W_['pe_pack'], ws['shared']['sine_tab'], ws['shared']['sine_period'],
                            ws['pe'] if (self.kind == 'S' or dbg) else None, ws['Xk'] if (self.kind == 'T' or dbg) else None, M=P,
                            row_index=ws['s2pos'])
@@ -626,7 +629,7 @@ class HeadEngine:
         o, W_, tk = ops, self.w, self._tick
         # a6: QueryGenerator: conv3x3 + ReLU + AvgPool2d(7) fused, one block per RoI (index-exact route: in split precision on the hi + lo cells)
         tk('qg_conv_gemm')
-        if self.exact:
+        if self.exact and 'conv' not in self.exact_skip:
             o.qg_conv_pool_x3(ws['roi_feat'], ws['roi_lo'], W_['qg_conv_wx3'], W_['qg_conv_b'], ws['x2'], R=R)
         else:
             o.qg_conv_pool(ws['roi_feat'], W_['qg_conv_wp'], W_['qg_conv_b'], ws['x2'], R=R)
@@ -653,7 +656,8 @@ class HeadEngine:
             if dbg is not None:
                 ws['dbg_q'][i].copy_(ws['q'])
             o.xattn_tile(ws['Qt'], xk_rows, xv_rows, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=self.empty_nan, waves=self.xattn_waves,
-                         Xk_lo=ws.get('xk_lo'), Xv_lo=ws.get('xv_lo'), dbg_logits=None if dbg is None else dbg[i],
+                         Xk_lo=None if 'attn' in self.exact_skip else ws.get('xk_lo'), Xv_lo=None if 'attn' in self.exact_skip else ws.get('xv_lo'),
+                         dbg_logits=None if dbg is None else dbg[i],
                          order=ws.get('q_order') if self.q_order else None)
 
         # the decoder starts from target = 0 (cross_attention_head.py:32): layer 0 reads a constant zero buffer and qpos directly, from
@@ -776,7 +780,7 @@ class HeadEngine:
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
         gkey = (ptrs, sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs, self.last_stage_heads,
                 self.xattn_waves, self.fuse_maps, self.keep_sine_rows, self.keep_xk, self.ffn_groups, self.force_nc, self.q_order,
-                self.fork_qg)   # load_state() re-allocates the weights; every route option of __init__ is in the key
+                self.fork_qg, self.exact_skip)   # load_state() re-allocates the weights; every route option of __init__ is in the key
         graphs = ws.setdefault('graphs', {})             # one graph per (input buffers, frame scalars): a producer that alternates between
         g = graphs.get(gkey)                             # a few static output buffers replays a few graphs, it does not re-capture
         if ws.pop('graph_stale', False):
