@@ -104,9 +104,13 @@ class HeadEngine:
         # can be compared bit for bit with the reference's (tests/test_gpu_golden.py).  Enqueue-only and hipGraph-replayable like the
         # default route (bench.py: samples_s_index_exact).
         self.exact = (os.environ.get('MV2D_EXACT', '0') == '1') if exact is None else bool(exact)
-        # diagnostics (tools/ablate_exact.py): stages of the index-exact route that fall back to the default route's single key16 rounding --
-        # any of 'attn' (hi rows only in the tile attention), 'pe' (fused key16 PE kernel), 'conv' (single-precision RoI conv); in the graph key
-        self.exact_skip = frozenset()
+        # Stages of the index-exact route that run with the default route's single key16 rounding -- any of 'attn' (hi rows only in the tile
+        # attention), 'pe' (fused key16 PE kernel), 'conv' (single-precision RoI conv); in the graph key.  Round 4 (tools/ablate_exact.py,
+        # profiles/r04_ablate_exact.txt): with fp16 cells the query generator's conv in SINGLE precision leaves the ranked indices and the
+        # class-logit error of the index-exact route where they are (cfg2_s 2 -> 2, cfg3_t 4 -> 4, cfg5_t 2 -> 0 of 300; cls 5.0e-6 -> 6.2e-6 /
+        # 5.1e-6 -> 4.9e-6 / 5.8e-6 -> 5.7e-6): its 2304-term dot products average the 2^-12 roundings down, and the 3 x MFMA-bound split-
+        # precision kernel (362 vs 123 us per 2400 RoIs) leaves the route.  Attention rows and PE stay hi + lo: dropping either costs ranks.
+        self.exact_skip = frozenset({'conv'})
         self.K16 = ops.key16_dtype()  # dtype of the key side's 16-bit buffers (csrc/common.h "key16": fp16 since round 4)
         self.load_state(state_dict)
 
@@ -526,7 +530,8 @@ class HeadEngine:
                 o.xattn_query_order(ws['row_ptr'], ws['col_idx'], grp, R, ws['q_order'], ws['qt_ctl'][1:])
             if not forked:
                 tk('roi_align')
-                o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'], out0_lo=ws.get('roi_lo') if self.exact else None, R=R)
+                o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'],
+                            out0_lo=ws.get('roi_lo') if (self.exact and 'conv' not in self.exact_skip) else None, R=R)
         else:
             # positions any RoIAlign tap can touch (own rect + 1 cell) -> PE only there
             o.roi_positions(rois, ws['zero_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'], R, V, h, w,
