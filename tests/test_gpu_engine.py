@@ -11,10 +11,9 @@ from mv2d_amd import synthetic
 
 pytestmark = pytest.mark.gpu
 
-# measured on MI355X (round 1): center 3e-4, ref 1e-4, qpos 2e-4, pe 4e-3, outs 8e-4, cls 4e-4, reg 1e-3 -> ~4x headroom
-# engine vs oracle on the same inputs; bounds = ~2 x the largest measured value (round 3: center 3.3e-4, ref 1.2e-4, qpos 2.2e-4, pe 4.3e-3 and
-# roi_feat 2.7e-3 (bf16 outputs), outs 5.2e-4, cls 2.3e-4, reg 4.3e-4)
-TOL = dict(center=7e-4, ref=3e-4, qpos=5e-4, pe=9e-3, outs=1.1e-3, cls=5e-4, reg=1.1e-3, roi_feat=6e-3, score=5e-3)
+# engine vs oracle on the same inputs; bounds = ~2 x the largest measured value (round 4, fp16 key side: see the dicts this file prints under -s;
+# round 3 with bf16 keys: center 3.3e-4, ref 1.2e-4, qpos 2.2e-4, pe 4.3e-3, roi_feat 2.7e-3, outs 5.2e-4, cls 2.3e-4, reg 4.3e-4)
+TOL = dict(center=1.3e-4, ref=4e-5, qpos=4e-5, pe=1e-3, outs=2e-4, cls=5e-5, reg=1.5e-4, roi_feat=7e-4, score=5e-4)
 
 
 def relmax(a, b):
