@@ -105,6 +105,16 @@ int mv2d_pe_fused_tab2(const void* A1, const void* Xfb, const float* Xf32, const
                        const void* Wr, const float* br, const void* We, const float* be,
                        const float* sine_tab, int tab_period, float* pe, void* Xk, int shape, void* stream);
 
+/* The same block in SPLIT PRECISION on unrounded fp32 inputs (index-exact route; csrc/pe_x3.hip): every product a_hi w_hi + a_lo w_hi + a_hi w_lo on
+ * bf16 MFMAs (2^-17 per operand), hidden layer split hi / lo in LDS.  A1 [M,192] fp32 (mv2d_pe_inputs' A_frustum_f32), Xmap = fp32 feature rows
+ * [.,256] indexed by row_index[m] (or m when NULL); weights as bf16 hi / lo pairs (mv2d_split_bf16x2), each in the fragment-major order of
+ * mv2d_pack_wfrag_bf16; pe [M,256] fp32 (optional) = sine_tab[position] + position_encoder(A1) * gate; Xk_hi / Xk_lo / Xv_hi / Xv_lo [M,256] key16
+ * (all four or none): key rows pe + feat and value rows feat as hi + lo pairs (what mv2d_xattn_tile_fwd gathers on that route). */
+int mv2d_pe_fused_x3(const float* A1, const float* Xmap, const int* row_index, const int* m_dev, int M,
+                     const void* W1a_hi, const void* W1a_lo, const float* b1a, const void* W1b_hi, const void* W1b_lo, const float* b1b,
+                     const void* Wr_hi, const void* Wr_lo, const float* br, const void* We_hi, const void* We_lo, const float* be,
+                     const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, void* stream);
+
 /* QueryGenerator shared conv + pooling fused, one block per RoI (RH/utils/query_generator.py:298-304,322-331,352-358):
  * out[r, n] = mean over the 49 cells of relu(conv3x3(roi_feat[r])[cell, n] + bias[n]).  roi_feat [R,49,256] key16 (cell-major),
  * Wp = the conv weight [256][tap][cin] (key16, K = 2304) in FRAGMENT-MAJOR order as produced by mv2d_pack_wfrag_bf16 (weights are

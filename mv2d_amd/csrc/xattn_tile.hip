@@ -273,40 +273,48 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
         const int kbase = beg + 16 * tt;
         const int myidx = col_idx[min(kbase + n, end - 1)];                          // lane (n, *): key n of the tile
         // ---- gather: Xk rows whole (lanes 0-31 one row, 32-63 the next), Xv rows as 16-byte column chunks of keys 4g..4g+3
-        uint4 kreg[8], vreg[4][2];
+        // (byte offsets as 32-bit unsigned: scalar base + vector offset addressing instead of 64-bit address arithmetic per row;
+        //  the row arrays must stay below 4 GB = 2^23 rows, include/mv2d_hip.h)
+        uint4 kreg[8], vreg[4][2], vlo[4][2];
+        auto load_v = [&](const unsigned short* V_, uint4 (&dst)[4][2]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned int vidx = (unsigned int)__shfl(myidx, 4 * g + e, 64);
+                const char* vp = reinterpret_cast<const char*>(V_) + (vidx * row_bytes + 16u * (unsigned)n);
+                dst[e][0] = *reinterpret_cast<const uint4*>(vp);
+                dst[e][1] = *reinterpret_cast<const uint4*>(vp + 256);
+            }
+        };
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            // (byte offsets as 32-bit unsigned: scalar base + vector offset addressing instead of 64-bit address arithmetic per row;
-            //  the row arrays must stay below 4 GB = 2^23 rows, include/mv2d_hip.h)
             const unsigned int ridx = (unsigned int)__shfl(myidx, 2 * i + (lane >> 5), 64);
             kreg[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Xk) + (ridx * row_bytes + (unsigned)(lane & 31) * 16u));
         }
+        if constexpr (XLO) {
+            // index-exact route, TWO PHASES per tile (round 4): the hi and lo halves of the 16 key rows are requested together (16 loads in flight) and
+            // go to LDS; only then the hi and lo value rows are requested -- into the registers the key rows just left -- and arrive while the
+            // logits and the softmax run.  (Round 3 requested K hi, V hi up front and the lo halves behind the first LDS writes, in 32 more
+            // registers: 314 us instead of 92 us per layer at cfg3_t for twice the bytes.)
+            uint4 klo[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned int vidx = (unsigned int)__shfl(myidx, 4 * g + e, 64);
-            const char* vp = reinterpret_cast<const char*>(Xv) + (vidx * row_bytes + 16u * (unsigned)n);
-            vreg[e][0] = *reinterpret_cast<const uint4*>(vp);
-            vreg[e][1] = *reinterpret_cast<const uint4*>(vp + 256);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int rowi = 2 * i + (lane >> 5);
-            kt[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = kreg[i];
-        }
-        uint4 vlo[4][2];
-        if (XLO) {
+            for (int i = 0; i < 8; ++i) {
+                const unsigned int ridx = (unsigned int)__shfl(myidx, 2 * i + (lane >> 5), 64);
+                klo[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Xk_lo) + (ridx * row_bytes + (unsigned)(lane & 31) * 16u));
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int rowi = 2 * i + (lane >> 5);
-                const int ridx = __shfl(myidx, rowi, 64);
-                kt2[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Xk_lo) + ((unsigned)ridx * row_bytes + (unsigned)(lane & 31) * 16u));
+                kt[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = kreg[i];
+                kt2[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = klo[i];
             }
+            load_v(Xv, vreg);
+            load_v(Xv_lo, vlo);
+        } else {
+            load_v(Xv, vreg);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int vidx = __shfl(myidx, 4 * g + e, 64);
-                const char* vp = reinterpret_cast<const char*>(Xv_lo) + ((unsigned)vidx * row_bytes + 16u * (unsigned)n);
-                vlo[e][0] = *reinterpret_cast<const uint4*>(vp);
-                vlo[e][1] = *reinterpret_cast<const uint4*>(vp + 256);
+            for (int i = 0; i < 8; ++i) {
+                const int rowi = 2 * i + (lane >> 5);
+                kt[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = kreg[i];
             }
         }
         __builtin_amdgcn_wave_barrier();

@@ -185,9 +185,12 @@ class HeadEngine:
         # K-concatenated split-precision weights [w_hi | w_hi | w_lo] (bf16) for the plain tile GEMM (partner of mv2d_split3_rows): the sine
         # branch's table is built in fp32-class arithmetic on BOTH routes (once per (weights, geometry)); the index-exact route runs all three
         # PE MLPs that way per frame
-        for n_, k_ in (pe_names if self.exact else pe_names[2:4]):
+        for n_, k_ in pe_names[2:4]:
             w['pe_' + n_ + '_c3'] = ops.cat3_weight(c1(k_ + '.weight'))
         if self.exact:
+            # bf16 hi / lo fragment-major pairs for the split-precision PE kernel (csrc/pe_x3.hip)
+            w['pe_x3'] = dict(b1a=w['pe_b1a'], b1b=w['pe_b1b'], br=w['pe_br'], be=w['pe_be'],
+                              **{n_: ops.pack_x3(c1(k_ + '.weight')) for n_, k_ in pe_names if n_ in ('w1a', 'w1b', 'wr', 'we')})
             w['qg_conv_wx3'] = ops.pack_key16_x3(conv)
         self.w = w
         for k in ('cls_w0', 'cls_w3', 'reg_w0', 'reg_w2'):                              # [L,256,256] -> bf16x3, fragment-major, stacked over L
@@ -310,14 +313,11 @@ class HeadEngine:
         # table), feature rows [.,256] (the SE gate's input; the value rows of the T path)
         ws['A1'] = e((P, 3 * self.depth_num), K16); ws['A2'] = e((P, 384), K16)
         ws['Xf_b'] = e((P, C), K16)
-        ws['Xf32'] = e((P, C)) if self.exact else None            # the fused PE kernel reads the feature rows from the map itself
         if self.exact:
-            # index-exact route: unrounded fp32 operands of the PE block (frustum inputs, gate), [hi | lo | hi] bf16 operands of its
-            # K-concatenated GEMMs, the lo halves of the key / value rows and RoI cells -- all pre-allocated (no per-frame allocation, no host
-            # synchronisation: the route is graph-replayable like the default one)
+            # index-exact route: the unrounded fp32 frustum rows of the PE block (the feature rows are read from the map), the lo halves of the
+            # key / value rows and RoI cells -- all pre-allocated (no per-frame allocation, no host synchronisation: the route is
+            # graph-replayable like the default one)
             ws['xa1'] = e((P, 3 * self.depth_num)); ws['xa2'] = e((P, 384))
-            ws['xgate'] = e((P, C)); ws['xp2'] = e((P, C))
-            ws['x3a'] = e((P, 3 * 384), BF16); ws['x3h'] = e((P, 3 * 4 * C), BF16)
             if self.kind == 'T':
                 ws['xk_lo'] = z((P, C), K16); ws['xv_lo'] = z((P, C), K16)
                 ws['roi_lo'] = e((R, 49, C), K16)                 # lo halves of the RoI cells (conv input)
@@ -587,31 +587,21 @@ class HeadEngine:
         tk('end')
 
     def _exact_pe(self, ws, featcl, P, V, h, w):
-        """Index-exact route: the PE block (MU/pe.py:36-48,64-77,150-166) on UNROUNDED fp32 inputs as fp32-class products on the plain
-        bf16 tile GEMM by K-concatenation, [a_hi | a_lo | a_hi] . [w_hi | w_hi | w_lo]^T (K' = 3 K; the hidden layers leave the GEMM already
-        in that form, c_split3 epilogue; device-side row count S; sigmoid and the gate product / sine-table sum in the epilogues), pe rows
-        into ws['pe']; T path: key / value rows as key16 hi + lo pairs.  No host synchronisation, no allocation: graph-replayable."""
+        """Index-exact route: the PE block (MU/pe.py:36-48,64-77,150-166) on UNROUNDED fp32 inputs in ONE split-precision launch
+        (mv2d_pe_fused_x3, csrc/pe_x3.hip: a_hi w_hi + a_lo w_hi + a_hi w_lo on bf16 MFMAs, hidden layer hi / lo in LDS, sigmoid, gate
+        product and sine-table sum in its epilogue; device-side row count S): pe rows into ws['pe'] (S path), key / value rows as key16 hi +
+        lo pairs (T path).  Round 3 ran it as four K-concatenated products on the tile GEMM (hidden layer through HBM) + four split passes:
+        1.09 ms (S) / 2.17 ms (T) per 16-sample launch.  No host synchronisation, no allocation: graph-replayable."""
         o, W_, T = ops, self.w, ws['tab']
         md = ws['S_dev']
         o.pe_inputs(ws['s2pos'], md, P, featcl, T['img2lidar'], T['coords_w'], T['coords_h'], T['coords_d'], T['embeds'],
-                    self.const['dim_t'], ws['A1'], ws['A2'] if self.keep_sine_rows else None, ws['Xf_b'], ws['Xf32'], V, h, w, self.depth_num,
+                    self.const['dim_t'], ws['A1'], ws['A2'] if self.keep_sine_rows else None, ws['Xf_b'], None, V, h, w, self.depth_num,
                     self.post_range_h64, A_frustum_f32=ws['xa1'], A_sine_f32=ws['xa2'] if self.keep_sine_rows else None)
-
-        def mlp(x32, n1, n2, **kw):
-            K1 = x32.shape[1]
-            a3 = ws['x3a'].view(-1)[:P * 3 * K1].view(P, 3 * K1)
-            o.split3_rows(x32, None, out=a3, m_dev=md, M=P)
-            b1 = W_['pe_b' + n1[1:]]
-            N1 = b1.numel()
-            h3 = ws['x3h'].view(-1)[:P * 3 * N1].view(P, 3 * N1)
-            o.gemm_bf16(a3, W_['pe_' + n1 + '_c3'], b1, m_dev=md, act=1, out=h3, split3=True, M=P)
-            return o.gemm_bf16(h3, W_['pe_' + n2 + '_c3'], W_['pe_b' + n2[1:]], m_dev=md, M=P, **kw)
-        mlp(ws['Xf32'], 'wr', 'we', act=2, out=ws['xgate'])                               # SE gate
         sh = ws['shared']
-        mlp(ws['xa1'], 'w1a', 'w1b', mul=ws['xgate'], add=sh['sine_tab'], add_index=ws['s2pos'], add_period=sh['sine_period'], out=ws['pe'])
-        if self.kind == 'T':
-            o.split_rows(ws['Xf32'], ws['pe'], hi=ws['Xk'], lo=ws['xk_lo'], m_dev=md, M=P)   # key rows = feat + pe
-            o.split_rows(ws['Xf32'], None, hi=ws['Xf_b'], lo=ws['xv_lo'], m_dev=md, M=P)     # value rows = feat
+        rows = self.kind == 'T'
+        dbg = self.keep_xk or getattr(self, '_stage_outputs', False)
+        o.pe_fused_x3(ws['xa1'], featcl, md, W_['pe_x3'], sh['sine_tab'], sh['sine_period'], pe=ws['pe'] if (not rows or dbg) else None,
+                      Xk=(ws['Xk'], ws['xk_lo']) if rows else None, Xv=(ws['Xf_b'], ws['xv_lo']) if rows else None, M=P, row_index=ws['s2pos'])
 
     def pe_input_rows(self, ws, positions, V, h, w, f32=False):
         """PE input rows (frustum [n,192], sine [n,384]; key16, or unrounded fp32 with f32=True) at the given map positions (int32, device)

@@ -364,6 +364,26 @@ def pe_fused_tab(A1, Xfb, Xf32, m_dev, wp, sine_tab, tab_period, pe, Xk, M=None,
     return pe, Xk
 
 
+def pe_fused_x3(A1, Xmap, m_dev, wx, sine_tab, tab_period, pe=None, Xk=None, Xv=None, M=None, row_index=None):
+    """The PE block in split precision on unrounded inputs (index-exact route, csrc/pe_x3.hip).  A1 [M,192] fp32; Xmap fp32 feature rows
+    (indexed by row_index when given); wx: dict 'w1a','w1b','wr','we' = pack_x3(weight) pairs + fp32 biases 'b1a','b1b','br','be'; pe [M,256]
+    fp32 and / or Xk = (hi, lo), Xv = (hi, lo) key16 [M,256] pairs (key rows pe + feat, value rows feat)."""
+    _req(A1, torch.float32, 'A1'); _req(Xmap, torch.float32, 'Xmap'); _req(sine_tab, torch.float32, 'sine_tab'); _req(pe, torch.float32, 'pe')
+    _req(row_index, torch.int32, 'row_index'); _req(m_dev, torch.int32, 'm_dev')
+    for pair in (Xk, Xv):
+        if pair is not None:
+            _req16(pair[0], 'hi'); _req16(pair[1], 'lo')
+    for k in ('w1a', 'w1b', 'wr', 'we'):
+        _req(wx[k][0], BF16, k); _req(wx[k][1], BF16, k)
+    M = A1.shape[0] if M is None else M
+    xk, xv = Xk or (None, None), Xv or (None, None)
+    check(_lib.load().mv2d_pe_fused_x3(_p(A1), _p(Xmap), _p(row_index), _p(m_dev), M, _p(wx['w1a'][0]), _p(wx['w1a'][1]), _p(wx['b1a']),
+                                       _p(wx['w1b'][0]), _p(wx['w1b'][1]), _p(wx['b1b']), _p(wx['wr'][0]), _p(wx['wr'][1]), _p(wx['br']),
+                                       _p(wx['we'][0]), _p(wx['we'][1]), _p(wx['be']), _p(sine_tab), int(tab_period), _p(pe), _p(xk[0]), _p(xk[1]),
+                                       _p(xv[0]), _p(xv[1]), _stream()), 'mv2d_pe_fused_x3')
+    return pe
+
+
 def pack_wfrag(W):
     """row-major 16-bit weight [N,K] (bf16 or key16) -> fragment-major copy of the same dtype (one MFMA fragment = one contiguous 1 KB)."""
     if W.dtype not in (BF16, torch.float16):

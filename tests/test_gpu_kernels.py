@@ -752,6 +752,47 @@ def test_pe_fused_tab_kernel(dev, M, use_mdev, use_ri):
     assert relerr(outs[1][1][:Mv].double(), xk_ref[:Mv]) < (1e-3 if k16 == torch.float16 else 8e-3)
 
 
+@pytest.mark.parametrize('M,use_mdev,use_ri,rows', [(63, False, False, False), (130, False, True, True), (1000, True, True, True), (8794, True, False, False)])
+def test_pe_fused_x3_kernel(dev, M, use_mdev, use_ri, rows):
+    """mv2d_pe_fused_x3 (csrc/pe_x3.hip, index-exact route): the PE block in split precision on UNROUNDED fp32 inputs against fp64 -- pe at
+    fp32-class accuracy; with `rows` the key rows pe + feat and the value rows feat come out as key16 hi + lo pairs."""
+    from mv2d_amd import ops
+    k16 = ops.key16_dtype()
+    NP = M + 50 if use_ri else M
+    A1 = (rnd((M, 192), 190) * 3.0).to(dev)
+    Xmap = rnd((NP, 256), 192).to(dev)
+    ri = torch.randperm(NP, generator=torch.Generator().manual_seed(6))[:M].to(torch.int32).to(dev) if use_ri else None
+    Xrows = Xmap[ri.long()] if use_ri else Xmap
+    W = {k: v.to(dev) for k, v in dict(w1a=rnd((1024, 192), 193, 0.08), w1b=rnd((256, 1024), 194, 0.04), wr=rnd((256, 256), 197, 0.07),
+                                        we=rnd((256, 256), 198, 0.07)).items()}
+    bias = {k: rnd((n,), 199 + i).to(dev) for i, (k, n) in enumerate(dict(b1a=1024, b1b=256, br=256, be=256).items())}
+    wx = {k: ops.pack_x3(v) for k, v in W.items()}
+    wx.update(bias)
+    period = 41
+    tab = rnd((period, 256), 231).to(dev)
+    md = torch.tensor([M - 13], dtype=torch.int32, device=dev) if use_mdev else None
+    pe = torch.zeros((M, 256), device=dev)
+    pairs = [tuple(torch.zeros((M, 256), device=dev, dtype=k16) for _ in range(2)) for _ in range(2)] if rows else [None, None]
+    ops.pe_fused_x3(A1, Xmap, md, wx, tab, period, pe=pe, Xk=pairs[0], Xv=pairs[1], M=M, row_index=ri)
+    torch.cuda.synchronize()
+    Mv = M - 13 if use_mdev else M
+    d = lambda t: t.double()                                                            # noqa: E731
+    p1 = torch.relu(d(A1) @ d(W['w1a']).T + d(bias['b1a'])) @ d(W['w1b']).T + d(bias['b1b'])
+    gate = torch.sigmoid(torch.relu(d(Xrows) @ d(W['wr']).T + d(bias['br'])) @ d(W['we']).T + d(bias['be']))
+    pos = (ri.long() if use_ri else torch.arange(M, device=dev)) % period
+    pe_ref = d(tab)[pos] + p1 * gate
+    assert relerr(pe[:Mv], pe_ref[:Mv]) < 2e-5                                          # bf16x3: 2^-17 per operand
+    assert not pe[Mv:].any()
+    if rows:
+        tol = 2e-6 if k16 == torch.float16 else 3e-5
+        assert relerr(d(pairs[0][0][:Mv]) + d(pairs[0][1][:Mv]), (pe_ref + d(Xrows))[:Mv]) < 2e-5 + tol
+        assert relerr(d(pairs[1][0][:Mv]) + d(pairs[1][1][:Mv]), d(Xrows)[:Mv]) < tol
+        assert torch.equal(pairs[1][0][:Mv], Xrows[:Mv].to(k16))
+        pe_only = torch.zeros((M, 256), device=dev)
+        ops.pe_fused_x3(A1, Xmap, md, wx, tab, period, pe=pe_only, M=M, row_index=ri)
+        assert torch.equal(pe_only, pe)
+
+
 def test_attn_out_fused_x3(dev):
     """split-precision (bf16x3) row-fused out_proj + LN (+ q proj): fp32-class accuracy against fp64."""
     from mv2d_amd import ops
