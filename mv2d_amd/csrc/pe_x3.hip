@@ -88,14 +88,6 @@ __device__ __forceinline__ void load_a(XFrag (&a)[RT], const unsigned char* Lh, 
     }
 }
 
-__device__ __forceinline__ f32x4_t mma3(const XFrag& w, const XFrag& a, f32x4_t c) {
-    // D^T[column][row] += W . A^T (swapped: a lane ends with 4 consecutive columns of one row); small terms first
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(px_bf16x8, w.l), __builtin_bit_cast(px_bf16x8, a.h), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(px_bf16x8, w.h), __builtin_bit_cast(px_bf16x8, a.l), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(px_bf16x8, w.h), __builtin_bit_cast(px_bf16x8, a.h), c, 0, 0, 0);
-    return c;
-}
-
 // N k-steps of one layer.  The activation fragments of step K + 1 are read from LDS before the MFMAs of step K issue.
 template <int T0, int N, int K = 0>
 __device__ __forceinline__ void steps(f32x4_t (&acc)[RT][CT], XFrag (&wq)[RING][CT], XFrag (&a)[2][RT], const WBase& w, const unsigned char* Lh,
@@ -105,10 +97,18 @@ __device__ __forceinline__ void steps(f32x4_t (&acc)[RT][CT], XFrag (&wq)[RING][
         ring_load<T0 + K + RING - 1>(wq, w);
         if constexpr (K + 1 < N) load_a(a[(K + 1) & 1], Lh, Ll, K + 1, fr, fg);
         __builtin_amdgcn_sched_barrier(0);             // the loads stay ahead of the MFMAs
+        // product-major: 16 independent MFMAs between two that accumulate into the same tile (a dependent MFMA waits ~8 passes for its input)
 #pragma unroll
-        for (int i = 0; i < RT; ++i)
+        for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int j = 0; j < CT; ++j) acc[i][j] = mma3(wq[(T0 + K) % RING][j], a[K & 1][i], acc[i][j]);
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    const XFrag& wf = wq[(T0 + K) % RING][j];
+                    const XFrag& af = a[K & 1][i];
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(px_bf16x8, t == 0 ? wf.l : wf.h),
+                                                                         __builtin_bit_cast(px_bf16x8, t == 1 ? af.l : af.h), acc[i][j], 0, 0, 0);
+                }
         __builtin_amdgcn_sched_barrier(0);
         steps<T0, N, K + 1>(acc, wq, a, w, Lh, Ll, fr, fg);
     }
