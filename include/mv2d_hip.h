@@ -387,6 +387,13 @@ int mv2d_roi_align_ex(const float* map0, const float* map1, const float* rois, v
 int mv2d_box_correlation(const float* rois, const int* view_start, const double* trans, const float* lin, const float* depths,
                          int* match, int R, int V, int sample_size, int num_depth, int topk, int pad_h, int pad_w,
                          float depth_start, float iou_thr, float ratio, int max_per_view, void* stream);
+/* The feature-independent geometry of a frame in ONE launch (a one-sample frame is bound by its number of kernels): mv2d_box_params +
+ * mv2d_box_correlation (same arguments, same results) + the clearing of zero_bytes bytes at zero_ptr (16-byte aligned, a multiple of 16; the
+ * engine's per-frame mask / flag bytes; may be NULL / 0). */
+int mv2d_frame_geometry(const float* rois, const double* viewK, const double* viewE, double* K_roi, float* intr, int ld_intr, float* minv,
+                        float roi_size, float intr_scale, float min_size, const int* view_start, const double* trans, const float* lin,
+                        const float* depths, int* match, int R, int V, int sample_size, int num_depth, int topk, int pad_h, int pad_w,
+                        float depth_start, float iou_thr, float ratio, int max_per_view, void* zero_ptr, long long zero_bytes, void* stream);
 
 long long mv2d_csr_workspace_bytes(int R, int V, int h, int w);
 
@@ -406,6 +413,11 @@ int mv2d_roi_positions(const float* rois, const unsigned char* pad_mask, unsigne
 
 /* S-path CSR over the RoI-feature memory rows r*49+cell (RH/mv2d_s_head.py:184-192). */
 int mv2d_csr_from_corr(const int* match, int* row_ptr, int* col_idx, int* nnz_out, int R, int V, int topk, void* stream);
+/* mv2d_roi_positions + mv2d_csr_from_corr in two launches instead of three (the position scan and the CSR run side by side in one): V = all
+ * views of the maps, Vg = views per sample (match is [R, Vg, topk]); Vg * topk < 64. */
+int mv2d_roi_positions_csr(const float* rois, const unsigned char* pad_mask, unsigned char* roi_mask, int* rect, int* pos2s, int* s2pos,
+                           int* S_out, int R, int V, int h, int w, float stride, float expand_stride, const int* match, int* row_ptr,
+                           int* col_idx, int* nnz_out, int Vg, int topk, void* stream);
 
 /* PE inputs at the listed key positions only (MU/pe.py:84-135 frustum, MU/positional_encoding.py:78-95 sine) + feature gather.
  * out: A_frustum [S,3*D] key16, A_sine [S,384] key16, Xf_k16 [S,256] key16, Xf_f32 [S,256] (optional: NULL when mv2d_pe_fused_tab reads the map).
@@ -421,10 +433,12 @@ int mv2d_pe_inputs(const int* s2pos, const int* S_dev, int S_max, const float* f
  * RH/bbox_heads/cross_attention_head.py:357-377): top-k over R*num_classes logits, denormalise, centre-range filter.
  * out: boxes [<=max_num,9], scores, labels (int64), bbox_index (int64), *count_out.
  * A batch (grp_start != NULL): one top-k per sample, outputs [n_samples][max_num], count_out [n_samples], bbox_index relative to
- * the sample's first row; max_grp_rows = rows of the largest sample. */
+ * the sample's first row; max_grp_rows = rows of the largest sample.
+ * payload (optional): [n_samples][max_num * 11 + 1] fp32, the wire format of the per-step all-gather (what mv2d_pack_detections writes) from the
+ * same launch. */
 int mv2d_decode_topk(const float* cls, const float* reg, int R, int num_classes, int max_num, const float* post_center_range,
                      float* boxes, float* scores, long long* labels, long long* bbox_index, int* count_out,
-                     long long* topk_index_dbg, const int* grp_start, int n_samples, int max_grp_rows, void* stream);
+                     long long* topk_index_dbg, const int* grp_start, int n_samples, int max_grp_rows, float* payload, void* stream);
 
 /* Rotated bird's-eye-view NMS for nms_thr < 1 (not a shipped value: with 1.0 nothing is suppressed and mv2d_result_pack alone is the
  * step after the head, mmdet3d_plugin/models/detectors/mv2d.py:265-287): per class, greedy in score order, IoU of the rotated

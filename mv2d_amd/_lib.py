@@ -84,6 +84,8 @@ SIGNATURES = {
     'mv2d_mask_compact': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, I, P]),
     'mv2d_roi_positions': (I, [P, P, P, P, P, P, P, I, I, I, I, F, F, P]),
     'mv2d_csr_from_corr': (I, [P, P, P, P, I, I, I, P]),
+    'mv2d_roi_positions_csr': (I, [P, P, P, P, P, P, P, I, I, I, I, F, F, P, P, P, P, I, I, P]),
+    'mv2d_frame_geometry': (I, [P, P, P, P, P, I, P, F, F, F, P, P, P, P, P, I, I, I, I, I, I, I, F, F, F, I, P, LL, P]),
     'mv2d_pe_inputs': (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
     'mv2d_result_pack': (I, [P, P, P, P, F, I, P, P, P, P, I, I, P]),
     'mv2d_nms_bev': (I, [P, P, P, P, F, P, I, I, P]),
@@ -99,7 +101,7 @@ SIGNATURES = {
     'mv2d_layer_norm_bwd': (I, [P, P, P, P, P, P, P, P, I, F, P]),
     'mv2d_match_cost': (I, [P, P, P, P, P, I, I, I, I, F, F, F, F, P]),
     'mv2d_set_loss': (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, F, F, F, I, P]),
-    'mv2d_decode_topk': (I, [P, P, I, I, I, P, P, P, P, P, P, P, P, I, I, P]),
+    'mv2d_decode_topk': (I, [P, P, I, I, I, P, P, P, P, P, P, P, P, I, I, P, P]),
 }
 
 _lib = None

@@ -34,10 +34,9 @@ __device__ bool inverse4x4(const double* m, double* inv) {
     return true;
 }
 
-__global__ void box_params_kernel(const float* __restrict__ rois, const double* __restrict__ viewK, const double* __restrict__ viewE,
-                                  double* __restrict__ K_roi, float* __restrict__ intr, int ld_intr, float* __restrict__ minv,
-                                  int R, float roi_size, float intr_scale, float min_size) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void box_params_row(int r, const float* __restrict__ rois, const double* __restrict__ viewK, const double* __restrict__ viewE,
+                                               double* __restrict__ K_roi, float* __restrict__ intr, int ld_intr, float* __restrict__ minv,
+                                               int R, float roi_size, float intr_scale, float min_size) {
     if (r >= R) return;
     const float* b = rois + r * 5;
     const int v = (int)b[0];
@@ -66,6 +65,12 @@ __global__ void box_params_kernel(const float* __restrict__ rois, const double* 
         }
     bool ok = inverse4x4(L, Li);
     for (int i = 0; i < 16; ++i) minv[r * 16 + i] = ok ? (float)Li[i] : __builtin_nanf("");
+}
+
+__global__ void box_params_kernel(const float* __restrict__ rois, const double* __restrict__ viewK, const double* __restrict__ viewE,
+                                  double* __restrict__ K_roi, float* __restrict__ intr, int ld_intr, float* __restrict__ minv,
+                                  int R, float roi_size, float intr_scale, float min_size) {
+    box_params_row(blockIdx.x * blockDim.x + threadIdx.x, rois, viewK, viewE, K_roi, intr, ld_intr, minv, R, roi_size, intr_scale, min_size);
 }
 
 // inverse(K_roi @ E^T).float() for arbitrary per-RoI fp64 matrices (module-level QueryGenerator.center2lidar)
@@ -281,16 +286,22 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------
 constexpr int MAX_PER_VIEW = 1024;
 
-__global__ __launch_bounds__(128) void box_corr_kernel(const float* __restrict__ rois, const int* __restrict__ view_start,
-                                                       const double* __restrict__ trans, const float* __restrict__ lin, const float* __restrict__ depths,
-                                                       int* __restrict__ match, int V, int ss, int D, int topk, float img_w_m1, float img_h_m1,
-                                                       float depth_start, float iou_thr, float ratio) {
+struct BoxCorrArgs {
+    const float* rois; const int* view_start; const double* trans; const float* lin; const float* depths; int* match;
+    int V, ss, D, topk; float img_w_m1, img_h_m1, depth_start, iou_thr, ratio;
+};
+
+__device__ __forceinline__ void box_corr_block(int r, int bl, const BoxCorrArgs& A) {
+    const float* __restrict__ rois = A.rois; const int* __restrict__ view_start = A.view_start; const double* __restrict__ trans = A.trans;
+    const float* __restrict__ lin = A.lin; const float* __restrict__ depths = A.depths; int* __restrict__ match = A.match;
+    const int V = A.V, ss = A.ss, D = A.D, topk = A.topk;
+    const float img_w_m1 = A.img_w_m1, img_h_m1 = A.img_h_m1, depth_start = A.depth_start, iou_thr = A.iou_thr, ratio = A.ratio;
     __shared__ float su[128], sv[128];
     __shared__ int svalid[128];
     __shared__ float siou[MAX_PER_VIEW];
     __shared__ float red[4][2];
     __shared__ int flag[2];
-    const int r = blockIdx.x, bl = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     int* out = match + ((long long)r * V + bl) * topk;
     for (int i = tid; i < topk; i += 128) out[i] = -1;
     const float* rb = rois + r * 5;
@@ -378,6 +389,37 @@ __global__ __launch_bounds__(128) void box_corr_kernel(const float* __restrict__
     }
 }
 
+__global__ __launch_bounds__(128) void box_corr_kernel(BoxCorrArgs A) { box_corr_block(blockIdx.x, blockIdx.y, A); }
+
+// The feature-independent geometry of a frame in ONE launch (round 4: a one-sample frame is bound by its NUMBER of kernels, 4.6 us per
+// dispatch): blocks (r < R, b) = box correlation of RoI r with view b; then, in row y = 0, ceil(R / 128) blocks of per-RoI cameras
+// (box_params_row) and the blocks that clear the per-frame flag / mask bytes (the engine's zbuf).  The three parts are independent.
+struct FrameGeoArgs {
+    BoxCorrArgs corr;
+    const double* viewK; const double* viewE; double* K_roi; float* intr; int ld_intr; float* minv; float roi_size, intr_scale, min_size;
+    uint4* zero_ptr; long long zero_vec16;      // 16-byte words to clear
+    int R;
+};
+constexpr int GEO_ZERO_PER_BLOCK = 128 * 8;    // uint4 per block
+
+__global__ __launch_bounds__(128) void frame_geometry_kernel(FrameGeoArgs G) {
+    const int bx = blockIdx.x;
+    if (bx < G.R) { box_corr_block(bx, blockIdx.y, G.corr); return; }
+    if (blockIdx.y != 0) return;
+    const int np = (G.R + 127) / 128;
+    if (bx < G.R + np) {
+        box_params_row((bx - G.R) * 128 + threadIdx.x, G.corr.rois, G.viewK, G.viewE, G.K_roi, G.intr, G.ld_intr, G.minv, G.R, G.roi_size, G.intr_scale,
+                       G.min_size);
+        return;
+    }
+    const long long z0 = (long long)(bx - G.R - np) * GEO_ZERO_PER_BLOCK;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long long i = z0 + k * 128 + threadIdx.x;
+        if (i < G.zero_vec16) G.zero_ptr[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // a11/a12: T-path masks -> compacted key list + CSR (RH/utils/box_correlation.py:101-115,147-157 and
 //          RH/mv2d_t_head.py:67-88).  cell centre c = (i + 0.5) * stride - 0.5; in-RoI iff
@@ -445,12 +487,12 @@ __device__ __forceinline__ unsigned int kept16(const unsigned char* __restrict__
     return bits;
 }
 
-__global__ __launch_bounds__(1024) void csr_scan_positions_kernel(const unsigned char* __restrict__ roi_mask, const unsigned char* __restrict__ pad_mask,
-                                                                  int* __restrict__ pos2s, int* __restrict__ s2pos, int* __restrict__ S_out, int P) {
+__device__ __forceinline__ void csr_scan_positions_block(int blk, int nblk, const unsigned char* __restrict__ roi_mask, const unsigned char* __restrict__ pad_mask,
+                                                         int* __restrict__ pos2s, int* __restrict__ s2pos, int* __restrict__ S_out, int P) {
     __shared__ int wsum[16];
     __shared__ int carry;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int seg0 = blockIdx.x * SCAN_SEG;
+    const int seg0 = blk * SCAN_SEG;
     const bool vec_ok = (P & 15) == 0 && ((uintptr_t)roi_mask & 15) == 0 && ((uintptr_t)pad_mask & 15) == 0 && ((uintptr_t)pos2s & 15) == 0;
     // ---- kept cells before this segment
     int before = 0;
@@ -485,7 +527,12 @@ __global__ __launch_bounds__(1024) void csr_scan_positions_kernel(const unsigned
         if (vec_ok && j0 + 3 < P) *reinterpret_cast<int4*>(pos2s + j0) = make_int4(v4[0], v4[1], v4[2], v4[3]);
         else for (int k = 0; k < 4; ++k) if (j0 + k < P) pos2s[j0 + k] = v4[k];
     }
-    if (blockIdx.x == gridDim.x - 1 && tid == 1023) *S_out = off;          // the last thread of the last segment ends at the total
+    if (blk == nblk - 1 && tid == 1023) *S_out = off;          // the last thread of the last segment ends at the total
+}
+
+__global__ __launch_bounds__(1024) void csr_scan_positions_kernel(const unsigned char* __restrict__ roi_mask, const unsigned char* __restrict__ pad_mask,
+                                                                  int* __restrict__ pos2s, int* __restrict__ s2pos, int* __restrict__ S_out, int P) {
+    csr_scan_positions_block(blockIdx.x, gridDim.x, roi_mask, pad_mask, pos2s, s2pos, S_out, P);
 }
 
 // per query: OR the rects of (self + matched RoIs) into an LDS bitmask over P cells, drop cells that are not
@@ -609,38 +656,74 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const unsigned int* __res
 
 // S-path CSR over the RoI-feature memory (R*49 rows): keys of query r = 49 cells of self, then of each kept
 // correlated RoI in (view, rank) order (RH/mv2d_s_head.py:184-192 + box_correlation.py:165-193).
-__global__ __launch_bounds__(1024) void csr_from_corr_kernel(const int* __restrict__ match, int* __restrict__ row_ptr, int* __restrict__ col_idx,
-                                                             int* __restrict__ nnz_out, int R, int V, int topk) {
+// Blocks of CFC_ROWS rows (round 4; round 1-3: ONE block walked all rows, 56 us at 4800 rows): a block first counts the RoIs listed by all
+// earlier rows itself (a few KB of match entries, cheaper than a second launch or a look-back chain), scans its own rows, then every wave
+// writes whole rows -- lanes = consecutive entries, the RoI ids of the row compacted through 256 B of LDS.
+constexpr int CFC_ROWS = 256;
+__device__ __forceinline__ void csr_from_corr_block(int blk, const int* __restrict__ match, int* __restrict__ row_ptr, int* __restrict__ col_idx,
+                                                    int* __restrict__ nnz_out, int R, int nm /* V * topk, < 64 */) {
     __shared__ int wsum[16];
-    __shared__ int carry;
+    __shared__ int before_s;
+    __shared__ int rowoff[CFC_ROWS + 1];
+    __shared__ int ids[16][64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) carry = 0;
+    const int base = blk * CFC_ROWS;
+    // ---- RoIs listed by the rows before this block (own RoI + kept matches)
+    int before = 0;
+    for (long long e = tid; e < (long long)base * nm; e += 1024) before += match[e] >= 0 ? 1 : 0;
+    before = (int)wave_sum((float)before);               // counts < 2^24: exact in fp32
+    if (lane == 0) wsum[wv] = before;
     __syncthreads();
-    for (int base = 0; base < R; base += 1024) {
-        const int r = base + tid;
-        int n = 0;
-        if (r < R) { n = 1; for (int j = 0; j < V * topk; ++j) n += match[(long long)r * V * topk + j] >= 0 ? 1 : 0; }
-        const int cnt = n * 49;
-        int sc = cnt;
+    if (tid == 0) { int t = base; for (int k = 0; k < 16; ++k) t += wsum[k]; before_s = t; }
+    __syncthreads();
+    // ---- this block's rows: one thread per row counts, the first four waves scan
+    int n = 0;
+    const int r_own = base + tid;
+    if (tid < CFC_ROWS && r_own < R) { n = 1; for (int j = 0; j < nm; ++j) n += match[(long long)r_own * nm + j] >= 0 ? 1 : 0; }
+    int sc = n;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(sc, o, 64); if (lane >= o) sc += t; }
-        if (lane == 63) wsum[wv] = sc;
-        __syncthreads();
-        int o = carry + sc - cnt;
-        for (int k = 0; k < wv; ++k) o += wsum[k];
-        if (r < R) {
-            row_ptr[r] = o;
-            for (int c = 0; c < 49; ++c) col_idx[o++] = r * 49 + c;
-            for (int j = 0; j < V * topk; ++j) {
-                const int m = match[(long long)r * V * topk + j];
-                if (m >= 0) for (int c = 0; c < 49; ++c) col_idx[o++] = m * 49 + c;
-            }
-        }
-        __syncthreads();
-        if (tid == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; carry += t; }
-        __syncthreads();
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(sc, o, 64); if (lane >= o) sc += t; }
+    __syncthreads();                                     // wsum is reused
+    if (lane == 63) wsum[wv] = sc;
+    __syncthreads();
+    if (tid < CFC_ROWS) {
+        int off = before_s + sc - n;
+        for (int k = 0; k < wv; ++k) off += wsum[k];
+        rowoff[tid] = off;
+        if (r_own < R) row_ptr[r_own] = off * 49;
+        if (r_own == R - 1) { row_ptr[R] = (off + n) * 49; *nnz_out = (off + n) * 49; }
     }
-    if (tid == 0) { row_ptr[R] = carry; *nnz_out = carry; }
+    __syncthreads();
+    // ---- a wave per row: compact the row's RoI ids (slot 0 = the row itself), then write 49 consecutive cells per id
+    for (int q = wv; q < CFC_ROWS; q += 16) {
+        const int r = base + q;
+        if (r >= R) break;
+        int id = -1;
+        if (lane == 0) id = r;
+        else if (lane <= nm) id = match[(long long)r * nm + lane - 1];
+        const unsigned long long bal = __ballot(id >= 0);
+        if (id >= 0) ids[wv][__popcll(bal & ((1ull << lane) - 1ull))] = id;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        const int cnt = __popcll(bal) * 49;
+        int* out = col_idx + (long long)rowoff[q] * 49;
+        for (int e = lane; e < cnt; e += 64) { const int k = e / 49; out[e] = ids[wv][k] * 49 + (e - k * 49); }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(1024) void csr_from_corr_kernel(const int* __restrict__ match, int* __restrict__ row_ptr, int* __restrict__ col_idx,
+                                                             int* __restrict__ nnz_out, int R, int nm) {
+    csr_from_corr_block(blockIdx.x, match, row_ptr, col_idx, nnz_out, R, nm);
+}
+
+// S path: the scan of the RoI-tap positions and the CSR over the correlated RoIs are independent: one launch, block roles by index
+__global__ __launch_bounds__(1024) void scan_and_csr_kernel(const unsigned char* __restrict__ roi_mask, const unsigned char* __restrict__ pad_mask,
+                                                            int* __restrict__ pos2s, int* __restrict__ s2pos, int* __restrict__ S_out, int P, int nscan,
+                                                            const int* __restrict__ match, int* __restrict__ row_ptr, int* __restrict__ col_idx,
+                                                            int* __restrict__ nnz_out, int R, int nm) {
+    if ((int)blockIdx.x < nscan) csr_scan_positions_block(blockIdx.x, nscan, roi_mask, pad_mask, pos2s, s2pos, S_out, P);
+    else csr_from_corr_block(blockIdx.x - nscan, match, row_ptr, col_idx, nnz_out, R, nm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -737,7 +820,8 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(const float* __restri
                                                            int npow2, float r0, float r1, float r2, float r3, float r4, float r5,
                                                            float* __restrict__ boxes, float* __restrict__ scores, long long* __restrict__ labels,
                                                            long long* __restrict__ bbox_index, int* __restrict__ count_out,
-                                                           long long* __restrict__ topk_index_dbg, const int* __restrict__ grp_start) {
+                                                           long long* __restrict__ topk_index_dbg, const int* __restrict__ grp_start,
+                                                           float* __restrict__ payload) {
     // keys: 64-bit (monotone logit bits << 32 | ~index) -> all distinct, "larger" = higher logit, then LOWER index.
     // 1) 8 rounds of 8-bit radix select find the K-th largest key; 2) the K survivors are ranked by counting
     //    (K^2 compares spread over 1024 threads) — no full sort of the R*ncls candidates.
@@ -754,6 +838,7 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(const float* __restri
         boxes += (long long)g * max_num * 9; scores += (long long)g * max_num; labels += (long long)g * max_num;
         bbox_index += (long long)g * max_num; count_out += g;
         if (topk_index_dbg) topk_index_dbg += (long long)g * max_num;
+        if (payload) payload += (long long)g * ((long long)max_num * 11 + 1);
     }
     const int tid = threadIdx.x, n = R * ncls;
     const int K = min(max_num, n);
@@ -848,6 +933,19 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(const float* __restri
         scores[o] = sc;
         labels[o] = idx % ncls;
         bbox_index[o] = idx / ncls;
+    }
+    // optional: the sample's row of the wire format of the per-step all-gather (pack_detections_kernel's output) in the same launch:
+    // max_num rows of (box[9], score, label) as fp32, rows >= count zeroed, then the count
+    if (payload) {
+        __syncthreads();                                     // the block's own global writes above are visible to all of its threads
+        const int cnt = min(*count_out, max_num);
+        for (int i = tid; i < max_num * 11; i += 1024) {
+            const int r = i / 11, c = i - r * 11;
+            float v = 0.f;
+            if (r < cnt) v = c < 9 ? boxes[r * 9 + c] : (c == 9 ? scores[r] : (float)labels[r]);
+            payload[i] = v;
+        }
+        if (tid == 0) payload[(long long)max_num * 11] = (float)*count_out;
     }
 }
 
@@ -998,8 +1096,29 @@ extern "C" int mv2d_box_correlation(const float* rois, const int* view_start, co
     MV2D_CHECK_ARG(sample_size * sample_size * num_depth <= 128, "mv2d_box_correlation: sample_size^2*num_depth must be <= 128");
     MV2D_CHECK_ARG(max_per_view <= MAX_PER_VIEW && topk >= 1, "mv2d_box_correlation: too many RoIs in one view (max 1024)");
     if (R == 0) return MV2D_OK;
-    hipLaunchKernelGGL(box_corr_kernel, dim3(R, V), dim3(128), 0, (hipStream_t)stream, rois, view_start, trans, lin, depths, match, V,
-                       sample_size, num_depth, topk, (float)(pad_w - 1), (float)(pad_h - 1), depth_start, iou_thr, ratio);
+    const BoxCorrArgs A{rois, view_start, trans, lin, depths, match, V, sample_size, num_depth, topk, (float)(pad_w - 1), (float)(pad_h - 1), depth_start,
+                        iou_thr, ratio};
+    hipLaunchKernelGGL(box_corr_kernel, dim3(R, V), dim3(128), 0, (hipStream_t)stream, A);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+// mv2d_box_params + mv2d_box_correlation + the clearing of `zero_bytes` bytes at zero_ptr (16-byte aligned, a multiple of 16; may be NULL)
+// in ONE launch: see frame_geometry_kernel
+extern "C" int mv2d_frame_geometry(const float* rois, const double* viewK, const double* viewE, double* K_roi, float* intr, int ld_intr, float* minv,
+                                   float roi_size, float intr_scale, float min_size, const int* view_start, const double* trans, const float* lin,
+                                   const float* depths, int* match, int R, int V, int sample_size, int num_depth, int topk, int pad_h, int pad_w,
+                                   float depth_start, float iou_thr, float ratio, int max_per_view, void* zero_ptr, long long zero_bytes, void* stream) {
+    MV2D_CHECK_ARG(rois && viewK && viewE && intr && minv && ld_intr >= 16 && view_start && trans && lin && depths && match, "mv2d_frame_geometry: null pointer");
+    MV2D_CHECK_ARG(sample_size * sample_size * num_depth <= 128, "mv2d_frame_geometry: sample_size^2*num_depth must be <= 128");
+    MV2D_CHECK_ARG(max_per_view <= MAX_PER_VIEW && topk >= 1, "mv2d_frame_geometry: too many RoIs in one view (max 1024)");
+    MV2D_CHECK_ARG(zero_bytes >= 0 && (zero_bytes % 16) == 0 && ((uintptr_t)zero_ptr & 15) == 0 && (zero_ptr || zero_bytes == 0),
+                   "mv2d_frame_geometry: the region to clear must be 16-byte aligned and a multiple of 16 bytes");
+    if (R == 0) return MV2D_OK;
+    FrameGeoArgs G{{rois, view_start, trans, lin, depths, match, V, sample_size, num_depth, topk, (float)(pad_w - 1), (float)(pad_h - 1), depth_start,
+                    iou_thr, ratio}, viewK, viewE, K_roi, intr, ld_intr, minv, roi_size, intr_scale, min_size, (uint4*)zero_ptr, zero_bytes / 16, R};
+    const int nz = (int)((zero_bytes / 16 + GEO_ZERO_PER_BLOCK - 1) / GEO_ZERO_PER_BLOCK);
+    hipLaunchKernelGGL(frame_geometry_kernel, dim3(R + cdiv(R, 128) + nz, V), dim3(128), 0, (hipStream_t)stream, G);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
@@ -1043,8 +1162,23 @@ extern "C" int mv2d_roi_positions(const float* rois, const unsigned char* pad_ma
 }
 
 extern "C" int mv2d_csr_from_corr(const int* match, int* row_ptr, int* col_idx, int* nnz_out, int R, int V, int topk, void* stream) {
-    MV2D_CHECK_ARG(match && row_ptr && col_idx && nnz_out && R > 0, "mv2d_csr_from_corr: bad args");
-    hipLaunchKernelGGL(csr_from_corr_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, match, row_ptr, col_idx, nnz_out, R, V, topk);
+    MV2D_CHECK_ARG(match && row_ptr && col_idx && nnz_out && R > 0 && V * topk < 64, "mv2d_csr_from_corr: bad args (V * topk < 64)");
+    hipLaunchKernelGGL(csr_from_corr_kernel, dim3(cdiv(R, CFC_ROWS)), dim3(1024), 0, (hipStream_t)stream, match, row_ptr, col_idx, nnz_out, R, V * topk);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+// mv2d_roi_positions + mv2d_csr_from_corr (S path) in TWO launches instead of three: the mark kernel, then the position scan and the CSR side by side
+extern "C" int mv2d_roi_positions_csr(const float* rois, const unsigned char* pad_mask, unsigned char* roi_mask, int* rect, int* pos2s, int* s2pos,
+                                      int* S_out, int R, int V, int h, int w, float stride, float expand_stride, const int* match, int* row_ptr,
+                                      int* col_idx, int* nnz_out, int Vg, int topk, void* stream) {
+    MV2D_CHECK_ARG(rois && pad_mask && roi_mask && rect && pos2s && s2pos && S_out && R > 0, "mv2d_roi_positions_csr: bad args");
+    MV2D_CHECK_ARG(match && row_ptr && col_idx && nnz_out && Vg * topk < 64, "mv2d_roi_positions_csr: bad CSR args (views per sample * topk < 64)");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(csr_mark_kernel, dim3(R), dim3(64), 0, st, rois, rect, roi_mask, h, w, stride, expand_stride);
+    const int nscan = cdiv(V * h * w, SCAN_SEG);
+    hipLaunchKernelGGL(scan_and_csr_kernel, dim3(nscan + cdiv(R, CFC_ROWS)), dim3(1024), 0, st, roi_mask, pad_mask, pos2s, s2pos, S_out, V * h * w, nscan,
+                       match, row_ptr, col_idx, nnz_out, R, Vg * topk);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
@@ -1083,7 +1217,7 @@ extern "C" int mv2d_result_pack(const float* boxes, const float* scores, const l
 
 extern "C" int mv2d_decode_topk(const float* cls, const float* reg, int R, int num_classes, int max_num, const float* post_center_range,
                                 float* boxes, float* scores, long long* labels, long long* bbox_index, int* count_out,
-                                long long* topk_index_dbg, const int* grp_start, int n_grp, int max_grp_rows, void* stream) {
+                                long long* topk_index_dbg, const int* grp_start, int n_grp, int max_grp_rows, float* payload, void* stream) {
     MV2D_CHECK_ARG(cls && reg && post_center_range && boxes && scores && labels && bbox_index && count_out, "mv2d_decode_topk: null pointer");
     MV2D_CHECK_ARG(max_num >= 1 && max_num <= 1024, "mv2d_decode_topk: max_num must be in [1, 1024]");
     MV2D_CHECK_ARG(!grp_start || (n_grp >= 1 && max_grp_rows >= 1 && max_grp_rows <= R), "mv2d_decode_topk: bad sample list");
@@ -1099,7 +1233,7 @@ extern "C" int mv2d_decode_topk(const float* cls, const float* reg, int R, int n
     }
     hipLaunchKernelGGL(decode_topk_kernel, dim3(grp_start ? n_grp : 1), dim3(1024), lds, (hipStream_t)stream, cls, reg, R, num_classes, max_num, npow2,
                        post_center_range[0], post_center_range[1], post_center_range[2], post_center_range[3], post_center_range[4],
-                       post_center_range[5], boxes, scores, labels, bbox_index, count_out, topk_index_dbg, grp_start);
+                       post_center_range[5], boxes, scores, labels, bbox_index, count_out, topk_index_dbg, grp_start, payload);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

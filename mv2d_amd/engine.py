@@ -500,15 +500,13 @@ class HeadEngine:
         else:
             featcl = o.nchw_to_nhwc(feat, ws['featcl'])
         ws['featcl_cur'], ws['map_shape'], ws['max_rows'] = featcl, (V, h, w), sc['max_rows']
-        tk('box_params')
-        # a3/a5/a7 per-RoI camera
-        o.box_params(rois, T['viewK'], T['viewE'], ws['enc'][:, 1024:], 1056, ws['minv'])
-        tk('box_corr')
-        # a9 epipolar correlation (independent of the features)
-        o.box_correlation(rois, ws['view_start'], T['trans'], self.const['lin'], self.const['depths'], ws['match'], Vg, self.topk,
-                          sc['pad_h'], sc['pad_w'], sc['max_per_view'], iou_thr=self.iou_thr, ratio=self.ratio)
+        tk('box_params'); tk('box_corr')
+        # a3/a5/a7 per-RoI camera + a9 epipolar correlation (both independent of the features) + the clearing of the frame's mask / flag
+        # bytes: one launch (round 4; a one-sample frame is bound by its NUMBER of kernels)
+        o.frame_geometry(rois, T['viewK'], T['viewE'], ws['enc'][:, 1024:], 1056, ws['minv'], ws['view_start'], T['trans'], self.const['lin'],
+                         self.const['depths'], ws['match'], Vg, self.topk, sc['pad_h'], sc['pad_w'], sc['max_per_view'], iou_thr=self.iou_thr,
+                         ratio=self.ratio, zero=ws['zbuf'])
         tk('csr')
-        ws['zbuf'].zero_()
         # T path: the query-generator chain (RoIAlign -> conv -> fcs -> ref points -> query_pos) only needs the feature map and
         # the per-RoI cameras, the key chain (correlation -> key list -> PE -> K/V) only the boxes: run them on two streams
         forked = self.kind == 'T' and self.prof is None and self.fork_qg and not self.exact
@@ -533,9 +531,6 @@ class HeadEngine:
                 o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'],
                             out0_lo=ws.get('roi_lo') if (self.exact and 'conv' not in self.exact_skip) else None, R=R)
         else:
-            # positions any RoIAlign tap can touch (own rect + 1 cell) -> PE only there
-            o.roi_positions(rois, ws['zero_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'], R, V, h, w,
-                            self.stride, 1.0)
             if self.force_nc is not None:
                 # the synthetic rig barely correlates RoIs across views, so the S-path sweep over n_c
                 # (RoIs per query) substitutes a synthetic correlation list: own RoI + (n_c - 1) others
@@ -548,7 +543,9 @@ class HeadEngine:
                         fmh[:, j - 1] = (ar + 37 * j) % R
                     fm = ws['forced_match'] = fmh.view(R, Vg, self.topk).to(self.dev)
                 ws['match'].copy_(fm)
-            o.csr_from_corr(ws['match'], ws['row_ptr'], ws['col_idx'], ws['nnz'], R, Vg, self.topk)
+            # positions any RoIAlign tap can touch (own rect + 1 cell) -> PE only there; CSR over the correlated RoIs' feature rows
+            o.roi_positions_csr(rois, ws['zero_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'], R, V, h, w, ws['match'],
+                                ws['row_ptr'], ws['col_idx'], ws['nnz'], Vg, self.topk, stride=self.stride, expand_stride=1.0)
         md = ws['S_dev']
         # a2: PE at the listed positions only
         if self.exact and 'pe' not in self.exact_skip:
@@ -583,7 +580,7 @@ class HeadEngine:
         tk('decode')
         # a21: NMS-free decode of the last layer (one top-k per sample)
         o.decode_topk(ws['cls'][L - 1], ws['reg'][L - 1], R, self.num_classes, self.max_num, self.post_range_h, ws['boxes'], ws['scores'],
-                      ws['labels'], ws['bbox_index'], ws['count'], grp_start=grp, max_grp_rows=sc['max_rows'])
+                      ws['labels'], ws['bbox_index'], ws['count'], grp_start=grp, max_grp_rows=sc['max_rows'], payload=ws.get('payload_out'))
         tk('end')
 
     def _exact_pe(self, ws, featcl, P, V, h, w):
@@ -722,19 +719,24 @@ class HeadEngine:
             out['stages'] = st
         return out
 
-    def run(self, feat, proposals, img_metas, keep_stages=False, use_graph=False):
+    def run(self, feat, proposals, img_metas, keep_stages=False, use_graph=False, payload=None):
         """One sample.  feat [V,256,h,w] fp32 on the GPU (NCHW, or channels_last memory format); proposals list of [n,6].
-        Enqueues the frame on the current stream; use_graph replays a captured hipGraph of the same shape."""
-        return self._run([feat], [proposals], [img_metas], keep_stages, use_graph, batch=False)
+        Enqueues the frame on the current stream; use_graph replays a captured hipGraph of the same shape.  payload (optional): fp32
+        [1, max_num * 11 + 1] on the GPU -- the decode kernel also writes the wire row of the all-gather of decoded boxes (mv2d_amd.dist)
+        there (its address is part of the graph key)."""
+        return self._run([feat], [proposals], [img_metas], keep_stages, use_graph, batch=False, payload=payload)
 
-    def run_batch(self, feats, proposals_list, metas_list, keep_stages=False, use_graph=False):
+    def run_batch(self, feats, proposals_list, metas_list, keep_stages=False, use_graph=False, payload=None):
         """Several samples through ONE sequence of launches (the reference runs one sample per call): feats = list of [V,256,h,w]
         maps (or one stacked [B*V,256,h,w] tensor), proposals_list / metas_list = one entry per sample.  Outputs: cls / reg
         [L,R_total,10] with the samples' queries concatenated (out['grp_start']), boxes [B,max_num,9], scores, labels, count [B]."""
-        return self._run(feats, proposals_list, metas_list, keep_stages, use_graph, batch=True)
+        return self._run(feats, proposals_list, metas_list, keep_stages, use_graph, batch=True, payload=payload)
 
-    def _run(self, feats, proposals_list, metas_list, keep_stages, use_graph, batch):
+    def _run(self, feats, proposals_list, metas_list, keep_stages, use_graph, batch, payload=None):
         B = len(proposals_list)
+        if payload is not None:
+            assert payload.is_cuda and payload.dtype == F32 and payload.is_contiguous() and tuple(payload.shape) == (B, self.max_num * 11 + 1), \
+                'payload: fp32 [samples, max_num * 11 + 1] on the GPU'
         stacked = torch.is_tensor(feats)
         fl = [feats] if stacked else list(feats)
         for f in fl:
@@ -759,6 +761,7 @@ class HeadEngine:
         # stream; measured in round 3: +1 % in long runs but 7400-7900 instead of 8300 samples/s in short ones -- without the host's wait the four
         # streams drift into phase and their wide kernels collide
         ws['dyn_d'].copy_(ws['dyn_h'], non_blocking=True)
+        ws['payload_out'] = payload
         self._stage_outputs = bool(keep_stages)          # intermediate buffers nothing downstream reads (pe on the T path, Xk on the S path)
         Rc = sc['cap']                     # launches run on the bucket size; R = the real rows
         if self.debug_attn:
@@ -773,7 +776,7 @@ class HeadEngine:
             return dict(self._result(ws, R, keep_stages, batch), dt=sc['dt'])
         # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
-        gkey = (ptrs, sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs, self.last_stage_heads,
+        gkey = (ptrs, 0 if payload is None else payload.data_ptr(), sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs, self.last_stage_heads,
                 self.xattn_waves, self.fuse_maps, self.keep_sine_rows, self.keep_xk, self.ffn_groups, self.force_nc, self.q_order,
                 self.fork_qg, self.exact_skip)   # load_state() re-allocates the weights; every route option of __init__ is in the key
         graphs = ws.setdefault('graphs', {})             # one graph per (input buffers, frame scalars): a producer that alternates between

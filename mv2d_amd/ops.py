@@ -697,6 +697,17 @@ def box_correlation(rois, view_start, trans, lin, depths, match, V, topk, pad_h,
                                            _stream()), 'mv2d_box_correlation')
 
 
+def frame_geometry(rois, viewK, viewE, intr, ld_intr, minv, view_start, trans, lin, depths, match, V, topk, pad_h, pad_w, max_per_view,
+                   K_roi=None, roi_size=7.0, intr_scale=0.1, min_size=4.0, sample_size=4, num_depth=8, depth_start=0.5, iou_thr=0.0, ratio=0.0, zero=None):
+    """box_params + box_correlation (+ clearing the uint8 buffer `zero`) in one launch."""
+    _req(rois, torch.float32, 'rois'); _req(viewK, torch.float64, 'viewK'); _req(viewE, torch.float64, 'viewE'); _req(view_start, torch.int32, 'view_start')
+    _req(trans, torch.float64, 'trans'); _req(match, torch.int32, 'match'); _req(zero, torch.uint8, 'zero')
+    check(_lib.load().mv2d_frame_geometry(_p(rois), _p(viewK), _p(viewE), _p(K_roi), _p(intr), ld_intr, _p(minv), roi_size, intr_scale, min_size,
+                                          _p(view_start), _p(trans), _p(lin), _p(depths), _p(match), rois.shape[0], V, sample_size, num_depth, topk,
+                                          pad_h, pad_w, depth_start, iou_thr, ratio, max_per_view, _p(zero), zero.numel() if zero is not None else 0,
+                                          _stream()), 'mv2d_frame_geometry')
+
+
 def csr_workspace_bytes(R, V, h, w):
     return _lib.load().mv2d_csr_workspace_bytes(R, V, h, w)
 
@@ -715,6 +726,14 @@ def roi_positions(rois, pad_mask, roi_mask, rect, pos2s, s2pos, S_out, R, V, h, 
                                          float(stride), float(expand_stride), _stream()), 'mv2d_roi_positions')
 
 
+def roi_positions_csr(rois, pad_mask, roi_mask, rect, pos2s, s2pos, S_out, R, V, h, w, match, row_ptr, col_idx, nnz_out, Vg, topk, stride=16.0,
+                      expand_stride=1.0):
+    """roi_positions + csr_from_corr (S path) in two launches."""
+    check(_lib.load().mv2d_roi_positions_csr(_p(rois), _p(pad_mask), _p(roi_mask), _p(rect), _p(pos2s), _p(s2pos), _p(S_out), R, V, h, w, float(stride),
+                                             float(expand_stride), _p(match), _p(row_ptr), _p(col_idx), _p(nnz_out), Vg, topk, _stream()),
+          'mv2d_roi_positions_csr')
+
+
 def csr_from_corr(match, row_ptr, col_idx, nnz_out, R, V, topk):
     check(_lib.load().mv2d_csr_from_corr(_p(match), _p(row_ptr), _p(col_idx), _p(nnz_out), R, V, topk, _stream()),
           'mv2d_csr_from_corr')
@@ -731,13 +750,14 @@ def pe_inputs(s2pos, S_dev, S_max, featcl, img2lidar, coords_w, coords_h, coords
 
 
 def decode_topk(cls, reg, R, num_classes, max_num, post_center_range_host, boxes, scores, labels, bbox_index, count, topk_dbg=None,
-                grp_start=None, max_grp_rows=0):
-    """grp_start (int32 [n+1], device) + max_grp_rows: one top-k per sample of a batch, outputs [n][max_num]."""
-    _req(cls, torch.float32, 'cls'); _req(reg, torch.float32, 'reg')
+                grp_start=None, max_grp_rows=0, payload=None):
+    """grp_start (int32 [n+1], device) + max_grp_rows: one top-k per sample of a batch, outputs [n][max_num]; payload (optional, fp32
+    [n][max_num * 11 + 1]): the wire rows of the all-gather of decoded boxes from the same launch."""
+    _req(cls, torch.float32, 'cls'); _req(reg, torch.float32, 'reg'); _req(payload, torch.float32, 'payload')
     n = 0 if grp_start is None else grp_start.numel() - 1
     check(_lib.load().mv2d_decode_topk(_p(cls), _p(reg), R, num_classes, max_num, post_center_range_host.data_ptr(), _p(boxes),
                                        _p(scores), _p(labels), _p(bbox_index), _p(count), _p(topk_dbg), _p(grp_start), n, max_grp_rows,
-                                       _stream()), 'mv2d_decode_topk')
+                                       _p(payload), _stream()), 'mv2d_decode_topk')
 
 
 def result_pack(boxes, scores, labels, count, score_thr, max_num, out_boxes, out_scores, out_labels, out_count, n_samples=1, in_stride=0):

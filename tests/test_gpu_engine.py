@@ -356,6 +356,31 @@ def test_engine_map_kernels_fused_or_separate_bitwise_equal(kind, name):
         assert torch.equal(nat['cls'], ref['cls']) and torch.equal(nat['reg'], ref['reg'])
 
 
+@pytest.mark.parametrize('kind,name,n', [('S', 'cfg1_s', 1), ('S', 'nc6_s', 3), ('T', 'cfg1_t', 2)])
+def test_decode_writes_the_all_gather_payload(kind, name, n):
+    """run(..., payload=buf): the decode kernel writes the wire rows of the per-step all-gather itself (one launch less per frame); they equal
+    what mv2d_pack_detections makes of the decoded boxes, also under hipGraph replay (the buffer's address is part of the graph key)."""
+    from mv2d_amd import ops
+    from mv2d_amd.engine import HeadEngine
+    dev = torch.device('cuda:0')
+    sd = synthetic.make_head_state(seed=0)
+    probs = [synthetic.make_problem(name, seed=s) for s in range(n)]
+    eng = HeadEngine(sd, kind, dev, num_views=probs[0]['views_per_frame'])
+    feats = [torch.from_numpy(p['feat']).to(dev) for p in probs]
+    props = [[torch.from_numpy(x) for x in p['proposals']] for p in probs]
+    metas = [p['img_metas'] for p in probs]
+    for use_graph in (False, True):
+        pay = torch.full((n, 300 * 11 + 1), -7.0, device=dev)
+        out = eng.run_batch(feats, props, metas, use_graph=use_graph, payload=pay) if n > 1 else eng.run(feats[0], props[0], metas[0], use_graph=use_graph, payload=pay)
+        ref = torch.empty_like(pay)
+        boxes, scores, labels = (out[k] if n > 1 else out[k][None] for k in ('boxes', 'scores', 'labels'))
+        ops.pack_detections(boxes.contiguous(), scores.contiguous(), labels.contiguous(), out['count'], ref)
+        torch.cuda.synchronize()
+        assert torch.equal(pay, ref) and int(out['count'].sum()) > 0
+    plain = eng.run_batch(feats, props, metas) if n > 1 else eng.run(feats[0], props[0], metas[0])       # without a payload: same decoded boxes
+    assert torch.equal(plain['boxes'], out['boxes'])
+
+
 def test_engine_stays_finite_when_features_exceed_the_fp16_range():
     """Range guard of the fp16 key side (csrc/common.h): feature values beyond +-65504 SATURATE in the key / value rows and RoI cells instead of
     becoming inf -- every output of the frame stays finite (an inf in a key row would turn its softmax rows into NaN and, through the next self
