@@ -51,6 +51,10 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
     srcs = _sources()
+    keep = {os.path.basename(f)[:-4] + '.o' for f in srcs}
+    for f in os.listdir(OBJDIR):                      # objects of sources that no longer exist (tools/build_variant.sh links every object here)
+        if f.endswith('.o') and f not in keep:
+            os.remove(os.path.join(OBJDIR, f))
 
     def cc(src):
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + '.o')

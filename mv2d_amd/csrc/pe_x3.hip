@@ -17,6 +17,13 @@
 // (3 x the MFMAs of the default kernel on the same loads).
 #include "common.h"
 
+#ifdef MV2D_PX_TRACE
+__device__ long long g_px_trace[32];
+#define PX_STAMP(i) do { if (blockIdx.x == MV2D_PX_TRACE && threadIdx.x == 0) g_px_trace[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PX_STAMP(i) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int C = 256;
@@ -152,30 +159,34 @@ __device__ __forceinline__ void layer1(XFrag (&wq)[RING][CT], XFrag (&a)[2][RT],
     __syncthreads();
 }
 
-// fp32 rows -> hi / lo LDS images: NCH 16-byte chunks (8 columns) per row, thread t moves float4 pieces (half a chunk each)
+// fp32 rows -> hi / lo LDS images: NCH 16-byte chunks (8 columns) per row, thread t moves float4 pieces (half a chunk each).  Two phases, so
+// that the loads can be in flight under MFMA work: stage_load issues them, stage_commit splits and writes the images.
 template <int NCH>
-__device__ __forceinline__ void stage_rows(const float* __restrict__ src, long long ld, const int* __restrict__ ridx, int m0, int M, unsigned char* Lh,
-                                           unsigned char* Ll, int tid) {
-    constexpr int PIECES = BM * NCH * 2, PER = PIECES / NTHR;
+struct Stage {
+    static constexpr int PIECES = BM * NCH * 2, PER = PIECES / NTHR;
     static_assert(PIECES % NTHR == 0, "");
     float4 v[PER];
+    __device__ __forceinline__ void load(const float* __restrict__ src, long long ld, const int* __restrict__ ridx, int m0, int M, int tid) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int c = tid + NTHR * i, row = c / (2 * NCH), piece = c - row * (2 * NCH);
-        const int m = min(m0 + row, M - 1);
-        const long long r = ridx ? ridx[m] : m;
-        v[i] = *reinterpret_cast<const float4*>(src + r * ld + piece * 4);
+        for (int i = 0; i < PER; ++i) {
+            const int c = tid + NTHR * i, row = c / (2 * NCH), piece = c - row * (2 * NCH);
+            const int m = min(m0 + row, M - 1);
+            const long long r = ridx ? ridx[m] : m;
+            v[i] = *reinterpret_cast<const float4*>(src + r * ld + piece * 4);
+        }
     }
+    __device__ __forceinline__ void commit(unsigned char* Lh, unsigned char* Ll, int tid) const {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int c = tid + NTHR * i, row = c / (2 * NCH), piece = c - row * (2 * NCH), chunk = piece >> 1;
-        uint2 hv, lv;
-        split4(v[i].x, v[i].y, v[i].z, v[i].w, hv, lv);
-        const int off = row * PITCH + ((chunk ^ (row & 15)) << 4) + (piece & 1) * 8;
-        *reinterpret_cast<uint2*>(Lh + off) = hv;
-        *reinterpret_cast<uint2*>(Ll + off) = lv;
+        for (int i = 0; i < PER; ++i) {
+            const int c = tid + NTHR * i, row = c / (2 * NCH), piece = c - row * (2 * NCH), chunk = piece >> 1;
+            uint2 hv, lv;
+            split4(v[i].x, v[i].y, v[i].z, v[i].w, hv, lv);
+            const int off = row * PITCH + ((chunk ^ (row & 15)) << 4) + (piece & 1) * 8;
+            *reinterpret_cast<uint2*>(Lh + off) = hv;
+            *reinterpret_cast<uint2*>(Ll + off) = lv;
+        }
     }
-}
+};
 
 __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
@@ -192,6 +203,7 @@ __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
     const long long lo = (long long)lane * 8 + (long long)wave * CT * 512;
     const WBase w{{p.Wr_h + lo, p.Wr_l + lo}, {p.We_h + lo, p.We_l + lo}, {p.W1a_h + lo, p.W1a_l + lo}, {p.W1b_h + lo, p.W1b_l + lo}};
     XFrag wq[RING][CT], a[2][RT];
+    PX_STAMP(0);
     ring_load<0>(wq, w);
     ring_load<1>(wq, w);
     {
@@ -206,25 +218,41 @@ __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
             }
         }
         // the frustum rows of the tile (192 channels = 24 chunks per row), fp32 -> hi / lo images
-        stage_rows<24>(p.A1, 192, nullptr, m0, M, Ah, Al, tid);
+        Stage<24> st;
+        st.load(p.A1, 192, nullptr, m0, M, tid);
+        st.commit(Ah, Al, tid);
     }
     __syncthreads();
+    PX_STAMP(1);
     const int n0 = wave * CT * 16 + 4 * fg;             // this lane's 4 output columns of column tile j start at n0 + 16 j
     f32x4_t accf[RT][CT];                               // P1 = position_encoder(A1), bias added at the end
 
     // ---- 1. P1 in four parts of 256 hidden columns
     zero_acc(accf);
     layer1<0>(wq, a, w, Ah, Al, Hh, Hl, Bs + B_1A, wave, fr, fg);
+    PX_STAMP(2);
     steps<first_of(0) + 6, 8>(accf, wq, a, w, Hh, Hl, fr, fg);
+    PX_STAMP(3);
     layer1<1>(wq, a, w, Ah, Al, Hh, Hl, Bs + B_1A + 256, wave, fr, fg);
+    PX_STAMP(4);
     steps<first_of(1) + 6, 8>(accf, wq, a, w, Hh, Hl, fr, fg);
+    PX_STAMP(5);
     layer1<2>(wq, a, w, Ah, Al, Hh, Hl, Bs + B_1A + 512, wave, fr, fg);
+    PX_STAMP(6);
     steps<first_of(2) + 6, 8>(accf, wq, a, w, Hh, Hl, fr, fg);
+    PX_STAMP(7);
+    // the feature rows of the tile (256 channels = 32 chunks per row, gathered through row_index) are requested a whole part ahead: they travel
+    // under the MFMAs of layer 1 (stamps of the first version: 22 k of a block's 145 k cycles waited for them right here)
+    Stage<32> fs;
+    fs.load(p.Xmap, C, p.row_index, m0, M, tid);
     layer1<3>(wq, a, w, Ah, Al, Hh, Hl, Bs + B_1A + 768, wave, fr, fg);        // after its barrier nobody reads the frustum images any more
-    // the feature rows of the tile (256 channels = 32 chunks per row) replace them; other waves may still run the last layer 2 (hidden images only)
-    stage_rows<32>(p.Xmap, C, p.row_index, m0, M, Ah, Al, tid);
+    PX_STAMP(8);
+    fs.commit(Ah, Al, tid);                            // other waves may still run the last layer 2 (hidden images only)
+    PX_STAMP(9);
     steps<first_of(3) + 6, 8>(accf, wq, a, w, Hh, Hl, fr, fg);
+    PX_STAMP(10);
     __syncthreads();                                   // the feature tile is in the A images (and the last layer 2 is done with the hidden tile)
+    PX_STAMP(11);
     // ---- 2. the gate
     f32x4_t acc[RT][CT];
     {
@@ -247,6 +275,7 @@ __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
         }
         __syncthreads();
     }
+    PX_STAMP(12);
     // read-back mapping of the output phase: lane -> (row r0 + 8 k, columns c4..c4+3 of 32); the row indices travel under layer 2
     constexpr int NK = BM / 8;
     const int c4 = (lane & 7) * 4, r0 = lane >> 3;
@@ -256,8 +285,21 @@ __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
         const int m = min(m0 + 8 * k + r0, M - 1);
         ri[k] = p.row_index ? p.row_index[m] : m;
     }
+    // the table rows (and, T path, the fp32 feature rows) of the first 32 output columns are requested before the gate's second layer
+    const bool rows16 = p.Xk_hi != nullptr;
+    float4 tvq[NK], fvq[NK];
+    auto request = [&](int jp) {
+        const long long gcol = wave * CT * 16 + jp * 32 + c4;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            tvq[k] = *reinterpret_cast<const float4*>(p.sine_tab + (long long)(ri[k] % p.tab_period) * C + gcol);
+            if (rows16) fvq[k] = *reinterpret_cast<const float4*>(p.Xmap + (long long)ri[k] * C + gcol);
+        }
+    };
+    request(0);
     zero_acc(acc);
     steps<first_of(4) + 8, 8>(acc, wq, a, w, Hh, Hl, fr, fg);
+    PX_STAMP(13);
     // ---- 3. pe = tab + (P1 + b) * gate; T path: Xk = pe + feat, Xv = feat as key16 hi + lo pairs.  Through a wave-private LDS tile
     // [BM rows][32 columns], then whole 128-byte row pieces.  The sigmoid in place, the bias of P1:
 #pragma unroll
@@ -273,8 +315,8 @@ __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
         }
     }
     __syncthreads();                                   // all LDS images free: they become the waves' output tiles
+    PX_STAMP(14);
     float* ot = reinterpret_cast<float*>(smem) + wave * (BM * OT_PITCH);
-    const bool rows16 = p.Xk_hi != nullptr;
 #pragma unroll
     for (int jp = 0; jp < CT / 2; ++jp) {               // 32 columns (two column tiles) at a time
         if (jp > 0) __builtin_amdgcn_wave_barrier();
@@ -290,12 +332,12 @@ __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
         for (int k = 0; k < NK; ++k) {
             const int row = 8 * k + r0, m = m0 + row;
             float4 v = *reinterpret_cast<const float4*>(ot + row * OT_PITCH + c4);
-            const float4 tv = *reinterpret_cast<const float4*>(p.sine_tab + (long long)(ri[k] % p.tab_period) * C + gcol);
+            const float4 tv = tvq[k];
             v = make_float4(v.x + tv.x, v.y + tv.y, v.z + tv.z, v.w + tv.w);
             if (m < M) {
                 if (p.pe) *reinterpret_cast<float4*>(p.pe + (long long)m * C + gcol) = v;
                 if (rows16) {
-                    const float4 f = *reinterpret_cast<const float4*>(p.Xmap + (long long)ri[k] * C + gcol);
+                    const float4 f = fvq[k];
                     uint2 h, l;
                     split_k16x2(v.x + f.x, v.y + f.y, h.x, l.x);
                     split_k16x2(v.z + f.z, v.w + f.w, h.y, l.y);
@@ -308,10 +350,16 @@ __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
                 }
             }
         }
+        if (jp + 1 < CT / 2) request(jp + 1);
+        PX_STAMP(15 + jp);
     }
 }
 
 }  // namespace
+
+#ifdef MV2D_PX_TRACE
+extern "C" int mv2d_px_trace_read(long long* host, int n) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_px_trace), n * sizeof(long long)) == hipSuccess ? 0 : -2; }
+#endif
 
 // C-ABI: include/mv2d_hip.h
 extern "C" int mv2d_pe_fused_x3(const float* A1, const float* Xmap, const int* row_index, const int* m_dev, int M,
