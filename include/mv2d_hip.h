@@ -313,8 +313,10 @@ int mv2d_xattn_ctxmap(const float* z, const void* WB_hi, const void* WB_lo, cons
                       int empty_nan, void* stream);
 
 /* T path (masked-map cross attention, RH/mv2d_t_head.py:79-109), launch order of the per-query blocks (csrc/xattn_order.hip): perm [R] = the rows of every sample sorted by their smallest key index (CSR rows ascending, as mv2d_mask_compact writes
- * them); flags[0] != 0: more than 4096 queries in a sample (natural order kept).  For mv2d_xattn_tile_fwd_ordered. */
-int mv2d_xattn_query_order(const int* row_ptr, const int* col_idx, const int* grp_start, int n_samples, int R, int* perm, int* flags, void* stream);
+ * them; stride = 0) -- or, stride > 0 (S path: 49), by the smallest of every stride-th entry (the first cell of every RoI a row lists);
+ * flags[0] != 0: more than 4096 queries in a sample (natural order kept).  For mv2d_xattn_tile_fwd_ordered. */
+int mv2d_xattn_query_order(const int* row_ptr, const int* col_idx, const int* grp_start, int n_samples, int R, int* perm, int* flags, int stride,
+                           void* stream);
 /* The two row kernels around the tile cross attention with its per-head maps fused in (one launch each instead of two; bitwise the
  * same results):
  * mv2d_attn_out_qmap_x3 = mv2d_attn_out_fused_x3 (out_proj + residual + LayerNorm of the self attention, cross-attention q projection)
@@ -414,10 +416,12 @@ int mv2d_roi_positions(const float* rois, const unsigned char* pad_mask, unsigne
 /* S-path CSR over the RoI-feature memory rows r*49+cell (RH/mv2d_s_head.py:184-192). */
 int mv2d_csr_from_corr(const int* match, int* row_ptr, int* col_idx, int* nnz_out, int R, int V, int topk, void* stream);
 /* mv2d_roi_positions + mv2d_csr_from_corr in two launches instead of three (the position scan and the CSR run side by side in one): V = all
- * views of the maps, Vg = views per sample (match is [R, Vg, topk]); Vg * topk < 64. */
+ * views of the maps, Vg = views per sample (match is [R, Vg, topk]); Vg * topk < 64.  order (optional, with grp_start [n_samples + 1]): the
+ * launch order of the attention blocks for mv2d_xattn_tile_fwd_ordered from the same launch -- the queries of every sample ranked by the
+ * smallest RoI they list (own or matched), so that matched RoIs of different views share an L2. */
 int mv2d_roi_positions_csr(const float* rois, const unsigned char* pad_mask, unsigned char* roi_mask, int* rect, int* pos2s, int* s2pos,
                            int* S_out, int R, int V, int h, int w, float stride, float expand_stride, const int* match, int* row_ptr,
-                           int* col_idx, int* nnz_out, int Vg, int topk, void* stream);
+                           int* col_idx, int* nnz_out, int Vg, int topk, const int* grp_start, int n_samples, int* order, void* stream);
 
 /* PE inputs at the listed key positions only (MU/pe.py:84-135 frustum, MU/positional_encoding.py:78-95 sine) + feature gather.
  * out: A_frustum [S,3*D] key16, A_sine [S,384] key16, Xf_k16 [S,256] key16, Xf_f32 [S,256] (optional: NULL when mv2d_pe_fused_tab reads the map).

@@ -71,7 +71,7 @@ SIGNATURES = {
     'mv2d_xattn_tile_fwd': (I, [P, P, P, P, P, P, P, P, P, LL, I, I, I, P]),
     'mv2d_xattn_tile_fwd_ex': (I, [P, P, P, P, P, P, P, P, P, LL, I, I, I, P, I, P]),
     'mv2d_xattn_tile_fwd_ordered': (I, [P, P, P, P, P, P, P, P, P, LL, I, I, I, P, P]),
-    'mv2d_xattn_query_order': (I, [P, P, P, I, I, P, P, P]),
+    'mv2d_xattn_query_order': (I, [P, P, P, I, I, P, P, I, P]),
     'mv2d_xattn_ctxmap': (I, [P, P, P, P, P, P, I, I, P]),
     'mv2d_box_params': (I, [P, P, P, P, P, I, P, I, F, F, F, P]),
     'mv2d_refpoint_posemb': (I, [P, I, P, P, P, P, P, I, P, P]),
@@ -84,7 +84,7 @@ SIGNATURES = {
     'mv2d_mask_compact': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, I, P]),
     'mv2d_roi_positions': (I, [P, P, P, P, P, P, P, I, I, I, I, F, F, P]),
     'mv2d_csr_from_corr': (I, [P, P, P, P, I, I, I, P]),
-    'mv2d_roi_positions_csr': (I, [P, P, P, P, P, P, P, I, I, I, I, F, F, P, P, P, P, I, I, P]),
+    'mv2d_roi_positions_csr': (I, [P, P, P, P, P, P, P, I, I, I, I, F, F, P, P, P, P, I, I, P, I, P, P]),
     'mv2d_frame_geometry': (I, [P, P, P, P, P, I, P, F, F, F, P, P, P, P, P, I, I, I, I, I, I, I, F, F, F, I, P, LL, P]),
     'mv2d_pe_inputs': (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
     'mv2d_result_pack': (I, [P, P, P, P, F, I, P, P, P, P, I, I, P]),

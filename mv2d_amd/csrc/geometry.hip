@@ -717,13 +717,53 @@ __global__ __launch_bounds__(1024) void csr_from_corr_kernel(const int* __restri
     csr_from_corr_block(blockIdx.x, match, row_ptr, col_idx, nnz_out, R, nm);
 }
 
-// S path: the scan of the RoI-tap positions and the CSR over the correlated RoIs are independent: one launch, block roles by index
+// S path, launch order of the attention blocks (xattn_tile_kernel's `order`): the queries of a sample ranked by the SMALLEST RoI they list (own
+// RoI or a matched one) -- RoIs of different views that are matched with each other then run side by side on one XCD and share its L2
+// (round 4: the overlapping-rig workload re-fetched 1.86 x its distinct key rows from HBM in the natural order).  Same ranking as
+// query_order_kernel (xattn_order.hip), with the key taken straight from the correlation lists: no CSR needed, so it rides in the same
+// launch.  Groups: sample g = rows [grp_start[g], grp_start[g+1]); the bucket-padding rows behind the last sample keep their places.
+constexpr int SORD_MAX = 4096, SORD_CHUNK = 128;
+__device__ __forceinline__ void s_order_block(int g, int chunk, const int* __restrict__ match, const int* __restrict__ grp_start, int n_grp, int R, int nm,
+                                              int* __restrict__ perm) {
+    __shared__ int key[SORD_MAX];
+    const int tid = threadIdx.x;
+    const int lo = g < n_grp ? grp_start[g] : grp_start[n_grp];
+    const int hi = g < n_grp ? grp_start[g + 1] : R;
+    const int n = hi - lo;
+    if (n > SORD_MAX || g >= n_grp) {                          // too many queries for the LDS ranking / padding rows: natural order
+        if (chunk == 0) for (int i = tid; i < n; i += 1024) perm[lo + i] = lo + i;
+        return;
+    }
+    if (chunk * SORD_CHUNK >= n) return;
+    for (int i = tid; i < n; i += 1024) {
+        int k = lo + i;
+        for (int j = 0; j < nm; ++j) { const int m = match[(long long)(lo + i) * nm + j]; if (m >= 0) k = min(k, m); }
+        key[i] = k;
+    }
+    __syncthreads();
+    const int i = chunk * SORD_CHUNK + (tid >> 3), sub = tid & 7;
+    int rank = 0;
+    if (i < n) {
+        const int ki = key[i];
+        for (int j = sub; j < n; j += 8) { const int kj = key[j]; rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
+    }
+    rank += __shfl_xor(rank, 1);
+    rank += __shfl_xor(rank, 2);
+    rank += __shfl_xor(rank, 4);
+    if (i < n && sub == 0) perm[lo + rank] = lo + i;
+}
+
+// S path: the scan of the RoI-tap positions, the CSR over the correlated RoIs and the launch order of the attention blocks are independent:
+// one launch, block roles by index
 __global__ __launch_bounds__(1024) void scan_and_csr_kernel(const unsigned char* __restrict__ roi_mask, const unsigned char* __restrict__ pad_mask,
                                                             int* __restrict__ pos2s, int* __restrict__ s2pos, int* __restrict__ S_out, int P, int nscan,
                                                             const int* __restrict__ match, int* __restrict__ row_ptr, int* __restrict__ col_idx,
-                                                            int* __restrict__ nnz_out, int R, int nm) {
-    if ((int)blockIdx.x < nscan) csr_scan_positions_block(blockIdx.x, nscan, roi_mask, pad_mask, pos2s, s2pos, S_out, P);
-    else csr_from_corr_block(blockIdx.x - nscan, match, row_ptr, col_idx, nnz_out, R, nm);
+                                                            int* __restrict__ nnz_out, int R, int nm, int ncsr, const int* __restrict__ grp_start, int n_grp,
+                                                            int ord_chunks, int* __restrict__ perm) {
+    const int b = blockIdx.x;
+    if (b < nscan) csr_scan_positions_block(b, nscan, roi_mask, pad_mask, pos2s, s2pos, S_out, P);
+    else if (b < nscan + ncsr) csr_from_corr_block(b - nscan, match, row_ptr, col_idx, nnz_out, R, nm);
+    else s_order_block((b - nscan - ncsr) / ord_chunks, (b - nscan - ncsr) % ord_chunks, match, grp_start, n_grp, R, nm, perm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1171,14 +1211,16 @@ extern "C" int mv2d_csr_from_corr(const int* match, int* row_ptr, int* col_idx, 
 // mv2d_roi_positions + mv2d_csr_from_corr (S path) in TWO launches instead of three: the mark kernel, then the position scan and the CSR side by side
 extern "C" int mv2d_roi_positions_csr(const float* rois, const unsigned char* pad_mask, unsigned char* roi_mask, int* rect, int* pos2s, int* s2pos,
                                       int* S_out, int R, int V, int h, int w, float stride, float expand_stride, const int* match, int* row_ptr,
-                                      int* col_idx, int* nnz_out, int Vg, int topk, void* stream) {
+                                      int* col_idx, int* nnz_out, int Vg, int topk, const int* grp_start, int n_samples, int* order, void* stream) {
+    MV2D_CHECK_ARG(!order || (grp_start && n_samples >= 1), "mv2d_roi_positions_csr: the block order needs the sample row ranges");
     MV2D_CHECK_ARG(rois && pad_mask && roi_mask && rect && pos2s && s2pos && S_out && R > 0, "mv2d_roi_positions_csr: bad args");
     MV2D_CHECK_ARG(match && row_ptr && col_idx && nnz_out && Vg * topk < 64, "mv2d_roi_positions_csr: bad CSR args (views per sample * topk < 64)");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(csr_mark_kernel, dim3(R), dim3(64), 0, st, rois, rect, roi_mask, h, w, stride, expand_stride);
-    const int nscan = cdiv(V * h * w, SCAN_SEG);
-    hipLaunchKernelGGL(scan_and_csr_kernel, dim3(nscan + cdiv(R, CFC_ROWS)), dim3(1024), 0, st, roi_mask, pad_mask, pos2s, s2pos, S_out, V * h * w, nscan,
-                       match, row_ptr, col_idx, nnz_out, R, Vg * topk);
+    const int nscan = cdiv(V * h * w, SCAN_SEG), ncsr = cdiv(R, CFC_ROWS);
+    const int ord_chunks = cdiv(R < SORD_MAX ? R : SORD_MAX, SORD_CHUNK), nord = order ? (n_samples + 1) * ord_chunks : 0;
+    hipLaunchKernelGGL(scan_and_csr_kernel, dim3(nscan + ncsr + nord), dim3(1024), 0, st, roi_mask, pad_mask, pos2s, s2pos, S_out, V * h * w, nscan,
+                       match, row_ptr, col_idx, nnz_out, R, Vg * topk, ncsr, grp_start, n_samples, ord_chunks, order);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -21,7 +21,7 @@ constexpr int ORD_CHUNK = 128;               // queries ranked per block (8 thre
 // grid (groups, chunks of ORD_CHUNK queries): every block holds the group's keys in LDS and ranks its chunk, 8 threads per query
 // (one block per group took 39 us for the ~950-query samples of cfg5_t)
 __global__ __launch_bounds__(1024) void query_order_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col_idx, const int* __restrict__ grp_start,
-                                                           int n_grp, int R, int* __restrict__ perm, int* __restrict__ flags) {
+                                                           int n_grp, int R, int* __restrict__ perm, int* __restrict__ flags, int stride) {
     __shared__ int key[GRP_MAX];
     const int g = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
     const int lo = g < n_grp ? grp_start[g] : grp_start[n_grp];
@@ -37,7 +37,10 @@ __global__ __launch_bounds__(1024) void query_order_kernel(const int* __restrict
     if (chunk * ORD_CHUNK >= n) return;
     for (int i = tid; i < n; i += 1024) {
         const int b = row_ptr[lo + i], e = row_ptr[lo + i + 1];
-        key[i] = e > b ? col_idx[b] : 0x7fffffff;              // the CSR rows are ascending: the first entry is the smallest key
+        int k = e > b ? col_idx[b] : 0x7fffffff;               // T path: the CSR rows are ascending, the first entry is the smallest key
+        // S path (stride = 49): a row lists whole RoIs (own RoI first, then the matched ones in view order): the smallest first cell
+        if (stride > 0) for (int q = b + stride; q < e; q += stride) k = min(k, col_idx[q]);
+        key[i] = k;
     }
     __syncthreads();
     const int i = chunk * ORD_CHUNK + (tid >> 3), sub = tid & 7;
@@ -55,13 +58,16 @@ __global__ __launch_bounds__(1024) void query_order_kernel(const int* __restrict
 }  // namespace
 
 // perm [R] = the queries of every sample sorted by their smallest key (bucket-padding rows behind the last sample keep their places as a
-// group of their own); flags [>= 1] int32, zeroed by the caller: flags[0] != 0 afterwards = a sample had more than 4096 queries and kept its
+// group of their own); stride = 0: the first entry of a CSR row is its smallest key (T path: ascending rows); stride > 0: the minimum over
+// every stride-th entry (S path, stride 49: the first cell of every RoI a row lists -- queries of RoIs that are matched with each other
+// then sit side by side, round 4: the overlapping-rig workload re-fetched 1.86 x its distinct rows from HBM in the natural order); flags [>= 1] int32, zeroed by the caller: flags[0] != 0 afterwards = a sample had more than 4096 queries and kept its
 // natural order (any order is correct).
-extern "C" int mv2d_xattn_query_order(const int* row_ptr, const int* col_idx, const int* grp_start, int n_samples, int R, int* perm, int* flags, void* stream) {
-    MV2D_CHECK_ARG(row_ptr && col_idx && grp_start && perm && flags && R > 0 && n_samples >= 1, "mv2d_xattn_query_order: bad args");
+extern "C" int mv2d_xattn_query_order(const int* row_ptr, const int* col_idx, const int* grp_start, int n_samples, int R, int* perm, int* flags, int stride,
+                                      void* stream) {
+    MV2D_CHECK_ARG(row_ptr && col_idx && grp_start && perm && flags && R > 0 && n_samples >= 1 && stride >= 0, "mv2d_xattn_query_order: bad args");
     const int n = R < GRP_MAX ? R : GRP_MAX;
     hipLaunchKernelGGL(query_order_kernel, dim3(n_samples + 1, (n + ORD_CHUNK - 1) / ORD_CHUNK), dim3(1024), 0, (hipStream_t)stream, row_ptr, col_idx,
-                       grp_start, n_samples, R, perm, flags);
+                       grp_start, n_samples, R, perm, flags, stride);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -93,7 +93,9 @@ class HeadEngine:
         self.keep_xk = False          # always write both pe and Xk (S path: nothing reads Xk; T path: nothing reads pe)
         # T path: the blocks of the per-query tile kernel run in the order of the queries' SMALLEST KEY (mv2d_xattn_query_order): neighbouring
         # blocks of an XCD then read overlapping key sets from its L2 (cfg3_t 54.8 -> 47.6 us per layer; bitwise the same results)
-        self.q_order = kind == 'T'
+        # S path (round 4): the queries ranked by the smallest RoI they list (own or matched; computed from the correlation lists inside the
+        # launch that builds the CSR) -- matched RoIs of different views then run side by side; a no-op for queries that read only their own RoI
+        self.q_order = True
         # waves per query of the tile kernel: the kernel alone takes the same time with 1, 2 or 4 (it is bound by what the memory system
         # delivers), but a launch with fewer waves leaves more of the chip to the other streams' kernels: cfg2_s 8067 / 8043 / 7869
         # samples/s for 1 / 2 / 4, cfg3_t (rows of ~200 keys) 5803 / 5868 / 5758
@@ -303,11 +305,11 @@ class HeadEngine:
             ws['row_count'] = e(R, torch.int32)
             ws['col_cap'] = R * self.col_cap_per_query
             ws['S_kv'] = P
-            ws['q_order'] = alloc(R, torch.int32, zero=True) if self.q_order else None
         else:
             ws['col_cap'] = R * (1 + Vg * self.topk) * 49
             ws['S_kv'] = R * 49
             ws['roi_sum'] = e((R, 49, C), K16)
+        ws['q_order'] = alloc(R, torch.int32, zero=True) if self.q_order else None
         ws['col_idx'] = e(ws['col_cap'], torch.int32)
         # key16 rows of the PE block's inputs: frustum [.,192], sine [.,384] (training route only: the inference kernel reads the folded
         # table), feature rows [.,256] (the SE gate's input; the value rows of the T path)
@@ -543,9 +545,11 @@ class HeadEngine:
                         fmh[:, j - 1] = (ar + 37 * j) % R
                     fm = ws['forced_match'] = fmh.view(R, Vg, self.topk).to(self.dev)
                 ws['match'].copy_(fm)
-            # positions any RoIAlign tap can touch (own rect + 1 cell) -> PE only there; CSR over the correlated RoIs' feature rows
+            # positions any RoIAlign tap can touch (own rect + 1 cell) -> PE only there; CSR over the correlated RoIs' feature rows; launch order of
+            # the attention blocks (queries ranked by the smallest RoI they list)
             o.roi_positions_csr(rois, ws['zero_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'], R, V, h, w, ws['match'],
-                                ws['row_ptr'], ws['col_idx'], ws['nnz'], Vg, self.topk, stride=self.stride, expand_stride=1.0)
+                                ws['row_ptr'], ws['col_idx'], ws['nnz'], Vg, self.topk, stride=self.stride, expand_stride=1.0, grp_start=grp,
+                                order=ws.get('q_order') if self.q_order else None)
         md = ws['S_dev']
         # a2: PE at the listed positions only
         if self.exact and 'pe' not in self.exact_skip:

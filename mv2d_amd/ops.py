@@ -556,9 +556,10 @@ def xattn_tile(Qt, Xk, Xv, row_ptr, col_idx, out=None, R=None, dbg_logits=None, 
     return out
 
 
-def xattn_query_order(row_ptr, col_idx, grp_start, R, perm, flags):
-    """perm [R] int32 = the query rows of every sample (grp_start [n+1], device) sorted by their smallest key; flags int32 [>=1] (zeroed by the caller)."""
-    check(_lib.load().mv2d_xattn_query_order(_p(row_ptr), _p(col_idx), _p(grp_start), grp_start.numel() - 1, R, _p(perm), _p(flags), _stream()),
+def xattn_query_order(row_ptr, col_idx, grp_start, R, perm, flags, stride=0):
+    """perm [R] int32 = the query rows of every sample (grp_start [n+1], device) sorted by their smallest key (stride 0: the first entry of a
+    CSR row; stride 49: the smallest first cell of the RoIs an S-path row lists); flags int32 [>=1] (zeroed by the caller)."""
+    check(_lib.load().mv2d_xattn_query_order(_p(row_ptr), _p(col_idx), _p(grp_start), grp_start.numel() - 1, R, _p(perm), _p(flags), int(stride), _stream()),
           'mv2d_xattn_query_order')
     return perm
 
@@ -727,10 +728,12 @@ def roi_positions(rois, pad_mask, roi_mask, rect, pos2s, s2pos, S_out, R, V, h, 
 
 
 def roi_positions_csr(rois, pad_mask, roi_mask, rect, pos2s, s2pos, S_out, R, V, h, w, match, row_ptr, col_idx, nnz_out, Vg, topk, stride=16.0,
-                      expand_stride=1.0):
-    """roi_positions + csr_from_corr (S path) in two launches."""
+                      expand_stride=1.0, grp_start=None, order=None):
+    """roi_positions + csr_from_corr (S path) in two launches; order (int32 [R]) + grp_start: also the launch order of the attention blocks."""
+    _req(order, torch.int32, 'order'); _req(grp_start, torch.int32, 'grp_start')
     check(_lib.load().mv2d_roi_positions_csr(_p(rois), _p(pad_mask), _p(roi_mask), _p(rect), _p(pos2s), _p(s2pos), _p(S_out), R, V, h, w, float(stride),
-                                             float(expand_stride), _p(match), _p(row_ptr), _p(col_idx), _p(nnz_out), Vg, topk, _stream()),
+                                             float(expand_stride), _p(match), _p(row_ptr), _p(col_idx), _p(nnz_out), Vg, topk, _p(grp_start),
+                                             grp_start.numel() - 1 if grp_start is not None else 0, _p(order), _stream()),
           'mv2d_roi_positions_csr')
 
 

@@ -584,16 +584,18 @@ def test_last_stage_heads_option(name, kind):
     assert torch.equal(ok['cls'], oa['cls'])
 
 
-@pytest.mark.parametrize('name,n', [('micro_t', 1), ('cfg1_t', 3), ('cfg3_t', 2)])
-def test_query_order_of_the_t_path(name, n):
-    """T path: mv2d_xattn_query_order ranks the queries of every sample by their smallest key (csrc/xattn_order.hip); the tile kernel launched
-    in that order gives bitwise the rows of the natural order (the order only decides which blocks share an L2)."""
+@pytest.mark.parametrize('name,n', [('micro_t', 1), ('cfg1_t', 3), ('cfg3_t', 2), ('nc6_s', 3), ('cfg1_s', 2)])
+def test_query_order_of_the_attention_blocks(name, n):
+    """The launch order of the per-query attention blocks: T path -- mv2d_xattn_query_order ranks the queries of every sample by their smallest
+    key (csrc/xattn_order.hip); S path -- by the smallest RoI they list, own or matched (computed from the correlation lists inside the CSR
+    launch).  The tile kernel launched in that order gives bitwise the rows of the natural order (the order only decides which blocks share an L2)."""
     from mv2d_amd import ops
     from mv2d_amd.engine import HeadEngine
     dev = torch.device('cuda:0')
     sd = synthetic.make_head_state(seed=0)
     probs = [synthetic.make_problem(name, seed=s) for s in range(n)]
-    eng = HeadEngine(sd, 'T', dev, num_views=probs[0]['views_per_frame'])
+    kind = probs[0]['kind']
+    eng = HeadEngine(sd, kind, dev, num_views=probs[0]['views_per_frame'])
     feats = [torch.from_numpy(p['feat']).to(dev) for p in probs]
     props = [[torch.from_numpy(x) for x in p['proposals']] for p in probs]
     metas = [p['img_metas'] for p in probs]
@@ -605,11 +607,18 @@ def test_query_order_of_the_t_path(name, n):
     perm = ws['q_order'].cpu().numpy()
     grp = list(ws['grp_start_h'].numpy()) + [Rl]
     assert sorted(perm[:Rl].tolist()) == list(range(Rl)) and int(ws['qt_ctl'][1].item()) == 0
-    for a, b in zip(grp[:-1], grp[1:]):                          # the order stays inside a sample and is ascending in the smallest key
+    for a, b in zip(grp[:-2], grp[1:-1]):                        # the order stays inside a sample and is ascending in the smallest key / RoI
         assert sorted(perm[a:b].tolist()) == list(range(a, b))
-        firsts = [ci[rp[r]] if rp[r + 1] > rp[r] else 2 ** 31 - 1 for r in perm[a:b]]
+        if kind == 'T':
+            firsts = [ci[rp[r]] if rp[r + 1] > rp[r] else 2 ** 31 - 1 for r in perm[a:b]]
+        else:
+            firsts = [int(ci[rp[r]:rp[r + 1]:49].min()) // 49 for r in perm[a:b]]
         assert firsts == sorted(firsts)
+    assert perm[grp[-2]:Rl].tolist() == list(range(grp[-2], Rl))        # bucket-padding rows keep their places
     z_t = ops.xattn_tile(ws['Qt'], ws['xk_rows'], ws['xv_rows'], ws['row_ptr'], ws['col_idx'], R=Rl, empty_nan=False, waves=2)
     z_o = ops.xattn_tile(ws['Qt'], ws['xk_rows'], ws['xv_rows'], ws['row_ptr'], ws['col_idx'], R=Rl, empty_nan=False, waves=2, order=ws['q_order'])
     assert torch.equal(z_o, z_t)
-
+    eng2 = HeadEngine(sd, kind, dev, num_views=probs[0]['views_per_frame'])
+    eng2.q_order = False
+    out2 = eng2.run_batch(feats, props, metas) if n > 1 else eng2.run(feats[0], props[0], metas[0])
+    assert torch.equal(out2['cls'], out['cls']) and torch.equal(out2['boxes'], out['boxes'])
