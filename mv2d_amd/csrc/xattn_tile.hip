@@ -269,9 +269,13 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
 #pragma unroll
         for (int s = 0; s < 8; ++s) qa[s].u = qp[s * 8];
     }
+    // the key indices of a tile are requested one tile AHEAD (round 4): a tile is two dependent round trips (index, then rows); the index trip of
+    // the next tile now runs under the current tile's gather and arithmetic (one register)
+    int idx_next = wave < ntile ? col_idx[min(beg + 16 * wave + n, end - 1)] : 0;
     for (int tt = wave; tt < ntile; tt += NW) {
         const int kbase = beg + 16 * tt;
-        const int myidx = col_idx[min(kbase + n, end - 1)];                          // lane (n, *): key n of the tile
+        const int myidx = idx_next;                                                  // lane (n, *): key n of the tile
+        if (tt + NW < ntile) idx_next = col_idx[min(kbase + 16 * NW + n, end - 1)];
         // ---- gather: Xk rows whole (lanes 0-31 one row, 32-63 the next), Xv rows as 16-byte column chunks of keys 4g..4g+3
         // (byte offsets as 32-bit unsigned: scalar base + vector offset addressing instead of 64-bit address arithmetic per row;
         //  the row arrays must stay below 4 GB = 2^23 rows, include/mv2d_hip.h)
