@@ -17,9 +17,6 @@ LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libmv2d_hip.so')
 OBJDIR = os.path.join(LIBDIR, 'obj')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-Wno-unused-value']
-# per-file extras: the tile attention issues ONE returning atomic per query and touches the result a whole query later; LLVM's atomic optimizer
-# would aggregate it over the wave (mbcnt / readfirstlane) and wait for it on the spot (csrc/xattn_tile.hip)
-EXTRA_FLAGS = {'xattn_tile.hip': ['-mllvm', '-amdgpu-atomic-optimizer-strategy=None']}
 
 
 def _hipcc():
@@ -39,7 +36,7 @@ def _digest():
         with open(os.path.join(CSRC, f), 'rb') as fh:
             h.update(f.encode())
             h.update(fh.read())
-    h.update((' '.join(FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
+    h.update(' '.join(FLAGS).encode())
     return h.hexdigest()
 
 
@@ -61,7 +58,7 @@ def build(force=False, verbose=True):
 
     def cc(src):
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + '.o')
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
+        cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed: %s\n%s' % (' '.join(cmd), r.stderr))

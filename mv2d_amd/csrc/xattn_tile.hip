@@ -252,26 +252,20 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
     int r = order ? order[xbase + bj] : xbase + bj;
     int beg = row_ptr[r], end = row_ptr[r + 1];
     int idx0 = (end > beg && wave < ((end - beg + 15) >> 4)) ? col_idx[min(beg + 16 * wave + n, end - 1)] : 0;
-    int ticket = 0;
     for (;;) {
     // ---- the next query's chain, stage 1: slot -> query; thread 0 claims the slot after next
     const bool has_nxt = j_nxt < xcount;
-    int r_n = 0, beg_n = 0, end_n = 0, idx0_n = 0;
+    int r_n = 0, beg_n = 0, end_n = 0, idx0_n = 0, j_claim = 0x7fffffff;
     if (has_nxt) r_n = order ? order[xbase + j_nxt] : xbase + j_nxt;
-    // The ticket atomic (thread 0) is issued BEHIND the first tile's gathers and its result is first touched right before the barrier that
-    // publishes it.  The vector-memory counter returns in order and the compiler waits for a load at its first use: an atomic issued at the
-    // top of the query sat in front of every wait of the first tile, and any use next to it -- even the addition of the offset, or the
-    // compiler's own wave-aggregation of atomics (off for this file: -amdgpu-atomic-optimizer-strategy=None) -- put an
-    // s_waitcnt vmcnt(0) at the top of every query.
+    if (tid == 0) j_claim = tickets ? 2 * gx + atomicAdd(&tickets[x], 1) : j_nxt + gx;
     bool got_rows = false;
     float* zr = z + (long long)r * (HEADS * C);
     if (end <= beg) {
         const float v = empty_nan ? __uint_as_float(0x7fc00000u) : 0.f;
         for (int i = tid; i < HEADS * C; i += 64 * NW) zr[i] = v;
-        if (tid == 0 && tickets) ticket = atomicAdd(&tickets[x], 1);
         if (has_nxt) { beg_n = row_ptr[r_n]; end_n = row_ptr[r_n + 1]; }
         if (has_nxt && end_n > beg_n && wave < ((end_n - beg_n + 15) >> 4)) idx0_n = col_idx[min(beg_n + 16 * wave + n, end_n - 1)];
-        if (tid == 0) s_claim = tickets ? 2 * gx + ticket : j_nxt + gx;
+        if (tid == 0) s_claim = j_claim;
         __syncthreads();
     } else {
     // this lane's rows of S / z: operand rows 4g + i; rows 0-7 carry the hi parts, 8-15 the lo parts of head (4 (g & 1) + i)
@@ -333,10 +327,8 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
             }
             load_v(Xv, vreg);
             load_v(Xv_lo, vlo);
-            if (tt == wave && tid == 0 && tickets) ticket = atomicAdd(&tickets[x], 1);
         } else {
             load_v(Xv, vreg);
-            if (tt == wave && tid == 0 && tickets) ticket = atomicAdd(&tickets[x], 1);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int rowi = 2 * i + (lane >> 5);
@@ -465,7 +457,7 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
                 *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             }
     }
-    if (tid == 0) s_claim = tickets ? 2 * gx + ticket : j_nxt + gx;
+    if (tid == 0) s_claim = j_claim;
     __syncthreads();
     // ---- merge the waves: thread -> (channel, half of the heads)
     {

@@ -5,8 +5,7 @@ name=$1; src=$2; shift 2
 cd "$(dirname "$0")/.."
 mkdir -p mv2d_amd/lib/variants
 base=$(basename $src .hip)
-extra=""; [ "$base" = xattn_tile ] && extra="-mllvm -amdgpu-atomic-optimizer-strategy=None"      # as mv2d_amd/build.py EXTRA_FLAGS
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-value $extra "$@" -c mv2d_amd/csrc/$src -o mv2d_amd/lib/variants/${name}_$base.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-value "$@" -c mv2d_amd/csrc/$src -o mv2d_amd/lib/variants/${name}_$base.o
 objs=$(ls mv2d_amd/lib/obj/*.o | grep -v "/$base.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs mv2d_amd/lib/variants/${name}_$base.o -o mv2d_amd/lib/variants/lib$name.so
 rm mv2d_amd/lib/variants/${name}_$base.o
