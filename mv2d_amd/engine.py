@@ -551,7 +551,7 @@ class HeadEngine:
             # the attention blocks (queries ranked by the smallest RoI they list)
             o.roi_positions_csr(rois, ws['zero_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'], R, V, h, w, ws['match'],
                                 ws['row_ptr'], ws['col_idx'], ws['nnz'], Vg, self.topk, stride=self.stride, expand_stride=1.0, grp_start=grp,
-                                order=ws.get('q_order') if self.q_order else None)
+                                order=ws.get('q_order') if self.q_order else None, tickets=ws['tickets'][i] if ws.get('tickets') is not None else None)
         md = ws['S_dev']
         # a2: PE at the listed positions only
         if self.exact and 'pe' not in self.exact_skip:
@@ -656,7 +656,7 @@ class HeadEngine:
             o.xattn_tile(ws['Qt'], xk_rows, xv_rows, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=self.empty_nan, waves=self.xattn_waves,
                          Xk_lo=None if 'attn' in self.exact_skip else ws.get('xk_lo'), Xv_lo=None if 'attn' in self.exact_skip else ws.get('xv_lo'),
                          dbg_logits=None if dbg is None else dbg[i],
-                         order=ws.get('q_order') if self.q_order else None, tickets=ws['tickets'][i] if ws.get('tickets') is not None else None)
+                         order=ws.get('q_order') if self.q_order else None)
 
         # the decoder starts from target = 0 (cross_attention_head.py:32): layer 0 reads a constant zero buffer and qpos directly, from
         # layer 1 on x / xq are the buffers the fused FFN tail writes
