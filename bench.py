@@ -499,12 +499,11 @@ def main():
         xk, xv = ws['xk_rows'], ws['xv_rows']
         q_ord = ws.get('q_order')                          # T path: blocks in the order of the queries' smallest key (as the engine launches it)
         xlo = dict(Xk_lo=ws['xk_lo'], Xv_lo=ws['xv_lo']) if (getattr(eng, 'exact', False) and ws.get('xk_lo') is not None) else {}      # index-exact route: hi + lo rows
-        tk_ = torch.zeros((23, 8), dtype=torch.int32, device=dev)      # one zeroed set of ticket counters per launch (as the engine passes them)
-        for i_ in range(3):
-            ops.xattn_tile(ws['Qt'], xk, xv, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=eng.empty_nan, waves=eng.xattn_waves, order=q_ord, tickets=tk_[i_], **xlo)
+        for _ in range(3):
+            ops.xattn_tile(ws['Qt'], xk, xv, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=eng.empty_nan, waves=eng.xattn_waves, order=q_ord, **xlo)
         e0.record()
-        for i_ in range(20):
-            ops.xattn_tile(ws['Qt'], xk, xv, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=eng.empty_nan, waves=eng.xattn_waves, order=q_ord, tickets=tk_[3 + i_], **xlo)
+        for _ in range(20):
+            ops.xattn_tile(ws['Qt'], xk, xv, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=eng.empty_nan, waves=eng.xattn_waves, order=q_ord, **xlo)
         e1.record()
         torch.cuda.synchronize()
         x_ms = e0.elapsed_time(e1) / 20

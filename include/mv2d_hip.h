@@ -304,15 +304,11 @@ int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* Xv, const vo
 int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                 const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
                                 const int* order, void* stream);
-/* ... and with a row pitch and dynamic work distribution.  The kernel runs PERSISTENT blocks (round 4: as many as fit the chip, each working
- * through queries while the next query's index chain resolves under the current one); tickets (optional): 8 int32 on the device, ZEROED by
- * the caller before every launch -- one counter per XCD from which the blocks claim their third and later queries (NULL: static round robin,
- * fine for rows of similar length).  Results do not depend on the distribution.
- * Row r of Xk / Xv / Xk_lo / Xv_lo starts at byte r * row_bytes (>= 512, a multiple of 16).  The index-exact route
+/* ... and with a row pitch: row r of Xk / Xv / Xk_lo / Xv_lo starts at byte r * row_bytes (>= 512, a multiple of 16).  The index-exact route
  * interleaves the hi and lo halves of a row (Xk_lo = Xk + 256 elements, row_bytes = 1024): one 1 KB stretch of DRAM per key instead of two. */
 int mv2d_xattn_tile_fwd_ex(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                            const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
-                           const int* order, int row_bytes, int* tickets, void* stream);
+                           const int* order, int row_bytes, void* stream);
 int mv2d_xattn_ctxmap(const float* z, const void* WB_hi, const void* WB_lo, const float* bv, const int* row_ptr, float* ctx, int R,
                       int empty_nan, void* stream);
 

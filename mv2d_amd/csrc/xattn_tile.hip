@@ -229,45 +229,31 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
                                                              const unsigned short* __restrict__ Xv_lo, const int* __restrict__ row_ptr,
                                                              const int* __restrict__ col_idx, float* __restrict__ z,
                                                              float* __restrict__ dbg_logits, long long dbg_stride, int R, int empty_nan,
-                                                             const int* __restrict__ order, unsigned int row_bytes, int* __restrict__ tickets) {
+                                                             const int* __restrict__ order, unsigned int row_bytes) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[NW * 8192 + NW * 512 + NW * 64 + (XLO ? NW * 8192 : 0)];
-    __shared__ int s_claim;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
-    // PERSISTENT blocks (round 4).  A query used to be one block: slot -> order -> row_ptr -> col_idx -> rows, four dependent round trips
-    // before the first MFMA of a block that then computes for a microsecond.  Now a block works through queries: while it processes one,
-    // the chain of the NEXT one (query id, row range, first key indices) resolves under it, and thread 0 claims the slot after next from a
-    // per-XCD ticket counter (dynamic: rows differ in length by 400 x on the T path).
-    // XCD-aware slot -> query map (block b runs on XCD b % 8): every XCD owns one contiguous range of the (optionally ordered: T path by
-    // smallest key, S path by smallest listed RoI) queries, so neighbouring queries share an L2.  Speed only; any map is correct.
-    const int b = blockIdx.x, x = b & 7, qn = R >> 3, rem = R & 7;
-    const int xbase = x < rem ? x * (qn + 1) : rem * (qn + 1) + (x - rem) * qn, xcount = qn + (x < rem ? 1 : 0);
-    const int gx = ((int)gridDim.x + 7 - x) >> 3, bj = b >> 3;          // blocks on this XCD, this block's index among them
-    uint4* kt = reinterpret_cast<uint4*>(smem) + wave * 512;
-    float* pl = reinterpret_cast<float*>(smem + NW * 8192) + wave * 128;
-    float* sst = reinterpret_cast<float*>(smem + NW * 8192 + NW * 512);              // [NW][8] running max, [NW][8] sums
-    uint4* kt2 = reinterpret_cast<uint4*>(smem + NW * 8192 + NW * 512 + NW * 64) + wave * 512;      // XLO: the lo parts of the key tile
-    // slots bj and gx + bj are this block's by construction; from the third on they are claimed (tickets == nullptr: static stride gx)
-    int j_nxt = bj + gx;
-    if (bj >= xcount) return;
-    int r = order ? order[xbase + bj] : xbase + bj;
-    int beg = row_ptr[r], end = row_ptr[r + 1];
-    int idx0 = (end > beg && wave < ((end - beg + 15) >> 4)) ? col_idx[min(beg + 16 * wave + n, end - 1)] : 0;
-    for (;;) {
-    // ---- the next query's chain, stage 1: slot -> query; thread 0 claims the slot after next
-    const bool has_nxt = j_nxt < xcount;
-    int r_n = 0, beg_n = 0, end_n = 0, idx0_n = 0, j_claim = 0x7fffffff;
-    if (has_nxt) r_n = order ? order[xbase + j_nxt] : xbase + j_nxt;
-    if (tid == 0) j_claim = tickets ? 2 * gx + atomicAdd(&tickets[x], 1) : j_nxt + gx;
-    bool got_rows = false;
+    // XCD-aware block -> query map (block b runs on XCD b % 8): every XCD gets one contiguous range of queries, so neighbouring
+    // queries (T path: overlapping key sets) share an L2.  Speed only; any map is correct.
+    int r;
+    {
+        const int b = blockIdx.x, x = b & 7, qn = R >> 3, rem = R & 7;
+        r = (x < rem ? x * (qn + 1) : rem * (qn + 1) + (x - rem) * qn) + (b >> 3);
+        // optional query order (T path: the queries of a sample sorted by their smallest key, mv2d_xattn_qtile_build's perm): blocks that run
+        // side by side on an XCD then read overlapping key sets and share its L2.  Speed only.
+        if (order) r = order[r];
+    }
+    const int beg = row_ptr[r], end = row_ptr[r + 1];
     float* zr = z + (long long)r * (HEADS * C);
     if (end <= beg) {
         const float v = empty_nan ? __uint_as_float(0x7fc00000u) : 0.f;
         for (int i = tid; i < HEADS * C; i += 64 * NW) zr[i] = v;
-        if (has_nxt) { beg_n = row_ptr[r_n]; end_n = row_ptr[r_n + 1]; }
-        if (has_nxt && end_n > beg_n && wave < ((end_n - beg_n + 15) >> 4)) idx0_n = col_idx[min(beg_n + 16 * wave + n, end_n - 1)];
-        if (tid == 0) s_claim = j_claim;
-        __syncthreads();
-    } else {
+        return;
+    }
+    uint4* kt = reinterpret_cast<uint4*>(smem) + wave * 512;
+    float* pl = reinterpret_cast<float*>(smem + NW * 8192) + wave * 128;
+    float* sst = reinterpret_cast<float*>(smem + NW * 8192 + NW * 512);              // [NW][8] running max, [NW][8] sums
+    uint4* kt2 = reinterpret_cast<uint4*>(smem + NW * 8192 + NW * 512 + NW * 64) + wave * 512;      // XLO: the lo parts of the key tile
+
     // this lane's rows of S / z: operand rows 4g + i; rows 0-7 carry the hi parts, 8-15 the lo parts of head (4 (g & 1) + i)
     float m_run[4], l_run[4];
     f32x4_t Z[16];
@@ -285,7 +271,7 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
     }
     // the key indices of a tile are requested one tile AHEAD (round 4): a tile is two dependent round trips (index, then rows); the index trip of
     // the next tile now runs under the current tile's gather and arithmetic (one register)
-    int idx_next = idx0;
+    int idx_next = wave < ntile ? col_idx[min(beg + 16 * wave + n, end - 1)] : 0;
     for (int tt = wave; tt < ntile; tt += NW) {
         const int kbase = beg + 16 * tt;
         const int myidx = idx_next;                                                  // lane (n, *): key n of the tile
@@ -415,12 +401,7 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
             }
         }
         __builtin_amdgcn_wave_barrier();                                             // before the next tile overwrites kt / pl
-        // the next query's chain, stage 2 (behind the first tile: its query id has arrived): row range
-        if (has_nxt && !got_rows) { beg_n = row_ptr[r_n]; end_n = row_ptr[r_n + 1]; got_rows = true; }
     }
-    if (has_nxt && !got_rows) { beg_n = row_ptr[r_n]; end_n = row_ptr[r_n + 1]; }
-    // stage 3: this wave's first key indices of the next query (consumed at the top of the next iteration; travels under the merge below)
-    if (has_nxt && end_n > beg_n && wave < ((end_n - beg_n + 15) >> 4)) idx0_n = col_idx[min(beg_n + 16 * wave + n, end_n - 1)];
     // ---- row sums over the 16 key lanes; partial (m, l, z) of the wave -> LDS (z into the wave's own key-tile region)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -457,7 +438,6 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
                 *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             }
     }
-    if (tid == 0) s_claim = j_claim;
     __syncthreads();
     // ---- merge the waves: thread -> (channel, half of the heads)
     {
@@ -477,12 +457,6 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
             zr[h * C + c] = num * __builtin_amdgcn_rcpf(den);
         }
     }
-    }   // (non-empty row)
-    if (!has_nxt) break;
-    const int j_nn = s_claim;
-    __syncthreads();                                         // the merge has read the LDS tiles / s_claim before the next query overwrites them
-    r = r_n; beg = beg_n; end = end_n; idx0 = idx0_n; j_nxt = j_nn;
-    }   // (queries of this block)
 }
 
 }  // namespace
@@ -514,7 +488,7 @@ extern "C" int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const
                                            const int* order, void* stream);
 extern "C" int mv2d_xattn_tile_fwd_ex(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                       const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
-                                      const int* order, int row_bytes, int* tickets, void* stream);
+                                      const int* order, int row_bytes, void* stream);
 
 extern "C" int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                    const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves, void* stream) {
@@ -524,12 +498,12 @@ extern "C" int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* X
 extern "C" int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                            const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
                                            const int* order, void* stream) {
-    return mv2d_xattn_tile_fwd_ex(Qt, Xk, Xv, Xk_lo, Xv_lo, row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan, waves, order, C * 2, nullptr, stream);
+    return mv2d_xattn_tile_fwd_ex(Qt, Xk, Xv, Xk_lo, Xv_lo, row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan, waves, order, C * 2, stream);
 }
 
 extern "C" int mv2d_xattn_tile_fwd_ex(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                       const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
-                                      const int* order, int row_bytes, int* tickets, void* stream) {
+                                      const int* order, int row_bytes, void* stream) {
     MV2D_CHECK_ARG(row_bytes >= C * 2 && (row_bytes % 16) == 0, "mv2d_xattn_tile_fwd_ex: row_bytes >= 512, a multiple of 16");
     MV2D_CHECK_ARG(Qt && Xk && Xv && row_ptr && col_idx && z && R >= 0, "mv2d_xattn_tile_fwd: bad args");
     MV2D_CHECK_ARG((Xk_lo == nullptr) == (Xv_lo == nullptr), "mv2d_xattn_tile_fwd: Xk_lo and Xv_lo come together");
@@ -538,13 +512,9 @@ extern "C" int mv2d_xattn_tile_fwd_ex(const void* Qt, const void* Xk, const void
     MV2D_CHECK_ARG(waves == 0 || waves == 1 || waves == 2 || waves == 4 || waves == 8, "mv2d_xattn_tile_fwd: waves per query must be 1, 2, 4 or 8 (0: default)");
     if (R == 0) return MV2D_OK;
     const int nw = waves ? waves : 2;      // the engine passes its own choice (2: see engine.py)
-    // persistent blocks: as many as fit the chip at two waves per SIMD (256 CUs x 8 waves / NW), a multiple of 8 (one share per XCD), at most one
-    // per query
-    const int fit = 256 * 8 / nw;
-    const int grid = R < fit ? ((R + 7) & ~7) : fit;
-#define MV2D_XT(NW, DBG, XLO) hipLaunchKernelGGL((xattn_tile_kernel<NW, DBG, XLO>), dim3(grid), dim3(64 * NW), 0, (hipStream_t)stream, (const uint4*)Qt, \
+#define MV2D_XT(NW, DBG, XLO) hipLaunchKernelGGL((xattn_tile_kernel<NW, DBG, XLO>), dim3(R), dim3(64 * NW), 0, (hipStream_t)stream, (const uint4*)Qt, \
                                                  (const unsigned short*)Xk, (const unsigned short*)Xv, (const unsigned short*)Xk_lo, (const unsigned short*)Xv_lo, \
-                                                 row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan, order, (unsigned int)row_bytes, tickets)
+                                                 row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan, order, (unsigned int)row_bytes)
     // index-exact route (hi + lo rows): two waves per SIMD like the default (round 3: the 312-register build ran one wave per SIMD, 133 us per layer)
     if (Xk_lo) { if (dbg_logits) MV2D_XT(4, true, true); else if (nw == 4) MV2D_XT(4, false, true); else MV2D_XT(2, false, true); }
     else if (dbg_logits) { if (nw == 8) MV2D_XT(8, true, false); else if (nw == 2) MV2D_XT(2, true, false); else if (nw == 1) MV2D_XT(1, true, false); else MV2D_XT(4, true, false); }

@@ -292,12 +292,10 @@ class HeadEngine:
         ws['xyz'] = e((R, 3)); ws['ref'] = e((R, 3)); ws['posemb'] = e((R, 384)); ws['qe1'] = e((R, C)); ws['qpos'] = e((R, C))
         ws['match'] = e((R, Vg, self.topk), torch.int32)
         Pp = (P + 15) // 16 * 16
-        ws['zbuf'] = z(Pp + 16 + 32 * L, torch.uint8)            # roi_mask | nnz[2] | flags | tickets: cleared once per frame (mv2d_frame_geometry)
+        ws['zbuf'] = z(Pp + 16, torch.uint8)                     # roi_mask | nnz[2]: cleared by ONE fill per frame
         ws['roi_mask'] = ws['zbuf'][:P]
         ws['nnz'] = ws['zbuf'][Pp:Pp + 8].view(torch.int32)
         ws['qt_ctl'] = ws['zbuf'][Pp + 8:Pp + 16].view(torch.int32)      # query-order flags (zeroed with zbuf)
-        # per decoder layer 8 ticket counters (one per XCD) of the persistent tile-attention blocks, zeroed with zbuf
-        ws['tickets'] = ws['zbuf'][Pp + 16:Pp + 16 + 32 * L].view(torch.int32).view(L, 8)
         ws['zero_mask'] = z(P, torch.uint8)
         ws['rect'] = e((R, 5), torch.int32); ws['pos2s'] = e(P, torch.int32); ws['s2pos'] = e(P, torch.int32)
         ws['S_dev'] = z(1, torch.int32)
@@ -551,7 +549,7 @@ class HeadEngine:
             # the attention blocks (queries ranked by the smallest RoI they list)
             o.roi_positions_csr(rois, ws['zero_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'], R, V, h, w, ws['match'],
                                 ws['row_ptr'], ws['col_idx'], ws['nnz'], Vg, self.topk, stride=self.stride, expand_stride=1.0, grp_start=grp,
-                                order=ws.get('q_order') if self.q_order else None, tickets=ws['tickets'][i] if ws.get('tickets') is not None else None)
+                                order=ws.get('q_order') if self.q_order else None)
         md = ws['S_dev']
         # a2: PE at the listed positions only
         if self.exact and 'pe' not in self.exact_skip:

@@ -539,7 +539,7 @@ def xattn_qmap(q, WA, Qt=None, R=None):
 
 
 def xattn_tile(Qt, Xk, Xv, row_ptr, col_idx, out=None, R=None, dbg_logits=None, empty_nan=True, waves=0, Xk_lo=None, Xv_lo=None, order=None,
-               row_bytes=512, tickets=None):
+               row_bytes=512):
     """Tile cross attention on the unprojected key / value rows: Qt from xattn_qmap, Xk / Xv [S,256] key16 -> z [R,8,256] fp32.
     Xk_lo / Xv_lo: optional key16 remainders of the rows (index-exact route: fp32-class key side)."""
     _req16(Qt, 'Qt')
@@ -549,10 +549,10 @@ def xattn_tile(Qt, Xk, Xv, row_ptr, col_idx, out=None, R=None, dbg_logits=None, 
     R = Qt.shape[0] if R is None else R
     if out is None:
         out = torch.empty((R, 8, 256), device=Qt.device, dtype=torch.float32)
-    _req(order, torch.int32, 'order'); _req(tickets, torch.int32, 'tickets')      # tickets: 8 zeroed int32 (dynamic distribution over the persistent blocks)
+    _req(order, torch.int32, 'order')
     check(_lib.load().mv2d_xattn_tile_fwd_ex(_p(Qt), _p(Xk), _p(Xv), _p(Xk_lo), _p(Xv_lo), _p(row_ptr), _p(col_idx), _p(out), _p(dbg_logits),
                                              dbg_logits.stride(0) if dbg_logits is not None else 0, R, 1 if empty_nan else 0, int(waves),
-                                             _p(order), int(row_bytes), _p(tickets), _stream()), 'mv2d_xattn_tile_fwd')
+                                             _p(order), int(row_bytes), _stream()), 'mv2d_xattn_tile_fwd')
     return out
 
 
