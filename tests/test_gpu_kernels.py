@@ -412,6 +412,7 @@ def _unpack_qt(Qt, R):
 
 
 @pytest.mark.parametrize('R,S,dens,waves', [(37, 500, 0.05, 4), (37, 500, 0.05, 1), (301, 5000, 0.02, 8), (301, 5000, 0.02, 2), (64, 49 * 64, -1.0, 2),
+                                            (2500, 3000, 0.01, 2), (1100, 49 * 1100, -1.0, 4),
                                             (20, 2000, 0.3, 4), (20, 2000, 0.3, 8), (20, 2000, 0.3, 1)])
 def test_xattn_tile_equals_projected_attention(dev, R, S, dens, waves):
     """The default cross-attention route (csrc/xattn_tile.hip): query map -> MFMA tile attention on the UNPROJECTED rows -> context map
@@ -463,6 +464,9 @@ def test_xattn_tile_equals_projected_attention(dev, R, S, dens, waves):
     assert float(ctx[~has].abs().max()) == 0.0 if bool((~has).any()) else True          # 'zero' policy: no value bias for a query without keys
     z2 = ops.xattn_tile(Qt, Xk, Xv, row_ptr, col, empty_nan=False, waves=waves)
     assert torch.equal(z2, z)                                                           # deterministic, debug output does not change the result
+    perm = torch.randperm(R, generator=torch.Generator().manual_seed(R)).to(torch.int32).to(dev)
+    z4 = ops.xattn_tile(Qt, Xk, Xv, row_ptr, col, empty_nan=False, waves=waves, order=perm)       # any launch order of the blocks: bitwise the same rows
+    assert torch.equal(z4, z)
     if dens > 0:
         assert float(z[5].abs().max()) == 0.0
         zn = ops.xattn_tile(Qt, Xk, Xv, row_ptr, col, waves=waves)
