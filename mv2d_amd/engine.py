@@ -72,7 +72,6 @@ class HeadEngine:
         # ---- route options (round 4: the retired A/B routes left the engine; what remains are ATTRIBUTES a caller may set before the first
         # run, every one of them part of the hipGraph key -- DESIGN.md "switches" table).  The only environment variable the engine reads is
         # MV2D_EXACT.
-        self.ffn_groups = 0           # hidden slices per FFN block (0: 8; it fixes the summation order, so it is NOT chosen by the row count)
         # adapt_pos3d(sine) (MU/pe.py:164-166) depends only on the weights and on the padding geometry of the rig, not on features, boxes
         # or calibration: it is constant-folded into a per-(weights version, geometry) table that the fused PE kernel adds in its epilogue
         self._weights_version = 0     # bumped by every load_state(): invalidates whatever was folded from the weights
@@ -90,7 +89,6 @@ class HeadEngine:
         # OPT-IN: evaluate the cls / reg branches of the last decoder layer only (what decoding reads).  Not the default: out['cls'] / out['reg']
         # then carry stale rows for the other layers, and the reference's forward does evaluate all six.
         self.last_stage_heads = False
-        self.keep_xk = False          # always write both pe and Xk (S path: nothing reads Xk; T path: nothing reads pe)
         # T path: the blocks of the per-query tile kernel run in the order of the queries' SMALLEST KEY (mv2d_xattn_query_order): neighbouring
         # blocks of an XCD then read overlapping key sets from its L2 (cfg3_t 54.8 -> 47.6 us per layer; bitwise the same results)
         # S path (round 4): the queries ranked by the smallest RoI they list (own or matched; computed from the correlation lists inside the
@@ -101,8 +99,8 @@ class HeadEngine:
         # samples/s for 1 / 2 / 4, cfg3_t (rows of ~200 keys) 5803 / 5868 / 5758
         self.xattn_waves = 2
         # INDEX-EXACT ROUTE (exact=True / MV2D_EXACT=1 / test_cfg.index_exact): every 16-bit rounding of the default route's key side is
-        # replaced by fp32-class arithmetic -- PE MLPs as K-concatenated split-precision products on unrounded inputs, the query generator's
-        # conv and the key / value rows of the tile attention as key16 hi + lo pairs -- so that the INTEGER outputs (labels, bbox_index)
+        # replaced by fp32-class arithmetic -- the PE block in one split-precision kernel on unrounded inputs (csrc/pe_x3.hip), the key / value
+        # rows of the tile attention (and, without exact_skip={'conv'}, the query generator's conv) as key16 hi + lo pairs -- so that the INTEGER outputs (labels, bbox_index)
         # can be compared bit for bit with the reference's (tests/test_gpu_golden.py).  Enqueue-only and hipGraph-replayable like the
         # default route (bench.py: samples_s_index_exact).
         self.exact = (os.environ.get('MV2D_EXACT', '0') == '1') if exact is None else bool(exact)
@@ -563,7 +561,7 @@ class HeadEngine:
             tk('pe_fused')
             # only what the path reads is written: S: pe (RoIAlign reads it; its keys are RoI-aligned rows), T: Xk (nothing reads pe);
             # a keep_stages run writes both
-            dbg = self.keep_xk or getattr(self, '_stage_outputs', False) or self.exact
+            dbg = getattr(self, '_stage_outputs', False) or self.exact
             o.pe_fused_tab(ws['A1'], ws['Xf_b'], featcl, md, W_['pe_pack'], ws['shared']['sine_tab'], ws['shared']['sine_period'],
                            ws['pe'] if (self.kind == 'S' or dbg) else None, ws['Xk'] if (self.kind == 'T' or dbg) else None, M=P,
                            row_index=ws['s2pos'])
@@ -600,7 +598,7 @@ class HeadEngine:
                     self.post_range_h64, A_frustum_f32=ws['xa1'], A_sine_f32=ws['xa2'] if self.keep_sine_rows else None)
         sh = ws['shared']
         rows = self.kind == 'T'
-        dbg = self.keep_xk or getattr(self, '_stage_outputs', False)
+        dbg = getattr(self, '_stage_outputs', False)
         o.pe_fused_x3(ws['xa1'], featcl, md, W_['pe_x3'], sh['sine_tab'], sh['sine_period'], pe=ws['pe'] if (not rows or dbg) else None,
                       Xk=(ws['Xk'], ws['xk_lo']) if rows else None, Xv=(ws['Xf_b'], ws['xv_lo']) if rows else None, M=P, row_index=ws['s2pos'])
 
@@ -684,7 +682,7 @@ class HeadEngine:
             # eight hidden slices accumulated per block: 4 slabs to write and re-read instead of 32 (round 3: 8371 vs 8289 samples/s for
             # 8 vs 4 slices, and half the slab traffic).  It fixes the summation order, so it is NOT chosen by the row count: a sample's
             # result must not depend on the batch it is in.
-            G = self.ffn_groups if self.ffn_groups else 8
+            G = 8
             parts = ws['parts'][:ws['parts'].shape[0] // G]
             o.ffn_fused_x3(ws['x2'], W_[f'ffn_w1x{i}'], W_[f'ffn_b1{i}'], W_[f'ffn_w2x{i}'], parts, R, groups=G)
             nxt = i + 1 < L
@@ -781,7 +779,7 @@ class HeadEngine:
         # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
         gkey = (ptrs, 0 if payload is None else payload.data_ptr(), sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs, self.last_stage_heads,
-                self.xattn_waves, self.fuse_maps, self.keep_sine_rows, self.keep_xk, self.ffn_groups, self.force_nc, self.q_order,
+                self.xattn_waves, self.fuse_maps, self.keep_sine_rows, self.force_nc, self.q_order,
                 self.fork_qg, self.exact_skip)   # load_state() re-allocates the weights; every route option of __init__ is in the key
         graphs = ws.setdefault('graphs', {})             # one graph per (input buffers, frame scalars): a producer that alternates between
         g = graphs.get(gkey)                             # a few static output buffers replays a few graphs, it does not re-capture

@@ -356,6 +356,54 @@ def test_engine_map_kernels_fused_or_separate_bitwise_equal(kind, name):
         assert torch.equal(nat['cls'], ref['cls']) and torch.equal(nat['reg'], ref['reg'])
 
 
+@pytest.mark.parametrize('kind,name', [('S', 'nc6_s'), ('T', 'cfg1_t')])
+def test_engine_route_options(kind, name):
+    """The remaining attributes of HeadEngine that select a route (DESIGN.md "Switches"), each against the default setting on the same
+    inputs: xattn_waves (waves per query of the tile kernel: bitwise the same -- the split of a tile over waves does not change the order
+    of any sum), keep_sine_rows (the training route's extra output of pe_inputs: inference results untouched), exact_skip on the
+    index-exact route (stages left at the default route's single rounding: class logits stay within the default route's bound of the
+    full index-exact result), force_nc (bench only, S path: every query lists exactly n_c RoIs = 49 n_c keys)."""
+    from mv2d_amd.engine import HeadEngine
+    prob = synthetic.make_problem(name, seed=0)
+    sd = synthetic.make_head_state(seed=0)
+    dev = torch.device('cuda:0')
+    feat = torch.from_numpy(prob['feat']).to(dev)
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    mk = lambda **kw: HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'], **kw)
+    eng = mk()
+    ref = eng.run(feat, props, prob['img_metas'])
+    ref = {k: ref[k].clone() for k in ('cls', 'reg')}
+    for nw in (1, 4):
+        eng.xattn_waves = nw
+        got = eng.run(feat, props, prob['img_metas'], use_graph=True)
+        assert torch.equal(got['cls'], ref['cls']) and torch.equal(got['reg'], ref['reg']), nw
+    eng.xattn_waves = 2
+    eng.keep_sine_rows = True
+    got = eng.run(feat, props, prob['img_metas'], use_graph=True)
+    assert torch.equal(got['cls'], ref['cls']) and torch.equal(got['reg'], ref['reg'])
+    ws = eng._ws[next(iter(eng._ws))]
+    a2 = ws['A2'][:int(ws['S_dev'].item())].float()                                  # sine / cosine rows of the listed positions
+    assert a2.shape[0] > 0 and bool(torch.isfinite(a2).all()) and 0.5 < float(a2.abs().max()) <= 1.0
+    # index-exact route: full split precision vs. the shipped setting (conv at single precision) vs. everything skipped (= the default route's arithmetic)
+    ex = mk(exact=True)
+    assert ex.exact_skip == frozenset({'conv'})
+    shipped = ex.run(feat, props, prob['img_metas'])['cls'].clone()
+    ex.exact_skip = frozenset()
+    full = ex.run(feat, props, prob['img_metas'])['cls'].clone()
+    ex.exact_skip = frozenset({'conv', 'pe', 'attn'})
+    none = ex.run(feat, props, prob['img_metas'])['cls'].clone()
+    e_ship, e_none = relmax(shipped, full), relmax(none, full)
+    print(f'[exact_skip {name}] cls vs full split precision: conv skipped {e_ship:.2e}, all skipped {e_none:.2e}, default route {relmax(ref["cls"], full):.2e}')
+    assert e_ship < 1e-5 and e_none < TOL['cls']
+    if kind == 'S':
+        f = mk()
+        f.force_nc = 3
+        out = f.run(feat, props, prob['img_metas'])
+        rp = f._ws[next(iter(f._ws))]['row_ptr'].cpu().numpy()
+        R = out['R']
+        assert (np.diff(rp[:R + 1]) == 3 * 49).all()
+
+
 @pytest.mark.parametrize('kind,name,n', [('S', 'cfg1_s', 1), ('S', 'nc6_s', 3), ('T', 'cfg1_t', 2)])
 def test_decode_writes_the_all_gather_payload(kind, name, n):
     """run(..., payload=buf): the decode kernel writes the wire rows of the per-step all-gather itself (one launch less per frame); they equal
