@@ -29,6 +29,15 @@ extern "C" void mv2d_set_error(const char* msg);
         }                                                     \
     } while (0)
 
+// XCD-chunked block order: the dispatcher deals consecutive workgroups (x fastest, then y, z) round robin to the 8 XCDs, each with its own
+// L2.  xcd_chunked(b, total) turns the dispatch index b into a logical index such that every XCD works through ONE contiguous range of
+// logical indices: blocks that share operands (the column blocks of one row block, the row blocks of one weight set) then share an L2
+// instead of fetching the operand once per XCD.  Speed / traffic only: any bijection is correct.
+__device__ __forceinline__ int xcd_chunked(int b, int total) {
+    const int x = b & 7, q = total >> 3, rem = total & 7;
+    return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + (b >> 3);
+}
+
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) {
     return __uint_as_float(((unsigned int)h) << 16);
 }

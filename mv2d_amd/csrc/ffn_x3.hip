@@ -46,6 +46,8 @@ __global__ __launch_bounds__(256, 2) void ffn_x3_kernel(const float* __restrict_
     constexpr int NHB = G > 1 ? 2 : 1;                   // H buffers (they alternate between the slices of a block)
     __shared__ __attribute__((aligned(16))) unsigned char xh[BR * C * 2], xl[BR * C * 2], hh[NHB][BR * HS * 2], hl[NHB][BR * HS * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    // (natural block order: with 4 slabs and x fastest, XCD k only ever sees slab k % 4, i.e. a quarter of the weights; the XCD-chunked order
+    //  of linear_x3 / heads -- all slabs of a row block on one XCD -- fetched 71 instead of 29 MB per launch here, round 4)
     const int slab = blockIdx.x, m0 = blockIdx.y * BR;
     const int nt = hidden / 16;
     // ---- issue everything that does not depend on LDS: X rows (coalesced), W1 fragments (hi, lo) of the first slice

@@ -944,7 +944,9 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinX3Params p) {
     }
     __shared__ __attribute__((aligned(16))) unsigned char ah[2][RT * 16 * 512], al[2][RT * 16 * 512];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-    const int mb = blockIdx.y * (16 * RT), n0 = blockIdx.x * 128;
+    // the column blocks of one row block run on ONE XCD (they read the same A rows: round 4, PMC: 4-8 x the A bytes fetched before)
+    const int lin = xcd_chunked(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    const int mb = (lin / gridDim.x) * (16 * RT), n0 = (lin % gridDim.x) * 128;
     if (p.m_dev) {                                                              // device-side M (block-uniform exit before any barrier)
         p.M = min(p.M, *p.m_dev);
         if (mb >= p.M) return;
@@ -1081,7 +1083,9 @@ __global__ __launch_bounds__(1024) void heads_fused_x3_kernel(HeadsX3Params p) {
     __shared__ __attribute__((aligned(16))) unsigned char ah[RT * 16 * 512], al[RT * 16 * 512];
     __shared__ __attribute__((aligned(16))) float tb[RT * 16 * C];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-    const int mb = blockIdx.x * (16 * RT), l = blockIdx.y, branch = blockIdx.z;
+    // the row blocks of one (layer, branch) run on ONE XCD: its 1 MB of weights is fetched by ~2 XCDs instead of all 8
+    const int lin = xcd_chunked(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+    const int mb = (lin % gridDim.x) * (16 * RT), l = (lin / gridDim.x) % gridDim.y, branch = lin / (gridDim.x * gridDim.y);
     const long long wo = (long long)l * C * C, bl = (long long)l * C;
     const unsigned short* W1h = (branch == 0 ? p.w0h : p.r0h) + wo;
     const unsigned short* W1l = (branch == 0 ? p.w0l : p.r0l) + wo;

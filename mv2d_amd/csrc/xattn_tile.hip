@@ -223,6 +223,7 @@ __device__ __forceinline__ float xt_row16_max(float v) {
     return v;
 }
 
+typedef unsigned int xt_u32x4 __attribute__((ext_vector_type(4)));      // staging registers (arrays of HIP's uint4 STRUCT that live across a loop end up in scratch)
 template <int NW, bool DBG, bool XLO>
 __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __restrict__ Qt, const unsigned short* __restrict__ Xk,
                                                              const unsigned short* __restrict__ Xv, const unsigned short* __restrict__ Xk_lo,
@@ -269,59 +270,35 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
 #pragma unroll
         for (int s = 0; s < 8; ++s) qa[s].u = qp[s * 8];
     }
-    // the key indices of a tile are requested one tile AHEAD (round 4): a tile is two dependent round trips (index, then rows); the index trip of
-    // the next tile now runs under the current tile's gather and arithmetic (one register)
-    int idx_next = wave < ntile ? col_idx[min(beg + 16 * wave + n, end - 1)] : 0;
-    for (int tt = wave; tt < ntile; tt += NW) {
-        const int kbase = beg + 16 * tt;
-        const int myidx = idx_next;                                                  // lane (n, *): key n of the tile
-        if (tt + NW < ntile) idx_next = col_idx[min(kbase + 16 * NW + n, end - 1)];
-        // ---- gather: Xk rows whole (lanes 0-31 one row, 32-63 the next), Xv rows as 16-byte column chunks of keys 4g..4g+3
-        // (byte offsets as 32-bit unsigned: scalar base + vector offset addressing instead of 64-bit address arithmetic per row;
-        //  the row arrays must stay below 4 GB = 2^23 rows, include/mv2d_hip.h)
-        uint4 kreg[8], vreg[4][2], vlo[4][2];
-        auto load_v = [&](const unsigned short* V_, uint4 (&dst)[4][2]) {
+    // ---- the pieces of a tile.  Gather: Xk rows whole (lanes 0-31 one row, 32-63 the next), Xv rows as 16-byte column chunks of keys 4g..4g+3
+    // (byte offsets as 32-bit unsigned: scalar base + vector offset addressing instead of 64-bit address arithmetic per row;
+    //  the row arrays must stay below 4 GB = 2^23 rows, include/mv2d_hip.h).  `myidx`: lane (n, *) holds the index of key n of the tile.
+    auto load_v = [&](const unsigned short* V_, int myidx, xt_u32x4 (&dst)[4][2]) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned int vidx = (unsigned int)__shfl(myidx, 4 * g + e, 64);
-                const char* vp = reinterpret_cast<const char*>(V_) + (vidx * row_bytes + 16u * (unsigned)n);
-                dst[e][0] = *reinterpret_cast<const uint4*>(vp);
-                dst[e][1] = *reinterpret_cast<const uint4*>(vp + 256);
-            }
-        };
+        for (int e = 0; e < 4; ++e) {
+            const unsigned int vidx = (unsigned int)__shfl(myidx, 4 * g + e, 64);
+            const char* vp = reinterpret_cast<const char*>(V_) + (vidx * row_bytes + 16u * (unsigned)n);
+            dst[e][0] = *reinterpret_cast<const xt_u32x4*>(vp);
+            dst[e][1] = *reinterpret_cast<const xt_u32x4*>(vp + 256);
+        }
+    };
+    auto load_k = [&](const unsigned short* K_, int myidx, xt_u32x4 (&dst)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const unsigned int ridx = (unsigned int)__shfl(myidx, 2 * i + (lane >> 5), 64);
-            kreg[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Xk) + (ridx * row_bytes + (unsigned)(lane & 31) * 16u));
+            dst[i] = *reinterpret_cast<const xt_u32x4*>(reinterpret_cast<const char*>(K_) + (ridx * row_bytes + (unsigned)(lane & 31) * 16u));
         }
-        if constexpr (XLO) {
-            // index-exact route, TWO PHASES per tile (round 4): the hi and lo halves of the 16 key rows are requested together (16 loads in flight) and
-            // go to LDS; only then the hi and lo value rows are requested -- into the registers the key rows just left -- and arrive while the
-            // logits and the softmax run.  (Round 3 requested K hi, V hi up front and the lo halves behind the first LDS writes, in 32 more
-            // registers: 314 us instead of 92 us per layer at cfg3_t for twice the bytes.)
-            uint4 klo[8];
+    };
+    auto store_k = [&](uint4* tile, const xt_u32x4 (&src)[8]) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const unsigned int ridx = (unsigned int)__shfl(myidx, 2 * i + (lane >> 5), 64);
-                klo[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Xk_lo) + (ridx * row_bytes + (unsigned)(lane & 31) * 16u));
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int rowi = 2 * i + (lane >> 5);
-                kt[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = kreg[i];
-                kt2[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = klo[i];
-            }
-            load_v(Xv, vreg);
-            load_v(Xv_lo, vlo);
-        } else {
-            load_v(Xv, vreg);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int rowi = 2 * i + (lane >> 5);
-                kt[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = kreg[i];
-            }
+        for (int i = 0; i < 8; ++i) {
+            const int rowi = 2 * i + (lane >> 5);
+            reinterpret_cast<xt_u32x4*>(tile)[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = src[i];
         }
-        __builtin_amdgcn_wave_barrier();
+    };
+    // logits, online softmax and P . V of tile tt: the key tile is in LDS (kt, XLO: kt2), the value rows in registers
+    auto compute = [&](int tt, const xt_u32x4 (&vreg)[4][2], const xt_u32x4 (&vlo)[4][2]) {
+        const int kbase = beg + 16 * tt;
         // ---- logits of the tile: D[row 4g+i][key n] = sum_c Qt[row][c] Xk[key][c]
         f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -401,6 +378,44 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
             }
         }
         __builtin_amdgcn_wave_barrier();                                             // before the next tile overwrites kt / pl
+    };
+    if constexpr (XLO) {
+        // index-exact route, TWO PHASES per tile (round 4): the hi and lo halves of the 16 key rows are requested together (16 loads in flight) and
+        // go to LDS; only then the hi and lo value rows are requested -- into the registers the key rows just left -- and arrive while the
+        // logits and the softmax run.  (Round 3 requested K hi, V hi up front and the lo halves behind the first LDS writes, in 32 more
+        // registers: 314 us instead of 92 us per layer at cfg3_t for twice the bytes.)  The key indices of a tile are requested one tile AHEAD.
+        int idx_next = wave < ntile ? col_idx[min(beg + 16 * wave + n, end - 1)] : 0;
+        for (int tt = wave; tt < ntile; tt += NW) {
+            const int myidx = idx_next;
+            if (tt + NW < ntile) idx_next = col_idx[min(beg + 16 * (tt + NW) + n, end - 1)];
+            xt_u32x4 kreg[8], klo[8], vreg[4][2], vlo[4][2];
+            load_k(Xk, myidx, kreg);
+            load_k(Xk_lo, myidx, klo);
+            store_k(kt, kreg);
+            store_k(kt2, klo);
+            load_v(Xv, myidx, vreg);
+            load_v(Xv_lo, myidx, vlo);
+            __builtin_amdgcn_wave_barrier();
+            compute(tt, vreg, vlo);
+        }
+    } else {
+        // default route: the key indices of a tile are requested one tile AHEAD (round 4: a tile is two dependent round trips, index then rows;
+        // the index trip of the next tile runs under the current tile's gather and arithmetic: cfg3_t 94.5 -> 87.3 us per layer).  Requesting
+        // the ROWS of the next tile ahead as well (software pipelining: key rows through a second register set, or key + value rows with two
+        // named value buffers, 230 / 256 registers) does not pay: cfg3_t 89.9 -> 87.9 / 91.3 us, cfg5_t 85.0 -> 81.8 / 84.6, cfg2_s 63.2 ->
+        // 66.3 / 68.2 (same box, round 4) -- twice the bytes in flight per wave buy nothing, the kernel sits at what the memory system
+        // delivers for 512-byte rows (4-5 TB/s from HBM, 10-12 TB/s where L2 serves the repeats), not at a per-wave latency chain.
+        int idx_next = wave < ntile ? col_idx[min(beg + 16 * wave + n, end - 1)] : 0;
+        for (int tt = wave; tt < ntile; tt += NW) {
+            const int myidx = idx_next;
+            if (tt + NW < ntile) idx_next = col_idx[min(beg + 16 * (tt + NW) + n, end - 1)];
+            xt_u32x4 kreg[8], vreg[4][2];
+            load_k(Xk, myidx, kreg);
+            load_v(Xv, myidx, vreg);
+            store_k(kt, kreg);
+            __builtin_amdgcn_wave_barrier();
+            compute(tt, vreg, vreg);
+        }
     }
     // ---- row sums over the 16 key lanes; partial (m, l, z) of the wave -> LDS (z into the wave's own key-tile region)
 #pragma unroll

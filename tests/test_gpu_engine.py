@@ -359,8 +359,8 @@ def test_engine_map_kernels_fused_or_separate_bitwise_equal(kind, name):
 @pytest.mark.parametrize('kind,name', [('S', 'nc6_s'), ('T', 'cfg1_t')])
 def test_engine_route_options(kind, name):
     """The remaining attributes of HeadEngine that select a route (DESIGN.md "Switches"), each against the default setting on the same
-    inputs: xattn_waves (waves per query of the tile kernel: bitwise the same -- the split of a tile over waves does not change the order
-    of any sum), keep_sine_rows (the training route's extra output of pe_inputs: inference results untouched), exact_skip on the
+    inputs: xattn_waves (waves per query of the tile kernel: the tiles of a row are dealt to the waves and their partial softmax sums merged at
+    the end, so the summation ORDER depends on it -- fp32 rounding differences only), keep_sine_rows (the training route's extra output of pe_inputs: inference results untouched), exact_skip on the
     index-exact route (stages left at the default route's single rounding: class logits stay within the default route's bound of the
     full index-exact result), force_nc (bench only, S path: every query lists exactly n_c RoIs = 49 n_c keys)."""
     from mv2d_amd.engine import HeadEngine
@@ -376,7 +376,9 @@ def test_engine_route_options(kind, name):
     for nw in (1, 4):
         eng.xattn_waves = nw
         got = eng.run(feat, props, prob['img_metas'], use_graph=True)
-        assert torch.equal(got['cls'], ref['cls']) and torch.equal(got['reg'], ref['reg']), nw
+        e = max(relmax(got['cls'], ref['cls']), relmax(got['reg'], ref['reg']))
+        print(f'[xattn_waves {name}] {nw} vs 2 waves: {e:.2e}')
+        assert e < 2e-5, (nw, e)                                                       # measured 6.6e-6 (nc6_s, 1 vs 2 waves)
     eng.xattn_waves = 2
     eng.keep_sine_rows = True
     got = eng.run(feat, props, prob['img_metas'], use_graph=True)
