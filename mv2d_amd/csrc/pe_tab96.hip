@@ -133,8 +133,8 @@ __device__ __forceinline__ void layer1(PFrag (&wq)[S::RING][S::CT], PFrag (&a)[2
         const float4 bb = *reinterpret_cast<const float4*>(bias + lcol);
 #pragma unroll
         for (int i = 0; i < S::RT; ++i) {
-            const uint2 hv = make_uint2(pack_k16x2(relu_f(acc1[i][j][0] + bb.x), relu_f(acc1[i][j][1] + bb.y)),
-                                        pack_k16x2(relu_f(acc1[i][j][2] + bb.z), relu_f(acc1[i][j][3] + bb.w)));
+            const uint2 hv = make_uint2(pack_k16x2_relu(acc1[i][j][0] + bb.x, acc1[i][j][1] + bb.y),
+                                        pack_k16x2_relu(acc1[i][j][2] + bb.z, acc1[i][j][3] + bb.w));
             *reinterpret_cast<uint2*>(Hb + (16 * i + fr) * PITCH + (((lcol >> 3) ^ fr) << 4) + (lcol & 4) * 2) = hv;
         }
     }
