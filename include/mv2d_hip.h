@@ -304,11 +304,6 @@ int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* Xv, const vo
 int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                 const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
                                 const int* order, void* stream);
-/* ... and with a row pitch: row r of Xk / Xv / Xk_lo / Xv_lo starts at byte r * row_bytes (>= 512, a multiple of 16).  The index-exact route
- * interleaves the hi and lo halves of a row (Xk_lo = Xk + 256 elements, row_bytes = 1024): one 1 KB stretch of DRAM per key instead of two. */
-int mv2d_xattn_tile_fwd_ex(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
-                           const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
-                           const int* order, int row_bytes, void* stream);
 int mv2d_xattn_ctxmap(const float* z, const void* WB_hi, const void* WB_lo, const float* bv, const int* row_ptr, float* ctx, int R,
                       int empty_nan, void* stream);
 

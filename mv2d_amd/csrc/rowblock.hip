@@ -192,7 +192,7 @@ __global__ __launch_bounds__(1024) void attn_out_fused_kernel(AttnOutParams p) {
     }
 }
 
-// The same fused chain in split precision ("bf16x3", cf. ffn_x3.hip / gemm_x3.hip): both weights come as bf16 hi/lo pairs in
+// The same fused chain in split precision ("bf16x3", cf. ffn_x3.hip): both weights come as bf16 hi/lo pairs in
 // fragment-major order (mv2d_split_bf16x2 + mv2d_pack_wfrag_bf16), the activation tile is split when it is staged into LDS.
 // 24 v_mfma_f32_16x16x32_bf16 per tile instead of 64 v_mfma_f32_16x16x4_f32 (408 vs 2048 matrix-pipe cycles per wave, and a
 // block's 16 waves share one CU), ~1e-5 relative error.
@@ -919,7 +919,7 @@ __global__ void pack_wfrag_f32_kernel(const float* __restrict__ W, float* __rest
 
 // Plain linear layer C = act(A . W^T + b) in split precision for the per-query MLPs with several hundred to a few thousand rows
 // (query generator: 256 -> 1024, 1056 -> 512, 512 -> 256; first self-attention in_proj): the per-wave-tile kernels (gemm_f32 /
-// gemm_x3: no LDS, every 16x16 tile fetches its own operands) are latency kernels for a few hundred rows and L2-bound beyond.
+// the retired round-2 gemm_x3 kernel: no LDS, every 16x16 tile fetches its own operands) are latency kernels for a few hundred rows and L2-bound beyond.
 // Block = RT x 16 rows x 128 columns, 8 waves (wave w = column tile w for all row tiles); K runs in chunks of 256: the fp32 A chunk
 // is split into bf16 hi / lo LDS images (double buffered), the fragment-major weight chunk (hi, lo) sits in registers, both are
 // requested one chunk ahead.  Columns >= n_split read A2 instead of A (in_proj of (q, k | v) from two inputs).

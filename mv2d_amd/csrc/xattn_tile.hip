@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
                                                              const unsigned short* __restrict__ Xv_lo, const int* __restrict__ row_ptr,
                                                              const int* __restrict__ col_idx, float* __restrict__ z,
                                                              float* __restrict__ dbg_logits, long long dbg_stride, int R, int empty_nan,
-                                                             const int* __restrict__ order, unsigned int row_bytes) {
+                                                             const int* __restrict__ order) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[NW * 8192 + NW * 512 + NW * 64 + (XLO ? NW * 8192 : 0)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
     // XCD-aware block -> query map (block b runs on XCD b % 8): every XCD gets one contiguous range of queries, so neighbouring
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
     {
         const int b = blockIdx.x, x = b & 7, qn = R >> 3, rem = R & 7;
         r = (x < rem ? x * (qn + 1) : rem * (qn + 1) + (x - rem) * qn) + (b >> 3);
-        // optional query order (T path: the queries of a sample sorted by their smallest key, mv2d_xattn_qtile_build's perm): blocks that run
+        // optional query order (T path: the queries of a sample sorted by their smallest key, mv2d_xattn_query_order's perm): blocks that run
         // side by side on an XCD then read overlapping key sets and share its L2.  Speed only.
         if (order) r = order[r];
     }
@@ -272,12 +272,12 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
     }
     // ---- the pieces of a tile.  Gather: Xk rows whole (lanes 0-31 one row, 32-63 the next), Xv rows as 16-byte column chunks of keys 4g..4g+3
     // (byte offsets as 32-bit unsigned: scalar base + vector offset addressing instead of 64-bit address arithmetic per row;
-    //  the row arrays must stay below 4 GB = 2^23 rows, include/mv2d_hip.h).  `myidx`: lane (n, *) holds the index of key n of the tile.
+    //  the row arrays must stay below 4 GB = 2^23 rows of 512 B, include/mv2d_hip.h).  `myidx`: lane (n, *) holds the index of key n of the tile.
     auto load_v = [&](const unsigned short* V_, int myidx, xt_u32x4 (&dst)[4][2]) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const unsigned int vidx = (unsigned int)__shfl(myidx, 4 * g + e, 64);
-            const char* vp = reinterpret_cast<const char*>(V_) + (vidx * row_bytes + 16u * (unsigned)n);
+            const char* vp = reinterpret_cast<const char*>(V_) + ((vidx << 9) + 16u * (unsigned)n);
             dst[e][0] = *reinterpret_cast<const xt_u32x4*>(vp);
             dst[e][1] = *reinterpret_cast<const xt_u32x4*>(vp + 256);
         }
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const unsigned int ridx = (unsigned int)__shfl(myidx, 2 * i + (lane >> 5), 64);
-            dst[i] = *reinterpret_cast<const xt_u32x4*>(reinterpret_cast<const char*>(K_) + (ridx * row_bytes + (unsigned)(lane & 31) * 16u));
+            dst[i] = *reinterpret_cast<const xt_u32x4*>(reinterpret_cast<const char*>(K_) + ((ridx << 9) + (unsigned)(lane & 31) * 16u));
         }
     };
     auto store_k = [&](uint4* tile, const xt_u32x4 (&src)[8]) {
@@ -314,7 +314,6 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
             }
         }
         const bool valid = kbase + n < end;
-        const bool first = tt == wave;                                              // (wave-uniform) nothing accumulated yet: no rescale
         float sv[4], p[4], alpha[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -350,6 +349,14 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
             pah = n < 8 ? make_uint2(h0, h1) : make_uint2(0u, 0u);
         }
         // ---- z = alpha z + P . Xv_tile; column tile (H, w): output column n <-> channel 128 H + 8 n + w
+        // The rescaling runs unconditionally.  In the first tile of a wave alpha = 2^-inf = 0 multiplies rows that are still 0; a guard `if (not the
+        // first tile)` is wave-uniform but not provably so and compiled to 64 v_cndmask per tile (a quarter of the loop's vector instructions:
+        // 65 -> 60 us per cfg2_s layer without it).  Skipping the 64 multiplications behind a ballot when no head's maximum moved is exact but
+        // slower (61.3 -> 62.2 us: the branch costs more than the multiplications it saves).
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Z[u][i] *= alpha[i];
 #pragma unroll
         for (int H = 0; H < 2; ++H) {
             const unsigned int r0[4] = {vreg[0][H].x, vreg[0][H].y, vreg[0][H].z, vreg[0][H].w};
@@ -362,10 +369,6 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
                 const uint2 vb = (w & 1) ? make_uint2(xt_hi_pair(r0[d], r1[d]), xt_hi_pair(r2[d], r3[d]))
                                          : make_uint2(xt_lo_pair(r0[d], r1[d]), xt_lo_pair(r2[d], r3[d]));
                 f32x4_t zc = Z[H * 8 + w];
-                if (!first) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) zc[i] *= alpha[i];
-                }
                 zc = mfma_k16_16x16x16(pa, vb, zc);
                 if (XLO) {
                     const unsigned int q0[4] = {vlo[0][H].x, vlo[0][H].y, vlo[0][H].z, vlo[0][H].w}, q1[4] = {vlo[1][H].x, vlo[1][H].y, vlo[1][H].z, vlo[1][H].w};
@@ -501,9 +504,6 @@ extern "C" int mv2d_xattn_ctxmap(const float* z, const void* WB_hi, const void* 
 extern "C" int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                            const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
                                            const int* order, void* stream);
-extern "C" int mv2d_xattn_tile_fwd_ex(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
-                                      const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
-                                      const int* order, int row_bytes, void* stream);
 
 extern "C" int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                    const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves, void* stream) {
@@ -513,13 +513,6 @@ extern "C" int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* X
 extern "C" int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                            const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
                                            const int* order, void* stream) {
-    return mv2d_xattn_tile_fwd_ex(Qt, Xk, Xv, Xk_lo, Xv_lo, row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan, waves, order, C * 2, stream);
-}
-
-extern "C" int mv2d_xattn_tile_fwd_ex(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
-                                      const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
-                                      const int* order, int row_bytes, void* stream) {
-    MV2D_CHECK_ARG(row_bytes >= C * 2 && (row_bytes % 16) == 0, "mv2d_xattn_tile_fwd_ex: row_bytes >= 512, a multiple of 16");
     MV2D_CHECK_ARG(Qt && Xk && Xv && row_ptr && col_idx && z && R >= 0, "mv2d_xattn_tile_fwd: bad args");
     MV2D_CHECK_ARG((Xk_lo == nullptr) == (Xv_lo == nullptr), "mv2d_xattn_tile_fwd: Xk_lo and Xv_lo come together");
     MV2D_CHECK_ARG(((uintptr_t)Qt & 15) == 0 && ((uintptr_t)Xk & 15) == 0 && ((uintptr_t)Xv & 15) == 0 && ((uintptr_t)z & 15) == 0 &&
@@ -529,7 +522,7 @@ extern "C" int mv2d_xattn_tile_fwd_ex(const void* Qt, const void* Xk, const void
     const int nw = waves ? waves : 2;      // the engine passes its own choice (2: see engine.py)
 #define MV2D_XT(NW, DBG, XLO) hipLaunchKernelGGL((xattn_tile_kernel<NW, DBG, XLO>), dim3(R), dim3(64 * NW), 0, (hipStream_t)stream, (const uint4*)Qt, \
                                                  (const unsigned short*)Xk, (const unsigned short*)Xv, (const unsigned short*)Xk_lo, (const unsigned short*)Xv_lo, \
-                                                 row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan, order, (unsigned int)row_bytes)
+                                                 row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan, order)
     // index-exact route (hi + lo rows): two waves per SIMD like the default (round 3: the 312-register build ran one wave per SIMD, 133 us per layer)
     if (Xk_lo) { if (dbg_logits) MV2D_XT(4, true, true); else if (nw == 4) MV2D_XT(4, false, true); else MV2D_XT(2, false, true); }
     else if (dbg_logits) { if (nw == 8) MV2D_XT(8, true, false); else if (nw == 2) MV2D_XT(2, true, false); else if (nw == 1) MV2D_XT(1, true, false); else MV2D_XT(4, true, false); }

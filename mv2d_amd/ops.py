@@ -538,21 +538,18 @@ def xattn_qmap(q, WA, Qt=None, R=None):
     return Qt
 
 
-def xattn_tile(Qt, Xk, Xv, row_ptr, col_idx, out=None, R=None, dbg_logits=None, empty_nan=True, waves=0, Xk_lo=None, Xv_lo=None, order=None,
-               row_bytes=512):
+def xattn_tile(Qt, Xk, Xv, row_ptr, col_idx, out=None, R=None, dbg_logits=None, empty_nan=True, waves=0, Xk_lo=None, Xv_lo=None, order=None):
     """Tile cross attention on the unprojected key / value rows: Qt from xattn_qmap, Xk / Xv [S,256] key16 -> z [R,8,256] fp32.
     Xk_lo / Xv_lo: optional key16 remainders of the rows (index-exact route: fp32-class key side)."""
-    _req16(Qt, 'Qt')
-    if row_bytes == 512:
-        _req16(Xk, 'Xk'); _req16(Xv, 'Xv'); _req16(Xk_lo, 'Xk_lo'); _req16(Xv_lo, 'Xv_lo')
+    _req16(Qt, 'Qt'); _req16(Xk, 'Xk'); _req16(Xv, 'Xv'); _req16(Xk_lo, 'Xk_lo'); _req16(Xv_lo, 'Xv_lo')
     _req(row_ptr, torch.int32, 'row_ptr'); _req(col_idx, torch.int32, 'col_idx'); _req(dbg_logits, torch.float32, 'dbg_logits')
     R = Qt.shape[0] if R is None else R
     if out is None:
         out = torch.empty((R, 8, 256), device=Qt.device, dtype=torch.float32)
     _req(order, torch.int32, 'order')
-    check(_lib.load().mv2d_xattn_tile_fwd_ex(_p(Qt), _p(Xk), _p(Xv), _p(Xk_lo), _p(Xv_lo), _p(row_ptr), _p(col_idx), _p(out), _p(dbg_logits),
-                                             dbg_logits.stride(0) if dbg_logits is not None else 0, R, 1 if empty_nan else 0, int(waves),
-                                             _p(order), int(row_bytes), _stream()), 'mv2d_xattn_tile_fwd')
+    check(_lib.load().mv2d_xattn_tile_fwd_ordered(_p(Qt), _p(Xk), _p(Xv), _p(Xk_lo), _p(Xv_lo), _p(row_ptr), _p(col_idx), _p(out), _p(dbg_logits),
+                                                  dbg_logits.stride(0) if dbg_logits is not None else 0, R, 1 if empty_nan else 0, int(waves),
+                                                  _p(order), _stream()), 'mv2d_xattn_tile_fwd')
     return out
 
 
