@@ -113,13 +113,15 @@ __device__ __forceinline__ f32x4_t mfma_k16_16x16x16(const uint2& a, const uint2
     return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(k16x4_t, a), __builtin_bit_cast(k16x4_t, b), c, 0, 0, 0);
 }
 #endif
-// key16 pair of relu(a), relu(b): ReLU and the range clamp are ONE median (0 <= x <= 65504), NaN put back like in k16_sat / relu_f
+// key16 pair of relu(a), relu(b) for the hidden layers of the key-side MLPs: ReLU and the range clamp are ONE median (0 <= x <= 65504) per value,
+// three instructions per pair with the conversion (the first fp16 build spent seven: compare + select ReLU, compare + select clamp, NaN put back;
+// the PE kernel's hidden-layer epilogues were a quarter of its vector instructions).  A NaN becomes 0 here (v_med3_f32 returns the minimum of its
+// operands for a NaN) -- the hidden layer is not where a poisoned input stays visible: the feature row itself goes into the key / value rows.
 __device__ __forceinline__ unsigned int pack_k16x2_relu(float a, float b) {
 #if MV2D_KEY16_IS_F16
     typedef __attribute__((ext_vector_type(2))) float f32x2_cv;
     typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_cv;
-    const float ca = __builtin_amdgcn_fmed3f(a, 0.f, 65504.f), cb = __builtin_amdgcn_fmed3f(b, 0.f, 65504.f);
-    const f32x2_cv v = {a != a ? a : ca, b != b ? b : cb};
+    const f32x2_cv v = {__builtin_amdgcn_fmed3f(a, 0.f, 65504.f), __builtin_amdgcn_fmed3f(b, 0.f, 65504.f)};
     return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2_cv));
 #else
     return pack_k16x2(a < 0.f ? 0.f : a, b < 0.f ? 0.f : b);

@@ -264,8 +264,10 @@ __global__ __launch_bounds__(S::NTHR, 2) void pe_tab_kernel(PeTabParams p) {
         const float4 fb = *reinterpret_cast<const float4*>(Bs + B_1B + n0 + 16 * j);
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
-            const f32x4_t g{1.f / (1.f + __expf(-(acc[i][j][0] + eb.x))), 1.f / (1.f + __expf(-(acc[i][j][1] + eb.y))),
-                            1.f / (1.f + __expf(-(acc[i][j][2] + eb.z))), 1.f / (1.f + __expf(-(acc[i][j][3] + eb.w)))};
+            // (v_rcp_f32, 1 ulp, instead of the IEEE division sequence: ~8 instructions less per value; the gate multiplies a value that is rounded
+            //  to key16 or added to an fp32 table row right after)
+            const f32x4_t g{__builtin_amdgcn_rcpf(1.f + __expf(-(acc[i][j][0] + eb.x))), __builtin_amdgcn_rcpf(1.f + __expf(-(acc[i][j][1] + eb.y))),
+                            __builtin_amdgcn_rcpf(1.f + __expf(-(acc[i][j][2] + eb.z))), __builtin_amdgcn_rcpf(1.f + __expf(-(acc[i][j][3] + eb.w)))};
             accf[i][j] = f32x4_t{(accf[i][j][0] + fb.x) * g[0], (accf[i][j][1] + fb.y) * g[1], (accf[i][j][2] + fb.z) * g[2], (accf[i][j][3] + fb.w) * g[3]};
         }
     }
