@@ -109,32 +109,29 @@ __device__ __forceinline__ void steps(f32x4_t (&acc)[S::RT][S::CT], PFrag (&wq)[
     }
 }
 
-template <class S>
-__device__ __forceinline__ void zero_acc(f32x4_t (&acc)[S::RT][S::CT]) {
-#pragma unroll
-    for (int i = 0; i < S::RT; ++i)
-#pragma unroll
-        for (int j = 0; j < S::CT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-}
-
 // layer 1 of part P into a hidden buffer: lane (fr, fg) holds hidden columns lcol..lcol+3 of row 16 i + fr -> bias, ReLU, key16, 8-byte
 // write.  Barrier after: the tile is complete.  With two hidden buffers the one written here was last read two barriers ago; with one,
 // a barrier before the stores waits for the previous part's layer 2.
 template <class S, int P>
 __device__ __forceinline__ void layer1(PFrag (&wq)[S::RING][S::CT], PFrag (&a)[2][S::RT], const WBase& w, const unsigned char* As, unsigned char* Hb,
                                        const float* bias /* LDS, this part's 256 */, int wave, int fr, int fg) {
+    // the accumulators START at the bias (lane (fr, fg) holds hidden columns lcol..lcol+3 of column tile j for every row tile): one vector add
+    // per hidden value less than adding it in the epilogue
     f32x4_t acc1[S::RT][S::CT];
-    zero_acc<S>(acc1);
+#pragma unroll
+    for (int j = 0; j < S::CT; ++j) {
+        const float4 bb = *reinterpret_cast<const float4*>(bias + (wave * S::CT + j) * 16 + 4 * fg);
+#pragma unroll
+        for (int i = 0; i < S::RT; ++i) acc1[i][j] = f32x4_t{bb.x, bb.y, bb.z, bb.w};
+    }
     steps<S, first_of(P), ks1_of(P)>(acc1, wq, a, w, As, fr, fg);
     if constexpr (S::HB == 1 && P > 0 && P < 4) __syncthreads();   // (the gate's layer 1 follows a block barrier anyway)
 #pragma unroll
     for (int j = 0; j < S::CT; ++j) {
         const int lcol = (wave * S::CT + j) * 16 + 4 * fg;
-        const float4 bb = *reinterpret_cast<const float4*>(bias + lcol);
 #pragma unroll
         for (int i = 0; i < S::RT; ++i) {
-            const uint2 hv = make_uint2(pack_k16x2_relu(acc1[i][j][0] + bb.x, acc1[i][j][1] + bb.y),
-                                        pack_k16x2_relu(acc1[i][j][2] + bb.z, acc1[i][j][3] + bb.w));
+            const uint2 hv = make_uint2(pack_k16x2_relu(acc1[i][j][0], acc1[i][j][1]), pack_k16x2_relu(acc1[i][j][2], acc1[i][j][3]));
             *reinterpret_cast<uint2*>(Hb + (16 * i + fr) * PITCH + (((lcol >> 3) ^ fr) << 4) + (lcol & 4) * 2) = hv;
         }
     }
@@ -194,7 +191,12 @@ __global__ __launch_bounds__(S::NTHR, 2) void pe_tab_kernel(PeTabParams p) {
     f32x4_t accf[RT][CT];                               // P1 = position_encoder(A1), bias added at the end
 
     // ---- 1. P1 in four parts of 256 hidden columns
-    zero_acc<S>(accf);
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {                      // (P1 starts at its bias b1b, the gate accumulator below at be)
+        const float4 fb = *reinterpret_cast<const float4*>(Bs + B_1B + n0 + 16 * j);
+#pragma unroll
+        for (int i = 0; i < RT; ++i) accf[i][j] = f32x4_t{fb.x, fb.y, fb.z, fb.w};
+    }
     layer1<S, 0>(wq, a, w, As, Hs0, Bs + B_1A, wave, fr, fg);
     PE_STAMP(2);
     steps<S, first_of(0) + 6, 8>(accf, wq, a, w, Hs0, fr, fg);
@@ -241,7 +243,12 @@ __global__ __launch_bounds__(S::NTHR, 2) void pe_tab_kernel(PeTabParams p) {
         const int m = min(m0 + 8 * k + r0, M - 1);
         ri[k] = p.row_index ? p.row_index[m] : m;
     }
-    zero_acc<S>(acc);
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+        const float4 eb = *reinterpret_cast<const float4*>(Bs + B_E + n0 + 16 * j);
+#pragma unroll
+        for (int i = 0; i < RT; ++i) acc[i][j] = f32x4_t{eb.x, eb.y, eb.z, eb.w};
+    }
     steps<S, first_of(4) + 8, 8>(acc, wq, a, w, Hs0, fr, fg);
     PE_STAMP(12);
     // ---- 3. pe = tab + (P1 + b) * gate, Xk = key16(pe + feat): through a wave-private LDS tile [BM rows][32 columns], then whole
@@ -257,18 +264,16 @@ __global__ __launch_bounds__(S::NTHR, 2) void pe_tab_kernel(PeTabParams p) {
         }
     };
     request(0);
-    // the sigmoid in place, the bias of P1
+    // the sigmoid in place (both accumulators started at their biases)
 #pragma unroll
     for (int j = 0; j < CT; ++j) {
-        const float4 eb = *reinterpret_cast<const float4*>(Bs + B_E + n0 + 16 * j);
-        const float4 fb = *reinterpret_cast<const float4*>(Bs + B_1B + n0 + 16 * j);
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
             // (v_rcp_f32, 1 ulp, instead of the IEEE division sequence: ~8 instructions less per value; the gate multiplies a value that is rounded
             //  to key16 or added to an fp32 table row right after)
-            const f32x4_t g{__builtin_amdgcn_rcpf(1.f + __expf(-(acc[i][j][0] + eb.x))), __builtin_amdgcn_rcpf(1.f + __expf(-(acc[i][j][1] + eb.y))),
-                            __builtin_amdgcn_rcpf(1.f + __expf(-(acc[i][j][2] + eb.z))), __builtin_amdgcn_rcpf(1.f + __expf(-(acc[i][j][3] + eb.w)))};
-            accf[i][j] = f32x4_t{(accf[i][j][0] + fb.x) * g[0], (accf[i][j][1] + fb.y) * g[1], (accf[i][j][2] + fb.z) * g[2], (accf[i][j][3] + fb.w) * g[3]};
+            const f32x4_t g{__builtin_amdgcn_rcpf(1.f + __expf(-acc[i][j][0])), __builtin_amdgcn_rcpf(1.f + __expf(-acc[i][j][1])),
+                            __builtin_amdgcn_rcpf(1.f + __expf(-acc[i][j][2])), __builtin_amdgcn_rcpf(1.f + __expf(-acc[i][j][3]))};
+            accf[i][j] = f32x4_t{accf[i][j][0] * g[0], accf[i][j][1] * g[1], accf[i][j][2] * g[2], accf[i][j][3] * g[3]};
         }
     }
     __syncthreads();                                   // all LDS tiles free: they become the waves' output tiles
