@@ -158,7 +158,9 @@ __device__ __forceinline__ void split_k16x2(float a, float b, unsigned int& hi, 
 #endif
 }
 
-// ReLU that keeps NaN like torch.relu (fmaxf(NaN, 0) would return 0 and hide a poisoned row)
+// ReLU that keeps NaN like torch.relu (fmaxf(NaN, 0) would return 0 and hide a poisoned row).  (An integer maximum with 0 on the bit pattern is one
+// instruction instead of two, but zeroes a NaN whose sign bit is set -- and the NaN rows of a fully masked query do carry it after the
+// LayerNorm: tests/test_gpu_golden.py::test_fully_masked_row_golden fails with it.  Round 4.)
 __device__ __forceinline__ float relu_f(float v) { return v < 0.f ? 0.f : v; }
 
 // Reductions over the 64 lanes of a wave without the LDS crossbar, in the order of the xor butterfly they replace (32, 16, 8, 4, 2, 1):
