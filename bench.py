@@ -169,6 +169,7 @@ def main():
     ap.add_argument('--no-parity-leg', action='store_true', help='skip the single-sample run that counts the integer mismatches against the reference golden')
     ap.add_argument('--min-seconds', type=float, default=1.0, help='when the K timed steps take less than this, a second, longer loop of the same step is timed and reported beside them')
     ap.add_argument('--xattn-waves', type=int, default=None, help='waves per query of the tile cross-attention kernel (engine default: 2)')
+    ap.add_argument('--fuse-maps', type=int, default=None, help='1 / 0: force the per-head maps of the tile attention into / out of the neighbouring row kernels (engine default: by row count)')
     ap.add_argument('--force-collective', action='store_true', help='one rank: initialise the process group (nccl = RCCL) anyway and run the per-step all-gather of decoded boxes')
     ap.add_argument('--no-collective-leg', action='store_true', help='skip the one-rank RCCL leg (a sub-process of this script with --force-collective)')
     args = ap.parse_args()
@@ -203,6 +204,8 @@ def main():
     base.force_nc = args.force_nc
     if args.xattn_waves:
         base.xattn_waves = args.xattn_waves
+    if args.fuse_maps is not None:
+        base.fuse_maps = bool(args.fuse_maps)
     base.fork_qg = args.inflight == 1
     engines = [base] + [base.clone_shared() for _ in range(args.inflight - 1)]
     # frames in flight go on streams that were MEASURED to run concurrently (queue/pipe sharing serialises others)
