@@ -213,8 +213,14 @@ int mv2d_ffn_fused(const float* X, const float* W1, const float* b1, const float
 int mv2d_ffn_fused_x3(const float* X, const void* W1hi, const void* W1lo, const float* b1, const void* W2hi, const void* W2lo,
                       float* slabs, int M, int hidden, int slices_per_block, void* stream);
 
-/* Whi = bf16(W), Wlo = bf16(W - Whi): the weight pairs of the bf16x3 (query-side) kernels */
+/* Whi = bf16(W), Wlo = bf16(W - Whi): bf16 pairs (the training route's K-concatenated operands, mv2d_gemm_bf16 partners) */
 int mv2d_split_bf16x2(const float* x, void* hi, void* lo, long long n, void* stream);
+/* The SPLIT format of the query side ("q16", csrc/common.h): every `*_hi / *_lo` weight pair of the split-precision kernels below
+ * (documented as "bf16x3" / mv2d_split_bf16x2 in rounds 1-4) is produced by mv2d_split_q16x2 of the SAME library.  mv2d_q16_format():
+ * 1 = IEEE fp16 pairs (round 5: 11 + 11 significand bits, 2.7e-7 relative on a 256-term product, saturating at +-65504),
+ * 0 = bf16 pairs (8 + 8 bits, 4.5e-6; a -DMV2D_Q16_BF16 build).  Same bytes, same three MFMAs per product. */
+int mv2d_q16_format(void);
+int mv2d_split_q16x2(const float* x, void* hi, void* lo, long long n, void* stream);
 
 /* ---- row-wise ops on the [M,256] query state ------------------------------------------------------------- */
 

@@ -50,6 +50,8 @@ SIGNATURES = {
     'mv2d_ffn_pack_weights': (I, [P, P, P, P, I, P]),
     'mv2d_ffn_fused_x3': (I, [P, P, P, P, P, P, P, I, I, I, P]),
     'mv2d_split_bf16x2': (I, [P, P, P, LL, P]),
+    'mv2d_split_q16x2': (I, [P, P, P, LL, P]),
+    'mv2d_q16_format': (I, []),
     'mv2d_row_ln': (I, [P, I, LL, P, P, P, P, I, P, P, P, P, P, P, I, F, I, P]),
     'mv2d_finalize_reg': (I, [P, P, I, I, P, F, P]),
     'mv2d_avgpool49': (I, [P, P, I, I, P]),

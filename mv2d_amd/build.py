@@ -77,5 +77,36 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_variant(name, defs, verbose=True):
+    """A whole-library A/B build with extra -D flags (e.g. -DMV2D_Q16_BF16: the round-4 query-side format) ->
+    mv2d_amd/lib/variants/lib<name>.so; load it with MV2D_HIP_LIB=... (tools/ab_lib.sh)."""
+    hipcc = _hipcc()
+    vdir = os.path.join(LIBDIR, 'variants')
+    odir = os.path.join(vdir, 'obj_' + name)
+    os.makedirs(odir, exist_ok=True)
+
+    def cc(src):
+        obj = os.path.join(odir, os.path.basename(src)[:-4] + '.o')
+        r = subprocess.run([hipcc] + FLAGS + list(defs) + ['-c', src, '-o', obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed: %s\n%s' % (src, r.stderr))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(cc, _sources()))
+    out = os.path.join(vdir, 'lib%s.so' % name)
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', out], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n' + r.stderr)
+    shutil.rmtree(odir)
+    if verbose:
+        print('built', out, file=sys.stderr)
+    return out
+
+
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    if '--variant' in sys.argv:
+        i = sys.argv.index('--variant')
+        build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith('-D')])
+    else:
+        build(force='--force' in sys.argv)

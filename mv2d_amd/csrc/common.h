@@ -158,6 +158,56 @@ __device__ __forceinline__ void split_k16x2(float a, float b, unsigned int& hi, 
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// "q16": the 16-bit SPLIT format of the query side (and of the split-precision PE kernel): every fp32 operand x is carried as a pair
+// x ~ hi + lo and a product is a_hi.w_hi + a_lo.w_hi + a_hi.w_lo on three 16-bit MFMAs with fp32 accumulation.  Rounds 1-4: bf16 pairs
+// (8 + 8 significand bits, 2^-17 per operand: 4.5e-6 relative on a 256-term dot product, the floor of the index-exact route's class-logit
+// error).  Round 5: IEEE fp16 pairs (11 + 11 bits, 2^-23 per operand: 2.7e-7 on the same product -- tighter than an fp32 accumulation of
+// the exact products, 7.6e-7) at the same MFMA rate and bytes.  Range: the conversions saturate at +-65504 (NaN kept) like the key side's;
+// a lo part below 2^-14 is an fp16 subnormal, which the MFMA keeps (tools/f16_mfma_probe.hip): absolute error 2^-25 there.
+// -DMV2D_Q16_BF16 builds the round-4 format; mv2d_q16_format() reports which one a library has (the weights are split by
+// mv2d_split_q16x2 of the same library, so the two can never be mixed).
+// ------------------------------------------------------------------------------------------------------------------------------
+#if defined(MV2D_Q16_BF16) || !MV2D_KEY16_IS_F16
+#define MV2D_Q16_IS_F16 0
+typedef __attribute__((ext_vector_type(8))) __bf16 q16x8_t;
+__device__ __forceinline__ unsigned short f32_to_q16(float f) { return f32_to_bf16(f); }
+__device__ __forceinline__ float q16_to_f32(unsigned short h) { return bf16_to_f32(h); }
+__device__ __forceinline__ void split_q16x2(float a, float b, unsigned int& hi, unsigned int& lo) {
+    hi = pack_bf16x2(a, b);
+    lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+template <class A, class B>
+__device__ __forceinline__ f32x4_t mfma_q16_16x16x32(const A& a, const B& b, f32x4_t c, int = 0, int = 0, int = 0) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(q16x8_t, a), __builtin_bit_cast(q16x8_t, b), c, 0, 0, 0);
+}
+#else
+#define MV2D_Q16_IS_F16 1
+typedef __attribute__((ext_vector_type(8))) _Float16 q16x8_t;
+__device__ __forceinline__ unsigned short f32_to_q16(float f) { return f32_to_k16(f); }
+__device__ __forceinline__ float q16_to_f32(unsigned short h) { return k16_to_f32(h); }
+__device__ __forceinline__ void split_q16x2(float a, float b, unsigned int& hi, unsigned int& lo) { split_k16x2(a, b, hi, lo); }
+template <class A, class B>
+__device__ __forceinline__ f32x4_t mfma_q16_16x16x32(const A& a, const B& b, f32x4_t c, int = 0, int = 0, int = 0) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(q16x8_t, a), __builtin_bit_cast(q16x8_t, b), c, 0, 0, 0);
+}
+#endif
+// hi / lo of ONE value (LDS images written element-wise); the remainder is taken from the saturated value (see split_k16x2)
+__device__ __forceinline__ void split_q16(float v, unsigned short& hi, unsigned short& lo) {
+#if MV2D_Q16_IS_F16
+    const float c = k16_sat(v);
+    hi = __builtin_bit_cast(unsigned short, (_Float16)c);
+    lo = __builtin_bit_cast(unsigned short, (_Float16)(c - (float)__builtin_bit_cast(_Float16, hi)));
+#else
+    hi = f32_to_bf16(v);
+    lo = f32_to_bf16(v - bf16_to_f32(hi));
+#endif
+}
+__device__ __forceinline__ void split_q16x4(const float4& v, uint2& hi, uint2& lo) {
+    split_q16x2(v.x, v.y, hi.x, lo.x);
+    split_q16x2(v.z, v.w, hi.y, lo.y);
+}
+
 // ReLU that keeps NaN like torch.relu (fmaxf(NaN, 0) would return 0 and hide a poisoned row).  (An integer maximum with 0 on the bit pattern is one
 // instruction instead of two, but zeroes a NaN whose sign bit is set -- and the NaN rows of a fully masked query do carry it after the
 // LayerNorm: tests/test_gpu_golden.py::test_fully_masked_row_golden fails with it.  Round 4.)

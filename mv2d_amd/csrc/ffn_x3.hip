@@ -14,7 +14,7 @@
 namespace {
 
 constexpr int C = 256, HS = 64;               // channels, hidden slice
-typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+typedef q16x8_t mfma_bf16x8;      // common.h "q16": fp16 pairs since round 5
 union Frag { uint4 u; mfma_bf16x8 v; };
 
 // bf16 LDS images: X [32][256] (512 B rows, 32 slots of 16 B), H [32][64] (128 B rows, 8 slots); slot ^= row bits
@@ -22,8 +22,7 @@ __device__ __forceinline__ int xoff(int row, int slot) { return row * (C * 2) + 
 __device__ __forceinline__ int hoff(int row, int slot) { return row * (HS * 2) + ((slot ^ (row & 7)) << 4); }
 
 __device__ __forceinline__ void split2(float a, float b, unsigned int& hi, unsigned int& lo) {
-    hi = pack_bf16x2(a, b);
-    lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+    split_q16x2(a, b, hi, lo);
 }
 
 // G consecutive 64-wide hidden slices per block, accumulated in registers: hidden/(64 G) slabs instead of hidden/64 (experiment switch:
@@ -123,9 +122,9 @@ __global__ __launch_bounds__(256, 2) void ffn_x3_kernel(const float* __restrict_
                 Frag ah, al;
                 ah.u = *reinterpret_cast<const uint4*>(xh + xoff(r * 16 + fr, 4 * s + fg));
                 al.u = *reinterpret_cast<const uint4*>(xl + xoff(r * 16 + fr, 4 * s + fg));
-                h0[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1h[s].v, ah.v, h0[r], 0, 0, 0);
-                h1[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1h[s].v, al.v, h1[r], 0, 0, 0);
-                h1[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1l[s].v, ah.v, h1[r], 0, 0, 0);
+                h0[r] = mfma_q16_16x16x32(w1h[s].v, ah.v, h0[r], 0, 0, 0);
+                h1[r] = mfma_q16_16x16x32(w1h[s].v, al.v, h1[r], 0, 0, 0);
+                h1[r] = mfma_q16_16x16x32(w1l[s].v, ah.v, h1[r], 0, 0, 0);
             }
         }
         if (g + 1 < G) load_w1(slice + 1);               // the next slice's W1: in flight during the epilogue and phase 2
@@ -154,9 +153,9 @@ __global__ __launch_bounds__(256, 2) void ffn_x3_kernel(const float* __restrict_
                 gl.u = *reinterpret_cast<const uint4*>(hlg + hoff(r * 16 + fr, 4 * s + fg));
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    acc[0][r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2h[t][s].v, gh.v, acc[0][r][t], 0, 0, 0);
-                    acc[NACC - 1][r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2h[t][s].v, gl.v, acc[NACC - 1][r][t], 0, 0, 0);
-                    acc[NACC - 1][r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2l[t][s].v, gh.v, acc[NACC - 1][r][t], 0, 0, 0);
+                    acc[0][r][t] = mfma_q16_16x16x32(w2h[t][s].v, gh.v, acc[0][r][t], 0, 0, 0);
+                    acc[NACC - 1][r][t] = mfma_q16_16x16x32(w2h[t][s].v, gl.v, acc[NACC - 1][r][t], 0, 0, 0);
+                    acc[NACC - 1][r][t] = mfma_q16_16x16x32(w2l[t][s].v, gh.v, acc[NACC - 1][r][t], 0, 0, 0);
                 }
             }
         }

@@ -35,7 +35,7 @@ constexpr int OT_PITCH = 36;                                // floats per row of
 constexpr int SMEM = 4 * IMG + B_FLOATS * 4;                // A hi | A lo | H hi | H lo | biases = 135 KB
 static_assert(NW * BM * OT_PITCH * 4 <= 4 * IMG, "the waves' output tiles fit into the LDS images they replace");
 
-typedef __attribute__((ext_vector_type(8))) __bf16 px_bf16x8;
+typedef q16x8_t px_bf16x8;      // common.h "q16": fp16 pairs since round 5
 struct XFrag { uint4 h, l; };
 
 struct PeX3Params {
@@ -113,8 +113,7 @@ __device__ __forceinline__ void steps(f32x4_t (&acc)[RT][CT], XFrag (&wq)[RING][
                 for (int j = 0; j < CT; ++j) {
                     const XFrag& wf = wq[(T0 + K) % RING][j];
                     const XFrag& af = a[K & 1][i];
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(px_bf16x8, t == 0 ? wf.l : wf.h),
-                                                                         __builtin_bit_cast(px_bf16x8, t == 1 ? af.l : af.h), acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_q16_16x16x32(t == 0 ? wf.l : wf.h, t == 1 ? af.l : af.h, acc[i][j]);
                 }
         __builtin_amdgcn_sched_barrier(0);
         steps<T0, N, K + 1>(acc, wq, a, w, Lh, Ll, fr, fg);
@@ -129,9 +128,8 @@ __device__ __forceinline__ void zero_acc(f32x4_t (&acc)[RT][CT]) {
 }
 
 __device__ __forceinline__ void split4(float a, float b, float c, float d, uint2& hi, uint2& lo) {
-    hi = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
-    lo = make_uint2(pack_bf16x2(a - __uint_as_float(hi.x << 16), b - __uint_as_float(hi.x & 0xffff0000u)),
-                    pack_bf16x2(c - __uint_as_float(hi.y << 16), d - __uint_as_float(hi.y & 0xffff0000u)));
+    split_q16x2(a, b, hi.x, lo.x);
+    split_q16x2(c, d, hi.y, lo.y);
 }
 
 // layer 1 of part P into the hidden images: lane (fr, fg) holds hidden columns lcol..lcol+3 of row 16 i + fr -> bias, ReLU, hi / lo split,

@@ -208,13 +208,11 @@ struct AttnOutX3Params {
     const uint4* WAh; const uint4* WAl; uint4* Qt;
 };
 
-typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+typedef q16x8_t mfma_bf16x8;      // the query side's 16-bit split format (common.h "q16": fp16 pairs since round 5)
 union BFrag { uint4 u; mfma_bf16x8 v; };
 
 __device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
-    hi = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
-    lo = make_uint2(pack_bf16x2(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xffff0000u)),
-                    pack_bf16x2(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xffff0000u)));
+    split_q16x4(v, hi, lo);
 }
 
 // one 16x16 tile: sum over 8 k-steps of a_hi.w_hi + a_lo.w_hi + a_hi.w_lo; activation rows from the bf16 LDS images (512 B rows,
@@ -228,9 +226,9 @@ __device__ __forceinline__ f32x4_t tile_mma_x3(const unsigned char* __restrict__
         const int off = fr * 512 + (((4 * s + fg) ^ fr) << 4);
         xh.u = *reinterpret_cast<const uint4*>(ah + off);
         xl.u = *reinterpret_cast<const uint4*>(al + off);
-        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh.v, wh[s].v, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl.v, wh[s].v, a1, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh.v, wl[s].v, a1, 0, 0, 0);
+        a0 = mfma_q16_16x16x32(xh.v, wh[s].v, a0, 0, 0, 0);
+        a1 = mfma_q16_16x16x32(xl.v, wh[s].v, a1, 0, 0, 0);
+        a1 = mfma_q16_16x16x32(xh.v, wl[s].v, a1, 0, 0, 0);
     }
     return f32x4_t{a0[0] + a1[0], a0[1] + a1[1], a0[2] + a1[2], a0[3] + a1[3]};
 }
@@ -287,9 +285,9 @@ __global__ __launch_bounds__(1024) void attn_out_fused_x3_kernel(AttnOutX3Params
                 split8(*reinterpret_cast<const float4*>(zp + 32 * s), *reinterpret_cast<const float4*>(zp + 32 * s + 4), zh, zl);
                 bh.u = wbh[s * 128];
                 bl.u = wbl[s * 128];
-                ca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zl.v, bh.v, ca, 0, 0, 0);
-                ca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zh.v, bl.v, ca, 0, 0, 0);
-                ca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zh.v, bh.v, ca, 0, 0, 0);
+                ca = mfma_q16_16x16x32(zl.v, bh.v, ca, 0, 0, 0);
+                ca = mfma_q16_16x16x32(zh.v, bl.v, ca, 0, 0, 0);
+                ca = mfma_q16_16x16x32(zh.v, bh.v, ca, 0, 0, 0);
             }
             const int col = 16 * wave + fr;
 #pragma unroll
@@ -297,10 +295,11 @@ __global__ __launch_bounds__(1024) void attn_out_fused_x3_kernel(AttnOutX3Params
                 const int row = 4 * fg + r, m = min(mb + 16 * t + row, p.M - 1);
                 float v = ca[r] + bias;
                 if (p.row_ptr[m + 1] <= p.row_ptr[m]) v = p.empty_nan ? __uint_as_float(0x7fc00000u) : 0.f;
-                const unsigned short hb = f32_to_bf16(v);
+                unsigned short hb, lb;
+                split_q16(v, hb, lb);
                 const int off = t * 8192 + row * 512 + (((col >> 3) ^ row) << 4) + (col & 7) * 2;
                 *reinterpret_cast<unsigned short*>(ah + off) = hb;
-                *reinterpret_cast<unsigned short*>(al + off) = f32_to_bf16(v - bf16_to_f32(hb));
+                *reinterpret_cast<unsigned short*>(al + off) = lb;
             }
         }
         load_w_x3(wh, wl, p.Woh, p.Wol, wave, lane);
@@ -398,12 +397,12 @@ __global__ __launch_bounds__(1024) void attn_out_fused_x3_kernel(AttnOutX3Params
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alf[2 * u].v, bh.v, a0, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf[2 * u].v, bl.v, a0, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf[2 * u].v, bh.v, a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alf[2 * u + 1].v, bh.v, a1, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf[2 * u + 1].v, bl.v, a1, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf[2 * u + 1].v, bh.v, a1, 0, 0, 0);
+                a0 = mfma_q16_16x16x32(alf[2 * u].v, bh.v, a0, 0, 0, 0);
+                a0 = mfma_q16_16x16x32(ahf[2 * u].v, bl.v, a0, 0, 0, 0);
+                a0 = mfma_q16_16x16x32(ahf[2 * u].v, bh.v, a0, 0, 0, 0);
+                a1 = mfma_q16_16x16x32(alf[2 * u + 1].v, bh.v, a1, 0, 0, 0);
+                a1 = mfma_q16_16x16x32(ahf[2 * u + 1].v, bl.v, a1, 0, 0, 0);
+                a1 = mfma_q16_16x16x32(ahf[2 * u + 1].v, bh.v, a1, 0, 0, 0);
                 BFrag hi, lo;
                 {
                     // the operand of the tile cross attention is stored in the KEY-SIDE format (common.h key16: fp16), like xattn_qmap_kernel
@@ -690,9 +689,9 @@ __global__ __launch_bounds__(1024) void ffn_out_fused_x3_kernel(FfnOutParams p) 
                     const int off = rt * 8192 + fr * 512 + (((4 * (4 * h + s) + fg) ^ fr) << 4);
                     ya.u = *reinterpret_cast<const uint4*>(ah + off);
                     yb.u = *reinterpret_cast<const uint4*>(al + off);
-                    a0[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya.v, wh[buf][s].v, a0[rt], 0, 0, 0);
-                    a1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yb.v, wh[buf][s].v, a1[rt], 0, 0, 0);
-                    a1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya.v, wl[buf][s].v, a1[rt], 0, 0, 0);
+                    a0[rt] = mfma_q16_16x16x32(ya.v, wh[buf][s].v, a0[rt], 0, 0, 0);
+                    a1[rt] = mfma_q16_16x16x32(yb.v, wh[buf][s].v, a1[rt], 0, 0, 0);
+                    a1[rt] = mfma_q16_16x16x32(ya.v, wl[buf][s].v, a1[rt], 0, 0, 0);
                 }
             }
         }
@@ -772,7 +771,8 @@ __global__ __launch_bounds__(1024) void query_embed_fused_x3_kernel(QEmbParams p
             const float a = pos / p.dim_t[i];
             const float v = (i & 1) ? cosf(a) : sinf(a);
             if (live) p.posemb[(long long)r * 384 + ch] = v;
-            const unsigned short hi = f32_to_bf16(v), lo = f32_to_bf16(v - bf16_to_f32(hi));
+            unsigned short hi, lo;
+            split_q16(v, hi, lo);
             const int off = wave * 1024 + (((ch >> 3) ^ wave) << 4) + (ch & 7) * 2;
             *reinterpret_cast<unsigned short*>(eh + off) = hi;
             *reinterpret_cast<unsigned short*>(el + off) = lo;
@@ -788,9 +788,9 @@ __global__ __launch_bounds__(1024) void query_embed_fused_x3_kernel(QEmbParams p
             const int off = fr * 1024 + (((4 * s + fg) ^ fr) << 4);
             xh.u = *reinterpret_cast<const uint4*>(eh + off);
             xl.u = *reinterpret_cast<const uint4*>(el + off);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh.v, wh[s & 7].v, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl.v, wh[s & 7].v, a1, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh.v, wl[s & 7].v, a1, 0, 0, 0);
+            a0 = mfma_q16_16x16x32(xh.v, wh[s & 7].v, a0, 0, 0, 0);
+            a1 = mfma_q16_16x16x32(xl.v, wh[s & 7].v, a1, 0, 0, 0);
+            a1 = mfma_q16_16x16x32(xh.v, wl[s & 7].v, a1, 0, 0, 0);
             if (s == 3) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -813,7 +813,8 @@ __global__ __launch_bounds__(1024) void query_embed_fused_x3_kernel(QEmbParams p
         for (int q = 0; q < 4; ++q) {
             const int row = 4 * fg + q;
             const float v = relu_f((a0[q] + a1[q]) + b);
-            const unsigned short hi = f32_to_bf16(v), lo = f32_to_bf16(v - bf16_to_f32(hi));
+            unsigned short hi, lo;
+            split_q16(v, hi, lo);
             const int off = row * 512 + (((col >> 3) ^ row) << 4) + (col & 7) * 2;
             *reinterpret_cast<unsigned short*>(hh + off) = hi;
             *reinterpret_cast<unsigned short*>(hl + off) = lo;
@@ -1015,9 +1016,9 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinX3Params p) {
                     const int off = t * 8192 + fr * 512 + (((4 * s + fg) ^ fr) << 4);
                     xh.u = *reinterpret_cast<const uint4*>(bh + off);
                     xl.u = *reinterpret_cast<const uint4*>(bl + off);
-                    a0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh.v, wh[s].v, a0[t], 0, 0, 0);
-                    a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl.v, wh[s].v, a1[t], 0, 0, 0);
-                    a1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh.v, wl[s].v, a1[t], 0, 0, 0);
+                    a0[t] = mfma_q16_16x16x32(xh.v, wh[s].v, a0[t], 0, 0, 0);
+                    a1[t] = mfma_q16_16x16x32(xl.v, wh[s].v, a1[t], 0, 0, 0);
+                    a1[t] = mfma_q16_16x16x32(xh.v, wl[s].v, a1[t], 0, 0, 0);
                 }
             }
         }

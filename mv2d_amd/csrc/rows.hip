@@ -103,6 +103,17 @@ __global__ void split_bf16x2_kernel(const float* __restrict__ x, unsigned short*
     lo[i] = f32_to_bf16(f - __uint_as_float(((unsigned int)h) << 16));
 }
 
+// fp32 -> (hi, lo) pair in the query side's split format (common.h "q16": fp16 pairs since round 5; bf16 pairs in a -DMV2D_Q16_BF16 build):
+// the static weights of the split-precision kernels (row-fused linears, FFN, heads, per-head maps, PE x3)
+__global__ void split_q16x2_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned short h, l;
+    split_q16(x[i], h, l);
+    hi[i] = h;
+    lo[i] = l;
+}
+
 // fp32 -> key16 (common.h: the key-side 16-bit format, fp16 since round 4): static weights of the key-side kernels; hi only, or hi + lo
 __global__ void f32_to_key16_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, long long n) {
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
@@ -236,6 +247,18 @@ extern "C" int mv2d_split_bf16x2(const float* x, void* hi, void* lo, long long n
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
+
+extern "C" int mv2d_split_q16x2(const float* x, void* hi, void* lo, long long n, void* stream) {
+    MV2D_CHECK_ARG(x && hi && lo && n >= 0, "mv2d_split_q16x2: bad args");
+    if (n == 0) return MV2D_OK;
+    hipLaunchKernelGGL(split_q16x2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)hi,
+                       (unsigned short*)lo, n);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+// 1 = IEEE fp16 pairs, 0 = bf16 pairs (a -DMV2D_Q16_BF16 build): the split format of the query side, see common.h
+extern "C" int mv2d_q16_format(void) { return MV2D_Q16_IS_F16; }
 
 // 1 = IEEE fp16, 0 = bf16 (a -DMV2D_KEY16_BF16 build): the 16-bit format of the key side, see common.h
 extern "C" int mv2d_key16_format(void) { return MV2D_KEY16_IS_F16; }

@@ -18,13 +18,11 @@ namespace {
 
 constexpr int C = 256, HD = 32, KC = 128;                 // channels, head dim, keys per LDS chunk
 constexpr int VPITCH = KC * 2 + 16;                       // bytes per row of the transposed V images (pad: conflict-free 8-byte reads)
-typedef __attribute__((ext_vector_type(8))) __bf16 sa_bf16x8;
+typedef q16x8_t sa_bf16x8;      // common.h "q16": fp16 pairs since round 5
 union SFrag { uint4 u; sa_bf16x8 v; uint2 h[2]; };
 
 __device__ __forceinline__ void sa_split4(const float4& v, uint2& hi, uint2& lo) {
-    hi = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
-    lo = make_uint2(pack_bf16x2(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xffff0000u)),
-                    pack_bf16x2(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xffff0000u)));
+    split_q16x4(v, hi, lo);
 }
 
 template <bool DN>
@@ -112,9 +110,9 @@ __global__ __launch_bounds__(256) void self_attn_x3_kernel(const float* __restri
                 kh.u = *reinterpret_cast<const uint4*>(Kh + off);
                 kl.u = *reinterpret_cast<const uint4*>(Kl + off);
                 f32x4_t a = {0.f, 0.f, 0.f, 0.f};
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl.v, qh.v, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh.v, ql.v, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh.v, qh.v, a, 0, 0, 0);
+                a = mfma_q16_16x16x32(kl.v, qh.v, a, 0, 0, 0);
+                a = mfma_q16_16x16x32(kh.v, ql.v, a, 0, 0, 0);
+                a = mfma_q16_16x16x32(kh.v, qh.v, a, 0, 0, 0);
                 s[t] = a;
             }
             float p[8], tmax = -INFINITY;
@@ -164,9 +162,9 @@ __global__ __launch_bounds__(256) void self_attn_x3_kernel(const float* __restri
                 vl.h[0] = *reinterpret_cast<const uint2*>(Vl + off);
                 vl.h[1] = *reinterpret_cast<const uint2*>(Vl + off + 32);
                 f32x4_t& o = m ? o1 : o0;
-                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl.v, ph.v, o, 0, 0, 0);
-                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh.v, pl.v, o, 0, 0, 0);
-                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh.v, ph.v, o, 0, 0, 0);
+                o = mfma_q16_16x16x32(vl.v, ph.v, o, 0, 0, 0);
+                o = mfma_q16_16x16x32(vh.v, pl.v, o, 0, 0, 0);
+                o = mfma_q16_16x16x32(vh.v, ph.v, o, 0, 0, 0);
             }
         }
     }

@@ -28,17 +28,14 @@ namespace {
 constexpr int C = 256, HEADS = 8;
 constexpr float LOG2E = 1.4426950408889634f;
 
-typedef __attribute__((ext_vector_type(8))) __bf16 xt_bf16x8;
+typedef q16x8_t xt_bf16x8;      // the maps run in the query side's split format (common.h "q16": fp16 pairs since round 5)
 union XtFrag { uint4 u; xt_bf16x8 v; };
 
 __device__ __forceinline__ void xt_split8(const float4& x0, const float4& x1, XtFrag& hi, XtFrag& lo) {
     const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
     unsigned int h[4], l[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        h[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
-        l[i] = pack_bf16x2(f[2 * i] - __uint_as_float(h[i] << 16), f[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
-    }
+    for (int i = 0; i < 4; ++i) split_q16x2(f[2 * i], f[2 * i + 1], h[i], l[i]);
     hi.u = make_uint4(h[0], h[1], h[2], h[3]);
     lo.u = make_uint4(l[0], l[1], l[2], l[3]);
 }
@@ -80,9 +77,9 @@ __global__ __launch_bounds__(512) void xattn_qmap_kernel(const float* __restrict
         ah.u = wh[t * 64];
         al.u = wl[t * 64];
         f32x4_t a = {0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.v, bh.v, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bl.v, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bh.v, a, 0, 0, 0);
+        a = mfma_q16_16x16x32(al.v, bh.v, a, 0, 0, 0);
+        a = mfma_q16_16x16x32(ah.v, bl.v, a, 0, 0, 0);
+        a = mfma_q16_16x16x32(ah.v, bh.v, a, 0, 0, 0);
         acc[t] = a;
     }
     // the wave's 16 rows x 1 KB go through LDS (two halves of 8 rows) so that every store instruction writes ONE row's 1 KB contiguously: the MFMA
@@ -178,9 +175,9 @@ __global__ __launch_bounds__(512) void xattn_ctxmap_kernel(const float* __restri
             XtFrag bh, bl;
             bh.u = wh[(s * 2 + nt) * 64];
             bl.u = wl[(s * 2 + nt) * 64];
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.v, bh.v, acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bl.v, acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bh.v, acc[nt], 0, 0, 0);
+            acc[nt] = mfma_q16_16x16x32(al.v, bh.v, acc[nt], 0, 0, 0);
+            acc[nt] = mfma_q16_16x16x32(ah.v, bl.v, acc[nt], 0, 0, 0);
+            acc[nt] = mfma_q16_16x16x32(ah.v, bh.v, acc[nt], 0, 0, 0);
         }
     }
 #pragma unroll

@@ -182,11 +182,9 @@ class HeadEngine:
         for n, t in zip(names, packs):
             w['pe_pack'][n] = flat[off:off + t.numel()]
             off += t.numel()
-        # K-concatenated split-precision weights [w_hi | w_hi | w_lo] (bf16) for the plain tile GEMM (partner of mv2d_split3_rows): the sine
-        # branch's table is built in fp32-class arithmetic on BOTH routes (once per (weights, geometry)); the index-exact route runs all three
-        # PE MLPs that way per frame
+        # the sine branch's table is built in fp32-class arithmetic (split-precision linears on the unrounded sine rows; once per (weights, geometry))
         for n_, k_ in pe_names[2:4]:
-            w['pe_' + n_ + '_c3'] = ops.cat3_weight(c1(k_ + '.weight'))
+            w['pe_' + n_ + '_x3'] = ops.pack_x3(c1(k_ + '.weight'))
         if self.exact:
             # bf16 hi / lo fragment-major pairs for the split-precision PE kernel (csrc/pe_x3.hip)
             w['pe_x3'] = dict(b1a=w['pe_b1a'], b1b=w['pe_b1b'], br=w['pe_br'], be=w['pe_be'],
@@ -441,8 +439,9 @@ class HeadEngine:
             o.pe_inputs(s2, torch.tensor([Pt], dtype=torch.int32, device=self.dev), Pt, ws['featcl'], T['img2lidar'], T['coords_w'], T['coords_h'],
                         T['coords_d'], T['embeds'], self.const['dim_t'], k16e(3 * self.depth_num), k16e(384), k16e(C), None, V, h, w, self.depth_num,
                         self.post_range_h64, A_frustum_f32=a1f, A_sine_f32=a2f)
-            h2 = o.gemm_bf16(o.split3_rows(a2f), W_['pe_w2a_c3'], W_['pe_b2a'], act=1, split3=True)
-            tab = o.gemm_bf16(h2, W_['pe_w2b_c3'], W_['pe_b2b'], out_dtype=torch.float32)
+            w2a, w2b = self._pe_w32['w2a'], self._pe_w32['w2b']
+            h2 = o.linear_x3(a2f, W_['pe_w2a_x3'], W_['pe_b2a'], N=w2a.shape[0], K=w2a.shape[1], act=1)
+            tab = o.linear_x3(h2, W_['pe_w2b_x3'], W_['pe_b2b'], N=w2b.shape[0], K=w2b.shape[1])
             del a1f, a2f, h2
             # kept with the tables the workspaces of this map shape share; a captured graph holds the pointer: same shape -> refreshed in place
             if sh.get('sine_tab') is None or sh['sine_tab'].shape != tab.shape:

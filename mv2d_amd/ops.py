@@ -126,8 +126,9 @@ def attn_out_fused(ctx, resid, Wo, bo, ln, x_out, *, qpos=None, Wq=None, bq=None
 
 
 def pack_x3(W):
-    """fp32 [N,K] weight -> (hi, lo) bf16 pair, each fragment-major, for the bf16x3 (query-side) kernels."""
-    hi, lo = split_bf16x2(W.contiguous())
+    """fp32 [N,K] weight -> (hi, lo) pair in the query side's split format (q16: fp16 pairs since round 5), each fragment-major, for the
+    split-precision ("x3") kernels."""
+    hi, lo = split_q16x2(W.contiguous())
     return pack_wfrag(hi), pack_wfrag(lo)
 
 
@@ -307,7 +308,7 @@ def ffn_fused_x3(x, W1hl, b1, W2hl, slabs=None, M=None, groups=1):
     accumulated per block: hidden/64/groups slabs come out."""
     _req(x, torch.float32, 'x'); _req(b1, torch.float32, 'b1')
     for t in (*W1hl, *W2hl):
-        _req(t, BF16, 'W')
+        _req(t, q16_dtype(), 'W')
     M = x.shape[0] if M is None else M
     hidden = W1hl[0].numel() // 256                  # packed (fragment-major) copies are flat
     if slabs is None:
@@ -323,6 +324,21 @@ def split_bf16x2(w):
     hi = torch.empty(w.shape, device=w.device, dtype=BF16)
     lo = torch.empty(w.shape, device=w.device, dtype=BF16)
     check(_lib.load().mv2d_split_bf16x2(_p(w), _p(hi), _p(lo), w.numel(), _stream()), 'mv2d_split_bf16x2')
+    return hi, lo
+
+
+def q16_dtype():
+    """torch dtype of the query side's split format (csrc/common.h "q16"): torch.float16 since round 5 (mv2d_q16_format() == 1)."""
+    return torch.float16 if _lib.load().mv2d_q16_format() == 1 else BF16
+
+
+def split_q16x2(w):
+    """fp32 tensor -> (hi, lo) pair with w ~= hi + lo in the library's q16 format (fp16: |err| ~ 2^-23 |w|, bf16: 2^-17 |w|)."""
+    _req(w, torch.float32, 'w')
+    dt = q16_dtype()
+    hi = torch.empty(w.shape, device=w.device, dtype=dt)
+    lo = torch.empty(w.shape, device=w.device, dtype=dt)
+    check(_lib.load().mv2d_split_q16x2(_p(w), _p(hi), _p(lo), w.numel(), _stream()), 'mv2d_split_q16x2')
     return hi, lo
 
 
@@ -374,7 +390,7 @@ def pe_fused_x3(A1, Xmap, m_dev, wx, sine_tab, tab_period, pe=None, Xk=None, Xv=
         if pair is not None:
             _req16(pair[0], 'hi'); _req16(pair[1], 'lo')
     for k in ('w1a', 'w1b', 'wr', 'we'):
-        _req(wx[k][0], BF16, k); _req(wx[k][1], BF16, k)
+        _req(wx[k][0], q16_dtype(), k); _req(wx[k][1], q16_dtype(), k)
     M = A1.shape[0] if M is None else M
     xk, xv = Xk or (None, None), Xv or (None, None)
     check(_lib.load().mv2d_pe_fused_x3(_p(A1), _p(Xmap), _p(row_index), _p(m_dev), M, _p(wx['w1a'][0]), _p(wx['w1a'][1]), _p(wx['b1a']),
@@ -524,12 +540,12 @@ def pack_xattn_maps(Wk, Wv):
     wa = Wk[32 * h + 8 * g + e, 32 * (t >> 1) + 8 * (m >> 2) + 4 * (t & 1) + (m & 3)].contiguous()
     h, s, nt, g, n_, e = torch.meshgrid(ar(8), ar(8), ar(2), ar(4), ar(16), ar(8), indexing='ij')
     wb = Wv[32 * h + 16 * nt + n_, 32 * s + 8 * g + e].contiguous()
-    return split_bf16x2(wa.view(-1)), split_bf16x2(wb.view(-1))
+    return split_q16x2(wa.view(-1)), split_q16x2(wb.view(-1))
 
 
 def xattn_qmap(q, WA, Qt=None, R=None):
     """q [R,256] fp32 (pre-scaled) -> Qt [R,4096] key16: the fragment-major 16 x 256 operand (hi / lo rows of the 8 per-head maps)."""
-    _req(q, torch.float32, 'q'); _req(WA[0], BF16, 'WA_hi'); _req(WA[1], BF16, 'WA_lo')
+    _req(q, torch.float32, 'q'); _req(WA[0], q16_dtype(), 'WA_hi'); _req(WA[1], q16_dtype(), 'WA_lo')
     R = q.shape[0] if R is None else R
     if Qt is None:
         Qt = torch.empty((R, 4096), device=q.device, dtype=key16_dtype())
@@ -563,7 +579,7 @@ def xattn_query_order(row_ptr, col_idx, grp_start, R, perm, flags, stride=0):
 
 def xattn_ctxmap(z, WB, bv, row_ptr, out=None, R=None, empty_nan=True):
     """z [R,8,256] fp32 -> ctx [R,256] = Wv_h z_h + bv; rows without a key (row_ptr) give NaN / 0."""
-    _req(z, torch.float32, 'z'); _req(WB[0], BF16, 'WB_hi'); _req(WB[1], BF16, 'WB_lo'); _req(bv, torch.float32, 'bv')
+    _req(z, torch.float32, 'z'); _req(WB[0], q16_dtype(), 'WB_hi'); _req(WB[1], q16_dtype(), 'WB_lo'); _req(bv, torch.float32, 'bv')
     _req(row_ptr, torch.int32, 'row_ptr')
     R = z.shape[0] if R is None else R
     if out is None:
