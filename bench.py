@@ -163,7 +163,11 @@ def main():
     ap.add_argument('--cpu-iters', type=int, default=24)       # ~10 s of CPU work on the bounded sample
     ap.add_argument('--cpu-threads', type=int, default=16)      # second CPU leg; the first uses os.cpu_count() threads (BASELINE.md protocol)
     ap.add_argument('--cpu-timeout', type=int, default=150)
-    ap.add_argument('--exact', action='store_true', help='run the timed loop on the index-exact route (HeadEngine(exact=True)) instead of the default route')
+    ap.add_argument('--cpu-all-budget', type=int, default=40, help='seconds of the bounded all-cores CPU leg (BASELINE.md protocol: os.cpu_count() threads, 3 warm-ups)')
+    ap.add_argument('--key16', action='store_true', help='run the timed loop in the OPT-IN key16 mode (HeadEngine(exact=False): one fp16 rounding of the key side, '
+                                                        'ranked indices differ from the reference) instead of the index-exact route, which is the default since round 5')
+    ap.add_argument('--exact', action='store_true', help='(round-4 flag; the index-exact route is the default now -- accepted and ignored)')
+    ap.add_argument('--spawn-check', action='store_true', help='only initialise the process group, all-gather the ranks, print one JSON line (no GPU work): the self-spawn test')
     ap.add_argument('--brief', action='store_true', help='headline timing + tile-kernel roofline only (what the other_workloads legs of the default run call)')
     ap.add_argument('--no-other-workloads', action='store_true', help='skip the short cfg3_t / cfg5_t legs (sub-processes of this script)')
     ap.add_argument('--no-parity-leg', action='store_true', help='skip the single-sample run that counts the integer mismatches against the reference golden')
@@ -183,6 +187,34 @@ def main():
             s_.close()
     if args.brief:
         args.no_extra_legs = args.no_cpu_baseline = args.no_other_workloads = args.no_collective_leg = True
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (tools/dist_test.sh:10-22 of the
+        # reference does the same with torch.distributed.launch).  The driver's own `python -m torch.distributed.run ... bench.py --gpus N` sets
+        # WORLD_SIZE and never comes here.
+        import socket
+        s_ = socket.socket()
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+    if args.spawn_check:
+        import torch.distributed as dist_
+        from mv2d_amd import dist as mdist_
+        rank_, world_, _ = mdist_.init_from_env(backend=args.backend)
+        assert world_ == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world_}'
+        got = [None] * world_
+        if world_ > 1:
+            dist_.all_gather_object(got, rank_)
+            dist_.barrier()
+            dist_.destroy_process_group()
+        else:
+            got = [0]
+        if rank_ == 0:
+            print(json.dumps(dict(spawn_check=True, world=world_, ranks=got, backend=args.backend or 'nccl')), flush=True)
+        return
 
     from mv2d_amd import dist as mdist
     from mv2d_amd import ops, synthetic
@@ -200,7 +232,7 @@ def main():
     prob = synthetic.make_problem(args.workload, seed=rank)        # weak scaling: every rank its own frames
     kind = prob['kind']
     sd = synthetic.make_head_state(seed=0)
-    base = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'], topk=args.corr_topk, exact=True if args.exact else None)
+    base = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'], topk=args.corr_topk, exact=not args.key16)
     base.force_nc = args.force_nc
     if args.xattn_waves:
         base.xattn_waves = args.xattn_waves
@@ -382,28 +414,32 @@ def main():
                 lat.append(time.perf_counter() - t_)
         extra['latency_ms_single_stream'] = round(statistics.median(lat) * 1e3, 4)
         extra['samples_s_single_stream'] = round(1.0 / statistics.median(lat), 2)
-        # (d) the INDEX-EXACT route (HeadEngine(exact=True): fp32-class key side, graph-replayed like the default route), same protocol
-        # as the headline: same streams, same rotating frame sets, same batch
-        ex_base = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'], topk=args.corr_topk, exact=True)
-        ex_base.fork_qg = False
-        ex_engines = [ex_base] + [ex_base.clone_shared() for _ in range(args.inflight - 1)]
+        # (d) the OTHER mode (the headline runs the index-exact route unless --key16: then this leg is the index-exact one), same protocol as the
+        # headline: same streams, same rotating frame sets, same batch.  key16 = HeadEngine(exact=False): ONE fp16 rounding of the key side, opt-in.
+        alt_base = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'], topk=args.corr_topk, exact=args.key16)
+        alt_base.fork_qg = False
+        alt_engines = [alt_base] + [alt_base.clone_shared() for _ in range(args.inflight - 1)]
         n_e = max(10, min(args.steps, 60))
-        el = timed(make_step(ex_engines, streams, sets_main, pool_main, B, payload), n_e, K + 1)
-        extra['samples_s_index_exact'] = round(args.inflight * B * n_e / el, 2)
-        extra['index_exact_vs_default'] = round(extra['samples_s_index_exact'] / value, 3)
-        # (e) integer parity of both routes against the REFERENCE's own output on the seed-0 frame of this workload (tests/golden/<workload>.npz,
+        el = timed(make_step(alt_engines, streams, sets_main, pool_main, B, payload), n_e, K + 1)
+        alt_v = round(args.inflight * B * n_e / el, 2)
+        ex_v, k16_v = (alt_v, value) if args.key16 else (value, alt_v)
+        extra['samples_s_index_exact'] = round(ex_v, 2)
+        extra['samples_s_key16_mode_opt_in'] = round(k16_v, 2)
+        extra['index_exact_vs_key16_mode'] = round(ex_v / k16_v, 3)
+        # (e) integer parity of both modes against the REFERENCE's own output on the seed-0 frame of this workload (tests/golden/<workload>.npz,
         # produced by the unmodified reference, oracle/gen_golden.py): ranked labels / ranked (query, class) indices / top-k set entries that differ
         gold = golden_for(args)
         if gold is not None:
-            extra['index_mismatches'] = dict(default=index_mismatches(base, gold, feat, props, metas), index_exact=index_mismatches(ex_base, gold, feat, props, metas),
+            ex_e, k16_e = (alt_base, base) if args.key16 else (base, alt_base)
+            extra['index_mismatches'] = dict(index_exact=index_mismatches(ex_e, gold, feat, props, metas), key16_mode=index_mismatches(k16_e, gold, feat, props, metas),
                                              reference='tests/golden/%s.npz (unmodified reference, seed-0 frame)' % args.workload)
-        del ex_engines, ex_base
+        del alt_engines, alt_base
 
     if 'index_mismatches' not in extra and world == 1 and not args.no_parity_leg:
         gold = golden_for(args)
-        if gold is not None:            # (--brief / --no-extra-legs: the default route only)
-            extra['index_mismatches'] = dict(default=index_mismatches(base, gold, feat, props, metas),
-                                             reference='tests/golden/%s.npz (unmodified reference, seed-0 frame)' % args.workload)
+        if gold is not None:            # (--brief / --no-extra-legs: the route of the timed loop only)
+            extra['index_mismatches'] = {'key16_mode' if args.key16 else 'index_exact': index_mismatches(base, gold, feat, props, metas),
+                                         'reference': 'tests/golden/%s.npz (unmodified reference, seed-0 frame)' % args.workload}
     # ---------------- per-stage timing of the same frame with HIP events on the launch stream (single stream, eager)
     eng = base
     run_once = (lambda: eng.run_batch(feats_b, props_b, metas_b)) if B > 1 else (lambda: eng.run(feat, props, metas))
@@ -513,15 +549,25 @@ def main():
         # algorithmic HBM bytes: every key row that some query reads, once (K and V, key16 = 2 B per element) + Qt in + z out.  Rows read by several queries
         # (T path: 2.9 per row) are counted once here — the repeats are L2 / Infinity Cache traffic; `gathered_bytes` counts them all.
         n_rows = min(nnz, S if kind == 'T' else R * 49)
-        row_b = 2 * 256 * 2 * (2 if xlo else 1)                                     # K + V row, key16 (index-exact route: hi + lo rows)
-        x_bytes = n_rows * row_b + R * (16 * 256 * 2 + 8 * 256 * 4)
-        x_gathered = nnz * row_b + R * (16 * 256 * 2 + 8 * 256 * 4)
+        b_el = 4 if xlo else 2                                                      # bytes per key / value element: fp16 hi + lo pair (fp32-class) or one fp16
+        row_b = 2 * 256 * b_el                                                      # K + V row
+        own = R * (16 * 256 * 2 + 8 * 256 * 4)                                      # Qt in + z out: intermediates of THIS decomposition (qmap -> tile -> ctxmap)
+        # SURVEY 8(d) per layer: read X_k, X_v (2 S C b) + query state in / out (2 Q C 4).  `frac` follows from these bytes ALONE (round 4 also
+        # counted Qt / z, which exist only because the attention is split into three kernels: that figure stays as frac_incl_own_intermediates)
+        x_bytes = n_rows * row_b + 2 * R * 256 * 4
+        x_gathered = nnz * row_b + own
         x_flops = 2.0 * nnz * 8 * 256 * 2                                          # logits + P.V in the 256-dim input space, 8 heads
         xattn = roof('xattn_tile', 'xattn_tile_kernel (sparse cross-attention in the raw key space, one launch per decoder layer)', x_ms, x_flops, x_bytes,
                      launches=eng.L)
+        gbs = lambda nb: nb / (x_ms * 1e-3) / 1e9      # noqa: E731
+        xattn['bytes_per_element'] = b_el
+        xattn['frac_incl_own_intermediates'] = round(gbs(n_rows * row_b + own) / PEAK_HBM_GBS, 4)
+        xattn['frac_at_survey_b2'] = round(gbs(n_rows * 2 * 256 * 2 + 2 * R * 256 * 4) / PEAK_HBM_GBS, 4)
         xattn['gathered_bytes_per_launch'] = int(x_gathered)
         xattn['gathered_gbs'] = round(x_gathered / (x_ms * 1e-3) / 1e9, 1)
-        xattn['note'] = ('bytes_per_launch = K and V rows read by at least one query, once, + Qt in + z out (the HBM lower bound); '
+        xattn['note'] = ('bytes_per_launch = SURVEY 8(d): K and V rows read by at least one query, once (b bytes per element: 4 = fp16 hi + lo pair of the '
+                         'index-exact route, the width the fp32 reference reads; 2 = key16 mode) + the query state in / out (2 Q C 4); frac_at_survey_b2 = the '
+                         'same time priced at the b = 2 SURVEY 8(d) assumed; frac_incl_own_intermediates also counts Qt in + z out (8 KB each per query); '
                          'gathered_bytes_per_launch = the rows of every allowed (query, key) pair (repeats are served by L2 / Infinity Cache)')
         stage_roofline['xattn_tile'] = xattn
     # the dominant kernel = the one with the most time per step (launch duration x launches per step)
@@ -533,10 +579,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import subprocess
 
-        def cpu_leg(threads, iters, tmo):
+        def cpu_leg(threads, iters, tmo, more=()):
             try:
                 r = subprocess.run([sys.executable, '-m', 'oracle.cpu_baseline', '--workload', args.workload, '--iters', str(iters),
-                                    '--threads', str(threads)], cwd=ROOT, capture_output=True, text=True, timeout=tmo)
+                                    '--threads', str(threads), *more], cwd=ROOT, capture_output=True, text=True, timeout=tmo)
                 lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
                 return json.loads(lines[-1]) if lines else dict(value=None, unit='samples/s', cores=threads, kind='port',
                                                                 sample=f'oracle subprocess failed: {r.stderr[-200:]}')
@@ -547,12 +593,12 @@ def main():
         # spend their time waking threads and may not finish; reported as measured either way)
         cpu = cpu_leg(min(os.cpu_count() or 1, args.cpu_threads), args.cpu_iters, args.cpu_timeout)
         nc_ = os.cpu_count() or 1
-        if nc_ != args.cpu_threads and nc_ <= 64:
-            cpu2 = cpu_leg(nc_, 3, 15)
-        elif nc_ != args.cpu_threads:
-            # measured in round 2: on the 256-thread hosts of this pool the oracle's many small operators spend their
-            # time waking threads (8 / 16 / 32 / 64 threads: 2.24 / 2.09 / 1.53 / 0.67 samples/s) and the all-cores leg never finished in 75 s
-            cpu2 = dict(value=None, unit='samples/s', cores=nc_, kind='port', sample='skipped: os.cpu_count() > 64 (thread sweep in DESIGN.md section 5)')
+        if nc_ != args.cpu_threads:
+            # torch.set_num_threads(os.cpu_count()), 3 warm-ups.  On the 256-thread hosts of this pool the oracle's many
+            # small operators spend their time waking threads (8 / 16 / 32 / 64 threads: 2.24 / 2.09 / 1.53 / 0.67 samples/s),
+            # so the leg is BOUNDED (the warm-ups stop after half of --cpu-all-budget seconds, the timing after all of it, at least one timed frame)
+            # and reports what it measured, however slow
+            cpu2 = cpu_leg(nc_, 3, args.cpu_all_budget * 2 + 60, ('--warmups', '3', '--budget-s', str(args.cpu_all_budget), '--no-decoder'))
 
     other = None
     if rank == 0 and world == 1 and not args.no_other_workloads and args.workload == 'cfg2_s':
@@ -567,16 +613,16 @@ def main():
                                     '--brief'], cwd=ROOT, capture_output=True, text=True, timeout=240)
                 ls_ = [l for l in r.stdout.splitlines() if l.startswith('{')]
                 d_ = json.loads(ls_[-1])
-                other[wl_] = {k: d_.get(k) for k in ('value', 'unit', 'ms_per_step', 'steps', 'config', 'decoder_ms_per_iter', 'decoder_ms_per_launch', 'roofline',
+                other[wl_] = {k: d_.get(k) for k in ('value', 'unit', 'route', 'ms_per_step', 'steps', 'config', 'decoder_ms_per_iter', 'decoder_ms_per_launch', 'roofline',
                                                      'index_mismatches')}
-                # ... and the same loop on the index-exact route
+                # ... and the same loop in the opt-in key16 mode
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), '--workload', wl_, '--batch', str(b_), '--steps', '60', '--warmup', '10',
-                                    '--brief', '--exact'], cwd=ROOT, capture_output=True, text=True, timeout=240)
+                                    '--brief', '--key16'], cwd=ROOT, capture_output=True, text=True, timeout=240)
                 ls_ = [l for l in r.stdout.splitlines() if l.startswith('{')]
                 d2_ = json.loads(ls_[-1])
-                other[wl_]['samples_s_index_exact'] = d2_.get('value')
-                other[wl_]['index_exact_vs_default'] = round(d2_['value'] / d_['value'], 3) if d_.get('value') else None
-                other[wl_]['index_mismatches_index_exact'] = (d2_.get('index_mismatches') or {}).get('default')
+                other[wl_]['samples_s_key16_mode_opt_in'] = d2_.get('value')
+                other[wl_]['index_exact_vs_key16_mode'] = round(d_['value'] / d2_['value'], 3) if d2_.get('value') else None
+                other[wl_]['index_mismatches_key16_mode'] = (d2_.get('index_mismatches') or {}).get('key16_mode')
             except Exception as ex_:          # noqa: BLE001
                 other[wl_] = dict(value=None, error=repr(ex_)[:300])
 
@@ -603,18 +649,26 @@ def main():
         def _cnt(d_):
             return None if not d_ else '%s/%s' % (d_.get('ranked_indices'), d_.get('of'))
         im_ = extra['index_mismatches']
-        parity = {args.workload: dict(default=_cnt(im_.get('default')), index_exact=_cnt(im_.get('index_exact')))}
+        parity = {args.workload: dict(index_exact=_cnt(im_.get('index_exact')), key16_mode=_cnt(im_.get('key16_mode')))}
         for wl_, d_ in (other or {}).items():
             if isinstance(d_, dict) and d_.get('index_mismatches'):
-                parity[wl_] = dict(default=_cnt(d_['index_mismatches'].get('default')), index_exact=_cnt(d_.get('index_mismatches_index_exact')))
+                parity[wl_] = dict(index_exact=_cnt(d_['index_mismatches'].get('index_exact')), key16_mode=_cnt(d_.get('index_mismatches_key16_mode')))
+        try:
+            rn_ = np.load(os.path.join(ROOT, 'tests', 'golden', 'refnoise.npz'))
+            parity['reference_vs_itself'] = {k[:-len('_pairwise_ranked_diff')]: '%d/300' % int(rn_[k].max()) for k in rn_.files if k.endswith('_pairwise_ranked_diff')}
+            parity['reference_vs_itself_note'] = ('ranked indices that differ between runs of the UNMODIFIED reference on the same inputs under other intra-op thread '
+                                                  'counts / oneDNN off (oracle/gen_golden_refnoise.py; <workload>_s<seed>): the resolution of "bit-exact"')
+        except Exception:      # noqa: BLE001
+            pass
 
     if rank == 0:
         line = {
             'metric': 'multi-view samples/sec (6-cam frames) through the MV2D RoI-head hot path',
             'value': round(value, 2), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'setup_steps': args.prime,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': (('%s hi + lo split precision on the key side (index-exact route) / bf16x3 (query side)' if args.exact else
-                       '%s (key side MFMA) / f32 + bf16x3 split precision (query side)') % ('f16' if ops.key16_dtype() == torch.float16 else 'bf16')), 'data': 'synthetic', 'route': 'index_exact' if args.exact else 'default',
+            'dtype': (('f16 (ONE rounding of the key side: opt-in key16 mode) / f16x3 split precision (query side)' if args.key16 else
+                       'f16x3: every operand an fp16 hi + lo pair, three MFMAs per product, fp32 accumulation (fp32-class, index-exact route)')), 'data': 'synthetic',
+            'route': 'key16_mode_opt_in' if args.key16 else 'index_exact',
             'config': {'workload': f'{args.workload}: MV2D-{kind} head, {len(metas)} views {metas[0]["img_shape"][1]}x{metas[0]["img_shape"][0]}, '
                                    f'R={R} queries, S={S} key positions, nnz={nnz} allowed (q,k) pairs = {nnz / max(R, 1):.1f} keys per query' + (f' (totals of the {B} samples of a launch)' if B > 1 else '') + (f', corr_topk={args.corr_topk}' if args.corr_topk else '') + (f', forced n_c={args.force_nc}' if args.force_nc else ''),
                        'frames_per_step_per_gpu': args.inflight * B, 'global_batch': world * args.inflight * B,

@@ -20,6 +20,10 @@ def main():
     ap.add_argument('--workload', default='cfg2_s')
     ap.add_argument('--iters', type=int, default=3)
     ap.add_argument('--threads', type=int, default=16)
+    ap.add_argument('--warmups', type=int, default=1, help='untimed frames first (BASELINE.md section 3 protocol: 3)')
+    ap.add_argument('--budget-s', type=float, default=0.0, help='> 0: stop warming up after half of it and stop timing after all of it (at least one '
+                                                               'timed frame is always taken): a bounded leg that reports what it measured')
+    ap.add_argument('--no-decoder', action='store_true', help='skip the decoder-only leg')
     a = ap.parse_args()
     import torch
     from mv2d_amd import synthetic
@@ -32,12 +36,24 @@ def main():
     feat = torch.from_numpy(prob['feat'])
     props = [torch.from_numpy(p) for p in prob['proposals']]
     ts = []
+    t_start = time.perf_counter()
+    over = lambda frac: a.budget_s > 0 and time.perf_counter() - t_start > frac * a.budget_s      # noqa: E731
+    warm = 0
     with torch.no_grad():
-        fn(sd, feat, props, prob['img_metas'], **kw)
+        for _ in range(max(a.warmups, 1)):
+            fn(sd, feat, props, prob['img_metas'], **kw)
+            warm += 1
+            if over(0.5):
+                break
         for _ in range(a.iters):
             t0 = time.perf_counter()
             fn(sd, feat, props, prob['img_metas'], **kw)
             ts.append(time.perf_counter() - t0)
+            if over(1.0):
+                break
+        td = [float('nan')]
+        if a.no_decoder:
+            return report(a, torch, ts, td, warm)
         # decoder-only leg (CrossAttentionBoxHead.forward on prepared inputs: 6 layers + heads), the second headline metric
         st = {}
         fn(sd, feat, props, prob['img_metas'], stages=st, **kw)
@@ -56,11 +72,17 @@ def main():
             t0 = time.perf_counter()
             dec()
             td.append(time.perf_counter() - t0)
+    report(a, torch, ts, td, warm)
+
+
+def report(a, torch, ts, td, warm):
     med = statistics.median(ts)
+    dec = statistics.median(td)
     print(json.dumps(dict(value=round(1.0 / med, 4), unit='samples/s', cores=a.threads, kind='port',
-                          decoder_ms_per_iter=round(statistics.median(td) * 1e3, 2),
-                          sample=f'{a.iters} frames of {a.workload} after 1 warm-up, median {med * 1e3:.0f} ms/frame, torch '
-                                 f'{torch.__version__} CPU fp32/fp64, {a.threads} threads of {os.cpu_count()} host cores')))
+                          decoder_ms_per_iter=None if dec != dec else round(dec * 1e3, 2), frames_timed=len(ts), warmups=warm,
+                          sample=f'{len(ts)} frames of {a.workload} after {warm} warm-up(s), median {med * 1e3:.0f} ms/frame, torch '
+                                 f'{torch.__version__} CPU fp32/fp64, {a.threads} threads of {os.cpu_count()} host cores' +
+                                 (f' (bounded to {a.budget_s:.0f} s)' if a.budget_s > 0 else ''))))
 
 
 if __name__ == '__main__':

@@ -16,12 +16,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--workload', default='cfg2_s')
 ap.add_argument('--batch', type=int, default=8)
 ap.add_argument('--steps', type=int, default=20)
-ap.add_argument('--exact', action='store_true')
+ap.add_argument('--exact', action='store_true', help='(the default since round 5; accepted and ignored)')
+ap.add_argument('--key16', action='store_true', help='the opt-in key16 mode (one fp16 rounding of the key side)')
 ap.add_argument('--eager', action='store_true')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 probs = [synthetic.make_problem(a.workload, seed=s) for s in range(a.batch)]
-eng = HeadEngine(synthetic.make_head_state(seed=0), probs[0]['kind'], dev, num_views=probs[0]['views_per_frame'], exact=a.exact)
+eng = HeadEngine(synthetic.make_head_state(seed=0), probs[0]['kind'], dev, num_views=probs[0]['views_per_frame'], exact=not a.key16)
 eng.fork_qg = False
 feats = torch.cat([torch.from_numpy(p['feat']) for p in probs]).to(dev)
 props = [[torch.from_numpy(x) for x in p['proposals']] for p in probs]
@@ -35,4 +36,4 @@ for _ in range(a.steps):
     run()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
-print(f'{a.workload} batch {a.batch} exact={a.exact}: {dt * 1e3:.3f} ms per launch sequence, {a.batch / dt:.0f} samples/s on one stream')
+print(f'{a.workload} batch {a.batch} route={'key16' if a.key16 else 'index-exact'}: {dt * 1e3:.3f} ms per launch sequence, {a.batch / dt:.0f} samples/s on one stream')
