@@ -28,7 +28,10 @@ namespace {
 
 constexpr int C = 256;
 constexpr int PITCH = 512;                                  // bytes per row of an LDS image (256 bf16), 16-byte chunk c of row r at c ^ (r & 15)
-constexpr int RT = 4, NW = 4, CT = 4, BM = 16 * RT, NTHR = 64 * NW, RING = 3;
+#ifndef MV2D_PX_RING
+#define MV2D_PX_RING 3
+#endif
+constexpr int RT = 4, NW = 4, CT = 4, BM = 16 * RT, NTHR = 64 * NW, RING = MV2D_PX_RING;
 constexpr int IMG = BM * PITCH;                             // one 64-row image: 32 KB
 enum { B_R = 0, B_E = 256, B_1A = 512, B_1B = 1536, B_FLOATS = 1792 };
 constexpr int OT_PITCH = 36;                                // floats per row of a wave's output tile [BM][32 columns]
@@ -204,6 +207,9 @@ __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
     PX_STAMP(0);
     ring_load<0>(wq, w);
     ring_load<1>(wq, w);
+    if constexpr (RING > 3) ring_load<2>(wq, w);
+    if constexpr (RING > 4) ring_load<3>(wq, w);
+    if constexpr (RING > 5) ring_load<4>(wq, w);
     {
         // biases -> LDS: [br | be | b1a | b1b] as 448 float4
         constexpr int NB = (B_FLOATS / 4 + NTHR - 1) / NTHR;

@@ -36,4 +36,4 @@ for _ in range(a.steps):
     run()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
-print(f'{a.workload} batch {a.batch} route={'key16' if a.key16 else 'index-exact'}: {dt * 1e3:.3f} ms per launch sequence, {a.batch / dt:.0f} samples/s on one stream')
+print(f'{a.workload} batch {a.batch} route={"key16" if a.key16 else "index-exact"}: {dt * 1e3:.3f} ms per launch sequence, {a.batch / dt:.0f} samples/s on one stream')
