@@ -424,6 +424,12 @@ int mv2d_roi_positions_csr(const float* rois, const unsigned char* pad_mask, uns
                            int* S_out, int R, int V, int h, int w, float stride, float expand_stride, const int* match, int* row_ptr,
                            int* col_idx, int* nnz_out, int Vg, int topk, const int* grp_start, int n_samples, int* order, void* stream);
 
+/* Frustum rows of the index-exact route's PE block alone: out [S, 3 depth_num] fp32 = float(inverse_sigmoid(normalised 3-D point of every depth bin)),
+ * computed in fp64 like the reference (MU/pe.py:96-131) at the positions s2pos[0 .. *S_dev); position_range = 6 doubles on the HOST.  Replaces the
+ * A_frustum_f32 output of mv2d_pe_inputs on the inference path (same values up to one fp32 ulp in ~1 element per 1e8; 3-4 x faster). */
+int mv2d_pe_frustum_f32(const int* s2pos, const int* S_dev, int S_max, const double* img2lidar, const double* coords_w, const double* coords_h,
+                        const double* coords_d, float* out, int V, int h, int w, int depth_num, const double* position_range, void* stream);
+
 /* PE inputs at the listed key positions only (MU/pe.py:84-135 frustum, MU/positional_encoding.py:78-95 sine) + feature gather.
  * out: A_frustum [S,3*D] key16, A_sine [S,384] key16, Xf_k16 [S,256] key16, Xf_f32 [S,256] (optional: NULL when mv2d_pe_fused_tab reads the map).
  * A_sine may be NULL (the sine branch of the PE block comes from the engine's folded table: the row is not produced).

@@ -766,6 +766,74 @@ __global__ __launch_bounds__(1024) void scan_and_csr_kernel(const unsigned char*
     else s_order_block((b - nscan - ncsr) / ord_chunks, (b - nscan - ncsr) % ord_chunks, match, grp_start, n_grp, R, nm, perm);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Frustum rows of the index-exact route's PE block, fp32 [S, 3 D], and nothing else (round 5; pe_inputs_kernel<true> also writes the key16
+// rows, a second fp32 logarithm and the feature rows nobody reads on that route, and spends ~200 fp64 operations per value on two IEEE
+// divisions and the library log: 156 us per 141 k positions, VALU-bound).  Same arithmetic in fp64 -- MU/pe.py:96-131: point of depth bin d
+// through img2lidar, normalisation to the position range, inverse_sigmoid (clamp(0,1), both arguments clamped at 1e-5), then .float() --
+// regrouped so that it costs ~40 operations per value:
+//   * the point is linear in the depth, M (cw dm, ch dm, d, 1) = dm (M0 cw + M1 ch) + d M2 + M3 (the per-position part is wave-uniform);
+//   * the normalisation multiplies by 1 / range;
+//   * log(x1 / x2) = log x1 - log x2 with a table-driven logarithm: x = 2^e m, c = the centre of m's 1/128 bin, r = m / c - 1 (|r| <= 2^-8),
+//     log m = log c + r - r^2/2 + ... - r^6/6 (truncation 2e-18); the table holds 1 / c and log c in fp64 (filled on the host at first use).
+// Every regrouping moves the fp64 value by a few 1e-16, i.e. the fp32 result differs from pe_inputs_kernel<true>'s in about one element
+// per 1e8, by one ulp (tests/test_gpu_kernels.py::test_pe_frustum_rows_fast_equals_reference_order).
+// ------------------------------------------------------------------------------------------------------------------------------
+__device__ double g_logtab[256];        // [i] = {1 / c_i, log c_i}, c_i = 1 + (i + 0.5) / 128
+
+__device__ __forceinline__ double log_diff_tab(double x1, double x2, const double* __restrict__ tab) {
+    const long long b1 = __double_as_longlong(x1), b2 = __double_as_longlong(x2);
+    const int e1 = (int)((b1 >> 52) & 0x7ff), e2 = (int)((b2 >> 52) & 0x7ff);
+    const int i1 = (int)((b1 >> 45) & 127), i2 = (int)((b2 >> 45) & 127);
+    const double m1 = __longlong_as_double((b1 & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
+    const double m2 = __longlong_as_double((b2 & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
+    const double r1 = fma(m1, tab[2 * i1], -1.0), r2 = fma(m2, tab[2 * i2], -1.0);
+    auto l1p = [](double r) {
+        double p = fma(r, -1.0 / 6.0, 1.0 / 5.0);
+        p = fma(r, p, -0.25);
+        p = fma(r, p, 1.0 / 3.0);
+        p = fma(r, p, -0.5);
+        p = fma(r, p, 1.0);
+        return r * p;
+    };
+    return fma((double)(e1 - e2), 0.6931471805599453094, (tab[2 * i1 + 1] - tab[2 * i2 + 1]) + (l1p(r1) - l1p(r2)));
+}
+
+__global__ __launch_bounds__(256) void pe_frustum_f32_kernel(const int* __restrict__ s2pos, const int* __restrict__ S_dev, const double* __restrict__ img2lidar,
+                                                             const double* __restrict__ coords_w, const double* __restrict__ coords_h,
+                                                             const double* __restrict__ coords_d, float* __restrict__ out, int h, int w, int D,
+                                                             double pr0, double pr1, double pr2, double ipd0, double ipd1, double ipd2) {
+    __shared__ double tab[256];
+    tab[threadIdx.x] = g_logtab[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = *S_dev;
+    for (int s = blockIdx.x * 4 + wave; s < S; s += gridDim.x * 4) {
+        const int pos = __builtin_amdgcn_readfirstlane(s2pos[s]);
+        const int v = pos / (h * w), rem = pos - v * h * w, y = rem / w, x = rem - y * w;
+        const double* M = img2lidar + v * 16;
+        const double cw = coords_w[x], chh = coords_h[y];
+        const double u[3] = {fma(M[0], cw, M[1] * chh), fma(M[4], cw, M[5] * chh), fma(M[8], cw, M[9] * chh)};
+        const double m2[3] = {M[2], M[6], M[10]}, m3[3] = {M[3] - pr0, M[7] - pr1, M[11] - pr2};
+        const double ipd[3] = {ipd0, ipd1, ipd2};
+        for (int dk = lane; dk < D; dk += 64) {
+            const double d = coords_d[dk];
+            const double dm = d < 1e-3 ? 1e-3 : d;
+            float o[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                double n = fma(u[i], dm, fma(m2[i], d, m3[i])) * ipd[i];
+                n = n < 0.0 ? 0.0 : (n > 1.0 ? 1.0 : n);
+                const double x1 = n < 1e-5 ? 1e-5 : n;
+                const double x2 = (1.0 - n) < 1e-5 ? 1e-5 : (1.0 - n);
+                o[i] = (float)log_diff_tab(x1, x2, tab);
+            }
+            float* dst = out + (long long)s * (3 * D) + dk * 3;
+            dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // a2 inputs: for every key position s of the compacted list build the three PE-MLP input rows and gather
 // the feature row (MU/pe.py:84-135 frustum coords in fp64, MU/positional_encoding.py:78-95 sine features).
@@ -1243,6 +1311,33 @@ extern "C" int mv2d_roi_positions_csr(const float* rois, const unsigned char* pa
     const int ord_chunks = cdiv(R < SORD_MAX ? R : SORD_MAX, SORD_CHUNK), nord = order ? (n_samples + 1) * ord_chunks : 0;
     hipLaunchKernelGGL(scan_and_csr_kernel, dim3(nscan + ncsr + nord), dim3(1024), 0, st, roi_mask, pad_mask, pos2s, s2pos, S_out, V * h * w, nscan,
                        match, row_ptr, col_idx, nnz_out, R, Vg * topk, ncsr, grp_start, n_samples, ord_chunks, order);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_pe_frustum_f32(const int* s2pos, const int* S_dev, int S_max, const double* img2lidar, const double* coords_w, const double* coords_h,
+                                   const double* coords_d, float* out, int V, int h, int w, int depth_num, const double* position_range, void* stream) {
+    MV2D_CHECK_ARG(s2pos && S_dev && img2lidar && coords_w && coords_h && coords_d && out && position_range, "mv2d_pe_frustum_f32: null pointer");
+    MV2D_CHECK_ARG(depth_num > 0 && depth_num <= 256 && V > 0 && h > 0 && w > 0, "mv2d_pe_frustum_f32: bad sizes");
+    if (S_max == 0) return MV2D_OK;
+    static bool tab_ready = false;          // (first call: a synchronous copy -- the engine's warm-up run precedes any graph capture)
+    if (!tab_ready) {
+        double t[256];
+        for (int i = 0; i < 128; ++i) {
+            const double c = 1.0 + (i + 0.5) / 128.0;
+            t[2 * i] = 1.0 / c;
+            t[2 * i + 1] = log(c);
+        }
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_logtab), t, sizeof(t)) != hipSuccess) {
+            mv2d_set_error("mv2d_pe_frustum_f32: table upload failed");
+            return MV2D_ERR_LAUNCH;
+        }
+        tab_ready = true;
+    }
+    const int blocks = cdiv(S_max, 4) < 4096 ? cdiv(S_max, 4) : 4096;
+    hipLaunchKernelGGL(pe_frustum_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s2pos, S_dev, img2lidar, coords_w, coords_h, coords_d, out, h, w,
+                       depth_num, position_range[0], position_range[1], position_range[2], 1.0 / (position_range[3] - position_range[0]),
+                       1.0 / (position_range[4] - position_range[1]), 1.0 / (position_range[5] - position_range[2]));
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -189,6 +189,23 @@ struct Stage {
     }
 };
 
+// The feature rows of a tile are a GATHER (64 rows x 1 KB through row_index) that all blocks of a round request at the same moment; loads return in
+// order, so the weight-ring wait behind them stalls for the whole gather (round-5 stamps: 18 k of a block's 141 k cycles in front of layer 1 of
+// part 3).  MV2D_PX_TOUCH: every thread reads ONE word of two of the tile's 512 cache lines early -- 1 = in the prologue (the frustum rows are waited
+// for there anyway), 2 = in front of part 2 -- so that the real loads find their lines in L2.
+#ifndef MV2D_PX_TOUCH
+#define MV2D_PX_TOUCH 2
+#endif
+#define PX_TOUCH_ISSUE()                                                                                   \
+    do {                                                                                                   \
+        const int c0_ = tid, c1_ = tid + NTHR;                                                             \
+        const int ma_ = min(m0 + (c0_ >> 3), M - 1), mb_ = min(m0 + (c1_ >> 3), M - 1);                    \
+        const long long ra_ = p.row_index ? p.row_index[ma_] : ma_, rb_ = p.row_index ? p.row_index[mb_] : mb_; \
+        touch0 = p.Xmap[ra_ * C + (c0_ & 7) * 32];                                                         \
+        touch1 = p.Xmap[rb_ * C + (c1_ & 7) * 32];                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    } while (0)
+
 __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     unsigned char* Ah = smem;
@@ -204,6 +221,7 @@ __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
     const long long lo = (long long)lane * 8 + (long long)wave * CT * 512;
     const WBase w{{p.Wr_h + lo, p.Wr_l + lo}, {p.We_h + lo, p.We_l + lo}, {p.W1a_h + lo, p.W1a_l + lo}, {p.W1b_h + lo, p.W1b_l + lo}};
     XFrag wq[RING][CT], a[2][RT];
+    float touch0 = 0.f, touch1 = 0.f;
     PX_STAMP(0);
     ring_load<0>(wq, w);
     ring_load<1>(wq, w);
@@ -226,6 +244,9 @@ __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
         st.load(p.A1, 192, nullptr, m0, M, tid);
         st.commit(Ah, Al, tid);
     }
+#if MV2D_PX_TOUCH == 1
+    PX_TOUCH_ISSUE();
+#endif
     __syncthreads();
     PX_STAMP(1);
     const int n0 = wave * CT * 16 + 4 * fg;             // this lane's 4 output columns of column tile j start at n0 + 16 j
@@ -241,6 +262,9 @@ __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
     PX_STAMP(4);
     steps<first_of(1) + 6, 8>(accf, wq, a, w, Hh, Hl, fr, fg);
     PX_STAMP(5);
+#if MV2D_PX_TOUCH == 2
+    PX_TOUCH_ISSUE();
+#endif
     layer1<2>(wq, a, w, Ah, Al, Hh, Hl, Bs + B_1A + 512, wave, fr, fg);
     PX_STAMP(6);
     steps<first_of(2) + 6, 8>(accf, wq, a, w, Hh, Hl, fr, fg);
@@ -249,6 +273,9 @@ __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
     // under the MFMAs of layer 1 (stamps of the first version: 22 k of a block's 145 k cycles waited for them right here)
     Stage<32> fs;
     fs.load(p.Xmap, C, p.row_index, m0, M, tid);
+#if MV2D_PX_TOUCH
+    asm volatile("" ::"v"(touch0), "v"(touch1));      // the touch loads are complete at the latest here (their lines sit in L2 for the loads above)
+#endif
     layer1<3>(wq, a, w, Ah, Al, Hh, Hl, Bs + B_1A + 768, wave, fr, fg);        // after its barrier nobody reads the frustum images any more
     PX_STAMP(8);
     fs.commit(Ah, Al, tid);                            // other waves may still run the last layer 2 (hidden images only)

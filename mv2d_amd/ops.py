@@ -765,6 +765,16 @@ def pe_inputs(s2pos, S_dev, S_max, featcl, img2lidar, coords_w, coords_h, coords
                                      _p(A_sine_f32), V, h, w, depth_num, position_range_host.data_ptr(), _stream()), 'mv2d_pe_inputs')
 
 
+def pe_frustum_f32(s2pos, S_dev, S_max, img2lidar, coords_w, coords_h, coords_d, out, V, h, w, depth_num, position_range_host):
+    """out [S, 3 D] fp32: the unrounded frustum rows of the PE block at the listed positions (index-exact route; fp64 arithmetic, fast form)."""
+    _req(s2pos, torch.int32, 's2pos'); _req(S_dev, torch.int32, 'S_dev'); _req(out, torch.float32, 'out')
+    for t, n_ in ((img2lidar, 'img2lidar'), (coords_w, 'coords_w'), (coords_h, 'coords_h'), (coords_d, 'coords_d')):
+        _req(t, torch.float64, n_)
+    check(_lib.load().mv2d_pe_frustum_f32(_p(s2pos), _p(S_dev), S_max, _p(img2lidar), _p(coords_w), _p(coords_h), _p(coords_d), _p(out), V, h, w,
+                                          depth_num, position_range_host.data_ptr(), _stream()), 'mv2d_pe_frustum_f32')
+    return out
+
+
 def decode_topk(cls, reg, R, num_classes, max_num, post_center_range_host, boxes, scores, labels, bbox_index, count, topk_dbg=None,
                 grp_start=None, max_grp_rows=0, payload=None):
     """grp_start (int32 [n+1], device) + max_grp_rows: one top-k per sample of a batch, outputs [n][max_num]; payload (optional, fp32

@@ -643,6 +643,45 @@ def test_pe_inputs(dev, name):
     assert float(A1[S:].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('name', ['cfg1_t', 'cfg1_s'])
+def test_pe_frustum_rows_fast_equals_reference_order(dev, name):
+    """mv2d_pe_frustum_f32 (round 5: linear-in-depth point, reciprocal ranges, table-driven fp64 log x1 - log x2) against (a) the oracle's
+    restatement of MU/pe.py:96-131 (fp64, .float()) and (b) pe_inputs_kernel<true> (the reference's operation order in fp64 on the device):
+    the fp32 rows are EQUAL except where the fp64 value sits within ~1e-15 of a rounding boundary (none expected in 1e5 values; bound: 1 ulp
+    in fewer than 1 of 1e4 elements)."""
+    from mv2d_amd import calib, ops
+    from oracle import mv2d_oracle as O
+    prob, props = _problem(name)
+    metas = prob['img_metas']
+    feat = torch.from_numpy(prob['feat'])
+    V, C, h, w = feat.shape
+    P = V * h * w
+    ft = calib.frame_tables(metas, h, w)
+    ct = calib.constant_tables()
+    g = np.random.Generator(np.random.PCG64(81))
+    sel = np.sort(g.choice(P, size=P // 2, replace=False)).astype(np.int32)
+    S = len(sel)
+    s2pos = torch.from_numpy(sel).to(dev)
+    S_dev = torch.tensor([S], dtype=torch.int32, device=dev)
+    pr = torch.tensor(O.POST_RANGE, dtype=torch.float64)
+    T = {k: ft[k].to(dev) for k in ('img2lidar', 'coords_w', 'coords_h', 'coords_d', 'embeds')}
+    fast = torch.zeros((P, 192), device=dev)
+    ops.pe_frustum_f32(s2pos, S_dev, P, T['img2lidar'], T['coords_w'], T['coords_h'], T['coords_d'], fast, V, h, w, 64, pr)
+    k16 = ops.key16_dtype()
+    slow = torch.zeros((P, 192), device=dev)
+    ops.pe_inputs(s2pos, S_dev, P, ops.nchw_to_nhwc(feat.to(dev)), T['img2lidar'], T['coords_w'], T['coords_h'], T['coords_d'], T['embeds'],
+                  ct['dim_t'].to(dev), torch.zeros((P, 192), dtype=k16, device=dev), torch.zeros((P, 384), dtype=k16, device=dev),
+                  torch.zeros((P, 256), dtype=k16, device=dev), None, V, h, w, 64, pr, A_frustum_f32=slow, A_sine_f32=torch.zeros((P, 384), device=dev))
+    ref = O.pe_frustum_input(metas, h, w).permute(0, 2, 3, 1).reshape(P, 192)[sel]
+    for other, label in ((slow[:S].cpu(), 'pe_inputs<true>'), (ref, 'oracle')):
+        d = (fast[:S].cpu() - other).abs()
+        n_diff = int((d > 0).sum())
+        print(f'[pe_frustum_f32 vs {label}] {name}: {n_diff} of {d.numel()} elements differ, max |diff| {float(d.max()):.2e}')
+        assert n_diff <= max(1, d.numel() // 10000)
+        assert float((d / other.abs().clamp_min(1e-3)).max()) < 3e-7
+    assert float(fast[S:].abs().max()) == 0.0
+
+
 def test_decode_topk_bit_exact(dev):
     from mv2d_amd import ops
     from oracle import mv2d_oracle as O
