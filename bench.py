@@ -580,14 +580,34 @@ def main():
         import subprocess
 
         def cpu_leg(threads, iters, tmo, more=()):
+            pr = subprocess.Popen([sys.executable, '-m', 'oracle.cpu_baseline', '--workload', args.workload, '--iters', str(iters),
+                                   '--threads', str(threads), *more], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
             try:
-                r = subprocess.run([sys.executable, '-m', 'oracle.cpu_baseline', '--workload', args.workload, '--iters', str(iters),
-                                    '--threads', str(threads), *more], cwd=ROOT, capture_output=True, text=True, timeout=tmo)
-                lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
-                return json.loads(lines[-1]) if lines else dict(value=None, unit='samples/s', cores=threads, kind='port',
-                                                                sample=f'oracle subprocess failed: {r.stderr[-200:]}')
+                so, se = pr.communicate(timeout=tmo)
+                timed_out = False
             except subprocess.TimeoutExpired:
-                return dict(value=None, unit='samples/s', cores=threads, kind='port', sample=f'oracle did not finish {iters}+1 frames (+ the decoder-only leg) in {tmo}s with {threads} threads')
+                pr.kill()
+                so, se = pr.communicate()
+                timed_out = True
+            recs = []
+            for l in (so or '').splitlines():
+                if l.startswith('{'):
+                    try:
+                        recs.append(json.loads(l))
+                    except ValueError:
+                        pass
+            final = [r_ for r_ in recs if 'value' in r_]
+            if final:
+                return final[-1]
+            # the leg was cut off: report what its per-frame progress lines say (a frame time IS a measurement, however slow)
+            fr = [r_['frame_s'] for r_ in recs if r_.get('progress') == 'timed'] or [r_['frame_s'] for r_ in recs if r_.get('progress') == 'warmup']
+            if fr:
+                med = statistics.median(fr)
+                return dict(value=round(1.0 / med, 4), unit='samples/s', cores=threads, kind='port', frames_timed=len(fr),
+                            sample=f'cut off after {tmo}s: median of the {len(fr)} frame(s) of {args.workload} that finished ({med:.1f} s per frame, {threads} threads)')
+            return dict(value=None, unit='samples/s', cores=threads, kind='port',
+                        sample=(f'not one frame of {args.workload} finished in {tmo}s with {threads} threads (< {1.0 / tmo:.4f} samples/s)' if timed_out
+                                else f'oracle subprocess failed: {(se or "")[-200:]}'))
         # the 16-thread leg is the baseline the ratios are quoted against; BASELINE.md section 3 / SURVEY 8(d) name
         # torch.set_num_threads(os.cpu_count()), so that leg is run too (bounded: on a 256-thread host the oracle's many small operators
         # spend their time waking threads and may not finish; reported as measured either way)
@@ -598,7 +618,7 @@ def main():
             # small operators spend their time waking threads (8 / 16 / 32 / 64 threads: 2.24 / 2.09 / 1.53 / 0.67 samples/s),
             # so the leg is BOUNDED (the warm-ups stop after half of --cpu-all-budget seconds, the timing after all of it, at least one timed frame)
             # and reports what it measured, however slow
-            cpu2 = cpu_leg(nc_, 3, args.cpu_all_budget * 2 + 60, ('--warmups', '3', '--budget-s', str(args.cpu_all_budget), '--no-decoder'))
+            cpu2 = cpu_leg(nc_, 3, args.cpu_all_budget * 2 + 20, ('--warmups', '3', '--budget-s', str(args.cpu_all_budget), '--no-decoder'))
 
     other = None
     if rank == 0 and world == 1 and not args.no_other_workloads and args.workload == 'cfg2_s':

@@ -419,10 +419,11 @@ int mv2d_csr_from_corr(const int* match, int* row_ptr, int* col_idx, int* nnz_ou
 /* mv2d_roi_positions + mv2d_csr_from_corr in two launches instead of three (the position scan and the CSR run side by side in one): V = all
  * views of the maps, Vg = views per sample (match is [R, Vg, topk]); Vg * topk < 64.  order (optional, with grp_start [n_samples + 1]): the
  * launch order of the attention blocks for mv2d_xattn_tile_fwd_ordered from the same launch -- the queries of every sample ranked by the
- * smallest RoI they list (own or matched), so that matched RoIs of different views share an L2. */
+ * smallest RoI they list (own or matched), so that matched RoIs of different views share an L2.  A sample with more than 4096 queries keeps its
+ * natural order and sets order_flags[0] = 1 (optional int[1], cleared by the caller; results are the same either way). */
 int mv2d_roi_positions_csr(const float* rois, const unsigned char* pad_mask, unsigned char* roi_mask, int* rect, int* pos2s, int* s2pos,
                            int* S_out, int R, int V, int h, int w, float stride, float expand_stride, const int* match, int* row_ptr,
-                           int* col_idx, int* nnz_out, int Vg, int topk, const int* grp_start, int n_samples, int* order, void* stream);
+                           int* col_idx, int* nnz_out, int Vg, int topk, const int* grp_start, int n_samples, int* order, int* order_flags, void* stream);
 
 /* Frustum rows of the index-exact route's PE block alone: out [S, 3 depth_num] fp32 = float(inverse_sigmoid(normalised 3-D point of every depth bin)),
  * computed in fp64 like the reference (MU/pe.py:96-131) at the positions s2pos[0 .. *S_dev); position_range = 6 doubles on the HOST.  Replaces the

@@ -85,7 +85,7 @@ SIGNATURES = {
     'mv2d_mask_compact': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, I, P]),
     'mv2d_roi_positions': (I, [P, P, P, P, P, P, P, I, I, I, I, F, F, P]),
     'mv2d_csr_from_corr': (I, [P, P, P, P, I, I, I, P]),
-    'mv2d_roi_positions_csr': (I, [P, P, P, P, P, P, P, I, I, I, I, F, F, P, P, P, P, I, I, P, I, P, P]),
+    'mv2d_roi_positions_csr': (I, [P, P, P, P, P, P, P, I, I, I, I, F, F, P, P, P, P, I, I, P, I, P, P, P]),
     'mv2d_frame_geometry': (I, [P, P, P, P, P, I, P, F, F, F, P, P, P, P, P, I, I, I, I, I, I, I, F, F, F, I, P, LL, P]),
     'mv2d_pe_inputs': (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
     'mv2d_pe_frustum_f32': (I, [P, P, I, P, P, P, P, P, I, I, I, I, P, P]),

@@ -724,13 +724,14 @@ __global__ __launch_bounds__(1024) void csr_from_corr_kernel(const int* __restri
 // launch.  Groups: sample g = rows [grp_start[g], grp_start[g+1]); the bucket-padding rows behind the last sample keep their places.
 constexpr int SORD_MAX = 4096, SORD_CHUNK = 128;
 __device__ __forceinline__ void s_order_block(int g, int chunk, const int* __restrict__ match, const int* __restrict__ grp_start, int n_grp, int R, int nm,
-                                              int* __restrict__ perm) {
+                                              int* __restrict__ perm, int* __restrict__ flags) {
     __shared__ int key[SORD_MAX];
     const int tid = threadIdx.x;
     const int lo = g < n_grp ? grp_start[g] : grp_start[n_grp];
     const int hi = g < n_grp ? grp_start[g + 1] : R;
     const int n = hi - lo;
     if (n > SORD_MAX || g >= n_grp) {                          // too many queries for the LDS ranking / padding rows: natural order
+        if (chunk == 0 && tid == 0 && flags && g < n_grp) flags[0] = 1;      // (like query_order_kernel: a sample whose L2-sharing order was dropped says so)
         if (chunk == 0) for (int i = tid; i < n; i += 1024) perm[lo + i] = lo + i;
         return;
     }
@@ -759,11 +760,11 @@ __global__ __launch_bounds__(1024) void scan_and_csr_kernel(const unsigned char*
                                                             int* __restrict__ pos2s, int* __restrict__ s2pos, int* __restrict__ S_out, int P, int nscan,
                                                             const int* __restrict__ match, int* __restrict__ row_ptr, int* __restrict__ col_idx,
                                                             int* __restrict__ nnz_out, int R, int nm, int ncsr, const int* __restrict__ grp_start, int n_grp,
-                                                            int ord_chunks, int* __restrict__ perm) {
+                                                            int ord_chunks, int* __restrict__ perm, int* __restrict__ order_flags) {
     const int b = blockIdx.x;
     if (b < nscan) csr_scan_positions_block(b, nscan, roi_mask, pad_mask, pos2s, s2pos, S_out, P);
     else if (b < nscan + ncsr) csr_from_corr_block(b - nscan, match, row_ptr, col_idx, nnz_out, R, nm);
-    else s_order_block((b - nscan - ncsr) / ord_chunks, (b - nscan - ncsr) % ord_chunks, match, grp_start, n_grp, R, nm, perm);
+    else s_order_block((b - nscan - ncsr) / ord_chunks, (b - nscan - ncsr) % ord_chunks, match, grp_start, n_grp, R, nm, perm, order_flags);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -1244,7 +1245,15 @@ extern "C" int mv2d_frame_geometry(const float* rois, const double* viewK, const
     MV2D_CHECK_ARG(max_per_view <= MAX_PER_VIEW && topk >= 1, "mv2d_frame_geometry: too many RoIs in one view (max 1024)");
     MV2D_CHECK_ARG(zero_bytes >= 0 && (zero_bytes % 16) == 0 && ((uintptr_t)zero_ptr & 15) == 0 && (zero_ptr || zero_bytes == 0),
                    "mv2d_frame_geometry: the region to clear must be 16-byte aligned and a multiple of 16 bytes");
-    if (R == 0) return MV2D_OK;
+    if (R == 0) {
+        // nothing to launch for, but the frame's mask / flag bytes are still this call's to clear (a direct ABI caller with an empty RoI list
+        // would otherwise keep the previous frame's roi_mask and overflow flags)
+        if (zero_ptr && zero_bytes > 0 && hipMemsetAsync(zero_ptr, 0, (size_t)zero_bytes, (hipStream_t)stream) != hipSuccess) {
+            mv2d_set_error("mv2d_frame_geometry: clearing the zero region failed");
+            return MV2D_ERR_LAUNCH;
+        }
+        return MV2D_OK;
+    }
     FrameGeoArgs G{{rois, view_start, trans, lin, depths, match, V, sample_size, num_depth, topk, (float)(pad_w - 1), (float)(pad_h - 1), depth_start,
                     iou_thr, ratio}, viewK, viewE, K_roi, intr, ld_intr, minv, roi_size, intr_scale, min_size, (uint4*)zero_ptr, zero_bytes / 16, R};
     const int nz = (int)((zero_bytes / 16 + GEO_ZERO_PER_BLOCK - 1) / GEO_ZERO_PER_BLOCK);
@@ -1301,7 +1310,7 @@ extern "C" int mv2d_csr_from_corr(const int* match, int* row_ptr, int* col_idx, 
 // mv2d_roi_positions + mv2d_csr_from_corr (S path) in TWO launches instead of three: the mark kernel, then the position scan and the CSR side by side
 extern "C" int mv2d_roi_positions_csr(const float* rois, const unsigned char* pad_mask, unsigned char* roi_mask, int* rect, int* pos2s, int* s2pos,
                                       int* S_out, int R, int V, int h, int w, float stride, float expand_stride, const int* match, int* row_ptr,
-                                      int* col_idx, int* nnz_out, int Vg, int topk, const int* grp_start, int n_samples, int* order, void* stream) {
+                                      int* col_idx, int* nnz_out, int Vg, int topk, const int* grp_start, int n_samples, int* order, int* order_flags, void* stream) {
     MV2D_CHECK_ARG(!order || (grp_start && n_samples >= 1), "mv2d_roi_positions_csr: the block order needs the sample row ranges");
     MV2D_CHECK_ARG(rois && pad_mask && roi_mask && rect && pos2s && s2pos && S_out && R > 0, "mv2d_roi_positions_csr: bad args");
     MV2D_CHECK_ARG(match && row_ptr && col_idx && nnz_out && Vg * topk < 64, "mv2d_roi_positions_csr: bad CSR args (views per sample * topk < 64)");
@@ -1310,7 +1319,7 @@ extern "C" int mv2d_roi_positions_csr(const float* rois, const unsigned char* pa
     const int nscan = cdiv(V * h * w, SCAN_SEG), ncsr = cdiv(R, CFC_ROWS);
     const int ord_chunks = cdiv(R < SORD_MAX ? R : SORD_MAX, SORD_CHUNK), nord = order ? (n_samples + 1) * ord_chunks : 0;
     hipLaunchKernelGGL(scan_and_csr_kernel, dim3(nscan + ncsr + nord), dim3(1024), 0, st, roi_mask, pad_mask, pos2s, s2pos, S_out, V * h * w, nscan,
-                       match, row_ptr, col_idx, nnz_out, R, Vg * topk, ncsr, grp_start, n_samples, ord_chunks, order);
+                       match, row_ptr, col_idx, nnz_out, R, Vg * topk, ncsr, grp_start, n_samples, ord_chunks, order, order_flags);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

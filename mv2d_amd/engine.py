@@ -547,7 +547,7 @@ class HeadEngine:
             # the attention blocks (queries ranked by the smallest RoI they list)
             o.roi_positions_csr(rois, ws['zero_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'], R, V, h, w, ws['match'],
                                 ws['row_ptr'], ws['col_idx'], ws['nnz'], Vg, self.topk, stride=self.stride, expand_stride=1.0, grp_start=grp,
-                                order=ws.get('q_order') if self.q_order else None)
+                                order=ws.get('q_order') if self.q_order else None, order_flags=ws['qt_ctl'][1:] if self.q_order else None)
         md = ws['S_dev']
         # a2: PE at the listed positions only
         if self.exact and 'pe' not in self.exact_skip:

@@ -741,12 +741,12 @@ def roi_positions(rois, pad_mask, roi_mask, rect, pos2s, s2pos, S_out, R, V, h, 
 
 
 def roi_positions_csr(rois, pad_mask, roi_mask, rect, pos2s, s2pos, S_out, R, V, h, w, match, row_ptr, col_idx, nnz_out, Vg, topk, stride=16.0,
-                      expand_stride=1.0, grp_start=None, order=None):
+                      expand_stride=1.0, grp_start=None, order=None, order_flags=None):
     """roi_positions + csr_from_corr (S path) in two launches; order (int32 [R]) + grp_start: also the launch order of the attention blocks."""
-    _req(order, torch.int32, 'order'); _req(grp_start, torch.int32, 'grp_start')
+    _req(order, torch.int32, 'order'); _req(grp_start, torch.int32, 'grp_start'); _req(order_flags, torch.int32, 'order_flags')
     check(_lib.load().mv2d_roi_positions_csr(_p(rois), _p(pad_mask), _p(roi_mask), _p(rect), _p(pos2s), _p(s2pos), _p(S_out), R, V, h, w, float(stride),
                                              float(expand_stride), _p(match), _p(row_ptr), _p(col_idx), _p(nnz_out), Vg, topk, _p(grp_start),
-                                             grp_start.numel() - 1 if grp_start is not None else 0, _p(order), _stream()),
+                                             grp_start.numel() - 1 if grp_start is not None else 0, _p(order), _p(order_flags), _stream()),
           'mv2d_roi_positions_csr')
 
 

@@ -40,15 +40,19 @@ def main():
     over = lambda frac: a.budget_s > 0 and time.perf_counter() - t_start > frac * a.budget_s      # noqa: E731
     warm = 0
     with torch.no_grad():
+        prog = lambda phase, t: print(json.dumps(dict(progress=phase, frame_s=round(t, 3), threads=a.threads)), flush=True)      # noqa: E731
         for _ in range(max(a.warmups, 1)):
+            t0 = time.perf_counter()
             fn(sd, feat, props, prob['img_metas'], **kw)
             warm += 1
+            prog('warmup', time.perf_counter() - t0)          # (one line per frame: a caller that gives up on this leg still sees what it measured)
             if over(0.5):
                 break
         for _ in range(a.iters):
             t0 = time.perf_counter()
             fn(sd, feat, props, prob['img_metas'], **kw)
             ts.append(time.perf_counter() - t0)
+            prog('timed', ts[-1])
             if over(1.0):
                 break
         td = [float('nan')]

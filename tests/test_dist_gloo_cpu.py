@@ -227,3 +227,22 @@ def test_bench_step_two_ranks_gloo():
             i, b = divmod(j, B)
             assert n == (rr * 7 + i * 3 + it + b) % 300 + 1
             assert abs(v - (100.0 * rr + 10.0 * i + it + 0.1 * b)) < 1e-3 and lab == (it + b) % 10
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_self_spawn_gloo():
+    """`python bench.py --gpus 2` WITHOUT a launcher re-executes itself under torch.distributed.run, one rank per GPU (round 4 asserted
+    WORLD_SIZE == --gpus and died).  --spawn-check stops after the rendezvous (no GPU here): two gloo ranks find each other and rank 0
+    prints the line."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--spawn-check'], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert r.returncode == 0 and lines, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    d = json.loads(lines[-1])
+    assert d == dict(spawn_check=True, world=2, ranks=[0, 1], backend='gloo')

@@ -452,6 +452,31 @@ def test_engine_stays_finite_when_features_exceed_the_fp16_range():
         assert bool(torch.isfinite(out['stages']['Xk'][:S].float()).all()) and float(out['stages']['Xk'][:S].float().abs().max()) == 65504.0
 
 
+@pytest.mark.parametrize('name', ['micro_t', 'micro_s'])
+def test_poisoned_feature_cell_stays_visible(name):
+    """A NaN in the feature map (bad input frame) must reach the outputs like it does in the reference (torch propagates NaN through conv / linear /
+    attention): the key / value rows, RoI cells and the PE gate read that cell, so the queries that attend to it -- and, through the next self
+    attention, the whole frame -- become NaN.  Both modes: the index-exact route (NaN-preserving ReLU + saturating conversions that keep NaN in
+    every split) and the opt-in key16 mode (its PE hidden layer turns a NaN into 0 -- common.h pack_k16x2_relu -- but the FEATURE ROW itself carries
+    the NaN into the key / value rows)."""
+    from mv2d_amd.engine import HeadEngine
+    prob = synthetic.make_problem(name, seed=0)
+    sd = synthetic.make_head_state(seed=0)
+    dev = torch.device('cuda:0')
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    b = prob['proposals'][0][0]
+    cx, cy = int((b[0] + b[2]) / 2 / 16), int((b[1] + b[3]) / 2 / 16)              # a cell inside the first RoI of view 0
+    feat = torch.from_numpy(prob['feat']).to(dev).clone()
+    feat[0, :, cy, cx] = float('nan')
+    for exact in (True, False):
+        eng = HeadEngine(sd, prob['kind'], dev, num_views=prob['views_per_frame'], exact=exact)
+        out = eng.run(feat, props, prob['img_metas'])
+        torch.cuda.synchronize()
+        R = out['R']
+        assert bool(torch.isnan(out['cls'][-1, :R]).any()), (name, exact, 'the poisoned cell did not reach the last layer')
+        assert int(out['count'].item()) < 10 * R
+
+
 def test_engine_full_size_properties_cfg5():
     """BASELINE.json's largest configuration (R101 1600x640, 12 views, 900 queries) through size-independent properties:
     CSR well-formedness, idempotence (same frame twice -> bitwise identical), fork/no-fork equality, and the decode kernel

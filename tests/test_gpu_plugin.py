@@ -386,3 +386,25 @@ def test_module_level_self_attention_with_attn_mask():
     assert err < 3e-3
     with pytest.raises(NotImplementedError):
         m(x, query_pos=pos, key_padding_mask=torch.zeros(1, T, dtype=torch.bool, device=DEV))
+
+
+def test_bench_two_ranks_rccl_when_two_gpus_are_visible():
+    """The N > 1 path on hardware: `python bench.py --gpus 2` (self-spawned, one rank per GPU, backend nccl = RCCL over xGMI) runs the step with the
+    per-step all-gather of decoded boxes; rank 0's line must carry n_gpus = 2 and a gathered tensor whose own slice equals what it packed.  Skipped
+    on the 1-GPU boxes of the test tier (the driver's SCALE run is the 8-GPU measurement)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip('one GPU visible: the 2-rank RCCL step needs two')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '10', '--warmup', '3', '--prime', '5', '--brief',
+                        '--no-parity-leg'], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert r.returncode == 0 and lines, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    d = json.loads(lines[-1])
+    assert d['n_gpus'] == 2 and d['value'] > 0
+    cc = d['collective_check']
+    assert cc['world'] == 2 and cc['backend'] == 'nccl' and cc['gathered_equals_packed'] and cc['gathered_shape'][0] == 2
