@@ -174,6 +174,7 @@ def main():
     ap.add_argument('--min-seconds', type=float, default=1.0, help='when the K timed steps take less than this, a second, longer loop of the same step is timed and reported beside them')
     ap.add_argument('--xattn-waves', type=int, default=None, help='waves per query of the tile cross-attention kernel (engine default: 2)')
     ap.add_argument('--fuse-maps', type=int, default=None, help='1 / 0: force the per-head maps of the tile attention into / out of the neighbouring row kernels (engine default: by row count)')
+    ap.add_argument('--fuse-xattn', type=int, default=None, help='1 / 0: force the one-launch cross attention (csrc/xattn_fused.hip) on / off (engine default: on for the S path)')
     ap.add_argument('--force-collective', action='store_true', help='one rank: initialise the process group (nccl = RCCL) anyway and run the per-step all-gather of decoded boxes')
     ap.add_argument('--no-collective-leg', action='store_true', help='skip the one-rank RCCL leg (a sub-process of this script with --force-collective)')
     args = ap.parse_args()
@@ -238,6 +239,8 @@ def main():
         base.xattn_waves = args.xattn_waves
     if args.fuse_maps is not None:
         base.fuse_maps = bool(args.fuse_maps)
+    if args.fuse_xattn is not None:
+        base.fuse_xattn = bool(args.fuse_xattn)
     base.fork_qg = args.inflight == 1
     engines = [base] + [base.clone_shared() for _ in range(args.inflight - 1)]
     # frames in flight go on streams that were MEASURED to run concurrently (queue/pipe sharing serialises others)

@@ -310,6 +310,14 @@ int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* Xv, const vo
 int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                 const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
                                 const int* order, void* stream);
+/* The three launches above as ONE (round 5, csrc/xattn_fused.hip): ctx [R,256] fp32 = xattn_ctxmap(xattn_tile(xattn_qmap(q))) for blocks of 8 queries,
+ * Qt and z never leave the chip (16 KB per query and layer less HBM traffic, two launches less).  Same operands as the three calls (q = the scaled,
+ * projected query rows [R,256] fp32; WA / WB = the packed map weights; Xk / Xv (+ _lo: index-exact route) the key16 row arrays; CSR; order = optional
+ * launch order of the queries); results bitwise equal to the three kernels with waves = 1.  Meant for rows of similar length (S path): a block
+ * waits for the longest of its 8 rows. */
+int mv2d_xattn_fused_fwd(const float* q, const void* WA_hi, const void* WA_lo, const void* WB_hi, const void* WB_lo, const float* bv, const void* Xk,
+                         const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr, const int* col_idx, float* ctx, int R, int empty_nan,
+                         const int* order, void* stream);
 int mv2d_xattn_ctxmap(const float* z, const void* WB_hi, const void* WB_lo, const float* bv, const int* row_ptr, float* ctx, int R,
                       int empty_nan, void* stream);
 

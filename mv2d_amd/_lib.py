@@ -72,6 +72,7 @@ SIGNATURES = {
     'mv2d_attn_out_zmap_x3': (I, [P, P, P, P, P, I, P, P, P, P, P, P, P, I, F, P]),
     'mv2d_xattn_tile_fwd': (I, [P, P, P, P, P, P, P, P, P, LL, I, I, I, P]),
     'mv2d_xattn_tile_fwd_ordered': (I, [P, P, P, P, P, P, P, P, P, LL, I, I, I, P, P]),
+    'mv2d_xattn_fused_fwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P, P]),
     'mv2d_xattn_query_order': (I, [P, P, P, I, I, P, P, I, P]),
     'mv2d_xattn_ctxmap': (I, [P, P, P, P, P, P, I, I, P]),
     'mv2d_box_params': (I, [P, P, P, P, P, I, P, I, F, F, F, P]),

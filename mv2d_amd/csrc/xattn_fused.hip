@@ -1,0 +1,361 @@
+// Cross attention of a decoder layer in ONE launch (round 5): query map -> tile attention -> context map, fused per block of 8 queries.
+//
+// Replaces the three launches of csrc/xattn_tile.hip (xattn_qmap_kernel, xattn_tile_kernel, xattn_ctxmap_kernel) for
+// PETRMultiheadAttention's core (MU/petr_transformer.py:426-513) on rows of similar length (the S path: a query reads the 49 cells of its own
+// RoI and of the few RoIs matched to it).  The arithmetic is the same, operation for operation (raw key space, see xattn_tile.hip: the K / V
+// in_proj ride on the query side, the key side reads the unprojected key16 hi + lo rows), so the results are BITWISE those of the three
+// kernels with one wave per query (tests/test_gpu_kernels.py::test_xattn_fused_equals_the_three_kernels); what disappears are the two
+// intermediates of that decomposition -- Qt (8 KB per query: the mapped query as a 16 x 256 key16 MFMA operand) and z (8 KB: the per-head
+// context sums in the key space) -- which the three kernels write to and read back from HBM: 16 of the ~121 KB a query of the index-exact
+// route moves per layer, and two launches of six.
+//
+// Block = 8 queries, 8 waves (two per SIMD), LDS 132 KB:
+//   phase A  wave = head h: Qt_h of the 8 queries (split-precision MFMAs on the fp32 query, packed weights WA from L2) -> LDS [query][head][1 KB]
+//   phase B  wave = query w: its Qt operand into 32 registers, then the tile loop of xattn_tile_kernel<1, false, XLO> over its CSR row (key
+//            tiles of 16 rows through the wave's 16 KB of LDS -- which alias the Qt area once every wave holds its operand); the un-normalised
+//            context sums z and the softmax denominators go to LDS
+//   phase C  wave = head h: ctx[:, 32 h .. 32 h + 31] = Wv_h z_h / l_h + bv for the 8 queries (packed weights WB from L2), NaN / 0 for a row
+//            without a key, written to HBM as the [R, 256] fp32 rows the out-projection kernel reads.
+// A block streams the packed weights of both maps (512 KB of hi + lo fragments) from L2 once per 8 queries = 64 KB per query against the
+// ~105 KB of key / value rows it gathers from HBM; the blocks of a launch are out of phase after the first round, so the map phases of one
+// CU overlap the gathers of the others.  Rows of very different length (the T path: 1 .. 400 keys) would wait for the longest of the 8 at
+// the barrier between B and C: the engine keeps the three kernels there.
+#include "common.h"
+
+namespace {
+
+constexpr int C = 256, HEADS = 8, QB = 8;                    // queries per block = waves per block
+constexpr float LOG2E = 1.4426950408889634f;
+
+typedef q16x8_t xf_q16x8;
+union XfFrag { uint4 u; xf_q16x8 v; };
+typedef unsigned int xf_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void xf_split8(const float4& x0, const float4& x1, XfFrag& hi, XfFrag& lo) {
+    const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    unsigned int h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_q16x2(f[2 * i], f[2 * i + 1], h[i], l[i]);
+    hi.u = make_uint4(h[0], h[1], h[2], h[3]);
+    lo.u = make_uint4(l[0], l[1], l[2], l[3]);
+}
+__device__ __forceinline__ void xf_split8_k16(const float4& x0, const float4& x1, XfFrag& hi, XfFrag& lo) {
+    const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    unsigned int h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_k16x2(f[2 * i], f[2 * i + 1], h[i], l[i]);
+    hi.u = make_uint4(h[0], h[1], h[2], h[3]);
+    lo.u = make_uint4(l[0], l[1], l[2], l[3]);
+}
+__device__ __forceinline__ unsigned int xf_lo_pair(unsigned int a, unsigned int b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+__device__ __forceinline__ unsigned int xf_hi_pair(unsigned int a, unsigned int b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+#define XF_DPP(v, ctrl) __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), ctrl, 0xF, 0xF, true))
+__device__ __forceinline__ float xf_row16_max(float v) {
+    v = fmaxf(v, XF_DPP(v, 0xB1));
+    v = fmaxf(v, XF_DPP(v, 0x4E));
+    v = fmaxf(v, XF_DPP(v, 0x141));
+    v = fmaxf(v, XF_DPP(v, 0x140));
+    return v;
+}
+
+constexpr int WAVE_LDS = 16384;                              // per wave: key tile hi (8 KB) | key tile lo (8 KB); phase A / C: Qt / z of query `wave` in the first 8 KB
+constexpr int SMEM = QB * WAVE_LDS + QB * 512 + QB * HEADS * 4 + QB * 4;
+
+template <bool XLO>
+__global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __restrict__ q, const uint4* __restrict__ WA_hi, const uint4* __restrict__ WA_lo,
+                                                                const uint4* __restrict__ WB_hi, const uint4* __restrict__ WB_lo, const float* __restrict__ bv,
+                                                                const unsigned short* __restrict__ Xk, const unsigned short* __restrict__ Xv,
+                                                                const unsigned short* __restrict__ Xk_lo, const unsigned short* __restrict__ Xv_lo,
+                                                                const int* __restrict__ row_ptr, const int* __restrict__ col_idx, float* __restrict__ ctx,
+                                                                int R, int empty_nan, const int* __restrict__ order) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
+    float* lsum = reinterpret_cast<float*>(smem + QB * WAVE_LDS + QB * 512);         // [query][head] softmax denominators
+    int* rq = reinterpret_cast<int*>(smem + QB * WAVE_LDS + QB * 512 + QB * HEADS * 4);       // [query slot] -> query row
+    // XCD-chunked block order (block b runs on XCD b % 8): every XCD works through one contiguous range of query slots; optional launch order
+    // of the queries (the S path ranks them by the smallest RoI they list, so that matched RoIs share an L2).  Speed only.
+    const int nblk = (R + QB - 1) / QB;
+    const int slot0 = xcd_chunked(blockIdx.x, nblk) * QB;
+    if (tid < QB) {
+        const int s = min(slot0 + tid, R - 1);
+        rq[tid] = order ? order[s] : s;
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- phase A: query maps, wave = head
+    {
+        const int h = wave, r = rq[n & 7];
+        const float* qp = q + (long long)r * C + 32 * h + 8 * g;
+        XfFrag bh, bl;
+        xf_split8(*reinterpret_cast<const float4*>(qp), *reinterpret_cast<const float4*>(qp + 4), bh, bl);
+        const uint4* wh = WA_hi + (long long)h * 16 * 64 + lane;
+        const uint4* wl = WA_lo + (long long)h * 16 * 64 + lane;
+        uint4* qt = reinterpret_cast<uint4*>(smem + (n & 7) * WAVE_LDS) + h * 64;      // this lane's query, this head: 64 chunks of 16 B
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            f32x4_t a[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                XfFrag ah, al;
+                ah.u = wh[(2 * u + k) * 64];
+                al.u = wl[(2 * u + k) * 64];
+                f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+                c = mfma_q16_16x16x32(al.v, bh.v, c);
+                c = mfma_q16_16x16x32(ah.v, bl.v, c);
+                c = mfma_q16_16x16x32(ah.v, bh.v, c);
+                a[k] = c;
+            }
+            XfFrag hi, lo;
+            xf_split8_k16(make_float4(a[0][0], a[0][1], a[0][2], a[0][3]), make_float4(a[1][0], a[1][1], a[1][2], a[1][3]), hi, lo);
+            if (n < 8) {
+                qt[u * 8 + g * 2] = hi.u;
+                qt[u * 8 + g * 2 + 1] = lo.u;
+            }
+        }
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- phase B: tile attention, wave = query
+    const int r = rq[wave];
+    const int beg = row_ptr[r], end = row_ptr[r + 1];
+    const int ntile = (end - beg + 15) >> 4;
+    XfFrag qa[8];
+    {
+        const uint4* qp = reinterpret_cast<const uint4*>(smem + wave * WAVE_LDS) + (n & 7) * 64 + g * 2 + (n >> 3);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) qa[s].u = qp[s * 8];
+    }
+    // (a wave's operand lies in its OWN 16 KB area, which only the wave itself overwrites with key tiles below: no barrier needed here)
+    uint4* kt = reinterpret_cast<uint4*>(smem + wave * WAVE_LDS);
+    uint4* kt2 = kt + 512;
+    float* pl = reinterpret_cast<float*>(smem + QB * WAVE_LDS) + wave * 128;
+    float m_run[4], l_run[4];
+    f32x4_t Z[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { m_run[i] = -INFINITY; l_run[i] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) Z[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    {
+        auto load_v = [&](const unsigned short* V_, int myidx, xf_u32x4 (&dst)[4][2]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned int vidx = (unsigned int)__shfl(myidx, 4 * g + e, 64);
+                const char* vp = reinterpret_cast<const char*>(V_) + ((vidx << 9) + 16u * (unsigned)n);
+                dst[e][0] = *reinterpret_cast<const xf_u32x4*>(vp);
+                dst[e][1] = *reinterpret_cast<const xf_u32x4*>(vp + 256);
+            }
+        };
+        auto load_k = [&](const unsigned short* K_, int myidx, xf_u32x4 (&dst)[8]) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned int ridx = (unsigned int)__shfl(myidx, 2 * i + (lane >> 5), 64);
+                dst[i] = *reinterpret_cast<const xf_u32x4*>(reinterpret_cast<const char*>(K_) + ((ridx << 9) + (unsigned)(lane & 31) * 16u));
+            }
+        };
+        auto store_k = [&](uint4* tile, const xf_u32x4 (&src)[8]) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int rowi = 2 * i + (lane >> 5);
+                reinterpret_cast<xf_u32x4*>(tile)[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = src[i];
+            }
+        };
+        auto compute = [&](int tt, const xf_u32x4 (&vreg)[4][2], const xf_u32x4 (&vlo)[4][2]) {
+            const int kbase = beg + 16 * tt;
+            f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                XfFrag kb;
+                kb.u = kt[n * 32 + ((4 * s + g) ^ n)];
+                sacc = mfma_k16_16x16x32(qa[s].u, kb.u, sacc);
+                if (XLO) {
+                    XfFrag kl, qh;
+                    kl.u = kt2[n * 32 + ((4 * s + g) ^ n)];
+                    qh.u = n < 8 ? qa[s].u : make_uint4(0u, 0u, 0u, 0u);
+                    sacc = mfma_k16_16x16x32(qh.u, kl.u, sacc);
+                }
+            }
+            const bool valid = kbase + n < end;
+            float sv[4], p[4], alpha[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sacc[i]), __float_as_uint(sacc[i]), false, false);
+                const float full = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                sv[i] = valid ? full * LOG2E : -INFINITY;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float tm = sv[i];
+                tm = xf_row16_max(tm);
+                const float m_new = fmaxf(m_run[i], tm);
+                alpha[i] = __builtin_amdgcn_exp2f(m_run[i] - m_new);
+                p[i] = __builtin_amdgcn_exp2f(sv[i] - m_new);
+                l_run[i] = l_run[i] * alpha[i] + p[i];
+                m_run[i] = m_new;
+            }
+            if (g < 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pl[(4 * g + i) * 16 + n] = p[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint2 pa, pah;
+            {
+                const float4 pv = *reinterpret_cast<const float4*>(pl + (n & 7) * 16 + 4 * g);
+                unsigned int h0, h1, l0, l1;
+                split_k16x2_bounded(pv.x, pv.y, h0, l0);
+                split_k16x2_bounded(pv.z, pv.w, h1, l1);
+                pa = n < 8 ? make_uint2(h0, h1) : make_uint2(l0, l1);
+                pah = n < 8 ? make_uint2(h0, h1) : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Z[u][i] *= alpha[i];
+#pragma unroll
+            for (int H = 0; H < 2; ++H) {
+                const unsigned int r0[4] = {vreg[0][H].x, vreg[0][H].y, vreg[0][H].z, vreg[0][H].w};
+                const unsigned int r1[4] = {vreg[1][H].x, vreg[1][H].y, vreg[1][H].z, vreg[1][H].w};
+                const unsigned int r2[4] = {vreg[2][H].x, vreg[2][H].y, vreg[2][H].z, vreg[2][H].w};
+                const unsigned int r3[4] = {vreg[3][H].x, vreg[3][H].y, vreg[3][H].z, vreg[3][H].w};
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    const int d = w >> 1;
+                    const uint2 vb = (w & 1) ? make_uint2(xf_hi_pair(r0[d], r1[d]), xf_hi_pair(r2[d], r3[d]))
+                                             : make_uint2(xf_lo_pair(r0[d], r1[d]), xf_lo_pair(r2[d], r3[d]));
+                    f32x4_t zc = Z[H * 8 + w];
+                    zc = mfma_k16_16x16x16(pa, vb, zc);
+                    if (XLO) {
+                        const unsigned int q0[4] = {vlo[0][H].x, vlo[0][H].y, vlo[0][H].z, vlo[0][H].w}, q1[4] = {vlo[1][H].x, vlo[1][H].y, vlo[1][H].z, vlo[1][H].w};
+                        const unsigned int q2[4] = {vlo[2][H].x, vlo[2][H].y, vlo[2][H].z, vlo[2][H].w}, q3[4] = {vlo[3][H].x, vlo[3][H].y, vlo[3][H].z, vlo[3][H].w};
+                        const uint2 vl = (w & 1) ? make_uint2(xf_hi_pair(q0[d], q1[d]), xf_hi_pair(q2[d], q3[d]))
+                                                 : make_uint2(xf_lo_pair(q0[d], q1[d]), xf_lo_pair(q2[d], q3[d]));
+                        zc = mfma_k16_16x16x16(pah, vl, zc);
+                    }
+                    Z[H * 8 + w] = zc;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        int idx_next = ntile > 0 ? col_idx[min(beg + n, end - 1)] : 0;
+        for (int tt = 0; tt < ntile; ++tt) {
+            const int myidx = idx_next;
+            if (tt + 1 < ntile) idx_next = col_idx[min(beg + 16 * (tt + 1) + n, end - 1)];
+            if constexpr (XLO) {
+                xf_u32x4 kreg[8], klo[8], vreg[4][2], vlo[4][2];
+                load_k(Xk, myidx, kreg);
+                load_k(Xk_lo, myidx, klo);
+                store_k(kt, kreg);
+                store_k(kt2, klo);
+                load_v(Xv, myidx, vreg);
+                load_v(Xv_lo, myidx, vlo);
+                __builtin_amdgcn_wave_barrier();
+                compute(tt, vreg, vlo);
+            } else {
+                xf_u32x4 kreg[8], vreg[4][2];
+                load_k(Xk, myidx, kreg);
+                load_v(Xv, myidx, vreg);
+                store_k(kt, kreg);
+                __builtin_amdgcn_wave_barrier();
+                compute(tt, vreg, vreg);
+            }
+        }
+    }
+    // ---- denominators (row sums over the 16 key lanes) and the un-normalised z of the query into the wave's own LDS area ([head][256] fp32 = 8 KB)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float l = l_run[i];
+        l += __shfl_xor(l, 1, 64);
+        l += __shfl_xor(l, 2, 64);
+        l += __shfl_xor(l, 4, 64);
+        l += __shfl_xor(l, 8, 64);
+        l_run[i] = l;
+    }
+    if (n == 0 && g < 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lsum[wave * HEADS + 4 * g + i] = l_run[i];
+    }
+    {
+        float* szw = reinterpret_cast<float*>(smem + wave * WAVE_LDS);
+#pragma unroll
+        for (int H = 0; H < 2; ++H)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(Z[H * 8 + w][i]), __float_as_uint(Z[H * 8 + w + 4][i]), false, false);
+                    v[w] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                }
+                float* dst = szw + (4 * (g & 1) + i) * C + 128 * H + 8 * n + 4 * (g >> 1);
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- phase C: context maps, wave = head
+    {
+        const int h = wave, j = n & 7;
+        const float* zp = reinterpret_cast<const float*>(smem + j * WAVE_LDS) + h * C + 8 * g;
+        // (xattn_tile_kernel normalises when it merges its waves: num * rcp(den), the factor of the single wave being exp2(0) = 1)
+        const float rl = __builtin_amdgcn_rcpf(lsum[j * HEADS + h]);
+        const uint4* wh = WB_hi + (long long)h * 16 * 64 + lane;
+        const uint4* wl = WB_lo + (long long)h * 16 * 64 + lane;
+        f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float4 x0 = *reinterpret_cast<const float4*>(zp + 32 * s);
+            float4 x1 = *reinterpret_cast<const float4*>(zp + 32 * s + 4);
+            x0 = make_float4(x0.x * rl, x0.y * rl, x0.z * rl, x0.w * rl);
+            x1 = make_float4(x1.x * rl, x1.y * rl, x1.z * rl, x1.w * rl);
+            XfFrag ah, al;
+            xf_split8(x0, x1, ah, al);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                XfFrag bh, bl;
+                bh.u = wh[(s * 2 + nt) * 64];
+                bl.u = wl[(s * 2 + nt) * 64];
+                acc[nt] = mfma_q16_16x16x32(al.v, bh.v, acc[nt]);
+                acc[nt] = mfma_q16_16x16x32(ah.v, bl.v, acc[nt]);
+                acc[nt] = mfma_q16_16x16x32(ah.v, bh.v, acc[nt]);
+            }
+        }
+        if (g < 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int js = 4 * g + i;
+                if (slot0 + js < R) {
+                    const int rr = rq[js];
+                    const bool empty = row_ptr[rr + 1] <= row_ptr[rr];
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const int col = 32 * h + 16 * nt + n;
+                        float v = acc[nt][i] + bv[col];
+                        if (empty) v = empty_nan ? __uint_as_float(0x7fc00000u) : 0.f;
+                        ctx[(long long)rr * C + col] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// C-ABI: include/mv2d_hip.h
+extern "C" int mv2d_xattn_fused_fwd(const float* q, const void* WA_hi, const void* WA_lo, const void* WB_hi, const void* WB_lo, const float* bv,
+                                    const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr, const int* col_idx,
+                                    float* ctx, int R, int empty_nan, const int* order, void* stream) {
+    MV2D_CHECK_ARG(q && WA_hi && WA_lo && WB_hi && WB_lo && bv && Xk && Xv && row_ptr && col_idx && ctx && R >= 0, "mv2d_xattn_fused_fwd: bad args");
+    MV2D_CHECK_ARG((Xk_lo == nullptr) == (Xv_lo == nullptr), "mv2d_xattn_fused_fwd: Xk_lo and Xv_lo come together");
+    MV2D_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)WA_hi & 15) == 0 && ((uintptr_t)WA_lo & 15) == 0 && ((uintptr_t)WB_hi & 15) == 0 &&
+                       ((uintptr_t)WB_lo & 15) == 0 && ((uintptr_t)Xk & 15) == 0 && ((uintptr_t)Xv & 15) == 0 && ((uintptr_t)Xk_lo & 15) == 0 &&
+                       ((uintptr_t)Xv_lo & 15) == 0, "mv2d_xattn_fused_fwd: operands must be 16-byte aligned");
+    if (R == 0) return MV2D_OK;
+    const dim3 grid((R + QB - 1) / QB), block(64 * QB);
+    if (Xk_lo)
+        hipLaunchKernelGGL((xattn_fused_kernel<true>), grid, block, 0, (hipStream_t)stream, q, (const uint4*)WA_hi, (const uint4*)WA_lo, (const uint4*)WB_hi,
+                           (const uint4*)WB_lo, bv, (const unsigned short*)Xk, (const unsigned short*)Xv, (const unsigned short*)Xk_lo,
+                           (const unsigned short*)Xv_lo, row_ptr, col_idx, ctx, R, empty_nan, order);
+    else
+        hipLaunchKernelGGL((xattn_fused_kernel<false>), grid, block, 0, (hipStream_t)stream, q, (const uint4*)WA_hi, (const uint4*)WA_lo, (const uint4*)WB_hi,
+                           (const uint4*)WB_lo, bv, (const unsigned short*)Xk, (const unsigned short*)Xv, (const unsigned short*)Xk_lo,
+                           (const unsigned short*)Xv_lo, row_ptr, col_idx, ctx, R, empty_nan, order);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}

@@ -521,7 +521,7 @@ extern "C" int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const
                                                  (const unsigned short*)Xk, (const unsigned short*)Xv, (const unsigned short*)Xk_lo, (const unsigned short*)Xv_lo, \
                                                  row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan, order)
     // index-exact route (hi + lo rows): two waves per SIMD like the default (round 3: the 312-register build ran one wave per SIMD, 133 us per layer)
-    if (Xk_lo) { if (dbg_logits) MV2D_XT(4, true, true); else if (nw == 4) MV2D_XT(4, false, true); else MV2D_XT(2, false, true); }
+    if (Xk_lo) { if (dbg_logits) MV2D_XT(4, true, true); else if (nw == 4) MV2D_XT(4, false, true); else if (nw == 1) MV2D_XT(1, false, true); else MV2D_XT(2, false, true); }
     else if (dbg_logits) { if (nw == 8) MV2D_XT(8, true, false); else if (nw == 2) MV2D_XT(2, true, false); else if (nw == 1) MV2D_XT(1, true, false); else MV2D_XT(4, true, false); }
     else { if (nw == 8) MV2D_XT(8, false, false); else if (nw == 2) MV2D_XT(2, false, false); else if (nw == 1) MV2D_XT(1, false, false); else MV2D_XT(4, false, false); }
 #undef MV2D_XT

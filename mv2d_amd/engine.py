@@ -98,6 +98,10 @@ class HeadEngine:
         # delivers), but a launch with fewer waves leaves more of the chip to the other streams' kernels: cfg2_s 8067 / 8043 / 7869
         # samples/s for 1 / 2 / 4, cfg3_t (rows of ~200 keys) 5803 / 5868 / 5758
         self.xattn_waves = 2
+        # S path (rows of similar length): query map -> tile attention -> context map as ONE launch per layer (csrc/xattn_fused.hip, round 5: blocks
+        # of 8 queries, Qt / z stay on chip; bitwise the three kernels with one wave per query).  None: on the S path when no debug output is asked
+        # for; False / True forces it.  In the graph key.
+        self.fuse_xattn = None
         # INDEX-EXACT ROUTE = THE DEFAULT since round 5 (exact=None -> True; exact=False / MV2D_EXACT=0 / test_cfg.index_exact=False selects the
         # opt-in "key16" mode with ONE fp16 rounding of the key side: ~1.3 x faster, 4-22 of 300 ranked indices differ from the reference's).
         # Every 16-bit rounding of the key side is replaced by fp32-class arithmetic -- the PE block in one split-precision kernel on unrounded inputs (csrc/pe_x3.hip), the key / value
@@ -651,6 +655,9 @@ class HeadEngine:
         xk_rows, xv_rows = ws['xk_rows'], ws['xv_rows']
         dbg = ws.get('dbg_logits')
         maps_fused = ((R <= 512) if self.fuse_maps is None else self.fuse_maps) and dbg is None
+        xattn_fused = ((self.kind == 'S' and not ws.get('dn')) if self.fuse_xattn is None else self.fuse_xattn) and dbg is None
+        lo_k = None if 'attn' in self.exact_skip else ws.get('xk_lo')
+        lo_v = None if 'attn' in self.exact_skip else ws.get('xv_lo')
 
         def tile_attn(i):
             if dbg is not None:
@@ -674,7 +681,12 @@ class HeadEngine:
                 o.self_attn(ws['qkv'], ws['ctx'], R, grp_start=ws['grp_start'], max_grp_rows=ws.get('max_rows', 0))
             sa_args = (ws['ctx'], x_in, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'])
             q_args = dict(qpos=ws['qpos'], Wq_x3=W_[f'ca_q_wx{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, M=R)
-            if maps_fused:
+            if xattn_fused:
+                o.attn_out_fused_x3(*sa_args, q_out=ws['q'], **q_args)
+                o.xattn_fused(ws['q'], W_[f'ca_mapA{i}'], W_[f'ca_mapB{i}'], W_[f'ca_v_b{i}'], xk_rows, xv_rows, ws['row_ptr'], ws['col_idx'], out=ws['ctx'], R=R,
+                              empty_nan=self.empty_nan, Xk_lo=lo_k, Xv_lo=lo_v, order=ws.get('q_order') if self.q_order else None)
+                o.attn_out_fused_x3(ws['ctx'], ws['x1'], W_[f'ca_out_wx{i}'], W_[f'ca_out_b{i}'], (W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), ws['x2'], M=R)
+            elif maps_fused:
                 o.attn_out_qmap_x3(*sa_args, WA=W_[f'ca_mapA{i}'], Qt=ws['Qt'], **q_args)
                 tile_attn(i)
                 o.attn_out_zmap_x3(ws['zh'], W_[f'ca_mapB{i}'], W_[f'ca_v_b{i}'], ws['row_ptr'], ws['x1'], W_[f'ca_out_wx{i}'], W_[f'ca_out_b{i}'],
@@ -785,7 +797,7 @@ class HeadEngine:
         # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
         gkey = (ptrs, 0 if payload is None else payload.data_ptr(), sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs, self.last_stage_heads,
-                self.xattn_waves, self.fuse_maps, self.keep_sine_rows, self.force_nc, self.q_order,
+                self.xattn_waves, self.fuse_maps, self.fuse_xattn, self.keep_sine_rows, self.force_nc, self.q_order,
                 self.fork_qg, self.exact_skip)   # load_state() re-allocates the weights; every route option of __init__ is in the key
         graphs = ws.setdefault('graphs', {})             # one graph per (input buffers, frame scalars): a producer that alternates between
         g = graphs.get(gkey)                             # a few static output buffers replays a few graphs, it does not re-capture

@@ -569,6 +569,22 @@ def xattn_tile(Qt, Xk, Xv, row_ptr, col_idx, out=None, R=None, dbg_logits=None, 
     return out
 
 
+def xattn_fused(q, WA, WB, bv, Xk, Xv, row_ptr, col_idx, out=None, R=None, empty_nan=True, Xk_lo=None, Xv_lo=None, order=None):
+    """ctx [R,256] fp32 = xattn_ctxmap(xattn_tile(xattn_qmap(q))) in ONE launch (csrc/xattn_fused.hip: blocks of 8 queries, Qt / z stay on chip);
+    bitwise equal to the three calls with waves=1."""
+    _req(q, torch.float32, 'q'); _req(bv, torch.float32, 'bv'); _req(row_ptr, torch.int32, 'row_ptr'); _req(col_idx, torch.int32, 'col_idx')
+    for t, n_ in ((WA[0], 'WA_hi'), (WA[1], 'WA_lo'), (WB[0], 'WB_hi'), (WB[1], 'WB_lo')):
+        _req(t, q16_dtype(), n_)
+    _req16(Xk, 'Xk'); _req16(Xv, 'Xv'); _req16(Xk_lo, 'Xk_lo'); _req16(Xv_lo, 'Xv_lo'); _req(order, torch.int32, 'order')
+    R = q.shape[0] if R is None else R
+    if out is None:
+        out = torch.empty((R, 256), device=q.device, dtype=torch.float32)
+    _req(out, torch.float32, 'out')
+    check(_lib.load().mv2d_xattn_fused_fwd(_p(q), _p(WA[0]), _p(WA[1]), _p(WB[0]), _p(WB[1]), _p(bv), _p(Xk), _p(Xv), _p(Xk_lo), _p(Xv_lo), _p(row_ptr),
+                                           _p(col_idx), _p(out), R, 1 if empty_nan else 0, _p(order), _stream()), 'mv2d_xattn_fused_fwd')
+    return out
+
+
 def xattn_query_order(row_ptr, col_idx, grp_start, R, perm, flags, stride=0):
     """perm [R] int32 = the query rows of every sample (grp_start [n+1], device) sorted by their smallest key (stride 0: the first entry of a
     CSR row; stride 49: the smallest first cell of the RoIs an S-path row lists); flags int32 [>=1] (zeroed by the caller)."""

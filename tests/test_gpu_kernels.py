@@ -411,6 +411,51 @@ def _unpack_qt(Qt, R):
     return t[:, :, :, :, 0].reshape(R, 8, 256), t[:, :, :, :, 1].reshape(R, 8, 256)
 
 
+@pytest.mark.parametrize('R,S,dens,lo', [(300, 700, 0.2, True), (37, 300, 0.5, True), (64, 64 * 49, 0.0, True), (300, 700, 0.2, False)])
+def test_xattn_fused_equals_the_three_kernels(dev, R, S, dens, lo):
+    """mv2d_xattn_fused_fwd (csrc/xattn_fused.hip, round 5: query map -> tile attention -> context map per block of 8 queries, Qt / z on chip)
+    == the three launches of csrc/xattn_tile.hip with one wave per query, BIT FOR BIT: ragged R (not a multiple of 8), rows of 0 .. 300 keys,
+    an empty row (NaN and zero policy), hi-only and hi + lo rows, any launch order."""
+    from mv2d_amd import ops
+    from oracle import mv2d_oracle as O
+    g = np.random.Generator(np.random.PCG64(460 + R))
+    if dens > 0:
+        allowed = torch.from_numpy(g.random((R, S)) < dens)
+        allowed[5] = False
+        allowed[7, :] = False
+        allowed[7, 123] = True
+    else:
+        allowed = torch.zeros((R, S), dtype=torch.bool)
+        for r in range(R):
+            allowed[r, r * 49:(r + 1) * 49] = True
+            if r % 3 == 0:
+                allowed[r, ((r + 3) % R) * 49:((r + 3) % R) * 49 + 49] = True
+    k16 = ops.key16_dtype()
+    q = (rnd((R, 256), 461) * 0.3).to(dev)
+    q[3] *= 8.0
+    xk32, xv32 = rnd((S, 256), 462).to(dev), rnd((S, 256), 463).to(dev)
+    Xk, Xk_lo = ops.f32_to_key16(xk32, with_lo=True)
+    Xv, Xv_lo = ops.f32_to_key16(xv32, with_lo=True)
+    if not lo:
+        Xk_lo = Xv_lo = None
+    Wk, Wv = rnd((256, 256), 464, 0.06).to(dev), rnd((256, 256), 466, 0.06).to(dev)
+    bv = rnd((256,), 467).to(dev)
+    row_ptr, col = O.csr_from_allowed(allowed)
+    row_ptr, col = row_ptr.to(dev), col.to(dev)
+    WA, WB = ops.pack_xattn_maps(Wk, Wv)
+    for empty_nan in (False, True):
+        Qt = ops.xattn_qmap(q, WA)
+        z = ops.xattn_tile(Qt, Xk, Xv, row_ptr, col, empty_nan=empty_nan, waves=1, Xk_lo=Xk_lo, Xv_lo=Xv_lo)
+        ref = ops.xattn_ctxmap(z, WB, bv, row_ptr, empty_nan=empty_nan)
+        out = ops.xattn_fused(q, WA, WB, bv, Xk, Xv, row_ptr, col, empty_nan=empty_nan, Xk_lo=Xk_lo, Xv_lo=Xv_lo)
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), (empty_nan, float((out - ref).abs().nan_to_num(0).max()))
+        perm = torch.randperm(R, generator=torch.Generator().manual_seed(R)).to(torch.int32).to(dev)
+        out2 = ops.xattn_fused(q, WA, WB, bv, Xk, Xv, row_ptr, col, empty_nan=empty_nan, Xk_lo=Xk_lo, Xv_lo=Xv_lo, order=perm)
+        assert torch.equal(out2.view(torch.int32), ref.view(torch.int32))
+    if dens > 0:
+        assert bool(torch.isnan(out[5]).all()) and bool(torch.isfinite(out[6:]).all())
+
+
 @pytest.mark.parametrize('R,S,dens,waves', [(37, 500, 0.05, 4), (37, 500, 0.05, 1), (301, 5000, 0.02, 8), (301, 5000, 0.02, 2), (64, 49 * 64, -1.0, 2),
                                             (2500, 3000, 0.01, 2), (1100, 49 * 1100, -1.0, 4),
                                             (20, 2000, 0.3, 4), (20, 2000, 0.3, 8), (20, 2000, 0.3, 1)])
