@@ -67,17 +67,21 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
                                                                 const unsigned short* __restrict__ Xk, const unsigned short* __restrict__ Xv,
                                                                 const unsigned short* __restrict__ Xk_lo, const unsigned short* __restrict__ Xv_lo,
                                                                 const int* __restrict__ row_ptr, const int* __restrict__ col_idx, float* __restrict__ ctx,
-                                                                int R, int empty_nan, const int* __restrict__ order) {
+                                                                int R, int empty_nan, const int* __restrict__ order, int nblk) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
     float* lsum = reinterpret_cast<float*>(smem + QB * WAVE_LDS + QB * 512);         // [query][head] softmax denominators
     int* rq = reinterpret_cast<int*>(smem + QB * WAVE_LDS + QB * 512 + QB * HEADS * 4);       // [query slot] -> query row
     // XCD-chunked block order (block b runs on XCD b % 8): every XCD works through one contiguous range of query slots; optional launch order
     // of the queries (the S path ranks them by the smallest RoI they list, so that matched RoIs share an L2).  Speed only.
-    const int nblk = (R + QB - 1) / QB;
-    const int slot0 = xcd_chunked(blockIdx.x, nblk) * QB;
+    // The R query slots are dealt EVENLY to nblk >= ceil(R / 8) blocks (the host rounds nblk up to a multiple of the CU count when that leaves >= 4
+    // queries per block: 4800 queries = 600 blocks of 8 are 2.34 rounds of 256 one-block-per-CU slots, and the third round costs nearly a full one;
+    // 768 blocks of 6-7 queries are three full rounds of 0.78 x the work each: 140 -> 112 us per layer).
+    const int blk = xcd_chunked(blockIdx.x, nblk);
+    const int slot0 = (int)((long long)blk * R / nblk), nq = (int)((long long)(blk + 1) * R / nblk) - slot0;
+    if (nq <= 0) return;
     if (tid < QB) {
-        const int s = min(slot0 + tid, R - 1);
+        const int s = slot0 + min(tid, nq - 1);
         rq[tid] = order ? order[s] : s;
     }
     __syncthreads();
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
     // ---------------------------------------------------------------- phase B: tile attention, wave = query
     const int r = rq[wave];
     const int beg = row_ptr[r], end = row_ptr[r + 1];
-    const int ntile = (end - beg + 15) >> 4;
+    const int ntile = wave < nq ? (end - beg + 15) >> 4 : 0;          // (waves beyond the block's queries: no tiles; their z / l are never read)
     XfFrag qa[8];
     {
         const uint4* qp = reinterpret_cast<const uint4*>(smem + wave * WAVE_LDS) + (n & 7) * 64 + g * 2 + (n >> 3);
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int js = 4 * g + i;
-                if (slot0 + js < R) {
+                if (js < nq) {
                     const int rr = rq[js];
                     const bool empty = row_ptr[rr + 1] <= row_ptr[rr];
 #pragma unroll
@@ -347,15 +351,26 @@ extern "C" int mv2d_xattn_fused_fwd(const float* q, const void* WA_hi, const voi
                        ((uintptr_t)WB_lo & 15) == 0 && ((uintptr_t)Xk & 15) == 0 && ((uintptr_t)Xv & 15) == 0 && ((uintptr_t)Xk_lo & 15) == 0 &&
                        ((uintptr_t)Xv_lo & 15) == 0, "mv2d_xattn_fused_fwd: operands must be 16-byte aligned");
     if (R == 0) return MV2D_OK;
-    const dim3 grid((R + QB - 1) / QB), block(64 * QB);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    int nblk = (R + QB - 1) / QB;
+    if (nblk > n_cu) {                                        // whole rounds of one block per CU, as long as a block keeps >= 4 queries
+        const int up = (nblk + n_cu - 1) / n_cu * n_cu;
+        if ((long long)up * 4 <= R) nblk = up;
+    }
+    const dim3 grid(nblk), block(64 * QB);
     if (Xk_lo)
         hipLaunchKernelGGL((xattn_fused_kernel<true>), grid, block, 0, (hipStream_t)stream, q, (const uint4*)WA_hi, (const uint4*)WA_lo, (const uint4*)WB_hi,
                            (const uint4*)WB_lo, bv, (const unsigned short*)Xk, (const unsigned short*)Xv, (const unsigned short*)Xk_lo,
-                           (const unsigned short*)Xv_lo, row_ptr, col_idx, ctx, R, empty_nan, order);
+                           (const unsigned short*)Xv_lo, row_ptr, col_idx, ctx, R, empty_nan, order, nblk);
     else
         hipLaunchKernelGGL((xattn_fused_kernel<false>), grid, block, 0, (hipStream_t)stream, q, (const uint4*)WA_hi, (const uint4*)WA_lo, (const uint4*)WB_hi,
                            (const uint4*)WB_lo, bv, (const unsigned short*)Xk, (const unsigned short*)Xv, (const unsigned short*)Xk_lo,
-                           (const unsigned short*)Xv_lo, row_ptr, col_idx, ctx, R, empty_nan, order);
+                           (const unsigned short*)Xv_lo, row_ptr, col_idx, ctx, R, empty_nan, order, nblk);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
