@@ -467,7 +467,7 @@ def main():
         stage_ms[a] = statistics.median(x.elapsed_time(y) for x, y in zip(prof[a], prof[b]))
     fl, by = stage_flops(kind, R, S), stage_bytes(kind, R, S)
     try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get(f'{args.workload}@{B}', {})
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get(f'{args.workload}@{B}' + (':key16' if args.key16 else ''), {})
     except Exception:
         pmc = {}
     try:
@@ -495,7 +495,15 @@ def main():
         o['traffic_detail'] = dict(t, source='profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)') if t else None
         return o
 
-    stage_roofline = {k: roof(k, f"{STAGE_KERNEL.get(k, 'gemm_bf16_kernel')}[{k}]", stage_ms[k], fl[k], by[k]) for k in fl if k in stage_ms}
+    sk = dict(STAGE_KERNEL)
+    if eng.exact:
+        # index-exact route: the PE stage = pe_frustum_f32_kernel + pe_x3_kernel (3 MFMAs per product: `mfma_issue_frac` prices the issued MFMA work,
+        # `frac` the algorithmic FLOPs as SURVEY 8(d) counts them)
+        sk['pe_fused'] = 'pe_frustum_f32_kernel + pe_x3_kernel (frustum rows in fp64, frustum MLP + gate in split precision, sine branch from the table)'
+        by['pe_fused'] = S * 192 * 4 * 2 + S * 256 * 4 * 2 + (192 * 1024 + 1024 * 256 + 2 * 256 * 256) * 4 + (S * 256 * (4 + 8) if kind == 'T' else S * 256 * 4)
+    stage_roofline = {k: roof(k, f"{sk.get(k, 'gemm_bf16_kernel')}[{k}]", stage_ms[k], fl[k], by[k]) for k in fl if k in stage_ms}
+    if eng.exact and 'pe_fused' in stage_roofline:
+        stage_roofline['pe_fused']['mfma_issue_frac'] = round(3 * fl['pe_fused'] / (stage_ms['pe_fused'] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
 
     # ---------------- decoder ms/iter (CrossAttentionBoxHead transformer on prepared inputs), hipGraph replay
     g = torch.cuda.CUDAGraph()
@@ -541,11 +549,21 @@ def main():
         xk, xv = ws['xk_rows'], ws['xv_rows']
         q_ord = ws.get('q_order')                          # T path: blocks in the order of the queries' smallest key (as the engine launches it)
         xlo = dict(Xk_lo=ws['xk_lo'], Xv_lo=ws['xv_lo']) if (getattr(eng, 'exact', False) and ws.get('xk_lo') is not None) else {}      # index-exact route: hi + lo rows
+        # the launch the engine makes per layer: the one-launch cross attention (S path: query map + tile attention + context map, csrc/xattn_fused.hip)
+        # or the tile kernel of the three-launch form (T path)
+        fused = (kind == 'S') if eng.fuse_xattn is None else bool(eng.fuse_xattn)
+        if fused:
+            W0 = eng.w
+            x_launch = lambda: ops.xattn_fused(ws['q'], W0['ca_mapA0'], W0['ca_mapB0'], W0['ca_v_b0'], xk, xv, ws['row_ptr'], ws['col_idx'], out=ws['ctx'], R=R,      # noqa: E731
+                                               empty_nan=eng.empty_nan, order=q_ord, **xlo)
+        else:
+            x_launch = lambda: ops.xattn_tile(ws['Qt'], xk, xv, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=eng.empty_nan, waves=eng.xattn_waves,      # noqa: E731
+                                              order=q_ord, **xlo)
         for _ in range(3):
-            ops.xattn_tile(ws['Qt'], xk, xv, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=eng.empty_nan, waves=eng.xattn_waves, order=q_ord, **xlo)
+            x_launch()
         e0.record()
         for _ in range(20):
-            ops.xattn_tile(ws['Qt'], xk, xv, ws['row_ptr'], ws['col_idx'], ws['zh'], R, empty_nan=eng.empty_nan, waves=eng.xattn_waves, order=q_ord, **xlo)
+            x_launch()
         e1.record()
         torch.cuda.synchronize()
         x_ms = e0.elapsed_time(e1) / 20
@@ -554,14 +572,16 @@ def main():
         n_rows = min(nnz, S if kind == 'T' else R * 49)
         b_el = 4 if xlo else 2                                                      # bytes per key / value element: fp16 hi + lo pair (fp32-class) or one fp16
         row_b = 2 * 256 * b_el                                                      # K + V row
-        own = R * (16 * 256 * 2 + 8 * 256 * 4)                                      # Qt in + z out: intermediates of THIS decomposition (qmap -> tile -> ctxmap)
+        own = 0 if fused else R * (16 * 256 * 2 + 8 * 256 * 4)                      # Qt in + z out: intermediates of the three-launch decomposition (none when fused)
         # SURVEY 8(d) per layer: read X_k, X_v (2 S C b) + query state in / out (2 Q C 4).  `frac` follows from these bytes ALONE (round 4 also
         # counted Qt / z, which exist only because the attention is split into three kernels: that figure stays as frac_incl_own_intermediates)
         x_bytes = n_rows * row_b + 2 * R * 256 * 4
         x_gathered = nnz * row_b + own
         x_flops = 2.0 * nnz * 8 * 256 * 2                                          # logits + P.V in the 256-dim input space, 8 heads
-        xattn = roof('xattn_tile', 'xattn_tile_kernel (sparse cross-attention in the raw key space, one launch per decoder layer)', x_ms, x_flops, x_bytes,
-                     launches=eng.L)
+        xattn = roof('xattn_fused' if fused else 'xattn_tile',
+                     ('xattn_fused_kernel (query map + sparse cross-attention in the raw key space + context map, ONE launch per decoder layer)' if fused else
+                      'xattn_tile_kernel (sparse cross-attention in the raw key space, one launch per decoder layer; query / context maps are separate launches)'),
+                     x_ms, x_flops, x_bytes, launches=eng.L)
         gbs = lambda nb: nb / (x_ms * 1e-3) / 1e9      # noqa: E731
         xattn['bytes_per_element'] = b_el
         xattn['frac_incl_own_intermediates'] = round(gbs(n_rows * row_b + own) / PEAK_HBM_GBS, 4)
@@ -572,7 +592,7 @@ def main():
                          'index-exact route, the width the fp32 reference reads; 2 = key16 mode) + the query state in / out (2 Q C 4); frac_at_survey_b2 = the '
                          'same time priced at the b = 2 SURVEY 8(d) assumed; frac_incl_own_intermediates also counts Qt in + z out (8 KB each per query); '
                          'gathered_bytes_per_launch = the rows of every allowed (query, key) pair (repeats are served by L2 / Infinity Cache)')
-        stage_roofline['xattn_tile'] = xattn
+        stage_roofline['xattn_fused' if fused else 'xattn_tile'] = xattn
     # the dominant kernel = the one with the most time per step (launch duration x launches per step)
     dom = max(stage_roofline, key=lambda k: stage_roofline[k]['launch_ms'] * stage_roofline[k]['launches_per_step'])
     roofline = stage_roofline[dom]

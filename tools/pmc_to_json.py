@@ -4,7 +4,7 @@ Per-launch HBM bytes of the kernels bench.py's roofline objects describe (averag
 doubled on gfx950, MI355X_MICROARCH.md section HBM)."""
 import json, os, sys
 
-KERNELS = {'pe_fused': ('pe_tab_kernel', 'pe_fused_kernel'), 'nchw_to_nhwc': ('nchw_to_nhwc',), 'pe_inputs': ('pe_inputs_kernel',), 'qg_conv_gemm': ('roi_conv_pool_kernel',), 'xattn_tile': ('xattn_tile_kernel',),
+KERNELS = {'pe_fused': ('pe_x3_kernel', 'pe_tab_kernel', 'pe_fused_kernel'), 'xattn_fused': ('xattn_fused_kernel',), 'pe_frustum': ('pe_frustum_f32_kernel',), 'nchw_to_nhwc': ('nchw_to_nhwc',), 'pe_inputs': ('pe_inputs_kernel',), 'qg_conv_gemm': ('roi_conv_pool_kernel',), 'xattn_tile': ('xattn_tile_kernel',),
            'roi_align': ('roi_align_kernel',), 'self_attn': ('self_attn_x3_kernel', 'self_attn_kernel'), 'ffn': ('ffn_x3_kernel',)}
 
 

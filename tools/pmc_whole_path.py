@@ -5,9 +5,9 @@ warm-up frames and the decoder-only timing leg, so the per-launch AVERAGE of eve
 (once-per-frame kernels: 1; per decoder layer: 6; out projections: 12) instead of dividing totals by a frame count."""
 import re, sys
 
-PER_FRAME = {'xattn_tile_kernel': 6, 'xattn_qmap_kernel': 6, 'xattn_ctxmap_kernel': 6, 'ffn_x3_kernel': 6, 'ffn_out_fused_x3_kernel': 6, 'attn_out_fused_x3_kernel': 12,
+PER_FRAME = {'xattn_fused_kernel': 6, 'xattn_tile_kernel': 6, 'xattn_qmap_kernel': 6, 'xattn_ctxmap_kernel': 6, 'ffn_x3_kernel': 6, 'ffn_out_fused_x3_kernel': 6, 'attn_out_fused_x3_kernel': 12,
              'attn_out_qmap': 6, 'attn_out_zmap': 6, 'self_attn_x3_kernel': 6, 'self_attn_kernel': 6}
-SKIP = ('spin_kernel', 'pack_wfrag', 'split_bf16x2', 'f32_to_key16', 'gemm_bf16', 'split3_rows', 'at6native', 'rocclr', 'elementwise')
+SKIP = ('spin_kernel', 'pack_wfrag', 'split_bf16x2', 'split_q16x2', 'f32_to_key16', 'gemm_bf16', 'split3_rows', 'at6native', 'rocclr', 'elementwise')
 
 
 def table(path):
