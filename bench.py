@@ -36,7 +36,7 @@ PEAK_HBM_GBS = 8000.0
 
 def stage_flops(kind, R, S, L=6):
     """Algorithmic FLOPs (2 x MAC) of the dense bf16 MFMA launches of one frame."""
-    # (the input-independent sine branch of the PE block is folded into a per-(weights, geometry) table, DESIGN.md section 8: its FLOPs are NOT counted)
+    # (the input-independent sine branch of the PE block is folded into a per-(weights, geometry) table, LOG.md section 8: its FLOPs are NOT counted)
     return {
         'pe_fused': 2.0 * S * (192 * 1024 + 1024 * 256 + 2 * 256 * 256),                       # 1.16 MFLOP per key position
         'qg_conv_gemm': 2.0 * R * 49 * 2304 * 256,
@@ -638,7 +638,7 @@ def main():
         nc_ = os.cpu_count() or 1
         if nc_ != args.cpu_threads:
             # torch.set_num_threads(os.cpu_count()), 3 warm-ups.  On the 256-thread hosts of this pool the oracle's many
-            # small operators spend their time waking threads (8 / 16 / 32 / 64 threads: 2.24 / 2.09 / 1.53 / 0.67 samples/s),
+            # small operators spend their time waking threads (8 / 16 / 32 / 64 threads: 2.24 / 2.09 / 1.53 / 0.67 samples/s, LOG.md section 5),
             # so the leg is BOUNDED (the warm-ups stop after half of --cpu-all-budget seconds, the timing after all of it, at least one timed frame)
             # and reports what it measured, however slow
             cpu2 = cpu_leg(nc_, 3, args.cpu_all_budget * 2 + 20, ('--warmups', '3', '--budget-s', str(args.cpu_all_budget), '--no-decoder'))

@@ -423,7 +423,7 @@ extern "C" int mv2d_sparse_xattn_fwd_drop(const float* q, const void* K, const v
     const AttnDrop drop = make_drop(p_drop, seed);
     if (R == 0) return MV2D_OK;
     // 8 waves x 4-key chunks: best of {2,4,8} waves x {4,8,16} keys with several samples per launch (cfg2_s decoder 0.671 -> 0.655 ms per
-    // 6-sample batch, cfg3_t 0.845 -> 0.817); with one sample per launch 8 x 8 was marginally ahead
+    // 6-sample batch, cfg3_t 0.845 -> 0.817); with one sample per launch 8 x 8 was marginally ahead (LOG.md section 8)
     hipLaunchKernelGGL((sparse_xattn_kernel<8, 4>), dim3(R), dim3(64 * 8), 0, (hipStream_t)stream, q, (const unsigned short*)K, (const unsigned short*)V,
                        row_ptr, col_idx, ctx, dbg_logits, dbg_stride, R, empty_nan, drop);
     MV2D_LAUNCH_CHECK();

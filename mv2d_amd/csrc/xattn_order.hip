@@ -8,7 +8,7 @@
 // cfg5_t 60.2 -> 51.7 us per layer, bitwise the same results (round 3).
 // (Round 3 also built a shared-key-tile kernel on this order -- 16 queries per workgroup, the union of their key lists streamed once
 //  through an LDS-DMA ring, 16-bit pair masks.  It read 1.40 x the distinct rows instead of 2.99 x and was 3 x SLOWER: a union tile is only
-//  ~35 % allowed pairs for a given pair of queries, the masked MFMA / softmax work tripled.  Retired in round 4)
+//  ~35 % allowed pairs for a given pair of queries, the masked MFMA / softmax work tripled.  Retired in round 4; LOG.md section 8.)
 #include "common.h"
 
 namespace {

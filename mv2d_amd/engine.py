@@ -779,7 +779,7 @@ class HeadEngine:
         # upload of the per-frame tables (RoI list, view / sample offsets, time steps): stream-ordered before the frame, outside the captured graph.
         # The "staging consumed" event stays at the END of the frame: recording it right behind this copy would let the host run a frame ahead on every
         # stream; measured in round 3: +1 % in long runs but 7400-7900 instead of 8300 samples/s in short ones -- without the host's wait the four
-        # streams drift into phase and their wide kernels collide
+        # streams drift into phase and their wide kernels collide (LOG.md section 8)
         ws['dyn_d'].copy_(ws['dyn_h'], non_blocking=True)
         ws['payload_out'] = payload
         self._stage_outputs = bool(keep_stages)          # intermediate buffers nothing downstream reads (pe on the T path, Xk on the S path)

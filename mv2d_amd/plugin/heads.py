@@ -6,7 +6,7 @@
 from the module's own ``state_dict`` — so a checkpoint loaded with the reference key layout is what runs.
 ``forward_train`` keeps the reference signature and loss dict; with gradients enabled it runs the autograd route (HIP attention / RoIAlign /
 loss kernels under torch autograd for the dense part) and fills the gradients of every parameter of the head and of the feature map
-(DESIGN.md 7.1).
+(LOG.md 7.1).
 """
 import copy
 
@@ -325,7 +325,7 @@ class MV2DHead(nn.Module):
     def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_3d, gt_labels_3d, ori_gt_bboxes_3d,
                       ori_gt_labels_3d, attr_labels=None, gt_bboxes_ignore=None, gt_masks=None, dn_noise=None, autograd=None, **kwargs):
         """The reference's signature (RH/mv2d_head.py:196-246, RH/mv2d_s_head.py:235-305) and loss dict (keys ``l{i}.loss_cls`` /
-        ``l{i}.loss_bbox`` / ``l{i}.dn_loss_cls`` / ``l{i}.dn_loss_bbox``, times the stage weights).  Two routes:
+        ``l{i}.loss_bbox`` / ``l{i}.dn_loss_cls`` / ``l{i}.dn_loss_bbox``, times the stage weights).  Two routes (LOG.md 7.1):
         ``autograd=False`` — everything through the fused engine kernels, forward only; ``autograd=True`` (default when gradients are
         enabled) — query generator / PE / key gathering through the engine (no gradient: they are treated as constants), decoder + heads
         through ``train.TrainDecoder`` (torch autograd around the HIP attention forward / backward kernels) and the HIP loss kernel, so

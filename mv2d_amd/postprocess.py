@@ -31,7 +31,7 @@ _NMS_WARNED = [False]
 
 def _warn_unpinned_nms():
     # mmcv 1.6.1's nms_bev is absent from the reference tree: the rotated-IoU suppression is pinned against this repo's oracle only
-    # (DESIGN.md section 7.1 f1).  Every shipped config uses nms_thr = 1.0 and never gets here.
+    # (LOG.md section 7.1 f1).  Every shipped config uses nms_thr = 1.0 and never gets here.
     if not _NMS_WARNED[0]:
         import warnings
         warnings.warn('mv2d_amd: nms_thr < 1 runs mv2d_nms_bev, whose parity with mmcv 1.6.1 nms_bev is not pinned by a reference-side golden '

@@ -579,7 +579,7 @@ def test_engine_ragged_views(kind):
 
 @pytest.mark.parametrize('kind', ['S', 'T'])
 def test_sine_table_with_padded_views_and_mixed_geometry_batches(kind):
-    """adapt_pos3d(sine) is read from a per-(weights, geometry) table.  With a padded view the PE rows still equal the
+    """adapt_pos3d(sine) is read from a per-(weights, geometry) table (LOG.md section 8).  With a padded view the PE rows still equal the
     oracle's (which evaluates the branch per frame like the reference), and a batch whose samples differ in padding geometry (one table row
     per position of the whole batch then) == the two single runs, bitwise."""
     from mv2d_amd import engine as E

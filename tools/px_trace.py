@@ -29,7 +29,7 @@ for _ in range(10):
     ops.pe_fused_x3(A1, X, None, wx, tab, 4096, pe=pe, row_index=ri)
 e1.record()
 torch.cuda.synchronize()
-print(f'pe_x3 {M} rows: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us')
+print(f'pe_x3 {M} rows: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us; output checksum {int(pe.view(torch.int32).to(torch.int64).sum().item())} (equal across bitwise-equal variants)')
 buf = (ctypes.c_longlong * 32)()
 lib = ctypes.CDLL(os.environ['MV2D_HIP_LIB'])
 if hasattr(lib, 'mv2d_px_trace_read'):
