@@ -58,30 +58,6 @@ __host__ __device__ constexpr int ks1_of(int p) { return p == 4 ? 8 : 6; }
 
 struct WBase { const unsigned short* wr[2]; const unsigned short* we[2]; const unsigned short* w1a[2]; const unsigned short* w1b[2]; };   // [hi, lo], + lane * 8 + wave * CT tiles
 
-// MV2D_PX_PIPE (round 5): the hidden-layer epilogue of part p (bias, ReLU, hi / lo split, LDS writes: ~3.5 k of a part's ~18 k cycles with the matrix
-// pipe idle) runs UNDER the layer-1 MFMAs of part p + 1, which only read the input images: two layer-1 accumulator sets, and the 72 k-steps in
-// the order  L1(0) | L1(1) L2(0) | L1(2) L2(1) | L1(3) L2(2) | L2(3) | gate L1 | gate L2.  Same products in the same order per accumulator: bitwise
-// the results of the unpipelined schedule.
-#ifndef MV2D_PX_PIPE
-#define MV2D_PX_PIPE 1
-#endif
-#if MV2D_PX_PIPE
-__host__ __device__ constexpr int sk_kind(int T) { return T < 6 ? 0 : T < 48 ? ((T - 6) % 14 < 6 ? 0 : 1) : T < 56 ? 1 : T < 64 ? 2 : 3; }      // 0 L1, 1 L2, 2 gate L1, 3 gate L2
-__host__ __device__ constexpr int sk_part(int T) { return T < 6 ? 0 : T < 48 ? ((T - 6) % 14 < 6 ? (T - 6) / 14 + 1 : (T - 6) / 14) : T < 56 ? 3 : 4; }
-__host__ __device__ constexpr int sk_k(int T) { return T < 6 ? T : T < 48 ? ((T - 6) % 14 < 6 ? (T - 6) % 14 : (T - 6) % 14 - 6) : (T - 48) % 8; }
-template <int T>
-__device__ __forceinline__ long long step_off() {
-    constexpr int kind = sk_kind(T), p = sk_part(T), k = sk_k(T);
-    if constexpr (kind == 0) return (long long)(k * 64 + p * 16) * 512;                         // W1a [ks][64 tiles], this part's 16 tiles
-    else if constexpr (kind == 1) return (long long)((p * 8 + k) * 16) * 512;                   // W1b [32 k-steps][16 tiles]
-    else return (long long)(k * 16) * 512;                                                      // Wr / We [ks][16 tiles]
-}
-template <int T>
-__device__ __forceinline__ const unsigned short* step_base(const WBase& w, int part) {
-    constexpr int kind = sk_kind(T);
-    return kind == 0 ? w.w1a[part] : kind == 1 ? w.w1b[part] : kind == 2 ? w.wr[part] : w.we[part];
-}
-#else
 template <int T>
 __device__ __forceinline__ long long step_off() {
     constexpr int p = part_of(T), t = T - first_of(p), ks1 = ks1_of(p);
@@ -99,7 +75,6 @@ __device__ __forceinline__ const unsigned short* step_base(const WBase& w, int p
     if constexpr (p == 4) return t < ks1 ? w.wr[part] : w.we[part];
     else return t < ks1 ? w.w1a[part] : w.w1b[part];
 }
-#endif
 
 template <int T>
 __device__ __forceinline__ void ring_load(XFrag (&wq)[RING][CT], const WBase& w) {
@@ -158,61 +133,6 @@ __device__ __forceinline__ void zero_acc(f32x4_t (&acc)[RT][CT]) {
 __device__ __forceinline__ void split4(float a, float b, float c, float d, uint2& hi, uint2& lo) {
     split_q16x2(a, b, hi.x, lo.x);
     split_q16x2(c, d, hi.y, lo.y);
-}
-
-// one unit of a hidden-layer epilogue: column tile j = U / RT, row tile i = U % RT of the layer-1 accumulators -> bias, ReLU, hi / lo split, LDS
-template <int U>
-__device__ __forceinline__ void epi_unit(const f32x4_t (&acc1)[RT][CT], unsigned char* Hh, unsigned char* Hl, const float* bias, int wave, int fr, int fg) {
-    constexpr int j = U / RT, i = U % RT;
-    const int lcol = (wave * CT + j) * 16 + 4 * fg;
-    const float4 bb = *reinterpret_cast<const float4*>(bias + lcol);
-    uint2 hv, lv;
-    split4(relu_f(acc1[i][j][0] + bb.x), relu_f(acc1[i][j][1] + bb.y), relu_f(acc1[i][j][2] + bb.z), relu_f(acc1[i][j][3] + bb.w), hv, lv);
-    const int off = (16 * i + fr) * PITCH + (((lcol >> 3) ^ fr) << 4) + (lcol & 4) * 2;
-    *reinterpret_cast<uint2*>(Hh + off) = hv;
-    *reinterpret_cast<uint2*>(Hl + off) = lv;
-}
-template <int U0, int U1>
-__device__ __forceinline__ void epi_units(const f32x4_t (&acc1)[RT][CT], unsigned char* Hh, unsigned char* Hl, const float* bias, int wave, int fr, int fg) {
-    if constexpr (U0 < U1) {
-        epi_unit<U0>(acc1, Hh, Hl, bias, wave, fr, fg);
-        epi_units<U0 + 1, U1>(acc1, Hh, Hl, bias, wave, fr, fg);
-    }
-}
-
-// N layer-1 k-steps into `acc` with the epilogue of the PREVIOUS part's accumulators `accE` dealt over them: step K carries the units
-// [16 K / N, 16 (K + 1) / N) behind its MFMAs, in the same scheduling region (the VALU / LDS work issues in the shadow of the matrix pipe)
-template <int T0, int N, int K = 0>
-__device__ __forceinline__ void steps_epi(f32x4_t (&acc)[RT][CT], XFrag (&wq)[RING][CT], XFrag (&a)[2][RT], const WBase& w, const unsigned char* Lh,
-                                          const unsigned char* Ll, int fr, int fg, const f32x4_t (&accE)[RT][CT], unsigned char* Hh, unsigned char* Hl,
-                                          const float* bias, int wave) {
-    if constexpr (K < N) {
-        if constexpr (K == 0) load_a(a[0], Lh, Ll, 0, fr, fg);
-        ring_load<T0 + K + RING - 1>(wq, w);
-        if constexpr (K + 1 < N) load_a(a[(K + 1) & 1], Lh, Ll, K + 1, fr, fg);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-#pragma unroll
-                for (int j = 0; j < CT; ++j) {
-                    const XFrag& wf = wq[(T0 + K) % RING][j];
-                    const XFrag& af = a[K & 1][i];
-                    acc[i][j] = mfma_q16_16x16x32(t == 0 ? wf.l : wf.h, t == 1 ? af.l : af.h, acc[i][j]);
-                }
-        epi_units<(RT * CT * K) / N, (RT * CT * (K + 1)) / N>(accE, Hh, Hl, bias, wave, fr, fg);
-#if MV2D_PX_PIPE == 2
-        // explicit pipeline: one MFMA, then up to three VALU instructions, 48 times
-#pragma unroll
-        for (int q = 0; q < 48; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-        }
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        steps_epi<T0, N, K + 1>(acc, wq, a, w, Lh, Ll, fr, fg, accE, Hh, Hl, bias, wave);
-    }
 }
 
 // layer 1 of part P into the hidden images: lane (fr, fg) holds hidden columns lcol..lcol+3 of row 16 i + fr -> bias, ReLU, hi / lo split,
@@ -334,51 +254,6 @@ __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
 
     // ---- 1. P1 in four parts of 256 hidden columns
     zero_acc(accf);
-#if MV2D_PX_PIPE
-    Stage<32> fs;
-    {
-        f32x4_t accA[RT][CT], accB[RT][CT];
-        zero_acc(accA);
-        steps<0, 6>(accA, wq, a, w, Ah, Al, fr, fg);                                                  // L1(0)
-        PX_STAMP(2);
-        zero_acc(accB);
-        steps_epi<6, 6>(accB, wq, a, w, Ah, Al, fr, fg, accA, Hh, Hl, Bs + B_1A, wave);              // L1(1) | epilogue(0)
-        __syncthreads();
-        PX_STAMP(3);
-        steps<12, 8>(accf, wq, a, w, Hh, Hl, fr, fg);                                                 // L2(0)
-        __syncthreads();
-        PX_STAMP(4);
-        zero_acc(accA);
-        steps_epi<20, 6>(accA, wq, a, w, Ah, Al, fr, fg, accB, Hh, Hl, Bs + B_1A + 256, wave);       // L1(2) | epilogue(1)
-        __syncthreads();
-        PX_STAMP(5);
-        steps<26, 8>(accf, wq, a, w, Hh, Hl, fr, fg);                                                 // L2(1)
-        __syncthreads();
-        PX_STAMP(6);
-#if MV2D_PX_TOUCH == 2
-        PX_TOUCH_ISSUE();
-#endif
-        zero_acc(accB);
-        steps_epi<34, 6>(accB, wq, a, w, Ah, Al, fr, fg, accA, Hh, Hl, Bs + B_1A + 512, wave);       // L1(3) | epilogue(2)
-        __syncthreads();                                   // every wave is done with the frustum images
-        PX_STAMP(7);
-        steps<40, 8>(accf, wq, a, w, Hh, Hl, fr, fg);                                                 // L2(2)
-        __syncthreads();
-        PX_STAMP(8);
-        // the feature rows of the tile (gathered through row_index; their lines were touched two parts earlier and sit in L2): requested here, they
-        // arrive under the last epilogue (held across L2(2) their 64 staging registers spilled)
-        fs.load(p.Xmap, C, p.row_index, m0, M, tid);
-#if MV2D_PX_TOUCH
-        asm volatile("" ::"v"(touch0), "v"(touch1));
-#endif
-        epi_units<0, RT * CT>(accB, Hh, Hl, Bs + B_1A + 768, wave, fr, fg);                           // epilogue(3)
-        fs.commit(Ah, Al, tid);
-        __syncthreads();
-        PX_STAMP(9);
-        steps<48, 8>(accf, wq, a, w, Hh, Hl, fr, fg);                                                 // L2(3)
-        PX_STAMP(10);
-    }
-#else
     layer1<0>(wq, a, w, Ah, Al, Hh, Hl, Bs + B_1A, wave, fr, fg);
     PX_STAMP(2);
     steps<first_of(0) + 6, 8>(accf, wq, a, w, Hh, Hl, fr, fg);
@@ -407,7 +282,6 @@ __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
     PX_STAMP(9);
     steps<first_of(3) + 6, 8>(accf, wq, a, w, Hh, Hl, fr, fg);
     PX_STAMP(10);
-#endif
     __syncthreads();                                   // the feature tile is in the A images (and the last layer 2 is done with the hidden tile)
     PX_STAMP(11);
     // ---- 2. the gate

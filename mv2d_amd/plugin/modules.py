@@ -515,20 +515,34 @@ class NMSFreeCoder:
 # box correlation (plain class constructed by kwargs, RH/mv2d_head.py:42)
 # ---------------------------------------------------------------------------------------------------------------
 class BoxCorrelation(nn.Module):
-    """RH/utils/box_correlation.py:11-398 ('topk_matched:k:thr:ratio' mode).  Returns the same tensors as the reference
-    (boolean feature masks for the T path, padded id lists for the S path) built from the device-side match lists."""
+    """RH/utils/box_correlation.py:11-398 ('topk_matched:k:thr:ratio', and 'all_matched' for the T path).  Returns the same tensors as the
+    reference (boolean feature masks for the T path, padded id lists for the S path) built from the device-side match lists.
+    'all_matched' (:305-338; no shipped config): every RoI of a view the epipolar points reach with IoU > 0 -- as a SET that is
+    topk_matched with k = all RoIs of the view, thr = ratio = 0; the T path only reads the union of the listed RoIs' cells, so it runs on the
+    same kernels with k = ALL_MATCHED_CAP (a frame with more RoIs in one view raises).  The S path would need the reference's list layout
+    [R, views x max RoIs per view] as keys: not built (NotImplementedError)."""
+    ALL_MATCHED_CAP = 128
 
     def __init__(self, sample_size=4, num_depth=8, depth_start=0.5, depth_end=70, correlation_mode=None, LID=True, expand_stride=0,
                  force_cpu=False):
         super().__init__()
-        assert LID and correlation_mode is not None and correlation_mode.startswith('topk_matched'), \
-            'kernel path implements the shipped topk_matched modes'
-        info = correlation_mode.split(':')
-        self.topk, self.iou_thr, self.ratio = int(info[1]), float(info[2]), float(info[3])
+        assert LID and correlation_mode is not None and (correlation_mode.startswith('topk_matched') or correlation_mode == 'all_matched'), \
+            "kernel path implements 'topk_matched:k:thr:ratio' and 'all_matched'"
+        self.all_matched = correlation_mode == 'all_matched'
+        if self.all_matched:
+            self.topk, self.iou_thr, self.ratio = self.ALL_MATCHED_CAP, 0.0, 0.0
+        else:
+            info = correlation_mode.split(':')
+            self.topk, self.iou_thr, self.ratio = int(info[1]), float(info[2]), float(info[3])
         self.sample_size, self.num_depth, self.depth_start, self.depth_end = sample_size, num_depth, depth_start, depth_end
         self.correlation_mode, self.expand_stride = correlation_mode, expand_stride
 
+    def check_counts(self, num_proposals_per_img):
+        if self.all_matched and max(num_proposals_per_img) > self.topk:
+            raise ValueError(f"correlation_mode='all_matched': at most {self.topk} RoIs per view (got {max(num_proposals_per_img)})")
+
     def _match(self, rois, num_proposals_per_img, img_metas):
+        self.check_counts(num_proposals_per_img)
         dev = rois.device
         V = len(img_metas)
         R = rois.shape[0]
@@ -547,6 +561,8 @@ class BoxCorrelation(nn.Module):
     def gen_box_roi_correlation(self, rois, num_proposals_per_img, img_metas):
         if rois.numel() == 0:
             return rois.new_zeros((0, 0), dtype=torch.int64), rois.new_zeros((0, 0), dtype=torch.bool)
+        if self.all_matched:
+            raise NotImplementedError("correlation_mode='all_matched' is built for the T path (gen_box_correlation) only")
         R = rois.shape[0]
         m = self._match(rois, num_proposals_per_img, img_metas).view(R, -1).to(torch.int64)
         ids = torch.cat([torch.arange(R, device=rois.device)[:, None], m], 1)

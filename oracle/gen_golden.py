@@ -26,9 +26,11 @@ from oracle import _stubs  # noqa: E402
 OUT = os.path.join(ROOT, 'tests', 'golden')
 
 
-def build_reference_head(kind, S_cls, T_cls, sd_np, num_views, train_cfg=None):
+def build_reference_head(kind, S_cls, T_cls, sd_np, num_views, train_cfg=None, corr_mode=None):
     cfg = configs.roi_head_cfg_s() if kind == 'S' else configs.roi_head_cfg_t()
     cfg.pop('type')
+    if corr_mode is not None:
+        cfg['box_correlation'] = dict(cfg['box_correlation'], correlation_mode=corr_mode)
     cfg['test_cfg'] = configs.TEST_CFG_RCNN
     if train_cfg is not None:
         cfg['train_cfg'] = train_cfg
@@ -142,13 +144,17 @@ def main():
     # per-layer [6,R,10] heads, final boxes (3P-derived arrays are listed in tests/golden/README.md)
     cases = [('micro_t', True), ('micro_s', True), ('cfg1_t', False), ('cfg1_s', False), ('cfg2_s', False), ('cfg3_t', False), ('cfg5_t', False),
              ('nc6_s', False),      # S path with up to 6 correlated RoIs per query (overlapping views, mv2d_amd/synthetic.py RIG)
-             ('cfg2_s_nc6', False)]  # ... and the same rig at the headline size (round 4)
+             ('cfg2_s_nc6', False),  # ... and the same rig at the headline size (round 4)
+             ('cfg1_t_allm', False), ('nc6_t_allm', False)]  # round 5: correlation_mode='all_matched' (box_correlation.py:305-338) on the T head
     only = [a for a in sys.argv[1:] if not a.startswith('-')]
     if only:
         cases = [c for c in cases if c[0] in only]
     for name, full in cases:
-        prob = synthetic.make_problem(name, seed=0)
-        head = build_reference_head(prob['kind'], S_cls, T_cls, sd_np, prob['views_per_frame'])
+        allm = name.endswith('_allm')
+        prob = synthetic.make_problem({'cfg1_t_allm': 'cfg1_t', 'nc6_t_allm': 'nc6_s'}.get(name, name), seed=0)
+        if allm:
+            prob['kind'] = 'T'                                   # (nc6_s: the overlapping rig -- its views share many RoIs -- through the T head)
+        head = build_reference_head(prob['kind'], S_cls, T_cls, sd_np, prob['views_per_frame'], corr_mode='all_matched' if allm else None)
         rec = run_case(head, prob['kind'], prob['feat'], prob['proposals'], prob['img_metas'], full)
         np.savez_compressed(os.path.join(OUT, name + '.npz'), **rec)
         print(name, {k: (v.shape, str(v.dtype)) for k, v in rec.items()})

@@ -238,7 +238,8 @@ def box_iou(a, b, eps=1e-4):
 
 def epipolar_in_box(rois, num_per_view, image_shape, trans, topk, iou_thr=0.0, ratio=0.0,
                     sample_size=4, num_depth=8, depth_start=0.5, depth_end=70):
-    """box_correlation.py:260-382, 'topk_matched:k:thr:ratio' mode.
+    """box_correlation.py:260-382, 'topk_matched:k:thr:ratio' mode; topk=None: 'all_matched' (:305-338: every RoI of a view the epipolar
+    points reach whose IoU with their bounding box is > 0, in the view's RoI order).
 
     Returns ragged python lists: for each RoI r a list of (roi_id, keep) in (view-major, IoU-rank) order —
     exactly the valid prefix the reference builds by pad_sequence/flatten (:376-380).  Ties in the IoU sort
@@ -272,9 +273,14 @@ def epipolar_in_box(rois, num_per_view, image_shape, trans, topk, iou_thr=0.0, r
             pmin = torch.where(m[:, None], p, torch.full_like(p, 1e4)).min(0)[0]
             t_roi = torch.cat([pmin, pmax])[None]                                 # [1,4]
             iou = box_iou(t_roi, rv[:, 1:])[0]                                    # [n_v]
-            order = torch.argsort(iou, descending=True, stable=True)[:topk]
-            top_iou = iou[order]
-            keep = ((top_iou > ratio * top_iou.max()) | (top_iou > iou_thr)) & (top_iou > 0)
+            if topk is None:                                                      # all_matched (:330-331): all_mask = iou > 0, RoI order
+                order = torch.arange(n_v)
+                top_iou = iou
+                keep = iou > 0
+            else:
+                order = torch.argsort(iou, descending=True, stable=True)[:topk]
+                top_iou = iou[order]
+                keep = ((top_iou > ratio * top_iou.max()) | (top_iou > iou_thr)) & (top_iou > 0)
             for j in range(order.numel()):
                 out[r].append((int(order[j]) + int(starts[v]), bool(keep[j])))
     return out

@@ -408,3 +408,43 @@ def test_bench_two_ranks_rccl_when_two_gpus_are_visible():
     assert d['n_gpus'] == 2 and d['value'] > 0
     cc = d['collective_check']
     assert cc['world'] == 2 and cc['backend'] == 'nccl' and cc['gathered_equals_packed'] and cc['gathered_shape'][0] == 2
+
+
+@pytest.mark.parametrize('name,src', [('cfg1_t_allm', 'cfg1_t'), ('nc6_t_allm', 'nc6_s')])
+def test_all_matched_correlation_mode_on_the_t_head(name, src):
+    """`box_correlation=dict(correlation_mode='all_matched')` (RH/utils/box_correlation.py:305-338) at the registry level, T head: simple_test
+    returns the ranked labels / scores of the reference's own all_matched run (tests/golden/<name>.npz), and the engine's key list and CSR are
+    bit for bit the reference's boolean cell masks.  The S head refuses the mode."""
+    import numpy as np
+    import os
+    from conftest import unpack_bits
+    prob = synthetic.make_problem(src, seed=0)
+    cfg = configs.roi_head_cfg_t()
+    cfg['num_views'] = prob['views_per_frame']
+    cfg['box_correlation'] = dict(cfg['box_correlation'], correlation_mode='all_matched')
+    head = mv2d_amd.build_head(cfg, test_cfg=dict(configs.TEST_CFG_RCNN))
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_head_state(seed=0).items()}, strict=True)
+    head = head.to(DEV).eval()
+    metas = [dict(m, box_type_3d=None) for m in prob['img_metas']]
+    feat = torch.from_numpy(prob['feat']).to(DEV)
+    props = [torch.from_numpy(p).to(DEV) for p in prob['proposals']]
+    boxes, scores, labels = head.simple_test([feat], props, metas)[0]
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name + '.npz'))
+    assert labels.cpu().numpy().tolist() == g['labels'].tolist()
+    assert float(np.abs(scores.cpu().numpy() - g['scores']).max()) < 3e-5 * float(g['scores'].max()) + 1e-6
+    eng = head._engine
+    assert eng.topk == 128 and eng.iou_thr == 0.0 and eng.ratio == 0.0
+    out = eng.run(feat, props, metas, keep_stages=True)
+    torch.cuda.synchronize()
+    st, R = out['stages'], out['R']
+    ffr = unpack_bits(g['feat_for_rois'], g['feat_for_rois_shape'])
+    roi_mask = ffr.any(0).reshape(-1)
+    np.testing.assert_array_equal(st['roi_mask'].cpu().numpy().astype(bool), roi_mask)
+    allowed = ffr.reshape(R, -1)[:, roi_mask] & ~g['key_padding'][None]
+    rp, ci = st['row_ptr'].cpu().numpy(), st['col_idx'].cpu().numpy()
+    for r in range(R):
+        np.testing.assert_array_equal(np.sort(ci[rp[r]:rp[r + 1]]), np.nonzero(allowed[r])[0])
+    cfg_s = configs.roi_head_cfg_s()
+    cfg_s['box_correlation'] = dict(cfg_s['box_correlation'], correlation_mode='all_matched')
+    with pytest.raises(NotImplementedError):
+        mv2d_amd.build_head(cfg_s, test_cfg=dict(configs.TEST_CFG_RCNN))

@@ -193,3 +193,23 @@ def test_oracle_logits_on_allowed_pairs(name):
     close(cap[0]['logits'].numpy()[:, rr, kk], ap[f'{name}/logits'], 1e-4)
     for l in range(6):
         close(cap[l]['attn_mean'].numpy()[rr, kk], ap[f'{name}/attn'][l], 1e-4)
+
+
+@pytest.mark.parametrize('name,src', [('cfg1_t_allm', 'cfg1_t'), ('nc6_t_allm', 'nc6_s')])
+def test_all_matched_correlation_mode_matches_reference(name, src):
+    """correlation_mode='all_matched' (RH/utils/box_correlation.py:305-338; no shipped config) through the T head: the goldens come from the
+    reference's own all_matched branch; the oracle's restatement (topk=None) reproduces its boolean cell masks bit for bit and its class
+    logits; topk_matched with k = 1 gives OTHER masks on the overlapping rig (the mode is not vacuous there)."""
+    g = load_golden(name)
+    prob = synthetic.make_problem(src, seed=0)
+    sd = synthetic.make_head_state(seed=0)
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    st = {}
+    O.forward_t(sd, torch.from_numpy(prob['feat']), props, prob['img_metas'], num_views=prob['views_per_frame'], topk=None, stages=st)
+    ffr = unpack_bits(g['feat_for_rois'], g['feat_for_rois_shape'])
+    np.testing.assert_array_equal(st['feat_for_rois'].numpy(), ffr)
+    close(st['cls'].numpy().reshape(g['cls'].shape), g['cls'], 1e-4)
+    if src == 'nc6_s':
+        st1 = {}
+        O.forward_t(sd, torch.from_numpy(prob['feat']), props, prob['img_metas'], num_views=prob['views_per_frame'], topk=1, stages=st1)
+        assert int((st1['feat_for_rois'].numpy() != ffr).sum()) > 0
