@@ -32,16 +32,16 @@ __device__ __forceinline__ void split2(float a, float b, unsigned int& hi, unsig
 // 4 wave .. 4 wave + 3 in phase 2 -- for BOTH row tiles, so every weight fragment is fetched by exactly one wave and used for all 32
 // rows.  (First version: waves = (row tile, column half); each fragment was fetched twice and used for 16 rows, and the kernel sat
 // at the per-CU L1 fill rate: 93 % of a block's time was waiting for weights.)
-#ifndef MV2D_FFN_RTB
-#define MV2D_FFN_RTB 2
-#endif
-constexpr int RTB = MV2D_FFN_RTB, BR = 16 * RTB, NXR = BR / 8;      // row tiles / rows per block, X staging rounds
-
-template <int G>
+// Row tiles per block RTB (round 5): 2 (32 rows) for small launches, 3 (48 rows) for batches -- 4800 rows are 600 blocks of 32 rows = 1.17 rounds of
+// the 512 two-per-CU slots, i.e. two rounds (49.8 us); 400 blocks of 48 rows run in one (42.8 us; 2400 rows: 31.0 -> 27.8; 320 rows: 17.3 -> 22.3, so
+// small launches keep 32).  A row's arithmetic does not depend on RTB (ONE accumulator per output tile, slices and products in a fixed order), so
+// the choice by row count keeps "a sample's result does not depend on its batch" bit for bit.
+template <int G, int RTB>
 __global__ __launch_bounds__(256, 2) void ffn_x3_kernel(const float* __restrict__ X, const unsigned short* __restrict__ W1h,
                                                         const unsigned short* __restrict__ W1l, const float* __restrict__ b1,
                                                         const unsigned short* __restrict__ W2h, const unsigned short* __restrict__ W2l,
                                                         float* __restrict__ slabs, int M, int hidden) {
+    constexpr int BR = 16 * RTB, NXR = BR / 8;           // rows per block, X staging rounds
     constexpr int NHB = G > 1 ? 2 : 1;                   // H buffers (they alternate between the slices of a block)
     __shared__ __attribute__((aligned(16))) unsigned char xh[BR * C * 2], xl[BR * C * 2], hh[NHB][BR * HS * 2], hl[NHB][BR * HS * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
@@ -80,13 +80,9 @@ __global__ __launch_bounds__(256, 2) void ffn_x3_kernel(const float* __restrict_
         *reinterpret_cast<uint4*>(xl + xoff(row, slot)) = l4;
     }
     __syncthreads();
-    // separate accumulators for the hi.hi products and the two correction products, or (MV2D_FFN_MERGE, needed for 4 row tiles per
-    // block to fit the registers) one fp32 accumulator for all three
-#ifdef MV2D_FFN_MERGE
+    // ONE fp32 accumulator per output tile for the hi.hi product and the two correction products (rounds 1-4 kept the corrections apart: 32 more
+    // registers, which 3 row tiles per block do not have; same 6e-7 against fp64 either way)
     constexpr int NACC = 1;
-#else
-    constexpr int NACC = 2;
-#endif
     f32x4_t acc[NACC][RTB][4];
 #pragma unroll
     for (int n = 0; n < NACC; ++n)
@@ -197,11 +193,12 @@ extern "C" int mv2d_ffn_fused_x3(const float* X, const void* W1hi, const void* W
     MV2D_CHECK_ARG((G == 1 || G == 2 || G == 4 || G == 8) && (hidden / HS) % G == 0, "mv2d_ffn_fused_x3: slices_per_block must be 1, 2, 4 or 8 and divide hidden/64");
     if (M == 0) return MV2D_OK;
     const unsigned short *w1h = (const unsigned short*)W1hi, *w1l = (const unsigned short*)W1lo, *w2h = (const unsigned short*)W2hi, *w2l = (const unsigned short*)W2lo;
-    const dim3 grid(hidden / HS / G, cdiv(M, BR));
-    if (G == 1) hipLaunchKernelGGL(ffn_x3_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, X, w1h, w1l, b1, w2h, w2l, slabs, M, hidden);
-    else if (G == 2) hipLaunchKernelGGL(ffn_x3_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, X, w1h, w1l, b1, w2h, w2l, slabs, M, hidden);
-    else if (G == 4) hipLaunchKernelGGL(ffn_x3_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, X, w1h, w1l, b1, w2h, w2l, slabs, M, hidden);
-    else hipLaunchKernelGGL(ffn_x3_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, X, w1h, w1l, b1, w2h, w2l, slabs, M, hidden);
+    const int rtb = M > 1024 ? 3 : 2;
+    const dim3 grid(hidden / HS / G, cdiv(M, 16 * rtb));
+#define MV2D_FFN(G_, R_) hipLaunchKernelGGL((ffn_x3_kernel<G_, R_>), grid, dim3(256), 0, (hipStream_t)stream, X, w1h, w1l, b1, w2h, w2l, slabs, M, hidden)
+    if (rtb == 3) { if (G == 1) MV2D_FFN(1, 3); else if (G == 2) MV2D_FFN(2, 3); else if (G == 4) MV2D_FFN(4, 3); else MV2D_FFN(8, 3); }
+    else { if (G == 1) MV2D_FFN(1, 2); else if (G == 2) MV2D_FFN(2, 2); else if (G == 4) MV2D_FFN(4, 2); else MV2D_FFN(8, 2); }
+#undef MV2D_FFN
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

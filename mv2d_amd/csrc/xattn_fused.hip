@@ -361,6 +361,11 @@ extern "C" int mv2d_xattn_fused_fwd(const float* q, const void* WA_hi, const voi
     if (nblk > n_cu) {                                        // whole rounds of one block per CU, as long as a block keeps >= 4 queries
         const int up = (nblk + n_cu - 1) / n_cu * n_cu;
         if ((long long)up * 4 <= R) nblk = up;
+    } else {
+        // a small launch (one sample: 300 queries = 38 blocks of 8 on a 256-CU chip): spread it, down to two queries per block -- the blocks stream
+        // the map weights from L2 either way, and the launch is bound by the longest block (26.5 -> ~14 us per layer at R = 300)
+        const int spread = R / 2 < n_cu ? R / 2 : n_cu;
+        if (spread > nblk) nblk = spread;
     }
     const dim3 grid(nblk), block(64 * QB);
     if (Xk_lo)
