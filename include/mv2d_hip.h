@@ -417,7 +417,9 @@ int mv2d_mask_compact(const float* rois, const int* match, const unsigned char* 
                       int* nnz_out, int col_cap, int R, int V, int h, int w, int topk, float stride, float expand_stride,
                       int n_samples /* maps of n_samples * V views; V = views per sample */, void* stream);
 
-/* mark + scan only: compact list of the map positions inside any RoI rect expanded by expand_stride cells
+/* (expand_stride < 0, round 5: instead of an expanded rectangle, EXACTLY the cells the bilinear taps of mv2d_roi_align touch for that RoI --
+ * aligned, adaptive sampling grid, spatial_scale = 1 / stride; the S path evaluates the PE block only there)
+ * mark + scan only: compact list of the map positions inside any RoI rect expanded by expand_stride cells
  * (S-path: the positions RoIAlign can touch, so that PE is evaluated only there). */
 int mv2d_roi_positions(const float* rois, const unsigned char* pad_mask, unsigned char* roi_mask, int* rect, int* pos2s,
                        int* s2pos, int* S_out, int R, int V, int h, int w, float stride, float expand_stride, void* stream);

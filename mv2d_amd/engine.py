@@ -547,10 +547,10 @@ class HeadEngine:
                         fmh[:, j - 1] = (ar + 37 * j) % R
                     fm = ws['forced_match'] = fmh.view(R, Vg, self.topk).to(self.dev)
                 ws['match'].copy_(fm)
-            # positions any RoIAlign tap can touch (own rect + 1 cell) -> PE only there; CSR over the correlated RoIs' feature rows; launch order of
+            # positions the RoIAlign taps touch (exact ranges, expand_stride < 0: csrc/geometry.hip roi_tap_range) -> PE only there; CSR over the correlated RoIs' feature rows; launch order of
             # the attention blocks (queries ranked by the smallest RoI they list)
             o.roi_positions_csr(rois, ws['zero_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'], R, V, h, w, ws['match'],
-                                ws['row_ptr'], ws['col_idx'], ws['nnz'], Vg, self.topk, stride=self.stride, expand_stride=1.0, grp_start=grp,
+                                ws['row_ptr'], ws['col_idx'], ws['nnz'], Vg, self.topk, stride=self.stride, expand_stride=-1.0, grp_start=grp,
                                 order=ws.get('q_order') if self.q_order else None, order_flags=ws['qt_ctl'][1:] if self.q_order else None)
         md = ws['S_dev']
         # a2: PE at the listed positions only

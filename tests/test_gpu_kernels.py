@@ -727,6 +727,61 @@ def test_pe_frustum_rows_fast_equals_reference_order(dev, name):
     assert float(fast[S:].abs().max()) == 0.0
 
 
+def test_roi_tap_positions_cover_every_roialign_tap_exactly(dev):
+    """mv2d_roi_positions with expand_stride < 0 (round 5): the marked rectangle of a RoI is exactly the bounding rectangle of the cells its
+    RoIAlign taps touch (same fp32 sample coordinates as roi_align_kernel: aligned, adaptive grid) -- RoIs inside the image, across its
+    borders, entirely outside, tiny and huge; so the S path's PE list holds every tap (RoIAlign(pe) is unchanged) and nothing else."""
+    from mv2d_amd import ops
+    H, W, V = 32, 88, 2
+    g = np.random.Generator(np.random.PCG64(77))
+    n = 400
+    x0 = g.uniform(-60, 1408 + 40, n).astype(np.float32); y0 = g.uniform(-60, 512 + 40, n).astype(np.float32)
+    bw = np.where(g.random(n) < 0.2, g.uniform(0.5, 8, n), g.uniform(8, 400, n)).astype(np.float32)
+    bh = np.where(g.random(n) < 0.2, g.uniform(0.5, 8, n), g.uniform(8, 300, n)).astype(np.float32)
+    rois = np.stack([g.integers(0, V, n).astype(np.float32), x0, y0, x0 + bw, y0 + bh], 1).astype(np.float32)
+    rois[0] = [0, 0, 0, 1408, 512]                                   # the whole image
+    rois[1] = [1, -500, -500, -400, -400]                            # entirely outside: no tap
+    rois[2] = [0, 1400, 500, 1500, 600]                              # across the lower right corner
+    P = V * H * W
+    rt = torch.from_numpy(rois).to(dev)
+    roi_mask = torch.zeros(P, dtype=torch.uint8, device=dev)
+    rect = torch.empty((n, 5), dtype=torch.int32, device=dev)
+    pos2s = torch.empty(P, dtype=torch.int32, device=dev); s2pos = torch.empty(P, dtype=torch.int32, device=dev)
+    S = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.roi_positions(rt, torch.zeros(P, dtype=torch.uint8, device=dev), roi_mask, rect, pos2s, s2pos, S, n, V, H, W, stride=16.0, expand_stride=-1.0)
+    rect = rect.cpu().numpy()
+    f32 = np.float32
+    exp_mask = np.zeros((V, H, W), bool)
+    for r in range(n):
+        v = int(rois[r, 0])
+        cells = []
+        for lo, hi, N in ((rois[r, 1], rois[r, 3], W), (rois[r, 2], rois[r, 4], H)):
+            a, b = f32(lo * f32(0.0625) - f32(0.5)), f32(hi * f32(0.0625) - f32(0.5))
+            ln = f32(b - a); bn = f32(ln / f32(7.0)); gr = int(np.ceil(f32(ln / f32(7.0))))
+            touched = set()
+            for pw in range(7):
+                for ix in range(gr):
+                    xx = f32(f32(a + f32(f32(pw) * bn)) + f32(f32(f32(ix + 0.5) * bn) / f32(gr)))
+                    if xx < -1.0 or xx > N:
+                        continue
+                    x = max(float(xx), 0.0)
+                    xl = int(x)
+                    if xl >= N - 1:
+                        xl = xh = N - 1
+                    else:
+                        xh = xl + 1
+                    touched.update((xl, xh))
+            cells.append(touched)
+        tx, ty = cells
+        if tx and ty:
+            assert (rect[r, 1], rect[r, 2], rect[r, 3], rect[r, 4]) == (min(ty), max(ty), min(tx), max(tx)), (r, rois[r], rect[r])
+            exp_mask[v, min(ty):max(ty) + 1, min(tx):max(tx) + 1] = True
+        else:
+            assert rect[r, 2] < rect[r, 1] or rect[r, 4] < rect[r, 3], (r, rois[r], rect[r])
+    np.testing.assert_array_equal(roi_mask.cpu().numpy().astype(bool).reshape(V, H, W), exp_mask)
+    assert int(S.item()) == int(exp_mask.sum())
+
+
 def test_decode_topk_bit_exact(dev):
     from mv2d_amd import ops
     from oracle import mv2d_oracle as O
