@@ -102,6 +102,13 @@ class HeadEngine:
         # of 8 queries, Qt / z stay on chip; bitwise the three kernels with one wave per query).  None: on the S path when no debug output is asked
         # for; False / True forces it.  In the graph key.
         self.fuse_xattn = None
+        # Layer 0 of the decoder starts from target = 0 (RH/bbox_heads/cross_attention_head.py:32): the VALUE rows of its self attention are
+        # in_proj_v(0) + b_v = b_v for every query, the softmax weights of a row sum to 1, so its context is b_v whatever the queries are
+        # (MU/petr_transformer.py:317-370: value = key before the positional embedding = target).  The engine feeds rows of b_v to the
+        # out-projection kernel instead of launching the in-projection and the attention core of layer 0 (the reference's own sum of
+        # probabilities is 1 +- 1e-7; a NaN query position still poisons the frame one layer later, through its cross attention).  In the
+        # graph key; the training forward (denoising mask) keeps the launches.
+        self.fold_sa0 = True
         # INDEX-EXACT ROUTE = THE DEFAULT since round 5 (exact=None -> True; exact=False / MV2D_EXACT=0 / test_cfg.index_exact=False selects the
         # opt-in "key16" mode with ONE fp16 rounding of the key side: ~1.3 x faster, 4-22 of 300 ranked indices differ from the reference's).
         # Every 16-bit rounding of the key side is replaced by fp32-class arithmetic -- the PE block in one split-precision kernel on unrounded inputs (csrc/pe_x3.hip), the key / value
@@ -338,6 +345,7 @@ class HeadEngine:
         for n in ('x', 'x1', 'x2', 'ctx', 'q'):
             ws[n] = e((R, C))
         ws['zero_rows'] = z((R, C))                              # never written
+        ws['sa0_ctx'] = e((R, C))                                # rows of the layer-0 self-attention value bias (fold_sa0), filled per weights version
         ws['qkv'] = e((R, 3 * C)); ws['parts'] = e((2048 // 64, R, C)); ws['outs'] = e((L, R, C))
         ws['cls'] = e((L, R, 10)); ws['reg'] = e((L, R, 10))
         ws['boxes'] = z((B, self.max_num, 9)); ws['scores'] = z((B, self.max_num))
@@ -670,16 +678,25 @@ class HeadEngine:
         # the decoder starts from target = 0 (cross_attention_head.py:32): layer 0 reads a constant zero buffer and qpos directly, from
         # layer 1 on x / xq are the buffers the fused FFN tail writes
         x_in, xq_in = ws['zero_rows'], ws['qpos']
+        fold0 = self.fold_sa0 and not ws.get('dn') and ws.get('sa0_ctx') is not None
+        if fold0 and ws.get('sa0_ver') != self._weights_version:
+            # (first run on this workspace after the weights changed: the eager warm-up in front of a graph capture comes through here)
+            ws['sa0_ctx'].copy_(W_['sa_in_b0'][2 * C:].expand(ws['sa0_ctx'].shape[0], C))
+            ws['sa0_ver'] = self._weights_version
         for i in range(L):
             if i == 1:
                 x_in = x
-            if i == 0:
-                o.linear_x3(xq_in, W_['sa_in_wx0'], W_['sa_in_b0'], N=3 * C, K=C, A2=x_in, n_split=2 * C, out=ws['qkv'], M=R)
-            if ws.get('dn'):
-                o.self_attn_dn(ws['qkv'], ws['dn'][0], ws['dn'][1], out=ws['ctx'])      # training: denoising rows first (train_forward)
+            sa_ctx = ws['ctx']
+            if i == 0 and fold0:
+                sa_ctx = ws['sa0_ctx']
             else:
-                o.self_attn(ws['qkv'], ws['ctx'], R, grp_start=ws['grp_start'], max_grp_rows=ws.get('max_rows', 0))
-            sa_args = (ws['ctx'], x_in, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'])
+                if i == 0:
+                    o.linear_x3(xq_in, W_['sa_in_wx0'], W_['sa_in_b0'], N=3 * C, K=C, A2=x_in, n_split=2 * C, out=ws['qkv'], M=R)
+                if ws.get('dn'):
+                    o.self_attn_dn(ws['qkv'], ws['dn'][0], ws['dn'][1], out=ws['ctx'])      # training: denoising rows first (train_forward)
+                else:
+                    o.self_attn(ws['qkv'], ws['ctx'], R, grp_start=ws['grp_start'], max_grp_rows=ws.get('max_rows', 0))
+            sa_args = (sa_ctx, x_in, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'])
             q_args = dict(qpos=ws['qpos'], Wq_x3=W_[f'ca_q_wx{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, M=R)
             if xattn_fused:
                 o.attn_out_fused_x3(*sa_args, q_out=ws['q'], **q_args)
@@ -797,7 +814,7 @@ class HeadEngine:
         # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
         gkey = (ptrs, 0 if payload is None else payload.data_ptr(), sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs, self.last_stage_heads,
-                self.xattn_waves, self.fuse_maps, self.fuse_xattn, self.keep_sine_rows, self.force_nc, self.q_order,
+                self.xattn_waves, self.fuse_maps, self.fuse_xattn, self.fold_sa0, self.keep_sine_rows, self.force_nc, self.q_order,
                 self.fork_qg, self.exact_skip)   # load_state() re-allocates the weights; every route option of __init__ is in the key
         graphs = ws.setdefault('graphs', {})             # one graph per (input buffers, frame scalars): a producer that alternates between
         g = graphs.get(gkey)                             # a few static output buffers replays a few graphs, it does not re-capture

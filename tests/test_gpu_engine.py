@@ -452,6 +452,37 @@ def test_engine_stays_finite_when_features_exceed_the_fp16_range():
         assert bool(torch.isfinite(out['stages']['Xk'][:S].float()).all()) and float(out['stages']['Xk'][:S].float().abs().max()) == 65504.0
 
 
+@pytest.mark.parametrize('name', ['cfg1_t', 'cfg1_s'])
+def test_layer0_self_attention_fold(name):
+    """HeadEngine.fold_sa0 (round 5): the decoder starts from target = 0, so the value rows of layer 0's self attention all equal the value
+    bias and its context is that bias for every query -- the engine feeds it to the out-projection directly.  Against the launched in-projection +
+    attention core (whose softmax rows sum to 1 +- 1e-7): class logits within 1e-6 of their scale, identical decoded indices; also as a batch
+    and under hipGraph replay."""
+    from mv2d_amd.engine import HeadEngine
+    dev = torch.device('cuda:0')
+    prob = synthetic.make_problem(name, seed=0)
+    sd = synthetic.make_head_state(seed=0)
+    feat = torch.from_numpy(prob['feat']).to(dev)
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    outs = {}
+    for fold in (True, False):
+        eng = HeadEngine(sd, prob['kind'], dev, num_views=prob['views_per_frame'])
+        eng.fold_sa0 = fold
+        o = eng.run(feat, props, prob['img_metas'])
+        torch.cuda.synchronize()
+        outs[fold] = {k: o[k].clone() for k in ('cls', 'reg', 'bbox_index', 'labels', 'count')}
+        if fold:
+            g = eng.run(feat, props, prob['img_metas'], use_graph=True)
+            torch.cuda.synchronize()
+            assert torch.equal(g['cls'], outs[True]['cls']) and torch.equal(g['bbox_index'], outs[True]['bbox_index'])
+    a, b = outs[True], outs[False]
+    err = float((a['cls'] - b['cls']).abs().max() / b['cls'].abs().max())
+    print(f'[fold_sa0] {name}: cls deviation {err:.1e}')
+    assert err < 1e-6
+    n = int(b['count'].item())
+    assert int(a['count'].item()) == n and torch.equal(a['bbox_index'][:n], b['bbox_index'][:n]) and torch.equal(a['labels'][:n], b['labels'][:n])
+
+
 @pytest.mark.parametrize('name', ['micro_t', 'micro_s'])
 def test_poisoned_feature_cell_stays_visible(name):
     """A NaN in the feature map (bad input frame) must reach the outputs like it does in the reference (torch propagates NaN through conv / linear /
@@ -690,9 +721,17 @@ def test_query_order_of_the_attention_blocks(name, n):
             firsts = [int(ci[rp[r]:rp[r + 1]:49].min()) // 49 for r in perm[a:b]]
         assert firsts == sorted(firsts)
     assert perm[grp[-2]:Rl].tolist() == list(range(grp[-2], Rl))        # bucket-padding rows keep their places
+    # (the S path runs the one-launch cross attention, which keeps Qt on chip: map the last layer's query rows here for the three-kernel form)
+    ops.xattn_qmap(ws['q'], eng.w[f'ca_mapA{eng.L - 1}'], ws['Qt'], R=Rl)
     z_t = ops.xattn_tile(ws['Qt'], ws['xk_rows'], ws['xv_rows'], ws['row_ptr'], ws['col_idx'], R=Rl, empty_nan=False, waves=2)
     z_o = ops.xattn_tile(ws['Qt'], ws['xk_rows'], ws['xv_rows'], ws['row_ptr'], ws['col_idx'], R=Rl, empty_nan=False, waves=2, order=ws['q_order'])
     assert torch.equal(z_o, z_t)
+    if kind == 'S':
+        c_t = ops.xattn_fused(ws['q'], eng.w['ca_mapA0'], eng.w['ca_mapB0'], eng.w['ca_v_b0'], ws['xk_rows'], ws['xv_rows'], ws['row_ptr'], ws['col_idx'], R=Rl,
+                              Xk_lo=ws['xk_lo'], Xv_lo=ws['xv_lo'])
+        c_o = ops.xattn_fused(ws['q'], eng.w['ca_mapA0'], eng.w['ca_mapB0'], eng.w['ca_v_b0'], ws['xk_rows'], ws['xv_rows'], ws['row_ptr'], ws['col_idx'], R=Rl,
+                              Xk_lo=ws['xk_lo'], Xv_lo=ws['xv_lo'], order=ws['q_order'])
+        assert torch.equal(c_o.view(torch.int32), c_t.view(torch.int32))
     eng2 = HeadEngine(sd, kind, dev, num_views=probs[0]['views_per_frame'])
     eng2.q_order = False
     out2 = eng2.run_batch(feats, props, metas) if n > 1 else eng2.run(feats[0], props[0], metas[0])
