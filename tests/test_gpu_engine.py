@@ -693,8 +693,8 @@ def test_last_stage_heads_option(name, kind):
 @pytest.mark.parametrize('name,n', [('micro_t', 1), ('cfg1_t', 3), ('cfg3_t', 2), ('nc6_s', 3), ('cfg1_s', 2)])
 def test_query_order_of_the_attention_blocks(name, n):
     """The launch order of the per-query attention blocks: T path -- mv2d_xattn_query_order ranks the queries of every sample by their smallest
-    key (csrc/xattn_order.hip); S path -- by the smallest RoI they list, own or matched (computed from the correlation lists inside the CSR
-    launch).  The tile kernel launched in that order gives bitwise the rows of the natural order (the order only decides which blocks share an L2)."""
+    key (csrc/xattn_order.hip); S path -- by the smallest RoI they list (own or matched; from the correlation lists, inside the CSR launch), with the
+    rows that list more RoIs first when matched RoIs are rare in the sample.  The tile kernel launched in that order gives bitwise the rows of the natural order (the order only decides which blocks share an L2)."""
     from mv2d_amd import ops
     from mv2d_amd.engine import HeadEngine
     dev = torch.device('cuda:0')
@@ -718,7 +718,11 @@ def test_query_order_of_the_attention_blocks(name, n):
         if kind == 'T':
             firsts = [ci[rp[r]] if rp[r + 1] > rp[r] else 2 ** 31 - 1 for r in perm[a:b]]
         else:
-            firsts = [int(ci[rp[r]:rp[r + 1]:49].min()) // 49 for r in perm[a:b]]
+            # S path (round 5): a sample with fewer than one matched RoI per two queries is ordered (more RoIs listed first, then the smallest
+            # listed RoI), otherwise by the smallest listed RoI alone
+            ncs = [(rp[r + 1] - rp[r]) // 49 for r in range(a, b)]
+            length_major = 2 * (sum(ncs) - (b - a)) < (b - a)
+            firsts = [((-((rp[r + 1] - rp[r]) // 49)) if length_major else 0, int(ci[rp[r]:rp[r + 1]:49].min()) // 49) for r in perm[a:b]]
         assert firsts == sorted(firsts)
     assert perm[grp[-2]:Rl].tolist() == list(range(grp[-2], Rl))        # bucket-padding rows keep their places
     # (the S path runs the one-launch cross attention, which keeps Qt on chip: map the last layer's query rows here for the three-kernel form)
