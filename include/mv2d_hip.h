@@ -243,6 +243,9 @@ int mv2d_f32_to_bf16(const float* x, void* y, long long n, void* stream);
 
 /* NCHW fp32 [V,C,HW] -> position-major [V*HW, C] fp32 (the layout every gather below reads). */
 int mv2d_nchw_to_nhwc(const float* x, float* y, int V, int C, int HW, void* stream);
+/* the same for the listed positions only: mask [V * HW] bytes (1 = some RoI's rectangle holds the position: mv2d_roi_positions* / mv2d_mask_compact's
+ * roi_mask); unlisted rows of y are not written (HW, C multiples of 4; x, y 16-byte aligned) */
+int mv2d_nchw_to_nhwc_masked(const float* x, float* y, const unsigned char* mask, int V, int C, int HW, void* stream);
 
 /* "next" row f2 — the extra FPN level between the 2-D detector and the RoI head (mmdet FPN, start_level = end_level = 2, num_outs = 1:
  * configs/mv2d/exp/*:32-39, mmdet3d_plugin/models/detectors/mv2d.py:122-127): out = conv3x3(conv1x1(x) + b_lat) + b_fpn.

@@ -57,6 +57,7 @@ SIGNATURES = {
     'mv2d_avgpool49': (I, [P, P, I, I, P]),
     'mv2d_f32_to_bf16': (I, [P, P, LL, P]),
     'mv2d_nchw_to_nhwc': (I, [P, P, I, I, I, P]),
+    'mv2d_nchw_to_nhwc_masked': (I, [P, P, P, I, I, I, P]),
     'mv2d_nchw_to_nhwc_bf16': (I, [P, P, I, I, I, P]),
     'mv2d_map_conv3x3': (I, [P, P, P, P, I, I, I, P]),
     'mv2d_self_attn_fwd': (I, [P, P, I, P, I, P]),

@@ -172,6 +172,48 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc64_kernel(const float* __rest
     }
 }
 
+// The same transposition restricted to the positions somebody reads (round 5): mask [V * HW] bytes, 1 = the position is inside some RoI's rectangle
+// (the engine's roi_mask: every RoIAlign tap, every key position and every row the PE block reads lies there).  A 64-position block without a listed
+// position is skipped, a row is only written where the mask is set; the other rows of y keep whatever they held.  37 % (S path) / 50 % (T path) of
+// the rows are listed: the 277 MB written per 16-sample cfg2_s frame become ~100 MB.
+__global__ __launch_bounds__(256) void nchw_to_nhwc64_masked_kernel(const float* __restrict__ x, float* __restrict__ y, const unsigned char* __restrict__ mask,
+                                                                   int V, int Cn, int HW) {
+    __shared__ float tile[64][65];
+    __shared__ unsigned char m[64];
+    __shared__ int any;
+    const int v = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int p = p0 + threadIdx.x;
+        const unsigned char b = p < HW ? mask[(long long)v * HW + p] : 0;
+        m[threadIdx.x] = b;
+        if (b) any = 1;
+    }
+    __syncthreads();
+    if (!any) return;
+    const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float4 in[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 16 * i, p = p0 + tq * 4;
+        in[i] = (c < Cn && p < HW) ? *reinterpret_cast<const float4*>(x + ((long long)v * Cn + c) * HW + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float* t = &tile[ty + 16 * i][tq * 4];
+        t[0] = in[i].x; t[1] = in[i].y; t[2] = in[i].z; t[3] = in[i].w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pl = ty + 16 * i, p = p0 + pl, c = c0 + tq * 4;
+        if (p < HW && c < Cn && m[pl])
+            *reinterpret_cast<float4*>(y + ((long long)v * HW + p) * Cn + c) =
+                make_float4(tile[tq * 4][pl], tile[tq * 4 + 1][pl], tile[tq * 4 + 2][pl], tile[tq * 4 + 3][pl]);
+    }
+}
+
 // cross_attention_head.py:216-238 tail: reg[0:2] = sigmoid(reg[0:2] + isig(ref)[0:2]), reg[4] = sigmoid(reg[4] + isig(ref)[2]),
 // de-normalise to metres with pc_range; RH/mv2d_t_head.py:136-140: reg[8:10] /= dt when dt != 0.  reg [L,R,10] in place.
 __global__ void finalize_reg_kernel(float* reg, const float* __restrict__ ref, int L, int R, float pc0, float pc1, float pc2,
@@ -269,6 +311,16 @@ extern "C" int mv2d_f32_to_key16(const float* x, void* hi, void* lo, long long n
     const long long threads = (n + 1) / 2;
     hipLaunchKernelGGL(f32_to_key16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)hi,
                        (unsigned short*)lo, n);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+extern "C" int mv2d_nchw_to_nhwc_masked(const float* x, float* y, const unsigned char* mask, int V, int Cn, int HW, void* stream) {
+    MV2D_CHECK_ARG(x && y && mask && V > 0 && Cn > 0 && HW > 0, "mv2d_nchw_to_nhwc_masked: bad args");
+    MV2D_CHECK_ARG((HW % 4) == 0 && (Cn % 4) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0,
+                   "mv2d_nchw_to_nhwc_masked: HW and C must be multiples of 4, x and y 16-byte aligned");
+    dim3 grid(cdiv(HW, 64), cdiv(Cn, 64), V);
+    hipLaunchKernelGGL(nchw_to_nhwc64_masked_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, mask, V, Cn, HW);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

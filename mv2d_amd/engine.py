@@ -109,6 +109,8 @@ class HeadEngine:
         # probabilities is 1 +- 1e-7; a NaN query position still poisons the frame one layer later, through its cross attention).  In the
         # graph key; the training forward (denoising mask) keeps the launches.
         self.fold_sa0 = True
+        # transpose only the map rows inside some RoI's rectangle (see _enqueue); in the graph key
+        self.masked_transpose = True
         # INDEX-EXACT ROUTE = THE DEFAULT since round 5 (exact=None -> True; exact=False / MV2D_EXACT=0 / test_cfg.index_exact=False selects the
         # opt-in "key16" mode with ONE fp16 rounding of the key side: ~1.3 x faster, 4-22 of 300 ranked indices differ from the reference's).
         # Every 16-bit rounding of the key side is replaced by fp32-class arithmetic -- the PE block in one split-precision kernel on unrounded inputs (csrc/pe_x3.hip), the key / value
@@ -501,16 +503,24 @@ class HeadEngine:
         tk = self._tick
         tk('h2d')
         rois = ws['rois']                                 # (the RoI list / row tables were uploaded by _run, outside any captured graph)
+        # position-major feature map.  Round 5: only the rows somebody reads are transposed (roi_mask: the RoIAlign taps, the key positions and the
+        # rows the PE block gates all lie inside some RoI's rectangle), so the transposition runs BEHIND the kernels that build the position list;
+        # the whole map is transposed for the training route, for keep_stages runs and when the query-generator chain is forked (key16 mode, T path)
+        forked = self.kind == 'T' and self.prof is None and self.fork_qg and not self.exact
+        masked = (self.masked_transpose and not forked and not self.keep_sine_rows and not getattr(self, '_stage_outputs', False) and
+                  (h * w) % 4 == 0 and not (torch.is_tensor(feat) and feat.is_contiguous(memory_format=torch.channels_last) and not feat.is_contiguous()))
+
+        def transpose(mask):
+            if isinstance(feat, (list, tuple)):
+                fcl, Pg = ws['featcl'], P // B
+                for b_, f in enumerate(feat):
+                    o.nchw_to_nhwc(f, fcl[b_ * Pg:(b_ + 1) * Pg], mask=None if mask is None else mask[b_ * Pg:(b_ + 1) * Pg])
+                return fcl
+            if feat.is_contiguous(memory_format=torch.channels_last) and not feat.is_contiguous():
+                return feat.permute(0, 2, 3, 1).reshape(P, C)                          # already position-major: no copy
+            return o.nchw_to_nhwc(feat, ws['featcl'], mask=mask)
         tk('transpose')
-        # position-major feature map
-        if isinstance(feat, (list, tuple)):
-            featcl, Pg = ws['featcl'], P // B
-            for b, f in enumerate(feat):
-                o.nchw_to_nhwc(f, featcl[b * Pg:(b + 1) * Pg])
-        elif feat.is_contiguous(memory_format=torch.channels_last) and not feat.is_contiguous():
-            featcl = feat.permute(0, 2, 3, 1).reshape(P, C)                         # already position-major: no copy
-        else:
-            featcl = o.nchw_to_nhwc(feat, ws['featcl'])
+        featcl = ws['featcl'] if masked else transpose(None)
         ws['featcl_cur'], ws['map_shape'], ws['max_rows'] = featcl, (V, h, w), sc['max_rows']
         tk('box_params'); tk('box_corr')
         # a3/a5/a7 per-RoI camera + a9 epipolar correlation (both independent of the features) + the clearing of the frame's mask / flag
@@ -521,7 +531,6 @@ class HeadEngine:
         tk('csr')
         # T path: the query-generator chain (RoIAlign -> conv -> fcs -> ref points -> query_pos) only needs the feature map and
         # the per-RoI cameras, the key chain (correlation -> key list -> PE -> K/V) only the boxes: run them on two streams
-        forked = self.kind == 'T' and self.prof is None and self.fork_qg and not self.exact
         if forked:
             main = torch.cuda.current_stream()
             side = ws.get('side_stream')
@@ -538,6 +547,8 @@ class HeadEngine:
                            self.stride, self.expand, col_cap=ws['col_cap'], n_samples=B)
             if self.q_order and ws.get('q_order') is not None:
                 o.xattn_query_order(ws['row_ptr'], ws['col_idx'], grp, R, ws['q_order'], ws['qt_ctl'][1:])
+            if masked:
+                transpose(ws['roi_mask'])
             if not forked:
                 tk('roi_align')
                 o.roi_align(featcl, rois, h, w, out0=ws['roi_feat'],
@@ -560,6 +571,8 @@ class HeadEngine:
             o.roi_positions_csr(rois, ws['zero_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'], R, V, h, w, ws['match'],
                                 ws['row_ptr'], ws['col_idx'], ws['nnz'], Vg, self.topk, stride=self.stride, expand_stride=-1.0, grp_start=grp,
                                 order=ws.get('q_order') if self.q_order else None, order_flags=ws['qt_ctl'][1:] if self.q_order else None)
+            if masked:
+                transpose(ws['roi_mask'])
         md = ws['S_dev']
         # a2: PE at the listed positions only
         if self.exact and 'pe' not in self.exact_skip:
@@ -814,7 +827,7 @@ class HeadEngine:
         # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
         gkey = (ptrs, 0 if payload is None else payload.data_ptr(), sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs, self.last_stage_heads,
-                self.xattn_waves, self.fuse_maps, self.fuse_xattn, self.fold_sa0, self.keep_sine_rows, self.force_nc, self.q_order,
+                self.xattn_waves, self.fuse_maps, self.fuse_xattn, self.fold_sa0, self.masked_transpose, self.keep_sine_rows, self.force_nc, self.q_order,
                 self.fork_qg, self.exact_skip)   # load_state() re-allocates the weights; every route option of __init__ is in the key
         graphs = ws.setdefault('graphs', {})             # one graph per (input buffers, frame scalars): a producer that alternates between
         g = graphs.get(gkey)                             # a few static output buffers replays a few graphs, it does not re-capture

@@ -461,13 +461,18 @@ def map_conv3x3(x_cl, Wp, bias, V, h, w, out=None):
     return out
 
 
-def nchw_to_nhwc(x, out=None):
-    """[V,C,h,w] fp32 -> position-major [V*h*w, C] fp32."""
-    _req(x, torch.float32, 'x')
+def nchw_to_nhwc(x, out=None, mask=None):
+    """[V,C,h,w] fp32 -> position-major [V*h*w, C] fp32.  mask (uint8 [V*h*w], device; needs `out`): only the rows whose byte is set are written."""
+    _req(x, torch.float32, 'x'); _req(mask, torch.uint8, 'mask')
     V, Cn, h, w = x.shape
     if out is None:
+        if mask is not None:
+            raise _lib.Mv2dHipError('nchw_to_nhwc: the masked form writes into a caller-owned buffer')
         out = torch.empty((V * h * w, Cn), device=x.device, dtype=torch.float32)
-    check(_lib.load().mv2d_nchw_to_nhwc(_p(x), _p(out), V, Cn, h * w, _stream()), 'mv2d_nchw_to_nhwc')
+    if mask is not None:
+        check(_lib.load().mv2d_nchw_to_nhwc_masked(_p(x), _p(out), _p(mask), V, Cn, h * w, _stream()), 'mv2d_nchw_to_nhwc_masked')
+    else:
+        check(_lib.load().mv2d_nchw_to_nhwc(_p(x), _p(out), V, Cn, h * w, _stream()), 'mv2d_nchw_to_nhwc')
     return out
 
 
