@@ -163,7 +163,7 @@ def main():
     ap.add_argument('--cpu-iters', type=int, default=24)       # ~10 s of CPU work on the bounded sample
     ap.add_argument('--cpu-threads', type=int, default=16)      # second CPU leg; the first uses os.cpu_count() threads (BASELINE.md protocol)
     ap.add_argument('--cpu-timeout', type=int, default=150)
-    ap.add_argument('--cpu-all-budget', type=int, default=40, help='seconds of the bounded all-cores CPU leg (BASELINE.md protocol: os.cpu_count() threads, 3 warm-ups)')
+    ap.add_argument('--cpu-all-budget', type=int, default=15, help='seconds of the bounded all-cores CPU leg (BASELINE.md protocol: os.cpu_count() threads, 3 warm-ups)')
     ap.add_argument('--key16', action='store_true', help='run the timed loop in the OPT-IN key16 mode (HeadEngine(exact=False): one fp16 rounding of the key side, '
                                                         'ranked indices differ from the reference) instead of the index-exact route, which is the default since round 5')
     ap.add_argument('--exact', action='store_true', help='(round-4 flag; the index-exact route is the default now -- accepted and ignored)')

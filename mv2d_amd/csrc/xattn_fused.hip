@@ -94,18 +94,24 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
         const uint4* wh = WA_hi + (long long)h * 16 * 64 + lane;
         const uint4* wl = WA_lo + (long long)h * 16 * 64 + lane;
         uint4* qt = reinterpret_cast<uint4*>(smem + (n & 7) * WAVE_LDS) + h * 64;      // this lane's query, this head: 64 chunks of 16 B
+        // ALL 32 weight fragments of the head are requested before the first MFMA (128 registers, free in this phase): the first build left the
+        // loads next to their MFMAs and the ISA showed 24 serialised L2 round trips per block and phase (tools/isa_waits.sh)
+        xf_u32x4 wa_h[16], wa_l[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            wa_h[t] = *reinterpret_cast<const xf_u32x4*>(wh + t * 64);
+            wa_l[t] = *reinterpret_cast<const xf_u32x4*>(wl + t * 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             f32x4_t a[2];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                XfFrag ah, al;
-                ah.u = wh[(2 * u + k) * 64];
-                al.u = wl[(2 * u + k) * 64];
                 f32x4_t c = {0.f, 0.f, 0.f, 0.f};
-                c = mfma_q16_16x16x32(al.v, bh.v, c);
-                c = mfma_q16_16x16x32(ah.v, bl.v, c);
-                c = mfma_q16_16x16x32(ah.v, bh.v, c);
+                c = mfma_q16_16x16x32(wa_l[2 * u + k], bh.v, c);
+                c = mfma_q16_16x16x32(wa_h[2 * u + k], bl.v, c);
+                c = mfma_q16_16x16x32(wa_h[2 * u + k], bh.v, c);
                 a[k] = c;
             }
             XfFrag hi, lo;
@@ -301,6 +307,21 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
         const uint4* wh = WB_hi + (long long)h * 16 * 64 + lane;
         const uint4* wl = WB_lo + (long long)h * 16 * 64 + lane;
         f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        xf_u32x4 wb_h[16], wb_l[16];                          // (all fragments of the head first, like phase A; and what the epilogue reads)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            wb_h[t] = *reinterpret_cast<const xf_u32x4*>(wh + t * 64);
+            wb_l[t] = *reinterpret_cast<const xf_u32x4*>(wl + t * 64);
+        }
+        int rr_[4], rp0_[4], rp1_[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rr_[i] = rq[(4 * g + i) & 7];
+            rp0_[i] = row_ptr[rr_[i]];
+            rp1_[i] = row_ptr[rr_[i] + 1];
+        }
+        const float bv0 = bv[32 * h + n], bv1 = bv[32 * h + 16 + n];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             float4 x0 = *reinterpret_cast<const float4*>(zp + 32 * s);
@@ -311,12 +332,9 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
             xf_split8(x0, x1, ah, al);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                XfFrag bh, bl;
-                bh.u = wh[(s * 2 + nt) * 64];
-                bl.u = wl[(s * 2 + nt) * 64];
-                acc[nt] = mfma_q16_16x16x32(al.v, bh.v, acc[nt]);
-                acc[nt] = mfma_q16_16x16x32(ah.v, bl.v, acc[nt]);
-                acc[nt] = mfma_q16_16x16x32(ah.v, bh.v, acc[nt]);
+                acc[nt] = mfma_q16_16x16x32(al.v, wb_h[s * 2 + nt], acc[nt]);
+                acc[nt] = mfma_q16_16x16x32(ah.v, wb_l[s * 2 + nt], acc[nt]);
+                acc[nt] = mfma_q16_16x16x32(ah.v, wb_h[s * 2 + nt], acc[nt]);
             }
         }
         if (g < 2) {
@@ -324,12 +342,12 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
             for (int i = 0; i < 4; ++i) {
                 const int js = 4 * g + i;
                 if (js < nq) {
-                    const int rr = rq[js];
-                    const bool empty = row_ptr[rr + 1] <= row_ptr[rr];
+                    const int rr = rr_[i];
+                    const bool empty = rp1_[i] <= rp0_[i];
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
                         const int col = 32 * h + 16 * nt + n;
-                        float v = acc[nt][i] + bv[col];
+                        float v = acc[nt][i] + (nt ? bv1 : bv0);
                         if (empty) v = empty_nan ? __uint_as_float(0x7fc00000u) : 0.f;
                         ctx[(long long)rr * C + col] = v;
                     }
