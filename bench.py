@@ -4,6 +4,10 @@
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...            # no launcher: re-executes itself under torch.distributed.run, one rank per GPU
+
+The timed loop runs the engine's route: INDEX-EXACT (fp16 hi + lo pairs on both sides; `route` in the line); `--key16` times the opt-in mode with one
+fp16 rounding of the key side instead, and the default line carries that mode as a labelled extra leg.
 
 One "step" = one pass of the whole hot path (PE -> RoI gather -> query generator -> box correlation -> key list/CSR
 -> 6-layer decoder with the tile cross attention -> heads -> top-k decode, + the all-gather of decoded boxes when N > 1) over

@@ -27,8 +27,9 @@ const char* mv2d_last_error(void);
 int mv2d_abi_version(void);
 /* The 16-bit storage / MFMA operand format of the KEY SIDE ("key16": gathered key / value rows, RoI cells, PE-MLP operands + hidden layer and
  * the weights those kernels read; csrc/common.h): 1 = IEEE fp16 (round 4: 11 significand bits, conversions saturate at +-65504), 0 = bf16 (a
- * -DMV2D_KEY16_BF16 build).  Every `void*` below that is documented as key16 holds that format; the query side (bf16x3 split precision on fp32
- * operands) and the generic tile GEMM mv2d_gemm_bf16 are bf16 in either build. */
+ * -DMV2D_KEY16_BF16 build).  Every `void*` below that is documented as key16 holds that format; the split-precision kernels ("bf16x3" / "x3" in the comments
+ * below, written in rounds 1-4) carry their operands in the q16 format -- IEEE fp16 pairs since round 5, see mv2d_q16_format(); the generic tile GEMM
+ * mv2d_gemm_bf16 and the training route's mv2d_gemm_f32x3 are bf16 in either build. */
 int mv2d_key16_format(void);
 /* fp32 -> key16: hi [n] = key16(x) and, when lo != NULL, lo [n] = key16(x - hi) (x ~ hi + lo: static weights of the key-side kernels) */
 int mv2d_f32_to_key16(const float* x, void* hi, void* lo, long long n, void* stream);

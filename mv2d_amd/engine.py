@@ -1,7 +1,7 @@
 """Fused MI355X inference engine for the MV2D RoI head hot path.
 
-One ``HeadEngine`` owns the packed weights (key16 = fp16 fragment-major copies for the key-side MFMA kernels, bf16 hi / lo pairs for the
-split-precision query-side kernels), a shape-keyed workspace (every buffer pre-allocated, kernels never allocate) and enqueues the whole
+One ``HeadEngine`` owns the packed weights (fp16 hi / lo pairs, fragment-major, for the split-precision kernels of the key and the query side;
+single fp16 copies for the query generator's conv), a shape-keyed workspace (every buffer pre-allocated, kernels never allocate) and enqueues the whole
 frame on the current HIP stream through the C-ABI (mv2d_amd.ops) without a single device->host synchronisation:
 
   T path (MV2DTHead, RH/mv2d_t_head.py:26-142)        S path (MV2DSHead eval branch, RH/mv2d_s_head.py:122-211)
@@ -11,8 +11,9 @@ frame on the current HIP stream through the C-ABI (mv2d_amd.ops) without a singl
   PE only at the S key positions -> key rows (feat + pe) / value rows (feat), key16, shared by all layers and heads
   6 x [self-attn, LN, cross-attn in the raw key space (K / V in_proj folded into the query side), LN, FFN, LN] -> heads -> top-k decode
 
-The reference evaluates PE on the whole map and runs dense [8,R,S] attention with a boolean mask; the outputs
-are identical up to the fp16 rounding of the key side; ``exact=True`` carries the key side as hi + lo pairs.
+The reference evaluates PE on the whole map and runs dense [8,R,S] attention with a boolean mask.  The engine's route is the INDEX-EXACT one
+(round 5: the default): every operand an fp16 hi + lo pair, three MFMAs per product -- the ranked box indices equal the reference's (DESIGN.md
+section 2).  ``exact=False`` selects the opt-in key16 mode (one fp16 rounding of the key side: faster, a few ranked indices move).
 """
 import math
 import os
