@@ -149,8 +149,8 @@ def test_engine_other_seeds(name, seed):
     (check_t_path if prob['kind'] == 'T' else check_s_path)(name, prob, state_seed=seed)
 
 
-@pytest.mark.parametrize('seed', [1, 2, 3])
-@pytest.mark.parametrize('name', ['cfg1_t', 'cfg1_s', 'nc6_s'])
+@pytest.mark.parametrize('name,seed', [('cfg1_t', 1), ('cfg1_t', 2), ('cfg1_t', 3), ('cfg1_s', 1), ('cfg1_s', 2), ('cfg1_s', 3), ('nc6_s', 1), ('nc6_s', 2),
+                                       ('nc6_s', 3), ('cfg2_s', 2), ('cfg2_s', 3), ('cfg3_t', 2)])      # the last three: FULL size, other weights + inputs
 def test_index_exact_route_other_seeds(name, seed):
     """HeadEngine(exact=True) on other random draws: the ranked (query, class) list of the decode equals the oracle's (fp32 restatement of the
     reference) up to fp32-rounding ties, scores at fp32 rounding level."""
@@ -176,12 +176,14 @@ def test_index_exact_route_other_seeds(name, seed):
     moved = int((got != ref).sum())
     err = float((out['scores'][:n].cpu() - st['scores']).abs().max())
     print(f'[index parity, exact route vs oracle] {name} seed {seed}: {moved}/{n} ranked (query, class) indices differ, max score err {err:.1e}')
-    assert err < 3e-5
-    assert moved <= 8                       # (pairs of scores closer than fp32 rounding of either pipeline may swap: every moved entry is checked to be one)
+    assert err < 3e-6                       # round 5 (fp16 pairs on the query side): measured <= 4e-7
+    # the oracle is an fp32 pipeline of its own: like the reference against itself (tests/golden/refnoise.npz: 0-4 ranks across gaps <= 4.1e-8) it may
+    # order exact score ties differently; every moved entry must sit on such a tie
+    assert moved <= 4
     sc = st['scores'].numpy()
     for i in np.nonzero(got != ref)[0]:
         j = int(np.nonzero(ref == got[i])[0][0]) if (ref == got[i]).any() else None
-        assert j is not None and abs(float(sc[i]) - float(sc[j])) < 1e-5
+        assert j is not None and abs(float(sc[i]) - float(sc[j])) < 2e-7
 
 
 def test_engine_two_frame_velocity_and_empty():
