@@ -542,6 +542,60 @@ long long mv2d_linear_bwd_x3_ws_bytes(int M, int N, int K);
 int mv2d_linear_bwd_x3(const float* x, const float* W, const float* y, const float* dy, float* dx, float* dW, float* db, int M, int N, int K, void* ws,
                        long long ws_bytes, void* stream);
 
+/* mv2d_gemm_f32x3 with C = act((op(A) op(B)^T + bias) * alpha); accumulate: C += (fp32 C; with split-K the slabs are summed onto C);
+ * out_bf16: C is a bf16 [M, ldc] image (one pass; the keys / values the sparse attention kernels read).
+ * mv2d_colsum_add: out[c] = add[c] + sum_r x[r, c] (add NULL: the plain sum; add == out accumulates). */
+int mv2d_gemm_f32x3_ex(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act, float alpha,
+                       int accumulate, int out_bf16, void* C, long long ldc, int M, int N, int K, void* ws, long long ws_bytes, void* stream);
+int mv2d_colsum_add(const float* x, long long ld, int rows, int cols, float* out, float* scratch, const float* add, void* stream);
+/* dW [N,K] = g^T x and db [N] = column sums of g (g [M,N], x [M,K] dense rows) -- db inside the product's kernel when it runs in one pass, a
+ * separate column sum after a split-K product (cs_scratch: [mv2d_colsum_scratch_rows(M), N] floats or NULL). */
+int mv2d_wgrad_f32x3(const float* g, const float* x, float* dW, float* db, int M, int N, int K, void* ws, long long ws_bytes, float* cs_scratch,
+                     void* stream);
+
+/* The decoder of the training route as ONE call per direction (replaces the per-operator autograd graph over PETRTransformerDecoder,
+ * MU/petr_transformer.py:195-311,404-418,501-508,563-590: six post-norm layers self_attn - norm - cross_attn - norm - ffn - norm, the shared
+ * post_norm on every intermediate output; mmcv residual / dropout rules).  The launch sequence is issued from C: the dx chain on `stream`, the
+ * parameter-gradient products and the key side of the cross attention on internal side streams that are joined before the call returns
+ * (device-side; the call itself never blocks).
+ * params / grads: 18 L + 2 device pointers -- per layer: self-attention in_proj weight [768,256] / bias, out_proj weight / bias, norm-0 weight /
+ * bias; the same six for the cross attention and norm 1; FFN linear-1 weight [F,256] / bias, linear-2 weight [256,F] / bias, norm 2; then
+ * post_norm weight / bias.  Gradients are written (not accumulated).
+ * qpos [T,256]; key_in / val_in [S,256] fp32; (row_ptr, col) CSR patterns of the self / cross attention, (key_ptr, pair_idx, pair_row) their
+ * transposes; outs / d_outs [L,T,256].  Dropout (probabilities in dims, 0 = eval): counter-hash masks of (seed, layer, site, element),
+ * regenerated by the backward.  act (mv2d_train_decoder_act_bytes) carries the activations from the forward to the backward;
+ * ws: mv2d_train_decoder_ws_bytes(dims, backward) bytes of scratch; both 256-byte aligned. */
+typedef struct mv2d_td_dims {
+    int T, S, L, F;
+    int sa_nnz, ca_nnz;
+    float p_sa_attn, p_sa_out, p_ca_attn, p_ca_out, p_ffn_act, p_ffn_out;
+    unsigned int seed;
+    float eps;
+} mv2d_td_dims;
+long long mv2d_train_decoder_act_bytes(const mv2d_td_dims* d);
+long long mv2d_train_decoder_ws_bytes(const mv2d_td_dims* d, int backward);
+int mv2d_train_decoder_fwd(const mv2d_td_dims* d, const float* const* params, const float* qpos, const float* key_in, const float* val_in,
+                           const int* sa_row_ptr, const int* sa_col, const int* ca_row_ptr, const int* ca_col, float* outs, void* act, void* ws,
+                           void* stream);
+int mv2d_train_decoder_bwd(const mv2d_td_dims* d, const float* const* params, float* const* grads, const float* qpos, const float* key_in,
+                           const float* val_in, const int* sa_row_ptr, const int* sa_col, const int* sa_key_ptr, const int* sa_pair_idx,
+                           const int* sa_pair_row, const int* ca_row_ptr, const int* ca_col, const int* ca_key_ptr, const int* ca_pair_idx,
+                           const int* ca_pair_row, const float* d_outs, const void* act, void* ws, float* d_qpos, float* d_key_in, float* d_val_in,
+                           void* stream);
+
+/* The classification / regression branches of all L intermediate outputs in one call per direction (RH/bbox_heads/cross_attention_head.py:118-142,
+ * 200-218): cls_l = Linear(ReLU(LN(Linear(ReLU(LN(Linear(out_l))))))), reg_l = Linear(ReLU(Linear(ReLU(Linear(out_l))))) (the raw box code).
+ * params / grads: 16 L device pointers -- per layer cls_branches.{0,1,3,4,6}.{weight,bias}, reg_branches.{0,2,4}.{weight,bias}.
+ * outs / d_outs [L,T,256]; cls / d_cls [L,T,NC]; reg / d_reg [L,T,10].  Layers run side by side on the caller's stream and the internal side
+ * streams (joined before the call returns, device-side).  act / ws as for mv2d_train_decoder_*. */
+typedef struct mv2d_th_dims { int T, L, NC; float eps; } mv2d_th_dims;
+long long mv2d_train_heads_act_bytes(const mv2d_th_dims* d);
+long long mv2d_train_heads_ws_bytes(const mv2d_th_dims* d, int backward);
+int mv2d_train_heads_fwd(const mv2d_th_dims* d, const float* const* params, const float* outs, float* cls, float* reg, void* act, void* ws,
+                         void* stream);
+int mv2d_train_heads_bwd(const mv2d_th_dims* d, const float* const* params, float* const* grads, const float* outs, const float* d_cls,
+                         const float* d_reg, const void* act, void* ws, float* d_outs, void* stream);
+
 /* Backward of mv2d_roi_align w.r.t. one map (training; mmcv's roi_align backward): grad_out [R][49][256] fp32 ->
  * grad_map [rows][256] fp32, ACCUMULATED with hardware fp32 atomics (the caller zeroes it; the summation order varies between runs).
  * index (may be null): position -> row of a compacted map, negative = no row (as map1_index of the forward). */

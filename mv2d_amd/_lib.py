@@ -17,6 +17,17 @@ class Mv2dHipError(RuntimeError):
 P, I, LL, F, D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
 ABI_VERSION = 4                  # include/mv2d_hip.h: mv2d_abi_version()
 
+class TdDims(C.Structure):
+    """struct mv2d_td_dims (include/mv2d_hip.h): the scalar arguments of mv2d_train_decoder_fwd / _bwd"""
+    _fields_ = [('T', I), ('S', I), ('L', I), ('F', I), ('sa_nnz', I), ('ca_nnz', I), ('p_sa_attn', F), ('p_sa_out', F), ('p_ca_attn', F),
+                ('p_ca_out', F), ('p_ffn_act', F), ('p_ffn_out', F), ('seed', C.c_uint), ('eps', F)]
+
+
+class ThDims(C.Structure):
+    """struct mv2d_th_dims (include/mv2d_hip.h): the scalar arguments of mv2d_train_heads_fwd / _bwd"""
+    _fields_ = [('T', I), ('L', I), ('NC', I), ('eps', F)]
+
+
 # name -> (restype, argtypes) — mirrors include/mv2d_hip.h one to one
 SIGNATURES = {
     'mv2d_last_error': (C.c_char_p, []),
@@ -99,6 +110,17 @@ SIGNATURES = {
     'mv2d_colsum': (I, [P, LL, I, I, P, P, P]),
     'mv2d_gemm_f32x3_ws_bytes': (LL, [I, I, I]),
     'mv2d_gemm_f32x3': (I, [P, LL, I, P, LL, I, P, I, P, LL, I, I, I, P, LL, P]),
+    'mv2d_gemm_f32x3_ex': (I, [P, LL, I, P, LL, I, P, I, F, I, I, P, LL, I, I, I, P, LL, P]),
+    'mv2d_colsum_add': (I, [P, LL, I, I, P, P, P, P]),
+    'mv2d_wgrad_f32x3': (I, [P, P, P, P, I, I, I, P, LL, P, P]),
+    'mv2d_train_decoder_act_bytes': (LL, [P]),
+    'mv2d_train_decoder_ws_bytes': (LL, [P, I]),
+    'mv2d_train_decoder_fwd': (I, [P] * 13),
+    'mv2d_train_decoder_bwd': (I, [P] * 23),
+    'mv2d_train_heads_act_bytes': (LL, [P]),
+    'mv2d_train_heads_ws_bytes': (LL, [P, I]),
+    'mv2d_train_heads_fwd': (I, [P] * 8),
+    'mv2d_train_heads_bwd': (I, [P] * 10),
     'mv2d_linear_bwd_x3_ws_bytes': (LL, [I, I, I]),
     'mv2d_linear_bwd_x3': (I, [P, P, P, P, P, P, P, I, I, I, P, LL, P]),
     'mv2d_layer_norm_bwd_blocks': (I, [I]),

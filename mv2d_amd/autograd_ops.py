@@ -228,3 +228,118 @@ class MatmulNTFn(torch.autograd.Function):
 
 def matmul_nt_ad(A, B):
     return MatmulNTFn.apply(A, B)
+
+
+DECODER_PARAMS = ('attentions.0.attn.in_proj_weight', 'attentions.0.attn.in_proj_bias', 'attentions.0.attn.out_proj.weight',
+                  'attentions.0.attn.out_proj.bias', 'norms.0.weight', 'norms.0.bias',
+                  'attentions.1.attn.in_proj_weight', 'attentions.1.attn.in_proj_bias', 'attentions.1.attn.out_proj.weight',
+                  'attentions.1.attn.out_proj.bias', 'norms.1.weight', 'norms.1.bias',
+                  'ffns.0.layers.0.0.weight', 'ffns.0.layers.0.0.bias', 'ffns.0.layers.1.weight', 'ffns.0.layers.1.bias',
+                  'norms.2.weight', 'norms.2.bias')        # the per-layer order of mv2d_train_decoder_fwd's pointer table (include/mv2d_hip.h)
+
+
+class DecoderFn(torch.autograd.Function):
+    """The six decoder layers + the shared post_norm (PETRTransformerDecoder, MU/petr_transformer.py:195-311,563-590) as ONE autograd node:
+    forward ``mv2d_train_decoder_fwd``, backward ``mv2d_train_decoder_bwd`` (csrc/train_decoder.hip) -- the launch sequence of either
+    direction is issued from C, the parameter-gradient products and the key side of the cross attention on side streams.
+    ``meta``: dict(sa=(row_ptr, col), sa_t=csr_transpose(...), ca=..., ca_t=..., drops=(p_sa_attn, p_sa_out, p_ca_attn, p_ca_out, p_ffn_act,
+    p_ffn_out), seed=int, L=layers); params: 18 L + 2 fp32 tensors in ``DECODER_PARAMS`` order per layer, then post_norm weight / bias.
+    Returns the intermediate outputs [L,T,256]."""
+
+    @staticmethod
+    def forward(ctx, qpos, key_in, val_in, meta, *params):
+        lib = _lib.load()
+        L = meta['L']
+        assert len(params) == 18 * L + 2
+        for t in (qpos, key_in, val_in) + params:
+            assert t.is_cuda and t.dtype == F32 and t.is_contiguous(), 'DecoderFn: fp32 contiguous device tensors'
+        T, S, Fw = qpos.shape[0], key_in.shape[0], params[12].shape[0]
+        dr = meta['drops']
+        dims = _lib.TdDims(T, S, L, Fw, meta['sa'][1].numel(), meta['ca'][1].numel(), dr[0], dr[1], dr[2], dr[3], dr[4], dr[5],
+                           int(meta['seed']) & 0xffffffff, 1e-5)
+        dev = qpos.device
+        act = torch.empty(int(lib.mv2d_train_decoder_act_bytes(_lib.C.byref(dims))), device=dev, dtype=torch.uint8)
+        ws = torch.empty(int(lib.mv2d_train_decoder_ws_bytes(_lib.C.byref(dims), 0)), device=dev, dtype=torch.uint8)
+        outs = torch.empty((L, T, 256), device=dev, dtype=F32)
+        ptrs = (_lib.C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        check(lib.mv2d_train_decoder_fwd(_lib.C.addressof(dims), _lib.C.addressof(ptrs), _p(qpos), _p(key_in), _p(val_in), _p(meta['sa'][0]),
+                                         _p(meta['sa'][1]), _p(meta['ca'][0]), _p(meta['ca'][1]), _p(outs), _p(act), _p(ws), _stream()),
+              'mv2d_train_decoder_fwd')
+        ctx.save_for_backward(qpos, key_in, val_in, *params)
+        ctx.keep = (dims, ptrs, act, meta)
+        return outs
+
+    @staticmethod
+    def backward(ctx, d_outs):
+        lib = _lib.load()
+        qpos, key_in, val_in = ctx.saved_tensors[:3]
+        params = ctx.saved_tensors[3:]
+        dims, ptrs, act, meta = ctx.keep
+        dev = qpos.device
+        d_outs = d_outs if (d_outs.dtype == F32 and d_outs.is_contiguous()) else d_outs.float().contiguous()
+        grads, gptr = _flat_grads(params, dev)
+        ws = torch.empty(int(lib.mv2d_train_decoder_ws_bytes(_lib.C.byref(dims), 1)), device=dev, dtype=torch.uint8)
+        d_qpos, d_key, d_val = torch.empty_like(qpos), torch.empty_like(key_in), torch.empty_like(val_in)
+        sa, sa_t, ca, ca_t = meta['sa'], meta['sa_t'], meta['ca'], meta['ca_t']
+        check(lib.mv2d_train_decoder_bwd(_lib.C.addressof(dims), _lib.C.addressof(ptrs), _lib.C.addressof(gptr), _p(qpos), _p(key_in), _p(val_in),
+                                         _p(sa[0]), _p(sa[1]), _p(sa_t[0]), _p(sa_t[1]), _p(sa_t[2]), _p(ca[0]), _p(ca[1]), _p(ca_t[0]), _p(ca_t[1]),
+                                         _p(ca_t[2]), _p(d_outs), _p(act), _p(ws), _p(d_qpos), _p(d_key), _p(d_val), _stream()),
+              'mv2d_train_decoder_bwd')
+        return (d_qpos, d_key, d_val, None) + tuple(grads)
+
+
+BRANCH_PARAMS = ('cls_branches.{l}.0.weight', 'cls_branches.{l}.0.bias', 'cls_branches.{l}.1.weight', 'cls_branches.{l}.1.bias',
+                 'cls_branches.{l}.3.weight', 'cls_branches.{l}.3.bias', 'cls_branches.{l}.4.weight', 'cls_branches.{l}.4.bias',
+                 'cls_branches.{l}.6.weight', 'cls_branches.{l}.6.bias', 'reg_branches.{l}.0.weight', 'reg_branches.{l}.0.bias',
+                 'reg_branches.{l}.2.weight', 'reg_branches.{l}.2.bias', 'reg_branches.{l}.4.weight', 'reg_branches.{l}.4.bias')
+
+
+def _flat_grads(params, dev):
+    """one flat fp32 buffer + the views the C entries write the parameter gradients into (64-float aligned pieces)"""
+    offs, n = [], 0
+    for p in params:
+        offs.append(n)
+        n += (p.numel() + 63) & ~63
+    flat = torch.empty(n, device=dev, dtype=F32)
+    return [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)], (_lib.C.c_void_p * len(params))(*[flat.data_ptr() + 4 * o for o in offs])
+
+
+class HeadsFn(torch.autograd.Function):
+    """The class / regression branches of all intermediate outputs (cross_attention_head.py:118-142,200-218) as ONE autograd node:
+    ``mv2d_train_heads_fwd`` / ``mv2d_train_heads_bwd`` (csrc/train_decoder.hip).  outs [L,T,256]; params: 16 L fp32 tensors in
+    ``BRANCH_PARAMS`` order per layer.  Returns (cls [L,T,NC], raw box code [L,T,10])."""
+
+    @staticmethod
+    def forward(ctx, outs, *params):
+        lib = _lib.load()
+        L, T = outs.shape[:2]
+        assert len(params) == 16 * L
+        for t in (outs,) + params:
+            assert t.is_cuda and t.dtype == F32 and t.is_contiguous(), 'HeadsFn: fp32 contiguous device tensors'
+        NC = params[8].shape[0]
+        dims = _lib.ThDims(T, L, NC, 1e-5)
+        dev = outs.device
+        act = torch.empty(int(lib.mv2d_train_heads_act_bytes(_lib.C.byref(dims))), device=dev, dtype=torch.uint8)
+        ws = torch.empty(int(lib.mv2d_train_heads_ws_bytes(_lib.C.byref(dims), 0)), device=dev, dtype=torch.uint8)
+        cls, reg = torch.empty((L, T, NC), device=dev, dtype=F32), torch.empty((L, T, 10), device=dev, dtype=F32)
+        ptrs = (_lib.C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        check(lib.mv2d_train_heads_fwd(_lib.C.addressof(dims), _lib.C.addressof(ptrs), _p(outs), _p(cls), _p(reg), _p(act), _p(ws), _stream()),
+              'mv2d_train_heads_fwd')
+        ctx.save_for_backward(outs, *params)
+        ctx.keep = (dims, ptrs, act)
+        return cls, reg
+
+    @staticmethod
+    def backward(ctx, d_cls, d_reg):
+        lib = _lib.load()
+        outs, params = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        dims, ptrs, act = ctx.keep
+        dev = outs.device
+        d_cls = d_cls if (d_cls.dtype == F32 and d_cls.is_contiguous()) else d_cls.float().contiguous()
+        d_reg = d_reg if (d_reg.dtype == F32 and d_reg.is_contiguous()) else d_reg.float().contiguous()
+        grads, gptr = _flat_grads(params, dev)
+        ws = torch.empty(int(lib.mv2d_train_heads_ws_bytes(_lib.C.byref(dims), 1)), device=dev, dtype=torch.uint8)
+        d_outs = torch.empty_like(outs)
+        check(lib.mv2d_train_heads_bwd(_lib.C.addressof(dims), _lib.C.addressof(ptrs), _lib.C.addressof(gptr), _p(outs), _p(d_cls), _p(d_reg), _p(act),
+                                       _p(ws), _p(d_outs), _stream()), 'mv2d_train_heads_bwd')
+        return (d_outs,) + tuple(grads)

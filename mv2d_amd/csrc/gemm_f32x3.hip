@@ -36,6 +36,10 @@ struct FxParams {
     float* C; long long ldc;
     int M, N, K, act;
     int k_tiles_per_split; long long c_split_stride;
+    float alpha;                // C = act((sum + bias) * alpha)
+    int accumulate;             // C += ... (one-pass products only; the split-K slabs are summed onto C by the caller's column sum)
+    int out_bf16;               // C holds bf16 (the keys / values the sparse attention kernels read)
+    float* rowsum;              // trans_a products in one pass: rowsum[m] = sum_k opA[m, k] (the bias gradient next to dW = g^T x), or NULL
 };
 
 // byte offset of k-group `kq` (4 consecutive k = 8 bytes) of row `row` in an image; 16-byte slots XOR-swizzled so that both the
@@ -50,6 +54,8 @@ __device__ __forceinline__ void fx_split4(const float4& v, uint2& hi, uint2& lo)
     lo.x = pack_bf16x2(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xffff0000u));
     lo.y = pack_bf16x2(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xffff0000u));
 }
+
+__device__ __forceinline__ float4 fx_add4(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 // 4 consecutive floats from p (element index e of a row of `limit` valid elements), zero beyond; vec: the row base and stride keep 16-byte alignment
 __device__ __forceinline__ float4 fx_load4(const float* __restrict__ row, int e, int limit, bool vec) {
@@ -132,11 +138,14 @@ __global__ __launch_bounds__(256) void gemm_f32x3_kernel(FxParams p) {
 
     FxTile<TA> ta;
     FxTile<TB> tb;
+    const bool want_rs = TA && p.rowsum != nullptr && n0 == 0;
+    float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
     if (kt0 < kt1) {
         ta.load(p.A, p.lda, m0, p.M, kt0 * BK, p.K, vecA, tid);
         tb.load(p.B, p.ldb, n0, p.N, kt0 * BK, p.K, vecB, tid);
         ta.store(Ah, Al, tid);
         tb.store(Bh, Bl, tid);
+        if (TA && want_rs) rs = fx_add4(rs, fx_add4(fx_add4(ta.v[0], ta.v[1]), fx_add4(ta.v[2], ta.v[3])));
     }
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
@@ -172,7 +181,21 @@ __global__ __launch_bounds__(256) void gemm_f32x3_kernel(FxParams p) {
         if (kt + 1 < kt1) {
             ta.store(Ah, Al, tid);
             tb.store(Bh, Bl, tid);
+            if (TA && want_rs) rs = fx_add4(rs, fx_add4(fx_add4(ta.v[0], ta.v[1]), fx_add4(ta.v[2], ta.v[3])));
             __syncthreads();
+        }
+    }
+    if (TA && want_rs) {
+        // thread (kg, rg) holds the sums over its k of rows 4 rg .. 4 rg + 3: reduce over the 16 kg in fixed order through LDS
+        float* red = reinterpret_cast<float*>(smem);                // (every wave is past the last MFMA stage: the images are free)
+        const int kg = tid >> 4, rg = tid & 15;
+        *reinterpret_cast<float4*>(red + kg * 64 + 4 * rg) = rs;
+        __syncthreads();
+        if (tid < 64 && m0 + tid < p.M) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) t += red[g * 64 + tid];
+            p.rowsum[m0 + tid] = t;
         }
     }
     // epilogue: the MFMA leaves C[row 4 fg + r][col fr] of every 16 x 16 tile in lane (fr, fg): 16 consecutive columns per store instruction
@@ -188,8 +211,10 @@ __global__ __launch_bounds__(256) void gemm_f32x3_kernel(FxParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wr * 32 + i * 16 + 4 * fg + r;
                 if (m < p.M) {
-                    float v = acc[i][j][r] + bv;
+                    float v = (acc[i][j][r] + bv) * p.alpha;
                     if (p.act == 1) v = relu_f(v);
+                    if (p.out_bf16) { reinterpret_cast<unsigned short*>(Cb)[(long long)m * p.ldc + n] = f32_to_bf16(v); continue; }
+                    if (p.accumulate) v += Cb[(long long)m * p.ldc + n];
                     Cb[(long long)m * p.ldc + n] = v;
                 }
             }
@@ -200,6 +225,7 @@ __global__ __launch_bounds__(256) void gemm_f32x3_kernel(FxParams p) {
 
 extern "C" int mv2d_colsum_scratch_rows(int rows);
 extern "C" int mv2d_colsum(const float* x, long long ld, int rows, int cols, float* out, float* scratch, void* stream);
+extern "C" int mv2d_colsum_add(const float* x, long long ld, int rows, int cols, float* out, float* scratch, const float* add, void* stream);
 
 static int fx_splits(int M, int N, int K, int act) {
     // few output tiles with a long contraction (weight gradients: K = the rows of the layer input): split K over blockIdx.y
@@ -222,20 +248,55 @@ extern "C" long long mv2d_gemm_f32x3_ws_bytes(int M, int N, int K) {
 // C [M, ldc] fp32 = act(op(A) op(B)^T + bias): see the file header.  A [M,K] (trans_a: [K,M]), B [N,K] (trans_b: [K,N]), unit column strides,
 // row strides lda / ldb (any; 16-byte aligned rows take the float4 path); bias [N] or NULL; act 0 none / 1 ReLU.  ws: workspace of
 // mv2d_gemm_f32x3_ws_bytes(M, N, K) bytes, 256-byte aligned; without it (or with ldc != N) a long contraction runs in one pass instead of split-K.
+extern "C" int mv2d_gemm_f32x3_ex(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act,
+                                  float alpha, int accumulate, int out_bf16, void* C, long long ldc, int M, int N, int K, void* ws,
+                                  long long ws_bytes, void* stream);
+static int gemm_f32x3_impl(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act,
+                           float alpha, int accumulate, int out_bf16, void* Cv, long long ldc, int M, int N, int K, void* ws, long long ws_bytes,
+                           float* rowsum, void* stream);
+
 extern "C" int mv2d_gemm_f32x3(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act,
                                float* C, long long ldc, int M, int N, int K, void* ws, long long ws_bytes, void* stream) {
+    return mv2d_gemm_f32x3_ex(A, lda, trans_a, B, ldb, trans_b, bias, act, 1.f, 0, 0, C, ldc, M, N, K, ws, ws_bytes, stream);
+}
+
+// The same product with C = act((op(A) op(B)^T + bias) * alpha); accumulate: C += (fp32 C); out_bf16: C is bf16 [M, ldc] (one pass, no accumulate).
+extern "C" int mv2d_gemm_f32x3_ex(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act,
+                                  float alpha, int accumulate, int out_bf16, void* Cv, long long ldc, int M, int N, int K, void* ws,
+                                  long long ws_bytes, void* stream) {
+    return gemm_f32x3_impl(A, lda, trans_a, B, ldb, trans_b, bias, act, alpha, accumulate, out_bf16, Cv, ldc, M, N, K, ws, ws_bytes, nullptr, stream);
+}
+
+// Weight + bias gradient of a linear layer in one call: dW [N,K] = g^T x (g [M,N], x [M,K] dense rows) and db [N] = column sums of g -- inside the
+// product's kernel when it runs in one pass (rows of op(A) = g^T summed by the blocks of the first column tile, fixed order), as a
+// separate mv2d_colsum after a split-K product (many rows).  cs_scratch: [mv2d_colsum_scratch_rows(M), N] floats or NULL.
+extern "C" int mv2d_wgrad_f32x3(const float* g, const float* x, float* dW, float* db, int M, int N, int K, void* ws, long long ws_bytes,
+                                float* cs_scratch, void* stream) {
+    MV2D_CHECK_ARG(g && x && dW && M >= 0 && N > 0 && K > 0, "mv2d_wgrad_f32x3: bad args");
+    if (M == 0) return MV2D_OK;
+    const bool one_pass = fx_splits(N, K, M, 0) <= 1 || !ws || ws_bytes < mv2d_gemm_f32x3_ws_bytes(N, K, M) || ((uintptr_t)ws & 255) != 0;
+    const int rc = gemm_f32x3_impl(g, N, 1, x, K, 1, nullptr, 0, 1.f, 0, 0, dW, K, N, K, M, ws, ws_bytes, (db && one_pass) ? db : nullptr, stream);
+    if (rc != MV2D_OK || !db || one_pass) return rc;
+    return mv2d_colsum_add(g, N, M, N, db, mv2d_colsum_scratch_rows(M) ? cs_scratch : nullptr, nullptr, stream);
+}
+
+static int gemm_f32x3_impl(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act,
+                           float alpha, int accumulate, int out_bf16, void* Cv, long long ldc, int M, int N, int K, void* ws, long long ws_bytes,
+                           float* rowsum, void* stream) {
+    float* C = (float*)Cv;
+    MV2D_CHECK_ARG(!(out_bf16 && accumulate), "mv2d_gemm_f32x3_ex: accumulate needs an fp32 C");
     MV2D_CHECK_ARG(A && B && C && M >= 0 && N > 0 && K > 0 && (act == 0 || act == 1) && ldc >= N, "mv2d_gemm_f32x3: bad args");
     if (M == 0) return MV2D_OK;
-    int splits = fx_splits(M, N, K, act);
+    int splits = out_bf16 ? 1 : fx_splits(M, N, K, act);
     if (splits > 1 && (ldc != N || !ws || ws_bytes < mv2d_gemm_f32x3_ws_bytes(M, N, K) || ((uintptr_t)ws & 255) != 0)) splits = 1;   // no slabs: one pass
     FxParams p;
-    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.bias = bias; p.M = M; p.N = N; p.K = K; p.act = act;
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.bias = bias; p.M = M; p.N = N; p.K = K; p.act = act; p.alpha = alpha; p.out_bf16 = out_bf16; p.rowsum = rowsum;
     const int nk = cdiv(K, BK);
     p.k_tiles_per_split = cdiv(nk, splits);
     splits = cdiv(nk, p.k_tiles_per_split);                 // (no empty split)
     float* slabs = (float*)ws;
-    if (splits > 1) { p.C = slabs; p.ldc = N; p.c_split_stride = (long long)M * N; }
-    else { p.C = C; p.ldc = ldc; p.c_split_stride = 0; }
+    if (splits > 1) { p.C = slabs; p.ldc = N; p.c_split_stride = (long long)M * N; p.accumulate = 0; }
+    else { p.C = C; p.ldc = ldc; p.c_split_stride = 0; p.accumulate = accumulate; }
     const dim3 grid(cdiv(M, BM) * cdiv(N, BN), splits);
     hipStream_t st = (hipStream_t)stream;
     if (trans_a && trans_b) hipLaunchKernelGGL((gemm_f32x3_kernel<true, true>), grid, dim3(256), 0, st, p);
@@ -245,7 +306,7 @@ extern "C" int mv2d_gemm_f32x3(const float* A, long long lda, int trans_a, const
     MV2D_LAUNCH_CHECK();
     if (splits > 1) {
         float* scratch = slabs + (long long)splits * M * N;
-        return mv2d_colsum(slabs, (long long)M * N, splits, M * N, C, mv2d_colsum_scratch_rows(splits) ? scratch : nullptr, stream);
+        return mv2d_colsum_add(slabs, (long long)M * N, splits, M * N, C, mv2d_colsum_scratch_rows(splits) ? scratch : nullptr, accumulate ? C : nullptr, stream);
     }
     return MV2D_OK;
 }

@@ -76,6 +76,7 @@ class HeadEngine:
         # adapt_pos3d(sine) (MU/pe.py:164-166) depends only on the weights and on the padding geometry of the rig, not on features, boxes
         # or calibration: it is constant-folded into a per-(weights version, geometry) table that the fused PE kernel adds in its epilogue
         self._weights_version = 0     # bumped by every load_state(): invalidates whatever was folded from the weights
+        self.stop_before_decoder = False   # the autograd training route only needs geometry, RoI features, PE inputs and reference points of a run
         self.keep_sine_rows = False   # the training route reads the per-key sine rows (ws['A2']) although the inference kernel does not
         self.force_nc = None          # bench only (S path): overwrite the correlation lists so that every query reads n_c RoIs
         # tests only (eager runs): keep the pre-softmax per-head logits of every layer's cross attention (out['stages']['dbg_logits']
@@ -600,6 +601,9 @@ class HeadEngine:
             self._enqueue_qg(ws, R)
         if forked:
             torch.cuda.current_stream().wait_stream(side)
+        if self.stop_before_decoder:
+            tk('end')
+            return
         # a16-a19: decoder
         tk('decoder')
         self._enqueue_decoder(ws, R)
@@ -829,7 +833,7 @@ class HeadEngine:
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
         gkey = (ptrs, 0 if payload is None else payload.data_ptr(), sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs, self.last_stage_heads,
                 self.xattn_waves, self.fuse_maps, self.fuse_xattn, self.fold_sa0, self.masked_transpose, self.keep_sine_rows, self.force_nc, self.q_order,
-                self.fork_qg, self.exact_skip)   # load_state() re-allocates the weights; every route option of __init__ is in the key
+                self.fork_qg, self.exact_skip, self.stop_before_decoder)   # load_state() re-allocates the weights; every route option of __init__ is in the key
         graphs = ws.setdefault('graphs', {})             # one graph per (input buffers, frame scalars): a producer that alternates between
         g = graphs.get(gkey)                             # a few static output buffers replays a few graphs, it does not re-capture
         if ws.pop('graph_stale', False):

@@ -344,7 +344,11 @@ class MV2DHead(nn.Module):
             autograd = torch.is_grad_enabled() and any(p.requires_grad for p in self.bbox_head.parameters())
         eng = self.engine(dev, img_metas, allow_stale=bool(autograd))
         eng.keep_sine_rows = bool(autograd)                 # the autograd route evaluates the sine branch of the PE block itself
-        out = eng.run(feat.detach().float(), [p[:, :6] for p in proposal_list], img_metas)
+        eng.stop_before_decoder = bool(autograd)            # ... and runs its own decoder: the engine stops after the query generator
+        try:
+            out = eng.run(feat.detach().float(), [p[:, :6] for p in proposal_list], img_metas)
+        finally:
+            eng.stop_before_decoder = False
         g = ori_gt_bboxes_3d[0]
         gt = g if torch.is_tensor(g) else torch.cat((g.gravity_center, g.tensor[:, 3:]), dim=1)
         gt = gt.to(dev, torch.float32).contiguous()

@@ -238,6 +238,8 @@ class TrainDecoder:
         self.roi_head = roi_head
         self.layers = getattr(getattr(bh.transformer, 'decoder', None), 'layers', None)
         self._warned = False
+        import os
+        self.fused = os.environ.get('MV2D_TRAIN_FUSED', '1') != '0'      # the C-issued decoder (round 5); '0': the per-operator autograd graph
 
     def _drops(self, i, j):
         """(attention-probability p, output-path callable) of attention j of layer i; identity / 0 in eval mode or without a module tree"""
@@ -313,14 +315,17 @@ class TrainDecoder:
                       P['bbox_head.query_embedding.2.weight'], P['bbox_head.query_embedding.2.bias'])
         key_in, val_in = key_in.float(), val_in.float()
         S = key_in.shape[0]
-        sa = self.self_attention_pattern(T, pad, single, dev)
-        sa_t = ops.csr_transpose(sa[0], sa[1], T)
+        sa, sa_t = self._sa_pattern(T, pad, single, dev)
         ca = (row_ptr.contiguous(), col_idx.contiguous())
         ca_t = ops.csr_transpose(ca[0], ca[1], S)
-        x = torch.zeros(T, qpos.shape[1], device=dev)
-        outs = []
         ln = lambda t, n: layer_norm(t, P[n + '.weight'], P[n + '.bias'])  # noqa: E731      (mv2d_row_ln / mv2d_layer_norm_bwd)
         training = self.layers is not None and self.roi_head.training
+        if self.fused and dn_keys is None:
+            # (round 5) the six layers + post_norm as one autograd node, launch sequences issued from C (csrc/train_decoder.hip)
+            outs = self._fused_layers(qpos, key_in, val_in, sa, sa_t, ca, ca_t, training)
+            return self._branches(outs, ref, pad, dt)
+        x = torch.zeros(T, qpos.shape[1], device=dev)
+        outs = []
         for i in range(self.L):
             lp = f'{pre}layers.{i}.'
             p_sa, drop_sa = self._drops(i, 0)
@@ -341,9 +346,48 @@ class TrainDecoder:
                 y = dl(y) if dl is not None else y
             x = ln(x + y, lp + 'norms.2')
             outs.append(ln(x, pre + 'post_norm'))
+        return self._branches(outs, ref, pad, dt)
+
+    def _sa_pattern(self, T, pad, single, dev):
+        """the self-attention pattern and its transpose: a function of (T, pad, single) only, kept between steps"""
+        key = (T, pad, single, str(dev))
+        if getattr(self, '_sa_key', None) != key:
+            sa = self.self_attention_pattern(T, pad, single, dev)
+            self._sa_key, self._sa = key, (sa, ops.csr_transpose(sa[0], sa[1], T))
+        return self._sa
+
+    def _fused_layers(self, qpos, key_in, val_in, sa, sa_t, ca, ca_t, training):
+        from .autograd_ops import DECODER_PARAMS, DecoderFn
+        P, pre = self.p, 'bbox_head.transformer.decoder.'
+        params = [P[f'{pre}layers.{i}.{n}'] for i in range(self.L) for n in DECODER_PARAMS] + [P[pre + 'post_norm.weight'], P[pre + 'post_norm.bias']]
+        drops = (0.0,) * 6
+        if training:
+            lay = self.layers[0]                      # (the shipped configs build every layer from one dict)
+            comb = lambda *ps: 1.0 - math.prod(1.0 - float(p) for p in ps)  # noqa: E731   two dropouts in a row = one with the product of the keep rates
+            pdrop = lambda m: float(getattr(m, 'p', 0.0) or 0.0)  # noqa: E731
+
+            def att(a):
+                return float(getattr(a.attn, 'dropout', 0.0) or 0.0), comb(pdrop(getattr(a, 'proj_drop', None)), pdrop(getattr(a, 'dropout_layer', None)))
+            ffn = lay.ffns[0]
+            drops = att(lay.attentions[0]) + att(lay.attentions[1]) + (pdrop(ffn.layers[0][2]), comb(pdrop(ffn.layers[2]), pdrop(getattr(ffn, 'dropout_layer', None))))
+        meta = dict(L=self.L, sa=sa, sa_t=sa_t, ca=ca, ca_t=ca_t, drops=drops, seed=self._next_seed(1.0 if any(drops) else 0.0))
+        return DecoderFn.apply(qpos.contiguous(), key_in.contiguous(), val_in.contiguous(), meta, *[p if p.is_contiguous() else p.contiguous() for p in params])
+
+    def _branches(self, outs, ref, pad, dt):
+        """classification / regression branches and the box code of every intermediate output (cross_attention_head.py:200-242)"""
+        import torch.nn.functional as F
+        from .autograd_ops import layer_norm, linear
+        P, dev = self.p, ref.device
+        ln = lambda t, n: layer_norm(t, P[n + '.weight'], P[n + '.bias'])  # noqa: E731
         r = ref.clamp(0, 1)
         inv = torch.log(r.clamp(min=1e-5) / (1 - r).clamp(min=1e-5))                 # inverse_sigmoid, mmdet
         lo, hi = self.pc_range[:3], self.pc_range[3:]
+        if torch.is_tensor(outs):
+            # (round 5) all branches of all layers as one autograd node, the layers side by side on streams (mv2d_train_heads_fwd / _bwd)
+            from .autograd_ops import BRANCH_PARAMS, HeadsFn
+            bp = [P['bbox_head.' + n.format(l=l)] for l in range(self.L) for n in BRANCH_PARAMS]
+            all_cls_t, t = HeadsFn.apply(outs, *[p if p.is_contiguous() else p.contiguous() for p in bp])
+            return all_cls_t, self._box_code(t, inv, lo, hi, pad, dt, dev)
         all_cls, ts = [], []
         for l in range(self.L):
             c, g = f'bbox_head.cls_branches.{l}.', f'bbox_head.reg_branches.{l}.'
@@ -352,19 +396,20 @@ class TrainDecoder:
             all_cls.append(linear(y, P[c + '6.weight'], P[c + '6.bias']))
             t = linear(outs[l], P[g + '0.weight'], P[g + '0.bias'], 1)
             ts.append(linear(linear(t, P[g + '2.weight'], P[g + '2.bias'], 1), P[g + '4.weight'], P[g + '4.bias']))
-        # box code of all layers at once (cross_attention_head.py:219-233; element-wise the same expressions as per layer)
-        t = torch.stack(ts)                                                              # [L,T,10]
+        return torch.stack(all_cls), self._box_code(torch.stack(ts), inv, lo, hi, pad, dt, dev)
+
+    def _box_code(self, t, inv, lo, hi, pad, dt, dev):
+        """raw code [L,T,10] -> boxes (cross_attention_head.py:219-233; element-wise the same expressions as per layer)"""
         if getattr(self, '_range_dev', None) != dev:                                    # (constants: uploaded once)
             self._range_dev = dev
             self._span = torch.tensor([hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]], device=dev)
             self._low = torch.tensor(lo, device=dev)
         span, low = self._span, self._low
-        cxyz = (t[..., [0, 1, 4]] + inv).sigmoid() * span + low
+        cxyz = (torch.cat([t[..., 0:2], t[..., 4:5]], -1) + inv).sigmoid() * span + low     # (an index LIST would be uploaded per call: a blocking copy)
         vel = t[..., 8:10]
         if dt:
             vel = torch.cat([vel[:, :pad], vel[:, pad:] / dt], 1)
-        all_reg = torch.cat([cxyz[..., 0:2], t[..., 2:4], cxyz[..., 2:3], t[..., 5:8], vel], -1)
-        return torch.stack(all_cls), all_reg
+        return torch.cat([cxyz[..., 0:2], t[..., 2:4], cxyz[..., 2:3], t[..., 5:8], vel], -1)
 
 
 def allreduce_gradients(parameters, bucket_bytes=256 << 20, average=True, group=None):

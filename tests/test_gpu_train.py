@@ -692,3 +692,115 @@ def test_sparse_attention_probability_dropout_forward_backward(p_drop):
     assert all(v < 5e-5 for v in errs.values()), errs
     out0 = ops.SparseCrossAttention.apply(q.detach(), K.detach(), V.detach(), row_ptr, col, False, None, 0.0, seed)
     assert torch.equal(out0, ops.sparse_xattn(q.detach(), K.detach().to(torch.bfloat16), V.detach().to(torch.bfloat16), row_ptr, col, empty_nan=False))
+
+
+# ---- round 5: decoder + branches issued from C (csrc/train_decoder.hip: mv2d_train_decoder_* / mv2d_train_heads_*) -------------------------
+def _captured_decoder_call(prob_name, kind, train_mode=False):
+    """A head on a synthetic problem and the arguments its ``TrainDecoder`` received in one forward_train (no denoising queries)."""
+    from mv2d_amd import registry, train
+    import mv2d_amd.plugin  # noqa: F401
+    prob = synthetic.make_problem(prob_name, seed=0)
+    cfg = configs.roi_head_cfg_s() if kind == 'S' else configs.roi_head_cfg_t()
+    if kind == 'T':
+        cfg['num_views'] = prob['views_per_frame']
+    head = registry.build_head(cfg, train_cfg=configs.TRAIN_CFG_RCNN, test_cfg=configs.TEST_CFG_RCNN)
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_head_state(seed=0).items()}, strict=False)
+    head = head.to(DEV)
+    head.train(train_mode)
+    gtc = synthetic.make_train_gt(9, 5)
+    feat = torch.from_numpy(prob['feat']).to(DEV)
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    metas = [dict(m, box_type_3d=None) for m in prob['img_metas']]
+    got, orig = {}, train.TrainDecoder.__call__
+
+    def rec(self, *a, **k):
+        got['a'], got['k'] = a, k
+        return orig(self, *a, **k)
+    train.TrainDecoder.__call__ = rec
+    try:
+        head.forward_train([feat], metas, props, None, None, None, None, [torch.from_numpy(gtc['gt'])], [torch.from_numpy(gtc['gt_labels'])], None,
+                           autograd=True)
+    finally:
+        train.TrainDecoder.__call__ = orig
+    return head, got['a'], got['k']
+
+
+def _decoder_outputs_and_grads(head, a, k, fused, g=None):
+    dec = head._train_decoder
+    dec.fused = fused
+    for p in head.parameters():
+        p.grad = None
+    ref, key_in, val_in = (t.detach().clone().requires_grad_(True) for t in a[:3])
+    all_cls, all_reg = dec(ref, key_in, val_in, *a[3:], **k)
+    if g is None:
+        gen = torch.Generator(device='cpu').manual_seed(3)
+        g = (torch.randn(all_cls.shape, generator=gen).to(DEV), torch.randn(all_reg.shape, generator=gen).to(DEV))
+    f = (all_cls * g[0]).sum() + (all_reg * g[1]).sum()
+    f.backward()
+    grads = {n: p.grad.clone() for n, p in head.named_parameters() if p.grad is not None}
+    grads.update(ref=ref.grad, key_in=key_in.grad, val_in=val_in.grad)
+    return all_cls.detach(), all_reg.detach(), grads, g, float(f.detach())
+
+
+@pytest.mark.parametrize('prob_name,kind', [('cfg1_s', 'S'), ('cfg1_t', 'T'), ('nc6_s', 'S')])
+def test_decoder_issued_from_c_equals_the_operator_graph(prob_name, kind):
+    """mv2d_train_decoder_fwd/_bwd + mv2d_train_heads_fwd/_bwd (one autograd node each, launch sequences issued from C, weight-gradient
+    products and the key side on side streams) against the per-operator autograd graph of rounds 3-4 on the same inputs and the same
+    upstream gradient, dropout off: the same outputs (bitwise) and the same gradient for every parameter, the key / value rows and the
+    reference points."""
+    head, a, k = _captured_decoder_call(prob_name, kind)
+    cls0, reg0, g0, g, _ = _decoder_outputs_and_grads(head, a, k, False)
+    cls1, reg1, g1, _, _ = _decoder_outputs_and_grads(head, a, k, True, g)
+    cls2, reg2, g2, _, _ = _decoder_outputs_and_grads(head, a, k, True, g)
+    assert torch.equal(cls1, cls2) and torch.equal(reg1, reg2) and all(torch.equal(g1[n], g2[n]) for n in g1), 'not deterministic'
+    # the same kernels on the same values in the same arithmetic order: the forward is bit-identical (so no ReLU unit switches between the
+    # routes), the gradients differ by summation order only
+    assert torch.equal(cls1, cls0) and torch.equal(reg1, reg0)
+    assert set(g0) == set(g1)
+    top = max(float(v.abs().max()) for n, v in g0.items() if n not in ('key_in', 'val_in', 'ref'))
+    worst = (0.0, None)
+    for n, v in g0.items():
+        m = float(v.abs().max())
+        if m < 1e-5 * top:
+            assert float(g1[n].abs().max()) < 1e-4 * top, n        # numerically zero in both (layer-0 self attention: every value row equal)
+            continue
+        worst = max(worst, (float((g1[n] - v).abs().max()) / m, n))
+    assert worst[0] <= 1e-4, worst
+
+
+def test_decoder_issued_from_c_dropout_masks_of_forward_and_backward_agree():
+    """Training mode (dropout 0.1 on the attention probabilities, both attentions' output paths and twice in the FFN -- configs/mv2d/exp/*:67-79):
+    the backward regenerates the masks of the forward from (seed, layer, site, element).  With the mask counter pinned, f is a fixed
+    piecewise-smooth function of the parameters, so a central difference along the gradient direction must reproduce |grad|; two different
+    draws give different outputs; eval mode drops nothing."""
+    head, a, k = _captured_decoder_call('cfg1_s', 'S', train_mode=True)
+    dec = head._train_decoder
+    names = [n for n, _ in head.named_parameters() if 'transformer.decoder' in n]
+    P = dict(head.named_parameters())
+
+    def run(counter):
+        dec._drop_calls = counter
+        torch.manual_seed(11)
+        return _decoder_outputs_and_grads(head, a, k, True, run.g)
+    run.g = None
+    cls_a, _, grads, run.g, f0 = run(0)
+    cls_b, _, _, _, _ = run(0)
+    cls_c, _, _, _, _ = run(5)
+    assert torch.equal(cls_a, cls_b) and not torch.equal(cls_a, cls_c)
+    gn = float(torch.sqrt(sum((grads[n].double() ** 2).sum() for n in names)))
+    eps = 2e-3
+    fs = []
+    for sgn in (1.0, -1.0):
+        with torch.no_grad():
+            for n in names:
+                P[n].add_(grads[n], alpha=sgn * eps / gn)
+        fs.append(run(0)[4])
+        with torch.no_grad():
+            for n in names:
+                P[n].add_(grads[n], alpha=-sgn * eps / gn)
+    fd = (fs[0] - fs[1]) / (2 * eps)
+    assert abs(fd - gn) <= 5e-2 * gn, (fd, gn, f0, fs)
+    head.eval()
+    cls_e, _, _, _, _ = run(0)
+    cls_f, _, _, _, _ = run(5)
+    assert torch.equal(cls_e, cls_f) and not torch.equal(cls_e, cls_a)

@@ -1,0 +1,4 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05t3; mkdir -p $O
+timeout 300 python $R/tools/train_fused_unit.py > $O/unit_cfg2s.json 2>$O/err.txt
+tail -5 $O/err.txt; cat $O/unit_cfg2s.json
