@@ -361,6 +361,11 @@ int mv2d_sparse_xattn_fwd_drop(const float* q, const void* K, const void* V, con
 int mv2d_sparse_xattn_bwd_drop(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
                                const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws, float* dq, float* dK,
                                float* dV, int R, int S, float p_drop, unsigned int seed, void* stream);
+/* long_rows != 0: for patterns with hundreds of keys per query AND of queries per key (the decoder's self attention in training): 16 waves per
+ * query in the query pass, one 4-wave block per key in the key pass; the results differ from long_rows = 0 by summation order only. */
+int mv2d_sparse_xattn_bwd_ex(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx, const float* dctx,
+                             const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws, float* dq, float* dK, float* dV, int R,
+                             int S, float p_drop, unsigned int seed, int long_rows, void* stream);
 
 /* ---- geometry / gather ---------------------------------------------------------------------------------- */
 

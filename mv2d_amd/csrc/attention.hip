@@ -274,12 +274,13 @@ __device__ __forceinline__ float head_sum(float d) {
 }
 
 // pass over the queries: dq, and per allowed pair e the probabilities / logit gradients of the 8 heads: pd[e][0..7] = p, pd[e][8..15] = ds
-__global__ __launch_bounds__(256) void sparse_xattn_bwd_q_kernel(const float* __restrict__ q, const unsigned short* __restrict__ K,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void sparse_xattn_bwd_q_kernel(const float* __restrict__ q, const unsigned short* __restrict__ K,
                                                                  const unsigned short* __restrict__ V, const int* __restrict__ row_ptr,
                                                                  const int* __restrict__ col_idx, const float* __restrict__ ctx,
                                                                  const float* __restrict__ dctx, float* __restrict__ dq, float* __restrict__ pd, int R,
                                                                  AttnDrop drop) {
-    __shared__ float sm[4][8], sl[4][8], sdq[4][C];
+    __shared__ float sm[NW][8], sl[NW][8], sdq[NW][C];
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 3;
     const int beg = row_ptr[r], end = row_ptr[r + 1];
     const long long ro = (long long)r * C + 4 * lane;
@@ -296,9 +297,9 @@ __global__ __launch_bounds__(256) void sparse_xattn_bwd_q_kernel(const float* __
     {
         int e = beg + wave;
         uint2 kn = e < end ? *reinterpret_cast<const uint2*>(K + (long long)col_idx[e] * C + 4 * lane) : make_uint2(0u, 0u);
-        for (; e < end; e += 4) {
+        for (; e < end; e += NW) {
             const float4 k4 = bf16x4(kn);
-            if (e + 4 < end) kn = *reinterpret_cast<const uint2*>(K + (long long)col_idx[e + 4] * C + 4 * lane);
+            if (e + NW < end) kn = *reinterpret_cast<const uint2*>(K + (long long)col_idx[e + NW] * C + 4 * lane);
             const float sv = head_sum(k4.x * q4.x + k4.y * q4.y + k4.z * q4.z + k4.w * q4.w);
             const float m_new = fmaxf(m_run, sv);
             l_run = l_run * expf(m_run - m_new) + expf(sv - m_new);
@@ -307,9 +308,11 @@ __global__ __launch_bounds__(256) void sparse_xattn_bwd_q_kernel(const float* __
     }
     if ((lane & 7) == 0) { sm[wave][h] = m_run; sl[wave][h] = l_run; }
     __syncthreads();
-    float M = fmaxf(fmaxf(sm[0][h], sm[1][h]), fmaxf(sm[2][h], sm[3][h])), den = 0.f;
+    float M = sm[0][h], den = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) den += sl[w][h] * expf(sm[w][h] - M);      // waves without a key: exp(-inf) = 0
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, sm[w][h]);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) den += sl[w][h] * expf(sm[w][h] - M);      // waves without a key: exp(-inf) = 0
     const float lse = M + logf(den);
     // ---- pass 2: p, ds per pair and head; dq
     float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -320,10 +323,10 @@ __global__ __launch_bounds__(256) void sparse_xattn_bwd_q_kernel(const float* __
             const long long ko = (long long)col_idx[e] * C + 4 * lane;
             kn = *reinterpret_cast<const uint2*>(K + ko); vn = *reinterpret_cast<const uint2*>(V + ko);
         }
-        for (; e < end; e += 4) {
+        for (; e < end; e += NW) {
             const float4 k4 = bf16x4(kn), v4 = bf16x4(vn);
-            if (e + 4 < end) {
-                const long long ko = (long long)col_idx[e + 4] * C + 4 * lane;
+            if (e + NW < end) {
+                const long long ko = (long long)col_idx[e + NW] * C + 4 * lane;
                 kn = *reinterpret_cast<const uint2*>(K + ko); vn = *reinterpret_cast<const uint2*>(V + ko);
             }
             const float sv = head_sum(k4.x * q4.x + k4.y * q4.y + k4.z * q4.z + k4.w * q4.w);
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256) void sparse_xattn_bwd_q_kernel(const float* __
     if (wave == 0) {
         float4 o = *reinterpret_cast<float4*>(&sdq[0][4 * lane]);
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < NW; ++w) {
             const float4 t = *reinterpret_cast<float4*>(&sdq[w][4 * lane]);
             o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
         }
@@ -370,6 +373,40 @@ __global__ __launch_bounds__(256) void sparse_xattn_bwd_kv_kernel(const float* _
     }
     *reinterpret_cast<float4*>(dK + (long long)s * C + 4 * lane) = gk;
     *reinterpret_cast<float4*>(dV + (long long)s * C + 4 * lane) = gv;
+}
+
+
+// The same pass for patterns with few keys and long key lists (the self attention: every query sees every query): one 4-wave block per
+// key, the key's pairs dealt to the waves round robin (the next pair's indices requested one step ahead), the four partial sums added in
+// fixed order through LDS.  (One wave per key walked 300 pairs through three dependent loads each: 168 us for 300 keys.)
+__global__ __launch_bounds__(256) void sparse_xattn_bwd_kv_split_kernel(const float* __restrict__ q, const float* __restrict__ dctx,
+                                                                        const float* __restrict__ pd, const int* __restrict__ key_ptr,
+                                                                        const int* __restrict__ pair_idx, const int* __restrict__ pair_row,
+                                                                        float* __restrict__ dK, float* __restrict__ dV, int S) {
+    __shared__ float sk[4][C], sv[4][C];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 3;
+    const int s = blockIdx.x;
+    float4 gk = make_float4(0.f, 0.f, 0.f, 0.f), gv = gk;
+    const int beg = key_ptr[s], end = key_ptr[s + 1];
+    int i = beg + wave;
+    int e = i < end ? pair_idx[i] : 0;
+    int row = i < end ? pair_row[e] : 0;
+    for (; i < end; i += 4) {
+        const int e_cur = e;
+        const long long ro = (long long)row * C + 4 * lane;
+        if (i + 4 < end) { e = pair_idx[i + 4]; row = pair_row[e]; }
+        const float pj = pd[(long long)e_cur * 16 + h], ds = pd[(long long)e_cur * 16 + 8 + h];
+        const float4 q4 = *reinterpret_cast<const float4*>(q + ro);
+        const float4 d4 = *reinterpret_cast<const float4*>(dctx + ro);
+        gk.x = fmaf(ds, q4.x, gk.x); gk.y = fmaf(ds, q4.y, gk.y); gk.z = fmaf(ds, q4.z, gk.z); gk.w = fmaf(ds, q4.w, gk.w);
+        gv.x = fmaf(pj, d4.x, gv.x); gv.y = fmaf(pj, d4.y, gv.y); gv.z = fmaf(pj, d4.z, gv.z); gv.w = fmaf(pj, d4.w, gv.w);
+    }
+    *reinterpret_cast<float4*>(&sk[wave][4 * lane]) = gk;
+    *reinterpret_cast<float4*>(&sv[wave][4 * lane]) = gv;
+    __syncthreads();
+    const int c = threadIdx.x;
+    dK[(long long)s * C + c] = (sk[0][c] + sk[1][c]) + (sk[2][c] + sk[3][c]);
+    dV[(long long)s * C + c] = (sv[0][c] + sv[1][c]) + (sv[2][c] + sv[3][c]);
 }
 
 }  // namespace
@@ -440,19 +477,41 @@ extern "C" int mv2d_sparse_xattn_bwd(const float* q, const void* K, const void* 
     return mv2d_sparse_xattn_bwd_drop(q, K, V, row_ptr, col_idx, ctx, dctx, key_ptr, pair_idx, pair_row, pair_ws, dq, dK, dV, R, S, 0.f, 0u, stream);
 }
 
+extern "C" int mv2d_sparse_xattn_bwd_ex(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
+                                        const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws,
+                                        float* dq, float* dK, float* dV, int R, int S, float p_drop, unsigned int seed, int long_rows, void* stream);
+
 extern "C" int mv2d_sparse_xattn_bwd_drop(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
                                           const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws,
                                           float* dq, float* dK, float* dV, int R, int S, float p_drop, unsigned int seed, void* stream) {
+    return mv2d_sparse_xattn_bwd_ex(q, K, V, row_ptr, col_idx, ctx, dctx, key_ptr, pair_idx, pair_row, pair_ws, dq, dK, dV, R, S, p_drop, seed, 0, stream);
+}
+
+// long_rows != 0: the pattern has hundreds of keys per query and of queries per key (the decoder's self attention): 16 waves per query in
+// the query pass, one block per key in the key pass.  The results differ from long_rows = 0 by summation order only.
+extern "C" int mv2d_sparse_xattn_bwd_ex(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
+                                        const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws,
+                                        float* dq, float* dK, float* dV, int R, int S, float p_drop, unsigned int seed, int long_rows, void* stream) {
     MV2D_CHECK_ARG(q && K && V && row_ptr && col_idx && ctx && dctx && key_ptr && pair_idx && pair_row && pair_ws && dq && dK && dV,
                    "mv2d_sparse_xattn_bwd: null pointer");
     MV2D_CHECK_ARG(R >= 0 && S >= 0 && p_drop >= 0.f && p_drop < 1.f, "mv2d_sparse_xattn_bwd: bad sizes / p_drop");
     const AttnDrop drop = make_drop(p_drop, seed);
-    if (R > 0)
-        hipLaunchKernelGGL(sparse_xattn_bwd_q_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, q, (const unsigned short*)K, (const unsigned short*)V,
-                           row_ptr, col_idx, ctx, dctx, dq, pair_ws, R, drop);
-    if (S > 0)
-        hipLaunchKernelGGL(sparse_xattn_bwd_kv_kernel, dim3(cdiv(S, 4)), dim3(256), 0, (hipStream_t)stream, q, dctx, pair_ws, key_ptr, pair_idx, pair_row,
-                           dK, dV, S);
+    if (R > 0) {
+        if (long_rows)
+            hipLaunchKernelGGL(sparse_xattn_bwd_q_kernel<16>, dim3(R), dim3(1024), 0, (hipStream_t)stream, q, (const unsigned short*)K,
+                               (const unsigned short*)V, row_ptr, col_idx, ctx, dctx, dq, pair_ws, R, drop);
+        else
+            hipLaunchKernelGGL(sparse_xattn_bwd_q_kernel<4>, dim3(R), dim3(256), 0, (hipStream_t)stream, q, (const unsigned short*)K,
+                               (const unsigned short*)V, row_ptr, col_idx, ctx, dctx, dq, pair_ws, R, drop);
+    }
+    if (S > 0) {
+        if (long_rows)
+            hipLaunchKernelGGL(sparse_xattn_bwd_kv_split_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, q, dctx, pair_ws, key_ptr, pair_idx, pair_row,
+                               dK, dV, S);
+        else
+            hipLaunchKernelGGL(sparse_xattn_bwd_kv_kernel, dim3(cdiv(S, 4)), dim3(256), 0, (hipStream_t)stream, q, dctx, pair_ws, key_ptr, pair_idx, pair_row,
+                               dK, dV, S);
+    }
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -117,7 +117,11 @@ struct FxTile {
     }
 };
 
-template <bool TA, bool TB>
+// PF = stages of global loads in flight (a register ring).  PF = 1: one stage ahead, few registers -- the products with hundreds of
+// blocks, where other blocks hide the latency.  PF = 4: the products of a training step with 4..160 blocks (300 query rows): their
+// duration is the chain stage -> stage of ONE block, so all (up to four) stages are requested before the first one is used
+// (10.8 -> ~6 us for 300 x 256 x 256).  Same k order either way: the results do not depend on PF.
+template <bool TA, bool TB, int PF>
 __global__ __launch_bounds__(256) void gemm_f32x3_kernel(FxParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * IMG];
     unsigned char *Ah = smem, *Al = smem + IMG, *Bh = smem + 2 * IMG, *Bl = smem + 3 * IMG;
@@ -136,53 +140,54 @@ __global__ __launch_bounds__(256) void gemm_f32x3_kernel(FxParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    FxTile<TA> ta;
-    FxTile<TB> tb;
+    FxTile<TA> ta[PF];
+    FxTile<TB> tb[PF];
     const bool want_rs = TA && p.rowsum != nullptr && n0 == 0;
     float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (kt0 < kt1) {
-        ta.load(p.A, p.lda, m0, p.M, kt0 * BK, p.K, vecA, tid);
-        tb.load(p.B, p.ldb, n0, p.N, kt0 * BK, p.K, vecB, tid);
-        ta.store(Ah, Al, tid);
-        tb.store(Bh, Bl, tid);
-        if (TA && want_rs) rs = fx_add4(rs, fx_add4(fx_add4(ta.v[0], ta.v[1]), fx_add4(ta.v[2], ta.v[3])));
-    }
-    __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
-        if (kt + 1 < kt1) {                                 // the next stage: in flight during the MFMAs below
-            ta.load(p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, vecA, tid);
-            tb.load(p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, vecB, tid);
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (kt0 + u < kt1) {
+            ta[u].load(p.A, p.lda, m0, p.M, (kt0 + u) * BK, p.K, vecA, tid);
+            tb[u].load(p.B, p.ldb, n0, p.N, (kt0 + u) * BK, p.K, vecB, tid);
         }
+    for (int ktb = kt0; ktb < kt1; ktb += PF) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            FxFrag ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = wr * 32 + i * 16 + fr, o = fx_off(row, 2 * (4 * ks + fg));
-                ah[i].u = *reinterpret_cast<const uint4*>(Ah + o);
-                al[i].u = *reinterpret_cast<const uint4*>(Al + o);
+        for (int u = 0; u < PF; ++u) {
+            const int kt = ktb + u;
+            if (kt >= kt1) break;                           // (uniform)
+            ta[u].store(Ah, Al, tid);
+            tb[u].store(Bh, Bl, tid);
+            if (TA && want_rs) rs = fx_add4(rs, fx_add4(fx_add4(ta[u].v[0], ta[u].v[1]), fx_add4(ta[u].v[2], ta[u].v[3])));
+            if (kt + PF < kt1) {                            // this register set is free again: the stage PF ahead
+                ta[u].load(p.A, p.lda, m0, p.M, (kt + PF) * BK, p.K, vecA, tid);
+                tb[u].load(p.B, p.ldb, n0, p.N, (kt + PF) * BK, p.K, vecB, tid);
             }
+            __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = wc * 32 + j * 16 + fr, o = fx_off(row, 2 * (4 * ks + fg));
-                bh[j].u = *reinterpret_cast<const uint4*>(Bh + o);
-                bl[j].u = *reinterpret_cast<const uint4*>(Bl + o);
-            }
+            for (int ks = 0; ks < 2; ++ks) {
+                FxFrag ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i) {
+                    const int row = wr * 32 + i * 16 + fr, o = fx_off(row, 2 * (4 * ks + fg));
+                    ah[i].u = *reinterpret_cast<const uint4*>(Ah + o);
+                    al[i].u = *reinterpret_cast<const uint4*>(Al + o);
+                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i].v, bh[j].v, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i].v, bh[j].v, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i].v, bl[j].v, acc[i][j], 0, 0, 0);
+                    const int row = wc * 32 + j * 16 + fr, o = fx_off(row, 2 * (4 * ks + fg));
+                    bh[j].u = *reinterpret_cast<const uint4*>(Bh + o);
+                    bl[j].u = *reinterpret_cast<const uint4*>(Bl + o);
                 }
-        }
-        __syncthreads();                                    // every wave is done reading this stage
-        if (kt + 1 < kt1) {
-            ta.store(Ah, Al, tid);
-            tb.store(Bh, Bl, tid);
-            if (TA && want_rs) rs = fx_add4(rs, fx_add4(fx_add4(ta.v[0], ta.v[1]), fx_add4(ta.v[2], ta.v[3])));
-            __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i].v, bl[j].v, acc[i][j], 0, 0, 0);
+                    }
+            }
+            __syncthreads();                                // every wave is done reading this stage
         }
     }
     if (TA && want_rs) {
@@ -299,10 +304,16 @@ static int gemm_f32x3_impl(const float* A, long long lda, int trans_a, const flo
     else { p.C = C; p.ldc = ldc; p.c_split_stride = 0; p.accumulate = accumulate; }
     const dim3 grid(cdiv(M, BM) * cdiv(N, BN), splits);
     hipStream_t st = (hipStream_t)stream;
-    if (trans_a && trans_b) hipLaunchKernelGGL((gemm_f32x3_kernel<true, true>), grid, dim3(256), 0, st, p);
-    else if (trans_a) hipLaunchKernelGGL((gemm_f32x3_kernel<true, false>), grid, dim3(256), 0, st, p);
-    else if (trans_b) hipLaunchKernelGGL((gemm_f32x3_kernel<false, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_f32x3_kernel<false, false>), grid, dim3(256), 0, st, p);
+    // few blocks: the product's duration is one block's chain of stages -> four stages of loads in flight
+    const bool deep = (long long)grid.x * grid.y <= 512;
+#define MV2D_FX_LAUNCH(TA_, TB_) do { \
+        if (deep) hipLaunchKernelGGL((gemm_f32x3_kernel<TA_, TB_, 4>), grid, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((gemm_f32x3_kernel<TA_, TB_, 1>), grid, dim3(256), 0, st, p); } while (0)
+    if (trans_a && trans_b) MV2D_FX_LAUNCH(true, true);
+    else if (trans_a) MV2D_FX_LAUNCH(true, false);
+    else if (trans_b) MV2D_FX_LAUNCH(false, true);
+    else MV2D_FX_LAUNCH(false, false);
+#undef MV2D_FX_LAUNCH
     MV2D_LAUNCH_CHECK();
     if (splits > 1) {
         float* scratch = slabs + (long long)splits * M * N;

@@ -14,6 +14,7 @@
 // (CSR; K / V in bf16 -- written as bf16 straight from the projection's epilogue).  Dropout masks are counter hashes of (seed, element),
 // regenerated in the backward, never stored.  No buffer of the backward is reused inside one call (side streams read them asynchronously).
 #include "common.h"
+#include <stdlib.h>
 
 extern "C" long long mv2d_gemm_f32x3_ws_bytes(int M, int N, int K);
 extern "C" int mv2d_gemm_f32x3_ex(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act,
@@ -29,6 +30,9 @@ extern "C" int mv2d_sparse_xattn_fwd_drop(const float* q, const void* K, const v
 extern "C" int mv2d_sparse_xattn_bwd_drop(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
                                           const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws,
                                           float* dq, float* dK, float* dV, int R, int S, float p_drop, unsigned int seed, void* stream);
+extern "C" int mv2d_sparse_xattn_bwd_ex(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
+                                        const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws,
+                                        float* dq, float* dK, float* dV, int R, int S, float p_drop, unsigned int seed, int long_rows, void* stream);
 
 // the scalar arguments of both entries (mirrored by mv2d_amd/_lib.py: TdDims)
 struct mv2d_td_dims {
@@ -217,6 +221,12 @@ constexpr int NSIDE = 3, NEV = 128;
 struct Pool { bool ready = false; hipStream_t side[NSIDE]; hipEvent_t ev[NEV]; int next = 0; };
 Pool g_pool[16];
 
+// MV2D_TD_SERIAL=1 (diagnostics): every "side stream" is the caller's stream -- the same launches without any overlap
+static bool td_serial() {
+    static const bool v = [] { const char* e = getenv("MV2D_TD_SERIAL"); return e && e[0] == '1'; }();
+    return v;
+}
+
 static Pool* pool() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
@@ -232,6 +242,7 @@ static Pool* pool() {
 }
 // `to` continues only after everything issued to `from` so far
 static void after(Pool* p, hipStream_t from, hipStream_t to) {
+    if (from == to) return;
     hipEvent_t e = p->ev[p->next];
     p->next = (p->next + 1) % NEV;
     (void)hipEventRecord(e, from);
@@ -350,7 +361,7 @@ extern "C" int mv2d_train_decoder_fwd(const mv2d_td_dims* d, const float* const*
     const long long gws = gemm_ws_max(*d), csb = (long long)(mv2d_colsum_scratch_rows(S > T ? S : T) + 1) * F;
     Lane mainl{st, cw.take<char>(gws), gws, cw.take<float>(csb)};
     Lane side[NSIDE];
-    for (int i = 0; i < NSIDE; ++i) side[i] = Lane{pl->side[i], cw.take<char>(gws), gws, cw.take<float>(csb)};
+    for (int i = 0; i < NSIDE; ++i) side[i] = Lane{td_serial() ? st : pl->side[i], cw.take<char>(gws), gws, cw.take<float>(csb)};
     float* tmp = cw.take<float>(TC);
 
     // the key side of all layers does not depend on the queries: K_l = key_in Wk_l^T + bk_l, V_l = val_in Wv_l^T + bv_l (bf16) on two side streams
@@ -435,7 +446,7 @@ extern "C" int mv2d_train_decoder_bwd(const mv2d_td_dims* d, const float* const*
     const long long gws = gemm_ws_max(*d), csb = (long long)(mv2d_colsum_scratch_rows(S > T ? S : T) + 1) * F;
     Lane mainl{st, cw.take<char>(gws), gws, cw.take<float>(csb)};
     Lane side[NSIDE];
-    for (int i = 0; i < NSIDE; ++i) side[i] = Lane{pl->side[i], cw.take<char>(gws), gws, cw.take<float>(csb)};
+    for (int i = 0; i < NSIDE; ++i) side[i] = Lane{td_serial() ? st : pl->side[i], cw.take<char>(gws), gws, cw.take<float>(csb)};
     const int nb = cdiv(T, LNB_ROWS);
     const float* post_w = params[L * NPL];
 
@@ -515,8 +526,8 @@ extern "C" int mv2d_train_decoder_bwd(const mv2d_td_dims* d, const float* const*
         ln_bwd(a.s1, b.ds2, b.Q1, nullptr, P[N0_W], b.ds1, b.do1, d1, b.part[4], b.part[5]);
         const float* do1 = d1.thr ? b.do1 : b.ds1;
         TD_RC(mainl.dgrad(do1, P[SA_OW], b.dctx1, T, C, C, 0));
-        TD_RC(mv2d_sparse_xattn_bwd_drop(a.q_sa, a.k_sa, a.v_sa, sa_row_ptr, sa_col, a.ctx_sa, b.dctx1, sa_key_ptr, sa_pair_idx, sa_pair_row, b.pw_sa,
-                                         b.dq1, b.dk1, b.dv1, T, T, d->p_sa_attn, site_seed(d->seed, l, 0), st));
+        TD_RC(mv2d_sparse_xattn_bwd_ex(a.q_sa, a.k_sa, a.v_sa, sa_row_ptr, sa_col, a.ctx_sa, b.dctx1, sa_key_ptr, sa_pair_idx, sa_pair_row, b.pw_sa,
+                                       b.dq1, b.dk1, b.dv1, T, T, d->p_sa_attn, site_seed(d->seed, l, 0), d->sa_nnz >= 64LL * T ? 1 : 0, st));
         hipLaunchKernelGGL(scale_kernel, dim3(blocks4(TC)), dim3(256), 0, st, b.dq1, TC / 4, qs);
         // d(x + query_pos) of the q / k inputs; d x of the value input joins the post_norm gradient of the layer below
         TD_RC(mainl.dgrad(b.dq1, P[SA_W], b.A, T, C, C, 0));
@@ -609,7 +620,7 @@ extern "C" int mv2d_train_heads_fwd(const mv2d_th_dims* d, const float* const* p
     const long long gws = th_gemm_ws(*d), csb = th_cs(*d);
     Lane lane[1 + NSIDE];
     lane[0] = Lane{st, cw.take<char>(gws), gws, cw.take<float>(csb)};
-    for (int i = 0; i < NSIDE; ++i) { lane[1 + i] = Lane{pl->side[i], cw.take<char>(gws), gws, cw.take<float>(csb)}; after(pl, st, pl->side[i]); }
+    for (int i = 0; i < NSIDE; ++i) { lane[1 + i] = Lane{td_serial() ? st : pl->side[i], cw.take<char>(gws), gws, cw.take<float>(csb)}; after(pl, st, lane[1 + i].st); }
     for (int l = 0; l < L; ++l) {
         const Lane& ln = lane[l % (1 + NSIDE)];
         const float* const* P = params + l * NPH;
@@ -625,7 +636,7 @@ extern "C" int mv2d_train_heads_fwd(const mv2d_th_dims* d, const float* const* p
         TD_RC(ln.linear(a.t2, P[R4_W], P[R4_B], 0, 1.f, 0, reg + (long long)l * T * NREG, T, NREG, C));
     }
     MV2D_LAUNCH_CHECK();
-    for (int i = 0; i < NSIDE; ++i) after(pl, pl->side[i], st);
+    for (int i = 0; i < NSIDE; ++i) after(pl, lane[1 + i].st, st);
     return MV2D_OK;
 }
 
@@ -644,7 +655,7 @@ extern "C" int mv2d_train_heads_bwd(const mv2d_th_dims* d, const float* const* p
     const long long gws = th_gemm_ws(*d), csb = th_cs(*d);
     Lane lane[1 + NSIDE];
     lane[0] = Lane{st, cw.take<char>(gws), gws, cw.take<float>(csb)};
-    for (int i = 0; i < NSIDE; ++i) { lane[1 + i] = Lane{pl->side[i], cw.take<char>(gws), gws, cw.take<float>(csb)}; after(pl, st, pl->side[i]); }
+    for (int i = 0; i < NSIDE; ++i) { lane[1 + i] = Lane{td_serial() ? st : pl->side[i], cw.take<char>(gws), gws, cw.take<float>(csb)}; after(pl, st, lane[1 + i].st); }
     const int nb = cdiv(T, LNB_ROWS);
     for (int l = 0; l < L; ++l) {
         const Lane& ln = lane[l % (1 + NSIDE)];
@@ -688,6 +699,6 @@ extern "C" int mv2d_train_heads_bwd(const mv2d_th_dims* d, const float* const* p
         TD_RC(ln.dgrad(dt0, P[R0_W], dx, T, C, C, 1));
     }
     MV2D_LAUNCH_CHECK();
-    for (int i = 0; i < NSIDE; ++i) after(pl, pl->side[i], st);
+    for (int i = 0; i < NSIDE; ++i) after(pl, lane[1 + i].st, st);
     return MV2D_OK;
 }

@@ -758,7 +758,7 @@ def test_decoder_issued_from_c_equals_the_operator_graph(prob_name, kind):
     assert torch.equal(cls1, cls0) and torch.equal(reg1, reg0)
     assert set(g0) == set(g1)
     top = max(float(v.abs().max()) for n, v in g0.items() if n not in ('key_in', 'val_in', 'ref'))
-    worst = (0.0, None)
+    worst = (0.0, '')
     for n, v in g0.items():
         m = float(v.abs().max())
         if m < 1e-5 * top:
