@@ -362,10 +362,11 @@ int mv2d_sparse_xattn_bwd_drop(const float* q, const void* K, const void* V, con
                                const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws, float* dq, float* dK,
                                float* dV, int R, int S, float p_drop, unsigned int seed, void* stream);
 /* long_rows != 0: for patterns with hundreds of keys per query AND of queries per key (the decoder's self attention in training): 16 waves per
- * query in the query pass, one 4-wave block per key in the key pass; the results differ from long_rows = 0 by summation order only. */
+ * query in the query pass, one 4-wave block per key in the key pass; the results differ from long_rows = 0 by summation order only.
+ * dq_scale: factor on dq (the 1 / sqrt(d) of the scaled query projection). */
 int mv2d_sparse_xattn_bwd_ex(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx, const float* dctx,
                              const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws, float* dq, float* dK, float* dV, int R,
-                             int S, float p_drop, unsigned int seed, int long_rows, void* stream);
+                             int S, float p_drop, unsigned int seed, int long_rows, float dq_scale, void* stream);
 
 /* ---- geometry / gather ---------------------------------------------------------------------------------- */
 
@@ -555,6 +556,9 @@ int mv2d_gemm_f32x3_ex(const float* A, long long lda, int trans_a, const float* 
 int mv2d_colsum_add(const float* x, long long ld, int rows, int cols, float* out, float* scratch, const float* add, void* stream);
 /* dW [N,K] = g^T x and db [N] = column sums of g (g [M,N], x [M,K] dense rows) -- db inside the product's kernel when it runs in one pass, a
  * separate column sum after a split-K product (cs_scratch: [mv2d_colsum_scratch_rows(M), N] floats or NULL). */
+/* dx [M,K] = (g [M,N] W [N,K]) * alpha, zeroed where relu_y [M,K] <= 0 (NULL: no mask) -- the ReLU (+ dropout scale) of the forward applied to the
+ * input gradient in the product's epilogue. */
+int mv2d_dgrad_relu_f32x3(const float* g, const float* W, const float* relu_y, float alpha, float* dx, int M, int N, int K, void* stream);
 int mv2d_wgrad_f32x3(const float* g, const float* x, float* dW, float* db, int M, int N, int K, void* ws, long long ws_bytes, float* cs_scratch,
                      void* stream);
 

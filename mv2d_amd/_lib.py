@@ -79,7 +79,8 @@ SIGNATURES = {
     'mv2d_sparse_xattn_bwd': (I, [P] * 14 + [I, I, P]),
     'mv2d_sparse_xattn_fwd_drop': (I, [P, P, P, P, P, P, P, LL, I, I, F, C.c_uint, P]),
     'mv2d_sparse_xattn_bwd_drop': (I, [P] * 14 + [I, I, F, C.c_uint, P]),
-    'mv2d_sparse_xattn_bwd_ex': (I, [P] * 14 + [I, I, F, C.c_uint, I, P]),
+    'mv2d_sparse_xattn_bwd_ex': (I, [P] * 14 + [I, I, F, C.c_uint, I, F, P]),
+    'mv2d_dgrad_relu_f32x3': (I, [P, P, P, F, P, I, I, I, P]),
     'mv2d_xattn_qmap': (I, [P, P, P, P, I, P]),
     'mv2d_attn_out_qmap_x3': (I, [P] * 12 + [F, P, P, P, I, F, P]),
     'mv2d_attn_out_zmap_x3': (I, [P, P, P, P, P, I, P, P, P, P, P, P, P, I, F, P]),

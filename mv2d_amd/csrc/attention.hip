@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64 * NW) void sparse_xattn_bwd_q_kernel(const float
                                                                  const unsigned short* __restrict__ V, const int* __restrict__ row_ptr,
                                                                  const int* __restrict__ col_idx, const float* __restrict__ ctx,
                                                                  const float* __restrict__ dctx, float* __restrict__ dq, float* __restrict__ pd, int R,
-                                                                 AttnDrop drop) {
+                                                                 AttnDrop drop, float dq_scale) {
     __shared__ float sm[NW][8], sl[NW][8], sdq[NW][C];
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 3;
     const int beg = row_ptr[r], end = row_ptr[r + 1];
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(64 * NW) void sparse_xattn_bwd_q_kernel(const float
             const float4 t = *reinterpret_cast<float4*>(&sdq[w][4 * lane]);
             o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
         }
-        *reinterpret_cast<float4*>(dq + ro) = o;
+        *reinterpret_cast<float4*>(dq + ro) = make_float4(o.x * dq_scale, o.y * dq_scale, o.z * dq_scale, o.w * dq_scale);
     }
 }
 
@@ -479,19 +479,20 @@ extern "C" int mv2d_sparse_xattn_bwd(const float* q, const void* K, const void* 
 
 extern "C" int mv2d_sparse_xattn_bwd_ex(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
                                         const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws,
-                                        float* dq, float* dK, float* dV, int R, int S, float p_drop, unsigned int seed, int long_rows, void* stream);
+                                        float* dq, float* dK, float* dV, int R, int S, float p_drop, unsigned int seed, int long_rows, float dq_scale, void* stream);
 
 extern "C" int mv2d_sparse_xattn_bwd_drop(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
                                           const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws,
                                           float* dq, float* dK, float* dV, int R, int S, float p_drop, unsigned int seed, void* stream) {
-    return mv2d_sparse_xattn_bwd_ex(q, K, V, row_ptr, col_idx, ctx, dctx, key_ptr, pair_idx, pair_row, pair_ws, dq, dK, dV, R, S, p_drop, seed, 0, stream);
+    return mv2d_sparse_xattn_bwd_ex(q, K, V, row_ptr, col_idx, ctx, dctx, key_ptr, pair_idx, pair_row, pair_ws, dq, dK, dV, R, S, p_drop, seed, 0, 1.f, stream);
 }
 
 // long_rows != 0: the pattern has hundreds of keys per query and of queries per key (the decoder's self attention): 16 waves per query in
 // the query pass, one block per key in the key pass.  The results differ from long_rows = 0 by summation order only.
+// dq_scale: dq is multiplied by it (the 1 / sqrt(d) of q = (x W^T + b) / sqrt(d): the gradient w.r.t. the unscaled projection).
 extern "C" int mv2d_sparse_xattn_bwd_ex(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
                                         const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws,
-                                        float* dq, float* dK, float* dV, int R, int S, float p_drop, unsigned int seed, int long_rows, void* stream) {
+                                        float* dq, float* dK, float* dV, int R, int S, float p_drop, unsigned int seed, int long_rows, float dq_scale, void* stream) {
     MV2D_CHECK_ARG(q && K && V && row_ptr && col_idx && ctx && dctx && key_ptr && pair_idx && pair_row && pair_ws && dq && dK && dV,
                    "mv2d_sparse_xattn_bwd: null pointer");
     MV2D_CHECK_ARG(R >= 0 && S >= 0 && p_drop >= 0.f && p_drop < 1.f, "mv2d_sparse_xattn_bwd: bad sizes / p_drop");
@@ -499,10 +500,10 @@ extern "C" int mv2d_sparse_xattn_bwd_ex(const float* q, const void* K, const voi
     if (R > 0) {
         if (long_rows)
             hipLaunchKernelGGL(sparse_xattn_bwd_q_kernel<16>, dim3(R), dim3(1024), 0, (hipStream_t)stream, q, (const unsigned short*)K,
-                               (const unsigned short*)V, row_ptr, col_idx, ctx, dctx, dq, pair_ws, R, drop);
+                               (const unsigned short*)V, row_ptr, col_idx, ctx, dctx, dq, pair_ws, R, drop, dq_scale);
         else
             hipLaunchKernelGGL(sparse_xattn_bwd_q_kernel<4>, dim3(R), dim3(256), 0, (hipStream_t)stream, q, (const unsigned short*)K,
-                               (const unsigned short*)V, row_ptr, col_idx, ctx, dctx, dq, pair_ws, R, drop);
+                               (const unsigned short*)V, row_ptr, col_idx, ctx, dctx, dq, pair_ws, R, drop, dq_scale);
     }
     if (S > 0) {
         if (long_rows)

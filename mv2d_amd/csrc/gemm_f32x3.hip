@@ -39,6 +39,7 @@ struct FxParams {
     float alpha;                // C = act((sum + bias) * alpha)
     int accumulate;             // C += ... (one-pass products only; the split-K slabs are summed onto C by the caller's column sum)
     int out_bf16;               // C holds bf16 (the keys / values the sparse attention kernels read)
+    const float* relu_y;        // fp32 [M, ldc] or NULL: C = relu_y > 0 ? value : 0 (the ReLU of the forward applied to a gradient)
     float* rowsum;              // trans_a products in one pass: rowsum[m] = sum_k opA[m, k] (the bias gradient next to dW = g^T x), or NULL
 };
 
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(256) void gemm_f32x3_kernel(FxParams p) {
                 if (m < p.M) {
                     float v = (acc[i][j][r] + bv) * p.alpha;
                     if (p.act == 1) v = relu_f(v);
+                    if (p.relu_y && !(p.relu_y[(long long)m * p.ldc + n] > 0.f)) v = 0.f;
                     if (p.out_bf16) { reinterpret_cast<unsigned short*>(Cb)[(long long)m * p.ldc + n] = f32_to_bf16(v); continue; }
                     if (p.accumulate) v += Cb[(long long)m * p.ldc + n];
                     Cb[(long long)m * p.ldc + n] = v;
@@ -258,7 +260,7 @@ extern "C" int mv2d_gemm_f32x3_ex(const float* A, long long lda, int trans_a, co
                                   long long ws_bytes, void* stream);
 static int gemm_f32x3_impl(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act,
                            float alpha, int accumulate, int out_bf16, void* Cv, long long ldc, int M, int N, int K, void* ws, long long ws_bytes,
-                           float* rowsum, void* stream);
+                           float* rowsum, const float* relu_y, void* stream);
 
 extern "C" int mv2d_gemm_f32x3(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act,
                                float* C, long long ldc, int M, int N, int K, void* ws, long long ws_bytes, void* stream) {
@@ -269,7 +271,15 @@ extern "C" int mv2d_gemm_f32x3(const float* A, long long lda, int trans_a, const
 extern "C" int mv2d_gemm_f32x3_ex(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act,
                                   float alpha, int accumulate, int out_bf16, void* Cv, long long ldc, int M, int N, int K, void* ws,
                                   long long ws_bytes, void* stream) {
-    return gemm_f32x3_impl(A, lda, trans_a, B, ldb, trans_b, bias, act, alpha, accumulate, out_bf16, Cv, ldc, M, N, K, ws, ws_bytes, nullptr, stream);
+    return gemm_f32x3_impl(A, lda, trans_a, B, ldb, trans_b, bias, act, alpha, accumulate, out_bf16, Cv, ldc, M, N, K, ws, ws_bytes, nullptr, nullptr, stream);
+}
+
+// dx [M,K] = (g [M,N] W [N,K]) * alpha, zeroed where relu_y [M,K] <= 0 (relu_y NULL: no mask): the input gradient of a linear layer whose input
+// came out of a ReLU (and a dropout: alpha = 1 / keep rate), mask applied in the product's epilogue.  One pass.
+extern "C" int mv2d_dgrad_relu_f32x3(const float* g, const float* W, const float* relu_y, float alpha, float* dx, int M, int N, int K, void* stream) {
+    MV2D_CHECK_ARG(g && W && dx && M >= 0 && N > 0 && K > 0, "mv2d_dgrad_relu_f32x3: bad args");
+    if (M == 0) return MV2D_OK;
+    return gemm_f32x3_impl(g, N, 0, W, K, 1, nullptr, 0, alpha, 0, 0, dx, K, M, K, N, nullptr, 0, nullptr, relu_y, stream);
 }
 
 // Weight + bias gradient of a linear layer in one call: dW [N,K] = g^T x (g [M,N], x [M,K] dense rows) and db [N] = column sums of g -- inside the
@@ -280,22 +290,22 @@ extern "C" int mv2d_wgrad_f32x3(const float* g, const float* x, float* dW, float
     MV2D_CHECK_ARG(g && x && dW && M >= 0 && N > 0 && K > 0, "mv2d_wgrad_f32x3: bad args");
     if (M == 0) return MV2D_OK;
     const bool one_pass = fx_splits(N, K, M, 0) <= 1 || !ws || ws_bytes < mv2d_gemm_f32x3_ws_bytes(N, K, M) || ((uintptr_t)ws & 255) != 0;
-    const int rc = gemm_f32x3_impl(g, N, 1, x, K, 1, nullptr, 0, 1.f, 0, 0, dW, K, N, K, M, ws, ws_bytes, (db && one_pass) ? db : nullptr, stream);
+    const int rc = gemm_f32x3_impl(g, N, 1, x, K, 1, nullptr, 0, 1.f, 0, 0, dW, K, N, K, M, ws, ws_bytes, (db && one_pass) ? db : nullptr, nullptr, stream);
     if (rc != MV2D_OK || !db || one_pass) return rc;
     return mv2d_colsum_add(g, N, M, N, db, mv2d_colsum_scratch_rows(M) ? cs_scratch : nullptr, nullptr, stream);
 }
 
 static int gemm_f32x3_impl(const float* A, long long lda, int trans_a, const float* B, long long ldb, int trans_b, const float* bias, int act,
                            float alpha, int accumulate, int out_bf16, void* Cv, long long ldc, int M, int N, int K, void* ws, long long ws_bytes,
-                           float* rowsum, void* stream) {
+                           float* rowsum, const float* relu_y, void* stream) {
     float* C = (float*)Cv;
     MV2D_CHECK_ARG(!(out_bf16 && accumulate), "mv2d_gemm_f32x3_ex: accumulate needs an fp32 C");
     MV2D_CHECK_ARG(A && B && C && M >= 0 && N > 0 && K > 0 && (act == 0 || act == 1) && ldc >= N, "mv2d_gemm_f32x3: bad args");
     if (M == 0) return MV2D_OK;
-    int splits = out_bf16 ? 1 : fx_splits(M, N, K, act);
+    int splits = (out_bf16 || relu_y) ? 1 : fx_splits(M, N, K, act);
     if (splits > 1 && (ldc != N || !ws || ws_bytes < mv2d_gemm_f32x3_ws_bytes(M, N, K) || ((uintptr_t)ws & 255) != 0)) splits = 1;   // no slabs: one pass
     FxParams p;
-    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.bias = bias; p.M = M; p.N = N; p.K = K; p.act = act; p.alpha = alpha; p.out_bf16 = out_bf16; p.rowsum = rowsum;
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.bias = bias; p.M = M; p.N = N; p.K = K; p.act = act; p.alpha = alpha; p.out_bf16 = out_bf16; p.rowsum = rowsum; p.relu_y = relu_y;
     const int nk = cdiv(K, BK);
     p.k_tiles_per_split = cdiv(nk, splits);
     splits = cdiv(nk, p.k_tiles_per_split);                 // (no empty split)

@@ -32,7 +32,8 @@ extern "C" int mv2d_sparse_xattn_bwd_drop(const float* q, const void* K, const v
                                           float* dq, float* dK, float* dV, int R, int S, float p_drop, unsigned int seed, void* stream);
 extern "C" int mv2d_sparse_xattn_bwd_ex(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
                                         const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws,
-                                        float* dq, float* dK, float* dV, int R, int S, float p_drop, unsigned int seed, int long_rows, void* stream);
+                                        float* dq, float* dK, float* dV, int R, int S, float p_drop, unsigned int seed, int long_rows, float dq_scale, void* stream);
+extern "C" int mv2d_dgrad_relu_f32x3(const float* g, const float* W, const float* relu_y, float alpha, float* dx, int M, int N, int K, void* stream);
 
 // the scalar arguments of both entries (mirrored by mv2d_amd/_lib.py: TdDims)
 struct mv2d_td_dims {
@@ -499,16 +500,16 @@ extern "C" int mv2d_train_decoder_bwd(const mv2d_td_dims* d, const float* const*
         const Drop d5 = mk_drop(d->p_ffn_out, site_seed(d->seed, l, 5));
         ln_bwd(a.s3, g0, g1, g2, P[N2_W], b.ds3, b.dyf, d5, b.part[0], b.part[1]);
         const float* dyf = d5.thr ? b.dyf : b.ds3;
-        TD_RC(mainl.dgrad(dyf, P[F2_W], b.dh, T, C, F, 0));
-        hipLaunchKernelGGL(relu_mask_scale_kernel, dim3(blocks4(TF)), dim3(256), 0, st, b.dh, a.h, TF / 4, d->p_ffn_act > 0.f ? 1.f / (1.f - d->p_ffn_act) : 1.f);
+        // dh = (dy W2) / keep rate where h > 0 (h = dropout(relu(.)) is positive exactly where the unit was active AND kept): mask in the epilogue
+        TD_RC(mv2d_dgrad_relu_f32x3(dyf, P[F2_W], a.h, d->p_ffn_act > 0.f ? 1.f / (1.f - d->p_ffn_act) : 1.f, b.dh, T, C, F, st));
         TD_RC(mainl.dgrad(b.dh, P[F1_W], b.dffn, T, F, C, 0));
         // ---- norm 1 and the cross attention (queries; the key pass goes to the side streams below)
         const Drop d3 = mk_drop(d->p_ca_out, site_seed(d->seed, l, 3));
         ln_bwd(a.s2, b.ds3, b.dffn, nullptr, P[N1_W], b.ds2, b.do2, d3, b.part[2], b.part[3]);
         const float* do2 = d3.thr ? b.do2 : b.ds2;
         TD_RC(mainl.dgrad(do2, P[CA_OW], b.dctx2, T, C, C, 0));
-        TD_RC(mv2d_sparse_xattn_bwd_drop(a.q_ca, a.K, a.V, ca_row_ptr, ca_col, a.ctx_ca, b.dctx2, ca_key_ptr, ca_pair_idx, ca_pair_row, b.pw_ca, b.dq2,
-                                         b.dK, b.dV, T, 0, d->p_ca_attn, site_seed(d->seed, l, 2), st));
+        TD_RC(mv2d_sparse_xattn_bwd_ex(a.q_ca, a.K, a.V, ca_row_ptr, ca_col, a.ctx_ca, b.dctx2, ca_key_ptr, ca_pair_idx, ca_pair_row, b.pw_ca, b.dq2,
+                                       b.dK, b.dV, T, 0, d->p_ca_attn, site_seed(d->seed, l, 2), 0, qs, st));
         // the key pass of the cross attention (dK, dV) and the projections behind it: side streams 1 (keys) and 2 (values)
         after(pl, st, side[1].st);
         TD_RC(mv2d_sparse_xattn_bwd_drop(a.q_ca, a.K, a.V, ca_row_ptr, ca_col, a.ctx_ca, b.dctx2, ca_key_ptr, ca_pair_idx, ca_pair_row, b.pw_ca, b.dq2,
@@ -519,7 +520,6 @@ extern "C" int mv2d_train_decoder_bwd(const mv2d_td_dims* d, const float* const*
         TD_RC(side[2].dgrad(b.dV, P[CA_W] + 2LL * C * C, d_val_in, S, C, C, first_kv ? 0 : 1));
         TD_RC(side[2].wgrad(b.dV, val_in, G[CA_W] + 2LL * C * C, G[CA_B] + 2 * C, S, C, C));
         first_kv = false;
-        hipLaunchKernelGGL(scale_kernel, dim3(blocks4(TC)), dim3(256), 0, st, b.dq2, TC / 4, qs);
         TD_RC(mainl.dgrad(b.dq2, P[CA_W], b.Q1, T, C, C, 0));
         // ---- norm 0 and the self attention
         const Drop d1 = mk_drop(d->p_sa_out, site_seed(d->seed, l, 1));
@@ -527,8 +527,7 @@ extern "C" int mv2d_train_decoder_bwd(const mv2d_td_dims* d, const float* const*
         const float* do1 = d1.thr ? b.do1 : b.ds1;
         TD_RC(mainl.dgrad(do1, P[SA_OW], b.dctx1, T, C, C, 0));
         TD_RC(mv2d_sparse_xattn_bwd_ex(a.q_sa, a.k_sa, a.v_sa, sa_row_ptr, sa_col, a.ctx_sa, b.dctx1, sa_key_ptr, sa_pair_idx, sa_pair_row, b.pw_sa,
-                                       b.dq1, b.dk1, b.dv1, T, T, d->p_sa_attn, site_seed(d->seed, l, 0), d->sa_nnz >= 64LL * T ? 1 : 0, st));
-        hipLaunchKernelGGL(scale_kernel, dim3(blocks4(TC)), dim3(256), 0, st, b.dq1, TC / 4, qs);
+                                       b.dq1, b.dk1, b.dv1, T, T, d->p_sa_attn, site_seed(d->seed, l, 0), d->sa_nnz >= 64LL * T ? 1 : 0, qs, st));
         // d(x + query_pos) of the q / k inputs; d x of the value input joins the post_norm gradient of the layer below
         TD_RC(mainl.dgrad(b.dq1, P[SA_W], b.A, T, C, C, 0));
         TD_RC(mainl.dgrad(b.dk1, P[SA_W] + (long long)C * C, b.A, T, C, C, 1));
@@ -690,11 +689,9 @@ extern "C" int mv2d_train_heads_bwd(const mv2d_th_dims* d, const float* const* p
         // regression branch
         const float* g4 = d_reg + (long long)l * T * NREG;
         TD_RC(ln.wgrad(g4, a.t2, G[R4_W], G[R4_B], T, NREG, C));
-        TD_RC(ln.dgrad(g4, P[R4_W], dt2, T, NREG, C, 0));
-        hipLaunchKernelGGL(relu_mask_scale_kernel, dim3(blocks4(TC)), dim3(256), 0, ln.st, dt2, a.t2, TC / 4, 1.f);
+        TD_RC(mv2d_dgrad_relu_f32x3(g4, P[R4_W], a.t2, 1.f, dt2, T, NREG, C, ln.st));
         TD_RC(ln.wgrad(dt2, a.t0, G[R2_W], G[R2_B], T, C, C));
-        TD_RC(ln.dgrad(dt2, P[R2_W], dt0, T, C, C, 0));
-        hipLaunchKernelGGL(relu_mask_scale_kernel, dim3(blocks4(TC)), dim3(256), 0, ln.st, dt0, a.t0, TC / 4, 1.f);
+        TD_RC(mv2d_dgrad_relu_f32x3(dt2, P[R2_W], a.t0, 1.f, dt0, T, C, C, ln.st));
         TD_RC(ln.wgrad(dt0, x, G[R0_W], G[R0_B], T, C, C));
         TD_RC(ln.dgrad(dt0, P[R0_W], dx, T, C, C, 1));
     }

@@ -265,19 +265,22 @@ class MV2DHead(nn.Module):
         # everything that enters an autograd Function is COPIED out of the engine's workspace: the next run() on the same bucket rewrites
         # those buffers through raw pointers (a second forward before backward(), an eval hook), which autograd's version counters cannot see
         row_ptr = ws['row_ptr'][:R + 1].clone()
-        nnz = int(row_ptr[R].item())
-        col = ws['col_idx'][:nnz].clone()
         # the input map, position-major, as a differentiable view: its gradient comes back through RoIAlign and the key rows
         V, _, h, w = feat.shape
         fm = feat.float().permute(0, 2, 3, 1).reshape(V * h * w, C)
         rois = ws['rois'][:R].clone()
         bbox_feats = ops.RoIAlignRows.apply(fm, None, rois, h, w)                                   # [R,49,256]
-        S = int(ws['S_dev'].item())
+        # reference points with the gradient of the query generator (issued before the first host read-back below: the host keeps
+        # launching while the engine's kernels run)
+        ref = train.query_generator_autograd(self, bbox_feats, ws['enc'][:R, 1024:1040].clone(), ws['minv'][:R].clone())
+        # ONE read-back for the data-dependent sizes: allowed pairs, listed positions, (T) whether a RoI has no key, (T) the key of position 0
+        empty = (row_ptr[1:] == row_ptr[:-1]).any().to(torch.int32) if self.KIND == 'T' else row_ptr.new_zeros(())
+        nnz, S, any_empty, s0 = (int(v) for v in torch.stack([row_ptr[R], ws['S_dev'].reshape(()).to(torch.int32), empty, ws['pos2s'][0].to(torch.int32)]).tolist())
+        col = ws['col_idx'][:nnz].clone()
         A1, A2, s2pos = ws['A1'][:S].clone(), ws['A2'][:S].clone(), ws['s2pos'][:S].long()
-        if self.KIND == 'T' and bool((row_ptr[1:] == row_ptr[:-1]).any().item()):
+        if self.KIND == 'T' and any_empty:
             # a RoI without a single visible key: in training the reference un-masks the key at map position (view 0, 0, 0) for it
             # (RH/mv2d_t_head.py:80-82) instead of producing a NaN row; that position joins the key list if no RoI lists it
-            s0 = int(ws['pos2s'][0].item())
             if s0 < 0:
                 a1, a2 = eng.pe_input_rows(ws, torch.zeros(1, dtype=torch.int32, device=fm.device), V, h, w)
                 A1, A2, s2pos, s0 = torch.cat([A1, a1]), torch.cat([A2, a2]), torch.cat([s2pos, s2pos.new_zeros(1)]), S
@@ -290,8 +293,6 @@ class MV2DHead(nn.Module):
             pe_aligned = ops.RoIAlignRows.apply(pe_rows, ws['pos2s'].clone(), rois, h, w, fm.detach())
             val_in = bbox_feats.reshape(R * 49, C)
             key_in = val_in + pe_aligned.reshape(R * 49, C)
-        # reference points with the gradient of the query generator
-        ref = train.query_generator_autograd(self, bbox_feats, ws['enc'][:R, 1024:1040].clone(), ws['minv'][:R].clone())
         ref_const, pad, single, md, keys = ws['ref'][:R].clone(), 0, 1, None, None
         if getattr(self, 'use_denoise', False):
             padded, _, md = train.prepare_for_dn(ref_const, gt, labels, self.denoise_scalar, self.denoise_noise_scale, self.denoise_noise_trans,

@@ -111,8 +111,13 @@ class HeadLoss:
         self.device = device
 
     def _layer_w(self, L, scale=1.0):
-        w = self.stage_loss_weights or [1.0] * L
-        return torch.tensor([float(x) * scale for x in w[:L]], dtype=torch.float32, device=self.device)
+        # (constants: uploaded once -- a tensor built from a Python list is a blocking host-to-device copy in every step)
+        key = (L, float(scale))
+        cache = self.__dict__.setdefault('_lw', {})
+        if key not in cache:
+            w = self.stage_loss_weights or [1.0] * L
+            cache[key] = torch.tensor([float(x) * scale for x in w[:L]], dtype=torch.float32, device=self.device)
+        return cache[key]
 
     def loss(self, all_cls_scores, all_bbox_preds, gt_bboxes, gt_labels, match=None):
         """all_cls_scores [L,R,C], all_bbox_preds [L,R,10] (one sample), gt_bboxes [G,9] gravity-centre boxes, gt_labels [G].
@@ -471,9 +476,12 @@ def query_generator_autograd(roi_head, roi_feat, intr_feat, minv):
     c = linear(x, qg.fc_center.weight, qg.fc_center.bias)
     hom = torch.cat([c[:, :2] * c[:, 2:3], c[:, 2:3], torch.ones_like(c[:, :1])], 1)
     xyz = (minv.detach().view(R, 4, 4) * hom[:, None, :]).sum(-1)[:, :3]                 # per-RoI 4x4 matrix . vector, element-wise (no BLAS call)
-    pr = [float(v) for v in roi_head.pc_range]
-    lo = xyz.new_tensor(pr[:3])
-    return (xyz - lo) / (xyz.new_tensor(pr[3:]) - lo)
+    rng = roi_head.__dict__.get('_qg_range')
+    if rng is None or rng[0].device != xyz.device:                      # (constants: uploaded once)
+        pr = [float(v) for v in roi_head.pc_range]
+        lo = xyz.new_tensor(pr[:3])
+        rng = roi_head.__dict__['_qg_range'] = (lo, xyz.new_tensor(pr[3:]) - lo)
+    return (xyz - rng[0]) / rng[1]
 
 
 def key_embedding_autograd(roi_head, A1, A2, Xf):

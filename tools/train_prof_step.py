@@ -34,7 +34,7 @@ gt, labels = [torch.from_numpy(gtc['gt'])], [torch.from_numpy(gtc['gt_labels'])]
 feat = torch.from_numpy(prob['feat']).to(dev).requires_grad_(True)
 props = [torch.from_numpy(p) for p in prob['proposals']]
 metas = [dict(m, box_type_3d=None) for m in prob['img_metas']]
-opt = torch.optim.AdamW([p for p in head.parameters() if p.requires_grad], lr=1e-6)
+opt = torch.optim.AdamW([p for p in head.parameters() if p.requires_grad], lr=1e-6, fused=True)      # (torch's single-kernel AdamW)
 
 
 def full_step():
