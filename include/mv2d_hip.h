@@ -605,6 +605,13 @@ int mv2d_train_heads_fwd(const mv2d_th_dims* d, const float* const* params, cons
 int mv2d_train_heads_bwd(const mv2d_th_dims* d, const float* const* params, float* const* grads, const float* outs, const float* d_cls,
                          const float* d_reg, const void* act, void* ws, float* d_outs, void* stream);
 
+/* Box code of all L intermediate outputs, forward and backward (RH/bbox_heads/cross_attention_head.py:216-238, RH/mv2d_t_head.py:136-140):
+ * out[0,1,4] = sigmoid(t[0,1,4] + inverse_sigmoid(ref)) * range + low; out[8,9] = t[8,9] / dt for the rows >= pad when dt != 0; the rest passes.
+ * t / out / g / d_t [L,T,10], ref / d_ref [T,3] (d_ref: summed over the layers; NULL = not wanted); pc_range: 6 HOST floats. */
+int mv2d_box_code_fwd(const float* t, const float* ref, float* out, int L, int T, int pad, float dt, const float* pc_range, void* stream);
+int mv2d_box_code_bwd(const float* g, const float* out, const float* ref, float* d_t, float* d_ref, int L, int T, int pad, float dt,
+                      const float* pc_range, void* stream);
+
 /* Backward of mv2d_roi_align w.r.t. one map (training; mmcv's roi_align backward): grad_out [R][49][256] fp32 ->
  * grad_map [rows][256] fp32, ACCUMULATED with hardware fp32 atomics (the caller zeroes it; the summation order varies between runs).
  * index (may be null): position -> row of a compacted map, negative = no row (as map1_index of the forward). */

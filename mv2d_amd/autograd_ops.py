@@ -343,3 +343,57 @@ class HeadsFn(torch.autograd.Function):
         check(lib.mv2d_train_heads_bwd(_lib.C.addressof(dims), _lib.C.addressof(ptrs), _lib.C.addressof(gptr), _p(outs), _p(d_cls), _p(d_reg), _p(act),
                                        _p(ws), _p(d_outs), _stream()), 'mv2d_train_heads_bwd')
         return (d_outs,) + tuple(grads)
+
+
+class BoxCodeFn(torch.autograd.Function):
+    """Raw code of all layers [L,T,10] + normalised reference points [T,3] -> boxes [L,T,10] (cross_attention_head.py:216-238,
+    RH/mv2d_t_head.py:136-140): ``mv2d_box_code_fwd`` / ``mv2d_box_code_bwd``, one launch each (the torch expression of rounds 3-4 was
+    ~12 element-wise launches forward and ~25 backward)."""
+
+    @staticmethod
+    def forward(ctx, t, ref, pc_range, pad, dt):
+        t, ref = _rows3(t), ref.float().contiguous()
+        L, T = t.shape[:2]
+        out = torch.empty_like(t)
+        rng = (_lib.C.c_float * 6)(*[float(v) for v in pc_range])
+        check(_lib.load().mv2d_box_code_fwd(_p(t), _p(ref), _p(out), L, T, int(pad), float(dt), _lib.C.addressof(rng), _stream()), 'mv2d_box_code_fwd')
+        ctx.save_for_backward(out, ref)
+        ctx.meta = (rng, int(pad), float(dt))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, ref = ctx.saved_tensors
+        rng, pad, dt = ctx.meta
+        L, T = out.shape[:2]
+        g = _rows3(g)
+        d_t = torch.empty_like(out)
+        d_ref = torch.empty_like(ref) if ctx.needs_input_grad[1] else None
+        check(_lib.load().mv2d_box_code_bwd(_p(g), _p(out), _p(ref), _p(d_t), _p(d_ref), L, T, pad, dt, _lib.C.addressof(rng), _stream()),
+              'mv2d_box_code_bwd')
+        return d_t, d_ref, None, None, None
+
+
+def _rows3(t):
+    return t if (t.dtype == F32 and t.is_contiguous()) else t.float().contiguous()
+
+
+class PosEmbFn(torch.autograd.Function):
+    """pos2posemb3d of the normalised reference points (MU/pe.py:20-33 as RH/bbox_heads/cross_attention_head.py:150-156 uses it) with the
+    gradient the query generator needs: forward ``mv2d_posemb3d`` (one launch), backward from the saved embedding --
+    d p = sum_k (g[2k] emb[2k+1] - g[2k+1] emb[2k]) 2 pi / dim_t[2k] per axis (sin' = cos, cos' = -sin)."""
+
+    @staticmethod
+    def forward(ctx, ref, dim_t):
+        emb = ops.posemb3d(ref.float().contiguous(), dim_t)
+        ctx.save_for_backward(emb, dim_t)
+        return emb
+
+    @staticmethod
+    def backward(ctx, g):
+        emb, dim_t = ctx.saved_tensors
+        T = emb.shape[0]
+        e, g = emb.view(T, 3, 64, 2), g.reshape(T, 3, 64, 2)
+        w = 6.283185307179586 / dim_t[0::2]
+        d = ((g[..., 0] * e[..., 1] - g[..., 1] * e[..., 0]) * w).sum(-1)            # [T, 3] in the embedding's axis order (y, x, z)
+        return torch.stack((d[:, 1], d[:, 0], d[:, 2]), 1), None

@@ -699,3 +699,96 @@ extern "C" int mv2d_train_heads_bwd(const mv2d_th_dims* d, const float* const* p
     for (int i = 0; i < NSIDE; ++i) after(pl, lane[1 + i].st, st);
     return MV2D_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Box code of every intermediate output (cross_attention_head.py:216-238; RH/mv2d_t_head.py:136-140), forward and backward:
+//   out[0,1,4] = sigmoid(t[0,1,4] + isig(ref)[0,1,2]) * range + low,  isig(x) = log(max(clamp(x, 0, 1), 1e-5) / max(1 - clamp(x, 0, 1), 1e-5));
+//   out[8,9] = t[8,9] / dt for the rows >= pad when dt != 0 (the denoising rows keep theirs); the other entries pass through.
+// The backward also returns the gradient w.r.t. the reference points (summed over the layers in fixed order): the query generator trains
+// through them.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct BoxRange { float lo[3], span[3]; };
+
+__device__ __forceinline__ float isig_f(float x) {
+    const float r = fminf(fmaxf(x, 0.f), 1.f);
+    return logf(fmaxf(r, 1e-5f) / fmaxf(1.f - r, 1e-5f));
+}
+
+__global__ __launch_bounds__(256) void box_code_fwd_kernel(const float* __restrict__ t, const float* __restrict__ ref, float* __restrict__ out, int L,
+                                                           int T, int pad, float dt, BoxRange rg) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= L * T) return;
+    const int r = i % T;
+    float v[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) v[k] = t[(long long)i * 10 + k];
+    const int col[3] = {0, 1, 4};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[col[k]] = 1.f / (1.f + expf(-(v[col[k]] + isig_f(ref[r * 3 + k])))) * rg.span[k] + rg.lo[k];
+    if (dt != 0.f && r >= pad) { v[8] = v[8] / dt; v[9] = v[9] / dt; }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) out[(long long)i * 10 + k] = v[k];
+}
+
+// d t (every layer) and, per row, d ref = sum over the layers of d z * d isig / d ref
+__global__ __launch_bounds__(256) void box_code_bwd_kernel(const float* __restrict__ g, const float* __restrict__ out, const float* __restrict__ ref,
+                                                           float* __restrict__ dt_out, float* __restrict__ dref, int L, int T, int pad, float dt,
+                                                           BoxRange rg) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= T) return;
+    float acc[3] = {0.f, 0.f, 0.f};
+    const int col[3] = {0, 1, 4};
+    for (int l = 0; l < L; ++l) {
+        const long long o = ((long long)l * T + r) * 10;
+        float v[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) v[k] = g[o + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float s = (out[o + col[k]] - rg.lo[k]) / rg.span[k];           // the sigmoid of the forward
+            v[col[k]] = v[col[k]] * rg.span[k] * s * (1.f - s);
+            acc[k] += v[col[k]];
+        }
+        if (dt != 0.f && r >= pad) { v[8] = v[8] / dt; v[9] = v[9] / dt; }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) dt_out[o + k] = v[k];
+    }
+    if (dref) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float x = ref[r * 3 + k];
+            float d = 0.f;
+            if (x > 0.f && x < 1.f) {                                           // clamp(x, 0, 1) passes the gradient inside the interval only
+                if (x > 1e-5f) d += 1.f / x;                                    // log(max(x, 1e-5))
+                if (1.f - x > 1e-5f) d += 1.f / (1.f - x);                      // -log(max(1 - x, 1e-5))
+            }
+            dref[r * 3 + k] = acc[k] * d;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mv2d_box_code_fwd(const float* t, const float* ref, float* out, int L, int T, int pad, float dt, const float* pc_range, void* stream) {
+    MV2D_CHECK_ARG(t && ref && out && pc_range && L > 0 && T >= 0, "mv2d_box_code_fwd: bad args");
+    if (T == 0) return MV2D_OK;
+    BoxRange rg;
+    for (int k = 0; k < 3; ++k) { rg.lo[k] = pc_range[k]; rg.span[k] = pc_range[3 + k] - pc_range[k]; }
+    hipLaunchKernelGGL(box_code_fwd_kernel, dim3(cdiv(L * T, 256)), dim3(256), 0, (hipStream_t)stream, t, ref, out, L, T, pad, dt, rg);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+// g: gradient of the boxes [L,T,10], out: the boxes of the forward -> d_t [L,T,10], d_ref [T,3] (NULL: not wanted)
+extern "C" int mv2d_box_code_bwd(const float* g, const float* out, const float* ref, float* d_t, float* d_ref, int L, int T, int pad, float dt,
+                                 const float* pc_range, void* stream) {
+    MV2D_CHECK_ARG(g && out && ref && d_t && pc_range && L > 0 && T >= 0, "mv2d_box_code_bwd: bad args");
+    if (T == 0) return MV2D_OK;
+    BoxRange rg;
+    for (int k = 0; k < 3; ++k) { rg.lo[k] = pc_range[k]; rg.span[k] = pc_range[3 + k] - pc_range[k]; }
+    hipLaunchKernelGGL(box_code_bwd_kernel, dim3(cdiv(T, 256)), dim3(256), 0, (hipStream_t)stream, g, out, ref, d_t, d_ref, L, T, pad, dt, rg);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}

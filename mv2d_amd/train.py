@@ -136,10 +136,11 @@ class HeadLoss:
         weighted = SetPredictionLoss.apply(all_cls_scores, all_bbox_preds, match, gt_bboxes, labels32, self.code_weights, lw,
                                            cls_avg, box_avg, self.alpha, self.gamma, self.w_cls, self.w_box, False)
         total = weighted.sum()
+        vals = weighted.reshape(-1).unbind(0)              # one autograd node for the 2 L entries (a select per entry is 2 L zero-filled gradients)
         losses = {}
         for l in range(L):
-            losses[f'l{l}.loss_cls'] = weighted[l, 0]
-            losses[f'l{l}.loss_bbox'] = weighted[l, 1]
+            losses[f'l{l}.loss_cls'] = vals[2 * l]
+            losses[f'l{l}.loss_bbox'] = vals[2 * l + 1]
         return losses, total, match
 
     def dn_loss(self, output_known_class, output_known_coord, known_bboxs, known_labels, num_tgt, split, neg_bbox_loss=False,
@@ -156,10 +157,11 @@ class HeadLoss:
                                            known_labels.to(self.device, torch.int32).contiguous(), self.dn_code_weights, lw,
                                            cls_avg, box_avg, self.alpha, self.gamma, self.w_cls, self.w_box, not neg_bbox_loss)
         total = weighted.sum()
+        vals = weighted.reshape(-1).unbind(0)
         losses = {}
         for l in range(L):
-            losses[f'l{l}.dn_loss_cls'] = weighted[l, 0]
-            losses[f'l{l}.dn_loss_bbox'] = weighted[l, 1]
+            losses[f'l{l}.dn_loss_cls'] = vals[2 * l]
+            losses[f'l{l}.dn_loss_bbox'] = vals[2 * l + 1]
         return losses, total
 
 
@@ -307,15 +309,15 @@ class TrainDecoder:
         P, T, dev = self.p, ref.shape[0], ref.device
         pre = 'bbox_head.transformer.decoder.'
         ref = ref.to(torch.float32)
-        dim_t = torch.arange(128, dtype=torch.float32)
-        dim_t = (10000 ** (2 * (dim_t // 2) / 128)).to(dev)                              # MU/pe.py:24-25, as mv2d_amd.calib builds it
-        if ref.requires_grad:                                                           # gradient into the query generator: pos2posemb3d in torch
-            def emb(p):
-                p = (p * (2 * math.pi))[..., None] / dim_t
-                return torch.stack((p[..., 0::2].sin(), p[..., 1::2].cos()), dim=-1).flatten(-2)
-            posemb = torch.cat((emb(ref[..., 1]), emb(ref[..., 0]), emb(ref[..., 2])), dim=-1)
+        if getattr(self, '_dim_t', None) is None or self._dim_t.device != dev:
+            dim_t = torch.arange(128, dtype=torch.float32)
+            self._dim_t = (10000 ** (2 * (dim_t // 2) / 128)).to(dev).contiguous()          # MU/pe.py:24-25, as mv2d_amd.calib builds it
+        dim_t = self._dim_t
+        if ref.requires_grad:                                                           # gradient into the query generator
+            from .autograd_ops import PosEmbFn
+            posemb = PosEmbFn.apply(ref, dim_t)
         else:
-            posemb = ops.posemb3d(ref.contiguous(), dim_t.contiguous())
+            posemb = ops.posemb3d(ref.contiguous(), dim_t)
         qpos = linear(linear(posemb, P['bbox_head.query_embedding.0.weight'], P['bbox_head.query_embedding.0.bias'], 1),
                       P['bbox_head.query_embedding.2.weight'], P['bbox_head.query_embedding.2.bias'])
         key_in, val_in = key_in.float(), val_in.float()
@@ -384,15 +386,12 @@ class TrainDecoder:
         from .autograd_ops import layer_norm, linear
         P, dev = self.p, ref.device
         ln = lambda t, n: layer_norm(t, P[n + '.weight'], P[n + '.bias'])  # noqa: E731
-        r = ref.clamp(0, 1)
-        inv = torch.log(r.clamp(min=1e-5) / (1 - r).clamp(min=1e-5))                 # inverse_sigmoid, mmdet
-        lo, hi = self.pc_range[:3], self.pc_range[3:]
         if torch.is_tensor(outs):
             # (round 5) all branches of all layers as one autograd node, the layers side by side on streams (mv2d_train_heads_fwd / _bwd)
             from .autograd_ops import BRANCH_PARAMS, HeadsFn
             bp = [P['bbox_head.' + n.format(l=l)] for l in range(self.L) for n in BRANCH_PARAMS]
             all_cls_t, t = HeadsFn.apply(outs, *[p if p.is_contiguous() else p.contiguous() for p in bp])
-            return all_cls_t, self._box_code(t, inv, lo, hi, pad, dt, dev)
+            return all_cls_t, self._box_code(t, ref, pad, dt)
         all_cls, ts = [], []
         for l in range(self.L):
             c, g = f'bbox_head.cls_branches.{l}.', f'bbox_head.reg_branches.{l}.'
@@ -401,20 +400,12 @@ class TrainDecoder:
             all_cls.append(linear(y, P[c + '6.weight'], P[c + '6.bias']))
             t = linear(outs[l], P[g + '0.weight'], P[g + '0.bias'], 1)
             ts.append(linear(linear(t, P[g + '2.weight'], P[g + '2.bias'], 1), P[g + '4.weight'], P[g + '4.bias']))
-        return torch.stack(all_cls), self._box_code(torch.stack(ts), inv, lo, hi, pad, dt, dev)
+        return torch.stack(all_cls), self._box_code(torch.stack(ts), ref, pad, dt)
 
-    def _box_code(self, t, inv, lo, hi, pad, dt, dev):
-        """raw code [L,T,10] -> boxes (cross_attention_head.py:219-233; element-wise the same expressions as per layer)"""
-        if getattr(self, '_range_dev', None) != dev:                                    # (constants: uploaded once)
-            self._range_dev = dev
-            self._span = torch.tensor([hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]], device=dev)
-            self._low = torch.tensor(lo, device=dev)
-        span, low = self._span, self._low
-        cxyz = (torch.cat([t[..., 0:2], t[..., 4:5]], -1) + inv).sigmoid() * span + low     # (an index LIST would be uploaded per call: a blocking copy)
-        vel = t[..., 8:10]
-        if dt:
-            vel = torch.cat([vel[:, :pad], vel[:, pad:] / dt], 1)
-        return torch.cat([cxyz[..., 0:2], t[..., 2:4], cxyz[..., 2:3], t[..., 5:8], vel], -1)
+    def _box_code(self, t, ref, pad, dt):
+        """raw code [L,T,10] -> boxes (cross_attention_head.py:219-233): one launch per direction (autograd_ops.BoxCodeFn)"""
+        from .autograd_ops import BoxCodeFn
+        return BoxCodeFn.apply(t, ref, self.pc_range, pad, float(dt or 0.0))
 
 
 def allreduce_gradients(parameters, bucket_bytes=256 << 20, average=True, group=None):

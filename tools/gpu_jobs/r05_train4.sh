@@ -1,5 +1,5 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05t9; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05t13; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/tools/train_prof_step.py > $O/step_plain.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats -o s -- python $R/tools/train_prof_step.py > $O/step_under_rocprof.json 2>/dev/null
