@@ -653,9 +653,11 @@ def sparse_xattn_bwd(q, K, V, row_ptr, col_idx, ctx, dctx, R=None, transposed=No
     dK = torch.empty((S, 256), device=q.device, dtype=torch.float32)
     dV = torch.empty((S, 256), device=q.device, dtype=torch.float32)
     pair_ws = torch.empty((max(nnz, 1), 16), device=q.device, dtype=torch.float32)
-    check(_lib.load().mv2d_sparse_xattn_bwd_drop(_p(q), _p(K), _p(V), _p(row_ptr), _p(col_idx), _p(ctx), _p(dctx.contiguous()), _p(key_ptr), _p(pair_idx),
-                                                 _p(pair_row), _p(pair_ws), _p(dq), _p(dK), _p(dV), R, S, float(p_drop), int(seed) & 0xffffffff, _stream()),
-          'mv2d_sparse_xattn_bwd')
+    # hundreds of keys per query and of queries per key (the self attention over [denoising | matched] queries): the long-row kernels
+    long_rows = 1 if (nnz >= 64 * max(R, 1) and nnz >= 64 * max(S, 1)) else 0
+    check(_lib.load().mv2d_sparse_xattn_bwd_ex(_p(q), _p(K), _p(V), _p(row_ptr), _p(col_idx), _p(ctx), _p(dctx.contiguous()), _p(key_ptr), _p(pair_idx),
+                                               _p(pair_row), _p(pair_ws), _p(dq), _p(dK), _p(dV), R, S, float(p_drop), int(seed) & 0xffffffff, long_rows,
+                                               1.0, _stream()), 'mv2d_sparse_xattn_bwd')
     return dq, dK, dV
 
 

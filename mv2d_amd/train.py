@@ -353,7 +353,8 @@ class TrainDecoder:
                 y = dl(y) if dl is not None else y
             x = ln(x + y, lp + 'norms.2')
             outs.append(ln(x, pre + 'post_norm'))
-        return self._branches(outs, ref, pad, dt)
+        # (with denoising queries the layers stay on the per-operator graph -- their dense block is not in the C entry -- the branches need not)
+        return self._branches(torch.stack(outs) if self.fused else outs, ref, pad, dt)
 
     def _sa_pattern(self, T, pad, single, dev):
         """the self-attention pattern and its transpose: a function of (T, pad, single) only, kept between steps"""
