@@ -281,6 +281,8 @@ class DecoderFn(torch.autograd.Function):
         ws = torch.empty(int(lib.mv2d_train_decoder_ws_bytes(_lib.C.byref(dims), 1)), device=dev, dtype=torch.uint8)
         d_qpos, d_key, d_val = torch.empty_like(qpos), torch.empty_like(key_in), torch.empty_like(val_in)
         sa, sa_t, ca, ca_t = meta['sa'], meta['sa_t'], meta['ca'], meta['ca_t']
+        if ca_t is None:
+            ca_t = ops.csr_transpose(ca[0], ca[1], key_in.shape[0])
         check(lib.mv2d_train_decoder_bwd(_lib.C.addressof(dims), _lib.C.addressof(ptrs), _lib.C.addressof(gptr), _p(qpos), _p(key_in), _p(val_in),
                                          _p(sa[0]), _p(sa[1]), _p(sa_t[0]), _p(sa_t[1]), _p(sa_t[2]), _p(ca[0]), _p(ca[1]), _p(ca_t[0]), _p(ca_t[1]),
                                          _p(ca_t[2]), _p(d_outs), _p(act), _p(ws), _p(d_qpos), _p(d_key), _p(d_val), _stream()),

@@ -324,10 +324,12 @@ class TrainDecoder:
         S = key_in.shape[0]
         sa, sa_t = self._sa_pattern(T, pad, single, dev)
         ca = (row_ptr.contiguous(), col_idx.contiguous())
-        ca_t = ops.csr_transpose(ca[0], ca[1], S)
+        use_c = self.fused and dn_keys is None
+        # the pattern grouped by key is only read by the backward: the C route builds it there (the backward has host time to spare)
+        ca_t = None if use_c else ops.csr_transpose(ca[0], ca[1], S)
         ln = lambda t, n: layer_norm(t, P[n + '.weight'], P[n + '.bias'])  # noqa: E731      (mv2d_row_ln / mv2d_layer_norm_bwd)
         training = self.layers is not None and self.roi_head.training
-        if self.fused and dn_keys is None:
+        if use_c:
             # (round 5) the six layers + post_norm as one autograd node, launch sequences issued from C (csrc/train_decoder.hip)
             outs = self._fused_layers(qpos, key_in, val_in, sa, sa_t, ca, ca_t, training)
             return self._branches(outs, ref, pad, dt)
