@@ -612,6 +612,13 @@ int mv2d_box_code_fwd(const float* t, const float* ref, float* out, int L, int T
 int mv2d_box_code_bwd(const float* g, const float* out, const float* ref, float* d_t, float* d_ref, int L, int T, int pad, float dt,
                       const float* pc_range, void* stream);
 
+/* HOST function (no device work): the linear sum assignment of HungarianAssigner3D for all decoder layers of a step
+ * (mmdet3d_plugin/core/bbox/assigners/hungarian_assigner_3d.py:137 calls scipy.optimize.linear_sum_assignment per layer): the same
+ * shortest-augmenting-path algorithm (Crouse 2016) with the same scan order and tie rule, one host thread per layer (threads <= 0) or
+ * `threads` threads.  cost [L,R,G] fp32 and match [L,R] int32 are host pointers; match = assigned box or -1.  An error for NaN / -inf costs
+ * or an infeasible problem (SciPy raises there). */
+int mv2d_lsap_layers(const float* cost, int L, int R, int G, int* match, int threads);
+
 /* Backward of mv2d_roi_align w.r.t. one map (training; mmcv's roi_align backward): grad_out [R][49][256] fp32 ->
  * grad_map [rows][256] fp32, ACCUMULATED with hardware fp32 atomics (the caller zeroes it; the summation order varies between runs).
  * index (may be null): position -> row of a compacted map, negative = no row (as map1_index of the forward). */
