@@ -556,6 +556,10 @@ int mv2d_gemm_f32x3_ex(const float* A, long long lda, int trans_a, const float* 
 int mv2d_colsum_add(const float* x, long long ld, int rows, int cols, float* out, float* scratch, const float* add, void* stream);
 /* dW [N,K] = g^T x and db [N] = column sums of g (g [M,N], x [M,K] dense rows) -- db inside the product's kernel when it runs in one pass, a
  * separate column sum after a split-K product (cs_scratch: [mv2d_colsum_scratch_rows(M), N] floats or NULL). */
+/* `batch` products of one shape in one launch: C_b [M, ldc] = op(A_b) op(B_b)^T, X_b = X + b * batch_x elements (the per-head products of a dense
+ * attention block: head b = a 32-column slice of [rows, 256] operands).  One pass over K, no bias / activation. */
+int mv2d_gemm_f32x3_batched(const float* A, long long lda, long long batch_a, int trans_a, const float* B, long long ldb, long long batch_b, int trans_b,
+                            float* C, long long ldc, long long batch_c, int M, int N, int K, int batch, void* stream);
 /* dx [M,K] = (g [M,N] W [N,K]) * alpha, zeroed where relu_y [M,K] <= 0 (NULL: no mask) -- the ReLU (+ dropout scale) of the forward applied to the
  * input gradient in the product's epilogue. */
 int mv2d_dgrad_relu_f32x3(const float* g, const float* W, const float* relu_y, float alpha, float* dx, int M, int N, int K, void* stream);

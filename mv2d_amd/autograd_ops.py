@@ -399,3 +399,55 @@ class PosEmbFn(torch.autograd.Function):
         w = 6.283185307179586 / dim_t[0::2]
         d = ((g[..., 0] * e[..., 1] - g[..., 1] * e[..., 0]) * w).sum(-1)            # [T, 3] in the embedding's axis order (y, x, z)
         return torch.stack((d[:, 1], d[:, 0], d[:, 2]), 1), None
+
+
+def _bgemm(A, lda, sa, ta, B, ldb, sb, tb, C, ldc, sc, M, N, K, batch):
+    check(_lib.load().mv2d_gemm_f32x3_batched(_p(A), lda, sa, 1 if ta else 0, _p(B), ldb, sb, 1 if tb else 0, _p(C), ldc, sc, M, N, K, batch, _stream()),
+          'mv2d_gemm_f32x3_batched')
+
+
+class DenseHeadsAttnFn(torch.autograd.Function):
+    """The denoising rows of the cross attention (RH/mv2d_t_head.py:90-98: they see every key some RoI sees -- a DENSE block): for H heads of
+    width d, ctx = dropout(softmax(q_h k_h^T)) v_h with q [n, H d] (pre-scaled), k / v [nk, H d].  The five per-head products of forward and
+    backward are ONE batched launch each (``mv2d_gemm_f32x3_batched``: head b = a d-column slice, batch stride d, row stride H d); softmax /
+    dropout / the softmax backward are element-wise torch kernels over [H, n, nk].  Rounds 3-4 looped over the heads in Python."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, H, p_drop):
+        import torch.nn.functional as Fnn
+        q, k, v = _rows3(q), _rows3(k), _rows3(v)
+        n, Cc = q.shape
+        nk, d = k.shape[0], Cc // H
+        nkp = (nk + 3) & ~3                        # rows of the [H, n, nk] matrices padded to 16 bytes (vector loads in the products); the pad
+        S = torch.empty((H, n, nkp), device=q.device, dtype=F32)      # columns hold -inf logits = zero probabilities
+        if nkp > nk:
+            S[..., nk:] = float('-inf')
+        _bgemm(q, Cc, d, False, k, Cc, d, False, S, nkp, n * nkp, n, nk, d, H)                     # logits_h = q_h k_h^T
+        P = torch.softmax(S, -1)
+        Pd = Fnn.dropout(P, p_drop, True) if p_drop > 0 else P
+        out = torch.empty((n, Cc), device=q.device, dtype=F32)
+        _bgemm(Pd, nkp, n * nkp, False, v, Cc, d, True, out, Cc, d, n, d, nk, H)                   # ctx_h = Pd_h v_h  (B = v_h^T read transposed)
+        ctx.save_for_backward(q, k, v, P, Pd)
+        ctx.meta = (H, float(p_drop))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, P, Pd = ctx.saved_tensors
+        H, p_drop = ctx.meta
+        n, Cc = q.shape
+        nk, d = k.shape[0], Cc // H
+        nkp = P.shape[-1]
+        g = _rows3(g)
+        dP = torch.empty((H, n, nkp), device=q.device, dtype=F32)
+        if nkp > nk:
+            dP[..., nk:] = 0.0
+        _bgemm(g, Cc, d, False, v, Cc, d, False, dP, nkp, n * nkp, n, nk, d, H)                    # dPd_h = g_h v_h^T
+        if p_drop > 0:
+            dP = dP * ((Pd != 0).to(F32) / (1.0 - p_drop))                                         # (a kept probability that is exactly 0 has dS = 0 anyway)
+        dS = P * (dP - (dP * P).sum(-1, keepdim=True))
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        _bgemm(dS, nkp, n * nkp, False, k, Cc, d, True, dq, Cc, d, n, d, nk, H)                    # dq_h = dS_h k_h
+        _bgemm(dS, nkp, n * nkp, True, q, Cc, d, True, dk, Cc, d, nk, d, n, H)                     # dk_h = dS_h^T q_h
+        _bgemm(Pd, nkp, n * nkp, True, g, Cc, d, True, dv, Cc, d, nk, d, n, H)                     # dv_h = Pd_h^T g_h
+        return dq, dk, dv, None, None

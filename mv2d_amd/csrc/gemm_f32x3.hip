@@ -40,6 +40,7 @@ struct FxParams {
     int accumulate;             // C += ... (one-pass products only; the split-K slabs are summed onto C by the caller's column sum)
     int out_bf16;               // C holds bf16 (the keys / values the sparse attention kernels read)
     const float* relu_y;        // fp32 [M, ldc] or NULL: C = relu_y > 0 ? value : 0 (the ReLU of the forward applied to a gradient)
+    long long batch_a, batch_b, batch_c;   // element strides of blockIdx.z (a batch of products with the same shape: the heads of an attention)
     float* rowsum;              // trans_a products in one pass: rowsum[m] = sum_k opA[m, k] (the bias gradient next to dW = g^T x), or NULL
 };
 
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(256) void gemm_f32x3_kernel(FxParams p) {
     unsigned char *Ah = smem, *Al = smem + IMG, *Bh = smem + 2 * IMG, *Bl = smem + 3 * IMG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;
+    p.A += blockIdx.z * p.batch_a; p.B += blockIdx.z * p.batch_b; p.C += blockIdx.z * p.batch_c;
     const int n_tiles = (p.N + BN - 1) / BN;
     const int m0 = (blockIdx.x / n_tiles) * BM, n0 = (blockIdx.x % n_tiles) * BN;
     const int nk_all = (p.K + BK - 1) / BK;
@@ -282,6 +284,32 @@ extern "C" int mv2d_dgrad_relu_f32x3(const float* g, const float* W, const float
     return gemm_f32x3_impl(g, N, 0, W, K, 1, nullptr, 0, alpha, 0, 0, dx, K, M, K, N, nullptr, 0, nullptr, relu_y, stream);
 }
 
+// `batch` products of one shape in one launch (blockIdx.z): C_b [M, ldc] = op(A_b) op(B_b)^T with A_b = A + b * batch_a (elements), likewise B_b, C_b
+// -- the per-head products of a dense attention block (head b = a 32-column slice of [rows, 256] operands: batch stride 32, row stride 256).
+// One pass over K (no split-K, no bias / activation).
+extern "C" int mv2d_gemm_f32x3_batched(const float* A, long long lda, long long batch_a, int trans_a, const float* B, long long ldb, long long batch_b,
+                                       int trans_b, float* C, long long ldc, long long batch_c, int M, int N, int K, int batch, void* stream) {
+    MV2D_CHECK_ARG(A && B && C && M >= 0 && N > 0 && K > 0 && batch >= 1 && batch <= 65535, "mv2d_gemm_f32x3_batched: bad args");
+    if (M == 0) return MV2D_OK;
+    FxParams p;
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.bias = nullptr; p.M = M; p.N = N; p.K = K; p.act = 0; p.alpha = 1.f; p.out_bf16 = 0; p.rowsum = nullptr;
+    p.relu_y = nullptr; p.accumulate = 0; p.batch_a = batch_a; p.batch_b = batch_b; p.batch_c = batch_c;
+    p.k_tiles_per_split = cdiv(K, BK); p.C = C; p.ldc = ldc; p.c_split_stride = 0;
+    const dim3 grid(cdiv(M, BM) * cdiv(N, BN), 1, batch);
+    hipStream_t st = (hipStream_t)stream;
+    const bool deep = (long long)grid.x * batch <= 512;
+#define MV2D_FX_LAUNCH(TA_, TB_) do { \
+        if (deep) hipLaunchKernelGGL((gemm_f32x3_kernel<TA_, TB_, 4>), grid, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((gemm_f32x3_kernel<TA_, TB_, 1>), grid, dim3(256), 0, st, p); } while (0)
+    if (trans_a && trans_b) MV2D_FX_LAUNCH(true, true);
+    else if (trans_a) MV2D_FX_LAUNCH(true, false);
+    else if (trans_b) MV2D_FX_LAUNCH(false, true);
+    else MV2D_FX_LAUNCH(false, false);
+#undef MV2D_FX_LAUNCH
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
 // Weight + bias gradient of a linear layer in one call: dW [N,K] = g^T x (g [M,N], x [M,K] dense rows) and db [N] = column sums of g -- inside the
 // product's kernel when it runs in one pass (rows of op(A) = g^T summed by the blocks of the first column tile, fixed order), as a
 // separate mv2d_colsum after a split-K product (many rows).  cs_scratch: [mv2d_colsum_scratch_rows(M), N] floats or NULL.
@@ -305,7 +333,7 @@ static int gemm_f32x3_impl(const float* A, long long lda, int trans_a, const flo
     int splits = (out_bf16 || relu_y) ? 1 : fx_splits(M, N, K, act);
     if (splits > 1 && (ldc != N || !ws || ws_bytes < mv2d_gemm_f32x3_ws_bytes(M, N, K) || ((uintptr_t)ws & 255) != 0)) splits = 1;   // no slabs: one pass
     FxParams p;
-    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.bias = bias; p.M = M; p.N = N; p.K = K; p.act = act; p.alpha = alpha; p.out_bf16 = out_bf16; p.rowsum = rowsum; p.relu_y = relu_y;
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.bias = bias; p.M = M; p.N = N; p.K = K; p.act = act; p.alpha = alpha; p.out_bf16 = out_bf16; p.rowsum = rowsum; p.relu_y = relu_y; p.batch_a = p.batch_b = p.batch_c = 0;
     const int nk = cdiv(K, BK);
     p.k_tiles_per_split = cdiv(nk, splits);
     splits = cdiv(nk, p.k_tiles_per_split);                 // (no empty split)

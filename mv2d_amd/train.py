@@ -297,13 +297,17 @@ class TrainDecoder:
         q, k, v = in_proj(q_in, k_in, v_in, w, b, 1.0 / (Cc // self.H) ** 0.5)       # one autograd node: dW / db land in one [3C, C] / [3C] buffer
         if dense is not None and dense[0] > 0:
             n, keys = dense
-            H, d = self.H, Cc // self.H
             kd, vd = k[keys], v[keys]
-            tops = []
-            for h in range(H):                  # the dense denoising block per head: logits and P V as HIP products, softmax / dropout element-wise
-                sl = slice(h * d, (h + 1) * d)
-                prob = F.dropout(torch.softmax(matmul_nt_ad(q[:n, sl].contiguous(), kd[:, sl].contiguous()), -1), p_attn, p_attn > 0)
-                tops.append(matmul_nt_ad(prob, vd[:, sl].t().contiguous()))
+            if self.fused:
+                from .autograd_ops import DenseHeadsAttnFn
+                tops = [DenseHeadsAttnFn.apply(q[:n], kd, vd, self.H, p_attn)]       # all heads: one batched launch per product (round 5)
+            else:
+                H, d = self.H, Cc // self.H
+                tops = []
+                for h in range(H):                  # the dense denoising block per head: logits and P V as HIP products, softmax / dropout element-wise
+                    sl = slice(h * d, (h + 1) * d)
+                    prob = F.dropout(torch.softmax(matmul_nt_ad(q[:n, sl].contiguous(), kd[:, sl].contiguous()), -1), p_attn, p_attn > 0)
+                    tops.append(matmul_nt_ad(prob, vd[:, sl].t().contiguous()))
             ctx = torch.cat([torch.cat(tops, 1), ops.SparseCrossAttention.apply(q[n:], k, v, csr[0], csr[1], False, tr, p_attn, self._next_seed(p_attn))])
         else:
             ctx = ops.SparseCrossAttention.apply(q, k, v, csr[0], csr[1], False, tr, p_attn, self._next_seed(p_attn))

@@ -695,7 +695,7 @@ def test_sparse_attention_probability_dropout_forward_backward(p_drop):
 
 
 # ---- round 5: decoder + branches issued from C (csrc/train_decoder.hip: mv2d_train_decoder_* / mv2d_train_heads_*) -------------------------
-def _captured_decoder_call(prob_name, kind, train_mode=False):
+def _captured_decoder_call(prob_name, kind, train_mode=False, denoise=False):
     """A head on a synthetic problem and the arguments its ``TrainDecoder`` received in one forward_train (no denoising queries)."""
     from mv2d_amd import registry, train
     import mv2d_amd.plugin  # noqa: F401
@@ -703,6 +703,7 @@ def _captured_decoder_call(prob_name, kind, train_mode=False):
     cfg = configs.roi_head_cfg_s() if kind == 'S' else configs.roi_head_cfg_t()
     if kind == 'T':
         cfg['num_views'] = prob['views_per_frame']
+        cfg['use_denoise'] = denoise
     head = registry.build_head(cfg, train_cfg=configs.TRAIN_CFG_RCNN, test_cfg=configs.TEST_CFG_RCNN)
     head.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_head_state(seed=0).items()}, strict=False)
     head = head.to(DEV)
@@ -768,6 +769,21 @@ def test_decoder_issued_from_c_equals_the_operator_graph(prob_name, kind):
     assert worst[0] <= 1e-4, worst
 
 
+def test_denoising_rows_batched_dense_block_equals_the_per_head_loop():
+    """With denoising queries (the two-frame head's training recipe) the layers stay on the per-operator graph, but their dense block runs
+    all heads in one batched launch per product and the branches come from the C entry: the same outputs (softmax over a padded row: a few
+    ulp) and gradients (by norm: a ReLU unit within rounding of zero may switch) as the per-head loop of rounds 3-4."""
+    head, a, k = _captured_decoder_call('cfg1_t', 'T', denoise=True)
+    assert k.get('dn_keys') is not None
+    cls0, reg0, g0, g, _ = _decoder_outputs_and_grads(head, a, k, False)
+    cls1, reg1, g1, _, _ = _decoder_outputs_and_grads(head, a, k, True, g)
+    assert float((cls1 - cls0).abs().max()) <= 2e-5 * float(cls0.abs().max()) and float((reg1 - reg0).abs().max()) <= 2e-5 * float(reg0.abs().max())
+    top = max(float(v.norm()) for n, v in g0.items() if n not in ('key_in', 'val_in', 'ref'))
+    errs = {n: float((g1[n] - v).norm()) / float(v.norm()) for n, v in g0.items() if float(v.norm()) >= 1e-5 * top}
+    worst = max(errs.items(), key=lambda t: t[1])
+    assert worst[1] <= 5e-2 and sorted(errs.values())[len(errs) // 2] <= 2e-3, (worst, sorted(errs.values())[len(errs) // 2])
+
+
 def test_decoder_issued_from_c_dropout_masks_of_forward_and_backward_agree():
     """Training mode (dropout 0.1 on the attention probabilities, both attentions' output paths and twice in the FFN -- configs/mv2d/exp/*:67-79):
     the backward regenerates the masks of the forward from (seed, layer, site, element).  With the mask counter pinned, f is a fixed
@@ -804,3 +820,32 @@ def test_decoder_issued_from_c_dropout_masks_of_forward_and_backward_agree():
     cls_e, _, _, _, _ = run(0)
     cls_f, _, _, _, _ = run(5)
     assert torch.equal(cls_e, cls_f) and not torch.equal(cls_e, cls_a)
+
+
+@pytest.mark.parametrize('n,nk,p', [(37, 203, 0.0), (400, 1501, 0.0), (64, 128, 0.25)])
+def test_dense_block_of_the_denoising_rows_batched_over_heads(n, nk, p):
+    """DenseHeadsAttnFn (one batched launch per product, mv2d_gemm_f32x3_batched) against fp64 torch attention per head: output and the
+    gradients of q, k, v; with dropout the mask is read back from the saved probabilities (kept = non-zero), so the backward sees the
+    forward's mask."""
+    from mv2d_amd.autograd_ops import DenseHeadsAttnFn
+    g = torch.Generator(device='cpu').manual_seed(n + nk)
+    q, k, v, go = (torch.randn(r, 256, generator=g).to(DEV) for r in (n, nk, nk, n))
+    q = q * 0.3
+    qa, ka, va = (t.clone().requires_grad_(True) for t in (q, k, v))
+    torch.manual_seed(5)
+    out = DenseHeadsAttnFn.apply(qa, ka, va, 8, p)
+    out.backward(go)
+    qd, kd, vd = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    S = torch.einsum('nhd,mhd->hnm', qd.view(n, 8, 32), kd.view(nk, 8, 32))
+    P = torch.softmax(S, -1)
+    if p > 0:
+        # the mask of the run above: regenerate it with the same seed on the same shape (padded to a multiple of 4 columns)
+        torch.manual_seed(5)
+        nkp = (nk + 3) & ~3
+        keep = (torch.nn.functional.dropout(torch.ones(8, n, nkp, device=DEV), p, True) != 0)[..., :nk].double()
+        P = P * keep / (1 - p)
+    ref = torch.einsum('hnm,mhd->nhd', P, vd.view(nk, 8, 32)).reshape(n, 256)
+    ref.backward(go.double())
+    for got, want, name in ((out, ref, 'out'), (qa.grad, qd.grad, 'dq'), (ka.grad, kd.grad, 'dk'), (va.grad, vd.grad, 'dv')):
+        err = float((got.double() - want).abs().max() / want.abs().max())
+        assert err < 1e-4, (name, err)
