@@ -557,9 +557,14 @@ int mv2d_colsum_add(const float* x, long long ld, int rows, int cols, float* out
 /* dW [N,K] = g^T x and db [N] = column sums of g (g [M,N], x [M,K] dense rows) -- db inside the product's kernel when it runs in one pass, a
  * separate column sum after a split-K product (cs_scratch: [mv2d_colsum_scratch_rows(M), N] floats or NULL). */
 /* `batch` products of one shape in one launch: C_b [M, ldc] = op(A_b) op(B_b)^T, X_b = X + b * batch_x elements (the per-head products of a dense
- * attention block: head b = a 32-column slice of [rows, 256] operands).  One pass over K, no bias / activation. */
+ * attention block: head b = a 32-column slice of [rows, 256] operands).  No bias / activation.  ws (16-byte aligned,
+ * mv2d_gemm_f32x3_batched_ws_bytes; NULL = one pass): split-K slabs for few output tiles with a long contraction, summed in fixed order. */
+/* Softmax backward of a dense attention block, in place: dP [rows, ld] (first cols columns) <- P * (dP m - rowsum(P dP m)), m = keep_scale where the
+ * dropped probabilities Pd are non-zero, 0 elsewhere (Pd == P: no dropout). */
+int mv2d_softmax_bwd_rows(const float* P, const float* Pd, float* dP, long long ld, int rows, int cols, float keep_scale, void* stream);
+long long mv2d_gemm_f32x3_batched_ws_bytes(int M, int N, int K, int batch);
 int mv2d_gemm_f32x3_batched(const float* A, long long lda, long long batch_a, int trans_a, const float* B, long long ldb, long long batch_b, int trans_b,
-                            float* C, long long ldc, long long batch_c, int M, int N, int K, int batch, void* stream);
+                            float* C, long long ldc, long long batch_c, int M, int N, int K, int batch, void* ws, long long ws_bytes, void* stream);
 /* dx [M,K] = (g [M,N] W [N,K]) * alpha, zeroed where relu_y [M,K] <= 0 (NULL: no mask) -- the ReLU (+ dropout scale) of the forward applied to the
  * input gradient in the product's epilogue. */
 int mv2d_dgrad_relu_f32x3(const float* g, const float* W, const float* relu_y, float alpha, float* dx, int M, int N, int K, void* stream);

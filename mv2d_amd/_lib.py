@@ -114,7 +114,9 @@ SIGNATURES = {
     'mv2d_gemm_f32x3': (I, [P, LL, I, P, LL, I, P, I, P, LL, I, I, I, P, LL, P]),
     'mv2d_gemm_f32x3_ex': (I, [P, LL, I, P, LL, I, P, I, F, I, I, P, LL, I, I, I, P, LL, P]),
     'mv2d_colsum_add': (I, [P, LL, I, I, P, P, P, P]),
-    'mv2d_gemm_f32x3_batched': (I, [P, LL, LL, I, P, LL, LL, I, P, LL, LL, I, I, I, I, P]),
+    'mv2d_softmax_bwd_rows': (I, [P, P, P, LL, I, I, F, P]),
+    'mv2d_gemm_f32x3_batched_ws_bytes': (LL, [I, I, I, I]),
+    'mv2d_gemm_f32x3_batched': (I, [P, LL, LL, I, P, LL, LL, I, P, LL, LL, I, I, I, I, P, LL, P]),
     'mv2d_wgrad_f32x3': (I, [P, P, P, P, I, I, I, P, LL, P, P]),
     'mv2d_train_decoder_act_bytes': (LL, [P]),
     'mv2d_train_decoder_ws_bytes': (LL, [P, I]),

@@ -402,8 +402,11 @@ class PosEmbFn(torch.autograd.Function):
 
 
 def _bgemm(A, lda, sa, ta, B, ldb, sb, tb, C, ldc, sc, M, N, K, batch):
-    check(_lib.load().mv2d_gemm_f32x3_batched(_p(A), lda, sa, 1 if ta else 0, _p(B), ldb, sb, 1 if tb else 0, _p(C), ldc, sc, M, N, K, batch, _stream()),
-          'mv2d_gemm_f32x3_batched')
+    lib = _lib.load()
+    nb = int(lib.mv2d_gemm_f32x3_batched_ws_bytes(M, N, K, batch))
+    ws = _workspace(nb, A.device) if nb else None
+    check(lib.mv2d_gemm_f32x3_batched(_p(A), lda, sa, 1 if ta else 0, _p(B), ldb, sb, 1 if tb else 0, _p(C), ldc, sc, M, N, K, batch, _p(ws),
+                                      ws.numel() if ws is not None else 0, _stream()), 'mv2d_gemm_f32x3_batched')
 
 
 class DenseHeadsAttnFn(torch.autograd.Function):
@@ -440,12 +443,11 @@ class DenseHeadsAttnFn(torch.autograd.Function):
         nkp = P.shape[-1]
         g = _rows3(g)
         dP = torch.empty((H, n, nkp), device=q.device, dtype=F32)
-        if nkp > nk:
-            dP[..., nk:] = 0.0
         _bgemm(g, Cc, d, False, v, Cc, d, False, dP, nkp, n * nkp, n, nk, d, H)                    # dPd_h = g_h v_h^T
-        if p_drop > 0:
-            dP = dP * ((Pd != 0).to(F32) / (1.0 - p_drop))                                         # (a kept probability that is exactly 0 has dS = 0 anyway)
-        dS = P * (dP - (dP * P).sum(-1, keepdim=True))
+        # dS = P (dP m - rowsum(P dP m)), m = the dropout mask read back from Pd (a kept probability that is exactly 0 has dS = 0 anyway): one launch, in place
+        check(_lib.load().mv2d_softmax_bwd_rows(_p(P), _p(Pd), _p(dP), nkp, H * n, nk, 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0, _stream()),
+              'mv2d_softmax_bwd_rows')
+        dS = dP
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         _bgemm(dS, nkp, n * nkp, False, k, Cc, d, True, dq, Cc, d, n, d, nk, H)                    # dq_h = dS_h k_h
         _bgemm(dS, nkp, n * nkp, True, q, Cc, d, True, dk, Cc, d, nk, d, n, H)                     # dk_h = dS_h^T q_h

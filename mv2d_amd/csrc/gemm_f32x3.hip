@@ -284,20 +284,55 @@ extern "C" int mv2d_dgrad_relu_f32x3(const float* g, const float* W, const float
     return gemm_f32x3_impl(g, N, 0, W, K, 1, nullptr, 0, alpha, 0, 0, dx, K, M, K, N, nullptr, 0, nullptr, relu_y, stream);
 }
 
+// sum of the split-K slabs of a batched product: out[m * ldc + b * batch_c + n] = sum_s slab[s][b][m][n] (fixed order)
+__global__ __launch_bounds__(256) void fx_batched_slab_sum_kernel(const float* __restrict__ slab, int splits, int batch, int M, int N, float* __restrict__ out,
+                                                                  long long ldc, long long batch_c) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x, per = (long long)batch * M * N;
+    if (i >= per) return;
+    float t = 0.f;
+    for (int s_ = 0; s_ < splits; ++s_) t += slab[s_ * per + i];
+    const int n = (int)(i % N), m = (int)((i / N) % M), b = (int)(i / ((long long)M * N));
+    out[(long long)m * ldc + b * batch_c + n] = t;
+}
+
+static int fx_batched_splits(int M, int N, int K, int batch) {
+    const long long tiles = (long long)cdiv(M, BM) * cdiv(N, BN) * batch;
+    const int nk = cdiv(K, BK);
+    if (tiles >= 256 || nk < 8) return 1;
+    long long s_ = 768 / tiles;
+    if (s_ > nk / 2) s_ = nk / 2;
+    if (s_ > 64) s_ = 64;
+    return s_ < 1 ? 1 : (int)s_;
+}
+
+// bytes of workspace the batched product wants for split-K (0: it runs in one pass)
+extern "C" long long mv2d_gemm_f32x3_batched_ws_bytes(int M, int N, int K, int batch) {
+    const int s_ = fx_batched_splits(M, N, K, batch);
+    return s_ <= 1 ? 0 : (long long)s_ * batch * M * N * 4;
+}
+
 // `batch` products of one shape in one launch (blockIdx.z): C_b [M, ldc] = op(A_b) op(B_b)^T with A_b = A + b * batch_a (elements), likewise B_b, C_b
 // -- the per-head products of a dense attention block (head b = a 32-column slice of [rows, 256] operands: batch stride 32, row stride 256).
-// One pass over K (no split-K, no bias / activation).
+// No bias / activation.  Few output tiles with a long contraction (P V and dS K of the denoising rows: 400 x 32 outputs per head over 16 k
+// keys) are split over K into slabs in `ws` (mv2d_gemm_f32x3_batched_ws_bytes; NULL: one pass) and summed in fixed order.
 extern "C" int mv2d_gemm_f32x3_batched(const float* A, long long lda, long long batch_a, int trans_a, const float* B, long long ldb, long long batch_b,
-                                       int trans_b, float* C, long long ldc, long long batch_c, int M, int N, int K, int batch, void* stream) {
+                                       int trans_b, float* C, long long ldc, long long batch_c, int M, int N, int K, int batch, void* ws,
+                                       long long ws_bytes, void* stream) {
     MV2D_CHECK_ARG(A && B && C && M >= 0 && N > 0 && K > 0 && batch >= 1 && batch <= 65535, "mv2d_gemm_f32x3_batched: bad args");
     if (M == 0) return MV2D_OK;
+    int splits = fx_batched_splits(M, N, K, batch);
+    if (splits > 1 && (!ws || ws_bytes < mv2d_gemm_f32x3_batched_ws_bytes(M, N, K, batch) || ((uintptr_t)ws & 15) != 0)) splits = 1;
     FxParams p;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.bias = nullptr; p.M = M; p.N = N; p.K = K; p.act = 0; p.alpha = 1.f; p.out_bf16 = 0; p.rowsum = nullptr;
-    p.relu_y = nullptr; p.accumulate = 0; p.batch_a = batch_a; p.batch_b = batch_b; p.batch_c = batch_c;
-    p.k_tiles_per_split = cdiv(K, BK); p.C = C; p.ldc = ldc; p.c_split_stride = 0;
-    const dim3 grid(cdiv(M, BM) * cdiv(N, BN), 1, batch);
+    p.relu_y = nullptr; p.accumulate = 0; p.batch_a = batch_a; p.batch_b = batch_b;
+    const int nk = cdiv(K, BK);
+    p.k_tiles_per_split = cdiv(nk, splits);
+    splits = cdiv(nk, p.k_tiles_per_split);
+    if (splits > 1) { p.C = (float*)ws; p.ldc = N; p.batch_c = (long long)M * N; p.c_split_stride = (long long)batch * M * N; }
+    else { p.C = C; p.ldc = ldc; p.batch_c = batch_c; p.c_split_stride = 0; }
+    const dim3 grid(cdiv(M, BM) * cdiv(N, BN), splits, batch);
     hipStream_t st = (hipStream_t)stream;
-    const bool deep = (long long)grid.x * batch <= 512;
+    const bool deep = (long long)grid.x * splits * batch <= 1024;
 #define MV2D_FX_LAUNCH(TA_, TB_) do { \
         if (deep) hipLaunchKernelGGL((gemm_f32x3_kernel<TA_, TB_, 4>), grid, dim3(256), 0, st, p); \
         else hipLaunchKernelGGL((gemm_f32x3_kernel<TA_, TB_, 1>), grid, dim3(256), 0, st, p); } while (0)
@@ -306,6 +341,10 @@ extern "C" int mv2d_gemm_f32x3_batched(const float* A, long long lda, long long 
     else if (trans_b) MV2D_FX_LAUNCH(false, true);
     else MV2D_FX_LAUNCH(false, false);
 #undef MV2D_FX_LAUNCH
+    if (splits > 1) {
+        const long long per = (long long)batch * M * N;
+        hipLaunchKernelGGL(fx_batched_slab_sum_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, (const float*)ws, splits, batch, M, N, C, ldc, batch_c);
+    }
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -90,7 +90,39 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict_
         for (long long j = i; j < n && j < i + 4; ++j) g[j] = y[j] > 0.f ? dy[j] : 0.f;
 }
 
+// Softmax backward of a dense attention block, row by row: dS = P * (dPm - sum_j P_j dPm_j), dPm = dP * (Pd != 0 ? keep_scale : 0)
+// (Pd = dropout(P): a kept probability is non-zero, and where P itself is 0 the product is 0 either way).  dP is overwritten with dS.
+// One block per row, two passes over the row (the second one finds it in L2).
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ P, const float* __restrict__ Pd, float* __restrict__ dP,
+                                                               long long ld, int cols, float keep_scale) {
+    __shared__ float red[4];
+    const long long o = (long long)blockIdx.x * ld;
+    const bool drop = Pd != P;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float m = drop ? (Pd[o + c] != 0.f ? keep_scale : 0.f) : 1.f;
+        s += P[o + c] * (dP[o + c] * m);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float r = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float m = drop ? (Pd[o + c] != 0.f ? keep_scale : 0.f) : 1.f;
+        dP[o + c] = P[o + c] * (dP[o + c] * m - r);
+    }
+}
+
 }  // namespace
+
+// dP [rows, ld] (first `cols` columns of every row) <- P * (dP m - rowsum(P dP m)), m = keep_scale where Pd != 0 else 0 (Pd == P: no dropout, m = 1)
+extern "C" int mv2d_softmax_bwd_rows(const float* P, const float* Pd, float* dP, long long ld, int rows, int cols, float keep_scale, void* stream) {
+    MV2D_CHECK_ARG(P && Pd && dP && rows >= 0 && cols >= 0 && ld >= cols, "mv2d_softmax_bwd_rows: bad args");
+    if (rows == 0 || cols == 0) return MV2D_OK;
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, P, Pd, dP, ld, cols, keep_scale);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
 
 extern "C" int mv2d_colsum_scratch_rows(int rows) { return rows > 2 * CS_ROWS ? cdiv(rows, CS_ROWS) : 0; }
 
