@@ -6,7 +6,8 @@ O=gpurun_out/r05
 for f in ablate_exact.txt bench_cfg2s_one_rank_rccl.json default_bench_cfg2s.json default_bench_cfg2s_kernel_stats.txt default_bench_cfg2s_under_rocprof.json \
          driver_shape_bench_cfg2s.json engine_exact_cfg2s_batch1_kernel_stats.txt engine_exact_cfg2s_kernel_stats.txt engine_key16_cfg2s_kernel_stats.txt \
          engine_exact_cfg3t_kernel_stats.txt engine_exact_cfg5t_kernel_stats.txt engine_exact_cfg2s_nc6_kernel_stats.txt gpu_tests_parity_lines.txt \
-         train_step_cfg2s.json train_step_cfg3t.json; do cp $O/$f profiles/r05_$f; done
+         train_step_cfg2s.json train_step_cfg3t.json train_step_cfg2s_operator_graph.json train_decoder_time.jsonl train_step_cfg2s_host_profile.txt \
+         train_step_cfg2s_under_rocprof.json train_step_cfg2s_kernel_stats.txt; do cp $O/$f profiles/r05_$f; done
 cp $O/prof_rccl/kernel_stats.txt profiles/r05_bench_cfg2s_one_rank_rccl_kernel_stats.txt
 for w in cfg2s cfg2s_nc6 cfg3t cfg5t cfg2s_key16; do for c in $O/pmc_$w/*.txt; do cp "$c" "profiles/r05_pmc_${w}_$(basename "$c")"; done; done
 N="${1:-rocprofv3 --kernel-trace --pmc (separate passes per counter), tools/pmc_bench.sh via tools/r05_evidence.sh, MI355X, round 5, index-exact route}"

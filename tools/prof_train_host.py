@@ -1,5 +1,5 @@
 import cProfile, pstats, sys, os, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tools')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mv2d_amd import configs, registry, synthetic
 import mv2d_amd.plugin

@@ -28,6 +28,12 @@ python tools/ablate_exact.py 2>/dev/null > $O/ablate_exact.txt
 # 6. training step (autograd route on the HIP kernels)
 python tools/bench_train.py 2>/dev/null | tail -n 1 > $O/train_step_cfg2s.json
 python tools/bench_train.py --problem cfg3_t 2>/dev/null | tail -n 1 > $O/train_step_cfg3t.json
+#    ... the same step with the per-operator graph of rounds 3-4, the decoder + branches alone (side streams on / off / per-operator), the host profile
+MV2D_TRAIN_FUSED=0 python tools/bench_train.py 2>/dev/null | tail -n 1 > $O/train_step_cfg2s_operator_graph.json
+(python tools/train_decoder_time.py; MV2D_TD_SERIAL=1 python tools/train_decoder_time.py; MV2D_TRAIN_FUSED=0 python tools/train_decoder_time.py) 2>/dev/null | grep '^{' > $O/train_decoder_time.jsonl
+python tools/prof_train_host.py 2>&1 | grep -v Warning > $O/train_step_cfg2s_host_profile.txt
+R_=$PWD; (cd /tmp && TMPDIR=/tmp timeout 300 rocprofv3 --kernel-trace --stats -d $R_/$O/train_stats -o s -- python $R_/tools/train_prof_step.py > $R_/$O/train_step_cfg2s_under_rocprof.json 2>/dev/null)
+python tools/rocpd_stats.py $(find $O/train_stats -name "s_results.db" | head -1) > $O/train_step_cfg2s_kernel_stats.txt 2>&1; rm -rf $O/train_stats
 # 7. per-phase stamps of the PE kernel
 python tools/px_trace.py > /dev/null 2>&1 || true
 # 8. the GPU test suite with the parity prints
