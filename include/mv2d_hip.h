@@ -557,14 +557,15 @@ int mv2d_colsum_add(const float* x, long long ld, int rows, int cols, float* out
 /* dW [N,K] = g^T x and db [N] = column sums of g (g [M,N], x [M,K] dense rows) -- db inside the product's kernel when it runs in one pass, a
  * separate column sum after a split-K product (cs_scratch: [mv2d_colsum_scratch_rows(M), N] floats or NULL). */
 /* `batch` products of one shape in one launch: C_b [M, ldc] = op(A_b) op(B_b)^T, X_b = X + b * batch_x elements (the per-head products of a dense
- * attention block: head b = a 32-column slice of [rows, 256] operands).  No bias / activation.  ws (16-byte aligned,
+ * attention block: head b = a 32-column slice of [rows, 256] operands).  C = alpha * product, no bias / activation.  ws (16-byte aligned,
  * mv2d_gemm_f32x3_batched_ws_bytes; NULL = one pass): split-K slabs for few output tiles with a long contraction, summed in fixed order. */
 /* Softmax backward of a dense attention block, in place: dP [rows, ld] (first cols columns) <- P * (dP m - rowsum(P dP m)), m = keep_scale where the
  * dropped probabilities Pd are non-zero, 0 elsewhere (Pd == P: no dropout). */
 int mv2d_softmax_bwd_rows(const float* P, const float* Pd, float* dP, long long ld, int rows, int cols, float keep_scale, void* stream);
 long long mv2d_gemm_f32x3_batched_ws_bytes(int M, int N, int K, int batch);
 int mv2d_gemm_f32x3_batched(const float* A, long long lda, long long batch_a, int trans_a, const float* B, long long ldb, long long batch_b, int trans_b,
-                            float* C, long long ldc, long long batch_c, int M, int N, int K, int batch, void* ws, long long ws_bytes, void* stream);
+                            float* C, long long ldc, long long batch_c, int M, int N, int K, int batch, float alpha, void* ws, long long ws_bytes,
+                            void* stream);
 /* dx [M,K] = (g [M,N] W [N,K]) * alpha, zeroed where relu_y [M,K] <= 0 (NULL: no mask) -- the ReLU (+ dropout scale) of the forward applied to the
  * input gradient in the product's epilogue. */
 int mv2d_dgrad_relu_f32x3(const float* g, const float* W, const float* relu_y, float alpha, float* dx, int M, int N, int K, void* stream);
@@ -581,7 +582,9 @@ int mv2d_wgrad_f32x3(const float* g, const float* x, float* dW, float* db, int M
  * post_norm weight / bias.  Gradients are written (not accumulated).
  * qpos [T,256]; key_in / val_in [S,256] fp32; (row_ptr, col) CSR patterns of the self / cross attention, (key_ptr, pair_idx, pair_row) their
  * transposes; outs / d_outs [L,T,256].  Dropout (probabilities in dims, 0 = eval): counter-hash masks of (seed, layer, site, element),
- * regenerated by the backward.  act (mv2d_train_decoder_act_bytes) carries the activations from the forward to the backward;
+ * regenerated by the backward.  Denoising queries (dims.pad > 0): the cross-attention pattern covers the rows pad..T-1 only, the first pad rows attend
+ * to the key rows dn_keys [nk] (sorted, unique; NULL = all S rows) as a dense block (RH/mv2d_t_head.py:90-98) on unrounded fp32 keys / values.
+ * act (mv2d_train_decoder_act_bytes) carries the activations from the forward to the backward;
  * ws: mv2d_train_decoder_ws_bytes(dims, backward) bytes of scratch; both 256-byte aligned. */
 typedef struct mv2d_td_dims {
     int T, S, L, F;
@@ -589,17 +592,18 @@ typedef struct mv2d_td_dims {
     float p_sa_attn, p_sa_out, p_ca_attn, p_ca_out, p_ffn_act, p_ffn_out;
     unsigned int seed;
     float eps;
+    int pad, nk;     /* the first `pad` rows are denoising queries: they see the nk key rows dn_keys (a dense block); 0, 0 = none */
 } mv2d_td_dims;
 long long mv2d_train_decoder_act_bytes(const mv2d_td_dims* d);
 long long mv2d_train_decoder_ws_bytes(const mv2d_td_dims* d, int backward);
 int mv2d_train_decoder_fwd(const mv2d_td_dims* d, const float* const* params, const float* qpos, const float* key_in, const float* val_in,
-                           const int* sa_row_ptr, const int* sa_col, const int* ca_row_ptr, const int* ca_col, float* outs, void* act, void* ws,
-                           void* stream);
+                           const int* sa_row_ptr, const int* sa_col, const int* ca_row_ptr, const int* ca_col, const int* dn_keys, float* outs, void* act,
+                           void* ws, void* stream);
 int mv2d_train_decoder_bwd(const mv2d_td_dims* d, const float* const* params, float* const* grads, const float* qpos, const float* key_in,
                            const float* val_in, const int* sa_row_ptr, const int* sa_col, const int* sa_key_ptr, const int* sa_pair_idx,
                            const int* sa_pair_row, const int* ca_row_ptr, const int* ca_col, const int* ca_key_ptr, const int* ca_pair_idx,
-                           const int* ca_pair_row, const float* d_outs, const void* act, void* ws, float* d_qpos, float* d_key_in, float* d_val_in,
-                           void* stream);
+                           const int* ca_pair_row, const int* dn_keys, const float* d_outs, const void* act, void* ws, float* d_qpos, float* d_key_in,
+                           float* d_val_in, void* stream);
 
 /* The classification / regression branches of all L intermediate outputs in one call per direction (RH/bbox_heads/cross_attention_head.py:118-142,
  * 200-218): cls_l = Linear(ReLU(LN(Linear(ReLU(LN(Linear(out_l))))))), reg_l = Linear(ReLU(Linear(ReLU(Linear(out_l))))) (the raw box code).

@@ -20,7 +20,7 @@ ABI_VERSION = 4                  # include/mv2d_hip.h: mv2d_abi_version()
 class TdDims(C.Structure):
     """struct mv2d_td_dims (include/mv2d_hip.h): the scalar arguments of mv2d_train_decoder_fwd / _bwd"""
     _fields_ = [('T', I), ('S', I), ('L', I), ('F', I), ('sa_nnz', I), ('ca_nnz', I), ('p_sa_attn', F), ('p_sa_out', F), ('p_ca_attn', F),
-                ('p_ca_out', F), ('p_ffn_act', F), ('p_ffn_out', F), ('seed', C.c_uint), ('eps', F)]
+                ('p_ca_out', F), ('p_ffn_act', F), ('p_ffn_out', F), ('seed', C.c_uint), ('eps', F), ('pad', I), ('nk', I)]
 
 
 class ThDims(C.Structure):
@@ -116,12 +116,12 @@ SIGNATURES = {
     'mv2d_colsum_add': (I, [P, LL, I, I, P, P, P, P]),
     'mv2d_softmax_bwd_rows': (I, [P, P, P, LL, I, I, F, P]),
     'mv2d_gemm_f32x3_batched_ws_bytes': (LL, [I, I, I, I]),
-    'mv2d_gemm_f32x3_batched': (I, [P, LL, LL, I, P, LL, LL, I, P, LL, LL, I, I, I, I, P, LL, P]),
+    'mv2d_gemm_f32x3_batched': (I, [P, LL, LL, I, P, LL, LL, I, P, LL, LL, I, I, I, I, F, P, LL, P]),
     'mv2d_wgrad_f32x3': (I, [P, P, P, P, I, I, I, P, LL, P, P]),
     'mv2d_train_decoder_act_bytes': (LL, [P]),
     'mv2d_train_decoder_ws_bytes': (LL, [P, I]),
-    'mv2d_train_decoder_fwd': (I, [P] * 13),
-    'mv2d_train_decoder_bwd': (I, [P] * 23),
+    'mv2d_train_decoder_fwd': (I, [P] * 14),
+    'mv2d_train_decoder_bwd': (I, [P] * 24),
     'mv2d_box_code_fwd': (I, [P, P, P, I, I, I, F, P, P]),
     'mv2d_box_code_bwd': (I, [P, P, P, P, P, I, I, I, F, P, P]),
     'mv2d_lsap_layers': (I, [P, I, I, I, P, I]),

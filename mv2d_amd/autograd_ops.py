@@ -255,16 +255,18 @@ class DecoderFn(torch.autograd.Function):
             assert t.is_cuda and t.dtype == F32 and t.is_contiguous(), 'DecoderFn: fp32 contiguous device tensors'
         T, S, Fw = qpos.shape[0], key_in.shape[0], params[12].shape[0]
         dr = meta['drops']
+        keys = meta.get('dn_keys')
+        pad = int(meta.get('pad', 0)) if keys is not None else 0
         dims = _lib.TdDims(T, S, L, Fw, meta['sa'][1].numel(), meta['ca'][1].numel(), dr[0], dr[1], dr[2], dr[3], dr[4], dr[5],
-                           int(meta['seed']) & 0xffffffff, 1e-5)
+                           int(meta['seed']) & 0xffffffff, 1e-5, pad, keys.numel() if pad else 0)
         dev = qpos.device
         act = torch.empty(int(lib.mv2d_train_decoder_act_bytes(_lib.C.byref(dims))), device=dev, dtype=torch.uint8)
         ws = torch.empty(int(lib.mv2d_train_decoder_ws_bytes(_lib.C.byref(dims), 0)), device=dev, dtype=torch.uint8)
         outs = torch.empty((L, T, 256), device=dev, dtype=F32)
         ptrs = (_lib.C.c_void_p * len(params))(*[p.data_ptr() for p in params])
         check(lib.mv2d_train_decoder_fwd(_lib.C.addressof(dims), _lib.C.addressof(ptrs), _p(qpos), _p(key_in), _p(val_in), _p(meta['sa'][0]),
-                                         _p(meta['sa'][1]), _p(meta['ca'][0]), _p(meta['ca'][1]), _p(outs), _p(act), _p(ws), _stream()),
-              'mv2d_train_decoder_fwd')
+                                         _p(meta['sa'][1]), _p(meta['ca'][0]), _p(meta['ca'][1]), _p(keys if pad else None), _p(outs), _p(act), _p(ws),
+                                         _stream()), 'mv2d_train_decoder_fwd')
         ctx.save_for_backward(qpos, key_in, val_in, *params)
         ctx.keep = (dims, ptrs, act, meta)
         return outs
@@ -285,8 +287,8 @@ class DecoderFn(torch.autograd.Function):
             ca_t = ops.csr_transpose(ca[0], ca[1], key_in.shape[0])
         check(lib.mv2d_train_decoder_bwd(_lib.C.addressof(dims), _lib.C.addressof(ptrs), _lib.C.addressof(gptr), _p(qpos), _p(key_in), _p(val_in),
                                          _p(sa[0]), _p(sa[1]), _p(sa_t[0]), _p(sa_t[1]), _p(sa_t[2]), _p(ca[0]), _p(ca[1]), _p(ca_t[0]), _p(ca_t[1]),
-                                         _p(ca_t[2]), _p(d_outs), _p(act), _p(ws), _p(d_qpos), _p(d_key), _p(d_val), _stream()),
-              'mv2d_train_decoder_bwd')
+                                         _p(ca_t[2]), _p(meta.get('dn_keys') if dims.pad else None), _p(d_outs), _p(act), _p(ws), _p(d_qpos), _p(d_key),
+                                         _p(d_val), _stream()), 'mv2d_train_decoder_bwd')
         return (d_qpos, d_key, d_val, None) + tuple(grads)
 
 
@@ -405,7 +407,7 @@ def _bgemm(A, lda, sa, ta, B, ldb, sb, tb, C, ldc, sc, M, N, K, batch):
     lib = _lib.load()
     nb = int(lib.mv2d_gemm_f32x3_batched_ws_bytes(M, N, K, batch))
     ws = _workspace(nb, A.device) if nb else None
-    check(lib.mv2d_gemm_f32x3_batched(_p(A), lda, sa, 1 if ta else 0, _p(B), ldb, sb, 1 if tb else 0, _p(C), ldc, sc, M, N, K, batch, _p(ws),
+    check(lib.mv2d_gemm_f32x3_batched(_p(A), lda, sa, 1 if ta else 0, _p(B), ldb, sb, 1 if tb else 0, _p(C), ldc, sc, M, N, K, batch, 1.0, _p(ws),
                                       ws.numel() if ws is not None else 0, _stream()), 'mv2d_gemm_f32x3_batched')
 
 

@@ -313,17 +313,17 @@ extern "C" long long mv2d_gemm_f32x3_batched_ws_bytes(int M, int N, int K, int b
 
 // `batch` products of one shape in one launch (blockIdx.z): C_b [M, ldc] = op(A_b) op(B_b)^T with A_b = A + b * batch_a (elements), likewise B_b, C_b
 // -- the per-head products of a dense attention block (head b = a 32-column slice of [rows, 256] operands: batch stride 32, row stride 256).
-// No bias / activation.  Few output tiles with a long contraction (P V and dS K of the denoising rows: 400 x 32 outputs per head over 16 k
+// No bias / activation; C = alpha * product.  Few output tiles with a long contraction (P V and dS K of the denoising rows: 400 x 32 outputs per head over 16 k
 // keys) are split over K into slabs in `ws` (mv2d_gemm_f32x3_batched_ws_bytes; NULL: one pass) and summed in fixed order.
 extern "C" int mv2d_gemm_f32x3_batched(const float* A, long long lda, long long batch_a, int trans_a, const float* B, long long ldb, long long batch_b,
-                                       int trans_b, float* C, long long ldc, long long batch_c, int M, int N, int K, int batch, void* ws,
+                                       int trans_b, float* C, long long ldc, long long batch_c, int M, int N, int K, int batch, float alpha, void* ws,
                                        long long ws_bytes, void* stream) {
     MV2D_CHECK_ARG(A && B && C && M >= 0 && N > 0 && K > 0 && batch >= 1 && batch <= 65535, "mv2d_gemm_f32x3_batched: bad args");
     if (M == 0) return MV2D_OK;
     int splits = fx_batched_splits(M, N, K, batch);
     if (splits > 1 && (!ws || ws_bytes < mv2d_gemm_f32x3_batched_ws_bytes(M, N, K, batch) || ((uintptr_t)ws & 15) != 0)) splits = 1;
     FxParams p;
-    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.bias = nullptr; p.M = M; p.N = N; p.K = K; p.act = 0; p.alpha = 1.f; p.out_bf16 = 0; p.rowsum = nullptr;
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.bias = nullptr; p.M = M; p.N = N; p.K = K; p.act = 0; p.alpha = alpha; p.out_bf16 = 0; p.rowsum = nullptr;
     p.relu_y = nullptr; p.accumulate = 0; p.batch_a = batch_a; p.batch_b = batch_b;
     const int nk = cdiv(K, BK);
     p.k_tiles_per_split = cdiv(nk, splits);

@@ -33,6 +33,12 @@ extern "C" int mv2d_sparse_xattn_bwd_drop(const float* q, const void* K, const v
 extern "C" int mv2d_sparse_xattn_bwd_ex(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
                                         const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws,
                                         float* dq, float* dK, float* dV, int R, int S, float p_drop, unsigned int seed, int long_rows, float dq_scale, void* stream);
+extern "C" long long mv2d_gemm_f32x3_batched_ws_bytes(int M, int N, int K, int batch);
+extern "C" int mv2d_gemm_f32x3_batched(const float* A, long long lda, long long batch_a, int trans_a, const float* B, long long ldb, long long batch_b,
+                                       int trans_b, float* C, long long ldc, long long batch_c, int M, int N, int K, int batch, float alpha, void* ws,
+                                       long long ws_bytes, void* stream);
+extern "C" int mv2d_softmax_bwd_rows(const float* P, const float* Pd, float* dP, long long ld, int rows, int cols, float keep_scale, void* stream);
+extern "C" int mv2d_f32_to_bf16(const float* x, void* y, long long n, void* stream);
 extern "C" int mv2d_dgrad_relu_f32x3(const float* g, const float* W, const float* relu_y, float alpha, float* dx, int M, int N, int K, void* stream);
 
 // the scalar arguments of both entries (mirrored by mv2d_amd/_lib.py: TdDims)
@@ -42,11 +48,12 @@ struct mv2d_td_dims {
     float p_sa_attn, p_sa_out, p_ca_attn, p_ca_out, p_ffn_act, p_ffn_out;      // dropout probabilities (0 in eval mode)
     unsigned int seed;
     float eps;
+    int pad, nk;                             // leading denoising rows (they see the nk rows dn_keys of the key side, a dense block); 0, 0: none
 };
 
 namespace {
 
-constexpr int C = 256, NPL = 18;             // channels; parameter tensors per layer
+constexpr int C = 256, NPL = 18, NH = 8, HD = 32;             // channels; parameter tensors per layer
 enum { SA_W, SA_B, SA_OW, SA_OB, N0_W, N0_B, CA_W, CA_B, CA_OW, CA_OB, N1_W, N1_B, F1_W, F1_B, F2_W, F2_B, N2_W, N2_B };
 
 struct Drop { unsigned int thr, seed; float scale; };
@@ -205,6 +212,49 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ 
         out[c] = t;
     }
 }
+// dst[i, :] = src[idx[i], :]  (rows of 256; idx NULL: the identity)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, int n) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), c = 4 * (threadIdx.x & 63);
+    if (i >= n) return;
+    st4(dst + (long long)i * C + c, ld4(src + (long long)(idx ? idx[i] : i) * C + c));
+}
+// dst[idx[i], :] += src[i, :]  (idx holds every row at most once: no atomics; idx NULL: the identity)
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(float* __restrict__ dst, const int* __restrict__ idx, const float* __restrict__ src, int n) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), c = 4 * (threadIdx.x & 63);
+    if (i >= n) return;
+    float* d = dst + (long long)(idx ? idx[i] : i) * C + c;
+    st4(d, add4(ld4(d), ld4(src + (long long)i * C + c)));
+}
+// P = softmax over the first `cols` entries of every row of S [rows, ld]; Pd = dropout(P) (counter hash of the element's offset).  Block per row.
+__global__ __launch_bounds__(256) void softmax_drop_rows_kernel(const float* __restrict__ S, float* __restrict__ P, float* __restrict__ Pd, long long ld,
+                                                                int cols, Drop d) {
+    __shared__ float red[4];
+    const long long o = (long long)blockIdx.x * ld;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, S[o + c]);
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) s += expf(S[o + c] - m);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float inv = 1.f / ((red[0] + red[1]) + (red[2] + red[3]));
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float pj = expf(S[o + c] - m) * inv;
+        P[o + c] = pj;
+        if (Pd != P) Pd[o + c] = pj * drop_factor(d, (unsigned int)(o + c));
+    }
+}
+// Pd = dropout(P) again (the backward regenerates the mask of softmax_drop_rows_kernel from the same counter)
+__global__ __launch_bounds__(256) void drop_regen_kernel(const float* __restrict__ P, float* __restrict__ Pd, long long ld, int cols, Drop d) {
+    const long long o = (long long)blockIdx.x * ld;
+    for (int c = threadIdx.x; c < cols; c += 256) Pd[o + c] = P[o + c] * drop_factor(d, (unsigned int)(o + c));
+}
 // out = sum of n buffers (fixed order)
 struct SumArgs { const float* src[16]; int n; };
 __global__ __launch_bounds__(256) void sum_n_kernel(SumArgs a, float* __restrict__ out, long long n4) {
@@ -263,6 +313,10 @@ static long long gemm_ws_max(const mv2d_td_dims& d) {
     const int shapes[][3] = {{T, C, C}, {T, F, C}, {T, C, F}, {C, C, T}, {F, C, T}, {C, F, T}, {C, C, S}, {S, C, C}};
     long long m = 0;
     for (auto& s : shapes) { const long long b = mv2d_gemm_f32x3_ws_bytes(s[0], s[1], s[2]); if (b > m) m = b; }
+    if (d.nk > 0) {
+        const int bshapes[][3] = {{d.pad, d.nk, HD}, {d.pad, HD, d.nk}, {d.nk, HD, d.pad}};
+        for (auto& s : bshapes) { const long long b = mv2d_gemm_f32x3_batched_ws_bytes(s[0], s[1], s[2], NH); if (b > m) m = b; }
+    }
     return al256(m) + 256;
 }
 
@@ -283,6 +337,11 @@ struct Lane {
     int wgrad(const float* g, const float* x, float* dW, float* db, int M, int N, int K) const {
         return mv2d_wgrad_f32x3(g, x, dW, db, M, N, K, ws, ws_bytes, cs, st);
     }
+    // NH products over 32-column head slices of [rows, C] operands (or over [NH, M, ld] stacks: batch stride given)
+    int bgemm(const float* A, long long lda, long long sa, int ta, const float* B, long long ldb, long long sb, int tb, float* Cm, long long ldc, long long sc,
+              int M, int N, int K, float alpha) const {
+        return mv2d_gemm_f32x3_batched(A, lda, sa, ta, B, ldb, sb, tb, Cm, ldc, sc, M, N, K, NH, alpha, ws, ws_bytes, st);
+    }
     // the two parameter gradients of a LayerNorm from the per-block partial sums of ln_bwd_ex_kernel: one launch
     void ln_params(const float* pw, const float* pb, int nb, float* gw, float* gb) const;
 };
@@ -297,6 +356,7 @@ static inline unsigned int blocks4(long long n) { return (unsigned int)((n / 4 +
 struct Act {
     float *xq, *q_sa, *ctx_sa, *s1, *x1, *xq1, *q_ca, *ctx_ca, *s2, *x2, *h, *s3, *x3;
     unsigned short *k_sa, *v_sa, *K, *V;
+    float *kd, *vd, *P;                     // denoising rows: projected key / value rows they see [nk, C] fp32, their probabilities [NH, pad, nkp]
 };
 struct ActLayout {
     float* x0; Act a[8];
@@ -312,13 +372,20 @@ struct ActLayout {
             a_.h = c.take<float>((long long)d.T * d.F); a_.s3 = c.take<float>(TC); a_.x3 = c.take<float>(TC);
             a_.k_sa = c.take<unsigned short>(TC); a_.v_sa = c.take<unsigned short>(TC);
             a_.K = c.take<unsigned short>((long long)d.S * C); a_.V = c.take<unsigned short>((long long)d.S * C);
+            a_.kd = a_.vd = a_.P = nullptr;
+            if (d.nk > 0) {
+                a_.kd = c.take<float>((long long)d.nk * C); a_.vd = c.take<float>((long long)d.nk * C);
+                a_.P = c.take<float>((long long)NH * d.pad * ((d.nk + 3) & ~3));
+            }
         }
         bytes = c.off;
     }
 };
 
 static bool dims_ok(const mv2d_td_dims* d) {
-    return d && d->T > 0 && d->S > 0 && d->L >= 1 && d->L <= 8 && d->F > 0 && d->F % 4 == 0 && d->sa_nnz >= 0 && d->ca_nnz >= 0;
+    return d && d->T > 0 && d->S > 0 && d->L >= 1 && d->L <= 8 && d->F > 0 && d->F % 4 == 0 && d->sa_nnz >= 0 && d->ca_nnz >= 0 && d->pad >= 0 &&
+           d->pad <= d->T && d->nk >= 0 && d->nk <= d->S && ((d->pad > 0) == (d->nk > 0)) &&
+           (long long)NH * d->pad * ((d->nk + 3) & ~3) < (1LL << 32);          // (the dropout counter of the dense block is 32 bits wide)
 }
 
 #define TD_RC(x) do { const int rc_ = (x); if (rc_ != MV2D_OK) return rc_; } while (0)
@@ -334,10 +401,11 @@ extern "C" long long mv2d_train_decoder_ws_bytes(const mv2d_td_dims* d, int back
     if (!dims_ok(d)) return -1;
     const long long TC = (long long)d->T * C, SC = (long long)d->S * C, TF = (long long)d->T * d->F;
     const long long lanes = (1 + NSIDE) * (gemm_ws_max(*d) + al256((long long)(mv2d_colsum_scratch_rows(d->S > d->T ? d->S : d->T) + 1) * d->F * 4));
-    if (!backward) return lanes + al256(TC * 4) + 4096;
+    const long long PB = al256((long long)NH * d->pad * ((d->nk + 3) & ~3) * 4), KB = al256((long long)d->nk * C * 4);      // 0 without denoising rows
+    if (!backward) return lanes + al256(TC * 4) + (d->nk > 0 ? 2 * PB + 2 * al256(SC * 4) : 0) + 4096;
     const int nb = cdiv(d->T, LNB_ROWS);
     const long long per_layer = 16 * al256(TC * 4) + 2 * al256(TF * 4) + 2 * al256(SC * 4) + al256((long long)(d->sa_nnz > 0 ? d->sa_nnz : 1) * 64) +
-                                al256((long long)(d->ca_nnz > 0 ? d->ca_nnz : 1) * 64) + 10 * al256((long long)nb * C * 4);
+                                al256((long long)(d->ca_nnz > 0 ? d->ca_nnz : 1) * 64) + 10 * al256((long long)nb * C * 4) + 2 * PB + 2 * KB;
     return lanes + d->L * per_layer + 4096;
 }
 
@@ -346,10 +414,11 @@ extern "C" long long mv2d_train_decoder_ws_bytes(const mv2d_td_dims* d, int back
 // qpos [T,C], key_in / val_in [S,C] fp32; CSR patterns of the two attentions; outs [L,T,C]: post_norm of every layer's output.
 // act: mv2d_train_decoder_act_bytes, kept by the caller until the backward; ws: mv2d_train_decoder_ws_bytes(d, 0).  256-byte aligned.
 extern "C" int mv2d_train_decoder_fwd(const mv2d_td_dims* d, const float* const* params, const float* qpos, const float* key_in, const float* val_in,
-                                      const int* sa_row_ptr, const int* sa_col, const int* ca_row_ptr, const int* ca_col, float* outs, void* act,
-                                      void* ws, void* stream) {
+                                      const int* sa_row_ptr, const int* sa_col, const int* ca_row_ptr, const int* ca_col, const int* dn_keys, float* outs,
+                                      void* act, void* ws, void* stream) {
     MV2D_CHECK_ARG(dims_ok(d) && params && qpos && key_in && val_in && sa_row_ptr && sa_col && ca_row_ptr && ca_col && outs && act && ws,
                    "mv2d_train_decoder_fwd: bad args");
+    MV2D_CHECK_ARG(dn_keys || d->nk == 0 || d->nk == d->S, "mv2d_train_decoder_fwd: dn_keys may only be NULL when the denoising rows see every key");
     MV2D_CHECK_ARG((((uintptr_t)act | (uintptr_t)ws) & 255) == 0, "mv2d_train_decoder_fwd: act / ws must be 256-byte aligned");
     Pool* pl = pool();
     MV2D_CHECK_ARG(pl != nullptr, "mv2d_train_decoder_fwd: could not create the side streams");
@@ -364,15 +433,33 @@ extern "C" int mv2d_train_decoder_fwd(const mv2d_td_dims* d, const float* const*
     Lane side[NSIDE];
     for (int i = 0; i < NSIDE; ++i) side[i] = Lane{td_serial() ? st : pl->side[i], cw.take<char>(gws), gws, cw.take<float>(csb)};
     float* tmp = cw.take<float>(TC);
+    const int pad = d->pad, nk = d->nk, nkp = (nk + 3) & ~3;
+    const long long PN = (long long)NH * pad * nkp;
+    float *dn_S = nullptr, *dn_Pd = nullptr, *k32 = nullptr, *v32 = nullptr;
+    if (nk > 0) { dn_S = cw.take<float>(PN); dn_Pd = cw.take<float>(PN); k32 = cw.take<float>((long long)S * C); v32 = cw.take<float>((long long)S * C); }
 
     // the key side of all layers does not depend on the queries: K_l = key_in Wk_l^T + bk_l, V_l = val_in Wv_l^T + bv_l (bf16) on two side streams
+    // (with denoising rows: in fp32 first -- their dense block reads the rows dn_keys of it unrounded, as the per-operator graph does)
     after(pl, st, side[1].st);
     after(pl, st, side[2].st);
     hipEvent_t kv_ready[8][2];
     for (int l = 0; l < L; ++l) {
         const float* const* P = params + l * NPL;
-        TD_RC(side[1].linear(key_in, P[CA_W] + (long long)C * C, P[CA_B] + C, 0, 1.f, 1, al.a[l].K, S, C, C));
-        TD_RC(side[2].linear(val_in, P[CA_W] + 2LL * C * C, P[CA_B] + 2 * C, 0, 1.f, 1, al.a[l].V, S, C, C));
+        if (nk > 0) {
+            float* kf = dn_keys ? k32 : al.a[l].kd;
+            float* vf = dn_keys ? v32 : al.a[l].vd;
+            TD_RC(side[1].linear(key_in, P[CA_W] + (long long)C * C, P[CA_B] + C, 0, 1.f, 0, kf, S, C, C));
+            TD_RC(mv2d_f32_to_bf16(kf, al.a[l].K, (long long)S * C, side[1].st));
+            TD_RC(side[2].linear(val_in, P[CA_W] + 2LL * C * C, P[CA_B] + 2 * C, 0, 1.f, 0, vf, S, C, C));
+            TD_RC(mv2d_f32_to_bf16(vf, al.a[l].V, (long long)S * C, side[2].st));
+            if (dn_keys) {
+                hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(nk, 4)), dim3(256), 0, side[1].st, (const float*)kf, dn_keys, al.a[l].kd, nk);
+                hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(nk, 4)), dim3(256), 0, side[2].st, (const float*)vf, dn_keys, al.a[l].vd, nk);
+            }
+        } else {
+            TD_RC(side[1].linear(key_in, P[CA_W] + (long long)C * C, P[CA_B] + C, 0, 1.f, 1, al.a[l].K, S, C, C));
+            TD_RC(side[2].linear(val_in, P[CA_W] + 2LL * C * C, P[CA_B] + 2 * C, 0, 1.f, 1, al.a[l].V, S, C, C));
+        }
         for (int j = 0; j < 2; ++j) {
             kv_ready[l][j] = pl->ev[pl->next];
             pl->next = (pl->next + 1) % NEV;
@@ -399,7 +486,17 @@ extern "C" int mv2d_train_decoder_fwd(const mv2d_td_dims* d, const float* const*
         TD_RC(mainl.linear(a.xq1, P[CA_W], P[CA_B], 0, qs, 0, a.q_ca, T, C, C));
         (void)hipStreamWaitEvent(st, kv_ready[l][0], 0);
         (void)hipStreamWaitEvent(st, kv_ready[l][1], 0);
-        TD_RC(mv2d_sparse_xattn_fwd_drop(a.q_ca, a.K, a.V, ca_row_ptr, ca_col, a.ctx_ca, nullptr, 0, T, 0, d->p_ca_attn, site_seed(d->seed, l, 2), st));
+        if (nk > 0) {
+            // the denoising rows: a dense block over the rows dn_keys -- logits, softmax + dropout, P V as one batched launch per product
+            TD_RC(mainl.bgemm(a.q_ca, C, HD, 0, a.kd, C, HD, 0, dn_S, nkp, (long long)pad * nkp, pad, nk, HD, 1.f));
+            const Drop d6 = mk_drop(d->p_ca_attn, site_seed(d->seed, l, 6));
+            float* pd = d6.thr ? dn_Pd : a.P;
+            hipLaunchKernelGGL(softmax_drop_rows_kernel, dim3(NH * pad), dim3(256), 0, st, (const float*)dn_S, a.P, pd, (long long)nkp, nk, d6);
+            TD_RC(mainl.bgemm(pd, nkp, (long long)pad * nkp, 0, a.vd, C, HD, 1, a.ctx_ca, C, HD, pad, HD, nk, 1.f));
+        }
+        if (T > pad)
+            TD_RC(mv2d_sparse_xattn_fwd_drop(a.q_ca + (long long)pad * C, a.K, a.V, ca_row_ptr, ca_col, a.ctx_ca + (long long)pad * C, nullptr, 0, T - pad, 0,
+                                             d->p_ca_attn, site_seed(d->seed, l, 2), st));
         TD_RC(mainl.linear(a.ctx_ca, P[CA_OW], P[CA_OB], 0, 1.f, 0, tmp, T, C, C));
         {
             ResLnArgs r{a.x1, tmp, P[N1_W], P[N1_B], nullptr, nullptr, nullptr, a.s2, a.x2, nullptr, nullptr, T, d->eps, mk_drop(d->p_ca_out, site_seed(d->seed, l, 3))};
@@ -429,13 +526,14 @@ extern "C" int mv2d_train_decoder_fwd(const mv2d_td_dims* d, const float* const*
 extern "C" int mv2d_train_decoder_bwd(const mv2d_td_dims* d, const float* const* params, float* const* grads, const float* qpos, const float* key_in,
                                       const float* val_in, const int* sa_row_ptr, const int* sa_col, const int* sa_key_ptr, const int* sa_pair_idx,
                                       const int* sa_pair_row, const int* ca_row_ptr, const int* ca_col, const int* ca_key_ptr, const int* ca_pair_idx,
-                                      const int* ca_pair_row, const float* d_outs, const void* act, void* ws, float* d_qpos, float* d_key_in,
-                                      float* d_val_in, void* stream) {
+                                      const int* ca_pair_row, const int* dn_keys, const float* d_outs, const void* act, void* ws, float* d_qpos,
+                                      float* d_key_in, float* d_val_in, void* stream) {
     MV2D_CHECK_ARG(dims_ok(d) && params && grads && qpos && key_in && val_in && sa_row_ptr && sa_col && sa_key_ptr && sa_pair_idx && sa_pair_row &&
                    ca_row_ptr && ca_col && ca_key_ptr && ca_pair_idx && ca_pair_row && d_outs && act && ws && d_qpos && d_key_in && d_val_in,
                    "mv2d_train_decoder_bwd: bad args");
     MV2D_CHECK_ARG((((uintptr_t)act | (uintptr_t)ws) & 255) == 0, "mv2d_train_decoder_bwd: act / ws must be 256-byte aligned");
     MV2D_CHECK_ARG(2 * d->L <= 16, "mv2d_train_decoder_bwd: too many layers");
+    MV2D_CHECK_ARG(dn_keys || d->nk == 0 || d->nk == d->S, "mv2d_train_decoder_bwd: dn_keys may only be NULL when the denoising rows see every key");
     Pool* pl = pool();
     MV2D_CHECK_ARG(pl != nullptr, "mv2d_train_decoder_bwd: could not create the side streams");
     const int T = d->T, S = d->S, L = d->L, F = d->F;
@@ -454,7 +552,10 @@ extern "C" int mv2d_train_decoder_bwd(const mv2d_td_dims* d, const float* const*
     struct Bufs {
         float *dxa, *A, *Q1, *ds3, *dyf, *dffn, *ds2, *do2, *dctx2, *dq2, *ds1, *do1, *dctx1, *dq1, *dk1, *dv1, *dh, *dK, *dV, *pw_sa, *pw_ca;
         float* part[8];
+        float *dS, *Pd, *dkd, *dvd;            // denoising rows: logit gradients / dropped probabilities [NH, pad, nkp], gradients of the rows they see [nk, C]
     } B[8];
+    const int pad = d->pad, nk = d->nk, nkp = (nk + 3) & ~3;
+    const long long PN = (long long)NH * pad * nkp;
     for (int l = 0; l < L; ++l) {
         Bufs& b = B[l];
         float** t16[] = {&b.dxa, &b.A, &b.Q1, &b.ds3, &b.dyf, &b.dffn, &b.ds2, &b.do2, &b.dctx2, &b.dq2, &b.ds1, &b.do1, &b.dctx1, &b.dq1, &b.dk1, &b.dv1};
@@ -465,6 +566,8 @@ extern "C" int mv2d_train_decoder_bwd(const mv2d_td_dims* d, const float* const*
         b.pw_sa = cw.take<float>((long long)(d->sa_nnz > 0 ? d->sa_nnz : 1) * 16);
         b.pw_ca = cw.take<float>((long long)(d->ca_nnz > 0 ? d->ca_nnz : 1) * 16);
         for (int j = 0; j < 8; ++j) b.part[j] = cw.take<float>((long long)nb * C);
+        b.dS = b.Pd = b.dkd = b.dvd = nullptr;
+        if (nk > 0) { b.dS = cw.take<float>(PN); b.Pd = cw.take<float>(PN); b.dkd = cw.take<float>((long long)nk * C); b.dvd = cw.take<float>((long long)nk * C); }
     }
     // the small weight-gradient products go to side[0]; the key side of the cross attention to side[1] (keys) and side[2] (values)
     for (int i = 0; i < NSIDE; ++i) after(pl, st, side[i].st);
@@ -508,13 +611,31 @@ extern "C" int mv2d_train_decoder_bwd(const mv2d_td_dims* d, const float* const*
         ln_bwd(a.s2, b.ds3, b.dffn, nullptr, P[N1_W], b.ds2, b.do2, d3, b.part[2], b.part[3]);
         const float* do2 = d3.thr ? b.do2 : b.ds2;
         TD_RC(mainl.dgrad(do2, P[CA_OW], b.dctx2, T, C, C, 0));
-        TD_RC(mv2d_sparse_xattn_bwd_ex(a.q_ca, a.K, a.V, ca_row_ptr, ca_col, a.ctx_ca, b.dctx2, ca_key_ptr, ca_pair_idx, ca_pair_row, b.pw_ca, b.dq2,
-                                       b.dK, b.dV, T, 0, d->p_ca_attn, site_seed(d->seed, l, 2), 0, qs, st));
+        const float* pd_l = nullptr;
+        if (nk > 0) {
+            // the denoising rows' dense block: dP = g v^T, dS = softmax backward (with the regenerated dropout mask), dq = dS k / sqrt(d)
+            TD_RC(mainl.bgemm(b.dctx2, C, HD, 0, a.vd, C, HD, 0, b.dS, nkp, (long long)pad * nkp, pad, nk, HD, 1.f));
+            const Drop d6 = mk_drop(d->p_ca_attn, site_seed(d->seed, l, 6));
+            if (d6.thr) hipLaunchKernelGGL(drop_regen_kernel, dim3(NH * pad), dim3(256), 0, st, (const float*)a.P, b.Pd, (long long)nkp, nk, d6);
+            pd_l = d6.thr ? b.Pd : a.P;
+            TD_RC(mv2d_softmax_bwd_rows(a.P, pd_l, b.dS, nkp, NH * pad, nk, d6.scale, st));
+            TD_RC(mainl.bgemm(b.dS, nkp, (long long)pad * nkp, 0, a.kd, C, HD, 1, b.dq2, C, HD, pad, HD, nk, qs));
+        }
+        const long long po = (long long)pad * C;
+        TD_RC(mv2d_sparse_xattn_bwd_ex(a.q_ca + po, a.K, a.V, ca_row_ptr, ca_col, a.ctx_ca + po, b.dctx2 + po, ca_key_ptr, ca_pair_idx, ca_pair_row, b.pw_ca,
+                                       b.dq2 + po, b.dK, b.dV, T - pad, 0, d->p_ca_attn, site_seed(d->seed, l, 2), 0, qs, st));
         // the key pass of the cross attention (dK, dV) and the projections behind it: side streams 1 (keys) and 2 (values)
         after(pl, st, side[1].st);
-        TD_RC(mv2d_sparse_xattn_bwd_drop(a.q_ca, a.K, a.V, ca_row_ptr, ca_col, a.ctx_ca, b.dctx2, ca_key_ptr, ca_pair_idx, ca_pair_row, b.pw_ca, b.dq2,
-                                         b.dK, b.dV, 0, S, d->p_ca_attn, site_seed(d->seed, l, 2), side[1].st));
+        TD_RC(mv2d_sparse_xattn_bwd_ex(a.q_ca + po, a.K, a.V, ca_row_ptr, ca_col, a.ctx_ca + po, b.dctx2 + po, ca_key_ptr, ca_pair_idx, ca_pair_row, b.pw_ca,
+                                       b.dq2 + po, b.dK, b.dV, 0, S, d->p_ca_attn, site_seed(d->seed, l, 2), 0, qs, side[1].st));
         after(pl, side[1].st, side[2].st);
+        if (nk > 0) {
+            // dk = dS^T q and dv = Pd^T g of the dense block, added to the rows dn_keys of dK / dV
+            TD_RC(side[1].bgemm(b.dS, nkp, (long long)pad * nkp, 1, a.q_ca, C, HD, 1, b.dkd, C, HD, nk, HD, pad, 1.f));
+            hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(cdiv(nk, 4)), dim3(256), 0, side[1].st, b.dK, dn_keys, (const float*)b.dkd, nk);
+            TD_RC(side[2].bgemm(pd_l, nkp, (long long)pad * nkp, 1, b.dctx2, C, HD, 1, b.dvd, C, HD, nk, HD, pad, 1.f));
+            hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(cdiv(nk, 4)), dim3(256), 0, side[2].st, b.dV, dn_keys, (const float*)b.dvd, nk);
+        }
         TD_RC(side[1].dgrad(b.dK, P[CA_W] + (long long)C * C, d_key_in, S, C, C, first_kv ? 0 : 1));
         TD_RC(side[1].wgrad(b.dK, key_in, G[CA_W] + (long long)C * C, G[CA_B] + C, S, C, C));
         TD_RC(side[2].dgrad(b.dV, P[CA_W] + 2LL * C * C, d_val_in, S, C, C, first_kv ? 0 : 1));

@@ -256,6 +256,7 @@ class TrainDecoder:
         self._warned = False
         import os
         self.fused = os.environ.get('MV2D_TRAIN_FUSED', '1') != '0'      # the C-issued decoder (round 5); '0': the per-operator autograd graph
+        self.batched_dense = True          # per-operator graph: the denoising rows' dense block batched over the heads (False: rounds 3-4's loop)
 
     def _drops(self, i, j):
         """(attention-probability p, output-path callable) of attention j of layer i; identity / 0 in eval mode or without a module tree"""
@@ -298,7 +299,7 @@ class TrainDecoder:
         if dense is not None and dense[0] > 0:
             n, keys = dense
             kd, vd = k[keys], v[keys]
-            if self.fused:
+            if self.batched_dense:
                 from .autograd_ops import DenseHeadsAttnFn
                 tops = [DenseHeadsAttnFn.apply(q[:n], kd, vd, self.H, p_attn)]       # all heads: one batched launch per product (round 5)
             else:
@@ -337,14 +338,14 @@ class TrainDecoder:
         S = key_in.shape[0]
         sa, sa_t = self._sa_pattern(T, pad, single, dev)
         ca = (row_ptr.contiguous(), col_idx.contiguous())
-        use_c = self.fused and dn_keys is None
+        use_c = self.fused and T > 0 and S > 0        # (an empty sample takes the per-operator graph: nothing to launch)
         # the pattern grouped by key is only read by the backward: the C route builds it there (the backward has host time to spare)
         ca_t = None if use_c else ops.csr_transpose(ca[0], ca[1], S)
         ln = lambda t, n: layer_norm(t, P[n + '.weight'], P[n + '.bias'])  # noqa: E731      (mv2d_row_ln / mv2d_layer_norm_bwd)
         training = self.layers is not None and self.roi_head.training
         if use_c:
             # (round 5) the six layers + post_norm as one autograd node, launch sequences issued from C (csrc/train_decoder.hip)
-            outs = self._fused_layers(qpos, key_in, val_in, sa, sa_t, ca, ca_t, training)
+            outs = self._fused_layers(qpos, key_in, val_in, sa, sa_t, ca, ca_t, training, pad if dn_keys is not None else 0, dn_keys)
             return self._branches(outs, ref, pad, dt)
         x = torch.zeros(T, qpos.shape[1], device=dev)
         outs = []
@@ -379,7 +380,7 @@ class TrainDecoder:
             self._sa_key, self._sa = key, (sa, ops.csr_transpose(sa[0], sa[1], T))
         return self._sa
 
-    def _fused_layers(self, qpos, key_in, val_in, sa, sa_t, ca, ca_t, training):
+    def _fused_layers(self, qpos, key_in, val_in, sa, sa_t, ca, ca_t, training, pad=0, dn_keys=None):
         from .autograd_ops import DECODER_PARAMS, DecoderFn
         P, pre = self.p, 'bbox_head.transformer.decoder.'
         params = [P[f'{pre}layers.{i}.{n}'] for i in range(self.L) for n in DECODER_PARAMS] + [P[pre + 'post_norm.weight'], P[pre + 'post_norm.bias']]
@@ -393,7 +394,8 @@ class TrainDecoder:
                 return float(getattr(a.attn, 'dropout', 0.0) or 0.0), comb(pdrop(getattr(a, 'proj_drop', None)), pdrop(getattr(a, 'dropout_layer', None)))
             ffn = lay.ffns[0]
             drops = att(lay.attentions[0]) + att(lay.attentions[1]) + (pdrop(ffn.layers[0][2]), comb(pdrop(ffn.layers[2]), pdrop(getattr(ffn, 'dropout_layer', None))))
-        meta = dict(L=self.L, sa=sa, sa_t=sa_t, ca=ca, ca_t=ca_t, drops=drops, seed=self._next_seed(1.0 if any(drops) else 0.0))
+        meta = dict(L=self.L, sa=sa, sa_t=sa_t, ca=ca, ca_t=ca_t, drops=drops, seed=self._next_seed(1.0 if any(drops) else 0.0), pad=pad,
+                    dn_keys=None if (dn_keys is None or pad == 0) else dn_keys.to(torch.int32).contiguous())
         return DecoderFn.apply(qpos.contiguous(), key_in.contiguous(), val_in.contiguous(), meta, *[p if p.is_contiguous() else p.contiguous() for p in params])
 
     def _branches(self, outs, ref, pad, dt):
@@ -402,6 +404,8 @@ class TrainDecoder:
         from .autograd_ops import layer_norm, linear
         P, dev = self.p, ref.device
         ln = lambda t, n: layer_norm(t, P[n + '.weight'], P[n + '.bias'])  # noqa: E731
+        if torch.is_tensor(outs) and outs.shape[1] == 0:
+            outs = list(outs.unbind(0))
         if torch.is_tensor(outs):
             # (round 5) all branches of all layers as one autograd node, the layers side by side on streams (mv2d_train_heads_fwd / _bwd)
             from .autograd_ops import BRANCH_PARAMS, HeadsFn

@@ -726,9 +726,10 @@ def _captured_decoder_call(prob_name, kind, train_mode=False, denoise=False):
     return head, got['a'], got['k']
 
 
-def _decoder_outputs_and_grads(head, a, k, fused, g=None):
+def _decoder_outputs_and_grads(head, a, k, fused, g=None, batched_dense=None):
     dec = head._train_decoder
     dec.fused = fused
+    dec.batched_dense = fused if batched_dense is None else batched_dense
     for p in head.parameters():
         p.grad = None
     ref, key_in, val_in = (t.detach().clone().requires_grad_(True) for t in a[:3])
@@ -769,14 +770,16 @@ def test_decoder_issued_from_c_equals_the_operator_graph(prob_name, kind):
     assert worst[0] <= 1e-4, worst
 
 
-def test_denoising_rows_batched_dense_block_equals_the_per_head_loop():
-    """With denoising queries (the two-frame head's training recipe) the layers stay on the per-operator graph, but their dense block runs
-    all heads in one batched launch per product and the branches come from the C entry: the same outputs (softmax over a padded row: a few
-    ulp) and gradients (by norm: a ReLU unit within rounding of zero may switch) as the per-head loop of rounds 3-4."""
+@pytest.mark.parametrize('route', ['c_entry', 'batched_dense'])
+def test_denoising_rows_equal_the_per_head_loop(route):
+    """With denoising queries (the two-frame head's training recipe) the first `pad` rows of the cross attention are a dense block over the keys
+    any RoI sees.  'c_entry': the whole decoder incl. that block from mv2d_train_decoder_* (batched products, its own softmax + dropout
+    kernel); 'batched_dense': the per-operator graph with the block batched over the heads -- both against the per-head loop of rounds 3-4:
+    the same outputs (softmax summation order: a few ulp) and gradients (by norm: a ReLU unit within rounding of zero may switch)."""
     head, a, k = _captured_decoder_call('cfg1_t', 'T', denoise=True)
     assert k.get('dn_keys') is not None
     cls0, reg0, g0, g, _ = _decoder_outputs_and_grads(head, a, k, False)
-    cls1, reg1, g1, _, _ = _decoder_outputs_and_grads(head, a, k, True, g)
+    cls1, reg1, g1, _, _ = _decoder_outputs_and_grads(head, a, k, route == 'c_entry', g, batched_dense=True)
     assert float((cls1 - cls0).abs().max()) <= 2e-5 * float(cls0.abs().max()) and float((reg1 - reg0).abs().max()) <= 2e-5 * float(reg0.abs().max())
     top = max(float(v.norm()) for n, v in g0.items() if n not in ('key_in', 'val_in', 'ref'))
     errs = {n: float((g1[n] - v).norm()) / float(v.norm()) for n, v in g0.items() if float(v.norm()) >= 1e-5 * top}
@@ -784,12 +787,13 @@ def test_denoising_rows_batched_dense_block_equals_the_per_head_loop():
     assert worst[1] <= 5e-2 and sorted(errs.values())[len(errs) // 2] <= 2e-3, (worst, sorted(errs.values())[len(errs) // 2])
 
 
-def test_decoder_issued_from_c_dropout_masks_of_forward_and_backward_agree():
+@pytest.mark.parametrize('prob_name,kind,denoise', [('cfg1_s', 'S', False), ('cfg1_t', 'T', True)])
+def test_decoder_issued_from_c_dropout_masks_of_forward_and_backward_agree(prob_name, kind, denoise):
     """Training mode (dropout 0.1 on the attention probabilities, both attentions' output paths and twice in the FFN -- configs/mv2d/exp/*:67-79):
     the backward regenerates the masks of the forward from (seed, layer, site, element).  With the mask counter pinned, f is a fixed
     piecewise-smooth function of the parameters, so a central difference along the gradient direction must reproduce |grad|; two different
     draws give different outputs; eval mode drops nothing."""
-    head, a, k = _captured_decoder_call('cfg1_s', 'S', train_mode=True)
+    head, a, k = _captured_decoder_call(prob_name, kind, train_mode=True, denoise=denoise)
     dec = head._train_decoder
     names = [n for n, _ in head.named_parameters() if 'transformer.decoder' in n]
     P = dict(head.named_parameters())
