@@ -225,35 +225,109 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(float* __restrict
     float* d = dst + (long long)(idx ? idx[i] : i) * C + c;
     st4(d, add4(ld4(d), ld4(src + (long long)i * C + c)));
 }
-// P = softmax over the first `cols` entries of every row of S [rows, ld]; Pd = dropout(P) (counter hash of the element's offset).  Block per row.
-__global__ __launch_bounds__(256) void softmax_drop_rows_kernel(const float* __restrict__ S, float* __restrict__ P, float* __restrict__ Pd, long long ld,
-                                                                int cols, Drop d) {
-    __shared__ float red[4];
-    const long long o = (long long)blockIdx.x * ld;
-    float m = -INFINITY;
-    for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, S[o + c]);
+// P = softmax over the first `cols` entries of every row of S [rows, ld]; Pd = dropout(P) (counter hash of the element's offset).  One
+// 1024-thread block per row; a row of up to 32 k entries is read ONCE and kept in registers (these matrices are 200 MB each: every pass over
+// one costs ~60 us), longer rows are re-read.
+constexpr int SMR = 32;
+__device__ __forceinline__ float block_max_1024(float v, float* red) {
 #pragma unroll
-    for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    for (int k = 32; k >= 1; k >>= 1) v = fmaxf(v, __shfl_xor(v, k, 64));
     __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    float s = 0.f;
-    for (int c = threadIdx.x; c < cols; c += 256) s += expf(S[o + c] - m);
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    const float inv = 1.f / ((red[0] + red[1]) + (red[2] + red[3]));
-    for (int c = threadIdx.x; c < cols; c += 256) {
-        const float pj = expf(S[o + c] - m) * inv;
-        P[o + c] = pj;
-        if (Pd != P) Pd[o + c] = pj * drop_factor(d, (unsigned int)(o + c));
-    }
+    float m = red[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) m = fmaxf(m, red[k]);
+    return m;
 }
-// Pd = dropout(P) again (the backward regenerates the mask of softmax_drop_rows_kernel from the same counter)
-__global__ __launch_bounds__(256) void drop_regen_kernel(const float* __restrict__ P, float* __restrict__ Pd, long long ld, int cols, Drop d) {
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k];
+    return t;
+}
+__global__ __launch_bounds__(1024) void softmax_drop_rows_kernel(const float* __restrict__ S, float* __restrict__ P, float* __restrict__ Pd, long long ld,
+                                                                 int cols, Drop d) {
+    __shared__ float red[16];
     const long long o = (long long)blockIdx.x * ld;
-    for (int c = threadIdx.x; c < cols; c += 256) Pd[o + c] = P[o + c] * drop_factor(d, (unsigned int)(o + c));
+    const bool in_regs = cols <= SMR * 1024;
+    float v[SMR];
+    float m = -INFINITY;
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < SMR; ++k) {
+            const int c = threadIdx.x + 1024 * k;
+            v[k] = c < cols ? S[o + c] : -INFINITY;
+            m = fmaxf(m, v[k]);
+        }
+    } else
+        for (int c = threadIdx.x; c < cols; c += 1024) m = fmaxf(m, S[o + c]);
+    m = block_max_1024(m, red);
+    float s = 0.f;
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < SMR; ++k) { v[k] = expf(v[k] - m); s += v[k]; }         // exp(-inf) = 0 beyond the row
+    } else
+        for (int c = threadIdx.x; c < cols; c += 1024) s += expf(S[o + c] - m);
+    const float inv = 1.f / block_sum_1024(s, red);
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < SMR; ++k) {
+            const int c = threadIdx.x + 1024 * k;
+            if (c < cols) {
+                const float pj = v[k] * inv;
+                P[o + c] = pj;
+                if (Pd != P) Pd[o + c] = pj * drop_factor(d, (unsigned int)(o + c));
+            }
+        }
+    } else
+        for (int c = threadIdx.x; c < cols; c += 1024) {
+            const float pj = expf(S[o + c] - m) * inv;
+            P[o + c] = pj;
+            if (Pd != P) Pd[o + c] = pj * drop_factor(d, (unsigned int)(o + c));
+        }
+}
+// Softmax backward of the dense block with the dropout mask REGENERATED from the counter (no stored mask): Pd = P m (written for the dv
+// product when dropout is on), dS = P (dP m - sum_j P_j dP_j m_j) in place of dP.  P and dP are read once (rows up to 32 k entries).
+__global__ __launch_bounds__(1024) void softmax_drop_bwd_rows_kernel(const float* __restrict__ P, float* __restrict__ Pd, float* __restrict__ dP, long long ld,
+                                                                     int cols, Drop d) {
+    __shared__ float red[16];
+    const long long o = (long long)blockIdx.x * ld;
+    const bool in_regs = cols <= (SMR / 2) * 1024;
+    float pv[SMR / 2], gv[SMR / 2];
+    float s = 0.f;
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < SMR / 2; ++k) {
+            const int c = threadIdx.x + 1024 * k;
+            pv[k] = 0.f; gv[k] = 0.f;
+            if (c < cols) {
+                const float f = drop_factor(d, (unsigned int)(o + c));
+                pv[k] = P[o + c];
+                gv[k] = dP[o + c] * f;
+                if (Pd) Pd[o + c] = pv[k] * f;
+                s += pv[k] * gv[k];
+            }
+        }
+    } else
+        for (int c = threadIdx.x; c < cols; c += 1024) {
+            const float f = drop_factor(d, (unsigned int)(o + c)), pj = P[o + c];
+            if (Pd) Pd[o + c] = pj * f;
+            s += pj * (dP[o + c] * f);
+        }
+    const float r = block_sum_1024(s, red);
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < SMR / 2; ++k) {
+            const int c = threadIdx.x + 1024 * k;
+            if (c < cols) dP[o + c] = pv[k] * (gv[k] - r);
+        }
+    } else
+        for (int c = threadIdx.x; c < cols; c += 1024) dP[o + c] = P[o + c] * (dP[o + c] * drop_factor(d, (unsigned int)(o + c)) - r);
 }
 // out = sum of n buffers (fixed order)
 struct SumArgs { const float* src[16]; int n; };
@@ -491,7 +565,7 @@ extern "C" int mv2d_train_decoder_fwd(const mv2d_td_dims* d, const float* const*
             TD_RC(mainl.bgemm(a.q_ca, C, HD, 0, a.kd, C, HD, 0, dn_S, nkp, (long long)pad * nkp, pad, nk, HD, 1.f));
             const Drop d6 = mk_drop(d->p_ca_attn, site_seed(d->seed, l, 6));
             float* pd = d6.thr ? dn_Pd : a.P;
-            hipLaunchKernelGGL(softmax_drop_rows_kernel, dim3(NH * pad), dim3(256), 0, st, (const float*)dn_S, a.P, pd, (long long)nkp, nk, d6);
+            hipLaunchKernelGGL(softmax_drop_rows_kernel, dim3(NH * pad), dim3(1024), 0, st, (const float*)dn_S, a.P, pd, (long long)nkp, nk, d6);
             TD_RC(mainl.bgemm(pd, nkp, (long long)pad * nkp, 0, a.vd, C, HD, 1, a.ctx_ca, C, HD, pad, HD, nk, 1.f));
         }
         if (T > pad)
@@ -616,9 +690,9 @@ extern "C" int mv2d_train_decoder_bwd(const mv2d_td_dims* d, const float* const*
             // the denoising rows' dense block: dP = g v^T, dS = softmax backward (with the regenerated dropout mask), dq = dS k / sqrt(d)
             TD_RC(mainl.bgemm(b.dctx2, C, HD, 0, a.vd, C, HD, 0, b.dS, nkp, (long long)pad * nkp, pad, nk, HD, 1.f));
             const Drop d6 = mk_drop(d->p_ca_attn, site_seed(d->seed, l, 6));
-            if (d6.thr) hipLaunchKernelGGL(drop_regen_kernel, dim3(NH * pad), dim3(256), 0, st, (const float*)a.P, b.Pd, (long long)nkp, nk, d6);
             pd_l = d6.thr ? b.Pd : a.P;
-            TD_RC(mv2d_softmax_bwd_rows(a.P, pd_l, b.dS, nkp, NH * pad, nk, d6.scale, st));
+            hipLaunchKernelGGL(softmax_drop_bwd_rows_kernel, dim3(NH * pad), dim3(1024), 0, st, (const float*)a.P, d6.thr ? b.Pd : (float*)nullptr, b.dS,
+                               (long long)nkp, nk, d6);
             TD_RC(mainl.bgemm(b.dS, nkp, (long long)pad * nkp, 0, a.kd, C, HD, 1, b.dq2, C, HD, pad, HD, nk, qs));
         }
         const long long po = (long long)pad * C;
