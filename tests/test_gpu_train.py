@@ -853,3 +853,104 @@ def test_dense_block_of_the_denoising_rows_batched_over_heads(n, nk, p):
     for got, want, name in ((out, ref, 'out'), (qa.grad, qd.grad, 'dq'), (ka.grad, kd.grad, 'dk'), (va.grad, vd.grad, 'dv')):
         err = float((got.double() - want).abs().max() / want.abs().max())
         assert err < 1e-4, (name, err)
+
+
+# ---- round 5: the extended product entries and the small fused nodes, one by one ---------------------------------------------------------
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 256, 256), (300, 256, 2048), (37, 10, 256), (5000, 256, 256)])
+def test_gemm_ex_alpha_accumulate_bf16(M, N, K):
+    """mv2d_gemm_f32x3_ex: C = (A B^T + bias) * alpha, C += ..., bf16 output -- against fp64 (split precision: ~1e-5 of the output maximum)."""
+    from mv2d_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device='cpu').manual_seed(M + N + K)
+    A, B, bias, C0 = (torch.randn(s, generator=g).to(DEV) for s in ((M, K), (N, K), (N,), (M, N)))
+    ws = torch.empty(max(int(lib.mv2d_gemm_f32x3_ws_bytes(M, N, K)), 1) + 512, device=DEV, dtype=torch.uint8)
+    want = (A.double() @ B.double().t() + bias.double()) * 0.25
+    scale = float(want.abs().max())
+
+    def run(acc, bf16, out):
+        _lib.check(lib.mv2d_gemm_f32x3_ex(A.data_ptr(), K, 0, B.data_ptr(), K, 0, bias.data_ptr(), 0, 0.25, acc, bf16, out.data_ptr(), N, M, N, K,
+                                          ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), 'gemm_ex')
+        return out
+    out = run(0, 0, torch.empty(M, N, device=DEV))
+    assert float((out.double() - want).abs().max()) <= 3e-5 * scale
+    acc = run(1, 0, C0.clone())
+    assert float((acc.double() - (want + C0.double())).abs().max()) <= 3e-5 * scale
+    b16 = run(0, 1, torch.empty(M, N, device=DEV, dtype=torch.bfloat16))
+    assert torch.equal(b16, out.to(torch.bfloat16))                     # the same fp32 value, rounded once
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 256, 256), (300, 2048, 256), (300, 10, 256), (14700, 256, 256), (700, 256, 2048)])
+def test_wgrad_with_bias_gradient_and_masked_dgrad(M, N, K):
+    """mv2d_wgrad_f32x3 (dW = g^T x, db = column sums of g inside the product's kernel when it runs in one pass, a separate sum after split-K)
+    and mv2d_dgrad_relu_f32x3 (dx = (g W) alpha where y > 0) against fp64."""
+    from mv2d_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device='cpu').manual_seed(M * 3 + N)
+    g, x, W, y = (torch.randn(s, generator=gen).to(DEV) for s in ((M, N), (M, K), (N, K), (M, K)))
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(max(int(lib.mv2d_gemm_f32x3_ws_bytes(N, K, M)), 1) + 512, device=DEV, dtype=torch.uint8)
+    cs = torch.empty((max(int(lib.mv2d_colsum_scratch_rows(M)), 1), N), device=DEV)
+    dW, db = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+    _lib.check(lib.mv2d_wgrad_f32x3(g.data_ptr(), x.data_ptr(), dW.data_ptr(), db.data_ptr(), M, N, K, ws.data_ptr(), ws.numel(), cs.data_ptr(), st), 'wgrad')
+    wW, wb = g.double().t() @ x.double(), g.double().sum(0)
+    assert float((dW.double() - wW).abs().max()) <= 3e-5 * float(wW.abs().max())
+    assert float((db.double() - wb).abs().max()) <= 1e-5 * float(wb.abs().max()) + 1e-4
+    dx = torch.empty(M, K, device=DEV)
+    _lib.check(lib.mv2d_dgrad_relu_f32x3(g.data_ptr(), W.data_ptr(), y.data_ptr(), 1.25, dx.data_ptr(), M, N, K, st), 'dgrad_relu')
+    want = torch.where(y > 0, (g.double() @ W.double()) * 1.25, torch.zeros((), device=DEV, dtype=torch.float64))
+    assert float((dx.double() - want).abs().max()) <= 3e-5 * float(want.abs().max())
+    assert bool((dx[y <= 0] == 0).all())
+
+
+def test_box_code_node_equals_the_torch_expression():
+    """BoxCodeFn (mv2d_box_code_fwd / _bwd) against the reference's expression (cross_attention_head.py:216-238; velocities of the rows >= pad
+    divided by dt, RH/mv2d_t_head.py:136-140) under torch autograd: boxes, d t, d reference points -- incl. reference points outside (0, 1)."""
+    from mv2d_amd.autograd_ops import BoxCodeFn
+    L, T, pad, dt = 6, 77, 13, 0.5
+    rng = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+    gen = torch.Generator(device='cpu').manual_seed(2)
+    t = torch.randn(L, T, 10, generator=gen).to(DEV)
+    ref = (torch.rand(T, 3, generator=gen) * 1.2 - 0.1).to(DEV)
+    ref[0, 0], ref[1, 1] = 0.0, 1.0
+    go = torch.randn(L, T, 10, generator=gen).to(DEV)
+    t1, r1 = t.clone().requires_grad_(True), ref.clone().requires_grad_(True)
+    out = BoxCodeFn.apply(t1, r1, rng, pad, dt)
+    out.backward(go)
+    t2, r2 = t.double().clone().requires_grad_(True), ref.double().clone().requires_grad_(True)
+    r = r2.clamp(0, 1)
+    inv = torch.log(r.clamp(min=1e-5) / (1 - r).clamp(min=1e-5))
+    lo, hi = torch.tensor(rng[:3], device=DEV, dtype=torch.float64), torch.tensor(rng[3:], device=DEV, dtype=torch.float64)
+    cxyz = (torch.cat([t2[..., 0:2], t2[..., 4:5]], -1) + inv).sigmoid() * (hi - lo) + lo
+    vel = torch.cat([t2[:, :pad, 8:10], t2[:, pad:, 8:10] / dt], 1)
+    want = torch.cat([cxyz[..., 0:2], t2[..., 2:4], cxyz[..., 2:3], t2[..., 5:8], vel], -1)
+    want.backward(go.double())
+    assert float((out.double() - want).abs().max()) <= 2e-5
+    assert float((t1.grad.double() - t2.grad).abs().max()) <= 2e-5 * float(t2.grad.abs().max())
+    assert float((r1.grad.double() - r2.grad).abs().max()) <= 1e-4 * float(r2.grad.abs().max())
+
+
+def test_position_embedding_node_gradient():
+    """PosEmbFn: forward = mv2d_posemb3d (the inference kernel), backward from the saved embedding -- against torch autograd of pos2posemb3d
+    (MU/pe.py:20-33)."""
+    import math
+    from mv2d_amd.autograd_ops import PosEmbFn
+    gen = torch.Generator(device='cpu').manual_seed(4)
+    ref = torch.rand(123, 3, generator=gen).to(DEV)
+    go = torch.randn(123, 384, generator=gen).to(DEV)
+    dim_t = torch.arange(128, dtype=torch.float32)
+    dim_t = (10000 ** (2 * (dim_t // 2) / 128)).to(DEV)
+    r1 = ref.clone().requires_grad_(True)
+    PosEmbFn.apply(r1, dim_t).backward(go)
+    r2 = ref.double().clone().requires_grad_(True)
+
+    def emb(p):
+        p = (p * (2 * math.pi))[..., None] / dim_t.double()
+        return torch.stack((p[..., 0::2].sin(), p[..., 1::2].cos()), dim=-1).flatten(-2)
+    want = torch.cat((emb(r2[..., 1]), emb(r2[..., 0]), emb(r2[..., 2])), dim=-1)
+    want.backward(go.double())
+    assert float((PosEmbFn.apply(ref, dim_t).double() - want).abs().max()) <= 2e-4        # (fp32 argument of sin / cos at up to 2 pi)
+    assert float((r1.grad.double() - r2.grad).abs().max()) <= 2e-4 * float(r2.grad.abs().max())
