@@ -880,7 +880,8 @@ def test_gemm_ex_alpha_accumulate_bf16(M, N, K):
     acc = run(1, 0, C0.clone())
     assert float((acc.double() - (want + C0.double())).abs().max()) <= 3e-5 * scale
     b16 = run(0, 1, torch.empty(M, N, device=DEV, dtype=torch.bfloat16))
-    assert torch.equal(b16, out.to(torch.bfloat16))                     # the same fp32 value, rounded once
+    # the fp32 value rounded once (a long contraction runs in one pass here, split-K above: the two fp32 values differ in their last bits)
+    assert bool(((b16.float() - out).abs() <= 2.0 ** -8 * out.abs() + 1e-6 * scale).all())
 
 
 @pytest.mark.parametrize('M,N,K', [(300, 256, 256), (300, 2048, 256), (300, 10, 256), (14700, 256, 256), (700, 256, 2048)])
