@@ -632,6 +632,11 @@ int mv2d_box_code_bwd(const float* g, const float* out, const float* ref, float*
  * or an infeasible problem (SciPy raises there). */
 int mv2d_lsap_layers(const float* cost, int L, int R, int G, int* match, int threads);
 
+/* The unfolded input of the query generator's 3 x 3 convolution over the 7 x 7 RoI features (RH/utils/query_generator.py:352-366; padding 1), so
+ * that the convolution is one product: x [R,49,256] -> cols [R*49, 2304], column order (tap = 3 ky + kx, channel); and its gradient. */
+int mv2d_im2col3x3(const float* x, float* cols, int R, void* stream);
+int mv2d_col2im3x3(const float* dcols, float* dx, int R, void* stream);
+
 /* Backward of mv2d_roi_align w.r.t. one map (training; mmcv's roi_align backward): grad_out [R][49][256] fp32 ->
  * grad_map [rows][256] fp32, ACCUMULATED with hardware fp32 atomics (the caller zeroes it; the summation order varies between runs).
  * index (may be null): position -> row of a compacted map, negative = no row (as map1_index of the forward). */

@@ -455,3 +455,24 @@ class DenseHeadsAttnFn(torch.autograd.Function):
         _bgemm(dS, nkp, n * nkp, True, q, Cc, d, True, dk, Cc, d, nk, d, n, H)                     # dk_h = dS_h^T q_h
         _bgemm(Pd, nkp, n * nkp, True, g, Cc, d, True, dv, Cc, d, nk, d, n, H)                     # dv_h = Pd_h^T g_h
         return dq, dk, dv, None, None
+
+
+class Im2Col3x3Fn(torch.autograd.Function):
+    """x [R,49,256] (7 x 7 cells) -> the unfolded input [R*49, 2304] of a 3 x 3 convolution with padding 1, column order (tap, channel):
+    ``mv2d_im2col3x3`` / ``mv2d_col2im3x3`` -- one launch per direction."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _rows3(x)
+        R = x.shape[0]
+        cols = torch.empty((R * 49, 2304), device=x.device, dtype=F32)
+        check(_lib.load().mv2d_im2col3x3(_p(x), _p(cols), R, _stream()), 'mv2d_im2col3x3')
+        ctx.R = R
+        return cols
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _rows3(g)
+        dx = torch.empty((ctx.R, 49, 256), device=g.device, dtype=F32)
+        check(_lib.load().mv2d_col2im3x3(_p(g), _p(dx), ctx.R, _stream()), 'mv2d_col2im3x3')
+        return dx

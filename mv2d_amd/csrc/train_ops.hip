@@ -205,3 +205,60 @@ extern "C" int mv2d_linear_bwd_x3(const float* x, const float* W, const float* y
     if (db) return mv2d_colsum(g, N, M, N, db, mv2d_colsum_scratch_rows(M) ? (float*)w : nullptr, stream);
     return MV2D_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The query generator's 3 x 3 convolution over the 7 x 7 RoI features (RH/utils/query_generator.py:352-366, padding 1) runs as ONE product
+// over the unfolded input: cols [R * 49, 9 * 256], column order (tap = 3 ky + kx, channel).  Rounds 3-4 unfolded with torch (pad + nine
+// shifted views + cat: 11 launches forward, ~30 backward with nine zero-filled gradients); here one kernel per direction.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// cols[(r, y, x), tap, c] = x[r, (y + ky - 1, x + kx - 1), c] or 0 outside the 7 x 7 cell grid
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ in, float* __restrict__ cols, int R) {
+    const int pos = blockIdx.x * 4 + (threadIdx.x >> 6), c = 4 * (threadIdx.x & 63);
+    if (pos >= R * 49) return;
+    const int r = pos / 49, p = pos % 49, y = p / 7, x = p % 7;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (yy >= 0 && yy < 7 && xx >= 0 && xx < 7) v = *reinterpret_cast<const float4*>(in + ((long long)r * 49 + yy * 7 + xx) * 256 + c);
+        *reinterpret_cast<float4*>(cols + (long long)pos * 2304 + tap * 256 + c) = v;
+    }
+}
+// dx[r, (y, x), c] = sum over the taps of dcols[(r, y - ky + 1, x - kx + 1), tap, c] (fixed order)
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict__ dcols, float* __restrict__ dx, int R) {
+    const int pos = blockIdx.x * 4 + (threadIdx.x >> 6), c = 4 * (threadIdx.x & 63);
+    if (pos >= R * 49) return;
+    const int r = pos / 49, p = pos % 49, y = p / 7, x = p % 7;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y - tap / 3 + 1, xx = x - tap % 3 + 1;
+        if (yy >= 0 && yy < 7 && xx >= 0 && xx < 7) {
+            const float4 v = *reinterpret_cast<const float4*>(dcols + ((long long)r * 49 + yy * 7 + xx) * 2304 + tap * 256 + c);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    *reinterpret_cast<float4*>(dx + (long long)pos * 256 + c) = s;
+}
+
+}  // namespace
+
+// x [R, 49, 256] fp32 (7 x 7 cells, row-major) -> cols [R * 49, 2304]
+extern "C" int mv2d_im2col3x3(const float* x, float* cols, int R, void* stream) {
+    MV2D_CHECK_ARG(x && cols && R >= 0, "mv2d_im2col3x3: bad args");
+    if (R == 0) return MV2D_OK;
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(cdiv(R * 49, 4)), dim3(256), 0, (hipStream_t)stream, x, cols, R);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}
+
+// gradient of mv2d_im2col3x3: dcols [R * 49, 2304] -> dx [R, 49, 256]
+extern "C" int mv2d_col2im3x3(const float* dcols, float* dx, int R, void* stream) {
+    MV2D_CHECK_ARG(dcols && dx && R >= 0, "mv2d_col2im3x3: bad args");
+    if (R == 0) return MV2D_OK;
+    hipLaunchKernelGGL(col2im3x3_kernel, dim3(cdiv(R * 49, 4)), dim3(256), 0, (hipStream_t)stream, dcols, dx, R);
+    MV2D_LAUNCH_CHECK();
+    return MV2D_OK;
+}

@@ -475,9 +475,10 @@ def query_generator_autograd(roi_head, roi_feat, intr_feat, minv):
     qg = roi_head.query_generator
     R = roi_feat.shape[0]
     Cc = roi_feat.shape[-1]
-    # conv3x3 (padding 1) as im2col (index plumbing: pad + 9 shifted views) + ONE product on the HIP GEMM, k order (tap, channel)
-    xp = F.pad(roi_feat.float().view(R, 7, 7, Cc), (0, 0, 1, 1, 1, 1))
-    cols = torch.cat([xp[:, ky:ky + 7, kx:kx + 7] for ky in range(3) for kx in range(3)], -1).reshape(R * 49, 9 * Cc)
+    # conv3x3 (padding 1) as im2col + ONE product on the HIP GEMM, k order (tap, channel); the unfolding is one launch per direction (round 5)
+    from .autograd_ops import Im2Col3x3Fn
+    assert Cc == 256
+    cols = Im2Col3x3Fn.apply(roi_feat.float().reshape(R, 49, Cc))
     conv = qg.shared_convs[0].conv
     x = linear(cols, conv.weight.permute(0, 2, 3, 1).reshape(conv.weight.shape[0], 9 * Cc), conv.bias, 1).view(R, 49, -1).mean(1)   # ReLU, AvgPool2d(7)
     x = linear(x, qg.shared_fcs[0].weight, qg.shared_fcs[0].bias, 1)
