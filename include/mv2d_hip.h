@@ -637,6 +637,11 @@ int mv2d_lsap_layers(const float* cost, int L, int R, int G, int* match, int thr
 int mv2d_im2col3x3(const float* x, float* cols, int R, void* stream);
 int mv2d_col2im3x3(const float* dcols, float* dx, int R, void* stream);
 
+/* center2lidar + normalisation of the reference points for training (RH/utils/query_generator.py:333-341, RH/mv2d_s_head.py:146-152):
+ * c [R,3] = (u, v, depth), minv [R,16] -> ref [R,3] = ((minv (u d, v d, d, 1))[:3] - low) / range; the backward returns d c.  pc_range: 6 HOST floats. */
+int mv2d_center2lidar_fwd(const float* c, const float* minv, float* ref, int R, const float* pc_range, void* stream);
+int mv2d_center2lidar_bwd(const float* g, const float* c, const float* minv, float* dc, int R, const float* pc_range, void* stream);
+
 /* Backward of mv2d_roi_align w.r.t. one map (training; mmcv's roi_align backward): grad_out [R][49][256] fp32 ->
  * grad_map [rows][256] fp32, ACCUMULATED with hardware fp32 atomics (the caller zeroes it; the summation order varies between runs).
  * index (may be null): position -> row of a compacted map, negative = no row (as map1_index of the forward). */

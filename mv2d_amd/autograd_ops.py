@@ -476,3 +476,27 @@ class Im2Col3x3Fn(torch.autograd.Function):
         dx = torch.empty((ctx.R, 49, 256), device=g.device, dtype=F32)
         check(_lib.load().mv2d_col2im3x3(_p(g), _p(dx), ctx.R, _stream()), 'mv2d_col2im3x3')
         return dx
+
+
+class Center2LidarFn(torch.autograd.Function):
+    """(u, v, depth) of every RoI + inverse(K_roi E^T) -> normalised reference point (RH/utils/query_generator.py:333-341,
+    RH/mv2d_s_head.py:146-152): ``mv2d_center2lidar_fwd`` / ``_bwd``, one launch each; differentiable in c."""
+
+    @staticmethod
+    def forward(ctx, c, minv, pc_range):
+        c, minv = _rows3(c), _rows3(minv)
+        R = c.shape[0]
+        ref = torch.empty((R, 3), device=c.device, dtype=F32)
+        rng = (_lib.C.c_float * 6)(*[float(v) for v in pc_range])
+        check(_lib.load().mv2d_center2lidar_fwd(_p(c), _p(minv), _p(ref), R, _lib.C.addressof(rng), _stream()), 'mv2d_center2lidar_fwd')
+        ctx.save_for_backward(c, minv)
+        ctx.rng = rng
+        return ref
+
+    @staticmethod
+    def backward(ctx, g):
+        c, minv = ctx.saved_tensors
+        dc = torch.empty_like(c)
+        check(_lib.load().mv2d_center2lidar_bwd(_p(_rows3(g)), _p(c), _p(minv), _p(dc), c.shape[0], _lib.C.addressof(ctx.rng), _stream()),
+              'mv2d_center2lidar_bwd')
+        return dc, None, None

@@ -486,14 +486,8 @@ def query_generator_autograd(roi_head, roi_feat, intr_feat, minv):
     x = linear(x, qg.extra_enc[0].weight, qg.extra_enc[0].bias, 1)
     x = linear(x, qg.extra_enc[2].weight, qg.extra_enc[2].bias, 1)
     c = linear(x, qg.fc_center.weight, qg.fc_center.bias)
-    hom = torch.cat([c[:, :2] * c[:, 2:3], c[:, 2:3], torch.ones_like(c[:, :1])], 1)
-    xyz = (minv.detach().view(R, 4, 4) * hom[:, None, :]).sum(-1)[:, :3]                 # per-RoI 4x4 matrix . vector, element-wise (no BLAS call)
-    rng = roi_head.__dict__.get('_qg_range')
-    if rng is None or rng[0].device != xyz.device:                      # (constants: uploaded once)
-        pr = [float(v) for v in roi_head.pc_range]
-        lo = xyz.new_tensor(pr[:3])
-        rng = roi_head.__dict__['_qg_range'] = (lo, xyz.new_tensor(pr[3:]) - lo)
-    return (xyz - rng[0]) / rng[1]
+    from .autograd_ops import Center2LidarFn
+    return Center2LidarFn.apply(c, minv.detach().reshape(R, 16), [float(v) for v in roi_head.pc_range])      # one launch per direction (round 5)
 
 
 def key_embedding_autograd(roi_head, A1, A2, Xf):

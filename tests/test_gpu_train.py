@@ -955,3 +955,36 @@ def test_position_embedding_node_gradient():
     want.backward(go.double())
     assert float((PosEmbFn.apply(ref, dim_t).double() - want).abs().max()) <= 2e-4        # (fp32 argument of sin / cos at up to 2 pi)
     assert float((r1.grad.double() - r2.grad).abs().max()) <= 2e-4 * float(r2.grad.abs().max())
+
+
+def test_center2lidar_node_and_unfolding_node():
+    """Center2LidarFn against the torch expression of the reference (query_generator.py:333-341, mv2d_s_head.py:146-152) under autograd;
+    Im2Col3x3Fn against pad + nine shifted views (what F.unfold does), forward and gradient."""
+    import torch.nn.functional as F
+    from mv2d_amd.autograd_ops import Center2LidarFn, Im2Col3x3Fn
+    gen = torch.Generator(device='cpu').manual_seed(8)
+    R, rng = 57, [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+    c = (torch.randn(R, 3, generator=gen) * torch.tensor([300.0, 200.0, 10.0]) + torch.tensor([400.0, 200.0, 30.0])).to(DEV)
+    minv = torch.randn(R, 16, generator=gen).to(DEV)
+    go = torch.randn(R, 3, generator=gen).to(DEV)
+    c1 = c.clone().requires_grad_(True)
+    ref = Center2LidarFn.apply(c1, minv, rng)
+    ref.backward(go)
+    c2 = c.double().clone().requires_grad_(True)
+    hom = torch.cat([c2[:, :2] * c2[:, 2:3], c2[:, 2:3], torch.ones_like(c2[:, :1])], 1)
+    xyz = (minv.double().view(R, 4, 4) * hom[:, None, :]).sum(-1)[:, :3]
+    lo, hi = torch.tensor(rng[:3], device=DEV, dtype=torch.float64), torch.tensor(rng[3:], device=DEV, dtype=torch.float64)
+    want = (xyz - lo) / (hi - lo)
+    want.backward(go.double())
+    assert float((ref.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    assert float((c1.grad.double() - c2.grad).abs().max()) <= 2e-6 * float(c2.grad.abs().max())
+    x = torch.randn(9, 49, 256, generator=gen).to(DEV)
+    gc = torch.randn(9 * 49, 2304, generator=gen).to(DEV)
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    cols = Im2Col3x3Fn.apply(x1)
+    cols.backward(gc)
+    xp = F.pad(x2.view(9, 7, 7, 256), (0, 0, 1, 1, 1, 1))
+    want = torch.cat([xp[:, ky:ky + 7, kx:kx + 7] for ky in range(3) for kx in range(3)], -1).reshape(9 * 49, 2304)
+    want.backward(gc)
+    assert torch.equal(cols, want)
+    assert float((x1.grad - x2.grad).abs().max()) <= 1e-5 * float(x2.grad.abs().max())
