@@ -642,6 +642,17 @@ int mv2d_col2im3x3(const float* dcols, float* dx, int R, void* stream);
 int mv2d_center2lidar_fwd(const float* c, const float* minv, float* ref, int R, const float* pc_range, void* stream);
 int mv2d_center2lidar_bwd(const float* g, const float* c, const float* minv, float* dc, int R, const float* pc_range, void* stream);
 
+/* Dense 8-head attention block of the denoising queries (RH/mv2d_t_head.py:90-98; MU/petr_transformer.py:404-418,501-508), forward and backward
+ * without materialising the logits: q [n,256] fp32 (already scaled by 1/sqrt(32)), k / v [nk,256] fp32 (head h = columns 32 h .. 32 h + 31) ->
+ * ctx [n,256] = dropout(softmax(q_h k_h^T)) v_h, lse [8][n] (log-sum-exp per row, for the backward).  The backward takes ctx / lse / dctx and the
+ * same (p_drop, seed) -- the mask is a counter hash of (seed, head, query, key) -- and returns dq (times dq_scale), dk, dv.
+ * ws: mv2d_dense_attn_ws_bytes(n, nk, backward) bytes, 256-byte aligned (per-head transposed copies of the operands). */
+long long mv2d_dense_attn_ws_bytes(int n, int nk, int backward);
+int mv2d_dense_attn_fwd(const float* q, const float* k, const float* v, int n, int nk, float p_drop, unsigned int seed, float* ctx, float* lse, void* ws,
+                        void* stream);
+int mv2d_dense_attn_bwd(const float* q, const float* k, const float* v, const float* ctx, const float* dctx, const float* lse, int n, int nk, float p_drop,
+                        unsigned int seed, float dq_scale, float* dq, float* dk, float* dv, void* ws, void* stream);
+
 /* Backward of mv2d_roi_align w.r.t. one map (training; mmcv's roi_align backward): grad_out [R][49][256] fp32 ->
  * grad_map [rows][256] fp32, ACCUMULATED with hardware fp32 atomics (the caller zeroes it; the summation order varies between runs).
  * index (may be null): position -> row of a compacted map, negative = no row (as map1_index of the forward). */

@@ -500,3 +500,36 @@ class Center2LidarFn(torch.autograd.Function):
         check(_lib.load().mv2d_center2lidar_bwd(_p(_rows3(g)), _p(c), _p(minv), _p(dc), c.shape[0], _lib.C.addressof(ctx.rng), _stream()),
               'mv2d_center2lidar_bwd')
         return dc, None, None
+
+
+class FlashDenseAttnFn(torch.autograd.Function):
+    """The same dense block as ``DenseHeadsAttnFn`` on ``mv2d_dense_attn_fwd`` / ``_bwd`` (csrc/dense_attn.hip): the logits of a 16-query x
+    32-key tile live in MFMA accumulators only, nothing of size [heads, n, nk] is written.  q [n,256] pre-scaled, k / v [nk,256]; the dropout mask
+    is a counter hash of (seed, head, query, key).  This is what ``mv2d_train_decoder_*`` runs for the denoising rows."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, p_drop, seed):
+        lib = _lib.load()
+        q, k, v = _rows3(q), _rows3(k), _rows3(v)
+        n, nk = q.shape[0], k.shape[0]
+        out = torch.empty_like(q)
+        lse = torch.empty((8, n), device=q.device, dtype=F32)
+        ws = torch.empty(int(lib.mv2d_dense_attn_ws_bytes(n, nk, 0)), device=q.device, dtype=torch.uint8)
+        check(lib.mv2d_dense_attn_fwd(_p(q), _p(k), _p(v), n, nk, float(p_drop), int(seed) & 0xffffffff, _p(out), _p(lse), _p(ws), _stream()),
+              'mv2d_dense_attn_fwd')
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.meta = (float(p_drop), int(seed) & 0xffffffff)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        q, k, v, out, lse = ctx.saved_tensors
+        p_drop, seed = ctx.meta
+        n, nk = q.shape[0], k.shape[0]
+        g = _rows3(g)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ws = torch.empty(int(lib.mv2d_dense_attn_ws_bytes(n, nk, 1)), device=q.device, dtype=torch.uint8)
+        check(lib.mv2d_dense_attn_bwd(_p(q), _p(k), _p(v), _p(out), _p(g), _p(lse), n, nk, p_drop, seed, 1.0, _p(dq), _p(dk), _p(dv), _p(ws), _stream()),
+              'mv2d_dense_attn_bwd')
+        return dq, dk, dv, None, None

@@ -33,12 +33,13 @@ extern "C" int mv2d_sparse_xattn_bwd_drop(const float* q, const void* K, const v
 extern "C" int mv2d_sparse_xattn_bwd_ex(const float* q, const void* K, const void* V, const int* row_ptr, const int* col_idx, const float* ctx,
                                         const float* dctx, const int* key_ptr, const int* pair_idx, const int* pair_row, float* pair_ws,
                                         float* dq, float* dK, float* dV, int R, int S, float p_drop, unsigned int seed, int long_rows, float dq_scale, void* stream);
-extern "C" long long mv2d_gemm_f32x3_batched_ws_bytes(int M, int N, int K, int batch);
-extern "C" int mv2d_gemm_f32x3_batched(const float* A, long long lda, long long batch_a, int trans_a, const float* B, long long ldb, long long batch_b,
-                                       int trans_b, float* C, long long ldc, long long batch_c, int M, int N, int K, int batch, float alpha, void* ws,
-                                       long long ws_bytes, void* stream);
-extern "C" int mv2d_softmax_bwd_rows(const float* P, const float* Pd, float* dP, long long ld, int rows, int cols, float keep_scale, void* stream);
 extern "C" int mv2d_f32_to_bf16(const float* x, void* y, long long n, void* stream);
+extern "C" long long mv2d_dense_attn_ws_bytes(int n, int nk, int backward);
+extern "C" int mv2d_dense_attn_fwd(const float* q, const float* k, const float* v, int n, int nk, float p_drop, unsigned int seed, float* ctx, float* lse,
+                                   void* ws, void* stream);
+extern "C" int mv2d_dense_attn_bwd_parts(const float* q, const float* k, const float* v, const float* ctx, const float* dctx, const float* lse, int n,
+                                         int nk, float p_drop, unsigned int seed, float dq_scale, float* dq, float* dk, float* dv, void* ws, int parts,
+                                         void* stream);
 extern "C" int mv2d_dgrad_relu_f32x3(const float* g, const float* W, const float* relu_y, float alpha, float* dx, int M, int N, int K, void* stream);
 
 // the scalar arguments of both entries (mirrored by mv2d_amd/_lib.py: TdDims)
@@ -225,110 +226,6 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(float* __restrict
     float* d = dst + (long long)(idx ? idx[i] : i) * C + c;
     st4(d, add4(ld4(d), ld4(src + (long long)i * C + c)));
 }
-// P = softmax over the first `cols` entries of every row of S [rows, ld]; Pd = dropout(P) (counter hash of the element's offset).  One
-// 1024-thread block per row; a row of up to 32 k entries is read ONCE and kept in registers (these matrices are 200 MB each: every pass over
-// one costs ~60 us), longer rows are re-read.
-constexpr int SMR = 32;
-__device__ __forceinline__ float block_max_1024(float v, float* red) {
-#pragma unroll
-    for (int k = 32; k >= 1; k >>= 1) v = fmaxf(v, __shfl_xor(v, k, 64));
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float m = red[0];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) m = fmaxf(m, red[k]);
-    return m;
-}
-__device__ __forceinline__ float block_sum_1024(float v, float* red) {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k];
-    return t;
-}
-__global__ __launch_bounds__(1024) void softmax_drop_rows_kernel(const float* __restrict__ S, float* __restrict__ P, float* __restrict__ Pd, long long ld,
-                                                                 int cols, Drop d) {
-    __shared__ float red[16];
-    const long long o = (long long)blockIdx.x * ld;
-    const bool in_regs = cols <= SMR * 1024;
-    float v[SMR];
-    float m = -INFINITY;
-    if (in_regs) {
-#pragma unroll
-        for (int k = 0; k < SMR; ++k) {
-            const int c = threadIdx.x + 1024 * k;
-            v[k] = c < cols ? S[o + c] : -INFINITY;
-            m = fmaxf(m, v[k]);
-        }
-    } else
-        for (int c = threadIdx.x; c < cols; c += 1024) m = fmaxf(m, S[o + c]);
-    m = block_max_1024(m, red);
-    float s = 0.f;
-    if (in_regs) {
-#pragma unroll
-        for (int k = 0; k < SMR; ++k) { v[k] = expf(v[k] - m); s += v[k]; }         // exp(-inf) = 0 beyond the row
-    } else
-        for (int c = threadIdx.x; c < cols; c += 1024) s += expf(S[o + c] - m);
-    const float inv = 1.f / block_sum_1024(s, red);
-    if (in_regs) {
-#pragma unroll
-        for (int k = 0; k < SMR; ++k) {
-            const int c = threadIdx.x + 1024 * k;
-            if (c < cols) {
-                const float pj = v[k] * inv;
-                P[o + c] = pj;
-                if (Pd != P) Pd[o + c] = pj * drop_factor(d, (unsigned int)(o + c));
-            }
-        }
-    } else
-        for (int c = threadIdx.x; c < cols; c += 1024) {
-            const float pj = expf(S[o + c] - m) * inv;
-            P[o + c] = pj;
-            if (Pd != P) Pd[o + c] = pj * drop_factor(d, (unsigned int)(o + c));
-        }
-}
-// Softmax backward of the dense block with the dropout mask REGENERATED from the counter (no stored mask): Pd = P m (written for the dv
-// product when dropout is on), dS = P (dP m - sum_j P_j dP_j m_j) in place of dP.  P and dP are read once (rows up to 32 k entries).
-__global__ __launch_bounds__(1024) void softmax_drop_bwd_rows_kernel(const float* __restrict__ P, float* __restrict__ Pd, float* __restrict__ dP, long long ld,
-                                                                     int cols, Drop d) {
-    __shared__ float red[16];
-    const long long o = (long long)blockIdx.x * ld;
-    const bool in_regs = cols <= (SMR / 2) * 1024;
-    float pv[SMR / 2], gv[SMR / 2];
-    float s = 0.f;
-    if (in_regs) {
-#pragma unroll
-        for (int k = 0; k < SMR / 2; ++k) {
-            const int c = threadIdx.x + 1024 * k;
-            pv[k] = 0.f; gv[k] = 0.f;
-            if (c < cols) {
-                const float f = drop_factor(d, (unsigned int)(o + c));
-                pv[k] = P[o + c];
-                gv[k] = dP[o + c] * f;
-                if (Pd) Pd[o + c] = pv[k] * f;
-                s += pv[k] * gv[k];
-            }
-        }
-    } else
-        for (int c = threadIdx.x; c < cols; c += 1024) {
-            const float f = drop_factor(d, (unsigned int)(o + c)), pj = P[o + c];
-            if (Pd) Pd[o + c] = pj * f;
-            s += pj * (dP[o + c] * f);
-        }
-    const float r = block_sum_1024(s, red);
-    if (in_regs) {
-#pragma unroll
-        for (int k = 0; k < SMR / 2; ++k) {
-            const int c = threadIdx.x + 1024 * k;
-            if (c < cols) dP[o + c] = pv[k] * (gv[k] - r);
-        }
-    } else
-        for (int c = threadIdx.x; c < cols; c += 1024) dP[o + c] = P[o + c] * (dP[o + c] * drop_factor(d, (unsigned int)(o + c)) - r);
-}
 // out = sum of n buffers (fixed order)
 struct SumArgs { const float* src[16]; int n; };
 __global__ __launch_bounds__(256) void sum_n_kernel(SumArgs a, float* __restrict__ out, long long n4) {
@@ -387,10 +284,6 @@ static long long gemm_ws_max(const mv2d_td_dims& d) {
     const int shapes[][3] = {{T, C, C}, {T, F, C}, {T, C, F}, {C, C, T}, {F, C, T}, {C, F, T}, {C, C, S}, {S, C, C}};
     long long m = 0;
     for (auto& s : shapes) { const long long b = mv2d_gemm_f32x3_ws_bytes(s[0], s[1], s[2]); if (b > m) m = b; }
-    if (d.nk > 0) {
-        const int bshapes[][3] = {{d.pad, d.nk, HD}, {d.pad, HD, d.nk}, {d.nk, HD, d.pad}};
-        for (auto& s : bshapes) { const long long b = mv2d_gemm_f32x3_batched_ws_bytes(s[0], s[1], s[2], NH); if (b > m) m = b; }
-    }
     return al256(m) + 256;
 }
 
@@ -411,11 +304,6 @@ struct Lane {
     int wgrad(const float* g, const float* x, float* dW, float* db, int M, int N, int K) const {
         return mv2d_wgrad_f32x3(g, x, dW, db, M, N, K, ws, ws_bytes, cs, st);
     }
-    // NH products over 32-column head slices of [rows, C] operands (or over [NH, M, ld] stacks: batch stride given)
-    int bgemm(const float* A, long long lda, long long sa, int ta, const float* B, long long ldb, long long sb, int tb, float* Cm, long long ldc, long long sc,
-              int M, int N, int K, float alpha) const {
-        return mv2d_gemm_f32x3_batched(A, lda, sa, ta, B, ldb, sb, tb, Cm, ldc, sc, M, N, K, NH, alpha, ws, ws_bytes, st);
-    }
     // the two parameter gradients of a LayerNorm from the per-block partial sums of ln_bwd_ex_kernel: one launch
     void ln_params(const float* pw, const float* pb, int nb, float* gw, float* gb) const;
 };
@@ -430,7 +318,7 @@ static inline unsigned int blocks4(long long n) { return (unsigned int)((n / 4 +
 struct Act {
     float *xq, *q_sa, *ctx_sa, *s1, *x1, *xq1, *q_ca, *ctx_ca, *s2, *x2, *h, *s3, *x3;
     unsigned short *k_sa, *v_sa, *K, *V;
-    float *kd, *vd, *P;                     // denoising rows: projected key / value rows they see [nk, C] fp32, their probabilities [NH, pad, nkp]
+    float *kd, *vd, *lse;                   // denoising rows: projected key / value rows they see [nk, C] fp32, log-sum-exp of their rows [NH, pad]
 };
 struct ActLayout {
     float* x0; Act a[8];
@@ -446,10 +334,10 @@ struct ActLayout {
             a_.h = c.take<float>((long long)d.T * d.F); a_.s3 = c.take<float>(TC); a_.x3 = c.take<float>(TC);
             a_.k_sa = c.take<unsigned short>(TC); a_.v_sa = c.take<unsigned short>(TC);
             a_.K = c.take<unsigned short>((long long)d.S * C); a_.V = c.take<unsigned short>((long long)d.S * C);
-            a_.kd = a_.vd = a_.P = nullptr;
+            a_.kd = a_.vd = a_.lse = nullptr;
             if (d.nk > 0) {
                 a_.kd = c.take<float>((long long)d.nk * C); a_.vd = c.take<float>((long long)d.nk * C);
-                a_.P = c.take<float>((long long)NH * d.pad * ((d.nk + 3) & ~3));
+                a_.lse = c.take<float>((long long)NH * d.pad);
             }
         }
         bytes = c.off;
@@ -459,7 +347,7 @@ struct ActLayout {
 static bool dims_ok(const mv2d_td_dims* d) {
     return d && d->T > 0 && d->S > 0 && d->L >= 1 && d->L <= 8 && d->F > 0 && d->F % 4 == 0 && d->sa_nnz >= 0 && d->ca_nnz >= 0 && d->pad >= 0 &&
            d->pad <= d->T && d->nk >= 0 && d->nk <= d->S && ((d->pad > 0) == (d->nk > 0)) &&
-           (long long)NH * d->pad * ((d->nk + 3) & ~3) < (1LL << 32);          // (the dropout counter of the dense block is 32 bits wide)
+           (long long)NH * d->pad * ((d->nk + 31) & ~31) < (1LL << 32);        // (the dropout counter of the dense block is 32 bits wide)
 }
 
 #define TD_RC(x) do { const int rc_ = (x); if (rc_ != MV2D_OK) return rc_; } while (0)
@@ -475,11 +363,12 @@ extern "C" long long mv2d_train_decoder_ws_bytes(const mv2d_td_dims* d, int back
     if (!dims_ok(d)) return -1;
     const long long TC = (long long)d->T * C, SC = (long long)d->S * C, TF = (long long)d->T * d->F;
     const long long lanes = (1 + NSIDE) * (gemm_ws_max(*d) + al256((long long)(mv2d_colsum_scratch_rows(d->S > d->T ? d->S : d->T) + 1) * d->F * 4));
-    const long long PB = al256((long long)NH * d->pad * ((d->nk + 3) & ~3) * 4), KB = al256((long long)d->nk * C * 4);      // 0 without denoising rows
-    if (!backward) return lanes + al256(TC * 4) + (d->nk > 0 ? 2 * PB + 2 * al256(SC * 4) : 0) + 4096;
+    const long long KB = al256((long long)d->nk * C * 4);                                                                 // 0 without denoising rows
+    const long long DF = d->nk > 0 ? al256(mv2d_dense_attn_ws_bytes(d->pad, d->nk, 0)) : 0, DB = d->nk > 0 ? al256(mv2d_dense_attn_ws_bytes(d->pad, d->nk, 1)) : 0;
+    if (!backward) return lanes + al256(TC * 4) + (d->nk > 0 ? DF + 2 * al256(SC * 4) : 0) + 4096;
     const int nb = cdiv(d->T, LNB_ROWS);
     const long long per_layer = 16 * al256(TC * 4) + 2 * al256(TF * 4) + 2 * al256(SC * 4) + al256((long long)(d->sa_nnz > 0 ? d->sa_nnz : 1) * 64) +
-                                al256((long long)(d->ca_nnz > 0 ? d->ca_nnz : 1) * 64) + 10 * al256((long long)nb * C * 4) + 2 * PB + 2 * KB;
+                                al256((long long)(d->ca_nnz > 0 ? d->ca_nnz : 1) * 64) + 10 * al256((long long)nb * C * 4) + DB + 2 * KB;
     return lanes + d->L * per_layer + 4096;
 }
 
@@ -507,10 +396,10 @@ extern "C" int mv2d_train_decoder_fwd(const mv2d_td_dims* d, const float* const*
     Lane side[NSIDE];
     for (int i = 0; i < NSIDE; ++i) side[i] = Lane{td_serial() ? st : pl->side[i], cw.take<char>(gws), gws, cw.take<float>(csb)};
     float* tmp = cw.take<float>(TC);
-    const int pad = d->pad, nk = d->nk, nkp = (nk + 3) & ~3;
-    const long long PN = (long long)NH * pad * nkp;
-    float *dn_S = nullptr, *dn_Pd = nullptr, *k32 = nullptr, *v32 = nullptr;
-    if (nk > 0) { dn_S = cw.take<float>(PN); dn_Pd = cw.take<float>(PN); k32 = cw.take<float>((long long)S * C); v32 = cw.take<float>((long long)S * C); }
+    const int pad = d->pad, nk = d->nk;
+    float *k32 = nullptr, *v32 = nullptr;
+    char* dn_ws = nullptr;
+    if (nk > 0) { dn_ws = cw.take<char>(mv2d_dense_attn_ws_bytes(pad, nk, 0)); k32 = cw.take<float>((long long)S * C); v32 = cw.take<float>((long long)S * C); }
 
     // the key side of all layers does not depend on the queries: K_l = key_in Wk_l^T + bk_l, V_l = val_in Wv_l^T + bv_l (bf16) on two side streams
     // (with denoising rows: in fp32 first -- their dense block reads the rows dn_keys of it unrounded, as the per-operator graph does)
@@ -561,12 +450,8 @@ extern "C" int mv2d_train_decoder_fwd(const mv2d_td_dims* d, const float* const*
         (void)hipStreamWaitEvent(st, kv_ready[l][0], 0);
         (void)hipStreamWaitEvent(st, kv_ready[l][1], 0);
         if (nk > 0) {
-            // the denoising rows: a dense block over the rows dn_keys -- logits, softmax + dropout, P V as one batched launch per product
-            TD_RC(mainl.bgemm(a.q_ca, C, HD, 0, a.kd, C, HD, 0, dn_S, nkp, (long long)pad * nkp, pad, nk, HD, 1.f));
-            const Drop d6 = mk_drop(d->p_ca_attn, site_seed(d->seed, l, 6));
-            float* pd = d6.thr ? dn_Pd : a.P;
-            hipLaunchKernelGGL(softmax_drop_rows_kernel, dim3(NH * pad), dim3(1024), 0, st, (const float*)dn_S, a.P, pd, (long long)nkp, nk, d6);
-            TD_RC(mainl.bgemm(pd, nkp, (long long)pad * nkp, 0, a.vd, C, HD, 1, a.ctx_ca, C, HD, pad, HD, nk, 1.f));
+            // the denoising rows: a dense block over the rows dn_keys (csrc/dense_attn.hip: the logits never leave the MFMA accumulators)
+            TD_RC(mv2d_dense_attn_fwd(a.q_ca, a.kd, a.vd, pad, nk, d->p_ca_attn, site_seed(d->seed, l, 6), a.ctx_ca, a.lse, dn_ws, st));
         }
         if (T > pad)
             TD_RC(mv2d_sparse_xattn_fwd_drop(a.q_ca + (long long)pad * C, a.K, a.V, ca_row_ptr, ca_col, a.ctx_ca + (long long)pad * C, nullptr, 0, T - pad, 0,
@@ -626,10 +511,9 @@ extern "C" int mv2d_train_decoder_bwd(const mv2d_td_dims* d, const float* const*
     struct Bufs {
         float *dxa, *A, *Q1, *ds3, *dyf, *dffn, *ds2, *do2, *dctx2, *dq2, *ds1, *do1, *dctx1, *dq1, *dk1, *dv1, *dh, *dK, *dV, *pw_sa, *pw_ca;
         float* part[8];
-        float *dS, *Pd, *dkd, *dvd;            // denoising rows: logit gradients / dropped probabilities [NH, pad, nkp], gradients of the rows they see [nk, C]
+        float *dkd, *dvd; char* dws;           // denoising rows: gradients of the key / value rows they see [nk, C]; scratch of the dense block's backward
     } B[8];
-    const int pad = d->pad, nk = d->nk, nkp = (nk + 3) & ~3;
-    const long long PN = (long long)NH * pad * nkp;
+    const int pad = d->pad, nk = d->nk;
     for (int l = 0; l < L; ++l) {
         Bufs& b = B[l];
         float** t16[] = {&b.dxa, &b.A, &b.Q1, &b.ds3, &b.dyf, &b.dffn, &b.ds2, &b.do2, &b.dctx2, &b.dq2, &b.ds1, &b.do1, &b.dctx1, &b.dq1, &b.dk1, &b.dv1};
@@ -640,8 +524,8 @@ extern "C" int mv2d_train_decoder_bwd(const mv2d_td_dims* d, const float* const*
         b.pw_sa = cw.take<float>((long long)(d->sa_nnz > 0 ? d->sa_nnz : 1) * 16);
         b.pw_ca = cw.take<float>((long long)(d->ca_nnz > 0 ? d->ca_nnz : 1) * 16);
         for (int j = 0; j < 8; ++j) b.part[j] = cw.take<float>((long long)nb * C);
-        b.dS = b.Pd = b.dkd = b.dvd = nullptr;
-        if (nk > 0) { b.dS = cw.take<float>(PN); b.Pd = cw.take<float>(PN); b.dkd = cw.take<float>((long long)nk * C); b.dvd = cw.take<float>((long long)nk * C); }
+        b.dkd = b.dvd = nullptr; b.dws = nullptr;
+        if (nk > 0) { b.dws = cw.take<char>(mv2d_dense_attn_ws_bytes(pad, nk, 1)); b.dkd = cw.take<float>((long long)nk * C); b.dvd = cw.take<float>((long long)nk * C); }
     }
     // the small weight-gradient products go to side[0]; the key side of the cross attention to side[1] (keys) and side[2] (values)
     for (int i = 0; i < NSIDE; ++i) after(pl, st, side[i].st);
@@ -685,16 +569,9 @@ extern "C" int mv2d_train_decoder_bwd(const mv2d_td_dims* d, const float* const*
         ln_bwd(a.s2, b.ds3, b.dffn, nullptr, P[N1_W], b.ds2, b.do2, d3, b.part[2], b.part[3]);
         const float* do2 = d3.thr ? b.do2 : b.ds2;
         TD_RC(mainl.dgrad(do2, P[CA_OW], b.dctx2, T, C, C, 0));
-        const float* pd_l = nullptr;
-        if (nk > 0) {
-            // the denoising rows' dense block: dP = g v^T, dS = softmax backward (with the regenerated dropout mask), dq = dS k / sqrt(d)
-            TD_RC(mainl.bgemm(b.dctx2, C, HD, 0, a.vd, C, HD, 0, b.dS, nkp, (long long)pad * nkp, pad, nk, HD, 1.f));
-            const Drop d6 = mk_drop(d->p_ca_attn, site_seed(d->seed, l, 6));
-            pd_l = d6.thr ? b.Pd : a.P;
-            hipLaunchKernelGGL(softmax_drop_bwd_rows_kernel, dim3(NH * pad), dim3(1024), 0, st, (const float*)a.P, d6.thr ? b.Pd : (float*)nullptr, b.dS,
-                               (long long)nkp, nk, d6);
-            TD_RC(mainl.bgemm(b.dS, nkp, (long long)pad * nkp, 0, a.kd, C, HD, 1, b.dq2, C, HD, pad, HD, nk, qs));
-        }
+        if (nk > 0)      // the denoising rows' dense block, query side (dq, scaled by 1 / sqrt(d)); its key side follows on the side stream below
+            TD_RC(mv2d_dense_attn_bwd_parts(a.q_ca, a.kd, a.vd, a.ctx_ca, b.dctx2, a.lse, pad, nk, d->p_ca_attn, site_seed(d->seed, l, 6), qs, b.dq2, b.dkd, b.dvd,
+                                            b.dws, 1, st));
         const long long po = (long long)pad * C;
         TD_RC(mv2d_sparse_xattn_bwd_ex(a.q_ca + po, a.K, a.V, ca_row_ptr, ca_col, a.ctx_ca + po, b.dctx2 + po, ca_key_ptr, ca_pair_idx, ca_pair_row, b.pw_ca,
                                        b.dq2 + po, b.dK, b.dV, T - pad, 0, d->p_ca_attn, site_seed(d->seed, l, 2), 0, qs, st));
@@ -702,14 +579,14 @@ extern "C" int mv2d_train_decoder_bwd(const mv2d_td_dims* d, const float* const*
         after(pl, st, side[1].st);
         TD_RC(mv2d_sparse_xattn_bwd_ex(a.q_ca + po, a.K, a.V, ca_row_ptr, ca_col, a.ctx_ca + po, b.dctx2 + po, ca_key_ptr, ca_pair_idx, ca_pair_row, b.pw_ca,
                                        b.dq2 + po, b.dK, b.dV, 0, S, d->p_ca_attn, site_seed(d->seed, l, 2), 0, qs, side[1].st));
-        after(pl, side[1].st, side[2].st);
         if (nk > 0) {
-            // dk = dS^T q and dv = Pd^T g of the dense block, added to the rows dn_keys of dK / dV
-            TD_RC(side[1].bgemm(b.dS, nkp, (long long)pad * nkp, 1, a.q_ca, C, HD, 1, b.dkd, C, HD, nk, HD, pad, 1.f));
+            // dk / dv of the dense block (one kernel), added to the rows dn_keys of dK / dV
+            TD_RC(mv2d_dense_attn_bwd_parts(a.q_ca, a.kd, a.vd, a.ctx_ca, b.dctx2, a.lse, pad, nk, d->p_ca_attn, site_seed(d->seed, l, 6), qs, b.dq2, b.dkd, b.dvd,
+                                            b.dws, 2, side[1].st));
             hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(cdiv(nk, 4)), dim3(256), 0, side[1].st, b.dK, dn_keys, (const float*)b.dkd, nk);
-            TD_RC(side[2].bgemm(pd_l, nkp, (long long)pad * nkp, 1, b.dctx2, C, HD, 1, b.dvd, C, HD, nk, HD, pad, 1.f));
-            hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(cdiv(nk, 4)), dim3(256), 0, side[2].st, b.dV, dn_keys, (const float*)b.dvd, nk);
+            hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(cdiv(nk, 4)), dim3(256), 0, side[1].st, b.dV, dn_keys, (const float*)b.dvd, nk);
         }
+        after(pl, side[1].st, side[2].st);
         TD_RC(side[1].dgrad(b.dK, P[CA_W] + (long long)C * C, d_key_in, S, C, C, first_kv ? 0 : 1));
         TD_RC(side[1].wgrad(b.dK, key_in, G[CA_W] + (long long)C * C, G[CA_B] + C, S, C, C));
         TD_RC(side[2].dgrad(b.dV, P[CA_W] + 2LL * C * C, d_val_in, S, C, C, first_kv ? 0 : 1));

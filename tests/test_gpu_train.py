@@ -988,3 +988,43 @@ def test_center2lidar_node_and_unfolding_node():
     want.backward(gc)
     assert torch.equal(cols, want)
     assert float((x1.grad - x2.grad).abs().max()) <= 1e-5 * float(x2.grad.abs().max())
+
+
+def _dense_drop_mask(n, nk, p, seed):
+    """keep / scale factors [8, n, nk] of mv2d_dense_attn_* (csrc/dense_attn.hip: murmur3 finaliser of the counter (head n + query) nkp + key)"""
+    nkp = (nk + 31) & ~31
+    pf = np.float32(p)
+    t = float(pf) * 4294967296.0
+    thr = (0xffffffff if t >= 4294967295.0 else int(t)) or 1
+    idx = ((np.arange(8)[:, None, None] * n + np.arange(n)[None, :, None]) * nkp + np.arange(nk)[None, None, :]).astype(np.uint64)
+    with np.errstate(over='ignore'):
+        u = ((idx * np.uint64(0x9E3779B1)) & np.uint64(0xffffffff)).astype(np.uint32) ^ np.uint32(seed & 0xffffffff)
+        u ^= u >> np.uint32(16); u = ((u.astype(np.uint64) * np.uint64(0x85EBCA6B)) & np.uint64(0xffffffff)).astype(np.uint32)
+        u ^= u >> np.uint32(13); u = ((u.astype(np.uint64) * np.uint64(0xC2B2AE35)) & np.uint64(0xffffffff)).astype(np.uint32)
+        u ^= u >> np.uint32(16)
+    return np.where(u >= np.uint32(thr), np.float32(1.0) / (np.float32(1.0) - pf), np.float32(0.0)).astype(np.float64)
+
+
+@pytest.mark.parametrize('n,nk,p', [(37, 203, 0.0), (400, 1501, 0.0), (64, 128, 0.25), (100, 4097, 0.1), (16, 31, 0.0)])
+def test_dense_block_without_materialised_logits(n, nk, p):
+    """mv2d_dense_attn_fwd / _bwd (the logits of a tile live in MFMA accumulators only) against fp64 attention per head with the kernel's own
+    dropout mask (numpy restatement of the counter hash): output, log-sum-exp, dq, dk, dv."""
+    from mv2d_amd.autograd_ops import FlashDenseAttnFn
+    g = torch.Generator(device='cpu').manual_seed(n * 7 + nk)
+    q, k, v, go = (torch.randn(r, 256, generator=g).to(DEV) for r in (n, nk, nk, n))
+    q = q * 0.3
+    qa, ka, va = (t.clone().requires_grad_(True) for t in (q, k, v))
+    out = FlashDenseAttnFn.apply(qa, ka, va, p, 1234)
+    out.backward(go)
+    assert torch.equal(out, FlashDenseAttnFn.apply(q, k, v, p, 1234))
+    qd, kd, vd = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    P = torch.softmax(torch.einsum('nhd,mhd->hnm', qd.view(n, 8, 32), kd.view(nk, 8, 32)), -1)
+    if p > 0:
+        m = torch.from_numpy(_dense_drop_mask(n, nk, p, 1234)).to(DEV)
+        assert abs(float((m > 0).double().mean()) - (1 - p)) < 0.02
+        P = P * m
+    ref = torch.einsum('hnm,mhd->nhd', P, vd.view(nk, 8, 32)).reshape(n, 256)
+    ref.backward(go.double())
+    for got, want, name in ((out, ref, 'out'), (qa.grad, qd.grad, 'dq'), (ka.grad, kd.grad, 'dk'), (va.grad, vd.grad, 'dv')):
+        err = float((got.double() - want).abs().max() / want.abs().max())
+        assert err < 1e-4, (name, err)

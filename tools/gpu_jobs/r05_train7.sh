@@ -1,5 +1,5 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05t7; mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests/test_gpu_train.py -q -k "gemm_ex or wgrad or box_code or position_embedding" 2>&1 > $O/pytest_train.txt
+timeout 900 python -m pytest tests/test_gpu_train.py -q -k "dense_block" 2>&1 > $O/pytest_train.txt
 grep -n "^E \|passed\|failed" $O/pytest_train.txt | cut -c1-600
