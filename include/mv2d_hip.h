@@ -646,12 +646,16 @@ int mv2d_center2lidar_bwd(const float* g, const float* c, const float* minv, flo
  * without materialising the logits: q [n,256] fp32 (already scaled by 1/sqrt(32)), k / v [nk,256] fp32 (head h = columns 32 h .. 32 h + 31) ->
  * ctx [n,256] = dropout(softmax(q_h k_h^T)) v_h, lse [8][n] (log-sum-exp per row, for the backward).  The backward takes ctx / lse / dctx and the
  * same (p_drop, seed) -- the mask is a counter hash of (seed, head, query, key) -- and returns dq (times dq_scale), dk, dv.
- * ws: mv2d_dense_attn_ws_bytes(n, nk, backward) bytes, 256-byte aligned (per-head transposed copies of the operands). */
+ * ws: mv2d_dense_attn_ws_bytes(n, nk, backward) bytes, 256-byte aligned (bf16 hi / lo images of the operands, row-major and per-head transposed). */
 long long mv2d_dense_attn_ws_bytes(int n, int nk, int backward);
 int mv2d_dense_attn_fwd(const float* q, const float* k, const float* v, int n, int nk, float p_drop, unsigned int seed, float* ctx, float* lse, void* ws,
                         void* stream);
 int mv2d_dense_attn_bwd(const float* q, const float* k, const float* v, const float* ctx, const float* dctx, const float* lse, int n, int nk, float p_drop,
                         unsigned int seed, float dq_scale, float* dq, float* dk, float* dv, void* ws, void* stream);
+/* parts: 1 = dq only (also fills the per-row dctx . ctx in ws), 2 = dk / dv only (after a parts = 1 call on the same ws, in stream order or behind an
+ * event: the training decoder issues it on a side stream), 3 = both. */
+int mv2d_dense_attn_bwd_parts(const float* q, const float* k, const float* v, const float* ctx, const float* dctx, const float* lse, int n, int nk,
+                              float p_drop, unsigned int seed, float dq_scale, float* dq, float* dk, float* dv, void* ws, int parts, void* stream);
 
 /* Backward of mv2d_roi_align w.r.t. one map (training; mmcv's roi_align backward): grad_out [R][49][256] fp32 ->
  * grad_map [rows][256] fp32, ACCUMULATED with hardware fp32 atomics (the caller zeroes it; the summation order varies between runs).

@@ -131,6 +131,7 @@ SIGNATURES = {
     'mv2d_dense_attn_ws_bytes': (LL, [I, I, I]),
     'mv2d_dense_attn_fwd': (I, [P, P, P, I, I, F, C.c_uint, P, P, P, P]),
     'mv2d_dense_attn_bwd': (I, [P, P, P, P, P, P, I, I, F, C.c_uint, F, P, P, P, P, P]),
+    'mv2d_dense_attn_bwd_parts': (I, [P, P, P, P, P, P, I, I, F, C.c_uint, F, P, P, P, P, I, P]),
     'mv2d_lsap_layers': (I, [P, I, I, I, P, I]),
     'mv2d_train_heads_act_bytes': (LL, [P]),
     'mv2d_train_heads_ws_bytes': (LL, [P, I]),
