@@ -322,6 +322,23 @@ int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const void* Xv, 
 int mv2d_xattn_fused_fwd(const float* q, const void* WA_hi, const void* WA_lo, const void* WB_hi, const void* WB_lo, const float* bv, const void* Xk,
                          const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr, const int* col_idx, float* ctx, int R, int empty_nan,
                          const int* order, void* stream);
+/* Key tiles SHARED BETWEEN QUERIES (round 6, csrc/xattn_group.hip; the masks of RH/mv2d_t_head.py:79-109 / the duplication of
+ * RH/mv2d_s_head.py:184-192 let 2.9-6.2 queries list the same key row).  mv2d_xattn_group_tables (once per frame): the queries of every sample
+ * (grp_start [n_samples + 1]; rows behind grp_start[n_samples] are bucket padding and form groups of their own), taken in `order` (a permutation that
+ * keeps every sample's rows in its own slot range, e.g. mv2d_xattn_query_order's; NULL = natural), are cut into groups of up to 8 consecutive slots;
+ * per group g < ng_max (>= mv2d_xattn_group_max(R, n_samples)): g_slot / g_cnt = first slot / members (0 = no such group), g_ptr / g_len = its UNION
+ * key list in ucol / umask (capacity ucap entries >= nnz + 16 ng_max; umask bit j = member j lists the key), padded to a multiple of 16 and sorted by
+ * (umask, key) inside windows of 16384 consecutive key indices.  u_total [1] and flags [1] int32 must be zero on entry (flags[0] != 0 afterwards:
+ * ucap exceeded).  A row of the CSR must not list a key twice.  mv2d_xattn_group_fwd: ctx [R,256] = the cross attention of mv2d_xattn_fused_fwd
+ * (same operands, same arithmetic per (query, key) pair) with one block per group walking the group's union once; the keys of a softmax row are
+ * visited in union order, so results agree with the per-query kernels to fp32 rounding, not bitwise. */
+int mv2d_xattn_group_max(int R, int n_samples);
+int mv2d_xattn_group_tables(const int* row_ptr, const int* col_idx, const int* order, const int* grp_start, int n_samples, int R, int ng_max, int* g_slot,
+                            int* g_cnt, int* g_ptr, int* g_len, int* ucol, unsigned char* umask, int ucap, int* u_total, int* flags, void* stream);
+int mv2d_xattn_group_fwd(const float* q, const void* WA_hi, const void* WA_lo, const void* WB_hi, const void* WB_lo, const float* bv, const void* Xk,
+                         const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr, const int* order, const int* g_slot, const int* g_cnt,
+                         const int* g_ptr, const int* g_len, const int* ucol, const unsigned char* umask, float* ctx, int ng_max, int empty_nan,
+                         void* stream);
 int mv2d_xattn_ctxmap(const float* z, const void* WB_hi, const void* WB_lo, const float* bv, const int* row_ptr, float* ctx, int R,
                       int empty_nan, void* stream);
 

@@ -87,6 +87,9 @@ SIGNATURES = {
     'mv2d_xattn_tile_fwd': (I, [P, P, P, P, P, P, P, P, P, LL, I, I, I, P]),
     'mv2d_xattn_tile_fwd_ordered': (I, [P, P, P, P, P, P, P, P, P, LL, I, I, I, P, P]),
     'mv2d_xattn_fused_fwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P, P]),
+    'mv2d_xattn_group_max': (I, [I, I]),
+    'mv2d_xattn_group_tables': (I, [P, P, P, P, I, I, I, P, P, P, P, P, P, I, P, P, P]),
+    'mv2d_xattn_group_fwd': (I, [P] * 19 + [I, I, P]),
     'mv2d_xattn_query_order': (I, [P, P, P, I, I, P, P, I, P]),
     'mv2d_xattn_ctxmap': (I, [P, P, P, P, P, P, I, I, P]),
     'mv2d_box_params': (I, [P, P, P, P, P, I, P, I, F, F, F, P]),

@@ -104,6 +104,11 @@ class HeadEngine:
         # of 8 queries, Qt / z stay on chip; bitwise the three kernels with one wave per query).  None: on the S path when no debug output is asked
         # for; False / True forces it.  In the graph key.
         self.fuse_xattn = None
+        # Round 6: key tiles SHARED between the queries of a group (csrc/xattn_group.hip: one block per 8 queries that are neighbours in the launch
+        # order walks the union of their key lists once; query / context maps in the same launch).  None: on the T path (a key row is listed by
+        # 2.9-6.2 queries there) when no debug output is asked for; True / False forces it (True on the S path pays when RoIs are matched across
+        # views).  In the graph key.
+        self.group_xattn = None
         # Layer 0 of the decoder starts from target = 0 (RH/bbox_heads/cross_attention_head.py:32): the VALUE rows of its self attention are
         # in_proj_v(0) + b_v = b_v for every query, the softmax weights of a row sum to 1, so its context is b_v whatever the queries are
         # (MU/petr_transformer.py:317-370: value = key before the positional embedding = target).  The engine feeds rows of b_v to the
@@ -304,10 +309,11 @@ class HeadEngine:
         ws['xyz'] = e((R, 3)); ws['ref'] = e((R, 3)); ws['posemb'] = e((R, 384)); ws['qe1'] = e((R, C)); ws['qpos'] = e((R, C))
         ws['match'] = e((R, Vg, self.topk), torch.int32)
         Pp = (P + 15) // 16 * 16
-        ws['zbuf'] = z(Pp + 16, torch.uint8)                     # roi_mask | nnz[2]: cleared by ONE fill per frame
+        ws['zbuf'] = z(Pp + 32, torch.uint8)                     # roi_mask | nnz[2] | qt_ctl[2] | grp_ctl[2]: cleared by ONE fill per frame
         ws['roi_mask'] = ws['zbuf'][:P]
         ws['nnz'] = ws['zbuf'][Pp:Pp + 8].view(torch.int32)
         ws['qt_ctl'] = ws['zbuf'][Pp + 8:Pp + 16].view(torch.int32)      # query-order flags (zeroed with zbuf)
+        ws['grp_ctl'] = ws['zbuf'][Pp + 16:Pp + 24].view(torch.int32)    # shared-tile cross attention: union entries allocated | capacity flag
         ws['zero_mask'] = z(P, torch.uint8)
         ws['rect'] = e((R, 5), torch.int32); ws['pos2s'] = e(P, torch.int32); ws['s2pos'] = e(P, torch.int32)
         ws['S_dev'] = z(1, torch.int32)
@@ -323,6 +329,11 @@ class HeadEngine:
             ws['roi_sum'] = e((R, 49, C), K16)
         ws['q_order'] = alloc(R, torch.int32, zero=True) if self.q_order else None
         ws['col_idx'] = e(ws['col_cap'], torch.int32)
+        # group tables of the shared-tile cross attention (csrc/xattn_group.hip): g_slot | g_cnt | g_ptr | g_len per group, the groups' union key lists
+        ng = ops.xattn_group_max(R, B)
+        ucap = ws['col_cap'] + 16 * ng
+        ws['grp_tab'] = dict(ng=ng, g=alloc((4, ng), torch.int32, zero=True), ucol=alloc(ucap, torch.int32, zero=True),
+                             umask=alloc(ucap, torch.uint8, zero=True), ucap=ucap, ctl=ws['grp_ctl'])
         # key16 rows of the PE block's inputs: frustum [.,192], sine [.,384] (training route only: the inference kernel reads the folded
         # table), feature rows [.,256] (the SE gate's input; the value rows of the T path)
         ws['A1'] = e((P, 3 * self.depth_num), K16); ws['A2'] = e((P, 384), K16)
@@ -549,6 +560,8 @@ class HeadEngine:
                            self.stride, self.expand, col_cap=ws['col_cap'], n_samples=B)
             if self.q_order and ws.get('q_order') is not None:
                 o.xattn_query_order(ws['row_ptr'], ws['col_idx'], grp, R, ws['q_order'], ws['qt_ctl'][1:])
+            if self._grouped(ws):
+                o.xattn_group_tables(ws['row_ptr'], ws['col_idx'], grp, R, ws['grp_tab'], order=ws.get('q_order') if self.q_order else None)
             if masked:
                 transpose(ws['roi_mask'])
             if not forked:
@@ -573,6 +586,8 @@ class HeadEngine:
             o.roi_positions_csr(rois, ws['zero_mask'], ws['roi_mask'], ws['rect'], ws['pos2s'], ws['s2pos'], ws['S_dev'], R, V, h, w, ws['match'],
                                 ws['row_ptr'], ws['col_idx'], ws['nnz'], Vg, self.topk, stride=self.stride, expand_stride=-1.0, grp_start=grp,
                                 order=ws.get('q_order') if self.q_order else None, order_flags=ws['qt_ctl'][1:] if self.q_order else None)
+            if self._grouped(ws):
+                o.xattn_group_tables(ws['row_ptr'], ws['col_idx'], grp, R, ws['grp_tab'], order=ws.get('q_order') if self.q_order else None)
             if masked:
                 transpose(ws['roi_mask'])
         md = ws['S_dev']
@@ -682,6 +697,7 @@ class HeadEngine:
         dbg = ws.get('dbg_logits')
         maps_fused = ((R <= 512) if self.fuse_maps is None else self.fuse_maps) and dbg is None
         xattn_fused = ((self.kind == 'S' and not ws.get('dn')) if self.fuse_xattn is None else self.fuse_xattn) and dbg is None
+        xattn_group = self._grouped(ws) and dbg is None
         lo_k = None if 'attn' in self.exact_skip else ws.get('xk_lo')
         lo_v = None if 'attn' in self.exact_skip else ws.get('xv_lo')
 
@@ -716,7 +732,12 @@ class HeadEngine:
                     o.self_attn(ws['qkv'], ws['ctx'], R, grp_start=ws['grp_start'], max_grp_rows=ws.get('max_rows', 0))
             sa_args = (sa_ctx, x_in, W_[f'sa_out_wx{i}'], W_[f'sa_out_b{i}'], (W_[f'ln0_w{i}'], W_[f'ln0_b{i}']), ws['x1'])
             q_args = dict(qpos=ws['qpos'], Wq_x3=W_[f'ca_q_wx{i}'], bq=W_[f'ca_q_b{i}'], qscale=ops.SCALE_Q, M=R)
-            if xattn_fused:
+            if xattn_group:
+                o.attn_out_fused_x3(*sa_args, q_out=ws['q'], **q_args)
+                o.xattn_group(ws['q'], W_[f'ca_mapA{i}'], W_[f'ca_mapB{i}'], W_[f'ca_v_b{i}'], xk_rows, xv_rows, ws['row_ptr'], ws['grp_tab'], out=ws['ctx'], R=R,
+                              empty_nan=self.empty_nan, Xk_lo=lo_k, Xv_lo=lo_v, order=ws.get('q_order') if self.q_order else None)
+                o.attn_out_fused_x3(ws['ctx'], ws['x1'], W_[f'ca_out_wx{i}'], W_[f'ca_out_b{i}'], (W_[f'ln1_w{i}'], W_[f'ln1_b{i}']), ws['x2'], M=R)
+            elif xattn_fused:
                 o.attn_out_fused_x3(*sa_args, q_out=ws['q'], **q_args)
                 o.xattn_fused(ws['q'], W_[f'ca_mapA{i}'], W_[f'ca_mapB{i}'], W_[f'ca_v_b{i}'], xk_rows, xv_rows, ws['row_ptr'], ws['col_idx'], out=ws['ctx'], R=R,
                               empty_nan=self.empty_nan, Xk_lo=lo_k, Xv_lo=lo_v, order=ws.get('q_order') if self.q_order else None)
@@ -742,6 +763,12 @@ class HeadEngine:
             o.ffn_out_fused_x3(parts, W_[f'ffn_b2{i}'], ws['x2'], (W_[f'ln2_w{i}'], W_[f'ln2_b{i}']), (W_['post_w'], W_['post_b']),
                                x, ws['qpos'], None, outs=ws['outs'][i], Win_x3=W_[f'sa_in_wx{i + 1}'] if nxt else None,
                                b_in=W_[f'sa_in_b{i + 1}'] if nxt else None, qkv=ws['qkv'] if nxt else None, M=R)
+
+    def _grouped(self, ws):
+        """Does this frame's cross attention run on shared key tiles (csrc/xattn_group.hip)?  Needs the group tables of the workspace (the training
+        forward's own decoder workspace has none) and no debug output."""
+        on = (self.kind == 'T') if self.group_xattn is None else bool(self.group_xattn)
+        return on and ws.get('grp_tab') is not None and not self.debug_attn and not ws.get('dn')
 
     def _enqueue_heads(self, ws, R, dt):
         # a14: every per-layer cls / reg branch + the reference-point tail in ONE launch (row-block fused, bf16x3)
@@ -832,7 +859,7 @@ class HeadEngine:
         # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
         gkey = (ptrs, 0 if payload is None else payload.data_ptr(), sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs, self.last_stage_heads,
-                self.xattn_waves, self.fuse_maps, self.fuse_xattn, self.fold_sa0, self.masked_transpose, self.keep_sine_rows, self.force_nc, self.q_order,
+                self.xattn_waves, self.fuse_maps, self.fuse_xattn, self.group_xattn, self.fold_sa0, self.masked_transpose, self.keep_sine_rows, self.force_nc, self.q_order,
                 self.fork_qg, self.exact_skip, self.stop_before_decoder)   # load_state() re-allocates the weights; every route option of __init__ is in the key
         graphs = ws.setdefault('graphs', {})             # one graph per (input buffers, frame scalars): a producer that alternates between
         g = graphs.get(gkey)                             # a few static output buffers replays a few graphs, it does not re-capture
@@ -947,6 +974,8 @@ class HeadEngine:
     def _check_capacity(ws):
         if int(ws['nnz'][1].item()) != 0:
             raise RuntimeError('mv2d engine: CSR capacity exceeded (raise col_cap_per_query)')
+        if ws.get('grp_ctl') is not None and int(ws['grp_ctl'][1].item()) != 0:
+            raise RuntimeError('mv2d engine: union-list capacity of the shared-tile cross attention exceeded (a CSR row lists a key twice?)')
 
     def results(self, out):
         """Synchronising accessor: sliced (boxes [K,9], scores [K], labels [K]) like simple_test returns."""

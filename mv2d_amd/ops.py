@@ -590,6 +590,50 @@ def xattn_fused(q, WA, WB, bv, Xk, Xv, row_ptr, col_idx, out=None, R=None, empty
     return out
 
 
+def xattn_group_max(R, n_samples):
+    """Upper bound of the number of query groups of mv2d_xattn_group_tables (host arithmetic only)."""
+    return (R + 7) // 8 + n_samples + 1
+
+
+def xattn_group_alloc(R, n_samples, col_cap, device):
+    """Buffers of the shared-tile cross attention's group tables for up to R query rows of n_samples samples and col_cap CSR entries:
+    dict(ng, g [4, ng] int32 = g_slot | g_cnt | g_ptr | g_len, ucol, umask, ucap, ctl [2] int32 = u_total | overflow flag -- the caller zeroes
+    ctl before every xattn_group_tables)."""
+    ng = xattn_group_max(R, n_samples)
+    ucap = col_cap + 16 * ng
+    return dict(ng=ng, g=torch.zeros((4, ng), device=device, dtype=torch.int32), ucol=torch.zeros(ucap, device=device, dtype=torch.int32),
+                umask=torch.zeros(ucap, device=device, dtype=torch.uint8), ucap=ucap, ctl=torch.zeros(2, device=device, dtype=torch.int32))
+
+
+def xattn_group_tables(row_ptr, col_idx, grp_start, R, tab, order=None):
+    """Per-group union key lists (csrc/xattn_group.hip) of the CSR for groups of 8 consecutive slots of every sample's `order`; tab =
+    xattn_group_alloc(...) with tab['ctl'] zeroed."""
+    _req(row_ptr, torch.int32, 'row_ptr'); _req(col_idx, torch.int32, 'col_idx'); _req(grp_start, torch.int32, 'grp_start'); _req(order, torch.int32, 'order')
+    g, ctl = tab['g'], tab['ctl']
+    check(_lib.load().mv2d_xattn_group_tables(_p(row_ptr), _p(col_idx), _p(order), _p(grp_start), grp_start.numel() - 1, R, tab['ng'], _p(g[0]), _p(g[1]),
+                                              _p(g[2]), _p(g[3]), _p(tab['ucol']), _p(tab['umask']), tab['ucap'], _p(ctl[:1]), _p(ctl[1:]), _stream()),
+          'mv2d_xattn_group_tables')
+    return tab
+
+
+def xattn_group(q, WA, WB, bv, Xk, Xv, row_ptr, tab, out=None, R=None, empty_nan=True, Xk_lo=None, Xv_lo=None, order=None):
+    """ctx [R,256] fp32 = the cross attention of xattn_fused with the key tiles of a group of 8 queries shared (one block per group walks the union of
+    the group's key lists once; tab = xattn_group_tables(...) built with the same `order`).  Equal to xattn_fused to fp32 rounding."""
+    _req(q, torch.float32, 'q'); _req(bv, torch.float32, 'bv'); _req(row_ptr, torch.int32, 'row_ptr'); _req(order, torch.int32, 'order')
+    for t, n_ in ((WA[0], 'WA_hi'), (WA[1], 'WA_lo'), (WB[0], 'WB_hi'), (WB[1], 'WB_lo')):
+        _req(t, q16_dtype(), n_)
+    _req16(Xk, 'Xk'); _req16(Xv, 'Xv'); _req16(Xk_lo, 'Xk_lo'); _req16(Xv_lo, 'Xv_lo')
+    R = q.shape[0] if R is None else R
+    if out is None:
+        out = torch.empty((R, 256), device=q.device, dtype=torch.float32)
+    _req(out, torch.float32, 'out')
+    g = tab['g']
+    check(_lib.load().mv2d_xattn_group_fwd(_p(q), _p(WA[0]), _p(WA[1]), _p(WB[0]), _p(WB[1]), _p(bv), _p(Xk), _p(Xv), _p(Xk_lo), _p(Xv_lo), _p(row_ptr),
+                                           _p(order), _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]), _p(tab['ucol']), _p(tab['umask']), _p(out), tab['ng'],
+                                           1 if empty_nan else 0, _stream()), 'mv2d_xattn_group_fwd')
+    return out
+
+
 def xattn_query_order(row_ptr, col_idx, grp_start, R, perm, flags, stride=0):
     """perm [R] int32 = the query rows of every sample (grp_start [n+1], device) sorted by their smallest key (stride 0: the first entry of a
     CSR row; stride 49: the smallest first cell of the RoIs an S-path row lists); flags int32 [>=1] (zeroed by the caller)."""

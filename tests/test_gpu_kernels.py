@@ -456,6 +456,104 @@ def test_xattn_fused_equals_the_three_kernels(dev, R, S, dens, lo):
         assert bool(torch.isnan(out[5]).all()) and bool(torch.isfinite(out[6:]).all())
 
 
+def _rect_pattern(R, S, seed, n_samples):
+    """A T-path-like mask: every query lists 1-3 runs of keys inside its sample's key range, runs shared between neighbouring queries
+    (the structure of RH/mv2d_t_head.py:84-88: rectangles of correlated RoIs), one empty row, one single-key row."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    allowed = torch.zeros((R, S), dtype=torch.bool)
+    bounds = np.linspace(0, R, n_samples + 1).astype(int)
+    kb = np.linspace(0, S, n_samples + 1).astype(int)
+    for b in range(n_samples):
+        k0, k1 = int(kb[b]), int(kb[b + 1])
+        runs = [(int(g.integers(k0, k1 - 40)), int(g.integers(8, 40))) for _ in range(max(4, (bounds[b + 1] - bounds[b]) // 2))]
+        for r in range(bounds[b], bounds[b + 1]):
+            for i in g.choice(len(runs), size=int(g.integers(1, 4)), replace=False):
+                a, n_ = runs[i]
+                allowed[r, a:a + n_] = True
+    allowed[5] = False
+    allowed[7] = False
+    allowed[7, min(123, S - 1)] = True
+    return allowed, torch.from_numpy(bounds.astype(np.int32))
+
+
+@pytest.mark.parametrize('R,S,n_samples,lo,ordered', [(300, 4000, 1, True, True), (301, 6000, 3, True, True), (37, 700, 2, True, False),
+                                                      (130, 40000, 2, True, True), (300, 4000, 1, False, True), (9, 300, 1, True, False)])
+def test_xattn_group_tables_and_attention(dev, R, S, n_samples, lo, ordered):
+    """Round 6, csrc/xattn_group.hip.  (1) mv2d_xattn_group_tables: groups = runs of 8 consecutive slots of every sample's order (never across samples;
+    the rows behind the last sample form groups of their own), a group's list = the UNION of its members' CSR rows, every key once, mask bit j = member j
+    lists it, sorted by (mask, key) inside 16384-key windows, padded to a multiple of 16 with mask-0 entries.  (2) mv2d_xattn_group_fwd == the per-query
+    kernels (mv2d_xattn_fused_fwd) to fp32 rounding: the same products per (query, key) pair, the keys of a softmax row visited in union order."""
+    from mv2d_amd import ops
+    from oracle import mv2d_oracle as O
+    allowed, grp = _rect_pattern(R, S, 600 + R, n_samples)
+    Rr = int(grp[-1])
+    if R > 100:
+        grp = grp.clone()
+        grp[-1] = R - 3                                       # three bucket-padding rows behind the last sample
+    row_ptr, col = O.csr_from_allowed(allowed)
+    row_ptr, col, grp_d = row_ptr.to(dev), col.to(dev), grp.to(dev)
+    order = None
+    if ordered:
+        order = torch.empty(R, dtype=torch.int32, device=dev)
+        ops.xattn_query_order(row_ptr, col, grp_d, R, order, torch.zeros(2, dtype=torch.int32, device=dev))
+    tab = ops.xattn_group_alloc(R, n_samples, int(col.numel()), dev)
+    ops.xattn_group_tables(row_ptr, col, grp_d, R, tab, order=order)
+    assert int(tab['ctl'][1]) == 0
+    gt, ucol, umask = tab['g'].cpu().numpy(), tab['ucol'].cpu().numpy(), tab['umask'].cpu().numpy()
+    ordr = order.cpu().numpy() if ordered else np.arange(R)
+    rp, ci = row_ptr.cpu().numpy(), col.cpu().numpy()
+    gl = grp.numpy().tolist() + [R]
+    seen_rows, gi, used = [], 0, np.zeros(tab['ucap'], dtype=bool)
+    for b in range(len(gl) - 1):
+        for s0 in range(gl[b], gl[b + 1], 8):
+            cnt = min(8, gl[b + 1] - s0)
+            assert gt[0, gi] == s0 and gt[1, gi] == cnt, (gi, gt[:, gi], s0, cnt)
+            members = ordr[s0:s0 + cnt]
+            seen_rows += members.tolist()
+            want = {}
+            for j, r in enumerate(members):
+                for k in ci[rp[r]:rp[r + 1]]:
+                    want[int(k)] = want.get(int(k), 0) | (1 << j)
+            n = int(gt[3, gi])
+            assert n == len(want)
+            if n:
+                p0 = int(gt[2, gi])
+                assert p0 % 16 == 0 and not used[p0:p0 + (n + 15) // 16 * 16].any()
+                used[p0:p0 + (n + 15) // 16 * 16] = True
+                keys, masks = ucol[p0:p0 + n], umask[p0:p0 + n]
+                assert {int(k): int(m) for k, m in zip(keys, masks)} == want
+                lo_k = min(want)
+                sortkey = ((keys - lo_k) // 16384).astype(np.int64) * (1 << 40) + masks.astype(np.int64) * (1 << 32) + keys
+                assert (np.diff(sortkey) > 0).all()
+                pad = slice(p0 + n, p0 + (n + 15) // 16 * 16)
+                assert (umask[pad] == 0).all() and ((ucol[pad] >= 0) & (ucol[pad] < S)).all()
+            gi += 1
+    assert sorted(seen_rows) == list(range(R)) and (gt[1, gi:] == 0).all()
+    # ---- (2) the attention
+    q = (rnd((R, 256), 661) * 0.3).to(dev)
+    q[3] *= 8.0
+    xk32, xv32 = rnd((S, 256), 662).to(dev), rnd((S, 256), 663).to(dev)
+    Xk, Xk_lo = ops.f32_to_key16(xk32, with_lo=True)
+    Xv, Xv_lo = ops.f32_to_key16(xv32, with_lo=True)
+    if not lo:
+        Xk_lo = Xv_lo = None
+    Wk, Wv = rnd((256, 256), 664, 0.06).to(dev), rnd((256, 256), 666, 0.06).to(dev)
+    bv = rnd((256,), 667).to(dev)
+    WA, WB = ops.pack_xattn_maps(Wk, Wv)
+    for empty_nan in (False, True):
+        ref = ops.xattn_fused(q, WA, WB, bv, Xk, Xv, row_ptr, col, empty_nan=empty_nan, Xk_lo=Xk_lo, Xv_lo=Xv_lo)
+        out = torch.full((R, 256), 7.0, device=dev)
+        ops.xattn_group(q, WA, WB, bv, Xk, Xv, row_ptr, tab, out=out, empty_nan=empty_nan, Xk_lo=Xk_lo, Xv_lo=Xv_lo, order=order)
+        assert torch.equal(torch.isnan(out), torch.isnan(ref))
+        err = float((out - ref).abs().nan_to_num(0).max()) / float(ref.abs().nan_to_num(0).max())
+        assert err < 2e-6, (empty_nan, err)
+        out2 = torch.empty_like(out)
+        ops.xattn_group(q, WA, WB, bv, Xk, Xv, row_ptr, tab, out=out2, empty_nan=empty_nan, Xk_lo=Xk_lo, Xv_lo=Xv_lo, order=order)
+        assert torch.equal(out2.view(torch.int32), out.view(torch.int32))          # run-to-run bitwise
+    assert bool(torch.isnan(out[5]).all()) and bool(torch.isfinite(out[6:]).all())
+    print(f'xattn_group R {R} S {S}: rel err vs per-query kernels {err:.2e}; union {int(tab["ctl"][0])} entries for {int(col.numel())} pairs')
+
+
 @pytest.mark.parametrize('R,S,dens,waves', [(37, 500, 0.05, 4), (37, 500, 0.05, 1), (301, 5000, 0.02, 8), (301, 5000, 0.02, 2), (64, 49 * 64, -1.0, 2),
                                             (2500, 3000, 0.01, 2), (1100, 49 * 1100, -1.0, 4),
                                             (20, 2000, 0.3, 4), (20, 2000, 0.3, 8), (20, 2000, 0.3, 1)])
