@@ -15,7 +15,7 @@ class Mv2dHipError(RuntimeError):
 
 
 P, I, LL, F, D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
-ABI_VERSION = 4                  # include/mv2d_hip.h: mv2d_abi_version()
+ABI_VERSION = 5                  # include/mv2d_hip.h: mv2d_abi_version()
 
 class TdDims(C.Structure):
     """struct mv2d_td_dims (include/mv2d_hip.h): the scalar arguments of mv2d_train_decoder_fwd / _bwd"""

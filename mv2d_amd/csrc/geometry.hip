@@ -816,7 +816,7 @@ __global__ __launch_bounds__(1024) void scan_and_csr_kernel(const unsigned char*
 // Every regrouping moves the fp64 value by a few 1e-16, i.e. the fp32 result differs from pe_inputs_kernel<true>'s in about one element
 // per 1e8, by one ulp (tests/test_gpu_kernels.py::test_pe_frustum_rows_fast_equals_reference_order).
 // ------------------------------------------------------------------------------------------------------------------------------
-__device__ double g_logtab[256];        // [i] = {1 / c_i, log c_i}, c_i = 1 + (i + 0.5) / 128
+struct LogTab { double t[256]; };         // [2 i] = 1 / c_i, [2 i + 1] = log c_i, c_i = 1 + (i + 0.5) / 128; a kernel ARGUMENT (2 KB): no per-device symbol, no copy inside a graph capture
 
 __device__ __forceinline__ double log_diff_tab(double x1, double x2, const double* __restrict__ tab) {
     const long long b1 = __double_as_longlong(x1), b2 = __double_as_longlong(x2);
@@ -839,9 +839,9 @@ __device__ __forceinline__ double log_diff_tab(double x1, double x2, const doubl
 __global__ __launch_bounds__(256) void pe_frustum_f32_kernel(const int* __restrict__ s2pos, const int* __restrict__ S_dev, const double* __restrict__ img2lidar,
                                                              const double* __restrict__ coords_w, const double* __restrict__ coords_h,
                                                              const double* __restrict__ coords_d, float* __restrict__ out, int h, int w, int D,
-                                                             double pr0, double pr1, double pr2, double ipd0, double ipd1, double ipd2) {
+                                                             double pr0, double pr1, double pr2, double ipd0, double ipd1, double ipd2, LogTab lt) {
     __shared__ double tab[256];
-    tab[threadIdx.x] = g_logtab[threadIdx.x];
+    tab[threadIdx.x] = lt.t[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int S = *S_dev;
@@ -1366,24 +1366,21 @@ extern "C" int mv2d_pe_frustum_f32(const int* s2pos, const int* S_dev, int S_max
     MV2D_CHECK_ARG(s2pos && S_dev && img2lidar && coords_w && coords_h && coords_d && out && position_range, "mv2d_pe_frustum_f32: null pointer");
     MV2D_CHECK_ARG(depth_num > 0 && depth_num <= 256 && V > 0 && h > 0 && w > 0, "mv2d_pe_frustum_f32: bad sizes");
     if (S_max == 0) return MV2D_OK;
-    static bool tab_ready = false;          // (first call: a synchronous copy -- the engine's warm-up run precedes any graph capture)
-    if (!tab_ready) {
-        double t[256];
+    // the logarithm table travels as a kernel argument (round 6; it was a __device__ symbol filled once per PROCESS: a second GPU of the process read
+    // zeros, and a first call under graph capture broke the capture -- ADVICE r5); built once, thread-safe
+    static const LogTab lt = [] {
+        LogTab t;
         for (int i = 0; i < 128; ++i) {
             const double c = 1.0 + (i + 0.5) / 128.0;
-            t[2 * i] = 1.0 / c;
-            t[2 * i + 1] = log(c);
+            t.t[2 * i] = 1.0 / c;
+            t.t[2 * i + 1] = log(c);
         }
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_logtab), t, sizeof(t)) != hipSuccess) {
-            mv2d_set_error("mv2d_pe_frustum_f32: table upload failed");
-            return MV2D_ERR_LAUNCH;
-        }
-        tab_ready = true;
-    }
+        return t;
+    }();
     const int blocks = cdiv(S_max, 4) < 4096 ? cdiv(S_max, 4) : 4096;
     hipLaunchKernelGGL(pe_frustum_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s2pos, S_dev, img2lidar, coords_w, coords_h, coords_d, out, h, w,
                        depth_num, position_range[0], position_range[1], position_range[2], 1.0 / (position_range[3] - position_range[0]),
-                       1.0 / (position_range[4] - position_range[1]), 1.0 / (position_range[5] - position_range[2]));
+                       1.0 / (position_range[4] - position_range[1]), 1.0 / (position_range[5] - position_range[2]), lt);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }

@@ -271,6 +271,17 @@ static void after(Pool* p, hipStream_t from, hipStream_t to) {
     (void)hipStreamWaitEvent(to, e, 0);
 }
 
+// Error path of the entries below (TD_RC returns as soon as a launch fails): the side streams were forked off the caller's stream and may still read / write
+// act and ws; the caller frees them as soon as it sees the error.  The guard joins every side stream back into the caller's stream on any exit that did not
+// reach the regular join at the end.
+struct SideJoin {
+    Pool* p; hipStream_t st; bool armed = true;
+    ~SideJoin() {
+        if (!armed || !p) return;
+        for (int i = 0; i < NSIDE; ++i) after(p, p->side[i], st);
+    }
+};
+
 static inline long long al256(long long b) { return (b + 255) & ~255LL; }
 
 struct Carver {
@@ -385,6 +396,7 @@ extern "C" int mv2d_train_decoder_fwd(const mv2d_td_dims* d, const float* const*
     MV2D_CHECK_ARG((((uintptr_t)act | (uintptr_t)ws) & 255) == 0, "mv2d_train_decoder_fwd: act / ws must be 256-byte aligned");
     Pool* pl = pool();
     MV2D_CHECK_ARG(pl != nullptr, "mv2d_train_decoder_fwd: could not create the side streams");
+    SideJoin side_join{pl, (hipStream_t)stream};
     const int T = d->T, S = d->S, L = d->L, F = d->F;
     const long long TC = (long long)T * C;
     const float qs = 1.f / sqrtf((float)(C / 8));
@@ -476,6 +488,7 @@ extern "C" int mv2d_train_decoder_fwd(const mv2d_td_dims* d, const float* const*
     }
     MV2D_LAUNCH_CHECK();
     for (int i = 1; i < NSIDE; ++i) after(pl, side[i].st, st);
+    side_join.armed = false;
     return MV2D_OK;
 }
 
@@ -495,6 +508,7 @@ extern "C" int mv2d_train_decoder_bwd(const mv2d_td_dims* d, const float* const*
     MV2D_CHECK_ARG(dn_keys || d->nk == 0 || d->nk == d->S, "mv2d_train_decoder_bwd: dn_keys may only be NULL when the denoising rows see every key");
     Pool* pl = pool();
     MV2D_CHECK_ARG(pl != nullptr, "mv2d_train_decoder_bwd: could not create the side streams");
+    SideJoin side_join{pl, (hipStream_t)stream};
     const int T = d->T, S = d->S, L = d->L, F = d->F;
     const long long TC = (long long)T * C, SC = (long long)S * C, TF = (long long)T * F;
     const float qs = 1.f / sqrtf((float)(C / 8));
@@ -628,6 +642,7 @@ extern "C" int mv2d_train_decoder_bwd(const mv2d_td_dims* d, const float* const*
     hipLaunchKernelGGL(sum_n_kernel, dim3(blocks4(TC)), dim3(256), 0, st, sa, d_qpos, TC / 4);
     MV2D_LAUNCH_CHECK();
     for (int i = 0; i < NSIDE; ++i) after(pl, side[i].st, st);
+    side_join.armed = false;
     return MV2D_OK;
 }
 
@@ -684,6 +699,7 @@ extern "C" int mv2d_train_heads_fwd(const mv2d_th_dims* d, const float* const* p
     MV2D_CHECK_ARG((((uintptr_t)act | (uintptr_t)ws) & 255) == 0, "mv2d_train_heads_fwd: act / ws must be 256-byte aligned");
     Pool* pl = pool();
     MV2D_CHECK_ARG(pl != nullptr, "mv2d_train_heads_fwd: could not create the side streams");
+    SideJoin side_join{pl, (hipStream_t)stream};
     const int T = d->T, L = d->L, NC = d->NC;
     hipStream_t st = (hipStream_t)stream;
     HActLayout al(*d, act);
@@ -708,6 +724,7 @@ extern "C" int mv2d_train_heads_fwd(const mv2d_th_dims* d, const float* const* p
     }
     MV2D_LAUNCH_CHECK();
     for (int i = 0; i < NSIDE; ++i) after(pl, lane[1 + i].st, st);
+    side_join.armed = false;
     return MV2D_OK;
 }
 
@@ -718,6 +735,7 @@ extern "C" int mv2d_train_heads_bwd(const mv2d_th_dims* d, const float* const* p
     MV2D_CHECK_ARG((((uintptr_t)act | (uintptr_t)ws) & 255) == 0, "mv2d_train_heads_bwd: act / ws must be 256-byte aligned");
     Pool* pl = pool();
     MV2D_CHECK_ARG(pl != nullptr, "mv2d_train_heads_bwd: could not create the side streams");
+    SideJoin side_join{pl, (hipStream_t)stream};
     const int T = d->T, L = d->L, NC = d->NC;
     const long long TC = (long long)T * C;
     hipStream_t st = (hipStream_t)stream;
@@ -769,6 +787,7 @@ extern "C" int mv2d_train_heads_bwd(const mv2d_th_dims* d, const float* const* p
     }
     MV2D_LAUNCH_CHECK();
     for (int i = 0; i < NSIDE; ++i) after(pl, lane[1 + i].st, st);
+    side_join.armed = false;
     return MV2D_OK;
 }
 

@@ -520,8 +520,10 @@ class HeadEngine:
         # rows the PE block gates all lie inside some RoI's rectangle), so the transposition runs BEHIND the kernels that build the position list;
         # the whole map is transposed for the training route, for keep_stages runs and when the query-generator chain is forked (key16 mode, T path)
         forked = self.kind == 'T' and self.prof is None and self.fork_qg and not self.exact
+        # (T path: roi_mask = the correlation rectangles, which contain every RoIAlign tap only when expand_stride >= 1 -- with the default 0 of
+        #  BoxCorrelation a bilinear tap can lie one cell outside its RoI's rectangle; the S path marks the exact tap range.  ADVICE r5)
         masked = (self.masked_transpose and not forked and not self.keep_sine_rows and not getattr(self, '_stage_outputs', False) and
-                  (h * w) % 4 == 0 and not (torch.is_tensor(feat) and feat.is_contiguous(memory_format=torch.channels_last) and not feat.is_contiguous()))
+                  (self.kind == 'S' or self.expand >= 1.0) and (h * w) % 4 == 0 and not (torch.is_tensor(feat) and feat.is_contiguous(memory_format=torch.channels_last) and not feat.is_contiguous()))
 
         def transpose(mask):
             if isinstance(feat, (list, tuple)):
@@ -535,6 +537,7 @@ class HeadEngine:
         tk('transpose')
         featcl = ws['featcl'] if masked else transpose(None)
         ws['featcl_cur'], ws['map_shape'], ws['max_rows'] = featcl, (V, h, w), sc['max_rows']
+        ws['feat_in'], ws['featcl_masked'] = feat, masked            # (train_forward: the masked transposition leaves rows outside every RoI rectangle unwritten)
         tk('box_params'); tk('box_corr')
         # a3/a5/a7 per-RoI camera + a9 epipolar correlation (both independent of the features) + the clearing of the frame's mask / flag
         # bytes: one launch (round 4; a one-sample frame is bound by its NUMBER of kernels)
@@ -915,7 +918,14 @@ class HeadEngine:
                 V_, h_, w_ = ws['map_shape']
                 # the PE row of that one position, fp32-class (K-concatenated products like the index-exact route; one row, outside any graph)
                 a1f, a2f = self.pe_input_rows(ws, torch.zeros(1, dtype=torch.int32, device=d), V_, h_, w_, f32=True)
-                f0 = ws['featcl_cur'][:1].contiguous()
+                # the feature row of map position 0 comes from the INPUT map: the masked transposition (round 5) writes only the rows inside some RoI's
+                # rectangle, and position 0 is by construction outside all of them here
+                fin = ws['feat_in']
+                fin0 = fin[0] if isinstance(fin, (list, tuple)) else fin
+                if fin0.is_contiguous(memory_format=torch.channels_last) and not fin0.is_contiguous():
+                    f0 = fin0.permute(0, 2, 3, 1).reshape(-1, C)[:1].contiguous()
+                else:
+                    f0 = fin0[0, :, 0, 0].reshape(1, C).contiguous()
                 def mlp1(x32, n1, n2, **kw):
                     h3 = o.gemm_bf16(o.split3_rows(x32), self._c3(n1), W_['pe_b' + n1[1:]], act=1, split3=True)
                     return o.gemm_bf16(h3, self._c3(n2), W_['pe_b' + n2[1:]], out_dtype=F32, **kw)
