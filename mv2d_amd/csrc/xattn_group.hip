@@ -3,16 +3,16 @@
 // PETRMultiheadAttention's core (MU/petr_transformer.py:426-513) with the boolean masks of the two heads (RH/mv2d_t_head.py:79-109: the
 // union of the correlated RoIs' rectangles; RH/mv2d_s_head.py:184-192: the cells of the correlated RoIs): a key row is allowed for 2.9 (cfg3_t)
 // to 6.2 (cfg5_t / the overlapping S rig) queries.  The per-query kernels (xattn_tile.hip, xattn_fused.hip) request it once per query and leave
-// the dedup to the L2s: 1.75-2.4 x the distinct rows cross the fabric.  Here a block owns a GROUP of up to 8 queries (wave = query) and walks the
-// UNION of their key lists ONCE: a 16-key tile (hi + lo key rows, hi + lo value rows = 32 KB) is brought into LDS by the LDS-DMA
-// (global_load_lds_dwordx4, a 4-deep ring, counted vmcnt + one barrier per tile) and every member query that lists a key of the tile runs its
-// logits / online softmax / P.V against it (the arithmetic of xattn_tile_kernel<1, false, XLO>, operand for operand).
+// the dedup to the L2s: 1.75-2.4 x the distinct rows cross the fabric.  Here a block owns a GROUP of up to 8 queries and walks the UNION of their
+// key lists ONCE: a 16-key tile (hi + lo key rows, hi + lo value rows = 32 KB) is brought into LDS by the LDS-DMA (global_load_lds_dwordx4, a
+// 4-deep ring, counted vmcnt + one barrier per tile) and all eight queries run their logits / online softmax / P.V against it.
 //
-// What makes that pay (round 3 built the idea on smallest-key order with position-ordered unions and lost 3 x on masked arithmetic, LOG.md):
-//   * the union of a group is SORTED BY MEMBERSHIP SIGNATURE (the byte of member bits), then by position: keys that the same subset of the
-//     group lists are contiguous, so a tile is walked only by the waves it belongs to and is (nearly) full for them -- (wave, tile) steps are
-//     1.1-1.15 x those of the per-query kernels instead of 2-3.5 x; the order of a softmax row's keys is free (fp32 rounding level);
-//   * one launch per layer: the query maps (phase A) and context maps (phase C) of xattn_fused.hip around the tile loop -- Qt and z stay in LDS.
+// Round 3 built the idea with wave = query on position-ordered unions and lost 3 x: a wave idled on tiles none of its query's keys were in and
+// did masked work on the others (LOG.md).  Here WAVE = HEAD: the 16 rows of a wave's MFMAs are (query, hi | lo part) of ONE head, the raw-key-space
+// logits of that head for all 8 queries are one MFMA chain, so the eight waves do the same work on every tile -- a (query, key) slot the query
+// does not list is masked at no cost in time -- and the per-head query map (phase A) and context map (phase C) of xattn_fused.hip stay inside
+// the wave: one launch per layer, Qt and z never leave the wave's LDS scratch.  The union of a group is sorted by membership signature
+// (the byte of member bits) inside a window of positions; the order of a softmax row's keys is free at fp32 rounding level.
 //
 // mv2d_xattn_group_tables builds the per-group tables once per frame from the CSR and a query order (groups = runs of 8 consecutive slots of
 // a sample's order: queries that share keys should be neighbours in it -- mv2d_xattn_query_order, or mv2d_xattn_cluster_order below).
@@ -247,10 +247,19 @@ __global__ __launch_bounds__(GT) void xattn_group_tables_kernel(const int* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// the attention kernel
+// the attention kernel.  Block = one group (up to 8 queries), 8 waves, WAVE = HEAD: the 16 MFMA rows of a wave are (query j, hi | lo part) of
+// its head's mapped query Qt_h, so every wave works on every tile of the union (no wave idles while another walks "its" keys; a query that
+// does not list a key has that (row, key) slot masked) and the three phases never leave the wave: the head's query map writes the wave's own
+// A operand, its context sums z_h feed its own context map.  What the waves share is the ring of key / value tiles.
+//   LDS: ring of NST stages [K hi 8 KB | K lo | V hi | V lo] (rows 512 B; key rows XOR-swizzled for the B-fragment reads, value rows
+//   chunk-swizzled for the transposing reads -- both permutations ride on the DMA's source addresses), 8 x 8 KB of wave-private scratch
+//   (Qt_h, later z_h; aliases stages 2-3 on the hi + lo route), P staging, the union's (row, mask) table of the current chunk.
 // ------------------------------------------------------------------------------------------------------------------------------
 constexpr int NST = 4;                                     // ring stages
 constexpr int CH = 4096;                                   // union entries whose (row, mask) a block keeps in LDS at a time
+#ifndef MV2D_XG_DBG
+#define MV2D_XG_DBG 0                                      // timing experiments only: 1 = no arithmetic in the tile loop, 2 = no DMA
+#endif
 
 // LDS-DMA of 16 bytes per lane: lane l of the wave writes LDS bytes [lds_dst + 16 l, + 16) from gbase + voff.  Inline asm: hipcc would put a
 // vmcnt(0) in front of every LDS read that follows a __builtin_amdgcn_global_load_lds (it cannot tell which stage the read touches), which
@@ -264,14 +273,23 @@ __device__ __forceinline__ void xg_dma16(const void* gbase, unsigned int voff, u
 }
 template <int N> __device__ __forceinline__ void xg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+typedef short xg_s16x4 __attribute__((ext_vector_type(4)));
+// B fragment of v_mfma_f32_16x16x16_f16 straight from a row-major [16 keys][256 channels] image: the 16 lanes of group g hand in the addresses of
+// keys 4 g + (n >> 2), channels c0 + 4 (n & 3) .. + 3 and get back keys 4 g .. 4 g + 3 of channel c0 + n (ds_read_b64_tr_b16; tools/probes/tr16_probe.hip)
+__device__ __forceinline__ uint2 xg_tr_read(const unsigned char* p) {
+    const xg_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) xg_s16x4*)p);
+    return __builtin_bit_cast(uint2, v);
+}
+
 template <bool XLO>
 struct XgCfg {
     static constexpr int ST = XLO ? 32768 : 16384;         // bytes of a stage: K hi | (K lo) | V hi | (V lo), 8 KB each
     static constexpr int RING = NST * ST;
-    static constexpr int AREA = RING > QB * 8192 ? RING : QB * 8192;    // phase A / C: Qt / z of the 8 queries, 8 KB each
-    static constexpr int OFF_PL = AREA, OFF_LSUM = OFF_PL + QB * 512, OFF_RQ = OFF_LSUM + QB * HEADS * 4, OFF_UC = OFF_RQ + 64,
-                         OFF_UM = OFF_UC + CH * 4, SMEM = OFF_UM + CH;
+    static constexpr int OFF_SCR = 65536;                  // wave-private scratch, 8 KB per wave (hi + lo route: stages 2 and 3)
+    static constexpr int AREA = RING > OFF_SCR + QB * 8192 ? RING : OFF_SCR + QB * 8192;
+    static constexpr int OFF_PL = AREA, OFF_RQ = OFF_PL + QB * 512, OFF_UC = OFF_RQ + 64, OFF_UM = OFF_UC + CH * 4, SMEM = OFF_UM + CH;
     static constexpr int DPT = XLO ? 4 : 2;                // DMA instructions per wave and tile
+    static constexpr int PRE = XLO ? 2 : 3;                // tiles that may be requested while the scratch holds Qt
 };
 
 template <bool XLO>
@@ -286,28 +304,64 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_group_kernel(const float* __
     using Cfg = XgCfg<XLO>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg::SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
-    float* lsum = reinterpret_cast<float*>(smem + Cfg::OFF_LSUM);
+    const int h = wave;                                      // this wave's head
     int* rq = reinterpret_cast<int*>(smem + Cfg::OFF_RQ);
     int* uc = reinterpret_cast<int*>(smem + Cfg::OFF_UC);
     unsigned char* um = smem + Cfg::OFF_UM;
+    unsigned char* scr = smem + Cfg::OFF_SCR + wave * 8192;
     const int grp = xcd_chunked(blockIdx.x, ng);
     const int nq = g_cnt[grp];
     if (nq <= 0) return;
     const int slot0 = g_slot[grp], ubase = g_ptr[grp], ulen = g_len[grp];
+    const int nchunk = (ulen + CH - 1) / CH;
     if (tid < QB) {
         const int s = slot0 + min(tid, nq - 1);
         rq[tid] = order ? order[s] : s;
     }
+    auto load_tables = [&](int c) {
+        const int ne = ((min(CH, ulen - c * CH) + 15) >> 4) * 16;
+        for (int i = tid; i < ne; i += 64 * QB) {
+            uc[i] = ucol[ubase + c * CH + i];
+            um[i] = umask[ubase + c * CH + i];
+        }
+    };
+    if (nchunk > 0) load_tables(0);
     __syncthreads();
-    // ---------------------------------------------------------------- phase A: query maps, wave = head (xattn_fused.hip)
+    const unsigned int lds0 = (unsigned int)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    auto issue = [&](int tt) {
+#if MV2D_XG_DBG != 2
+        // rows 2 w, 2 w + 1 of the tile: lanes 0-31 one row, 32-63 the next; 16-byte chunk c of key row r lands at slot c ^ r, of value row r at
+        // slot c ^ 2 (r & 7) (the source address carries the permutation, the DMA writes lane-linear)
+        const int row = 2 * wave + (lane >> 5);
+        const unsigned int k = (unsigned int)uc[16 * tt + row];
+        const unsigned int sl = (unsigned int)(lane & 31);
+        const unsigned int koff = (k << 9) + ((sl ^ (unsigned int)row) << 4), voff = (k << 9) + ((sl ^ (2u * (unsigned int)(row & 7))) << 4);
+        const unsigned int dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned int)((tt & (NST - 1)) * Cfg::ST + wave * 1024));
+        xg_dma16(Xk, koff, dst);
+        if constexpr (XLO) {
+            xg_dma16(Xk_lo, koff, dst + 8192);
+            xg_dma16(Xv, voff, dst + 16384);
+            xg_dma16(Xv_lo, voff, dst + 24576);
+        } else {
+            xg_dma16(Xv, voff, dst + 8192);
+        }
+#endif
+    };
+    int ntile = nchunk > 0 ? (min(CH, ulen) + 15) >> 4 : 0;
+#pragma unroll
+    for (int t = 0; t < Cfg::PRE; ++t)
+        if (t < ntile) issue(t);
+    // ---------------------------------------------------------------- phase A: Qt_h of the group's queries (split-precision MFMAs on the fp32 query,
+    // packed weights WA from L2; xattn_fused.hip) -> the wave's scratch -> its A operand: row n = (query n & 7, part n >> 3)
+    XgFrag qa[8];
     {
-        const int h = wave, r = rq[n & 7];
+        const int r = rq[n & 7];
         const float* qp = q + (long long)r * C + 32 * h + 8 * g;
         XgFrag bh, bl;
         xg_split8(*reinterpret_cast<const float4*>(qp), *reinterpret_cast<const float4*>(qp + 4), bh, bl);
         const uint4* wh = WA_hi + (long long)h * 16 * 64 + lane;
         const uint4* wl = WA_lo + (long long)h * 16 * 64 + lane;
-        uint4* qt = reinterpret_cast<uint4*>(smem + (n & 7) * 8192) + h * 64;
+        uint4* qt = reinterpret_cast<uint4*>(scr) + (n & 7) * 64;
         xg_u32x4 wa_h[16], wa_l[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -333,75 +387,58 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_group_kernel(const float* __
                 qt[u * 8 + g * 2 + 1] = lo.u;
             }
         }
-    }
-    __syncthreads();
-    // ---------------------------------------------------------------- phase B: wave = query, the union of the group in shared tiles
-    XgFrag qa[8];
-    {
-        const uint4* qp = reinterpret_cast<const uint4*>(smem + wave * 8192) + (n & 7) * 64 + g * 2 + (n >> 3);
+        __builtin_amdgcn_wave_barrier();
+        const uint4* qr = reinterpret_cast<const uint4*>(scr) + (n & 7) * 64 + g * 2 + (n >> 3);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) qa[s].u = qp[s * 8];
+        for (int s = 0; s < 8; ++s) qa[s].u = qr[s * 8];
     }
+    // ---------------------------------------------------------------- phase B: the union of the group, tile by tile
     float* pl = reinterpret_cast<float*>(smem + Cfg::OFF_PL) + wave * 128;
     float m_run[4], l_run[4];
-    f32x4_t Z[16];
+    f32x4_t Z[16];                                           // Z[ct][i]: row 4 g + i, channel 16 ct + n
 #pragma unroll
     for (int i = 0; i < 4; ++i) { m_run[i] = -INFINITY; l_run[i] = 0.f; }
 #pragma unroll
     for (int u = 0; u < 16; ++u) Z[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const bool active = wave < nq;
-    const unsigned int lds0 = (unsigned int)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int qbit = 4 * (g & 1);                            // row 4 g + i belongs to query 4 (g & 1) + i
+    // per-lane offsets of the operand reads inside a stage
+    const int koffs = n * 512;                               // key row n; chunk (4 s + g) ^ n
+    const int vkey = 4 * g + (n >> 2);
+    const int voffs = vkey * 512 + (n & 1) * 8, vsw = 2 * (vkey & 7), vch = (n & 3) >> 1;
 
-    auto issue = [&](int tt) {
-        // rows 2 w, 2 w + 1 of the tile: lanes 0-31 one row, 32-63 the next; key rows land XOR-swizzled (chunk c of row r at slot c ^ r: the
-        // source address carries the permutation, the DMA writes lane-linear), value rows linear
-        const int row = 2 * wave + (lane >> 5);
-        const unsigned int k = (unsigned int)uc[16 * tt + row];
-        const unsigned int sl = (unsigned int)(lane & 31);
-        const unsigned int koff = (k << 9) + ((sl ^ (unsigned int)row) << 4), voff = (k << 9) + (sl << 4);
-        const unsigned int dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned int)((tt & (NST - 1)) * Cfg::ST + wave * 1024));
-        xg_dma16(Xk, koff, dst);
-        if constexpr (XLO) {
-            xg_dma16(Xk_lo, koff, dst + 8192);
-            xg_dma16(Xv, voff, dst + 16384);
-            xg_dma16(Xv_lo, voff, dst + 24576);
-        } else {
-            xg_dma16(Xv, voff, dst + 8192);
-        }
-    };
-    auto compute = [&](int tt, bool valid) {
+    auto compute = [&](int tt) {
         const unsigned char* stg = smem + (tt & (NST - 1)) * Cfg::ST;
-        const uint4* kt = reinterpret_cast<const uint4*>(stg);
-        const uint4* kt2 = reinterpret_cast<const uint4*>(stg + 8192);
-        const unsigned char* vh = stg + (XLO ? 16384 : 8192);
-        const unsigned char* vl = stg + 24576;
+        const unsigned char* kh = stg + koffs;
+        const unsigned char* vh = stg + (XLO ? 16384 : 8192) + voffs;
+        const unsigned int mb = um[16 * tt + n];
         f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            XgFrag kb;
-            kb.u = kt[n * 32 + ((4 * s + g) ^ n)];
-            sacc = mfma_k16_16x16x32(qa[s].u, kb.u, sacc);
+            const int sl = ((4 * s + g) ^ n) << 4;
+            const uint4 kb = *reinterpret_cast<const uint4*>(kh + sl);
+            sacc = mfma_k16_16x16x32(qa[s].u, kb, sacc);
             if (XLO) {
-                XgFrag kl, qh;
-                kl.u = kt2[n * 32 + ((4 * s + g) ^ n)];
-                qh.u = n < 8 ? qa[s].u : make_uint4(0u, 0u, 0u, 0u);
-                sacc = mfma_k16_16x16x32(qh.u, kl.u, sacc);
+                const uint4 kl = *reinterpret_cast<const uint4*>(kh + 8192 + sl);
+                sacc = mfma_k16_16x16x32(qa[s].u, kl, sacc);      // (hi + lo rows of Qt) x K lo: the lo x lo term rides along
             }
         }
         float sv[4], p[4], alpha[4];
+        bool resc = false;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sacc[i]), __float_as_uint(sacc[i]), false, false);
             const float full = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-            sv[i] = valid ? full * LOG2E : -INFINITY;
+            sv[i] = ((mb >> (qbit + i)) & 1u) ? full * LOG2E : -INFINITY;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float tm = sv[i];
-            tm = xg_row16_max(tm);
+            const float tm = xg_row16_max(sv[i]);
             const float m_new = fmaxf(m_run[i], tm);
-            alpha[i] = __builtin_amdgcn_exp2f(m_run[i] - m_new);
-            p[i] = __builtin_amdgcn_exp2f(sv[i] - m_new);
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;          // a query that lists no key so far: p = 0, nothing to rescale
+            const bool moved = m_new != m_run[i];
+            alpha[i] = moved ? __builtin_amdgcn_exp2f(m_run[i] - m_use) : 1.f;
+            resc = resc || moved;
+            p[i] = __builtin_amdgcn_exp2f(sv[i] - m_use);
             l_run[i] = l_run[i] * alpha[i] + p[i];
             m_run[i] = m_new;
         }
@@ -410,57 +447,43 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_group_kernel(const float* __
             for (int i = 0; i < 4; ++i) pl[(4 * g + i) * 16 + n] = p[i];
         }
         __builtin_amdgcn_wave_barrier();
-        uint2 pa, pah;
+        uint2 pa;
         {
             const float4 pv = *reinterpret_cast<const float4*>(pl + (n & 7) * 16 + 4 * g);
             unsigned int h0, h1, l0, l1;
             split_k16x2_bounded(pv.x, pv.y, h0, l0);
             split_k16x2_bounded(pv.z, pv.w, h1, l1);
             pa = n < 8 ? make_uint2(h0, h1) : make_uint2(l0, l1);
-            pah = n < 8 ? make_uint2(h0, h1) : make_uint2(0u, 0u);
+        }
+        if (__ballot(resc) != 0ull) {                         // (wave-uniform: a scalar branch; the maxima stop moving after a row's first tiles)
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Z[u][i] *= alpha[i];
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) Z[u][i] *= alpha[i];
-#pragma unroll
-        for (int H = 0; H < 2; ++H) {
-            // value rows of keys 4 g .. 4 g + 3, 16-byte column chunk n + 16 H (lanes of a read group differ in n: conflict-free without a swizzle)
-            xg_u32x4 r_[4], q_[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                r_[e] = *reinterpret_cast<const xg_u32x4*>(vh + (4 * g + e) * 512 + (n + 16 * H) * 16);
-                if (XLO) q_[e] = *reinterpret_cast<const xg_u32x4*>(vl + (4 * g + e) * 512 + (n + 16 * H) * 16);
-            }
-#pragma unroll
-            for (int w = 0; w < 8; ++w) {
-                const int d = w >> 1;
-                const uint2 vb = (w & 1) ? make_uint2(xg_hi_pair(r_[0][d], r_[1][d]), xg_hi_pair(r_[2][d], r_[3][d]))
-                                         : make_uint2(xg_lo_pair(r_[0][d], r_[1][d]), xg_lo_pair(r_[2][d], r_[3][d]));
-                f32x4_t zc = Z[H * 8 + w];
-                zc = mfma_k16_16x16x16(pa, vb, zc);
-                if (XLO) {
-                    const uint2 vl2 = (w & 1) ? make_uint2(xg_hi_pair(q_[0][d], q_[1][d]), xg_hi_pair(q_[2][d], q_[3][d]))
-                                              : make_uint2(xg_lo_pair(q_[0][d], q_[1][d]), xg_lo_pair(q_[2][d], q_[3][d]));
-                    zc = mfma_k16_16x16x16(pah, vl2, zc);
-                }
-                Z[H * 8 + w] = zc;
-            }
+        for (int ct = 0; ct < 16; ++ct) {
+            const int sl = ((2 * ct + vch) ^ vsw) << 4;
+            f32x4_t zc = Z[ct];
+            zc = mfma_k16_16x16x16(pa, xg_tr_read(vh + sl), zc);
+            if (XLO) zc = mfma_k16_16x16x16(pa, xg_tr_read(vh + 8192 + sl), zc);      // (hi + lo rows of P) x V lo
+            Z[ct] = zc;
         }
         __builtin_amdgcn_wave_barrier();
     };
 
-    for (int c0 = 0; c0 < ulen; c0 += CH) {
-        const int clen = min(CH, ulen - c0), ntile = (clen + 15) >> 4;
-        __syncthreads();                                     // (second chunk on: every wave is done with uc / um and the ring; first: with the Qt area)
-        for (int i = tid; i < ntile * 16; i += 64 * QB) {
-            uc[i] = ucol[ubase + c0 + i];
-            um[i] = umask[ubase + c0 + i];
+    __syncthreads();                                         // every wave holds its operand: the scratch (stages 2, 3 on the hi + lo route) may be overwritten
+    for (int c = 0; c < nchunk; ++c) {
+        if (c > 0) {
+            __syncthreads();                                 // every wave is done with the table and the ring
+            load_tables(c);
+            ntile = (min(CH, ulen - c * CH) + 15) >> 4;
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < Cfg::PRE; ++t)
+                if (t < ntile) issue(t);
         }
-        __syncthreads();
-        issue(0);
-        if (ntile > 1) issue(1);
-        if (ntile > 2) issue(2);
+        if (Cfg::PRE < 3 && ntile > 2) issue(2);
         for (int tt = 0; tt < ntile; ++tt) {
             const int rem = ntile - 1 - tt;
             // this wave's pieces of tile tt have landed (loads return in order; tiles tt + 1, tt + 2 may stay in flight) ...
@@ -469,47 +492,40 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_group_kernel(const float* __
             else xg_wait_vm<0>();
             __builtin_amdgcn_s_barrier();                    // ... and everybody's; every wave is past tile tt - 1, whose stage tile tt + 3 takes
             if (tt + 3 < ntile) issue(tt + 3);
-            const bool valid = active && ((um[16 * tt + n] >> wave) & 1);
-            if (__ballot(valid) != 0ull) compute(tt, valid);
+#if MV2D_XG_DBG != 1
+            compute(tt);
+#endif
         }
     }
-    __syncthreads();                                         // the ring becomes the z area
-    // ---- denominators and the un-normalised z of the query ([head][256] fp32 = 8 KB per query)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float l = l_run[i];
-        l += __shfl_xor(l, 1, 64);
-        l += __shfl_xor(l, 2, 64);
-        l += __shfl_xor(l, 4, 64);
-        l += __shfl_xor(l, 8, 64);
-        l_run[i] = l;
-    }
-    if (n == 0 && g < 2) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) lsum[wave * HEADS + 4 * g + i] = l_run[i];
-    }
+    __syncthreads();                                         // the ring is idle: the scratch takes z
+    // ---- z_h / l of the 8 queries -> the wave's scratch ([query][256] fp32)
     {
-        float* szw = reinterpret_cast<float*>(smem + wave * 8192);
+        float rl[4];
 #pragma unroll
-        for (int H = 0; H < 2; ++H)
+        for (int i = 0; i < 4; ++i) {
+            float l = l_run[i];
+            l += __shfl_xor(l, 1, 64);
+            l += __shfl_xor(l, 2, 64);
+            l += __shfl_xor(l, 4, 64);
+            l += __shfl_xor(l, 8, 64);
+            rl[i] = __builtin_amdgcn_rcpf(l);
+        }
+        float* zs = reinterpret_cast<float*>(scr);
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float v[4];
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(Z[H * 8 + w][i]), __float_as_uint(Z[H * 8 + w + 4][i]), false, false);
-                    v[w] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-                }
-                float* dst = szw + (4 * (g & 1) + i) * C + 128 * H + 8 * n + 4 * (g >> 1);
-                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                // hi rows (lanes 0-31) + lo rows (lanes 32-63): afterwards lanes g < 2 hold column tile ct, lanes g >= 2 column tile ct + 8 of query 4 (g & 1) + i
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(Z[ct][i]), __float_as_uint(Z[ct + 8][i]), false, false);
+                const float v = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) * rl[i];
+                zs[(qbit + i) * C + 16 * (ct + 8 * (g >> 1)) + n] = v;
             }
+        __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
-    // ---------------------------------------------------------------- phase C: context maps, wave = head (xattn_fused.hip)
+    // ---------------------------------------------------------------- phase C: ctx[:, 32 h .. 32 h + 31] = Wv_h z_h + bv (xattn_fused.hip)
     {
-        const int h = wave, j = n & 7;
-        const float* zp = reinterpret_cast<const float*>(smem + j * 8192) + h * C + 8 * g;
-        const float rl = __builtin_amdgcn_rcpf(lsum[j * HEADS + h]);
+        const int j = n & 7;
+        const float* zp = reinterpret_cast<const float*>(scr) + j * C + 8 * g;
         const uint4* wh = WB_hi + (long long)h * 16 * 64 + lane;
         const uint4* wl = WB_lo + (long long)h * 16 * 64 + lane;
         f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -530,10 +546,8 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_group_kernel(const float* __
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            float4 x0 = *reinterpret_cast<const float4*>(zp + 32 * s);
-            float4 x1 = *reinterpret_cast<const float4*>(zp + 32 * s + 4);
-            x0 = make_float4(x0.x * rl, x0.y * rl, x0.z * rl, x0.w * rl);
-            x1 = make_float4(x1.x * rl, x1.y * rl, x1.z * rl, x1.w * rl);
+            const float4 x0 = *reinterpret_cast<const float4*>(zp + 32 * s);
+            const float4 x1 = *reinterpret_cast<const float4*>(zp + 32 * s + 4);
             XgFrag ah, al;
             xg_split8(x0, x1, ah, al);
 #pragma unroll
