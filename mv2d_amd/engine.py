@@ -104,10 +104,12 @@ class HeadEngine:
         # of 8 queries, Qt / z stay on chip; bitwise the three kernels with one wave per query).  None: on the S path when no debug output is asked
         # for; False / True forces it.  In the graph key.
         self.fuse_xattn = None
-        # Round 6: key tiles SHARED between the queries of a group (csrc/xattn_group.hip: one block per 8 queries that are neighbours in the launch
-        # order walks the union of their key lists once; query / context maps in the same launch).  None: on the T path (a key row is listed by
-        # 2.9-6.2 queries there) when no debug output is asked for; True / False forces it (True on the S path pays when RoIs are matched across
-        # views).  In the graph key.
+        # Round 6, OPT-IN: key tiles SHARED between the queries of a group (csrc/xattn_group.hip: one block per 8 queries that are neighbours in the
+        # launch order walks the union of their key lists once through an LDS-DMA ring; wave = head, query / context maps in the same launch).  It
+        # reads what it should (1.34-1.68 x the distinct rows instead of 2.99 x at cfg3_t) and is SLOWER than the per-query kernels (242-326 us
+        # against 158 + 33 us per cfg3_t layer): eight heads x every union tile is 2.7 x the (wave, tile) steps of the per-query walk, and the
+        # 32 KB tiles of the hi + lo route leave the 160 KB of LDS no room to run the queries' own walks side by side (LOG.md, round 6).  None /
+        # False: off; True forces it.  In the graph key.
         self.group_xattn = None
         # Layer 0 of the decoder starts from target = 0 (RH/bbox_heads/cross_attention_head.py:32): the VALUE rows of its self attention are
         # in_proj_v(0) + b_v = b_v for every query, the softmax weights of a row sum to 1, so its context is b_v whatever the queries are
@@ -770,7 +772,7 @@ class HeadEngine:
     def _grouped(self, ws):
         """Does this frame's cross attention run on shared key tiles (csrc/xattn_group.hip)?  Needs the group tables of the workspace (the training
         forward's own decoder workspace has none) and no debug output."""
-        on = (self.kind == 'T') if self.group_xattn is None else bool(self.group_xattn)
+        on = bool(self.group_xattn)
         return on and ws.get('grp_tab') is not None and not self.debug_attn and not ws.get('dn')
 
     def _enqueue_heads(self, ws, R, dt):

@@ -343,12 +343,13 @@ def test_engine_map_kernels_fused_or_separate_bitwise_equal(kind, name):
     eng = HeadEngine(sd, kind, dev, num_views=prob['views_per_frame'])
     grouped = None
     if kind == 'T':
-        # round 6: the T path's default is the shared-tile cross attention (csrc/xattn_group.hip), which visits the keys of a softmax row in the
-        # order of its group's union: equal to the per-query kernels to fp32 rounding, not bitwise.  The options below belong to the per-query route.
+        # round 6: the opt-in shared-tile cross attention (csrc/xattn_group.hip) visits the keys of a softmax row in the order of its group's union:
+        # equal to the per-query kernels to fp32 rounding, not bitwise; eager and graph replay agree bitwise
+        eng.group_xattn = True
         grouped = {k: v.clone() for k, v in eng.run(feat, props, prob['img_metas']).items() if k in ('cls', 'reg')}
         g2 = eng.run(feat, props, prob['img_metas'], use_graph=True)
         assert torch.equal(g2['cls'], grouped['cls']) and torch.equal(g2['reg'], grouped['reg'])
-        eng.group_xattn = False
+        eng.group_xattn = None
     out = eng.run(feat, props, prob['img_metas'])
     o2 = eng.run(feat, props, prob['img_metas'], use_graph=True)
     assert torch.equal(o2['cls'], out['cls'])
