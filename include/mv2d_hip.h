@@ -115,6 +115,14 @@ int mv2d_pe_fused_x3(const float* A1, const float* Xmap, const int* row_index, c
                      const void* W1a_hi, const void* W1a_lo, const float* b1a, const void* W1b_hi, const void* W1b_lo, const float* b1b,
                      const void* Wr_hi, const void* Wr_lo, const float* br, const void* We_hi, const void* We_lo, const float* be,
                      const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, void* stream);
+/* The same block on the second shape of the kernel (round 6, csrc/pe_x3b.hip): a wave owns 16 rows through both layers of each MLP, the hidden layer
+ * stays in registers (no LDS image, no barrier between the layers), the weights go through a 4-deep LDS ring (LDS-DMA) shared by the 8 waves of a 128-row
+ * block, two waves per SIMD.  Same operands EXCEPT that W1a and Wr (the first layers) are packed from the weight with its rows in the order
+ * packed row 32 b + 16 t + 4 g + e = original row 32 b + 8 g + 4 t + e (ops.rowperm32); outputs bitwise those of mv2d_pe_fused_x3. */
+int mv2d_pe_fused_x3b(const float* A1, const float* Xmap, const int* row_index, const int* m_dev, int M,
+                     const void* W1a_hi, const void* W1a_lo, const float* b1a, const void* W1b_hi, const void* W1b_lo, const float* b1b,
+                     const void* Wr_hi, const void* Wr_lo, const float* br, const void* We_hi, const void* We_lo, const float* be,
+                     const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, void* stream);
 
 /* QueryGenerator shared conv + pooling fused, one block per RoI (RH/utils/query_generator.py:298-304,322-331,352-358):
  * out[r, n] = mean over the 49 cells of relu(conv3x3(roi_feat[r])[cell, n] + bias[n]).  roi_feat [R,49,256] key16 (cell-major),

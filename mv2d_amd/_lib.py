@@ -40,6 +40,7 @@ SIGNATURES = {
     'mv2d_pe_fused_tab': (I, [P, P, P, P, P, I] + [P] * 9 + [I, P, P, P]),
     'mv2d_pe_fused_tab2': (I, [P, P, P, P, P, I] + [P] * 9 + [I, P, P, I, P]),
     'mv2d_pe_fused_x3': (I, [P, P, P, P, I] + [P] * 13 + [I] + [P] * 6),
+    'mv2d_pe_fused_x3b': (I, [P, P, P, P, I] + [P] * 13 + [I] + [P] * 6),
     'mv2d_key16_format': (I, []),
     'mv2d_f32_to_key16': (I, [P, P, P, LL, P]),
     'mv2d_split_rows_key16': (I, [P, P, P, P, I, I, P, P]),

@@ -134,6 +134,11 @@ class HeadEngine:
         # 5.1e-6 -> 4.9e-6 / 5.8e-6 -> 5.7e-6): its 2304-term dot products average the 2^-12 roundings down, and the 3 x MFMA-bound split-
         # precision kernel (362 vs 123 us per 2400 RoIs) leaves the route.  Attention rows and PE stay hi + lo: dropping either costs ranks.
         self.exact_skip = frozenset({'conv'})
+        # Round 6, OPT-IN: the split-precision PE block on the second shape of its kernel (csrc/pe_x3b.hip: a wave owns 32 rows through both layers of
+        # each MLP, the hidden layer stays in registers, the weights go through an LDS-DMA ring shared by the block's 4 waves; BITWISE the outputs of
+        # csrc/pe_x3.hip).  Measured no faster (1213 vs 1165-1244 us per 250 k rows; 8 waves x 16 rows: 1056 us, bound by 8 x 32 KB of LDS reads per
+        # k-step): LOG.md round 6.  In the graph key.
+        self.pe_rows_in_waves = False
         self.K16 = ops.key16_dtype()  # dtype of the key side's 16-bit buffers (csrc/common.h "key16": fp16 since round 4)
         self.load_state(state_dict)
 
@@ -212,6 +217,9 @@ class HeadEngine:
             # bf16 hi / lo fragment-major pairs for the split-precision PE kernel (csrc/pe_x3.hip)
             w['pe_x3'] = dict(b1a=w['pe_b1a'], b1b=w['pe_b1b'], br=w['pe_br'], be=w['pe_be'],
                               **{n_: ops.pack_x3(c1(k_ + '.weight')) for n_, k_ in pe_names if n_ in ('w1a', 'w1b', 'wr', 'we')})
+            # first-layer weights with their rows in the order csrc/pe_x3b.hip chains the two layers in registers with
+            w['pe_x3']['w1a_p'] = ops.pack_x3_rowperm(c1('position_encoder.0.weight'))
+            w['pe_x3']['wr_p'] = ops.pack_x3_rowperm(c1('fpe.conv_reduce.weight'))
             w['qg_conv_wx3'] = ops.pack_key16_x3(conv)
         self.w = w
         for k in ('cls_w0', 'cls_w3', 'reg_w0', 'reg_w2'):                              # [L,256,256] -> bf16x3, fragment-major, stacked over L
@@ -655,8 +663,9 @@ class HeadEngine:
         sh = ws['shared']
         rows = self.kind == 'T'
         dbg = getattr(self, '_stage_outputs', False)
-        o.pe_fused_x3(ws['xa1'], featcl, md, W_['pe_x3'], sh['sine_tab'], sh['sine_period'], pe=ws['pe'] if (not rows or dbg) else None,
-                      Xk=(ws['Xk'], ws['xk_lo']) if rows else None, Xv=(ws['Xf_b'], ws['xv_lo']) if rows else None, M=P, row_index=ws['s2pos'])
+        (o.pe_fused_x3b if self.pe_rows_in_waves else o.pe_fused_x3)(
+            ws['xa1'], featcl, md, W_['pe_x3'], sh['sine_tab'], sh['sine_period'], pe=ws['pe'] if (not rows or dbg) else None,
+            Xk=(ws['Xk'], ws['xk_lo']) if rows else None, Xv=(ws['Xf_b'], ws['xv_lo']) if rows else None, M=P, row_index=ws['s2pos'])
 
     def pe_input_rows(self, ws, positions, V, h, w, f32=False):
         """PE input rows (frustum [n,192], sine [n,384]; key16, or unrounded fp32 with f32=True) at the given map positions (int32, device)
@@ -864,7 +873,7 @@ class HeadEngine:
         # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
         gkey = (ptrs, 0 if payload is None else payload.data_ptr(), sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs, self.last_stage_heads,
-                self.xattn_waves, self.fuse_maps, self.fuse_xattn, self.group_xattn, self.fold_sa0, self.masked_transpose, self.keep_sine_rows, self.force_nc, self.q_order,
+                self.xattn_waves, self.fuse_maps, self.fuse_xattn, self.group_xattn, self.pe_rows_in_waves, self.fold_sa0, self.masked_transpose, self.keep_sine_rows, self.force_nc, self.q_order,
                 self.fork_qg, self.exact_skip, self.stop_before_decoder)   # load_state() re-allocates the weights; every route option of __init__ is in the key
         graphs = ws.setdefault('graphs', {})             # one graph per (input buffers, frame scalars): a producer that alternates between
         g = graphs.get(gkey)                             # a few static output buffers replays a few graphs, it does not re-capture

@@ -132,6 +132,21 @@ def pack_x3(W):
     return pack_wfrag(hi), pack_wfrag(lo)
 
 
+def rowperm32(N, device=None):
+    """Row order of a first-layer weight for csrc/pe_x3b.hip: inside every block of 32 rows, packed row 16 t + 4 fg + e holds original row
+    8 fg + 4 t + e -- the accumulator tiles 2 s, 2 s + 1 of a lane (columns 4 fg .. 4 fg + 3 of each) are then the hidden columns
+    32 s + 8 fg + {0..3}, {4..7}: the B fragment of k-step s of the next layer."""
+    r = torch.arange(N, device=device)
+    b, t, m = r // 32, (r % 32) // 16, r % 16
+    return 32 * b + 8 * (m // 4) + 4 * t + (m % 4)
+
+
+def pack_x3_rowperm(W):
+    """pack_x3 of the rows of W [N,K] in rowperm32 order (N a multiple of 32)."""
+    assert W.shape[0] % 32 == 0
+    return pack_x3(W[rowperm32(W.shape[0], W.device)].contiguous())
+
+
 def pack_key16(W):
     """fp32 [N,K] weight -> key16, fragment-major: the weights of the key-side kernels (PE MLPs, query-generator conv)."""
     return pack_wfrag(f32_to_key16(W.contiguous()))
@@ -397,6 +412,25 @@ def pe_fused_x3(A1, Xmap, m_dev, wx, sine_tab, tab_period, pe=None, Xk=None, Xv=
                                        _p(wx['w1b'][0]), _p(wx['w1b'][1]), _p(wx['b1b']), _p(wx['wr'][0]), _p(wx['wr'][1]), _p(wx['br']),
                                        _p(wx['we'][0]), _p(wx['we'][1]), _p(wx['be']), _p(sine_tab), int(tab_period), _p(pe), _p(xk[0]), _p(xk[1]),
                                        _p(xv[0]), _p(xv[1]), _stream()), 'mv2d_pe_fused_x3')
+    return pe
+
+
+def pe_fused_x3b(A1, Xmap, m_dev, wx, sine_tab, tab_period, pe=None, Xk=None, Xv=None, M=None, row_index=None):
+    """pe_fused_x3 on the second shape of the kernel (csrc/pe_x3b.hip: a wave owns 16 rows through both layers, the hidden layer stays in registers, the
+    weights go through an LDS ring): bitwise the same outputs.  wx additionally holds 'w1a_p', 'wr_p' = pack_x3_rowperm of the two first-layer weights."""
+    _req(A1, torch.float32, 'A1'); _req(Xmap, torch.float32, 'Xmap'); _req(sine_tab, torch.float32, 'sine_tab'); _req(pe, torch.float32, 'pe')
+    _req(row_index, torch.int32, 'row_index'); _req(m_dev, torch.int32, 'm_dev')
+    for pair in (Xk, Xv):
+        if pair is not None:
+            _req16(pair[0], 'hi'); _req16(pair[1], 'lo')
+    for k in ('w1a_p', 'w1b', 'wr_p', 'we'):
+        _req(wx[k][0], q16_dtype(), k); _req(wx[k][1], q16_dtype(), k)
+    M = A1.shape[0] if M is None else M
+    xk, xv = Xk or (None, None), Xv or (None, None)
+    check(_lib.load().mv2d_pe_fused_x3b(_p(A1), _p(Xmap), _p(row_index), _p(m_dev), M, _p(wx['w1a_p'][0]), _p(wx['w1a_p'][1]), _p(wx['b1a']),
+                                        _p(wx['w1b'][0]), _p(wx['w1b'][1]), _p(wx['b1b']), _p(wx['wr_p'][0]), _p(wx['wr_p'][1]), _p(wx['br']),
+                                        _p(wx['we'][0]), _p(wx['we'][1]), _p(wx['be']), _p(sine_tab), int(tab_period), _p(pe), _p(xk[0]), _p(xk[1]),
+                                        _p(xv[0]), _p(xv[1]), _stream()), 'mv2d_pe_fused_x3b')
     return pe
 
 

@@ -1032,6 +1032,19 @@ def test_pe_fused_x3_kernel(dev, M, use_mdev, use_ri, rows):
         pe_only = torch.zeros((M, 256), device=dev)
         ops.pe_fused_x3(A1, Xmap, md, wx, tab, period, pe=pe_only, M=M, row_index=ri)
         assert torch.equal(pe_only, pe)
+    # round 6: the second shape of the kernel (csrc/pe_x3b.hip: rows owned by waves, hidden layer in registers, weights through an LDS ring) does the
+    # same products in the same k order: BITWISE the same outputs
+    wx['w1a_p'], wx['wr_p'] = ops.pack_x3_rowperm(W['w1a']), ops.pack_x3_rowperm(W['wr'])
+    pe_b = torch.zeros((M, 256), device=dev)
+    pairs_b = [tuple(torch.zeros((M, 256), device=dev, dtype=k16) for _ in range(2)) for _ in range(2)] if rows else [None, None]
+    ops.pe_fused_x3b(A1, Xmap, md, wx, tab, period, pe=pe_b, Xk=pairs_b[0], Xv=pairs_b[1], M=M, row_index=ri)
+    assert torch.equal(pe_b.view(torch.int32), pe.view(torch.int32)), float((pe_b - pe).abs().max())
+    if rows:
+        for a, b in zip(pairs_b, pairs):
+            assert torch.equal(a[0].view(torch.int16), b[0].view(torch.int16)) and torch.equal(a[1].view(torch.int16), b[1].view(torch.int16))
+        nop = [tuple(torch.zeros((M, 256), device=dev, dtype=k16) for _ in range(2)) for _ in range(2)]
+        ops.pe_fused_x3b(A1, Xmap, md, wx, tab, period, Xk=nop[0], Xv=nop[1], M=M, row_index=ri)          # (T path: no pe output)
+        assert torch.equal(nop[0][0].view(torch.int16), pairs[0][0].view(torch.int16))
 
 
 def test_attn_out_fused_x3(dev):

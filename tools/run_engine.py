@@ -19,12 +19,15 @@ ap.add_argument('--steps', type=int, default=20)
 ap.add_argument('--exact', action='store_true', help='(the default since round 5; accepted and ignored)')
 ap.add_argument('--key16', action='store_true', help='the opt-in key16 mode (one fp16 rounding of the key side)')
 ap.add_argument('--eager', action='store_true')
+ap.add_argument('--pe-v2', action='store_true', help='the opt-in second shape of the PE kernel (csrc/pe_x3b.hip) instead of csrc/pe_x3.hip')
 ap.add_argument('--group', type=int, default=None, help='1 / 0: force the shared-tile cross attention (csrc/xattn_group.hip) on / off; default: the engine chooses (T path: on)')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 probs = [synthetic.make_problem(a.workload, seed=s) for s in range(a.batch)]
 eng = HeadEngine(synthetic.make_head_state(seed=0), probs[0]['kind'], dev, num_views=probs[0]['views_per_frame'], exact=not a.key16)
 eng.fork_qg = False
+if a.pe_v2:
+    eng.pe_rows_in_waves = True
 if a.group is not None:
     eng.group_xattn = bool(a.group)
 feats = torch.cat([torch.from_numpy(p['feat']) for p in probs]).to(dev)
