@@ -207,9 +207,15 @@ WORKLOADS = {
     # the same overlapping rig at the HEADLINE size (BASELINE.json configs[1]: 6 cams 1408x512, 300 RoIs): the non-trivial S workload of the bench
     # line (round 4) -- every query reads its own RoI plus up to five matched ones instead of the 1.01 RoIs of the ring rig
     'cfg2_s_nc6': ('S', 6, 1, 512, 1408, None, 50),
+    # round 6 -- the S path at the cap of SURVEY 8.0 (75 boxes per view, R = 450), and near-duplicate 2-D boxes (a fifth of every view's boxes
+    # are copies of others: half of them exact, half a quarter pixel larger) at the headline S size and at the cfg-5 T size: ties and near-ties
+    # in the IoU ranking of the box correlation (RH/utils/box_correlation.py:370-374)
+    'cfg2_s_r450': ('S', 6, 1, 512, 1408, None, 75),
+    'cfg2_s_dup': ('S', 6, 1, 512, 1408, None, 50),
+    'cfg5_t_dup': ('T', 6, 2, 640, 1600, None, 75),
 }
 # rigs that are not a full ring: yaw step in degrees and lateral camera spacing in metres
-RIG = {'nc6_s': (8.0, 0.35), 'cfg2_s_nc6': (8.0, 0.35)}
+RIG = {'nc6_s': (8.0, 0.35), 'cfg2_s_nc6': (8.0, 0.35), 'cfg2_s_dup': (8.0, 0.35)}       # (the duplicates of cfg2_s_dup on the overlapping rig: matched RoIs exist)
 
 
 def make_problem(name, seed=0, with_feat=True, ego=0.0):
@@ -221,6 +227,14 @@ def make_problem(name, seed=0, with_feat=True, ego=0.0):
     yaw, base = RIG.get(name, ((40.0 if vpf < 6 else None), 0.0))
     metas = make_img_metas(vpf, H, W, frames, pad_w=pw, yaw_step_deg=yaw, ego=ego, baseline=base)
     props = make_proposals(V, n, H, W, seed + 1)
+    if name.endswith('_dup'):
+        # the last fifth of every view's boxes become copies of its first ones: even copies exact, odd ones a quarter pixel LARGER (x2, y2 + 0.25: a near
+        # tie in the IoU ranking; a shifted copy of equal size would tie EXACTLY with a different box whenever the epipolar rectangle contains both, and
+        # the reference's unstable argsort, RH/utils/box_correlation.py:370, would then decide which features a query reads)
+        for v_ in range(V):
+            k = n // 5
+            props[v_][n - k:, :4] = props[v_][:k, :4]
+            props[v_][n - k + 1::2, 2:4] += np.float32(0.25)
     feat = make_feat(V, H // 16, pw // 16, seed + 2) if with_feat else None
     return dict(kind=kind, feat=feat, proposals=props, img_metas=metas, name=name,
                 views_per_frame=vpf, frames=frames)

@@ -246,3 +246,26 @@ def test_bench_self_spawn_gloo():
     assert r.returncode == 0 and lines, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
     d = json.loads(lines[-1])
     assert d == dict(spawn_check=True, world=2, ranks=[0, 1], backend='gloo')
+
+
+def test_bench_two_ranks_end_to_end_gloo_stub_engine():
+    """`python bench.py --gpus 2 --backend gloo --stub-engine --steps 2`: the self-spawn, the timed loop with its barriers and max over ranks, the
+    per-step all-gather on ping-pong buffers and the JSON line, END TO END on two CPU ranks (round 6; the HIP engine is replaced by bench.StubEngine,
+    the line is labelled and is not a measurement).  Checks: both ranks ran, every rank's slice of the gathered tensor is what it packed, all ranks hold
+    the same gathered tensor, `value` is the weak-scaling aggregate world x frames per step x steps / max-over-ranks time."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--stub-engine', '--steps', '2', '--warmup', '1',
+                        '--prime', '1', '--batch', '3', '--inflight', '2', '--rounds', '2'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    d = json.loads(lines[-1])
+    assert d['stub_engine'] is True and d['n_gpus'] == 2 and d['steps'] == 2 and d['scaling'] == 'weak'
+    assert d['config']['frames_per_step_per_gpu'] == 2 * 2 * 3 and d['config']['global_batch'] == 2 * 12
+    c = d['collective_check']
+    assert c['backend'] == 'gloo' and c['world'] == 2 and c['gathered_shape'] == [2, 12, 3301]
+    assert c['gathered_equals_packed'] and c['every_rank_holds_the_same_gathered_tensor'] and c['payload_nonzero_entries'] > 0
+    assert c['steps_with_collective'] == 4                                   # prime + warm-up + 2 timed steps
+    assert abs(d['value'] - 24 * 2 / d['timed_seconds']) <= 1e-2 * d['value'] and abs(d['ms_per_step'] - d['timed_seconds'] / 2 * 1e3) < 1e-2

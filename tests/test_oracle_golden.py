@@ -45,10 +45,10 @@ def check_common(st, g):
     close(st['cls'].numpy().reshape(g['cls'].shape) if st['cls'].numel() == g['cls'].size else st['cls'], g['cls'], 1e-4)
 
 
-@pytest.mark.parametrize('name', ['micro_t', 'cfg1_t', 'cfg3_t', 'cfg5_t'])
-def test_t_path_matches_reference(name):
-    g = load_golden(name)
-    st = run(name)
+@pytest.mark.parametrize('name,seed', [('micro_t', 0), ('cfg1_t', 0), ('cfg3_t', 0), ('cfg5_t', 0), ('cfg3_t', 2), ('cfg5_t_dup', 0)])      # round 6: a third seed; near-duplicate boxes
+def test_t_path_matches_reference(name, seed):
+    g = load_golden(name if seed == 0 else f'{name}_seed{seed}')
+    st = run(name, synthetic.make_problem(name, seed=seed))
     check_common(st, g)
     ffr = unpack_bits(g['feat_for_rois'], g['feat_for_rois_shape'])
     np.testing.assert_array_equal(st['feat_for_rois'].numpy(), ffr)                 # bit-exact bool
@@ -56,7 +56,7 @@ def test_t_path_matches_reference(name):
     np.testing.assert_array_equal((~st['feat_for_rois'])[:, st['roi_mask']].numpy(), blocked)
     np.testing.assert_array_equal(st['key_padding'].numpy(), g['key_padding'])
     reg = st['reg'].numpy().reshape(g['reg'].shape)
-    if name in ('cfg3_t', 'cfg5_t'):
+    if name in ('cfg3_t', 'cfg5_t', 'cfg5_t_dup'):
         # two frames: the golden 'reg' is CrossAttentionBoxHead.forward's output, BEFORE RH/mv2d_t_head.py:136-140 divides the velocities
         # by dt = 0.5 s (the golden 'boxes' are after it)
         reg = np.concatenate([reg[..., :8], reg[..., 8:] * 0.5], -1)
@@ -81,12 +81,19 @@ def test_t_path_matches_reference(name):
             close(cap[l]['attn_mean'], g['attn_mean'][l], 1e-4)
 
 
-@pytest.mark.parametrize('name', ['micro_s', 'cfg1_s', 'cfg2_s', 'nc6_s', 'cfg2_s_nc6'])      # nc6_s / cfg2_s_nc6: up to 6 correlated RoIs per query
-def test_s_path_matches_reference(name):
-    g = load_golden(name)
-    st = run(name)
+@pytest.mark.parametrize('name,seed', [('micro_s', 0), ('cfg1_s', 0), ('cfg2_s', 0), ('nc6_s', 0), ('cfg2_s_nc6', 0),      # nc6_s / cfg2_s_nc6: up to 6 correlated RoIs per query
+                                       ('cfg2_s_nc6', 2), ('cfg2_s_r450', 0), ('cfg2_s_dup', 0)])                       # round 6: third seed, R = 450, near-duplicate boxes
+def test_s_path_matches_reference(name, seed):
+    g = load_golden(name if seed == 0 else f'{name}_seed{seed}')
+    st = run(name, synthetic.make_problem(name, seed=seed))
     check_common(st, g)
-    np.testing.assert_array_equal(st['corr'].numpy(), g['corr'])                    # bit-exact int64
+    if name.endswith('_dup'):
+        # a fifth of the boxes are copies: an IoU tie between IDENTICAL boxes is broken by the reference's unstable argsort (RH/utils/box_correlation.py:370;
+        # observed: towards the higher index) and by the oracle towards the lower one -- the matched RoI may differ, its box (and so its features) may not
+        rois = O.bbox2roi([torch.from_numpy(p)[:, :4] for p in synthetic.make_problem(name, seed=seed)['proposals']]).numpy()
+        assert np.array_equal(rois[st['corr'].numpy()], rois[g['corr']]) and (st['corr'].numpy() != g['corr']).any()
+    else:
+        np.testing.assert_array_equal(st['corr'].numpy(), g['corr'])                # bit-exact int64
     np.testing.assert_array_equal(st['corr_mask'].numpy(), g['corr_mask'])          # bit-exact bool
     close(st['reg'].numpy().reshape(g['reg'].shape), g['reg'], 1e-4)
     np.testing.assert_array_equal(st['labels'].numpy(), g['labels'])
