@@ -21,10 +21,14 @@
 // CU overlap the gathers of the others.  Rows of very different length (the T path: 1 .. 400 keys) would wait for the longest of the 8 at
 // the barrier between B and C: the engine keeps the three kernels there.
 #include "common.h"
+#include <stdlib.h>
+#ifndef MV2D_XF_QB_DEFAULT
+#define MV2D_XF_QB_DEFAULT 8
+#endif
 
 namespace {
 
-constexpr int C = 256, HEADS = 8, QB = 8;                    // queries per block = waves per block
+constexpr int C = 256, HEADS = 8;                            // (QB = queries per block = waves per block: a template parameter, 8 or 4)
 constexpr float LOG2E = 1.4426950408889634f;
 
 typedef q16x8_t xf_q16x8;
@@ -59,15 +63,17 @@ __device__ __forceinline__ float xf_row16_max(float v) {
 }
 
 constexpr int WAVE_LDS = 16384;                              // per wave: key tile hi (8 KB) | key tile lo (8 KB); phase A / C: Qt / z of query `wave` in the first 8 KB
-constexpr int SMEM = QB * WAVE_LDS + QB * 512 + QB * HEADS * 4 + QB * 4;
 
-template <bool XLO>
+// QB = 8: one block per CU (132 KB of LDS); QB = 4 (round 6): 66 KB, two blocks per CU -- the map phases of one block (packed weights from L2, the
+// gather idle) run under the tile loop of the other; a wave then maps two heads in phases A and C
+template <bool XLO, int QB>
 __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __restrict__ q, const uint4* __restrict__ WA_hi, const uint4* __restrict__ WA_lo,
                                                                 const uint4* __restrict__ WB_hi, const uint4* __restrict__ WB_lo, const float* __restrict__ bv,
                                                                 const unsigned short* __restrict__ Xk, const unsigned short* __restrict__ Xv,
                                                                 const unsigned short* __restrict__ Xk_lo, const unsigned short* __restrict__ Xv_lo,
                                                                 const int* __restrict__ row_ptr, const int* __restrict__ col_idx, float* __restrict__ ctx,
                                                                 int R, int empty_nan, const int* __restrict__ order, int nblk) {
+    constexpr int SMEM = QB * WAVE_LDS + QB * 512 + QB * HEADS * 4 + QB * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
     float* lsum = reinterpret_cast<float*>(smem + QB * WAVE_LDS + QB * 512);         // [query][head] softmax denominators
@@ -86,14 +92,14 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
     }
     __syncthreads();
     // ---------------------------------------------------------------- phase A: query maps, wave = head
-    {
-        const int h = wave, r = rq[n & 7];
+    for (int h = wave; h < HEADS; h += QB) {
+        const int r = rq[n & (QB - 1)];
         const float* qp = q + (long long)r * C + 32 * h + 8 * g;
         XfFrag bh, bl;
         xf_split8(*reinterpret_cast<const float4*>(qp), *reinterpret_cast<const float4*>(qp + 4), bh, bl);
         const uint4* wh = WA_hi + (long long)h * 16 * 64 + lane;
         const uint4* wl = WA_lo + (long long)h * 16 * 64 + lane;
-        uint4* qt = reinterpret_cast<uint4*>(smem + (n & 7) * WAVE_LDS) + h * 64;      // this lane's query, this head: 64 chunks of 16 B
+        uint4* qt = reinterpret_cast<uint4*>(smem + (n & (QB - 1)) * WAVE_LDS) + h * 64;      // this lane's query, this head: 64 chunks of 16 B
         // ALL 32 weight fragments of the head are requested before the first MFMA (128 registers, free in this phase): the first build left the
         // loads next to their MFMAs and the ISA showed 24 serialised L2 round trips per block and phase (tools/isa_waits.sh)
         xf_u32x4 wa_h[16], wa_l[16];
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
             }
             XfFrag hi, lo;
             xf_split8_k16(make_float4(a[0][0], a[0][1], a[0][2], a[0][3]), make_float4(a[1][0], a[1][1], a[1][2], a[1][3]), hi, lo);
-            if (n < 8) {
+            if (n < QB) {
                 qt[u * 8 + g * 2] = hi.u;
                 qt[u * 8 + g * 2 + 1] = lo.u;
             }
@@ -299,8 +305,8 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
     }
     __syncthreads();
     // ---------------------------------------------------------------- phase C: context maps, wave = head
-    {
-        const int h = wave, j = n & 7;
+    for (int h = wave; h < HEADS; h += QB) {
+        const int j = n & (QB - 1);
         const float* zp = reinterpret_cast<const float*>(smem + j * WAVE_LDS) + h * C + 8 * g;
         // (xattn_tile_kernel normalises when it merges its waves: num * rcp(den), the factor of the single wave being exp2(0) = 1)
         const float rl = __builtin_amdgcn_rcpf(lsum[j * HEADS + h]);
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
         int rr_[4], rp0_[4], rp1_[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            rr_[i] = rq[(4 * g + i) & 7];
+            rr_[i] = rq[(4 * g + i) & (QB - 1)];
             rp0_[i] = row_ptr[rr_[i]];
             rp1_[i] = row_ptr[rr_[i] + 1];
         }
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
                 acc[nt] = mfma_q16_16x16x32(ah.v, wb_h[s * 2 + nt], acc[nt]);
             }
         }
-        if (g < 2) {
+        if (4 * g < QB) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int js = 4 * g + i;
@@ -375,10 +381,14 @@ extern "C" int mv2d_xattn_fused_fwd(const float* q, const void* WA_hi, const voi
         int dev = 0;
         n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
+    // queries per block: 8 (one block per CU) or 4 (two per CU: the map phases of one block under the tile loop of the other).  MV2D_XF_QB=4 / 8 forces it.
+    static const int qb_env = [] { const char* e = getenv("MV2D_XF_QB"); return e ? atoi(e) : 0; }();
+    const int QB = qb_env == 4 || qb_env == 8 ? qb_env : MV2D_XF_QB_DEFAULT;
+    const int slots = n_cu * (QB == 4 ? 2 : 1);               // blocks of a round
     int nblk = (R + QB - 1) / QB;
-    if (nblk > n_cu) {                                        // whole rounds of one block per CU, as long as a block keeps >= 4 queries
-        const int up = (nblk + n_cu - 1) / n_cu * n_cu;
-        if ((long long)up * 4 <= R) nblk = up;
+    if (nblk > slots) {                                       // whole rounds, as long as a block keeps >= QB / 2 queries
+        const int up = (nblk + slots - 1) / slots * slots;
+        if ((long long)up * (QB / 2) <= R) nblk = up;
     } else {
         // a small launch (one sample: 300 queries = 38 blocks of 8 on a 256-CU chip): spread it, down to two queries per block -- the blocks stream
         // the map weights from L2 either way, and the launch is bound by the longest block (26.5 -> ~14 us per layer at R = 300)
@@ -386,14 +396,12 @@ extern "C" int mv2d_xattn_fused_fwd(const float* q, const void* WA_hi, const voi
         if (spread > nblk) nblk = spread;
     }
     const dim3 grid(nblk), block(64 * QB);
-    if (Xk_lo)
-        hipLaunchKernelGGL((xattn_fused_kernel<true>), grid, block, 0, (hipStream_t)stream, q, (const uint4*)WA_hi, (const uint4*)WA_lo, (const uint4*)WB_hi,
-                           (const uint4*)WB_lo, bv, (const unsigned short*)Xk, (const unsigned short*)Xv, (const unsigned short*)Xk_lo,
-                           (const unsigned short*)Xv_lo, row_ptr, col_idx, ctx, R, empty_nan, order, nblk);
-    else
-        hipLaunchKernelGGL((xattn_fused_kernel<false>), grid, block, 0, (hipStream_t)stream, q, (const uint4*)WA_hi, (const uint4*)WA_lo, (const uint4*)WB_hi,
-                           (const uint4*)WB_lo, bv, (const unsigned short*)Xk, (const unsigned short*)Xv, (const unsigned short*)Xk_lo,
-                           (const unsigned short*)Xv_lo, row_ptr, col_idx, ctx, R, empty_nan, order, nblk);
+#define MV2D_XF(XLO_, QB_) hipLaunchKernelGGL((xattn_fused_kernel<XLO_, QB_>), grid, block, 0, (hipStream_t)stream, q, (const uint4*)WA_hi, (const uint4*)WA_lo, \
+                                              (const uint4*)WB_hi, (const uint4*)WB_lo, bv, (const unsigned short*)Xk, (const unsigned short*)Xv,                     \
+                                              (const unsigned short*)Xk_lo, (const unsigned short*)Xv_lo, row_ptr, col_idx, ctx, R, empty_nan, order, nblk)
+    if (Xk_lo) { if (QB == 4) MV2D_XF(true, 4); else MV2D_XF(true, 8); }
+    else { if (QB == 4) MV2D_XF(false, 4); else MV2D_XF(false, 8); }
+#undef MV2D_XF
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
