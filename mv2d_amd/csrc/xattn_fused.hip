@@ -26,6 +26,13 @@
 #define MV2D_XF_QB_DEFAULT 8
 #endif
 
+#ifdef MV2D_XF_TRACE
+__device__ long long g_xf_trace[32];
+#define XF_STAMP(i) do { if (blockIdx.x == MV2D_XF_TRACE && threadIdx.x == 0) g_xf_trace[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define XF_STAMP(i) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int C = 256, HEADS = 8;                            // (QB = queries per block = waves per block: a template parameter, 8 or 4)
@@ -73,11 +80,13 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
                                                                 const unsigned short* __restrict__ Xk_lo, const unsigned short* __restrict__ Xv_lo,
                                                                 const int* __restrict__ row_ptr, const int* __restrict__ col_idx, float* __restrict__ ctx,
                                                                 int R, int empty_nan, const int* __restrict__ order, int nblk) {
-    constexpr int SMEM = QB * WAVE_LDS + QB * 512 + QB * HEADS * 4 + QB * 4;
+    constexpr int SMEM = QB * WAVE_LDS + QB * 512 + QB * HEADS * 4 + 3 * QB * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
     float* lsum = reinterpret_cast<float*>(smem + QB * WAVE_LDS + QB * 512);         // [query][head] softmax denominators
-    int* rq = reinterpret_cast<int*>(smem + QB * WAVE_LDS + QB * 512 + QB * HEADS * 4);       // [query slot] -> query row
+    int* rq = reinterpret_cast<int*>(smem + QB * WAVE_LDS + QB * 512 + QB * HEADS * 4);       // [query slot] -> query row, then the ends of its CSR row
+    int* rbeg = rq + QB;
+    int* rend = rq + 2 * QB;
     // XCD-chunked block order (block b runs on XCD b % 8): every XCD works through one contiguous range of query slots; optional launch order
     // of the queries (the S path ranks them by the smallest RoI they list, so that matched RoIs share an L2).  Speed only.
     // The R query slots are dealt EVENLY to nblk >= ceil(R / 8) blocks (the host rounds nblk up to a multiple of the CU count when that leaves >= 4
@@ -86,11 +95,31 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
     const int blk = xcd_chunked(blockIdx.x, nblk);
     const int slot0 = (int)((long long)blk * R / nblk), nq = (int)((long long)(blk + 1) * R / nblk) - slot0;
     if (nq <= 0) return;
+    XF_STAMP(0);
     if (tid < QB) {
         const int s = slot0 + min(tid, nq - 1);
-        rq[tid] = order ? order[s] : s;
+        const int r_ = order ? order[s] : s;
+        rq[tid] = r_;
+        rbeg[tid] = row_ptr[r_];
+        rend[tid] = row_ptr[r_ + 1];
     }
     __syncthreads();
+    XF_STAMP(1);
+    // Round 6 (per-phase stamps, tools/xf_trace.py: 43 % of a block's time was the wait for a tile's key rows, the first tile's behind three dependent round
+    // trips -- row ends, key indices, rows -- that only started after phase A): the wave's CSR row ends come with the slot table, the indices of its first
+    // tile are requested in front of phase A and the hi + lo key rows of that tile in the middle of it, so that they travel under the query maps.
+    const int r = rq[wave];
+    const int beg = rbeg[wave], end = rend[wave];
+    const int ntile = wave < nq ? (end - beg + 15) >> 4 : 0;          // (waves beyond the block's queries: no tiles; their z / l are never read)
+    int idx_next = ntile > 0 ? col_idx[min(beg + n, end - 1)] : 0;
+    xf_u32x4 kreg0[8], klo0[8];
+    auto load_k0 = [&](const unsigned short* K_, int myidx, xf_u32x4 (&dst)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned int ridx = (unsigned int)__shfl(myidx, 2 * i + (lane >> 5), 64);
+            dst[i] = *reinterpret_cast<const xf_u32x4*>(reinterpret_cast<const char*>(K_) + ((ridx << 9) + (unsigned)(lane & 31) * 16u));
+        }
+    };
     // ---------------------------------------------------------------- phase A: query maps, wave = head
     for (int h = wave; h < HEADS; h += QB) {
         const int r = rq[n & (QB - 1)];
@@ -126,13 +155,18 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
                 qt[u * 8 + g * 2] = hi.u;
                 qt[u * 8 + g * 2 + 1] = lo.u;
             }
+            if (u == (XLO ? 5 : 3) && h == wave && ntile > 0) {   // (all weight fragments of the head have been requested: the rows queue behind them; late enough for their 64 registers)
+                load_k0(Xk, idx_next, kreg0);
+                if (XLO) load_k0(Xk_lo, idx_next, klo0);
+            }
         }
     }
-    __syncthreads();
+    // (LDS only: __syncthreads() would also wait for the key rows that are still in flight -- vmcnt(0) -- and put their latency back in front of phase B)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    XF_STAMP(2);
     // ---------------------------------------------------------------- phase B: tile attention, wave = query
-    const int r = rq[wave];
-    const int beg = row_ptr[r], end = row_ptr[r + 1];
-    const int ntile = wave < nq ? (end - beg + 15) >> 4 : 0;          // (waves beyond the block's queries: no tiles; their z / l are never read)
+    (void)r;
     XfFrag qa[8];
     {
         const uint4* qp = reinterpret_cast<const uint4*>(smem + wave * WAVE_LDS) + (n & 7) * 64 + g * 2 + (n >> 3);
@@ -249,25 +283,39 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
             }
             __builtin_amdgcn_wave_barrier();
         };
-        int idx_next = ntile > 0 ? col_idx[min(beg + n, end - 1)] : 0;
+        // the first tile's key rows were requested during phase A: into LDS right away (the wave's Qt operand sits in qa by now)
+        if (ntile > 0) {
+            store_k(kt, kreg0);
+            if constexpr (XLO) store_k(kt2, klo0);
+        }
         for (int tt = 0; tt < ntile; ++tt) {
             const int myidx = idx_next;
             if (tt + 1 < ntile) idx_next = col_idx[min(beg + 16 * (tt + 1) + n, end - 1)];
             if constexpr (XLO) {
-                xf_u32x4 kreg[8], klo[8], vreg[4][2], vlo[4][2];
-                load_k(Xk, myidx, kreg);
-                load_k(Xk_lo, myidx, klo);
-                store_k(kt, kreg);
-                store_k(kt2, klo);
+                xf_u32x4 vreg[4][2], vlo[4][2];
+                if (tt > 0) {
+                    xf_u32x4 kreg[8], klo[8];
+                    load_k(Xk, myidx, kreg);
+                    load_k(Xk_lo, myidx, klo);
+                    store_k(kt, kreg);
+                    store_k(kt2, klo);
+                }
                 load_v(Xv, myidx, vreg);
                 load_v(Xv_lo, myidx, vlo);
                 __builtin_amdgcn_wave_barrier();
+                XF_STAMP(3 + 2 * min(tt, 5));
                 compute(tt, vreg, vlo);
+                XF_STAMP(4 + 2 * min(tt, 5));
             } else {
-                xf_u32x4 kreg[8], vreg[4][2];
-                load_k(Xk, myidx, kreg);
-                load_v(Xv, myidx, vreg);
-                store_k(kt, kreg);
+                xf_u32x4 vreg[4][2];
+                if (tt > 0) {
+                    xf_u32x4 kreg[8];
+                    load_k(Xk, myidx, kreg);
+                    load_v(Xv, myidx, vreg);
+                    store_k(kt, kreg);
+                } else {
+                    load_v(Xv, myidx, vreg);
+                }
                 __builtin_amdgcn_wave_barrier();
                 compute(tt, vreg, vreg);
             }
@@ -303,7 +351,9 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
                 *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             }
     }
+    XF_STAMP(15);
     __syncthreads();
+    XF_STAMP(16);
     // ---------------------------------------------------------------- phase C: context maps, wave = head
     for (int h = wave; h < HEADS; h += QB) {
         const int j = n & (QB - 1);
@@ -323,8 +373,8 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             rr_[i] = rq[(4 * g + i) & (QB - 1)];
-            rp0_[i] = row_ptr[rr_[i]];
-            rp1_[i] = row_ptr[rr_[i] + 1];
+            rp0_[i] = rbeg[(4 * g + i) & (QB - 1)];
+            rp1_[i] = rend[(4 * g + i) & (QB - 1)];
         }
         const float bv0 = bv[32 * h + n], bv1 = bv[32 * h + 16 + n];
         __builtin_amdgcn_sched_barrier(0);
@@ -361,9 +411,14 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
             }
         }
     }
+    XF_STAMP(17);
 }
 
 }  // namespace
+
+#ifdef MV2D_XF_TRACE
+extern "C" int mv2d_xf_trace_read(long long* host, int n) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_xf_trace), n * sizeof(long long)) == hipSuccess ? 0 : -2; }
+#endif
 
 // C-ABI: include/mv2d_hip.h
 extern "C" int mv2d_xattn_fused_fwd(const float* q, const void* WA_hi, const void* WA_lo, const void* WB_hi, const void* WB_lo, const float* bv,
