@@ -755,3 +755,30 @@ def test_query_order_of_the_attention_blocks(name, n):
     eng2.q_order = False
     out2 = eng2.run_batch(feats, props, metas) if n > 1 else eng2.run(feats[0], props[0], metas[0])
     assert torch.equal(out2['cls'], out['cls']) and torch.equal(out2['boxes'], out['boxes'])
+
+
+def test_t_head_with_expand_stride_0_reads_transposed_rows():
+    """BoxCorrelation's default expand_stride = 0 (the shipped T configs use 2): a bilinear RoIAlign tap may then lie one cell OUTSIDE its RoI's rectangle, i.e.
+    outside roi_mask, so the masked transposition of the feature map (round 5) must stay off on the T path (round-6 fix of an advisor finding: it read rows that
+    this frame never wrote).  The engine first runs another frame on the same workspace (stale rows everywhere), then the frame under test; its integer outputs
+    and class logits must be those of the oracle with the same expand_stride."""
+    from mv2d_amd.engine import HeadEngine
+    from oracle import mv2d_oracle as O
+    dev = torch.device('cuda:0')
+    prob = synthetic.make_problem('cfg1_t', seed=0)
+    other = synthetic.make_problem('cfg1_t', seed=7)
+    sd = synthetic.make_head_state(seed=0)
+    eng = HeadEngine(sd, 'T', dev, num_views=prob['views_per_frame'], expand_stride=0)
+    tp = lambda pr: [torch.from_numpy(np.asarray(p)) for p in pr['proposals']]      # noqa: E731
+    eng.run(torch.from_numpy(other['feat'] * 50.0).to(dev), tp(other), other['img_metas'])
+    out = eng.run(torch.from_numpy(prob['feat']).to(dev), tp(prob), prob['img_metas'])
+    torch.cuda.synchronize()
+    st = {}
+    O.forward_t(sd, torch.from_numpy(prob['feat']), tp(prob), prob['img_metas'], num_views=prob['views_per_frame'], expand_stride=0, stages=st)
+    R = out['R']
+    ref_cls = st['cls'].reshape(out['cls'][:, :R].shape)
+    err = float((out['cls'][:, :R].cpu() - ref_cls).abs().max() / ref_cls.abs().max())
+    assert err < 1e-5, err
+    n = int(out['count'].item())
+    assert n == st['labels'].numel()
+    assert torch.equal(out['labels'][:n].cpu(), st['labels']) and torch.equal(out['bbox_index'][:n].cpu(), st['bbox_index'])

@@ -474,6 +474,31 @@ def test_fallback_key_for_a_roi_without_visible_keys():
     assert gr and all(bool(torch.isfinite(x).all()) for x in gr)
 
 
+def test_fallback_key_row_comes_from_the_input_map():
+    """The fallback key of a RoI without visible keys is map position (view 0, 0, 0) (RH/mv2d_t_head.py:80-82).  With the masked transposition that row of the
+    engine's position-major copy is only written when some RoI rectangle covers it: here a first frame (other boxes, a map of 1000s) does cover it, the frame
+    under test does not -- the row must still be taken from THIS frame's input map (round-6 fix of an advisor finding), i.e. the losses equal those of a fresh head."""
+    g = load_golden('nanrow_t')
+    prob = dict(kind='T', views_per_frame=2, img_metas=synthetic.make_img_metas(2, 128, 96, frames=1, pad_w=192, yaw_step_deg=40.0),
+                proposals=[g['proposals_v0'], g['proposals_v1']], feat=synthetic.make_feat(2, 8, 12, seed=22))
+    gtc = synthetic.make_train_gt(5, 3)
+    feat = torch.from_numpy(prob['feat']).to(DEV)
+    props = [torch.from_numpy(np.asarray(p)) for p in prob['proposals']]
+    metas = [dict(m, box_type_3d=None) for m in prob['img_metas']]
+    rnd = torch.from_numpy(synthetic.make_dn_noise(5 * 10, 3)).to(DEV)
+    mk = lambda f, pr: ([f], metas, pr, None, None, None, None, [torch.from_numpy(gtc['gt'])], [torch.from_numpy(gtc['gt_labels'])], None)      # noqa: E731
+    fresh = _dropout_off(_t_head(prob)).forward_train(*mk(feat, props), dn_noise=rnd, autograd=False)
+    head = _dropout_off(_t_head(prob))
+    cover = [torch.tensor([[0., 0., 40., 40., 0.9, 1.], [20., 30., 70., 90., 0.8, 2.]]), torch.tensor([[10., 20., 60., 80., 0.7, 3.]])]
+    eng = head.engine(feat.device, metas)
+    eng.run(torch.full_like(feat, 1000.0), cover, prob['img_metas'])              # leaves 1000s in the workspace's position-major row 0
+    torch.cuda.synchronize()
+    again = head.forward_train(*mk(feat, props), dn_noise=rnd, autograd=False)
+    assert all(bool(torch.isfinite(v).all()) for v in again.values())
+    for k in fresh:
+        assert float(fresh[k]) == float(again[k]), (k, float(fresh[k]), float(again[k]))
+
+
 def test_training_route_applies_the_configured_dropout():
     """The shipped configs put dropout 0.1 on both attentions' output paths and in the FFN: in training mode the autograd route applies it
     (two draws differ, and differ from the dropout-free losses); in eval mode nothing is dropped."""
