@@ -93,7 +93,17 @@ def timed(fn):
 
 kw = dict(Xk_lo=ws['xk_lo'], Xv_lo=ws['xv_lo'])
 W_ = eng.w
-for label, o in (('natural', None), ('smallest key (engine)', base), ('cluster order', clu)):
+# launch orders that put rows of similar LENGTH side by side (the one-launch kernel waits for the longest of a block's 8 rows): by length inside every
+# sample, and by length inside windows of 64 / 256 slots of the smallest-key order
+bylen, win64, win256 = base.copy(), base.copy(), base.copy()
+for b in range(len(grp) - 1):
+    seg = base[grp[b]:grp[b + 1]]
+    bylen[grp[b]:grp[b + 1]] = seg[np.argsort(-ln[seg], kind='stable')]
+    for o_, w_ in ((win64, 64), (win256, 256)):
+        for s0 in range(grp[b], grp[b + 1], w_):
+            sg = o_[s0:min(s0 + w_, grp[b + 1])]
+            o_[s0:s0 + len(sg)] = sg[np.argsort(-ln[sg], kind='stable')]
+for label, o in (('natural', None), ('smallest key (engine)', base), ('cluster order', clu), ('by row length', bylen), ('smallest key, length in 64s', win64), ('smallest key, length in 256s', win256)):
     od = None if o is None else torch.from_numpy(o.astype(np.int32)).to(dev)
     t_tile = timed(lambda: ops.xattn_tile(ws['Qt'], ws['xk_rows'], ws['xv_rows'], ws['row_ptr'], ws['col_idx'], ws['zh'], R, waves=eng.xattn_waves, order=od, **kw))
     t_fused = timed(lambda: ops.xattn_fused(ws['q'], W_['ca_mapA0'], W_['ca_mapB0'], W_['ca_v_b0'], ws['xk_rows'], ws['xv_rows'], ws['row_ptr'], ws['col_idx'],
