@@ -767,7 +767,7 @@ def main():
         else:
             for th in (8, 16, 32, 64):
                 if th <= nc_:
-                    r_ = cpu_leg(th, 6, 75, ('--warmups', '3', '--budget-s', '30', '--no-decoder'))
+                    r_ = cpu_leg(th, 6, 60, ('--warmups', '3', '--budget-s', '20', '--no-decoder'))
                     sweep[th] = r_.get('value')
         best = max(sweep, key=lambda k: sweep[k] or 0.0) if sweep else min(nc_, 16)
         cpu = cpu_leg(best, args.cpu_iters, args.cpu_timeout, ('--warmups', '3'))
