@@ -134,6 +134,9 @@ class HeadEngine:
         # 5.1e-6 -> 4.9e-6 / 5.8e-6 -> 5.7e-6): its 2304-term dot products average the 2^-12 roundings down, and the 3 x MFMA-bound split-
         # precision kernel (362 vs 123 us per 2400 RoIs) leaves the route.  Attention rows and PE stay hi + lo: dropping either costs ranks.
         self.exact_skip = frozenset({'conv'})
+        # experiments only (tools/ablate_exact.py): zero the lo halves of the value / key rows after they were written -- what a route with hi-only value
+        # (or key) rows would compute, at the full route's cost
+        self.ablate_zero_lo = frozenset()
         # Round 6, OPT-IN: the split-precision PE block on the second shape of its kernel (csrc/pe_x3b.hip: a wave owns 32 rows through both layers of
         # each MLP, the hidden layer stays in registers, the weights go through an LDS-DMA ring shared by the block's 4 waves; BITWISE the outputs of
         # csrc/pe_x3.hip).  Measured no faster (1213 vs 1165-1244 us per 250 k rows; 8 waves x 16 rows: 1056 us, bound by 8 x 32 KB of LDS reads per
@@ -625,6 +628,11 @@ class HeadEngine:
             # key rows = RoIAlign(feat) + RoIAlign(pe), value rows = RoIAlign(feat) (index-exact route: both as key16 hi + lo pairs)
             o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=ws['pos2s'], out1_is_sum=True,
                         out0_lo=ws['xv_lo'] if self.exact else None, out1_lo=ws['xk_lo'] if self.exact else None, R=R)
+        if self.ablate_zero_lo and self.exact:
+            if 'v' in self.ablate_zero_lo and ws.get('xv_lo') is not None:
+                ws['xv_lo'].zero_()
+            if 'k' in self.ablate_zero_lo and ws.get('xk_lo') is not None:
+                ws['xk_lo'].zero_()
         if not forked:
             self._enqueue_qg(ws, R)
         if forked:
@@ -874,7 +882,7 @@ class HeadEngine:
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
         gkey = (ptrs, 0 if payload is None else payload.data_ptr(), sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs, self.last_stage_heads,
                 self.xattn_waves, self.fuse_maps, self.fuse_xattn, self.group_xattn, self.pe_rows_in_waves, self.fold_sa0, self.masked_transpose, self.keep_sine_rows, self.force_nc, self.q_order,
-                self.fork_qg, self.exact_skip, self.stop_before_decoder)   # load_state() re-allocates the weights; every route option of __init__ is in the key
+                self.fork_qg, self.exact_skip, self.ablate_zero_lo, self.stop_before_decoder)   # load_state() re-allocates the weights; every route option of __init__ is in the key
         graphs = ws.setdefault('graphs', {})             # one graph per (input buffers, frame scalars): a producer that alternates between
         g = graphs.get(gkey)                             # a few static output buffers replays a few graphs, it does not re-capture
         if ws.pop('graph_stale', False):
