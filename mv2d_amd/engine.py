@@ -633,6 +633,17 @@ class HeadEngine:
                 ws['xv_lo'].zero_()
             if 'k' in self.ablate_zero_lo and ws.get('xk_lo') is not None:
                 ws['xk_lo'].zero_()
+            if '8' in self.ablate_zero_lo:                   # the lo halves rounded to 8-bit floats: what 256-byte lo rows would carry.  '8f': OCP e4m3 under the
+                for nm in ('xk_lo', 'xv_lo'):                # FIXED scale 2^12 (|lo| <= 2^-12 |x|: the format a kernel can write without a reduction); '8z': e4m3fnuz, '8': e5m2fnuz, per-tensor scale
+                    t = ws.get(nm)
+                    if t is not None:
+                        if '8f' in self.ablate_zero_lo:
+                            t.copy_(((t.float() * 4096.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() / 4096.0).to(t.dtype))
+                            continue
+                        f8 = torch.float8_e4m3fnuz if '8z' in self.ablate_zero_lo else torch.float8_e5m2fnuz
+                        m = t.float().abs().max().clamp_min(1e-30)
+                        q8 = torch.exp2(torch.floor(torch.log2((100.0 if f8 == torch.float8_e4m3fnuz else 16000.0) / m)))
+                        t.copy_(((t.float() * q8).to(f8).float() / q8).to(t.dtype))
         if not forked:
             self._enqueue_qg(ws, R)
         if forked:

@@ -22,11 +22,11 @@ for name in (sys.argv[1:] or ['cfg2_s', 'cfg3_t', 'cfg5_t', 'cfg2_s_nc6']):
     props = [torch.from_numpy(p) for p in prob['proposals']]
     variants = [('default route', None), ('exact, all stages', frozenset()), ('exact minus attn', frozenset({'attn'})), ('exact minus pe', frozenset({'pe'})),
                 ('exact minus conv', frozenset({'conv'})), ('exact: attn only', frozenset({'pe', 'conv'})), ('exact: pe only', frozenset({'attn', 'conv'})),
-                ('exact: conv only', frozenset({'attn', 'pe'})), ('exact, value rows hi only', 'zero_v'), ('exact, key rows hi only', 'zero_k')]
+                ('exact: conv only', frozenset({'attn', 'pe'})), ('exact, value rows hi only', 'zero_v'), ('exact, key rows hi only', 'zero_k'), ('exact, lo rows as e4m3', 'f8z'), ('exact, lo rows as e5m2', 'f8')]
     for label, skip in variants:
         eng = HeadEngine(sd, prob['kind'], dev, num_views=prob['views_per_frame'], exact=skip is not None)
         if isinstance(skip, str):
-            eng.ablate_zero_lo = frozenset({skip[-1]})
+            eng.ablate_zero_lo = frozenset({'8', '8z'}) if skip == 'f8z' else frozenset({'8'}) if skip == 'f8' else frozenset({skip[-1]})
         elif skip is not None:
             eng.exact_skip = skip
         out = eng.run(feat, props, prob['img_metas'])

@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""Would 256-byte lo rows (8-bit floats) keep the index-exact route index-exact?  Runs tests/test_gpu_golden.py's exact-mode parity test on all of its
+(workload, seed) cases with the lo halves of the key / value rows rounded to OCP e4m3 under the fixed scale 2^12 after they were written
+(HeadEngine.ablate_zero_lo = {'8', '8f'}: an emulation of the storage format, the kernels unchanged).
+    python tools/ablate_lo8_cases.py [8f|8z|8]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import test_gpu_golden as T  # noqa: E402
+
+from mv2d_amd.engine import HeadEngine  # noqa: E402
+
+mode = sys.argv[1] if len(sys.argv) > 1 else '8f'
+init = HeadEngine.__init__
+
+
+def patched(self, *a, **k):
+    init(self, *a, **k)
+    if self.exact:
+        self.ablate_zero_lo = frozenset({'8', mode})
+
+
+HeadEngine.__init__ = patched
+cases = [m.args for m in T.test_exact_mode_integer_outputs_equal_the_reference.pytestmark if m.name == 'parametrize'][0][1]
+bad = 0
+for name, seed in cases:
+    try:
+        T.test_exact_mode_integer_outputs_equal_the_reference(name, seed)
+        print(f'    -> {name} seed {seed}: within the test bounds')
+    except AssertionError as e:
+        bad += 1
+        print(f'    -> {name} seed {seed}: FAILS the test bounds: {e}')
+print(f'{len(cases) - bad} of {len(cases)} cases pass with lo rows as 8-bit floats ({mode})')
