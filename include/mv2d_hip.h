@@ -110,11 +110,13 @@ int mv2d_pe_fused_tab2(const void* A1, const void* Xfb, const float* Xf32, const
  * bf16 MFMAs (2^-17 per operand), hidden layer split hi / lo in LDS.  A1 [M,192] fp32 (mv2d_pe_inputs' A_frustum_f32), Xmap = fp32 feature rows
  * [.,256] indexed by row_index[m] (or m when NULL); weights as bf16 hi / lo pairs (mv2d_split_bf16x2), each in the fragment-major order of
  * mv2d_pack_wfrag_bf16; pe [M,256] fp32 (optional) = sine_tab[position] + position_encoder(A1) * gate; Xk_hi / Xk_lo / Xv_hi / Xv_lo [M,256] key16
- * (all four or none): key rows pe + feat and value rows feat as hi + lo pairs (what mv2d_xattn_tile_fwd gathers on that route). */
+ * (all four or none): key rows pe + feat and value rows feat as hi + lo pairs (what mv2d_xattn_tile_fwd gathers on that route).
+ * lo_fmt (round 6, ABI 6): 0 = the lo outputs are key16 rows [M,256] (512 B); 1 = "lo8" rows [M,256] of BYTES: OCP e4m3 (bias 7, max 448) of
+ * key16_lo * 2^12, round-to-nearest-even, saturating (csrc/common.h) -- 256 B per row, what the cross attention gathers by default. */
 int mv2d_pe_fused_x3(const float* A1, const float* Xmap, const int* row_index, const int* m_dev, int M,
                      const void* W1a_hi, const void* W1a_lo, const float* b1a, const void* W1b_hi, const void* W1b_lo, const float* b1b,
                      const void* Wr_hi, const void* Wr_lo, const float* br, const void* We_hi, const void* We_lo, const float* be,
-                     const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, void* stream);
+                     const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, int lo_fmt, void* stream);
 /* The same block on the second shape of the kernel (round 6, csrc/pe_x3b.hip): a wave owns 16 rows through both layers of each MLP, the hidden layer
  * stays in registers (no LDS image, no barrier between the layers), the weights go through a 4-deep LDS ring (LDS-DMA) shared by the 8 waves of a 128-row
  * block, two waves per SIMD.  Same operands EXCEPT that W1a and Wr (the first layers) are packed from the weight with its rows in the order
@@ -122,7 +124,7 @@ int mv2d_pe_fused_x3(const float* A1, const float* Xmap, const int* row_index, c
 int mv2d_pe_fused_x3b(const float* A1, const float* Xmap, const int* row_index, const int* m_dev, int M,
                      const void* W1a_hi, const void* W1a_lo, const float* b1a, const void* W1b_hi, const void* W1b_lo, const float* b1b,
                      const void* Wr_hi, const void* Wr_lo, const float* br, const void* We_hi, const void* We_lo, const float* be,
-                     const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, void* stream);
+                     const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, int lo_fmt, void* stream);
 
 /* QueryGenerator shared conv + pooling fused, one block per RoI (RH/utils/query_generator.py:298-304,322-331,352-358):
  * out[r, n] = mean over the 49 cells of relu(conv3x3(roi_feat[r])[cell, n] + bias[n]).  roi_feat [R,49,256] key16 (cell-major),
@@ -310,7 +312,8 @@ int mv2d_sparse_xattn_fwd(const float* q, const void* K, const void* V, const in
  *   of the query map and of P: fp32-class on the query side), online softmax.  waves = 1 | 2 | 4 | 8 waves per query (0: default = 2).
  *   The row arrays are addressed with 32-bit byte offsets: fewer than 2^23 rows (4 GB) each.
  *   Xk_lo / Xv_lo (both or neither, may be NULL): key16 remainders of the rows (rows = Xk + Xk_lo): the fp32-class key side of the
- *   engine's index-exact validation mode.  Rows without an allowed key: z = NaN (empty_nan = 1) or 0.  dbg_logits (optional): head h at dbg_logits[h*dbg_stride + e],
+ *   engine's index-exact route; mv2d_xattn_tile_fwd_ordered / mv2d_xattn_fused_fwd take lo_fmt: 0 = key16 lo rows, 1 = e4m3 "lo8" rows (256 B per row,
+ *   see mv2d_pe_fused_x3; decoded to key16 in registers: results bitwise those of key16 lo rows holding the decoded values).  Rows without an allowed key: z = NaN (empty_nan = 1) or 0.  dbg_logits (optional): head h at dbg_logits[h*dbg_stride + e],
  *   e in CSR order, WITHOUT the per-(query, head) constant q_h . bk_h that cancels in the softmax.
  * mv2d_xattn_ctxmap: ctx [R,256] = Wv_h z_h + bv (bf16x3; WB_hi / WB_lo = the packed value in_proj weight); rows without an
  *   allowed key (row_ptr) give NaN / 0 like nn.MultiheadAttention / the 'zero' policy of the engine. */
@@ -321,7 +324,7 @@ int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* Xv, const vo
  * sample sorted by their smallest key): neighbouring blocks then read overlapping key sets and share an L2.  Results are identical. */
 int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                 const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
-                                const int* order, void* stream);
+                                const int* order, int lo_fmt, void* stream);
 /* The three launches above as ONE (round 5, csrc/xattn_fused.hip): ctx [R,256] fp32 = xattn_ctxmap(xattn_tile(xattn_qmap(q))) for blocks of 8 queries,
  * Qt and z never leave the chip (16 KB per query and layer less HBM traffic, two launches less).  Same operands as the three calls (q = the scaled,
  * projected query rows [R,256] fp32; WA / WB = the packed map weights; Xk / Xv (+ _lo: index-exact route) the key16 row arrays; CSR; order = optional
@@ -329,7 +332,7 @@ int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const void* Xv, 
  * waits for the longest of its 8 rows. */
 int mv2d_xattn_fused_fwd(const float* q, const void* WA_hi, const void* WA_lo, const void* WB_hi, const void* WB_lo, const float* bv, const void* Xk,
                          const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr, const int* col_idx, float* ctx, int R, int empty_nan,
-                         const int* order, void* stream);
+                         const int* order, int lo_fmt, void* stream);
 /* Key tiles SHARED BETWEEN QUERIES (round 6, csrc/xattn_group.hip; the masks of RH/mv2d_t_head.py:79-109 / the duplication of
  * RH/mv2d_s_head.py:184-192 let 2.9-6.2 queries list the same key row).  mv2d_xattn_group_tables (once per frame): the queries of every sample
  * (grp_start [n_samples + 1]; rows behind grp_start[n_samples] are bucket padding and form groups of their own), taken in `order` (a permutation that
@@ -421,10 +424,11 @@ int mv2d_roi_align(const float* map0, const float* map1, const float* rois, void
                    float* out1_f32, int R, int H, int W, int channels, float spatial_scale, int sampling_ratio,
                    const int* map1_index, int out1_is_sum, void* stream);
 /* mv2d_roi_align with key16 REMAINDER outputs: out0_lo / out1_lo = key16(x - key16(x)) next to out0 / out1 (x ~ hi + lo, ~2^-22 relative):
- * the fp32-class key / value / conv-input rows of the index-exact route. */
+ * the fp32-class key / value / conv-input rows of the index-exact route.  out0_lo8 / out1_lo8 (optional, ABI 6): the same remainders as e4m3 "lo8"
+ * rows [R,49,256] bytes (see mv2d_pe_fused_x3). */
 int mv2d_roi_align_ex(const float* map0, const float* map1, const float* rois, void* out0, void* out1, float* out0_f32, float* out1_f32,
                       int R, int H, int W, int channels, float spatial_scale, int sampling_ratio, const int* map1_index, int out1_is_sum,
-                      void* out0_lo, void* out1_lo, void* stream);
+                      void* out0_lo, void* out1_lo, void* out0_lo8, void* out1_lo8, void* stream);
 
 /* BoxCorrelation.epipolar_in_box, 'topk_matched:k:thr:ratio' (RH/utils/box_correlation.py:196-398).
  * V = views per sample; view_start[n_views+1]: first RoI of each view; trans [n_views,V,16] fp64 = lidar2img[b] @ inv(lidar2img[a])

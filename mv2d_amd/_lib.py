@@ -15,7 +15,7 @@ class Mv2dHipError(RuntimeError):
 
 
 P, I, LL, F, D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
-ABI_VERSION = 5                  # include/mv2d_hip.h: mv2d_abi_version()
+ABI_VERSION = 6                  # include/mv2d_hip.h: mv2d_abi_version()
 
 class TdDims(C.Structure):
     """struct mv2d_td_dims (include/mv2d_hip.h): the scalar arguments of mv2d_train_decoder_fwd / _bwd"""
@@ -39,8 +39,8 @@ SIGNATURES = {
     'mv2d_split3_rows': (I, [P, P, P, I, I, P, P]),
     'mv2d_pe_fused_tab': (I, [P, P, P, P, P, I] + [P] * 9 + [I, P, P, P]),
     'mv2d_pe_fused_tab2': (I, [P, P, P, P, P, I] + [P] * 9 + [I, P, P, I, P]),
-    'mv2d_pe_fused_x3': (I, [P, P, P, P, I] + [P] * 13 + [I] + [P] * 6),
-    'mv2d_pe_fused_x3b': (I, [P, P, P, P, I] + [P] * 13 + [I] + [P] * 6),
+    'mv2d_pe_fused_x3': (I, [P, P, P, P, I] + [P] * 13 + [I] + [P] * 5 + [I, P]),
+    'mv2d_pe_fused_x3b': (I, [P, P, P, P, I] + [P] * 13 + [I] + [P] * 5 + [I, P]),
     'mv2d_key16_format': (I, []),
     'mv2d_f32_to_key16': (I, [P, P, P, LL, P]),
     'mv2d_split_rows_key16': (I, [P, P, P, P, I, I, P, P]),
@@ -86,8 +86,8 @@ SIGNATURES = {
     'mv2d_attn_out_qmap_x3': (I, [P] * 12 + [F, P, P, P, I, F, P]),
     'mv2d_attn_out_zmap_x3': (I, [P, P, P, P, P, I, P, P, P, P, P, P, P, I, F, P]),
     'mv2d_xattn_tile_fwd': (I, [P, P, P, P, P, P, P, P, P, LL, I, I, I, P]),
-    'mv2d_xattn_tile_fwd_ordered': (I, [P, P, P, P, P, P, P, P, P, LL, I, I, I, P, P]),
-    'mv2d_xattn_fused_fwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P, P]),
+    'mv2d_xattn_tile_fwd_ordered': (I, [P, P, P, P, P, P, P, P, P, LL, I, I, I, P, I, P]),
+    'mv2d_xattn_fused_fwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P, I, P]),
     'mv2d_xattn_group_max': (I, [I, I]),
     'mv2d_xattn_group_tables': (I, [P, P, P, P, I, I, I, P, P, P, P, P, P, I, P, P, P]),
     'mv2d_xattn_group_fwd': (I, [P] * 19 + [I, I, P]),
@@ -98,7 +98,7 @@ SIGNATURES = {
     'mv2d_lidar2img_inverse': (I, [P, P, P, I, P]),
     'mv2d_posemb3d': (I, [P, P, P, I, P]),
     'mv2d_roi_align': (I, [P, P, P, P, P, P, P, I, I, I, I, F, I, P, I, P]),
-    'mv2d_roi_align_ex': (I, [P, P, P, P, P, P, P, I, I, I, I, F, I, P, I, P, P, P]),
+    'mv2d_roi_align_ex': (I, [P, P, P, P, P, P, P, I, I, I, I, F, I, P, I, P, P, P, P, P]),
     'mv2d_box_correlation': (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, F, F, F, I, P]),
     'mv2d_csr_workspace_bytes': (LL, [I, I, I, I]),
     'mv2d_mask_compact': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, I, P]),

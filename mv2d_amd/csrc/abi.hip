@@ -11,7 +11,7 @@ extern "C" void mv2d_set_error(const char* msg) {
 
 extern "C" const char* mv2d_last_error(void) { return g_err; }
 
-extern "C" int mv2d_abi_version(void) { return 5; }      // 5 (rounds 5-6): mv2d_roi_positions_csr (+order_flags), packed x3 weights = fp16 pairs, mv2d_xattn_group_*; 4 (round 4): key16 = fp16 operands, mv2d_decode_topk (+payload) / mv2d_xattn_query_order (+stride) changed, retired entries removed; 3: tile cross attention (mv2d_xattn_*); 2: batches of samples (grp_start arguments), bf16x3 linears / heads, attention backward
+extern "C" int mv2d_abi_version(void) { return 6; }      // 6 (round 6): e4m3 lo rows (lo_fmt arguments of mv2d_pe_fused_x3 / x3b, mv2d_xattn_tile_fwd_ordered, mv2d_xattn_fused_fwd; mv2d_roi_align_ex +out*_lo8); 5 (rounds 5-6): mv2d_roi_positions_csr (+order_flags), packed x3 weights = fp16 pairs, mv2d_xattn_group_*; 4 (round 4): key16 = fp16 operands, mv2d_decode_topk (+payload) / mv2d_xattn_query_order (+stride) changed, retired entries removed; 3: tile cross attention (mv2d_xattn_*); 2: batches of samples (grp_start arguments), bf16x3 linears / heads, attention backward
 
 // returns the gfx arch name of the current device into buf (e.g. "gfx950:sramecc+:xnack-"); 0 on success
 extern "C" int mv2d_device_arch(char* buf, int buflen) {

@@ -159,6 +159,40 @@ __device__ __forceinline__ void split_k16x2(float a, float b, unsigned int& hi, 
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// "lo8" (round 6): the lo halves of the key / value rows of the index-exact route as 8-BIT floats -- OCP e4m3 (4 exponent, 3 mantissa bits, bias 7,
+// max 448) of lo * 2^12 -- in 256-byte rows next to the 512-byte key16 (hi) rows: a (query, key) pair gathers 1.5 KB instead of 2 KB.  The remainder
+// of an fp16 rounding is at most half an ulp, |lo| <= 2^-12 |x| 2^frac <= 2^-11 |x|, so lo * 2^12 <= 2 |x| lies in the normal range of the format
+// [2^-6, 448] for 2^-7 <= |x| <= 224 (subnormal steps of 2^-9 below: absolute error <= 2^-22 there; saturation above, never reached by the head's
+// feature rows) under ONE FIXED scale: no reduction over the rows, the producers write the bytes in their epilogues.  The lo part enters a product
+// with relative weight 2^-12, its own rounding (2^-4 relative) therefore with 2^-16: the class logits move by <= 3e-7 of their range and all 17
+// reference parity cases keep their ranked indices (profiles/r06_ablate_exact.txt, tools/ablate_lo8_cases.py; e5m2 -- 2 mantissa bits -- does not).
+// The conversions are the hardware's (tools/probes/fp8_probe.hip checks both against a restatement of the OCP format: every byte, every fp16 pattern):
+//   lo8_pack4:   two key16 lo PAIRS -> 4 bytes, round-to-nearest-even of fp16(lo) * 2^12 clamped to +-448 (a NaN stays NaN: 0x7f / 0xff)
+//   lo8_pair:    bytes (2 w, 2 w + 1) of a dword -> the key16 pair fp16(e4m3 * 2^-12), subnormal results kept (v_cvt_scalef32_pk_f16_fp8)
+// The route's results are those of fp16 lo rows that hold the dequantised values, bit for bit (tests/test_gpu_kernels.py).
+// ------------------------------------------------------------------------------------------------------------------------------
+#if MV2D_KEY16_IS_F16
+__device__ __forceinline__ float lo8_clamp(float v) {
+    const float c = __builtin_amdgcn_fmed3f(v, -448.f, 448.f);
+    return v != v ? v : c;
+}
+__device__ __forceinline__ unsigned int lo8_pack4(unsigned int lo01, unsigned int lo23) {
+    int e = 0;
+    e = __builtin_amdgcn_cvt_pk_fp8_f32(lo8_clamp(k16_lo_of_pair(lo01) * 4096.f), lo8_clamp(k16_hi_of_pair(lo01) * 4096.f), e, false);
+    e = __builtin_amdgcn_cvt_pk_fp8_f32(lo8_clamp(k16_lo_of_pair(lo23) * 4096.f), lo8_clamp(k16_hi_of_pair(lo23) * 4096.f), e, true);
+    return (unsigned int)e;
+}
+template <int W>
+__device__ __forceinline__ unsigned int lo8_pair(unsigned int src) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_cv;
+    const f16x2_cv v = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)src, 0.000244140625f, W != 0);
+    return __builtin_bit_cast(unsigned int, v);
+}
+// 8 bytes -> the 16-byte key16 chunk of the same 8 channels
+__device__ __forceinline__ uint4 lo8_chunk(const uint2& b) { return make_uint4(lo8_pair<0>(b.x), lo8_pair<1>(b.x), lo8_pair<0>(b.y), lo8_pair<1>(b.y)); }
+#endif
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // "q16": the 16-bit SPLIT format of the query side (and of the split-precision PE kernel): every fp32 operand x is carried as a pair
 // x ~ hi + lo and a product is a_hi.w_hi + a_lo.w_hi + a_hi.w_lo on three 16-bit MFMAs with fp32 accumulation.  Rounds 1-4: bf16 pairs
 // (8 + 8 significand bits, 2^-17 per operand: 4.5e-6 relative on a 256-term dot product, the floor of the index-exact route's class-logit

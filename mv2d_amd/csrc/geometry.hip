@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
                                                         float* __restrict__ out0_f32, float* __restrict__ out1_f32, int H, int W,
                                                         float spatial_scale, int sampling_ratio, const int* __restrict__ map1_index,
                                                         int out1_is_sum, int R, unsigned short* __restrict__ out0_lo,
-                                                        unsigned short* __restrict__ out1_lo) {
+                                                        unsigned short* __restrict__ out1_lo, unsigned char* __restrict__ out0_lo8,
+                                                        unsigned char* __restrict__ out1_lo8) {
     // one block per RoI and bin row; wave w takes the bins w, w + 4 of the row, lane l the channels 4l .. 4l+3: every
     // bilinear tap is one 16-byte load per lane (a full 1 KB row per wave), every output one 8-byte (key16) / 16-byte (fp32) store.
     // XCD-aware block map (block b runs on XCD b % 8): the 7 bin rows of a RoI tap overlapping map rows, so they take consecutive slots
@@ -205,25 +206,26 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
         const long long o = ((long long)r * 49 + ph * 7 + pw) * C + c;
         s0 = make_float4(s0.x / count, s0.y / count, s0.z / count, s0.w / count);
         // key16 outputs (common.h: fp16 since round 4); out*_lo: the remainder x - key16(x) next to the value: the fp32-class hi + lo rows of the
-        // index-exact route
-        auto put = [&](unsigned short* hi, unsigned short* lo, const float4& t) {
-            if (lo) {
+        // index-exact route; out*_lo8 (round 6): the same remainder as 256-byte e4m3 rows (common.h "lo8": what the cross attention gathers)
+        auto put = [&](unsigned short* hi, unsigned short* lo, unsigned char* lo8, const float4& t) {
+            if (lo || lo8) {
                 uint2 hh, ll;
                 split_k16x2(t.x, t.y, hh.x, ll.x);
                 split_k16x2(t.z, t.w, hh.y, ll.y);
                 *reinterpret_cast<uint2*>(hi + o) = hh;
-                *reinterpret_cast<uint2*>(lo + o) = ll;
+                if (lo) *reinterpret_cast<uint2*>(lo + o) = ll;
+                if (lo8) *reinterpret_cast<unsigned int*>(lo8 + o) = lo8_pack4(ll.x, ll.y);
             } else {
                 *reinterpret_cast<uint2*>(hi + o) = make_uint2(pack_k16x2(t.x, t.y), pack_k16x2(t.z, t.w));
             }
         };
-        if (out0) put(out0, out0_lo, s0);
+        if (out0) put(out0, out0_lo, out0_lo8, s0);
         if (out0_f32) *reinterpret_cast<float4*>(out0_f32 + o) = s0;
         if (nmaps == 2) {
             s1 = make_float4(s1.x / count, s1.y / count, s1.z / count, s1.w / count);
             if (out1) {
                 const float4 t = out1_is_sum ? make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w) : s1;
-                put(out1, out1_lo, t);
+                put(out1, out1_lo, out1_lo8, t);
             }
             if (out1_f32) *reinterpret_cast<float4*>(out1_f32 + o) = s1;
         }
@@ -1227,14 +1229,14 @@ extern "C" int mv2d_posemb3d(const float* ref, const float* dim_t, float* posemb
 
 extern "C" int mv2d_roi_align_ex(const float* map0, const float* map1, const float* rois, void* out0, void* out1, float* out0_f32,
                                  float* out1_f32, int R, int H, int W, int channels, float spatial_scale, int sampling_ratio,
-                                 const int* map1_index, int out1_is_sum, void* out0_lo, void* out1_lo, void* stream) {
+                                 const int* map1_index, int out1_is_sum, void* out0_lo, void* out1_lo, void* out0_lo8, void* out1_lo8, void* stream) {
     MV2D_CHECK_ARG(map0 && rois && channels == C, "mv2d_roi_align: needs 256-channel position-major maps");
     MV2D_CHECK_ARG(out0 || out0_f32, "mv2d_roi_align: no output");
-    MV2D_CHECK_ARG((!out0_lo || out0) && (!out1_lo || out1), "mv2d_roi_align_ex: a lo output needs its key16 (hi) output");
+    MV2D_CHECK_ARG((!(out0_lo || out0_lo8) || out0) && (!(out1_lo || out1_lo8) || out1), "mv2d_roi_align_ex: a lo output needs its key16 (hi) output");
     if (R == 0) return MV2D_OK;
     hipLaunchKernelGGL(roi_align_kernel, dim3(56 * cdiv(R, 8)), dim3(256), 0, (hipStream_t)stream, map0, map1, rois, (unsigned short*)out0,
                        (unsigned short*)out1, out0_f32, out1_f32, H, W, spatial_scale, sampling_ratio, map1_index, out1_is_sum, R,
-                       (unsigned short*)out0_lo, (unsigned short*)out1_lo);
+                       (unsigned short*)out0_lo, (unsigned short*)out1_lo, (unsigned char*)out0_lo8, (unsigned char*)out1_lo8);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
@@ -1243,7 +1245,7 @@ extern "C" int mv2d_roi_align(const float* map0, const float* map1, const float*
                               float* out1_f32, int R, int H, int W, int channels, float spatial_scale, int sampling_ratio,
                               const int* map1_index, int out1_is_sum, void* stream) {
     return mv2d_roi_align_ex(map0, map1, rois, out0, out1, out0_f32, out1_f32, R, H, W, channels, spatial_scale, sampling_ratio, map1_index,
-                             out1_is_sum, nullptr, nullptr, stream);
+                             out1_is_sum, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int mv2d_roi_align_bwd(const float* grad_out, const float* rois, float* grad_map, const int* index, int R, int H, int W,

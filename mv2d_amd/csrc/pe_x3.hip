@@ -47,6 +47,7 @@ struct PeX3Params {
     const unsigned short* Wr_h; const unsigned short* Wr_l; const float* br; const unsigned short* We_h; const unsigned short* We_l; const float* be;
     const float* sine_tab; int tab_period;
     float* pe; unsigned short* Xk_hi; unsigned short* Xk_lo; unsigned short* Xv_hi; unsigned short* Xv_lo;
+    int lo8;                                                 // the lo row outputs are 256-byte e4m3 rows (common.h "lo8")
 };
 
 // ---- the 72 k-steps of a block as one compile-time schedule (pe_tab96.hip): parts 0..3 = hidden columns 256 p .. of the frustum MLP
@@ -373,11 +374,13 @@ __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
                     split_k16x2(v.x + f.x, v.y + f.y, h.x, l.x);
                     split_k16x2(v.z + f.z, v.w + f.w, h.y, l.y);
                     *reinterpret_cast<uint2*>(p.Xk_hi + (long long)m * C + gcol) = h;
-                    *reinterpret_cast<uint2*>(p.Xk_lo + (long long)m * C + gcol) = l;
+                    if (p.lo8) *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(p.Xk_lo) + (long long)m * C + gcol) = lo8_pack4(l.x, l.y);
+                    else *reinterpret_cast<uint2*>(p.Xk_lo + (long long)m * C + gcol) = l;
                     split_k16x2(f.x, f.y, h.x, l.x);
                     split_k16x2(f.z, f.w, h.y, l.y);
                     *reinterpret_cast<uint2*>(p.Xv_hi + (long long)m * C + gcol) = h;
-                    *reinterpret_cast<uint2*>(p.Xv_lo + (long long)m * C + gcol) = l;
+                    if (p.lo8) *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(p.Xv_lo) + (long long)m * C + gcol) = lo8_pack4(l.x, l.y);
+                    else *reinterpret_cast<uint2*>(p.Xv_lo + (long long)m * C + gcol) = l;
                 }
             }
         }
@@ -396,19 +399,20 @@ extern "C" int mv2d_px_trace_read(long long* host, int n) { return hipMemcpyFrom
 extern "C" int mv2d_pe_fused_x3(const float* A1, const float* Xmap, const int* row_index, const int* m_dev, int M,
                                 const void* W1a_hi, const void* W1a_lo, const float* b1a, const void* W1b_hi, const void* W1b_lo, const float* b1b,
                                 const void* Wr_hi, const void* Wr_lo, const float* br, const void* We_hi, const void* We_lo, const float* be,
-                                const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, void* stream) {
+                                const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, int lo_fmt, void* stream) {
     MV2D_CHECK_ARG(A1 && Xmap && W1a_hi && W1a_lo && b1a && W1b_hi && W1b_lo && b1b && Wr_hi && Wr_lo && br && We_hi && We_lo && be && sine_tab,
                    "mv2d_pe_fused_x3: null pointer");
     MV2D_CHECK_ARG(pe || Xk_hi, "mv2d_pe_fused_x3: no output");
     MV2D_CHECK_ARG((Xk_hi != nullptr) == (Xk_lo != nullptr) && (Xk_hi != nullptr) == (Xv_hi != nullptr) && (Xk_hi != nullptr) == (Xv_lo != nullptr),
                    "mv2d_pe_fused_x3: the four key / value row outputs come together");
     MV2D_CHECK_ARG(M >= 0 && tab_period > 0, "mv2d_pe_fused_x3: M must be >= 0 and tab_period > 0");
+    MV2D_CHECK_ARG(lo_fmt == 0 || lo_fmt == 1, "mv2d_pe_fused_x3: lo_fmt is 0 (key16 lo rows) or 1 (e4m3 lo rows)");
     MV2D_CHECK_ARG(((uintptr_t)A1 & 15) == 0 && ((uintptr_t)Xmap & 15) == 0 && ((uintptr_t)sine_tab & 15) == 0, "mv2d_pe_fused_x3: rows must be 16-byte aligned");
     if (M == 0) return MV2D_OK;
     PeX3Params p{A1, Xmap, row_index, m_dev, M, (const unsigned short*)W1a_hi, (const unsigned short*)W1a_lo, b1a, (const unsigned short*)W1b_hi,
                  (const unsigned short*)W1b_lo, b1b, (const unsigned short*)Wr_hi, (const unsigned short*)Wr_lo, br, (const unsigned short*)We_hi,
                  (const unsigned short*)We_lo, be, sine_tab, tab_period, pe, (unsigned short*)Xk_hi, (unsigned short*)Xk_lo, (unsigned short*)Xv_hi,
-                 (unsigned short*)Xv_lo};
+                 (unsigned short*)Xv_lo, lo_fmt};
     hipLaunchKernelGGL(pe_x3_kernel, dim3(cdiv(M, BM)), dim3(NTHR), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;

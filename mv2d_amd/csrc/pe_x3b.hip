@@ -41,6 +41,7 @@ struct PeX3bParams {
     const unsigned short* Wr_h; const unsigned short* Wr_l; const float* br; const unsigned short* We_h; const unsigned short* We_l; const float* be;
     const float* sine_tab; int tab_period;
     float* pe; unsigned short* Xk_hi; unsigned short* Xk_lo; unsigned short* Xv_hi; unsigned short* Xv_lo;
+    int lo8;                                                 // the lo row outputs are 256-byte e4m3 rows (common.h "lo8")
 };
 
 // ---- the 80 steps of a block: parts 0..3 = hidden columns 256 p .. of the frustum MLP (6 + 8 k-steps each), part 4 = the gate: 8 k-steps of its
@@ -320,11 +321,13 @@ struct Pe {
                 split_k16x2(v.x + f.x, v.y + f.y, h.x, l.x);
                 split_k16x2(v.z + f.z, v.w + f.w, h.y, l.y);
                 *reinterpret_cast<uint2*>(p.Xk_hi + (long long)m * C + 4 * lane) = h;
-                *reinterpret_cast<uint2*>(p.Xk_lo + (long long)m * C + 4 * lane) = l;
+                if (p.lo8) *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(p.Xk_lo) + (long long)m * C + 4 * lane) = lo8_pack4(l.x, l.y);
+                else *reinterpret_cast<uint2*>(p.Xk_lo + (long long)m * C + 4 * lane) = l;
                 split_k16x2(f.x, f.y, h.x, l.x);
                 split_k16x2(f.z, f.w, h.y, l.y);
                 *reinterpret_cast<uint2*>(p.Xv_hi + (long long)m * C + 4 * lane) = h;
-                *reinterpret_cast<uint2*>(p.Xv_lo + (long long)m * C + 4 * lane) = l;
+                if (p.lo8) *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(p.Xv_lo) + (long long)m * C + 4 * lane) = lo8_pack4(l.x, l.y);
+                else *reinterpret_cast<uint2*>(p.Xv_lo + (long long)m * C + 4 * lane) = l;
             }
         }
     }
@@ -341,13 +344,14 @@ __global__ __launch_bounds__(256, 1) void pe_x3b_kernel_4x2(PeX3bParams p) {
 extern "C" int mv2d_pe_fused_x3b(const float* A1, const float* Xmap, const int* row_index, const int* m_dev, int M,
                                  const void* W1a_hi, const void* W1a_lo, const float* b1a, const void* W1b_hi, const void* W1b_lo, const float* b1b,
                                  const void* Wr_hi, const void* Wr_lo, const float* br, const void* We_hi, const void* We_lo, const float* be,
-                                 const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, void* stream) {
+                                 const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, int lo_fmt, void* stream) {
     MV2D_CHECK_ARG(A1 && Xmap && W1a_hi && W1a_lo && b1a && W1b_hi && W1b_lo && b1b && Wr_hi && Wr_lo && br && We_hi && We_lo && be && sine_tab,
                    "mv2d_pe_fused_x3b: null pointer");
     MV2D_CHECK_ARG(pe || Xk_hi, "mv2d_pe_fused_x3b: no output");
     MV2D_CHECK_ARG((Xk_hi != nullptr) == (Xk_lo != nullptr) && (Xk_hi != nullptr) == (Xv_hi != nullptr) && (Xk_hi != nullptr) == (Xv_lo != nullptr),
                    "mv2d_pe_fused_x3b: the four key / value row outputs come together");
     MV2D_CHECK_ARG(M >= 0 && tab_period > 0, "mv2d_pe_fused_x3b: M must be >= 0 and tab_period > 0");
+    MV2D_CHECK_ARG(lo_fmt == 0 || lo_fmt == 1, "mv2d_pe_fused_x3b: lo_fmt is 0 (key16 lo rows) or 1 (e4m3 lo rows)");
     MV2D_CHECK_ARG(((uintptr_t)A1 & 15) == 0 && ((uintptr_t)Xmap & 15) == 0 && ((uintptr_t)sine_tab & 15) == 0, "mv2d_pe_fused_x3b: rows must be 16-byte aligned");
     MV2D_CHECK_ARG((((uintptr_t)W1a_hi | (uintptr_t)W1a_lo | (uintptr_t)W1b_hi | (uintptr_t)W1b_lo | (uintptr_t)Wr_hi | (uintptr_t)Wr_lo | (uintptr_t)We_hi |
                      (uintptr_t)We_lo) & 15) == 0, "mv2d_pe_fused_x3b: packed weights must be 16-byte aligned");
@@ -355,7 +359,7 @@ extern "C" int mv2d_pe_fused_x3b(const float* A1, const float* Xmap, const int* 
     PeX3bParams p{A1, Xmap, row_index, m_dev, M, (const unsigned short*)W1a_hi, (const unsigned short*)W1a_lo, b1a, (const unsigned short*)W1b_hi,
                   (const unsigned short*)W1b_lo, b1b, (const unsigned short*)Wr_hi, (const unsigned short*)Wr_lo, br, (const unsigned short*)We_hi,
                   (const unsigned short*)We_lo, be, sine_tab, tab_period, pe, (unsigned short*)Xk_hi, (unsigned short*)Xk_lo, (unsigned short*)Xv_hi,
-                  (unsigned short*)Xv_lo};
+                  (unsigned short*)Xv_lo, lo_fmt};
     hipLaunchKernelGGL(pe_x3b_kernel_4x2, dim3(cdiv(M, 128)), dim3(256), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;

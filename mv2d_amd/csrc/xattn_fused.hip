@@ -41,6 +41,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 typedef q16x8_t xf_q16x8;
 union XfFrag { uint4 u; xf_q16x8 v; };
 typedef unsigned int xf_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int xf_u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void xf_split8(const float4& x0, const float4& x1, XfFrag& hi, XfFrag& lo) {
     const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
@@ -73,7 +74,8 @@ constexpr int WAVE_LDS = 16384;                              // per wave: key ti
 
 // QB = 8: one block per CU (132 KB of LDS); QB = 4 (round 6): 66 KB, two blocks per CU -- the map phases of one block (packed weights from L2, the
 // gather idle) run under the tile loop of the other; a wave then maps two heads in phases A and C
-template <bool XLO, int QB>
+// XLO: 0 = key16 rows alone, 1 = hi + key16 lo rows, 2 = hi + e4m3 lo rows (common.h "lo8"; see xattn_tile_kernel)
+template <int XLO, int QB>
 __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __restrict__ q, const uint4* __restrict__ WA_hi, const uint4* __restrict__ WA_lo,
                                                                 const uint4* __restrict__ WB_hi, const uint4* __restrict__ WB_lo, const float* __restrict__ bv,
                                                                 const unsigned short* __restrict__ Xk, const unsigned short* __restrict__ Xv,
@@ -112,12 +114,21 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
     const int beg = rbeg[wave], end = rend[wave];
     const int ntile = wave < nq ? (end - beg + 15) >> 4 : 0;          // (waves beyond the block's queries: no tiles; their z / l are never read)
     int idx_next = ntile > 0 ? col_idx[min(beg + n, end - 1)] : 0;
-    xf_u32x4 kreg0[8], klo0[8];
+    xf_u32x4 kreg0[8], klo0[XLO == 1 ? 8 : 1];
+    xf_u32x2 klo0b[XLO == 2 ? 8 : 1];
     auto load_k0 = [&](const unsigned short* K_, int myidx, xf_u32x4 (&dst)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const unsigned int ridx = (unsigned int)__shfl(myidx, 2 * i + (lane >> 5), 64);
             dst[i] = *reinterpret_cast<const xf_u32x4*>(reinterpret_cast<const char*>(K_) + ((ridx << 9) + (unsigned)(lane & 31) * 16u));
+        }
+    };
+    // e4m3 lo rows: the same lane -> (row, channels) assignment at half the bytes (a half wave reads one 256-byte row)
+    auto load_k8 = [&](const unsigned short* K_, int myidx, xf_u32x2 (&dst)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned int ridx = (unsigned int)__shfl(myidx, 2 * i + (lane >> 5), 64);
+            dst[i] = *reinterpret_cast<const xf_u32x2*>(reinterpret_cast<const char*>(K_) + ((ridx << 8) + (unsigned)(lane & 31) * 8u));
         }
     };
     // ---------------------------------------------------------------- phase A: query maps, wave = head
@@ -157,7 +168,8 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
             }
             if (u == (XLO ? 5 : 3) && h == wave && ntile > 0) {   // (all weight fragments of the head have been requested: the rows queue behind them; late enough for their 64 registers)
                 load_k0(Xk, idx_next, kreg0);
-                if (XLO) load_k0(Xk_lo, idx_next, klo0);
+                if constexpr (XLO == 1) load_k0(Xk_lo, idx_next, klo0);
+                if constexpr (XLO == 2) load_k8(Xk_lo, idx_next, klo0b);
             }
         }
     }
@@ -207,7 +219,23 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
                 reinterpret_cast<xf_u32x4*>(tile)[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = src[i];
             }
         };
-        auto compute = [&](int tt, const xf_u32x4 (&vreg)[4][2], const xf_u32x4 (&vlo)[4][2]) {
+        auto load_v8 = [&](const unsigned short* V_, int myidx, xf_u32x2 (&dst)[4][2]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned int vidx = (unsigned int)__shfl(myidx, 4 * g + e, 64);
+                const char* vp = reinterpret_cast<const char*>(V_) + ((vidx << 8) + 8u * (unsigned)n);
+                dst[e][0] = *reinterpret_cast<const xf_u32x2*>(vp);
+                dst[e][1] = *reinterpret_cast<const xf_u32x2*>(vp + 128);
+            }
+        };
+        auto store_k8 = [&](uint4* tile, const xf_u32x2 (&src)[8]) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int rowi = 2 * i + (lane >> 5);
+                tile[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = lo8_chunk(make_uint2(src[i].x, src[i].y));
+            }
+        };
+        auto compute = [&](int tt, const xf_u32x4 (&vreg)[4][2], const auto& vlo) {
             const int kbase = beg + 16 * tt;
             f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -271,11 +299,17 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
                                              : make_uint2(xf_lo_pair(r0[d], r1[d]), xf_lo_pair(r2[d], r3[d]));
                     f32x4_t zc = Z[H * 8 + w];
                     zc = mfma_k16_16x16x16(pa, vb, zc);
-                    if (XLO) {
-                        const unsigned int q0[4] = {vlo[0][H].x, vlo[0][H].y, vlo[0][H].z, vlo[0][H].w}, q1[4] = {vlo[1][H].x, vlo[1][H].y, vlo[1][H].z, vlo[1][H].w};
-                        const unsigned int q2[4] = {vlo[2][H].x, vlo[2][H].y, vlo[2][H].z, vlo[2][H].w}, q3[4] = {vlo[3][H].x, vlo[3][H].y, vlo[3][H].z, vlo[3][H].w};
-                        const uint2 vl = (w & 1) ? make_uint2(xf_hi_pair(q0[d], q1[d]), xf_hi_pair(q2[d], q3[d]))
-                                                 : make_uint2(xf_lo_pair(q0[d], q1[d]), xf_lo_pair(q2[d], q3[d]));
+                    if constexpr (XLO != 0) {
+                        auto lo_pair_of = [&](int e) -> unsigned int {
+                            if constexpr (XLO == 2) {
+                                const unsigned int b = vlo[e][H][d >> 1];
+                                return (d & 1) ? lo8_pair<1>(b) : lo8_pair<0>(b);
+                            } else {
+                                return vlo[e][H][d];
+                            }
+                        };
+                        const unsigned int q0 = lo_pair_of(0), q1 = lo_pair_of(1), q2 = lo_pair_of(2), q3 = lo_pair_of(3);
+                        const uint2 vl = (w & 1) ? make_uint2(xf_hi_pair(q0, q1), xf_hi_pair(q2, q3)) : make_uint2(xf_lo_pair(q0, q1), xf_lo_pair(q2, q3));
                         zc = mfma_k16_16x16x16(pah, vl, zc);
                     }
                     Z[H * 8 + w] = zc;
@@ -286,12 +320,30 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
         // the first tile's key rows were requested during phase A: into LDS right away (the wave's Qt operand sits in qa by now)
         if (ntile > 0) {
             store_k(kt, kreg0);
-            if constexpr (XLO) store_k(kt2, klo0);
+            if constexpr (XLO == 1) store_k(kt2, klo0);
+            if constexpr (XLO == 2) store_k8(kt2, klo0b);
         }
         for (int tt = 0; tt < ntile; ++tt) {
             const int myidx = idx_next;
             if (tt + 1 < ntile) idx_next = col_idx[min(beg + 16 * (tt + 1) + n, end - 1)];
-            if constexpr (XLO) {
+            if constexpr (XLO == 2) {
+                xf_u32x4 vreg[4][2];
+                xf_u32x2 vlo[4][2];
+                if (tt > 0) {
+                    xf_u32x4 kreg[8];
+                    xf_u32x2 klo[8];
+                    load_k(Xk, myidx, kreg);
+                    load_k8(Xk_lo, myidx, klo);
+                    store_k(kt, kreg);
+                    store_k8(kt2, klo);
+                }
+                load_v(Xv, myidx, vreg);
+                load_v8(Xv_lo, myidx, vlo);
+                __builtin_amdgcn_wave_barrier();
+                XF_STAMP(3 + 2 * min(tt, 5));
+                compute(tt, vreg, vlo);
+                XF_STAMP(4 + 2 * min(tt, 5));
+            } else if constexpr (XLO == 1) {
                 xf_u32x4 vreg[4][2], vlo[4][2];
                 if (tt > 0) {
                     xf_u32x4 kreg[8], klo[8];
@@ -423,7 +475,8 @@ extern "C" int mv2d_xf_trace_read(long long* host, int n) { return hipMemcpyFrom
 // C-ABI: include/mv2d_hip.h
 extern "C" int mv2d_xattn_fused_fwd(const float* q, const void* WA_hi, const void* WA_lo, const void* WB_hi, const void* WB_lo, const float* bv,
                                     const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr, const int* col_idx,
-                                    float* ctx, int R, int empty_nan, const int* order, void* stream) {
+                                    float* ctx, int R, int empty_nan, const int* order, int lo_fmt, void* stream) {
+    MV2D_CHECK_ARG(lo_fmt == 0 || (lo_fmt == 1 && Xk_lo), "mv2d_xattn_fused_fwd: lo_fmt is 0 (key16 lo rows) or 1 (e4m3 lo rows; needs the lo rows)");
     MV2D_CHECK_ARG(q && WA_hi && WA_lo && WB_hi && WB_lo && bv && Xk && Xv && row_ptr && col_idx && ctx && R >= 0, "mv2d_xattn_fused_fwd: bad args");
     MV2D_CHECK_ARG((Xk_lo == nullptr) == (Xv_lo == nullptr), "mv2d_xattn_fused_fwd: Xk_lo and Xv_lo come together");
     MV2D_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)WA_hi & 15) == 0 && ((uintptr_t)WA_lo & 15) == 0 && ((uintptr_t)WB_hi & 15) == 0 &&
@@ -454,8 +507,9 @@ extern "C" int mv2d_xattn_fused_fwd(const float* q, const void* WA_hi, const voi
 #define MV2D_XF(XLO_, QB_) hipLaunchKernelGGL((xattn_fused_kernel<XLO_, QB_>), grid, block, 0, (hipStream_t)stream, q, (const uint4*)WA_hi, (const uint4*)WA_lo, \
                                               (const uint4*)WB_hi, (const uint4*)WB_lo, bv, (const unsigned short*)Xk, (const unsigned short*)Xv,                     \
                                               (const unsigned short*)Xk_lo, (const unsigned short*)Xv_lo, row_ptr, col_idx, ctx, R, empty_nan, order, nblk)
-    if (Xk_lo) { if (QB == 4) MV2D_XF(true, 4); else MV2D_XF(true, 8); }
-    else { if (QB == 4) MV2D_XF(false, 4); else MV2D_XF(false, 8); }
+    if (Xk_lo && lo_fmt == 1) { if (QB == 4) MV2D_XF(2, 4); else MV2D_XF(2, 8); }
+    else if (Xk_lo) { if (QB == 4) MV2D_XF(1, 4); else MV2D_XF(1, 8); }
+    else { if (QB == 4) MV2D_XF(0, 4); else MV2D_XF(0, 8); }
 #undef MV2D_XF
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;

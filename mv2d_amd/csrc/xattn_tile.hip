@@ -221,7 +221,10 @@ __device__ __forceinline__ float xt_row16_max(float v) {
 }
 
 typedef unsigned int xt_u32x4 __attribute__((ext_vector_type(4)));      // staging registers (arrays of HIP's uint4 STRUCT that live across a loop end up in scratch)
-template <int NW, bool DBG, bool XLO>
+typedef unsigned int xt_u32x2 __attribute__((ext_vector_type(2)));
+// XLO: 0 = key16 rows alone (default route), 1 = hi + key16 lo rows, 2 = hi + e4m3 lo rows (common.h "lo8": 256-byte rows, converted to key16 in registers
+// on their way into the LDS tile / the v_perm transposes -- the MFMAs and everything behind them are those of XLO = 1)
+template <int NW, bool DBG, int XLO>
 __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __restrict__ Qt, const unsigned short* __restrict__ Xk,
                                                              const unsigned short* __restrict__ Xv, const unsigned short* __restrict__ Xk_lo,
                                                              const unsigned short* __restrict__ Xv_lo, const int* __restrict__ row_ptr,
@@ -293,8 +296,32 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
             reinterpret_cast<xt_u32x4*>(tile)[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = src[i];
         }
     };
+    // e4m3 lo rows: the same lane -> (row, channels) assignment at half the bytes (8 per lane and row: a half wave reads one 256-byte row)
+    auto load_v8 = [&](const unsigned short* V_, int myidx, xt_u32x2 (&dst)[4][2]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned int vidx = (unsigned int)__shfl(myidx, 4 * g + e, 64);
+            const char* vp = reinterpret_cast<const char*>(V_) + ((vidx << 8) + 8u * (unsigned)n);
+            dst[e][0] = *reinterpret_cast<const xt_u32x2*>(vp);
+            dst[e][1] = *reinterpret_cast<const xt_u32x2*>(vp + 128);
+        }
+    };
+    auto load_k8 = [&](const unsigned short* K_, int myidx, xt_u32x2 (&dst)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned int ridx = (unsigned int)__shfl(myidx, 2 * i + (lane >> 5), 64);
+            dst[i] = *reinterpret_cast<const xt_u32x2*>(reinterpret_cast<const char*>(K_) + ((ridx << 8) + (unsigned)(lane & 31) * 8u));
+        }
+    };
+    auto store_k8 = [&](uint4* tile, const xt_u32x2 (&src)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rowi = 2 * i + (lane >> 5);
+            tile[rowi * 32 + ((lane & 31) ^ (rowi & 15))] = lo8_chunk(make_uint2(src[i].x, src[i].y));
+        }
+    };
     // logits, online softmax and P . V of tile tt: the key tile is in LDS (kt, XLO: kt2), the value rows in registers
-    auto compute = [&](int tt, const xt_u32x4 (&vreg)[4][2], const xt_u32x4 (&vlo)[4][2]) {
+    auto compute = [&](int tt, const xt_u32x4 (&vreg)[4][2], const auto& vlo) {
         const int kbase = beg + 16 * tt;
         // ---- logits of the tile: D[row 4g+i][key n] = sum_c Qt[row][c] Xk[key][c]
         f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
@@ -367,11 +394,18 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
                                          : make_uint2(xt_lo_pair(r0[d], r1[d]), xt_lo_pair(r2[d], r3[d]));
                 f32x4_t zc = Z[H * 8 + w];
                 zc = mfma_k16_16x16x16(pa, vb, zc);
-                if (XLO) {
-                    const unsigned int q0[4] = {vlo[0][H].x, vlo[0][H].y, vlo[0][H].z, vlo[0][H].w}, q1[4] = {vlo[1][H].x, vlo[1][H].y, vlo[1][H].z, vlo[1][H].w};
-                    const unsigned int q2[4] = {vlo[2][H].x, vlo[2][H].y, vlo[2][H].z, vlo[2][H].w}, q3[4] = {vlo[3][H].x, vlo[3][H].y, vlo[3][H].z, vlo[3][H].w};
-                    const uint2 vl = (w & 1) ? make_uint2(xt_hi_pair(q0[d], q1[d]), xt_hi_pair(q2[d], q3[d]))
-                                             : make_uint2(xt_lo_pair(q0[d], q1[d]), xt_lo_pair(q2[d], q3[d]));
+                if constexpr (XLO != 0) {
+                    // channel pair d of key e: a dword of the key16 lo row, or two bytes of the e4m3 row converted here (one v_cvt per pair and key)
+                    auto lo_pair_of = [&](int e) -> unsigned int {
+                        if constexpr (XLO == 2) {
+                            const unsigned int b = vlo[e][H][d >> 1];
+                            return (d & 1) ? lo8_pair<1>(b) : lo8_pair<0>(b);
+                        } else {
+                            return vlo[e][H][d];
+                        }
+                    };
+                    const unsigned int q0 = lo_pair_of(0), q1 = lo_pair_of(1), q2 = lo_pair_of(2), q3 = lo_pair_of(3);
+                    const uint2 vl = (w & 1) ? make_uint2(xt_hi_pair(q0, q1), xt_hi_pair(q2, q3)) : make_uint2(xt_lo_pair(q0, q1), xt_lo_pair(q2, q3));
                     zc = mfma_k16_16x16x16(pah, vl, zc);
                 }
                 Z[H * 8 + w] = zc;
@@ -379,7 +413,24 @@ __global__ __launch_bounds__(64 * NW, 2) void xattn_tile_kernel(const uint4* __r
         }
         __builtin_amdgcn_wave_barrier();                                             // before the next tile overwrites kt / pl
     };
-    if constexpr (XLO) {
+    if constexpr (XLO == 2) {
+        // index-exact route with e4m3 lo rows (round 6): the order of XLO = 1 below; the lo halves are 8-byte loads and 16 + 16 staging registers
+        int idx_next = wave < ntile ? col_idx[min(beg + 16 * wave + n, end - 1)] : 0;
+        for (int tt = wave; tt < ntile; tt += NW) {
+            const int myidx = idx_next;
+            if (tt + NW < ntile) idx_next = col_idx[min(beg + 16 * (tt + NW) + n, end - 1)];
+            xt_u32x4 kreg[8], vreg[4][2];
+            xt_u32x2 klo[8], vlo[4][2];
+            load_k(Xk, myidx, kreg);
+            load_k8(Xk_lo, myidx, klo);
+            store_k(kt, kreg);
+            store_k8(kt2, klo);
+            load_v(Xv, myidx, vreg);
+            load_v8(Xv_lo, myidx, vlo);
+            __builtin_amdgcn_wave_barrier();
+            compute(tt, vreg, vlo);
+        }
+    } else if constexpr (XLO == 1) {
         // index-exact route, TWO PHASES per tile (round 4): the hi and lo halves of the 16 key rows are requested together (16 loads in flight) and
         // go to LDS; only then the hi and lo value rows are requested -- into the registers the key rows just left -- and arrive while the
         // logits and the softmax run.  (Round 3 requested K hi, V hi up front and the lo halves behind the first LDS writes, in 32 more
@@ -500,17 +551,18 @@ extern "C" int mv2d_xattn_ctxmap(const float* z, const void* WB_hi, const void* 
 
 extern "C" int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                            const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
-                                           const int* order, void* stream);
+                                           const int* order, int lo_fmt, void* stream);
 
 extern "C" int mv2d_xattn_tile_fwd(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                    const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves, void* stream) {
-    return mv2d_xattn_tile_fwd_ordered(Qt, Xk, Xv, Xk_lo, Xv_lo, row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan, waves, nullptr, stream);
+    return mv2d_xattn_tile_fwd_ordered(Qt, Xk, Xv, Xk_lo, Xv_lo, row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan, waves, nullptr, 0, stream);
 }
 
 extern "C" int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const void* Xv, const void* Xk_lo, const void* Xv_lo, const int* row_ptr,
                                            const int* col_idx, float* z, float* dbg_logits, long long dbg_stride, int R, int empty_nan, int waves,
-                                           const int* order, void* stream) {
+                                           const int* order, int lo_fmt, void* stream) {
     MV2D_CHECK_ARG(Qt && Xk && Xv && row_ptr && col_idx && z && R >= 0, "mv2d_xattn_tile_fwd: bad args");
+    MV2D_CHECK_ARG(lo_fmt == 0 || (lo_fmt == 1 && Xk_lo), "mv2d_xattn_tile_fwd: lo_fmt is 0 (key16 lo rows) or 1 (e4m3 lo rows; needs the lo rows)");
     MV2D_CHECK_ARG((Xk_lo == nullptr) == (Xv_lo == nullptr), "mv2d_xattn_tile_fwd: Xk_lo and Xv_lo come together");
     MV2D_CHECK_ARG(((uintptr_t)Qt & 15) == 0 && ((uintptr_t)Xk & 15) == 0 && ((uintptr_t)Xv & 15) == 0 && ((uintptr_t)z & 15) == 0 &&
                        ((uintptr_t)Xk_lo & 15) == 0 && ((uintptr_t)Xv_lo & 15) == 0, "mv2d_xattn_tile_fwd: operands must be 16-byte aligned");
@@ -521,9 +573,10 @@ extern "C" int mv2d_xattn_tile_fwd_ordered(const void* Qt, const void* Xk, const
                                                  (const unsigned short*)Xk, (const unsigned short*)Xv, (const unsigned short*)Xk_lo, (const unsigned short*)Xv_lo, \
                                                  row_ptr, col_idx, z, dbg_logits, dbg_stride, R, empty_nan, order)
     // index-exact route (hi + lo rows): two waves per SIMD like the default (round 3: the 312-register build ran one wave per SIMD, 133 us per layer)
-    if (Xk_lo) { if (dbg_logits) MV2D_XT(4, true, true); else if (nw == 4) MV2D_XT(4, false, true); else if (nw == 1) MV2D_XT(1, false, true); else MV2D_XT(2, false, true); }
-    else if (dbg_logits) { if (nw == 8) MV2D_XT(8, true, false); else if (nw == 2) MV2D_XT(2, true, false); else if (nw == 1) MV2D_XT(1, true, false); else MV2D_XT(4, true, false); }
-    else { if (nw == 8) MV2D_XT(8, false, false); else if (nw == 2) MV2D_XT(2, false, false); else if (nw == 1) MV2D_XT(1, false, false); else MV2D_XT(4, false, false); }
+    if (Xk_lo && lo_fmt == 1) { if (dbg_logits) MV2D_XT(4, true, 2); else if (nw == 4) MV2D_XT(4, false, 2); else if (nw == 1) MV2D_XT(1, false, 2); else MV2D_XT(2, false, 2); }
+    else if (Xk_lo) { if (dbg_logits) MV2D_XT(4, true, 1); else if (nw == 4) MV2D_XT(4, false, 1); else if (nw == 1) MV2D_XT(1, false, 1); else MV2D_XT(2, false, 1); }
+    else if (dbg_logits) { if (nw == 8) MV2D_XT(8, true, 0); else if (nw == 2) MV2D_XT(2, true, 0); else if (nw == 1) MV2D_XT(1, true, 0); else MV2D_XT(4, true, 0); }
+    else { if (nw == 8) MV2D_XT(8, false, 0); else if (nw == 2) MV2D_XT(2, false, 0); else if (nw == 1) MV2D_XT(1, false, 0); else MV2D_XT(4, false, 0); }
 #undef MV2D_XT
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;

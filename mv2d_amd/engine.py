@@ -134,7 +134,14 @@ class HeadEngine:
         # 5.1e-6 -> 4.9e-6 / 5.8e-6 -> 5.7e-6): its 2304-term dot products average the 2^-12 roundings down, and the 3 x MFMA-bound split-
         # precision kernel (362 vs 123 us per 2400 RoIs) leaves the route.  Attention rows and PE stay hi + lo: dropping either costs ranks.
         self.exact_skip = frozenset({'conv'})
-        # experiments only (tools/ablate_exact.py): zero the lo halves of the value / key rows after they were written -- what a route with hi-only value
+        # Round 6: the lo halves of the key / value rows as 8-BIT floats (csrc/common.h "lo8": OCP e4m3 of lo * 2^12, 256-byte rows) -- a (query, key)
+        # pair of the cross attention gathers 1.5 KB instead of 2 KB and the row producers write a quarter less.  The lo part carries 2^-12 of a
+        # product, its e4m3 rounding 2^-16: all 17 reference parity cases keep their ranked indices (class logits 6.2e-7 .. 1.1e-6 of their range
+        # against 6.3e-7 .. 8.0e-7 with key16 lo rows, bound 3e-6; an e5m2 lo half or a missing one moves ranks: profiles/r06_ablate_exact.txt).
+        # The kernels decode the bytes to key16 in registers: results are bitwise those of key16 lo rows holding the decoded values.  False: key16 lo
+        # rows (rounds 3-5).  The shared-tile kernel (group_xattn) reads key16 lo rows only.  In the graph key.
+        self.lo8_rows = True
+        # experiments only (tools/ablate_exact.py; needs lo8_rows = False): zero the lo halves of the value / key rows after they were written -- what a route with hi-only value
         # (or key) rows would compute, at the full route's cost
         self.ablate_zero_lo = frozenset()
         # Round 6, OPT-IN: the split-precision PE block on the second shape of its kernel (csrc/pe_x3b.hip: a wave owns 32 rows through both layers of
@@ -356,12 +363,15 @@ class HeadEngine:
             # key / value rows and RoI cells -- all pre-allocated (no per-frame allocation, no host synchronisation: the route is
             # graph-replayable like the default one)
             ws['xa1'] = e((P, 3 * self.depth_num)); ws['xa2'] = e((P, 384))
+            lo8 = self._lo8()
+            LO = torch.uint8 if lo8 else K16
             if self.kind == 'T':
-                ws['xk_lo'] = z((P, C), K16); ws['xv_lo'] = z((P, C), K16)
+                ws['xk_lo'] = z((P, C), LO); ws['xv_lo'] = z((P, C), LO)
                 ws['roi_lo'] = e((R, 49, C), K16)                 # lo halves of the RoI cells (conv input)
             else:
-                ws['xk_lo'] = z((R * 49, C), K16); ws['xv_lo'] = z((R * 49, C), K16)
-                ws['roi_lo'] = ws['xv_lo'].view(R, 49, C)          # S path: the value rows ARE the RoI cells
+                ws['xk_lo'] = z((R * 49, C), LO); ws['xv_lo'] = z((R * 49, C), LO)
+                # S path: the value rows ARE the RoI cells (key16 lo rows: one array for both; lo8 rows: the split-precision conv, when it runs, reads its own key16 lo cells)
+                ws['roi_lo'] = e((R, 49, C), K16) if lo8 else ws['xv_lo'].view(R, 49, C)
         ws['pe'] = e((P, C)); ws['Xk'] = e((P, C), K16)
         # cross attention in the raw key space: per-query operand Qt (key16 hi | lo rows of the 8 per-head maps), per-head context sums z
         ws['Qt'] = e((R, 16 * C), K16); ws['zh'] = e((R, 8 * C))
@@ -626,9 +636,15 @@ class HeadEngine:
         if self.kind == 'S':
             tk('roi_align')
             # key rows = RoIAlign(feat) + RoIAlign(pe), value rows = RoIAlign(feat) (index-exact route: both as key16 hi + lo pairs)
-            o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=ws['pos2s'], out1_is_sum=True,
-                        out0_lo=ws['xv_lo'] if self.exact else None, out1_lo=ws['xk_lo'] if self.exact else None, R=R)
+            if self.exact and self._lo8():
+                o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=ws['pos2s'], out1_is_sum=True,
+                            out0_lo=ws.get('roi_lo') if 'conv' not in self.exact_skip else None, out0_lo8=ws['xv_lo'], out1_lo8=ws['xk_lo'], R=R)
+            else:
+                o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=ws['pos2s'], out1_is_sum=True,
+                            out0_lo=ws['xv_lo'] if self.exact else None, out1_lo=ws['xk_lo'] if self.exact else None, R=R)
         if self.ablate_zero_lo and self.exact:
+            if self._lo8():
+                raise ValueError('ablate_zero_lo works on key16 lo rows: set lo8_rows = False')
             if 'v' in self.ablate_zero_lo and ws.get('xv_lo') is not None:
                 ws['xv_lo'].zero_()
             if 'k' in self.ablate_zero_lo and ws.get('xk_lo') is not None:
@@ -797,6 +813,10 @@ class HeadEngine:
                                x, ws['qpos'], None, outs=ws['outs'][i], Win_x3=W_[f'sa_in_wx{i + 1}'] if nxt else None,
                                b_in=W_[f'sa_in_b{i + 1}'] if nxt else None, qkv=ws['qkv'] if nxt else None, M=R)
 
+    def _lo8(self):
+        """Are the lo halves of the key / value rows e4m3 bytes (csrc/common.h "lo8")?  Not with the shared-tile kernel (its LDS-DMA tiles are key16 rows)."""
+        return bool(self.lo8_rows) and self.exact and not self.group_xattn
+
     def _grouped(self, ws):
         """Does this frame's cross attention run on shared key tiles (csrc/xattn_group.hip)?  Needs the group tables of the workspace (the training
         forward's own decoder workspace has none) and no debug output."""
@@ -892,7 +912,7 @@ class HeadEngine:
         # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
         gkey = (ptrs, 0 if payload is None else payload.data_ptr(), sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs, self.last_stage_heads,
-                self.xattn_waves, self.fuse_maps, self.fuse_xattn, self.group_xattn, self.pe_rows_in_waves, self.fold_sa0, self.masked_transpose, self.keep_sine_rows, self.force_nc, self.q_order,
+                self.xattn_waves, self.fuse_maps, self.fuse_xattn, self.group_xattn, self.lo8_rows, self.pe_rows_in_waves, self.fold_sa0, self.masked_transpose, self.keep_sine_rows, self.force_nc, self.q_order,
                 self.fork_qg, self.exact_skip, self.ablate_zero_lo, self.stop_before_decoder)   # load_state() re-allocates the weights; every route option of __init__ is in the key
         graphs = ws.setdefault('graphs', {})             # one graph per (input buffers, frame scalars): a producer that alternates between
         g = graphs.get(gkey)                             # a few static output buffers replays a few graphs, it does not re-capture

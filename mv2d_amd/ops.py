@@ -52,6 +52,31 @@ def _req16(t, name):
     _req(t, key16_dtype(), name)
 
 
+def _lo_fmt(*los):
+    """lo_fmt of include/mv2d_hip.h for a set of lo row arrays: 1 = e4m3 "lo8" rows (torch.uint8, 256 B per row), 0 = key16 rows (or none)."""
+    ts = [t for t in los if t is not None]
+    if ts and all(t.dtype == torch.uint8 for t in ts):
+        for t in ts:
+            _req(t, torch.uint8, 'lo8 rows')
+        return 1
+    for t in ts:
+        _req16(t, 'lo rows')
+    return 0
+
+
+LO8_SCALE = 4096.0            # csrc/common.h "lo8": byte = e4m3(key16_lo * 2^12)
+
+
+def lo8_decode(b):
+    """e4m3 "lo8" rows (uint8) -> the key16 lo rows they stand for (exact: every e4m3 value / 2^12 is an fp16 number or subnormal)."""
+    return (b.view(torch.float8_e4m3fn).float() / LO8_SCALE).to(key16_dtype())
+
+
+def lo8_encode(lo):
+    """key16 lo rows -> e4m3 "lo8" rows (uint8): round-to-nearest-even of lo * 2^12 clamped to +-448 -- what the kernels write (csrc/common.h lo8_pack4)."""
+    return (lo.float() * LO8_SCALE).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+
+
 def f32_to_key16(x, out=None, with_lo=False):
     """fp32 -> key16 (the key-side format); with_lo: returns (hi, lo) with x ~ hi + lo."""
     _req(x, torch.float32, 'x')
@@ -403,7 +428,8 @@ def pe_fused_x3(A1, Xmap, m_dev, wx, sine_tab, tab_period, pe=None, Xk=None, Xv=
     _req(row_index, torch.int32, 'row_index'); _req(m_dev, torch.int32, 'm_dev')
     for pair in (Xk, Xv):
         if pair is not None:
-            _req16(pair[0], 'hi'); _req16(pair[1], 'lo')
+            _req16(pair[0], 'hi')
+    lo_fmt = _lo_fmt(Xk[1] if Xk else None, Xv[1] if Xv else None)
     for k in ('w1a', 'w1b', 'wr', 'we'):
         _req(wx[k][0], q16_dtype(), k); _req(wx[k][1], q16_dtype(), k)
     M = A1.shape[0] if M is None else M
@@ -411,7 +437,7 @@ def pe_fused_x3(A1, Xmap, m_dev, wx, sine_tab, tab_period, pe=None, Xk=None, Xv=
     check(_lib.load().mv2d_pe_fused_x3(_p(A1), _p(Xmap), _p(row_index), _p(m_dev), M, _p(wx['w1a'][0]), _p(wx['w1a'][1]), _p(wx['b1a']),
                                        _p(wx['w1b'][0]), _p(wx['w1b'][1]), _p(wx['b1b']), _p(wx['wr'][0]), _p(wx['wr'][1]), _p(wx['br']),
                                        _p(wx['we'][0]), _p(wx['we'][1]), _p(wx['be']), _p(sine_tab), int(tab_period), _p(pe), _p(xk[0]), _p(xk[1]),
-                                       _p(xv[0]), _p(xv[1]), _stream()), 'mv2d_pe_fused_x3')
+                                       _p(xv[0]), _p(xv[1]), lo_fmt, _stream()), 'mv2d_pe_fused_x3')
     return pe
 
 
@@ -422,7 +448,8 @@ def pe_fused_x3b(A1, Xmap, m_dev, wx, sine_tab, tab_period, pe=None, Xk=None, Xv
     _req(row_index, torch.int32, 'row_index'); _req(m_dev, torch.int32, 'm_dev')
     for pair in (Xk, Xv):
         if pair is not None:
-            _req16(pair[0], 'hi'); _req16(pair[1], 'lo')
+            _req16(pair[0], 'hi')
+    lo_fmt = _lo_fmt(Xk[1] if Xk else None, Xv[1] if Xv else None)
     for k in ('w1a_p', 'w1b', 'wr_p', 'we'):
         _req(wx[k][0], q16_dtype(), k); _req(wx[k][1], q16_dtype(), k)
     M = A1.shape[0] if M is None else M
@@ -430,7 +457,7 @@ def pe_fused_x3b(A1, Xmap, m_dev, wx, sine_tab, tab_period, pe=None, Xk=None, Xv
     check(_lib.load().mv2d_pe_fused_x3b(_p(A1), _p(Xmap), _p(row_index), _p(m_dev), M, _p(wx['w1a_p'][0]), _p(wx['w1a_p'][1]), _p(wx['b1a']),
                                         _p(wx['w1b'][0]), _p(wx['w1b'][1]), _p(wx['b1b']), _p(wx['wr_p'][0]), _p(wx['wr_p'][1]), _p(wx['br']),
                                         _p(wx['we'][0]), _p(wx['we'][1]), _p(wx['be']), _p(sine_tab), int(tab_period), _p(pe), _p(xk[0]), _p(xk[1]),
-                                        _p(xv[0]), _p(xv[1]), _stream()), 'mv2d_pe_fused_x3b')
+                                        _p(xv[0]), _p(xv[1]), lo_fmt, _stream()), 'mv2d_pe_fused_x3b')
     return pe
 
 
@@ -595,8 +622,9 @@ def xattn_qmap(q, WA, Qt=None, R=None):
 
 def xattn_tile(Qt, Xk, Xv, row_ptr, col_idx, out=None, R=None, dbg_logits=None, empty_nan=True, waves=0, Xk_lo=None, Xv_lo=None, order=None):
     """Tile cross attention on the unprojected key / value rows: Qt from xattn_qmap, Xk / Xv [S,256] key16 -> z [R,8,256] fp32.
-    Xk_lo / Xv_lo: optional key16 remainders of the rows (index-exact route: fp32-class key side)."""
-    _req16(Qt, 'Qt'); _req16(Xk, 'Xk'); _req16(Xv, 'Xv'); _req16(Xk_lo, 'Xk_lo'); _req16(Xv_lo, 'Xv_lo')
+    Xk_lo / Xv_lo: optional remainders of the rows (index-exact route: fp32-class key side): key16 [S,256], or e4m3 "lo8" rows (uint8 [S,256])."""
+    _req16(Qt, 'Qt'); _req16(Xk, 'Xk'); _req16(Xv, 'Xv')
+    lo_fmt = _lo_fmt(Xk_lo, Xv_lo)
     _req(row_ptr, torch.int32, 'row_ptr'); _req(col_idx, torch.int32, 'col_idx'); _req(dbg_logits, torch.float32, 'dbg_logits')
     R = Qt.shape[0] if R is None else R
     if out is None:
@@ -604,7 +632,7 @@ def xattn_tile(Qt, Xk, Xv, row_ptr, col_idx, out=None, R=None, dbg_logits=None, 
     _req(order, torch.int32, 'order')
     check(_lib.load().mv2d_xattn_tile_fwd_ordered(_p(Qt), _p(Xk), _p(Xv), _p(Xk_lo), _p(Xv_lo), _p(row_ptr), _p(col_idx), _p(out), _p(dbg_logits),
                                                   dbg_logits.stride(0) if dbg_logits is not None else 0, R, 1 if empty_nan else 0, int(waves),
-                                                  _p(order), _stream()), 'mv2d_xattn_tile_fwd')
+                                                  _p(order), lo_fmt, _stream()), 'mv2d_xattn_tile_fwd')
     return out
 
 
@@ -614,13 +642,14 @@ def xattn_fused(q, WA, WB, bv, Xk, Xv, row_ptr, col_idx, out=None, R=None, empty
     _req(q, torch.float32, 'q'); _req(bv, torch.float32, 'bv'); _req(row_ptr, torch.int32, 'row_ptr'); _req(col_idx, torch.int32, 'col_idx')
     for t, n_ in ((WA[0], 'WA_hi'), (WA[1], 'WA_lo'), (WB[0], 'WB_hi'), (WB[1], 'WB_lo')):
         _req(t, q16_dtype(), n_)
-    _req16(Xk, 'Xk'); _req16(Xv, 'Xv'); _req16(Xk_lo, 'Xk_lo'); _req16(Xv_lo, 'Xv_lo'); _req(order, torch.int32, 'order')
+    _req16(Xk, 'Xk'); _req16(Xv, 'Xv'); _req(order, torch.int32, 'order')
+    lo_fmt = _lo_fmt(Xk_lo, Xv_lo)
     R = q.shape[0] if R is None else R
     if out is None:
         out = torch.empty((R, 256), device=q.device, dtype=torch.float32)
     _req(out, torch.float32, 'out')
     check(_lib.load().mv2d_xattn_fused_fwd(_p(q), _p(WA[0]), _p(WA[1]), _p(WB[0]), _p(WB[1]), _p(bv), _p(Xk), _p(Xv), _p(Xk_lo), _p(Xv_lo), _p(row_ptr),
-                                           _p(col_idx), _p(out), R, 1 if empty_nan else 0, _p(order), _stream()), 'mv2d_xattn_fused_fwd')
+                                           _p(col_idx), _p(out), R, 1 if empty_nan else 0, _p(order), lo_fmt, _stream()), 'mv2d_xattn_fused_fwd')
     return out
 
 
@@ -795,12 +824,14 @@ def posemb3d(ref, dim_t, out=None):
 
 
 def roi_align(map0, rois, H, W, *, map1=None, out0=None, out1=None, out0_f32=None, out1_f32=None, spatial_scale=1.0 / 16,
-              sampling_ratio=-1, map1_index=None, out1_is_sum=False, R=None, out0_lo=None, out1_lo=None):
+              sampling_ratio=-1, map1_index=None, out1_is_sum=False, R=None, out0_lo=None, out1_lo=None, out0_lo8=None, out1_lo8=None):
     _req(map0, torch.float32, 'map0'); _req(map1, torch.float32, 'map1'); _req(rois, torch.float32, 'rois')
     _req16(out0, 'out0'); _req16(out1, 'out1'); _req16(out0_lo, 'out0_lo'); _req16(out1_lo, 'out1_lo')
+    _req(out0_lo8, torch.uint8, 'out0_lo8'); _req(out1_lo8, torch.uint8, 'out1_lo8')
     check(_lib.load().mv2d_roi_align_ex(_p(map0), _p(map1), _p(rois), _p(out0), _p(out1), _p(out0_f32), _p(out1_f32),
                                         rois.shape[0] if R is None else R, H, W, map0.shape[-1], spatial_scale, sampling_ratio,
-                                        _p(map1_index), 1 if out1_is_sum else 0, _p(out0_lo), _p(out1_lo), _stream()), 'mv2d_roi_align')
+                                        _p(map1_index), 1 if out1_is_sum else 0, _p(out0_lo), _p(out1_lo), _p(out0_lo8), _p(out1_lo8), _stream()),
+          'mv2d_roi_align')
 
 
 def box_correlation(rois, view_start, trans, lin, depths, match, V, topk, pad_h, pad_w, max_per_view, sample_size=4,

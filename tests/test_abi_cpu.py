@@ -33,7 +33,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_error_reporting_without_gpu(lib):
-    assert lib.mv2d_abi_version() == 5
+    assert lib.mv2d_abi_version() == 6
     rc = lib.mv2d_gemm_f32(None, None, 0, None, None, 1, 1, 32, 32, 32, 1, 0, 1.0, 0.0, None, 0, 1, 0, 1, 0, 0, 0, 0, None)
     assert rc == -1
     assert b'mv2d_gemm_f32' in lib.mv2d_last_error()

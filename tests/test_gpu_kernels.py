@@ -454,6 +454,61 @@ def test_xattn_fused_equals_the_three_kernels(dev, R, S, dens, lo):
         assert torch.equal(out2.view(torch.int32), ref.view(torch.int32))
     if dens > 0:
         assert bool(torch.isnan(out[5]).all()) and bool(torch.isfinite(out[6:]).all())
+    if lo:
+        # round 6, e4m3 "lo8" rows (256-byte lo rows, csrc/common.h): the kernels decode the bytes to key16 in registers -- BITWISE the results of key16 lo
+        # rows that hold the decoded values, for the tile kernel (1, 2, 4 waves per query) and the fused one; and close to the unquantised rows
+        k8, v8 = ops.lo8_encode(Xk_lo), ops.lo8_encode(Xv_lo)
+        kd, vd = ops.lo8_decode(k8), ops.lo8_decode(v8)
+        assert float((kd.float() - Xk_lo.float()).abs().max()) <= float(Xk_lo.float().abs().max()) * 2.0 ** -4
+        Qt = ops.xattn_qmap(q, WA)
+        for waves in (1, 2, 4):
+            z8 = ops.xattn_tile(Qt, Xk, Xv, row_ptr, col, waves=waves, Xk_lo=k8, Xv_lo=v8)
+            zd = ops.xattn_tile(Qt, Xk, Xv, row_ptr, col, waves=waves, Xk_lo=kd, Xv_lo=vd)
+            assert torch.equal(z8.view(torch.int32), zd.view(torch.int32)), waves
+        o8 = ops.xattn_fused(q, WA, WB, bv, Xk, Xv, row_ptr, col, Xk_lo=k8, Xv_lo=v8)
+        od = ops.xattn_fused(q, WA, WB, bv, Xk, Xv, row_ptr, col, Xk_lo=kd, Xv_lo=vd)
+        assert torch.equal(o8.view(torch.int32), od.view(torch.int32))
+        assert torch.equal(o8.view(torch.int32), ops.xattn_ctxmap(ops.xattn_tile(Qt, Xk, Xv, row_ptr, col, waves=1, Xk_lo=k8, Xv_lo=v8), WB, bv, row_ptr).view(torch.int32))
+        fin = torch.isfinite(out)
+        # (against the unquantised lo rows: the logits of this test reach +-100 -- q[3] is scaled by 8 -- so their 2^-16 relative change is visible in the softmax;
+        #  the head's own logits are what tests/test_gpu_golden.py measures: class logits within 1.1e-6 of the reference's)
+        assert float((o8 - out)[fin].abs().max()) < 1e-3 * float(out[fin].abs().max())
+        with pytest.raises(Exception):
+            ops.xattn_fused(q, WA, WB, bv, Xk, Xv, row_ptr, col, Xk_lo=k8, Xv_lo=Xv_lo)          # mixed lo formats
+
+
+def test_lo8_row_format(dev):
+    """The e4m3 "lo8" conversions of csrc/common.h against torch's OCP e4m3: every byte decodes to fp16(e4m3 / 2^12) (subnormal results kept, the
+    two NaN bytes stay NaN), and the row producers (RoIAlign outputs; the PE kernels: test_pe_fused_x3_kernel) write round-to-nearest-even bytes of
+    their key16 lo halves, saturating at +-448."""
+    from mv2d_amd import ops
+    k16 = ops.key16_dtype()
+    if k16 != torch.float16:
+        pytest.skip('lo8 rows need the fp16 key format')
+    # decode through the attention kernel: one query, one head-map = identity is more plumbing than it is worth; the producers + ops.lo8_decode pin the
+    # format, tools/probes/fp8_probe.hip checks the two instructions exhaustively.  Here: RoIAlign's lo8 outputs == lo8_encode of its key16 lo outputs.
+    H, W, R = 24, 40, 37
+    g = torch.Generator().manual_seed(77)
+    m0 = (torch.randn((2 * H * W, 256), generator=g) * torch.logspace(-3, 2.6, 256)).to(dev)       # magnitudes 1e-3 .. 400: subnormal and saturated lo bytes
+    m1 = torch.randn((2 * H * W, 256), generator=g).to(dev)
+    x1 = torch.rand(R, generator=g) * (W * 16 - 64); y1 = torch.rand(R, generator=g) * (H * 16 - 64)
+    rois = torch.stack([torch.randint(0, 2, (R,), generator=g).float(), x1, y1, x1 + 8 + torch.rand(R, generator=g) * 120, y1 + 8 + torch.rand(R, generator=g) * 120], 1).to(dev)
+    o = {n_: torch.zeros((R, 49, 256), device=dev, dtype=k16) for n_ in ('a', 'a_lo', 'b', 'b_lo', 'a2', 'b2', 'a2_lo')}
+    o8 = {n_: torch.zeros((R, 49, 256), device=dev, dtype=torch.uint8) for n_ in ('a', 'b')}
+    ops.roi_align(m0, rois, H, W, map1=m1, out0=o['a'], out1=o['b'], out1_is_sum=True, out0_lo=o['a_lo'], out1_lo=o['b_lo'])
+    ops.roi_align(m0, rois, H, W, map1=m1, out0=o['a2'], out1=o['b2'], out1_is_sum=True, out0_lo=o['a2_lo'], out0_lo8=o8['a'], out1_lo8=o8['b'])
+    torch.cuda.synchronize()
+    assert torch.equal(o['a'], o['a2']) and torch.equal(o['b'], o['b2']) and torch.equal(o['a_lo'], o['a2_lo'])
+    for n_ in ('a', 'b'):
+        want = ops.lo8_encode(o[n_ + '_lo'])
+        assert torch.equal(o8[n_], want), int((o8[n_] != want).sum())
+        dec = ops.lo8_decode(o8[n_]).float()
+        lo = o[n_ + '_lo'].float()
+        # relative 2^-4 in the normal range of the format, absolute 2^-22 below it; the largest magnitudes saturate (|lo| * 2^12 > 448)
+        sat = lo.abs() * 4096.0 > 448.0
+        assert bool((((dec - lo).abs() <= lo.abs() * 2.0 ** -4 + 2.0 ** -22) | sat).all())
+        assert int(((o8[n_] & 0x7f) < 8).sum()) > 0                                    # subnormal bytes occur
+    assert bool((ops.lo8_decode(o8['a'])[(o['a_lo'].float().abs() * 4096.0 > 460.0)].float().abs() == 448.0 / 4096.0).all())
 
 
 def _rect_pattern(R, S, seed, n_samples):
@@ -1045,6 +1100,14 @@ def test_pe_fused_x3_kernel(dev, M, use_mdev, use_ri, rows):
         nop = [tuple(torch.zeros((M, 256), device=dev, dtype=k16) for _ in range(2)) for _ in range(2)]
         ops.pe_fused_x3b(A1, Xmap, md, wx, tab, period, Xk=nop[0], Xv=nop[1], M=M, row_index=ri)          # (T path: no pe output)
         assert torch.equal(nop[0][0].view(torch.int16), pairs[0][0].view(torch.int16))
+        if k16 == torch.float16:
+            # round 6: the lo halves as e4m3 "lo8" rows (256 B): the bytes are the encoding of the key16 lo halves, the hi rows are untouched; both kernels
+            for fn in (ops.pe_fused_x3, ops.pe_fused_x3b):
+                p8 = [(torch.zeros((M, 256), device=dev, dtype=k16), torch.zeros((M, 256), device=dev, dtype=torch.uint8)) for _ in range(2)]
+                fn(A1, Xmap, md, wx, tab, period, Xk=p8[0], Xv=p8[1], M=M, row_index=ri)
+                for a, b in zip(p8, pairs):
+                    assert torch.equal(a[0].view(torch.int16), b[0].view(torch.int16))
+                    assert torch.equal(a[1][:Mv], ops.lo8_encode(b[1][:Mv])) and not a[1][Mv:].any()
 
 
 def test_attn_out_fused_x3(dev):

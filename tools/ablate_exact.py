@@ -26,6 +26,7 @@ for name in (sys.argv[1:] or ['cfg2_s', 'cfg3_t', 'cfg5_t', 'cfg2_s_nc6']):
     for label, skip in variants:
         eng = HeadEngine(sd, prob['kind'], dev, num_views=prob['views_per_frame'], exact=skip is not None)
         if isinstance(skip, str):
+            eng.lo8_rows = False                                     # (the emulations rewrite key16 lo rows)
             eng.ablate_zero_lo = frozenset({'8', '8z'}) if skip == 'f8z' else frozenset({'8'}) if skip == 'f8' else frozenset({skip[-1]})
         elif skip is not None:
             eng.exact_skip = skip

@@ -20,6 +20,7 @@ init = HeadEngine.__init__
 def patched(self, *a, **k):
     init(self, *a, **k)
     if self.exact:
+        self.lo8_rows = False                                        # (the emulation rewrites key16 lo rows)
         self.ablate_zero_lo = frozenset({'8', mode})
 
 
