@@ -691,7 +691,8 @@ def main():
         # algorithmic HBM bytes: every key row that some query reads, once (K and V, key16 = 2 B per element) + Qt in + z out.  Rows read by several queries
         # (T path: 2.9 per row) are counted once here — the repeats are L2 / Infinity Cache traffic; `gathered_bytes` counts them all.
         n_rows = min(nnz, S if kind == 'T' else R * 49)
-        b_el = 4 if xlo else 2                                                      # bytes per key / value element: fp16 hi + lo pair (fp32-class) or one fp16
+        lo8 = bool(xlo) and xlo['Xk_lo'].dtype == torch.uint8
+        b_el = (3 if lo8 else 4) if xlo else 2                                      # bytes per key / value element: fp16 hi + e4m3 lo (round 6), fp16 hi + fp16 lo, or one fp16
         row_b = 2 * 256 * b_el                                                      # K + V row
         own = 0 if fused else R * (16 * 256 * 2 + 8 * 256 * 4)                      # Qt in + z out: intermediates of the three-launch decomposition (none when fused)
         # SURVEY 8(d) per layer: read X_k, X_v (2 S C b) + query state in / out (2 Q C 4).  `frac` follows from these bytes ALONE (round 4 also
@@ -711,11 +712,13 @@ def main():
                                    'launch_ms_rocprof_committed (average duration of the kernel in the committed rocprofv3 kernel trace of the default four-stream bench, profiles/)')
         xattn['frac_incl_own_intermediates'] = round(gbs(n_rows * row_b + own) / PEAK_HBM_GBS, 4)
         xattn['frac_at_survey_b2'] = round(gbs(n_rows * 2 * 256 * 2 + 2 * R * 256 * 4) / PEAK_HBM_GBS, 4)
+        xattn['frac_at_b4'] = round(gbs(n_rows * 2 * 256 * 4 + 2 * R * 256 * 4) / PEAK_HBM_GBS, 4)
         xattn['gathered_bytes_per_launch'] = int(x_gathered)
         xattn['gathered_gbs'] = round(x_gathered / (x_ms * 1e-3) / 1e9, 1)
-        xattn['note'] = ('bytes_per_launch = SURVEY 8(d): K and V rows read by at least one query, once (b bytes per element: 4 = fp16 hi + lo pair of the '
-                         'index-exact route, the width the fp32 reference reads; 2 = key16 mode) + the query state in / out (2 Q C 4); frac_at_survey_b2 = the '
-                         'same time priced at the b = 2 SURVEY 8(d) assumed; frac_incl_own_intermediates also counts Qt in + z out (8 KB each per query); '
+        xattn['note'] = ('bytes_per_launch = SURVEY 8(d): K and V rows read by at least one query, once (b bytes per element: 3 = fp16 hi + e4m3 lo of the '
+                         'index-exact route since round 6 -- the bytes this kernel has to move; 4 = fp16 hi + lo pairs (lo8_rows = False, rounds 3-5), the width the '
+                         'fp32 reference reads; 2 = key16 mode) + the query state in / out (2 Q C 4); frac_at_survey_b2 / frac_at_b4 = the same time priced at the '
+                         'b = 2 SURVEY 8(d) assumed / at the fp32 reference\'s b = 4 (what rounds 3-5 quoted as frac); frac_incl_own_intermediates also counts Qt in + z out (8 KB each per query); '
                          'gathered_bytes_per_launch = the rows of every allowed (query, key) pair (repeats are served by L2 / Infinity Cache)')
         stage_roofline['xattn_fused' if fused else 'xattn_tile'] = xattn
     # the dominant kernel = the one with the most time per step (launch duration x launches per step)

@@ -25,6 +25,9 @@
 #ifndef MV2D_XF_QB_DEFAULT
 #define MV2D_XF_QB_DEFAULT 8
 #endif
+#ifndef MV2D_XF_PIPE
+#define MV2D_XF_PIPE 0          // 1: e4m3 lo rows, the key rows of tile t + 1 requested in front of tile t's arithmetic -- measured SLOWER (see the loop), off
+#endif
 
 #ifdef MV2D_XF_TRACE
 __device__ long long g_xf_trace[32];
@@ -114,6 +117,7 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
     const int beg = rbeg[wave], end = rend[wave];
     const int ntile = wave < nq ? (end - beg + 15) >> 4 : 0;          // (waves beyond the block's queries: no tiles; their z / l are never read)
     int idx_next = ntile > 0 ? col_idx[min(beg + n, end - 1)] : 0;
+    int idx_nx1 = (XLO == 2 && MV2D_XF_PIPE && ntile > 1) ? col_idx[min(beg + 16 + n, end - 1)] : 0;      // (pipelined tile loop: the indices run two tiles ahead)
     xf_u32x4 kreg0[8], klo0[XLO == 1 ? 8 : 1];
     xf_u32x2 klo0b[XLO == 2 ? 8 : 1];
     auto load_k0 = [&](const unsigned short* K_, int myidx, xf_u32x4 (&dst)[8]) {
@@ -132,7 +136,18 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
         }
     };
     // ---------------------------------------------------------------- phase A: query maps, wave = head
+#ifdef MV2D_XF_NOMAPS      // timing experiment: the tile loops alone (no map phases, garbage results).  Round 6, e4m3 lo rows, idle GPU: 76.4 us per cfg2_s launch
+                           // against 99.3 with the maps (cfg2_s_nc6: 153.6 / 178.4): the gathers alone move their 371 MB at 4.86 TB/s -- the rate every row-gather
+                           // kernel of this library tops out at (0.77 of the 6.3 TB/s a streaming read reaches) -- and the two map phases cost 23-25 us per launch
+    if (ntile > 0) {
+        load_k0(Xk, idx_next, kreg0);
+        if constexpr (XLO == 1) load_k0(Xk_lo, idx_next, klo0);
+        if constexpr (XLO == 2) load_k8(Xk_lo, idx_next, klo0b);
+    }
+    for (int h = wave; h < 0; h += QB) {
+#else
     for (int h = wave; h < HEADS; h += QB) {
+#endif
         const int r = rq[n & (QB - 1)];
         const float* qp = q + (long long)r * C + 32 * h + 8 * g;
         XfFrag bh, bl;
@@ -323,6 +338,37 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
             if constexpr (XLO == 1) store_k(kt2, klo0);
             if constexpr (XLO == 2) store_k8(kt2, klo0b);
         }
+        if constexpr (XLO == 2 && MV2D_XF_PIPE != 0) {
+            // Round 6, e4m3 lo rows: a tile's rows are 48 + 48 staging registers instead of 64 + 64, so the key rows of tile t + 1 (hi + lo: 16 loads) are
+            // requested right behind the value rows of tile t and travel under tile t's logits, softmax and P.V; they go to LDS when the tile is done with
+            // its own.  One exposed round trip per tile (the value rows, partly under the logits) instead of two; the indices run two tiles ahead.
+            // MEASURED (same box, idle GPU): 110.6 us per cfg2_s launch against 98.6 us for the two-phase order below, 194.8 against 178.3 at cfg2_s_nc6 (256
+            // registers with 16 loop-invariant values in scratch) -- like round 4's software pipelining of the tile kernel, more rows in flight per wave buy
+            // nothing: the launch sits at what the memory system delivers for row gathers, not at a per-wave latency chain.  Compiled out (MV2D_XF_PIPE=1).
+            int idx_cur = idx_next, idx_nx = idx_nx1;
+            for (int tt = 0; tt < ntile; ++tt) {
+                const int idx_nn = tt + 2 < ntile ? col_idx[min(beg + 16 * (tt + 2) + n, end - 1)] : 0;
+                xf_u32x4 vreg[4][2], kreg[8];
+                xf_u32x2 vlo[4][2], klo[8];
+                load_v(Xv, idx_cur, vreg);
+                load_v8(Xv_lo, idx_cur, vlo);
+                const bool more = tt + 1 < ntile;
+                if (more) {
+                    load_k(Xk, idx_nx, kreg);
+                    load_k8(Xk_lo, idx_nx, klo);
+                }
+                __builtin_amdgcn_wave_barrier();
+                XF_STAMP(3 + 2 * min(tt, 5));
+                compute(tt, vreg, vlo);
+                XF_STAMP(4 + 2 * min(tt, 5));
+                if (more) {
+                    store_k(kt, kreg);
+                    store_k8(kt2, klo);
+                }
+                idx_cur = idx_nx;
+                idx_nx = idx_nn;
+            }
+        } else
         for (int tt = 0; tt < ntile; ++tt) {
             const int myidx = idx_next;
             if (tt + 1 < ntile) idx_next = col_idx[min(beg + 16 * (tt + 1) + n, end - 1)];
@@ -407,7 +453,12 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
     __syncthreads();
     XF_STAMP(16);
     // ---------------------------------------------------------------- phase C: context maps, wave = head
+#ifdef MV2D_XF_NOMAPS
+    if (tid == 0) ctx[(long long)r * C] = reinterpret_cast<const float*>(smem)[lane];
+    for (int h = wave; h < 0; h += QB) {
+#else
     for (int h = wave; h < HEADS; h += QB) {
+#endif
         const int j = n & (QB - 1);
         const float* zp = reinterpret_cast<const float*>(smem + j * WAVE_LDS) + h * C + 8 * g;
         // (xattn_tile_kernel normalises when it merges its waves: num * rcp(den), the factor of the single wave being exp2(0) = 1)
