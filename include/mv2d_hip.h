@@ -112,11 +112,15 @@ int mv2d_pe_fused_tab2(const void* A1, const void* Xfb, const float* Xf32, const
  * mv2d_pack_wfrag_bf16; pe [M,256] fp32 (optional) = sine_tab[position] + position_encoder(A1) * gate; Xk_hi / Xk_lo / Xv_hi / Xv_lo [M,256] key16
  * (all four or none): key rows pe + feat and value rows feat as hi + lo pairs (what mv2d_xattn_tile_fwd gathers on that route).
  * lo_fmt (round 6, ABI 6): 0 = the lo outputs are key16 rows [M,256] (512 B); 1 = "lo8" rows [M,256] of BYTES: OCP e4m3 (bias 7, max 448) of
- * key16_lo * 2^12, round-to-nearest-even, saturating (csrc/common.h) -- 256 B per row, what the cross attention gathers by default. */
+ * key16_lo * 2^12, round-to-nearest-even, saturating (csrc/common.h) -- 256 B per row, what the cross attention gathers by default.
+ * pe_at_index (ABI 6): 1 = pe row m is written at row row_index[m] of `pe` -- a position-indexed map that mv2d_roi_align_ex reads without the
+ * position -> row table (one dependent load less per bilinear tap); rows no m lists keep what they held (the caller zero-fills the map once).
+ * lo8_flag (device int, may be NULL): |= 1 when a remainder leaves the e4m3 range (|x| beyond ~224: that element keeps key16 precision only). */
 int mv2d_pe_fused_x3(const float* A1, const float* Xmap, const int* row_index, const int* m_dev, int M,
                      const void* W1a_hi, const void* W1a_lo, const float* b1a, const void* W1b_hi, const void* W1b_lo, const float* b1b,
                      const void* Wr_hi, const void* Wr_lo, const float* br, const void* We_hi, const void* We_lo, const float* be,
-                     const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, int lo_fmt, void* stream);
+                     const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, int lo_fmt, int pe_at_index,
+                     int* lo8_flag, void* stream);
 /* The same block on the second shape of the kernel (round 6, csrc/pe_x3b.hip): a wave owns 16 rows through both layers of each MLP, the hidden layer
  * stays in registers (no LDS image, no barrier between the layers), the weights go through a 4-deep LDS ring (LDS-DMA) shared by the 8 waves of a 128-row
  * block, two waves per SIMD.  Same operands EXCEPT that W1a and Wr (the first layers) are packed from the weight with its rows in the order
@@ -124,7 +128,8 @@ int mv2d_pe_fused_x3(const float* A1, const float* Xmap, const int* row_index, c
 int mv2d_pe_fused_x3b(const float* A1, const float* Xmap, const int* row_index, const int* m_dev, int M,
                      const void* W1a_hi, const void* W1a_lo, const float* b1a, const void* W1b_hi, const void* W1b_lo, const float* b1b,
                      const void* Wr_hi, const void* Wr_lo, const float* br, const void* We_hi, const void* We_lo, const float* be,
-                     const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, int lo_fmt, void* stream);
+                     const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, int lo_fmt, int pe_at_index,
+                     int* lo8_flag, void* stream);
 
 /* QueryGenerator shared conv + pooling fused, one block per RoI (RH/utils/query_generator.py:298-304,322-331,352-358):
  * out[r, n] = mean over the 49 cells of relu(conv3x3(roi_feat[r])[cell, n] + bias[n]).  roi_feat [R,49,256] key16 (cell-major),
@@ -425,10 +430,10 @@ int mv2d_roi_align(const float* map0, const float* map1, const float* rois, void
                    const int* map1_index, int out1_is_sum, void* stream);
 /* mv2d_roi_align with key16 REMAINDER outputs: out0_lo / out1_lo = key16(x - key16(x)) next to out0 / out1 (x ~ hi + lo, ~2^-22 relative):
  * the fp32-class key / value / conv-input rows of the index-exact route.  out0_lo8 / out1_lo8 (optional, ABI 6): the same remainders as e4m3 "lo8"
- * rows [R,49,256] bytes (see mv2d_pe_fused_x3). */
+ * rows [R,49,256] bytes; lo8_flag: saturation report (see mv2d_pe_fused_x3). */
 int mv2d_roi_align_ex(const float* map0, const float* map1, const float* rois, void* out0, void* out1, float* out0_f32, float* out1_f32,
                       int R, int H, int W, int channels, float spatial_scale, int sampling_ratio, const int* map1_index, int out1_is_sum,
-                      void* out0_lo, void* out1_lo, void* out0_lo8, void* out1_lo8, void* stream);
+                      void* out0_lo, void* out1_lo, void* out0_lo8, void* out1_lo8, int* lo8_flag, void* stream);
 
 /* BoxCorrelation.epipolar_in_box, 'topk_matched:k:thr:ratio' (RH/utils/box_correlation.py:196-398).
  * V = views per sample; view_start[n_views+1]: first RoI of each view; trans [n_views,V,16] fp64 = lidar2img[b] @ inv(lidar2img[a])

@@ -39,8 +39,8 @@ SIGNATURES = {
     'mv2d_split3_rows': (I, [P, P, P, I, I, P, P]),
     'mv2d_pe_fused_tab': (I, [P, P, P, P, P, I] + [P] * 9 + [I, P, P, P]),
     'mv2d_pe_fused_tab2': (I, [P, P, P, P, P, I] + [P] * 9 + [I, P, P, I, P]),
-    'mv2d_pe_fused_x3': (I, [P, P, P, P, I] + [P] * 13 + [I] + [P] * 5 + [I, P]),
-    'mv2d_pe_fused_x3b': (I, [P, P, P, P, I] + [P] * 13 + [I] + [P] * 5 + [I, P]),
+    'mv2d_pe_fused_x3': (I, [P, P, P, P, I] + [P] * 13 + [I] + [P] * 5 + [I, I, P, P]),
+    'mv2d_pe_fused_x3b': (I, [P, P, P, P, I] + [P] * 13 + [I] + [P] * 5 + [I, I, P, P]),
     'mv2d_key16_format': (I, []),
     'mv2d_f32_to_key16': (I, [P, P, P, LL, P]),
     'mv2d_split_rows_key16': (I, [P, P, P, P, I, I, P, P]),
@@ -98,7 +98,7 @@ SIGNATURES = {
     'mv2d_lidar2img_inverse': (I, [P, P, P, I, P]),
     'mv2d_posemb3d': (I, [P, P, P, I, P]),
     'mv2d_roi_align': (I, [P, P, P, P, P, P, P, I, I, I, I, F, I, P, I, P]),
-    'mv2d_roi_align_ex': (I, [P, P, P, P, P, P, P, I, I, I, I, F, I, P, I, P, P, P, P, P]),
+    'mv2d_roi_align_ex': (I, [P, P, P, P, P, P, P, I, I, I, I, F, I, P, I, P, P, P, P, P, P]),
     'mv2d_box_correlation': (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, F, F, F, I, P]),
     'mv2d_csr_workspace_bytes': (LL, [I, I, I, I]),
     'mv2d_mask_compact': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, I, P]),

@@ -182,6 +182,13 @@ __device__ __forceinline__ unsigned int lo8_pack4(unsigned int lo01, unsigned in
     e = __builtin_amdgcn_cvt_pk_fp8_f32(lo8_clamp(k16_lo_of_pair(lo23) * 4096.f), lo8_clamp(k16_hi_of_pair(lo23) * 4096.f), e, true);
     return (unsigned int)e;
 }
+// the same, and *flag |= 1 (device memory, may be NULL) when one of the four remainders leaves the e4m3 range (|lo| 2^12 > 448, i.e. |x| beyond ~224: that
+// element keeps its hi half's precision only) -- the engine reports it (HeadEngine._check_capacity) instead of degrading silently
+__device__ __forceinline__ unsigned int lo8_pack4_flag(unsigned int lo01, unsigned int lo23, int* flag) {
+    const float a = k16_lo_of_pair(lo01) * 4096.f, b = k16_hi_of_pair(lo01) * 4096.f, c = k16_lo_of_pair(lo23) * 4096.f, d = k16_hi_of_pair(lo23) * 4096.f;
+    if (flag && fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d))) > 448.f) atomicOr(flag, 1);
+    return lo8_pack4(lo01, lo23);
+}
 template <int W>
 __device__ __forceinline__ unsigned int lo8_pair(unsigned int src) {
     typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_cv;

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
                                                         float spatial_scale, int sampling_ratio, const int* __restrict__ map1_index,
                                                         int out1_is_sum, int R, unsigned short* __restrict__ out0_lo,
                                                         unsigned short* __restrict__ out1_lo, unsigned char* __restrict__ out0_lo8,
-                                                        unsigned char* __restrict__ out1_lo8) {
+                                                        unsigned char* __restrict__ out1_lo8, int* __restrict__ lo8_flag) {
     // one block per RoI and bin row; wave w takes the bins w, w + 4 of the row, lane l the channels 4l .. 4l+3: every
     // bilinear tap is one 16-byte load per lane (a full 1 KB row per wave), every output one 8-byte (key16) / 16-byte (fp32) store.
     // XCD-aware block map (block b runs on XCD b % 8): the 7 bin rows of a RoI tap overlapping map rows, so they take consecutive slots
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
                 split_k16x2(t.z, t.w, hh.y, ll.y);
                 *reinterpret_cast<uint2*>(hi + o) = hh;
                 if (lo) *reinterpret_cast<uint2*>(lo + o) = ll;
-                if (lo8) *reinterpret_cast<unsigned int*>(lo8 + o) = lo8_pack4(ll.x, ll.y);
+                if (lo8) *reinterpret_cast<unsigned int*>(lo8 + o) = lo8_pack4_flag(ll.x, ll.y, lo8_flag);
             } else {
                 *reinterpret_cast<uint2*>(hi + o) = make_uint2(pack_k16x2(t.x, t.y), pack_k16x2(t.z, t.w));
             }
@@ -1229,14 +1229,14 @@ extern "C" int mv2d_posemb3d(const float* ref, const float* dim_t, float* posemb
 
 extern "C" int mv2d_roi_align_ex(const float* map0, const float* map1, const float* rois, void* out0, void* out1, float* out0_f32,
                                  float* out1_f32, int R, int H, int W, int channels, float spatial_scale, int sampling_ratio,
-                                 const int* map1_index, int out1_is_sum, void* out0_lo, void* out1_lo, void* out0_lo8, void* out1_lo8, void* stream) {
+                                 const int* map1_index, int out1_is_sum, void* out0_lo, void* out1_lo, void* out0_lo8, void* out1_lo8, int* lo8_flag, void* stream) {
     MV2D_CHECK_ARG(map0 && rois && channels == C, "mv2d_roi_align: needs 256-channel position-major maps");
     MV2D_CHECK_ARG(out0 || out0_f32, "mv2d_roi_align: no output");
     MV2D_CHECK_ARG((!(out0_lo || out0_lo8) || out0) && (!(out1_lo || out1_lo8) || out1), "mv2d_roi_align_ex: a lo output needs its key16 (hi) output");
     if (R == 0) return MV2D_OK;
     hipLaunchKernelGGL(roi_align_kernel, dim3(56 * cdiv(R, 8)), dim3(256), 0, (hipStream_t)stream, map0, map1, rois, (unsigned short*)out0,
                        (unsigned short*)out1, out0_f32, out1_f32, H, W, spatial_scale, sampling_ratio, map1_index, out1_is_sum, R,
-                       (unsigned short*)out0_lo, (unsigned short*)out1_lo, (unsigned char*)out0_lo8, (unsigned char*)out1_lo8);
+                       (unsigned short*)out0_lo, (unsigned short*)out1_lo, (unsigned char*)out0_lo8, (unsigned char*)out1_lo8, lo8_flag);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
 }
@@ -1245,7 +1245,7 @@ extern "C" int mv2d_roi_align(const float* map0, const float* map1, const float*
                               float* out1_f32, int R, int H, int W, int channels, float spatial_scale, int sampling_ratio,
                               const int* map1_index, int out1_is_sum, void* stream) {
     return mv2d_roi_align_ex(map0, map1, rois, out0, out1, out0_f32, out1_f32, R, H, W, channels, spatial_scale, sampling_ratio, map1_index,
-                             out1_is_sum, nullptr, nullptr, nullptr, nullptr, stream);
+                             out1_is_sum, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int mv2d_roi_align_bwd(const float* grad_out, const float* rois, float* grad_map, const int* index, int R, int H, int W,

@@ -48,6 +48,8 @@ struct PeX3Params {
     const float* sine_tab; int tab_period;
     float* pe; unsigned short* Xk_hi; unsigned short* Xk_lo; unsigned short* Xv_hi; unsigned short* Xv_lo;
     int lo8;                                                 // the lo row outputs are 256-byte e4m3 rows (common.h "lo8")
+    int* lo8_flag;                                           // |= 1 when a lo remainder leaves the e4m3 range (may be NULL)
+    int pe_at_index;                                         // pe row m is written at row row_index[m] (a position-indexed map) instead of row m
 };
 
 // ---- the 72 k-steps of a block as one compile-time schedule (pe_tab96.hip): parts 0..3 = hidden columns 256 p .. of the frustum MLP
@@ -169,6 +171,9 @@ struct Stage {
     static_assert(PIECES % NTHR == 0, "");
     float4 v[PER];
     __device__ __forceinline__ void load(const float* __restrict__ src, long long ld, const int* __restrict__ ridx, int m0, int M, int tid) {
+        // all row indices first, then all rows: written as one loop, the compiler waited for index i AND row i - 1 (vmcnt(0)) in front of every row -- PER
+        // dependent round trips per block instead of two (round 6, tools/isa_waits.sh)
+#ifdef MV2D_PX_ROUND5_STAGE      // (timing A/B: the round-5 form)
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int c = tid + NTHR * i, row = c / (2 * NCH), piece = c - row * (2 * NCH);
@@ -176,6 +181,20 @@ struct Stage {
             const long long r = ridx ? ridx[m] : m;
             v[i] = *reinterpret_cast<const float4*>(src + r * ld + piece * 4);
         }
+#else
+        int r[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = tid + NTHR * i, row = c / (2 * NCH);
+            const int m = min(m0 + row, M - 1);
+            r[i] = ridx ? ridx[m] : m;
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = tid + NTHR * i, row = c / (2 * NCH), piece = c - row * (2 * NCH);
+            v[i] = *reinterpret_cast<const float4*>(src + (long long)r[i] * ld + piece * 4);
+        }
+#endif
     }
     __device__ __forceinline__ void commit(unsigned char* Lh, unsigned char* Ll, int tid) const {
 #pragma unroll
@@ -274,6 +293,9 @@ __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
     // under the MFMAs of layer 1 (stamps of the first version: 22 k of a block's 145 k cycles waited for them right here)
     Stage<32> fs;
     fs.load(p.Xmap, C, p.row_index, m0, M, tid);
+#ifndef MV2D_PX_ROUND5_STAGE
+    __builtin_amdgcn_sched_barrier(0);                 // (without it hipcc sinks the 16 row loads to fs.commit below: 16 dependent round trips per block, tools/isa_waits.sh)
+#endif
 #if MV2D_PX_TOUCH
     asm volatile("" ::"v"(touch0), "v"(touch1));      // the touch loads are complete at the latest here (their lines sit in L2 for the loads above)
 #endif
@@ -367,19 +389,19 @@ __global__ __launch_bounds__(NTHR, 1) void pe_x3_kernel(PeX3Params p) {
             const float4 tv = tvq[k];
             v = make_float4(v.x + tv.x, v.y + tv.y, v.z + tv.z, v.w + tv.w);
             if (m < M) {
-                if (p.pe) *reinterpret_cast<float4*>(p.pe + (long long)m * C + gcol) = v;
+                if (p.pe) *reinterpret_cast<float4*>(p.pe + (long long)(p.pe_at_index ? ri[k] : m) * C + gcol) = v;
                 if (rows16) {
                     const float4 f = fvq[k];
                     uint2 h, l;
                     split_k16x2(v.x + f.x, v.y + f.y, h.x, l.x);
                     split_k16x2(v.z + f.z, v.w + f.w, h.y, l.y);
                     *reinterpret_cast<uint2*>(p.Xk_hi + (long long)m * C + gcol) = h;
-                    if (p.lo8) *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(p.Xk_lo) + (long long)m * C + gcol) = lo8_pack4(l.x, l.y);
+                    if (p.lo8) *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(p.Xk_lo) + (long long)m * C + gcol) = lo8_pack4_flag(l.x, l.y, p.lo8_flag);
                     else *reinterpret_cast<uint2*>(p.Xk_lo + (long long)m * C + gcol) = l;
                     split_k16x2(f.x, f.y, h.x, l.x);
                     split_k16x2(f.z, f.w, h.y, l.y);
                     *reinterpret_cast<uint2*>(p.Xv_hi + (long long)m * C + gcol) = h;
-                    if (p.lo8) *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(p.Xv_lo) + (long long)m * C + gcol) = lo8_pack4(l.x, l.y);
+                    if (p.lo8) *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(p.Xv_lo) + (long long)m * C + gcol) = lo8_pack4_flag(l.x, l.y, p.lo8_flag);
                     else *reinterpret_cast<uint2*>(p.Xv_lo + (long long)m * C + gcol) = l;
                 }
             }
@@ -399,10 +421,11 @@ extern "C" int mv2d_px_trace_read(long long* host, int n) { return hipMemcpyFrom
 extern "C" int mv2d_pe_fused_x3(const float* A1, const float* Xmap, const int* row_index, const int* m_dev, int M,
                                 const void* W1a_hi, const void* W1a_lo, const float* b1a, const void* W1b_hi, const void* W1b_lo, const float* b1b,
                                 const void* Wr_hi, const void* Wr_lo, const float* br, const void* We_hi, const void* We_lo, const float* be,
-                                const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, int lo_fmt, void* stream) {
+                                const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, int lo_fmt, int pe_at_index, int* lo8_flag, void* stream) {
     MV2D_CHECK_ARG(A1 && Xmap && W1a_hi && W1a_lo && b1a && W1b_hi && W1b_lo && b1b && Wr_hi && Wr_lo && br && We_hi && We_lo && be && sine_tab,
                    "mv2d_pe_fused_x3: null pointer");
     MV2D_CHECK_ARG(pe || Xk_hi, "mv2d_pe_fused_x3: no output");
+    MV2D_CHECK_ARG(!pe_at_index || (pe && row_index), "mv2d_pe_fused_x3: pe_at_index needs pe and row_index");
     MV2D_CHECK_ARG((Xk_hi != nullptr) == (Xk_lo != nullptr) && (Xk_hi != nullptr) == (Xv_hi != nullptr) && (Xk_hi != nullptr) == (Xv_lo != nullptr),
                    "mv2d_pe_fused_x3: the four key / value row outputs come together");
     MV2D_CHECK_ARG(M >= 0 && tab_period > 0, "mv2d_pe_fused_x3: M must be >= 0 and tab_period > 0");
@@ -412,7 +435,7 @@ extern "C" int mv2d_pe_fused_x3(const float* A1, const float* Xmap, const int* r
     PeX3Params p{A1, Xmap, row_index, m_dev, M, (const unsigned short*)W1a_hi, (const unsigned short*)W1a_lo, b1a, (const unsigned short*)W1b_hi,
                  (const unsigned short*)W1b_lo, b1b, (const unsigned short*)Wr_hi, (const unsigned short*)Wr_lo, br, (const unsigned short*)We_hi,
                  (const unsigned short*)We_lo, be, sine_tab, tab_period, pe, (unsigned short*)Xk_hi, (unsigned short*)Xk_lo, (unsigned short*)Xv_hi,
-                 (unsigned short*)Xv_lo, lo_fmt};
+                 (unsigned short*)Xv_lo, lo_fmt, lo8_flag, pe_at_index};
     hipLaunchKernelGGL(pe_x3_kernel, dim3(cdiv(M, BM)), dim3(NTHR), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;

@@ -42,6 +42,8 @@ struct PeX3bParams {
     const float* sine_tab; int tab_period;
     float* pe; unsigned short* Xk_hi; unsigned short* Xk_lo; unsigned short* Xv_hi; unsigned short* Xv_lo;
     int lo8;                                                 // the lo row outputs are 256-byte e4m3 rows (common.h "lo8")
+    int* lo8_flag;                                           // |= 1 when a lo remainder leaves the e4m3 range (may be NULL)
+    int pe_at_index;                                         // pe row m is written at row row_index[m] (a position-indexed map) instead of row m
 };
 
 // ---- the 80 steps of a block: parts 0..3 = hidden columns 256 p .. of the frustum MLP (6 + 8 k-steps each), part 4 = the gate: 8 k-steps of its
@@ -314,19 +316,19 @@ struct Pe {
             float4 v = *reinterpret_cast<const float4*>(ot + r * C + ((lane ^ (r & 15)) << 2));
             const float4 tv = *reinterpret_cast<const float4*>(p.sine_tab + (long long)((int)ri % p.tab_period) * C + 4 * lane);
             v = make_float4(v.x + tv.x, v.y + tv.y, v.z + tv.z, v.w + tv.w);
-            if (p.pe) *reinterpret_cast<float4*>(p.pe + (long long)m * C + 4 * lane) = v;
+            if (p.pe) *reinterpret_cast<float4*>(p.pe + (p.pe_at_index ? ri : (long long)m) * C + 4 * lane) = v;
             if (rows16) {
                 const float4 f = *reinterpret_cast<const float4*>(p.Xmap + ri * C + 4 * lane);
                 uint2 h, l;
                 split_k16x2(v.x + f.x, v.y + f.y, h.x, l.x);
                 split_k16x2(v.z + f.z, v.w + f.w, h.y, l.y);
                 *reinterpret_cast<uint2*>(p.Xk_hi + (long long)m * C + 4 * lane) = h;
-                if (p.lo8) *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(p.Xk_lo) + (long long)m * C + 4 * lane) = lo8_pack4(l.x, l.y);
+                if (p.lo8) *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(p.Xk_lo) + (long long)m * C + 4 * lane) = lo8_pack4_flag(l.x, l.y, p.lo8_flag);
                 else *reinterpret_cast<uint2*>(p.Xk_lo + (long long)m * C + 4 * lane) = l;
                 split_k16x2(f.x, f.y, h.x, l.x);
                 split_k16x2(f.z, f.w, h.y, l.y);
                 *reinterpret_cast<uint2*>(p.Xv_hi + (long long)m * C + 4 * lane) = h;
-                if (p.lo8) *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(p.Xv_lo) + (long long)m * C + 4 * lane) = lo8_pack4(l.x, l.y);
+                if (p.lo8) *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(p.Xv_lo) + (long long)m * C + 4 * lane) = lo8_pack4_flag(l.x, l.y, p.lo8_flag);
                 else *reinterpret_cast<uint2*>(p.Xv_lo + (long long)m * C + 4 * lane) = l;
             }
         }
@@ -344,10 +346,11 @@ __global__ __launch_bounds__(256, 1) void pe_x3b_kernel_4x2(PeX3bParams p) {
 extern "C" int mv2d_pe_fused_x3b(const float* A1, const float* Xmap, const int* row_index, const int* m_dev, int M,
                                  const void* W1a_hi, const void* W1a_lo, const float* b1a, const void* W1b_hi, const void* W1b_lo, const float* b1b,
                                  const void* Wr_hi, const void* Wr_lo, const float* br, const void* We_hi, const void* We_lo, const float* be,
-                                 const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, int lo_fmt, void* stream) {
+                                 const float* sine_tab, int tab_period, float* pe, void* Xk_hi, void* Xk_lo, void* Xv_hi, void* Xv_lo, int lo_fmt, int pe_at_index, int* lo8_flag, void* stream) {
     MV2D_CHECK_ARG(A1 && Xmap && W1a_hi && W1a_lo && b1a && W1b_hi && W1b_lo && b1b && Wr_hi && Wr_lo && br && We_hi && We_lo && be && sine_tab,
                    "mv2d_pe_fused_x3b: null pointer");
     MV2D_CHECK_ARG(pe || Xk_hi, "mv2d_pe_fused_x3b: no output");
+    MV2D_CHECK_ARG(!pe_at_index || (pe && row_index), "mv2d_pe_fused_x3b: pe_at_index needs pe and row_index");
     MV2D_CHECK_ARG((Xk_hi != nullptr) == (Xk_lo != nullptr) && (Xk_hi != nullptr) == (Xv_hi != nullptr) && (Xk_hi != nullptr) == (Xv_lo != nullptr),
                    "mv2d_pe_fused_x3b: the four key / value row outputs come together");
     MV2D_CHECK_ARG(M >= 0 && tab_period > 0, "mv2d_pe_fused_x3b: M must be >= 0 and tab_period > 0");
@@ -359,7 +362,7 @@ extern "C" int mv2d_pe_fused_x3b(const float* A1, const float* Xmap, const int* 
     PeX3bParams p{A1, Xmap, row_index, m_dev, M, (const unsigned short*)W1a_hi, (const unsigned short*)W1a_lo, b1a, (const unsigned short*)W1b_hi,
                   (const unsigned short*)W1b_lo, b1b, (const unsigned short*)Wr_hi, (const unsigned short*)Wr_lo, br, (const unsigned short*)We_hi,
                   (const unsigned short*)We_lo, be, sine_tab, tab_period, pe, (unsigned short*)Xk_hi, (unsigned short*)Xk_lo, (unsigned short*)Xv_hi,
-                  (unsigned short*)Xv_lo, lo_fmt};
+                  (unsigned short*)Xv_lo, lo_fmt, lo8_flag, pe_at_index};
     hipLaunchKernelGGL(pe_x3b_kernel_4x2, dim3(cdiv(M, 128)), dim3(256), 0, (hipStream_t)stream, p);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;

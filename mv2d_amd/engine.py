@@ -141,6 +141,11 @@ class HeadEngine:
         # The kernels decode the bytes to key16 in registers: results are bitwise those of key16 lo rows holding the decoded values.  False: key16 lo
         # rows (rounds 3-5).  The shared-tile kernel (group_xattn) reads key16 lo rows only.  In the graph key.
         self.lo8_rows = True
+        # Round 6, S path: the PE rows are written AT THEIR MAP POSITIONS (a position-indexed fp32 map, zero-filled once) instead of compacted in key-list
+        # order, so that RoIAlign reads its second map without the position -> row table: one dependent load less in front of every bilinear tap of the
+        # PE map (the kernel is a chain of such round trips).  Same values, same arithmetic.  Off for keep_stages runs (they expose the
+        # compact rows) and in key16 mode; MV2D_PE_AT_POS=0 turns it off (A/B runs).  In the graph key.
+        self.pe_at_positions = os.environ.get('MV2D_PE_AT_POS', '1') != '0'
         # experiments only (tools/ablate_exact.py; needs lo8_rows = False): zero the lo halves of the value / key rows after they were written -- what a route with hi-only value
         # (or key) rows would compute, at the full route's cost
         self.ablate_zero_lo = frozenset()
@@ -329,11 +334,12 @@ class HeadEngine:
         ws['xyz'] = e((R, 3)); ws['ref'] = e((R, 3)); ws['posemb'] = e((R, 384)); ws['qe1'] = e((R, C)); ws['qpos'] = e((R, C))
         ws['match'] = e((R, Vg, self.topk), torch.int32)
         Pp = (P + 15) // 16 * 16
-        ws['zbuf'] = z(Pp + 32, torch.uint8)                     # roi_mask | nnz[2] | qt_ctl[2] | grp_ctl[2]: cleared by ONE fill per frame
+        ws['zbuf'] = z(Pp + 32, torch.uint8)                     # roi_mask | nnz[2] | qt_ctl[2] | grp_ctl[2] | lo8_flag: cleared by ONE fill per frame
         ws['roi_mask'] = ws['zbuf'][:P]
         ws['nnz'] = ws['zbuf'][Pp:Pp + 8].view(torch.int32)
         ws['qt_ctl'] = ws['zbuf'][Pp + 8:Pp + 16].view(torch.int32)      # query-order flags (zeroed with zbuf)
         ws['grp_ctl'] = ws['zbuf'][Pp + 16:Pp + 24].view(torch.int32)    # shared-tile cross attention: union entries allocated | capacity flag
+        ws['lo8_flag'] = ws['zbuf'][Pp + 24:Pp + 28].view(torch.int32)   # e4m3 lo rows: a remainder left the format's range in this frame (csrc/common.h lo8_pack4_flag)
         ws['zero_mask'] = z(P, torch.uint8)
         ws['rect'] = e((R, 5), torch.int32); ws['pos2s'] = e(P, torch.int32); ws['s2pos'] = e(P, torch.int32)
         ws['S_dev'] = z(1, torch.int32)
@@ -373,6 +379,7 @@ class HeadEngine:
                 # S path: the value rows ARE the RoI cells (key16 lo rows: one array for both; lo8 rows: the split-precision conv, when it runs, reads its own key16 lo cells)
                 ws['roi_lo'] = e((R, 49, C), K16) if lo8 else ws['xv_lo'].view(R, 49, C)
         ws['pe'] = e((P, C)); ws['Xk'] = e((P, C), K16)
+        ws['pe_pos'] = z((P, C)) if (self.kind == 'S' and self.exact and self.pe_at_positions) else None      # never-listed rows stay 0 (they only ever meet weight 0)
         # cross attention in the raw key space: per-query operand Qt (key16 hi | lo rows of the 8 per-head maps), per-head context sums z
         ws['Qt'] = e((R, 16 * C), K16); ws['zh'] = e((R, 8 * C))
         # unprojected key / value input rows of the cross attention (key + key_pos, key): shared by all layers
@@ -636,11 +643,13 @@ class HeadEngine:
         if self.kind == 'S':
             tk('roi_align')
             # key rows = RoIAlign(feat) + RoIAlign(pe), value rows = RoIAlign(feat) (index-exact route: both as key16 hi + lo pairs)
+            at_pos = self._pe_at_pos(ws)
+            pe_map, pe_idx = (ws['pe_pos'], None) if at_pos else (ws['pe'], ws['pos2s'])
             if self.exact and self._lo8():
-                o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=ws['pos2s'], out1_is_sum=True,
-                            out0_lo=ws.get('roi_lo') if 'conv' not in self.exact_skip else None, out0_lo8=ws['xv_lo'], out1_lo8=ws['xk_lo'], R=R)
+                o.roi_align(featcl, rois, h, w, map1=pe_map, out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=pe_idx, out1_is_sum=True,
+                            out0_lo=ws.get('roi_lo') if 'conv' not in self.exact_skip else None, out0_lo8=ws['xv_lo'], out1_lo8=ws['xk_lo'], lo8_flag=ws['lo8_flag'], R=R)
             else:
-                o.roi_align(featcl, rois, h, w, map1=ws['pe'], out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=ws['pos2s'], out1_is_sum=True,
+                o.roi_align(featcl, rois, h, w, map1=pe_map, out0=ws['roi_feat'], out1=ws['roi_sum'], map1_index=pe_idx, out1_is_sum=True,
                             out0_lo=ws['xv_lo'] if self.exact else None, out1_lo=ws['xk_lo'] if self.exact else None, R=R)
         if self.ablate_zero_lo and self.exact:
             if self._lo8():
@@ -698,9 +707,10 @@ class HeadEngine:
         sh = ws['shared']
         rows = self.kind == 'T'
         dbg = getattr(self, '_stage_outputs', False)
+        at_pos = self._pe_at_pos(ws)
         (o.pe_fused_x3b if self.pe_rows_in_waves else o.pe_fused_x3)(
-            ws['xa1'], featcl, md, W_['pe_x3'], sh['sine_tab'], sh['sine_period'], pe=ws['pe'] if (not rows or dbg) else None,
-            Xk=(ws['Xk'], ws['xk_lo']) if rows else None, Xv=(ws['Xf_b'], ws['xv_lo']) if rows else None, M=P, row_index=ws['s2pos'])
+            ws['xa1'], featcl, md, W_['pe_x3'], sh['sine_tab'], sh['sine_period'], pe=(ws['pe_pos'] if at_pos else ws['pe']) if (not rows or dbg) else None,
+            Xk=(ws['Xk'], ws['xk_lo']) if rows else None, Xv=(ws['Xf_b'], ws['xv_lo']) if rows else None, M=P, row_index=ws['s2pos'], pe_at_index=at_pos, lo8_flag=ws['lo8_flag'] if (rows and self._lo8()) else None)
 
     def pe_input_rows(self, ws, positions, V, h, w, f32=False):
         """PE input rows (frustum [n,192], sine [n,384]; key16, or unrounded fp32 with f32=True) at the given map positions (int32, device)
@@ -813,6 +823,11 @@ class HeadEngine:
                                x, ws['qpos'], None, outs=ws['outs'][i], Win_x3=W_[f'sa_in_wx{i + 1}'] if nxt else None,
                                b_in=W_[f'sa_in_b{i + 1}'] if nxt else None, qkv=ws['qkv'] if nxt else None, M=R)
 
+    def _pe_at_pos(self, ws):
+        """S path, index-exact route: are the PE rows written at their map positions (ws['pe_pos']) rather than compacted (ws['pe'])?"""
+        return (self.kind == 'S' and self.exact and 'pe' not in self.exact_skip and bool(self.pe_at_positions) and ws.get('pe_pos') is not None and
+                not getattr(self, '_stage_outputs', False))
+
     def _lo8(self):
         """Are the lo halves of the key / value rows e4m3 bytes (csrc/common.h "lo8")?  Not with the shared-tile kernel (its LDS-DMA tiles are key16 rows)."""
         return bool(self.lo8_rows) and self.exact and not self.group_xattn
@@ -912,7 +927,7 @@ class HeadEngine:
         # the graph bakes in the input pointers (the producer's output buffers are static under graph replay) and the
         # frame scalars; anything else changing (RoI boxes, calibration tables, feature values) is data.
         gkey = (ptrs, 0 if payload is None else payload.data_ptr(), sc['pad_h'], sc['pad_w'], sc['max_rows'], self._weights_version, self._stage_outputs, self.last_stage_heads,
-                self.xattn_waves, self.fuse_maps, self.fuse_xattn, self.group_xattn, self.lo8_rows, self.pe_rows_in_waves, self.fold_sa0, self.masked_transpose, self.keep_sine_rows, self.force_nc, self.q_order,
+                self.xattn_waves, self.fuse_maps, self.fuse_xattn, self.group_xattn, self.lo8_rows, self.pe_at_positions, self.pe_rows_in_waves, self.fold_sa0, self.masked_transpose, self.keep_sine_rows, self.force_nc, self.q_order,
                 self.fork_qg, self.exact_skip, self.ablate_zero_lo, self.stop_before_decoder)   # load_state() re-allocates the weights; every route option of __init__ is in the key
         graphs = ws.setdefault('graphs', {})             # one graph per (input buffers, frame scalars): a producer that alternates between
         g = graphs.get(gkey)                             # a few static output buffers replays a few graphs, it does not re-capture
@@ -1036,6 +1051,10 @@ class HeadEngine:
             raise RuntimeError('mv2d engine: CSR capacity exceeded (raise col_cap_per_query)')
         if ws.get('grp_ctl') is not None and int(ws['grp_ctl'][1].item()) != 0:
             raise RuntimeError('mv2d engine: union-list capacity of the shared-tile cross attention exceeded (a CSR row lists a key twice?)')
+        if ws.get('lo8_flag') is not None and int(ws['lo8_flag'][0].item()) != 0:
+            import warnings
+            warnings.warn('mv2d engine: key / value rows beyond +-224 in this frame: their 8-bit lo halves saturated (those elements keep key16 precision); '
+                          'set HeadEngine.lo8_rows = False for fp16 lo rows', RuntimeWarning, stacklevel=3)
 
     def results(self, out):
         """Synchronising accessor: sliced (boxes [K,9], scores [K], labels [K]) like simple_test returns."""

@@ -420,10 +420,11 @@ def pe_fused_tab(A1, Xfb, Xf32, m_dev, wp, sine_tab, tab_period, pe, Xk, M=None,
     return pe, Xk
 
 
-def pe_fused_x3(A1, Xmap, m_dev, wx, sine_tab, tab_period, pe=None, Xk=None, Xv=None, M=None, row_index=None):
+def pe_fused_x3(A1, Xmap, m_dev, wx, sine_tab, tab_period, pe=None, Xk=None, Xv=None, M=None, row_index=None, pe_at_index=False, lo8_flag=None):
     """The PE block in split precision on unrounded inputs (index-exact route, csrc/pe_x3.hip).  A1 [M,192] fp32; Xmap fp32 feature rows
     (indexed by row_index when given); wx: dict 'w1a','w1b','wr','we' = pack_x3(weight) pairs + fp32 biases 'b1a','b1b','br','be'; pe [M,256]
-    fp32 and / or Xk = (hi, lo), Xv = (hi, lo) key16 [M,256] pairs (key rows pe + feat, value rows feat)."""
+    fp32 and / or Xk = (hi, lo), Xv = (hi, lo) key16 [M,256] pairs (key rows pe + feat, value rows feat).  pe_at_index: pe row m goes to row
+    row_index[m] of `pe` (a position-indexed map for roi_align without map1_index)."""
     _req(A1, torch.float32, 'A1'); _req(Xmap, torch.float32, 'Xmap'); _req(sine_tab, torch.float32, 'sine_tab'); _req(pe, torch.float32, 'pe')
     _req(row_index, torch.int32, 'row_index'); _req(m_dev, torch.int32, 'm_dev')
     for pair in (Xk, Xv):
@@ -437,11 +438,11 @@ def pe_fused_x3(A1, Xmap, m_dev, wx, sine_tab, tab_period, pe=None, Xk=None, Xv=
     check(_lib.load().mv2d_pe_fused_x3(_p(A1), _p(Xmap), _p(row_index), _p(m_dev), M, _p(wx['w1a'][0]), _p(wx['w1a'][1]), _p(wx['b1a']),
                                        _p(wx['w1b'][0]), _p(wx['w1b'][1]), _p(wx['b1b']), _p(wx['wr'][0]), _p(wx['wr'][1]), _p(wx['br']),
                                        _p(wx['we'][0]), _p(wx['we'][1]), _p(wx['be']), _p(sine_tab), int(tab_period), _p(pe), _p(xk[0]), _p(xk[1]),
-                                       _p(xv[0]), _p(xv[1]), lo_fmt, _stream()), 'mv2d_pe_fused_x3')
+                                       _p(xv[0]), _p(xv[1]), lo_fmt, 1 if (pe_at_index and row_index is not None) else 0, _p(lo8_flag), _stream()), 'mv2d_pe_fused_x3')
     return pe
 
 
-def pe_fused_x3b(A1, Xmap, m_dev, wx, sine_tab, tab_period, pe=None, Xk=None, Xv=None, M=None, row_index=None):
+def pe_fused_x3b(A1, Xmap, m_dev, wx, sine_tab, tab_period, pe=None, Xk=None, Xv=None, M=None, row_index=None, pe_at_index=False, lo8_flag=None):
     """pe_fused_x3 on the second shape of the kernel (csrc/pe_x3b.hip: a wave owns 16 rows through both layers, the hidden layer stays in registers, the
     weights go through an LDS ring): bitwise the same outputs.  wx additionally holds 'w1a_p', 'wr_p' = pack_x3_rowperm of the two first-layer weights."""
     _req(A1, torch.float32, 'A1'); _req(Xmap, torch.float32, 'Xmap'); _req(sine_tab, torch.float32, 'sine_tab'); _req(pe, torch.float32, 'pe')
@@ -457,7 +458,7 @@ def pe_fused_x3b(A1, Xmap, m_dev, wx, sine_tab, tab_period, pe=None, Xk=None, Xv
     check(_lib.load().mv2d_pe_fused_x3b(_p(A1), _p(Xmap), _p(row_index), _p(m_dev), M, _p(wx['w1a_p'][0]), _p(wx['w1a_p'][1]), _p(wx['b1a']),
                                         _p(wx['w1b'][0]), _p(wx['w1b'][1]), _p(wx['b1b']), _p(wx['wr_p'][0]), _p(wx['wr_p'][1]), _p(wx['br']),
                                         _p(wx['we'][0]), _p(wx['we'][1]), _p(wx['be']), _p(sine_tab), int(tab_period), _p(pe), _p(xk[0]), _p(xk[1]),
-                                        _p(xv[0]), _p(xv[1]), lo_fmt, _stream()), 'mv2d_pe_fused_x3b')
+                                        _p(xv[0]), _p(xv[1]), lo_fmt, 1 if (pe_at_index and row_index is not None) else 0, _p(lo8_flag), _stream()), 'mv2d_pe_fused_x3b')
     return pe
 
 
@@ -824,13 +825,13 @@ def posemb3d(ref, dim_t, out=None):
 
 
 def roi_align(map0, rois, H, W, *, map1=None, out0=None, out1=None, out0_f32=None, out1_f32=None, spatial_scale=1.0 / 16,
-              sampling_ratio=-1, map1_index=None, out1_is_sum=False, R=None, out0_lo=None, out1_lo=None, out0_lo8=None, out1_lo8=None):
+              sampling_ratio=-1, map1_index=None, out1_is_sum=False, R=None, out0_lo=None, out1_lo=None, out0_lo8=None, out1_lo8=None, lo8_flag=None):
     _req(map0, torch.float32, 'map0'); _req(map1, torch.float32, 'map1'); _req(rois, torch.float32, 'rois')
     _req16(out0, 'out0'); _req16(out1, 'out1'); _req16(out0_lo, 'out0_lo'); _req16(out1_lo, 'out1_lo')
-    _req(out0_lo8, torch.uint8, 'out0_lo8'); _req(out1_lo8, torch.uint8, 'out1_lo8')
+    _req(out0_lo8, torch.uint8, 'out0_lo8'); _req(out1_lo8, torch.uint8, 'out1_lo8'); _req(lo8_flag, torch.int32, 'lo8_flag')
     check(_lib.load().mv2d_roi_align_ex(_p(map0), _p(map1), _p(rois), _p(out0), _p(out1), _p(out0_f32), _p(out1_f32),
                                         rois.shape[0] if R is None else R, H, W, map0.shape[-1], spatial_scale, sampling_ratio,
-                                        _p(map1_index), 1 if out1_is_sum else 0, _p(out0_lo), _p(out1_lo), _p(out0_lo8), _p(out1_lo8), _stream()),
+                                        _p(map1_index), 1 if out1_is_sum else 0, _p(out0_lo), _p(out1_lo), _p(out0_lo8), _p(out1_lo8), _p(lo8_flag), _stream()),
           'mv2d_roi_align')
 
 

@@ -421,6 +421,78 @@ def test_engine_route_options(kind, name):
         assert (np.diff(rp[:R + 1]) == 3 * 49).all()
 
 
+@pytest.mark.parametrize('kind,name', [('S', 'nc6_s'), ('S', 'cfg2_s'), ('T', 'cfg1_t')])
+def test_round6_storage_options(kind, name):
+    """The two storage choices of round 6 against their predecessors on the same inputs.  pe_at_positions (S path: the PE rows written at their map
+    positions, RoIAlign reads them without the position -> row table): BITWISE the results of the compacted rows, also when the map still holds the rows
+    of another frame (stale rows only ever meet weight 0).  lo8_rows (the lo halves of the key / value rows as e4m3 bytes instead of fp16): class logits
+    within 1e-6 of their scale, the same ranked (query, class) indices."""
+    from mv2d_amd.engine import HeadEngine
+    dev = torch.device('cuda:0')
+    sd = synthetic.make_head_state(seed=0)
+    probs = [synthetic.make_problem(name, seed=s_) for s_ in (0, 3)]
+    mk = lambda **kw: HeadEngine(sd, kind, dev, num_views=probs[0]['views_per_frame'], **kw)
+    keys = ('cls', 'reg', 'boxes', 'scores', 'labels', 'bbox_index', 'count')
+
+    def frames(eng, order):
+        outs = []
+        for i in order:
+            p_ = probs[i]
+            o = eng.run(torch.from_numpy(p_['feat']).to(dev), [torch.from_numpy(x) for x in p_['proposals']], p_['img_metas'])
+            torch.cuda.synchronize()
+            outs.append({k: o[k].clone() for k in keys})
+        return outs
+    a = mk()
+    assert a.exact and a.lo8_rows and a.pe_at_positions
+    ra = frames(a, (0, 1, 0))
+    ws = a._ws[next(iter(a._ws))]
+    assert ws['xk_lo'].dtype == torch.uint8 and (ws['pe_pos'] is not None) == (kind == 'S')
+    for k in keys:
+        assert torch.equal(ra[0][k], ra[2][k]), k                                       # the first frame again, after another one went through the same buffers
+    b = mk()
+    b.pe_at_positions = False
+    rb = frames(b, (0, 1))
+    for i in (0, 1):
+        for k in keys:
+            assert torch.equal(ra[i][k], rb[i][k]), (i, k)
+    c = mk()
+    c.lo8_rows = False
+    rc = frames(c, (0, 1))
+    assert c._ws[next(iter(c._ws))]['xk_lo'].dtype == ops_key16()
+    for i in (0, 1):
+        e = relmax(ra[i]['cls'], rc[i]['cls'])
+        n = int(rc[i]['count'].item())
+        print(f'[lo8 rows vs fp16 lo rows] {name} frame {i}: cls {e:.2e}, ranked indices equal: {bool(torch.equal(ra[i]["bbox_index"][:n], rc[i]["bbox_index"][:n]))}')
+        assert e < 1e-6, e
+        assert int(ra[i]['count'].item()) == n and torch.equal(ra[i]['bbox_index'][:n], rc[i]['bbox_index'][:n]) and torch.equal(ra[i]['labels'][:n], rc[i]['labels'][:n])
+
+
+@pytest.mark.parametrize('kind,name', [('S', 'cfg1_s'), ('T', 'cfg1_t')])
+def test_lo8_saturation_is_reported(kind, name):
+    """Feature values beyond +-224 do not fit the fixed scale of the e4m3 lo rows (csrc/common.h "lo8"): those elements keep their hi halves only.  The row
+    producers raise a device flag, the synchronising accessor turns it into a RuntimeWarning; frames inside the range raise none."""
+    import warnings
+    from mv2d_amd.engine import HeadEngine
+    dev = torch.device('cuda:0')
+    prob = synthetic.make_problem(name, seed=0)
+    eng = HeadEngine(synthetic.make_head_state(seed=0), kind, dev, num_views=prob['views_per_frame'])
+    props = [torch.from_numpy(p) for p in prob['proposals']]
+    feat = torch.from_numpy(prob['feat']).to(dev)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        eng.results(eng.run(feat, props, prob['img_metas']))
+    with pytest.warns(RuntimeWarning, match='lo halves saturated'):
+        eng.results(eng.run(feat * 400.0, props, prob['img_metas']))
+    with warnings.catch_warnings():                                                     # the flag is per frame
+        warnings.simplefilter('error')
+        eng.results(eng.run(feat, props, prob['img_metas']))
+
+
+def ops_key16():
+    from mv2d_amd import ops
+    return ops.key16_dtype()
+
+
 @pytest.mark.parametrize('kind,name,n', [('S', 'cfg1_s', 1), ('S', 'nc6_s', 3), ('T', 'cfg1_t', 2)])
 def test_decode_writes_the_all_gather_payload(kind, name, n):
     """run(..., payload=buf): the decode kernel writes the wire rows of the per-step all-gather itself (one launch less per frame); they equal

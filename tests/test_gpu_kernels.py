@@ -496,7 +496,8 @@ def test_lo8_row_format(dev):
     o = {n_: torch.zeros((R, 49, 256), device=dev, dtype=k16) for n_ in ('a', 'a_lo', 'b', 'b_lo', 'a2', 'b2', 'a2_lo')}
     o8 = {n_: torch.zeros((R, 49, 256), device=dev, dtype=torch.uint8) for n_ in ('a', 'b')}
     ops.roi_align(m0, rois, H, W, map1=m1, out0=o['a'], out1=o['b'], out1_is_sum=True, out0_lo=o['a_lo'], out1_lo=o['b_lo'])
-    ops.roi_align(m0, rois, H, W, map1=m1, out0=o['a2'], out1=o['b2'], out1_is_sum=True, out0_lo=o['a2_lo'], out0_lo8=o8['a'], out1_lo8=o8['b'])
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.roi_align(m0, rois, H, W, map1=m1, out0=o['a2'], out1=o['b2'], out1_is_sum=True, out0_lo=o['a2_lo'], out0_lo8=o8['a'], out1_lo8=o8['b'], lo8_flag=flag)
     torch.cuda.synchronize()
     assert torch.equal(o['a'], o['a2']) and torch.equal(o['b'], o['b2']) and torch.equal(o['a_lo'], o['a2_lo'])
     for n_ in ('a', 'b'):
@@ -509,6 +510,11 @@ def test_lo8_row_format(dev):
         assert bool((((dec - lo).abs() <= lo.abs() * 2.0 ** -4 + 2.0 ** -22) | sat).all())
         assert int(((o8[n_] & 0x7f) < 8).sum()) > 0                                    # subnormal bytes occur
     assert bool((ops.lo8_decode(o8['a'])[(o['a_lo'].float().abs() * 4096.0 > 460.0)].float().abs() == 448.0 / 4096.0).all())
+    # the saturation report: set by this map (values up to 400), not by one inside the format's range
+    assert int(flag.item()) == 1
+    flag.zero_()
+    ops.roi_align(m1, rois, H, W, out0=o['a2'], out0_lo8=o8['a'], lo8_flag=flag)
+    assert int(flag.item()) == 0
 
 
 def _rect_pattern(R, S, seed, n_samples):
@@ -1100,6 +1106,15 @@ def test_pe_fused_x3_kernel(dev, M, use_mdev, use_ri, rows):
         nop = [tuple(torch.zeros((M, 256), device=dev, dtype=k16) for _ in range(2)) for _ in range(2)]
         ops.pe_fused_x3b(A1, Xmap, md, wx, tab, period, Xk=nop[0], Xv=nop[1], M=M, row_index=ri)          # (T path: no pe output)
         assert torch.equal(nop[0][0].view(torch.int16), pairs[0][0].view(torch.int16))
+        # round 6: the pe rows written at row row_index[m] of a position-indexed map (what RoIAlign then reads without the position -> row table)
+        if use_ri:
+            for fn in (ops.pe_fused_x3, ops.pe_fused_x3b):
+                pe_map = torch.full((NP, 256), 7.0, device=dev)
+                fn(A1, Xmap, md, wx, tab, period, pe=pe_map, M=M, row_index=ri, pe_at_index=True)
+                assert torch.equal(pe_map[ri.long()[:Mv]].view(torch.int32), pe[:Mv].view(torch.int32))
+                rest = torch.ones(NP, dtype=torch.bool, device=dev)
+                rest[ri.long()[:Mv]] = False
+                assert bool((pe_map[rest] == 7.0).all())
         if k16 == torch.float16:
             # round 6: the lo halves as e4m3 "lo8" rows (256 B): the bytes are the encoding of the key16 lo halves, the hi rows are untouched; both kernels
             for fn in (ops.pe_fused_x3, ops.pe_fused_x3b):
