@@ -99,7 +99,7 @@ class HeadEngine:
         # waves per query of the tile kernel: the kernel alone takes the same time with 1, 2 or 4 (it is bound by what the memory system
         # delivers), but a launch with fewer waves leaves more of the chip to the other streams' kernels: cfg2_s 8067 / 8043 / 7869
         # samples/s for 1 / 2 / 4, cfg3_t (rows of ~200 keys) 5803 / 5868 / 5758
-        self.xattn_waves = 2
+        self.xattn_waves = int(os.environ.get('MV2D_XATTN_WAVES', '2'))       # (the variable: A/B runs)
         # S path (rows of similar length): query map -> tile attention -> context map as ONE launch per layer (csrc/xattn_fused.hip, round 5: blocks
         # of 8 queries, Qt / z stay on chip; bitwise the three kernels with one wave per query).  None: on the S path when no debug output is asked
         # for; False / True forces it.  In the graph key.
