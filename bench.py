@@ -847,7 +847,7 @@ def main():
             'value': round(value, 2), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'setup_steps': args.prime,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': (('f16 (ONE rounding of the key side: opt-in key16 mode) / f16x3 split precision (query side)' if args.key16 else
-                       'f16x3: every operand an fp16 hi + lo pair, three MFMAs per product, fp32 accumulation (fp32-class, index-exact route)')), 'data': 'synthetic',
+                       'f16x3: every operand an fp16 hi + lo pair, three MFMAs per product, fp32 accumulation (fp32-class, index-exact route; the lo halves of the key / value rows are STORED as e4m3 bytes)')), 'data': 'synthetic',
             'route': 'key16_mode_opt_in' if args.key16 else 'index_exact',
             'timed_seconds': round(elapsed, 3),
             'config': {'workload': f'{args.workload}: MV2D-{kind} head, {len(metas)} views {metas[0]["img_shape"][1]}x{metas[0]["img_shape"][0]}, '
