@@ -223,6 +223,8 @@ class MV2DHead(nn.Module):
                                       iou_thr=bc.iou_thr, ratio=bc.ratio, num_classes=self.bbox_head.num_classes,
                                       masked_row=(self.test_cfg or {}).get('masked_row', 'nan'),
                                       exact=(self.test_cfg or {}).get('index_exact', None))      # None: MV2D_EXACT decides
+            if 'lo8_rows' in (self.test_cfg or {}):                              # test_cfg.lo8_rows=False: fp16 lo halves of the key / value rows (engine.py; default: e4m3 bytes)
+                self._engine.lo8_rows = bool(self.test_cfg['lo8_rows'])
             self._engine_ver = ver
         return self._engine
 
