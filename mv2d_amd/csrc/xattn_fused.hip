@@ -25,6 +25,9 @@
 #ifndef MV2D_XF_QB_DEFAULT
 #define MV2D_XF_QB_DEFAULT 8
 #endif
+#ifndef MV2D_XF_WBATCH
+#define MV2D_XF_WBATCH 0
+#endif
 #ifndef MV2D_XF_PIPE
 #define MV2D_XF_PIPE 0          // 1: e4m3 lo rows, the key rows of tile t + 1 requested in front of tile t's arithmetic -- measured SLOWER (see the loop), off
 #endif
@@ -150,22 +153,41 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
 #endif
         const int r = rq[n & (QB - 1)];
         const float* qp = q + (long long)r * C + 32 * h + 8 * g;
-        XfFrag bh, bl;
-        xf_split8(*reinterpret_cast<const float4*>(qp), *reinterpret_cast<const float4*>(qp + 4), bh, bl);
+        // (the query values are REQUESTED here and split behind the weight requests: split first, hipcc waited for them -- a full round trip -- before it issued
+        //  the first weight load: 3.4 k of a block's 62 k cycles, round 6 stamps)
+        const float4 q0 = *reinterpret_cast<const float4*>(qp), q1 = *reinterpret_cast<const float4*>(qp + 4);
         const uint4* wh = WA_hi + (long long)h * 16 * 64 + lane;
         const uint4* wl = WA_lo + (long long)h * 16 * 64 + lane;
         uint4* qt = reinterpret_cast<uint4*>(smem + (n & (QB - 1)) * WAVE_LDS) + h * 64;      // this lane's query, this head: 64 chunks of 16 B
         // ALL 32 weight fragments of the head are requested before the first MFMA (128 registers, free in this phase): the first build left the
         // loads next to their MFMAs and the ISA showed 24 serialised L2 round trips per block and phase (tools/isa_waits.sh)
         xf_u32x4 wa_h[16], wa_l[16];
+        auto request = [&](int t0, int t1) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            wa_h[t] = *reinterpret_cast<const xf_u32x4*>(wh + t * 64);
-            wa_l[t] = *reinterpret_cast<const xf_u32x4*>(wl + t * 64);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int t = t0; t < t1; ++t) {
+                wa_h[t] = *reinterpret_cast<const xf_u32x4*>(wh + t * 64);
+                wa_l[t] = *reinterpret_cast<const xf_u32x4*>(wl + t * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#if MV2D_XF_WBATCH
+        // (experiment: the fragments in three batches, the later ones requested between the MFMA groups -- issuing 32 x 1 KB per wave is itself 3.7 k cycles at the
+        //  L1's 64 B / clk, during which the wave computes nothing)
+        request(0, 8);
+#else
+        request(0, 16);
+#endif
+        XF_STAMP(20);
+        XfFrag bh, bl;
+        xf_split8(q0, q1, bh, bl);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
+            if (u == 1) XF_STAMP(21);
+            if (u == 4) XF_STAMP(22);
+#if MV2D_XF_WBATCH
+            if (u == 0) request(8, 12);
+            if (u == 2) request(12, 16);
+#endif
             f32x4_t a[2];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -188,6 +210,7 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
             }
         }
     }
+    XF_STAMP(23);
     // (LDS only: __syncthreads() would also wait for the key rows that are still in flight -- vmcnt(0) -- and put their latency back in front of phase B)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

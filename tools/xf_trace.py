@@ -45,3 +45,4 @@ if hasattr(lib, 'mv2d_xf_trace_read'):
             print(f'  {names[i]:40s} {t[i] - prev:8d}')
             prev = t[i]
     print('  total', t[17] - t[0], '(s_memtime ticks: 100 MHz)')
+    print('  inside phase A (from the slot table): weight + query loads issued', t[20] - t[1], '| first two fragments used', t[21] - t[1], '| half', t[22] - t[1], '| all MFMAs issued', t[23] - t[1], '| barrier passed', t[2] - t[1])
