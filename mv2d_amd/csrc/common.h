@@ -144,11 +144,18 @@ __device__ __forceinline__ void split_k16x2_bounded(float a, float b, unsigned i
 // hi + lo split of two fp32 values into key16 pairs: x ~ hi + lo.  The remainder is taken from the CLAMPED value: a saturated (or infinite) input
 // has hi = +-65504 exactly and therefore remainder 0, a NaN stays NaN in both parts, and the remainder of anything else is at most half an fp16 ulp
 // (<= 16), so the second conversion needs no clamp.
+// MV2D_F16_OVFL_MODE (a kernel-local #define, with mv2d_set_f16_ovfl() at the kernel's entry): MODE.FP16_OVFL makes every fp32 -> fp16 conversion of the
+// wave clamp an overflow to +-65504 itself (NaN kept, a true infinity stays infinite), so the three clamp instructions per value go away.
+__device__ __forceinline__ void mv2d_set_f16_ovfl() { __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1); }      // hwreg(HW_REG_MODE, 23, 1) = 1
 __device__ __forceinline__ void split_k16x2(float a, float b, unsigned int& hi, unsigned int& lo) {
 #if MV2D_KEY16_IS_F16
     typedef __attribute__((ext_vector_type(2))) float f32x2_cv;
     typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_cv;
+#ifdef MV2D_F16_OVFL_MODE
+    const f32x2_cv v = {a, b};
+#else
     const f32x2_cv v = {k16_sat(a), k16_sat(b)};
+#endif
     hi = __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2_cv));
     const f32x2_cv r = {v[0] - k16_lo_of_pair(hi), v[1] - k16_hi_of_pair(hi)};
     lo = __builtin_bit_cast(unsigned int, __builtin_convertvector(r, f16x2_cv));

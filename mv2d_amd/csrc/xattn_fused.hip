@@ -20,6 +20,17 @@
 // ~105 KB of key / value rows it gathers from HBM; the blocks of a launch are out of phase after the first round, so the map phases of one
 // CU overlap the gathers of the others.  Rows of very different length (the T path: 1 .. 400 keys) would wait for the longest of the 8 at
 // the barrier between B and C: the engine keeps the three kernels there.
+// Round 6 experiment, OFF: MODE.FP16_OVFL for the whole kernel (mv2d_set_f16_ovfl at its entry; -DMV2D_XF_OVFL=1): the fp32 -> fp16 conversions of the hi / lo splits in
+// the two map phases then clamp an overflow themselves, which takes 3 of the ~11 vector instructions per split pair away: 98.0 -> 95.8 us per cfg2_s launch, in-range
+// results bit for bit.  But with the bit set a NaN in a key row, a value row or the query no longer reaches the output (the conversions do keep it --
+// tools/probes/f16_ovfl_probe.hip -- so it is lost in the f16 MFMAs), and a poisoned input frame must stay visible (tests/test_gpu_engine.py::
+// test_poisoned_feature_cell_stays_visible, tools/gpu_jobs/nan_dbg.py).  Toggling the bit around every split would fence the MFMAs off from the splits.
+#ifndef MV2D_XF_OVFL
+#define MV2D_XF_OVFL 0
+#endif
+#if MV2D_XF_OVFL
+#define MV2D_F16_OVFL_MODE 1
+#endif
 #include "common.h"
 #include <stdlib.h>
 #ifndef MV2D_XF_QB_DEFAULT
@@ -90,6 +101,9 @@ __global__ __launch_bounds__(64 * QB, 2) void xattn_fused_kernel(const float* __
                                                                 int R, int empty_nan, const int* __restrict__ order, int nblk) {
     constexpr int SMEM = QB * WAVE_LDS + QB * 512 + QB * HEADS * 4 + 3 * QB * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+#if MV2D_XF_OVFL
+    mv2d_set_f16_ovfl();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
     float* lsum = reinterpret_cast<float*>(smem + QB * WAVE_LDS + QB * 512);         // [query][head] softmax denominators
     int* rq = reinterpret_cast<int*>(smem + QB * WAVE_LDS + QB * 512 + QB * HEADS * 4);       // [query slot] -> query row, then the ends of its CSR row

@@ -454,6 +454,23 @@ def test_xattn_fused_equals_the_three_kernels(dev, R, S, dens, lo):
         assert torch.equal(out2.view(torch.int32), ref.view(torch.int32))
     if dens > 0:
         assert bool(torch.isnan(out[5]).all()) and bool(torch.isfinite(out[6:]).all())
+    # a mapped query beyond the fp16 range (saturating splits): finite results; a NaN in a key row, a value row or the query: every row that lists it is NaN
+    big = ops.xattn_fused(q * 3e4, WA, WB, bv, Xk, Xv, row_ptr, col, empty_nan=False, Xk_lo=Xk_lo, Xv_lo=Xv_lo)
+    assert bool(torch.isfinite(big).all())
+    if dens > 0:
+        hit = allowed[:, 123].to(dev)
+        for which in ('k', 'v', 'q'):
+            k2, v2, q2 = Xk.clone(), Xv.clone(), q.clone()
+            if which == 'k':
+                k2[123] = float('nan')
+            elif which == 'v':
+                v2[123] = float('nan')
+            else:
+                q2[9] = float('nan')
+            o_ = ops.xattn_fused(q2, WA, WB, bv, k2, v2, row_ptr, col, empty_nan=False, Xk_lo=Xk_lo, Xv_lo=Xv_lo)
+            bad = torch.isnan(o_).all(1)
+            want = hit if which != 'q' else (torch.arange(R, device=dev) == 9) & (row_ptr[1:] > row_ptr[:-1])
+            assert torch.equal(bad, want), which
     if lo:
         # round 6, e4m3 "lo8" rows (256-byte lo rows, csrc/common.h): the kernels decode the bytes to key16 in registers -- BITWISE the results of key16 lo
         # rows that hold the decoded values, for the tile kernel (1, 2, 4 waves per query) and the fused one; and close to the unquantised rows
