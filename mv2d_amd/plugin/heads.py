@@ -182,9 +182,6 @@ class MV2DHead(nn.Module):
         self.query_generator = QueryGenerator(**query_generator)
         self.position_encoding = PE(**pe)
         self.box_corr_module = BoxCorrelation(**box_correlation)
-        if self.box_corr_module.all_matched and self.KIND == 'S':
-            raise NotImplementedError("correlation_mode='all_matched' is built for the T head only (the S head would read the reference's "
-                                      "[R, views x RoIs per view] id lists as keys; no shipped config uses it)")
         self.pc_range, self.intrins_feat_scale, self.feat_lvl, self.force_fp32 = pc_range, intrins_feat_scale, feat_lvl, force_fp32
         self.stage_loss_weights = train_cfg.get('stage_loss_weights') if train_cfg else None
         self._engine, self._engine_ver = None, None

@@ -519,8 +519,9 @@ class BoxCorrelation(nn.Module):
     reference (boolean feature masks for the T path, padded id lists for the S path) built from the device-side match lists.
     'all_matched' (:305-338; no shipped config): every RoI of a view the epipolar points reach with IoU > 0 -- as a SET that is
     topk_matched with k = all RoIs of the view, thr = ratio = 0; the T path only reads the union of the listed RoIs' cells, so it runs on the
-    same kernels with k = ALL_MATCHED_CAP (a frame with more RoIs in one view raises).  The S path would need the reference's list layout
-    [R, views x max RoIs per view] as keys: not built (NotImplementedError)."""
+    same kernels with k = ALL_MATCHED_CAP (a frame with more RoIs in one view raises).  S path (round 6): the same lists, every view's ids put back
+    into the view's RoI order, are the reference's compacted [R, n_c] id lists (:165-193); the engine attends over their cells (the order of
+    the keys inside a row does not matter to the softmax)."""
     ALL_MATCHED_CAP = 128
 
     def __init__(self, sample_size=4, num_depth=8, depth_start=0.5, depth_end=70, correlation_mode=None, LID=True, expand_stride=0,
@@ -561,10 +562,14 @@ class BoxCorrelation(nn.Module):
     def gen_box_roi_correlation(self, rois, num_proposals_per_img, img_metas):
         if rois.numel() == 0:
             return rois.new_zeros((0, 0), dtype=torch.int64), rois.new_zeros((0, 0), dtype=torch.bool)
-        if self.all_matched:
-            raise NotImplementedError("correlation_mode='all_matched' is built for the T path (gen_box_correlation) only")
         R = rois.shape[0]
-        m = self._match(rois, num_proposals_per_img, img_metas).view(R, -1).to(torch.int64)
+        m = self._match(rois, num_proposals_per_img, img_metas)                        # [R, V, topk] int32, -1 = none; IoU-rank order inside a view
+        if self.all_matched:
+            # the reference lists the RoIs of a view in the view's RoI order (:330-337: all_roi_id = rois_ids_view, all_mask = iou > 0)
+            big = torch.iinfo(torch.int32).max
+            m = torch.where(m < 0, torch.full_like(m, big), m).sort(dim=2).values
+            m = torch.where(m == big, torch.full_like(m, -1), m)
+        m = m.view(R, -1).to(torch.int64)
         ids = torch.cat([torch.arange(R, device=rois.device)[:, None], m], 1)
         valid = ids >= 0
         order = torch.argsort((~valid).to(torch.int8), dim=1, stable=True)           # valid entries first, order preserved

@@ -145,15 +145,16 @@ def main():
     cases = [('micro_t', True), ('micro_s', True), ('cfg1_t', False), ('cfg1_s', False), ('cfg2_s', False), ('cfg3_t', False), ('cfg5_t', False),
              ('nc6_s', False),      # S path with up to 6 correlated RoIs per query (overlapping views, mv2d_amd/synthetic.py RIG)
              ('cfg2_s_nc6', False),  # ... and the same rig at the headline size (round 4)
-             ('cfg1_t_allm', False), ('nc6_t_allm', False)]  # round 5: correlation_mode='all_matched' (box_correlation.py:305-338) on the T head
+             ('cfg1_t_allm', False), ('nc6_t_allm', False),  # round 5: correlation_mode='all_matched' (box_correlation.py:305-338) on the T head
+             ('cfg1_s_allm', False), ('nc6_s_allm', False)]  # round 6: ... and on the S head (gen_box_roi_correlation: the id lists [R, views x RoIs per view] as keys)
     only = [a for a in sys.argv[1:] if not a.startswith('-')]
     if only:
         cases = [c for c in cases if c[0] in only]
     for name, full in cases:
         allm = name.endswith('_allm')
-        prob = synthetic.make_problem({'cfg1_t_allm': 'cfg1_t', 'nc6_t_allm': 'nc6_s'}.get(name, name), seed=0)
+        prob = synthetic.make_problem({'cfg1_t_allm': 'cfg1_t', 'nc6_t_allm': 'nc6_s', 'cfg1_s_allm': 'cfg1_s', 'nc6_s_allm': 'nc6_s'}.get(name, name), seed=0)
         if allm:
-            prob['kind'] = 'T'                                   # (nc6_s: the overlapping rig -- its views share many RoIs -- through the T head)
+            prob['kind'] = 'T' if '_t_' in name else 'S'         # (nc6_s: the overlapping rig -- its views share many RoIs -- through the T head too)
         head = build_reference_head(prob['kind'], S_cls, T_cls, sd_np, prob['views_per_frame'], corr_mode='all_matched' if allm else None)
         rec = run_case(head, prob['kind'], prob['feat'], prob['proposals'], prob['img_metas'], full)
         np.savez_compressed(os.path.join(OUT, name + '.npz'), **rec)

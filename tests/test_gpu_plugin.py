@@ -414,7 +414,7 @@ def test_bench_two_ranks_rccl_when_two_gpus_are_visible():
 def test_all_matched_correlation_mode_on_the_t_head(name, src):
     """`box_correlation=dict(correlation_mode='all_matched')` (RH/utils/box_correlation.py:305-338) at the registry level, T head: simple_test
     returns the ranked labels / scores of the reference's own all_matched run (tests/golden/<name>.npz), and the engine's key list and CSR are
-    bit for bit the reference's boolean cell masks.  The S head refuses the mode."""
+    bit for bit the reference's boolean cell masks."""
     import numpy as np
     import os
     from conftest import unpack_bits
@@ -448,7 +448,39 @@ def test_all_matched_correlation_mode_on_the_t_head(name, src):
     rp, ci, s2pos = st['row_ptr'].cpu().numpy(), st['col_idx'].cpu().numpy(), st['s2pos'].cpu().numpy()
     for r in range(R):
         np.testing.assert_array_equal(np.sort(s2pos[ci[rp[r]:rp[r + 1]]]), np.nonzero(ffr[r].reshape(-1) & ~padded)[0])
-    cfg_s = configs.roi_head_cfg_s()
-    cfg_s['box_correlation'] = dict(cfg_s['box_correlation'], correlation_mode='all_matched')
-    with pytest.raises(NotImplementedError):
-        mv2d_amd.build_head(cfg_s, test_cfg=dict(configs.TEST_CFG_RCNN))
+
+
+@pytest.mark.parametrize('name,src', [('cfg1_s_allm', 'cfg1_s'), ('nc6_s_allm', 'nc6_s')])
+def test_all_matched_correlation_mode_on_the_s_head(name, src):
+    """The same mode through the S head (round 6; RH/utils/box_correlation.py:165-193): `gen_box_roi_correlation` returns the reference's compacted id
+    lists bit for bit (up to 33 RoIs per query on the overlapping rig), simple_test the ranked labels / scores of the reference's own all_matched run,
+    and every CSR row of the engine lists exactly the 49 cells of each listed RoI."""
+    import numpy as np
+    import os
+    prob = synthetic.make_problem(src, seed=0)
+    cfg = configs.roi_head_cfg_s()
+    cfg['box_correlation'] = dict(cfg['box_correlation'], correlation_mode='all_matched')
+    head = mv2d_amd.build_head(cfg, test_cfg=dict(configs.TEST_CFG_RCNN))
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_head_state(seed=0).items()}, strict=True)
+    head = head.to(DEV).eval()
+    metas = [dict(m, box_type_3d=None) for m in prob['img_metas']]
+    feat = torch.from_numpy(prob['feat']).to(DEV)
+    props = [torch.from_numpy(p).to(DEV) for p in prob['proposals']]
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name + '.npz'))
+    from oracle import mv2d_oracle as O
+    rois = O.bbox2roi([p.cpu() for p in props]).to(DEV)
+    corr, mask = head.box_corr_module.gen_box_roi_correlation(rois, [len(p) for p in props], metas)
+    np.testing.assert_array_equal(mask.cpu().numpy(), g['corr_mask'])
+    np.testing.assert_array_equal(corr.cpu().numpy() * g['corr_mask'], g['corr'] * g['corr_mask'])
+    boxes, scores, labels = head.simple_test([feat], props, metas)[0]
+    assert labels.cpu().numpy().tolist() == g['labels'].tolist()
+    assert float(np.abs(scores.cpu().numpy() - g['scores']).max()) < 3e-5 * float(g['scores'].max()) + 1e-6
+    eng = head._engine
+    assert eng.topk == 128 and eng.iou_thr == 0.0 and eng.ratio == 0.0
+    out = eng.run(feat, props, metas, keep_stages=True)
+    torch.cuda.synchronize()
+    st, R = out['stages'], out['R']
+    rp, ci = st['row_ptr'].cpu().numpy(), st['col_idx'].cpu().numpy()
+    for r in range(R):
+        want = np.sort(np.concatenate([np.arange(49) + 49 * int(i) for i in g['corr'][r][g['corr_mask'][r]]]))
+        np.testing.assert_array_equal(np.sort(ci[rp[r]:rp[r + 1]]), want)

@@ -202,6 +202,22 @@ def test_oracle_logits_on_allowed_pairs(name):
         close(cap[l]['attn_mean'].numpy()[rr, kk], ap[f'{name}/attn'][l], 1e-4)
 
 
+@pytest.mark.parametrize('name,src', [('cfg1_s_allm', 'cfg1_s'), ('nc6_s_allm', 'nc6_s')])
+def test_all_matched_correlation_mode_on_the_s_head_matches_reference(name, src):
+    """correlation_mode='all_matched' through the S head (round 6; RH/utils/box_correlation.py:165-193 with the branch :305-338): the reference's own
+    compacted id lists [R, n_c] (up to 33 RoIs per query on the overlapping rig) and its class logits against the oracle's restatement (topk=None)."""
+    g = load_golden(name)
+    prob = synthetic.make_problem(src, seed=0)
+    sd = synthetic.make_head_state(seed=0)
+    st = {}
+    O.forward_s(sd, torch.from_numpy(prob['feat']), [torch.from_numpy(p) for p in prob['proposals']], prob['img_metas'], topk=None, stages=st)
+    np.testing.assert_array_equal(st['corr_mask'].numpy(), g['corr_mask'])
+    np.testing.assert_array_equal(st['corr'].numpy() * g['corr_mask'], g['corr'] * g['corr_mask'])
+    close(st['cls'].numpy().reshape(g['cls'].shape), g['cls'], 1e-4)
+    if src == 'nc6_s':
+        assert g['corr_mask'].sum(1).max() > 7                      # more RoIs per query than topk_matched:1 can list: the mode is not vacuous here
+
+
 @pytest.mark.parametrize('name,src', [('cfg1_t_allm', 'cfg1_t'), ('nc6_t_allm', 'nc6_s')])
 def test_all_matched_correlation_mode_matches_reference(name, src):
     """correlation_mode='all_matched' (RH/utils/box_correlation.py:305-338; no shipped config) through the T head: the goldens come from the
