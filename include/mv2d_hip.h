@@ -471,7 +471,7 @@ int mv2d_roi_positions(const float* rois, const unsigned char* pad_mask, unsigne
 /* S-path CSR over the RoI-feature memory rows r*49+cell (RH/mv2d_s_head.py:184-192). */
 int mv2d_csr_from_corr(const int* match, int* row_ptr, int* col_idx, int* nnz_out, int R, int V, int topk, void* stream);
 /* mv2d_roi_positions + mv2d_csr_from_corr in two launches instead of three (the position scan and the CSR run side by side in one): V = all
- * views of the maps, Vg = views per sample (match is [R, Vg, topk]); Vg * topk < 64.  order (optional, with grp_start [n_samples + 1]): the
+ * views of the maps, Vg = views per sample (match is [R, Vg, topk]); Vg * topk <= 4096.  order (optional, with grp_start [n_samples + 1]): the
  * launch order of the attention blocks for mv2d_xattn_tile_fwd_ordered from the same launch -- the queries of every sample ranked by the
  * smallest RoI they list (own or matched), so that matched RoIs of different views share an L2.  A sample with more than 4096 queries keeps its
  * natural order and sets order_flags[0] = 1 (optional int[1], cleared by the caller; results are the same either way). */

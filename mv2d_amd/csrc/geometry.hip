@@ -686,7 +686,7 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const unsigned int* __res
 // writes whole rows -- lanes = consecutive entries, the RoI ids of the row compacted through 256 B of LDS.
 constexpr int CFC_ROWS = 256;
 __device__ __forceinline__ void csr_from_corr_block(int blk, const int* __restrict__ match, int* __restrict__ row_ptr, int* __restrict__ col_idx,
-                                                    int* __restrict__ nnz_out, int R, int nm /* V * topk, < 64 */) {
+                                                    int* __restrict__ nnz_out, int R, int nm /* V * topk */) {
     __shared__ int wsum[16];
     __shared__ int before_s;
     __shared__ int rowoff[CFC_ROWS + 1];
@@ -723,17 +723,23 @@ __device__ __forceinline__ void csr_from_corr_block(int blk, const int* __restri
     for (int q = wv; q < CFC_ROWS; q += 16) {
         const int r = base + q;
         if (r >= R) break;
-        int id = -1;
-        if (lane == 0) id = r;
-        else if (lane <= nm) id = match[(long long)r * nm + lane - 1];
-        const unsigned long long bal = __ballot(id >= 0);
-        if (id >= 0) ids[wv][__popcll(bal & ((1ull << lane) - 1ull))] = id;
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        const int cnt = __popcll(bal) * 49;
+        // list positions p = 0 (the row itself), 1 .. nm (its match entries), 64 at a time (one pass when nm < 64: the shipped 'topk_matched' lists;
+        // 'all_matched' lists up to views x 128 RoIs, round 6)
         int* out = col_idx + (long long)rowoff[q] * 49;
-        for (int e = lane; e < cnt; e += 64) { const int k = e / 49; out[e] = ids[wv][k] * 49 + (e - k * 49); }
-        __builtin_amdgcn_wave_barrier();
+        for (int p0 = 0; p0 <= nm; p0 += 64) {
+            const int p = p0 + lane;
+            int id = -1;
+            if (p == 0) id = r;
+            else if (p <= nm) id = match[(long long)r * nm + p - 1];
+            const unsigned long long bal = __ballot(id >= 0);
+            if (id >= 0) ids[wv][__popcll(bal & ((1ull << lane) - 1ull))] = id;
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            const int cnt = __popcll(bal) * 49;
+            for (int e = lane; e < cnt; e += 64) { const int k = e / 49; out[e] = ids[wv][k] * 49 + (e - k * 49); }
+            out += cnt;
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
@@ -1339,7 +1345,7 @@ extern "C" int mv2d_roi_positions(const float* rois, const unsigned char* pad_ma
 }
 
 extern "C" int mv2d_csr_from_corr(const int* match, int* row_ptr, int* col_idx, int* nnz_out, int R, int V, int topk, void* stream) {
-    MV2D_CHECK_ARG(match && row_ptr && col_idx && nnz_out && R > 0 && V * topk < 64, "mv2d_csr_from_corr: bad args (V * topk < 64)");
+    MV2D_CHECK_ARG(match && row_ptr && col_idx && nnz_out && R > 0 && V * topk >= 0 && V * topk <= 4096, "mv2d_csr_from_corr: bad args (V * topk <= 4096)");
     hipLaunchKernelGGL(csr_from_corr_kernel, dim3(cdiv(R, CFC_ROWS)), dim3(1024), 0, (hipStream_t)stream, match, row_ptr, col_idx, nnz_out, R, V * topk);
     MV2D_LAUNCH_CHECK();
     return MV2D_OK;
@@ -1351,7 +1357,7 @@ extern "C" int mv2d_roi_positions_csr(const float* rois, const unsigned char* pa
                                       int* col_idx, int* nnz_out, int Vg, int topk, const int* grp_start, int n_samples, int* order, int* order_flags, void* stream) {
     MV2D_CHECK_ARG(!order || (grp_start && n_samples >= 1), "mv2d_roi_positions_csr: the block order needs the sample row ranges");
     MV2D_CHECK_ARG(rois && pad_mask && roi_mask && rect && pos2s && s2pos && S_out && R > 0, "mv2d_roi_positions_csr: bad args");
-    MV2D_CHECK_ARG(match && row_ptr && col_idx && nnz_out && Vg * topk < 64, "mv2d_roi_positions_csr: bad CSR args (views per sample * topk < 64)");
+    MV2D_CHECK_ARG(match && row_ptr && col_idx && nnz_out && Vg * topk >= 0 && Vg * topk <= 4096, "mv2d_roi_positions_csr: bad CSR args (views per sample * topk <= 4096)");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(csr_mark_kernel, dim3(R), dim3(64), 0, st, rois, rect, roi_mask, h, w, stride, expand_stride);
     const int nscan = cdiv(V * h * w, SCAN_SEG), ncsr = cdiv(R, CFC_ROWS);
