@@ -3,7 +3,7 @@
 # usage: bash tools/copy_evidence.sh "<provenance note>"
 cd "$(dirname "$0")/.."
 O=gpurun_out/r06
-for f in ablate_exact.txt bench_cfg2s_one_rank_rccl.json default_bench_cfg2s.json default_bench_cfg2s_kernel_stats.txt default_bench_cfg2s_under_rocprof.json \
+for f in soak_bench_cfg2s.json ablate_exact.txt bench_cfg2s_one_rank_rccl.json default_bench_cfg2s.json default_bench_cfg2s_kernel_stats.txt default_bench_cfg2s_under_rocprof.json \
          driver_shape_bench_cfg2s.json engine_exact_cfg2s_batch1_kernel_stats.txt engine_exact_cfg2s_kernel_stats.txt engine_key16_cfg2s_kernel_stats.txt \
          engine_exact_cfg3t_kernel_stats.txt engine_exact_cfg5t_kernel_stats.txt engine_exact_cfg2s_nc6_kernel_stats.txt engine_optin_group_xattn_cfg3t_kernel_stats.txt \
          engine_optin_pe_rows_in_waves_cfg3t_kernel_stats.txt gpu_tests_parity_lines.txt cluster_order_and_shared_tiles.txt pe_kernel_shapes.txt \

@@ -5,6 +5,8 @@ mkdir -p $O
 # 1. the default bench line (index-exact route; CPU baseline legs, key16-mode leg, one-rank RCCL leg, mismatch counts, other workloads) and the driver's call shape
 timeout 1500 python bench.py > $O/default_bench_cfg2s.json 2> $O/bench.err
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/driver_shape_bench_cfg2s.json 2>> $O/bench.err
+# 1b. a sustained run: 640 steps of 384 frames (~29 s of timed steps) -- clocks and throughput under a long load
+timeout 900 python bench.py --steps 640 --warmup 20 --brief --no-parity-leg 2>> $O/bench.err | tail -n 1 > $O/soak_bench_cfg2s.json
 # 2. rocprofv3 kernel summary of the default command (extra legs off) + PMC passes of the eager single-stream bench per workload
 HEAD=5 tools/prof_stats.sh r06/stats_default --steps 40 --no-extra-legs --no-parity-leg --no-collective-leg > /dev/null 2>&1
 mv $O/stats_default/kernel_stats.txt $O/default_bench_cfg2s_kernel_stats.txt; mv $O/stats_default/bench_under_rocprof.json $O/default_bench_cfg2s_under_rocprof.json; rmdir $O/stats_default
