@@ -193,7 +193,8 @@ __device__ __forceinline__ unsigned int lo8_pack4(unsigned int lo01, unsigned in
 // element keeps its hi half's precision only) -- the engine reports it (HeadEngine._check_capacity) instead of degrading silently
 __device__ __forceinline__ unsigned int lo8_pack4_flag(unsigned int lo01, unsigned int lo23, int* flag) {
     const float a = k16_lo_of_pair(lo01) * 4096.f, b = k16_hi_of_pair(lo01) * 4096.f, c = k16_lo_of_pair(lo23) * 4096.f, d = k16_hi_of_pair(lo23) * 4096.f;
-    if (flag && fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d))) > 448.f) atomicOr(flag, 1);
+    // (the flag is read first: a frame full of such values would otherwise send one atomic per lane and store)
+    if (flag && fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d))) > 448.f && *reinterpret_cast<volatile int*>(flag) == 0) atomicOr(flag, 1);
     return lo8_pack4(lo01, lo23);
 }
 template <int W>

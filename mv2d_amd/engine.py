@@ -87,7 +87,7 @@ class HeadEngine:
         # _zmap_x3: 6 instead of 8 launches per layer, bitwise the same results) for SMALL launches (<= 512 query rows, i.e. one sample per
         # call: the two saved launches per layer count there) and as separate kernels for batches (a row kernel is bound by streaming its
         # weights through ONE CU per 32 rows; the fused ones stream twice as much).  None: by the row count; True / False forces it.
-        self.fuse_maps = None
+        self.fuse_maps = {'0': False, '1': True}.get(os.environ.get('MV2D_FUSE_MAPS', ''), None)      # (the variable: A/B runs)
         # OPT-IN: evaluate the cls / reg branches of the last decoder layer only (what decoding reads).  Not the default: out['cls'] / out['reg']
         # then carry stale rows for the other layers, and the reference's forward does evaluate all six.
         self.last_stage_heads = False
