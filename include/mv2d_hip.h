@@ -481,8 +481,8 @@ int mv2d_roi_positions_csr(const float* rois, const unsigned char* pad_mask, uns
 
 /* Frustum rows of the index-exact route's PE block alone: out [S, 3 depth_num] fp32 = float(inverse_sigmoid(normalised 3-D point of every depth bin)),
  * computed in fp64 like the reference (MU/pe.py:96-131) at the positions s2pos[0 .. *S_dev); position_range = 6 doubles on the HOST.  Replaces the
- * A_frustum_f32 output of mv2d_pe_inputs on the inference path (same values up to one fp32 ulp in ~1 element per 1e8; 3-4 x faster).  The FIRST call of a
- * process uploads a 2 KB logarithm table with a synchronous copy: make it outside a stream capture (the engine's warm-up run does). */
+ * A_frustum_f32 output of mv2d_pe_inputs on the inference path (same values up to one fp32 ulp in ~1 element per 1e8; 3-4 x faster).  Its 2 KB
+ * logarithm table travels as a kernel argument (round 6): no per-device state, safe inside a stream capture and with several GPUs per process. */
 int mv2d_pe_frustum_f32(const int* s2pos, const int* S_dev, int S_max, const double* img2lidar, const double* coords_w, const double* coords_h,
                         const double* coords_d, float* out, int V, int h, int w, int depth_num, const double* position_range, void* stream);
 
